@@ -1,0 +1,126 @@
+"""
+ORACLE - TEST INFRASTRUCTURE ONLY: ctypes binding of oracle/libswe2d_ref.so (the C restatement).
+Used by tests/ as the fast checker on meshes too big for the numpy oracle, and by bench.py's
+``cpu_baseline`` leg.  Never imported by the product package.
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'libswe2d_ref.so')
+
+BC_CLOSED, BC_ELEV, BC_UV, BC_UN, BC_FLUX = 0, 1, 2, 4, 8
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+class _RefStruct(ctypes.Structure):
+    _fields_ = [('n_cells', ctypes.c_int), ('nbr', _ip), ('nbf', ctypes.POINTER(ctypes.c_byte)),
+                ('xy', _dp), ('h', _dp), ('g', ctypes.c_double), ('nonlinear', ctypes.c_int),
+                ('use_lf', ctypes.c_int), ('sigma_lf', ctypes.c_double),
+                ('coriolis', _dp), ('linear_drag', ctypes.c_double), ('quad_drag', ctypes.c_double),
+                ('manning', ctypes.c_double), ('norm_smoother', ctypes.c_double),
+                ('patm', _dp), ('mom_src', _dp), ('vol_src', _dp),
+                ('n_markers', ctypes.c_int), ('bc_kind', _ip), ('bc_elev', _dp), ('bc_uv', _dp),
+                ('bc_un', _dp), ('bc_flux', _dp), ('bc_len', _dp)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, 'swe2d_ref.c')):
+        subprocess.check_call(['make', '-C', _HERE, '-B', 'libswe2d_ref.so'], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def load():
+    if not os.path.exists(_SO):
+        build()
+    lib = ctypes.CDLL(_SO)
+    lib.swe2d_ref_tendency.argtypes = [ctypes.POINTER(_RefStruct), _dp, _dp, ctypes.c_double, _dp, _dp]
+    lib.swe2d_ref_tendency.restype = None
+    lib.swe2d_ref_advance.argtypes = [ctypes.POINTER(_RefStruct), _dp, _dp, ctypes.c_double, ctypes.c_int, _dp]
+    lib.swe2d_ref_advance.restype = None
+    lib.swe2d_ref_num_threads.restype = ctypes.c_int
+    lib.swe2d_ref_set_num_threads.argtypes = [ctypes.c_int]
+    return lib
+
+
+def _ptr(a, tp=_dp):
+    return None if a is None else a.ctypes.data_as(tp)
+
+
+class RefSWE(object):
+    """C restatement bound to plain mesh arrays (cell_xy (N,3,2), nbr (N,3), nbf (N,3), h (N,3))."""
+
+    def __init__(self, cell_xy, cell_nbr, cell_nbr_facet, h_nodal, g=9.81, use_nonlinear_equations=True,
+                 use_lax_friedrichs_velocity=True, lax_friedrichs_velocity_scaling_factor=1.0,
+                 coriolis=None, linear_drag_coefficient=None, quadratic_drag_coefficient=None,
+                 manning_drag_coefficient=None, norm_smoother=0.0, atmospheric_pressure=None,
+                 momentum_source=None, volume_source=None, bnd_conditions=None, boundary_len=None):
+        self.lib = load()
+        n = cell_xy.shape[0]
+        self.n = n
+        c = np.ascontiguousarray
+        self._keep = dict(
+            xy=c(cell_xy, dtype=np.float64), nbr=c(cell_nbr, dtype=np.int32),
+            nbf=c(cell_nbr_facet, dtype=np.int8), h=c(h_nodal, dtype=np.float64),
+            coriolis=None if coriolis is None else c(np.broadcast_to(coriolis, (n, 3)), dtype=np.float64),
+            patm=None if atmospheric_pressure is None else c(atmospheric_pressure, dtype=np.float64),
+            mom_src=None if momentum_source is None else c(np.broadcast_to(momentum_source, (n, 3, 2)), dtype=np.float64),
+            vol_src=None if volume_source is None else c(np.broadcast_to(volume_source, (n, 3)), dtype=np.float64))
+        k = self._keep
+        nm = 1
+        bnd_conditions = bnd_conditions or {}
+        if bnd_conditions:
+            nm = max(bnd_conditions.keys()) + 1
+        kind = np.zeros(nm, dtype=np.int32)
+        elev = np.zeros(nm); uvb = np.zeros((nm, 2)); un = np.zeros(nm); flux = np.zeros(nm); blen = np.ones(nm)
+        for mk, funcs in bnd_conditions.items():
+            if 'elev' in funcs:
+                kind[mk] |= BC_ELEV; elev[mk] = funcs['elev']
+            if 'uv' in funcs:
+                kind[mk] |= BC_UV; uvb[mk] = funcs['uv']
+            elif 'un' in funcs:
+                kind[mk] |= BC_UN; un[mk] = funcs['un']
+            elif 'flux' in funcs:
+                kind[mk] |= BC_FLUX; flux[mk] = funcs['flux']
+            if boundary_len is not None and mk in boundary_len:
+                blen[mk] = boundary_len[mk]
+        k.update(kind=kind, elev=elev, uvb=uvb, un=un, flux=flux, blen=blen)
+        s = _RefStruct()
+        s.n_cells = n
+        s.nbr = _ptr(k['nbr'], _ip)
+        s.nbf = _ptr(k['nbf'], ctypes.POINTER(ctypes.c_byte))
+        s.xy = _ptr(k['xy']); s.h = _ptr(k['h'])
+        s.g = g; s.nonlinear = int(use_nonlinear_equations); s.use_lf = int(use_lax_friedrichs_velocity)
+        s.sigma_lf = lax_friedrichs_velocity_scaling_factor
+        s.coriolis = _ptr(k['coriolis'])
+        s.linear_drag = -1.0 if linear_drag_coefficient is None else linear_drag_coefficient
+        s.quad_drag = -1.0 if quadratic_drag_coefficient is None else quadratic_drag_coefficient
+        s.manning = -1.0 if manning_drag_coefficient is None else manning_drag_coefficient
+        s.norm_smoother = norm_smoother
+        s.patm = _ptr(k['patm']); s.mom_src = _ptr(k['mom_src']); s.vol_src = _ptr(k['vol_src'])
+        s.n_markers = nm
+        s.bc_kind = _ptr(kind, _ip); s.bc_elev = _ptr(elev); s.bc_uv = _ptr(uvb); s.bc_un = _ptr(un)
+        s.bc_flux = _ptr(flux); s.bc_len = _ptr(blen)
+        self.s = s
+
+    def tendency(self, uv, eta, dt):
+        uv = np.ascontiguousarray(uv, dtype=np.float64); eta = np.ascontiguousarray(eta, dtype=np.float64)
+        ku = np.empty_like(uv); ke = np.empty_like(eta)
+        self.lib.swe2d_ref_tendency(ctypes.byref(self.s), _ptr(uv), _ptr(eta), dt, _ptr(ku), _ptr(ke))
+        return ku, ke
+
+    def advance(self, uv, eta, dt, n_steps):
+        """n_steps SSPRK33 steps; returns new (uv, eta)."""
+        uv = np.array(uv, dtype=np.float64, order='C'); eta = np.array(eta, dtype=np.float64, order='C')
+        work = np.empty(18*self.n)
+        self.lib.swe2d_ref_advance(ctypes.byref(self.s), _ptr(uv), _ptr(eta), dt, n_steps, _ptr(work))
+        return uv, eta
+
+    def num_threads(self):
+        return self.lib.swe2d_ref_num_threads()
+
+    def set_num_threads(self, n):
+        self.lib.swe2d_ref_set_num_threads(n)

@@ -1,0 +1,330 @@
+/*
+ * ORACLE - TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+ *
+ * Plain-C (OpenMP) restatement of the DG-P1 2D shallow-water residual + block mass inverse + SSPRK33
+ * Shu-Osher update that Thetis builds in UFL and hands to Firedrake.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load the shared object built from this file.
+ *
+ * PARITY UNPINNED at round-off level (see oracle/swe2d_oracle.py header and DESIGN.md): the reference's
+ * arithmetic lives in Firedrake/PETSc, which cannot be installed or run here.  This file is pinned against
+ * oracle/swe2d_oracle.py (literal UFL restatement, quadrature everywhere) and through it against the
+ * reference's own known-answer tests.
+ *
+ * Formulation: element-centric (every cell evaluates the numerical flux of its three facets itself, so both
+ * sides of an interior facet compute it once each), closed-form P1 cell integrals
+ *   int l_i = A/3,  int l_i l_j = A(1+d_ij)/12        
+ * and 2-point Gauss-Legendre on facets.  Reference forms (file:line under /root/reference/thetis):
+ *   ExternalPressureGradientTerm shallowwater_eq.py:360-381     HUDivTerm shallowwater_eq.py:421-442
+ *   HorizontalAdvectionTerm      shallowwater_eq.py:470-510     get_bnd_functions shallowwater_eq.py:232-272
+ *   CoriolisTerm :623-634  LinearDragTerm :734-740  QuadraticDragTerm :679-701  AtmosphericPressureTerm :658-663
+ *   MomentumSourceTerm :805-811  ContinuitySourceTerm :825-831
+ *   mass inverse equation.py:105 (M_K = A/12 [[2,1,1],[1,2,1],[1,1,2]])   SSPRK33 rungekutta.py:326-347,908-946
+ *
+ * Data layout: cell-major AoS like the numpy oracle: uv[N][3][2], eta[N][3], xy[N][3][2], h[N][3].
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define BC_CLOSED 0
+#define BC_ELEV   1
+#define BC_UV     2
+#define BC_UN     4
+#define BC_FLUX   8
+
+typedef struct {
+    int n_cells;
+    const int *nbr;            /* [N][3]  >=0 neighbour cell, <0: -(marker)            */
+    const signed char *nbf;    /* [N][3]  local facet id inside the neighbour          */
+    const double *xy;          /* [N][3][2]                                            */
+    const double *h;           /* [N][3]  bathymetry at the cell nodes (CG-P1)         */
+    double g;
+    int nonlinear;             /* use_nonlinear_equations                              */
+    int use_lf;                /* use_lax_friedrichs_velocity                          */
+    double sigma_lf;
+    /* optional cell-local terms: NULL / 0 = off */
+    const double *coriolis;    /* [N][3]                                               */
+    double linear_drag;        /* constant, <0 = off                                   */
+    double quad_drag;          /* constant C_D, <0 = off                               */
+    double manning;            /* constant mu, <0 = off                                */
+    double norm_smoother;
+    const double *patm;        /* [N][3]                                               */
+    const double *mom_src;     /* [N][3][2]                                            */
+    const double *vol_src;     /* [N][3]                                               */
+    /* open boundaries, indexed by marker (0..n_markers-1 -> marker = index) */
+    int n_markers;
+    const int *bc_kind;        /* bitmask of BC_*                                      */
+    const double *bc_elev;     /* per marker                                           */
+    const double *bc_uv;       /* per marker [2]                                       */
+    const double *bc_un;       /* per marker                                           */
+    const double *bc_flux;     /* per marker                                           */
+    const double *bc_len;      /* per marker total boundary length                     */
+} swe2d_ref_t;
+
+static const double GL_XI[2] = {0.21132486540518713, 0.78867513459481287};
+
+/* Dunavant degree-4 6-point rule for the non-polynomial (Manning) cell integrand */
+static const double TRI_B[6][3] = {
+    {0.108103018168070, 0.445948490915965, 0.445948490915965},
+    {0.445948490915965, 0.108103018168070, 0.445948490915965},
+    {0.445948490915965, 0.445948490915965, 0.108103018168070},
+    {0.816847572980459, 0.091576213509771, 0.091576213509771},
+    {0.091576213509771, 0.816847572980459, 0.091576213509771},
+    {0.091576213509771, 0.091576213509771, 0.816847572980459}};
+static const double TRI_W[6] = {0.223381589678011, 0.223381589678011, 0.223381589678011,
+                                0.109951743655322, 0.109951743655322, 0.109951743655322};
+
+static inline double total_depth(const swe2d_ref_t *m, double h, double eta)
+{
+    return m->nonlinear ? h + eta : h;
+}
+
+/* int a*b over the cell, a,b P1 */
+static inline double int2(double A, const double a[3], const double b[3])
+{
+    double sa = a[0] + a[1] + a[2], sb = b[0] + b[1] + b[2];
+    return A/12.0*(sa*sb + a[0]*b[0] + a[1]*b[1] + a[2]*b[2]);
+}
+
+/* k = M^-1 (dt R(U)) for one cell */
+static void cell_tendency(const swe2d_ref_t *m, int k, const double *uv, const double *eta, double dt,
+                          double *k_uv, double *k_eta)
+{
+    const double g = m->g;
+    const double *p = m->xy + 6*(size_t)k;
+    const double *hk = m->h + 3*(size_t)k;
+    double u[3], v[3], e[3], H[3];
+    for (int i = 0; i < 3; i++) {
+        u[i] = uv[6*(size_t)k + 2*i];
+        v[i] = uv[6*(size_t)k + 2*i + 1];
+        e[i] = eta[3*(size_t)k + i];
+        H[i] = total_depth(m, hk[i], e[i]);
+    }
+    const double A = 0.5*((p[2] - p[0])*(p[5] - p[1]) - (p[4] - p[0])*(p[3] - p[1]));
+    double gx[3], gy[3];       /* grad phi_i */
+    for (int i = 0; i < 3; i++) {
+        int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+        gx[i] = (p[2*i1 + 1] - p[2*i2 + 1])/(2*A);
+        gy[i] = (p[2*i2] - p[2*i1])/(2*A);
+    }
+    double bu[3] = {0, 0, 0}, bv[3] = {0, 0, 0}, be[3] = {0, 0, 0};
+
+    /* ---- cell integrals */
+    const double esum = e[0] + e[1] + e[2];
+    const double IHu = int2(A, H, u), IHv = int2(A, H, v);
+    double Iuu = 0, Iuv = 0, Ivv = 0, divu = 0;
+    if (m->nonlinear) {
+        Iuu = int2(A, u, u); Iuv = int2(A, u, v); Ivv = int2(A, v, v);
+        for (int i = 0; i < 3; i++) divu += gx[i]*u[i] + gy[i]*v[i];
+    }
+    const double usum = u[0] + u[1] + u[2], vsum = v[0] + v[1] + v[2];
+    for (int i = 0; i < 3; i++) {
+        bu[i] += g*gx[i]*A/3.0*esum;                               /* +g eta div(psi)          :361 */
+        bv[i] += g*gy[i]*A/3.0*esum;
+        be[i] += gx[i]*IHu + gy[i]*IHv;                            /* +grad(phi).(H u)         :422 */
+        if (m->nonlinear) {                                        /* +(psi div u + u.grad psi) u :478 */
+            bu[i] += divu*A/12.0*(usum + u[i]) + gx[i]*Iuu + gy[i]*Iuv;
+            bv[i] += divu*A/12.0*(vsum + v[i]) + gx[i]*Iuv + gy[i]*Ivv;
+        }
+    }
+    if (m->coriolis) {                                             /* :632-633, f P1: cubic integrand */
+        const double *f = m->coriolis + 3*(size_t)k;
+        for (int i = 0; i < 3; i++) {
+            double su = 0, sv = 0;
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+                /* int l_i l_a l_b = A*{6,2,1}/60 */
+                int same = (i == a) + (i == b) + (a == b);
+                double w = (same == 3) ? 6.0 : (same == 1 ? 2.0 : 1.0);
+                su += w*f[a]*u[b]; sv += w*f[a]*v[b];
+            }
+            bu[i] += A/60.0*sv;       /* -f*(-v psi_x) */
+            bv[i] -= A/60.0*su;       /* -f*( u psi_y) */
+        }
+    }
+    if (m->linear_drag >= 0) {                                     /* :738 */
+        for (int i = 0; i < 3; i++) {
+            bu[i] -= m->linear_drag*A/12.0*(usum + u[i]);
+            bv[i] -= m->linear_drag*A/12.0*(vsum + v[i]);
+        }
+    }
+    if (m->quad_drag >= 0 || m->manning >= 0) {                    /* :685-700, quadrature */
+        for (int q = 0; q < 6; q++) {
+            const double *b = TRI_B[q];
+            double uq = b[0]*u[0] + b[1]*u[1] + b[2]*u[2];
+            double vq = b[0]*v[0] + b[1]*v[1] + b[2]*v[2];
+            double Hq = b[0]*H[0] + b[1]*H[1] + b[2]*H[2];
+            double cd = (m->manning >= 0) ? g*m->manning*m->manning/cbrt(Hq) : m->quad_drag;
+            double s = TRI_W[q]*A*cd*sqrt(uq*uq + vq*vq + m->norm_smoother*m->norm_smoother)/Hq;
+            for (int i = 0; i < 3; i++) { bu[i] -= s*b[i]*uq; bv[i] -= s*b[i]*vq; }
+        }
+    }
+    if (m->patm) {                                                 /* :662 */
+        const double *pa = m->patm + 3*(size_t)k;
+        double px = gx[0]*pa[0] + gx[1]*pa[1] + gx[2]*pa[2];
+        double py = gy[0]*pa[0] + gy[1]*pa[1] + gy[2]*pa[2];
+        for (int i = 0; i < 3; i++) { bu[i] -= px/1000.0*A/3.0; bv[i] -= py/1000.0*A/3.0; }
+    }
+    if (m->mom_src) {                                              /* :810 */
+        const double *s = m->mom_src + 6*(size_t)k;
+        double sx = s[0] + s[2] + s[4], sy = s[1] + s[3] + s[5];
+        for (int i = 0; i < 3; i++) { bu[i] += A/12.0*(sx + s[2*i]); bv[i] += A/12.0*(sy + s[2*i + 1]); }
+    }
+    if (m->vol_src) {                                              /* :830 */
+        const double *s = m->vol_src + 3*(size_t)k;
+        double ss = s[0] + s[1] + s[2];
+        for (int i = 0; i < 3; i++) be[i] += A/12.0*(ss + s[i]);
+    }
+
+    /* ---- facets */
+    for (int f = 0; f < 3; f++) {
+        const int a = f, b = (f + 1) % 3;
+        const double dx = p[2*b] - p[2*a], dy = p[2*b + 1] - p[2*a + 1];
+        const double len = sqrt(dx*dx + dy*dy);
+        const double nx = dy/len, ny = -dx/len;
+        const int nb = m->nbr[3*(size_t)k + f];
+        double ua_n = 0, ub_n = 0, va_n = 0, vb_n = 0, ea_n = 0, eb_n = 0;
+        int kind = BC_CLOSED, marker = 0;
+        if (nb >= 0) {
+            const int f2 = m->nbf[3*(size_t)k + f];
+            const int na = (f2 + 1) % 3, nbb = f2;      /* neighbour traverses the facet backwards */
+            ua_n = uv[6*(size_t)nb + 2*na];   va_n = uv[6*(size_t)nb + 2*na + 1];   ea_n = eta[3*(size_t)nb + na];
+            ub_n = uv[6*(size_t)nb + 2*nbb];  vb_n = uv[6*(size_t)nb + 2*nbb + 1];  eb_n = eta[3*(size_t)nb + nbb];
+        } else {
+            marker = -nb;
+            if (marker < m->n_markers && m->bc_kind) kind = m->bc_kind[marker];
+        }
+        for (int q = 0; q < 2; q++) {
+            const double xb = GL_XI[q], xa = 1.0 - xb;
+            const double w = 0.5*len;
+            const double uq = xa*u[a] + xb*u[b], vq = xa*v[a] + xb*v[b], eq = xa*e[a] + xb*e[b];
+            const double hq = xa*hk[a] + xb*hk[b];
+            const double Hq = total_depth(m, hq, eq);
+            double fu = 0, fv = 0, fe = 0;     /* the form f; residual is -f */
+            if (nb >= 0) {
+                const double un_ = xa*ua_n + xb*ub_n, vn_ = xa*va_n + xb*vb_n, en_ = xa*ea_n + xb*eb_n;
+                const double Hn = total_depth(m, hq, en_);
+                const double Hav = 0.5*(Hq + Hn);
+                const double uav = 0.5*(uq + un_), vav = 0.5*(vq + vn_);
+                const double jump_un = (uq - un_)*nx + (vq - vn_)*ny;
+                const double head_star = 0.5*(eq + en_) + sqrt(Hav/g)*jump_un;           /* :363 */
+                fu += g*head_star*nx; fv += g*head_star*ny;                               /* :366 */
+                const double c2 = sqrt(g/Hav)*(eq - en_);
+                fe += Hav*((uav + c2*nx)*nx + (vav + c2*ny)*ny);                          /* :424-427 */
+                if (m->nonlinear) {
+                    const double un_own = uq*nx + vq*ny;
+                    fu += uav*un_own; fv += vav*un_own;                                   /* :483 */
+                    if (m->use_lf) {
+                        const double gamma = 0.5*fabs(uav*nx + vav*ny)*m->sigma_lf;       /* :487 */
+                        fu += gamma*(uq - un_); fv += gamma*(vq - vn_);                   /* :488 */
+                    }
+                }
+            } else if (kind == BC_CLOSED) {
+                const double un_own = uq*nx + vq*ny;
+                const double head_rie = eq + sqrt(Hq/g)*un_own;                           /* :379-380 */
+                fu += g*head_rie*nx; fv += g*head_rie*ny;
+                if (m->nonlinear && m->use_lf) {
+                    const double gamma = 0.5*fabs(un_own)*m->sigma_lf;                    /* :496 */
+                    fu += gamma*2.0*un_own*nx; fv += gamma*2.0*un_own*ny;                 /* :497 */
+                }
+            } else {
+                /* external state, get_bnd_functions :243-267 */
+                double e_ext = eq, u_ext = uq, v_ext = vq;
+                if (kind & BC_ELEV) e_ext = m->bc_elev[marker];
+                if (kind & BC_UV) { u_ext = m->bc_uv[2*marker]; v_ext = m->bc_uv[2*marker + 1]; }
+                else if (kind & BC_UN) { u_ext = m->bc_un[marker]*nx; v_ext = m->bc_un[marker]*ny; }
+                else if (kind & BC_FLUX) {
+                    const double H_ext0 = total_depth(m, hq, e_ext);
+                    const double s = m->bc_flux[marker]/(H_ext0*m->bc_len[marker]);
+                    u_ext = s*nx; v_ext = s*ny;
+                }
+                const double H_ext = total_depth(m, hq, e_ext);
+                const double un_jump = (uq - u_ext)*nx + (vq - v_ext)*ny;
+                const double eta_rie = 0.5*(eq + e_ext) + sqrt(Hq/g)*un_jump;             /* :374 */
+                fu += g*eta_rie*nx; fv += g*eta_rie*ny;                                   /* :375 */
+                const double h_av = 0.5*(Hq + H_ext);
+                const double eta_jump = eq - e_ext;
+                const double un_avg = 0.5*((uq + u_ext)*nx + (vq + v_ext)*ny);
+                const double un_rie = un_avg + sqrt(g/h_av)*eta_jump;                     /* :438 */
+                const double eta_rie2 = 0.5*(eq + e_ext) + sqrt(h_av/g)*un_jump;          /* :440 */
+                fe += total_depth(m, hq, eta_rie2)*un_rie;                                /* :441-442 */
+                if (m->nonlinear) {
+                    const double un_rie3 = un_avg + sqrt(g/Hq)*eta_jump;                  /* :507 */
+                    fu += un_rie3*0.5*(u_ext + uq); fv += un_rie3*0.5*(v_ext + vq);       /* :508-509 */
+                }
+            }
+            bu[a] -= w*xa*fu; bu[b] -= w*xb*fu;
+            bv[a] -= w*xa*fv; bv[b] -= w*xb*fv;
+            be[a] -= w*xa*fe; be[b] -= w*xb*fe;
+        }
+    }
+    /* ---- mass inverse: (M^-1 b)_i = 3/A (4 b_i - sum b) */
+    const double s = 3.0*dt/A;
+    const double su = bu[0] + bu[1] + bu[2], sv = bv[0] + bv[1] + bv[2], se = be[0] + be[1] + be[2];
+    for (int i = 0; i < 3; i++) {
+        k_uv[6*(size_t)k + 2*i] = s*(4.0*bu[i] - su);
+        k_uv[6*(size_t)k + 2*i + 1] = s*(4.0*bv[i] - sv);
+        k_eta[3*(size_t)k + i] = s*(4.0*be[i] - se);
+    }
+}
+
+/* k = M^-1 (dt R(U)) for the whole mesh */
+void swe2d_ref_tendency(const swe2d_ref_t *m, const double *uv, const double *eta, double dt,
+                        double *k_uv, double *k_eta)
+{
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < m->n_cells; k++)
+        cell_tendency(m, k, uv, eta, dt, k_uv, k_eta);
+}
+
+/* n_steps SSPRK33 steps in place; work must hold 4 states = 4*9*N doubles.  Shu-Osher form, expression
+ * order of rungekutta.py:911-913: tendency*beta + sum_j stage_sol[j]*alpha.  Constant-in-time forcing only. */
+void swe2d_ref_advance(const swe2d_ref_t *m, double *uv, double *eta, double dt, int n_steps, double *work)
+{
+    const size_t n = (size_t)m->n_cells;
+    double *u0 = work, *e0 = u0 + 6*n;
+    double *ku = e0 + 3*n, *ke = ku + 6*n;
+    static const double A30 = 0.33333333333333337, A32 = 0.6666666666666666, B32 = 0.6666666666666666;
+    for (int it = 0; it < n_steps; it++) {
+        memcpy(u0, uv, 6*n*sizeof(double));
+        memcpy(e0, eta, 3*n*sizeof(double));
+        /* stage 0: U1 = k*1 + U0*1 */
+        swe2d_ref_tendency(m, uv, eta, dt, ku, ke);
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)(6*n); i++) uv[i] = ku[i]*1.0 + u0[i]*1.0;
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)(3*n); i++) eta[i] = ke[i]*1.0 + e0[i]*1.0;
+        /* stage 1: U2 = k*0.25 + U0*0.75 + U1*0.25   (U1 is the current solution) */
+        swe2d_ref_tendency(m, uv, eta, dt, ku, ke);
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)(6*n); i++) uv[i] = ku[i]*0.25 + u0[i]*0.75 + uv[i]*0.25;
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)(3*n); i++) eta[i] = ke[i]*0.25 + e0[i]*0.75 + eta[i]*0.25;
+        /* stage 2: U3 = k*B32 + U0*A30 + U1*0 + U2*A32 */
+        swe2d_ref_tendency(m, uv, eta, dt, ku, ke);
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)(6*n); i++) uv[i] = ku[i]*B32 + u0[i]*A30 + uv[i]*A32;
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)(3*n); i++) eta[i] = ke[i]*B32 + e0[i]*A30 + eta[i]*A32;
+    }
+}
+
+int swe2d_ref_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void swe2d_ref_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
