@@ -1,0 +1,129 @@
+#!/usr/bin/env python
+"""
+bench.py - headline benchmark of the hot path (BASELINE.json: "DG element-updates/sec + achieved HBM GB/s,
+2D SWE SSPRK33 at 1/2/4/8 GPUs").
+
+Workload = BASELINE.json configs[1]/[2] (SURVEY.md 8d cfg 2/3): RectangleMesh(1000, 500, 100e3, 50e3) = 1,000,000
+triangles, DG-P1, flat bathymetry h=20, eta0 = 0.5 exp(-r^2/(5km)^2) + U(-1e-3,1e-3) noise, u0 noise +-1e-3
+(numpy default_rng(1234)), closed walls, sigma_LF=1, dt=0.25 s.  One "step" = one SSPRK33 time step = 3 stage
+kernels = 3 element-updates per cell.  Inputs are resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU;
+                                                        the same 1M-triangle mesh is strip-partitioned: strong scaling)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NX, NY, LX, LY = 1000, 500, 100e3, 50e3
+DT = 0.25
+HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_ELEMENT_STEP = 684.0          # 180 + 252 + 252 algorithmic bytes per triangle per step
+BYTES_PER_ELEMENT_UPDATE = BYTES_PER_ELEMENT_STEP/3.0
+
+
+def build_case(nx=NX, ny=NY):
+    from thetis_amd.mesh import RectangleMesh
+    mesh = RectangleMesh(nx, ny, LX, LY)
+    bath = np.full(mesh.num_vertices, 20.0)
+    n = mesh.num_cells
+    rng = np.random.default_rng(1234)
+    cxy = mesh.cell_xy()
+    eta = 0.5*np.exp(-((cxy[:, :, 0] - 50e3)**2 + (cxy[:, :, 1] - 25e3)**2)/(5e3)**2)
+    eta = eta + 1e-3*rng.uniform(-1, 1, size=(n, 3))
+    uv = 1e-3*rng.uniform(-1, 1, size=(n, 3, 2))
+    return mesh, bath, uv, eta
+
+
+def cpu_baseline(mesh, bath, uv, eta, budget_s=12.0):
+    """The oracle's C restatement (OpenMP, all host cores) timed on a bounded number of steps of the same workload."""
+    from oracle.ref_lib import RefSWE
+    ref = RefSWE(mesh.cell_xy(), mesh.cell_nbr, mesh.cell_nbr_facet, bath[mesh.cells], boundary_len=mesh.boundary_len)
+    n = mesh.num_cells
+    ref.advance(uv, eta, DT, 1)                                   # warm-up (thread pool, page faults)
+    t0 = time.perf_counter()
+    ref.advance(uv, eta, DT, 2)
+    t2 = time.perf_counter() - t0
+    steps = int(max(2, min(100, budget_s/(t2/2.0))))
+    t0 = time.perf_counter()
+    u_c, e_c = ref.advance(uv, eta, DT, steps)
+    t = time.perf_counter() - t0
+    return {'value': n*3.0*steps/t, 'unit': 'element-updates/s', 'cores': ref.num_threads(), 'kind': 'port',
+            'sample': '{:d} SSPRK33 steps of the same 1M-triangle workload, oracle/swe2d_ref.c (OpenMP, {:d} threads), '
+                      '{:.1f} s'.format(steps, ref.num_threads(), t)}, (steps, u_c, e_c)
+
+
+def run_single(args):
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = build_case()
+    n = mesh.num_cells
+    dev = Swe2dDevice(mesh, bath, DT, device_id=0)
+    dev.set_state(uv, eta)
+    dev.advance(args.warmup)
+    dev.synchronize()
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev.advance(args.steps)
+    dev.synchronize()
+    torch.cuda.synchronize()
+    t_wall = time.perf_counter() - t0
+    # per-launch kernel duration: HIP events around every stage launch, on the launch stream (separate pass so that
+    # the event records do not sit inside the timed region above)
+    n_ev = min(args.steps, 50)
+    ms_tot, ms_kernel = dev.advance_timed(n_ev, per_launch=True)
+    d = dev.diagnostics()
+    assert np.isfinite(d).all()
+    value = n*3.0*args.steps/t_wall
+    achieved = BYTES_PER_ELEMENT_UPDATE*n/(ms_kernel*1e-3)/1e9
+    out = {
+        'metric': 'DG element-updates/sec, 2D SWE DG-P1 SSPRK33',
+        'value': value, 'unit': 'element-updates/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3*t_wall/args.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE cfg2: RectangleMesh(1000,500,100e3,50e3) = 1M triangles, DG-P1 SWE, SSPRK33, '
+                               'flat h=20, closed walls, dt=0.25', 'n_cells': n, 'parallelism': 'single'},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved/HBM_PEAK_GBS, 'traffic': None,
+                     'kernel': 'swe_stage_kernel', 'avg_launch_ms': ms_kernel,
+                     'algorithmic_bytes_per_launch': BYTES_PER_ELEMENT_UPDATE*n},
+    }
+    if not args.no_cpu:
+        cb, (steps_c, u_c, e_c) = cpu_baseline(mesh, bath, uv, eta)
+        out['cpu_baseline'] = cb
+        # parity of the two paths on the baseline's sample (reported)
+        dev.set_state(uv, eta)
+        dev.advance(steps_c)
+        u_g, e_g = dev.get_state()
+        out['cpu_baseline']['gpu_vs_cpu_rel_linf'] = {
+            'uv': float(np.abs(u_g - u_c).max()/np.abs(u_c).max()),
+            'eta': float(np.abs(e_g - e_c).max()/np.abs(e_c).max()), 'steps': steps_c}
+    dev.close()
+    print(json.dumps(out))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    args = ap.parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 or world > 1:
+        from thetis_amd.distributed import run_distributed_bench
+        run_distributed_bench(args, build_case, DT, BYTES_PER_ELEMENT_UPDATE, HBM_PEAK_GBS)
+    else:
+        run_single(args)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,162 @@
+/*
+ * swe2d.h - C ABI of the MI355X-native explicit 2D shallow-water stepper (libswe2d_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of thetisproject/thetis: the SSPRK33 time step of the
+ * DG-P1 ('dg-dg', degree 1) 2D shallow water equations.  In the reference that path is
+ *
+ *   FlowSolver2d.iterate()                         thetis/solver2d.py:974-1144
+ *     -> timestepper.advance(t, update_forcings)   thetis/rungekutta.py:949-952   (ERKGenericShuOsher)
+ *        -> solve_stage(i): LinearVariationalSolver.solve() of  M k = dt R(U)     thetis/rungekutta.py:930-946
+ *           R = ShallowWaterEquations.residual('all', U, U, ...)                  thetis/shallowwater_eq.py:922-928
+ *
+ * and the only contract FlowSolver2d has with a stepper is TimeIntegratorBase (thetis/timeintegrator.py:13-39):
+ * ctor(equation, solution, fields, dt, options, bnd_conditions), initialize(solution), advance(t, update_forcings),
+ * set_dt(dt); state is exchanged in place through `solution`.  Every entry point below names the reference
+ * interface it replaces.  Plain pointers and sizes only; no exceptions cross the boundary: every function
+ * returns 0 on success or a negative swe2d_status, and swe2d_last_error() gives the message.
+ *
+ * Host arrays use the reference's (Firedrake-side, [FD-assumed]) dof layout: cell c owns DG nodes 3c..3c+2 (= its
+ * vertices in cell_vertices order); uv is (3N,2) row-major, eta is (3N).  Device layout is private (SoA planes).
+ *
+ * Threading: one host thread drives a handle; functions are not re-entrant per handle.  All work is enqueued on
+ * the handle's HIP stream; functions that return data to host pointers synchronise that stream.
+ */
+#ifndef SWE2D_H
+#define SWE2D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWE2D_ABI_VERSION 1
+#define SWE2D_MAX_MARKERS 16          /* boundary markers must be in 1..SWE2D_MAX_MARKERS-1 */
+
+typedef enum {
+    SWE2D_OK = 0,
+    SWE2D_ERR_INVALID_ARGUMENT = -1,
+    SWE2D_ERR_NO_DEVICE = -2,          /* no HIP device / HIP runtime error at init: the library never falls back to the CPU */
+    SWE2D_ERR_HIP = -3,
+    SWE2D_ERR_UNSUPPORTED = -4,
+    SWE2D_ERR_NOT_FINITE = -5
+} swe2d_status;
+
+/* Boundary-condition kinds, bitmask.  Keys of bnd_functions['shallow_water'][marker]
+ * (thetis/shallowwater_eq.py:232-296).  0 = closed (land) boundary. */
+#define SWE2D_BC_ELEV 1
+#define SWE2D_BC_UV   2
+#define SWE2D_BC_UN   4
+#define SWE2D_BC_FLUX 8
+
+/* Nodal coefficient fields, `fields` dict of get_swe_timestepper (thetis/solver2d.py:547-559). */
+typedef enum {
+    SWE2D_FIELD_CORIOLIS = 0,              /* options.coriolis_frequency      shallowwater_eq.py:623-634 */
+    SWE2D_FIELD_ATMOSPHERIC_PRESSURE = 1,  /* options.atmospheric_pressure    shallowwater_eq.py:658-663 */
+    SWE2D_FIELD_MOMENTUM_SOURCE = 2,       /* options.momentum_source_2d (3N,2) shallowwater_eq.py:805-811 */
+    SWE2D_FIELD_VOLUME_SOURCE = 3,         /* options.volume_source_2d        shallowwater_eq.py:825-831 */
+    SWE2D_FIELD_COUNT = 4
+} swe2d_field;
+
+/* Scalar coefficients (Constants in the reference). */
+typedef enum {
+    SWE2D_SCALAR_LINEAR_DRAG = 0,          /* options.linear_drag_coefficient     shallowwater_eq.py:734-740 */
+    SWE2D_SCALAR_QUADRATIC_DRAG = 1,       /* options.quadratic_drag_coefficient  shallowwater_eq.py:683,699-700 */
+    SWE2D_SCALAR_MANNING_DRAG = 2,         /* options.manning_drag_coefficient    shallowwater_eq.py:685-688 */
+    SWE2D_SCALAR_NORM_SMOOTHER = 3,        /* options.norm_smoother               shallowwater_eq.py:700 */
+    SWE2D_SCALAR_COUNT = 4
+} swe2d_scalar;
+
+/* Mesh = what FlowSolver2d(mesh2d, bathymetry_2d) receives (thetis/solver2d.py:81-147) flattened to arrays.
+ * Triangles only (nodes_per_cell == 3), counter-clockwise.  Local facet f joins local vertices f and (f+1)%3.
+ * In a multi-GPU partition the first n_owned cells are updated by this handle and cells n_owned..n_cells-1 are
+ * ghost cells (one layer, facet-adjacent) whose state arrives through swe2d_halo_*. */
+typedef struct {
+    int32_t n_cells;
+    int32_t n_owned;                   /* == n_cells on a single device */
+    int32_t n_vertices;
+    int32_t nodes_per_cell;            /* 3 */
+    const int32_t *cell_vertices;      /* [n_cells][3] */
+    const double  *vertex_xy;          /* [n_vertices][2] */
+    const int32_t *cell_neighbours;    /* [n_cells][3]  >=0: neighbour cell, <0: -(boundary marker) */
+    const int8_t  *cell_neighbour_facets; /* [n_cells][3] local facet id of the shared facet inside the neighbour */
+    const double  *bathymetry;         /* [n_vertices] CG-P1 bathymetry, positive down (fields.bathymetry_2d) */
+    const double  *boundary_len;       /* [SWE2D_MAX_MARKERS] total length per marker (utility.py:821-832), may be NULL on
+                                          a single device (computed); REQUIRED for partitions (global lengths) */
+} swe2d_mesh;
+
+/* The ModelOptions2d entries the path reads (thetis/options.py:583-733). */
+typedef struct {
+    double  g_grav;                              /* physical_constants['g_grav'] = 9.81 */
+    double  dt;                                  /* options.timestep */
+    int32_t use_nonlinear_equations;             /* default 1 */
+    int32_t use_lax_friedrichs_velocity;         /* default 1 */
+    double  lax_friedrichs_velocity_scaling_factor; /* default 1.0 */
+    int32_t device_id;                           /* HIP device ordinal */
+} swe2d_params;
+
+typedef struct swe2d_handle swe2d_handle;
+
+/* version / capability */
+int  swe2d_abi_version(void);
+int  swe2d_device_count(void);                                   /* number of visible HIP devices, <0 on error */
+
+/* lifetime: replaces ERKGenericShuOsher.__init__/update_solver (rungekutta.py:877-924) */
+int  swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handle **out);
+void swe2d_destroy(swe2d_handle *h);
+const char *swe2d_last_error(const swe2d_handle *h);             /* h may be NULL: error of the last failed create */
+
+/* state: the mixed Function solution_2d = (uv_2d, elev_2d) (solver2d.py:410-413); host pointers */
+int  swe2d_set_state(swe2d_handle *h, const double *uv, const double *eta);
+int  swe2d_get_state(swe2d_handle *h, double *uv, double *eta);
+
+/* TimeIntegrator.set_dt (timeintegrator.py:70-73) */
+int  swe2d_set_dt(swe2d_handle *h, double dt);
+
+/* bnd_functions['shallow_water'][marker] = {...} with constant values (shallowwater_eq.py:232-272).
+ * kind = bitmask of SWE2D_BC_*; values = {elev, u, v, un, flux}.  May be called between stages
+ * (update_forcings, rungekutta.py:933-934). */
+int  swe2d_set_bc(swe2d_handle *h, int marker, int kind, const double values[5]);
+
+/* coefficient fields: nodal DG-P1 values (3N) [(3N,2) for the momentum source] or NULL to switch the term off */
+int  swe2d_set_field(swe2d_handle *h, int field, const double *nodal);
+/* scalar coefficients; a negative value switches the term off (norm_smoother: >= 0) */
+int  swe2d_set_scalar(swe2d_handle *h, int which, double value);
+
+/* ERKGenericShuOsher.advance (rungekutta.py:949-952) repeated n_steps times, forcings constant in time.
+ * Asynchronous: returns after enqueueing. */
+int  swe2d_advance(swe2d_handle *h, int n_steps);
+/* ERKGenericShuOsher.solve_stage(i_stage) (rungekutta.py:930-946); i_stage = 0,1,2 in order. */
+int  swe2d_solve_stage(swe2d_handle *h, int i_stage);
+/* n_steps steps bracketed by HIP events on the handle's stream; *ms_total = elapsed GPU time,
+ * *ms_kernel_avg = mean duration of one stage kernel launch (events around every launch when per_launch != 0). */
+int  swe2d_advance_timed(swe2d_handle *h, int n_steps, int per_launch, float *ms_total, float *ms_kernel_avg);
+int  swe2d_synchronize(swe2d_handle *h);
+
+/* parity hook: tendency k = M^-1 (dt R(U)) of the current state (what solver.solve() leaves in `tendency`,
+ * rungekutta.py:940), host layout as the state. */
+int  swe2d_tendency(swe2d_handle *h, double *k_uv, double *k_eta);
+
+/* print_state norms + VolumeConservation2DCallback (solver2d.py:955-956, callback.py:350-364, utility.py:421-425):
+ * out = { int eta^2 dx, int |u|^2 dx, int (eta+h) dx, min nodal (h+eta) } over the owned cells
+ * (sums, not roots, so that partitions can be added). */
+int  swe2d_diagnostics(swe2d_handle *h, double out[4]);
+
+/* ---- multi-GPU plumbing (one process per GPU; the exchange itself is done by the host with RCCL) ----
+ * send_cells: local ids of owned cells whose state peers need, grouped by peer; the n_cells-n_owned ghost cells are
+ * stored in the order the peers' send lists deliver them.  Buffers are device pointers owned by the caller
+ * (cell-major: 9 doubles u0 u1 u2 v0 v1 v2 e0 e1 e2 per cell, [n][9], so per-peer segments are contiguous). */
+int  swe2d_halo_setup(swe2d_handle *h, int32_t n_send, const int32_t *send_cells);
+int  swe2d_halo_pack(swe2d_handle *h, int i_stage, double *send_buf_dev);          /* state entering stage i */
+int  swe2d_halo_unpack(swe2d_handle *h, int i_stage, const double *recv_buf_dev);
+/* stage split for overlap: cells [0, n_interior) need no ghost data, cells [n_interior, n_owned) do. */
+int  swe2d_set_interior_split(swe2d_handle *h, int32_t n_interior);
+int  swe2d_solve_stage_range(swe2d_handle *h, int i_stage, int which /*0: interior, 1: boundary, 2: all*/);
+/* run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the handle's own */
+int  swe2d_set_stream(swe2d_handle *h, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWE2D_H */

@@ -1,0 +1,35 @@
+"""Shared builders for the parity tests (mesh + seeded state + the two checkers)."""
+import numpy as np
+
+from thetis_amd.mesh import RectangleMesh, _rect_marker_fn
+
+
+def channel_case(nx=12, ny=5, lx=100e3, ly=30e3, seed=0, amp_eta=0.5, amp_u=0.5, flat=False):
+    mesh = RectangleMesh(nx, ny, lx, ly)
+    x, y = mesh.vertex_xy.T
+    bath = np.full(len(x), 20.0) if flat else 20.0 - 15.0*x/lx + 2.0*np.sin(y/5000.0)
+    rng = np.random.default_rng(seed)
+    n = mesh.num_cells
+    uv = amp_u*rng.normal(size=(n, 3, 2))
+    eta = amp_eta*rng.normal(size=(n, 3))
+    return mesh, bath, uv, eta
+
+
+def make_oracle(mesh, bath, **kw):
+    from oracle.swe2d_oracle import SWEOracle
+    return SWEOracle(mesh.vertex_xy, mesh.cells, bath, topo_vertex=mesh.topo_vertex,
+                     marker_fn=_rect_marker_fn(mesh.lx, mesh.ly), **kw)
+
+
+def make_ref(mesh, bath, **kw):
+    from oracle.ref_lib import RefSWE
+    kw = dict(kw)
+    for k in ('coriolis', 'atmospheric_pressure'):
+        if k in kw and kw[k] is not None and np.ndim(kw[k]) == 1:
+            kw[k] = np.asarray(kw[k])[mesh.cells]
+    return RefSWE(mesh.cell_xy(), mesh.cell_nbr, mesh.cell_nbr_facet, np.asarray(bath)[mesh.cells],
+                  boundary_len=mesh.boundary_len, **kw)
+
+
+def rel_linf(a, b):
+    return float(np.abs(a - b).max()/max(np.abs(b).max(), 1e-300))

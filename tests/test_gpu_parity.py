@@ -1,0 +1,177 @@
+"""
+GPU parity tests proper: the HIP path, called through the C ABI, against the oracle on the same seeded inputs.
+
+Tolerance (FP64): rel. Linf <= 1e-12 per tendency evaluation, <= 1e-10 after 100 steps.
+The device kernel uses FMA contraction and the algebraically equal sqrt(g*H) for g*sqrt(H/g) and H*sqrt(g/H), so
+bitwise identity with the CPU is not expected; 1e-12 leaves ~4 decimal digits of slack over observed round-off.
+"""
+import numpy as np
+import pytest
+
+from helpers import channel_case, make_oracle, make_ref, rel_linf
+
+pytestmark = pytest.mark.gpu
+
+TOL_RHS = 1e-12
+TOL_100 = 1e-10
+
+
+def _device(mesh, bath, dt, **kw):
+    from thetis_amd.device import Swe2dDevice
+    return Swe2dDevice(mesh, bath, dt, **kw)
+
+
+@pytest.mark.parametrize('opts', [
+    dict(),
+    dict(use_nonlinear_equations=False),
+    dict(use_lax_friedrichs_velocity=False),
+    dict(lax_friedrichs_velocity_scaling_factor=0.5),
+])
+def test_tendency_matches_numpy_oracle(hip_lib, opts):
+    mesh, bath, uv, eta = channel_case()
+    dt = 3.0
+    orc = make_oracle(mesh, bath, **opts)
+    ku_o, ke_o = orc.tendency(uv, eta, dt)
+    dev = _device(mesh, bath, dt, **opts)
+    dev.set_state(uv, eta)
+    ku, ke = dev.tendency()
+    assert rel_linf(ku, ku_o) < TOL_RHS
+    assert rel_linf(ke, ke_o) < TOL_RHS
+    # set/get round trip is exact
+    uv2, eta2 = dev.get_state()
+    assert np.array_equal(uv2, uv) and np.array_equal(eta2, eta)
+    dev.close()
+
+
+def test_step_matches_numpy_oracle(hip_lib):
+    mesh, bath, uv, eta = channel_case(amp_eta=0.3, amp_u=0.2)
+    dt = 2.0
+    orc = make_oracle(mesh, bath)
+    uo, eo = uv, eta
+    dev = _device(mesh, bath, dt)
+    dev.set_state(uv, eta)
+    for _ in range(3):
+        uo, eo = orc.ssprk33_step(uo, eo, dt)
+    dev.advance(3)
+    ud, ed = dev.get_state()
+    assert rel_linf(ud, uo) < 10*TOL_RHS
+    assert rel_linf(ed, eo) < 10*TOL_RHS
+    # stage-by-stage entry point gives the same result as advance()
+    dev.set_state(uv, eta)
+    for _ in range(3):
+        for s in range(3):
+            dev.solve_stage(s)
+    ud2, ed2 = dev.get_state()
+    assert np.array_equal(ud, ud2) and np.array_equal(ed, ed2)
+    dev.close()
+
+
+def test_source_terms_match_oracle(hip_lib):
+    from thetis_amd import _lib
+    mesh, bath, uv, eta = channel_case(seed=3)
+    x, y = mesh.vertex_xy.T
+    rng = np.random.default_rng(5)
+    n = mesh.num_cells
+    cor = 1e-4*(1 + y/30e3)
+    patm = 1e5 + 300*np.sin(x/2e4)
+    msrc = 1e-3*rng.normal(size=(n, 3, 2))
+    vsrc = 1e-3*rng.normal(size=(n, 3))
+    dt = 3.0
+    cases = [
+        dict(coriolis=cor, linear_drag_coefficient=1e-3, atmospheric_pressure=patm, momentum_source=msrc, volume_source=vsrc),
+        dict(manning_drag_coefficient=0.02),
+        dict(quadratic_drag_coefficient=0.0025, norm_smoother=0.1),
+    ]
+    for kw in cases:
+        orc = make_oracle(mesh, bath, **kw)
+        ku_o, ke_o = orc.tendency(uv, np.abs(eta), dt)
+        dev = _device(mesh, bath, dt)
+        if 'coriolis' in kw:
+            dev.set_field(_lib.FIELD_CORIOLIS, cor[mesh.cells])
+            dev.set_field(_lib.FIELD_ATMOSPHERIC_PRESSURE, patm[mesh.cells])
+            dev.set_field(_lib.FIELD_MOMENTUM_SOURCE, msrc)
+            dev.set_field(_lib.FIELD_VOLUME_SOURCE, vsrc)
+            dev.set_scalar(_lib.SCALAR_LINEAR_DRAG, 1e-3)
+        if 'manning_drag_coefficient' in kw:
+            dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+        if 'quadratic_drag_coefficient' in kw:
+            dev.set_scalar(_lib.SCALAR_QUADRATIC_DRAG, 0.0025)
+            dev.set_scalar(_lib.SCALAR_NORM_SMOOTHER, 0.1)
+        dev.set_state(uv, np.abs(eta))
+        ku, ke = dev.tendency()
+        assert rel_linf(ku, ku_o) < TOL_RHS, kw.keys()
+        assert rel_linf(ke, ke_o) < TOL_RHS, kw.keys()
+        dev.close()
+
+
+@pytest.mark.parametrize('bcs', [
+    {1: {'elev': 0.3}, 2: {'un': 0.2}, 3: {'flux': 1e4, 'elev': 0.1}},
+    {4: {'uv': (0.1, -0.2)}, 1: {'flux': -3e3}, 2: {'elev': 0.1, 'uv': (0.3, 0.1)}, 3: {'elev': -0.1, 'un': 0.05}},
+])
+def test_open_boundaries_match_oracle(hip_lib, bcs):
+    mesh, bath, uv, eta = channel_case(seed=11)
+    dt = 3.0
+    orc = make_oracle(mesh, bath, bnd_conditions=bcs)
+    ku_o, ke_o = orc.tendency(uv, eta, dt)
+    dev = _device(mesh, bath, dt)
+    for marker, funcs in bcs.items():
+        dev.set_bc(marker, funcs)
+    dev.set_state(uv, eta)
+    ku, ke = dev.tendency()
+    assert rel_linf(ku, ku_o) < TOL_RHS
+    assert rel_linf(ke, ke_o) < TOL_RHS
+    dev.close()
+
+
+def test_100_steps_vs_c_restatement_medium_mesh(hip_lib, ref_so):
+    """40k triangles, 100 SSPRK33 steps, against the C restatement (itself pinned to the numpy oracle)."""
+    mesh, bath, _, _ = channel_case(nx=200, ny=100, lx=100e3, ly=50e3)
+    n = mesh.num_cells
+    rng = np.random.default_rng(1234)
+    cx, cy = mesh.cell_xy()[:, :, 0], mesh.cell_xy()[:, :, 1]
+    eta = 0.5*np.exp(-((cx - 50e3)**2 + (cy - 25e3)**2)/(5e3)**2) + 1e-3*rng.uniform(-1, 1, size=(n, 3))
+    uv = 1e-3*rng.uniform(-1, 1, size=(n, 3, 2))
+    dt = 1.0
+    ref = make_ref(mesh, bath)
+    dev = _device(mesh, bath, dt)
+    dev.set_state(uv, eta)
+    ku, ke = dev.tendency()
+    ku_r, ke_r = ref.tendency(uv, eta, dt)
+    assert rel_linf(ku, ku_r) < TOL_RHS and rel_linf(ke, ke_r) < TOL_RHS
+    dev.advance(100)
+    ud, ed = dev.get_state()
+    ur, er = ref.advance(uv, eta, dt, 100)
+    assert rel_linf(ud, ur) < TOL_100
+    assert rel_linf(ed, er) < TOL_100
+    # closed domain: volume is conserved to round-off (test/barotropicChannel/test_closed_channel.py:77-78 bar: 1e-12)
+    d1 = dev.diagnostics()
+    dev.set_state(uv, eta)
+    d0 = dev.diagnostics()
+    assert abs(d1[2] - d0[2])/d0[2] < 1e-12
+    dev.close()
+
+
+def test_full_size_properties(hip_lib):
+    """BASELINE cfg 2 size (1M triangles): size-independent properties - lake at rest, volume conservation."""
+    from thetis_amd.mesh import RectangleMesh
+    mesh = RectangleMesh(1000, 500, 100e3, 50e3)
+    x, y = mesh.vertex_xy.T
+    bath = 20.0 - 10.0*x/100e3 + 2.0*np.sin(y/5000.0)
+    n = mesh.num_cells
+    dt = 0.25
+    dev = _device(mesh, bath, dt)
+    # lake at rest over variable bathymetry: tendency is zero to round-off
+    dev.set_state(np.zeros((n, 3, 2)), np.full((n, 3), 0.37))
+    ku, ke = dev.tendency()
+    assert np.abs(ku).max() < 1e-13*9.81*20 and np.abs(ke).max() == 0.0
+    rng = np.random.default_rng(1234)
+    cx, cy = mesh.cell_xy()[:, :, 0], mesh.cell_xy()[:, :, 1]
+    eta = 0.5*np.exp(-((cx - 50e3)**2 + (cy - 25e3)**2)/(5e3)**2) + 1e-3*rng.uniform(-1, 1, size=(n, 3))
+    uv = 1e-3*rng.uniform(-1, 1, size=(n, 3, 2))
+    dev.set_state(uv, eta)
+    d0 = dev.diagnostics()
+    dev.advance(20)
+    d1 = dev.diagnostics()
+    assert abs(d1[2] - d0[2])/d0[2] < 1e-12
+    assert np.isfinite(d1).all()
+    dev.close()

@@ -1,0 +1,102 @@
+"""
+ctypes binding of the C ABI declared in include/swe2d.h (libswe2d_hip.so).
+
+There is deliberately no fallback: if the shared library is missing this raises, and if no HIP device is
+visible ``swe2d_create`` fails with SWE2D_ERR_NO_DEVICE - the product never computes on the CPU.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libswe2d_hip.so')
+
+MAX_MARKERS = 16
+BC_ELEV, BC_UV, BC_UN, BC_FLUX = 1, 2, 4, 8
+FIELD_CORIOLIS, FIELD_ATMOSPHERIC_PRESSURE, FIELD_MOMENTUM_SOURCE, FIELD_VOLUME_SOURCE = 0, 1, 2, 3
+SCALAR_LINEAR_DRAG, SCALAR_QUADRATIC_DRAG, SCALAR_MANNING_DRAG, SCALAR_NORM_SMOOTHER = 0, 1, 2, 3
+
+OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NOT_FINITE = 0, -1, -2, -3, -4, -5
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+_bp = ctypes.POINTER(ctypes.c_int8)
+
+
+class Swe2dMesh(ctypes.Structure):
+    _fields_ = [('n_cells', ctypes.c_int32), ('n_owned', ctypes.c_int32), ('n_vertices', ctypes.c_int32),
+                ('nodes_per_cell', ctypes.c_int32), ('cell_vertices', _ip), ('vertex_xy', _dp),
+                ('cell_neighbours', _ip), ('cell_neighbour_facets', _bp), ('bathymetry', _dp),
+                ('boundary_len', _dp)]
+
+
+class Swe2dParams(ctypes.Structure):
+    _fields_ = [('g_grav', ctypes.c_double), ('dt', ctypes.c_double),
+                ('use_nonlinear_equations', ctypes.c_int32), ('use_lax_friedrichs_velocity', ctypes.c_int32),
+                ('lax_friedrichs_velocity_scaling_factor', ctypes.c_double), ('device_id', ctypes.c_int32)]
+
+
+# every symbol include/swe2d.h declares: name -> (restype, argtypes)
+_H = ctypes.c_void_p
+SYMBOLS = {
+    'swe2d_abi_version': (ctypes.c_int, []),
+    'swe2d_device_count': (ctypes.c_int, []),
+    'swe2d_create': (ctypes.c_int, [ctypes.POINTER(Swe2dMesh), ctypes.POINTER(Swe2dParams), ctypes.POINTER(_H)]),
+    'swe2d_destroy': (None, [_H]),
+    'swe2d_last_error': (ctypes.c_char_p, [_H]),
+    'swe2d_set_state': (ctypes.c_int, [_H, _dp, _dp]),
+    'swe2d_get_state': (ctypes.c_int, [_H, _dp, _dp]),
+    'swe2d_set_dt': (ctypes.c_int, [_H, ctypes.c_double]),
+    'swe2d_set_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),
+    'swe2d_set_field': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
+    'swe2d_set_scalar': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_double]),
+    'swe2d_advance': (ctypes.c_int, [_H, ctypes.c_int]),
+    'swe2d_solve_stage': (ctypes.c_int, [_H, ctypes.c_int]),
+    'swe2d_advance_timed': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
+                                           ctypes.POINTER(ctypes.c_float)]),
+    'swe2d_synchronize': (ctypes.c_int, [_H]),
+    'swe2d_tendency': (ctypes.c_int, [_H, _dp, _dp]),
+    'swe2d_diagnostics': (ctypes.c_int, [_H, _dp]),
+    'swe2d_halo_setup': (ctypes.c_int, [_H, ctypes.c_int32, _ip]),
+    'swe2d_halo_pack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_void_p]),
+    'swe2d_halo_unpack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_void_p]),
+    'swe2d_set_interior_split': (ctypes.c_int, [_H, ctypes.c_int32]),
+    'swe2d_solve_stage_range': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int]),
+    'swe2d_set_stream': (ctypes.c_int, [_H, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+class Swe2dError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('swe2d error {:d}: {:s}'.format(code, msg))
+        self.code = code
+
+
+def load():
+    """Load libswe2d_hip.so (built by ``thetis_amd._build.build`` / ``__graft_entry__.build``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('HIP extension {:} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                          '(there is no CPU fallback)'.format(LIB_PATH))
+    # PyTorch-ROCm bundles its own libamdhip64; two HIP runtimes in one process do not see each other's devices.
+    # Import torch first (when present) so that the extension binds to the runtime torch uses for RCCL / streams.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)         # AttributeError if the library does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, handle=None):
+    if rc != OK:
+        msg = load().swe2d_last_error(handle)
+        raise Swe2dError(rc, msg.decode() if msg else '')

@@ -1,0 +1,587 @@
+// swe2d_api.hip - C ABI (include/swe2d.h) over the HIP stage kernels.  gfx950 only, no CPU fallback: every entry
+// point fails with SWE2D_ERR_NO_DEVICE / SWE2D_ERR_HIP when the HIP runtime or a device is missing.
+#include "../../include/swe2d.h"
+#include "swe2d_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+static_assert(SWE2D_MAX_MARKERS == SWE_MAX_MARKERS, "marker table size mismatch");
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// Shu-Osher coefficients of SSPRK33: output of thetis/rungekutta.py:13-87 (butcher_to_shuosher_form) for the
+// tableau of rungekutta.py:342-346; pinned by tests/golden/shuosher_ssprk33.json.
+//   U1 = 1*k0 + 1*U0;  U2 = 1/4*k1 + 3/4*U0 + 1/4*U1;  U3 = b32*k2 + a30*U0 + a32*U2
+const double kBeta[3] = {1.0, 0.25, 0.6666666666666666};
+const double kAlpha0[3] = {1.0, 0.75, 0.33333333333333337};   // weight of stage_sol[0]
+const double kAlphaIn[3] = {0.0, 0.25, 0.6666666666666666};   // weight of the stage's input (stage 0: U0 itself)
+
+struct Handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipStream_t my_stream = nullptr;
+    int n_cells = 0, n_owned = 0, n_interior = 0, n_vertices = 0;
+    size_t stride = 0;
+    double *state[3] = {nullptr, nullptr, nullptr};   // A (U0 / step result), B (U1), C (U2)
+    int *nbr = nullptr, *cv = nullptr;
+    double *vx = nullptr, *vy = nullptr, *vh = nullptr;
+    double *field[SWE2D_FIELD_COUNT] = {nullptr, nullptr, nullptr, nullptr};
+    double scalar[SWE2D_SCALAR_COUNT] = {-1.0, -1.0, -1.0, 0.0};
+    double *stage_uv = nullptr, *stage_eta = nullptr;  // device staging in host layout (6N + 3N)
+    double *partial = nullptr;                         // diagnostics partial sums
+    int n_partial_blocks = 0;
+    int *send_cells = nullptr;
+    int n_send = 0;
+    swe2d_params par{};
+    SweBcTable bc{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+};
+
+inline Handle *H(swe2d_handle *h) { return reinterpret_cast<Handle *>(h); }
+inline const Handle *H(const swe2d_handle *h) { return reinterpret_cast<const Handle *>(h); }
+
+int fail(Handle *h, int code, const std::string &msg)
+{
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(h, SWE2D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+bool has_sources(const Handle *h)
+{
+    for (int i = 0; i < SWE2D_FIELD_COUNT; i++) if (h->field[i]) return true;
+    return h->scalar[SWE2D_SCALAR_LINEAR_DRAG] >= 0 || h->scalar[SWE2D_SCALAR_QUADRATIC_DRAG] >= 0
+           || h->scalar[SWE2D_SCALAR_MANNING_DRAG] >= 0;
+}
+
+typedef void (*stage_kernel_t)(const SweStageArgs);
+
+template <bool NL, bool LF, bool U0>
+stage_kernel_t pick_src(bool src)
+{
+    return src ? swe_stage_kernel<NL, LF, U0, true> : swe_stage_kernel<NL, LF, U0, false>;
+}
+template <bool NL, bool LF>
+stage_kernel_t pick_u0(bool u0, bool src) { return u0 ? pick_src<NL, LF, true>(src) : pick_src<NL, LF, false>(src); }
+template <bool NL>
+stage_kernel_t pick_lf(bool lf, bool u0, bool src) { return lf ? pick_u0<NL, true>(u0, src) : pick_u0<NL, false>(u0, src); }
+stage_kernel_t pick_kernel(bool nl, bool lf, bool u0, bool src)
+{
+    return nl ? pick_lf<true>(lf, u0, src) : pick_lf<false>(lf, u0, src);
+}
+
+// Launch one stage on cells [c0, c1).  in/out/u0 are state buffer indices.
+int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1)
+{
+    if (c1 <= c0) return SWE2D_OK;
+    SweStageArgs a;
+    a.uin = h->state[in];
+    a.u0 = h->state[u0];
+    a.uout = h->state[out];
+    a.stride = h->stride;
+    a.nbr = h->nbr;
+    a.cv = h->cv;
+    a.vx = h->vx; a.vy = h->vy; a.vh = h->vh;
+    a.cell_begin = c0; a.cell_end = c1;
+    a.g = h->par.g_grav;
+    a.sigma_lf = h->par.lax_friedrichs_velocity_scaling_factor;
+    a.dt = h->par.dt;
+    a.a0 = a0; a.a1 = a1; a.beta = beta;
+    a.coriolis = h->field[SWE2D_FIELD_CORIOLIS];
+    a.patm = h->field[SWE2D_FIELD_ATMOSPHERIC_PRESSURE];
+    a.msrc = h->field[SWE2D_FIELD_MOMENTUM_SOURCE];
+    a.vsrc = h->field[SWE2D_FIELD_VOLUME_SOURCE];
+    a.linear_drag = h->scalar[SWE2D_SCALAR_LINEAR_DRAG];
+    a.quad_drag = h->scalar[SWE2D_SCALAR_QUADRATIC_DRAG];
+    a.manning = h->scalar[SWE2D_SCALAR_MANNING_DRAG];
+    a.norm_smoother = h->scalar[SWE2D_SCALAR_NORM_SMOOTHER];
+    a.bc = h->bc;
+    const bool has_u0 = (a0 != 0.0);
+    stage_kernel_t kern = pick_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0,
+                                      has_u0, has_sources(h));
+    const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
+    // the XCD-chunked block map needs a grid that is a multiple of 8; surplus blocks exit immediately
+    const int grid = ((nblocks + 7)/8)*8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
+}
+
+// stage i of the Shu-Osher SSPRK33 (rungekutta.py:930-946): buffers A -> B -> C -> A
+int stage_on_range(Handle *h, int i_stage, int c0, int c1)
+{
+    switch (i_stage) {
+    case 0: return launch_stage(h, 0, 0, 1, 0.0, 1.0, kBeta[0], c0, c1);          // U1 = k + U0 (U0 is the input)
+    case 1: return launch_stage(h, 1, 0, 2, kAlpha0[1], kAlphaIn[1], kBeta[1], c0, c1);
+    case 2: return launch_stage(h, 2, 0, 0, kAlpha0[2], kAlphaIn[2], kBeta[2], c0, c1);
+    default: return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "i_stage must be 0, 1 or 2");
+    }
+}
+
+int grid_for(int n) { return (n + 255)/256; }
+
+}  // namespace
+
+extern "C" {
+
+int swe2d_abi_version(void) { return SWE2D_ABI_VERSION; }
+
+int swe2d_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return SWE2D_ERR_NO_DEVICE;
+    return n;
+}
+
+const char *swe2d_last_error(const swe2d_handle *h)
+{
+    return h ? H(h)->err.c_str() : g_create_error.c_str();
+}
+
+int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handle **out)
+{
+    if (!mesh || !params || !out) return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (mesh->nodes_per_cell != 3)
+        return fail(nullptr, SWE2D_ERR_UNSUPPORTED, "only triangles (nodes_per_cell == 3) are supported");
+    if (mesh->n_cells <= 0 || mesh->n_owned <= 0 || mesh->n_owned > mesh->n_cells || mesh->n_vertices <= 0)
+        return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "bad mesh sizes");
+    if (mesh->n_cells >= (1 << 29))
+        return fail(nullptr, SWE2D_ERR_UNSUPPORTED, "more than 2^29 cells per device");
+    if (!mesh->cell_vertices || !mesh->vertex_xy || !mesh->cell_neighbours || !mesh->cell_neighbour_facets
+        || !mesh->bathymetry)
+        return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "null mesh array");
+    if (!(params->dt > 0.0) || !(params->g_grav > 0.0))
+        return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "dt and g_grav must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, SWE2D_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (params->device_id < 0 || params->device_id >= ndev)
+        return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "device_id out of range");
+
+    Handle *h = new (std::nothrow) Handle();
+    if (!h) return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "out of host memory");
+    h->device = params->device_id;
+    h->par = *params;
+    const int n = mesh->n_cells, nv = mesh->n_vertices;
+    h->n_cells = n; h->n_owned = mesh->n_owned; h->n_interior = mesh->n_owned; h->n_vertices = nv;
+    h->stride = ((size_t)n + 255)/256*256;
+
+#define HIP_TRY_C(expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            int rc_ = fail(nullptr, SWE2D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+            swe2d_destroy(reinterpret_cast<swe2d_handle *>(h));                                          \
+            return rc_;                                                                                  \
+        }                                                                                                \
+    } while (0)
+
+    HIP_TRY_C(hipSetDevice(h->device));
+    HIP_TRY_C(hipStreamCreateWithFlags(&h->my_stream, hipStreamNonBlocking));
+    h->stream = h->my_stream; h->own_stream = true;
+    HIP_TRY_C(hipEventCreate(&h->ev0));
+    HIP_TRY_C(hipEventCreate(&h->ev1));
+    const size_t S = h->stride;
+    for (int b = 0; b < 3; b++) {
+        HIP_TRY_C(hipMalloc(&h->state[b], 9*S*sizeof(double)));
+        HIP_TRY_C(hipMemsetAsync(h->state[b], 0, 9*S*sizeof(double), h->stream));
+    }
+    HIP_TRY_C(hipMalloc(&h->nbr, 3*S*sizeof(int)));
+    HIP_TRY_C(hipMalloc(&h->cv, 3*S*sizeof(int)));
+    HIP_TRY_C(hipMalloc(&h->vx, (size_t)nv*sizeof(double)));
+    HIP_TRY_C(hipMalloc(&h->vy, (size_t)nv*sizeof(double)));
+    HIP_TRY_C(hipMalloc(&h->vh, (size_t)nv*sizeof(double)));
+    HIP_TRY_C(hipMalloc(&h->stage_uv, 6*(size_t)n*sizeof(double)));
+    HIP_TRY_C(hipMalloc(&h->stage_eta, 3*(size_t)n*sizeof(double)));
+    h->n_partial_blocks = (h->n_owned + SWE_BLOCK - 1)/SWE_BLOCK;
+    HIP_TRY_C(hipMalloc(&h->partial, 4*(size_t)h->n_partial_blocks*sizeof(double)));
+
+    // connectivity -> SoA planes, validated on the way
+    std::vector<int> nbr(3*S, 0), cv(3*S, 0);
+    std::vector<double> vx(nv), vy(nv), vh(nv);
+    double blen[SWE2D_MAX_MARKERS];
+    for (int m = 0; m < SWE2D_MAX_MARKERS; m++) blen[m] = 0.0;
+    for (int i = 0; i < nv; i++) {
+        vx[i] = mesh->vertex_xy[2*(size_t)i];
+        vy[i] = mesh->vertex_xy[2*(size_t)i + 1];
+        vh[i] = mesh->bathymetry[i];
+    }
+    for (int k = 0; k < n; k++) {
+        for (int f = 0; f < 3; f++) {
+            const int vid = mesh->cell_vertices[3*(size_t)k + f];
+            if (vid < 0 || vid >= nv) {
+                swe2d_destroy(reinterpret_cast<swe2d_handle *>(h));
+                return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "cell_vertices entry out of range");
+            }
+            cv[(size_t)f*S + k] = vid;
+            const int nb = mesh->cell_neighbours[3*(size_t)k + f];
+            int packed;
+            if (nb >= 0) {
+                const int f2 = mesh->cell_neighbour_facets[3*(size_t)k + f];
+                if (nb >= n || f2 < 0 || f2 > 2) {
+                    swe2d_destroy(reinterpret_cast<swe2d_handle *>(h));
+                    return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "cell_neighbours entry out of range");
+                }
+                packed = (nb << 2) | f2;
+            } else {
+                const int marker = -nb;
+                if (marker >= SWE2D_MAX_MARKERS && k < mesh->n_owned) {
+                    swe2d_destroy(reinterpret_cast<swe2d_handle *>(h));
+                    return fail(nullptr, SWE2D_ERR_UNSUPPORTED, "boundary marker >= SWE2D_MAX_MARKERS");
+                }
+                packed = -marker;
+                if (k < mesh->n_owned && marker < SWE2D_MAX_MARKERS) {
+                    const int va = mesh->cell_vertices[3*(size_t)k + f], vb = mesh->cell_vertices[3*(size_t)k + (f + 1) % 3];
+                    blen[marker] += std::hypot(vx[vb] - vx[va], vy[vb] - vy[va]);
+                }
+            }
+            nbr[(size_t)f*S + k] = packed;
+        }
+        // orientation check
+        const int a = mesh->cell_vertices[3*(size_t)k], b = mesh->cell_vertices[3*(size_t)k + 1],
+                  c = mesh->cell_vertices[3*(size_t)k + 2];
+        const double area2 = (vx[b] - vx[a])*(vy[c] - vy[a]) - (vx[c] - vx[a])*(vy[b] - vy[a]);
+        if (!(area2 > 0.0)) {
+            swe2d_destroy(reinterpret_cast<swe2d_handle *>(h));
+            return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "cells must be counter-clockwise with positive area");
+        }
+    }
+    if (mesh->n_owned != mesh->n_cells && !mesh->boundary_len) {
+        swe2d_destroy(reinterpret_cast<swe2d_handle *>(h));
+        return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "boundary_len is required for a partitioned mesh");
+    }
+    std::memset(&h->bc, 0, sizeof(h->bc));
+    for (int m = 0; m < SWE2D_MAX_MARKERS; m++) h->bc.len[m] = mesh->boundary_len ? mesh->boundary_len[m] : blen[m];
+
+    HIP_TRY_C(hipMemcpyAsync(h->nbr, nbr.data(), 3*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY_C(hipMemcpyAsync(h->cv, cv.data(), 3*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY_C(hipMemcpyAsync(h->vx, vx.data(), (size_t)nv*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY_C(hipMemcpyAsync(h->vy, vy.data(), (size_t)nv*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY_C(hipMemcpyAsync(h->vh, vh.data(), (size_t)nv*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY_C(hipStreamSynchronize(h->stream));
+#undef HIP_TRY_C
+    *out = reinterpret_cast<swe2d_handle *>(h);
+    return SWE2D_OK;
+}
+
+void swe2d_destroy(swe2d_handle *hh)
+{
+    Handle *h = H(hh);
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->my_stream) (void)hipStreamSynchronize(h->my_stream);
+    for (int b = 0; b < 3; b++) if (h->state[b]) (void)hipFree(h->state[b]);
+    for (int i = 0; i < SWE2D_FIELD_COUNT; i++) if (h->field[i]) (void)hipFree(h->field[i]);
+    void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->my_stream) (void)hipStreamDestroy(h->my_stream);
+    delete h;
+}
+
+int swe2d_set_stream(swe2d_handle *hh, void *hip_stream)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (hip_stream) { h->stream = reinterpret_cast<hipStream_t>(hip_stream); h->own_stream = false; }
+    else { h->stream = h->my_stream; h->own_stream = true; }
+    return SWE2D_OK;
+}
+
+int swe2d_set_state(swe2d_handle *hh, const double *uv, const double *eta)
+{
+    Handle *h = H(hh);
+    if (!h || !uv || !eta) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t n = h->n_cells;
+    HIP_TRY(h, hipMemcpyAsync(h->stage_uv, uv, 6*n*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->stage_eta, eta, 3*n*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(swe_aos_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                       h->stage_uv, h->stage_eta, h->state[0], h->stride, h->n_cells);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
+    return SWE2D_OK;
+}
+
+int swe2d_get_state(swe2d_handle *hh, double *uv, double *eta)
+{
+    Handle *h = H(hh);
+    if (!h || !uv || !eta) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t n = h->n_cells;
+    hipLaunchKernelGGL(swe_planes_to_aos, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                       h->state[0], h->stage_uv, h->stage_eta, h->stride, h->n_cells);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(uv, h->stage_uv, 6*n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(eta, h->stage_eta, 3*n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWE2D_OK;
+}
+
+int swe2d_set_dt(swe2d_handle *hh, double dt)
+{
+    Handle *h = H(hh);
+    if (!h || !(dt > 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "dt must be positive");
+    h->par.dt = dt;
+    return SWE2D_OK;
+}
+
+int swe2d_set_bc(swe2d_handle *hh, int marker, int kind, const double values[5])
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (marker <= 0 || marker >= SWE2D_MAX_MARKERS) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "marker out of range");
+    if (kind & ~(SWE2D_BC_ELEV | SWE2D_BC_UV | SWE2D_BC_UN | SWE2D_BC_FLUX))
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "unknown boundary kind bits");
+    if (kind != 0 && !values) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "values required");
+    h->bc.kind[marker] = kind;
+    if (values) {
+        h->bc.elev[marker] = values[0];
+        h->bc.u[marker] = values[1];
+        h->bc.v[marker] = values[2];
+        h->bc.un[marker] = values[3];
+        h->bc.flux[marker] = values[4];
+    }
+    return SWE2D_OK;
+}
+
+int swe2d_set_field(swe2d_handle *hh, int field, const double *nodal)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (field < 0 || field >= SWE2D_FIELD_COUNT) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "unknown field id");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int ncomp = (field == SWE2D_FIELD_MOMENTUM_SOURCE) ? 2 : 1;
+    if (!nodal) {
+        if (h->field[field]) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            HIP_TRY(h, hipFree(h->field[field]));
+            h->field[field] = nullptr;
+        }
+        return SWE2D_OK;
+    }
+    if (!h->field[field]) {
+        HIP_TRY(h, hipMalloc(&h->field[field], 3*(size_t)ncomp*h->stride*sizeof(double)));
+        HIP_TRY(h, hipMemsetAsync(h->field[field], 0, 3*(size_t)ncomp*h->stride*sizeof(double), h->stream));
+    }
+    // stage through stage_uv (6N doubles is enough for either shape)
+    const size_t n = h->n_cells;
+    HIP_TRY(h, hipMemcpyAsync(h->stage_uv, nodal, 3*(size_t)ncomp*n*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(swe_nodal_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                       h->stage_uv, h->field[field], h->stride, h->n_cells, ncomp);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWE2D_OK;
+}
+
+int swe2d_set_scalar(swe2d_handle *hh, int which, double value)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (which < 0 || which >= SWE2D_SCALAR_COUNT) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "unknown scalar id");
+    if (which == SWE2D_SCALAR_NORM_SMOOTHER && value < 0.0)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "norm_smoother must be >= 0");
+    if (which == SWE2D_SCALAR_MANNING_DRAG && value >= 0.0 && h->scalar[SWE2D_SCALAR_QUADRATIC_DRAG] >= 0.0)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "Cannot set both dimensionless and Manning drag parameter");
+    if (which == SWE2D_SCALAR_QUADRATIC_DRAG && value >= 0.0 && h->scalar[SWE2D_SCALAR_MANNING_DRAG] >= 0.0)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "Cannot set both dimensionless and Manning drag parameter");
+    h->scalar[which] = value;
+    return SWE2D_OK;
+}
+
+int swe2d_set_interior_split(swe2d_handle *hh, int32_t n_interior)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (n_interior < 0 || n_interior > h->n_owned) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "n_interior out of range");
+    h->n_interior = n_interior;
+    return SWE2D_OK;
+}
+
+int swe2d_solve_stage_range(swe2d_handle *hh, int i_stage, int which)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    switch (which) {
+    case 0: return stage_on_range(h, i_stage, 0, h->n_interior);
+    case 1: return stage_on_range(h, i_stage, h->n_interior, h->n_owned);
+    case 2: return stage_on_range(h, i_stage, 0, h->n_owned);
+    default: return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "which must be 0, 1 or 2");
+    }
+}
+
+int swe2d_solve_stage(swe2d_handle *hh, int i_stage) { return swe2d_solve_stage_range(hh, i_stage, 2); }
+
+int swe2d_advance(swe2d_handle *hh, int n_steps)
+{
+    Handle *h = H(hh);
+    if (!h || n_steps < 0) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad n_steps");
+    if (h->n_owned != h->n_cells)
+        return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_advance on a partition: drive stages + halo exchange from the host");
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (int it = 0; it < n_steps; it++)
+        for (int s = 0; s < 3; s++) {
+            int rc = stage_on_range(h, s, 0, h->n_owned);
+            if (rc) return rc;
+        }
+    return SWE2D_OK;
+}
+
+int swe2d_advance_timed(swe2d_handle *hh, int n_steps, int per_launch, float *ms_total, float *ms_kernel_avg)
+{
+    Handle *h = H(hh);
+    if (!h || n_steps <= 0 || !ms_total) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad argument");
+    if (h->n_owned != h->n_cells)
+        return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_advance_timed on a partition is not supported");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!per_launch) {
+        HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+        int rc = swe2d_advance(hh, n_steps);
+        if (rc) return rc;
+        HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+        HIP_TRY(h, hipEventSynchronize(h->ev1));
+        HIP_TRY(h, hipEventElapsedTime(ms_total, h->ev0, h->ev1));
+        if (ms_kernel_avg) *ms_kernel_avg = *ms_total/(3.0f*n_steps);
+        return SWE2D_OK;
+    }
+    // events around every stage launch, on the launch stream
+    const int nl = 3*n_steps;
+    std::vector<hipEvent_t> ev(2*(size_t)nl);
+    for (auto &e : ev) HIP_TRY(h, hipEventCreate(&e));
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    int l = 0;
+    for (int it = 0; it < n_steps; it++)
+        for (int s = 0; s < 3; s++, l++) {
+            HIP_TRY(h, hipEventRecord(ev[2*l], h->stream));
+            int rc = stage_on_range(h, s, 0, h->n_owned);
+            if (rc) return rc;
+            HIP_TRY(h, hipEventRecord(ev[2*l + 1], h->stream));
+        }
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    HIP_TRY(h, hipEventElapsedTime(ms_total, h->ev0, h->ev1));
+    double sum = 0.0;
+    for (int i = 0; i < nl; i++) {
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, ev[2*i], ev[2*i + 1]));
+        sum += ms;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    if (ms_kernel_avg) *ms_kernel_avg = (float)(sum/nl);
+    return SWE2D_OK;
+}
+
+int swe2d_synchronize(swe2d_handle *hh)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWE2D_OK;
+}
+
+int swe2d_tendency(swe2d_handle *hh, double *k_uv, double *k_eta)
+{
+    Handle *h = H(hh);
+    if (!h || !k_uv || !k_eta) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    // k into buffer B: U_out = 1*k + 0*U0 + 0*U_in
+    int rc = launch_stage(h, 0, 0, 1, 0.0, 0.0, 1.0, 0, h->n_owned);
+    if (rc) return rc;
+    const size_t n = h->n_cells;
+    hipLaunchKernelGGL(swe_planes_to_aos, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                       h->state[1], h->stage_uv, h->stage_eta, h->stride, h->n_cells);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(k_uv, h->stage_uv, 6*n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(k_eta, h->stage_eta, 3*n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWE2D_OK;
+}
+
+int swe2d_diagnostics(swe2d_handle *hh, double out[4])
+{
+    Handle *h = H(hh);
+    if (!h || !out) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(swe_diag_kernel, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
+                       h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial);
+    HIP_TRY(h, hipGetLastError());
+    std::vector<double> part(4*(size_t)h->n_partial_blocks);
+    HIP_TRY(h, hipMemcpyAsync(part.data(), h->partial, part.size()*sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    out[0] = out[1] = out[2] = 0.0;
+    out[3] = 1e300;
+    for (int b = 0; b < h->n_partial_blocks; b++) {
+        out[0] += part[4*(size_t)b];
+        out[1] += part[4*(size_t)b + 1];
+        out[2] += part[4*(size_t)b + 2];
+        out[3] = std::fmin(out[3], part[4*(size_t)b + 3]);
+    }
+    if (!std::isfinite(out[0]) || !std::isfinite(out[1]) || !std::isfinite(out[2]))
+        return fail(h, SWE2D_ERR_NOT_FINITE, "state is not finite");
+    return SWE2D_OK;
+}
+
+int swe2d_halo_setup(swe2d_handle *hh, int32_t n_send, const int32_t *send_cells)
+{
+    Handle *h = H(hh);
+    if (!h || n_send < 0 || (n_send > 0 && !send_cells)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad halo lists");
+    for (int i = 0; i < n_send; i++)
+        if (send_cells[i] < 0 || send_cells[i] >= h->n_owned)
+            return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "send cell is not an owned cell");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->send_cells) { HIP_TRY(h, hipFree(h->send_cells)); h->send_cells = nullptr; }
+    h->n_send = n_send;
+    if (n_send > 0) {
+        HIP_TRY(h, hipMalloc(&h->send_cells, (size_t)n_send*sizeof(int)));
+        HIP_TRY(h, hipMemcpy(h->send_cells, send_cells, (size_t)n_send*sizeof(int), hipMemcpyHostToDevice));
+    }
+    return SWE2D_OK;
+}
+
+int swe2d_halo_pack(swe2d_handle *hh, int i_stage, double *send_buf_dev)
+{
+    Handle *h = H(hh);
+    if (!h || i_stage < 0 || i_stage > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad stage");
+    if (h->n_send == 0) return SWE2D_OK;
+    if (!send_buf_dev) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null send buffer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(swe_halo_pack, dim3(grid_for(9*h->n_send)), dim3(256), 0, h->stream,
+                       h->state[i_stage], h->stride, h->send_cells, h->n_send, send_buf_dev);
+    HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
+}
+
+int swe2d_halo_unpack(swe2d_handle *hh, int i_stage, const double *recv_buf_dev)
+{
+    Handle *h = H(hh);
+    if (!h || i_stage < 0 || i_stage > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad stage");
+    const int ng = h->n_cells - h->n_owned;
+    if (ng == 0) return SWE2D_OK;
+    if (!recv_buf_dev) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null recv buffer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(swe_halo_unpack, dim3(grid_for(9*ng)), dim3(256), 0, h->stream,
+                       h->state[i_stage], h->stride, h->n_owned, ng, recv_buf_dev);
+    HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,465 @@
+// swe2d_kernels.h - device code of the MI355X (gfx950) DG-P1 shallow-water stage kernel.
+//
+// One launch = one SSPRK33 stage for a range of cells:   U_out = beta*k + a0*U0 + a1*U_in,
+//   k = M^-1 (dt R(U_in)),  R = ExternalPressureGradient + HUDiv + HorizontalAdvection(+Lax-Friedrichs)
+//   (+ Coriolis, drag, atmospheric pressure, sources) of thetis/shallowwater_eq.py:335-510,619-831,
+//   M^-1 from thetis/equation.py:105, update from thetis/rungekutta.py:908-946.
+//
+// Design (HBM-bound FP64 gather/stream kernel; no dense contraction, hence no MFMA):
+//  * one lane = one triangle; everything a cell needs is recomputed by the cell itself (both sides of an interior
+//    facet evaluate the same numerical flux) -> no atomics, no inter-lane reduction, bitwise deterministic.
+//  * state is 9 SoA planes (u0 u1 u2 v0 v1 v2 e0 e1 e2) of `stride` doubles: own-cell loads/stores are fully
+//    coalesced 512-B wave transactions; neighbour traces are 8-B gathers that hit L2 because consecutive cells are
+//    mesh neighbours and the block->cell-range map keeps each XCD on one contiguous chunk of the mesh.
+//  * residual, 3x3 mass inverse and the Shu-Osher combine are fused: per stage each cell's state is read once
+//    (+U0 once in stages 1,2) and written once: 180/252/252 algorithmic bytes.
+//  * closed forms for the P1 cell integrals (no cell quadrature, no division: A*grad(phi_i) = -nF_{i+1}/2) and one
+//    sqrt per facet quadrature point: g*sqrt(H/g) = H*sqrt(g/H) = sqrt(g*H).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SWE_MAX_MARKERS 16
+#define SWE_BC_ELEV 1
+#define SWE_BC_UV 2
+#define SWE_BC_UN 4
+#define SWE_BC_FLUX 8
+#define SWE_BLOCK 256
+
+struct SweBcTable {
+    int kind[SWE_MAX_MARKERS];
+    double elev[SWE_MAX_MARKERS];
+    double u[SWE_MAX_MARKERS];
+    double v[SWE_MAX_MARKERS];
+    double un[SWE_MAX_MARKERS];
+    double flux[SWE_MAX_MARKERS];
+    double len[SWE_MAX_MARKERS];
+};
+
+struct SweStageArgs {
+    const double *uin;     // 9 planes, state entering the stage
+    const double *u0;      // 9 planes, stage_sol[0]
+    double *uout;          // 9 planes
+    size_t stride;         // plane length (doubles)
+    const int *nbr;        // 3 planes: (cell<<2)|facet_in_neighbour, or -(marker)
+    const int *cv;         // 3 planes: vertex ids
+    const double *vx, *vy, *vh;   // per vertex: coordinates, bathymetry
+    int cell_begin, cell_end;
+    double g, sigma_lf, dt;
+    double a0, a1, beta;   // U_out = beta*k + a0*U0 + a1*U_in
+    // optional cell-local terms (SRC variant)
+    const double *coriolis;   // 3 planes or null
+    const double *patm;       // 3 planes or null
+    const double *msrc;       // 6 planes (x0 x1 x2 y0 y1 y2) or null
+    const double *vsrc;       // 3 planes or null
+    double linear_drag, quad_drag, manning, norm_smoother;   // <0: off
+    SweBcTable bc;
+};
+
+// 2-point Gauss-Legendre on [0,1] (facet rule of degree 3, shallowwater_eq.py:225-230 [FD-assumed])
+#define SWE_XI0 0.21132486540518713
+#define SWE_XI1 0.78867513459481287
+
+// Block -> logical block: the dispatcher places block b on XCD b%8 (observed; used for speed only).  Give every XCD
+// one contiguous eighth of the cell range so that facet-neighbour gathers are served by the XCD's own L2.
+__device__ __forceinline__ int swe_logical_block(int b, int nblocks)
+{
+    const int per = (nblocks + 7) >> 3;
+    return (b & 7)*per + (b >> 3);
+}
+
+// 12/A * int a*b dx for P1 a, b
+__device__ __forceinline__ double swe_int2(const double a[3], const double b[3])
+{
+    return (a[0] + a[1] + a[2])*(b[0] + b[1] + b[2]) + a[0]*b[0] + a[1]*b[1] + a[2]*b[2];
+}
+
+// Boundary facet (closed wall or open boundary); rare, so written for clarity with unit normals.
+// Returns the form values f (residual is -f) already multiplied by the facet length.
+template <bool NONLIN, bool LF>
+__device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int marker, double uq, double vq, double eq,
+                                               double hq, double nxs, double nys, double L, double rL,
+                                               double &fu, double &fv, double &fe)
+{
+    const double g = p.g;
+    const double nx = nxs*rL, ny = nys*rL;
+    const double Hq = NONLIN ? hq + eq : hq;
+    const int kind = (marker < SWE_MAX_MARKERS) ? p.bc.kind[marker] : 0;
+    const double un_own = uq*nx + vq*ny;
+    if (kind == 0) {
+        // land boundary, shallowwater_eq.py:377-381 and :489-497
+        const double head_rie = eq + sqrt(Hq/g)*un_own;
+        fu = g*head_rie*nx;
+        fv = g*head_rie*ny;
+        fe = 0.0;
+        if (NONLIN && LF) {
+            const double gamma = 0.5*fabs(un_own)*p.sigma_lf;
+            fu += gamma*2.0*un_own*nx;
+            fv += gamma*2.0*un_own*ny;
+        }
+    } else {
+        // external state, get_bnd_functions shallowwater_eq.py:243-267
+        double e_ext = eq, u_ext = uq, v_ext = vq;
+        if (kind & SWE_BC_ELEV) e_ext = p.bc.elev[marker];
+        if (kind & SWE_BC_UV) {
+            u_ext = p.bc.u[marker];
+            v_ext = p.bc.v[marker];
+        } else if (kind & SWE_BC_UN) {
+            u_ext = p.bc.un[marker]*nx;
+            v_ext = p.bc.un[marker]*ny;
+        } else if (kind & SWE_BC_FLUX) {
+            const double H0 = NONLIN ? hq + e_ext : hq;
+            const double s = p.bc.flux[marker]/(H0*p.bc.len[marker]);
+            u_ext = s*nx;
+            v_ext = s*ny;
+        }
+        const double H_ext = NONLIN ? hq + e_ext : hq;
+        const double un_jump = (uq - u_ext)*nx + (vq - v_ext)*ny;
+        const double eta_rie = 0.5*(eq + e_ext) + sqrt(Hq/g)*un_jump;                 // :374
+        fu = g*eta_rie*nx;
+        fv = g*eta_rie*ny;
+        const double h_av = 0.5*(Hq + H_ext);
+        const double eta_jump = eq - e_ext;
+        const double un_avg = 0.5*((uq + u_ext)*nx + (vq + v_ext)*ny);
+        const double un_rie = un_avg + sqrt(g/h_av)*eta_jump;                          // :438
+        const double eta_rie2 = 0.5*(eq + e_ext) + sqrt(h_av/g)*un_jump;               // :440
+        fe = (NONLIN ? hq + eta_rie2 : hq)*un_rie;                                     // :441-442
+        if (NONLIN) {
+            const double un_rie3 = un_avg + sqrt(g/Hq)*eta_jump;                       // :507
+            fu += un_rie3*0.5*(u_ext + uq);
+            fv += un_rie3*0.5*(v_ext + vq);
+        }
+    }
+    fu *= L;
+    fv *= L;
+    fe *= L;
+}
+
+template <bool NONLIN, bool LF, bool HASU0, bool SRC>
+__global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel(const SweStageArgs p)
+{
+    const int lb = swe_logical_block(blockIdx.x, gridDim.x);
+    const int k = p.cell_begin + lb*SWE_BLOCK + (int)threadIdx.x;
+    if (k >= p.cell_end) return;
+    const size_t S = p.stride;
+    const double g = p.g;
+
+    // ---- own state, connectivity (coalesced) and vertex data (gather)
+    double u[3], v[3], e[3];
+    int nb[3], vid[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        u[i] = p.uin[(size_t)i*S + k];
+        v[i] = p.uin[(size_t)(3 + i)*S + k];
+        e[i] = p.uin[(size_t)(6 + i)*S + k];
+        nb[i] = p.nbr[(size_t)i*S + k];
+        vid[i] = p.cv[(size_t)i*S + k];
+    }
+    double px[3], py[3], h[3], H[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        px[i] = p.vx[vid[i]];
+        py[i] = p.vy[vid[i]];
+        h[i] = p.vh[vid[i]];
+        H[i] = NONLIN ? h[i] + e[i] : h[i];
+    }
+    // scaled outward normals nF_f = |F| n of facet f (vertex f -> f+1); counter-clockwise cell
+    double nx[3], ny[3];
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        const int b = (f + 1) % 3;
+        nx[f] = py[b] - py[f];
+        ny[f] = px[f] - px[b];
+    }
+    const double twoA = nx[0]*ny[1] - ny[0]*nx[1];
+    // A*grad(phi_i) = -nF_{i+1}/2
+    double gxs[3], gys[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        gxs[i] = -0.5*nx[(i + 1) % 3];
+        gys[i] = -0.5*ny[(i + 1) % 3];
+    }
+
+    // ---- cell integrals (closed form)
+    double bu[3], bv[3], be[3];
+    {
+        const double ge3 = g*(e[0] + e[1] + e[2])*(1.0/3.0);
+        const double SHu = swe_int2(H, u)*(1.0/12.0), SHv = swe_int2(H, v)*(1.0/12.0);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            bu[i] = gxs[i]*ge3;                              // +g eta div(psi)       shallowwater_eq.py:361
+            bv[i] = gys[i]*ge3;
+            be[i] = gxs[i]*SHu + gys[i]*SHv;                 // +grad(phi).(H u)      shallowwater_eq.py:422
+        }
+        if (NONLIN) {                                        // +(psi div u + u.grad psi).u  shallowwater_eq.py:478
+            const double Suu = swe_int2(u, u)*(1.0/12.0), Suv = swe_int2(u, v)*(1.0/12.0),
+                         Svv = swe_int2(v, v)*(1.0/12.0);
+            const double D12 = (gxs[0]*u[0] + gxs[1]*u[1] + gxs[2]*u[2]
+                                + gys[0]*v[0] + gys[1]*v[1] + gys[2]*v[2])*(1.0/12.0);
+            const double us = u[0] + u[1] + u[2], vs = v[0] + v[1] + v[2];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                bu[i] += D12*(us + u[i]) + gxs[i]*Suu + gys[i]*Suv;
+                bv[i] += D12*(vs + v[i]) + gxs[i]*Suv + gys[i]*Svv;
+            }
+        }
+    }
+    if (SRC) {
+        const double A = 0.5*twoA;
+        const double us = u[0] + u[1] + u[2], vs = v[0] + v[1] + v[2];
+        if (p.coriolis) {                                    // shallowwater_eq.py:632-633
+            double f[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) f[i] = p.coriolis[(size_t)i*S + k];
+            const double fs = f[0] + f[1] + f[2];
+            const double fu_ = f[0]*u[0] + f[1]*u[1] + f[2]*u[2], fv_ = f[0]*v[0] + f[1]*v[1] + f[2]*v[2];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                // 60/A int phi_i f w = fs*ws + sum f_a w_a + f_i*ws + w_i*fs + 2 f_i w_i
+                const double tv = fs*vs + fv_ + f[i]*vs + v[i]*fs + 2.0*f[i]*v[i];
+                const double tu = fs*us + fu_ + f[i]*us + u[i]*fs + 2.0*f[i]*u[i];
+                bu[i] += A*(1.0/60.0)*tv;
+                bv[i] -= A*(1.0/60.0)*tu;
+            }
+        }
+        if (p.linear_drag >= 0.0) {                          // shallowwater_eq.py:738
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                bu[i] -= p.linear_drag*A*(1.0/12.0)*(us + u[i]);
+                bv[i] -= p.linear_drag*A*(1.0/12.0)*(vs + v[i]);
+            }
+        }
+        if (p.quad_drag >= 0.0 || p.manning >= 0.0) {        // shallowwater_eq.py:685-700, 6-point degree-4 rule
+            const double a1 = 0.445948490915965, b1 = 0.108103018168070, w1 = 0.223381589678011;
+            const double a2 = 0.091576213509771, b2 = 0.816847572980459, w2 = 0.109951743655322;
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const double aa = q < 3 ? a1 : a2, bb = q < 3 ? b1 : b2, ww = q < 3 ? w1 : w2;
+                double l[3] = {aa, aa, aa};
+                l[q % 3] = bb;
+                const double uq = l[0]*u[0] + l[1]*u[1] + l[2]*u[2];
+                const double vq = l[0]*v[0] + l[1]*v[1] + l[2]*v[2];
+                const double Hq = l[0]*H[0] + l[1]*H[1] + l[2]*H[2];
+                const double cd = (p.manning >= 0.0) ? g*p.manning*p.manning/cbrt(Hq) : p.quad_drag;
+                const double s = ww*A*cd*sqrt(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother)/Hq;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    bu[i] -= s*l[i]*uq;
+                    bv[i] -= s*l[i]*vq;
+                }
+            }
+        }
+        if (p.patm) {                                        // shallowwater_eq.py:662, rho0 = 1000
+            double gpx = 0.0, gpy = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const double pa = p.patm[(size_t)i*S + k];
+                gpx += gxs[i]*pa;
+                gpy += gys[i]*pa;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                bu[i] -= gpx*(1.0/3000.0);
+                bv[i] -= gpy*(1.0/3000.0);
+            }
+        }
+        if (p.msrc) {                                        // shallowwater_eq.py:810
+            double sx[3], sy[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                sx[i] = p.msrc[(size_t)i*S + k];
+                sy[i] = p.msrc[(size_t)(3 + i)*S + k];
+            }
+            const double ssx = sx[0] + sx[1] + sx[2], ssy = sy[0] + sy[1] + sy[2];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                bu[i] += A*(1.0/12.0)*(ssx + sx[i]);
+                bv[i] += A*(1.0/12.0)*(ssy + sy[i]);
+            }
+        }
+        if (p.vsrc) {                                        // shallowwater_eq.py:830
+            double s[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) s[i] = p.vsrc[(size_t)i*S + k];
+            const double ss = s[0] + s[1] + s[2];
+#pragma unroll
+            for (int i = 0; i < 3; i++) be[i] += A*(1.0/12.0)*(ss + s[i]);
+        }
+    }
+
+    // ---- facet integrals: 2-point Gauss-Legendre, numerical fluxes seen from this cell
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        const int a = f, b = (f + 1) % 3;
+        const double nxs = nx[f], nys = ny[f];
+        const double len2 = nxs*nxs + nys*nys;
+        const double L = sqrt(len2);
+        const double rL = 1.0/L;
+        const int nbf = nb[f];
+        double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
+        if (nbf >= 0) {
+            // neighbour traverses the shared facet backwards: its node (f2+1)%3 sits on my node a, its node f2 on my b
+            const int kn = nbf >> 2, f2 = nbf & 3;
+            const int na = (f2 == 2) ? 0 : f2 + 1;
+            const double ua_n = p.uin[(size_t)na*S + kn], ub_n = p.uin[(size_t)f2*S + kn];
+            const double va_n = p.uin[(size_t)(3 + na)*S + kn], vb_n = p.uin[(size_t)(3 + f2)*S + kn];
+            const double ea_n = p.uin[(size_t)(6 + na)*S + kn], eb_n = p.uin[(size_t)(6 + f2)*S + kn];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+                const double uq = xa*u[a] + xb*u[b], vq = xa*v[a] + xb*v[b], eq = xa*e[a] + xb*e[b];
+                const double hq = xa*h[a] + xb*h[b];
+                const double un = xa*ua_n + xb*ub_n, vn = xa*va_n + xb*vb_n, en = xa*ea_n + xb*eb_n;
+                const double eav = 0.5*(eq + en);
+                const double Hav = NONLIN ? hq + eav : hq;
+                const double c = sqrt(g*Hav);
+                const double du = uq - un, dv = vq - vn;
+                const double dun = du*nxs + dv*nys;                       // |F| jump(u.n)
+                const double spg = g*eav + c*dun*rL;                      // g*head_star            :363
+                double fu = spg*nxs, fv = spg*nys;                        //                        :366
+                const double uav = 0.5*(uq + un), vav = 0.5*(vq + vn);
+                const double uavn = uav*nxs + vav*nys;                    // |F| {u}.n
+                const double fe = Hav*uavn + c*(eq - en)*L;               // {H}({u}+sqrt(g/{H})[eta n]).n  :424-427
+                if (NONLIN) {
+                    const double unown = uq*nxs + vq*nys;
+                    fu += uav*unown;                                      //                        :483
+                    fv += vav*unown;
+                    if (LF) {
+                        const double gam = 0.5*fabs(uavn)*p.sigma_lf;     //                        :487
+                        fu += gam*du;                                     //                        :488
+                        fv += gam*dv;
+                    }
+                }
+                Fau += xa*fu; Fbu += xb*fu;
+                Fav += xa*fv; Fbv += xb*fv;
+                Fae += xa*fe; Fbe += xb*fe;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+                const double uq = xa*u[a] + xb*u[b], vq = xa*v[a] + xb*v[b], eq = xa*e[a] + xb*e[b];
+                const double hq = xa*h[a] + xb*h[b];
+                double fu, fv, fe;
+                swe_boundary_flux<NONLIN, LF>(p, -nbf, uq, vq, eq, hq, nxs, nys, L, rL, fu, fv, fe);
+                Fau += xa*fu; Fbu += xb*fu;
+                Fav += xa*fv; Fbv += xb*fv;
+                Fae += xa*fe; Fbe += xb*fe;
+            }
+        }
+        bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
+        bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
+        be[a] -= 0.5*Fae; be[b] -= 0.5*Fbe;
+    }
+
+    // ---- mass inverse (M^-1 b)_i = 3/A (4 b_i - sum b), times dt, and the Shu-Osher combine
+    const double s = 6.0*p.dt/twoA;
+    const double su = bu[0] + bu[1] + bu[2], sv = bv[0] + bv[1] + bv[2], se = be[0] + be[1] + be[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double ku = s*(4.0*bu[i] - su), kv = s*(4.0*bv[i] - sv), ke = s*(4.0*be[i] - se);
+        double ou = p.beta*ku, ov = p.beta*kv, oe = p.beta*ke;
+        if (HASU0) {
+            ou += p.a0*p.u0[(size_t)i*S + k];
+            ov += p.a0*p.u0[(size_t)(3 + i)*S + k];
+            oe += p.a0*p.u0[(size_t)(6 + i)*S + k];
+        }
+        ou += p.a1*u[i];
+        ov += p.a1*v[i];
+        oe += p.a1*e[i];
+        p.uout[(size_t)i*S + k] = ou;
+        p.uout[(size_t)(3 + i)*S + k] = ov;
+        p.uout[(size_t)(6 + i)*S + k] = oe;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// layout conversion: host (Firedrake-like) AoS  uv[3N][2], eta[3N]  <->  9 SoA planes
+__global__ void swe_aos_to_planes(const double *uv, const double *eta, double *planes, size_t stride, int n)
+{
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= n) return;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        planes[(size_t)i*stride + k] = uv[6*(size_t)k + 2*i];
+        planes[(size_t)(3 + i)*stride + k] = uv[6*(size_t)k + 2*i + 1];
+        planes[(size_t)(6 + i)*stride + k] = eta[3*(size_t)k + i];
+    }
+}
+
+__global__ void swe_planes_to_aos(const double *planes, double *uv, double *eta, size_t stride, int n)
+{
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= n) return;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        uv[6*(size_t)k + 2*i] = planes[(size_t)i*stride + k];
+        uv[6*(size_t)k + 2*i + 1] = planes[(size_t)(3 + i)*stride + k];
+        eta[3*(size_t)k + i] = planes[(size_t)(6 + i)*stride + k];
+    }
+}
+
+// nodal scalar field (3N) -> 3 planes;  vector (3N,2) -> 6 planes (x0 x1 x2 y0 y1 y2)
+__global__ void swe_nodal_to_planes(const double *nodal, double *planes, size_t stride, int n, int ncomp)
+{
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    for (int i = 0; i < 3; i++)
+        for (int c = 0; c < ncomp; c++)
+            planes[(size_t)(3*c + i)*stride + k] = nodal[(size_t)ncomp*(3*(size_t)k + i) + c];
+}
+
+// halo: message layout [n][9] (cell-major), so the per-peer segments of one buffer are contiguous
+__global__ void swe_halo_pack(const double *planes, size_t stride, const int *cells, int n, double *buf)
+{
+    const int t = blockIdx.x*blockDim.x + threadIdx.x;
+    if (t >= 9*n) return;
+    const int j = t/9, q = t - 9*j;
+    buf[t] = planes[(size_t)q*stride + cells[j]];
+}
+
+__global__ void swe_halo_unpack(double *planes, size_t stride, int first_ghost, int n, const double *buf)
+{
+    const int t = blockIdx.x*blockDim.x + threadIdx.x;
+    if (t >= 9*n) return;
+    const int j = t/9, q = t - 9*j;
+    planes[(size_t)q*stride + first_ghost + j] = buf[t];
+}
+
+// diagnostics: per-block partial sums { int eta^2, int |u|^2, int (eta+h), min(h+eta) }, finished on the host
+__global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel(const double *planes, size_t stride, const int *cv,
+                                                             const double *vx, const double *vy, const double *vh,
+                                                             int n, double *partial)
+{
+    __shared__ double red[4][SWE_BLOCK];
+    const int k = blockIdx.x*SWE_BLOCK + threadIdx.x;
+    double s_e2 = 0.0, s_u2 = 0.0, s_vol = 0.0, s_min = 1e300;
+    if (k < n) {
+        double u[3], v[3], e[3], px[3], py[3], h[3];
+        for (int i = 0; i < 3; i++) {
+            u[i] = planes[(size_t)i*stride + k];
+            v[i] = planes[(size_t)(3 + i)*stride + k];
+            e[i] = planes[(size_t)(6 + i)*stride + k];
+            const int vid = cv[(size_t)i*stride + k];
+            px[i] = vx[vid]; py[i] = vy[vid]; h[i] = vh[vid];
+        }
+        const double A = 0.5*((px[1] - px[0])*(py[2] - py[0]) - (px[2] - px[0])*(py[1] - py[0]));
+        s_e2 = A*(1.0/12.0)*swe_int2(e, e);
+        s_u2 = A*(1.0/12.0)*(swe_int2(u, u) + swe_int2(v, v));
+        s_vol = A*(1.0/3.0)*(e[0] + e[1] + e[2] + h[0] + h[1] + h[2]);
+        s_min = fmin(fmin(h[0] + e[0], h[1] + e[1]), h[2] + e[2]);
+    }
+    red[0][threadIdx.x] = s_e2; red[1][threadIdx.x] = s_u2; red[2][threadIdx.x] = s_vol; red[3][threadIdx.x] = s_min;
+    __syncthreads();
+    for (int off = SWE_BLOCK/2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+            red[2][threadIdx.x] += red[2][threadIdx.x + off];
+            red[3][threadIdx.x] = fmin(red[3][threadIdx.x], red[3][threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 4; q++) partial[4*(size_t)blockIdx.x + q] = red[q][0];
+}

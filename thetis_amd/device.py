@@ -1,0 +1,177 @@
+"""
+``Swe2dDevice``: one HIP device stepping one (partition of a) mesh - a thin object over the C ABI.
+
+Arrays cross the boundary in the reference's dof layout (cell c owns nodes 3c..3c+2): ``uv`` (N,3,2),
+``eta`` (N,3) float64.
+"""
+import ctypes
+import numpy as np
+
+from . import _lib
+
+__all__ = ['Swe2dDevice']
+
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Swe2dDevice(object):
+    def __init__(self, mesh, bathymetry_vertex, dt, g_grav=9.81, use_nonlinear_equations=True,
+                 use_lax_friedrichs_velocity=True, lax_friedrichs_velocity_scaling_factor=1.0,
+                 device_id=0, n_owned=None, boundary_len=None):
+        """
+        :arg mesh: object with ``cells`` (N,3), ``vertex_xy`` (V,2), ``cell_nbr`` (N,3), ``cell_nbr_facet`` (N,3)
+        :arg bathymetry_vertex: (V,) CG-P1 bathymetry at the vertices
+        """
+        self.lib = _lib.load()
+        self.n_cells = int(mesh.cells.shape[0])
+        self.n_owned = self.n_cells if n_owned is None else int(n_owned)
+        c = np.ascontiguousarray
+        self._keep = [c(mesh.cells, dtype=np.int32), c(mesh.vertex_xy, dtype=np.float64),
+                      c(mesh.cell_nbr, dtype=np.int32), c(mesh.cell_nbr_facet, dtype=np.int8),
+                      c(bathymetry_vertex, dtype=np.float64)]
+        cells, xy, nbr, nbf, bath = self._keep
+        if bath.shape != (xy.shape[0],):
+            raise ValueError('bathymetry must have one value per vertex')
+        m = _lib.Swe2dMesh()
+        m.n_cells = self.n_cells
+        m.n_owned = self.n_owned
+        m.n_vertices = xy.shape[0]
+        m.nodes_per_cell = 3
+        m.cell_vertices = cells.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        m.vertex_xy = _ptr(xy)
+        m.cell_neighbours = nbr.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        m.cell_neighbour_facets = nbf.ctypes.data_as(ctypes.POINTER(ctypes.c_int8))
+        m.bathymetry = _ptr(bath)
+        if boundary_len is not None:
+            bl = np.zeros(_lib.MAX_MARKERS)
+            for k, v in boundary_len.items():
+                if 0 < k < _lib.MAX_MARKERS:
+                    bl[k] = v
+            self._keep.append(bl)
+            m.boundary_len = _ptr(bl)
+        p = _lib.Swe2dParams()
+        p.g_grav = g_grav
+        p.dt = dt
+        p.use_nonlinear_equations = int(bool(use_nonlinear_equations))
+        p.use_lax_friedrichs_velocity = int(bool(use_lax_friedrichs_velocity))
+        p.lax_friedrichs_velocity_scaling_factor = float(lax_friedrichs_velocity_scaling_factor)
+        p.device_id = device_id
+        self.h = ctypes.c_void_p()
+        _lib.check(self.lib.swe2d_create(ctypes.byref(m), ctypes.byref(p), ctypes.byref(self.h)))
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.swe2d_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        _lib.check(rc, self.h)
+
+    # -- state
+    def set_state(self, uv, eta):
+        uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(self.n_cells, 3, 2)
+        eta = np.ascontiguousarray(eta, dtype=np.float64).reshape(self.n_cells, 3)
+        self._ck(self.lib.swe2d_set_state(self.h, _ptr(uv), _ptr(eta)))
+
+    def get_state(self):
+        uv = np.empty((self.n_cells, 3, 2))
+        eta = np.empty((self.n_cells, 3))
+        self._ck(self.lib.swe2d_get_state(self.h, _ptr(uv), _ptr(eta)))
+        return uv, eta
+
+    def set_dt(self, dt):
+        self._ck(self.lib.swe2d_set_dt(self.h, float(dt)))
+
+    def set_bc(self, marker, funcs):
+        """``funcs``: dict with constant 'elev' / 'uv' / 'un' / 'flux' values, or None / {} for a closed boundary."""
+        kind = 0
+        vals = np.zeros(5)
+        for key, value in (funcs or {}).items():
+            if key == 'elev':
+                kind |= _lib.BC_ELEV
+                vals[0] = float(value)
+            elif key == 'uv':
+                kind |= _lib.BC_UV
+                vals[1], vals[2] = float(value[0]), float(value[1])
+            elif key == 'un':
+                kind |= _lib.BC_UN
+                vals[3] = float(value)
+            elif key == 'flux':
+                kind |= _lib.BC_FLUX
+                vals[4] = float(value)
+            elif key == 'drag':
+                raise NotImplementedError('boundary drag is not supported on the device path yet')
+            else:
+                raise Exception('Invalid boundary tag "{:}" specified on boundary {:}'.format(key, marker))
+        self._ck(self.lib.swe2d_set_bc(self.h, int(marker), kind, _ptr(vals)))
+
+    def set_field(self, field, nodal):
+        if nodal is None:
+            self._ck(self.lib.swe2d_set_field(self.h, field, None))
+            return
+        shape = (self.n_cells, 3, 2) if field == _lib.FIELD_MOMENTUM_SOURCE else (self.n_cells, 3)
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(nodal, dtype=np.float64), shape))
+        self._ck(self.lib.swe2d_set_field(self.h, field, _ptr(a)))
+
+    def set_scalar(self, which, value):
+        self._ck(self.lib.swe2d_set_scalar(self.h, which, -1.0 if value is None else float(value)))
+
+    # -- time stepping
+    def advance(self, n_steps=1):
+        self._ck(self.lib.swe2d_advance(self.h, int(n_steps)))
+
+    def solve_stage(self, i_stage):
+        self._ck(self.lib.swe2d_solve_stage(self.h, int(i_stage)))
+
+    def solve_stage_range(self, i_stage, which):
+        self._ck(self.lib.swe2d_solve_stage_range(self.h, int(i_stage), int(which)))
+
+    def advance_timed(self, n_steps, per_launch=False):
+        """Returns (total ms, mean ms per stage-kernel launch), measured with HIP events on the launch stream."""
+        tot = ctypes.c_float()
+        avg = ctypes.c_float()
+        self._ck(self.lib.swe2d_advance_timed(self.h, int(n_steps), int(per_launch), ctypes.byref(tot), ctypes.byref(avg)))
+        return tot.value, avg.value
+
+    def synchronize(self):
+        self._ck(self.lib.swe2d_synchronize(self.h))
+
+    def tendency(self):
+        ku = np.empty((self.n_cells, 3, 2))
+        ke = np.empty((self.n_cells, 3))
+        self._ck(self.lib.swe2d_tendency(self.h, _ptr(ku), _ptr(ke)))
+        return ku, ke
+
+    def diagnostics(self):
+        """{int eta^2, int |u|^2, int (eta+h), min(h+eta)} over owned cells."""
+        out = np.empty(4)
+        self._ck(self.lib.swe2d_diagnostics(self.h, _ptr(out)))
+        return out
+
+    # -- multi-GPU plumbing
+    def halo_setup(self, send_cells):
+        a = np.ascontiguousarray(send_cells, dtype=np.int32)
+        self._ck(self.lib.swe2d_halo_setup(self.h, a.size, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+
+    def halo_pack(self, i_stage, send_buf_ptr):
+        self._ck(self.lib.swe2d_halo_pack(self.h, i_stage, ctypes.c_void_p(send_buf_ptr)))
+
+    def halo_unpack(self, i_stage, recv_buf_ptr):
+        self._ck(self.lib.swe2d_halo_unpack(self.h, i_stage, ctypes.c_void_p(recv_buf_ptr)))
+
+    def set_interior_split(self, n_interior):
+        self._ck(self.lib.swe2d_set_interior_split(self.h, int(n_interior)))
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.swe2d_set_stream(self.h, ctypes.c_void_p(stream_ptr) if stream_ptr else None))
