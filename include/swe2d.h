@@ -102,6 +102,11 @@ typedef struct swe2d_handle swe2d_handle;
 int  swe2d_abi_version(void);
 int  swe2d_device_count(void);                                   /* number of visible HIP devices, <0 on error */
 
+/* Shu-Osher coefficients the stage kernels use (host-only, needs no device): stage i computes
+ * U_{i+1} = beta[i]*k_i + alpha0[i]*U_0 + alpha_in[i]*U_i  (alpha_in[0] multiplies U_0 itself).  Values are the output of
+ * butcher_to_shuosher_form (thetis/rungekutta.py:13-87) for SSPRK33Abstract (rungekutta.py:342-346). */
+void swe2d_ssprk33_coefficients(double alpha0[3], double alpha_in[3], double beta[3]);
+
 /* lifetime: replaces ERKGenericShuOsher.__init__/update_solver (rungekutta.py:877-924) */
 int  swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handle **out);
 void swe2d_destroy(swe2d_handle *h);

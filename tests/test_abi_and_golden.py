@@ -1,0 +1,89 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/swe2d.h declares; golden Shu-Osher vectors."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'swe2d.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(swe2d_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_every_declared_symbol_is_exported(hip_lib):
+    from thetis_amd import _lib
+    names = _declared_symbols()
+    assert len(names) >= 20
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in names:
+        assert hasattr(raw, name), 'libswe2d_hip.so does not export {:}'.format(name)
+    # and the ctypes binding knows every one of them (and nothing else)
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_abi_version_and_loud_failure_without_device(hip_lib):
+    from thetis_amd import _lib
+    from thetis_amd.device import Swe2dDevice
+    from thetis_amd.mesh import RectangleMesh
+    assert hip_lib.swe2d_abi_version() == 1
+    if hip_lib.swe2d_device_count() > 0:
+        pytest.skip('a GPU is present')
+    mesh = RectangleMesh(4, 3, 1.0, 1.0)
+    with pytest.raises(_lib.Swe2dError) as err:
+        Swe2dDevice(mesh, np.ones(mesh.num_vertices), 0.1)
+    assert err.value.code == _lib.ERR_NO_DEVICE          # no CPU fallback
+
+
+def test_struct_layout_matches_header(hip_lib):
+    from thetis_amd import _lib
+    # swe2d_mesh: 4 x int32 + 6 pointers; swe2d_params: see include/swe2d.h
+    assert ctypes.sizeof(_lib.Swe2dMesh) == 16 + 6*8
+    assert ctypes.sizeof(_lib.Swe2dParams) == 8 + 8 + 4 + 4 + 8 + 4 + 4
+
+
+def _golden():
+    with open(os.path.join(ROOT, 'tests', 'golden', 'shuosher_ssprk33.json')) as f:
+        return json.load(f)
+
+
+def test_shuosher_golden_pins_python_classes_and_oracle():
+    g = _golden()
+    alpha = np.array([[float.fromhex(x) for x in row] for row in g['alpha_hex']])
+    beta = np.array([[float.fromhex(x) for x in row] for row in g['beta_hex']])
+    assert np.array_equal(alpha, np.array(g['alpha'])) and np.array_equal(beta, np.array(g['beta']))
+    from thetis_amd.rungekutta import SSPRK33Abstract
+    assert np.array_equal(SSPRK33Abstract.alpha, alpha)        # bit-exact
+    assert np.array_equal(SSPRK33Abstract.beta, beta)
+    assert np.array_equal(SSPRK33Abstract.a, np.array(g['a']))
+    assert np.array_equal(SSPRK33Abstract.b, np.array(g['b']))
+    assert list(SSPRK33Abstract.c) == list(g['c']) and SSPRK33Abstract.cfl_coeff == g['cfl_coeff']
+    from oracle import swe2d_oracle as orc
+    assert np.array_equal(np.array(orc.SSPRK33_ALPHA), alpha)
+    assert np.array_equal(np.array(orc.SSPRK33_BETA), beta)
+    assert list(orc.SSPRK33_C) == list(g['c'])
+    # consistency of a Shu-Osher form (rungekutta.py:80-85)
+    assert np.allclose(alpha.sum(axis=1), 1.0)
+
+
+def test_shuosher_golden_pins_device_coefficients(hip_lib):
+    g = _golden()
+    a0 = (ctypes.c_double*3)()
+    ai = (ctypes.c_double*3)()
+    be = (ctypes.c_double*3)()
+    hip_lib.swe2d_ssprk33_coefficients(a0, ai, be)
+    alpha = np.array(g['alpha'])
+    beta = np.array(g['beta'])
+    for i in range(3):
+        assert be[i] == beta[i + 1][i]
+        # stage i: sum_j alpha[i+1][j] U_j, of which only j = 0 and j = i are non-zero for SSPRK33
+        if i == 0:
+            assert ai[0] == alpha[1][0] and a0[0] == 0.0
+        else:
+            assert a0[i] == alpha[i + 1][0] and ai[i] == alpha[i + 1][i]
+            assert all(alpha[i + 1][j] == 0.0 for j in range(1, i))

@@ -1,0 +1,20 @@
+"""
+thetis_amd - MI355X-native explicit 2D shallow-water time stepper behind Thetis's FlowSolver2d surface.
+
+    from thetis_amd import *
+    mesh2d = RectangleMesh(80, 3, 100e3, 3750)
+    bathymetry_2d = Function(get_functionspace(mesh2d, 'CG', 1)).interpolate(lambda x, y: 20 - 15*x/100e3)
+    solver_obj = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+    solver_obj.options.swe_timestepper_type = 'SSPRK33'
+    ...
+    solver_obj.iterate()
+
+Importing this package never loads the HIP extension; creating a time stepper does, and fails loudly without it.
+"""
+from . import solver2d  # noqa: F401
+from .function import Function, FunctionSpace, get_functionspace  # noqa: F401
+from .mesh import Mesh2d, PeriodicRectangleMesh, RectangleMesh, SquareMesh, UnitSquareMesh  # noqa: F401
+from .options import Constant, ModelOptions2d  # noqa: F401
+from .shallowwater_eq import g_grav, rho_0  # noqa: F401
+
+physical_constants = {'g_grav': g_grav, 'rho0': rho_0, 'von_karman': 0.4}

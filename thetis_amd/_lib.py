@@ -40,6 +40,7 @@ _H = ctypes.c_void_p
 SYMBOLS = {
     'swe2d_abi_version': (ctypes.c_int, []),
     'swe2d_device_count': (ctypes.c_int, []),
+    'swe2d_ssprk33_coefficients': (None, [_dp, _dp, _dp]),
     'swe2d_create': (ctypes.c_int, [ctypes.POINTER(Swe2dMesh), ctypes.POINTER(Swe2dParams), ctypes.POINTER(_H)]),
     'swe2d_destroy': (None, [_H]),
     'swe2d_last_error': (ctypes.c_char_p, [_H]),

@@ -148,6 +148,14 @@ int swe2d_device_count(void)
     return n;
 }
 
+void swe2d_ssprk33_coefficients(double alpha0[3], double alpha_in[3], double beta[3])
+{
+    // as used by stage_on_range: stage 0 reads U0 as its input, so its U0 weight is carried by alpha_in
+    const double a0[3] = {0.0, kAlpha0[1], kAlpha0[2]};
+    const double ai[3] = {kAlpha0[0], kAlphaIn[1], kAlphaIn[2]};
+    for (int i = 0; i < 3; i++) { alpha0[i] = a0[i]; alpha_in[i] = ai[i]; beta[i] = kBeta[i]; }
+}
+
 const char *swe2d_last_error(const swe2d_handle *h)
 {
     return h ? H(h)->err.c_str() : g_create_error.c_str();

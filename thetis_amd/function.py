@@ -1,0 +1,207 @@
+"""
+Minimal ``FunctionSpace`` / ``Function`` stand-ins for the pieces of Firedrake the 2D driver touches:
+P1 (CG, vertex values), P1DG (cell-node values) and their vector versions, ``interpolate`` / ``project`` / ``assign``.
+
+Host arrays use the layout the C ABI takes (include/swe2d.h): DG node 3c+i = vertex i of cell c.
+Expressions are callables ``f(x, y)`` (UFL is not available), numbers, ``Constant``s or other ``Function``s.
+"""
+import numpy as np
+
+from .options import Constant
+
+__all__ = ['FunctionSpace', 'Function', 'MixedFunction', 'get_functionspace', 'triangle_quadrature']
+
+# 6-point, degree-4 Dunavant rule (barycentric points, weights sum to 1)
+_a1, _b1, _w1 = 0.445948490915965, 0.108103018168070, 0.223381589678011
+_a2, _b2, _w2 = 0.091576213509771, 0.816847572980459, 0.109951743655322
+
+
+def triangle_quadrature():
+    bary = np.array([[_b1, _a1, _a1], [_a1, _b1, _a1], [_a1, _a1, _b1],
+                     [_b2, _a2, _a2], [_a2, _b2, _a2], [_a2, _a2, _b2]])
+    w = np.array([_w1, _w1, _w1, _w2, _w2, _w2])
+    return bary, w/w.sum()
+
+
+class FunctionSpace(object):
+    def __init__(self, mesh, family, degree, vector=False, name=None):
+        family = {'DQ': 'DG', 'Discontinuous Lagrange': 'DG', 'Lagrange': 'CG'}.get(family, family)
+        if family not in ('CG', 'DG') or degree not in (0, 1):
+            raise NotImplementedError('only CG1, DG0 and DG1 spaces exist on this path')
+        if family == 'CG' and degree == 0:
+            raise ValueError('CG0 does not exist')
+        self.mesh_obj, self.family, self.degree, self.vector, self.name = mesh, family, degree, vector, name
+
+    def mesh(self):
+        return self.mesh_obj
+
+    def dim(self):
+        m = self.mesh_obj
+        n = m.num_vertices if self.family == 'CG' else m.num_cells*(3 if self.degree == 1 else 1)
+        return n*(2 if self.vector else 1)
+
+    def node_count(self):
+        m = self.mesh_obj
+        return m.num_vertices if self.family == 'CG' else m.num_cells*(3 if self.degree == 1 else 1)
+
+    def node_xy(self):
+        m = self.mesh_obj
+        if self.family == 'CG':
+            return m.vertex_xy
+        if self.degree == 1:
+            return m.cell_xy().reshape(-1, 2)
+        return m.cell_xy().mean(axis=1)
+
+
+def get_functionspace(mesh, h_family, h_degree, v_family=None, v_degree=None, vector=False, name=None, **kwargs):
+    """thetis/utility.py:135-189 restricted to 2D meshes."""
+    return FunctionSpace(mesh, h_family, h_degree, vector=vector, name=name)
+
+
+class _Dat(object):
+    def __init__(self, func):
+        self._f = func
+
+    @property
+    def data(self):
+        self._f._pull()
+        self._f._host_version += 1      # a writable view was handed out
+        return self._f._data
+
+    @property
+    def data_ro(self):
+        self._f._pull()
+        return self._f._data
+
+
+class Function(object):
+    def __init__(self, function_space, name=None, val=None):
+        self._fs = function_space
+        self._name = name
+        shape = (function_space.node_count(), 2) if function_space.vector else (function_space.node_count(),)
+        self._data = np.zeros(shape)
+        self._host_version = 0
+        self._pull_hook = None          # set by a device time stepper: refreshes _data from HBM when stale
+        self.dat = _Dat(self)
+        if val is not None:
+            self.assign(val)
+
+    def function_space(self):
+        return self._fs
+
+    def name(self):
+        return self._name
+
+    def _pull(self):
+        if self._pull_hook is not None:
+            self._pull_hook()
+
+    # ---- writes
+    def assign(self, value):
+        self._pull()
+        if isinstance(value, Function):
+            if value._fs.node_count() == self._fs.node_count() and value._fs.vector == self._fs.vector:
+                self._data[...] = value.dat.data_ro
+            else:
+                self._data[...] = value._as_space(self._fs)
+        elif isinstance(value, Constant):
+            self._data[...] = np.asarray(value.values() if self._fs.vector else float(value))
+        else:
+            self._data[...] = np.asarray(value, dtype=float)
+        self._host_version += 1
+        return self
+
+    def interpolate(self, expr):
+        """Nodal interpolation."""
+        self._pull()
+        self._data[...] = _evaluate(expr, self._fs.node_xy(), self._fs)
+        self._host_version += 1
+        return self
+
+    def project(self, expr):
+        """L2 projection (``elev_2d.project(elev)``, solver2d.py:763-766).  Into DG-P1 this is a cell-local 3x3 solve;
+        CG-P1 -> DG-P1 is exact nodal injection."""
+        fs = self._fs
+        if isinstance(expr, Function) or isinstance(expr, Constant) or np.isscalar(expr) \
+                or (not callable(expr)):
+            # P1 (CG or DG on the same mesh) and constants are in the DG-P1 space: projection = injection
+            return self.interpolate(expr)
+        if fs.family != 'DG' or fs.degree != 1:
+            raise NotImplementedError('projection of expressions is implemented for DG-P1 targets only')
+        mesh = fs.mesh_obj
+        bary, w = triangle_quadrature()
+        p = mesh.cell_xy()
+        n = mesh.num_cells
+        ncomp = 2 if fs.vector else 1
+        b = np.zeros((n, 3, ncomp))
+        for l, wq in zip(bary, w):
+            xq = np.einsum('nic,i->nc', p, l)
+            val = expr(xq[:, 0], xq[:, 1])
+            if fs.vector:
+                val = np.stack([np.asarray(val[0])*np.ones(n), np.asarray(val[1])*np.ones(n)], axis=1)
+            else:
+                val = (np.asarray(val)*np.ones(n))[:, None]
+            for i in range(3):
+                b[:, i, :] += wq*l[i]*val          # divided by the cell area
+        # (M/A)^-1 = 12 [[2,1,1],..]^-1  ->  x_i = 3 (4 b_i - sum b)
+        x = 3.0*(4.0*b - b.sum(axis=1, keepdims=True))
+        self._pull()
+        self._data[...] = x.reshape(self._data.shape)
+        self._host_version += 1
+        return self
+
+    # ---- reads
+    def _as_space(self, fs):
+        """Values of this P1 function at the nodes of another P1 space on the same mesh."""
+        mesh = fs.mesh_obj
+        src = self._fs
+        data = self.dat.data_ro
+        if src.family == 'CG' and fs.family == 'DG' and fs.degree == 1:
+            return data[mesh.cells.reshape(-1)]
+        if src.family == 'DG' and src.degree == 0 and fs.family == 'DG' and fs.degree == 1:
+            return np.repeat(data, 3, axis=0)
+        raise NotImplementedError('cannot inject {:}{:} into {:}{:}'.format(src.family, src.degree, fs.family, fs.degree))
+
+    def cell_node_values(self):
+        """(N, 3[, 2]) values at the three nodes of every cell."""
+        mesh = self._fs.mesh_obj
+        d = self.dat.data_ro
+        if self._fs.family == 'CG':
+            return d[mesh.cells]
+        if self._fs.degree == 1:
+            return d.reshape((mesh.num_cells, 3) + d.shape[1:])
+        return np.repeat(d[:, None], 3, axis=1)
+
+    def at(self, xy):
+        raise NotImplementedError('point evaluation is not part of the hot path')
+
+
+def _evaluate(expr, xy, fs):
+    n = xy.shape[0]
+    if isinstance(expr, Function):
+        return expr._as_space(fs) if expr._fs.node_count() != n or expr._fs.family != fs.family else expr.dat.data_ro
+    if isinstance(expr, Constant):
+        return np.asarray(expr.values())*np.ones((n, 2)) if fs.vector else float(expr)*np.ones(n)
+    if callable(expr):
+        val = expr(xy[:, 0], xy[:, 1])
+        if fs.vector:
+            return np.stack([np.asarray(val[0])*np.ones(n), np.asarray(val[1])*np.ones(n)], axis=1)
+        return np.asarray(val)*np.ones(n)
+    val = np.asarray(expr, dtype=float)
+    return val*np.ones((n, 2)) if fs.vector else val*np.ones(n)
+
+
+class MixedFunction(object):
+    """``solution_2d`` on V_2d = U_2d x H_2d (solver2d.py:345, 410-413)."""
+
+    def __init__(self, subfunctions, name=None):
+        self.subfunctions = tuple(subfunctions)
+        self._name = name
+
+    def split(self):
+        return self.subfunctions
+
+    def assign(self, other):
+        for a, b in zip(self.subfunctions, other.subfunctions):
+            a.assign(b)
+        return self

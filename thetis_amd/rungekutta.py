@@ -1,0 +1,192 @@
+"""
+SSPRK(3,3) in Shu-Osher form, stepping on the GPU.
+
+Mirrors ``thetis/rungekutta.py``: ``SSPRK33Abstract`` (:326-347) carries the tableau, ``ERKGenericShuOsher``
+(:870-952) the stage loop
+
+    for i in 0..2:  update_forcings(t + c_i dt);  k = M^-1 dt R(U);  U <- beta_{i+1,i} k + sum_j alpha_{i+1,j} U_j
+
+where the reference's ``self.solver.solve()`` + ``solution.assign(sol_expressions[i])`` + stage copies is ONE fused HIP
+kernel launch per stage here (swe2d_solve_stage in include/swe2d.h).
+"""
+import numpy as np
+
+from . import _lib
+from .device import Swe2dDevice
+from .function import Function
+from .options import Constant
+from .shallowwater_eq import g_grav
+from .timeintegrator import TimeIntegrator
+
+__all__ = ['SSPRK33Abstract', 'ERKGenericShuOsher', 'SSPRK33']
+
+
+class SSPRK33Abstract(object):
+    """3rd order Strong Stability Preserving Runge-Kutta scheme, SSP(3,3) (rungekutta.py:326-347)."""
+    a = np.array([[0, 0, 0], [1.0, 0, 0], [0.25, 0.25, 0]])
+    b = np.array([1.0/6.0, 1.0/6.0, 2.0/3.0])
+    c = np.array([0, 1.0, 0.5])
+    cfl_coeff = 1.0
+    n_stages = 3
+    is_implicit = False
+    is_dirk = False
+    # Shu-Osher form = output of the reference's butcher_to_shuosher_form(a, b) (rungekutta.py:13-87);
+    # bit-exact values pinned by tests/golden/shuosher_ssprk33.json
+    alpha = np.array([[1.0, 0.0, 0.0, 0.0],
+                      [1.0, 0.0, 0.0, 0.0],
+                      [0.75, 0.25, 0.0, 0.0],
+                      [0.33333333333333337, 0.0, 0.6666666666666666, 0.0]])
+    beta = np.array([[0.0, 0.0, 0.0, 0.0],
+                     [1.0, 0.0, 0.0, 0.0],
+                     [0.0, 0.25, 0.0, 0.0],
+                     [0.0, 0.0, 0.6666666666666666, 0.0]])
+
+
+def _const_value(v):
+    if v is None:
+        return None
+    if isinstance(v, Constant):
+        vals = v.values()
+        return vals[0] if len(vals) == 1 else tuple(vals)
+    if isinstance(v, (tuple, list, np.ndarray)):
+        return tuple(float(x) for x in v)
+    return float(v)
+
+
+class ERKGenericShuOsher(TimeIntegrator):
+    """Generic explicit Runge-Kutta time integrator in Shu-Osher form, device resident (rungekutta.py:870-952)."""
+
+    def __init__(self, equation, solution, fields, dt, options, bnd_conditions, terms_to_add='all',
+                 device_id=0):
+        super(ERKGenericShuOsher, self).__init__(equation, solution, fields, dt, options)
+        if terms_to_add != 'all':
+            raise NotImplementedError("the fused stage kernel evaluates all terms; terms_to_add must be 'all'")
+        equation.check_fields(fields)
+        self.bnd_conditions = bnd_conditions
+        mesh = equation.mesh
+        opts = equation.options
+        bath = equation.depth.bathymetry_2d
+        if not (isinstance(bath, Function) and bath.function_space().family == 'CG'):
+            raise NotImplementedError('bathymetry_2d must be a CG-P1 Function (continuous bathymetry)')
+        self.device = Swe2dDevice(
+            mesh, bath.dat.data_ro, dt, g_grav=g_grav,
+            use_nonlinear_equations=opts.use_nonlinear_equations,
+            use_lax_friedrichs_velocity=opts.use_lax_friedrichs_velocity,
+            lax_friedrichs_velocity_scaling_factor=float(fields.get('lax_friedrichs_velocity_scaling_factor') or 1.0),
+            device_id=device_id, boundary_len=getattr(mesh, 'boundary_len', None))
+        self._uploaded_version = None
+        self._device_ahead = False
+        self._push_fields()
+        self._push_bcs()
+        uv, eta = self.solution.subfunctions
+        uv._pull_hook = self._pull_solution
+        eta._pull_hook = self._pull_solution
+
+    # ---- coefficient / boundary upload
+    def _nodal(self, value, vector=False):
+        """Constant | callable | Function  ->  (N,3[,2]) nodal values."""
+        mesh = self.equation.mesh
+        if isinstance(value, Function):
+            return value.cell_node_values()
+        p = mesh.cell_xy()
+        if callable(value):
+            val = value(p[:, :, 0], p[:, :, 1])
+            if vector:
+                return np.stack([np.asarray(val[0])*np.ones(p.shape[:2]), np.asarray(val[1])*np.ones(p.shape[:2])], axis=2)
+            return np.asarray(val)*np.ones(p.shape[:2])
+        c = _const_value(value)
+        if vector:
+            return np.broadcast_to(np.asarray(c, dtype=float), p.shape).copy()
+        return np.full(p.shape[:2], float(c))
+
+    def _push_fields(self):
+        f = self.fields
+        dev = self.device
+        dev.set_scalar(_lib.SCALAR_NORM_SMOOTHER, float(getattr(self.equation.options, 'norm_smoother', 0.0) or 0.0))
+        dev.set_scalar(_lib.SCALAR_LINEAR_DRAG, _const_value(f.get('linear_drag_coefficient')))
+        dev.set_scalar(_lib.SCALAR_QUADRATIC_DRAG, _const_value(f.get('quadratic_drag_coefficient')))
+        dev.set_scalar(_lib.SCALAR_MANNING_DRAG, _const_value(f.get('manning_drag_coefficient')))
+        for key, fid, vec in (('coriolis', _lib.FIELD_CORIOLIS, False),
+                              ('atmospheric_pressure', _lib.FIELD_ATMOSPHERIC_PRESSURE, False),
+                              ('momentum_source', _lib.FIELD_MOMENTUM_SOURCE, True),
+                              ('volume_source', _lib.FIELD_VOLUME_SOURCE, False)):
+            v = f.get(key)
+            dev.set_field(fid, None if v is None else self._nodal(v, vector=vec))
+
+    def _push_bcs(self):
+        mesh = self.equation.mesh
+        for marker in mesh.boundary_markers:
+            funcs = self.bnd_conditions.get(marker)
+            if funcs is None:
+                self.device.set_bc(marker, None)
+                continue
+            vals = {}
+            for key, v in funcs.items():
+                if key not in ('elev', 'uv', 'un', 'flux', 'drag'):
+                    raise Exception('Invalid boundary tag "{:}" specified on boundary {:}'.format(key, marker))
+                if isinstance(v, Function) or callable(v):
+                    raise NotImplementedError('boundary values must be constants on the device path')
+                vals[key] = _const_value(v)
+            self.device.set_bc(marker, vals)
+
+    # ---- host <-> device state
+    def _host_version(self):
+        uv, eta = self.solution.subfunctions
+        return (uv._host_version, eta._host_version)
+
+    def _push_solution(self):
+        uv, eta = self.solution.subfunctions
+        self.device.set_state(uv._data, eta._data)
+        self._uploaded_version = self._host_version()
+        self._device_ahead = False
+
+    def _pull_solution(self):
+        """Refresh the host copy of ``solution`` (called lazily when someone reads ``.dat.data``)."""
+        if self._device_ahead:
+            uv, eta = self.solution.subfunctions
+            u, e = self.device.get_state()
+            uv._data[...] = u.reshape(uv._data.shape)
+            eta._data[...] = e.reshape(eta._data.shape)
+            self._device_ahead = False
+
+    def _sync_to_device(self):
+        if self._uploaded_version != self._host_version():
+            self._pull_solution()           # no-op unless the device is ahead (then host edits win on top of it)
+            self._push_solution()
+
+    def initialize(self, solution):
+        """rungekutta.py:926-927 is a no-op; here the initial state goes to HBM."""
+        self._push_solution()
+
+    def set_dt(self, dt):
+        super(ERKGenericShuOsher, self).set_dt(dt)
+        self.device.set_dt(dt)
+
+    def solve_stage(self, i_stage, t, update_forcings=None):
+        """Solve i-th stage and assign solution to :attr:`self.solution` (rungekutta.py:930-946)."""
+        if update_forcings is not None:
+            update_forcings(t + self.c[i_stage]*self.dt)
+            self._push_bcs()
+        if i_stage == 0:
+            self._sync_to_device()
+        self.device.solve_stage(i_stage)
+        self._device_ahead = True
+
+    def advance(self, t, update_forcings=None):
+        """Advances equations for one time step (rungekutta.py:949-952)."""
+        if update_forcings is None:
+            self._sync_to_device()
+            self.device.advance(1)
+            self._device_ahead = True
+        else:
+            for i in range(self.n_stages):
+                self.solve_stage(i, t, update_forcings)
+
+    def diagnostics(self):
+        """{int eta^2, int |u|^2, int (eta+h), min(h+eta)} of the device-resident state."""
+        self._sync_to_device()
+        return self.device.diagnostics()
+
+
+class SSPRK33(ERKGenericShuOsher, SSPRK33Abstract):
+    pass

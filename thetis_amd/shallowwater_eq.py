@@ -1,0 +1,66 @@
+"""
+Descriptor of the 2D shallow water equations for the device path.
+
+In the reference ``ShallowWaterEquations`` (thetis/shallowwater_eq.py:893-928) is a bag of UFL terms; the terms
+themselves are symbolic and Firedrake turns them into kernels.  Here the terms *are* the HIP stage kernel
+(thetis_amd/csrc/swe2d_kernels.h), so this class only records which of them are switched on and checks that the
+configuration is one the kernel implements:
+
+  ExternalPressureGradientTerm :335   HUDivTerm :396   HorizontalAdvectionTerm :453 (+ Lax-Friedrichs)
+  CoriolisTerm :619   AtmosphericPressureTerm :652   QuadraticDragTerm :666 (constant C_D or Manning)
+  LinearDragTerm :728   MomentumSourceTerm :794   ContinuitySourceTerm :814
+  boundary conditions 'elev' / 'uv' / 'un' / 'flux' with constant values (get_bnd_functions :232-272)
+"""
+from .options import Constant
+
+__all__ = ['ShallowWaterEquations', 'DepthExpression', 'g_grav', 'rho_0']
+
+g_grav = 9.81      # thetis/physical_constants.py:7
+rho_0 = 1000.0     # thetis/physical_constants.py:8
+
+
+class DepthExpression(object):
+    """Total depth options (thetis/utility.py:936-996): H = h (linear), h + eta (nonlinear)."""
+
+    def __init__(self, bathymetry_2d, use_nonlinear_equations=True, use_wetting_and_drying=False,
+                 wetting_and_drying_alpha=0.5):
+        self.bathymetry_2d = bathymetry_2d
+        self.use_nonlinear_equations = use_nonlinear_equations
+        self.use_wetting_and_drying = use_wetting_and_drying
+        self.wetting_and_drying_alpha = wetting_and_drying_alpha
+
+
+class ShallowWaterEquations(object):
+    SUPPORTED_TERMS = ('ExternalPressureGradientTerm', 'HorizontalAdvectionTerm', 'CoriolisTerm',
+                       'AtmosphericPressureTerm', 'QuadraticDragTerm', 'LinearDragTerm', 'MomentumSourceTerm',
+                       'HUDivTerm', 'ContinuitySourceTerm')
+
+    def __init__(self, function_space, depth, options, tidal_farms=None):
+        self.function_space = function_space
+        self.mesh = function_space.mesh()
+        self.depth = depth
+        self.options = options
+        if tidal_farms:
+            raise NotImplementedError('TurbineDragTerm is outside the device hot path')
+        if options.element_family != 'dg-dg' or options.polynomial_degree != 1:
+            raise NotImplementedError("the device path implements element_family='dg-dg', polynomial_degree=1 only "
+                                      "(got {!r}, degree {:})".format(options.element_family, options.polynomial_degree))
+        if depth.use_wetting_and_drying:
+            # mass_term(TrialFunction) is not bilinear with wetting-drying (shallowwater_eq.py:917-920,
+            # rungekutta.py:900), so the reference itself cannot run SSPRK33 with it.
+            raise NotImplementedError('use_wetting_and_drying is not a valid configuration of the explicit SSPRK33 path')
+
+    def check_fields(self, fields):
+        """Raise for coefficients whose terms the kernel does not implement (never silently ignore physics)."""
+        if fields.get('viscosity_h') is not None:
+            raise NotImplementedError('HorizontalViscosityTerm (SIPG) is not implemented on the device path yet')
+        if fields.get('wind_stress') is not None:
+            raise NotImplementedError('WindStressTerm is not implemented on the device path yet')
+        if fields.get('nikuradse_bed_roughness') is not None:
+            raise NotImplementedError('Nikuradse bed roughness is not implemented on the device path yet')
+        if fields.get('quadratic_drag_coefficient') is not None and fields.get('manning_drag_coefficient') is not None:
+            raise Exception('Cannot set both dimensionless and Manning drag parameter')
+        for key in ('linear_drag_coefficient', 'quadratic_drag_coefficient', 'manning_drag_coefficient'):
+            v = fields.get(key)
+            if v is not None and not isinstance(v, (int, float, Constant)):
+                raise NotImplementedError('{:} must be a constant on the device path'.format(key))

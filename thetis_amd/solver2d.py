@@ -1,0 +1,290 @@
+"""
+``FlowSolver2d``: the user-facing driver with the reference's surface (thetis/solver2d.py) - options, boundary
+functions, ``assign_initial_conditions`` and the ``iterate`` / ``create_iterator`` time loop - whose time stepper is
+the MI355X-resident SSPRK33 (thetis_amd/rungekutta.py -> C ABI -> HIP stage kernel).
+
+Kept from the reference: option names and defaults, generator semantics of ``create_iterator`` (yields the time
+*before* it is incremented, solver2d.py:1122-1127), export cadence with ``t_epsilon = 1e-5`` (:1036),
+``simulation_time = t0 + k*dt`` (:1127), ``print_state`` line format (:931-970), the ``steppers`` table (:662-672).
+Not kept: exporters (VTK/HDF5 I/O), log files, ``load_state``, the implicit steppers and the 3D/NH/sediment couplings.
+"""
+import math
+import sys
+import time as time_mod
+
+import numpy as np
+
+from . import callback
+from .function import Function, FunctionSpace, MixedFunction, get_functionspace
+from .log import print_output
+from .options import Constant, ModelOptions2d
+from .rungekutta import SSPRK33
+from .shallowwater_eq import DepthExpression, ShallowWaterEquations, g_grav
+
+__all__ = ['FlowSolver2d']
+
+
+class AttrDict(dict):
+    """Dictionary whose keys are attributes too (thetis/utility.py:87-100)."""
+
+    def __init__(self, *args, **kwargs):
+        super(AttrDict, self).__init__(*args, **kwargs)
+        self.__dict__ = self
+
+
+class FieldDict(AttrDict):
+    """AttrDict that checks the values are fields (thetis/utility.py:103-132)."""
+
+
+class FlowSolver2d(object):
+    def __init__(self, mesh2d, bathymetry_2d, options=None, keep_log=False):
+        self._initialized = False
+        self.mesh2d = mesh2d
+        self.dt = None
+        self.options = ModelOptions2d()
+        if options is not None:
+            self.options.update(options)
+        self.simulation_time = 0
+        self.iteration = 0
+        self.i_export = 0
+        self.next_export_t = self.simulation_time + self.options.simulation_export_time
+        self.callbacks = callback.CallbackManager()
+        self.fields = FieldDict()
+        self.function_spaces = AttrDict()
+        self.fields.bathymetry_2d = bathymetry_2d
+        self.export_initial_state = True
+        self.bnd_functions = {'shallow_water': {}, 'tracer': {}, 'sediment': {}}
+        self.solve_tracer = False
+        self.keep_log = keep_log
+        self.device_id = 0
+
+    # ------------------------------------------------------------------ time step
+    def compute_time_step(self, u_scale=0.0):
+        """Maximum explicit time step from the CFL condition (solver2d.py:149-177): the L2 projection onto CG-P1 of
+        ``h_elem_size / (sqrt(g max(h, 0.05)) + u_scale)`` with the consistent CG mass matrix, as ``solve(a == l)`` does."""
+        from .cgproject import project_to_p1
+        mesh = self.mesh2d
+        csize = self.fields.h_elem_size_2d
+        bath = np.maximum(self.fields.bathymetry_2d.dat.data_ro, 0.05)
+        u = np.sqrt(g_grav*bath) + float(u_scale)                   # P1 nodal
+        # integrand csize/u: evaluate at quadrature points from the P1 fields
+        sol = project_to_p1(mesh, lambda lam, cells: (csize.dat.data_ro[cells] @ lam)/(u[cells] @ lam))
+        out = Function(self.function_spaces.P1_2d)
+        out.assign(sol)
+        return out
+
+    def set_time_step(self, alpha=0.05):
+        """solver2d.py:213-248"""
+        automatic_timestep = False
+        for o in (self.options.swe_timestepper_options, self.options.tracer_timestepper_options):
+            if hasattr(o, 'use_automatic_timestep') and o.use_automatic_timestep:
+                automatic_timestep = True
+        if automatic_timestep:
+            mesh2d_dt = self.compute_time_step(u_scale=float(self.options.horizontal_velocity_scale))
+            self.dt = self.options.cfl_2d*alpha*float(mesh2d_dt.dat.data_ro.min())
+        else:
+            assert self.options.timestep is not None
+            assert self.options.timestep > 0.0
+            self.dt = self.options.timestep
+        print_output('dt = {:}'.format(self.dt))
+
+    # ------------------------------------------------------------------ setup
+    def create_function_spaces(self):
+        """solver2d.py:307-352, 'dg-dg' branch"""
+        m = self.mesh2d
+        fs = self.function_spaces
+        fs.P0_2d = get_functionspace(m, 'DG', 0, name='P0_2d')
+        fs.P1_2d = get_functionspace(m, 'CG', 1, name='P1_2d')
+        fs.P1v_2d = get_functionspace(m, 'CG', 1, name='P1v_2d', vector=True)
+        fs.P1DG_2d = get_functionspace(m, 'DG', 1, name='P1DG_2d')
+        fs.P1DGv_2d = get_functionspace(m, 'DG', 1, name='P1DGv_2d', vector=True)
+        if self.options.element_family != 'dg-dg':
+            raise NotImplementedError("only element_family='dg-dg' runs on the device path")
+        fs.U_2d = get_functionspace(m, 'DG', self.options.polynomial_degree, name='U_2d', vector=True)
+        fs.H_2d = get_functionspace(m, 'DG', self.options.polynomial_degree, name='H_2d')
+        fs.V_2d = (fs.U_2d, fs.H_2d)
+        fs.Q_2d = get_functionspace(m, 'DG', 1, name='Q_2d')
+
+    def create_fields(self):
+        """solver2d.py:389-449"""
+        if not hasattr(self.function_spaces, 'U_2d'):
+            self.create_function_spaces()
+        uv_2d = Function(self.function_spaces.U_2d, name='uv_2d')
+        elev_2d = Function(self.function_spaces.H_2d, name='elev_2d')
+        self.fields.solution_2d = MixedFunction((uv_2d, elev_2d), name='solution_2d')
+        self.fields.uv_2d = uv_2d
+        self.fields.elev_2d = elev_2d
+        # mesh element size: CG-P1 L2 projection of sqrt(cell area), utility.py:620-640 (needed for automatic dt only)
+        self.fields.h_elem_size_2d = None
+        self.depth = DepthExpression(self.fields.bathymetry_2d,
+                                     use_nonlinear_equations=self.options.use_nonlinear_equations,
+                                     use_wetting_and_drying=self.options.use_wetting_and_drying,
+                                     wetting_and_drying_alpha=self.options.wetting_and_drying_alpha)
+
+    def create_equations(self):
+        """solver2d.py:453-539"""
+        if not hasattr(self.fields, 'uv_2d'):
+            self.create_fields()
+        self.equations = AttrDict()
+        self.equations.sw = ShallowWaterEquations(self.function_spaces.H_2d, self.depth, self.options)
+        self.equations.sw.bnd_functions = self.bnd_functions['shallow_water']
+
+    def get_swe_timestepper(self, integrator):
+        """Gets shallow water timestepper object with appropriate parameters (solver2d.py:542-573)"""
+        o = self.options
+        fields = {
+            'linear_drag_coefficient': o.linear_drag_coefficient,
+            'quadratic_drag_coefficient': o.quadratic_drag_coefficient,
+            'manning_drag_coefficient': o.manning_drag_coefficient,
+            'nikuradse_bed_roughness': o.nikuradse_bed_roughness,
+            'viscosity_h': o.horizontal_viscosity,
+            'lax_friedrichs_velocity_scaling_factor': o.lax_friedrichs_velocity_scaling_factor,
+            'coriolis': o.coriolis_frequency,
+            'wind_stress': o.wind_stress,
+            'atmospheric_pressure': o.atmospheric_pressure,
+            'momentum_source': o.momentum_source_2d,
+            'volume_source': o.volume_source_2d,
+        }
+        bnd_conditions = self.bnd_functions['shallow_water']
+        return integrator(self.equations.sw, self.fields.solution_2d, fields, self.dt,
+                          o.swe_timestepper_options, bnd_conditions, device_id=self.device_id)
+
+    def create_timestepper(self):
+        """solver2d.py:651-700"""
+        if not hasattr(self, 'equations'):
+            self.create_equations()
+        if any(hasattr(o, 'use_automatic_timestep') and o.use_automatic_timestep
+               for o in (self.options.swe_timestepper_options,)):
+            from .cgproject import elem_size_p1
+            self.fields.h_elem_size_2d = Function(self.function_spaces.P1_2d).assign(elem_size_p1(self.mesh2d))
+        self.compute_mesh_stats()
+        self.set_time_step()
+        steppers = {'SSPRK33': SSPRK33}
+        name = self.options.swe_timestepper_type
+        if self.solve_tracer or self.options.tracer:
+            raise NotImplementedError('2D tracers are not on the device path yet')
+        if name not in steppers:
+            raise NotImplementedError("swe_timestepper_type {!r} needs a global (non)linear solve and is outside the "
+                                      "explicit device path; use 'SSPRK33'".format(name))
+        self.timestepper = self.get_swe_timestepper(steppers[name])
+        print_output('Using time integrator: {:}'.format(self.timestepper.__class__.__name__))
+
+    def compute_mesh_stats(self):
+        """solver2d.py:179-211"""
+        m = self.mesh2d
+        print_output('Element family: {:}, degree: {:}'.format(self.options.element_family, self.options.polynomial_degree))
+        print_output('2D cell type: triangle')
+        print_output('2D mesh: {:} vertices, {:} elements'.format(m.num_vertices, m.num_cells))
+        a = np.sqrt(m.cell_areas())
+        print_output('Horizontal element size: {:.2f} ... {:.2f} m'.format(a.min(), a.max()))
+        print_output('Number of 2D elevation DOFs: {:}'.format(self.function_spaces.H_2d.dim()))
+        print_output('Number of 2D velocity DOFs: {:}'.format(self.function_spaces.U_2d.dim()))
+
+    def create_exporters(self):
+        """solver2d.py:704-730 - field export is out of scope for the hot path."""
+        self.exporters = {}
+
+    def initialize(self):
+        """solver2d.py:732-744"""
+        if not hasattr(self.function_spaces, 'U_2d'):
+            self.create_function_spaces()
+        if not hasattr(self, 'equations'):
+            self.create_equations()
+        if not hasattr(self, 'timestepper'):
+            self.create_timestepper()
+        if not hasattr(self, 'exporters'):
+            self.create_exporters()
+        self._initialized = True
+
+    def assign_initial_conditions(self, elev=None, uv=None, **tracers):
+        """Assigns initial conditions by L2 projection (solver2d.py:747-785)"""
+        if not self._initialized:
+            self.initialize()
+        uv_2d, elev_2d = self.fields.solution_2d.subfunctions
+        if elev is not None:
+            elev_2d.project(elev)
+        if uv is not None:
+            uv_2d.project(uv)
+        if tracers:
+            raise NotImplementedError('2D tracers are not on the device path yet')
+        self.timestepper.initialize(self.fields.solution_2d)
+
+    def add_callback(self, callback, eval_interval='export'):
+        """solver2d.py:788-797"""
+        self.callbacks.add(callback, eval_interval)
+
+    def export(self, time=None):
+        """solver2d.py:799-812: evaluate export callbacks (no field files on this path)."""
+        self.callbacks.evaluate(mode='export', index=self.i_export)
+
+    def load_state(self, *args, **kwargs):
+        raise NotImplementedError('restart from HDF5 checkpoints is outside the hot path')
+
+    # ------------------------------------------------------------------ time loop
+    def print_state(self, cputime, print_header=False):
+        """Print a summary of the model state on stdout (solver2d.py:923-971)"""
+        entries = [('exp', self.i_export, '5d'), ('iter', self.iteration, '5d')]
+        time_str = '{:.2f}'.format(self.simulation_time).rjust(15)
+        entries += [('time', time_str, '15s')]
+        d = self.timestepper.diagnostics()
+        norm_h = math.sqrt(d[0])
+        norm_u = math.sqrt(d[1])
+        entries += [('eta norm', norm_h, '14.4f'), ('u norm', norm_u, '14.4f')]
+        entries.append(('Tcpu', cputime, '6.2f'))
+        if print_header:
+            header = ' '.join([e[0].rjust(len('{:{fmt}}'.format(e[1], fmt=e[2]))) for e in entries])
+            print_output(header)
+        line = ' '.join(['{:{fmt}}'.format(e[1], fmt=e[2]) for e in entries])
+        print_output(line)
+        sys.stdout.flush()
+
+    def iterate(self, update_forcings=None, export_func=None):
+        """Runs the simulation (solver2d.py:974-994)"""
+        for _ in self.create_iterator(update_forcings=update_forcings, export_func=export_func):
+            pass
+
+    def create_iterator(self, update_forcings=None, export_func=None):
+        """Generator over the time loop (solver2d.py:997-1144)"""
+        if not self._initialized:
+            self.initialize()
+        t_epsilon = 1.0e-5
+        cputimestamp = time_mod.perf_counter()
+        next_export_t = self.simulation_time + self.options.simulation_export_time
+        if self.options.check_volume_conservation_2d:
+            c = callback.VolumeConservation2DCallback(self, export_to_hdf5=False, append_to_log=True)
+            self.add_callback(c)
+        initial_simulation_time = self.simulation_time
+        internal_iteration = 0
+        assert self.options.simulation_end_time is not None, 'simulation_end_time must be set'
+
+        # initial export
+        self.print_state(0.0, print_header=True)
+        if self.export_initial_state:
+            self.export(time=self.simulation_time)
+            if export_func is not None:
+                export_func()
+
+        while self.simulation_time <= self.options.simulation_end_time - t_epsilon:
+            self.timestepper.advance(self.simulation_time, update_forcings)
+
+            # returns internal simulation time
+            yield self.simulation_time
+
+            # Move to next time step
+            self.iteration += 1
+            internal_iteration += 1
+            self.simulation_time = initial_simulation_time + internal_iteration*self.dt
+
+            self.callbacks.evaluate(mode='timestep')
+
+            # Write the solution to file
+            if self.simulation_time >= next_export_t - t_epsilon:
+                self.i_export += 1
+                next_export_t += self.options.simulation_export_time
+                cputime = time_mod.perf_counter() - cputimestamp
+                cputimestamp = time_mod.perf_counter()
+                self.print_state(cputime)
+                self.export(time=self.simulation_time)
+                if export_func is not None:
+                    export_func()
+        return self.simulation_time
