@@ -1,0 +1,119 @@
+"""Worker bodies for the 2-rank tests (spawned processes; gloo rendezvous on 127.0.0.1)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _case():
+    from helpers import channel_case
+    return channel_case(nx=16, ny=6, seed=21, amp_eta=0.3, amp_u=0.2)
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['RANK'] = str(rank)
+    os.environ['WORLD_SIZE'] = str(world)
+    dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    return dist
+
+
+def cpu_worker(rank, world, port, n_steps, out_dir, axis):
+    """Partition + halo exchange logic of the product, with the oracle's C restatement as the (CPU) compute."""
+    import torch
+    from oracle.ref_lib import RefSWE
+    from thetis_amd.distributed import HaloExchanger
+    from thetis_amd.partition import build_partition, strip_owner
+    dist = _init(rank, world, port)
+    mesh, bath, uv, eta = _case()
+    owner = strip_owner(mesh, world, axis=axis)
+    part = build_partition(mesh, owner, rank)
+    ref = RefSWE(part.cell_xy(), part.cell_nbr, part.cell_nbr_facet, bath[part.vertex_global][part.cells],
+                 boundary_len=part.boundary_len)
+    g = part.local_to_global
+    u, e = uv[g].copy(), eta[g].copy()
+    halo = HaloExchanger(part, torch.device('cpu'))
+    dt = 2.0
+    no = part.n_owned
+    al0 = [0.0, 0.75, 0.33333333333333337]
+    ali = [1.0, 0.25, 0.6666666666666666]
+    be = [1.0, 0.25, 0.6666666666666666]
+
+    def exchange(u, e):
+        sc = part.send_cells
+        packed = np.concatenate([u[sc, :, 0], u[sc, :, 1], e[sc]], axis=1)      # [n][9] = u0 u1 u2 v0 v1 v2 e0 e1 e2
+        halo.send_buf[:packed.size] = torch.from_numpy(packed.reshape(-1))
+        halo.finish(halo.start())
+        r = halo.recv_buf[:9*part.n_ghost].numpy().reshape(-1, 9)
+        u[no:, :, 0], u[no:, :, 1], e[no:] = r[:, 0:3], r[:, 3:6], r[:, 6:9]
+
+    for _ in range(n_steps):
+        u0, e0 = u.copy(), e.copy()
+        for i in range(3):
+            exchange(u, e)
+            ku, ke = ref.tendency(u, e, dt)
+            u[:no] = be[i]*ku[:no] + al0[i]*u0[:no] + ali[i]*u[:no]
+            e[:no] = be[i]*ke[:no] + al0[i]*e0[:no] + ali[i]*e[:no]
+    np.savez(os.path.join(out_dir, 'rank{:d}.npz'.format(rank)), ids=g[:no], uv=u[:no], eta=e[:no],
+             n_interior=part.n_interior, n_ghost=part.n_ghost)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gpu_worker(rank, world, port, n_steps, out_dir, axis):
+    """The real DistributedSwe2d on ONE GPU shared by both ranks (gloo + host staging stands in for RCCL)."""
+    from thetis_amd.distributed import DistributedSwe2d
+    from thetis_amd.partition import strip_owner
+    dist = _init(rank, world, port)
+    mesh, bath, uv, eta = _case()
+    owner = strip_owner(mesh, world, axis=axis)
+    solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, host_staged=True)
+    solver.set_state_global(uv, eta)
+    d0 = solver.diagnostics()
+    solver.advance(n_steps, use_graph=False)
+    solver.synchronize()
+    d1 = solver.diagnostics()
+    ids, u, e = solver.get_state_owned()
+    np.savez(os.path.join(out_dir, 'rank{:d}.npz'.format(rank)), ids=ids, uv=u, eta=e, d0=d0, d1=d1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_workers(target, world, n_steps, out_dir, axis=0):
+    import multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=target, args=(r, world, port, n_steps, out_dir, axis)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            raise RuntimeError('distributed worker timed out')
+        assert p.exitcode == 0, 'distributed worker failed with exit code {:}'.format(p.exitcode)
+
+
+def gather(out_dir, world, n_cells):
+    uv = np.full((n_cells, 3, 2), np.nan)
+    eta = np.full((n_cells, 3), np.nan)
+    extra = []
+    for r in range(world):
+        d = np.load(os.path.join(out_dir, 'rank{:d}.npz'.format(r)))
+        uv[d['ids']] = d['uv']
+        eta[d['ids']] = d['eta']
+        extra.append(d)
+    assert not np.isnan(uv).any() and not np.isnan(eta).any(), 'some cell is owned by no rank'
+    return uv, eta, extra

@@ -1,0 +1,124 @@
+"""FlowSolver2d surface on the GPU: examples/channel2d (regression length) and forcing/boundary plumbing."""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import make_ref, rel_linf
+from thetis_amd import Constant, Function, RectangleMesh, get_functionspace, solver2d
+
+pytestmark = pytest.mark.gpu
+
+
+def _channel2d_solver(dt=2.0, t_end=500.0):
+    # examples/channel2d/channel2d.py:21-61 with THETIS_REGRESSION_TEST (t_end = 5 exports)
+    lx, ly, nx, ny = 100e3, 3750.0, 80, 3
+    mesh2d = RectangleMesh(nx, ny, lx, ly)
+    P1_2d = get_functionspace(mesh2d, 'CG', 1)
+    bathymetry_2d = Function(P1_2d, name='Bathymetry')
+    bathymetry_2d.interpolate(lambda x, y: 20.0 + (5.0 - 20.0)*x/lx)
+    solver_obj = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+    options = solver_obj.options
+    options.simulation_export_time = 100.0
+    options.simulation_end_time = t_end
+    options.horizontal_velocity_scale = Constant(6.0)
+    options.check_volume_conservation_2d = True
+    options.fields_to_export = ['uv_2d', 'elev_2d']
+    options.swe_timestepper_type = 'SSPRK33'
+    options.swe_timestepper_options.use_automatic_timestep = False
+    options.timestep = dt
+    elev_init = Function(P1_2d)
+    elev_init.interpolate(lambda x, y: np.where(x < 30e3, 6.0*(1 - x/30e3), 0.0))
+    return solver_obj, mesh2d, bathymetry_2d, elev_init
+
+
+def test_channel2d_example_matches_cpu_restatement(hip_lib, ref_so, capsys):
+    solver_obj, mesh, bath, elev_init = _channel2d_solver()
+    solver_obj.assign_initial_conditions(elev=elev_init)
+    times = [t for t in solver_obj.create_iterator()]
+    # generator yields the time before it is incremented (solver2d.py:1122-1127)
+    assert times[0] == 0 and math.isclose(times[-1], 498.0) and len(times) == 250
+    assert solver_obj.iteration == 250 and solver_obj.i_export == 5 and math.isclose(solver_obj.simulation_time, 500.0)
+    uv, eta = solver_obj.fields.solution_2d.subfunctions
+    ref = make_ref(mesh, bath.dat.data_ro)
+    eta0 = elev_init.dat.data_ro[mesh.cells]
+    u_r, e_r = ref.advance(np.zeros((mesh.num_cells, 3, 2)), eta0, 2.0, 250)
+    assert rel_linf(eta.dat.data_ro.reshape(-1, 3), e_r) < 1e-10
+    assert rel_linf(uv.dat.data_ro.reshape(-1, 3, 2), u_r) < 1e-10
+    out = capsys.readouterr().out
+    assert 'Using time integrator: SSPRK33' in out and 'eta norm' in out
+    rel = [float(l.split()[-1]) for l in out.splitlines() if l.startswith('volume2d rel. error')]
+    assert len(rel) == 6 and max(abs(r) for r in rel) < 1e-12      # reference bar: test_closed_channel.py:77-78
+    # print_state line format (solver2d.py:931-970)
+    line = [l for l in out.splitlines() if l.strip().startswith('5   250')][0]
+    assert line.split()[2] == '500.00'
+
+
+def test_automatic_timestep_runs(hip_lib):
+    solver_obj, mesh, bath, elev_init = _channel2d_solver(t_end=100.0)
+    solver_obj.options.swe_timestepper_options.use_automatic_timestep = True
+    solver_obj.assign_initial_conditions(elev=elev_init)
+    # CFL dt with alpha = 0.05 (solver2d.py:214): min over nodes of dx/(sqrt(g h) + 6)
+    assert 0.5 < solver_obj.dt < 2.0
+    solver_obj.iterate()
+    d = solver_obj.timestepper.diagnostics()
+    assert np.isfinite(d).all()
+
+
+def test_update_forcings_and_open_boundary(hip_lib, ref_so):
+    """Time-dependent elevation on marker 2 through ``update_forcings`` at t + c_i dt (rungekutta.py:933-934)."""
+    lx, ly = 13800.0, 7200.0
+    mesh2d = RectangleMesh(12, 6, lx, ly)
+    bath = Function(get_functionspace(mesh2d, 'CG', 1)).interpolate(lambda x, y: 5.0 + x/2760.0)
+    s = solver2d.FlowSolver2d(mesh2d, bath)
+    o = s.options
+    o.swe_timestepper_type = 'SSPRK33'
+    o.swe_timestepper_options.use_automatic_timestep = False
+    o.timestep = 5.0
+    o.simulation_end_time = 100.0
+    o.simulation_export_time = 50.0
+    o.manning_drag_coefficient = Constant(0.02)
+    elev_bc = Constant(0.0)
+    s.bnd_functions['shallow_water'] = {2: {'elev': elev_bc}}
+    calls = []
+
+    def update_forcings(t):
+        calls.append(t)
+        elev_bc.assign(-0.5*math.sin(2*math.pi*t/1000.0))
+    s.assign_initial_conditions(elev=Constant(0.0))
+    s.iterate(update_forcings=update_forcings)
+    assert calls[:3] == [0.0, 5.0, 2.5]                      # c = (0, 1, 1/2)
+    uv, eta = s.fields.solution_2d.subfunctions
+    # same sequence with the numpy oracle (literal forms incl. Manning quadrature and the Riemann boundary)
+    from helpers import make_oracle
+    val = {'v': 0.0}
+    orc = make_oracle(mesh2d, bath.dat.data_ro, manning_drag_coefficient=0.02,
+                      bnd_conditions={2: {'elev': lambda t: val['v']}})
+
+    def uf(t):
+        val['v'] = -0.5*math.sin(2*math.pi*t/1000.0)
+    u_o = np.zeros((mesh2d.num_cells, 3, 2))
+    e_o = np.zeros((mesh2d.num_cells, 3))
+    for k in range(20):
+        u_o, e_o = orc.ssprk33_step(u_o, e_o, 5.0, t=5.0*k, update_forcings=uf)
+    assert rel_linf(eta.dat.data_ro.reshape(-1, 3), e_o) < 1e-10
+    assert rel_linf(uv.dat.data_ro.reshape(-1, 3, 2), u_o) < 1e-10
+
+
+def test_unsupported_configurations_fail_loudly(hip_lib):
+    solver_obj, mesh, bath, elev_init = _channel2d_solver()
+    solver_obj.options.swe_timestepper_type = 'CrankNicolson'
+    with pytest.raises(NotImplementedError):
+        solver_obj.assign_initial_conditions(elev=elev_init)
+    s2, *_ = _channel2d_solver()
+    s2.options.use_wetting_and_drying = True
+    with pytest.raises(NotImplementedError):
+        s2.assign_initial_conditions(elev=elev_init)
+    s3, *_ = _channel2d_solver()
+    s3.options.horizontal_viscosity = Constant(10.0)
+    with pytest.raises(NotImplementedError):
+        s3.assign_initial_conditions(elev=elev_init)
+    s4, *_ = _channel2d_solver()
+    s4.bnd_functions['shallow_water'] = {1: {'temperature': Constant(1.0)}}
+    with pytest.raises(Exception):
+        s4.assign_initial_conditions(elev=elev_init)

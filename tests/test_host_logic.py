@@ -1,0 +1,120 @@
+"""CPU tests of the host-side mirror of the reference interface: options, functions/projection, meshes, CFL dt."""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import make_oracle
+from thetis_amd import (Constant, Function, ModelOptions2d, PeriodicRectangleMesh, RectangleMesh, get_functionspace)
+
+
+def test_options_defaults_match_reference():
+    o = ModelOptions2d()
+    # thetis/options.py:583-733,866-945
+    assert o.element_family == 'dg-dg' and o.polynomial_degree == 1
+    assert o.use_nonlinear_equations is True and o.use_lax_friedrichs_velocity is True
+    assert float(o.lax_friedrichs_velocity_scaling_factor) == 1.0
+    assert o.timestep == 10.0 and o.simulation_export_time == 100.0 and o.simulation_end_time is None
+    assert float(o.horizontal_velocity_scale) == 0.1 and o.cfl_2d == 1.0
+    assert o.swe_timestepper_type == 'CrankNicolson' and o.use_limiter_for_tracers is True
+    assert o.use_wetting_and_drying is False and float(o.wetting_and_drying_alpha) == 0.5
+    assert o.manning_drag_coefficient is None and o.coriolis_frequency is None
+    assert float(o.norm_smoother) == 0.0 and o.check_volume_conservation_2d is False
+
+
+def test_options_are_frozen_validated_and_paired():
+    o = ModelOptions2d()
+    with pytest.raises(TypeError):
+        o.not_an_option = 1                                # configuration.py:294-331
+    with pytest.raises(AssertionError):
+        o.timestep = -1.0
+    with pytest.raises(ValueError):
+        o.swe_timestepper_type = 'RK4'
+    o.swe_timestepper_type = 'SSPRK33'                     # options.py:838-852 paired options
+    assert o.swe_timestepper_options.use_automatic_timestep is True
+    assert o.swe_timestepper_options.solver_parameters['pc_type'] == 'bjacobi'   # options.py:145-152
+    assert not hasattr(ModelOptions2d().swe_timestepper_options, 'use_automatic_timestep')  # CrankNicolson default
+    o.set_timestepper_type('SSPRK33', use_automatic_timestep=False)
+    assert o.tracer_timestepper_type == 'SSPRK33' and o.swe_timestepper_options.use_automatic_timestep is False
+    o.update({'timestep': 2.0, 'horizontal_velocity_scale': 6.0})
+    assert o.timestep == 2.0 and isinstance(o.horizontal_velocity_scale, Constant)
+    o.add_tracer_2d('tracer_2d', 'Depth averaged tracer', 'Tracer2d')
+    with pytest.raises(AssertionError):
+        o.add_tracer_2d('tracer_2d', 'again', 'Tracer2d')
+
+
+def test_rectangle_mesh_conventions():
+    m = RectangleMesh(80, 3, 100e3, 3750.0)                # examples/channel2d/channel2d.py:21-25
+    assert m.num_cells == 480 and m.num_vertices == 81*4
+    assert m.boundary_markers == [1, 2, 3, 4]
+    assert m.boundary_len == {1: 3750.0, 2: 3750.0, 3: 100e3, 4: 100e3}
+    assert np.all(m.cell_areas() > 0) and math.isclose(m.cell_areas().sum(), 100e3*3750.0)
+    # neighbour symmetry and shared vertices
+    for k in range(m.num_cells):
+        for f in range(3):
+            nb = m.cell_nbr[k, f]
+            if nb >= 0:
+                f2 = m.cell_nbr_facet[k, f]
+                assert m.cell_nbr[nb, f2] == k and m.cell_nbr_facet[nb, f2] == f
+                assert m.cells[k, f] == m.cells[nb, (f2 + 1) % 3] and m.cells[k, (f + 1) % 3] == m.cells[nb, f2]
+    # marker geometry: 1: x=0, 2: x=Lx, 3: y=0, 4: y=Ly
+    c, f = np.nonzero(m.cell_nbr < 0)
+    mid = 0.5*(m.vertex_xy[m.cells[c, f]] + m.vertex_xy[m.cells[c, (f + 1) % 3]])
+    mk = -m.cell_nbr[c, f]
+    assert np.allclose(mid[mk == 1, 0], 0) and np.allclose(mid[mk == 2, 0], 100e3)
+    assert np.allclose(mid[mk == 3, 1], 0) and np.allclose(mid[mk == 4, 1], 3750.0)
+
+
+def test_periodic_mesh_and_renumbering():
+    m = PeriodicRectangleMesh(6, 4, 3.0, 2.0, direction='x')
+    assert m.boundary_markers == [3, 4] and (m.cell_nbr >= 0).sum() == 3*m.num_cells - 2*6
+    perm = np.random.default_rng(0).permutation(m.num_cells)
+    r = m.renumbered(perm)
+    for k in range(r.num_cells):
+        for f in range(3):
+            nb = r.cell_nbr[k, f]
+            if nb >= 0:
+                assert perm[nb] == m.cell_nbr[perm[k], f]
+            else:
+                assert nb == m.cell_nbr[perm[k], f]
+
+
+def test_projection_and_interpolation():
+    m = RectangleMesh(7, 5, 3.0, 2.0)
+    P1 = get_functionspace(m, 'CG', 1)
+    P1DG = get_functionspace(m, 'DG', 1)
+    P1DGv = get_functionspace(m, 'DG', 1, vector=True)
+    lin = lambda x, y: 1.0 + 2.0*x - 3.0*y
+    f = Function(P1DG).project(lin)
+    assert np.allclose(f.dat.data_ro, lin(*P1DG.node_xy().T), atol=1e-13)    # P1 functions are reproduced
+    g = Function(P1).interpolate(lin)
+    h = Function(P1DG).project(g)                                           # CG-P1 -> DG-P1 is injection
+    assert np.allclose(h.dat.data_ro, f.dat.data_ro, atol=1e-13)
+    # non-polynomial: equals the oracle's projection (same rule)
+    orc = make_oracle(m, np.ones(m.num_vertices))
+    fn = lambda x, y: np.cos(x)*np.exp(-y)
+    assert np.allclose(Function(P1DG).project(fn).cell_node_values(), orc.project(fn), atol=1e-14)
+    fv = lambda x, y: (np.sin(x), y*x)
+    assert np.allclose(Function(P1DGv).project(fv).cell_node_values(), orc.project(fv, vector=True), atol=1e-14)
+    assert Function(P1DG).assign(Constant(2.5)).dat.data_ro.min() == 2.5
+
+
+def test_automatic_time_step_formula():
+    """solver2d.py:149-177,213-248 on a uniform mesh: dt = cfl_2d * 0.05 * sqrt(cell area)/(sqrt(g h) + U)."""
+    from thetis_amd import solver2d
+    from thetis_amd.cgproject import elem_size_p1
+    m = RectangleMesh(10, 4, 1000.0, 400.0)
+    bath = Function(get_functionspace(m, 'CG', 1)).assign(20.0)
+    s = solver2d.FlowSolver2d(m, bath)
+    s.options.swe_timestepper_type = 'SSPRK33'
+    s.options.horizontal_velocity_scale = Constant(6.0)
+    s.create_function_spaces()
+    s.create_fields()
+    s.fields.h_elem_size_2d = Function(s.function_spaces.P1_2d).assign(elem_size_p1(m))
+    s.set_time_step()
+    expect = 1.0*0.05*math.sqrt(100.0*100.0/2)/(math.sqrt(9.81*20.0) + 6.0)
+    assert math.isclose(s.dt, expect, rel_tol=1e-12)
+    s.options.swe_timestepper_options.use_automatic_timestep = False
+    s.options.timestep = 2.0
+    s.set_time_step()
+    assert s.dt == 2.0
