@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libswe2d_hip.so')
+LIB_PATH = os.environ.get('THETIS_AMD_LIB') or os.path.join(_HERE, 'libswe2d_hip.so')   # env: kernel A/B experiments
 
 MAX_MARKERS = 16
 BC_ELEV, BC_UV, BC_UN, BC_FLUX = 1, 2, 4, 8

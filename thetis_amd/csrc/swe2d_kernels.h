@@ -24,7 +24,15 @@
 #define SWE_BC_UV 2
 #define SWE_BC_UN 4
 #define SWE_BC_FLUX 8
+#ifndef SWE_BLOCK
 #define SWE_BLOCK 256
+#endif
+#ifndef SWE_MIN_WAVES
+#define SWE_MIN_WAVES 1          // __launch_bounds__ 2nd argument: minimum waves per SIMD
+#endif
+#ifndef SWE_FAST_SQRT
+#define SWE_FAST_SQRT 1          // rsq/rcp + Goldschmidt/Newton without the denormal-range scaling of sqrt()/operator/
+#endif
 
 struct SweBcTable {
     int kind[SWE_MAX_MARKERS];
@@ -66,6 +74,53 @@ __device__ __forceinline__ int swe_logical_block(int b, int nblocks)
 {
     const int per = (nblocks + 7) >> 3;
     return (b & 7)*per + (b >> 3);
+}
+
+// sqrt(x) and 1/sqrt(x) for normal-range x > 0: v_rsq_f64 seed, one Goldschmidt iteration, two residual corrections
+// (the sequence LLVM emits for f64 sqrt, minus its 2^-767 rescaling and class checks).  ~1 ulp.
+__device__ __forceinline__ void swe_sqrt_rsqrt(double x, double &s, double &rs)
+{
+#if SWE_FAST_SQRT
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x*y, h = 0.5*y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d0 = fma(-g, g, x);
+    g = fma(d0, h, g);
+    const double d1 = fma(-g, g, x);
+    g = fma(d1, h, g);
+    s = g;
+    rs = h + h;
+#else
+    s = sqrt(x);
+    rs = 1.0/s;
+#endif
+}
+
+// sqrt(x) for x >= 0 (x == 0 -> 0; x < 0 -> NaN, like sqrt)
+__device__ __forceinline__ double swe_sqrt(double x)
+{
+#if SWE_FAST_SQRT
+    double s, rs;
+    swe_sqrt_rsqrt(x, s, rs);
+    return x == 0.0 ? 0.0 : s;
+#else
+    return sqrt(x);
+#endif
+}
+
+// 1/x for normal-range x: v_rcp_f64 seed + two Newton steps
+__device__ __forceinline__ double swe_rcp(double x)
+{
+#if SWE_FAST_SQRT
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0/x;
+#endif
 }
 
 // 12/A * int a*b dx for P1 a, b
@@ -135,25 +190,170 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
     fe *= L;
 }
 
-template <bool NONLIN, bool LF, bool HASU0, bool SRC>
-__global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel(const SweStageArgs p)
+// Both quadrature points of a boundary facet; kept out of line of the interior fast path (few cells take it).
+template <bool NONLIN, bool LF>
+__device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int marker, double ua, double ub, double va,
+                                                   double vb, double ea, double eb, double ha, double hb, double nxs,
+                                                   double nys, double L, double rL, double &Fau, double &Fbu,
+                                                   double &Fav, double &Fbv, double &Fae, double &Fbe)
 {
+#pragma unroll 1
+    for (int q = 0; q < 2; q++) {
+        const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+        const double uq = xa*ua + xb*ub, vq = xa*va + xb*vb, eq = xa*ea + xb*eb, hq = xa*ha + xb*hb;
+        double fu, fv, fe;
+        swe_boundary_flux<NONLIN, LF>(p, marker, uq, vq, eq, hq, nxs, nys, L, rL, fu, fv, fe);
+        Fau += xa*fu; Fbu += xb*fu;
+        Fav += xa*fv; Fbv += xb*fv;
+        Fae += xa*fe; Fbe += xb*fe;
+    }
+}
+
+// Optional cell-local terms (SRC kernel variant): Coriolis, linear / quadratic / Manning drag, atmospheric pressure
+// gradient, momentum and volume sources.  b-vectors are the assembled integrals (before the mass inverse).
+__device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, size_t S, double twoA, const double u[3],
+                                                 const double v[3], const double H[3], const double gxs[3],
+                                                 const double gys[3], double bu[3], double bv[3], double be[3])
+{
+    const double g = p.g;
+    const double A = 0.5*twoA;
+    const double us = u[0] + u[1] + u[2], vs = v[0] + v[1] + v[2];
+    if (p.coriolis) {                                    // shallowwater_eq.py:632-633
+        double f[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) f[i] = p.coriolis[(size_t)i*S + k];
+        const double fs = f[0] + f[1] + f[2];
+        const double fu_ = f[0]*u[0] + f[1]*u[1] + f[2]*u[2], fv_ = f[0]*v[0] + f[1]*v[1] + f[2]*v[2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            // 60/A int phi_i f w = fs*ws + sum f_a w_a + f_i*ws + w_i*fs + 2 f_i w_i
+            const double tv = fs*vs + fv_ + f[i]*vs + v[i]*fs + 2.0*f[i]*v[i];
+            const double tu = fs*us + fu_ + f[i]*us + u[i]*fs + 2.0*f[i]*u[i];
+            bu[i] += A*(1.0/60.0)*tv;
+            bv[i] -= A*(1.0/60.0)*tu;
+        }
+    }
+    if (p.linear_drag >= 0.0) {                          // shallowwater_eq.py:738
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            bu[i] -= p.linear_drag*A*(1.0/12.0)*(us + u[i]);
+            bv[i] -= p.linear_drag*A*(1.0/12.0)*(vs + v[i]);
+        }
+    }
+    if (p.quad_drag >= 0.0 || p.manning >= 0.0) {        // shallowwater_eq.py:685-700, 6-point degree-4 rule
+        const double a1 = 0.445948490915965, b1 = 0.108103018168070, w1 = 0.223381589678011;
+        const double a2 = 0.091576213509771, b2 = 0.816847572980459, w2 = 0.109951743655322;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const double aa = q < 3 ? a1 : a2, bb = q < 3 ? b1 : b2, ww = q < 3 ? w1 : w2;
+            double l[3] = {aa, aa, aa};
+            l[q % 3] = bb;
+            const double uq = l[0]*u[0] + l[1]*u[1] + l[2]*u[2];
+            const double vq = l[0]*v[0] + l[1]*v[1] + l[2]*v[2];
+            const double Hq = l[0]*H[0] + l[1]*H[1] + l[2]*H[2];
+            const double cd = (p.manning >= 0.0) ? g*p.manning*p.manning/cbrt(Hq) : p.quad_drag;
+            const double s = ww*A*cd*sqrt(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother)/Hq;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                bu[i] -= s*l[i]*uq;
+                bv[i] -= s*l[i]*vq;
+            }
+        }
+    }
+    if (p.patm) {                                        // shallowwater_eq.py:662, rho0 = 1000
+        double gpx = 0.0, gpy = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const double pa = p.patm[(size_t)i*S + k];
+            gpx += gxs[i]*pa;
+            gpy += gys[i]*pa;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            bu[i] -= gpx*(1.0/3000.0);
+            bv[i] -= gpy*(1.0/3000.0);
+        }
+    }
+    if (p.msrc) {                                        // shallowwater_eq.py:810
+        double sx[3], sy[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            sx[i] = p.msrc[(size_t)i*S + k];
+            sy[i] = p.msrc[(size_t)(3 + i)*S + k];
+        }
+        const double ssx = sx[0] + sx[1] + sx[2], ssy = sy[0] + sy[1] + sy[2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            bu[i] += A*(1.0/12.0)*(ssx + sx[i]);
+            bv[i] += A*(1.0/12.0)*(ssy + sy[i]);
+        }
+    }
+    if (p.vsrc) {                                        // shallowwater_eq.py:830
+        double sv_[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) sv_[i] = p.vsrc[(size_t)i*S + k];
+        const double ss = sv_[0] + sv_[1] + sv_[2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) be[i] += A*(1.0/12.0)*(ss + sv_[i]);
+    }
+}
+
+template <bool NONLIN, bool LF, bool HASU0, bool SRC>
+__global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(const SweStageArgs p)
+{
+#ifdef SWE_NO_XCD_MAP
+    const int lb = blockIdx.x;
+#else
     const int lb = swe_logical_block(blockIdx.x, gridDim.x);
+#endif
     const int k = p.cell_begin + lb*SWE_BLOCK + (int)threadIdx.x;
     if (k >= p.cell_end) return;
     const size_t S = p.stride;
     const double g = p.g;
 
-    // ---- own state, connectivity (coalesced) and vertex data (gather)
+    // ---- every load of the cell is issued here, unconditionally, so that a wave pays two memory round trips
+    //      (own data + indices, then the gathers) instead of one per facet and one per output plane.
     double u[3], v[3], e[3];
     int nb[3], vid[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        nb[i] = p.nbr[(size_t)i*S + k];
+        vid[i] = p.cv[(size_t)i*S + k];
+    }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         u[i] = p.uin[(size_t)i*S + k];
         v[i] = p.uin[(size_t)(3 + i)*S + k];
         e[i] = p.uin[(size_t)(6 + i)*S + k];
-        nb[i] = p.nbr[(size_t)i*S + k];
-        vid[i] = p.cv[(size_t)i*S + k];
+    }
+    // w = a0*U0 + a1*U_in, the part of the Shu-Osher combine that does not depend on the tendency
+    double wu[3], wv[3], we[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        wu[i] = p.a1*u[i];
+        wv[i] = p.a1*v[i];
+        we[i] = p.a1*e[i];
+        if (HASU0) {
+            wu[i] += p.a0*p.u0[(size_t)i*S + k];
+            wv[i] += p.a0*p.u0[(size_t)(3 + i)*S + k];
+            we[i] += p.a0*p.u0[(size_t)(6 + i)*S + k];
+        }
+    }
+    // neighbour traces: the neighbour traverses the shared facet backwards, its node (f2+1)%3 sits on my node f and
+    // its node f2 on my node f+1.  Boundary facets read this cell itself (value unused) to keep the loads branch-free.
+    double una[3], unb[3], vna[3], vnb[3], ena[3], enb[3];
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        const int nbf = nb[f];
+        const int kn = nbf >= 0 ? (nbf >> 2) : k;
+        const int f2 = nbf >= 0 ? (nbf & 3) : f;
+        const int na = (f2 == 2) ? 0 : f2 + 1;
+        una[f] = p.uin[(size_t)na*S + kn];
+        unb[f] = p.uin[(size_t)f2*S + kn];
+        vna[f] = p.uin[(size_t)(3 + na)*S + kn];
+        vnb[f] = p.uin[(size_t)(3 + f2)*S + kn];
+        ena[f] = p.uin[(size_t)(6 + na)*S + kn];
+        enb[f] = p.uin[(size_t)(6 + f2)*S + kn];
     }
     double px[3], py[3], h[3], H[3];
 #pragma unroll
@@ -204,88 +404,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel(const SweStageArgs
             }
         }
     }
-    if (SRC) {
-        const double A = 0.5*twoA;
-        const double us = u[0] + u[1] + u[2], vs = v[0] + v[1] + v[2];
-        if (p.coriolis) {                                    // shallowwater_eq.py:632-633
-            double f[3];
-#pragma unroll
-            for (int i = 0; i < 3; i++) f[i] = p.coriolis[(size_t)i*S + k];
-            const double fs = f[0] + f[1] + f[2];
-            const double fu_ = f[0]*u[0] + f[1]*u[1] + f[2]*u[2], fv_ = f[0]*v[0] + f[1]*v[1] + f[2]*v[2];
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                // 60/A int phi_i f w = fs*ws + sum f_a w_a + f_i*ws + w_i*fs + 2 f_i w_i
-                const double tv = fs*vs + fv_ + f[i]*vs + v[i]*fs + 2.0*f[i]*v[i];
-                const double tu = fs*us + fu_ + f[i]*us + u[i]*fs + 2.0*f[i]*u[i];
-                bu[i] += A*(1.0/60.0)*tv;
-                bv[i] -= A*(1.0/60.0)*tu;
-            }
-        }
-        if (p.linear_drag >= 0.0) {                          // shallowwater_eq.py:738
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                bu[i] -= p.linear_drag*A*(1.0/12.0)*(us + u[i]);
-                bv[i] -= p.linear_drag*A*(1.0/12.0)*(vs + v[i]);
-            }
-        }
-        if (p.quad_drag >= 0.0 || p.manning >= 0.0) {        // shallowwater_eq.py:685-700, 6-point degree-4 rule
-            const double a1 = 0.445948490915965, b1 = 0.108103018168070, w1 = 0.223381589678011;
-            const double a2 = 0.091576213509771, b2 = 0.816847572980459, w2 = 0.109951743655322;
-#pragma unroll
-            for (int q = 0; q < 6; q++) {
-                const double aa = q < 3 ? a1 : a2, bb = q < 3 ? b1 : b2, ww = q < 3 ? w1 : w2;
-                double l[3] = {aa, aa, aa};
-                l[q % 3] = bb;
-                const double uq = l[0]*u[0] + l[1]*u[1] + l[2]*u[2];
-                const double vq = l[0]*v[0] + l[1]*v[1] + l[2]*v[2];
-                const double Hq = l[0]*H[0] + l[1]*H[1] + l[2]*H[2];
-                const double cd = (p.manning >= 0.0) ? g*p.manning*p.manning/cbrt(Hq) : p.quad_drag;
-                const double s = ww*A*cd*sqrt(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother)/Hq;
-#pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    bu[i] -= s*l[i]*uq;
-                    bv[i] -= s*l[i]*vq;
-                }
-            }
-        }
-        if (p.patm) {                                        // shallowwater_eq.py:662, rho0 = 1000
-            double gpx = 0.0, gpy = 0.0;
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const double pa = p.patm[(size_t)i*S + k];
-                gpx += gxs[i]*pa;
-                gpy += gys[i]*pa;
-            }
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                bu[i] -= gpx*(1.0/3000.0);
-                bv[i] -= gpy*(1.0/3000.0);
-            }
-        }
-        if (p.msrc) {                                        // shallowwater_eq.py:810
-            double sx[3], sy[3];
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                sx[i] = p.msrc[(size_t)i*S + k];
-                sy[i] = p.msrc[(size_t)(3 + i)*S + k];
-            }
-            const double ssx = sx[0] + sx[1] + sx[2], ssy = sy[0] + sy[1] + sy[2];
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                bu[i] += A*(1.0/12.0)*(ssx + sx[i]);
-                bv[i] += A*(1.0/12.0)*(ssy + sy[i]);
-            }
-        }
-        if (p.vsrc) {                                        // shallowwater_eq.py:830
-            double s[3];
-#pragma unroll
-            for (int i = 0; i < 3; i++) s[i] = p.vsrc[(size_t)i*S + k];
-            const double ss = s[0] + s[1] + s[2];
-#pragma unroll
-            for (int i = 0; i < 3; i++) be[i] += A*(1.0/12.0)*(ss + s[i]);
-        }
-    }
+    if (SRC) swe_source_terms(p, k, S, twoA, u, v, H, gxs, gys, bu, bv, be);
 
     // ---- facet integrals: 2-point Gauss-Legendre, numerical fluxes seen from this cell
 #pragma unroll
@@ -293,26 +412,19 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel(const SweStageArgs
         const int a = f, b = (f + 1) % 3;
         const double nxs = nx[f], nys = ny[f];
         const double len2 = nxs*nxs + nys*nys;
-        const double L = sqrt(len2);
-        const double rL = 1.0/L;
-        const int nbf = nb[f];
+        double L, rL;
+        swe_sqrt_rsqrt(len2, L, rL);
         double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
-        if (nbf >= 0) {
-            // neighbour traverses the shared facet backwards: its node (f2+1)%3 sits on my node a, its node f2 on my b
-            const int kn = nbf >> 2, f2 = nbf & 3;
-            const int na = (f2 == 2) ? 0 : f2 + 1;
-            const double ua_n = p.uin[(size_t)na*S + kn], ub_n = p.uin[(size_t)f2*S + kn];
-            const double va_n = p.uin[(size_t)(3 + na)*S + kn], vb_n = p.uin[(size_t)(3 + f2)*S + kn];
-            const double ea_n = p.uin[(size_t)(6 + na)*S + kn], eb_n = p.uin[(size_t)(6 + f2)*S + kn];
+        if (nb[f] >= 0) {
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
                 const double uq = xa*u[a] + xb*u[b], vq = xa*v[a] + xb*v[b], eq = xa*e[a] + xb*e[b];
                 const double hq = xa*h[a] + xb*h[b];
-                const double un = xa*ua_n + xb*ub_n, vn = xa*va_n + xb*vb_n, en = xa*ea_n + xb*eb_n;
+                const double un = xa*una[f] + xb*unb[f], vn = xa*vna[f] + xb*vnb[f], en = xa*ena[f] + xb*enb[f];
                 const double eav = 0.5*(eq + en);
                 const double Hav = NONLIN ? hq + eav : hq;
-                const double c = sqrt(g*Hav);
+                const double c = swe_sqrt(g*Hav);
                 const double du = uq - un, dv = vq - vn;
                 const double dun = du*nxs + dv*nys;                       // |F| jump(u.n)
                 const double spg = g*eav + c*dun*rL;                      // g*head_star            :363
@@ -335,17 +447,8 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel(const SweStageArgs
                 Fae += xa*fe; Fbe += xb*fe;
             }
         } else {
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
-                const double uq = xa*u[a] + xb*u[b], vq = xa*v[a] + xb*v[b], eq = xa*e[a] + xb*e[b];
-                const double hq = xa*h[a] + xb*h[b];
-                double fu, fv, fe;
-                swe_boundary_flux<NONLIN, LF>(p, -nbf, uq, vq, eq, hq, nxs, nys, L, rL, fu, fv, fe);
-                Fau += xa*fu; Fbu += xb*fu;
-                Fav += xa*fv; Fbv += xb*fv;
-                Fae += xa*fe; Fbe += xb*fe;
-            }
+            swe_boundary_facet<NONLIN, LF>(p, -nb[f], u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], nxs, nys, L, rL,
+                                           Fau, Fbu, Fav, Fbv, Fae, Fbe);
         }
         bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
         bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
@@ -353,23 +456,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel(const SweStageArgs
     }
 
     // ---- mass inverse (M^-1 b)_i = 3/A (4 b_i - sum b), times dt, and the Shu-Osher combine
-    const double s = 6.0*p.dt/twoA;
+    const double s = 6.0*p.dt*p.beta*swe_rcp(twoA);
     const double su = bu[0] + bu[1] + bu[2], sv = bv[0] + bv[1] + bv[2], se = be[0] + be[1] + be[2];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const double ku = s*(4.0*bu[i] - su), kv = s*(4.0*bv[i] - sv), ke = s*(4.0*be[i] - se);
-        double ou = p.beta*ku, ov = p.beta*kv, oe = p.beta*ke;
-        if (HASU0) {
-            ou += p.a0*p.u0[(size_t)i*S + k];
-            ov += p.a0*p.u0[(size_t)(3 + i)*S + k];
-            oe += p.a0*p.u0[(size_t)(6 + i)*S + k];
-        }
-        ou += p.a1*u[i];
-        ov += p.a1*v[i];
-        oe += p.a1*e[i];
-        p.uout[(size_t)i*S + k] = ou;
-        p.uout[(size_t)(3 + i)*S + k] = ov;
-        p.uout[(size_t)(6 + i)*S + k] = oe;
+        p.uout[(size_t)i*S + k] = s*(4.0*bu[i] - su) + wu[i];
+        p.uout[(size_t)(3 + i)*S + k] = s*(4.0*bv[i] - sv) + wv[i];
+        p.uout[(size_t)(6 + i)*S + k] = s*(4.0*be[i] - se) + we[i];
     }
 }
 

@@ -7,7 +7,7 @@ Arrays cross the boundary in the reference's dof layout (cell c owns nodes 3c..3
 import ctypes
 import numpy as np
 
-from . import _lib
+from . import _lib, ordering
 
 __all__ = ['Swe2dDevice']
 
@@ -21,21 +21,61 @@ def _ptr(a):
 class Swe2dDevice(object):
     def __init__(self, mesh, bathymetry_vertex, dt, g_grav=9.81, use_nonlinear_equations=True,
                  use_lax_friedrichs_velocity=True, lax_friedrichs_velocity_scaling_factor=1.0,
-                 device_id=0, n_owned=None, boundary_len=None):
+                 device_id=0, n_owned=None, boundary_len=None, reorder='auto', ranges=None):
         """
         :arg mesh: object with ``cells`` (N,3), ``vertex_xy`` (V,2), ``cell_nbr`` (N,3), ``cell_nbr_facet`` (N,3)
         :arg bathymetry_vertex: (V,) CG-P1 bathymetry at the vertices
+        :kwarg reorder: None | 'auto' | 'hilbert' | explicit cell permutation: device-side cell numbering (callers never see it)
+        :kwarg ranges: cell ranges that a reordering must not mix, e.g. (n_interior, n_owned) of a partition
         """
         self.lib = _lib.load()
         self.n_cells = int(mesh.cells.shape[0])
         self.n_owned = self.n_cells if n_owned is None else int(n_owned)
         c = np.ascontiguousarray
-        self._keep = [c(mesh.cells, dtype=np.int32), c(mesh.vertex_xy, dtype=np.float64),
-                      c(mesh.cell_nbr, dtype=np.int32), c(mesh.cell_nbr_facet, dtype=np.int8),
-                      c(bathymetry_vertex, dtype=np.float64)]
-        cells, xy, nbr, nbf, bath = self._keep
-        if bath.shape != (xy.shape[0],):
+        cells0 = np.asarray(mesh.cells)
+        xy0 = np.asarray(mesh.vertex_xy, dtype=np.float64)
+        nbr0 = np.asarray(mesh.cell_nbr)
+        nbf0 = np.asarray(mesh.cell_nbr_facet)
+        bath0 = np.asarray(bathymetry_vertex, dtype=np.float64)
+        if bath0.shape != (xy0.shape[0],):
             raise ValueError('bathymetry must have one value per vertex')
+        # ---- device numbering: perm[i_dev] = i_caller
+        self.perm = None
+        if reorder is not None:
+            if isinstance(reorder, str):
+                if reorder not in ('hilbert', 'auto'):
+                    raise ValueError('unknown reorder {!r}'.format(reorder))
+                cen = xy0[cells0].mean(axis=1)
+                bounds = [0] + [int(b) for b in (ranges or (self.n_owned,))] + [self.n_cells]
+                bounds = sorted(set(bounds))
+                perm = np.arange(self.n_cells)
+                for a, b in zip(bounds[:-1], bounds[1:]):
+                    if b - a > 1 and a < self.n_owned:          # ghosts keep the order the halo messages deliver
+                        if reorder == 'auto':
+                            perm[a:b] = a + ordering.auto_cell_order(mesh, a, b)
+                        else:
+                            perm[a:b] = a + ordering.hilbert_cell_order(cen[a:b])
+            else:
+                perm = np.asarray(reorder, dtype=np.int64)
+                assert sorted(perm) == list(range(self.n_cells))
+            inv = np.empty_like(perm)
+            inv[perm] = np.arange(self.n_cells)
+            self.perm, self.inv_perm = perm, inv
+            cells0 = cells0[perm]
+            nb = nbr0[perm].astype(np.int64)
+            pos = nb >= 0
+            nb[pos] = inv[nb[pos]]
+            nbr0 = nb
+            nbf0 = nbf0[perm]
+            vperm = ordering.first_touch_vertex_order(cells0)
+            vinv = np.full(xy0.shape[0], -1, dtype=np.int64)
+            vinv[vperm] = np.arange(len(vperm))
+            cells0 = vinv[cells0]
+            xy0 = xy0[vperm]
+            bath0 = bath0[vperm]
+        self._keep = [c(cells0, dtype=np.int32), c(xy0, dtype=np.float64),
+                      c(nbr0, dtype=np.int32), c(nbf0, dtype=np.int8), c(bath0, dtype=np.float64)]
+        cells, xy, nbr, nbf, bath = self._keep
         m = _lib.Swe2dMesh()
         m.n_cells = self.n_cells
         m.n_owned = self.n_owned
@@ -80,14 +120,19 @@ class Swe2dDevice(object):
 
     # -- state
     def set_state(self, uv, eta):
-        uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(self.n_cells, 3, 2)
-        eta = np.ascontiguousarray(eta, dtype=np.float64).reshape(self.n_cells, 3)
+        uv = np.asarray(uv, dtype=np.float64).reshape(self.n_cells, 3, 2)
+        eta = np.asarray(eta, dtype=np.float64).reshape(self.n_cells, 3)
+        if self.perm is not None:
+            uv, eta = uv[self.perm], eta[self.perm]
+        uv, eta = np.ascontiguousarray(uv), np.ascontiguousarray(eta)
         self._ck(self.lib.swe2d_set_state(self.h, _ptr(uv), _ptr(eta)))
 
     def get_state(self):
         uv = np.empty((self.n_cells, 3, 2))
         eta = np.empty((self.n_cells, 3))
         self._ck(self.lib.swe2d_get_state(self.h, _ptr(uv), _ptr(eta)))
+        if self.perm is not None:
+            uv, eta = uv[self.inv_perm], eta[self.inv_perm]
         return uv, eta
 
     def set_dt(self, dt):
@@ -121,7 +166,10 @@ class Swe2dDevice(object):
             self._ck(self.lib.swe2d_set_field(self.h, field, None))
             return
         shape = (self.n_cells, 3, 2) if field == _lib.FIELD_MOMENTUM_SOURCE else (self.n_cells, 3)
-        a = np.ascontiguousarray(np.broadcast_to(np.asarray(nodal, dtype=np.float64), shape))
+        a = np.broadcast_to(np.asarray(nodal, dtype=np.float64), shape)
+        if self.perm is not None:
+            a = a[self.perm]
+        a = np.ascontiguousarray(a)
         self._ck(self.lib.swe2d_set_field(self.h, field, _ptr(a)))
 
     def set_scalar(self, which, value):
@@ -151,6 +199,8 @@ class Swe2dDevice(object):
         ku = np.empty((self.n_cells, 3, 2))
         ke = np.empty((self.n_cells, 3))
         self._ck(self.lib.swe2d_tendency(self.h, _ptr(ku), _ptr(ke)))
+        if self.perm is not None:
+            ku, ke = ku[self.inv_perm], ke[self.inv_perm]
         return ku, ke
 
     def diagnostics(self):
@@ -161,7 +211,10 @@ class Swe2dDevice(object):
 
     # -- multi-GPU plumbing
     def halo_setup(self, send_cells):
-        a = np.ascontiguousarray(send_cells, dtype=np.int32)
+        a = np.asarray(send_cells, dtype=np.int64)
+        if self.perm is not None:
+            a = self.inv_perm[a]
+        a = np.ascontiguousarray(a, dtype=np.int32)
         self._ck(self.lib.swe2d_halo_setup(self.h, a.size, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
 
     def halo_pack(self, i_stage, send_buf_ptr):

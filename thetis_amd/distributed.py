@@ -72,7 +72,7 @@ class DistributedSwe2d(object):
         torch.cuda.set_device(device_id)
         self.torch_device = torch.device('cuda', device_id)
         self.dev = Swe2dDevice(p, np.asarray(bathymetry_vertex)[p.vertex_global], dt, device_id=device_id,
-                               n_owned=p.n_owned, boundary_len=p.boundary_len, **opts)
+                               n_owned=p.n_owned, boundary_len=p.boundary_len, ranges=(p.n_interior, p.n_owned), **opts)
         self.dev.halo_setup(p.send_cells)
         self.dev.set_interior_split(p.n_interior)
         self.halo = HaloExchanger(p, self.torch_device, host_staged=host_staged)

@@ -192,6 +192,7 @@ def RectangleMesh(nx, ny, lx, ly, quadrilateral=False, diagonal='left', name='me
     vertex_xy = np.stack([xx.ravel(), yy.ravel()], axis=1)
     mesh = Mesh2d(vertex_xy, _grid_cells(nx, ny, diagonal), marker_fn=_rect_marker_fn(lx, ly), name=name)
     mesh.nx, mesh.ny, mesh.lx, mesh.ly = nx, ny, float(lx), float(ly)
+    mesh.structured = True              # cell = 2*(j*nx + i) + t: lets the device pick a tiled numbering
     return mesh
 
 
@@ -212,6 +213,7 @@ def PeriodicRectangleMesh(nx, ny, lx, ly, direction='x', quadrilateral=False, di
     mesh = Mesh2d(vertex_xy, _grid_cells(nx, ny, diagonal), topo_vertex=topo,
                   marker_fn=_rect_marker_fn(lx, ly), name=name)
     mesh.nx, mesh.ny, mesh.lx, mesh.ly = nx, ny, float(lx), float(ly)
+    mesh.structured = True
     return mesh
 
 

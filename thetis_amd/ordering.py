@@ -1,0 +1,96 @@
+"""
+Locality ordering of cells and vertices for the device (invisible to callers: ``Swe2dDevice`` permutes on the way in
+and out).  Consecutive cells should be mesh neighbours so that (i) a 256-cell workgroup is a compact patch whose
+facet-neighbour gathers mostly hit lines it loaded itself and (ii) the contiguous eighth of the cell range that every
+XCD works on (swe_logical_block in csrc/swe2d_kernels.h) only shares a thin seam with the other XCDs' L2s.
+Firedrake gives the reference the same service by reordering DMPlex points (reverse Cuthill-McKee) [FD-assumed].
+"""
+import numpy as np
+
+__all__ = ['hilbert_index', 'hilbert_cell_order', 'tile_cell_order', 'structured_tile_order', 'auto_cell_order',
+           'patch_row_order', 'first_touch_vertex_order']
+
+
+def hilbert_index(ix, iy, order):
+    """Hilbert curve index of integer grid points (ix, iy) in [0, 2^order)^2 (vectorised xy -> d)."""
+    ix = ix.astype(np.int64).copy()
+    iy = iy.astype(np.int64).copy()
+    d = np.zeros_like(ix)
+    s = 1 << (order - 1)
+    while s > 0:
+        rx = (ix & s) > 0
+        ry = (iy & s) > 0
+        d += s*s*((3*rx.astype(np.int64)) ^ ry.astype(np.int64))
+        # rotate
+        flip = ~ry & rx
+        ix = np.where(flip, s - 1 - ix, ix)
+        iy = np.where(flip, s - 1 - iy, iy)
+        swap = ~ry
+        ix, iy = np.where(swap, iy, ix), np.where(swap, ix, iy)
+        s >>= 1
+    return d
+
+
+def hilbert_cell_order(cell_centroids, order=16):
+    """Permutation ``perm`` such that new cell i = old cell perm[i], sorted along a Hilbert curve through the centroids."""
+    c = np.asarray(cell_centroids, dtype=np.float64)
+    lo = c.min(axis=0)
+    span = np.maximum(c.max(axis=0) - lo, 1e-300)
+    scale = (2**order - 1)/span.max()               # isotropic: keeps the curve's locality on elongated domains
+    q = np.floor((c - lo)*scale).astype(np.int64)
+    d = hilbert_index(q[:, 0], q[:, 1], order)
+    return np.lexsort((np.arange(len(d)), d))
+
+
+def patch_row_order(cell_centroids, perm, patch=256):
+    """Refine a locality order: inside every block of ``patch`` consecutive cells sort by rows (y band, then x) so that
+    consecutive lanes of a wave walk along mesh rows (their neighbour gathers then coalesce too)."""
+    c = np.asarray(cell_centroids)[perm]
+    n = len(perm)
+    out = perm.copy()
+    for a in range(0, n, patch):
+        b = min(a + patch, n)
+        cc = c[a:b]
+        span = cc.max(axis=0) - cc.min(axis=0)
+        # band height ~ typical cell size: area of the patch / number of cells
+        hcell = np.sqrt(max(span[0]*span[1], 1e-300)/(b - a))*1.4142
+        band = np.floor((cc[:, 1] - cc[:, 1].min())/max(hcell, 1e-300) + 1e-9)
+        out[a:b] = perm[a:b][np.lexsort((cc[:, 0], band))]
+    return out
+
+
+def tile_cell_order(mesh, bx=16, by=8):
+    """Structured meshes (RectangleMesh): order by tiles of bx x by quads, row-major inside a tile."""
+    nx = mesh.nx
+    q = np.arange(mesh.num_cells)//2
+    i, j = q % nx, q//nx
+    return np.lexsort((np.arange(mesh.num_cells), i % bx, j % by, i//bx, j//by))
+
+
+def structured_tile_order(nx, ny, bx=16, by=8):
+    """RectangleMesh numbering (cell = 2*(j*nx + i) + t): tiles of bx x by quads visited along a Hilbert curve over the
+    tile grid, row-major inside a tile - a 256-cell workgroup is one 16 x 8 tile and a wave walks along mesh rows."""
+    n = 2*nx*ny
+    q = np.arange(n)//2
+    i, j = q % nx, q//nx
+    order = max(1, int(np.ceil(np.log2(max(nx//bx + 1, ny//by + 1)))))
+    d = hilbert_index(i//bx, j//by, order)
+    return np.lexsort((np.arange(n), i % bx, j % by, d))
+
+
+def auto_cell_order(mesh, a=0, b=None):
+    """Default device ordering of cells a..b of ``mesh``: structured tiles when the mesh says it is a plain
+    RectangleMesh, a Hilbert curve through the centroids otherwise."""
+    b = mesh.cells.shape[0] if b is None else b
+    if a == 0 and b == mesh.cells.shape[0] and getattr(mesh, 'structured', False):
+        return structured_tile_order(mesh.nx, mesh.ny)
+    cen = np.asarray(mesh.vertex_xy)[np.asarray(mesh.cells)[a:b]].mean(axis=1)
+    return hilbert_cell_order(cen)
+
+
+def first_touch_vertex_order(cells):
+    """Vertex permutation: vertices numbered in the order the (re-ordered) cells first reference them.
+    Returns ``vperm`` with new vertex i = old vertex vperm[i]."""
+    flat = np.asarray(cells).reshape(-1)
+    _, first = np.unique(flat, return_index=True)
+    return flat[np.sort(first)]

@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Kernel A/B harness: times the stage kernels of one libswe2d_hip.so build (THETIS_AMD_LIB) on the bench workload.
+   python tools/kbench.py [--order natural|tile:BX:BY] [--steps K]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def tile_perm(mesh, bx, by):
+    """Cell order by (tile row, tile col, row in tile, col in tile) of bx x by quads."""
+    nx, ny = mesh.nx, mesh.ny
+    q = np.arange(mesh.num_cells)//2
+    i, j = q % nx, q//nx
+    key = np.lexsort((np.arange(mesh.num_cells), i % bx, j % by, i//bx, j//by))
+    return key
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--order', default='natural')
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--tag', default='')
+    args = ap.parse_args()
+    import bench
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = bench.build_case()
+    reorder = None
+    if args.order.startswith('tile'):
+        _, bx, by = args.order.split(':')
+        reorder = tile_perm(mesh, int(bx), int(by))
+    elif args.order == 'hilbert':
+        reorder = 'hilbert'
+    elif args.order == 'hilbert-rows':
+        from thetis_amd import ordering
+        cen = mesh.cell_xy().mean(axis=1)
+        reorder = ordering.patch_row_order(cen, ordering.hilbert_cell_order(cen))
+    elif args.order.startswith('htile'):
+        # tiles of bx x by quads visited along a Hilbert curve over the tile grid, row-major inside a tile
+        from thetis_amd import ordering
+        _, bx, by = args.order.split(':')
+        bx, by = int(bx), int(by)
+        q = np.arange(mesh.num_cells)//2
+        i, j = q % mesh.nx, q//mesh.nx
+        d = ordering.hilbert_index(i//bx, j//by, 12)
+        reorder = np.lexsort((np.arange(mesh.num_cells), i % bx, j % by, d))
+    dev = Swe2dDevice(mesh, bath, bench.DT, reorder=reorder)
+    dev.set_state(uv, eta)
+    dev.advance(5)
+    dev.synchronize()
+    best = 1e9
+    for rep in range(3):
+        ms_tot, _ = dev.advance_timed(args.steps, per_launch=False)
+        best = min(best, ms_tot/args.steps)
+    _, ms_k = dev.advance_timed(args.steps, per_launch=True)
+    d = dev.diagnostics()
+    n = mesh.num_cells
+    print(json.dumps({'tag': args.tag or os.environ.get('THETIS_AMD_LIB', 'default'), 'order': args.order,
+                      'us_per_step': 1e3*best, 'us_per_launch': 1e3*ms_k, 'frac': 684.0*n/(best*1e-3)/8e12,
+                      'vol': d[2]}))
+    dev.close()
+
+
+if __name__ == '__main__':
+    main()
