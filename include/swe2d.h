@@ -148,6 +148,31 @@ int  swe2d_tendency(swe2d_handle *h, double *k_uv, double *k_eta);
  * (sums, not roots, so that partitions can be added). */
 int  swe2d_diagnostics(swe2d_handle *h, double out[4]);
 
+/* ---- 2D tracers (thetis/tracer_eq_2d.py, non-conservative form) and the vertex-based P1DG limiter -----------------
+ * A tracer is a scalar DG-P1 field (3N nodal values, same node layout as eta) advected by the CURRENT shallow-water
+ * velocity of the handle.  Single-device handles only for now. */
+int  swe2d_tracer_add(swe2d_handle *h, int *tracer_id);          /* options.add_tracer_2d (options.py:945-983) */
+/* options.use_lax_friedrichs_tracer, lax_friedrichs_tracer_scaling_factor, tracer_advective_velocity_factor */
+int  swe2d_tracer_set_options(swe2d_handle *h, int use_lax_friedrichs_tracer, double lax_friedrichs_tracer_scaling_factor,
+                              double tracer_advective_velocity_factor);
+int  swe2d_tracer_set_state(swe2d_handle *h, int tracer_id, const double *nodal);
+int  swe2d_tracer_get_state(swe2d_handle *h, int tracer_id, double *nodal);
+/* bnd_functions['tracer_2d'][marker] = {'value': c}; has_value = 0 restores the default boundary term
+ * c (u.n) phi (tracer_eq_2d.py:177-191).  Velocity-type keys are not supported. */
+int  swe2d_tracer_set_bc(swe2d_handle *h, int tracer_id, int marker, int has_value, double value);
+int  swe2d_tracer_set_source(swe2d_handle *h, int tracer_id, const double *nodal);   /* SourceTerm tracer_eq_2d.py:281-298 */
+int  swe2d_tracer_solve_stage(swe2d_handle *h, int tracer_id, int i_stage);          /* rungekutta.py:930-946 for the tracer */
+int  swe2d_tracer_tendency(swe2d_handle *h, int tracer_id, double *k_nodal);         /* parity hook */
+/* VertexBasedP1DGLimiter (thetis/limiter.py:48-198): topology of the mesh vertices (periodic meshes identify them);
+ * optional - defaults to cell_vertices. */
+int  swe2d_limiter_setup(swe2d_handle *h, int32_t n_topo_vertices, const int32_t *cell_topo_vertices);
+int  swe2d_tracer_limit(swe2d_handle *h, int tracer_id);                             /* limiter.apply(field) */
+/* out = { int T*H dx (comp_tracer_mass_2d, utility.py:437-445), int T dx, min nodal T, max nodal T } */
+int  swe2d_tracer_diagnostics(swe2d_handle *h, int tracer_id, double out[4]);
+/* GeneralCoupledTimeIntegrator2D.advance (coupled_timeintegrator_2d.py:93-113) x n_steps: SWE step (unless tracer_only),
+ * then every tracer with the updated velocity, then the limiter (once per step) */
+int  swe2d_advance_coupled(swe2d_handle *h, int n_steps, int tracer_only, int use_limiter);
+
 /* ---- multi-GPU plumbing (one process per GPU; the exchange itself is done by the host with RCCL) ----
  * send_cells: local ids of owned cells whose state peers need, grouped by peer; the n_cells-n_owned ghost cells are
  * stored in the order the peers' send lists deliver them.  Buffers are device pointers owned by the caller

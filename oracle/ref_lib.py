@@ -124,3 +124,65 @@ class RefSWE(object):
 
     def set_num_threads(self, n):
         self.lib.swe2d_ref_set_num_threads(n)
+
+
+class _RefTracerStruct(ctypes.Structure):
+    _fields_ = [('use_lf', ctypes.c_int), ('lf_factor', ctypes.c_double), ('velocity_factor', ctypes.c_double),
+                ('source', _dp), ('n_markers', ctypes.c_int), ('bc_has_value', _ip), ('bc_value', _dp)]
+
+
+class RefTracer(object):
+    """Tracer advection + vertex limiter of the C restatement, on top of a ``RefSWE`` mesh."""
+
+    def __init__(self, ref, use_lax_friedrichs_tracer=False, lax_friedrichs_tracer_scaling_factor=1.0,
+                 tracer_advective_velocity_factor=1.0, source=None, bnd_values=None, cell_topo_vertices=None):
+        self.ref = ref
+        lib = ref.lib
+        lib.swe2d_ref_tracer_tendency.argtypes = [ctypes.POINTER(_RefStruct), ctypes.POINTER(_RefTracerStruct), _dp, _dp,
+                                                  ctypes.c_double, _dp]
+        lib.swe2d_ref_tracer_tendency.restype = None
+        lib.swe2d_ref_tracer_step.argtypes = [ctypes.POINTER(_RefStruct), ctypes.POINTER(_RefTracerStruct), _dp, _dp,
+                                              ctypes.c_double, _dp]
+        lib.swe2d_ref_tracer_step.restype = None
+        lib.swe2d_ref_limit.argtypes = [ctypes.POINTER(_RefStruct), _ip, ctypes.c_int, _dp, _dp, _dp]
+        lib.swe2d_ref_limit.restype = None
+        n = ref.n
+        bnd_values = bnd_values or {}
+        nm = max(list(bnd_values.keys()) + [0]) + 1
+        has = np.zeros(nm, dtype=np.int32)
+        val = np.zeros(nm)
+        for mk, v in bnd_values.items():
+            has[mk] = 1
+            val[mk] = v
+        src = None if source is None else np.ascontiguousarray(np.broadcast_to(source, (n, 3)), dtype=np.float64)
+        self._keep = (has, val, src)
+        t = _RefTracerStruct()
+        t.use_lf = int(use_lax_friedrichs_tracer)
+        t.lf_factor = lax_friedrichs_tracer_scaling_factor
+        t.velocity_factor = tracer_advective_velocity_factor
+        t.source = _ptr(src)
+        t.n_markers = nm
+        t.bc_has_value = _ptr(has, _ip)
+        t.bc_value = _ptr(val)
+        self.t = t
+        self.topo = None if cell_topo_vertices is None else np.ascontiguousarray(cell_topo_vertices, dtype=np.int32)
+
+    def tendency(self, T, uv, dt):
+        T = np.ascontiguousarray(T, dtype=np.float64); uv = np.ascontiguousarray(uv, dtype=np.float64)
+        k = np.empty_like(T)
+        self.ref.lib.swe2d_ref_tracer_tendency(ctypes.byref(self.ref.s), ctypes.byref(self.t), _ptr(T), _ptr(uv), dt, _ptr(k))
+        return k
+
+    def step(self, T, uv, dt):
+        T = np.array(T, dtype=np.float64, order='C'); uv = np.ascontiguousarray(uv, dtype=np.float64)
+        work = np.empty(6*self.ref.n)
+        self.ref.lib.swe2d_ref_tracer_step(ctypes.byref(self.ref.s), ctypes.byref(self.t), _ptr(T), _ptr(uv), dt, _ptr(work))
+        return T
+
+    def limit(self, T):
+        assert self.topo is not None, 'cell_topo_vertices required for the limiter'
+        T = np.array(T, dtype=np.float64, order='C')
+        nv = int(self.topo.max()) + 1
+        qmin = np.empty(nv); qmax = np.empty(nv)
+        self.ref.lib.swe2d_ref_limit(ctypes.byref(self.ref.s), _ptr(self.topo, _ip), nv, _ptr(T), _ptr(qmin), _ptr(qmax))
+        return T

@@ -328,3 +328,148 @@ void swe2d_ref_set_num_threads(int n)
     (void)n;
 #endif
 }
+
+/* ===================================================================================================================
+ * 2D tracer (non-conservative form) and the vertex-based P1DG limiter.
+ *   tracer_eq_2d.HorizontalAdvectionTerm  thetis/tracer_eq_2d.py:147-193   SourceTerm :281-298
+ *   VertexBasedP1DGLimiter               thetis/limiter.py:48-198 (+ firedrake.VertexBasedLimiter [FD-assumed])
+ * Closed walls / boundaries without a tracer BC use  f += c (u.n) phi  (:189-191); boundaries with a 'value' use the
+ * upwind blend between c and value with the interior velocity (:181-188, no 'uv'/'un'/'flux' given).
+ * =================================================================================================================== */
+typedef struct {
+    int use_lf;                /* use_lax_friedrichs_tracer                                */
+    double lf_factor;          /* lax_friedrichs_tracer_scaling_factor                     */
+    double velocity_factor;    /* tracer_advective_velocity_factor                         */
+    const double *source;      /* [N][3] or NULL                                           */
+    int n_markers;
+    const int *bc_has_value;   /* per marker: 1 if a 'value' boundary condition is set     */
+    const double *bc_value;    /* per marker                                               */
+} swe2d_ref_tracer_t;
+
+static void cell_tracer_tendency(const swe2d_ref_t *m, const swe2d_ref_tracer_t *tp, int k, const double *T,
+                                 const double *uv, double dt, double *kT)
+{
+    const double *p = m->xy + 6*(size_t)k;
+    const double cf = tp->velocity_factor;
+    double u[3], v[3], c[3];
+    for (int i = 0; i < 3; i++) {
+        u[i] = cf*uv[6*(size_t)k + 2*i];
+        v[i] = cf*uv[6*(size_t)k + 2*i + 1];
+        c[i] = T[3*(size_t)k + i];
+    }
+    const double A = 0.5*((p[2] - p[0])*(p[5] - p[1]) - (p[4] - p[0])*(p[3] - p[1]));
+    double gx[3], gy[3];
+    for (int i = 0; i < 3; i++) {
+        int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+        gx[i] = (p[2*i1 + 1] - p[2*i2 + 1])/(2*A);
+        gy[i] = (p[2*i2] - p[2*i1])/(2*A);
+    }
+    double b[3] = {0, 0, 0};
+    /* cell: +(phi div u + u.grad phi) c */
+    double divu = 0;
+    for (int i = 0; i < 3; i++) divu += gx[i]*u[i] + gy[i]*v[i];
+    const double Iuc = int2(A, u, c), Ivc = int2(A, v, c);
+    const double csum = c[0] + c[1] + c[2];
+    for (int i = 0; i < 3; i++) b[i] += divu*A/12.0*(csum + c[i]) + gx[i]*Iuc + gy[i]*Ivc;
+    if (tp->source) {
+        const double *s = tp->source + 3*(size_t)k;
+        double ss = s[0] + s[1] + s[2];
+        for (int i = 0; i < 3; i++) b[i] += A/12.0*(ss + s[i]);
+    }
+    for (int f = 0; f < 3; f++) {
+        const int a = f, bb = (f + 1) % 3;
+        const double dx = p[2*bb] - p[2*a], dy = p[2*bb + 1] - p[2*a + 1];
+        const double len = sqrt(dx*dx + dy*dy);
+        const double nx = dy/len, ny = -dx/len;
+        const int nb = m->nbr[3*(size_t)k + f];
+        double ua_n = 0, ub_n = 0, va_n = 0, vb_n = 0, ca_n = 0, cb_n = 0;
+        if (nb >= 0) {
+            const int f2 = m->nbf[3*(size_t)k + f];
+            const int na = (f2 + 1) % 3, nbb = f2;
+            ua_n = cf*uv[6*(size_t)nb + 2*na];  va_n = cf*uv[6*(size_t)nb + 2*na + 1];  ca_n = T[3*(size_t)nb + na];
+            ub_n = cf*uv[6*(size_t)nb + 2*nbb]; vb_n = cf*uv[6*(size_t)nb + 2*nbb + 1]; cb_n = T[3*(size_t)nb + nbb];
+        }
+        for (int q = 0; q < 2; q++) {
+            const double xb = GL_XI[q], xa = 1.0 - xb, w = 0.5*len;
+            const double uq = xa*u[a] + xb*u[bb], vq = xa*v[a] + xb*v[bb], cq = xa*c[a] + xb*c[bb];
+            const double un_own = uq*nx + vq*ny;
+            double fq;
+            if (nb >= 0) {
+                const double un_ = xa*ua_n + xb*ub_n, vn_ = xa*va_n + xb*vb_n, cn_ = xa*ca_n + xb*cb_n;
+                const double un_av = 0.5*((uq + un_)*nx + (vq + vn_)*ny);      /* seen from this cell */
+                const double c_up = un_av > 0 ? cq : (un_av < 0 ? cn_ : 0.5*(cq + cn_));
+                fq = c_up*un_own;
+                if (tp->use_lf) fq += 0.5*fabs(un_av)*tp->lf_factor*(cq - cn_);
+            } else {
+                const int marker = -nb;
+                if (tp->bc_has_value && marker < tp->n_markers && tp->bc_has_value[marker]) {
+                    const double c_up = un_own > 0 ? cq : (un_own < 0 ? tp->bc_value[marker] : 0.5*(cq + tp->bc_value[marker]));
+                    fq = c_up*un_own;
+                } else {
+                    fq = cq*un_own;
+                }
+            }
+            b[a] -= w*xa*fq; b[bb] -= w*xb*fq;
+        }
+    }
+    const double s = 3.0*dt/A, sb = b[0] + b[1] + b[2];
+    for (int i = 0; i < 3; i++) kT[3*(size_t)k + i] = s*(4.0*b[i] - sb);
+}
+
+void swe2d_ref_tracer_tendency(const swe2d_ref_t *m, const swe2d_ref_tracer_t *tp, const double *T, const double *uv,
+                               double dt, double *kT)
+{
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < m->n_cells; k++) cell_tracer_tendency(m, tp, k, T, uv, dt, kT);
+}
+
+/* one tracer SSPRK33 step with frozen velocity; work holds 2*3*N doubles */
+void swe2d_ref_tracer_step(const swe2d_ref_t *m, const swe2d_ref_tracer_t *tp, double *T, const double *uv, double dt,
+                           double *work)
+{
+    const size_t n = 3*(size_t)m->n_cells;
+    double *T0 = work, *kT = work + n;
+    static const double A30 = 0.33333333333333337, A32 = 0.6666666666666666, B32 = 0.6666666666666666;
+    memcpy(T0, T, n*sizeof(double));
+    swe2d_ref_tracer_tendency(m, tp, T, uv, dt, kT);
+    for (size_t i = 0; i < n; i++) T[i] = kT[i]*1.0 + T0[i]*1.0;
+    swe2d_ref_tracer_tendency(m, tp, T, uv, dt, kT);
+    for (size_t i = 0; i < n; i++) T[i] = kT[i]*0.25 + T0[i]*0.75 + T[i]*0.25;
+    swe2d_ref_tracer_tendency(m, tp, T, uv, dt, kT);
+    for (size_t i = 0; i < n; i++) T[i] = kT[i]*B32 + T0[i]*A30 + T[i]*A32;
+}
+
+/* vertex-based limiter; cell_vertex = [N][3] topological vertex ids, qmin/qmax = work arrays of n_vertices */
+void swe2d_ref_limit(const swe2d_ref_t *m, const int *cell_vertex, int n_vertices, double *T, double *qmin, double *qmax)
+{
+    const int n = m->n_cells;
+    for (int v = 0; v < n_vertices; v++) { qmax[v] = -1.0e10; qmin[v] = 1.0e10; }
+    for (int k = 0; k < n; k++) {
+        const double *c = T + 3*(size_t)k;
+        const double mean = (c[0] + c[1] + c[2])/3.0;
+        for (int i = 0; i < 3; i++) {
+            const int v = cell_vertex[3*(size_t)k + i];
+            qmax[v] = fmax(qmax[v], mean); qmin[v] = fmin(qmin[v], mean);
+        }
+    }
+    for (int k = 0; k < n; k++)
+        for (int f = 0; f < 3; f++)
+            if (m->nbr[3*(size_t)k + f] < 0) {
+                const int a = f, b = (f + 1) % 3;
+                const double fm = (T[3*(size_t)k + a] + T[3*(size_t)k + b])/2.0;
+                const int va = cell_vertex[3*(size_t)k + a], vb = cell_vertex[3*(size_t)k + b];
+                qmax[va] = fmax(qmax[va], fm); qmin[va] = fmin(qmin[va], fm);
+                qmax[vb] = fmax(qmax[vb], fm); qmin[vb] = fmin(qmin[vb], fm);
+            }
+    for (int k = 0; k < n; k++) {
+        double *c = T + 3*(size_t)k;
+        const double mean = (c[0] + c[1] + c[2])/3.0;
+        double alpha = 1.0;
+        for (int i = 0; i < 3; i++) {
+            const int v = cell_vertex[3*(size_t)k + i];
+            if (c[i] > mean) alpha = fmin(alpha, fmin(1.0, (qmax[v] - mean)/(c[i] - mean)));
+            else if (c[i] < mean) alpha = fmin(alpha, fmin(1.0, (mean - qmin[v])/(mean - c[i])));
+        }
+        for (int i = 0; i < 3; i++) c[i] = mean + alpha*(c[i] - mean);
+    }
+}

@@ -1,0 +1,174 @@
+"""GPU: tracer stage kernel, limiter kernels and the coupled step against the oracle; test_consistency_2d scenario."""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import channel_case, make_oracle, make_ref, rel_linf
+from thetis_amd import Constant, Function, PeriodicRectangleMesh, RectangleMesh, UnitSquareMesh, get_functionspace, solver2d
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def _dev(mesh, bath, dt, **kw):
+    from thetis_amd.device import Swe2dDevice
+    return Swe2dDevice(mesh, bath, dt, **kw)
+
+
+@pytest.mark.parametrize('case', ['default', 'lf', 'value_bc'])
+def test_tracer_tendency_and_step_match_oracle(hip_lib, case):
+    mesh, bath, uv, eta = channel_case(seed=6)
+    rng = np.random.default_rng(3)
+    T = rng.normal(size=(mesh.num_cells, 3))
+    src = 1e-3*rng.normal(size=T.shape)
+    dt = 3.0
+    orc = make_oracle(mesh, bath)
+    dev = _dev(mesh, bath, dt)
+    tid = dev.add_tracer()
+    kw = {}
+    if case == 'lf':
+        kw = dict(use_lax_friedrichs_tracer=True, lax_friedrichs_tracer_scaling_factor=0.7,
+                  tracer_advective_velocity_factor=0.9, source=src)
+        dev.tracer_set_options(True, 0.7, 0.9)
+        dev.tracer_set_source(tid, src)
+    if case == 'value_bc':
+        kw = dict(bnd_conditions={1: {'value': 2.0}, 3: {'value': -1.0}})
+        dev.tracer_set_bc(tid, 1, 2.0)
+        dev.tracer_set_bc(tid, 3, -1.0)
+    dev.set_state(uv, eta)
+    dev.tracer_set_state(tid, T)
+    assert np.array_equal(dev.tracer_get_state(tid), T)
+    assert rel_linf(dev.tracer_tendency(tid), orc.tracer_tendency(T, uv, eta, dt, **kw)) < TOL
+    for s in range(3):
+        dev.tracer_solve_stage(tid, s)
+    assert rel_linf(dev.tracer_get_state(tid), orc.tracer_ssprk33_step(T, uv, eta, dt, **kw)) < TOL
+    # tracer mass / integral / min / max
+    d = dev.tracer_diagnostics(tid)
+    T1 = dev.tracer_get_state(tid)
+    assert math.isclose(d[0], orc.tracer_mass(T1, eta), rel_tol=1e-12)
+    assert math.isclose(d[1], float(np.sum(orc.area[:, None]/3*T1)), rel_tol=1e-12, abs_tol=1e-6)
+    assert d[2] == T1.min() and d[3] == T1.max()
+    dev.close()
+
+
+def test_limiter_matches_oracle(hip_lib):
+    # device code contracts mean + alpha*(c - mean) into an FMA: equal to the oracle to round-off, not bitwise
+    mesh, bath, uv, eta = channel_case(seed=4)
+    T = np.random.default_rng(0).normal(size=(mesh.num_cells, 3))
+    dev = _dev(mesh, bath, 1.0)
+    tid = dev.add_tracer()
+    dev.tracer_set_state(tid, T)
+    dev.tracer_limit(tid)
+    assert rel_linf(dev.tracer_get_state(tid), make_oracle(mesh, bath).limit(T)) < 1e-14
+    dev.close()
+    # periodic mesh: identified vertices
+    pm = PeriodicRectangleMesh(6, 4, 3.0, 2.0, direction='x')
+    from oracle.swe2d_oracle import SWEOracle
+    orc = SWEOracle(pm.vertex_xy, pm.cells, np.ones(pm.num_vertices), topo_vertex=pm.topo_vertex)
+    T = np.random.default_rng(1).normal(size=(pm.num_cells, 3))
+    dev = _dev(pm, np.ones(pm.num_vertices), 1.0)
+    tid = dev.add_tracer()
+    dev.tracer_set_state(tid, T)
+    dev.tracer_limit(tid)
+    assert rel_linf(dev.tracer_get_state(tid), orc.limit(T, topo_cells=pm.topo_vertex[pm.cells])) < 1e-14
+    dev.close()
+
+
+def test_limiter_class_reference_criteria(hip_lib):
+    """test/slopelimiter/test_slopelimiter.py:50-57 through the VertexBasedP1DGLimiter class."""
+    from thetis_amd.limiter import VertexBasedP1DGLimiter
+    mesh2d = UnitSquareMesh(5, 5)
+    p1dg = get_functionspace(mesh2d, 'DP' if False else 'DG', 1)
+    area = mesh2d.cell_areas()
+    for ax in (0, 1):
+        orig = Function(p1dg).project(lambda x, y: (x, y)[ax])
+        tracer = Function(p1dg).project(orig)
+        VertexBasedP1DGLimiter(p1dg).apply(tracer)
+        assert np.abs(tracer.dat.data_ro - orig.dat.data_ro).max() < 1e-12
+        orig = Function(p1dg).project(lambda x, y: 0.5 + 0.5*np.tanh(20*((x, y)[ax] - 0.5)))
+        tracer = Function(p1dg).project(orig)
+        VertexBasedP1DGLimiter(p1dg).apply(tracer)
+        mass = lambda f: float(np.sum(area[:, None]/3*f.cell_node_values()))
+        assert abs(mass(tracer) - mass(orig)) < 1e-12
+        assert tracer.dat.data_ro.min() > -2e-5
+
+
+def test_coupled_steps_match_cpu_restatement(hip_lib, ref_so):
+    """SWE step -> tracer step with the updated velocity -> limiter, 20 times (coupled_timeintegrator_2d.py:93-113)."""
+    from oracle.ref_lib import RefTracer
+    mesh, bath, uv, eta = channel_case(nx=24, ny=10, seed=8, amp_eta=0.2, amp_u=0.1)
+    cxy = mesh.cell_xy()
+    T = np.where(cxy[:, :, 0] < 40e3, 0.0, 30.0) + 0.0
+    dt = 20.0
+    ref = make_ref(mesh, bath)
+    rt = RefTracer(ref, cell_topo_vertices=mesh.topo_vertex[mesh.cells])
+    dev = _dev(mesh, bath, dt)
+    tid = dev.add_tracer()
+    dev.set_state(uv, eta)
+    dev.tracer_set_state(tid, T)
+    dev.advance_coupled(20, tracer_only=False, use_limiter=True)
+    u_r, e_r, T_r = uv, eta, T
+    for _ in range(20):
+        u_r, e_r = ref.advance(u_r, e_r, dt, 1)
+        T_r = rt.limit(rt.step(T_r, u_r, dt))
+    u_d, e_d = dev.get_state()
+    assert rel_linf(u_d, u_r) < 1e-11 and rel_linf(e_d, e_r) < 1e-11
+    assert rel_linf(dev.tracer_get_state(tid), T_r) < 1e-10
+    dev.close()
+
+
+def _consistency_solver(constant_c):
+    # test/tracerEq/test_consistency_2d.py:17-110 with timestepper_type='SSPRK33'
+    t_cycle, depth = 2000.0, 50.0
+    lx = math.sqrt(9.81*depth)*t_cycle
+    ly, nx, ny = 3000.0, 18, 2
+    mesh2d = RectangleMesh(nx, ny, lx, ly)
+    p1_2d = get_functionspace(mesh2d, 'CG', 1)
+    bathymetry_2d = Function(p1_2d, name='Bathymetry')
+    bathymetry_2d.interpolate(lambda x, y: depth + depth/10.*np.sin(x/lx*np.pi))
+    solver_obj = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+    options = solver_obj.options
+    options.use_limiter_for_tracers = not constant_c
+    options.use_nonlinear_equations = True
+    options.add_tracer_2d('tracer_2d', 'Depth averaged tracer', 'Tracer2d', use_conservative_form=False)
+    options.simulation_export_time = round(float(t_cycle/8))
+    options.simulation_end_time = 2.5*t_cycle
+    options.horizontal_velocity_scale = Constant(1.0)
+    options.check_volume_conservation_2d = True
+    options.check_tracer_conservation = True
+    options.check_tracer_overshoot = True
+    options.set_timestepper_type('SSPRK33')
+    options.no_exports = True
+    solver_obj.create_function_spaces()
+    elev_init = Function(solver_obj.function_spaces.H_2d)
+    elev_init.project(lambda x, y: -2.0*np.cos(2*np.pi*x/lx))
+    tracer_init2d = Function(solver_obj.function_spaces.Q_2d, name='initial tracer')
+    if constant_c:
+        tracer_init2d.assign(4.5)
+    else:
+        tracer_init2d.interpolate(lambda x, y: 0.0 + (30.0 - 0.0)*0.5*(1.0 + np.sign(x - lx/4)))
+    solver_obj.assign_initial_conditions(elev=elev_init, tracer=tracer_init2d)
+    return solver_obj
+
+
+@pytest.mark.parametrize('constant_c', [True, False])
+def test_reference_tracer_consistency_scenario(hip_lib, constant_c):
+    solver_obj = _consistency_solver(constant_c)
+    t_end = solver_obj.options.simulation_end_time
+    it = solver_obj.create_iterator()
+    while True:
+        try:
+            t = next(it)
+        except StopIteration as e:
+            t = e.value
+            break
+    assert t >= t_end - 1e-5
+    vol2d, vol2d_rerr = solver_obj.callbacks['export']['volume2d']()
+    assert vol2d_rerr < 1e-10, '2D volume is not conserved'
+    tracer_int, tracer_int_rerr = solver_obj.callbacks['export']['tracer_2d mass']()
+    assert abs(tracer_int_rerr) < 1.2e-4, 'tracer is not conserved'
+    smin, smax, undershoot, overshoot = solver_obj.callbacks['export']['tracer_2d overshoot']()
+    assert max(abs(undershoot), abs(overshoot)) < 1e-11
+    if constant_c:
+        assert np.abs(solver_obj.fields.tracer_2d.dat.data_ro - 4.5).max() < 1e-11

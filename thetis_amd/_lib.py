@@ -57,6 +57,18 @@ SYMBOLS = {
     'swe2d_synchronize': (ctypes.c_int, [_H]),
     'swe2d_tendency': (ctypes.c_int, [_H, _dp, _dp]),
     'swe2d_diagnostics': (ctypes.c_int, [_H, _dp]),
+    'swe2d_tracer_add': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int)]),
+    'swe2d_tracer_set_options': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_double, ctypes.c_double]),
+    'swe2d_tracer_set_state': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
+    'swe2d_tracer_get_state': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
+    'swe2d_tracer_set_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
+    'swe2d_tracer_set_source': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
+    'swe2d_tracer_solve_stage': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int]),
+    'swe2d_tracer_tendency': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
+    'swe2d_limiter_setup': (ctypes.c_int, [_H, ctypes.c_int32, _ip]),
+    'swe2d_tracer_limit': (ctypes.c_int, [_H, ctypes.c_int]),
+    'swe2d_tracer_diagnostics': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
+    'swe2d_advance_coupled': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'swe2d_halo_setup': (ctypes.c_int, [_H, ctypes.c_int32, _ip]),
     'swe2d_halo_pack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_void_p]),
     'swe2d_halo_unpack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_void_p]),

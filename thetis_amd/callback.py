@@ -11,7 +11,8 @@ import numpy
 
 from .log import print_output
 
-__all__ = ['CallbackManager', 'DiagnosticCallback', 'ScalarConservationCallback', 'VolumeConservation2DCallback']
+__all__ = ['CallbackManager', 'DiagnosticCallback', 'ScalarConservationCallback', 'VolumeConservation2DCallback',
+           'TracerMassConservation2DCallback', 'MinMaxConservationCallback', 'TracerOvershootCallBack']
 
 
 class CallbackManager(defaultdict):
@@ -90,3 +91,53 @@ class VolumeConservation2DCallback(ScalarConservationCallback):
         def vol2d():
             return float(self.solver_obj.timestepper.diagnostics()[2])
         super(VolumeConservation2DCallback, self).__init__(vol2d, solver_obj, **kwargs)
+
+
+class TracerMassConservation2DCallback(ScalarConservationCallback):
+    """Checks conservation of depth-averaged tracer mass = int T*H dx (callback.py:366-389), reduced on the device."""
+    name = 'tracer mass'
+
+    def __init__(self, tracer_name, solver_obj, **kwargs):
+        self.name = tracer_name + ' mass'
+
+        def mass():
+            ts = solver_obj.timestepper.tracers[tracer_name]
+            ts._sync_to_device()
+            return float(ts.device.tracer_diagnostics(ts.tid)[0])
+        super(TracerMassConservation2DCallback, self).__init__(mass, solver_obj, **kwargs)
+
+
+class MinMaxConservationCallback(DiagnosticCallback):
+    """Base class for callbacks that check conservation of a minimum/maximum (callback.py:433-460)"""
+    variable_names = ['min_value', 'max_value', 'undershoot', 'overshoot']
+
+    def __init__(self, minmax_callback, solver_obj, **kwargs):
+        super(MinMaxConservationCallback, self).__init__(solver_obj, **kwargs)
+        self.minmax_callback = minmax_callback
+        self.initial_value = None
+
+    def __call__(self):
+        value = self.minmax_callback()
+        if self.initial_value is None:
+            self.initial_value = value
+        overshoot = max(value[1] - self.initial_value[1], 0.0)
+        undershoot = min(value[0] - self.initial_value[0], 0.0)
+        return value[0], value[1], undershoot, overshoot
+
+    def message_str(self, *args):
+        return '{0:s} {1:g} {2:g}'.format(self.name, args[2], args[3])
+
+
+class TracerOvershootCallBack(MinMaxConservationCallback):
+    """Checks overshoots of the given tracer field (callback.py:463-483): nodal min/max, reduced on the device."""
+    name = 'tracer overshoot'
+
+    def __init__(self, tracer_name, solver_obj, **kwargs):
+        self.name = tracer_name + ' overshoot'
+
+        def minmax():
+            ts = solver_obj.timestepper.tracers[tracer_name]
+            ts._sync_to_device()
+            d = ts.device.tracer_diagnostics(ts.tid)
+            return float(d[2]), float(d[3])
+        super(TracerOvershootCallBack, self).__init__(minmax, solver_obj, **kwargs)

@@ -1,0 +1,129 @@
+"""
+Coupled 2D time integrator: shallow water step, then every tracer with the UPDATED velocity, then the limiter once per
+time step (thetis/coupled_timeintegrator_2d.py:93-113).  All of it stays on the device: the tracers are extra DG-P1
+fields of the same C-ABI handle that steps the shallow water equations.
+"""
+import numpy as np
+
+from .log import print_output
+from .options import Constant
+from .timeintegrator import TimeIntegratorBase
+
+__all__ = ['DeviceTracerSSPRK33', 'GeneralCoupledTimeIntegrator2D']
+
+
+def _cval(v):
+    return None if v is None else float(v)
+
+
+class DeviceTracerSSPRK33(object):
+    """SSPRK33 of one tracer equation on the device handle of the shallow water stepper (rungekutta.py:870-952)."""
+    n_stages = 3
+    c = (0.0, 1.0, 0.5)
+
+    def __init__(self, equation, solution, fields, dt, options, bnd_conditions, swe_stepper):
+        equation.check_bnd_conditions(bnd_conditions)
+        self.equation, self.solution, self.fields, self.dt = equation, solution, fields, dt
+        self.bnd_conditions = bnd_conditions or {}
+        self.swe = swe_stepper
+        self.device = swe_stepper.device
+        self.tid = self.device.add_tracer()
+        self._uploaded = None
+        self._device_ahead = False
+        self.solution._pull_hook = self._pull
+        src = fields.get('source-{:}'.format(equation.label))
+        if src is not None:
+            self.device.tracer_set_source(self.tid, swe_stepper._nodal(src))
+        self._push_bcs()
+
+    def _push_bcs(self):
+        for marker in self.equation.mesh.boundary_markers:
+            funcs = self.bnd_conditions.get(marker)
+            v = None if funcs is None else funcs.get('value')
+            self.device.tracer_set_bc(self.tid, marker, _cval(v))
+
+    def _pull(self):
+        if self._device_ahead:
+            self.solution._data[...] = self.device.tracer_get_state(self.tid).reshape(self.solution._data.shape)
+            self._device_ahead = False
+
+    def _sync_to_device(self):
+        if self._uploaded != self.solution._host_version:
+            self._pull()
+            self.device.tracer_set_state(self.tid, self.solution._data.reshape(-1, 3))
+            self._uploaded = self.solution._host_version
+            self._device_ahead = False
+
+    def initialize(self, solution):
+        self._uploaded = None
+        self._sync_to_device()
+
+    def set_dt(self, dt):
+        self.dt = dt            # the handle's dt is set by the shallow water stepper
+
+    def solve_stage(self, i_stage, t, update_forcings=None):
+        if update_forcings is not None:
+            update_forcings(t + self.c[i_stage]*self.dt)
+            self._push_bcs()
+        if i_stage == 0:
+            self._sync_to_device()
+        self.device.tracer_solve_stage(self.tid, i_stage)
+        self._device_ahead = True
+
+    def advance(self, t, update_forcings=None):
+        for i in range(self.n_stages):
+            self.solve_stage(i, t, update_forcings)
+
+
+class GeneralCoupledTimeIntegrator2D(TimeIntegratorBase):
+    def __init__(self, solver, swe_stepper, tracer_steppers):
+        self.solver = solver
+        self.options = solver.options
+        self.fields = solver.fields
+        self.timesteppers = {'swe2d': swe_stepper}
+        self.timesteppers.update(tracer_steppers)
+        self.swe = swe_stepper
+        self.tracers = tracer_steppers
+        self.device = swe_stepper.device
+        print_output('Coupled time integrator: {:}'.format(self.__class__.__name__))
+        if not self.options.tracer_only:
+            print_output('  Shallow Water time integrator: {:}'.format(swe_stepper.__class__.__name__))
+        print_output('  Tracer time integrator: SSPRK33')
+        o = self.options
+        self.device.tracer_set_options(o.use_lax_friedrichs_tracer, float(o.lax_friedrichs_tracer_scaling_factor),
+                                       float(o.tracer_advective_velocity_factor)
+                                       if isinstance(o.tracer_advective_velocity_factor, (int, float, Constant)) else 1.0)
+
+    def set_dt(self, dt):
+        for stepper in sorted(self.timesteppers):
+            self.timesteppers[stepper].set_dt(dt)
+
+    def initialize(self, solution2d):
+        assert solution2d == self.fields.solution_2d
+        self.swe.initialize(self.fields.solution_2d)
+        for label, ts in self.tracers.items():
+            ts.initialize(self.fields[label])
+
+    def advance(self, t, update_forcings=None):
+        """coupled_timeintegrator_2d.py:93-113"""
+        use_limiter = self.options.use_limiter_for_tracers and self.options.polynomial_degree > 0
+        if update_forcings is None:
+            self.swe._sync_to_device()
+            for ts in self.tracers.values():
+                ts._sync_to_device()
+            self.device.advance_coupled(1, tracer_only=self.options.tracer_only, use_limiter=use_limiter)
+            self.swe._device_ahead = True
+            for ts in self.tracers.values():
+                ts._device_ahead = True
+            return
+        if not self.options.tracer_only:
+            self.swe.advance(t, update_forcings=update_forcings)
+        else:
+            self.swe._sync_to_device()
+        for label, ts in self.tracers.items():
+            ts.advance(t, update_forcings=update_forcings)
+            if use_limiter:
+                self.device.tracer_limit(ts.tid)
+
+    def diagnostics(self):
+        return self.swe.diagnostics()

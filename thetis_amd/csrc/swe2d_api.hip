@@ -3,6 +3,7 @@
 #include "../../include/swe2d.h"
 #include "swe2d_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -40,6 +41,21 @@ struct Handle {
     int n_partial_blocks = 0;
     int *send_cells = nullptr;
     int n_send = 0;
+    // tracers + limiter
+    struct Tracer {
+        double *buf[3] = {nullptr, nullptr, nullptr};   // A (T0 / result), B, C: 3 planes each
+        double *source = nullptr;
+        int bc_has_value[SWE_MAX_MARKERS];
+        double bc_value[SWE_MAX_MARKERS];
+    };
+    std::vector<Tracer> tracers;
+    int tracer_use_lf = 0;
+    double tracer_lf_factor = 1.0, tracer_vel_factor = 1.0;
+    std::vector<int> host_cells;                 // [n][3] vertex ids as given (limiter default topology)
+    std::vector<int> host_nbr;                   // [n][3]
+    int lim_nv = 0;
+    int *lim_v2c_off = nullptr, *lim_v2c_cell = nullptr, *lim_vbf_off = nullptr, *lim_vbf_facet = nullptr, *lim_tv = nullptr;
+    double *lim_mean = nullptr, *lim_qmin = nullptr, *lim_qmax = nullptr;
     swe2d_params par{};
     SweBcTable bc{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -230,6 +246,8 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
         vy[i] = mesh->vertex_xy[2*(size_t)i + 1];
         vh[i] = mesh->bathymetry[i];
     }
+    h->host_cells.assign(mesh->cell_vertices, mesh->cell_vertices + 3*(size_t)n);
+    h->host_nbr.assign(mesh->cell_neighbours, mesh->cell_neighbours + 3*(size_t)n);
     for (int k = 0; k < n; k++) {
         for (int f = 0; f < 3; f++) {
             const int vid = mesh->cell_vertices[3*(size_t)k + f];
@@ -296,7 +314,13 @@ void swe2d_destroy(swe2d_handle *hh)
     if (h->my_stream) (void)hipStreamSynchronize(h->my_stream);
     for (int b = 0; b < 3; b++) if (h->state[b]) (void)hipFree(h->state[b]);
     for (int i = 0; i < SWE2D_FIELD_COUNT; i++) if (h->field[i]) (void)hipFree(h->field[i]);
-    void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells};
+    for (auto &t : h->tracers) {
+        for (int b = 0; b < 3; b++) if (t.buf[b]) (void)hipFree(t.buf[b]);
+        if (t.source) (void)hipFree(t.source);
+    }
+    void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells,
+                    h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
+                    h->lim_qmin, h->lim_qmax};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -589,6 +613,314 @@ int swe2d_halo_unpack(swe2d_handle *hh, int i_stage, const double *recv_buf_dev)
     hipLaunchKernelGGL(swe_halo_unpack, dim3(grid_for(9*ng)), dim3(256), 0, h->stream,
                        h->state[i_stage], h->stride, h->n_owned, ng, recv_buf_dev);
     HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// tracers + limiter
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+typedef void (*tracer_kernel_t)(const SweTracerArgs);
+
+tracer_kernel_t pick_tracer_kernel(bool lf, bool t0, bool src)
+{
+    if (lf) {
+        if (t0) return src ? swe_tracer_stage_kernel<true, true, true> : swe_tracer_stage_kernel<true, true, false>;
+        return src ? swe_tracer_stage_kernel<true, false, true> : swe_tracer_stage_kernel<true, false, false>;
+    }
+    if (t0) return src ? swe_tracer_stage_kernel<false, true, true> : swe_tracer_stage_kernel<false, true, false>;
+    return src ? swe_tracer_stage_kernel<false, false, true> : swe_tracer_stage_kernel<false, false, false>;
+}
+
+int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1, double beta)
+{
+    Handle::Tracer &t = h->tracers[id];
+    SweTracerArgs a;
+    a.tin = t.buf[in];
+    a.t0 = t.buf[0];
+    a.tout = t.buf[out];
+    a.uv = h->state[0];
+    a.stride = h->stride;
+    a.nbr = h->nbr; a.cv = h->cv; a.vx = h->vx; a.vy = h->vy;
+    a.cell_begin = 0; a.cell_end = h->n_owned;
+    a.dt = h->par.dt; a.a0 = a0; a.a1 = a1; a.beta = beta;
+    a.vel_factor = h->tracer_vel_factor;
+    a.lf_factor = h->tracer_lf_factor;
+    a.source = t.source;
+    for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_has_value[m] = t.bc_has_value[m]; a.bc_value[m] = t.bc_value[m]; }
+    tracer_kernel_t kern = pick_tracer_kernel(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr);
+    const int nblocks = (h->n_owned + SWE_BLOCK - 1)/SWE_BLOCK;
+    const int grid = ((nblocks + 7)/8)*8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
+}
+
+int tracer_stage(Handle *h, int id, int i_stage)
+{
+    switch (i_stage) {
+    case 0: return launch_tracer_stage(h, id, 0, 1, 0.0, 1.0, kBeta[0]);
+    case 1: return launch_tracer_stage(h, id, 1, 2, kAlpha0[1], kAlphaIn[1], kBeta[1]);
+    case 2: return launch_tracer_stage(h, id, 2, 0, kAlpha0[2], kAlphaIn[2], kBeta[2]);
+    default: return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "i_stage must be 0, 1 or 2");
+    }
+}
+
+int check_tracer(Handle *h, int id)
+{
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (id < 0 || id >= (int)h->tracers.size()) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "unknown tracer id");
+    return SWE2D_OK;
+}
+
+// vertex -> cells CSR and vertex -> boundary facets CSR on the host, uploaded once
+int limiter_build(Handle *h, int nv, const int *topo /* [n][3] */)
+{
+    const int n = h->n_cells;
+    const size_t S = h->stride;
+    std::vector<int> off(nv + 1, 0), boff(nv + 1, 0);
+    for (int k = 0; k < n; k++)
+        for (int i = 0; i < 3; i++) {
+            const int v = topo[3*(size_t)k + i];
+            if (v < 0 || v >= nv) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "topological vertex id out of range");
+            off[v + 1]++;
+            if (h->host_nbr[3*(size_t)k + i] < 0) { boff[v + 1]++; boff[topo[3*(size_t)k + (i + 1) % 3] + 1]++; }
+        }
+    for (int v = 0; v < nv; v++) { off[v + 1] += off[v]; boff[v + 1] += boff[v]; }
+    std::vector<int> cell(off[nv]), bf(std::max(1, boff[nv])), pos(off.begin(), off.end() - 1), bpos(boff.begin(), boff.end() - 1);
+    std::vector<int> tv(3*S, 0);
+    for (int k = 0; k < n; k++)
+        for (int i = 0; i < 3; i++) {
+            const int v = topo[3*(size_t)k + i];
+            cell[pos[v]++] = k;
+            tv[(size_t)i*S + k] = v;
+            if (h->host_nbr[3*(size_t)k + i] < 0) {          // facet i joins local vertices i and i+1
+                const int v2 = topo[3*(size_t)k + (i + 1) % 3];
+                bf[bpos[v]++] = (k << 2) | i;
+                bf[bpos[v2]++] = (k << 2) | i;
+            }
+        }
+    int **ptrs[] = {&h->lim_v2c_off, &h->lim_v2c_cell, &h->lim_vbf_off, &h->lim_vbf_facet, &h->lim_tv};
+    for (int **pp : ptrs) if (*pp) { HIP_TRY(h, hipFree(*pp)); *pp = nullptr; }
+    double **dptrs[] = {&h->lim_mean, &h->lim_qmin, &h->lim_qmax};
+    for (double **pp : dptrs) if (*pp) { HIP_TRY(h, hipFree(*pp)); *pp = nullptr; }
+    HIP_TRY(h, hipMalloc(&h->lim_v2c_off, off.size()*sizeof(int)));
+    HIP_TRY(h, hipMalloc(&h->lim_v2c_cell, cell.size()*sizeof(int)));
+    HIP_TRY(h, hipMalloc(&h->lim_vbf_off, boff.size()*sizeof(int)));
+    HIP_TRY(h, hipMalloc(&h->lim_vbf_facet, bf.size()*sizeof(int)));
+    HIP_TRY(h, hipMalloc(&h->lim_tv, tv.size()*sizeof(int)));
+    HIP_TRY(h, hipMalloc(&h->lim_mean, S*sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->lim_qmin, (size_t)nv*sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->lim_qmax, (size_t)nv*sizeof(double)));
+    HIP_TRY(h, hipMemcpy(h->lim_v2c_off, off.data(), off.size()*sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->lim_v2c_cell, cell.data(), cell.size()*sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->lim_vbf_off, boff.data(), boff.size()*sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->lim_vbf_facet, bf.data(), bf.size()*sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->lim_tv, tv.data(), tv.size()*sizeof(int), hipMemcpyHostToDevice));
+    h->lim_nv = nv;
+    return SWE2D_OK;
+}
+
+int limiter_apply(Handle *h, int id)
+{
+    if (h->n_owned != h->n_cells)
+        return fail(h, SWE2D_ERR_UNSUPPORTED, "the vertex limiter is not available on partitions yet");
+    if (h->lim_nv == 0) {
+        int rc = limiter_build(h, h->n_vertices, h->host_cells.data());
+        if (rc) return rc;
+    }
+    double *t = h->tracers[id].buf[0];
+    const int n = h->n_cells, nv = h->lim_nv;
+    hipLaunchKernelGGL(swe_limiter_cell_mean, dim3(grid_for(n)), dim3(256), 0, h->stream, t, h->stride, n, h->lim_mean);
+    hipLaunchKernelGGL(swe_limiter_vertex_bounds, dim3(grid_for(nv)), dim3(256), 0, h->stream, h->lim_v2c_off,
+                       h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_mean, t, h->stride, nv, h->lim_qmin,
+                       h->lim_qmax);
+    hipLaunchKernelGGL(swe_limiter_apply, dim3(grid_for(n)), dim3(256), 0, h->stream, t, h->stride, n, h->lim_tv,
+                       h->lim_qmin, h->lim_qmax);
+    HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int swe2d_tracer_add(swe2d_handle *hh, int *tracer_id)
+{
+    Handle *h = H(hh);
+    if (!h || !tracer_id) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    if (h->n_owned != h->n_cells) return fail(h, SWE2D_ERR_UNSUPPORTED, "tracers are not available on partitions yet");
+    HIP_TRY(h, hipSetDevice(h->device));
+    Handle::Tracer t;
+    for (int m = 0; m < SWE_MAX_MARKERS; m++) { t.bc_has_value[m] = 0; t.bc_value[m] = 0.0; }
+    for (int b = 0; b < 3; b++) {
+        HIP_TRY(h, hipMalloc(&t.buf[b], 3*h->stride*sizeof(double)));
+        HIP_TRY(h, hipMemsetAsync(t.buf[b], 0, 3*h->stride*sizeof(double), h->stream));
+    }
+    h->tracers.push_back(t);
+    *tracer_id = (int)h->tracers.size() - 1;
+    return SWE2D_OK;
+}
+
+int swe2d_tracer_set_options(swe2d_handle *hh, int use_lax_friedrichs_tracer, double lax_friedrichs_tracer_scaling_factor,
+                             double tracer_advective_velocity_factor)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    h->tracer_use_lf = use_lax_friedrichs_tracer ? 1 : 0;
+    h->tracer_lf_factor = lax_friedrichs_tracer_scaling_factor;
+    h->tracer_vel_factor = tracer_advective_velocity_factor;
+    return SWE2D_OK;
+}
+
+int swe2d_tracer_set_state(swe2d_handle *hh, int id, const double *nodal)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (!nodal) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->stage_eta, nodal, 3*(size_t)h->n_cells*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(swe_nodal_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                       h->stage_eta, h->tracers[id].buf[0], h->stride, h->n_cells, 1);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWE2D_OK;
+}
+
+static int tracer_read_back(Handle *h, const double *planes, double *nodal)
+{
+    hipLaunchKernelGGL(swe_planes_to_nodal, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                       planes, h->stage_eta, h->stride, h->n_cells);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(nodal, h->stage_eta, 3*(size_t)h->n_cells*sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWE2D_OK;
+}
+
+int swe2d_tracer_get_state(swe2d_handle *hh, int id, double *nodal)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (!nodal) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return tracer_read_back(h, h->tracers[id].buf[0], nodal);
+}
+
+int swe2d_tracer_set_bc(swe2d_handle *hh, int id, int marker, int has_value, double value)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (marker <= 0 || marker >= SWE2D_MAX_MARKERS) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "marker out of range");
+    h->tracers[id].bc_has_value[marker] = has_value ? 1 : 0;
+    h->tracers[id].bc_value[marker] = value;
+    return SWE2D_OK;
+}
+
+int swe2d_tracer_set_source(swe2d_handle *hh, int id, const double *nodal)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    Handle::Tracer &t = h->tracers[id];
+    if (!nodal) {
+        if (t.source) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipFree(t.source)); t.source = nullptr; }
+        return SWE2D_OK;
+    }
+    if (!t.source) HIP_TRY(h, hipMalloc(&t.source, 3*h->stride*sizeof(double)));
+    HIP_TRY(h, hipMemcpyAsync(h->stage_eta, nodal, 3*(size_t)h->n_cells*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(swe_nodal_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                       h->stage_eta, t.source, h->stride, h->n_cells, 1);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWE2D_OK;
+}
+
+int swe2d_tracer_solve_stage(swe2d_handle *hh, int id, int i_stage)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return tracer_stage(h, id, i_stage);
+}
+
+int swe2d_tracer_tendency(swe2d_handle *hh, int id, double *k_nodal)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (!k_nodal) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    rc = launch_tracer_stage(h, id, 0, 1, 0.0, 0.0, 1.0);
+    if (rc) return rc;
+    return tracer_read_back(h, h->tracers[id].buf[1], k_nodal);
+}
+
+int swe2d_limiter_setup(swe2d_handle *hh, int32_t n_topo_vertices, const int32_t *cell_topo_vertices)
+{
+    Handle *h = H(hh);
+    if (!h || n_topo_vertices <= 0 || !cell_topo_vertices) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad limiter topology");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return limiter_build(h, n_topo_vertices, cell_topo_vertices);
+}
+
+int swe2d_tracer_limit(swe2d_handle *hh, int id)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return limiter_apply(h, id);
+}
+
+int swe2d_tracer_diagnostics(swe2d_handle *hh, int id, double out[4])
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (!out) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(swe_tracer_diag_kernel, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
+                       h->tracers[id].buf[0], h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh,
+                       h->par.use_nonlinear_equations, h->n_owned, h->partial);
+    HIP_TRY(h, hipGetLastError());
+    std::vector<double> part(4*(size_t)h->n_partial_blocks);
+    HIP_TRY(h, hipMemcpyAsync(part.data(), h->partial, part.size()*sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    out[0] = out[1] = 0.0; out[2] = 1e300; out[3] = -1e300;
+    for (int b = 0; b < h->n_partial_blocks; b++) {
+        out[0] += part[4*(size_t)b];
+        out[1] += part[4*(size_t)b + 1];
+        out[2] = std::fmin(out[2], part[4*(size_t)b + 2]);
+        out[3] = std::fmax(out[3], part[4*(size_t)b + 3]);
+    }
+    if (!std::isfinite(out[0]) || !std::isfinite(out[1]))
+        return fail(h, SWE2D_ERR_NOT_FINITE, "tracer is not finite");
+    return SWE2D_OK;
+}
+
+int swe2d_advance_coupled(swe2d_handle *hh, int n_steps, int tracer_only, int use_limiter)
+{
+    Handle *h = H(hh);
+    if (!h || n_steps < 0) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad n_steps");
+    if (h->n_owned != h->n_cells) return fail(h, SWE2D_ERR_UNSUPPORTED, "coupled stepping on a partition is not supported yet");
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (int it = 0; it < n_steps; it++) {
+        if (!tracer_only)
+            for (int s = 0; s < 3; s++) { int rc = stage_on_range(h, s, 0, h->n_owned); if (rc) return rc; }
+        for (int id = 0; id < (int)h->tracers.size(); id++) {
+            for (int s = 0; s < 3; s++) { int rc = tracer_stage(h, id, s); if (rc) return rc; }
+            if (use_limiter) { int rc = limiter_apply(h, id); if (rc) return rc; }
+        }
+    }
     return SWE2D_OK;
 }
 

@@ -556,3 +556,250 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel(const double *plane
     if (threadIdx.x == 0)
         for (int q = 0; q < 4; q++) partial[4*(size_t)blockIdx.x + q] = red[q][0];
 }
+
+// ===============================================================================================================
+// 2D tracer advection stage (non-conservative form) and the vertex-based P1DG limiter
+//   thetis/tracer_eq_2d.py:147-193 (HorizontalAdvectionTerm), :281-298 (SourceTerm)
+//   thetis/limiter.py:48-198 + firedrake.VertexBasedLimiter [FD-assumed]
+//   thetis/coupled_timeintegrator_2d.py:93-113: SWE step, then every tracer with the UPDATED velocity, then the limiter
+// Same structure as the SWE stage: one lane per triangle, all loads up front, closed-form cell integrals, fused mass
+// inverse and Shu-Osher combine.  Algorithmic bytes per cell per stage: T read 24 + write 24 (+24 T0 in stages 2,3)
+// + u,v read 48 + static 36.
+// ===============================================================================================================
+struct SweTracerArgs {
+    const double *tin;     // 3 planes
+    const double *t0;      // 3 planes (stage_sol[0])
+    double *tout;          // 3 planes
+    const double *uv;      // SWE state planes (u0 u1 u2 v0 v1 v2 ...): the advecting velocity
+    size_t stride;
+    const int *nbr, *cv;
+    const double *vx, *vy;
+    int cell_begin, cell_end;
+    double dt, a0, a1, beta;
+    double vel_factor;     // tracer_advective_velocity_factor
+    double lf_factor;      // lax_friedrichs_tracer_scaling_factor
+    const double *source;  // 3 planes or null
+    int bc_has_value[SWE_MAX_MARKERS];
+    double bc_value[SWE_MAX_MARKERS];
+};
+
+template <bool LF, bool HAST0, bool SRC>
+__global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTracerArgs p)
+{
+#ifdef SWE_NO_XCD_MAP
+    const int lb = blockIdx.x;
+#else
+    const int lb = swe_logical_block(blockIdx.x, gridDim.x);
+#endif
+    const int k = p.cell_begin + lb*SWE_BLOCK + (int)threadIdx.x;
+    if (k >= p.cell_end) return;
+    const size_t S = p.stride;
+    const double cf = p.vel_factor;
+
+    double u[3], v[3], c[3], w[3];
+    int nb[3], vid[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        nb[i] = p.nbr[(size_t)i*S + k];
+        vid[i] = p.cv[(size_t)i*S + k];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        u[i] = cf*p.uv[(size_t)i*S + k];
+        v[i] = cf*p.uv[(size_t)(3 + i)*S + k];
+        c[i] = p.tin[(size_t)i*S + k];
+        w[i] = p.a1*c[i];
+        if (HAST0) w[i] += p.a0*p.t0[(size_t)i*S + k];
+    }
+    double una[3], unb[3], vna[3], vnb[3], cna[3], cnb[3];
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        const int nbf = nb[f];
+        const int kn = nbf >= 0 ? (nbf >> 2) : k;
+        const int f2 = nbf >= 0 ? (nbf & 3) : f;
+        const int na = (f2 == 2) ? 0 : f2 + 1;
+        una[f] = cf*p.uv[(size_t)na*S + kn];
+        unb[f] = cf*p.uv[(size_t)f2*S + kn];
+        vna[f] = cf*p.uv[(size_t)(3 + na)*S + kn];
+        vnb[f] = cf*p.uv[(size_t)(3 + f2)*S + kn];
+        cna[f] = p.tin[(size_t)na*S + kn];
+        cnb[f] = p.tin[(size_t)f2*S + kn];
+    }
+    double px[3], py[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        px[i] = p.vx[vid[i]];
+        py[i] = p.vy[vid[i]];
+    }
+    double nx[3], ny[3];
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        const int b = (f + 1) % 3;
+        nx[f] = py[b] - py[f];
+        ny[f] = px[f] - px[b];
+    }
+    const double twoA = nx[0]*ny[1] - ny[0]*nx[1];
+    double gxs[3], gys[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        gxs[i] = -0.5*nx[(i + 1) % 3];
+        gys[i] = -0.5*ny[(i + 1) % 3];
+    }
+    // cell integral  +(phi div u + u.grad phi) c                                      tracer_eq_2d.py:157-158
+    double b[3];
+    {
+        const double D12 = (gxs[0]*u[0] + gxs[1]*u[1] + gxs[2]*u[2]
+                            + gys[0]*v[0] + gys[1]*v[1] + gys[2]*v[2])*(1.0/12.0);
+        const double Suc = swe_int2(u, c)*(1.0/12.0), Svc = swe_int2(v, c)*(1.0/12.0);
+        const double cs = c[0] + c[1] + c[2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) b[i] = D12*(cs + c[i]) + gxs[i]*Suc + gys[i]*Svc;
+    }
+    if (SRC) {                                                                         // tracer_eq_2d.py:293-297
+        const double A = 0.5*twoA;
+        double s[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) s[i] = p.source[(size_t)i*S + k];
+        const double ss = s[0] + s[1] + s[2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) b[i] += A*(1.0/12.0)*(ss + s[i]);
+    }
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        const int a = f, bb = (f + 1) % 3;
+        const double nxs = nx[f], nys = ny[f];
+        double Fa = 0.0, Fb = 0.0;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+            const double uq = xa*u[a] + xb*u[bb], vq = xa*v[a] + xb*v[bb], cq = xa*c[a] + xb*c[bb];
+            const double unown = uq*nxs + vq*nys;                       // |F| u.n of this side   :170-171
+            double fq;
+            if (nb[f] >= 0) {
+                const double un = xa*una[f] + xb*unb[f], vn = xa*vna[f] + xb*vnb[f], cn = xa*cna[f] + xb*cnb[f];
+                const double uavn = 0.5*((uq + un)*nxs + (vq + vn)*nys);                   // :163-165
+                const double cup = uavn > 0.0 ? cq : (uavn < 0.0 ? cn : 0.5*(cq + cn));   // :166-168
+                fq = cup*unown;
+                if (LF) fq += 0.5*fabs(uavn)*p.lf_factor*(cq - cn);                       // :173-175
+            } else {
+                const int marker = -nb[f];
+                if (marker < SWE_MAX_MARKERS && p.bc_has_value[marker]) {                  // :181-188, uv_ext = uv_in
+                    const double cext = p.bc_value[marker];
+                    const double cup = unown > 0.0 ? cq : (unown < 0.0 ? cext : 0.5*(cq + cext));
+                    fq = cup*unown;
+                } else {
+                    fq = cq*unown;                                                         // :189-191
+                }
+            }
+            Fa += xa*fq;
+            Fb += xb*fq;
+        }
+        b[a] -= 0.5*Fa;
+        b[bb] -= 0.5*Fb;
+    }
+    const double s = 6.0*p.dt*p.beta*swe_rcp(twoA);
+    const double sb = b[0] + b[1] + b[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) p.tout[(size_t)i*S + k] = s*(4.0*b[i] - sb) + w[i];
+}
+
+// ---- limiter, step 1: cell means (P0 projection of an affine P1 field = mean of the nodal values)
+__global__ void swe_limiter_cell_mean(const double *t, size_t stride, int n, double *mean)
+{
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    mean[k] = (t[k] + t[stride + k] + t[2*stride + k])/3.0;
+}
+
+// ---- limiter, step 2: per (topological) vertex min/max of the means of the cells around it (CSR gather: no atomics,
+// deterministic) + Thetis's boundary-facet means (limiter.py:109-145)
+__global__ void swe_limiter_vertex_bounds(const int *v2c_off, const int *v2c_cell, const int *vbf_off, const int *vbf_facet,
+                                          const double *mean, const double *t, size_t stride, int nv,
+                                          double *qmin, double *qmax)
+{
+    const int v = blockIdx.x*blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    double lo = 1.0e10, hi = -1.0e10;
+    for (int j = v2c_off[v]; j < v2c_off[v + 1]; j++) {
+        const double m = mean[v2c_cell[j]];
+        lo = fmin(lo, m);
+        hi = fmax(hi, m);
+    }
+    for (int j = vbf_off[v]; j < vbf_off[v + 1]; j++) {
+        const int packed = vbf_facet[j];
+        const int k = packed >> 2, a = packed & 3, b = (a == 2) ? 0 : a + 1;
+        const double fm = (t[(size_t)a*stride + k] + t[(size_t)b*stride + k])/2.0;
+        lo = fmin(lo, fm);
+        hi = fmax(hi, fm);
+    }
+    qmin[v] = lo;
+    qmax[v] = hi;
+}
+
+// ---- limiter, step 3: per-cell scaling towards the mean
+__global__ void swe_limiter_apply(double *t, size_t stride, int n, const int *tv, const double *qmin, const double *qmax)
+{
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double c[3];
+    int vv[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        c[i] = t[(size_t)i*stride + k];
+        vv[i] = tv[(size_t)i*stride + k];
+    }
+    const double mean = (c[0] + c[1] + c[2])/3.0;
+    double alpha = 1.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (c[i] > mean) alpha = fmin(alpha, fmin(1.0, (qmax[vv[i]] - mean)/(c[i] - mean)));
+        else if (c[i] < mean) alpha = fmin(alpha, fmin(1.0, (mean - qmin[vv[i]])/(mean - c[i])));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) t[(size_t)i*stride + k] = mean + alpha*(c[i] - mean);
+}
+
+// ---- tracer diagnostics: per-block { int T*H dx, int T dx, min T, max T }
+__global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel(const double *t, const double *state, size_t stride,
+                                                                    const int *cv, const double *vx, const double *vy,
+                                                                    const double *vh, int nonlinear, int n, double *partial)
+{
+    __shared__ double red[4][SWE_BLOCK];
+    const int k = blockIdx.x*SWE_BLOCK + threadIdx.x;
+    double s_m = 0.0, s_i = 0.0, s_min = 1e300, s_max = -1e300;
+    if (k < n) {
+        double c[3], H[3], px[3], py[3];
+        for (int i = 0; i < 3; i++) {
+            c[i] = t[(size_t)i*stride + k];
+            const int vid = cv[(size_t)i*stride + k];
+            px[i] = vx[vid]; py[i] = vy[vid];
+            H[i] = vh[vid] + (nonlinear ? state[(size_t)(6 + i)*stride + k] : 0.0);
+        }
+        const double A = 0.5*((px[1] - px[0])*(py[2] - py[0]) - (px[2] - px[0])*(py[1] - py[0]));
+        s_m = A*(1.0/12.0)*swe_int2(c, H);
+        s_i = A*(1.0/3.0)*(c[0] + c[1] + c[2]);
+        s_min = fmin(fmin(c[0], c[1]), c[2]);
+        s_max = fmax(fmax(c[0], c[1]), c[2]);
+    }
+    red[0][threadIdx.x] = s_m; red[1][threadIdx.x] = s_i; red[2][threadIdx.x] = s_min; red[3][threadIdx.x] = s_max;
+    __syncthreads();
+    for (int off = SWE_BLOCK/2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+            red[2][threadIdx.x] = fmin(red[2][threadIdx.x], red[2][threadIdx.x + off]);
+            red[3][threadIdx.x] = fmax(red[3][threadIdx.x], red[3][threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 4; q++) partial[4*(size_t)blockIdx.x + q] = red[q][0];
+}
+
+// scalar nodal field (3N) <-> 3 planes
+__global__ void swe_planes_to_nodal(const double *planes, double *nodal, size_t stride, int n)
+{
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    for (int i = 0; i < 3; i++) nodal[3*(size_t)k + i] = planes[(size_t)i*stride + k];
+}

@@ -73,6 +73,15 @@ class Swe2dDevice(object):
             cells0 = vinv[cells0]
             xy0 = xy0[vperm]
             bath0 = bath0[vperm]
+        self._topo_cells = None
+        self._limiter_ready = False
+        topo = getattr(mesh, 'topo_vertex', None)
+        if topo is not None and not np.array_equal(np.asarray(topo), np.arange(len(topo))):
+            tc = np.asarray(topo)[np.asarray(mesh.cells)]
+            if self.perm is not None:
+                tc = tc[self.perm]
+            _, tc = np.unique(tc, return_inverse=True)                # compact ids
+            self._topo_cells = tc.reshape(-1, 3)
         self._keep = [c(cells0, dtype=np.int32), c(xy0, dtype=np.float64),
                       c(nbr0, dtype=np.int32), c(nbf0, dtype=np.int8), c(bath0, dtype=np.float64)]
         cells, xy, nbr, nbf, bath = self._keep
@@ -208,6 +217,72 @@ class Swe2dDevice(object):
         out = np.empty(4)
         self._ck(self.lib.swe2d_diagnostics(self.h, _ptr(out)))
         return out
+
+    # -- tracers + limiter
+    def _nodal_in(self, a):
+        a = np.asarray(a, dtype=np.float64).reshape(self.n_cells, 3)
+        if self.perm is not None:
+            a = a[self.perm]
+        return np.ascontiguousarray(a)
+
+    def _nodal_out(self, a):
+        return a[self.inv_perm] if self.perm is not None else a
+
+    def add_tracer(self):
+        tid = ctypes.c_int()
+        self._ck(self.lib.swe2d_tracer_add(self.h, ctypes.byref(tid)))
+        if self._topo_cells is not None and not self._limiter_ready:
+            t = np.ascontiguousarray(self._topo_cells, dtype=np.int32)
+            self._ck(self.lib.swe2d_limiter_setup(self.h, int(t.max()) + 1, t.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+            self._limiter_ready = True
+        return tid.value
+
+    def tracer_set_options(self, use_lax_friedrichs_tracer=False, lax_friedrichs_tracer_scaling_factor=1.0,
+                           tracer_advective_velocity_factor=1.0):
+        self._ck(self.lib.swe2d_tracer_set_options(self.h, int(bool(use_lax_friedrichs_tracer)),
+                                                   float(lax_friedrichs_tracer_scaling_factor),
+                                                   float(tracer_advective_velocity_factor)))
+
+    def tracer_set_state(self, tid, nodal):
+        a = self._nodal_in(nodal)
+        self._ck(self.lib.swe2d_tracer_set_state(self.h, tid, _ptr(a)))
+
+    def tracer_get_state(self, tid):
+        a = np.empty((self.n_cells, 3))
+        self._ck(self.lib.swe2d_tracer_get_state(self.h, tid, _ptr(a)))
+        return self._nodal_out(a)
+
+    def tracer_set_bc(self, tid, marker, value):
+        """``value``: constant Dirichlet value or None (default boundary term)."""
+        self._ck(self.lib.swe2d_tracer_set_bc(self.h, tid, int(marker), 0 if value is None else 1,
+                                              0.0 if value is None else float(value)))
+
+    def tracer_set_source(self, tid, nodal):
+        if nodal is None:
+            self._ck(self.lib.swe2d_tracer_set_source(self.h, tid, None))
+        else:
+            a = self._nodal_in(np.broadcast_to(np.asarray(nodal, dtype=np.float64), (self.n_cells, 3)))
+            self._ck(self.lib.swe2d_tracer_set_source(self.h, tid, _ptr(a)))
+
+    def tracer_solve_stage(self, tid, i_stage):
+        self._ck(self.lib.swe2d_tracer_solve_stage(self.h, tid, int(i_stage)))
+
+    def tracer_tendency(self, tid):
+        a = np.empty((self.n_cells, 3))
+        self._ck(self.lib.swe2d_tracer_tendency(self.h, tid, _ptr(a)))
+        return self._nodal_out(a)
+
+    def tracer_limit(self, tid):
+        self._ck(self.lib.swe2d_tracer_limit(self.h, tid))
+
+    def tracer_diagnostics(self, tid):
+        """{int T*H dx, int T dx, min nodal T, max nodal T}"""
+        out = np.empty(4)
+        self._ck(self.lib.swe2d_tracer_diagnostics(self.h, tid, _ptr(out)))
+        return out
+
+    def advance_coupled(self, n_steps=1, tracer_only=False, use_limiter=True):
+        self._ck(self.lib.swe2d_advance_coupled(self.h, int(n_steps), int(bool(tracer_only)), int(bool(use_limiter))))
 
     # -- multi-GPU plumbing
     def halo_setup(self, send_cells):

@@ -14,12 +14,14 @@ import time as time_mod
 
 import numpy as np
 
-from . import callback
+from . import callback, coupled_timeintegrator_2d
 from .function import Function, FunctionSpace, MixedFunction, get_functionspace
 from .log import print_output
 from .options import Constant, ModelOptions2d
 from .rungekutta import SSPRK33
 from .shallowwater_eq import DepthExpression, ShallowWaterEquations, g_grav
+from .limiter import VertexBasedP1DGLimiter
+from .tracer_eq_2d import TracerEquation2D
 
 __all__ = ['FlowSolver2d']
 
@@ -114,6 +116,8 @@ class FlowSolver2d(object):
         self.fields.solution_2d = MixedFunction((uv_2d, elev_2d), name='solution_2d')
         self.fields.uv_2d = uv_2d
         self.fields.elev_2d = elev_2d
+        for label, topts in self.options.tracer.items():
+            self.fields[label] = topts.function if topts.function is not None else Function(self.function_spaces.Q_2d, name=label)
         # mesh element size: CG-P1 L2 projection of sqrt(cell area), utility.py:620-640 (needed for automatic dt only)
         self.fields.h_elem_size_2d = None
         self.depth = DepthExpression(self.fields.bathymetry_2d,
@@ -128,6 +132,13 @@ class FlowSolver2d(object):
         self.equations = AttrDict()
         self.equations.sw = ShallowWaterEquations(self.function_spaces.H_2d, self.depth, self.options)
         self.equations.sw.bnd_functions = self.bnd_functions['shallow_water']
+        self.solve_tracer = len(self.options.tracer) > 0
+        for label in self.options.tracer:
+            self.equations[label] = TracerEquation2D(label, self.function_spaces.Q_2d, self.depth, self.options)
+        if self.solve_tracer and self.options.use_limiter_for_tracers and self.options.polynomial_degree > 0:
+            self.tracer_limiter = VertexBasedP1DGLimiter(self.function_spaces.Q_2d, device_id=self.device_id)
+        else:
+            self.tracer_limiter = None
 
     def get_swe_timestepper(self, integrator):
         """Gets shallow water timestepper object with appropriate parameters (solver2d.py:542-573)"""
@@ -149,6 +160,26 @@ class FlowSolver2d(object):
         return integrator(self.equations.sw, self.fields.solution_2d, fields, self.dt,
                           o.swe_timestepper_options, bnd_conditions, device_id=self.device_id)
 
+    def get_tracer_timestepper(self, integrator, system, swe_stepper):
+        """Gets tracer timestepper object with appropriate parameters (solver2d.py:576-598)"""
+        uv, elev = self.fields.solution_2d.subfunctions
+        fields = {
+            'elev_2d': elev,
+            'uv_2d': uv,
+            'lax_friedrichs_tracer_scaling_factor': self.options.lax_friedrichs_tracer_scaling_factor,
+            'tracer_advective_velocity_factor': self.options.tracer_advective_velocity_factor,
+        }
+        for label in system.split(','):
+            fields['diffusivity_h-{:}'.format(label)] = self.options.tracer[label].diffusivity
+            fields['source-{:}'.format(label)] = self.options.tracer[label].source
+        bcs = {}
+        if system in self.bnd_functions:
+            bcs = self.bnd_functions[system]
+        elif system[:-3] in self.bnd_functions:
+            bcs = self.bnd_functions[system[:-3]]
+        return integrator(self.equations[system], self.fields[system], fields, self.dt,
+                          self.options.tracer_timestepper_options, bcs, swe_stepper)
+
     def create_timestepper(self):
         """solver2d.py:651-700"""
         if not hasattr(self, 'equations'):
@@ -161,12 +192,20 @@ class FlowSolver2d(object):
         self.set_time_step()
         steppers = {'SSPRK33': SSPRK33}
         name = self.options.swe_timestepper_type
-        if self.solve_tracer or self.options.tracer:
-            raise NotImplementedError('2D tracers are not on the device path yet')
         if name not in steppers:
             raise NotImplementedError("swe_timestepper_type {!r} needs a global (non)linear solve and is outside the "
                                       "explicit device path; use 'SSPRK33'".format(name))
-        self.timestepper = self.get_swe_timestepper(steppers[name])
+        if self.solve_tracer:
+            if self.options.tracer_timestepper_type != 'SSPRK33':
+                raise NotImplementedError("tracer_timestepper_type {!r} is outside the explicit device path; use "
+                                          "'SSPRK33'".format(self.options.tracer_timestepper_type))
+            swe = self.get_swe_timestepper(steppers[name])
+            tracers = {}
+            for system in self.options.tracer_fields:
+                tracers[system] = self.get_tracer_timestepper(coupled_timeintegrator_2d.DeviceTracerSSPRK33, system, swe)
+            self.timestepper = coupled_timeintegrator_2d.GeneralCoupledTimeIntegrator2D(self, swe, tracers)
+        else:
+            self.timestepper = self.get_swe_timestepper(steppers[name])
         print_output('Using time integrator: {:}'.format(self.timestepper.__class__.__name__))
 
     def compute_mesh_stats(self):
@@ -205,8 +244,10 @@ class FlowSolver2d(object):
             elev_2d.project(elev)
         if uv is not None:
             uv_2d.project(uv)
-        if tracers:
-            raise NotImplementedError('2D tracers are not on the device path yet')
+        for l, func in tracers.items():
+            label = l if len(l) > 3 and l[-3:] == '_2d' else l + '_2d'
+            assert label in self.options.tracer, 'Unknown tracer label {:}'.format(label)
+            self.fields[label].project(func)
         self.timestepper.initialize(self.fields.solution_2d)
 
     def add_callback(self, callback, eval_interval='export'):
@@ -226,10 +267,17 @@ class FlowSolver2d(object):
         entries = [('exp', self.i_export, '5d'), ('iter', self.iteration, '5d')]
         time_str = '{:.2f}'.format(self.simulation_time).rjust(15)
         entries += [('time', time_str, '15s')]
-        d = self.timestepper.diagnostics()
-        norm_h = math.sqrt(d[0])
-        norm_u = math.sqrt(d[1])
-        entries += [('eta norm', norm_h, '14.4f'), ('u norm', norm_u, '14.4f')]
+        if self.options.tracer_only:
+            area = self.mesh2d.cell_areas()
+            for label in self.options.tracer:
+                q = self.fields[label].cell_node_values()
+                norm_q = math.sqrt(float(np.sum(area/12.0*(q.sum(axis=1)**2 + (q**2).sum(axis=1)))))
+                entries.append((label, norm_q, '10.4f'))
+        else:
+            d = self.timestepper.diagnostics()
+            norm_h = math.sqrt(d[0])
+            norm_u = math.sqrt(d[1])
+            entries += [('eta norm', norm_h, '14.4f'), ('u norm', norm_u, '14.4f')]
         entries.append(('Tcpu', cputime, '6.2f'))
         if print_header:
             header = ' '.join([e[0].rjust(len('{:{fmt}}'.format(e[1], fmt=e[2]))) for e in entries])
@@ -253,6 +301,14 @@ class FlowSolver2d(object):
         if self.options.check_volume_conservation_2d:
             c = callback.VolumeConservation2DCallback(self, export_to_hdf5=False, append_to_log=True)
             self.add_callback(c)
+        if self.options.check_tracer_conservation:
+            for label, tracer in self.options.tracer.items():
+                c = callback.TracerMassConservation2DCallback(label, self, export_to_hdf5=False, append_to_log=True)
+                self.add_callback(c, eval_interval='export')
+        if self.options.check_tracer_overshoot:
+            for label in self.options.tracer:
+                c = callback.TracerOvershootCallBack(label, self, export_to_hdf5=False, append_to_log=True)
+                self.add_callback(c, eval_interval='export')
         initial_simulation_time = self.simulation_time
         internal_iteration = 0
         assert self.options.simulation_end_time is not None, 'simulation_end_time must be set'
