@@ -122,3 +122,41 @@ def test_unsupported_configurations_fail_loudly(hip_lib):
     s4.bnd_functions['shallow_water'] = {1: {'temperature': Constant(1.0)}}
     with pytest.raises(Exception):
         s4.assign_initial_conditions(elev=elev_init)
+
+
+def test_rossby_soliton_reference_criterion(hip_lib):
+    """test/swe2d/test_rossby_wave.py::test_convergence[SSPRK33-dg-dg] through FlowSolver2d on the device."""
+    import rossby
+    import thetis_amd
+    g_saved = float(thetis_amd.physical_constants['g_grav'])
+    thetis_amd.physical_constants['g_grav'].assign(1.0)
+    try:
+        res = []
+        for level in (24, 48):
+            mesh2d = rossby.rossby_mesh(level)
+            P1_2d = get_functionspace(mesh2d, 'CG', 1)
+            bathymetry2d = Function(P1_2d).assign(1.0)
+            solver_obj = solver2d.FlowSolver2d(mesh2d, bathymetry2d)
+            options = solver_obj.options
+            options.swe_timestepper_type = 'SSPRK33'
+            options.element_family = 'dg-dg'
+            options.swe_timestepper_options.use_automatic_timestep = False
+            options.timestep = 0.96/level
+            options.simulation_export_time = 5.0
+            options.simulation_end_time = 30.0
+            options.horizontal_viscosity = None
+            solver_obj.create_function_spaces()
+            options.coriolis_frequency = Function(solver_obj.function_spaces.P1_2d).interpolate(lambda x, y: y)
+            options.no_exports = True
+            solver_obj.create_equations()
+            for tag in mesh2d.boundary_markers:
+                solver_obj.bnd_functions['shallow_water'][tag] = {'uv': Constant((0., 0.))}
+            uv_a = Function(solver_obj.function_spaces.U_2d).interpolate(rossby.asymptotic_uv)
+            elev_a = Function(solver_obj.function_spaces.H_2d).interpolate(rossby.asymptotic_elev)
+            solver_obj.assign_initial_conditions(uv=uv_a, elev=elev_a)
+            solver_obj.iterate()
+            eta = solver_obj.fields.elev_2d.cell_node_values()
+            res.append(rossby.metrics(mesh2d.cell_xy(), eta))
+        rossby.check_convergence(res[0], res[1])
+    finally:
+        thetis_amd.physical_constants['g_grav'].assign(g_saved)

@@ -15,6 +15,4 @@ from . import solver2d  # noqa: F401
 from .function import Function, FunctionSpace, get_functionspace  # noqa: F401
 from .mesh import Mesh2d, PeriodicRectangleMesh, RectangleMesh, SquareMesh, UnitSquareMesh  # noqa: F401
 from .options import Constant, ModelOptions2d  # noqa: F401
-from .shallowwater_eq import g_grav, rho_0  # noqa: F401
-
-physical_constants = {'g_grav': g_grav, 'rho0': rho_0, 'von_karman': 0.4}
+from .shallowwater_eq import g_grav, physical_constants, rho_0  # noqa: F401

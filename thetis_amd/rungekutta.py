@@ -69,7 +69,7 @@ class ERKGenericShuOsher(TimeIntegrator):
         if not (isinstance(bath, Function) and bath.function_space().family == 'CG'):
             raise NotImplementedError('bathymetry_2d must be a CG-P1 Function (continuous bathymetry)')
         self.device = Swe2dDevice(
-            mesh, bath.dat.data_ro, dt, g_grav=g_grav,
+            mesh, bath.dat.data_ro, dt, g_grav=float(g_grav),
             use_nonlinear_equations=opts.use_nonlinear_equations,
             use_lax_friedrichs_velocity=opts.use_lax_friedrichs_velocity,
             lax_friedrichs_velocity_scaling_factor=float(fields.get('lax_friedrichs_velocity_scaling_factor') or 1.0),

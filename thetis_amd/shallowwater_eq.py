@@ -13,10 +13,12 @@ configuration is one the kernel implements:
 """
 from .options import Constant
 
-__all__ = ['ShallowWaterEquations', 'DepthExpression', 'g_grav', 'rho_0']
+__all__ = ['ShallowWaterEquations', 'DepthExpression', 'g_grav', 'rho_0', 'physical_constants']
 
-g_grav = 9.81      # thetis/physical_constants.py:7
-rho_0 = 1000.0     # thetis/physical_constants.py:8
+# thetis/physical_constants.py:6-11: Constants, so that tests can re-assign them (test/swe2d/test_rossby_wave.py:154-155)
+physical_constants = {'g_grav': Constant(9.81), 'rho0': Constant(1000.0), 'von_karman': Constant(0.4)}
+g_grav = physical_constants['g_grav']
+rho_0 = physical_constants['rho0']
 
 
 class DepthExpression(object):

@@ -68,7 +68,7 @@ class FlowSolver2d(object):
         mesh = self.mesh2d
         csize = self.fields.h_elem_size_2d
         bath = np.maximum(self.fields.bathymetry_2d.dat.data_ro, 0.05)
-        u = np.sqrt(g_grav*bath) + float(u_scale)                   # P1 nodal
+        u = np.sqrt(float(g_grav)*bath) + float(u_scale)                   # P1 nodal
         # integrand csize/u: evaluate at quadrature points from the P1 fields
         sol = project_to_p1(mesh, lambda lam, cells: (csize.dat.data_ro[cells] @ lam)/(u[cells] @ lam))
         out = Function(self.function_spaces.P1_2d)
