@@ -61,6 +61,21 @@ def cpu_baseline(mesh, bath, uv, eta, budget_s=12.0):
                       '{:.1f} s'.format(steps, ref.num_threads(), t)}, (steps, u_c, e_c)
 
 
+def measured_traffic(n_cells):
+    """HBM bytes per stage-kernel launch from the committed PMC passes (rocprofv3 cannot run inside the timed bench):
+    FETCH_SIZE/WRITE_SIZE collected in separate --pmc runs and corrected with the calibration copy kernel, see
+    profiles/README.md.  Only valid for the workload it was measured on."""
+    path = os.path.join(ROOT, 'profiles', 'r01d_traffic.json')
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if n_cells == 1000000:
+            return float(t['traffic_bytes_per_launch']), 'profiles/r01d_traffic.json'
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
 def run_single(args):
     from thetis_amd.device import Swe2dDevice
     mesh, bath, uv, eta = build_case()
@@ -84,6 +99,7 @@ def run_single(args):
     assert np.isfinite(d).all()
     value = n*3.0*args.steps/t_wall
     achieved = BYTES_PER_ELEMENT_UPDATE*n/(ms_kernel*1e-3)/1e9
+    traffic, traffic_src = measured_traffic(n)
     out = {
         'metric': 'DG element-updates/sec, 2D SWE DG-P1 SSPRK33',
         'value': value, 'unit': 'element-updates/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
@@ -92,7 +108,8 @@ def run_single(args):
         'config': {'workload': 'BASELINE cfg2: RectangleMesh(1000,500,100e3,50e3) = 1M triangles, DG-P1 SWE, SSPRK33, '
                                'flat h=20, closed walls, dt=0.25', 'n_cells': n, 'parallelism': 'single'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved/HBM_PEAK_GBS, 'traffic': None,
+                     'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
+                     'traffic_source': traffic_src,
                      'kernel': 'swe_stage_kernel', 'avg_launch_ms': ms_kernel,
                      'algorithmic_bytes_per_launch': BYTES_PER_ELEMENT_UPDATE*n},
     }
@@ -118,7 +135,7 @@ def main():
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get('THETIS_AMD_FORCE_DIST'):   # env: exercise the N>1 code path on one GPU
         from thetis_amd.distributed import run_distributed_bench
         run_distributed_bench(args, build_case, DT, BYTES_PER_ELEMENT_UPDATE, HBM_PEAK_GBS)
     else:

@@ -173,6 +173,10 @@ int  swe2d_tracer_diagnostics(swe2d_handle *h, int tracer_id, double out[4]);
  * then every tracer with the updated velocity, then the limiter (once per step) */
 int  swe2d_advance_coupled(swe2d_handle *h, int n_steps, int tracer_only, int use_limiter);
 
+/* profiling aid: n_times streaming copies of the 9 state planes (9*stride doubles read + written, 8 B per lane) to calibrate
+ * the FETCH_SIZE / WRITE_SIZE counters on a known byte count; does not change the state */
+int  swe2d_debug_calibration_copy(swe2d_handle *h, int n_times);
+
 /* ---- multi-GPU plumbing (one process per GPU; the exchange itself is done by the host with RCCL) ----
  * send_cells: local ids of owned cells whose state peers need, grouped by peer; the n_cells-n_owned ghost cells are
  * stored in the order the peers' send lists deliver them.  Buffers are device pointers owned by the caller

@@ -907,6 +907,22 @@ int swe2d_tracer_diagnostics(swe2d_handle *hh, int id, double out[4])
     return SWE2D_OK;
 }
 
+int swe2d_debug_calibration_copy(swe2d_handle *hh, int n_times)
+{
+    Handle *h = H(hh);
+    if (!h || n_times < 0) return SWE2D_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t n = 9*h->stride;
+    for (int i = 0; i < n_times; i++) {
+        // buffer C is dead between steps: copying A -> C does not disturb the state
+        hipLaunchKernelGGL(swe_calibration_copy, dim3((unsigned)((n + SWE_BLOCK - 1)/SWE_BLOCK)), dim3(SWE_BLOCK), 0, h->stream,
+                           h->state[0], h->state[2], n);
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWE2D_OK;
+}
+
 int swe2d_advance_coupled(swe2d_handle *hh, int n_steps, int tracer_only, int use_limiter)
 {
     Handle *h = H(hh);

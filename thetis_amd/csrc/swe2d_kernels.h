@@ -803,3 +803,11 @@ __global__ void swe_planes_to_nodal(const double *planes, double *nodal, size_t 
     if (k >= n) return;
     for (int i = 0; i < 3; i++) nodal[3*(size_t)k + i] = planes[(size_t)i*stride + k];
 }
+
+// PMC calibration aid (MI355X_MICROARCH.md section HBM: "calibrate on a known byte count in your own access pattern"):
+// streams n doubles per plane with the same 8-B/lane coalesced loads and stores the stage kernel uses.
+__global__ __launch_bounds__(SWE_BLOCK) void swe_calibration_copy(const double *src, double *dst, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x*SWE_BLOCK + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}

@@ -193,23 +193,30 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     t = float(tt.item())
     d1 = solver.diagnostics()
-    ok = bool(np.isfinite(d1).all()) and abs(d1[2] - d0[2])/d0[2] < 1e-10
+    ok = bool(np.isfinite(d1).all() and abs(d1[2] - d0[2])/d0[2] < 1e-10)
+    hip_graph = bool(solver.graph is not None)
+    out = None
     if rank == 0:
         value = n_total*3.0*args.steps/t
         per_gpu_bytes = bytes_per_update*n_total/world
         out = {
             'metric': 'DG element-updates/sec, 2D SWE DG-P1 SSPRK33',
-            'value': value, 'unit': 'element-updates/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3*t/args.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'value': float(value), 'unit': 'element-updates/s', 'n_gpus': int(world), 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': float(1e3*t/args.steps), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'BASELINE cfg3: the cfg2 1M-triangle channel strip-partitioned along x over {:d} GPUs, '
                                    'RCCL facet-halo exchange per stage'.format(world),
-                       'n_cells': n_total, 'parallelism': 'dd{:d} (domain decomposition, 1-cell halo)'.format(world),
-                       'hip_graph': solver.graph is not None, 'volume_conserved': ok},
-            'roofline': {'bound': 'hbm', 'achieved': per_gpu_bytes*3*args.steps/t/1e9, 'peak': hbm_peak, 'unit': 'GB/s',
-                         'frac': per_gpu_bytes*3*args.steps/t/1e9/hbm_peak, 'traffic': None,
+                       'n_cells': int(n_total), 'parallelism': 'dd{:d} (domain decomposition, 1-cell halo)'.format(world),
+                       'hip_graph': hip_graph, 'volume_conserved': ok},
+            'roofline': {'bound': 'hbm', 'achieved': float(per_gpu_bytes*3*args.steps/t/1e9), 'peak': hbm_peak, 'unit': 'GB/s',
+                         'frac': float(per_gpu_bytes*3*args.steps/t/1e9/hbm_peak), 'traffic': None,
                          'note': 'per GPU, algorithmic bytes over wall time per stage (includes halo exchange); '
                                  'kernel-only figure is measured at N=1'},
         }
-        print(json.dumps(out))
+    # RCCL writes its version banner to stdout: tear the communicator down first so that the JSON is the LAST stdout line
+    solver.dev.close()
     dist.destroy_process_group()
+    if rank == 0:
+        import sys
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)

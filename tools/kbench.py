@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--order', default='natural')
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--tag', default='')
+    ap.add_argument('--calibrate', action='store_true', help='also run the PMC calibration copy kernel')
     args = ap.parse_args()
     import bench
     from thetis_amd.device import Swe2dDevice
@@ -53,6 +54,8 @@ def main():
     dev.set_state(uv, eta)
     dev.advance(5)
     dev.synchronize()
+    if args.calibrate:
+        dev._ck(dev.lib.swe2d_debug_calibration_copy(dev.h, 5))
     best = 1e9
     for rep in range(3):
         ms_tot, _ = dev.advance_timed(args.steps, per_launch=False)
