@@ -10,8 +10,14 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)
 
 
+CASE = 'channel'
+
+
 def _case():
-    from helpers import channel_case
+    from helpers import channel_case, delaunay_case
+    if CASE == 'delaunay':
+        mesh, bath, uv, eta = delaunay_case(n_points=600, lx=100e3, ly=60e3, seed=7)
+        return mesh, bath, 0.1*uv, 0.1*eta
     return channel_case(nx=16, ny=6, seed=21, amp_eta=0.3, amp_u=0.2)
 
 
@@ -25,7 +31,9 @@ def _init(rank, world, port):
     return dist
 
 
-def cpu_worker(rank, world, port, n_steps, out_dir, axis):
+def cpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
+    global CASE
+    CASE = case
     """Partition + halo exchange logic of the product, with the oracle's C restatement as the (CPU) compute."""
     import torch
     from oracle.ref_lib import RefSWE
@@ -67,7 +75,9 @@ def cpu_worker(rank, world, port, n_steps, out_dir, axis):
     dist.destroy_process_group()
 
 
-def gpu_worker(rank, world, port, n_steps, out_dir, axis):
+def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
+    global CASE
+    CASE = case
     """The real DistributedSwe2d on ONE GPU shared by both ranks (gloo + host staging stands in for RCCL)."""
     from thetis_amd.distributed import DistributedSwe2d
     from thetis_amd.partition import strip_owner
@@ -86,7 +96,7 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis):
     dist.destroy_process_group()
 
 
-def run_workers(target, world, n_steps, out_dir, axis=0):
+def run_workers(target, world, n_steps, out_dir, axis=0, case='channel'):
     import multiprocessing as mp
     import socket
     s = socket.socket()
@@ -94,7 +104,7 @@ def run_workers(target, world, n_steps, out_dir, axis=0):
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context('spawn')
-    procs = [ctx.Process(target=target, args=(r, world, port, n_steps, out_dir, axis)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, n_steps, out_dir, axis, case)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

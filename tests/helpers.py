@@ -33,3 +33,30 @@ def make_ref(mesh, bath, **kw):
 
 def rel_linf(a, b):
     return float(np.abs(a - b).max()/max(np.abs(b).max(), 1e-300))
+
+
+def delaunay_case(n_points=400, lx=10e3, ly=6e3, seed=0):
+    """Unstructured triangulation of a rectangle (random interior points + regular boundary points), markers 1..4."""
+    from scipy.spatial import Delaunay
+    from thetis_amd.mesh import Mesh2d
+    rng = np.random.default_rng(seed)
+    nb = int(np.sqrt(n_points))
+    bx = np.linspace(0, lx, nb + 1)
+    by = np.linspace(0, ly, nb + 1)
+    bnd = np.concatenate([np.stack([bx, 0*bx], 1), np.stack([bx, 0*bx + ly], 1),
+                          np.stack([0*by[1:-1], by[1:-1]], 1), np.stack([0*by[1:-1] + lx, by[1:-1]], 1)])
+    inner = rng.uniform([0.03*lx, 0.03*ly], [0.97*lx, 0.97*ly], size=(n_points, 2))
+    pts = np.concatenate([bnd, inner])
+    tri = Delaunay(pts)
+    cells = tri.simplices
+    p = pts[cells]
+    area2 = np.abs((p[:, 1, 0] - p[:, 0, 0])*(p[:, 2, 1] - p[:, 0, 1]) - (p[:, 2, 0] - p[:, 0, 0])*(p[:, 1, 1] - p[:, 0, 1]))
+    cells = cells[area2 > 1e-9*lx*ly]                       # drop degenerate slivers on the straight boundary
+    mesh = Mesh2d(pts, cells, marker_fn=_rect_marker_fn(lx, ly))
+    mesh.lx, mesh.ly = lx, ly
+    x, y = mesh.vertex_xy.T
+    bath = 15.0 + 5.0*np.sin(x/lx*3.0)*np.cos(y/ly*2.0)
+    n = mesh.num_cells
+    uv = 0.3*rng.normal(size=(n, 3, 2))
+    eta = 0.3*rng.normal(size=(n, 3))
+    return mesh, bath, uv, eta

@@ -91,3 +91,16 @@ def test_hip_graph_capture_single_rank(hip_lib):
     assert np.array_equal(u, ref_state[0]) and np.array_equal(e, ref_state[1])
     dev.set_stream(None)
     dev.close()
+
+
+def test_gloo_unstructured_partition_equals_global(tmp_path, ref_so):
+    import dist_worker
+    dist_worker.CASE = 'delaunay'
+    try:
+        mesh, bath, uv, eta = dist_worker._case()
+        run_workers(cpu_worker, 3, 2, str(tmp_path), axis=0, case='delaunay')
+        u_p, e_p, _ = gather(str(tmp_path), 3, mesh.num_cells)
+    finally:
+        dist_worker.CASE = 'channel'
+    u_g, e_g = make_ref(mesh, bath).advance(uv, eta, 2.0, 2)
+    assert np.array_equal(u_p, u_g) and np.array_equal(e_p, e_g)
