@@ -69,14 +69,15 @@ typedef enum {
 } swe2d_scalar;
 
 /* Mesh = what FlowSolver2d(mesh2d, bathymetry_2d) receives (thetis/solver2d.py:81-147) flattened to arrays.
- * Triangles only (nodes_per_cell == 3), counter-clockwise.  Local facet f joins local vertices f and (f+1)%3.
+ * Triangles (nodes_per_cell == 3, DG-P1) or parallelogram quadrilaterals (nodes_per_cell == 4, DQ-1), counter-clockwise.
+ * Local facet f joins local vertices f and (f+1)%nodes_per_cell; all [..][3] shapes below read [..][nodes_per_cell].
  * In a multi-GPU partition the first n_owned cells are updated by this handle and cells n_owned..n_cells-1 are
  * ghost cells (one layer, facet-adjacent) whose state arrives through swe2d_halo_*. */
 typedef struct {
     int32_t n_cells;
     int32_t n_owned;                   /* == n_cells on a single device */
     int32_t n_vertices;
-    int32_t nodes_per_cell;            /* 3 */
+    int32_t nodes_per_cell;            /* 3 or 4 */
     const int32_t *cell_vertices;      /* [n_cells][3] */
     const double  *vertex_xy;          /* [n_vertices][2] */
     const int32_t *cell_neighbours;    /* [n_cells][3]  >=0: neighbour cell, <0: -(boundary marker) */
@@ -180,7 +181,7 @@ int  swe2d_debug_calibration_copy(swe2d_handle *h, int n_times);
 /* ---- multi-GPU plumbing (one process per GPU; the exchange itself is done by the host with RCCL) ----
  * send_cells: local ids of owned cells whose state peers need, grouped by peer; the n_cells-n_owned ghost cells are
  * stored in the order the peers' send lists deliver them.  Buffers are device pointers owned by the caller
- * (cell-major: 9 doubles u0 u1 u2 v0 v1 v2 e0 e1 e2 per cell, [n][9], so per-peer segments are contiguous). */
+ * (cell-major: 3k doubles u0..u(k-1) v0.. e0.. per cell, [n][3k], k = nodes_per_cell, so per-peer segments are contiguous). */
 int  swe2d_halo_setup(swe2d_handle *h, int32_t n_send, const int32_t *send_cells);
 int  swe2d_halo_pack(swe2d_handle *h, int i_stage, double *send_buf_dev);          /* state entering stage i */
 int  swe2d_halo_unpack(swe2d_handle *h, int i_stage, const double *recv_buf_dev);

@@ -24,7 +24,7 @@ class _RefStruct(ctypes.Structure):
                 ('manning', ctypes.c_double), ('norm_smoother', ctypes.c_double),
                 ('patm', _dp), ('mom_src', _dp), ('vol_src', _dp),
                 ('n_markers', ctypes.c_int), ('bc_kind', _ip), ('bc_elev', _dp), ('bc_uv', _dp),
-                ('bc_un', _dp), ('bc_flux', _dp), ('bc_len', _dp)]
+                ('bc_un', _dp), ('bc_flux', _dp), ('bc_len', _dp), ('npc', ctypes.c_int)]
 
 
 def build(force=False):
@@ -61,14 +61,16 @@ class RefSWE(object):
         self.lib = load()
         n = cell_xy.shape[0]
         self.n = n
+        npc = cell_xy.shape[1]
+        self.npc = npc
         c = np.ascontiguousarray
         self._keep = dict(
             xy=c(cell_xy, dtype=np.float64), nbr=c(cell_nbr, dtype=np.int32),
             nbf=c(cell_nbr_facet, dtype=np.int8), h=c(h_nodal, dtype=np.float64),
-            coriolis=None if coriolis is None else c(np.broadcast_to(coriolis, (n, 3)), dtype=np.float64),
+            coriolis=None if coriolis is None else c(np.broadcast_to(coriolis, (n, npc)), dtype=np.float64),
             patm=None if atmospheric_pressure is None else c(atmospheric_pressure, dtype=np.float64),
-            mom_src=None if momentum_source is None else c(np.broadcast_to(momentum_source, (n, 3, 2)), dtype=np.float64),
-            vol_src=None if volume_source is None else c(np.broadcast_to(volume_source, (n, 3)), dtype=np.float64))
+            mom_src=None if momentum_source is None else c(np.broadcast_to(momentum_source, (n, npc, 2)), dtype=np.float64),
+            vol_src=None if volume_source is None else c(np.broadcast_to(volume_source, (n, npc)), dtype=np.float64))
         k = self._keep
         nm = 1
         bnd_conditions = bnd_conditions or {}
@@ -104,6 +106,7 @@ class RefSWE(object):
         s.n_markers = nm
         s.bc_kind = _ptr(kind, _ip); s.bc_elev = _ptr(elev); s.bc_uv = _ptr(uvb); s.bc_un = _ptr(un)
         s.bc_flux = _ptr(flux); s.bc_len = _ptr(blen)
+        s.npc = npc
         self.s = s
 
     def tendency(self, uv, eta, dt):
@@ -115,7 +118,7 @@ class RefSWE(object):
     def advance(self, uv, eta, dt, n_steps):
         """n_steps SSPRK33 steps; returns new (uv, eta)."""
         uv = np.array(uv, dtype=np.float64, order='C'); eta = np.array(eta, dtype=np.float64, order='C')
-        work = np.empty(18*self.n)
+        work = np.empty(6*self.npc*self.n)
         self.lib.swe2d_ref_advance(ctypes.byref(self.s), _ptr(uv), _ptr(eta), dt, n_steps, _ptr(work))
         return uv, eta
 

@@ -20,7 +20,9 @@
  *   MomentumSourceTerm :805-811  ContinuitySourceTerm :825-831
  *   mass inverse equation.py:105 (M_K = A/12 [[2,1,1],[1,2,1],[1,1,2]])   SSPRK33 rungekutta.py:326-347,908-946
  *
- * Data layout: cell-major AoS like the numpy oracle: uv[N][3][2], eta[N][3], xy[N][3][2], h[N][3].
+ * Data layout: cell-major AoS like the numpy oracle: uv[N][k][2], eta[N][k], xy[N][k][2], h[N][k], k = npc.
+ * Quadrilaterals (k = 4, parallelograms): bilinear basis on the unit square, nodes counter-clockwise from (0,0);
+ * cell integrals by the 2 x 2 Gauss-Legendre rule, M^-1 = (1/A) m^-1 (x) m^-1 with m^-1 = [[4,-2],[-2,4]].
  */
 #include <math.h>
 #include <stdlib.h>
@@ -62,6 +64,7 @@ typedef struct {
     const double *bc_un;       /* per marker                                           */
     const double *bc_flux;     /* per marker                                           */
     const double *bc_len;      /* per marker total boundary length                     */
+    int npc;                   /* nodes per cell: 3 (DG-P1 triangles) or 4 (DQ-1 parallelograms) */
 } swe2d_ref_t;
 
 static const double GL_XI[2] = {0.21132486540518713, 0.78867513459481287};
@@ -89,28 +92,88 @@ static inline double int2(double A, const double a[3], const double b[3])
     return A/12.0*(sa*sb + a[0]*b[0] + a[1]*b[1] + a[2]*b[2]);
 }
 
+/* cell integrals of a parallelogram (DQ-1), 2 x 2 Gauss-Legendre; returns the area */
+static double quad_cell_terms(const swe2d_ref_t *m, int k, const double *p, const double u[4], const double v[4],
+                              const double e[4], const double H[4], double bu[4], double bv[4], double be[4])
+{
+    const double g = m->g;
+    const double ax = p[2] - p[0], ay = p[3] - p[1];          /* a = p1 - p0 */
+    const double bx = p[6] - p[0], by = p[7] - p[1];          /* b = p3 - p0 */
+    const double A = ax*by - ay*bx;
+    const double xix = by/A, xiy = -bx/A, zex = -ay/A, zey = ax/A;     /* grad xi, grad zeta */
+    const double *cor = m->coriolis ? m->coriolis + 4*(size_t)k : 0;
+    const double *pa = m->patm ? m->patm + 4*(size_t)k : 0;
+    const double *ms = m->mom_src ? m->mom_src + 8*(size_t)k : 0;
+    const double *vs = m->vol_src ? m->vol_src + 4*(size_t)k : 0;
+    for (int qi = 0; qi < 2; qi++) for (int qz = 0; qz < 2; qz++) {
+        const double xi = GL_XI[qi], ze = GL_XI[qz], w = 0.25*A;
+        const double phi[4] = {(1 - xi)*(1 - ze), xi*(1 - ze), xi*ze, (1 - xi)*ze};
+        const double dxi[4] = {-(1 - ze), (1 - ze), ze, -ze};
+        const double dze[4] = {-(1 - xi), -xi, xi, (1 - xi)};
+        double gx[4], gy[4], uq = 0, vq = 0, eq = 0, Hq = 0, divu = 0;
+        for (int i = 0; i < 4; i++) {
+            gx[i] = dxi[i]*xix + dze[i]*zex;
+            gy[i] = dxi[i]*xiy + dze[i]*zey;
+            uq += phi[i]*u[i]; vq += phi[i]*v[i]; eq += phi[i]*e[i]; Hq += phi[i]*H[i];
+            divu += gx[i]*u[i] + gy[i]*v[i];
+        }
+        double corq = 0, gpx = 0, gpy = 0, sx = 0, sy = 0, sv = 0;
+        for (int i = 0; i < 4; i++) {
+            if (cor) corq += phi[i]*cor[i];
+            if (pa) { gpx += gx[i]*pa[i]; gpy += gy[i]*pa[i]; }
+            if (ms) { sx += phi[i]*ms[2*i]; sy += phi[i]*ms[2*i + 1]; }
+            if (vs) sv += phi[i]*vs[i];
+        }
+        double drag = 0;
+        if (m->quad_drag >= 0 || m->manning >= 0) {
+            const double cd = (m->manning >= 0) ? g*m->manning*m->manning/cbrt(Hq) : m->quad_drag;
+            drag = cd*sqrt(uq*uq + vq*vq + m->norm_smoother*m->norm_smoother)/Hq;
+        }
+        if (m->linear_drag >= 0) drag += m->linear_drag;
+        for (int i = 0; i < 4; i++) {
+            double fu = g*eq*gx[i], fv = g*eq*gy[i];                              /* :361 */
+            if (m->nonlinear) {                                                   /* :478 */
+                const double adv = phi[i]*divu + uq*gx[i] + vq*gy[i];
+                fu += adv*uq; fv += adv*vq;
+            }
+            fu += corq*vq*phi[i]; fv -= corq*uq*phi[i];                           /* :632-633 */
+            fu -= drag*phi[i]*uq; fv -= drag*phi[i]*vq;                           /* :700, :738 */
+            fu -= gpx/1000.0*phi[i]; fv -= gpy/1000.0*phi[i];                     /* :662 */
+            fu += sx*phi[i]; fv += sy*phi[i];                                     /* :810 */
+            bu[i] += w*fu; bv[i] += w*fv;
+            be[i] += w*(Hq*(gx[i]*uq + gy[i]*vq) + sv*phi[i]);                    /* :422, :830 */
+        }
+    }
+    return A;
+}
+
 /* k = M^-1 (dt R(U)) for one cell */
 static void cell_tendency(const swe2d_ref_t *m, int k, const double *uv, const double *eta, double dt,
                           double *k_uv, double *k_eta)
 {
     const double g = m->g;
-    const double *p = m->xy + 6*(size_t)k;
-    const double *hk = m->h + 3*(size_t)k;
-    double u[3], v[3], e[3], H[3];
-    for (int i = 0; i < 3; i++) {
-        u[i] = uv[6*(size_t)k + 2*i];
-        v[i] = uv[6*(size_t)k + 2*i + 1];
-        e[i] = eta[3*(size_t)k + i];
+    const int npc = m->npc;
+    const double *p = m->xy + 2*(size_t)npc*k;
+    const double *hk = m->h + (size_t)npc*k;
+    double u[4], v[4], e[4], H[4];
+    for (int i = 0; i < npc; i++) {
+        u[i] = uv[2*(size_t)npc*k + 2*i];
+        v[i] = uv[2*(size_t)npc*k + 2*i + 1];
+        e[i] = eta[(size_t)npc*k + i];
         H[i] = total_depth(m, hk[i], e[i]);
     }
-    const double A = 0.5*((p[2] - p[0])*(p[5] - p[1]) - (p[4] - p[0])*(p[3] - p[1]));
+    double bu[4] = {0, 0, 0, 0}, bv[4] = {0, 0, 0, 0}, be[4] = {0, 0, 0, 0};
+    double A;
+    if (npc == 4) {
+        A = quad_cell_terms(m, k, p, u, v, e, H, bu, bv, be);
+    } else {
+    A = 0.5*((p[2] - p[0])*(p[5] - p[1]) - (p[4] - p[0])*(p[3] - p[1]));
     double gx[3], gy[3];       /* grad phi_i */
     for (int i = 0; i < 3; i++) {
         int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
         gx[i] = (p[2*i1 + 1] - p[2*i2 + 1])/(2*A);
         gy[i] = (p[2*i2] - p[2*i1])/(2*A);
     }
-    double bu[3] = {0, 0, 0}, bv[3] = {0, 0, 0}, be[3] = {0, 0, 0};
 
     /* ---- cell integrals */
     const double esum = e[0] + e[1] + e[2];
@@ -178,20 +241,23 @@ static void cell_tendency(const swe2d_ref_t *m, int k, const double *uv, const d
         for (int i = 0; i < 3; i++) be[i] += A/12.0*(ss + s[i]);
     }
 
+    }   /* npc == 3 */
+
     /* ---- facets */
-    for (int f = 0; f < 3; f++) {
-        const int a = f, b = (f + 1) % 3;
+    for (int f = 0; f < npc; f++) {
+        const int a = f, b = (f + 1) % npc;
         const double dx = p[2*b] - p[2*a], dy = p[2*b + 1] - p[2*a + 1];
         const double len = sqrt(dx*dx + dy*dy);
         const double nx = dy/len, ny = -dx/len;
-        const int nb = m->nbr[3*(size_t)k + f];
+        const int nb = m->nbr[(size_t)npc*k + f];
         double ua_n = 0, ub_n = 0, va_n = 0, vb_n = 0, ea_n = 0, eb_n = 0;
         int kind = BC_CLOSED, marker = 0;
         if (nb >= 0) {
-            const int f2 = m->nbf[3*(size_t)k + f];
-            const int na = (f2 + 1) % 3, nbb = f2;      /* neighbour traverses the facet backwards */
-            ua_n = uv[6*(size_t)nb + 2*na];   va_n = uv[6*(size_t)nb + 2*na + 1];   ea_n = eta[3*(size_t)nb + na];
-            ub_n = uv[6*(size_t)nb + 2*nbb];  vb_n = uv[6*(size_t)nb + 2*nbb + 1];  eb_n = eta[3*(size_t)nb + nbb];
+            const int f2 = m->nbf[(size_t)npc*k + f];
+            const int na = (f2 + 1) % npc, nbb = f2;      /* neighbour traverses the facet backwards */
+            const size_t o = 2*(size_t)npc*nb, oe = (size_t)npc*nb;
+            ua_n = uv[o + 2*na];   va_n = uv[o + 2*na + 1];   ea_n = eta[oe + na];
+            ub_n = uv[o + 2*nbb];  vb_n = uv[o + 2*nbb + 1];  eb_n = eta[oe + nbb];
         } else {
             marker = -nb;
             if (marker < m->n_markers && m->bc_kind) kind = m->bc_kind[marker];
@@ -260,6 +326,17 @@ static void cell_tendency(const swe2d_ref_t *m, int k, const double *uv, const d
             be[a] -= w*xa*fe; be[b] -= w*xb*fe;
         }
     }
+    if (npc == 4) {
+        /* (M^-1 b)_i = (16 b_i - 8 b_{i+1} - 8 b_{i-1} + 4 b_{i+2})/A  (tensor of the 1D inverse [[4,-2],[-2,4]]) */
+        const double s4 = dt/A;
+        for (int i = 0; i < 4; i++) {
+            const int n1 = (i + 1) % 4, n2 = (i + 2) % 4, n3 = (i + 3) % 4;
+            k_uv[8*(size_t)k + 2*i] = s4*(16.0*bu[i] - 8.0*bu[n1] - 8.0*bu[n3] + 4.0*bu[n2]);
+            k_uv[8*(size_t)k + 2*i + 1] = s4*(16.0*bv[i] - 8.0*bv[n1] - 8.0*bv[n3] + 4.0*bv[n2]);
+            k_eta[4*(size_t)k + i] = s4*(16.0*be[i] - 8.0*be[n1] - 8.0*be[n3] + 4.0*be[n2]);
+        }
+        return;
+    }
     /* ---- mass inverse: (M^-1 b)_i = 3/A (4 b_i - sum b) */
     const double s = 3.0*dt/A;
     const double su = bu[0] + bu[1] + bu[2], sv = bv[0] + bv[1] + bv[2], se = be[0] + be[1] + be[2];
@@ -283,31 +360,31 @@ void swe2d_ref_tendency(const swe2d_ref_t *m, const double *uv, const double *et
  * order of rungekutta.py:911-913: tendency*beta + sum_j stage_sol[j]*alpha.  Constant-in-time forcing only. */
 void swe2d_ref_advance(const swe2d_ref_t *m, double *uv, double *eta, double dt, int n_steps, double *work)
 {
-    const size_t n = (size_t)m->n_cells;
-    double *u0 = work, *e0 = u0 + 6*n;
-    double *ku = e0 + 3*n, *ke = ku + 6*n;
+    const size_t nu = 2*(size_t)m->npc*(size_t)m->n_cells, ne = (size_t)m->npc*(size_t)m->n_cells;
+    double *u0 = work, *e0 = u0 + nu;
+    double *ku = e0 + ne, *ke = ku + nu;
     static const double A30 = 0.33333333333333337, A32 = 0.6666666666666666, B32 = 0.6666666666666666;
     for (int it = 0; it < n_steps; it++) {
-        memcpy(u0, uv, 6*n*sizeof(double));
-        memcpy(e0, eta, 3*n*sizeof(double));
+        memcpy(u0, uv, nu*sizeof(double));
+        memcpy(e0, eta, ne*sizeof(double));
         /* stage 0: U1 = k*1 + U0*1 */
         swe2d_ref_tendency(m, uv, eta, dt, ku, ke);
 #pragma omp parallel for schedule(static)
-        for (long i = 0; i < (long)(6*n); i++) uv[i] = ku[i]*1.0 + u0[i]*1.0;
+        for (long i = 0; i < (long)nu; i++) uv[i] = ku[i]*1.0 + u0[i]*1.0;
 #pragma omp parallel for schedule(static)
-        for (long i = 0; i < (long)(3*n); i++) eta[i] = ke[i]*1.0 + e0[i]*1.0;
+        for (long i = 0; i < (long)ne; i++) eta[i] = ke[i]*1.0 + e0[i]*1.0;
         /* stage 1: U2 = k*0.25 + U0*0.75 + U1*0.25   (U1 is the current solution) */
         swe2d_ref_tendency(m, uv, eta, dt, ku, ke);
 #pragma omp parallel for schedule(static)
-        for (long i = 0; i < (long)(6*n); i++) uv[i] = ku[i]*0.25 + u0[i]*0.75 + uv[i]*0.25;
+        for (long i = 0; i < (long)nu; i++) uv[i] = ku[i]*0.25 + u0[i]*0.75 + uv[i]*0.25;
 #pragma omp parallel for schedule(static)
-        for (long i = 0; i < (long)(3*n); i++) eta[i] = ke[i]*0.25 + e0[i]*0.75 + eta[i]*0.25;
+        for (long i = 0; i < (long)ne; i++) eta[i] = ke[i]*0.25 + e0[i]*0.75 + eta[i]*0.25;
         /* stage 2: U3 = k*B32 + U0*A30 + U1*0 + U2*A32 */
         swe2d_ref_tendency(m, uv, eta, dt, ku, ke);
 #pragma omp parallel for schedule(static)
-        for (long i = 0; i < (long)(6*n); i++) uv[i] = ku[i]*B32 + u0[i]*A30 + uv[i]*A32;
+        for (long i = 0; i < (long)nu; i++) uv[i] = ku[i]*B32 + u0[i]*A30 + uv[i]*A32;
 #pragma omp parallel for schedule(static)
-        for (long i = 0; i < (long)(3*n); i++) eta[i] = ke[i]*B32 + e0[i]*A30 + eta[i]*A32;
+        for (long i = 0; i < (long)ne; i++) eta[i] = ke[i]*B32 + e0[i]*A30 + eta[i]*A32;
     }
 }
 

@@ -14,7 +14,9 @@ CASE = 'channel'
 
 
 def _case():
-    from helpers import channel_case, delaunay_case
+    from helpers import channel_case, delaunay_case, quad_case
+    if CASE == 'quad':
+        return quad_case(nx=16, ny=6, seed=21, amp_eta=0.3, amp_u=0.2)
     if CASE == 'delaunay':
         mesh, bath, uv, eta = delaunay_case(n_points=600, lx=100e3, ly=60e3, seed=7)
         return mesh, bath, 0.1*uv, 0.1*eta
@@ -117,8 +119,9 @@ def run_workers(target, world, n_steps, out_dir, axis=0, case='channel'):
 
 
 def gather(out_dir, world, n_cells):
-    uv = np.full((n_cells, 3, 2), np.nan)
-    eta = np.full((n_cells, 3), np.nan)
+    k = np.load(os.path.join(out_dir, 'rank0.npz'))['eta'].shape[1]
+    uv = np.full((n_cells, k, 2), np.nan)
+    eta = np.full((n_cells, k), np.nan)
     extra = []
     for r in range(world):
         d = np.load(os.path.join(out_dir, 'rank{:d}.npz'.format(r)))

@@ -60,3 +60,35 @@ def delaunay_case(n_points=400, lx=10e3, ly=6e3, seed=0):
     uv = 0.3*rng.normal(size=(n, 3, 2))
     eta = 0.3*rng.normal(size=(n, 3))
     return mesh, bath, uv, eta
+
+
+def quad_case(nx=10, ny=6, lx=100e3, ly=30e3, seed=0, amp_eta=0.5, amp_u=0.5, skew=0.0):
+    """Quadrilateral (parallelogram) mesh; ``skew`` shears the grid so that cells are not axis-aligned rectangles."""
+    mesh = RectangleMesh(nx, ny, lx, ly, quadrilateral=True)
+    if skew:
+        xy = mesh.vertex_xy.copy()
+        xy[:, 0] += skew*xy[:, 1]
+        from thetis_amd.mesh import Mesh2d
+        sheared = Mesh2d(xy, mesh.cells, marker_fn=None)
+        sheared.cell_nbr = mesh.cell_nbr            # same topology and markers as the rectangle grid
+        sheared.boundary_len = sheared._boundary_length()
+        sheared.lx, sheared.ly = lx, ly
+        mesh = sheared
+    x, y = mesh.vertex_xy.T
+    bath = 20.0 - 15.0*x/(lx + abs(skew)*ly) + 2.0*np.sin(y/5000.0)
+    rng = np.random.default_rng(seed)
+    n = mesh.num_cells
+    uv = amp_u*rng.normal(size=(n, 4, 2))
+    eta = amp_eta*rng.normal(size=(n, 4))
+    return mesh, bath, uv, eta
+
+
+def make_oracle_generic(mesh, bath, **kw):
+    """Oracle on a mesh whose markers are already in ``mesh.cell_nbr`` (no marker function needed)."""
+    from oracle.swe2d_oracle import SWEOracle
+    orc = SWEOracle(mesh.vertex_xy, mesh.cells, bath, topo_vertex=mesh.topo_vertex, **kw)
+    k = mesh.cells.shape[1]
+    K, a, _ = orc.ext_facets.T
+    orc.ext_marker = -mesh.cell_nbr[K, a]            # facet f starts at local node f
+    orc.boundary_len = dict(mesh.boundary_len)
+    return orc

@@ -1,0 +1,185 @@
+"""DQ-1 on parallelogram quadrilaterals: oracle pins on CPU, HIP parity on GPU (BASELINE cfg 1(ii), demo_2d_tracer mesh)."""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import make_oracle_generic, make_ref, quad_case, rel_linf
+from thetis_amd import Constant, Function, RectangleMesh, get_functionspace, solver2d
+
+_BCS = {1: {'elev': 0.3}, 2: {'un': 0.2}, 3: {'flux': 1e4, 'elev': 0.1}, 4: {'uv': (0.1, -0.2)}}
+
+
+def _cases(mesh, n):
+    x, y = mesh.vertex_xy.T
+    rng = np.random.default_rng(9)
+    return {
+        'default': {}, 'linear': dict(use_nonlinear_equations=False), 'no_lf': dict(use_lax_friedrichs_velocity=False),
+        'sources': dict(coriolis=1e-4*(1 + y/30e3), linear_drag_coefficient=1e-3,
+                        atmospheric_pressure=1e5 + 300*np.sin(x/2e4), momentum_source=1e-3*rng.normal(size=(n, 4, 2)),
+                        volume_source=1e-3*rng.normal(size=(n, 4))),
+        'manning': dict(manning_drag_coefficient=0.02),
+        'quad_drag': dict(quadratic_drag_coefficient=0.0025, norm_smoother=0.1),
+        'bcs': dict(bnd_conditions=_BCS),
+    }
+
+
+def test_quad_mesh_connectivity():
+    m = RectangleMesh(7, 4, 14.0, 4.0, quadrilateral=True)
+    assert m.num_cells == 28 and m.nodes_per_cell == 4 and m.boundary_len == {1: 4.0, 2: 4.0, 3: 14.0, 4: 14.0}
+    assert np.allclose(m.cell_areas(), 2.0)
+    for c in range(m.num_cells):
+        for f in range(4):
+            nb = m.cell_nbr[c, f]
+            if nb >= 0:
+                f2 = m.cell_nbr_facet[c, f]
+                assert m.cell_nbr[nb, f2] == c
+                assert m.cells[c, f] == m.cells[nb, (f2 + 1) % 4] and m.cells[c, (f + 1) % 4] == m.cells[nb, f2]
+    with pytest.raises(NotImplementedError):
+        from thetis_amd.mesh import Mesh2d
+        Mesh2d(np.array([[0, 0], [1, 0], [1.2, 1.1], [0, 1.0]]), np.array([[0, 1, 2, 3]]))      # not a parallelogram
+
+
+def test_quad_oracle_invariants():
+    mesh, bath, uv, eta = quad_case(skew=0.3)
+    orc = make_oracle_generic(mesh, bath)
+    ru, re = orc.residual(np.zeros_like(uv), np.full_like(eta, 0.3))
+    assert np.abs(ru).max() < 1e-9 and np.abs(re).max() == 0.0                 # lake at rest
+    ru, re = orc.residual(uv, eta)
+    assert abs(re.sum()) < 1e-12*np.abs(re).sum()                              # closed domain conserves volume
+    # exact integration of the polynomial integrands: 2x2 and 3x3 tensor Gauss rules give the same residual
+    from oracle.swe2d_oracle import SWEOracle
+    o3 = SWEOracle(mesh.vertex_xy, mesh.cells, bath, quad_rule_points=3)
+    ru3, re3 = o3.residual(uv, eta)
+    assert rel_linf(ru3, ru) < 1e-13 and rel_linf(re3, re) < 1e-13
+    # constant tracer stays constant; limiter keeps x-linear fields and conserves mass
+    T = np.full((mesh.num_cells, 4), 4.5)
+    assert np.abs(orc.tracer_residual(T, uv, eta)).max() < 1e-9
+    u1, e1 = orc.ssprk33_step(uv, eta, 2.0)
+    assert abs(orc.volume(e1) - orc.volume(eta))/orc.volume(eta) < 1e-13
+
+
+@pytest.mark.parametrize('case', ['default', 'linear', 'no_lf', 'sources', 'manning', 'quad_drag', 'bcs'])
+@pytest.mark.parametrize('skew', [0.0, 0.3])
+def test_quad_numpy_and_c_restatements_agree(ref_so, case, skew):
+    mesh, bath, uv, eta = quad_case(skew=skew, seed=1)
+    kw = _cases(mesh, mesh.num_cells)[case]
+    if case in ('manning', 'quad_drag'):
+        eta = np.abs(eta)
+    orc = make_oracle_generic(mesh, bath, **kw)
+    ref = make_ref(mesh, bath, **kw)
+    ku, ke = orc.tendency(uv, eta, 3.0)
+    ku2, ke2 = ref.tendency(uv, eta, 3.0)
+    assert rel_linf(ku2, ku) < 1e-13 and rel_linf(ke2, ke) < 1e-13
+    u1, e1 = orc.ssprk33_step(uv, eta, 3.0)
+    u2, e2 = ref.advance(uv, eta, 3.0, 1)
+    assert rel_linf(u2, u1) < 1e-13 and rel_linf(e2, e1) < 1e-13
+
+
+def test_quad_standing_wave_second_order(ref_so):
+    """Linear standing wave of test/swe2d/test_standing_wave.py on quadrilaterals: order > 2*0.8 in space."""
+    errs = []
+    for nx in (20, 40, 80):
+        lx, ly, depth = 5e3, 1e3, 100.0
+        mesh = RectangleMesh(nx, 1, lx, ly, quadrilateral=True)
+        bath = np.full(mesh.num_vertices, depth)
+        period = 2*lx/math.sqrt(9.81*depth)
+        n_steps = 40*nx
+        eta0 = np.cos(np.pi*mesh.cell_xy()[:, :, 0]/lx)
+        ref = make_ref(mesh, bath, use_nonlinear_equations=False)
+        uv, eta = ref.advance(np.zeros((mesh.num_cells, 4, 2)), eta0, period/n_steps, n_steps)
+        orc = make_oracle_generic(mesh, bath)
+        errs.append(orc.l2_norm(eta - eta0)/math.sqrt(lx*ly))
+    rates = [math.log(errs[i]/errs[i + 1], 2) for i in range(2)]
+    assert all(r > 1.6 for r in rates), (errs, rates)
+    assert errs[-1] < 1.25e-3
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['default', 'linear', 'no_lf', 'sources', 'manning', 'quad_drag', 'bcs'])
+def test_quad_gpu_tendency_matches_oracle(hip_lib, case):
+    from thetis_amd import _lib
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = quad_case(skew=0.3, seed=1)
+    kw = _cases(mesh, mesh.num_cells)[case]
+    if case in ('manning', 'quad_drag'):
+        eta = np.abs(eta)
+    dt = 3.0
+    orc = make_oracle_generic(mesh, bath, **kw)
+    dev_kw = {k: kw[k] for k in ('use_nonlinear_equations', 'use_lax_friedrichs_velocity') if k in kw}
+    dev = Swe2dDevice(mesh, bath, dt, boundary_len=mesh.boundary_len, **dev_kw)
+    if case == 'sources':
+        dev.set_field(_lib.FIELD_CORIOLIS, kw['coriolis'][mesh.cells])
+        dev.set_field(_lib.FIELD_ATMOSPHERIC_PRESSURE, kw['atmospheric_pressure'][mesh.cells])
+        dev.set_field(_lib.FIELD_MOMENTUM_SOURCE, kw['momentum_source'])
+        dev.set_field(_lib.FIELD_VOLUME_SOURCE, kw['volume_source'])
+        dev.set_scalar(_lib.SCALAR_LINEAR_DRAG, 1e-3)
+    if case == 'manning':
+        dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+    if case == 'quad_drag':
+        dev.set_scalar(_lib.SCALAR_QUADRATIC_DRAG, 0.0025)
+        dev.set_scalar(_lib.SCALAR_NORM_SMOOTHER, 0.1)
+    if case == 'bcs':
+        for m, funcs in _BCS.items():
+            dev.set_bc(m, funcs)
+    dev.set_state(uv, eta)
+    ku, ke = dev.tendency()
+    ku_o, ke_o = orc.tendency(uv, eta, dt)
+    assert rel_linf(ku, ku_o) < 1e-12 and rel_linf(ke, ke_o) < 1e-12
+    uv2, eta2 = dev.get_state()
+    assert np.array_equal(uv2, uv) and np.array_equal(eta2, eta)
+    dev.advance(2)
+    ud, ed = dev.get_state()
+    uo, eo = orc.ssprk33_step(*orc.ssprk33_step(uv, eta, dt), dt)
+    assert rel_linf(ud, uo) < 1e-11 and rel_linf(ed, eo) < 1e-11
+    d = dev.diagnostics()
+    assert math.isclose(d[2], orc.volume(ed), rel_tol=1e-12)
+    assert math.isclose(math.sqrt(d[0]), orc.l2_norm(ed), rel_tol=1e-12)
+    assert math.isclose(math.sqrt(d[1]), orc.l2_norm(ud), rel_tol=1e-12)
+    dev.close()
+
+
+@pytest.mark.gpu
+def test_baseline_cfg1_quad_unit_rectangle(hip_lib, ref_so):
+    """BASELINE.json configs[0] as literally written: 40x25-quad unit rectangle, DG(DQ)-P1, SSPRK33, h = 1, g = 9.81,
+    eta0 = 0.01 cos(pi x), closed, dt = 1e-3, 100 steps (SURVEY.md 8d cfg 1(ii)) through FlowSolver2d."""
+    mesh2d = RectangleMesh(40, 25, 1.0, 1.0, quadrilateral=True)
+    bath = Function(get_functionspace(mesh2d, 'CG', 1)).assign(1.0)
+    s = solver2d.FlowSolver2d(mesh2d, bath)
+    o = s.options
+    o.swe_timestepper_type = 'SSPRK33'
+    o.swe_timestepper_options.use_automatic_timestep = False
+    o.timestep = 1e-3
+    o.simulation_end_time = 0.1
+    o.simulation_export_time = 0.05
+    o.check_volume_conservation_2d = True
+    s.assign_initial_conditions(elev=lambda x, y: 0.01*np.cos(np.pi*x))
+    eta0 = s.fields.elev_2d.cell_node_values().copy()
+    s.iterate()
+    assert s.iteration == 100
+    ref = make_ref(mesh2d, bath.dat.data_ro)
+    u_r, e_r = ref.advance(np.zeros((1000, 4, 2)), eta0, 1e-3, 100)
+    assert rel_linf(s.fields.elev_2d.cell_node_values(), e_r) < 1e-10
+    assert rel_linf(s.fields.uv_2d.cell_node_values(), u_r) < 1e-10
+    vol, rerr = s.callbacks['export']['volume2d']()
+    assert abs(rerr) < 1e-12
+
+
+@pytest.mark.gpu
+def test_quad_two_ranks_on_one_gpu(tmp_path, hip_lib):
+    import dist_worker
+    from thetis_amd.device import Swe2dDevice
+    dist_worker.CASE = 'quad'
+    try:
+        mesh, bath, uv, eta = dist_worker._case()
+        dist_worker.run_workers(dist_worker.gpu_worker, 2, 3, str(tmp_path), axis=0, case='quad')
+        u_p, e_p, _ = dist_worker.gather(str(tmp_path), 2, mesh.num_cells)
+    finally:
+        dist_worker.CASE = 'channel'
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev.set_state(uv, eta)
+    dev.advance(3)
+    u_s, e_s = dev.get_state()
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+    dev.close()

@@ -30,6 +30,7 @@ struct Handle {
     bool own_stream = false;
     hipStream_t my_stream = nullptr;
     int n_cells = 0, n_owned = 0, n_interior = 0, n_vertices = 0;
+    int npc = 3;                                       // nodes per cell: 3 triangles, 4 parallelograms
     size_t stride = 0;
     double *state[3] = {nullptr, nullptr, nullptr};   // A (U0 / step result), B (U1), C (U2)
     int *nbr = nullptr, *cv = nullptr;
@@ -101,6 +102,20 @@ stage_kernel_t pick_kernel(bool nl, bool lf, bool u0, bool src)
     return nl ? pick_lf<true>(lf, u0, src) : pick_lf<false>(lf, u0, src);
 }
 
+template <bool NL, bool LF, bool U0>
+stage_kernel_t pickq_src(bool src)
+{
+    return src ? swe_stage_kernel_quad<NL, LF, U0, true> : swe_stage_kernel_quad<NL, LF, U0, false>;
+}
+template <bool NL, bool LF>
+stage_kernel_t pickq_u0(bool u0, bool src) { return u0 ? pickq_src<NL, LF, true>(src) : pickq_src<NL, LF, false>(src); }
+template <bool NL>
+stage_kernel_t pickq_lf(bool lf, bool u0, bool src) { return lf ? pickq_u0<NL, true>(u0, src) : pickq_u0<NL, false>(u0, src); }
+stage_kernel_t pick_kernel_quad(bool nl, bool lf, bool u0, bool src)
+{
+    return nl ? pickq_lf<true>(lf, u0, src) : pickq_lf<false>(lf, u0, src);
+}
+
 // Launch one stage on cells [c0, c1).  in/out/u0 are state buffer indices.
 int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1)
 {
@@ -128,8 +143,9 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.norm_smoother = h->scalar[SWE2D_SCALAR_NORM_SMOOTHER];
     a.bc = h->bc;
     const bool has_u0 = (a0 != 0.0);
-    stage_kernel_t kern = pick_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0,
-                                      has_u0, has_sources(h));
+    stage_kernel_t kern = (h->npc == 4)
+        ? pick_kernel_quad(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
+        : pick_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h));
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
     // the XCD-chunked block map needs a grid that is a multiple of 8; surplus blocks exit immediately
     const int grid = ((nblocks + 7)/8)*8;
@@ -181,8 +197,8 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
 {
     if (!mesh || !params || !out) return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
-    if (mesh->nodes_per_cell != 3)
-        return fail(nullptr, SWE2D_ERR_UNSUPPORTED, "only triangles (nodes_per_cell == 3) are supported");
+    if (mesh->nodes_per_cell != 3 && mesh->nodes_per_cell != 4)
+        return fail(nullptr, SWE2D_ERR_UNSUPPORTED, "nodes_per_cell must be 3 (triangles) or 4 (parallelograms)");
     if (mesh->n_cells <= 0 || mesh->n_owned <= 0 || mesh->n_owned > mesh->n_cells || mesh->n_vertices <= 0)
         return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "bad mesh sizes");
     if (mesh->n_cells >= (1 << 29))
@@ -203,6 +219,8 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
     h->device = params->device_id;
     h->par = *params;
     const int n = mesh->n_cells, nv = mesh->n_vertices;
+    const int npc = mesh->nodes_per_cell;
+    h->npc = npc;
     h->n_cells = n; h->n_owned = mesh->n_owned; h->n_interior = mesh->n_owned; h->n_vertices = nv;
     h->stride = ((size_t)n + 255)/256*256;
 
@@ -223,21 +241,21 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
     HIP_TRY_C(hipEventCreate(&h->ev1));
     const size_t S = h->stride;
     for (int b = 0; b < 3; b++) {
-        HIP_TRY_C(hipMalloc(&h->state[b], 9*S*sizeof(double)));
-        HIP_TRY_C(hipMemsetAsync(h->state[b], 0, 9*S*sizeof(double), h->stream));
+        HIP_TRY_C(hipMalloc(&h->state[b], 3*(size_t)npc*S*sizeof(double)));
+        HIP_TRY_C(hipMemsetAsync(h->state[b], 0, 3*(size_t)npc*S*sizeof(double), h->stream));
     }
-    HIP_TRY_C(hipMalloc(&h->nbr, 3*S*sizeof(int)));
-    HIP_TRY_C(hipMalloc(&h->cv, 3*S*sizeof(int)));
+    HIP_TRY_C(hipMalloc(&h->nbr, (size_t)npc*S*sizeof(int)));
+    HIP_TRY_C(hipMalloc(&h->cv, (size_t)npc*S*sizeof(int)));
     HIP_TRY_C(hipMalloc(&h->vx, (size_t)nv*sizeof(double)));
     HIP_TRY_C(hipMalloc(&h->vy, (size_t)nv*sizeof(double)));
     HIP_TRY_C(hipMalloc(&h->vh, (size_t)nv*sizeof(double)));
-    HIP_TRY_C(hipMalloc(&h->stage_uv, 6*(size_t)n*sizeof(double)));
-    HIP_TRY_C(hipMalloc(&h->stage_eta, 3*(size_t)n*sizeof(double)));
+    HIP_TRY_C(hipMalloc(&h->stage_uv, 2*(size_t)npc*n*sizeof(double)));
+    HIP_TRY_C(hipMalloc(&h->stage_eta, (size_t)npc*n*sizeof(double)));
     h->n_partial_blocks = (h->n_owned + SWE_BLOCK - 1)/SWE_BLOCK;
     HIP_TRY_C(hipMalloc(&h->partial, 4*(size_t)h->n_partial_blocks*sizeof(double)));
 
     // connectivity -> SoA planes, validated on the way
-    std::vector<int> nbr(3*S, 0), cv(3*S, 0);
+    std::vector<int> nbr((size_t)npc*S, 0), cv((size_t)npc*S, 0);
     std::vector<double> vx(nv), vy(nv), vh(nv);
     double blen[SWE2D_MAX_MARKERS];
     for (int m = 0; m < SWE2D_MAX_MARKERS; m++) blen[m] = 0.0;
@@ -246,21 +264,21 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
         vy[i] = mesh->vertex_xy[2*(size_t)i + 1];
         vh[i] = mesh->bathymetry[i];
     }
-    h->host_cells.assign(mesh->cell_vertices, mesh->cell_vertices + 3*(size_t)n);
-    h->host_nbr.assign(mesh->cell_neighbours, mesh->cell_neighbours + 3*(size_t)n);
+    h->host_cells.assign(mesh->cell_vertices, mesh->cell_vertices + (size_t)npc*n);
+    h->host_nbr.assign(mesh->cell_neighbours, mesh->cell_neighbours + (size_t)npc*n);
     for (int k = 0; k < n; k++) {
-        for (int f = 0; f < 3; f++) {
-            const int vid = mesh->cell_vertices[3*(size_t)k + f];
+        for (int f = 0; f < npc; f++) {
+            const int vid = mesh->cell_vertices[(size_t)npc*k + f];
             if (vid < 0 || vid >= nv) {
                 swe2d_destroy(reinterpret_cast<swe2d_handle *>(h));
                 return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "cell_vertices entry out of range");
             }
             cv[(size_t)f*S + k] = vid;
-            const int nb = mesh->cell_neighbours[3*(size_t)k + f];
+            const int nb = mesh->cell_neighbours[(size_t)npc*k + f];
             int packed;
             if (nb >= 0) {
-                const int f2 = mesh->cell_neighbour_facets[3*(size_t)k + f];
-                if (nb >= n || f2 < 0 || f2 > 2) {
+                const int f2 = mesh->cell_neighbour_facets[(size_t)npc*k + f];
+                if (nb >= n || f2 < 0 || f2 >= npc) {
                     swe2d_destroy(reinterpret_cast<swe2d_handle *>(h));
                     return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "cell_neighbours entry out of range");
                 }
@@ -273,19 +291,27 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
                 }
                 packed = -marker;
                 if (k < mesh->n_owned && marker < SWE2D_MAX_MARKERS) {
-                    const int va = mesh->cell_vertices[3*(size_t)k + f], vb = mesh->cell_vertices[3*(size_t)k + (f + 1) % 3];
+                    const int va = mesh->cell_vertices[(size_t)npc*k + f], vb = mesh->cell_vertices[(size_t)npc*k + (f + 1) % npc];
                     blen[marker] += std::hypot(vx[vb] - vx[va], vy[vb] - vy[va]);
                 }
             }
             nbr[(size_t)f*S + k] = packed;
         }
-        // orientation check
-        const int a = mesh->cell_vertices[3*(size_t)k], b = mesh->cell_vertices[3*(size_t)k + 1],
-                  c = mesh->cell_vertices[3*(size_t)k + 2];
+        // orientation check (and, for quadrilaterals, that the cell is a parallelogram: the kernel assumes an affine map)
+        const int a = mesh->cell_vertices[(size_t)npc*k], b = mesh->cell_vertices[(size_t)npc*k + 1],
+                  c = mesh->cell_vertices[(size_t)npc*k + npc - 1];
         const double area2 = (vx[b] - vx[a])*(vy[c] - vy[a]) - (vx[c] - vx[a])*(vy[b] - vy[a]);
         if (!(area2 > 0.0)) {
             swe2d_destroy(reinterpret_cast<swe2d_handle *>(h));
             return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "cells must be counter-clockwise with positive area");
+        }
+        if (npc == 4) {
+            const int d = mesh->cell_vertices[4*(size_t)k + 2];
+            const double sx = vx[a] - vx[b] + vx[d] - vx[c], sy = vy[a] - vy[b] + vy[d] - vy[c];
+            if (std::fabs(sx) + std::fabs(sy) > 1e-9*std::sqrt(area2)) {
+                swe2d_destroy(reinterpret_cast<swe2d_handle *>(h));
+                return fail(nullptr, SWE2D_ERR_UNSUPPORTED, "quadrilateral cells must be parallelograms");
+            }
         }
     }
     if (mesh->n_owned != mesh->n_cells && !mesh->boundary_len) {
@@ -295,8 +321,8 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
     std::memset(&h->bc, 0, sizeof(h->bc));
     for (int m = 0; m < SWE2D_MAX_MARKERS; m++) h->bc.len[m] = mesh->boundary_len ? mesh->boundary_len[m] : blen[m];
 
-    HIP_TRY_C(hipMemcpyAsync(h->nbr, nbr.data(), 3*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY_C(hipMemcpyAsync(h->cv, cv.data(), 3*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY_C(hipMemcpyAsync(h->nbr, nbr.data(), (size_t)npc*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY_C(hipMemcpyAsync(h->cv, cv.data(), (size_t)npc*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY_C(hipMemcpyAsync(h->vx, vx.data(), (size_t)nv*sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY_C(hipMemcpyAsync(h->vy, vy.data(), (size_t)nv*sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY_C(hipMemcpyAsync(h->vh, vh.data(), (size_t)nv*sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -343,11 +369,11 @@ int swe2d_set_state(swe2d_handle *hh, const double *uv, const double *eta)
     Handle *h = H(hh);
     if (!h || !uv || !eta) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t n = h->n_cells;
-    HIP_TRY(h, hipMemcpyAsync(h->stage_uv, uv, 6*n*sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->stage_eta, eta, 3*n*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const size_t n = (size_t)h->n_cells*h->npc;
+    HIP_TRY(h, hipMemcpyAsync(h->stage_uv, uv, 2*n*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->stage_eta, eta, n*sizeof(double), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(swe_aos_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                       h->stage_uv, h->stage_eta, h->state[0], h->stride, h->n_cells);
+                       h->stage_uv, h->stage_eta, h->state[0], h->stride, h->n_cells, h->npc);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
     return SWE2D_OK;
@@ -358,12 +384,12 @@ int swe2d_get_state(swe2d_handle *hh, double *uv, double *eta)
     Handle *h = H(hh);
     if (!h || !uv || !eta) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t n = h->n_cells;
+    const size_t n = (size_t)h->n_cells*h->npc;
     hipLaunchKernelGGL(swe_planes_to_aos, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                       h->state[0], h->stage_uv, h->stage_eta, h->stride, h->n_cells);
+                       h->state[0], h->stage_uv, h->stage_eta, h->stride, h->n_cells, h->npc);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(uv, h->stage_uv, 6*n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(eta, h->stage_eta, 3*n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(uv, h->stage_uv, 2*n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(eta, h->stage_eta, n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SWE2D_OK;
 }
@@ -411,14 +437,14 @@ int swe2d_set_field(swe2d_handle *hh, int field, const double *nodal)
         return SWE2D_OK;
     }
     if (!h->field[field]) {
-        HIP_TRY(h, hipMalloc(&h->field[field], 3*(size_t)ncomp*h->stride*sizeof(double)));
-        HIP_TRY(h, hipMemsetAsync(h->field[field], 0, 3*(size_t)ncomp*h->stride*sizeof(double), h->stream));
+        HIP_TRY(h, hipMalloc(&h->field[field], (size_t)h->npc*ncomp*h->stride*sizeof(double)));
+        HIP_TRY(h, hipMemsetAsync(h->field[field], 0, (size_t)h->npc*ncomp*h->stride*sizeof(double), h->stream));
     }
-    // stage through stage_uv (6N doubles is enough for either shape)
-    const size_t n = h->n_cells;
-    HIP_TRY(h, hipMemcpyAsync(h->stage_uv, nodal, 3*(size_t)ncomp*n*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // stage through stage_uv (2kN doubles is enough for either shape)
+    const size_t n = (size_t)h->n_cells*h->npc;
+    HIP_TRY(h, hipMemcpyAsync(h->stage_uv, nodal, (size_t)ncomp*n*sizeof(double), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(swe_nodal_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                       h->stage_uv, h->field[field], h->stride, h->n_cells, ncomp);
+                       h->stage_uv, h->field[field], h->stride, h->n_cells, ncomp, h->npc);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SWE2D_OK;
@@ -538,12 +564,12 @@ int swe2d_tendency(swe2d_handle *hh, double *k_uv, double *k_eta)
     // k into buffer B: U_out = 1*k + 0*U0 + 0*U_in
     int rc = launch_stage(h, 0, 0, 1, 0.0, 0.0, 1.0, 0, h->n_owned);
     if (rc) return rc;
-    const size_t n = h->n_cells;
+    const size_t n = (size_t)h->n_cells*h->npc;
     hipLaunchKernelGGL(swe_planes_to_aos, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                       h->state[1], h->stage_uv, h->stage_eta, h->stride, h->n_cells);
+                       h->state[1], h->stage_uv, h->stage_eta, h->stride, h->n_cells, h->npc);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(k_uv, h->stage_uv, 6*n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(k_eta, h->stage_eta, 3*n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(k_uv, h->stage_uv, 2*n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(k_eta, h->stage_eta, n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SWE2D_OK;
 }
@@ -553,8 +579,12 @@ int swe2d_diagnostics(swe2d_handle *hh, double out[4])
     Handle *h = H(hh);
     if (!h || !out) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(swe_diag_kernel, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
-                       h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial);
+    if (h->npc == 4)
+        hipLaunchKernelGGL(swe_diag_kernel_quad, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
+                           h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial);
+    else
+        hipLaunchKernelGGL(swe_diag_kernel, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
+                           h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial);
     HIP_TRY(h, hipGetLastError());
     std::vector<double> part(4*(size_t)h->n_partial_blocks);
     HIP_TRY(h, hipMemcpyAsync(part.data(), h->partial, part.size()*sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -596,8 +626,8 @@ int swe2d_halo_pack(swe2d_handle *hh, int i_stage, double *send_buf_dev)
     if (h->n_send == 0) return SWE2D_OK;
     if (!send_buf_dev) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null send buffer");
     HIP_TRY(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(swe_halo_pack, dim3(grid_for(9*h->n_send)), dim3(256), 0, h->stream,
-                       h->state[i_stage], h->stride, h->send_cells, h->n_send, send_buf_dev);
+    hipLaunchKernelGGL(swe_halo_pack, dim3(grid_for(3*h->npc*h->n_send)), dim3(256), 0, h->stream,
+                       h->state[i_stage], h->stride, h->send_cells, h->n_send, send_buf_dev, 3*h->npc);
     HIP_TRY(h, hipGetLastError());
     return SWE2D_OK;
 }
@@ -610,8 +640,8 @@ int swe2d_halo_unpack(swe2d_handle *hh, int i_stage, const double *recv_buf_dev)
     if (ng == 0) return SWE2D_OK;
     if (!recv_buf_dev) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null recv buffer");
     HIP_TRY(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(swe_halo_unpack, dim3(grid_for(9*ng)), dim3(256), 0, h->stream,
-                       h->state[i_stage], h->stride, h->n_owned, ng, recv_buf_dev);
+    hipLaunchKernelGGL(swe_halo_unpack, dim3(grid_for(3*h->npc*ng)), dim3(256), 0, h->stream,
+                       h->state[i_stage], h->stride, h->n_owned, ng, recv_buf_dev, 3*h->npc);
     HIP_TRY(h, hipGetLastError());
     return SWE2D_OK;
 }
@@ -753,6 +783,7 @@ int swe2d_tracer_add(swe2d_handle *hh, int *tracer_id)
     Handle *h = H(hh);
     if (!h || !tracer_id) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     if (h->n_owned != h->n_cells) return fail(h, SWE2D_ERR_UNSUPPORTED, "tracers are not available on partitions yet");
+    if (h->npc != 3) return fail(h, SWE2D_ERR_UNSUPPORTED, "tracers are implemented for triangles only so far");
     HIP_TRY(h, hipSetDevice(h->device));
     Handle::Tracer t;
     for (int m = 0; m < SWE_MAX_MARKERS; m++) { t.bc_has_value[m] = 0; t.bc_value[m] = 0.0; }
@@ -785,7 +816,7 @@ int swe2d_tracer_set_state(swe2d_handle *hh, int id, const double *nodal)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(h->stage_eta, nodal, 3*(size_t)h->n_cells*sizeof(double), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(swe_nodal_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                       h->stage_eta, h->tracers[id].buf[0], h->stride, h->n_cells, 1);
+                       h->stage_eta, h->tracers[id].buf[0], h->stride, h->n_cells, 1, 3);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SWE2D_OK;
@@ -794,7 +825,7 @@ int swe2d_tracer_set_state(swe2d_handle *hh, int id, const double *nodal)
 static int tracer_read_back(Handle *h, const double *planes, double *nodal)
 {
     hipLaunchKernelGGL(swe_planes_to_nodal, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                       planes, h->stage_eta, h->stride, h->n_cells);
+                       planes, h->stage_eta, h->stride, h->n_cells, 3);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(nodal, h->stage_eta, 3*(size_t)h->n_cells*sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -836,7 +867,7 @@ int swe2d_tracer_set_source(swe2d_handle *hh, int id, const double *nodal)
     if (!t.source) HIP_TRY(h, hipMalloc(&t.source, 3*h->stride*sizeof(double)));
     HIP_TRY(h, hipMemcpyAsync(h->stage_eta, nodal, 3*(size_t)h->n_cells*sizeof(double), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(swe_nodal_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                       h->stage_eta, t.source, h->stride, h->n_cells, 1);
+                       h->stage_eta, t.source, h->stride, h->n_cells, 1, 3);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SWE2D_OK;
@@ -912,7 +943,7 @@ int swe2d_debug_calibration_copy(swe2d_handle *hh, int n_times)
     Handle *h = H(hh);
     if (!h || n_times < 0) return SWE2D_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t n = 9*h->stride;
+    const size_t n = 3*(size_t)h->npc*h->stride;
     for (int i = 0; i < n_times; i++) {
         // buffer C is dead between steps: copying A -> C does not disturb the state
         hipLaunchKernelGGL(swe_calibration_copy, dim3((unsigned)((n + SWE_BLOCK - 1)/SWE_BLOCK)), dim3(SWE_BLOCK), 0, h->stream,

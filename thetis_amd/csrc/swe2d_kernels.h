@@ -467,55 +467,53 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// layout conversion: host (Firedrake-like) AoS  uv[3N][2], eta[3N]  <->  9 SoA planes
-__global__ void swe_aos_to_planes(const double *uv, const double *eta, double *planes, size_t stride, int n)
+// layout conversion: host (Firedrake-like) AoS  uv[kN][2], eta[kN]  <->  3k SoA planes (k = nodes per cell)
+__global__ void swe_aos_to_planes(const double *uv, const double *eta, double *planes, size_t stride, int n, int npc)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        planes[(size_t)i*stride + k] = uv[6*(size_t)k + 2*i];
-        planes[(size_t)(3 + i)*stride + k] = uv[6*(size_t)k + 2*i + 1];
-        planes[(size_t)(6 + i)*stride + k] = eta[3*(size_t)k + i];
+    for (int i = 0; i < npc; i++) {
+        planes[(size_t)i*stride + k] = uv[2*((size_t)npc*k + i)];
+        planes[(size_t)(npc + i)*stride + k] = uv[2*((size_t)npc*k + i) + 1];
+        planes[(size_t)(2*npc + i)*stride + k] = eta[(size_t)npc*k + i];
     }
 }
 
-__global__ void swe_planes_to_aos(const double *planes, double *uv, double *eta, size_t stride, int n)
+__global__ void swe_planes_to_aos(const double *planes, double *uv, double *eta, size_t stride, int n, int npc)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        uv[6*(size_t)k + 2*i] = planes[(size_t)i*stride + k];
-        uv[6*(size_t)k + 2*i + 1] = planes[(size_t)(3 + i)*stride + k];
-        eta[3*(size_t)k + i] = planes[(size_t)(6 + i)*stride + k];
+    for (int i = 0; i < npc; i++) {
+        uv[2*((size_t)npc*k + i)] = planes[(size_t)i*stride + k];
+        uv[2*((size_t)npc*k + i) + 1] = planes[(size_t)(npc + i)*stride + k];
+        eta[(size_t)npc*k + i] = planes[(size_t)(2*npc + i)*stride + k];
     }
 }
 
-// nodal scalar field (3N) -> 3 planes;  vector (3N,2) -> 6 planes (x0 x1 x2 y0 y1 y2)
-__global__ void swe_nodal_to_planes(const double *nodal, double *planes, size_t stride, int n, int ncomp)
+// nodal scalar field (kN) -> k planes;  vector (kN,2) -> 2k planes (x0.. y0..)
+__global__ void swe_nodal_to_planes(const double *nodal, double *planes, size_t stride, int n, int ncomp, int npc)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < npc; i++)
         for (int c = 0; c < ncomp; c++)
-            planes[(size_t)(3*c + i)*stride + k] = nodal[(size_t)ncomp*(3*(size_t)k + i) + c];
+            planes[(size_t)(npc*c + i)*stride + k] = nodal[(size_t)ncomp*((size_t)npc*k + i) + c];
 }
 
-// halo: message layout [n][9] (cell-major), so the per-peer segments of one buffer are contiguous
-__global__ void swe_halo_pack(const double *planes, size_t stride, const int *cells, int n, double *buf)
+// halo: message layout [n][np] (cell-major, np = 3k planes), so the per-peer segments of one buffer are contiguous
+__global__ void swe_halo_pack(const double *planes, size_t stride, const int *cells, int n, double *buf, int np)
 {
     const int t = blockIdx.x*blockDim.x + threadIdx.x;
-    if (t >= 9*n) return;
-    const int j = t/9, q = t - 9*j;
+    if (t >= np*n) return;
+    const int j = t/np, q = t - np*j;
     buf[t] = planes[(size_t)q*stride + cells[j]];
 }
 
-__global__ void swe_halo_unpack(double *planes, size_t stride, int first_ghost, int n, const double *buf)
+__global__ void swe_halo_unpack(double *planes, size_t stride, int first_ghost, int n, const double *buf, int np)
 {
     const int t = blockIdx.x*blockDim.x + threadIdx.x;
-    if (t >= 9*n) return;
-    const int j = t/9, q = t - 9*j;
+    if (t >= np*n) return;
+    const int j = t/np, q = t - np*j;
     planes[(size_t)q*stride + first_ghost + j] = buf[t];
 }
 
@@ -797,11 +795,11 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel(const double
 }
 
 // scalar nodal field (3N) <-> 3 planes
-__global__ void swe_planes_to_nodal(const double *planes, double *nodal, size_t stride, int n)
+__global__ void swe_planes_to_nodal(const double *planes, double *nodal, size_t stride, int n, int npc)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
-    for (int i = 0; i < 3; i++) nodal[3*(size_t)k + i] = planes[(size_t)i*stride + k];
+    for (int i = 0; i < npc; i++) nodal[(size_t)npc*k + i] = planes[(size_t)i*stride + k];
 }
 
 // PMC calibration aid (MI355X_MICROARCH.md section HBM: "calibrate on a known byte count in your own access pattern"):
@@ -810,4 +808,252 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_calibration_copy(const double *
 {
     const size_t i = (size_t)blockIdx.x*SWE_BLOCK + threadIdx.x;
     if (i < n) dst[i] = src[i];
+}
+
+// ===============================================================================================================
+// DQ-1 on parallelogram quadrilaterals (demos/demo_2d_tracer.py:19 mesh type; 'DQ' branch of solver2d.py:319).
+// 12 SoA planes u0..u3 v0..v3 e0..e3; bilinear basis on the unit square, nodes counter-clockwise from (0,0):
+//   x = p0 + xi a + zeta b,  a = p1 - p0,  b = p3 - p0,  detJ = a x b = area,
+//   grad xi = (b_y, -b_x)/A,  grad zeta = (-a_y, a_x)/A.
+// Cell integrals: 2 x 2 Gauss-Legendre (degree 3 per direction, exact for every polynomial integrand of the path);
+// facets: the same 2-point rule and numerical fluxes as the triangles (a facet carries two nodes);
+// mass inverse: (M^-1 b)_i = (16 b_i - 8 b_{i+1} - 8 b_{i-1} + 4 b_{i+2})/A.
+// Algorithmic bytes per cell per stage: 96 read + 96 write (+96 U0 in stages 2,3) + 56 static.
+// ===============================================================================================================
+template <bool NONLIN, bool LF, bool HASU0, bool SRC>
+__global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStageArgs p)
+{
+#ifdef SWE_NO_XCD_MAP
+    const int lb = blockIdx.x;
+#else
+    const int lb = swe_logical_block(blockIdx.x, gridDim.x);
+#endif
+    const int k = p.cell_begin + lb*SWE_BLOCK + (int)threadIdx.x;
+    if (k >= p.cell_end) return;
+    const size_t S = p.stride;
+    const double g = p.g;
+
+    double u[4], v[4], e[4];
+    int nb[4], vid[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        nb[i] = p.nbr[(size_t)i*S + k];
+        vid[i] = p.cv[(size_t)i*S + k];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u[i] = p.uin[(size_t)i*S + k];
+        v[i] = p.uin[(size_t)(4 + i)*S + k];
+        e[i] = p.uin[(size_t)(8 + i)*S + k];
+    }
+    double wu[4], wv[4], we[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        wu[i] = p.a1*u[i];
+        wv[i] = p.a1*v[i];
+        we[i] = p.a1*e[i];
+        if (HASU0) {
+            wu[i] += p.a0*p.u0[(size_t)i*S + k];
+            wv[i] += p.a0*p.u0[(size_t)(4 + i)*S + k];
+            we[i] += p.a0*p.u0[(size_t)(8 + i)*S + k];
+        }
+    }
+    double una[4], unb[4], vna[4], vnb[4], ena[4], enb[4];
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        const int nbf = nb[f];
+        const int kn = nbf >= 0 ? (nbf >> 2) : k;
+        const int f2 = nbf >= 0 ? (nbf & 3) : f;
+        const int na = (f2 + 1) & 3;
+        una[f] = p.uin[(size_t)na*S + kn];
+        unb[f] = p.uin[(size_t)f2*S + kn];
+        vna[f] = p.uin[(size_t)(4 + na)*S + kn];
+        vnb[f] = p.uin[(size_t)(4 + f2)*S + kn];
+        ena[f] = p.uin[(size_t)(8 + na)*S + kn];
+        enb[f] = p.uin[(size_t)(8 + f2)*S + kn];
+    }
+    double px[4], py[4], h[4], H[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        px[i] = p.vx[vid[i]];
+        py[i] = p.vy[vid[i]];
+        h[i] = p.vh[vid[i]];
+        H[i] = NONLIN ? h[i] + e[i] : h[i];
+    }
+    const double ax = px[1] - px[0], ay = py[1] - py[0];
+    const double bx = px[3] - px[0], by = py[3] - py[0];
+    const double A = ax*by - ay*bx;
+    const double rA = swe_rcp(A);
+    // A * grad(xi), A * grad(zeta)
+    const double xix = by, xiy = -bx, zex = -ay, zey = ax;
+
+    double bu[4] = {0.0, 0.0, 0.0, 0.0}, bv[4] = {0.0, 0.0, 0.0, 0.0}, be[4] = {0.0, 0.0, 0.0, 0.0};
+    // ---- cell integrals, 2 x 2 Gauss-Legendre; weights A/4, gradients carry 1/A  ->  factor 1/4 on gradient terms
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) {
+#pragma unroll
+        for (int qz = 0; qz < 2; qz++) {
+            const double xi = qi ? SWE_XI1 : SWE_XI0, ze = qz ? SWE_XI1 : SWE_XI0;
+            const double phi[4] = {(1.0 - xi)*(1.0 - ze), xi*(1.0 - ze), xi*ze, (1.0 - xi)*ze};
+            const double dxi[4] = {-(1.0 - ze), (1.0 - ze), ze, -ze};
+            const double dze[4] = {-(1.0 - xi), -xi, xi, (1.0 - xi)};
+            double gx[4], gy[4];                           // A * grad(phi_i)
+            double uq = 0.0, vq = 0.0, eq = 0.0, Hq = 0.0, D = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                gx[i] = dxi[i]*xix + dze[i]*zex;
+                gy[i] = dxi[i]*xiy + dze[i]*zey;
+                uq += phi[i]*u[i];
+                vq += phi[i]*v[i];
+                eq += phi[i]*e[i];
+                Hq += phi[i]*H[i];
+                D += gx[i]*u[i] + gy[i]*v[i];              // A * div(u)
+            }
+            double cu = 0.0, cv_ = 0.0, ce = 0.0;          // coefficients of phi_i (times A)
+            if (SRC) {
+                double corq = 0.0, gpx = 0.0, gpy = 0.0, sx = 0.0, sy = 0.0, sv = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (p.coriolis) corq += phi[i]*p.coriolis[(size_t)i*S + k];
+                    if (p.patm) {
+                        const double pa = p.patm[(size_t)i*S + k];
+                        gpx += gx[i]*pa;
+                        gpy += gy[i]*pa;
+                    }
+                    if (p.msrc) {
+                        sx += phi[i]*p.msrc[(size_t)i*S + k];
+                        sy += phi[i]*p.msrc[(size_t)(4 + i)*S + k];
+                    }
+                    if (p.vsrc) sv += phi[i]*p.vsrc[(size_t)i*S + k];
+                }
+                double drag = 0.0;
+                if (p.quad_drag >= 0.0 || p.manning >= 0.0) {
+                    const double cd = (p.manning >= 0.0) ? g*p.manning*p.manning/cbrt(Hq) : p.quad_drag;
+                    drag = cd*sqrt(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother)/Hq;
+                }
+                if (p.linear_drag >= 0.0) drag += p.linear_drag;
+                cu = A*(corq*vq - drag*uq + sx) - gpx*(1.0/1000.0);
+                cv_ = A*(-corq*uq - drag*vq + sy) - gpy*(1.0/1000.0);
+                ce = A*sv;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                double fu = g*eq*gx[i], fv = g*eq*gy[i];                       // shallowwater_eq.py:361
+                if (NONLIN) {                                                  // :478
+                    const double adv = phi[i]*D + uq*gx[i] + vq*gy[i];
+                    fu += adv*uq;
+                    fv += adv*vq;
+                }
+                bu[i] += 0.25*(fu + cu*phi[i]);
+                bv[i] += 0.25*(fv + cv_*phi[i]);
+                be[i] += 0.25*(Hq*(gx[i]*uq + gy[i]*vq) + ce*phi[i]);          // :422
+            }
+        }
+    }
+
+    // ---- facets
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        const int a = f, b = (f + 1) & 3;
+        const double nxs = py[b] - py[a], nys = px[a] - px[b];
+        const double len2 = nxs*nxs + nys*nys;
+        double L, rL;
+        swe_sqrt_rsqrt(len2, L, rL);
+        double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
+        if (nb[f] >= 0) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+                const double uq = xa*u[a] + xb*u[b], vq = xa*v[a] + xb*v[b], eq = xa*e[a] + xb*e[b];
+                const double hq = xa*h[a] + xb*h[b];
+                const double un = xa*una[f] + xb*unb[f], vn = xa*vna[f] + xb*vnb[f], en = xa*ena[f] + xb*enb[f];
+                const double eav = 0.5*(eq + en);
+                const double Hav = NONLIN ? hq + eav : hq;
+                const double c = swe_sqrt(g*Hav);
+                const double du = uq - un, dv = vq - vn;
+                const double dun = du*nxs + dv*nys;
+                const double spg = g*eav + c*dun*rL;
+                double fu = spg*nxs, fv = spg*nys;
+                const double uav = 0.5*(uq + un), vav = 0.5*(vq + vn);
+                const double uavn = uav*nxs + vav*nys;
+                const double fe = Hav*uavn + c*(eq - en)*L;
+                if (NONLIN) {
+                    const double unown = uq*nxs + vq*nys;
+                    fu += uav*unown;
+                    fv += vav*unown;
+                    if (LF) {
+                        const double gam = 0.5*fabs(uavn)*p.sigma_lf;
+                        fu += gam*du;
+                        fv += gam*dv;
+                    }
+                }
+                Fau += xa*fu; Fbu += xb*fu;
+                Fav += xa*fv; Fbv += xb*fv;
+                Fae += xa*fe; Fbe += xb*fe;
+            }
+        } else {
+            swe_boundary_facet<NONLIN, LF>(p, -nb[f], u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], nxs, nys, L, rL,
+                                           Fau, Fbu, Fav, Fbv, Fae, Fbe);
+        }
+        bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
+        bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
+        be[a] -= 0.5*Fae; be[b] -= 0.5*Fbe;
+    }
+
+    // ---- tensor mass inverse and Shu-Osher combine
+    const double s = p.dt*p.beta*rA;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int n1 = (i + 1) & 3, n2 = (i + 2) & 3, n3 = (i + 3) & 3;
+        p.uout[(size_t)i*S + k] = s*(16.0*bu[i] - 8.0*bu[n1] - 8.0*bu[n3] + 4.0*bu[n2]) + wu[i];
+        p.uout[(size_t)(4 + i)*S + k] = s*(16.0*bv[i] - 8.0*bv[n1] - 8.0*bv[n3] + 4.0*bv[n2]) + wv[i];
+        p.uout[(size_t)(8 + i)*S + k] = s*(16.0*be[i] - 8.0*be[n1] - 8.0*be[n3] + 4.0*be[n2]) + we[i];
+    }
+}
+
+// quad diagnostics: int a*b over a parallelogram = A/36 * a^T K b, K = [[4,2,1,2],[2,4,2,1],[1,2,4,2],[2,1,2,4]]
+__device__ __forceinline__ double swe_int2_quad(const double a[4], const double b[4])
+{
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        s += a[i]*(4.0*b[i] + 2.0*b[(i + 1) & 3] + 2.0*b[(i + 3) & 3] + b[(i + 2) & 3]);
+    return s;
+}
+
+__global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel_quad(const double *planes, size_t stride, const int *cv,
+                                                                  const double *vx, const double *vy, const double *vh,
+                                                                  int n, double *partial)
+{
+    __shared__ double red[4][SWE_BLOCK];
+    const int k = blockIdx.x*SWE_BLOCK + threadIdx.x;
+    double s_e2 = 0.0, s_u2 = 0.0, s_vol = 0.0, s_min = 1e300;
+    if (k < n) {
+        double u[4], v[4], e[4], px[4], py[4], h[4];
+        for (int i = 0; i < 4; i++) {
+            u[i] = planes[(size_t)i*stride + k];
+            v[i] = planes[(size_t)(4 + i)*stride + k];
+            e[i] = planes[(size_t)(8 + i)*stride + k];
+            const int vid = cv[(size_t)i*stride + k];
+            px[i] = vx[vid]; py[i] = vy[vid]; h[i] = vh[vid];
+        }
+        const double A = (px[1] - px[0])*(py[3] - py[0]) - (py[1] - py[0])*(px[3] - px[0]);
+        s_e2 = A*(1.0/36.0)*swe_int2_quad(e, e);
+        s_u2 = A*(1.0/36.0)*(swe_int2_quad(u, u) + swe_int2_quad(v, v));
+        s_vol = A*0.25*(e[0] + e[1] + e[2] + e[3] + h[0] + h[1] + h[2] + h[3]);
+        s_min = fmin(fmin(h[0] + e[0], h[1] + e[1]), fmin(h[2] + e[2], h[3] + e[3]));
+    }
+    red[0][threadIdx.x] = s_e2; red[1][threadIdx.x] = s_u2; red[2][threadIdx.x] = s_vol; red[3][threadIdx.x] = s_min;
+    __syncthreads();
+    for (int off = SWE_BLOCK/2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+            red[2][threadIdx.x] += red[2][threadIdx.x + off];
+            red[3][threadIdx.x] = fmin(red[3][threadIdx.x], red[3][threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 4; q++) partial[4*(size_t)blockIdx.x + q] = red[q][0];
 }

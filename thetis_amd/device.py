@@ -30,6 +30,7 @@ class Swe2dDevice(object):
         """
         self.lib = _lib.load()
         self.n_cells = int(mesh.cells.shape[0])
+        self.npc = int(mesh.cells.shape[1])
         self.n_owned = self.n_cells if n_owned is None else int(n_owned)
         c = np.ascontiguousarray
         cells0 = np.asarray(mesh.cells)
@@ -81,7 +82,7 @@ class Swe2dDevice(object):
             if self.perm is not None:
                 tc = tc[self.perm]
             _, tc = np.unique(tc, return_inverse=True)                # compact ids
-            self._topo_cells = tc.reshape(-1, 3)
+            self._topo_cells = tc.reshape(-1, self.npc)
         self._keep = [c(cells0, dtype=np.int32), c(xy0, dtype=np.float64),
                       c(nbr0, dtype=np.int32), c(nbf0, dtype=np.int8), c(bath0, dtype=np.float64)]
         cells, xy, nbr, nbf, bath = self._keep
@@ -89,7 +90,7 @@ class Swe2dDevice(object):
         m.n_cells = self.n_cells
         m.n_owned = self.n_owned
         m.n_vertices = xy.shape[0]
-        m.nodes_per_cell = 3
+        m.nodes_per_cell = self.npc
         m.cell_vertices = cells.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
         m.vertex_xy = _ptr(xy)
         m.cell_neighbours = nbr.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
@@ -129,16 +130,16 @@ class Swe2dDevice(object):
 
     # -- state
     def set_state(self, uv, eta):
-        uv = np.asarray(uv, dtype=np.float64).reshape(self.n_cells, 3, 2)
-        eta = np.asarray(eta, dtype=np.float64).reshape(self.n_cells, 3)
+        uv = np.asarray(uv, dtype=np.float64).reshape(self.n_cells, self.npc, 2)
+        eta = np.asarray(eta, dtype=np.float64).reshape(self.n_cells, self.npc)
         if self.perm is not None:
             uv, eta = uv[self.perm], eta[self.perm]
         uv, eta = np.ascontiguousarray(uv), np.ascontiguousarray(eta)
         self._ck(self.lib.swe2d_set_state(self.h, _ptr(uv), _ptr(eta)))
 
     def get_state(self):
-        uv = np.empty((self.n_cells, 3, 2))
-        eta = np.empty((self.n_cells, 3))
+        uv = np.empty((self.n_cells, self.npc, 2))
+        eta = np.empty((self.n_cells, self.npc))
         self._ck(self.lib.swe2d_get_state(self.h, _ptr(uv), _ptr(eta)))
         if self.perm is not None:
             uv, eta = uv[self.inv_perm], eta[self.inv_perm]
@@ -174,7 +175,7 @@ class Swe2dDevice(object):
         if nodal is None:
             self._ck(self.lib.swe2d_set_field(self.h, field, None))
             return
-        shape = (self.n_cells, 3, 2) if field == _lib.FIELD_MOMENTUM_SOURCE else (self.n_cells, 3)
+        shape = (self.n_cells, self.npc, 2) if field == _lib.FIELD_MOMENTUM_SOURCE else (self.n_cells, self.npc)
         a = np.broadcast_to(np.asarray(nodal, dtype=np.float64), shape)
         if self.perm is not None:
             a = a[self.perm]
@@ -205,8 +206,8 @@ class Swe2dDevice(object):
         self._ck(self.lib.swe2d_synchronize(self.h))
 
     def tendency(self):
-        ku = np.empty((self.n_cells, 3, 2))
-        ke = np.empty((self.n_cells, 3))
+        ku = np.empty((self.n_cells, self.npc, 2))
+        ke = np.empty((self.n_cells, self.npc))
         self._ck(self.lib.swe2d_tendency(self.h, _ptr(ku), _ptr(ke)))
         if self.perm is not None:
             ku, ke = ku[self.inv_perm], ke[self.inv_perm]

@@ -5,7 +5,7 @@ the CPU tests) around the per-rank C-ABI handle.
 Per SSPRK33 stage:   pack owned boundary cells -> isend/irecv with the (<= 2 for strips) peers
                                     || interior stage kernel      (no ghost data needed)
                                     -> unpack ghosts -> boundary stage kernel
-The exchange is 72 B per cut-facet cell (cfg 3: ~500 cells = 36 KB per peer per stage), i.e. pure latency; the whole
+The exchange is 72 B (96 B for quadrilaterals) per cut-facet cell (cfg 3: ~500 cells = 36 KB per peer per stage), i.e. pure latency; the whole
 multi-step loop is captured in a HIP graph (torch.cuda.graph) when capture succeeds so that no Python or launch
 latency sits between the ~10 us kernels.
 """
@@ -25,8 +25,9 @@ class HaloExchanger(object):
     def __init__(self, part, device, host_staged=False):
         import torch
         self.part = part
-        self.send_buf = torch.zeros(max(1, len(part.send_cells))*9, dtype=torch.float64, device=device)
-        self.recv_buf = torch.zeros(max(1, part.n_ghost)*9, dtype=torch.float64, device=device)
+        self.w = w = 3*int(part.cells.shape[1])        # doubles per cell: u, v, eta at every node
+        self.send_buf = torch.zeros(max(1, len(part.send_cells))*w, dtype=torch.float64, device=device)
+        self.recv_buf = torch.zeros(max(1, part.n_ghost)*w, dtype=torch.float64, device=device)
         # gloo cannot move device memory: stage through the host (test path only; RCCL sends device buffers directly)
         self.host_staged = host_staged
         if host_staged:
@@ -43,13 +44,14 @@ class HaloExchanger(object):
             self._send_h.copy_(self.send_buf)
             sbuf, rbuf = self._send_h, self._recv_h
         ops = []
+        w = self.w
         for q in self.part.peers:
             if q in self.part.recv:
                 off, cnt = self.part.recv[q]
-                ops.append(dist.P2POp(dist.irecv, rbuf[9*off:9*(off + cnt)], q))
+                ops.append(dist.P2POp(dist.irecv, rbuf[w*off:w*(off + cnt)], q))
             if q in self.part.send:
                 off, cnt = self.part.send[q]
-                ops.append(dist.P2POp(dist.isend, sbuf[9*off:9*(off + cnt)], q))
+                ops.append(dist.P2POp(dist.isend, sbuf[w*off:w*(off + cnt)], q))
         return dist.batch_isend_irecv(ops) if ops else []
 
     def finish(self, reqs):

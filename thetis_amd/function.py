@@ -9,7 +9,8 @@ import numpy as np
 
 from .options import Constant
 
-__all__ = ['FunctionSpace', 'Function', 'MixedFunction', 'get_functionspace', 'triangle_quadrature']
+__all__ = ['FunctionSpace', 'Function', 'MixedFunction', 'get_functionspace', 'triangle_quadrature',
+           'quadrilateral_quadrature', 'cell_quadrature']
 
 # 6-point, degree-4 Dunavant rule (barycentric points, weights sum to 1)
 _a1, _b1, _w1 = 0.445948490915965, 0.108103018168070, 0.223381589678011
@@ -21,6 +22,23 @@ def triangle_quadrature():
                      [_b2, _a2, _a2], [_a2, _b2, _a2], [_a2, _a2, _b2]])
     w = np.array([_w1, _w1, _w1, _w2, _w2, _w2])
     return bary, w/w.sum()
+
+
+def quadrilateral_quadrature(n=2):
+    """Tensor Gauss-Legendre rule on the unit square: basis values phi (n*n, 4) (nodes counter-clockwise from (0,0))
+    and weights summing to 1."""
+    gx, gw = np.polynomial.legendre.leggauss(n)
+    gx, gw = 0.5*(gx + 1.0), 0.5*gw
+    phi, w = [], []
+    for xi, wx in zip(gx, gw):
+        for ze, wz in zip(gx, gw):
+            phi.append([(1 - xi)*(1 - ze), xi*(1 - ze), xi*ze, (1 - xi)*ze])
+            w.append(wx*wz)
+    return np.array(phi), np.array(w)
+
+
+def cell_quadrature(npc):
+    return triangle_quadrature() if npc == 3 else quadrilateral_quadrature()
 
 
 class FunctionSpace(object):
@@ -35,14 +53,16 @@ class FunctionSpace(object):
     def mesh(self):
         return self.mesh_obj
 
+    @property
+    def npc(self):
+        return int(self.mesh_obj.cells.shape[1])
+
     def dim(self):
-        m = self.mesh_obj
-        n = m.num_vertices if self.family == 'CG' else m.num_cells*(3 if self.degree == 1 else 1)
-        return n*(2 if self.vector else 1)
+        return self.node_count()*(2 if self.vector else 1)
 
     def node_count(self):
         m = self.mesh_obj
-        return m.num_vertices if self.family == 'CG' else m.num_cells*(3 if self.degree == 1 else 1)
+        return m.num_vertices if self.family == 'CG' else m.num_cells*(self.npc if self.degree == 1 else 1)
 
     def node_xy(self):
         m = self.mesh_obj
@@ -129,11 +149,12 @@ class Function(object):
         if fs.family != 'DG' or fs.degree != 1:
             raise NotImplementedError('projection of expressions is implemented for DG-P1 targets only')
         mesh = fs.mesh_obj
-        bary, w = triangle_quadrature()
+        npc = fs.npc
+        bary, w = cell_quadrature(npc)
         p = mesh.cell_xy()
         n = mesh.num_cells
         ncomp = 2 if fs.vector else 1
-        b = np.zeros((n, 3, ncomp))
+        b = np.zeros((n, npc, ncomp))
         for l, wq in zip(bary, w):
             xq = np.einsum('nic,i->nc', p, l)
             val = expr(xq[:, 0], xq[:, 1])
@@ -141,10 +162,14 @@ class Function(object):
                 val = np.stack([np.asarray(val[0])*np.ones(n), np.asarray(val[1])*np.ones(n)], axis=1)
             else:
                 val = (np.asarray(val)*np.ones(n))[:, None]
-            for i in range(3):
+            for i in range(npc):
                 b[:, i, :] += wq*l[i]*val          # divided by the cell area
-        # (M/A)^-1 = 12 [[2,1,1],..]^-1  ->  x_i = 3 (4 b_i - sum b)
-        x = 3.0*(4.0*b - b.sum(axis=1, keepdims=True))
+        if npc == 3:
+            # (M/A)^-1 = 12 [[2,1,1],..]^-1  ->  x_i = 3 (4 b_i - sum b)
+            x = 3.0*(4.0*b - b.sum(axis=1, keepdims=True))
+        else:
+            # parallelogram: (M/A)^-1 = m^-1 (x) m^-1, m^-1 = [[4,-2],[-2,4]]
+            x = 16.0*b - 8.0*np.roll(b, -1, axis=1) - 8.0*np.roll(b, 1, axis=1) + 4.0*np.roll(b, 2, axis=1)
         self._pull()
         self._data[...] = x.reshape(self._data.shape)
         self._host_version += 1
@@ -159,18 +184,19 @@ class Function(object):
         if src.family == 'CG' and fs.family == 'DG' and fs.degree == 1:
             return data[mesh.cells.reshape(-1)]
         if src.family == 'DG' and src.degree == 0 and fs.family == 'DG' and fs.degree == 1:
-            return np.repeat(data, 3, axis=0)
+            return np.repeat(data, fs.npc, axis=0)
         raise NotImplementedError('cannot inject {:}{:} into {:}{:}'.format(src.family, src.degree, fs.family, fs.degree))
 
     def cell_node_values(self):
-        """(N, 3[, 2]) values at the three nodes of every cell."""
+        """(N, k[, 2]) values at the nodes of every cell."""
         mesh = self._fs.mesh_obj
         d = self.dat.data_ro
+        k = self._fs.npc
         if self._fs.family == 'CG':
             return d[mesh.cells]
         if self._fs.degree == 1:
-            return d.reshape((mesh.num_cells, 3) + d.shape[1:])
-        return np.repeat(d[:, None], 3, axis=1)
+            return d.reshape((mesh.num_cells, k) + d.shape[1:])
+        return np.repeat(d[:, None], k, axis=1)
 
     def at(self, xy):
         raise NotImplementedError('point evaluation is not part of the hot path')

@@ -7,10 +7,12 @@ or ``UnitSquareMesh(.., quadrilateral=True)`` (demos/demo_2d_tracer.py:19) and l
 own topology.  Here a mesh is a handful of numpy arrays that go straight to HBM:
 
 ``vertex_xy``   (V, 2) float64   geometric vertices (periodic meshes keep *unwrapped* duplicates)
-``cells``       (N, 3) int32     counter-clockwise vertex ids of every triangle
-``cell_nbr``    (N, 3) int32     facet f joins local vertices f and (f+1)%3;  >=0: neighbour cell,
+``cells``       (N, k) int32     counter-clockwise vertex ids of every triangle (k=3) or quadrilateral (k=4)
+``cell_nbr``    (N, k) int32     facet f joins local vertices f and (f+1)%k;  >=0: neighbour cell,
                                  <0: ``-marker`` of the boundary the facet lies on
-``cell_nbr_facet`` (N, 3) int8   local facet number of the same facet inside the neighbour
+``cell_nbr_facet`` (N, k) int8   local facet number of the same facet inside the neighbour
+
+Quadrilaterals must be parallelograms (affine; every quadrilateral mesh of the reference is a rectangle grid).
 
 Conventions [FD-assumed, SURVEY.md A.8]: vertices on a regular grid, 'left' diagonal
 (from (i, j+1) to (i+1, j)), boundary markers 1: x=0, 2: x=Lx, 3: y=0, 4: y=Ly.
@@ -20,8 +22,14 @@ import numpy as np
 __all__ = ['Mesh2d', 'RectangleMesh', 'PeriodicRectangleMesh', 'UnitSquareMesh', 'SquareMesh']
 
 
+def _signed_area2(p):
+    """Twice the signed area of polygons p (N, k, 2)."""
+    d = p[:, 1:] - p[:, :1]                 # fan from vertex 0: differences first, no cancellation far from the origin
+    return np.sum(d[:, :-1, 0]*d[:, 1:, 1] - d[:, 1:, 0]*d[:, :-1, 1], axis=1)
+
+
 class Mesh2d(object):
-    """Triangular 2D mesh with facet-neighbour connectivity."""
+    """2D mesh of triangles or parallelogram quadrilaterals with facet-neighbour connectivity."""
 
     def __init__(self, vertex_xy, cells, topo_vertex=None, marker_fn=None, name='mesh2d'):
         """
@@ -33,15 +41,22 @@ class Mesh2d(object):
         self.name = name
         self.vertex_xy = np.ascontiguousarray(vertex_xy, dtype=np.float64)
         cells = np.array(cells, dtype=np.int32, copy=True)
-        assert cells.ndim == 2 and cells.shape[1] == 3, 'only triangles are supported'
+        assert cells.ndim == 2 and cells.shape[1] in (3, 4), 'cells must be triangles or quadrilaterals'
+        self.nodes_per_cell = int(cells.shape[1])
         # orient counter-clockwise
         p = self.vertex_xy[cells]
-        area2 = ((p[:, 1, 0] - p[:, 0, 0])*(p[:, 2, 1] - p[:, 0, 1])
-                 - (p[:, 2, 0] - p[:, 0, 0])*(p[:, 1, 1] - p[:, 0, 1]))
+        area2 = _signed_area2(p)
         if np.any(area2 == 0):
             raise ValueError('degenerate (zero area) cell in mesh')
         flip = area2 < 0
-        cells[flip, 1], cells[flip, 2] = cells[flip, 2].copy(), cells[flip, 1].copy()
+        if self.nodes_per_cell == 3:
+            cells[flip, 1], cells[flip, 2] = cells[flip, 2].copy(), cells[flip, 1].copy()
+        else:
+            cells[flip, 1], cells[flip, 3] = cells[flip, 3].copy(), cells[flip, 1].copy()
+            p = self.vertex_xy[cells]
+            skew = np.abs(p[:, 0] - p[:, 1] + p[:, 2] - p[:, 3]).max(axis=1)
+            if np.any(skew > 1e-9*np.sqrt(np.abs(area2))):
+                raise NotImplementedError('quadrilateral cells must be parallelograms (affine)')
         self.cells = np.ascontiguousarray(cells)
         self.topo_vertex = (np.arange(len(self.vertex_xy), dtype=np.int64) if topo_vertex is None
                             else np.asarray(topo_vertex, dtype=np.int64))
@@ -66,19 +81,20 @@ class Mesh2d(object):
         same_prev[1:] = same_next[:-1]
         if np.any(same_next & same_prev):
             raise ValueError('non-manifold mesh: a facet is shared by more than two cells')
-        nbr = np.full(3*n, np.iinfo(np.int32).min, dtype=np.int64)
-        nbf = np.zeros(3*n, dtype=np.int8)
+        k = self.nodes_per_cell
+        nbr = np.full(k*n, np.iinfo(np.int32).min, dtype=np.int64)
+        nbf = np.zeros(k*n, dtype=np.int8)
         first = order[same_next]
         second = order[same_prev]
-        nbr[first] = second // 3
-        nbf[first] = second % 3
-        nbr[second] = first // 3
-        nbf[second] = first % 3
+        nbr[first] = second // k
+        nbf[first] = second % k
+        nbr[second] = first // k
+        nbf[second] = first % k
         ext = order[~(same_next | same_prev)]
         if len(ext):
-            c, f = ext // 3, ext % 3
+            c, f = ext // k, ext % k
             pa = self.vertex_xy[self.cells[c, f]]
-            pb = self.vertex_xy[self.cells[c, (f + 1) % 3]]
+            pb = self.vertex_xy[self.cells[c, (f + 1) % k]]
             mid = 0.5*(pa + pb)
             if marker_fn is None:
                 markers = np.ones(len(ext), dtype=np.int64)
@@ -87,8 +103,8 @@ class Mesh2d(object):
             if np.any(markers <= 0):
                 raise ValueError('boundary markers must be positive integers')
             nbr[ext] = -markers
-        self.cell_nbr = np.ascontiguousarray(nbr.reshape(n, 3).astype(np.int32))
-        self.cell_nbr_facet = np.ascontiguousarray(nbf.reshape(n, 3))
+        self.cell_nbr = np.ascontiguousarray(nbr.reshape(n, k).astype(np.int32))
+        self.cell_nbr_facet = np.ascontiguousarray(nbf.reshape(n, k))
 
     @property
     def num_cells(self):
@@ -104,20 +120,18 @@ class Mesh2d(object):
         return sorted(int(i) for i in np.unique(m))
 
     def cell_xy(self):
-        """(N, 3, 2) coordinates of the DG-P1 nodes (= cell vertices)."""
+        """(N, k, 2) coordinates of the DG-P1 / DQ-1 nodes (= cell vertices)."""
         return self.vertex_xy[self.cells]
 
     def cell_areas(self):
-        p = self.cell_xy()
-        return 0.5*((p[:, 1, 0] - p[:, 0, 0])*(p[:, 2, 1] - p[:, 0, 1])
-                    - (p[:, 2, 0] - p[:, 0, 0])*(p[:, 1, 1] - p[:, 0, 1]))
+        return 0.5*_signed_area2(self.cell_xy())
 
     def _boundary_length(self):
         """Total length of every boundary marker (thetis/utility.py:821-832, ``assemble(1*ds(i))``)."""
         out = {}
         c, f = np.nonzero(self.cell_nbr < 0)
         pa = self.vertex_xy[self.cells[c, f]]
-        pb = self.vertex_xy[self.cells[c, (f + 1) % 3]]
+        pb = self.vertex_xy[self.cells[c, (f + 1) % self.nodes_per_cell]]
         ln = np.hypot(*(pb - pa).T)
         mk = -self.cell_nbr[c, f]
         for m in np.unique(mk):
@@ -132,6 +146,7 @@ class Mesh2d(object):
         inv[perm] = np.arange(len(perm))
         new = object.__new__(Mesh2d)
         new.name = self.name
+        new.nodes_per_cell = self.nodes_per_cell
         new.vertex_xy = self.vertex_xy
         new.topo_vertex = self.topo_vertex
         new.cells = np.ascontiguousarray(self.cells[perm])
@@ -170,6 +185,14 @@ def _grid_cells(nx, ny, diagonal):
     return cells
 
 
+def _grid_quads(nx, ny):
+    """Quadrilaterals of an (nx x ny) grid, cell = j*nx + i, vertices counter-clockwise from (i, j)."""
+    i, j = np.meshgrid(np.arange(nx), np.arange(ny), indexing='xy')
+    i = i.ravel()
+    j = j.ravel()
+    return np.stack([i*(ny + 1) + j, (i + 1)*(ny + 1) + j, (i + 1)*(ny + 1) + j + 1, i*(ny + 1) + j + 1], axis=1)
+
+
 def _rect_marker_fn(lx, ly, periodic_x=False, periodic_y=False):
     def fn(xm, ym):
         tol = 1e-9*max(lx, ly)
@@ -183,14 +206,13 @@ def _rect_marker_fn(lx, ly, periodic_x=False, periodic_y=False):
 
 
 def RectangleMesh(nx, ny, lx, ly, quadrilateral=False, diagonal='left', name='mesh2d'):
-    """``RectangleMesh(nx, ny, Lx, Ly)``: 2*nx*ny triangles, markers 1..4 [FD-assumed, A.8]."""
-    if quadrilateral:
-        raise NotImplementedError('quadrilateral cells are not supported yet (triangles only)')
+    """``RectangleMesh(nx, ny, Lx, Ly)``: 2*nx*ny triangles or nx*ny quadrilaterals, markers 1..4 [FD-assumed, A.8]."""
     xs = np.linspace(0.0, lx, nx + 1)
     ys = np.linspace(0.0, ly, ny + 1)
     xx, yy = np.meshgrid(xs, ys, indexing='ij')
     vertex_xy = np.stack([xx.ravel(), yy.ravel()], axis=1)
-    mesh = Mesh2d(vertex_xy, _grid_cells(nx, ny, diagonal), marker_fn=_rect_marker_fn(lx, ly), name=name)
+    cells = _grid_quads(nx, ny) if quadrilateral else _grid_cells(nx, ny, diagonal)
+    mesh = Mesh2d(vertex_xy, cells, marker_fn=_rect_marker_fn(lx, ly), name=name)
     mesh.nx, mesh.ny, mesh.lx, mesh.ly = nx, ny, float(lx), float(ly)
     mesh.structured = True              # cell = 2*(j*nx + i) + t: lets the device pick a tiled numbering
     return mesh
@@ -198,8 +220,6 @@ def RectangleMesh(nx, ny, lx, ly, quadrilateral=False, diagonal='left', name='me
 
 def PeriodicRectangleMesh(nx, ny, lx, ly, direction='x', quadrilateral=False, diagonal='left', name='mesh2d'):
     """Rectangle periodic in ``direction`` ('x', 'y' or 'both'); geometry stays unwrapped."""
-    if quadrilateral:
-        raise NotImplementedError('quadrilateral cells are not supported yet (triangles only)')
     xs = np.linspace(0.0, lx, nx + 1)
     ys = np.linspace(0.0, ly, ny + 1)
     xx, yy = np.meshgrid(xs, ys, indexing='ij')
@@ -210,8 +230,8 @@ def PeriodicRectangleMesh(nx, ny, lx, ly, direction='x', quadrilateral=False, di
     if direction in ('y', 'both'):
         jj = jj % ny
     topo = (ii*(ny + 1) + jj).ravel()
-    mesh = Mesh2d(vertex_xy, _grid_cells(nx, ny, diagonal), topo_vertex=topo,
-                  marker_fn=_rect_marker_fn(lx, ly), name=name)
+    cells = _grid_quads(nx, ny) if quadrilateral else _grid_cells(nx, ny, diagonal)
+    mesh = Mesh2d(vertex_xy, cells, topo_vertex=topo, marker_fn=_rect_marker_fn(lx, ly), name=name)
     mesh.nx, mesh.ny, mesh.lx, mesh.ly = nx, ny, float(lx), float(ly)
     mesh.structured = True
     return mesh

@@ -67,11 +67,12 @@ def tile_cell_order(mesh, bx=16, by=8):
     return np.lexsort((np.arange(mesh.num_cells), i % bx, j % by, i//bx, j//by))
 
 
-def structured_tile_order(nx, ny, bx=16, by=8):
-    """RectangleMesh numbering (cell = 2*(j*nx + i) + t): tiles of bx x by quads visited along a Hilbert curve over the
-    tile grid, row-major inside a tile - a 256-cell workgroup is one 16 x 8 tile and a wave walks along mesh rows."""
-    n = 2*nx*ny
-    q = np.arange(n)//2
+def structured_tile_order(nx, ny, bx=16, by=8, cells_per_quad=2):
+    """RectangleMesh numbering (cell = 2*(j*nx + i) + t, or j*nx + i for quadrilaterals): tiles of bx x by quads visited
+    along a Hilbert curve over the tile grid, row-major inside a tile - a 256-cell workgroup is one 16 x 8 tile of
+    triangles (16 x 16 of quadrilaterals) and a wave walks along mesh rows."""
+    n = cells_per_quad*nx*ny
+    q = np.arange(n)//cells_per_quad
     i, j = q % nx, q//nx
     order = max(1, int(np.ceil(np.log2(max(nx//bx + 1, ny//by + 1)))))
     d = hilbert_index(i//bx, j//by, order)
@@ -83,6 +84,8 @@ def auto_cell_order(mesh, a=0, b=None):
     RectangleMesh, a Hilbert curve through the centroids otherwise."""
     b = mesh.cells.shape[0] if b is None else b
     if a == 0 and b == mesh.cells.shape[0] and getattr(mesh, 'structured', False):
+        if np.asarray(mesh.cells).shape[1] == 4:
+            return structured_tile_order(mesh.nx, mesh.ny, bx=16, by=16, cells_per_quad=1)
         return structured_tile_order(mesh.nx, mesh.ny)
     cen = np.asarray(mesh.vertex_xy)[np.asarray(mesh.cells)[a:b]].mean(axis=1)
     return hilbert_cell_order(cen)

@@ -56,7 +56,7 @@ def build_partition(mesh, owner, rank):
     n_parts = int(owner.max()) + 1
     nbr = mesh.cell_nbr
     mine = np.nonzero(owner == rank)[0]
-    nb = nbr[mine]                                            # (n_mine, 3) global ids
+    nb = nbr[mine]                                            # (n_mine, k) global ids
     valid = nb >= 0
     nb_owner = np.where(valid, owner[np.where(valid, nb, 0)], rank)
     touches_ghost = (nb_owner != rank).any(axis=1)

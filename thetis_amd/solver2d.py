@@ -133,6 +133,8 @@ class FlowSolver2d(object):
         self.equations.sw = ShallowWaterEquations(self.function_spaces.H_2d, self.depth, self.options)
         self.equations.sw.bnd_functions = self.bnd_functions['shallow_water']
         self.solve_tracer = len(self.options.tracer) > 0
+        if self.solve_tracer and self.mesh2d.cells.shape[1] != 3:
+            raise NotImplementedError('2D tracers on quadrilateral meshes are not on the device path yet')
         for label in self.options.tracer:
             self.equations[label] = TracerEquation2D(label, self.function_spaces.Q_2d, self.depth, self.options)
         if self.solve_tracer and self.options.use_limiter_for_tracers and self.options.polynomial_degree > 0:
@@ -212,7 +214,7 @@ class FlowSolver2d(object):
         """solver2d.py:179-211"""
         m = self.mesh2d
         print_output('Element family: {:}, degree: {:}'.format(self.options.element_family, self.options.polynomial_degree))
-        print_output('2D cell type: triangle')
+        print_output('2D cell type: {:}'.format('triangle' if m.cells.shape[1] == 3 else 'quadrilateral'))
         print_output('2D mesh: {:} vertices, {:} elements'.format(m.num_vertices, m.num_cells))
         a = np.sqrt(m.cell_areas())
         print_output('Horizontal element size: {:.2f} ... {:.2f} m'.format(a.min(), a.max()))
