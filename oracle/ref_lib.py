@@ -157,7 +157,7 @@ class RefTracer(object):
         for mk, v in bnd_values.items():
             has[mk] = 1
             val[mk] = v
-        src = None if source is None else np.ascontiguousarray(np.broadcast_to(source, (n, 3)), dtype=np.float64)
+        src = None if source is None else np.ascontiguousarray(np.broadcast_to(source, (n, ref.npc)), dtype=np.float64)
         self._keep = (has, val, src)
         t = _RefTracerStruct()
         t.use_lf = int(use_lax_friedrichs_tracer)
@@ -178,7 +178,7 @@ class RefTracer(object):
 
     def step(self, T, uv, dt):
         T = np.array(T, dtype=np.float64, order='C'); uv = np.ascontiguousarray(uv, dtype=np.float64)
-        work = np.empty(6*self.ref.n)
+        work = np.empty(2*self.ref.npc*self.ref.n)
         self.ref.lib.swe2d_ref_tracer_step(ctypes.byref(self.ref.s), ctypes.byref(self.t), _ptr(T), _ptr(uv), dt, _ptr(work))
         return T
 

@@ -426,45 +426,69 @@ typedef struct {
 static void cell_tracer_tendency(const swe2d_ref_t *m, const swe2d_ref_tracer_t *tp, int k, const double *T,
                                  const double *uv, double dt, double *kT)
 {
-    const double *p = m->xy + 6*(size_t)k;
+    const int npc = m->npc;
+    const double *p = m->xy + 2*(size_t)npc*k;
     const double cf = tp->velocity_factor;
-    double u[3], v[3], c[3];
-    for (int i = 0; i < 3; i++) {
-        u[i] = cf*uv[6*(size_t)k + 2*i];
-        v[i] = cf*uv[6*(size_t)k + 2*i + 1];
-        c[i] = T[3*(size_t)k + i];
+    double u[4], v[4], c[4];
+    for (int i = 0; i < npc; i++) {
+        u[i] = cf*uv[2*(size_t)npc*k + 2*i];
+        v[i] = cf*uv[2*(size_t)npc*k + 2*i + 1];
+        c[i] = T[(size_t)npc*k + i];
     }
-    const double A = 0.5*((p[2] - p[0])*(p[5] - p[1]) - (p[4] - p[0])*(p[3] - p[1]));
-    double gx[3], gy[3];
-    for (int i = 0; i < 3; i++) {
-        int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
-        gx[i] = (p[2*i1 + 1] - p[2*i2 + 1])/(2*A);
-        gy[i] = (p[2*i2] - p[2*i1])/(2*A);
+    double b[4] = {0, 0, 0, 0};
+    double A;
+    const double *src = tp->source ? tp->source + (size_t)npc*k : 0;
+    if (npc == 4) {
+        const double ax = p[2] - p[0], ay = p[3] - p[1], bx = p[6] - p[0], by = p[7] - p[1];
+        A = ax*by - ay*bx;
+        const double xix = by/A, xiy = -bx/A, zex = -ay/A, zey = ax/A;
+        for (int qi = 0; qi < 2; qi++) for (int qz = 0; qz < 2; qz++) {
+            const double xi = GL_XI[qi], ze = GL_XI[qz], w = 0.25*A;
+            const double phi[4] = {(1 - xi)*(1 - ze), xi*(1 - ze), xi*ze, (1 - xi)*ze};
+            const double dxi[4] = {-(1 - ze), (1 - ze), ze, -ze};
+            const double dze[4] = {-(1 - xi), -xi, xi, (1 - xi)};
+            double gx[4], gy[4], uq = 0, vq = 0, cq = 0, divu = 0, sq = 0;
+            for (int i = 0; i < 4; i++) {
+                gx[i] = dxi[i]*xix + dze[i]*zex;
+                gy[i] = dxi[i]*xiy + dze[i]*zey;
+                uq += phi[i]*u[i]; vq += phi[i]*v[i]; cq += phi[i]*c[i];
+                divu += gx[i]*u[i] + gy[i]*v[i];
+                if (src) sq += phi[i]*src[i];
+            }
+            for (int i = 0; i < 4; i++) b[i] += w*((phi[i]*divu + uq*gx[i] + vq*gy[i])*cq + sq*phi[i]);
+        }
+    } else {
+        A = 0.5*((p[2] - p[0])*(p[5] - p[1]) - (p[4] - p[0])*(p[3] - p[1]));
+        double gx[3], gy[3];
+        for (int i = 0; i < 3; i++) {
+            int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+            gx[i] = (p[2*i1 + 1] - p[2*i2 + 1])/(2*A);
+            gy[i] = (p[2*i2] - p[2*i1])/(2*A);
+        }
+        /* cell: +(phi div u + u.grad phi) c */
+        double divu = 0;
+        for (int i = 0; i < 3; i++) divu += gx[i]*u[i] + gy[i]*v[i];
+        const double Iuc = int2(A, u, c), Ivc = int2(A, v, c);
+        const double csum = c[0] + c[1] + c[2];
+        for (int i = 0; i < 3; i++) b[i] += divu*A/12.0*(csum + c[i]) + gx[i]*Iuc + gy[i]*Ivc;
+        if (src) {
+            double ss = src[0] + src[1] + src[2];
+            for (int i = 0; i < 3; i++) b[i] += A/12.0*(ss + src[i]);
+        }
     }
-    double b[3] = {0, 0, 0};
-    /* cell: +(phi div u + u.grad phi) c */
-    double divu = 0;
-    for (int i = 0; i < 3; i++) divu += gx[i]*u[i] + gy[i]*v[i];
-    const double Iuc = int2(A, u, c), Ivc = int2(A, v, c);
-    const double csum = c[0] + c[1] + c[2];
-    for (int i = 0; i < 3; i++) b[i] += divu*A/12.0*(csum + c[i]) + gx[i]*Iuc + gy[i]*Ivc;
-    if (tp->source) {
-        const double *s = tp->source + 3*(size_t)k;
-        double ss = s[0] + s[1] + s[2];
-        for (int i = 0; i < 3; i++) b[i] += A/12.0*(ss + s[i]);
-    }
-    for (int f = 0; f < 3; f++) {
-        const int a = f, bb = (f + 1) % 3;
+    for (int f = 0; f < npc; f++) {
+        const int a = f, bb = (f + 1) % npc;
         const double dx = p[2*bb] - p[2*a], dy = p[2*bb + 1] - p[2*a + 1];
         const double len = sqrt(dx*dx + dy*dy);
         const double nx = dy/len, ny = -dx/len;
-        const int nb = m->nbr[3*(size_t)k + f];
+        const int nb = m->nbr[(size_t)npc*k + f];
         double ua_n = 0, ub_n = 0, va_n = 0, vb_n = 0, ca_n = 0, cb_n = 0;
         if (nb >= 0) {
-            const int f2 = m->nbf[3*(size_t)k + f];
-            const int na = (f2 + 1) % 3, nbb = f2;
-            ua_n = cf*uv[6*(size_t)nb + 2*na];  va_n = cf*uv[6*(size_t)nb + 2*na + 1];  ca_n = T[3*(size_t)nb + na];
-            ub_n = cf*uv[6*(size_t)nb + 2*nbb]; vb_n = cf*uv[6*(size_t)nb + 2*nbb + 1]; cb_n = T[3*(size_t)nb + nbb];
+            const int f2 = m->nbf[(size_t)npc*k + f];
+            const int na = (f2 + 1) % npc, nbb = f2;
+            const size_t o = 2*(size_t)npc*nb, oc = (size_t)npc*nb;
+            ua_n = cf*uv[o + 2*na];  va_n = cf*uv[o + 2*na + 1];  ca_n = T[oc + na];
+            ub_n = cf*uv[o + 2*nbb]; vb_n = cf*uv[o + 2*nbb + 1]; cb_n = T[oc + nbb];
         }
         for (int q = 0; q < 2; q++) {
             const double xb = GL_XI[q], xa = 1.0 - xb, w = 0.5*len;
@@ -489,6 +513,12 @@ static void cell_tracer_tendency(const swe2d_ref_t *m, const swe2d_ref_tracer_t 
             b[a] -= w*xa*fq; b[bb] -= w*xb*fq;
         }
     }
+    if (npc == 4) {
+        const double s4 = dt/A;
+        for (int i = 0; i < 4; i++)
+            kT[4*(size_t)k + i] = s4*(16.0*b[i] - 8.0*b[(i + 1) % 4] - 8.0*b[(i + 3) % 4] + 4.0*b[(i + 2) % 4]);
+        return;
+    }
     const double s = 3.0*dt/A, sb = b[0] + b[1] + b[2];
     for (int i = 0; i < 3; i++) kT[3*(size_t)k + i] = s*(4.0*b[i] - sb);
 }
@@ -504,7 +534,7 @@ void swe2d_ref_tracer_tendency(const swe2d_ref_t *m, const swe2d_ref_tracer_t *t
 void swe2d_ref_tracer_step(const swe2d_ref_t *m, const swe2d_ref_tracer_t *tp, double *T, const double *uv, double dt,
                            double *work)
 {
-    const size_t n = 3*(size_t)m->n_cells;
+    const size_t n = (size_t)m->npc*(size_t)m->n_cells;
     double *T0 = work, *kT = work + n;
     static const double A30 = 0.33333333333333337, A32 = 0.6666666666666666, B32 = 0.6666666666666666;
     memcpy(T0, T, n*sizeof(double));
@@ -519,34 +549,38 @@ void swe2d_ref_tracer_step(const swe2d_ref_t *m, const swe2d_ref_tracer_t *tp, d
 /* vertex-based limiter; cell_vertex = [N][3] topological vertex ids, qmin/qmax = work arrays of n_vertices */
 void swe2d_ref_limit(const swe2d_ref_t *m, const int *cell_vertex, int n_vertices, double *T, double *qmin, double *qmax)
 {
-    const int n = m->n_cells;
+    const int n = m->n_cells, npc = m->npc;
     for (int v = 0; v < n_vertices; v++) { qmax[v] = -1.0e10; qmin[v] = 1.0e10; }
     for (int k = 0; k < n; k++) {
-        const double *c = T + 3*(size_t)k;
-        const double mean = (c[0] + c[1] + c[2])/3.0;
-        for (int i = 0; i < 3; i++) {
-            const int v = cell_vertex[3*(size_t)k + i];
+        const double *c = T + (size_t)npc*k;
+        double mean = 0;
+        for (int i = 0; i < npc; i++) mean += c[i];
+        mean /= npc;
+        for (int i = 0; i < npc; i++) {
+            const int v = cell_vertex[(size_t)npc*k + i];
             qmax[v] = fmax(qmax[v], mean); qmin[v] = fmin(qmin[v], mean);
         }
     }
     for (int k = 0; k < n; k++)
-        for (int f = 0; f < 3; f++)
-            if (m->nbr[3*(size_t)k + f] < 0) {
-                const int a = f, b = (f + 1) % 3;
-                const double fm = (T[3*(size_t)k + a] + T[3*(size_t)k + b])/2.0;
-                const int va = cell_vertex[3*(size_t)k + a], vb = cell_vertex[3*(size_t)k + b];
+        for (int f = 0; f < npc; f++)
+            if (m->nbr[(size_t)npc*k + f] < 0) {
+                const int a = f, b = (f + 1) % npc;
+                const double fm = (T[(size_t)npc*k + a] + T[(size_t)npc*k + b])/2.0;
+                const int va = cell_vertex[(size_t)npc*k + a], vb = cell_vertex[(size_t)npc*k + b];
                 qmax[va] = fmax(qmax[va], fm); qmin[va] = fmin(qmin[va], fm);
                 qmax[vb] = fmax(qmax[vb], fm); qmin[vb] = fmin(qmin[vb], fm);
             }
     for (int k = 0; k < n; k++) {
-        double *c = T + 3*(size_t)k;
-        const double mean = (c[0] + c[1] + c[2])/3.0;
+        double *c = T + (size_t)npc*k;
+        double mean = 0;
+        for (int i = 0; i < npc; i++) mean += c[i];
+        mean /= npc;
         double alpha = 1.0;
-        for (int i = 0; i < 3; i++) {
-            const int v = cell_vertex[3*(size_t)k + i];
+        for (int i = 0; i < npc; i++) {
+            const int v = cell_vertex[(size_t)npc*k + i];
             if (c[i] > mean) alpha = fmin(alpha, fmin(1.0, (qmax[v] - mean)/(c[i] - mean)));
             else if (c[i] < mean) alpha = fmin(alpha, fmin(1.0, (mean - qmin[v])/(mean - c[i])));
         }
-        for (int i = 0; i < 3; i++) c[i] = mean + alpha*(c[i] - mean);
+        for (int i = 0; i < npc; i++) c[i] = mean + alpha*(c[i] - mean);
     }
 }

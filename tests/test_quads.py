@@ -183,3 +183,93 @@ def test_quad_two_ranks_on_one_gpu(tmp_path, hip_lib):
     u_s, e_s = dev.get_state()
     assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
     dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['default', 'lf', 'value_bc'])
+def test_quad_tracer_and_limiter_match_oracle(hip_lib, case):
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = quad_case(skew=0.3, seed=2)
+    rng = np.random.default_rng(3)
+    T = rng.normal(size=(mesh.num_cells, 4))
+    src = 1e-3*rng.normal(size=T.shape)
+    dt = 3.0
+    orc = make_oracle_generic(mesh, bath)
+    dev = Swe2dDevice(mesh, bath, dt, boundary_len=mesh.boundary_len)
+    tid = dev.add_tracer()
+    kw = {}
+    if case == 'lf':
+        kw = dict(use_lax_friedrichs_tracer=True, lax_friedrichs_tracer_scaling_factor=0.7,
+                  tracer_advective_velocity_factor=0.9, source=src)
+        dev.tracer_set_options(True, 0.7, 0.9)
+        dev.tracer_set_source(tid, src)
+    if case == 'value_bc':
+        kw = dict(bnd_conditions={1: {'value': 2.0}, 3: {'value': -1.0}})
+        dev.tracer_set_bc(tid, 1, 2.0)
+        dev.tracer_set_bc(tid, 3, -1.0)
+    dev.set_state(uv, eta)
+    dev.tracer_set_state(tid, T)
+    assert np.array_equal(dev.tracer_get_state(tid), T)
+    assert rel_linf(dev.tracer_tendency(tid), orc.tracer_tendency(T, uv, eta, dt, **kw)) < 1e-12
+    for s in range(3):
+        dev.tracer_solve_stage(tid, s)
+    T1 = dev.tracer_get_state(tid)
+    assert rel_linf(T1, orc.tracer_ssprk33_step(T, uv, eta, dt, **kw)) < 1e-12
+    d = dev.tracer_diagnostics(tid)
+    assert math.isclose(d[0], orc.tracer_mass(T1, eta), rel_tol=1e-12)
+    assert d[2] == T1.min() and d[3] == T1.max()
+    dev.tracer_set_state(tid, T)
+    dev.tracer_limit(tid)
+    assert rel_linf(dev.tracer_get_state(tid), orc.limit(T)) < 1e-14
+    dev.close()
+
+
+@pytest.mark.gpu
+def test_demo_2d_tracer_solid_body_rotation(hip_lib, ref_so):
+    """demos/demo_2d_tracer.py:19-137: LeVeque bell + cone + slotted cylinder on UnitSquareMesh(40, 40, quadrilateral),
+    tracer_only, SSPRK33, dt = pi/300, one rotation; checked step by step against the CPU restatement."""
+    from oracle.ref_lib import RefTracer
+    from thetis_amd import UnitSquareMesh
+    mesh2d = UnitSquareMesh(40, 40, quadrilateral=True)
+    P1_2d = get_functionspace(mesh2d, 'CG', 1)
+    bathymetry2d = Function(P1_2d).assign(1.0)
+    solver_obj = solver2d.FlowSolver2d(mesh2d, bathymetry2d)
+    options = solver_obj.options
+    options.add_tracer_2d('tracer_2d', 'Depth averaged tracer', 'Tracer2d', source=None, diffusivity=None)
+    options.tracer_only = True
+    t_end, timestep = 2*math.pi, math.pi/300.0
+    options.tracer_timestepper_type = 'SSPRK33'
+    options.timestep = timestep
+    options.simulation_end_time = t_end
+    options.simulation_export_time = math.pi/15.0
+    options.tracer_timestepper_options.use_automatic_timestep = False
+    options.use_lax_friedrichs_tracer = False
+    options.use_limiter_for_tracers = False
+    solver_obj.bnd_functions['tracer_2d'] = {'on_boundary': {'value': Constant(1.0)}}
+
+    def q0(x, y):
+        bell = 0.25*(1 + np.cos(np.pi*np.minimum(np.sqrt((x - 0.25)**2 + (y - 0.5)**2)/0.15, 1.0)))
+        cone = 1.0 - np.minimum(np.sqrt((x - 0.5)**2 + (y - 0.25)**2)/0.15, 1.0)
+        cyl = np.where(np.sqrt((x - 0.5)**2 + (y - 0.75)**2) < 0.15,
+                       np.where((x > 0.475) & (x < 0.525) & (y < 0.85), 0.0, 1.0), 0.0)
+        return 1.0 + bell + cone + cyl
+    q_init = Function(P1_2d).interpolate(q0)
+    solver_obj.assign_initial_conditions(uv=lambda x, y: (0.5 - y, x - 0.5), tracer_2d=q_init)
+    it = solver_obj.create_iterator()
+    t = 0
+    while t < t_end - timestep:
+        t = next(it)
+    q = solver_obj.fields.tracer_2d.cell_node_values()
+    q_i = q_init.cell_node_values()
+    orc = make_oracle_generic(mesh2d, np.ones(mesh2d.num_vertices))
+    l2 = orc.l2_norm(q - q_i)/orc.l2_norm(q_i)
+    assert l2 < 0.1                                         # dispersion of the unlimited scheme on a 40x40 mesh
+    # same number of steps with the CPU restatement
+    ref = make_ref(mesh2d, np.ones(mesh2d.num_vertices))
+    rt = RefTracer(ref, cell_topo_vertices=mesh2d.cells)
+    uv = solver_obj.fields.uv_2d.cell_node_values()
+    T = q_i.copy()
+    # the generator yields after advance() and before the counter is incremented (solver2d.py:1116-1125)
+    for _ in range(solver_obj.iteration + 1):
+        T = rt.step(T, uv, timestep)
+    assert rel_linf(q, T) < 1e-10

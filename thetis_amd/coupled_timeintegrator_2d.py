@@ -50,7 +50,7 @@ class DeviceTracerSSPRK33(object):
     def _sync_to_device(self):
         if self._uploaded != self.solution._host_version:
             self._pull()
-            self.device.tracer_set_state(self.tid, self.solution._data.reshape(-1, 3))
+            self.device.tracer_set_state(self.tid, self.solution._data.reshape(-1, self.device.npc))
             self._uploaded = self.solution._host_version
             self._device_ahead = False
 

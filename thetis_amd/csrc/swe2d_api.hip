@@ -655,6 +655,16 @@ namespace {
 
 typedef void (*tracer_kernel_t)(const SweTracerArgs);
 
+tracer_kernel_t pick_tracer_kernel_quad(bool lf, bool t0, bool src)
+{
+    if (lf) {
+        if (t0) return src ? swe_tracer_stage_kernel_quad<true, true, true> : swe_tracer_stage_kernel_quad<true, true, false>;
+        return src ? swe_tracer_stage_kernel_quad<true, false, true> : swe_tracer_stage_kernel_quad<true, false, false>;
+    }
+    if (t0) return src ? swe_tracer_stage_kernel_quad<false, true, true> : swe_tracer_stage_kernel_quad<false, true, false>;
+    return src ? swe_tracer_stage_kernel_quad<false, false, true> : swe_tracer_stage_kernel_quad<false, false, false>;
+}
+
 tracer_kernel_t pick_tracer_kernel(bool lf, bool t0, bool src)
 {
     if (lf) {
@@ -681,7 +691,8 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     a.lf_factor = h->tracer_lf_factor;
     a.source = t.source;
     for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_has_value[m] = t.bc_has_value[m]; a.bc_value[m] = t.bc_value[m]; }
-    tracer_kernel_t kern = pick_tracer_kernel(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr);
+    tracer_kernel_t kern = (h->npc == 4) ? pick_tracer_kernel_quad(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr)
+                                         : pick_tracer_kernel(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr);
     const int nblocks = (h->n_owned + SWE_BLOCK - 1)/SWE_BLOCK;
     const int grid = ((nblocks + 7)/8)*8;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
@@ -709,26 +720,26 @@ int check_tracer(Handle *h, int id)
 // vertex -> cells CSR and vertex -> boundary facets CSR on the host, uploaded once
 int limiter_build(Handle *h, int nv, const int *topo /* [n][3] */)
 {
-    const int n = h->n_cells;
+    const int n = h->n_cells, npc = h->npc;
     const size_t S = h->stride;
     std::vector<int> off(nv + 1, 0), boff(nv + 1, 0);
     for (int k = 0; k < n; k++)
-        for (int i = 0; i < 3; i++) {
-            const int v = topo[3*(size_t)k + i];
+        for (int i = 0; i < npc; i++) {
+            const int v = topo[(size_t)npc*k + i];
             if (v < 0 || v >= nv) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "topological vertex id out of range");
             off[v + 1]++;
-            if (h->host_nbr[3*(size_t)k + i] < 0) { boff[v + 1]++; boff[topo[3*(size_t)k + (i + 1) % 3] + 1]++; }
+            if (h->host_nbr[(size_t)npc*k + i] < 0) { boff[v + 1]++; boff[topo[(size_t)npc*k + (i + 1) % npc] + 1]++; }
         }
     for (int v = 0; v < nv; v++) { off[v + 1] += off[v]; boff[v + 1] += boff[v]; }
     std::vector<int> cell(off[nv]), bf(std::max(1, boff[nv])), pos(off.begin(), off.end() - 1), bpos(boff.begin(), boff.end() - 1);
-    std::vector<int> tv(3*S, 0);
+    std::vector<int> tv((size_t)npc*S, 0);
     for (int k = 0; k < n; k++)
-        for (int i = 0; i < 3; i++) {
-            const int v = topo[3*(size_t)k + i];
+        for (int i = 0; i < npc; i++) {
+            const int v = topo[(size_t)npc*k + i];
             cell[pos[v]++] = k;
             tv[(size_t)i*S + k] = v;
-            if (h->host_nbr[3*(size_t)k + i] < 0) {          // facet i joins local vertices i and i+1
-                const int v2 = topo[3*(size_t)k + (i + 1) % 3];
+            if (h->host_nbr[(size_t)npc*k + i] < 0) {          // facet i joins local vertices i and i+1
+                const int v2 = topo[(size_t)npc*k + (i + 1) % npc];
                 bf[bpos[v]++] = (k << 2) | i;
                 bf[bpos[v2]++] = (k << 2) | i;
             }
@@ -764,12 +775,12 @@ int limiter_apply(Handle *h, int id)
     }
     double *t = h->tracers[id].buf[0];
     const int n = h->n_cells, nv = h->lim_nv;
-    hipLaunchKernelGGL(swe_limiter_cell_mean, dim3(grid_for(n)), dim3(256), 0, h->stream, t, h->stride, n, h->lim_mean);
+    hipLaunchKernelGGL(swe_limiter_cell_mean, dim3(grid_for(n)), dim3(256), 0, h->stream, t, h->stride, n, h->lim_mean, h->npc);
     hipLaunchKernelGGL(swe_limiter_vertex_bounds, dim3(grid_for(nv)), dim3(256), 0, h->stream, h->lim_v2c_off,
                        h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_mean, t, h->stride, nv, h->lim_qmin,
-                       h->lim_qmax);
+                       h->lim_qmax, h->npc);
     hipLaunchKernelGGL(swe_limiter_apply, dim3(grid_for(n)), dim3(256), 0, h->stream, t, h->stride, n, h->lim_tv,
-                       h->lim_qmin, h->lim_qmax);
+                       h->lim_qmin, h->lim_qmax, h->npc);
     HIP_TRY(h, hipGetLastError());
     return SWE2D_OK;
 }
@@ -783,13 +794,12 @@ int swe2d_tracer_add(swe2d_handle *hh, int *tracer_id)
     Handle *h = H(hh);
     if (!h || !tracer_id) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     if (h->n_owned != h->n_cells) return fail(h, SWE2D_ERR_UNSUPPORTED, "tracers are not available on partitions yet");
-    if (h->npc != 3) return fail(h, SWE2D_ERR_UNSUPPORTED, "tracers are implemented for triangles only so far");
     HIP_TRY(h, hipSetDevice(h->device));
     Handle::Tracer t;
     for (int m = 0; m < SWE_MAX_MARKERS; m++) { t.bc_has_value[m] = 0; t.bc_value[m] = 0.0; }
     for (int b = 0; b < 3; b++) {
-        HIP_TRY(h, hipMalloc(&t.buf[b], 3*h->stride*sizeof(double)));
-        HIP_TRY(h, hipMemsetAsync(t.buf[b], 0, 3*h->stride*sizeof(double), h->stream));
+        HIP_TRY(h, hipMalloc(&t.buf[b], (size_t)h->npc*h->stride*sizeof(double)));
+        HIP_TRY(h, hipMemsetAsync(t.buf[b], 0, (size_t)h->npc*h->stride*sizeof(double), h->stream));
     }
     h->tracers.push_back(t);
     *tracer_id = (int)h->tracers.size() - 1;
@@ -814,9 +824,9 @@ int swe2d_tracer_set_state(swe2d_handle *hh, int id, const double *nodal)
     if (rc) return rc;
     if (!nodal) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpyAsync(h->stage_eta, nodal, 3*(size_t)h->n_cells*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->stage_eta, nodal, (size_t)h->npc*h->n_cells*sizeof(double), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(swe_nodal_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                       h->stage_eta, h->tracers[id].buf[0], h->stride, h->n_cells, 1, 3);
+                       h->stage_eta, h->tracers[id].buf[0], h->stride, h->n_cells, 1, h->npc);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SWE2D_OK;
@@ -825,9 +835,9 @@ int swe2d_tracer_set_state(swe2d_handle *hh, int id, const double *nodal)
 static int tracer_read_back(Handle *h, const double *planes, double *nodal)
 {
     hipLaunchKernelGGL(swe_planes_to_nodal, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                       planes, h->stage_eta, h->stride, h->n_cells, 3);
+                       planes, h->stage_eta, h->stride, h->n_cells, h->npc);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(nodal, h->stage_eta, 3*(size_t)h->n_cells*sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(nodal, h->stage_eta, (size_t)h->npc*h->n_cells*sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SWE2D_OK;
 }
@@ -864,10 +874,10 @@ int swe2d_tracer_set_source(swe2d_handle *hh, int id, const double *nodal)
         if (t.source) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipFree(t.source)); t.source = nullptr; }
         return SWE2D_OK;
     }
-    if (!t.source) HIP_TRY(h, hipMalloc(&t.source, 3*h->stride*sizeof(double)));
-    HIP_TRY(h, hipMemcpyAsync(h->stage_eta, nodal, 3*(size_t)h->n_cells*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (!t.source) HIP_TRY(h, hipMalloc(&t.source, (size_t)h->npc*h->stride*sizeof(double)));
+    HIP_TRY(h, hipMemcpyAsync(h->stage_eta, nodal, (size_t)h->npc*h->n_cells*sizeof(double), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(swe_nodal_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                       h->stage_eta, t.source, h->stride, h->n_cells, 1, 3);
+                       h->stage_eta, t.source, h->stride, h->n_cells, 1, h->npc);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SWE2D_OK;
@@ -919,9 +929,14 @@ int swe2d_tracer_diagnostics(swe2d_handle *hh, int id, double out[4])
     if (rc) return rc;
     if (!out) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(swe_tracer_diag_kernel, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
-                       h->tracers[id].buf[0], h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh,
-                       h->par.use_nonlinear_equations, h->n_owned, h->partial);
+    if (h->npc == 4)
+        hipLaunchKernelGGL(swe_tracer_diag_kernel_quad, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
+                           h->tracers[id].buf[0], h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh,
+                           h->par.use_nonlinear_equations, h->n_owned, h->partial);
+    else
+        hipLaunchKernelGGL(swe_tracer_diag_kernel, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
+                           h->tracers[id].buf[0], h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh,
+                           h->par.use_nonlinear_equations, h->n_owned, h->partial);
     HIP_TRY(h, hipGetLastError());
     std::vector<double> part(4*(size_t)h->n_partial_blocks);
     HIP_TRY(h, hipMemcpyAsync(part.data(), h->partial, part.size()*sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -701,19 +701,21 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
     for (int i = 0; i < 3; i++) p.tout[(size_t)i*S + k] = s*(4.0*b[i] - sb) + w[i];
 }
 
-// ---- limiter, step 1: cell means (P0 projection of an affine P1 field = mean of the nodal values)
-__global__ void swe_limiter_cell_mean(const double *t, size_t stride, int n, double *mean)
+// ---- limiter, step 1: cell means (P0 projection of an affine P1 / Q1 field = mean of the nodal values)
+__global__ void swe_limiter_cell_mean(const double *t, size_t stride, int n, double *mean, int npc)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
-    mean[k] = (t[k] + t[stride + k] + t[2*stride + k])/3.0;
+    double s = 0.0;
+    for (int i = 0; i < npc; i++) s += t[(size_t)i*stride + k];
+    mean[k] = s/(double)npc;
 }
 
 // ---- limiter, step 2: per (topological) vertex min/max of the means of the cells around it (CSR gather: no atomics,
 // deterministic) + Thetis's boundary-facet means (limiter.py:109-145)
 __global__ void swe_limiter_vertex_bounds(const int *v2c_off, const int *v2c_cell, const int *vbf_off, const int *vbf_facet,
                                           const double *mean, const double *t, size_t stride, int nv,
-                                          double *qmin, double *qmax)
+                                          double *qmin, double *qmax, int npc)
 {
     const int v = blockIdx.x*blockDim.x + threadIdx.x;
     if (v >= nv) return;
@@ -725,7 +727,7 @@ __global__ void swe_limiter_vertex_bounds(const int *v2c_off, const int *v2c_cel
     }
     for (int j = vbf_off[v]; j < vbf_off[v + 1]; j++) {
         const int packed = vbf_facet[j];
-        const int k = packed >> 2, a = packed & 3, b = (a == 2) ? 0 : a + 1;
+        const int k = packed >> 2, a = packed & 3, b = (a + 1 == npc) ? 0 : a + 1;
         const double fm = (t[(size_t)a*stride + k] + t[(size_t)b*stride + k])/2.0;
         lo = fmin(lo, fm);
         hi = fmax(hi, fm);
@@ -735,26 +737,26 @@ __global__ void swe_limiter_vertex_bounds(const int *v2c_off, const int *v2c_cel
 }
 
 // ---- limiter, step 3: per-cell scaling towards the mean
-__global__ void swe_limiter_apply(double *t, size_t stride, int n, const int *tv, const double *qmin, const double *qmax)
+__global__ void swe_limiter_apply(double *t, size_t stride, int n, const int *tv, const double *qmin, const double *qmax,
+                                  int npc)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
-    double c[3];
-    int vv[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
+    double c[4];
+    int vv[4];
+    double s = 0.0;
+    for (int i = 0; i < npc; i++) {
         c[i] = t[(size_t)i*stride + k];
         vv[i] = tv[(size_t)i*stride + k];
+        s += c[i];
     }
-    const double mean = (c[0] + c[1] + c[2])/3.0;
+    const double mean = s/(double)npc;
     double alpha = 1.0;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < npc; i++) {
         if (c[i] > mean) alpha = fmin(alpha, fmin(1.0, (qmax[vv[i]] - mean)/(c[i] - mean)));
         else if (c[i] < mean) alpha = fmin(alpha, fmin(1.0, (mean - qmin[vv[i]])/(mean - c[i])));
     }
-#pragma unroll
-    for (int i = 0; i < 3; i++) t[(size_t)i*stride + k] = mean + alpha*(c[i] - mean);
+    for (int i = 0; i < npc; i++) t[(size_t)i*stride + k] = mean + alpha*(c[i] - mean);
 }
 
 // ---- tracer diagnostics: per-block { int T*H dx, int T dx, min T, max T }
@@ -1051,6 +1053,159 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel_quad(const double *
             red[1][threadIdx.x] += red[1][threadIdx.x + off];
             red[2][threadIdx.x] += red[2][threadIdx.x + off];
             red[3][threadIdx.x] = fmin(red[3][threadIdx.x], red[3][threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 4; q++) partial[4*(size_t)blockIdx.x + q] = red[q][0];
+}
+
+// ---- tracer stage on parallelogram quadrilaterals (see swe_tracer_stage_kernel and swe_stage_kernel_quad)
+template <bool LF, bool HAST0, bool SRC>
+__global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const SweTracerArgs p)
+{
+#ifdef SWE_NO_XCD_MAP
+    const int lb = blockIdx.x;
+#else
+    const int lb = swe_logical_block(blockIdx.x, gridDim.x);
+#endif
+    const int k = p.cell_begin + lb*SWE_BLOCK + (int)threadIdx.x;
+    if (k >= p.cell_end) return;
+    const size_t S = p.stride;
+    const double cf = p.vel_factor;
+
+    double u[4], v[4], c[4], w[4];
+    int nb[4], vid[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        nb[i] = p.nbr[(size_t)i*S + k];
+        vid[i] = p.cv[(size_t)i*S + k];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u[i] = cf*p.uv[(size_t)i*S + k];
+        v[i] = cf*p.uv[(size_t)(4 + i)*S + k];
+        c[i] = p.tin[(size_t)i*S + k];
+        w[i] = p.a1*c[i];
+        if (HAST0) w[i] += p.a0*p.t0[(size_t)i*S + k];
+    }
+    double una[4], unb[4], vna[4], vnb[4], cna[4], cnb[4];
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        const int nbf = nb[f];
+        const int kn = nbf >= 0 ? (nbf >> 2) : k;
+        const int f2 = nbf >= 0 ? (nbf & 3) : f;
+        const int na = (f2 + 1) & 3;
+        una[f] = cf*p.uv[(size_t)na*S + kn];
+        unb[f] = cf*p.uv[(size_t)f2*S + kn];
+        vna[f] = cf*p.uv[(size_t)(4 + na)*S + kn];
+        vnb[f] = cf*p.uv[(size_t)(4 + f2)*S + kn];
+        cna[f] = p.tin[(size_t)na*S + kn];
+        cnb[f] = p.tin[(size_t)f2*S + kn];
+    }
+    double px[4], py[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        px[i] = p.vx[vid[i]];
+        py[i] = p.vy[vid[i]];
+    }
+    const double ax = px[1] - px[0], ay = py[1] - py[0];
+    const double bx = px[3] - px[0], by = py[3] - py[0];
+    const double A = ax*by - ay*bx;
+    const double xix = by, xiy = -bx, zex = -ay, zey = ax;       // A*grad(xi), A*grad(zeta)
+    double b[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) {
+#pragma unroll
+        for (int qz = 0; qz < 2; qz++) {
+            const double xi = qi ? SWE_XI1 : SWE_XI0, ze = qz ? SWE_XI1 : SWE_XI0;
+            const double phi[4] = {(1.0 - xi)*(1.0 - ze), xi*(1.0 - ze), xi*ze, (1.0 - xi)*ze};
+            const double dxi[4] = {-(1.0 - ze), (1.0 - ze), ze, -ze};
+            const double dze[4] = {-(1.0 - xi), -xi, xi, (1.0 - xi)};
+            double gx[4], gy[4], uq = 0.0, vq = 0.0, cq = 0.0, D = 0.0, sq = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                gx[i] = dxi[i]*xix + dze[i]*zex;
+                gy[i] = dxi[i]*xiy + dze[i]*zey;
+                uq += phi[i]*u[i];
+                vq += phi[i]*v[i];
+                cq += phi[i]*c[i];
+                D += gx[i]*u[i] + gy[i]*v[i];
+                if (SRC) sq += phi[i]*p.source[(size_t)i*S + k];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) b[i] += 0.25*((phi[i]*D + uq*gx[i] + vq*gy[i])*cq + A*sq*phi[i]);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        const int a = f, bb = (f + 1) & 3;
+        const double nxs = py[bb] - py[a], nys = px[a] - px[bb];
+        double Fa = 0.0, Fb = 0.0;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+            const double uq = xa*u[a] + xb*u[bb], vq = xa*v[a] + xb*v[bb], cq = xa*c[a] + xb*c[bb];
+            const double unown = uq*nxs + vq*nys;
+            double fq;
+            if (nb[f] >= 0) {
+                const double un = xa*una[f] + xb*unb[f], vn = xa*vna[f] + xb*vnb[f], cn = xa*cna[f] + xb*cnb[f];
+                const double uavn = 0.5*((uq + un)*nxs + (vq + vn)*nys);
+                const double cup = uavn > 0.0 ? cq : (uavn < 0.0 ? cn : 0.5*(cq + cn));
+                fq = cup*unown;
+                if (LF) fq += 0.5*fabs(uavn)*p.lf_factor*(cq - cn);
+            } else {
+                const int marker = -nb[f];
+                if (marker < SWE_MAX_MARKERS && p.bc_has_value[marker]) {
+                    const double cext = p.bc_value[marker];
+                    const double cup = unown > 0.0 ? cq : (unown < 0.0 ? cext : 0.5*(cq + cext));
+                    fq = cup*unown;
+                } else {
+                    fq = cq*unown;
+                }
+            }
+            Fa += xa*fq;
+            Fb += xb*fq;
+        }
+        b[a] -= 0.5*Fa;
+        b[bb] -= 0.5*Fb;
+    }
+    const double s = p.dt*p.beta*swe_rcp(A);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        p.tout[(size_t)i*S + k] = s*(16.0*b[i] - 8.0*b[(i + 1) & 3] - 8.0*b[(i + 3) & 3] + 4.0*b[(i + 2) & 3]) + w[i];
+}
+
+// tracer diagnostics on quadrilaterals
+__global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel_quad(const double *t, const double *state, size_t stride,
+                                                                         const int *cv, const double *vx, const double *vy,
+                                                                         const double *vh, int nonlinear, int n, double *partial)
+{
+    __shared__ double red[4][SWE_BLOCK];
+    const int k = blockIdx.x*SWE_BLOCK + threadIdx.x;
+    double s_m = 0.0, s_i = 0.0, s_min = 1e300, s_max = -1e300;
+    if (k < n) {
+        double c[4], H[4], px[4], py[4];
+        for (int i = 0; i < 4; i++) {
+            c[i] = t[(size_t)i*stride + k];
+            const int vid = cv[(size_t)i*stride + k];
+            px[i] = vx[vid]; py[i] = vy[vid];
+            H[i] = vh[vid] + (nonlinear ? state[(size_t)(8 + i)*stride + k] : 0.0);
+        }
+        const double A = (px[1] - px[0])*(py[3] - py[0]) - (py[1] - py[0])*(px[3] - px[0]);
+        s_m = A*(1.0/36.0)*swe_int2_quad(c, H);
+        s_i = A*0.25*(c[0] + c[1] + c[2] + c[3]);
+        s_min = fmin(fmin(c[0], c[1]), fmin(c[2], c[3]));
+        s_max = fmax(fmax(c[0], c[1]), fmax(c[2], c[3]));
+    }
+    red[0][threadIdx.x] = s_m; red[1][threadIdx.x] = s_i; red[2][threadIdx.x] = s_min; red[3][threadIdx.x] = s_max;
+    __syncthreads();
+    for (int off = SWE_BLOCK/2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+            red[2][threadIdx.x] = fmin(red[2][threadIdx.x], red[2][threadIdx.x + off]);
+            red[3][threadIdx.x] = fmax(red[3][threadIdx.x], red[3][threadIdx.x + off]);
         }
         __syncthreads();
     }

@@ -221,7 +221,7 @@ class Swe2dDevice(object):
 
     # -- tracers + limiter
     def _nodal_in(self, a):
-        a = np.asarray(a, dtype=np.float64).reshape(self.n_cells, 3)
+        a = np.asarray(a, dtype=np.float64).reshape(self.n_cells, self.npc)
         if self.perm is not None:
             a = a[self.perm]
         return np.ascontiguousarray(a)
@@ -249,7 +249,7 @@ class Swe2dDevice(object):
         self._ck(self.lib.swe2d_tracer_set_state(self.h, tid, _ptr(a)))
 
     def tracer_get_state(self, tid):
-        a = np.empty((self.n_cells, 3))
+        a = np.empty((self.n_cells, self.npc))
         self._ck(self.lib.swe2d_tracer_get_state(self.h, tid, _ptr(a)))
         return self._nodal_out(a)
 
@@ -262,14 +262,14 @@ class Swe2dDevice(object):
         if nodal is None:
             self._ck(self.lib.swe2d_tracer_set_source(self.h, tid, None))
         else:
-            a = self._nodal_in(np.broadcast_to(np.asarray(nodal, dtype=np.float64), (self.n_cells, 3)))
+            a = self._nodal_in(np.broadcast_to(np.asarray(nodal, dtype=np.float64), (self.n_cells, self.npc)))
             self._ck(self.lib.swe2d_tracer_set_source(self.h, tid, _ptr(a)))
 
     def tracer_solve_stage(self, tid, i_stage):
         self._ck(self.lib.swe2d_tracer_solve_stage(self.h, tid, int(i_stage)))
 
     def tracer_tendency(self, tid):
-        a = np.empty((self.n_cells, 3))
+        a = np.empty((self.n_cells, self.npc))
         self._ck(self.lib.swe2d_tracer_tendency(self.h, tid, _ptr(a)))
         return self._nodal_out(a)
 

@@ -36,6 +36,6 @@ class VertexBasedP1DGLimiter(object):
         data = field.dat.data
         comps = [data[:, i] for i in range(data.shape[1])] if self.is_vector else [data]
         for comp in comps:
-            dev.tracer_set_state(self._tid, comp.reshape(-1, 3))
+            dev.tracer_set_state(self._tid, comp.reshape(-1, dev.npc))
             dev.tracer_limit(self._tid)
             comp[...] = dev.tracer_get_state(self._tid).reshape(comp.shape)

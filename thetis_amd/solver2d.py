@@ -133,8 +133,6 @@ class FlowSolver2d(object):
         self.equations.sw = ShallowWaterEquations(self.function_spaces.H_2d, self.depth, self.options)
         self.equations.sw.bnd_functions = self.bnd_functions['shallow_water']
         self.solve_tracer = len(self.options.tracer) > 0
-        if self.solve_tracer and self.mesh2d.cells.shape[1] != 3:
-            raise NotImplementedError('2D tracers on quadrilateral meshes are not on the device path yet')
         for label in self.options.tracer:
             self.equations[label] = TracerEquation2D(label, self.function_spaces.Q_2d, self.depth, self.options)
         if self.solve_tracer and self.options.use_limiter_for_tracers and self.options.polynomial_degree > 0:
@@ -187,13 +185,16 @@ class FlowSolver2d(object):
         if not hasattr(self, 'equations'):
             self.create_equations()
         if any(hasattr(o, 'use_automatic_timestep') and o.use_automatic_timestep
-               for o in (self.options.swe_timestepper_options,)):
+               for o in (self.options.swe_timestepper_options, self.options.tracer_timestepper_options)):
             from .cgproject import elem_size_p1
             self.fields.h_elem_size_2d = Function(self.function_spaces.P1_2d).assign(elem_size_p1(self.mesh2d))
         self.compute_mesh_stats()
         self.set_time_step()
         steppers = {'SSPRK33': SSPRK33}
         name = self.options.swe_timestepper_type
+        if self.options.tracer_only and self.options.tracer:
+            name = 'SSPRK33'        # the shallow water state is frozen (coupled_timeintegrator_2d.py:98): the stepper
+            #                         object only holds the device-resident velocity, its type option is not used
         if name not in steppers:
             raise NotImplementedError("swe_timestepper_type {!r} needs a global (non)linear solve and is outside the "
                                       "explicit device path; use 'SSPRK33'".format(name))
@@ -273,7 +274,11 @@ class FlowSolver2d(object):
             area = self.mesh2d.cell_areas()
             for label in self.options.tracer:
                 q = self.fields[label].cell_node_values()
-                norm_q = math.sqrt(float(np.sum(area/12.0*(q.sum(axis=1)**2 + (q**2).sum(axis=1)))))
+                if q.shape[1] == 3:
+                    norm_q = math.sqrt(float(np.sum(area/12.0*(q.sum(axis=1)**2 + (q**2).sum(axis=1)))))
+                else:
+                    kq = 4*q + 2*np.roll(q, -1, axis=1) + 2*np.roll(q, 1, axis=1) + np.roll(q, 2, axis=1)
+                    norm_q = math.sqrt(float(np.sum(area/36.0*(q*kq).sum(axis=1))))
                 entries.append((label, norm_q, '10.4f'))
         else:
             d = self.timestepper.diagnostics()
