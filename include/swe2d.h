@@ -130,6 +130,12 @@ int  swe2d_set_field(swe2d_handle *h, int field, const double *nodal);
 /* scalar coefficients; a negative value switches the term off (norm_smoother: >= 0) */
 int  swe2d_set_scalar(swe2d_handle *h, int which, double value);
 
+/* options.use_wetting_and_drying + options.wetting_and_drying_alpha (thetis/options.py:872-884), alpha given at the mesh
+ * vertices (constant or the P1 field of set_wetting_and_drying_alpha, solver2d.py:251-303).  The reference cannot run
+ * SSPRK33 with wetting-drying; this enables the build's own explicit nodal formulation of the same
+ * displaced depth.  swe2d_diagnostics then reports int D dx, min D in slots 2, 3. */
+int  swe2d_set_wetting_and_drying(swe2d_handle *h, int enable, const double *alpha_vertex);
+
 /* ERKGenericShuOsher.advance (rungekutta.py:949-952) repeated n_steps times, forcings constant in time.
  * Asynchronous: returns after enqueueing. */
 int  swe2d_advance(swe2d_handle *h, int n_steps);

@@ -24,7 +24,7 @@ class _RefStruct(ctypes.Structure):
                 ('manning', ctypes.c_double), ('norm_smoother', ctypes.c_double),
                 ('patm', _dp), ('mom_src', _dp), ('vol_src', _dp),
                 ('n_markers', ctypes.c_int), ('bc_kind', _ip), ('bc_elev', _dp), ('bc_uv', _dp),
-                ('bc_un', _dp), ('bc_flux', _dp), ('bc_len', _dp), ('npc', ctypes.c_int)]
+                ('bc_un', _dp), ('bc_flux', _dp), ('bc_len', _dp), ('npc', ctypes.c_int), ('wd', ctypes.c_int), ('alpha', _dp)]
 
 
 def build(force=False):
@@ -57,7 +57,8 @@ class RefSWE(object):
                  use_lax_friedrichs_velocity=True, lax_friedrichs_velocity_scaling_factor=1.0,
                  coriolis=None, linear_drag_coefficient=None, quadratic_drag_coefficient=None,
                  manning_drag_coefficient=None, norm_smoother=0.0, atmospheric_pressure=None,
-                 momentum_source=None, volume_source=None, bnd_conditions=None, boundary_len=None):
+                 momentum_source=None, volume_source=None, bnd_conditions=None, boundary_len=None,
+                 use_wetting_and_drying=False, wetting_and_drying_alpha=0.5):
         self.lib = load()
         n = cell_xy.shape[0]
         self.n = n
@@ -107,6 +108,10 @@ class RefSWE(object):
         s.bc_kind = _ptr(kind, _ip); s.bc_elev = _ptr(elev); s.bc_uv = _ptr(uvb); s.bc_un = _ptr(un)
         s.bc_flux = _ptr(flux); s.bc_len = _ptr(blen)
         s.npc = npc
+        s.wd = int(bool(use_wetting_and_drying))
+        alpha = c(np.broadcast_to(np.asarray(wetting_and_drying_alpha, dtype=np.float64), (n, npc)))
+        k['alpha'] = alpha
+        s.alpha = _ptr(alpha)
         self.s = s
 
     def tendency(self, uv, eta, dt):

@@ -65,6 +65,9 @@ typedef struct {
     const double *bc_flux;     /* per marker                                           */
     const double *bc_len;      /* per marker total boundary length                     */
     int npc;                   /* nodes per cell: 3 (DG-P1 triangles) or 4 (DQ-1 parallelograms) */
+    /* explicit wetting-drying (this build's own nodal formulation, see oracle/swe2d_oracle.py header) */
+    int wd;                    /* use_wetting_and_drying                                */
+    const double *alpha;       /* [N][k] wetting_and_drying_alpha at the cell nodes     */
 } swe2d_ref_t;
 
 static const double GL_XI[2] = {0.21132486540518713, 0.78867513459481287};
@@ -83,6 +86,19 @@ static const double TRI_W[6] = {0.223381589678011, 0.223381589678011, 0.22338158
 static inline double total_depth(const swe2d_ref_t *m, double h, double eta)
 {
     return m->nonlinear ? h + eta : h;
+}
+
+/* displaced depth D = (H + sqrt(H^2 + a^2))/2, H = h + eta   (utility.py:975-993) */
+static inline double wd_depth(double h, double eta, double a)
+{
+    const double H = h + eta;
+    return 0.5*(H + sqrt(H*H + a*a));
+}
+
+/* pointwise depth for external (boundary) states */
+static inline double depth_pt(const swe2d_ref_t *m, double h, double eta, double a)
+{
+    return m->wd ? wd_depth(h, eta, a) : total_depth(m, h, eta);
 }
 
 /* int a*b over the cell, a,b P1 */
@@ -155,12 +171,13 @@ static void cell_tendency(const swe2d_ref_t *m, int k, const double *uv, const d
     const int npc = m->npc;
     const double *p = m->xy + 2*(size_t)npc*k;
     const double *hk = m->h + (size_t)npc*k;
-    double u[4], v[4], e[4], H[4];
+    double u[4], v[4], e[4], H[4], al[4] = {0, 0, 0, 0};
     for (int i = 0; i < npc; i++) {
         u[i] = uv[2*(size_t)npc*k + 2*i];
         v[i] = uv[2*(size_t)npc*k + 2*i + 1];
         e[i] = eta[(size_t)npc*k + i];
-        H[i] = total_depth(m, hk[i], e[i]);
+        if (m->wd) al[i] = m->alpha[(size_t)npc*k + i];
+        H[i] = m->wd ? wd_depth(hk[i], e[i], al[i]) : total_depth(m, hk[i], e[i]);
     }
     double bu[4] = {0, 0, 0, 0}, bv[4] = {0, 0, 0, 0}, be[4] = {0, 0, 0, 0};
     double A;
@@ -267,11 +284,13 @@ static void cell_tendency(const swe2d_ref_t *m, int k, const double *uv, const d
             const double w = 0.5*len;
             const double uq = xa*u[a] + xb*u[b], vq = xa*v[a] + xb*v[b], eq = xa*e[a] + xb*e[b];
             const double hq = xa*hk[a] + xb*hk[b];
-            const double Hq = total_depth(m, hq, eq);
+            const double alq = xa*al[a] + xb*al[b];
+            const double Hq = m->wd ? xa*H[a] + xb*H[b] : total_depth(m, hq, eq);
             double fu = 0, fv = 0, fe = 0;     /* the form f; residual is -f */
             if (nb >= 0) {
                 const double un_ = xa*ua_n + xb*ub_n, vn_ = xa*va_n + xb*vb_n, en_ = xa*ea_n + xb*eb_n;
-                const double Hn = total_depth(m, hq, en_);
+                const double Hn = m->wd ? xa*wd_depth(hk[a], ea_n, al[a]) + xb*wd_depth(hk[b], eb_n, al[b])
+                                        : total_depth(m, hq, en_);
                 const double Hav = 0.5*(Hq + Hn);
                 const double uav = 0.5*(uq + un_), vav = 0.5*(vq + vn_);
                 const double jump_un = (uq - un_)*nx + (vq - vn_)*ny;
@@ -302,11 +321,11 @@ static void cell_tendency(const swe2d_ref_t *m, int k, const double *uv, const d
                 if (kind & BC_UV) { u_ext = m->bc_uv[2*marker]; v_ext = m->bc_uv[2*marker + 1]; }
                 else if (kind & BC_UN) { u_ext = m->bc_un[marker]*nx; v_ext = m->bc_un[marker]*ny; }
                 else if (kind & BC_FLUX) {
-                    const double H_ext0 = total_depth(m, hq, e_ext);
+                    const double H_ext0 = depth_pt(m, hq, e_ext, alq);
                     const double s = m->bc_flux[marker]/(H_ext0*m->bc_len[marker]);
                     u_ext = s*nx; v_ext = s*ny;
                 }
-                const double H_ext = total_depth(m, hq, e_ext);
+                const double H_ext = depth_pt(m, hq, e_ext, alq);
                 const double un_jump = (uq - u_ext)*nx + (vq - v_ext)*ny;
                 const double eta_rie = 0.5*(eq + e_ext) + sqrt(Hq/g)*un_jump;             /* :374 */
                 fu += g*eta_rie*nx; fv += g*eta_rie*ny;                                   /* :375 */
@@ -315,7 +334,7 @@ static void cell_tendency(const swe2d_ref_t *m, int k, const double *uv, const d
                 const double un_avg = 0.5*((uq + u_ext)*nx + (vq + v_ext)*ny);
                 const double un_rie = un_avg + sqrt(g/h_av)*eta_jump;                     /* :438 */
                 const double eta_rie2 = 0.5*(eq + e_ext) + sqrt(h_av/g)*un_jump;          /* :440 */
-                fe += total_depth(m, hq, eta_rie2)*un_rie;                                /* :441-442 */
+                fe += depth_pt(m, hq, eta_rie2, alq)*un_rie;                              /* :441-442 */
                 if (m->nonlinear) {
                     const double un_rie3 = un_avg + sqrt(g/Hq)*eta_jump;                  /* :507 */
                     fu += un_rie3*0.5*(u_ext + uq); fv += un_rie3*0.5*(v_ext + vq);       /* :508-509 */
@@ -358,6 +377,15 @@ void swe2d_ref_tendency(const swe2d_ref_t *m, const double *uv, const double *et
 
 /* n_steps SSPRK33 steps in place; work must hold 4 states = 4*9*N doubles.  Shu-Osher form, expression
  * order of rungekutta.py:911-913: tendency*beta + sum_j stage_sol[j]*alpha.  Constant-in-time forcing only. */
+/* explicit wetting-drying: the continuity equation advances zeta = D - h; eta is recovered from H = D - a^2/(4 D) */
+static inline double wd_combine(const swe2d_ref_t *m, long i, double bk, double e0, double a0, double e1, double a1)
+{
+    const double h = m->h[i], a = m->alpha[i];
+    const double zeta = bk + (wd_depth(h, e0, a) - h)*a0 + (wd_depth(h, e1, a) - h)*a1;
+    const double D = zeta + h;
+    return D - a*a/(4.0*D) - h;
+}
+
 void swe2d_ref_advance(const swe2d_ref_t *m, double *uv, double *eta, double dt, int n_steps, double *work)
 {
     const size_t nu = 2*(size_t)m->npc*(size_t)m->n_cells, ne = (size_t)m->npc*(size_t)m->n_cells;
@@ -372,19 +400,22 @@ void swe2d_ref_advance(const swe2d_ref_t *m, double *uv, double *eta, double dt,
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < (long)nu; i++) uv[i] = ku[i]*1.0 + u0[i]*1.0;
 #pragma omp parallel for schedule(static)
-        for (long i = 0; i < (long)ne; i++) eta[i] = ke[i]*1.0 + e0[i]*1.0;
+        for (long i = 0; i < (long)ne; i++)
+            eta[i] = m->wd ? wd_combine(m, i, ke[i]*1.0, e0[i], 1.0, e0[i], 0.0) : ke[i]*1.0 + e0[i]*1.0;
         /* stage 1: U2 = k*0.25 + U0*0.75 + U1*0.25   (U1 is the current solution) */
         swe2d_ref_tendency(m, uv, eta, dt, ku, ke);
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < (long)nu; i++) uv[i] = ku[i]*0.25 + u0[i]*0.75 + uv[i]*0.25;
 #pragma omp parallel for schedule(static)
-        for (long i = 0; i < (long)ne; i++) eta[i] = ke[i]*0.25 + e0[i]*0.75 + eta[i]*0.25;
+        for (long i = 0; i < (long)ne; i++)
+            eta[i] = m->wd ? wd_combine(m, i, ke[i]*0.25, e0[i], 0.75, eta[i], 0.25) : ke[i]*0.25 + e0[i]*0.75 + eta[i]*0.25;
         /* stage 2: U3 = k*B32 + U0*A30 + U1*0 + U2*A32 */
         swe2d_ref_tendency(m, uv, eta, dt, ku, ke);
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < (long)nu; i++) uv[i] = ku[i]*B32 + u0[i]*A30 + uv[i]*A32;
 #pragma omp parallel for schedule(static)
-        for (long i = 0; i < (long)ne; i++) eta[i] = ke[i]*B32 + e0[i]*A30 + eta[i]*A32;
+        for (long i = 0; i < (long)ne; i++)
+            eta[i] = m->wd ? wd_combine(m, i, ke[i]*B32, e0[i], A30, eta[i], A32) : ke[i]*B32 + e0[i]*A30 + eta[i]*A32;
     }
 }
 

@@ -111,8 +111,9 @@ def test_unsupported_configurations_fail_loudly(hip_lib):
     with pytest.raises(NotImplementedError):
         solver_obj.assign_initial_conditions(elev=elev_init)
     s2, *_ = _channel2d_solver()
-    s2.options.use_wetting_and_drying = True
-    with pytest.raises(NotImplementedError):
+    s2.options.use_wetting_and_drying = True        # needs the nonlinear equations
+    s2.options.use_nonlinear_equations = False
+    with pytest.raises(Exception):
         s2.assign_initial_conditions(elev=elev_init)
     s3, *_ = _channel2d_solver()
     s3.options.horizontal_viscosity = Constant(10.0)

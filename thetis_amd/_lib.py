@@ -50,6 +50,7 @@ SYMBOLS = {
     'swe2d_set_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),
     'swe2d_set_field': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_set_scalar': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_double]),
+    'swe2d_set_wetting_and_drying': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_advance': (ctypes.c_int, [_H, ctypes.c_int]),
     'swe2d_solve_stage': (ctypes.c_int, [_H, ctypes.c_int]),
     'swe2d_advance_timed': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),

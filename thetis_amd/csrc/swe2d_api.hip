@@ -35,6 +35,8 @@ struct Handle {
     double *state[3] = {nullptr, nullptr, nullptr};   // A (U0 / step result), B (U1), C (U2)
     int *nbr = nullptr, *cv = nullptr;
     double *vx = nullptr, *vy = nullptr, *vh = nullptr;
+    double *valpha = nullptr;                          // per-vertex wetting-drying alpha
+    bool wd = false;
     double *field[SWE2D_FIELD_COUNT] = {nullptr, nullptr, nullptr, nullptr};
     double scalar[SWE2D_SCALAR_COUNT] = {-1.0, -1.0, -1.0, 0.0};
     double *stage_uv = nullptr, *stage_eta = nullptr;  // device staging in host layout (6N + 3N)
@@ -91,7 +93,19 @@ typedef void (*stage_kernel_t)(const SweStageArgs);
 template <bool NL, bool LF, bool U0>
 stage_kernel_t pick_src(bool src)
 {
-    return src ? swe_stage_kernel<NL, LF, U0, true> : swe_stage_kernel<NL, LF, U0, false>;
+    return src ? swe_stage_kernel<NL, LF, U0, true, false> : swe_stage_kernel<NL, LF, U0, false, false>;
+}
+// wetting-drying variants (nonlinear equations only)
+template <bool LF, bool U0>
+stage_kernel_t pick_wd_src(bool src, bool quad)
+{
+    if (quad) return src ? swe_stage_kernel_quad<true, LF, U0, true, true> : swe_stage_kernel_quad<true, LF, U0, false, true>;
+    return src ? swe_stage_kernel<true, LF, U0, true, true> : swe_stage_kernel<true, LF, U0, false, true>;
+}
+stage_kernel_t pick_kernel_wd(bool lf, bool u0, bool src, bool quad)
+{
+    if (lf) return u0 ? pick_wd_src<true, true>(src, quad) : pick_wd_src<true, false>(src, quad);
+    return u0 ? pick_wd_src<false, true>(src, quad) : pick_wd_src<false, false>(src, quad);
 }
 template <bool NL, bool LF>
 stage_kernel_t pick_u0(bool u0, bool src) { return u0 ? pick_src<NL, LF, true>(src) : pick_src<NL, LF, false>(src); }
@@ -105,7 +119,7 @@ stage_kernel_t pick_kernel(bool nl, bool lf, bool u0, bool src)
 template <bool NL, bool LF, bool U0>
 stage_kernel_t pickq_src(bool src)
 {
-    return src ? swe_stage_kernel_quad<NL, LF, U0, true> : swe_stage_kernel_quad<NL, LF, U0, false>;
+    return src ? swe_stage_kernel_quad<NL, LF, U0, true, false> : swe_stage_kernel_quad<NL, LF, U0, false, false>;
 }
 template <bool NL, bool LF>
 stage_kernel_t pickq_u0(bool u0, bool src) { return u0 ? pickq_src<NL, LF, true>(src) : pickq_src<NL, LF, false>(src); }
@@ -128,6 +142,7 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.nbr = h->nbr;
     a.cv = h->cv;
     a.vx = h->vx; a.vy = h->vy; a.vh = h->vh;
+    a.valpha = h->valpha;
     a.cell_begin = c0; a.cell_end = c1;
     a.g = h->par.g_grav;
     a.sigma_lf = h->par.lax_friedrichs_velocity_scaling_factor;
@@ -143,7 +158,8 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.norm_smoother = h->scalar[SWE2D_SCALAR_NORM_SMOOTHER];
     a.bc = h->bc;
     const bool has_u0 = (a0 != 0.0);
-    stage_kernel_t kern = (h->npc == 4)
+    stage_kernel_t kern = h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4)
+        : (h->npc == 4)
         ? pick_kernel_quad(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
         : pick_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h));
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
@@ -346,7 +362,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax};
+                    h->lim_qmin, h->lim_qmax, h->valpha};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -462,6 +478,24 @@ int swe2d_set_scalar(swe2d_handle *hh, int which, double value)
     if (which == SWE2D_SCALAR_QUADRATIC_DRAG && value >= 0.0 && h->scalar[SWE2D_SCALAR_MANNING_DRAG] >= 0.0)
         return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "Cannot set both dimensionless and Manning drag parameter");
     h->scalar[which] = value;
+    return SWE2D_OK;
+}
+
+int swe2d_set_wetting_and_drying(swe2d_handle *hh, int enable, const double *alpha_vertex)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (!enable) { h->wd = false; return SWE2D_OK; }
+    if (!alpha_vertex) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "alpha_vertex is required");
+    if (!h->par.use_nonlinear_equations)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "wetting and drying needs use_nonlinear_equations");
+    for (int i = 0; i < h->n_vertices; i++)
+        if (!(alpha_vertex[i] >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "alpha must be >= 0");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->valpha) HIP_TRY(h, hipMalloc(&h->valpha, (size_t)h->n_vertices*sizeof(double)));
+    HIP_TRY(h, hipMemcpyAsync(h->valpha, alpha_vertex, (size_t)h->n_vertices*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->wd = true;
     return SWE2D_OK;
 }
 
@@ -581,10 +615,12 @@ int swe2d_diagnostics(swe2d_handle *hh, double out[4])
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->npc == 4)
         hipLaunchKernelGGL(swe_diag_kernel_quad, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
-                           h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial);
+                           h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial,
+                           h->wd ? h->valpha : nullptr);
     else
         hipLaunchKernelGGL(swe_diag_kernel, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
-                           h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial);
+                           h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial,
+                           h->wd ? h->valpha : nullptr);
     HIP_TRY(h, hipGetLastError());
     std::vector<double> part(4*(size_t)h->n_partial_blocks);
     HIP_TRY(h, hipMemcpyAsync(part.data(), h->partial, part.size()*sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -52,6 +52,7 @@ struct SweStageArgs {
     const int *nbr;        // 3 planes: (cell<<2)|facet_in_neighbour, or -(marker)
     const int *cv;         // 3 planes: vertex ids
     const double *vx, *vy, *vh;   // per vertex: coordinates, bathymetry
+    const double *valpha;         // per vertex: wetting-drying parameter alpha (WD variant)
     int cell_begin, cell_end;
     double g, sigma_lf, dt;
     double a0, a1, beta;   // U_out = beta*k + a0*U0 + a1*U_in
@@ -123,6 +124,20 @@ __device__ __forceinline__ double swe_rcp(double x)
 #endif
 }
 
+// Wetting-drying (explicit nodal formulation, see oracle/swe2d_oracle.py header and DESIGN.md): displaced total depth
+// D = (H + sqrt(H^2 + a^2))/2 with H = h + eta (thetis/utility.py:975-993), and its inverse H = D - a^2/(4 D).
+__device__ __forceinline__ double swe_wd_depth(double H, double a)
+{
+    return 0.5*(H + sqrt(H*H + a*a));
+}
+
+// total depth of a pointwise (external / Riemann) state
+template <bool NONLIN, bool WD>
+__device__ __forceinline__ double swe_depth_pt(double h, double eta, double a)
+{
+    return WD ? swe_wd_depth(h + eta, a) : (NONLIN ? h + eta : h);
+}
+
 // 12/A * int a*b dx for P1 a, b
 __device__ __forceinline__ double swe_int2(const double a[3], const double b[3])
 {
@@ -131,14 +146,13 @@ __device__ __forceinline__ double swe_int2(const double a[3], const double b[3])
 
 // Boundary facet (closed wall or open boundary); rare, so written for clarity with unit normals.
 // Returns the form values f (residual is -f) already multiplied by the facet length.
-template <bool NONLIN, bool LF>
+template <bool NONLIN, bool LF, bool WD>
 __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int marker, double uq, double vq, double eq,
-                                               double hq, double nxs, double nys, double L, double rL,
-                                               double &fu, double &fv, double &fe)
+                                               double hq, double Hq, double alq, double nxs, double nys, double L,
+                                               double rL, double &fu, double &fv, double &fe)
 {
     const double g = p.g;
     const double nx = nxs*rL, ny = nys*rL;
-    const double Hq = NONLIN ? hq + eq : hq;
     const int kind = (marker < SWE_MAX_MARKERS) ? p.bc.kind[marker] : 0;
     const double un_own = uq*nx + vq*ny;
     if (kind == 0) {
@@ -163,12 +177,12 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
             u_ext = p.bc.un[marker]*nx;
             v_ext = p.bc.un[marker]*ny;
         } else if (kind & SWE_BC_FLUX) {
-            const double H0 = NONLIN ? hq + e_ext : hq;
+            const double H0 = swe_depth_pt<NONLIN, WD>(hq, e_ext, alq);
             const double s = p.bc.flux[marker]/(H0*p.bc.len[marker]);
             u_ext = s*nx;
             v_ext = s*ny;
         }
-        const double H_ext = NONLIN ? hq + e_ext : hq;
+        const double H_ext = swe_depth_pt<NONLIN, WD>(hq, e_ext, alq);
         const double un_jump = (uq - u_ext)*nx + (vq - v_ext)*ny;
         const double eta_rie = 0.5*(eq + e_ext) + sqrt(Hq/g)*un_jump;                 // :374
         fu = g*eta_rie*nx;
@@ -178,7 +192,7 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
         const double un_avg = 0.5*((uq + u_ext)*nx + (vq + v_ext)*ny);
         const double un_rie = un_avg + sqrt(g/h_av)*eta_jump;                          // :438
         const double eta_rie2 = 0.5*(eq + e_ext) + sqrt(h_av/g)*un_jump;               // :440
-        fe = (NONLIN ? hq + eta_rie2 : hq)*un_rie;                                     // :441-442
+        fe = swe_depth_pt<NONLIN, WD>(hq, eta_rie2, alq)*un_rie;                       // :441-442
         if (NONLIN) {
             const double un_rie3 = un_avg + sqrt(g/Hq)*eta_jump;                       // :507
             fu += un_rie3*0.5*(u_ext + uq);
@@ -191,9 +205,10 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
 }
 
 // Both quadrature points of a boundary facet; kept out of line of the interior fast path (few cells take it).
-template <bool NONLIN, bool LF>
+template <bool NONLIN, bool LF, bool WD>
 __device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int marker, double ua, double ub, double va,
-                                                   double vb, double ea, double eb, double ha, double hb, double nxs,
+                                                   double vb, double ea, double eb, double ha, double hb, double Ha,
+                                                   double Hb, double ala, double alb, double nxs,
                                                    double nys, double L, double rL, double &Fau, double &Fbu,
                                                    double &Fav, double &Fbv, double &Fae, double &Fbe)
 {
@@ -201,8 +216,9 @@ __device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int ma
     for (int q = 0; q < 2; q++) {
         const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
         const double uq = xa*ua + xb*ub, vq = xa*va + xb*vb, eq = xa*ea + xb*eb, hq = xa*ha + xb*hb;
+        const double Hq = xa*Ha + xb*Hb, alq = xa*ala + xb*alb;     // Ha, Hb: nodal total depth (h, h + eta or D)
         double fu, fv, fe;
-        swe_boundary_flux<NONLIN, LF>(p, marker, uq, vq, eq, hq, nxs, nys, L, rL, fu, fv, fe);
+        swe_boundary_flux<NONLIN, LF, WD>(p, marker, uq, vq, eq, hq, Hq, alq, nxs, nys, L, rL, fu, fv, fe);
         Fau += xa*fu; Fbu += xb*fu;
         Fav += xa*fv; Fbv += xb*fv;
         Fae += xa*fe; Fbe += xb*fe;
@@ -298,7 +314,7 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
     }
 }
 
-template <bool NONLIN, bool LF, bool HASU0, bool SRC>
+template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD>
 __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(const SweStageArgs p)
 {
 #ifdef SWE_NO_XCD_MAP
@@ -336,8 +352,13 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         if (HASU0) {
             wu[i] += p.a0*p.u0[(size_t)i*S + k];
             wv[i] += p.a0*p.u0[(size_t)(3 + i)*S + k];
-            we[i] += p.a0*p.u0[(size_t)(6 + i)*S + k];
+            if (!WD) we[i] += p.a0*p.u0[(size_t)(6 + i)*S + k];
         }
+    }
+    double e0[3] = {0.0, 0.0, 0.0};
+    if (WD && HASU0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) e0[i] = p.u0[(size_t)(6 + i)*S + k];
     }
     // neighbour traces: the neighbour traverses the shared facet backwards, its node (f2+1)%3 sits on my node f and
     // its node f2 on my node f+1.  Boundary facets read this cell itself (value unused) to keep the loads branch-free.
@@ -355,13 +376,18 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         ena[f] = p.uin[(size_t)(6 + na)*S + kn];
         enb[f] = p.uin[(size_t)(6 + f2)*S + kn];
     }
-    double px[3], py[3], h[3], H[3];
+    double px[3], py[3], h[3], H[3], al[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         px[i] = p.vx[vid[i]];
         py[i] = p.vy[vid[i]];
         h[i] = p.vh[vid[i]];
-        H[i] = NONLIN ? h[i] + e[i] : h[i];
+        if (WD) al[i] = p.valpha[vid[i]];
+        H[i] = WD ? swe_wd_depth(h[i] + e[i], al[i]) : (NONLIN ? h[i] + e[i] : h[i]);
+        if (WD) {           // the continuity equation advances zeta = D - h
+            we[i] = p.a1*(H[i] - h[i]);
+            if (HASU0) we[i] += p.a0*(swe_wd_depth(h[i] + e0[i], al[i]) - h[i]);
+        }
     }
     // scaled outward normals nF_f = |F| n of facet f (vertex f -> f+1); counter-clockwise cell
     double nx[3], ny[3];
@@ -416,6 +442,9 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         swe_sqrt_rsqrt(len2, L, rL);
         double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
         if (nb[f] >= 0) {
+            // neighbour's nodal depth on this facet (bathymetry and alpha are continuous: same vertices)
+            const double Dna = WD ? swe_wd_depth(h[a] + ena[f], al[a]) : 0.0;
+            const double Dnb = WD ? swe_wd_depth(h[b] + enb[f], al[b]) : 0.0;
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
@@ -423,7 +452,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
                 const double hq = xa*h[a] + xb*h[b];
                 const double un = xa*una[f] + xb*unb[f], vn = xa*vna[f] + xb*vnb[f], en = xa*ena[f] + xb*enb[f];
                 const double eav = 0.5*(eq + en);
-                const double Hav = NONLIN ? hq + eav : hq;
+                const double Hav = WD ? 0.5*((xa*H[a] + xb*H[b]) + (xa*Dna + xb*Dnb)) : (NONLIN ? hq + eav : hq);
                 const double c = swe_sqrt(g*Hav);
                 const double du = uq - un, dv = vq - vn;
                 const double dun = du*nxs + dv*nys;                       // |F| jump(u.n)
@@ -447,8 +476,8 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
                 Fae += xa*fe; Fbe += xb*fe;
             }
         } else {
-            swe_boundary_facet<NONLIN, LF>(p, -nb[f], u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], nxs, nys, L, rL,
-                                           Fau, Fbu, Fav, Fbv, Fae, Fbe);
+            swe_boundary_facet<NONLIN, LF, WD>(p, -nb[f], u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
+                                               al[a], al[b], nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
         }
         bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
         bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
@@ -462,7 +491,13 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     for (int i = 0; i < 3; i++) {
         p.uout[(size_t)i*S + k] = s*(4.0*bu[i] - su) + wu[i];
         p.uout[(size_t)(3 + i)*S + k] = s*(4.0*bv[i] - sv) + wv[i];
-        p.uout[(size_t)(6 + i)*S + k] = s*(4.0*be[i] - se) + we[i];
+        const double znew = s*(4.0*be[i] - se) + we[i];
+        if (WD) {
+            const double D = znew + h[i];
+            p.uout[(size_t)(6 + i)*S + k] = D - al[i]*al[i]/(4.0*D) - h[i];
+        } else {
+            p.uout[(size_t)(6 + i)*S + k] = znew;
+        }
     }
 }
 
@@ -520,7 +555,7 @@ __global__ void swe_halo_unpack(double *planes, size_t stride, int first_ghost, 
 // diagnostics: per-block partial sums { int eta^2, int |u|^2, int (eta+h), min(h+eta) }, finished on the host
 __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel(const double *planes, size_t stride, const int *cv,
                                                              const double *vx, const double *vy, const double *vh,
-                                                             int n, double *partial)
+                                                             int n, double *partial, const double *valpha)
 {
     __shared__ double red[4][SWE_BLOCK];
     const int k = blockIdx.x*SWE_BLOCK + threadIdx.x;
@@ -533,12 +568,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel(const double *plane
             e[i] = planes[(size_t)(6 + i)*stride + k];
             const int vid = cv[(size_t)i*stride + k];
             px[i] = vx[vid]; py[i] = vy[vid]; h[i] = vh[vid];
+            h[i] = valpha ? swe_wd_depth(h[i] + e[i], valpha[vid]) : h[i] + e[i];      // nodal total depth
         }
         const double A = 0.5*((px[1] - px[0])*(py[2] - py[0]) - (px[2] - px[0])*(py[1] - py[0]));
         s_e2 = A*(1.0/12.0)*swe_int2(e, e);
         s_u2 = A*(1.0/12.0)*(swe_int2(u, u) + swe_int2(v, v));
-        s_vol = A*(1.0/3.0)*(e[0] + e[1] + e[2] + h[0] + h[1] + h[2]);
-        s_min = fmin(fmin(h[0] + e[0], h[1] + e[1]), h[2] + e[2]);
+        s_vol = A*(1.0/3.0)*(h[0] + h[1] + h[2]);
+        s_min = fmin(fmin(h[0], h[1]), h[2]);
     }
     red[0][threadIdx.x] = s_e2; red[1][threadIdx.x] = s_u2; red[2][threadIdx.x] = s_vol; red[3][threadIdx.x] = s_min;
     __syncthreads();
@@ -822,7 +858,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_calibration_copy(const double *
 // mass inverse: (M^-1 b)_i = (16 b_i - 8 b_{i+1} - 8 b_{i-1} + 4 b_{i+2})/A.
 // Algorithmic bytes per cell per stage: 96 read + 96 write (+96 U0 in stages 2,3) + 56 static.
 // ===============================================================================================================
-template <bool NONLIN, bool LF, bool HASU0, bool SRC>
+template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD>
 __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStageArgs p)
 {
 #ifdef SWE_NO_XCD_MAP
@@ -857,8 +893,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         if (HASU0) {
             wu[i] += p.a0*p.u0[(size_t)i*S + k];
             wv[i] += p.a0*p.u0[(size_t)(4 + i)*S + k];
-            we[i] += p.a0*p.u0[(size_t)(8 + i)*S + k];
+            if (!WD) we[i] += p.a0*p.u0[(size_t)(8 + i)*S + k];
         }
+    }
+    double e0[4] = {0.0, 0.0, 0.0, 0.0};
+    if (WD && HASU0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) e0[i] = p.u0[(size_t)(8 + i)*S + k];
     }
     double una[4], unb[4], vna[4], vnb[4], ena[4], enb[4];
 #pragma unroll
@@ -874,13 +915,18 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         ena[f] = p.uin[(size_t)(8 + na)*S + kn];
         enb[f] = p.uin[(size_t)(8 + f2)*S + kn];
     }
-    double px[4], py[4], h[4], H[4];
+    double px[4], py[4], h[4], H[4], al[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         px[i] = p.vx[vid[i]];
         py[i] = p.vy[vid[i]];
         h[i] = p.vh[vid[i]];
-        H[i] = NONLIN ? h[i] + e[i] : h[i];
+        if (WD) al[i] = p.valpha[vid[i]];
+        H[i] = WD ? swe_wd_depth(h[i] + e[i], al[i]) : (NONLIN ? h[i] + e[i] : h[i]);
+        if (WD) {           // the continuity equation advances zeta = D - h
+            we[i] = p.a1*(H[i] - h[i]);
+            if (HASU0) we[i] += p.a0*(swe_wd_depth(h[i] + e0[i], al[i]) - h[i]);
+        }
     }
     const double ax = px[1] - px[0], ay = py[1] - py[0];
     const double bx = px[3] - px[0], by = py[3] - py[0];
@@ -963,6 +1009,9 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         swe_sqrt_rsqrt(len2, L, rL);
         double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
         if (nb[f] >= 0) {
+            // neighbour's nodal depth on this facet (bathymetry and alpha are continuous: same vertices)
+            const double Dna = WD ? swe_wd_depth(h[a] + ena[f], al[a]) : 0.0;
+            const double Dnb = WD ? swe_wd_depth(h[b] + enb[f], al[b]) : 0.0;
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
@@ -970,7 +1019,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
                 const double hq = xa*h[a] + xb*h[b];
                 const double un = xa*una[f] + xb*unb[f], vn = xa*vna[f] + xb*vnb[f], en = xa*ena[f] + xb*enb[f];
                 const double eav = 0.5*(eq + en);
-                const double Hav = NONLIN ? hq + eav : hq;
+                const double Hav = WD ? 0.5*((xa*H[a] + xb*H[b]) + (xa*Dna + xb*Dnb)) : (NONLIN ? hq + eav : hq);
                 const double c = swe_sqrt(g*Hav);
                 const double du = uq - un, dv = vq - vn;
                 const double dun = du*nxs + dv*nys;
@@ -994,8 +1043,8 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
                 Fae += xa*fe; Fbe += xb*fe;
             }
         } else {
-            swe_boundary_facet<NONLIN, LF>(p, -nb[f], u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], nxs, nys, L, rL,
-                                           Fau, Fbu, Fav, Fbv, Fae, Fbe);
+            swe_boundary_facet<NONLIN, LF, WD>(p, -nb[f], u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
+                                               al[a], al[b], nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
         }
         bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
         bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
@@ -1009,7 +1058,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         const int n1 = (i + 1) & 3, n2 = (i + 2) & 3, n3 = (i + 3) & 3;
         p.uout[(size_t)i*S + k] = s*(16.0*bu[i] - 8.0*bu[n1] - 8.0*bu[n3] + 4.0*bu[n2]) + wu[i];
         p.uout[(size_t)(4 + i)*S + k] = s*(16.0*bv[i] - 8.0*bv[n1] - 8.0*bv[n3] + 4.0*bv[n2]) + wv[i];
-        p.uout[(size_t)(8 + i)*S + k] = s*(16.0*be[i] - 8.0*be[n1] - 8.0*be[n3] + 4.0*be[n2]) + we[i];
+        const double znew = s*(16.0*be[i] - 8.0*be[n1] - 8.0*be[n3] + 4.0*be[n2]) + we[i];
+        if (WD) {
+            const double D = znew + h[i];
+            p.uout[(size_t)(8 + i)*S + k] = D - al[i]*al[i]/(4.0*D) - h[i];
+        } else {
+            p.uout[(size_t)(8 + i)*S + k] = znew;
+        }
     }
 }
 
@@ -1025,7 +1080,7 @@ __device__ __forceinline__ double swe_int2_quad(const double a[4], const double 
 
 __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel_quad(const double *planes, size_t stride, const int *cv,
                                                                   const double *vx, const double *vy, const double *vh,
-                                                                  int n, double *partial)
+                                                                  int n, double *partial, const double *valpha)
 {
     __shared__ double red[4][SWE_BLOCK];
     const int k = blockIdx.x*SWE_BLOCK + threadIdx.x;
@@ -1038,12 +1093,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel_quad(const double *
             e[i] = planes[(size_t)(8 + i)*stride + k];
             const int vid = cv[(size_t)i*stride + k];
             px[i] = vx[vid]; py[i] = vy[vid]; h[i] = vh[vid];
+            h[i] = valpha ? swe_wd_depth(h[i] + e[i], valpha[vid]) : h[i] + e[i];      // nodal total depth
         }
         const double A = (px[1] - px[0])*(py[3] - py[0]) - (py[1] - py[0])*(px[3] - px[0]);
         s_e2 = A*(1.0/36.0)*swe_int2_quad(e, e);
         s_u2 = A*(1.0/36.0)*(swe_int2_quad(u, u) + swe_int2_quad(v, v));
-        s_vol = A*0.25*(e[0] + e[1] + e[2] + e[3] + h[0] + h[1] + h[2] + h[3]);
-        s_min = fmin(fmin(h[0] + e[0], h[1] + e[1]), fmin(h[2] + e[2], h[3] + e[3]));
+        s_vol = A*0.25*(h[0] + h[1] + h[2] + h[3]);
+        s_min = fmin(fmin(h[0], h[1]), fmin(h[2], h[3]));
     }
     red[0][threadIdx.x] = s_e2; red[1][threadIdx.x] = s_u2; red[2][threadIdx.x] = s_vol; red[3][threadIdx.x] = s_min;
     __syncthreads();

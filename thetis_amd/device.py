@@ -42,6 +42,7 @@ class Swe2dDevice(object):
             raise ValueError('bathymetry must have one value per vertex')
         # ---- device numbering: perm[i_dev] = i_caller
         self.perm = None
+        self._vperm = None
         if reorder is not None:
             if isinstance(reorder, str):
                 if reorder not in ('hilbert', 'auto'):
@@ -74,6 +75,7 @@ class Swe2dDevice(object):
             cells0 = vinv[cells0]
             xy0 = xy0[vperm]
             bath0 = bath0[vperm]
+            self._vperm = vperm
         self._topo_cells = None
         self._limiter_ready = False
         topo = getattr(mesh, 'topo_vertex', None)
@@ -170,6 +172,21 @@ class Swe2dDevice(object):
             else:
                 raise Exception('Invalid boundary tag "{:}" specified on boundary {:}'.format(key, marker))
         self._ck(self.lib.swe2d_set_bc(self.h, int(marker), kind, _ptr(vals)))
+
+    def set_wetting_and_drying(self, alpha):
+        """Enable the explicit wetting-drying formulation; ``alpha``: constant or per-vertex array; None disables."""
+        if alpha is None:
+            self._ck(self.lib.swe2d_set_wetting_and_drying(self.h, 0, None))
+            return
+        nv = self._keep[1].shape[0]                      # device vertices (first-touch numbering)
+        a = np.asarray(alpha, dtype=np.float64)
+        if a.ndim == 0:
+            a = np.full(nv, float(a))
+        elif self._vperm is not None:
+            a = a[self._vperm]
+        a = np.ascontiguousarray(a)
+        assert a.shape == (nv,), 'alpha must be a constant or have one value per vertex'
+        self._ck(self.lib.swe2d_set_wetting_and_drying(self.h, 1, _ptr(a)))
 
     def set_field(self, field, nodal):
         if nodal is None:

@@ -76,6 +76,15 @@ class ERKGenericShuOsher(TimeIntegrator):
             device_id=device_id, boundary_len=getattr(mesh, 'boundary_len', None))
         self._uploaded_version = None
         self._device_ahead = False
+        if equation.depth.use_wetting_and_drying:
+            alpha = equation.depth.wetting_and_drying_alpha
+            if isinstance(alpha, Function):
+                if alpha.function_space().family != 'CG':
+                    raise NotImplementedError('wetting_and_drying_alpha must be a Constant or a CG-P1 Function')
+                alpha = alpha.dat.data_ro
+            else:
+                alpha = float(alpha)
+            self.device.set_wetting_and_drying(alpha)
         self._push_fields()
         self._push_bcs()
         uv, eta = self.solution.subfunctions

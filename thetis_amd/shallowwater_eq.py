@@ -47,10 +47,12 @@ class ShallowWaterEquations(object):
         if options.element_family != 'dg-dg' or options.polynomial_degree != 1:
             raise NotImplementedError("the device path implements element_family='dg-dg', polynomial_degree=1 only "
                                       "(got {!r}, degree {:})".format(options.element_family, options.polynomial_degree))
-        if depth.use_wetting_and_drying:
-            # mass_term(TrialFunction) is not bilinear with wetting-drying (shallowwater_eq.py:917-920,
-            # rungekutta.py:900), so the reference itself cannot run SSPRK33 with it.
-            raise NotImplementedError('use_wetting_and_drying is not a valid configuration of the explicit SSPRK33 path')
+        if depth.use_wetting_and_drying and not options.use_nonlinear_equations:
+            raise Exception('use_wetting_and_drying needs use_nonlinear_equations')
+        # NOTE with use_wetting_and_drying the reference's mass_term(TrialFunction) is not bilinear (shallowwater_eq.py:
+        # 917-920, rungekutta.py:900), i.e. the reference cannot run SSPRK33 with it.  The device path
+        # runs this build's own explicit formulation of the same displaced depth: nodally
+        # interpolated D = (H + sqrt(H^2 + alpha^2))/2, continuity advanced in zeta = D - h.
 
     def check_fields(self, fields):
         """Raise for coefficients whose terms the kernel does not implement (never silently ignore physics)."""

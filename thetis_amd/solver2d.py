@@ -90,6 +90,43 @@ class FlowSolver2d(object):
             self.dt = self.options.timestep
         print_output('dt = {:}'.format(self.dt))
 
+    def set_wetting_and_drying_alpha(self):
+        """Wetting-drying parameter alpha ~ |L_x grad h| (solver2d.py:251-303, Kaernae et al. 2011): per cell the
+        bounding widths (utility.py:729-738) dotted with |grad h|, clipped to [alpha_min, alpha_max], then brought to P1.
+        Firedrake ``interpolate``s the cell-wise expression into P1 [FD-assumed: which adjacent cell a vertex takes its
+        value from is unspecified]; here a vertex takes the maximum over its adjacent cells."""
+        o = self.options
+        if not o.use_wetting_and_drying:
+            return
+        if o.use_automatic_wetting_and_drying_alpha:
+            m = self.mesh2d
+            p = m.cell_xy()
+            h = self.fields.bathymetry_2d.dat.data_ro[m.cells]
+            widths = np.abs(p - np.roll(p, 1, axis=1)).max(axis=1)                      # (N, 2): max |dx|, max |dy|
+            # grad h of the P1/Q1 bathymetry, from a least-squares plane through the cell's vertices
+            d = p - p.mean(axis=1, keepdims=True)
+            g = np.einsum('nij,nj->ni', np.linalg.pinv(d), h - h.mean(axis=1, keepdims=True))
+            alpha_c = (widths*np.abs(g)).sum(axis=1)
+            amax, amin = o.wetting_and_drying_alpha_max, o.wetting_and_drying_alpha_min
+            if amax is not None:
+                alpha_c = np.minimum(float(amax), alpha_c)
+            if amin is not None:
+                alpha_c = np.maximum(float(amin), alpha_c)
+            av = np.zeros(m.num_vertices)
+            for i in range(m.cells.shape[1]):
+                np.maximum.at(av, m.cells[:, i], alpha_c)
+            if not hasattr(self.function_spaces, 'P1_2d'):
+                self.create_function_spaces()
+            o.wetting_and_drying_alpha = Function(self.function_spaces.P1_2d).assign(av)
+        alpha = o.wetting_and_drying_alpha
+        if isinstance(alpha, Function):
+            a = alpha.dat.data_ro
+            assert a.min() >= 0.0
+            print_output('Using spatially varying wetting and drying parameter (min {:.2f} max {:.2f})'.format(a.min(), a.max()))
+        else:
+            assert float(alpha) >= 0.0
+            print_output('Using constant wetting and drying parameter (value {:.2f})'.format(float(alpha)))
+
     # ------------------------------------------------------------------ setup
     def create_function_spaces(self):
         """solver2d.py:307-352, 'dg-dg' branch"""
@@ -120,6 +157,7 @@ class FlowSolver2d(object):
             self.fields[label] = topts.function if topts.function is not None else Function(self.function_spaces.Q_2d, name=label)
         # mesh element size: CG-P1 L2 projection of sqrt(cell area), utility.py:620-640 (needed for automatic dt only)
         self.fields.h_elem_size_2d = None
+        self.set_wetting_and_drying_alpha()
         self.depth = DepthExpression(self.fields.bathymetry_2d,
                                      use_nonlinear_equations=self.options.use_nonlinear_equations,
                                      use_wetting_and_drying=self.options.use_wetting_and_drying,
