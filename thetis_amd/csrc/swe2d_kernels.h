@@ -314,6 +314,8 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
     }
 }
 
+// Register budget: 132 (first stage) / 150 VGPRs, 3 waves per SIMD, no scratch.  Forcing 4 waves on the first stage
+// (128 VGPRs) spills 20 B/lane, adds 16 MB of scratch writes per launch and is not faster; forcing 5-6 waves is 2-3x slower.
 template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD>
 __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(const SweStageArgs p)
 {

@@ -35,8 +35,10 @@ def main():
     if args.order.startswith('tile'):
         _, bx, by = args.order.split(':')
         reorder = tile_perm(mesh, int(bx), int(by))
-    elif args.order == 'hilbert':
-        reorder = 'hilbert'
+    elif args.order in ('hilbert', 'auto'):
+        reorder = args.order
+    elif args.order != 'natural':
+        raise SystemExit('unknown --order ' + args.order)
     elif args.order == 'hilbert-rows':
         from thetis_amd import ordering
         cen = mesh.cell_xy().mean(axis=1)
