@@ -185,15 +185,17 @@ int  swe2d_advance_coupled(swe2d_handle *h, int n_steps, int tracer_only, int us
 int  swe2d_debug_calibration_copy(swe2d_handle *h, int n_times);
 
 /* ---- multi-GPU plumbing (one process per GPU; the exchange itself is done by the host with RCCL) ----
- * send_cells: local ids of owned cells whose state peers need, grouped by peer; the n_cells-n_owned ghost cells are
- * stored in the order the peers' send lists deliver them.  Buffers are device pointers owned by the caller
- * (cell-major: 3k doubles u0..u(k-1) v0.. e0.. per cell, [n][3k], k = nodes_per_cell, so per-peer segments are contiguous). */
-int  swe2d_halo_setup(swe2d_handle *h, int32_t n_send, const int32_t *send_cells);
-int  swe2d_halo_pack(swe2d_handle *h, int i_stage, double *send_buf_dev);          /* state entering stage i */
-int  swe2d_halo_unpack(swe2d_handle *h, int i_stage, const double *recv_buf_dev);
-/* stage split for overlap: cells [0, n_interior) need no ghost data, cells [n_interior, n_owned) do. */
-int  swe2d_set_interior_split(swe2d_handle *h, int32_t n_interior);
-int  swe2d_solve_stage_range(swe2d_handle *h, int i_stage, int which /*0: interior, 1: boundary, 2: all*/);
+ * Replaces PyOP2's per-par_loop halo exchange [FD-assumed] by ONE exchange per time step: a partition carries three layers
+ * of ghost cells (cells n_owned..n_cells-1, layer by layer); stage i is run on cells [0, n_owned + layers still needed),
+ * see thetis_amd/partition.py.  send_cells: local ids of owned cells whose state peers need, grouped by peer;
+ * recv_cells: local ids of the ghost cells in the order the peers' messages deliver them.  Buffers are device pointers
+ * owned by the caller (cell-major: 3k doubles u0..u(k-1) v0.. e0.. per cell, [n][3k], k = nodes_per_cell, so per-peer
+ * segments are contiguous).  i_buffer selects the state buffer (0 = the step result / stage-1 input). */
+int  swe2d_halo_setup(swe2d_handle *h, int32_t n_send, const int32_t *send_cells, int32_t n_recv, const int32_t *recv_cells);
+int  swe2d_halo_pack(swe2d_handle *h, int i_buffer, double *send_buf_dev);
+int  swe2d_halo_unpack(swe2d_handle *h, int i_buffer, const double *recv_buf_dev);
+/* ERKGenericShuOsher.solve_stage restricted to cells [cell_begin, cell_end) (may include ghost layers) */
+int  swe2d_solve_stage_cells(swe2d_handle *h, int i_stage, int32_t cell_begin, int32_t cell_end);
 /* run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the handle's own */
 int  swe2d_set_stream(swe2d_handle *h, void *hip_stream);
 

@@ -34,9 +34,10 @@ def _init(rank, world, port):
 
 
 def cpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
+    """Partition + halo exchange logic of the product (3-layer halo, one exchange per step), with the oracle's C
+    restatement as the (CPU) compute."""
     global CASE
     CASE = case
-    """Partition + halo exchange logic of the product, with the oracle's C restatement as the (CPU) compute."""
     import torch
     from oracle.ref_lib import RefSWE
     from thetis_amd.distributed import HaloExchanger
@@ -52,25 +53,33 @@ def cpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     halo = HaloExchanger(part, torch.device('cpu'))
     dt = 2.0
     no = part.n_owned
+    k = part.cells.shape[1]
     al0 = [0.0, 0.75, 0.33333333333333337]
     ali = [1.0, 0.25, 0.6666666666666666]
     be = [1.0, 0.25, 0.6666666666666666]
 
     def exchange(u, e):
-        sc = part.send_cells
-        packed = np.concatenate([u[sc, :, 0], u[sc, :, 1], e[sc]], axis=1)      # [n][9] = u0 u1 u2 v0 v1 v2 e0 e1 e2
+        sc, rc = part.send_cells, part.recv_cells
+        packed = np.concatenate([u[sc, :, 0], u[sc, :, 1], e[sc]], axis=1)      # [n][3k] = u.. v.. e..
         halo.send_buf[:packed.size] = torch.from_numpy(packed.reshape(-1))
         halo.finish(halo.start())
-        r = halo.recv_buf[:9*part.n_ghost].numpy().reshape(-1, 9)
-        u[no:, :, 0], u[no:, :, 1], e[no:] = r[:, 0:3], r[:, 3:6], r[:, 6:9]
+        r = halo.recv_buf[:3*k*len(rc)].numpy().reshape(-1, 3*k)
+        u[rc, :, 0], u[rc, :, 1], e[rc] = r[:, 0:k], r[:, k:2*k], r[:, 2*k:3*k]
 
     for _ in range(n_steps):
-        u0, e0 = u.copy(), e.copy()
+        u0, e0 = u.copy(), e.copy()                 # ghosts of the step input are valid (initial state / last exchange)
+        cur_u, cur_e = u, e
         for i in range(3):
-            exchange(u, e)
-            ku, ke = ref.tendency(u, e, dt)
-            u[:no] = be[i]*ku[:no] + al0[i]*u0[:no] + ali[i]*u[:no]
-            e[:no] = be[i]*ke[:no] + al0[i]*e0[:no] + ali[i]*e[:no]
+            end = part.stage_range(i)
+            ku, ke = ref.tendency(cur_u, cur_e, dt)      # computed everywhere; only cells [0, end) are meaningful
+            new_u, new_e = cur_u.copy(), cur_e.copy()
+            new_u[:end] = be[i]*ku[:end] + al0[i]*u0[:end] + ali[i]*cur_u[:end]
+            new_e[:end] = be[i]*ke[:end] + al0[i]*e0[:end] + ali[i]*cur_e[:end]
+            new_u[end:], new_e[end:] = np.nan, np.nan    # stale layers must never be read by a later stage
+            cur_u, cur_e = new_u, new_e
+        u, e = cur_u, cur_e
+        exchange(u, e)
+        assert not np.isnan(u).any() and not np.isnan(e).any()
     np.savez(os.path.join(out_dir, 'rank{:d}.npz'.format(rank)), ids=g[:no], uv=u[:no], eta=e[:no],
              n_interior=part.n_interior, n_ghost=part.n_ghost)
     dist.barrier()

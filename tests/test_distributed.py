@@ -19,22 +19,31 @@ def test_partition_invariants(world, axis):
     assert sorted(seen) == list(range(mesh.num_cells))           # every cell owned exactly once
     for p in parts:
         g = p.local_to_global
-        # interior cells touch no ghost, boundary cells do
-        nb = p.cell_nbr[:p.n_owned]
-        touches = (nb >= p.n_owned).any(axis=1)
-        assert not touches[:p.n_interior].any() and touches[p.n_interior:].all()
-        # local connectivity is the global one
-        for k in range(p.n_owned):
+        assert len(p.layer_sizes) == 3 and sum(p.layer_sizes) == p.n_ghost
+        assert [p.stage_range(i) for i in range(3)] == [p.n_owned + p.layer_sizes[0] + p.layer_sizes[1],
+                                                        p.n_owned + p.layer_sizes[0], p.n_owned]
+        # a cell updated by stage i only reads cells that stage i-1 updated (or the exchanged step input)
+        for i in range(3):
+            end = p.stage_range(i)
+            valid_in = p.num_cells if i == 0 else p.stage_range(i - 1)
+            nb = p.cell_nbr[:end]
+            assert nb.max() < valid_in
+        # interior cells are in nobody's halo; send cells are
+        sent = np.zeros(p.num_cells, dtype=bool)
+        sent[p.send_cells] = True
+        assert not sent[:p.n_interior].any() and sent[p.n_interior:p.n_owned].all() and not sent[p.n_owned:].any()
+        # local connectivity is the global one wherever a cell is updated
+        for k in range(p.stage_range(0)):
             for f in range(3):
                 gn = mesh.cell_nbr[g[k], f]
                 assert (gn < 0 and p.cell_nbr[k, f] == gn) or g[p.cell_nbr[k, f]] == gn
-        # what peer q sends is exactly my ghost block from q, in the same order
+        # what peer q sends is exactly what I expect to receive from q, in the same order
         for q, (off, cnt) in p.recv.items():
             soff, scnt = parts[q].send[p.rank]
             assert scnt == cnt
             sent_global = parts[q].local_to_global[parts[q].send_cells[soff:soff + scnt]]
-            assert np.array_equal(sent_global, g[p.n_owned + off:p.n_owned + off + cnt])
-        assert sum(c for _, c in p.recv.values()) == p.n_ghost
+            assert np.array_equal(sent_global, g[p.recv_cells[off:off + cnt]])
+        assert sorted(p.recv_cells) == list(range(p.n_owned, p.num_cells))    # every ghost is received exactly once
         assert len(p.peers) <= 2                                  # strips: one xGMI link per side
 
 

@@ -71,11 +71,10 @@ SYMBOLS = {
     'swe2d_tracer_diagnostics': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_advance_coupled': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'swe2d_debug_calibration_copy': (ctypes.c_int, [_H, ctypes.c_int]),
-    'swe2d_halo_setup': (ctypes.c_int, [_H, ctypes.c_int32, _ip]),
+    'swe2d_halo_setup': (ctypes.c_int, [_H, ctypes.c_int32, _ip, ctypes.c_int32, _ip]),
     'swe2d_halo_pack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_void_p]),
     'swe2d_halo_unpack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_void_p]),
-    'swe2d_set_interior_split': (ctypes.c_int, [_H, ctypes.c_int32]),
-    'swe2d_solve_stage_range': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int]),
+    'swe2d_solve_stage_cells': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_set_stream': (ctypes.c_int, [_H, ctypes.c_void_p]),
 }
 

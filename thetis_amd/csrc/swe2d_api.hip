@@ -42,8 +42,8 @@ struct Handle {
     double *stage_uv = nullptr, *stage_eta = nullptr;  // device staging in host layout (6N + 3N)
     double *partial = nullptr;                         // diagnostics partial sums
     int n_partial_blocks = 0;
-    int *send_cells = nullptr;
-    int n_send = 0;
+    int *send_cells = nullptr, *recv_cells = nullptr;
+    int n_send = 0, n_recv = 0;
     // tracers + limiter
     struct Tracer {
         double *buf[3] = {nullptr, nullptr, nullptr};   // A (T0 / result), B, C: 3 planes each
@@ -360,7 +360,7 @@ void swe2d_destroy(swe2d_handle *hh)
         for (int b = 0; b < 3; b++) if (t.buf[b]) (void)hipFree(t.buf[b]);
         if (t.source) (void)hipFree(t.source);
     }
-    void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells,
+    void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
                     h->lim_qmin, h->lim_qmax, h->valpha};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -499,29 +499,22 @@ int swe2d_set_wetting_and_drying(swe2d_handle *hh, int enable, const double *alp
     return SWE2D_OK;
 }
 
-int swe2d_set_interior_split(swe2d_handle *hh, int32_t n_interior)
+int swe2d_solve_stage_cells(swe2d_handle *hh, int i_stage, int32_t cell_begin, int32_t cell_end)
 {
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
-    if (n_interior < 0 || n_interior > h->n_owned) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "n_interior out of range");
-    h->n_interior = n_interior;
-    return SWE2D_OK;
-}
-
-int swe2d_solve_stage_range(swe2d_handle *hh, int i_stage, int which)
-{
-    Handle *h = H(hh);
-    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (cell_begin < 0 || cell_end > h->n_cells || cell_begin > cell_end)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell range");
     HIP_TRY(h, hipSetDevice(h->device));
-    switch (which) {
-    case 0: return stage_on_range(h, i_stage, 0, h->n_interior);
-    case 1: return stage_on_range(h, i_stage, h->n_interior, h->n_owned);
-    case 2: return stage_on_range(h, i_stage, 0, h->n_owned);
-    default: return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "which must be 0, 1 or 2");
-    }
+    return stage_on_range(h, i_stage, cell_begin, cell_end);
 }
 
-int swe2d_solve_stage(swe2d_handle *hh, int i_stage) { return swe2d_solve_stage_range(hh, i_stage, 2); }
+int swe2d_solve_stage(swe2d_handle *hh, int i_stage)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    return swe2d_solve_stage_cells(hh, i_stage, 0, h->n_owned);
+}
 
 int swe2d_advance(swe2d_handle *hh, int n_steps)
 {
@@ -638,46 +631,55 @@ int swe2d_diagnostics(swe2d_handle *hh, double out[4])
     return SWE2D_OK;
 }
 
-int swe2d_halo_setup(swe2d_handle *hh, int32_t n_send, const int32_t *send_cells)
+int swe2d_halo_setup(swe2d_handle *hh, int32_t n_send, const int32_t *send_cells, int32_t n_recv, const int32_t *recv_cells)
 {
     Handle *h = H(hh);
-    if (!h || n_send < 0 || (n_send > 0 && !send_cells)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad halo lists");
+    if (!h || n_send < 0 || n_recv < 0 || (n_send > 0 && !send_cells) || (n_recv > 0 && !recv_cells))
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad halo lists");
     for (int i = 0; i < n_send; i++)
         if (send_cells[i] < 0 || send_cells[i] >= h->n_owned)
             return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "send cell is not an owned cell");
+    for (int i = 0; i < n_recv; i++)
+        if (recv_cells[i] < h->n_owned || recv_cells[i] >= h->n_cells)
+            return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "receive cell is not a ghost cell");
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->send_cells) { HIP_TRY(h, hipFree(h->send_cells)); h->send_cells = nullptr; }
+    if (h->recv_cells) { HIP_TRY(h, hipFree(h->recv_cells)); h->recv_cells = nullptr; }
     h->n_send = n_send;
+    h->n_recv = n_recv;
     if (n_send > 0) {
         HIP_TRY(h, hipMalloc(&h->send_cells, (size_t)n_send*sizeof(int)));
         HIP_TRY(h, hipMemcpy(h->send_cells, send_cells, (size_t)n_send*sizeof(int), hipMemcpyHostToDevice));
     }
+    if (n_recv > 0) {
+        HIP_TRY(h, hipMalloc(&h->recv_cells, (size_t)n_recv*sizeof(int)));
+        HIP_TRY(h, hipMemcpy(h->recv_cells, recv_cells, (size_t)n_recv*sizeof(int), hipMemcpyHostToDevice));
+    }
     return SWE2D_OK;
 }
 
-int swe2d_halo_pack(swe2d_handle *hh, int i_stage, double *send_buf_dev)
+int swe2d_halo_pack(swe2d_handle *hh, int i_buffer, double *send_buf_dev)
 {
     Handle *h = H(hh);
-    if (!h || i_stage < 0 || i_stage > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad stage");
+    if (!h || i_buffer < 0 || i_buffer > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad buffer index");
     if (h->n_send == 0) return SWE2D_OK;
     if (!send_buf_dev) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null send buffer");
     HIP_TRY(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(swe_halo_pack, dim3(grid_for(3*h->npc*h->n_send)), dim3(256), 0, h->stream,
-                       h->state[i_stage], h->stride, h->send_cells, h->n_send, send_buf_dev, 3*h->npc);
+                       h->state[i_buffer], h->stride, h->send_cells, h->n_send, send_buf_dev, 3*h->npc);
     HIP_TRY(h, hipGetLastError());
     return SWE2D_OK;
 }
 
-int swe2d_halo_unpack(swe2d_handle *hh, int i_stage, const double *recv_buf_dev)
+int swe2d_halo_unpack(swe2d_handle *hh, int i_buffer, const double *recv_buf_dev)
 {
     Handle *h = H(hh);
-    if (!h || i_stage < 0 || i_stage > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad stage");
-    const int ng = h->n_cells - h->n_owned;
-    if (ng == 0) return SWE2D_OK;
+    if (!h || i_buffer < 0 || i_buffer > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad buffer index");
+    if (h->n_recv == 0) return SWE2D_OK;
     if (!recv_buf_dev) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null recv buffer");
     HIP_TRY(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(swe_halo_unpack, dim3(grid_for(3*h->npc*ng)), dim3(256), 0, h->stream,
-                       h->state[i_stage], h->stride, h->n_owned, ng, recv_buf_dev, 3*h->npc);
+    hipLaunchKernelGGL(swe_halo_unpack, dim3(grid_for(3*h->npc*h->n_recv)), dim3(256), 0, h->stream,
+                       h->state[i_buffer], h->stride, h->recv_cells, h->n_recv, recv_buf_dev, 3*h->npc);
     HIP_TRY(h, hipGetLastError());
     return SWE2D_OK;
 }

@@ -546,12 +546,12 @@ __global__ void swe_halo_pack(const double *planes, size_t stride, const int *ce
     buf[t] = planes[(size_t)q*stride + cells[j]];
 }
 
-__global__ void swe_halo_unpack(double *planes, size_t stride, int first_ghost, int n, const double *buf, int np)
+__global__ void swe_halo_unpack(double *planes, size_t stride, const int *cells, int n, const double *buf, int np)
 {
     const int t = blockIdx.x*blockDim.x + threadIdx.x;
     if (t >= np*n) return;
     const int j = t/np, q = t - np*j;
-    planes[(size_t)q*stride + first_ghost + j] = buf[t];
+    planes[(size_t)q*stride + cells[j]] = buf[t];
 }
 
 // diagnostics: per-block partial sums { int eta^2, int |u|^2, int (eta+h), min(h+eta) }, finished on the host

@@ -209,8 +209,9 @@ class Swe2dDevice(object):
     def solve_stage(self, i_stage):
         self._ck(self.lib.swe2d_solve_stage(self.h, int(i_stage)))
 
-    def solve_stage_range(self, i_stage, which):
-        self._ck(self.lib.swe2d_solve_stage_range(self.h, int(i_stage), int(which)))
+    def solve_stage_cells(self, i_stage, cell_begin, cell_end):
+        """Stage ``i_stage`` on device cells [cell_begin, cell_end) (partitions: may include ghost layers)."""
+        self._ck(self.lib.swe2d_solve_stage_cells(self.h, int(i_stage), int(cell_begin), int(cell_end)))
 
     def advance_timed(self, n_steps, per_launch=False):
         """Returns (total ms, mean ms per stage-kernel launch), measured with HIP events on the launch stream."""
@@ -303,21 +304,21 @@ class Swe2dDevice(object):
         self._ck(self.lib.swe2d_advance_coupled(self.h, int(n_steps), int(bool(tracer_only)), int(bool(use_limiter))))
 
     # -- multi-GPU plumbing
-    def halo_setup(self, send_cells):
-        a = np.asarray(send_cells, dtype=np.int64)
-        if self.perm is not None:
-            a = self.inv_perm[a]
-        a = np.ascontiguousarray(a, dtype=np.int32)
-        self._ck(self.lib.swe2d_halo_setup(self.h, a.size, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+    def halo_setup(self, send_cells, recv_cells):
+        def dev_ids(c):
+            a = np.asarray(c, dtype=np.int64)
+            if self.perm is not None:
+                a = self.inv_perm[a]
+            return np.ascontiguousarray(a, dtype=np.int32)
+        a, b = dev_ids(send_cells), dev_ids(recv_cells)
+        ip = ctypes.POINTER(ctypes.c_int32)
+        self._ck(self.lib.swe2d_halo_setup(self.h, a.size, a.ctypes.data_as(ip), b.size, b.ctypes.data_as(ip)))
 
-    def halo_pack(self, i_stage, send_buf_ptr):
-        self._ck(self.lib.swe2d_halo_pack(self.h, i_stage, ctypes.c_void_p(send_buf_ptr)))
+    def halo_pack(self, i_buffer, send_buf_ptr):
+        self._ck(self.lib.swe2d_halo_pack(self.h, i_buffer, ctypes.c_void_p(send_buf_ptr)))
 
-    def halo_unpack(self, i_stage, recv_buf_ptr):
-        self._ck(self.lib.swe2d_halo_unpack(self.h, i_stage, ctypes.c_void_p(recv_buf_ptr)))
-
-    def set_interior_split(self, n_interior):
-        self._ck(self.lib.swe2d_set_interior_split(self.h, int(n_interior)))
+    def halo_unpack(self, i_buffer, recv_buf_ptr):
+        self._ck(self.lib.swe2d_halo_unpack(self.h, i_buffer, ctypes.c_void_p(recv_buf_ptr)))
 
     def set_stream(self, stream_ptr):
         self._ck(self.lib.swe2d_set_stream(self.h, ctypes.c_void_p(stream_ptr) if stream_ptr else None))

@@ -2,12 +2,14 @@
 One process per GPU: halo exchange over torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
 the CPU tests) around the per-rank C-ABI handle.
 
-Per SSPRK33 stage:   pack owned boundary cells -> isend/irecv with the (<= 2 for strips) peers
-                                    || interior stage kernel      (no ghost data needed)
-                                    -> unpack ghosts -> boundary stage kernel
-The exchange is 72 B (96 B for quadrilaterals) per cut-facet cell (cfg 3: ~500 cells = 36 KB per peer per stage), i.e. pure latency; the whole
-multi-step loop is captured in a HIP graph (torch.cuda.graph) when capture succeeds so that no Python or launch
-latency sits between the ~10 us kernels.
+Per time step (thetis_amd/partition.py: three ghost layers, ONE exchange per step instead of one per stage):
+
+    stage 1 on owned + ghost layers 1,2  ->  stage 2 on owned + layer 1  ->  stage 3 on the send cells
+    -> pack -> isend/irecv with the (<= 2 for strips) peers  ||  stage 3 on the interior cells  -> unpack ghosts
+
+The exchange is 72 B (96 B for quadrilaterals) per halo cell (cfg 3: 1500 cells = 108 KB per peer per step), i.e. pure
+latency, hidden behind the interior part of stage 3; the whole multi-step loop is captured in a HIP graph
+(torch.cuda.graph) when capture succeeds so that no Python or launch latency sits between the ~6 us kernels.
 """
 import os
 import time
@@ -27,7 +29,7 @@ class HaloExchanger(object):
         self.part = part
         self.w = w = 3*int(part.cells.shape[1])        # doubles per cell: u, v, eta at every node
         self.send_buf = torch.zeros(max(1, len(part.send_cells))*w, dtype=torch.float64, device=device)
-        self.recv_buf = torch.zeros(max(1, part.n_ghost)*w, dtype=torch.float64, device=device)
+        self.recv_buf = torch.zeros(max(1, len(part.recv_cells))*w, dtype=torch.float64, device=device)
         # gloo cannot move device memory: stage through the host (test path only; RCCL sends device buffers directly)
         self.host_staged = host_staged
         if host_staged:
@@ -75,8 +77,8 @@ class DistributedSwe2d(object):
         self.torch_device = torch.device('cuda', device_id)
         self.dev = Swe2dDevice(p, np.asarray(bathymetry_vertex)[p.vertex_global], dt, device_id=device_id,
                                n_owned=p.n_owned, boundary_len=p.boundary_len, ranges=(p.n_interior, p.n_owned), **opts)
-        self.dev.halo_setup(p.send_cells)
-        self.dev.set_interior_split(p.n_interior)
+        self.dev.halo_setup(p.send_cells, p.recv_cells)
+        self._ranges = [p.stage_range(i) for i in range(3)]
         self.halo = HaloExchanger(p, self.torch_device, host_staged=host_staged)
         self.stream = torch.cuda.Stream(device=self.torch_device)
         self.dev.set_stream(self.stream.cuda_stream)
@@ -93,19 +95,20 @@ class DistributedSwe2d(object):
         n = self.part.n_owned
         return self.part.local_to_global[:n], uv[:n], eta[:n]
 
-    def _stage(self, i):
-        dev, halo = self.dev, self.halo
-        dev.halo_pack(i, halo.send_buf.data_ptr())
+    def _step(self):
+        dev, halo, p = self.dev, self.halo, self.part
+        dev.solve_stage_cells(0, 0, self._ranges[0])        # owned + ghost layers 1, 2
+        dev.solve_stage_cells(1, 0, self._ranges[1])        # owned + ghost layer 1
+        dev.solve_stage_cells(2, p.n_interior, p.n_owned)   # the cells the peers are waiting for
+        dev.halo_pack(0, halo.send_buf.data_ptr())          # stage 3 leaves the step result in buffer 0
         reqs = halo.start()
-        dev.solve_stage_range(i, 0)              # interior cells overlap the exchange
+        dev.solve_stage_cells(2, 0, p.n_interior)           # interior cells overlap the exchange
         halo.finish(reqs)
-        dev.halo_unpack(i, halo.recv_buf.data_ptr())
-        dev.solve_stage_range(i, 1)              # cells that read ghost traces
+        dev.halo_unpack(0, halo.recv_buf.data_ptr())
 
     def _steps_eager(self, n_steps):
         for _ in range(n_steps):
-            for i in range(3):
-                self._stage(i)
+            self._step()
 
     def advance(self, n_steps, use_graph=True):
         """``n_steps`` SSPRK33 steps (enqueued; call ``synchronize``)."""
@@ -207,8 +210,8 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
             'ms_per_step': float(1e3*t/args.steps), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'BASELINE cfg3: the cfg2 1M-triangle channel strip-partitioned along x over {:d} GPUs, '
-                                   'RCCL facet-halo exchange per stage'.format(world),
-                       'n_cells': int(n_total), 'parallelism': 'dd{:d} (domain decomposition, 1-cell halo)'.format(world),
+                                   '3-layer halo, one RCCL exchange per time step'.format(world),
+                       'n_cells': int(n_total), 'parallelism': 'dd{:d} (domain decomposition, 3-cell halo, 1 exchange/step)'.format(world),
                        'hip_graph': hip_graph, 'volume_conserved': ok},
             'roofline': {'bound': 'hbm', 'achieved': float(per_gpu_bytes*3*args.steps/t/1e9), 'peak': hbm_peak, 'unit': 'GB/s',
                          'frac': float(per_gpu_bytes*3*args.steps/t/1e9/hbm_peak), 'traffic': None,

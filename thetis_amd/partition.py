@@ -2,14 +2,17 @@
 Element partitioning for one-process-per-GPU runs.
 
 The DG stencil couples facet neighbours only (every dS term of thetis/shallowwater_eq.py:363-366,424-427,480-488 uses
-'+'/'-' traces), so a partition = owned cells + ONE layer of facet-adjacent ghost cells - the same overlap Firedrake's
-DMPlex gives the reference [FD-assumed].  Local cell order on every rank:
+'+'/'-' traces).  Firedrake/PyOP2 exchange a one-cell halo before every par_loop, i.e. once per RK stage [FD-assumed].
+On 8 MI355X a stage of the 1M-triangle channel is ~6 us of work, less than one RCCL call, so the exchange is made
+ONCE PER TIME STEP instead: every rank keeps ``halo_depth`` = 3 layers of facet-adjacent ghost cells (one per SSPRK33
+stage) and recomputes them redundantly - stage 1 updates owned + layers 1,2, stage 2 owned + layer 1, stage 3 the owned
+cells only (cfg 3: 2 x 1500 extra cell-updates per rank and step, 0.5 %).  Local cell order on every rank:
 
-    [ interior owned | boundary owned (touch a ghost) | ghosts grouped by owner rank ]
+    [ interior owned | send owned (in some peer's halo) | ghost layer 1 | layer 2 | layer 3 ]
 
-so the interior range can be computed while the halo is in flight.  Send lists and ghost blocks are both ordered by
-global cell id, which makes the layout deterministic on both sides without any handshake: every rank builds its own
-partition from the (replicated) global mesh.
+so that stage 3 can update the send cells first, start the exchange, and update the interior while it is in flight.
+Send lists and receive lists are both ordered by global cell id, which makes the layout deterministic on both sides
+without any handshake: every rank builds its own partition from the (replicated) global mesh.
 """
 import numpy as np
 
@@ -29,7 +32,7 @@ def strip_owner(mesh, n_parts, axis=0):
 
 
 class LocalPartition(object):
-    """Mesh-like view of one rank's cells (owned + ghosts) with halo bookkeeping."""
+    """Mesh-like view of one rank's cells (owned + ghost layers) with halo bookkeeping."""
 
     def __init__(self, rank, n_parts):
         self.rank, self.n_parts = rank, n_parts
@@ -49,27 +52,58 @@ class LocalPartition(object):
     def cell_xy(self):
         return self.vertex_xy[self.cells]
 
+    def stage_range(self, i_stage):
+        """Cells [0, end) that stage ``i_stage`` has to update so that the owned cells are right after stage 3."""
+        depth = len(self.layer_sizes)
+        keep = max(0, depth - 1 - i_stage)              # ghost layers still needed after this stage
+        return self.n_owned + int(sum(self.layer_sizes[:keep]))
 
-def build_partition(mesh, owner, rank):
+
+def _halo_layers(nbr, inside, depth):
+    """Facet-distance layers 1..depth around the cell set ``inside`` (boolean mask)."""
+    dist = np.where(inside, 0, -1).astype(np.int32)
+    frontier = np.nonzero(inside)[0]
+    layers = []
+    for d in range(1, depth + 1):
+        nb = nbr[frontier].ravel()
+        nb = nb[nb >= 0]
+        new = np.unique(nb[dist[nb] < 0])
+        dist[new] = d
+        layers.append(new)
+        frontier = new
+    return layers, dist
+
+
+def build_partition(mesh, owner, rank, halo_depth=3):
     """Local partition of ``rank`` given the global ``owner`` array."""
     owner = np.asarray(owner)
     n_parts = int(owner.max()) + 1
     nbr = mesh.cell_nbr
-    mine = np.nonzero(owner == rank)[0]
-    nb = nbr[mine]                                            # (n_mine, k) global ids
-    valid = nb >= 0
-    nb_owner = np.where(valid, owner[np.where(valid, nb, 0)], rank)
-    touches_ghost = (nb_owner != rank).any(axis=1)
-    interior = mine[~touches_ghost]
-    boundary = mine[touches_ghost]
-    ghost_ids = np.unique(nb[valid & (nb_owner != rank)])
-    ghost_owner = owner[ghost_ids]
-    gorder = np.lexsort((ghost_ids, ghost_owner))             # by owner rank, then global id
-    ghost_ids = ghost_ids[gorder]
-    ghost_owner = ghost_owner[gorder]
+    mine_mask = owner == rank
+    layers, _ = _halo_layers(nbr, mine_mask, halo_depth)
+    # which of my cells do the peers need?  (cells within halo_depth of the peer's owned set)
+    send_global = {}
+    for q in range(n_parts):
+        if q == rank:
+            continue
+        _, dist_q = _halo_layers(nbr, owner == q, halo_depth)
+        hit = np.nonzero(mine_mask & (dist_q > 0))[0]
+        if len(hit):
+            send_global[q] = np.sort(hit)
+    in_send = np.zeros(mesh.num_cells, dtype=bool)
+    for g in send_global.values():
+        in_send[g] = True
+    mine = np.nonzero(mine_mask)[0]
+    interior = mine[~in_send[mine]]
+    send_owned = mine[in_send[mine]]
 
     part = LocalPartition(rank, n_parts)
-    local_global = np.concatenate([interior, boundary, ghost_ids]).astype(np.int64)
+    ghost_layers = []
+    for lay in layers:
+        o = owner[lay]
+        ghost_layers.append(lay[np.lexsort((lay, o))])           # by owner rank, then global id
+    part.layer_sizes = [len(l) for l in ghost_layers]
+    local_global = np.concatenate([interior, send_owned] + ghost_layers).astype(np.int64)
     part.local_to_global = local_global
     part.n_interior = len(interior)
     part.n_owned = len(mine)
@@ -88,37 +122,34 @@ def build_partition(mesh, owner, rank):
     nb_l = nbr[local_global].astype(np.int64)
     pos = nb_l >= 0
     mapped = np.where(pos, g2l[np.where(pos, nb_l, 0)], nb_l)
-    # ghosts are never updated: neighbours of a ghost that are not local are irrelevant; point them at a wall
-    mapped[(mapped < 0) & pos] = -1
-    assert np.all(mapped[:part.n_owned][pos[:part.n_owned]] >= 0)
+    # only the outermost ghost layer has neighbours that are not local; it is never updated: point them at a wall
+    outer = (mapped < 0) & pos
+    n_inner = part.n_owned + int(sum(part.layer_sizes[:-1])) if halo_depth > 0 else part.n_owned
+    assert not outer[:n_inner].any(), 'a cell that is updated has a non-local neighbour'
+    mapped[outer] = -1
     part.cell_nbr = np.ascontiguousarray(mapped.astype(np.int32))
     part.cell_nbr_facet = np.ascontiguousarray(mesh.cell_nbr_facet[local_global])
     part.boundary_len = dict(mesh.boundary_len)
     part.boundary_markers = mesh.boundary_markers
 
-    # ghost blocks by peer
-    part.recv = {}
+    # send lists (segments of one buffer, by peer) and receive lists (local ghost ids in the order the peer sends them)
+    part.send, part.recv = {}, {}
+    send_cells, recv_cells = [], []
+    off = 0
+    for q in sorted(send_global):
+        loc = g2l[send_global[q]]
+        part.send[q] = (off, len(loc))
+        send_cells.append(loc)
+        off += len(loc)
+    ghosts = np.concatenate(ghost_layers) if ghost_layers else np.zeros(0, dtype=np.int64)
+    ghost_owner = owner[ghosts]
     off = 0
     for q in np.unique(ghost_owner):
-        cnt = int((ghost_owner == q).sum())
-        part.recv[int(q)] = (off, cnt)
-        off += cnt
-    # send lists: my cells that are ghosts of peer q, ordered by global id (the order q stores them in)
-    part.send = {}
-    send_cells = []
-    off = 0
-    for q in range(n_parts):
-        if q == rank:
-            continue
-        theirs = np.nonzero(owner == q)[0]
-        nbq = nbr[theirs]
-        v = nbq >= 0
-        hit = np.unique(nbq[v & (owner[np.where(v, nbq, 0)] == rank)])
-        if len(hit):
-            loc = g2l[hit]
-            part.send[q] = (off, len(hit))
-            send_cells.append(loc)
-            off += len(hit)
+        gq = np.sort(ghosts[ghost_owner == q])                    # global ids, the order peer q packs them in
+        part.recv[int(q)] = (off, len(gq))
+        recv_cells.append(g2l[gq])
+        off += len(gq)
     part.send_cells = (np.concatenate(send_cells) if send_cells else np.zeros(0, dtype=np.int64)).astype(np.int32)
+    part.recv_cells = (np.concatenate(recv_cells) if recv_cells else np.zeros(0, dtype=np.int64)).astype(np.int32)
     part.peers = sorted(set(part.send) | set(part.recv))
     return part
