@@ -56,7 +56,8 @@ typedef enum {
     SWE2D_FIELD_ATMOSPHERIC_PRESSURE = 1,  /* options.atmospheric_pressure    shallowwater_eq.py:658-663 */
     SWE2D_FIELD_MOMENTUM_SOURCE = 2,       /* options.momentum_source_2d (3N,2) shallowwater_eq.py:805-811 */
     SWE2D_FIELD_VOLUME_SOURCE = 3,         /* options.volume_source_2d        shallowwater_eq.py:825-831 */
-    SWE2D_FIELD_COUNT = 4
+    SWE2D_FIELD_WIND_STRESS = 4,           /* options.wind_stress (3N,2)      shallowwater_eq.py:643-649 */
+    SWE2D_FIELD_COUNT = 5
 } swe2d_field;
 
 /* Scalar coefficients (Constants in the reference). */
@@ -125,7 +126,10 @@ int  swe2d_set_dt(swe2d_handle *h, double dt);
  * (update_forcings, rungekutta.py:933-934). */
 int  swe2d_set_bc(swe2d_handle *h, int marker, int kind, const double values[5]);
 
-/* coefficient fields: nodal DG-P1 values (3N) [(3N,2) for the momentum source] or NULL to switch the term off */
+/* bnd_functions['shallow_water'][marker]['drag'] = C_D (BoundaryDragTerm, shallowwater_eq.py:704-725); negative: none */
+int  swe2d_set_boundary_drag(swe2d_handle *h, int marker, double drag_coefficient);
+
+/* coefficient fields: nodal DG-P1 values (3N) [(3N,2) for the momentum source and the wind stress] or NULL to switch the term off */
 int  swe2d_set_field(swe2d_handle *h, int field, const double *nodal);
 /* scalar coefficients; a negative value switches the term off (norm_smoother: >= 0) */
 int  swe2d_set_scalar(swe2d_handle *h, int which, double value);

@@ -24,7 +24,7 @@ class _RefStruct(ctypes.Structure):
                 ('manning', ctypes.c_double), ('norm_smoother', ctypes.c_double),
                 ('patm', _dp), ('mom_src', _dp), ('vol_src', _dp),
                 ('n_markers', ctypes.c_int), ('bc_kind', _ip), ('bc_elev', _dp), ('bc_uv', _dp),
-                ('bc_un', _dp), ('bc_flux', _dp), ('bc_len', _dp), ('npc', ctypes.c_int), ('wd', ctypes.c_int), ('alpha', _dp)]
+                ('bc_un', _dp), ('bc_flux', _dp), ('bc_len', _dp), ('npc', ctypes.c_int), ('wd', ctypes.c_int), ('alpha', _dp), ('wind', _dp), ('bc_drag', _dp)]
 
 
 def build(force=False):
@@ -58,7 +58,7 @@ class RefSWE(object):
                  coriolis=None, linear_drag_coefficient=None, quadratic_drag_coefficient=None,
                  manning_drag_coefficient=None, norm_smoother=0.0, atmospheric_pressure=None,
                  momentum_source=None, volume_source=None, bnd_conditions=None, boundary_len=None,
-                 use_wetting_and_drying=False, wetting_and_drying_alpha=0.5):
+                 use_wetting_and_drying=False, wetting_and_drying_alpha=0.5, wind_stress=None):
         self.lib = load()
         n = cell_xy.shape[0]
         self.n = n
@@ -112,6 +112,15 @@ class RefSWE(object):
         alpha = c(np.broadcast_to(np.asarray(wetting_and_drying_alpha, dtype=np.float64), (n, npc)))
         k['alpha'] = alpha
         s.alpha = _ptr(alpha)
+        wind = None if wind_stress is None else c(np.broadcast_to(wind_stress, (n, npc, 2)), dtype=np.float64)
+        k['wind'] = wind
+        s.wind = _ptr(wind)
+        drag = np.full(nm, -1.0)
+        for mk, funcs in bnd_conditions.items():
+            if 'drag' in funcs:
+                drag[mk] = funcs['drag']
+        k['drag'] = drag
+        s.bc_drag = _ptr(drag)
         self.s = s
 
     def tendency(self, uv, eta, dt):

@@ -68,6 +68,8 @@ typedef struct {
     /* explicit wetting-drying (this build's own nodal formulation, see oracle/swe2d_oracle.py header) */
     int wd;                    /* use_wetting_and_drying                                */
     const double *alpha;       /* [N][k] wetting_and_drying_alpha at the cell nodes     */
+    const double *wind;        /* [N][k][2] wind stress (WindStressTerm shallowwater_eq.py:643-649) or NULL */
+    const double *bc_drag;     /* per marker boundary drag C_D (BoundaryDragTerm :712-725), <0 = none, or NULL */
 } swe2d_ref_t;
 
 static const double GL_XI[2] = {0.21132486540518713, 0.78867513459481287};
@@ -134,6 +136,10 @@ static double quad_cell_terms(const swe2d_ref_t *m, int k, const double *p, cons
             divu += gx[i]*u[i] + gy[i]*v[i];
         }
         double corq = 0, gpx = 0, gpy = 0, sx = 0, sy = 0, sv = 0;
+        if (m->wind) {
+            const double *ws = m->wind + 8*(size_t)k;
+            for (int i = 0; i < 4; i++) { sx += phi[i]*ws[2*i]/(Hq*1000.0); sy += phi[i]*ws[2*i + 1]/(Hq*1000.0); }
+        }
         for (int i = 0; i < 4; i++) {
             if (cor) corq += phi[i]*cor[i];
             if (pa) { gpx += gx[i]*pa[i]; gpy += gy[i]*pa[i]; }
@@ -241,6 +247,16 @@ static void cell_tendency(const swe2d_ref_t *m, int k, const double *uv, const d
             for (int i = 0; i < 3; i++) { bu[i] -= s*b[i]*uq; bv[i] -= s*b[i]*vq; }
         }
     }
+    if (m->wind) {                                                 /* :648, +tau.psi/(H rho0), 6-point rule */
+        const double *ws = m->wind + 6*(size_t)k;
+        for (int q = 0; q < 6; q++) {
+            const double *b = TRI_B[q];
+            double Hq = b[0]*H[0] + b[1]*H[1] + b[2]*H[2];
+            double wx = b[0]*ws[0] + b[1]*ws[2] + b[2]*ws[4], wy = b[0]*ws[1] + b[1]*ws[3] + b[2]*ws[5];
+            double s = TRI_W[q]*A/(Hq*1000.0);
+            for (int i = 0; i < 3; i++) { bu[i] += s*b[i]*wx; bv[i] += s*b[i]*wy; }
+        }
+    }
     if (m->patm) {                                                 /* :662 */
         const double *pa = m->patm + 3*(size_t)k;
         double px = gx[0]*pa[0] + gx[1]*pa[1] + gx[2]*pa[2];
@@ -339,6 +355,12 @@ static void cell_tendency(const swe2d_ref_t *m, int k, const double *uv, const d
                     const double un_rie3 = un_avg + sqrt(g/Hq)*eta_jump;                  /* :507 */
                     fu += un_rie3*0.5*(u_ext + uq); fv += un_rie3*0.5*(v_ext + vq);       /* :508-509 */
                 }
+            }
+            if (nb < 0 && m->bc_drag && marker < m->n_markers && m->bc_drag[marker] >= 0) {      /* :717-724 */
+                const double un_own = uq*nx + vq*ny;
+                const double utx = uq - un_own*nx, uty = vq - un_own*ny;
+                const double mag = sqrt(utx*utx + uty*uty);
+                fu += m->bc_drag[marker]*mag*utx; fv += m->bc_drag[marker]*mag*uty;
             }
             bu[a] -= w*xa*fu; bu[b] -= w*xb*fu;
             bv[a] -= w*xa*fv; bv[b] -= w*xb*fv;

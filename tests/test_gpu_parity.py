@@ -81,6 +81,7 @@ def test_source_terms_match_oracle(hip_lib):
         dict(coriolis=cor, linear_drag_coefficient=1e-3, atmospheric_pressure=patm, momentum_source=msrc, volume_source=vsrc),
         dict(manning_drag_coefficient=0.02),
         dict(quadratic_drag_coefficient=0.0025, norm_smoother=0.1),
+        dict(wind_stress=0.1*rng.normal(size=(n, 3, 2)), bnd_conditions={3: {'drag': 0.0025}, 1: {'drag': 0.01, 'elev': 0.1}}),
     ]
     for kw in cases:
         orc = make_oracle(mesh, bath, **kw)
@@ -97,6 +98,10 @@ def test_source_terms_match_oracle(hip_lib):
         if 'quadratic_drag_coefficient' in kw:
             dev.set_scalar(_lib.SCALAR_QUADRATIC_DRAG, 0.0025)
             dev.set_scalar(_lib.SCALAR_NORM_SMOOTHER, 0.1)
+        if 'wind_stress' in kw:
+            dev.set_field(_lib.FIELD_WIND_STRESS, kw['wind_stress'])
+            for marker, funcs in kw['bnd_conditions'].items():
+                dev.set_bc(marker, funcs)
         dev.set_state(uv, np.abs(eta))
         ku, ke = dev.tendency()
         assert rel_linf(ku, ku_o) < TOL_RHS, kw.keys()

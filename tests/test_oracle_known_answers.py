@@ -43,7 +43,8 @@ _BCS1 = {1: {'elev': 0.3}, 2: {'un': 0.2}, 3: {'flux': 1e4, 'elev': 0.1}}
 _BCS2 = {4: {'uv': (0.1, -0.2)}, 1: {'flux': -3e3}, 2: {'elev': 0.1, 'uv': (0.3, 0.1)}, 3: {'elev': -0.1, 'un': 0.05}}
 
 
-@pytest.mark.parametrize('case', ['default', 'linear', 'no_lf', 'half_lf', 'sources', 'manning', 'quad_drag', 'bcs1', 'bcs2'])
+@pytest.mark.parametrize('case', ['default', 'linear', 'no_lf', 'half_lf', 'sources', 'manning', 'quad_drag', 'bcs1', 'bcs2',
+                                  'wind_bdrag'])
 def test_numpy_and_c_restatements_agree(ref_so, case):
     """Literal UFL restatement (quadrature everywhere, facet loop) vs element-centric closed forms in C."""
     mesh, bath, uv, eta = channel_case(seed=1)
@@ -59,8 +60,10 @@ def test_numpy_and_c_restatements_agree(ref_so, case):
         'manning': dict(manning_drag_coefficient=0.02),
         'quad_drag': dict(quadratic_drag_coefficient=0.0025, norm_smoother=0.1),
         'bcs1': dict(bnd_conditions=_BCS1), 'bcs2': dict(bnd_conditions=_BCS2),
+        'wind_bdrag': dict(wind_stress=0.1*rng.normal(size=(n, 3, 2)),
+                           bnd_conditions={3: {'drag': 0.0025}, 1: {'drag': 0.01, 'elev': 0.1}}),
     }[case]
-    if case in ('manning', 'quad_drag'):
+    if case in ('manning', 'quad_drag', 'wind_bdrag'):
         eta = np.abs(eta)
     orc = make_oracle(mesh, bath, **kw)
     ref = make_ref(mesh, bath, **kw)

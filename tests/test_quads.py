@@ -21,6 +21,8 @@ def _cases(mesh, n):
         'manning': dict(manning_drag_coefficient=0.02),
         'quad_drag': dict(quadratic_drag_coefficient=0.0025, norm_smoother=0.1),
         'bcs': dict(bnd_conditions=_BCS),
+        'wind_bdrag': dict(wind_stress=0.1*rng.normal(size=(n, 4, 2)),
+                           bnd_conditions={3: {'drag': 0.0025}, 1: {'drag': 0.01, 'elev': 0.1}}),
     }
 
 
@@ -59,12 +61,12 @@ def test_quad_oracle_invariants():
     assert abs(orc.volume(e1) - orc.volume(eta))/orc.volume(eta) < 1e-13
 
 
-@pytest.mark.parametrize('case', ['default', 'linear', 'no_lf', 'sources', 'manning', 'quad_drag', 'bcs'])
+@pytest.mark.parametrize('case', ['default', 'linear', 'no_lf', 'sources', 'manning', 'quad_drag', 'bcs', 'wind_bdrag'])
 @pytest.mark.parametrize('skew', [0.0, 0.3])
 def test_quad_numpy_and_c_restatements_agree(ref_so, case, skew):
     mesh, bath, uv, eta = quad_case(skew=skew, seed=1)
     kw = _cases(mesh, mesh.num_cells)[case]
-    if case in ('manning', 'quad_drag'):
+    if case in ('manning', 'quad_drag', 'wind_bdrag'):
         eta = np.abs(eta)
     orc = make_oracle_generic(mesh, bath, **kw)
     ref = make_ref(mesh, bath, **kw)
@@ -97,13 +99,13 @@ def test_quad_standing_wave_second_order(ref_so):
 
 # ------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', ['default', 'linear', 'no_lf', 'sources', 'manning', 'quad_drag', 'bcs'])
+@pytest.mark.parametrize('case', ['default', 'linear', 'no_lf', 'sources', 'manning', 'quad_drag', 'bcs', 'wind_bdrag'])
 def test_quad_gpu_tendency_matches_oracle(hip_lib, case):
     from thetis_amd import _lib
     from thetis_amd.device import Swe2dDevice
     mesh, bath, uv, eta = quad_case(skew=0.3, seed=1)
     kw = _cases(mesh, mesh.num_cells)[case]
-    if case in ('manning', 'quad_drag'):
+    if case in ('manning', 'quad_drag', 'wind_bdrag'):
         eta = np.abs(eta)
     dt = 3.0
     orc = make_oracle_generic(mesh, bath, **kw)
@@ -122,6 +124,10 @@ def test_quad_gpu_tendency_matches_oracle(hip_lib, case):
         dev.set_scalar(_lib.SCALAR_NORM_SMOOTHER, 0.1)
     if case == 'bcs':
         for m, funcs in _BCS.items():
+            dev.set_bc(m, funcs)
+    if case == 'wind_bdrag':
+        dev.set_field(_lib.FIELD_WIND_STRESS, kw['wind_stress'])
+        for m, funcs in kw['bnd_conditions'].items():
             dev.set_bc(m, funcs)
     dev.set_state(uv, eta)
     ku, ke = dev.tendency()

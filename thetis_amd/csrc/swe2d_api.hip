@@ -37,7 +37,7 @@ struct Handle {
     double *vx = nullptr, *vy = nullptr, *vh = nullptr;
     double *valpha = nullptr;                          // per-vertex wetting-drying alpha
     bool wd = false;
-    double *field[SWE2D_FIELD_COUNT] = {nullptr, nullptr, nullptr, nullptr};
+    double *field[SWE2D_FIELD_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double scalar[SWE2D_SCALAR_COUNT] = {-1.0, -1.0, -1.0, 0.0};
     double *stage_uv = nullptr, *stage_eta = nullptr;  // device staging in host layout (6N + 3N)
     double *partial = nullptr;                         // diagnostics partial sums
@@ -152,6 +152,7 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.patm = h->field[SWE2D_FIELD_ATMOSPHERIC_PRESSURE];
     a.msrc = h->field[SWE2D_FIELD_MOMENTUM_SOURCE];
     a.vsrc = h->field[SWE2D_FIELD_VOLUME_SOURCE];
+    a.wind = h->field[SWE2D_FIELD_WIND_STRESS];
     a.linear_drag = h->scalar[SWE2D_SCALAR_LINEAR_DRAG];
     a.quad_drag = h->scalar[SWE2D_SCALAR_QUADRATIC_DRAG];
     a.manning = h->scalar[SWE2D_SCALAR_MANNING_DRAG];
@@ -335,6 +336,7 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
         return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "boundary_len is required for a partitioned mesh");
     }
     std::memset(&h->bc, 0, sizeof(h->bc));
+    for (int m = 0; m < SWE2D_MAX_MARKERS; m++) h->bc.drag[m] = -1.0;
     for (int m = 0; m < SWE2D_MAX_MARKERS; m++) h->bc.len[m] = mesh->boundary_len ? mesh->boundary_len[m] : blen[m];
 
     HIP_TRY_C(hipMemcpyAsync(h->nbr, nbr.data(), (size_t)npc*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -437,13 +439,22 @@ int swe2d_set_bc(swe2d_handle *hh, int marker, int kind, const double values[5])
     return SWE2D_OK;
 }
 
+int swe2d_set_boundary_drag(swe2d_handle *hh, int marker, double drag_coefficient)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (marker <= 0 || marker >= SWE2D_MAX_MARKERS) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "marker out of range");
+    h->bc.drag[marker] = drag_coefficient;
+    return SWE2D_OK;
+}
+
 int swe2d_set_field(swe2d_handle *hh, int field, const double *nodal)
 {
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
     if (field < 0 || field >= SWE2D_FIELD_COUNT) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "unknown field id");
     HIP_TRY(h, hipSetDevice(h->device));
-    const int ncomp = (field == SWE2D_FIELD_MOMENTUM_SOURCE) ? 2 : 1;
+    const int ncomp = (field == SWE2D_FIELD_MOMENTUM_SOURCE || field == SWE2D_FIELD_WIND_STRESS) ? 2 : 1;
     if (!nodal) {
         if (h->field[field]) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -42,6 +42,7 @@ struct SweBcTable {
     double un[SWE_MAX_MARKERS];
     double flux[SWE_MAX_MARKERS];
     double len[SWE_MAX_MARKERS];
+    double drag[SWE_MAX_MARKERS];     // boundary drag C_D ('drag' key, BoundaryDragTerm), < 0: none
 };
 
 struct SweStageArgs {
@@ -61,6 +62,7 @@ struct SweStageArgs {
     const double *patm;       // 3 planes or null
     const double *msrc;       // 6 planes (x0 x1 x2 y0 y1 y2) or null
     const double *vsrc;       // 3 planes or null
+    const double *wind;       // 6 planes (x0.. y0..) wind stress or null
     double linear_drag, quad_drag, manning, norm_smoother;   // <0: off
     SweBcTable bc;
 };
@@ -199,6 +201,13 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
             fv += un_rie3*0.5*(v_ext + vq);
         }
     }
+    const double cdb = (marker < SWE_MAX_MARKERS) ? p.bc.drag[marker] : -1.0;
+    if (cdb >= 0.0) {                                                                  // BoundaryDragTerm :717-724
+        const double utx = uq - un_own*nx, uty = vq - un_own*ny;
+        const double mag = sqrt(utx*utx + uty*uty);
+        fu += cdb*mag*utx;
+        fv += cdb*mag*uty;
+    }
     fu *= L;
     fv *= L;
     fe *= L;
@@ -273,6 +282,30 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
             for (int i = 0; i < 3; i++) {
                 bu[i] -= s*l[i]*uq;
                 bv[i] -= s*l[i]*vq;
+            }
+        }
+    }
+    if (p.wind) {                                        // shallowwater_eq.py:648, + tau.psi/(H rho0), 6-point rule
+        const double a1 = 0.445948490915965, b1 = 0.108103018168070, w1 = 0.223381589678011;
+        const double a2 = 0.091576213509771, b2 = 0.816847572980459, w2 = 0.109951743655322;
+        double tx[3], ty[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            tx[i] = p.wind[(size_t)i*S + k];
+            ty[i] = p.wind[(size_t)(3 + i)*S + k];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const double aa = q < 3 ? a1 : a2, bb = q < 3 ? b1 : b2, ww = q < 3 ? w1 : w2;
+            double l[3] = {aa, aa, aa};
+            l[q % 3] = bb;
+            const double Hq = l[0]*H[0] + l[1]*H[1] + l[2]*H[2];
+            const double s = ww*A/(Hq*1000.0);
+            const double wx = l[0]*tx[0] + l[1]*tx[1] + l[2]*tx[2], wy = l[0]*ty[0] + l[1]*ty[1] + l[2]*ty[2];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                bu[i] += s*l[i]*wx;
+                bv[i] += s*l[i]*wy;
             }
         }
     }
@@ -975,6 +1008,10 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
                         sy += phi[i]*p.msrc[(size_t)(4 + i)*S + k];
                     }
                     if (p.vsrc) sv += phi[i]*p.vsrc[(size_t)i*S + k];
+                    if (p.wind) {
+                        sx += phi[i]*p.wind[(size_t)i*S + k]/(Hq*1000.0);
+                        sy += phi[i]*p.wind[(size_t)(4 + i)*S + k]/(Hq*1000.0);
+                    }
                 }
                 double drag = 0.0;
                 if (p.quad_drag >= 0.0 || p.manning >= 0.0) {

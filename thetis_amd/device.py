@@ -168,10 +168,12 @@ class Swe2dDevice(object):
                 kind |= _lib.BC_FLUX
                 vals[4] = float(value)
             elif key == 'drag':
-                raise NotImplementedError('boundary drag is not supported on the device path yet')
+                pass            # handled below
             else:
                 raise Exception('Invalid boundary tag "{:}" specified on boundary {:}'.format(key, marker))
         self._ck(self.lib.swe2d_set_bc(self.h, int(marker), kind, _ptr(vals)))
+        drag = (funcs or {}).get('drag')
+        self._ck(self.lib.swe2d_set_boundary_drag(self.h, int(marker), -1.0 if drag is None else float(drag)))
 
     def set_wetting_and_drying(self, alpha):
         """Enable the explicit wetting-drying formulation; ``alpha``: constant or per-vertex array; None disables."""
@@ -192,7 +194,8 @@ class Swe2dDevice(object):
         if nodal is None:
             self._ck(self.lib.swe2d_set_field(self.h, field, None))
             return
-        shape = (self.n_cells, self.npc, 2) if field == _lib.FIELD_MOMENTUM_SOURCE else (self.n_cells, self.npc)
+        vec = field in (_lib.FIELD_MOMENTUM_SOURCE, _lib.FIELD_WIND_STRESS)
+        shape = (self.n_cells, self.npc, 2) if vec else (self.n_cells, self.npc)
         a = np.broadcast_to(np.asarray(nodal, dtype=np.float64), shape)
         if self.perm is not None:
             a = a[self.perm]

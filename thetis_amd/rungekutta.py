@@ -118,7 +118,8 @@ class ERKGenericShuOsher(TimeIntegrator):
         for key, fid, vec in (('coriolis', _lib.FIELD_CORIOLIS, False),
                               ('atmospheric_pressure', _lib.FIELD_ATMOSPHERIC_PRESSURE, False),
                               ('momentum_source', _lib.FIELD_MOMENTUM_SOURCE, True),
-                              ('volume_source', _lib.FIELD_VOLUME_SOURCE, False)):
+                              ('volume_source', _lib.FIELD_VOLUME_SOURCE, False),
+                              ('wind_stress', _lib.FIELD_WIND_STRESS, True)):
             v = f.get(key)
             dev.set_field(fid, None if v is None else self._nodal(v, vector=vec))
 

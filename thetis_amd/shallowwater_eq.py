@@ -8,7 +8,7 @@ configuration is one the kernel implements:
 
   ExternalPressureGradientTerm :335   HUDivTerm :396   HorizontalAdvectionTerm :453 (+ Lax-Friedrichs)
   CoriolisTerm :619   AtmosphericPressureTerm :652   QuadraticDragTerm :666 (constant C_D or Manning)
-  LinearDragTerm :728   MomentumSourceTerm :794   ContinuitySourceTerm :814
+  LinearDragTerm :728   MomentumSourceTerm :794   ContinuitySourceTerm :814   WindStressTerm :637   BoundaryDragTerm :704
   boundary conditions 'elev' / 'uv' / 'un' / 'flux' with constant values (get_bnd_functions :232-272)
 """
 from .options import Constant
@@ -58,8 +58,6 @@ class ShallowWaterEquations(object):
         """Raise for coefficients whose terms the kernel does not implement (never silently ignore physics)."""
         if fields.get('viscosity_h') is not None:
             raise NotImplementedError('HorizontalViscosityTerm (SIPG) is not implemented on the device path yet')
-        if fields.get('wind_stress') is not None:
-            raise NotImplementedError('WindStressTerm is not implemented on the device path yet')
         if fields.get('nikuradse_bed_roughness') is not None:
             raise NotImplementedError('Nikuradse bed roughness is not implemented on the device path yet')
         if fields.get('quadratic_drag_coefficient') is not None and fields.get('manning_drag_coefficient') is not None:
