@@ -40,6 +40,19 @@ class Swe2dDevice(object):
         bath0 = np.asarray(bathymetry_vertex, dtype=np.float64)
         if bath0.shape != (xy0.shape[0],):
             raise ValueError('bathymetry must have one value per vertex')
+        # boundary markers are arbitrary positive ids in mesh files (e.g. 100, 200 in demos/north_sea.msh); the C ABI
+        # indexes a small table, so they are mapped to slots 1..15 here
+        markers = sorted(int(m) for m in np.unique(-nbr0[nbr0 < 0])) if (nbr0 < 0).any() else []
+        if len(markers) >= _lib.MAX_MARKERS:
+            raise NotImplementedError('more than {:d} distinct boundary markers'.format(_lib.MAX_MARKERS - 1))
+        self._marker_slot = {m: i + 1 for i, m in enumerate(markers)}
+        if markers and markers != list(range(1, len(markers) + 1)):
+            lut = np.zeros(max(markers) + 1, dtype=np.int64)
+            for m, sl in self._marker_slot.items():
+                lut[m] = sl
+            nbr0 = np.where(nbr0 < 0, -lut[np.where(nbr0 < 0, -nbr0, 0)], nbr0)
+        if boundary_len is not None:
+            boundary_len = {self._marker_slot[m]: v for m, v in boundary_len.items() if m in self._marker_slot}
         # ---- device numbering: perm[i_dev] = i_caller
         self.perm = None
         self._vperm = None
@@ -150,8 +163,15 @@ class Swe2dDevice(object):
     def set_dt(self, dt):
         self._ck(self.lib.swe2d_set_dt(self.h, float(dt)))
 
+    def _slot(self, marker):
+        try:
+            return self._marker_slot[int(marker)]
+        except KeyError:
+            raise KeyError('the mesh has no boundary with marker {:}'.format(marker))
+
     def set_bc(self, marker, funcs):
         """``funcs``: dict with constant 'elev' / 'uv' / 'un' / 'flux' values, or None / {} for a closed boundary."""
+        marker = self._slot(marker)
         kind = 0
         vals = np.zeros(5)
         for key, value in (funcs or {}).items():
@@ -276,7 +296,7 @@ class Swe2dDevice(object):
 
     def tracer_set_bc(self, tid, marker, value):
         """``value``: constant Dirichlet value or None (default boundary term)."""
-        self._ck(self.lib.swe2d_tracer_set_bc(self.h, tid, int(marker), 0 if value is None else 1,
+        self._ck(self.lib.swe2d_tracer_set_bc(self.h, tid, self._slot(marker), 0 if value is None else 1,
                                               0.0 if value is None else float(value)))
 
     def tracer_set_source(self, tid, nodal):
