@@ -161,3 +161,27 @@ def test_rossby_soliton_reference_criterion(hip_lib):
         rossby.check_convergence(res[0], res[1])
     finally:
         thetis_amd.physical_constants['g_grav'].assign(g_saved)
+
+
+def test_export_and_restart(hip_lib, tmp_path):
+    """VTK export + checkpoint restart (solver2d.py:704-730,820-921): a run continued from export 2 equals the uninterrupted run."""
+    def make(outdir):
+        s, mesh, bath, elev_init = _channel2d_solver(t_end=400.0)
+        s.options.no_exports = False
+        s.options.output_directory = str(outdir)
+        s.options.fields_to_export = ['elev_2d', 'uv_2d']
+        s.options.fields_to_export_hdf5 = ['elev_2d', 'uv_2d']
+        return s, elev_init
+    s1, elev_init = make(tmp_path/'a')
+    s1.assign_initial_conditions(elev=elev_init)
+    s1.iterate()
+    e_full = s1.fields.elev_2d.cell_node_values().copy()
+    import os
+    assert os.path.exists(tmp_path/'a'/'Elevation2d'/'Elevation2d_4.vtu') and os.path.exists(tmp_path/'a'/'Velocity2d'/'Velocity2d.pvd')
+    assert os.path.exists(tmp_path/'a'/'hdf5'/'Elevation2d_00002.npz')
+    s2, _ = make(tmp_path/'b')
+    s2.load_state(2, outputdir=str(tmp_path/'a'))
+    assert s2.iteration == 100 and math.isclose(s2.simulation_time, 200.0) and s2.i_export == 2
+    s2.iterate()
+    assert s2.iteration == 200 and s2.i_export == 4
+    assert np.array_equal(s2.fields.elev_2d.cell_node_values(), e_full)          # deterministic kernel: bitwise restart

@@ -1,0 +1,128 @@
+"""
+Field export and restart files around the hot path (thetis/exporter.py, thetis/solver2d.py:704-730,820-921).
+
+* ``VTKExporter``: ParaView ``.vtu`` (ASCII XML) per export + a ``.pvd`` collection, directory/file naming of the
+  reference (``<outputdir>/<Filename>/<Filename>_<ix>.vtu``, exporter.py:64-120).  DG fields are written cell by cell
+  (duplicated points), i.e. exactly the discontinuous data.
+* ``CheckpointExporter``: the reference stores restart files with Firedrake's ``CheckpointFile`` (HDF5, exporter.py:123-242);
+  neither h5py nor Firedrake exists here, so the same information (nodal data in the C-ABI host layout, export index,
+  simulation time) goes to ``<outputdir>/hdf5/<Filename>_<ix:05d>.npz``.  NOT interchangeable with the reference's files.
+"""
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+__all__ = ['field_metadata', 'VTKExporter', 'CheckpointExporter', 'ExportManager']
+
+# thetis/field_defs.py:37-42,67-72 (+ tracer metadata comes from options.add_tracer_2d)
+field_metadata = {
+    'uv_2d': {'name': 'Depth averaged velocity', 'shortname': 'Depth averaged velocity', 'unit': 'm s-1', 'filename': 'Velocity2d'},
+    'elev_2d': {'name': 'Water elevation', 'shortname': 'Elevation', 'unit': 'm', 'filename': 'Elevation2d'},
+}
+
+
+class VTKExporter(object):
+    def __init__(self, func_name, outputdir, filename, next_export_ix=0):
+        self.func_name, self.filename = func_name, filename
+        self.dir = os.path.join(outputdir, filename)
+        self.next_export_ix = next_export_ix
+        self.entries = []
+        os.makedirs(self.dir, exist_ok=True)
+
+    def set_next_export_ix(self, ix):
+        self.next_export_ix = ix
+
+    def export(self, function, time=None):
+        fs = function.function_space()
+        mesh = fs.mesh()
+        vals = function.cell_node_values()                     # (N, k[, 2])
+        n, k = vals.shape[0], vals.shape[1]
+        pts = np.concatenate([mesh.cell_xy().reshape(-1, 2), np.zeros((n*k, 1))], axis=1)
+        fname = '{:s}_{:d}.vtu'.format(self.filename, self.next_export_ix)
+        with open(os.path.join(self.dir, fname), 'w') as f:
+            f.write('<?xml version="1.0"?>\n<VTKFile type="UnstructuredGrid" version="0.1" byte_order="LittleEndian">\n')
+            f.write('<UnstructuredGrid>\n<Piece NumberOfPoints="{:d}" NumberOfCells="{:d}">\n'.format(n*k, n))
+            f.write('<Points>\n<DataArray type="Float64" NumberOfComponents="3" format="ascii">\n')
+            np.savetxt(f, pts, fmt='%.17g')
+            f.write('</DataArray>\n</Points>\n<Cells>\n<DataArray type="Int32" Name="connectivity" format="ascii">\n')
+            np.savetxt(f, np.arange(n*k).reshape(n, k), fmt='%d')
+            f.write('</DataArray>\n<DataArray type="Int32" Name="offsets" format="ascii">\n')
+            np.savetxt(f, (np.arange(n) + 1)*k, fmt='%d')
+            f.write('</DataArray>\n<DataArray type="UInt8" Name="types" format="ascii">\n')
+            np.savetxt(f, np.full(n, 5 if k == 3 else 9), fmt='%d')
+            f.write('</DataArray>\n</Cells>\n')
+            if vals.ndim == 3:
+                data = np.concatenate([vals.reshape(-1, 2), np.zeros((n*k, 1))], axis=1)
+                f.write('<PointData Vectors="{0}">\n<DataArray type="Float64" Name="{0}" NumberOfComponents="3" format="ascii">\n'.format(self.func_name))
+            else:
+                data = vals.reshape(-1, 1)
+                f.write('<PointData Scalars="{0}">\n<DataArray type="Float64" Name="{0}" format="ascii">\n'.format(self.func_name))
+            np.savetxt(f, data, fmt='%.17g')
+            f.write('</DataArray>\n</PointData>\n</Piece>\n</UnstructuredGrid>\n</VTKFile>\n')
+        self.entries.append((self.next_export_ix if time is None else time, fname))
+        with open(os.path.join(self.dir, self.filename + '.pvd'), 'w') as f:
+            f.write('<?xml version="1.0"?>\n<VTKFile type="Collection" version="0.1">\n<Collection>\n')
+            for t, name in self.entries:
+                f.write('<DataSet timestep="{:}" part="0" file="{:s}"/>\n'.format(t, name))
+            f.write('</Collection>\n</VTKFile>\n')
+        self.next_export_ix += 1
+
+
+class CheckpointExporter(object):
+    """Stand-in for ``HDF5Exporter`` (exporter.py:123-242): one ``.npz`` per export index."""
+
+    def __init__(self, outputdir, filename_prefix, next_export_ix=0):
+        self.dir, self.prefix = outputdir, filename_prefix
+        self.next_export_ix = next_export_ix
+        os.makedirs(self.dir, exist_ok=True)
+
+    def set_next_export_ix(self, ix):
+        self.next_export_ix = ix
+
+    def gen_filename(self, iexport):
+        return os.path.join(self.dir, '{:s}_{:05d}.npz'.format(self.prefix, iexport))
+
+    def export_as_index(self, iexport, function, time=None):
+        np.savez(self.gen_filename(iexport), data=function.dat.data_ro, time=np.nan if time is None else float(time),
+                 cells=function.function_space().mesh().cells)
+
+    def export(self, function, time=None):
+        self.export_as_index(self.next_export_ix, function, time=time)
+        self.next_export_ix += 1
+
+    def load(self, iexport, function):
+        path = self.gen_filename(iexport)
+        if not os.path.exists(path):
+            raise IOError('checkpoint {:s} does not exist'.format(path))
+        d = np.load(path)
+        if not np.array_equal(d['cells'], function.function_space().mesh().cells):
+            raise ValueError('checkpoint {:s} was written for a different mesh'.format(path))
+        function.assign(d['data'])
+        t = float(d['time'])
+        return {} if np.isnan(t) else {'time': t}
+
+
+class ExportManager(object):
+    """Helper object for exporting multiple fields simultaneously (exporter.py:245-386)."""
+
+    def __init__(self, outputdir, fields_to_export, functions, metadata, export_type='vtk', next_export_ix=0):
+        self.exporters = OrderedDict()
+        self.functions = dict(functions)
+        for key in fields_to_export:
+            field = self.functions.get(key)
+            if field is None or not hasattr(field, 'cell_node_values'):
+                continue
+            meta = metadata[key]
+            if export_type == 'vtk':
+                self.exporters[key] = VTKExporter(meta['shortname'], outputdir, meta['filename'], next_export_ix)
+            else:
+                self.exporters[key] = CheckpointExporter(outputdir, meta['filename'], next_export_ix)
+
+    def set_next_export_ix(self, ix):
+        for e in self.exporters.values():
+            e.set_next_export_ix(ix)
+
+    def export(self, time=None):
+        for key, e in self.exporters.items():
+            e.export(self.functions[key], time=time)

@@ -10,11 +10,14 @@ Not kept: exporters (VTK/HDF5 I/O), log files, ``load_state``, the implicit step
 """
 import math
 import sys
+from collections import OrderedDict
 import time as time_mod
 
 import numpy as np
 
-from . import callback, coupled_timeintegrator_2d
+import os
+
+from . import callback, coupled_timeintegrator_2d, exporter
 from .function import Function, FunctionSpace, MixedFunction, get_functionspace
 from .log import print_output
 from .options import Constant, ModelOptions2d
@@ -260,9 +263,24 @@ class FlowSolver2d(object):
         print_output('Number of 2D elevation DOFs: {:}'.format(self.function_spaces.H_2d.dim()))
         print_output('Number of 2D velocity DOFs: {:}'.format(self.function_spaces.U_2d.dim()))
 
+    def _field_metadata(self):
+        meta = dict(exporter.field_metadata)
+        for label, topts in self.options.tracer.items():
+            meta[label] = topts.metadata
+        return meta
+
     def create_exporters(self):
-        """solver2d.py:704-730 - field export is out of scope for the hot path."""
-        self.exporters = {}
+        """Creates file exporters (solver2d.py:704-730): VTK for fields_to_export, checkpoints for fields_to_export_hdf5."""
+        self.exporters = OrderedDict()
+        if self.options.no_exports:
+            return
+        o = self.options
+        if o.fields_to_export:
+            self.exporters['vtk'] = exporter.ExportManager(o.output_directory, o.fields_to_export, self.fields,
+                                                           self._field_metadata(), export_type='vtk')
+        if o.fields_to_export_hdf5:
+            self.exporters['hdf5'] = exporter.ExportManager(os.path.join(o.output_directory, 'hdf5'), o.fields_to_export_hdf5,
+                                                            self.fields, self._field_metadata(), export_type='hdf5')
 
     def initialize(self):
         """solver2d.py:732-744"""
@@ -296,11 +314,38 @@ class FlowSolver2d(object):
         self.callbacks.add(callback, eval_interval)
 
     def export(self, time=None):
-        """solver2d.py:799-812: evaluate export callbacks (no field files on this path)."""
+        """Export all fields to disk and evaluate the export callbacks (solver2d.py:799-812)."""
         self.callbacks.evaluate(mode='export', index=self.i_export)
+        for e in self.exporters.values():
+            e.export(time=time)
 
-    def load_state(self, *args, **kwargs):
-        raise NotImplementedError('restart from HDF5 checkpoints is outside the hot path')
+    def load_state(self, i_stored, outputdir=None, t=None, iteration=None, i_export=None):
+        """Loads simulation state from the checkpoint files of an earlier run and restores the export / iteration
+        bookkeeping (solver2d.py:820-921).  Replaces :meth:`assign_initial_conditions`."""
+        if not self._initialized:
+            self.initialize()
+        if outputdir is None:
+            outputdir = self.options.output_directory
+        e = exporter.ExportManager(os.path.join(outputdir, 'hdf5'), ['uv_2d', 'elev_2d'], self.fields,
+                                   self._field_metadata(), export_type='hdf5')
+        metadata = {}
+        metadata.update(e.exporters['uv_2d'].load(i_stored, self.fields.uv_2d))
+        metadata.update(e.exporters['elev_2d'].load(i_stored, self.fields.elev_2d))
+        self.assign_initial_conditions()
+        if i_export is None:
+            i_export = i_stored
+        self.i_export = i_export
+        self.next_export_t = self.i_export*self.options.simulation_export_time
+        if iteration is None:
+            iteration = int(np.ceil(self.next_export_t/self.dt))
+        if t is None:
+            t = metadata.get('time', iteration*self.dt)
+        self.iteration = iteration
+        self.simulation_time = t
+        self.next_export_t += self.options.simulation_export_time
+        for ex in self.exporters.values():
+            ex.set_next_export_ix(self.i_export + 1)
+        self.export_initial_state = False
 
     # ------------------------------------------------------------------ time loop
     def print_state(self, cputime, print_header=False):
