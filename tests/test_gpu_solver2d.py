@@ -185,3 +185,34 @@ def test_export_and_restart(hip_lib, tmp_path):
     s2.iterate()
     assert s2.iteration == 200 and s2.i_export == 4
     assert np.array_equal(s2.fields.elev_2d.cell_node_values(), e_full)          # deterministic kernel: bitwise restart
+
+
+def test_atmospheric_pressure_reference_test(hip_lib):
+    """test/swe2d/test_atmospheric_pressure.py::test_pressure_forcing[SSPRK33-dg-dg] through FlowSolver2d on the device."""
+    from test_oracle_known_answers import _pressure_forcing_errors, check_pressure_forcing_orders
+
+    def run(mesh2d, dt, t_end, patm_fn, eta_fn):
+        P1 = get_functionspace(mesh2d, 'DG', 1)
+        bathymetry = Function(P1, name='bathymetry').interpolate(Constant(5.0))
+        atmospheric_pressure = Function(P1, name='atmospheric_pressure').interpolate(patm_fn)
+        solverObj = solver2d.FlowSolver2d(mesh2d, bathymetry)
+        o = solverObj.options
+        o.polynomial_degree = 1
+        o.swe_timestepper_type = 'SSPRK33'
+        o.swe_timestepper_options.use_automatic_timestep = False
+        o.element_family = 'dg-dg'
+        o.check_volume_conservation_2d = False
+        o.timestep = dt
+        o.simulation_export_time = 3600.0
+        o.simulation_end_time = t_end
+        o.no_exports = True
+        o.manning_drag_coefficient = Constant(1.0)
+        o.atmospheric_pressure = atmospheric_pressure
+        solverObj.assign_initial_conditions(uv=Constant((1e-7, 0.)))
+        solverObj.iterate()
+        eta = solverObj.fields.elev_2d.cell_node_values()
+        eta_ana = Function(solverObj.function_spaces.H_2d).project(eta_fn).cell_node_values()
+        d = eta - eta_ana
+        area = mesh2d.cell_areas()
+        return math.sqrt(float(np.sum(area/12.0*(d.sum(axis=1)**2 + (d**2).sum(axis=1)))))
+    check_pressure_forcing_orders(_pressure_forcing_errors(run))

@@ -193,3 +193,43 @@ def test_rossby_soliton_metrics_do_not_diverge(ref_so):
     # the soliton keeps most of its height on the finer mesh (FVCOM at dx = 0.25: 0.85 / 0.818, test/swe2d/data/FVCOM.json);
     # the phase metric is normalised for T = 120 and only has to be non-divergent at t_end = 30
     assert all(0.8 < m < 1.1 for m in res[1][:2]), res
+
+
+def _pressure_forcing_errors(run):
+    """test/swe2d/test_atmospheric_pressure.py: steady balance eta = A cos(pi x/L) cos(pi y/L) between the atmospheric
+    pressure gradient and the elevation gradient (Manning mu = 1 damps the transient), closed 10 km box, h = 5,
+    SSPRK33 on n = 2, 4, 8; returns the three L2 errors / sqrt(area).
+    Time step: the reference uses dt = 20/2^i; at n = 2 that is the edge of SSPRK33's real-axis stability interval for the
+    stiff drag term (2 C_D |u|/H dt ~ 2.8 with this build's 6-point cell rule vs the limit 2.51), so whether it survives
+    depends on Firedrake's degree-3 cell quadrature, which is unknowable here ([FD-assumed], parity unpinned).  The test
+    measures a STEADY state, so dt = 10/2^i is used: same criterion, same answer."""
+    lx = ly = 10000.0
+    A = 2.0
+    errs = []
+    for i in range(3):
+        n, dt = 2**(i + 1), 10.0/2**i
+        mesh = RectangleMesh(n, n, lx, ly)
+        errs.append(run(mesh, dt, 43200.0,
+                        lambda x, y: -1000.0*9.81*A*np.cos(np.pi*x/lx)*np.cos(np.pi*y/ly),
+                        lambda x, y: A*np.cos(np.pi*x/lx)*np.cos(np.pi*y/ly))/math.sqrt(lx*ly))
+    return np.array(errs)
+
+
+def check_pressure_forcing_orders(errs):
+    expected_order = 2
+    assert all(errs[:-1]/errs[1:] > 2.**expected_order*0.75), errs           # test_atmospheric_pressure.py:93
+    assert errs[0]/errs[-1] > (2.**expected_order)**(len(errs) - 1)*0.75, errs   # :94
+
+
+def test_atmospheric_pressure_balance_second_order(ref_so):
+    def run(mesh, dt, t_end, patm_fn, eta_fn):
+        cxy = mesh.cell_xy()
+        patm = patm_fn(cxy[:, :, 0], cxy[:, :, 1])                          # DG-P1 interpolation (:60-61)
+        bath = np.full(mesh.num_vertices, 5.0)
+        ref = make_ref(mesh, bath, manning_drag_coefficient=1.0, atmospheric_pressure=patm)
+        uv0 = np.zeros((mesh.num_cells, 3, 2))
+        uv0[:, :, 0] = 1e-7
+        uv, eta = ref.advance(uv0, np.zeros((mesh.num_cells, 3)), dt, int(round(t_end/dt)))
+        orc = make_oracle(mesh, bath)
+        return orc.l2_norm(eta - orc.project(eta_fn))
+    check_pressure_forcing_orders(_pressure_forcing_errors(run))
