@@ -14,5 +14,11 @@ Importing this package never loads the HIP extension; creating a time stepper do
 from . import solver2d  # noqa: F401
 from .function import Function, FunctionSpace, get_functionspace  # noqa: F401
 from .mesh import Mesh2d, PeriodicRectangleMesh, RectangleMesh, SquareMesh, UnitSquareMesh  # noqa: F401
+from .meshio import read_gmsh, write_gmsh  # noqa: F401
 from .options import Constant, ModelOptions2d  # noqa: F401
 from .shallowwater_eq import g_grav, physical_constants, rho_0  # noqa: F401
+
+
+def Mesh(path, **kwargs):
+    """``Mesh('file.msh')`` as in Firedrake user scripts: Gmsh MSH 2.2 files."""
+    return read_gmsh(path, **kwargs)

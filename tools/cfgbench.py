@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""Per-configuration timings of the other BASELINE configs (not the headline bench line): cfg 1(ii)/quads, cfg 4
+(coupled SWE + tracer + limiter), cfg 5 (wetting-drying), each with algorithmic bytes per step and the HBM fraction.
+   python tools/cfgbench.py"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from thetis_amd import _lib                      # noqa: E402
+from thetis_amd.device import Swe2dDevice        # noqa: E402
+from thetis_amd.mesh import RectangleMesh        # noqa: E402
+
+
+def timed(dev, fn, steps):
+    fn(5)
+    dev.synchronize()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fn(steps)
+        dev.synchronize()
+        best = min(best, (time.perf_counter() - t0)/steps)
+    return best
+
+
+def report(name, n_cells, bytes_per_cell_step, t_step, extra=None):
+    out = {'config': name, 'n_cells': n_cells, 'us_per_step': 1e6*t_step,
+           'algorithmic_bytes_per_cell_step': bytes_per_cell_step,
+           'achieved_GBs': bytes_per_cell_step*n_cells/t_step/1e9,
+           'frac_of_8TBs': bytes_per_cell_step*n_cells/t_step/8e12}
+    out.update(extra or {})
+    print(json.dumps(out))
+
+
+def main():
+    rng = np.random.default_rng(1234)
+    # ---- cfg 2 reference point: triangles, SWE only (684 B per cell per step)
+    mesh = RectangleMesh(1000, 500, 100e3, 50e3)
+    n = mesh.num_cells
+    bath = np.full(mesh.num_vertices, 20.0)
+    cxy = mesh.cell_xy()
+    eta = 0.5*np.exp(-((cxy[:, :, 0] - 50e3)**2 + (cxy[:, :, 1] - 25e3)**2)/(5e3)**2) + 1e-3*rng.uniform(-1, 1, size=(n, 3))
+    uv = 1e-3*rng.uniform(-1, 1, size=(n, 3, 2))
+    dev = Swe2dDevice(mesh, bath, 0.25)
+    dev.set_state(uv, eta)
+    report('cfg2 triangles SWE', n, 684.0, timed(dev, dev.advance, 50))
+    # ---- cfg 4: coupled SWE + 1 tracer + limiter.  Tracer per stage: 24 r + 24 w (+24 T0) + 48 velocity + 36 static
+    #      = 132 / 156 / 156 B; limiter once per step: 24 r (means) + 8 w + 8 r + vertex bounds ~16 + 24 r + 24 w + 12 idx ~ 116 B
+    tid = dev.add_tracer()
+    dev.tracer_set_state(tid, np.where(cxy[:, :, 0] < 40e3, 0.0, 30.0))
+    report('cfg4 triangles SWE + tracer + limiter', n, 684.0 + 444.0 + 116.0,
+           timed(dev, lambda k: dev.advance_coupled(k, tracer_only=False, use_limiter=True), 50))
+    report('cfg4 tracer only + limiter', n, 444.0 + 116.0,
+           timed(dev, lambda k: dev.advance_coupled(k, tracer_only=True, use_limiter=True), 50))
+    dev.close()
+    # ---- cfg 5: wetting-drying variant on the Balzano geometry, 500k triangles (+12 B alpha per cell-stage via vertices ~ +6)
+    mesh5 = RectangleMesh(707, 354, 13800.0, 7200.0)
+    n5 = mesh5.num_cells
+    dev = Swe2dDevice(mesh5, mesh5.vertex_xy[:, 0]/2760.0, 0.1)
+    dev.set_wetting_and_drying(0.4)
+    dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+    dev.set_bc(2, {'elev': -0.5})
+    dev.set_state(np.zeros((n5, 3, 2)), np.zeros((n5, 3)))
+    report('cfg5 triangles SWE wetting-drying + Manning + open bc', n5, 684.0 + 18.0, timed(dev, dev.advance, 50))
+    dev.close()
+    # ---- quads: 1M quadrilaterals (cfg 1(ii) cell type at bench size): 248 / 344 / 344 = 936 B per cell per step
+    meshq = RectangleMesh(1000, 1000, 100e3, 100e3, quadrilateral=True)
+    nq = meshq.num_cells
+    cq = meshq.cell_xy()
+    etaq = 0.5*np.exp(-((cq[:, :, 0] - 50e3)**2 + (cq[:, :, 1] - 50e3)**2)/(5e3)**2)
+    dev = Swe2dDevice(meshq, np.full(meshq.num_vertices, 20.0), 0.25)
+    dev.set_state(1e-3*rng.uniform(-1, 1, size=(nq, 4, 2)), etaq)
+    report('quadrilaterals SWE (DQ-1)', nq, 936.0, timed(dev, dev.advance, 50))
+    dev.close()
+
+
+if __name__ == '__main__':
+    main()
