@@ -49,6 +49,11 @@ typedef enum {
 #define SWE2D_BC_UV   2
 #define SWE2D_BC_UN   4
 #define SWE2D_BC_FLUX 8
+/* Function-valued boundary data (e.g. a tidal elevation field on an open boundary, updated by update_forcings): OR the
+ * flag into `kind`; the value is then read from the nodal field given to swe2d_set_bc_field instead of values[]. */
+#define SWE2D_BC_ELEV_FIELD 16
+#define SWE2D_BC_UV_FIELD   32
+#define SWE2D_BC_UN_FIELD   64
 
 /* Nodal coefficient fields, `fields` dict of get_swe_timestepper (thetis/solver2d.py:547-559). */
 typedef enum {
@@ -125,6 +130,11 @@ int  swe2d_set_dt(swe2d_handle *h, double dt);
  * kind = bitmask of SWE2D_BC_*; values = {elev, u, v, un, flux}.  May be called between stages
  * (update_forcings, rungekutta.py:933-934). */
 int  swe2d_set_bc(swe2d_handle *h, int marker, int kind, const double values[5]);
+
+/* Function-valued boundary data shared by all markers (every boundary facet has exactly one marker): nodal DG values in
+ * the host layout, which = 0: elevation (kN), 1: velocity (kN,2), 2: normal velocity (kN).  Only boundary-facet nodes
+ * are read.  May be called between stages. */
+int  swe2d_set_bc_field(swe2d_handle *h, int which, const double *nodal);
 
 /* bnd_functions['shallow_water'][marker]['drag'] = C_D (BoundaryDragTerm, shallowwater_eq.py:704-725); negative: none */
 int  swe2d_set_boundary_drag(swe2d_handle *h, int marker, double drag_coefficient);

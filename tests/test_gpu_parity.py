@@ -180,3 +180,30 @@ def test_full_size_properties(hip_lib):
     assert abs(d1[2] - d0[2])/d0[2] < 1e-12
     assert np.isfinite(d1).all()
     dev.close()
+
+
+@pytest.mark.parametrize('quad', [False, True])
+def test_function_valued_boundary_data(hip_lib, quad):
+    """Spatially varying external elevation / velocity / normal velocity (Function-valued bnd_functions entries)."""
+    from helpers import make_oracle_generic, quad_case
+    from thetis_amd.device import Swe2dDevice
+    if quad:
+        mesh, bath, uv, eta = quad_case(seed=5)
+    else:
+        mesh, bath, uv, eta = channel_case(seed=5)
+    n, k = mesh.cells.shape
+    cxy = mesh.cell_xy()
+    elev_f = 0.3*np.sin(cxy[:, :, 1]/4000.0)                                   # varies along the boundary x = 0
+    un_f = 0.1*np.cos(cxy[:, :, 1]/6000.0)
+    uv_f = np.stack([0.2*np.sin(cxy[:, :, 0]/2e4), -0.1*np.cos(cxy[:, :, 0]/3e4)], axis=2)
+    bcs = {1: {'elev': elev_f}, 2: {'un': un_f, 'elev': 0.1}, 3: {'uv': uv_f}, 4: {'elev': elev_f, 'uv': uv_f}}
+    dt = 3.0
+    orc = make_oracle_generic(mesh, bath, bnd_conditions=bcs)
+    dev = Swe2dDevice(mesh, bath, dt, boundary_len=mesh.boundary_len)
+    for m, funcs in bcs.items():
+        dev.set_bc(m, funcs)
+    dev.set_state(uv, eta)
+    ku, ke = dev.tendency()
+    ku_o, ke_o = orc.tendency(uv, eta, dt)
+    assert rel_linf(ku, ku_o) < TOL_RHS and rel_linf(ke, ke_o) < TOL_RHS
+    dev.close()

@@ -216,3 +216,36 @@ def test_atmospheric_pressure_reference_test(hip_lib):
         area = mesh2d.cell_areas()
         return math.sqrt(float(np.sum(area/12.0*(d.sum(axis=1)**2 + (d**2).sum(axis=1)))))
     check_pressure_forcing_orders(_pressure_forcing_errors(run))
+
+
+def test_function_valued_tidal_boundary(hip_lib):
+    """A tidal elevation FIELD on an open boundary, re-assigned by update_forcings every stage (the set-up of
+    demos/demo_2d_north_sea: bnd_functions['shallow_water'] = {marker: {'elev': tidal_elev}}), against the numpy oracle."""
+    from helpers import make_oracle
+    lx, ly = 13800.0, 7200.0
+    mesh2d = RectangleMesh(12, 6, lx, ly)
+    P1_2d = get_functionspace(mesh2d, 'CG', 1)
+    bath = Function(P1_2d).interpolate(lambda x, y: 5.0 + x/2760.0)
+    s = solver2d.FlowSolver2d(mesh2d, bath)
+    o = s.options
+    o.swe_timestepper_type = 'SSPRK33'
+    o.swe_timestepper_options.use_automatic_timestep = False
+    o.timestep = 5.0
+    o.simulation_end_time = 50.0
+    o.simulation_export_time = 25.0
+    tidal_elev = Function(P1_2d)
+    s.bnd_functions['shallow_water'] = {2: {'elev': tidal_elev}}
+    shape = lambda x, y: 1.0 + 0.3*np.sin(2*np.pi*y/ly)
+    tide = lambda t: -0.5*math.sin(2*math.pi*t/1000.0)
+    s.assign_initial_conditions(elev=Constant(0.0))
+    s.iterate(update_forcings=lambda t: tidal_elev.interpolate(lambda x, y: tide(t)*shape(x, y)))
+    eta = s.fields.elev_2d.cell_node_values()
+    uv = s.fields.uv_2d.cell_node_values()
+    cxy = mesh2d.cell_xy()
+    val = {'t': 0.0}
+    orc = make_oracle(mesh2d, bath.dat.data_ro,
+                      bnd_conditions={2: {'elev': lambda t: tide(val['t'])*shape(cxy[:, :, 0], cxy[:, :, 1])}})
+    u_o, e_o = np.zeros_like(uv), np.zeros_like(eta)
+    for kstep in range(10):
+        u_o, e_o = orc.ssprk33_step(u_o, e_o, 5.0, t=5.0*kstep, update_forcings=lambda t: val.__setitem__('t', t))
+    assert rel_linf(eta, e_o) < 1e-10 and rel_linf(uv, u_o) < 1e-10

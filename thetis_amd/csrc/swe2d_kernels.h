@@ -24,6 +24,9 @@
 #define SWE_BC_UV 2
 #define SWE_BC_UN 4
 #define SWE_BC_FLUX 8
+#define SWE_BC_ELEV_FIELD 16     // the external elevation is a nodal field (Function-valued boundary data)
+#define SWE_BC_UV_FIELD 32
+#define SWE_BC_UN_FIELD 64
 #ifndef SWE_BLOCK
 #define SWE_BLOCK 256
 #endif
@@ -63,6 +66,10 @@ struct SweStageArgs {
     const double *msrc;       // 6 planes (x0 x1 x2 y0 y1 y2) or null
     const double *vsrc;       // 3 planes or null
     const double *wind;       // 6 planes (x0.. y0..) wind stress or null
+    const double *bc_elev_f;  // k planes: Function-valued external elevation (read at boundary facet nodes) or null
+    const double *bc_uv_f;    // 2k planes
+    const double *bc_un_f;    // k planes
+    int npc_;                 // nodes per cell (plane offsets of the vector boundary field)
     double linear_drag, quad_drag, manning, norm_smoother;   // <0: off
     SweBcTable bc;
 };
@@ -148,10 +155,12 @@ __device__ __forceinline__ double swe_int2(const double a[3], const double b[3])
 
 // Boundary facet (closed wall or open boundary); rare, so written for clarity with unit normals.
 // Returns the form values f (residual is -f) already multiplied by the facet length.
+struct SweBcFieldValues { double elev, u, v, un; };   // Function-valued boundary data at the quadrature point
+
 template <bool NONLIN, bool LF, bool WD>
 __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int marker, double uq, double vq, double eq,
                                                double hq, double Hq, double alq, double nxs, double nys, double L,
-                                               double rL, double &fu, double &fv, double &fe)
+                                               double rL, const SweBcFieldValues &bf, double &fu, double &fv, double &fe)
 {
     const double g = p.g;
     const double nx = nxs*rL, ny = nys*rL;
@@ -171,13 +180,14 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
     } else {
         // external state, get_bnd_functions shallowwater_eq.py:243-267
         double e_ext = eq, u_ext = uq, v_ext = vq;
-        if (kind & SWE_BC_ELEV) e_ext = p.bc.elev[marker];
+        if (kind & SWE_BC_ELEV) e_ext = (kind & SWE_BC_ELEV_FIELD) ? bf.elev : p.bc.elev[marker];
         if (kind & SWE_BC_UV) {
-            u_ext = p.bc.u[marker];
-            v_ext = p.bc.v[marker];
+            u_ext = (kind & SWE_BC_UV_FIELD) ? bf.u : p.bc.u[marker];
+            v_ext = (kind & SWE_BC_UV_FIELD) ? bf.v : p.bc.v[marker];
         } else if (kind & SWE_BC_UN) {
-            u_ext = p.bc.un[marker]*nx;
-            v_ext = p.bc.un[marker]*ny;
+            const double un_ext = (kind & SWE_BC_UN_FIELD) ? bf.un : p.bc.un[marker];
+            u_ext = un_ext*nx;
+            v_ext = un_ext*ny;
         } else if (kind & SWE_BC_FLUX) {
             const double H0 = swe_depth_pt<NONLIN, WD>(hq, e_ext, alq);
             const double s = p.bc.flux[marker]/(H0*p.bc.len[marker]);
@@ -215,19 +225,32 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
 
 // Both quadrature points of a boundary facet; kept out of line of the interior fast path (few cells take it).
 template <bool NONLIN, bool LF, bool WD>
-__device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int marker, double ua, double ub, double va,
+__device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int marker, int k, int a, int b, double ua,
+                                                   double ub, double va,
                                                    double vb, double ea, double eb, double ha, double hb, double Ha,
                                                    double Hb, double ala, double alb, double nxs,
                                                    double nys, double L, double rL, double &Fau, double &Fbu,
                                                    double &Fav, double &Fbv, double &Fae, double &Fbe)
 {
+    // Function-valued boundary data live on the same DG nodes as the state: read the two facet nodes of this cell
+    const int kind = (marker < SWE_MAX_MARKERS) ? p.bc.kind[marker] : 0;
+    const size_t S = p.stride;
+    double fea = 0.0, feb = 0.0, fua = 0.0, fub = 0.0, fva = 0.0, fvb = 0.0, fna = 0.0, fnb = 0.0;
+    if ((kind & SWE_BC_ELEV_FIELD) && p.bc_elev_f) { fea = p.bc_elev_f[(size_t)a*S + k]; feb = p.bc_elev_f[(size_t)b*S + k]; }
+    if ((kind & SWE_BC_UV_FIELD) && p.bc_uv_f) {
+        fua = p.bc_uv_f[(size_t)a*S + k]; fub = p.bc_uv_f[(size_t)b*S + k];
+        fva = p.bc_uv_f[(size_t)(p.npc_ + a)*S + k]; fvb = p.bc_uv_f[(size_t)(p.npc_ + b)*S + k];
+    }
+    if ((kind & SWE_BC_UN_FIELD) && p.bc_un_f) { fna = p.bc_un_f[(size_t)a*S + k]; fnb = p.bc_un_f[(size_t)b*S + k]; }
 #pragma unroll 1
     for (int q = 0; q < 2; q++) {
         const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+        SweBcFieldValues bf;
+        bf.elev = xa*fea + xb*feb; bf.u = xa*fua + xb*fub; bf.v = xa*fva + xb*fvb; bf.un = xa*fna + xb*fnb;
         const double uq = xa*ua + xb*ub, vq = xa*va + xb*vb, eq = xa*ea + xb*eb, hq = xa*ha + xb*hb;
         const double Hq = xa*Ha + xb*Hb, alq = xa*ala + xb*alb;     // Ha, Hb: nodal total depth (h, h + eta or D)
         double fu, fv, fe;
-        swe_boundary_flux<NONLIN, LF, WD>(p, marker, uq, vq, eq, hq, Hq, alq, nxs, nys, L, rL, fu, fv, fe);
+        swe_boundary_flux<NONLIN, LF, WD>(p, marker, uq, vq, eq, hq, Hq, alq, nxs, nys, L, rL, bf, fu, fv, fe);
         Fau += xa*fu; Fbu += xb*fu;
         Fav += xa*fv; Fbv += xb*fv;
         Fae += xa*fe; Fbe += xb*fe;
@@ -511,7 +534,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
                 Fae += xa*fe; Fbe += xb*fe;
             }
         } else {
-            swe_boundary_facet<NONLIN, LF, WD>(p, -nb[f], u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
+            swe_boundary_facet<NONLIN, LF, WD>(p, -nb[f], k, a, b, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
                                                al[a], al[b], nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
         }
         bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
@@ -1082,7 +1105,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
                 Fae += xa*fe; Fbe += xb*fe;
             }
         } else {
-            swe_boundary_facet<NONLIN, LF, WD>(p, -nb[f], u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
+            swe_boundary_facet<NONLIN, LF, WD>(p, -nb[f], k, a, b, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
                                                al[a], al[b], nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
         }
         bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;

@@ -174,16 +174,29 @@ class Swe2dDevice(object):
         marker = self._slot(marker)
         kind = 0
         vals = np.zeros(5)
+        is_field = lambda v: isinstance(v, np.ndarray) and v.ndim >= 2
         for key, value in (funcs or {}).items():
             if key == 'elev':
                 kind |= _lib.BC_ELEV
-                vals[0] = float(value)
+                if is_field(value):
+                    kind |= _lib.BC_ELEV_FIELD
+                    self.set_bc_field(0, value)
+                else:
+                    vals[0] = float(value)
             elif key == 'uv':
                 kind |= _lib.BC_UV
-                vals[1], vals[2] = float(value[0]), float(value[1])
+                if is_field(value):
+                    kind |= _lib.BC_UV_FIELD
+                    self.set_bc_field(1, value)
+                else:
+                    vals[1], vals[2] = float(value[0]), float(value[1])
             elif key == 'un':
                 kind |= _lib.BC_UN
-                vals[3] = float(value)
+                if is_field(value):
+                    kind |= _lib.BC_UN_FIELD
+                    self.set_bc_field(2, value)
+                else:
+                    vals[3] = float(value)
             elif key == 'flux':
                 kind |= _lib.BC_FLUX
                 vals[4] = float(value)
@@ -209,6 +222,15 @@ class Swe2dDevice(object):
         a = np.ascontiguousarray(a)
         assert a.shape == (nv,), 'alpha must be a constant or have one value per vertex'
         self._ck(self.lib.swe2d_set_wetting_and_drying(self.h, 1, _ptr(a)))
+
+    def set_bc_field(self, which, nodal):
+        """Function-valued boundary data: nodal DG values (N,k) [(N,k,2) for which = 1] shared by all markers."""
+        shape = (self.n_cells, self.npc, 2) if which == 1 else (self.n_cells, self.npc)
+        a = np.asarray(nodal, dtype=np.float64).reshape(shape)
+        if self.perm is not None:
+            a = a[self.perm]
+        a = np.ascontiguousarray(a)
+        self._ck(self.lib.swe2d_set_bc_field(self.h, int(which), _ptr(a)))
 
     def set_field(self, field, nodal):
         if nodal is None:

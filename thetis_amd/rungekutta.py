@@ -145,9 +145,16 @@ class ERKGenericShuOsher(TimeIntegrator):
             for key, v in funcs.items():
                 if key not in ('elev', 'uv', 'un', 'flux', 'drag'):
                     raise Exception('Invalid boundary tag "{:}" specified on boundary {:}'.format(key, marker))
-                if isinstance(v, Function) or callable(v):
-                    raise NotImplementedError('boundary values must be constants on the device path')
-                vals[key] = _const_value(v)
+                if isinstance(v, Function):
+                    # Function-valued boundary data (e.g. a tidal elevation field): nodal values at the DG nodes
+                    if key not in ('elev', 'uv', 'un'):
+                        raise NotImplementedError("'{:}' must be a constant on the device path".format(key))
+                    vals[key] = np.ascontiguousarray(v.cell_node_values() if v.function_space().family == 'DG'
+                                                     else v.dat.data_ro[mesh.cells])
+                elif callable(v):
+                    raise NotImplementedError('boundary values must be Constants or Functions on the device path')
+                else:
+                    vals[key] = _const_value(v)
             self.device.set_bc(marker, vals)
 
     # ---- host <-> device state
