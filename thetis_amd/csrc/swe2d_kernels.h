@@ -370,8 +370,71 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
     }
 }
 
-// Register budget: 132 (first stage) / 150 VGPRs, 3 waves per SIMD, no scratch.  Forcing 4 waves on the first stage
-// (128 VGPRs) spills 20 B/lane, adds 16 MB of scratch writes per launch and is not faster; forcing 5-6 waves is 2-3x slower.
+// Boundary facets (walls, open boundaries, boundary drag) are < 0.3 % of the work but their code needs ~60 registers of
+// temporaries.  They are therefore NOT evaluated inside the facet loop of the stage kernels (which treats them as zero) but
+// in this epilogue, which runs for cells with a boundary facet after the rest of the cell update is finished - when the
+// large working set of the main part is dead - reloads the few inputs it needs (L1/L2 hits) and adds the correction
+// beta*dt*M^-1(boundary flux) to the output values that are still in registers.  The residual is linear in the facet
+// contributions, so the result is the same up to summation order.
+template <bool NONLIN, bool LF, bool WD, int NPC>
+__device__ __forceinline__ void swe_boundary_epilogue(const SweStageArgs &p, int k, int nb0, int nb1, int nb2, int nb3,
+                                                      double ou[NPC], double ov[NPC], double oe[NPC])
+{
+    const size_t S = p.stride;
+    // cell area from three vertices (static indices); parallelogram: A = a x b, triangle: 2A
+    double sfac;
+    {
+        const int v0 = p.cv[k], v1 = p.cv[S + k], vl = p.cv[(size_t)(NPC - 1)*S + k];
+        const double x0 = p.vx[v0], y0 = p.vy[v0];
+        const double cross = (p.vx[v1] - x0)*(p.vy[vl] - y0) - (p.vy[v1] - y0)*(p.vx[vl] - x0);    // 2A (tri) or A (quad)
+        sfac = (NPC == 3 ? 6.0 : 1.0)*p.dt*p.beta*swe_rcp(cross);
+    }
+    // one facet at a time, everything addressed in memory by plane index: no dynamically indexed register arrays
+#pragma unroll 1
+    for (int f = 0; f < NPC; f++) {
+        const int nbf = (f == 0) ? nb0 : (f == 1) ? nb1 : (f == 2) ? nb2 : nb3;
+        if (nbf >= 0) continue;
+        const int a = f, b = (f + 1 == NPC) ? 0 : f + 1;
+        const int va = p.cv[(size_t)a*S + k], vb = p.cv[(size_t)b*S + k];
+        const double xa_ = p.vx[va], ya_ = p.vy[va], xb_ = p.vx[vb], yb_ = p.vy[vb];
+        const double ha = p.vh[va], hb = p.vh[vb];
+        const double ala = WD ? p.valpha[va] : 0.0, alb = WD ? p.valpha[vb] : 0.0;
+        const double ua = p.uin[(size_t)a*S + k], ub = p.uin[(size_t)b*S + k];
+        const double va_ = p.uin[(size_t)(NPC + a)*S + k], vb_ = p.uin[(size_t)(NPC + b)*S + k];
+        const double ea = p.uin[(size_t)(2*NPC + a)*S + k], eb = p.uin[(size_t)(2*NPC + b)*S + k];
+        const double Ha = WD ? swe_wd_depth(ha + ea, ala) : (NONLIN ? ha + ea : ha);
+        const double Hb = WD ? swe_wd_depth(hb + eb, alb) : (NONLIN ? hb + eb : hb);
+        const double nxs = yb_ - ya_, nys = xa_ - xb_;
+        double L, rL;
+        swe_sqrt_rsqrt(nxs*nxs + nys*nys, L, rL);
+        double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
+        swe_boundary_facet<NONLIN, LF, WD>(p, -nbf, k, a, b, ua, ub, va_, vb_, ea, eb, ha, hb, Ha, Hb, ala, alb, nxs, nys,
+                                           L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
+        const double dau = -0.5*Fau, dbu = -0.5*Fbu, dav = -0.5*Fav, dbv = -0.5*Fbv, dae = -0.5*Fae, dbe = -0.5*Fbe;
+        // M^-1 of a vector that is non-zero at nodes a and b only, scattered with static output indices
+#pragma unroll
+        for (int i = 0; i < NPC; i++) {
+            if (NPC == 3) {
+                const double wa = (i == a) ? 3.0 : -1.0, wb = (i == b) ? 3.0 : -1.0;      // 4 d_i - (d_a + d_b)
+                ou[i] += sfac*(wa*dau + wb*dbu);
+                ov[i] += sfac*(wa*dav + wb*dbv);
+                oe[i] += sfac*(wa*dae + wb*dbe);
+            } else {
+                // tensor inverse weights: 16 on the node, -8 on its two edge neighbours, 4 on the opposite node
+                const int da_ = (i - a) & 3, db_ = (i - b) & 3;
+                const double wa = (da_ == 0) ? 16.0 : (da_ == 2) ? 4.0 : -8.0;
+                const double wb = (db_ == 0) ? 16.0 : (db_ == 2) ? 4.0 : -8.0;
+                ou[i] += sfac*(wa*dau + wb*dbu);
+                ov[i] += sfac*(wa*dav + wb*dbv);
+                oe[i] += sfac*(wa*dae + wb*dbe);
+            }
+        }
+    }
+}
+
+// Register budget: see the -Rpass-analysis output quoted in DESIGN.md; forcing more waves per SIMD than the allocation
+// gives naturally spills (20 B/lane at 128 VGPRs for the first stage: +16 MB scratch writes per launch, not faster;
+// 5-6 waves: 2-3x slower).
 template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD>
 __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(const SweStageArgs p)
 {
@@ -533,10 +596,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
                 Fav += xa*fv; Fbv += xb*fv;
                 Fae += xa*fe; Fbe += xb*fe;
             }
-        } else {
-            swe_boundary_facet<NONLIN, LF, WD>(p, -nb[f], k, a, b, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
-                                               al[a], al[b], nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
-        }
+        }       // boundary facets: see swe_boundary_epilogue_*
         bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
         bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
         be[a] -= 0.5*Fae; be[b] -= 0.5*Fbe;
@@ -545,16 +605,24 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     // ---- mass inverse (M^-1 b)_i = 3/A (4 b_i - sum b), times dt, and the Shu-Osher combine
     const double s = 6.0*p.dt*p.beta*swe_rcp(twoA);
     const double su = bu[0] + bu[1] + bu[2], sv = bv[0] + bv[1] + bv[2], se = be[0] + be[1] + be[2];
+    double ou[3], ov[3], oe[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        p.uout[(size_t)i*S + k] = s*(4.0*bu[i] - su) + wu[i];
-        p.uout[(size_t)(3 + i)*S + k] = s*(4.0*bv[i] - sv) + wv[i];
-        const double znew = s*(4.0*be[i] - se) + we[i];
-        if (WD) {
-            const double D = znew + h[i];
+        ou[i] = s*(4.0*bu[i] - su) + wu[i];
+        ov[i] = s*(4.0*bv[i] - sv) + wv[i];
+        oe[i] = s*(4.0*be[i] - se) + we[i];          // eta, or zeta = D - h with wetting-drying
+    }
+    // boundary facets were skipped above; their correction is added to the finished outputs (see swe_boundary_epilogue)
+    if ((nb[0] | nb[1] | nb[2]) < 0) swe_boundary_epilogue<NONLIN, LF, WD, 3>(p, k, nb[0], nb[1], nb[2], 0, ou, ov, oe);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        p.uout[(size_t)i*S + k] = ou[i];
+        p.uout[(size_t)(3 + i)*S + k] = ov[i];
+        if (WD) {           // back from zeta = D - h to eta:  H = D - alpha^2/(4D)
+            const double D = oe[i] + h[i];
             p.uout[(size_t)(6 + i)*S + k] = D - al[i]*al[i]/(4.0*D) - h[i];
         } else {
-            p.uout[(size_t)(6 + i)*S + k] = znew;
+            p.uout[(size_t)(6 + i)*S + k] = oe[i];
         }
     }
 }
@@ -1104,10 +1172,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
                 Fav += xa*fv; Fbv += xb*fv;
                 Fae += xa*fe; Fbe += xb*fe;
             }
-        } else {
-            swe_boundary_facet<NONLIN, LF, WD>(p, -nb[f], k, a, b, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
-                                               al[a], al[b], nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
-        }
+        }       // boundary facets: see swe_boundary_epilogue_*
         bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
         bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
         be[a] -= 0.5*Fae; be[b] -= 0.5*Fbe;
@@ -1115,17 +1180,25 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
 
     // ---- tensor mass inverse and Shu-Osher combine
     const double s = p.dt*p.beta*rA;
+    double ou[4], ov[4], oe[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int n1 = (i + 1) & 3, n2 = (i + 2) & 3, n3 = (i + 3) & 3;
-        p.uout[(size_t)i*S + k] = s*(16.0*bu[i] - 8.0*bu[n1] - 8.0*bu[n3] + 4.0*bu[n2]) + wu[i];
-        p.uout[(size_t)(4 + i)*S + k] = s*(16.0*bv[i] - 8.0*bv[n1] - 8.0*bv[n3] + 4.0*bv[n2]) + wv[i];
-        const double znew = s*(16.0*be[i] - 8.0*be[n1] - 8.0*be[n3] + 4.0*be[n2]) + we[i];
-        if (WD) {
-            const double D = znew + h[i];
+        ou[i] = s*(16.0*bu[i] - 8.0*bu[n1] - 8.0*bu[n3] + 4.0*bu[n2]) + wu[i];
+        ov[i] = s*(16.0*bv[i] - 8.0*bv[n1] - 8.0*bv[n3] + 4.0*bv[n2]) + wv[i];
+        oe[i] = s*(16.0*be[i] - 8.0*be[n1] - 8.0*be[n3] + 4.0*be[n2]) + we[i];
+    }
+    // boundary facets were skipped above; their correction is added to the finished outputs (see swe_boundary_epilogue)
+    if ((nb[0] | nb[1] | nb[2] | nb[3]) < 0) swe_boundary_epilogue<NONLIN, LF, WD, 4>(p, k, nb[0], nb[1], nb[2], nb[3], ou, ov, oe);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        p.uout[(size_t)i*S + k] = ou[i];
+        p.uout[(size_t)(4 + i)*S + k] = ov[i];
+        if (WD) {           // back from zeta = D - h to eta:  H = D - alpha^2/(4D)
+            const double D = oe[i] + h[i];
             p.uout[(size_t)(8 + i)*S + k] = D - al[i]*al[i]/(4.0*D) - h[i];
         } else {
-            p.uout[(size_t)(8 + i)*S + k] = znew;
+            p.uout[(size_t)(8 + i)*S + k] = oe[i];
         }
     }
 }
