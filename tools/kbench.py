@@ -26,11 +26,16 @@ def main():
     ap.add_argument('--order', default='natural')
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--tag', default='')
+    ap.add_argument('--nx', type=int, default=0, help='override the mesh: RectangleMesh(nx, ny), same cell size')
+    ap.add_argument('--ny', type=int, default=0)
     ap.add_argument('--calibrate', action='store_true', help='also run the PMC calibration copy kernel')
     args = ap.parse_args()
     import bench
     from thetis_amd.device import Swe2dDevice
-    mesh, bath, uv, eta = bench.build_case()
+    if args.nx:
+        mesh, bath, uv, eta = bench.build_case(args.nx, args.ny)
+    else:
+        mesh, bath, uv, eta = bench.build_case()
     reorder = None
     if args.order.startswith('tile'):
         _, bx, by = args.order.split(':')
@@ -65,7 +70,7 @@ def main():
     _, ms_k = dev.advance_timed(args.steps, per_launch=True)
     d = dev.diagnostics()
     n = mesh.num_cells
-    print(json.dumps({'tag': args.tag or os.environ.get('THETIS_AMD_LIB', 'default'), 'order': args.order,
+    print(json.dumps({'tag': args.tag or os.environ.get('THETIS_AMD_LIB', 'default'), 'order': args.order, 'n_cells': n,
                       'us_per_step': 1e3*best, 'us_per_launch': 1e3*ms_k, 'frac': 684.0*n/(best*1e-3)/8e12,
                       'vol': d[2]}))
     dev.close()
