@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SWE2D_ABI_VERSION 1
+#define SWE2D_ABI_VERSION 2
 #define SWE2D_MAX_MARKERS 16          /* boundary markers must be in 1..SWE2D_MAX_MARKERS-1 */
 
 typedef enum {
@@ -169,6 +169,15 @@ int  swe2d_tendency(swe2d_handle *h, double *k_uv, double *k_eta);
  * (sums, not roots, so that partitions can be added). */
 int  swe2d_diagnostics(swe2d_handle *h, double out[4]);
 
+/* ---- SIPG horizontal viscosity: HorizontalViscosityTerm (thetis/shallowwater_eq.py:554-616), fields['viscosity_h'] =
+ * options.horizontal_viscosity (solver2d.py:551).  nu is a constant (nu_vertex == NULL) or a continuous P1 field given per
+ * vertex; sipg_factor = options.sipg_factor (options.py:730); the two flags are options.use_grad_div_viscosity_term and
+ * use_grad_depth_viscosity_term (options.py:597-606).  Dirichlet boundary terms follow the velocity-type boundary
+ * conditions set with swe2d_set_bc (:584-609).  Triangles only; not with wetting and drying.  enable = 0 switches the
+ * term off (viscosity_h None, :559-560). */
+int  swe2d_set_viscosity(swe2d_handle *h, int enable, const double *nu_vertex, double nu_const, double sipg_factor,
+                         int use_grad_div_viscosity_term, int use_grad_depth_viscosity_term);
+
 /* ---- 2D tracers (thetis/tracer_eq_2d.py, non-conservative form) and the vertex-based P1DG limiter -----------------
  * A tracer is a scalar DG-P1 field (3N nodal values, same node layout as eta) advected by the CURRENT shallow-water
  * velocity of the handle.  Single-device handles only for now. */
@@ -182,6 +191,16 @@ int  swe2d_tracer_get_state(swe2d_handle *h, int tracer_id, double *nodal);
  * c (u.n) phi (tracer_eq_2d.py:177-191).  Velocity-type keys are not supported. */
 int  swe2d_tracer_set_bc(swe2d_handle *h, int tracer_id, int marker, int has_value, double value);
 int  swe2d_tracer_set_source(swe2d_handle *h, int tracer_id, const double *nodal);   /* SourceTerm tracer_eq_2d.py:281-298 */
+/* SIPG horizontal diffusion: HorizontalDiffusionTerm (tracer_eq_2d.py:226-278), fields['diffusivity_h-<label>'] =
+ * options.tracer[label].diffusivity (solver2d.py:588); constant or per-vertex P1; sipg_factor_tracer options.py:732 */
+int  swe2d_tracer_set_diffusivity(swe2d_handle *h, int tracer_id, int enable, const double *mu_vertex, double mu_const,
+                                  double sipg_factor_tracer);
+/* boundary term of the diffusion operator on `marker` (tracer_eq_2d.py:264-277): kind 0 = none (no boundary dict),
+ * 1 = prescribed 'diff_flux' (-phi*diff_flux), 2 = any other boundary dict (-phi mu s grad(c).n, s the upwind switch) */
+#define SWE2D_DIFF_BC_NONE 0
+#define SWE2D_DIFF_BC_DIFF_FLUX 1
+#define SWE2D_DIFF_BC_UPWIND 2
+int  swe2d_tracer_set_diffusion_bc(swe2d_handle *h, int tracer_id, int marker, int kind, double diff_flux);
 int  swe2d_tracer_solve_stage(swe2d_handle *h, int tracer_id, int i_stage);          /* rungekutta.py:930-946 for the tracer */
 int  swe2d_tracer_tendency(swe2d_handle *h, int tracer_id, double *k_nodal);         /* parity hook */
 /* VertexBasedP1DGLimiter (thetis/limiter.py:48-198): topology of the mesh vertices (periodic meshes identify them);

@@ -1,0 +1,160 @@
+"""CPU: the oracle's SIPG terms (HorizontalViscosityTerm shallowwater_eq.py:554-616, tracer HorizontalDiffusionTerm
+tracer_eq_2d.py:226-278) - structural properties of the symmetric interior penalty forms and the reference's own
+known-answer test test/tracerEq/test_h-diffusion_mes_2d.py (erf profile, SSPRK33, limiter on, rate > 1.8)."""
+import math
+
+import numpy as np
+import pytest
+from scipy import stats
+from scipy.special import erf
+
+from helpers import channel_case, delaunay_case, make_oracle
+from thetis_amd.mesh import PeriodicRectangleMesh, RectangleMesh
+
+
+def _interior_cells(mesh):
+    return np.all(mesh.cell_nbr >= 0, axis=1)
+
+
+def test_linear_fields_have_zero_diffusive_residual_in_the_interior():
+    """Jumps vanish for a globally linear field and the cell term balances the consistency term (divergence theorem)."""
+    mesh, bath, _, _ = delaunay_case(n_points=250, seed=1)
+    xy = mesh.cell_xy()
+    x, y = xy[:, :, 0], xy[:, :, 1]
+    orc = make_oracle(mesh, bath, horizontal_viscosity=3.0, use_grad_depth_viscosity_term=False)
+    uv = np.stack([1.0 + 2e-3*x - 1e-3*y, -0.5 + 4e-4*x + 3e-3*y], axis=2)
+    inner = _interior_cells(mesh)
+    for gd in (False, True):
+        orc.use_grad_div = gd
+        f = orc.viscosity_form(uv, np.zeros_like(x))
+        scale = 3.0*3e-3*np.sqrt(orc.area).max()
+        assert np.abs(f[inner]).max() < 1e-11*scale
+    T = 2.0 - 1e-3*x + 5e-4*y
+    f = orc.tracer_diffusion_form(T, uv, np.zeros_like(x), orc._nodal(7.0), 1.0, {}, 1.0, 0.0)
+    assert np.abs(f[inner]).max() < 1e-11*7.0*1e-3*np.sqrt(orc.area).max()
+
+
+@pytest.mark.parametrize('grad_div', [False, True])
+def test_sipg_viscosity_form_is_symmetric_and_dissipative(grad_div):
+    """a(u, w) = a(w, u) for the interior-penalty form (closed boundaries, no grad-depth source), and a(u, u) >= 0."""
+    mesh, bath, _, _ = delaunay_case(n_points=200, seed=3)
+    rng = np.random.default_rng(0)
+    nu = 0.5 + rng.uniform(size=mesh.num_vertices)                 # continuous P1 viscosity
+    orc = make_oracle(mesh, bath, horizontal_viscosity=nu, use_grad_div_viscosity_term=grad_div,
+                      use_grad_depth_viscosity_term=False, sipg_factor=2.0)
+    u = rng.normal(size=(mesh.num_cells, 3, 2))
+    w = rng.normal(size=(mesh.num_cells, 3, 2))
+    e = np.zeros((mesh.num_cells, 3))
+    a_uw = np.sum(w*orc.viscosity_form(u, e))
+    a_wu = np.sum(u*orc.viscosity_form(w, e))
+    assert math.isclose(a_uw, a_wu, rel_tol=1e-11)
+    assert np.sum(u*orc.viscosity_form(u, e)) > 0.0
+    # scalar operator: same properties
+    mu = orc._nodal(nu)
+    c, d = rng.normal(size=(2, mesh.num_cells, 3))
+    a_cd = np.sum(d*orc.tracer_diffusion_form(c, u, e, mu, 2.0, {}, 1.0, 0.0))
+    a_dc = np.sum(c*orc.tracer_diffusion_form(d, u, e, mu, 2.0, {}, 1.0, 0.0))
+    assert math.isclose(a_cd, a_dc, rel_tol=1e-11)
+    assert np.sum(c*orc.tracer_diffusion_form(c, u, e, mu, 2.0, {}, 1.0, 0.0)) > 0.0
+
+
+def test_viscosity_without_grad_div_is_componentwise_scalar_diffusion():
+    """stress = nu grad(u): each velocity component sees the scalar SIPG operator (continuous nu)."""
+    mesh, bath, uv, eta = channel_case(seed=2)
+    rng = np.random.default_rng(5)
+    nu = 1.0 + rng.uniform(size=mesh.num_vertices)
+    orc = make_oracle(mesh, bath, horizontal_viscosity=nu, use_grad_depth_viscosity_term=False, sipg_factor=1.5)
+    f = orc.viscosity_form(uv, eta)
+    for c in range(2):
+        fc = orc.tracer_diffusion_form(uv[:, :, c], uv, eta, orc._nodal(nu), 1.5, {}, 1.0, 0.0)
+        assert np.abs(f[:, :, c] - fc).max() < 1e-12*np.abs(fc).max()
+
+
+def test_diffusion_conserves_tracer_integral_in_closed_domain():
+    """Test function 1 is in the space: sum of the assembled form vanishes (no boundary dict => no boundary term)."""
+    mesh, bath, uv, eta = channel_case(seed=8)
+    T = np.random.default_rng(2).normal(size=(mesh.num_cells, 3))
+    orc = make_oracle(mesh, bath)
+    f = orc.tracer_diffusion_form(T, uv, eta, orc._nodal(50.0), 1.0, {}, 1.0, 0.0)
+    assert abs(f.sum()) < 1e-12*np.abs(f).sum()
+
+
+def test_prescribed_diffusive_flux_boundary():
+    """'diff_flux' adds -int phi*diff_flux ds on that boundary only (tracer_eq_2d.py:267-268)."""
+    mesh, bath, uv, eta = channel_case(seed=8)
+    T = np.random.default_rng(2).normal(size=(mesh.num_cells, 3))
+    orc = make_oracle(mesh, bath)
+    mu = orc._nodal(50.0)
+    f0 = orc.tracer_diffusion_form(T, uv, eta, mu, 1.0, {}, 1.0, 0.0)
+    f1 = orc.tracer_diffusion_form(T, uv, eta, mu, 1.0, {2: {'diff_flux': 0.3}}, 1.0, 0.0)
+    assert math.isclose((f1 - f0).sum(), -0.3*orc.boundary_len[2], rel_tol=1e-12)
+
+
+def _run_h_diffusion(refinement):
+    """test_h-diffusion_mes_2d.py:9-103 with the oracle: tracer-only SSPRK33 steps + limiter, zero velocity."""
+    lx, ly = 20.0e3, 5.0e3/refinement
+    depth, mu = 30.0, 1.0e3
+    nx = 8*refinement + 1
+    mesh = RectangleMesh(nx, 1, lx, ly)
+    bath = np.full(mesh.num_vertices, depth)
+    orc = make_oracle(mesh, bath, use_nonlinear_equations=False)
+    t, t_end = 1000.0, 3000.0
+    x0 = lx/2.0
+
+    def ana(x, tt):
+        return -erf((x - x0)/np.sqrt(4*mu*tt))          # u_max = 1, u_min = -1
+
+    T = orc.project(lambda x, y: ana(x, t))
+    uv = np.zeros((mesh.num_cells, 3, 2))
+    eta = np.zeros((mesh.num_cells, 3))
+    # the reference's automatic time step (solver2d.py:213-248): cfl_2d * 0.05 * dx/(sqrt(g h) + U), U = 1
+    dx = np.sqrt(orc.area.min())
+    dt = 0.05*dx/(math.sqrt(9.81*depth) + 1.0)
+    n = int(math.ceil((t_end - t)/dt - 1e-9))
+    dt = (t_end - t)/n
+    for _ in range(n):
+        T = orc.tracer_ssprk33_step(T, uv, eta, dt, diffusivity=mu)
+        T = orc.limit(T)
+    # L2 error against the analytical profile (degree-4 cell quadrature), normalised as in the reference
+    err2 = 0.0
+    for bary, _, wA in orc.cell_quad:
+        xq = orc.p[:, :, 0] @ bary
+        err2 += np.sum(wA*((T @ bary) - ana(xq, t_end))**2)
+    return math.sqrt(err2)/math.sqrt(lx*ly)
+
+
+def test_horizontal_diffusion_convergence_rate():
+    """test_h-diffusion_mes_2d.py:162-175: SSPRK33, P1, refinements 1, 2, 3, slope > 1.8."""
+    refs = [1, 2, 3]
+    errs = [_run_h_diffusion(r) for r in refs]
+    slope = stats.linregress(np.log10(np.array(refs, dtype=float)**-1), np.log10(errs)).slope
+    assert slope > 1.8, (errs, slope)
+
+
+def test_decaying_shear_flow_with_viscosity():
+    """Own known answer for the viscosity term inside the full SWE residual: linear equations, flat bed, periodic in both
+    directions, u = sin(k y) e^{-nu k^2 t}: the momentum equation reduces to u_t = nu u_yy.  (On the triangulated grid the
+    discrete operator is not translation invariant inside a cell pair, so eta and v pick up an O(h^2) disturbance.)"""
+    errs = []
+    for n in (8, 16):
+        ly = lx = 1000.0
+        mesh = PeriodicRectangleMesh(n, n, lx, ly, direction='both')
+        bath = np.full(mesh.num_vertices, 10.0)
+        nu = 20.0
+        orc = make_oracle(mesh, bath, use_nonlinear_equations=False, horizontal_viscosity=nu)
+        k = 2*math.pi/ly
+        xy = mesh.cell_xy()
+        uv = np.zeros((mesh.num_cells, 3, 2))
+        uv[:, :, 0] = np.sin(k*xy[:, :, 1])
+        eta = np.zeros((mesh.num_cells, 3))
+        t_end = 0.1/(nu*k*k)
+        dt = min(0.02*(lx/n)**2/nu, 0.05*(lx/n)/math.sqrt(9.81*10.0))     # diffusive and gravity-wave limits
+        nsteps = int(math.ceil(t_end/dt))
+        dt = t_end/nsteps
+        for _ in range(nsteps):
+            uv, eta = orc.ssprk33_step(uv, eta, dt)
+        exact = np.sin(k*xy[:, :, 1])*math.exp(-nu*k*k*t_end)
+        assert np.abs(eta).max() < 5e-3 and np.abs(uv[:, :, 1]).max() < 1e-2
+        errs.append(np.sqrt(np.mean((uv[:, :, 0] - exact)**2)))
+    assert errs[0] < 0.02
+    assert math.log2(errs[0]/errs[1]) > 1.7, errs

@@ -54,6 +54,7 @@ SYMBOLS = {
     'swe2d_set_field': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_set_scalar': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_double]),
     'swe2d_set_wetting_and_drying': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
+    'swe2d_set_viscosity': (ctypes.c_int, [_H, ctypes.c_int, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
     'swe2d_advance': (ctypes.c_int, [_H, ctypes.c_int]),
     'swe2d_solve_stage': (ctypes.c_int, [_H, ctypes.c_int]),
     'swe2d_advance_timed': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
@@ -67,6 +68,8 @@ SYMBOLS = {
     'swe2d_tracer_get_state': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_tracer_set_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
     'swe2d_tracer_set_source': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
+    'swe2d_tracer_set_diffusivity': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_double, ctypes.c_double]),
+    'swe2d_tracer_set_diffusion_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
     'swe2d_tracer_solve_stage': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int]),
     'swe2d_tracer_tendency': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_limiter_setup': (ctypes.c_int, [_H, ctypes.c_int32, _ip]),

@@ -2,6 +2,7 @@
 // point fails with SWE2D_ERR_NO_DEVICE / SWE2D_ERR_HIP when the HIP runtime or a device is missing.
 #include "../../include/swe2d.h"
 #include "swe2d_kernels.h"
+#include "swe2d_sipg.h"
 
 #include <algorithm>
 #include <cmath>
@@ -38,6 +39,11 @@ struct Handle {
     double *bc_field[3] = {nullptr, nullptr, nullptr};  // Function-valued boundary data: elev (k planes), uv (2k), un (k)
     double *valpha = nullptr;                          // per-vertex wetting-drying alpha
     bool wd = false;
+    // SIPG horizontal viscosity (optional pass after each stage kernel)
+    bool visc = false;
+    double *nu_v = nullptr;                            // per-vertex viscosity or null (constant)
+    double nu_const = 0.0, sipg_factor = 1.0;
+    int visc_grad_div = 0, visc_grad_depth = 1;
     double *field[SWE2D_FIELD_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double scalar[SWE2D_SCALAR_COUNT] = {-1.0, -1.0, -1.0, 0.0};
     double *stage_uv = nullptr, *stage_eta = nullptr;  // device staging in host layout (6N + 3N)
@@ -51,6 +57,11 @@ struct Handle {
         double *source = nullptr;
         int bc_has_value[SWE_MAX_MARKERS];
         double bc_value[SWE_MAX_MARKERS];
+        bool diff = false;                              // SIPG horizontal diffusion
+        double *mu_v = nullptr;
+        double mu_const = 0.0, sipg_factor = 1.0;
+        int bc_diff_kind[SWE_MAX_MARKERS];
+        double bc_diff_flux[SWE_MAX_MARKERS];
     };
     std::vector<Tracer> tracers;
     int tracer_use_lf = 0;
@@ -171,6 +182,25 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     const int grid = ((nblocks + 7)/8)*8;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
+    if (h->visc) {
+        // HorizontalViscosityTerm: U_out[uv] += beta*dt*M^-1 R_visc(U_in) on the same cells (swe2d_sipg.h)
+        SweSipgArgs v{};
+        v.in = h->state[in];
+        v.out = h->state[out];
+        v.stride = h->stride;
+        v.nbr = h->nbr; v.cv = h->cv; v.vx = h->vx; v.vy = h->vy; v.vh = h->vh;
+        v.mu_v = h->nu_v; v.mu_const = h->nu_const;
+        v.sipg = 3.0*h->sipg_factor;
+        v.dt = h->par.dt; v.beta = beta;
+        v.cell_begin = c0; v.cell_end = c1;
+        v.grad_div = h->visc_grad_div; v.grad_depth = h->visc_grad_depth;
+        v.nonlin = h->par.use_nonlinear_equations;
+        v.eta = h->state[in] + 6*h->stride;
+        v.bc = h->bc;
+        v.bc_elev_f = h->bc_field[0]; v.bc_uv_f = h->bc_field[1]; v.bc_un_f = h->bc_field[2];
+        hipLaunchKernelGGL(swe_sipg_kernel<2>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
+        HIP_TRY(h, hipGetLastError());
+    }
     return SWE2D_OK;
 }
 
@@ -364,10 +394,11 @@ void swe2d_destroy(swe2d_handle *hh)
     for (auto &t : h->tracers) {
         for (int b = 0; b < 3; b++) if (t.buf[b]) (void)hipFree(t.buf[b]);
         if (t.source) (void)hipFree(t.source);
+        if (t.mu_v) (void)hipFree(t.mu_v);
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2]};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->nu_v};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -527,6 +558,7 @@ int swe2d_set_wetting_and_drying(swe2d_handle *hh, int enable, const double *alp
     if (!alpha_vertex) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "alpha_vertex is required");
     if (!h->par.use_nonlinear_equations)
         return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "wetting and drying needs use_nonlinear_equations");
+    if (h->visc) return fail(h, SWE2D_ERR_UNSUPPORTED, "SIPG viscosity with wetting and drying");
     for (int i = 0; i < h->n_vertices; i++)
         if (!(alpha_vertex[i] >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "alpha must be >= 0");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -534,6 +566,42 @@ int swe2d_set_wetting_and_drying(swe2d_handle *hh, int enable, const double *alp
     HIP_TRY(h, hipMemcpyAsync(h->valpha, alpha_vertex, (size_t)h->n_vertices*sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->wd = true;
+    return SWE2D_OK;
+}
+
+// shared by swe2d_set_viscosity / swe2d_tracer_set_diffusivity: upload (or drop) a per-vertex coefficient
+static int upload_vertex_coefficient(Handle *h, const double *vertex_values, double **dev)
+{
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!vertex_values) {
+        if (*dev) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipFree(*dev)); *dev = nullptr; }
+        return SWE2D_OK;
+    }
+    for (int i = 0; i < h->n_vertices; i++)
+        if (!(vertex_values[i] >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "diffusion coefficient must be >= 0");
+    if (!*dev) HIP_TRY(h, hipMalloc(dev, (size_t)h->n_vertices*sizeof(double)));
+    HIP_TRY(h, hipMemcpyAsync(*dev, vertex_values, (size_t)h->n_vertices*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWE2D_OK;
+}
+
+int swe2d_set_viscosity(swe2d_handle *hh, int enable, const double *nu_vertex, double nu_const, double sipg_factor,
+                        int use_grad_div_viscosity_term, int use_grad_depth_viscosity_term)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (!enable) { h->visc = false; return SWE2D_OK; }
+    if (h->npc != 3) return fail(h, SWE2D_ERR_UNSUPPORTED, "SIPG viscosity: triangles only");
+    if (h->wd) return fail(h, SWE2D_ERR_UNSUPPORTED, "SIPG viscosity with wetting and drying");
+    if (!nu_vertex && !(nu_const >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "viscosity must be >= 0");
+    if (!(sipg_factor > 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "sipg_factor must be > 0");
+    int rc = upload_vertex_coefficient(h, nu_vertex, &h->nu_v);
+    if (rc) return rc;
+    h->nu_const = nu_const;
+    h->sipg_factor = sipg_factor;
+    h->visc_grad_div = use_grad_div_viscosity_term ? 1 : 0;
+    h->visc_grad_depth = use_grad_depth_viscosity_term ? 1 : 0;
+    h->visc = true;
     return SWE2D_OK;
 }
 
@@ -773,6 +841,23 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     const int grid = ((nblocks + 7)/8)*8;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
+    if (t.diff) {
+        // HorizontalDiffusionTerm: T_out += beta*dt*M^-1 R_diff(T_in) (swe2d_sipg.h)
+        SweSipgArgs v{};
+        v.in = t.buf[in];
+        v.out = t.buf[out];
+        v.stride = h->stride;
+        v.nbr = h->nbr; v.cv = h->cv; v.vx = h->vx; v.vy = h->vy; v.vh = h->vh;
+        v.mu_v = t.mu_v; v.mu_const = t.mu_const;
+        v.sipg = 3.0*t.sipg_factor;
+        v.dt = h->par.dt; v.beta = beta;
+        v.cell_begin = 0; v.cell_end = h->n_owned;
+        v.uv = h->state[0];
+        v.vel_factor = h->tracer_vel_factor;
+        for (int m = 0; m < SWE_MAX_MARKERS; m++) { v.bc_diff_kind[m] = t.bc_diff_kind[m]; v.bc_diff_flux[m] = t.bc_diff_flux[m]; }
+        hipLaunchKernelGGL(swe_sipg_kernel<1>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
+        HIP_TRY(h, hipGetLastError());
+    }
     return SWE2D_OK;
 }
 
@@ -872,7 +957,10 @@ int swe2d_tracer_add(swe2d_handle *hh, int *tracer_id)
     if (h->n_owned != h->n_cells) return fail(h, SWE2D_ERR_UNSUPPORTED, "tracers are not available on partitions yet");
     HIP_TRY(h, hipSetDevice(h->device));
     Handle::Tracer t;
-    for (int m = 0; m < SWE_MAX_MARKERS; m++) { t.bc_has_value[m] = 0; t.bc_value[m] = 0.0; }
+    for (int m = 0; m < SWE_MAX_MARKERS; m++) {
+        t.bc_has_value[m] = 0; t.bc_value[m] = 0.0;
+        t.bc_diff_kind[m] = SWE_SIPG_BC_NONE; t.bc_diff_flux[m] = 0.0;
+    }
     for (int b = 0; b < 3; b++) {
         HIP_TRY(h, hipMalloc(&t.buf[b], (size_t)h->npc*h->stride*sizeof(double)));
         HIP_TRY(h, hipMemsetAsync(t.buf[b], 0, (size_t)h->npc*h->stride*sizeof(double), h->stream));
@@ -956,6 +1044,37 @@ int swe2d_tracer_set_source(swe2d_handle *hh, int id, const double *nodal)
                        h->stage_eta, t.source, h->stride, h->n_cells, 1, h->npc);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWE2D_OK;
+}
+
+int swe2d_tracer_set_diffusivity(swe2d_handle *hh, int id, int enable, const double *mu_vertex, double mu_const,
+                                 double sipg_factor_tracer)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    Handle::Tracer &t = h->tracers[id];
+    if (!enable) { t.diff = false; return SWE2D_OK; }
+    if (h->npc != 3) return fail(h, SWE2D_ERR_UNSUPPORTED, "SIPG tracer diffusion: triangles only");
+    if (!mu_vertex && !(mu_const >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "diffusivity must be >= 0");
+    if (!(sipg_factor_tracer > 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "sipg_factor_tracer must be > 0");
+    rc = upload_vertex_coefficient(h, mu_vertex, &t.mu_v);
+    if (rc) return rc;
+    t.mu_const = mu_const;
+    t.sipg_factor = sipg_factor_tracer;
+    t.diff = true;
+    return SWE2D_OK;
+}
+
+int swe2d_tracer_set_diffusion_bc(swe2d_handle *hh, int id, int marker, int kind, double diff_flux)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (marker <= 0 || marker >= SWE2D_MAX_MARKERS) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "marker out of range");
+    if (kind < SWE_SIPG_BC_NONE || kind > SWE_SIPG_BC_UPWIND) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad diffusion boundary kind");
+    h->tracers[id].bc_diff_kind[marker] = kind;
+    h->tracers[id].bc_diff_flux[marker] = diff_flux;
     return SWE2D_OK;
 }
 

@@ -223,6 +223,40 @@ class Swe2dDevice(object):
         assert a.shape == (nv,), 'alpha must be a constant or have one value per vertex'
         self._ck(self.lib.swe2d_set_wetting_and_drying(self.h, 1, _ptr(a)))
 
+    def _vertex_coefficient(self, value):
+        """constant -> (None, float); per-vertex array (mesh numbering) -> (device-ordered array, 0.0)"""
+        a = np.asarray(value, dtype=np.float64)
+        if a.ndim == 0:
+            return None, float(a)
+        nv = self._keep[1].shape[0]
+        if self._vperm is not None:
+            a = a[self._vperm]
+        a = np.ascontiguousarray(a)
+        assert a.shape == (nv,), 'coefficient must be a constant or have one value per vertex'
+        return a, 0.0
+
+    def set_viscosity(self, nu, sipg_factor=1.0, use_grad_div_viscosity_term=False, use_grad_depth_viscosity_term=True):
+        """SIPG horizontal viscosity (shallowwater_eq.py:554-616); ``nu``: constant, per-vertex array, or None (off)."""
+        if nu is None:
+            self._ck(self.lib.swe2d_set_viscosity(self.h, 0, None, 0.0, 1.0, 0, 0))
+            return
+        arr, const = self._vertex_coefficient(nu)
+        self._ck(self.lib.swe2d_set_viscosity(self.h, 1, None if arr is None else _ptr(arr), const, float(sipg_factor),
+                                              int(bool(use_grad_div_viscosity_term)), int(bool(use_grad_depth_viscosity_term))))
+
+    def tracer_set_diffusivity(self, tracer_id, mu, sipg_factor_tracer=1.0):
+        """SIPG horizontal diffusion of a tracer (tracer_eq_2d.py:226-278); constant, per-vertex array or None (off)."""
+        if mu is None:
+            self._ck(self.lib.swe2d_tracer_set_diffusivity(self.h, int(tracer_id), 0, None, 0.0, 1.0))
+            return
+        arr, const = self._vertex_coefficient(mu)
+        self._ck(self.lib.swe2d_tracer_set_diffusivity(self.h, int(tracer_id), 1, None if arr is None else _ptr(arr), const,
+                                                       float(sipg_factor_tracer)))
+
+    def tracer_set_diffusion_bc(self, tracer_id, marker, kind, diff_flux=0.0):
+        """kind: 0 none, 1 prescribed 'diff_flux', 2 upwind-gradient boundary term (any other boundary dict)."""
+        self._ck(self.lib.swe2d_tracer_set_diffusion_bc(self.h, int(tracer_id), self._slot(marker), int(kind), float(diff_flux)))
+
     def set_bc_field(self, which, nodal):
         """Function-valued boundary data: nodal DG values (N,k) [(N,k,2) for which = 1] shared by all markers."""
         shape = (self.n_cells, self.npc, 2) if which == 1 else (self.n_cells, self.npc)
