@@ -147,3 +147,98 @@ def test_sipg_rejects_unsupported_configurations(hip_lib):
     with pytest.raises(RuntimeError, match='wetting'):
         dev.set_viscosity(1.0)
     dev.close()
+
+
+def _run_h_diffusion_solver(refinement):
+    """test/tracerEq/test_h-diffusion_mes_2d.py:9-103 through FlowSolver2d (custom time loop on the tracer stepper)."""
+    import math
+    from scipy.special import erf
+    from thetis_amd import Constant, Function, RectangleMesh, get_functionspace, solver2d
+    lx, ly = 20.0e3, 5.0e3/refinement
+    depth = 30.0
+    horizontal_diffusivity = Constant(1.0e3)
+    mesh2d = RectangleMesh(8*refinement + 1, 1, lx, ly)
+    t_end, t_init = 3000.0, 1000.0
+    p1_2d = get_functionspace(mesh2d, 'CG', 1)
+    bathymetry_2d = Function(p1_2d, name='Bathymetry')
+    bathymetry_2d.assign(depth)
+    solverobj = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+    options = solverobj.options
+    options.use_nonlinear_equations = False
+    options.horizontal_velocity_scale = Constant(1.0)
+    options.no_exports = True
+    options.simulation_end_time = t_end
+    options.simulation_export_time = (t_end - t_init)/8.0
+    options.add_tracer_2d('tracer_2d', 'Depth averaged tracer', 'Tracer2d', diffusivity=horizontal_diffusivity)
+    options.use_limiter_for_tracers = True
+    options.horizontal_viscosity_scale = horizontal_diffusivity
+    options.swe_timestepper_type = 'SSPRK33'
+    options.tracer_timestepper_type = 'SSPRK33'
+    solverobj.create_equations()
+    mu = float(horizontal_diffusivity)
+    x0 = lx/2.0
+
+    def tracer_expr(t):
+        return lambda x, y: -erf((x - x0)/np.sqrt(4*mu*t))
+    elev_init = Function(solverobj.function_spaces.H_2d, name='elev init')
+    solverobj.assign_initial_conditions(elev=elev_init, tracer=tracer_expr(t_init))
+    ti = solverobj.timestepper.timesteppers.tracer_2d
+    t = t_init
+    while t < t_end - 1e-8:
+        ti.advance(t)                      # the tracer stepper alone: no limiter in this loop (as in the reference)
+        t += solverobj.dt
+    T = solverobj.fields.tracer_2d.cell_node_values()
+    # L2 error (degree-4 cell quadrature) / sqrt(area)
+    from thetis_amd.function import triangle_quadrature
+    xy = mesh2d.cell_xy()
+    err2 = 0.0
+    for bary, w in zip(*triangle_quadrature()):
+        xq = xy[:, :, 0] @ bary
+        err2 += np.sum(w*mesh2d.cell_areas()*((T @ bary) - tracer_expr(t)(xq, 0.0))**2)
+    return math.sqrt(err2)/math.sqrt(lx*ly)
+
+
+def test_horizontal_diffusion_convergence_through_solver(hip_lib):
+    """The reference's test_horizontal_diffusion[SSPRK33-1-1.8] on the device path."""
+    from scipy import stats
+    refs = [1, 2, 3]
+    errs = [_run_h_diffusion_solver(r) for r in refs]
+    slope = stats.linregress(np.log10(np.array(refs, dtype=float)**-1), np.log10(errs)).slope
+    assert slope > 1.8, (errs, slope)
+
+
+def test_decaying_shear_flow_through_solver(hip_lib):
+    """options.horizontal_viscosity through FlowSolver2d: u = sin(k y) e^{-nu k^2 t} (linear equations, periodic box);
+    same scenario as tests/test_oracle_sipg.py::test_decaying_shear_flow_with_viscosity."""
+    import math
+    from thetis_amd import Constant, Function, PeriodicRectangleMesh, get_functionspace, solver2d
+    errs = []
+    for n in (8, 16):
+        lx = ly = 1000.0
+        nu = 20.0
+        mesh2d = PeriodicRectangleMesh(n, n, lx, ly, direction='both')
+        bath = Function(get_functionspace(mesh2d, 'CG', 1), name='Bathymetry').assign(10.0)
+        so = solver2d.FlowSolver2d(mesh2d, bath)
+        o = so.options
+        o.use_nonlinear_equations = False
+        o.horizontal_viscosity = Constant(nu)
+        o.swe_timestepper_type = 'SSPRK33'
+        o.swe_timestepper_options.use_automatic_timestep = False
+        k = 2*math.pi/ly
+        t_end = 0.1/(nu*k*k)
+        dt = min(0.02*(lx/n)**2/nu, 0.05*(lx/n)/math.sqrt(9.81*10.0))
+        nsteps = int(math.ceil(t_end/dt))
+        o.timestep = t_end/nsteps
+        o.simulation_end_time = t_end
+        o.simulation_export_time = t_end
+        o.no_exports = True
+        so.assign_initial_conditions(uv=lambda x, y: (np.sin(k*y), 0.0*x))
+        so.iterate()
+        uv = so.fields.uv_2d.cell_node_values()
+        xy = mesh2d.cell_xy()
+        # the initial condition is L2-projected (not interpolated): compare with the projected exact solution's decay
+        exact = np.sin(k*xy[:, :, 1])*math.exp(-nu*k*k*t_end)
+        errs.append(np.sqrt(np.mean((uv[:, :, 0] - exact)**2)))
+        assert abs(so.simulation_time - t_end) < 1e-9*t_end
+    assert errs[0] < 0.05
+    assert math.log2(errs[0]/errs[1]) > 1.7, errs

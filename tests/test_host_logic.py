@@ -118,3 +118,23 @@ def test_automatic_time_step_formula():
     s.options.timestep = 2.0
     s.set_time_step()
     assert s.dt == 2.0
+
+
+def test_viscosity_and_diffusivity_configuration_checks():
+    """Unsupported SIPG configurations raise instead of silently dropping the term."""
+    from thetis_amd import Constant, Function, RectangleMesh, get_functionspace
+    from thetis_amd.options import ModelOptions2d
+    from thetis_amd.shallowwater_eq import DepthExpression, ShallowWaterEquations
+    mesh = RectangleMesh(4, 3, 10.0, 10.0)
+    bath = Function(get_functionspace(mesh, 'CG', 1)).assign(5.0)
+    opts = ModelOptions2d()
+    eq = ShallowWaterEquations(get_functionspace(mesh, 'DG', 1), DepthExpression(bath), opts)
+    eq.check_fields({'viscosity_h': Constant(1.0)})
+    eq.check_fields({'viscosity_h': Function(get_functionspace(mesh, 'CG', 1)).assign(2.0)})
+    with pytest.raises(NotImplementedError, match='continuous'):
+        eq.check_fields({'viscosity_h': Function(get_functionspace(mesh, 'DG', 1)).assign(2.0)})
+    qmesh = RectangleMesh(4, 3, 10.0, 10.0, quadrilateral=True)
+    qbath = Function(get_functionspace(qmesh, 'CG', 1)).assign(5.0)
+    qeq = ShallowWaterEquations(get_functionspace(qmesh, 'DG', 1), DepthExpression(qbath), opts)
+    with pytest.raises(NotImplementedError, match='triangles'):
+        qeq.check_fields({'viscosity_h': Constant(1.0)})

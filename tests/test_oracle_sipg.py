@@ -1,6 +1,6 @@
 """CPU: the oracle's SIPG terms (HorizontalViscosityTerm shallowwater_eq.py:554-616, tracer HorizontalDiffusionTerm
 tracer_eq_2d.py:226-278) - structural properties of the symmetric interior penalty forms and the reference's own
-known-answer test test/tracerEq/test_h-diffusion_mes_2d.py (erf profile, SSPRK33, limiter on, rate > 1.8)."""
+known-answer test test/tracerEq/test_h-diffusion_mes_2d.py (erf profile, SSPRK33, rate > 1.8)."""
 import math
 
 import numpy as np
@@ -91,7 +91,7 @@ def test_prescribed_diffusive_flux_boundary():
 
 
 def _run_h_diffusion(refinement):
-    """test_h-diffusion_mes_2d.py:9-103 with the oracle: tracer-only SSPRK33 steps + limiter, zero velocity."""
+    """test_h-diffusion_mes_2d.py:9-103 with the oracle: tracer-only SSPRK33 steps, zero velocity."""
     lx, ly = 20.0e3, 5.0e3/refinement
     depth, mu = 30.0, 1.0e3
     nx = 8*refinement + 1
@@ -113,8 +113,7 @@ def _run_h_diffusion(refinement):
     n = int(math.ceil((t_end - t)/dt - 1e-9))
     dt = (t_end - t)/n
     for _ in range(n):
-        T = orc.tracer_ssprk33_step(T, uv, eta, dt, diffusivity=mu)
-        T = orc.limit(T)
+        T = orc.tracer_ssprk33_step(T, uv, eta, dt, diffusivity=mu)      # ti.advance(t): no limiter in this loop
     # L2 error against the analytical profile (degree-4 cell quadrature), normalised as in the reference
     err2 = 0.0
     for bary, _, wA in orc.cell_quad:

@@ -12,6 +12,12 @@ from .timeintegrator import TimeIntegratorBase
 __all__ = ['DeviceTracerSSPRK33', 'GeneralCoupledTimeIntegrator2D']
 
 
+class _AttrDict(dict):
+    def __init__(self, *args, **kwargs):
+        super(_AttrDict, self).__init__(*args, **kwargs)
+        self.__dict__ = self
+
+
 def _cval(v):
     return None if v is None else float(v)
 
@@ -34,6 +40,11 @@ class DeviceTracerSSPRK33(object):
         src = fields.get('source-{:}'.format(equation.label))
         if src is not None:
             self.device.tracer_set_source(self.tid, swe_stepper._nodal(src))
+        mu = fields.get('diffusivity_h-{:}'.format(equation.label))
+        self.diffusive = mu is not None
+        if self.diffusive:                      # HorizontalDiffusionTerm, tracer_eq_2d.py:226-278
+            self.device.tracer_set_diffusivity(self.tid, swe_stepper._vertex_coefficient(mu),
+                                               float(equation.options.sipg_factor_tracer))
         self._push_bcs()
 
     def _push_bcs(self):
@@ -41,6 +52,13 @@ class DeviceTracerSSPRK33(object):
             funcs = self.bnd_conditions.get(marker)
             v = None if funcs is None else funcs.get('value')
             self.device.tracer_set_bc(self.tid, marker, _cval(v))
+            if self.diffusive:                  # boundary term of the diffusion operator, tracer_eq_2d.py:264-277
+                if funcs is None:
+                    self.device.tracer_set_diffusion_bc(self.tid, marker, 0)
+                elif 'diff_flux' in funcs:
+                    self.device.tracer_set_diffusion_bc(self.tid, marker, 1, _cval(funcs['diff_flux']))
+                else:
+                    self.device.tracer_set_diffusion_bc(self.tid, marker, 2)
 
     def _pull(self):
         if self._device_ahead:
@@ -80,7 +98,7 @@ class GeneralCoupledTimeIntegrator2D(TimeIntegratorBase):
         self.solver = solver
         self.options = solver.options
         self.fields = solver.fields
-        self.timesteppers = {'swe2d': swe_stepper}
+        self.timesteppers = _AttrDict(swe2d=swe_stepper)      # AttrDict in the reference (coupled_timeintegrator_2d.py:33)
         self.timesteppers.update(tracer_steppers)
         self.swe = swe_stepper
         self.tracers = tracer_steppers

@@ -133,6 +133,21 @@ class ERKGenericShuOsher(TimeIntegrator):
                               ('wind_stress', _lib.FIELD_WIND_STRESS, True)):
             v = f.get(key)
             dev.set_field(fid, None if v is None else self._nodal(v, vector=vec))
+        nu = f.get('viscosity_h')
+        if nu is not None:                       # HorizontalViscosityTerm, shallowwater_eq.py:554-616
+            opts = self.equation.options
+            dev.set_viscosity(self._vertex_coefficient(nu), sipg_factor=float(_const_value(opts.sipg_factor)),
+                              use_grad_div_viscosity_term=opts.use_grad_div_viscosity_term,
+                              use_grad_depth_viscosity_term=opts.use_grad_depth_viscosity_term)
+
+    @staticmethod
+    def _vertex_coefficient(value):
+        """Constant -> float;  continuous P1 Function -> per-vertex array (the SIPG kernels take either)."""
+        if isinstance(value, Function):
+            if value.function_space().family != 'CG':
+                raise NotImplementedError('diffusion coefficients must be Constants or continuous (CG-P1) Functions')
+            return np.ascontiguousarray(value.dat.data_ro, dtype=np.float64)
+        return float(_const_value(value))
 
     def _push_bcs(self):
         mesh = self.equation.mesh

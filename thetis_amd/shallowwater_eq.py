@@ -9,8 +9,10 @@ configuration is one the kernel implements:
   ExternalPressureGradientTerm :335   HUDivTerm :396   HorizontalAdvectionTerm :453 (+ Lax-Friedrichs)
   CoriolisTerm :619   AtmosphericPressureTerm :652   QuadraticDragTerm :666 (constant C_D or Manning)
   LinearDragTerm :728   MomentumSourceTerm :794   ContinuitySourceTerm :814   WindStressTerm :637   BoundaryDragTerm :704
+  HorizontalViscosityTerm :513 (SIPG; separate pass kernel csrc/swe2d_sipg.h, triangles, Constant or CG-P1 viscosity)
   boundary conditions 'elev' / 'uv' / 'un' / 'flux' with constant values (get_bnd_functions :232-272)
 """
+from .function import Function
 from .options import Constant
 
 __all__ = ['ShallowWaterEquations', 'DepthExpression', 'g_grav', 'rho_0', 'physical_constants']
@@ -35,7 +37,8 @@ class DepthExpression(object):
 class ShallowWaterEquations(object):
     SUPPORTED_TERMS = ('ExternalPressureGradientTerm', 'HorizontalAdvectionTerm', 'CoriolisTerm',
                        'AtmosphericPressureTerm', 'QuadraticDragTerm', 'LinearDragTerm', 'MomentumSourceTerm',
-                       'HUDivTerm', 'ContinuitySourceTerm')
+                       'HUDivTerm', 'ContinuitySourceTerm', 'WindStressTerm', 'BoundaryDragTerm',
+                       'HorizontalViscosityTerm')
 
     def __init__(self, function_space, depth, options, tidal_farms=None):
         self.function_space = function_space
@@ -56,8 +59,15 @@ class ShallowWaterEquations(object):
 
     def check_fields(self, fields):
         """Raise for coefficients whose terms the kernel does not implement (never silently ignore physics)."""
-        if fields.get('viscosity_h') is not None:
-            raise NotImplementedError('HorizontalViscosityTerm (SIPG) is not implemented on the device path yet')
+        nu = fields.get('viscosity_h')
+        if nu is not None:
+            # HorizontalViscosityTerm (SIPG, shallowwater_eq.py:554-616): swe_sipg_kernel<2>, triangles only
+            if self.mesh.cells.shape[1] != 3:
+                raise NotImplementedError('HorizontalViscosityTerm is implemented for triangles only')
+            if self.depth.use_wetting_and_drying:
+                raise NotImplementedError('HorizontalViscosityTerm with wetting and drying is not implemented')
+            if isinstance(nu, Function) and nu.function_space().family != 'CG':
+                raise NotImplementedError('horizontal_viscosity must be a Constant or a continuous (CG-P1) Function')
         if fields.get('nikuradse_bed_roughness') is not None:
             raise NotImplementedError('Nikuradse bed roughness is not implemented on the device path yet')
         if fields.get('quadratic_drag_coefficient') is not None and fields.get('manning_drag_coefficient') is not None:

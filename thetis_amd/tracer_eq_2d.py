@@ -3,8 +3,9 @@ Descriptor of the 2D tracer equation for the device path (thetis/tracer_eq_2d.py
 
 Implemented by ``swe_tracer_stage_kernel`` (csrc/swe2d_kernels.h): non-conservative ``HorizontalAdvectionTerm``
 (:124-193; upwind DG, optional Lax-Friedrichs) and ``SourceTerm`` (:281-298), boundaries without a condition or with a
-constant ``'value'``.  Everything else (SIPG diffusion :196-278, conservative form :325-445, SUPG :490-501, CG tracers,
-velocity-type boundary keys) raises instead of silently changing the physics.
+constant ``'value'``; ``HorizontalDiffusionTerm`` (SIPG, :196-278) by the pass kernel ``swe_sipg_kernel<1>``
+(csrc/swe2d_sipg.h; triangles, Constant or CG-P1 diffusivity, ``'diff_flux'`` boundaries).  Everything else (conservative
+form :325-445, SUPG :490-501, CG tracers, velocity-type boundary keys) raises instead of silently changing the physics.
 """
 from .options import Constant
 
@@ -23,8 +24,8 @@ class TracerEquation2D(object):
             raise NotImplementedError("tracer_element_family='cg' is not on the device path")
         if topts.use_conservative_form or options.use_tracer_conservative_form:
             raise NotImplementedError('the conservative tracer form is not on the device path yet')
-        if topts.diffusivity is not None:
-            raise NotImplementedError('horizontal tracer diffusion (SIPG) is not on the device path yet')
+        if topts.diffusivity is not None and self.mesh.cells.shape[1] != 3:
+            raise NotImplementedError('horizontal tracer diffusion (SIPG) is implemented for triangles only')
         if options.use_supg_tracer:
             raise NotImplementedError('SUPG stabilisation applies to CG tracers only')
 
@@ -32,7 +33,8 @@ class TracerEquation2D(object):
     def check_bnd_conditions(bnd_conditions):
         for marker, funcs in (bnd_conditions or {}).items():
             for key, v in funcs.items():
-                if key not in ('value', 'elev'):
-                    raise NotImplementedError('tracer boundary key {!r} is not on the device path (only "value")'.format(key))
-                if key == 'value' and not isinstance(v, (int, float, Constant)):
+                if key not in ('value', 'elev', 'diff_flux'):
+                    raise NotImplementedError('tracer boundary key {!r} is not on the device path '
+                                              '(only "value" and "diff_flux")'.format(key))
+                if key in ('value', 'diff_flux') and not isinstance(v, (int, float, Constant)):
                     raise NotImplementedError('tracer boundary values must be constants on the device path')
