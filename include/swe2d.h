@@ -191,6 +191,9 @@ int  swe2d_tracer_get_state(swe2d_handle *h, int tracer_id, double *nodal);
  * c (u.n) phi (tracer_eq_2d.py:177-191).  Velocity-type keys are not supported. */
 int  swe2d_tracer_set_bc(swe2d_handle *h, int tracer_id, int marker, int has_value, double value);
 int  swe2d_tracer_set_source(swe2d_handle *h, int tracer_id, const double *nodal);   /* SourceTerm tracer_eq_2d.py:281-298 */
+/* options.tracer[label].use_conservative_form (options.py:543): the tracer field is the depth-integrated q = H*T and the
+ * stage kernels evaluate ConservativeHorizontalAdvectionTerm / ConservativeSourceTerm (tracer_eq_2d.py:325-437) */
+int  swe2d_tracer_set_conservative(swe2d_handle *h, int tracer_id, int use_conservative_form);
 /* SIPG horizontal diffusion: HorizontalDiffusionTerm (tracer_eq_2d.py:226-278), fields['diffusivity_h-<label>'] =
  * options.tracer[label].diffusivity (solver2d.py:588); constant or per-vertex P1; sipg_factor_tracer options.py:732 */
 int  swe2d_tracer_set_diffusivity(swe2d_handle *h, int tracer_id, int enable, const double *mu_vertex, double mu_const,

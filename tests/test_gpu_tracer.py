@@ -52,6 +52,51 @@ def test_tracer_tendency_and_step_match_oracle(hip_lib, case):
     dev.close()
 
 
+@pytest.mark.parametrize('cells', ['triangles', 'quadrilaterals'])
+@pytest.mark.parametrize('case', ['default', 'lf_source', 'value_bc'])
+def test_conservative_tracer_form_matches_oracle(hip_lib, case, cells):
+    """options.tracer[label].use_conservative_form: ConservativeHorizontalAdvectionTerm / ConservativeSourceTerm
+    (tracer_eq_2d.py:325-437); the field is q = H*T."""
+    from helpers import make_oracle_generic, quad_case
+    if cells == 'triangles':
+        mesh, bath, uv, eta = channel_case(seed=16)
+        orc = make_oracle(mesh, bath)
+    else:
+        mesh, bath, uv, eta = quad_case(skew=0.3, seed=12)
+        orc = make_oracle_generic(mesh, bath)
+    k = mesh.cells.shape[1]
+    rng = np.random.default_rng(13)
+    q = 20.0 + rng.normal(size=(mesh.num_cells, k))
+    src = 1e-3*rng.normal(size=q.shape)
+    dt = 3.0
+    dev = _dev(mesh, bath, dt, boundary_len=mesh.boundary_len)
+    tid = dev.add_tracer()
+    dev.tracer_set_conservative(tid, True)
+    kw = dict(conservative=True)
+    if case == 'lf_source':
+        kw.update(use_lax_friedrichs_tracer=True, lax_friedrichs_tracer_scaling_factor=0.7,
+                  tracer_advective_velocity_factor=0.9, source=src)
+        dev.tracer_set_options(True, 0.7, 0.9)
+        dev.tracer_set_source(tid, src)
+    if case == 'value_bc':
+        kw['bnd_conditions'] = {1: {'value': 2.0}, 3: {'value': -1.0}}
+        dev.tracer_set_bc(tid, 1, 2.0)
+        dev.tracer_set_bc(tid, 3, -1.0)
+    dev.set_state(uv, eta)
+    dev.tracer_set_state(tid, q)
+    k_o = orc.tracer_tendency(q, uv, eta, dt, **kw)
+    kw_nc = dict(kw, conservative=False)
+    assert rel_linf(orc.tracer_tendency(q, uv, eta, dt, **kw_nc), k_o) > 1e-3      # the two forms differ visibly
+    assert rel_linf(dev.tracer_tendency(tid), k_o) < TOL
+    for s in range(3):
+        dev.tracer_solve_stage(tid, s)
+    assert rel_linf(dev.tracer_get_state(tid), orc.tracer_ssprk33_step(q, uv, eta, dt, **kw)) < TOL
+    dev.tracer_set_conservative(tid, False)
+    dev.tracer_set_state(tid, q)
+    assert rel_linf(dev.tracer_tendency(tid), orc.tracer_tendency(q, uv, eta, dt, **kw_nc)) < TOL
+    dev.close()
+
+
 def test_limiter_matches_oracle(hip_lib):
     # device code contracts mean + alpha*(c - mean) into an FMA: equal to the oracle to round-off, not bitwise
     mesh, bath, uv, eta = channel_case(seed=4)
@@ -118,7 +163,7 @@ def test_coupled_steps_match_cpu_restatement(hip_lib, ref_so):
     dev.close()
 
 
-def _consistency_solver(constant_c):
+def _consistency_solver(constant_c, conservative=False, limiter=None):
     # test/tracerEq/test_consistency_2d.py:17-110 with timestepper_type='SSPRK33'
     t_cycle, depth = 2000.0, 50.0
     lx = math.sqrt(9.81*depth)*t_cycle
@@ -129,9 +174,9 @@ def _consistency_solver(constant_c):
     bathymetry_2d.interpolate(lambda x, y: depth + depth/10.*np.sin(x/lx*np.pi))
     solver_obj = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
     options = solver_obj.options
-    options.use_limiter_for_tracers = not constant_c
+    options.use_limiter_for_tracers = (not constant_c) if limiter is None else limiter
     options.use_nonlinear_equations = True
-    options.add_tracer_2d('tracer_2d', 'Depth averaged tracer', 'Tracer2d', use_conservative_form=False)
+    options.add_tracer_2d('tracer_2d', 'Depth averaged tracer', 'Tracer2d', use_conservative_form=conservative)
     options.simulation_export_time = round(float(t_cycle/8))
     options.simulation_end_time = 2.5*t_cycle
     options.horizontal_velocity_scale = Constant(1.0)
@@ -172,3 +217,21 @@ def test_reference_tracer_consistency_scenario(hip_lib, constant_c):
     assert max(abs(undershoot), abs(overshoot)) < 1e-11
     if constant_c:
         assert np.abs(solver_obj.fields.tracer_2d.dat.data_ro - 4.5).max() < 1e-11
+
+
+def test_reference_conservative_tracer_scenario(hip_lib):
+    """test_consistency_2d.py::test_nonconst_tracer_conservative[SSPRK33]: no limiter, depth-integrated tracer conserved."""
+    solver_obj = _consistency_solver(False, conservative=True, limiter=False)
+    t_end = solver_obj.options.simulation_end_time
+    it = solver_obj.create_iterator()
+    while True:
+        try:
+            t = next(it)
+        except StopIteration as e:
+            t = e.value
+            break
+    assert t >= t_end - 1e-5
+    vol2d, vol2d_rerr = solver_obj.callbacks['export']['volume2d']()
+    assert vol2d_rerr < 1e-10, '2D volume is not conserved'
+    tracer_int, tracer_int_rerr = solver_obj.callbacks['export']['tracer_2d mass']()
+    assert abs(tracer_int_rerr) < 1.2e-4, 'tracer is not conserved'

@@ -78,3 +78,35 @@ def test_tracer_numpy_and_c_restatements_agree(ref_so, case):
     rt = _tracer(ref, mesh, **kw_c)
     assert rel_linf(rt.tendency(T, uv, 3.0), orc.tracer_tendency(T, uv, eta, 3.0, **kw_np)) < 1e-13
     assert rel_linf(rt.step(T, uv, 3.0), orc.tracer_ssprk33_step(T, uv, eta, 3.0, **kw_np)) < 1e-13
+
+
+def test_conservative_form_conserves_the_depth_integrated_tracer_on_a_periodic_mesh():
+    """ConservativeHorizontalAdvectionTerm (tracer_eq_2d.py:341-395): with test function 1 the cell term vanishes and the
+    upwind fluxes cancel pairwise, so int q dx is constant to round-off when there is no boundary."""
+    from thetis_amd.mesh import PeriodicRectangleMesh
+    mesh = PeriodicRectangleMesh(7, 5, 70.0, 40.0, direction='both')
+    rng = np.random.default_rng(4)
+    bath = 10.0 + rng.uniform(size=mesh.num_vertices)
+    orc = make_oracle(mesh, bath)
+    n = mesh.num_cells
+    uv = rng.normal(size=(n, 3, 2))
+    eta = 0.1*rng.normal(size=(n, 3))
+    q = 5.0 + rng.normal(size=(n, 3))
+    for lf in (False, True):
+        r = orc.tracer_residual(q, uv, eta, conservative=True, use_lax_friedrichs_tracer=lf)
+        assert abs(r.sum()) < 1e-12*np.abs(r).sum()
+    # the non-conservative form does not have this property for a divergent velocity field
+    r = orc.tracer_residual(q, uv, eta)
+    assert abs(r.sum()) > 1e-6*np.abs(r).sum()
+
+
+def test_conservative_and_nonconservative_forms_agree_for_divergence_free_constant_velocity():
+    """u = const: div u = 0 and both sides carry the same velocity, so the two weak forms coincide."""
+    mesh, bath, _, eta = channel_case(seed=3)
+    orc = make_oracle(mesh, bath)
+    n = mesh.num_cells
+    uv = np.broadcast_to(np.array([0.7, -0.3]), (n, 3, 2)).copy()
+    T = np.random.default_rng(1).normal(size=(n, 3))
+    r0 = orc.tracer_residual(T, uv, eta, bnd_conditions={m: {'value': 1.0} for m in (1, 2, 3, 4)})
+    r1 = orc.tracer_residual(T, uv, eta, bnd_conditions={m: {'value': 1.0} for m in (1, 2, 3, 4)}, conservative=True)
+    assert np.abs(r0 - r1).max() < 1e-12*np.abs(r0).max()

@@ -68,6 +68,7 @@ SYMBOLS = {
     'swe2d_tracer_get_state': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_tracer_set_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
     'swe2d_tracer_set_source': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
+    'swe2d_tracer_set_conservative': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int]),
     'swe2d_tracer_set_diffusivity': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_double, ctypes.c_double]),
     'swe2d_tracer_set_diffusion_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
     'swe2d_tracer_solve_stage': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int]),

@@ -12,7 +12,7 @@ import numpy
 from .log import print_output
 
 __all__ = ['CallbackManager', 'DiagnosticCallback', 'ScalarConservationCallback', 'VolumeConservation2DCallback',
-           'TracerMassConservation2DCallback', 'MinMaxConservationCallback', 'TracerOvershootCallBack']
+           'TracerMassConservation2DCallback', 'ConservativeTracerMassConservation2DCallback', 'MinMaxConservationCallback', 'TracerOvershootCallBack']
 
 
 class CallbackManager(defaultdict):
@@ -105,6 +105,20 @@ class TracerMassConservation2DCallback(ScalarConservationCallback):
             ts._sync_to_device()
             return float(ts.device.tracer_diagnostics(ts.tid)[0])
         super(TracerMassConservation2DCallback, self).__init__(mass, solver_obj, **kwargs)
+
+
+class ConservativeTracerMassConservation2DCallback(ScalarConservationCallback):
+    """Conservative (depth-integrated) tracer: mass = int q dx (callback.py:392-412), reduced on the device."""
+    name = 'tracer mass'
+
+    def __init__(self, tracer_name, solver_obj, **kwargs):
+        self.name = tracer_name + ' mass'
+
+        def mass():
+            ts = solver_obj.timestepper.tracers[tracer_name]
+            ts._sync_to_device()
+            return float(ts.device.tracer_diagnostics(ts.tid)[1])
+        super(ConservativeTracerMassConservation2DCallback, self).__init__(mass, solver_obj, **kwargs)
 
 
 class MinMaxConservationCallback(DiagnosticCallback):

@@ -40,6 +40,8 @@ class DeviceTracerSSPRK33(object):
         src = fields.get('source-{:}'.format(equation.label))
         if src is not None:
             self.device.tracer_set_source(self.tid, swe_stepper._nodal(src))
+        if getattr(equation, 'conservative', False):
+            self.device.tracer_set_conservative(self.tid, True)
         mu = fields.get('diffusivity_h-{:}'.format(equation.label))
         self.diffusive = mu is not None
         if self.diffusive:                      # HorizontalDiffusionTerm, tracer_eq_2d.py:226-278

@@ -55,6 +55,7 @@ struct Handle {
     struct Tracer {
         double *buf[3] = {nullptr, nullptr, nullptr};   // A (T0 / result), B, C: 3 planes each
         double *source = nullptr;
+        bool conservative = false;                      // options.tracer[label].use_conservative_form
         int bc_has_value[SWE_MAX_MARKERS];
         double bc_value[SWE_MAX_MARKERS];
         bool diff = false;                              // SIPG horizontal diffusion
@@ -834,6 +835,9 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     a.vel_factor = h->tracer_vel_factor;
     a.lf_factor = h->tracer_lf_factor;
     a.source = t.source;
+    a.conservative = t.conservative ? 1 : 0;
+    a.depth_mode = h->wd ? 2 : (h->par.use_nonlinear_equations ? 1 : 0);
+    a.vh = h->vh; a.valpha = h->valpha;
     for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_has_value[m] = t.bc_has_value[m]; a.bc_value[m] = t.bc_value[m]; }
     tracer_kernel_t kern = (h->npc == 4) ? pick_tracer_kernel_quad(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr)
                                          : pick_tracer_kernel(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr);
@@ -1044,6 +1048,15 @@ int swe2d_tracer_set_source(swe2d_handle *hh, int id, const double *nodal)
                        h->stage_eta, t.source, h->stride, h->n_cells, 1, h->npc);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWE2D_OK;
+}
+
+int swe2d_tracer_set_conservative(swe2d_handle *hh, int id, int use_conservative_form)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    h->tracers[id].conservative = use_conservative_form != 0;
     return SWE2D_OK;
 }
 

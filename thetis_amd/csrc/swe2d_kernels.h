@@ -739,6 +739,9 @@ struct SweTracerArgs {
     double vel_factor;     // tracer_advective_velocity_factor
     double lf_factor;      // lax_friedrichs_tracer_scaling_factor
     const double *source;  // 3 planes or null
+    int conservative;      // ConservativeHorizontalAdvectionTerm / ConservativeSourceTerm (tracer_eq_2d.py:325-437)
+    int depth_mode;        // total depth of the conservative source term: 0 = h, 1 = h + eta, 2 = wetting-drying D
+    const double *vh, *valpha;
     int bc_has_value[SWE_MAX_MARKERS];
     double bc_value[SWE_MAX_MARKERS];
 };
@@ -812,8 +815,9 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
                             + gys[0]*v[0] + gys[1]*v[1] + gys[2]*v[2])*(1.0/12.0);
         const double Suc = swe_int2(u, c)*(1.0/12.0), Svc = swe_int2(v, c)*(1.0/12.0);
         const double cs = c[0] + c[1] + c[2];
+        // conservative form: +grad(phi).u q only                                      tracer_eq_2d.py:358-359
 #pragma unroll
-        for (int i = 0; i < 3; i++) b[i] = D12*(cs + c[i]) + gxs[i]*Suc + gys[i]*Svc;
+        for (int i = 0; i < 3; i++) b[i] = (p.conservative ? 0.0 : D12*(cs + c[i])) + gxs[i]*Suc + gys[i]*Svc;
     }
     if (SRC) {                                                                         // tracer_eq_2d.py:293-297
         const double A = 0.5*twoA;
@@ -821,8 +825,22 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
 #pragma unroll
         for (int i = 0; i < 3; i++) s[i] = p.source[(size_t)i*S + k];
         const double ss = s[0] + s[1] + s[2];
+        if (p.conservative) {                                                          // H*source, :434-436
+            double H[3];
 #pragma unroll
-        for (int i = 0; i < 3; i++) b[i] += A*(1.0/12.0)*(ss + s[i]);
+            for (int i = 0; i < 3; i++) {
+                const double hh = p.vh[vid[i]];
+                const double ee = p.uv[(size_t)(6 + i)*S + k];
+                H[i] = p.depth_mode == 2 ? swe_wd_depth(hh + ee, p.valpha[vid[i]]) : (p.depth_mode == 1 ? hh + ee : hh);
+            }
+            const double Hs = H[0] + H[1] + H[2], Hss = H[0]*s[0] + H[1]*s[1] + H[2]*s[2];
+#pragma unroll
+            for (int i = 0; i < 3; i++)      // 60/A int phi_i H s = Hs*ss + sum H_a s_a + H_i*ss + s_i*Hs + 2 H_i s_i
+                b[i] += A*(1.0/60.0)*(Hs*ss + Hss + H[i]*ss + s[i]*Hs + 2.0*H[i]*s[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; i++) b[i] += A*(1.0/12.0)*(ss + s[i]);
+        }
     }
 #pragma unroll
     for (int f = 0; f < 3; f++) {
@@ -840,6 +858,10 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
                 const double uavn = 0.5*((uq + un)*nxs + (vq + vn)*nys);                   // :163-165
                 const double cup = uavn > 0.0 ? cq : (uavn < 0.0 ? cn : 0.5*(cq + cn));   // :166-168
                 fq = cup*unown;
+                if (p.conservative) {                           // upwind FLUX q u (both from the upwind side), :366-372
+                    const double fn = cn*(un*nxs + vn*nys);
+                    fq = uavn > 0.0 ? cq*unown : (uavn < 0.0 ? fn : 0.5*(cq*unown + fn));
+                }
                 if (LF) fq += 0.5*fabs(uavn)*p.lf_factor*(cq - cn);                       // :173-175
             } else {
                 const int marker = -nb[f];
@@ -1324,8 +1346,19 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
                 D += gx[i]*u[i] + gy[i]*v[i];
                 if (SRC) sq += phi[i]*p.source[(size_t)i*S + k];
             }
+            if (SRC && p.conservative) {                                               // H*source, :434-436
+                double Hq = 0.0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) b[i] += 0.25*((phi[i]*D + uq*gx[i] + vq*gy[i])*cq + A*sq*phi[i]);
+                for (int i = 0; i < 4; i++) {
+                    const double hh = p.vh[vid[i]];
+                    const double ee = p.uv[(size_t)(8 + i)*S + k];
+                    Hq += phi[i]*(p.depth_mode == 2 ? swe_wd_depth(hh + ee, p.valpha[vid[i]]) : (p.depth_mode == 1 ? hh + ee : hh));
+                }
+                sq *= Hq;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                b[i] += 0.25*(((p.conservative ? 0.0 : phi[i]*D) + uq*gx[i] + vq*gy[i])*cq + A*sq*phi[i]);
         }
     }
 #pragma unroll
@@ -1344,6 +1377,10 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
                 const double uavn = 0.5*((uq + un)*nxs + (vq + vn)*nys);
                 const double cup = uavn > 0.0 ? cq : (uavn < 0.0 ? cn : 0.5*(cq + cn));
                 fq = cup*unown;
+                if (p.conservative) {
+                    const double fn = cn*(un*nxs + vn*nys);
+                    fq = uavn > 0.0 ? cq*unown : (uavn < 0.0 ? fn : 0.5*(cq*unown + fn));
+                }
                 if (LF) fq += 0.5*fabs(uavn)*p.lf_factor*(cq - cn);
             } else {
                 const int marker = -nb[f];

@@ -244,6 +244,10 @@ class Swe2dDevice(object):
         self._ck(self.lib.swe2d_set_viscosity(self.h, 1, None if arr is None else _ptr(arr), const, float(sipg_factor),
                                               int(bool(use_grad_div_viscosity_term)), int(bool(use_grad_depth_viscosity_term))))
 
+    def tracer_set_conservative(self, tracer_id, use_conservative_form=True):
+        """The tracer field is the depth-integrated q = H*T (tracer_eq_2d.py:325-437)."""
+        self._ck(self.lib.swe2d_tracer_set_conservative(self.h, int(tracer_id), int(bool(use_conservative_form))))
+
     def tracer_set_diffusivity(self, tracer_id, mu, sipg_factor_tracer=1.0):
         """SIPG horizontal diffusion of a tracer (tracer_eq_2d.py:226-278); constant, per-vertex array or None (off)."""
         if mu is None:

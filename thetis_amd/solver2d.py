@@ -393,7 +393,9 @@ class FlowSolver2d(object):
             self.add_callback(c)
         if self.options.check_tracer_conservation:
             for label, tracer in self.options.tracer.items():
-                c = callback.TracerMassConservation2DCallback(label, self, export_to_hdf5=False, append_to_log=True)
+                cls = (callback.ConservativeTracerMassConservation2DCallback if tracer.use_conservative_form
+                       else callback.TracerMassConservation2DCallback)          # solver2d.py:1047-1059
+                c = cls(label, self, export_to_hdf5=False, append_to_log=True)
                 self.add_callback(c, eval_interval='export')
         if self.options.check_tracer_overshoot:
             for label in self.options.tracer:
