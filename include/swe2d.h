@@ -205,7 +205,14 @@ int  swe2d_tracer_set_diffusivity(swe2d_handle *h, int tracer_id, int enable, co
 #define SWE2D_DIFF_BC_UPWIND 2
 int  swe2d_tracer_set_diffusion_bc(swe2d_handle *h, int tracer_id, int marker, int kind, double diff_flux);
 int  swe2d_tracer_solve_stage(swe2d_handle *h, int tracer_id, int i_stage);          /* rungekutta.py:930-946 for the tracer */
-int  swe2d_tracer_tendency(swe2d_handle *h, int tracer_id, double *k_nodal);         /* parity hook */
+int  swe2d_tracer_tendency(swe2d_handle *h, int tracer_id, double *k_nodal);
+/* partitions (one handle per GPU): the tracer stage on a local cell range, the limiter on cells [0, cell_end) with means
+ * and vertex bounds taken over every local cell (the ghost layers must hold the neighbours' unlimited values), and the
+ * tracer's part of the halo exchange (same cell lists as swe2d_halo_setup, nodes_per_cell doubles per cell) */
+int  swe2d_tracer_solve_stage_cells(swe2d_handle *h, int tracer_id, int i_stage, int32_t cell_begin, int32_t cell_end);
+int  swe2d_tracer_limit_cells(swe2d_handle *h, int tracer_id, int32_t cell_end);
+int  swe2d_tracer_halo_pack(swe2d_handle *h, int tracer_id, int i_buffer, double *send_buf_dev);
+int  swe2d_tracer_halo_unpack(swe2d_handle *h, int tracer_id, int i_buffer, const double *recv_buf_dev);         /* parity hook */
 /* VertexBasedP1DGLimiter (thetis/limiter.py:48-198): topology of the mesh vertices (periodic meshes identify them);
  * optional - defaults to cell_vertices. */
 int  swe2d_limiter_setup(swe2d_handle *h, int32_t n_topo_vertices, const int32_t *cell_topo_vertices);

@@ -86,6 +86,116 @@ def cpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     dist.destroy_process_group()
 
 
+AL0 = [0.0, 0.75, 0.33333333333333337]
+ALI = [1.0, 0.25, 0.6666666666666666]
+BE = [1.0, 0.25, 0.6666666666666666]
+
+
+def tracer_initial(mesh):
+    xy = mesh.cell_xy()
+    rng = np.random.default_rng(77)
+    # a front (the limiter has work to do) plus noise
+    return 10.0*(xy[:, :, 0] > 0.4*xy[:, :, 0].max()) + rng.normal(size=xy.shape[:2])
+
+
+def coupled_step_reference(ref, rt, u, e, T, dt, ranges, n_limit, exchange=None):
+    """One coupled step (SWE, tracer with the updated velocity, limiter) written stage by stage on cell ranges; with
+    ranges = (n, n, n) and n_limit = n it is the plain global algorithm, with a partition's ranges it is the
+    distributed one.  Stale cells are poisoned with NaN so that a wrong range shows up."""
+    u0, e0 = u.copy(), e.copy()
+    cur_u, cur_e = u, e
+    for i in range(3):
+        end = ranges[i]
+        ku, ke = ref.tendency(cur_u, cur_e, dt)
+        new_u, new_e = np.full_like(cur_u, np.nan), np.full_like(cur_e, np.nan)
+        new_u[:end] = BE[i]*ku[:end] + AL0[i]*u0[:end] + ALI[i]*cur_u[:end]
+        new_e[:end] = BE[i]*ke[:end] + AL0[i]*e0[:end] + ALI[i]*cur_e[:end]
+        cur_u, cur_e = new_u, new_e
+    u, e = cur_u, cur_e
+    if exchange is not None:
+        exchange(u=u, e=e)
+    T0, cur = T.copy(), T
+    for i in range(3):
+        end = ranges[i]
+        k = rt.tendency(np.nan_to_num(cur), np.nan_to_num(u), dt)      # garbage in = garbage out beyond `end`, never used
+        new = np.full_like(cur, np.nan)
+        new[:end] = BE[i]*k[:end] + AL0[i]*T0[:end] + ALI[i]*cur[:end]
+        cur = new
+    T = cur
+    if exchange is not None:
+        exchange(T=T)
+    assert not np.isnan(T).any()
+    lim = rt.limit(T)
+    T = T.copy()
+    T[:n_limit] = lim[:n_limit]
+    return u, e, T
+
+
+def cpu_coupled_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
+    """Coupled SWE + tracer + vertex limiter on a 4-layer vertex-adjacent halo with the C restatement as compute."""
+    global CASE
+    CASE = case
+    import torch
+    from oracle.ref_lib import RefSWE, RefTracer
+    from thetis_amd.distributed import HaloExchanger
+    from thetis_amd.partition import build_partition, strip_owner
+    dist = _init(rank, world, port)
+    mesh, bath, uv, eta = _case()
+    owner = strip_owner(mesh, world, axis=axis)
+    part = build_partition(mesh, owner, rank, halo_depth=4, adjacency='vertex')
+    ref = RefSWE(part.cell_xy(), part.cell_nbr, part.cell_nbr_facet, bath[part.vertex_global][part.cells],
+                 boundary_len=part.boundary_len)
+    rt = RefTracer(ref, cell_topo_vertices=part.topo_vertex[part.cells])
+    g = part.local_to_global
+    u, e, T = uv[g].copy(), eta[g].copy(), tracer_initial(mesh)[g].copy()
+    k = part.cells.shape[1]
+    halo = HaloExchanger(part, torch.device('cpu'))
+    thalo = HaloExchanger(part, torch.device('cpu'), width=k)
+    sc, rc = part.send_cells, part.recv_cells
+
+    def exchange(u=None, e=None, T=None):
+        if T is None:
+            packed = np.concatenate([u[sc, :, 0], u[sc, :, 1], e[sc]], axis=1)
+            halo.send_buf[:packed.size] = torch.from_numpy(packed.reshape(-1))
+            halo.finish(halo.start())
+            r = halo.recv_buf[:3*k*len(rc)].numpy().reshape(-1, 3*k)
+            u[rc, :, 0], u[rc, :, 1], e[rc] = r[:, 0:k], r[:, k:2*k], r[:, 2*k:3*k]
+        else:
+            thalo.send_buf[:k*len(sc)] = torch.from_numpy(np.ascontiguousarray(T[sc]).reshape(-1))
+            thalo.finish(thalo.start())
+            T[rc] = thalo.recv_buf[:k*len(rc)].numpy().reshape(-1, k)
+    ranges = [part.stage_range(i) for i in range(3)]
+    for _ in range(n_steps):
+        u, e, T = coupled_step_reference(ref, rt, u, e, T, 2.0, ranges, part.layer_end(3), exchange)
+        assert not np.isnan(u).any() and not np.isnan(e).any()
+    no = part.n_owned
+    np.savez(os.path.join(out_dir, 'rank{:d}.npz'.format(rank)), ids=g[:no], uv=u[:no], eta=e[:no], T=T[:no])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gpu_coupled_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
+    """DistributedSwe2d with one tracer + limiter, two ranks sharing ONE GPU (gloo + host staging stands in for RCCL)."""
+    global CASE
+    CASE = case
+    from thetis_amd.distributed import DistributedSwe2d
+    from thetis_amd.partition import strip_owner
+    dist = _init(rank, world, port)
+    mesh, bath, uv, eta = _case()
+    owner = strip_owner(mesh, world, axis=axis)
+    solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, host_staged=True, n_tracers=1)
+    solver.set_state_global(uv, eta)
+    solver.set_tracer_global(0, tracer_initial(mesh))
+    solver.advance(n_steps, use_graph=False)
+    solver.synchronize()
+    ids, u, e = solver.get_state_owned()
+    _, T = solver.get_tracer_owned(0)
+    td = solver.tracer_diagnostics(0)
+    np.savez(os.path.join(out_dir, 'rank{:d}.npz'.format(rank)), ids=ids, uv=u, eta=e, T=T, td=td)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     global CASE
     CASE = case
@@ -137,5 +247,11 @@ def gather(out_dir, world, n_cells):
         uv[d['ids']] = d['uv']
         eta[d['ids']] = d['eta']
         extra.append(d)
+    if 'T' in extra[0]:
+        T = np.full((n_cells, k), np.nan)
+        for d in extra:
+            T[d['ids']] = d['T']
+        assert not np.isnan(T).any()
+        extra.append(T)
     assert not np.isnan(uv).any() and not np.isnan(eta).any(), 'some cell is owned by no rank'
     return uv, eta, extra

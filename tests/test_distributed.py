@@ -3,7 +3,8 @@ GPU: the real DistributedSwe2d with two ranks sharing the one GPU of the test bo
 import numpy as np
 import pytest
 
-from dist_worker import _case, cpu_worker, gather, gpu_worker, run_workers
+from dist_worker import (_case, coupled_step_reference, cpu_coupled_worker, cpu_worker, gather, gpu_coupled_worker,
+                         gpu_worker, run_workers, tracer_initial)
 from helpers import make_ref, rel_linf
 from thetis_amd.partition import build_partition, strip_owner
 
@@ -113,3 +114,74 @@ def test_gloo_unstructured_partition_equals_global(tmp_path, ref_so):
         dist_worker.CASE = 'channel'
     u_g, e_g = make_ref(mesh, bath).advance(uv, eta, 2.0, 2)
     assert np.array_equal(u_p, u_g) and np.array_equal(e_p, e_g)
+
+
+@pytest.mark.parametrize('world,axis', [(2, 0), (3, 1)])
+def test_vertex_halo_partition_invariants(world, axis):
+    """halo_depth=4, adjacency='vertex' (coupled runs with the vertex-based limiter): every cell around a vertex of a cell
+    in owned + layers 1-3 is local, and the facet-stencil invariants of the 3-layer ranges still hold."""
+    mesh, bath, uv, eta = _case()
+    owner = strip_owner(mesh, world, axis=axis)
+    parts = [build_partition(mesh, owner, r, halo_depth=4, adjacency='vertex') for r in range(world)]
+    v2c = [[] for _ in range(mesh.num_vertices)]
+    for c, vs in enumerate(mesh.cells):
+        for v in vs:
+            v2c[v].append(c)
+    for p in parts:
+        g = p.local_to_global
+        assert len(p.layer_sizes) == 4 and sum(p.layer_sizes) == p.n_ghost
+        local = set(g.tolist())
+        for k in range(p.layer_end(3)):
+            for v in mesh.cells[g[k]]:
+                assert set(v2c[v]) <= local
+        for i in range(3):
+            end = p.stage_range(i)
+            valid_in = p.layer_end(3) if i == 0 else p.stage_range(i - 1)
+            assert p.cell_nbr[:end].max() < valid_in
+        for q, (off, cnt) in p.recv.items():
+            soff, scnt = parts[q].send[p.rank]
+            assert scnt == cnt
+            assert np.array_equal(parts[q].local_to_global[parts[q].send_cells[soff:soff + scnt]], g[p.recv_cells[off:off + cnt]])
+        assert sorted(p.recv_cells) == list(range(p.n_owned, p.num_cells))
+
+
+@pytest.mark.parametrize('world,axis', [(2, 0), (3, 1)])
+def test_gloo_partitioned_coupled_step_equals_global(tmp_path, ref_so, world, axis):
+    """SWE + tracer + vertex limiter on partitions == the same algorithm on the whole mesh, bitwise."""
+    from oracle.ref_lib import RefTracer
+    mesh, bath, uv, eta = _case()
+    n_steps = 3
+    run_workers(cpu_coupled_worker, world, n_steps, str(tmp_path), axis=axis)
+    u_p, e_p, extra = gather(str(tmp_path), world, mesh.num_cells)
+    T_p = extra[-1]
+    ref = make_ref(mesh, bath)
+    rt = RefTracer(ref, cell_topo_vertices=mesh.topo_vertex[mesh.cells])
+    n = mesh.num_cells
+    u, e, T = uv.copy(), eta.copy(), tracer_initial(mesh)
+    for _ in range(n_steps):
+        u, e, T = coupled_step_reference(ref, rt, u, e, T, 2.0, (n, n, n), n)
+    assert np.array_equal(u_p, u) and np.array_equal(e_p, e) and np.array_equal(T_p, T)
+    # the limiter was active (otherwise the test would not see a wrong limiter halo)
+    rt_step = rt.step(tracer_initial(mesh), uv, 2.0)
+    assert np.abs(rt.limit(rt_step) - rt_step).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_two_ranks_coupled_on_one_gpu_match_single_device(tmp_path, hip_lib):
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = _case()
+    run_workers(gpu_coupled_worker, 2, 3, str(tmp_path), axis=0)
+    u_p, e_p, extra = gather(str(tmp_path), 2, mesh.num_cells)
+    T_p = extra[-1]
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    tid = dev.add_tracer()
+    dev.set_state(uv, eta)
+    dev.tracer_set_state(tid, tracer_initial(mesh))
+    dev.advance_coupled(3, tracer_only=False, use_limiter=True)
+    u_s, e_s = dev.get_state()
+    T_s = dev.tracer_get_state(tid)
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+    assert np.array_equal(T_p, T_s)                                  # deterministic kernels, exact halo data: bitwise
+    d = dev.tracer_diagnostics(tid)
+    assert np.allclose(extra[0]['td'][:2], d[:2], rtol=1e-13) and extra[0]['td'][2] == d[2] and extra[0]['td'][3] == d[3]
+    dev.close()

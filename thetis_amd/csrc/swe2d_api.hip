@@ -820,8 +820,9 @@ tracer_kernel_t pick_tracer_kernel(bool lf, bool t0, bool src)
     return src ? swe_tracer_stage_kernel<false, false, true> : swe_tracer_stage_kernel<false, false, false>;
 }
 
-int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1, double beta)
+int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1, double beta, int c0, int c1)
 {
+    if (c1 <= c0) return SWE2D_OK;
     Handle::Tracer &t = h->tracers[id];
     SweTracerArgs a;
     a.tin = t.buf[in];
@@ -830,7 +831,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     a.uv = h->state[0];
     a.stride = h->stride;
     a.nbr = h->nbr; a.cv = h->cv; a.vx = h->vx; a.vy = h->vy;
-    a.cell_begin = 0; a.cell_end = h->n_owned;
+    a.cell_begin = c0; a.cell_end = c1;
     a.dt = h->par.dt; a.a0 = a0; a.a1 = a1; a.beta = beta;
     a.vel_factor = h->tracer_vel_factor;
     a.lf_factor = h->tracer_lf_factor;
@@ -841,7 +842,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_has_value[m] = t.bc_has_value[m]; a.bc_value[m] = t.bc_value[m]; }
     tracer_kernel_t kern = (h->npc == 4) ? pick_tracer_kernel_quad(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr)
                                          : pick_tracer_kernel(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr);
-    const int nblocks = (h->n_owned + SWE_BLOCK - 1)/SWE_BLOCK;
+    const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
     const int grid = ((nblocks + 7)/8)*8;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
@@ -855,7 +856,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
         v.mu_v = t.mu_v; v.mu_const = t.mu_const;
         v.sipg = 3.0*t.sipg_factor;
         v.dt = h->par.dt; v.beta = beta;
-        v.cell_begin = 0; v.cell_end = h->n_owned;
+        v.cell_begin = c0; v.cell_end = c1;
         v.uv = h->state[0];
         v.vel_factor = h->tracer_vel_factor;
         for (int m = 0; m < SWE_MAX_MARKERS; m++) { v.bc_diff_kind[m] = t.bc_diff_kind[m]; v.bc_diff_flux[m] = t.bc_diff_flux[m]; }
@@ -865,12 +866,12 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     return SWE2D_OK;
 }
 
-int tracer_stage(Handle *h, int id, int i_stage)
+int tracer_stage(Handle *h, int id, int i_stage, int c0, int c1)
 {
     switch (i_stage) {
-    case 0: return launch_tracer_stage(h, id, 0, 1, 0.0, 1.0, kBeta[0]);
-    case 1: return launch_tracer_stage(h, id, 1, 2, kAlpha0[1], kAlphaIn[1], kBeta[1]);
-    case 2: return launch_tracer_stage(h, id, 2, 0, kAlpha0[2], kAlphaIn[2], kBeta[2]);
+    case 0: return launch_tracer_stage(h, id, 0, 1, 0.0, 1.0, kBeta[0], c0, c1);
+    case 1: return launch_tracer_stage(h, id, 1, 2, kAlpha0[1], kAlphaIn[1], kBeta[1], c0, c1);
+    case 2: return launch_tracer_stage(h, id, 2, 0, kAlpha0[2], kAlphaIn[2], kBeta[2], c0, c1);
     default: return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "i_stage must be 0, 1 or 2");
     }
 }
@@ -930,10 +931,11 @@ int limiter_build(Handle *h, int nv, const int *topo /* [n][3] */)
     return SWE2D_OK;
 }
 
-int limiter_apply(Handle *h, int id)
+// Means and vertex bounds over every local cell / vertex, limited values written to cells [0, cell_end).  On a
+// partition cell_end excludes the outermost ghost layer, whose vertex neighbourhoods are incomplete (partition.py).
+int limiter_apply(Handle *h, int id, int cell_end)
 {
-    if (h->n_owned != h->n_cells)
-        return fail(h, SWE2D_ERR_UNSUPPORTED, "the vertex limiter is not available on partitions yet");
+    if (cell_end < 0 || cell_end > h->n_cells) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell range");
     if (h->lim_nv == 0) {
         int rc = limiter_build(h, h->n_vertices, h->host_cells.data());
         if (rc) return rc;
@@ -944,8 +946,9 @@ int limiter_apply(Handle *h, int id)
     hipLaunchKernelGGL(swe_limiter_vertex_bounds, dim3(grid_for(nv)), dim3(256), 0, h->stream, h->lim_v2c_off,
                        h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_mean, t, h->stride, nv, h->lim_qmin,
                        h->lim_qmax, h->npc);
-    hipLaunchKernelGGL(swe_limiter_apply, dim3(grid_for(n)), dim3(256), 0, h->stream, t, h->stride, n, h->lim_tv,
-                       h->lim_qmin, h->lim_qmax, h->npc);
+    if (cell_end > 0)
+        hipLaunchKernelGGL(swe_limiter_apply, dim3(grid_for(cell_end)), dim3(256), 0, h->stream, t, h->stride, cell_end,
+                           h->lim_tv, h->lim_qmin, h->lim_qmax, h->npc);
     HIP_TRY(h, hipGetLastError());
     return SWE2D_OK;
 }
@@ -958,7 +961,6 @@ int swe2d_tracer_add(swe2d_handle *hh, int *tracer_id)
 {
     Handle *h = H(hh);
     if (!h || !tracer_id) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
-    if (h->n_owned != h->n_cells) return fail(h, SWE2D_ERR_UNSUPPORTED, "tracers are not available on partitions yet");
     HIP_TRY(h, hipSetDevice(h->device));
     Handle::Tracer t;
     for (int m = 0; m < SWE_MAX_MARKERS; m++) {
@@ -1097,7 +1099,7 @@ int swe2d_tracer_solve_stage(swe2d_handle *hh, int id, int i_stage)
     int rc = check_tracer(h, id);
     if (rc) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
-    return tracer_stage(h, id, i_stage);
+    return tracer_stage(h, id, i_stage, 0, h->n_owned);
 }
 
 int swe2d_tracer_tendency(swe2d_handle *hh, int id, double *k_nodal)
@@ -1107,7 +1109,7 @@ int swe2d_tracer_tendency(swe2d_handle *hh, int id, double *k_nodal)
     if (rc) return rc;
     if (!k_nodal) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
-    rc = launch_tracer_stage(h, id, 0, 1, 0.0, 0.0, 1.0);
+    rc = launch_tracer_stage(h, id, 0, 1, 0.0, 0.0, 1.0, 0, h->n_owned);
     if (rc) return rc;
     return tracer_read_back(h, h->tracers[id].buf[1], k_nodal);
 }
@@ -1127,7 +1129,58 @@ int swe2d_tracer_limit(swe2d_handle *hh, int id)
     int rc = check_tracer(h, id);
     if (rc) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
-    return limiter_apply(h, id);
+    if (h->n_owned != h->n_cells)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "on a partition use swe2d_tracer_limit_cells (the outermost ghost layer cannot be limited)");
+    return limiter_apply(h, id, h->n_cells);
+}
+
+int swe2d_tracer_limit_cells(swe2d_handle *hh, int id, int32_t cell_end)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return limiter_apply(h, id, cell_end);
+}
+
+int swe2d_tracer_solve_stage_cells(swe2d_handle *hh, int id, int i_stage, int32_t cell_begin, int32_t cell_end)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (cell_begin < 0 || cell_end > h->n_cells || cell_begin > cell_end) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return tracer_stage(h, id, i_stage, cell_begin, cell_end);
+}
+
+int swe2d_tracer_halo_pack(swe2d_handle *hh, int id, int i_buffer, double *send_buf_dev)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (i_buffer < 0 || i_buffer > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad buffer index");
+    if (h->n_send == 0) return SWE2D_OK;
+    if (!send_buf_dev) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null send buffer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(swe_halo_pack, dim3(grid_for(h->npc*h->n_send)), dim3(256), 0, h->stream,
+                       h->tracers[id].buf[i_buffer], h->stride, h->send_cells, h->n_send, send_buf_dev, h->npc);
+    HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
+}
+
+int swe2d_tracer_halo_unpack(swe2d_handle *hh, int id, int i_buffer, const double *recv_buf_dev)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (i_buffer < 0 || i_buffer > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad buffer index");
+    if (h->n_recv == 0) return SWE2D_OK;
+    if (!recv_buf_dev) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null recv buffer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(swe_halo_unpack, dim3(grid_for(h->npc*h->n_recv)), dim3(256), 0, h->stream,
+                       h->tracers[id].buf[i_buffer], h->stride, h->recv_cells, h->n_recv, recv_buf_dev, h->npc);
+    HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
 }
 
 int swe2d_tracer_diagnostics(swe2d_handle *hh, int id, double out[4])
@@ -1181,14 +1234,14 @@ int swe2d_advance_coupled(swe2d_handle *hh, int n_steps, int tracer_only, int us
 {
     Handle *h = H(hh);
     if (!h || n_steps < 0) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad n_steps");
-    if (h->n_owned != h->n_cells) return fail(h, SWE2D_ERR_UNSUPPORTED, "coupled stepping on a partition is not supported yet");
+    if (h->n_owned != h->n_cells) return fail(h, SWE2D_ERR_UNSUPPORTED, "on a partition the host drives the coupled step (stages on cell ranges + halo exchanges, thetis_amd/distributed.py)");
     HIP_TRY(h, hipSetDevice(h->device));
     for (int it = 0; it < n_steps; it++) {
         if (!tracer_only)
             for (int s = 0; s < 3; s++) { int rc = stage_on_range(h, s, 0, h->n_owned); if (rc) return rc; }
         for (int id = 0; id < (int)h->tracers.size(); id++) {
-            for (int s = 0; s < 3; s++) { int rc = tracer_stage(h, id, s); if (rc) return rc; }
-            if (use_limiter) { int rc = limiter_apply(h, id); if (rc) return rc; }
+            for (int s = 0; s < 3; s++) { int rc = tracer_stage(h, id, s, 0, h->n_owned); if (rc) return rc; }
+            if (use_limiter) { int rc = limiter_apply(h, id, h->n_cells); if (rc) return rc; }
         }
     }
     return SWE2D_OK;

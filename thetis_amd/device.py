@@ -377,6 +377,20 @@ class Swe2dDevice(object):
     def tracer_limit(self, tid):
         self._ck(self.lib.swe2d_tracer_limit(self.h, tid))
 
+    # -- tracers on partitions (device cell ranges; ghosts keep the caller's order)
+    def tracer_solve_stage_cells(self, tid, i_stage, cell_begin, cell_end):
+        self._ck(self.lib.swe2d_tracer_solve_stage_cells(self.h, int(tid), int(i_stage), int(cell_begin), int(cell_end)))
+
+    def tracer_limit_cells(self, tid, cell_end):
+        """Limiter on cells [0, cell_end); means / vertex bounds over every local cell."""
+        self._ck(self.lib.swe2d_tracer_limit_cells(self.h, int(tid), int(cell_end)))
+
+    def tracer_halo_pack(self, tid, i_buffer, send_buf_ptr):
+        self._ck(self.lib.swe2d_tracer_halo_pack(self.h, int(tid), int(i_buffer), ctypes.c_void_p(send_buf_ptr)))
+
+    def tracer_halo_unpack(self, tid, i_buffer, recv_buf_ptr):
+        self._ck(self.lib.swe2d_tracer_halo_unpack(self.h, int(tid), int(i_buffer), ctypes.c_void_p(recv_buf_ptr)))
+
     def tracer_diagnostics(self, tid):
         """{int T*H dx, int T dx, min nodal T, max nodal T}"""
         out = np.empty(4)

@@ -24,10 +24,11 @@ __all__ = ['HaloExchanger', 'DistributedSwe2d', 'run_distributed_bench']
 class HaloExchanger(object):
     """Neighbour exchange of [n][9] cell states between ranks; tensors may live on the CPU (gloo) or the GPU (RCCL)."""
 
-    def __init__(self, part, device, host_staged=False):
+    def __init__(self, part, device, host_staged=False, width=None):
         import torch
         self.part = part
-        self.w = w = 3*int(part.cells.shape[1])        # doubles per cell: u, v, eta at every node
+        # doubles per cell: u, v, eta at every node (state) or one value per node (a tracer)
+        self.w = w = 3*int(part.cells.shape[1]) if width is None else int(width)
         self.send_buf = torch.zeros(max(1, len(part.send_cells))*w, dtype=torch.float64, device=device)
         self.recv_buf = torch.zeros(max(1, len(part.recv_cells))*w, dtype=torch.float64, device=device)
         # gloo cannot move device memory: stage through the host (test path only; RCCL sends device buffers directly)
@@ -66,12 +67,24 @@ class HaloExchanger(object):
 class DistributedSwe2d(object):
     """SSPRK33 on a strip-partitioned mesh, one rank per GPU."""
 
-    def __init__(self, mesh, bathymetry_vertex, dt, rank, world_size, device_id, owner=None, host_staged=False, **opts):
+    def __init__(self, mesh, bathymetry_vertex, dt, rank, world_size, device_id, owner=None, host_staged=False,
+                 n_tracers=0, use_limiter=True, tracer_only=False, **opts):
+        """``n_tracers`` > 0: the coupled step of GeneralCoupledTimeIntegrator2D.advance (coupled_timeintegrator_2d.py:
+        93-113) on the partition - shallow water step, then every tracer with the updated velocity, then the limiter.
+        The vertex-based limiter needs every cell around a vertex, so coupled runs with the limiter use four ghost layers
+        built by VERTEX distance: the ghosts receive the neighbours' unlimited values once per step and every rank limits
+        its owned cells and layers 1-3 redundantly (same means, same bounds => bitwise the owner's result); layer 4 is
+        only ever read by the limiter."""
         import torch
         from .device import Swe2dDevice
         self.rank, self.world = rank, world_size
         owner = strip_owner(mesh, world_size) if owner is None else owner
-        self.part = build_partition(mesh, owner, rank)
+        self.use_limiter = bool(use_limiter) and n_tracers > 0
+        self.tracer_only = bool(tracer_only)
+        if self.use_limiter:
+            self.part = build_partition(mesh, owner, rank, halo_depth=4, adjacency='vertex')
+        else:
+            self.part = build_partition(mesh, owner, rank)
         p = self.part
         torch.cuda.set_device(device_id)
         self.torch_device = torch.device('cuda', device_id)
@@ -84,6 +97,27 @@ class DistributedSwe2d(object):
         self.dev.set_stream(self.stream.cuda_stream)
         self.graph = None
         self.graph_steps = 0
+        self.tids = [self.dev.add_tracer() for _ in range(n_tracers)]
+        self.thalo = HaloExchanger(p, self.torch_device, host_staged=host_staged, width=p.cells.shape[1]) if n_tracers else None
+
+    def set_tracer_global(self, i_tracer, nodal):
+        self.dev.tracer_set_state(self.tids[i_tracer], np.asarray(nodal)[self.part.local_to_global])
+
+    def get_tracer_owned(self, i_tracer):
+        n = self.part.n_owned
+        return self.part.local_to_global[:n], self.dev.tracer_get_state(self.tids[i_tracer])[:n]
+
+    def tracer_diagnostics(self, i_tracer):
+        """Global {int T*H dx, int T dx, min, max} of tracer ``i_tracer``."""
+        import torch
+        import torch.distributed as dist
+        d = self.dev.tracer_diagnostics(self.tids[i_tracer])
+        s = torch.tensor(d[:2], dtype=torch.float64, device=self.torch_device)
+        m = torch.tensor([d[2], -d[3]], dtype=torch.float64, device=self.torch_device)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        dist.all_reduce(m, op=dist.ReduceOp.MIN)
+        m = m.cpu().numpy()
+        return np.concatenate([s.cpu().numpy(), [m[0], -m[1]]])
 
     def set_state_global(self, uv, eta):
         g = self.part.local_to_global
@@ -96,6 +130,27 @@ class DistributedSwe2d(object):
         return self.part.local_to_global[:n], uv[:n], eta[:n]
 
     def _step(self):
+        if not self.tracer_only:
+            self._step_swe()
+        for tid in self.tids:
+            self._step_tracer(tid)
+
+    def _step_tracer(self, tid):
+        """One tracer SSPRK33 step with the (already exchanged) updated velocity, same ranges and overlap as the shallow
+        water step, then the limiter on owned cells + ghost layers 1-3."""
+        dev, halo, p = self.dev, self.thalo, self.part
+        dev.tracer_solve_stage_cells(tid, 0, 0, self._ranges[0])
+        dev.tracer_solve_stage_cells(tid, 1, 0, self._ranges[1])
+        dev.tracer_solve_stage_cells(tid, 2, p.n_interior, p.n_owned)
+        dev.tracer_halo_pack(tid, 0, halo.send_buf.data_ptr())
+        reqs = halo.start()
+        dev.tracer_solve_stage_cells(tid, 2, 0, p.n_interior)
+        halo.finish(reqs)
+        dev.tracer_halo_unpack(tid, 0, halo.recv_buf.data_ptr())
+        if self.use_limiter:
+            dev.tracer_limit_cells(tid, p.layer_end(3))
+
+    def _step_swe(self):
         dev, halo, p = self.dev, self.halo, self.part
         dev.solve_stage_cells(0, 0, self._ranges[0])        # owned + ghost layers 1, 2
         dev.solve_stage_cells(1, 0, self._ranges[1])        # owned + ghost layer 1

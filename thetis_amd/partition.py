@@ -52,21 +52,49 @@ class LocalPartition(object):
     def cell_xy(self):
         return self.vertex_xy[self.cells]
 
-    def stage_range(self, i_stage):
-        """Cells [0, end) that stage ``i_stage`` has to update so that the owned cells are right after stage 3."""
-        depth = len(self.layer_sizes)
+    def stage_range(self, i_stage, depth=3):
+        """Cells [0, end) that stage ``i_stage`` has to update so that the owned cells are right after stage 3, when the
+        stage input is valid on ``depth`` ghost layers (3 = one per SSPRK33 stage; a deeper halo only serves the limiter)."""
+        depth = min(depth, len(self.layer_sizes))
         keep = max(0, depth - 1 - i_stage)              # ghost layers still needed after this stage
         return self.n_owned + int(sum(self.layer_sizes[:keep]))
 
+    def layer_end(self, n_layers):
+        """owned cells + the first ``n_layers`` ghost layers"""
+        return self.n_owned + int(sum(self.layer_sizes[:n_layers]))
 
-def _halo_layers(nbr, inside, depth):
-    """Facet-distance layers 1..depth around the cell set ``inside`` (boolean mask)."""
+
+class _VertexAdjacency(object):
+    """cells around every (topological) vertex, CSR"""
+
+    def __init__(self, topo_cells):
+        n, k = topo_cells.shape
+        flat = topo_cells.ravel()
+        order = np.argsort(flat, kind='stable')
+        self.cell = (order//k).astype(np.int64)
+        self.off = np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=int(flat.max()) + 1))])
+        self.topo_cells = topo_cells
+
+    def neighbours(self, cells):
+        """all cells sharing a vertex with any of ``cells``"""
+        v = np.unique(self.topo_cells[cells])
+        starts, ends = self.off[v], self.off[v + 1]
+        idx = np.concatenate([np.arange(a, b) for a, b in zip(starts, ends)]) if len(v) else np.zeros(0, dtype=np.int64)
+        return np.unique(self.cell[idx])
+
+
+def _halo_layers(nbr, inside, depth, vadj=None):
+    """Layers 1..depth around the cell set ``inside`` (boolean mask): facet distance, or vertex distance when a
+    _VertexAdjacency is given (a superset: the vertex-based limiter needs every cell around a vertex)."""
     dist = np.where(inside, 0, -1).astype(np.int32)
     frontier = np.nonzero(inside)[0]
     layers = []
     for d in range(1, depth + 1):
-        nb = nbr[frontier].ravel()
-        nb = nb[nb >= 0]
+        if vadj is not None:
+            nb = vadj.neighbours(frontier)
+        else:
+            nb = nbr[frontier].ravel()
+            nb = nb[nb >= 0]
         new = np.unique(nb[dist[nb] < 0])
         dist[new] = d
         layers.append(new)
@@ -74,19 +102,26 @@ def _halo_layers(nbr, inside, depth):
     return layers, dist
 
 
-def build_partition(mesh, owner, rank, halo_depth=3):
-    """Local partition of ``rank`` given the global ``owner`` array."""
+def build_partition(mesh, owner, rank, halo_depth=3, adjacency='facet'):
+    """Local partition of ``rank`` given the global ``owner`` array.  ``adjacency='vertex'`` builds the ghost layers by
+    vertex distance (coupled runs with the vertex-based limiter use halo_depth=4, adjacency='vertex')."""
     owner = np.asarray(owner)
     n_parts = int(owner.max()) + 1
     nbr = mesh.cell_nbr
     mine_mask = owner == rank
-    layers, _ = _halo_layers(nbr, mine_mask, halo_depth)
+    vadj = None
+    if adjacency == 'vertex':
+        topo = getattr(mesh, 'topo_vertex', None)
+        vadj = _VertexAdjacency(np.asarray(mesh.cells if topo is None else np.asarray(topo)[mesh.cells], dtype=np.int64))
+    elif adjacency != 'facet':
+        raise ValueError("adjacency must be 'facet' or 'vertex'")
+    layers, _ = _halo_layers(nbr, mine_mask, halo_depth, vadj)
     # which of my cells do the peers need?  (cells within halo_depth of the peer's owned set)
     send_global = {}
     for q in range(n_parts):
         if q == rank:
             continue
-        _, dist_q = _halo_layers(nbr, owner == q, halo_depth)
+        _, dist_q = _halo_layers(nbr, owner == q, halo_depth, vadj)
         hit = np.nonzero(mine_mask & (dist_q > 0))[0]
         if len(hit):
             send_global[q] = np.sort(hit)
@@ -118,6 +153,14 @@ def build_partition(mesh, owner, rank, halo_depth=3):
     part.vertex_global = used
     part.vertex_xy = np.ascontiguousarray(mesh.vertex_xy[used])
     part.cells = np.ascontiguousarray(v_g2l[cells_g].astype(np.int32))
+    # topological vertex ids (periodic meshes identify vertices) of the local vertices, compact local numbering
+    topo = getattr(mesh, 'topo_vertex', None)
+    if topo is not None:
+        _, tinv = np.unique(np.asarray(topo)[used], return_inverse=True)
+        part.topo_vertex = tinv.astype(np.int64)
+    else:
+        part.topo_vertex = np.arange(len(used), dtype=np.int64)
+    part.halo_depth, part.adjacency = halo_depth, adjacency
 
     nb_l = nbr[local_global].astype(np.int64)
     pos = nb_l >= 0
