@@ -116,9 +116,12 @@ def test_unsupported_configurations_fail_loudly(hip_lib):
     with pytest.raises(Exception):
         s2.assign_initial_conditions(elev=elev_init)
     s3, *_ = _channel2d_solver()
-    s3.options.horizontal_viscosity = Constant(10.0)
+    s3.options.horizontal_viscosity = Function(get_functionspace(mesh, 'DG', 1)).assign(10.0)    # discontinuous viscosity
     with pytest.raises(NotImplementedError):
         s3.assign_initial_conditions(elev=elev_init)
+    s5, *_ = _channel2d_solver()
+    s5.options.horizontal_viscosity = Constant(10.0)           # supported since the SIPG pass kernel exists
+    s5.assign_initial_conditions(elev=elev_init)
     s4, *_ = _channel2d_solver()
     s4.bnd_functions['shallow_water'] = {1: {'temperature': Constant(1.0)}}
     with pytest.raises(Exception):

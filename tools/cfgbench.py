@@ -38,8 +38,23 @@ def report(name, n_cells, bytes_per_cell_step, t_step, extra=None):
     print(json.dumps(out))
 
 
+def quads(rng):
+    # ---- quads: 1M quadrilaterals (cfg 1(ii) cell type at bench size): 248 / 344 / 344 = 936 B per cell per step
+    meshq = RectangleMesh(1000, 1000, 100e3, 100e3, quadrilateral=True)
+    nq = meshq.num_cells
+    cq = meshq.cell_xy()
+    etaq = 0.5*np.exp(-((cq[:, :, 0] - 50e3)**2 + (cq[:, :, 1] - 50e3)**2)/(5e3)**2)
+    dev = Swe2dDevice(meshq, np.full(meshq.num_vertices, 20.0), 0.25)
+    dev.set_state(1e-3*rng.uniform(-1, 1, size=(nq, 4, 2)), etaq)
+    report('quadrilaterals SWE (DQ-1)', nq, 936.0, timed(dev, dev.advance, 50))
+    dev.close()
+
+
 def main():
+    only = os.environ.get('CFGBENCH_ONLY', '')          # e.g. 'quads' for kernel A/B runs
     rng = np.random.default_rng(1234)
+    if only == 'quads':
+        return quads(rng)
     # ---- cfg 2 reference point: triangles, SWE only (684 B per cell per step)
     mesh = RectangleMesh(1000, 500, 100e3, 50e3)
     n = mesh.num_cells
@@ -69,15 +84,8 @@ def main():
     dev.set_state(np.zeros((n5, 3, 2)), np.zeros((n5, 3)))
     report('cfg5 triangles SWE wetting-drying + Manning + open bc', n5, 684.0 + 18.0, timed(dev, dev.advance, 50))
     dev.close()
-    # ---- quads: 1M quadrilaterals (cfg 1(ii) cell type at bench size): 248 / 344 / 344 = 936 B per cell per step
-    meshq = RectangleMesh(1000, 1000, 100e3, 100e3, quadrilateral=True)
-    nq = meshq.num_cells
-    cq = meshq.cell_xy()
-    etaq = 0.5*np.exp(-((cq[:, :, 0] - 50e3)**2 + (cq[:, :, 1] - 50e3)**2)/(5e3)**2)
-    dev = Swe2dDevice(meshq, np.full(meshq.num_vertices, 20.0), 0.25)
-    dev.set_state(1e-3*rng.uniform(-1, 1, size=(nq, 4, 2)), etaq)
-    report('quadrilaterals SWE (DQ-1)', nq, 936.0, timed(dev, dev.advance, 50))
-    dev.close()
+    quads(rng)
+
 
 
 if __name__ == '__main__':
