@@ -155,6 +155,9 @@ int  swe2d_set_wetting_and_drying(swe2d_handle *h, int enable, const double *alp
 int  swe2d_advance(swe2d_handle *h, int n_steps);
 /* ERKGenericShuOsher.solve_stage(i_stage) (rungekutta.py:930-946); i_stage = 0,1,2 in order. */
 int  swe2d_solve_stage(swe2d_handle *h, int i_stage);
+/* timeintegrator.ForwardEuler.advance (thetis/timeintegrator.py:115-165; 'ForwardEuler' in the steppers table,
+ * solver2d.py:664) x n_steps:  U <- U + dt M^-1 R(U) - the first Shu-Osher stage followed by a buffer swap */
+int  swe2d_advance_forward_euler(swe2d_handle *h, int n_steps);
 /* n_steps steps bracketed by HIP events on the handle's stream; *ms_total = elapsed GPU time,
  * *ms_kernel_avg = mean duration of one stage kernel launch (events around every launch when per_launch != 0). */
 int  swe2d_advance_timed(swe2d_handle *h, int n_steps, int per_launch, float *ms_total, float *ms_kernel_avg);
@@ -206,6 +209,7 @@ int  swe2d_tracer_set_diffusivity(swe2d_handle *h, int tracer_id, int enable, co
 int  swe2d_tracer_set_diffusion_bc(swe2d_handle *h, int tracer_id, int marker, int kind, double diff_flux);
 int  swe2d_tracer_solve_stage(swe2d_handle *h, int tracer_id, int i_stage);          /* rungekutta.py:930-946 for the tracer */
 int  swe2d_tracer_tendency(swe2d_handle *h, int tracer_id, double *k_nodal);
+int  swe2d_tracer_forward_euler(swe2d_handle *h, int tracer_id);                     /* one ForwardEuler step of the tracer */
 /* partitions (one handle per GPU): the tracer stage on a local cell range, the limiter on cells [0, cell_end) with means
  * and vertex bounds taken over every local cell (the ghost layers must hold the neighbours' unlimited values), and the
  * tracer's part of the halo exchange (same cell lists as swe2d_halo_setup, nodes_per_cell doubles per cell) */

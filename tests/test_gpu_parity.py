@@ -207,3 +207,31 @@ def test_function_valued_boundary_data(hip_lib, quad):
     ku_o, ke_o = orc.tendency(uv, eta, dt)
     assert rel_linf(ku, ku_o) < TOL_RHS and rel_linf(ke, ke_o) < TOL_RHS
     dev.close()
+
+
+@pytest.mark.parametrize('cells', ['triangles', 'quadrilaterals'])
+def test_forward_euler_steps_match_oracle(hip_lib, cells):
+    """timeintegrator.ForwardEuler (thetis/timeintegrator.py:115-165), the other explicit stepper of solver2d.py:662-672."""
+    from helpers import make_oracle_generic, quad_case
+    if cells == 'triangles':
+        mesh, bath, uv, eta = channel_case(seed=31)
+        orc = make_oracle(mesh, bath, bnd_conditions={2: {'elev': 0.1}})
+    else:
+        mesh, bath, uv, eta = quad_case(seed=31)
+        orc = make_oracle_generic(mesh, bath, bnd_conditions={2: {'elev': 0.1}})
+    dt = 1.5
+    dev = _device(mesh, bath, dt, boundary_len=mesh.boundary_len)
+    dev.set_bc(2, {'elev': 0.1})
+    dev.set_state(uv, eta)
+    dev.advance_forward_euler(3)
+    u, e = dev.get_state()
+    uo, eo = uv, eta
+    for _ in range(3):
+        uo, eo = orc.forward_euler_step(uo, eo, dt)
+    assert rel_linf(u, uo) < TOL_RHS and rel_linf(e, eo) < TOL_RHS
+    # mixing steppers on one handle keeps working (buffer swap is transparent)
+    dev.advance(1)
+    u, e = dev.get_state()
+    uo, eo = orc.ssprk33_step(uo, eo, dt)
+    assert rel_linf(u, uo) < TOL_RHS and rel_linf(e, eo) < TOL_RHS
+    dev.close()

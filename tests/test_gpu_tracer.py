@@ -163,7 +163,7 @@ def test_coupled_steps_match_cpu_restatement(hip_lib, ref_so):
     dev.close()
 
 
-def _consistency_solver(constant_c, conservative=False, limiter=None):
+def _consistency_solver(constant_c, conservative=False, limiter=None, stepper='SSPRK33'):
     # test/tracerEq/test_consistency_2d.py:17-110 with timestepper_type='SSPRK33'
     t_cycle, depth = 2000.0, 50.0
     lx = math.sqrt(9.81*depth)*t_cycle
@@ -183,7 +183,7 @@ def _consistency_solver(constant_c, conservative=False, limiter=None):
     options.check_volume_conservation_2d = True
     options.check_tracer_conservation = True
     options.check_tracer_overshoot = True
-    options.set_timestepper_type('SSPRK33')
+    options.set_timestepper_type(stepper)
     options.no_exports = True
     solver_obj.create_function_spaces()
     elev_init = Function(solver_obj.function_spaces.H_2d)
@@ -235,3 +235,42 @@ def test_reference_conservative_tracer_scenario(hip_lib):
     assert vol2d_rerr < 1e-10, '2D volume is not conserved'
     tracer_int, tracer_int_rerr = solver_obj.callbacks['export']['tracer_2d mass']()
     assert abs(tracer_int_rerr) < 1.2e-4, 'tracer is not conserved'
+
+
+def test_reference_const_tracer_scenario_forward_euler(hip_lib):
+    """test_consistency_2d.py::test_const_tracer[ForwardEuler]: constant tracer stays constant, volume conserved."""
+    solver_obj = _consistency_solver(True, stepper='ForwardEuler')
+    assert type(solver_obj.timestepper.swe).__name__ == 'ForwardEuler'
+    t_end = solver_obj.options.simulation_end_time
+    it = solver_obj.create_iterator()
+    while True:
+        try:
+            t = next(it)
+        except StopIteration as e:
+            t = e.value
+            break
+    assert t >= t_end - 1e-5
+    vol2d, vol2d_rerr = solver_obj.callbacks['export']['volume2d']()
+    assert vol2d_rerr < 1e-10
+    tracer_int, tracer_int_rerr = solver_obj.callbacks['export']['tracer_2d mass']()
+    assert abs(tracer_int_rerr) < 1.2e-4
+    smin, smax, undershoot, overshoot = solver_obj.callbacks['export']['tracer_2d overshoot']()
+    assert max(abs(undershoot), abs(overshoot)) < 1e-11
+    assert np.abs(solver_obj.fields.tracer_2d.dat.data_ro - 4.5).max() < 1e-11
+
+
+def test_tracer_forward_euler_matches_oracle(hip_lib):
+    mesh, bath, uv, eta = channel_case(seed=17)
+    T = np.random.default_rng(5).normal(size=(mesh.num_cells, 3))
+    dt = 2.0
+    orc = make_oracle(mesh, bath)
+    dev = _dev(mesh, bath, dt)
+    tid = dev.add_tracer()
+    dev.set_state(uv, eta)
+    dev.tracer_set_state(tid, T)
+    To = T
+    for _ in range(3):
+        dev.tracer_forward_euler(tid)
+        To = To + orc.tracer_tendency(To, uv, eta, dt)
+    assert rel_linf(dev.tracer_get_state(tid), To) < TOL
+    dev.close()

@@ -72,6 +72,8 @@ SYMBOLS = {
     'swe2d_tracer_limit_cells': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int32]),
     'swe2d_tracer_halo_pack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'swe2d_tracer_halo_unpack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'swe2d_advance_forward_euler': (ctypes.c_int, [_H, ctypes.c_int]),
+    'swe2d_tracer_forward_euler': (ctypes.c_int, [_H, ctypes.c_int]),
     'swe2d_tracer_set_conservative': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int]),
     'swe2d_tracer_set_diffusivity': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_double, ctypes.c_double]),
     'swe2d_tracer_set_diffusion_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]),

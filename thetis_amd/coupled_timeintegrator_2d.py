@@ -9,7 +9,7 @@ from .log import print_output
 from .options import Constant
 from .timeintegrator import TimeIntegratorBase
 
-__all__ = ['DeviceTracerSSPRK33', 'GeneralCoupledTimeIntegrator2D']
+__all__ = ['DeviceTracerSSPRK33', 'DeviceTracerForwardEuler', 'GeneralCoupledTimeIntegrator2D']
 
 
 class _AttrDict(dict):
@@ -95,6 +95,24 @@ class DeviceTracerSSPRK33(object):
             self.solve_stage(i, t, update_forcings)
 
 
+class DeviceTracerForwardEuler(DeviceTracerSSPRK33):
+    """timeintegrator.ForwardEuler of one tracer equation (thetis/timeintegrator.py:115-165)."""
+    n_stages = 1
+    c = (0.0,)
+
+    def solve_stage(self, i_stage, t, update_forcings=None):
+        assert i_stage == 0
+        self.advance(t, update_forcings)
+
+    def advance(self, t, update_forcings=None):
+        if update_forcings is not None:
+            update_forcings(t + self.dt)
+            self._push_bcs()
+        self._sync_to_device()
+        self.device.tracer_forward_euler(self.tid)
+        self._device_ahead = True
+
+
 class GeneralCoupledTimeIntegrator2D(TimeIntegratorBase):
     def __init__(self, solver, swe_stepper, tracer_steppers):
         self.solver = solver
@@ -108,7 +126,7 @@ class GeneralCoupledTimeIntegrator2D(TimeIntegratorBase):
         print_output('Coupled time integrator: {:}'.format(self.__class__.__name__))
         if not self.options.tracer_only:
             print_output('  Shallow Water time integrator: {:}'.format(swe_stepper.__class__.__name__))
-        print_output('  Tracer time integrator: SSPRK33')
+        print_output('  Tracer time integrator: {:}'.format(self.options.tracer_timestepper_type))
         o = self.options
         self.device.tracer_set_options(o.use_lax_friedrichs_tracer, float(o.lax_friedrichs_tracer_scaling_factor),
                                        float(o.tracer_advective_velocity_factor)
@@ -127,7 +145,8 @@ class GeneralCoupledTimeIntegrator2D(TimeIntegratorBase):
     def advance(self, t, update_forcings=None):
         """coupled_timeintegrator_2d.py:93-113"""
         use_limiter = self.options.use_limiter_for_tracers and self.options.polynomial_degree > 0
-        if update_forcings is None:
+        fused = all(ts.n_stages == 3 for ts in self.tracers.values()) and self.swe.n_stages == 3
+        if update_forcings is None and fused:        # all SSPRK33: one C call per time step
             self.swe._sync_to_device()
             for ts in self.tracers.values():
                 ts._sync_to_device()

@@ -638,6 +638,21 @@ int swe2d_advance(swe2d_handle *hh, int n_steps)
     return SWE2D_OK;
 }
 
+int swe2d_advance_forward_euler(swe2d_handle *hh, int n_steps)
+{
+    Handle *h = H(hh);
+    if (!h || n_steps < 0) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad n_steps");
+    if (h->n_owned != h->n_cells) return fail(h, SWE2D_ERR_UNSUPPORTED, "ForwardEuler is not available on partitions");
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (int it = 0; it < n_steps; it++) {
+        // U_new = U + dt M^-1 R(U): stage 0 of the Shu-Osher form; the result becomes buffer A by a pointer swap
+        int rc = launch_stage(h, 0, 0, 1, 0.0, 1.0, 1.0, 0, h->n_owned);
+        if (rc) return rc;
+        std::swap(h->state[0], h->state[1]);
+    }
+    return SWE2D_OK;
+}
+
 int swe2d_advance_timed(swe2d_handle *hh, int n_steps, int per_launch, float *ms_total, float *ms_kernel_avg)
 {
     Handle *h = H(hh);
@@ -1050,6 +1065,19 @@ int swe2d_tracer_set_source(swe2d_handle *hh, int id, const double *nodal)
                        h->stage_eta, t.source, h->stride, h->n_cells, 1, h->npc);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWE2D_OK;
+}
+
+int swe2d_tracer_forward_euler(swe2d_handle *hh, int id)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (h->n_owned != h->n_cells) return fail(h, SWE2D_ERR_UNSUPPORTED, "ForwardEuler is not available on partitions");
+    HIP_TRY(h, hipSetDevice(h->device));
+    rc = launch_tracer_stage(h, id, 0, 1, 0.0, 1.0, 1.0, 0, h->n_owned);
+    if (rc) return rc;
+    std::swap(h->tracers[id].buf[0], h->tracers[id].buf[1]);
     return SWE2D_OK;
 }
 

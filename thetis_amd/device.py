@@ -292,6 +292,13 @@ class Swe2dDevice(object):
     def solve_stage(self, i_stage):
         self._ck(self.lib.swe2d_solve_stage(self.h, int(i_stage)))
 
+    def advance_forward_euler(self, n_steps=1):
+        """timeintegrator.ForwardEuler steps (thetis/timeintegrator.py:115-165)."""
+        self._ck(self.lib.swe2d_advance_forward_euler(self.h, int(n_steps)))
+
+    def tracer_forward_euler(self, tid):
+        self._ck(self.lib.swe2d_tracer_forward_euler(self.h, int(tid)))
+
     def solve_stage_cells(self, i_stage, cell_begin, cell_end):
         """Stage ``i_stage`` on device cells [cell_begin, cell_end) (partitions: may include ghost layers)."""
         self._ck(self.lib.swe2d_solve_stage_cells(self.h, int(i_stage), int(cell_begin), int(cell_end)))

@@ -18,7 +18,7 @@ from .options import Constant
 from .shallowwater_eq import g_grav
 from .timeintegrator import TimeIntegrator
 
-__all__ = ['SSPRK33Abstract', 'ERKGenericShuOsher', 'SSPRK33']
+__all__ = ['ForwardEuler', 'SSPRK33Abstract', 'ERKGenericShuOsher', 'SSPRK33']
 
 
 class SSPRK33Abstract(object):
@@ -233,3 +233,23 @@ class ERKGenericShuOsher(TimeIntegrator):
 
 class SSPRK33(ERKGenericShuOsher, SSPRK33Abstract):
     pass
+
+
+class ForwardEuler(ERKGenericShuOsher):
+    """Standard forward Euler time integration scheme (thetis/timeintegrator.py:115-165), the other explicit entry of the
+    steppers table (solver2d.py:664), on the same device state and kernels: ``U <- U + dt M^-1 R(U)``."""
+    cfl_coeff = 1.0
+    n_stages = 1
+    c = (0.0,)
+
+    def solve_stage(self, i_stage, t, update_forcings=None):
+        assert i_stage == 0
+        self.advance(t, update_forcings)
+
+    def advance(self, t, update_forcings=None):
+        if update_forcings is not None:
+            update_forcings(t + self.dt)            # the reference evaluates the forcings at the NEW time (:161-162)
+            self._push_bcs()
+        self._sync_to_device()
+        self.device.advance_forward_euler(1)
+        self._device_ahead = True

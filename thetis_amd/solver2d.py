@@ -21,7 +21,7 @@ from . import callback, coupled_timeintegrator_2d, exporter
 from .function import Function, FunctionSpace, MixedFunction, get_functionspace
 from .log import print_output
 from .options import Constant, ModelOptions2d
-from .rungekutta import SSPRK33
+from .rungekutta import SSPRK33, ForwardEuler
 from .shallowwater_eq import DepthExpression, ShallowWaterEquations, g_grav
 from .limiter import VertexBasedP1DGLimiter
 from .tracer_eq_2d import TracerEquation2D
@@ -231,22 +231,24 @@ class FlowSolver2d(object):
             self.fields.h_elem_size_2d = Function(self.function_spaces.P1_2d).assign(elem_size_p1(self.mesh2d))
         self.compute_mesh_stats()
         self.set_time_step()
-        steppers = {'SSPRK33': SSPRK33}
+        steppers = {'SSPRK33': SSPRK33, 'ForwardEuler': ForwardEuler}           # the explicit entries of solver2d.py:662-672
+        tracer_steppers = {'SSPRK33': coupled_timeintegrator_2d.DeviceTracerSSPRK33,
+                           'ForwardEuler': coupled_timeintegrator_2d.DeviceTracerForwardEuler}
         name = self.options.swe_timestepper_type
         if self.options.tracer_only and self.options.tracer:
             name = 'SSPRK33'        # the shallow water state is frozen (coupled_timeintegrator_2d.py:98): the stepper
             #                         object only holds the device-resident velocity, its type option is not used
         if name not in steppers:
             raise NotImplementedError("swe_timestepper_type {!r} needs a global (non)linear solve and is outside the "
-                                      "explicit device path; use 'SSPRK33'".format(name))
+                                      "explicit device path; use 'SSPRK33' or 'ForwardEuler'".format(name))
         if self.solve_tracer:
-            if self.options.tracer_timestepper_type != 'SSPRK33':
+            if self.options.tracer_timestepper_type not in tracer_steppers:
                 raise NotImplementedError("tracer_timestepper_type {!r} is outside the explicit device path; use "
-                                          "'SSPRK33'".format(self.options.tracer_timestepper_type))
+                                          "'SSPRK33' or 'ForwardEuler'".format(self.options.tracer_timestepper_type))
             swe = self.get_swe_timestepper(steppers[name])
             tracers = {}
             for system in self.options.tracer_fields:
-                tracers[system] = self.get_tracer_timestepper(coupled_timeintegrator_2d.DeviceTracerSSPRK33, system, swe)
+                tracers[system] = self.get_tracer_timestepper(tracer_steppers[self.options.tracer_timestepper_type], system, swe)
             self.timestepper = coupled_timeintegrator_2d.GeneralCoupledTimeIntegrator2D(self, swe, tracers)
         else:
             self.timestepper = self.get_swe_timestepper(steppers[name])
