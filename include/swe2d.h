@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SWE2D_ABI_VERSION 2
+#define SWE2D_ABI_VERSION 3
 #define SWE2D_MAX_MARKERS 16          /* boundary markers must be in 1..SWE2D_MAX_MARKERS-1 */
 
 typedef enum {
@@ -54,6 +54,7 @@ typedef enum {
 #define SWE2D_BC_ELEV_FIELD 16
 #define SWE2D_BC_UV_FIELD   32
 #define SWE2D_BC_UN_FIELD   64
+#define SWE2D_BC_FLUX_FIELD 128
 
 /* Nodal coefficient fields, `fields` dict of get_swe_timestepper (thetis/solver2d.py:547-559). */
 typedef enum {
@@ -131,10 +132,11 @@ int  swe2d_set_dt(swe2d_handle *h, double dt);
  * (update_forcings, rungekutta.py:933-934). */
 int  swe2d_set_bc(swe2d_handle *h, int marker, int kind, const double values[5]);
 
-/* Function-valued boundary data shared by all markers (every boundary facet has exactly one marker): nodal DG values in
- * the host layout, which = 0: elevation (kN), 1: velocity (kN,2), 2: normal velocity (kN).  Only boundary-facet nodes
- * are read.  May be called between stages. */
-int  swe2d_set_bc_field(swe2d_handle *h, int which, const double *nodal);
+/* Function-valued boundary data of ONE marker (bnd_functions[...][marker][key] = Function): nodal DG values of the whole
+ * mesh in the host layout, which = 0: elevation (kN), 1: velocity (kN,2), 2: normal velocity (kN), 3: flux (kN).  Only the
+ * nodes of boundary facets carrying `marker` are copied (stored per facet, so the two boundaries meeting at a corner cell
+ * keep their own values).  Select the field with the SWE2D_BC_*_FIELD bit in swe2d_set_bc.  May be called between stages. */
+int  swe2d_set_bc_field(swe2d_handle *h, int which, int marker, const double *nodal);
 
 /* bnd_functions['shallow_water'][marker]['drag'] = C_D (BoundaryDragTerm, shallowwater_eq.py:704-725); negative: none */
 int  swe2d_set_boundary_drag(swe2d_handle *h, int marker, double drag_coefficient);

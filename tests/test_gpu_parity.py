@@ -235,3 +235,28 @@ def test_forward_euler_steps_match_oracle(hip_lib, cells):
     uo, eo = orc.ssprk33_step(uo, eo, dt)
     assert rel_linf(u, uo) < TOL_RHS and rel_linf(e, eo) < TOL_RHS
     dev.close()
+
+
+def test_per_marker_boundary_fields_with_corner_cells(hip_lib):
+    """Different Functions of the same kind on different markers (the MMS scenarios prescribe -flux_x, +flux_x, -flux_y):
+    stored per facet, so the corner cells (two boundary facets sharing a node) keep both."""
+    mesh, bath, uv, eta = channel_case(nx=6, ny=4, seed=41)
+    rng = np.random.default_rng(9)
+    n = mesh.num_cells
+    f = lambda s=1.0: s*rng.normal(size=(n, 3))
+    bcs = {1: {'elev': f(0.1), 'flux': f(2e4)}, 2: {'flux': f(2e4)}, 3: {'elev': f(0.1), 'un': f(0.3)},
+           4: {'uv': 0.3*rng.normal(size=(n, 3, 2))}}
+    corner = np.sum(mesh.cell_nbr < 0, axis=1) == 2
+    assert corner.any()
+    dt = 2.0
+    orc = make_oracle(mesh, bath, bnd_conditions=bcs, horizontal_viscosity=30.0)
+    dev = _device(mesh, bath, dt)
+    for marker, funcs in bcs.items():
+        dev.set_bc(marker, funcs)
+    dev.set_viscosity(30.0)
+    dev.set_state(uv, eta)
+    ku, ke = dev.tendency()
+    ku_o, ke_o = orc.tendency(uv, eta, dt)
+    assert rel_linf(ku, ku_o) < TOL_RHS and rel_linf(ke, ke_o) < TOL_RHS
+    assert rel_linf(ku[corner], ku_o[corner]) < TOL_RHS
+    dev.close()

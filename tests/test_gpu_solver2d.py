@@ -252,3 +252,18 @@ def test_function_valued_tidal_boundary(hip_lib):
     for kstep in range(10):
         u_o, e_o = orc.ssprk33_step(u_o, e_o, 5.0, t=5.0*kstep, update_forcings=lambda t: val.__setitem__('t', t))
     assert rel_linf(eta, e_o) < 1e-10 and rel_linf(uv, u_o) < 1e-10
+
+
+@pytest.mark.parametrize('name', ['setup7', 'setup8', 'setup9'])
+def test_steady_state_basin_mms_convergence(hip_lib, name):
+    """test/swe2d/test_steady_state_basin_mms.py::test_steady_state_basin_convergence[dg-dg] with SSPRK33 on the device:
+    refinements [1, 2, 4, 6], second order for elevation and velocity within the reference's 20 % slope tolerance."""
+    import mms_basin
+    refs = [1, 2, 4, 6]
+    errs = [mms_basin.run_device(name, r) for r in refs]
+    slope_e, slope_u = mms_basin.convergence_rates(errs, refs)
+    assert abs(slope_e - 2.0)/2.0 < 0.2, (errs, slope_e)
+    assert abs(slope_u - 2.0)/2.0 < 0.2, (errs, slope_u)
+    # and the device result is the oracle's (same scenario, refinement 1)
+    eo, uo = mms_basin.run_oracle(name, 1)
+    assert abs(errs[0][0] - eo) < 1e-3*eo and abs(errs[0][1] - uo) < 1e-3*uo

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('THETIS_AMD_LIB') or os.path.join(_HERE, 'libswe2d_hip
 
 MAX_MARKERS = 16
 BC_ELEV, BC_UV, BC_UN, BC_FLUX = 1, 2, 4, 8
-BC_ELEV_FIELD, BC_UV_FIELD, BC_UN_FIELD = 16, 32, 64
+BC_ELEV_FIELD, BC_UV_FIELD, BC_UN_FIELD, BC_FLUX_FIELD = 16, 32, 64, 128
 FIELD_CORIOLIS, FIELD_ATMOSPHERIC_PRESSURE, FIELD_MOMENTUM_SOURCE, FIELD_VOLUME_SOURCE, FIELD_WIND_STRESS = 0, 1, 2, 3, 4
 SCALAR_LINEAR_DRAG, SCALAR_QUADRATIC_DRAG, SCALAR_MANNING_DRAG, SCALAR_NORM_SMOOTHER = 0, 1, 2, 3
 
@@ -49,7 +49,7 @@ SYMBOLS = {
     'swe2d_get_state': (ctypes.c_int, [_H, _dp, _dp]),
     'swe2d_set_dt': (ctypes.c_int, [_H, ctypes.c_double]),
     'swe2d_set_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),
-    'swe2d_set_bc_field': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
+    'swe2d_set_bc_field': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),
     'swe2d_set_boundary_drag': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_double]),
     'swe2d_set_field': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_set_scalar': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_double]),

@@ -36,7 +36,7 @@ struct Handle {
     double *state[3] = {nullptr, nullptr, nullptr};   // A (U0 / step result), B (U1), C (U2)
     int *nbr = nullptr, *cv = nullptr;
     double *vx = nullptr, *vy = nullptr, *vh = nullptr;
-    double *bc_field[3] = {nullptr, nullptr, nullptr};  // Function-valued boundary data: elev (k planes), uv (2k), un (k)
+    double *bc_field[4] = {nullptr, nullptr, nullptr, nullptr};  // Function-valued boundary data per facet: elev, uv, un, flux
     double *valpha = nullptr;                          // per-vertex wetting-drying alpha
     bool wd = false;
     // SIPG horizontal viscosity (optional pass after each stage kernel)
@@ -166,7 +166,7 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.msrc = h->field[SWE2D_FIELD_MOMENTUM_SOURCE];
     a.vsrc = h->field[SWE2D_FIELD_VOLUME_SOURCE];
     a.wind = h->field[SWE2D_FIELD_WIND_STRESS];
-    a.bc_elev_f = h->bc_field[0]; a.bc_uv_f = h->bc_field[1]; a.bc_un_f = h->bc_field[2];
+    a.bc_elev_f = h->bc_field[0]; a.bc_uv_f = h->bc_field[1]; a.bc_un_f = h->bc_field[2]; a.bc_flux_f = h->bc_field[3];
     a.npc_ = h->npc;
     a.linear_drag = h->scalar[SWE2D_SCALAR_LINEAR_DRAG];
     a.quad_drag = h->scalar[SWE2D_SCALAR_QUADRATIC_DRAG];
@@ -198,7 +198,7 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
         v.nonlin = h->par.use_nonlinear_equations;
         v.eta = h->state[in] + 6*h->stride;
         v.bc = h->bc;
-        v.bc_elev_f = h->bc_field[0]; v.bc_uv_f = h->bc_field[1]; v.bc_un_f = h->bc_field[2];
+        v.bc_elev_f = h->bc_field[0]; v.bc_uv_f = h->bc_field[1]; v.bc_un_f = h->bc_field[2]; v.bc_flux_f = h->bc_field[3];
         hipLaunchKernelGGL(swe_sipg_kernel<2>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         HIP_TRY(h, hipGetLastError());
     }
@@ -399,7 +399,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->nu_v};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -461,10 +461,10 @@ int swe2d_set_bc(swe2d_handle *hh, int marker, int kind, const double values[5])
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
     if (marker <= 0 || marker >= SWE2D_MAX_MARKERS) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "marker out of range");
     if (kind & ~(SWE2D_BC_ELEV | SWE2D_BC_UV | SWE2D_BC_UN | SWE2D_BC_FLUX | SWE2D_BC_ELEV_FIELD | SWE2D_BC_UV_FIELD
-                 | SWE2D_BC_UN_FIELD))
+                 | SWE2D_BC_UN_FIELD | SWE2D_BC_FLUX_FIELD))
         return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "unknown boundary kind bits");
     if (((kind & SWE2D_BC_ELEV_FIELD) && !h->bc_field[0]) || ((kind & SWE2D_BC_UV_FIELD) && !h->bc_field[1])
-        || ((kind & SWE2D_BC_UN_FIELD) && !h->bc_field[2]))
+        || ((kind & SWE2D_BC_UN_FIELD) && !h->bc_field[2]) || ((kind & SWE2D_BC_FLUX_FIELD) && !h->bc_field[3]))
         return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "boundary field not set (swe2d_set_bc_field)");
     if (kind != 0 && !values) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "values required");
     h->bc.kind[marker] = kind;
@@ -478,21 +478,23 @@ int swe2d_set_bc(swe2d_handle *hh, int marker, int kind, const double values[5])
     return SWE2D_OK;
 }
 
-int swe2d_set_bc_field(swe2d_handle *hh, int which, const double *nodal)
+int swe2d_set_bc_field(swe2d_handle *hh, int which, int marker, const double *nodal)
 {
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
-    if (which < 0 || which > 2 || !nodal) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad boundary field");
+    if (which < 0 || which > 3 || !nodal) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad boundary field");
+    if (marker <= 0 || marker >= SWE2D_MAX_MARKERS) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "marker out of range");
     HIP_TRY(h, hipSetDevice(h->device));
     const int ncomp = (which == 1) ? 2 : 1;
+    const size_t bytes = (size_t)2*h->npc*ncomp*h->stride*sizeof(double);
     if (!h->bc_field[which]) {
-        HIP_TRY(h, hipMalloc(&h->bc_field[which], (size_t)h->npc*ncomp*h->stride*sizeof(double)));
-        HIP_TRY(h, hipMemsetAsync(h->bc_field[which], 0, (size_t)h->npc*ncomp*h->stride*sizeof(double), h->stream));
+        HIP_TRY(h, hipMalloc(&h->bc_field[which], bytes));
+        HIP_TRY(h, hipMemsetAsync(h->bc_field[which], 0, bytes, h->stream));
     }
     const size_t n = (size_t)h->n_cells*h->npc;
     HIP_TRY(h, hipMemcpyAsync(h->stage_uv, nodal, (size_t)ncomp*n*sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(swe_nodal_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                       h->stage_uv, h->bc_field[which], h->stride, h->n_cells, ncomp, h->npc);
+    hipLaunchKernelGGL(swe_bc_field_scatter, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                       h->stage_uv, h->bc_field[which], h->stride, h->nbr, h->n_cells, ncomp, h->npc, marker);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SWE2D_OK;

@@ -27,6 +27,7 @@
 #define SWE_BC_ELEV_FIELD 16     // the external elevation is a nodal field (Function-valued boundary data)
 #define SWE_BC_UV_FIELD 32
 #define SWE_BC_UN_FIELD 64
+#define SWE_BC_FLUX_FIELD 128
 #ifndef SWE_BLOCK
 #define SWE_BLOCK 256
 #endif
@@ -66,9 +67,12 @@ struct SweStageArgs {
     const double *msrc;       // 6 planes (x0 x1 x2 y0 y1 y2) or null
     const double *vsrc;       // 3 planes or null
     const double *wind;       // 6 planes (x0.. y0..) wind stress or null
-    const double *bc_elev_f;  // k planes: Function-valued external elevation (read at boundary facet nodes) or null
-    const double *bc_uv_f;    // 2k planes
-    const double *bc_un_f;    // k planes
+    // Function-valued boundary data, stored PER FACET (a corner cell has two boundary facets with different markers that
+    // share a node): plane 2f holds the value at the facet's first node f, plane 2f+1 at its second node f+1
+    const double *bc_elev_f;  // 2k planes: external elevation, or null
+    const double *bc_uv_f;    // 4k planes (u: 0..2k-1, v: 2k..4k-1)
+    const double *bc_un_f;    // 2k planes
+    const double *bc_flux_f;  // 2k planes
     int npc_;                 // nodes per cell (plane offsets of the vector boundary field)
     double linear_drag, quad_drag, manning, norm_smoother;   // <0: off
     SweBcTable bc;
@@ -170,7 +174,7 @@ __device__ __forceinline__ double swe_int2(const double a[3], const double b[3])
 
 // Boundary facet (closed wall or open boundary); rare, so written for clarity with unit normals.
 // Returns the form values f (residual is -f) already multiplied by the facet length.
-struct SweBcFieldValues { double elev, u, v, un; };   // Function-valued boundary data at the quadrature point
+struct SweBcFieldValues { double elev, u, v, un, flux; };   // Function-valued boundary data at the quadrature point
 
 template <bool NONLIN, bool LF, bool WD>
 __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int marker, double uq, double vq, double eq,
@@ -205,7 +209,7 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
             v_ext = un_ext*ny;
         } else if (kind & SWE_BC_FLUX) {
             const double H0 = swe_depth_pt<NONLIN, WD>(hq, e_ext, alq);
-            const double s = p.bc.flux[marker]/(H0*p.bc.len[marker]);
+            const double s = ((kind & SWE_BC_FLUX_FIELD) ? bf.flux : p.bc.flux[marker])/(H0*p.bc.len[marker]);
             u_ext = s*nx;
             v_ext = s*ny;
         }
@@ -250,18 +254,22 @@ __device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int ma
     // Function-valued boundary data live on the same DG nodes as the state: read the two facet nodes of this cell
     const int kind = (marker < SWE_MAX_MARKERS) ? p.bc.kind[marker] : 0;
     const size_t S = p.stride;
-    double fea = 0.0, feb = 0.0, fua = 0.0, fub = 0.0, fva = 0.0, fvb = 0.0, fna = 0.0, fnb = 0.0;
-    if ((kind & SWE_BC_ELEV_FIELD) && p.bc_elev_f) { fea = p.bc_elev_f[(size_t)a*S + k]; feb = p.bc_elev_f[(size_t)b*S + k]; }
+    double fea = 0.0, feb = 0.0, fua = 0.0, fub = 0.0, fva = 0.0, fvb = 0.0, fna = 0.0, fnb = 0.0, fxa = 0.0, fxb = 0.0;
+    const size_t pa = (size_t)(2*a)*S + k, pb = pa + S;            // per-facet planes: facet index = first node a
+    if ((kind & SWE_BC_ELEV_FIELD) && p.bc_elev_f) { fea = p.bc_elev_f[pa]; feb = p.bc_elev_f[pb]; }
     if ((kind & SWE_BC_UV_FIELD) && p.bc_uv_f) {
-        fua = p.bc_uv_f[(size_t)a*S + k]; fub = p.bc_uv_f[(size_t)b*S + k];
-        fva = p.bc_uv_f[(size_t)(p.npc_ + a)*S + k]; fvb = p.bc_uv_f[(size_t)(p.npc_ + b)*S + k];
+        const size_t ov = (size_t)(2*p.npc_)*S;
+        fua = p.bc_uv_f[pa]; fub = p.bc_uv_f[pb];
+        fva = p.bc_uv_f[ov + pa]; fvb = p.bc_uv_f[ov + pb];
     }
-    if ((kind & SWE_BC_UN_FIELD) && p.bc_un_f) { fna = p.bc_un_f[(size_t)a*S + k]; fnb = p.bc_un_f[(size_t)b*S + k]; }
+    if ((kind & SWE_BC_UN_FIELD) && p.bc_un_f) { fna = p.bc_un_f[pa]; fnb = p.bc_un_f[pb]; }
+    if ((kind & SWE_BC_FLUX_FIELD) && p.bc_flux_f) { fxa = p.bc_flux_f[pa]; fxb = p.bc_flux_f[pb]; }
 #pragma unroll 1
     for (int q = 0; q < 2; q++) {
         const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
         SweBcFieldValues bf;
         bf.elev = xa*fea + xb*feb; bf.u = xa*fua + xb*fub; bf.v = xa*fva + xb*fvb; bf.un = xa*fna + xb*fnb;
+        bf.flux = xa*fxa + xb*fxb;
         const double uq = xa*ua + xb*ub, vq = xa*va + xb*vb, eq = xa*ea + xb*eb, hq = xa*ha + xb*hb;
         const double Hq = xa*Ha + xb*Hb, alq = xa*ala + xb*alb;     // Ha, Hb: nodal total depth (h, h + eta or D)
         double fu, fv, fe;
@@ -674,6 +682,23 @@ __global__ void swe_nodal_to_planes(const double *nodal, double *planes, size_t 
     for (int i = 0; i < npc; i++)
         for (int c = 0; c < ncomp; c++)
             planes[(size_t)(npc*c + i)*stride + k] = nodal[(size_t)ncomp*((size_t)npc*k + i) + c];
+}
+
+// Function-valued boundary data of ONE marker: copy the two end-node values of every boundary facet carrying `marker` from a
+// nodal field in host layout into the per-facet planes (plane 2f: node f, plane 2f+1: node f+1; component c: + 2*npc*c)
+__global__ void swe_bc_field_scatter(const double *nodal, double *planes, size_t stride, const int *nbr, int n, int ncomp,
+                                     int npc, int marker)
+{
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    for (int f = 0; f < npc; f++) {
+        if (nbr[(size_t)f*stride + k] != -marker) continue;
+        const int b = (f + 1 == npc) ? 0 : f + 1;
+        for (int c = 0; c < ncomp; c++) {
+            planes[(size_t)(2*npc*c + 2*f)*stride + k] = nodal[(size_t)ncomp*((size_t)npc*k + f) + c];
+            planes[(size_t)(2*npc*c + 2*f + 1)*stride + k] = nodal[(size_t)ncomp*((size_t)npc*k + b) + c];
+        }
+    }
 }
 
 // halo: message layout [n][np] (cell-major, np = 3k planes), so the per-peer segments of one buffer are contiguous

@@ -32,7 +32,7 @@ struct SweSipgArgs {
     int grad_div, grad_depth, nonlin;
     const double *eta;      // 3 planes (total depth of the grad-depth term and of 'flux' boundaries)
     SweBcTable bc;
-    const double *bc_elev_f, *bc_uv_f, *bc_un_f;
+    const double *bc_elev_f, *bc_uv_f, *bc_un_f, *bc_flux_f;     // per-facet planes, see SweStageArgs
     // tracer only
     const double *uv;       // velocity planes (upwind switch of the boundary term)
     double vel_factor;
@@ -197,13 +197,15 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
                 const int kind = p.bc.kind[marker];
                 if (!(kind & (SWE_BC_UN | SWE_BC_UV | SWE_BC_FLUX))) continue;
                 const double sigma = p.sipg*L/A;
-                double fua = 0.0, fub = 0.0, fva = 0.0, fvb = 0.0, fna = 0.0, fnb = 0.0, fea = 0.0, feb = 0.0;
+                double fua = 0.0, fub = 0.0, fva = 0.0, fvb = 0.0, fna = 0.0, fnb = 0.0, fea = 0.0, feb = 0.0, fxa = 0.0, fxb = 0.0;
+                const size_t pa = (size_t)(2*a)*S + k, pb = pa + S;
                 if ((kind & SWE_BC_UV_FIELD) && p.bc_uv_f) {
-                    fua = p.bc_uv_f[(size_t)a*S + k]; fub = p.bc_uv_f[(size_t)bb*S + k];
-                    fva = p.bc_uv_f[(size_t)(3 + a)*S + k]; fvb = p.bc_uv_f[(size_t)(3 + bb)*S + k];
+                    fua = p.bc_uv_f[pa]; fub = p.bc_uv_f[pb];
+                    fva = p.bc_uv_f[6*S + pa]; fvb = p.bc_uv_f[6*S + pb];
                 }
-                if ((kind & SWE_BC_UN_FIELD) && p.bc_un_f) { fna = p.bc_un_f[(size_t)a*S + k]; fnb = p.bc_un_f[(size_t)bb*S + k]; }
-                if ((kind & SWE_BC_ELEV_FIELD) && p.bc_elev_f) { fea = p.bc_elev_f[(size_t)a*S + k]; feb = p.bc_elev_f[(size_t)bb*S + k]; }
+                if ((kind & SWE_BC_UN_FIELD) && p.bc_un_f) { fna = p.bc_un_f[pa]; fnb = p.bc_un_f[pb]; }
+                if ((kind & SWE_BC_ELEV_FIELD) && p.bc_elev_f) { fea = p.bc_elev_f[pa]; feb = p.bc_elev_f[pb]; }
+                if ((kind & SWE_BC_FLUX_FIELD) && p.bc_flux_f) { fxa = p.bc_flux_f[pa]; fxb = p.bc_flux_f[pb]; }
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
                         const double eq = xa*eo[a] + xb*eo[bb], hq = xa*ho[a] + xb*ho[bb];
                         const double e_ext = (kind & SWE_BC_ELEV) ? ((kind & SWE_BC_ELEV_FIELD) ? xa*fea + xb*feb : p.bc.elev[marker]) : eq;
                         const double H0 = p.nonlin ? hq + e_ext : hq;
-                        const double s = p.bc.flux[marker]/(H0*p.bc.len[marker]);
+                        const double s = ((kind & SWE_BC_FLUX_FIELD) ? xa*fxa + xb*fxb : p.bc.flux[marker])/(H0*p.bc.len[marker]);
                         dlt[0] = uq - s*n0; dlt[1] = vq - s*n1;
                     }
                     const double nn[2] = {n0, n1};

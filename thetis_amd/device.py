@@ -180,26 +180,30 @@ class Swe2dDevice(object):
                 kind |= _lib.BC_ELEV
                 if is_field(value):
                     kind |= _lib.BC_ELEV_FIELD
-                    self.set_bc_field(0, value)
+                    self.set_bc_field(0, marker, value)
                 else:
                     vals[0] = float(value)
             elif key == 'uv':
                 kind |= _lib.BC_UV
                 if is_field(value):
                     kind |= _lib.BC_UV_FIELD
-                    self.set_bc_field(1, value)
+                    self.set_bc_field(1, marker, value)
                 else:
                     vals[1], vals[2] = float(value[0]), float(value[1])
             elif key == 'un':
                 kind |= _lib.BC_UN
                 if is_field(value):
                     kind |= _lib.BC_UN_FIELD
-                    self.set_bc_field(2, value)
+                    self.set_bc_field(2, marker, value)
                 else:
                     vals[3] = float(value)
             elif key == 'flux':
                 kind |= _lib.BC_FLUX
-                vals[4] = float(value)
+                if is_field(value):
+                    kind |= _lib.BC_FLUX_FIELD
+                    self.set_bc_field(3, marker, value)
+                else:
+                    vals[4] = float(value)
             elif key == 'drag':
                 pass            # handled below
             else:
@@ -261,14 +265,15 @@ class Swe2dDevice(object):
         """kind: 0 none, 1 prescribed 'diff_flux', 2 upwind-gradient boundary term (any other boundary dict)."""
         self._ck(self.lib.swe2d_tracer_set_diffusion_bc(self.h, int(tracer_id), self._slot(marker), int(kind), float(diff_flux)))
 
-    def set_bc_field(self, which, nodal):
-        """Function-valued boundary data: nodal DG values (N,k) [(N,k,2) for which = 1] shared by all markers."""
+    def set_bc_field(self, which, slot, nodal):
+        """Function-valued boundary data of one marker slot: nodal DG values (N,k) [(N,k,2) for which = 1]; which = 0 elev,
+        1 uv, 2 un, 3 flux."""
         shape = (self.n_cells, self.npc, 2) if which == 1 else (self.n_cells, self.npc)
         a = np.asarray(nodal, dtype=np.float64).reshape(shape)
         if self.perm is not None:
             a = a[self.perm]
         a = np.ascontiguousarray(a)
-        self._ck(self.lib.swe2d_set_bc_field(self.h, int(which), _ptr(a)))
+        self._ck(self.lib.swe2d_set_bc_field(self.h, int(which), int(slot), _ptr(a)))
 
     def set_field(self, field, nodal):
         if nodal is None:

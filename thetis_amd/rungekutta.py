@@ -162,7 +162,7 @@ class ERKGenericShuOsher(TimeIntegrator):
                     raise Exception('Invalid boundary tag "{:}" specified on boundary {:}'.format(key, marker))
                 if isinstance(v, Function):
                     # Function-valued boundary data (e.g. a tidal elevation field): nodal values at the DG nodes
-                    if key not in ('elev', 'uv', 'un'):
+                    if key not in ('elev', 'uv', 'un', 'flux'):
                         raise NotImplementedError("'{:}' must be a constant on the device path".format(key))
                     vals[key] = np.ascontiguousarray(v.cell_node_values() if v.function_space().family == 'DG'
                                                      else v.dat.data_ro[mesh.cells])
