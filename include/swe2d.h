@@ -195,6 +195,9 @@ int  swe2d_tracer_get_state(swe2d_handle *h, int tracer_id, double *nodal);
 /* bnd_functions['tracer_2d'][marker] = {'value': c}; has_value = 0 restores the default boundary term
  * c (u.n) phi (tracer_eq_2d.py:177-191).  Velocity-type keys are not supported. */
 int  swe2d_tracer_set_bc(swe2d_handle *h, int tracer_id, int marker, int has_value, double value);
+/* Function-valued 'value' on `marker`: nodal DG values of the whole mesh in the host layout (kN); only cells with a
+ * boundary facet carrying `marker` are copied (all their nodes: the diffusive boundary term uses the cell gradient) */
+int  swe2d_tracer_set_bc_field(swe2d_handle *h, int tracer_id, int marker, const double *nodal);
 int  swe2d_tracer_set_source(swe2d_handle *h, int tracer_id, const double *nodal);   /* SourceTerm tracer_eq_2d.py:281-298 */
 /* options.tracer[label].use_conservative_form (options.py:543): the tracer field is the depth-integrated q = H*T and the
  * stage kernels evaluate ConservativeHorizontalAdvectionTerm / ConservativeSourceTerm (tracer_eq_2d.py:325-437) */
@@ -204,10 +207,13 @@ int  swe2d_tracer_set_conservative(swe2d_handle *h, int tracer_id, int use_conse
 int  swe2d_tracer_set_diffusivity(swe2d_handle *h, int tracer_id, int enable, const double *mu_vertex, double mu_const,
                                   double sipg_factor_tracer);
 /* boundary term of the diffusion operator on `marker` (tracer_eq_2d.py:264-277): kind 0 = none (no boundary dict),
- * 1 = prescribed 'diff_flux' (-phi*diff_flux), 2 = any other boundary dict (-phi mu s grad(c).n, s the upwind switch) */
+ * 1 = prescribed 'diff_flux' (-phi*diff_flux); otherwise -phi mu grad(c_up).n with c_up = s c + (1-s) c_ext, s the upwind
+ * switch: 2 = constant 'value' (grad c_ext = 0), 3 = boundary dict without 'value' (c_ext = c), 4 = Function 'value' */
 #define SWE2D_DIFF_BC_NONE 0
 #define SWE2D_DIFF_BC_DIFF_FLUX 1
 #define SWE2D_DIFF_BC_UPWIND 2
+#define SWE2D_DIFF_BC_GRAD_IN 3
+#define SWE2D_DIFF_BC_VALUE_FIELD 4
 int  swe2d_tracer_set_diffusion_bc(swe2d_handle *h, int tracer_id, int marker, int kind, double diff_flux);
 int  swe2d_tracer_solve_stage(swe2d_handle *h, int tracer_id, int i_stage);          /* rungekutta.py:930-946 for the tracer */
 int  swe2d_tracer_tendency(swe2d_handle *h, int tracer_id, double *k_nodal);

@@ -274,3 +274,52 @@ def test_tracer_forward_euler_matches_oracle(hip_lib):
         To = To + orc.tracer_tendency(To, uv, eta, dt)
     assert rel_linf(dev.tracer_get_state(tid), To) < TOL
     dev.close()
+
+
+@pytest.mark.parametrize('cells', ['triangles', 'quadrilaterals'])
+def test_function_valued_tracer_boundary_matches_oracle(hip_lib, cells):
+    """bnd_functions['tracer'][marker] = {'value': Function}: advective boundary flux on both cell types, and on triangles
+    the diffusive boundary term with the cell gradient of the external value (tracer_eq_2d.py:270-276)."""
+    from helpers import make_oracle_generic, quad_case
+    if cells == 'triangles':
+        mesh, bath, uv, eta = channel_case(nx=6, ny=4, seed=51)
+        orc = make_oracle(mesh, bath)
+    else:
+        mesh, bath, uv, eta = quad_case(nx=6, ny=4, seed=51)
+        orc = make_oracle_generic(mesh, bath)
+    k = mesh.cells.shape[1]
+    rng = np.random.default_rng(15)
+    T = rng.normal(size=(mesh.num_cells, k))
+    bcs = {1: {'value': rng.normal(size=T.shape)}, 2: {'value': rng.normal(size=T.shape)}, 3: {'value': 0.7}, 4: {'elev': 0.1}}
+    dt = 2.0
+    dev = _dev(mesh, bath, dt, boundary_len=mesh.boundary_len)
+    tid = dev.add_tracer()
+    kw = dict(bnd_conditions=bcs)
+    for m_ in (1, 2):
+        dev.tracer_set_bc(tid, m_, bcs[m_]['value'])
+    dev.tracer_set_bc(tid, 3, 0.7)
+    if cells == 'triangles':
+        kw.update(diffusivity=40.0)
+        dev.tracer_set_diffusivity(tid, 40.0)
+        for m_, kind in ((1, 4), (2, 4), (3, 2), (4, 3)):
+            dev.tracer_set_diffusion_bc(tid, m_, kind)
+    dev.set_state(uv, eta)
+    dev.tracer_set_state(tid, T)
+    assert rel_linf(dev.tracer_tendency(tid), orc.tracer_tendency(T, uv, eta, dt, **kw)) < TOL
+    for s in range(3):
+        dev.tracer_solve_stage(tid, s)
+    assert rel_linf(dev.tracer_get_state(tid), orc.tracer_ssprk33_step(T, uv, eta, dt, **kw)) < TOL
+    dev.close()
+
+
+@pytest.mark.parametrize('name,conservative', [('setup1', False), ('setup1', True), ('setup2', False), ('setup2', True),
+                                               ('setup3', False), ('setup3', True), ('setup4', True)])
+def test_tracer_adv_diff_mms_convergence(hip_lib, name, conservative):
+    """test/tracerEq/test_steady_adv-diff_mms_2d.py::test_convergence / test_convergence_conservative_only with SSPRK33:
+    refinements [1, 2, 3], second order within the reference's 20 % slope tolerance."""
+    from scipy import stats
+    import mms_tracer
+    refs = [1, 2, 3]
+    errs = [mms_tracer.run_device(name, r, conservative) for r in refs]
+    slope = stats.linregress(np.log10(np.array(refs, dtype=float)**-1), np.log10(errs)).slope
+    assert abs(slope - 2.0)/2.0 < 0.2, (errs, slope)

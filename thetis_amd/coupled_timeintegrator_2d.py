@@ -5,6 +5,7 @@ fields of the same C-ABI handle that steps the shallow water equations.
 """
 import numpy as np
 
+from .function import Function
 from .log import print_output
 from .options import Constant
 from .timeintegrator import TimeIntegratorBase
@@ -53,14 +54,23 @@ class DeviceTracerSSPRK33(object):
         for marker in self.equation.mesh.boundary_markers:
             funcs = self.bnd_conditions.get(marker)
             v = None if funcs is None else funcs.get('value')
-            self.device.tracer_set_bc(self.tid, marker, _cval(v))
+            is_field = isinstance(v, Function)
+            if is_field:            # Function-valued 'value': nodal values at the DG nodes
+                v = np.ascontiguousarray(v.cell_node_values() if v.function_space().family == 'DG'
+                                         else v.dat.data_ro[self.equation.mesh.cells])
+                self.device.tracer_set_bc(self.tid, marker, v)
+            else:
+                self.device.tracer_set_bc(self.tid, marker, _cval(v))
             if self.diffusive:                  # boundary term of the diffusion operator, tracer_eq_2d.py:264-277
                 if funcs is None:
-                    self.device.tracer_set_diffusion_bc(self.tid, marker, 0)
+                    kind, dfl = 0, 0.0
                 elif 'diff_flux' in funcs:
-                    self.device.tracer_set_diffusion_bc(self.tid, marker, 1, _cval(funcs['diff_flux']))
+                    kind, dfl = 1, _cval(funcs['diff_flux'])
+                elif 'value' not in funcs:
+                    kind, dfl = 3, 0.0
                 else:
-                    self.device.tracer_set_diffusion_bc(self.tid, marker, 2)
+                    kind, dfl = (4 if is_field else 2), 0.0
+                self.device.tracer_set_diffusion_bc(self.tid, marker, kind, dfl)
 
     def _pull(self):
         if self._device_ahead:

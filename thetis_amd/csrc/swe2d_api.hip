@@ -56,6 +56,7 @@ struct Handle {
         double *buf[3] = {nullptr, nullptr, nullptr};   // A (T0 / result), B, C: 3 planes each
         double *source = nullptr;
         bool conservative = false;                      // options.tracer[label].use_conservative_form
+        double *bc_value_f = nullptr;                   // Function-valued 'value' boundaries, npc*npc planes
         int bc_has_value[SWE_MAX_MARKERS];
         double bc_value[SWE_MAX_MARKERS];
         bool diff = false;                              // SIPG horizontal diffusion
@@ -396,6 +397,7 @@ void swe2d_destroy(swe2d_handle *hh)
         for (int b = 0; b < 3; b++) if (t.buf[b]) (void)hipFree(t.buf[b]);
         if (t.source) (void)hipFree(t.source);
         if (t.mu_v) (void)hipFree(t.mu_v);
+        if (t.bc_value_f) (void)hipFree(t.bc_value_f);
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
@@ -857,6 +859,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     a.depth_mode = h->wd ? 2 : (h->par.use_nonlinear_equations ? 1 : 0);
     a.vh = h->vh; a.valpha = h->valpha;
     for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_has_value[m] = t.bc_has_value[m]; a.bc_value[m] = t.bc_value[m]; }
+    a.bc_value_f = t.bc_value_f;
     tracer_kernel_t kern = (h->npc == 4) ? pick_tracer_kernel_quad(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr)
                                          : pick_tracer_kernel(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr);
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
@@ -877,6 +880,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
         v.uv = h->state[0];
         v.vel_factor = h->tracer_vel_factor;
         for (int m = 0; m < SWE_MAX_MARKERS; m++) { v.bc_diff_kind[m] = t.bc_diff_kind[m]; v.bc_diff_flux[m] = t.bc_diff_flux[m]; }
+        v.bc_value_f = t.bc_value_f;
         hipLaunchKernelGGL(swe_sipg_kernel<1>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         HIP_TRY(h, hipGetLastError());
     }
@@ -1050,6 +1054,28 @@ int swe2d_tracer_set_bc(swe2d_handle *hh, int id, int marker, int has_value, dou
     return SWE2D_OK;
 }
 
+int swe2d_tracer_set_bc_field(swe2d_handle *hh, int id, int marker, const double *nodal)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (marker <= 0 || marker >= SWE2D_MAX_MARKERS || !nodal) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad boundary field");
+    HIP_TRY(h, hipSetDevice(h->device));
+    Handle::Tracer &t = h->tracers[id];
+    const size_t bytes = (size_t)h->npc*h->npc*h->stride*sizeof(double);
+    if (!t.bc_value_f) {
+        HIP_TRY(h, hipMalloc(&t.bc_value_f, bytes));
+        HIP_TRY(h, hipMemsetAsync(t.bc_value_f, 0, bytes, h->stream));
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->stage_eta, nodal, (size_t)h->npc*h->n_cells*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(swe_bc_cellfield_scatter, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                       h->stage_eta, t.bc_value_f, h->stride, h->nbr, h->n_cells, h->npc, marker);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    t.bc_has_value[marker] = 2;
+    return SWE2D_OK;
+}
+
 int swe2d_tracer_set_source(swe2d_handle *hh, int id, const double *nodal)
 {
     Handle *h = H(hh);
@@ -1117,7 +1143,9 @@ int swe2d_tracer_set_diffusion_bc(swe2d_handle *hh, int id, int marker, int kind
     int rc = check_tracer(h, id);
     if (rc) return rc;
     if (marker <= 0 || marker >= SWE2D_MAX_MARKERS) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "marker out of range");
-    if (kind < SWE_SIPG_BC_NONE || kind > SWE_SIPG_BC_UPWIND) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad diffusion boundary kind");
+    if (kind < SWE_SIPG_BC_NONE || kind > SWE_SIPG_BC_VALUE_FIELD) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad diffusion boundary kind");
+    if (kind == SWE_SIPG_BC_VALUE_FIELD && !h->tracers[id].bc_value_f)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "boundary field not set (swe2d_tracer_set_bc_field)");
     h->tracers[id].bc_diff_kind[marker] = kind;
     h->tracers[id].bc_diff_flux[marker] = diff_flux;
     return SWE2D_OK;

@@ -701,6 +701,19 @@ __global__ void swe_bc_field_scatter(const double *nodal, double *planes, size_t
     }
 }
 
+// Function-valued tracer boundary value of ONE marker: all npc nodal values of the cell are kept per boundary facet (the
+// diffusive boundary term needs the cell gradient of the external value, tracer_eq_2d.py:270-276): plane npc*f + i
+__global__ void swe_bc_cellfield_scatter(const double *nodal, double *planes, size_t stride, const int *nbr, int n, int npc,
+                                         int marker)
+{
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    for (int f = 0; f < npc; f++) {
+        if (nbr[(size_t)f*stride + k] != -marker) continue;
+        for (int i = 0; i < npc; i++) planes[(size_t)(npc*f + i)*stride + k] = nodal[(size_t)npc*k + i];
+    }
+}
+
 // halo: message layout [n][np] (cell-major, np = 3k planes), so the per-peer segments of one buffer are contiguous
 __global__ void swe_halo_pack(const double *planes, size_t stride, const int *cells, int n, double *buf, int np)
 {
@@ -782,8 +795,9 @@ struct SweTracerArgs {
     int conservative;      // ConservativeHorizontalAdvectionTerm / ConservativeSourceTerm (tracer_eq_2d.py:325-437)
     int depth_mode;        // total depth of the conservative source term: 0 = h, 1 = h + eta, 2 = wetting-drying D
     const double *vh, *valpha;
-    int bc_has_value[SWE_MAX_MARKERS];
+    int bc_has_value[SWE_MAX_MARKERS];   // 0: no 'value', 1: constant, 2: Function (bc_value_f)
     double bc_value[SWE_MAX_MARKERS];
+    const double *bc_value_f;            // k*k planes: plane k*f + i = node i of the cell for its boundary facet f, or null
 };
 
 template <bool LF, bool HAST0, bool SRC>
@@ -906,7 +920,9 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
             } else {
                 const int marker = -nb[f];
                 if (marker < SWE_MAX_MARKERS && p.bc_has_value[marker]) {                  // :181-188, uv_ext = uv_in
-                    const double cext = p.bc_value[marker];
+                    const double cext = (p.bc_has_value[marker] == 2)
+                        ? xa*p.bc_value_f[(size_t)(3*f + a)*S + k] + xb*p.bc_value_f[(size_t)(3*f + bb)*S + k]
+                        : p.bc_value[marker];
                     const double cup = unown > 0.0 ? cq : (unown < 0.0 ? cext : 0.5*(cq + cext));
                     fq = cup*unown;
                 } else {
@@ -1428,7 +1444,9 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
             } else {
                 const int marker = -nb[f];
                 if (marker < SWE_MAX_MARKERS && p.bc_has_value[marker]) {
-                    const double cext = p.bc_value[marker];
+                    const double cext = (p.bc_has_value[marker] == 2)
+                        ? xa*p.bc_value_f[(size_t)(4*f + a)*S + k] + xb*p.bc_value_f[(size_t)(4*f + bb)*S + k]
+                        : p.bc_value[marker];
                     const double cup = unown > 0.0 ? cq : (unown < 0.0 ? cext : 0.5*(cq + cext));
                     fq = cup*unown;
                 } else {

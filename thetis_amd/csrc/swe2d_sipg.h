@@ -15,7 +15,9 @@
 
 #define SWE_SIPG_BC_NONE 0          // funcs is None: no boundary term
 #define SWE_SIPG_BC_DIFF_FLUX 1     // tracer 'diff_flux'                            tracer_eq_2d.py:267-268
-#define SWE_SIPG_BC_UPWIND 2        // tracer, any other funcs: -phi mu s grad(c).n  tracer_eq_2d.py:270-276
+#define SWE_SIPG_BC_UPWIND 2        // tracer, constant 'value': -phi mu s grad(c).n (grad c_ext = 0)   tracer_eq_2d.py:270-276
+#define SWE_SIPG_BC_GRAD_IN 3       // tracer, funcs without 'value' (c_ext = c_in): -phi mu grad(c).n
+#define SWE_SIPG_BC_VALUE_FIELD 4   // tracer, Function 'value': -phi mu (s grad(c) + (1-s) grad(c_ext)).n
 
 struct SweSipgArgs {
     const double *in;       // 3*NC planes: row c, node i at in[(3c + i)*S + k]
@@ -38,6 +40,7 @@ struct SweSipgArgs {
     double vel_factor;
     int bc_diff_kind[SWE_MAX_MARKERS];
     double bc_diff_flux[SWE_MAX_MARKERS];
+    const double *bc_value_f;   // 9 planes (3f + i), see SweTracerArgs
 };
 
 template <int NC>
@@ -241,10 +244,18 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
             } else {
                 const int kd = p.bc_diff_kind[marker];
                 if (kd == SWE_SIPG_BC_NONE) continue;
-                double ua = 0.0, ub = 0.0, va = 0.0, vb = 0.0;
-                if (kd == SWE_SIPG_BC_UPWIND) {
+                double ua = 0.0, ub = 0.0, va = 0.0, vb = 0.0, gex = 0.0, gey = 0.0;
+                if (kd == SWE_SIPG_BC_UPWIND || kd == SWE_SIPG_BC_VALUE_FIELD) {
                     ua = p.vel_factor*p.uv[(size_t)a*S + k]; ub = p.vel_factor*p.uv[(size_t)bb*S + k];
                     va = p.vel_factor*p.uv[(size_t)(3 + a)*S + k]; vb = p.vel_factor*p.uv[(size_t)(3 + bb)*S + k];
+                }
+                if (kd == SWE_SIPG_BC_VALUE_FIELD) {               // cell gradient of the boundary Function
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        const double ce = p.bc_value_f[(size_t)(3*f + i)*S + k];
+                        gex += ce*gx[i];
+                        gey += ce*gy[i];
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
@@ -255,8 +266,8 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
                     } else {
                         const double muq = xa*mu[a] + xb*mu[bb];
                         const double un = (xa*ua + xb*ub)*n0 + (xa*va + xb*vb)*n1;          // uv_ext = uv_in
-                        const double s = un > 0.0 ? 1.0 : (un < 0.0 ? 0.0 : 0.5);
-                        val = -muq*s*(G[0][0]*n0 + G[0][1]*n1);
+                        const double s = (kd == SWE_SIPG_BC_GRAD_IN) ? 1.0 : (un > 0.0 ? 1.0 : (un < 0.0 ? 0.0 : 0.5));
+                        val = -muq*((s*G[0][0] + (1.0 - s)*gex)*n0 + (s*G[0][1] + (1.0 - s)*gey)*n1);
                     }
                     b[0][a] -= w*xa*val;
                     b[0][bb] -= w*xb*val;

@@ -262,7 +262,7 @@ class Swe2dDevice(object):
                                                        float(sipg_factor_tracer)))
 
     def tracer_set_diffusion_bc(self, tracer_id, marker, kind, diff_flux=0.0):
-        """kind: 0 none, 1 prescribed 'diff_flux', 2 upwind-gradient boundary term (any other boundary dict)."""
+        """kind: 0 none, 1 prescribed 'diff_flux', 2 constant 'value', 3 boundary dict without 'value', 4 Function 'value'."""
         self._ck(self.lib.swe2d_tracer_set_diffusion_bc(self.h, int(tracer_id), self._slot(marker), int(kind), float(diff_flux)))
 
     def set_bc_field(self, which, slot, nodal):
@@ -367,7 +367,10 @@ class Swe2dDevice(object):
         return self._nodal_out(a)
 
     def tracer_set_bc(self, tid, marker, value):
-        """``value``: constant Dirichlet value or None (default boundary term)."""
+        """``value``: constant Dirichlet value, nodal DG array (N,k) of a Function, or None (default boundary term)."""
+        if isinstance(value, np.ndarray) and value.ndim >= 2:
+            self._ck(self.lib.swe2d_tracer_set_bc_field(self.h, tid, self._slot(marker), _ptr(self._nodal_in(value))))
+            return
         self._ck(self.lib.swe2d_tracer_set_bc(self.h, tid, self._slot(marker), 0 if value is None else 1,
                                               0.0 if value is None else float(value)))
 

@@ -146,8 +146,21 @@ class Function(object):
                 or (not callable(expr)):
             # P1 (CG or DG on the same mesh) and constants are in the DG-P1 space: projection = injection
             return self.interpolate(expr)
+        if fs.family == 'CG' and fs.degree == 1 and not fs.vector:
+            # global L2 projection onto the continuous P1 space (bathymetry_2d.project(expr) in the reference's tests)
+            from .cgproject import project_to_p1
+            mesh = fs.mesh_obj
+            p = mesh.cell_xy()
+
+            def integrand(lam, cells):
+                xq = np.einsum('nic,i->nc', p, lam)
+                return np.asarray(expr(xq[:, 0], xq[:, 1]))*np.ones(len(cells))
+            self._pull()
+            self._data[...] = project_to_p1(mesh, integrand).reshape(self._data.shape)
+            self._host_version += 1
+            return self
         if fs.family != 'DG' or fs.degree != 1:
-            raise NotImplementedError('projection of expressions is implemented for DG-P1 targets only')
+            raise NotImplementedError('projection of expressions is implemented for DG-P1 and scalar CG-P1 targets only')
         mesh = fs.mesh_obj
         npc = fs.npc
         bary, w = cell_quadrature(npc)

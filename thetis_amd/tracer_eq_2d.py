@@ -7,6 +7,7 @@ constant ``'value'``; ``HorizontalDiffusionTerm`` (SIPG, :196-278) by the pass k
 (csrc/swe2d_sipg.h; triangles, Constant or CG-P1 diffusivity, ``'diff_flux'`` boundaries); the conservative form
 (:325-437) is a flag of the same kernels.  Everything else (SUPG :490-501, CG tracers, velocity-type boundary keys) raises instead of silently changing the physics.
 """
+from .function import Function
 from .options import Constant
 
 __all__ = ['TracerEquation2D']
@@ -37,5 +38,7 @@ class TracerEquation2D(object):
                 if key not in ('value', 'elev', 'diff_flux'):
                     raise NotImplementedError('tracer boundary key {!r} is not on the device path '
                                               '(only "value" and "diff_flux")'.format(key))
-                if key in ('value', 'diff_flux') and not isinstance(v, (int, float, Constant)):
-                    raise NotImplementedError('tracer boundary values must be constants on the device path')
+                if key == 'diff_flux' and not isinstance(v, (int, float, Constant)):
+                    raise NotImplementedError("'diff_flux' must be a constant on the device path")
+                if key == 'value' and not isinstance(v, (int, float, Constant, Function)):
+                    raise NotImplementedError('tracer boundary values must be Constants or Functions on the device path')
