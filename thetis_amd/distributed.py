@@ -277,6 +277,13 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
     solver.dev.close()
     dist.destroy_process_group()
     if rank == 0:
+        import ctypes
         import sys
+        # RCCL's banner sits in the C stdio buffer (flushed at exit when stdout is a pipe or a file): flush it now so that
+        # the JSON line is the last thing on stdout
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
