@@ -260,3 +260,51 @@ def test_per_marker_boundary_fields_with_corner_cells(hip_lib):
     assert rel_linf(ku, ku_o) < TOL_RHS and rel_linf(ke, ke_o) < TOL_RHS
     assert rel_linf(ku[corner], ku_o[corner]) < TOL_RHS
     dev.close()
+
+
+def test_edge_cases_of_the_c_abi(hip_lib):
+    """Smallest meshes (2 cells; 1 cell with walls all round), zero steps, ragged block tails (n not a multiple of 256 or
+    of the 8-block XCD grid), invalid arguments returning error codes instead of crashing."""
+    from thetis_amd import _lib
+    from thetis_amd.mesh import Mesh2d, RectangleMesh
+    # one triangle, three wall facets
+    xy = np.array([[0.0, 0.0], [100.0, 0.0], [0.0, 80.0]])
+    mesh = Mesh2d(xy, np.array([[0, 1, 2]]))
+    bath = np.full(3, 5.0)
+    uv = np.array([[[0.1, -0.2], [0.05, 0.1], [-0.1, 0.0]]])
+    eta = np.array([[0.01, -0.02, 0.03]])
+    from oracle.swe2d_oracle import SWEOracle
+    orc = SWEOracle(mesh.vertex_xy, mesh.cells, bath)        # every exterior facet: marker 1, closed
+    dev = _device(mesh, bath, 0.5)
+    dev.set_state(uv, eta)
+    dev.advance(0)                                           # no-op
+    u0, e0 = dev.get_state()
+    assert np.array_equal(u0, uv) and np.array_equal(e0, eta)
+    dev.advance(2)
+    u, e = dev.get_state()
+    uo, eo = uv, eta
+    for _ in range(2):
+        uo, eo = orc.ssprk33_step(uo, eo, 0.5)
+    assert rel_linf(u, uo) < TOL_RHS and rel_linf(e, eo) < TOL_RHS
+    # invalid arguments: error codes + message, handle stays usable
+    assert hip_lib.swe2d_solve_stage(dev.h, 3) != 0
+    assert b'i_stage' in hip_lib.swe2d_last_error(dev.h)
+    assert hip_lib.swe2d_advance(dev.h, -1) != 0
+    assert hip_lib.swe2d_set_dt(dev.h, -1.0) != 0
+    assert hip_lib.swe2d_set_bc(dev.h, 99, 1, None) != 0
+    assert hip_lib.swe2d_tracer_solve_stage(dev.h, 0, 0) != 0          # no such tracer
+    dev.advance(1)
+    dev.close()
+    # ragged sizes: 2, 254, 258 and 2050 cells (block tail, XCD-grid padding)
+    for nx, ny in ((1, 1), (127, 1), (129, 1), (41, 25)):
+        mesh = RectangleMesh(nx, ny, 1000.0*nx, 900.0*ny)
+        rng = np.random.default_rng(nx)
+        bath = 10.0 + rng.uniform(size=mesh.num_vertices)
+        uv = 0.1*rng.normal(size=(mesh.num_cells, 3, 2))
+        eta = 0.05*rng.normal(size=(mesh.num_cells, 3))
+        dev = _device(mesh, bath, 1.0)
+        dev.set_state(uv, eta)
+        ku, ke = dev.tendency()
+        ku_o, ke_o = make_oracle(mesh, bath).tendency(uv, eta, 1.0)
+        assert rel_linf(ku, ku_o) < TOL_RHS and rel_linf(ke, ke_o) < TOL_RHS
+        dev.close()
