@@ -73,6 +73,15 @@ def main():
            timed(dev, lambda k: dev.advance_coupled(k, tracer_only=False, use_limiter=True), 50))
     report('cfg4 tracer only + limiter', n, 444.0 + 116.0,
            timed(dev, lambda k: dev.advance_coupled(k, tracer_only=True, use_limiter=True), 50))
+    # ---- optional SIPG passes (swe2d_sipg.h): per stage the pass re-reads the rows (+ neighbour rows through L2) and
+    #      read-modify-writes them: viscosity 48 r + 48 r/w + 24 eta + 36 static = 204 B, tracer diffusion 24 + 48 + 36 = 108 B
+    dev.tracer_set_diffusivity(tid, 10.0)
+    report('tracer only + SIPG diffusion (no limiter)', n, 444.0 + 3*108.0,
+           timed(dev, lambda k: dev.advance_coupled(k, tracer_only=True, use_limiter=False), 50))
+    dev.tracer_set_diffusivity(tid, None)
+    dev.set_viscosity(10.0)
+    report('cfg2 + SIPG viscosity', n, 684.0 + 3*204.0, timed(dev, dev.advance, 50))
+    dev.set_viscosity(None)
     dev.close()
     # ---- cfg 5: wetting-drying variant on the Balzano geometry, 500k triangles (+12 B alpha per cell-stage via vertices ~ +6)
     mesh5 = RectangleMesh(707, 354, 13800.0, 7200.0)
