@@ -1,12 +1,14 @@
 """
 ``FlowSolver2d``: the user-facing driver with the reference's surface (thetis/solver2d.py) - options, boundary
 functions, ``assign_initial_conditions`` and the ``iterate`` / ``create_iterator`` time loop - whose time stepper is
-the MI355X-resident SSPRK33 (thetis_amd/rungekutta.py -> C ABI -> HIP stage kernel).
+the MI355X-resident SSPRK33 or ForwardEuler (thetis_amd/rungekutta.py -> C ABI -> HIP stage kernels), coupled with the
+2D tracers and the vertex limiter when ``options.add_tracer_2d`` is used.
 
 Kept from the reference: option names and defaults, generator semantics of ``create_iterator`` (yields the time
 *before* it is incremented, solver2d.py:1122-1127), export cadence with ``t_epsilon = 1e-5`` (:1036),
 ``simulation_time = t0 + k*dt`` (:1127), ``print_state`` line format (:931-970), the ``steppers`` table (:662-672).
-Not kept: exporters (VTK/HDF5 I/O), log files, ``load_state``, the implicit steppers and the 3D/NH/sediment couplings.
+Exports are VTK (.vtu/.pvd) plus .npz checkpoints that ``load_state`` reads back (thetis_amd/exporter.py; h5py is not
+available here).  Not kept: log files, the implicit steppers and the 3D/NH/sediment couplings.
 """
 import math
 import sys
