@@ -35,6 +35,8 @@ struct Handle {
     size_t stride = 0;
     double *state[3] = {nullptr, nullptr, nullptr};   // A (U0 / step result), B (U1), C (U2)
     int *nbr = nullptr, *cv = nullptr;
+    int4 *idx4 = nullptr;                               // packed triangle connectivity (stage kernel), see SweStageArgs
+    int2 *idx2 = nullptr;
     double *vx = nullptr, *vy = nullptr, *vh = nullptr;
     double *bc_field[4] = {nullptr, nullptr, nullptr, nullptr};  // Function-valued boundary data per facet: elev, uv, un, flux
     double *valpha = nullptr;                          // per-vertex wetting-drying alpha
@@ -157,6 +159,7 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.cv = h->cv;
     a.vx = h->vx; a.vy = h->vy; a.vh = h->vh;
     a.valpha = h->valpha;
+    a.idx4 = h->idx4; a.idx2 = h->idx2;
     a.cell_begin = c0; a.cell_end = c1;
     a.g = h->par.g_grav;
     a.sigma_lf = h->par.lax_friedrichs_velocity_scaling_factor;
@@ -374,6 +377,18 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
     for (int m = 0; m < SWE2D_MAX_MARKERS; m++) h->bc.drag[m] = -1.0;
     for (int m = 0; m < SWE2D_MAX_MARKERS; m++) h->bc.len[m] = mesh->boundary_len ? mesh->boundary_len[m] : blen[m];
 
+    if (npc == 3) {
+        std::vector<int4> p4((size_t)S, int4{0, 0, 0, 0});
+        std::vector<int2> p2((size_t)S, int2{0, 0});
+        for (int kk = 0; kk < n; kk++) {
+            p4[kk] = int4{nbr[kk], nbr[S + kk], nbr[2*S + kk], cv[kk]};
+            p2[kk] = int2{cv[S + kk], cv[2*S + kk]};
+        }
+        HIP_TRY_C(hipMalloc(&h->idx4, (size_t)S*sizeof(int4)));
+        HIP_TRY_C(hipMalloc(&h->idx2, (size_t)S*sizeof(int2)));
+        HIP_TRY_C(hipMemcpy(h->idx4, p4.data(), (size_t)S*sizeof(int4), hipMemcpyHostToDevice));
+        HIP_TRY_C(hipMemcpy(h->idx2, p2.data(), (size_t)S*sizeof(int2), hipMemcpyHostToDevice));
+    }
     HIP_TRY_C(hipMemcpyAsync(h->nbr, nbr.data(), (size_t)npc*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY_C(hipMemcpyAsync(h->cv, cv.data(), (size_t)npc*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY_C(hipMemcpyAsync(h->vx, vx.data(), (size_t)nv*sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -401,7 +416,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

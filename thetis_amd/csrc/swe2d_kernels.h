@@ -58,6 +58,10 @@ struct SweStageArgs {
     const int *cv;         // 3 planes: vertex ids
     const double *vx, *vy, *vh;   // per vertex: coordinates, bathymetry
     const double *valpha;         // per vertex: wetting-drying parameter alpha (WD variant)
+    // packed copy of the triangle connectivity for the stage kernel: idx4[k] = {nbr0, nbr1, nbr2, cv0}, idx2[k] = {cv1, cv2}
+    // (one 16-B and one 8-B load per lane instead of six 4-B loads from six planes)
+    const int4 *idx4;
+    const int2 *idx2;
     int cell_begin, cell_end;
     double g, sigma_lf, dt;
     double a0, a1, beta;   // U_out = beta*k + a0*U0 + a1*U_in
@@ -475,10 +479,11 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     //      (own data + indices, then the gathers) instead of one per facet and one per output plane.
     double u[3], v[3], e[3];
     int nb[3], vid[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        nb[i] = p.nbr[(size_t)i*S + k];
-        vid[i] = p.cv[(size_t)i*S + k];
+    {
+        const int4 q4 = p.idx4[k];
+        const int2 q2 = p.idx2[k];
+        nb[0] = q4.x; nb[1] = q4.y; nb[2] = q4.z;
+        vid[0] = q4.w; vid[1] = q2.x; vid[2] = q2.y;
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
