@@ -865,6 +865,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     a.uv = h->state[0];
     a.stride = h->stride;
     a.nbr = h->nbr; a.cv = h->cv; a.vx = h->vx; a.vy = h->vy;
+    a.idx4 = h->idx4; a.idx2 = h->idx2;
     a.cell_begin = c0; a.cell_end = c1;
     a.dt = h->par.dt; a.a0 = a0; a.a1 = a1; a.beta = beta;
     a.vel_factor = h->tracer_vel_factor;

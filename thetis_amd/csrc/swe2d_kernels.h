@@ -791,6 +791,8 @@ struct SweTracerArgs {
     const double *uv;      // SWE state planes (u0 u1 u2 v0 v1 v2 ...): the advecting velocity
     size_t stride;
     const int *nbr, *cv;
+    const int4 *idx4;      // packed triangle connectivity, see SweStageArgs (null for quadrilaterals)
+    const int2 *idx2;
     const double *vx, *vy;
     int cell_begin, cell_end;
     double dt, a0, a1, beta;
@@ -820,10 +822,11 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
 
     double u[3], v[3], c[3], w[3];
     int nb[3], vid[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        nb[i] = p.nbr[(size_t)i*S + k];
-        vid[i] = p.cv[(size_t)i*S + k];
+    {
+        const int4 q4 = p.idx4[k];
+        const int2 q2 = p.idx2[k];
+        nb[0] = q4.x; nb[1] = q4.y; nb[2] = q4.z;
+        vid[0] = q4.w; vid[1] = q2.x; vid[2] = q2.y;
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
