@@ -56,9 +56,17 @@ def cpu_baseline(mesh, bath, uv, eta, budget_s=12.0):
     t0 = time.perf_counter()
     u_c, e_c = ref.advance(uv, eta, DT, steps)
     t = time.perf_counter() - t0
-    return {'value': n*3.0*steps/t, 'unit': 'element-updates/s', 'cores': ref.num_threads(), 'kind': 'port',
-            'sample': '{:d} SSPRK33 steps of the same 1M-triangle workload, oracle/swe2d_ref.c (OpenMP, {:d} threads), '
-                      '{:.1f} s'.format(steps, ref.num_threads(), t)}, (steps, u_c, e_c)
+    out = {'value': n*3.0*steps/t, 'unit': 'element-updates/s', 'cores': ref.num_threads(), 'kind': 'port',
+           'sample': '{:d} SSPRK33 steps of the same 1M-triangle workload, oracle/swe2d_ref.c (OpenMP, {:d} threads), '
+                     '{:.1f} s'.format(steps, ref.num_threads(), t)}
+    # single-core figure: one step of the same workload on one thread
+    nthreads = ref.num_threads()
+    ref.set_num_threads(1)
+    t0 = time.perf_counter()
+    ref.advance(uv, eta, DT, 1)
+    out['value_1core'] = n*3.0/(time.perf_counter() - t0)
+    ref.set_num_threads(nthreads)
+    return out, (steps, u_c, e_c)
 
 
 def measured_traffic(n_cells):
