@@ -398,37 +398,37 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
 }
 
 // Boundary facets (walls, open boundaries, boundary drag) are < 0.3 % of the work but their code needs ~60 registers of
-// temporaries.  They are therefore NOT evaluated inside the facet loop of the stage kernels (which treats them as zero) but
-// in this epilogue, which runs for cells with a boundary facet after the rest of the cell update is finished - when the
-// large working set of the main part is dead - reloads the few inputs it needs (L1/L2 hits) and adds the correction
+// temporaries.  In the TRIANGLE kernel they are therefore not evaluated inside the facet loop (which treats them as zero)
+// but in this epilogue, which runs for cells with a boundary facet after the rest of the cell update is finished - when
+// the large working set of the main part is dead - reloads the few inputs it needs (L1/L2 hits) and adds the correction
 // beta*dt*M^-1(boundary flux) to the output values that are still in registers.  The residual is linear in the facet
-// contributions, so the result is the same up to summation order.
-template <bool NONLIN, bool LF, bool WD, int NPC>
-__device__ __forceinline__ void swe_boundary_epilogue(const SweStageArgs &p, int k, int nb0, int nb1, int nb2, int nb3,
-                                                      double ou[NPC], double ov[NPC], double oe[NPC])
+// contributions, so the result is the same up to summation order.  (The quadrilateral kernel runs at 2 waves/SIMD either
+// way and keeps its boundary facets inline: the epilogue costs 14 % there.)
+template <bool NONLIN, bool LF, bool WD>
+__device__ __forceinline__ void swe_boundary_epilogue(const SweStageArgs &p, int k, int nb0, int nb1, int nb2,
+                                                      double ou[3], double ov[3], double oe[3])
 {
     const size_t S = p.stride;
-    // cell area from three vertices (static indices); parallelogram: A = a x b, triangle: 2A
-    double sfac;
+    double sfac;                                         // 6 dt beta / (2A)
     {
-        const int v0 = p.cv[k], v1 = p.cv[S + k], vl = p.cv[(size_t)(NPC - 1)*S + k];
+        const int v0 = p.cv[k], v1 = p.cv[S + k], v2 = p.cv[2*S + k];
         const double x0 = p.vx[v0], y0 = p.vy[v0];
-        const double cross = (p.vx[v1] - x0)*(p.vy[vl] - y0) - (p.vy[v1] - y0)*(p.vx[vl] - x0);    // 2A (tri) or A (quad)
-        sfac = (NPC == 3 ? 6.0 : 1.0)*p.dt*p.beta*swe_rcp(cross);
+        const double cross = (p.vx[v1] - x0)*(p.vy[v2] - y0) - (p.vy[v1] - y0)*(p.vx[v2] - x0);
+        sfac = 6.0*p.dt*p.beta*swe_rcp(cross);
     }
     // one facet at a time, everything addressed in memory by plane index: no dynamically indexed register arrays
 #pragma unroll 1
-    for (int f = 0; f < NPC; f++) {
-        const int nbf = (f == 0) ? nb0 : (f == 1) ? nb1 : (f == 2) ? nb2 : nb3;
+    for (int f = 0; f < 3; f++) {
+        const int nbf = (f == 0) ? nb0 : (f == 1) ? nb1 : nb2;
         if (nbf >= 0) continue;
-        const int a = f, b = (f + 1 == NPC) ? 0 : f + 1;
+        const int a = f, b = (f == 2) ? 0 : f + 1;
         const int va = p.cv[(size_t)a*S + k], vb = p.cv[(size_t)b*S + k];
         const double xa_ = p.vx[va], ya_ = p.vy[va], xb_ = p.vx[vb], yb_ = p.vy[vb];
         const double ha = p.vh[va], hb = p.vh[vb];
         const double ala = WD ? p.valpha[va] : 0.0, alb = WD ? p.valpha[vb] : 0.0;
         const double ua = p.uin[(size_t)a*S + k], ub = p.uin[(size_t)b*S + k];
-        const double va_ = p.uin[(size_t)(NPC + a)*S + k], vb_ = p.uin[(size_t)(NPC + b)*S + k];
-        const double ea = p.uin[(size_t)(2*NPC + a)*S + k], eb = p.uin[(size_t)(2*NPC + b)*S + k];
+        const double va_ = p.uin[(size_t)(3 + a)*S + k], vb_ = p.uin[(size_t)(3 + b)*S + k];
+        const double ea = p.uin[(size_t)(6 + a)*S + k], eb = p.uin[(size_t)(6 + b)*S + k];
         const double Ha = WD ? swe_wd_depth(ha + ea, ala) : (NONLIN ? ha + ea : ha);
         const double Hb = WD ? swe_wd_depth(hb + eb, alb) : (NONLIN ? hb + eb : hb);
         const double nxs = yb_ - ya_, nys = xa_ - xb_;
@@ -438,23 +438,13 @@ __device__ __forceinline__ void swe_boundary_epilogue(const SweStageArgs &p, int
         swe_boundary_facet<NONLIN, LF, WD>(p, -nbf, k, a, b, ua, ub, va_, vb_, ea, eb, ha, hb, Ha, Hb, ala, alb, nxs, nys,
                                            L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
         const double dau = -0.5*Fau, dbu = -0.5*Fbu, dav = -0.5*Fav, dbv = -0.5*Fbv, dae = -0.5*Fae, dbe = -0.5*Fbe;
-        // M^-1 of a vector that is non-zero at nodes a and b only, scattered with static output indices
+        // M^-1 of a vector that is non-zero at nodes a and b only (4 d_i - (d_a + d_b)), static output indices
 #pragma unroll
-        for (int i = 0; i < NPC; i++) {
-            if (NPC == 3) {
-                const double wa = (i == a) ? 3.0 : -1.0, wb = (i == b) ? 3.0 : -1.0;      // 4 d_i - (d_a + d_b)
-                ou[i] += sfac*(wa*dau + wb*dbu);
-                ov[i] += sfac*(wa*dav + wb*dbv);
-                oe[i] += sfac*(wa*dae + wb*dbe);
-            } else {
-                // tensor inverse weights: 16 on the node, -8 on its two edge neighbours, 4 on the opposite node
-                const int da_ = (i - a) & 3, db_ = (i - b) & 3;
-                const double wa = (da_ == 0) ? 16.0 : (da_ == 2) ? 4.0 : -8.0;
-                const double wb = (db_ == 0) ? 16.0 : (db_ == 2) ? 4.0 : -8.0;
-                ou[i] += sfac*(wa*dau + wb*dbu);
-                ov[i] += sfac*(wa*dav + wb*dbv);
-                oe[i] += sfac*(wa*dae + wb*dbe);
-            }
+        for (int i = 0; i < 3; i++) {
+            const double wa = (i == a) ? 3.0 : -1.0, wb = (i == b) ? 3.0 : -1.0;
+            ou[i] += sfac*(wa*dau + wb*dbu);
+            ov[i] += sfac*(wa*dav + wb*dbv);
+            oe[i] += sfac*(wa*dae + wb*dbe);
         }
     }
 }
@@ -624,7 +614,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
                 Fav += xa*fv; Fbv += xb*fv;
                 Fae += xa*fe; Fbe += xb*fe;
             }
-        }       // boundary facets: see swe_boundary_epilogue_*
+        }       // boundary facets: see swe_boundary_epilogue
         bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
         bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
         be[a] -= 0.5*Fae; be[b] -= 0.5*Fbe;
@@ -641,7 +631,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         oe[i] = s*(4.0*be[i] - se) + we[i];          // eta, or zeta = D - h with wetting-drying
     }
     // boundary facets were skipped above; their correction is added to the finished outputs (see swe_boundary_epilogue)
-    if ((nb[0] | nb[1] | nb[2]) < 0) swe_boundary_epilogue<NONLIN, LF, WD, 3>(p, k, nb[0], nb[1], nb[2], 0, ou, ov, oe);
+    if ((nb[0] | nb[1] | nb[2]) < 0) swe_boundary_epilogue<NONLIN, LF, WD>(p, k, nb[0], nb[1], nb[2], ou, ov, oe);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         p.uout[(size_t)i*S + k] = ou[i];
