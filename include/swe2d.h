@@ -72,7 +72,8 @@ typedef enum {
     SWE2D_SCALAR_QUADRATIC_DRAG = 1,       /* options.quadratic_drag_coefficient  shallowwater_eq.py:683,699-700 */
     SWE2D_SCALAR_MANNING_DRAG = 2,         /* options.manning_drag_coefficient    shallowwater_eq.py:685-688 */
     SWE2D_SCALAR_NORM_SMOOTHER = 3,        /* options.norm_smoother               shallowwater_eq.py:700 */
-    SWE2D_SCALAR_COUNT = 4
+    SWE2D_SCALAR_NIKURADSE = 4,            /* options.nikuradse_bed_roughness     shallowwater_eq.py:692-700 (kappa = 0.4) */
+    SWE2D_SCALAR_COUNT = 5
 } swe2d_scalar;
 
 /* Mesh = what FlowSolver2d(mesh2d, bathymetry_2d) receives (thetis/solver2d.py:81-147) flattened to arrays.

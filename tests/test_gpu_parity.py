@@ -81,6 +81,8 @@ def test_source_terms_match_oracle(hip_lib):
         dict(coriolis=cor, linear_drag_coefficient=1e-3, atmospheric_pressure=patm, momentum_source=msrc, volume_source=vsrc),
         dict(manning_drag_coefficient=0.02),
         dict(quadratic_drag_coefficient=0.0025, norm_smoother=0.1),
+        dict(nikuradse_bed_roughness=0.05, norm_smoother=0.01),
+        dict(nikuradse_bed_roughness=18.0),             # k_s above part of the depth range: C_D = 0 there (:696-697)
         dict(wind_stress=0.1*rng.normal(size=(n, 3, 2)), bnd_conditions={3: {'drag': 0.0025}, 1: {'drag': 0.01, 'elev': 0.1}}),
     ]
     for kw in cases:
@@ -98,6 +100,9 @@ def test_source_terms_match_oracle(hip_lib):
         if 'quadratic_drag_coefficient' in kw:
             dev.set_scalar(_lib.SCALAR_QUADRATIC_DRAG, 0.0025)
             dev.set_scalar(_lib.SCALAR_NORM_SMOOTHER, 0.1)
+        if 'nikuradse_bed_roughness' in kw:
+            dev.set_scalar(_lib.SCALAR_NIKURADSE, kw['nikuradse_bed_roughness'])
+            dev.set_scalar(_lib.SCALAR_NORM_SMOOTHER, kw.get('norm_smoother', 0.0))
         if 'wind_stress' in kw:
             dev.set_field(_lib.FIELD_WIND_STRESS, kw['wind_stress'])
             for marker, funcs in kw['bnd_conditions'].items():

@@ -138,3 +138,20 @@ def test_viscosity_and_diffusivity_configuration_checks():
     qeq = ShallowWaterEquations(get_functionspace(qmesh, 'DG', 1), DepthExpression(qbath), opts)
     with pytest.raises(NotImplementedError, match='triangles'):
         qeq.check_fields({'viscosity_h': Constant(1.0)})
+
+
+def test_drag_parameter_combinations_raise_like_the_reference():
+    """shallowwater_eq.py:686-696: at most one of quadratic / Manning / Nikuradse."""
+    from thetis_amd import Constant, Function, RectangleMesh, get_functionspace
+    from thetis_amd.options import ModelOptions2d
+    from thetis_amd.shallowwater_eq import DepthExpression, ShallowWaterEquations
+    mesh = RectangleMesh(4, 3, 10.0, 10.0)
+    bath = Function(get_functionspace(mesh, 'CG', 1)).assign(5.0)
+    eq = ShallowWaterEquations(get_functionspace(mesh, 'DG', 1), DepthExpression(bath), ModelOptions2d())
+    eq.check_fields({'nikuradse_bed_roughness': Constant(0.05)})
+    with pytest.raises(Exception, match='Nikuradse drag and Manning'):
+        eq.check_fields({'nikuradse_bed_roughness': Constant(0.05), 'manning_drag_coefficient': Constant(0.02)})
+    with pytest.raises(Exception, match='dimensionless and Nikuradse'):
+        eq.check_fields({'nikuradse_bed_roughness': Constant(0.05), 'quadratic_drag_coefficient': Constant(0.002)})
+    with pytest.raises(Exception, match='dimensionless and Manning'):
+        eq.check_fields({'manning_drag_coefficient': Constant(0.02), 'quadratic_drag_coefficient': Constant(0.002)})

@@ -47,7 +47,7 @@ struct Handle {
     double nu_const = 0.0, sipg_factor = 1.0;
     int visc_grad_div = 0, visc_grad_depth = 1;
     double *field[SWE2D_FIELD_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    double scalar[SWE2D_SCALAR_COUNT] = {-1.0, -1.0, -1.0, 0.0};
+    double scalar[SWE2D_SCALAR_COUNT] = {-1.0, -1.0, -1.0, 0.0, -1.0};
     double *stage_uv = nullptr, *stage_eta = nullptr;  // device staging in host layout (6N + 3N)
     double *partial = nullptr;                         // diagnostics partial sums
     int n_partial_blocks = 0;
@@ -101,7 +101,7 @@ bool has_sources(const Handle *h)
 {
     for (int i = 0; i < SWE2D_FIELD_COUNT; i++) if (h->field[i]) return true;
     return h->scalar[SWE2D_SCALAR_LINEAR_DRAG] >= 0 || h->scalar[SWE2D_SCALAR_QUADRATIC_DRAG] >= 0
-           || h->scalar[SWE2D_SCALAR_MANNING_DRAG] >= 0;
+           || h->scalar[SWE2D_SCALAR_MANNING_DRAG] >= 0 || h->scalar[SWE2D_SCALAR_NIKURADSE] >= 0;
 }
 
 typedef void (*stage_kernel_t)(const SweStageArgs);
@@ -176,6 +176,7 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.quad_drag = h->scalar[SWE2D_SCALAR_QUADRATIC_DRAG];
     a.manning = h->scalar[SWE2D_SCALAR_MANNING_DRAG];
     a.norm_smoother = h->scalar[SWE2D_SCALAR_NORM_SMOOTHER];
+    a.nikuradse = h->scalar[SWE2D_SCALAR_NIKURADSE];
     a.bc = h->bc;
     const bool has_u0 = (a0 != 0.0);
     stage_kernel_t kern = h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4)
@@ -566,6 +567,16 @@ int swe2d_set_scalar(swe2d_handle *hh, int which, double value)
         return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "Cannot set both dimensionless and Manning drag parameter");
     if (which == SWE2D_SCALAR_QUADRATIC_DRAG && value >= 0.0 && h->scalar[SWE2D_SCALAR_MANNING_DRAG] >= 0.0)
         return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "Cannot set both dimensionless and Manning drag parameter");
+    if (which == SWE2D_SCALAR_NIKURADSE && value >= 0.0) {
+        if (h->scalar[SWE2D_SCALAR_MANNING_DRAG] >= 0.0)
+            return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "Cannot set both Nikuradse drag and Manning drag parameter");
+        if (h->scalar[SWE2D_SCALAR_QUADRATIC_DRAG] >= 0.0)
+            return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "Cannot set both dimensionless and Nikuradse drag parameter");
+        if (value == 0.0) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "nikuradse_bed_roughness must be > 0");
+    }
+    if ((which == SWE2D_SCALAR_MANNING_DRAG || which == SWE2D_SCALAR_QUADRATIC_DRAG) && value >= 0.0
+        && h->scalar[SWE2D_SCALAR_NIKURADSE] >= 0.0)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "Cannot combine the Nikuradse drag with another quadratic drag parameter");
     h->scalar[which] = value;
     return SWE2D_OK;
 }

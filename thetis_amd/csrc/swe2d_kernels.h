@@ -79,6 +79,7 @@ struct SweStageArgs {
     const double *bc_flux_f;  // 2k planes
     int npc_;                 // nodes per cell (plane offsets of the vector boundary field)
     double linear_drag, quad_drag, manning, norm_smoother;   // <0: off
+    double nikuradse;                                        // Nikuradse bed roughness length k_s, <0: off
     SweBcTable bc;
 };
 
@@ -315,7 +316,7 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
             bv[i] -= p.linear_drag*A*(1.0/12.0)*(vs + v[i]);
         }
     }
-    if (p.quad_drag >= 0.0 || p.manning >= 0.0) {        // shallowwater_eq.py:685-700, 6-point degree-4 rule
+    if (p.quad_drag >= 0.0 || p.manning >= 0.0 || p.nikuradse >= 0.0) {        // shallowwater_eq.py:685-700, 6-point rule
         const double a1 = 0.445948490915965, b1 = 0.108103018168070, w1 = 0.223381589678011;
         const double a2 = 0.091576213509771, b2 = 0.816847572980459, w2 = 0.109951743655322;
 #pragma unroll
@@ -326,7 +327,11 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
             const double uq = l[0]*u[0] + l[1]*u[1] + l[2]*u[2];
             const double vq = l[0]*v[0] + l[1]*v[1] + l[2]*v[2];
             const double Hq = l[0]*H[0] + l[1]*H[1] + l[2]*H[2];
-            const double cd = (p.manning >= 0.0) ? g*p.manning*p.manning*swe_rcbrt(Hq) : p.quad_drag;
+            double cd = (p.manning >= 0.0) ? g*p.manning*p.manning*swe_rcbrt(Hq) : p.quad_drag;
+            if (p.nikuradse >= 0.0) {                    // C_D = 2 kappa^2 / ln(11.036 H/k_s)^2 for H > k_s, else 0   :696-697
+                const double lg = log(11.036*Hq/p.nikuradse);
+                cd = (Hq > p.nikuradse) ? 0.32/(lg*lg) : 0.0;
+            }
             const double s = ww*A*cd*swe_sqrt(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother)*swe_rcp(Hq);
 #pragma unroll
             for (int i = 0; i < 3; i++) {
@@ -1181,8 +1186,12 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
                     }
                 }
                 double drag = 0.0;
-                if (p.quad_drag >= 0.0 || p.manning >= 0.0) {
-                    const double cd = (p.manning >= 0.0) ? g*p.manning*p.manning*swe_rcbrt(Hq) : p.quad_drag;
+                if (p.quad_drag >= 0.0 || p.manning >= 0.0 || p.nikuradse >= 0.0) {
+                    double cd = (p.manning >= 0.0) ? g*p.manning*p.manning*swe_rcbrt(Hq) : p.quad_drag;
+                    if (p.nikuradse >= 0.0) {
+                        const double lg = log(11.036*Hq/p.nikuradse);
+                        cd = (Hq > p.nikuradse) ? 0.32/(lg*lg) : 0.0;
+                    }
                     drag = cd*swe_sqrt(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother)*swe_rcp(Hq);
                 }
                 if (p.linear_drag >= 0.0) drag += p.linear_drag;

@@ -126,6 +126,7 @@ class ERKGenericShuOsher(TimeIntegrator):
         dev.set_scalar(_lib.SCALAR_LINEAR_DRAG, _const_value(f.get('linear_drag_coefficient')))
         dev.set_scalar(_lib.SCALAR_QUADRATIC_DRAG, _const_value(f.get('quadratic_drag_coefficient')))
         dev.set_scalar(_lib.SCALAR_MANNING_DRAG, _const_value(f.get('manning_drag_coefficient')))
+        dev.set_scalar(_lib.SCALAR_NIKURADSE, _const_value(f.get('nikuradse_bed_roughness')))
         for key, fid, vec in (('coriolis', _lib.FIELD_CORIOLIS, False),
                               ('atmospheric_pressure', _lib.FIELD_ATMOSPHERIC_PRESSURE, False),
                               ('momentum_source', _lib.FIELD_MOMENTUM_SOURCE, True),

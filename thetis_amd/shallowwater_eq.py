@@ -68,11 +68,15 @@ class ShallowWaterEquations(object):
                 raise NotImplementedError('HorizontalViscosityTerm with wetting and drying is not implemented')
             if isinstance(nu, Function) and nu.function_space().family != 'CG':
                 raise NotImplementedError('horizontal_viscosity must be a Constant or a continuous (CG-P1) Function')
-        if fields.get('nikuradse_bed_roughness') is not None:
-            raise NotImplementedError('Nikuradse bed roughness is not implemented on the device path yet')
         if fields.get('quadratic_drag_coefficient') is not None and fields.get('manning_drag_coefficient') is not None:
             raise Exception('Cannot set both dimensionless and Manning drag parameter')
-        for key in ('linear_drag_coefficient', 'quadratic_drag_coefficient', 'manning_drag_coefficient'):
+        if fields.get('nikuradse_bed_roughness') is not None:          # shallowwater_eq.py:692-696
+            if fields.get('manning_drag_coefficient') is not None:
+                raise Exception('Cannot set both Nikuradse drag and Manning drag parameter')
+            if fields.get('quadratic_drag_coefficient') is not None:
+                raise Exception('Cannot set both dimensionless and Nikuradse drag parameter')
+        for key in ('linear_drag_coefficient', 'quadratic_drag_coefficient', 'manning_drag_coefficient',
+                    'nikuradse_bed_roughness'):
             v = fields.get(key)
             if v is not None and not isinstance(v, (int, float, Constant)):
                 raise NotImplementedError('{:} must be a constant on the device path'.format(key))
