@@ -267,3 +267,25 @@ def test_steady_state_basin_mms_convergence(hip_lib, name):
     # and the device result is the oracle's (same scenario, refinement 1)
     eo, uo = mms_basin.run_oracle(name, 1)
     assert abs(errs[0][0] - eo) < 1e-3*eo and abs(errs[0][1] - uo) < 1e-3*uo
+
+
+@pytest.mark.parametrize('dt,t_end', [(2.0, 500.0), (3.0, 470.0)])
+def test_iterate_batches_steps_between_exports_with_identical_results(hip_lib, capsys, dt, t_end):
+    """iterate() issues all steps up to the next export in one library call (no forcings, no per-step callbacks): same
+    step count, times, export instants, printed state lines and bitwise the same state as the step-by-step generator."""
+    a, _, _, elev_init = _channel2d_solver(dt=dt, t_end=t_end)
+    a.options.no_exports = True
+    a.assign_initial_conditions(elev=elev_init)
+    for _ in a.create_iterator():
+        pass
+    out_a = capsys.readouterr().out
+    b, _, _, elev_init = _channel2d_solver(dt=dt, t_end=t_end)
+    b.options.no_exports = True
+    b.assign_initial_conditions(elev=elev_init)
+    b.iterate()
+    out_b = capsys.readouterr().out
+    assert (a.iteration, a.i_export, a.simulation_time) == (b.iteration, b.i_export, b.simulation_time)
+    assert np.array_equal(a.fields.uv_2d.dat.data_ro, b.fields.uv_2d.dat.data_ro)
+    assert np.array_equal(a.fields.elev_2d.dat.data_ro, b.fields.elev_2d.dat.data_ro)
+    strip = lambda s: [' '.join(l.split()[:-1]) for l in s.splitlines() if l.strip() and l.split()[0].isdigit()]   # drop Tcpu
+    assert strip(out_a) == strip(out_b) and len(strip(out_a)) >= 5

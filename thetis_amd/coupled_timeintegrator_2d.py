@@ -174,5 +174,21 @@ class GeneralCoupledTimeIntegrator2D(TimeIntegratorBase):
             if use_limiter:
                 self.device.tracer_limit(ts.tid)
 
+    def advance_steps(self, t, n_steps):
+        """``n_steps`` coupled steps without forcing updates; one library call when every stepper is SSPRK33."""
+        use_limiter = self.options.use_limiter_for_tracers and self.options.polynomial_degree > 0
+        fused = all(ts.n_stages == 3 for ts in self.tracers.values()) and self.swe.n_stages == 3
+        if not fused:
+            for i in range(int(n_steps)):
+                self.advance(t + i*self.swe.dt)
+            return
+        self.swe._sync_to_device()
+        for ts in self.tracers.values():
+            ts._sync_to_device()
+        self.device.advance_coupled(int(n_steps), tracer_only=self.options.tracer_only, use_limiter=use_limiter)
+        self.swe._device_ahead = True
+        for ts in self.tracers.values():
+            ts._device_ahead = True
+
     def diagnostics(self):
         return self.swe.diagnostics()

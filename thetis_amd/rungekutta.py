@@ -226,6 +226,13 @@ class ERKGenericShuOsher(TimeIntegrator):
             for i in range(self.n_stages):
                 self.solve_stage(i, t, update_forcings)
 
+    def advance_steps(self, t, n_steps):
+        """``n_steps`` time steps without forcing updates in ONE call into the library (FlowSolver2d.iterate batches the
+        steps between exports: no Python between the launches)."""
+        self._sync_to_device()
+        self.device.advance(int(n_steps))
+        self._device_ahead = True
+
     def diagnostics(self):
         """{int eta^2, int |u|^2, int (eta+h), min(h+eta)} of the device-resident state."""
         self._sync_to_device()
@@ -253,4 +260,9 @@ class ForwardEuler(ERKGenericShuOsher):
             self._push_bcs()
         self._sync_to_device()
         self.device.advance_forward_euler(1)
+        self._device_ahead = True
+
+    def advance_steps(self, t, n_steps):
+        self._sync_to_device()
+        self.device.advance_forward_euler(int(n_steps))
         self._device_ahead = True

@@ -382,11 +382,14 @@ class FlowSolver2d(object):
 
     def iterate(self, update_forcings=None, export_func=None):
         """Runs the simulation (solver2d.py:974-994)"""
-        for _ in self.create_iterator(update_forcings=update_forcings, export_func=export_func):
+        for _ in self.create_iterator(update_forcings=update_forcings, export_func=export_func, _batch=True):
             pass
 
-    def create_iterator(self, update_forcings=None, export_func=None):
-        """Generator over the time loop (solver2d.py:997-1144)"""
+    def create_iterator(self, update_forcings=None, export_func=None, _batch=False):
+        """Generator over the time loop (solver2d.py:997-1144).  ``_batch`` (used by :meth:`iterate`, which discards the
+        yielded times): without forcing updates and per-time-step callbacks, all steps up to the next export are issued in
+        one call into the library and the generator yields once per batch; times, iteration counts and export instants are
+        exactly those of the step-by-step loop."""
         if not self._initialized:
             self.initialize()
         t_epsilon = 1.0e-5
@@ -416,15 +419,27 @@ class FlowSolver2d(object):
             if export_func is not None:
                 export_func()
 
+        batch = (_batch and update_forcings is None and not self.callbacks['timestep']
+                 and hasattr(self.timestepper, 'advance_steps'))
         while self.simulation_time <= self.options.simulation_end_time - t_epsilon:
-            self.timestepper.advance(self.simulation_time, update_forcings)
+            n_adv = 1
+            if batch:
+                # number of steps until the loop would export or stop (same arithmetic as the step-by-step loop)
+                while True:
+                    t_k = initial_simulation_time + (internal_iteration + n_adv)*self.dt
+                    if t_k >= next_export_t - t_epsilon or not t_k <= self.options.simulation_end_time - t_epsilon:
+                        break
+                    n_adv += 1
+                self.timestepper.advance_steps(self.simulation_time, n_adv)
+            else:
+                self.timestepper.advance(self.simulation_time, update_forcings)
 
             # returns internal simulation time
             yield self.simulation_time
 
             # Move to next time step
-            self.iteration += 1
-            internal_iteration += 1
+            self.iteration += n_adv
+            internal_iteration += n_adv
             self.simulation_time = initial_simulation_time + internal_iteration*self.dt
 
             self.callbacks.evaluate(mode='timestep')
