@@ -194,8 +194,11 @@ int  swe2d_tracer_set_options(swe2d_handle *h, int use_lax_friedrichs_tracer, do
 int  swe2d_tracer_set_state(swe2d_handle *h, int tracer_id, const double *nodal);
 int  swe2d_tracer_get_state(swe2d_handle *h, int tracer_id, double *nodal);
 /* bnd_functions['tracer_2d'][marker] = {'value': c}; has_value = 0 restores the default boundary term
- * c (u.n) phi (tracer_eq_2d.py:177-191).  Velocity-type keys are not supported. */
+ * c (u.n) phi (tracer_eq_2d.py:177-191).  Velocity-type keys: swe2d_tracer_set_bc_velocity. */
 int  swe2d_tracer_set_bc(swe2d_handle *h, int tracer_id, int marker, int has_value, double value);
+/* external velocity of the tracer's boundary dict on `marker` (tracer_eq_2d.py:70-110): kind 0 = none (uv_ext = uv_in),
+ * 1 = 'uv': (u, v), multiplied by tracer_advective_velocity_factor, 2 = 'un': normal velocity u (v unused) */
+int  swe2d_tracer_set_bc_velocity(swe2d_handle *h, int tracer_id, int marker, int kind, double u, double v);
 /* Function-valued 'value' on `marker`: nodal DG values of the whole mesh in the host layout (kN); only cells with a
  * boundary facet carrying `marker` are copied (all their nodes: the diffusive boundary term uses the cell gradient) */
 int  swe2d_tracer_set_bc_field(swe2d_handle *h, int tracer_id, int marker, const double *nodal);

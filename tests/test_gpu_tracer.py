@@ -323,3 +323,90 @@ def test_tracer_adv_diff_mms_convergence(hip_lib, name, conservative):
     errs = [mms_tracer.run_device(name, r, conservative) for r in refs]
     slope = stats.linregress(np.log10(np.array(refs, dtype=float)**-1), np.log10(errs)).slope
     assert abs(slope - 2.0)/2.0 < 0.2, (errs, slope)
+
+
+@pytest.mark.parametrize('conservative', [False, True])
+@pytest.mark.parametrize('cells', ['triangles', 'quadrilaterals'])
+def test_tracer_boundary_velocity_keys_match_oracle(hip_lib, cells, conservative):
+    """bnd_functions['tracer'][marker] = {'value': c, 'uv': (u, v)} / {'un': un} (tracer_eq_2d.py:70-110): the upwind
+    switch uses the average of the interior and the external velocity; also in the diffusive boundary term."""
+    from helpers import make_oracle_generic, quad_case
+    if cells == 'triangles':
+        mesh, bath, uv, eta = channel_case(nx=6, ny=4, seed=61)
+        orc = make_oracle(mesh, bath)
+    else:
+        mesh, bath, uv, eta = quad_case(nx=6, ny=4, seed=61)
+        orc = make_oracle_generic(mesh, bath)
+    k = mesh.cells.shape[1]
+    T = np.random.default_rng(25).normal(size=(mesh.num_cells, k))
+    bcs = {1: {'value': 1.5, 'uv': np.array([0.6, -0.2])}, 2: {'uv': np.array([-0.5, 0.1])}, 3: {'value': -0.5, 'un': 0.4},
+           4: {'un': -0.3}}
+    dt = 2.0
+    dev = _dev(mesh, bath, dt, boundary_len=mesh.boundary_len)
+    tid = dev.add_tracer()
+    dev.tracer_set_options(False, 1.0, 0.8)
+    dev.tracer_set_conservative(tid, conservative)
+    kw = dict(bnd_conditions=bcs, tracer_advective_velocity_factor=0.8, conservative=conservative)
+    dev.tracer_set_bc(tid, 1, 1.5)
+    dev.tracer_set_bc(tid, 3, -0.5)
+    dev.tracer_set_bc_velocity(tid, 1, uv=(0.6, -0.2))
+    dev.tracer_set_bc_velocity(tid, 2, uv=(-0.5, 0.1))
+    dev.tracer_set_bc_velocity(tid, 3, un=0.4)
+    dev.tracer_set_bc_velocity(tid, 4, un=-0.3)
+    if cells == 'triangles':
+        kw.update(diffusivity=30.0)
+        dev.tracer_set_diffusivity(tid, 30.0)
+        for m_, kind in ((1, 2), (2, 3), (3, 2), (4, 3)):
+            dev.tracer_set_diffusion_bc(tid, m_, kind)
+    dev.set_state(uv, eta)
+    dev.tracer_set_state(tid, T)
+    assert rel_linf(dev.tracer_tendency(tid), orc.tracer_tendency(T, uv, eta, dt, **kw)) < TOL
+    dev.close()
+
+
+@pytest.mark.parametrize('stepper', ['SSPRK33', 'ForwardEuler'])
+def test_reference_horizontal_advection_convergence(hip_lib, stepper):
+    """test/tracerEq/test_h-advection_mes_2d.py::test_horizontal_advection[1-SSPRK33 | ForwardEuler]: a Gaussian advected by
+    u = 1 through a channel, tracer boundaries {'value': 0, 'uv': (u, 0)}, limiter on, custom loop on the tracer stepper;
+    convergence slope over refinements [1, 2, 3] above 2*(1 - 0.2)."""
+    from scipy import stats
+    from mms_basin import l2_error
+    errs = []
+    refs = [1, 2, 3]
+    for refinement in refs:
+        lx, ly = 15.0e3, 6.0e3/refinement
+        depth, u = 40.0, 1.0
+        mesh2d = RectangleMesh(6*refinement + 1, 1, lx, ly)
+        t_end = 3000.0
+        bathymetry_2d = Function(get_functionspace(mesh2d, 'CG', 1), name='Bathymetry').assign(depth)
+        so = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+        o = so.options
+        o.use_nonlinear_equations = False
+        o.use_lax_friedrichs_velocity = True
+        o.lax_friedrichs_velocity_scaling_factor = Constant(1.0)
+        o.use_lax_friedrichs_tracer = False
+        o.horizontal_velocity_scale = Constant(abs(u))
+        o.no_exports = True
+        o.simulation_end_time = t_end
+        o.simulation_export_time = t_end/8.0
+        so.create_function_spaces()
+        o.tracer_advective_velocity_factor = Function(so.function_spaces.H_2d, name='uv tracer factor').assign(1.0)
+        o.add_tracer_2d('tracer_2d', 'Depth averaged tracer', 'Tracer2d')
+        o.use_limiter_for_tracers = True
+        o.swe_timestepper_type = stepper
+        o.tracer_timestepper_type = stepper
+        bnd_salt_2d = {'value': Constant(0.0), 'uv': (u, 0.0)}
+        so.bnd_functions['tracer'] = {1: bnd_salt_2d, 2: bnd_salt_2d}
+        so.bnd_functions['momentum'] = {1: {'uv': (u, 0.0)}, 2: {'uv': (u, 0.0)}}
+        so.create_equations()
+        x0, sigma = 0.3*lx, 1600.0
+        ana = lambda t: (lambda x, y: np.exp(-(x - x0 - u*t)**2/sigma**2))
+        so.assign_initial_conditions(uv=lambda x, y: (u + 0*x, 0*x), tracer=ana(0.0))
+        ti = so.timestepper.timesteppers.tracer_2d
+        t = 0.0
+        while t < t_end - 1e-8:
+            ti.advance(t)               # the tracer stepper alone, as in the reference's custom loop (:98-110)
+            t += so.dt
+        errs.append(l2_error(mesh2d, so.fields.tracer_2d.cell_node_values(), ana(t)))
+    slope = stats.linregress(np.log10(np.array(refs, dtype=float)**-1), np.log10(errs)).slope
+    assert slope > 2*(1 - 0.2), (errs, slope)

@@ -67,6 +67,7 @@ SYMBOLS = {
     'swe2d_tracer_set_state': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_tracer_get_state': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_tracer_set_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
+    'swe2d_tracer_set_bc_velocity': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]),
     'swe2d_tracer_set_bc_field': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),
     'swe2d_tracer_set_source': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_tracer_solve_stage_cells': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int32, ctypes.c_int32]),

@@ -13,6 +13,17 @@ from .timeintegrator import TimeIntegratorBase
 __all__ = ['DeviceTracerSSPRK33', 'DeviceTracerForwardEuler', 'GeneralCoupledTimeIntegrator2D']
 
 
+def _velocity_factor(f):
+    """options.tracer_advective_velocity_factor: a Constant, or a Function that is spatially constant (as in
+    test/tracerEq/test_h-advection_mes_2d.py:52-53); a varying Function is not on the device path."""
+    if isinstance(f, Function):
+        d = f.dat.data_ro
+        if d.size and np.abs(d - d.flat[0]).max() > 1e-14*max(1.0, abs(float(d.flat[0]))):
+            raise NotImplementedError('a spatially varying tracer_advective_velocity_factor is not on the device path')
+        return float(d.flat[0]) if d.size else 1.0
+    return float(f)
+
+
 class _AttrDict(dict):
     def __init__(self, *args, **kwargs):
         super(_AttrDict, self).__init__(*args, **kwargs)
@@ -21,6 +32,13 @@ class _AttrDict(dict):
 
 def _cval(v):
     return None if v is None else float(v)
+
+
+def _vec(v):
+    """constant 2-vector given as a tuple / array / vector Constant"""
+    a = np.asarray(v.values() if hasattr(v, 'values') and callable(v.values) else v, dtype=float).ravel()
+    assert a.shape == (2,), "tracer boundary 'uv' must be a constant 2-vector"
+    return a
 
 
 class DeviceTracerSSPRK33(object):
@@ -61,6 +79,11 @@ class DeviceTracerSSPRK33(object):
                 self.device.tracer_set_bc(self.tid, marker, v)
             else:
                 self.device.tracer_set_bc(self.tid, marker, _cval(v))
+            uv_b = None if funcs is None else funcs.get('uv')
+            un_b = None if funcs is None else funcs.get('un')
+            self.device.tracer_set_bc_velocity(self.tid, marker,
+                                               uv=None if uv_b is None else _vec(uv_b),
+                                               un=None if un_b is None or uv_b is not None else _cval(un_b))
             if self.diffusive:                  # boundary term of the diffusion operator, tracer_eq_2d.py:264-277
                 if funcs is None:
                     kind, dfl = 0, 0.0
@@ -139,8 +162,7 @@ class GeneralCoupledTimeIntegrator2D(TimeIntegratorBase):
         print_output('  Tracer time integrator: {:}'.format(self.options.tracer_timestepper_type))
         o = self.options
         self.device.tracer_set_options(o.use_lax_friedrichs_tracer, float(o.lax_friedrichs_tracer_scaling_factor),
-                                       float(o.tracer_advective_velocity_factor)
-                                       if isinstance(o.tracer_advective_velocity_factor, (int, float, Constant)) else 1.0)
+                                       _velocity_factor(o.tracer_advective_velocity_factor))
 
     def set_dt(self, dt):
         for stepper in sorted(self.timesteppers):

@@ -59,6 +59,8 @@ struct Handle {
         double *source = nullptr;
         bool conservative = false;                      // options.tracer[label].use_conservative_form
         double *bc_value_f = nullptr;                   // Function-valued 'value' boundaries, npc*npc planes
+        int bc_vel_kind[SWE_MAX_MARKERS];               // 0 none, 1 'uv', 2 'un'
+        double bc_u[SWE_MAX_MARKERS], bc_v[SWE_MAX_MARKERS];
         int bc_has_value[SWE_MAX_MARKERS];
         double bc_value[SWE_MAX_MARKERS];
         bool diff = false;                              // SIPG horizontal diffusion
@@ -887,6 +889,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     a.vh = h->vh; a.valpha = h->valpha;
     for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_has_value[m] = t.bc_has_value[m]; a.bc_value[m] = t.bc_value[m]; }
     a.bc_value_f = t.bc_value_f;
+    for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_vel_kind[m] = t.bc_vel_kind[m]; a.bc_u[m] = t.bc_u[m]; a.bc_v[m] = t.bc_v[m]; }
     tracer_kernel_t kern = (h->npc == 4) ? pick_tracer_kernel_quad(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr)
                                          : pick_tracer_kernel(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr);
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
@@ -908,6 +911,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
         v.vel_factor = h->tracer_vel_factor;
         for (int m = 0; m < SWE_MAX_MARKERS; m++) { v.bc_diff_kind[m] = t.bc_diff_kind[m]; v.bc_diff_flux[m] = t.bc_diff_flux[m]; }
         v.bc_value_f = t.bc_value_f;
+        for (int m = 0; m < SWE_MAX_MARKERS; m++) { v.bc_vel_kind[m] = t.bc_vel_kind[m]; v.bc_u[m] = t.bc_u[m]; v.bc_v[m] = t.bc_v[m]; }
         hipLaunchKernelGGL(swe_sipg_kernel<1>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         HIP_TRY(h, hipGetLastError());
     }
@@ -1014,6 +1018,7 @@ int swe2d_tracer_add(swe2d_handle *hh, int *tracer_id)
     for (int m = 0; m < SWE_MAX_MARKERS; m++) {
         t.bc_has_value[m] = 0; t.bc_value[m] = 0.0;
         t.bc_diff_kind[m] = SWE_SIPG_BC_NONE; t.bc_diff_flux[m] = 0.0;
+        t.bc_vel_kind[m] = 0; t.bc_u[m] = 0.0; t.bc_v[m] = 0.0;
     }
     for (int b = 0; b < 3; b++) {
         HIP_TRY(h, hipMalloc(&t.buf[b], (size_t)h->npc*h->stride*sizeof(double)));
@@ -1078,6 +1083,19 @@ int swe2d_tracer_set_bc(swe2d_handle *hh, int id, int marker, int has_value, dou
     if (marker <= 0 || marker >= SWE2D_MAX_MARKERS) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "marker out of range");
     h->tracers[id].bc_has_value[marker] = has_value ? 1 : 0;
     h->tracers[id].bc_value[marker] = value;
+    return SWE2D_OK;
+}
+
+int swe2d_tracer_set_bc_velocity(swe2d_handle *hh, int id, int marker, int kind, double u, double v)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (marker <= 0 || marker >= SWE2D_MAX_MARKERS) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "marker out of range");
+    if (kind < 0 || kind > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "velocity kind must be 0 (none), 1 ('uv') or 2 ('un')");
+    h->tracers[id].bc_vel_kind[marker] = kind;
+    h->tracers[id].bc_u[marker] = u;
+    h->tracers[id].bc_v[marker] = v;
     return SWE2D_OK;
 }
 

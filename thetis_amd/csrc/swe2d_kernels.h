@@ -800,7 +800,33 @@ struct SweTracerArgs {
     int bc_has_value[SWE_MAX_MARKERS];   // 0: no 'value', 1: constant, 2: Function (bc_value_f)
     double bc_value[SWE_MAX_MARKERS];
     const double *bc_value_f;            // k*k planes: plane k*f + i = node i of the cell for its boundary facet f, or null
+    int bc_vel_kind[SWE_MAX_MARKERS];    // external velocity of the boundary dict: 0 = uv_in, 1 = 'uv' (times vel_factor), 2 = 'un'*n
+    double bc_u[SWE_MAX_MARKERS], bc_v[SWE_MAX_MARKERS];      // 'uv' components, or 'un' in bc_u
 };
+
+// boundary facet of the tracer stage kernels (tracer_eq_2d.py:177-191 and :380-393): upwind value / flux with the external
+// state of get_bnd_functions (:70-110).  nxs, nys: normal scaled by the facet length; returns the form value times |F|.
+__device__ __forceinline__ double swe_tracer_boundary_flux(const SweTracerArgs &p, int marker, double cq, double cext,
+                                                           double uq, double vq, double nxs, double nys)
+{
+    double ue = uq, ve = vq;
+    const int vk = p.bc_vel_kind[marker];
+    if (vk == 1) {
+        ue = p.vel_factor*p.bc_u[marker];
+        ve = p.vel_factor*p.bc_v[marker];
+    } else if (vk == 2) {
+        const double rl = 1.0/sqrt(nxs*nxs + nys*nys);
+        ue = p.bc_u[marker]*nxs*rl;
+        ve = p.bc_u[marker]*nys*rl;
+    }
+    const double unav = 0.5*((uq + ue)*nxs + (vq + ve)*nys);
+    if (p.conservative) {                    // flux_up = c_in*uv*s + c_ext*uv_ext*(1-s)
+        const double fin = cq*(uq*nxs + vq*nys), fex = cext*(ue*nxs + ve*nys);
+        return unav > 0.0 ? fin : (unav < 0.0 ? fex : 0.5*(fin + fex));
+    }
+    const double cup = unav > 0.0 ? cq : (unav < 0.0 ? cext : 0.5*(cq + cext));
+    return cup*unav;
+}
 
 template <bool LF, bool HAST0, bool SRC>
 __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTracerArgs p)
@@ -922,12 +948,11 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
                 if (LF) fq += 0.5*fabs(uavn)*p.lf_factor*(cq - cn);                       // :173-175
             } else {
                 const int marker = -nb[f];
-                if (marker < SWE_MAX_MARKERS && p.bc_has_value[marker]) {                  // :181-188, uv_ext = uv_in
+                if (marker < SWE_MAX_MARKERS && (p.bc_has_value[marker] || p.bc_vel_kind[marker])) {     // :181-188
                     const double cext = (p.bc_has_value[marker] == 2)
                         ? xa*p.bc_value_f[(size_t)(3*f + a)*S + k] + xb*p.bc_value_f[(size_t)(3*f + bb)*S + k]
-                        : p.bc_value[marker];
-                    const double cup = unown > 0.0 ? cq : (unown < 0.0 ? cext : 0.5*(cq + cext));
-                    fq = cup*unown;
+                        : (p.bc_has_value[marker] ? p.bc_value[marker] : cq);
+                    fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys);
                 } else {
                     fq = cq*unown;                                                         // :189-191
                 }
@@ -1450,12 +1475,11 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
                 if (LF) fq += 0.5*fabs(uavn)*p.lf_factor*(cq - cn);
             } else {
                 const int marker = -nb[f];
-                if (marker < SWE_MAX_MARKERS && p.bc_has_value[marker]) {
+                if (marker < SWE_MAX_MARKERS && (p.bc_has_value[marker] || p.bc_vel_kind[marker])) {
                     const double cext = (p.bc_has_value[marker] == 2)
                         ? xa*p.bc_value_f[(size_t)(4*f + a)*S + k] + xb*p.bc_value_f[(size_t)(4*f + bb)*S + k]
-                        : p.bc_value[marker];
-                    const double cup = unown > 0.0 ? cq : (unown < 0.0 ? cext : 0.5*(cq + cext));
-                    fq = cup*unown;
+                        : (p.bc_has_value[marker] ? p.bc_value[marker] : cq);
+                    fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys);
                 } else {
                     fq = cq*unown;
                 }

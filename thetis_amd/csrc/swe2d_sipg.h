@@ -41,6 +41,8 @@ struct SweSipgArgs {
     int bc_diff_kind[SWE_MAX_MARKERS];
     double bc_diff_flux[SWE_MAX_MARKERS];
     const double *bc_value_f;   // 9 planes (3f + i), see SweTracerArgs
+    int bc_vel_kind[SWE_MAX_MARKERS];        // external velocity of the boundary dict, see SweTracerArgs
+    double bc_u[SWE_MAX_MARKERS], bc_v[SWE_MAX_MARKERS];
 };
 
 template <int NC>
@@ -265,7 +267,10 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
                         val = -p.bc_diff_flux[marker];
                     } else {
                         const double muq = xa*mu[a] + xb*mu[bb];
-                        const double un = (xa*ua + xb*ub)*n0 + (xa*va + xb*vb)*n1;          // uv_ext = uv_in
+                        double uq = xa*ua + xb*ub, vq = xa*va + xb*vb, ue = uq, ve = vq;
+                        if (p.bc_vel_kind[marker] == 1) { ue = p.vel_factor*p.bc_u[marker]; ve = p.vel_factor*p.bc_v[marker]; }
+                        else if (p.bc_vel_kind[marker] == 2) { ue = p.bc_u[marker]*n0; ve = p.bc_u[marker]*n1; }
+                        const double un = 0.5*((uq + ue)*n0 + (vq + ve)*n1);                 // uv_av . n
                         const double s = (kd == SWE_SIPG_BC_GRAD_IN) ? 1.0 : (un > 0.0 ? 1.0 : (un < 0.0 ? 0.0 : 0.5));
                         val = -muq*((s*G[0][0] + (1.0 - s)*gex)*n0 + (s*G[0][1] + (1.0 - s)*gey)*n1);
                     }

@@ -374,6 +374,16 @@ class Swe2dDevice(object):
         self._ck(self.lib.swe2d_tracer_set_bc(self.h, tid, self._slot(marker), 0 if value is None else 1,
                                               0.0 if value is None else float(value)))
 
+    def tracer_set_bc_velocity(self, tid, marker, uv=None, un=None):
+        """External velocity of the tracer's boundary dict: 'uv' (2 components) or 'un'; neither: uv_ext = uv_in."""
+        if uv is not None:
+            kind, u, v = 1, float(uv[0]), float(uv[1])
+        elif un is not None:
+            kind, u, v = 2, float(un), 0.0
+        else:
+            kind, u, v = 0, 0.0, 0.0
+        self._ck(self.lib.swe2d_tracer_set_bc_velocity(self.h, int(tid), self._slot(marker), kind, u, v))
+
     def tracer_set_source(self, tid, nodal):
         if nodal is None:
             self._ck(self.lib.swe2d_tracer_set_source(self.h, tid, None))
