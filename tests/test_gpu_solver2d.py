@@ -289,3 +289,32 @@ def test_iterate_batches_steps_between_exports_with_identical_results(hip_lib, c
     assert np.array_equal(a.fields.elev_2d.dat.data_ro, b.fields.elev_2d.dat.data_ro)
     strip = lambda s: [' '.join(l.split()[:-1]) for l in s.splitlines() if l.strip() and l.split()[0].isdigit()]   # drop Tcpu
     assert strip(out_a) == strip(out_b) and len(strip(out_a)) >= 5
+
+
+def test_steady_state_channel_reference_scenario(hip_lib):
+    """test/swe2d/test_steady_state_channel.py through FlowSolver2d with SSPRK33 marching (the reference uses an implicit
+    solve): Function-valued 'un' inflow and 'elev' outflow, linear drag; L2 error of eta against 1 - x/lx below 1e-2."""
+    from mms_basin import l2_error
+    lx, ly = 5e3, 1e3
+    mesh2d = RectangleMesh(10, 1, lx, ly)
+    p1_2d = get_functionspace(mesh2d, 'CG', 1)
+    bathymetry_2d = Function(p1_2d, name='bathymetry').assign(100.0)
+    g = 9.81
+    so = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+    o = so.options
+    o.use_nonlinear_equations = False
+    o.no_exports = True
+    o.swe_timestepper_type = 'SSPRK33'
+    o.swe_timestepper_options.use_automatic_timestep = False
+    o.timestep = 2.0
+    o.simulation_export_time = 1000.0
+    o.simulation_end_time = 6000.0
+    o.linear_drag_coefficient = Constant(g/lx)
+    inflow_func = Function(p1_2d).assign(-1.0)                   # NOTE negative into domain
+    outflow_func = Function(p1_2d).assign(0.0)
+    so.bnd_functions['shallow_water'] = {1: {'un': inflow_func}, 2: {'elev': outflow_func}}
+    so.create_equations()
+    so.assign_initial_conditions(uv=Constant((1.0, 0.0)))
+    so.iterate()
+    eta = so.fields.elev_2d.cell_node_values()
+    assert l2_error(mesh2d, eta, lambda x, y: 1.0 - x/lx) < 1e-2

@@ -233,3 +233,28 @@ def test_atmospheric_pressure_balance_second_order(ref_so):
         orc = make_oracle(mesh, bath)
         return orc.l2_norm(eta - orc.project(eta_fn))
     check_pressure_forcing_orders(_pressure_forcing_errors(run))
+
+
+def test_steady_state_channel_linear_drag():
+    """test/swe2d/test_steady_state_channel.py with explicit marching instead of the implicit solve: linear equations,
+    linear drag f = g/lx, inflow un = -1 on marker 1, elev = 0 on marker 2, initial u = (1, 0); the steady free surface is
+    eta = 1 - x/lx (the reference's criterion: L2 error / sqrt(area) < 1e-2)."""
+    lx, ly = 5e3, 1e3
+    mesh = RectangleMesh(10, 1, lx, ly)
+    bath = np.full(mesh.num_vertices, 100.0)
+    g = 9.81
+    orc = make_oracle(mesh, bath, use_nonlinear_equations=False, linear_drag_coefficient=g/lx,
+                      bnd_conditions={1: {'un': -1.0}, 2: {'elev': 0.0}})
+    n = mesh.num_cells
+    uv = np.zeros((n, 3, 2))
+    uv[:, :, 0] = 1.0
+    eta = np.zeros((n, 3))
+    dt = 2.0
+    for _ in range(int(6000.0/dt)):                  # ~12 drag time scales (1/f = 510 s)
+        uv, eta = orc.ssprk33_step(uv, eta, dt)
+    x = mesh.cell_xy()[:, :, 0]
+    err2 = 0.0
+    for bary, _, wA in orc.cell_quad:
+        err2 += np.sum(wA*((eta @ bary) - (1.0 - (x @ bary)/lx))**2)
+    assert math.sqrt(err2/(lx*ly)) < 1e-2
+    assert np.abs(uv[:, :, 0] - 1.0).max() < 2e-2 and np.abs(uv[:, :, 1]).max() < 1e-2
