@@ -318,3 +318,50 @@ def test_steady_state_channel_reference_scenario(hip_lib):
     so.iterate()
     eta = so.fields.elev_2d.cell_node_values()
     assert l2_error(mesh2d, eta, lambda x, y: 1.0 - x/lx) < 1e-2
+
+
+def test_steady_state_channel_mms_reference_scenario(hip_lib):
+    """test/swe2d/test_steady_state_channel_mms.py[dg-dg]: nonlinear equations, quadratic drag C_D = 0.0025, manufactured
+    eta = cos(kx), u = Q/H with the momentum source of :42, Function-valued 'un' inflow / 'elev' outflow, meshes
+    48*2^i x 1.  The reference finds the steady state with a Newton solve; here SSPRK33 marches to it (1e5 s, up to 1e6
+    steps of the 768-cell mesh, ~1 min of GPU time) from the reference's initial guess u = (1, 0).  Criteria :113-127:
+    every refinement divides the eta and u errors by more than 4*0.75, the total by more than 4^3*0.75."""
+    from mms_basin import l2_error
+    lx, ly = 5e3, 1e3
+    g, H0, Q, eta0, C_D = 9.81, 10.0, 10.0, 1.0, 0.0025
+    k = 4.0*math.pi/lx
+    eta_f = lambda x, y: eta0*np.cos(k*x)
+    H_f = lambda x: H0 + eta0*np.cos(k*x)
+    u_f = lambda x, y: Q/H_f(x)
+    src_f = lambda x, y: (k*eta0*(Q**2/H_f(x)**3 - g)*np.sin(k*x) + C_D*np.abs(u_f(x, y))*u_f(x, y)/H_f(x), 0.0*x)
+    eta_errs, u_errs = [], []
+    for i in range(4):
+        n = 48*2**i
+        mesh2d = RectangleMesh(n, 1, lx, ly)
+        p1_2d = get_functionspace(mesh2d, 'CG', 1)
+        bathymetry_2d = Function(p1_2d, name='bathymetry').assign(H0)
+        so = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+        o = so.options
+        o.element_family = 'dg-dg'
+        o.polynomial_degree = 1
+        o.use_nonlinear_equations = True
+        o.quadratic_drag_coefficient = Constant(C_D)
+        o.no_exports = True
+        o.swe_timestepper_type = 'SSPRK33'
+        o.swe_timestepper_options.use_automatic_timestep = False
+        o.timestep = 0.08*(lx/n)/math.sqrt(g*(H0 + eta0))
+        o.simulation_end_time = 1.0e5
+        o.simulation_export_time = 1.0e5
+        so.create_function_spaces()
+        o.momentum_source_2d = Function(so.function_spaces.U_2d, name='Source').project(src_f)
+        inflow_func = Function(p1_2d).interpolate(lambda x, y: -u_f(x, y))
+        outflow_func = Function(p1_2d).assign(eta0)
+        so.bnd_functions['shallow_water'] = {1: {'un': inflow_func}, 2: {'elev': outflow_func}}
+        so.create_equations()
+        so.assign_initial_conditions(uv=Constant((1.0, 0.0)))
+        so.iterate()
+        eta_errs.append(l2_error(mesh2d, so.fields.elev_2d.cell_node_values(), eta_f))
+        u_errs.append(l2_error(mesh2d, so.fields.uv_2d.cell_node_values()[:, :, 0], u_f))
+    for errs in (np.array(eta_errs), np.array(u_errs)):
+        assert all(errs[:-1]/errs[1:] > 2.0**2*0.75), errs
+        assert errs[0]/errs[-1] > (2.0**2)**3*0.75, errs
