@@ -44,7 +44,11 @@ def cpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     from thetis_amd.partition import build_partition, strip_owner
     dist = _init(rank, world, port)
     mesh, bath, uv, eta = _case()
-    owner = strip_owner(mesh, world, axis=axis)
+    if axis < 0:                       # recursive coordinate bisection instead of strips
+        from thetis_amd.partition import rcb_owner
+        owner = rcb_owner(mesh, world)
+    else:
+        owner = strip_owner(mesh, world, axis=axis)
     part = build_partition(mesh, owner, rank)
     ref = RefSWE(part.cell_xy(), part.cell_nbr, part.cell_nbr_facet, bath[part.vertex_global][part.cells],
                  boundary_len=part.boundary_len)

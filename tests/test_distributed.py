@@ -185,3 +185,48 @@ def test_two_ranks_coupled_on_one_gpu_match_single_device(tmp_path, hip_lib):
     d = dev.tracer_diagnostics(tid)
     assert np.allclose(extra[0]['td'][:2], d[:2], rtol=1e-13) and extra[0]['td'][2] == d[2] and extra[0]['td'][3] == d[3]
     dev.close()
+
+
+def test_rcb_partition_invariants_and_halo_consistency():
+    """Recursive coordinate bisection for general meshes: balanced, compact parts; more than two peers per
+    rank (corner neighbours); the 3-layer halo bookkeeping holds for any owner array."""
+    from thetis_amd.partition import rcb_owner
+    import dist_worker
+    dist_worker.CASE = 'delaunay'
+    try:
+        mesh, bath, uv, eta = dist_worker._case()
+    finally:
+        dist_worker.CASE = 'channel'
+    for world in (4, 6):
+        owner = rcb_owner(mesh, world)
+        counts = np.bincount(owner, minlength=world)
+        assert counts.min() > 0 and counts.max() - counts.min() <= world
+        parts = [build_partition(mesh, owner, r) for r in range(world)]
+        assert sorted(np.concatenate([p.local_to_global[:p.n_owned] for p in parts])) == list(range(mesh.num_cells))
+        assert max(len(p.peers) for p in parts) > 2
+        for p in parts:
+            g = p.local_to_global
+            for i in range(3):
+                end = p.stage_range(i)
+                valid_in = p.num_cells if i == 0 else p.stage_range(i - 1)
+                assert p.cell_nbr[:end].max() < valid_in
+            for q, (off, cnt) in p.recv.items():
+                soff, scnt = parts[q].send[p.rank]
+                assert scnt == cnt
+                assert np.array_equal(parts[q].local_to_global[parts[q].send_cells[soff:soff + scnt]],
+                                      g[p.recv_cells[off:off + cnt]])
+            assert sorted(p.recv_cells) == list(range(p.n_owned, p.num_cells))
+
+
+def test_gloo_rcb_partition_equals_global(tmp_path, ref_so):
+    """4 ranks, RCB owner array on the unstructured mesh: bitwise the global result."""
+    import dist_worker
+    dist_worker.CASE = 'delaunay'
+    try:
+        mesh, bath, uv, eta = dist_worker._case()
+        run_workers(cpu_worker, 4, 2, str(tmp_path), axis=-1, case='delaunay')
+        u_p, e_p, _ = gather(str(tmp_path), 4, mesh.num_cells)
+    finally:
+        dist_worker.CASE = 'channel'
+    u_g, e_g = make_ref(mesh, bath).advance(uv, eta, 2.0, 2)
+    assert np.array_equal(u_p, u_g) and np.array_equal(e_p, e_g)

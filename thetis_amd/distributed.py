@@ -78,6 +78,7 @@ class DistributedSwe2d(object):
         import torch
         from .device import Swe2dDevice
         self.rank, self.world = rank, world_size
+        # default: strips (<= 2 peers = one xGMI link each); pass owner=rcb_owner(mesh, n) for compact parts of a general mesh
         owner = strip_owner(mesh, world_size) if owner is None else owner
         self.use_limiter = bool(use_limiter) and n_tracers > 0
         self.tracer_only = bool(tracer_only)

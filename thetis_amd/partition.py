@@ -16,7 +16,7 @@ without any handshake: every rank builds its own partition from the (replicated)
 """
 import numpy as np
 
-__all__ = ['strip_owner', 'LocalPartition', 'build_partition']
+__all__ = ['strip_owner', 'rcb_owner', 'LocalPartition', 'build_partition']
 
 
 def strip_owner(mesh, n_parts, axis=0):
@@ -28,6 +28,29 @@ def strip_owner(mesh, n_parts, axis=0):
     bounds = np.linspace(0, mesh.num_cells, n_parts + 1).astype(np.int64)
     for p in range(n_parts):
         owner[order[bounds[p]:bounds[p + 1]]] = p
+    return owner
+
+
+def rcb_owner(mesh, n_parts):
+    """Recursive coordinate bisection of the cell centroids (general meshes): the cell set is split along its
+    longer extent into two parts whose sizes follow the split of ``n_parts`` (any count, not only powers of two), and so
+    on.  Compact parts => short halos; a part then has up to 8 neighbours on a 2D mesh (strips: 2).  Ties are broken by
+    cell id, so every rank computes the same owner array."""
+    c = mesh.cell_xy().mean(axis=1)
+    owner = np.zeros(mesh.num_cells, dtype=np.int32)
+
+    def split(ids, first, count):
+        if count == 1:
+            owner[ids] = first
+            return
+        left = count//2
+        ext = c[ids].max(axis=0) - c[ids].min(axis=0)
+        axis = 0 if ext[0] >= ext[1] else 1
+        order = ids[np.lexsort((ids, np.round(c[ids, axis], 9)))]
+        n_left = int(round(len(ids)*left/float(count)))
+        split(order[:n_left], first, left)
+        split(order[n_left:], first + left, count - left)
+    split(np.arange(mesh.num_cells), 0, int(n_parts))
     return owner
 
 
