@@ -1,0 +1,34 @@
+"""GPU: bench.py keeps its contract - one JSON line (the LAST stdout line) with the fields the driver reads."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('env', [{}, {'THETIS_AMD_FORCE_DIST': '1'}], ids=['single', 'distributed_path_world1'])
+def test_bench_prints_one_json_line_with_the_contract_fields(hip_lib, env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '2', '--no-cpu'],
+                       capture_output=True, text=True, env=e, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    d = json.loads(lines[-1])                      # the JSON is the last stdout line (RCCL banner flushed before it)
+    assert sum(1 for l in lines if l.lstrip().startswith('{"metric"')) == 1
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert key in d, key
+    assert d['steps'] == 6 and d['warmup'] == 2 and d['n_gpus'] == 1 and d['dtype'] == 'f64' and d['vs_baseline'] is None
+    assert d['unit'] == 'element-updates/s' and d['higher_is_better'] is True and d['data'] == 'synthetic'
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    rf = d['roofline']
+    assert rf['bound'] == 'hbm' and rf['peak'] == 8000.0 and rf['unit'] == 'GB/s'
+    assert abs(rf['frac'] - rf['achieved']/rf['peak']) < 1e-12
+    # whole-job throughput = cells * 3 stages * steps / time
+    assert abs(d['value'] - 1e6*3*6/(d['ms_per_step']*6e-3))/d['value'] < 1e-9
+    assert 1e9 < d['value'] < 1e11
