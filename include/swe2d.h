@@ -63,7 +63,13 @@ typedef enum {
     SWE2D_FIELD_MOMENTUM_SOURCE = 2,       /* options.momentum_source_2d (3N,2) shallowwater_eq.py:805-811 */
     SWE2D_FIELD_VOLUME_SOURCE = 3,         /* options.volume_source_2d        shallowwater_eq.py:825-831 */
     SWE2D_FIELD_WIND_STRESS = 4,           /* options.wind_stress (3N,2)      shallowwater_eq.py:643-649 */
-    SWE2D_FIELD_COUNT = 5
+    /* spatially varying drag coefficients (nodal DG values); a field replaces the scalar of the same name, the same
+     * exclusions apply (at most one of quadratic / Manning / Nikuradse, shallowwater_eq.py:686-696) */
+    SWE2D_FIELD_LINEAR_DRAG = 5,           /* options.linear_drag_coefficient as a Function */
+    SWE2D_FIELD_QUADRATIC_DRAG = 6,        /* options.quadratic_drag_coefficient as a Function */
+    SWE2D_FIELD_MANNING_DRAG = 7,          /* options.manning_drag_coefficient as a Function */
+    SWE2D_FIELD_NIKURADSE = 8,             /* options.nikuradse_bed_roughness as a Function */
+    SWE2D_FIELD_COUNT = 9
 } swe2d_field;
 
 /* Scalar coefficients (Constants in the reference). */

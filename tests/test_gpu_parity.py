@@ -83,6 +83,10 @@ def test_source_terms_match_oracle(hip_lib):
         dict(quadratic_drag_coefficient=0.0025, norm_smoother=0.1),
         dict(nikuradse_bed_roughness=0.05, norm_smoother=0.01),
         dict(nikuradse_bed_roughness=18.0),             # k_s above part of the depth range: C_D = 0 there (:696-697)
+        # spatially varying coefficients (Functions in the reference): per-vertex P1 fields
+        dict(manning_drag_coefficient=0.02*(1 + x/100e3), linear_drag_coefficient=1e-3*(1 + y/30e3)),
+        dict(quadratic_drag_coefficient=0.0025*(1 + y/30e3), norm_smoother=0.1),
+        dict(nikuradse_bed_roughness=0.05*(1 + x/100e3)),
         dict(wind_stress=0.1*rng.normal(size=(n, 3, 2)), bnd_conditions={3: {'drag': 0.0025}, 1: {'drag': 0.01, 'elev': 0.1}}),
     ]
     for kw in cases:
@@ -95,14 +99,18 @@ def test_source_terms_match_oracle(hip_lib):
             dev.set_field(_lib.FIELD_MOMENTUM_SOURCE, msrc)
             dev.set_field(_lib.FIELD_VOLUME_SOURCE, vsrc)
             dev.set_scalar(_lib.SCALAR_LINEAR_DRAG, 1e-3)
-        if 'manning_drag_coefficient' in kw:
-            dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
-        if 'quadratic_drag_coefficient' in kw:
-            dev.set_scalar(_lib.SCALAR_QUADRATIC_DRAG, 0.0025)
-            dev.set_scalar(_lib.SCALAR_NORM_SMOOTHER, 0.1)
-        if 'nikuradse_bed_roughness' in kw:
-            dev.set_scalar(_lib.SCALAR_NIKURADSE, kw['nikuradse_bed_roughness'])
-            dev.set_scalar(_lib.SCALAR_NORM_SMOOTHER, kw.get('norm_smoother', 0.0))
+        is_field = lambda v: isinstance(v, np.ndarray)
+        for key, sid, fid in (('manning_drag_coefficient', _lib.SCALAR_MANNING_DRAG, _lib.FIELD_MANNING_DRAG),
+                              ('quadratic_drag_coefficient', _lib.SCALAR_QUADRATIC_DRAG, _lib.FIELD_QUADRATIC_DRAG),
+                              ('nikuradse_bed_roughness', _lib.SCALAR_NIKURADSE, _lib.FIELD_NIKURADSE),
+                              ('linear_drag_coefficient', _lib.SCALAR_LINEAR_DRAG, _lib.FIELD_LINEAR_DRAG)):
+            if key in kw and 'coriolis' not in kw:
+                if is_field(kw[key]):
+                    dev.set_field(fid, kw[key][mesh.cells])
+                else:
+                    dev.set_scalar(sid, kw[key])
+        if 'norm_smoother' in kw:
+            dev.set_scalar(_lib.SCALAR_NORM_SMOOTHER, kw['norm_smoother'])
         if 'wind_stress' in kw:
             dev.set_field(_lib.FIELD_WIND_STRESS, kw['wind_stress'])
             for marker, funcs in kw['bnd_conditions'].items():

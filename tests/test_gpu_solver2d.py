@@ -365,3 +365,29 @@ def test_steady_state_channel_mms_reference_scenario(hip_lib):
     for errs in (np.array(eta_errs), np.array(u_errs)):
         assert all(errs[:-1]/errs[1:] > 2.0**2*0.75), errs
         assert errs[0]/errs[-1] > (2.0**2)**3*0.75, errs
+
+
+def test_spatially_varying_drag_coefficients_through_solver(hip_lib):
+    """options.manning_drag_coefficient / linear_drag_coefficient given as Functions (roughness maps): nodal fields on the
+    device; the same run with the oracle."""
+    from helpers import make_oracle
+    solver_obj, mesh, bath, elev_init = _channel2d_solver(dt=2.0, t_end=20.0)
+    P1_2d = get_functionspace(mesh, 'CG', 1)
+    mann = Function(P1_2d).interpolate(lambda x, y: 0.02*(1.0 + x/100e3))
+    lin = Function(P1_2d).interpolate(lambda x, y: 1e-4*(1.0 + y/3750.0))
+    o = solver_obj.options
+    o.manning_drag_coefficient = mann
+    o.linear_drag_coefficient = lin
+    o.no_exports = True
+    o.simulation_export_time = 20.0
+    solver_obj.assign_initial_conditions(elev=elev_init)
+    uv0 = solver_obj.fields.uv_2d.cell_node_values().copy()
+    e0 = solver_obj.fields.elev_2d.cell_node_values().copy()
+    solver_obj.iterate()
+    orc = make_oracle(mesh, bath.dat.data_ro, manning_drag_coefficient=mann.dat.data_ro, linear_drag_coefficient=lin.dat.data_ro)
+    u, e = uv0, e0
+    for _ in range(solver_obj.iteration):
+        u, e = orc.ssprk33_step(u, e, 2.0)
+    assert solver_obj.iteration == 10
+    assert rel_linf(solver_obj.fields.uv_2d.cell_node_values(), u) < 1e-11
+    assert rel_linf(solver_obj.fields.elev_2d.cell_node_values(), e) < 1e-11

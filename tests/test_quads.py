@@ -20,6 +20,8 @@ def _cases(mesh, n):
                         volume_source=1e-3*rng.normal(size=(n, 4))),
         'manning': dict(manning_drag_coefficient=0.02),
         'quad_drag': dict(quadratic_drag_coefficient=0.0025, norm_smoother=0.1),
+        'drag_fields': dict(manning_drag_coefficient=0.02*(1 + x/x.max()), linear_drag_coefficient=1e-3*(1 + y/y.max())),
+        'nikuradse_field': dict(nikuradse_bed_roughness=0.05*(1 + x/x.max())),
         'bcs': dict(bnd_conditions=_BCS),
         'wind_bdrag': dict(wind_stress=0.1*rng.normal(size=(n, 4, 2)),
                            bnd_conditions={3: {'drag': 0.0025}, 1: {'drag': 0.01, 'elev': 0.1}}),
@@ -99,13 +101,14 @@ def test_quad_standing_wave_second_order(ref_so):
 
 # ------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', ['default', 'linear', 'no_lf', 'sources', 'manning', 'quad_drag', 'bcs', 'wind_bdrag'])
+@pytest.mark.parametrize('case', ['default', 'linear', 'no_lf', 'sources', 'manning', 'quad_drag', 'drag_fields',
+                                  'nikuradse_field', 'bcs', 'wind_bdrag'])
 def test_quad_gpu_tendency_matches_oracle(hip_lib, case):
     from thetis_amd import _lib
     from thetis_amd.device import Swe2dDevice
     mesh, bath, uv, eta = quad_case(skew=0.3, seed=1)
     kw = _cases(mesh, mesh.num_cells)[case]
-    if case in ('manning', 'quad_drag', 'wind_bdrag'):
+    if case in ('manning', 'quad_drag', 'wind_bdrag', 'drag_fields', 'nikuradse_field'):
         eta = np.abs(eta)
     dt = 3.0
     orc = make_oracle_generic(mesh, bath, **kw)
@@ -122,6 +125,11 @@ def test_quad_gpu_tendency_matches_oracle(hip_lib, case):
     if case == 'quad_drag':
         dev.set_scalar(_lib.SCALAR_QUADRATIC_DRAG, 0.0025)
         dev.set_scalar(_lib.SCALAR_NORM_SMOOTHER, 0.1)
+    if case == 'drag_fields':
+        dev.set_field(_lib.FIELD_MANNING_DRAG, kw['manning_drag_coefficient'][mesh.cells])
+        dev.set_field(_lib.FIELD_LINEAR_DRAG, kw['linear_drag_coefficient'][mesh.cells])
+    if case == 'nikuradse_field':
+        dev.set_field(_lib.FIELD_NIKURADSE, kw['nikuradse_bed_roughness'][mesh.cells])
     if case == 'bcs':
         for m, funcs in _BCS.items():
             dev.set_bc(m, funcs)

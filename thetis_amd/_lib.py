@@ -14,6 +14,7 @@ MAX_MARKERS = 16
 BC_ELEV, BC_UV, BC_UN, BC_FLUX = 1, 2, 4, 8
 BC_ELEV_FIELD, BC_UV_FIELD, BC_UN_FIELD, BC_FLUX_FIELD = 16, 32, 64, 128
 FIELD_CORIOLIS, FIELD_ATMOSPHERIC_PRESSURE, FIELD_MOMENTUM_SOURCE, FIELD_VOLUME_SOURCE, FIELD_WIND_STRESS = 0, 1, 2, 3, 4
+FIELD_LINEAR_DRAG, FIELD_QUADRATIC_DRAG, FIELD_MANNING_DRAG, FIELD_NIKURADSE = 5, 6, 7, 8
 SCALAR_LINEAR_DRAG, SCALAR_QUADRATIC_DRAG, SCALAR_MANNING_DRAG, SCALAR_NORM_SMOOTHER, SCALAR_NIKURADSE = 0, 1, 2, 3, 4
 
 OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NOT_FINITE = 0, -1, -2, -3, -4, -5

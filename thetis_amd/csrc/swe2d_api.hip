@@ -46,7 +46,7 @@ struct Handle {
     double *nu_v = nullptr;                            // per-vertex viscosity or null (constant)
     double nu_const = 0.0, sipg_factor = 1.0;
     int visc_grad_div = 0, visc_grad_depth = 1;
-    double *field[SWE2D_FIELD_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *field[SWE2D_FIELD_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double scalar[SWE2D_SCALAR_COUNT] = {-1.0, -1.0, -1.0, 0.0, -1.0};
     double *stage_uv = nullptr, *stage_eta = nullptr;  // device staging in host layout (6N + 3N)
     double *partial = nullptr;                         // diagnostics partial sums
@@ -179,6 +179,11 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.manning = h->scalar[SWE2D_SCALAR_MANNING_DRAG];
     a.norm_smoother = h->scalar[SWE2D_SCALAR_NORM_SMOOTHER];
     a.nikuradse = h->scalar[SWE2D_SCALAR_NIKURADSE];
+    a.lin_drag_f = h->field[SWE2D_FIELD_LINEAR_DRAG];
+    a.quad_f = nullptr; a.quad_f_kind = 0;
+    if (h->field[SWE2D_FIELD_QUADRATIC_DRAG]) { a.quad_f = h->field[SWE2D_FIELD_QUADRATIC_DRAG]; a.quad_f_kind = 1; }
+    if (h->field[SWE2D_FIELD_MANNING_DRAG]) { a.quad_f = h->field[SWE2D_FIELD_MANNING_DRAG]; a.quad_f_kind = 2; }
+    if (h->field[SWE2D_FIELD_NIKURADSE]) { a.quad_f = h->field[SWE2D_FIELD_NIKURADSE]; a.quad_f_kind = 3; }
     a.bc = h->bc;
     const bool has_u0 = (a0 != 0.0);
     stage_kernel_t kern = h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4)
@@ -544,6 +549,17 @@ int swe2d_set_field(swe2d_handle *hh, int field, const double *nodal)
         }
         return SWE2D_OK;
     }
+    if (field >= SWE2D_FIELD_QUADRATIC_DRAG && field <= SWE2D_FIELD_NIKURADSE) {
+        // shallowwater_eq.py:686-696: at most one of quadratic / Manning / Nikuradse (fields and scalars alike)
+        for (int f2 = SWE2D_FIELD_QUADRATIC_DRAG; f2 <= SWE2D_FIELD_NIKURADSE; f2++)
+            if (f2 != field && h->field[f2])
+                return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "Cannot set more than one of the quadratic / Manning / Nikuradse drag parameters");
+        if (h->scalar[SWE2D_SCALAR_QUADRATIC_DRAG] >= 0.0 || h->scalar[SWE2D_SCALAR_MANNING_DRAG] >= 0.0
+            || h->scalar[SWE2D_SCALAR_NIKURADSE] >= 0.0)
+            return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "Cannot combine a drag coefficient field with a scalar quadratic / Manning / Nikuradse parameter");
+    }
+    if (field == SWE2D_FIELD_LINEAR_DRAG && h->scalar[SWE2D_SCALAR_LINEAR_DRAG] >= 0.0)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "linear drag is already set as a scalar");
     if (!h->field[field]) {
         HIP_TRY(h, hipMalloc(&h->field[field], (size_t)h->npc*ncomp*h->stride*sizeof(double)));
         HIP_TRY(h, hipMemsetAsync(h->field[field], 0, (size_t)h->npc*ncomp*h->stride*sizeof(double), h->stream));
@@ -576,6 +592,12 @@ int swe2d_set_scalar(swe2d_handle *hh, int which, double value)
             return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "Cannot set both dimensionless and Nikuradse drag parameter");
         if (value == 0.0) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "nikuradse_bed_roughness must be > 0");
     }
+    if ((which == SWE2D_SCALAR_MANNING_DRAG || which == SWE2D_SCALAR_QUADRATIC_DRAG || which == SWE2D_SCALAR_NIKURADSE)
+        && value >= 0.0
+        && (h->field[SWE2D_FIELD_QUADRATIC_DRAG] || h->field[SWE2D_FIELD_MANNING_DRAG] || h->field[SWE2D_FIELD_NIKURADSE]))
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "Cannot combine a scalar quadratic / Manning / Nikuradse parameter with a drag coefficient field");
+    if (which == SWE2D_SCALAR_LINEAR_DRAG && value >= 0.0 && h->field[SWE2D_FIELD_LINEAR_DRAG])
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "linear drag is already set as a field");
     if ((which == SWE2D_SCALAR_MANNING_DRAG || which == SWE2D_SCALAR_QUADRATIC_DRAG) && value >= 0.0
         && h->scalar[SWE2D_SCALAR_NIKURADSE] >= 0.0)
         return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "Cannot combine the Nikuradse drag with another quadratic drag parameter");

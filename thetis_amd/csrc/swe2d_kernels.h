@@ -80,6 +80,10 @@ struct SweStageArgs {
     int npc_;                 // nodes per cell (plane offsets of the vector boundary field)
     double linear_drag, quad_drag, manning, norm_smoother;   // <0: off
     double nikuradse;                                        // Nikuradse bed roughness length k_s, <0: off
+    // spatially varying drag coefficients (k planes each, or null): the field replaces the scalar of its kind
+    const double *lin_drag_f;
+    const double *quad_f;     // quadratic C_D, Manning mu or Nikuradse k_s, according to quad_f_kind
+    int quad_f_kind;          // 0 none, 1 quadratic, 2 Manning, 3 Nikuradse
     SweBcTable bc;
 };
 
@@ -309,16 +313,32 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
             bv[i] -= A*(1.0/60.0)*tu;
         }
     }
-    if (p.linear_drag >= 0.0) {                          // shallowwater_eq.py:738
+    if (p.lin_drag_f) {                                  // LinearDragTerm with a P1 coefficient: int phi_i c w, cubic
+        double c[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) c[i] = p.lin_drag_f[(size_t)i*S + k];
+        const double cs = c[0] + c[1] + c[2];
+        const double cu_ = c[0]*u[0] + c[1]*u[1] + c[2]*u[2], cv_ = c[0]*v[0] + c[1]*v[1] + c[2]*v[2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            bu[i] -= A*(1.0/60.0)*(cs*us + cu_ + c[i]*us + u[i]*cs + 2.0*c[i]*u[i]);
+            bv[i] -= A*(1.0/60.0)*(cs*vs + cv_ + c[i]*vs + v[i]*cs + 2.0*c[i]*v[i]);
+        }
+    } else if (p.linear_drag >= 0.0) {                   // shallowwater_eq.py:738
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             bu[i] -= p.linear_drag*A*(1.0/12.0)*(us + u[i]);
             bv[i] -= p.linear_drag*A*(1.0/12.0)*(vs + v[i]);
         }
     }
-    if (p.quad_drag >= 0.0 || p.manning >= 0.0 || p.nikuradse >= 0.0) {        // shallowwater_eq.py:685-700, 6-point rule
+    if (p.quad_drag >= 0.0 || p.manning >= 0.0 || p.nikuradse >= 0.0 || p.quad_f) {   // shallowwater_eq.py:685-700, 6-point rule
         const double a1 = 0.445948490915965, b1 = 0.108103018168070, w1 = 0.223381589678011;
         const double a2 = 0.091576213509771, b2 = 0.816847572980459, w2 = 0.109951743655322;
+        double cf[3] = {0.0, 0.0, 0.0};
+        if (p.quad_f) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) cf[i] = p.quad_f[(size_t)i*S + k];
+        }
 #pragma unroll
         for (int q = 0; q < 6; q++) {
             const double aa = q < 3 ? a1 : a2, bb = q < 3 ? b1 : b2, ww = q < 3 ? w1 : w2;
@@ -327,10 +347,14 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
             const double uq = l[0]*u[0] + l[1]*u[1] + l[2]*u[2];
             const double vq = l[0]*v[0] + l[1]*v[1] + l[2]*v[2];
             const double Hq = l[0]*H[0] + l[1]*H[1] + l[2]*H[2];
-            double cd = (p.manning >= 0.0) ? g*p.manning*p.manning*swe_rcbrt(Hq) : p.quad_drag;
-            if (p.nikuradse >= 0.0) {                    // C_D = 2 kappa^2 / ln(11.036 H/k_s)^2 for H > k_s, else 0   :696-697
-                const double lg = log(11.036*Hq/p.nikuradse);
-                cd = (Hq > p.nikuradse) ? 0.32/(lg*lg) : 0.0;
+            const double cq = l[0]*cf[0] + l[1]*cf[1] + l[2]*cf[2];              // field coefficient at the point
+            const int kind = p.quad_f ? p.quad_f_kind : (p.manning >= 0.0 ? 2 : (p.nikuradse >= 0.0 ? 3 : 1));
+            const double coef = p.quad_f ? cq : (kind == 2 ? p.manning : (kind == 3 ? p.nikuradse : p.quad_drag));
+            double cd = coef;
+            if (kind == 2) cd = g*coef*coef*swe_rcbrt(Hq);
+            if (kind == 3) {                             // C_D = 2 kappa^2 / ln(11.036 H/k_s)^2 for H > k_s, else 0   :696-697
+                const double lg = log(11.036*Hq/coef);
+                cd = (Hq > coef) ? 0.32/(lg*lg) : 0.0;
             }
             const double s = ww*A*cd*swe_sqrt(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother)*swe_rcp(Hq);
 #pragma unroll
@@ -1211,15 +1235,26 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
                     }
                 }
                 double drag = 0.0;
-                if (p.quad_drag >= 0.0 || p.manning >= 0.0 || p.nikuradse >= 0.0) {
-                    double cd = (p.manning >= 0.0) ? g*p.manning*p.manning*swe_rcbrt(Hq) : p.quad_drag;
-                    if (p.nikuradse >= 0.0) {
-                        const double lg = log(11.036*Hq/p.nikuradse);
-                        cd = (Hq > p.nikuradse) ? 0.32/(lg*lg) : 0.0;
+                if (p.quad_drag >= 0.0 || p.manning >= 0.0 || p.nikuradse >= 0.0 || p.quad_f) {
+                    double cq = 0.0;
+                    if (p.quad_f) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) cq += phi[i]*p.quad_f[(size_t)i*S + k];
+                    }
+                    const int kind = p.quad_f ? p.quad_f_kind : (p.manning >= 0.0 ? 2 : (p.nikuradse >= 0.0 ? 3 : 1));
+                    const double coef = p.quad_f ? cq : (kind == 2 ? p.manning : (kind == 3 ? p.nikuradse : p.quad_drag));
+                    double cd = coef;
+                    if (kind == 2) cd = g*coef*coef*swe_rcbrt(Hq);
+                    if (kind == 3) {
+                        const double lg = log(11.036*Hq/coef);
+                        cd = (Hq > coef) ? 0.32/(lg*lg) : 0.0;
                     }
                     drag = cd*swe_sqrt(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother)*swe_rcp(Hq);
                 }
-                if (p.linear_drag >= 0.0) drag += p.linear_drag;
+                if (p.lin_drag_f) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) drag += phi[i]*p.lin_drag_f[(size_t)i*S + k];
+                } else if (p.linear_drag >= 0.0) drag += p.linear_drag;
                 cu = A*(corq*vq - drag*uq + sx) - gpx*(1.0/1000.0);
                 cv_ = A*(-corq*uq - drag*vq + sy) - gpy*(1.0/1000.0);
                 ce = A*sv;

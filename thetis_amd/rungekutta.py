@@ -123,10 +123,18 @@ class ERKGenericShuOsher(TimeIntegrator):
         f = self.fields
         dev = self.device
         dev.set_scalar(_lib.SCALAR_NORM_SMOOTHER, float(getattr(self.equation.options, 'norm_smoother', 0.0) or 0.0))
-        dev.set_scalar(_lib.SCALAR_LINEAR_DRAG, _const_value(f.get('linear_drag_coefficient')))
-        dev.set_scalar(_lib.SCALAR_QUADRATIC_DRAG, _const_value(f.get('quadratic_drag_coefficient')))
-        dev.set_scalar(_lib.SCALAR_MANNING_DRAG, _const_value(f.get('manning_drag_coefficient')))
-        dev.set_scalar(_lib.SCALAR_NIKURADSE, _const_value(f.get('nikuradse_bed_roughness')))
+        # drag coefficients: Constants go to the scalar slots, Functions (spatially varying) to nodal fields
+        for key, sid, fid in (('linear_drag_coefficient', _lib.SCALAR_LINEAR_DRAG, _lib.FIELD_LINEAR_DRAG),
+                              ('quadratic_drag_coefficient', _lib.SCALAR_QUADRATIC_DRAG, _lib.FIELD_QUADRATIC_DRAG),
+                              ('manning_drag_coefficient', _lib.SCALAR_MANNING_DRAG, _lib.FIELD_MANNING_DRAG),
+                              ('nikuradse_bed_roughness', _lib.SCALAR_NIKURADSE, _lib.FIELD_NIKURADSE)):
+            v = f.get(key)
+            if isinstance(v, Function) or callable(v):
+                dev.set_scalar(sid, None)
+                dev.set_field(fid, self._nodal(v))
+            else:
+                dev.set_field(fid, None)
+                dev.set_scalar(sid, _const_value(v))
         for key, fid, vec in (('coriolis', _lib.FIELD_CORIOLIS, False),
                               ('atmospheric_pressure', _lib.FIELD_ATMOSPHERIC_PRESSURE, False),
                               ('momentum_source', _lib.FIELD_MOMENTUM_SOURCE, True),

@@ -75,8 +75,4 @@ class ShallowWaterEquations(object):
                 raise Exception('Cannot set both Nikuradse drag and Manning drag parameter')
             if fields.get('quadratic_drag_coefficient') is not None:
                 raise Exception('Cannot set both dimensionless and Nikuradse drag parameter')
-        for key in ('linear_drag_coefficient', 'quadratic_drag_coefficient', 'manning_drag_coefficient',
-                    'nikuradse_bed_roughness'):
-            v = fields.get(key)
-            if v is not None and not isinstance(v, (int, float, Constant)):
-                raise NotImplementedError('{:} must be a constant on the device path'.format(key))
+        # drag coefficients may be Constants or (spatially varying) Functions: nodal fields on the device
