@@ -391,3 +391,44 @@ def test_spatially_varying_drag_coefficients_through_solver(hip_lib):
     assert solver_obj.iteration == 10
     assert rel_linf(solver_obj.fields.uv_2d.cell_node_values(), u) < 1e-11
     assert rel_linf(solver_obj.fields.elev_2d.cell_node_values(), e) < 1e-11
+
+
+def test_time_dependent_forcing_fields_follow_update_forcings(hip_lib):
+    """A wind-stress Function (and an atmospheric pressure Function) rewritten by ``update_forcings`` at every stage time
+    t + c_i dt (rungekutta.py:933-934): the device copies are refreshed when the Functions change."""
+    from helpers import make_oracle
+    solver_obj, mesh, bath, elev_init = _channel2d_solver(dt=2.0, t_end=12.0)
+    o = solver_obj.options
+    o.no_exports = True
+    o.simulation_export_time = 12.0
+    solver_obj.create_function_spaces()
+    wind = Function(solver_obj.function_spaces.U_2d, name='wind stress')
+    patm = Function(solver_obj.function_spaces.H_2d, name='atmospheric pressure')
+    o.wind_stress = wind
+    o.atmospheric_pressure = patm
+    xy = mesh.cell_xy()
+
+    def tau(t):
+        return np.stack([0.3*np.sin(0.4*t)*(1.0 + xy[:, :, 0]/100e3), 0.1*np.cos(0.3*t) + 0.0*xy[:, :, 0]], axis=2)
+
+    def pa(t):
+        return 1.0e5 + 500.0*np.sin(0.2*t)*np.cos(xy[:, :, 0]/2e4)
+    calls = []
+
+    def update_forcings(t):
+        calls.append(t)
+        wind.dat.data[...] = tau(t).reshape(wind.dat.data_ro.shape)
+        patm.dat.data[...] = pa(t).reshape(patm.dat.data_ro.shape)
+    update_forcings(0.0)
+    solver_obj.assign_initial_conditions(elev=elev_init)
+    u, e = solver_obj.fields.uv_2d.cell_node_values().copy(), solver_obj.fields.elev_2d.cell_node_values().copy()
+    solver_obj.iterate(update_forcings=update_forcings)
+    orc = make_oracle(mesh, bath.dat.data_ro, wind_stress=tau(0.0), atmospheric_pressure=pa(0.0))
+
+    def orc_forcings(t):
+        orc.wind, orc.patm = tau(t), pa(t)
+    for k in range(solver_obj.iteration):
+        u, e = orc.ssprk33_step(u, e, 2.0, t=2.0*k, update_forcings=orc_forcings)
+    assert solver_obj.iteration == 6 and calls[1:4] == [0.0, 2.0, 1.0]          # c = (0, 1, 1/2)
+    assert rel_linf(solver_obj.fields.uv_2d.cell_node_values(), u) < 1e-11
+    assert rel_linf(solver_obj.fields.elev_2d.cell_node_values(), e) < 1e-11

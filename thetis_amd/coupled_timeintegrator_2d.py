@@ -56,9 +56,8 @@ class DeviceTracerSSPRK33(object):
         self._uploaded = None
         self._device_ahead = False
         self.solution._pull_hook = self._pull
-        src = fields.get('source-{:}'.format(equation.label))
-        if src is not None:
-            self.device.tracer_set_source(self.tid, swe_stepper._nodal(src))
+        self._src_signature = None
+        self._push_source()
         if getattr(equation, 'conservative', False):
             self.device.tracer_set_conservative(self.tid, True)
         mu = fields.get('diffusivity_h-{:}'.format(equation.label))
@@ -67,6 +66,14 @@ class DeviceTracerSSPRK33(object):
             self.device.tracer_set_diffusivity(self.tid, swe_stepper._vertex_coefficient(mu),
                                                float(equation.options.sipg_factor_tracer))
         self._push_bcs()
+
+    def _push_source(self):
+        """(re-)upload the tracer source when it changed (a Function updated by update_forcings, or a Constant)"""
+        src = self.fields.get('source-{:}'.format(self.equation.label))
+        sig = self.swe._signature(src)
+        if sig != self._src_signature:
+            self.device.tracer_set_source(self.tid, None if src is None else self.swe._nodal(src))
+            self._src_signature = sig
 
     def _push_bcs(self):
         for marker in self.equation.mesh.boundary_markers:
@@ -118,6 +125,7 @@ class DeviceTracerSSPRK33(object):
         if update_forcings is not None:
             update_forcings(t + self.c[i_stage]*self.dt)
             self._push_bcs()
+            self._push_source()
         if i_stage == 0:
             self._sync_to_device()
         self.device.tracer_solve_stage(self.tid, i_stage)
@@ -141,6 +149,7 @@ class DeviceTracerForwardEuler(DeviceTracerSSPRK33):
         if update_forcings is not None:
             update_forcings(t + self.dt)
             self._push_bcs()
+            self._push_source()
         self._sync_to_device()
         self.device.tracer_forward_euler(self.tid)
         self._device_ahead = True

@@ -119,15 +119,36 @@ class ERKGenericShuOsher(TimeIntegrator):
             return np.broadcast_to(np.asarray(c, dtype=float), p.shape).copy()
         return np.full(p.shape[:2], float(c))
 
-    def _push_fields(self):
+    @staticmethod
+    def _signature(v):
+        """Changes when a coefficient may have changed: Functions carry a host version, Constants their value."""
+        if isinstance(v, Function):
+            return ('f', id(v), v._host_version)
+        if v is None or callable(v):
+            return ('o', id(v))
+        return ('c', _const_value(v))
+
+    def _push_fields(self, only_changed=False):
+        """Upload the coefficient fields.  ``only_changed``: after an ``update_forcings`` call - the reference's forms see
+        updated Functions / Constants automatically (rungekutta.py:933-934), here the ones whose signature changed are
+        uploaded again (e.g. a time-dependent wind stress or atmospheric pressure field)."""
         f = self.fields
         dev = self.device
-        dev.set_scalar(_lib.SCALAR_NORM_SMOOTHER, float(getattr(self.equation.options, 'norm_smoother', 0.0) or 0.0))
+        seen = getattr(self, '_field_signatures', {}) if only_changed else {}
+        new = {}
+
+        def changed(key):
+            new[key] = self._signature(f.get(key))
+            return seen.get(key) != new[key]
+        if not only_changed:
+            dev.set_scalar(_lib.SCALAR_NORM_SMOOTHER, float(getattr(self.equation.options, 'norm_smoother', 0.0) or 0.0))
         # drag coefficients: Constants go to the scalar slots, Functions (spatially varying) to nodal fields
         for key, sid, fid in (('linear_drag_coefficient', _lib.SCALAR_LINEAR_DRAG, _lib.FIELD_LINEAR_DRAG),
                               ('quadratic_drag_coefficient', _lib.SCALAR_QUADRATIC_DRAG, _lib.FIELD_QUADRATIC_DRAG),
                               ('manning_drag_coefficient', _lib.SCALAR_MANNING_DRAG, _lib.FIELD_MANNING_DRAG),
                               ('nikuradse_bed_roughness', _lib.SCALAR_NIKURADSE, _lib.FIELD_NIKURADSE)):
+            if not changed(key):
+                continue
             v = f.get(key)
             if isinstance(v, Function) or callable(v):
                 dev.set_scalar(sid, None)
@@ -140,14 +161,20 @@ class ERKGenericShuOsher(TimeIntegrator):
                               ('momentum_source', _lib.FIELD_MOMENTUM_SOURCE, True),
                               ('volume_source', _lib.FIELD_VOLUME_SOURCE, False),
                               ('wind_stress', _lib.FIELD_WIND_STRESS, True)):
+            if not changed(key):
+                continue
             v = f.get(key)
             dev.set_field(fid, None if v is None else self._nodal(v, vector=vec))
-        nu = f.get('viscosity_h')
-        if nu is not None:                       # HorizontalViscosityTerm, shallowwater_eq.py:554-616
-            opts = self.equation.options
-            dev.set_viscosity(self._vertex_coefficient(nu), sipg_factor=float(_const_value(opts.sipg_factor)),
-                              use_grad_div_viscosity_term=opts.use_grad_div_viscosity_term,
-                              use_grad_depth_viscosity_term=opts.use_grad_depth_viscosity_term)
+        if changed('viscosity_h'):
+            nu = f.get('viscosity_h')
+            if nu is not None:                   # HorizontalViscosityTerm, shallowwater_eq.py:554-616
+                opts = self.equation.options
+                dev.set_viscosity(self._vertex_coefficient(nu), sipg_factor=float(_const_value(opts.sipg_factor)),
+                                  use_grad_div_viscosity_term=opts.use_grad_div_viscosity_term,
+                                  use_grad_depth_viscosity_term=opts.use_grad_depth_viscosity_term)
+            elif only_changed:
+                dev.set_viscosity(None)
+        self._field_signatures = new
 
     @staticmethod
     def _vertex_coefficient(value):
@@ -219,6 +246,7 @@ class ERKGenericShuOsher(TimeIntegrator):
         if update_forcings is not None:
             update_forcings(t + self.c[i_stage]*self.dt)
             self._push_bcs()
+            self._push_fields(only_changed=True)
         if i_stage == 0:
             self._sync_to_device()
         self.device.solve_stage(i_stage)
@@ -266,6 +294,7 @@ class ForwardEuler(ERKGenericShuOsher):
         if update_forcings is not None:
             update_forcings(t + self.dt)            # the reference evaluates the forcings at the NEW time (:161-162)
             self._push_bcs()
+            self._push_fields(only_changed=True)
         self._sync_to_device()
         self.device.advance_forward_euler(1)
         self._device_ahead = True
