@@ -186,9 +186,16 @@ class ERKGenericShuOsher(TimeIntegrator):
         return float(_const_value(value))
 
     def _push_bcs(self):
+        """Upload the boundary conditions; called again after every ``update_forcings`` - markers whose Constants / Functions
+        did not change since the last upload are skipped (a Function-valued boundary costs a nodal field copy)."""
         mesh = self.equation.mesh
+        cache = self.__dict__.setdefault('_bc_signatures', {})
         for marker in mesh.boundary_markers:
             funcs = self.bnd_conditions.get(marker)
+            sig = None if funcs is None else tuple(sorted((k, self._signature(v)) for k, v in funcs.items()))
+            if marker in cache and cache[marker] == sig:
+                continue
+            cache[marker] = sig
             if funcs is None:
                 self.device.set_bc(marker, None)
                 continue
