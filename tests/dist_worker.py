@@ -200,8 +200,15 @@ def gpu_coupled_worker(rank, world, port, n_steps, out_dir, axis, case='channel'
     dist.destroy_process_group()
 
 
+def viscosity_field(mesh):
+    x, y = mesh.vertex_xy.T
+    return 20.0 + 30.0*(x - x.min())/(x.max() - x.min()) + 10.0*np.sin(y/(y.max() + 1.0)*3.0)
+
+
 def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     global CASE
+    viscous = case.endswith('+visc')
+    case = case.replace('+visc', '')
     CASE = case
     """The real DistributedSwe2d on ONE GPU shared by both ranks (gloo + host staging stands in for RCCL)."""
     from thetis_amd.distributed import DistributedSwe2d
@@ -210,6 +217,8 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     mesh, bath, uv, eta = _case()
     owner = strip_owner(mesh, world, axis=axis)
     solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, host_staged=True)
+    if viscous:     # SIPG pass on the partition: same cell ranges as the stage kernels, per-vertex viscosity of the local vertices
+        solver.dev.set_viscosity(viscosity_field(mesh)[solver.part.vertex_global], use_grad_div_viscosity_term=True)
     solver.set_state_global(uv, eta)
     d0 = solver.diagnostics()
     solver.advance(n_steps, use_graph=False)

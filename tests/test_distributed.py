@@ -230,3 +230,25 @@ def test_gloo_rcb_partition_equals_global(tmp_path, ref_so):
         dist_worker.CASE = 'channel'
     u_g, e_g = make_ref(mesh, bath).advance(uv, eta, 2.0, 2)
     assert np.array_equal(u_p, u_g) and np.array_equal(e_p, e_g)
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_viscosity_match_single_device(tmp_path, hip_lib):
+    """The SIPG viscosity pass on partitions (range launches, neighbour gradients across the halo): bitwise the single-
+    device result."""
+    from dist_worker import viscosity_field
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = _case()
+    run_workers(gpu_worker, 2, 3, str(tmp_path), axis=0, case='channel+visc')
+    u_p, e_p, _ = gather(str(tmp_path), 2, mesh.num_cells)
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev.set_viscosity(viscosity_field(mesh), use_grad_div_viscosity_term=True)
+    dev.set_state(uv, eta)
+    dev.advance(3)
+    u_s, e_s = dev.get_state()
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+    dev.set_viscosity(None)
+    dev.set_state(uv, eta)
+    dev.advance(3)
+    assert not np.array_equal(dev.get_state()[0], u_s)           # the viscous term was active
+    dev.close()
