@@ -410,3 +410,37 @@ def test_reference_horizontal_advection_convergence(hip_lib, stepper):
         errs.append(l2_error(mesh2d, so.fields.tracer_2d.cell_node_values(), ana(t)))
     slope = stats.linregress(np.log10(np.array(refs, dtype=float)**-1), np.log10(errs)).slope
     assert slope > 2*(1 - 0.2), (errs, slope)
+
+
+@pytest.mark.parametrize('cells', ['triangles', 'quadrilaterals'])
+def test_conservative_tracer_source_with_wetting_drying_depth(hip_lib, cells):
+    """ConservativeSourceTerm multiplies the source by the total depth (tracer_eq_2d.py:430-437); with wetting-drying that is
+    the displaced depth D of the explicit formulation (nodal interpolation)."""
+    from helpers import make_oracle_generic, quad_case
+    if cells == 'triangles':
+        mesh, bath, uv, eta = channel_case(seed=71)
+        mk = make_oracle
+    else:
+        mesh, bath, uv, eta = quad_case(seed=71)
+        mk = make_oracle_generic
+    bath = bath - 19.0                                   # partly dry: h + eta changes sign
+    alpha = 0.6
+    orc = mk(mesh, bath, use_wetting_and_drying=True, wetting_and_drying_alpha=alpha, wd_mode='nodal')
+    k = mesh.cells.shape[1]
+    rng = np.random.default_rng(3)
+    q = 5.0 + rng.normal(size=(mesh.num_cells, k))
+    src = 1e-2*rng.normal(size=q.shape)
+    dt = 0.5
+    dev = _dev(mesh, bath, dt, boundary_len=mesh.boundary_len)
+    dev.set_wetting_and_drying(alpha)
+    tid = dev.add_tracer()
+    dev.tracer_set_conservative(tid, True)
+    dev.tracer_set_source(tid, src)
+    dev.set_state(uv, eta)
+    dev.tracer_set_state(tid, q)
+    k_o = orc.tracer_tendency(q, uv, eta, dt, conservative=True, source=src)
+    assert rel_linf(dev.tracer_tendency(tid), k_o) < TOL
+    # the depth matters: the same call without wetting-drying differs
+    orc0 = mk(mesh, bath)
+    assert rel_linf(orc0.tracer_tendency(q, uv, eta, dt, conservative=True, source=src), k_o) > 1e-6
+    dev.close()
