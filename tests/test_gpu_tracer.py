@@ -440,6 +440,11 @@ def test_conservative_tracer_source_with_wetting_drying_depth(hip_lib, cells):
     dev.tracer_set_state(tid, q)
     k_o = orc.tracer_tendency(q, uv, eta, dt, conservative=True, source=src)
     assert rel_linf(dev.tracer_tendency(tid), k_o) < TOL
+    # tracer mass = int q-or-T * total depth, with the displaced depth D (callback.py:386-388 with get_total_depth)
+    d = dev.tracer_diagnostics(tid)
+    D = orc.nodal_depth(eta)
+    mass = sum(float(np.sum(w*(q @ bary)*(D @ bary))) for bary, _, w in orc.cell_quad)
+    assert math.isclose(d[0], mass, rel_tol=1e-12)
     # the depth matters: the same call without wetting-drying differs
     orc0 = mk(mesh, bath)
     assert rel_linf(orc0.tracer_tendency(q, uv, eta, dt, conservative=True, source=src), k_o) > 1e-6

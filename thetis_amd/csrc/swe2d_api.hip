@@ -1318,11 +1318,11 @@ int swe2d_tracer_diagnostics(swe2d_handle *hh, int id, double out[4])
     if (h->npc == 4)
         hipLaunchKernelGGL(swe_tracer_diag_kernel_quad, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
                            h->tracers[id].buf[0], h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh,
-                           h->par.use_nonlinear_equations, h->n_owned, h->partial);
+                           h->par.use_nonlinear_equations, h->n_owned, h->partial, h->wd ? h->valpha : nullptr);
     else
         hipLaunchKernelGGL(swe_tracer_diag_kernel, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
                            h->tracers[id].buf[0], h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh,
-                           h->par.use_nonlinear_equations, h->n_owned, h->partial);
+                           h->par.use_nonlinear_equations, h->n_owned, h->partial, h->wd ? h->valpha : nullptr);
     HIP_TRY(h, hipGetLastError());
     std::vector<double> part(4*(size_t)h->n_partial_blocks);
     HIP_TRY(h, hipMemcpyAsync(part.data(), h->partial, part.size()*sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -1054,7 +1054,8 @@ __global__ void swe_limiter_apply(double *t, size_t stride, int n, const int *tv
 // ---- tracer diagnostics: per-block { int T*H dx, int T dx, min T, max T }
 __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel(const double *t, const double *state, size_t stride,
                                                                     const int *cv, const double *vx, const double *vy,
-                                                                    const double *vh, int nonlinear, int n, double *partial)
+                                                                    const double *vh, int nonlinear, int n, double *partial,
+                                                                    const double *valpha)
 {
     __shared__ double red[4][SWE_BLOCK];
     const int k = blockIdx.x*SWE_BLOCK + threadIdx.x;
@@ -1066,6 +1067,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel(const double
             const int vid = cv[(size_t)i*stride + k];
             px[i] = vx[vid]; py[i] = vy[vid];
             H[i] = vh[vid] + (nonlinear ? state[(size_t)(6 + i)*stride + k] : 0.0);
+            if (valpha) H[i] = swe_wd_depth(H[i], valpha[vid]);        // total depth with wetting-drying: the displaced depth D
         }
         const double A = 0.5*((px[1] - px[0])*(py[2] - py[0]) - (px[2] - px[0])*(py[1] - py[0]));
         s_m = A*(1.0/12.0)*swe_int2(c, H);
@@ -1534,7 +1536,8 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
 // tracer diagnostics on quadrilaterals
 __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel_quad(const double *t, const double *state, size_t stride,
                                                                          const int *cv, const double *vx, const double *vy,
-                                                                         const double *vh, int nonlinear, int n, double *partial)
+                                                                         const double *vh, int nonlinear, int n, double *partial,
+                                                                         const double *valpha)
 {
     __shared__ double red[4][SWE_BLOCK];
     const int k = blockIdx.x*SWE_BLOCK + threadIdx.x;
@@ -1546,6 +1549,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel_quad(const d
             const int vid = cv[(size_t)i*stride + k];
             px[i] = vx[vid]; py[i] = vy[vid];
             H[i] = vh[vid] + (nonlinear ? state[(size_t)(8 + i)*stride + k] : 0.0);
+            if (valpha) H[i] = swe_wd_depth(H[i], valpha[vid]);
         }
         const double A = (px[1] - px[0])*(py[3] - py[0]) - (py[1] - py[0])*(px[3] - px[0]);
         s_m = A*(1.0/36.0)*swe_int2_quad(c, H);
