@@ -135,12 +135,6 @@ def test_tracer_diffusion_matches_oracle(hip_lib, case):
 
 
 def test_sipg_rejects_unsupported_configurations(hip_lib):
-    from helpers import quad_case
-    mesh, bath, uv, eta = quad_case()
-    dev = _dev(mesh, bath, 1.0)
-    with pytest.raises(RuntimeError, match='triangles only'):
-        dev.set_viscosity(1.0)
-    dev.close()
     mesh, bath, uv, eta = channel_case()
     dev = _dev(mesh, bath, 1.0)
     dev.set_wetting_and_drying(0.5)
@@ -294,3 +288,79 @@ def test_diffusive_flux_boundary_convergence(hip_lib, stepper):
         exact = lambda x, y: _fourier_series_solution(x, lx, diff_flux, float(nu), t_reached)
         errors.append(l2_error(mesh2d, sol, exact)*np.sqrt(lx*ly))
     assert errors[0]/errors[1] > 2 and errors[1]/errors[2] > 2, errors
+
+
+QUAD_VISC_CASES = {
+    'const': dict(nu='const'),
+    'field_grad_div': dict(nu='field', sipg_factor=2.5, use_grad_div_viscosity_term=True),
+    'no_grad_depth_linear': dict(nu='field', use_grad_depth_viscosity_term=False, use_nonlinear_equations=False),
+}
+
+
+@pytest.mark.parametrize('case', sorted(QUAD_VISC_CASES))
+def test_quad_viscosity_matches_oracle(hip_lib, case):
+    """swe_sipg_kernel_quad<2> on skewed parallelograms, with Dirichlet terms of every velocity-type boundary kind."""
+    from helpers import make_oracle_generic, quad_case
+    cfg = dict(QUAD_VISC_CASES[case])
+    mesh, bath, uv, eta = quad_case(nx=8, ny=6, skew=0.3, seed=33)
+    rng = np.random.default_rng(17)
+    nu = 40.0 if cfg.pop('nu') == 'const' else 20.0 + 30.0*rng.uniform(size=mesh.num_vertices)
+    nonlin = cfg.pop('use_nonlinear_equations', True)
+    n = mesh.num_cells
+    bcs = {1: {'un': 0.3}, 2: {'elev': 0.2, 'flux': -1.5e4}, 3: {'uv': 0.3*rng.normal(size=(n, 4, 2))}, 4: {'elev': 0.1}}
+    dt = 2.0
+    orc = make_oracle_generic(mesh, bath, horizontal_viscosity=nu, use_nonlinear_equations=nonlin, bnd_conditions=bcs, **cfg)
+    dev = _dev(mesh, bath, dt, use_nonlinear_equations=nonlin, boundary_len=mesh.boundary_len)
+    for marker, funcs in bcs.items():
+        dev.set_bc(marker, funcs)
+    dev.set_viscosity(nu, sipg_factor=cfg.get('sipg_factor', 1.0),
+                      use_grad_div_viscosity_term=cfg.get('use_grad_div_viscosity_term', False),
+                      use_grad_depth_viscosity_term=cfg.get('use_grad_depth_viscosity_term', True))
+    dev.set_state(uv, eta)
+    ku, ke = dev.tendency()
+    ku_o, ke_o = orc.tendency(uv, eta, dt)
+    orc0 = make_oracle_generic(mesh, bath, use_nonlinear_equations=nonlin, bnd_conditions=bcs)
+    assert rel_linf(orc0.tendency(uv, eta, dt)[0], ku_o) > 1e-4
+    assert rel_linf(ku, ku_o) < TOL and rel_linf(ke, ke_o) < TOL
+    dev.advance(2)
+    u1, e1 = dev.get_state()
+    uo, eo = uv, eta
+    for _ in range(2):
+        uo, eo = orc.ssprk33_step(uo, eo, dt)
+    assert rel_linf(u1, uo) < TOL and rel_linf(e1, eo) < TOL
+    dev.close()
+
+
+@pytest.mark.parametrize('case', ['const', 'field_and_bcs'])
+def test_quad_tracer_diffusion_matches_oracle(hip_lib, case):
+    from helpers import make_oracle_generic, quad_case
+    mesh, bath, uv, eta = quad_case(nx=8, ny=6, skew=0.3, seed=35)
+    rng = np.random.default_rng(19)
+    n = mesh.num_cells
+    T = rng.normal(size=(n, 4))
+    dt = 2.0
+    orc = make_oracle_generic(mesh, bath)
+    dev = _dev(mesh, bath, dt, boundary_len=mesh.boundary_len)
+    tid = dev.add_tracer()
+    if case == 'const':
+        mu, sipg, bcs = 25.0, 1.0, {}
+    else:
+        mu, sipg = 15.0 + 10.0*rng.uniform(size=mesh.num_vertices), 1.7
+        bcs = {1: {'value': rng.normal(size=(n, 4))}, 2: {'diff_flux': 0.05}, 3: {'value': 0.7, 'uv': np.array([0.3, -0.2])},
+               4: {'elev': 0.1}}
+        dev.tracer_set_bc(tid, 1, bcs[1]['value'])
+        dev.tracer_set_bc(tid, 3, 0.7)
+        dev.tracer_set_bc_velocity(tid, 3, uv=(0.3, -0.2))
+        for m_, kind, fl in ((1, 4, 0.0), (2, 1, 0.05), (3, 2, 0.0), (4, 3, 0.0)):
+            dev.tracer_set_diffusion_bc(tid, m_, kind, fl)
+    kw = dict(diffusivity=mu, sipg_factor_tracer=sipg, bnd_conditions=bcs)
+    dev.tracer_set_diffusivity(tid, mu, sipg)
+    dev.set_state(uv, eta)
+    dev.tracer_set_state(tid, T)
+    k_o = orc.tracer_tendency(T, uv, eta, dt, **kw)
+    assert rel_linf(orc.tracer_tendency(T, uv, eta, dt, bnd_conditions=bcs), k_o) > 1e-4
+    assert rel_linf(dev.tracer_tendency(tid), k_o) < TOL
+    for s in range(3):
+        dev.tracer_solve_stage(tid, s)
+    assert rel_linf(dev.tracer_get_state(tid), orc.tracer_ssprk33_step(T, uv, eta, dt, **kw)) < TOL
+    dev.close()

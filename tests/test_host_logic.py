@@ -136,8 +136,7 @@ def test_viscosity_and_diffusivity_configuration_checks():
     qmesh = RectangleMesh(4, 3, 10.0, 10.0, quadrilateral=True)
     qbath = Function(get_functionspace(qmesh, 'CG', 1)).assign(5.0)
     qeq = ShallowWaterEquations(get_functionspace(qmesh, 'DG', 1), DepthExpression(qbath), opts)
-    with pytest.raises(NotImplementedError, match='triangles'):
-        qeq.check_fields({'viscosity_h': Constant(1.0)})
+    qeq.check_fields({'viscosity_h': Constant(1.0)})          # quadrilaterals: swe_sipg_kernel_quad
 
 
 def test_drag_parameter_combinations_raise_like_the_reference():

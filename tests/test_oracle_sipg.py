@@ -157,3 +157,36 @@ def test_decaying_shear_flow_with_viscosity():
         errs.append(np.sqrt(np.mean((uv[:, :, 0] - exact)**2)))
     assert errs[0] < 0.02
     assert math.log2(errs[0]/errs[1]) > 1.7, errs
+
+
+@pytest.mark.parametrize('grad_div', [False, True])
+def test_sipg_forms_on_parallelogram_quadrilaterals(grad_div):
+    """DQ-1 on skewed parallelograms (cp = 4, gradients vary along a facet): the viscosity / diffusion forms stay
+    symmetric and dissipative, vanish for globally linear fields in interior cells, and conserve the tracer integral."""
+    from helpers import make_oracle_generic, quad_case
+    mesh, bath, uv0, eta0 = quad_case(nx=9, ny=7, skew=0.3, seed=4)
+    rng = np.random.default_rng(2)
+    nu = 0.5 + rng.uniform(size=mesh.num_vertices)
+    orc = make_oracle_generic(mesh, bath, horizontal_viscosity=nu, use_grad_div_viscosity_term=grad_div,
+                              use_grad_depth_viscosity_term=False, sipg_factor=2.0)
+    n = mesh.num_cells
+    u, w = rng.normal(size=(2, n, 4, 2))
+    e = np.zeros((n, 4))
+    assert math.isclose(np.sum(w*orc.viscosity_form(u, e)), np.sum(u*orc.viscosity_form(w, e)), rel_tol=1e-11)
+    assert np.sum(u*orc.viscosity_form(u, e)) > 0.0
+    mu = orc._nodal(nu)
+    c, d = rng.normal(size=(2, n, 4))
+    a_cd = np.sum(d*orc.tracer_diffusion_form(c, u, e, mu, 2.0, {}, 1.0, 0.0))
+    a_dc = np.sum(c*orc.tracer_diffusion_form(d, u, e, mu, 2.0, {}, 1.0, 0.0))
+    assert math.isclose(a_cd, a_dc, rel_tol=1e-11)
+    fc = orc.tracer_diffusion_form(c, u, e, mu, 2.0, {}, 1.0, 0.0)
+    assert abs(fc.sum()) < 1e-12*np.abs(fc).sum()
+    # linear fields: zero in interior cells (constant coefficient)
+    orc_c = make_oracle_generic(mesh, bath, horizontal_viscosity=3.0, use_grad_div_viscosity_term=grad_div,
+                                use_grad_depth_viscosity_term=False)
+    xy = mesh.cell_xy()
+    x, y = xy[:, :, 0], xy[:, :, 1]
+    ulin = np.stack([1.0 + 2e-3*x - 1e-3*y, -0.5 + 4e-4*x + 3e-3*y], axis=2)
+    inner = np.all(mesh.cell_nbr >= 0, axis=1)
+    f = orc_c.viscosity_form(ulin, e)
+    assert np.abs(f[inner]).max() < 1e-10*3.0*3e-3*np.sqrt(orc_c.area).max()

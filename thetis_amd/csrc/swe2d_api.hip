@@ -203,15 +203,16 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
         v.stride = h->stride;
         v.nbr = h->nbr; v.cv = h->cv; v.vx = h->vx; v.vy = h->vy; v.vh = h->vh;
         v.mu_v = h->nu_v; v.mu_const = h->nu_const;
-        v.sipg = 3.0*h->sipg_factor;
+        v.sipg = (h->npc == 4 ? 4.0 : 3.0)*h->sipg_factor;              // sipg_factor * cp
         v.dt = h->par.dt; v.beta = beta;
         v.cell_begin = c0; v.cell_end = c1;
         v.grad_div = h->visc_grad_div; v.grad_depth = h->visc_grad_depth;
         v.nonlin = h->par.use_nonlinear_equations;
-        v.eta = h->state[in] + 6*h->stride;
+        v.eta = h->state[in] + (size_t)2*h->npc*h->stride;
         v.bc = h->bc;
         v.bc_elev_f = h->bc_field[0]; v.bc_uv_f = h->bc_field[1]; v.bc_un_f = h->bc_field[2]; v.bc_flux_f = h->bc_field[3];
-        hipLaunchKernelGGL(swe_sipg_kernel<2>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
+        if (h->npc == 4) hipLaunchKernelGGL(swe_sipg_kernel_quad<2>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
+        else hipLaunchKernelGGL(swe_sipg_kernel<2>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         HIP_TRY(h, hipGetLastError());
     }
     return SWE2D_OK;
@@ -646,7 +647,6 @@ int swe2d_set_viscosity(swe2d_handle *hh, int enable, const double *nu_vertex, d
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
     if (!enable) { h->visc = false; return SWE2D_OK; }
-    if (h->npc != 3) return fail(h, SWE2D_ERR_UNSUPPORTED, "SIPG viscosity: triangles only");
     if (h->wd) return fail(h, SWE2D_ERR_UNSUPPORTED, "SIPG viscosity with wetting and drying");
     if (!nu_vertex && !(nu_const >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "viscosity must be >= 0");
     if (!(sipg_factor > 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "sipg_factor must be > 0");
@@ -926,7 +926,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
         v.stride = h->stride;
         v.nbr = h->nbr; v.cv = h->cv; v.vx = h->vx; v.vy = h->vy; v.vh = h->vh;
         v.mu_v = t.mu_v; v.mu_const = t.mu_const;
-        v.sipg = 3.0*t.sipg_factor;
+        v.sipg = (h->npc == 4 ? 4.0 : 3.0)*t.sipg_factor;
         v.dt = h->par.dt; v.beta = beta;
         v.cell_begin = c0; v.cell_end = c1;
         v.uv = h->state[0];
@@ -934,7 +934,8 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
         for (int m = 0; m < SWE_MAX_MARKERS; m++) { v.bc_diff_kind[m] = t.bc_diff_kind[m]; v.bc_diff_flux[m] = t.bc_diff_flux[m]; }
         v.bc_value_f = t.bc_value_f;
         for (int m = 0; m < SWE_MAX_MARKERS; m++) { v.bc_vel_kind[m] = t.bc_vel_kind[m]; v.bc_u[m] = t.bc_u[m]; v.bc_v[m] = t.bc_v[m]; }
-        hipLaunchKernelGGL(swe_sipg_kernel<1>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
+        if (h->npc == 4) hipLaunchKernelGGL(swe_sipg_kernel_quad<1>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
+        else hipLaunchKernelGGL(swe_sipg_kernel<1>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         HIP_TRY(h, hipGetLastError());
     }
     return SWE2D_OK;
@@ -1193,7 +1194,6 @@ int swe2d_tracer_set_diffusivity(swe2d_handle *hh, int id, int enable, const dou
     if (rc) return rc;
     Handle::Tracer &t = h->tracers[id];
     if (!enable) { t.diff = false; return SWE2D_OK; }
-    if (h->npc != 3) return fail(h, SWE2D_ERR_UNSUPPORTED, "SIPG tracer diffusion: triangles only");
     if (!mu_vertex && !(mu_const >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "diffusivity must be >= 0");
     if (!(sipg_factor_tracer > 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "sipg_factor_tracer must be > 0");
     rc = upload_vertex_coefficient(h, mu_vertex, &t.mu_v);

@@ -288,3 +288,272 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
         for (int i = 0; i < 3; i++) p.out[(size_t)(3*r + i)*S + k] += s*(4.0*b[r][i] - sb);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same operators on parallelogram quadrilaterals (DQ-1): cp = (p+1)^2 = 4; the gradients of the bilinear basis vary
+// along a facet, so both sides' gradients are evaluated at the facet quadrature points through the affine maps
+// x = p0 + xi a + zeta b of the cell and of the neighbour (whose two far vertices are gathered).  2 x 2 Gauss rule in the
+// cell (exact for the polynomial integrands), tensor mass inverse.  Boundary-field planes: 2*4 per component.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void swe_q1_basis(double xi, double ze, double gxi_x, double gxi_y, double gze_x, double gze_y,
+                                             double phi[4], double gx[4], double gy[4])
+{
+    const double dxi[4] = {-(1.0 - ze), (1.0 - ze), ze, -ze};
+    const double dze[4] = {-(1.0 - xi), -xi, xi, (1.0 - xi)};
+    phi[0] = (1.0 - xi)*(1.0 - ze); phi[1] = xi*(1.0 - ze); phi[2] = xi*ze; phi[3] = (1.0 - xi)*ze;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        gx[i] = dxi[i]*gxi_x + dze[i]*gze_x;
+        gy[i] = dxi[i]*gxi_y + dze[i]*gze_y;
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgArgs p)
+{
+    const int lb = swe_logical_block(blockIdx.x, gridDim.x);
+    const int k = p.cell_begin + lb*SWE_BLOCK + (int)threadIdx.x;
+    if (k >= p.cell_end) return;
+    const size_t S = p.stride;
+    const bool gd = (NC == 2) && p.grad_div;
+    const double RX[4] = {0.0, 1.0, 1.0, 0.0}, RZ[4] = {0.0, 0.0, 1.0, 1.0};      // reference corners
+
+    int nb[4], vid[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        nb[i] = p.nbr[(size_t)i*S + k];
+        vid[i] = p.cv[(size_t)i*S + k];
+    }
+    double c[NC][4];
+#pragma unroll
+    for (int r = 0; r < NC; r++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) c[r][i] = p.in[(size_t)(4*r + i)*S + k];
+    double px[4], py[4], mu[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        px[i] = p.vx[vid[i]];
+        py[i] = p.vy[vid[i]];
+        mu[i] = p.mu_v ? p.mu_v[vid[i]] : p.mu_const;
+    }
+    const double ax = px[1] - px[0], ay = py[1] - py[0], bx = px[3] - px[0], by = py[3] - py[0];
+    const double A = ax*by - ay*bx, rA = 1.0/A;
+    const double gxi_x = by*rA, gxi_y = -bx*rA, gze_x = -ay*rA, gze_y = ax*rA;     // grad(xi), grad(zeta)
+    double eo[4] = {0.0, 0.0, 0.0, 0.0}, ho[4] = {0.0, 0.0, 0.0, 0.0};
+    if (NC == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            ho[i] = p.vh[vid[i]];
+            eo[i] = p.eta[(size_t)i*S + k];
+        }
+    }
+    double b[NC][4];
+#pragma unroll
+    for (int r = 0; r < NC; r++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) b[r][i] = 0.0;
+
+    // ---- cell integrals, 2 x 2 Gauss-Legendre (weight A/4)
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) {
+#pragma unroll
+        for (int qz = 0; qz < 2; qz++) {
+            double phi[4], gx[4], gy[4];
+            swe_q1_basis(qi ? SWE_XI1 : SWE_XI0, qz ? SWE_XI1 : SWE_XI0, gxi_x, gxi_y, gze_x, gze_y, phi, gx, gy);
+            double muq = 0.0, Hq = 0.0, gHx = 0.0, gHy = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                muq += phi[i]*mu[i];
+                if (NC == 2 && p.grad_depth) {
+                    const double Hn = p.nonlin ? ho[i] + eo[i] : ho[i];
+                    Hq += phi[i]*Hn; gHx += gx[i]*Hn; gHy += gy[i]*Hn;
+                }
+            }
+            double G[NC][2], S0[NC][2];
+#pragma unroll
+            for (int r = 0; r < NC; r++) {
+                G[r][0] = 0.0; G[r][1] = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { G[r][0] += c[r][i]*gx[i]; G[r][1] += c[r][i]*gy[i]; }
+            }
+#pragma unroll
+            for (int r = 0; r < NC; r++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) S0[r][j] = G[r][j] + ((NC == 2 && gd) ? G[j % NC][r] : 0.0);
+            const double w = 0.25*A*muq;
+#pragma unroll
+            for (int r = 0; r < NC; r++) {
+                const double tr = (NC == 2 && p.grad_depth) ? (gHx*S0[0][r % NC] + gHy*S0[1 % NC][r % NC])/Hq : 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) b[r][i] += w*(phi[i]*tr - (gx[i]*S0[r][0] + gy[i]*S0[r][1]));
+            }
+        }
+    }
+
+    // ---- facets
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        const int a = f, bb = (f + 1) & 3;
+        const double nxs = py[bb] - py[a], nys = px[a] - px[bb];
+        const double L = sqrt(nxs*nxs + nys*nys);
+        const double n0 = nxs/L, n1 = nys/L;
+        const double w = 0.5*L;
+        const double nn[2] = {n0, n1};
+        if (nb[f] >= 0) {
+            const int kn = nb[f] >> 2, f2 = nb[f] & 3;
+            const int na = (f2 + 1) & 3, n2 = (f2 + 2) & 3, n3 = (f2 + 3) & 3;   // neighbour: na on my a, f2 on my bb
+            // neighbour geometry from its four vertices (two shared, two gathered), indexed by ITS local numbering
+            double qx[4], qy[4], cn[NC][4];
+            qx[na] = px[a]; qy[na] = py[a]; qx[f2] = px[bb]; qy[f2] = py[bb];
+            {
+                const int v2 = p.cv[(size_t)n2*S + kn], v3 = p.cv[(size_t)n3*S + kn];
+                qx[n2] = p.vx[v2]; qy[n2] = p.vy[v2]; qx[n3] = p.vx[v3]; qy[n3] = p.vy[v3];
+            }
+#pragma unroll
+            for (int r = 0; r < NC; r++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) cn[r][i] = p.in[(size_t)(4*r + i)*S + kn];
+            const double anx = qx[1] - qx[0], any_ = qy[1] - qy[0], bnx = qx[3] - qx[0], bny = qy[3] - qy[0];
+            const double An = anx*bny - any_*bnx, rAn = 1.0/An;
+            const double hxi_x = bny*rAn, hxi_y = -bnx*rAn, hze_x = -any_*rAn, hze_y = anx*rAn;
+            const double sigma = p.sipg*L/fmin(A, An);
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const double s = q ? SWE_XI1 : SWE_XI0;
+                double phi[4], gx[4], gy[4], phn[4], hx[4], hy[4];
+                swe_q1_basis((1.0 - s)*RX[a] + s*RX[bb], (1.0 - s)*RZ[a] + s*RZ[bb], gxi_x, gxi_y, gze_x, gze_y, phi, gx, gy);
+                swe_q1_basis((1.0 - s)*RX[na] + s*RX[f2], (1.0 - s)*RZ[na] + s*RZ[f2], hxi_x, hxi_y, hze_x, hze_y, phn, hx, hy);
+                const double muq = (1.0 - s)*mu[a] + s*mu[bb];
+                double jmp[NC], S0[NC][2], S0n[NC][2], G[NC][2], Gn[NC][2];
+#pragma unroll
+                for (int r = 0; r < NC; r++) {
+                    jmp[r] = ((1.0 - s)*c[r][a] + s*c[r][bb]) - ((1.0 - s)*cn[r][na] + s*cn[r][f2]);
+                    G[r][0] = G[r][1] = Gn[r][0] = Gn[r][1] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        G[r][0] += c[r][i]*gx[i]; G[r][1] += c[r][i]*gy[i];
+                        Gn[r][0] += cn[r][i]*hx[i]; Gn[r][1] += cn[r][i]*hy[i];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < NC; r++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        S0[r][j] = G[r][j] + ((NC == 2 && gd) ? G[j % NC][r] : 0.0);
+                        S0n[r][j] = Gn[r][j] + ((NC == 2 && gd) ? Gn[j % NC][r] : 0.0);
+                    }
+#pragma unroll
+                for (int r = 0; r < NC; r++) {
+                    const double sj0 = muq*(jmp[r]*n0 + ((NC == 2 && gd) ? jmp[0]*nn[r] : 0.0));
+                    const double sj1 = muq*(jmp[r]*n1 + ((NC == 2 && gd) ? jmp[1 % NC]*nn[r] : 0.0));
+                    const double avn = 0.5*muq*((S0[r][0] + S0n[r][0])*n0 + (S0[r][1] + S0n[r][1])*n1);
+                    const double val = sigma*(sj0*n0 + sj1*n1) - avn;
+                    b[r][a] -= w*(1.0 - s)*val;
+                    b[r][bb] -= w*s*val;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) b[r][i] += w*0.5*(gx[i]*sj0 + gy[i]*sj1);
+                }
+            }
+        } else {
+            const int marker = -nb[f];
+            if (marker >= SWE_MAX_MARKERS) continue;
+            const size_t pa = (size_t)(2*a)*S + k, pb = pa + S;              // per-facet boundary-field planes
+            if (NC == 2) {
+                const int kind = p.bc.kind[marker];
+                if (!(kind & (SWE_BC_UN | SWE_BC_UV | SWE_BC_FLUX))) continue;
+                const double sigma = p.sipg*L/A;
+                double fua = 0.0, fub = 0.0, fva = 0.0, fvb = 0.0, fna = 0.0, fnb = 0.0, fea = 0.0, feb = 0.0, fxa = 0.0, fxb = 0.0;
+                if ((kind & SWE_BC_UV_FIELD) && p.bc_uv_f) {
+                    fua = p.bc_uv_f[pa]; fub = p.bc_uv_f[pb];
+                    fva = p.bc_uv_f[8*S + pa]; fvb = p.bc_uv_f[8*S + pb];
+                }
+                if ((kind & SWE_BC_UN_FIELD) && p.bc_un_f) { fna = p.bc_un_f[pa]; fnb = p.bc_un_f[pb]; }
+                if ((kind & SWE_BC_ELEV_FIELD) && p.bc_elev_f) { fea = p.bc_elev_f[pa]; feb = p.bc_elev_f[pb]; }
+                if ((kind & SWE_BC_FLUX_FIELD) && p.bc_flux_f) { fxa = p.bc_flux_f[pa]; fxb = p.bc_flux_f[pb]; }
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const double s = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - s, xb = s;
+                    double phi[4], gx[4], gy[4];
+                    swe_q1_basis(xa*RX[a] + xb*RX[bb], xa*RZ[a] + xb*RZ[bb], gxi_x, gxi_y, gze_x, gze_y, phi, gx, gy);
+                    const double muq = xa*mu[a] + xb*mu[bb];
+                    const double uq = xa*c[0][a] + xb*c[0][bb], vq = xa*c[1 % NC][a] + xb*c[1 % NC][bb];
+                    double dlt[2];
+                    if (kind & SWE_BC_UN) {
+                        const double un_ext = (kind & SWE_BC_UN_FIELD) ? xa*fna + xb*fnb : p.bc.un[marker];
+                        const double d = uq*n0 + vq*n1 - un_ext;
+                        dlt[0] = d*n0; dlt[1] = d*n1;
+                    } else if (kind & SWE_BC_UV) {
+                        dlt[0] = uq - ((kind & SWE_BC_UV_FIELD) ? xa*fua + xb*fub : p.bc.u[marker]);
+                        dlt[1] = vq - ((kind & SWE_BC_UV_FIELD) ? xa*fva + xb*fvb : p.bc.v[marker]);
+                    } else {
+                        const double eq = xa*eo[a] + xb*eo[bb], hq = xa*ho[a] + xb*ho[bb];
+                        const double e_ext = (kind & SWE_BC_ELEV) ? ((kind & SWE_BC_ELEV_FIELD) ? xa*fea + xb*feb : p.bc.elev[marker]) : eq;
+                        const double H0 = p.nonlin ? hq + e_ext : hq;
+                        const double sc = ((kind & SWE_BC_FLUX_FIELD) ? xa*fxa + xb*fxb : p.bc.flux[marker])/(H0*p.bc.len[marker]);
+                        dlt[0] = uq - sc*n0; dlt[1] = vq - sc*n1;
+                    }
+                    double G[NC][2];
+#pragma unroll
+                    for (int r = 0; r < NC; r++) {
+                        G[r][0] = G[r][1] = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { G[r][0] += c[r][i]*gx[i]; G[r][1] += c[r][i]*gy[i]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < NC; r++) {
+                        const double s00 = G[r][0] + (gd ? G[0][r % 2] : 0.0), s01 = G[r][1] + (gd ? G[1 % NC][r % 2] : 0.0);
+                        const double sj0 = muq*(dlt[r % 2]*n0 + (gd ? dlt[0]*nn[r % 2] : 0.0));
+                        const double sj1 = muq*(dlt[r % 2]*n1 + (gd ? dlt[1]*nn[r % 2] : 0.0));
+                        const double val = sigma*(sj0*n0 + sj1*n1) - muq*(s00*n0 + s01*n1);
+                        b[r][a] -= w*xa*val;
+                        b[r][bb] -= w*xb*val;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) b[r][i] += w*(gx[i]*sj0 + gy[i]*sj1);
+                    }
+                }
+            } else {
+                const int kd = p.bc_diff_kind[marker];
+                if (kd == SWE_SIPG_BC_NONE) continue;
+                double ua = 0.0, ub = 0.0, va = 0.0, vb = 0.0, ce[4] = {0.0, 0.0, 0.0, 0.0};
+                if (kd == SWE_SIPG_BC_UPWIND || kd == SWE_SIPG_BC_VALUE_FIELD) {
+                    ua = p.vel_factor*p.uv[(size_t)a*S + k]; ub = p.vel_factor*p.uv[(size_t)bb*S + k];
+                    va = p.vel_factor*p.uv[(size_t)(4 + a)*S + k]; vb = p.vel_factor*p.uv[(size_t)(4 + bb)*S + k];
+                }
+                if (kd == SWE_SIPG_BC_VALUE_FIELD) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) ce[i] = p.bc_value_f[(size_t)(4*f + i)*S + k];
+                }
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const double s = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - s, xb = s;
+                    double val;
+                    if (kd == SWE_SIPG_BC_DIFF_FLUX) {
+                        val = -p.bc_diff_flux[marker];
+                    } else {
+                        double phi[4], gx[4], gy[4];
+                        swe_q1_basis(xa*RX[a] + xb*RX[bb], xa*RZ[a] + xb*RZ[bb], gxi_x, gxi_y, gze_x, gze_y, phi, gx, gy);
+                        double g0 = 0.0, g1 = 0.0, e0_ = 0.0, e1_ = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { g0 += c[0][i]*gx[i]; g1 += c[0][i]*gy[i]; e0_ += ce[i]*gx[i]; e1_ += ce[i]*gy[i]; }
+                        const double muq = xa*mu[a] + xb*mu[bb];
+                        double uq = xa*ua + xb*ub, vq = xa*va + xb*vb, ue = uq, ve = vq;
+                        if (p.bc_vel_kind[marker] == 1) { ue = p.vel_factor*p.bc_u[marker]; ve = p.vel_factor*p.bc_v[marker]; }
+                        else if (p.bc_vel_kind[marker] == 2) { ue = p.bc_u[marker]*n0; ve = p.bc_u[marker]*n1; }
+                        const double un = 0.5*((uq + ue)*n0 + (vq + ve)*n1);
+                        const double sw = (kd == SWE_SIPG_BC_GRAD_IN) ? 1.0 : (un > 0.0 ? 1.0 : (un < 0.0 ? 0.0 : 0.5));
+                        val = -muq*((sw*g0 + (1.0 - sw)*e0_)*n0 + (sw*g1 + (1.0 - sw)*e1_)*n1);
+                    }
+                    b[0][a] -= w*xa*val;
+                    b[0][bb] -= w*xb*val;
+                }
+            }
+        }
+    }
+    // ---- tensor mass inverse (M^-1 b)_i = (16 b_i - 8 b_{i+1} - 8 b_{i-1} + 4 b_{i+2})/A
+    const double sc = p.dt*p.beta*rA;
+#pragma unroll
+    for (int r = 0; r < NC; r++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            p.out[(size_t)(4*r + i)*S + k] += sc*(16.0*b[r][i] - 8.0*b[r][(i + 1) & 3] - 8.0*b[r][(i + 3) & 3] + 4.0*b[r][(i + 2) & 3]);
+}

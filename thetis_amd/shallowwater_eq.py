@@ -9,7 +9,7 @@ configuration is one the kernel implements:
   ExternalPressureGradientTerm :335   HUDivTerm :396   HorizontalAdvectionTerm :453 (+ Lax-Friedrichs)
   CoriolisTerm :619   AtmosphericPressureTerm :652   QuadraticDragTerm :666 (constant C_D or Manning)
   LinearDragTerm :728   MomentumSourceTerm :794   ContinuitySourceTerm :814   WindStressTerm :637   BoundaryDragTerm :704
-  HorizontalViscosityTerm :513 (SIPG; separate pass kernel csrc/swe2d_sipg.h, triangles, Constant or CG-P1 viscosity)
+  HorizontalViscosityTerm :513 (SIPG; separate pass kernels csrc/swe2d_sipg.h, Constant or CG-P1 viscosity)
   boundary conditions 'elev' / 'uv' / 'un' / 'flux' with constant values (get_bnd_functions :232-272)
 """
 from .function import Function
@@ -61,9 +61,7 @@ class ShallowWaterEquations(object):
         """Raise for coefficients whose terms the kernel does not implement (never silently ignore physics)."""
         nu = fields.get('viscosity_h')
         if nu is not None:
-            # HorizontalViscosityTerm (SIPG, shallowwater_eq.py:554-616): swe_sipg_kernel<2>, triangles only
-            if self.mesh.cells.shape[1] != 3:
-                raise NotImplementedError('HorizontalViscosityTerm is implemented for triangles only')
+            # HorizontalViscosityTerm (SIPG, shallowwater_eq.py:554-616): swe_sipg_kernel<2> / swe_sipg_kernel_quad<2>
             if self.depth.use_wetting_and_drying:
                 raise NotImplementedError('HorizontalViscosityTerm with wetting and drying is not implemented')
             if isinstance(nu, Function) and nu.function_space().family != 'CG':

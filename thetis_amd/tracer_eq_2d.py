@@ -4,7 +4,7 @@ Descriptor of the 2D tracer equation for the device path (thetis/tracer_eq_2d.py
 Implemented by ``swe_tracer_stage_kernel`` (csrc/swe2d_kernels.h): non-conservative ``HorizontalAdvectionTerm``
 (:124-193; upwind DG, optional Lax-Friedrichs) and ``SourceTerm`` (:281-298), boundaries without a condition or with a
 constant ``'value'``; ``HorizontalDiffusionTerm`` (SIPG, :196-278) by the pass kernel ``swe_sipg_kernel<1>``
-(csrc/swe2d_sipg.h; triangles, Constant or CG-P1 diffusivity, ``'diff_flux'`` boundaries); the conservative form
+(csrc/swe2d_sipg.h; Constant or CG-P1 diffusivity, ``'diff_flux'`` boundaries); the conservative form
 (:325-437) is a flag of the same kernels.  Everything else (SUPG :490-501, CG tracers, Function-valued velocity boundary keys, 'flux') raises instead of silently changing the physics.
 """
 from .function import Function
@@ -26,8 +26,6 @@ class TracerEquation2D(object):
         # conservative form (q = H*T; ConservativeHorizontalAdvectionTerm :341-395, ConservativeSourceTerm :424-437):
         # a flag of the same stage kernels
         self.conservative = bool(topts.use_conservative_form)
-        if topts.diffusivity is not None and self.mesh.cells.shape[1] != 3:
-            raise NotImplementedError('horizontal tracer diffusion (SIPG) is implemented for triangles only')
         if options.use_supg_tracer:
             raise NotImplementedError('SUPG stabilisation applies to CG tracers only')
 
