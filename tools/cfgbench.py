@@ -47,6 +47,14 @@ def quads(rng):
     dev = Swe2dDevice(meshq, np.full(meshq.num_vertices, 20.0), 0.25)
     dev.set_state(1e-3*rng.uniform(-1, 1, size=(nq, 4, 2)), etaq)
     report('quadrilaterals SWE (DQ-1)', nq, 936.0, timed(dev, dev.advance, 50))
+    # cfg 4 on its own cell type (demos/demo_2d_tracer.py is a quadrilateral mesh): tracer per stage 32 r + 32 w (+32 T0)
+    # + 64 velocity + 56 static = 184 / 216 / 216 B; limiter ~ 32 + 8 + 8 + 8 + 32 + 32 + 16 = 136 B
+    tid = dev.add_tracer()
+    dev.tracer_set_state(tid, np.where(cq[:, :, 0] < 40e3, 0.0, 30.0))
+    report('cfg4 quadrilaterals SWE + tracer + limiter', nq, 936.0 + 616.0 + 136.0,
+           timed(dev, lambda k: dev.advance_coupled(k, tracer_only=False, use_limiter=True), 50))
+    report('cfg4 quadrilaterals tracer only + limiter (demo_2d_tracer mode)', nq, 616.0 + 136.0,
+           timed(dev, lambda k: dev.advance_coupled(k, tracer_only=True, use_limiter=True), 50))
     dev.close()
 
 
