@@ -10,6 +10,13 @@ kernels = 3 element-updates per cell.  Inputs are resident in HBM before the tim
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU;
                                                         the same 1M-triangle mesh is strip-partitioned: strong scaling)
+
+Clock pre-warm: an MI355X needs ~0.2-0.3 s of sustained load to settle its clocks (measured: 0.147 ms/step right after start
+with W = 10, 0.128 ms/step after 0.3 s of the same work), and W warm-up steps of 0.14 ms are over long before that.  Since
+production runs are thousands of steps, the bench first runs PREWARM_S seconds of the same time stepping (i.e. extra
+untimed warm-up steps; the state simply keeps evolving - a host-side state reset would idle the GPU for ~20 ms and cool it
+down again) and only then does the W untimed warm-up steps and the K timed steps; `config.prewarm_s` reports it
+(--prewarm 0 switches it off).
 """
 import argparse
 import json
@@ -25,6 +32,7 @@ if ROOT not in sys.path:
 
 NX, NY, LX, LY = 1000, 500, 100e3, 50e3
 DT = 0.25
+PREWARM_S = 0.5                          # seconds of untimed stepping before the warm-up (clock settling), see above
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_ELEMENT_STEP = 684.0          # 180 + 252 + 252 algorithmic bytes per triangle per step
 BYTES_PER_ELEMENT_UPDATE = BYTES_PER_ELEMENT_STEP/3.0
@@ -90,6 +98,11 @@ def run_single(args):
     n = mesh.num_cells
     dev = Swe2dDevice(mesh, bath, DT, device_id=0)
     dev.set_state(uv, eta)
+    if args.prewarm > 0:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < args.prewarm:
+            dev.advance(200)
+            dev.synchronize()
     dev.advance(args.warmup)
     dev.synchronize()
     import torch
@@ -114,7 +127,8 @@ def run_single(args):
         'ms_per_step': 1e3*t_wall/args.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
         'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'BASELINE cfg2: RectangleMesh(1000,500,100e3,50e3) = 1M triangles, DG-P1 SWE, SSPRK33, '
-                               'flat h=20, closed walls, dt=0.25', 'n_cells': n, 'parallelism': 'single'},
+                               'flat h=20, closed walls, dt=0.25', 'n_cells': n, 'parallelism': 'single',
+                   'prewarm_s': args.prewarm},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
                      'traffic_source': traffic_src,
@@ -141,6 +155,7 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--prewarm', type=float, default=PREWARM_S, help='seconds of untimed stepping before the warm-up steps')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 or world > 1 or os.environ.get('THETIS_AMD_FORCE_DIST'):   # env: exercise the N>1 code path on one GPU

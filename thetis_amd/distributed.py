@@ -235,6 +235,11 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
     solver.set_state_global(uv, eta)
     d0 = solver.diagnostics()
     use_graph = not os.environ.get('THETIS_AMD_NO_GRAPH')
+    prewarm = float(getattr(args, 'prewarm', 0.0) or 0.0)
+    if prewarm > 0:
+        # clock settling (bench.py docstring): a FIXED number of steps so that every rank posts the same exchanges
+        solver.advance(int(prewarm/100e-6), use_graph=False)
+        solver.synchronize()
     if args.warmup > 0:
         solver.advance(args.warmup, use_graph=False)
     solver.synchronize()
@@ -268,7 +273,7 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
             'config': {'workload': 'BASELINE cfg3: the cfg2 1M-triangle channel strip-partitioned along x over {:d} GPUs, '
                                    '3-layer halo, one RCCL exchange per time step'.format(world),
                        'n_cells': int(n_total), 'parallelism': 'dd{:d} (domain decomposition, 3-cell halo, 1 exchange/step)'.format(world),
-                       'hip_graph': hip_graph, 'volume_conserved': ok},
+                       'hip_graph': hip_graph, 'volume_conserved': ok, 'prewarm_s': prewarm},
             'roofline': {'bound': 'hbm', 'achieved': float(per_gpu_bytes*3*args.steps/t/1e9), 'peak': hbm_peak, 'unit': 'GB/s',
                          'frac': float(per_gpu_bytes*3*args.steps/t/1e9/hbm_peak), 'traffic': None,
                          'note': 'per GPU, algorithmic bytes over wall time per stage (includes halo exchange); '
