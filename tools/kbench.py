@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--tag', default='')
     ap.add_argument('--nx', type=int, default=0, help='override the mesh: RectangleMesh(nx, ny), same cell size')
     ap.add_argument('--ny', type=int, default=0)
+    ap.add_argument('--prewarm', type=float, default=0.3, help='seconds of stepping before the measurement (clock settling)')
     ap.add_argument('--calibrate', action='store_true', help='also run the PMC calibration copy kernel')
     args = ap.parse_args()
     import bench
@@ -59,8 +60,13 @@ def main():
         reorder = np.lexsort((np.arange(mesh.num_cells), i % bx, j % by, d))
     dev = Swe2dDevice(mesh, bath, bench.DT, reorder=reorder)
     dev.set_state(uv, eta)
+    import time
+    t0 = time.perf_counter()
     dev.advance(5)
     dev.synchronize()
+    while time.perf_counter() - t0 < args.prewarm:
+        dev.advance(100)
+        dev.synchronize()
     if args.calibrate:
         dev._ck(dev.lib.swe2d_debug_calibration_copy(dev.h, 5))
     best = 1e9
