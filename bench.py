@@ -108,14 +108,16 @@ def run_single(args):
     import torch
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    dev.advance(args.steps)
+    # the K timed steps, bracketed on the launch stream by two HIP events (swe2d_advance_timed) and by the host clock
+    ms_events, _ = dev.advance_timed(args.steps, per_launch=False)
     dev.synchronize()
     torch.cuda.synchronize()
     t_wall = time.perf_counter() - t0
-    # per-launch kernel duration: HIP events around every stage launch, on the launch stream (separate pass so that
-    # the event records do not sit inside the timed region above)
+    # mean stage-kernel launch duration over the timed region: 3 back-to-back launches per step, no gaps in between
+    ms_kernel = ms_events/(3.0*args.steps)
+    # cross-check (separate pass): events around every single launch; ~3 % higher because of the event brackets
     n_ev = min(args.steps, 50)
-    ms_tot, ms_kernel = dev.advance_timed(n_ev, per_launch=True)
+    _, ms_kernel_each = dev.advance_timed(n_ev, per_launch=True)
     d = dev.diagnostics()
     assert np.isfinite(d).all()
     value = n*3.0*args.steps/t_wall
@@ -132,7 +134,7 @@ def run_single(args):
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
                      'traffic_source': traffic_src,
-                     'kernel': 'swe_stage_kernel', 'avg_launch_ms': ms_kernel,
+                     'kernel': 'swe_stage_kernel', 'avg_launch_ms': ms_kernel, 'avg_launch_ms_per_launch_events': ms_kernel_each,
                      'algorithmic_bytes_per_launch': BYTES_PER_ELEMENT_UPDATE*n},
     }
     if not args.no_cpu:
