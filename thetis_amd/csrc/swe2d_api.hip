@@ -272,6 +272,11 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
         return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "null mesh array");
     if (!(params->dt > 0.0) || !(params->g_grav > 0.0))
         return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "dt and g_grav must be positive");
+    // the stage kernels address a group of nodes_per_cell planes through one 4 GiB raw buffer resource (32-bit offsets)
+    if ((((size_t)mesh->n_cells + 255)/256*256)*(size_t)mesh->nodes_per_cell*sizeof(double) >= ((size_t)1 << 32)
+        || (size_t)mesh->n_vertices*sizeof(double) >= ((size_t)1 << 32))
+        return fail(nullptr, SWE2D_ERR_UNSUPPORTED,
+                    "mesh too large for one device: nodes_per_cell*n_cells*8 bytes must stay below 4 GiB (partition it)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, SWE2D_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");

@@ -289,6 +289,28 @@ __device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int ma
     }
 }
 
+// Raw buffer addressing (SGPR resource + 32-bit per-lane BYTE offset + uniform SGPR byte offset): one VGPR offset serves
+// every plane of a cell, the plane offsets stay in SGPRs, and no 64-bit per-lane address arithmetic is issued.
+// A resource spans 4 GiB: one resource per group of three planes, swe2d_create rejects 3*stride*8 >= 2^32.
+typedef unsigned int swe_u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t swe_rsrc_t;
+__device__ __forceinline__ swe_rsrc_t swe_rsrc(const void *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ double swe_ld(swe_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ int swe_ldi(swe_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
+__device__ __forceinline__ void swe_st(swe_rsrc_t r, unsigned voff, unsigned soff, double x)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(swe_u32x2, x), r, voff, soff, 0);
+}
+
 // Optional cell-local terms (SRC kernel variant): Coriolis, linear / quadratic / Manning drag, atmospheric pressure
 // gradient, momentum and volume sources.  b-vectors are the assembled integrals (before the mass inverse).
 __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, size_t S, double twoA, const double u[3],
@@ -297,11 +319,12 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
 {
     const double g = p.g;
     const double A = 0.5*twoA;
+    const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u;
     const double us = u[0] + u[1] + u[2], vs = v[0] + v[1] + v[2];
     if (p.coriolis) {                                    // shallowwater_eq.py:632-633
         double f[3];
 #pragma unroll
-        for (int i = 0; i < 3; i++) f[i] = p.coriolis[(size_t)i*S + k];
+        for (int i = 0; i < 3; i++) f[i] = swe_ld(swe_rsrc(p.coriolis), k8, i*S8);
         const double fs = f[0] + f[1] + f[2];
         const double fu_ = f[0]*u[0] + f[1]*u[1] + f[2]*u[2], fv_ = f[0]*v[0] + f[1]*v[1] + f[2]*v[2];
 #pragma unroll
@@ -316,7 +339,7 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
     if (p.lin_drag_f) {                                  // LinearDragTerm with a P1 coefficient: int phi_i c w, cubic
         double c[3];
 #pragma unroll
-        for (int i = 0; i < 3; i++) c[i] = p.lin_drag_f[(size_t)i*S + k];
+        for (int i = 0; i < 3; i++) c[i] = swe_ld(swe_rsrc(p.lin_drag_f), k8, i*S8);
         const double cs = c[0] + c[1] + c[2];
         const double cu_ = c[0]*u[0] + c[1]*u[1] + c[2]*u[2], cv_ = c[0]*v[0] + c[1]*v[1] + c[2]*v[2];
 #pragma unroll
@@ -337,7 +360,7 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
         double cf[3] = {0.0, 0.0, 0.0};
         if (p.quad_f) {
 #pragma unroll
-            for (int i = 0; i < 3; i++) cf[i] = p.quad_f[(size_t)i*S + k];
+            for (int i = 0; i < 3; i++) cf[i] = swe_ld(swe_rsrc(p.quad_f), k8, i*S8);
         }
 #pragma unroll
         for (int q = 0; q < 6; q++) {
@@ -370,8 +393,8 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
         double tx[3], ty[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            tx[i] = p.wind[(size_t)i*S + k];
-            ty[i] = p.wind[(size_t)(3 + i)*S + k];
+            tx[i] = swe_ld(swe_rsrc(p.wind), k8, i*S8);
+            ty[i] = swe_ld(swe_rsrc(p.wind + 3*S), k8, i*S8);
         }
 #pragma unroll
         for (int q = 0; q < 6; q++) {
@@ -392,7 +415,7 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
         double gpx = 0.0, gpy = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            const double pa = p.patm[(size_t)i*S + k];
+            const double pa = swe_ld(swe_rsrc(p.patm), k8, i*S8);
             gpx += gxs[i]*pa;
             gpy += gys[i]*pa;
         }
@@ -406,8 +429,8 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
         double sx[3], sy[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            sx[i] = p.msrc[(size_t)i*S + k];
-            sy[i] = p.msrc[(size_t)(3 + i)*S + k];
+            sx[i] = swe_ld(swe_rsrc(p.msrc), k8, i*S8);
+            sy[i] = swe_ld(swe_rsrc(p.msrc + 3*S), k8, i*S8);
         }
         const double ssx = sx[0] + sx[1] + sx[2], ssy = sy[0] + sy[1] + sy[2];
 #pragma unroll
@@ -419,7 +442,7 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
     if (p.vsrc) {                                        // shallowwater_eq.py:830
         double sv_[3];
 #pragma unroll
-        for (int i = 0; i < 3; i++) sv_[i] = p.vsrc[(size_t)i*S + k];
+        for (int i = 0; i < 3; i++) sv_[i] = swe_ld(swe_rsrc(p.vsrc), k8, i*S8);
         const double ss = sv_[0] + sv_[1] + sv_[2];
 #pragma unroll
         for (int i = 0; i < 3; i++) be[i] += A*(1.0/12.0)*(ss + sv_[i]);
@@ -493,6 +516,8 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     if (k >= p.cell_end) return;
     const size_t S = p.stride;
     const double g = p.g;
+    const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u;
+    const swe_rsrc_t gu = swe_rsrc(p.uin), gv = swe_rsrc(p.uin + 3*S), ge = swe_rsrc(p.uin + 6*S);
 
     // ---- every load of the cell is issued here, unconditionally, so that a wave pays two memory round trips
     //      (own data + indices, then the gathers) instead of one per facet and one per output plane.
@@ -506,27 +531,29 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        u[i] = p.uin[(size_t)i*S + k];
-        v[i] = p.uin[(size_t)(3 + i)*S + k];
-        e[i] = p.uin[(size_t)(6 + i)*S + k];
+        u[i] = swe_ld(gu, k8, i*S8);
+        v[i] = swe_ld(gv, k8, i*S8);
+        e[i] = swe_ld(ge, k8, i*S8);
     }
     // w = a0*U0 + a1*U_in, the part of the Shu-Osher combine that does not depend on the tendency
     double wu[3], wv[3], we[3];
+    swe_rsrc_t g0u, g0v, g0e;
+    if (HASU0) { g0u = swe_rsrc(p.u0); g0v = swe_rsrc(p.u0 + 3*S); g0e = swe_rsrc(p.u0 + 6*S); }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         wu[i] = p.a1*u[i];
         wv[i] = p.a1*v[i];
         we[i] = p.a1*e[i];
         if (HASU0) {
-            wu[i] += p.a0*p.u0[(size_t)i*S + k];
-            wv[i] += p.a0*p.u0[(size_t)(3 + i)*S + k];
-            if (!WD) we[i] += p.a0*p.u0[(size_t)(6 + i)*S + k];
+            wu[i] += p.a0*swe_ld(g0u, k8, i*S8);
+            wv[i] += p.a0*swe_ld(g0v, k8, i*S8);
+            if (!WD) we[i] += p.a0*swe_ld(g0e, k8, i*S8);
         }
     }
     double e0[3] = {0.0, 0.0, 0.0};
     if (WD && HASU0) {
 #pragma unroll
-        for (int i = 0; i < 3; i++) e0[i] = p.u0[(size_t)(6 + i)*S + k];
+        for (int i = 0; i < 3; i++) e0[i] = swe_ld(g0e, k8, i*S8);
     }
     // neighbour traces: the neighbour traverses the shared facet backwards, its node (f2+1)%3 sits on my node f and
     // its node f2 on my node f+1.  Boundary facets read this cell itself (value unused) to keep the loads branch-free.
@@ -536,21 +563,25 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         const int nbf = nb[f];
         const int kn = nbf >= 0 ? (nbf >> 2) : k;
         const int f2 = nbf >= 0 ? (nbf & 3) : f;
-        const int na = (f2 == 2) ? 0 : f2 + 1;
-        una[f] = p.uin[(size_t)na*S + kn];
-        unb[f] = p.uin[(size_t)f2*S + kn];
-        vna[f] = p.uin[(size_t)(3 + na)*S + kn];
-        vnb[f] = p.uin[(size_t)(3 + f2)*S + kn];
-        ena[f] = p.uin[(size_t)(6 + na)*S + kn];
-        enb[f] = p.uin[(size_t)(6 + f2)*S + kn];
+        const unsigned kn8 = (unsigned)kn*8u;
+        const unsigned ob = kn8 + (f2 == 0 ? 0u : (f2 == 1 ? S8 : 2u*S8));         // node f2
+        const unsigned oa = kn8 + (f2 == 0 ? S8 : (f2 == 1 ? 2u*S8 : 0u));         // node (f2 + 1) % 3
+        una[f] = swe_ld(gu, oa, 0);
+        unb[f] = swe_ld(gu, ob, 0);
+        vna[f] = swe_ld(gv, oa, 0);
+        vnb[f] = swe_ld(gv, ob, 0);
+        ena[f] = swe_ld(ge, oa, 0);
+        enb[f] = swe_ld(ge, ob, 0);
     }
     double px[3], py[3], h[3], H[3], al[3] = {0.0, 0.0, 0.0};
+    const swe_rsrc_t rvx = swe_rsrc(p.vx), rvy = swe_rsrc(p.vy), rvh = swe_rsrc(p.vh);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        px[i] = p.vx[vid[i]];
-        py[i] = p.vy[vid[i]];
-        h[i] = p.vh[vid[i]];
-        if (WD) al[i] = p.valpha[vid[i]];
+        const unsigned v8 = (unsigned)vid[i]*8u;
+        px[i] = swe_ld(rvx, v8, 0);
+        py[i] = swe_ld(rvy, v8, 0);
+        h[i] = swe_ld(rvh, v8, 0);
+        if (WD) al[i] = swe_ld(swe_rsrc(p.valpha), v8, 0);
         H[i] = WD ? swe_wd_depth(h[i] + e[i], al[i]) : (NONLIN ? h[i] + e[i] : h[i]);
         if (WD) {           // the continuity equation advances zeta = D - h
             we[i] = p.a1*(H[i] - h[i]);
@@ -661,15 +692,16 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     }
     // boundary facets were skipped above; their correction is added to the finished outputs (see swe_boundary_epilogue)
     if ((nb[0] | nb[1] | nb[2]) < 0) swe_boundary_epilogue<NONLIN, LF, WD>(p, k, nb[0], nb[1], nb[2], ou, ov, oe);
+    const swe_rsrc_t gou = swe_rsrc(p.uout), gov = swe_rsrc(p.uout + 3*S), goe = swe_rsrc(p.uout + 6*S);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        p.uout[(size_t)i*S + k] = ou[i];
-        p.uout[(size_t)(3 + i)*S + k] = ov[i];
+        swe_st(gou, k8, i*S8, ou[i]);
+        swe_st(gov, k8, i*S8, ov[i]);
         if (WD) {           // back from zeta = D - h to eta:  H = D - alpha^2/(4D)
             const double D = oe[i] + h[i];
-            p.uout[(size_t)(6 + i)*S + k] = D - al[i]*al[i]/(4.0*D) - h[i];
+            swe_st(goe, k8, i*S8, D - al[i]*al[i]/(4.0*D) - h[i]);
         } else {
-            p.uout[(size_t)(6 + i)*S + k] = oe[i];
+            swe_st(goe, k8, i*S8, oe[i]);
         }
     }
 }
@@ -864,6 +896,8 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
     if (k >= p.cell_end) return;
     const size_t S = p.stride;
     const double cf = p.vel_factor;
+    const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u;       // raw buffer addressing, see swe_ld
+    const swe_rsrc_t gu = swe_rsrc(p.uv), gv = swe_rsrc(p.uv + 3*S), gt = swe_rsrc(p.tin);
 
     double u[3], v[3], c[3], w[3];
     int nb[3], vid[3];
@@ -875,11 +909,11 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        u[i] = cf*p.uv[(size_t)i*S + k];
-        v[i] = cf*p.uv[(size_t)(3 + i)*S + k];
-        c[i] = p.tin[(size_t)i*S + k];
+        u[i] = cf*swe_ld(gu, k8, i*S8);
+        v[i] = cf*swe_ld(gv, k8, i*S8);
+        c[i] = swe_ld(gt, k8, i*S8);
         w[i] = p.a1*c[i];
-        if (HAST0) w[i] += p.a0*p.t0[(size_t)i*S + k];
+        if (HAST0) w[i] += p.a0*swe_ld(swe_rsrc(p.t0), k8, i*S8);
     }
     double una[3], unb[3], vna[3], vnb[3], cna[3], cnb[3];
 #pragma unroll
@@ -887,19 +921,21 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
         const int nbf = nb[f];
         const int kn = nbf >= 0 ? (nbf >> 2) : k;
         const int f2 = nbf >= 0 ? (nbf & 3) : f;
-        const int na = (f2 == 2) ? 0 : f2 + 1;
-        una[f] = cf*p.uv[(size_t)na*S + kn];
-        unb[f] = cf*p.uv[(size_t)f2*S + kn];
-        vna[f] = cf*p.uv[(size_t)(3 + na)*S + kn];
-        vnb[f] = cf*p.uv[(size_t)(3 + f2)*S + kn];
-        cna[f] = p.tin[(size_t)na*S + kn];
-        cnb[f] = p.tin[(size_t)f2*S + kn];
+        const unsigned kn8 = (unsigned)kn*8u;
+        const unsigned ob = kn8 + (f2 == 0 ? 0u : (f2 == 1 ? S8 : 2u*S8));         // node f2
+        const unsigned oa = kn8 + (f2 == 0 ? S8 : (f2 == 1 ? 2u*S8 : 0u));         // node (f2 + 1) % 3
+        una[f] = cf*swe_ld(gu, oa, 0);
+        unb[f] = cf*swe_ld(gu, ob, 0);
+        vna[f] = cf*swe_ld(gv, oa, 0);
+        vnb[f] = cf*swe_ld(gv, ob, 0);
+        cna[f] = swe_ld(gt, oa, 0);
+        cnb[f] = swe_ld(gt, ob, 0);
     }
     double px[3], py[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        px[i] = p.vx[vid[i]];
-        py[i] = p.vy[vid[i]];
+        px[i] = swe_ld(swe_rsrc(p.vx), (unsigned)vid[i]*8u, 0);
+        py[i] = swe_ld(swe_rsrc(p.vy), (unsigned)vid[i]*8u, 0);
     }
     double nx[3], ny[3];
 #pragma unroll
@@ -930,14 +966,14 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
         const double A = 0.5*twoA;
         double s[3];
 #pragma unroll
-        for (int i = 0; i < 3; i++) s[i] = p.source[(size_t)i*S + k];
+        for (int i = 0; i < 3; i++) s[i] = swe_ld(swe_rsrc(p.source), k8, i*S8);
         const double ss = s[0] + s[1] + s[2];
         if (p.conservative) {                                                          // H*source, :434-436
             double H[3];
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 const double hh = p.vh[vid[i]];
-                const double ee = p.uv[(size_t)(6 + i)*S + k];
+                const double ee = swe_ld(swe_rsrc(p.uv + 6*S), k8, i*S8);
                 H[i] = p.depth_mode == 2 ? swe_wd_depth(hh + ee, p.valpha[vid[i]]) : (p.depth_mode == 1 ? hh + ee : hh);
             }
             const double Hs = H[0] + H[1] + H[2], Hss = H[0]*s[0] + H[1]*s[1] + H[2]*s[2];
@@ -990,7 +1026,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
     const double s = 6.0*p.dt*p.beta*swe_rcp(twoA);
     const double sb = b[0] + b[1] + b[2];
 #pragma unroll
-    for (int i = 0; i < 3; i++) p.tout[(size_t)i*S + k] = s*(4.0*b[i] - sb) + w[i];
+    for (int i = 0; i < 3; i++) swe_st(swe_rsrc(p.tout), k8, i*S8, s*(4.0*b[i] - sb) + w[i]);
 }
 
 // ---- limiter, step 1: cell means (P0 projection of an affine P1 / Q1 field = mean of the nodal values)
@@ -1128,19 +1164,22 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
     if (k >= p.cell_end) return;
     const size_t S = p.stride;
     const double g = p.g;
+    // raw buffer addressing (see swe_ld): one resource per group of four planes, 4*stride*8 < 2^32 checked at create
+    const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u, S4 = (unsigned)S*4u, k4 = (unsigned)k*4u;
+    const swe_rsrc_t gu = swe_rsrc(p.uin), gv = swe_rsrc(p.uin + 4*S), ge = swe_rsrc(p.uin + 8*S);
 
     double u[4], v[4], e[4];
     int nb[4], vid[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        nb[i] = p.nbr[(size_t)i*S + k];
-        vid[i] = p.cv[(size_t)i*S + k];
+        nb[i] = swe_ldi(swe_rsrc(p.nbr), k4, i*S4);
+        vid[i] = swe_ldi(swe_rsrc(p.cv), k4, i*S4);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        u[i] = p.uin[(size_t)i*S + k];
-        v[i] = p.uin[(size_t)(4 + i)*S + k];
-        e[i] = p.uin[(size_t)(8 + i)*S + k];
+        u[i] = swe_ld(gu, k8, i*S8);
+        v[i] = swe_ld(gv, k8, i*S8);
+        e[i] = swe_ld(ge, k8, i*S8);
     }
     double wu[4], wv[4], we[4];
 #pragma unroll
@@ -1149,15 +1188,15 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         wv[i] = p.a1*v[i];
         we[i] = p.a1*e[i];
         if (HASU0) {
-            wu[i] += p.a0*p.u0[(size_t)i*S + k];
-            wv[i] += p.a0*p.u0[(size_t)(4 + i)*S + k];
-            if (!WD) we[i] += p.a0*p.u0[(size_t)(8 + i)*S + k];
+            wu[i] += p.a0*swe_ld(swe_rsrc(p.u0), k8, i*S8);
+            wv[i] += p.a0*swe_ld(swe_rsrc(p.u0 + 4*S), k8, i*S8);
+            if (!WD) we[i] += p.a0*swe_ld(swe_rsrc(p.u0 + 8*S), k8, i*S8);
         }
     }
     double e0[4] = {0.0, 0.0, 0.0, 0.0};
     if (WD && HASU0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) e0[i] = p.u0[(size_t)(8 + i)*S + k];
+        for (int i = 0; i < 4; i++) e0[i] = swe_ld(swe_rsrc(p.u0 + 8*S), k8, i*S8);
     }
     double una[4], unb[4], vna[4], vnb[4], ena[4], enb[4];
 #pragma unroll
@@ -1166,20 +1205,24 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         const int kn = nbf >= 0 ? (nbf >> 2) : k;
         const int f2 = nbf >= 0 ? (nbf & 3) : f;
         const int na = (f2 + 1) & 3;
-        una[f] = p.uin[(size_t)na*S + kn];
-        unb[f] = p.uin[(size_t)f2*S + kn];
-        vna[f] = p.uin[(size_t)(4 + na)*S + kn];
-        vnb[f] = p.uin[(size_t)(4 + f2)*S + kn];
-        ena[f] = p.uin[(size_t)(8 + na)*S + kn];
-        enb[f] = p.uin[(size_t)(8 + f2)*S + kn];
+        const unsigned kn8 = (unsigned)kn*8u;
+        const unsigned ob = kn8 + ((f2 & 1) ? S8 : 0u) + ((f2 & 2) ? 2u*S8 : 0u);
+        const unsigned oa = kn8 + ((na & 1) ? S8 : 0u) + ((na & 2) ? 2u*S8 : 0u);
+        una[f] = swe_ld(gu, oa, 0);
+        unb[f] = swe_ld(gu, ob, 0);
+        vna[f] = swe_ld(gv, oa, 0);
+        vnb[f] = swe_ld(gv, ob, 0);
+        ena[f] = swe_ld(ge, oa, 0);
+        enb[f] = swe_ld(ge, ob, 0);
     }
     double px[4], py[4], h[4], H[4], al[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        px[i] = p.vx[vid[i]];
-        py[i] = p.vy[vid[i]];
-        h[i] = p.vh[vid[i]];
-        if (WD) al[i] = p.valpha[vid[i]];
+        const unsigned v8 = (unsigned)vid[i]*8u;
+        px[i] = swe_ld(swe_rsrc(p.vx), v8, 0);
+        py[i] = swe_ld(swe_rsrc(p.vy), v8, 0);
+        h[i] = swe_ld(swe_rsrc(p.vh), v8, 0);
+        if (WD) al[i] = swe_ld(swe_rsrc(p.valpha), v8, 0);
         H[i] = WD ? swe_wd_depth(h[i] + e[i], al[i]) : (NONLIN ? h[i] + e[i] : h[i]);
         if (WD) {           // the continuity equation advances zeta = D - h
             we[i] = p.a1*(H[i] - h[i]);
@@ -1220,20 +1263,20 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
                 double corq = 0.0, gpx = 0.0, gpy = 0.0, sx = 0.0, sy = 0.0, sv = 0.0;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    if (p.coriolis) corq += phi[i]*p.coriolis[(size_t)i*S + k];
+                    if (p.coriolis) corq += phi[i]*swe_ld(swe_rsrc(p.coriolis), k8, i*S8);
                     if (p.patm) {
-                        const double pa = p.patm[(size_t)i*S + k];
+                        const double pa = swe_ld(swe_rsrc(p.patm), k8, i*S8);
                         gpx += gx[i]*pa;
                         gpy += gy[i]*pa;
                     }
                     if (p.msrc) {
-                        sx += phi[i]*p.msrc[(size_t)i*S + k];
-                        sy += phi[i]*p.msrc[(size_t)(4 + i)*S + k];
+                        sx += phi[i]*swe_ld(swe_rsrc(p.msrc), k8, i*S8);
+                        sy += phi[i]*swe_ld(swe_rsrc(p.msrc + 4*S), k8, i*S8);
                     }
-                    if (p.vsrc) sv += phi[i]*p.vsrc[(size_t)i*S + k];
+                    if (p.vsrc) sv += phi[i]*swe_ld(swe_rsrc(p.vsrc), k8, i*S8);
                     if (p.wind) {
-                        sx += phi[i]*p.wind[(size_t)i*S + k]/(Hq*1000.0);
-                        sy += phi[i]*p.wind[(size_t)(4 + i)*S + k]/(Hq*1000.0);
+                        sx += phi[i]*swe_ld(swe_rsrc(p.wind), k8, i*S8)/(Hq*1000.0);
+                        sy += phi[i]*swe_ld(swe_rsrc(p.wind + 4*S), k8, i*S8)/(Hq*1000.0);
                     }
                 }
                 double drag = 0.0;
@@ -1241,7 +1284,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
                     double cq = 0.0;
                     if (p.quad_f) {
 #pragma unroll
-                        for (int i = 0; i < 4; i++) cq += phi[i]*p.quad_f[(size_t)i*S + k];
+                        for (int i = 0; i < 4; i++) cq += phi[i]*swe_ld(swe_rsrc(p.quad_f), k8, i*S8);
                     }
                     const int kind = p.quad_f ? p.quad_f_kind : (p.manning >= 0.0 ? 2 : (p.nikuradse >= 0.0 ? 3 : 1));
                     const double coef = p.quad_f ? cq : (kind == 2 ? p.manning : (kind == 3 ? p.nikuradse : p.quad_drag));
@@ -1255,7 +1298,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
                 }
                 if (p.lin_drag_f) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) drag += phi[i]*p.lin_drag_f[(size_t)i*S + k];
+                    for (int i = 0; i < 4; i++) drag += phi[i]*swe_ld(swe_rsrc(p.lin_drag_f), k8, i*S8);
                 } else if (p.linear_drag >= 0.0) drag += p.linear_drag;
                 cu = A*(corq*vq - drag*uq + sx) - gpx*(1.0/1000.0);
                 cv_ = A*(-corq*uq - drag*vq + sy) - gpy*(1.0/1000.0);
@@ -1342,13 +1385,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        p.uout[(size_t)i*S + k] = ou[i];
-        p.uout[(size_t)(4 + i)*S + k] = ov[i];
+        swe_st(swe_rsrc(p.uout), k8, i*S8, ou[i]);
+        swe_st(swe_rsrc(p.uout + 4*S), k8, i*S8, ov[i]);
         if (WD) {           // back from zeta = D - h to eta:  H = D - alpha^2/(4D)
             const double D = oe[i] + h[i];
-            p.uout[(size_t)(8 + i)*S + k] = D - al[i]*al[i]/(4.0*D) - h[i];
+            swe_st(swe_rsrc(p.uout + 8*S), k8, i*S8, D - al[i]*al[i]/(4.0*D) - h[i]);
         } else {
-            p.uout[(size_t)(8 + i)*S + k] = oe[i];
+            swe_st(swe_rsrc(p.uout + 8*S), k8, i*S8, oe[i]);
         }
     }
 }
