@@ -1456,22 +1456,24 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
     const int k = p.cell_begin + lb*SWE_BLOCK + (int)threadIdx.x;
     if (k >= p.cell_end) return;
     const size_t S = p.stride;
+    const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u, S4 = (unsigned)S*4u, k4 = (unsigned)k*4u;    // see swe_ld
+    const swe_rsrc_t gu = swe_rsrc(p.uv), gv = swe_rsrc(p.uv + 4*S), gt = swe_rsrc(p.tin);
     const double cf = p.vel_factor;
 
     double u[4], v[4], c[4], w[4];
     int nb[4], vid[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        nb[i] = p.nbr[(size_t)i*S + k];
-        vid[i] = p.cv[(size_t)i*S + k];
+        nb[i] = swe_ldi(swe_rsrc(p.nbr), k4, i*S4);
+        vid[i] = swe_ldi(swe_rsrc(p.cv), k4, i*S4);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        u[i] = cf*p.uv[(size_t)i*S + k];
-        v[i] = cf*p.uv[(size_t)(4 + i)*S + k];
-        c[i] = p.tin[(size_t)i*S + k];
+        u[i] = cf*swe_ld(gu, k8, i*S8);
+        v[i] = cf*swe_ld(gv, k8, i*S8);
+        c[i] = swe_ld(gt, k8, i*S8);
         w[i] = p.a1*c[i];
-        if (HAST0) w[i] += p.a0*p.t0[(size_t)i*S + k];
+        if (HAST0) w[i] += p.a0*swe_ld(swe_rsrc(p.t0), k8, i*S8);
     }
     double una[4], unb[4], vna[4], vnb[4], cna[4], cnb[4];
 #pragma unroll
@@ -1480,18 +1482,21 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
         const int kn = nbf >= 0 ? (nbf >> 2) : k;
         const int f2 = nbf >= 0 ? (nbf & 3) : f;
         const int na = (f2 + 1) & 3;
-        una[f] = cf*p.uv[(size_t)na*S + kn];
-        unb[f] = cf*p.uv[(size_t)f2*S + kn];
-        vna[f] = cf*p.uv[(size_t)(4 + na)*S + kn];
-        vnb[f] = cf*p.uv[(size_t)(4 + f2)*S + kn];
-        cna[f] = p.tin[(size_t)na*S + kn];
-        cnb[f] = p.tin[(size_t)f2*S + kn];
+        const unsigned kn8 = (unsigned)kn*8u;
+        const unsigned ob = kn8 + ((f2 & 1) ? S8 : 0u) + ((f2 & 2) ? 2u*S8 : 0u);
+        const unsigned oa = kn8 + ((na & 1) ? S8 : 0u) + ((na & 2) ? 2u*S8 : 0u);
+        una[f] = cf*swe_ld(gu, oa, 0);
+        unb[f] = cf*swe_ld(gu, ob, 0);
+        vna[f] = cf*swe_ld(gv, oa, 0);
+        vnb[f] = cf*swe_ld(gv, ob, 0);
+        cna[f] = swe_ld(gt, oa, 0);
+        cnb[f] = swe_ld(gt, ob, 0);
     }
     double px[4], py[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        px[i] = p.vx[vid[i]];
-        py[i] = p.vy[vid[i]];
+        px[i] = swe_ld(swe_rsrc(p.vx), (unsigned)vid[i]*8u, 0);
+        py[i] = swe_ld(swe_rsrc(p.vy), (unsigned)vid[i]*8u, 0);
     }
     const double ax = px[1] - px[0], ay = py[1] - py[0];
     const double bx = px[3] - px[0], by = py[3] - py[0];
@@ -1515,14 +1520,14 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
                 vq += phi[i]*v[i];
                 cq += phi[i]*c[i];
                 D += gx[i]*u[i] + gy[i]*v[i];
-                if (SRC) sq += phi[i]*p.source[(size_t)i*S + k];
+                if (SRC) sq += phi[i]*swe_ld(swe_rsrc(p.source), k8, i*S8);
             }
             if (SRC && p.conservative) {                                               // H*source, :434-436
                 double Hq = 0.0;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const double hh = p.vh[vid[i]];
-                    const double ee = p.uv[(size_t)(8 + i)*S + k];
+                    const double ee = swe_ld(swe_rsrc(p.uv + 8*S), k8, i*S8);
                     Hq += phi[i]*(p.depth_mode == 2 ? swe_wd_depth(hh + ee, p.valpha[vid[i]]) : (p.depth_mode == 1 ? hh + ee : hh));
                 }
                 sq *= Hq;
@@ -1573,7 +1578,8 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
     const double s = p.dt*p.beta*swe_rcp(A);
 #pragma unroll
     for (int i = 0; i < 4; i++)
-        p.tout[(size_t)i*S + k] = s*(16.0*b[i] - 8.0*b[(i + 1) & 3] - 8.0*b[(i + 3) & 3] + 4.0*b[(i + 2) & 3]) + w[i];
+        swe_st(swe_rsrc(p.tout), k8, i*S8,
+               s*(16.0*b[i] - 8.0*b[(i + 1) & 3] - 8.0*b[(i + 3) & 3] + 4.0*b[(i + 2) & 3]) + w[i]);
 }
 
 // tracer diagnostics on quadrilaterals

@@ -53,24 +53,30 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
     if (k >= p.cell_end) return;
     const size_t S = p.stride;
     const bool gd = (NC == 2) && p.grad_div;
+    // raw buffer addressing (swe_ld, swe2d_kernels.h): SGPR plane offsets, one 32-bit lane offset per gathered cell
+    const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u, S4 = (unsigned)S*4u, k4 = (unsigned)k*4u;
+    const swe_rsrc_t rcv = swe_rsrc(p.cv), rvx = swe_rsrc(p.vx), rvy = swe_rsrc(p.vy);
+    swe_rsrc_t rin[NC];
+#pragma unroll
+    for (int r = 0; r < NC; r++) rin[r] = swe_rsrc(p.in + (size_t)3*r*S);
 
     int nb[3], vid[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        nb[i] = p.nbr[(size_t)i*S + k];
-        vid[i] = p.cv[(size_t)i*S + k];
+        nb[i] = swe_ldi(swe_rsrc(p.nbr), k4, i*S4);
+        vid[i] = swe_ldi(rcv, k4, i*S4);
     }
     double c[NC][3];
 #pragma unroll
     for (int r = 0; r < NC; r++)
 #pragma unroll
-        for (int i = 0; i < 3; i++) c[r][i] = p.in[(size_t)(3*r + i)*S + k];
+        for (int i = 0; i < 3; i++) c[r][i] = swe_ld(rin[r], k8, i*S8);
     double px[3], py[3], mu[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        px[i] = p.vx[vid[i]];
-        py[i] = p.vy[vid[i]];
-        mu[i] = p.mu_v ? p.mu_v[vid[i]] : p.mu_const;
+        px[i] = swe_ld(rvx, (unsigned)vid[i]*8u, 0);
+        py[i] = swe_ld(rvy, (unsigned)vid[i]*8u, 0);
+        mu[i] = p.mu_v ? swe_ld(swe_rsrc(p.mu_v), (unsigned)vid[i]*8u, 0) : p.mu_const;
     }
     double nx[3], ny[3];
 #pragma unroll
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
         ny[f] = px[f] - px[b];
     }
     const double twoA = nx[0]*ny[1] - ny[0]*nx[1];
-    const double A = 0.5*twoA, r2A = 1.0/twoA;
+    const double A = 0.5*twoA, r2A = swe_rcp(twoA);
     double gx[3], gy[3];                              // grad(phi_i) = -nF_{i+1}/(2A)
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -111,8 +117,8 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
     if (NC == 2) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            ho[i] = p.vh[vid[i]];
-            eo[i] = p.eta[(size_t)i*S + k];
+            ho[i] = swe_ld(swe_rsrc(p.vh), (unsigned)vid[i]*8u, 0);
+            eo[i] = swe_ld(swe_rsrc(p.eta), k8, i*S8);
         }
     }
     if (NC == 2 && p.grad_depth) {
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
             l[q % 3] = bb;
             const double Hq = l[0]*Hn[0] + l[1]*Hn[1] + l[2]*Hn[2];
             const double muq = l[0]*mu[0] + l[1]*mu[1] + l[2]*mu[2];
-            const double fac = ww*A*muq/Hq;
+            const double fac = ww*A*muq*swe_rcp(Hq);
 #pragma unroll
             for (int r = 0; r < NC; r++)
 #pragma unroll
@@ -145,24 +151,30 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
     for (int f = 0; f < 3; f++) {
         const int a = f, bb = (f + 1) % 3;
         const double nxs = nx[f], nys = ny[f];
-        const double L = sqrt(nxs*nxs + nys*nys);
-        const double n0 = nxs/L, n1 = nys/L;
+        double L, rL;
+        swe_sqrt_rsqrt(nxs*nxs + nys*nys, L, rL);
+        const double n0 = nxs*rL, n1 = nys*rL;
         const double w = 0.5*L;                                    // Gauss weight * facet length
         if (nb[f] >= 0) {
             const int kn = nb[f] >> 2, f2 = nb[f] & 3;
             const int na = (f2 == 2) ? 0 : f2 + 1, no = (f2 == 0) ? 2 : f2 - 1;      // neighbour nodes on my a, opposite
-            const int vo = p.cv[(size_t)no*S + kn];
+            const unsigned sel_b = f2 == 0 ? 0u : (f2 == 1 ? 1u : 2u), sel_a = (unsigned)na, sel_o = (unsigned)no;
+            const int vo = swe_ldi(rcv, (unsigned)kn*4u + (sel_o == 0 ? 0u : (sel_o == 1 ? S4 : 2u*S4)), 0);
+            const unsigned kn8 = (unsigned)kn*8u;
+            const unsigned oa = kn8 + (sel_a == 0 ? 0u : (sel_a == 1 ? S8 : 2u*S8));
+            const unsigned ob = kn8 + (sel_b == 0 ? 0u : (sel_b == 1 ? S8 : 2u*S8));
+            const unsigned oo = kn8 + (sel_o == 0 ? 0u : (sel_o == 1 ? S8 : 2u*S8));
             const double e1x = px[bb] - px[a], e1y = py[bb] - py[a];
-            const double e2x = p.vx[vo] - px[a], e2y = p.vy[vo] - py[a];
+            const double e2x = swe_ld(rvx, (unsigned)vo*8u, 0) - px[a], e2y = swe_ld(rvy, (unsigned)vo*8u, 0) - py[a];
             const double det = e1x*e2y - e1y*e2x;                  // -2 A_n (the neighbour lies to the right of a -> b)
-            const double rdet = 1.0/det;
+            const double rdet = swe_rcp(det);
             const double An = 0.5*fabs(det);
             double ca[NC], cb[NC], S0n[NC][2], Gn[NC][2];
 #pragma unroll
             for (int r = 0; r < NC; r++) {
-                ca[r] = p.in[(size_t)(3*r + na)*S + kn];
-                cb[r] = p.in[(size_t)(3*r + f2)*S + kn];
-                const double co = p.in[(size_t)(3*r + no)*S + kn];
+                ca[r] = swe_ld(rin[r], oa, 0);
+                cb[r] = swe_ld(rin[r], ob, 0);
+                const double co = swe_ld(rin[r], oo, 0);
                 const double d1 = cb[r] - ca[r], d2 = co - ca[r];
                 Gn[r][0] = (d1*e2y - d2*e1y)*rdet;
                 Gn[r][1] = (d2*e1x - d1*e2x)*rdet;
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
             for (int r = 0; r < NC; r++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) S0n[r][j] = Gn[r][j] + ((NC == 2 && gd) ? Gn[j % NC][r] : 0.0);
-            const double sigma = p.sipg*L/fmin(A, An);             // max over the two sides of sipg*cp*|F|/A
+            const double sigma = p.sipg*L*swe_rcp(fmin(A, An));             // max over the two sides of sipg*cp*|F|/A
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
@@ -285,7 +297,10 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
     for (int r = 0; r < NC; r++) {
         const double sb = b[r][0] + b[r][1] + b[r][2];
 #pragma unroll
-        for (int i = 0; i < 3; i++) p.out[(size_t)(3*r + i)*S + k] += s*(4.0*b[r][i] - sb);
+        for (int i = 0; i < 3; i++) {
+            const swe_rsrc_t ro = swe_rsrc(p.out + (size_t)3*r*S);
+            swe_st(ro, k8, i*S8, swe_ld(ro, k8, i*S8) + s*(4.0*b[r][i] - sb));
+        }
     }
 }
 
@@ -316,35 +331,40 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
     if (k >= p.cell_end) return;
     const size_t S = p.stride;
     const bool gd = (NC == 2) && p.grad_div;
+    const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u, S4 = (unsigned)S*4u, k4 = (unsigned)k*4u;    // see swe_ld
+    const swe_rsrc_t rcv = swe_rsrc(p.cv), rvx = swe_rsrc(p.vx), rvy = swe_rsrc(p.vy);
+    swe_rsrc_t rin[NC];
+#pragma unroll
+    for (int r = 0; r < NC; r++) rin[r] = swe_rsrc(p.in + (size_t)4*r*S);
     const double RX[4] = {0.0, 1.0, 1.0, 0.0}, RZ[4] = {0.0, 0.0, 1.0, 1.0};      // reference corners
 
     int nb[4], vid[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        nb[i] = p.nbr[(size_t)i*S + k];
-        vid[i] = p.cv[(size_t)i*S + k];
+        nb[i] = swe_ldi(swe_rsrc(p.nbr), k4, i*S4);
+        vid[i] = swe_ldi(rcv, k4, i*S4);
     }
     double c[NC][4];
 #pragma unroll
     for (int r = 0; r < NC; r++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) c[r][i] = p.in[(size_t)(4*r + i)*S + k];
+        for (int i = 0; i < 4; i++) c[r][i] = swe_ld(rin[r], k8, i*S8);
     double px[4], py[4], mu[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        px[i] = p.vx[vid[i]];
-        py[i] = p.vy[vid[i]];
-        mu[i] = p.mu_v ? p.mu_v[vid[i]] : p.mu_const;
+        px[i] = swe_ld(rvx, (unsigned)vid[i]*8u, 0);
+        py[i] = swe_ld(rvy, (unsigned)vid[i]*8u, 0);
+        mu[i] = p.mu_v ? swe_ld(swe_rsrc(p.mu_v), (unsigned)vid[i]*8u, 0) : p.mu_const;
     }
     const double ax = px[1] - px[0], ay = py[1] - py[0], bx = px[3] - px[0], by = py[3] - py[0];
-    const double A = ax*by - ay*bx, rA = 1.0/A;
+    const double A = ax*by - ay*bx, rA = swe_rcp(A);
     const double gxi_x = by*rA, gxi_y = -bx*rA, gze_x = -ay*rA, gze_y = ax*rA;     // grad(xi), grad(zeta)
     double eo[4] = {0.0, 0.0, 0.0, 0.0}, ho[4] = {0.0, 0.0, 0.0, 0.0};
     if (NC == 2) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            ho[i] = p.vh[vid[i]];
-            eo[i] = p.eta[(size_t)i*S + k];
+            ho[i] = swe_ld(swe_rsrc(p.vh), (unsigned)vid[i]*8u, 0);
+            eo[i] = swe_ld(swe_rsrc(p.eta), k8, i*S8);
         }
     }
     double b[NC][4];
@@ -381,9 +401,10 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
 #pragma unroll
                 for (int j = 0; j < 2; j++) S0[r][j] = G[r][j] + ((NC == 2 && gd) ? G[j % NC][r] : 0.0);
             const double w = 0.25*A*muq;
+            const double rHq = (NC == 2 && p.grad_depth) ? swe_rcp(Hq) : 0.0;
 #pragma unroll
             for (int r = 0; r < NC; r++) {
-                const double tr = (NC == 2 && p.grad_depth) ? (gHx*S0[0][r % NC] + gHy*S0[1 % NC][r % NC])/Hq : 0.0;
+                const double tr = (NC == 2 && p.grad_depth) ? (gHx*S0[0][r % NC] + gHy*S0[1 % NC][r % NC])*rHq : 0.0;
 #pragma unroll
                 for (int i = 0; i < 4; i++) b[r][i] += w*(phi[i]*tr - (gx[i]*S0[r][0] + gy[i]*S0[r][1]));
             }
@@ -395,8 +416,9 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
     for (int f = 0; f < 4; f++) {
         const int a = f, bb = (f + 1) & 3;
         const double nxs = py[bb] - py[a], nys = px[a] - px[bb];
-        const double L = sqrt(nxs*nxs + nys*nys);
-        const double n0 = nxs/L, n1 = nys/L;
+        double L, rL;
+        swe_sqrt_rsqrt(nxs*nxs + nys*nys, L, rL);
+        const double n0 = nxs*rL, n1 = nys*rL;
         const double w = 0.5*L;
         const double nn[2] = {n0, n1};
         if (nb[f] >= 0) {
@@ -406,17 +428,20 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
             double qx[4], qy[4], cn[NC][4];
             qx[na] = px[a]; qy[na] = py[a]; qx[f2] = px[bb]; qy[f2] = py[bb];
             {
-                const int v2 = p.cv[(size_t)n2*S + kn], v3 = p.cv[(size_t)n3*S + kn];
-                qx[n2] = p.vx[v2]; qy[n2] = p.vy[v2]; qx[n3] = p.vx[v3]; qy[n3] = p.vy[v3];
+                const unsigned kn4 = (unsigned)kn*4u;
+                const int v2 = swe_ldi(rcv, kn4 + ((n2 & 1) ? S4 : 0u) + ((n2 & 2) ? 2u*S4 : 0u), 0);
+                const int v3 = swe_ldi(rcv, kn4 + ((n3 & 1) ? S4 : 0u) + ((n3 & 2) ? 2u*S4 : 0u), 0);
+                qx[n2] = swe_ld(rvx, (unsigned)v2*8u, 0); qy[n2] = swe_ld(rvy, (unsigned)v2*8u, 0);
+                qx[n3] = swe_ld(rvx, (unsigned)v3*8u, 0); qy[n3] = swe_ld(rvy, (unsigned)v3*8u, 0);
             }
 #pragma unroll
             for (int r = 0; r < NC; r++)
 #pragma unroll
-                for (int i = 0; i < 4; i++) cn[r][i] = p.in[(size_t)(4*r + i)*S + kn];
+                for (int i = 0; i < 4; i++) cn[r][i] = swe_ld(rin[r], (unsigned)kn*8u, i*S8);
             const double anx = qx[1] - qx[0], any_ = qy[1] - qy[0], bnx = qx[3] - qx[0], bny = qy[3] - qy[0];
-            const double An = anx*bny - any_*bnx, rAn = 1.0/An;
+            const double An = anx*bny - any_*bnx, rAn = swe_rcp(An);
             const double hxi_x = bny*rAn, hxi_y = -bnx*rAn, hze_x = -any_*rAn, hze_y = anx*rAn;
-            const double sigma = p.sipg*L/fmin(A, An);
+            const double sigma = p.sipg*L*swe_rcp(fmin(A, An));
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const double s = q ? SWE_XI1 : SWE_XI0;
@@ -554,6 +579,9 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
 #pragma unroll
     for (int r = 0; r < NC; r++)
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            p.out[(size_t)(4*r + i)*S + k] += sc*(16.0*b[r][i] - 8.0*b[r][(i + 1) & 3] - 8.0*b[r][(i + 3) & 3] + 4.0*b[r][(i + 2) & 3]);
+        for (int i = 0; i < 4; i++) {
+            const swe_rsrc_t ro = swe_rsrc(p.out + (size_t)4*r*S);
+            swe_st(ro, k8, i*S8, swe_ld(ro, k8, i*S8)
+                   + sc*(16.0*b[r][i] - 8.0*b[r][(i + 1) & 3] - 8.0*b[r][(i + 3) & 3] + 4.0*b[r][(i + 2) & 3]));
+        }
 }
