@@ -23,6 +23,14 @@ def _case():
     return channel_case(nx=16, ny=6, seed=21, amp_eta=0.3, amp_u=0.2)
 
 
+def _split_every(case):
+    """'channel+every2' -> ('channel', 2): exchange_every of the distributed stepper"""
+    if '+every' in case:
+        case, m = case.split('+every')
+        return case, int(m)
+    return case, 1
+
+
 def _init(rank, world, port):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -37,6 +45,7 @@ def cpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     """Partition + halo exchange logic of the product (3-layer halo, one exchange per step), with the oracle's C
     restatement as the (CPU) compute."""
     global CASE
+    case, every = _split_every(case)
     CASE = case
     import torch
     from oracle.ref_lib import RefSWE
@@ -49,7 +58,7 @@ def cpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
         owner = rcb_owner(mesh, world)
     else:
         owner = strip_owner(mesh, world, axis=axis)
-    part = build_partition(mesh, owner, rank)
+    part = build_partition(mesh, owner, rank, halo_depth=3*every)
     ref = RefSWE(part.cell_xy(), part.cell_nbr, part.cell_nbr_facet, bath[part.vertex_global][part.cells],
                  boundary_len=part.boundary_len)
     g = part.local_to_global
@@ -70,11 +79,14 @@ def cpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
         r = halo.recv_buf[:3*k*len(rc)].numpy().reshape(-1, 3*k)
         u[rc, :, 0], u[rc, :, 1], e[rc] = r[:, 0:k], r[:, k:2*k], r[:, 2*k:3*k]
 
-    for _ in range(n_steps):
+    for step in range(n_steps):
+        # exchange_every = m: cycles of m steps (the last one may be shorter) on 3m ghost layers, one exchange per cycle
+        in_cycle = step % every
+        cycle_len = min(every, n_steps - (step - in_cycle))
         u0, e0 = u.copy(), e.copy()                 # ghosts of the step input are valid (initial state / last exchange)
         cur_u, cur_e = u, e
         for i in range(3):
-            end = part.stage_range(i)
+            end = part.stage_range(3*in_cycle + i, depth=3*cycle_len)
             ku, ke = ref.tendency(cur_u, cur_e, dt)      # computed everywhere; only cells [0, end) are meaningful
             new_u, new_e = cur_u.copy(), cur_e.copy()
             new_u[:end] = be[i]*ku[:end] + al0[i]*u0[:end] + ali[i]*cur_u[:end]
@@ -82,8 +94,9 @@ def cpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
             new_u[end:], new_e[end:] = np.nan, np.nan    # stale layers must never be read by a later stage
             cur_u, cur_e = new_u, new_e
         u, e = cur_u, cur_e
-        exchange(u, e)
-        assert not np.isnan(u).any() and not np.isnan(e).any()
+        if in_cycle == cycle_len - 1:
+            exchange(u, e)
+            assert not np.isnan(u).any() and not np.isnan(e).any()
     np.savez(os.path.join(out_dir, 'rank{:d}.npz'.format(rank)), ids=g[:no], uv=u[:no], eta=e[:no],
              n_interior=part.n_interior, n_ghost=part.n_ghost)
     dist.barrier()
@@ -207,6 +220,7 @@ def viscosity_field(mesh):
 
 def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     global CASE
+    case, every = _split_every(case)
     viscous = case.endswith('+visc')
     case = case.replace('+visc', '')
     CASE = case
@@ -216,7 +230,7 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     dist = _init(rank, world, port)
     mesh, bath, uv, eta = _case()
     owner = strip_owner(mesh, world, axis=axis)
-    solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, host_staged=True)
+    solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, host_staged=True, exchange_every=every)
     if viscous:     # SIPG pass on the partition: same cell ranges as the stage kernels, per-vertex viscosity of the local vertices
         solver.dev.set_viscosity(viscosity_field(mesh)[solver.part.vertex_global], use_grad_div_viscosity_term=True)
     solver.set_state_global(uv, eta)

@@ -58,6 +58,32 @@ def test_gloo_partitioned_step_equals_global(tmp_path, ref_so, world, axis):
     assert np.array_equal(u_p, u_g) and np.array_equal(e_p, e_g)
 
 
+@pytest.mark.parametrize('world,axis,every,n_steps', [(2, 0, 2, 5), (3, 1, 3, 4), (2, 1, 4, 8)])
+def test_gloo_exchange_every_m_steps_equals_global(tmp_path, ref_so, world, axis, every, n_steps):
+    """3m ghost layers, one exchange per m steps (the last cycle may be shorter): stale layers are NaN-poisoned in the
+    worker, the result is bitwise the global one."""
+    mesh, bath, uv, eta = _case()
+    run_workers(cpu_worker, world, n_steps, str(tmp_path), axis=axis, case='channel+every{:d}'.format(every))
+    u_p, e_p, extra = gather(str(tmp_path), world, mesh.num_cells)
+    u_g, e_g = make_ref(mesh, bath).advance(uv, eta, 2.0, n_steps)
+    assert np.array_equal(u_p, u_g) and np.array_equal(e_p, e_g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('every,n_steps', [(2, 5), (4, 4)])
+def test_two_ranks_exchange_every_m_steps_on_one_gpu(tmp_path, hip_lib, every, n_steps):
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = _case()
+    run_workers(gpu_worker, 2, n_steps, str(tmp_path), axis=0, case='channel+every{:d}'.format(every))
+    u_p, e_p, extra = gather(str(tmp_path), 2, mesh.num_cells)
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev.set_state(uv, eta)
+    dev.advance(n_steps)
+    u_s, e_s = dev.get_state()
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+    dev.close()
+
+
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_match_single_device(tmp_path, hip_lib):
     from thetis_amd.device import Swe2dDevice

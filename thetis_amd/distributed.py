@@ -68,13 +68,19 @@ class DistributedSwe2d(object):
     """SSPRK33 on a strip-partitioned mesh, one rank per GPU."""
 
     def __init__(self, mesh, bathymetry_vertex, dt, rank, world_size, device_id, owner=None, host_staged=False,
-                 n_tracers=0, use_limiter=True, tracer_only=False, **opts):
+                 n_tracers=0, use_limiter=True, tracer_only=False, exchange_every=1, **opts):
         """``n_tracers`` > 0: the coupled step of GeneralCoupledTimeIntegrator2D.advance (coupled_timeintegrator_2d.py:
         93-113) on the partition - shallow water step, then every tracer with the updated velocity, then the limiter.
         The vertex-based limiter needs every cell around a vertex, so coupled runs with the limiter use four ghost layers
         built by VERTEX distance: the ghosts receive the neighbours' unlimited values once per step and every rank limits
         its owned cells and layers 1-3 redundantly (same means, same bounds => bitwise the owner's result); layer 4 is
-        only ever read by the limiter."""
+        only ever read by the limiter.
+
+        ``exchange_every`` = m > 1 (shallow water only): 3m facet-adjacent ghost layers and ONE exchange every m time
+        steps - stage g = 0..3m-1 of a cycle updates the owned cells and the first 3m-1-g layers, so the redundant work
+        shrinks by one layer per stage (strips of the 1 M-triangle bench mesh at 8 ranks, m = 4: 2 x 12 layers of ~500
+        cells, on average +5 % cell updates) while the latency of the exchange (pack, RCCL send/recv, unpack: several
+        stage-kernel times at this size) is paid once per m steps.  Results are bitwise those of m = 1."""
         import torch
         from .device import Swe2dDevice
         self.rank, self.world = rank, world_size
@@ -82,7 +88,12 @@ class DistributedSwe2d(object):
         owner = strip_owner(mesh, world_size) if owner is None else owner
         self.use_limiter = bool(use_limiter) and n_tracers > 0
         self.tracer_only = bool(tracer_only)
-        if self.use_limiter:
+        self.exchange_every = m = int(exchange_every)
+        if m < 1 or (m > 1 and n_tracers > 0):
+            raise ValueError('exchange_every > 1 is implemented for shallow-water-only runs')
+        if m > 1:
+            self.part = build_partition(mesh, owner, rank, halo_depth=3*m)
+        elif self.use_limiter:
             self.part = build_partition(mesh, owner, rank, halo_depth=4, adjacency='vertex')
         else:
             self.part = build_partition(mesh, owner, rank)
@@ -132,7 +143,7 @@ class DistributedSwe2d(object):
 
     def _step(self):
         if not self.tracer_only:
-            self._step_swe()
+            self._cycle_swe(1)
         for tid in self.tids:
             self._step_tracer(tid)
 
@@ -151,10 +162,13 @@ class DistributedSwe2d(object):
         if self.use_limiter:
             dev.tracer_limit_cells(tid, p.layer_end(3))
 
-    def _step_swe(self):
+    def _cycle_swe(self, n_steps):
+        """``n_steps`` (<= exchange_every) time steps on shrinking cell ranges, then one exchange.  One step:
+        stage 1 on owned + ghost layers 1, 2; stage 2 on owned + layer 1; stage 3 on the owned cells."""
         dev, halo, p = self.dev, self.halo, self.part
-        dev.solve_stage_cells(0, 0, self._ranges[0])        # owned + ghost layers 1, 2
-        dev.solve_stage_cells(1, 0, self._ranges[1])        # owned + ghost layer 1
+        n = 3*n_steps
+        for g in range(n - 1):
+            dev.solve_stage_cells(g % 3, 0, p.stage_range(g, depth=n))
         dev.solve_stage_cells(2, p.n_interior, p.n_owned)   # the cells the peers are waiting for
         dev.halo_pack(0, halo.send_buf.data_ptr())          # stage 3 leaves the step result in buffer 0
         reqs = halo.start()
@@ -163,8 +177,15 @@ class DistributedSwe2d(object):
         dev.halo_unpack(0, halo.recv_buf.data_ptr())
 
     def _steps_eager(self, n_steps):
-        for _ in range(n_steps):
-            self._step()
+        m = self.exchange_every
+        if m == 1:
+            for _ in range(n_steps):
+                self._step()
+            return
+        for _ in range(n_steps//m):
+            self._cycle_swe(m)
+        if n_steps % m:
+            self._cycle_swe(n_steps % m)
 
     def advance(self, n_steps, use_graph=True):
         """``n_steps`` SSPRK33 steps (enqueued; call ``synchronize``)."""
@@ -231,7 +252,9 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
                             device_id=torch.device('cuda', local_rank))
     mesh, bath, uv, eta = build_case()
     n_total = mesh.num_cells
-    solver = DistributedSwe2d(mesh, bath, dt, rank, world, local_rank)
+    # one exchange per `every` time steps on 3*every ghost layers (bitwise the same result; see DistributedSwe2d)
+    every = max(1, int(os.environ.get('THETIS_AMD_EXCHANGE_EVERY', '4')))
+    solver = DistributedSwe2d(mesh, bath, dt, rank, world, local_rank, exchange_every=every)
     solver.set_state_global(uv, eta)
     d0 = solver.diagnostics()
     use_graph = not os.environ.get('THETIS_AMD_NO_GRAPH')
@@ -271,8 +294,11 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
             'ms_per_step': float(1e3*t/args.steps), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'BASELINE cfg3: the cfg2 1M-triangle channel strip-partitioned along x over {:d} GPUs, '
-                                   '3-layer halo, one RCCL exchange per time step'.format(world),
-                       'n_cells': int(n_total), 'parallelism': 'dd{:d} (domain decomposition, 3-cell halo, 1 exchange/step)'.format(world),
+                                   '{:d}-layer halo, one RCCL exchange per {:d} time steps'.format(world, 3*every, every),
+                       'n_cells': int(n_total),
+                       'parallelism': 'dd{:d} (domain decomposition, {:d}-cell halo, 1 exchange per {:d} steps)'.format(
+                           world, 3*every, every),
+                       'exchange_every': every,
                        'hip_graph': hip_graph, 'volume_conserved': ok, 'prewarm_s': prewarm},
             'roofline': {'bound': 'hbm', 'achieved': float(per_gpu_bytes*3*args.steps/t/1e9), 'peak': hbm_peak, 'unit': 'GB/s',
                          'frac': float(per_gpu_bytes*3*args.steps/t/1e9/hbm_peak), 'traffic': None,

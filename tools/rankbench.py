@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Per-rank cost of the strip-partitioned bench on ONE GPU: builds rank r's partition of a `world`-rank run and times its
+step loop (stage kernels on the shrinking ranges, pack, unpack) with the exchange itself stubbed out (recv buffer =
+stale data; the numbers are timing only).  python tools/rankbench.py --world 8 --rank 3 --every 4 --steps 240"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--world', type=int, default=8)
+    ap.add_argument('--rank', type=int, default=3)
+    ap.add_argument('--every', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=240)
+    ap.add_argument('--prewarm', type=float, default=0.5)
+    args = ap.parse_args()
+    import torch
+    import bench
+    from thetis_amd import distributed
+
+    class NoExchange(distributed.HaloExchanger):
+        def start(self):
+            return []
+
+        def finish(self, reqs):
+            pass
+
+    distributed.HaloExchanger = NoExchange
+    mesh, bath, uv, eta = bench.build_case()
+    s = distributed.DistributedSwe2d(mesh, bath, bench.DT, args.rank, args.world, 0, exchange_every=args.every)
+    s.set_state_global(uv, eta)
+    p = s.part
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < args.prewarm:
+        s.advance(args.every*25, use_graph=False)
+        s.synchronize()
+    s.set_state_global(uv, eta)
+    s._capture(args.steps)
+    best = 1e9
+    for rep in range(3):
+        s.set_state_global(uv, eta)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.advance(args.steps, use_graph=True)
+        s.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    print(json.dumps({'world': args.world, 'rank': args.rank, 'every': args.every, 'n_owned': int(p.n_owned),
+                      'n_ghost': int(p.n_ghost), 'n_send': int(len(p.send_cells)), 'graph': s.graph is not None,
+                      'us_per_step': 1e6*best/args.steps}))
+
+
+if __name__ == '__main__':
+    main()
