@@ -122,7 +122,10 @@ int  swe2d_device_count(void);                                   /* number of vi
  * butcher_to_shuosher_form (thetis/rungekutta.py:13-87) for SSPRK33Abstract (rungekutta.py:342-346). */
 void swe2d_ssprk33_coefficients(double alpha0[3], double alpha_in[3], double beta[3]);
 
-/* lifetime: replaces ERKGenericShuOsher.__init__/update_solver (rungekutta.py:877-924) */
+/* lifetime: replaces ERKGenericShuOsher.__init__/update_solver (rungekutta.py:877-924).
+ * One handle = one device.  The kernels address a group of nodes_per_cell SoA planes through one 4 GiB buffer resource with
+ * 32-bit offsets: nodes_per_cell * n_cells * 8 bytes must stay below 2^32 (about 178 M triangles / 134 M quadrilaterals per
+ * device), larger meshes return SWE2D_ERR_UNSUPPORTED and have to be partitioned (one handle per part). */
 int  swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handle **out);
 void swe2d_destroy(swe2d_handle *h);
 const char *swe2d_last_error(const swe2d_handle *h);             /* h may be NULL: error of the last failed create */

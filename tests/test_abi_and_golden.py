@@ -40,6 +40,32 @@ def test_abi_version_and_loud_failure_without_device(hip_lib):
     assert err.value.code == _lib.ERR_NO_DEVICE          # no CPU fallback
 
 
+def test_create_rejects_meshes_beyond_the_32bit_plane_offsets(hip_lib):
+    """The size check runs before any device work (include/swe2d.h, swe2d_create): no compute call, CPU-safe."""
+    import ctypes
+    from thetis_amd import _lib
+    dummy_i = (ctypes.c_int32*4)()
+    dummy_d = (ctypes.c_double*4)()
+    dummy_b = (ctypes.c_uint8*4)()
+    for npc, n_cells, expect_unsupported in ((3, 178956971, True), (4, 134217729, True), (3, 1000, False)):
+        mesh = _lib.Swe2dMesh(n_cells=n_cells, n_owned=n_cells, n_vertices=10, nodes_per_cell=npc,
+                              cell_vertices=ctypes.cast(dummy_i, type(_lib.Swe2dMesh().cell_vertices)),
+                              vertex_xy=ctypes.cast(dummy_d, type(_lib.Swe2dMesh().vertex_xy)),
+                              cell_neighbours=ctypes.cast(dummy_i, type(_lib.Swe2dMesh().cell_neighbours)),
+                              cell_neighbour_facets=ctypes.cast(dummy_b, type(_lib.Swe2dMesh().cell_neighbour_facets)),
+                              bathymetry=ctypes.cast(dummy_d, type(_lib.Swe2dMesh().bathymetry)),
+                              boundary_len=ctypes.cast(dummy_d, type(_lib.Swe2dMesh().boundary_len)))
+        par = _lib.Swe2dParams(g_grav=9.81, dt=1.0, use_nonlinear_equations=1, use_lax_friedrichs_velocity=1,
+                               lax_friedrichs_velocity_scaling_factor=1.0, device_id=0)
+        out = ctypes.c_void_p()
+        if not expect_unsupported and hip_lib.swe2d_device_count() > 0:
+            continue                                    # would really build a handle from the dummy arrays
+        rc = hip_lib.swe2d_create(ctypes.byref(mesh), ctypes.byref(par), ctypes.byref(out))
+        assert rc == (_lib.ERR_UNSUPPORTED if expect_unsupported else _lib.ERR_NO_DEVICE), rc
+        if expect_unsupported:
+            assert b'4 GiB' in hip_lib.swe2d_last_error(None)
+
+
 def test_struct_layout_matches_header(hip_lib):
     from thetis_amd import _lib
     # swe2d_mesh: 4 x int32 + 6 pointers; swe2d_params: see include/swe2d.h
