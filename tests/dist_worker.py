@@ -24,11 +24,15 @@ def _case():
 
 
 def _split_every(case):
-    """'channel+every2' -> ('channel', 2): exchange_every of the distributed stepper"""
+    """'channel+every2+overlap3' -> ('channel', 2, 3): exchange_every and overlap_stages of the distributed stepper"""
+    overlap = 0
+    if '+overlap' in case:
+        case, j = case.split('+overlap')
+        overlap = int(j)
     if '+every' in case:
         case, m = case.split('+every')
-        return case, int(m)
-    return case, 1
+        return case, int(m), overlap
+    return case, 1, overlap
 
 
 def _init(rank, world, port):
@@ -42,10 +46,12 @@ def _init(rank, world, port):
 
 
 def cpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
-    """Partition + halo exchange logic of the product (3-layer halo, one exchange per step), with the oracle's C
-    restatement as the (CPU) compute."""
+    """Partition + halo exchange logic of the product (3m-layer halo, one exchange per m steps, optional overlap of the
+    exchange with the ghost-independent part of the next stages), with the oracle's C restatement as the (CPU) compute.
+    Mirrors DistributedSwe2d._steps_eager / _cycle_swe launch by launch on three rotating buffers; everything a launch
+    must not read is NaN: stale ghost layers, ghosts between pack and unpack, cells a stage has not written yet."""
     global CASE
-    case, every = _split_every(case)
+    case, every, overlap = _split_every(case)
     CASE = case
     import torch
     from oracle.ref_lib import RefSWE
@@ -62,41 +68,59 @@ def cpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     ref = RefSWE(part.cell_xy(), part.cell_nbr, part.cell_nbr_facet, bath[part.vertex_global][part.cells],
                  boundary_len=part.boundary_len)
     g = part.local_to_global
-    u, e = uv[g].copy(), eta[g].copy()
     halo = HaloExchanger(part, torch.device('cpu'))
     dt = 2.0
     no = part.n_owned
     k = part.cells.shape[1]
-    al0 = [0.0, 0.75, 0.33333333333333337]
-    ali = [1.0, 0.25, 0.6666666666666666]
-    be = [1.0, 0.25, 0.6666666666666666]
+    # buffers 0..2 as the device rotates them: stage 0 reads 0 writes 1, stage 1 reads 1 writes 2, stage 2 reads 2 writes 0
+    U = [uv[g].copy(), np.full_like(uv[g], np.nan), np.full_like(uv[g], np.nan)]
+    E = [eta[g].copy(), np.full_like(eta[g], np.nan), np.full_like(eta[g], np.nan)]
 
-    def exchange(u, e):
-        sc, rc = part.send_cells, part.recv_cells
-        packed = np.concatenate([u[sc, :, 0], u[sc, :, 1], e[sc]], axis=1)      # [n][3k] = u.. v.. e..
+    def stage(i, begin, end, keep_rest=False):
+        """one launch; afterwards everything of the output buffer beyond ``end`` is stale (NaN) unless ``keep_rest``
+        (launches that write a part of buffer 0 while the rest still holds the step result)"""
+        src, dst = i, (i + 1) % 3
+        ku, ke = ref.tendency(U[src], E[src], dt)          # computed everywhere; only [begin, end) is used
+        nu = BE[i]*ku[begin:end] + AL0[i]*U[0][begin:end] + ALI[i]*U[src][begin:end]
+        ne = BE[i]*ke[begin:end] + AL0[i]*E[0][begin:end] + ALI[i]*E[src][begin:end]
+        assert not np.isnan(nu).any() and not np.isnan(ne).any(), 'stage {:d} on [{:d}, {:d}) read stale data'.format(i, begin, end)
+        U[dst][begin:end], E[dst][begin:end] = nu, ne
+        if not keep_rest:
+            U[dst][end:], E[dst][end:] = np.nan, np.nan
+
+    def start_exchange():
+        sc = part.send_cells
+        packed = np.concatenate([U[0][sc, :, 0], U[0][sc, :, 1], E[0][sc]], axis=1)      # [n][3k] = u.. v.. e..
         halo.send_buf[:packed.size] = torch.from_numpy(packed.reshape(-1))
-        halo.finish(halo.start())
-        r = halo.recv_buf[:3*k*len(rc)].numpy().reshape(-1, 3*k)
-        u[rc, :, 0], u[rc, :, 1], e[rc] = r[:, 0:k], r[:, k:2*k], r[:, 2*k:3*k]
+        U[0][no:], E[0][no:] = np.nan, np.nan               # ghosts are stale until the unpack
+        return halo.start()
 
-    for step in range(n_steps):
-        # exchange_every = m: cycles of m steps (the last one may be shorter) on 3m ghost layers, one exchange per cycle
-        in_cycle = step % every
-        cycle_len = min(every, n_steps - (step - in_cycle))
-        u0, e0 = u.copy(), e.copy()                 # ghosts of the step input are valid (initial state / last exchange)
-        cur_u, cur_e = u, e
-        for i in range(3):
-            end = part.stage_range(3*in_cycle + i, depth=3*cycle_len)
-            ku, ke = ref.tendency(cur_u, cur_e, dt)      # computed everywhere; only cells [0, end) are meaningful
-            new_u, new_e = cur_u.copy(), cur_e.copy()
-            new_u[:end] = be[i]*ku[:end] + al0[i]*u0[:end] + ali[i]*cur_u[:end]
-            new_e[:end] = be[i]*ke[:end] + al0[i]*e0[:end] + ali[i]*cur_e[:end]
-            new_u[end:], new_e[end:] = np.nan, np.nan    # stale layers must never be read by a later stage
-            cur_u, cur_e = new_u, new_e
-        u, e = cur_u, cur_e
-        if in_cycle == cycle_len - 1:
-            exchange(u, e)
-            assert not np.isnan(u).any() and not np.isnan(e).any()
+    def finish_exchange(reqs):
+        rc = part.recv_cells
+        halo.finish(reqs)
+        r = halo.recv_buf[:3*k*len(rc)].numpy().reshape(-1, 3*k)
+        U[0][rc, :, 0], U[0][rc, :, 1], E[0][rc] = r[:, 0:k], r[:, k:2*k], r[:, 2*k:3*k]
+
+    cycles = [every]*(n_steps//every) + ([n_steps % every] if n_steps % every else [])
+    early = 0
+    for ic, r in enumerate(cycles):
+        nxt = min(overlap, 3*cycles[ic + 1] - 1) if ic + 1 < len(cycles) else 0
+        n = 3*r
+        for gs in range(n - 1):
+            begin = part.owned_prefix(gs + 2) if gs < early else 0
+            end = part.stage_range(gs, depth=n)
+            stage(gs % 3, begin, end)
+        stage(2, part.n_interior, no, keep_rest=True)
+        reqs = start_exchange()
+        stage(2, 0, part.n_interior, keep_rest=True)
+        for gs in range(nxt):
+            # the first early launch into buffer 1 / 2 finds nothing there that anyone still needs; buffer 0 holds the step
+            # result, and from the second round on the rest of a buffer holds the previous round's early output
+            stage(gs % 3, 0, part.owned_prefix(gs + 2), keep_rest=(gs >= 2))
+        finish_exchange(reqs)
+        early = nxt
+    u, e = U[0], E[0]
+    assert not np.isnan(u).any() and not np.isnan(e).any()
     np.savez(os.path.join(out_dir, 'rank{:d}.npz'.format(rank)), ids=g[:no], uv=u[:no], eta=e[:no],
              n_interior=part.n_interior, n_ghost=part.n_ghost)
     dist.barrier()
@@ -220,7 +244,7 @@ def viscosity_field(mesh):
 
 def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     global CASE
-    case, every = _split_every(case)
+    case, every, overlap = _split_every(case)
     viscous = case.endswith('+visc')
     case = case.replace('+visc', '')
     CASE = case
@@ -230,7 +254,8 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     dist = _init(rank, world, port)
     mesh, bath, uv, eta = _case()
     owner = strip_owner(mesh, world, axis=axis)
-    solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, host_staged=True, exchange_every=every)
+    solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, host_staged=True, exchange_every=every,
+                              overlap_stages=overlap)
     if viscous:     # SIPG pass on the partition: same cell ranges as the stage kernels, per-vertex viscosity of the local vertices
         solver.dev.set_viscosity(viscosity_field(mesh)[solver.part.vertex_global], use_grad_div_viscosity_term=True)
     solver.set_state_global(uv, eta)

@@ -69,6 +69,62 @@ def test_gloo_exchange_every_m_steps_equals_global(tmp_path, ref_so, world, axis
     assert np.array_equal(u_p, u_g) and np.array_equal(e_p, e_g)
 
 
+@pytest.mark.parametrize('world,axis,every,overlap,n_steps', [(2, 0, 1, 2, 4), (2, 0, 2, 3, 7), (3, 1, 2, 5, 6), (2, 1, 4, 3, 9),
+                                                              (3, 0, 1, 1, 3)])
+def test_gloo_overlapped_exchange_equals_global(tmp_path, ref_so, world, axis, every, overlap, n_steps):
+    """The exchange stays in flight while the next cycle's first ``overlap`` stages run on the cells that cannot see ghost
+    data yet; the worker mirrors the launch sequence on three rotating buffers with NaN for everything stale."""
+    mesh, bath, uv, eta = _case()
+    run_workers(cpu_worker, world, n_steps, str(tmp_path), axis=axis,
+                case='channel+every{:d}+overlap{:d}'.format(every, overlap))
+    u_p, e_p, extra = gather(str(tmp_path), world, mesh.num_cells)
+    u_g, e_g = make_ref(mesh, bath).advance(uv, eta, 2.0, n_steps)
+    assert np.array_equal(u_p, u_g) and np.array_equal(e_p, e_g)
+
+
+def test_owned_cells_are_sorted_by_distance_from_the_cut():
+    from thetis_amd.partition import build_partition, rcb_owner
+    mesh, bath, uv, eta = _case()
+    for owner, depth in ((strip_owner(mesh, 2), 6), (rcb_owner(mesh, 4), 3)):
+        for rank in range(int(owner.max()) + 1):
+            p = build_partition(mesh, owner, rank, halo_depth=depth)
+            g = p.local_to_global
+            mine = np.zeros(mesh.num_cells, dtype=bool)
+            mine[g[:p.n_owned]] = True
+            # brute-force facet distance of every owned cell from the non-owned cells
+            dist = np.where(mine, -1, 0)
+            frontier = np.nonzero(~mine)[0]
+            d = 0
+            while len(frontier):
+                d += 1
+                nb = mesh.cell_nbr[frontier].ravel()
+                nb = nb[nb >= 0]
+                new = np.unique(nb[dist[nb] < 0])
+                dist[new] = d
+                frontier = new
+            dl = dist[g[:p.n_owned]]
+            dl = np.where(dl < 0, 10**6, dl)                      # unreachable (single part): interior
+            for dd in range(0, depth + 2):
+                n = p.owned_prefix(dd)
+                assert (dl[:n] >= dd).all() and (dl[n:] < dd).all(), (rank, dd)
+            assert p.owned_prefix(1) == p.n_owned and p.owned_prefix(depth + 1) == p.n_interior
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('every,overlap,n_steps', [(1, 2, 4), (2, 3, 7), (4, 3, 8)])
+def test_two_ranks_overlapped_exchange_on_one_gpu(tmp_path, hip_lib, every, overlap, n_steps):
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = _case()
+    run_workers(gpu_worker, 2, n_steps, str(tmp_path), axis=0, case='channel+every{:d}+overlap{:d}'.format(every, overlap))
+    u_p, e_p, extra = gather(str(tmp_path), 2, mesh.num_cells)
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev.set_state(uv, eta)
+    dev.advance(n_steps)
+    u_s, e_s = dev.get_state()
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+    dev.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('every,n_steps', [(2, 5), (4, 4)])
 def test_two_ranks_exchange_every_m_steps_on_one_gpu(tmp_path, hip_lib, every, n_steps):

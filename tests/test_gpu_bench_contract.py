@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('env', [{}, {'THETIS_AMD_FORCE_DIST': '1'}], ids=['single', 'distributed_path_world1'])
+@pytest.mark.parametrize('env', [{}, {'THETIS_AMD_FORCE_DIST': '1'},
+                                 {'THETIS_AMD_FORCE_DIST': '1', 'THETIS_AMD_TUNE_SCHEDULE': '1'}],
+                         ids=['single', 'distributed_path_world1', 'distributed_path_world1_schedule_tuning'])
 def test_bench_prints_one_json_line_with_the_contract_fields(hip_lib, env):
     e = dict(os.environ)
     e.update(env)
@@ -32,3 +34,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields(hip_lib, env):
     # whole-job throughput = cells * 3 stages * steps / time
     assert abs(d['value'] - 1e6*3*6/(d['ms_per_step']*6e-3))/d['value'] < 1e-9
     assert 1e9 < d['value'] < 1e11
+    if env.get('THETIS_AMD_TUNE_SCHEDULE'):
+        tuned = d['config']['schedule_tuning']
+        assert len(tuned) == 5 and all(t['us_per_step'] > 0 for t in tuned)
+        best = min(tuned, key=lambda t: t['us_per_step'])
+        assert (d['config']['exchange_every'], d['config']['overlap_stages']) == (best['exchange_every'], best['overlap_stages'])
+        assert d['config']['volume_conserved'] is True

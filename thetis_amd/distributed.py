@@ -68,7 +68,7 @@ class DistributedSwe2d(object):
     """SSPRK33 on a strip-partitioned mesh, one rank per GPU."""
 
     def __init__(self, mesh, bathymetry_vertex, dt, rank, world_size, device_id, owner=None, host_staged=False,
-                 n_tracers=0, use_limiter=True, tracer_only=False, exchange_every=1, **opts):
+                 n_tracers=0, use_limiter=True, tracer_only=False, exchange_every=1, overlap_stages=0, **opts):
         """``n_tracers`` > 0: the coupled step of GeneralCoupledTimeIntegrator2D.advance (coupled_timeintegrator_2d.py:
         93-113) on the partition - shallow water step, then every tracer with the updated velocity, then the limiter.
         The vertex-based limiter needs every cell around a vertex, so coupled runs with the limiter use four ghost layers
@@ -80,7 +80,14 @@ class DistributedSwe2d(object):
         steps - stage g = 0..3m-1 of a cycle updates the owned cells and the first 3m-1-g layers, so the redundant work
         shrinks by one layer per stage (strips of the 1 M-triangle bench mesh at 8 ranks, m = 4: 2 x 12 layers of ~500
         cells, on average +5 % cell updates) while the latency of the exchange (pack, RCCL send/recv, unpack: several
-        stage-kernel times at this size) is paid once per m steps.  Results are bitwise those of m = 1."""
+        stage-kernel times at this size) is paid once per m steps.  Results are bitwise those of m = 1.
+
+        ``overlap_stages`` = j > 0 (shallow water only): while an exchange is in flight the next cycle already runs its
+        first j stages on the owned cells that cannot see ghost data yet - stage g of a cycle reaches ghost cells only
+        through cells at distance <= g + 1 from the cut, and the owned cells at distance >= d are a prefix of the local
+        numbering (LocalPartition.owned_prefix) - and completes those stages on the remaining wedge (cells at distance
+        <= g + 1 and the ghost layers) after the unpack.  Disjoint read / write sets (a late stage g reads distance
+        <= g + 2, an early stage g' > g writes distance >= g' + 2), bitwise the same result."""
         import torch
         from .device import Swe2dDevice
         self.rank, self.world = rank, world_size
@@ -89,8 +96,11 @@ class DistributedSwe2d(object):
         self.use_limiter = bool(use_limiter) and n_tracers > 0
         self.tracer_only = bool(tracer_only)
         self.exchange_every = m = int(exchange_every)
-        if m < 1 or (m > 1 and n_tracers > 0):
-            raise ValueError('exchange_every > 1 is implemented for shallow-water-only runs')
+        self.overlap_stages = int(overlap_stages)
+        if m < 1 or ((m > 1 or self.overlap_stages > 0) and n_tracers > 0):
+            raise ValueError('exchange_every > 1 and overlap_stages are implemented for shallow-water-only runs')
+        if not 0 <= self.overlap_stages <= 3*m - 1:
+            raise ValueError('overlap_stages must be in 0 .. 3*exchange_every - 1')
         if m > 1:
             self.part = build_partition(mesh, owner, rank, halo_depth=3*m)
         elif self.use_limiter:
@@ -101,7 +111,7 @@ class DistributedSwe2d(object):
         torch.cuda.set_device(device_id)
         self.torch_device = torch.device('cuda', device_id)
         self.dev = Swe2dDevice(p, np.asarray(bathymetry_vertex)[p.vertex_global], dt, device_id=device_id,
-                               n_owned=p.n_owned, boundary_len=p.boundary_len, ranges=(p.n_interior, p.n_owned), **opts)
+                               n_owned=p.n_owned, boundary_len=p.boundary_len, ranges=p.reorder_ranges(), **opts)
         self.dev.halo_setup(p.send_cells, p.recv_cells)
         self._ranges = [p.stage_range(i) for i in range(3)]
         self.halo = HaloExchanger(p, self.torch_device, host_staged=host_staged)
@@ -162,30 +172,39 @@ class DistributedSwe2d(object):
         if self.use_limiter:
             dev.tracer_limit_cells(tid, p.layer_end(3))
 
-    def _cycle_swe(self, n_steps):
+    def _cycle_swe(self, n_steps, early_done=0, early_next=0):
         """``n_steps`` (<= exchange_every) time steps on shrinking cell ranges, then one exchange.  One step:
-        stage 1 on owned + ghost layers 1, 2; stage 2 on owned + layer 1; stage 3 on the owned cells."""
+        stage 1 on owned + ghost layers 1, 2; stage 2 on owned + layer 1; stage 3 on the owned cells.
+        ``early_done``: stages of this cycle whose ghost-independent part ran during the previous exchange;
+        ``early_next``: stages of the next cycle to run (ghost-independent part only) during this cycle's exchange."""
         dev, halo, p = self.dev, self.halo, self.part
         n = 3*n_steps
+        assert early_done <= n - 1
         for g in range(n - 1):
-            dev.solve_stage_cells(g % 3, 0, p.stage_range(g, depth=n))
+            begin = p.owned_prefix(g + 2) if g < early_done else 0
+            dev.solve_stage_cells(g % 3, begin, p.stage_range(g, depth=n))
         dev.solve_stage_cells(2, p.n_interior, p.n_owned)   # the cells the peers are waiting for
         dev.halo_pack(0, halo.send_buf.data_ptr())          # stage 3 leaves the step result in buffer 0
         reqs = halo.start()
         dev.solve_stage_cells(2, 0, p.n_interior)           # interior cells overlap the exchange
+        for g in range(early_next):                         # ... and so does the ghost-independent part of the next stages
+            dev.solve_stage_cells(g % 3, 0, p.owned_prefix(g + 2))
         halo.finish(reqs)
         dev.halo_unpack(0, halo.recv_buf.data_ptr())
 
     def _steps_eager(self, n_steps):
         m = self.exchange_every
-        if m == 1:
+        if self.tids or self.tracer_only:
             for _ in range(n_steps):
                 self._step()
             return
-        for _ in range(n_steps//m):
-            self._cycle_swe(m)
-        if n_steps % m:
-            self._cycle_swe(n_steps % m)
+        cycles = [m]*(n_steps//m) + ([n_steps % m] if n_steps % m else [])
+        early = 0
+        for i, r in enumerate(cycles):
+            # never across advance() calls: after the last cycle buffer 0 holds the result and nothing is half done
+            nxt = min(self.overlap_stages, 3*cycles[i + 1] - 1) if i + 1 < len(cycles) else 0
+            self._cycle_swe(r, early_done=early, early_next=nxt)
+            early = nxt
 
     def advance(self, n_steps, use_graph=True):
         """``n_steps`` SSPRK33 steps (enqueued; call ``synchronize``)."""
@@ -252,12 +271,50 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
                             device_id=torch.device('cuda', local_rank))
     mesh, bath, uv, eta = build_case()
     n_total = mesh.num_cells
-    # one exchange per `every` time steps on 3*every ghost layers (bitwise the same result; see DistributedSwe2d)
-    every = max(1, int(os.environ.get('THETIS_AMD_EXCHANGE_EVERY', '4')))
-    solver = DistributedSwe2d(mesh, bath, dt, rank, world, local_rank, exchange_every=every)
+    use_graph = not os.environ.get('THETIS_AMD_NO_GRAPH')
+    # Exchange schedule: one exchange per `every` time steps on 3*every ghost layers, optionally overlapped with the first
+    # `overlap` stages of the next cycle (bitwise the same result for every choice; see DistributedSwe2d).  The best
+    # choice depends on the RCCL point-to-point latency of the node, so a few candidates are timed during set-up (not in
+    # the timed region; every rank takes the max over ranks and therefore the same decision).
+    if os.environ.get('THETIS_AMD_EXCHANGE_EVERY'):
+        candidates = [(max(1, int(os.environ['THETIS_AMD_EXCHANGE_EVERY'])), int(os.environ.get('THETIS_AMD_OVERLAP_STAGES', '0')))]
+    elif world == 1 and not os.environ.get('THETIS_AMD_TUNE_SCHEDULE'):
+        candidates = [(4, 0)]
+    else:
+        candidates = [(2, 0), (4, 0), (4, 3), (8, 0), (8, 3)]
+    solver, tuning = None, []
+    for every_c, overlap_c in candidates:
+        cand = DistributedSwe2d(mesh, bath, dt, rank, world, local_rank, exchange_every=every_c, overlap_stages=overlap_c)
+        cand.set_state_global(uv, eta)
+        if len(candidates) == 1:
+            solver, every, overlap = cand, every_c, overlap_c
+            break
+        n_tune = 48
+        cand.advance(n_tune if tuning else 2000, use_graph=False)      # RCCL connections; clocks (first candidate)
+        cand.synchronize()
+        if use_graph:
+            cand._capture(n_tune)
+        best_t = float('inf')
+        for _ in range(3):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cand.advance(n_tune, use_graph=use_graph)
+            cand.synchronize()
+            best_t = min(best_t, time.perf_counter() - t0)
+        tt = torch.tensor([best_t], dtype=torch.float64, device=cand.torch_device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        us = 1e6*float(tt.item())/n_tune
+        tuning.append({'exchange_every': every_c, 'overlap_stages': overlap_c, 'us_per_step': us})
+        if solver is None or us < best_us:
+            if solver is not None:
+                solver.dev.close()
+            solver, every, overlap, best_us = cand, every_c, overlap_c, us
+        else:
+            cand.dev.close()
+    solver.graph = None
     solver.set_state_global(uv, eta)
     d0 = solver.diagnostics()
-    use_graph = not os.environ.get('THETIS_AMD_NO_GRAPH')
     prewarm = float(getattr(args, 'prewarm', 0.0) or 0.0)
     if prewarm > 0:
         # clock settling (bench.py docstring): a FIXED number of steps so that every rank posts the same exchanges
@@ -270,6 +327,11 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
         # build the graph for the timed step count before the timed region (capture is set-up, not stepping);
         # _capture restores the state it perturbs
         solver._capture(args.steps)
+        if solver.graph is not None:
+            # the first launch of an instantiated graph uploads it to the device (~1 ms for a few thousand nodes): spend
+            # it on K more untimed warm-up steps instead of inside the timed region
+            solver.advance(args.steps, use_graph=True)
+            solver.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -298,8 +360,8 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
                        'n_cells': int(n_total),
                        'parallelism': 'dd{:d} (domain decomposition, {:d}-cell halo, 1 exchange per {:d} steps)'.format(
                            world, 3*every, every),
-                       'exchange_every': every,
-                       'hip_graph': hip_graph, 'volume_conserved': ok, 'prewarm_s': prewarm},
+                       'exchange_every': every, 'overlap_stages': overlap, 'schedule_tuning': tuning,
+                       'hip_graph': hip_graph, 'graph_warm_replays': int(hip_graph), 'volume_conserved': ok, 'prewarm_s': prewarm},
             'roofline': {'bound': 'hbm', 'achieved': float(per_gpu_bytes*3*args.steps/t/1e9), 'peak': hbm_peak, 'unit': 'GB/s',
                          'frac': float(per_gpu_bytes*3*args.steps/t/1e9/hbm_peak), 'traffic': None,
                          'note': 'per GPU, algorithmic bytes over wall time per stage (includes halo exchange); '

@@ -8,7 +8,7 @@ ONCE PER TIME STEP instead: every rank keeps ``halo_depth`` = 3 layers of facet-
 stage) and recomputes them redundantly - stage 1 updates owned + layers 1,2, stage 2 owned + layer 1, stage 3 the owned
 cells only (cfg 3: 2 x 1500 extra cell-updates per rank and step, 0.5 %).  Local cell order on every rank:
 
-    [ interior owned | send owned (in some peer's halo) | ghost layer 1 | layer 2 | layer 3 ]
+    [ interior owned | send owned (in some peer's halo; by decreasing distance from the cut) | ghost layer 1 | layer 2 | layer 3 ]
 
 so that stage 3 can update the send cells first, start the exchange, and update the interior while it is in flight.
 Send lists and receive lists are both ordered by global cell id, which makes the layout deterministic on both sides
@@ -82,6 +82,16 @@ class LocalPartition(object):
         keep = max(0, depth - 1 - i_stage)              # ghost layers still needed after this stage
         return self.n_owned + int(sum(self.layer_sizes[:keep]))
 
+    def owned_prefix(self, min_dist):
+        """Number of leading local cells that are owned and at facet (or vertex) distance >= ``min_dist`` from every
+        non-owned cell; ``min_dist`` <= 1: all owned cells, beyond the halo depth: the interior cells."""
+        d = int(min(max(min_dist, 0), len(self.owned_dist_ge) - 1))
+        return int(self.owned_dist_ge[d])
+
+    def reorder_ranges(self):
+        """Boundaries a device-side renumbering must not cross: the distance bands of the owned cells."""
+        return tuple(sorted(set(int(x) for x in self.owned_dist_ge)))
+
     def layer_end(self, n_layers):
         """owned cells + the first ``n_layers`` ghost layers"""
         return self.n_owned + int(sum(self.layer_sizes[:n_layers]))
@@ -154,6 +164,14 @@ def build_partition(mesh, owner, rank, halo_depth=3, adjacency='facet'):
     mine = np.nonzero(mine_mask)[0]
     interior = mine[~in_send[mine]]
     send_owned = mine[in_send[mine]]
+    # send cells by decreasing distance d from the nearest non-owned cell (d = halo_depth ... 1): the cells at distance
+    # >= d are then a PREFIX of the local numbering, which is what overlapping the exchange with the first stages of the
+    # next step needs (stage g of a step reads ghost data only through cells at distance <= g + 1)
+    _, dist_out = _halo_layers(nbr, ~mine_mask, halo_depth, vadj)
+    d_send = dist_out[send_owned]
+    assert (d_send >= 1).all()
+    send_owned = send_owned[np.lexsort((send_owned, -d_send))]
+    d_sorted = dist_out[send_owned]
 
     part = LocalPartition(rank, n_parts)
     ghost_layers = []
@@ -165,6 +183,8 @@ def build_partition(mesh, owner, rank, halo_depth=3, adjacency='facet'):
     part.local_to_global = local_global
     part.n_interior = len(interior)
     part.n_owned = len(mine)
+    # owned_dist_ge[d] = number of owned cells at distance >= d from the non-owned cells (a prefix), d = 0 .. halo_depth + 1
+    part.owned_dist_ge = np.array([len(interior) + int((d_sorted >= d).sum()) for d in range(halo_depth + 2)], dtype=np.int64)
     g2l = np.full(mesh.num_cells, -1, dtype=np.int64)
     g2l[local_global] = np.arange(len(local_global))
 

@@ -18,6 +18,7 @@ def main():
     ap.add_argument('--rank', type=int, default=3)
     ap.add_argument('--every', type=int, default=1)
     ap.add_argument('--steps', type=int, default=240)
+    ap.add_argument('--overlap', type=int, default=0)
     ap.add_argument('--prewarm', type=float, default=0.5)
     args = ap.parse_args()
     import torch
@@ -33,7 +34,7 @@ def main():
 
     distributed.HaloExchanger = NoExchange
     mesh, bath, uv, eta = bench.build_case()
-    s = distributed.DistributedSwe2d(mesh, bath, bench.DT, args.rank, args.world, 0, exchange_every=args.every)
+    s = distributed.DistributedSwe2d(mesh, bath, bench.DT, args.rank, args.world, 0, exchange_every=args.every, overlap_stages=args.overlap)
     s.set_state_global(uv, eta)
     p = s.part
     t0 = time.perf_counter()
@@ -50,7 +51,7 @@ def main():
         s.advance(args.steps, use_graph=True)
         s.synchronize()
         best = min(best, time.perf_counter() - t0)
-    print(json.dumps({'world': args.world, 'rank': args.rank, 'every': args.every, 'n_owned': int(p.n_owned),
+    print(json.dumps({'world': args.world, 'rank': args.rank, 'every': args.every, 'overlap': args.overlap, 'n_owned': int(p.n_owned),
                       'n_ghost': int(p.n_ghost), 'n_send': int(len(p.send_cells)), 'graph': s.graph is not None,
                       'us_per_step': 1e6*best/args.steps}))
 
