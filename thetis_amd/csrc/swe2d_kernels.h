@@ -29,7 +29,7 @@
 #define SWE_BC_UN_FIELD 64
 #define SWE_BC_FLUX_FIELD 128
 #ifndef SWE_BLOCK
-#define SWE_BLOCK 256
+#define SWE_BLOCK 64
 #endif
 #ifndef SWE_MIN_WAVES
 #define SWE_MIN_WAVES 1          // __launch_bounds__ 2nd argument: minimum waves per SIMD
