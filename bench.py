@@ -81,12 +81,12 @@ def measured_traffic(n_cells):
     """HBM bytes per stage-kernel launch from the committed PMC passes (rocprofv3 cannot run inside the timed bench):
     FETCH_SIZE/WRITE_SIZE collected in separate --pmc runs and corrected with the calibration copy kernel, see
     profiles/README.md.  Only valid for the workload it was measured on."""
-    path = os.path.join(ROOT, 'profiles', 'r01m_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r01n_traffic.json')
     try:
         with open(path) as f:
             t = json.load(f)
         if n_cells == 1000000:
-            return float(t['traffic_bytes_per_launch']), 'profiles/r01m_traffic.json'
+            return float(t['traffic_bytes_per_launch']), 'profiles/r01n_traffic.json'
     except (OSError, KeyError, ValueError):
         pass
     return None, None
