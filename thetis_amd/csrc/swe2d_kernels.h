@@ -629,7 +629,6 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
             }
         }
     }
-    if (SRC) swe_source_terms(p, k, S, twoA, u, v, H, gxs, gys, bu, bv, be);
 
     // ---- facet integrals: 2-point Gauss-Legendre, numerical fluxes seen from this cell
 #pragma unroll
@@ -679,6 +678,10 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
         be[a] -= 0.5*Fae; be[b] -= 0.5*Fbe;
     }
+
+    // optional cell-local terms AFTER the facet loop: the 18 neighbour traces are dead by now, which keeps the SRC variants
+    // at 146 (162 with wetting-drying) VGPRs = 3 waves/SIMD instead of 188 (194) = 2
+    if (SRC) swe_source_terms(p, k, S, twoA, u, v, H, gxs, gys, bu, bv, be);
 
     // ---- mass inverse (M^-1 b)_i = 3/A (4 b_i - sum b), times dt, and the Shu-Osher combine
     const double s = 6.0*p.dt*p.beta*swe_rcp(twoA);
@@ -1237,10 +1240,66 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
     const double xix = by, xiy = -bx, zex = -ay, zey = ax;
 
     double bu[4] = {0.0, 0.0, 0.0, 0.0}, bv[4] = {0.0, 0.0, 0.0, 0.0}, be[4] = {0.0, 0.0, 0.0, 0.0};
+    // ---- facets first: the 24 neighbour traces (48 VGPRs) are dead before the cell quadrature starts
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        const int a = f, b = (f + 1) & 3;
+        const double nxs = py[b] - py[a], nys = px[a] - px[b];
+        const double len2 = nxs*nxs + nys*nys;
+        double L, rL;
+        swe_sqrt_rsqrt(len2, L, rL);
+        double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
+        if (nb[f] >= 0) {
+            // neighbour's nodal depth on this facet (bathymetry and alpha are continuous: same vertices)
+            const double Dna = WD ? swe_wd_depth(h[a] + ena[f], al[a]) : 0.0;
+            const double Dnb = WD ? swe_wd_depth(h[b] + enb[f], al[b]) : 0.0;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+                const double uq = xa*u[a] + xb*u[b], vq = xa*v[a] + xb*v[b], eq = xa*e[a] + xb*e[b];
+                const double hq = xa*h[a] + xb*h[b];
+                const double un = xa*una[f] + xb*unb[f], vn = xa*vna[f] + xb*vnb[f], en = xa*ena[f] + xb*enb[f];
+                const double eav = 0.5*(eq + en);
+                const double Hav = WD ? 0.5*((xa*H[a] + xb*H[b]) + (xa*Dna + xb*Dnb)) : (NONLIN ? hq + eav : hq);
+                const double c = swe_sqrt(g*Hav);
+                const double du = uq - un, dv = vq - vn;
+                const double dun = du*nxs + dv*nys;
+                const double spg = g*eav + c*dun*rL;
+                double fu = spg*nxs, fv = spg*nys;
+                const double uav = 0.5*(uq + un), vav = 0.5*(vq + vn);
+                const double uavn = uav*nxs + vav*nys;
+                const double fe = Hav*uavn + c*(eq - en)*L;
+                if (NONLIN) {
+                    const double unown = uq*nxs + vq*nys;
+                    fu += uav*unown;
+                    fv += vav*unown;
+                    if (LF) {
+                        const double gam = 0.5*fabs(uavn)*p.sigma_lf;
+                        fu += gam*du;
+                        fv += gam*dv;
+                    }
+                }
+                Fau += xa*fu; Fbu += xb*fu;
+                Fav += xa*fv; Fbv += xb*fv;
+                Fae += xa*fe; Fbe += xb*fe;
+            }
+        } else {
+            // boundary facets inline: this kernel runs at 2 waves/SIMD either way, and the post-compute epilogue of the
+            // triangle kernel costs 14 % here (measured: 249 vs 219 us/step on 1M quadrilaterals)
+            swe_boundary_facet<NONLIN, LF, WD>(p, -nb[f], k, a, b, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
+                                               al[a], al[b], nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
+        }
+        bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
+        bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
+        be[a] -= 0.5*Fae; be[b] -= 0.5*Fbe;
+    }
+
     // ---- cell integrals, 2 x 2 Gauss-Legendre; weights A/4, gradients carry 1/A  ->  factor 1/4 on gradient terms
-#pragma unroll
+    // (with the optional terms the unrolled loop needs 286-306 VGPRs = 1 wave/SIMD; rolled: 205-223 = 2 waves)
+    constexpr int UNROLL_Q = SRC ? 1 : 2;
+#pragma unroll UNROLL_Q
     for (int qi = 0; qi < 2; qi++) {
-#pragma unroll
+#pragma unroll UNROLL_Q
         for (int qz = 0; qz < 2; qz++) {
             const double xi = qi ? SWE_XI1 : SWE_XI0, ze = qz ? SWE_XI1 : SWE_XI0;
             const double phi[4] = {(1.0 - xi)*(1.0 - ze), xi*(1.0 - ze), xi*ze, (1.0 - xi)*ze};
@@ -1317,60 +1376,6 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
                 be[i] += 0.25*(Hq*(gx[i]*uq + gy[i]*vq) + ce*phi[i]);          // :422
             }
         }
-    }
-
-    // ---- facets
-#pragma unroll
-    for (int f = 0; f < 4; f++) {
-        const int a = f, b = (f + 1) & 3;
-        const double nxs = py[b] - py[a], nys = px[a] - px[b];
-        const double len2 = nxs*nxs + nys*nys;
-        double L, rL;
-        swe_sqrt_rsqrt(len2, L, rL);
-        double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
-        if (nb[f] >= 0) {
-            // neighbour's nodal depth on this facet (bathymetry and alpha are continuous: same vertices)
-            const double Dna = WD ? swe_wd_depth(h[a] + ena[f], al[a]) : 0.0;
-            const double Dnb = WD ? swe_wd_depth(h[b] + enb[f], al[b]) : 0.0;
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
-                const double uq = xa*u[a] + xb*u[b], vq = xa*v[a] + xb*v[b], eq = xa*e[a] + xb*e[b];
-                const double hq = xa*h[a] + xb*h[b];
-                const double un = xa*una[f] + xb*unb[f], vn = xa*vna[f] + xb*vnb[f], en = xa*ena[f] + xb*enb[f];
-                const double eav = 0.5*(eq + en);
-                const double Hav = WD ? 0.5*((xa*H[a] + xb*H[b]) + (xa*Dna + xb*Dnb)) : (NONLIN ? hq + eav : hq);
-                const double c = swe_sqrt(g*Hav);
-                const double du = uq - un, dv = vq - vn;
-                const double dun = du*nxs + dv*nys;
-                const double spg = g*eav + c*dun*rL;
-                double fu = spg*nxs, fv = spg*nys;
-                const double uav = 0.5*(uq + un), vav = 0.5*(vq + vn);
-                const double uavn = uav*nxs + vav*nys;
-                const double fe = Hav*uavn + c*(eq - en)*L;
-                if (NONLIN) {
-                    const double unown = uq*nxs + vq*nys;
-                    fu += uav*unown;
-                    fv += vav*unown;
-                    if (LF) {
-                        const double gam = 0.5*fabs(uavn)*p.sigma_lf;
-                        fu += gam*du;
-                        fv += gam*dv;
-                    }
-                }
-                Fau += xa*fu; Fbu += xb*fu;
-                Fav += xa*fv; Fbv += xb*fv;
-                Fae += xa*fe; Fbe += xb*fe;
-            }
-        } else {
-            // boundary facets inline: this kernel runs at 2 waves/SIMD either way, and the post-compute epilogue of the
-            // triangle kernel costs 14 % here (measured: 249 vs 219 us/step on 1M quadrilaterals)
-            swe_boundary_facet<NONLIN, LF, WD>(p, -nb[f], k, a, b, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
-                                               al[a], al[b], nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
-        }
-        bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
-        bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
-        be[a] -= 0.5*Fae; be[b] -= 0.5*Fbe;
     }
 
     // ---- tensor mass inverse and Shu-Osher combine

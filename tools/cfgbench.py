@@ -49,6 +49,9 @@ def quads(rng):
     dev = Swe2dDevice(meshq, np.full(meshq.num_vertices, 20.0), 0.25)
     dev.set_state(1e-3*rng.uniform(-1, 1, size=(nq, 4, 2)), etaq)
     report('quadrilaterals SWE (DQ-1)', nq, 936.0, timed(dev, dev.advance, 50))
+    dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+    report('quadrilaterals SWE + Manning drag', nq, 936.0, timed(dev, dev.advance, 50))
+    dev.set_scalar(_lib.SCALAR_MANNING_DRAG, None)
     # cfg 4 on its own cell type (demos/demo_2d_tracer.py is a quadrilateral mesh): tracer per stage 32 r + 32 w (+32 T0)
     # + 64 velocity + 56 static = 184 / 216 / 216 B; limiter ~ 32 + 8 + 8 + 8 + 32 + 32 + 16 = 136 B
     tid = dev.add_tracer()
