@@ -894,7 +894,8 @@ tracer_kernel_t pick_tracer_kernel(bool lf, bool t0, bool src)
     return src ? swe_tracer_stage_kernel<false, false, true> : swe_tracer_stage_kernel<false, false, false>;
 }
 
-int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1, double beta, int c0, int c1)
+int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1, double beta, int c0, int c1,
+                        double *mean_out = nullptr)
 {
     if (c1 <= c0) return SWE2D_OK;
     Handle::Tracer &t = h->tracers[id];
@@ -902,6 +903,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     a.tin = t.buf[in];
     a.t0 = t.buf[0];
     a.tout = t.buf[out];
+    a.mean_out = mean_out;
     a.uv = h->state[0];
     a.stride = h->stride;
     a.nbr = h->nbr; a.cv = h->cv; a.vx = h->vx; a.vy = h->vy;
@@ -946,8 +948,9 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     return SWE2D_OK;
 }
 
-int tracer_stage(Handle *h, int id, int i_stage, int c0, int c1)
+int tracer_stage(Handle *h, int id, int i_stage, int c0, int c1, double *mean_out = nullptr)
 {
+    if (mean_out) return launch_tracer_stage(h, id, 2, 0, kAlpha0[2], kAlphaIn[2], kBeta[2], c0, c1, mean_out);
     switch (i_stage) {
     case 0: return launch_tracer_stage(h, id, 0, 1, 0.0, 1.0, kBeta[0], c0, c1);
     case 1: return launch_tracer_stage(h, id, 1, 2, kAlpha0[1], kAlphaIn[1], kBeta[1], c0, c1);
@@ -1013,7 +1016,7 @@ int limiter_build(Handle *h, int nv, const int *topo /* [n][3] */)
 
 // Means and vertex bounds over every local cell / vertex, limited values written to cells [0, cell_end).  On a
 // partition cell_end excludes the outermost ghost layer, whose vertex neighbourhoods are incomplete (partition.py).
-int limiter_apply(Handle *h, int id, int cell_end)
+int limiter_apply(Handle *h, int id, int cell_end, bool means_done = false)
 {
     if (cell_end < 0 || cell_end > h->n_cells) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell range");
     if (h->lim_nv == 0) {
@@ -1022,7 +1025,8 @@ int limiter_apply(Handle *h, int id, int cell_end)
     }
     double *t = h->tracers[id].buf[0];
     const int n = h->n_cells, nv = h->lim_nv;
-    hipLaunchKernelGGL(swe_limiter_cell_mean, dim3(grid_for(n)), dim3(256), 0, h->stream, t, h->stride, n, h->lim_mean, h->npc);
+    if (!means_done)       // swe2d_advance_coupled has the last tracer stage write the means
+        hipLaunchKernelGGL(swe_limiter_cell_mean, dim3(grid_for(n)), dim3(256), 0, h->stream, t, h->stride, n, h->lim_mean, h->npc);
     hipLaunchKernelGGL(swe_limiter_vertex_bounds, dim3(grid_for(nv)), dim3(256), 0, h->stream, h->lim_v2c_off,
                        h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_mean, t, h->stride, nv, h->lim_qmin,
                        h->lim_qmax, h->npc);
@@ -1370,8 +1374,17 @@ int swe2d_advance_coupled(swe2d_handle *hh, int n_steps, int tracer_only, int us
         if (!tracer_only)
             for (int s = 0; s < 3; s++) { int rc = stage_on_range(h, s, 0, h->n_owned); if (rc) return rc; }
         for (int id = 0; id < (int)h->tracers.size(); id++) {
-            for (int s = 0; s < 3; s++) { int rc = tracer_stage(h, id, s, 0, h->n_owned); if (rc) return rc; }
-            if (use_limiter) { int rc = limiter_apply(h, id, h->n_cells); if (rc) return rc; }
+            // without a diffusion pass behind it the last stage kernel also writes the cell means the limiter starts from
+            const bool fuse_mean = use_limiter && !h->tracers[id].diff;
+            if (fuse_mean && h->lim_nv == 0) {
+                int rc = limiter_build(h, h->n_vertices, h->host_cells.data());
+                if (rc) return rc;
+            }
+            for (int s = 0; s < 3; s++) {
+                int rc = tracer_stage(h, id, s, 0, h->n_owned, (s == 2 && fuse_mean) ? h->lim_mean : nullptr);
+                if (rc) return rc;
+            }
+            if (use_limiter) { int rc = limiter_apply(h, id, h->n_cells, fuse_mean); if (rc) return rc; }
         }
     }
     return SWE2D_OK;

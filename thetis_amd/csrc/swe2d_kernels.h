@@ -842,6 +842,7 @@ struct SweTracerArgs {
     const double *tin;     // 3 planes
     const double *t0;      // 3 planes (stage_sol[0])
     double *tout;          // 3 planes
+    double *mean_out;      // or null: cell means of the output for the limiter (= swe_limiter_cell_mean, same arithmetic)
     const double *uv;      // SWE state planes (u0 u1 u2 v0 v1 v2 ...): the advecting velocity
     size_t stride;
     const int *nbr, *cv;
@@ -1028,8 +1029,14 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
     }
     const double s = 6.0*p.dt*p.beta*swe_rcp(twoA);
     const double sb = b[0] + b[1] + b[2];
+    double msum = 0.0;
 #pragma unroll
-    for (int i = 0; i < 3; i++) swe_st(swe_rsrc(p.tout), k8, i*S8, s*(4.0*b[i] - sb) + w[i]);
+    for (int i = 0; i < 3; i++) {
+        const double o = s*(4.0*b[i] - sb) + w[i];
+        swe_st(swe_rsrc(p.tout), k8, i*S8, o);
+        msum += o;
+    }
+    if (p.mean_out) p.mean_out[k] = msum/3.0;
 }
 
 // ---- limiter, step 1: cell means (P0 projection of an affine P1 / Q1 field = mean of the nodal values)
@@ -1581,10 +1588,14 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
         b[bb] -= 0.5*Fb;
     }
     const double s = p.dt*p.beta*swe_rcp(A);
+    double msum = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-        swe_st(swe_rsrc(p.tout), k8, i*S8,
-               s*(16.0*b[i] - 8.0*b[(i + 1) & 3] - 8.0*b[(i + 3) & 3] + 4.0*b[(i + 2) & 3]) + w[i]);
+    for (int i = 0; i < 4; i++) {
+        const double o = s*(16.0*b[i] - 8.0*b[(i + 1) & 3] - 8.0*b[(i + 3) & 3] + 4.0*b[(i + 2) & 3]) + w[i];
+        swe_st(swe_rsrc(p.tout), k8, i*S8, o);
+        msum += o;
+    }
+    if (p.mean_out) p.mean_out[k] = msum/4.0;
 }
 
 // tracer diagnostics on quadrilaterals
