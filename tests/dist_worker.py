@@ -244,6 +244,8 @@ def viscosity_field(mesh):
 
 def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     global CASE
+    graphed = case.endswith('+graph')      # per-cycle HIP graphs around the (eager, host-staged) exchange
+    case = case.replace('+graph', '')
     case, every, overlap = _split_every(case)
     viscous = case.endswith('+visc')
     case = case.replace('+visc', '')
@@ -260,7 +262,13 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
         solver.dev.set_viscosity(viscosity_field(mesh)[solver.part.vertex_global], use_grad_div_viscosity_term=True)
     solver.set_state_global(uv, eta)
     d0 = solver.diagnostics()
-    solver.advance(n_steps, use_graph=False)
+    if graphed:
+        # twice the same advance: the second call replays the graphs the first one captured
+        solver.advance(n_steps - n_steps//2, use_graph=True)
+        solver.advance(n_steps//2, use_graph=True)
+        assert solver.graphed and solver.graph_mode == 'cycle'
+    else:
+        solver.advance(n_steps, use_graph=False)
     solver.synchronize()
     d1 = solver.diagnostics()
     ids, u, e = solver.get_state_owned()

@@ -111,11 +111,15 @@ def test_owned_cells_are_sorted_by_distance_from_the_cut():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('every,overlap,n_steps', [(1, 2, 4), (2, 3, 7), (4, 3, 8)])
-def test_two_ranks_overlapped_exchange_on_one_gpu(tmp_path, hip_lib, every, overlap, n_steps):
+@pytest.mark.parametrize('every,overlap,n_steps,graph', [(1, 2, 4, ''), (2, 3, 7, ''), (4, 3, 8, ''), (2, 3, 8, '+graph'),
+                                                         (4, 0, 16, '+graph'), (1, 0, 6, '+graph')])
+def test_two_ranks_overlapped_exchange_on_one_gpu(tmp_path, hip_lib, every, overlap, n_steps, graph):
+    """``+graph``: the kernel sequences before / during an exchange run from HIP graphs (graph_mode 'cycle'), the exchange
+    (gloo + host staging here, RCCL on a multi-GPU node) stays eager between two graph launches."""
     from thetis_amd.device import Swe2dDevice
     mesh, bath, uv, eta = _case()
-    run_workers(gpu_worker, 2, n_steps, str(tmp_path), axis=0, case='channel+every{:d}+overlap{:d}'.format(every, overlap))
+    run_workers(gpu_worker, 2, n_steps, str(tmp_path), axis=0,
+                case='channel+every{:d}+overlap{:d}{:}'.format(every, overlap, graph))
     u_p, e_p, extra = gather(str(tmp_path), 2, mesh.num_cells)
     dev = Swe2dDevice(mesh, bath, 2.0)
     dev.set_state(uv, eta)

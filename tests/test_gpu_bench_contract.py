@@ -36,7 +36,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields(hip_lib, env):
     assert 1e9 < d['value'] < 1e11
     if env.get('THETIS_AMD_TUNE_SCHEDULE'):
         tuned = d['config']['schedule_tuning']
-        assert len(tuned) == 5 and all(t['us_per_step'] > 0 for t in tuned)
+        assert len(tuned) == 7 and all(t['us_per_step'] > 0 for t in tuned)
         best = min(tuned, key=lambda t: t['us_per_step'])
-        assert (d['config']['exchange_every'], d['config']['overlap_stages']) == (best['exchange_every'], best['overlap_stages'])
+        assert (d['config']['exchange_every'], d['config']['overlap_stages'], d['config']['graph_mode']) == (
+            best['exchange_every'], best['overlap_stages'], best['graph_mode'])
         assert d['config']['volume_conserved'] is True

@@ -68,7 +68,8 @@ class DistributedSwe2d(object):
     """SSPRK33 on a strip-partitioned mesh, one rank per GPU."""
 
     def __init__(self, mesh, bathymetry_vertex, dt, rank, world_size, device_id, owner=None, host_staged=False,
-                 n_tracers=0, use_limiter=True, tracer_only=False, exchange_every=1, overlap_stages=0, **opts):
+                 n_tracers=0, use_limiter=True, tracer_only=False, exchange_every=1, overlap_stages=0,
+                 graph_mode=None, **opts):
         """``n_tracers`` > 0: the coupled step of GeneralCoupledTimeIntegrator2D.advance (coupled_timeintegrator_2d.py:
         93-113) on the partition - shallow water step, then every tracer with the updated velocity, then the limiter.
         The vertex-based limiter needs every cell around a vertex, so coupled runs with the limiter use four ghost layers
@@ -119,6 +120,13 @@ class DistributedSwe2d(object):
         self.dev.set_stream(self.stream.cuda_stream)
         self.graph = None
         self.graph_steps = 0
+        # 'cycle' (default): HIP graphs of the kernel sequences before / during an exchange, the exchange itself launched
+        # eagerly in between (nothing of RCCL inside a capture); 'full': the whole K-step loop incl. the RCCL calls in ONE
+        # graph (fewest launches; needs RCCL point-to-point capture to work on the node); 'none': eager launches
+        self.graph_mode = graph_mode or os.environ.get('THETIS_AMD_GRAPH_MODE', 'cycle')
+        if self.graph_mode not in ('cycle', 'full', 'none'):
+            raise ValueError("graph_mode / THETIS_AMD_GRAPH_MODE must be 'cycle', 'full' or 'none'")
+        self._cycle_graphs = {}
         self.tids = [self.dev.add_tracer() for _ in range(n_tracers)]
         self.thalo = HaloExchanger(p, self.torch_device, host_staged=host_staged, width=p.cells.shape[1]) if n_tracers else None
 
@@ -172,27 +180,60 @@ class DistributedSwe2d(object):
         if self.use_limiter:
             dev.tracer_limit_cells(tid, p.layer_end(3))
 
-    def _cycle_swe(self, n_steps, early_done=0, early_next=0):
+    def _cycle_swe(self, n_steps, early_done=0, early_next=0, graphed=False):
         """``n_steps`` (<= exchange_every) time steps on shrinking cell ranges, then one exchange.  One step:
         stage 1 on owned + ghost layers 1, 2; stage 2 on owned + layer 1; stage 3 on the owned cells.
         ``early_done``: stages of this cycle whose ghost-independent part ran during the previous exchange;
         ``early_next``: stages of the next cycle to run (ghost-independent part only) during this cycle's exchange."""
-        dev, halo, p = self.dev, self.halo, self.part
+        halo = self.halo
+        self._launch(('A', n_steps, early_done), lambda: self._cycle_before_exchange(n_steps, early_done), graphed)
+        reqs = halo.start()
+        self._launch(('B', early_next), lambda: self._cycle_during_exchange(early_next), graphed)
+        halo.finish(reqs)
+        self.dev.halo_unpack(0, halo.recv_buf.data_ptr())
+
+    def _cycle_before_exchange(self, n_steps, early_done):
+        dev, p = self.dev, self.part
         n = 3*n_steps
         assert early_done <= n - 1
         for g in range(n - 1):
             begin = p.owned_prefix(g + 2) if g < early_done else 0
             dev.solve_stage_cells(g % 3, begin, p.stage_range(g, depth=n))
-        dev.solve_stage_cells(2, p.n_interior, p.n_owned)   # the cells the peers are waiting for
-        dev.halo_pack(0, halo.send_buf.data_ptr())          # stage 3 leaves the step result in buffer 0
-        reqs = halo.start()
-        dev.solve_stage_cells(2, 0, p.n_interior)           # interior cells overlap the exchange
-        for g in range(early_next):                         # ... and so does the ghost-independent part of the next stages
-            dev.solve_stage_cells(g % 3, 0, p.owned_prefix(g + 2))
-        halo.finish(reqs)
-        dev.halo_unpack(0, halo.recv_buf.data_ptr())
+        dev.solve_stage_cells(2, p.n_interior, p.n_owned)       # the cells the peers are waiting for
+        dev.halo_pack(0, self.halo.send_buf.data_ptr())         # stage 3 leaves the step result in buffer 0
 
-    def _steps_eager(self, n_steps):
+    def _cycle_during_exchange(self, early_next):
+        dev, p = self.dev, self.part
+        dev.solve_stage_cells(2, 0, p.n_interior)               # interior cells overlap the exchange
+        for g in range(early_next):                             # ... and so does the ghost-independent part of the next stages
+            dev.solve_stage_cells(g % 3, 0, p.owned_prefix(g + 2))
+
+    def _launch(self, key, fn, graphed):
+        """Run the kernel sequence ``fn`` now, or replay its HIP graph (captured on first use).  Only kernels of this
+        library are captured: the RCCL send/recv stay ordinary stream work between two graph launches."""
+        import torch
+        if not graphed:
+            fn()
+            return
+        g = self._cycle_graphs.get(key)
+        if g is None and self.graph_mode == 'cycle':
+            try:
+                g = torch.cuda.CUDAGraph()
+                self.stream.synchronize()
+                with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
+                    fn()
+                self._cycle_graphs[key] = g
+            except Exception as e:       # capture refused: eager from now on (same results; a capture executes nothing)
+                if self.rank == 0:
+                    print('[thetis_amd] HIP graph capture unavailable ({:}); running eagerly'.format(str(e).splitlines()[0]))
+                self.graph_mode, g = 'none', None
+                torch.cuda.synchronize()
+        if g is not None:
+            g.replay()
+        else:
+            fn()
+
+    def _steps_eager(self, n_steps, graphed=False):
         m = self.exchange_every
         if self.tids or self.tracer_only:
             for _ in range(n_steps):
@@ -203,15 +244,18 @@ class DistributedSwe2d(object):
         for i, r in enumerate(cycles):
             # never across advance() calls: after the last cycle buffer 0 holds the result and nothing is half done
             nxt = min(self.overlap_stages, 3*cycles[i + 1] - 1) if i + 1 < len(cycles) else 0
-            self._cycle_swe(r, early_done=early, early_next=nxt)
+            self._cycle_swe(r, early_done=early, early_next=nxt, graphed=graphed)
             early = nxt
 
     def advance(self, n_steps, use_graph=True):
         """``n_steps`` SSPRK33 steps (enqueued; call ``synchronize``)."""
         import torch
         with torch.cuda.stream(self.stream):
-            if not use_graph:
+            if not use_graph or self.graph_mode == 'none' or os.environ.get('THETIS_AMD_NO_GRAPH'):
                 self._steps_eager(n_steps)
+                return
+            if self.graph_mode == 'cycle' and not (self.tids or self.tracer_only):
+                self._steps_eager(n_steps, graphed=True)
                 return
             if self.graph is None or self.graph_steps != n_steps:
                 self._capture(n_steps)
@@ -223,7 +267,15 @@ class DistributedSwe2d(object):
     def _capture(self, n_steps):
         import torch
         self.graph, self.graph_steps = None, n_steps
-        if os.environ.get('THETIS_AMD_NO_GRAPH'):
+        if os.environ.get('THETIS_AMD_NO_GRAPH') or self.graph_mode == 'none':
+            return
+        if self.graph_mode == 'cycle' and not (self.tids or self.tracer_only):
+            # build the per-cycle graphs of this step count's schedule by running it once (state restored)
+            saved = self.dev.get_state()
+            self._steps_eager(1)                     # RCCL connections, module loading: never inside a capture
+            self._steps_eager(n_steps, graphed=True)
+            self.stream.synchronize()
+            self.dev.set_state(*saved)
             return
         try:
             g = torch.cuda.CUDAGraph()
@@ -240,6 +292,11 @@ class DistributedSwe2d(object):
                 print('[thetis_amd] HIP graph capture unavailable ({:}); running eagerly'.format(str(e).splitlines()[0]))
             self.graph = None
             torch.cuda.synchronize()
+
+    @property
+    def graphed(self):
+        """True when the step loop runs from HIP graphs (either mode)."""
+        return self.graph is not None or bool(self._cycle_graphs)
 
     def synchronize(self):
         self.stream.synchronize()
@@ -276,36 +333,40 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
     # `overlap` stages of the next cycle (bitwise the same result for every choice; see DistributedSwe2d).  The best
     # choice depends on the RCCL point-to-point latency of the node, so a few candidates are timed during set-up (not in
     # the timed region; every rank takes the max over ranks and therefore the same decision).
+    mode0 = os.environ.get('THETIS_AMD_GRAPH_MODE', 'cycle')      # 'full' (RCCL calls inside one graph) only on request
     if os.environ.get('THETIS_AMD_EXCHANGE_EVERY'):
-        candidates = [(max(1, int(os.environ['THETIS_AMD_EXCHANGE_EVERY'])), int(os.environ.get('THETIS_AMD_OVERLAP_STAGES', '0')))]
+        candidates = [(max(1, int(os.environ['THETIS_AMD_EXCHANGE_EVERY'])), int(os.environ.get('THETIS_AMD_OVERLAP_STAGES', '0')), mode0)]
     elif world == 1 and not os.environ.get('THETIS_AMD_TUNE_SCHEDULE'):
-        candidates = [(4, 0)]
+        candidates = [(4, 0, mode0)]
     else:
-        candidates = [(2, 0), (4, 0), (4, 3), (8, 0), (8, 3)]
+        # graphs take the per-launch CPU cost off the critical path (it matters once an RCCL enqueue sits in every cycle);
+        # when the CPU keeps up anyway eager launches are ~3 us/step faster: time both
+        candidates = [(2, 0, mode0), (4, 0, mode0), (4, 3, mode0), (8, 0, mode0), (8, 3, mode0), (4, 0, 'none'), (8, 0, 'none')]
     solver, tuning = None, []
-    for every_c, overlap_c in candidates:
-        cand = DistributedSwe2d(mesh, bath, dt, rank, world, local_rank, exchange_every=every_c, overlap_stages=overlap_c)
+    for every_c, overlap_c, mode_c in candidates:
+        cand = DistributedSwe2d(mesh, bath, dt, rank, world, local_rank, exchange_every=every_c, overlap_stages=overlap_c,
+                                graph_mode=mode_c)
         cand.set_state_global(uv, eta)
         if len(candidates) == 1:
             solver, every, overlap = cand, every_c, overlap_c
             break
-        n_tune = 48
+        n_tune = 96
         cand.advance(n_tune if tuning else 2000, use_graph=False)      # RCCL connections; clocks (first candidate)
         cand.synchronize()
-        if use_graph:
+        if use_graph and mode_c != 'none':
             cand._capture(n_tune)
         best_t = float('inf')
-        for _ in range(3):
+        for _ in range(4):
             dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            cand.advance(n_tune, use_graph=use_graph)
+            cand.advance(n_tune, use_graph=use_graph and mode_c != 'none')
             cand.synchronize()
             best_t = min(best_t, time.perf_counter() - t0)
         tt = torch.tensor([best_t], dtype=torch.float64, device=cand.torch_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         us = 1e6*float(tt.item())/n_tune
-        tuning.append({'exchange_every': every_c, 'overlap_stages': overlap_c, 'us_per_step': us})
+        tuning.append({'exchange_every': every_c, 'overlap_stages': overlap_c, 'graph_mode': mode_c, 'us_per_step': us})
         if solver is None or us < best_us:
             if solver is not None:
                 solver.dev.close()
@@ -313,6 +374,7 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
         else:
             cand.dev.close()
     solver.graph = None
+    graph_mode = solver.graph_mode
     solver.set_state_global(uv, eta)
     d0 = solver.diagnostics()
     prewarm = float(getattr(args, 'prewarm', 0.0) or 0.0)
@@ -323,11 +385,12 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
     if args.warmup > 0:
         solver.advance(args.warmup, use_graph=False)
     solver.synchronize()
+    use_graph = use_graph and solver.graph_mode != 'none'
     if use_graph:
         # build the graph for the timed step count before the timed region (capture is set-up, not stepping);
         # _capture restores the state it perturbs
         solver._capture(args.steps)
-        if solver.graph is not None:
+        if solver.graphed:
             # the first launch of an instantiated graph uploads it to the device (~1 ms for a few thousand nodes): spend
             # it on K more untimed warm-up steps instead of inside the timed region
             solver.advance(args.steps, use_graph=True)
@@ -345,7 +408,7 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
     t = float(tt.item())
     d1 = solver.diagnostics()
     ok = bool(np.isfinite(d1).all() and abs(d1[2] - d0[2])/d0[2] < 1e-10)
-    hip_graph = bool(solver.graph is not None)
+    hip_graph = bool(solver.graphed)
     out = None
     if rank == 0:
         value = n_total*3.0*args.steps/t
@@ -361,7 +424,7 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
                        'parallelism': 'dd{:d} (domain decomposition, {:d}-cell halo, 1 exchange per {:d} steps)'.format(
                            world, 3*every, every),
                        'exchange_every': every, 'overlap_stages': overlap, 'schedule_tuning': tuning,
-                       'hip_graph': hip_graph, 'graph_warm_replays': int(hip_graph), 'volume_conserved': ok, 'prewarm_s': prewarm},
+                       'hip_graph': hip_graph, 'graph_mode': graph_mode, 'graph_warm_replays': int(hip_graph), 'volume_conserved': ok, 'prewarm_s': prewarm},
             'roofline': {'bound': 'hbm', 'achieved': float(per_gpu_bytes*3*args.steps/t/1e9), 'peak': hbm_peak, 'unit': 'GB/s',
                          'frac': float(per_gpu_bytes*3*args.steps/t/1e9/hbm_peak), 'traffic': None,
                          'note': 'per GPU, algorithmic bytes over wall time per stage (includes halo exchange); '

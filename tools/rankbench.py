@@ -52,7 +52,7 @@ def main():
         s.synchronize()
         best = min(best, time.perf_counter() - t0)
     print(json.dumps({'world': args.world, 'rank': args.rank, 'every': args.every, 'overlap': args.overlap, 'n_owned': int(p.n_owned),
-                      'n_ghost': int(p.n_ghost), 'n_send': int(len(p.send_cells)), 'graph': s.graph is not None,
+                      'n_ghost': int(p.n_ghost), 'n_send': int(len(p.send_cells)), 'graph': s.graphed, 'graph_mode': s.graph_mode,
                       'us_per_step': 1e6*best/args.steps}))
 
 
