@@ -2,14 +2,16 @@
 One process per GPU: halo exchange over torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
 the CPU tests) around the per-rank C-ABI handle.
 
-Per time step (thetis_amd/partition.py: three ghost layers, ONE exchange per step instead of one per stage):
+Per cycle of m = ``exchange_every`` time steps (thetis_amd/partition.py: 3m ghost layers, ONE exchange per cycle
+instead of one per stage):
 
-    stage 1 on owned + ghost layers 1,2  ->  stage 2 on owned + layer 1  ->  stage 3 on the send cells
-    -> pack -> isend/irecv with the (<= 2 for strips) peers  ||  stage 3 on the interior cells  -> unpack ghosts
+    stage g = 0 .. 3m-2 on owned + the first 3m-1-g ghost layers  ->  last stage on the send cells  -> pack
+    -> isend/irecv with the (<= 2 for strips) peers  ||  last stage on the interior cells
+       (+ optionally the ghost-independent part of the next cycle's first stages)  -> unpack ghosts
 
-The exchange is 72 B (96 B for quadrilaterals) per halo cell (cfg 3: 1500 cells = 108 KB per peer per step), i.e. pure
-latency, hidden behind the interior part of stage 3; the whole multi-step loop is captured in a HIP graph
-(torch.cuda.graph) when capture succeeds so that no Python or launch latency sits between the ~6 us kernels.
+The exchange is 72 B (96 B for quadrilaterals) per halo cell, i.e. pure latency.  The kernel sequences before and
+during an exchange run from HIP graphs (torch.cuda.graph); the RCCL calls stay eager stream work between two graph
+launches (``graph_mode``, see DistributedSwe2d).
 """
 import os
 import time
