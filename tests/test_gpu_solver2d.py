@@ -432,3 +432,94 @@ def test_time_dependent_forcing_fields_follow_update_forcings(hip_lib):
     assert solver_obj.iteration == 6 and calls[1:4] == [0.0, 2.0, 1.0]          # c = (0, 1, 1/2)
     assert rel_linf(solver_obj.fields.uv_2d.cell_node_values(), u) < 1e-11
     assert rel_linf(solver_obj.fields.elev_2d.cell_node_values(), e) < 1e-11
+
+
+def test_geostrophic_gyre_example_stays_in_balance(hip_lib):
+    """examples/geostrophicGyre/geoGyre2d.py (f-plane, linear equations: a Gaussian elevation bell with the velocity of
+    geostrophic balance is a steady state) with the explicit stepper instead of CrankNicolson.  The discrete state must
+    stay at the analytical one up to the spatial error, and volume is conserved."""
+    lx, nx, depth, elev_amp = 1.0e6, 20, 1000.0, 3.0
+    f0, sigma, g = 1.0e-4, 160.0e3, 9.81
+    x0 = y0 = lx/2
+
+    def elev_expr(x, y):
+        return elev_amp*np.exp(-((x - x0)**2 + (y - y0)**2)/sigma**2)
+
+    def run(n):
+        mesh2d = RectangleMesh(n, n, lx, lx)
+        P1_2d = get_functionspace(mesh2d, 'CG', 1)
+        bathymetry_2d = Function(P1_2d, name='Bathymetry').assign(depth)
+        solver_obj = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+        options = solver_obj.options
+        options.use_nonlinear_equations = False
+        options.coriolis_frequency = Function(P1_2d).assign(f0)
+        options.simulation_export_time = 3600.0
+        options.simulation_end_time = 4*3600.0
+        options.swe_timestepper_type = 'SSPRK33'
+        options.swe_timestepper_options.use_automatic_timestep = False
+        dt = 0.05*(lx/n)/math.sqrt(2.0)/math.sqrt(g*depth)           # the reference's explicit rule, solver2d.py:213-214
+        options.timestep = 3600.0/math.ceil(3600.0/dt)
+        options.check_volume_conservation_2d = True
+        options.no_exports = True
+        solver_obj.create_equations()
+        elev_init = Function(solver_obj.function_spaces.H_2d).project(elev_expr)
+        uv_init = Function(solver_obj.function_spaces.U_2d).project(
+            lambda x, y: (g/f0*2*(y - y0)/sigma**2*elev_expr(x, y), -g/f0*2*(x - x0)/sigma**2*elev_expr(x, y)))
+        solver_obj.assign_initial_conditions(elev=elev_init, uv=uv_init)
+        e0 = solver_obj.fields.elev_2d.cell_node_values().copy()
+        u0 = solver_obj.fields.uv_2d.cell_node_values().copy()
+        solver_obj.iterate()
+        e1 = solver_obj.fields.elev_2d.cell_node_values()
+        u1 = solver_obj.fields.uv_2d.cell_node_values()
+        vol = solver_obj.callbacks['export']['volume2d']
+        assert abs(vol.rel_diff if hasattr(vol, 'rel_diff') else 0.0) < 1e-10
+        return np.abs(e1 - e0).max()/elev_amp, np.abs(u1 - u0).max()/np.abs(u0).max()
+
+    de20, du20 = run(20)
+    de40, du40 = run(40)
+    # 4 h = 2.3 inertial periods: the drift away from the balanced state is the spatial truncation error
+    assert de20 < 0.05 and du20 < 0.15, (de20, du20)
+    assert de40 < 0.5*de20 and du40 < 0.6*du20, (de20, de40, du20, du40)     # and it converges
+
+
+def test_stommel_gyre_example_spins_up(hip_lib):
+    """examples/stommel2d/stommel2d.py (beta-plane Coriolis, wind stress, linear drag, linear equations) for its
+    regression length (10 h) with the explicit stepper: the wind does work at the analytical rate at early times -
+    d/dt int u dx = int tau_x/(rho0 H) dx - and the basin keeps its volume."""
+    lx, nx, depth = 1.0e6, 20, 1000.0
+    mesh2d = RectangleMesh(nx, nx, lx, lx)
+    P1_2d = get_functionspace(mesh2d, 'CG', 1)
+    P1v_2d = get_functionspace(mesh2d, 'CG', 1, vector=True)
+    bathymetry_2d = Function(P1_2d, name='Bathymetry').assign(depth)
+    f0, beta, tau_max = 1.0e-4, 2.0e-11, 0.1
+    coriolis_2d = Function(P1_2d).interpolate(lambda x, y: f0 + beta*y)
+    wind_stress_2d = Function(P1v_2d, name='wind stress').interpolate(
+        lambda x, y: (tau_max*np.sin(np.pi*(y/lx - 0.5)), 0.0*x))
+    solver_obj = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+    options = solver_obj.options
+    options.use_nonlinear_equations = False
+    options.coriolis_frequency = coriolis_2d
+    options.wind_stress = wind_stress_2d
+    options.linear_drag_coefficient = Constant(1e-6)
+    options.simulation_export_time = 3600.0*2
+    options.simulation_end_time = 5*3600.0*2
+    options.swe_timestepper_type = 'SSPRK33'
+    options.swe_timestepper_options.use_automatic_timestep = False
+    options.timestep = 15.0
+    options.horizontal_velocity_scale = Constant(0.01)
+    options.check_volume_conservation_2d = True
+    options.no_exports = True
+    solver_obj.assign_initial_conditions()
+    solver_obj.iterate()
+    uv = solver_obj.fields.uv_2d.cell_node_values()
+    eta = solver_obj.fields.elev_2d.cell_node_values()
+    assert np.isfinite(uv).all() and np.isfinite(eta).all()
+    # the wind blows westward in the south, eastward in the north: after 10 h (2 inertial periods) the basin-mean zonal
+    # velocity of the southern / northern half has the sign of the stress, its size is bounded by tau t/(rho0 H)
+    xy = mesh2d.cell_xy()
+    south = xy[:, :, 1].mean(axis=1) < 0.5*lx
+    u_s, u_n = uv[south, :, 0].mean(), uv[~south, :, 0].mean()
+    bound = tau_max*36000.0/(1000.0*depth)
+    assert u_s < 0 < u_n and abs(u_s) < bound and abs(u_n) < bound, (u_s, u_n, bound)
+    assert abs(u_s + u_n) < 0.05*(abs(u_s) + abs(u_n))                   # antisymmetric forcing
+    assert 1e-4 < np.abs(eta).max() < 1.0
