@@ -523,3 +523,50 @@ def test_stommel_gyre_example_spins_up(hip_lib):
     assert u_s < 0 < u_n and abs(u_s) < bound and abs(u_n) < bound, (u_s, u_n, bound)
     assert abs(u_s + u_n) < 0.05*(abs(u_s) + abs(u_n))                   # antisymmetric forcing
     assert 1e-4 < np.abs(eta).max() < 1.0
+
+
+def test_demo_2d_channel_bnd_time_dependent_flux(hip_lib):
+    """demos/demo_2d_channel_bnd.py: 'elev' + 'flux' on the right boundary, a tidal 'flux' Constant on the left updated by
+    ``update_forcings``; SSPRK33 in place of CrankNicolson, the first 20 minutes, against the numpy oracle step by step."""
+    lx, ly, nx, ny, depth = 40e3, 2e3, 25, 2, 20.0
+    mesh2d = RectangleMesh(nx, ny, lx, ly)
+    P1_2d = get_functionspace(mesh2d, 'CG', 1)
+    bathymetry_2d = Function(P1_2d, name='Bathymetry').assign(depth)
+    solver_obj = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+    options = solver_obj.options
+    dt, t_end = 4.0, 1200.0
+    options.simulation_export_time = 300.0
+    options.simulation_end_time = t_end
+    options.swe_timestepper_type = 'SSPRK33'
+    options.swe_timestepper_options.use_automatic_timestep = False
+    options.timestep = dt
+    options.no_exports = True
+    left_bnd_id, right_bnd_id, in_flux = 1, 2, 1e3
+
+    def timedep_flux(simulation_time):
+        return -2e3*math.sin(2*math.pi*simulation_time/(12*3600.0)) + in_flux
+    tide_flux_const = Constant(timedep_flux(0))
+    solver_obj.bnd_functions['shallow_water'] = {right_bnd_id: {'elev': Constant(0.0), 'flux': Constant(-in_flux)},
+                                                 left_bnd_id: {'flux': tide_flux_const}}
+
+    def update_forcings(t_new):
+        tide_flux_const.assign(timedep_flux(t_new))
+    solver_obj.assign_initial_conditions()
+    solver_obj.iterate(update_forcings=update_forcings)
+    uv, eta = solver_obj.fields.solution_2d.subfunctions
+    e_d = eta.dat.data_ro.reshape(-1, 3)
+    u_d = uv.dat.data_ro.reshape(-1, 3, 2)
+
+    from helpers import make_oracle
+    val = {'f': timedep_flux(0)}
+    orc = make_oracle(mesh2d, bathymetry_2d.dat.data_ro,
+                      bnd_conditions={right_bnd_id: {'elev': 0.0, 'flux': -in_flux}, left_bnd_id: {'flux': lambda t: val['f']}})
+
+    def uf(t):
+        val['f'] = timedep_flux(t)
+    u_o = np.zeros((mesh2d.num_cells, 3, 2))
+    e_o = np.zeros((mesh2d.num_cells, 3))
+    for k in range(int(round(t_end/dt))):
+        u_o, e_o = orc.ssprk33_step(u_o, e_o, dt, t=dt*k, update_forcings=uf)
+    assert rel_linf(e_d, e_o) < 1e-10 and rel_linf(u_d, u_o) < 1e-10
+    assert np.abs(e_d).max() < 0.5 and np.abs(u_d).max() < 0.2
