@@ -570,3 +570,53 @@ def test_demo_2d_channel_bnd_time_dependent_flux(hip_lib):
         u_o, e_o = orc.ssprk33_step(u_o, e_o, dt, t=dt*k, update_forcings=uf)
     assert rel_linf(e_d, e_o) < 1e-10 and rel_linf(u_d, u_o) < 1e-10
     assert np.abs(e_d).max() < 0.5 and np.abs(u_d).max() < 0.2
+
+
+def test_wave_eq_2d_example_returns_to_initial_state(hip_lib):
+    """examples/waveEq2d/channel2d_waveEq.py with its explicit-scheme time step (dt/40): linear standing wave whose
+    initial condition repeats every 20 exports; one full cycle with SSPRK33."""
+    lx, ly, nx, ny, depth, elev_amp = 44294.46, 3000.0, 25, 2, 50.0, 1.0
+    mesh2d = RectangleMesh(nx, ny, lx, ly)
+    P1_2d = get_functionspace(mesh2d, 'CG', 1)
+    bathymetry_2d = Function(P1_2d, name='Bathymetry').assign(depth)
+    c_wave = math.sqrt(9.81*depth)
+    t_cycle = lx/c_wave
+    dt = round(t_cycle/20)
+    solver_obj = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+    options = solver_obj.options
+    options.use_nonlinear_equations = False
+    options.simulation_export_time = dt
+    options.simulation_end_time = 20*dt
+    options.horizontal_velocity_scale = Constant(0.5)
+    options.check_volume_conservation_2d = True
+    options.swe_timestepper_type = 'SSPRK33'
+    options.swe_timestepper_options.use_automatic_timestep = False
+    options.timestep = dt/40.0
+    options.no_exports = True
+    solver_obj.create_equations()
+    elev_init = Function(solver_obj.function_spaces.H_2d).interpolate(lambda x, y: -elev_amp*np.cos(2*np.pi*x/lx))
+    solver_obj.assign_initial_conditions(elev=elev_init)
+    e0 = solver_obj.fields.elev_2d.cell_node_values().copy()
+    solver_obj.iterate()
+    e1 = solver_obj.fields.elev_2d.cell_node_values()
+    u1 = solver_obj.fields.uv_2d.cell_node_values()
+    # 20 exports of round(T/20) s are 0.2 % longer than the true period; the rest is the (small) dispersion error
+    err = np.sqrt(((e1 - e0)**2).mean())/np.sqrt((e0**2).mean())
+    assert err < 0.03, err
+    # velocity amplitude of the wave is a c/H = 0.44 m/s at mid-cycle; at a full cycle it is back at (nearly) rest
+    assert np.abs(u1[:, :, 0]).max() < 0.02 and np.abs(u1[:, :, 1]).max() < 0.01
+    # mid-cycle the wave is inverted: run half a cycle from the same start
+    solver2 = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+    o2 = solver2.options
+    o2.use_nonlinear_equations = False
+    o2.simulation_export_time = dt
+    o2.simulation_end_time = 10*dt
+    o2.swe_timestepper_type = 'SSPRK33'
+    o2.swe_timestepper_options.use_automatic_timestep = False
+    o2.timestep = dt/40.0
+    o2.no_exports = True
+    solver2.create_equations()
+    solver2.assign_initial_conditions(elev=elev_init)
+    solver2.iterate()
+    eh = solver2.fields.elev_2d.cell_node_values()
+    assert np.sqrt(((eh + e0)**2).mean())/np.sqrt((e0**2).mean()) < 0.03
