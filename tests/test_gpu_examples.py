@@ -38,3 +38,9 @@ def test_multi_gpu_example_single_rank(hip_lib):
                env={'RANK': '0', 'WORLD_SIZE': '1', 'LOCAL_RANK': '0', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29533'})
     line = [l for l in out.splitlines() if 'element-updates/s' in l][-1]      # RCCL prints its banner after it at exit
     assert float(line.split()[-1]) < 1e-10
+
+
+def test_balzano_example(hip_lib):
+    out = _run([os.path.join('examples', 'balzano.py'), '--hours', '4'])
+    last = [l for l in out.splitlines() if l.startswith('finite')][-1].split()
+    assert last[1] == 'True' and float(last[5]) < 0.0 and float(last[9]) < 3.0        # the upper beach fell dry; sane speeds
