@@ -14,6 +14,17 @@ def _dev(mesh, bath, dt, **kw):
     return Swe2dDevice(mesh, bath, dt, **kw)
 
 
+@pytest.fixture(params=['fused', 'separate_pass'], autouse=True)
+def viscosity_path(request, monkeypatch):
+    """Every test of this file runs on both implementations of the triangle viscosity: fused into the stage kernel
+    (default) and as the separate SIPG pass (THETIS_AMD_NO_VISC_FUSION, read by swe2d_create)."""
+    if request.param == 'separate_pass':
+        monkeypatch.setenv('THETIS_AMD_NO_VISC_FUSION', '1')
+    else:
+        monkeypatch.delenv('THETIS_AMD_NO_VISC_FUSION', raising=False)
+    return request.param
+
+
 VISC_CASES = {
     'const': dict(nu='const'),
     'vertex_field': dict(nu='field', sipg_factor=2.5),
@@ -364,3 +375,31 @@ def test_quad_tracer_diffusion_matches_oracle(hip_lib, case):
         dev.tracer_solve_stage(tid, s)
     assert rel_linf(dev.tracer_get_state(tid), orc.tracer_ssprk33_step(T, uv, eta, dt, **kw)) < TOL
     dev.close()
+
+
+def test_fused_and_separate_viscosity_agree_to_roundoff(hip_lib, monkeypatch, viscosity_path):
+    """Same physics, different summation order: the two paths differ by round-off only (open and closed boundaries,
+    sources, a vertex field, several steps)."""
+    if viscosity_path != 'fused':
+        pytest.skip('one comparison is enough')
+    from thetis_amd import _lib
+    mesh, bath, uv, eta = channel_case(nx=14, ny=6, seed=11)
+    rng = np.random.default_rng(3)
+    nu = 20.0 + 30.0*rng.uniform(size=mesh.num_vertices)
+    out = {}
+    for mode in ('fused', 'separate'):
+        if mode == 'separate':
+            monkeypatch.setenv('THETIS_AMD_NO_VISC_FUSION', '1')
+        else:
+            monkeypatch.delenv('THETIS_AMD_NO_VISC_FUSION', raising=False)
+        dev = _dev(mesh, bath, 1.0)
+        dev.set_viscosity(nu, sipg_factor=1.5, use_grad_div_viscosity_term=True)
+        dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+        for marker in mesh.boundary_markers:
+            dev.set_bc(marker, {'un': 0.05})
+        dev.set_state(uv, eta)
+        dev.advance(5)
+        out[mode] = dev.get_state()
+        dev.close()
+    assert rel_linf(out['fused'][0], out['separate'][0]) < 1e-13 and rel_linf(out['fused'][1], out['separate'][1]) < 1e-13
+    assert np.isfinite(out['fused'][0]).all()

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -35,6 +36,10 @@ struct Handle {
     size_t stride = 0;
     double *state[3] = {nullptr, nullptr, nullptr};   // A (U0 / step result), B (U1), C (U2)
     int *nbr = nullptr, *cv = nullptr;
+    int4 *opp4 = nullptr;                               // triangles: opposite vertices of the neighbours (fused viscosity)
+    int *bnd_cells = nullptr;                           // cells with a boundary facet (boundary-only SIPG launch)
+    int n_bnd = 0;
+    bool fuse_visc = true;                              // THETIS_AMD_NO_VISC_FUSION=1: separate SIPG pass (A/B, debugging)
     int4 *idx4 = nullptr;                               // packed triangle connectivity (stage kernel), see SweStageArgs
     int2 *idx2 = nullptr;
     double *vx = nullptr, *vy = nullptr, *vh = nullptr;
@@ -133,6 +138,20 @@ stage_kernel_t pick_kernel(bool nl, bool lf, bool u0, bool src)
 {
     return nl ? pick_lf<true>(lf, u0, src) : pick_lf<false>(lf, u0, src);
 }
+// triangles with the horizontal viscosity fused in (swe_visc_interior)
+template <bool NL, bool LF, bool U0>
+stage_kernel_t pickv_src(bool src)
+{
+    return src ? swe_stage_kernel<NL, LF, U0, true, false, true> : swe_stage_kernel<NL, LF, U0, false, false, true>;
+}
+template <bool NL, bool LF>
+stage_kernel_t pickv_u0(bool u0, bool src) { return u0 ? pickv_src<NL, LF, true>(src) : pickv_src<NL, LF, false>(src); }
+template <bool NL>
+stage_kernel_t pickv_lf(bool lf, bool u0, bool src) { return lf ? pickv_u0<NL, true>(u0, src) : pickv_u0<NL, false>(u0, src); }
+stage_kernel_t pick_kernel_visc(bool nl, bool lf, bool u0, bool src)
+{
+    return nl ? pickv_lf<true>(lf, u0, src) : pickv_lf<false>(lf, u0, src);
+}
 
 template <bool NL, bool LF, bool U0>
 stage_kernel_t pickq_src(bool src)
@@ -186,7 +205,16 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     if (h->field[SWE2D_FIELD_NIKURADSE]) { a.quad_f = h->field[SWE2D_FIELD_NIKURADSE]; a.quad_f_kind = 3; }
     a.bc = h->bc;
     const bool has_u0 = (a0 != 0.0);
-    stage_kernel_t kern = h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4)
+    // triangles: cell integral and interior facets of the viscosity inside the stage kernel, boundary facets by a small
+    // launch over the boundary cells
+    const bool fused_visc = h->visc && h->fuse_visc && h->npc == 3 && !h->wd && h->opp4;
+    a.opp4 = h->opp4;
+    a.nu_v = h->nu_v; a.nu_const = h->nu_const;
+    a.visc_sipg = 3.0*h->sipg_factor;
+    a.visc_grad_div = h->visc_grad_div; a.visc_grad_depth = h->visc_grad_depth;
+    stage_kernel_t kern = fused_visc
+        ? pick_kernel_visc(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
+        : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4)
         : (h->npc == 4)
         ? pick_kernel_quad(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
         : pick_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h));
@@ -211,7 +239,12 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
         v.eta = h->state[in] + (size_t)2*h->npc*h->stride;
         v.bc = h->bc;
         v.bc_elev_f = h->bc_field[0]; v.bc_uv_f = h->bc_field[1]; v.bc_un_f = h->bc_field[2]; v.bc_flux_f = h->bc_field[3];
-        if (h->npc == 4) hipLaunchKernelGGL(swe_sipg_kernel_quad<2>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
+        if (fused_visc) {
+            v.cell_list = h->bnd_cells; v.n_list = h->n_bnd;
+            if (h->n_bnd > 0)
+                hipLaunchKernelGGL((swe_sipg_kernel<2, true>), dim3((h->n_bnd + SWE_BLOCK - 1)/SWE_BLOCK), dim3(SWE_BLOCK), 0,
+                                   h->stream, v);
+        } else if (h->npc == 4) hipLaunchKernelGGL(swe_sipg_kernel_quad<2>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         else hipLaunchKernelGGL(swe_sipg_kernel<2>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         HIP_TRY(h, hipGetLastError());
     }
@@ -402,6 +435,28 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
         HIP_TRY_C(hipMalloc(&h->idx2, (size_t)S*sizeof(int2)));
         HIP_TRY_C(hipMemcpy(h->idx4, p4.data(), (size_t)S*sizeof(int4), hipMemcpyHostToDevice));
         HIP_TRY_C(hipMemcpy(h->idx2, p2.data(), (size_t)S*sizeof(int2), hipMemcpyHostToDevice));
+        // fused viscosity: the neighbour's vertex opposite the shared facet (its node (f2 + 2) % 3) per facet, and the list
+        // of cells that own a boundary facet
+        std::vector<int> bnd;
+        for (int kk = 0; kk < n; kk++) {
+            int vo[3];
+            bool on_bnd = false;
+            for (int f = 0; f < 3; f++) {
+                const int code = nbr[(size_t)f*S + kk];
+                vo[f] = code >= 0 ? cv[(size_t)(((code & 3) + 2) % 3)*S + (code >> 2)] : cv[(size_t)f*S + kk];
+                on_bnd = on_bnd || code < 0;
+            }
+            p4[kk] = int4{vo[0], vo[1], vo[2], 0};
+            if (on_bnd) bnd.push_back(kk);
+        }
+        HIP_TRY_C(hipMalloc(&h->opp4, (size_t)S*sizeof(int4)));
+        HIP_TRY_C(hipMemcpy(h->opp4, p4.data(), (size_t)S*sizeof(int4), hipMemcpyHostToDevice));
+        h->n_bnd = (int)bnd.size();
+        if (h->n_bnd) {
+            HIP_TRY_C(hipMalloc(&h->bnd_cells, bnd.size()*sizeof(int)));
+            HIP_TRY_C(hipMemcpy(h->bnd_cells, bnd.data(), bnd.size()*sizeof(int), hipMemcpyHostToDevice));
+        }
+        h->fuse_visc = std::getenv("THETIS_AMD_NO_VISC_FUSION") == nullptr;
     }
     HIP_TRY_C(hipMemcpyAsync(h->nbr, nbr.data(), (size_t)npc*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY_C(hipMemcpyAsync(h->cv, cv.data(), (size_t)npc*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -430,7 +485,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -62,6 +62,11 @@ struct SweStageArgs {
     // (one 16-B and one 8-B load per lane instead of six 4-B loads from six planes)
     const int4 *idx4;
     const int2 *idx2;
+    // horizontal viscosity fused into the triangle stage kernel (VISC variants; swe_visc_interior)
+    const int4 *opp4;             // {vertex of neighbour 0 / 1 / 2 opposite the shared facet, 0}
+    const double *nu_v;           // per-vertex viscosity or null (then nu_const)
+    double nu_const, visc_sipg;   // visc_sipg = sipg_factor * cp, cp = 3
+    int visc_grad_div, visc_grad_depth;
     int cell_begin, cell_end;
     double g, sigma_lf, dt;
     double a0, a1, beta;   // U_out = beta*k + a0*U0 + a1*U_in
@@ -501,10 +506,144 @@ __device__ __forceinline__ void swe_boundary_epilogue(const SweStageArgs &p, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// HorizontalViscosityTerm (SIPG, thetis/shallowwater_eq.py:554-616) of a triangle WITHOUT its boundary-facet terms: the
+// cell integral, the optional grad-depth term and the interior facets, added to the assembled momentum residuals bu, bv.
+// Same arithmetic as swe_sipg_kernel<2> (swe2d_sipg.h), but inside the stage kernel: the own state, the facet traces of
+// the neighbours, the geometry and the mass inverse are already there; extra per facet are the neighbour's third node
+// (2 gathers) and third vertex (id from the opp4 table, 2 gathers).  Boundary facets: swe_sipg_kernel<2, true> launch.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void swe_visc_interior(const SweStageArgs &p, int k, unsigned S8, swe_rsrc_t gu, swe_rsrc_t gv,
+                                                  const int nb[3], const int vid[3], const double u[3], const double v[3],
+                                                  const double una[3], const double unb[3], const double vna[3],
+                                                  const double vnb[3], const double px[3], const double py[3],
+                                                  const double nx[3], const double ny[3], double twoA, const double Hn[3],
+                                                  double bu[3], double bv[3])
+{
+    const bool gd = p.visc_grad_div != 0;
+    const int4 o4 = p.opp4[k];
+    const swe_rsrc_t rvx = swe_rsrc(p.vx), rvy = swe_rsrc(p.vy);
+    // every extra load up front
+    double uo[3], vo_[3], xo[3], yo[3], mu[3];
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        const int nbf = nb[f];
+        const int kn = nbf >= 0 ? (nbf >> 2) : k;
+        const int f2 = nbf >= 0 ? (nbf & 3) : f;
+        const unsigned oo = (unsigned)kn*8u + (f2 == 0 ? 2u*S8 : (f2 == 1 ? 0u : S8));      // node (f2 + 2) % 3
+        uo[f] = swe_ld(gu, oo, 0);
+        vo_[f] = swe_ld(gv, oo, 0);
+        const unsigned v8 = (unsigned)(f == 0 ? o4.x : (f == 1 ? o4.y : o4.z))*8u;
+        xo[f] = swe_ld(rvx, v8, 0);
+        yo[f] = swe_ld(rvy, v8, 0);
+        mu[f] = p.nu_v ? swe_ld(swe_rsrc(p.nu_v), (unsigned)vid[f]*8u, 0) : p.nu_const;
+    }
+    const double A = 0.5*twoA, r2A = swe_rcp(twoA);
+    double gx[3], gy[3];                              // grad(phi_i) = -nF_{i+1}/(2A)
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        gx[i] = -nx[(i + 1) % 3]*r2A;
+        gy[i] = -ny[(i + 1) % 3]*r2A;
+    }
+    double G[2][2], S0[2][2];
+    G[0][0] = u[0]*gx[0] + u[1]*gx[1] + u[2]*gx[2];
+    G[0][1] = u[0]*gy[0] + u[1]*gy[1] + u[2]*gy[2];
+    G[1][0] = v[0]*gx[0] + v[1]*gx[1] + v[2]*gx[2];
+    G[1][1] = v[0]*gy[0] + v[1]*gy[1] + v[2]*gy[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) S0[r][j] = G[r][j] + (gd ? G[j][r] : 0.0);
+    double b[2][3];
+    {
+        const double am = A*(mu[0] + mu[1] + mu[2])*(1.0/3.0);
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) b[r][i] = -am*(gx[i]*S0[r][0] + gy[i]*S0[r][1]);
+    }
+    if (p.visc_grad_depth) {                          // -dot(test, dot(grad(H)/H, stress))*dx          :611-612
+        const double gHx = Hn[0]*gx[0] + Hn[1]*gx[1] + Hn[2]*gx[2], gHy = Hn[0]*gy[0] + Hn[1]*gy[1] + Hn[2]*gy[2];
+        double t[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) t[r] = gHx*S0[0][r] + gHy*S0[1][r];
+        const double a1 = 0.445948490915965, b1 = 0.108103018168070, w1 = 0.223381589678011;
+        const double a2 = 0.091576213509771, b2 = 0.816847572980459, w2 = 0.109951743655322;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const double aa = q < 3 ? a1 : a2, bb = q < 3 ? b1 : b2, ww = q < 3 ? w1 : w2;
+            double l[3] = {aa, aa, aa};
+            l[q % 3] = bb;
+            const double Hq = l[0]*Hn[0] + l[1]*Hn[1] + l[2]*Hn[2];
+            const double muq = l[0]*mu[0] + l[1]*mu[1] + l[2]*mu[2];
+            const double fac = ww*A*muq*swe_rcp(Hq);
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) b[r][i] += fac*l[i]*t[r];
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        if (nb[f] < 0) continue;
+        const int a = f, bb = (f + 1) % 3;
+        const double nxs = nx[f], nys = ny[f];
+        double L, rL;
+        swe_sqrt_rsqrt(nxs*nxs + nys*nys, L, rL);
+        const double n0 = nxs*rL, n1 = nys*rL;
+        const double w = 0.5*L;
+        const double e1x = px[bb] - px[a], e1y = py[bb] - py[a];
+        const double e2x = xo[f] - px[a], e2y = yo[f] - py[a];
+        const double det = e1x*e2y - e1y*e2x;                      // -2 A_n
+        const double rdet = swe_rcp(det);
+        const double An = 0.5*fabs(det);
+        const double ca[2] = {una[f], vna[f]}, cb[2] = {unb[f], vnb[f]}, co[2] = {uo[f], vo_[f]};
+        const double c[2][3] = {{u[0], u[1], u[2]}, {v[0], v[1], v[2]}};
+        double S0n[2][2], Gn[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const double d1 = cb[r] - ca[r], d2 = co[r] - ca[r];
+            Gn[r][0] = (d1*e2y - d2*e1y)*rdet;
+            Gn[r][1] = (d2*e1x - d1*e2x)*rdet;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) S0n[r][j] = Gn[r][j] + (gd ? Gn[j][r] : 0.0);
+        const double sigma = p.visc_sipg*L*swe_rcp(fmin(A, An));
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+            const double muq = xa*mu[a] + xb*mu[bb];
+            double jmp[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) jmp[r] = (xa*c[r][a] + xb*c[r][bb]) - (xa*ca[r] + xb*cb[r]);
+            const double nn[2] = {n0, n1};
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const double sj0 = muq*(jmp[r]*n0 + (gd ? jmp[0]*nn[r] : 0.0));
+                const double sj1 = muq*(jmp[r]*n1 + (gd ? jmp[1]*nn[r] : 0.0));
+                const double sjn = sj0*n0 + sj1*n1;
+                const double avn = 0.5*muq*((S0[r][0] + S0n[r][0])*n0 + (S0[r][1] + S0n[r][1])*n1);
+                const double val = sigma*sjn - avn;
+                b[r][a] -= w*xa*val;
+                b[r][bb] -= w*xb*val;
+#pragma unroll
+                for (int i = 0; i < 3; i++) b[r][i] += w*0.5*(gx[i]*sj0 + gy[i]*sj1);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        bu[i] += b[0][i];
+        bv[i] += b[1][i];
+    }
+}
+
 // Register budget: see the -Rpass-analysis output quoted in DESIGN.md; forcing more waves per SIMD than the allocation
 // gives naturally spills (20 B/lane at 128 VGPRs for the first stage: +16 MB scratch writes per launch, not faster;
 // 5-6 waves: 2-3x slower).
-template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD>
+template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD, bool VISC = false>
 __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(const SweStageArgs p)
 {
 #ifdef SWE_NO_XCD_MAP
@@ -682,6 +821,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     // optional cell-local terms AFTER the facet loop: the 18 neighbour traces are dead by now, which keeps the SRC variants
     // at 146 (162 with wetting-drying) VGPRs = 3 waves/SIMD instead of 188 (194) = 2
     if (SRC) swe_source_terms(p, k, S, twoA, u, v, H, gxs, gys, bu, bv, be);
+    if (VISC) swe_visc_interior(p, k, S8, gu, gv, nb, vid, u, v, una, unb, vna, vnb, px, py, nx, ny, twoA, H, bu, bv);
 
     // ---- mass inverse (M^-1 b)_i = 3/A (4 b_i - sum b), times dt, and the Shu-Osher combine
     const double s = 6.0*p.dt*p.beta*swe_rcp(twoA);

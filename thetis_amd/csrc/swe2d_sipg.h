@@ -30,6 +30,10 @@ struct SweSipgArgs {
     double sipg;            // sipg_factor * cp,  cp = (p+1)(p+2)/2 = 3          shallowwater_eq.py:571-576
     double dt, beta;
     int cell_begin, cell_end;
+    // BND_ONLY launches (the viscosity of triangles is otherwise fused into the stage kernel): lane t works on cell
+    // cell_list[t], cells outside [cell_begin, cell_end) are skipped
+    const int *cell_list;
+    int n_list;
     // viscosity only
     int grad_div, grad_depth, nonlin;
     const double *eta;      // 3 planes (total depth of the grad-depth term and of 'flux' boundaries)
@@ -45,12 +49,22 @@ struct SweSipgArgs {
     double bc_u[SWE_MAX_MARKERS], bc_v[SWE_MAX_MARKERS];
 };
 
-template <int NC>
+// BND_ONLY: only the boundary-facet terms (cells taken from p.cell_list); the cell integral and the interior facets of the
+// viscosity are then evaluated inside the stage kernel (swe_visc_interior).
+template <int NC, bool BND_ONLY = false>
 __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p)
 {
-    const int lb = swe_logical_block(blockIdx.x, gridDim.x);
-    const int k = p.cell_begin + lb*SWE_BLOCK + (int)threadIdx.x;
-    if (k >= p.cell_end) return;
+    int k;
+    if (BND_ONLY) {
+        const int t = blockIdx.x*SWE_BLOCK + (int)threadIdx.x;
+        if (t >= p.n_list) return;
+        k = p.cell_list[t];
+        if (k < p.cell_begin || k >= p.cell_end) return;
+    } else {
+        const int lb = swe_logical_block(blockIdx.x, gridDim.x);
+        k = p.cell_begin + lb*SWE_BLOCK + (int)threadIdx.x;
+        if (k >= p.cell_end) return;
+    }
     const size_t S = p.stride;
     const bool gd = (NC == 2) && p.grad_div;
     // raw buffer addressing (swe_ld, swe2d_kernels.h): SGPR plane offsets, one 32-bit lane offset per gathered cell
@@ -111,7 +125,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
 #pragma unroll
         for (int r = 0; r < NC; r++)
 #pragma unroll
-            for (int i = 0; i < 3; i++) b[r][i] = -am*(gx[i]*S0[r][0] + gy[i]*S0[r][1]);     // inner(grad test, stress)*dx
+            for (int i = 0; i < 3; i++) b[r][i] = BND_ONLY ? 0.0 : -am*(gx[i]*S0[r][0] + gy[i]*S0[r][1]);     // inner(grad test, stress)*dx
     }
     double eo[3] = {0.0, 0.0, 0.0}, ho[3] = {0.0, 0.0, 0.0};
     if (NC == 2) {
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
             eo[i] = swe_ld(swe_rsrc(p.eta), k8, i*S8);
         }
     }
-    if (NC == 2 && p.grad_depth) {
+    if (NC == 2 && p.grad_depth && !BND_ONLY) {
         // -dot(test, dot(grad(H)/H, stress))*dx, shallowwater_eq.py:611-612; 6-point rule as the drag terms
         double Hn[3];
 #pragma unroll
@@ -156,6 +170,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
         const double n0 = nxs*rL, n1 = nys*rL;
         const double w = 0.5*L;                                    // Gauss weight * facet length
         if (nb[f] >= 0) {
+            if (BND_ONLY) continue;
             const int kn = nb[f] >> 2, f2 = nb[f] & 3;
             const int na = (f2 == 2) ? 0 : f2 + 1, no = (f2 == 0) ? 2 : f2 - 1;      // neighbour nodes on my a, opposite
             const unsigned sel_b = f2 == 0 ? 0u : (f2 == 1 ? 1u : 2u), sel_a = (unsigned)na, sel_o = (unsigned)no;
