@@ -240,8 +240,11 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
         v.bc = h->bc;
         v.bc_elev_f = h->bc_field[0]; v.bc_uv_f = h->bc_field[1]; v.bc_un_f = h->bc_field[2]; v.bc_flux_f = h->bc_field[3];
         if (fused_visc) {
+            // Dirichlet terms exist only where the boundary dict defines an external velocity (un / uv / flux)
+            bool any = false;
+            for (int m = 0; m < SWE_MAX_MARKERS; m++) any = any || (h->bc.kind[m] & (SWE_BC_UN | SWE_BC_UV | SWE_BC_FLUX)) != 0;
             v.cell_list = h->bnd_cells; v.n_list = h->n_bnd;
-            if (h->n_bnd > 0)
+            if (any && h->n_bnd > 0)
                 hipLaunchKernelGGL((swe_sipg_kernel<2, true>), dim3((h->n_bnd + SWE_BLOCK - 1)/SWE_BLOCK), dim3(SWE_BLOCK), 0,
                                    h->stream, v);
         } else if (h->npc == 4) hipLaunchKernelGGL(swe_sipg_kernel_quad<2>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
@@ -939,6 +942,16 @@ tracer_kernel_t pick_tracer_kernel_quad(bool lf, bool t0, bool src)
     return src ? swe_tracer_stage_kernel_quad<false, false, true> : swe_tracer_stage_kernel_quad<false, false, false>;
 }
 
+tracer_kernel_t pick_tracer_kernel_diff(bool lf, bool t0, bool src)      // horizontal diffusion fused in (swe_diff_interior)
+{
+    if (lf) {
+        if (t0) return src ? swe_tracer_stage_kernel<true, true, true, true> : swe_tracer_stage_kernel<true, true, false, true>;
+        return src ? swe_tracer_stage_kernel<true, false, true, true> : swe_tracer_stage_kernel<true, false, false, true>;
+    }
+    if (t0) return src ? swe_tracer_stage_kernel<false, true, true, true> : swe_tracer_stage_kernel<false, true, false, true>;
+    return src ? swe_tracer_stage_kernel<false, false, true, true> : swe_tracer_stage_kernel<false, false, false, true>;
+}
+
 tracer_kernel_t pick_tracer_kernel(bool lf, bool t0, bool src)
 {
     if (lf) {
@@ -974,8 +987,15 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_has_value[m] = t.bc_has_value[m]; a.bc_value[m] = t.bc_value[m]; }
     a.bc_value_f = t.bc_value_f;
     for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_vel_kind[m] = t.bc_vel_kind[m]; a.bc_u[m] = t.bc_u[m]; a.bc_v[m] = t.bc_v[m]; }
+    // triangles: cell integral and interior facets of the diffusion inside the stage kernel, boundary facets by a launch
+    // over the boundary cells (only when a marker has a diffusive boundary term at all)
+    const bool fused_diff = t.diff && h->fuse_visc && h->npc == 3 && h->opp4;
+    a.opp4 = h->opp4;
+    a.mu_v = t.mu_v; a.mu_const = t.mu_const;
+    a.diff_sipg = 3.0*t.sipg_factor;
     tracer_kernel_t kern = (h->npc == 4) ? pick_tracer_kernel_quad(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr)
-                                         : pick_tracer_kernel(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr);
+        : fused_diff ? pick_tracer_kernel_diff(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr)
+                     : pick_tracer_kernel(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr);
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
     const int grid = ((nblocks + 7)/8)*8;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
@@ -996,7 +1016,14 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
         for (int m = 0; m < SWE_MAX_MARKERS; m++) { v.bc_diff_kind[m] = t.bc_diff_kind[m]; v.bc_diff_flux[m] = t.bc_diff_flux[m]; }
         v.bc_value_f = t.bc_value_f;
         for (int m = 0; m < SWE_MAX_MARKERS; m++) { v.bc_vel_kind[m] = t.bc_vel_kind[m]; v.bc_u[m] = t.bc_u[m]; v.bc_v[m] = t.bc_v[m]; }
-        if (h->npc == 4) hipLaunchKernelGGL(swe_sipg_kernel_quad<1>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
+        if (fused_diff) {
+            bool any = false;
+            for (int m = 0; m < SWE_MAX_MARKERS; m++) any = any || t.bc_diff_kind[m] != SWE_SIPG_BC_NONE;
+            v.cell_list = h->bnd_cells; v.n_list = h->n_bnd;
+            if (any && h->n_bnd > 0)
+                hipLaunchKernelGGL((swe_sipg_kernel<1, true>), dim3((h->n_bnd + SWE_BLOCK - 1)/SWE_BLOCK), dim3(SWE_BLOCK), 0,
+                                   h->stream, v);
+        } else if (h->npc == 4) hipLaunchKernelGGL(swe_sipg_kernel_quad<1>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         else hipLaunchKernelGGL(swe_sipg_kernel<1>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         HIP_TRY(h, hipGetLastError());
     }

@@ -983,6 +983,10 @@ struct SweTracerArgs {
     const double *t0;      // 3 planes (stage_sol[0])
     double *tout;          // 3 planes
     double *mean_out;      // or null: cell means of the output for the limiter (= swe_limiter_cell_mean, same arithmetic)
+    // horizontal diffusion fused into the triangle tracer kernel (DIFF variants; swe_diff_interior)
+    const int4 *opp4;      // see SweStageArgs
+    const double *mu_v;    // per-vertex diffusivity or null (then mu_const)
+    double mu_const, diff_sipg;
     const double *uv;      // SWE state planes (u0 u1 u2 v0 v1 v2 ...): the advecting velocity
     size_t stride;
     const int *nbr, *cv;
@@ -1028,7 +1032,78 @@ __device__ __forceinline__ double swe_tracer_boundary_flux(const SweTracerArgs &
     return cup*unav;
 }
 
-template <bool LF, bool HAST0, bool SRC>
+// tracer HorizontalDiffusionTerm (SIPG, thetis/tracer_eq_2d.py:226-278) of a triangle without its boundary-facet terms,
+// inside the tracer stage kernel: same arithmetic as swe_sipg_kernel<1>; see swe_visc_interior.
+__device__ __forceinline__ void swe_diff_interior(const SweTracerArgs &p, int k, unsigned S8, swe_rsrc_t gt, const int nb[3],
+                                                  const int vid[3], const double c[3], const double cna[3],
+                                                  const double cnb[3], const double px[3], const double py[3],
+                                                  const double nx[3], const double ny[3], double twoA, double b[3])
+{
+    const int4 o4 = p.opp4[k];
+    const swe_rsrc_t rvx = swe_rsrc(p.vx), rvy = swe_rsrc(p.vy);
+    double co[3], xo[3], yo[3], mu[3];
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        const int nbf = nb[f];
+        const int kn = nbf >= 0 ? (nbf >> 2) : k;
+        const int f2 = nbf >= 0 ? (nbf & 3) : f;
+        co[f] = swe_ld(gt, (unsigned)kn*8u + (f2 == 0 ? 2u*S8 : (f2 == 1 ? 0u : S8)), 0);      // node (f2 + 2) % 3
+        const unsigned v8 = (unsigned)(f == 0 ? o4.x : (f == 1 ? o4.y : o4.z))*8u;
+        xo[f] = swe_ld(rvx, v8, 0);
+        yo[f] = swe_ld(rvy, v8, 0);
+        mu[f] = p.mu_v ? swe_ld(swe_rsrc(p.mu_v), (unsigned)vid[f]*8u, 0) : p.mu_const;
+    }
+    const double A = 0.5*twoA, r2A = swe_rcp(twoA);
+    double gx[3], gy[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        gx[i] = -nx[(i + 1) % 3]*r2A;
+        gy[i] = -ny[(i + 1) % 3]*r2A;
+    }
+    const double G0 = c[0]*gx[0] + c[1]*gx[1] + c[2]*gx[2], G1 = c[0]*gy[0] + c[1]*gy[1] + c[2]*gy[2];
+    double d[3];
+    {
+        const double am = A*(mu[0] + mu[1] + mu[2])*(1.0/3.0);
+#pragma unroll
+        for (int i = 0; i < 3; i++) d[i] = -am*(gx[i]*G0 + gy[i]*G1);
+    }
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        if (nb[f] < 0) continue;
+        const int a = f, bb = (f + 1) % 3;
+        const double nxs = nx[f], nys = ny[f];
+        double L, rL;
+        swe_sqrt_rsqrt(nxs*nxs + nys*nys, L, rL);
+        const double n0 = nxs*rL, n1 = nys*rL;
+        const double w = 0.5*L;
+        const double e1x = px[bb] - px[a], e1y = py[bb] - py[a];
+        const double e2x = xo[f] - px[a], e2y = yo[f] - py[a];
+        const double det = e1x*e2y - e1y*e2x;
+        const double rdet = swe_rcp(det);
+        const double An = 0.5*fabs(det);
+        const double d1 = cnb[f] - cna[f], d2 = co[f] - cna[f];
+        const double Gn0 = (d1*e2y - d2*e1y)*rdet, Gn1 = (d2*e1x - d1*e2x)*rdet;
+        const double sigma = p.diff_sipg*L*swe_rcp(fmin(A, An));
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+            const double muq = xa*mu[a] + xb*mu[bb];
+            const double jmp = (xa*c[a] + xb*c[bb]) - (xa*cna[f] + xb*cnb[f]);
+            const double sj0 = muq*(jmp*n0), sj1 = muq*(jmp*n1);
+            const double sjn = sj0*n0 + sj1*n1;
+            const double avn = 0.5*muq*((G0 + Gn0)*n0 + (G1 + Gn1)*n1);
+            const double val = sigma*sjn - avn;
+            d[a] -= w*xa*val;
+            d[bb] -= w*xb*val;
+#pragma unroll
+            for (int i = 0; i < 3; i++) d[i] += w*0.5*(gx[i]*sj0 + gy[i]*sj1);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) b[i] += d[i];
+}
+
+template <bool LF, bool HAST0, bool SRC, bool DIFF = false>
 __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTracerArgs p)
 {
 #ifdef SWE_NO_XCD_MAP
@@ -1167,6 +1242,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
         b[a] -= 0.5*Fa;
         b[bb] -= 0.5*Fb;
     }
+    if (DIFF) swe_diff_interior(p, k, S8, gt, nb, vid, c, cna, cnb, px, py, nx, ny, twoA, b);
     const double s = 6.0*p.dt*p.beta*swe_rcp(twoA);
     const double sb = b[0] + b[1] + b[2];
     double msum = 0.0;
