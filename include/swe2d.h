@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SWE2D_ABI_VERSION 3
+#define SWE2D_ABI_VERSION 4
 #define SWE2D_MAX_MARKERS 16          /* boundary markers must be in 1..SWE2D_MAX_MARKERS-1 */
 
 typedef enum {
@@ -147,6 +147,12 @@ int  swe2d_set_bc(swe2d_handle *h, int marker, int kind, const double values[5])
  * nodes of boundary facets carrying `marker` are copied (stored per facet, so the two boundaries meeting at a corner cell
  * keep their own values).  Select the field with the SWE2D_BC_*_FIELD bit in swe2d_set_bc.  May be called between stages. */
 int  swe2d_set_bc_field(swe2d_handle *h, int which, int marker, const double *nodal);
+/* The same data as a COMPACT list - what update_forcings should cost per call (a tidal elevation Function re-evaluated at
+ * t + c_i dt, rungekutta.py:933-934: a few KB instead of the whole nodal field): entry t is boundary facet facets[t] of cell
+ * cells[t] (caller's cell numbering as passed to swe2d_create), values[t][j][c] the value at the facet's first (j = 0) and
+ * second (j = 1) node, component c (2 components for which = 1, else 1).  Facets not listed keep their values. */
+int  swe2d_set_bc_facets(swe2d_handle *h, int which, int32_t n_facets, const int32_t *cells, const int32_t *facets,
+                         const double *values);
 
 /* bnd_functions['shallow_water'][marker]['drag'] = C_D (BoundaryDragTerm, shallowwater_eq.py:704-725); negative: none */
 int  swe2d_set_boundary_drag(swe2d_handle *h, int marker, double drag_coefficient);
@@ -211,6 +217,9 @@ int  swe2d_tracer_set_bc_velocity(swe2d_handle *h, int tracer_id, int marker, in
 /* Function-valued 'value' on `marker`: nodal DG values of the whole mesh in the host layout (kN); only cells with a
  * boundary facet carrying `marker` are copied (all their nodes: the diffusive boundary term uses the cell gradient) */
 int  swe2d_tracer_set_bc_field(swe2d_handle *h, int tracer_id, int marker, const double *nodal);
+/* compact form: values[t][i] = external value at node i of cell cells[t], stored for its boundary facet facets[t] */
+int  swe2d_tracer_set_bc_facets(swe2d_handle *h, int tracer_id, int32_t n_facets, const int32_t *cells, const int32_t *facets,
+                                const double *values);     /* then select them: swe2d_tracer_set_bc(..., has_value = 2, 0) */
 int  swe2d_tracer_set_source(swe2d_handle *h, int tracer_id, const double *nodal);   /* SourceTerm tracer_eq_2d.py:281-298 */
 /* options.tracer[label].use_conservative_form (options.py:543): the tracer field is the depth-integrated q = H*T and the
  * stage kernels evaluate ConservativeHorizontalAdvectionTerm / ConservativeSourceTerm (tracer_eq_2d.py:325-437) */

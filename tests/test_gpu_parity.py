@@ -321,3 +321,41 @@ def test_edge_cases_of_the_c_abi(hip_lib):
         ku_o, ke_o = make_oracle(mesh, bath).tendency(uv, eta, 1.0)
         assert rel_linf(ku, ku_o) < TOL_RHS and rel_linf(ke, ke_o) < TOL_RHS
         dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('reorder', ['auto', None])
+def test_compact_boundary_facet_upload_equals_nodal_field_upload(hip_lib, reorder):
+    """swe2d_set_bc_facets / swe2d_tracer_set_bc_facets (what update_forcings costs per call: the boundary facets' values)
+    against swe2d_set_bc_field / swe2d_tracer_set_bc_field (the whole nodal field): identical tendencies."""
+    from thetis_amd import _lib
+    from thetis_amd.device import FacetValues, Swe2dDevice
+    mesh, bath, uv, eta = channel_case(nx=9, ny=5, seed=5)
+    rng = np.random.default_rng(8)
+    n, k = mesh.num_cells, 3
+    f_elev, f_uv, f_T = 0.2*rng.normal(size=(n, k)), 0.2*rng.normal(size=(n, k, 2)), rng.normal(size=(n, k))
+    res = {}
+    for mode in ('nodal', 'compact'):
+        dev = Swe2dDevice(mesh, bath, 2.0, reorder=reorder)
+        tid = dev.add_tracer()
+        dev.tracer_set_diffusivity(tid, 30.0, 1.0)
+        if mode == 'nodal':
+            dev.set_bc(1, {'elev': f_elev})
+            dev.set_bc(2, {'uv': f_uv})
+            dev.tracer_set_bc(tid, 2, f_T)
+        else:
+            dev.set_bc(1, {'elev': dev.facet_node_values(1, f_elev)})
+            dev.set_bc(2, {'uv': dev.facet_node_values(2, f_uv)})
+            assert isinstance(dev.facet_node_values(2, f_uv), FacetValues)
+            cells, _ = dev.boundary_facets(dev._slot(2))
+            dev.tracer_set_bc_facets(tid, dev._slot(2), f_T[cells])
+        dev.tracer_set_diffusion_bc(tid, 2, 4, 0.0)
+        dev.set_state(uv, eta)
+        dev.tracer_set_state(tid, 3.0 + rng.normal(size=(n, k))*0 + np.arange(n)[:, None]*1e-3)
+        res[mode] = (dev.tendency(), dev.tracer_tendency(tid))
+        dev.close()
+    (ku_a, ke_a), kt_a = res['nodal']
+    (ku_b, ke_b), kt_b = res['compact']
+    assert np.array_equal(ku_a, ku_b) and np.array_equal(ke_a, ke_b) and np.array_equal(kt_a, kt_b)
+    # the boundary values matter: a different field gives a different tendency
+    assert np.abs(ku_a).max() > 0

@@ -51,6 +51,7 @@ SYMBOLS = {
     'swe2d_set_dt': (ctypes.c_int, [_H, ctypes.c_double]),
     'swe2d_set_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),
     'swe2d_set_bc_field': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),
+    'swe2d_set_bc_facets': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int32, _ip, _ip, _dp]),
     'swe2d_set_boundary_drag': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_double]),
     'swe2d_set_field': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_set_scalar': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_double]),
@@ -70,6 +71,7 @@ SYMBOLS = {
     'swe2d_tracer_set_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
     'swe2d_tracer_set_bc_velocity': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]),
     'swe2d_tracer_set_bc_field': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),
+    'swe2d_tracer_set_bc_facets': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int32, _ip, _ip, _dp]),
     'swe2d_tracer_set_source': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_tracer_solve_stage_cells': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_tracer_limit_cells': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int32]),

@@ -80,10 +80,20 @@ class DeviceTracerSSPRK33(object):
             funcs = self.bnd_conditions.get(marker)
             v = None if funcs is None else funcs.get('value')
             is_field = isinstance(v, Function)
-            if is_field:            # Function-valued 'value': nodal values at the DG nodes
-                v = np.ascontiguousarray(v.cell_node_values() if v.function_space().family == 'DG'
-                                         else v.dat.data_ro[self.equation.mesh.cells])
-                self.device.tracer_set_bc(self.tid, marker, v)
+            sig = None if funcs is None else tuple(sorted((k, self.swe._signature(x)) for k, x in funcs.items()))
+            cache = self.__dict__.setdefault('_bc_signatures', {})
+            if marker in cache and cache[marker] == sig:
+                continue                # nothing on this marker changed since the last upload
+            cache[marker] = sig
+            if is_field:            # Function-valued 'value': the nodal values of the boundary cells only (compact upload)
+                mesh = self.equation.mesh
+                cells, _ = self.device.boundary_facets(self.device._slot(marker))
+                fs = v.function_space()
+                if fs.family == 'CG':
+                    vals = v.dat.data_ro[np.asarray(mesh.cells)[cells]]
+                else:
+                    vals = v.cell_node_values()[cells]
+                self.device.tracer_set_bc_facets(self.tid, self.device._slot(marker), vals)
             else:
                 self.device.tracer_set_bc(self.tid, marker, _cval(v))
             uv_b = None if funcs is None else funcs.get('uv')

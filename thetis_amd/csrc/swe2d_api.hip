@@ -589,6 +589,47 @@ int swe2d_set_bc_field(swe2d_handle *hh, int which, int marker, const double *no
     return SWE2D_OK;
 }
 
+// shared by swe2d_set_bc_facets / swe2d_tracer_set_bc_facets: upload the compact lists and scatter them into `planes`
+static int scatter_facet_values(Handle *h, double *planes, int n, const int32_t *cells, const int32_t *facets, const double *values,
+                                int ncomp, int nval)
+{
+    if (n == 0) return SWE2D_OK;
+    const size_t nv = (size_t)n*nval*ncomp;
+    if (nv*sizeof(double) + 2*(size_t)n*sizeof(int) > (size_t)2*h->npc*h->n_cells*sizeof(double))
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "more boundary facets than the staging buffer holds");
+    for (int t = 0; t < n; t++)
+        if (cells[t] < 0 || cells[t] >= h->n_cells || facets[t] < 0 || facets[t] >= h->npc)
+            return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "boundary facet list: cell or facet index out of range");
+    // staging: values, then the two index lists, in the uv staging buffer (2*npc*n_cells doubles)
+    double *dv = h->stage_uv;
+    int *dc = reinterpret_cast<int *>(dv + nv), *df = dc + n;
+    HIP_TRY(h, hipMemcpyAsync(dv, values, nv*sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dc, cells, (size_t)n*sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(df, facets, (size_t)n*sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(swe_bc_facet_scatter, dim3(grid_for(n)), dim3(256), 0, h->stream, dv, planes, h->stride, dc, df, n, ncomp,
+                       h->npc, nval);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));      // host buffers may be reused by the caller
+    return SWE2D_OK;
+}
+
+int swe2d_set_bc_facets(swe2d_handle *hh, int which, int n_facets, const int32_t *cells, const int32_t *facets,
+                        const double *values)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (which < 0 || which > 3 || n_facets < 0 || (n_facets > 0 && (!cells || !facets || !values)))
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad boundary facet values");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int ncomp = (which == 1) ? 2 : 1;
+    const size_t bytes = (size_t)2*h->npc*ncomp*h->stride*sizeof(double);
+    if (!h->bc_field[which]) {
+        HIP_TRY(h, hipMalloc(&h->bc_field[which], bytes));
+        HIP_TRY(h, hipMemsetAsync(h->bc_field[which], 0, bytes, h->stream));
+    }
+    return scatter_facet_values(h, h->bc_field[which], n_facets, cells, facets, values, ncomp, 2);
+}
+
 int swe2d_set_boundary_drag(swe2d_handle *hh, int marker, double drag_coefficient)
 {
     Handle *h = H(hh);
@@ -1195,7 +1236,8 @@ int swe2d_tracer_set_bc(swe2d_handle *hh, int id, int marker, int has_value, dou
     int rc = check_tracer(h, id);
     if (rc) return rc;
     if (marker <= 0 || marker >= SWE2D_MAX_MARKERS) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "marker out of range");
-    h->tracers[id].bc_has_value[marker] = has_value ? 1 : 0;
+    // 0: no value, 1: constant, 2: Function values uploaded by swe2d_tracer_set_bc_field / swe2d_tracer_set_bc_facets
+    h->tracers[id].bc_has_value[marker] = has_value == 2 ? 2 : (has_value ? 1 : 0);
     h->tracers[id].bc_value[marker] = value;
     return SWE2D_OK;
 }
@@ -1211,6 +1253,24 @@ int swe2d_tracer_set_bc_velocity(swe2d_handle *hh, int id, int marker, int kind,
     h->tracers[id].bc_u[marker] = u;
     h->tracers[id].bc_v[marker] = v;
     return SWE2D_OK;
+}
+
+int swe2d_tracer_set_bc_facets(swe2d_handle *hh, int id, int n_facets, const int32_t *cells, const int32_t *facets,
+                               const double *values)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (n_facets < 0 || (n_facets > 0 && (!cells || !facets || !values)))
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad boundary facet values");
+    HIP_TRY(h, hipSetDevice(h->device));
+    Handle::Tracer &t = h->tracers[id];
+    const size_t bytes = (size_t)h->npc*h->npc*h->stride*sizeof(double);
+    if (!t.bc_value_f) {
+        HIP_TRY(h, hipMalloc(&t.bc_value_f, bytes));
+        HIP_TRY(h, hipMemsetAsync(t.bc_value_f, 0, bytes, h->stream));
+    }
+    return scatter_facet_values(h, t.bc_value_f, n_facets, cells, facets, values, 1, h->npc);
 }
 
 int swe2d_tracer_set_bc_field(swe2d_handle *hh, int id, int marker, const double *nodal)

@@ -900,6 +900,22 @@ __global__ void swe_bc_field_scatter(const double *nodal, double *planes, size_t
     }
 }
 
+// The same from a COMPACT list: entry t = boundary facet `facet[t]` of cell `cell[t]` with `nval` values per component
+// (2 = the facet's end nodes -> planes 2f, 2f+1 of component c at + 2*npc*c; npc = all nodes of the cell -> planes npc*f + i).
+// What a time-dependent boundary Function costs per update: a few KB over PCIe instead of the whole nodal field.
+__global__ void swe_bc_facet_scatter(const double *vals, double *planes, size_t stride, const int *cell, const int *facet, int n,
+                                     int ncomp, int npc, int nval)
+{
+    const int t = blockIdx.x*blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int k = cell[t], f = facet[t];
+    for (int c = 0; c < ncomp; c++)
+        for (int j = 0; j < nval; j++) {
+            const size_t plane = (nval == 2) ? (size_t)(2*npc*c + 2*f + j) : (size_t)(npc*f + j);
+            planes[plane*stride + k] = vals[((size_t)t*nval + j)*ncomp + c];
+        }
+}
+
 // Function-valued tracer boundary value of ONE marker: all npc nodal values of the cell are kept per boundary facet (the
 // diffusive boundary term needs the cell gradient of the external value, tracer_eq_2d.py:270-276): plane npc*f + i
 __global__ void swe_bc_cellfield_scatter(const double *nodal, double *planes, size_t stride, const int *nbr, int n, int npc,

@@ -18,6 +18,18 @@ def _ptr(a):
     return a.ctypes.data_as(_dp)
 
 
+def _iptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+class FacetValues(object):
+    """Function-valued boundary data of one marker in compact form: the values at the two end nodes of every boundary
+    facet, in the order of ``Swe2dDevice.boundary_facets`` - (n_facets, 2) or (n_facets, 2, 2) for a velocity."""
+
+    def __init__(self, values):
+        self.values = np.asarray(values, dtype=np.float64)
+
+
 class Swe2dDevice(object):
     def __init__(self, mesh, bathymetry_vertex, dt, g_grav=9.81, use_nonlinear_equations=True,
                  use_lax_friedrichs_velocity=True, lax_friedrichs_velocity_scaling_factor=1.0,
@@ -51,6 +63,7 @@ class Swe2dDevice(object):
             for m, sl in self._marker_slot.items():
                 lut[m] = sl
             nbr0 = np.where(nbr0 < 0, -lut[np.where(nbr0 < 0, -nbr0, 0)], nbr0)
+        self._caller_nbr = np.array(nbr0)        # (N, k), boundary facets = -slot, caller's cell numbering
         if boundary_len is not None:
             boundary_len = {self._marker_slot[m]: v for m, v in boundary_len.items() if m in self._marker_slot}
         # ---- device numbering: perm[i_dev] = i_caller
@@ -174,34 +187,34 @@ class Swe2dDevice(object):
         marker = self._slot(marker)
         kind = 0
         vals = np.zeros(5)
-        is_field = lambda v: isinstance(v, np.ndarray) and v.ndim >= 2
+        is_field = lambda v: isinstance(v, FacetValues) or (isinstance(v, np.ndarray) and v.ndim >= 2)
         for key, value in (funcs or {}).items():
             if key == 'elev':
                 kind |= _lib.BC_ELEV
                 if is_field(value):
                     kind |= _lib.BC_ELEV_FIELD
-                    self.set_bc_field(0, marker, value)
+                    self._set_bc_function(0, marker, value)
                 else:
                     vals[0] = float(value)
             elif key == 'uv':
                 kind |= _lib.BC_UV
                 if is_field(value):
                     kind |= _lib.BC_UV_FIELD
-                    self.set_bc_field(1, marker, value)
+                    self._set_bc_function(1, marker, value)
                 else:
                     vals[1], vals[2] = float(value[0]), float(value[1])
             elif key == 'un':
                 kind |= _lib.BC_UN
                 if is_field(value):
                     kind |= _lib.BC_UN_FIELD
-                    self.set_bc_field(2, marker, value)
+                    self._set_bc_function(2, marker, value)
                 else:
                     vals[3] = float(value)
             elif key == 'flux':
                 kind |= _lib.BC_FLUX
                 if is_field(value):
                     kind |= _lib.BC_FLUX_FIELD
-                    self.set_bc_field(3, marker, value)
+                    self._set_bc_function(3, marker, value)
                 else:
                     vals[4] = float(value)
             elif key == 'drag':
@@ -264,6 +277,51 @@ class Swe2dDevice(object):
     def tracer_set_diffusion_bc(self, tracer_id, marker, kind, diff_flux=0.0):
         """kind: 0 none, 1 prescribed 'diff_flux', 2 constant 'value', 3 boundary dict without 'value', 4 Function 'value'."""
         self._ck(self.lib.swe2d_tracer_set_diffusion_bc(self.h, int(tracer_id), self._slot(marker), int(kind), float(diff_flux)))
+
+    def _set_bc_function(self, which, slot, value):
+        if isinstance(value, FacetValues):
+            self.set_bc_facets(which, slot, value.values)
+        else:
+            self.set_bc_field(which, slot, value)
+
+    def facet_node_values(self, marker, function_values, cells_of_vertices=None):
+        """Compact boundary data of ``marker`` from a P1 field: ``function_values`` are DG nodal values (N, k[, 2]) or, with
+        ``cells_of_vertices`` = the (N, k) cell-vertex table, CG vertex values (V[, 2])."""
+        cells, facets = self.boundary_facets(self._slot(marker))
+        nxt = (facets + 1) % self.npc
+        d = np.asarray(function_values)
+        if cells_of_vertices is None:
+            return FacetValues(np.stack([d[cells, facets], d[cells, nxt]], axis=1))
+        cv = np.asarray(cells_of_vertices)
+        return FacetValues(np.stack([d[cv[cells, facets]], d[cv[cells, nxt]]], axis=1))
+
+    def boundary_facets(self, slot):
+        """(cells, facets) of the boundary facets carrying marker slot ``slot``, in the CALLER's cell numbering (cached)."""
+        cache = self.__dict__.setdefault('_bnd_facets', {})
+        if slot not in cache:
+            c, f = np.nonzero(self._caller_nbr == -int(slot))
+            cache[slot] = (np.ascontiguousarray(c.astype(np.int32)), np.ascontiguousarray(f.astype(np.int32)))
+        return cache[slot]
+
+    def _device_cells(self, cells):
+        return np.ascontiguousarray((cells if self.perm is None else self.inv_perm[cells]).astype(np.int32))
+
+    def set_bc_facets(self, which, slot, values):
+        """Function-valued boundary data of one marker slot in compact form: ``values`` (n_facets, 2) [(n_facets, 2, 2) for
+        which = 1] = the value at the first and second node of every facet of ``boundary_facets(slot)``."""
+        cells, facets = self.boundary_facets(slot)
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.float64).reshape((len(cells), 2, 2) if which == 1 else (len(cells), 2)))
+        self._ck(self.lib.swe2d_set_bc_facets(self.h, int(which), len(cells), _iptr(self._device_cells(cells)), _iptr(facets),
+                                              _ptr(v)))
+
+    def tracer_set_bc_facets(self, tid, slot, values):
+        """compact form of ``tracer_set_bc`` with a Function value: ``values`` (n_facets, k) = the external value at every
+        node of the boundary cells of ``boundary_facets(slot)``."""
+        cells, facets = self.boundary_facets(slot)
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.float64).reshape(len(cells), self.npc))
+        self._ck(self.lib.swe2d_tracer_set_bc_facets(self.h, int(tid), len(cells), _iptr(self._device_cells(cells)),
+                                                     _iptr(facets), _ptr(v)))
+        self._ck(self.lib.swe2d_tracer_set_bc(self.h, int(tid), int(slot), 2, 0.0))
 
     def set_bc_field(self, which, slot, nodal):
         """Function-valued boundary data of one marker slot: nodal DG values (N,k) [(N,k,2) for which = 1]; which = 0 elev,

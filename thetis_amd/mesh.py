@@ -116,8 +116,13 @@ class Mesh2d(object):
 
     @property
     def boundary_markers(self):
-        m = -self.cell_nbr[self.cell_nbr < 0]
-        return sorted(int(i) for i in np.unique(m))
+        # cached per connectivity array: the time steppers ask for it at every stage (update_forcings)
+        cache = self.__dict__.get('_boundary_markers')
+        if cache is None or cache[0] is not self.cell_nbr:
+            m = -self.cell_nbr[self.cell_nbr < 0]
+            cache = (self.cell_nbr, sorted(int(i) for i in np.unique(m)))
+            self.__dict__['_boundary_markers'] = cache
+        return list(cache[1])
 
     def cell_xy(self):
         """(N, k, 2) coordinates of the DG-P1 / DQ-1 nodes (= cell vertices)."""

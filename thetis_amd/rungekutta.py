@@ -207,8 +207,15 @@ class ERKGenericShuOsher(TimeIntegrator):
                     # Function-valued boundary data (e.g. a tidal elevation field): nodal values at the DG nodes
                     if key not in ('elev', 'uv', 'un', 'flux'):
                         raise NotImplementedError("'{:}' must be a constant on the device path".format(key))
-                    vals[key] = np.ascontiguousarray(v.cell_node_values() if v.function_space().family == 'DG'
-                                                     else v.dat.data_ro[mesh.cells])
+                    # only the values on this marker's boundary facets travel to the device (a few KB per update_forcings)
+                    fs = v.function_space()
+                    if fs.family == 'DG' and fs.degree == 1:
+                        d = v.dat.data_ro
+                        vals[key] = self.device.facet_node_values(marker, d.reshape((mesh.num_cells, fs.npc) + d.shape[1:]))
+                    elif fs.family == 'CG':
+                        vals[key] = self.device.facet_node_values(marker, v.dat.data_ro, cells_of_vertices=mesh.cells)
+                    else:
+                        vals[key] = np.ascontiguousarray(v.cell_node_values())
                 elif callable(v):
                     raise NotImplementedError('boundary values must be Constants or Functions on the device path')
                 else:
