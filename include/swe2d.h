@@ -159,6 +159,10 @@ int  swe2d_set_boundary_drag(swe2d_handle *h, int marker, double drag_coefficien
 
 /* coefficient fields: nodal DG-P1 values (3N) [(3N,2) for the momentum source and the wind stress] or NULL to switch the term off */
 int  swe2d_set_field(swe2d_handle *h, int field, const double *nodal);
+/* a CONTINUOUS P1 coefficient given per vertex (numbering of swe2d_mesh.vertex_xy), [n_vertices] or [n_vertices][2] for the
+ * vector fields: the injection into the DG nodes happens on the device.  A time-dependent wind / pressure Function then costs
+ * one value per vertex per update instead of one per DG node. */
+int  swe2d_set_field_vertex(swe2d_handle *h, int field, const double *vertex_values);
 /* scalar coefficients; a negative value switches the term off (norm_smoother: >= 0) */
 int  swe2d_set_scalar(swe2d_handle *h, int which, double value);
 

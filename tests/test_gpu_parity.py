@@ -359,3 +359,33 @@ def test_compact_boundary_facet_upload_equals_nodal_field_upload(hip_lib, reorde
     assert np.array_equal(ku_a, ku_b) and np.array_equal(ke_a, ke_b) and np.array_equal(kt_a, kt_b)
     # the boundary values matter: a different field gives a different tendency
     assert np.abs(ku_a).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cells', ['tri', 'quad'])
+def test_vertex_field_upload_equals_nodal_upload(hip_lib, cells):
+    """swe2d_set_field_vertex (continuous P1 coefficient by vertex values, injected into the DG nodes on the device)
+    against swe2d_set_field with the host-side injection."""
+    from thetis_amd import _lib
+    from thetis_amd.device import Swe2dDevice
+    if cells == 'quad':
+        from helpers import quad_case
+        mesh, bath, uv, eta = quad_case(nx=7, ny=5, skew=0.2, seed=2)
+    else:
+        mesh, bath, uv, eta = channel_case(nx=9, ny=5, seed=5)
+    rng = np.random.default_rng(9)
+    f_cor = 1e-4*(1.0 + rng.uniform(size=mesh.num_vertices))
+    tau = 0.1*rng.normal(size=(mesh.num_vertices, 2))
+    res = []
+    for mode in ('nodal', 'vertex'):
+        dev = Swe2dDevice(mesh, bath, 1.0)
+        if mode == 'nodal':
+            dev.set_field(_lib.FIELD_CORIOLIS, f_cor[mesh.cells])
+            dev.set_field(_lib.FIELD_WIND_STRESS, tau[mesh.cells])
+        else:
+            dev.set_field_vertex(_lib.FIELD_CORIOLIS, f_cor)
+            dev.set_field_vertex(_lib.FIELD_WIND_STRESS, tau)
+        dev.set_state(uv, eta)
+        res.append(dev.tendency())
+        dev.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])

@@ -54,6 +54,7 @@ SYMBOLS = {
     'swe2d_set_bc_facets': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int32, _ip, _ip, _dp]),
     'swe2d_set_boundary_drag': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_double]),
     'swe2d_set_field': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
+    'swe2d_set_field_vertex': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_set_scalar': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_double]),
     'swe2d_set_wetting_and_drying': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_set_viscosity': (ctypes.c_int, [_H, ctypes.c_int, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int]),

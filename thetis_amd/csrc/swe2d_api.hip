@@ -639,7 +639,17 @@ int swe2d_set_boundary_drag(swe2d_handle *hh, int marker, double drag_coefficien
     return SWE2D_OK;
 }
 
-int swe2d_set_field(swe2d_handle *hh, int field, const double *nodal)
+static int set_field_impl(swe2d_handle *hh, int field, const double *nodal, bool per_vertex);
+
+int swe2d_set_field(swe2d_handle *hh, int field, const double *nodal) { return set_field_impl(hh, field, nodal, false); }
+
+int swe2d_set_field_vertex(swe2d_handle *hh, int field, const double *vertex_values)
+{
+    if (!vertex_values) return fail(H(hh), SWE2D_ERR_INVALID_ARGUMENT, "null vertex values (clear a field with swe2d_set_field(h, field, NULL))");
+    return set_field_impl(hh, field, vertex_values, true);
+}
+
+static int set_field_impl(swe2d_handle *hh, int field, const double *nodal, bool per_vertex)
 {
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
@@ -669,11 +679,17 @@ int swe2d_set_field(swe2d_handle *hh, int field, const double *nodal)
         HIP_TRY(h, hipMalloc(&h->field[field], (size_t)h->npc*ncomp*h->stride*sizeof(double)));
         HIP_TRY(h, hipMemsetAsync(h->field[field], 0, (size_t)h->npc*ncomp*h->stride*sizeof(double), h->stream));
     }
-    // stage through stage_uv (2kN doubles is enough for either shape)
+    // stage through stage_uv (2kN doubles is enough for either shape; n_vertices <= kN)
     const size_t n = (size_t)h->n_cells*h->npc;
-    HIP_TRY(h, hipMemcpyAsync(h->stage_uv, nodal, (size_t)ncomp*n*sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(swe_nodal_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                       h->stage_uv, h->field[field], h->stride, h->n_cells, ncomp, h->npc);
+    if (per_vertex) {
+        HIP_TRY(h, hipMemcpyAsync(h->stage_uv, nodal, (size_t)ncomp*h->n_vertices*sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(swe_vertex_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                           h->stage_uv, h->field[field], h->stride, h->cv, h->n_cells, ncomp, h->npc);
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(h->stage_uv, nodal, (size_t)ncomp*n*sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(swe_nodal_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                           h->stage_uv, h->field[field], h->stride, h->n_cells, ncomp, h->npc);
+    }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SWE2D_OK;

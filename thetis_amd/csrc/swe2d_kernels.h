@@ -883,6 +883,18 @@ __global__ void swe_nodal_to_planes(const double *nodal, double *planes, size_t 
             planes[(size_t)(npc*c + i)*stride + k] = nodal[(size_t)ncomp*((size_t)npc*k + i) + c];
 }
 
+// continuous P1 coefficient given per VERTEX -> nodal planes (the CG -> DG injection done on the device: a time-dependent
+// wind / pressure field costs one value per vertex over PCIe instead of one per DG node plus a host-side gather)
+__global__ void swe_vertex_to_planes(const double *vert, double *planes, size_t stride, const int *cv, int n, int ncomp, int npc)
+{
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    for (int i = 0; i < npc; i++) {
+        const size_t v = (size_t)cv[(size_t)i*stride + k];
+        for (int c = 0; c < ncomp; c++) planes[(size_t)(npc*c + i)*stride + k] = vert[v*ncomp + c];
+    }
+}
+
 // Function-valued boundary data of ONE marker: copy the two end-node values of every boundary facet carrying `marker` from a
 // nodal field in host layout into the per-facet planes (plane 2f: node f, plane 2f+1: node f+1; component c: + 2*npc*c)
 __global__ void swe_bc_field_scatter(const double *nodal, double *planes, size_t stride, const int *nbr, int n, int ncomp,

@@ -345,6 +345,17 @@ class Swe2dDevice(object):
         a = np.ascontiguousarray(a)
         self._ck(self.lib.swe2d_set_field(self.h, field, _ptr(a)))
 
+    def set_field_vertex(self, field, vertex_values):
+        """A continuous P1 coefficient by its vertex values (V,) or (V, 2) in the mesh's vertex numbering; the CG -> DG
+        injection runs on the device."""
+        vec = field in (_lib.FIELD_MOMENTUM_SOURCE, _lib.FIELD_WIND_STRESS)
+        nv = self._keep[1].shape[0]
+        a = np.asarray(vertex_values, dtype=np.float64).reshape((nv, 2) if vec else (nv,))
+        if self._vperm is not None:
+            a = a[self._vperm]
+        a = np.ascontiguousarray(a)
+        self._ck(self.lib.swe2d_set_field_vertex(self.h, field, _ptr(a)))
+
     def set_scalar(self, which, value):
         self._ck(self.lib.swe2d_set_scalar(self.h, which, -1.0 if value is None else float(value)))
 

@@ -152,7 +152,7 @@ class ERKGenericShuOsher(TimeIntegrator):
             v = f.get(key)
             if isinstance(v, Function) or callable(v):
                 dev.set_scalar(sid, None)
-                dev.set_field(fid, self._nodal(v))
+                self._set_field(fid, v)
             else:
                 dev.set_field(fid, None)
                 dev.set_scalar(sid, _const_value(v))
@@ -164,7 +164,7 @@ class ERKGenericShuOsher(TimeIntegrator):
             if not changed(key):
                 continue
             v = f.get(key)
-            dev.set_field(fid, None if v is None else self._nodal(v, vector=vec))
+            self._set_field(fid, v, vector=vec)
         if changed('viscosity_h'):
             nu = f.get('viscosity_h')
             if nu is not None:                   # HorizontalViscosityTerm, shallowwater_eq.py:554-616
@@ -175,6 +175,16 @@ class ERKGenericShuOsher(TimeIntegrator):
             elif only_changed:
                 dev.set_viscosity(None)
         self._field_signatures = new
+
+    def _set_field(self, fid, v, vector=False):
+        """Upload one coefficient field; a continuous (CG-P1) Function goes as one value per vertex and is injected into the
+        DG nodes on the device (the cheap path for forcing fields that ``update_forcings`` changes every step)."""
+        if v is None:
+            self.device.set_field(fid, None)
+        elif isinstance(v, Function) and v.function_space().family == 'CG' and v.function_space().vector == vector:
+            self.device.set_field_vertex(fid, v.dat.data_ro)
+        else:
+            self.device.set_field(fid, self._nodal(v, vector=vector))
 
     @staticmethod
     def _vertex_coefficient(value):
