@@ -130,6 +130,22 @@ def test_two_ranks_overlapped_exchange_on_one_gpu(tmp_path, hip_lib, every, over
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('world,case,n_steps', [(4, 'channel+every2+overlap3+graph', 9), (3, 'channel+every4+overlap0+graph', 8)])
+def test_three_and_four_ranks_on_one_gpu(tmp_path, hip_lib, world, case, n_steps):
+    """Strips with two peers per interior rank (what an 8-GPU run looks like to a rank), per-cycle graphs, overlap."""
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = _case()
+    run_workers(gpu_worker, world, n_steps, str(tmp_path), axis=0, case=case)
+    u_p, e_p, extra = gather(str(tmp_path), world, mesh.num_cells)
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev.set_state(uv, eta)
+    dev.advance(n_steps)
+    u_s, e_s = dev.get_state()
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+    dev.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('every,n_steps', [(2, 5), (4, 4)])
 def test_two_ranks_exchange_every_m_steps_on_one_gpu(tmp_path, hip_lib, every, n_steps):
     from thetis_amd.device import Swe2dDevice
