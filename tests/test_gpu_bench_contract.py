@@ -41,3 +41,23 @@ def test_bench_prints_one_json_line_with_the_contract_fields(hip_lib, env):
         assert (d['config']['exchange_every'], d['config']['overlap_stages'], d['config']['graph_mode']) == (
             best['exchange_every'], best['overlap_stages'], best['graph_mode'])
         assert d['config']['volume_conserved'] is True
+
+
+def test_bench_two_ranks_through_torch_distributed_run(hip_lib):
+    """The driver's N > 1 invocation (python -m torch.distributed.run ... bench.py --gpus N) with two ranks sharing the GPU
+    of the test box: gloo + host staging stands in for RCCL (THETIS_AMD_DIST_BACKEND), everything else - partitioning,
+    schedule tuning with the max over ranks, graph capture, the timed region, rank 0 printing one JSON line - is the
+    code a multi-GPU node runs."""
+    e = dict(os.environ)
+    e.update({'THETIS_AMD_DIST_BACKEND': 'gloo'})
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', '29577', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '16',
+                        '--warmup', '2', '--prewarm', '0.05'],
+                       capture_output=True, text=True, env=e, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.lstrip().startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 16 and d['scaling'] == 'strong'
+    assert len(d['config']['schedule_tuning']) == 7 and d['config']['volume_conserved'] is True
+    assert 1e8 < d['value'] < 1e11

@@ -325,9 +325,17 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
     local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29511')
+    # THETIS_AMD_DIST_BACKEND=gloo: test hook - several ranks share the visible GPU(s), the exchange is staged through the
+    # host (RCCL refuses two ranks on one device); everything else of this function runs as on a multi-GPU node
+    backend = os.environ.get('THETIS_AMD_DIST_BACKEND', 'nccl')
+    host_staged = backend != 'nccl'
+    if host_staged:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend='nccl', rank=rank, world_size=world,
-                            device_id=torch.device('cuda', local_rank))
+    if host_staged:
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    else:
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     mesh, bath, uv, eta = build_case()
     n_total = mesh.num_cells
     use_graph = not os.environ.get('THETIS_AMD_NO_GRAPH')
@@ -347,7 +355,7 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
     solver, tuning = None, []
     for every_c, overlap_c, mode_c in candidates:
         cand = DistributedSwe2d(mesh, bath, dt, rank, world, local_rank, exchange_every=every_c, overlap_stages=overlap_c,
-                                graph_mode=mode_c)
+                                graph_mode=mode_c, host_staged=host_staged)
         cand.set_state_global(uv, eta)
         if len(candidates) == 1:
             solver, every, overlap = cand, every_c, overlap_c
