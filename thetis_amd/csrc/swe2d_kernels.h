@@ -517,8 +517,9 @@ __device__ __forceinline__ void swe_visc_interior(const SweStageArgs &p, int k, 
                                                   const int nb[3], const int vid[3], const double u[3], const double v[3],
                                                   const double una[3], const double unb[3], const double vna[3],
                                                   const double vnb[3], const double px[3], const double py[3],
-                                                  const double nx[3], const double ny[3], double twoA, const double Hn[3],
-                                                  double bu[3], double bv[3])
+                                                  const double nx[3], const double ny[3], const double Lf[3],
+                                                  const double rLf[3], double twoA, const double Hn[3], double bu[3],
+                                                  double bv[3])
 {
     const bool gd = p.visc_grad_div != 0;
     const int4 o4 = p.opp4[k];
@@ -588,8 +589,7 @@ __device__ __forceinline__ void swe_visc_interior(const SweStageArgs &p, int k, 
         if (nb[f] < 0) continue;
         const int a = f, bb = (f + 1) % 3;
         const double nxs = nx[f], nys = ny[f];
-        double L, rL;
-        swe_sqrt_rsqrt(nxs*nxs + nys*nys, L, rL);
+        const double L = Lf[f], rL = rLf[f];                       // facet lengths of the hyperbolic facet loop
         const double n0 = nxs*rL, n1 = nys*rL;
         const double w = 0.5*L;
         const double e1x = px[bb] - px[a], e1y = py[bb] - py[a];
@@ -770,6 +770,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     }
 
     // ---- facet integrals: 2-point Gauss-Legendre, numerical fluxes seen from this cell
+    double Lf[3] = {0.0, 0.0, 0.0}, rLf[3] = {0.0, 0.0, 0.0};     // kept for the fused viscosity only
 #pragma unroll
     for (int f = 0; f < 3; f++) {
         const int a = f, b = (f + 1) % 3;
@@ -777,6 +778,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         const double len2 = nxs*nxs + nys*nys;
         double L, rL;
         swe_sqrt_rsqrt(len2, L, rL);
+        if (VISC) { Lf[f] = L; rLf[f] = rL; }
         double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
         if (nb[f] >= 0) {
             // neighbour's nodal depth on this facet (bathymetry and alpha are continuous: same vertices)
@@ -821,7 +823,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     // optional cell-local terms AFTER the facet loop: the 18 neighbour traces are dead by now, which keeps the SRC variants
     // at 146 (162 with wetting-drying) VGPRs = 3 waves/SIMD instead of 188 (194) = 2
     if (SRC) swe_source_terms(p, k, S, twoA, u, v, H, gxs, gys, bu, bv, be);
-    if (VISC) swe_visc_interior(p, k, S8, gu, gv, nb, vid, u, v, una, unb, vna, vnb, px, py, nx, ny, twoA, H, bu, bv);
+    if (VISC) swe_visc_interior(p, k, S8, gu, gv, nb, vid, u, v, una, unb, vna, vnb, px, py, nx, ny, Lf, rLf, twoA, H, bu, bv);
 
     // ---- mass inverse (M^-1 b)_i = 3/A (4 b_i - sum b), times dt, and the Shu-Osher combine
     const double s = 6.0*p.dt*p.beta*swe_rcp(twoA);
