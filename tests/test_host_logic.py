@@ -154,3 +154,38 @@ def test_drag_parameter_combinations_raise_like_the_reference():
         eq.check_fields({'nikuradse_bed_roughness': Constant(0.05), 'quadratic_drag_coefficient': Constant(0.002)})
     with pytest.raises(Exception, match='dimensionless and Manning'):
         eq.check_fields({'manning_drag_coefficient': Constant(0.02), 'quadratic_drag_coefficient': Constant(0.002)})
+
+
+def test_vtu_export_is_readable_binary(tmp_path):
+    """The .vtu writer (XML header + raw appended blocks, UInt64 byte counts): parse it back and compare."""
+    import re
+    from thetis_amd import Function, RectangleMesh, get_functionspace
+    from thetis_amd.exporter import VTKExporter
+    mesh = RectangleMesh(5, 3, 10.0, 6.0)
+    H = get_functionspace(mesh, 'DG', 1)
+    U = get_functionspace(mesh, 'DG', 1, vector=True)
+    elev = Function(H, name='elev_2d').interpolate(lambda x, y: 0.1*x - 0.2*y)
+    uv = Function(U, name='uv_2d').interpolate(lambda x, y: (x, -y))
+    for func, name in ((elev, 'Elevation2d'), (uv, 'Velocity2d')):
+        ex = VTKExporter(func.name(), str(tmp_path), name)
+        ex.export(func, time=1.5)
+        raw = open(tmp_path/name/(name + '_0.vtu'), 'rb').read()
+        head, tail = raw.split(b'<AppendedData encoding="raw">\n_')
+        offs = [int(o) for o in re.findall(rb'offset="(\d+)"', head)]
+        assert len(offs) == 5 and b'header_type="UInt64"' in head
+
+        def block(i, dtype):
+            nbytes = int(np.frombuffer(tail, dtype='<u8', count=1, offset=offs[i])[0])
+            return np.frombuffer(tail, dtype=dtype, count=nbytes//np.dtype(dtype).itemsize, offset=offs[i] + 8)
+        pts = block(0, '<f8').reshape(-1, 3)
+        assert np.array_equal(pts[:, :2], mesh.cell_xy().reshape(-1, 2)) and not pts[:, 2].any()
+        assert np.array_equal(block(1, '<i4'), np.arange(3*mesh.num_cells))
+        assert np.array_equal(block(2, '<i4'), 3*(np.arange(mesh.num_cells) + 1)) and (block(3, 'u1') == 5).all()
+        vals = func.cell_node_values()
+        data = block(4, '<f8')
+        if vals.ndim == 3:
+            assert np.array_equal(data.reshape(-1, 3)[:, :2], vals.reshape(-1, 2))
+        else:
+            assert np.array_equal(data, vals.reshape(-1))
+        assert tail.rstrip().endswith(b'</VTKFile>')
+        assert 'timestep="1.5"' in open(tmp_path/name/(name + '.pvd')).read()

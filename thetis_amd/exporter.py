@@ -1,7 +1,7 @@
 """
 Field export and restart files around the hot path (thetis/exporter.py, thetis/solver2d.py:704-730,820-921).
 
-* ``VTKExporter``: ParaView ``.vtu`` (ASCII XML) per export + a ``.pvd`` collection, directory/file naming of the
+* ``VTKExporter``: ParaView ``.vtu`` (XML header + raw appended binary data) per export + a ``.pvd`` collection, directory/file naming of the
   reference (``<outputdir>/<Filename>/<Filename>_<ix>.vtu``, exporter.py:64-120).  DG fields are written cell by cell
   (duplicated points), i.e. exactly the discontinuous data.
 * ``CheckpointExporter``: the reference stores restart files with Firedrake's ``CheckpointFile`` (HDF5, exporter.py:123-242);
@@ -40,26 +40,39 @@ class VTKExporter(object):
         n, k = vals.shape[0], vals.shape[1]
         pts = np.concatenate([mesh.cell_xy().reshape(-1, 2), np.zeros((n*k, 1))], axis=1)
         fname = '{:s}_{:d}.vtu'.format(self.filename, self.next_export_ix)
-        with open(os.path.join(self.dir, fname), 'w') as f:
-            f.write('<?xml version="1.0"?>\n<VTKFile type="UnstructuredGrid" version="0.1" byte_order="LittleEndian">\n')
-            f.write('<UnstructuredGrid>\n<Piece NumberOfPoints="{:d}" NumberOfCells="{:d}">\n'.format(n*k, n))
-            f.write('<Points>\n<DataArray type="Float64" NumberOfComponents="3" format="ascii">\n')
-            np.savetxt(f, pts, fmt='%.17g')
-            f.write('</DataArray>\n</Points>\n<Cells>\n<DataArray type="Int32" Name="connectivity" format="ascii">\n')
-            np.savetxt(f, np.arange(n*k).reshape(n, k), fmt='%d')
-            f.write('</DataArray>\n<DataArray type="Int32" Name="offsets" format="ascii">\n')
-            np.savetxt(f, (np.arange(n) + 1)*k, fmt='%d')
-            f.write('</DataArray>\n<DataArray type="UInt8" Name="types" format="ascii">\n')
-            np.savetxt(f, np.full(n, 5 if k == 3 else 9), fmt='%d')
-            f.write('</DataArray>\n</Cells>\n')
-            if vals.ndim == 3:
-                data = np.concatenate([vals.reshape(-1, 2), np.zeros((n*k, 1))], axis=1)
-                f.write('<PointData Vectors="{0}">\n<DataArray type="Float64" Name="{0}" NumberOfComponents="3" format="ascii">\n'.format(self.func_name))
-            else:
-                data = vals.reshape(-1, 1)
-                f.write('<PointData Scalars="{0}">\n<DataArray type="Float64" Name="{0}" format="ascii">\n'.format(self.func_name))
-            np.savetxt(f, data, fmt='%.17g')
-            f.write('</DataArray>\n</PointData>\n</Piece>\n</UnstructuredGrid>\n</VTKFile>\n')
+        if vals.ndim == 3:
+            data = np.concatenate([vals.reshape(-1, 2), np.zeros((n*k, 1))], axis=1)
+            point_data = ('<PointData Vectors="{0}">\n<DataArray type="Float64" Name="{0}" NumberOfComponents="3" '
+                          'format="appended" offset="{1}"/>\n')
+        else:
+            data = vals.reshape(-1, 1)
+            point_data = '<PointData Scalars="{0}">\n<DataArray type="Float64" Name="{0}" format="appended" offset="{1}"/>\n'
+        # raw appended binary blocks (UInt64 byte count + little-endian data): ParaView / VTK read them natively and a
+        # million-cell export takes a fraction of a second instead of the tens of seconds of ASCII
+        blocks = [np.ascontiguousarray(pts, dtype='<f8'),
+                  np.ascontiguousarray(np.arange(n*k), dtype='<i4'),
+                  np.ascontiguousarray((np.arange(n) + 1)*k, dtype='<i4'),
+                  np.full(n, 5 if k == 3 else 9, dtype='u1'),
+                  np.ascontiguousarray(data, dtype='<f8')]
+        offsets, off = [], 0
+        for blk in blocks:
+            offsets.append(off)
+            off += 8 + blk.nbytes
+        with open(os.path.join(self.dir, fname), 'wb') as f:
+            w = lambda text: f.write(text.encode('ascii'))
+            w('<?xml version="1.0"?>\n<VTKFile type="UnstructuredGrid" version="1.0" byte_order="LittleEndian" '
+              'header_type="UInt64">\n')
+            w('<UnstructuredGrid>\n<Piece NumberOfPoints="{:d}" NumberOfCells="{:d}">\n'.format(n*k, n))
+            w('<Points>\n<DataArray type="Float64" NumberOfComponents="3" format="appended" offset="{:d}"/>\n</Points>\n'.format(offsets[0]))
+            w('<Cells>\n<DataArray type="Int32" Name="connectivity" format="appended" offset="{:d}"/>\n'.format(offsets[1]))
+            w('<DataArray type="Int32" Name="offsets" format="appended" offset="{:d}"/>\n'.format(offsets[2]))
+            w('<DataArray type="UInt8" Name="types" format="appended" offset="{:d}"/>\n</Cells>\n'.format(offsets[3]))
+            w(point_data.format(self.func_name, offsets[4]))
+            w('</PointData>\n</Piece>\n</UnstructuredGrid>\n<AppendedData encoding="raw">\n_')
+            for blk in blocks:
+                f.write(np.array([blk.nbytes], dtype='<u8').tobytes())
+                f.write(blk.tobytes())
+            w('\n</AppendedData>\n</VTKFile>\n')
         self.entries.append((self.next_export_ix if time is None else time, fname))
         with open(os.path.join(self.dir, self.filename + '.pvd'), 'w') as f:
             f.write('<?xml version="1.0"?>\n<VTKFile type="Collection" version="0.1">\n<Collection>\n')
