@@ -103,7 +103,7 @@ def _random_config(rng, mesh, quad):
     return o, dev_ops, bcs, wd
 
 
-@pytest.mark.parametrize('seed', range(96))
+@pytest.mark.parametrize('seed', range(192))
 def test_random_option_combinations_match_oracle(hip_lib, seed):
     from thetis_amd.device import Swe2dDevice
     rng = np.random.default_rng(1000 + seed)
@@ -144,7 +144,7 @@ def test_random_option_combinations_match_oracle(hip_lib, seed):
     dev.close()
 
 
-@pytest.mark.parametrize('seed', range(60))
+@pytest.mark.parametrize('seed', range(120))
 def test_random_tracer_option_combinations_match_oracle(hip_lib, seed):
     """The tracer stage (+ SIPG pass): conservative / non-conservative, Lax-Friedrichs, velocity factor, source, diffusivity
     (constant or field), boundary dicts with constant / Function values, velocity keys and prescribed diffusive fluxes."""
