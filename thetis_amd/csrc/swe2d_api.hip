@@ -36,6 +36,11 @@ struct Handle {
     size_t stride = 0;
     double *state[3] = {nullptr, nullptr, nullptr};   // A (U0 / step result), B (U1), C (U2)
     int *nbr = nullptr, *cv = nullptr;
+    // compact boundary uploads (swe2d_set_bc_facets): the (cell, facet) lists of the last calls stay on the device, a repeated
+    // call with the same lists (update_forcings at every stage) only uploads the values
+    struct FacetList { std::vector<int32_t> cells, facets; int *dev = nullptr; };
+    FacetList facet_lists[8];
+    int facet_list_next = 0;
     int4 *opp4 = nullptr;                               // triangles: opposite vertices of the neighbours (fused viscosity)
     int *bnd_cells = nullptr;                           // cells with a boundary facet (boundary-only SIPG launch)
     int n_bnd = 0;
@@ -490,6 +495,7 @@ void swe2d_destroy(swe2d_handle *hh)
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
                     h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->my_stream) (void)hipStreamDestroy(h->my_stream);
@@ -590,22 +596,39 @@ int swe2d_set_bc_field(swe2d_handle *hh, int which, int marker, const double *no
 }
 
 // shared by swe2d_set_bc_facets / swe2d_tracer_set_bc_facets: upload the compact lists and scatter them into `planes`
-static int scatter_facet_values(Handle *h, double *planes, int n, const int32_t *cells, const int32_t *facets, const double *values,
-                                int ncomp, int nval)
+static int scatter_facet_values(Handle *h, double *planes, int n, const int32_t *cells, const int32_t *facets,
+                                const double *values, int ncomp, int nval)
 {
     if (n == 0) return SWE2D_OK;
     const size_t nv = (size_t)n*nval*ncomp;
-    if (nv*sizeof(double) + 2*(size_t)n*sizeof(int) > (size_t)2*h->npc*h->n_cells*sizeof(double))
+    if (nv*sizeof(double) > (size_t)2*h->npc*h->n_cells*sizeof(double))
         return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "more boundary facets than the staging buffer holds");
-    for (int t = 0; t < n; t++)
-        if (cells[t] < 0 || cells[t] >= h->n_cells || facets[t] < 0 || facets[t] >= h->npc)
-            return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "boundary facet list: cell or facet index out of range");
-    // staging: values, then the two index lists, in the uv staging buffer (2*npc*n_cells doubles)
-    double *dv = h->stage_uv;
-    int *dc = reinterpret_cast<int *>(dv + nv), *df = dc + n;
+    // a small cache of the lists seen last (one per marker and field in practice), matched by content
+    int slot = -1;
+    for (int i = 0; i < 8 && slot < 0; i++) {
+        const Handle::FacetList &c = h->facet_lists[i];
+        if ((int)c.cells.size() == n && std::memcmp(c.cells.data(), cells, (size_t)n*sizeof(int32_t)) == 0
+            && std::memcmp(c.facets.data(), facets, (size_t)n*sizeof(int32_t)) == 0)
+            slot = i;
+    }
+    const bool same = slot >= 0;
+    if (!same) slot = (h->facet_list_next++) & 7;
+    Handle::FacetList &fl = h->facet_lists[slot];
+    if (!same) {
+        for (int t = 0; t < n; t++)
+            if (cells[t] < 0 || cells[t] >= h->n_cells || facets[t] < 0 || facets[t] >= h->npc)
+                return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "boundary facet list: cell or facet index out of range");
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (fl.dev) { HIP_TRY(h, hipFree(fl.dev)); fl.dev = nullptr; }
+        HIP_TRY(h, hipMalloc(&fl.dev, 2*(size_t)n*sizeof(int)));
+        HIP_TRY(h, hipMemcpy(fl.dev, cells, (size_t)n*sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(fl.dev + n, facets, (size_t)n*sizeof(int), hipMemcpyHostToDevice));
+        fl.cells.assign(cells, cells + n);
+        fl.facets.assign(facets, facets + n);
+    }
+    double *dv = h->stage_uv;                           // values staged in the uv staging buffer (2*npc*n_cells doubles)
+    const int *dc = fl.dev, *df = fl.dev + n;
     HIP_TRY(h, hipMemcpyAsync(dv, values, nv*sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(dc, cells, (size_t)n*sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(df, facets, (size_t)n*sizeof(int), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(swe_bc_facet_scatter, dim3(grid_for(n)), dim3(256), 0, h->stream, dv, planes, h->stride, dc, df, n, ncomp,
                        h->npc, nval);
     HIP_TRY(h, hipGetLastError());

@@ -304,7 +304,12 @@ class Swe2dDevice(object):
         return cache[slot]
 
     def _device_cells(self, cells):
-        return np.ascontiguousarray((cells if self.perm is None else self.inv_perm[cells]).astype(np.int32))
+        """caller cell ids -> device cell ids (cached per list object: boundary_facets hands out the same arrays)"""
+        cache = self.__dict__.setdefault('_device_cell_lists', {})
+        key = id(cells)
+        if key not in cache:
+            cache[key] = (cells, np.ascontiguousarray((cells if self.perm is None else self.inv_perm[cells]).astype(np.int32)))
+        return cache[key][1]
 
     def set_bc_facets(self, which, slot, values):
         """Function-valued boundary data of one marker slot in compact form: ``values`` (n_facets, 2) [(n_facets, 2, 2) for
