@@ -17,6 +17,7 @@ FIELD_CORIOLIS, FIELD_ATMOSPHERIC_PRESSURE, FIELD_MOMENTUM_SOURCE, FIELD_VOLUME_
 FIELD_LINEAR_DRAG, FIELD_QUADRATIC_DRAG, FIELD_MANNING_DRAG, FIELD_NIKURADSE = 5, 6, 7, 8
 SCALAR_LINEAR_DRAG, SCALAR_QUADRATIC_DRAG, SCALAR_MANNING_DRAG, SCALAR_NORM_SMOOTHER, SCALAR_NIKURADSE = 0, 1, 2, 3, 4
 
+ABI_VERSION = 4          # include/swe2d.h SWE2D_ABI_VERSION
 OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NOT_FINITE = 0, -1, -2, -3, -4, -5
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -130,6 +131,10 @@ def load():
             raise
         fn.restype = restype
         fn.argtypes = argtypes
+    if not os.environ.get('THETIS_AMD_LIB') and lib.swe2d_abi_version() != ABI_VERSION:
+        raise ImportError('{:} implements ABI version {:d}, this package binds version {:d}: rebuild it '
+                          '(python -c "import __graft_entry__ as g; g.build()")'.format(LIB_PATH, lib.swe2d_abi_version(),
+                                                                                          ABI_VERSION))
     _lib = lib
     return lib
 
