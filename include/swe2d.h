@@ -277,6 +277,11 @@ int  swe2d_halo_pack(swe2d_handle *h, int i_buffer, double *send_buf_dev);
 int  swe2d_halo_unpack(swe2d_handle *h, int i_buffer, const double *recv_buf_dev);
 /* ERKGenericShuOsher.solve_stage restricted to cells [cell_begin, cell_end) (may include ghost layers) */
 int  swe2d_solve_stage_cells(swe2d_handle *h, int i_stage, int32_t cell_begin, int32_t cell_end);
+/* ForwardEuler (timeintegrator.py:115-165) on a partition: the step from state buffer 0 into buffer 1 on a cell range;
+ * after the last range of a step swe2d_swap_state_buffers makes buffer 1 the state (halo pack / unpack take the buffer
+ * index).  Not capturable in a replayed graph across an odd number of swaps. */
+int  swe2d_forward_euler_cells(swe2d_handle *h, int32_t cell_begin, int32_t cell_end);
+int  swe2d_swap_state_buffers(swe2d_handle *h);
 /* run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the handle's own */
 int  swe2d_set_stream(swe2d_handle *h, void *hip_stream);
 

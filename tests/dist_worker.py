@@ -51,6 +51,8 @@ def cpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     Mirrors DistributedSwe2d._steps_eager / _cycle_swe launch by launch on three rotating buffers; everything a launch
     must not read is NaN: stale ghost layers, ghosts between pack and unpack, cells a stage has not written yet."""
     global CASE
+    fe = case.endswith('+fe')              # ForwardEuler: one stage and one ghost layer per step
+    case = case.replace('+fe', '')
     case, every, overlap = _split_every(case)
     CASE = case
     import torch
@@ -64,7 +66,7 @@ def cpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
         owner = rcb_owner(mesh, world)
     else:
         owner = strip_owner(mesh, world, axis=axis)
-    part = build_partition(mesh, owner, rank, halo_depth=3*every)
+    part = build_partition(mesh, owner, rank, halo_depth=(every if fe else 3*every))
     ref = RefSWE(part.cell_xy(), part.cell_nbr, part.cell_nbr_facet, bath[part.vertex_global][part.cells],
                  boundary_len=part.boundary_len)
     g = part.local_to_global
@@ -103,6 +105,25 @@ def cpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
 
     cycles = [every]*(n_steps//every) + ([n_steps % every] if n_steps % every else [])
     early = 0
+    if fe:
+        # DistributedSwe2d._cycle_forward_euler: the step goes from buffer 0 into buffer 1, then the buffers trade places
+        def swap():
+            U[0], U[1] = U[1], U[0]
+            E[0], E[1] = E[1], E[0]
+        for r in cycles:
+            for gs in range(r - 1):
+                stage(0, 0, part.stage_range(gs, depth=r))
+                swap()
+            stage(0, part.n_interior, no, keep_rest=True)
+            sc = part.send_cells
+            packed = np.concatenate([U[1][sc, :, 0], U[1][sc, :, 1], E[1][sc]], axis=1)
+            halo.send_buf[:packed.size] = torch.from_numpy(packed.reshape(-1))
+            reqs = halo.start()
+            stage(0, 0, part.n_interior, keep_rest=True)
+            swap()
+            U[0][no:], E[0][no:] = np.nan, np.nan
+            finish_exchange(reqs)
+        cycles = []
     for ic, r in enumerate(cycles):
         nxt = min(overlap, 3*cycles[ic + 1] - 1) if ic + 1 < len(cycles) else 0
         n = 3*r
@@ -246,6 +267,8 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     global CASE
     graphed = case.endswith('+graph')      # per-cycle HIP graphs around the (eager, host-staged) exchange
     case = case.replace('+graph', '')
+    fe = case.endswith('+fe')
+    case = case.replace('+fe', '')
     case, every, overlap = _split_every(case)
     viscous = case.endswith('+visc')
     case = case.replace('+visc', '')
@@ -257,7 +280,7 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     mesh, bath, uv, eta = _case()
     owner = strip_owner(mesh, world, axis=axis)
     solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, host_staged=True, exchange_every=every,
-                              overlap_stages=overlap)
+                              overlap_stages=overlap, stepper=('ForwardEuler' if fe else 'SSPRK33'))
     if viscous:     # SIPG pass on the partition: same cell ranges as the stage kernels, per-vertex viscosity of the local vertices
         solver.dev.set_viscosity(viscosity_field(mesh)[solver.part.vertex_global], use_grad_div_viscosity_term=True)
     solver.set_state_global(uv, eta)

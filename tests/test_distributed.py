@@ -82,6 +82,35 @@ def test_gloo_overlapped_exchange_equals_global(tmp_path, ref_so, world, axis, e
     assert np.array_equal(u_p, u_g) and np.array_equal(e_p, e_g)
 
 
+@pytest.mark.parametrize('world,axis,every,n_steps', [(2, 0, 1, 4), (3, 1, 3, 7), (2, 1, 4, 9)])
+def test_gloo_forward_euler_on_partitions_equals_global(tmp_path, ref_so, world, axis, every, n_steps):
+    """ForwardEuler (timeintegrator.py:115-165) on partitions: one ghost layer per step, one exchange per m steps."""
+    mesh, bath, uv, eta = _case()
+    run_workers(cpu_worker, world, n_steps, str(tmp_path), axis=axis, case='channel+every{:d}+fe'.format(every))
+    u_p, e_p, extra = gather(str(tmp_path), world, mesh.num_cells)
+    ref = make_ref(mesh, bath)
+    u_g, e_g = uv.copy(), eta.copy()
+    for _ in range(n_steps):
+        ku, ke = ref.tendency(u_g, e_g, 2.0)
+        u_g, e_g = u_g + ku, e_g + ke
+    assert np.array_equal(u_p, u_g) and np.array_equal(e_p, e_g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('every,n_steps', [(1, 3), (3, 7)])
+def test_two_ranks_forward_euler_on_one_gpu(tmp_path, hip_lib, every, n_steps):
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = _case()
+    run_workers(gpu_worker, 2, n_steps, str(tmp_path), axis=0, case='channel+every{:d}+fe'.format(every))
+    u_p, e_p, extra = gather(str(tmp_path), 2, mesh.num_cells)
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev.set_state(uv, eta)
+    dev.advance_forward_euler(n_steps)
+    u_s, e_s = dev.get_state()
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+    dev.close()
+
+
 def test_owned_cells_are_sorted_by_distance_from_the_cut():
     from thetis_amd.partition import build_partition, rcb_owner
     mesh, bath, uv, eta = _case()

@@ -95,6 +95,8 @@ SYMBOLS = {
     'swe2d_halo_pack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_void_p]),
     'swe2d_halo_unpack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_void_p]),
     'swe2d_solve_stage_cells': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int32, ctypes.c_int32]),
+    'swe2d_forward_euler_cells': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
+    'swe2d_swap_state_buffers': (ctypes.c_int, [_H]),
     'swe2d_set_stream': (ctypes.c_int, [_H, ctypes.c_void_p]),
 }
 

@@ -850,6 +850,26 @@ int swe2d_advance_forward_euler(swe2d_handle *hh, int n_steps)
     return SWE2D_OK;
 }
 
+// ForwardEuler on cell ranges (partitions): U_new = U + dt M^-1 R(U) from buffer 0 into buffer 1 on [cell_begin, cell_end);
+// when every range of the step is launched, swe2d_swap_state_buffers makes buffer 1 the current state.
+int swe2d_forward_euler_cells(swe2d_handle *hh, int32_t cell_begin, int32_t cell_end)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (cell_begin < 0 || cell_end > h->n_cells || cell_begin > cell_end)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return launch_stage(h, 0, 0, 1, 0.0, 1.0, 1.0, cell_begin, cell_end);
+}
+
+int swe2d_swap_state_buffers(swe2d_handle *hh)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    std::swap(h->state[0], h->state[1]);
+    return SWE2D_OK;
+}
+
 int swe2d_advance_timed(swe2d_handle *hh, int n_steps, int per_launch, float *ms_total, float *ms_kernel_avg)
 {
     Handle *h = H(hh);

@@ -382,6 +382,13 @@ class Swe2dDevice(object):
         """Stage ``i_stage`` on device cells [cell_begin, cell_end) (partitions: may include ghost layers)."""
         self._ck(self.lib.swe2d_solve_stage_cells(self.h, int(i_stage), int(cell_begin), int(cell_end)))
 
+    def forward_euler_cells(self, cell_begin, cell_end):
+        """ForwardEuler step of device cells [cell_begin, cell_end) from state buffer 0 into buffer 1 (partitions)."""
+        self._ck(self.lib.swe2d_forward_euler_cells(self.h, int(cell_begin), int(cell_end)))
+
+    def swap_state_buffers(self):
+        self._ck(self.lib.swe2d_swap_state_buffers(self.h))
+
     def advance_timed(self, n_steps, per_launch=False):
         """Returns (total ms, mean ms per stage-kernel launch), measured with HIP events on the launch stream."""
         tot = ctypes.c_float()

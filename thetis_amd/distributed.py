@@ -71,7 +71,7 @@ class DistributedSwe2d(object):
 
     def __init__(self, mesh, bathymetry_vertex, dt, rank, world_size, device_id, owner=None, host_staged=False,
                  n_tracers=0, use_limiter=True, tracer_only=False, exchange_every=1, overlap_stages=0,
-                 graph_mode=None, **opts):
+                 graph_mode=None, stepper='SSPRK33', **opts):
         """``n_tracers`` > 0: the coupled step of GeneralCoupledTimeIntegrator2D.advance (coupled_timeintegrator_2d.py:
         93-113) on the partition - shallow water step, then every tracer with the updated velocity, then the limiter.
         The vertex-based limiter needs every cell around a vertex, so coupled runs with the limiter use four ghost layers
@@ -98,13 +98,21 @@ class DistributedSwe2d(object):
         owner = strip_owner(mesh, world_size) if owner is None else owner
         self.use_limiter = bool(use_limiter) and n_tracers > 0
         self.tracer_only = bool(tracer_only)
+        if stepper not in ('SSPRK33', 'ForwardEuler'):
+            raise ValueError("stepper must be 'SSPRK33' or 'ForwardEuler'")
+        # ForwardEuler (the other explicit entry of the steppers table): one stage per step, one ghost layer per step
+        self.stages_per_step = 3 if stepper == 'SSPRK33' else 1
+        if self.stages_per_step == 1 and (n_tracers > 0 or int(overlap_stages) > 0):
+            raise ValueError('ForwardEuler on partitions: shallow water only, no overlap_stages')
         self.exchange_every = m = int(exchange_every)
         self.overlap_stages = int(overlap_stages)
         if m < 1 or ((m > 1 or self.overlap_stages > 0) and n_tracers > 0):
             raise ValueError('exchange_every > 1 and overlap_stages are implemented for shallow-water-only runs')
         if not 0 <= self.overlap_stages <= 3*m - 1:
             raise ValueError('overlap_stages must be in 0 .. 3*exchange_every - 1')
-        if m > 1:
+        if self.stages_per_step == 1:
+            self.part = build_partition(mesh, owner, rank, halo_depth=m)
+        elif m > 1:
             self.part = build_partition(mesh, owner, rank, halo_depth=3*m)
         elif self.use_limiter:
             self.part = build_partition(mesh, owner, rank, halo_depth=4, adjacency='vertex')
@@ -126,6 +134,8 @@ class DistributedSwe2d(object):
         # eagerly in between (nothing of RCCL inside a capture); 'full': the whole K-step loop incl. the RCCL calls in ONE
         # graph (fewest launches; needs RCCL point-to-point capture to work on the node); 'none': eager launches
         self.graph_mode = graph_mode or os.environ.get('THETIS_AMD_GRAPH_MODE', 'cycle')
+        if self.stages_per_step == 1:
+            self.graph_mode = 'none'        # the step swaps the state buffers: kernel arguments change from replay to replay
         if self.graph_mode not in ('cycle', 'full', 'none'):
             raise ValueError("graph_mode / THETIS_AMD_GRAPH_MODE must be 'cycle', 'full' or 'none'")
         self._cycle_graphs = {}
@@ -188,11 +198,27 @@ class DistributedSwe2d(object):
         ``early_done``: stages of this cycle whose ghost-independent part ran during the previous exchange;
         ``early_next``: stages of the next cycle to run (ghost-independent part only) during this cycle's exchange."""
         halo = self.halo
+        if self.stages_per_step == 1:
+            return self._cycle_forward_euler(n_steps)
         self._launch(('A', n_steps, early_done), lambda: self._cycle_before_exchange(n_steps, early_done), graphed)
         reqs = halo.start()
         self._launch(('B', early_next), lambda: self._cycle_during_exchange(early_next), graphed)
         halo.finish(reqs)
         self.dev.halo_unpack(0, halo.recv_buf.data_ptr())
+
+    def _cycle_forward_euler(self, n_steps):
+        """``n_steps`` ForwardEuler steps on shrinking ranges (one ghost layer per step), then one exchange."""
+        dev, halo, p = self.dev, self.halo, self.part
+        for g in range(n_steps - 1):
+            dev.forward_euler_cells(0, p.stage_range(g, depth=n_steps))
+            dev.swap_state_buffers()
+        dev.forward_euler_cells(p.n_interior, p.n_owned)            # the cells the peers are waiting for (into buffer 1)
+        dev.halo_pack(1, halo.send_buf.data_ptr())
+        reqs = halo.start()
+        dev.forward_euler_cells(0, p.n_interior)
+        dev.swap_state_buffers()
+        halo.finish(reqs)
+        dev.halo_unpack(0, halo.recv_buf.data_ptr())
 
     def _cycle_before_exchange(self, n_steps, early_done):
         dev, p = self.dev, self.part
