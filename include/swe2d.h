@@ -216,7 +216,9 @@ int  swe2d_tracer_get_state(swe2d_handle *h, int tracer_id, double *nodal);
  * c (u.n) phi (tracer_eq_2d.py:177-191).  Velocity-type keys: swe2d_tracer_set_bc_velocity. */
 int  swe2d_tracer_set_bc(swe2d_handle *h, int tracer_id, int marker, int has_value, double value);
 /* external velocity of the tracer's boundary dict on `marker` (tracer_eq_2d.py:70-110): kind 0 = none (uv_ext = uv_in),
- * 1 = 'uv': (u, v), multiplied by tracer_advective_velocity_factor, 2 = 'un': normal velocity u (v unused) */
+ * 1 = 'uv': (u, v), multiplied by tracer_advective_velocity_factor, 2 = 'un': normal velocity u (v unused),
+ * 3 = 'flux': volume flux u out of the domain, uv_ext = factor * u / (H(elev_in) * boundary_len) n,
+ * 4 = 'flux' with a constant 'elev' in the dict: the same with H(v) */
 int  swe2d_tracer_set_bc_velocity(swe2d_handle *h, int tracer_id, int marker, int kind, double u, double v);
 /* Function-valued 'value' on `marker`: nodal DG values of the whole mesh in the host layout (kN); only cells with a
  * boundary facet carrying `marker` are copied (all their nodes: the diffusive boundary term uses the cell gradient) */

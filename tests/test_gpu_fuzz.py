@@ -183,7 +183,7 @@ def test_random_tracer_option_combinations_match_oracle(hip_lib, seed):
         dev.tracer_set_diffusivity(tid, mu, sipg)
     bcs = {}
     for marker in (1, 2, 3, 4):
-        r = rng.integers(0, 7)
+        r = rng.integers(0, 9)
         funcs = None
         if r == 1:
             funcs = {'value': float(rng.normal())}
@@ -197,6 +197,10 @@ def test_random_tracer_option_combinations_match_oracle(hip_lib, seed):
             funcs = {'diff_flux': float(0.05*rng.normal())}
         elif r == 6:
             funcs = {'elev': 0.1}
+        elif r == 7:                    # 'flux' (volume flux out of the domain) with the interior elevation
+            funcs = {'value': float(rng.normal()), 'flux': float(2e3*rng.normal())}
+        elif r == 8:                    # 'flux' with an external elevation
+            funcs = {'flux': float(2e3*rng.normal()), 'elev': float(0.2*rng.normal())}
         if funcs is None:
             continue
         bcs[marker] = funcs
@@ -205,6 +209,8 @@ def test_random_tracer_option_combinations_match_oracle(hip_lib, seed):
             dev.tracer_set_bc(tid, marker, v)
         if 'uv' in funcs:
             dev.tracer_set_bc_velocity(tid, marker, uv=funcs['uv'])
+        elif 'flux' in funcs:
+            dev.tracer_set_bc_velocity(tid, marker, flux=funcs['flux'], elev=funcs.get('elev'))
         elif 'un' in funcs:
             dev.tracer_set_bc_velocity(tid, marker, un=funcs['un'])
         if diff:

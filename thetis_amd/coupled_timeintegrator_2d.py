@@ -98,9 +98,13 @@ class DeviceTracerSSPRK33(object):
                 self.device.tracer_set_bc(self.tid, marker, _cval(v))
             uv_b = None if funcs is None else funcs.get('uv')
             un_b = None if funcs is None else funcs.get('un')
+            fl_b = None if funcs is None else funcs.get('flux')
+            el_b = None if funcs is None else funcs.get('elev')
             self.device.tracer_set_bc_velocity(self.tid, marker,
                                                uv=None if uv_b is None else _vec(uv_b),
-                                               un=None if un_b is None or uv_b is not None else _cval(un_b))
+                                               un=None if un_b is None else _cval(un_b),
+                                               flux=None if fl_b is None else _cval(fl_b),
+                                               elev=None if el_b is None else _cval(el_b))
             if self.diffusive:                  # boundary term of the diffusion operator, tracer_eq_2d.py:264-277
                 if funcs is None:
                     kind, dfl = 0, 0.0

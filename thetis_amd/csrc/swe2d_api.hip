@@ -1087,6 +1087,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_has_value[m] = t.bc_has_value[m]; a.bc_value[m] = t.bc_value[m]; }
     a.bc_value_f = t.bc_value_f;
     for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_vel_kind[m] = t.bc_vel_kind[m]; a.bc_u[m] = t.bc_u[m]; a.bc_v[m] = t.bc_v[m]; }
+    for (int m = 0; m < SWE_MAX_MARKERS; m++) a.bc_len[m] = h->bc.len[m];
     // triangles: cell integral and interior facets of the diffusion inside the stage kernel, boundary facets by a launch
     // over the boundary cells (only when a marker has a diffusive boundary term at all)
     const bool fused_diff = t.diff && h->fuse_visc && h->npc == 3 && h->opp4;
@@ -1116,6 +1117,8 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
         for (int m = 0; m < SWE_MAX_MARKERS; m++) { v.bc_diff_kind[m] = t.bc_diff_kind[m]; v.bc_diff_flux[m] = t.bc_diff_flux[m]; }
         v.bc_value_f = t.bc_value_f;
         for (int m = 0; m < SWE_MAX_MARKERS; m++) { v.bc_vel_kind[m] = t.bc_vel_kind[m]; v.bc_u[m] = t.bc_u[m]; v.bc_v[m] = t.bc_v[m]; }
+        v.bc = h->bc;                                   // boundary lengths ('flux' key)
+        v.depth_mode = a.depth_mode; v.valpha = h->valpha;
         if (fused_diff) {
             bool any = false;
             for (int m = 0; m < SWE_MAX_MARKERS; m++) any = any || t.bc_diff_kind[m] != SWE_SIPG_BC_NONE;
@@ -1307,7 +1310,8 @@ int swe2d_tracer_set_bc_velocity(swe2d_handle *hh, int id, int marker, int kind,
     int rc = check_tracer(h, id);
     if (rc) return rc;
     if (marker <= 0 || marker >= SWE2D_MAX_MARKERS) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "marker out of range");
-    if (kind < 0 || kind > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "velocity kind must be 0 (none), 1 ('uv') or 2 ('un')");
+    if (kind < 0 || kind > 4)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "velocity kind must be 0 (none), 1 ('uv'), 2 ('un'), 3 ('flux') or 4 ('flux' + 'elev')");
     h->tracers[id].bc_vel_kind[marker] = kind;
     h->tracers[id].bc_u[marker] = u;
     h->tracers[id].bc_v[marker] = v;

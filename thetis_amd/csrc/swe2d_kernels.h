@@ -1034,18 +1034,37 @@ struct SweTracerArgs {
     int bc_has_value[SWE_MAX_MARKERS];   // 0: no 'value', 1: constant, 2: Function (bc_value_f)
     double bc_value[SWE_MAX_MARKERS];
     const double *bc_value_f;            // k*k planes: plane k*f + i = node i of the cell for its boundary facet f, or null
-    int bc_vel_kind[SWE_MAX_MARKERS];    // external velocity of the boundary dict: 0 = uv_in, 1 = 'uv' (times vel_factor), 2 = 'un'*n
+    int bc_vel_kind[SWE_MAX_MARKERS];    // external velocity of the boundary dict: 0 = uv_in, 1 = 'uv' (times vel_factor), 2 = 'un'*n,
+                                         // 3 = 'flux' (bc_u) with elev_in, 4 = 'flux' with the constant 'elev' in bc_v
+    double bc_len[SWE_MAX_MARKERS];      // boundary lengths (the 'flux' key divides by H_ext * length)
     double bc_u[SWE_MAX_MARKERS], bc_v[SWE_MAX_MARKERS];      // 'uv' components, or 'un' in bc_u
 };
 
 // boundary facet of the tracer stage kernels (tracer_eq_2d.py:177-191 and :380-393): upwind value / flux with the external
 // state of get_bnd_functions (:70-110).  nxs, nys: normal scaled by the facet length; returns the form value times |F|.
+// |uv_ext| of the tracers' 'flux' boundary key (tracer_eq_2d.py:105-109): corr_factor*flux/(H_ext*boundary_len), H_ext the total
+// depth at the external elevation (the constant 'elev' of the dict, else the interior one)
+__device__ __forceinline__ double swe_tracer_flux_speed(int depth_mode, double hq, double eq, double alq, int elev_given,
+                                                        double elev_ext, double flux, double len, double vel_factor)
+{
+    const double ee = elev_given ? elev_ext : eq;
+    const double Hx = depth_mode == 2 ? swe_wd_depth(hq + ee, alq) : (depth_mode == 1 ? hq + ee : hq);
+    return vel_factor*flux/(Hx*len);
+}
+
 __device__ __forceinline__ double swe_tracer_boundary_flux(const SweTracerArgs &p, int marker, double cq, double cext,
-                                                           double uq, double vq, double nxs, double nys)
+                                                           double uq, double vq, double nxs, double nys, double hq = 0.0,
+                                                           double eq = 0.0, double alq = 0.0)
 {
     double ue = uq, ve = vq;
     const int vk = p.bc_vel_kind[marker];
-    if (vk == 1) {
+    if (vk >= 3) {
+        const double rl = 1.0/sqrt(nxs*nxs + nys*nys);
+        const double sp = swe_tracer_flux_speed(p.depth_mode, hq, eq, alq, vk == 4, p.bc_v[marker], p.bc_u[marker],
+                                                p.bc_len[marker], p.vel_factor);
+        ue = sp*nxs*rl;
+        ve = sp*nys*rl;
+    } else if (vk == 1) {
         ue = p.vel_factor*p.bc_u[marker];
         ve = p.vel_factor*p.bc_v[marker];
     } else if (vk == 2) {
@@ -1261,7 +1280,15 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
                     const double cext = (p.bc_has_value[marker] == 2)
                         ? xa*p.bc_value_f[(size_t)(3*f + a)*S + k] + xb*p.bc_value_f[(size_t)(3*f + bb)*S + k]
                         : (p.bc_has_value[marker] ? p.bc_value[marker] : cq);
-                    fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys);
+                    double hq = 0.0, eq = 0.0, alq = 0.0;
+                    if (p.bc_vel_kind[marker] >= 3) {                  // 'flux': total depth at the quadrature point
+                        const unsigned va8 = (unsigned)vid[a]*8u, vb8 = (unsigned)vid[bb]*8u;
+                        hq = xa*swe_ld(swe_rsrc(p.vh), va8, 0) + xb*swe_ld(swe_rsrc(p.vh), vb8, 0);
+                        if (p.depth_mode == 2) alq = xa*swe_ld(swe_rsrc(p.valpha), va8, 0) + xb*swe_ld(swe_rsrc(p.valpha), vb8, 0);
+                        const swe_rsrc_t ge = swe_rsrc(p.uv + 6*S);
+                        eq = xa*swe_ld(ge, k8, a*S8) + xb*swe_ld(ge, k8, bb*S8);
+                    }
+                    fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys, hq, eq, alq);
                 } else {
                     fq = cq*unown;                                                         // :189-191
                 }
@@ -1822,7 +1849,15 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
                     const double cext = (p.bc_has_value[marker] == 2)
                         ? xa*p.bc_value_f[(size_t)(4*f + a)*S + k] + xb*p.bc_value_f[(size_t)(4*f + bb)*S + k]
                         : (p.bc_has_value[marker] ? p.bc_value[marker] : cq);
-                    fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys);
+                    double hq = 0.0, eq = 0.0, alq = 0.0;
+                    if (p.bc_vel_kind[marker] >= 3) {                  // 'flux': total depth at the quadrature point
+                        const unsigned va8 = (unsigned)vid[a]*8u, vb8 = (unsigned)vid[bb]*8u;
+                        hq = xa*swe_ld(swe_rsrc(p.vh), va8, 0) + xb*swe_ld(swe_rsrc(p.vh), vb8, 0);
+                        if (p.depth_mode == 2) alq = xa*swe_ld(swe_rsrc(p.valpha), va8, 0) + xb*swe_ld(swe_rsrc(p.valpha), vb8, 0);
+                        const swe_rsrc_t ge = swe_rsrc(p.uv + 8*S);
+                        eq = xa*swe_ld(ge, k8, a*S8) + xb*swe_ld(ge, k8, bb*S8);
+                    }
+                    fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys, hq, eq, alq);
                 } else {
                     fq = cq*unown;
                 }

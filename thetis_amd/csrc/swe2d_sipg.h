@@ -46,6 +46,8 @@ struct SweSipgArgs {
     double bc_diff_flux[SWE_MAX_MARKERS];
     const double *bc_value_f;   // 9 planes (3f + i), see SweTracerArgs
     int bc_vel_kind[SWE_MAX_MARKERS];        // external velocity of the boundary dict, see SweTracerArgs
+    int depth_mode;                          // tracer 'flux' boundaries: total depth rule (SweTracerArgs), with vh / valpha
+    const double *valpha;
     double bc_u[SWE_MAX_MARKERS], bc_v[SWE_MAX_MARKERS];
 };
 
@@ -297,6 +299,16 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
                         double uq = xa*ua + xb*ub, vq = xa*va + xb*vb, ue = uq, ve = vq;
                         if (p.bc_vel_kind[marker] == 1) { ue = p.vel_factor*p.bc_u[marker]; ve = p.vel_factor*p.bc_v[marker]; }
                         else if (p.bc_vel_kind[marker] == 2) { ue = p.bc_u[marker]*n0; ve = p.bc_u[marker]*n1; }
+                        else if (p.bc_vel_kind[marker] >= 3) {                               // 'flux'
+                            const unsigned va8 = (unsigned)vid[a]*8u, vb8 = (unsigned)vid[bb]*8u;
+                            const double hq = xa*swe_ld(swe_rsrc(p.vh), va8, 0) + xb*swe_ld(swe_rsrc(p.vh), vb8, 0);
+                            const double alq = p.depth_mode == 2
+                                ? xa*swe_ld(swe_rsrc(p.valpha), va8, 0) + xb*swe_ld(swe_rsrc(p.valpha), vb8, 0) : 0.0;
+                            const double eq = xa*p.uv[(size_t)(6 + a)*S + k] + xb*p.uv[(size_t)(6 + bb)*S + k];
+                            const double sp = swe_tracer_flux_speed(p.depth_mode, hq, eq, alq, p.bc_vel_kind[marker] == 4,
+                                                                    p.bc_v[marker], p.bc_u[marker], p.bc.len[marker], p.vel_factor);
+                            ue = sp*n0; ve = sp*n1;
+                        }
                         const double un = 0.5*((uq + ue)*n0 + (vq + ve)*n1);                 // uv_av . n
                         const double s = (kd == SWE_SIPG_BC_GRAD_IN) ? 1.0 : (un > 0.0 ? 1.0 : (un < 0.0 ? 0.0 : 0.5));
                         val = -muq*((s*G[0][0] + (1.0 - s)*gex)*n0 + (s*G[0][1] + (1.0 - s)*gey)*n1);
@@ -579,6 +591,16 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
                         double uq = xa*ua + xb*ub, vq = xa*va + xb*vb, ue = uq, ve = vq;
                         if (p.bc_vel_kind[marker] == 1) { ue = p.vel_factor*p.bc_u[marker]; ve = p.vel_factor*p.bc_v[marker]; }
                         else if (p.bc_vel_kind[marker] == 2) { ue = p.bc_u[marker]*n0; ve = p.bc_u[marker]*n1; }
+                        else if (p.bc_vel_kind[marker] >= 3) {                               // 'flux'
+                            const unsigned va8 = (unsigned)vid[a]*8u, vb8 = (unsigned)vid[bb]*8u;
+                            const double hq = xa*swe_ld(swe_rsrc(p.vh), va8, 0) + xb*swe_ld(swe_rsrc(p.vh), vb8, 0);
+                            const double alq = p.depth_mode == 2
+                                ? xa*swe_ld(swe_rsrc(p.valpha), va8, 0) + xb*swe_ld(swe_rsrc(p.valpha), vb8, 0) : 0.0;
+                            const double eq = xa*p.uv[(size_t)(8 + a)*S + k] + xb*p.uv[(size_t)(8 + bb)*S + k];
+                            const double sp = swe_tracer_flux_speed(p.depth_mode, hq, eq, alq, p.bc_vel_kind[marker] == 4,
+                                                                    p.bc_v[marker], p.bc_u[marker], p.bc.len[marker], p.vel_factor);
+                            ue = sp*n0; ve = sp*n1;
+                        }
                         const double un = 0.5*((uq + ue)*n0 + (vq + ve)*n1);
                         const double sw = (kd == SWE_SIPG_BC_GRAD_IN) ? 1.0 : (un > 0.0 ? 1.0 : (un < 0.0 ? 0.0 : 0.5));
                         val = -muq*((sw*g0 + (1.0 - sw)*e0_)*n0 + (sw*g1 + (1.0 - sw)*e1_)*n1);

@@ -455,10 +455,13 @@ class Swe2dDevice(object):
         self._ck(self.lib.swe2d_tracer_set_bc(self.h, tid, self._slot(marker), 0 if value is None else 1,
                                               0.0 if value is None else float(value)))
 
-    def tracer_set_bc_velocity(self, tid, marker, uv=None, un=None):
-        """External velocity of the tracer's boundary dict: 'uv' (2 components) or 'un'; neither: uv_ext = uv_in."""
+    def tracer_set_bc_velocity(self, tid, marker, uv=None, un=None, flux=None, elev=None):
+        """External velocity of the tracer's boundary dict: 'uv' (2 components), 'flux' (with the dict's constant 'elev', if
+        any) or 'un', in the precedence of tracer_eq_2d.py:100-112; none of them: uv_ext = uv_in."""
         if uv is not None:
             kind, u, v = 1, float(uv[0]), float(uv[1])
+        elif flux is not None:
+            kind, u, v = (3, float(flux), 0.0) if elev is None else (4, float(flux), float(elev))
         elif un is not None:
             kind, u, v = 2, float(un), 0.0
         else:

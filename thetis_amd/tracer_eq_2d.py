@@ -5,7 +5,7 @@ Implemented by ``swe_tracer_stage_kernel`` (csrc/swe2d_kernels.h): non-conservat
 (:124-193; upwind DG, optional Lax-Friedrichs) and ``SourceTerm`` (:281-298), boundaries without a condition or with a
 constant ``'value'``; ``HorizontalDiffusionTerm`` (SIPG, :196-278) by the pass kernel ``swe_sipg_kernel<1>``
 (csrc/swe2d_sipg.h; Constant or CG-P1 diffusivity, ``'diff_flux'`` boundaries); the conservative form
-(:325-437) is a flag of the same kernels.  Everything else (SUPG :490-501, CG tracers, Function-valued velocity boundary keys, 'flux') raises instead of silently changing the physics.
+(:325-437) is a flag of the same kernels.  Everything else (SUPG :490-501, CG tracers, Function-valued velocity boundary keys) raises instead of silently changing the physics.
 """
 from .function import Function
 from .options import Constant
@@ -33,10 +33,10 @@ class TracerEquation2D(object):
     def check_bnd_conditions(bnd_conditions):
         for marker, funcs in (bnd_conditions or {}).items():
             for key, v in funcs.items():
-                if key not in ('value', 'elev', 'diff_flux', 'uv', 'un'):
+                if key not in ('value', 'elev', 'diff_flux', 'uv', 'un', 'flux'):
                     raise NotImplementedError('tracer boundary key {!r} is not on the device path '
-                                              '("value", "uv", "un", "diff_flux")'.format(key))
-                if key in ('uv', 'un') and isinstance(v, Function):
+                                              '("value", "uv", "un", "flux", "elev", "diff_flux")'.format(key))
+                if key in ('uv', 'un', 'flux', 'elev') and isinstance(v, Function):
                     raise NotImplementedError("tracer boundary '{:}' must be a constant on the device path".format(key))
                 if key == 'diff_flux' and not isinstance(v, (int, float, Constant)):
                     raise NotImplementedError("'diff_flux' must be a constant on the device path")
