@@ -4,6 +4,8 @@
 #include "swe2d_kernels.h"
 #include "swe2d_sipg.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -108,6 +110,42 @@ int fail(Handle *h, int code, const std::string &msg)
         if (e_ != hipSuccess)                                                                    \
             return fail(h, SWE2D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
     } while (0)
+
+// Optional ROCTx ranges around the entry points that advance the state (THETIS_AMD_ROCTX=1): they show up as named ranges in
+// `rocprofv3 --marker-trace` next to the kernel trace.  The tracing library is looked up at run time (rocprofiler-sdk's
+// librocprofiler-sdk-roctx.so, else roctracer's libroctx64.so); without it, or without the variable, the ranges are no-ops.
+struct RoctxRange {
+    typedef int (*push_t)(const char *);
+    typedef int (*pop_t)();
+    static void resolve(push_t &push, pop_t &pop)
+    {
+        static bool done = false;
+        static push_t p_push = nullptr;
+        static pop_t p_pop = nullptr;
+        if (!done) {
+            done = true;
+            if (std::getenv("THETIS_AMD_ROCTX")) {
+                for (const char *name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+                    if (void *lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                        p_push = reinterpret_cast<push_t>(dlsym(lib, "roctxRangePushA"));
+                        p_pop = reinterpret_cast<pop_t>(dlsym(lib, "roctxRangePop"));
+                        if (p_push && p_pop) break;
+                        p_push = nullptr; p_pop = nullptr;
+                    }
+                }
+            }
+        }
+        push = p_push; pop = p_pop;
+    }
+    pop_t pop_ = nullptr;
+    explicit RoctxRange(const char *name)
+    {
+        push_t push;
+        resolve(push, pop_);
+        if (push) push(name); else pop_ = nullptr;
+    }
+    ~RoctxRange() { if (pop_) pop_(); }
+};
 
 bool has_sources(const Handle *h)
 {
@@ -810,6 +848,8 @@ int swe2d_solve_stage_cells(swe2d_handle *hh, int i_stage, int32_t cell_begin, i
     if (cell_begin < 0 || cell_end > h->n_cells || cell_begin > cell_end)
         return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell range");
     HIP_TRY(h, hipSetDevice(h->device));
+    static const char *names[3] = {"swe2d_solve_stage[0]", "swe2d_solve_stage[1]", "swe2d_solve_stage[2]"};
+    RoctxRange range(names[(i_stage >= 0 && i_stage < 3) ? i_stage : 0]);
     return stage_on_range(h, i_stage, cell_begin, cell_end);
 }
 
@@ -827,6 +867,7 @@ int swe2d_advance(swe2d_handle *hh, int n_steps)
     if (h->n_owned != h->n_cells)
         return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_advance on a partition: drive stages + halo exchange from the host");
     HIP_TRY(h, hipSetDevice(h->device));
+    RoctxRange range("swe2d_advance");
     for (int it = 0; it < n_steps; it++)
         for (int s = 0; s < 3; s++) {
             int rc = stage_on_range(h, s, 0, h->n_owned);
@@ -1575,6 +1616,7 @@ int swe2d_advance_coupled(swe2d_handle *hh, int n_steps, int tracer_only, int us
     if (!h || n_steps < 0) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad n_steps");
     if (h->n_owned != h->n_cells) return fail(h, SWE2D_ERR_UNSUPPORTED, "on a partition the host drives the coupled step (stages on cell ranges + halo exchanges, thetis_amd/distributed.py)");
     HIP_TRY(h, hipSetDevice(h->device));
+    RoctxRange range("swe2d_advance_coupled");
     for (int it = 0; it < n_steps; it++) {
         if (!tracer_only)
             for (int s = 0; s < 3; s++) { int rc = stage_on_range(h, s, 0, h->n_owned); if (rc) return rc; }
