@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SWE2D_ABI_VERSION 4
+#define SWE2D_ABI_VERSION 5
 #define SWE2D_MAX_MARKERS 16          /* boundary markers must be in 1..SWE2D_MAX_MARKERS-1 */
 
 typedef enum {
@@ -133,6 +133,9 @@ const char *swe2d_last_error(const swe2d_handle *h);             /* h may be NUL
 /* state: the mixed Function solution_2d = (uv_2d, elev_2d) (solver2d.py:410-413); host pointers */
 int  swe2d_set_state(swe2d_handle *h, const double *uv, const double *eta);
 int  swe2d_get_state(swe2d_handle *h, double *uv, double *eta);
+/* the stage solution the reference assigns to `solution` after solve_stage(i_stage) (rungekutta.py:930-946): i_stage 0, 1 read
+ * the buffers holding U1, U2; i_stage 2 (= swe2d_get_state) the step result */
+int  swe2d_get_stage_state(swe2d_handle *h, int i_stage, double *uv, double *eta);
 
 /* TimeIntegrator.set_dt (timeintegrator.py:70-73) */
 int  swe2d_set_dt(swe2d_handle *h, double dt);
@@ -277,6 +280,27 @@ int  swe2d_debug_calibration_copy(swe2d_handle *h, int n_times);
 int  swe2d_halo_setup(swe2d_handle *h, int32_t n_send, const int32_t *send_cells, int32_t n_recv, const int32_t *recv_cells);
 int  swe2d_halo_pack(swe2d_handle *h, int i_buffer, double *send_buf_dev);
 int  swe2d_halo_unpack(swe2d_handle *h, int i_buffer, const double *recv_buf_dev);
+/* ---- peer-to-peer halo exchange through IPC-mapped device memory: the exchange as two kernels on the handle's stream (no host
+ * or RCCL call in the step loop, capturable in a HIP graph).  Same role as swe2d_halo_pack + send/recv + swe2d_halo_unpack.
+ * After swe2d_halo_setup:  swe2d_p2p_create (landing zone for n_recv cells x 2 slots per channel; channel 0 = the SWE state,
+ * width 3k doubles per cell, channel 1 + t = tracer t, width k)  ->  swe2d_p2p_export (64-byte hipIpcMemHandle_t to hand to
+ * the peers through any side channel, e.g. an all-gather; local_base serves peers inside the same process)  ->  every rank
+ * swe2d_p2p_open()s the zones of the ranks it sends to  ->  swe2d_p2p_connect: peer i receives send-list cells
+ * [send_offset[i], + send_count[i]) at cell offset remote_recv_offset[i] of ITS recv list (remote_n_recv[i] cells long) and
+ * knows me as its sender number remote_flag_index[i]; n_from = number of ranks that send to me (their flag indices are
+ * 0..n_from-1).  Then, per exchange and channel, on every rank in the same order: swe2d_p2p_push ... swe2d_p2p_wait_unpack.
+ * A rank may run at most one exchange ahead of a peer (double-buffered slots); waits are bounded (THETIS_AMD_P2P_TIMEOUT_S,
+ * default 5 s) and counted in swe2d_p2p_status.timeouts instead of hanging the device. */
+#define SWE2D_IPC_HANDLE_BYTES 64
+int  swe2d_p2p_create(swe2d_handle *h, int32_t n_channels, const int32_t *widths);
+int  swe2d_p2p_export(swe2d_handle *h, void *ipc_handle_out, void **local_base, int32_t *zone_kind);
+int  swe2d_p2p_open(swe2d_handle *h, const void *ipc_handle, void **remote_base);
+int  swe2d_p2p_connect(swe2d_handle *h, int32_t n_peers, void *const *remote_base, const int32_t *send_offset,
+                       const int32_t *send_count, const int32_t *remote_recv_offset, const int32_t *remote_flag_index,
+                       const int32_t *remote_n_recv, int32_t n_from);
+int  swe2d_p2p_push(swe2d_handle *h, int channel, int i_buffer);
+int  swe2d_p2p_wait_unpack(swe2d_handle *h, int channel, int i_buffer);
+int  swe2d_p2p_status(swe2d_handle *h, int64_t *epochs_sent, int64_t *epochs_received, int32_t *timeouts);
 /* ERKGenericShuOsher.solve_stage restricted to cells [cell_begin, cell_end) (may include ghost layers) */
 int  swe2d_solve_stage_cells(swe2d_handle *h, int i_stage, int32_t cell_begin, int32_t cell_end);
 /* ForwardEuler (timeintegrator.py:115-165) on a partition: the step from state buffer 0 into buffer 1 on a cell range;

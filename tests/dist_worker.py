@@ -239,13 +239,14 @@ def cpu_coupled_worker(rank, world, port, n_steps, out_dir, axis, case='channel'
 def gpu_coupled_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     """DistributedSwe2d with one tracer + limiter, two ranks sharing ONE GPU (gloo + host staging stands in for RCCL)."""
     global CASE
-    CASE = case
+    CASE = case.replace('+p2p', '')
     from thetis_amd.distributed import DistributedSwe2d
     from thetis_amd.partition import strip_owner
     dist = _init(rank, world, port)
     mesh, bath, uv, eta = _case()
     owner = strip_owner(mesh, world, axis=axis)
-    solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, host_staged=True, n_tracers=1)
+    solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, n_tracers=1,
+                              exchange=('p2p' if case.endswith('+p2p') else 'host'))
     solver.set_state_global(uv, eta)
     solver.set_tracer_global(0, tracer_initial(mesh))
     solver.advance(n_steps, use_graph=False)
@@ -265,8 +266,11 @@ def viscosity_field(mesh):
 
 def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     global CASE
-    graphed = case.endswith('+graph')      # per-cycle HIP graphs around the (eager, host-staged) exchange
-    case = case.replace('+graph', '')
+    flags = {}
+    for f in ('+capture', '+graph', '+p2p', '+nosplit'):   # order-independent suffix flags
+        flags[f] = f in case
+        case = case.replace(f, '')
+    graphed = flags['+graph']              # per-cycle HIP graphs (around the eager host-staged exchange, or incl. the p2p kernels)
     fe = case.endswith('+fe')
     case = case.replace('+fe', '')
     case, every, overlap = _split_every(case)
@@ -279,13 +283,22 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     dist = _init(rank, world, port)
     mesh, bath, uv, eta = _case()
     owner = strip_owner(mesh, world, axis=axis)
-    solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, host_staged=True, exchange_every=every,
-                              overlap_stages=overlap, stepper=('ForwardEuler' if fe else 'SSPRK33'))
+    solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, exchange=('p2p' if flags['+p2p'] else 'host'),
+                              exchange_every=every, overlap_stages=overlap, split_last_stage=not flags['+nosplit'],
+                              stepper=('ForwardEuler' if fe else 'SSPRK33'))
     if viscous:     # SIPG pass on the partition: same cell ranges as the stage kernels, per-vertex viscosity of the local vertices
         solver.dev.set_viscosity(viscosity_field(mesh)[solver.part.vertex_global], use_grad_div_viscosity_term=True)
     solver.set_state_global(uv, eta)
     d0 = solver.diagnostics()
-    if graphed:
+    if flags['+capture']:
+        # what bench.py does: capture outside advance() (state restored), one untimed replay, state reset, the run
+        solver._capture(n_steps)
+        assert solver.graphed
+        solver.advance(n_steps, use_graph=True)
+        solver.synchronize()
+        solver.set_state_global(uv, eta)
+        solver.advance(n_steps, use_graph=True)
+    elif graphed:
         # twice the same advance: the second call replays the graphs the first one captured
         solver.advance(n_steps - n_steps//2, use_graph=True)
         solver.advance(n_steps//2, use_graph=True)
@@ -293,6 +306,9 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     else:
         solver.advance(n_steps, use_graph=False)
     solver.synchronize()
+    if solver.p2p is not None:
+        sent, received, timeouts = solver.dev.p2p_status()
+        assert timeouts == 0 and sent[0] == received[0] > 0, (sent, received, timeouts)
     d1 = solver.diagnostics()
     ids, u, e = solver.get_state_owned()
     np.savez(os.path.join(out_dir, 'rank{:d}.npz'.format(rank)), ids=ids, uv=u, eta=e, d0=d0, d1=d1)

@@ -383,3 +383,73 @@ def test_two_ranks_with_viscosity_match_single_device(tmp_path, hip_lib):
     dev.advance(3)
     assert not np.array_equal(dev.get_state()[0], u_s)           # the viscous term was active
     dev.close()
+
+
+def _single_device(n_steps):
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = _case()
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev.set_state(uv, eta)
+    dev.advance(n_steps)
+    out = dev.get_state()
+    dev.close()
+    return mesh, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,case,n_steps', [
+    (2, 'channel+p2p', 3), (2, 'channel+every2+p2p', 5), (2, 'channel+every4+overlap3+p2p+graph', 16),
+    (2, 'channel+every2+p2p+nosplit+graph', 9), (3, 'channel+every4+p2p+graph', 8), (4, 'channel+every2+overlap3+p2p+graph', 9),
+    (2, 'quad+p2p', 3), (2, 'delaunay+every2+p2p+graph', 6), (2, 'channel+every3+fe+p2p', 7)])
+def test_ranks_on_one_gpu_with_peer_to_peer_halos(tmp_path, hip_lib, world, case, n_steps):
+    """The exchange as two kernels writing into / polling IPC-mapped landing zones (csrc/swe2d_p2p.h): separate processes on
+    one GPU map each other's zones with hipIpcOpenMemHandle exactly as ranks on different GPUs do; with '+graph' the whole
+    cycle incl. the exchange kernels is replayed from one HIP graph.  Bitwise the single-device result."""
+    from thetis_amd.device import Swe2dDevice
+    import dist_worker
+    base = case.split('+')[0]
+    dist_worker.CASE = base
+    mesh, bath, uv, eta = dist_worker._case()
+    run_workers(gpu_worker, world, n_steps, str(tmp_path), axis=0, case=case)
+    u_p, e_p, extra = gather(str(tmp_path), world, mesh.num_cells)
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev.set_state(uv, eta)
+    if '+fe' in case:
+        dev.advance_forward_euler(n_steps)
+    else:
+        dev.advance(n_steps)
+    u_s, e_s = dev.get_state()
+    dev.close()
+    dist_worker.CASE = 'channel'
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['channel+every2+overlap3+capture', 'channel+every4+p2p+capture'])
+def test_capture_outside_advance_as_the_bench_does(tmp_path, hip_lib, case):
+    """bench.py calls DistributedSwe2d._capture directly (not through advance): the capture run must use the solver's own
+    stream for the exchange ordering and restore the state only after everything it enqueued has finished."""
+    n_steps = 8
+    mesh, (u_s, e_s) = _single_device(n_steps)
+    run_workers(gpu_worker, 2, n_steps, str(tmp_path), axis=0, case=case)
+    u_p, e_p, extra = gather(str(tmp_path), 2, mesh.num_cells)
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+
+
+@pytest.mark.gpu
+def test_two_ranks_coupled_with_peer_to_peer_halos(tmp_path, hip_lib):
+    """tracer channels of the landing zone: SWE state on channel 0, the tracer on channel 1"""
+    from thetis_amd.device import Swe2dDevice
+    from dist_worker import tracer_initial
+    mesh, bath, uv, eta = _case()
+    run_workers(gpu_coupled_worker, 2, 3, str(tmp_path), axis=0, case='channel+p2p')
+    u_p, e_p, extra = gather(str(tmp_path), 2, mesh.num_cells)
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev.set_state(uv, eta)
+    tid = dev.add_tracer()
+    dev.tracer_set_state(tid, tracer_initial(mesh))
+    dev.advance_coupled(3)
+    u_s, e_s = dev.get_state()
+    T_s = dev.tracer_get_state(tid)
+    dev.close()
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s) and np.array_equal(extra[-1], T_s)

@@ -36,18 +36,21 @@ def test_bench_prints_one_json_line_with_the_contract_fields(hip_lib, env):
     assert 1e9 < d['value'] < 1e11
     if env.get('THETIS_AMD_TUNE_SCHEDULE'):
         tuned = d['config']['schedule_tuning']
-        assert len(tuned) == 7 and all(t['us_per_step'] > 0 for t in tuned)
+        assert len(tuned) >= 5 and all(t['us_per_step'] > 0 for t in tuned)
         best = min(tuned, key=lambda t: t['us_per_step'])
-        assert (d['config']['exchange_every'], d['config']['overlap_stages'], d['config']['graph_mode']) == (
-            best['exchange_every'], best['overlap_stages'], best['graph_mode'])
+        assert (d['config']['exchange'], d['config']['exchange_every'], d['config']['overlap_stages']) == (
+            best['exchange'], best['exchange_every'], best['overlap_stages'])
         assert d['config']['volume_conserved'] is True
+    if env:
+        assert d['config']['failures'] == [] and 'p2p' in d['config']['transports_verified']
 
 
 def test_bench_two_ranks_through_torch_distributed_run(hip_lib):
     """The driver's N > 1 invocation (python -m torch.distributed.run ... bench.py --gpus N) with two ranks sharing the GPU
-    of the test box: gloo + host staging stands in for RCCL (THETIS_AMD_DIST_BACKEND), everything else - partitioning,
-    schedule tuning with the max over ranks, graph capture, the timed region, rank 0 printing one JSON line - is the
-    code a multi-GPU node runs."""
+    of the test box: RCCL refuses two ranks on one device, so THETIS_AMD_DIST_BACKEND=gloo drops the 'rccl' transport; the
+    peer-to-peer transport (IPC-mapped landing zones, the default choice on a multi-GPU node) is verified bit for bit
+    against the host-staged exchange and timed, and everything else - partitioning, schedule tuning with the max over
+    ranks, graph capture, the timed region, rank 0 printing one JSON line - is the code a multi-GPU node runs."""
     e = dict(os.environ)
     e.update({'THETIS_AMD_DIST_BACKEND': 'gloo'})
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
@@ -59,5 +62,25 @@ def test_bench_two_ranks_through_torch_distributed_run(hip_lib):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 16 and d['scaling'] == 'strong'
-    assert len(d['config']['schedule_tuning']) == 7 and d['config']['volume_conserved'] is True
+    cfg = d['config']
+    assert len(cfg['schedule_tuning']) >= 5 and cfg['volume_conserved'] is True
+    assert cfg['transports_verified'] == ['p2p', 'host'] and cfg['exchange'] == 'p2p' and cfg['p2p_timeouts'] == 0
+    assert cfg['failures'] == [] and cfg['hip_graph'] is True
     assert 1e8 < d['value'] < 1e11
+
+
+def test_bench_survives_a_transport_that_fails(hip_lib):
+    """First contact with a node where a transport is broken must still end with the JSON line: the peer-to-peer zone
+    cannot be opened (THETIS_AMD_TEST_BREAK_P2P makes swe2d_p2p_open fail), the bench records the failure and falls back."""
+    e = dict(os.environ)
+    e.update({'THETIS_AMD_DIST_BACKEND': 'gloo', 'THETIS_AMD_TEST_BREAK_P2P': '1'})
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', '29578', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '8',
+                        '--warmup', '2', '--prewarm', '0.05'],
+                       capture_output=True, text=True, env=e, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.lstrip().startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['config']['exchange'] == 'host' and d['config']['transports_verified'] == ['host']
+    assert any('p2p' in f for f in d['config']['failures']) and d['value'] > 1e7

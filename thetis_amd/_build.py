@@ -4,8 +4,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, 'csrc', 'swe2d_api.hip')
-DEPS = [SRC, os.path.join(_HERE, 'csrc', 'swe2d_kernels.h'),
-        os.path.join(_HERE, '..', 'include', 'swe2d.h')]
+import glob
+# every header the translation unit can include: editing any of them must trigger a rebuild
+DEPS = [SRC] + sorted(glob.glob(os.path.join(_HERE, 'csrc', '*.h'))) + [os.path.join(_HERE, '..', 'include', 'swe2d.h')]
 LIB = os.path.join(_HERE, 'libswe2d_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared']

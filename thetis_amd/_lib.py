@@ -17,7 +17,8 @@ FIELD_CORIOLIS, FIELD_ATMOSPHERIC_PRESSURE, FIELD_MOMENTUM_SOURCE, FIELD_VOLUME_
 FIELD_LINEAR_DRAG, FIELD_QUADRATIC_DRAG, FIELD_MANNING_DRAG, FIELD_NIKURADSE = 5, 6, 7, 8
 SCALAR_LINEAR_DRAG, SCALAR_QUADRATIC_DRAG, SCALAR_MANNING_DRAG, SCALAR_NORM_SMOOTHER, SCALAR_NIKURADSE = 0, 1, 2, 3, 4
 
-ABI_VERSION = 4          # include/swe2d.h SWE2D_ABI_VERSION
+IPC_HANDLE_BYTES = 64    # include/swe2d.h SWE2D_IPC_HANDLE_BYTES (sizeof(hipIpcMemHandle_t))
+ABI_VERSION = 5          # include/swe2d.h SWE2D_ABI_VERSION
 OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NOT_FINITE = 0, -1, -2, -3, -4, -5
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -49,6 +50,7 @@ SYMBOLS = {
     'swe2d_last_error': (ctypes.c_char_p, [_H]),
     'swe2d_set_state': (ctypes.c_int, [_H, _dp, _dp]),
     'swe2d_get_state': (ctypes.c_int, [_H, _dp, _dp]),
+    'swe2d_get_stage_state': (ctypes.c_int, [_H, ctypes.c_int, _dp, _dp]),
     'swe2d_set_dt': (ctypes.c_int, [_H, ctypes.c_double]),
     'swe2d_set_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),
     'swe2d_set_bc_field': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),
@@ -94,6 +96,14 @@ SYMBOLS = {
     'swe2d_halo_setup': (ctypes.c_int, [_H, ctypes.c_int32, _ip, ctypes.c_int32, _ip]),
     'swe2d_halo_pack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_void_p]),
     'swe2d_halo_unpack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_void_p]),
+    'swe2d_p2p_create': (ctypes.c_int, [_H, ctypes.c_int32, _ip]),
+    'swe2d_p2p_export': (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), _ip]),
+    'swe2d_p2p_open': (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    'swe2d_p2p_connect': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), _ip, _ip, _ip, _ip, _ip,
+                                          ctypes.c_int32]),
+    'swe2d_p2p_push': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int]),
+    'swe2d_p2p_wait_unpack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int]),
+    'swe2d_p2p_status': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _ip]),
     'swe2d_solve_stage_cells': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_forward_euler_cells': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_swap_state_buffers': (ctypes.c_int, [_H]),

@@ -3,6 +3,7 @@
 #include "../../include/swe2d.h"
 #include "swe2d_kernels.h"
 #include "swe2d_sipg.h"
+#include "swe2d_p2p.h"
 
 #include <dlfcn.h>
 
@@ -65,6 +66,21 @@ struct Handle {
     int n_partial_blocks = 0;
     int *send_cells = nullptr, *recv_cells = nullptr;
     int n_send = 0, n_recv = 0;
+    // peer-to-peer halo (swe2d_p2p.h): my landing zone, the peers' zones mapped here, per-channel device counters
+    struct P2p {
+        void *zone = nullptr;
+        size_t zone_bytes = 0;
+        int zone_kind = 0;                               // 1 uncached, 2 fine-grained, 3 ordinary device memory
+        int n_channels = 0;
+        int width[SWE_P2P_MAX_CHANNELS] = {0};
+        SweP2pCounters *ctr = nullptr;                   // [n_channels]
+        std::vector<void *> opened;                      // hipIpcOpenMemHandle mappings to close
+        int n_peers = 0, n_from = 0;
+        int off[SWE_P2P_MAX_PEERS], cnt[SWE_P2P_MAX_PEERS], remote_off[SWE_P2P_MAX_PEERS], remote_flag[SWE_P2P_MAX_PEERS],
+            remote_n_recv[SWE_P2P_MAX_PEERS];
+        char *remote_base[SWE_P2P_MAX_PEERS];
+        double timeout_s = 5.0;
+    } p2p;
     // tracers + limiter
     struct Tracer {
         double *buf[3] = {nullptr, nullptr, nullptr};   // A (T0 / result), B, C: 3 planes each
@@ -534,6 +550,9 @@ void swe2d_destroy(swe2d_handle *hh)
                     h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
+    for (void *m : h->p2p.opened) (void)hipIpcCloseMemHandle(m);
+    if (h->p2p.zone) (void)hipFree(h->p2p.zone);
+    if (h->p2p.ctr) (void)hipFree(h->p2p.ctr);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->my_stream) (void)hipStreamDestroy(h->my_stream);
@@ -565,14 +584,17 @@ int swe2d_set_state(swe2d_handle *hh, const double *uv, const double *eta)
     return SWE2D_OK;
 }
 
-int swe2d_get_state(swe2d_handle *hh, double *uv, double *eta)
+int swe2d_get_state(swe2d_handle *hh, double *uv, double *eta) { return swe2d_get_stage_state(hh, 2, uv, eta); }
+
+int swe2d_get_stage_state(swe2d_handle *hh, int i_stage, double *uv, double *eta)
 {
     Handle *h = H(hh);
     if (!h || !uv || !eta) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    if (i_stage < 0 || i_stage > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "i_stage must be 0, 1 or 2");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t n = (size_t)h->n_cells*h->npc;
     hipLaunchKernelGGL(swe_planes_to_aos, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                       h->state[0], h->stage_uv, h->stage_eta, h->stride, h->n_cells, h->npc);
+                       h->state[(i_stage + 1) % 3], h->stage_uv, h->stage_eta, h->stride, h->n_cells, h->npc);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(uv, h->stage_uv, 2*n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(eta, h->stage_eta, n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1634,6 +1656,201 @@ int swe2d_advance_coupled(swe2d_handle *hh, int n_steps, int tracer_only, int us
             if (use_limiter) { int rc = limiter_apply(h, id, h->n_cells, fuse_mean); if (rc) return rc; }
         }
     }
+    return SWE2D_OK;
+}
+
+}  // extern "C"
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// peer-to-peer halo exchange (swe2d_p2p.h)
+namespace {
+// byte offset of channel c's slot 0 in the landing zone of a rank with n_recv halo cells (both sides compute it)
+size_t p2p_channel_offset(const int *width, int c, int n_recv)
+{
+    size_t off = SWE_P2P_HEADER_BYTES;
+    for (int i = 0; i < c; i++) off += 2*(size_t)n_recv*width[i]*sizeof(double);
+    return off;
+}
+}  // namespace
+
+extern "C" {
+
+int swe2d_p2p_create(swe2d_handle *hh, int32_t n_channels, const int32_t *widths)
+{
+    Handle *h = H(hh);
+    if (!h || n_channels < 1 || n_channels > SWE_P2P_MAX_CHANNELS || !widths)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_create: 1..8 channels");
+    if (h->p2p.zone) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_create: already created");
+    HIP_TRY(h, hipSetDevice(h->device));
+    auto &z = h->p2p;
+    z.n_channels = n_channels;
+    for (int c = 0; c < n_channels; c++) {
+        if (widths[c] < 1) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_create: bad channel width");
+        z.width[c] = widths[c];
+    }
+    z.zone_bytes = p2p_channel_offset(z.width, n_channels, h->n_recv);
+    z.zone_bytes = (z.zone_bytes + 4095)/4096*4096;
+    // remote GPUs write here and local kernels poll it: keep it out of the (non-coherent) L2 when the runtime allows
+    const char *force = std::getenv("THETIS_AMD_P2P_ZONE");        // "uncached" | "finegrained" | "device" (debugging)
+    const int want = !force ? 0 : !std::strcmp(force, "uncached") ? 1 : !std::strcmp(force, "finegrained") ? 2 : 3;
+    z.zone_kind = 0;
+    if ((want == 0 || want == 1) && hipExtMallocWithFlags(&z.zone, z.zone_bytes, hipDeviceMallocUncached) == hipSuccess) z.zone_kind = 1;
+    if (!z.zone_kind) (void)hipGetLastError();
+    if (!z.zone_kind && (want == 0 || want == 2)
+        && hipExtMallocWithFlags(&z.zone, z.zone_bytes, hipDeviceMallocFinegrained) == hipSuccess) z.zone_kind = 2;
+    if (!z.zone_kind) {
+        (void)hipGetLastError();
+        HIP_TRY(h, hipMalloc(&z.zone, z.zone_bytes));
+        z.zone_kind = 3;
+    }
+    HIP_TRY(h, hipMemset(z.zone, 0, z.zone_bytes));
+    HIP_TRY(h, hipMalloc(&z.ctr, n_channels*sizeof(SweP2pCounters)));
+    HIP_TRY(h, hipMemset(z.ctr, 0, n_channels*sizeof(SweP2pCounters)));
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (const char *t = std::getenv("THETIS_AMD_P2P_TIMEOUT_S")) z.timeout_s = std::atof(t);
+    return SWE2D_OK;
+}
+
+int swe2d_p2p_export(swe2d_handle *hh, void *ipc_handle_out, void **local_base, int32_t *zone_kind)
+{
+    Handle *h = H(hh);
+    if (!h || !h->p2p.zone) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_export: no landing zone");
+    static_assert(sizeof(hipIpcMemHandle_t) == SWE2D_IPC_HANDLE_BYTES, "IPC handle size");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (ipc_handle_out) {
+        hipIpcMemHandle_t mh;
+        HIP_TRY(h, hipIpcGetMemHandle(&mh, h->p2p.zone));
+        std::memcpy(ipc_handle_out, &mh, sizeof(mh));
+    }
+    if (local_base) *local_base = h->p2p.zone;
+    if (zone_kind) *zone_kind = h->p2p.zone_kind;
+    return SWE2D_OK;
+}
+
+int swe2d_p2p_open(swe2d_handle *hh, const void *ipc_handle, void **remote_base)
+{
+    Handle *h = H(hh);
+    if (!h || !ipc_handle || !remote_base) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_open: null argument");
+    if (std::getenv("THETIS_AMD_TEST_BREAK_P2P"))             // tests: a node whose IPC mapping does not work
+        return fail(h, SWE2D_ERR_HIP, "swe2d_p2p_open: disabled by THETIS_AMD_TEST_BREAK_P2P");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipIpcMemHandle_t mh;
+    std::memcpy(&mh, ipc_handle, sizeof(mh));
+    void *p = nullptr;
+    HIP_TRY(h, hipIpcOpenMemHandle(&p, mh, hipIpcMemLazyEnablePeerAccess));
+    h->p2p.opened.push_back(p);
+    *remote_base = p;
+    return SWE2D_OK;
+}
+
+int swe2d_p2p_connect(swe2d_handle *hh, int32_t n_peers, void *const *remote_base, const int32_t *send_offset,
+                      const int32_t *send_count, const int32_t *remote_recv_offset, const int32_t *remote_flag_index,
+                      const int32_t *remote_n_recv, int32_t n_from)
+{
+    Handle *h = H(hh);
+    if (!h || !h->p2p.zone) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_connect: no landing zone");
+    if (n_peers < 0 || n_peers > SWE_P2P_MAX_PEERS || n_from < 0 || n_from > SWE_P2P_MAX_PEERS)
+        return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_p2p_connect: at most 8 peers per rank");
+    auto &z = h->p2p;
+    int end = 0;
+    for (int i = 0; i < n_peers; i++) {
+        if (!remote_base[i] || send_offset[i] != end || send_count[i] < 0 || remote_flag_index[i] < 0
+            || remote_flag_index[i] >= SWE_P2P_MAX_PEERS || remote_recv_offset[i] < 0
+            || remote_recv_offset[i] + send_count[i] > remote_n_recv[i])
+            return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_connect: segments must tile the send list in order");
+        end += send_count[i];
+        z.remote_base[i] = static_cast<char *>(remote_base[i]);
+        z.off[i] = send_offset[i]; z.cnt[i] = send_count[i];
+        z.remote_off[i] = remote_recv_offset[i]; z.remote_flag[i] = remote_flag_index[i]; z.remote_n_recv[i] = remote_n_recv[i];
+    }
+    if (end != h->n_send) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_connect: segments do not cover the send list");
+    z.n_peers = n_peers;
+    z.n_from = n_from;
+    return SWE2D_OK;
+}
+
+namespace {
+int p2p_field(Handle *h, int channel, int i_buffer, double **planes, int *np)
+{
+    if (channel < 0 || channel >= h->p2p.n_channels || i_buffer < 0 || i_buffer > 2)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "p2p: bad channel or buffer index");
+    if (channel == 0) { *planes = h->state[i_buffer]; *np = 3*h->npc; }
+    else {
+        if (channel - 1 >= (int)h->tracers.size()) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "p2p: channel has no tracer");
+        *planes = h->tracers[channel - 1].buf[i_buffer]; *np = h->npc;
+    }
+    if (*np != h->p2p.width[channel]) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "p2p: channel width mismatch");
+    return SWE2D_OK;
+}
+}  // namespace
+
+int swe2d_p2p_push(swe2d_handle *hh, int channel, int i_buffer)
+{
+    Handle *h = H(hh);
+    if (!h || !h->p2p.zone) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_push: not connected");
+    double *planes; int np;
+    if (int rc = p2p_field(h, channel, i_buffer, &planes, &np)) return rc;
+    auto &z = h->p2p;
+    if (z.n_peers == 0 || h->n_send == 0) return SWE2D_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    SweP2pPushArgs a{};
+    a.planes = planes; a.stride = h->stride; a.send_cells = h->send_cells; a.n_send = h->n_send; a.np = np;
+    a.n_peers = z.n_peers;
+    for (int i = 0; i < z.n_peers; i++) {
+        a.off[i] = z.off[i]; a.cnt[i] = z.cnt[i];
+        char *base = z.remote_base[i];
+        a.rdata[i] = reinterpret_cast<double *>(base + p2p_channel_offset(z.width, channel, z.remote_n_recv[i]))
+                     + (size_t)z.remote_off[i]*np;
+        a.rslot[i] = (size_t)z.remote_n_recv[i]*np;
+        a.rflag[i] = reinterpret_cast<unsigned long long *>(base)
+                     + (size_t)(channel*SWE_P2P_MAX_PEERS + z.remote_flag[i])*SWE_P2P_FLAG_STRIDE;
+    }
+    a.ctr = z.ctr + channel;
+    hipLaunchKernelGGL(swe_p2p_push_kernel, dim3(grid_for(np*h->n_send)), dim3(256), 0, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
+}
+
+int swe2d_p2p_wait_unpack(swe2d_handle *hh, int channel, int i_buffer)
+{
+    Handle *h = H(hh);
+    if (!h || !h->p2p.zone) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_wait_unpack: not connected");
+    double *planes; int np;
+    if (int rc = p2p_field(h, channel, i_buffer, &planes, &np)) return rc;
+    auto &z = h->p2p;
+    if (z.n_from == 0 || h->n_recv == 0) return SWE2D_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    SweP2pUnpackArgs a{};
+    a.planes = planes; a.stride = h->stride; a.recv_cells = h->recv_cells; a.n_recv = h->n_recv; a.np = np;
+    a.n_from = z.n_from;
+    char *base = static_cast<char *>(z.zone);
+    for (int i = 0; i < z.n_from; i++)
+        a.flag[i] = reinterpret_cast<const unsigned long long *>(base) + (size_t)(channel*SWE_P2P_MAX_PEERS + i)*SWE_P2P_FLAG_STRIDE;
+    a.zone = reinterpret_cast<const double *>(base + p2p_channel_offset(z.width, channel, h->n_recv));
+    a.slot = (size_t)h->n_recv*np;
+    a.timeout_ticks = (unsigned long long)(z.timeout_s*1e8);
+    a.ctr = z.ctr + channel;
+    hipLaunchKernelGGL(swe_p2p_unpack_kernel, dim3(grid_for(np*h->n_recv)), dim3(256), 0, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
+}
+
+int swe2d_p2p_status(swe2d_handle *hh, int64_t *epochs_sent, int64_t *epochs_received, int32_t *timeouts)
+{
+    Handle *h = H(hh);
+    if (!h || !h->p2p.ctr) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_status: not created");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::vector<SweP2pCounters> c(h->p2p.n_channels);
+    HIP_TRY(h, hipMemcpy(c.data(), h->p2p.ctr, c.size()*sizeof(SweP2pCounters), hipMemcpyDeviceToHost));
+    int to = 0;
+    for (int i = 0; i < h->p2p.n_channels; i++) {
+        if (epochs_sent) epochs_sent[i] = (int64_t)c[i].epoch_send;
+        if (epochs_received) epochs_received[i] = (int64_t)c[i].epoch_recv;
+        to += (int)c[i].timeouts;
+    }
+    if (timeouts) *timeouts = to;
     return SWE2D_OK;
 }
 

@@ -1,0 +1,135 @@
+// swe2d_p2p.h - peer-to-peer halo exchange through IPC-mapped device memory (gfx950, xGMI or same-device peers).
+//
+// Replaces the per-par_loop halo exchange of PyOP2 under mpiexec [FD-assumed] (examples/README.md:51-56) for one process per
+// GPU.  No host call and no RCCL call sits in the step loop: a rank PUSHES the state of its send cells straight into the
+// landing zone of every peer (stores over xGMI) and raises a per-peer epoch flag there; the receiver's WAIT+UNPACK kernel
+// spins on its own flags (local, uncached memory) and scatters the landed cells into its ghost cells.  Both are ordinary
+// kernels on the handle's stream, so a whole exchange cycle (stage kernels, push, overlapped interior work, wait+unpack) is
+// ONE HIP graph.
+//
+// Landing zone of a rank (one allocation, hipDeviceMallocUncached when available, exported with hipIpcGetMemHandle):
+//   [ header: 64-bit epoch flags, one per (channel, sending peer), 64 B apart ]
+//   [ channel 0: slot 0 | slot 1 ]  [ channel 1: slot 0 | slot 1 ] ...      slot = [n_recv][width] doubles, in recv-list order
+// A channel is one exchanged field set (0: the SWE state, width 3k; 1..: tracers, width k).  Epochs count exchanges per
+// channel; exchange e lands in slot e & 1.  Two slots suffice: a peer can push exchange e+1 only after it has received my
+// exchange e, which I push after having unpacked exchange e-1 (stream order) - the slot it overwrites is already consumed.
+// The epoch counters live in device memory and are advanced by the kernels themselves, so a captured graph replays correctly.
+//
+// Memory ordering (MI355X_MICROARCH.md, inter-workgroup visibility): payload is written with system-scope (sc0 sc1,
+// write-through) stores; every workgroup drains them (s_waitcnt vmcnt(0)), one lane issues a system-scope release fence and
+// takes a ticket; the last workgroup to arrive fences again and then stores the flags (system scope, release).  The consumer
+// polls with system-scope relaxed loads, fences (acquire) once, and reads the payload with system-scope loads.
+// Every spin is bounded (wall clock); a timeout is recorded in the status word, the kernel carries on and later waits of the
+// channel do not spin at all, so a lost peer costs one timeout and can never hang the GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SWE_P2P_MAX_PEERS 8
+#define SWE_P2P_MAX_CHANNELS 8
+#define SWE_P2P_HEADER_BYTES 8192          // SWE_P2P_MAX_CHANNELS * SWE_P2P_MAX_PEERS flags, 64 B apart, rounded up
+#define SWE_P2P_FLAG_STRIDE 8              // in 8-byte words
+
+// per-channel device counters (ordinary device memory of the owning rank)
+struct SweP2pCounters {
+    unsigned long long epoch_send, epoch_recv;      // completed pushes / unpacks
+    unsigned int ticket_send, ticket_recv;
+    unsigned int timeouts, pad;
+};
+
+struct SweP2pPushArgs {
+    const double *planes;          // np planes of the field to send
+    size_t stride;
+    const int *send_cells;
+    int n_send, np;
+    int n_peers;
+    int off[SWE_P2P_MAX_PEERS], cnt[SWE_P2P_MAX_PEERS];      // per peer: segment of the send list (cells)
+    double *rdata[SWE_P2P_MAX_PEERS];                        // peer's landing segment for me, slot 0
+    size_t rslot[SWE_P2P_MAX_PEERS];                         // doubles between the peer's slot 0 and slot 1
+    unsigned long long *rflag[SWE_P2P_MAX_PEERS];            // my flag in the peer's header
+    SweP2pCounters *ctr;
+};
+
+struct SweP2pUnpackArgs {
+    double *planes;
+    size_t stride;
+    const int *recv_cells;
+    int n_recv, np;
+    int n_from;                                              // number of peers that send to me
+    const unsigned long long *flag[SWE_P2P_MAX_PEERS];       // their flags in MY header
+    const double *zone;                                      // my landing data of this channel, slot 0
+    size_t slot;                                             // doubles between slot 0 and slot 1
+    unsigned long long timeout_ticks;                        // wall_clock64 ticks (100 MHz)
+    SweP2pCounters *ctr;
+};
+
+__device__ __forceinline__ void swe_p2p_store(double *p, double x)
+{
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);          // global_store_dwordx2 sc0 sc1
+}
+__device__ __forceinline__ double swe_p2p_load(const double *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // global_load_dwordx2 sc0 sc1
+}
+
+__global__ __launch_bounds__(256) void swe_p2p_push_kernel(const SweP2pPushArgs a)
+{
+    const unsigned long long target = a.ctr->epoch_send + 1ull;      // every workgroup reads it before the last one advances it
+    const int t = blockIdx.x*256 + threadIdx.x;
+    if (t < a.np*a.n_send) {
+        const int j = t/a.np, q = t - a.np*j;
+        int p = 0;
+#pragma unroll 1
+        for (int i = 1; i < a.n_peers; i++) if (j >= a.off[i]) p = i;                // segments are sorted by offset
+        if (j < a.off[p] + a.cnt[p]) {
+            const double x = a.planes[(size_t)q*a.stride + a.send_cells[j]];
+            swe_p2p_store(a.rdata[p] + (target & 1ull)*a.rslot[p] + (size_t)(j - a.off[p])*a.np + q, x);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                                // system scope
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int ticket = __hip_atomic_fetch_add(&a.ctr->ticket_send, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == gridDim.x - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int i = 0; i < a.n_peers; i++)
+                __hip_atomic_store(a.rflag[i], target, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            a.ctr->ticket_send = 0u;
+            a.ctr->epoch_send = target;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void swe_p2p_unpack_kernel(const SweP2pUnpackArgs a)
+{
+    const unsigned long long target = a.ctr->epoch_recv + 1ull;
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        bool late = a.ctr->timeouts != 0u;              // sticky: after one timeout (a lost peer) no later wait spins again
+        for (int i = 0; i < a.n_from && !late; i++) {
+            while (__hip_atomic_load(a.flag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
+                if (wall_clock64() - t0 > a.timeout_ticks) { late = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (late && blockIdx.x == 0) atomicAdd(&a.ctr->timeouts, 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                                // system scope
+    }
+    __syncthreads();
+    const int t = blockIdx.x*256 + threadIdx.x;
+    if (t < a.np*a.n_recv) {
+        const int j = t/a.np, q = t - a.np*j;
+        a.planes[(size_t)q*a.stride + a.recv_cells[j]] = swe_p2p_load(a.zone + (target & 1ull)*a.slot + t);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int ticket = __hip_atomic_fetch_add(&a.ctr->ticket_recv, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == gridDim.x - 1) {
+            a.ctr->ticket_recv = 0u;
+            a.ctr->epoch_recv = target;
+        }
+    }
+}

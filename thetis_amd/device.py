@@ -165,10 +165,11 @@ class Swe2dDevice(object):
         uv, eta = np.ascontiguousarray(uv), np.ascontiguousarray(eta)
         self._ck(self.lib.swe2d_set_state(self.h, _ptr(uv), _ptr(eta)))
 
-    def get_state(self):
+    def get_state(self, i_stage=2):
+        """The step result, or with ``i_stage`` = 0 / 1 the stage solution left by ``solve_stage(i_stage)``."""
         uv = np.empty((self.n_cells, self.npc, 2))
         eta = np.empty((self.n_cells, self.npc))
-        self._ck(self.lib.swe2d_get_state(self.h, _ptr(uv), _ptr(eta)))
+        self._ck(self.lib.swe2d_get_stage_state(self.h, int(i_stage), _ptr(uv), _ptr(eta)))
         if self.perm is not None:
             uv, eta = uv[self.inv_perm], eta[self.inv_perm]
         return uv, eta
@@ -525,6 +526,46 @@ class Swe2dDevice(object):
 
     def halo_unpack(self, i_buffer, recv_buf_ptr):
         self._ck(self.lib.swe2d_halo_unpack(self.h, i_buffer, ctypes.c_void_p(recv_buf_ptr)))
+
+    # -- peer-to-peer halo exchange through IPC-mapped memory (include/swe2d.h, csrc/swe2d_p2p.h)
+    def p2p_create(self, widths):
+        w = np.ascontiguousarray(widths, dtype=np.int32)
+        self._ck(self.lib.swe2d_p2p_create(self.h, w.size, _iptr(w)))
+
+    def p2p_export(self):
+        """(64-byte IPC handle, device address of my landing zone, zone kind: 1 uncached, 2 fine-grained, 3 ordinary)"""
+        buf = ctypes.create_string_buffer(_lib.IPC_HANDLE_BYTES)
+        base = ctypes.c_void_p()
+        kind = ctypes.c_int32()
+        self._ck(self.lib.swe2d_p2p_export(self.h, buf, ctypes.byref(base), ctypes.byref(kind)))
+        return buf.raw, int(base.value), int(kind.value)
+
+    def p2p_open(self, ipc_handle):
+        base = ctypes.c_void_p()
+        self._ck(self.lib.swe2d_p2p_open(self.h, ctypes.create_string_buffer(bytes(ipc_handle), _lib.IPC_HANDLE_BYTES),
+                                         ctypes.byref(base)))
+        return int(base.value)
+
+    def p2p_connect(self, remote_base, send_offset, send_count, remote_recv_offset, remote_flag_index, remote_n_recv, n_from):
+        n = len(remote_base)
+        bases = (ctypes.c_void_p*max(n, 1))(*[ctypes.c_void_p(b) for b in remote_base])
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (send_offset, send_count, remote_recv_offset,
+                                                                   remote_flag_index, remote_n_recv)]
+        self._ck(self.lib.swe2d_p2p_connect(self.h, n, bases, *[_iptr(a) for a in arrs], int(n_from)))
+
+    def p2p_push(self, channel, i_buffer):
+        self._ck(self.lib.swe2d_p2p_push(self.h, int(channel), int(i_buffer)))
+
+    def p2p_wait_unpack(self, channel, i_buffer):
+        self._ck(self.lib.swe2d_p2p_wait_unpack(self.h, int(channel), int(i_buffer)))
+
+    def p2p_status(self, n_channels=1):
+        """(epochs sent, epochs received, number of timed-out waits) after a stream synchronisation"""
+        a = (ctypes.c_int64*n_channels)()
+        b = (ctypes.c_int64*n_channels)()
+        t = ctypes.c_int32()
+        self._ck(self.lib.swe2d_p2p_status(self.h, a, b, ctypes.byref(t)))
+        return list(a), list(b), int(t.value)
 
     def set_stream(self, stream_ptr):
         self._ck(self.lib.swe2d_set_stream(self.h, ctypes.c_void_p(stream_ptr) if stream_ptr else None))

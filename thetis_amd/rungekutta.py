@@ -247,7 +247,9 @@ class ERKGenericShuOsher(TimeIntegrator):
         """Refresh the host copy of ``solution`` (called lazily when someone reads ``.dat.data``)."""
         if self._device_ahead:
             uv, eta = self.solution.subfunctions
-            u, e = self.device.get_state()
+            # the reference assigns every stage solution to `solution` (rungekutta.py:930-946): between stages a reader (e.g.
+            # update_forcings) sees the last completed stage, not the old step
+            u, e = self.device.get_state(getattr(self, '_last_stage', 2))
             uv._data[...] = u.reshape(uv._data.shape)
             eta._data[...] = e.reshape(eta._data.shape)
             self._device_ahead = False
@@ -273,7 +275,10 @@ class ERKGenericShuOsher(TimeIntegrator):
             self._push_fields(only_changed=True)
         if i_stage == 0:
             self._sync_to_device()
+        # (host WRITES to `solution` between the stages of a step are not supported: the device keeps U0 and the stage solutions
+        #  in separate buffers; reads see the last completed stage, see _pull_solution)
         self.device.solve_stage(i_stage)
+        self._last_stage = i_stage
         self._device_ahead = True
 
     def advance(self, t, update_forcings=None):
@@ -281,6 +286,7 @@ class ERKGenericShuOsher(TimeIntegrator):
         if update_forcings is None:
             self._sync_to_device()
             self.device.advance(1)
+            self._last_stage = 2
             self._device_ahead = True
         else:
             for i in range(self.n_stages):
@@ -291,6 +297,7 @@ class ERKGenericShuOsher(TimeIntegrator):
         steps between exports: no Python between the launches)."""
         self._sync_to_device()
         self.device.advance(int(n_steps))
+        self._last_stage = 2
         self._device_ahead = True
 
     def diagnostics(self):

@@ -72,10 +72,12 @@ class FlowSolver2d(object):
         from .cgproject import project_to_p1
         mesh = self.mesh2d
         csize = self.fields.h_elem_size_2d
-        bath = np.maximum(self.fields.bathymetry_2d.dat.data_ro, 0.05)
-        u = np.sqrt(float(g_grav)*bath) + float(u_scale)                   # P1 nodal
-        # integrand csize/u: evaluate at quadrature points from the P1 fields
-        sol = project_to_p1(mesh, lambda lam, cells: (csize.dat.data_ro[cells] @ lam)/(u[cells] @ lam))
+        # per-cell nodal values: the bathymetry may be CG-P1 (per vertex) or a continuous field held in DG-P1 (per cell node)
+        bath = np.maximum(self.fields.bathymetry_2d.cell_node_values(), 0.05)
+        u = np.sqrt(float(g_grav)*bath) + float(u_scale)                   # (N, k) P1 nodal
+        cs = csize.cell_node_values()
+        # integrand csize/u at the quadrature points (project_to_p1 integrates over all cells, in mesh order)
+        sol = project_to_p1(mesh, lambda lam, cells: (cs @ lam)/(u @ lam))
         out = Function(self.function_spaces.P1_2d)
         out.assign(sol)
         return out
@@ -347,9 +349,12 @@ class FlowSolver2d(object):
         self.iteration = iteration
         self.simulation_time = t
         self.next_export_t += self.options.simulation_export_time
+        # a restart that writes into a NEW directory exports its initial state and numbers its exports from i_export; a
+        # continuation in the same directory does neither (solver2d.py:905-912)
+        self.export_initial_state = outputdir != self.options.output_directory
+        offset = 0 if self.export_initial_state else 1
         for ex in self.exporters.values():
-            ex.set_next_export_ix(self.i_export + 1)
-        self.export_initial_state = False
+            ex.set_next_export_ix(self.i_export + offset)
 
     # ------------------------------------------------------------------ time loop
     def print_state(self, cputime, print_header=False):
