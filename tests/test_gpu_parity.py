@@ -389,3 +389,41 @@ def test_vertex_field_upload_equals_nodal_upload(hip_lib, cells):
         res.append(dev.tendency())
         dev.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize('setup', ['walls', 'open', 'fields+sources+drag', 'wetting-drying'])
+def test_boundary_inline_variant_gives_the_bits_of_the_epilogue_variant(hip_lib, setup):
+    """Small launches (<= two waves per SIMD) evaluate boundary fluxes inside the facet loop (template parameter BINL), large
+    ones after the cell's outputs are finished from reloaded values: a partition and the whole mesh take different variants,
+    so their results must not differ in a single bit (tests/test_distributed.py compares them bitwise)."""
+    import os
+    from thetis_amd import _lib
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = channel_case(nx=24, ny=9, seed=17, amp_eta=0.3, amp_u=0.2)
+    cxy = mesh.cell_xy()
+    out = {}
+    for force in ('0', '1'):
+        os.environ['THETIS_AMD_BND_INLINE'] = force
+        try:
+            dev = Swe2dDevice(mesh, bath, 2.0, boundary_len=mesh.boundary_len)
+            if setup == 'open':
+                for m, funcs in {1: {'elev': 0.3}, 2: {'un': 0.2}, 3: {'flux': 1e4, 'elev': 0.1}, 4: {'uv': (0.1, -0.2)}}.items():
+                    dev.set_bc(m, funcs)
+            elif setup == 'fields+sources+drag':
+                elev_f = 0.3*np.sin(cxy[:, :, 1]/4000.0)
+                uv_f = np.stack([0.2*np.sin(cxy[:, :, 0]/2e4), -0.1*np.cos(cxy[:, :, 0]/3e4)], axis=2)
+                for m, funcs in {1: {'elev': elev_f}, 2: {'un': 0.1*np.cos(cxy[:, :, 1]/6000.0), 'elev': 0.1},
+                                 3: {'uv': uv_f, 'drag': 0.01}, 4: {'flux': 0.5e4*np.ones_like(elev_f)}}.items():
+                    dev.set_bc(m, funcs)
+                dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+                dev.set_field(_lib.FIELD_CORIOLIS, 1e-4*np.ones_like(eta))
+            elif setup == 'wetting-drying':
+                dev.set_wetting_and_drying(0.5)
+                dev.set_bc(2, {'elev': 0.2})
+            dev.set_state(uv, eta)
+            dev.advance(3)
+            out[force] = dev.get_state()
+            dev.close()
+        finally:
+            os.environ.pop('THETIS_AMD_BND_INLINE', None)
+    assert np.array_equal(out['0'][0], out['1'][0]) and np.array_equal(out['0'][1], out['1'][1])

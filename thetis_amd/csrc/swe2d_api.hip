@@ -173,8 +173,9 @@ bool has_sources(const Handle *h)
 typedef void (*stage_kernel_t)(const SweStageArgs);
 
 template <bool NL, bool LF, bool U0>
-stage_kernel_t pick_src(bool src)
+stage_kernel_t pick_src(bool src, bool binl)
 {
+    if (binl) return src ? swe_stage_kernel<NL, LF, U0, true, false, false, true> : swe_stage_kernel<NL, LF, U0, false, false, false, true>;
     return src ? swe_stage_kernel<NL, LF, U0, true, false> : swe_stage_kernel<NL, LF, U0, false, false>;
 }
 // wetting-drying variants (nonlinear equations only)
@@ -190,12 +191,12 @@ stage_kernel_t pick_kernel_wd(bool lf, bool u0, bool src, bool quad)
     return u0 ? pick_wd_src<false, true>(src, quad) : pick_wd_src<false, false>(src, quad);
 }
 template <bool NL, bool LF>
-stage_kernel_t pick_u0(bool u0, bool src) { return u0 ? pick_src<NL, LF, true>(src) : pick_src<NL, LF, false>(src); }
+stage_kernel_t pick_u0(bool u0, bool src, bool binl) { return u0 ? pick_src<NL, LF, true>(src, binl) : pick_src<NL, LF, false>(src, binl); }
 template <bool NL>
-stage_kernel_t pick_lf(bool lf, bool u0, bool src) { return lf ? pick_u0<NL, true>(u0, src) : pick_u0<NL, false>(u0, src); }
-stage_kernel_t pick_kernel(bool nl, bool lf, bool u0, bool src)
+stage_kernel_t pick_lf(bool lf, bool u0, bool src, bool binl) { return lf ? pick_u0<NL, true>(u0, src, binl) : pick_u0<NL, false>(u0, src, binl); }
+stage_kernel_t pick_kernel(bool nl, bool lf, bool u0, bool src, bool binl)
 {
-    return nl ? pick_lf<true>(lf, u0, src) : pick_lf<false>(lf, u0, src);
+    return nl ? pick_lf<true>(lf, u0, src, binl) : pick_lf<false>(lf, u0, src, binl);
 }
 // triangles with the horizontal viscosity fused in (swe_visc_interior)
 template <bool NL, bool LF, bool U0>
@@ -241,6 +242,7 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.valpha = h->valpha;
     a.idx4 = h->idx4; a.idx2 = h->idx2;
     a.cell_begin = c0; a.cell_end = c1;
+    a.stagger = 0;
     a.g = h->par.g_grav;
     a.sigma_lf = h->par.lax_friedrichs_velocity_scaling_factor;
     a.dt = h->par.dt;
@@ -271,16 +273,27 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.nu_v = h->nu_v; a.nu_const = h->nu_const;
     a.visc_sipg = 3.0*h->sipg_factor;
     a.visc_grad_div = h->visc_grad_div; a.visc_grad_depth = h->visc_grad_depth;
+    // grids of up to ~3.5 waves per SIMD (1024 SIMDs; measured: -10 % at 125 k cells, -12 % at 137 k, even at 250 k, +6 % at
+    // 500 k): the boundary-inline variant (same bits, shorter critical path of the
+    // boundary waves, 2 waves/SIMD); THETIS_AMD_BND_INLINE=0/1 forces the choice (parity tests, A/B)
+    const char *env_binl_s = std::getenv("THETIS_AMD_BND_INLINE");       // read per launch: tests switch it inside one process
+    const int env_binl = env_binl_s ? std::atoi(env_binl_s) : -1;
+    const bool binl = env_binl >= 0 ? env_binl != 0 : (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK <= 3584;
     stage_kernel_t kern = fused_visc
         ? pick_kernel_visc(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
         : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4)
         : (h->npc == 4)
         ? pick_kernel_quad(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
-        : pick_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h));
+        : pick_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), binl);
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
     // the XCD-chunked block map needs a grid that is a multiple of 8; surplus blocks exit immediately
     const int grid = ((nblocks + 7)/8)*8;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
+    // experiments (tools/kbench.py): THETIS_AMD_STAGE_LDS = dynamic LDS bytes per workgroup (caps the workgroups per CU:
+    // 160 KiB / bytes), THETIS_AMD_STAGGER = late start of every other group of 8 workgroups, in units of 512 cycles
+    static const int env_lds = std::getenv("THETIS_AMD_STAGE_LDS") ? std::atoi(std::getenv("THETIS_AMD_STAGE_LDS")) : 0;
+    static const int env_stagger = std::getenv("THETIS_AMD_STAGGER") ? std::atoi(std::getenv("THETIS_AMD_STAGGER")) : 0;
+    a.stagger = env_stagger;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), env_lds, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     if (h->visc) {
         // HorizontalViscosityTerm: U_out[uv] += beta*dt*M^-1 R_visc(U_in) on the same cells (swe2d_sipg.h)
@@ -1807,7 +1820,7 @@ int swe2d_p2p_push(swe2d_handle *hh, int channel, int i_buffer)
                      + (size_t)(channel*SWE_P2P_MAX_PEERS + z.remote_flag[i])*SWE_P2P_FLAG_STRIDE;
     }
     a.ctr = z.ctr + channel;
-    hipLaunchKernelGGL(swe_p2p_push_kernel, dim3(grid_for(np*h->n_send)), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(swe_p2p_push_kernel, dim3(std::min(SWE_P2P_MAX_BLOCKS, grid_for(np*h->n_send))), dim3(256), 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     return SWE2D_OK;
 }
@@ -1831,7 +1844,8 @@ int swe2d_p2p_wait_unpack(swe2d_handle *hh, int channel, int i_buffer)
     a.slot = (size_t)h->n_recv*np;
     a.timeout_ticks = (unsigned long long)(z.timeout_s*1e8);
     a.ctr = z.ctr + channel;
-    hipLaunchKernelGGL(swe_p2p_unpack_kernel, dim3(grid_for(np*h->n_recv)), dim3(256), 0, h->stream, a);
+    a.fence = z.zone_kind == 3;
+    hipLaunchKernelGGL(swe_p2p_unpack_kernel, dim3(std::min(SWE_P2P_MAX_BLOCKS, grid_for(np*h->n_recv))), dim3(256), 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     return SWE2D_OK;
 }
@@ -1855,3 +1869,14 @@ int swe2d_p2p_status(swe2d_handle *hh, int64_t *epochs_sent, int64_t *epochs_rec
 }
 
 }  // extern "C"
+
+#ifdef SWE_WAVE_TIMING
+// profiling build only: copies the time stamps of the LAST stage launch (5 x SWE_WT_MAX, 100 MHz ticks)
+extern "C" int swe2d_debug_read_wave_timing(swe2d_handle *hh, unsigned long long *out)
+{
+    Handle *h = H(hh);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(swe_wave_ts), sizeof(unsigned long long)*6*SWE_WT_MAX));
+    return SWE2D_OK;
+}
+#endif

@@ -68,6 +68,7 @@ struct SweStageArgs {
     double nu_const, visc_sipg;   // visc_sipg = sipg_factor * cp, cp = 3
     int visc_grad_div, visc_grad_depth;
     int cell_begin, cell_end;
+    int stagger;                  // small grids: odd workgroups start `stagger` x 512 cycles late (see launch_stage)
     double g, sigma_lf, dt;
     double a0, a1, beta;   // U_out = beta*k + a0*U0 + a1*U_in
     // optional cell-local terms (SRC variant)
@@ -186,6 +187,11 @@ __device__ __forceinline__ double swe_int2(const double a[3], const double b[3])
     return (a[0] + a[1] + a[2])*(b[0] + b[1] + b[2]) + a[0]*b[0] + a[1]*b[1] + a[2]*b[2];
 }
 
+// a*b + c*d with the contraction spelled out.  The boundary code below is inlined into two variants of the stage kernel (and
+// into the quadrilateral kernel); a sum of two products leaves it to the compiler which product is fused, and it chooses
+// differently from one context to the other - one ulp, which would break the bitwise agreement of the variants.
+__device__ __forceinline__ double swe_dot2(double a, double b, double c, double d) { return fma(a, b, c*d); }
+
 // Boundary facet (closed wall or open boundary); rare, so written for clarity with unit normals.
 // Returns the form values f (residual is -f) already multiplied by the facet length.
 struct SweBcFieldValues { double elev, u, v, un, flux; };   // Function-valued boundary data at the quadrature point
@@ -195,10 +201,14 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
                                                double hq, double Hq, double alq, double nxs, double nys, double L,
                                                double rL, const SweBcFieldValues &bf, double &fu, double &fv, double &fe)
 {
+    // No implicit contraction in the boundary code: it is inlined into several kernels (epilogue / inline-boundary variants,
+    // quadrilaterals), which must agree bit for bit, and where the compiler fuses depends on the surrounding code.  Every
+    // operation below is individually rounded; fma() is written out where wanted.
+#pragma clang fp contract(off)
     const double g = p.g;
     const double nx = nxs*rL, ny = nys*rL;
     const int kind = (marker < SWE_MAX_MARKERS) ? p.bc.kind[marker] : 0;
-    const double un_own = uq*nx + vq*ny;
+    const double un_own = swe_dot2(uq, nx, vq, ny);
     if (kind == 0) {
         // land boundary, shallowwater_eq.py:377-381 and :489-497
         const double head_rie = eq + sqrt(Hq/g)*un_own;
@@ -228,13 +238,13 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
             v_ext = s*ny;
         }
         const double H_ext = swe_depth_pt<NONLIN, WD>(hq, e_ext, alq);
-        const double un_jump = (uq - u_ext)*nx + (vq - v_ext)*ny;
+        const double un_jump = swe_dot2(uq - u_ext, nx, vq - v_ext, ny);
         const double eta_rie = 0.5*(eq + e_ext) + sqrt(Hq/g)*un_jump;                 // :374
         fu = g*eta_rie*nx;
         fv = g*eta_rie*ny;
         const double h_av = 0.5*(Hq + H_ext);
         const double eta_jump = eq - e_ext;
-        const double un_avg = 0.5*((uq + u_ext)*nx + (vq + v_ext)*ny);
+        const double un_avg = 0.5*swe_dot2(uq + u_ext, nx, vq + v_ext, ny);
         const double un_rie = un_avg + sqrt(g/h_av)*eta_jump;                          // :438
         const double eta_rie2 = 0.5*(eq + e_ext) + sqrt(h_av/g)*un_jump;               // :440
         fe = swe_depth_pt<NONLIN, WD>(hq, eta_rie2, alq)*un_rie;                       // :441-442
@@ -247,7 +257,7 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
     const double cdb = (marker < SWE_MAX_MARKERS) ? p.bc.drag[marker] : -1.0;
     if (cdb >= 0.0) {                                                                  // BoundaryDragTerm :717-724
         const double utx = uq - un_own*nx, uty = vq - un_own*ny;
-        const double mag = sqrt(utx*utx + uty*uty);
+        const double mag = sqrt(swe_dot2(utx, utx, uty, uty));
         fu += cdb*mag*utx;
         fv += cdb*mag*uty;
     }
@@ -265,6 +275,7 @@ __device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int ma
                                                    double nys, double L, double rL, double &Fau, double &Fbu,
                                                    double &Fav, double &Fbv, double &Fae, double &Fbe)
 {
+#pragma clang fp contract(off)
     // Function-valued boundary data live on the same DG nodes as the state: read the two facet nodes of this cell
     const int kind = (marker < SWE_MAX_MARKERS) ? p.bc.kind[marker] : 0;
     const size_t S = p.stride;
@@ -282,10 +293,12 @@ __device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int ma
     for (int q = 0; q < 2; q++) {
         const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
         SweBcFieldValues bf;
-        bf.elev = xa*fea + xb*feb; bf.u = xa*fua + xb*fub; bf.v = xa*fva + xb*fvb; bf.un = xa*fna + xb*fnb;
-        bf.flux = xa*fxa + xb*fxb;
-        const double uq = xa*ua + xb*ub, vq = xa*va + xb*vb, eq = xa*ea + xb*eb, hq = xa*ha + xb*hb;
-        const double Hq = xa*Ha + xb*Hb, alq = xa*ala + xb*alb;     // Ha, Hb: nodal total depth (h, h + eta or D)
+        bf.elev = swe_dot2(xa, fea, xb, feb); bf.u = swe_dot2(xa, fua, xb, fub); bf.v = swe_dot2(xa, fva, xb, fvb);
+        bf.un = swe_dot2(xa, fna, xb, fnb);
+        bf.flux = swe_dot2(xa, fxa, xb, fxb);
+        const double uq = swe_dot2(xa, ua, xb, ub), vq = swe_dot2(xa, va, xb, vb), eq = swe_dot2(xa, ea, xb, eb),
+                     hq = swe_dot2(xa, ha, xb, hb);
+        const double Hq = swe_dot2(xa, Ha, xb, Hb), alq = swe_dot2(xa, ala, xb, alb);   // Ha, Hb: nodal total depth (h, h + eta or D)
         double fu, fv, fe;
         swe_boundary_flux<NONLIN, LF, WD>(p, marker, uq, vq, eq, hq, Hq, alq, nxs, nys, L, rL, bf, fu, fv, fe);
         Fau += xa*fu; Fbu += xb*fu;
@@ -311,9 +324,12 @@ __device__ __forceinline__ int swe_ldi(swe_rsrc_t r, unsigned voff, unsigned sof
 {
     return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
 }
+#ifndef SWE_ST_AUX
+#define SWE_ST_AUX 0             // cache policy of the state stores (experiments: 16 = sc1 write-through, 2 = nt)
+#endif
 __device__ __forceinline__ void swe_st(swe_rsrc_t r, unsigned voff, unsigned soff, double x)
 {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(swe_u32x2, x), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(swe_u32x2, x), r, voff, soff, SWE_ST_AUX);
 }
 
 // Optional cell-local terms (SRC kernel variant): Coriolis, linear / quadratic / Manning drag, atmospheric pressure
@@ -461,17 +477,25 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
 // beta*dt*M^-1(boundary flux) to the output values that are still in registers.  The residual is linear in the facet
 // contributions, so the result is the same up to summation order.  (The quadrilateral kernel runs at 2 waves/SIMD either
 // way and keeps its boundary facets inline: the epilogue costs 14 % there.)
+// 2A of a triangle for the boundary correction, with the contraction spelled out: the two variants of the stage kernel
+// (swe_boundary_epilogue / BINL) see these operands in different forms (reloaded / shared with the facet normals) and, left to
+// the compiler, fuse a different one of the two products - a one-ulp difference in sfac
+__device__ __forceinline__ double swe_cross2a(double x0, double y0, double x1, double y1, double x2, double y2)
+{
+    return fma(x1 - x0, y2 - y0, -((y1 - y0)*(x2 - x0)));
+}
+
 template <bool NONLIN, bool LF, bool WD>
 __device__ __forceinline__ void swe_boundary_epilogue(const SweStageArgs &p, int k, int nb0, int nb1, int nb2,
                                                       double ou[3], double ov[3], double oe[3])
 {
+#pragma clang fp contract(off)
     const size_t S = p.stride;
     double sfac;                                         // 6 dt beta / (2A)
     {
         const int v0 = p.cv[k], v1 = p.cv[S + k], v2 = p.cv[2*S + k];
         const double x0 = p.vx[v0], y0 = p.vy[v0];
-        const double cross = (p.vx[v1] - x0)*(p.vy[v2] - y0) - (p.vy[v1] - y0)*(p.vx[v2] - x0);
-        sfac = 6.0*p.dt*p.beta*swe_rcp(cross);
+        sfac = 6.0*p.dt*p.beta*swe_rcp(swe_cross2a(x0, y0, p.vx[v1], p.vy[v1], p.vx[v2], p.vy[v2]));
     }
     // one facet at a time, everything addressed in memory by plane index: no dynamically indexed register arrays
 #pragma unroll 1
@@ -490,7 +514,7 @@ __device__ __forceinline__ void swe_boundary_epilogue(const SweStageArgs &p, int
         const double Hb = WD ? swe_wd_depth(hb + eb, alb) : (NONLIN ? hb + eb : hb);
         const double nxs = yb_ - ya_, nys = xa_ - xb_;
         double L, rL;
-        swe_sqrt_rsqrt(nxs*nxs + nys*nys, L, rL);
+        swe_sqrt_rsqrt(swe_dot2(nxs, nxs, nys, nys), L, rL);
         double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
         swe_boundary_facet<NONLIN, LF, WD>(p, -nbf, k, a, b, ua, ub, va_, vb_, ea, eb, ha, hb, Ha, Hb, ala, alb, nxs, nys,
                                            L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
@@ -499,9 +523,11 @@ __device__ __forceinline__ void swe_boundary_epilogue(const SweStageArgs &p, int
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const double wa = (i == a) ? 3.0 : -1.0, wb = (i == b) ? 3.0 : -1.0;
-            ou[i] += sfac*(wa*dau + wb*dbu);
-            ov[i] += sfac*(wa*dav + wb*dbv);
-            oe[i] += sfac*(wa*dae + wb*dbe);
+            // explicit fma: the inline-boundary variant of the stage kernel repeats these lines with compile-time wa, wb and
+            // must round identically (left to the compiler, constant weights contract differently from run-time ones)
+            ou[i] = fma(sfac, fma(wa, dau, wb*dbu), ou[i]);
+            ov[i] = fma(sfac, fma(wa, dav, wb*dbv), ov[i]);
+            oe[i] = fma(sfac, fma(wa, dae, wb*dbe), oe[i]);
         }
     }
 }
@@ -643,9 +669,40 @@ __device__ __forceinline__ void swe_visc_interior(const SweStageArgs &p, int k, 
 // Register budget: see the -Rpass-analysis output quoted in DESIGN.md; forcing more waves per SIMD than the allocation
 // gives naturally spills (20 B/lane at 128 VGPRs for the first stage: +16 MB scratch writes per launch, not faster;
 // 5-6 waves: 2-3x slower).
-template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD, bool VISC = false>
+#ifdef SWE_WAVE_TIMING
+// profiling build only (tools/wavetiming.py): per one-wave workgroup the 100 MHz wall clock at five points of the stage kernel
+#define SWE_WT_MAX 8192
+__device__ unsigned long long swe_wave_ts[6][SWE_WT_MAX];
+#define SWE_WT(i) do { if (threadIdx.x == 0 && blockIdx.x < SWE_WT_MAX) swe_wave_ts[i][blockIdx.x] = wall_clock64(); } while (0)
+#define SWE_WT_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define SWE_WT(i)
+#define SWE_WT_DRAIN()
+#endif
+
+// BINL: boundary fluxes are evaluated inside the facet loop from the values the lane already holds, instead of reloading the
+// facet's nodes in swe_boundary_epilogue.  Costs registers (184-202 VGPRs = 2 waves/SIMD instead of 3), removes two dependent
+// memory round trips from the waves that own boundary cells: the variant for grids of at most two waves per SIMD (small
+// partitions), where those waves were the last to finish.  Same bits as the epilogue path (tests/test_gpu_parity.py).
+template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD, bool VISC = false, bool BINL = false>
 __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(const SweStageArgs p)
 {
+    SWE_WT(0);
+#ifdef SWE_WAVE_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < SWE_WT_MAX) {      // where does the wave run?  HW_ID (wave, simd, cu, sh, se) | XCC_ID << 32
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        swe_wave_ts[5][blockIdx.x] = (unsigned long long)hw | ((unsigned long long)(xcc & 0xf) << 32);
+    }
+#endif
+    if (p.stagger > 0 && (blockIdx.x & 8)) {
+        // Small grids run in lock step: every wave waits for its loads (a bandwidth-bound phase), then every wave computes (a
+        // VALU-bound phase).  Delaying half of the workgroups by about half a memory phase lets one half compute while the
+        // other half loads.  (blockIdx & 8: whole groups of 8 consecutive blocks = one block per XCD.)
+#pragma unroll 1
+        for (int i = 0; i < p.stagger; i++) __builtin_amdgcn_s_sleep(8);
+    }
 #ifdef SWE_NO_XCD_MAP
     const int lb = blockIdx.x;
 #else
@@ -668,6 +725,10 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         nb[0] = q4.x; nb[1] = q4.y; nb[2] = q4.z;
         vid[0] = q4.w; vid[1] = q2.x; vid[2] = q2.y;
     }
+#ifdef SWE_WAVE_TIMING
+    if (nb[0] == 0x7fffffff) return;          // forces the index loads to land before the time stamp
+    SWE_WT(1);
+#endif
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         u[i] = swe_ld(gu, k8, i*S8);
@@ -727,6 +788,11 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
             if (HASU0) we[i] += p.a0*(swe_wd_depth(h[i] + e0[i], al[i]) - h[i]);
         }
     }
+    SWE_WT_DRAIN();
+    SWE_WT(2);
+    // 2A exactly as swe_boundary_epilogue forms it (the boundary correction must not depend on which of the two paths ran)
+    const double bnd_cross = BINL ? swe_cross2a(px[0], py[0], px[1], py[1], px[2], py[2]) : 0.0;
+    double bF[3][6];
     // scaled outward normals nF_f = |F| n of facet f (vertex f -> f+1); counter-clockwise cell
     double nx[3], ny[3];
 #pragma unroll
@@ -775,7 +841,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     for (int f = 0; f < 3; f++) {
         const int a = f, b = (f + 1) % 3;
         const double nxs = nx[f], nys = ny[f];
-        const double len2 = nxs*nxs + nys*nys;
+        const double len2 = swe_dot2(nxs, nxs, nys, nys);
         double L, rL;
         swe_sqrt_rsqrt(len2, L, rL);
         if (VISC) { Lf[f] = L; rLf[f] = rL; }
@@ -815,6 +881,16 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
                 Fae += xa*fe; Fbe += xb*fe;
             }
         }       // boundary facets: see swe_boundary_epilogue
+        else if (BINL) {
+            // the flux of a boundary facet, from the values this lane already holds (no second trip to memory: on a small
+            // grid the dependent reloads of swe_boundary_epilogue made the boundary waves the last ones to finish, 8.5-9.6 us
+            // against 5.7 us for an interior wave of the 125 k-cell partition); applied to the finished outputs below with the
+            // arithmetic of swe_boundary_epilogue, so both paths give the same bits
+            double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0, b4 = 0.0, b5 = 0.0;
+            swe_boundary_facet<NONLIN, LF, WD>(p, -nb[f], k, a, b, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
+                                               al[a], al[b], nxs, nys, L, rL, b0, b1, b2, b3, b4, b5);
+            bF[f][0] = b0; bF[f][1] = b1; bF[f][2] = b2; bF[f][3] = b3; bF[f][4] = b4; bF[f][5] = b5;
+        }
         bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
         bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
         be[a] -= 0.5*Fae; be[b] -= 0.5*Fbe;
@@ -836,8 +912,30 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         oe[i] = s*(4.0*be[i] - se) + we[i];          // eta, or zeta = D - h with wetting-drying
     }
     // boundary facets were skipped above; their correction is added to the finished outputs (see swe_boundary_epilogue)
-    if ((nb[0] | nb[1] | nb[2]) < 0) swe_boundary_epilogue<NONLIN, LF, WD>(p, k, nb[0], nb[1], nb[2], ou, ov, oe);
+    if (BINL && (nb[0] | nb[1] | nb[2]) < 0) {
+#pragma clang fp contract(off)
+        const double sfac = 6.0*p.dt*p.beta*swe_rcp(bnd_cross);
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            if (nb[f] >= 0) continue;
+            const int a = f, b = (f + 1) % 3;
+            const double dau = -0.5*bF[f][0], dbu = -0.5*bF[f][1], dav = -0.5*bF[f][2], dbv = -0.5*bF[f][3],
+                         dae = -0.5*bF[f][4], dbe = -0.5*bF[f][5];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const double wa = (i == a) ? 3.0 : -1.0, wb = (i == b) ? 3.0 : -1.0;
+                ou[i] = fma(sfac, fma(wa, dau, wb*dbu), ou[i]);      // as in swe_boundary_epilogue, bit for bit
+                ov[i] = fma(sfac, fma(wa, dav, wb*dbv), ov[i]);
+                oe[i] = fma(sfac, fma(wa, dae, wb*dbe), oe[i]);
+            }
+        }
+    }
+    if (!BINL && (nb[0] | nb[1] | nb[2]) < 0) swe_boundary_epilogue<NONLIN, LF, WD>(p, k, nb[0], nb[1], nb[2], ou, ov, oe);
     const swe_rsrc_t gou = swe_rsrc(p.uout), gov = swe_rsrc(p.uout + 3*S), goe = swe_rsrc(p.uout + 6*S);
+#ifdef SWE_WAVE_TIMING
+    if (ou[0] == 1.2345e300) return;          // the arithmetic has to be finished before the time stamp
+    SWE_WT(3);
+#endif
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         swe_st(gou, k8, i*S8, ou[i]);
@@ -849,6 +947,8 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
             swe_st(goe, k8, i*S8, oe[i]);
         }
     }
+    SWE_WT_DRAIN();
+    SWE_WT(4);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

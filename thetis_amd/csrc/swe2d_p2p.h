@@ -16,9 +16,10 @@
 // The epoch counters live in device memory and are advanced by the kernels themselves, so a captured graph replays correctly.
 //
 // Memory ordering (MI355X_MICROARCH.md, inter-workgroup visibility): payload is written with system-scope (sc0 sc1,
-// write-through) stores; every workgroup drains them (s_waitcnt vmcnt(0)), one lane issues a system-scope release fence and
-// takes a ticket; the last workgroup to arrive fences again and then stores the flags (system scope, release).  The consumer
-// polls with system-scope relaxed loads, fences (acquire) once, and reads the payload with system-scope loads.
+// write-through) stores; every workgroup drains them (s_waitcnt vmcnt(0)) and takes a ticket; the last workgroup to arrive
+// stores the flags (system scope).  The consumer polls with system-scope relaxed loads and reads the payload with
+// system-scope loads from the uncached zone (no cache holds a line of it).  One workgroup per CU at most: per-workgroup
+// fences (buffer_wbl2 / buffer_inv) cost microseconds each and are not needed for write-through payload.
 // Every spin is bounded (wall clock); a timeout is recorded in the status word, the kernel carries on and later waits of the
 // channel do not spin at all, so a lost peer costs one timeout and can never hang the GPU.
 #pragma once
@@ -60,6 +61,7 @@ struct SweP2pUnpackArgs {
     const double *zone;                                      // my landing data of this channel, slot 0
     size_t slot;                                             // doubles between slot 0 and slot 1
     unsigned long long timeout_ticks;                        // wall_clock64 ticks (100 MHz)
+    int fence;                                               // zone is ordinary device memory: acquire fence after the wait
     SweP2pCounters *ctr;
 };
 
@@ -72,31 +74,47 @@ __device__ __forceinline__ double swe_p2p_load(const double *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // global_load_dwordx2 sc0 sc1
 }
 
+#define SWE_P2P_MAX_BLOCKS 256            // one 256-lane workgroup per CU, grid-stride over the message
+
+__device__ __forceinline__ int swe_p2p_peer_of(const SweP2pPushArgs &a, int j)
+{
+    int p = 0;
+#pragma unroll 1
+    for (int i = 1; i < a.n_peers; i++) if (j >= a.off[i]) p = i;                    // segments are sorted by offset
+    return p;
+}
+
 __global__ __launch_bounds__(256) void swe_p2p_push_kernel(const SweP2pPushArgs a)
 {
     const unsigned long long target = a.ctr->epoch_send + 1ull;      // every workgroup reads it before the last one advances it
-    const int t = blockIdx.x*256 + threadIdx.x;
-    if (t < a.np*a.n_send) {
-        const int j = t/a.np, q = t - a.np*j;
-        int p = 0;
-#pragma unroll 1
-        for (int i = 1; i < a.n_peers; i++) if (j >= a.off[i]) p = i;                // segments are sorted by offset
-        if (j < a.off[p] + a.cnt[p]) {
-            const double x = a.planes[(size_t)q*a.stride + a.send_cells[j]];
-            swe_p2p_store(a.rdata[p] + (target & 1ull)*a.rslot[p] + (size_t)(j - a.off[p])*a.np + q, x);
+    const int total = a.np*a.n_send, step = gridDim.x*256;
+    // four elements per lane and trip: the gathers from the planes are all in flight before the first remote store
+    for (int t0 = blockIdx.x*256 + threadIdx.x; t0 < total; t0 += 4*step) {
+        double x[4];
+        int j[4], q[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int t = t0 + r*step;
+            j[r] = t/a.np; q[r] = t - a.np*j[r];
+            x[r] = t < total ? a.planes[(size_t)q[r]*a.stride + a.send_cells[j[r]]] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (t0 + r*step >= total) continue;
+            const int p = swe_p2p_peer_of(a, j[r]);
+            swe_p2p_store(a.rdata[p] + (target & 1ull)*a.rslot[p] + (size_t)(j[r] - a.off[p])*a.np + q[r], x[r]);
         }
     }
+    // the payload stores are write-through (sc0 sc1): nothing of them stays dirty in the L2, draining them is the release
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                                // system scope
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int ticket = __hip_atomic_fetch_add(&a.ctr->ticket_send, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == gridDim.x - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
+        const unsigned int ticket = __hip_atomic_fetch_add(&a.ctr->ticket_send, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == gridDim.x - 1) {                                               // every workgroup has drained its stores
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                            // belt and braces, once per exchange
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             for (int i = 0; i < a.n_peers; i++)
-                __hip_atomic_store(a.rflag[i], target, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.rflag[i], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             a.ctr->ticket_send = 0u;
             a.ctr->epoch_send = target;
         }
@@ -112,21 +130,33 @@ __global__ __launch_bounds__(256) void swe_p2p_unpack_kernel(const SweP2pUnpackA
         for (int i = 0; i < a.n_from && !late; i++) {
             while (__hip_atomic_load(a.flag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
                 if (wall_clock64() - t0 > a.timeout_ticks) { late = true; break; }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
         }
         if (late && blockIdx.x == 0) atomicAdd(&a.ctr->timeouts, 1u);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                                // system scope
+        // an uncached / fine-grained zone is read past the caches by the system-scope loads below; an ordinary allocation
+        // (fallback) needs the caches invalidated first
+        if (a.fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
     __syncthreads();
-    const int t = blockIdx.x*256 + threadIdx.x;
-    if (t < a.np*a.n_recv) {
-        const int j = t/a.np, q = t - a.np*j;
-        a.planes[(size_t)q*a.stride + a.recv_cells[j]] = swe_p2p_load(a.zone + (target & 1ull)*a.slot + t);
+    asm volatile("" ::: "memory");
+    const int total = a.np*a.n_recv, step = gridDim.x*256;
+    const double *src = a.zone + (target & 1ull)*a.slot;
+    for (int t0 = blockIdx.x*256 + threadIdx.x; t0 < total; t0 += 4*step) {
+        double x[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) x[r] = (t0 + r*step < total) ? swe_p2p_load(src + t0 + r*step) : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int t = t0 + r*step;
+            if (t >= total) continue;
+            const int j = t/a.np, q = t - a.np*j;
+            a.planes[(size_t)q*a.stride + a.recv_cells[j]] = x[r];
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int ticket = __hip_atomic_fetch_add(&a.ctr->ticket_recv, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int ticket = __hip_atomic_fetch_add(&a.ctr->ticket_recv, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ticket == gridDim.x - 1) {
             a.ctr->ticket_recv = 0u;
             a.ctr->epoch_recv = target;

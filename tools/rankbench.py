@@ -20,6 +20,10 @@ def main():
     ap.add_argument('--steps', type=int, default=240)
     ap.add_argument('--overlap', type=int, default=0)
     ap.add_argument('--prewarm', type=float, default=0.5)
+    ap.add_argument('--exchange', default='stub', help="'stub': pack/unpack kernels, no transfer; 'p2p': the peer-to-peer "
+                    "kernels pushing into this rank's OWN landing zone (same-device loopback: timing only)")
+    ap.add_argument('--nosplit', action='store_true')
+    ap.add_argument('--graph-mode', default=None)
     args = ap.parse_args()
     import torch
     import bench
@@ -32,9 +36,30 @@ def main():
         def finish(self, reqs):
             pass
 
+    class LoopbackP2P(object):
+        """every peer's landing segment is my own: the push kernel stores into this device's zone, the wait finds the flags
+        it raised itself (strips: what I send to a peer is as long as what I receive from it)"""
+        def __init__(self, dev, part, rank, world, n_tracers=0, group=None):
+            k = int(part.cells.shape[1])
+            self.dev, self.n_channels = dev, 1
+            dev.p2p_create([3*k])
+            _, base, kind = dev.p2p_export()
+            self.zone_kind = {1: 'uncached', 2: 'fine-grained', 3: 'device'}.get(kind, '?')
+            peers = sorted(part.send)
+            assert peers == sorted(part.recv) and all(part.send[q][1] == part.recv[q][1] for q in peers)
+            dev.p2p_connect([base]*len(peers), [part.send[q][0] for q in peers], [part.send[q][1] for q in peers],
+                            [part.recv[q][0] for q in peers], list(range(len(peers))), [len(part.recv_cells)]*len(peers),
+                            n_from=len(peers))
+
+        def timeouts(self):
+            return self.dev.p2p_status(1)[2]
+
     distributed.HaloExchanger = NoExchange
+    distributed.P2PHalo = LoopbackP2P
     mesh, bath, uv, eta = bench.build_case()
-    s = distributed.DistributedSwe2d(mesh, bath, bench.DT, args.rank, args.world, 0, exchange_every=args.every, overlap_stages=args.overlap)
+    s = distributed.DistributedSwe2d(mesh, bath, bench.DT, args.rank, args.world, 0, exchange_every=args.every, overlap_stages=args.overlap,
+                                     exchange=('p2p' if args.exchange == 'p2p' else 'rccl'), split_last_stage=not args.nosplit,
+                                     graph_mode=args.graph_mode)
     s.set_state_global(uv, eta)
     p = s.part
     t0 = time.perf_counter()
@@ -51,7 +76,9 @@ def main():
         s.advance(args.steps, use_graph=True)
         s.synchronize()
         best = min(best, time.perf_counter() - t0)
-    print(json.dumps({'world': args.world, 'rank': args.rank, 'every': args.every, 'overlap': args.overlap, 'n_owned': int(p.n_owned),
+    to = s.p2p.timeouts() if s.p2p is not None else 0
+    print(json.dumps({'exchange': args.exchange, 'split': not args.nosplit, 'p2p_timeouts': to,
+                      'world': args.world, 'rank': args.rank, 'every': args.every, 'overlap': args.overlap, 'n_owned': int(p.n_owned),
                       'n_ghost': int(p.n_ghost), 'n_send': int(len(p.send_cells)), 'graph': s.graphed, 'graph_mode': s.graph_mode,
                       'us_per_step': 1e6*best/args.steps}))
 
