@@ -273,12 +273,11 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.nu_v = h->nu_v; a.nu_const = h->nu_const;
     a.visc_sipg = 3.0*h->sipg_factor;
     a.visc_grad_div = h->visc_grad_div; a.visc_grad_depth = h->visc_grad_depth;
-    // grids of up to ~3.5 waves per SIMD (1024 SIMDs; measured: -10 % at 125 k cells, -12 % at 137 k, even at 250 k, +6 % at
-    // 500 k): the boundary-inline variant (same bits, shorter critical path of the
-    // boundary waves, 2 waves/SIMD); THETIS_AMD_BND_INLINE=0/1 forces the choice (parity tests, A/B)
+    // Boundary-inline variant of the triangle kernel (BINL, swe2d_kernels.h): measured faster than the epilogue variant at every
+    // size (us/step, same box: 125 k cells 36.6 -> 29.1, 250 k 53.0 -> 46.7, 500 k 81.7 -> 76.1, 1 M 138.1 -> 135.7) although it
+    // runs at 2 waves/SIMD; both give the same bits.  THETIS_AMD_BND_INLINE=0 selects the epilogue variant (parity test, A/B).
     const char *env_binl_s = std::getenv("THETIS_AMD_BND_INLINE");       // read per launch: tests switch it inside one process
-    const int env_binl = env_binl_s ? std::atoi(env_binl_s) : -1;
-    const bool binl = env_binl >= 0 ? env_binl != 0 : (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK <= 3584;
+    const bool binl = env_binl_s ? std::atoi(env_binl_s) != 0 : true;
     stage_kernel_t kern = fused_visc
         ? pick_kernel_visc(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
         : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4)

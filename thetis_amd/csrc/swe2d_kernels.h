@@ -206,12 +206,16 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
     // operation below is individually rounded; fma() is written out where wanted.
 #pragma clang fp contract(off)
     const double g = p.g;
+    // square roots and quotients through the v_rsq / v_rcp based helpers (~10 instructions each) instead of the IEEE library
+    // sequences (~40-60): a wave that owns one boundary cell executes this code for all its lanes, and on a small partition
+    // a quarter of the waves do
+    const double rg = swe_rcp(g);
     const double nx = nxs*rL, ny = nys*rL;
     const int kind = (marker < SWE_MAX_MARKERS) ? p.bc.kind[marker] : 0;
     const double un_own = swe_dot2(uq, nx, vq, ny);
     if (kind == 0) {
         // land boundary, shallowwater_eq.py:377-381 and :489-497
-        const double head_rie = eq + sqrt(Hq/g)*un_own;
+        const double head_rie = eq + swe_sqrt(Hq*rg)*un_own;
         fu = g*head_rie*nx;
         fv = g*head_rie*ny;
         fe = 0.0;
@@ -233,23 +237,27 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
             v_ext = un_ext*ny;
         } else if (kind & SWE_BC_FLUX) {
             const double H0 = swe_depth_pt<NONLIN, WD>(hq, e_ext, alq);
-            const double s = ((kind & SWE_BC_FLUX_FIELD) ? bf.flux : p.bc.flux[marker])/(H0*p.bc.len[marker]);
+            const double s = ((kind & SWE_BC_FLUX_FIELD) ? bf.flux : p.bc.flux[marker])*swe_rcp(H0*p.bc.len[marker]);
             u_ext = s*nx;
             v_ext = s*ny;
         }
         const double H_ext = swe_depth_pt<NONLIN, WD>(hq, e_ext, alq);
         const double un_jump = swe_dot2(uq - u_ext, nx, vq - v_ext, ny);
-        const double eta_rie = 0.5*(eq + e_ext) + sqrt(Hq/g)*un_jump;                 // :374
+        double sq_Hg, sq_gH;                                                           // sqrt(H/g), sqrt(g/H)
+        swe_sqrt_rsqrt(Hq*rg, sq_Hg, sq_gH);
+        const double eta_rie = 0.5*(eq + e_ext) + sq_Hg*un_jump;                       // :374
         fu = g*eta_rie*nx;
         fv = g*eta_rie*ny;
         const double h_av = 0.5*(Hq + H_ext);
         const double eta_jump = eq - e_ext;
         const double un_avg = 0.5*swe_dot2(uq + u_ext, nx, vq + v_ext, ny);
-        const double un_rie = un_avg + sqrt(g/h_av)*eta_jump;                          // :438
-        const double eta_rie2 = 0.5*(eq + e_ext) + sqrt(h_av/g)*un_jump;               // :440
+        double sq_hg, sq_gh;                                                           // sqrt(h_av/g), sqrt(g/h_av)
+        swe_sqrt_rsqrt(h_av*rg, sq_hg, sq_gh);
+        const double un_rie = un_avg + sq_gh*eta_jump;                                 // :438
+        const double eta_rie2 = 0.5*(eq + e_ext) + sq_hg*un_jump;                      // :440
         fe = swe_depth_pt<NONLIN, WD>(hq, eta_rie2, alq)*un_rie;                       // :441-442
         if (NONLIN) {
-            const double un_rie3 = un_avg + sqrt(g/Hq)*eta_jump;                       // :507
+            const double un_rie3 = un_avg + sq_gH*eta_jump;                            // :507
             fu += un_rie3*0.5*(u_ext + uq);
             fv += un_rie3*0.5*(v_ext + vq);
         }
@@ -257,7 +265,7 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
     const double cdb = (marker < SWE_MAX_MARKERS) ? p.bc.drag[marker] : -1.0;
     if (cdb >= 0.0) {                                                                  // BoundaryDragTerm :717-724
         const double utx = uq - un_own*nx, uty = vq - un_own*ny;
-        const double mag = sqrt(swe_dot2(utx, utx, uty, uty));
+        const double mag = swe_sqrt(swe_dot2(utx, utx, uty, uty));
         fu += cdb*mag*utx;
         fv += cdb*mag*uty;
     }
@@ -790,9 +798,6 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     }
     SWE_WT_DRAIN();
     SWE_WT(2);
-    // 2A exactly as swe_boundary_epilogue forms it (the boundary correction must not depend on which of the two paths ran)
-    const double bnd_cross = BINL ? swe_cross2a(px[0], py[0], px[1], py[1], px[2], py[2]) : 0.0;
-    double bF[3][6];
     // scaled outward normals nF_f = |F| n of facet f (vertex f -> f+1); counter-clockwise cell
     double nx[3], ny[3];
 #pragma unroll
@@ -846,7 +851,10 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         swe_sqrt_rsqrt(len2, L, rL);
         if (VISC) { Lf[f] = L; rLf[f] = rL; }
         double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
-        if (nb[f] >= 0) {
+        // Branch-free: a boundary facet carries this cell's own values as "neighbour" traces (finite numbers), its flux is
+        // evaluated like any other and discarded below.  With `if (nb[f] >= 0)` around this block the compiler sank the six
+        // trace loads of a facet into the branch - a third dependent trip to memory in every wave.
+        {
             // neighbour's nodal depth on this facet (bathymetry and alpha are continuous: same vertices)
             const double Dna = WD ? swe_wd_depth(h[a] + ena[f], al[a]) : 0.0;
             const double Dnb = WD ? swe_wd_depth(h[b] + enb[f], al[b]) : 0.0;
@@ -880,17 +888,8 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
                 Fav += xa*fv; Fbv += xb*fv;
                 Fae += xa*fe; Fbe += xb*fe;
             }
-        }       // boundary facets: see swe_boundary_epilogue
-        else if (BINL) {
-            // the flux of a boundary facet, from the values this lane already holds (no second trip to memory: on a small
-            // grid the dependent reloads of swe_boundary_epilogue made the boundary waves the last ones to finish, 8.5-9.6 us
-            // against 5.7 us for an interior wave of the 125 k-cell partition); applied to the finished outputs below with the
-            // arithmetic of swe_boundary_epilogue, so both paths give the same bits
-            double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0, b4 = 0.0, b5 = 0.0;
-            swe_boundary_facet<NONLIN, LF, WD>(p, -nb[f], k, a, b, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
-                                               al[a], al[b], nxs, nys, L, rL, b0, b1, b2, b3, b4, b5);
-            bF[f][0] = b0; bF[f][1] = b1; bF[f][2] = b2; bF[f][3] = b3; bF[f][4] = b4; bF[f][5] = b5;
         }
+        if (nb[f] < 0) { Fau = 0.0; Fbu = 0.0; Fav = 0.0; Fbv = 0.0; Fae = 0.0; Fbe = 0.0; }   // see swe_boundary_epilogue / BINL
         bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
         bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
         be[a] -= 0.5*Fae; be[b] -= 0.5*Fbe;
@@ -913,14 +912,30 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     }
     // boundary facets were skipped above; their correction is added to the finished outputs (see swe_boundary_epilogue)
     if (BINL && (nb[0] | nb[1] | nb[2]) < 0) {
+        // Boundary facets from the values this lane still holds (no second trip to memory: on a small grid the dependent
+        // reloads of swe_boundary_epilogue made the boundary waves the last ones to finish).  Every lane works on ITS
+        // boundary facet - the wave runs the boundary code once (twice where a corner cell is among its lanes), not once per
+        // facet slot - in ascending facet order and with the arithmetic of swe_boundary_epilogue: the same bits.
 #pragma clang fp contract(off)
-        const double sfac = 6.0*p.dt*p.beta*swe_rcp(bnd_cross);
-#pragma unroll
-        for (int f = 0; f < 3; f++) {
-            if (nb[f] >= 0) continue;
-            const int a = f, b = (f + 1) % 3;
-            const double dau = -0.5*bF[f][0], dbu = -0.5*bF[f][1], dav = -0.5*bF[f][2], dbv = -0.5*bF[f][3],
-                         dae = -0.5*bF[f][4], dbe = -0.5*bF[f][5];
+        // 2A exactly as swe_boundary_epilogue forms it, from the facet normals that are still live: x1 - x0 = -ny[0],
+        // y2 - y0 = -nx[2], y1 - y0 = nx[0], x2 - x0 = ny[2] (negation is exact)
+        const double sfac = 6.0*p.dt*p.beta*swe_rcp(fma(-ny[0], -nx[2], -(nx[0]*ny[2])));
+        int rem = (nb[0] < 0 ? 1 : 0) | (nb[1] < 0 ? 2 : 0) | (nb[2] < 0 ? 4 : 0);
+#define SWE_SEL3(x, i) ((i) == 0 ? (x)[0] : ((i) == 1 ? (x)[1] : (x)[2]))
+#pragma unroll 1
+        while (rem) {
+            const int f = (rem & 1) ? 0 : ((rem & 2) ? 1 : 2);
+            rem &= rem - 1;
+            const int a = f, b = (f == 2) ? 0 : f + 1;
+            const double nxs = SWE_SEL3(nx, f), nys = SWE_SEL3(ny, f);
+            double L, rL;
+            swe_sqrt_rsqrt(swe_dot2(nxs, nxs, nys, nys), L, rL);
+            double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
+            swe_boundary_facet<NONLIN, LF, WD>(p, -SWE_SEL3(nb, f), k, a, b, SWE_SEL3(u, a), SWE_SEL3(u, b), SWE_SEL3(v, a),
+                                               SWE_SEL3(v, b), SWE_SEL3(e, a), SWE_SEL3(e, b), SWE_SEL3(h, a), SWE_SEL3(h, b),
+                                               SWE_SEL3(H, a), SWE_SEL3(H, b), SWE_SEL3(al, a), SWE_SEL3(al, b), nxs, nys, L, rL,
+                                               Fau, Fbu, Fav, Fbv, Fae, Fbe);
+            const double dau = -0.5*Fau, dbu = -0.5*Fbu, dav = -0.5*Fav, dbv = -0.5*Fbv, dae = -0.5*Fae, dbe = -0.5*Fbe;
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 const double wa = (i == a) ? 3.0 : -1.0, wb = (i == b) ? 3.0 : -1.0;
@@ -929,6 +944,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
                 oe[i] = fma(sfac, fma(wa, dae, wb*dbe), oe[i]);
             }
         }
+#undef SWE_SEL3
     }
     if (!BINL && (nb[0] | nb[1] | nb[2]) < 0) swe_boundary_epilogue<NONLIN, LF, WD>(p, k, nb[0], nb[1], nb[2], ou, ov, oe);
     const swe_rsrc_t gou = swe_rsrc(p.uout), gov = swe_rsrc(p.uout + 3*S), goe = swe_rsrc(p.uout + 6*S);

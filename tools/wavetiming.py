@@ -46,6 +46,7 @@ def main():
         t = ts[:5, :nw].astype(np.int64)
         ok = (t[4] > 0)
         t = t[:, ok]
+        ph = [(t[i + 1] - t[i]) for i in range(4)]
         hw = ts[5, :nw][ok]
         # gfx9 HW_ID: wave_id [3:0], simd_id [5:4], pipe [7:6], cu_id [11:8], sh_id [12], se_id [15:13]; XCC id in bits 32..35
         simd_key = ((hw >> np.uint64(4)) & np.uint64(0x3)) | (((hw >> np.uint64(8)) & np.uint64(0xff)) << np.uint64(2)) \
@@ -57,6 +58,19 @@ def main():
         load = per_simd[inv]                       # waves sharing the SIMD of each wave
         tot = (t[4] - t[0])/100.0
         by_load = {int(l): float(tot[load == l].mean()) for l in np.unique(load)}
+        # which waves finish last?  phases of the slowest 5 %, and how many of them own boundary cells
+        nb_dev = np.asarray(dev._keep[2])                     # (N, k) neighbours in device numbering, < 0: boundary
+        bnd_cell = (nb_dev < 0).any(axis=1)
+        per = (nw + 7) >> 3
+        blocks = np.nonzero(ok)[0]
+        lb = (blocks & 7)*per + (blocks >> 3)
+        has_bnd = np.array([bnd_cell[64*b:64*b + 64].any() for b in lb])
+        slow = tot >= np.percentile(tot, 95)
+        tail = {'n': int(slow.sum()), 'boundary_waves_in_tail': int(has_bnd[slow].sum()), 'boundary_waves_total': int(has_bnd.sum()),
+                'index_us': float(ph[0][slow].mean())/100.0, 'loads_us': float(ph[1][slow].mean())/100.0,
+                'arithmetic_us': float(ph[2][slow].mean())/100.0, 'stores_us': float(ph[3][slow].mean())/100.0,
+                'boundary_wave_total_us': float(tot[has_bnd].mean()) if has_bnd.any() else None,
+                'interior_wave_total_us': float(tot[~has_bnd].mean())}
         base = t[0].min()
         us = lambda x: float(x)/100.0
         ph = [(t[i + 1] - t[i]) for i in range(4)]
@@ -67,7 +81,7 @@ def main():
                     'simds_used': int(len(per_simd)), 'cus_used': int(len(per_cu)),
                     'waves_per_simd_hist': {int(k): int(v) for k, v in zip(*np.unique(per_simd, return_counts=True))},
                     'waves_per_cu_hist': {int(k): int(v) for k, v in zip(*np.unique(per_cu, return_counts=True))},
-                    'wave_total_us_by_simd_load': by_load, 'wave_total_max_us': float(tot.max()),
+                    'wave_total_us_by_simd_load': by_load, 'slowest_5pct': tail, 'wave_total_max_us': float(tot.max()),
                     'index_loads_us': us(ph[0].mean()), 'gathers_and_own_loads_us': us(ph[1].mean()),
                     'arithmetic_us': us(ph[2].mean()), 'stores_us': us(ph[3].mean())})
     print(json.dumps({'n_cells': mesh.num_cells, 'stage': args.stage, 'runs': res}, indent=1))
