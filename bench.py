@@ -36,6 +36,8 @@ PREWARM_S = 0.5                          # seconds of untimed stepping before th
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_ELEMENT_STEP = 684.0          # 180 + 252 + 252 algorithmic bytes per triangle per step
 BYTES_PER_ELEMENT_UPDATE = BYTES_PER_ELEMENT_STEP/3.0
+TRAFFIC_JSON = 'r01n_traffic.json'         # committed PMC passes of the stage kernel on this workload (profiles/README.md)
+BEYOND_CACHE_NX, BEYOND_CACHE_NY = 2000, 1000   # 4M triangles: 3 x 288 MB of state, beyond the 256 MB Infinity Cache
 
 
 def build_case(nx=NX, ny=NY):
@@ -51,45 +53,106 @@ def build_case(nx=NX, ny=NY):
     return mesh, bath, uv, eta
 
 
-def cpu_baseline(mesh, bath, uv, eta, budget_s=12.0):
-    """The oracle's C restatement (OpenMP, all host cores) timed on a bounded number of steps of the same workload."""
-    from oracle.ref_lib import RefSWE
-    ref = RefSWE(mesh.cell_xy(), mesh.cell_nbr, mesh.cell_nbr_facet, bath[mesh.cells], boundary_len=mesh.boundary_len)
-    n = mesh.num_cells
-    ref.advance(uv, eta, DT, 1)                                   # warm-up (thread pool, page faults)
-    t0 = time.perf_counter()
-    ref.advance(uv, eta, DT, 2)
-    t2 = time.perf_counter() - t0
-    steps = int(max(2, min(100, budget_s/(t2/2.0))))
-    t0 = time.perf_counter()
-    u_c, e_c = ref.advance(uv, eta, DT, steps)
-    t = time.perf_counter() - t0
-    out = {'value': n*3.0*steps/t, 'unit': 'element-updates/s', 'cores': ref.num_threads(), 'kind': 'port',
-           'sample': '{:d} SSPRK33 steps of the same 1M-triangle workload, oracle/swe2d_ref.c (OpenMP, {:d} threads), '
-                     '{:.1f} s'.format(steps, ref.num_threads(), t)}
-    # single-core figure (SURVEY.md 8d): one step of the same workload on one thread
-    nthreads = ref.num_threads()
-    ref.set_num_threads(1)
-    t0 = time.perf_counter()
-    ref.advance(uv, eta, DT, 1)
-    out['value_1core'] = n*3.0/(time.perf_counter() - t0)
-    ref.set_num_threads(nthreads)
-    return out, (steps, u_c, e_c)
+def cpu_baseline(budget_s=10.0):
+    """The oracle's C restatement (oracle/swe2d_ref.c, swe2d_ref_advance_blocked: persistent OpenMP team, cell blocks owned and
+    first touched by one thread each, fused stage update) timed on the host cores on a bounded number of steps of the same
+    1M-triangle workload - in a process of its own (oracle/cpu_bench.py) so that the OpenMP runtime starts with thread
+    binding; two placements are tried (one thread per hardware thread, one per second hardware thread) and the faster one is
+    reported.  Returns (cpu_baseline dict, steps, uv, eta of the reported run)."""
+    import subprocess
+    import tempfile
+    best, best_state = None, None
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    # a container may see every hardware thread of the host and still be held to a CPU-time quota (cgroup v2 cpu.max, e.g.
+    # "1600000 100000" = 16 CPUs on the 256-thread GPU boxes): more threads than that only contend for the same 16 CPUs
+    quota = ncpu
+    try:
+        q, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            quota = max(1, min(ncpu, int(float(q)/float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    tried = []
+    placements = [('one thread per CPU of the cgroup quota, spread over the cores', quota, 'spread')]
+    if quota < ncpu:
+        placements.append(('twice the cgroup quota', min(ncpu, 2*quota), 'spread'))
+    else:
+        placements.append(('every second hardware thread', max(1, ncpu//2), 'spread'))
+    with tempfile.TemporaryDirectory() as tmp:
+        for label, nthreads, bind in placements:
+            env = dict(os.environ)
+            env.update({'OMP_PROC_BIND': bind, 'OMP_PLACES': 'cores', 'OMP_NUM_THREADS': str(nthreads)})
+            out_npz = os.path.join(tmp, 'state{:d}.npz'.format(nthreads))
+            try:
+                r = subprocess.run([sys.executable, '-m', 'oracle.cpu_bench', '--nx', str(NX), '--ny', str(NY), '--budget',
+                                    str(budget_s/2.0), '--out', out_npz], capture_output=True, text=True, env=env, cwd=ROOT,
+                                   timeout=600)
+                d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+            except Exception as e:                       # the baseline is reported, never fatal
+                tried.append({'placement': label, 'error': str(e)[:200]})
+                continue
+            tried.append({'placement': label, 'threads': d['cores'], 'value': d['value'], 'speedup_over_1core': d['speedup_over_1core']})
+            if best is None or d['value'] > best['value']:
+                best, best_label = d, label
+                z = np.load(out_npz)
+                best_state = (int(z['steps']), z['uv'], z['eta'])
+            if quota == 1:
+                break
+    if best is None:
+        return {'value': None, 'unit': 'element-updates/s', 'cores': 0, 'kind': 'port', 'sample': 'failed', 'tried': tried}, None
+    out = {'value': best['value'], 'unit': 'element-updates/s', 'cores': best['cores'], 'kind': 'port',
+           'sample': 'median of 3 runs of {:d} SSPRK33 steps of the same 1M-triangle workload, oracle/swe2d_ref.c '
+                     '(swe2d_ref_advance_blocked: one OpenMP region, static cell blocks first-touched by their owner, fused '
+                     'stage update), {:d} threads ({:}); the host shows {:d} hardware threads, the cgroup CPU quota is {:d}; '
+                     'OMP_PROC_BIND={:} OMP_PLACES=cores, {:.1f} s per run'.format(
+                         best['steps'], best['cores'], best_label, ncpu, quota, best['omp']['OMP_PROC_BIND'],
+                         float(np.median(best['seconds']))),
+           'cpu_quota': quota, 'hardware_threads': ncpu,
+           'value_1core': best['value_1core'], 'speedup_over_1core': best['speedup_over_1core'],
+           'sample_1core': 'median of 3 runs of 2 steps on one thread', 'placements': tried}
+    return out, best_state
 
 
 def measured_traffic(n_cells):
     """HBM bytes per stage-kernel launch from the committed PMC passes (rocprofv3 cannot run inside the timed bench):
     FETCH_SIZE/WRITE_SIZE collected in separate --pmc runs and corrected with the calibration copy kernel, see
     profiles/README.md.  Only valid for the workload it was measured on."""
-    path = os.path.join(ROOT, 'profiles', 'r01n_traffic.json')
+    path = os.path.join(ROOT, 'profiles', TRAFFIC_JSON)
     try:
         with open(path) as f:
             t = json.load(f)
         if n_cells == 1000000:
-            return float(t['traffic_bytes_per_launch']), 'profiles/r01n_traffic.json'
+            return float(t['traffic_bytes_per_launch']), 'profiles/' + TRAFFIC_JSON
     except (OSError, KeyError, ValueError):
         pass
     return None, None
+
+
+def beyond_cache(args):
+    """The same stage kernel on a 4M-triangle mesh of the same channel (state 3 x 288 MB: nothing of it stays in the 256 MB
+    Infinity Cache from one stage to the next, which the 1M-triangle headline workload - 3 x 72 MB - largely does):
+    roofline.frac_beyond_cache, measured like roofline.frac (HIP events around K back-to-back steps on the launch stream)."""
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = build_case(BEYOND_CACHE_NX, BEYOND_CACHE_NY)
+    n = mesh.num_cells
+    dev = Swe2dDevice(mesh, bath, DT/2.0, device_id=0)
+    dev.set_state(uv, eta)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < max(0.3, args.prewarm):
+        dev.advance(50)
+        dev.synchronize()
+    steps = max(10, min(50, args.steps))
+    ms_events = min(dev.advance_timed(steps, per_launch=False)[0] for _ in range(2))
+    ms_kernel = ms_events/(3.0*steps)
+    assert np.isfinite(dev.diagnostics()).all()
+    dev.close()
+    achieved = BYTES_PER_ELEMENT_UPDATE*n/(ms_kernel*1e-3)/1e9
+    return {'frac_beyond_cache': achieved/HBM_PEAK_GBS,
+            'beyond_cache': {'workload': 'RectangleMesh({:d},{:d}) = {:d} triangles, same channel and kernel'.format(
+                                 BEYOND_CACHE_NX, BEYOND_CACHE_NY, n),
+                             'achieved': achieved, 'avg_launch_ms': ms_kernel, 'steps': steps,
+                             'algorithmic_bytes_per_launch': BYTES_PER_ELEMENT_UPDATE*n,
+                             'element_updates_per_s': n*3.0*steps/(ms_events*1e-3)}}
 
 
 def run_single(args):
@@ -137,16 +200,20 @@ def run_single(args):
                      'kernel': 'swe_stage_kernel', 'avg_launch_ms': ms_kernel, 'avg_launch_ms_per_launch_events': ms_kernel_each,
                      'algorithmic_bytes_per_launch': BYTES_PER_ELEMENT_UPDATE*n},
     }
+    if not args.no_beyond_cache:
+        out['roofline'].update(beyond_cache(args))
     if not args.no_cpu:
-        cb, (steps_c, u_c, e_c) = cpu_baseline(mesh, bath, uv, eta)
+        cb, state = cpu_baseline()
         out['cpu_baseline'] = cb
-        # parity of the two paths on the baseline's sample (reported)
-        dev.set_state(uv, eta)
-        dev.advance(steps_c)
-        u_g, e_g = dev.get_state()
-        out['cpu_baseline']['gpu_vs_cpu_rel_linf'] = {
-            'uv': float(np.abs(u_g - u_c).max()/np.abs(u_c).max()),
-            'eta': float(np.abs(e_g - e_c).max()/np.abs(e_c).max()), 'steps': steps_c}
+        if state is not None:
+            # parity of the two paths on the baseline's sample (reported)
+            steps_c, u_c, e_c = state
+            dev.set_state(uv, eta)
+            dev.advance(steps_c)
+            u_g, e_g = dev.get_state()
+            out['cpu_baseline']['gpu_vs_cpu_rel_linf'] = {
+                'uv': float(np.abs(u_g - u_c).max()/np.abs(u_c).max()),
+                'eta': float(np.abs(e_g - e_c).max()/np.abs(e_c).max()), 'steps': steps_c}
     dev.close()
     print(json.dumps(out))
 
@@ -157,6 +224,7 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--no-beyond-cache', action='store_true', help='skip the 4M-triangle run behind roofline.frac_beyond_cache')
     ap.add_argument('--prewarm', type=float, default=PREWARM_S, help='seconds of untimed stepping before the warm-up steps')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -136,6 +136,18 @@ class RefSWE(object):
         self.lib.swe2d_ref_advance(ctypes.byref(self.s), _ptr(uv), _ptr(eta), dt, n_steps, _ptr(work))
         return uv, eta
 
+    def advance_blocked(self, uv, eta, dt, n_steps):
+        """The timed CPU baseline (swe2d_ref_advance_blocked): same bits as ``advance``; returns (uv, eta, seconds in the
+        step loop)."""
+        uv = np.array(uv, dtype=np.float64, order='C'); eta = np.array(eta, dtype=np.float64, order='C')
+        fn = self.lib.swe2d_ref_advance_blocked
+        fn.restype = ctypes.c_double
+        fn.argtypes = [ctypes.POINTER(_RefStruct), _dp, _dp, ctypes.c_double, ctypes.c_int]
+        sec = fn(ctypes.byref(self.s), _ptr(uv), _ptr(eta), dt, int(n_steps))
+        if sec < 0:
+            raise RuntimeError('swe2d_ref_advance_blocked: configuration outside its scope (or out of memory)')
+        return uv, eta, sec
+
     def num_threads(self):
         return self.lib.swe2d_ref_num_threads()
 

@@ -24,9 +24,11 @@
  * Quadrilaterals (k = 4, parallelograms): bilinear basis on the unit square, nodes counter-clockwise from (0,0);
  * cell integrals by the 2 x 2 Gauss-Legendre rule, M^-1 = (1/A) m^-1 (x) m^-1 with m^-1 = [[4,-2],[-2,4]].
  */
+#define _POSIX_C_SOURCE 200112L
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -170,6 +172,7 @@ static double quad_cell_terms(const swe2d_ref_t *m, int k, const double *p, cons
 }
 
 /* k = M^-1 (dt R(U)) for one cell */
+/* k_uv, k_eta: the output of THIS cell (2*npc and npc doubles) */
 static void cell_tendency(const swe2d_ref_t *m, int k, const double *uv, const double *eta, double dt,
                           double *k_uv, double *k_eta)
 {
@@ -372,9 +375,9 @@ static void cell_tendency(const swe2d_ref_t *m, int k, const double *uv, const d
         const double s4 = dt/A;
         for (int i = 0; i < 4; i++) {
             const int n1 = (i + 1) % 4, n2 = (i + 2) % 4, n3 = (i + 3) % 4;
-            k_uv[8*(size_t)k + 2*i] = s4*(16.0*bu[i] - 8.0*bu[n1] - 8.0*bu[n3] + 4.0*bu[n2]);
-            k_uv[8*(size_t)k + 2*i + 1] = s4*(16.0*bv[i] - 8.0*bv[n1] - 8.0*bv[n3] + 4.0*bv[n2]);
-            k_eta[4*(size_t)k + i] = s4*(16.0*be[i] - 8.0*be[n1] - 8.0*be[n3] + 4.0*be[n2]);
+            k_uv[2*i] = s4*(16.0*bu[i] - 8.0*bu[n1] - 8.0*bu[n3] + 4.0*bu[n2]);
+            k_uv[2*i + 1] = s4*(16.0*bv[i] - 8.0*bv[n1] - 8.0*bv[n3] + 4.0*bv[n2]);
+            k_eta[i] = s4*(16.0*be[i] - 8.0*be[n1] - 8.0*be[n3] + 4.0*be[n2]);
         }
         return;
     }
@@ -382,9 +385,9 @@ static void cell_tendency(const swe2d_ref_t *m, int k, const double *uv, const d
     const double s = 3.0*dt/A;
     const double su = bu[0] + bu[1] + bu[2], sv = bv[0] + bv[1] + bv[2], se = be[0] + be[1] + be[2];
     for (int i = 0; i < 3; i++) {
-        k_uv[6*(size_t)k + 2*i] = s*(4.0*bu[i] - su);
-        k_uv[6*(size_t)k + 2*i + 1] = s*(4.0*bv[i] - sv);
-        k_eta[3*(size_t)k + i] = s*(4.0*be[i] - se);
+        k_uv[2*i] = s*(4.0*bu[i] - su);
+        k_uv[2*i + 1] = s*(4.0*bv[i] - sv);
+        k_eta[i] = s*(4.0*be[i] - se);
     }
 }
 
@@ -394,7 +397,7 @@ void swe2d_ref_tendency(const swe2d_ref_t *m, const double *uv, const double *et
 {
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < m->n_cells; k++)
-        cell_tendency(m, k, uv, eta, dt, k_uv, k_eta);
+        cell_tendency(m, k, uv, eta, dt, k_uv + 2*(size_t)m->npc*(size_t)k, k_eta + (size_t)m->npc*(size_t)k);
 }
 
 /* n_steps SSPRK33 steps in place; work must hold 4 states = 4*9*N doubles.  Shu-Osher form, expression
@@ -439,6 +442,103 @@ void swe2d_ref_advance(const swe2d_ref_t *m, double *uv, double *eta, double dt,
         for (long i = 0; i < (long)ne; i++)
             eta[i] = m->wd ? wd_combine(m, i, ke[i]*B32, e0[i], A30, eta[i], A32) : ke[i]*B32 + e0[i]*A30 + eta[i]*A32;
     }
+}
+
+/* ---- the timed CPU baseline of bench.py ------------------------------------------------------------------------------
+ * The same n_steps SSPRK33 steps as swe2d_ref_advance, bit for bit (tests/test_oracle_known_answers.py), organised the way
+ * a production CPU code would be: ONE parallel region for the whole run (a persistent thread team, three barriers per step),
+ * every thread owns a contiguous block of cells, residual + mass inverse + Shu-Osher combine fused per cell on three rotating
+ * state buffers (no tendency arrays, no copies of U0), and every per-cell array - mesh data and state - is copied into
+ * buffers that the owning thread touches first, so that with OMP_PROC_BIND=close the pages of a block live on the NUMA node
+ * of the cores that sweep it.  Closed walls / constant forcing, no wetting-drying (the bench workload); returns the seconds
+ * spent in the step loop (copy-in / copy-out excluded), or -1 if the configuration is outside that scope. */
+static void *ref_alloc(size_t bytes)
+{
+    void *p = NULL;
+    return posix_memalign(&p, 4096, bytes ? bytes : 4096) == 0 ? p : NULL;
+}
+
+double swe2d_ref_advance_blocked(const swe2d_ref_t *m, double *uv, double *eta, double dt, int n_steps)
+{
+    if (m->wd) return -1.0;
+    const size_t n = (size_t)m->n_cells, k = (size_t)m->npc;
+    static const double A30 = 0.33333333333333337, A32 = 0.6666666666666666, B32 = 0.6666666666666666;
+    swe2d_ref_t loc = *m;
+    int *nbr = ref_alloc(n*k*sizeof(int));
+    signed char *nbf = ref_alloc(n*k);
+    double *xy = ref_alloc(n*k*2*sizeof(double)), *h = ref_alloc(n*k*sizeof(double));
+    double *U[3], *E[3];
+    for (int b = 0; b < 3; b++) { U[b] = ref_alloc(n*k*2*sizeof(double)); E[b] = ref_alloc(n*k*sizeof(double)); }
+    double seconds = -1.0;
+    if (nbr && nbf && xy && h && U[0] && U[1] && U[2] && E[0] && E[1] && E[2]) {
+        loc.nbr = nbr; loc.nbf = nbf; loc.xy = xy; loc.h = h;
+#ifdef _OPENMP
+        double t0 = 0.0;
+#pragma omp parallel
+#else
+        clock_t c0 = 0;
+#endif
+        {
+            /* first touch = owner: the static schedule below is the one every later loop uses */
+#pragma omp for schedule(static)
+            for (long c = 0; c < (long)n; c++) {
+                memcpy(nbr + c*k, m->nbr + c*k, k*sizeof(int));
+                memcpy(nbf + c*k, m->nbf + c*k, k);
+                memcpy(xy + c*k*2, m->xy + c*k*2, k*2*sizeof(double));
+                memcpy(h + c*k, m->h + c*k, k*sizeof(double));
+                memcpy(U[0] + c*k*2, uv + c*k*2, k*2*sizeof(double));
+                memcpy(E[0] + c*k, eta + c*k, k*sizeof(double));
+                memset(U[1] + c*k*2, 0, k*2*sizeof(double)); memset(U[2] + c*k*2, 0, k*2*sizeof(double));
+                memset(E[1] + c*k, 0, k*sizeof(double)); memset(E[2] + c*k, 0, k*sizeof(double));
+            }
+#ifdef _OPENMP
+#pragma omp master
+            t0 = omp_get_wtime();
+#else
+            c0 = clock();
+#endif
+            for (int it = 0; it < n_steps; it++) {
+                /* stage i reads buffer i (and U0 = buffer 0), writes buffer (i + 1) % 3; the implicit barrier of each
+                 * `omp for` separates the stages; stage 2 overwrites U0 in place (only its own cell reads it) */
+                for (int st = 0; st < 3; st++) {
+                    const double *ui = U[st], *ei = E[st];
+                    double *uo = U[(st + 1) % 3], *eo = E[(st + 1) % 3];
+#pragma omp for schedule(static)
+                    for (long c = 0; c < (long)n; c++) {
+                        double ku[8], ke[4];
+                        cell_tendency(&loc, (int)c, ui, ei, dt, ku, ke);
+                        const double *u0 = U[0] + c*k*2, *e0 = E[0] + c*k, *u1 = ui + c*k*2, *e1 = ei + c*k;
+                        double *ou = uo + c*k*2, *oe = eo + c*k;
+                        if (st == 0) {
+                            for (size_t i = 0; i < 2*k; i++) ou[i] = ku[i]*1.0 + u0[i]*1.0;
+                            for (size_t i = 0; i < k; i++) oe[i] = ke[i]*1.0 + e0[i]*1.0;
+                        } else if (st == 1) {
+                            for (size_t i = 0; i < 2*k; i++) ou[i] = ku[i]*0.25 + u0[i]*0.75 + u1[i]*0.25;
+                            for (size_t i = 0; i < k; i++) oe[i] = ke[i]*0.25 + e0[i]*0.75 + e1[i]*0.25;
+                        } else {
+                            for (size_t i = 0; i < 2*k; i++) ou[i] = ku[i]*B32 + u0[i]*A30 + u1[i]*A32;
+                            for (size_t i = 0; i < k; i++) oe[i] = ke[i]*B32 + e0[i]*A30 + e1[i]*A32;
+                        }
+                    }
+                }
+            }
+#ifdef _OPENMP
+#pragma omp master
+            seconds = omp_get_wtime() - t0;
+#pragma omp barrier
+#else
+            seconds = (double)(clock() - c0)/CLOCKS_PER_SEC;
+#endif
+#pragma omp for schedule(static)
+            for (long c = 0; c < (long)n; c++) {
+                memcpy(uv + c*k*2, U[0] + c*k*2, k*2*sizeof(double));
+                memcpy(eta + c*k, E[0] + c*k, k*sizeof(double));
+            }
+        }
+    }
+    free(nbr); free(nbf); free(xy); free(h);
+    for (int b = 0; b < 3; b++) { free(U[b]); free(E[b]); }
+    return seconds;
 }
 
 int swe2d_ref_num_threads(void)

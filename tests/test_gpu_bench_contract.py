@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_prints_one_json_line_with_the_contract_fields(hip_lib, env):
     e = dict(os.environ)
     e.update(env)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '2', '--no-cpu', '--prewarm', '0.05'],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '2', '--no-cpu', '--prewarm', '0.05']
+                       + (['--no-beyond-cache'] if env else []),
                        capture_output=True, text=True, env=e, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -34,6 +35,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields(hip_lib, env):
     # whole-job throughput = cells * 3 stages * steps / time
     assert abs(d['value'] - 1e6*3*6/(d['ms_per_step']*6e-3))/d['value'] < 1e-9
     assert 1e9 < d['value'] < 1e11
+    if not env:
+        # the same kernel beyond the Infinity Cache (4M triangles), reported next to the headline fraction
+        assert 0.05 < rf['frac_beyond_cache'] < 1.0 and rf['beyond_cache']['algorithmic_bytes_per_launch'] == 228.0*4e6
     if env.get('THETIS_AMD_TUNE_SCHEDULE'):
         tuned = d['config']['schedule_tuning']
         assert len(tuned) >= 5 and all(t['us_per_step'] > 0 for t in tuned)

@@ -427,3 +427,4 @@ def test_boundary_inline_variant_gives_the_bits_of_the_epilogue_variant(hip_lib,
         finally:
             os.environ.pop('THETIS_AMD_BND_INLINE', None)
     assert np.array_equal(out['0'][0], out['1'][0]) and np.array_equal(out['0'][1], out['1'][1])
+

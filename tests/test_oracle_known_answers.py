@@ -258,3 +258,14 @@ def test_steady_state_channel_linear_drag():
         err2 += np.sum(wA*((eta @ bary) - (1.0 - (x @ bary)/lx))**2)
     assert math.sqrt(err2/(lx*ly)) < 1e-2
     assert np.abs(uv[:, :, 0] - 1.0).max() < 2e-2 and np.abs(uv[:, :, 1]).max() < 1e-2
+
+
+def test_blocked_baseline_stepper_gives_the_bits_of_the_plain_one(ref_so):
+    """bench.py's cpu_baseline times swe2d_ref_advance_blocked (one OpenMP region, owner-touched cell blocks, fused stage
+    update on three rotating buffers): same operator, same expression order, bit for bit the stepper the parity tests use."""
+    from helpers import channel_case, make_ref, quad_case
+    for mesh, bath, uv, eta in (channel_case(nx=30, ny=14, seed=3), quad_case(nx=14, ny=9, seed=4)):
+        ref = make_ref(mesh, bath)
+        u_a, e_a = ref.advance(uv, eta, 1.5, 4)
+        u_b, e_b, seconds = ref.advance_blocked(uv, eta, 1.5, 4)
+        assert seconds >= 0.0 and np.array_equal(u_a, u_b) and np.array_equal(e_a, e_b)

@@ -180,15 +180,16 @@ stage_kernel_t pick_src(bool src, bool binl)
 }
 // wetting-drying variants (nonlinear equations only)
 template <bool LF, bool U0>
-stage_kernel_t pick_wd_src(bool src, bool quad)
+stage_kernel_t pick_wd_src(bool src, bool quad, bool binl)
 {
     if (quad) return src ? swe_stage_kernel_quad<true, LF, U0, true, true> : swe_stage_kernel_quad<true, LF, U0, false, true>;
+    if (binl) return src ? swe_stage_kernel<true, LF, U0, true, true, false, true> : swe_stage_kernel<true, LF, U0, false, true, false, true>;
     return src ? swe_stage_kernel<true, LF, U0, true, true> : swe_stage_kernel<true, LF, U0, false, true>;
 }
-stage_kernel_t pick_kernel_wd(bool lf, bool u0, bool src, bool quad)
+stage_kernel_t pick_kernel_wd(bool lf, bool u0, bool src, bool quad, bool binl)
 {
-    if (lf) return u0 ? pick_wd_src<true, true>(src, quad) : pick_wd_src<true, false>(src, quad);
-    return u0 ? pick_wd_src<false, true>(src, quad) : pick_wd_src<false, false>(src, quad);
+    if (lf) return u0 ? pick_wd_src<true, true>(src, quad, binl) : pick_wd_src<true, false>(src, quad, binl);
+    return u0 ? pick_wd_src<false, true>(src, quad, binl) : pick_wd_src<false, false>(src, quad, binl);
 }
 template <bool NL, bool LF>
 stage_kernel_t pick_u0(bool u0, bool src, bool binl) { return u0 ? pick_src<NL, LF, true>(src, binl) : pick_src<NL, LF, false>(src, binl); }
@@ -242,7 +243,6 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.valpha = h->valpha;
     a.idx4 = h->idx4; a.idx2 = h->idx2;
     a.cell_begin = c0; a.cell_end = c1;
-    a.stagger = 0;
     a.g = h->par.g_grav;
     a.sigma_lf = h->par.lax_friedrichs_velocity_scaling_factor;
     a.dt = h->par.dt;
@@ -273,26 +273,21 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.nu_v = h->nu_v; a.nu_const = h->nu_const;
     a.visc_sipg = 3.0*h->sipg_factor;
     a.visc_grad_div = h->visc_grad_div; a.visc_grad_depth = h->visc_grad_depth;
-    // Boundary-inline variant of the triangle kernel (BINL, swe2d_kernels.h): measured faster than the epilogue variant at every
-    // size (us/step, same box: 125 k cells 36.6 -> 29.1, 250 k 53.0 -> 46.7, 500 k 81.7 -> 76.1, 1 M 138.1 -> 135.7) although it
-    // runs at 2 waves/SIMD; both give the same bits.  THETIS_AMD_BND_INLINE=0 selects the epilogue variant (parity test, A/B).
+    // Boundary-inline variant of the triangle kernel (BINL, swe2d_kernels.h): faster than the epilogue variant at every size
+    // (us/step, same box, first BINL version: 125 k cells 36.6 -> 29.1, 250 k 53.0 -> 46.7, 500 k 81.7 -> 76.1, 1 M 138.1 ->
+    // 135.7); both give the same bits.  THETIS_AMD_BND_INLINE=0 selects the epilogue variant (parity test, A/B).
     const char *env_binl_s = std::getenv("THETIS_AMD_BND_INLINE");       // read per launch: tests switch it inside one process
-    const bool binl = env_binl_s ? std::atoi(env_binl_s) != 0 : true;
+    const bool binl = !(env_binl_s && std::atoi(env_binl_s) == 0);
     stage_kernel_t kern = fused_visc
         ? pick_kernel_visc(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
-        : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4)
+        : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4, binl)
         : (h->npc == 4)
         ? pick_kernel_quad(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
         : pick_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), binl);
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
     // the XCD-chunked block map needs a grid that is a multiple of 8; surplus blocks exit immediately
     const int grid = ((nblocks + 7)/8)*8;
-    // experiments (tools/kbench.py): THETIS_AMD_STAGE_LDS = dynamic LDS bytes per workgroup (caps the workgroups per CU:
-    // 160 KiB / bytes), THETIS_AMD_STAGGER = late start of every other group of 8 workgroups, in units of 512 cycles
-    static const int env_lds = std::getenv("THETIS_AMD_STAGE_LDS") ? std::atoi(std::getenv("THETIS_AMD_STAGE_LDS")) : 0;
-    static const int env_stagger = std::getenv("THETIS_AMD_STAGGER") ? std::atoi(std::getenv("THETIS_AMD_STAGGER")) : 0;
-    a.stagger = env_stagger;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), env_lds, h->stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     if (h->visc) {
         // HorizontalViscosityTerm: U_out[uv] += beta*dt*M^-1 R_visc(U_in) on the same cells (swe2d_sipg.h)

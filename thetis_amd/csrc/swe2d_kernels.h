@@ -68,7 +68,6 @@ struct SweStageArgs {
     double nu_const, visc_sipg;   // visc_sipg = sipg_factor * cp, cp = 3
     int visc_grad_div, visc_grad_depth;
     int cell_begin, cell_end;
-    int stagger;                  // small grids: odd workgroups start `stagger` x 512 cycles late (see launch_stage)
     double g, sigma_lf, dt;
     double a0, a1, beta;   // U_out = beta*k + a0*U0 + a1*U_in
     // optional cell-local terms (SRC variant)
@@ -688,10 +687,11 @@ __device__ unsigned long long swe_wave_ts[6][SWE_WT_MAX];
 #define SWE_WT_DRAIN()
 #endif
 
-// BINL: boundary fluxes are evaluated inside the facet loop from the values the lane already holds, instead of reloading the
-// facet's nodes in swe_boundary_epilogue.  Costs registers (184-202 VGPRs = 2 waves/SIMD instead of 3), removes two dependent
-// memory round trips from the waves that own boundary cells: the variant for grids of at most two waves per SIMD (small
-// partitions), where those waves were the last to finish.  Same bits as the epilogue path (tests/test_gpu_parity.py).
+// BINL: boundary fluxes are evaluated after the cell's outputs are finished from the values the lane still holds (one pass per
+// lane over ITS boundary facet), instead of reloading the facet's nodes in swe_boundary_epilogue: no dependent memory round
+// trips in the waves that own boundary cells (a quarter of the waves of a 125 k-cell partition, and the last to finish).
+// 164-166 VGPRs, no scratch, 3 waves/SIMD (the boundary markers travel packed in one register, h + eta is re-formed).
+// Same bits as the epilogue path (tests/test_gpu_parity.py).
 template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD, bool VISC = false, bool BINL = false>
 __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(const SweStageArgs p)
 {
@@ -704,13 +704,6 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         swe_wave_ts[5][blockIdx.x] = (unsigned long long)hw | ((unsigned long long)(xcc & 0xf) << 32);
     }
 #endif
-    if (p.stagger > 0 && (blockIdx.x & 8)) {
-        // Small grids run in lock step: every wave waits for its loads (a bandwidth-bound phase), then every wave computes (a
-        // VALU-bound phase).  Delaying half of the workgroups by about half a memory phase lets one half compute while the
-        // other half loads.  (blockIdx & 8: whole groups of 8 consecutive blocks = one block per XCD.)
-#pragma unroll 1
-        for (int i = 0; i < p.stagger; i++) __builtin_amdgcn_s_sleep(8);
-    }
 #ifdef SWE_NO_XCD_MAP
     const int lb = blockIdx.x;
 #else
@@ -733,6 +726,9 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         nb[0] = q4.x; nb[1] = q4.y; nb[2] = q4.z;
         vid[0] = q4.w; vid[1] = q2.x; vid[2] = q2.y;
     }
+    // boundary markers of the three facets in one register (0: interior facet): all the boundary pass of the BINL variant
+    // needs of nb[] at the end of the kernel
+    const int bmarkers = (nb[0] < 0 ? -nb[0] : 0) | (nb[1] < 0 ? (-nb[1]) << 8 : 0) | (nb[2] < 0 ? (-nb[2]) << 16 : 0);
 #ifdef SWE_WAVE_TIMING
     if (nb[0] == 0x7fffffff) return;          // forces the index loads to land before the time stamp
     SWE_WT(1);
@@ -911,7 +907,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         oe[i] = s*(4.0*be[i] - se) + we[i];          // eta, or zeta = D - h with wetting-drying
     }
     // boundary facets were skipped above; their correction is added to the finished outputs (see swe_boundary_epilogue)
-    if (BINL && (nb[0] | nb[1] | nb[2]) < 0) {
+    if (BINL && bmarkers != 0) {
         // Boundary facets from the values this lane still holds (no second trip to memory: on a small grid the dependent
         // reloads of swe_boundary_epilogue made the boundary waves the last ones to finish).  Every lane works on ITS
         // boundary facet - the wave runs the boundary code once (twice where a corner cell is among its lanes), not once per
@@ -920,7 +916,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         // 2A exactly as swe_boundary_epilogue forms it, from the facet normals that are still live: x1 - x0 = -ny[0],
         // y2 - y0 = -nx[2], y1 - y0 = nx[0], x2 - x0 = ny[2] (negation is exact)
         const double sfac = 6.0*p.dt*p.beta*swe_rcp(fma(-ny[0], -nx[2], -(nx[0]*ny[2])));
-        int rem = (nb[0] < 0 ? 1 : 0) | (nb[1] < 0 ? 2 : 0) | (nb[2] < 0 ? 4 : 0);
+        int rem = ((bmarkers & 0xff) ? 1 : 0) | ((bmarkers & 0xff00) ? 2 : 0) | ((bmarkers & 0xff0000) ? 4 : 0);
 #define SWE_SEL3(x, i) ((i) == 0 ? (x)[0] : ((i) == 1 ? (x)[1] : (x)[2]))
 #pragma unroll 1
         while (rem) {
@@ -931,9 +927,12 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
             double L, rL;
             swe_sqrt_rsqrt(swe_dot2(nxs, nxs, nys, nys), L, rL);
             double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
-            swe_boundary_facet<NONLIN, LF, WD>(p, -SWE_SEL3(nb, f), k, a, b, SWE_SEL3(u, a), SWE_SEL3(u, b), SWE_SEL3(v, a),
+            // (nodal depth: h + eta re-formed here for the plain nonlinear case instead of keeping H[] live - the same sum)
+            const double Ha_ = (WD || !NONLIN) ? SWE_SEL3(H, a) : SWE_SEL3(h, a) + SWE_SEL3(e, a);
+            const double Hb_ = (WD || !NONLIN) ? SWE_SEL3(H, b) : SWE_SEL3(h, b) + SWE_SEL3(e, b);
+            swe_boundary_facet<NONLIN, LF, WD>(p, (bmarkers >> (8*f)) & 0xff, k, a, b, SWE_SEL3(u, a), SWE_SEL3(u, b), SWE_SEL3(v, a),
                                                SWE_SEL3(v, b), SWE_SEL3(e, a), SWE_SEL3(e, b), SWE_SEL3(h, a), SWE_SEL3(h, b),
-                                               SWE_SEL3(H, a), SWE_SEL3(H, b), SWE_SEL3(al, a), SWE_SEL3(al, b), nxs, nys, L, rL,
+                                               Ha_, Hb_, SWE_SEL3(al, a), SWE_SEL3(al, b), nxs, nys, L, rL,
                                                Fau, Fbu, Fav, Fbv, Fae, Fbe);
             const double dau = -0.5*Fau, dbu = -0.5*Fbu, dav = -0.5*Fav, dbv = -0.5*Fbv, dae = -0.5*Fae, dbe = -0.5*Fbe;
 #pragma unroll
