@@ -399,11 +399,12 @@ def test_boundary_inline_variant_gives_the_bits_of_the_epilogue_variant(hip_lib,
     import os
     from thetis_amd import _lib
     from thetis_amd.device import Swe2dDevice
-    mesh, bath, uv, eta = channel_case(nx=24, ny=9, seed=17, amp_eta=0.3, amp_u=0.2)
+    mesh, bath, uv, eta = channel_case(nx=24, ny=9, seed=17, amp_eta=0.3, amp_u=0.2)      # 432 cells: 6.75 blocks
     cxy = mesh.cell_xy()
     out = {}
-    for force in ('0', '1'):
-        os.environ['THETIS_AMD_BND_INLINE'] = force
+    for force in ('0', '1', '1+ldsx'):            # epilogue variant, boundary-inline variant, the same with the LDS exchange
+        os.environ['THETIS_AMD_BND_INLINE'] = force[0]
+        os.environ['THETIS_AMD_LDSX'] = '1' if force.endswith('ldsx') else '0'
         try:
             dev = Swe2dDevice(mesh, bath, 2.0, boundary_len=mesh.boundary_len)
             if setup == 'open':
@@ -426,5 +427,31 @@ def test_boundary_inline_variant_gives_the_bits_of_the_epilogue_variant(hip_lib,
             dev.close()
         finally:
             os.environ.pop('THETIS_AMD_BND_INLINE', None)
-    assert np.array_equal(out['0'][0], out['1'][0]) and np.array_equal(out['0'][1], out['1'][1])
+            os.environ.pop('THETIS_AMD_LDSX', None)
+    for force in ('1', '1+ldsx'):
+        assert np.array_equal(out['0'][0], out[force][0]) and np.array_equal(out['0'][1], out[force][1]), force
 
+
+
+def test_stage_kernel_variants_agree_bitwise_on_a_large_launch(hip_lib):
+    """The host picks the stage-kernel variant by launch size (LDS exchange from 400 k cells up), so a partition and the
+    whole mesh of the bench run different variants: 200 k cells, 5 steps, every variant forced in turn."""
+    import os
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = channel_case(nx=400, ny=250, lx=100e3, ly=50e3, seed=5, amp_eta=0.3, amp_u=0.2)
+    out = {}
+    for binl, ldsx in (('0', '0'), ('1', '0'), ('1', '1')):
+        os.environ['THETIS_AMD_BND_INLINE'], os.environ['THETIS_AMD_LDSX'] = binl, ldsx
+        try:
+            dev = Swe2dDevice(mesh, bath, 0.5)
+            dev.set_bc(2, {'elev': 0.1})
+            dev.set_state(uv, eta)
+            dev.advance(5)
+            out[binl + ldsx] = dev.get_state()
+            dev.close()
+        finally:
+            os.environ.pop('THETIS_AMD_BND_INLINE', None)
+            os.environ.pop('THETIS_AMD_LDSX', None)
+    assert np.isfinite(out['00'][1]).all()
+    for key in ('10', '11'):
+        assert np.array_equal(out['00'][0], out[key][0]) and np.array_equal(out['00'][1], out[key][1]), key

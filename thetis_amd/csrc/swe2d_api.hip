@@ -173,8 +173,9 @@ bool has_sources(const Handle *h)
 typedef void (*stage_kernel_t)(const SweStageArgs);
 
 template <bool NL, bool LF, bool U0>
-stage_kernel_t pick_src(bool src, bool binl)
+stage_kernel_t pick_src(bool src, int binl)          // binl: 0 epilogue variant, 1 boundary-inline, 2 boundary-inline + LDS exchange
 {
+    if (binl == 2) return src ? swe_stage_kernel<NL, LF, U0, true, false, false, true, true> : swe_stage_kernel<NL, LF, U0, false, false, false, true, true>;
     if (binl) return src ? swe_stage_kernel<NL, LF, U0, true, false, false, true> : swe_stage_kernel<NL, LF, U0, false, false, false, true>;
     return src ? swe_stage_kernel<NL, LF, U0, true, false> : swe_stage_kernel<NL, LF, U0, false, false>;
 }
@@ -192,10 +193,10 @@ stage_kernel_t pick_kernel_wd(bool lf, bool u0, bool src, bool quad, bool binl)
     return u0 ? pick_wd_src<false, true>(src, quad, binl) : pick_wd_src<false, false>(src, quad, binl);
 }
 template <bool NL, bool LF>
-stage_kernel_t pick_u0(bool u0, bool src, bool binl) { return u0 ? pick_src<NL, LF, true>(src, binl) : pick_src<NL, LF, false>(src, binl); }
+stage_kernel_t pick_u0(bool u0, bool src, int binl) { return u0 ? pick_src<NL, LF, true>(src, binl) : pick_src<NL, LF, false>(src, binl); }
 template <bool NL>
-stage_kernel_t pick_lf(bool lf, bool u0, bool src, bool binl) { return lf ? pick_u0<NL, true>(u0, src, binl) : pick_u0<NL, false>(u0, src, binl); }
-stage_kernel_t pick_kernel(bool nl, bool lf, bool u0, bool src, bool binl)
+stage_kernel_t pick_lf(bool lf, bool u0, bool src, int binl) { return lf ? pick_u0<NL, true>(u0, src, binl) : pick_u0<NL, false>(u0, src, binl); }
+stage_kernel_t pick_kernel(bool nl, bool lf, bool u0, bool src, int binl)
 {
     return nl ? pick_lf<true>(lf, u0, src, binl) : pick_lf<false>(lf, u0, src, binl);
 }
@@ -278,12 +279,16 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     // 135.7); both give the same bits.  THETIS_AMD_BND_INLINE=0 selects the epilogue variant (parity test, A/B).
     const char *env_binl_s = std::getenv("THETIS_AMD_BND_INLINE");       // read per launch: tests switch it inside one process
     const bool binl = !(env_binl_s && std::atoi(env_binl_s) == 0);
+    // ... and for launches of half a million cells or more with the in-wave neighbour traces exchanged through LDS (LDSX;
+    // THETIS_AMD_LDSX=0/1 forces the choice).  Same bits in every variant: the kernel has no implicit contraction.
+    const char *env_ldsx_s = std::getenv("THETIS_AMD_LDSX");
+    const bool ldsx = env_ldsx_s ? std::atoi(env_ldsx_s) != 0 : (c1 - c0) >= 400000;
     stage_kernel_t kern = fused_visc
         ? pick_kernel_visc(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
         : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4, binl)
         : (h->npc == 4)
         ? pick_kernel_quad(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
-        : pick_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), binl);
+        : pick_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), binl ? (ldsx ? 2 : 1) : 0);
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
     // the XCD-chunked block map needs a grid that is a multiple of 8; surplus blocks exit immediately
     const int grid = ((nblocks + 7)/8)*8;

@@ -155,7 +155,7 @@ __device__ __forceinline__ double swe_rcp(double x)
 // D = (H + sqrt(H^2 + a^2))/2 with H = h + eta (thetis/utility.py:975-993), and its inverse H = D - a^2/(4 D).
 __device__ __forceinline__ double swe_wd_depth(double H, double a)
 {
-    return 0.5*(H + swe_sqrt(H*H + a*a));
+    return 0.5*(H + swe_sqrt(fma(H, H, a*a)));
 }
 
 // x^(-1/3) for normal-range x > 0 (Manning: C_D = g mu^2 / H^(1/3), shallowwater_eq.py:693): f32 seed through
@@ -180,16 +180,16 @@ __device__ __forceinline__ double swe_depth_pt(double h, double eta, double a)
     return WD ? swe_wd_depth(h + eta, a) : (NONLIN ? h + eta : h);
 }
 
-// 12/A * int a*b dx for P1 a, b
-__device__ __forceinline__ double swe_int2(const double a[3], const double b[3])
-{
-    return (a[0] + a[1] + a[2])*(b[0] + b[1] + b[2]) + a[0]*b[0] + a[1]*b[1] + a[2]*b[2];
-}
-
 // a*b + c*d with the contraction spelled out.  The boundary code below is inlined into two variants of the stage kernel (and
 // into the quadrilateral kernel); a sum of two products leaves it to the compiler which product is fused, and it chooses
 // differently from one context to the other - one ulp, which would break the bitwise agreement of the variants.
 __device__ __forceinline__ double swe_dot2(double a, double b, double c, double d) { return fma(a, b, c*d); }
+
+// 12/A * int a*b dx for P1 a, b
+__device__ __forceinline__ double swe_int2(const double a[3], const double b[3])
+{
+    return fma(a[2], b[2], fma(a[1], b[1], fma(a[0], b[0], (a[0] + a[1] + a[2])*(b[0] + b[1] + b[2]))));
+}
 
 // Boundary facet (closed wall or open boundary); rare, so written for clarity with unit normals.
 // Returns the form values f (residual is -f) already multiplied by the facet length.
@@ -692,9 +692,13 @@ __device__ unsigned long long swe_wave_ts[6][SWE_WT_MAX];
 // trips in the waves that own boundary cells (a quarter of the waves of a 125 k-cell partition, and the last to finish).
 // 164-166 VGPRs, no scratch, 3 waves/SIMD (the boundary markers travel packed in one register, h + eta is re-formed).
 // Same bits as the epilogue path (tests/test_gpu_parity.py).
-template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD, bool VISC = false, bool BINL = false>
+template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD, bool VISC = false, bool BINL = false, bool LDSX = false>
 __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(const SweStageArgs p)
 {
+    // No implicit contraction in this kernel: which of two products the compiler fuses depends on the code around it, and the
+    // variants of this template (boundary handling, LDS exchange, sources ...) must give the same bits - a partition takes a
+    // different variant than the whole mesh.  Every fused multiply-add below is written out.
+#pragma clang fp contract(off)
     SWE_WT(0);
 #ifdef SWE_WAVE_TIMING
     if (threadIdx.x == 0 && blockIdx.x < SWE_WT_MAX) {      // where does the wave run?  HW_ID (wave, simd, cu, sh, se) | XCC_ID << 32
@@ -749,9 +753,9 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         wv[i] = p.a1*v[i];
         we[i] = p.a1*e[i];
         if (HASU0) {
-            wu[i] += p.a0*swe_ld(g0u, k8, i*S8);
-            wv[i] += p.a0*swe_ld(g0v, k8, i*S8);
-            if (!WD) we[i] += p.a0*swe_ld(g0e, k8, i*S8);
+            wu[i] = fma(p.a0, swe_ld(g0u, k8, i*S8), wu[i]);
+            wv[i] = fma(p.a0, swe_ld(g0v, k8, i*S8), wv[i]);
+            if (!WD) we[i] = fma(p.a0, swe_ld(g0e, k8, i*S8), we[i]);
         }
     }
     double e0[3] = {0.0, 0.0, 0.0};
@@ -762,6 +766,49 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     // neighbour traces: the neighbour traverses the shared facet backwards, its node (f2+1)%3 sits on my node f and
     // its node f2 on my node f+1.  Boundary facets read this cell itself (value unused) to keep the loads branch-free.
     double una[3], unb[3], vna[3], vnb[3], ena[3], enb[3];
+    if constexpr (LDSX) {
+    // LDSX (large launches): neighbour traces of cells inside this wave's own 64-cell block (~85 % with the tile-Hilbert numbering) come from LDS: the
+    // wave publishes its nine nodal values there (one-wave workgroup: the barrier is local to the wave), only the others are
+    // gathered from memory, issued before the exchange.  Same values either way.  Measured (us/step, same box, without /
+    // with): 125 k cells 28.4 / 28.8, 250 k 45.4 / 47.0, 500 k 75.8 / 76.2, 1 M 137-140 / 129-134 (-5 %), 4 M 833 / 714 (-14 %):
+    // the in-wave gathers no longer compete with the streaming loads for the L1's 64 B/clk; below ~0.5 M cells the launch
+    // is latency-bound and the extra LDS round trip costs more than it saves, so the host picks the variant by launch size.
+    __shared__ double xs[9][SWE_BLOCK];
+    const int lane = (int)threadIdx.x, kw0 = k - lane, kw1 = min(kw0 + SWE_BLOCK, p.cell_end);
+    int lnb[3], nodeb[3];
+    bool inw[3];
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        const int nbf = nb[f];
+        const int kn = nbf >= 0 ? (nbf >> 2) : k;
+        const int f2 = nbf >= 0 ? (nbf & 3) : f;
+        inw[f] = kn >= kw0 && kn < kw1;
+        lnb[f] = kn - kw0; nodeb[f] = f2;
+        if (!inw[f]) {
+            const unsigned kn8 = (unsigned)kn*8u;
+            const unsigned ob = kn8 + (f2 == 0 ? 0u : (f2 == 1 ? S8 : 2u*S8));
+            const unsigned oa = kn8 + (f2 == 0 ? S8 : (f2 == 1 ? 2u*S8 : 0u));
+            una[f] = swe_ld(gu, oa, 0);
+            unb[f] = swe_ld(gu, ob, 0);
+            vna[f] = swe_ld(gv, oa, 0);
+            vnb[f] = swe_ld(gv, ob, 0);
+            ena[f] = swe_ld(ge, oa, 0);
+            enb[f] = swe_ld(ge, ob, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { xs[i][lane] = u[i]; xs[3 + i][lane] = v[i]; xs[6 + i][lane] = e[i]; }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        if (inw[f]) {
+            const int nb_ = nodeb[f], na_ = nb_ == 2 ? 0 : nb_ + 1;
+            una[f] = xs[na_][lnb[f]];     unb[f] = xs[nb_][lnb[f]];
+            vna[f] = xs[3 + na_][lnb[f]]; vnb[f] = xs[3 + nb_][lnb[f]];
+            ena[f] = xs[6 + na_][lnb[f]]; enb[f] = xs[6 + nb_][lnb[f]];
+        }
+    }
+    } else {
 #pragma unroll
     for (int f = 0; f < 3; f++) {
         const int nbf = nb[f];
@@ -777,6 +824,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         ena[f] = swe_ld(ge, oa, 0);
         enb[f] = swe_ld(ge, ob, 0);
     }
+    }
     double px[3], py[3], h[3], H[3], al[3] = {0.0, 0.0, 0.0};
     const swe_rsrc_t rvx = swe_rsrc(p.vx), rvy = swe_rsrc(p.vy), rvh = swe_rsrc(p.vh);
 #pragma unroll
@@ -789,7 +837,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         H[i] = WD ? swe_wd_depth(h[i] + e[i], al[i]) : (NONLIN ? h[i] + e[i] : h[i]);
         if (WD) {           // the continuity equation advances zeta = D - h
             we[i] = p.a1*(H[i] - h[i]);
-            if (HASU0) we[i] += p.a0*(swe_wd_depth(h[i] + e0[i], al[i]) - h[i]);
+            if (HASU0) we[i] = fma(p.a0, swe_wd_depth(h[i] + e0[i], al[i]) - h[i], we[i]);
         }
     }
     SWE_WT_DRAIN();
@@ -802,7 +850,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         nx[f] = py[b] - py[f];
         ny[f] = px[f] - px[b];
     }
-    const double twoA = nx[0]*ny[1] - ny[0]*nx[1];
+    const double twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
     // A*grad(phi_i) = -nF_{i+1}/2
     double gxs[3], gys[3];
 #pragma unroll
@@ -820,18 +868,18 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         for (int i = 0; i < 3; i++) {
             bu[i] = gxs[i]*ge3;                              // +g eta div(psi)       shallowwater_eq.py:361
             bv[i] = gys[i]*ge3;
-            be[i] = gxs[i]*SHu + gys[i]*SHv;                 // +grad(phi).(H u)      shallowwater_eq.py:422
+            be[i] = swe_dot2(gxs[i], SHu, gys[i], SHv);      // +grad(phi).(H u)      shallowwater_eq.py:422
         }
         if (NONLIN) {                                        // +(psi div u + u.grad psi).u  shallowwater_eq.py:478
             const double Suu = swe_int2(u, u)*(1.0/12.0), Suv = swe_int2(u, v)*(1.0/12.0),
                          Svv = swe_int2(v, v)*(1.0/12.0);
-            const double D12 = (gxs[0]*u[0] + gxs[1]*u[1] + gxs[2]*u[2]
-                                + gys[0]*v[0] + gys[1]*v[1] + gys[2]*v[2])*(1.0/12.0);
+            const double D12 = fma(gys[2], v[2], fma(gys[1], v[1], fma(gys[0], v[0],
+                               fma(gxs[2], u[2], fma(gxs[1], u[1], gxs[0]*u[0])))))*(1.0/12.0);
             const double us = u[0] + u[1] + u[2], vs = v[0] + v[1] + v[2];
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                bu[i] += D12*(us + u[i]) + gxs[i]*Suu + gys[i]*Suv;
-                bv[i] += D12*(vs + v[i]) + gxs[i]*Suv + gys[i]*Svv;
+                bu[i] = fma(gys[i], Suv, fma(gxs[i], Suu, fma(D12, us + u[i], bu[i])));
+                bv[i] = fma(gys[i], Svv, fma(gxs[i], Suv, fma(D12, vs + v[i], bv[i])));
             }
         }
     }
@@ -857,38 +905,39 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
-                const double uq = xa*u[a] + xb*u[b], vq = xa*v[a] + xb*v[b], eq = xa*e[a] + xb*e[b];
-                const double hq = xa*h[a] + xb*h[b];
-                const double un = xa*una[f] + xb*unb[f], vn = xa*vna[f] + xb*vnb[f], en = xa*ena[f] + xb*enb[f];
+                const double uq = swe_dot2(xa, u[a], xb, u[b]), vq = swe_dot2(xa, v[a], xb, v[b]), eq = swe_dot2(xa, e[a], xb, e[b]);
+                const double hq = swe_dot2(xa, h[a], xb, h[b]);
+                const double un = swe_dot2(xa, una[f], xb, unb[f]), vn = swe_dot2(xa, vna[f], xb, vnb[f]),
+                             en = swe_dot2(xa, ena[f], xb, enb[f]);
                 const double eav = 0.5*(eq + en);
-                const double Hav = WD ? 0.5*((xa*H[a] + xb*H[b]) + (xa*Dna + xb*Dnb)) : (NONLIN ? hq + eav : hq);
+                const double Hav = WD ? 0.5*(swe_dot2(xa, H[a], xb, H[b]) + swe_dot2(xa, Dna, xb, Dnb)) : (NONLIN ? hq + eav : hq);
                 const double c = swe_sqrt(g*Hav);
                 const double du = uq - un, dv = vq - vn;
-                const double dun = du*nxs + dv*nys;                       // |F| jump(u.n)
-                const double spg = g*eav + c*dun*rL;                      // g*head_star            :363
+                const double dun = swe_dot2(du, nxs, dv, nys);            // |F| jump(u.n)
+                const double spg = fma(c*dun, rL, g*eav);                 // g*head_star            :363
                 double fu = spg*nxs, fv = spg*nys;                        //                        :366
                 const double uav = 0.5*(uq + un), vav = 0.5*(vq + vn);
-                const double uavn = uav*nxs + vav*nys;                    // |F| {u}.n
-                const double fe = Hav*uavn + c*(eq - en)*L;               // {H}({u}+sqrt(g/{H})[eta n]).n  :424-427
+                const double uavn = swe_dot2(uav, nxs, vav, nys);         // |F| {u}.n
+                const double fe = fma(c*(eq - en), L, Hav*uavn);          // {H}({u}+sqrt(g/{H})[eta n]).n  :424-427
                 if (NONLIN) {
-                    const double unown = uq*nxs + vq*nys;
-                    fu += uav*unown;                                      //                        :483
-                    fv += vav*unown;
+                    const double unown = swe_dot2(uq, nxs, vq, nys);
+                    fu = fma(uav, unown, fu);                             //                        :483
+                    fv = fma(vav, unown, fv);
                     if (LF) {
                         const double gam = 0.5*fabs(uavn)*p.sigma_lf;     //                        :487
-                        fu += gam*du;                                     //                        :488
-                        fv += gam*dv;
+                        fu = fma(gam, du, fu);                            //                        :488
+                        fv = fma(gam, dv, fv);
                     }
                 }
-                Fau += xa*fu; Fbu += xb*fu;
-                Fav += xa*fv; Fbv += xb*fv;
-                Fae += xa*fe; Fbe += xb*fe;
+                Fau = fma(xa, fu, Fau); Fbu = fma(xb, fu, Fbu);
+                Fav = fma(xa, fv, Fav); Fbv = fma(xb, fv, Fbv);
+                Fae = fma(xa, fe, Fae); Fbe = fma(xb, fe, Fbe);
             }
         }
         if (nb[f] < 0) { Fau = 0.0; Fbu = 0.0; Fav = 0.0; Fbv = 0.0; Fae = 0.0; Fbe = 0.0; }   // see swe_boundary_epilogue / BINL
-        bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
-        bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
-        be[a] -= 0.5*Fae; be[b] -= 0.5*Fbe;
+        bu[a] = fma(-0.5, Fau, bu[a]); bu[b] = fma(-0.5, Fbu, bu[b]);
+        bv[a] = fma(-0.5, Fav, bv[a]); bv[b] = fma(-0.5, Fbv, bv[b]);
+        be[a] = fma(-0.5, Fae, be[a]); be[b] = fma(-0.5, Fbe, be[b]);
     }
 
     // optional cell-local terms AFTER the facet loop: the 18 neighbour traces are dead by now, which keeps the SRC variants
@@ -902,9 +951,9 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     double ou[3], ov[3], oe[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        ou[i] = s*(4.0*bu[i] - su) + wu[i];
-        ov[i] = s*(4.0*bv[i] - sv) + wv[i];
-        oe[i] = s*(4.0*be[i] - se) + we[i];          // eta, or zeta = D - h with wetting-drying
+        ou[i] = fma(s, fma(4.0, bu[i], -su), wu[i]);
+        ov[i] = fma(s, fma(4.0, bv[i], -sv), wv[i]);
+        oe[i] = fma(s, fma(4.0, be[i], -se), we[i]);          // eta, or zeta = D - h with wetting-drying
     }
     // boundary facets were skipped above; their correction is added to the finished outputs (see swe_boundary_epilogue)
     if (BINL && bmarkers != 0) {

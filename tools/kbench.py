@@ -58,7 +58,9 @@ def main():
         i, j = q % mesh.nx, q//mesh.nx
         d = ordering.hilbert_index(i//bx, j//by, 12)
         reorder = np.lexsort((np.arange(mesh.num_cells), i % bx, j % by, d))
-    dev = Swe2dDevice(mesh, bath, bench.DT, reorder=reorder)
+    # keep the CFL number of the bench workload when the mesh is refined
+    dt = bench.DT*min(1.0, 1000.0/max(args.nx, 1) if args.nx else 1.0, 500.0/max(args.ny, 1) if args.ny else 1.0)
+    dev = Swe2dDevice(mesh, bath, dt, reorder=reorder)
     dev.set_state(uv, eta)
     import time
     t0 = time.perf_counter()
