@@ -172,7 +172,10 @@ int  swe2d_set_scalar(swe2d_handle *h, int which, double value);
 /* options.use_wetting_and_drying + options.wetting_and_drying_alpha (thetis/options.py:872-884), alpha given at the mesh
  * vertices (constant or the P1 field of set_wetting_and_drying_alpha, solver2d.py:251-303).  The reference cannot run
  * SSPRK33 with wetting-drying; this enables the build's own explicit nodal formulation of the same
- * displaced depth.  swe2d_diagnostics then reports int D dx, min D in slots 2, 3. */
+ * displaced depth: the continuity equation advances zeta = D - h, every stage ends with a positivity
+ * limiter on the nodal depths (D >= 0.1 alpha) and a relaxation of the velocity on dry ground.  Enable it BEFORE
+ * swe2d_set_state: the state is then brought to the admissible set (nodal depths through the limiter).  swe2d_diagnostics
+ * reports int D dx, min D in slots 2, 3; swe2d_tendency returns the raw tendencies of (u, v, zeta). */
 int  swe2d_set_wetting_and_drying(swe2d_handle *h, int enable, const double *alpha_vertex);
 
 /* ERKGenericShuOsher.advance (rungekutta.py:949-952) repeated n_steps times, forcings constant in time.

@@ -403,12 +403,61 @@ void swe2d_ref_tendency(const swe2d_ref_t *m, const double *uv, const double *et
 /* n_steps SSPRK33 steps in place; work must hold 4 states = 4*9*N doubles.  Shu-Osher form, expression
  * order of rungekutta.py:911-913: tendency*beta + sum_j stage_sol[j]*alpha.  Constant-in-time forcing only. */
 /* explicit wetting-drying: the continuity equation advances zeta = D - h; eta is recovered from H = D - a^2/(4 D) */
-static inline double wd_combine(const swe2d_ref_t *m, long i, double bk, double e0, double a0, double e1, double a1)
+/* One cell of a wetting-drying stage: zeta_new = bk + a0 zeta(e0) + a1 zeta(e1) at every node, D = zeta + h, the positivity
+ * limiter, eta from D.  The nodal values of a DG-P1 depth can undershoot although the cell mean stays positive (the mass
+ * inverse amplifies nodal changes by up to 9), and eta(D) = D - a^2/(4D) - h has a pole at D = 0: one negative nodal D and
+ * the step is lost.  Limiter (Xing-Zhang type, cell-local, keeps the cell mean = conservative): the nodal deviations from the
+ * mean are scaled by theta = min(1, (mean - floor)/(mean - min)) so that every node has D >= floor = WD_FLOOR * alpha (the
+ * depth at which H = h + eta = -(1/(4 WD_FLOOR) - WD_FLOOR) alpha, i.e. the water table |H| of a dry node is bounded by a
+ * multiple of alpha and with it the speed sqrt(g |H|) of the waves the modified continuity equation carries there).  A cell
+ * whose MEAN fell below the floor is flattened to its mean (conservative) and only below a tenth of the floor raised to that.
+ * Restated in numpy as SWEOracle.wd_finish_stage (oracle/swe2d_oracle.py). */
+#define WD_FLOOR 0.1             /* oracle/swe2d_oracle.py WD_FLOOR */
+static inline void wd_stage_cell(const swe2d_ref_t *m, long c, const double *bk, const double *e0, double a0, const double *e1,
+                                 double a1, double *out)
 {
-    const double h = m->h[i], a = m->alpha[i];
-    const double zeta = bk + (wd_depth(h, e0, a) - h)*a0 + (wd_depth(h, e1, a) - h)*a1;
-    const double D = zeta + h;
-    return D - a*a/(4.0*D) - h;
+    const int k = m->npc;
+    double D[4], mean = 0.0, dmin = 1e300, fl = 0.0;
+    for (int i = 0; i < k; i++) {
+        const double h = m->h[c*k + i], a = m->alpha[c*k + i];
+        D[i] = bk[i] + (wd_depth(h, e0[i], a) - h)*a0 + (wd_depth(h, e1[i], a) - h)*a1 + h;
+        mean += D[i];
+        if (D[i] < dmin) dmin = D[i];
+        if (WD_FLOOR*a > fl) fl = WD_FLOOR*a;
+    }
+    mean /= k;
+    if (dmin < fl) {
+        if (mean <= fl) {
+            /* the whole cell is below the floor: flatten it (no volume added) down to a hard floor of a tenth of it */
+            const double flat = mean > 0.1*fl ? mean : 0.1*fl;
+            for (int i = 0; i < k; i++) D[i] = flat;
+        }
+        else {
+            const double theta = (mean - fl)/(mean - dmin);
+            for (int i = 0; i < k; i++) D[i] = mean + theta*(D[i] - mean);
+        }
+    }
+    for (int i = 0; i < k; i++) {
+        const double h = m->h[c*k + i], a = m->alpha[c*k + i];
+        out[i] = D[i] - a*a/(4.0*D[i]) - h;
+    }
+}
+
+/* dry-ground velocity relaxation of the explicit wetting-drying scheme: u <- u exp(-dt_stage/tau * psi^2),
+ * tau = WD_TAU_FACTOR * sqrt(alpha/g), psi = clamp(-H/alpha - 1, 0, 1): nothing where the water table is less than alpha below
+ * the bed, full strength from 2 alpha on (oracle/swe2d_oracle.py, module docstring). */
+#define WD_TAU_FACTOR 10.0       /* oracle/swe2d_oracle.py WD_TAU */
+static inline void wd_damp_cell(const swe2d_ref_t *m, long c, const double *eta_new, double dt_stage, double *uv_cell)
+{
+    const int k = m->npc;
+    for (int i = 0; i < k; i++) {
+        const double h = m->h[c*k + i], a = m->alpha[c*k + i];
+        double psi = -(h + eta_new[i])/a - 1.0;
+        psi = psi < 0.0 ? 0.0 : (psi > 1.0 ? 1.0 : psi);
+        const double fac = exp(-dt_stage/(WD_TAU_FACTOR*sqrt(a/m->g))*psi*psi);
+        uv_cell[2*i] *= fac;
+        uv_cell[2*i + 1] *= fac;
+    }
 }
 
 void swe2d_ref_advance(const swe2d_ref_t *m, double *uv, double *eta, double dt, int n_steps, double *work)
@@ -424,23 +473,50 @@ void swe2d_ref_advance(const swe2d_ref_t *m, double *uv, double *eta, double dt,
         swe2d_ref_tendency(m, uv, eta, dt, ku, ke);
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < (long)nu; i++) uv[i] = ku[i]*1.0 + u0[i]*1.0;
+        if (m->wd) {
 #pragma omp parallel for schedule(static)
-        for (long i = 0; i < (long)ne; i++)
-            eta[i] = m->wd ? wd_combine(m, i, ke[i]*1.0, e0[i], 1.0, e0[i], 0.0) : ke[i]*1.0 + e0[i]*1.0;
+            for (long c = 0; c < (long)m->n_cells; c++) {
+                double b[4];
+                for (int i = 0; i < m->npc; i++) b[i] = ke[c*m->npc + i]*1.0;
+                wd_stage_cell(m, c, b, e0 + c*m->npc, 1.0, e0 + c*m->npc, 0.0, eta + c*m->npc);
+                wd_damp_cell(m, c, eta + c*m->npc, 1.0*dt, uv + 2*c*m->npc);
+            }
+        } else {
+#pragma omp parallel for schedule(static)
+            for (long i = 0; i < (long)ne; i++) eta[i] = ke[i]*1.0 + e0[i]*1.0;
+        }
         /* stage 1: U2 = k*0.25 + U0*0.75 + U1*0.25   (U1 is the current solution) */
         swe2d_ref_tendency(m, uv, eta, dt, ku, ke);
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < (long)nu; i++) uv[i] = ku[i]*0.25 + u0[i]*0.75 + uv[i]*0.25;
+        if (m->wd) {
 #pragma omp parallel for schedule(static)
-        for (long i = 0; i < (long)ne; i++)
-            eta[i] = m->wd ? wd_combine(m, i, ke[i]*0.25, e0[i], 0.75, eta[i], 0.25) : ke[i]*0.25 + e0[i]*0.75 + eta[i]*0.25;
+            for (long c = 0; c < (long)m->n_cells; c++) {
+                double b[4];
+                for (int i = 0; i < m->npc; i++) b[i] = ke[c*m->npc + i]*0.25;
+                wd_stage_cell(m, c, b, e0 + c*m->npc, 0.75, eta + c*m->npc, 0.25, eta + c*m->npc);
+                wd_damp_cell(m, c, eta + c*m->npc, 0.25*dt, uv + 2*c*m->npc);
+            }
+        } else {
+#pragma omp parallel for schedule(static)
+            for (long i = 0; i < (long)ne; i++) eta[i] = ke[i]*0.25 + e0[i]*0.75 + eta[i]*0.25;
+        }
         /* stage 2: U3 = k*B32 + U0*A30 + U1*0 + U2*A32 */
         swe2d_ref_tendency(m, uv, eta, dt, ku, ke);
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < (long)nu; i++) uv[i] = ku[i]*B32 + u0[i]*A30 + uv[i]*A32;
+        if (m->wd) {
 #pragma omp parallel for schedule(static)
-        for (long i = 0; i < (long)ne; i++)
-            eta[i] = m->wd ? wd_combine(m, i, ke[i]*B32, e0[i], A30, eta[i], A32) : ke[i]*B32 + e0[i]*A30 + eta[i]*A32;
+            for (long c = 0; c < (long)m->n_cells; c++) {
+                double b[4];
+                for (int i = 0; i < m->npc; i++) b[i] = ke[c*m->npc + i]*B32;
+                wd_stage_cell(m, c, b, e0 + c*m->npc, A30, eta + c*m->npc, A32, eta + c*m->npc);
+                wd_damp_cell(m, c, eta + c*m->npc, B32*dt, uv + 2*c*m->npc);
+            }
+        } else {
+#pragma omp parallel for schedule(static)
+            for (long i = 0; i < (long)ne; i++) eta[i] = ke[i]*B32 + e0[i]*A30 + eta[i]*A32;
+        }
     }
 }
 

@@ -592,6 +592,15 @@ int swe2d_set_state(swe2d_handle *hh, const double *uv, const double *eta)
     hipLaunchKernelGGL(swe_aos_to_planes, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
                        h->stage_uv, h->stage_eta, h->state[0], h->stride, h->n_cells, h->npc);
     HIP_TRY(h, hipGetLastError());
+    if (h->wd) {
+        // explicit wetting-drying: the admissible state next to the one handed in (nodal depths through the positivity
+        // limiter; enable wetting-drying BEFORE setting the state)
+        if (h->npc == 4) hipLaunchKernelGGL(swe_wd_clip_kernel<4>, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                                            h->state[0], h->stride, h->cv, h->vh, h->valpha, h->n_cells);
+        else hipLaunchKernelGGL(swe_wd_clip_kernel<3>, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                                h->state[0], h->stride, h->cv, h->vh, h->valpha, h->n_cells);
+        HIP_TRY(h, hipGetLastError());
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
     return SWE2D_OK;
 }

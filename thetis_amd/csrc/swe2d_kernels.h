@@ -158,6 +158,54 @@ __device__ __forceinline__ double swe_wd_depth(double H, double a)
     return 0.5*(H + swe_sqrt(fma(H, H, a*a)));
 }
 
+// End of a wetting-drying stage in one cell (explicit formulation, oracle/swe2d_oracle.py module docstring and
+// SWEOracle.wd_finish_stage): oe[] holds zeta = D - h on entry and eta on exit.
+//  (1) positivity limiter on the nodal depths: deviations from the cell mean scaled so that every node keeps
+//      D >= SWE_WD_FLOOR * alpha (mean unchanged = conservative); a cell whose mean is below the floor is flattened to its
+//      mean, below a tenth of the floor raised to that;
+//  (2) eta from D in closed form, H = D - alpha^2/(4 D);
+//  (3) relaxation of the velocity on dry ground: u *= exp(-dt_stage/tau psi^2), tau = SWE_WD_TAU sqrt(alpha/g),
+//      psi = clamp(-H/alpha - 1, 0, 1).
+#define SWE_WD_FLOOR 0.1
+#define SWE_WD_TAU 10.0
+template <int K>
+__device__ __forceinline__ void swe_wd_finish(double g, double dt_stage, const double h[K], const double al[K], double ou[K],
+                                              double ov[K], double oe[K])
+{
+#pragma clang fp contract(off)
+    double D[K], mean = 0.0, dmin = 1e300, fl = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        D[i] = oe[i] + h[i];
+        mean += D[i];
+        dmin = fmin(dmin, D[i]);
+        fl = fmax(fl, SWE_WD_FLOOR*al[i]);
+    }
+    mean *= (K == 3 ? (1.0/3.0) : 0.25);
+    if (dmin < fl) {
+        if (mean <= fl) {
+            const double flat = fmax(mean, 0.1*fl);
+#pragma unroll
+            for (int i = 0; i < K; i++) D[i] = flat;
+        } else {
+            const double theta = (mean - fl)/(mean - dmin);
+#pragma unroll
+            for (int i = 0; i < K; i++) D[i] = mean + theta*(D[i] - mean);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        const double eta = D[i] - al[i]*al[i]/(4.0*D[i]) - h[i];
+        oe[i] = eta;
+        const double psi = fmin(1.0, fmax(0.0, -(h[i] + eta)/al[i] - 1.0));
+        if (psi > 0.0) {
+            const double fac = exp(-dt_stage/(SWE_WD_TAU*sqrt(al[i]/g))*psi*psi);
+            ou[i] *= fac;
+            ov[i] *= fac;
+        }
+    }
+}
+
 // x^(-1/3) for normal-range x > 0 (Manning: C_D = g mu^2 / H^(1/3), shallowwater_eq.py:693): f32 seed through
 // v_log_f32 / v_exp_f32, two Newton steps y <- y + y (1 - x y^3)/3 in f64 (quadratic: 1e-7 -> 1e-13 -> round-off)
 __device__ __forceinline__ double swe_rcbrt(double x)
@@ -1000,16 +1048,14 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     if (ou[0] == 1.2345e300) return;          // the arithmetic has to be finished before the time stamp
     SWE_WT(3);
 #endif
+    // zeta = D - h -> limited depth -> eta; dry-ground relaxation.  (Not for the parity hook swe2d_tendency, a0 = a1 = 0: it
+    // returns the raw tendencies of (u, v, zeta).)
+    if (WD && !(p.a0 == 0.0 && p.a1 == 0.0)) swe_wd_finish<3>(g, p.beta*p.dt, h, al, ou, ov, oe);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         swe_st(gou, k8, i*S8, ou[i]);
         swe_st(gov, k8, i*S8, ov[i]);
-        if (WD) {           // back from zeta = D - h to eta:  H = D - alpha^2/(4D)
-            const double D = oe[i] + h[i];
-            swe_st(goe, k8, i*S8, D - al[i]*al[i]/(4.0*D) - h[i]);
-        } else {
-            swe_st(goe, k8, i*S8, oe[i]);
-        }
+        swe_st(goe, k8, i*S8, oe[i]);
     }
     SWE_WT_DRAIN();
     SWE_WT(4);
@@ -1122,6 +1168,25 @@ __global__ void swe_halo_unpack(double *planes, size_t stride, const int *cells,
     if (t >= np*n) return;
     const int j = t/np, q = t - np*j;
     planes[(size_t)q*stride + cells[j]] = buf[t];
+}
+
+// wetting-drying: bring a state handed in by the caller to the admissible set of the explicit scheme (every nodal depth through
+// the positivity limiter of swe_wd_finish; velocities untouched) - otherwise the first stage would do it and the volume of the
+// initial state would not be the volume the run conserves
+template <int K>
+__global__ void swe_wd_clip_kernel(double *planes, size_t stride, const int *cv, const double *vh, const double *valpha, int n)
+{
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double h[K], al[K], zu[K], zv[K], ze[K];
+    for (int i = 0; i < K; i++) {
+        const int v = cv[(size_t)i*stride + k];
+        h[i] = vh[v]; al[i] = valpha[v];
+        zu[i] = 0.0; zv[i] = 0.0;
+        ze[i] = swe_wd_depth(h[i] + planes[(size_t)(2*K + i)*stride + k], al[i]) - h[i];
+    }
+    swe_wd_finish<K>(9.81, 0.0, h, al, zu, zv, ze);
+    for (int i = 0; i < K; i++) planes[(size_t)(2*K + i)*stride + k] = ze[i];
 }
 
 // diagnostics: per-block partial sums { int eta^2, int |u|^2, int (eta+h), min(h+eta) }, finished on the host
@@ -1832,16 +1897,12 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         ov[i] = s*(16.0*bv[i] - 8.0*bv[n1] - 8.0*bv[n3] + 4.0*bv[n2]) + wv[i];
         oe[i] = s*(16.0*be[i] - 8.0*be[n1] - 8.0*be[n3] + 4.0*be[n2]) + we[i];
     }
+    if (WD && !(p.a0 == 0.0 && p.a1 == 0.0)) swe_wd_finish<4>(p.g, p.beta*p.dt, h, al, ou, ov, oe);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         swe_st(swe_rsrc(p.uout), k8, i*S8, ou[i]);
         swe_st(swe_rsrc(p.uout + 4*S), k8, i*S8, ov[i]);
-        if (WD) {           // back from zeta = D - h to eta:  H = D - alpha^2/(4D)
-            const double D = oe[i] + h[i];
-            swe_st(swe_rsrc(p.uout + 8*S), k8, i*S8, D - al[i]*al[i]/(4.0*D) - h[i]);
-        } else {
-            swe_st(swe_rsrc(p.uout + 8*S), k8, i*S8, oe[i]);
-        }
+        swe_st(swe_rsrc(p.uout + 8*S), k8, i*S8, oe[i]);
     }
 }
 
