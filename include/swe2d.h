@@ -226,6 +226,11 @@ int  swe2d_tracer_set_bc(swe2d_handle *h, int tracer_id, int marker, int has_val
  * 3 = 'flux': volume flux u out of the domain, uv_ext = factor * u / (H(elev_in) * boundary_len) n,
  * 4 = 'flux' with a constant 'elev' in the dict: the same with H(v) */
 int  swe2d_tracer_set_bc_velocity(swe2d_handle *h, int tracer_id, int marker, int kind, double u, double v);
+/* the same with Function-valued entries in compact form (tracer_eq_2d.py:100-109): values[n_facets][2] (kind 1 'uv':
+ * [n_facets][2][2]) = the entry at the first and second node of boundary facet `facets[i]` of cell `cells[i]`; elev: the
+ * constant 'elev' of a 'flux' entry (kind 4), ignored otherwise */
+int  swe2d_tracer_set_bc_velocity_facets(swe2d_handle *h, int tracer_id, int marker, int kind, double elev, int32_t n_facets,
+                                         const int32_t *cells, const int32_t *facets, const double *values);
 /* Function-valued 'value' on `marker`: nodal DG values of the whole mesh in the host layout (kN); only cells with a
  * boundary facet carrying `marker` are copied (all their nodes: the diffusive boundary term uses the cell gradient) */
 int  swe2d_tracer_set_bc_field(swe2d_handle *h, int tracer_id, int marker, const double *nodal);

@@ -364,6 +364,47 @@ def test_tracer_boundary_velocity_keys_match_oracle(hip_lib, cells, conservative
     dev.close()
 
 
+@pytest.mark.parametrize('conservative', [False, True])
+@pytest.mark.parametrize('cells', ['triangles', 'quadrilaterals'])
+def test_function_valued_tracer_boundary_velocities_match_oracle(hip_lib, cells, conservative):
+    """Function-valued 'uv' / 'un' / 'flux' entries of bnd_functions['tracer'][marker] (tracer_eq_2d.py:100-109): spatially
+    varying external velocities along the boundary, uploaded as the values at the end nodes of the boundary facets."""
+    from helpers import make_oracle_generic, quad_case
+    if cells == 'triangles':
+        mesh, bath, uv, eta = channel_case(nx=7, ny=5, seed=71)
+        orc = make_oracle(mesh, bath)
+    else:
+        mesh, bath, uv, eta = quad_case(nx=7, ny=5, seed=71)
+        orc = make_oracle_generic(mesh, bath)
+    k = mesh.cells.shape[1]
+    cxy = mesh.cell_xy()
+    T = np.random.default_rng(26).normal(size=(mesh.num_cells, k))
+    uv_f = np.stack([0.6*np.cos(cxy[:, :, 1]/9e3), -0.3*np.sin(cxy[:, :, 1]/7e3)], axis=2)
+    un_f = 0.4*np.sin(cxy[:, :, 0]/2e4) - 0.1
+    fl_f = 2e4*(1.0 + 0.5*np.cos(cxy[:, :, 1]/8e3))
+    bcs = {1: {'value': 1.5, 'uv': uv_f}, 2: {'flux': fl_f, 'elev': 0.2}, 3: {'value': -0.5, 'un': un_f}, 4: {'flux': -fl_f}}
+    dt = 2.0
+    dev = _dev(mesh, bath, dt, boundary_len=mesh.boundary_len)
+    tid = dev.add_tracer()
+    dev.tracer_set_options(False, 1.0, 0.8)
+    dev.tracer_set_conservative(tid, conservative)
+    dev.tracer_set_bc(tid, 1, 1.5)
+    dev.tracer_set_bc(tid, 3, -0.5)
+    dev.tracer_set_bc_velocity(tid, 1, uv=uv_f)
+    dev.tracer_set_bc_velocity(tid, 2, flux=fl_f, elev=0.2)
+    dev.tracer_set_bc_velocity(tid, 3, un=un_f)
+    dev.tracer_set_bc_velocity(tid, 4, flux=dev.facet_node_values(4, -fl_f))          # compact form handed in directly
+    dev.set_state(uv, eta)
+    dev.tracer_set_state(tid, T)
+    kw = dict(bnd_conditions=bcs, tracer_advective_velocity_factor=0.8, conservative=conservative)
+    assert rel_linf(dev.tracer_tendency(tid), orc.tracer_tendency(T, uv, eta, dt, **kw)) < TOL
+    # back to a constant on one marker: the field flag of that marker is dropped
+    dev.tracer_set_bc_velocity(tid, 3, un=0.25)
+    bcs[3] = {'value': -0.5, 'un': 0.25}
+    assert rel_linf(dev.tracer_tendency(tid), orc.tracer_tendency(T, uv, eta, dt, **kw)) < TOL
+    dev.close()
+
+
 @pytest.mark.parametrize('stepper', ['SSPRK33', 'ForwardEuler'])
 def test_reference_horizontal_advection_convergence(hip_lib, stepper):
     """test/tracerEq/test_h-advection_mes_2d.py::test_horizontal_advection[1-SSPRK33 | ForwardEuler]: a Gaussian advected by
@@ -436,7 +477,8 @@ def test_conservative_tracer_source_with_wetting_drying_depth(hip_lib, cells):
     tid = dev.add_tracer()
     dev.tracer_set_conservative(tid, True)
     dev.tracer_set_source(tid, src)
-    dev.set_state(uv, eta)
+    dev.set_state(uv, eta)                     # wetting-drying: the state is brought to the admissible set
+    eta = orc.wd_clip_state(eta)
     dev.tracer_set_state(tid, q)
     k_o = orc.tracer_tendency(q, uv, eta, dt, conservative=True, source=src)
     assert rel_linf(dev.tracer_tendency(tid), k_o) < TOL

@@ -74,6 +74,8 @@ SYMBOLS = {
     'swe2d_tracer_get_state': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_tracer_set_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
     'swe2d_tracer_set_bc_velocity': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]),
+    'swe2d_tracer_set_bc_velocity_facets': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int32,
+                                                            _ip, _ip, _dp]),
     'swe2d_tracer_set_bc_field': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),
     'swe2d_tracer_set_bc_facets': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int32, _ip, _ip, _dp]),
     'swe2d_tracer_set_source': (ctypes.c_int, [_H, ctypes.c_int, _dp]),

@@ -100,10 +100,17 @@ class DeviceTracerSSPRK33(object):
             un_b = None if funcs is None else funcs.get('un')
             fl_b = None if funcs is None else funcs.get('flux')
             el_b = None if funcs is None else funcs.get('elev')
-            self.device.tracer_set_bc_velocity(self.tid, marker,
-                                               uv=None if uv_b is None else _vec(uv_b),
-                                               un=None if un_b is None else _cval(un_b),
-                                               flux=None if fl_b is None else _cval(fl_b),
+            def entry(x, vector=False):
+                """a Constant / number, or a Function as the values at the end nodes of the marker's boundary facets"""
+                if x is None:
+                    return None
+                if isinstance(x, Function):
+                    fs = x.function_space()
+                    if fs.family == 'CG':
+                        return self.device.facet_node_values(marker, x.dat.data_ro, cells_of_vertices=self.equation.mesh.cells)
+                    return self.device.facet_node_values(marker, x.cell_node_values())
+                return _vec(x) if vector else _cval(x)
+            self.device.tracer_set_bc_velocity(self.tid, marker, uv=entry(uv_b, vector=True), un=entry(un_b), flux=entry(fl_b),
                                                elev=None if el_b is None else _cval(el_b))
             if self.diffusive:                  # boundary term of the diffusion operator, tracer_eq_2d.py:264-277
                 if funcs is None:

@@ -89,6 +89,8 @@ struct Handle {
         double *bc_value_f = nullptr;                   // Function-valued 'value' boundaries, npc*npc planes
         int bc_vel_kind[SWE_MAX_MARKERS];               // 0 none, 1 'uv', 2 'un'
         double bc_u[SWE_MAX_MARKERS], bc_v[SWE_MAX_MARKERS];
+        double *bc_vel_f = nullptr;                     // Function-valued 'uv' / 'un' / 'flux', 4*npc planes per facet layout
+        int bc_vel_field[SWE_MAX_MARKERS];
         int bc_has_value[SWE_MAX_MARKERS];
         double bc_value[SWE_MAX_MARKERS];
         bool diff = false;                              // SIPG horizontal diffusion
@@ -556,6 +558,7 @@ void swe2d_destroy(swe2d_handle *hh)
         if (t.source) (void)hipFree(t.source);
         if (t.mu_v) (void)hipFree(t.mu_v);
         if (t.bc_value_f) (void)hipFree(t.bc_value_f);
+        if (t.bc_vel_f) (void)hipFree(t.bc_vel_f);
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
@@ -1170,7 +1173,8 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     a.vh = h->vh; a.valpha = h->valpha;
     for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_has_value[m] = t.bc_has_value[m]; a.bc_value[m] = t.bc_value[m]; }
     a.bc_value_f = t.bc_value_f;
-    for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_vel_kind[m] = t.bc_vel_kind[m]; a.bc_u[m] = t.bc_u[m]; a.bc_v[m] = t.bc_v[m]; }
+    for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_vel_kind[m] = t.bc_vel_kind[m]; a.bc_u[m] = t.bc_u[m]; a.bc_v[m] = t.bc_v[m]; a.bc_vel_field[m] = t.bc_vel_field[m]; }
+    a.bc_vel_f = t.bc_vel_f;
     for (int m = 0; m < SWE_MAX_MARKERS; m++) a.bc_len[m] = h->bc.len[m];
     // triangles: cell integral and interior facets of the diffusion inside the stage kernel, boundary facets by a launch
     // over the boundary cells (only when a marker has a diffusive boundary term at all)
@@ -1319,7 +1323,7 @@ int swe2d_tracer_add(swe2d_handle *hh, int *tracer_id)
     for (int m = 0; m < SWE_MAX_MARKERS; m++) {
         t.bc_has_value[m] = 0; t.bc_value[m] = 0.0;
         t.bc_diff_kind[m] = SWE_SIPG_BC_NONE; t.bc_diff_flux[m] = 0.0;
-        t.bc_vel_kind[m] = 0; t.bc_u[m] = 0.0; t.bc_v[m] = 0.0;
+        t.bc_vel_kind[m] = 0; t.bc_u[m] = 0.0; t.bc_v[m] = 0.0; t.bc_vel_field[m] = 0;
     }
     for (int b = 0; b < 3; b++) {
         HIP_TRY(h, hipMalloc(&t.buf[b], (size_t)h->npc*h->stride*sizeof(double)));
@@ -1399,7 +1403,32 @@ int swe2d_tracer_set_bc_velocity(swe2d_handle *hh, int id, int marker, int kind,
     h->tracers[id].bc_vel_kind[marker] = kind;
     h->tracers[id].bc_u[marker] = u;
     h->tracers[id].bc_v[marker] = v;
+    h->tracers[id].bc_vel_field[marker] = 0;
     return SWE2D_OK;
+}
+
+int swe2d_tracer_set_bc_velocity_facets(swe2d_handle *hh, int id, int marker, int kind, double elev, int n_facets,
+                                        const int32_t *cells, const int32_t *facets, const double *values)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (marker <= 0 || marker >= SWE2D_MAX_MARKERS) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "marker out of range");
+    if (kind < 1 || kind > 4) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "velocity kind must be 1 ('uv'), 2 ('un'), 3 ('flux') or 4 ('flux' + 'elev')");
+    if (n_facets < 0 || (n_facets > 0 && (!cells || !facets || !values)))
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad boundary facet values");
+    HIP_TRY(h, hipSetDevice(h->device));
+    Handle::Tracer &t = h->tracers[id];
+    const size_t bytes = (size_t)4*h->npc*h->stride*sizeof(double);
+    if (!t.bc_vel_f) {
+        HIP_TRY(h, hipMalloc(&t.bc_vel_f, bytes));
+        HIP_TRY(h, hipMemsetAsync(t.bc_vel_f, 0, bytes, h->stream));
+    }
+    t.bc_vel_kind[marker] = kind;
+    t.bc_vel_field[marker] = 1;
+    t.bc_u[marker] = 0.0;
+    t.bc_v[marker] = elev;                              // constant 'elev' of a 'flux' entry (kind 4)
+    return scatter_facet_values(h, t.bc_vel_f, n_facets, cells, facets, values, kind == 1 ? 2 : 1, 2);
 }
 
 int swe2d_tracer_set_bc_facets(swe2d_handle *hh, int id, int n_facets, const int32_t *cells, const int32_t *facets,

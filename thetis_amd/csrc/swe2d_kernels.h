@@ -1267,6 +1267,10 @@ struct SweTracerArgs {
                                          // 3 = 'flux' (bc_u) with elev_in, 4 = 'flux' with the constant 'elev' in bc_v
     double bc_len[SWE_MAX_MARKERS];      // boundary lengths (the 'flux' key divides by H_ext * length)
     double bc_u[SWE_MAX_MARKERS], bc_v[SWE_MAX_MARKERS];      // 'uv' components, or 'un' in bc_u
+    // Function-valued 'uv' / 'un' / 'flux' of the boundary dict, per boundary facet like the shallow water boundary fields:
+    // plane 2f (+1) = value at the first (second) node of facet f, second component at + 2k planes; or null
+    const double *bc_vel_f;
+    int bc_vel_field[SWE_MAX_MARKERS];   // 1: the marker's 'uv' / 'un' / 'flux' comes from bc_vel_f
 };
 
 // boundary facet of the tracer stage kernels (tracer_eq_2d.py:177-191 and :380-393): upwind value / flux with the external
@@ -1281,25 +1285,33 @@ __device__ __forceinline__ double swe_tracer_flux_speed(int depth_mode, double h
     return vel_factor*flux/(Hx*len);
 }
 
+// xa, xb: weights of the facet's end nodes at the quadrature point; k, f, npc_, S: where the Function-valued boundary
+// velocity of this facet lives in bc_vel_f
 __device__ __forceinline__ double swe_tracer_boundary_flux(const SweTracerArgs &p, int marker, double cq, double cext,
-                                                           double uq, double vq, double nxs, double nys, double hq = 0.0,
-                                                           double eq = 0.0, double alq = 0.0)
+                                                           double uq, double vq, double nxs, double nys, double hq,
+                                                           double eq, double alq, double xa, double xb, int k, int f,
+                                                           int npc_, size_t S)
 {
     double ue = uq, ve = vq;
     const int vk = p.bc_vel_kind[marker];
+    double bu = p.bc_u[marker], bv = p.bc_v[marker];
+    if (p.bc_vel_field[marker] && p.bc_vel_f) {                  // tracer_eq_2d.py:100-109 with Function-valued entries
+        const size_t pa = (size_t)(2*f)*S + k;
+        bu = xa*p.bc_vel_f[pa] + xb*p.bc_vel_f[pa + S];
+        if (vk == 1) bv = xa*p.bc_vel_f[pa + (size_t)(2*npc_)*S] + xb*p.bc_vel_f[pa + (size_t)(2*npc_ + 1)*S];
+    }
     if (vk >= 3) {
         const double rl = 1.0/sqrt(nxs*nxs + nys*nys);
-        const double sp = swe_tracer_flux_speed(p.depth_mode, hq, eq, alq, vk == 4, p.bc_v[marker], p.bc_u[marker],
-                                                p.bc_len[marker], p.vel_factor);
+        const double sp = swe_tracer_flux_speed(p.depth_mode, hq, eq, alq, vk == 4, bv, bu, p.bc_len[marker], p.vel_factor);
         ue = sp*nxs*rl;
         ve = sp*nys*rl;
     } else if (vk == 1) {
-        ue = p.vel_factor*p.bc_u[marker];
-        ve = p.vel_factor*p.bc_v[marker];
+        ue = p.vel_factor*bu;
+        ve = p.vel_factor*bv;
     } else if (vk == 2) {
         const double rl = 1.0/sqrt(nxs*nxs + nys*nys);
-        ue = p.bc_u[marker]*nxs*rl;
-        ve = p.bc_u[marker]*nys*rl;
+        ue = bu*nxs*rl;
+        ve = bu*nys*rl;
     }
     const double unav = 0.5*((uq + ue)*nxs + (vq + ve)*nys);
     if (p.conservative) {                    // flux_up = c_in*uv*s + c_ext*uv_ext*(1-s)
@@ -1517,7 +1529,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
                         const swe_rsrc_t ge = swe_rsrc(p.uv + 6*S);
                         eq = xa*swe_ld(ge, k8, a*S8) + xb*swe_ld(ge, k8, bb*S8);
                     }
-                    fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys, hq, eq, alq);
+                    fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys, hq, eq, alq, xa, xb, k, f, 3, S);
                 } else {
                     fq = cq*unown;                                                         // :189-191
                 }
@@ -2082,7 +2094,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
                         const swe_rsrc_t ge = swe_rsrc(p.uv + 8*S);
                         eq = xa*swe_ld(ge, k8, a*S8) + xb*swe_ld(ge, k8, bb*S8);
                     }
-                    fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys, hq, eq, alq);
+                    fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys, hq, eq, alq, xa, xb, k, f, 4, S);
                 } else {
                     fq = cq*unown;
                 }

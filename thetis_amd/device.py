@@ -458,16 +458,31 @@ class Swe2dDevice(object):
 
     def tracer_set_bc_velocity(self, tid, marker, uv=None, un=None, flux=None, elev=None):
         """External velocity of the tracer's boundary dict: 'uv' (2 components), 'flux' (with the dict's constant 'elev', if
-        any) or 'un', in the precedence of tracer_eq_2d.py:100-112; none of them: uv_ext = uv_in."""
-        if uv is not None:
-            kind, u, v = 1, float(uv[0]), float(uv[1])
-        elif flux is not None:
-            kind, u, v = (3, float(flux), 0.0) if elev is None else (4, float(flux), float(elev))
-        elif un is not None:
-            kind, u, v = 2, float(un), 0.0
-        else:
-            kind, u, v = 0, 0.0, 0.0
-        self._ck(self.lib.swe2d_tracer_set_bc_velocity(self.h, int(tid), self._slot(marker), kind, u, v))
+        any) or 'un', in the precedence of tracer_eq_2d.py:100-112; none of them: uv_ext = uv_in.  Constants, or Function-
+        valued entries as DG nodal arrays (N, k[, 2]) / ``FacetValues``."""
+        is_field = lambda v: isinstance(v, FacetValues) or (isinstance(v, np.ndarray) and v.ndim >= 2)
+        slot = self._slot(marker)
+        for kind, v in ((1, uv), (3 if elev is None else 4, flux), (2, un)):
+            if v is None:
+                continue
+            if is_field(v):
+                fv = v if isinstance(v, FacetValues) else self.facet_node_values(marker, v)
+                cells, facets = self.boundary_facets(slot)
+                vals = np.ascontiguousarray(np.asarray(fv.values, dtype=np.float64).reshape(
+                    (len(cells), 2, 2) if kind == 1 else (len(cells), 2)))
+                self._ck(self.lib.swe2d_tracer_set_bc_velocity_facets(
+                    self.h, int(tid), slot, kind, 0.0 if elev is None else float(elev), len(cells),
+                    _iptr(self._device_cells(cells)), _iptr(facets), _ptr(vals)))
+                return
+            if kind == 1:
+                u, w = float(v[0]), float(v[1])
+            elif kind == 2:
+                u, w = float(v), 0.0
+            else:
+                u, w = float(v), (0.0 if elev is None else float(elev))
+            self._ck(self.lib.swe2d_tracer_set_bc_velocity(self.h, int(tid), slot, kind, u, w))
+            return
+        self._ck(self.lib.swe2d_tracer_set_bc_velocity(self.h, int(tid), slot, 0, 0.0, 0.0))
 
     def tracer_set_source(self, tid, nodal):
         if nodal is None:

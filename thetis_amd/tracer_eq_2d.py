@@ -36,8 +36,8 @@ class TracerEquation2D(object):
                 if key not in ('value', 'elev', 'diff_flux', 'uv', 'un', 'flux'):
                     raise NotImplementedError('tracer boundary key {!r} is not on the device path '
                                               '("value", "uv", "un", "flux", "elev", "diff_flux")'.format(key))
-                if key in ('uv', 'un', 'flux', 'elev') and isinstance(v, Function):
-                    raise NotImplementedError("tracer boundary '{:}' must be a constant on the device path".format(key))
+                if key == 'elev' and isinstance(v, Function):
+                    raise NotImplementedError("tracer boundary 'elev' must be a constant on the device path")
                 if key == 'diff_flux' and not isinstance(v, (int, float, Constant)):
                     raise NotImplementedError("'diff_flux' must be a constant on the device path")
                 if key == 'value' and not isinstance(v, (int, float, Constant, Function)):
