@@ -189,3 +189,39 @@ def test_vtu_export_is_readable_binary(tmp_path):
             assert np.array_equal(data, vals.reshape(-1))
         assert tail.rstrip().endswith(b'</VTKFile>')
         assert 'timestep="1.5"' in open(tmp_path/name/(name + '.pvd')).read()
+
+
+def test_firedrake_shaped_arrays_give_the_swe2d_mesh_of_mesh2d():
+    """The array contract of the reference-side binding (thetis_amd/firedrake_adapter.py): a
+    hand-written fixture in the shapes a Firedrake mesh hands out (cell_node_map, interior / exterior facet tables with FIAT
+    local facet numbers, markers, a clockwise cell) is flattened to the swe2d_mesh arrays; they must be the arrays Mesh2d
+    derives independently from vertices and cells (edge matching) - what every device test of this repository runs on."""
+    import json
+    import os
+    from thetis_amd.firedrake_adapter import swe2d_mesh_arrays
+    from thetis_amd.mesh import Mesh2d, _rect_marker_fn
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'firedrake_like_mesh.json')) as f:
+        fx = json.load(f)
+    out = swe2d_mesh_arrays(fx['coords'], fx['cell_vertices'], fx['int_facet_cell'], fx['int_local_facet'], fx['ext_facet_cell'],
+                            fx['ext_local_facet'], fx['ext_markers'], dg_cell_nodes=fx['dg_cell_nodes'])
+    assert np.array_equal(out['cell_vertices'], fx['expected_cell_vertices_ccw'])
+    assert np.array_equal(out['dg_perm'], fx['expected_dg_perm'])
+    mesh = Mesh2d(np.array(fx['coords']), np.array(fx['cell_vertices']), marker_fn=_rect_marker_fn(2.0, 1.0))
+    assert np.array_equal(mesh.cells, out['cell_vertices'])
+    assert np.array_equal(mesh.cell_nbr, out['cell_neighbours'])
+    assert np.array_equal(mesh.cell_nbr_facet, out['cell_neighbour_facets'])
+    # node i of cell c in the C ABI's cell-major layout is the vertex cell_vertices[c, i]: the DG permutation follows the flip
+    dg_vertex = np.empty(12, dtype=int)
+    dg_vertex[np.array(fx['dg_cell_nodes']).ravel()] = np.array(fx['cell_vertices']).ravel()      # DG dof -> vertex it sits on
+    assert np.array_equal(dg_vertex[out['dg_perm']], out['cell_vertices'])
+    # a facet that is in neither table, or an unmarked exterior facet, is an error, not a silent wall
+    with pytest.raises(ValueError):
+        swe2d_mesh_arrays(fx['coords'], fx['cell_vertices'], fx['int_facet_cell'][:2], fx['int_local_facet'][:2],
+                          fx['ext_facet_cell'], fx['ext_local_facet'], fx['ext_markers'])
+    bad = list(fx['ext_markers'])
+    bad[0] = 0
+    with pytest.raises(ValueError):
+        swe2d_mesh_arrays(fx['coords'], fx['cell_vertices'], fx['int_facet_cell'], fx['int_local_facet'], fx['ext_facet_cell'],
+                          fx['ext_local_facet'], bad)
+    assert (swe2d_mesh_arrays(fx['coords'], fx['cell_vertices'], fx['int_facet_cell'], fx['int_local_facet'],
+                              fx['ext_facet_cell'], fx['ext_local_facet'], bad, halo_marker=9)['cell_neighbours'] == -9).sum() == 1
