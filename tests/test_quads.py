@@ -341,3 +341,4 @@ def test_demo_2d_multiple_tracers(hip_lib, ref_so):
         assert rel_linf(q, T) < 1e-10, label
     # the three fields are different tracers, not copies
     assert np.abs(solver_obj.fields['bell_2d'].cell_node_values() - solver_obj.fields['cone_2d'].cell_node_values()).max() > 0.1
+

@@ -1679,6 +1679,8 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_calibration_copy(const double *
 template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD>
 __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStageArgs p)
 {
+    // no implicit contraction (see swe_stage_kernel)
+#pragma clang fp contract(off)
 #ifdef SWE_NO_XCD_MAP
     const int lb = blockIdx.x;
 #else
@@ -1712,9 +1714,9 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         wv[i] = p.a1*v[i];
         we[i] = p.a1*e[i];
         if (HASU0) {
-            wu[i] += p.a0*swe_ld(swe_rsrc(p.u0), k8, i*S8);
-            wv[i] += p.a0*swe_ld(swe_rsrc(p.u0 + 4*S), k8, i*S8);
-            if (!WD) we[i] += p.a0*swe_ld(swe_rsrc(p.u0 + 8*S), k8, i*S8);
+            wu[i] = fma(p.a0, swe_ld(swe_rsrc(p.u0), k8, i*S8), wu[i]);
+            wv[i] = fma(p.a0, swe_ld(swe_rsrc(p.u0 + 4*S), k8, i*S8), wv[i]);
+            if (!WD) we[i] = fma(p.a0, swe_ld(swe_rsrc(p.u0 + 8*S), k8, i*S8), we[i]);
         }
     }
     double e0[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1723,21 +1725,24 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         for (int i = 0; i < 4; i++) e0[i] = swe_ld(swe_rsrc(p.u0 + 8*S), k8, i*S8);
     }
     double una[4], unb[4], vna[4], vnb[4], ena[4], enb[4];
+    {   // (an LDS exchange of the in-wave traces as in swe_stage_kernel<..., LDSX> was measured: 201 vs 203 us/step at 1 M
+        //  quadrilaterals - this kernel is bound by its 198 VGPRs and its arithmetic, not by the gathers; not kept)
 #pragma unroll
-    for (int f = 0; f < 4; f++) {
-        const int nbf = nb[f];
-        const int kn = nbf >= 0 ? (nbf >> 2) : k;
-        const int f2 = nbf >= 0 ? (nbf & 3) : f;
-        const int na = (f2 + 1) & 3;
-        const unsigned kn8 = (unsigned)kn*8u;
-        const unsigned ob = kn8 + ((f2 & 1) ? S8 : 0u) + ((f2 & 2) ? 2u*S8 : 0u);
-        const unsigned oa = kn8 + ((na & 1) ? S8 : 0u) + ((na & 2) ? 2u*S8 : 0u);
-        una[f] = swe_ld(gu, oa, 0);
-        unb[f] = swe_ld(gu, ob, 0);
-        vna[f] = swe_ld(gv, oa, 0);
-        vnb[f] = swe_ld(gv, ob, 0);
-        ena[f] = swe_ld(ge, oa, 0);
-        enb[f] = swe_ld(ge, ob, 0);
+        for (int f = 0; f < 4; f++) {
+            const int nbf = nb[f];
+            const int kn = nbf >= 0 ? (nbf >> 2) : k;
+            const int f2 = nbf >= 0 ? (nbf & 3) : f;
+            const int na = (f2 + 1) & 3;
+            const unsigned kn8 = (unsigned)kn*8u;
+            const unsigned ob = kn8 + ((f2 & 1) ? S8 : 0u) + ((f2 & 2) ? 2u*S8 : 0u);
+            const unsigned oa = kn8 + ((na & 1) ? S8 : 0u) + ((na & 2) ? 2u*S8 : 0u);
+            una[f] = swe_ld(gu, oa, 0);
+            unb[f] = swe_ld(gu, ob, 0);
+            vna[f] = swe_ld(gv, oa, 0);
+            vnb[f] = swe_ld(gv, ob, 0);
+            ena[f] = swe_ld(ge, oa, 0);
+            enb[f] = swe_ld(ge, ob, 0);
+        }
     }
     double px[4], py[4], h[4], H[4], al[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1750,12 +1755,12 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         H[i] = WD ? swe_wd_depth(h[i] + e[i], al[i]) : (NONLIN ? h[i] + e[i] : h[i]);
         if (WD) {           // the continuity equation advances zeta = D - h
             we[i] = p.a1*(H[i] - h[i]);
-            if (HASU0) we[i] += p.a0*(swe_wd_depth(h[i] + e0[i], al[i]) - h[i]);
+            if (HASU0) we[i] = fma(p.a0, swe_wd_depth(h[i] + e0[i], al[i]) - h[i], we[i]);
         }
     }
     const double ax = px[1] - px[0], ay = py[1] - py[0];
     const double bx = px[3] - px[0], by = py[3] - py[0];
-    const double A = ax*by - ay*bx;
+    const double A = fma(ax, by, -(ay*bx));
     const double rA = swe_rcp(A);
     // A * grad(xi), A * grad(zeta)
     const double xix = by, xiy = -bx, zex = -ay, zey = ax;
@@ -1766,53 +1771,56 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
     for (int f = 0; f < 4; f++) {
         const int a = f, b = (f + 1) & 3;
         const double nxs = py[b] - py[a], nys = px[a] - px[b];
-        const double len2 = nxs*nxs + nys*nys;
+        const double len2 = swe_dot2(nxs, nxs, nys, nys);
         double L, rL;
         swe_sqrt_rsqrt(len2, L, rL);
         double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
-        if (nb[f] >= 0) {
+        {   // branch-free (see swe_stage_kernel): a boundary facet carries the cell's own values as traces, its flux is discarded
             // neighbour's nodal depth on this facet (bathymetry and alpha are continuous: same vertices)
             const double Dna = WD ? swe_wd_depth(h[a] + ena[f], al[a]) : 0.0;
             const double Dnb = WD ? swe_wd_depth(h[b] + enb[f], al[b]) : 0.0;
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
-                const double uq = xa*u[a] + xb*u[b], vq = xa*v[a] + xb*v[b], eq = xa*e[a] + xb*e[b];
-                const double hq = xa*h[a] + xb*h[b];
-                const double un = xa*una[f] + xb*unb[f], vn = xa*vna[f] + xb*vnb[f], en = xa*ena[f] + xb*enb[f];
+                const double uq = swe_dot2(xa, u[a], xb, u[b]), vq = swe_dot2(xa, v[a], xb, v[b]), eq = swe_dot2(xa, e[a], xb, e[b]);
+                const double hq = swe_dot2(xa, h[a], xb, h[b]);
+                const double un = swe_dot2(xa, una[f], xb, unb[f]), vn = swe_dot2(xa, vna[f], xb, vnb[f]),
+                             en = swe_dot2(xa, ena[f], xb, enb[f]);
                 const double eav = 0.5*(eq + en);
-                const double Hav = WD ? 0.5*((xa*H[a] + xb*H[b]) + (xa*Dna + xb*Dnb)) : (NONLIN ? hq + eav : hq);
+                const double Hav = WD ? 0.5*(swe_dot2(xa, H[a], xb, H[b]) + swe_dot2(xa, Dna, xb, Dnb)) : (NONLIN ? hq + eav : hq);
                 const double c = swe_sqrt(g*Hav);
                 const double du = uq - un, dv = vq - vn;
-                const double dun = du*nxs + dv*nys;
-                const double spg = g*eav + c*dun*rL;
+                const double dun = swe_dot2(du, nxs, dv, nys);
+                const double spg = fma(c*dun, rL, g*eav);
                 double fu = spg*nxs, fv = spg*nys;
                 const double uav = 0.5*(uq + un), vav = 0.5*(vq + vn);
-                const double uavn = uav*nxs + vav*nys;
-                const double fe = Hav*uavn + c*(eq - en)*L;
+                const double uavn = swe_dot2(uav, nxs, vav, nys);
+                const double fe = fma(c*(eq - en), L, Hav*uavn);
                 if (NONLIN) {
-                    const double unown = uq*nxs + vq*nys;
-                    fu += uav*unown;
-                    fv += vav*unown;
+                    const double unown = swe_dot2(uq, nxs, vq, nys);
+                    fu = fma(uav, unown, fu);
+                    fv = fma(vav, unown, fv);
                     if (LF) {
                         const double gam = 0.5*fabs(uavn)*p.sigma_lf;
-                        fu += gam*du;
-                        fv += gam*dv;
+                        fu = fma(gam, du, fu);
+                        fv = fma(gam, dv, fv);
                     }
                 }
-                Fau += xa*fu; Fbu += xb*fu;
-                Fav += xa*fv; Fbv += xb*fv;
-                Fae += xa*fe; Fbe += xb*fe;
+                Fau = fma(xa, fu, Fau); Fbu = fma(xb, fu, Fbu);
+                Fav = fma(xa, fv, Fav); Fbv = fma(xb, fv, Fbv);
+                Fae = fma(xa, fe, Fae); Fbe = fma(xb, fe, Fbe);
             }
-        } else {
+        }
+        if (nb[f] < 0) {
             // boundary facets inline: this kernel runs at 2 waves/SIMD either way, and the post-compute epilogue of the
             // triangle kernel costs 14 % here (measured: 249 vs 219 us/step on 1M quadrilaterals)
+            Fau = 0.0; Fbu = 0.0; Fav = 0.0; Fbv = 0.0; Fae = 0.0; Fbe = 0.0;
             swe_boundary_facet<NONLIN, LF, WD>(p, -nb[f], k, a, b, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
                                                al[a], al[b], nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
         }
-        bu[a] -= 0.5*Fau; bu[b] -= 0.5*Fbu;
-        bv[a] -= 0.5*Fav; bv[b] -= 0.5*Fbv;
-        be[a] -= 0.5*Fae; be[b] -= 0.5*Fbe;
+        bu[a] = fma(-0.5, Fau, bu[a]); bu[b] = fma(-0.5, Fbu, bu[b]);
+        bv[a] = fma(-0.5, Fav, bv[a]); bv[b] = fma(-0.5, Fbv, bv[b]);
+        be[a] = fma(-0.5, Fae, be[a]); be[b] = fma(-0.5, Fbe, be[b]);
     }
 
     // ---- cell integrals, 2 x 2 Gauss-Legendre; weights A/4, gradients carry 1/A  ->  factor 1/4 on gradient terms
@@ -1830,13 +1838,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
             double uq = 0.0, vq = 0.0, eq = 0.0, Hq = 0.0, D = 0.0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                gx[i] = dxi[i]*xix + dze[i]*zex;
-                gy[i] = dxi[i]*xiy + dze[i]*zey;
-                uq += phi[i]*u[i];
-                vq += phi[i]*v[i];
-                eq += phi[i]*e[i];
-                Hq += phi[i]*H[i];
-                D += gx[i]*u[i] + gy[i]*v[i];              // A * div(u)
+                gx[i] = swe_dot2(dxi[i], xix, dze[i], zex);
+                gy[i] = swe_dot2(dxi[i], xiy, dze[i], zey);
+                uq = fma(phi[i], u[i], uq);
+                vq = fma(phi[i], v[i], vq);
+                eq = fma(phi[i], e[i], eq);
+                Hq = fma(phi[i], H[i], Hq);
+                D = fma(gy[i], v[i], fma(gx[i], u[i], D));  // A * div(u)
             }
             double cu = 0.0, cv_ = 0.0, ce = 0.0;          // coefficients of phi_i (times A)
             if (SRC) {
@@ -1888,13 +1896,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
             for (int i = 0; i < 4; i++) {
                 double fu = g*eq*gx[i], fv = g*eq*gy[i];                       // shallowwater_eq.py:361
                 if (NONLIN) {                                                  // :478
-                    const double adv = phi[i]*D + uq*gx[i] + vq*gy[i];
-                    fu += adv*uq;
-                    fv += adv*vq;
+                    const double adv = fma(vq, gy[i], fma(uq, gx[i], phi[i]*D));
+                    fu = fma(adv, uq, fu);
+                    fv = fma(adv, vq, fv);
                 }
-                bu[i] += 0.25*(fu + cu*phi[i]);
-                bv[i] += 0.25*(fv + cv_*phi[i]);
-                be[i] += 0.25*(Hq*(gx[i]*uq + gy[i]*vq) + ce*phi[i]);          // :422
+                bu[i] = fma(0.25, fma(cu, phi[i], fu), bu[i]);
+                bv[i] = fma(0.25, fma(cv_, phi[i], fv), bv[i]);
+                be[i] = fma(0.25, fma(ce, phi[i], Hq*swe_dot2(gx[i], uq, gy[i], vq)), be[i]);          // :422
             }
         }
     }
@@ -1905,9 +1913,9 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int n1 = (i + 1) & 3, n2 = (i + 2) & 3, n3 = (i + 3) & 3;
-        ou[i] = s*(16.0*bu[i] - 8.0*bu[n1] - 8.0*bu[n3] + 4.0*bu[n2]) + wu[i];
-        ov[i] = s*(16.0*bv[i] - 8.0*bv[n1] - 8.0*bv[n3] + 4.0*bv[n2]) + wv[i];
-        oe[i] = s*(16.0*be[i] - 8.0*be[n1] - 8.0*be[n3] + 4.0*be[n2]) + we[i];
+        ou[i] = fma(s, fma(4.0, bu[n2], fma(-8.0, bu[n3], fma(-8.0, bu[n1], 16.0*bu[i]))), wu[i]);
+        ov[i] = fma(s, fma(4.0, bv[n2], fma(-8.0, bv[n3], fma(-8.0, bv[n1], 16.0*bv[i]))), wv[i]);
+        oe[i] = fma(s, fma(4.0, be[n2], fma(-8.0, be[n3], fma(-8.0, be[n1], 16.0*be[i]))), we[i]);
     }
     if (WD && !(p.a0 == 0.0 && p.a1 == 0.0)) swe_wd_finish<4>(p.g, p.beta*p.dt, h, al, ou, ov, oe);
 #pragma unroll
