@@ -44,7 +44,9 @@ def main():
     tri = tri[keep]
     a, b, cc = p[tri[:, 0]], p[tri[:, 1]], p[tri[:, 2]]
     area2 = (b[:, 0] - a[:, 0])*(cc[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1])*(cc[:, 0] - a[:, 0])
-    tri = tri[np.abs(area2) > 1e3]                                            # drop degenerate slivers on the boundary curves
+    # drop slivers on the boundary curves: smallest altitude (2A / longest edge) at least 120 m
+    e = np.stack([np.hypot(*(b - a).T), np.hypot(*(cc - b).T), np.hypot(*(a - cc).T)], axis=1)
+    tri = tri[np.abs(area2)/e.max(axis=1) > 120.0]
     tri = tri[rng.permutation(len(tri))]                                      # a mesh generator's numbering: no locality
     used = np.unique(tri)
     remap = np.full(len(p), -1)
@@ -66,7 +68,10 @@ def main():
     mesh.boundary_len = mesh._boundary_length()
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'coast.msh')
     write_gmsh(mesh, out)
-    print(out, mesh.num_cells, 'triangles', mesh.num_vertices, 'vertices', mesh.boundary_len)
+    p3 = mesh.cell_xy()
+    ed = np.stack([np.hypot(*(p3[:, (i + 1) % 3] - p3[:, i]).T) for i in range(3)], axis=1)
+    print(out, mesh.num_cells, 'triangles', mesh.num_vertices, 'vertices', mesh.boundary_len, 'min altitude',
+          (2*mesh.cell_areas()/ed.max(axis=1)).min())
 
 
 if __name__ == '__main__':
