@@ -268,6 +268,8 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     if (h->field[SWE2D_FIELD_MANNING_DRAG]) { a.quad_f = h->field[SWE2D_FIELD_MANNING_DRAG]; a.quad_f_kind = 2; }
     if (h->field[SWE2D_FIELD_NIKURADSE]) { a.quad_f = h->field[SWE2D_FIELD_NIKURADSE]; a.quad_f_kind = 3; }
     a.bc = h->bc;
+    for (int m = 0; m < SWE_MAX_MARKERS; m++)
+        if (a.bc.drag[m] >= 0.0) a.bc.kind[m] |= SWE_BC_HAS_DRAG;          // one table read per boundary facet in the kernel
     const bool has_u0 = (a0 != 0.0);
     // triangles: cell integral and interior facets of the viscosity inside the stage kernel, boundary facets by a small
     // launch over the boundary cells

@@ -28,6 +28,7 @@
 #define SWE_BC_UV_FIELD 32
 #define SWE_BC_UN_FIELD 64
 #define SWE_BC_FLUX_FIELD 128
+#define SWE_BC_HAS_DRAG 256       // set by the host in the table handed to a launch: the marker has a boundary drag >= 0
 #ifndef SWE_BLOCK
 #define SWE_BLOCK 64
 #endif
@@ -246,7 +247,8 @@ struct SweBcFieldValues { double elev, u, v, un, flux; };   // Function-valued b
 template <bool NONLIN, bool LF, bool WD>
 __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int marker, double uq, double vq, double eq,
                                                double hq, double Hq, double alq, double nxs, double nys, double L,
-                                               double rL, const SweBcFieldValues &bf, double &fu, double &fv, double &fe)
+                                               double rL, const SweBcFieldValues &bf, double &fu, double &fv, double &fe,
+                                               int kind_all)
 {
     // No implicit contraction in the boundary code: it is inlined into several kernels (epilogue / inline-boundary variants,
     // quadrilaterals), which must agree bit for bit, and where the compiler fuses depends on the surrounding code.  Every
@@ -258,7 +260,9 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
     // a quarter of the waves do
     const double rg = swe_rcp(g);
     const double nx = nxs*rL, ny = nys*rL;
-    const int kind = (marker < SWE_MAX_MARKERS) ? p.bc.kind[marker] : 0;
+    // kind_all: the marker's entry of the table incl. SWE_BC_HAS_DRAG, read ONCE per facet by the caller (an entry of the
+    // kernel-argument table indexed per lane is a load from memory: here it would be a dependent one per use)
+    const int kind = kind_all & 0xff;
     const double un_own = swe_dot2(uq, nx, vq, ny);
     if (kind == 0) {
         // land boundary, shallowwater_eq.py:377-381 and :489-497
@@ -309,8 +313,8 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
             fv += un_rie3*0.5*(v_ext + vq);
         }
     }
-    const double cdb = (marker < SWE_MAX_MARKERS) ? p.bc.drag[marker] : -1.0;
-    if (cdb >= 0.0) {                                                                  // BoundaryDragTerm :717-724
+    if (kind_all & SWE_BC_HAS_DRAG) {                                                  // BoundaryDragTerm :717-724
+        const double cdb = p.bc.drag[marker];
         const double utx = uq - un_own*nx, uty = vq - un_own*ny;
         const double mag = swe_sqrt(swe_dot2(utx, utx, uty, uty));
         fu += cdb*mag*utx;
@@ -328,11 +332,13 @@ __device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int ma
                                                    double vb, double ea, double eb, double ha, double hb, double Ha,
                                                    double Hb, double ala, double alb, double nxs,
                                                    double nys, double L, double rL, double &Fau, double &Fbu,
-                                                   double &Fav, double &Fbv, double &Fae, double &Fbe)
+                                                   double &Fav, double &Fbv, double &Fae, double &Fbe, int kind_in = -1)
 {
 #pragma clang fp contract(off)
     // Function-valued boundary data live on the same DG nodes as the state: read the two facet nodes of this cell
-    const int kind = (marker < SWE_MAX_MARKERS) ? p.bc.kind[marker] : 0;
+    // (kind_in >= 0: the marker's table entry, already fetched by the caller together with its other loads)
+    const int kind_all = kind_in >= 0 ? kind_in : ((marker < SWE_MAX_MARKERS) ? p.bc.kind[marker] : 0);
+    const int kind = kind_all & 0xff;
     const size_t S = p.stride;
     double fea = 0.0, feb = 0.0, fua = 0.0, fub = 0.0, fva = 0.0, fvb = 0.0, fna = 0.0, fnb = 0.0, fxa = 0.0, fxb = 0.0;
     const size_t pa = (size_t)(2*a)*S + k, pb = pa + S;            // per-facet planes: facet index = first node a
@@ -355,7 +361,7 @@ __device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int ma
                      hq = swe_dot2(xa, ha, xb, hb);
         const double Hq = swe_dot2(xa, Ha, xb, Hb), alq = swe_dot2(xa, ala, xb, alb);   // Ha, Hb: nodal total depth (h, h + eta or D)
         double fu, fv, fe;
-        swe_boundary_flux<NONLIN, LF, WD>(p, marker, uq, vq, eq, hq, Hq, alq, nxs, nys, L, rL, bf, fu, fv, fe);
+        swe_boundary_flux<NONLIN, LF, WD>(p, marker, uq, vq, eq, hq, Hq, alq, nxs, nys, L, rL, bf, fu, fv, fe, kind_all);
         Fau += xa*fu; Fbu += xb*fu;
         Fav += xa*fv; Fbv += xb*fv;
         Fae += xa*fe; Fbe += xb*fe;
@@ -781,6 +787,13 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     // boundary markers of the three facets in one register (0: interior facet): all the boundary pass of the BINL variant
     // needs of nb[] at the end of the kernel
     const int bmarkers = (nb[0] < 0 ? -nb[0] : 0) | (nb[1] < 0 ? (-nb[1]) << 8 : 0) | (nb[2] < 0 ? (-nb[2]) << 16 : 0);
+    // ... and the table entry of the lane's first boundary facet, requested now with all the other loads: read inside the boundary
+    // pass it was a dependent trip to memory in every boundary wave (+0.9 us of "loads" in their wave timing)
+    int bkind1 = 0;
+    if (BINL && bmarkers != 0) {
+        const int m1 = (bmarkers & 0xff) ? (bmarkers & 0xff) : ((bmarkers & 0xff00) ? ((bmarkers >> 8) & 0xff) : (bmarkers >> 16));
+        bkind1 = m1 < SWE_MAX_MARKERS ? p.bc.kind[m1] : 0;
+    }
 #ifdef SWE_WAVE_TIMING
     if (nb[0] == 0x7fffffff) return;          // forces the index loads to land before the time stamp
     SWE_WT(1);
@@ -1016,6 +1029,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         // y2 - y0 = -nx[2], y1 - y0 = nx[0], x2 - x0 = ny[2] (negation is exact)
         const double sfac = 6.0*p.dt*p.beta*swe_rcp(fma(-ny[0], -nx[2], -(nx[0]*ny[2])));
         int rem = ((bmarkers & 0xff) ? 1 : 0) | ((bmarkers & 0xff00) ? 2 : 0) | ((bmarkers & 0xff0000) ? 4 : 0);
+        int kind_next = bkind1;                     // first pass: prefetched; a second pass (corner cell) reads the table
 #define SWE_SEL3(x, i) ((i) == 0 ? (x)[0] : ((i) == 1 ? (x)[1] : (x)[2]))
 #pragma unroll 1
         while (rem) {
@@ -1032,7 +1046,8 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
             swe_boundary_facet<NONLIN, LF, WD>(p, (bmarkers >> (8*f)) & 0xff, k, a, b, SWE_SEL3(u, a), SWE_SEL3(u, b), SWE_SEL3(v, a),
                                                SWE_SEL3(v, b), SWE_SEL3(e, a), SWE_SEL3(e, b), SWE_SEL3(h, a), SWE_SEL3(h, b),
                                                Ha_, Hb_, SWE_SEL3(al, a), SWE_SEL3(al, b), nxs, nys, L, rL,
-                                               Fau, Fbu, Fav, Fbv, Fae, Fbe);
+                                               Fau, Fbu, Fav, Fbv, Fae, Fbe, kind_next);
+            kind_next = -1;
             const double dau = -0.5*Fau, dbu = -0.5*Fbu, dav = -0.5*Fav, dbv = -0.5*Fbv, dae = -0.5*Fae, dbe = -0.5*Fbe;
 #pragma unroll
             for (int i = 0; i < 3; i++) {
