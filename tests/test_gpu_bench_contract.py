@@ -88,3 +88,28 @@ def test_bench_survives_a_transport_that_fails(hip_lib):
     d = json.loads(lines[0])
     assert d['config']['exchange'] == 'host' and d['config']['transports_verified'] == ['host']
     assert any('p2p' in f for f in d['config']['failures']) and d['value'] > 1e7
+
+
+def test_bench_survives_rccl_refusing_its_ranks(hip_lib):
+    """First-contact rehearsal with the REAL nccl backend: two ranks on the one GPU of the test box - RCCL refuses the duplicate
+    device ("invalid usage") at its first collective.  The bench must record that, keep the transports that verified (peer-to-peer
+    through IPC + the host-staged yardstick) and print its one JSON line from rank 0."""
+    base = dict(os.environ)
+    base.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29612', 'WORLD_SIZE': '2', 'LOCAL_RANK': '0',
+                 'THETIS_AMD_DIST_TIMEOUT_S': '120'})
+    base.pop('THETIS_AMD_DIST_BACKEND', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '8', '--warmup', '2', '--prewarm', '0.05']
+    procs = []
+    for rank in (1, 0):
+        e = dict(base)
+        e['RANK'] = str(rank)
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e, cwd=ROOT))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[1][1][-2000:]
+    lines = [l for l in outs[1][0].splitlines() if l.lstrip().startswith('{"metric"')]           # rank 0
+    assert len(lines) == 1 and not any(l.lstrip().startswith('{"metric"') for l in outs[0][0].splitlines())
+    d = json.loads(lines[0])
+    cfg = d['config']
+    assert cfg['transports_verified'] == ['p2p', 'host'] and cfg['exchange'] == 'p2p' and cfg['p2p_timeouts'] == 0
+    assert any("transport 'rccl'" in f for f in cfg['failures']) and cfg['volume_conserved'] is True
+    assert d['n_gpus'] == 2 and d['value'] > 1e8
