@@ -402,66 +402,66 @@ class FlowSolver2d(object):
         exactly those of the step-by-step loop."""
         if not self._initialized:
             self.initialize()
-        t_epsilon = 1.0e-5
-        cputimestamp = time_mod.perf_counter()
-        next_export_t = self.simulation_time + self.options.simulation_export_time
-        if self.options.check_volume_conservation_2d:
-            c = callback.VolumeConservation2DCallback(self, export_to_hdf5=False, append_to_log=True)
-            self.add_callback(c)
-        if self.options.check_tracer_conservation:
-            for label, tracer in self.options.tracer.items():
-                cls = (callback.ConservativeTracerMassConservation2DCallback if tracer.use_conservative_form
-                       else callback.TracerMassConservation2DCallback)          # solver2d.py:1047-1059
-                c = cls(label, self, export_to_hdf5=False, append_to_log=True)
-                self.add_callback(c, eval_interval='export')
-        if self.options.check_tracer_overshoot:
-            for label in self.options.tracer:
-                c = callback.TracerOvershootCallBack(label, self, export_to_hdf5=False, append_to_log=True)
-                self.add_callback(c, eval_interval='export')
-        initial_simulation_time = self.simulation_time
-        internal_iteration = 0
-        assert self.options.simulation_end_time is not None, 'simulation_end_time must be set'
-
-        # initial export
+        o = self.options
+        assert o.simulation_end_time is not None, 'simulation_end_time must be set'
+        eps = 1.0e-5                                    # the reference's t_epsilon (solver2d.py:1036)
+        self._register_requested_checks()
+        t_start, n_done = self.simulation_time, 0
+        export_due = t_start + o.simulation_export_time
+        wall = time_mod.perf_counter()
         self.print_state(0.0, print_header=True)
         if self.export_initial_state:
-            self.export(time=self.simulation_time)
-            if export_func is not None:
-                export_func()
+            self._export_now(export_func)
+        stepper = self.timestepper
+        can_batch = (_batch and update_forcings is None and not self.callbacks['timestep'] and hasattr(stepper, 'advance_steps'))
 
-        batch = (_batch and update_forcings is None and not self.callbacks['timestep']
-                 and hasattr(self.timestepper, 'advance_steps'))
-        while self.simulation_time <= self.options.simulation_end_time - t_epsilon:
-            n_adv = 1
-            if batch:
-                # number of steps until the loop would export or stop (same arithmetic as the step-by-step loop)
-                while True:
-                    t_k = initial_simulation_time + (internal_iteration + n_adv)*self.dt
-                    if t_k >= next_export_t - t_epsilon or not t_k <= self.options.simulation_end_time - t_epsilon:
-                        break
-                    n_adv += 1
-                self.timestepper.advance_steps(self.simulation_time, n_adv)
+        def steps_to_next_event():
+            """steps until the loop below would export or stop, by the loop's own arithmetic: t_k = t_start + k*dt"""
+            n = 1
+            while True:
+                t_k = t_start + (n_done + n)*self.dt
+                if t_k >= export_due - eps or not t_k <= o.simulation_end_time - eps:
+                    return n
+                n += 1
+
+        while self.simulation_time <= o.simulation_end_time - eps:
+            if can_batch:
+                n = steps_to_next_event()
+                stepper.advance_steps(self.simulation_time, n)
             else:
-                self.timestepper.advance(self.simulation_time, update_forcings)
-
-            # returns internal simulation time
-            yield self.simulation_time
-
-            # Move to next time step
-            self.iteration += n_adv
-            internal_iteration += n_adv
-            self.simulation_time = initial_simulation_time + internal_iteration*self.dt
-
+                n = 1
+                stepper.advance(self.simulation_time, update_forcings)
+            yield self.simulation_time                  # the time the step STARTED from, as the reference's generator does
+            n_done += n
+            self.iteration += n
+            self.simulation_time = t_start + n_done*self.dt          # k*dt, never an accumulated sum (solver2d.py:1127)
             self.callbacks.evaluate(mode='timestep')
-
-            # Write the solution to file
-            if self.simulation_time >= next_export_t - t_epsilon:
+            if self.simulation_time >= export_due - eps:
                 self.i_export += 1
-                next_export_t += self.options.simulation_export_time
-                cputime = time_mod.perf_counter() - cputimestamp
-                cputimestamp = time_mod.perf_counter()
-                self.print_state(cputime)
-                self.export(time=self.simulation_time)
-                if export_func is not None:
-                    export_func()
+                export_due += o.simulation_export_time
+                now = time_mod.perf_counter()
+                self.print_state(now - wall)
+                wall = now
+                self._export_now(export_func)
         return self.simulation_time
+
+    def _export_now(self, export_func=None):
+        self.export(time=self.simulation_time)
+        if export_func is not None:
+            export_func()
+
+    def _register_requested_checks(self):
+        """the conservation / overshoot checks the options ask for (solver2d.py:1040-1086), evaluated at every export"""
+        o = self.options
+        checks = []
+        if o.check_volume_conservation_2d:
+            checks.append(callback.VolumeConservation2DCallback(self))
+        for label, tracer in o.tracer.items():
+            if o.check_tracer_conservation:
+                make = (callback.ConservativeTracerMassConservation2DCallback if tracer.use_conservative_form
+                        else callback.TracerMassConservation2DCallback)
+                checks.append(make(label, self))
+            if o.check_tracer_overshoot:
+                checks.append(callback.TracerOvershootCallBack(label, self))
+        for c in checks:
+            self.add_callback(c, eval_interval='export')
