@@ -278,15 +278,17 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.nu_v = h->nu_v; a.nu_const = h->nu_const;
     a.visc_sipg = 3.0*h->sipg_factor;
     a.visc_grad_div = h->visc_grad_div; a.visc_grad_depth = h->visc_grad_depth;
-    // Boundary-inline variant of the triangle kernel (BINL, swe2d_kernels.h): faster than the epilogue variant at every size
-    // (us/step, same box, first BINL version: 125 k cells 36.6 -> 29.1, 250 k 53.0 -> 46.7, 500 k 81.7 -> 76.1, 1 M 138.1 ->
-    // 135.7); both give the same bits.  THETIS_AMD_BND_INLINE=0 selects the epilogue variant (parity test, A/B).
+    // Boundary-inline variant of the triangle kernel (BINL, swe2d_kernels.h): faster than or equal to the epilogue variant at
+    // every size (us/step, same box, production numbering: 125 k cells 27.9 -> 26.3, 250 k 41.0 -> 38.2, 500 k 66.1 -> 63.6,
+    // 1 M 117.9 -> 117.8); both give the same bits.  THETIS_AMD_BND_INLINE=0 selects the epilogue variant (parity test, A/B).
     const char *env_binl_s = std::getenv("THETIS_AMD_BND_INLINE");       // read per launch: tests switch it inside one process
     const bool binl = !(env_binl_s && std::atoi(env_binl_s) == 0);
-    // ... and for launches of half a million cells or more with the in-wave neighbour traces exchanged through LDS (LDSX;
-    // THETIS_AMD_LDSX=0/1 forces the choice).  Same bits in every variant: the kernel has no implicit contraction.
+    // ... and for launches of three million cells or more (state beyond the Infinity Cache) with the in-wave neighbour traces
+    // exchanged through LDS (LDSX; THETIS_AMD_LDSX=0/1 forces the choice).  With the device's tile-Hilbert numbering, same box,
+    // us/step without / with: 250 k cells 37.9 / 42.2, 500 k 63.5 / 68.3, 1 M 115-118 / 118-119, 2 M 295-312 / 297-298,
+    // 4 M 573-583 / 544.  Same bits in every variant: the kernel has no implicit contraction.
     const char *env_ldsx_s = std::getenv("THETIS_AMD_LDSX");
-    const bool ldsx = env_ldsx_s ? std::atoi(env_ldsx_s) != 0 : (c1 - c0) >= 400000;
+    const bool ldsx = env_ldsx_s ? std::atoi(env_ldsx_s) != 0 : (c1 - c0) >= 3000000;
     stage_kernel_t kern = fused_visc
         ? pick_kernel_visc(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
         : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4, binl)

@@ -830,10 +830,12 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     if constexpr (LDSX) {
     // LDSX (large launches): neighbour traces of cells inside this wave's own 64-cell block (~85 % with the tile-Hilbert numbering) come from LDS: the
     // wave publishes its nine nodal values there (one-wave workgroup: the barrier is local to the wave), only the others are
-    // gathered from memory, issued before the exchange.  Same values either way.  Measured (us/step, same box, without /
-    // with): 125 k cells 28.4 / 28.8, 250 k 45.4 / 47.0, 500 k 75.8 / 76.2, 1 M 137-140 / 129-134 (-5 %), 4 M 833 / 714 (-14 %):
-    // the in-wave gathers no longer compete with the streaming loads for the L1's 64 B/clk; below ~0.5 M cells the launch
-    // is latency-bound and the extra LDS round trip costs more than it saves, so the host picks the variant by launch size.
+    // gathered from memory, issued before the exchange.  Same values either way.  Measured with the device's tile-Hilbert
+    // numbering (us/step, same box, without / with): 250 k cells 37.9 / 42.2, 500 k 63.5 / 68.3, 1 M 115-118 / 118-119,
+    // 2 M 295-312 / 297-298, 4 M 573-583 / 544 (-6 %): it pays where the state no longer fits the Infinity Cache and the
+    // gathers compete with the streaming loads for HBM-side bandwidth; below that the extra LDS round trip costs more than it
+    // saves, so the host picks the variant by launch size.  (With a row-major cell numbering, where a third of the traces
+    // come from the next row, the gain is larger and starts at 1 M cells: -5 % there, -14 % at 4 M.)
     __shared__ double xs[9][SWE_BLOCK];
     const int lane = (int)threadIdx.x, kw0 = k - lane, kw1 = min(kw0 + SWE_BLOCK, p.cell_end);
     int lnb[3], nodeb[3];

@@ -23,7 +23,8 @@ def tile_perm(mesh, bx, by):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--order', default='natural')
+    ap.add_argument('--order', default='auto', help="device cell numbering: 'auto' (what every other entry point uses), 'natural', "
+                    "'hilbert', 'tile:BX:BY', 'htile:BX:BY'")
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--tag', default='')
     ap.add_argument('--nx', type=int, default=0, help='override the mesh: RectangleMesh(nx, ny), same cell size')
