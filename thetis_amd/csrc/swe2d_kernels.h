@@ -189,18 +189,21 @@ __device__ __forceinline__ void swe_wd_finish(double g, double dt_stage, const d
 #pragma unroll
             for (int i = 0; i < K; i++) D[i] = flat;
         } else {
-            const double theta = (mean - fl)/(mean - dmin);
+            const double theta = (mean - fl)*swe_rcp(mean - dmin);
 #pragma unroll
             for (int i = 0; i < K; i++) D[i] = mean + theta*(D[i] - mean);
         }
     }
+    // (quotients and the square root through the v_rcp / v_rsq helpers: this kernel is bound by its arithmetic)
+    const double rg = swe_rcp(g);
 #pragma unroll
     for (int i = 0; i < K; i++) {
-        const double eta = D[i] - al[i]*al[i]/(4.0*D[i]) - h[i];
+        const double eta = D[i] - 0.25*al[i]*al[i]*swe_rcp(D[i]) - h[i];
         oe[i] = eta;
-        const double psi = fmin(1.0, fmax(0.0, -(h[i] + eta)/al[i] - 1.0));
+        const double ral = swe_rcp(al[i]);
+        const double psi = fmin(1.0, fmax(0.0, -(h[i] + eta)*ral - 1.0));
         if (psi > 0.0) {
-            const double fac = exp(-dt_stage/(SWE_WD_TAU*sqrt(al[i]/g))*psi*psi);
+            const double fac = exp(-dt_stage*(1.0/SWE_WD_TAU)*swe_sqrt(g*ral)*psi*psi);     // 1/sqrt(alpha/g) = sqrt(g/alpha)
             ou[i] *= fac;
             ov[i] *= fac;
         }
@@ -455,13 +458,19 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
             const double cq = l[0]*cf[0] + l[1]*cf[1] + l[2]*cf[2];              // field coefficient at the point
             const int kind = p.quad_f ? p.quad_f_kind : (p.manning >= 0.0 ? 2 : (p.nikuradse >= 0.0 ? 3 : 1));
             const double coef = p.quad_f ? cq : (kind == 2 ? p.manning : (kind == 3 ? p.nikuradse : p.quad_drag));
-            double cd = coef;
-            if (kind == 2) cd = g*coef*coef*swe_rcbrt(Hq);
-            if (kind == 3) {                             // C_D = 2 kappa^2 / ln(11.036 H/k_s)^2 for H > k_s, else 0   :696-697
-                const double lg = log(11.036*Hq/coef);
-                cd = (Hq > coef) ? 0.32/(lg*lg) : 0.0;
+            double cdh;                                  // C_D / H
+            if (kind == 2) {                             // Manning: C_D/H = g mu^2 H^(-4/3) = g mu^2 (H^(-1/3))^4: no reciprocal
+                const double y = swe_rcbrt(Hq);
+                cdh = g*coef*coef*((y*y)*(y*y));
+            } else {
+                double cd = coef;
+                if (kind == 3) {                         // C_D = 2 kappa^2 / ln(11.036 H/k_s)^2 for H > k_s, else 0   :696-697
+                    const double lg = log(11.036*Hq/coef);
+                    cd = (Hq > coef) ? 0.32/(lg*lg) : 0.0;
+                }
+                cdh = cd*swe_rcp(Hq);
             }
-            const double s = ww*A*cd*swe_sqrt(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother)*swe_rcp(Hq);
+            const double s = ww*A*cdh*swe_sqrt(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother);
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 bu[i] -= s*l[i]*uq;
