@@ -42,6 +42,30 @@ def main():
     with open(OUT, 'w') as f:
         json.dump(data, f, indent=1)
     print(json.dumps(data, indent=1))
+    # every EXPLICIT tableau the reference defines (zero diagonal of a): pins a general re-implementation of the conversion
+    allx = {}
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name.endswith('Abstract') and node.name != 'AbstractRKScheme':
+            tab = {}
+            for stmt in node.body:
+                if isinstance(stmt, ast.Assign):
+                    try:
+                        exec(compile(ast.Module(body=[stmt], type_ignores=[]), REF, 'exec'), {'numpy': numpy, 'np': numpy}, tab)
+                    except Exception:
+                        pass
+            if 'a' not in tab or 'b' not in tab:
+                continue
+            a = numpy.array(tab['a'], dtype=float)
+            b = numpy.array(tab['b'], dtype=float)
+            if a.ndim != 2 or numpy.diag(a).any():
+                continue
+            al, be = ns['butcher_to_shuosher_form'](a, b)
+            allx[node.name] = {'a': a.tolist(), 'b': b.tolist(), 'alpha_hex': [[float(x).hex() for x in r] for r in al],
+                               'beta_hex': [[float(x).hex() for x in r] for r in be]}
+    with open(os.path.join(os.path.dirname(OUT), 'shuosher_explicit.json'), 'w') as f:
+        json.dump({'source': 'thetis/rungekutta.py:13-87 executed on every explicit *Abstract tableau of the file', 'schemes': allx},
+                  f, indent=1)
+    print(sorted(allx))
 
 
 if __name__ == '__main__':

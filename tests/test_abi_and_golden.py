@@ -113,3 +113,25 @@ def test_shuosher_golden_pins_device_coefficients(hip_lib):
         else:
             assert a0[i] == alpha[i + 1][0] and ai[i] == alpha[i + 1][i]
             assert all(alpha[i + 1][j] == 0.0 for j in range(1, i))
+
+
+def test_general_butcher_to_shuosher_conversion_matches_the_reference_output():
+    """thetis_amd.rungekutta.butcher_to_shuosher_form (own back substitution) against tests/golden/shuosher_explicit.json = the
+    reference's function executed on every explicit tableau of its file (tests/golden/make_shuosher_golden.py): bit for bit for
+    SSPRK33 (what the device coefficients are), to round-off for the others (the reference inverts with LAPACK)."""
+    import json
+    import os
+    from thetis_amd.rungekutta import SSPRK33Abstract, butcher_to_shuosher_form
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'shuosher_explicit.json')) as f:
+        gold = json.load(f)['schemes']
+    assert set(gold) >= {'SSPRK33Abstract', 'ForwardEulerAbstract', 'ERKMidpointAbstract', 'ERKLSPUM2Abstract', 'ERKLPUM2Abstract'}
+    for name, g in gold.items():
+        al, be = butcher_to_shuosher_form(np.array(g['a']), np.array(g['b']))
+        al_g = np.array([[float.fromhex(x) for x in r] for r in g['alpha_hex']])
+        be_g = np.array([[float.fromhex(x) for x in r] for r in g['beta_hex']])
+        assert np.allclose(al, al_g, rtol=0, atol=4e-16) and np.allclose(be, be_g, rtol=0, atol=4e-16), name
+        if name == 'SSPRK33Abstract':
+            assert np.array_equal(al, al_g) and np.array_equal(be, be_g)
+            assert np.array_equal(al, SSPRK33Abstract.alpha) and np.array_equal(be, SSPRK33Abstract.beta)
+    with pytest.raises(NotImplementedError):
+        butcher_to_shuosher_form(np.array([[0.5]]), np.array([1.0]))              # implicit midpoint: not this path

@@ -18,7 +18,42 @@ from .options import Constant
 from .shallowwater_eq import g_grav
 from .timeintegrator import TimeIntegrator
 
-__all__ = ['ForwardEuler', 'SSPRK33Abstract', 'ERKGenericShuOsher', 'SSPRK33']
+__all__ = ['ForwardEuler', 'SSPRK33Abstract', 'ERKGenericShuOsher', 'SSPRK33', 'butcher_to_shuosher_form']
+
+
+def butcher_to_shuosher_form(a, b):
+    """Shu-Osher arrays (alpha, beta), both (s+1, s+1), of an EXPLICIT s-stage Butcher tableau (a, b) - the form the reference
+    builds in rungekutta.py:13-87: beta holds the sub-diagonal of the stacked tableau K = [a; b], alpha follows from
+
+        K[i, :] = sum_j alpha[i, j] K[j, :] + beta[i, :]          (row i of the stage u_i = u_0 + dt sum_m K[i, m] F_m)
+
+    solved row by row by back substitution (the reference inverts the lower-triangular block with numpy.linalg instead), and
+    alpha[i, 0] = 1 - sum_j alpha[i, j] by consistency.  Entries below 1e-13 are rounded to zero as the reference does.
+    tests/golden/shuosher_explicit.json holds the reference function's own output for every explicit tableau of its file."""
+    a = np.atleast_2d(np.asarray(a, dtype=float))
+    b = np.asarray(b, dtype=float).reshape(-1)
+    s_ = a.shape[0]
+    if a.shape != (s_, s_) or b.shape != (s_,):
+        raise ValueError('a must be (s, s) and b (s,)')
+    if np.diag(a).any() or np.triu(a, 1).any():
+        raise NotImplementedError('implicit tableaus are outside the explicit path of this build')
+    K = np.vstack([a, b])                                  # row i: weights of F_0..F_{s-1} in stage i (row s: the step)
+    alpha = np.zeros((s_ + 1, s_ + 1))
+    beta = np.zeros((s_ + 1, s_ + 1))
+    alpha[0, 0] = 1.0
+    for i in range(1, s_ + 1):
+        beta[i, i - 1] = K[i, i - 1]
+        for m in range(i - 2, -1, -1):                     # column m fixes alpha[i, m + 1]
+            if K[m + 1, m] == 0.0:
+                raise NotImplementedError('zero sub-diagonal entry: this Shu-Osher form does not exist for the tableau')
+            rest = sum(alpha[i, j]*K[j, m] for j in range(m + 2, i))
+            alpha[i, m + 1] = (K[i, m] - rest)/K[m + 1, m]
+        alpha[i, 0] = 1.0 - alpha[i, 1:].sum()
+    alpha[np.abs(alpha) < 1e-13] = 0.0
+    beta[np.abs(beta) < 1e-13] = 0.0
+    assert np.allclose(alpha.sum(axis=1), 1.0)
+    assert np.allclose(beta[:, :-1] + alpha[:, :-1] @ a, K)
+    return alpha, beta
 
 
 class SSPRK33Abstract(object):
