@@ -18,6 +18,64 @@
 
 static_assert(SWE2D_MAX_MARKERS == SWE_MAX_MARKERS, "marker table size mismatch");
 
+#ifdef SWE_RANGE_CHECK
+// Range-checked build (swe2d_kernels.h): every device allocation of this library is recorded with its requested size;
+// the sorted table is copied to the device before a launch whenever it changed.
+#include <map>
+#include <mutex>
+namespace {
+std::mutex g_chk_mutex;
+std::map<unsigned long long, unsigned long long> g_chk_allocs;       // base -> end
+bool g_chk_dirty = true;
+unsigned long long g_chk_launches = 0;
+hipError_t swe_chk_malloc(void **p, size_t n)
+{
+    const hipError_t e = hipMalloc(p, n);
+    if (e == hipSuccess && *p) {
+        std::lock_guard<std::mutex> lock(g_chk_mutex);
+        const char *st = getenv("THETIS_AMD_RANGE_SELFTEST");                  // negative control: record half of every allocation
+        g_chk_allocs[(unsigned long long)*p] = (unsigned long long)*p + ((st && atoi(st)) ? n/2 : n);
+        g_chk_dirty = true;
+    }
+    return e;
+}
+template <class T> hipError_t swe_chk_malloc(T **p, size_t n) { return swe_chk_malloc((void **)p, n); }
+hipError_t swe_chk_free(void *p)
+{
+    { std::lock_guard<std::mutex> lock(g_chk_mutex); g_chk_allocs.erase((unsigned long long)p); g_chk_dirty = true; }
+    return hipFree(p);
+}
+void swe_chk_sync(hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lock(g_chk_mutex);
+    g_chk_launches++;
+    if (!g_chk_dirty) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return;
+    static SweChkTable t;
+    t.n = 0;
+    for (auto &kv : g_chk_allocs) if (t.n < SWE_CHK_MAX) { t.lo[t.n] = kv.first; t.hi[t.n] = kv.second; t.n++; }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(swe_chk_tab), &t, sizeof(t));
+    g_chk_dirty = false;
+}
+}
+#define hipMalloc(p, n) swe_chk_malloc(p, n)
+#define hipFree(p) swe_chk_free(p)
+#define SWE_CHK_SYNC(stream) swe_chk_sync(stream)
+extern "C" int swe2d_debug_range_report(unsigned long long out[5])
+{
+    std::lock_guard<std::mutex> lock(g_chk_mutex);
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(swe_chk_report), 4*sizeof(unsigned long long)) != hipSuccess) return 1;
+    out[3] = g_chk_launches;
+    out[4] = g_chk_allocs.size();
+    return 0;
+}
+#else
+#define SWE_CHK_SYNC(stream) ((void)0)
+#endif
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -298,6 +356,7 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
     // the XCD-chunked block map needs a grid that is a multiple of 8; surplus blocks exit immediately
     const int grid = ((nblocks + 7)/8)*8;
+    SWE_CHK_SYNC(h->stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     if (h->visc) {
@@ -1036,6 +1095,7 @@ int swe2d_diagnostics(swe2d_handle *hh, double out[4])
     Handle *h = H(hh);
     if (!h || !out) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    SWE_CHK_SYNC(h->stream);
     if (h->npc == 4)
         hipLaunchKernelGGL(swe_diag_kernel_quad, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
                            h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial,
@@ -1191,6 +1251,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
                      : pick_tracer_kernel(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr);
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
     const int grid = ((nblocks + 7)/8)*8;
+    SWE_CHK_SYNC(h->stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     if (t.diff) {

@@ -375,6 +375,10 @@ __device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int ma
 // every plane of a cell, the plane offsets stay in SGPRs, and no 64-bit per-lane address arithmetic is issued.
 // A resource spans 4 GiB: one resource per group of three planes, swe2d_create rejects 3*stride*8 >= 2^32.
 typedef unsigned int swe_u32x2 __attribute__((ext_vector_type(2)));
+#ifndef SWE_ST_AUX
+#define SWE_ST_AUX 0             // cache policy of the state stores (experiments: 16 = sc1 write-through, 2 = nt)
+#endif
+#ifndef SWE_RANGE_CHECK
 typedef __amdgpu_buffer_rsrc_t swe_rsrc_t;
 __device__ __forceinline__ swe_rsrc_t swe_rsrc(const void *base)
 {
@@ -388,13 +392,54 @@ __device__ __forceinline__ int swe_ldi(swe_rsrc_t r, unsigned voff, unsigned sof
 {
     return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
 }
-#ifndef SWE_ST_AUX
-#define SWE_ST_AUX 0             // cache policy of the state stores (experiments: 16 = sc1 write-through, 2 = nt)
-#endif
 __device__ __forceinline__ void swe_st(swe_rsrc_t r, unsigned voff, unsigned soff, double x)
 {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(swe_u32x2, x), r, voff, soff, SWE_ST_AUX);
 }
+#else
+// Range-checked build (tools/range_check.sh; never the shipped library): every raw-buffer access of the stage, tracer and
+// viscosity kernels is tested against the table of the library's own device allocations (exact requested sizes, filled by
+// the host before each launch).  An access outside every allocation is counted, its address and source line recorded, and
+// not performed.  The raw-buffer resources of the product build span 4 GiB, i.e. the hardware checks nothing there.
+#define SWE_CHK_MAX 4096
+struct SweChkTable { unsigned long long lo[SWE_CHK_MAX], hi[SWE_CHK_MAX]; int n; };
+__device__ SweChkTable swe_chk_tab;                          // sorted by lo, disjoint
+__device__ unsigned long long swe_chk_report[4];             // violations, first address, its source line, (host) checked launches
+struct swe_rsrc_t { __amdgpu_buffer_rsrc_t r; unsigned long long base; };
+__device__ __forceinline__ swe_rsrc_t swe_rsrc(const void *base)
+{
+    swe_rsrc_t x;
+    x.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xffffffff, 0x00020000);
+    x.base = (unsigned long long)base;
+    return x;
+}
+__device__ __noinline__ bool swe_chk(unsigned long long addr, unsigned bytes, int line)
+{
+    int lo = 0, hi = swe_chk_tab.n;                          // last entry with lo <= addr
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (swe_chk_tab.lo[mid] <= addr) lo = mid; else hi = mid; }
+    const bool ok = swe_chk_tab.n > 0 && swe_chk_tab.lo[lo] <= addr && addr + bytes <= swe_chk_tab.hi[lo];
+    if (!ok && atomicAdd(&swe_chk_report[0], 1ull) == 0ull) { swe_chk_report[1] = addr; swe_chk_report[2] = (unsigned long long)line; }
+    return ok;
+}
+__device__ __forceinline__ double swe_ld_chk(swe_rsrc_t r, unsigned voff, unsigned soff, int line)
+{
+    if (!swe_chk(r.base + voff + soff, 8, line)) return 0.0;
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r.r, voff, soff, 0));
+}
+__device__ __forceinline__ int swe_ldi_chk(swe_rsrc_t r, unsigned voff, unsigned soff, int line)
+{
+    if (!swe_chk(r.base + voff + soff, 4, line)) return 0;
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(r.r, voff, soff, 0);
+}
+__device__ __forceinline__ void swe_st_chk(swe_rsrc_t r, unsigned voff, unsigned soff, double x, int line)
+{
+    if (!swe_chk(r.base + voff + soff, 8, line)) return;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(swe_u32x2, x), r.r, voff, soff, SWE_ST_AUX);
+}
+#define swe_ld(r, v, s) swe_ld_chk(r, v, s, __LINE__)
+#define swe_ldi(r, v, s) swe_ldi_chk(r, v, s, __LINE__)
+#define swe_st(r, v, s, x) swe_st_chk(r, v, s, x, __LINE__)
+#endif
 
 // Optional cell-local terms (SRC kernel variant): Coriolis, linear / quadratic / Manning drag, atmospheric pressure
 // gradient, momentum and volume sources.  b-vectors are the assembled integrals (before the mass inverse).
