@@ -3,6 +3,7 @@
 #include "../../include/swe2d.h"
 #include "swe2d_kernels.h"
 #include "swe2d_sipg.h"
+#include "swe2d_step.h"
 #include "swe2d_p2p.h"
 
 #include <dlfcn.h>
@@ -108,6 +109,11 @@ struct Handle {
     bool fuse_visc = true;                              // THETIS_AMD_NO_VISC_FUSION=1: separate SIPG pass (A/B, debugging)
     int4 *idx4 = nullptr;                               // packed triangle connectivity (stage kernel), see SweStageArgs
     int2 *idx2 = nullptr;
+    // fused SSPRK33 step (swe2d_step.h): host copy of the packed neighbour codes [3][S] and the tile lists per cell range
+    std::vector<int> h_nbr, h_cv;
+    struct StepTiles { int c0 = 0, c1 = 0, B = 0, n_tiles = 0; int4 *slot = nullptr; int2 *vert = nullptr; int4 *n = nullptr; };
+    std::vector<StepTiles> step_tiles;
+    int step_tile_cells = 128, step_block = 256;        // THETIS_AMD_STEP_TILE=C,B (B a multiple of 64, <= SWE_STEP_MAX_BLOCK)
     double *vx = nullptr, *vy = nullptr, *vh = nullptr;
     double *bc_field[4] = {nullptr, nullptr, nullptr, nullptr};  // Function-valued boundary data per facet: elev, uv, un, flux
     double *valpha = nullptr;                          // per-vertex wetting-drying alpha
@@ -289,11 +295,8 @@ stage_kernel_t pick_kernel_quad(bool nl, bool lf, bool u0, bool src)
     return nl ? pickq_lf<true>(lf, u0, src) : pickq_lf<false>(lf, u0, src);
 }
 
-// Launch one stage on cells [c0, c1).  in/out/u0 are state buffer indices.
-int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1)
+void fill_stage_args(Handle *h, SweStageArgs &a, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1)
 {
-    if (c1 <= c0) return SWE2D_OK;
-    SweStageArgs a;
     a.uin = h->state[in];
     a.u0 = h->state[u0];
     a.uout = h->state[out];
@@ -328,14 +331,22 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     a.bc = h->bc;
     for (int m = 0; m < SWE_MAX_MARKERS; m++)
         if (a.bc.drag[m] >= 0.0) a.bc.kind[m] |= SWE_BC_HAS_DRAG;          // one table read per boundary facet in the kernel
-    const bool has_u0 = (a0 != 0.0);
-    // triangles: cell integral and interior facets of the viscosity inside the stage kernel, boundary facets by a small
-    // launch over the boundary cells
-    const bool fused_visc = h->visc && h->fuse_visc && h->npc == 3 && !h->wd && h->opp4;
     a.opp4 = h->opp4;
     a.nu_v = h->nu_v; a.nu_const = h->nu_const;
     a.visc_sipg = 3.0*h->sipg_factor;
     a.visc_grad_div = h->visc_grad_div; a.visc_grad_depth = h->visc_grad_depth;
+}
+
+// Launch one stage on cells [c0, c1).  in/out/u0 are state buffer indices.
+int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1)
+{
+    if (c1 <= c0) return SWE2D_OK;
+    SweStageArgs a;
+    fill_stage_args(h, a, in, u0, out, a0, a1, beta, c0, c1);
+    const bool has_u0 = (a0 != 0.0);
+    // triangles: cell integral and interior facets of the viscosity inside the stage kernel, boundary facets by a small
+    // launch over the boundary cells
+    const bool fused_visc = h->visc && h->fuse_visc && h->npc == 3 && !h->wd && h->opp4;
     // Boundary-inline variant of the triangle kernel (BINL, swe2d_kernels.h): faster than or equal to the epilogue variant at
     // every size (us/step, same box, production numbering: 125 k cells 27.9 -> 26.3, 250 k 41.0 -> 38.2, 500 k 66.1 -> 63.6,
     // 1 M 117.9 -> 117.8); both give the same bits.  THETIS_AMD_BND_INLINE=0 selects the epilogue variant (parity test, A/B).
@@ -402,6 +413,120 @@ int stage_on_range(Handle *h, int i_stage, int c0, int c1)
 }
 
 int grid_for(int n) { return (n + 255)/256; }
+
+// ---- fused SSPRK33 step (swe2d_step.h)
+typedef void (*step_kernel_t)(const SweStepArgs);
+template <bool NL, bool LF>
+step_kernel_t pick_step_src(bool src) { return src ? swe_step_kernel<NL, LF, true> : swe_step_kernel<NL, LF, false>; }
+step_kernel_t pick_step_kernel(bool nl, bool lf, bool src)
+{
+    return nl ? (lf ? pick_step_src<true, true>(src) : pick_step_src<true, false>(src))
+              : (lf ? pick_step_src<false, true>(src) : pick_step_src<false, false>(src));
+}
+
+// the configurations the fused step kernel covers; everything else steps stage by stage (same bits)
+bool step_kernel_covers(const Handle *h)
+{
+    const char *e = std::getenv("THETIS_AMD_BND_INLINE");
+    return h->npc == 3 && !h->wd && !h->visc && !h->h_nbr.empty() && !(e && std::atoi(e) == 0);
+}
+
+// Tiles of the cells [c0, c1): C consecutive cells + three rings of facet neighbours; core + rings 1, 2 (the cells a stage is
+// computed on) take at most B slots, ring 3 (read only) may spill into SWE_STEP_EXTRA more.  The core shrinks where the rings
+// are large: ragged ends of the numbering, unstructured patches.  Built once per range, kept on the device.
+Handle::StepTiles *step_tiles_for(Handle *h, int c0, int c1)
+{
+    for (auto &t : h->step_tiles) if (t.c0 == c0 && t.c1 == c1) return &t;
+    const int B = h->step_block, XS = B + SWE_STEP_EXTRA, n = h->n_cells;
+    const size_t S = h->stride;
+    const int *nbr = h->h_nbr.data(), *cv = h->h_cv.data();
+    std::vector<int> slot_of((size_t)n, -1), slots;
+    std::vector<int4> slot_rows, counts;
+    std::vector<int2> vert_rows;
+    auto grow = [&](int from, int to) {             // neighbours of slots [from, to) that have no slot yet
+        for (int j = from; j < to; j++)
+            for (int f = 0; f < 3; f++) {
+                const int code = nbr[(size_t)f*S + slots[j]];
+                if (code < 0) continue;
+                const int kn = code >> 2;
+                if (slot_of[kn] < 0) { slot_of[kn] = (int)slots.size(); slots.push_back(kn); }
+            }
+    };
+    int start = c0;
+    while (start < c1) {
+        int cnt = std::min(h->step_tile_cells, c1 - start);
+        int n1 = 0, n2 = 0, n3 = 0;
+        for (;;) {
+            slots.clear();
+            for (int i = 0; i < cnt; i++) { slot_of[start + i] = i; slots.push_back(start + i); }
+            grow(0, cnt);
+            n1 = (int)slots.size();
+            grow(cnt, n1);
+            n2 = (int)slots.size();
+            grow(n1, n2);
+            n3 = (int)slots.size();
+            if ((n2 <= B && n3 <= XS) || cnt == 1) break;
+            for (int kk : slots) slot_of[kk] = -1;
+            cnt = std::max(1, cnt*3/4);
+        }
+        if (n2 > B || n3 > XS) { for (int kk : slots) slot_of[kk] = -1; return nullptr; }      // a cell with hundreds of cells around it
+        const size_t base = slot_rows.size(), vbase = vert_rows.size();
+        slot_rows.resize(base + XS, int4{0, 0, 0, 0});
+        vert_rows.resize(vbase + B, int2{0, 0});
+        for (int j = 0; j < n3; j++) {
+            const int kk = slots[j];
+            unsigned w = 0;
+            int meta = 0;
+            for (int f = 0; f < 3; f++) {
+                const int code = nbr[(size_t)f*S + kk];
+                const int ls = code >= 0 ? slot_of[code >> 2] : -1;
+                w |= (ls >= 0 ? (unsigned)ls : SWE_STEP_NO_SLOT) << (10*f);
+                meta |= code < 0 ? ((-code) & 0xff) << (8*f) : 0;                   // boundary marker of the facet
+                meta |= (code >= 0 ? (code & 3) : f) << (24 + 2*f);                 // the neighbour's facet that faces this one
+            }
+            slot_rows[base + j] = int4{kk, (int)w, meta, cv[kk]};
+            if (j < n2) vert_rows[vbase + j] = int2{cv[S + kk], cv[2*S + kk]};
+        }
+        counts.push_back(int4{cnt, n1, n2, n3});
+        for (int kk : slots) slot_of[kk] = -1;
+        start += cnt;
+    }
+    Handle::StepTiles t;
+    t.c0 = c0; t.c1 = c1; t.B = B; t.n_tiles = (int)counts.size();
+    if (hipMalloc(&t.slot, slot_rows.size()*sizeof(int4)) != hipSuccess || hipMalloc(&t.vert, vert_rows.size()*sizeof(int2)) != hipSuccess
+        || hipMalloc(&t.n, counts.size()*sizeof(int4)) != hipSuccess) return nullptr;
+    if (hipMemcpy(t.slot, slot_rows.data(), slot_rows.size()*sizeof(int4), hipMemcpyHostToDevice) != hipSuccess
+        || hipMemcpy(t.vert, vert_rows.data(), vert_rows.size()*sizeof(int2), hipMemcpyHostToDevice) != hipSuccess
+        || hipMemcpy(t.n, counts.data(), counts.size()*sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    if (h->step_tiles.size() >= 64) {               // ranges come from a fixed schedule; a caller that keeps inventing new ones recycles
+        auto &o = h->step_tiles.front();
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipFree(o.slot); (void)hipFree(o.vert); (void)hipFree(o.n);
+        h->step_tiles.erase(h->step_tiles.begin());
+    }
+    h->step_tiles.push_back(t);
+    return &h->step_tiles.back();
+}
+
+// One SSPRK33 step of the cells [c0, c1): state buffer 0 -> state buffer 1 (the caller swaps the buffers when all ranges are done)
+int launch_step(Handle *h, int c0, int c1)
+{
+    if (c1 <= c0) return SWE2D_OK;
+    if (!step_kernel_covers(h)) return fail(h, SWE2D_ERR_UNSUPPORTED, "the fused step kernel covers triangles without wetting-drying and viscosity");
+    Handle::StepTiles *t = step_tiles_for(h, c0, c1);
+    if (!t) return fail(h, SWE2D_ERR_HIP, "fused step: tile lists could not be built");
+    SweStepArgs q;
+    fill_stage_args(h, q.st, 0, 0, 1, 0.0, 1.0, 1.0, c0, c1);
+    q.tile_slot = t->slot; q.tile_vert = t->vert; q.tile_n = t->n;
+    q.n_tiles = t->n_tiles; q.B = t->B;
+    for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
+    step_kernel_t kern = pick_step_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h));
+    const int grid = ((t->n_tiles + 7)/8)*8;
+    SWE_CHK_SYNC(h->stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(t->B), (size_t)9*(t->B + SWE_STEP_EXTRA)*sizeof(double), h->stream, q);
+    HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
+}
 
 }  // namespace
 
@@ -564,6 +689,14 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
     for (int m = 0; m < SWE2D_MAX_MARKERS; m++) h->bc.len[m] = mesh->boundary_len ? mesh->boundary_len[m] : blen[m];
 
     if (npc == 3) {
+        h->h_nbr = nbr;
+        h->h_cv = cv;
+        if (const char *st = std::getenv("THETIS_AMD_STEP_TILE")) {
+            int c = 0, b = 0;
+            if (std::sscanf(st, "%d,%d", &c, &b) == 2 && c >= 1 && b >= c && b <= SWE_STEP_MAX_BLOCK && b % 64 == 0) {
+                h->step_tile_cells = c; h->step_block = b;
+            }
+        }
         std::vector<int4> p4((size_t)S, int4{0, 0, 0, 0});
         std::vector<int2> p2((size_t)S, int2{0, 0});
         for (int kk = 0; kk < n; kk++) {
@@ -629,6 +762,7 @@ void swe2d_destroy(swe2d_handle *hh)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
     for (void *m : h->p2p.opened) (void)hipIpcCloseMemHandle(m);
+    for (auto &t : h->step_tiles) { if (t.slot) (void)hipFree(t.slot); if (t.vert) (void)hipFree(t.vert); if (t.n) (void)hipFree(t.n); }
     if (h->p2p.zone) (void)hipFree(h->p2p.zone);
     if (h->p2p.ctr) (void)hipFree(h->p2p.ctr);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -977,12 +1111,42 @@ int swe2d_advance(swe2d_handle *hh, int n_steps)
         return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_advance on a partition: drive stages + halo exchange from the host");
     HIP_TRY(h, hipSetDevice(h->device));
     RoctxRange range("swe2d_advance");
+    // The whole step in one launch (swe2d_step.h) where that is the faster path: small meshes.  Same box, us/step, three stage
+    // launches -> one step launch (128-cell tiles): 2.5 k cells 17.3 -> 14.0, 10 k 16.8 -> 13.9, 31 k 18.0 -> 13.3, 62 k 20.7 ->
+    // 16.3, 90 k 24.1 -> 22.2, 125 k 24.5 -> 25.6, 1 M 121 -> 145: beyond two workgroups per compute unit the tiles queue up and
+    // the redundant ring work and the two-waves-per-SIMD occupancy of the step kernel cost more than the launches and the
+    // HBM traffic it saves.  THETIS_AMD_FUSED_STEP=0 / 1 forces the choice (both give the same bits).
+    const char *env_fs = std::getenv("THETIS_AMD_FUSED_STEP");
+    const bool fused = env_fs ? std::atoi(env_fs) != 0 : (h->n_owned <= 80000 && !has_sources(h));
+    if (fused && step_kernel_covers(h)) {
+        for (int it = 0; it < n_steps; it++) {
+            int rc = launch_step(h, 0, h->n_owned);
+            if (rc) return rc;
+            std::swap(h->state[0], h->state[1]);
+        }
+        return SWE2D_OK;
+    }
     for (int it = 0; it < n_steps; it++)
         for (int s = 0; s < 3; s++) {
             int rc = stage_on_range(h, s, 0, h->n_owned);
             if (rc) return rc;
         }
     return SWE2D_OK;
+}
+
+int swe2d_solve_step_cells(swe2d_handle *hh, int32_t cell_begin, int32_t cell_end)
+{
+    Handle *h = H(hh);
+    if (!h || cell_begin < 0 || cell_end > h->n_cells || cell_begin > cell_end)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return launch_step(h, cell_begin, cell_end);
+}
+
+int swe2d_fused_step_supported(swe2d_handle *hh)
+{
+    Handle *h = H(hh);
+    return (h && step_kernel_covers(h)) ? 1 : 0;
 }
 
 int swe2d_advance_forward_euler(swe2d_handle *hh, int n_steps)

@@ -390,6 +390,15 @@ class Swe2dDevice(object):
     def swap_state_buffers(self):
         self._ck(self.lib.swe2d_swap_state_buffers(self.h))
 
+    def solve_step_cells(self, cell_begin, cell_end):
+        """A whole SSPRK33 step of device cells [cell_begin, cell_end) in one launch, state buffer 0 -> buffer 1 (the caller
+        swaps the buffers after the last range); bit for bit the three ``solve_stage_cells`` calls."""
+        self._ck(self.lib.swe2d_solve_step_cells(self.h, int(cell_begin), int(cell_end)))
+
+    def fused_step_supported(self):
+        """True where the one-launch step kernel covers the current configuration (triangles, no wetting-drying, no viscosity)."""
+        return bool(self.lib.swe2d_fused_step_supported(self.h))
+
     def advance_timed(self, n_steps, per_launch=False):
         """Returns (total ms, mean ms per stage-kernel launch), measured with HIP events on the launch stream."""
         tot = ctypes.c_float()
