@@ -236,17 +236,95 @@ def cpu_coupled_worker(rank, world, port, n_steps, out_dir, axis, case='channel'
     dist.destroy_process_group()
 
 
+def cpu_coupled_cycles_worker(rank, world, port, n_steps, out_dir, axis, case='channel+every2'):
+    """The product's coupled cycles (m coupled steps between two exchanges of all fields, coupled_cycle_schedule) launch by
+    launch with the C restatement as compute; everything a launch must not read is NaN."""
+    global CASE
+    no_lim = '+nolim' in case
+    case = case.replace('+nolim', '')
+    case, every, _ = _split_every(case)
+    CASE = case
+    import torch
+    from oracle.ref_lib import RefSWE, RefTracer
+    from thetis_amd.distributed import HaloExchanger, coupled_cycle_schedule, coupled_halo_depth
+    from thetis_amd.partition import build_partition, strip_owner
+    dist = _init(rank, world, port)
+    mesh, bath, uv, eta = _case()
+    owner = strip_owner(mesh, world, axis=axis)
+    part = build_partition(mesh, owner, rank, halo_depth=coupled_halo_depth(every, not no_lim),
+                           adjacency='facet' if no_lim else 'vertex')
+    ref = RefSWE(part.cell_xy(), part.cell_nbr, part.cell_nbr_facet, bath[part.vertex_global][part.cells],
+                 boundary_len=part.boundary_len)
+    rt = RefTracer(ref, cell_topo_vertices=part.topo_vertex[part.cells])
+    g = part.local_to_global
+    u, e, T = uv[g].copy(), eta[g].copy(), tracer_initial(mesh)[g].copy()
+    k = part.cells.shape[1]
+    halo = HaloExchanger(part, torch.device('cpu'))
+    thalo = HaloExchanger(part, torch.device('cpu'), width=k)
+    sc, rc = part.send_cells, part.recv_cells
+    dt = 2.0
+    left = n_steps
+    while left > 0:
+        r = min(every, left)
+        left -= r
+        for op in coupled_cycle_schedule(part, r, 1, not no_lim):
+            if op[0] == 'swe':
+                _, i, end = op
+                if i == 0:
+                    u0, e0 = u.copy(), e.copy()
+                ku, ke = ref.tendency(u, e, dt)
+                nu, ne = np.full_like(u, np.nan), np.full_like(e, np.nan)
+                nu[:end] = BE[i]*ku[:end] + AL0[i]*u0[:end] + ALI[i]*u[:end]
+                ne[:end] = BE[i]*ke[:end] + AL0[i]*e0[:end] + ALI[i]*e[:end]
+                assert not np.isnan(nu[:end]).any() and not np.isnan(ne[:end]).any()
+                u, e = nu, ne
+            elif op[0] == 'tracer':
+                _, _, i, end = op
+                if i == 0:
+                    T0 = T.copy()
+                # NaN in -> NaN out for the cells that read it: the C restatement propagates them like the arithmetic does
+                kt = rt.tendency(T, u, dt)
+                nt = np.full_like(T, np.nan)
+                nt[:end] = BE[i]*kt[:end] + AL0[i]*T0[:end] + ALI[i]*T[:end]
+                assert not np.isnan(nt[:end]).any()
+                T = nt
+            elif op[0] == 'limit':
+                end = op[2]
+                lim = rt.limit(T)
+                nt = np.full_like(T, np.nan)
+                nt[:end] = lim[:end]
+                assert not np.isnan(nt[:end]).any()
+                T = nt
+        packed = np.concatenate([u[sc, :, 0], u[sc, :, 1], e[sc]], axis=1)
+        assert not np.isnan(packed).any() and not np.isnan(T[sc]).any()
+        halo.send_buf[:packed.size] = torch.from_numpy(packed.reshape(-1))
+        halo.finish(halo.start())
+        rr = halo.recv_buf[:3*k*len(rc)].numpy().reshape(-1, 3*k)
+        u[rc, :, 0], u[rc, :, 1], e[rc] = rr[:, 0:k], rr[:, k:2*k], rr[:, 2*k:3*k]
+        thalo.send_buf[:k*len(sc)] = torch.from_numpy(np.ascontiguousarray(T[sc]).reshape(-1))
+        thalo.finish(thalo.start())
+        T[rc] = thalo.recv_buf[:k*len(rc)].numpy().reshape(-1, k)
+        assert not np.isnan(u).any() and not np.isnan(e).any() and not np.isnan(T).any()
+    no = part.n_owned
+    np.savez(os.path.join(out_dir, 'rank{:d}.npz'.format(rank)), ids=g[:no], uv=u[:no], eta=e[:no], T=T[:no])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def gpu_coupled_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     """DistributedSwe2d with one tracer + limiter, two ranks sharing ONE GPU (gloo + host staging stands in for RCCL)."""
     global CASE
-    CASE = case.replace('+p2p', '')
+    p2p, combined, no_lim = '+p2p' in case, '+combined' in case, '+nolim' in case
+    case = case.replace('+p2p', '').replace('+combined', '').replace('+nolim', '')
+    case, every, _ = _split_every(case)
+    CASE = case
     from thetis_amd.distributed import DistributedSwe2d
     from thetis_amd.partition import strip_owner
     dist = _init(rank, world, port)
     mesh, bath, uv, eta = _case()
     owner = strip_owner(mesh, world, axis=axis)
-    solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, n_tracers=1,
-                              exchange=('p2p' if case.endswith('+p2p') else 'host'))
+    solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, n_tracers=1, exchange=('p2p' if p2p else 'host'),
+                              exchange_every=every, combined_exchange=combined, use_limiter=not no_lim)
     solver.set_state_global(uv, eta)
     solver.set_tracer_global(0, tracer_initial(mesh))
     solver.advance(n_steps, use_graph=False)

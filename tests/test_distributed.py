@@ -3,7 +3,8 @@ GPU: the real DistributedSwe2d with two ranks sharing the one GPU of the test bo
 import numpy as np
 import pytest
 
-from dist_worker import (_case, coupled_step_reference, cpu_coupled_worker, cpu_worker, gather, gpu_coupled_worker,
+from dist_worker import (_case, coupled_step_reference, cpu_coupled_cycles_worker, cpu_coupled_worker, cpu_worker, gather,
+                         gpu_coupled_worker,
                          gpu_worker, run_workers, tracer_initial)
 from helpers import make_ref, rel_linf
 from thetis_amd.partition import build_partition, strip_owner
@@ -295,6 +296,67 @@ def test_gloo_partitioned_coupled_step_equals_global(tmp_path, ref_so, world, ax
     # the limiter was active (otherwise the test would not see a wrong limiter halo)
     rt_step = rt.step(tracer_initial(mesh), uv, 2.0)
     assert np.abs(rt.limit(rt_step) - rt_step).max() > 1e-3
+
+
+@pytest.mark.parametrize('world,axis,case,n_steps', [(2, 0, 'channel+every2', 5), (3, 1, 'channel+every1', 3),
+                                                      (2, 1, 'channel+every3+nolim', 4), (3, 0, 'delaunay+every2', 3)])
+def test_gloo_coupled_cycles_with_one_exchange_equal_global(tmp_path, ref_so, world, axis, case, n_steps):
+    """m coupled steps between two exchanges of all fields on 4m + 3 vertex layers (3m + 3 facet layers without the limiter),
+    every launch on the range coupled_cycle_schedule gives it (stale cells poisoned with NaN) == the whole-mesh algorithm,
+    bitwise; odd step counts end with a shorter cycle."""
+    import dist_worker
+    from oracle.ref_lib import RefTracer
+    dist_worker.CASE = case.split('+')[0]
+    try:
+        mesh, bath, uv, eta = _case()
+    finally:
+        dist_worker.CASE = 'channel'
+    run_workers(cpu_coupled_cycles_worker, world, n_steps, str(tmp_path), axis=axis, case=case)
+    u_p, e_p, extra = gather(str(tmp_path), world, mesh.num_cells)
+    T_p = extra[-1]
+    ref = make_ref(mesh, bath)
+    rt = RefTracer(ref, cell_topo_vertices=mesh.topo_vertex[mesh.cells])
+    n = mesh.num_cells
+    u, e, T = uv.copy(), eta.copy(), tracer_initial(mesh)
+    for _ in range(n_steps):
+        u, e, T = coupled_step_reference(ref, rt, u, e, T, 2.0, (n, n, n), 0 if '+nolim' in case else n)
+    assert np.array_equal(u_p, u) and np.array_equal(e_p, e) and np.array_equal(T_p, T)
+
+
+def test_coupled_cycle_schedule_counts_layers():
+    from thetis_amd.distributed import coupled_cycle_schedule, coupled_halo_depth
+    from thetis_amd.partition import build_partition, strip_owner
+    mesh, bath, uv, eta = _case()
+    assert coupled_halo_depth(1, True) == 7 and coupled_halo_depth(2, True) == 11 and coupled_halo_depth(2, False) == 9
+    part = build_partition(mesh, strip_owner(mesh, 2), 0, halo_depth=7, adjacency='vertex')
+    ops = coupled_cycle_schedule(part, 1, 2, True)
+    assert [o[0] for o in ops] == ['swe']*3 + ['swe_done'] + ['tracer']*6 + ['limit']*2
+    assert [o[-1] for o in ops[:3]] == [part.layer_end(6), part.layer_end(5), part.layer_end(4)]
+    assert [o[-1] for o in ops[4:7]] == [part.layer_end(3), part.layer_end(2), part.layer_end(1)]
+    assert ops[-1] == ('limit', 1, part.n_owned)
+    with pytest.raises(ValueError):
+        coupled_cycle_schedule(part, 2, 1, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case,n_steps', [('channel+every2', 5), ('channel+combined', 3), ('channel+every2+p2p', 4),
+                                          ('channel+every3+nolim+p2p', 4)])
+def test_two_ranks_coupled_cycles_with_one_exchange_match_single_device(tmp_path, hip_lib, case, n_steps):
+    """DistributedSwe2d(n_tracers=1, exchange_every=m | combined_exchange): one exchange of all fields per m coupled steps,
+    host-staged and peer-to-peer, == the single-device coupled stepping, bitwise."""
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = _case()
+    run_workers(gpu_coupled_worker, 2, n_steps, str(tmp_path), axis=0, case=case)
+    u_p, e_p, extra = gather(str(tmp_path), 2, mesh.num_cells)
+    T_p = extra[-1]
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    tid = dev.add_tracer()
+    dev.set_state(uv, eta)
+    dev.tracer_set_state(tid, tracer_initial(mesh))
+    dev.advance_coupled(n_steps, tracer_only=False, use_limiter='+nolim' not in case)
+    u_s, e_s = dev.get_state()
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s) and np.array_equal(T_p, dev.tracer_get_state(tid))
+    dev.close()
 
 
 @pytest.mark.gpu

@@ -129,19 +129,66 @@ class P2PHalo(object):
         return self.dev.p2p_status(self.n_channels)[2]
 
 
+def coupled_halo_depth(exchange_every, use_limiter):
+    """Ghost layers a coupled cycle of ``exchange_every`` steps with ONE exchange at its end needs (vertex-adjacent layers with
+    the limiter, facet-adjacent ones without): a step costs the shallow water state three layers; the tracer stages read the
+    new velocity one layer further out than they write, so the tracer ends a step three (with the limiter: four) layers
+    inside the shallow water state it started from."""
+    return (4 if use_limiter else 3)*int(exchange_every) + 3
+
+
+def coupled_cycle_schedule(part, n_steps, n_tracers, use_limiter, tracer_only=False):
+    """Launch list of ``n_steps`` coupled steps (GeneralCoupledTimeIntegrator2D.advance, coupled_timeintegrator_2d.py:93-113:
+    shallow water step, every tracer with the updated velocity, limiter) between two exchanges of ALL fields, on the shrinking
+    cell ranges that stay exact: ('swe', stage, cell_end) | ('tracer', i_tracer, stage, cell_end) | ('limit', i_tracer, cell_end)
+    | ('swe_done',) after the last shallow water stage of the cycle (its exchange can start there).  Validity is counted in
+    ghost layers: a stage is exact on one layer less than its input, the tracer stages also need the velocity on the layer
+    they read, the limiter needs the cell means one (vertex) layer further out."""
+    depth = coupled_halo_depth(n_steps, use_limiter)
+    if depth > len(part.layer_sizes):
+        raise ValueError('a coupled cycle of {:d} steps needs {:d} ghost layers, the partition has {:d}'.format(
+            n_steps, depth, len(part.layer_sizes)))
+    v_swe = v_t = depth
+    ops = []
+    for k in range(n_steps):
+        if not tracer_only:
+            for g in range(3):
+                v_swe -= 1
+                ops.append(('swe', g, part.layer_end(v_swe)))
+            if k == n_steps - 1:
+                ops.append(('swe_done',))
+        v_in = min(v_t, v_swe)
+        for i in range(n_tracers):
+            for g in range(3):
+                ops.append(('tracer', i, g, part.layer_end(v_in - 1 - g)))
+        v_t = v_in - 3
+        if use_limiter:
+            v_t -= 1
+            for i in range(n_tracers):
+                ops.append(('limit', i, part.layer_end(v_t)))
+    assert v_t >= 0 and v_swe >= 0
+    return ops
+
+
 class DistributedSwe2d(object):
     """SSPRK33 on a strip-partitioned mesh, one rank per GPU."""
 
     def __init__(self, mesh, bathymetry_vertex, dt, rank, world_size, device_id, owner=None, host_staged=False,
                  n_tracers=0, use_limiter=True, tracer_only=False, exchange_every=1, overlap_stages=0,
                  graph_mode=None, stepper='SSPRK33', exchange=None, split_last_stage=True, group=None, partition=None,
-                 **opts):
+                 combined_exchange=False, **opts):
         """``n_tracers`` > 0: the coupled step of GeneralCoupledTimeIntegrator2D.advance (coupled_timeintegrator_2d.py:
         93-113) on the partition - shallow water step, then every tracer with the updated velocity, then the limiter.
         The vertex-based limiter needs every cell around a vertex, so coupled runs with the limiter use four ghost layers
         built by VERTEX distance: the ghosts receive the neighbours' unlimited values once per step and every rank limits
         its owned cells and layers 1-3 redundantly (same means, same bounds => bitwise the owner's result); layer 4 is
         only ever read by the limiter.
+
+        Coupled runs with ``exchange_every`` = m > 1 (or ``combined_exchange``): m coupled steps between two exchanges of ALL
+        fields (shallow water state and every tracer, one exchange instead of 1 + n_tracers per step) on 4m + 3 vertex-adjacent
+        ghost layers (3m + 3 facet-adjacent ones without the limiter), every launch on the largest cell range that is still
+        exact (coupled_cycle_schedule); the shallow water exchange starts after the cycle's last shallow water stage and
+        overlaps the tracer work.  Bitwise the results of the per-step exchanges.
 
         ``exchange_every`` = m > 1 (shallow water only): 3m facet-adjacent ghost layers and ONE exchange every m time
         steps - stage g = 0..3m-1 of a cycle updates the owned cells and the first 3m-1-g layers, so the redundant work
@@ -177,8 +224,11 @@ class DistributedSwe2d(object):
             raise ValueError('ForwardEuler on partitions: shallow water only, no overlap_stages')
         self.exchange_every = m = int(exchange_every)
         self.overlap_stages = int(overlap_stages)
-        if m < 1 or ((m > 1 or self.overlap_stages > 0) and n_tracers > 0):
-            raise ValueError('exchange_every > 1 and overlap_stages are implemented for shallow-water-only runs')
+        if m < 1 or (self.overlap_stages > 0 and n_tracers > 0):
+            raise ValueError('overlap_stages is implemented for shallow-water-only runs')
+        # coupled runs: exchange_every = 1 exchanges after the shallow water step and after every tracer step (four ghost
+        # layers); exchange_every = m > 1 (or combined_exchange) runs m coupled steps between two exchanges of ALL fields
+        self.coupled_cycles = n_tracers > 0 and (m > 1 or bool(combined_exchange))
         if not 0 <= self.overlap_stages <= 3*m - 1:
             raise ValueError('overlap_stages must be in 0 .. 3*exchange_every - 1')
         self.exchange = exchange or ('host' if host_staged else 'rccl')
@@ -191,6 +241,9 @@ class DistributedSwe2d(object):
             self.part = partition                   # built by the caller with the matching halo depth (bench: reused)
         elif self.stages_per_step == 1:
             self.part = build_partition(mesh, owner, rank, halo_depth=m)
+        elif self.coupled_cycles:
+            self.part = build_partition(mesh, owner, rank, halo_depth=coupled_halo_depth(m, self.use_limiter),
+                                        adjacency='vertex' if self.use_limiter else 'facet')
         elif m > 1:
             self.part = build_partition(mesh, owner, rank, halo_depth=3*m)
         elif self.use_limiter:
@@ -387,8 +440,32 @@ class DistributedSwe2d(object):
         else:
             fn()
 
+    def _cycle_coupled(self, n_steps):
+        """``n_steps`` (<= exchange_every) coupled steps, then one exchange of the shallow water state and every tracer."""
+        dev = self.dev
+        reqs = None
+        sent = False
+        for op in coupled_cycle_schedule(self.part, n_steps, len(self.tids), self.use_limiter, self.tracer_only):
+            if op[0] == 'swe':
+                dev.solve_stage_cells(op[1], 0, op[2])
+            elif op[0] == 'swe_done':
+                reqs = self._send(0, 0)               # travels while the tracers step
+                sent = True
+            elif op[0] == 'tracer':
+                dev.tracer_solve_stage_cells(self.tids[op[1]], op[2], 0, op[3])
+            else:
+                dev.tracer_limit_cells(self.tids[op[1]], op[2])
+        if sent:
+            self._receive(0, 0, reqs)
+        for i in range(len(self.tids)):
+            self._receive(1 + i, 0, self._send(1 + i, 0))
+
     def _steps_eager(self, n_steps, graphed=False):
         m = self.exchange_every
+        if self.coupled_cycles:
+            for r in [m]*(n_steps//m) + ([n_steps % m] if n_steps % m else []):
+                self._cycle_coupled(r)
+            return
         if self.tids or self.tracer_only:
             for _ in range(n_steps):
                 self._step()
