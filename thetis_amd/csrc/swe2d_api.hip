@@ -7,6 +7,7 @@
 #include "swe2d_p2p.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -2019,6 +2020,27 @@ int swe2d_p2p_open(swe2d_handle *hh, const void *ipc_handle, void **remote_base)
     void *p = nullptr;
     HIP_TRY(h, hipIpcOpenMemHandle(&p, mh, hipIpcMemLazyEnablePeerAccess));
     h->p2p.opened.push_back(p);
+    // First contact with a peer's memory must fail with an error code, never with a memory fault inside the push kernel (which
+    // would take the process down): the mapping has to be a device pointer of this process, a host-initiated copy into the
+    // unused upper half of the zone header has to round-trip, and so has a store + load from a kernel of this device.
+    hipPointerAttribute_t attr;
+    HIP_TRY(h, hipPointerGetAttributes(&attr, p));
+    unsigned long long *probe = reinterpret_cast<unsigned long long *>(static_cast<char *>(p) + SWE_P2P_HEADER_BYTES/2)
+                                + (unsigned)getpid() % (SWE_P2P_HEADER_BYTES/16);
+    const unsigned long long pattern = 0x5157453244503250ull ^ ((unsigned long long)getpid() << 20) ^ (unsigned long long)h->device;
+    unsigned long long back = 0;
+    HIP_TRY(h, hipMemcpy(probe, &pattern, sizeof(pattern), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(&back, probe, sizeof(back), hipMemcpyDeviceToHost));
+    if (back != pattern) return fail(h, SWE2D_ERR_HIP, "swe2d_p2p_open: a copy into the peer's landing zone does not read back");
+    unsigned long long *dback = nullptr;
+    HIP_TRY(h, hipMalloc(&dback, sizeof(*dback)));
+    hipLaunchKernelGGL(swe_p2p_probe_kernel, dim3(1), dim3(64), 0, h->stream, probe, ~pattern, dback);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(&back, dback, sizeof(back), hipMemcpyDeviceToHost);
+    (void)hipFree(dback);
+    if (e != hipSuccess) return fail(h, SWE2D_ERR_HIP, "swe2d_p2p_open: the probe kernel failed on the peer's landing zone");
+    if (back != ~pattern) return fail(h, SWE2D_ERR_HIP, "swe2d_p2p_open: a kernel store into the peer's landing zone does not read back");
     *remote_base = p;
     return SWE2D_OK;
 }

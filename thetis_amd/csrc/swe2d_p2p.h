@@ -74,6 +74,16 @@ __device__ __forceinline__ double swe_p2p_load(const double *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // global_load_dwordx2 sc0 sc1
 }
 
+// first-contact probe of a freshly mapped peer zone (swe2d_p2p_open): system-scope store + load of one word
+__global__ void swe_p2p_probe_kernel(unsigned long long *word, unsigned long long pattern, unsigned long long *out)
+{
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(word, pattern, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *out = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 #define SWE_P2P_MAX_BLOCKS 256            // one 256-lane workgroup per CU, grid-stride over the message
 
 __device__ __forceinline__ int swe_p2p_peer_of(const SweP2pPushArgs &a, int j)
