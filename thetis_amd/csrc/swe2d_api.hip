@@ -1113,10 +1113,9 @@ int swe2d_advance(swe2d_handle *hh, int n_steps)
     HIP_TRY(h, hipSetDevice(h->device));
     RoctxRange range("swe2d_advance");
     // The whole step in one launch (swe2d_step.h) where that is the faster path: small meshes.  Same box, us/step, three stage
-    // launches -> one step launch (128-cell tiles): 2.5 k cells 17.3 -> 14.0, 10 k 16.8 -> 13.9, 31 k 18.0 -> 13.3, 62 k 20.7 ->
-    // 16.3, 90 k 24.1 -> 22.2, 125 k 24.5 -> 25.6, 1 M 121 -> 145: beyond two workgroups per compute unit the tiles queue up and
-    // the redundant ring work and the two-waves-per-SIMD occupancy of the step kernel cost more than the launches and the
-    // HBM traffic it saves.  THETIS_AMD_FUSED_STEP=0 / 1 forces the choice (both give the same bits).
+    // launches -> one step launch (128-cell tiles): 2.5 k cells 17.3 -> 14.0, 10 k 16.8 -> 14.1, 31 k 18.0 -> 13.3, 62 k 20.3 ->
+    // 17.0, 90 k 24.1 -> 22.2, 125 k 24.4 -> 25.5, 1 M 124 -> 135: beyond ~100 k cells throughput counts, and the redundant ring
+    // work of the tiles costs more FP64 issue time than the launches and the HBM traffic it saves are worth.  THETIS_AMD_FUSED_STEP=0 / 1 forces the choice (both give the same bits).
     const char *env_fs = std::getenv("THETIS_AMD_FUSED_STEP");
     const bool fused = env_fs ? std::atoi(env_fs) != 0 : (h->n_owned <= 80000 && !has_sources(h));
     if (fused && step_kernel_covers(h)) {

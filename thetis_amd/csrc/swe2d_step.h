@@ -20,13 +20,15 @@
 //
 // Per cell and STEP memory sees: the step input once (72 B, the ring reads hit the L2), the tile lists (~35 B), the result once
 // (72 B) - about a third of three per-stage launches; the price is the redundant ring work ((3C + 2 r1 + r2)/(3C) = 1.3 for
-// 128-cell tiles, r1 ~ 38, r2 ~ 41 on the bench mesh; whole waves: 9 wave-stages where 6 are the minimum) and an occupancy of two
-// waves per SIMD (228 VGPRs; capped at 168 the kernel spills 51 and is twice as slow).
-// Measured (MI355X, same box, us/step, three stage launches -> one step launch): 2.5 k cells 17.3 -> 14.0, 10 k 16.8 -> 13.9,
-// 31 k 18.0 -> 13.3, 62 k 20.7 -> 16.3, 90 k 24.1 -> 22.2, 125 k 24.5 -> 25.6, 1 M 121 -> 145 (256-cell tiles: 167).  The step
-// kernel wins where the grid fits two workgroups per compute unit - there a step is latency: one launch, one trip to memory,
-// three short stages - and loses beyond: the tiles queue up, the FP64 issue slots it wastes on ring cells and on barrier
-// waits are then worth more than the HBM traffic it saves.  swe2d_advance takes it for meshes of at most 80 k cells.
+// 128-cell tiles, r1 ~ 38, r2 ~ 41 on the bench mesh; whole waves: 9 wave-stages where 6 are the minimum).  168 VGPRs, no
+// scratch = three waves per SIMD = three 256-lane workgroups per compute unit - but only because the stage loop hides its
+// invariants from the optimiser (see the asm statement there): hoisted out of the loop they cost 228 VGPRs or 51 spills.
+// Measured (MI355X, same box, us/step, three stage launches -> one step launch): 2.5 k cells 17.3 -> 14.0, 10 k 16.8 -> 14.1,
+// 31 k 18.0 -> 13.3, 62 k 20.3 -> 17.0, 90 k 24.1 -> 22.2, 125 k 24.4 -> 25.5, 250 k 38.2 -> 42.4, 1 M 124 -> 135 (256-cell tiles
+// in 384-lane workgroups: 153 - two six-wave workgroups do not share a compute unit's SIMDs evenly).  The step kernel wins where a
+// step is latency - one launch, one trip to memory, three short stages - and loses beyond ~100 k cells, where throughput counts:
+// there it is bound by the FP64 issue rate (1.95 us of SIMD time per wave-stage at 3 waves per SIMD against 1.1 us of pure
+// issue), and the 1.3x ring work costs more than the HBM traffic it saves.  swe2d_advance takes it for meshes of at most 80 k cells.
 //
 // The arithmetic is that of swe_stage_kernel<NONLIN, LF, ., SRC, false, false, true(BINL)>, operation for operation and under
 // the same `fp contract(off)`: the step result is bit for bit the one of three stage launches (tests/test_gpu_step_kernel.py).
@@ -34,10 +36,10 @@
 #include "swe2d_kernels.h"
 
 #ifndef SWE_STEP_MAX_BLOCK
-#define SWE_STEP_MAX_BLOCK 512
+#define SWE_STEP_MAX_BLOCK 384
 #endif
 #ifndef SWE_STEP_OCCUPANCY
-#define SWE_STEP_OCCUPANCY            // e.g. __attribute__((amdgpu_waves_per_eu(3, 3)))
+#define SWE_STEP_OCCUPANCY __attribute__((amdgpu_waves_per_eu(3, 3)))      // 168 VGPRs, no scratch: two 384-lane workgroups per CU
 #endif
 #define SWE_STEP_NO_SLOT 0x3ffu
 
@@ -226,7 +228,9 @@ __global__ __launch_bounds__(SWE_STEP_MAX_BLOCK) SWE_STEP_OCCUPANCY void swe_ste
     const bool in_tile = j < tn.w;
     const int4 sl = in_tile ? slots[j] : int4{0, 0, 0, 0};
     const int k = sl.x, meta = sl.z;
-    const unsigned lnb = (unsigned)sl.y, k8 = (unsigned)k*8u;
+    const unsigned k8 = (unsigned)k*8u;
+    unsigned lnb_v = (unsigned)sl.y;
+    int meta_v = sl.z;
     double u[3], v[3], e[3];
     if (in_tile) {
 #pragma unroll
@@ -268,13 +272,19 @@ __global__ __launch_bounds__(SWE_STEP_MAX_BLOCK) SWE_STEP_OCCUPANCY void swe_ste
     }
     __syncthreads();
     if (j >= tn.z) return;                                     // ring 3 and unused slots: whole waves leave, the rest is masked
-    const double twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
-    const int bmarkers = meta & 0xffffff;
-
     double ou[3], ov[3], oe[3];
 #pragma unroll 1
     for (int s = 0; s < 3; s++) {
+        // Opaque to the optimiser: without this every stage-invariant quantity (facet lengths, reciprocals, selected slots and
+        // LDS addresses, gradients ...) is hoisted out of the stage loop and kept live across it - past the register budget.
+        // The per-stage kernel recomputes them in every stage as well.
+#pragma unroll
+        for (int i = 0; i < 3; i++) asm volatile("" : "+v"(nx[i]), "+v"(ny[i]), "+v"(h[i]));
+        asm volatile("" : "+v"(lnb_v), "+v"(meta_v));
+        const unsigned lnb = lnb_v;
+        const int meta = meta_v, bmarkers = meta_v & 0xffffff;
         double bu[3], bv[3], be[3], wu[3], wv[3], we[3];
+        const double twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
         swe_step_rhs<NONLIN, LF, SRC>(p, k, u, v, e, h, xs, XS, j, lnb, meta, nx, ny, twoA, bu, bv, be);
         // w = a0*U(0) + a1*U_in: the first stage has no U(0) term (swe_stage_kernel<., ., HASU0 = false>); later stages read
         // U(0) of the cell again (L2) instead of keeping it in registers
