@@ -26,13 +26,15 @@ def _steps_fused(dev, n):
         dev.swap_state_buffers()
 
 
-@pytest.mark.parametrize('case', ['channel', 'channel_open', 'unstructured', 'linear', 'no_lf', 'sources', 'ragged_ranges'])
+@pytest.mark.parametrize('case', ['channel', 'channel_open', 'unstructured', 'linear', 'no_lf', 'sources', 'sources_large',
+                                  'ragged_ranges'])
 def test_fused_step_gives_the_bits_of_three_stage_launches(hip_lib, case):
     from thetis_amd import _lib
     if case == 'unstructured':
         mesh, bath, uv, eta = delaunay_case(n_points=3000, seed=5)[:4]
     else:
-        mesh, bath, uv, eta = channel_case(nx=67, ny=31, seed=11)
+        nx, ny = (250, 125) if case == 'sources_large' else (67, 31)      # large: 62 k cells (one-ulp differences need cells to show)
+        mesh, bath, uv, eta = channel_case(nx=nx, ny=ny, seed=11)
     kw = {}
     if case == 'linear':
         kw['use_nonlinear_equations'] = False
@@ -44,13 +46,13 @@ def test_fused_step_gives_the_bits_of_three_stage_launches(hip_lib, case):
         assert dev.fused_step_supported()
         k = mesh.cells.shape[1]
         cxy = mesh.cell_xy()
-        if case in ('channel_open', 'sources'):
+        if case in ('channel_open', 'sources', 'sources_large'):
             m = mesh.boundary_markers
             dev.set_bc(m[0], {'elev': 0.2*np.sin(cxy[:, :, 1]/3e3)})
             dev.set_bc(m[-1], {'un': 0.05, 'drag': 0.01})
             if len(m) > 2:
                 dev.set_bc(m[1], {'flux': 30.0})
-        if case == 'sources':
+        if case in ('sources', 'sources_large'):
             dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
             dev.set_field(_lib.FIELD_CORIOLIS, 1e-4*np.ones((mesh.num_cells, k)))
             dev.set_field(_lib.FIELD_WIND_STRESS, 0.1*np.ones((mesh.num_cells, k, 2)))

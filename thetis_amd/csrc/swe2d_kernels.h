@@ -447,23 +447,27 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
                                                  const double v[3], const double H[3], const double gxs[3],
                                                  const double gys[3], double bu[3], double bv[3], double be[3])
 {
+    // No implicit contraction (the pragma of a kernel does not reach into the functions inlined into it): this code is inlined
+    // into every SRC variant of the stage kernels and into the step kernel, which must all give the same bits.
+#pragma clang fp contract(off)
     const double g = p.g;
     const double A = 0.5*twoA;
     const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u;
     const double us = u[0] + u[1] + u[2], vs = v[0] + v[1] + v[2];
+    const double A60 = A*(1.0/60.0), A12 = A*(1.0/12.0);
     if (p.coriolis) {                                    // shallowwater_eq.py:632-633
         double f[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) f[i] = swe_ld(swe_rsrc(p.coriolis), k8, i*S8);
         const double fs = f[0] + f[1] + f[2];
-        const double fu_ = f[0]*u[0] + f[1]*u[1] + f[2]*u[2], fv_ = f[0]*v[0] + f[1]*v[1] + f[2]*v[2];
+        const double fu_ = fma(f[2], u[2], fma(f[1], u[1], f[0]*u[0])), fv_ = fma(f[2], v[2], fma(f[1], v[1], f[0]*v[0]));
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             // 60/A int phi_i f w = fs*ws + sum f_a w_a + f_i*ws + w_i*fs + 2 f_i w_i
-            const double tv = fs*vs + fv_ + f[i]*vs + v[i]*fs + 2.0*f[i]*v[i];
-            const double tu = fs*us + fu_ + f[i]*us + u[i]*fs + 2.0*f[i]*u[i];
-            bu[i] += A*(1.0/60.0)*tv;
-            bv[i] -= A*(1.0/60.0)*tu;
+            const double tv = fma(2.0*f[i], v[i], fma(v[i], fs, fma(f[i], vs, fma(fs, vs, fv_))));
+            const double tu = fma(2.0*f[i], u[i], fma(u[i], fs, fma(f[i], us, fma(fs, us, fu_))));
+            bu[i] = fma(A60, tv, bu[i]);
+            bv[i] = fma(-A60, tu, bv[i]);
         }
     }
     if (p.lin_drag_f) {                                  // LinearDragTerm with a P1 coefficient: int phi_i c w, cubic
@@ -471,17 +475,18 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
 #pragma unroll
         for (int i = 0; i < 3; i++) c[i] = swe_ld(swe_rsrc(p.lin_drag_f), k8, i*S8);
         const double cs = c[0] + c[1] + c[2];
-        const double cu_ = c[0]*u[0] + c[1]*u[1] + c[2]*u[2], cv_ = c[0]*v[0] + c[1]*v[1] + c[2]*v[2];
+        const double cu_ = fma(c[2], u[2], fma(c[1], u[1], c[0]*u[0])), cv_ = fma(c[2], v[2], fma(c[1], v[1], c[0]*v[0]));
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            bu[i] -= A*(1.0/60.0)*(cs*us + cu_ + c[i]*us + u[i]*cs + 2.0*c[i]*u[i]);
-            bv[i] -= A*(1.0/60.0)*(cs*vs + cv_ + c[i]*vs + v[i]*cs + 2.0*c[i]*v[i]);
+            bu[i] = fma(-A60, fma(2.0*c[i], u[i], fma(u[i], cs, fma(c[i], us, fma(cs, us, cu_)))), bu[i]);
+            bv[i] = fma(-A60, fma(2.0*c[i], v[i], fma(v[i], cs, fma(c[i], vs, fma(cs, vs, cv_)))), bv[i]);
         }
     } else if (p.linear_drag >= 0.0) {                   // shallowwater_eq.py:738
+        const double cA = p.linear_drag*A12;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            bu[i] -= p.linear_drag*A*(1.0/12.0)*(us + u[i]);
-            bv[i] -= p.linear_drag*A*(1.0/12.0)*(vs + v[i]);
+            bu[i] = fma(-cA, us + u[i], bu[i]);
+            bv[i] = fma(-cA, vs + v[i], bv[i]);
         }
     }
     if (p.quad_drag >= 0.0 || p.manning >= 0.0 || p.nikuradse >= 0.0 || p.quad_f) {   // shallowwater_eq.py:685-700, 6-point rule
@@ -492,15 +497,16 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
 #pragma unroll
             for (int i = 0; i < 3; i++) cf[i] = swe_ld(swe_rsrc(p.quad_f), k8, i*S8);
         }
+        const double sm2 = p.norm_smoother*p.norm_smoother;
 #pragma unroll
         for (int q = 0; q < 6; q++) {
             const double aa = q < 3 ? a1 : a2, bb = q < 3 ? b1 : b2, ww = q < 3 ? w1 : w2;
             double l[3] = {aa, aa, aa};
             l[q % 3] = bb;
-            const double uq = l[0]*u[0] + l[1]*u[1] + l[2]*u[2];
-            const double vq = l[0]*v[0] + l[1]*v[1] + l[2]*v[2];
-            const double Hq = l[0]*H[0] + l[1]*H[1] + l[2]*H[2];
-            const double cq = l[0]*cf[0] + l[1]*cf[1] + l[2]*cf[2];              // field coefficient at the point
+            const double uq = fma(l[2], u[2], fma(l[1], u[1], l[0]*u[0]));
+            const double vq = fma(l[2], v[2], fma(l[1], v[1], l[0]*v[0]));
+            const double Hq = fma(l[2], H[2], fma(l[1], H[1], l[0]*H[0]));
+            const double cq = fma(l[2], cf[2], fma(l[1], cf[1], l[0]*cf[0]));    // field coefficient at the point
             const int kind = p.quad_f ? p.quad_f_kind : (p.manning >= 0.0 ? 2 : (p.nikuradse >= 0.0 ? 3 : 1));
             const double coef = p.quad_f ? cq : (kind == 2 ? p.manning : (kind == 3 ? p.nikuradse : p.quad_drag));
             double cdh;                                  // C_D / H
@@ -515,11 +521,12 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
                 }
                 cdh = cd*swe_rcp(Hq);
             }
-            const double s = ww*A*cdh*swe_sqrt(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother);
+            const double s = ww*A*cdh*swe_sqrt(fma(uq, uq, fma(vq, vq, sm2)));
+            const double su = s*uq, sv = s*vq;
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                bu[i] -= s*l[i]*uq;
-                bv[i] -= s*l[i]*vq;
+                bu[i] = fma(-su, l[i], bu[i]);
+                bv[i] = fma(-sv, l[i], bv[i]);
             }
         }
     }
@@ -537,13 +544,13 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
             const double aa = q < 3 ? a1 : a2, bb = q < 3 ? b1 : b2, ww = q < 3 ? w1 : w2;
             double l[3] = {aa, aa, aa};
             l[q % 3] = bb;
-            const double Hq = l[0]*H[0] + l[1]*H[1] + l[2]*H[2];
+            const double Hq = fma(l[2], H[2], fma(l[1], H[1], l[0]*H[0]));
             const double s = ww*A/(Hq*1000.0);
-            const double wx = l[0]*tx[0] + l[1]*tx[1] + l[2]*tx[2], wy = l[0]*ty[0] + l[1]*ty[1] + l[2]*ty[2];
+            const double wx = s*fma(l[2], tx[2], fma(l[1], tx[1], l[0]*tx[0])), wy = s*fma(l[2], ty[2], fma(l[1], ty[1], l[0]*ty[0]));
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                bu[i] += s*l[i]*wx;
-                bv[i] += s*l[i]*wy;
+                bu[i] = fma(wx, l[i], bu[i]);
+                bv[i] = fma(wy, l[i], bv[i]);
             }
         }
     }
@@ -552,13 +559,13 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const double pa = swe_ld(swe_rsrc(p.patm), k8, i*S8);
-            gpx += gxs[i]*pa;
-            gpy += gys[i]*pa;
+            gpx = fma(gxs[i], pa, gpx);
+            gpy = fma(gys[i], pa, gpy);
         }
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            bu[i] -= gpx*(1.0/3000.0);
-            bv[i] -= gpy*(1.0/3000.0);
+            bu[i] = fma(-gpx, 1.0/3000.0, bu[i]);
+            bv[i] = fma(-gpy, 1.0/3000.0, bv[i]);
         }
     }
     if (p.msrc) {                                        // shallowwater_eq.py:810
@@ -571,8 +578,8 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
         const double ssx = sx[0] + sx[1] + sx[2], ssy = sy[0] + sy[1] + sy[2];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            bu[i] += A*(1.0/12.0)*(ssx + sx[i]);
-            bv[i] += A*(1.0/12.0)*(ssy + sy[i]);
+            bu[i] = fma(A12, ssx + sx[i], bu[i]);
+            bv[i] = fma(A12, ssy + sy[i], bv[i]);
         }
     }
     if (p.vsrc) {                                        // shallowwater_eq.py:830
@@ -581,7 +588,7 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
         for (int i = 0; i < 3; i++) sv_[i] = swe_ld(swe_rsrc(p.vsrc), k8, i*S8);
         const double ss = sv_[0] + sv_[1] + sv_[2];
 #pragma unroll
-        for (int i = 0; i < 3; i++) be[i] += A*(1.0/12.0)*(ss + sv_[i]);
+        for (int i = 0; i < 3; i++) be[i] = fma(A12, ss + sv_[i], be[i]);
     }
 }
 

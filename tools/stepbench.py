@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--tiles', nargs='*', default=['256,384'])
     ap.add_argument('--prewarm', type=float, default=0.3)
+    ap.add_argument('--sources', action='store_true', help='Manning drag + Coriolis + wind stress (the SRC kernel variants)')
     args = ap.parse_args()
     import numpy as np
     import bench
@@ -46,6 +47,11 @@ def main():
                 os.environ['THETIS_AMD_FUSED_STEP'] = '1'
                 os.environ['THETIS_AMD_STEP_TILE'] = tile
             dev = Swe2dDevice(mesh, bath, dt, boundary_len=mesh.boundary_len)
+            if args.sources:
+                from thetis_amd import _lib
+                dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+                dev.set_field(_lib.FIELD_CORIOLIS, 1e-4*np.ones((mesh.num_cells, 3)))
+                dev.set_field(_lib.FIELD_WIND_STRESS, 0.1*np.ones((mesh.num_cells, 3, 2)))
             dev.set_state(uv, eta)
             t_end = time.perf_counter() + args.prewarm
             while time.perf_counter() < t_end:
