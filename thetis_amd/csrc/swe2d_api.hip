@@ -114,7 +114,7 @@ struct Handle {
     std::vector<int> h_nbr, h_cv;
     struct StepTiles { int c0 = 0, c1 = 0, B = 0, n_tiles = 0; int4 *slot = nullptr; int2 *vert = nullptr; int4 *n = nullptr; };
     std::vector<StepTiles> step_tiles;
-    int step_tile_cells = 128, step_block = 256;        // THETIS_AMD_STEP_TILE=C,B (B a multiple of 64, <= SWE_STEP_MAX_BLOCK)
+    int step_tile_cells = 128, step_block = 256;        // THETIS_AMD_STEP_TILE=C,B (B = 256 or 384: the instantiated workgroup sizes)
     double *vx = nullptr, *vy = nullptr, *vh = nullptr;
     double *bc_field[4] = {nullptr, nullptr, nullptr, nullptr};  // Function-valued boundary data per facet: elev, uv, un, flux
     double *valpha = nullptr;                          // per-vertex wetting-drying alpha
@@ -417,12 +417,17 @@ int grid_for(int n) { return (n + 255)/256; }
 
 // ---- fused SSPRK33 step (swe2d_step.h)
 typedef void (*step_kernel_t)(const SweStepArgs);
-template <bool NL, bool LF>
-step_kernel_t pick_step_src(bool src) { return src ? swe_step_kernel<NL, LF, true> : swe_step_kernel<NL, LF, false>; }
-step_kernel_t pick_step_kernel(bool nl, bool lf, bool src)
+template <bool NL, bool LF, int B>
+step_kernel_t pick_step_src(bool src) { return src ? swe_step_kernel<NL, LF, true, B> : swe_step_kernel<NL, LF, false, B>; }
+template <int B>
+step_kernel_t pick_step_b(bool nl, bool lf, bool src)
 {
-    return nl ? (lf ? pick_step_src<true, true>(src) : pick_step_src<true, false>(src))
-              : (lf ? pick_step_src<false, true>(src) : pick_step_src<false, false>(src));
+    return nl ? (lf ? pick_step_src<true, true, B>(src) : pick_step_src<true, false, B>(src))
+              : (lf ? pick_step_src<false, true, B>(src) : pick_step_src<false, false, B>(src));
+}
+step_kernel_t pick_step_kernel(bool nl, bool lf, bool src, int block)
+{
+    return block == 384 ? pick_step_b<384>(nl, lf, src) : pick_step_b<256>(nl, lf, src);
 }
 
 // the configurations the fused step kernel covers; everything else steps stage by stage (same bits)
@@ -521,7 +526,7 @@ int launch_step(Handle *h, int c0, int c1)
     q.tile_slot = t->slot; q.tile_vert = t->vert; q.tile_n = t->n;
     q.n_tiles = t->n_tiles; q.B = t->B;
     for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
-    step_kernel_t kern = pick_step_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h));
+    step_kernel_t kern = pick_step_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h), t->B);
     const int grid = ((t->n_tiles + 7)/8)*8;
     SWE_CHK_SYNC(h->stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(t->B), (size_t)9*(t->B + SWE_STEP_EXTRA)*sizeof(double), h->stream, q);
@@ -694,7 +699,7 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
         h->h_cv = cv;
         if (const char *st = std::getenv("THETIS_AMD_STEP_TILE")) {
             int c = 0, b = 0;
-            if (std::sscanf(st, "%d,%d", &c, &b) == 2 && c >= 1 && b >= c && b <= SWE_STEP_MAX_BLOCK && b % 64 == 0) {
+            if (std::sscanf(st, "%d,%d", &c, &b) == 2 && c >= 1 && b >= c && (b == 256 || b == 384)) {
                 h->step_tile_cells = c; h->step_block = b;
             }
         }

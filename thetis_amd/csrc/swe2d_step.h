@@ -24,7 +24,7 @@
 // scratch = three waves per SIMD = three 256-lane workgroups per compute unit - but only because the stage loop hides its
 // invariants from the optimiser (see the asm statement there): hoisted out of the loop they cost 228 VGPRs or 51 spills.
 // Measured (MI355X, same box, us/step, three stage launches -> one step launch): 2.5 k cells 17.3 -> 14.0, 10 k 16.8 -> 14.1,
-// 31 k 18.0 -> 13.3, 62 k 20.3 -> 17.0, 90 k 24.1 -> 22.2, 125 k 24.4 -> 25.5, 250 k 38.2 -> 42.4, 1 M 124 -> 135 (256-cell tiles
+// 31 k 18.0 -> 13.3, 62 k 20.3 -> 17.0, 90 k 24.1 -> 22.2, 125 k 24.3 -> 24.9, 250 k 38.2 -> 42.4, 1 M 117 -> 131 (256-cell tiles
 // in 384-lane workgroups: 153 - two six-wave workgroups do not share a compute unit's SIMDs evenly).  The step kernel wins where a
 // step is latency - one launch, one trip to memory, three short stages - and loses beyond ~100 k cells, where throughput counts:
 // there it is bound by the FP64 issue rate (1.95 us of SIMD time per wave-stage at 3 waves per SIMD against 1.1 us of pure
@@ -35,9 +35,6 @@
 #pragma once
 #include "swe2d_kernels.h"
 
-#ifndef SWE_STEP_MAX_BLOCK
-#define SWE_STEP_MAX_BLOCK 384
-#endif
 #ifndef SWE_STEP_OCCUPANCY
 #define SWE_STEP_OCCUPANCY __attribute__((amdgpu_waves_per_eu(3, 3)))      // 168 VGPRs, no scratch: two 384-lane workgroups per CU
 #endif
@@ -200,15 +197,17 @@ __device__ __forceinline__ void swe_step_finish(const SweStageArgs &p, int k, do
     }
 }
 
-template <bool NONLIN, bool LF, bool SRC>
-__global__ __launch_bounds__(SWE_STEP_MAX_BLOCK) SWE_STEP_OCCUPANCY void swe_step_kernel(const SweStepArgs q)
+// BLOCK: the workgroup size as a compile-time constant - the LDS plane offsets of every trace read become instruction immediates
+template <bool NONLIN, bool LF, bool SRC, int BLOCK>
+__global__ __launch_bounds__(BLOCK) SWE_STEP_OCCUPANCY void swe_step_kernel(const SweStepArgs q)
 {
 #pragma clang fp contract(off)
     extern __shared__ double swe_step_xs[];                    // [9][B + SWE_STEP_EXTRA]: the stage values of the tile's slots
     const SweStageArgs &p = q.st;
     const int tile = swe_logical_block(blockIdx.x, gridDim.x);
     if (tile >= q.n_tiles) return;
-    const int B = q.B, XS = B + SWE_STEP_EXTRA, j = (int)threadIdx.x;
+    constexpr int B = BLOCK, XS = BLOCK + SWE_STEP_EXTRA;
+    const int j = (int)threadIdx.x;
     const int4 tn = q.tile_n[tile];
     double *xs = swe_step_xs;
     const size_t S = p.stride;
