@@ -320,9 +320,12 @@ int  swe2d_swap_state_buffers(swe2d_handle *h);
  * [cell_begin, cell_end) in ONE launch (csrc/swe2d_step.h: the stages of a tile of cells stay on the compute unit), from state
  * buffer 0 into buffer 1: the cells of the range must have three valid layers of facet neighbours around them in buffer 0.
  * After the last range of a step swe2d_swap_state_buffers makes buffer 1 the state.  Bit for bit the result of the three
- * swe2d_solve_stage(_cells) calls.  Covers triangles without wetting-drying and viscosity (swe2d_fused_step_supported;
- * SWE2D_ERR_UNSUPPORTED otherwise); swe2d_advance uses it on its own where it applies (THETIS_AMD_FUSED_STEP=0: never). */
+ * swe2d_solve_stage(_cells) calls.  Covers triangles without wetting-drying and viscosity (swe2d_fused_step_supported: 0 not
+ * covered, 1 covered, 2 covered and without source terms; SWE2D_ERR_UNSUPPORTED otherwise); swe2d_advance uses it on its own where it applies (THETIS_AMD_FUSED_STEP=0: never). */
 int  swe2d_solve_step_cells(swe2d_handle *h, int32_t cell_begin, int32_t cell_end);
+/* builds (and keeps) the tile lists of a cell range without launching: the first swe2d_solve_step_cells of a range allocates,
+ * which a stream capture does not allow */
+int  swe2d_prepare_step_cells(swe2d_handle *h, int32_t cell_begin, int32_t cell_end);
 int  swe2d_fused_step_supported(swe2d_handle *h);
 /* run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the handle's own */
 int  swe2d_set_stream(swe2d_handle *h, void *hip_stream);

@@ -487,6 +487,32 @@ def test_ranks_on_one_gpu_with_peer_to_peer_halos(tmp_path, hip_lib, world, case
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('world,case,n_steps', [
+    (2, 'channel+fused', 3), (2, 'channel+every2+fused', 5), (2, 'channel+p2p+fused', 3), (3, 'channel+every3+p2p+fused+graph', 11),
+    (2, 'channel+every2+p2p+fused+nosplit+graph', 9), (2, 'channel+every4+p2p+fused+capture', 8), (3, 'delaunay+p2p+fused+graph', 2)])
+def test_ranks_on_one_gpu_with_one_launch_per_step(tmp_path, hip_lib, world, case, n_steps):
+    """fused_step: a cycle = m step-kernel launches on shrinking ranges (csrc/swe2d_step.h), the last one split around the send,
+    state buffers swapped on the host after every step - eager, host-staged and peer-to-peer, and replayed from per-cycle HIP
+    graphs (odd cycle lengths: the replay re-applies the swap, both buffer orientations get their own graph).  Bitwise the
+    single-device result."""
+    from thetis_amd.device import Swe2dDevice
+    import dist_worker
+    dist_worker.CASE = case.split('+')[0]
+    try:
+        mesh, bath, uv, eta = dist_worker._case()
+        run_workers(gpu_worker, world, n_steps, str(tmp_path), axis=0, case=case)
+    finally:
+        dist_worker.CASE = 'channel'
+    u_p, e_p, extra = gather(str(tmp_path), world, mesh.num_cells)
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev.set_state(uv, eta)
+    dev.advance(n_steps)
+    u_s, e_s = dev.get_state()
+    dev.close()
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('case', ['channel+every2+overlap3+capture', 'channel+every4+p2p+capture'])
 def test_capture_outside_advance_as_the_bench_does(tmp_path, hip_lib, case):
     """bench.py calls DistributedSwe2d._capture directly (not through advance): the capture run must use the solver's own

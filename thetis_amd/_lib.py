@@ -111,6 +111,7 @@ SYMBOLS = {
     'swe2d_swap_state_buffers': (ctypes.c_int, [_H]),
     'swe2d_solve_step_cells': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_fused_step_supported': (ctypes.c_int, [_H]),
+    'swe2d_prepare_step_cells': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_set_stream': (ctypes.c_int, [_H, ctypes.c_void_p]),
 }
 

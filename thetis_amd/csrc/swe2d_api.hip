@@ -1148,10 +1148,22 @@ int swe2d_solve_step_cells(swe2d_handle *hh, int32_t cell_begin, int32_t cell_en
     return launch_step(h, cell_begin, cell_end);
 }
 
+int swe2d_prepare_step_cells(swe2d_handle *hh, int32_t cell_begin, int32_t cell_end)
+{
+    Handle *h = H(hh);
+    if (!h || cell_begin < 0 || cell_end > h->n_cells || cell_begin > cell_end)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell range");
+    if (cell_end == cell_begin) return SWE2D_OK;
+    if (!step_kernel_covers(h)) return fail(h, SWE2D_ERR_UNSUPPORTED, "the fused step kernel covers triangles without wetting-drying and viscosity");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return step_tiles_for(h, cell_begin, cell_end) ? SWE2D_OK : fail(h, SWE2D_ERR_HIP, "fused step: tile lists could not be built");
+}
+
 int swe2d_fused_step_supported(swe2d_handle *hh)
 {
     Handle *h = H(hh);
-    return (h && step_kernel_covers(h)) ? 1 : 0;
+    if (!h || !step_kernel_covers(h)) return 0;
+    return has_sources(h) ? 1 : 2;          // 2: covered and without source terms (where it is the faster path on small meshes)
 }
 
 int swe2d_advance_forward_euler(swe2d_handle *hh, int n_steps)

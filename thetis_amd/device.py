@@ -395,9 +395,17 @@ class Swe2dDevice(object):
         swaps the buffers after the last range); bit for bit the three ``solve_stage_cells`` calls."""
         self._ck(self.lib.swe2d_solve_step_cells(self.h, int(cell_begin), int(cell_end)))
 
+    def prepare_step_cells(self, cell_begin, cell_end):
+        """Build the tile lists of a range ahead of its first ``solve_step_cells`` (which must not allocate inside a capture)."""
+        self._ck(self.lib.swe2d_prepare_step_cells(self.h, int(cell_begin), int(cell_end)))
+
     def fused_step_supported(self):
         """True where the one-launch step kernel covers the current configuration (triangles, no wetting-drying, no viscosity)."""
         return bool(self.lib.swe2d_fused_step_supported(self.h))
+
+    def fused_step_preferred(self):
+        """... and no source terms are set: the configuration where it is the faster path on small meshes."""
+        return self.lib.swe2d_fused_step_supported(self.h) == 2
 
     def advance_timed(self, n_steps, per_launch=False):
         """Returns (total ms, mean ms per stage-kernel launch), measured with HIP events on the launch stream."""

@@ -176,7 +176,7 @@ class DistributedSwe2d(object):
     def __init__(self, mesh, bathymetry_vertex, dt, rank, world_size, device_id, owner=None, host_staged=False,
                  n_tracers=0, use_limiter=True, tracer_only=False, exchange_every=1, overlap_stages=0,
                  graph_mode=None, stepper='SSPRK33', exchange=None, split_last_stage=True, group=None, partition=None,
-                 combined_exchange=False, **opts):
+                 combined_exchange=False, fused_step=None, **opts):
         """``n_tracers`` > 0: the coupled step of GeneralCoupledTimeIntegrator2D.advance (coupled_timeintegrator_2d.py:
         93-113) on the partition - shallow water step, then every tracer with the updated velocity, then the limiter.
         The vertex-based limiter needs every cell around a vertex, so coupled runs with the limiter use four ghost layers
@@ -202,6 +202,14 @@ class DistributedSwe2d(object):
         numbering (LocalPartition.owned_prefix) - and completes those stages on the remaining wedge (cells at distance
         <= g + 1 and the ghost layers) after the unpack.  Disjoint read / write sets (a late stage g reads distance
         <= g + 2, an early stage g' > g writes distance >= g' + 2), bitwise the same result.
+
+        ``fused_step``: the whole SSPRK33 step of a cell range in ONE launch (csrc/swe2d_step.h; bit for bit the three stage
+        launches) instead of one launch per stage: None = where it is the faster path (eager launches - graph_mode 'none' -,
+        shallow water only, triangles without wetting-drying / viscosity / source terms, at most 80 k owned cells, no
+        ``overlap_stages``; in replayed graphs the stage launches have no host gaps and win), True = wherever the
+        kernel covers the configuration, False = never.  A cycle is then m step launches on shrinking ranges; the step
+        result lands in the other state buffer, so the buffers are swapped on the host after every step (a replayed graph
+        re-applies the swaps it stands for).
 
         ``exchange``: 'p2p' | 'rccl' | 'host' (module docstring); default 'host' if ``host_staged`` else 'rccl'.
         ``partition``: a LocalPartition already built for this rank with the halo depth the other arguments imply.
@@ -256,6 +264,8 @@ class DistributedSwe2d(object):
         self.dev = Swe2dDevice(p, np.asarray(bathymetry_vertex)[p.vertex_global], dt, device_id=device_id,
                                n_owned=p.n_owned, boundary_len=p.boundary_len, ranges=p.reorder_ranges(), **opts)
         self.dev.halo_setup(p.send_cells, p.recv_cells)
+        self._fused_request = fused_step
+        self._flip = 0                       # parity of the state-buffer swaps (fused steps): graphs hold absolute pointers
         self._ranges = [p.stage_range(i) for i in range(3)]
         self.tids = [self.dev.add_tracer() for _ in range(n_tracers)]
         self.halo = self.thalo = self.p2p = None
@@ -284,6 +294,71 @@ class DistributedSwe2d(object):
 
     def close(self):
         self.dev.close()
+
+    @property
+    def fused(self):
+        """True when a cycle runs as one launch per step (see ``fused_step``); evaluated per call: the device configuration
+        (source terms, viscosity, wetting-drying) may be set after construction."""
+        if self._fused_request is False:
+            return False
+        plain = (self.stages_per_step == 3 and not self.tids and not self.tracer_only and self.overlap_stages == 0)
+        if not plain or not self.dev.fused_step_supported():
+            if self._fused_request is True:
+                raise ValueError('fused_step=True: the step kernel covers SSPRK33 shallow-water-only runs on triangles without '
+                                 'wetting-drying, viscosity and overlap_stages')
+            return False
+        if self._fused_request is True:
+            return True
+        # inside replayed graphs the stage launches have no host gaps and the step kernel loses its advantage (measured per
+        # rank, p2p, m = 4: 62 k cells 24.9 us/step stage-wise vs 26.6 fused, 31 k 20.1 vs 20.1): eager launches only
+        return self.graph_mode == 'none' and self.part.n_owned <= 80000 and self.dev.fused_step_preferred()
+
+    def _swap(self):
+        self.dev.swap_state_buffers()
+        self._flip ^= 1
+
+    def _cycle_swe_fused(self, n_steps, graphed):
+        """``n_steps`` time steps as one step-kernel launch each (state buffer 0 -> 1, then the host swaps the buffers) on the
+        shrinking ranges that stay exact, the last one split around the send like the last stage of the stage-wise cycle."""
+        dev, p = self.dev, self.part
+        if graphed and ('FP', n_steps, self._flip) not in self._cycle_graphs:
+            # the tile lists of the ranges are built at their first launch: not inside the capture that follows
+            for s in range(n_steps - 1):
+                dev.prepare_step_cells(0, p.stage_range(3*s + 2, depth=3*n_steps))
+            for a, b in ((p.n_interior, p.n_owned), (0, p.n_interior), (0, p.n_owned)):
+                dev.prepare_step_cells(a, b)
+
+        def before():
+            for s in range(n_steps - 1):
+                dev.solve_step_cells(0, p.stage_range(3*s + 2, depth=3*n_steps))
+                self._swap()
+            if self.split_last_stage:
+                dev.solve_step_cells(p.n_interior, p.n_owned)      # the cells the peers are waiting for
+            else:
+                dev.solve_step_cells(0, p.n_owned)
+
+        def during():
+            if self.split_last_stage:
+                dev.solve_step_cells(0, p.n_interior)
+            self._swap()                                           # buffer 0 is the new state; its ghosts arrive next
+
+        if self.p2p is not None:
+            def whole_cycle():
+                before()
+                dev.p2p_push(0, 1)                                 # the step result still sits in buffer 1
+                during()
+                dev.p2p_wait_unpack(0, 0)
+            ran = self._launch(('FP', n_steps, self._flip), whole_cycle, graphed)
+            if not ran:                                            # a replay: the swaps the graph stands for
+                for _ in range(n_steps % 2):
+                    self._swap()
+            return
+        before()                                                   # host-staged / RCCL exchange: eager launches
+        dev.halo_pack(1, self.halo.send_buf.data_ptr())
+        reqs = self.halo.start()
+        during()
+        self.halo.finish(reqs)
+        dev.halo_unpack(0, self.halo.recv_buf.data_ptr())
 
     def set_tracer_global(self, i_tracer, nodal):
         self.dev.tracer_set_state(self.tids[i_tracer], np.asarray(nodal)[self.part.local_to_global])
@@ -369,6 +444,8 @@ class DistributedSwe2d(object):
         ``early_next``: stages of the next cycle to run (ghost-independent part only) during this cycle's exchange."""
         if self.stages_per_step == 1:
             return self._cycle_forward_euler(n_steps)
+        if self.fused:
+            return self._cycle_swe_fused(n_steps, graphed)
         if self.p2p is not None:
             # the exchange is two kernels of this library: the whole cycle is one capturable launch sequence
             def whole_cycle():
@@ -417,48 +494,36 @@ class DistributedSwe2d(object):
 
     def _launch(self, key, fn, graphed):
         """Run the kernel sequence ``fn`` now, or replay its HIP graph (captured on first use).  Only kernels of this
-        library are captured: RCCL send/recv stay ordinary stream work between two graph launches."""
+        library are captured: RCCL send/recv stay ordinary stream work between two graph launches.  Returns True when
+        ``fn`` itself ran in this call (eagerly, or for the capture): its host-side effects have then happened."""
         import torch
         if not graphed:
             fn()
-            return
+            return True
+        ran = False
         g = self._cycle_graphs.get(key)
         if g is None and self.graph_mode == 'cycle':
+            flip = self._flip
             try:
                 g = torch.cuda.CUDAGraph()
                 self.stream.synchronize()
                 with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
                     fn()
                 self._cycle_graphs[key] = g
+                ran = True
             except Exception as e:       # capture refused: eager from now on (same results; a capture executes nothing)
                 if self.rank == 0:
                     print('[thetis_amd] HIP graph capture unavailable ({:}); running eagerly'.format(str(e).splitlines()[0]))
                 self.graph_mode, g = 'none', None
                 torch.cuda.synchronize()
+                if self._flip != flip:   # undo the buffer swaps of the aborted capture before running for real
+                    self._swap()
         if g is not None:
             g.replay()
         else:
             fn()
-
-    def _cycle_coupled(self, n_steps):
-        """``n_steps`` (<= exchange_every) coupled steps, then one exchange of the shallow water state and every tracer."""
-        dev = self.dev
-        reqs = None
-        sent = False
-        for op in coupled_cycle_schedule(self.part, n_steps, len(self.tids), self.use_limiter, self.tracer_only):
-            if op[0] == 'swe':
-                dev.solve_stage_cells(op[1], 0, op[2])
-            elif op[0] == 'swe_done':
-                reqs = self._send(0, 0)               # travels while the tracers step
-                sent = True
-            elif op[0] == 'tracer':
-                dev.tracer_solve_stage_cells(self.tids[op[1]], op[2], 0, op[3])
-            else:
-                dev.tracer_limit_cells(self.tids[op[1]], op[2])
-        if sent:
-            self._receive(0, 0, reqs)
-        for i in range(len(self.tids)):
-            self._receive(1 + i, 0, self._send(1 + i, 0))
+            ran = True
+        return ran
 
     def _steps_eager(self, n_steps, graphed=False):
         m = self.exchange_every
