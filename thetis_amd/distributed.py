@@ -525,6 +525,26 @@ class DistributedSwe2d(object):
             ran = True
         return ran
 
+    def _cycle_coupled(self, n_steps):
+        """``n_steps`` (<= exchange_every) coupled steps, then one exchange of the shallow water state and every tracer."""
+        dev = self.dev
+        reqs = None
+        sent = False
+        for op in coupled_cycle_schedule(self.part, n_steps, len(self.tids), self.use_limiter, self.tracer_only):
+            if op[0] == 'swe':
+                dev.solve_stage_cells(op[1], 0, op[2])
+            elif op[0] == 'swe_done':
+                reqs = self._send(0, 0)               # travels while the tracers step
+                sent = True
+            elif op[0] == 'tracer':
+                dev.tracer_solve_stage_cells(self.tids[op[1]], op[2], 0, op[3])
+            else:
+                dev.tracer_limit_cells(self.tids[op[1]], op[2])
+        if sent:
+            self._receive(0, 0, reqs)
+        for i in range(len(self.tids)):
+            self._receive(1 + i, 0, self._send(1 + i, 0))
+
     def _steps_eager(self, n_steps, graphed=False):
         m = self.exchange_every
         if self.coupled_cycles:
