@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 2 closing evidence with the final library: bench, kernel-trace stats of the bench command, PMC traffic (1M, 4M)
 set -u
-O=gpurun_out/r02v; mkdir -p $O
+O=gpurun_out/evidence_bench; mkdir -p $O
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 2 final evidence: full GPU suite, bench, kernel-trace stats, PMC traffic (1M, 4M), configuration table, rank bench, sweep
 set -u
-O=gpurun_out/r02r; mkdir -p $O
+O=gpurun_out/evidence_cfgs; mkdir -p $O
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_all.log 2>&1; echo "pytest rc=$?" >> $O/pytest_all.log
