@@ -27,11 +27,17 @@ def _steps_fused(dev, n):
 
 
 @pytest.mark.parametrize('case', ['channel', 'channel_open', 'unstructured', 'linear', 'no_lf', 'sources', 'sources_large',
-                                  'ragged_ranges'])
+                                  'ragged_ranges', 'periodic'])
 def test_fused_step_gives_the_bits_of_three_stage_launches(hip_lib, case):
     from thetis_amd import _lib
     if case == 'unstructured':
         mesh, bath, uv, eta = delaunay_case(n_points=3000, seed=5)[:4]
+    elif case == 'periodic':
+        from thetis_amd.mesh import PeriodicRectangleMesh
+        mesh = PeriodicRectangleMesh(61, 29, 100e3, 30e3, direction='x')       # tiles wrap around the periodic direction
+        rng = np.random.default_rng(17)
+        bath = 20.0 + 2.0*np.sin(mesh.vertex_xy[:, 1]/5000.0)
+        uv, eta = 0.5*rng.normal(size=(mesh.num_cells, 3, 2)), 0.5*rng.normal(size=(mesh.num_cells, 3))
     else:
         nx, ny = (250, 125) if case == 'sources_large' else (67, 31)      # large: 62 k cells (one-ulp differences need cells to show)
         mesh, bath, uv, eta = channel_case(nx=nx, ny=ny, seed=11)
