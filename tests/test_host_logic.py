@@ -225,3 +225,28 @@ def test_firedrake_shaped_arrays_give_the_swe2d_mesh_of_mesh2d():
                           fx['ext_local_facet'], bad)
     assert (swe2d_mesh_arrays(fx['coords'], fx['cell_vertices'], fx['int_facet_cell'], fx['int_local_facet'],
                               fx['ext_facet_cell'], fx['ext_local_facet'], bad, halo_marker=9)['cell_neighbours'] == -9).sum() == 1
+
+
+def test_firedrake_shaped_quadrilateral_arrays_give_the_swe2d_mesh_of_mesh2d():
+    """... and for FIAT tensor-product quadrilaterals (lexicographic, non-cyclic local vertices; facets x=0, x=1, y=0, y=1; one
+    mirrored cell; tests/golden/make_firedrake_like_quad_mesh.py): cyclic counter-clockwise cells, the facet tables and the DQ-1
+    permutation must be what Mesh2d derives from the cyclic cells by edge matching."""
+    import json
+    import os
+    from thetis_amd.firedrake_adapter import swe2d_mesh_arrays
+    from thetis_amd.mesh import Mesh2d, _rect_marker_fn
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'firedrake_like_quad_mesh.json')) as f:
+        fx = json.load(f)
+    out = swe2d_mesh_arrays(fx['coords'], fx['cell_vertices'], fx['int_facet_cell'], fx['int_local_facet'], fx['ext_facet_cell'],
+                            fx['ext_local_facet'], fx['ext_markers'], dg_cell_nodes=fx['dg_cell_nodes'])
+    assert np.array_equal(out['cell_vertices'], fx['expected_cell_vertices_ccw'])
+    assert np.array_equal(out['dg_perm'], fx['expected_dg_perm'])
+    mesh = Mesh2d(np.array(fx['coords'], dtype=float), np.array(fx['expected_cell_vertices_ccw']), marker_fn=_rect_marker_fn(2.0, 2.0))
+    assert np.array_equal(mesh.cells, out['cell_vertices'])
+    assert np.array_equal(mesh.cell_nbr, out['cell_neighbours'])
+    assert np.array_equal(mesh.cell_nbr_facet, out['cell_neighbour_facets'])
+    dg_vertex = np.empty(16, dtype=int)
+    dg_vertex[np.array(fx['dg_cell_nodes']).ravel()] = np.array(fx['cell_vertices']).ravel()
+    assert np.array_equal(dg_vertex[out['dg_perm']], out['cell_vertices'])
+    with pytest.raises(NotImplementedError):
+        swe2d_mesh_arrays(fx['coords'], [c + [0] for c in fx['cell_vertices']], [], [], [], [], [])
