@@ -1,5 +1,7 @@
 """Multi-rank path: partition, halo lists and exchange.  CPU: world_size 2-3 gloo with the oracle as compute;
 GPU: the real DistributedSwe2d with two ranks sharing the one GPU of the test box."""
+import os
+
 import numpy as np
 import pytest
 
@@ -541,3 +543,43 @@ def test_two_ranks_coupled_with_peer_to_peer_halos(tmp_path, hip_lib):
     T_s = dev.tracer_get_state(tid)
     dev.close()
     assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s) and np.array_equal(extra[-1], T_s)
+
+
+@pytest.mark.gpu
+def test_a_lost_peer_costs_one_bounded_wait_and_never_hangs_the_device(hip_lib):
+    """The wait of the peer-to-peer unpack is bounded (THETIS_AMD_P2P_TIMEOUT_S) and sticky: a peer that never pushes costs one
+    timeout, the next waits of the handle do not spin at all, the state stays finite and the device answers.  (Loopback zone:
+    the rank is its own peer, and nobody pushes.)"""
+    import time
+    from thetis_amd.device import Swe2dDevice
+    from thetis_amd.partition import build_partition, strip_owner
+    mesh, bath, uv, eta = _case()
+    part = build_partition(mesh, strip_owner(mesh, 2), 0)
+    os.environ['THETIS_AMD_P2P_TIMEOUT_S'] = '0.3'
+    try:
+        dev = Swe2dDevice(part, bath[part.vertex_global], 2.0, n_owned=part.n_owned, boundary_len=part.boundary_len,
+                          ranges=part.reorder_ranges())
+        dev.halo_setup(part.send_cells, part.recv_cells)
+        dev.set_state(uv[part.local_to_global], eta[part.local_to_global])
+        dev.p2p_create([9])
+        _, base, _ = dev.p2p_export()
+        peers = sorted(part.send)
+        dev.p2p_connect([base]*len(peers), [part.send[q][0] for q in peers], [part.send[q][1] for q in peers],
+                        [part.recv[q][0] for q in peers], list(range(len(peers))), [len(part.recv_cells)]*len(peers), n_from=len(peers))
+        t0 = time.perf_counter()
+        dev.p2p_wait_unpack(0, 0)                      # nobody pushed: runs into the timeout
+        sent, received, timeouts = dev.p2p_status()
+        t1 = time.perf_counter()
+        assert timeouts == 1 and 0.25 < t1 - t0 < 5.0
+        dev.p2p_wait_unpack(0, 0)                      # sticky: no second spin
+        dev.p2p_wait_unpack(0, 0)
+        _, _, timeouts = dev.p2p_status()
+        assert timeouts >= 1 and time.perf_counter() - t1 < 0.25
+        dev.p2p_push(0, 0)                             # the device still works
+        for i in range(3):
+            dev.solve_stage_cells(i, 0, part.n_owned)
+        u, e = dev.get_state()
+        assert np.isfinite(u[:part.n_owned]).all() and np.isfinite(e[:part.n_owned]).all()
+        dev.close()
+    finally:
+        os.environ.pop('THETIS_AMD_P2P_TIMEOUT_S', None)
