@@ -261,6 +261,9 @@ int  swe2d_tracer_forward_euler(swe2d_handle *h, int tracer_id);                
  * and vertex bounds taken over every local cell (the ghost layers must hold the neighbours' unlimited values), and the
  * tracer's part of the halo exchange (same cell lists as swe2d_halo_setup, nodes_per_cell doubles per cell) */
 int  swe2d_tracer_solve_stage_cells(swe2d_handle *h, int tracer_id, int i_stage, int32_t cell_begin, int32_t cell_end);
+/* ForwardEuler for a tracer on a partition: swe2d_tracer_solve_stage_cells(id, 0, begin, end) is the step from tracer buffer 0
+ * into buffer 1 on a cell range; after the last range swe2d_tracer_swap_buffers makes buffer 1 the tracer (cf. swe2d_forward_euler_cells) */
+int  swe2d_tracer_swap_buffers(swe2d_handle *h, int tracer_id);
 int  swe2d_tracer_limit_cells(swe2d_handle *h, int tracer_id, int32_t cell_end);
 int  swe2d_tracer_halo_pack(swe2d_handle *h, int tracer_id, int i_buffer, double *send_buf_dev);
 int  swe2d_tracer_halo_unpack(swe2d_handle *h, int tracer_id, int i_buffer, const double *recv_buf_dev);         /* parity hook */

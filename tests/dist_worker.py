@@ -240,10 +240,11 @@ def cpu_coupled_cycles_worker(rank, world, port, n_steps, out_dir, axis, case='c
     """The product's coupled cycles (m coupled steps between two exchanges of all fields, coupled_cycle_schedule) launch by
     launch with the C restatement as compute; everything a launch must not read is NaN."""
     global CASE
-    no_lim = '+nolim' in case
-    case = case.replace('+nolim', '')
+    no_lim, fe = '+nolim' in case, '+fe' in case
+    case = case.replace('+nolim', '').replace('+fe', '')
     case, every, _ = _split_every(case)
     CASE = case
+    sps = 1 if fe else 3
     import torch
     from oracle.ref_lib import RefSWE, RefTracer
     from thetis_amd.distributed import HaloExchanger, coupled_cycle_schedule, coupled_halo_depth
@@ -251,7 +252,7 @@ def cpu_coupled_cycles_worker(rank, world, port, n_steps, out_dir, axis, case='c
     dist = _init(rank, world, port)
     mesh, bath, uv, eta = _case()
     owner = strip_owner(mesh, world, axis=axis)
-    part = build_partition(mesh, owner, rank, halo_depth=coupled_halo_depth(every, not no_lim),
+    part = build_partition(mesh, owner, rank, halo_depth=coupled_halo_depth(every, not no_lim, sps),
                            adjacency='facet' if no_lim else 'vertex')
     ref = RefSWE(part.cell_xy(), part.cell_nbr, part.cell_nbr_facet, bath[part.vertex_global][part.cells],
                  boundary_len=part.boundary_len)
@@ -267,7 +268,7 @@ def cpu_coupled_cycles_worker(rank, world, port, n_steps, out_dir, axis, case='c
     while left > 0:
         r = min(every, left)
         left -= r
-        for op in coupled_cycle_schedule(part, r, 1, not no_lim):
+        for op in coupled_cycle_schedule(part, r, 1, not no_lim, stages_per_step=sps):
             if op[0] == 'swe':
                 _, i, end = op
                 if i == 0:
@@ -314,8 +315,8 @@ def cpu_coupled_cycles_worker(rank, world, port, n_steps, out_dir, axis, case='c
 def gpu_coupled_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     """DistributedSwe2d with one tracer + limiter, two ranks sharing ONE GPU (gloo + host staging stands in for RCCL)."""
     global CASE
-    p2p, combined, no_lim = '+p2p' in case, '+combined' in case, '+nolim' in case
-    case = case.replace('+p2p', '').replace('+combined', '').replace('+nolim', '')
+    p2p, combined, no_lim, fe = '+p2p' in case, '+combined' in case, '+nolim' in case, '+fe' in case
+    case = case.replace('+p2p', '').replace('+combined', '').replace('+nolim', '').replace('+fe', '')
     case, every, _ = _split_every(case)
     CASE = case
     from thetis_amd.distributed import DistributedSwe2d
@@ -324,7 +325,8 @@ def gpu_coupled_worker(rank, world, port, n_steps, out_dir, axis, case='channel'
     mesh, bath, uv, eta = _case()
     owner = strip_owner(mesh, world, axis=axis)
     solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, n_tracers=1, exchange=('p2p' if p2p else 'host'),
-                              exchange_every=every, combined_exchange=combined, use_limiter=not no_lim)
+                              exchange_every=every, combined_exchange=combined, use_limiter=not no_lim,
+                              stepper=('ForwardEuler' if fe else 'SSPRK33'))
     solver.set_state_global(uv, eta)
     solver.set_tracer_global(0, tracer_initial(mesh))
     solver.advance(n_steps, use_graph=False)

@@ -301,7 +301,8 @@ def test_gloo_partitioned_coupled_step_equals_global(tmp_path, ref_so, world, ax
 
 
 @pytest.mark.parametrize('world,axis,case,n_steps', [(2, 0, 'channel+every2', 5), (3, 1, 'channel+every1', 3),
-                                                      (2, 1, 'channel+every3+nolim', 4), (3, 0, 'delaunay+every2', 3)])
+                                                      (2, 1, 'channel+every3+nolim', 4), (3, 0, 'delaunay+every2', 3),
+                                                      (2, 0, 'channel+every3+fe', 7), (3, 1, 'channel+every2+fe+nolim', 5)])
 def test_gloo_coupled_cycles_with_one_exchange_equal_global(tmp_path, ref_so, world, axis, case, n_steps):
     """m coupled steps between two exchanges of all fields on 4m + 3 vertex layers (3m + 3 facet layers without the limiter),
     every launch on the range coupled_cycle_schedule gives it (stale cells poisoned with NaN) == the whole-mesh algorithm,
@@ -321,7 +322,14 @@ def test_gloo_coupled_cycles_with_one_exchange_equal_global(tmp_path, ref_so, wo
     n = mesh.num_cells
     u, e, T = uv.copy(), eta.copy(), tracer_initial(mesh)
     for _ in range(n_steps):
-        u, e, T = coupled_step_reference(ref, rt, u, e, T, 2.0, (n, n, n), 0 if '+nolim' in case else n)
+        if '+fe' in case:                                   # ForwardEuler: U + dt M^-1 R(U), tracer with the updated velocity
+            ku, ke = ref.tendency(u, e, 2.0)
+            u, e = u + ku, e + ke
+            T = T + rt.tendency(T, u, 2.0)
+            if '+nolim' not in case:
+                T = rt.limit(T)
+        else:
+            u, e, T = coupled_step_reference(ref, rt, u, e, T, 2.0, (n, n, n), 0 if '+nolim' in case else n)
     assert np.array_equal(u_p, u) and np.array_equal(e_p, e) and np.array_equal(T_p, T)
 
 
@@ -330,6 +338,7 @@ def test_coupled_cycle_schedule_counts_layers():
     from thetis_amd.partition import build_partition, strip_owner
     mesh, bath, uv, eta = _case()
     assert coupled_halo_depth(1, True) == 7 and coupled_halo_depth(2, True) == 11 and coupled_halo_depth(2, False) == 9
+    assert coupled_halo_depth(3, True, 1) == 7 and coupled_halo_depth(3, False, 1) == 4
     part = build_partition(mesh, strip_owner(mesh, 2), 0, halo_depth=7, adjacency='vertex')
     ops = coupled_cycle_schedule(part, 1, 2, True)
     assert [o[0] for o in ops] == ['swe']*3 + ['swe_done'] + ['tracer']*6 + ['limit']*2
@@ -342,7 +351,7 @@ def test_coupled_cycle_schedule_counts_layers():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('case,n_steps', [('channel+every2', 5), ('channel+combined', 3), ('channel+every2+p2p', 4),
-                                          ('channel+every3+nolim+p2p', 4)])
+                                          ('channel+every3+nolim+p2p', 4), ('channel+every2+fe', 5), ('channel+every1+fe+p2p', 3)])
 def test_two_ranks_coupled_cycles_with_one_exchange_match_single_device(tmp_path, hip_lib, case, n_steps):
     """DistributedSwe2d(n_tracers=1, exchange_every=m | combined_exchange): one exchange of all fields per m coupled steps,
     host-staged and peer-to-peer, == the single-device coupled stepping, bitwise."""
@@ -355,7 +364,14 @@ def test_two_ranks_coupled_cycles_with_one_exchange_match_single_device(tmp_path
     tid = dev.add_tracer()
     dev.set_state(uv, eta)
     dev.tracer_set_state(tid, tracer_initial(mesh))
-    dev.advance_coupled(n_steps, tracer_only=False, use_limiter='+nolim' not in case)
+    if '+fe' in case:
+        for _ in range(n_steps):
+            dev.advance_forward_euler(1)
+            dev.tracer_forward_euler(tid)
+            if '+nolim' not in case:
+                dev.tracer_limit(tid)
+    else:
+        dev.advance_coupled(n_steps, tracer_only=False, use_limiter='+nolim' not in case)
     u_s, e_s = dev.get_state()
     assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s) and np.array_equal(T_p, dev.tracer_get_state(tid))
     dev.close()

@@ -80,6 +80,7 @@ SYMBOLS = {
     'swe2d_tracer_set_bc_facets': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int32, _ip, _ip, _dp]),
     'swe2d_tracer_set_source': (ctypes.c_int, [_H, ctypes.c_int, _dp]),
     'swe2d_tracer_solve_stage_cells': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_int32, ctypes.c_int32]),
+    'swe2d_tracer_swap_buffers': (ctypes.c_int, [_H, ctypes.c_int]),
     'swe2d_tracer_limit_cells': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int32]),
     'swe2d_tracer_halo_pack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'swe2d_tracer_halo_unpack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

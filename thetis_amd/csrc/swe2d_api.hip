@@ -1750,6 +1750,17 @@ int swe2d_tracer_forward_euler(swe2d_handle *hh, int id)
     return SWE2D_OK;
 }
 
+// ForwardEuler on cell ranges (partitions): swe2d_tracer_solve_stage_cells(id, 0, ...) is the step from tracer buffer 0 into
+// buffer 1; when every range of the step is launched this makes buffer 1 the tracer.
+int swe2d_tracer_swap_buffers(swe2d_handle *hh, int id)
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    std::swap(h->tracers[id].buf[0], h->tracers[id].buf[1]);
+    return SWE2D_OK;
+}
+
 int swe2d_tracer_set_conservative(swe2d_handle *hh, int id, int use_conservative_form)
 {
     Handle *h = H(hh);

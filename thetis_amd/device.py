@@ -523,6 +523,10 @@ class Swe2dDevice(object):
     def tracer_solve_stage_cells(self, tid, i_stage, cell_begin, cell_end):
         self._ck(self.lib.swe2d_tracer_solve_stage_cells(self.h, int(tid), int(i_stage), int(cell_begin), int(cell_end)))
 
+    def tracer_swap_buffers(self, tid):
+        """after ``tracer_solve_stage_cells(tid, 0, ...)`` on every range of a ForwardEuler step: buffer 1 becomes the tracer"""
+        self._ck(self.lib.swe2d_tracer_swap_buffers(self.h, int(tid)))
+
     def tracer_limit_cells(self, tid, cell_end):
         """Limiter on cells [0, cell_end); means / vertex bounds over every local cell."""
         self._ck(self.lib.swe2d_tracer_limit_cells(self.h, int(tid), int(cell_end)))

@@ -129,22 +129,24 @@ class P2PHalo(object):
         return self.dev.p2p_status(self.n_channels)[2]
 
 
-def coupled_halo_depth(exchange_every, use_limiter):
+def coupled_halo_depth(exchange_every, use_limiter, stages_per_step=3):
     """Ghost layers a coupled cycle of ``exchange_every`` steps with ONE exchange at its end needs (vertex-adjacent layers with
-    the limiter, facet-adjacent ones without): a step costs the shallow water state three layers; the tracer stages read the
-    new velocity one layer further out than they write, so the tracer ends a step three (with the limiter: four) layers
-    inside the shallow water state it started from."""
-    return (4 if use_limiter else 3)*int(exchange_every) + 3
+    the limiter, facet-adjacent ones without): a step costs the shallow water state one layer per stage (three for SSPRK33, one
+    for ForwardEuler); the tracer stages read the new velocity one layer further out than they write, so the tracer ends a step
+    ``stages_per_step`` (with the limiter: one more) layers inside the shallow water state it started from."""
+    sps = int(stages_per_step)
+    return (sps + 1 if use_limiter else sps)*int(exchange_every) + sps
 
 
-def coupled_cycle_schedule(part, n_steps, n_tracers, use_limiter, tracer_only=False):
+def coupled_cycle_schedule(part, n_steps, n_tracers, use_limiter, tracer_only=False, stages_per_step=3):
     """Launch list of ``n_steps`` coupled steps (GeneralCoupledTimeIntegrator2D.advance, coupled_timeintegrator_2d.py:93-113:
     shallow water step, every tracer with the updated velocity, limiter) between two exchanges of ALL fields, on the shrinking
     cell ranges that stay exact: ('swe', stage, cell_end) | ('tracer', i_tracer, stage, cell_end) | ('limit', i_tracer, cell_end)
     | ('swe_done',) after the last shallow water stage of the cycle (its exchange can start there).  Validity is counted in
     ghost layers: a stage is exact on one layer less than its input, the tracer stages also need the velocity on the layer
-    they read, the limiter needs the cell means one (vertex) layer further out."""
-    depth = coupled_halo_depth(n_steps, use_limiter)
+    they read, the limiter needs the cell means one (vertex) layer further out.  ``stages_per_step``: 3 SSPRK33, 1 ForwardEuler."""
+    sps = int(stages_per_step)
+    depth = coupled_halo_depth(n_steps, use_limiter, sps)
     if depth > len(part.layer_sizes):
         raise ValueError('a coupled cycle of {:d} steps needs {:d} ghost layers, the partition has {:d}'.format(
             n_steps, depth, len(part.layer_sizes)))
@@ -152,16 +154,16 @@ def coupled_cycle_schedule(part, n_steps, n_tracers, use_limiter, tracer_only=Fa
     ops = []
     for k in range(n_steps):
         if not tracer_only:
-            for g in range(3):
+            for g in range(sps):
                 v_swe -= 1
                 ops.append(('swe', g, part.layer_end(v_swe)))
             if k == n_steps - 1:
                 ops.append(('swe_done',))
         v_in = min(v_t, v_swe)
         for i in range(n_tracers):
-            for g in range(3):
+            for g in range(sps):
                 ops.append(('tracer', i, g, part.layer_end(v_in - 1 - g)))
-        v_t = v_in - 3
+        v_t = v_in - sps
         if use_limiter:
             v_t -= 1
             for i in range(n_tracers):
@@ -228,15 +230,15 @@ class DistributedSwe2d(object):
             raise ValueError("stepper must be 'SSPRK33' or 'ForwardEuler'")
         # ForwardEuler (the other explicit entry of the steppers table): one stage per step, one ghost layer per step
         self.stages_per_step = 3 if stepper == 'SSPRK33' else 1
-        if self.stages_per_step == 1 and (n_tracers > 0 or int(overlap_stages) > 0):
-            raise ValueError('ForwardEuler on partitions: shallow water only, no overlap_stages')
+        if self.stages_per_step == 1 and int(overlap_stages) > 0:
+            raise ValueError('ForwardEuler on partitions: no overlap_stages')
         self.exchange_every = m = int(exchange_every)
         self.overlap_stages = int(overlap_stages)
         if m < 1 or (self.overlap_stages > 0 and n_tracers > 0):
             raise ValueError('overlap_stages is implemented for shallow-water-only runs')
         # coupled runs: exchange_every = 1 exchanges after the shallow water step and after every tracer step (four ghost
         # layers); exchange_every = m > 1 (or combined_exchange) runs m coupled steps between two exchanges of ALL fields
-        self.coupled_cycles = n_tracers > 0 and (m > 1 or bool(combined_exchange))
+        self.coupled_cycles = n_tracers > 0 and (m > 1 or bool(combined_exchange) or self.stages_per_step == 1)
         if not 0 <= self.overlap_stages <= 3*m - 1:
             raise ValueError('overlap_stages must be in 0 .. 3*exchange_every - 1')
         self.exchange = exchange or ('host' if host_staged else 'rccl')
@@ -247,11 +249,11 @@ class DistributedSwe2d(object):
             raise ValueError('overlap_stages needs split_last_stage')
         if partition is not None:
             self.part = partition                   # built by the caller with the matching halo depth (bench: reused)
+        elif self.coupled_cycles:
+            self.part = build_partition(mesh, owner, rank, halo_depth=coupled_halo_depth(m, self.use_limiter, self.stages_per_step),
+                                        adjacency='vertex' if self.use_limiter else 'facet')
         elif self.stages_per_step == 1:
             self.part = build_partition(mesh, owner, rank, halo_depth=m)
-        elif self.coupled_cycles:
-            self.part = build_partition(mesh, owner, rank, halo_depth=coupled_halo_depth(m, self.use_limiter),
-                                        adjacency='vertex' if self.use_limiter else 'facet')
         elif m > 1:
             self.part = build_partition(mesh, owner, rank, halo_depth=3*m)
         elif self.use_limiter:
@@ -530,14 +532,21 @@ class DistributedSwe2d(object):
         dev = self.dev
         reqs = None
         sent = False
-        for op in coupled_cycle_schedule(self.part, n_steps, len(self.tids), self.use_limiter, self.tracer_only):
+        fe = self.stages_per_step == 1         # ForwardEuler: a "stage" is the whole step, buffer 0 -> 1, then the buffers swap
+        for op in coupled_cycle_schedule(self.part, n_steps, len(self.tids), self.use_limiter, self.tracer_only, self.stages_per_step):
             if op[0] == 'swe':
-                dev.solve_stage_cells(op[1], 0, op[2])
+                if fe:
+                    dev.forward_euler_cells(0, op[2])
+                    dev.swap_state_buffers()
+                else:
+                    dev.solve_stage_cells(op[1], 0, op[2])
             elif op[0] == 'swe_done':
                 reqs = self._send(0, 0)               # travels while the tracers step
                 sent = True
             elif op[0] == 'tracer':
                 dev.tracer_solve_stage_cells(self.tids[op[1]], op[2], 0, op[3])
+                if fe:
+                    dev.tracer_swap_buffers(self.tids[op[1]])
             else:
                 dev.tracer_limit_cells(self.tids[op[1]], op[2])
         if sent:
