@@ -491,3 +491,52 @@ def test_conservative_tracer_source_with_wetting_drying_depth(hip_lib, cells):
     orc0 = mk(mesh, bath)
     assert rel_linf(orc0.tracer_tendency(q, uv, eta, dt, conservative=True, source=src), k_o) > 1e-6
     dev.close()
+
+
+@pytest.mark.parametrize('cells', ['quadrilaterals', 'triangles'])
+def test_full_size_coupled_tracer_properties(hip_lib, cells):
+    """BASELINE cfg 4 at bench size (1 M cells; demo_2d_tracer.py:19,91-119 scaled up): size-independent properties of the coupled
+    step with the vertex-based limiter on the device - solid-body rotation of the LeVeque field keeps the tracer integral to
+    round-off and creates no new extrema; with the shallow water equations stepping underneath, a constant tracer stays
+    constant (consistency, test_consistency_2d.py) and the volume is conserved."""
+    from thetis_amd.device import Swe2dDevice
+    from thetis_amd.mesh import RectangleMesh
+    quad = cells == 'quadrilaterals'
+    mesh = RectangleMesh(1000, 1000 if quad else 500, 1.0, 1.0, quadrilateral=quad)
+    k = mesh.cells.shape[1]
+    assert mesh.num_cells == 1000000
+    xy = mesh.cell_xy()
+    x, y = xy[:, :, 0], xy[:, :, 1]
+    bell = 0.25*(1 + np.cos(np.pi*np.minimum(np.sqrt((x - 0.25)**2 + (y - 0.5)**2)/0.15, 1.0)))
+    cone = 1.0 - np.minimum(np.sqrt((x - 0.5)**2 + (y - 0.25)**2)/0.15, 1.0)
+    cyl = np.where(np.sqrt((x - 0.5)**2 + (y - 0.75)**2) < 0.15, np.where((x > 0.475) & (x < 0.525) & (y < 0.85), 0.0, 1.0), 0.0)
+    q0 = 1.0 + bell + cone + cyl
+    dt = np.pi/300.0*40.0/1000.0
+    # (1) tracer-only mode, prescribed rotation
+    dev = Swe2dDevice(mesh, np.ones(mesh.num_vertices), dt, boundary_len=mesh.boundary_len)
+    tid = dev.add_tracer()
+    dev.set_state(np.stack([0.5 - y, x - 0.5], axis=-1), np.zeros((mesh.num_cells, k)))
+    dev.tracer_set_state(tid, q0)
+    for m in mesh.boundary_markers:                  # 'on_boundary': {'value': 1} (demo_2d_tracer.py:84): the rotation crosses the sides
+        dev.tracer_set_bc(tid, m, 1.0)
+    d0 = dev.tracer_diagnostics(tid)
+    dev.advance_coupled(20, tracer_only=True, use_limiter=True)
+    d1 = dev.tracer_diagnostics(tid)
+    assert abs(d1[1] - d0[1]) < 1e-10*abs(d0[1])                         # int T dx (div-free flow, T = 1 on and near the sides)
+    # limited once per step (coupled_timeintegrator_2d.py:102-105): the bounds hold up to the within-step over/undershoot of the
+    # cell means at the slotted cylinder's jump (40 x 40 cells: 0.99 / 2.01, tests/test_gpu_examples.py)
+    assert 0.98 < d1[2] <= d0[2] and d0[3] <= d1[3] + 1e-12 < 2.02
+    dev.close()
+    # (2) coupled with the shallow water equations: a constant tracer stays constant, the volume is conserved
+    dev = Swe2dDevice(mesh, np.ones(mesh.num_vertices), 4e-5, boundary_len=mesh.boundary_len)      # 0.12 dx / sqrt(g h)
+    tid = dev.add_tracer()
+    eta = 0.05*np.exp(-((x - 0.5)**2 + (y - 0.5)**2)/0.1**2)
+    dev.set_state(np.zeros((mesh.num_cells, k, 2)), eta)
+    dev.tracer_set_state(tid, np.full((mesh.num_cells, k), 4.5))
+    v0 = dev.diagnostics()[2]
+    dev.advance_coupled(10, tracer_only=False, use_limiter=True)
+    T = dev.tracer_get_state(tid)
+    assert np.abs(T - 4.5).max() < 1e-11
+    d = dev.diagnostics()
+    assert abs(d[2] - v0) < 1e-12*abs(v0) and d[1] > 0.0                 # volume conserved, the water moves
+    dev.close()
