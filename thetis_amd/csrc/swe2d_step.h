@@ -7,7 +7,7 @@
 // This kernel keeps the stages of a TILE of cells on the CU:
 //
 //   * a workgroup owns a tile = C consecutive cells of the device numbering (compact in space: tile-Hilbert order) plus
-//     the two rings of facet-neighbours around them (host-built slot lists: core | ring 1 | ring 2);
+//     the three rings of facet-neighbours around them (host-built slot lists: core | ring 1 | ring 2 | ring 3);
 //   * every slot's lane loads its cell's U(0) (and ring 3, which is only ever read, rides along on the first lanes) and
 //     publishes it in LDS: from here on no stage touches memory for a neighbour;
 //   * stage 1 runs on core + ring 1 + ring 2, stage 2 on core + ring 1, stage 3 on the core cells: the six neighbour traces of a
@@ -20,8 +20,8 @@
 //
 // Per cell and STEP memory sees: the step input once (72 B, the ring reads hit the L2), the tile lists (~35 B), the result once
 // (72 B) - about a third of three per-stage launches; the price is the redundant ring work ((3C + 2 r1 + r2)/(3C) = 1.3 for
-// 128-cell tiles, r1 ~ 38, r2 ~ 41 on the bench mesh; whole waves: 9 wave-stages where 6 are the minimum).  168 VGPRs, no
-// scratch = three waves per SIMD = three 256-lane workgroups per compute unit - but only because the stage loop hides its
+// 128-cell tiles, r1 ~ 38, r2 ~ 41 on the bench mesh; whole waves: 9 wave-stages where 6 are the minimum).  168 VGPRs, two of
+// them spilled = three waves per SIMD = three 256-lane workgroups per compute unit - but only because the stage loop hides its
 // invariants from the optimiser (see the asm statement there): hoisted out of the loop they cost 228 VGPRs or 51 spills.
 // Measured (MI355X, same box, us/step, three stage launches -> one step launch): 2.5 k cells 17.3 -> 14.0, 10 k 16.8 -> 14.1,
 // 31 k 18.0 -> 13.3, 62 k 20.3 -> 17.0, 90 k 24.1 -> 22.2, 125 k 24.3 -> 24.9, 250 k 38.2 -> 42.4, 1 M 117 -> 131 (256-cell tiles
@@ -36,7 +36,7 @@
 #include "swe2d_kernels.h"
 
 #ifndef SWE_STEP_OCCUPANCY
-#define SWE_STEP_OCCUPANCY __attribute__((amdgpu_waves_per_eu(3, 3)))      // 168 VGPRs, no scratch: two 384-lane workgroups per CU
+#define SWE_STEP_OCCUPANCY __attribute__((amdgpu_waves_per_eu(3, 3)))      // 168 VGPRs: three 256-lane workgroups per CU
 #endif
 #define SWE_STEP_NO_SLOT 0x3ffu
 
@@ -53,7 +53,7 @@ struct SweStepArgs {
 };
 
 // right-hand side integrals of one cell: cell integrals + interior facet fluxes (boundary facets contribute zero here).
-// xs: the tile's stage values in LDS, plane stride XS; lnb: the neighbours' slots; nf2: the neighbours' facing facets.
+// xs: the tile's stage values in LDS, plane stride XS; lnb: the neighbours' slots; meta: boundary markers | the neighbours' facing facets << 24.
 // The neighbour traverses the shared facet backwards: its node (f2 + 1) % 3 sits on my node f and its node f2 on my node
 // f + 1; a boundary facet reads this cell's own slot (finite values, flux discarded) like the stage kernel reads its own cell.
 template <bool NONLIN, bool LF, bool SRC>
