@@ -812,6 +812,10 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
             if ex == 'p2p':
                 candidates += [(ex, 2, 0, False, mode0), (ex, 4, 0, False, mode0), (ex, 4, 0, True, mode0),
                                (ex, 8, 0, False, mode0), (ex, 8, 3, True, mode0)]
+                # one graph per cycle costs a graph launch per cycle; the whole timed loop in ONE graph, or no graph at all, were
+                # both faster for a 125 k-cell rank (us/step, m = 4: cycle 30.8, none 29.7, full 29.2): let the node decide
+                if mode0 == 'cycle' and use_graph:
+                    candidates += [(ex, 4, 0, False, 'full'), (ex, 8, 0, False, 'full'), (ex, 4, 0, False, 'none')]
             elif ex == 'rccl':
                 # graphs take the per-launch CPU cost off the critical path (it matters once an RCCL enqueue sits in every
                 # cycle); when the CPU keeps up anyway eager launches are a little faster: time both

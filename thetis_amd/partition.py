@@ -181,6 +181,8 @@ def build_partition(mesh, owner, rank, halo_depth=3, adjacency='facet'):
     part.layer_sizes = [len(l) for l in ghost_layers]
     local_global = np.concatenate([interior, send_owned] + ghost_layers).astype(np.int64)
     part.local_to_global = local_global
+    if getattr(mesh, 'structured', False):       # a partition of a RectangleMesh keeps the parent's tile numbering on the device
+        part.structured_parent = (int(mesh.nx), int(mesh.ny))
     part.n_interior = len(interior)
     part.n_owned = len(mine)
     # owned_dist_ge[d] = number of owned cells at distance >= d from the non-owned cells (a prefix), d = 0 .. halo_depth + 1
