@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SWE2D_ABI_VERSION 6
+#define SWE2D_ABI_VERSION 7
 #define SWE2D_MAX_MARKERS 16          /* boundary markers must be in 1..SWE2D_MAX_MARKERS-1 */
 
 typedef enum {
@@ -330,6 +330,20 @@ int  swe2d_solve_step_cells(swe2d_handle *h, int32_t cell_begin, int32_t cell_en
  * which a stream capture does not allow */
 int  swe2d_prepare_step_cells(swe2d_handle *h, int32_t cell_begin, int32_t cell_end);
 int  swe2d_fused_step_supported(swe2d_handle *h);
+/* n_stages (a multiple of 3, at most 48) consecutive solve_stage calls - i.e. n_stages / 3 calls of ERKGenericShuOsher.advance
+ * (rungekutta.py:949-952) - in ONE launch without a grid-wide barrier between the stages (csrc/swe2d_flow.h): stage s updates
+ * the cells [0, cell_end[s]) (cell_end non-increasing: the shrinking ranges of a partition's exchange cycle, or n_owned
+ * throughout), a 64-cell block starts stage s + 1 as soon as the blocks its facets touch have finished stage s.  Bit for bit
+ * the result of the swe2d_solve_stage_cells calls it stands for.  Needs every block of the handle resident at once:
+ * swe2d_flow_supported returns 0 when the mesh is too large for that (or the configuration is not covered: quadrilaterals,
+ * wetting-drying, viscosity), 1 covered, 2 covered and without source terms; SWE2D_ERR_UNSUPPORTED from swe2d_solve_flow
+ * otherwise.  Every wait inside the kernel is bounded (THETIS_AMD_FLOW_TIMEOUT_S, default 2 s); a timeout invalidates the
+ * state and is reported as SWE2D_ERR_HIP by the next swe2d_synchronize / swe2d_get_state / swe2d_diagnostics
+ * (swe2d_flow_status reads the count without failing). */
+int  swe2d_solve_flow(swe2d_handle *h, int32_t n_stages, const int32_t *cell_end);
+int  swe2d_flow_supported(swe2d_handle *h);
+int  swe2d_flow_status(swe2d_handle *h, int32_t *timeouts);
+int  swe2d_debug_flow_poke(swe2d_handle *h, int32_t block, int32_t delta);      /* test hook: skews one block's stage counter */
 /* run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the handle's own */
 int  swe2d_set_stream(swe2d_handle *h, void *hip_stream);
 

@@ -1,0 +1,166 @@
+"""GPU: the dataflow stage loop (csrc/swe2d_flow.h: many stages in one launch, blocks wait for their neighbours' stage
+counters instead of a kernel boundary) gives the bits of the stage launches it stands for."""
+import numpy as np
+import pytest
+
+from helpers import channel_case, delaunay_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _device(mesh, bath, dt, **kw):
+    from thetis_amd.device import Swe2dDevice
+    return Swe2dDevice(mesh, bath, dt, boundary_len=mesh.boundary_len, **kw)
+
+
+def _by_stage(dev, ends):
+    for s, end in enumerate(ends):
+        dev.solve_stage_cells(s % 3, 0, end)
+
+
+def _configure(dev, mesh, case):
+    from thetis_amd import _lib
+    k = mesh.cells.shape[1]
+    cxy = mesh.cell_xy()
+    if case in ('channel_open', 'sources', 'sources_large'):
+        m = mesh.boundary_markers
+        dev.set_bc(m[0], {'elev': 0.2*np.sin(cxy[:, :, 1]/3e3)})
+        dev.set_bc(m[-1], {'un': 0.05, 'drag': 0.01})
+        if len(m) > 2:
+            dev.set_bc(m[1], {'flux': 30.0})
+    if case in ('sources', 'sources_large'):
+        dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+        dev.set_field(_lib.FIELD_CORIOLIS, 1e-4*np.ones((mesh.num_cells, k)))
+        dev.set_field(_lib.FIELD_WIND_STRESS, 0.1*np.ones((mesh.num_cells, k, 2)))
+
+
+@pytest.mark.parametrize('case', ['channel', 'channel_open', 'unstructured', 'linear', 'no_lf', 'sources', 'sources_large',
+                                  'large', 'periodic', 'tiny'])
+def test_flow_launch_gives_the_bits_of_the_stage_launches(hip_lib, case):
+    if case == 'unstructured':
+        mesh, bath, uv, eta = delaunay_case(n_points=3000, seed=5)[:4]
+    elif case == 'periodic':
+        from thetis_amd.mesh import PeriodicRectangleMesh
+        mesh = PeriodicRectangleMesh(61, 29, 100e3, 30e3, direction='x')
+        rng = np.random.default_rng(17)
+        bath = 20.0 + 2.0*np.sin(mesh.vertex_xy[:, 1]/5000.0)
+        uv, eta = 0.5*rng.normal(size=(mesh.num_cells, 3, 2)), 0.5*rng.normal(size=(mesh.num_cells, 3))
+    else:
+        nx, ny = {'sources_large': (250, 125), 'large': (300, 250), 'tiny': (3, 2)}.get(case, (67, 31))
+        mesh, bath, uv, eta = channel_case(nx=nx, ny=ny, seed=11)
+    kw = {}
+    if case == 'linear':
+        kw['use_nonlinear_equations'] = False
+    if case == 'no_lf':
+        kw['use_lax_friedrichs_velocity'] = False
+    out = []
+    n_steps = 5
+    for flow in (False, True):
+        dev = _device(mesh, bath, 0.05 if case != 'unstructured' else 0.02, **kw)
+        _configure(dev, mesh, case)
+        assert dev.flow_supported() == (1 if case.startswith('sources') else 2)
+        dev.set_state(uv, eta)
+        ends = [dev.n_cells]*(3*n_steps)
+        if flow:
+            dev.solve_flow(ends[:6])            # two launches: the stage counters carry over
+            dev.solve_flow(ends[6:])
+        else:
+            _by_stage(dev, ends)
+        out.append(dev.get_state())
+        assert dev.flow_timeouts() == 0
+        dev.close()
+    assert np.isfinite(out[0][0]).all() and np.abs(out[0][0]).max() > 0
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize('shape', ['shrinking', 'ragged'])
+def test_flow_launch_on_shrinking_ranges(hip_lib, shape):
+    """The ranges of a partition's exchange cycle: stage s updates [0, end_s), ends non-increasing and not block-aligned;
+    blocks retire when the ranges have passed them, partially covered blocks keep their outer lanes' values."""
+    mesh, bath, uv, eta = channel_case(nx=120, ny=60, seed=4)
+    n = mesh.num_cells
+    if shape == 'shrinking':
+        ends = [n - 37*s for s in range(12)]
+    else:
+        ends = [n, n, n - 1, n - 65, n - 65, n//2 + 3, n//2 + 3, n//2 + 3, 130, 64, 63, 1]
+    out = []
+    for flow in (False, True):
+        dev = _device(mesh, bath, 0.05, reorder=None)
+        dev.set_state(uv, eta)
+        if flow:
+            dev.solve_flow(ends)
+        else:
+            _by_stage(dev, ends)
+        # all three buffers: a stage's range ends in the middle of the cells the next one reads
+        out.append([dev.get_state(i) for i in range(3)])
+        assert dev.flow_timeouts() == 0
+        dev.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_advance_takes_the_flow_path_and_matches_the_stage_by_stage_path(hip_lib, monkeypatch):
+    mesh, bath, uv, eta = channel_case(nx=41, ny=23, seed=3)
+    res = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('THETIS_AMD_FLOW', flag)
+        monkeypatch.setenv('THETIS_AMD_FUSED_STEP', '0')
+        dev = _device(mesh, bath, 0.05)
+        dev.set_state(uv, eta)
+        dev.advance(37)             # three launches of at most 16 steps
+        res.append(dev.get_state() + (dev.diagnostics(),))
+        dev.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+def test_flow_is_refused_where_it_does_not_apply(hip_lib, monkeypatch):
+    from thetis_amd._lib import Swe2dError
+    mesh, bath, uv, eta = channel_case(nx=9, ny=5, seed=1)
+    dev = _device(mesh, bath - 0.6*bath.max(), 0.05)
+    dev.set_wetting_and_drying(0.5)
+    assert not dev.flow_supported()
+    with pytest.raises(Swe2dError):
+        dev.solve_flow([dev.n_cells]*3)
+    dev.close()
+    dev = _device(mesh, bath, 0.05)
+    for bad in ([dev.n_cells]*4, [10, 20, 20], [dev.n_cells + 1]*3, []):
+        with pytest.raises(Swe2dError):
+            dev.solve_flow(bad)
+    dev.close()
+    # more blocks than the device holds resident at once: refused, not deadlocked
+    monkeypatch.setenv('THETIS_AMD_FLOW_CAPACITY', '16')
+    mesh, bath, uv, eta = channel_case(nx=40, ny=20, seed=1)        # 1600 cells = 25 blocks
+    dev = _device(mesh, bath, 0.05)
+    assert dev.flow_supported() == 0
+    with pytest.raises(Swe2dError):
+        dev.solve_flow([dev.n_cells]*3)
+    dev.close()
+
+
+def test_a_block_that_never_arrives_costs_a_bounded_wait_and_is_reported(hip_lib, monkeypatch):
+    """Residency cannot be broken on purpose from here, so the flags are: a launch whose stage counters start out of step
+    (one block's counter is behind: its neighbours wait for a stage it believes it has already published) ends after the
+    bounded wait, and the next synchronisation point reports it."""
+    import ctypes
+    from thetis_amd._lib import Swe2dError
+    monkeypatch.setenv('THETIS_AMD_FLOW_TIMEOUT_S', '0.05')
+    mesh, bath, uv, eta = channel_case(nx=40, ny=20, seed=1)
+    dev = _device(mesh, bath, 0.05)
+    dev.set_state(uv, eta)
+    dev.solve_flow([dev.n_cells]*3)
+    dev.synchronize()
+    assert dev.lib.swe2d_debug_flow_poke(dev.h, 3, 1000) == 0        # block 3 starts the next launch 1000 stages "ahead"
+    dev.solve_flow([dev.n_cells]*3)
+    assert dev.flow_timeouts() > 0
+    with pytest.raises(Swe2dError, match='timed out'):
+        dev.synchronize()
+    # the handle is usable again
+    dev.set_state(uv, eta)
+    dev.solve_flow([dev.n_cells]*3)
+    dev.synchronize()
+    a = dev.get_state()
+    dev.set_state(uv, eta)
+    _by_stage(dev, [dev.n_cells]*3)
+    b = dev.get_state()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    dev.close()

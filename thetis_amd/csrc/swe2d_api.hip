@@ -4,6 +4,7 @@
 #include "swe2d_kernels.h"
 #include "swe2d_sipg.h"
 #include "swe2d_step.h"
+#include "swe2d_flow.h"
 #include "swe2d_p2p.h"
 
 #include <dlfcn.h>
@@ -115,6 +116,12 @@ struct Handle {
     struct StepTiles { int c0 = 0, c1 = 0, B = 0, n_tiles = 0; int4 *slot = nullptr; int2 *vert = nullptr; int4 *n = nullptr; };
     std::vector<StepTiles> step_tiles;
     int step_tile_cells = 128, step_block = 256;        // THETIS_AMD_STEP_TILE=C,B (B = 256 or 384: the instantiated workgroup sizes)
+    // dataflow stage loop (swe2d_flow.h): per-block stage counters, status word {timeouts, first late block + 1}
+    unsigned *flow_flag = nullptr, *flow_status = nullptr;
+    int flow_blocks = 0;                                // 64-cell blocks of the handle
+    int flow_capacity = -1;                             // resident one-wave workgroups of the flow kernel on this device (-1: not asked yet)
+    bool flow_used = false;                             // a flow launch since the status word was last read
+    double flow_timeout_s = 2.0;                        // THETIS_AMD_FLOW_TIMEOUT_S
     double *vx = nullptr, *vy = nullptr, *vh = nullptr;
     double *bc_field[4] = {nullptr, nullptr, nullptr, nullptr};  // Function-valued boundary data per facet: elev, uv, un, flux
     double *valpha = nullptr;                          // per-vertex wetting-drying alpha
@@ -534,6 +541,87 @@ int launch_step(Handle *h, int c0, int c1)
     return SWE2D_OK;
 }
 
+// ---- dataflow stage loop (swe2d_flow.h)
+typedef void (*flow_kernel_t)(const SweFlowArgs);
+template <bool NL, bool LF>
+flow_kernel_t pick_flow_src(bool src) { return src ? swe_flow_kernel<NL, LF, true> : swe_flow_kernel<NL, LF, false>; }
+flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src)
+{
+    return nl ? (lf ? pick_flow_src<true, true>(src) : pick_flow_src<true, false>(src))
+              : (lf ? pick_flow_src<false, true>(src) : pick_flow_src<false, false>(src));
+}
+
+// the configurations the flow kernel covers (the step kernel's: triangles, no wetting-drying, no viscosity)
+bool flow_kernel_covers(const Handle *h)
+{
+    const char *e = std::getenv("THETIS_AMD_BND_INLINE");
+    return h->npc == 3 && !h->wd && !h->visc && h->idx4 && h->flow_flag && !(e && std::atoi(e) == 0);
+}
+
+// Resident one-wave workgroups of the flow kernel: every block of a launch must be resident (a block waits for its
+// neighbours' flags), so the grid must not exceed what the device holds at once.
+int flow_capacity(Handle *h)
+{
+    if (h->flow_capacity >= 0) return h->flow_capacity;
+    h->flow_capacity = 0;
+    int per_cu = 0, dev_cus = 0;
+    flow_kernel_t kern = pick_flow_kernel(true, true, true);           // the largest variant
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), SWE_BLOCK, 0) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) return 0;
+    per_cu = std::min(per_cu, 12);                                      // amdgpu_waves_per_eu(3, 3): three waves on each of the four SIMDs
+    if (const char *e = std::getenv("THETIS_AMD_FLOW_CAPACITY")) h->flow_capacity = std::atoi(e);      // tests: force the limit
+    else h->flow_capacity = per_cu*dev_cus;
+    return h->flow_capacity;
+}
+
+// n_stages stages (a multiple of 3) on the ranges [0, cell_end[s]) in ONE launch
+int launch_flow(Handle *h, int n_stages, const int32_t *cell_end)
+{
+    if (!flow_kernel_covers(h)) return fail(h, SWE2D_ERR_UNSUPPORTED, "the flow kernel covers triangles without wetting-drying and viscosity");
+    if (n_stages <= 0 || n_stages % 3 != 0 || n_stages > SWE_FLOW_MAX_STAGES)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "flow: n_stages must be a multiple of 3 in 3..48");
+    for (int s = 0; s < n_stages; s++)
+        if (cell_end[s] < 0 || cell_end[s] > h->n_cells || (s > 0 && cell_end[s] > cell_end[s - 1]))
+            return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "flow: the stage ranges must shrink and stay inside the mesh");
+    const int grid = ((h->flow_blocks + 7)/8)*8;
+    if (grid > flow_capacity(h)) return fail(h, SWE2D_ERR_UNSUPPORTED, "flow: more 64-cell blocks than the device holds resident at once");
+    SweFlowArgs q;
+    fill_stage_args(h, q.st, 0, 0, 1, 0.0, 1.0, 1.0, 0, 0);
+    for (int i = 0; i < 3; i++) q.buf[i] = h->state[i];
+    q.flag = h->flow_flag; q.status = h->flow_status;
+    q.n_blocks = h->flow_blocks; q.n_stages = n_stages;
+    for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) q.cell_end[s] = s < n_stages ? cell_end[s] : 0;
+    for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
+    q.timeout_ticks = (unsigned long long)(h->flow_timeout_s*1e8);
+    flow_kernel_t kern = pick_flow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h));
+    SWE_CHK_SYNC(h->stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, q);
+    HIP_TRY(h, hipGetLastError());
+    h->flow_used = true;
+    return SWE2D_OK;
+}
+
+// after a synchronisation of the stream: did a wave of a flow launch give up waiting?  (then the state is wrong)
+int flow_check(Handle *h)
+{
+    if (!h->flow_used || !h->flow_status) return SWE2D_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (h->stream && hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return SWE2D_OK;
+    unsigned st[2] = {0u, 0u};
+    HIP_TRY(h, hipMemcpyAsync(st, h->flow_status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->flow_used = false;
+    if (st[0] == 0u) return SWE2D_OK;
+    // leave the handle usable: counters and flags back to a consistent start
+    (void)hipMemsetAsync(h->flow_status, 0, 2*sizeof(unsigned), h->stream);
+    (void)hipMemsetAsync(h->flow_flag, 0, (size_t)2*h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned), h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    char msg[200];
+    std::snprintf(msg, sizeof(msg), "flow kernel: %u block waits timed out (first: block %u) - blocks not resident together? The state is invalid",
+                  st[0], st[1] - 1u);
+    return fail(h, SWE2D_ERR_HIP, msg);
+}
+
 }  // namespace
 
 extern "C" {
@@ -735,6 +823,14 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
             HIP_TRY_C(hipMemcpy(h->bnd_cells, bnd.data(), bnd.size()*sizeof(int), hipMemcpyHostToDevice));
         }
         h->fuse_visc = std::getenv("THETIS_AMD_NO_VISC_FUSION") == nullptr;
+        // dataflow stage loop: one stage counter per 64-cell block (64 B apart: a flag is polled by the blocks around it and
+        // rewritten every stage) and the status word
+        h->flow_blocks = (n + SWE_BLOCK - 1)/SWE_BLOCK;
+        HIP_TRY_C(hipMalloc(&h->flow_flag, (size_t)2*h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned)));
+        HIP_TRY_C(hipMalloc(&h->flow_status, 2*sizeof(unsigned)));
+        HIP_TRY_C(hipMemset(h->flow_flag, 0, (size_t)2*h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned)));
+        HIP_TRY_C(hipMemset(h->flow_status, 0, 2*sizeof(unsigned)));
+        if (const char *e = std::getenv("THETIS_AMD_FLOW_TIMEOUT_S")) { const double t = std::atof(e); if (t > 0.0) h->flow_timeout_s = t; }
     }
     HIP_TRY_C(hipMemcpyAsync(h->nbr, nbr.data(), (size_t)npc*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY_C(hipMemcpyAsync(h->cv, cv.data(), (size_t)npc*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -764,7 +860,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
     for (void *m : h->p2p.opened) (void)hipIpcCloseMemHandle(m);
@@ -826,7 +922,7 @@ int swe2d_get_stage_state(swe2d_handle *hh, int i_stage, double *uv, double *eta
     HIP_TRY(h, hipMemcpyAsync(uv, h->stage_uv, 2*n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(eta, h->stage_eta, n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return SWE2D_OK;
+    return flow_check(h);
 }
 
 int swe2d_set_dt(swe2d_handle *hh, double dt)
@@ -1121,6 +1217,23 @@ int swe2d_advance(swe2d_handle *hh, int n_steps)
     // launches -> one step launch (128-cell tiles): 2.5 k cells 17.3 -> 14.0, 10 k 16.8 -> 14.1, 31 k 18.0 -> 13.3, 62 k 20.3 ->
     // 17.0, 90 k 24.1 -> 22.2, 125 k 24.4 -> 25.5, 1 M 124 -> 135: beyond ~100 k cells throughput counts, and the redundant ring
     // work of the tiles costs more FP64 issue time than the launches and the HBM traffic it saves are worth.  THETIS_AMD_FUSED_STEP=0 / 1 forces the choice (both give the same bits).
+    // Many steps in one launch without grid barriers (swe2d_flow.h) where every 64-cell block of the mesh is resident at once.
+    // THETIS_AMD_FLOW=0 / 1 forces the choice (the same bits either way).
+    {
+        const char *env_fl = std::getenv("THETIS_AMD_FLOW");
+        const bool want = env_fl ? std::atoi(env_fl) != 0 : false;
+        if (want && n_steps > 0 && flow_kernel_covers(h) && ((h->flow_blocks + 7)/8)*8 <= flow_capacity(h)) {
+            int32_t ends[SWE_FLOW_MAX_STAGES];
+            for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) ends[s] = h->n_owned;
+            for (int done = 0; done < n_steps;) {
+                const int m = std::min(n_steps - done, SWE_FLOW_MAX_STAGES/3);
+                int rc = launch_flow(h, 3*m, ends);
+                if (rc) return rc;
+                done += m;
+            }
+            return SWE2D_OK;
+        }
+    }
     const char *env_fs = std::getenv("THETIS_AMD_FUSED_STEP");
     const bool fused = env_fs ? std::atoi(env_fs) != 0 : (h->n_owned <= 80000 && !has_sources(h));
     if (fused && step_kernel_covers(h)) {
@@ -1164,6 +1277,51 @@ int swe2d_fused_step_supported(swe2d_handle *hh)
     Handle *h = H(hh);
     if (!h || !step_kernel_covers(h)) return 0;
     return has_sources(h) ? 1 : 2;          // 2: covered and without source terms (where it is the faster path on small meshes)
+}
+
+int swe2d_solve_flow(swe2d_handle *hh, int32_t n_stages, const int32_t *cell_end)
+{
+    Handle *h = H(hh);
+    if (!h || !cell_end) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    RoctxRange range("swe2d_solve_flow");
+    return launch_flow(h, n_stages, cell_end);
+}
+
+int swe2d_flow_supported(swe2d_handle *hh)
+{
+    Handle *h = H(hh);
+    if (!h || !flow_kernel_covers(h)) return 0;
+    if (hipSetDevice(h->device) != hipSuccess) return 0;
+    return ((h->flow_blocks + 7)/8)*8 <= flow_capacity(h) ? (has_sources(h) ? 1 : 2) : 0;
+}
+
+int swe2d_flow_status(swe2d_handle *hh, int32_t *timeouts)
+{
+    Handle *h = H(hh);
+    if (!h || !timeouts) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    *timeouts = 0;
+    if (!h->flow_status) return SWE2D_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    unsigned st[2] = {0u, 0u};
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(st, h->flow_status, sizeof(st), hipMemcpyDeviceToHost));
+    *timeouts = (int32_t)st[0];
+    return SWE2D_OK;
+}
+
+// test hook: adds `delta` to the stage counter of one block (tests/test_gpu_flow_kernel.py: a block whose neighbours wait for it)
+int swe2d_debug_flow_poke(swe2d_handle *hh, int32_t block, int32_t delta)
+{
+    Handle *h = H(hh);
+    if (!h || !h->flow_flag || block < 0 || block >= h->flow_blocks) return SWE2D_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    unsigned v = 0;
+    HIP_TRY(h, hipMemcpy(&v, h->flow_flag + (size_t)block*SWE_FLOW_FLAG_STRIDE, sizeof(v), hipMemcpyDeviceToHost));
+    v += (unsigned)delta;
+    HIP_TRY(h, hipMemcpy(h->flow_flag + (size_t)block*SWE_FLOW_FLAG_STRIDE, &v, sizeof(v), hipMemcpyHostToDevice));
+    return SWE2D_OK;
 }
 
 int swe2d_advance_forward_euler(swe2d_handle *hh, int n_steps)
@@ -1250,7 +1408,7 @@ int swe2d_synchronize(swe2d_handle *hh)
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return SWE2D_OK;
+    return flow_check(h);
 }
 
 int swe2d_tendency(swe2d_handle *hh, double *k_uv, double *k_eta)
@@ -1297,6 +1455,7 @@ int swe2d_diagnostics(swe2d_handle *hh, double out[4])
         out[2] += part[4*(size_t)b + 2];
         out[3] = std::fmin(out[3], part[4*(size_t)b + 3]);
     }
+    if (int rc = flow_check(h)) return rc;
     if (!std::isfinite(out[0]) || !std::isfinite(out[1]) || !std::isfinite(out[2]))
         return fail(h, SWE2D_ERR_NOT_FINITE, "state is not finite");
     return SWE2D_OK;

@@ -399,6 +399,22 @@ class Swe2dDevice(object):
         """Build the tile lists of a range ahead of its first ``solve_step_cells`` (which must not allocate inside a capture)."""
         self._ck(self.lib.swe2d_prepare_step_cells(self.h, int(cell_begin), int(cell_end)))
 
+    def solve_flow(self, cell_ends):
+        """``len(cell_ends)`` (a multiple of 3) consecutive stages in ONE launch without grid-wide barriers (csrc/swe2d_flow.h):
+        stage s updates the device cells [0, cell_ends[s]); bit for bit the ``solve_stage_cells`` calls it stands for."""
+        ends = np.ascontiguousarray(cell_ends, dtype=np.int32)
+        self._ck(self.lib.swe2d_solve_flow(self.h, int(len(ends)), _iptr(ends)))
+
+    def flow_supported(self):
+        """0: the flow kernel does not cover this handle (configuration, or more 64-cell blocks than the device holds
+        resident); 1: covered; 2: covered and without source terms."""
+        return int(self.lib.swe2d_flow_supported(self.h))
+
+    def flow_timeouts(self):
+        n = ctypes.c_int32()
+        self._ck(self.lib.swe2d_flow_status(self.h, ctypes.byref(n)))
+        return n.value
+
     def fused_step_supported(self):
         """True where the one-launch step kernel covers the current configuration (triangles, no wetting-drying, no viscosity)."""
         return bool(self.lib.swe2d_fused_step_supported(self.h))

@@ -178,7 +178,7 @@ class DistributedSwe2d(object):
     def __init__(self, mesh, bathymetry_vertex, dt, rank, world_size, device_id, owner=None, host_staged=False,
                  n_tracers=0, use_limiter=True, tracer_only=False, exchange_every=1, overlap_stages=0,
                  graph_mode=None, stepper='SSPRK33', exchange=None, split_last_stage=True, group=None, partition=None,
-                 combined_exchange=False, fused_step=None, **opts):
+                 combined_exchange=False, fused_step=None, flow=None, **opts):
         """``n_tracers`` > 0: the coupled step of GeneralCoupledTimeIntegrator2D.advance (coupled_timeintegrator_2d.py:
         93-113) on the partition - shallow water step, then every tracer with the updated velocity, then the limiter.
         The vertex-based limiter needs every cell around a vertex, so coupled runs with the limiter use four ghost layers
@@ -212,6 +212,11 @@ class DistributedSwe2d(object):
         kernel covers the configuration, False = never.  A cycle is then m step launches on shrinking ranges; the step
         result lands in the other state buffer, so the buffers are swapped on the host after every step (a replayed graph
         re-applies the swaps it stands for).
+
+        ``flow``: the 3m stages of a cycle as ONE launch without grid-wide barriers (csrc/swe2d_flow.h: a 64-cell block starts
+        its next stage as soon as the blocks around it have finished the previous one; bit for bit the stage launches),
+        followed by the exchange: None = where the kernel covers the partition (every block resident at once; shallow water
+        only, triangles without wetting-drying / viscosity, no ``overlap_stages``), True = required, False = never.
 
         ``exchange``: 'p2p' | 'rccl' | 'host' (module docstring); default 'host' if ``host_staged`` else 'rccl'.
         ``partition``: a LocalPartition already built for this rank with the halo depth the other arguments imply.
@@ -267,6 +272,7 @@ class DistributedSwe2d(object):
                                n_owned=p.n_owned, boundary_len=p.boundary_len, ranges=p.reorder_ranges(), **opts)
         self.dev.halo_setup(p.send_cells, p.recv_cells)
         self._fused_request = fused_step
+        self._flow_request = flow
         self._flip = 0                       # parity of the state-buffer swaps (fused steps): graphs hold absolute pointers
         self._ranges = [p.stage_range(i) for i in range(3)]
         self.tids = [self.dev.add_tracer() for _ in range(n_tracers)]
@@ -314,6 +320,37 @@ class DistributedSwe2d(object):
         # inside replayed graphs the stage launches have no host gaps and the step kernel loses its advantage (measured per
         # rank, p2p, m = 4: 62 k cells 24.9 us/step stage-wise vs 26.6 fused, 31 k 20.1 vs 20.1): eager launches only
         return self.graph_mode == 'none' and self.part.n_owned <= 80000 and self.dev.fused_step_preferred()
+
+    @property
+    def flow(self):
+        """True when a cycle runs as one dataflow launch (see ``flow``); evaluated per call like ``fused``."""
+        if self._flow_request is False or os.environ.get('THETIS_AMD_FLOW') == '0':
+            return False
+        plain = (self.stages_per_step == 3 and not self.tids and not self.tracer_only and self.overlap_stages == 0
+                 and 3*self.exchange_every <= 48)
+        if not plain or not self.dev.flow_supported():
+            if self._flow_request is True:
+                raise ValueError('flow=True: the flow kernel covers SSPRK33 shallow-water-only runs on triangles without wetting-drying, '
+                                 'viscosity and overlap_stages, on partitions whose 64-cell blocks are all resident at once')
+            return False
+        return True
+
+    def _cycle_swe_flow(self, n_steps, graphed):
+        """``n_steps`` time steps = 3 n_steps stages on the shrinking ranges in ONE launch, then the exchange."""
+        dev, p = self.dev, self.part
+        n = 3*n_steps
+        ends = [p.stage_range(g, depth=n) for g in range(n)]
+        if self.p2p is not None:
+            def whole_cycle():
+                dev.solve_flow(ends)
+                dev.p2p_push(0, 0)
+                dev.p2p_wait_unpack(0, 0)
+            return self._launch(('W', n_steps), whole_cycle, graphed)
+        self._launch(('WA', n_steps), lambda: dev.solve_flow(ends), graphed)
+        dev.halo_pack(0, self.halo.send_buf.data_ptr())
+        reqs = self.halo.start()
+        self.halo.finish(reqs)
+        dev.halo_unpack(0, self.halo.recv_buf.data_ptr())
 
     def _swap(self):
         self.dev.swap_state_buffers()
@@ -446,6 +483,8 @@ class DistributedSwe2d(object):
         ``early_next``: stages of the next cycle to run (ghost-independent part only) during this cycle's exchange."""
         if self.stages_per_step == 1:
             return self._cycle_forward_euler(n_steps)
+        if self.flow and not self._fused_request:
+            return self._cycle_swe_flow(n_steps, graphed)
         if self.fused:
             return self._cycle_swe_fused(n_steps, graphed)
         if self.p2p is not None:

@@ -1,0 +1,17 @@
+#!/bin/bash
+O=gpurun_out/r03c; mkdir -p $O
+for v in flow_wt flow_local_wt; do
+  for nx in 125 354; do
+    echo "== $v nx=$nx" >> $O/timing.log
+    THETIS_AMD_LIB=$PWD/variants/$v.so timeout 300 python tools/flowtiming.py --nx $nx --ny $((nx/2)) > $O/t.json 2> $O/t.err
+    python - >> $O/timing.log <<PY
+import json
+try:
+    d = json.load(open('$O/t.json'))
+    for r in d['runs'][1:4]: print(json.dumps(r))
+except Exception as e:
+    print('failed', e); print(open('$O/t.err').read()[-2000:]); print(open('$O/t.json').read()[:500])
+PY
+  done
+done
+cat $O/timing.log
