@@ -46,7 +46,7 @@ def test_flow_launch_gives_the_bits_of_the_stage_launches(hip_lib, case):
         bath = 20.0 + 2.0*np.sin(mesh.vertex_xy[:, 1]/5000.0)
         uv, eta = 0.5*rng.normal(size=(mesh.num_cells, 3, 2)), 0.5*rng.normal(size=(mesh.num_cells, 3))
     else:
-        nx, ny = {'sources_large': (250, 125), 'large': (300, 250), 'tiny': (3, 2)}.get(case, (67, 31))
+        nx, ny = {'sources_large': (250, 125), 'large': (300, 200), 'tiny': (3, 2)}.get(case, (67, 31))
         mesh, bath, uv, eta = channel_case(nx=nx, ny=ny, seed=11)
     kw = {}
     if case == 'linear':
@@ -75,14 +75,17 @@ def test_flow_launch_gives_the_bits_of_the_stage_launches(hip_lib, case):
 
 @pytest.mark.parametrize('shape', ['shrinking', 'ragged'])
 def test_flow_launch_on_shrinking_ranges(hip_lib, shape):
-    """The ranges of a partition's exchange cycle: stage s updates [0, end_s), ends non-increasing and not block-aligned;
-    blocks retire when the ranges have passed them, partially covered blocks keep their outer lanes' values."""
-    mesh, bath, uv, eta = channel_case(nx=120, ny=60, seed=4)
-    n = mesh.num_cells
+    """The ranges of an exchange cycle: stage s updates [0, end_s), ends non-increasing and not block-aligned, every cell of a
+    stage's range has its neighbours inside the previous stage's range (natural numbering: a cell's neighbours lie within one
+    mesh row of 2 nx cells, so ranges that lose at least a row per stage qualify).  Blocks retire when the ranges have passed
+    them, partially covered blocks keep their outer lanes' values; state buffer 0 ends as the stage launches leave it."""
+    nx = 120
+    mesh, bath, uv, eta = channel_case(nx=nx, ny=60, seed=4)
+    n, row = mesh.num_cells, 2*nx
     if shape == 'shrinking':
-        ends = [n - 37*s for s in range(12)]
+        ends = [n - row*s for s in range(12)]
     else:
-        ends = [n, n, n - 1, n - 65, n - 65, n//2 + 3, n//2 + 3, n//2 + 3, 130, 64, 63, 1]
+        ends = [n, n, n, n - row, n - 2*row, n - 10*row, n - 11*row, n - 12*row, 30*row, 29*row, 5*row, 4*row]
     out = []
     for flow in (False, True):
         dev = _device(mesh, bath, 0.05, reorder=None)
@@ -91,12 +94,34 @@ def test_flow_launch_on_shrinking_ranges(hip_lib, shape):
             dev.solve_flow(ends)
         else:
             _by_stage(dev, ends)
-        # all three buffers: a stage's range ends in the middle of the cells the next one reads
-        out.append([dev.get_state(i) for i in range(3)])
+        out.append(dev.get_state())
         assert dev.flow_timeouts() == 0
         dev.close()
-    for a, b in zip(out[0], out[1]):
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_flow_launch_on_the_ranges_of_a_partition(hip_lib):
+    """One rank's cells of a strip partition with a six-layer halo (two time steps between exchanges): owned cells in the
+    device's tile order, ghost layers appended, the stage ranges of partition.py."""
+    from thetis_amd.device import Swe2dDevice
+    from thetis_amd.partition import build_partition, strip_owner
+    mesh, bath, uv, eta = channel_case(nx=160, ny=48, seed=9)
+    part = build_partition(mesh, strip_owner(mesh, 4), 1, halo_depth=6)
+    g = part.local_to_global
+    ends = [part.stage_range(s, depth=6) for s in range(6)]
+    out = []
+    for flow in (False, True):
+        dev = Swe2dDevice(part, np.asarray(bath)[part.vertex_global], 0.05, n_owned=part.n_owned, boundary_len=part.boundary_len,
+                          ranges=part.reorder_ranges())
+        dev.set_state(uv[g], eta[g])
+        if flow:
+            dev.solve_flow(ends)
+        else:
+            _by_stage(dev, ends)
+        out.append(dev.get_state())
+        assert dev.flow_timeouts() == 0
+        dev.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
 def test_advance_takes_the_flow_path_and_matches_the_stage_by_stage_path(hip_lib, monkeypatch):

@@ -118,6 +118,13 @@ struct Handle {
     int step_tile_cells = 128, step_block = 256;        // THETIS_AMD_STEP_TILE=C,B (B = 256 or 384: the instantiated workgroup sizes)
     // dataflow stage loop (swe2d_flow.h): per-block stage counters, status word {timeouts, first late block + 1}
     unsigned *flow_flag = nullptr, *flow_status = nullptr;
+    int4 *flow_xo4 = nullptr;                           // exchange slots of the rim facets (facets between two 64-cell blocks), see SweFlowArgs
+    int2 *flow_xo2 = nullptr;
+    int2 *flow_xblk = nullptr;
+    int *flow_xsrc = nullptr;
+    unsigned flow_parity_bytes = 0;
+    void *flow_ex = nullptr;
+    size_t flow_ex_bytes = 0;
     int flow_blocks = 0;                                // 64-cell blocks of the handle
     int flow_capacity = -1;                             // resident one-wave workgroups of the flow kernel on this device (-1: not asked yet)
     bool flow_used = false;                             // a flow launch since the status word was last read
@@ -555,7 +562,7 @@ flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src)
 bool flow_kernel_covers(const Handle *h)
 {
     const char *e = std::getenv("THETIS_AMD_BND_INLINE");
-    return h->npc == 3 && !h->wd && !h->visc && h->idx4 && h->flow_flag && !(e && std::atoi(e) == 0);
+    return h->npc == 3 && !h->wd && !h->visc && h->idx4 && h->flow_flag && h->flow_ex && !(e && std::atoi(e) == 0);
 }
 
 // Resident one-wave workgroups of the flow kernel: every block of a launch must be resident (a block waits for its
@@ -568,7 +575,6 @@ int flow_capacity(Handle *h)
     flow_kernel_t kern = pick_flow_kernel(true, true, true);           // the largest variant
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), SWE_BLOCK, 0) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) return 0;
-    per_cu = std::min(per_cu, 12);                                      // amdgpu_waves_per_eu(3, 3): three waves on each of the four SIMDs
     if (const char *e = std::getenv("THETIS_AMD_FLOW_CAPACITY")) h->flow_capacity = std::atoi(e);      // tests: force the limit
     else h->flow_capacity = per_cu*dev_cus;
     return h->flow_capacity;
@@ -589,6 +595,8 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end)
     fill_stage_args(h, q.st, 0, 0, 1, 0.0, 1.0, 1.0, 0, 0);
     for (int i = 0; i < 3; i++) q.buf[i] = h->state[i];
     q.flag = h->flow_flag; q.status = h->flow_status;
+    q.xo4 = h->flow_xo4; q.xo2 = h->flow_xo2; q.ex = h->flow_ex;
+    q.xblk = h->flow_xblk; q.xsrc = h->flow_xsrc; q.parity_bytes = h->flow_parity_bytes;
     q.n_blocks = h->flow_blocks; q.n_stages = n_stages;
     for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) q.cell_end[s] = s < n_stages ? cell_end[s] : 0;
     for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
@@ -614,7 +622,8 @@ int flow_check(Handle *h)
     if (st[0] == 0u) return SWE2D_OK;
     // leave the handle usable: counters and flags back to a consistent start
     (void)hipMemsetAsync(h->flow_status, 0, 2*sizeof(unsigned), h->stream);
-    (void)hipMemsetAsync(h->flow_flag, 0, (size_t)2*h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned), h->stream);
+    (void)hipMemsetAsync(h->flow_flag, 0, (size_t)h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned), h->stream);
+    (void)hipMemsetAsync(h->flow_ex, 0, h->flow_ex_bytes, h->stream);
     (void)hipStreamSynchronize(h->stream);
     char msg[200];
     std::snprintf(msg, sizeof(msg), "flow kernel: %u block waits timed out (first: block %u) - blocks not resident together? The state is invalid",
@@ -823,13 +832,75 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
             HIP_TRY_C(hipMemcpy(h->bnd_cells, bnd.data(), bnd.size()*sizeof(int), hipMemcpyHostToDevice));
         }
         h->fuse_visc = std::getenv("THETIS_AMD_NO_VISC_FUSION") == nullptr;
-        // dataflow stage loop: one stage counter per 64-cell block (64 B apart: a flag is polled by the blocks around it and
-        // rewritten every stage) and the status word
+        // dataflow stage loop (swe2d_flow.h): one stage counter per 64-cell block, the status word, and the exchange slots of
+        // the rim facets - interior facets whose two cells sit in different blocks - numbered in cell order
         h->flow_blocks = (n + SWE_BLOCK - 1)/SWE_BLOCK;
-        HIP_TRY_C(hipMalloc(&h->flow_flag, (size_t)2*h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned)));
+        HIP_TRY_C(hipMalloc(&h->flow_flag, (size_t)h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned)));
         HIP_TRY_C(hipMalloc(&h->flow_status, 2*sizeof(unsigned)));
-        HIP_TRY_C(hipMemset(h->flow_flag, 0, (size_t)2*h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned)));
+        HIP_TRY_C(hipMemset(h->flow_flag, 0, (size_t)h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned)));
         HIP_TRY_C(hipMemset(h->flow_status, 0, 2*sizeof(unsigned)));
+        {
+            // rim facets: interior facets whose two cells sit in different 64-cell blocks.  A block's slots are contiguous and
+            // grouped by the block they face (so the chunk block A writes for block B is contiguous: B reads it coalesced).
+            struct Rim { int nbblock, k, f; };
+            std::vector<int> own((size_t)3*S, -1);                               // global slot of (k, f)
+            std::vector<int2> blk((size_t)h->flow_blocks, int2{0, 0});
+            int n_slots = 0;
+            std::vector<Rim> rim;
+            for (int b = 0; b < h->flow_blocks; b++) {
+                rim.clear();
+                for (int kk = b*SWE_BLOCK; kk < std::min(n, (b + 1)*SWE_BLOCK); kk++)
+                    for (int f = 0; f < 3; f++) {
+                        const int code = nbr[(size_t)f*S + kk];
+                        if (code >= 0 && (code >> 2)/SWE_BLOCK != b) rim.push_back(Rim{(code >> 2)/SWE_BLOCK, kk, f});
+                    }
+                std::sort(rim.begin(), rim.end(), [](const Rim &x, const Rim &y) {
+                    return x.nbblock != y.nbblock ? x.nbblock < y.nbblock : (x.k != y.k ? x.k < y.k : x.f < y.f); });
+                blk[b] = int2{n_slots, (int)rim.size()};
+                for (const Rim &r : rim) own[(size_t)r.f*S + r.k] = n_slots++;
+            }
+            // incoming list of a block: the slots its neighbours write for it, neighbour by neighbour in THEIR slot order;
+            // entry = producer's slot << 6 | lane of the consuming cell; xin(k, f) = position of the slot facing (k, f)
+            std::vector<int> xsrc((size_t)std::max(n_slots, 1), 0), xin((size_t)3*S, -1);
+            std::vector<std::pair<int, int>> inc;                                // (producer's slot, consumer (k << 2 | f))
+            for (int b = 0; b < h->flow_blocks; b++) {
+                inc.clear();
+                for (int kk = b*SWE_BLOCK; kk < std::min(n, (b + 1)*SWE_BLOCK); kk++)
+                    for (int f = 0; f < 3; f++)
+                        if (own[(size_t)f*S + kk] >= 0) {
+                            const int code = nbr[(size_t)f*S + kk];
+                            inc.push_back({own[(size_t)(code & 3)*S + (code >> 2)], (kk << 2) | f});
+                        }
+                std::sort(inc.begin(), inc.end());                               // by producer's slot = by neighbour block, then its order
+                for (size_t i = 0; i < inc.size(); i++) {
+                    const int kk = inc[i].second >> 2, f = inc[i].second & 3;
+                    xsrc[(size_t)blk[b].x + i] = (inc[i].first << 6) | (kk & (SWE_BLOCK - 1));
+                    xin[(size_t)f*S + kk] = (int)i;
+                }
+            }
+            for (int kk = 0; kk < n; kk++) {
+                const int b0 = blk[kk/SWE_BLOCK].x;
+                int lo[3];
+                for (int f = 0; f < 3; f++) lo[f] = own[(size_t)f*S + kk] >= 0 ? own[(size_t)f*S + kk] - b0 : -1;
+                p4[kk] = int4{lo[0], lo[1], lo[2], xin[kk]};
+                p2[kk] = int2{xin[S + kk], xin[2*S + kk]};
+            }
+            // (slot << 6 must fit an int, the exchange array must stay below SWE_FLOW_NOWHERE)
+            if ((size_t)2*n_slots*SWE_FLOW_SLOT_BYTES < ((size_t)1 << 31) && n_slots < (1 << 25)) {      // else: no flow kernel for this handle
+                h->flow_parity_bytes = (unsigned)((size_t)std::max(n_slots, 1)*SWE_FLOW_SLOT_BYTES);
+                h->flow_ex_bytes = (size_t)2*h->flow_parity_bytes;
+                HIP_TRY_C(hipMalloc(&h->flow_xblk, blk.size()*sizeof(int2)));
+                HIP_TRY_C(hipMemcpy(h->flow_xblk, blk.data(), blk.size()*sizeof(int2), hipMemcpyHostToDevice));
+                HIP_TRY_C(hipMalloc(&h->flow_xsrc, xsrc.size()*sizeof(int)));
+                HIP_TRY_C(hipMemcpy(h->flow_xsrc, xsrc.data(), xsrc.size()*sizeof(int), hipMemcpyHostToDevice));
+                HIP_TRY_C(hipMalloc(&h->flow_xo4, (size_t)S*sizeof(int4)));
+                HIP_TRY_C(hipMalloc(&h->flow_xo2, (size_t)S*sizeof(int2)));
+                HIP_TRY_C(hipMemcpy(h->flow_xo4, p4.data(), (size_t)S*sizeof(int4), hipMemcpyHostToDevice));
+                HIP_TRY_C(hipMemcpy(h->flow_xo2, p2.data(), (size_t)S*sizeof(int2), hipMemcpyHostToDevice));
+                HIP_TRY_C(hipMalloc(&h->flow_ex, h->flow_ex_bytes));
+                HIP_TRY_C(hipMemset(h->flow_ex, 0, h->flow_ex_bytes));
+            }
+        }
         if (const char *e = std::getenv("THETIS_AMD_FLOW_TIMEOUT_S")) { const double t = std::atof(e); if (t > 0.0) h->flow_timeout_s = t; }
     }
     HIP_TRY_C(hipMemcpyAsync(h->nbr, nbr.data(), (size_t)npc*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -860,7 +931,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
     for (void *m : h->p2p.opened) (void)hipIpcCloseMemHandle(m);

@@ -1,5 +1,5 @@
 // swe2d_flow.h - many SSPRK33 stages of the triangle DG-P1 shallow water equations in ONE launch, without a grid barrier:
-// a dataflow stage loop for cell ranges whose 64-cell blocks are all resident at once (gfx950; <= ~190 k cells).
+// a dataflow stage loop for cell ranges whose 64-cell blocks are all resident at once (gfx950; <= ~130-190 k cells).
 //
 // What it replaces: the reference runs solve_stage(i) on the whole mesh and then solve_stage(i + 1) (thetis/rungekutta.py:930-952),
 // and under mpiexec every par_loop is preceded by a halo exchange (examples/README.md:51-56).  On one rank of eight of the 1 M
@@ -7,27 +7,48 @@
 // index loads + 2.5 us loads + 2.1 us arithmetic + 0.3 us stores in lock step, a tail of boundary waves, 1.5-1.9 us of kernel
 // boundary and a reload of the state into L2s that the boundary invalidated.  Here
 //
-//   * one wave OWNS one 64-cell block of the device numbering for the whole launch: connectivity, geometry and the block's own
-//     nodal values stay in registers from stage to stage (no index loads, no own-cell loads after the first stage);
-//   * a block at stage s + 1 waits only for the blocks its facets touch to have finished stage s: every block publishes a
-//     monotonically growing stage counter (flag), a lane polls the counters of ITS three neighbour cells' blocks - no grid
-//     barrier, so the load phase of some blocks overlaps the arithmetic of others and nobody waits for the slowest wave of the
-//     grid;
-//   * stage values travel through memory, write-through: `sc1` stores, every storing wave drains them (s_waitcnt vmcnt(0))
-//     before ONE lane raises the block's flag with an agent-scope store; consumers poll with agent-scope loads and gather the
-//     neighbour traces with `sc1` loads (past the CU's L1, which other CUs' stores never refresh).  This is the
-//     placement-independent hand-off of MI355X_MICROARCH.md ("sc1 loads may replace the acquire only when the producer stored
-//     sc1"); the XCD-chunked block map (swe_logical_block) is used for speed only.
+//   * one wave OWNS one 64-cell block of the device numbering for the whole launch: connectivity, geometry, the block's stage
+//     values and its U(0) stay in registers from stage to stage; state planes are read once at the start of the launch and
+//     written once per time step (the step result, buffer 0);
+//   * traces of neighbours INSIDE the block (~85 % with the tile numbering) go through LDS: the wave publishes its nine nodal
+//     values per cell there at the top of a stage and reads its neighbours' - no memory, no waiting;
+//   * traces of neighbours in OTHER blocks travel as 16-byte granules {value, stage tag}: a facet on the block's rim owns a slot
+//     (host-built numbering: a block's slots are contiguous and grouped by the block they face), its six trace values are
+//     stored there after every stage, each granule by ONE 16-byte `sc1` (write-through) store of one lane, tag = stage counter;
+//     the block across the rim re-reads the granules with `sc1` loads (past its CU's L1) until all carry the tag of the stage
+//     it needs.  The data IS the flag:
+//     no drain (s_waitcnt vmcnt(0)) before a flag store, no flag store, no separate poll before a dependent gather - measured
+//     on the first version of this kernel (stage values through the state planes + one stage counter per block) those three
+//     hops were 2.1 of the 4.0 us a stage took with one block per compute unit.  A naturally aligned 16-byte store of one lane
+//     lands untorn on gfx950 (MI355X_MICROARCH.md, "observed untorn, also for 16-B sc1 halves; not an architectural
+//     guarantee"); the parity tests would see a torn granule as a wrong bit.  Two slots per facet alternate by stage parity:
+//     the producer overwrites the values of stage s at the end of stage s + 2, which it can only reach after the consumer has
+//     finished stage s + 1, i.e. has read them.
+//     Both directions are coalesced through an LDS staging area: the rim lanes drop their values there by slot and the wave
+//     writes the block's whole slot range with consecutive lanes on consecutive granules (full 128-byte lines); the chunk a
+//     neighbour block wrote for this block is contiguous too, the wave reads it the same way and the rim lanes pick their
+//     traces from LDS.  (One 16-byte access per lane and granule is one partial-line request each: 216 per block, stage and
+//     polling pass instead of ~36 lines - measured 3 us just to issue the stores at 125 k cells, and the polling passes of
+//     eight waves saturate a compute unit's memory pipeline.)
+//   * no grid barrier and no per-block flag wait: a block starts stage s + 1 as soon as the granules of ITS rim facets have
+//     arrived, so the load phase of some blocks overlaps the arithmetic of others.
+//
+// Placement-independent (MI355X_MICROARCH.md, inter-workgroup visibility): every shared word is written with sc1 stores and
+// read with sc1 loads; the XCD-chunked block map (swe_logical_block) is used for speed only.
 //
 // Deadlock freedom needs every block of the launch resident: the host launches this kernel only when the grid fits the
 // occupancy the runtime reports (swe2d_api.hip: flow_capacity), and every spin is bounded by the wall clock - a timeout is
 // counted in the status word, the wave carries on (the result is then wrong and the host reports SWE2D_ERR_HIP at the next
 // synchronisation point), it never hangs the device.
 //
-// Flags never need re-initialisation: a block that retires (its cells are outside the range of the remaining stages) raises
-// its flag to `base + n_stages` as well, so after a launch every flag of the handle holds the same value, which is the next
-// launch's base (read from the block's own flag).  The grid therefore always covers ALL blocks of the handle, also those that
-// take part in no stage.
+// Stage tags never need re-initialisation: they count stages over ALL launches of the handle.  Every block keeps the count in
+// its own word (flag[block]); a block that retires early (its cells are outside the range of the remaining stages) or takes
+// part in no stage advances its word by n_stages as well, so all words stay equal and the grid always covers ALL blocks.
+//
+// Ranges: stage s updates the cells [0, cell_end[s]), non-increasing, and every cell of stage s + 1's range must have its three
+// facet neighbours inside stage s's range - the shrinking ranges of a halo-exchange cycle (partition.py: stage_range), or the
+// whole mesh throughout.  After the launch state buffer 0 holds what the stage launches would have left there; buffers 1, 2
+// (the intermediate stage solutions) are not written.
 //
 // The arithmetic is that of swe_stage_kernel<NONLIN, LF, ., SRC, false, false, true(BINL)>, operation for operation and under
 // the same `fp contract(off)`: bit for bit the result of the stage launches on the same ranges (tests/test_gpu_flow_kernel.py).
@@ -35,18 +56,31 @@
 #include "swe2d_kernels.h"
 
 #ifndef SWE_FLOW_OCCUPANCY
-#define SWE_FLOW_OCCUPANCY __attribute__((amdgpu_waves_per_eu(3, 3)))      // <= 168 VGPRs: three one-wave workgroups per SIMD
+#define SWE_FLOW_OCCUPANCY __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 VGPRs: two one-wave workgroups per SIMD
 #endif
 #define SWE_FLOW_MAX_STAGES 48             // 16 time steps per launch
 #ifndef SWE_FLOW_FLAG_STRIDE
-#define SWE_FLOW_FLAG_STRIDE 16           // unsigned words between two blocks' flags (64 B)
+#define SWE_FLOW_FLAG_STRIDE 16           // unsigned words between two blocks' stage counters (64 B)
 #endif
+#define SWE_FLOW_SLOT_BYTES 128            // exchange slot of one rim facet and stage parity: 8 granules of 16 B (6 values + 2 pads)
+#define SWE_FLOW_MAX_RIM (3*SWE_BLOCK)     // rim facets of a block
+
+typedef unsigned int swe_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int swe_u32x3 __attribute__((ext_vector_type(3)));
+#define SWE_FLOW_NOWHERE 0x80000000u       // byte offset beyond the exchange array (< 2 GiB): a load returns zeros without touching memory
 
 struct SweFlowArgs {
     SweStageArgs st;                       // geometry, connectivity, boundary tables, sources; uin/u0/uout/a0/a1/beta/cell_* unused
-    double *buf[3];                        // state buffers A (U0 / step result), B, C
-    unsigned *flag;                        // [n_blocks][SWE_FLOW_FLAG_STRIDE] stages finished by the block, monotonic over launches
+    double *buf[3];                        // state buffers A (U0 / step result), B, C (B, C are not touched)
+    unsigned *flag;                        // [n_blocks][SWE_FLOW_FLAG_STRIDE] stages counted by the block over all launches
     unsigned *status;                      // [0] timeouts, [1] first block that timed out + 1
+    const int4 *xo4;                       // per cell, counted from the block's first slot: {my slot of facet 0, 1, 2 (-1: not a rim
+    const int2 *xo2;                       //  facet), position of facet 0's incoming slot in the block's incoming list}, {... of facets 1, 2}
+    const int2 *xblk;                      // per block {first slot, number of slots}: a block's slots are contiguous
+    const int *xsrc;                       // [n_slots] incoming list of every block at its own slot range: entry i = (slot the
+                                           //  neighbour block writes for my i-th incoming facet) << 6 | lane of my cell that reads it
+    void *ex;                              // [2 stage parities][n_slots] exchange slots, SWE_FLOW_SLOT_BYTES each
+    unsigned parity_bytes;                 // n_slots * SWE_FLOW_SLOT_BYTES
     int n_blocks;                          // blocks of the handle (cells rounded up to 64)
     int n_stages;                          // a multiple of 3: stage s is Shu-Osher stage s % 3
     int cell_end[SWE_FLOW_MAX_STAGES];     // stage s updates the cells [0, cell_end[s]); non-increasing
@@ -54,36 +88,32 @@ struct SweFlowArgs {
     unsigned long long timeout_ticks;      // wall_clock64 ticks (100 MHz)
 };
 
-#ifndef SWE_FLOW_LD_AUX
-#define SWE_FLOW_LD_AUX 16                // cache policy of the stage-value loads / stores: 16 = sc1 (experiments: 0 = plain)
-#endif
-#ifndef SWE_FLOW_ST_AUX
-#define SWE_FLOW_ST_AUX 16
-#endif
-__device__ __forceinline__ double swe_ld_sc1(swe_rsrc_t r, unsigned voff, unsigned soff)
+// one granule: {value, tag} written / read by ONE 16-byte access of one lane, sc1 (aux 16): write-through / past the L1
+__device__ __forceinline__ void swe_flow_put(__amdgpu_buffer_rsrc_t r, unsigned off, double x, unsigned tag)
 {
-#ifndef SWE_RANGE_CHECK
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, SWE_FLOW_LD_AUX));       // aux 16 = sc1
-#else
-    return swe_ld(r, voff, soff);
-#endif
+    const swe_u32x2 xb = __builtin_bit_cast(swe_u32x2, x);
+    const swe_u32x4 g = {xb.x, xb.y, tag, 0u};
+    __builtin_amdgcn_raw_buffer_store_b128(g, r, off, 0, 16);
 }
-__device__ __forceinline__ void swe_st_sc1(swe_rsrc_t r, unsigned voff, unsigned soff, double x)
+__device__ __forceinline__ swe_u32x3 swe_flow_get(__amdgpu_buffer_rsrc_t r, unsigned off)       // value + tag: 12 of the 16 bytes
 {
-#ifndef SWE_RANGE_CHECK
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(swe_u32x2, x), r, voff, soff, SWE_FLOW_ST_AUX);
-#else
-    swe_st(r, voff, soff, x);
-#endif
+    return __builtin_amdgcn_raw_buffer_load_b96(r, off, 0, 16);
+}
+__device__ __forceinline__ double swe_flow_val(swe_u32x3 g)
+{
+    const swe_u32x2 xb = {g.x, g.y};
+    return __builtin_bit_cast(double, xb);
 }
 
-// right-hand side integrals of one cell from values in registers: cell integrals + interior facet fluxes (boundary facets
-// contribute zero here, their flux is evaluated from the cell's own values and discarded - the branch-free facet loop of
-// swe_stage_kernel).  Lines as in swe_stage_kernel, same order.
+// right-hand side integrals of one cell: cell integrals + interior facet fluxes (boundary facets contribute zero here, their
+// flux is evaluated from the cell's own values and discarded - the branch-free facet loop of swe_stage_kernel).  The six traces
+// of facet f are read from LDS where the flux is formed: tr[f] = the LDS addresses (in doubles from `lds`) of {u, v, e at the
+// neighbour's node on my node f + 1; u, v, e at its node on my node f} - the block's own stage values for a neighbour inside
+// the block (a boundary facet points at this cell itself), the incoming staging entry for a rim facet.
+// Lines as in swe_stage_kernel, same order.
 template <bool NONLIN, bool LF, bool SRC>
 __device__ __forceinline__ void swe_flow_rhs(const SweStageArgs &p, int k, const double u[3], const double v[3], const double e[3],
-                                             const double h[3], const double una[3], const double unb[3], const double vna[3],
-                                             const double vnb[3], const double ena[3], const double enb[3], int bmarkers,
+                                             const double h[3], const double *lds, const unsigned tr[3][3], int bmarkers,
                                              const double nx[3], const double ny[3], double twoA, double bu[3], double bv[3],
                                              double be[3])
 {
@@ -121,6 +151,10 @@ __device__ __forceinline__ void swe_flow_rhs(const SweStageArgs &p, int k, const
     for (int f = 0; f < 3; f++) {
         const int a = f, b = (f + 1) % 3;
         const bool bnd = ((bmarkers >> (8*f)) & 0xff) != 0;
+        // tr[f][c] = address of component c (u, v, e) at the neighbour's node on my node f + 1 | the same on my node f << 16
+        const double unb = lds[tr[f][0] & 0xffffu], una = lds[tr[f][0] >> 16];
+        const double vnb = lds[tr[f][1] & 0xffffu], vna = lds[tr[f][1] >> 16];
+        const double enb = lds[tr[f][2] & 0xffffu], ena = lds[tr[f][2] >> 16];
         const double nxs = nx[f], nys = ny[f];
         double Lf, rLf;
         swe_sqrt_rsqrt(swe_dot2(nxs, nxs, nys, nys), Lf, rLf);
@@ -130,7 +164,7 @@ __device__ __forceinline__ void swe_flow_rhs(const SweStageArgs &p, int k, const
             const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
             const double uq = swe_dot2(xa, u[a], xb, u[b]), vq = swe_dot2(xa, v[a], xb, v[b]), eq = swe_dot2(xa, e[a], xb, e[b]);
             const double hq = swe_dot2(xa, h[a], xb, h[b]);
-            const double un = swe_dot2(xa, una[f], xb, unb[f]), vn = swe_dot2(xa, vna[f], xb, vnb[f]), en = swe_dot2(xa, ena[f], xb, enb[f]);
+            const double un = swe_dot2(xa, una, xb, unb), vn = swe_dot2(xa, vna, xb, vnb), en = swe_dot2(xa, ena, xb, enb);
             const double eav = 0.5*(eq + en);
             const double Hav = NONLIN ? hq + eav : hq;
             const double c = swe_sqrt(g*Hav);
@@ -217,11 +251,6 @@ __device__ __forceinline__ void swe_flow_finish(const SweStageArgs &p, int k, do
     }
 }
 
-__device__ __forceinline__ unsigned swe_flow_ld_flag(const unsigned *f)
-{
-    return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // global_load_dword sc1
-}
-
 #ifdef SWE_WAVE_TIMING
 // profiling build only (tools/flowtiming.py): the 100 MHz wall clock of every block at five points of ONE stage of the launch
 #ifndef SWE_FLOW_TS_STAGE
@@ -232,10 +261,17 @@ __device__ __forceinline__ unsigned swe_flow_ld_flag(const unsigned *f)
 #define SWE_FT(i)
 #endif
 
+// LDS of a block, in doubles: [0, 9*64) the block's stage values xs[plane][lane] (u0 u1 u2 v0 v1 v2 e0 e1 e2),
+// then the rim staging area xg[slot][6] (incoming traces at the top of a stage, outgoing ones at its end)
+#define SWE_FLOW_XG (9*SWE_BLOCK)
+#define SWE_FLOW_LDS_DOUBLES (SWE_FLOW_XG + 6*SWE_FLOW_MAX_RIM)
+
 template <bool NONLIN, bool LF, bool SRC>
 __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(const SweFlowArgs q)
 {
 #pragma clang fp contract(off)
+    __shared__ double lds[SWE_FLOW_LDS_DOUBLES];
+    __shared__ int xsrc[SWE_FLOW_MAX_RIM];                     // the block's incoming list (SweFlowArgs::xsrc)
     const SweStageArgs &p = q.st;
     const int lb = swe_logical_block(blockIdx.x, gridDim.x);
     if (lb >= q.n_blocks) return;                              // padding of the grid to a multiple of 8
@@ -244,39 +280,71 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
     const size_t S = p.stride;
     const unsigned S8 = (unsigned)S*8u;
     unsigned *const myflag = q.flag + (size_t)lb*SWE_FLOW_FLAG_STRIDE;
-    const unsigned base = *myflag;                             // written by this block's wave in the previous launch (or 0)
+    const unsigned base = *myflag;                             // stages counted so far: written by this block's wave in the previous launch
     const unsigned fin = base + (unsigned)q.n_stages;
     if (lb*SWE_BLOCK >= q.cell_end[0]) {                       // this block takes part in no stage of the launch
-        if (lane == 0) __hip_atomic_store(myflag, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) *myflag = fin;
         return;
     }
-    // lanes beyond the first stage's range mimic the range's last cell: finite values, never stored
+    // lanes beyond the first stage's range mimic the range's last cell: finite values, never stored or published
     const int k = min(kraw, q.cell_end[0] - 1);
     const unsigned k8 = (unsigned)k*8u;
+    // bounds-checked resource: a load from SWE_FLOW_NOWHERE costs no memory access
+    const __amdgpu_buffer_rsrc_t rex = __builtin_amdgcn_make_buffer_rsrc(q.ex, 0, 2*q.parity_bytes, 0x00020000);
+    const int2 myslots = q.xblk[lb];                           // uniform: first slot, count
+    const int nrim = myslots.y;
+    for (int i = lane; i < nrim; i += SWE_BLOCK) xsrc[i] = q.xsrc[myslots.x + i];
 
-    // ---- launch invariants of the cell: connectivity, neighbour addresses, geometry
+    // ---- launch invariants of the cell: connectivity, exchange slots, geometry
     int bmarkers, bkind1 = 0;
-    unsigned oa[3], ob[3];                 // byte offsets of the neighbour's nodes on my nodes f and f + 1 (inside a 3-plane group)
-    int kn[3];                             // neighbour cells (this cell itself for a boundary facet)
+    unsigned tr[3][3];                     // LDS addresses of the six traces of every facet (see swe_flow_rhs)
+    int xown[3];                           // rim facets: my slot, counted from the block's first slot; else -1
     double h[3], nx[3], ny[3];
+    double u[3], v[3], e[3];
     {
         const int4 q4 = p.idx4[k];
         const int2 q2 = p.idx2[k];
+        const int4 x4 = q.xo4[k];
+        const int2 x2 = q.xo2[k];
         const int nb[3] = {q4.x, q4.y, q4.z};
         const int vid[3] = {q4.w, q2.x, q2.y};
+        const int xin[3] = {x4.w, x2.x, x2.y};
+        xown[0] = x4.x; xown[1] = x4.y; xown[2] = x4.z;
         bmarkers = (nb[0] < 0 ? -nb[0] : 0) | (nb[1] < 0 ? (-nb[1]) << 8 : 0) | (nb[2] < 0 ? (-nb[2]) << 16 : 0);
         if (bmarkers != 0) {
             const int m1 = (bmarkers & 0xff) ? (bmarkers & 0xff) : ((bmarkers & 0xff00) ? ((bmarkers >> 8) & 0xff) : (bmarkers >> 16));
             bkind1 = m1 < SWE_MAX_MARKERS ? p.bc.kind[m1] : 0;
         }
+        // the launch's input: written by earlier kernels, plain loads
+        const swe_rsrc_t gu = swe_rsrc(q.buf[0]), gv = swe_rsrc(q.buf[0] + 3*S), ge = swe_rsrc(q.buf[0] + 6*S);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            u[i] = swe_ld(gu, k8, i*S8);
+            v[i] = swe_ld(gv, k8, i*S8);
+            e[i] = swe_ld(ge, k8, i*S8);
+        }
+        double r0[3][6];                   // first stage: the rim traces come from the state planes too
 #pragma unroll
         for (int f = 0; f < 3; f++) {
             const int nbf = nb[f];
-            kn[f] = nbf >= 0 ? (nbf >> 2) : k;
-            const int f2 = nbf >= 0 ? (nbf & 3) : f;
-            const unsigned kn8 = (unsigned)kn[f]*8u;
-            ob[f] = kn8 + (f2 == 0 ? 0u : (f2 == 1 ? S8 : 2u*S8));         // node f2
-            oa[f] = kn8 + (f2 == 0 ? S8 : (f2 == 1 ? 2u*S8 : 0u));         // node (f2 + 1) % 3
+            const bool rim = xown[f] >= 0;                                 // interior facet whose neighbour lives in another block
+            const bool inw = nbf >= 0 && !rim;
+            // the neighbour traverses the shared facet backwards: its node f2 sits on my node f + 1, its node (f2 + 1) % 3 on my node f
+            const int ls = inw ? ((nbf >> 2) & (SWE_BLOCK - 1)) : lane;
+            const int f2 = inw ? (nbf & 3) : f, f2a = f2 == 2 ? 0 : f2 + 1;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const unsigned ab = rim ? (unsigned)(SWE_FLOW_XG + 6*xin[f] + c) : (unsigned)((3*c + f2)*SWE_BLOCK + ls);
+                const unsigned aa = rim ? (unsigned)(SWE_FLOW_XG + 6*xin[f] + 3 + c) : (unsigned)((3*c + f2a)*SWE_BLOCK + ls);
+                tr[f][c] = ab | (aa << 16);
+            }
+            const int code = rim ? nbf : ((k << 2) | f);
+            const unsigned kn8 = (unsigned)(code >> 2)*8u;
+            const int g2 = code & 3;
+            const unsigned ob = kn8 + (g2 == 0 ? 0u : (g2 == 1 ? S8 : 2u*S8));         // node g2
+            const unsigned oa = kn8 + (g2 == 0 ? S8 : (g2 == 1 ? 2u*S8 : 0u));         // node (g2 + 1) % 3
+            r0[f][0] = swe_ld(gu, ob, 0); r0[f][1] = swe_ld(gv, ob, 0); r0[f][2] = swe_ld(ge, ob, 0);
+            r0[f][3] = swe_ld(gu, oa, 0); r0[f][4] = swe_ld(gv, oa, 0); r0[f][5] = swe_ld(ge, oa, 0);
         }
         double px[3], py[3];
         const swe_rsrc_t rvx = swe_rsrc(p.vx), rvy = swe_rsrc(p.vy), rvh = swe_rsrc(p.vh);
@@ -293,18 +361,15 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             nx[f] = py[b] - py[f];
             ny[f] = px[f] - px[b];
         }
-    }
-    // the launch's input: written by earlier kernels, plain loads
-    double u[3], v[3], e[3];
-    {
-        const swe_rsrc_t gu = swe_rsrc(q.buf[0]), gv = swe_rsrc(q.buf[0] + 3*S), ge = swe_rsrc(q.buf[0] + 6*S);
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            u[i] = swe_ld(gu, k8, i*S8);
-            v[i] = swe_ld(gv, k8, i*S8);
-            e[i] = swe_ld(ge, k8, i*S8);
+        for (int f = 0; f < 3; f++) {
+            if (xown[f] >= 0) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) lds[SWE_FLOW_XG + 6*xin[f] + j] = r0[f][j];
+            }
         }
     }
+    double u0[3], v0[3], e0[3];            // U(0) of the running time step
     unsigned long long t_start = 0ull;
     bool late = false;
 
@@ -323,77 +388,71 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             swe_wave_ts[5][lb] = (unsigned long long)hw | ((unsigned long long)(xcc & 0xf) << 32);
         }
 #endif
-        const double *bin = q.buf[i3];
-        double *bout = q.buf[i3 == 2 ? 0 : i3 + 1];
         // Opaque to the optimiser: without this every stage-invariant quantity (facet lengths, reciprocals, gradients ...) is
         // hoisted out of the stage loop and kept live across it - past the register budget.  The per-stage kernel recomputes
         // them in every stage as well.
 #pragma unroll
         for (int i = 0; i < 3; i++) asm volatile("" : "+v"(nx[i]), "+v"(ny[i]), "+v"(h[i]));
         asm volatile("" : "+v"(bmarkers));
-        // w = a0*U(0) + a1*U_in; U(0) of the cell is this block's own stage-3 result of the previous step (or the launch input):
-        // requested before the wait
-        const double a0 = q.a0[i3], a1 = q.a1[i3];
-        double wu[3], wv[3], we[3];
+        if (i3 == 0) {
 #pragma unroll
-        for (int i = 0; i < 3; i++) { wu[i] = a1*u[i]; wv[i] = a1*v[i]; we[i] = a1*e[i]; }
-        double u0[3], v0[3], e0[3];
-        if (i3 > 0) {
-            const swe_rsrc_t g0u = swe_rsrc(q.buf[0]), g0v = swe_rsrc(q.buf[0] + 3*S), g0e = swe_rsrc(q.buf[0] + 6*S);
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                u0[i] = swe_ld_sc1(g0u, k8, i*S8);
-                v0[i] = swe_ld_sc1(g0v, k8, i*S8);
-                e0[i] = swe_ld_sc1(g0e, k8, i*S8);
-            }
+            for (int i = 0; i < 3; i++) { u0[i] = u[i]; v0[i] = v[i]; e0[i] = e[i]; }
         }
-        // ---- wait until the blocks of my three neighbour cells have finished stage s - 1 (a neighbour that stage s - 1 did not
-        //      update - outside its range - is read as it is, like a stage launch would)
-        if (s > 0 && !late) {
-            const int end_p = q.cell_end[s - 1];
-            const unsigned need = base + (unsigned)s;
-            const unsigned *f0 = q.flag + (size_t)(kn[0] < end_p ? (kn[0] >> 6) : lb)*SWE_FLOW_FLAG_STRIDE;
-            const unsigned *f1 = q.flag + (size_t)(kn[1] < end_p ? (kn[1] >> 6) : lb)*SWE_FLOW_FLAG_STRIDE;
-            const unsigned *f2 = q.flag + (size_t)(kn[2] < end_p ? (kn[2] >> 6) : lb)*SWE_FLOW_FLAG_STRIDE;
+        // ---- the block's stage values for its own lanes
+#pragma unroll
+        for (int i = 0; i < 3; i++) { lds[i*SWE_BLOCK + lane] = u[i]; lds[(3 + i)*SWE_BLOCK + lane] = v[i]; lds[(6 + i)*SWE_BLOCK + lane] = e[i]; }
+        // ---- traces across the rim: the chunks the neighbour blocks wrote for this block, consecutive lanes on consecutive
+        //      granules, re-read until every granule a cell of this stage's range needs carries this stage's tag
+        if (s > 0) {
+            const unsigned need = base + (unsigned)s;          // written at the end of stage s - 1
+            const unsigned par = ((unsigned)(s - 1) & 1u)*q.parity_bytes;
+            __syncthreads();                                   // the incoming list / the previous stage's staging reads
             for (unsigned spins = 0;; spins++) {
-#ifdef SWE_FLOW_LOCAL_EXPERIMENT
-                const size_t lo = (size_t)q.n_blocks*SWE_FLOW_FLAG_STRIDE;
-                const unsigned g0 = swe_flow_ld_flag(f0), g1 = swe_flow_ld_flag(f1), g2 = swe_flow_ld_flag(f2);
-                const unsigned l0 = swe_flow_ld_flag(f0 + lo), l1 = swe_flow_ld_flag(f1 + lo), l2 = swe_flow_ld_flag(f2 + lo);
-                const unsigned c0 = (int)(l0 - g0) > 0 ? l0 : g0, c1 = (int)(l1 - g1) > 0 ? l1 : g1, c2 = (int)(l2 - g2) > 0 ? l2 : g2;
-#else
-                const unsigned c0 = swe_flow_ld_flag(f0), c1 = swe_flow_ld_flag(f1), c2 = swe_flow_ld_flag(f2);
-#endif
-                const bool ok = (int)(c0 - need) >= 0 && (int)(c1 - need) >= 0 && (int)(c2 - need) >= 0;
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(1);
-                if ((spins & 63u) == 63u) {
+                bool ok = true;
+                for (int c0 = 0; c0 < 8*nrim; c0 += 8*SWE_BLOCK) {         // eight loads per lane in flight (64 rim facets per trip)
+                    swe_u32x3 g[8];
+                    int ent[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int t = c0 + j*SWE_BLOCK + lane;
+                        ent[j] = t < 8*nrim ? xsrc[t >> 3] : -1;
+                        // a cell outside this stage's range needs nothing (and its neighbour may never have published)
+                        if (ent[j] >= 0 && lb*SWE_BLOCK + (ent[j] & (SWE_BLOCK - 1)) >= end_s) ent[j] = -1;
+                        g[j] = swe_flow_get(rex, ent[j] >= 0 ? (unsigned)(ent[j] >> 6)*SWE_FLOW_SLOT_BYTES + 16u*(unsigned)(t & 7) + par
+                                                             : SWE_FLOW_NOWHERE);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int t = c0 + j*SWE_BLOCK + lane;
+                        if (ent[j] >= 0) {
+                            ok = ok && (int)(g[j].z - need) >= 0;
+                            if ((t & 7) < 6) lds[SWE_FLOW_XG + 6*(t >> 3) + (t & 7)] = swe_flow_val(g[j]);
+                        }
+                    }
+                }
+                if (__all(ok) || late) break;
+                __builtin_amdgcn_s_sleep(2);
+                if ((spins & 31u) == 31u) {
                     const unsigned long long now = wall_clock64();
                     if (t_start == 0ull) t_start = now;
-                    else if (now - t_start > q.timeout_ticks) { late = true; break; }
+                    else if (now - t_start > q.timeout_ticks) {
+                        late = true;
+                        if (lane == 0 && atomicAdd(q.status, 1u) == 0u) q.status[1] = (unsigned)lb + 1u;
+                    }
                 }
             }
             t_start = 0ull;
-            if (late && lane == 0) {
-                if (atomicAdd(q.status, 1u) == 0u) q.status[1] = (unsigned)lb + 1u;
-            }
         }
-        asm volatile("" ::: "memory");
+        __syncthreads();
         SWE_FT(1);
-        // ---- neighbour traces of stage s - 1 (sc1: past this CU's L1, which other CUs' stores never refresh)
-        double una[3], unb[3], vna[3], vnb[3], ena[3], enb[3];
-        {
-            const swe_rsrc_t gu = swe_rsrc(bin), gv = swe_rsrc(bin + 3*S), ge = swe_rsrc(bin + 6*S);
+        SWE_FT(2);
+        double bu[3], bv[3], be[3], ou[3], ov[3], oe[3], wu[3], wv[3], we[3];
+        const double twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
+        swe_flow_rhs<NONLIN, LF, SRC>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+        // w = a0*U(0) + a1*U_in: the first stage of a step has no U(0) term (swe_stage_kernel<., ., HASU0 = false>)
+        const double a0 = q.a0[i3], a1 = q.a1[i3];
 #pragma unroll
-            for (int f = 0; f < 3; f++) {
-                una[f] = swe_ld_sc1(gu, oa[f], 0);
-                unb[f] = swe_ld_sc1(gu, ob[f], 0);
-                vna[f] = swe_ld_sc1(gv, oa[f], 0);
-                vnb[f] = swe_ld_sc1(gv, ob[f], 0);
-                ena[f] = swe_ld_sc1(ge, oa[f], 0);
-                enb[f] = swe_ld_sc1(ge, ob[f], 0);
-            }
-        }
+        for (int i = 0; i < 3; i++) { wu[i] = a1*u[i]; wv[i] = a1*v[i]; we[i] = a1*e[i]; }
         if (i3 > 0) {
 #pragma unroll
             for (int i = 0; i < 3; i++) {
@@ -402,37 +461,48 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                 we[i] = fma(a0, e0[i], we[i]);
             }
         }
-#ifdef SWE_WAVE_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        SWE_FT(2);
-#endif
-        double bu[3], bv[3], be[3], ou[3], ov[3], oe[3];
-        const double twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
-        swe_flow_rhs<NONLIN, LF, SRC>(p, k, u, v, e, h, una, unb, vna, vnb, ena, enb, bmarkers, nx, ny, twoA, bu, bv, be);
         swe_flow_finish<NONLIN, LF>(p, k, q.beta[i3], u, v, e, h, nx, ny, twoA, bmarkers, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
 #ifdef SWE_WAVE_TIMING
         if (ou[0] == 1.2345e300) return;          // the arithmetic has to be finished before the time stamp
         SWE_FT(3);
 #endif
-        // ---- publish: write-through stores, drained by this (the only storing) wave, then the block's flag
-        if (act) {
-            const swe_rsrc_t gou = swe_rsrc(bout), gov = swe_rsrc(bout + 3*S), goe = swe_rsrc(bout + 6*S);
+        // ---- publish the rim traces: facet f carries my nodes f (granules 0-2) and f + 1 (granules 3-5), tag = stages done.
+        //      The values go to the staging area by slot, then the wave stores the block's whole slot range, consecutive lanes
+        //      on consecutive granules (full lines).  (A rim cell outside this stage's range leaves its entry as it was: its
+        //      slot gets a value nobody reads.)
+        if (s + 1 < q.n_stages) {
+            const unsigned tag = base + (unsigned)s + 1u;
+            const unsigned par = ((unsigned)s & 1u)*q.parity_bytes + (unsigned)myslots.x*SWE_FLOW_SLOT_BYTES;
+            __syncthreads();                                   // every lane has read its incoming traces
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                swe_st_sc1(gou, k8, i*S8, ou[i]);
-                swe_st_sc1(gov, k8, i*S8, ov[i]);
-                swe_st_sc1(goe, k8, i*S8, oe[i]);
+            for (int f = 0; f < 3; f++) {
+                if (xown[f] >= 0 && act) {
+                    const int a = f, b = (f + 1) % 3;
+                    double *d = lds + SWE_FLOW_XG + 6*xown[f];
+                    d[0] = ou[a]; d[1] = ov[a]; d[2] = oe[a]; d[3] = ou[b]; d[4] = ov[b]; d[5] = oe[b];
+                }
+            }
+            __syncthreads();
+            for (int t = lane; t < 8*nrim; t += SWE_BLOCK) {
+                const int gi = t & 7;
+                const double x = gi < 6 ? lds[SWE_FLOW_XG + 6*(t >> 3) + gi] : 0.0;
+                swe_flow_put(rex, par + 16u*(unsigned)t, x, tag);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- the step result (every third stage) goes to state buffer 0: read by later launches only
+        if (act && i3 == 2) {
+            const swe_rsrc_t gou = swe_rsrc(q.buf[0]), gov = swe_rsrc(q.buf[0] + 3*S), goe = swe_rsrc(q.buf[0] + 6*S);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                swe_st(gou, k8, i*S8, ou[i]);
+                swe_st(gov, k8, i*S8, ov[i]);
+                swe_st(goe, k8, i*S8, oe[i]);
+            }
+        }
         SWE_FT(4);
-#ifdef SWE_FLOW_LOCAL_EXPERIMENT
-        if (lane == 0 && s + 1 < q.n_stages) *(volatile unsigned *)(myflag + (size_t)q.n_blocks*SWE_FLOW_FLAG_STRIDE) = base + (unsigned)s + 1u;
-#endif
-        if (lane == 0 && s + 1 < q.n_stages) __hip_atomic_store(myflag, base + (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int i = 0; i < 3; i++) { u[i] = ou[i]; v[i] = ov[i]; e[i] = oe[i]; }
     }
-    // retired or finished: every flag of the handle ends the launch at base + n_stages
-    if (lane == 0) __hip_atomic_store(myflag, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // retired or finished: every block's counter ends the launch at base + n_stages
+    if (lane == 0) *myflag = fin;
 }

@@ -282,6 +282,8 @@ class ModelOptions2d(CommonModelOptions):
         ('use_automatic_wetting_and_drying_alpha', (False, _bool)),
         ('wetting_and_drying_alpha_min', (None, _any)),
         ('wetting_and_drying_alpha_max', (lambda: Constant(2.0), _any)),
+        # this build's explicit wetting-drying: factor applied to the automatic time step (not a reference option)
+        ('wetting_and_drying_cfl_factor', (0.4, _positive_float)),
         ('check_tracer_conservation', (False, _bool)),
         ('tracer_advective_velocity_factor', (lambda: Constant(1.0), _any)),
         ('check_tracer_overshoot', (False, _bool)),

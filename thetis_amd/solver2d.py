@@ -95,7 +95,9 @@ class FlowSolver2d(object):
                 # the explicit wetting-drying formulation carries waves of speed sqrt(g |H|) through dry ground
                 # (|H| up to 2.4 alpha) and was measured stable up to ~0.4-0.5 of this step on the reference's Thacker and
                 # Balzano set-ups (tests/test_wetting_drying.py)
-                self.dt *= 0.4
+                factor = float(getattr(self.options, 'wetting_and_drying_cfl_factor', 0.4))
+                self.dt *= factor
+                print_output('explicit wetting-drying: automatic dt scaled by wetting_and_drying_cfl_factor = {:g}'.format(factor))
         else:
             assert self.options.timestep is not None
             assert self.options.timestep > 0.0
