@@ -319,22 +319,14 @@ int  swe2d_solve_stage_cells(swe2d_handle *h, int i_stage, int32_t cell_begin, i
  * index).  Not capturable in a replayed graph across an odd number of swaps. */
 int  swe2d_forward_euler_cells(swe2d_handle *h, int32_t cell_begin, int32_t cell_end);
 int  swe2d_swap_state_buffers(swe2d_handle *h);
-/* A whole SSPRK33 step (rungekutta.py:316-339: the three solve_stage calls of ERKGenericShuOsher.advance) of the cells
- * [cell_begin, cell_end) in ONE launch (csrc/swe2d_step.h: the stages of a tile of cells stay on the compute unit), from state
- * buffer 0 into buffer 1: the cells of the range must have three valid layers of facet neighbours around them in buffer 0.
- * After the last range of a step swe2d_swap_state_buffers makes buffer 1 the state.  Bit for bit the result of the three
- * swe2d_solve_stage(_cells) calls.  Covers triangles without wetting-drying and viscosity (swe2d_fused_step_supported: 0 not
- * covered, 1 covered, 2 covered and without source terms; SWE2D_ERR_UNSUPPORTED otherwise); swe2d_advance uses it on its own where it applies (THETIS_AMD_FUSED_STEP=0: never). */
-int  swe2d_solve_step_cells(swe2d_handle *h, int32_t cell_begin, int32_t cell_end);
-/* builds (and keeps) the tile lists of a cell range without launching: the first swe2d_solve_step_cells of a range allocates,
- * which a stream capture does not allow */
-int  swe2d_prepare_step_cells(swe2d_handle *h, int32_t cell_begin, int32_t cell_end);
-int  swe2d_fused_step_supported(swe2d_handle *h);
 /* n_stages (a multiple of 3, at most 48) consecutive solve_stage calls - i.e. n_stages / 3 calls of ERKGenericShuOsher.advance
  * (rungekutta.py:949-952) - in ONE launch without a grid-wide barrier between the stages (csrc/swe2d_flow.h): stage s updates
- * the cells [0, cell_end[s]) (cell_end non-increasing: the shrinking ranges of a partition's exchange cycle, or n_owned
- * throughout), a 64-cell block starts stage s + 1 as soon as the blocks its facets touch have finished stage s.  Bit for bit
- * the result of the swe2d_solve_stage_cells calls it stands for.  Needs every block of the handle resident at once:
+ * the cells [0, cell_end[s]) (cell_end non-increasing, and every cell of stage s + 1's range has its facet neighbours inside
+ * stage s's range: the shrinking ranges of a partition's exchange cycle, or n_owned throughout), a 64-cell block starts stage
+ * s + 1 as soon as the trace values it needs from the blocks around it have arrived.  State buffer 0 (swe2d_get_state) ends bit for
+ * bit as the swe2d_solve_stage_cells calls it stands for leave it; the intermediate stage solutions (swe2d_get_stage_state 0, 1)
+ * are not produced.  swe2d_advance uses it on its own where it applies (THETIS_AMD_FLOW=0: never).  Needs every block of the
+ * handle resident at once:
  * swe2d_flow_supported returns 0 when the mesh is too large for that (or the configuration is not covered: quadrilaterals,
  * wetting-drying, viscosity), 1 covered, 2 covered and without source terms; SWE2D_ERR_UNSUPPORTED from swe2d_solve_flow
  * otherwise.  Every wait inside the kernel is bounded (THETIS_AMD_FLOW_TIMEOUT_S, default 2 s); a timeout invalidates the
@@ -342,6 +334,11 @@ int  swe2d_fused_step_supported(swe2d_handle *h);
  * (swe2d_flow_status reads the count without failing). */
 int  swe2d_solve_flow(swe2d_handle *h, int32_t n_stages, const int32_t *cell_end);
 int  swe2d_flow_supported(swe2d_handle *h);
+/* The kernel's 64-cell blocks are consecutive cells of a FLOW ORDER (default: the numbering of swe2d_mesh).  A partition whose
+ * ghost layers are appended to the numbering layer by layer (what the stage ranges need) passes an order - a permutation of
+ * the cell ids - in which every ghost cell sits next to the cells it touches: blocks then stay compact patches and few facets
+ * cross block rims.  Results do not depend on the order.  Synchronises the stream; not inside a stream capture. */
+int  swe2d_flow_set_order(swe2d_handle *h, const int32_t *cells_in_flow_order);
 int  swe2d_flow_status(swe2d_handle *h, int32_t *timeouts);
 int  swe2d_debug_flow_poke(swe2d_handle *h, int32_t block, int32_t delta);      /* test hook: skews one block's stage counter */
 /* run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the handle's own */

@@ -506,13 +506,12 @@ def test_ranks_on_one_gpu_with_peer_to_peer_halos(tmp_path, hip_lib, world, case
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('world,case,n_steps', [
-    (2, 'channel+fused', 3), (2, 'channel+every2+fused', 5), (2, 'channel+p2p+fused', 3), (3, 'channel+every3+p2p+fused+graph', 11),
-    (2, 'channel+every2+p2p+fused+nosplit+graph', 9), (2, 'channel+every4+p2p+fused+capture', 8), (3, 'delaunay+p2p+fused+graph', 2)])
-def test_ranks_on_one_gpu_with_one_launch_per_step(tmp_path, hip_lib, world, case, n_steps):
-    """fused_step: a cycle = m step-kernel launches on shrinking ranges (csrc/swe2d_step.h), the last one split around the send,
-    state buffers swapped on the host after every step - eager, host-staged and peer-to-peer, and replayed from per-cycle HIP
-    graphs (odd cycle lengths: the replay re-applies the swap, both buffer orientations get their own graph).  Bitwise the
-    single-device result."""
+    (2, 'channel+flow', 3), (2, 'channel+every2+flow', 5), (2, 'channel+p2p+flow', 3), (3, 'channel+every3+p2p+flow+graph', 11),
+    (2, 'channel+every2+p2p+flow+nosplit+graph', 9), (2, 'channel+every4+p2p+flow+capture', 8), (3, 'delaunay+p2p+flow+graph', 2)])
+def test_ranks_on_one_gpu_with_one_launch_per_cycle(tmp_path, hip_lib, world, case, n_steps):
+    """flow: the 3m stages of a cycle in ONE dataflow launch on the shrinking ranges (csrc/swe2d_flow.h; the blocks of the
+    launch follow a locality order over owned and ghost cells), then the exchange - eager, host-staged and peer-to-peer, and
+    replayed from per-cycle HIP graphs, with a shorter trailing cycle.  Bitwise the single-device result."""
     from thetis_amd.device import Swe2dDevice
     import dist_worker
     dist_worker.CASE = case.split('+')[0]

@@ -100,7 +100,34 @@ def test_flow_launch_on_shrinking_ranges(hip_lib, shape):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
-def test_flow_launch_on_the_ranges_of_a_partition(hip_lib):
+def test_results_do_not_depend_on_the_flow_order(hip_lib):
+    """Blocks of a random permutation of the cells (every facet a rim facet, blocks with 192 slots) and of a reversed order:
+    the same bits as the default blocks - and as the stage launches."""
+    mesh, bath, uv, eta = channel_case(nx=50, ny=21, seed=6)
+    rng = np.random.default_rng(3)
+    n = mesh.num_cells
+    out = []
+    for order in (None, 'stages', rng.permutation(n), np.arange(n)[::-1]):
+        dev = _device(mesh, bath, 0.05)
+        m = mesh.boundary_markers
+        dev.set_bc(m[0], {'elev': 0.1})
+        dev.set_state(uv, eta)
+        ends = [n]*9
+        if isinstance(order, str):
+            _by_stage(dev, ends)
+        else:
+            if order is not None:
+                dev.flow_set_order(order)
+            dev.solve_flow(ends)
+        out.append(dev.get_state())
+        assert dev.flow_timeouts() == 0
+        dev.close()
+    for o in out[1:]:
+        assert np.array_equal(out[0][0], o[0]) and np.array_equal(out[0][1], o[1])
+
+
+@pytest.mark.parametrize('flow_order', [False, True])
+def test_flow_launch_on_the_ranges_of_a_partition(hip_lib, flow_order):
     """One rank's cells of a strip partition with a six-layer halo (two time steps between exchanges): owned cells in the
     device's tile order, ghost layers appended, the stage ranges of partition.py."""
     from thetis_amd.device import Swe2dDevice
@@ -115,6 +142,9 @@ def test_flow_launch_on_the_ranges_of_a_partition(hip_lib):
                           ranges=part.reorder_ranges())
         dev.set_state(uv[g], eta[g])
         if flow:
+            if flow_order:          # ghost cells next to the owned cells they touch
+                from thetis_amd import ordering
+                dev.flow_set_order(ordering.auto_cell_order(part, 0, part.num_cells))
             dev.solve_flow(ends)
         else:
             _by_stage(dev, ends)

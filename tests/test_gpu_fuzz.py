@@ -142,15 +142,14 @@ def test_random_option_combinations_match_oracle(hip_lib, seed):
     u1, e1 = dev.get_state()
     uo, eo = orc.ssprk33_step(uv, eta, dt)
     assert rel_linf(u1, uo) < 10*TOL and rel_linf(e1, eo) < 10*TOL, desc
-    if dev.fused_step_supported():
-        # the whole step in one launch (csrc/swe2d_step.h) and three stage launches: the same bits for any option combination
+    if dev.flow_supported():
+        # two steps in one dataflow launch (csrc/swe2d_flow.h) and six stage launches: the same bits for any option combination
         dev.set_state(uv, eta)
-        for i in range(3):
-            dev.solve_stage(i)
+        for i in range(6):
+            dev.solve_stage(i % 3)
         us, es = dev.get_state()
         dev.set_state(uv, eta)
-        dev.solve_step_cells(0, mesh.num_cells)
-        dev.swap_state_buffers()
+        dev.solve_flow([mesh.num_cells]*6)
         uf, ef = dev.get_state()
         assert np.array_equal(us, uf) and np.array_equal(es, ef), desc
     dev.close()

@@ -110,13 +110,11 @@ SYMBOLS = {
     'swe2d_solve_stage_cells': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_forward_euler_cells': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_swap_state_buffers': (ctypes.c_int, [_H]),
-    'swe2d_solve_step_cells': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
-    'swe2d_fused_step_supported': (ctypes.c_int, [_H]),
     'swe2d_solve_flow': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_flow_supported': (ctypes.c_int, [_H]),
+    'swe2d_flow_set_order': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_flow_status': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_debug_flow_poke': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
-    'swe2d_prepare_step_cells': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_set_stream': (ctypes.c_int, [_H, ctypes.c_void_p]),
 }
 

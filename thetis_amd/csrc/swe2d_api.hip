@@ -3,7 +3,6 @@
 #include "../../include/swe2d.h"
 #include "swe2d_kernels.h"
 #include "swe2d_sipg.h"
-#include "swe2d_step.h"
 #include "swe2d_flow.h"
 #include "swe2d_p2p.h"
 
@@ -111,17 +110,14 @@ struct Handle {
     bool fuse_visc = true;                              // THETIS_AMD_NO_VISC_FUSION=1: separate SIPG pass (A/B, debugging)
     int4 *idx4 = nullptr;                               // packed triangle connectivity (stage kernel), see SweStageArgs
     int2 *idx2 = nullptr;
-    // fused SSPRK33 step (swe2d_step.h): host copy of the packed neighbour codes [3][S] and the tile lists per cell range
-    std::vector<int> h_nbr, h_cv;
-    struct StepTiles { int c0 = 0, c1 = 0, B = 0, n_tiles = 0; int4 *slot = nullptr; int2 *vert = nullptr; int4 *n = nullptr; };
-    std::vector<StepTiles> step_tiles;
-    int step_tile_cells = 128, step_block = 256;        // THETIS_AMD_STEP_TILE=C,B (B = 256 or 384: the instantiated workgroup sizes)
+    std::vector<int> h_nbr;                             // host copy of the packed neighbour codes [3][S] (triangles; flow_build)
     // dataflow stage loop (swe2d_flow.h): per-block stage counters, status word {timeouts, first late block + 1}
     unsigned *flow_flag = nullptr, *flow_status = nullptr;
     int4 *flow_xo4 = nullptr;                           // exchange slots of the rim facets (facets between two 64-cell blocks), see SweFlowArgs
     int2 *flow_xo2 = nullptr;
     int2 *flow_xblk = nullptr;
     int *flow_xsrc = nullptr;
+    int *flow_cell = nullptr;                           // [flow_blocks*64] flow position -> cell (< 0: padding lane, -1 - cell to mimic)
     unsigned flow_parity_bytes = 0;
     void *flow_ex = nullptr;
     size_t flow_ex_bytes = 0;
@@ -429,122 +425,102 @@ int stage_on_range(Handle *h, int i_stage, int c0, int c1)
 
 int grid_for(int n) { return (n + 255)/256; }
 
-// ---- fused SSPRK33 step (swe2d_step.h)
-typedef void (*step_kernel_t)(const SweStepArgs);
-template <bool NL, bool LF, int B>
-step_kernel_t pick_step_src(bool src) { return src ? swe_step_kernel<NL, LF, true, B> : swe_step_kernel<NL, LF, false, B>; }
-template <int B>
-step_kernel_t pick_step_b(bool nl, bool lf, bool src)
+// ---- dataflow stage loop (swe2d_flow.h): host tables
+// The kernel's 64-cell blocks are consecutive positions of a FLOW ORDER of the cells (default: the device numbering; a
+// partition passes an order in which its ghost layers - appended layer by layer to the numbering the stage ranges need - sit
+// next to the owned cells they touch, swe2d_flow_set_order).  Rim facets = interior facets whose two cells sit in different
+// blocks.  A block's exchange slots are contiguous and grouped by the block they face, so the chunk block A writes for block B
+// is contiguous and B reads it coalesced.
+int flow_build(Handle *h, const int32_t *order)
 {
-    return nl ? (lf ? pick_step_src<true, true, B>(src) : pick_step_src<true, false, B>(src))
-              : (lf ? pick_step_src<false, true, B>(src) : pick_step_src<false, false, B>(src));
-}
-step_kernel_t pick_step_kernel(bool nl, bool lf, bool src, int block)
-{
-    return block == 384 ? pick_step_b<384>(nl, lf, src) : pick_step_b<256>(nl, lf, src);
-}
-
-// the configurations the fused step kernel covers; everything else steps stage by stage (same bits)
-bool step_kernel_covers(const Handle *h)
-{
-    const char *e = std::getenv("THETIS_AMD_BND_INLINE");
-    return h->npc == 3 && !h->wd && !h->visc && !h->h_nbr.empty() && !(e && std::atoi(e) == 0);
-}
-
-// Tiles of the cells [c0, c1): C consecutive cells + three rings of facet neighbours; core + rings 1, 2 (the cells a stage is
-// computed on) take at most B slots, ring 3 (read only) may spill into SWE_STEP_EXTRA more.  The core shrinks where the rings
-// are large: ragged ends of the numbering, unstructured patches.  Built once per range, kept on the device.
-Handle::StepTiles *step_tiles_for(Handle *h, int c0, int c1)
-{
-    for (auto &t : h->step_tiles) if (t.c0 == c0 && t.c1 == c1) return &t;
-    const int B = h->step_block, XS = B + SWE_STEP_EXTRA, n = h->n_cells;
+    const int n = h->n_cells;
     const size_t S = h->stride;
-    const int *nbr = h->h_nbr.data(), *cv = h->h_cv.data();
-    std::vector<int> slot_of((size_t)n, -1), slots;
-    std::vector<int4> slot_rows, counts;
-    std::vector<int2> vert_rows;
-    auto grow = [&](int from, int to) {             // neighbours of slots [from, to) that have no slot yet
-        for (int j = from; j < to; j++)
-            for (int f = 0; f < 3; f++) {
-                const int code = nbr[(size_t)f*S + slots[j]];
-                if (code < 0) continue;
-                const int kn = code >> 2;
-                if (slot_of[kn] < 0) { slot_of[kn] = (int)slots.size(); slots.push_back(kn); }
-            }
-    };
-    int start = c0;
-    while (start < c1) {
-        int cnt = std::min(h->step_tile_cells, c1 - start);
-        int n1 = 0, n2 = 0, n3 = 0;
-        for (;;) {
-            slots.clear();
-            for (int i = 0; i < cnt; i++) { slot_of[start + i] = i; slots.push_back(start + i); }
-            grow(0, cnt);
-            n1 = (int)slots.size();
-            grow(cnt, n1);
-            n2 = (int)slots.size();
-            grow(n1, n2);
-            n3 = (int)slots.size();
-            if ((n2 <= B && n3 <= XS) || cnt == 1) break;
-            for (int kk : slots) slot_of[kk] = -1;
-            cnt = std::max(1, cnt*3/4);
-        }
-        if (n2 > B || n3 > XS) { for (int kk : slots) slot_of[kk] = -1; return nullptr; }      // a cell with hundreds of cells around it
-        const size_t base = slot_rows.size(), vbase = vert_rows.size();
-        slot_rows.resize(base + XS, int4{0, 0, 0, 0});
-        vert_rows.resize(vbase + B, int2{0, 0});
-        for (int j = 0; j < n3; j++) {
-            const int kk = slots[j];
-            unsigned w = 0;
-            int meta = 0;
-            for (int f = 0; f < 3; f++) {
-                const int code = nbr[(size_t)f*S + kk];
-                const int ls = code >= 0 ? slot_of[code >> 2] : -1;
-                w |= (ls >= 0 ? (unsigned)ls : SWE_STEP_NO_SLOT) << (10*f);
-                meta |= code < 0 ? ((-code) & 0xff) << (8*f) : 0;                   // boundary marker of the facet
-                meta |= (code >= 0 ? (code & 3) : f) << (24 + 2*f);                 // the neighbour's facet that faces this one
-            }
-            slot_rows[base + j] = int4{kk, (int)w, meta, cv[kk]};
-            if (j < n2) vert_rows[vbase + j] = int2{cv[S + kk], cv[2*S + kk]};
-        }
-        counts.push_back(int4{cnt, n1, n2, n3});
-        for (int kk : slots) slot_of[kk] = -1;
-        start += cnt;
+    if (h->npc != 3 || h->h_nbr.empty()) return SWE2D_OK;
+    const int *nbr = h->h_nbr.data();
+    const int nb = (n + SWE_BLOCK - 1)/SWE_BLOCK;
+    std::vector<int> fcell((size_t)nb*SWE_BLOCK, -1), fpos((size_t)n, -1);
+    for (int pp = 0; pp < n; pp++) {
+        const int c = order ? order[pp] : pp;
+        if (c < 0 || c >= n || fpos[c] >= 0) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "flow order: not a permutation of the cells");
+        fcell[pp] = c;
+        fpos[c] = pp;
     }
-    Handle::StepTiles t;
-    t.c0 = c0; t.c1 = c1; t.B = B; t.n_tiles = (int)counts.size();
-    if (hipMalloc(&t.slot, slot_rows.size()*sizeof(int4)) != hipSuccess || hipMalloc(&t.vert, vert_rows.size()*sizeof(int2)) != hipSuccess
-        || hipMalloc(&t.n, counts.size()*sizeof(int4)) != hipSuccess) return nullptr;
-    if (hipMemcpy(t.slot, slot_rows.data(), slot_rows.size()*sizeof(int4), hipMemcpyHostToDevice) != hipSuccess
-        || hipMemcpy(t.vert, vert_rows.data(), vert_rows.size()*sizeof(int2), hipMemcpyHostToDevice) != hipSuccess
-        || hipMemcpy(t.n, counts.data(), counts.size()*sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    if (h->step_tiles.size() >= 64) {               // ranges come from a fixed schedule; a caller that keeps inventing new ones recycles
-        auto &o = h->step_tiles.front();
-        (void)hipStreamSynchronize(h->stream);
-        (void)hipFree(o.slot); (void)hipFree(o.vert); (void)hipFree(o.n);
-        h->step_tiles.erase(h->step_tiles.begin());
+    for (int pp = n; pp < nb*SWE_BLOCK; pp++) fcell[pp] = -1 - fcell[n - 1];          // padding lanes mimic the last cell
+    struct Rim { int nbblock, pos, f; };
+    std::vector<int> own((size_t)3*nb*SWE_BLOCK, -1);                                // global slot of (position, f)
+    std::vector<int2> blk((size_t)nb, int2{0, 0});
+    int n_slots = 0;
+    std::vector<Rim> rim;
+    for (int b = 0; b < nb; b++) {
+        rim.clear();
+        for (int pp = b*SWE_BLOCK; pp < std::min(n, (b + 1)*SWE_BLOCK); pp++)
+            for (int f = 0; f < 3; f++) {
+                const int code = nbr[(size_t)f*S + fcell[pp]];
+                if (code >= 0 && fpos[code >> 2]/SWE_BLOCK != b) rim.push_back(Rim{fpos[code >> 2]/SWE_BLOCK, pp, f});
+            }
+        std::sort(rim.begin(), rim.end(), [](const Rim &x, const Rim &y) {
+            return x.nbblock != y.nbblock ? x.nbblock < y.nbblock : (x.pos != y.pos ? x.pos < y.pos : x.f < y.f); });
+        blk[b] = int2{n_slots, (int)rim.size()};
+        for (const Rim &r : rim) own[(size_t)3*r.pos + r.f] = n_slots++;
     }
-    h->step_tiles.push_back(t);
-    return &h->step_tiles.back();
-}
-
-// One SSPRK33 step of the cells [c0, c1): state buffer 0 -> state buffer 1 (the caller swaps the buffers when all ranges are done)
-int launch_step(Handle *h, int c0, int c1)
-{
-    if (c1 <= c0) return SWE2D_OK;
-    if (!step_kernel_covers(h)) return fail(h, SWE2D_ERR_UNSUPPORTED, "the fused step kernel covers triangles without wetting-drying and viscosity");
-    Handle::StepTiles *t = step_tiles_for(h, c0, c1);
-    if (!t) return fail(h, SWE2D_ERR_HIP, "fused step: tile lists could not be built");
-    SweStepArgs q;
-    fill_stage_args(h, q.st, 0, 0, 1, 0.0, 1.0, 1.0, c0, c1);
-    q.tile_slot = t->slot; q.tile_vert = t->vert; q.tile_n = t->n;
-    q.n_tiles = t->n_tiles; q.B = t->B;
-    for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
-    step_kernel_t kern = pick_step_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h), t->B);
-    const int grid = ((t->n_tiles + 7)/8)*8;
-    SWE_CHK_SYNC(h->stream);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(t->B), (size_t)9*(t->B + SWE_STEP_EXTRA)*sizeof(double), h->stream, q);
-    HIP_TRY(h, hipGetLastError());
+    // incoming list of a block: the slots its neighbours write for it, neighbour by neighbour in THEIR slot order;
+    // entry = producer's slot << 6 | lane of the consuming cell; xin(position, f) = place of the slot facing (position, f)
+    std::vector<int> xsrc((size_t)std::max(n_slots, 1), 0), xin((size_t)3*nb*SWE_BLOCK, -1);
+    std::vector<std::pair<int, int>> inc;                                            // (producer's slot, consumer position*4 + f)
+    for (int b = 0; b < nb; b++) {
+        inc.clear();
+        for (int pp = b*SWE_BLOCK; pp < std::min(n, (b + 1)*SWE_BLOCK); pp++)
+            for (int f = 0; f < 3; f++)
+                if (own[(size_t)3*pp + f] >= 0) {
+                    const int code = nbr[(size_t)f*S + fcell[pp]];
+                    inc.push_back({own[(size_t)3*fpos[code >> 2] + (code & 3)], (pp << 2) | f});
+                }
+        std::sort(inc.begin(), inc.end());                                           // by producer's slot = by neighbour block, then its order
+        for (size_t i = 0; i < inc.size(); i++) {
+            const int pp = inc[i].second >> 2, f = inc[i].second & 3;
+            xsrc[(size_t)blk[b].x + i] = (inc[i].first << 6) | (pp & (SWE_BLOCK - 1));
+            xin[(size_t)3*pp + f] = (int)i;
+        }
+    }
+    // per position: {my slot of facet 0, 1, 2 counted from the block's first (-1: not a rim facet), w}, {w, w} with w = place of the
+    // incoming slot (rim facet) or the lane of the neighbour inside the block (this lane itself for a boundary facet)
+    std::vector<int4> p4((size_t)nb*SWE_BLOCK, int4{-1, -1, -1, 0});
+    std::vector<int2> p2((size_t)nb*SWE_BLOCK, int2{0, 0});
+    for (int pp = 0; pp < nb*SWE_BLOCK; pp++) {
+        if (pp >= n) { p4[pp] = int4{-1, -1, -1, pp & (SWE_BLOCK - 1)}; p2[pp] = int2{pp & (SWE_BLOCK - 1), pp & (SWE_BLOCK - 1)}; continue; }
+        const int b0 = blk[pp/SWE_BLOCK].x;
+        int lo[3], w[3];
+        for (int f = 0; f < 3; f++) {
+            const int code = nbr[(size_t)f*S + fcell[pp]];
+            const int o = own[(size_t)3*pp + f];
+            lo[f] = o >= 0 ? o - b0 : -1;
+            w[f] = o >= 0 ? xin[(size_t)3*pp + f] : (code >= 0 ? (fpos[code >> 2] & (SWE_BLOCK - 1)) : (pp & (SWE_BLOCK - 1)));
+        }
+        p4[pp] = int4{lo[0], lo[1], lo[2], w[0]};
+        p2[pp] = int2{w[1], w[2]};
+    }
+    // (slot << 6 must fit an int, the exchange array must stay below SWE_FLOW_NOWHERE)
+    if (!((size_t)2*n_slots*SWE_FLOW_SLOT_BYTES < ((size_t)1 << 31) && n_slots < (1 << 25))) return SWE2D_OK;    // no flow kernel for this handle
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (void *ptr : {(void *)h->flow_xblk, (void *)h->flow_xsrc, (void *)h->flow_xo4, (void *)h->flow_xo2, (void *)h->flow_ex, (void *)h->flow_cell})
+        if (ptr) (void)hipFree(ptr);
+    h->flow_xblk = nullptr; h->flow_xsrc = nullptr; h->flow_xo4 = nullptr; h->flow_xo2 = nullptr; h->flow_ex = nullptr; h->flow_cell = nullptr;
+    h->flow_parity_bytes = (unsigned)((size_t)std::max(n_slots, 1)*SWE_FLOW_SLOT_BYTES);
+    h->flow_ex_bytes = (size_t)2*h->flow_parity_bytes;
+    HIP_TRY(h, hipMalloc(&h->flow_xblk, blk.size()*sizeof(int2)));
+    HIP_TRY(h, hipMemcpy(h->flow_xblk, blk.data(), blk.size()*sizeof(int2), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc(&h->flow_xsrc, xsrc.size()*sizeof(int)));
+    HIP_TRY(h, hipMemcpy(h->flow_xsrc, xsrc.data(), xsrc.size()*sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc(&h->flow_cell, fcell.size()*sizeof(int)));
+    HIP_TRY(h, hipMemcpy(h->flow_cell, fcell.data(), fcell.size()*sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc(&h->flow_xo4, p4.size()*sizeof(int4)));
+    HIP_TRY(h, hipMalloc(&h->flow_xo2, p2.size()*sizeof(int2)));
+    HIP_TRY(h, hipMemcpy(h->flow_xo4, p4.data(), p4.size()*sizeof(int4), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->flow_xo2, p2.data(), p2.size()*sizeof(int2), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc(&h->flow_ex, h->flow_ex_bytes));
+    HIP_TRY(h, hipMemset(h->flow_ex, 0, h->flow_ex_bytes));
+    // the stage counters restart with the slots
+    HIP_TRY(h, hipMemset(h->flow_flag, 0, (size_t)h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned)));
     return SWE2D_OK;
 }
 
@@ -597,6 +573,7 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end)
     q.flag = h->flow_flag; q.status = h->flow_status;
     q.xo4 = h->flow_xo4; q.xo2 = h->flow_xo2; q.ex = h->flow_ex;
     q.xblk = h->flow_xblk; q.xsrc = h->flow_xsrc; q.parity_bytes = h->flow_parity_bytes;
+    q.fcell = h->flow_cell;
     q.n_blocks = h->flow_blocks; q.n_stages = n_stages;
     for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) q.cell_end[s] = s < n_stages ? cell_end[s] : 0;
     for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
@@ -793,13 +770,6 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
 
     if (npc == 3) {
         h->h_nbr = nbr;
-        h->h_cv = cv;
-        if (const char *st = std::getenv("THETIS_AMD_STEP_TILE")) {
-            int c = 0, b = 0;
-            if (std::sscanf(st, "%d,%d", &c, &b) == 2 && c >= 1 && b >= c && (b == 256 || b == 384)) {
-                h->step_tile_cells = c; h->step_block = b;
-            }
-        }
         std::vector<int4> p4((size_t)S, int4{0, 0, 0, 0});
         std::vector<int2> p2((size_t)S, int2{0, 0});
         for (int kk = 0; kk < n; kk++) {
@@ -839,68 +809,7 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
         HIP_TRY_C(hipMalloc(&h->flow_status, 2*sizeof(unsigned)));
         HIP_TRY_C(hipMemset(h->flow_flag, 0, (size_t)h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned)));
         HIP_TRY_C(hipMemset(h->flow_status, 0, 2*sizeof(unsigned)));
-        {
-            // rim facets: interior facets whose two cells sit in different 64-cell blocks.  A block's slots are contiguous and
-            // grouped by the block they face (so the chunk block A writes for block B is contiguous: B reads it coalesced).
-            struct Rim { int nbblock, k, f; };
-            std::vector<int> own((size_t)3*S, -1);                               // global slot of (k, f)
-            std::vector<int2> blk((size_t)h->flow_blocks, int2{0, 0});
-            int n_slots = 0;
-            std::vector<Rim> rim;
-            for (int b = 0; b < h->flow_blocks; b++) {
-                rim.clear();
-                for (int kk = b*SWE_BLOCK; kk < std::min(n, (b + 1)*SWE_BLOCK); kk++)
-                    for (int f = 0; f < 3; f++) {
-                        const int code = nbr[(size_t)f*S + kk];
-                        if (code >= 0 && (code >> 2)/SWE_BLOCK != b) rim.push_back(Rim{(code >> 2)/SWE_BLOCK, kk, f});
-                    }
-                std::sort(rim.begin(), rim.end(), [](const Rim &x, const Rim &y) {
-                    return x.nbblock != y.nbblock ? x.nbblock < y.nbblock : (x.k != y.k ? x.k < y.k : x.f < y.f); });
-                blk[b] = int2{n_slots, (int)rim.size()};
-                for (const Rim &r : rim) own[(size_t)r.f*S + r.k] = n_slots++;
-            }
-            // incoming list of a block: the slots its neighbours write for it, neighbour by neighbour in THEIR slot order;
-            // entry = producer's slot << 6 | lane of the consuming cell; xin(k, f) = position of the slot facing (k, f)
-            std::vector<int> xsrc((size_t)std::max(n_slots, 1), 0), xin((size_t)3*S, -1);
-            std::vector<std::pair<int, int>> inc;                                // (producer's slot, consumer (k << 2 | f))
-            for (int b = 0; b < h->flow_blocks; b++) {
-                inc.clear();
-                for (int kk = b*SWE_BLOCK; kk < std::min(n, (b + 1)*SWE_BLOCK); kk++)
-                    for (int f = 0; f < 3; f++)
-                        if (own[(size_t)f*S + kk] >= 0) {
-                            const int code = nbr[(size_t)f*S + kk];
-                            inc.push_back({own[(size_t)(code & 3)*S + (code >> 2)], (kk << 2) | f});
-                        }
-                std::sort(inc.begin(), inc.end());                               // by producer's slot = by neighbour block, then its order
-                for (size_t i = 0; i < inc.size(); i++) {
-                    const int kk = inc[i].second >> 2, f = inc[i].second & 3;
-                    xsrc[(size_t)blk[b].x + i] = (inc[i].first << 6) | (kk & (SWE_BLOCK - 1));
-                    xin[(size_t)f*S + kk] = (int)i;
-                }
-            }
-            for (int kk = 0; kk < n; kk++) {
-                const int b0 = blk[kk/SWE_BLOCK].x;
-                int lo[3];
-                for (int f = 0; f < 3; f++) lo[f] = own[(size_t)f*S + kk] >= 0 ? own[(size_t)f*S + kk] - b0 : -1;
-                p4[kk] = int4{lo[0], lo[1], lo[2], xin[kk]};
-                p2[kk] = int2{xin[S + kk], xin[2*S + kk]};
-            }
-            // (slot << 6 must fit an int, the exchange array must stay below SWE_FLOW_NOWHERE)
-            if ((size_t)2*n_slots*SWE_FLOW_SLOT_BYTES < ((size_t)1 << 31) && n_slots < (1 << 25)) {      // else: no flow kernel for this handle
-                h->flow_parity_bytes = (unsigned)((size_t)std::max(n_slots, 1)*SWE_FLOW_SLOT_BYTES);
-                h->flow_ex_bytes = (size_t)2*h->flow_parity_bytes;
-                HIP_TRY_C(hipMalloc(&h->flow_xblk, blk.size()*sizeof(int2)));
-                HIP_TRY_C(hipMemcpy(h->flow_xblk, blk.data(), blk.size()*sizeof(int2), hipMemcpyHostToDevice));
-                HIP_TRY_C(hipMalloc(&h->flow_xsrc, xsrc.size()*sizeof(int)));
-                HIP_TRY_C(hipMemcpy(h->flow_xsrc, xsrc.data(), xsrc.size()*sizeof(int), hipMemcpyHostToDevice));
-                HIP_TRY_C(hipMalloc(&h->flow_xo4, (size_t)S*sizeof(int4)));
-                HIP_TRY_C(hipMalloc(&h->flow_xo2, (size_t)S*sizeof(int2)));
-                HIP_TRY_C(hipMemcpy(h->flow_xo4, p4.data(), (size_t)S*sizeof(int4), hipMemcpyHostToDevice));
-                HIP_TRY_C(hipMemcpy(h->flow_xo2, p2.data(), (size_t)S*sizeof(int2), hipMemcpyHostToDevice));
-                HIP_TRY_C(hipMalloc(&h->flow_ex, h->flow_ex_bytes));
-                HIP_TRY_C(hipMemset(h->flow_ex, 0, h->flow_ex_bytes));
-            }
-        }
+        if (int rc = flow_build(h, nullptr)) { g_create_error = h->err; swe2d_destroy(reinterpret_cast<swe2d_handle *>(h)); return rc; }
         if (const char *e = std::getenv("THETIS_AMD_FLOW_TIMEOUT_S")) { const double t = std::atof(e); if (t > 0.0) h->flow_timeout_s = t; }
     }
     HIP_TRY_C(hipMemcpyAsync(h->nbr, nbr.data(), (size_t)npc*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -931,11 +840,10 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
     for (void *m : h->p2p.opened) (void)hipIpcCloseMemHandle(m);
-    for (auto &t : h->step_tiles) { if (t.slot) (void)hipFree(t.slot); if (t.vert) (void)hipFree(t.vert); if (t.n) (void)hipFree(t.n); }
     if (h->p2p.zone) (void)hipFree(h->p2p.zone);
     if (h->p2p.ctr) (void)hipFree(h->p2p.ctr);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1284,15 +1192,13 @@ int swe2d_advance(swe2d_handle *hh, int n_steps)
         return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_advance on a partition: drive stages + halo exchange from the host");
     HIP_TRY(h, hipSetDevice(h->device));
     RoctxRange range("swe2d_advance");
-    // The whole step in one launch (swe2d_step.h) where that is the faster path: small meshes.  Same box, us/step, three stage
-    // launches -> one step launch (128-cell tiles): 2.5 k cells 17.3 -> 14.0, 10 k 16.8 -> 14.1, 31 k 18.0 -> 13.3, 62 k 20.3 ->
-    // 17.0, 90 k 24.1 -> 22.2, 125 k 24.4 -> 25.5, 1 M 124 -> 135: beyond ~100 k cells throughput counts, and the redundant ring
-    // work of the tiles costs more FP64 issue time than the launches and the HBM traffic it saves are worth.  THETIS_AMD_FUSED_STEP=0 / 1 forces the choice (both give the same bits).
-    // Many steps in one launch without grid barriers (swe2d_flow.h) where every 64-cell block of the mesh is resident at once.
-    // THETIS_AMD_FLOW=0 / 1 forces the choice (the same bits either way).
+    // Up to 16 steps per launch without grid barriers (swe2d_flow.h) where every 64-cell block of the mesh is resident at once
+    // (<= 131 k cells) and the kernel covers the configuration.  Same box, us/step, three stage launches per step -> flow launches:
+    // 15 k cells 16.5 -> 15.3, 62 k 20.1 -> 15.1, 125 k 24.3 -> 18.3 (the one-launch step kernel of round 2, which this replaces:
+    // 14.1 / 16.8 / 24.9).  THETIS_AMD_FLOW=0 selects the stage launches (the same bits either way).
     {
         const char *env_fl = std::getenv("THETIS_AMD_FLOW");
-        const bool want = env_fl ? std::atoi(env_fl) != 0 : false;
+        const bool want = env_fl ? std::atoi(env_fl) != 0 : true;
         if (want && n_steps > 0 && flow_kernel_covers(h) && ((h->flow_blocks + 7)/8)*8 <= flow_capacity(h)) {
             int32_t ends[SWE_FLOW_MAX_STAGES];
             for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) ends[s] = h->n_owned;
@@ -1305,49 +1211,12 @@ int swe2d_advance(swe2d_handle *hh, int n_steps)
             return SWE2D_OK;
         }
     }
-    const char *env_fs = std::getenv("THETIS_AMD_FUSED_STEP");
-    const bool fused = env_fs ? std::atoi(env_fs) != 0 : (h->n_owned <= 80000 && !has_sources(h));
-    if (fused && step_kernel_covers(h)) {
-        for (int it = 0; it < n_steps; it++) {
-            int rc = launch_step(h, 0, h->n_owned);
-            if (rc) return rc;
-            std::swap(h->state[0], h->state[1]);
-        }
-        return SWE2D_OK;
-    }
     for (int it = 0; it < n_steps; it++)
         for (int s = 0; s < 3; s++) {
             int rc = stage_on_range(h, s, 0, h->n_owned);
             if (rc) return rc;
         }
     return SWE2D_OK;
-}
-
-int swe2d_solve_step_cells(swe2d_handle *hh, int32_t cell_begin, int32_t cell_end)
-{
-    Handle *h = H(hh);
-    if (!h || cell_begin < 0 || cell_end > h->n_cells || cell_begin > cell_end)
-        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell range");
-    HIP_TRY(h, hipSetDevice(h->device));
-    return launch_step(h, cell_begin, cell_end);
-}
-
-int swe2d_prepare_step_cells(swe2d_handle *hh, int32_t cell_begin, int32_t cell_end)
-{
-    Handle *h = H(hh);
-    if (!h || cell_begin < 0 || cell_end > h->n_cells || cell_begin > cell_end)
-        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell range");
-    if (cell_end == cell_begin) return SWE2D_OK;
-    if (!step_kernel_covers(h)) return fail(h, SWE2D_ERR_UNSUPPORTED, "the fused step kernel covers triangles without wetting-drying and viscosity");
-    HIP_TRY(h, hipSetDevice(h->device));
-    return step_tiles_for(h, cell_begin, cell_end) ? SWE2D_OK : fail(h, SWE2D_ERR_HIP, "fused step: tile lists could not be built");
-}
-
-int swe2d_fused_step_supported(swe2d_handle *hh)
-{
-    Handle *h = H(hh);
-    if (!h || !step_kernel_covers(h)) return 0;
-    return has_sources(h) ? 1 : 2;          // 2: covered and without source terms (where it is the faster path on small meshes)
 }
 
 int swe2d_solve_flow(swe2d_handle *hh, int32_t n_stages, const int32_t *cell_end)
@@ -1357,6 +1226,16 @@ int swe2d_solve_flow(swe2d_handle *hh, int32_t n_stages, const int32_t *cell_end
     HIP_TRY(h, hipSetDevice(h->device));
     RoctxRange range("swe2d_solve_flow");
     return launch_flow(h, n_stages, cell_end);
+}
+
+int swe2d_flow_set_order(swe2d_handle *hh, const int32_t *cells_in_flow_order)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (!h->flow_flag) return fail(h, SWE2D_ERR_UNSUPPORTED, "the flow kernel covers triangles");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc = flow_check(h)) return rc;
+    return flow_build(h, cells_in_flow_order);
 }
 
 int swe2d_flow_supported(swe2d_handle *hh)

@@ -74,8 +74,10 @@ struct SweFlowArgs {
     double *buf[3];                        // state buffers A (U0 / step result), B, C (B, C are not touched)
     unsigned *flag;                        // [n_blocks][SWE_FLOW_FLAG_STRIDE] stages counted by the block over all launches
     unsigned *status;                      // [0] timeouts, [1] first block that timed out + 1
-    const int4 *xo4;                       // per cell, counted from the block's first slot: {my slot of facet 0, 1, 2 (-1: not a rim
-    const int2 *xo2;                       //  facet), position of facet 0's incoming slot in the block's incoming list}, {... of facets 1, 2}
+    const int *fcell;                      // [n_blocks*64] the cell of every flow position (block*64 + lane); < 0: padding lane, mimics cell -1 - x
+    const int4 *xo4;                       // per position, counted from the block's first slot: {my slot of facet 0, 1, 2 (-1: not a rim facet),
+    const int2 *xo2;                       //  w0}, {w1, w2}: w = place of the facet's incoming slot in the block's incoming list (rim facet) or the
+                                           //  lane of the neighbour inside the block (the lane itself for a boundary facet)
     const int2 *xblk;                      // per block {first slot, number of slots}: a block's slots are contiguous
     const int *xsrc;                       // [n_slots] incoming list of every block at its own slot range: entry i = (slot the
                                            //  neighbour block writes for my i-th incoming facet) << 6 | lane of my cell that reads it
@@ -272,22 +274,23 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 #pragma clang fp contract(off)
     __shared__ double lds[SWE_FLOW_LDS_DOUBLES];
     __shared__ int xsrc[SWE_FLOW_MAX_RIM];                     // the block's incoming list (SweFlowArgs::xsrc)
+    __shared__ int lact[SWE_BLOCK];                            // is the lane's cell inside the running stage's range?
     const SweStageArgs &p = q.st;
     const int lb = swe_logical_block(blockIdx.x, gridDim.x);
     if (lb >= q.n_blocks) return;                              // padding of the grid to a multiple of 8
     const int lane = (int)threadIdx.x;
-    const int kraw = lb*SWE_BLOCK + lane;
+    const int kcode = q.fcell[lb*SWE_BLOCK + lane];
+    const bool real = kcode >= 0;                              // padding lanes mimic a cell: finite values, never stored or published
+    const int k = real ? kcode : -1 - kcode;
     const size_t S = p.stride;
     const unsigned S8 = (unsigned)S*8u;
     unsigned *const myflag = q.flag + (size_t)lb*SWE_FLOW_FLAG_STRIDE;
     const unsigned base = *myflag;                             // stages counted so far: written by this block's wave in the previous launch
     const unsigned fin = base + (unsigned)q.n_stages;
-    if (lb*SWE_BLOCK >= q.cell_end[0]) {                       // this block takes part in no stage of the launch
+    if (!__any(real && k < q.cell_end[0])) {                   // this block takes part in no stage of the launch
         if (lane == 0) *myflag = fin;
         return;
     }
-    // lanes beyond the first stage's range mimic the range's last cell: finite values, never stored or published
-    const int k = min(kraw, q.cell_end[0] - 1);
     const unsigned k8 = (unsigned)k*8u;
     // bounds-checked resource: a load from SWE_FLOW_NOWHERE costs no memory access
     const __amdgpu_buffer_rsrc_t rex = __builtin_amdgcn_make_buffer_rsrc(q.ex, 0, 2*q.parity_bytes, 0x00020000);
@@ -304,8 +307,8 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
     {
         const int4 q4 = p.idx4[k];
         const int2 q2 = p.idx2[k];
-        const int4 x4 = q.xo4[k];
-        const int2 x2 = q.xo2[k];
+        const int4 x4 = q.xo4[lb*SWE_BLOCK + lane];
+        const int2 x2 = q.xo2[lb*SWE_BLOCK + lane];
         const int nb[3] = {q4.x, q4.y, q4.z};
         const int vid[3] = {q4.w, q2.x, q2.y};
         const int xin[3] = {x4.w, x2.x, x2.y};
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             const bool rim = xown[f] >= 0;                                 // interior facet whose neighbour lives in another block
             const bool inw = nbf >= 0 && !rim;
             // the neighbour traverses the shared facet backwards: its node f2 sits on my node f + 1, its node (f2 + 1) % 3 on my node f
-            const int ls = inw ? ((nbf >> 2) & (SWE_BLOCK - 1)) : lane;
+            const int ls = rim ? lane : xin[f];
             const int f2 = inw ? (nbf & 3) : f, f2a = f2 == 2 ? 0 : f2 + 1;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -376,8 +379,8 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 #pragma unroll 1
     for (int s = 0; s < q.n_stages; s++) {
         const int end_s = q.cell_end[s];
-        if (lb*SWE_BLOCK >= end_s) break;                      // retired: the ranges only shrink
-        const bool act = kraw < end_s;
+        const bool act = real && k < end_s;
+        if (!__any(act)) break;                                // retired: the ranges only shrink
         const int i3 = s % 3;
         SWE_FT(0);
 #ifdef SWE_WAVE_TIMING
@@ -394,6 +397,8 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 #pragma unroll
         for (int i = 0; i < 3; i++) asm volatile("" : "+v"(nx[i]), "+v"(ny[i]), "+v"(h[i]));
         asm volatile("" : "+v"(bmarkers));
+#pragma unroll
+        for (int f = 0; f < 3; f++) asm volatile("" : "+v"(tr[f][0]), "+v"(tr[f][1]), "+v"(tr[f][2]));
         if (i3 == 0) {
 #pragma unroll
             for (int i = 0; i < 3; i++) { u0[i] = u[i]; v0[i] = v[i]; e0[i] = e[i]; }
@@ -401,6 +406,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
         // ---- the block's stage values for its own lanes
 #pragma unroll
         for (int i = 0; i < 3; i++) { lds[i*SWE_BLOCK + lane] = u[i]; lds[(3 + i)*SWE_BLOCK + lane] = v[i]; lds[(6 + i)*SWE_BLOCK + lane] = e[i]; }
+        lact[lane] = act ? 1 : 0;
         // ---- traces across the rim: the chunks the neighbour blocks wrote for this block, consecutive lanes on consecutive
         //      granules, re-read until every granule a cell of this stage's range needs carries this stage's tag
         if (s > 0) {
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                         const int t = c0 + j*SWE_BLOCK + lane;
                         ent[j] = t < 8*nrim ? xsrc[t >> 3] : -1;
                         // a cell outside this stage's range needs nothing (and its neighbour may never have published)
-                        if (ent[j] >= 0 && lb*SWE_BLOCK + (ent[j] & (SWE_BLOCK - 1)) >= end_s) ent[j] = -1;
+                        if (ent[j] >= 0 && !lact[ent[j] & (SWE_BLOCK - 1)]) ent[j] = -1;
                         g[j] = swe_flow_get(rex, ent[j] >= 0 ? (unsigned)(ent[j] >> 6)*SWE_FLOW_SLOT_BYTES + 16u*(unsigned)(t & 7) + par
                                                              : SWE_FLOW_NOWHERE);
                     }

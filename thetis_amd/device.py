@@ -390,20 +390,20 @@ class Swe2dDevice(object):
     def swap_state_buffers(self):
         self._ck(self.lib.swe2d_swap_state_buffers(self.h))
 
-    def solve_step_cells(self, cell_begin, cell_end):
-        """A whole SSPRK33 step of device cells [cell_begin, cell_end) in one launch, state buffer 0 -> buffer 1 (the caller
-        swaps the buffers after the last range); bit for bit the three ``solve_stage_cells`` calls."""
-        self._ck(self.lib.swe2d_solve_step_cells(self.h, int(cell_begin), int(cell_end)))
-
-    def prepare_step_cells(self, cell_begin, cell_end):
-        """Build the tile lists of a range ahead of its first ``solve_step_cells`` (which must not allocate inside a capture)."""
-        self._ck(self.lib.swe2d_prepare_step_cells(self.h, int(cell_begin), int(cell_end)))
-
     def solve_flow(self, cell_ends):
         """``len(cell_ends)`` (a multiple of 3) consecutive stages in ONE launch without grid-wide barriers (csrc/swe2d_flow.h):
         stage s updates the device cells [0, cell_ends[s]); bit for bit the ``solve_stage_cells`` calls it stands for."""
         ends = np.ascontiguousarray(cell_ends, dtype=np.int32)
         self._ck(self.lib.swe2d_solve_flow(self.h, int(len(ends)), _iptr(ends)))
+
+    def flow_set_order(self, cells_in_flow_order):
+        """The flow kernel's blocks = consecutive cells of this order (a permutation of the caller's cell ids; default: the
+        device numbering).  For partitions: an order in which the ghost cells sit next to the owned cells they touch."""
+        order = np.asarray(cells_in_flow_order, dtype=np.int64)
+        if self.perm is not None:
+            order = self.inv_perm[order]
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        self._ck(self.lib.swe2d_flow_set_order(self.h, _iptr(order)))
 
     def flow_supported(self):
         """0: the flow kernel does not cover this handle (configuration, or more 64-cell blocks than the device holds
@@ -414,14 +414,6 @@ class Swe2dDevice(object):
         n = ctypes.c_int32()
         self._ck(self.lib.swe2d_flow_status(self.h, ctypes.byref(n)))
         return n.value
-
-    def fused_step_supported(self):
-        """True where the one-launch step kernel covers the current configuration (triangles, no wetting-drying, no viscosity)."""
-        return bool(self.lib.swe2d_fused_step_supported(self.h))
-
-    def fused_step_preferred(self):
-        """... and no source terms are set: the configuration where it is the faster path on small meshes."""
-        return self.lib.swe2d_fused_step_supported(self.h) == 2
 
     def advance_timed(self, n_steps, per_launch=False):
         """Returns (total ms, mean ms per stage-kernel launch), measured with HIP events on the launch stream."""

@@ -178,7 +178,7 @@ class DistributedSwe2d(object):
     def __init__(self, mesh, bathymetry_vertex, dt, rank, world_size, device_id, owner=None, host_staged=False,
                  n_tracers=0, use_limiter=True, tracer_only=False, exchange_every=1, overlap_stages=0,
                  graph_mode=None, stepper='SSPRK33', exchange=None, split_last_stage=True, group=None, partition=None,
-                 combined_exchange=False, fused_step=None, flow=None, **opts):
+                 combined_exchange=False, flow=None, **opts):
         """``n_tracers`` > 0: the coupled step of GeneralCoupledTimeIntegrator2D.advance (coupled_timeintegrator_2d.py:
         93-113) on the partition - shallow water step, then every tracer with the updated velocity, then the limiter.
         The vertex-based limiter needs every cell around a vertex, so coupled runs with the limiter use four ghost layers
@@ -204,14 +204,6 @@ class DistributedSwe2d(object):
         numbering (LocalPartition.owned_prefix) - and completes those stages on the remaining wedge (cells at distance
         <= g + 1 and the ghost layers) after the unpack.  Disjoint read / write sets (a late stage g reads distance
         <= g + 2, an early stage g' > g writes distance >= g' + 2), bitwise the same result.
-
-        ``fused_step``: the whole SSPRK33 step of a cell range in ONE launch (csrc/swe2d_step.h; bit for bit the three stage
-        launches) instead of one launch per stage: None = where it is the faster path (eager launches - graph_mode 'none' -,
-        shallow water only, triangles without wetting-drying / viscosity / source terms, at most 80 k owned cells, no
-        ``overlap_stages``; in replayed graphs the stage launches have no host gaps and win), True = wherever the
-        kernel covers the configuration, False = never.  A cycle is then m step launches on shrinking ranges; the step
-        result lands in the other state buffer, so the buffers are swapped on the host after every step (a replayed graph
-        re-applies the swaps it stands for).
 
         ``flow``: the 3m stages of a cycle as ONE launch without grid-wide barriers (csrc/swe2d_flow.h: a 64-cell block starts
         its next stage as soon as the blocks around it have finished the previous one; bit for bit the stage launches),
@@ -271,9 +263,12 @@ class DistributedSwe2d(object):
         self.dev = Swe2dDevice(p, np.asarray(bathymetry_vertex)[p.vertex_global], dt, device_id=device_id,
                                n_owned=p.n_owned, boundary_len=p.boundary_len, ranges=p.reorder_ranges(), **opts)
         self.dev.halo_setup(p.send_cells, p.recv_cells)
-        self._fused_request = fused_step
         self._flow_request = flow
-        self._flip = 0                       # parity of the state-buffer swaps (fused steps): graphs hold absolute pointers
+        if flow is not False and self.dev.flow_supported():
+            # the flow kernel's blocks: all local cells (owned + ghost layers) in one locality order, so that a ghost cell
+            # shares its block with the cells it touches
+            from . import ordering
+            self.dev.flow_set_order(ordering.auto_cell_order(p, 0, p.num_cells))
         self._ranges = [p.stage_range(i) for i in range(3)]
         self.tids = [self.dev.add_tracer() for _ in range(n_tracers)]
         self.halo = self.thalo = self.p2p = None
@@ -304,26 +299,9 @@ class DistributedSwe2d(object):
         self.dev.close()
 
     @property
-    def fused(self):
-        """True when a cycle runs as one launch per step (see ``fused_step``); evaluated per call: the device configuration
-        (source terms, viscosity, wetting-drying) may be set after construction."""
-        if self._fused_request is False:
-            return False
-        plain = (self.stages_per_step == 3 and not self.tids and not self.tracer_only and self.overlap_stages == 0)
-        if not plain or not self.dev.fused_step_supported():
-            if self._fused_request is True:
-                raise ValueError('fused_step=True: the step kernel covers SSPRK33 shallow-water-only runs on triangles without '
-                                 'wetting-drying, viscosity and overlap_stages')
-            return False
-        if self._fused_request is True:
-            return True
-        # inside replayed graphs the stage launches have no host gaps and the step kernel loses its advantage (measured per
-        # rank, p2p, m = 4: 62 k cells 24.9 us/step stage-wise vs 26.6 fused, 31 k 20.1 vs 20.1): eager launches only
-        return self.graph_mode == 'none' and self.part.n_owned <= 80000 and self.dev.fused_step_preferred()
-
-    @property
     def flow(self):
-        """True when a cycle runs as one dataflow launch (see ``flow``); evaluated per call like ``fused``."""
+        """True when a cycle runs as one dataflow launch (see ``flow``); evaluated per call: the device configuration (source
+        terms, viscosity, wetting-drying) may be set after construction."""
         if self._flow_request is False or os.environ.get('THETIS_AMD_FLOW') == '0':
             return False
         plain = (self.stages_per_step == 3 and not self.tids and not self.tracer_only and self.overlap_stages == 0
@@ -349,53 +327,6 @@ class DistributedSwe2d(object):
         self._launch(('WA', n_steps), lambda: dev.solve_flow(ends), graphed)
         dev.halo_pack(0, self.halo.send_buf.data_ptr())
         reqs = self.halo.start()
-        self.halo.finish(reqs)
-        dev.halo_unpack(0, self.halo.recv_buf.data_ptr())
-
-    def _swap(self):
-        self.dev.swap_state_buffers()
-        self._flip ^= 1
-
-    def _cycle_swe_fused(self, n_steps, graphed):
-        """``n_steps`` time steps as one step-kernel launch each (state buffer 0 -> 1, then the host swaps the buffers) on the
-        shrinking ranges that stay exact, the last one split around the send like the last stage of the stage-wise cycle."""
-        dev, p = self.dev, self.part
-        if graphed and ('FP', n_steps, self._flip) not in self._cycle_graphs:
-            # the tile lists of the ranges are built at their first launch: not inside the capture that follows
-            for s in range(n_steps - 1):
-                dev.prepare_step_cells(0, p.stage_range(3*s + 2, depth=3*n_steps))
-            for a, b in ((p.n_interior, p.n_owned), (0, p.n_interior), (0, p.n_owned)):
-                dev.prepare_step_cells(a, b)
-
-        def before():
-            for s in range(n_steps - 1):
-                dev.solve_step_cells(0, p.stage_range(3*s + 2, depth=3*n_steps))
-                self._swap()
-            if self.split_last_stage:
-                dev.solve_step_cells(p.n_interior, p.n_owned)      # the cells the peers are waiting for
-            else:
-                dev.solve_step_cells(0, p.n_owned)
-
-        def during():
-            if self.split_last_stage:
-                dev.solve_step_cells(0, p.n_interior)
-            self._swap()                                           # buffer 0 is the new state; its ghosts arrive next
-
-        if self.p2p is not None:
-            def whole_cycle():
-                before()
-                dev.p2p_push(0, 1)                                 # the step result still sits in buffer 1
-                during()
-                dev.p2p_wait_unpack(0, 0)
-            ran = self._launch(('FP', n_steps, self._flip), whole_cycle, graphed)
-            if not ran:                                            # a replay: the swaps the graph stands for
-                for _ in range(n_steps % 2):
-                    self._swap()
-            return
-        before()                                                   # host-staged / RCCL exchange: eager launches
-        dev.halo_pack(1, self.halo.send_buf.data_ptr())
-        reqs = self.halo.start()
-        during()
         self.halo.finish(reqs)
         dev.halo_unpack(0, self.halo.recv_buf.data_ptr())
 
@@ -483,10 +414,8 @@ class DistributedSwe2d(object):
         ``early_next``: stages of the next cycle to run (ghost-independent part only) during this cycle's exchange."""
         if self.stages_per_step == 1:
             return self._cycle_forward_euler(n_steps)
-        if self.flow and not self._fused_request:
+        if self.flow:
             return self._cycle_swe_flow(n_steps, graphed)
-        if self.fused:
-            return self._cycle_swe_fused(n_steps, graphed)
         if self.p2p is not None:
             # the exchange is two kernels of this library: the whole cycle is one capturable launch sequence
             def whole_cycle():
@@ -544,7 +473,6 @@ class DistributedSwe2d(object):
         ran = False
         g = self._cycle_graphs.get(key)
         if g is None and self.graph_mode == 'cycle':
-            flip = self._flip
             try:
                 g = torch.cuda.CUDAGraph()
                 self.stream.synchronize()
@@ -557,8 +485,6 @@ class DistributedSwe2d(object):
                     print('[thetis_amd] HIP graph capture unavailable ({:}); running eagerly'.format(str(e).splitlines()[0]))
                 self.graph_mode, g = 'none', None
                 torch.cuda.synchronize()
-                if self._flip != flip:   # undo the buffer swaps of the aborted capture before running for real
-                    self._swap()
         if g is not None:
             g.replay()
         else:

@@ -58,12 +58,9 @@ def exercise():
             for i in range(3):                      # sub-range launches with ragged ends
                 dev.solve_stage_cells(i, 0, mesh.num_cells//3 + 1)
                 dev.solve_stage_cells(i, mesh.num_cells//3 + 1, mesh.num_cells)
-            if dev.fused_step_supported():          # the one-launch step kernel on ragged ranges
-                n = mesh.num_cells
-                for a, b in ((0, 1), (1, n//3 + 5), (n//3 + 5, n)):
-                    dev.solve_step_cells(a, b)
-                dev.swap_state_buffers()
-                n_launch += 3
+            if dev.flow_supported():                # the dataflow launch (plane accesses are checked; granules use a bounded resource)
+                dev.solve_flow([mesh.num_cells]*6)
+                n_launch += 1
             dev.tendency()
             d = dev.diagnostics()
             assert np.isfinite(d).all(), (name, variant, d)

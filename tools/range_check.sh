@@ -16,5 +16,5 @@ export THETIS_AMD_LIB=$PWD/variants/libswe2d_rangecheck.so
 timeout 900 python tools/range_check.py; echo "range_check rc=$?"
 THETIS_AMD_RANGE_SELFTEST=1 timeout 900 python tools/range_check.py | tail -1; echo "negative control rc=$?"
 # the checked kernels are an order of magnitude slower: the small-mesh tests only
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_tracer.py tests/test_gpu_sipg.py tests/test_quads.py tests/test_gpu_step_kernel.py \
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_tracer.py tests/test_gpu_sipg.py tests/test_quads.py tests/test_gpu_flow_kernel.py \
     -m gpu -q -k "not large_launch and not full_size" 2>&1 | tail -60
