@@ -598,3 +598,41 @@ def test_a_lost_peer_costs_one_bounded_wait_and_never_hangs_the_device(hip_lib):
         dev.close()
     finally:
         os.environ.pop('THETIS_AMD_P2P_TIMEOUT_S', None)
+
+
+@pytest.mark.parametrize('world,depth', [(4, 6), (3, 12)])
+def test_strip_submesh_partition_equals_the_partition_of_the_global_mesh(world, depth):
+    """bench.py's large-mesh line builds every rank's strip from a sub-rectangle of the channel instead of the 8 M-cell mesh:
+    the same cells (centroids), the same ghost layers, and send lists that are the peers' receive lists."""
+    from thetis_amd.distributed import strip_submesh_case
+    from thetis_amd.mesh import RectangleMesh
+    from thetis_amd.partition import build_partition, strip_owner
+    nx, ny, lx, ly = 96, 10, 100e3, 50e3
+    glob = RectangleMesh(nx, ny, lx, ly)
+    owner = strip_owner(glob, world)
+    parts = [strip_submesh_case(r, world, nx, ny, lx, ly, depth)[0] for r in range(world)]
+
+    def cen(p, cells=None):
+        c = p.vertex_xy[p.cells].mean(axis=1)
+        return c if cells is None else c[cells]
+    for r in range(world):
+        ref = build_partition(glob, owner, r, halo_depth=depth)
+        p = parts[r]
+        assert p.n_owned == ref.n_owned and p.layer_sizes == ref.layer_sizes and sorted(p.send) == sorted(ref.send)
+        # the same owned cells and the same cells layer by layer (as sets of centroids)
+        key = lambda a: np.round(a, 3)[np.lexsort(np.round(a, 3).T)]
+        assert np.array_equal(key(cen(p)[:p.n_owned]), key(cen(ref)[:ref.n_owned]))
+        a = p.n_owned
+        for size in p.layer_sizes:
+            assert np.array_equal(key(cen(p)[a:a + size]), key(cen(ref)[a:a + size]))
+            a += size
+        assert p.boundary_len == {1: ly, 2: ly, 3: lx, 4: lx}
+        # channel ends are walls, strip ends are not: the owned cells carry markers only where the global partition does
+        assert sorted(np.unique(-p.cell_nbr[:p.n_owned][p.cell_nbr[:p.n_owned] < 0])) == \
+            sorted(np.unique(-ref.cell_nbr[:ref.n_owned][ref.cell_nbr[:ref.n_owned] < 0]))
+    for r in range(world - 1):
+        a, c = parts[r], parts[r + 1]
+        for s, d in ((a, c), (c, a)):
+            o, n = s.send[d.rank]
+            o2, n2 = d.recv[s.rank]
+            assert n == n2 and np.abs(cen(s, s.send_cells[o:o + n]) - cen(d, d.recv_cells[o2:o2 + n2])).max() < 1e-9

@@ -56,7 +56,7 @@ def test_bench_two_ranks_through_torch_distributed_run(hip_lib):
     against the host-staged exchange and timed, and everything else - partitioning, schedule tuning with the max over
     ranks, graph capture, the timed region, rank 0 printing one JSON line - is the code a multi-GPU node runs."""
     e = dict(os.environ)
-    e.update({'THETIS_AMD_DIST_BACKEND': 'gloo'})
+    e.update({'THETIS_AMD_DIST_BACKEND': 'gloo', 'THETIS_AMD_LARGE_MESH': '1600,400'})
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                         '127.0.0.1', '--master-port', '29577', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '16',
                         '--warmup', '2', '--prewarm', '0.05'],
@@ -69,8 +69,29 @@ def test_bench_two_ranks_through_torch_distributed_run(hip_lib):
     cfg = d['config']
     assert len(cfg['schedule_tuning']) >= 5 and cfg['volume_conserved'] is True
     assert cfg['transports_verified'] == ['p2p', 'host'] and cfg['exchange'] == 'p2p' and cfg['p2p_timeouts'] == 0
-    assert cfg['failures'] == [] and cfg['hip_graph'] is True
+    assert cfg['failures'] == [] and any(t['graph_mode'] != 'none' for t in cfg['schedule_tuning'])
     assert 1e8 < d['value'] < 1e11
+    # set-up (transport checks + schedule tuning) is bounded: candidates beyond the budget are skipped and listed
+    assert cfg['setup_s'] <= cfg['setup_budget_s'] + 15.0 and cfg['setup_budget_s'] == 60.0 and isinstance(cfg['setup_skipped'], list)
+    # the second, untuned timed region on the larger mesh of the same channel (here shrunk: 2 ranks share one GPU)
+    lm = cfg['large_mesh']
+    assert lm['n_cells'] == 2*1600*400 and lm['volume_conserved'] is True and lm['value'] > 1e8 and lm['speedup_model'] > 0
+
+
+def test_bench_set_up_budget_cuts_the_candidate_list_short(hip_lib):
+    """THETIS_AMD_SETUP_BUDGET_S = 0: after the first transport and the first candidate nothing more is tried; the line is
+    still complete and says what was skipped."""
+    e = dict(os.environ)
+    e.update({'THETIS_AMD_DIST_BACKEND': 'gloo', 'THETIS_AMD_SETUP_BUDGET_S': '0', 'THETIS_AMD_NO_LARGE_MESH': '1'})
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', '29579', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '8',
+                        '--warmup', '2', '--prewarm', '0.05'],
+                       capture_output=True, text=True, env=e, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.lstrip().startswith('{"metric"')][0])
+    cfg = d['config']
+    assert len(cfg['schedule_tuning']) == 1 and len(cfg['setup_skipped']) >= 5 and cfg['volume_conserved'] is True
+    assert 'large_mesh' not in cfg and d['value'] > 1e8
 
 
 def test_bench_survives_a_transport_that_fails(hip_lib):

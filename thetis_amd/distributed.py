@@ -220,7 +220,8 @@ class DistributedSwe2d(object):
         self.rank, self.world = rank, world_size
         self.group = group
         # default: strips (<= 2 peers = one xGMI link each); pass owner=rcb_owner(mesh, n) for compact parts of a general mesh
-        owner = strip_owner(mesh, world_size) if owner is None else owner
+        if partition is None:
+            owner = strip_owner(mesh, world_size) if owner is None else owner
         self.use_limiter = bool(use_limiter) and n_tracers > 0
         self.tracer_only = bool(tracer_only)
         if stepper not in ('SSPRK33', 'ForwardEuler'):
@@ -361,6 +362,7 @@ class DistributedSwe2d(object):
 
     def get_state_owned(self):
         """(global ids, uv, eta) of the owned cells."""
+        self._check_exchange()
         uv, eta = self.dev.get_state()
         n = self.part.n_owned
         return self.part.local_to_global[:n], uv[:n], eta[:n]
@@ -593,12 +595,23 @@ class DistributedSwe2d(object):
         """True when the step loop runs from HIP graphs (either mode)."""
         return self.graph is not None or bool(self._cycle_graphs)
 
+    def _check_exchange(self):
+        """A peer-to-peer wait that timed out (a lost or very late peer: bounded, counted, sticky - csrc/swe2d_p2p.h) leaves stale
+        ghost values behind: every point where results leave the device raises instead of returning them."""
+        if self.p2p is not None:
+            n = self.p2p.timeouts()
+            if n:
+                raise RuntimeError('{:d} peer-to-peer halo waits timed out on rank {:d} (THETIS_AMD_P2P_TIMEOUT_S): the ghost cells '
+                                   'are stale, the state is invalid'.format(n, self.rank))
+
     def synchronize(self):
         self.stream.synchronize()
+        self._check_exchange()
 
     def diagnostics(self):
         """Global {int eta^2, int |u|^2, int (eta+h), min(h+eta)}: per-rank partial sums all-reduced."""
         import torch.distributed as dist
+        self._check_exchange()
         d = self.dev.diagnostics()
         return np.concatenate([self._all_reduce(d[:3], dist.ReduceOp.SUM), self._all_reduce(d[3:], dist.ReduceOp.MIN)])
 
@@ -694,12 +707,15 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
     parts = {}
     owner = strip_owner(mesh, world)
 
-    def make(exchange, every, overlap, split, mode):
+    def make(exchange, every, overlap, split, mode, flow=False):
         if every not in parts:
             parts[every] = build_partition(mesh, owner, rank, halo_depth=3*every)
         s = DistributedSwe2d(mesh, bath, dt, rank, world, local_rank, exchange_every=every, overlap_stages=overlap,
                              graph_mode=mode, exchange=exchange, split_last_stage=split, partition=parts[every],
-                             group=(ctrl if exchange != 'rccl' else None))
+                             group=(ctrl if exchange != 'rccl' else None), flow=flow)
+        if flow and not agree.all_ok(s.flow):          # the kernel must cover every rank's partition (all its blocks resident at once)
+            s.close()
+            raise RuntimeError('the flow kernel does not cover the partition of every rank')
         s.set_state_global(uv, eta)
         return s
 
@@ -726,6 +742,14 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
     #      its result bit for bit on a short run (an exchange is a pure copy)
     n_check = 9
     transports = []
+    # everything from here to the timed region is set-up: transport checks and schedule tuning stop adding candidates once
+    # THETIS_AMD_SETUP_BUDGET_S (default 60 s) is spent, so that first contact with a node always reaches the timed region
+    t_setup0 = time.perf_counter()
+    setup_budget = float(os.environ.get('THETIS_AMD_SETUP_BUDGET_S', '60'))
+    skipped = []
+
+    def budget_left():
+        return agree.max(time.perf_counter() - t_setup0) < setup_budget
     forced = os.environ.get('THETIS_AMD_EXCHANGE')
     wanted = [forced] if forced else ['p2p'] + (['rccl'] if have_rccl else []) + ['host']
     digest_ref = None
@@ -750,6 +774,9 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
             if digest_ref is not None or forced or world == 1:
                 transports.append(ex)
             continue
+        if transports and not budget_left():
+            skipped.append("transport '{:}'".format(ex))
+            continue
         ok, dg = attempt("transport '{:}'".format(ex), lambda ex=ex: short_run(ex))
         if ok and digest_ref is not None:
             same = agree.all_ok(dg == digest_ref)
@@ -767,31 +794,40 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
     #      timed region; every rank takes the max over ranks and therefore the same decision).
     if os.environ.get('THETIS_AMD_EXCHANGE_EVERY'):
         sched = [(max(1, int(os.environ['THETIS_AMD_EXCHANGE_EVERY'])), int(os.environ.get('THETIS_AMD_OVERLAP_STAGES', '0')),
-                  not os.environ.get('THETIS_AMD_NO_SPLIT'), mode0)]
+                  not os.environ.get('THETIS_AMD_NO_SPLIT'), mode0, os.environ.get('THETIS_AMD_FLOW') == '1')]
         candidates = [(transports[0],) + sched[0]]
     elif world == 1 and not os.environ.get('THETIS_AMD_TUNE_SCHEDULE'):
-        candidates = [(transports[0], 4, 0, True, mode0)]
+        candidates = [(transports[0], 4, 0, True, mode0, False)]
     else:
         candidates = []
         for ex in transports:
+            # most promising first: the set-up budget may cut the list short.  flow = the 3m stages of a cycle as one dataflow
+            # launch (csrc/swe2d_flow.h; needs every 64-cell block of the partition resident at once: <= 131 k cells, i.e.
+            # m <= 2 for an eighth of the bench mesh)
             if ex == 'p2p':
-                candidates += [(ex, 2, 0, False, mode0), (ex, 4, 0, False, mode0), (ex, 4, 0, True, mode0),
-                               (ex, 8, 0, False, mode0), (ex, 8, 3, True, mode0)]
+                candidates += [(ex, 4, 0, False, mode0, False), (ex, 2, 0, False, mode0, True), (ex, 8, 0, False, mode0, False)]
                 # one graph per cycle costs a graph launch per cycle; the whole timed loop in ONE graph, or no graph at all, were
                 # both faster for a 125 k-cell rank (us/step, m = 4: cycle 30.8, none 29.7, full 29.2): let the node decide
                 if mode0 == 'cycle' and use_graph:
-                    candidates += [(ex, 4, 0, False, 'full'), (ex, 8, 0, False, 'full'), (ex, 4, 0, False, 'none')]
+                    candidates += [(ex, 2, 0, False, 'full', True), (ex, 4, 0, False, 'full', False), (ex, 8, 0, False, 'full', False),
+                                   (ex, 4, 0, False, 'none', False)]
+                candidates += [(ex, 4, 0, True, mode0, False), (ex, 8, 3, True, mode0, False), (ex, 2, 0, False, mode0, False),
+                               (ex, 1, 0, False, mode0, True)]
             elif ex == 'rccl':
                 # graphs take the per-launch CPU cost off the critical path (it matters once an RCCL enqueue sits in every
                 # cycle); when the CPU keeps up anyway eager launches are a little faster: time both
-                candidates += [(ex, 4, 0, True, mode0), (ex, 8, 0, True, mode0), (ex, 8, 3, True, mode0), (ex, 8, 0, True, 'none')]
+                candidates += [(ex, 4, 0, True, mode0, False), (ex, 8, 0, True, mode0, False), (ex, 2, 0, False, mode0, True),
+                               (ex, 8, 3, True, mode0, False), (ex, 8, 0, True, 'none', False)]
             elif len(transports) == 1:
-                candidates += [(ex, 8, 0, True, 'none')]
+                candidates += [(ex, 8, 0, True, 'none', False)]
     solver, chosen, best_us, tuning = None, None, float('inf'), []
     n_tune = 96
     first = True
     for cand in candidates:
-        ex, every_c, overlap_c, split_c, mode_c = cand
+        ex, every_c, overlap_c, split_c, mode_c, flow_c = cand
+        if solver is not None and not budget_left():
+            skipped.append(str(cand))
+            continue
 
         def time_candidate():
             s = make(*cand)
@@ -829,7 +865,7 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
         s, t_best = res
         us = 1e6*agree.max(t_best)/n_tune
         tuning.append({'exchange': ex, 'exchange_every': every_c, 'overlap_stages': overlap_c, 'split_last_stage': split_c,
-                       'graph_mode': mode_c, 'us_per_step': us})
+                       'graph_mode': mode_c, 'flow': bool(flow_c), 'us_per_step': us})
         if us < best_us:
             if solver is not None:
                 solver.close()
@@ -838,16 +874,29 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
             s.close()
     if solver is None:
         # last resort: host-staged exchange, eager launches
-        chosen = ('host', 4, 0, True, 'none')
+        chosen = ('host', 4, 0, True, 'none', False)
         ok, solver = attempt('fallback {:}'.format(chosen), lambda: make(*chosen))
         if not ok:
             solver = None
+    setup_s = agree.max(time.perf_counter() - t_setup0)
     out = None
     if solver is not None:
         ok, out = attempt('timed region', lambda: _timed_region(args, solver, chosen, agree, uv, eta, use_graph, n_total, world,
                                                                 bytes_per_update, hbm_peak, tuning, transports))
         if not ok:
             out = None
+    if out is not None:
+        out['config'].update({'setup_s': setup_s, 'setup_budget_s': setup_budget, 'setup_skipped': skipped})
+        # second, untuned timed region: an 8x larger mesh of the same channel (1 M triangles per rank at N = 8), where a rank is
+        # bandwidth-bound like the single-GPU headline - it shows whether partitions, halo transport and graphs scale once the
+        # latency floor of a 125 k-cell rank is out of the picture
+        if world > 1 and not os.environ.get('THETIS_AMD_NO_LARGE_MESH'):
+            if solver is not None:
+                solver.close()
+                solver = None
+            ok, large = attempt('large-mesh region', lambda: _large_mesh_region(args, chosen, agree, rank, world, local_rank, ctrl, dt,
+                                                                               use_graph, bytes_per_update, hbm_peak))
+            out['config']['large_mesh'] = large if ok else None
     if out is None:
         out = {'metric': 'DG element-updates/sec, 2D SWE DG-P1 SSPRK33', 'value': 0.0, 'unit': 'element-updates/s', 'n_gpus': int(world),
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'strong',
@@ -875,9 +924,89 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
         print(json.dumps(out), flush=True)
 
 
+LARGE_NX, LARGE_NY = 4000, 1000          # 8 M triangles of the bench channel (100 km x 50 km): 1 M per rank at N = 8
+
+
+def strip_submesh_case(rank, world, nx, ny, lx, ly, halo_depth):
+    """Rank ``rank``'s strip of RectangleMesh(nx, ny, lx, ly) WITHOUT building the global mesh: the sub-rectangle of its own
+    columns plus ``halo_depth + 2`` columns either side (two triangles per quad: more than ``halo_depth`` facet layers), as a
+    RectangleMesh of its own, partitioned with the neighbours' columns owned by rank -+ 1.  Cells of the overlap have the same
+    relative order in both ranks' sub-meshes (row by row, column by column), so the send list of one is the receive list of
+    the other, as with the global mesh.  Returns (LocalPartition, bathymetry per sub-mesh vertex, uv, eta per sub-mesh cell):
+    flat bathymetry, the bench's Gaussian hump plus a deterministic ripple (a function of position, so that a ghost cell
+    starts from its owner's values)."""
+    from .mesh import RectangleMesh
+    i0, i1 = rank*nx//world, (rank + 1)*nx//world
+    a, b = max(0, i0 - (halo_depth + 2)), min(nx, i1 + halo_depth + 2)
+    dx = lx/nx
+    sub = RectangleMesh(b - a, ny, dx*(b - a), ly)
+    sub.vertex_xy = sub.vertex_xy + np.array([a*dx, 0.0])
+    # the strip's ends are walls only where they are the channel's ends; boundary lengths are those of the whole channel
+    sub.boundary_len = {1: ly, 2: ly, 3: lx, 4: lx}
+    col = (np.arange(sub.num_cells)//2) % (b - a) + a
+    owner = np.where(col < i0, rank - 1, np.where(col < i1, rank, rank + 1))
+    part = build_partition(sub, owner, rank, halo_depth=halo_depth)
+    cxy = sub.cell_xy()
+    x, y = cxy[:, :, 0], cxy[:, :, 1]
+    eta = 0.5*np.exp(-((x - 0.5*lx)**2 + (y - 0.5*ly)**2)/(5e3)**2) + 1e-3*np.sin(x/731.0)*np.cos(y/517.0)
+    uv = 1e-3*np.stack([np.sin(x/613.0 + y/389.0), np.cos(x/457.0 - y/823.0)], axis=-1)
+    return part, np.full(sub.num_vertices, 20.0), uv, eta
+
+
+def _large_mesh_region(args, chosen, agree, rank, world, local_rank, ctrl, dt, use_graph, bytes_per_update, hbm_peak):
+    """config.large_mesh: K timed steps on RectangleMesh(4000, 1000) of the same channel with the chosen transport, one exchange
+    per 4 steps, stage launches (untuned)."""
+    import torch
+    ex, mode = chosen[0], chosen[4]
+    every = 4
+    lx, ly = 100e3, 50e3
+    nx_l, ny_l = LARGE_NX, LARGE_NY
+    if os.environ.get('THETIS_AMD_LARGE_MESH'):                # tests: "nx,ny"
+        nx_l, ny_l = (int(v) for v in os.environ['THETIS_AMD_LARGE_MESH'].split(','))
+    part, bath, uv, eta = strip_submesh_case(rank, world, nx_l, ny_l, lx, ly, 3*every)
+    n_total = 2*nx_l*ny_l
+    s = DistributedSwe2d(None, bath, dt*1000.0/nx_l, rank, world, local_rank, exchange_every=every, graph_mode=mode, exchange=ex,
+                         split_last_stage=True, partition=part, group=(ctrl if ex != 'rccl' else None), flow=False)
+    try:
+        s.dev.set_state(uv[part.local_to_global], eta[part.local_to_global])
+        d0 = s.diagnostics()
+        s.advance(200, use_graph=False)                        # connections, clocks
+        s.synchronize()
+        graph = use_graph and s.graph_mode != 'none'
+        if graph:
+            s._capture(args.steps)
+            if s.graphed:
+                s.advance(args.steps, use_graph=True)
+                s.synchronize()
+        agree.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.advance(args.steps, use_graph=graph)
+        s.synchronize()
+        agree.barrier()
+        torch.cuda.synchronize()
+        t = agree.max(time.perf_counter() - t0)
+        d1 = s.diagnostics()
+        ok = bool(np.isfinite(d1).all() and abs(d1[2] - d0[2])/d0[2] < 1e-10)
+        # model of the same mesh on ONE GPU: the stage kernels beyond the Infinity Cache run at 0.58 of the 8 TB/s roofline
+        # (roofline.frac_beyond_cache of the N = 1 line; 8 M cells measured 1115 us/step in round 2)
+        t1_model = 3.0*bytes_per_update*n_total/(0.58*hbm_peak*1e9)
+        return {'workload': 'RectangleMesh({:d},{:d},100e3,50e3) = {:d} triangles, strips along x, {:d} cells per rank'.format(
+                    nx_l, ny_l, n_total, n_total//world),
+                'n_cells': n_total, 'ms_per_step': float(1e3*t/args.steps), 'value': float(n_total*3.0*args.steps/t),
+                'unit': 'element-updates/s', 'exchange': ex, 'exchange_every': every, 'graph_mode': s.graph_mode, 'hip_graph': bool(s.graphed),
+                'frac_of_hbm_roofline_per_gpu': float(bytes_per_update*n_total/world*3*args.steps/t/1e9/hbm_peak),
+                'speedup_model': float(t1_model/(t/args.steps)),
+                'speedup_model_note': 'against a MODEL of one GPU on the same mesh (stage kernels at 0.58 of 8 TB/s beyond the '
+                                      'Infinity Cache = {:.0f} us/step); not a measured single-GPU run'.format(1e6*t1_model),
+                'volume_conserved': ok}
+    finally:
+        s.close()
+
+
 def _timed_region(args, solver, chosen, agree, uv, eta, use_graph, n_total, world, bytes_per_update, hbm_peak, tuning, transports):
     import torch
-    ex, every, overlap, split, _ = chosen
+    ex, every, overlap, split, _, flow_on = chosen
     solver.graph = None
     solver.set_state_global(uv, eta)
     d0 = solver.diagnostics()
@@ -928,7 +1057,8 @@ def _timed_region(args, solver, chosen, agree, uv, eta, use_graph, n_total, worl
                    'parallelism': 'dd{:d} (domain decomposition, {:d}-cell halo, 1 exchange per {:d} steps)'.format(
                        world, 3*every, every),
                    'exchange': ex, 'exchange_transport': transport, 'transports_verified': transports,
-                   'exchange_every': every, 'overlap_stages': overlap, 'split_last_stage': split, 'schedule_tuning': tuning,
+                   'exchange_every': every, 'overlap_stages': overlap, 'split_last_stage': split, 'flow': bool(solver.flow),
+                   'flow_timeouts': int(solver.dev.flow_timeouts()), 'schedule_tuning': tuning,
                    'hip_graph': hip_graph, 'graph_mode': solver.graph_mode, 'graph_warm_replays': int(hip_graph),
                    'volume_conserved': ok, 'p2p_timeouts': int(timeouts), 'prewarm_s': prewarm},
         'roofline': {'bound': 'hbm', 'achieved': float(per_gpu_bytes*3*args.steps/t/1e9), 'peak': hbm_peak, 'unit': 'GB/s',
