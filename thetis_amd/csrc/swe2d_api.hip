@@ -123,6 +123,7 @@ struct Handle {
     size_t flow_ex_bytes = 0;
     int flow_blocks = 0;                                // 64-cell blocks of the handle
     int flow_capacity = -1;                             // resident one-wave workgroups of the flow kernel on this device (-1: not asked yet)
+    int launch_parity = 0;                              // direction of the next large stage launch (launch_stage)
     bool flow_used = false;                             // a flow launch since the status word was last read
     double flow_timeout_s = 2.0;                        // THETIS_AMD_FLOW_TIMEOUT_S
     double *vx = nullptr, *vy = nullptr, *vh = nullptr;
@@ -318,6 +319,7 @@ void fill_stage_args(Handle *h, SweStageArgs &a, int in, int u0, int out, double
     a.valpha = h->valpha;
     a.idx4 = h->idx4; a.idx2 = h->idx2;
     a.cell_begin = c0; a.cell_end = c1;
+    a.reverse = 0;
     a.g = h->par.g_grav;
     a.sigma_lf = h->par.lax_friedrichs_velocity_scaling_factor;
     a.dt = h->par.dt;
@@ -378,6 +380,14 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
     // the XCD-chunked block map needs a grid that is a multiple of 8; surplus blocks exit immediately
     const int grid = ((nblocks + 7)/8)*8;
+    // Launches whose state no longer fits the Infinity Cache (three buffers of 72 B per cell against 256 MB: beyond ~1.2 M
+    // triangles) alternate the direction in which they walk the range: the cells a launch touched last - still in the cache -
+    // are the first the next one reads.  Same results (cells are independent).  THETIS_AMD_ALTERNATE=0/1 forces the choice.
+    if (h->npc == 3 && !fused_visc) {
+        const char *env_alt = std::getenv("THETIS_AMD_ALTERNATE");
+        const bool alt = env_alt ? std::atoi(env_alt) != 0 : (c1 - c0) >= 1500000;
+        if (alt) { a.reverse = h->launch_parity; h->launch_parity ^= 1; }
+    }
     SWE_CHK_SYNC(h->stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());

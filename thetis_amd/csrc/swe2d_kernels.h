@@ -69,6 +69,7 @@ struct SweStageArgs {
     double nu_const, visc_sipg;   // visc_sipg = sipg_factor * cp, cp = 3
     int visc_grad_div, visc_grad_depth;
     int cell_begin, cell_end;
+    int reverse;                  // walk the blocks of the range from its end (launches beyond the Infinity Cache alternate, see launch_stage)
     double g, sigma_lf, dt;
     double a0, a1, beta;   // U_out = beta*k + a0*U0 + a1*U_in
     // optional cell-local terms (SRC variant)
@@ -824,10 +825,14 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     }
 #endif
 #ifdef SWE_NO_XCD_MAP
-    const int lb = blockIdx.x;
+    int lb = blockIdx.x;
 #else
-    const int lb = swe_logical_block(blockIdx.x, gridDim.x);
+    int lb = swe_logical_block(blockIdx.x, gridDim.x);
 #endif
+    if (p.reverse) {              // the blocks dispatched first take the END of the range: what the previous launch touched last
+        lb = (p.cell_end - p.cell_begin + SWE_BLOCK - 1)/SWE_BLOCK - 1 - lb;
+        if (lb < 0) return;
+    }
     const int k = p.cell_begin + lb*SWE_BLOCK + (int)threadIdx.x;
     if (k >= p.cell_end) return;
     const size_t S = p.stride;

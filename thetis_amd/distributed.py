@@ -828,6 +828,14 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
         if solver is not None and not budget_left():
             skipped.append(str(cand))
             continue
+        if flow_c and len(candidates) > 1:
+            # the flow kernel needs every 64-cell block of the partition resident at once (2 one-wave workgroups per SIMD x 1024
+            # SIMDs on an MI355X): not a candidate for larger partitions - decided on every rank the same way, no failure
+            if every_c not in parts:
+                parts[every_c] = build_partition(mesh, owner, rank, halo_depth=3*every_c)
+            if not agree.all_ok(parts[every_c].num_cells <= 2048*64):
+                skipped.append(str(cand) + ': partition too large for the flow kernel')
+                continue
 
         def time_candidate():
             s = make(*cand)
