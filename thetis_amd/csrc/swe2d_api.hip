@@ -380,12 +380,14 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
     // the XCD-chunked block map needs a grid that is a multiple of 8; surplus blocks exit immediately
     const int grid = ((nblocks + 7)/8)*8;
-    // Launches whose state no longer fits the Infinity Cache (three buffers of 72 B per cell against 256 MB: beyond ~1.2 M
-    // triangles) alternate the direction in which they walk the range: the cells a launch touched last - still in the cache -
-    // are the first the next one reads.  Same results (cells are independent).  THETIS_AMD_ALTERNATE=0/1 forces the choice.
-    if (h->npc == 3 && !fused_visc) {
+    // Launches whose state no longer fits the Infinity Cache (three buffers of 24 B per node against 256 MB: beyond ~1.2 M
+    // triangles / 0.9 M quadrilaterals) alternate the direction in which they walk the range: the cells a launch touched last -
+    // still in the cache - are the first the next one reads.  Same results (cells are independent).  Same box, fraction of the
+    // 8 TB/s roofline without / with: 2 M triangles 0.530 / 0.588, 4 M 0.581 / 0.602, 8 M 0.582 / 0.598 (1 M, which fits: 0.728 /
+    // 0.732).  THETIS_AMD_ALTERNATE=0/1 forces the choice.
+    if (!fused_visc) {
         const char *env_alt = std::getenv("THETIS_AMD_ALTERNATE");
-        const bool alt = env_alt ? std::atoi(env_alt) != 0 : (c1 - c0) >= 1500000;
+        const bool alt = env_alt ? std::atoi(env_alt) != 0 : (size_t)(c1 - c0)*h->npc*72 >= ((size_t)256 << 20);
         if (alt) { a.reverse = h->launch_parity; h->launch_parity ^= 1; }
     }
     SWE_CHK_SYNC(h->stream);

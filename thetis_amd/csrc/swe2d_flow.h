@@ -383,14 +383,6 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
         if (!__any(act)) break;                                // retired: the ranges only shrink
         const int i3 = s % 3;
         SWE_FT(0);
-#ifdef SWE_WAVE_TIMING
-        if (s == SWE_FLOW_TS_STAGE && lane == 0 && lb < SWE_WT_MAX) {
-            unsigned hw, xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            swe_wave_ts[5][lb] = (unsigned long long)hw | ((unsigned long long)(xcc & 0xf) << 32);
-        }
-#endif
         // Opaque to the optimiser: without this every stage-invariant quantity (facet lengths, reciprocals, gradients ...) is
         // hoisted out of the stage loop and kept live across it - past the register budget.  The per-stage kernel recomputes
         // them in every stage as well.
@@ -506,6 +498,13 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             }
         }
         SWE_FT(4);
+#ifdef SWE_WAVE_TIMING
+        if (s == SWE_FLOW_TS_STAGE - 1 && lane == 0 && lb < SWE_WT_MAX) {         // when the previous stage's granules left, and from which XCD
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            swe_wave_ts[5][lb] = (wall_clock64() & 0xffffffffffffull) | ((unsigned long long)(xcc & 0xf) << 56);
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < 3; i++) { u[i] = ou[i]; v[i] = ov[i]; e[i] = oe[i]; }
     }

@@ -1767,10 +1767,14 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
     // no implicit contraction (see swe_stage_kernel)
 #pragma clang fp contract(off)
 #ifdef SWE_NO_XCD_MAP
-    const int lb = blockIdx.x;
+    int lb = blockIdx.x;
 #else
-    const int lb = swe_logical_block(blockIdx.x, gridDim.x);
+    int lb = swe_logical_block(blockIdx.x, gridDim.x);
 #endif
+    if (p.reverse) {              // see swe_stage_kernel: launches beyond the Infinity Cache alternate their direction
+        lb = (p.cell_end - p.cell_begin + SWE_BLOCK - 1)/SWE_BLOCK - 1 - lb;
+        if (lb < 0) return;
+    }
     const int k = p.cell_begin + lb*SWE_BLOCK + (int)threadIdx.x;
     if (k >= p.cell_end) return;
     const size_t S = p.stride;

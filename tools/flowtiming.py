@@ -39,26 +39,50 @@ def main():
     nmax = 8192
     nb = (mesh.num_cells + 63)//64
     runs = []
+    # neighbour blocks of every block (device numbering; the default flow order is the device numbering)
+    nb_dev = np.asarray(dev._keep[2])
+    cell_blk = np.arange(mesh.num_cells)//64
+    pairs = set()
+    for f in range(3):
+        ok = nb_dev[:, f] >= 0
+        a, b = cell_blk[ok], nb_dev[ok, f]//64
+        d = a != b
+        pairs.update(zip(a[d].tolist(), b[d].tolist()))
+    nbrs = [[] for _ in range(nb)]
+    for a, b in pairs:
+        nbrs[a].append(b)
     for rep in range(5):
         dev.solve_flow(ends)
         ts = np.zeros((6, nmax), dtype=np.uint64)
         dev._ck(fn(dev.h, ts.ctypes.data))
-        t = ts[:5, :min(nb, nmax)].astype(np.int64)
+        m = min(nb, nmax)
+        t = ts[:5, :m].astype(np.int64)
+        pub = (ts[5, :m] & np.uint64(0xffffffffffff)).astype(np.int64)      # previous stage's granules issued
+        xcc = (ts[5, :m] >> np.uint64(56)).astype(np.int64)
+        t48 = t & 0xffffffffffff
         us = lambda x: float(np.mean(x))/100.0
-        xcc = (ts[5, :min(nb, nmax)] >> np.uint64(32)).astype(np.int64)
-        per = ((nb + 7)//8*8)//8
-        expect = np.arange(min(nb, nmax))//per
-        runs.append({'blocks': int(t.shape[1]), 'wait_us': us(t[1] - t[0]), 'gather_us': us(t[2] - t[1]), 'arith_us': us(t[3] - t[2]),
-                     'drain_us': us(t[4] - t[3]), 'stage_us': us(t[4] - t[0]),
+        # hop latency: from the moment the LAST neighbour issued its granules (or this block started polling, whichever is later)
+        # to the moment this block's polling pass saw them all
+        hop, hop_same, hop_cross = [], [], []
+        for b in range(m):
+            ns = [a for a in nbrs[b] if a < m]
+            if not ns:
+                continue
+            last = max(ns, key=lambda a: pub[a])
+            lat = t48[1, b] - max(pub[last], t48[0, b])
+            hop.append(lat)
+            (hop_same if xcc[last] == xcc[b] else hop_cross).append(lat)
+        runs.append({'blocks': int(m), 'wait_us': us(t[1] - t[0]), 'arith_us': us(t[3] - t[2]),
+                     'publish_us': us(t[4] - t[3]), 'stage_us': us(t[4] - t[0]),
                      'stage_p10_p90_us': [float(np.percentile(t[4] - t[0], 10))/100.0, float(np.percentile(t[4] - t[0], 90))/100.0],
                      'front_spread_us': float(t[4].max() - t[4].min())/100.0,
-                     'blocks_on_expected_xcd': float((xcc == expected_chunk(expect)).mean())})
+                     'hop_us': us(hop), 'hop_p10_p90_us': [float(np.percentile(hop, 10))/100.0, float(np.percentile(hop, 90))/100.0],
+                     'hop_same_xcd_us': us(hop_same) if hop_same else None, 'hop_cross_xcd_us': us(hop_cross) if hop_cross else None,
+                     'last_neighbour_on_same_xcd': float(len(hop_same))/max(1, len(hop)),
+                     'waiting_before_last_publish_frac': float(np.mean([t48[0, b] < pub[max([a for a in nbrs[b] if a < m], key=lambda a: pub[a])]
+                                                                         for b in range(m) if [a for a in nbrs[b] if a < m]]))})
     print(json.dumps({'n_cells': mesh.num_cells, 'stages': args.stages, 'runs': runs}, indent=1))
     dev.close()
-
-
-def expected_chunk(c):
-    return c
 
 
 if __name__ == '__main__':
