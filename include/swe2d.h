@@ -204,7 +204,8 @@ int  swe2d_diagnostics(swe2d_handle *h, double out[4]);
  * options.horizontal_viscosity (solver2d.py:551).  nu is a constant (nu_vertex == NULL) or a continuous P1 field given per
  * vertex; sipg_factor = options.sipg_factor (options.py:730); the two flags are options.use_grad_div_viscosity_term and
  * use_grad_depth_viscosity_term (options.py:597-606).  Dirichlet boundary terms follow the velocity-type boundary
- * conditions set with swe2d_set_bc (:584-609).  Not with wetting and drying.  enable = 0 switches the
+ * conditions set with swe2d_set_bc (:584-609).  With wetting and drying the depth of the grad-depth term is the displaced depth
+ * and the dry-ground relaxation acts on the whole new velocity (viscous share included).  enable = 0 switches the
  * term off (viscosity_h None, :559-560). */
 int  swe2d_set_viscosity(swe2d_handle *h, int enable, const double *nu_vertex, double nu_const, double sipg_factor,
                          int use_grad_div_viscosity_term, int use_grad_depth_viscosity_term);

@@ -73,7 +73,7 @@ def _random_config(rng, mesh, quad):
         o['norm_smoother'] = 0.05
         dev_ops.append(('set_scalar', (_lib.SCALAR_NORM_SMOOTHER, 0.05)))
     visc = None
-    if not wd and rng.random() < 0.4:
+    if rng.random() < 0.4:
         nu = 30.0 if rng.random() < 0.5 else 20.0 + 20.0*rng.uniform(size=mesh.num_vertices)
         visc = dict(sipg_factor=float(rng.choice([1.0, 2.0])), use_grad_div_viscosity_term=bool(rng.integers(0, 2)),
                     use_grad_depth_viscosity_term=bool(rng.integers(0, 2)))

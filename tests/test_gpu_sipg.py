@@ -145,12 +145,45 @@ def test_tracer_diffusion_matches_oracle(hip_lib, case):
     dev.close()
 
 
-def test_sipg_rejects_unsupported_configurations(hip_lib):
-    mesh, bath, uv, eta = channel_case()
-    dev = _dev(mesh, bath, 1.0)
-    dev.set_wetting_and_drying(0.5)
-    with pytest.raises(RuntimeError, match='wetting'):
-        dev.set_viscosity(1.0)
+@pytest.mark.parametrize('mesh_kind', ['channel', 'quads'])
+@pytest.mark.parametrize('grad_depth', [True, False])
+def test_viscosity_with_wetting_and_drying_matches_oracle(hip_lib, mesh_kind, grad_depth):
+    """HorizontalViscosityTerm together with the explicit wetting-drying formulation (shallowwater_eq.py:554-616 with
+    total_h = the displaced depth): the depth of the grad-depth term and of 'flux' boundaries is D, and the dry-ground
+    relaxation of a stage acts on the whole new velocity, viscous share included (the oracle's order of operations)."""
+    from helpers import make_oracle_generic, quad_case
+    if mesh_kind == 'quads':
+        mesh, bath, uv, eta = quad_case(nx=9, ny=6, skew=0.2, seed=4)
+        mk = make_oracle_generic
+    else:
+        mesh, bath, uv, eta = channel_case(nx=9, ny=6, seed=4)
+        mk = make_oracle
+    bath = bath - 12.0                                              # partly dry
+    rng = np.random.default_rng(11)
+    nu = 20.0 + 30.0*rng.uniform(size=mesh.num_vertices)
+    alpha = 0.4 + 0.3*rng.uniform(size=mesh.num_vertices)
+    dt = 0.5
+    bcs = {1: {'flux': 2.0e3}, 2: {'elev': 0.3, 'un': 0.1}}
+    orc = mk(mesh, bath, horizontal_viscosity=nu, use_grad_depth_viscosity_term=grad_depth, use_grad_div_viscosity_term=True,
+             use_wetting_and_drying=True, wetting_and_drying_alpha=alpha, wd_mode='nodal', bnd_conditions=bcs)
+    dev = _dev(mesh, bath, dt)
+    dev.set_wetting_and_drying(alpha)
+    dev.set_viscosity(nu, use_grad_div_viscosity_term=True, use_grad_depth_viscosity_term=grad_depth)
+    for m, f in bcs.items():
+        dev.set_bc(m, f)
+    eta0 = orc.wd_clip_state(eta)
+    dev.set_state(uv, eta)
+    ku, ke = dev.tendency()
+    ku_o, ke_o = orc.tendency(uv, eta0, dt)
+    orc0 = mk(mesh, bath, use_wetting_and_drying=True, wetting_and_drying_alpha=alpha, wd_mode='nodal', bnd_conditions=bcs)
+    assert rel_linf(orc0.tendency(uv, eta0, dt)[0], ku_o) > 1e-4   # the viscous part is visible
+    assert rel_linf(ku, ku_o) < 1e-9 and rel_linf(ke, ke_o) < 1e-9
+    dev.advance(3)
+    u1, e1 = dev.get_state()
+    uo, eo = uv, eta0
+    for _ in range(3):
+        uo, eo = orc.ssprk33_step(uo, eo, dt)
+    assert np.isfinite(u1).all() and rel_linf(u1, uo) < 1e-9 and rel_linf(e1, eo) < 1e-9
     dev.close()
 
 

@@ -320,6 +320,7 @@ void fill_stage_args(Handle *h, SweStageArgs &a, int in, int u0, int out, double
     a.idx4 = h->idx4; a.idx2 = h->idx2;
     a.cell_begin = c0; a.cell_end = c1;
     a.reverse = 0;
+    a.wd_skip_relax = (h->wd && h->visc) ? 1 : 0;
     a.g = h->par.g_grav;
     a.sigma_lf = h->par.lax_friedrichs_velocity_scaling_factor;
     a.dt = h->par.dt;
@@ -406,6 +407,8 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
         v.cell_begin = c0; v.cell_end = c1;
         v.grad_div = h->visc_grad_div; v.grad_depth = h->visc_grad_depth;
         v.nonlin = h->par.use_nonlinear_equations;
+        v.wd = h->wd ? 1 : 0;
+        v.valpha = h->valpha;
         v.eta = h->state[in] + (size_t)2*h->npc*h->stride;
         v.bc = h->bc;
         v.bc_elev_f = h->bc_field[0]; v.bc_uv_f = h->bc_field[1]; v.bc_un_f = h->bc_field[2]; v.bc_flux_f = h->bc_field[3];
@@ -420,6 +423,17 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
         } else if (h->npc == 4) hipLaunchKernelGGL(swe_sipg_kernel_quad<2>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         else hipLaunchKernelGGL(swe_sipg_kernel<2>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         HIP_TRY(h, hipGetLastError());
+        if (h->wd && !(a0 == 0.0 && a1 == 0.0)) {
+            // wetting-drying: the dry-ground relaxation acts on the whole new velocity, viscous share included (not for the
+            // tendency hook, a0 = a1 = 0)
+            if (h->npc == 4)
+                hipLaunchKernelGGL(swe_wd_relax_kernel<4>, dim3((c1 - c0 + 255)/256), dim3(256), 0, h->stream, h->state[out], h->stride,
+                                   h->cv, h->vh, h->valpha, h->par.g_grav, beta*h->par.dt, c0, c1);
+            else
+                hipLaunchKernelGGL(swe_wd_relax_kernel<3>, dim3((c1 - c0 + 255)/256), dim3(256), 0, h->stream, h->state[out], h->stride,
+                                   h->cv, h->vh, h->valpha, h->par.g_grav, beta*h->par.dt, c0, c1);
+            HIP_TRY(h, hipGetLastError());
+        }
     }
     return SWE2D_OK;
 }
@@ -1131,7 +1145,6 @@ int swe2d_set_wetting_and_drying(swe2d_handle *hh, int enable, const double *alp
     if (!alpha_vertex) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "alpha_vertex is required");
     if (!h->par.use_nonlinear_equations)
         return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "wetting and drying needs use_nonlinear_equations");
-    if (h->visc) return fail(h, SWE2D_ERR_UNSUPPORTED, "SIPG viscosity with wetting and drying");
     for (int i = 0; i < h->n_vertices; i++)
         if (!(alpha_vertex[i] >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "alpha must be >= 0");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1164,7 +1177,6 @@ int swe2d_set_viscosity(swe2d_handle *hh, int enable, const double *nu_vertex, d
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
     if (!enable) { h->visc = false; return SWE2D_OK; }
-    if (h->wd) return fail(h, SWE2D_ERR_UNSUPPORTED, "SIPG viscosity with wetting and drying");
     if (!nu_vertex && !(nu_const >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "viscosity must be >= 0");
     if (!(sipg_factor > 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "sipg_factor must be > 0");
     int rc = upload_vertex_coefficient(h, nu_vertex, &h->nu_v);

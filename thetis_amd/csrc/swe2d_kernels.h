@@ -69,6 +69,7 @@ struct SweStageArgs {
     double nu_const, visc_sipg;   // visc_sipg = sipg_factor * cp, cp = 3
     int visc_grad_div, visc_grad_depth;
     int cell_begin, cell_end;
+    int wd_skip_relax;            // wetting-drying + viscosity: the dry-ground relaxation of the velocity follows the viscosity pass
     int reverse;                  // walk the blocks of the range from its end (launches beyond the Infinity Cache alternate, see launch_stage)
     double g, sigma_lf, dt;
     double a0, a1, beta;   // U_out = beta*k + a0*U0 + a1*U_in
@@ -172,7 +173,7 @@ __device__ __forceinline__ double swe_wd_depth(double H, double a)
 #define SWE_WD_TAU 10.0
 template <int K>
 __device__ __forceinline__ void swe_wd_finish(double g, double dt_stage, const double h[K], const double al[K], double ou[K],
-                                              double ov[K], double oe[K])
+                                              double ov[K], double oe[K], bool relax = true)
 {
 #pragma clang fp contract(off)
     double D[K], mean = 0.0, dmin = 1e300, fl = 0.0;
@@ -201,6 +202,7 @@ __device__ __forceinline__ void swe_wd_finish(double g, double dt_stage, const d
     for (int i = 0; i < K; i++) {
         const double eta = D[i] - 0.25*al[i]*al[i]*swe_rcp(D[i]) - h[i];
         oe[i] = eta;
+        if (!relax) continue;      // viscous runs: the relaxation follows the viscosity pass (swe_wd_relax_kernel)
         const double ral = swe_rcp(al[i]);
         const double psi = fmin(1.0, fmax(0.0, -(h[i] + eta)*ral - 1.0));
         if (psi > 0.0) {
@@ -1135,7 +1137,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
 #endif
     // zeta = D - h -> limited depth -> eta; dry-ground relaxation.  (Not for the parity hook swe2d_tendency, a0 = a1 = 0: it
     // returns the raw tendencies of (u, v, zeta).)
-    if (WD && !(p.a0 == 0.0 && p.a1 == 0.0)) swe_wd_finish<3>(g, p.beta*p.dt, h, al, ou, ov, oe);
+    if (WD && !(p.a0 == 0.0 && p.a1 == 0.0)) swe_wd_finish<3>(g, p.beta*p.dt, h, al, ou, ov, oe, !p.wd_skip_relax);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         swe_st(gou, k8, i*S8, ou[i]);
@@ -1272,6 +1274,28 @@ __global__ void swe_wd_clip_kernel(double *planes, size_t stride, const int *cv,
     }
     swe_wd_finish<K>(9.81, 0.0, h, al, zu, zv, ze);
     for (int i = 0; i < K; i++) planes[(size_t)(2*K + i)*stride + k] = ze[i];
+}
+
+// Dry-ground relaxation of the velocity as a pass of its own (the last part of swe_wd_finish): viscous runs with wetting-drying
+// apply it AFTER the viscosity pass has added its share of the stage update, so that the whole new velocity is relaxed -
+// u <- u exp(-dt_stage/tau psi^2), tau = SWE_WD_TAU sqrt(alpha/g), psi = clamp(-H/alpha - 1, 0, 1) with the stage's new eta.
+template <int K>
+__global__ void swe_wd_relax_kernel(double *planes, size_t stride, const int *cv, const double *vh, const double *valpha, double g,
+                                    double dt_stage, int c0, int c1)
+{
+    const int k = c0 + blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= c1) return;
+    for (int i = 0; i < K; i++) {
+        const int vtx = cv[(size_t)i*stride + k];
+        const double al = valpha[vtx], eta = planes[(size_t)(2*K + i)*stride + k];
+        const double ral = swe_rcp(al);
+        const double psi = fmin(1.0, fmax(0.0, -(vh[vtx] + eta)*ral - 1.0));
+        if (psi > 0.0) {
+            const double fac = exp(-dt_stage*(1.0/SWE_WD_TAU)*swe_sqrt(g*ral)*psi*psi);
+            planes[(size_t)i*stride + k] *= fac;
+            planes[(size_t)(K + i)*stride + k] *= fac;
+        }
+    }
 }
 
 // diagnostics: per-block partial sums { int eta^2, int |u|^2, int (eta+h), min(h+eta) }, finished on the host
@@ -2006,7 +2030,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         ov[i] = fma(s, fma(4.0, bv[n2], fma(-8.0, bv[n3], fma(-8.0, bv[n1], 16.0*bv[i]))), wv[i]);
         oe[i] = fma(s, fma(4.0, be[n2], fma(-8.0, be[n3], fma(-8.0, be[n1], 16.0*be[i]))), we[i]);
     }
-    if (WD && !(p.a0 == 0.0 && p.a1 == 0.0)) swe_wd_finish<4>(p.g, p.beta*p.dt, h, al, ou, ov, oe);
+    if (WD && !(p.a0 == 0.0 && p.a1 == 0.0)) swe_wd_finish<4>(p.g, p.beta*p.dt, h, al, ou, ov, oe, !p.wd_skip_relax);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         swe_st(swe_rsrc(p.uout), k8, i*S8, ou[i]);

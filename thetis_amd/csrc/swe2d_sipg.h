@@ -36,6 +36,7 @@ struct SweSipgArgs {
     int n_list;
     // viscosity only
     int grad_div, grad_depth, nonlin;
+    int wd;                 // wetting-drying: the total depth is the nodally displaced depth D (valpha per vertex)
     const double *eta;      // 3 planes (total depth of the grad-depth term and of 'flux' boundaries)
     SweBcTable bc;
     const double *bc_elev_f, *bc_uv_f, *bc_un_f, *bc_flux_f;     // per-facet planes, see SweStageArgs
@@ -129,19 +130,20 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
 #pragma unroll
             for (int i = 0; i < 3; i++) b[r][i] = BND_ONLY ? 0.0 : -am*(gx[i]*S0[r][0] + gy[i]*S0[r][1]);     // inner(grad test, stress)*dx
     }
-    double eo[3] = {0.0, 0.0, 0.0}, ho[3] = {0.0, 0.0, 0.0};
+    double eo[3] = {0.0, 0.0, 0.0}, ho[3] = {0.0, 0.0, 0.0}, alo[3] = {0.0, 0.0, 0.0};
     if (NC == 2) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             ho[i] = swe_ld(swe_rsrc(p.vh), (unsigned)vid[i]*8u, 0);
             eo[i] = swe_ld(swe_rsrc(p.eta), k8, i*S8);
+            if (p.wd) alo[i] = swe_ld(swe_rsrc(p.valpha), (unsigned)vid[i]*8u, 0);
         }
     }
     if (NC == 2 && p.grad_depth && !BND_ONLY) {
         // -dot(test, dot(grad(H)/H, stress))*dx, shallowwater_eq.py:611-612; 6-point rule as the drag terms
         double Hn[3];
 #pragma unroll
-        for (int i = 0; i < 3; i++) Hn[i] = p.nonlin ? ho[i] + eo[i] : ho[i];
+        for (int i = 0; i < 3; i++) Hn[i] = p.wd ? swe_wd_depth(ho[i] + eo[i], alo[i]) : (p.nonlin ? ho[i] + eo[i] : ho[i]);
         const double gHx = Hn[0]*gx[0] + Hn[1]*gx[1] + Hn[2]*gx[2], gHy = Hn[0]*gy[0] + Hn[1]*gy[1] + Hn[2]*gy[2];
         double t[2];
 #pragma unroll
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
                     } else {
                         const double eq = xa*eo[a] + xb*eo[bb], hq = xa*ho[a] + xb*ho[bb];
                         const double e_ext = (kind & SWE_BC_ELEV) ? ((kind & SWE_BC_ELEV_FIELD) ? xa*fea + xb*feb : p.bc.elev[marker]) : eq;
-                        const double H0 = p.nonlin ? hq + e_ext : hq;
+                        const double H0 = p.wd ? swe_wd_depth(hq + e_ext, xa*alo[a] + xb*alo[bb]) : (p.nonlin ? hq + e_ext : hq);
                         const double s = ((kind & SWE_BC_FLUX_FIELD) ? xa*fxa + xb*fxb : p.bc.flux[marker])/(H0*p.bc.len[marker]);
                         dlt[0] = uq - s*n0; dlt[1] = vq - s*n1;
                     }
@@ -386,12 +388,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
     const double ax = px[1] - px[0], ay = py[1] - py[0], bx = px[3] - px[0], by = py[3] - py[0];
     const double A = ax*by - ay*bx, rA = swe_rcp(A);
     const double gxi_x = by*rA, gxi_y = -bx*rA, gze_x = -ay*rA, gze_y = ax*rA;     // grad(xi), grad(zeta)
-    double eo[4] = {0.0, 0.0, 0.0, 0.0}, ho[4] = {0.0, 0.0, 0.0, 0.0};
+    double eo[4] = {0.0, 0.0, 0.0, 0.0}, ho[4] = {0.0, 0.0, 0.0, 0.0}, alo[4] = {0.0, 0.0, 0.0, 0.0};
     if (NC == 2) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             ho[i] = swe_ld(swe_rsrc(p.vh), (unsigned)vid[i]*8u, 0);
             eo[i] = swe_ld(swe_rsrc(p.eta), k8, i*S8);
+            if (p.wd) alo[i] = swe_ld(swe_rsrc(p.valpha), (unsigned)vid[i]*8u, 0);
         }
     }
     double b[NC][4];
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
             for (int i = 0; i < 4; i++) {
                 muq += phi[i]*mu[i];
                 if (NC == 2 && p.grad_depth) {
-                    const double Hn = p.nonlin ? ho[i] + eo[i] : ho[i];
+                    const double Hn = p.wd ? swe_wd_depth(ho[i] + eo[i], alo[i]) : (p.nonlin ? ho[i] + eo[i] : ho[i]);
                     Hq += phi[i]*Hn; gHx += gx[i]*Hn; gHy += gy[i]*Hn;
                 }
             }
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
                     } else {
                         const double eq = xa*eo[a] + xb*eo[bb], hq = xa*ho[a] + xb*ho[bb];
                         const double e_ext = (kind & SWE_BC_ELEV) ? ((kind & SWE_BC_ELEV_FIELD) ? xa*fea + xb*feb : p.bc.elev[marker]) : eq;
-                        const double H0 = p.nonlin ? hq + e_ext : hq;
+                        const double H0 = p.wd ? swe_wd_depth(hq + e_ext, xa*alo[a] + xb*alo[bb]) : (p.nonlin ? hq + e_ext : hq);
                         const double sc = ((kind & SWE_BC_FLUX_FIELD) ? xa*fxa + xb*fxb : p.bc.flux[marker])/(H0*p.bc.len[marker]);
                         dlt[0] = uq - sc*n0; dlt[1] = vq - sc*n1;
                     }

@@ -62,8 +62,6 @@ class ShallowWaterEquations(object):
         nu = fields.get('viscosity_h')
         if nu is not None:
             # HorizontalViscosityTerm (SIPG, shallowwater_eq.py:554-616): swe_sipg_kernel<2> / swe_sipg_kernel_quad<2>
-            if self.depth.use_wetting_and_drying:
-                raise NotImplementedError('HorizontalViscosityTerm with wetting and drying is not implemented')
             if isinstance(nu, Function) and nu.function_space().family != 'CG':
                 raise NotImplementedError('horizontal_viscosity must be a Constant or a continuous (CG-P1) Function')
         if fields.get('quadratic_drag_coefficient') is not None and fields.get('manning_drag_coefficient') is not None:
