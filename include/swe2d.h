@@ -335,6 +335,18 @@ int  swe2d_swap_state_buffers(swe2d_handle *h);
  * (swe2d_flow_status reads the count without failing). */
 int  swe2d_solve_flow(swe2d_handle *h, int32_t n_stages, const int32_t *cell_end);
 int  swe2d_flow_supported(swe2d_handle *h);
+/* The same with the peer-to-peer halo exchange of a partition INSIDE the launch (channel 0 of swe2d_p2p_*, connected): n_cycles
+ * exchange cycles (at most 16) of stages_per_cycle stages each (at most 48 stages in all) on the ranges cell_end[0 .. stages_per_cycle)
+ * of ONE cycle.  Every cycle but the launch's first starts by receiving what the peers pushed at the end of their previous cycle
+ * (the ghost cells' lanes read the landing zone; the first cycle does so too if a push of an earlier launch is still pending, i.e.
+ * pushes > receives in swe2d_p2p_status), and ends by pushing this rank's send cells into the peers' zones.  One launch replaces
+ * n_cycles x (swe2d_solve_flow + swe2d_p2p_push + swe2d_p2p_wait_unpack) - except that the LAST cycle's push is received by the
+ * next launch of this kind or by an explicit swe2d_p2p_wait_unpack(h, 0, 0) (needed before the state leaves the device).  Cells
+ * sent to more than two peers are not supported (SWE2D_ERR_UNSUPPORTED).  Same results bit for bit. */
+int  swe2d_solve_flow_exchange(swe2d_handle *h, int32_t n_cycles, int32_t stages_per_cycle, const int32_t *cell_end);
+/* builds the tables of the former ahead of its first launch (which otherwise does it: allocations and a stream synchronisation,
+ * not allowed inside a stream capture); after swe2d_halo_setup and swe2d_flow_set_order */
+int  swe2d_flow_prepare_exchange(swe2d_handle *h);
 /* The kernel's 64-cell blocks are consecutive cells of a FLOW ORDER (default: the numbering of swe2d_mesh).  A partition whose
  * ghost layers are appended to the numbering layer by layer (what the stage ranges need) passes an order - a permutation of
  * the cell ids - in which every ghost cell sits next to the cells it touches: blocks then stay compact patches and few facets

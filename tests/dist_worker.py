@@ -347,7 +347,7 @@ def viscosity_field(mesh):
 def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     global CASE
     flags = {}
-    for f in ('+capture', '+graph', '+p2p', '+nosplit', '+flow'):   # order-independent suffix flags
+    for f in ('+capture', '+graph', '+p2p', '+nosplit', '+flowx', '+flow'):   # order-independent suffix flags
         flags[f] = f in case
         case = case.replace(f, '')
     graphed = flags['+graph']              # per-cycle HIP graphs (around the eager host-staged exchange, or incl. the p2p kernels)
@@ -365,7 +365,7 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     owner = strip_owner(mesh, world, axis=axis)
     solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, exchange=('p2p' if flags['+p2p'] else 'host'),
                               exchange_every=every, overlap_stages=overlap, split_last_stage=not flags['+nosplit'],
-                              stepper=('ForwardEuler' if fe else 'SSPRK33'), flow=(True if flags['+flow'] else False))
+                              stepper=('ForwardEuler' if fe else 'SSPRK33'), flow=(True if (flags['+flow'] or flags['+flowx']) else False), flow_exchange=flags['+flowx'])
     if viscous:     # SIPG pass on the partition: same cell ranges as the stage kernels, per-vertex viscosity of the local vertices
         solver.dev.set_viscosity(viscosity_field(mesh)[solver.part.vertex_global], use_grad_div_viscosity_term=True)
     solver.set_state_global(uv, eta)

@@ -112,6 +112,8 @@ SYMBOLS = {
     'swe2d_swap_state_buffers': (ctypes.c_int, [_H]),
     'swe2d_solve_flow': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_flow_supported': (ctypes.c_int, [_H]),
+    'swe2d_flow_prepare_exchange': (ctypes.c_int, [_H]),
+    'swe2d_solve_flow_exchange': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_flow_set_order': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_flow_status': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_debug_flow_poke': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),

@@ -117,6 +117,13 @@ struct Handle {
     int2 *flow_xo2 = nullptr;
     int2 *flow_xblk = nullptr;
     int *flow_xsrc = nullptr;
+    std::vector<int> h_send, h_recv;                    // host copies of the halo lists (swe2d_halo_setup)
+    std::vector<int> flow_fpos;                         // cell -> flow position
+    int2 *flow_xsend = nullptr;                         // FX: per position, the cell's places in the send list
+    int *flow_xrecv = nullptr;                          // FX: per position, the cell's place in the receive list
+    unsigned *flow_xtick = nullptr;
+    int flow_push_blocks = 0, flow_recv_blocks = 0;
+    bool flow_x_ready = false;                          // the FX tables match the halo lists and the flow order
     int *flow_cell = nullptr;                           // [flow_blocks*64] flow position -> cell (< 0: padding lane, -1 - cell to mimic)
     unsigned flow_parity_bytes = 0;
     void *flow_ex = nullptr;
@@ -476,6 +483,7 @@ int flow_build(Handle *h, const int32_t *order)
     std::vector<int> own((size_t)3*nb*SWE_BLOCK, -1);                                // global slot of (position, f)
     std::vector<int2> blk((size_t)nb, int2{0, 0});
     int n_slots = 0;
+    bool too_many = false;
     std::vector<Rim> rim;
     for (int b = 0; b < nb; b++) {
         rim.clear();
@@ -486,6 +494,7 @@ int flow_build(Handle *h, const int32_t *order)
             }
         std::sort(rim.begin(), rim.end(), [](const Rim &x, const Rim &y) {
             return x.nbblock != y.nbblock ? x.nbblock < y.nbblock : (x.pos != y.pos ? x.pos < y.pos : x.f < y.f); });
+        if ((int)rim.size() > SWE_FLOW_MAX_RIM) too_many = true;      // the kernel's staging area holds SWE_FLOW_MAX_RIM facets
         blk[b] = int2{n_slots, (int)rim.size()};
         for (const Rim &r : rim) own[(size_t)3*r.pos + r.f] = n_slots++;
     }
@@ -526,11 +535,15 @@ int flow_build(Handle *h, const int32_t *order)
         p2[pp] = int2{w[1], w[2]};
     }
     // (slot << 6 must fit an int, the exchange array must stay below SWE_FLOW_NOWHERE)
-    if (!((size_t)2*n_slots*SWE_FLOW_SLOT_BYTES < ((size_t)1 << 31) && n_slots < (1 << 25))) return SWE2D_OK;    // no flow kernel for this handle
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (void *ptr : {(void *)h->flow_xblk, (void *)h->flow_xsrc, (void *)h->flow_xo4, (void *)h->flow_xo2, (void *)h->flow_ex, (void *)h->flow_cell})
         if (ptr) (void)hipFree(ptr);
     h->flow_xblk = nullptr; h->flow_xsrc = nullptr; h->flow_xo4 = nullptr; h->flow_xo2 = nullptr; h->flow_ex = nullptr; h->flow_cell = nullptr;
+    // no flow kernel for this handle / this order: a block with more rim facets than the staging area holds (cells numbered without
+    // locality), or slot numbers that do not fit
+    if (too_many || !((size_t)2*n_slots*SWE_FLOW_SLOT_BYTES < ((size_t)1 << 31) && n_slots < (1 << 25))) return SWE2D_OK;
+    h->flow_fpos = fpos;
+    h->flow_x_ready = false;
     h->flow_parity_bytes = (unsigned)((size_t)std::max(n_slots, 1)*SWE_FLOW_SLOT_BYTES);
     h->flow_ex_bytes = (size_t)2*h->flow_parity_bytes;
     HIP_TRY(h, hipMalloc(&h->flow_xblk, blk.size()*sizeof(int2)));
@@ -553,11 +566,15 @@ int flow_build(Handle *h, const int32_t *order)
 // ---- dataflow stage loop (swe2d_flow.h)
 typedef void (*flow_kernel_t)(const SweFlowArgs);
 template <bool NL, bool LF>
-flow_kernel_t pick_flow_src(bool src) { return src ? swe_flow_kernel<NL, LF, true> : swe_flow_kernel<NL, LF, false>; }
-flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src)
+flow_kernel_t pick_flow_src(bool src, bool fx)
 {
-    return nl ? (lf ? pick_flow_src<true, true>(src) : pick_flow_src<true, false>(src))
-              : (lf ? pick_flow_src<false, true>(src) : pick_flow_src<false, false>(src));
+    if (fx) return src ? swe_flow_kernel<NL, LF, true, true> : swe_flow_kernel<NL, LF, false, true>;
+    return src ? swe_flow_kernel<NL, LF, true, false> : swe_flow_kernel<NL, LF, false, false>;
+}
+flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src, bool fx = false)
+{
+    return nl ? (lf ? pick_flow_src<true, true>(src, fx) : pick_flow_src<true, false>(src, fx))
+              : (lf ? pick_flow_src<false, true>(src, fx) : pick_flow_src<false, false>(src, fx));
 }
 
 // the configurations the flow kernel covers (the step kernel's: triangles, no wetting-drying, no viscosity)
@@ -574,7 +591,7 @@ int flow_capacity(Handle *h)
     if (h->flow_capacity >= 0) return h->flow_capacity;
     h->flow_capacity = 0;
     int per_cu = 0, dev_cus = 0;
-    flow_kernel_t kern = pick_flow_kernel(true, true, true);           // the largest variant
+    flow_kernel_t kern = pick_flow_kernel(true, true, true, true);     // the largest variant
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), SWE_BLOCK, 0) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) return 0;
     if (const char *e = std::getenv("THETIS_AMD_FLOW_CAPACITY")) h->flow_capacity = std::atoi(e);      // tests: force the limit
@@ -582,29 +599,100 @@ int flow_capacity(Handle *h)
     return h->flow_capacity;
 }
 
-// n_stages stages (a multiple of 3) on the ranges [0, cell_end[s]) in ONE launch
-int launch_flow(Handle *h, int n_stages, const int32_t *cell_end)
+// byte offset of channel c's slot 0 in the landing zone of a rank with n_recv halo cells (both sides compute it)
+size_t p2p_channel_offset(const int *width, int c, int n_recv)
+{
+    size_t off = SWE_P2P_HEADER_BYTES;
+    for (int i = 0; i < c; i++) off += 2*(size_t)n_recv*width[i]*sizeof(double);
+    return off;
+}
+
+// FX launches: the places of every flow position's cell in the halo lists, the blocks that hold send / ghost cells
+int flow_build_exchange(Handle *h)
+{
+    if (h->flow_x_ready) return SWE2D_OK;
+    const int np = h->flow_blocks*SWE_BLOCK;
+    if ((int)h->flow_fpos.size() != h->n_cells) return fail(h, SWE2D_ERR_UNSUPPORTED, "flow: no tables");
+    std::vector<int2> xs((size_t)np, int2{-1, -1});
+    std::vector<int> xr((size_t)np, -1);
+    for (int j = 0; j < h->n_send; j++) {
+        int2 &e = xs[h->flow_fpos[h->h_send[j]]];
+        if (e.x < 0) e.x = j;
+        else if (e.y < 0) e.y = j;
+        else return fail(h, SWE2D_ERR_UNSUPPORTED, "flow with the exchange inside: a cell is sent to more than two peers");
+    }
+    for (int j = 0; j < h->n_recv; j++) xr[h->flow_fpos[h->h_recv[j]]] = j;
+    h->flow_push_blocks = h->flow_recv_blocks = 0;
+    for (int b = 0; b < h->flow_blocks; b++) {
+        bool anys = false, anyr = false;
+        for (int l = 0; l < SWE_BLOCK; l++) { anys = anys || xs[(size_t)b*SWE_BLOCK + l].x >= 0; anyr = anyr || xr[(size_t)b*SWE_BLOCK + l] >= 0; }
+        h->flow_push_blocks += anys; h->flow_recv_blocks += anyr;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!h->flow_xsend) HIP_TRY(h, hipMalloc(&h->flow_xsend, (size_t)np*sizeof(int2)));
+    if (!h->flow_xrecv) HIP_TRY(h, hipMalloc(&h->flow_xrecv, (size_t)np*sizeof(int)));
+    if (!h->flow_xtick) {
+        HIP_TRY(h, hipMalloc(&h->flow_xtick, SWE_FLOW_MAX_CYCLES*sizeof(unsigned)));
+        HIP_TRY(h, hipMemset(h->flow_xtick, 0, SWE_FLOW_MAX_CYCLES*sizeof(unsigned)));
+    }
+    HIP_TRY(h, hipMemcpy(h->flow_xsend, xs.data(), (size_t)np*sizeof(int2), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->flow_xrecv, xr.data(), (size_t)np*sizeof(int), hipMemcpyHostToDevice));
+    h->flow_x_ready = true;
+    return SWE2D_OK;
+}
+
+// n_stages stages (a multiple of 3) on the ranges [0, cell_end[s]) in ONE launch; n_cycles > 0: n_cycles exchange cycles of
+// n_stages stages each with the peer-to-peer halo exchange (channel 0) inside the launch
+int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles = 0)
 {
     if (!flow_kernel_covers(h)) return fail(h, SWE2D_ERR_UNSUPPORTED, "the flow kernel covers triangles without wetting-drying and viscosity");
-    if (n_stages <= 0 || n_stages % 3 != 0 || n_stages > SWE_FLOW_MAX_STAGES)
-        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "flow: n_stages must be a multiple of 3 in 3..48");
+    const bool fx = n_cycles > 0;
+    const int total = n_stages*(fx ? n_cycles : 1);
+    if (n_stages <= 0 || n_stages % 3 != 0 || total > SWE_FLOW_MAX_STAGES || n_cycles > SWE_FLOW_MAX_CYCLES)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "flow: n_stages must be a multiple of 3, at most 48 stages and 16 cycles per launch");
     for (int s = 0; s < n_stages; s++)
         if (cell_end[s] < 0 || cell_end[s] > h->n_cells || (s > 0 && cell_end[s] > cell_end[s - 1]))
             return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "flow: the stage ranges must shrink and stay inside the mesh");
     const int grid = ((h->flow_blocks + 7)/8)*8;
     if (grid > flow_capacity(h)) return fail(h, SWE2D_ERR_UNSUPPORTED, "flow: more 64-cell blocks than the device holds resident at once");
-    SweFlowArgs q;
+    SweFlowArgs q{};
+    if (fx) {
+        auto &z = h->p2p;
+        if (!z.zone || !z.ctr || z.n_peers == 0 || z.n_from == 0 || h->n_send == 0 || h->n_recv == 0)
+            return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "flow with the exchange inside: the peer-to-peer halo is not connected");
+        if (z.width[0] != 9) return fail(h, SWE2D_ERR_UNSUPPORTED, "flow with the exchange inside: channel 0 must carry the shallow water state");
+        if (int rc = flow_build_exchange(h)) return rc;
+        q.n_cycles = n_cycles; q.stages_per_cycle = n_stages;
+        q.xsend = h->flow_xsend; q.xrecv = h->flow_xrecv; q.xtick = h->flow_xtick;
+        q.n_push_blocks = h->flow_push_blocks; q.n_recv_blocks = h->flow_recv_blocks;
+        q.xctr = z.ctr;
+        q.x_n_peers = z.n_peers; q.x_n_from = z.n_from;
+        for (int i = 0; i < z.n_peers; i++) {                // as swe2d_p2p_push, channel 0
+            q.x_off[i] = z.off[i]; q.x_cnt[i] = z.cnt[i];
+            char *base = z.remote_base[i];
+            q.x_rdata[i] = reinterpret_cast<double *>(base + p2p_channel_offset(z.width, 0, z.remote_n_recv[i])) + (size_t)z.remote_off[i]*9;
+            q.x_rslot[i] = (size_t)z.remote_n_recv[i]*9;
+            q.x_rflag[i] = reinterpret_cast<unsigned long long *>(base) + (size_t)z.remote_flag[i]*SWE_P2P_FLAG_STRIDE;
+        }
+        char *mine = static_cast<char *>(z.zone);            // as swe2d_p2p_wait_unpack, channel 0
+        for (int i = 0; i < z.n_from; i++)
+            q.x_flag[i] = reinterpret_cast<const unsigned long long *>(mine) + (size_t)i*SWE_P2P_FLAG_STRIDE;
+        q.x_zone = reinterpret_cast<const double *>(mine + p2p_channel_offset(z.width, 0, h->n_recv));
+        q.x_slot = (size_t)h->n_recv*9;
+        q.x_timeout = (unsigned long long)(z.timeout_s*1e8);
+        q.x_fence = z.zone_kind == 3;
+    }
     fill_stage_args(h, q.st, 0, 0, 1, 0.0, 1.0, 1.0, 0, 0);
     for (int i = 0; i < 3; i++) q.buf[i] = h->state[i];
     q.flag = h->flow_flag; q.status = h->flow_status;
     q.xo4 = h->flow_xo4; q.xo2 = h->flow_xo2; q.ex = h->flow_ex;
     q.xblk = h->flow_xblk; q.xsrc = h->flow_xsrc; q.parity_bytes = h->flow_parity_bytes;
     q.fcell = h->flow_cell;
-    q.n_blocks = h->flow_blocks; q.n_stages = n_stages;
+    q.n_blocks = h->flow_blocks; q.n_stages = total;
     for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) q.cell_end[s] = s < n_stages ? cell_end[s] : 0;
     for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
     q.timeout_ticks = (unsigned long long)(h->flow_timeout_s*1e8);
-    flow_kernel_t kern = pick_flow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h));
+    flow_kernel_t kern = pick_flow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h), fx);
     SWE_CHK_SYNC(h->stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, q);
     HIP_TRY(h, hipGetLastError());
@@ -866,7 +954,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
     for (void *m : h->p2p.opened) (void)hipIpcCloseMemHandle(m);
@@ -1252,6 +1340,23 @@ int swe2d_solve_flow(swe2d_handle *hh, int32_t n_stages, const int32_t *cell_end
     return launch_flow(h, n_stages, cell_end);
 }
 
+int swe2d_solve_flow_exchange(swe2d_handle *hh, int32_t n_cycles, int32_t stages_per_cycle, const int32_t *cell_end)
+{
+    Handle *h = H(hh);
+    if (!h || !cell_end || n_cycles < 1) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    RoctxRange range("swe2d_solve_flow_exchange");
+    return launch_flow(h, stages_per_cycle, cell_end, n_cycles);
+}
+
+int swe2d_flow_prepare_exchange(swe2d_handle *hh)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return flow_build_exchange(h);
+}
+
 int swe2d_flow_set_order(swe2d_handle *hh, const int32_t *cells_in_flow_order)
 {
     Handle *h = H(hh);
@@ -1451,6 +1556,9 @@ int swe2d_halo_setup(swe2d_handle *hh, int32_t n_send, const int32_t *send_cells
     if (h->recv_cells) { HIP_TRY(h, hipFree(h->recv_cells)); h->recv_cells = nullptr; }
     h->n_send = n_send;
     h->n_recv = n_recv;
+    h->h_send.assign(send_cells, send_cells + n_send);
+    h->h_recv.assign(recv_cells, recv_cells + n_recv);
+    h->flow_x_ready = false;
     if (n_send > 0) {
         HIP_TRY(h, hipMalloc(&h->send_cells, (size_t)n_send*sizeof(int)));
         HIP_TRY(h, hipMemcpy(h->send_cells, send_cells, (size_t)n_send*sizeof(int), hipMemcpyHostToDevice));
@@ -2104,15 +2212,6 @@ int swe2d_advance_coupled(swe2d_handle *hh, int n_steps, int tracer_only, int us
 
 // ------------------------------------------------------------------------------------------------------------------
 // peer-to-peer halo exchange (swe2d_p2p.h)
-namespace {
-// byte offset of channel c's slot 0 in the landing zone of a rank with n_recv halo cells (both sides compute it)
-size_t p2p_channel_offset(const int *width, int c, int n_recv)
-{
-    size_t off = SWE_P2P_HEADER_BYTES;
-    for (int i = 0; i < c; i++) off += 2*(size_t)n_recv*width[i]*sizeof(double);
-    return off;
-}
-}  // namespace
 
 extern "C" {
 

@@ -54,16 +54,18 @@
 // the same `fp contract(off)`: bit for bit the result of the stage launches on the same ranges (tests/test_gpu_flow_kernel.py).
 #pragma once
 #include "swe2d_kernels.h"
+#include "swe2d_p2p.h"
 
 #ifndef SWE_FLOW_OCCUPANCY
 #define SWE_FLOW_OCCUPANCY __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 VGPRs: two one-wave workgroups per SIMD
 #endif
 #define SWE_FLOW_MAX_STAGES 48             // 16 time steps per launch
+#define SWE_FLOW_MAX_CYCLES 16             // exchange cycles per launch (FX kernels)
 #ifndef SWE_FLOW_FLAG_STRIDE
 #define SWE_FLOW_FLAG_STRIDE 16           // unsigned words between two blocks' stage counters (64 B)
 #endif
 #define SWE_FLOW_SLOT_BYTES 128            // exchange slot of one rim facet and stage parity: 8 granules of 16 B (6 values + 2 pads)
-#define SWE_FLOW_MAX_RIM (3*SWE_BLOCK)     // rim facets of a block
+#define SWE_FLOW_MAX_RIM 160               // rim facets of a block (3*64 at worst: such flow orders are refused, see flow_build)
 
 typedef unsigned int swe_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int swe_u32x3 __attribute__((ext_vector_type(3)));
@@ -88,6 +90,26 @@ struct SweFlowArgs {
     int cell_end[SWE_FLOW_MAX_STAGES];     // stage s updates the cells [0, cell_end[s]); non-increasing
     double a0[3], a1[3], beta[3];          // Shu-Osher weights per stage (swe2d_ssprk33_coefficients)
     unsigned long long timeout_ticks;      // wall_clock64 ticks (100 MHz)
+    // ---- FX kernels: the halo exchange of a partition inside the launch (peer-to-peer channel 0 of swe2d_p2p.h).  The launch
+    //      runs n_cycles exchange cycles of stages_per_cycle stages (n_stages = their product; cell_end[g] holds the ranges of
+    //      ONE cycle): a cycle starts with the receive of the previous cycle's push (ghost lanes read their cells from the landing
+    //      zone), ends with the push of the send cells into the peers' zones.
+    int n_cycles, stages_per_cycle;
+    const int2 *xsend;                     // per position: the cell's (up to two) places in the send list, -1: none
+    const int *xrecv;                      // per position: the cell's place in the receive list, -1: not a ghost cell
+    int n_push_blocks, n_recv_blocks;      // blocks holding send cells / ghost cells
+    unsigned *xtick;                       // [SWE_FLOW_MAX_CYCLES] arrival counters of a cycle's receives and pushes (self-cleaning)
+    SweP2pCounters *xctr;                  // epochs of channel 0
+    int x_n_peers, x_n_from;
+    int x_off[SWE_P2P_MAX_PEERS], x_cnt[SWE_P2P_MAX_PEERS];                 // per peer: segment of the send list (cells)
+    double *x_rdata[SWE_P2P_MAX_PEERS];                                      // peer's landing segment for me, slot 0
+    size_t x_rslot[SWE_P2P_MAX_PEERS];                                       // doubles between the peer's slot 0 and slot 1
+    unsigned long long *x_rflag[SWE_P2P_MAX_PEERS];                          // my flag in the peer's header
+    const unsigned long long *x_flag[SWE_P2P_MAX_PEERS];                     // the peers' flags in MY header
+    const double *x_zone;                                                    // my landing data, slot 0
+    size_t x_slot;                                                           // doubles between slot 0 and slot 1
+    unsigned long long x_timeout;                                            // wall_clock64 ticks
+    int x_fence;                                                             // the zone is ordinary device memory: acquire fence after the wait
 };
 
 // one granule: {value, tag} written / read by ONE 16-byte access of one lane, sc1 (aux 16): write-through / past the L1
@@ -268,13 +290,18 @@ __device__ __forceinline__ void swe_flow_finish(const SweStageArgs &p, int k, do
 #define SWE_FLOW_XG (9*SWE_BLOCK)
 #define SWE_FLOW_LDS_DOUBLES (SWE_FLOW_XG + 6*SWE_FLOW_MAX_RIM)
 
-template <bool NONLIN, bool LF, bool SRC>
+// FX = false: n_stages stages on the ranges cell_end[0 .. n_stages); the rim traces of the first stage come from the state planes.
+// FX = true:  n_cycles exchange cycles (see SweFlowArgs); every cycle starts by publishing its input across the rims (the ghost
+//             cells' input arrives in the landing zone, not in the planes), so a stage always finds its rim traces in granules.
+// Tags count publishes: publish number pc of the launch carries tag base + pc + 1 and goes to slot parity pc & 1.
+template <bool NONLIN, bool LF, bool SRC, bool FX>
 __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(const SweFlowArgs q)
 {
 #pragma clang fp contract(off)
     __shared__ double lds[SWE_FLOW_LDS_DOUBLES];
     __shared__ int xsrc[SWE_FLOW_MAX_RIM];                     // the block's incoming list (SweFlowArgs::xsrc)
     __shared__ int lact[SWE_BLOCK];                            // is the lane's cell inside the running stage's range?
+    __shared__ double lu0[9][SWE_BLOCK];                       // U(0) of the running time step (18 registers the stage loop cannot spare)
     const SweStageArgs &p = q.st;
     const int lb = swe_logical_block(blockIdx.x, gridDim.x);
     if (lb >= q.n_blocks) return;                              // padding of the grid to a multiple of 8
@@ -285,9 +312,9 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
     const size_t S = p.stride;
     const unsigned S8 = (unsigned)S*8u;
     unsigned *const myflag = q.flag + (size_t)lb*SWE_FLOW_FLAG_STRIDE;
-    const unsigned base = *myflag;                             // stages counted so far: written by this block's wave in the previous launch
+    const unsigned base = *myflag;                             // publishes counted so far: written by this block's wave in the previous launch
     const unsigned fin = base + (unsigned)q.n_stages;
-    if (!__any(real && k < q.cell_end[0])) {                   // this block takes part in no stage of the launch
+    if (!FX && !__any(real && k < q.cell_end[0])) {            // this block takes part in no stage of the launch
         if (lane == 0) *myflag = fin;
         return;
     }
@@ -326,7 +353,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             v[i] = swe_ld(gv, k8, i*S8);
             e[i] = swe_ld(ge, k8, i*S8);
         }
-        double r0[3][6];                   // first stage: the rim traces come from the state planes too
+        double r0[3][6];                   // first stage (FX = false): the rim traces come from the state planes too
 #pragma unroll
         for (int f = 0; f < 3; f++) {
             const int nbf = nb[f];
@@ -341,13 +368,15 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                 const unsigned aa = rim ? (unsigned)(SWE_FLOW_XG + 6*xin[f] + 3 + c) : (unsigned)((3*c + f2a)*SWE_BLOCK + ls);
                 tr[f][c] = ab | (aa << 16);
             }
-            const int code = rim ? nbf : ((k << 2) | f);
-            const unsigned kn8 = (unsigned)(code >> 2)*8u;
-            const int g2 = code & 3;
-            const unsigned ob = kn8 + (g2 == 0 ? 0u : (g2 == 1 ? S8 : 2u*S8));         // node g2
-            const unsigned oa = kn8 + (g2 == 0 ? S8 : (g2 == 1 ? 2u*S8 : 0u));         // node (g2 + 1) % 3
-            r0[f][0] = swe_ld(gu, ob, 0); r0[f][1] = swe_ld(gv, ob, 0); r0[f][2] = swe_ld(ge, ob, 0);
-            r0[f][3] = swe_ld(gu, oa, 0); r0[f][4] = swe_ld(gv, oa, 0); r0[f][5] = swe_ld(ge, oa, 0);
+            if (!FX) {
+                const int code = rim ? nbf : ((k << 2) | f);
+                const unsigned kn8 = (unsigned)(code >> 2)*8u;
+                const int g2 = code & 3;
+                const unsigned ob = kn8 + (g2 == 0 ? 0u : (g2 == 1 ? S8 : 2u*S8));         // node g2
+                const unsigned oa = kn8 + (g2 == 0 ? S8 : (g2 == 1 ? 2u*S8 : 0u));         // node (g2 + 1) % 3
+                r0[f][0] = swe_ld(gu, ob, 0); r0[f][1] = swe_ld(gv, ob, 0); r0[f][2] = swe_ld(ge, ob, 0);
+                r0[f][3] = swe_ld(gu, oa, 0); r0[f][4] = swe_ld(gv, oa, 0); r0[f][5] = swe_ld(ge, oa, 0);
+            }
         }
         double px[3], py[3];
         const swe_rsrc_t rvx = swe_rsrc(p.vx), rvy = swe_rsrc(p.vy), rvh = swe_rsrc(p.vh);
@@ -364,150 +393,248 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             nx[f] = py[b] - py[f];
             ny[f] = px[f] - px[b];
         }
+        if (!FX) {
 #pragma unroll
-        for (int f = 0; f < 3; f++) {
-            if (xown[f] >= 0) {
+            for (int f = 0; f < 3; f++) {
+                if (xown[f] >= 0) {
 #pragma unroll
-                for (int j = 0; j < 6; j++) lds[SWE_FLOW_XG + 6*xin[f] + j] = r0[f][j];
+                    for (int j = 0; j < 6; j++) lds[SWE_FLOW_XG + 6*xin[f] + j] = r0[f][j];
+                }
             }
         }
     }
-    double u0[3], v0[3], e0[3];            // U(0) of the running time step
+    // ---- FX: this cell's places in the halo lists, the epochs the launch starts from
+    int xs1 = -1, xs2 = -1, xr = -1;
+    unsigned long long S0 = 0ull, R0 = 0ull;
+    bool pend0 = false, has_ghost = false, has_send = false;
+    if (FX) {
+        const int2 t = q.xsend[lb*SWE_BLOCK + lane];
+        xs1 = real ? t.x : -1; xs2 = real ? t.y : -1;
+        xr = real ? q.xrecv[lb*SWE_BLOCK + lane] : -1;
+        // both counters are only written by the launch's LAST arrival (below): stable for every wave of the launch
+        S0 = q.xctr->epoch_send; R0 = q.xctr->epoch_recv;
+        pend0 = S0 > R0;                   // a push of the previous launch has not been received yet
+        has_ghost = __any(xr >= 0);
+        has_send = __any(xs1 >= 0);
+    }
+    const int ncyc = FX ? q.n_cycles : 1, spc = FX ? q.stages_per_cycle : q.n_stages;
     unsigned long long t_start = 0ull;
     bool late = false;
+    int s = 0;                             // stage counter of the launch
+
+    // arrival at the end of a cycle's receive / push: the last one raises this rank's flags at the peers (all my ghost cells of
+    // the cycle have been read - the peers may overwrite that slot two pushes later - and all my send cells have landed)
+#define SWE_FLOW_ARRIVE(c_) do {                                                                                                  \
+        if (lane == 0) {                                                                                                          \
+            const unsigned expected = (unsigned)q.n_push_blocks + ((((c_) > 0) || pend0) ? (unsigned)q.n_recv_blocks : 0u);       \
+            const unsigned t_ = __hip_atomic_fetch_add(&q.xtick[(c_)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           \
+            if (t_ == expected - 1u) {                                                                                            \
+                __hip_atomic_store(&q.xtick[(c_)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                               \
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                                                                     \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                  \
+                for (int i_ = 0; i_ < q.x_n_peers; i_++)                                                                          \
+                    __hip_atomic_store(q.x_rflag[i_], S0 + (unsigned long long)(c_) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+                if ((c_) == ncyc - 1) {                                                                                           \
+                    q.xctr->epoch_send = S0 + (unsigned long long)ncyc;                                                           \
+                    q.xctr->epoch_recv = R0 + (unsigned long long)(ncyc - 1) + (pend0 ? 1ull : 0ull);                             \
+                }                                                                                                                 \
+            }                                                                                                                     \
+        }                                                                                                                         \
+    } while (0)
+
+    // publish the rim traces held in (pu, pv, pe) of the lanes in `who`: facet f carries my nodes f (granules 0-2) and f + 1
+    // (granules 3-5).  The values go to the staging area by slot, then the wave stores the block's whole slot range, consecutive
+    // lanes on consecutive granules (full lines).  (A rim cell outside `who` leaves its entry as it was: a value nobody reads.)
+#define SWE_FLOW_PUBLISH(pu, pv, pe, who, pc_) do {                                                                               \
+        const unsigned tag_ = base + (unsigned)(pc_) + 1u;                                                                        \
+        const unsigned par_ = ((unsigned)(pc_) & 1u)*q.parity_bytes + (unsigned)myslots.x*SWE_FLOW_SLOT_BYTES;                    \
+        __syncthreads();                                       /* every lane has read its incoming traces */                      \
+        _Pragma("unroll")                                                                                                         \
+        for (int f = 0; f < 3; f++) {                                                                                             \
+            if (xown[f] >= 0 && (who)) {                                                                                          \
+                const int a_ = f, b_ = (f + 1) % 3;                                                                               \
+                double *d_ = lds + SWE_FLOW_XG + 6*xown[f];                                                                       \
+                d_[0] = pu[a_]; d_[1] = pv[a_]; d_[2] = pe[a_]; d_[3] = pu[b_]; d_[4] = pv[b_]; d_[5] = pe[b_];                   \
+            }                                                                                                                     \
+        }                                                                                                                         \
+        __syncthreads();                                                                                                          \
+        for (int t_ = lane; t_ < 8*nrim; t_ += SWE_BLOCK) {                                                                       \
+            const int gi_ = t_ & 7;                                                                                               \
+            const double x_ = gi_ < 6 ? lds[SWE_FLOW_XG + 6*(t_ >> 3) + gi_] : 0.0;                                               \
+            swe_flow_put(rex, par_ + 16u*(unsigned)t_, x_, tag_);                                                                 \
+        }                                                                                                                         \
+    } while (0)
 
 #pragma unroll 1
-    for (int s = 0; s < q.n_stages; s++) {
-        const int end_s = q.cell_end[s];
-        const bool act = real && k < end_s;
-        if (!__any(act)) break;                                // retired: the ranges only shrink
-        const int i3 = s % 3;
-        SWE_FT(0);
-        // Opaque to the optimiser: without this every stage-invariant quantity (facet lengths, reciprocals, gradients ...) is
-        // hoisted out of the stage loop and kept live across it - past the register budget.  The per-stage kernel recomputes
-        // them in every stage as well.
-#pragma unroll
-        for (int i = 0; i < 3; i++) asm volatile("" : "+v"(nx[i]), "+v"(ny[i]), "+v"(h[i]));
-        asm volatile("" : "+v"(bmarkers));
-#pragma unroll
-        for (int f = 0; f < 3; f++) asm volatile("" : "+v"(tr[f][0]), "+v"(tr[f][1]), "+v"(tr[f][2]));
-        if (i3 == 0) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) { u0[i] = u[i]; v0[i] = v[i]; e0[i] = e[i]; }
-        }
-        // ---- the block's stage values for its own lanes
-#pragma unroll
-        for (int i = 0; i < 3; i++) { lds[i*SWE_BLOCK + lane] = u[i]; lds[(3 + i)*SWE_BLOCK + lane] = v[i]; lds[(6 + i)*SWE_BLOCK + lane] = e[i]; }
-        lact[lane] = act ? 1 : 0;
-        // ---- traces across the rim: the chunks the neighbour blocks wrote for this block, consecutive lanes on consecutive
-        //      granules, re-read until every granule a cell of this stage's range needs carries this stage's tag
-        if (s > 0) {
-            const unsigned need = base + (unsigned)s;          // written at the end of stage s - 1
-            const unsigned par = ((unsigned)(s - 1) & 1u)*q.parity_bytes;
-            __syncthreads();                                   // the incoming list / the previous stage's staging reads
-            for (unsigned spins = 0;; spins++) {
-                bool ok = true;
-                for (int c0 = 0; c0 < 8*nrim; c0 += 8*SWE_BLOCK) {         // eight loads per lane in flight (64 rim facets per trip)
-                    swe_u32x3 g[8];
-                    int ent[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int t = c0 + j*SWE_BLOCK + lane;
-                        ent[j] = t < 8*nrim ? xsrc[t >> 3] : -1;
-                        // a cell outside this stage's range needs nothing (and its neighbour may never have published)
-                        if (ent[j] >= 0 && !lact[ent[j] & (SWE_BLOCK - 1)]) ent[j] = -1;
-                        g[j] = swe_flow_get(rex, ent[j] >= 0 ? (unsigned)(ent[j] >> 6)*SWE_FLOW_SLOT_BYTES + 16u*(unsigned)(t & 7) + par
-                                                             : SWE_FLOW_NOWHERE);
+    for (int c = 0; c < ncyc; c++) {
+        if (FX) {
+            // ---- receive: the push the peers made at the end of the previous cycle (or launch)
+            if (((c > 0) || pend0) && has_ghost) {
+                const unsigned long long target = R0 + (unsigned long long)c + (pend0 ? 1ull : 0ull);
+                bool lost = q.xctr->timeouts != 0u;            // sticky, as in swe_p2p_unpack_kernel: a lost peer costs one bounded wait
+                const unsigned long long w0 = wall_clock64();
+                for (int i = 0; i < q.x_n_from && !lost; i++) {
+                    while (__hip_atomic_load(q.x_flag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
+                        if (wall_clock64() - w0 > q.x_timeout) { lost = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
                     }
+                }
+                if (lost && lane == 0) atomicAdd(&q.xctr->timeouts, 1u);
+                if (q.x_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                asm volatile("" ::: "memory");
+                if (xr >= 0) {
+                    const double *src = q.x_zone + (target & 1ull)*q.x_slot + (size_t)xr*9;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int t = c0 + j*SWE_BLOCK + lane;
-                        if (ent[j] >= 0) {
-                            ok = ok && (int)(g[j].z - need) >= 0;
-                            if ((t & 7) < 6) lds[SWE_FLOW_XG + 6*(t >> 3) + (t & 7)] = swe_flow_val(g[j]);
+                    for (int i = 0; i < 3; i++) { u[i] = swe_p2p_load(src + i); v[i] = swe_p2p_load(src + 3 + i); e[i] = swe_p2p_load(src + 6 + i); }
+                    // ... and into the state planes, for the kernels after this launch
+                    const swe_rsrc_t gou = swe_rsrc(q.buf[0]), gov = swe_rsrc(q.buf[0] + 3*S), goe = swe_rsrc(q.buf[0] + 6*S);
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { swe_st(gou, k8, i*S8, u[i]); swe_st(gov, k8, i*S8, v[i]); swe_st(goe, k8, i*S8, e[i]); }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zone has been read
+                SWE_FLOW_ARRIVE(c);
+            }
+            // ---- the cycle's input across the rims
+            SWE_FLOW_PUBLISH(u, v, e, real, c*spc);
+        }
+#pragma unroll 1
+        for (int g = 0; g < spc; g++, s++) {
+            const int end_s = q.cell_end[g];
+            const bool act = real && k < end_s;
+            if (!__any(act)) {                                 // the ranges of a cycle only shrink: nothing left for this block
+                if (FX) { s += spc - g; break; }               // ... until the next cycle
+                c = ncyc; break;
+            }
+            const int i3 = g % 3;
+            SWE_FT(0);
+            // Opaque to the optimiser: without this every stage-invariant quantity (facet lengths, reciprocals, gradients ...) is
+            // hoisted out of the stage loop and kept live across it - past the register budget.  The per-stage kernel recomputes
+            // them in every stage as well.
+#pragma unroll
+            for (int i = 0; i < 3; i++) asm volatile("" : "+v"(nx[i]), "+v"(ny[i]), "+v"(h[i]));
+            asm volatile("" : "+v"(bmarkers));
+#pragma unroll
+            for (int f = 0; f < 3; f++) asm volatile("" : "+v"(tr[f][0]), "+v"(tr[f][1]), "+v"(tr[f][2]));
+            if (i3 == 0) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) { lu0[i][lane] = u[i]; lu0[3 + i][lane] = v[i]; lu0[6 + i][lane] = e[i]; }
+            }
+            // ---- the block's stage values for its own lanes
+#pragma unroll
+            for (int i = 0; i < 3; i++) { lds[i*SWE_BLOCK + lane] = u[i]; lds[(3 + i)*SWE_BLOCK + lane] = v[i]; lds[(6 + i)*SWE_BLOCK + lane] = e[i]; }
+            lact[lane] = act ? 1 : 0;
+            // ---- traces across the rim: the chunks the neighbour blocks wrote for this block, consecutive lanes on consecutive
+            //      granules, re-read until every granule a cell of this stage's range needs carries this stage's tag
+            if (FX || g > 0) {
+                const int pc_in = FX ? c*spc + g : g - 1;      // the publish this stage reads
+                const unsigned need = base + (unsigned)pc_in + 1u;
+                const unsigned par = ((unsigned)pc_in & 1u)*q.parity_bytes;
+                __syncthreads();                               // the incoming list / the previous stage's staging reads
+                for (unsigned spins = 0;; spins++) {
+                    bool ok = true;
+                    for (int c0 = 0; c0 < 8*nrim; c0 += 8*SWE_BLOCK) {         // eight loads per lane in flight (64 rim facets per trip)
+                        swe_u32x3 gr[8];
+                        int ent[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const int t = c0 + j*SWE_BLOCK + lane;
+                            ent[j] = t < 8*nrim ? xsrc[t >> 3] : -1;
+                            // a cell outside this stage's range needs nothing (and its neighbour may never have published)
+                            if (ent[j] >= 0 && !lact[ent[j] & (SWE_BLOCK - 1)]) ent[j] = -1;
+                            gr[j] = swe_flow_get(rex, ent[j] >= 0 ? (unsigned)(ent[j] >> 6)*SWE_FLOW_SLOT_BYTES + 16u*(unsigned)(t & 7) + par
+                                                                  : SWE_FLOW_NOWHERE);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const int t = c0 + j*SWE_BLOCK + lane;
+                            if (ent[j] >= 0) {
+                                ok = ok && (int)(gr[j].z - need) >= 0;
+                                if ((t & 7) < 6) lds[SWE_FLOW_XG + 6*(t >> 3) + (t & 7)] = swe_flow_val(gr[j]);
+                            }
+                        }
+                    }
+                    if (__all(ok) || late) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if ((spins & 31u) == 31u) {
+                        const unsigned long long now = wall_clock64();
+                        if (t_start == 0ull) t_start = now;
+                        else if (now - t_start > q.timeout_ticks) {
+                            late = true;
+                            if (lane == 0 && atomicAdd(q.status, 1u) == 0u) q.status[1] = (unsigned)lb + 1u;
                         }
                     }
                 }
-                if (__all(ok) || late) break;
-                __builtin_amdgcn_s_sleep(2);
-                if ((spins & 31u) == 31u) {
-                    const unsigned long long now = wall_clock64();
-                    if (t_start == 0ull) t_start = now;
-                    else if (now - t_start > q.timeout_ticks) {
-                        late = true;
-                        if (lane == 0 && atomicAdd(q.status, 1u) == 0u) q.status[1] = (unsigned)lb + 1u;
-                    }
-                }
-            }
-            t_start = 0ull;
-        }
-        __syncthreads();
-        SWE_FT(1);
-        SWE_FT(2);
-        double bu[3], bv[3], be[3], ou[3], ov[3], oe[3], wu[3], wv[3], we[3];
-        const double twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
-        swe_flow_rhs<NONLIN, LF, SRC>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
-        // w = a0*U(0) + a1*U_in: the first stage of a step has no U(0) term (swe_stage_kernel<., ., HASU0 = false>)
-        const double a0 = q.a0[i3], a1 = q.a1[i3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) { wu[i] = a1*u[i]; wv[i] = a1*v[i]; we[i] = a1*e[i]; }
-        if (i3 > 0) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                wu[i] = fma(a0, u0[i], wu[i]);
-                wv[i] = fma(a0, v0[i], wv[i]);
-                we[i] = fma(a0, e0[i], we[i]);
-            }
-        }
-        swe_flow_finish<NONLIN, LF>(p, k, q.beta[i3], u, v, e, h, nx, ny, twoA, bmarkers, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
-#ifdef SWE_WAVE_TIMING
-        if (ou[0] == 1.2345e300) return;          // the arithmetic has to be finished before the time stamp
-        SWE_FT(3);
-#endif
-        // ---- publish the rim traces: facet f carries my nodes f (granules 0-2) and f + 1 (granules 3-5), tag = stages done.
-        //      The values go to the staging area by slot, then the wave stores the block's whole slot range, consecutive lanes
-        //      on consecutive granules (full lines).  (A rim cell outside this stage's range leaves its entry as it was: its
-        //      slot gets a value nobody reads.)
-        if (s + 1 < q.n_stages) {
-            const unsigned tag = base + (unsigned)s + 1u;
-            const unsigned par = ((unsigned)s & 1u)*q.parity_bytes + (unsigned)myslots.x*SWE_FLOW_SLOT_BYTES;
-            __syncthreads();                                   // every lane has read its incoming traces
-#pragma unroll
-            for (int f = 0; f < 3; f++) {
-                if (xown[f] >= 0 && act) {
-                    const int a = f, b = (f + 1) % 3;
-                    double *d = lds + SWE_FLOW_XG + 6*xown[f];
-                    d[0] = ou[a]; d[1] = ov[a]; d[2] = oe[a]; d[3] = ou[b]; d[4] = ov[b]; d[5] = oe[b];
-                }
+                t_start = 0ull;
             }
             __syncthreads();
-            for (int t = lane; t < 8*nrim; t += SWE_BLOCK) {
-                const int gi = t & 7;
-                const double x = gi < 6 ? lds[SWE_FLOW_XG + 6*(t >> 3) + gi] : 0.0;
-                swe_flow_put(rex, par + 16u*(unsigned)t, x, tag);
-            }
-        }
-        // ---- the step result (every third stage) goes to state buffer 0: read by later launches only
-        if (act && i3 == 2) {
-            const swe_rsrc_t gou = swe_rsrc(q.buf[0]), gov = swe_rsrc(q.buf[0] + 3*S), goe = swe_rsrc(q.buf[0] + 6*S);
+            SWE_FT(1);
+            SWE_FT(2);
+            double bu[3], bv[3], be[3], ou[3], ov[3], oe[3], wu[3], wv[3], we[3];
+            const double twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
+            swe_flow_rhs<NONLIN, LF, SRC>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+            // w = a0*U(0) + a1*U_in: the first stage of a step has no U(0) term (swe_stage_kernel<., ., HASU0 = false>)
+            const double a0 = q.a0[i3], a1 = q.a1[i3];
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                swe_st(gou, k8, i*S8, ou[i]);
-                swe_st(gov, k8, i*S8, ov[i]);
-                swe_st(goe, k8, i*S8, oe[i]);
+            for (int i = 0; i < 3; i++) { wu[i] = a1*u[i]; wv[i] = a1*v[i]; we[i] = a1*e[i]; }
+            if (i3 > 0) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    wu[i] = fma(a0, lu0[i][lane], wu[i]);
+                    wv[i] = fma(a0, lu0[3 + i][lane], wv[i]);
+                    we[i] = fma(a0, lu0[6 + i][lane], we[i]);
+                }
             }
-        }
-        SWE_FT(4);
+            swe_flow_finish<NONLIN, LF>(p, k, q.beta[i3], u, v, e, h, nx, ny, twoA, bmarkers, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
 #ifdef SWE_WAVE_TIMING
-        if (s == SWE_FLOW_TS_STAGE - 1 && lane == 0 && lb < SWE_WT_MAX) {         // when the previous stage's granules left, and from which XCD
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            swe_wave_ts[5][lb] = (wall_clock64() & 0xffffffffffffull) | ((unsigned long long)(xcc & 0xf) << 56);
-        }
+            if (ou[0] == 1.2345e300) return;          // the arithmetic has to be finished before the time stamp
+            SWE_FT(3);
+#endif
+            // ---- publish the rim traces of this stage's result (FX: the last stage of a cycle leaves that to the next cycle's input
+            //      publish, after the exchange; FX = false: nobody reads the last stage of the launch)
+            if (FX ? g + 1 < spc : s + 1 < q.n_stages) SWE_FLOW_PUBLISH(ou, ov, oe, act, FX ? c*spc + g + 1 : s);
+            // ---- the step result (every third stage) goes to state buffer 0: read by later launches only
+            if (act && i3 == 2) {
+                const swe_rsrc_t gou = swe_rsrc(q.buf[0]), gov = swe_rsrc(q.buf[0] + 3*S), goe = swe_rsrc(q.buf[0] + 6*S);
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    swe_st(gou, k8, i*S8, ou[i]);
+                    swe_st(gov, k8, i*S8, ov[i]);
+                    swe_st(goe, k8, i*S8, oe[i]);
+                }
+            }
+            SWE_FT(4);
+#ifdef SWE_WAVE_TIMING
+            if (s == SWE_FLOW_TS_STAGE - 1 && lane == 0 && lb < SWE_WT_MAX) {         // when the previous stage's granules left, and from which XCD
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                swe_wave_ts[5][lb] = (wall_clock64() & 0xffffffffffffull) | ((unsigned long long)(xcc & 0xf) << 56);
+            }
 #endif
 #pragma unroll
-        for (int i = 0; i < 3; i++) { u[i] = ou[i]; v[i] = ov[i]; e[i] = oe[i]; }
+            for (int i = 0; i < 3; i++) { u[i] = ou[i]; v[i] = ov[i]; e[i] = oe[i]; }
+        }
+        if (FX && has_send) {
+            // ---- push: the send cells of this block straight into the peers' landing zones (the cycle's last stage left the step
+            //      result in u, v, e), then this block's arrival
+            const unsigned long long target = S0 + (unsigned long long)c + 1ull;
+#pragma unroll
+            for (int w = 0; w < 2; w++) {
+                const int j = w ? xs2 : xs1;
+                if (j >= 0) {
+                    int pp = 0;
+#pragma unroll 1
+                    for (int i = 1; i < q.x_n_peers; i++) if (j >= q.x_off[i]) pp = i;          // segments are sorted by offset
+                    double *dst = q.x_rdata[pp] + (target & 1ull)*q.x_rslot[pp] + (size_t)(j - q.x_off[pp])*9;
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { swe_p2p_store(dst + i, u[i]); swe_p2p_store(dst + 3 + i, v[i]); swe_p2p_store(dst + 6 + i, e[i]); }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // write-through stores: drained = delivered
+            SWE_FLOW_ARRIVE(c);
+        }
     }
+#undef SWE_FLOW_ARRIVE
+#undef SWE_FLOW_PUBLISH
     // retired or finished: every block's counter ends the launch at base + n_stages
     if (lane == 0) *myflag = fin;
 }

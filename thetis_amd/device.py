@@ -396,6 +396,16 @@ class Swe2dDevice(object):
         ends = np.ascontiguousarray(cell_ends, dtype=np.int32)
         self._ck(self.lib.swe2d_solve_flow(self.h, int(len(ends)), _iptr(ends)))
 
+    def solve_flow_exchange(self, n_cycles, cell_ends):
+        """``n_cycles`` exchange cycles of ``len(cell_ends)`` stages each in ONE launch, the peer-to-peer halo exchange inside
+        (csrc/swe2d_flow.h, FX kernels): the last cycle's push is received by the next such launch or by ``p2p_wait_unpack(0, 0)``."""
+        ends = np.ascontiguousarray(cell_ends, dtype=np.int32)
+        self._ck(self.lib.swe2d_solve_flow_exchange(self.h, int(n_cycles), int(len(ends)), _iptr(ends)))
+
+    def flow_prepare_exchange(self):
+        """Tables of ``solve_flow_exchange`` ahead of its first launch (which must not allocate inside a capture)."""
+        self._ck(self.lib.swe2d_flow_prepare_exchange(self.h))
+
     def flow_set_order(self, cells_in_flow_order):
         """The flow kernel's blocks = consecutive cells of this order (a permutation of the caller's cell ids; default: the
         device numbering).  For partitions: an order in which the ghost cells sit next to the owned cells they touch."""

@@ -178,7 +178,7 @@ class DistributedSwe2d(object):
     def __init__(self, mesh, bathymetry_vertex, dt, rank, world_size, device_id, owner=None, host_staged=False,
                  n_tracers=0, use_limiter=True, tracer_only=False, exchange_every=1, overlap_stages=0,
                  graph_mode=None, stepper='SSPRK33', exchange=None, split_last_stage=True, group=None, partition=None,
-                 combined_exchange=False, flow=None, **opts):
+                 combined_exchange=False, flow=None, flow_exchange=None, **opts):
         """``n_tracers`` > 0: the coupled step of GeneralCoupledTimeIntegrator2D.advance (coupled_timeintegrator_2d.py:
         93-113) on the partition - shallow water step, then every tracer with the updated velocity, then the limiter.
         The vertex-based limiter needs every cell around a vertex, so coupled runs with the limiter use four ghost layers
@@ -209,6 +209,11 @@ class DistributedSwe2d(object):
         its next stage as soon as the blocks around it have finished the previous one; bit for bit the stage launches),
         followed by the exchange: None = where the kernel covers the partition (every block resident at once; shallow water
         only, triangles without wetting-drying / viscosity, no ``overlap_stages``), True = required, False = never.
+
+        ``flow_exchange`` (with ``flow`` and the peer-to-peer transport): the exchange INSIDE the flow launch - up to 16 cycles per
+        launch, a cycle starts by reading the ghost cells from the landing zone and ends by pushing the send cells into the
+        peers' zones (csrc/swe2d_flow.h, FX kernels); the push of an advance's last cycle is received by one unpack kernel at
+        its end.  None = where it applies, False = flow launch + push + unpack kernels per cycle.
 
         ``exchange``: 'p2p' | 'rccl' | 'host' (module docstring); default 'host' if ``host_staged`` else 'rccl'.
         ``partition``: a LocalPartition already built for this rank with the halo depth the other arguments imply.
@@ -265,9 +270,11 @@ class DistributedSwe2d(object):
                                n_owned=p.n_owned, boundary_len=p.boundary_len, ranges=p.reorder_ranges(), **opts)
         self.dev.halo_setup(p.send_cells, p.recv_cells)
         self._flow_request = flow
-        if flow is not False and self.dev.flow_supported():
+        self._flowx_request = flow_exchange
+        if flow is not False and self.dev.npc == 3:
             # the flow kernel's blocks: all local cells (owned + ghost layers) in one locality order, so that a ghost cell
-            # shares its block with the cells it touches
+            # shares its block with the cells it touches (in the device numbering - ghost layers appended layer by layer - a
+            # block of ghost cells has more rim facets than the kernel's staging area holds)
             from . import ordering
             self.dev.flow_set_order(ordering.auto_cell_order(p, 0, p.num_cells))
         self._ranges = [p.stage_range(i) for i in range(3)]
@@ -313,6 +320,29 @@ class DistributedSwe2d(object):
                                  'viscosity and overlap_stages, on partitions whose 64-cell blocks are all resident at once')
             return False
         return True
+
+    @property
+    def flow_exchange(self):
+        """True when the exchange runs inside the flow launches (see ``flow_exchange``)."""
+        return self.flow and self.p2p is not None and self._flowx_request is not False and os.environ.get('THETIS_AMD_FLOWX') != '0'
+
+    def _steps_flow_exchange(self, n_steps, graphed):
+        """``n_steps`` time steps as flow launches with the exchange inside: up to 16 cycles (48 stages) per launch, a shorter
+        trailing cycle in a launch of its own, and one unpack kernel for the last push."""
+        dev, p, m = self.dev, self.part, self.exchange_every
+        if graphed:
+            dev.flow_prepare_exchange()            # tables: never inside the capture of the first launch
+        full, rem = divmod(n_steps, m)
+        per_launch = max(1, min(16, 48//(3*m)))
+        ends = [p.stage_range(g, depth=3*m) for g in range(3*m)]
+        while full > 0:
+            nc = min(per_launch, full)
+            self._launch(('X', nc, m), lambda nc=nc: dev.solve_flow_exchange(nc, ends), graphed)
+            full -= nc
+        if rem:
+            ends_r = [p.stage_range(g, depth=3*rem) for g in range(3*rem)]
+            self._launch(('X', 1, rem), lambda: dev.solve_flow_exchange(1, ends_r), graphed)
+        self._launch(('XU',), lambda: dev.p2p_wait_unpack(0, 0), graphed)
 
     def _cycle_swe_flow(self, n_steps, graphed):
         """``n_steps`` time steps = 3 n_steps stages on the shrinking ranges in ONE launch, then the exchange."""
@@ -531,6 +561,8 @@ class DistributedSwe2d(object):
             for _ in range(n_steps):
                 self._step()
             return
+        if self.flow_exchange and self.stages_per_step == 3:
+            return self._steps_flow_exchange(n_steps, graphed)
         cycles = [m]*(n_steps//m) + ([n_steps % m] if n_steps % m else [])
         early = 0
         for i, r in enumerate(cycles):

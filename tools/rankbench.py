@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--nosplit', action='store_true')
     ap.add_argument('--graph-mode', default=None)
     ap.add_argument('--flow', type=int, default=-1, help='1 / 0: the stages of a cycle as one dataflow launch (csrc/swe2d_flow.h) / stage launches (default: the solver decides)')
+    ap.add_argument('--flowx', type=int, default=-1, help='1 / 0: the exchange inside the flow launches / separate push and unpack kernels')
     ap.add_argument('--nx', type=int, default=0, help='mesh RectangleMesh(nx, nx/2) instead of the bench mesh')
     args = ap.parse_args()
     import torch
@@ -63,7 +64,7 @@ def main():
     s = distributed.DistributedSwe2d(mesh, bath, dt, args.rank, args.world, 0, exchange_every=args.every, overlap_stages=args.overlap,
                                      exchange=('p2p' if args.exchange == 'p2p' else 'rccl'), split_last_stage=not args.nosplit,
                                      graph_mode=args.graph_mode,
-                                     flow=(None if args.flow < 0 else bool(args.flow)))
+                                     flow=(None if args.flow < 0 else bool(args.flow)), flow_exchange=(None if args.flowx < 0 else bool(args.flowx)))
     s.set_state_global(uv, eta)
     p = s.part
     t0 = time.perf_counter()
@@ -83,7 +84,7 @@ def main():
     to = s.p2p.timeouts() if s.p2p is not None else 0
     print(json.dumps({'exchange': args.exchange, 'split': not args.nosplit, 'p2p_timeouts': to,
                       'world': args.world, 'rank': args.rank, 'every': args.every, 'overlap': args.overlap, 'n_owned': int(p.n_owned),
-                      'n_ghost': int(p.n_ghost), 'n_send': int(len(p.send_cells)), 'graph': s.graphed, 'graph_mode': s.graph_mode, 'flow': bool(s.flow), 'flow_timeouts': s.dev.flow_timeouts(),
+                      'n_ghost': int(p.n_ghost), 'n_send': int(len(p.send_cells)), 'graph': s.graphed, 'graph_mode': s.graph_mode, 'flow': bool(s.flow), 'flow_exchange': bool(s.flow_exchange), 'flow_timeouts': s.dev.flow_timeouts(),
                       'us_per_step': 1e6*best/args.steps}))
 
 
