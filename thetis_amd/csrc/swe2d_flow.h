@@ -61,6 +61,7 @@
 #endif
 #define SWE_FLOW_MAX_STAGES 48             // 16 time steps per launch
 #define SWE_FLOW_MAX_CYCLES 16             // exchange cycles per launch (FX kernels)
+#define SWE_FLOW_MAX_NBB 32                // blocks across a block's rim (more: no FX launches for this flow order)
 #ifndef SWE_FLOW_FLAG_STRIDE
 #define SWE_FLOW_FLAG_STRIDE 16           // unsigned words between two blocks' stage counters (64 B)
 #endif
@@ -81,6 +82,7 @@ struct SweFlowArgs {
     const int2 *xo2;                       //  w0}, {w1, w2}: w = place of the facet's incoming slot in the block's incoming list (rim facet) or the
                                            //  lane of the neighbour inside the block (the lane itself for a boundary facet)
     const int2 *xblk;                      // per block {first slot, number of slots}: a block's slots are contiguous
+    const int *xnbb;                       // [n_blocks][SWE_FLOW_MAX_NBB] the blocks across this block's rim, -1 terminated (FX)
     const int *xsrc;                       // [n_slots] incoming list of every block at its own slot range: entry i = (slot the
                                            //  neighbour block writes for my i-th incoming facet) << 6 | lane of my cell that reads it
     void *ex;                              // [2 stage parities][n_slots] exchange slots, SWE_FLOW_SLOT_BYTES each
@@ -467,6 +469,28 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 
 #pragma unroll 1
     for (int c = 0; c < ncyc; c++) {
+        if (FX && c > 0) {
+            // ---- a block whose cells sit in the outer ghost layers skips the late stages of a cycle and would be back here long
+            //      before its neighbours: it must not overwrite the granules they still have to read (the cycle's input goes to
+            //      the slot parity of the last but one publish).  Every block ends a cycle by raising its counter word; nobody
+            //      starts the next cycle before the blocks across its rim have ended this one.
+            const int nbb = lane < SWE_FLOW_MAX_NBB ? q.xnbb[lb*SWE_FLOW_MAX_NBB + lane] : -1;
+            const unsigned need_c = base + (unsigned)(c*spc);
+            for (unsigned spins = 0;; spins++) {
+                const bool ok = nbb < 0 || (int)(__hip_atomic_load(q.flag + (size_t)nbb*SWE_FLOW_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need_c) >= 0;
+                if (__all(ok) || late) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((spins & 31u) == 31u) {
+                    const unsigned long long now = wall_clock64();
+                    if (t_start == 0ull) t_start = now;
+                    else if (now - t_start > q.timeout_ticks) {
+                        late = true;
+                        if (lane == 0 && atomicAdd(q.status, 1u) == 0u) q.status[1] = (unsigned)lb + 1u;
+                    }
+                }
+            }
+            t_start = 0ull;
+        }
         if (FX) {
             // ---- receive: the push the peers made at the end of the previous cycle (or launch)
             if (((c > 0) || pend0) && has_ghost) {
@@ -632,6 +656,8 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // write-through stores: drained = delivered
             SWE_FLOW_ARRIVE(c);
         }
+        // this block has read everything it reads in the cycle
+        if (FX && lane == 0) __hip_atomic_store(myflag, base + (unsigned)((c + 1)*spc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #undef SWE_FLOW_ARRIVE
 #undef SWE_FLOW_PUBLISH

@@ -872,6 +872,14 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
         def time_candidate():
             s = make(*cand)
             try:
+                if flow_c and digest_ref is not None:
+                    # the flow kernels move the halo themselves (FX): what was verified for the transport's exchange kernels is
+                    # verified again for this path - the same short run must reproduce the host-staged result bit for bit
+                    s.advance(n_check, use_graph=False)
+                    s.synchronize()
+                    if not agree.all_ok(_state_digest(s) == digest_ref):
+                        raise RuntimeError('the flow path does not reproduce the host-staged exchange bit for bit')
+                    s.set_state_global(uv, eta)
                 s.advance(2000 if first else n_tune, use_graph=False)          # connections; clocks (first candidate)
                 s.synchronize()
                 graph_c = use_graph and mode_c != 'none'
@@ -1082,8 +1090,10 @@ def _timed_region(args, solver, chosen, agree, uv, eta, use_graph, n_total, worl
     hip_graph = bool(solver.graphed)
     value = n_total*3.0*args.steps/t
     per_gpu_bytes = bytes_per_update*n_total/world
-    transport = {'p2p': 'peer-to-peer stores into IPC-mapped landing zones ({:} memory) + epoch flags, exchange kernels inside the '
-                        'per-cycle HIP graph'.format(solver.p2p.zone_kind if solver.p2p is not None else ''),
+    transport = {'p2p': 'peer-to-peer stores into IPC-mapped landing zones ({:} memory) + epoch flags, {:}'.format(
+                        solver.p2p.zone_kind if solver.p2p is not None else '',
+                        'made by the flow kernel itself (FX: up to 16 exchange cycles per launch)' if solver.flow_exchange
+                        else 'exchange kernels inside the per-cycle HIP graph'),
                  'rccl': 'RCCL batch_isend_irecv between two graph launches',
                  'host': 'gloo through host memory (fallback)'}[ex]
     return {
@@ -1097,7 +1107,7 @@ def _timed_region(args, solver, chosen, agree, uv, eta, use_graph, n_total, worl
                    'parallelism': 'dd{:d} (domain decomposition, {:d}-cell halo, 1 exchange per {:d} steps)'.format(
                        world, 3*every, every),
                    'exchange': ex, 'exchange_transport': transport, 'transports_verified': transports,
-                   'exchange_every': every, 'overlap_stages': overlap, 'split_last_stage': split, 'flow': bool(solver.flow),
+                   'exchange_every': every, 'overlap_stages': overlap, 'split_last_stage': split, 'flow': bool(solver.flow), 'flow_exchange': bool(solver.flow_exchange),
                    'flow_timeouts': int(solver.dev.flow_timeouts()), 'schedule_tuning': tuning,
                    'hip_graph': hip_graph, 'graph_mode': solver.graph_mode, 'graph_warm_replays': int(hip_graph),
                    'volume_conserved': ok, 'p2p_timeouts': int(timeouts), 'prewarm_s': prewarm},
