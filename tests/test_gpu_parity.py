@@ -455,3 +455,29 @@ def test_stage_kernel_variants_agree_bitwise_on_a_large_launch(hip_lib):
     assert np.isfinite(out['00'][1]).all()
     for key in ('10', '11'):
         assert np.array_equal(out['00'][0], out[key][0]) and np.array_equal(out['00'][1], out[key][1]), key
+
+
+@pytest.mark.parametrize('quad', [False, True])
+def test_alternating_launch_direction_gives_the_same_bits(hip_lib, monkeypatch, quad):
+    """Launches whose state does not fit the Infinity Cache walk the cell range alternately forwards and backwards
+    (SweStageArgs::reverse): forced on a small mesh, odd and even numbers of launches, a ragged last block, sub-ranges."""
+    from helpers import quad_case
+    from thetis_amd.device import Swe2dDevice
+    monkeypatch.setenv('THETIS_AMD_FLOW', '0')                  # the stage launches themselves
+    mesh, bath, uv, eta = quad_case(nx=53, ny=31, seed=5) if quad else channel_case(nx=53, ny=31, seed=5)
+    out = []
+    for alt in ('0', '1'):
+        monkeypatch.setenv('THETIS_AMD_ALTERNATE', alt)
+        dev = Swe2dDevice(mesh, bath, 0.5)
+        dev.set_bc(2, {'elev': 0.1})
+        dev.set_state(uv, eta)
+        dev.advance(3)
+        dev.solve_stage(0)                                      # an odd number of launches so far
+        n = dev.n_cells
+        dev.solve_stage_cells(1, 0, n//3 + 5)
+        dev.solve_stage_cells(1, n//3 + 5, n)
+        dev.solve_stage(2)
+        out.append(dev.get_state())
+        dev.close()
+    assert np.isfinite(out[0][0]).all()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
