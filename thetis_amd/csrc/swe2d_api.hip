@@ -116,8 +116,6 @@ struct Handle {
     int4 *flow_xo4 = nullptr;                           // exchange slots of the rim facets (facets between two 64-cell blocks), see SweFlowArgs
     int2 *flow_xo2 = nullptr;
     int2 *flow_xblk = nullptr;
-    int *flow_xnbb = nullptr;                           // blocks across every block's rim (FX launches)
-    bool flow_nbb_ok = true;                            // at most SWE_FLOW_MAX_NBB of them everywhere
     int *flow_xsrc = nullptr;
     std::vector<int> h_send, h_recv;                    // host copies of the halo lists (swe2d_halo_setup)
     std::vector<int> flow_fpos;                         // cell -> flow position
@@ -485,8 +483,7 @@ int flow_build(Handle *h, const int32_t *order)
     std::vector<int> own((size_t)3*nb*SWE_BLOCK, -1);                                // global slot of (position, f)
     std::vector<int2> blk((size_t)nb, int2{0, 0});
     int n_slots = 0;
-    bool too_many = false, nbb_ok = true;
-    std::vector<int> nbb((size_t)nb*SWE_FLOW_MAX_NBB, -1);
+    bool too_many = false;
     std::vector<Rim> rim;
     for (int b = 0; b < nb; b++) {
         rim.clear();
@@ -498,16 +495,6 @@ int flow_build(Handle *h, const int32_t *order)
         std::sort(rim.begin(), rim.end(), [](const Rim &x, const Rim &y) {
             return x.nbblock != y.nbblock ? x.nbblock < y.nbblock : (x.pos != y.pos ? x.pos < y.pos : x.f < y.f); });
         if ((int)rim.size() > SWE_FLOW_MAX_RIM) too_many = true;      // the kernel's staging area holds SWE_FLOW_MAX_RIM facets
-        {
-            int cnt = 0, last = -1;                                   // rim is sorted by neighbour block
-            for (const Rim &r : rim)
-                if (r.nbblock != last) {
-                    last = r.nbblock;
-                    if (cnt < SWE_FLOW_MAX_NBB) nbb[(size_t)b*SWE_FLOW_MAX_NBB + cnt] = r.nbblock;
-                    cnt++;
-                }
-            if (cnt > SWE_FLOW_MAX_NBB) nbb_ok = false;
-        }
         blk[b] = int2{n_slots, (int)rim.size()};
         for (const Rim &r : rim) own[(size_t)3*r.pos + r.f] = n_slots++;
     }
@@ -549,22 +536,18 @@ int flow_build(Handle *h, const int32_t *order)
     }
     // (slot << 6 must fit an int, the exchange array must stay below SWE_FLOW_NOWHERE)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    for (void *ptr : {(void *)h->flow_xblk, (void *)h->flow_xsrc, (void *)h->flow_xo4, (void *)h->flow_xo2, (void *)h->flow_ex, (void *)h->flow_cell, (void *)h->flow_xnbb})
+    for (void *ptr : {(void *)h->flow_xblk, (void *)h->flow_xsrc, (void *)h->flow_xo4, (void *)h->flow_xo2, (void *)h->flow_ex, (void *)h->flow_cell})
         if (ptr) (void)hipFree(ptr);
-    h->flow_xnbb = nullptr;
     h->flow_xblk = nullptr; h->flow_xsrc = nullptr; h->flow_xo4 = nullptr; h->flow_xo2 = nullptr; h->flow_ex = nullptr; h->flow_cell = nullptr;
     // no flow kernel for this handle / this order: a block with more rim facets than the staging area holds (cells numbered without
     // locality), or slot numbers that do not fit
-    if (too_many || !((size_t)2*n_slots*SWE_FLOW_SLOT_BYTES < ((size_t)1 << 31) && n_slots < (1 << 25))) return SWE2D_OK;
+    if (too_many || !((size_t)3*n_slots*SWE_FLOW_SLOT_BYTES < ((size_t)1 << 31) && n_slots < (1 << 25))) return SWE2D_OK;
     h->flow_fpos = fpos;
     h->flow_x_ready = false;
     h->flow_parity_bytes = (unsigned)((size_t)std::max(n_slots, 1)*SWE_FLOW_SLOT_BYTES);
-    h->flow_ex_bytes = (size_t)2*h->flow_parity_bytes;
+    h->flow_ex_bytes = (size_t)3*h->flow_parity_bytes;
     HIP_TRY(h, hipMalloc(&h->flow_xblk, blk.size()*sizeof(int2)));
     HIP_TRY(h, hipMemcpy(h->flow_xblk, blk.data(), blk.size()*sizeof(int2), hipMemcpyHostToDevice));
-    h->flow_nbb_ok = nbb_ok;
-    HIP_TRY(h, hipMalloc(&h->flow_xnbb, nbb.size()*sizeof(int)));
-    HIP_TRY(h, hipMemcpy(h->flow_xnbb, nbb.data(), nbb.size()*sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMalloc(&h->flow_xsrc, xsrc.size()*sizeof(int)));
     HIP_TRY(h, hipMemcpy(h->flow_xsrc, xsrc.data(), xsrc.size()*sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMalloc(&h->flow_cell, fcell.size()*sizeof(int)));
@@ -649,8 +632,8 @@ int flow_build_exchange(Handle *h)
     if (!h->flow_xsend) HIP_TRY(h, hipMalloc(&h->flow_xsend, (size_t)np*sizeof(int2)));
     if (!h->flow_xrecv) HIP_TRY(h, hipMalloc(&h->flow_xrecv, (size_t)np*sizeof(int)));
     if (!h->flow_xtick) {
-        HIP_TRY(h, hipMalloc(&h->flow_xtick, SWE_FLOW_MAX_CYCLES*sizeof(unsigned)));
-        HIP_TRY(h, hipMemset(h->flow_xtick, 0, SWE_FLOW_MAX_CYCLES*sizeof(unsigned)));
+        HIP_TRY(h, hipMalloc(&h->flow_xtick, (2*SWE_FLOW_MAX_CYCLES + 32)*sizeof(unsigned)));
+        HIP_TRY(h, hipMemset(h->flow_xtick, 0, (2*SWE_FLOW_MAX_CYCLES + 32)*sizeof(unsigned)));
     }
     HIP_TRY(h, hipMemcpy(h->flow_xsend, xs.data(), (size_t)np*sizeof(int2), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->flow_xrecv, xr.data(), (size_t)np*sizeof(int), hipMemcpyHostToDevice));
@@ -677,7 +660,6 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles =
         auto &z = h->p2p;
         if (!z.zone || !z.ctr || z.n_peers == 0 || z.n_from == 0 || h->n_send == 0 || h->n_recv == 0)
             return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "flow with the exchange inside: the peer-to-peer halo is not connected");
-        if (!h->flow_nbb_ok) return fail(h, SWE2D_ERR_UNSUPPORTED, "flow with the exchange inside: a block touches more than 32 other blocks");
         if (z.width[0] != 9) return fail(h, SWE2D_ERR_UNSUPPORTED, "flow with the exchange inside: channel 0 must carry the shallow water state");
         if (int rc = flow_build_exchange(h)) return rc;
         q.n_cycles = n_cycles; q.stages_per_cycle = n_stages;
@@ -705,7 +687,6 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles =
     q.flag = h->flow_flag; q.status = h->flow_status;
     q.xo4 = h->flow_xo4; q.xo2 = h->flow_xo2; q.ex = h->flow_ex;
     q.xblk = h->flow_xblk; q.xsrc = h->flow_xsrc; q.parity_bytes = h->flow_parity_bytes;
-    q.xnbb = h->flow_xnbb;
     q.fcell = h->flow_cell;
     q.n_blocks = h->flow_blocks; q.n_stages = total;
     for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) q.cell_end[s] = s < n_stages ? cell_end[s] : 0;
@@ -973,7 +954,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick, h->flow_xnbb};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
     for (void *m : h->p2p.opened) (void)hipIpcCloseMemHandle(m);

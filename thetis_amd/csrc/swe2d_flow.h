@@ -61,7 +61,6 @@
 #endif
 #define SWE_FLOW_MAX_STAGES 48             // 16 time steps per launch
 #define SWE_FLOW_MAX_CYCLES 16             // exchange cycles per launch (FX kernels)
-#define SWE_FLOW_MAX_NBB 32                // blocks across a block's rim (more: no FX launches for this flow order)
 #ifndef SWE_FLOW_FLAG_STRIDE
 #define SWE_FLOW_FLAG_STRIDE 16           // unsigned words between two blocks' stage counters (64 B)
 #endif
@@ -82,10 +81,9 @@ struct SweFlowArgs {
     const int2 *xo2;                       //  w0}, {w1, w2}: w = place of the facet's incoming slot in the block's incoming list (rim facet) or the
                                            //  lane of the neighbour inside the block (the lane itself for a boundary facet)
     const int2 *xblk;                      // per block {first slot, number of slots}: a block's slots are contiguous
-    const int *xnbb;                       // [n_blocks][SWE_FLOW_MAX_NBB] the blocks across this block's rim, -1 terminated (FX)
     const int *xsrc;                       // [n_slots] incoming list of every block at its own slot range: entry i = (slot the
                                            //  neighbour block writes for my i-th incoming facet) << 6 | lane of my cell that reads it
-    void *ex;                              // [2 stage parities][n_slots] exchange slots, SWE_FLOW_SLOT_BYTES each
+    void *ex;                              // [3 slot sets][n_slots] exchange slots, SWE_FLOW_SLOT_BYTES each: two stage parities + the cycle inputs (FX)
     unsigned parity_bytes;                 // n_slots * SWE_FLOW_SLOT_BYTES
     int n_blocks;                          // blocks of the handle (cells rounded up to 64)
     int n_stages;                          // a multiple of 3: stage s is Shu-Osher stage s % 3
@@ -100,7 +98,8 @@ struct SweFlowArgs {
     const int2 *xsend;                     // per position: the cell's (up to two) places in the send list, -1: none
     const int *xrecv;                      // per position: the cell's place in the receive list, -1: not a ghost cell
     int n_push_blocks, n_recv_blocks;      // blocks holding send cells / ghost cells
-    unsigned *xtick;                       // [SWE_FLOW_MAX_CYCLES] arrival counters of a cycle's receives and pushes (self-cleaning)
+    unsigned *xtick;                       // [SWE_FLOW_MAX_CYCLES] arrival counters of a cycle's receives and pushes (self-cleaning);
+                                           //  word 2*SWE_FLOW_MAX_CYCLES (128 B further): 64-bit count of this rank's completed pushes
     SweP2pCounters *xctr;                  // epochs of channel 0
     int x_n_peers, x_n_from;
     int x_off[SWE_P2P_MAX_PEERS], x_cnt[SWE_P2P_MAX_PEERS];                 // per peer: segment of the send list (cells)
@@ -295,7 +294,11 @@ __device__ __forceinline__ void swe_flow_finish(const SweStageArgs &p, int k, do
 // FX = false: n_stages stages on the ranges cell_end[0 .. n_stages); the rim traces of the first stage come from the state planes.
 // FX = true:  n_cycles exchange cycles (see SweFlowArgs); every cycle starts by publishing its input across the rims (the ghost
 //             cells' input arrives in the landing zone, not in the planes), so a stage always finds its rim traces in granules.
-// Tags count publishes: publish number pc of the launch carries tag base + pc + 1 and goes to slot parity pc & 1.
+// Tags count publishes: publish number pc of the launch carries tag base + pc + 1.  Stage results go to slot set pc & 1, a cycle's
+// input to a third set: a block whose cells sit in the outer ghost layers skips the late stages of a cycle and is back at the next
+// cycle's start long before its neighbours have read its last stage results - it may overwrite its previous INPUT (read by stage 0
+// of the previous cycle, which every neighbour that needs it has finished before this rank's push, hence before the flags that
+// lets this block start the cycle: it also waits for this rank's own previous push to be complete) but nothing else.
 template <bool NONLIN, bool LF, bool SRC, bool FX>
 __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(const SweFlowArgs q)
 {
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
     }
     const unsigned k8 = (unsigned)k*8u;
     // bounds-checked resource: a load from SWE_FLOW_NOWHERE costs no memory access
-    const __amdgpu_buffer_rsrc_t rex = __builtin_amdgcn_make_buffer_rsrc(q.ex, 0, 2*q.parity_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rex = __builtin_amdgcn_make_buffer_rsrc(q.ex, 0, 3*q.parity_bytes, 0x00020000);
     const int2 myslots = q.xblk[lb];                           // uniform: first slot, count
     const int nrim = myslots.y;
     for (int i = lane; i < nrim; i += SWE_BLOCK) xsrc[i] = q.xsrc[myslots.x + i];
@@ -420,6 +423,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
         has_send = __any(xs1 >= 0);
     }
     const int ncyc = FX ? q.n_cycles : 1, spc = FX ? q.stages_per_cycle : q.n_stages;
+    unsigned long long *const xdone = reinterpret_cast<unsigned long long *>(q.xtick + 2*SWE_FLOW_MAX_CYCLES);      // a cache line of its own
     unsigned long long t_start = 0ull;
     bool late = false;
     int s = 0;                             // stage counter of the launch
@@ -436,6 +440,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                  \
                 for (int i_ = 0; i_ < q.x_n_peers; i_++)                                                                          \
                     __hip_atomic_store(q.x_rflag[i_], S0 + (unsigned long long)(c_) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+                __hip_atomic_store(xdone, S0 + (unsigned long long)(c_) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      \
                 if ((c_) == ncyc - 1) {                                                                                           \
                     q.xctr->epoch_send = S0 + (unsigned long long)ncyc;                                                           \
                     q.xctr->epoch_recv = R0 + (unsigned long long)(ncyc - 1) + (pend0 ? 1ull : 0ull);                             \
@@ -447,9 +452,9 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
     // publish the rim traces held in (pu, pv, pe) of the lanes in `who`: facet f carries my nodes f (granules 0-2) and f + 1
     // (granules 3-5).  The values go to the staging area by slot, then the wave stores the block's whole slot range, consecutive
     // lanes on consecutive granules (full lines).  (A rim cell outside `who` leaves its entry as it was: a value nobody reads.)
-#define SWE_FLOW_PUBLISH(pu, pv, pe, who, pc_) do {                                                                               \
+#define SWE_FLOW_PUBLISH(pu, pv, pe, who, pc_, set_) do {                                                                               \
         const unsigned tag_ = base + (unsigned)(pc_) + 1u;                                                                        \
-        const unsigned par_ = ((unsigned)(pc_) & 1u)*q.parity_bytes + (unsigned)myslots.x*SWE_FLOW_SLOT_BYTES;                    \
+        const unsigned par_ = (unsigned)(set_)*q.parity_bytes + (unsigned)myslots.x*SWE_FLOW_SLOT_BYTES;                    \
         __syncthreads();                                       /* every lane has read its incoming traces */                      \
         _Pragma("unroll")                                                                                                         \
         for (int f = 0; f < 3; f++) {                                                                                             \
@@ -469,40 +474,30 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 
 #pragma unroll 1
     for (int c = 0; c < ncyc; c++) {
-        if (FX && c > 0) {
-            // ---- a block whose cells sit in the outer ghost layers skips the late stages of a cycle and would be back here long
-            //      before its neighbours: it must not overwrite the granules they still have to read (the cycle's input goes to
-            //      the slot parity of the last but one publish).  Every block ends a cycle by raising its counter word; nobody
-            //      starts the next cycle before the blocks across its rim have ended this one.
-            const int nbb = lane < SWE_FLOW_MAX_NBB ? q.xnbb[lb*SWE_FLOW_MAX_NBB + lane] : -1;
-            const unsigned need_c = base + (unsigned)(c*spc);
-            for (unsigned spins = 0;; spins++) {
-                const bool ok = nbb < 0 || (int)(__hip_atomic_load(q.flag + (size_t)nbb*SWE_FLOW_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need_c) >= 0;
-                if (__all(ok) || late) break;
-                __builtin_amdgcn_s_sleep(1);
-                if ((spins & 31u) == 31u) {
-                    const unsigned long long now = wall_clock64();
-                    if (t_start == 0ull) t_start = now;
-                    else if (now - t_start > q.timeout_ticks) {
-                        late = true;
-                        if (lane == 0 && atomicAdd(q.status, 1u) == 0u) q.status[1] = (unsigned)lb + 1u;
-                    }
-                }
-            }
-            t_start = 0ull;
-        }
         if (FX) {
             // ---- receive: the push the peers made at the end of the previous cycle (or launch)
             if (((c > 0) || pend0) && has_ghost) {
                 const unsigned long long target = R0 + (unsigned long long)c + (pend0 ? 1ull : 0ull);
                 bool lost = q.xctr->timeouts != 0u;            // sticky, as in swe_p2p_unpack_kernel: a lost peer costs one bounded wait
-                const unsigned long long w0 = wall_clock64();
-                for (int i = 0; i < q.x_n_from && !lost; i++) {
-                    while (__hip_atomic_load(q.x_flag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
-                        if (wall_clock64() - w0 > q.x_timeout) { lost = true; break; }
-                        __builtin_amdgcn_s_sleep(1);
+                if (lane == 0) {                               // ONE lane polls (MI355X_MICROARCH.md, polling-cost)
+                    const unsigned long long w0 = wall_clock64();
+                    // not before THIS rank has finished its previous cycle (its push is complete: every block has read what it reads in
+                    // that cycle).  The peers' flags only say that THEY are done; a block of outer ghost cells skips the late stages
+                    // and would otherwise be back here - overwriting its previous input - a whole cycle ahead of its neighbours.
+                    if (c > 0) {
+                        while (__hip_atomic_load(xdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S0 + (unsigned long long)c) {
+                            if (wall_clock64() - w0 > q.x_timeout) { lost = true; break; }
+                            __builtin_amdgcn_s_sleep(4);
+                        }
+                    }
+                    for (int i = 0; i < q.x_n_from && !lost; i++) {
+                        while (__hip_atomic_load(q.x_flag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
+                            if (wall_clock64() - w0 > q.x_timeout) { lost = true; break; }
+                            __builtin_amdgcn_s_sleep(4);
+                        }
                     }
                 }
+                lost = __any(lost);
                 if (lost && lane == 0) atomicAdd(&q.xctr->timeouts, 1u);
                 if (q.x_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
                 asm volatile("" ::: "memory");
@@ -519,7 +514,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                 SWE_FLOW_ARRIVE(c);
             }
             // ---- the cycle's input across the rims
-            SWE_FLOW_PUBLISH(u, v, e, real, c*spc);
+            SWE_FLOW_PUBLISH(u, v, e, real, c*spc, 2);
         }
 #pragma unroll 1
         for (int g = 0; g < spc; g++, s++) {
@@ -552,7 +547,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             if (FX || g > 0) {
                 const int pc_in = FX ? c*spc + g : g - 1;      // the publish this stage reads
                 const unsigned need = base + (unsigned)pc_in + 1u;
-                const unsigned par = ((unsigned)pc_in & 1u)*q.parity_bytes;
+                const unsigned par = ((FX && g == 0) ? 2u : ((unsigned)pc_in & 1u))*q.parity_bytes;       // a cycle's input has a slot set of its own
                 __syncthreads();                               // the incoming list / the previous stage's staging reads
                 for (unsigned spins = 0;; spins++) {
                     bool ok = true;
@@ -615,7 +610,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 #endif
             // ---- publish the rim traces of this stage's result (FX: the last stage of a cycle leaves that to the next cycle's input
             //      publish, after the exchange; FX = false: nobody reads the last stage of the launch)
-            if (FX ? g + 1 < spc : s + 1 < q.n_stages) SWE_FLOW_PUBLISH(ou, ov, oe, act, FX ? c*spc + g + 1 : s);
+            if (FX ? g + 1 < spc : s + 1 < q.n_stages) SWE_FLOW_PUBLISH(ou, ov, oe, act, FX ? c*spc + g + 1 : s, (FX ? c*spc + g + 1 : s) & 1);
             // ---- the step result (every third stage) goes to state buffer 0: read by later launches only
             if (act && i3 == 2) {
                 const swe_rsrc_t gou = swe_rsrc(q.buf[0]), gov = swe_rsrc(q.buf[0] + 3*S), goe = swe_rsrc(q.buf[0] + 6*S);
@@ -656,8 +651,6 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // write-through stores: drained = delivered
             SWE_FLOW_ARRIVE(c);
         }
-        // this block has read everything it reads in the cycle
-        if (FX && lane == 0) __hip_atomic_store(myflag, base + (unsigned)((c + 1)*spc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #undef SWE_FLOW_ARRIVE
 #undef SWE_FLOW_PUBLISH
