@@ -335,18 +335,21 @@ int  swe2d_swap_state_buffers(swe2d_handle *h);
  * (swe2d_flow_status reads the count without failing). */
 int  swe2d_solve_flow(swe2d_handle *h, int32_t n_stages, const int32_t *cell_end);
 int  swe2d_flow_supported(swe2d_handle *h);
-/* The same with the peer-to-peer halo exchange of a partition INSIDE the launch (channel 0 of swe2d_p2p_*, connected): n_cycles
- * exchange cycles (at most 16) of stages_per_cycle stages each (at most 48 stages in all) on the ranges cell_end[0 .. stages_per_cycle)
- * of ONE cycle.  Every cycle but the launch's first starts by receiving what the peers pushed at the end of their previous cycle
- * (the ghost cells' lanes read the landing zone; the first cycle does so too if a push of an earlier launch is still pending, i.e.
- * pushes > receives in swe2d_p2p_status), and ends by pushing this rank's send cells into the peers' zones.  One launch replaces
- * n_cycles x (swe2d_solve_flow + swe2d_p2p_push + swe2d_p2p_wait_unpack) - except that the LAST cycle's push is received by the
- * next launch of this kind or by an explicit swe2d_p2p_wait_unpack(h, 0, 0) (needed before the state leaves the device).  Cells
- * sent to more than two peers are not supported (SWE2D_ERR_UNSUPPORTED).  Same results bit for bit. */
+/* The same with the halo exchange of a partition INSIDE the launch, cell by cell: n_cycles exchange cycles (at most 16) of
+ * stages_per_cycle stages each (at most 48 stages in all) on the ranges cell_end[0 .. stages_per_cycle) of ONE cycle.  Needs the
+ * peer-to-peer halo connected with a LAST channel of width 18 (swe2d_p2p_create: nine 16-byte {value, push number} granules per
+ * cell; the channel's epoch flags are not used).  Every cycle but the launch's first starts by receiving what the peers pushed at
+ * the end of their previous cycle - every ghost cell's lane waits for the nine granules of ITS cell, so a ghost cell is ready as
+ * soon as the one block of the peer that owns it has finished (the first cycle receives too if a push of an earlier launch is
+ * still pending: pushes > receives of that channel in swe2d_p2p_status) - and ends by storing this rank's send cells as granules
+ * into the peers' zones.  One launch replaces n_cycles x (swe2d_solve_flow + swe2d_p2p_push + swe2d_p2p_wait_unpack); the LAST
+ * cycle's push is received by the next launch of this kind or by swe2d_flow_unpack_pending (needed before other kernels read the
+ * ghost cells).  Cells sent to more than two peers are not supported (SWE2D_ERR_UNSUPPORTED).  Same results bit for bit. */
 int  swe2d_solve_flow_exchange(swe2d_handle *h, int32_t n_cycles, int32_t stages_per_cycle, const int32_t *cell_end);
 /* builds the tables of the former ahead of its first launch (which otherwise does it: allocations and a stream synchronisation,
  * not allowed inside a stream capture); after swe2d_halo_setup and swe2d_flow_set_order */
 int  swe2d_flow_prepare_exchange(swe2d_handle *h);
+int  swe2d_flow_unpack_pending(swe2d_handle *h);
 /* The kernel's 64-cell blocks are consecutive cells of a FLOW ORDER (default: the numbering of swe2d_mesh).  A partition whose
  * ghost layers are appended to the numbering layer by layer (what the stage ranges need) passes an order - a permutation of
  * the cell ids - in which every ghost cell sits next to the cells it touches: blocks then stay compact patches and few facets

@@ -387,8 +387,10 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
         solver.advance(n_steps, use_graph=False)
     solver.synchronize()
     if solver.p2p is not None:
-        sent, received, timeouts = solver.dev.p2p_status()
-        assert timeouts == 0 and sent[0] == received[0] > 0, (sent, received, timeouts)
+        # channel 0 carries the exchange kernels' halo, the last channel the flow kernel's granules ('+flowx')
+        sent, received, timeouts = solver.dev.p2p_status(solver.p2p.n_channels)
+        ch = solver.p2p.n_channels - 1 if solver.flow_exchange else 0
+        assert timeouts == 0 and sent == received and sent[ch] > 0 and solver.dev.flow_timeouts() == 0, (sent, received, timeouts)
     d1 = solver.diagnostics()
     ids, u, e = solver.get_state_owned()
     np.savez(os.path.join(out_dir, 'rank{:d}.npz'.format(rank)), ids=ids, uv=u, eta=e, d0=d0, d1=d1)

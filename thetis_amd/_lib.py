@@ -113,6 +113,7 @@ SYMBOLS = {
     'swe2d_solve_flow': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_flow_supported': (ctypes.c_int, [_H]),
     'swe2d_flow_prepare_exchange': (ctypes.c_int, [_H]),
+    'swe2d_flow_unpack_pending': (ctypes.c_int, [_H]),
     'swe2d_solve_flow_exchange': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_flow_set_order': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_flow_status': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),

@@ -658,29 +658,30 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles =
     SweFlowArgs q{};
     if (fx) {
         auto &z = h->p2p;
+        const int ch = z.n_channels - 1;                     // the granule channel: the last one, nine 16-byte granules per cell
         if (!z.zone || !z.ctr || z.n_peers == 0 || z.n_from == 0 || h->n_send == 0 || h->n_recv == 0)
             return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "flow with the exchange inside: the peer-to-peer halo is not connected");
-        if (z.width[0] != 9) return fail(h, SWE2D_ERR_UNSUPPORTED, "flow with the exchange inside: channel 0 must carry the shallow water state");
+        if (ch < 0 || z.width[ch] != 18)
+            return fail(h, SWE2D_ERR_UNSUPPORTED, "flow with the exchange inside: the last peer-to-peer channel must have width 18 (nine granules per cell)");
         if (int rc = flow_build_exchange(h)) return rc;
         q.n_cycles = n_cycles; q.stages_per_cycle = n_stages;
         q.xsend = h->flow_xsend; q.xrecv = h->flow_xrecv; q.xtick = h->flow_xtick;
-        q.n_push_blocks = h->flow_push_blocks; q.n_recv_blocks = h->flow_recv_blocks;
-        q.xctr = z.ctr;
-        q.x_n_peers = z.n_peers; q.x_n_from = z.n_from;
-        for (int i = 0; i < z.n_peers; i++) {                // as swe2d_p2p_push, channel 0
-            q.x_off[i] = z.off[i]; q.x_cnt[i] = z.cnt[i];
+        q.xctr = z.ctr + ch;
+        q.x_n_peers = z.n_peers;
+        for (int i = 0; i < z.n_peers; i++) {                // as swe2d_p2p_push
+            if (i > 0 && z.off[i] < z.off[i - 1]) return fail(h, SWE2D_ERR_UNSUPPORTED, "flow with the exchange inside: send segments must be sorted by offset");
+            q.x_off[i] = z.off[i];
             char *base = z.remote_base[i];
-            q.x_rdata[i] = reinterpret_cast<double *>(base + p2p_channel_offset(z.width, 0, z.remote_n_recv[i])) + (size_t)z.remote_off[i]*9;
-            q.x_rslot[i] = (size_t)z.remote_n_recv[i]*9;
-            q.x_rflag[i] = reinterpret_cast<unsigned long long *>(base) + (size_t)z.remote_flag[i]*SWE_P2P_FLAG_STRIDE;
+            q.x_rdata[i] = base + p2p_channel_offset(z.width, ch, z.remote_n_recv[i]) + (size_t)z.remote_off[i]*144;
+            q.x_rslot[i] = (unsigned)((size_t)z.remote_n_recv[i]*144);
+            // my segment ends cnt cells after its start in both slots: the resource covers slot 0 .. the end of my segment in slot 1
+            q.x_rbytes[i] = q.x_rslot[i] + (unsigned)((size_t)z.cnt[i]*144);
         }
-        char *mine = static_cast<char *>(z.zone);            // as swe2d_p2p_wait_unpack, channel 0
-        for (int i = 0; i < z.n_from; i++)
-            q.x_flag[i] = reinterpret_cast<const unsigned long long *>(mine) + (size_t)i*SWE_P2P_FLAG_STRIDE;
-        q.x_zone = reinterpret_cast<const double *>(mine + p2p_channel_offset(z.width, 0, h->n_recv));
-        q.x_slot = (size_t)h->n_recv*9;
+        char *mine = static_cast<char *>(z.zone);            // as swe2d_p2p_wait_unpack
+        q.x_zone = mine + p2p_channel_offset(z.width, ch, h->n_recv);
+        q.x_slot = (unsigned)((size_t)h->n_recv*144);
+        q.x_zbytes = 2*q.x_slot;
         q.x_timeout = (unsigned long long)(z.timeout_s*1e8);
-        q.x_fence = z.zone_kind == 3;
     }
     fill_stage_args(h, q.st, 0, 0, 1, 0.0, 1.0, 1.0, 0, 0);
     for (int i = 0; i < 3; i++) q.buf[i] = h->state[i];
@@ -712,7 +713,7 @@ int flow_check(Handle *h)
     h->flow_used = false;
     if (st[0] == 0u) return SWE2D_OK;
     // leave the handle usable: counters and flags back to a consistent start
-    (void)hipMemsetAsync(h->flow_status, 0, 2*sizeof(unsigned), h->stream);
+    (void)hipMemsetAsync(h->flow_status, 0, 4*sizeof(unsigned), h->stream);
     (void)hipMemsetAsync(h->flow_flag, 0, (size_t)h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned), h->stream);
     (void)hipMemsetAsync(h->flow_ex, 0, h->flow_ex_bytes, h->stream);
     (void)hipStreamSynchronize(h->stream);
@@ -920,9 +921,9 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
         // the rim facets - interior facets whose two cells sit in different blocks - numbered in cell order
         h->flow_blocks = (n + SWE_BLOCK - 1)/SWE_BLOCK;
         HIP_TRY_C(hipMalloc(&h->flow_flag, (size_t)h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned)));
-        HIP_TRY_C(hipMalloc(&h->flow_status, 2*sizeof(unsigned)));
+        HIP_TRY_C(hipMalloc(&h->flow_status, 4*sizeof(unsigned)));
         HIP_TRY_C(hipMemset(h->flow_flag, 0, (size_t)h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned)));
-        HIP_TRY_C(hipMemset(h->flow_status, 0, 2*sizeof(unsigned)));
+        HIP_TRY_C(hipMemset(h->flow_status, 0, 4*sizeof(unsigned)));
         if (int rc = flow_build(h, nullptr)) { g_create_error = h->err; swe2d_destroy(reinterpret_cast<swe2d_handle *>(h)); return rc; }
         if (const char *e = std::getenv("THETIS_AMD_FLOW_TIMEOUT_S")) { const double t = std::atof(e); if (t > 0.0) h->flow_timeout_s = t; }
     }
@@ -1347,6 +1348,26 @@ int swe2d_solve_flow_exchange(swe2d_handle *hh, int32_t n_cycles, int32_t stages
     HIP_TRY(h, hipSetDevice(h->device));
     RoctxRange range("swe2d_solve_flow_exchange");
     return launch_flow(h, stages_per_cycle, cell_end, n_cycles);
+}
+
+int swe2d_flow_unpack_pending(swe2d_handle *hh)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    auto &z = h->p2p;
+    const int ch = z.n_channels - 1;
+    if (!z.zone || !z.ctr || ch < 0 || z.width[ch] != 18 || !h->flow_status)
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_flow_unpack_pending: no granule channel");
+    if (h->n_recv == 0) return SWE2D_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    char *mine = static_cast<char *>(z.zone);
+    const unsigned slot = (unsigned)((size_t)h->n_recv*144);
+    hipLaunchKernelGGL(swe_flow_unpack_kernel, dim3(std::min(256, grid_for(h->n_recv))), dim3(256), 0, h->stream, h->state[0], h->stride,
+                       h->recv_cells, h->n_recv, (void *)(mine + p2p_channel_offset(z.width, ch, h->n_recv)), 2*slot, slot, z.ctr + ch,
+                       h->flow_status, (unsigned long long)(z.timeout_s*1e8));
+    HIP_TRY(h, hipGetLastError());
+    h->flow_used = true;
+    return SWE2D_OK;
 }
 
 int swe2d_flow_prepare_exchange(swe2d_handle *hh)

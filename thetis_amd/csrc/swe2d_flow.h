@@ -90,27 +90,24 @@ struct SweFlowArgs {
     int cell_end[SWE_FLOW_MAX_STAGES];     // stage s updates the cells [0, cell_end[s]); non-increasing
     double a0[3], a1[3], beta[3];          // Shu-Osher weights per stage (swe2d_ssprk33_coefficients)
     unsigned long long timeout_ticks;      // wall_clock64 ticks (100 MHz)
-    // ---- FX kernels: the halo exchange of a partition inside the launch (peer-to-peer channel 0 of swe2d_p2p.h).  The launch
-    //      runs n_cycles exchange cycles of stages_per_cycle stages (n_stages = their product; cell_end[g] holds the ranges of
-    //      ONE cycle): a cycle starts with the receive of the previous cycle's push (ghost lanes read their cells from the landing
-    //      zone), ends with the push of the send cells into the peers' zones.
+    // ---- FX kernels: the halo exchange of a partition inside the launch, cell by cell through tagged granules in the peers'
+    //      landing zones (a peer-to-peer channel of swe2d_p2p.h of width 18 = nine granules per cell; its epoch flags are not
+    //      used).  The launch runs n_cycles exchange cycles of stages_per_cycle stages (n_stages = their product; cell_end[g] holds
+    //      the ranges of ONE cycle): a cycle starts with the receive of the previous cycle's push (every ghost lane waits for the
+    //      nine granules of ITS cell to carry the push number), ends with the push of the send cells into the peers' zones.
     int n_cycles, stages_per_cycle;
     const int2 *xsend;                     // per position: the cell's (up to two) places in the send list, -1: none
     const int *xrecv;                      // per position: the cell's place in the receive list, -1: not a ghost cell
-    int n_push_blocks, n_recv_blocks;      // blocks holding send cells / ghost cells
-    unsigned *xtick;                       // [SWE_FLOW_MAX_CYCLES] arrival counters of a cycle's receives and pushes (self-cleaning);
-                                           //  word 2*SWE_FLOW_MAX_CYCLES (128 B further): 64-bit count of this rank's completed pushes
-    SweP2pCounters *xctr;                  // epochs of channel 0
-    int x_n_peers, x_n_from;
-    int x_off[SWE_P2P_MAX_PEERS], x_cnt[SWE_P2P_MAX_PEERS];                 // per peer: segment of the send list (cells)
-    double *x_rdata[SWE_P2P_MAX_PEERS];                                      // peer's landing segment for me, slot 0
-    size_t x_rslot[SWE_P2P_MAX_PEERS];                                       // doubles between the peer's slot 0 and slot 1
-    unsigned long long *x_rflag[SWE_P2P_MAX_PEERS];                          // my flag in the peer's header
-    const unsigned long long *x_flag[SWE_P2P_MAX_PEERS];                     // the peers' flags in MY header
-    const double *x_zone;                                                    // my landing data, slot 0
-    size_t x_slot;                                                           // doubles between slot 0 and slot 1
+    unsigned *xtick;                       // arrival counter of the launch's blocks (the last one advances the epochs)
+    SweP2pCounters *xctr;                  // pushes made / received so far (the granule channel's counters)
+    int x_n_peers;
+    int x_off[SWE_P2P_MAX_PEERS];                                            // per peer: start of its segment of the send list (cells)
+    void *x_rdata[SWE_P2P_MAX_PEERS];                                        // peer's landing segment for me, slot 0
+    unsigned x_rbytes[SWE_P2P_MAX_PEERS];                                    // its size in bytes (both slots)
+    unsigned x_rslot[SWE_P2P_MAX_PEERS];                                     // bytes between the peer's slot 0 and slot 1
+    void *x_zone;                                                            // my landing data, slot 0
+    unsigned x_zbytes, x_slot;                                               // its size (both slots), bytes between slot 0 and slot 1
     unsigned long long x_timeout;                                            // wall_clock64 ticks
-    int x_fence;                                                             // the zone is ordinary device memory: acquire fence after the wait
 };
 
 // one granule: {value, tag} written / read by ONE 16-byte access of one lane, sc1 (aux 16): write-through / past the L1
@@ -123,6 +120,17 @@ __device__ __forceinline__ void swe_flow_put(__amdgpu_buffer_rsrc_t r, unsigned 
 __device__ __forceinline__ swe_u32x3 swe_flow_get(__amdgpu_buffer_rsrc_t r, unsigned off)       // value + tag: 12 of the 16 bytes
 {
     return __builtin_amdgcn_raw_buffer_load_b96(r, off, 0, 16);
+}
+// the same across devices: system scope (sc0 sc1, aux 17), tag = push number
+__device__ __forceinline__ void swe_flow_put_sys(__amdgpu_buffer_rsrc_t r, unsigned off, double x, unsigned tag)
+{
+    const swe_u32x2 xb = __builtin_bit_cast(swe_u32x2, x);
+    const swe_u32x4 g = {xb.x, xb.y, tag, 0u};
+    __builtin_amdgcn_raw_buffer_store_b128(g, r, off, 0, 17);
+}
+__device__ __forceinline__ swe_u32x3 swe_flow_get_sys(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    return __builtin_amdgcn_raw_buffer_load_b96(r, off, 0, 17);
 }
 __device__ __forceinline__ double swe_flow_val(swe_u32x3 g)
 {
@@ -416,38 +424,16 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
         const int2 t = q.xsend[lb*SWE_BLOCK + lane];
         xs1 = real ? t.x : -1; xs2 = real ? t.y : -1;
         xr = real ? q.xrecv[lb*SWE_BLOCK + lane] : -1;
-        // both counters are only written by the launch's LAST arrival (below): stable for every wave of the launch
+        // both counters are only written by the launch's LAST block to finish (below): stable for every wave of the launch
         S0 = q.xctr->epoch_send; R0 = q.xctr->epoch_recv;
         pend0 = S0 > R0;                   // a push of the previous launch has not been received yet
         has_ghost = __any(xr >= 0);
         has_send = __any(xs1 >= 0);
     }
     const int ncyc = FX ? q.n_cycles : 1, spc = FX ? q.stages_per_cycle : q.n_stages;
-    unsigned long long *const xdone = reinterpret_cast<unsigned long long *>(q.xtick + 2*SWE_FLOW_MAX_CYCLES);      // a cache line of its own
     unsigned long long t_start = 0ull;
     bool late = false;
     int s = 0;                             // stage counter of the launch
-
-    // arrival at the end of a cycle's receive / push: the last one raises this rank's flags at the peers (all my ghost cells of
-    // the cycle have been read - the peers may overwrite that slot two pushes later - and all my send cells have landed)
-#define SWE_FLOW_ARRIVE(c_) do {                                                                                                  \
-        if (lane == 0) {                                                                                                          \
-            const unsigned expected = (unsigned)q.n_push_blocks + ((((c_) > 0) || pend0) ? (unsigned)q.n_recv_blocks : 0u);       \
-            const unsigned t_ = __hip_atomic_fetch_add(&q.xtick[(c_)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           \
-            if (t_ == expected - 1u) {                                                                                            \
-                __hip_atomic_store(&q.xtick[(c_)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                               \
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                                                                     \
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                  \
-                for (int i_ = 0; i_ < q.x_n_peers; i_++)                                                                          \
-                    __hip_atomic_store(q.x_rflag[i_], S0 + (unsigned long long)(c_) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
-                __hip_atomic_store(xdone, S0 + (unsigned long long)(c_) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      \
-                if ((c_) == ncyc - 1) {                                                                                           \
-                    q.xctr->epoch_send = S0 + (unsigned long long)ncyc;                                                           \
-                    q.xctr->epoch_recv = R0 + (unsigned long long)(ncyc - 1) + (pend0 ? 1ull : 0ull);                             \
-                }                                                                                                                 \
-            }                                                                                                                     \
-        }                                                                                                                         \
-    } while (0)
 
     // publish the rim traces held in (pu, pv, pe) of the lanes in `who`: facet f carries my nodes f (granules 0-2) and f + 1
     // (granules 3-5).  The values go to the staging area by slot, then the wave stores the block's whole slot range, consecutive
@@ -475,43 +461,64 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 #pragma unroll 1
     for (int c = 0; c < ncyc; c++) {
         if (FX) {
-            // ---- receive: the push the peers made at the end of the previous cycle (or launch)
+            // ---- receive: what the peers pushed at the end of their previous cycle (or launch).  Every ghost lane waits for the nine
+            //      granules of ITS cell to carry that push's number - no flag per rank: a ghost cell is ready as soon as the one block
+            //      of the peer that owns it has finished, and the peer may overwrite the slot two pushes later only after it has
+            //      received this rank's next push, which depends on this cell having been read
             if (((c > 0) || pend0) && has_ghost) {
-                const unsigned long long target = R0 + (unsigned long long)c + (pend0 ? 1ull : 0ull);
-                bool lost = q.xctr->timeouts != 0u;            // sticky, as in swe_p2p_unpack_kernel: a lost peer costs one bounded wait
-                if (lane == 0) {                               // ONE lane polls (MI355X_MICROARCH.md, polling-cost)
-                    const unsigned long long w0 = wall_clock64();
-                    // not before THIS rank has finished its previous cycle (its push is complete: every block has read what it reads in
-                    // that cycle).  The peers' flags only say that THEY are done; a block of outer ghost cells skips the late stages
-                    // and would otherwise be back here - overwriting its previous input - a whole cycle ahead of its neighbours.
-                    if (c > 0) {
-                        while (__hip_atomic_load(xdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S0 + (unsigned long long)c) {
-                            if (wall_clock64() - w0 > q.x_timeout) { lost = true; break; }
-                            __builtin_amdgcn_s_sleep(4);
+                const unsigned target = (unsigned)(R0 + (unsigned long long)c + (pend0 ? 1ull : 0ull));
+                const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(q.x_zone, 0, q.x_zbytes, 0x00020000);
+                const unsigned zo = xr >= 0 ? (target & 1u)*q.x_slot + (unsigned)xr*144u : SWE_FLOW_NOWHERE;
+                // A block of outer ghost cells skips the late stages of a cycle and waits here for most of it: ONE lane watches ONE
+                // granule, slowly (every polling pass of every lane is nine fabric reads per ghost cell - MI355X_MICROARCH.md,
+                // polling-cost), the full passes start when that one has arrived
+                {
+                    const unsigned long long gm = __ballot(xr >= 0);
+                    const int first = (int)__builtin_ctzll(gm);
+                    const unsigned hint = __builtin_amdgcn_readlane(zo, first);
+                    for (unsigned spins = 0; !late; spins++) {
+                        const swe_u32x3 g1 = swe_flow_get_sys(rz, lane == 0 ? hint : SWE_FLOW_NOWHERE);
+                        if (__any(lane == 0 && (int)(g1.z - target) >= 0)) break;
+                        __builtin_amdgcn_s_sleep(16);
+                        if ((spins & 15u) == 15u) {
+                            const unsigned long long now = wall_clock64();
+                            if (t_start == 0ull) t_start = now;
+                            else if (now - t_start > q.x_timeout) {
+                                late = true;
+                                if (lane == 0 && atomicAdd(q.status, 1u) == 0u) q.status[1] = (unsigned)lb + 1u;
+                            }
                         }
                     }
-                    for (int i = 0; i < q.x_n_from && !lost; i++) {
-                        while (__hip_atomic_load(q.x_flag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
-                            if (wall_clock64() - w0 > q.x_timeout) { lost = true; break; }
-                            __builtin_amdgcn_s_sleep(4);
+                    t_start = 0ull;
+                }
+                for (unsigned spins = 0;; spins++) {
+                    swe_u32x3 gz[9];
+#pragma unroll
+                    for (int i = 0; i < 9; i++) gz[i] = swe_flow_get_sys(rz, zo + 16u*i);
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < 9; i++) ok = ok && (int)(gz[i].z - target) >= 0;
+                    if (xr >= 0) {
+#pragma unroll
+                        for (int i = 0; i < 3; i++) { u[i] = swe_flow_val(gz[i]); v[i] = swe_flow_val(gz[3 + i]); e[i] = swe_flow_val(gz[6 + i]); }
+                    }
+                    if (__all(ok || xr < 0) || late) break;
+                    __builtin_amdgcn_s_sleep(4);
+                    if ((spins & 31u) == 31u) {
+                        const unsigned long long now = wall_clock64();
+                        if (t_start == 0ull) t_start = now;
+                        else if (now - t_start > q.x_timeout) {
+                            late = true;
+                            if (lane == 0 && atomicAdd(q.status, 1u) == 0u) q.status[1] = (unsigned)lb + 1u;
                         }
                     }
                 }
-                lost = __any(lost);
-                if (lost && lane == 0) atomicAdd(&q.xctr->timeouts, 1u);
-                if (q.x_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-                asm volatile("" ::: "memory");
-                if (xr >= 0) {
-                    const double *src = q.x_zone + (target & 1ull)*q.x_slot + (size_t)xr*9;
-#pragma unroll
-                    for (int i = 0; i < 3; i++) { u[i] = swe_p2p_load(src + i); v[i] = swe_p2p_load(src + 3 + i); e[i] = swe_p2p_load(src + 6 + i); }
-                    // ... and into the state planes, for the kernels after this launch
+                t_start = 0ull;
+                if (xr >= 0) {                                 // ... and into the state planes, for the kernels after this launch
                     const swe_rsrc_t gou = swe_rsrc(q.buf[0]), gov = swe_rsrc(q.buf[0] + 3*S), goe = swe_rsrc(q.buf[0] + 6*S);
 #pragma unroll
                     for (int i = 0; i < 3; i++) { swe_st(gou, k8, i*S8, u[i]); swe_st(gov, k8, i*S8, v[i]); swe_st(goe, k8, i*S8, e[i]); }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zone has been read
-                SWE_FLOW_ARRIVE(c);
             }
             // ---- the cycle's input across the rims
             SWE_FLOW_PUBLISH(u, v, e, real, c*spc, 2);
@@ -633,27 +640,79 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             for (int i = 0; i < 3; i++) { u[i] = ou[i]; v[i] = ov[i]; e[i] = oe[i]; }
         }
         if (FX && has_send) {
-            // ---- push: the send cells of this block straight into the peers' landing zones (the cycle's last stage left the step
-            //      result in u, v, e), then this block's arrival
-            const unsigned long long target = S0 + (unsigned long long)c + 1ull;
+            // ---- push: the send cells of this block straight into the peers' landing zones as granules tagged with the push number
+            //      (the cycle's last stage left the step result in u, v, e).  No drain, no flag.
+            const unsigned target = (unsigned)(S0 + (unsigned long long)c + 1ull);
+            for (int pp = 0; pp < q.x_n_peers; pp++) {         // uniform: one buffer resource per peer
+                const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(q.x_rdata[pp], 0, q.x_rbytes[pp], 0x00020000);
+                const int lo = q.x_off[pp], hi = pp + 1 < q.x_n_peers ? q.x_off[pp + 1] : 0x7fffffff;
 #pragma unroll
-            for (int w = 0; w < 2; w++) {
-                const int j = w ? xs2 : xs1;
-                if (j >= 0) {
-                    int pp = 0;
-#pragma unroll 1
-                    for (int i = 1; i < q.x_n_peers; i++) if (j >= q.x_off[i]) pp = i;          // segments are sorted by offset
-                    double *dst = q.x_rdata[pp] + (target & 1ull)*q.x_rslot[pp] + (size_t)(j - q.x_off[pp])*9;
+                for (int w = 0; w < 2; w++) {
+                    const int j = w ? xs2 : xs1;
+                    if (j >= lo && j < hi) {
+                        const unsigned o = (target & 1u)*q.x_rslot[pp] + (unsigned)(j - lo)*144u;
 #pragma unroll
-                    for (int i = 0; i < 3; i++) { swe_p2p_store(dst + i, u[i]); swe_p2p_store(dst + 3 + i, v[i]); swe_p2p_store(dst + 6 + i, e[i]); }
+                        for (int i = 0; i < 3; i++) {
+                            swe_flow_put_sys(rp, o + 16u*i, u[i], target);
+                            swe_flow_put_sys(rp, o + 16u*(3 + i), v[i], target);
+                            swe_flow_put_sys(rp, o + 16u*(6 + i), e[i], target);
+                        }
+                    }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // write-through stores: drained = delivered
-            SWE_FLOW_ARRIVE(c);
         }
     }
-#undef SWE_FLOW_ARRIVE
 #undef SWE_FLOW_PUBLISH
     // retired or finished: every block's counter ends the launch at base + n_stages
     if (lane == 0) *myflag = fin;
+    if (FX && lane == 0) {
+        // the last block to finish advances the epochs (nobody reads them any more in this launch)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t_ = __hip_atomic_fetch_add(q.xtick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t_ == (unsigned)q.n_blocks - 1u) {
+            __hip_atomic_store(q.xtick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q.xctr->epoch_send = S0 + (unsigned long long)ncyc;
+            q.xctr->epoch_recv = R0 + (unsigned long long)(ncyc - 1) + (pend0 ? 1ull : 0ull);
+        }
+    }
+}
+
+// Receives a pending push (pushes > receives) outside a flow launch: the ghost cells' granules into the state planes.  For the
+// end of an advance - the next FX launch would do it itself, but the state may leave the device or other kernels may run first.
+__global__ __launch_bounds__(256) void swe_flow_unpack_kernel(double *planes, size_t stride, const int *recv_cells, int n_recv,
+                                                              void *zone, unsigned zbytes, unsigned slot, SweP2pCounters *ctr,
+                                                              unsigned *status, unsigned long long timeout_ticks)
+{
+    const unsigned long long S0 = ctr->epoch_send, R0 = ctr->epoch_recv;
+    if (S0 <= R0) return;                                      // nothing pending (uniform over the grid)
+    const unsigned target = (unsigned)(R0 + 1ull);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(zone, 0, zbytes, 0x00020000);
+    const unsigned long long w0 = wall_clock64();
+    for (int j = blockIdx.x*256 + threadIdx.x; j < n_recv; j += gridDim.x*256) {
+        const unsigned zo = (target & 1u)*slot + (unsigned)j*144u;
+        double x[9];
+        for (;;) {
+            bool ok = true;
+            for (int i = 0; i < 9; i++) {
+                const swe_u32x3 g = swe_flow_get_sys(rz, zo + 16u*i);
+                x[i] = swe_flow_val(g);
+                ok = ok && (int)(g.z - target) >= 0;
+            }
+            if (ok) break;
+            if (wall_clock64() - w0 > timeout_ticks) { atomicAdd(status, 1u); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        const int k = recv_cells[j];
+        for (int i = 0; i < 9; i++) planes[(size_t)i*stride + k] = x[i];
+    }
+    // the epoch: advanced by the last block (every block read R0 before it)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned *tick = status + 2;
+        const unsigned t_ = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t_ == gridDim.x - 1u) {
+            __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctr->epoch_recv = R0 + 1ull;
+        }
+    }
 }

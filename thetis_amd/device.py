@@ -398,9 +398,13 @@ class Swe2dDevice(object):
 
     def solve_flow_exchange(self, n_cycles, cell_ends):
         """``n_cycles`` exchange cycles of ``len(cell_ends)`` stages each in ONE launch, the peer-to-peer halo exchange inside
-        (csrc/swe2d_flow.h, FX kernels): the last cycle's push is received by the next such launch or by ``p2p_wait_unpack(0, 0)``."""
+        (csrc/swe2d_flow.h, FX kernels): the last cycle's push is received by the next such launch or by ``flow_unpack_pending``."""
         ends = np.ascontiguousarray(cell_ends, dtype=np.int32)
         self._ck(self.lib.swe2d_solve_flow_exchange(self.h, int(n_cycles), int(len(ends)), _iptr(ends)))
+
+    def flow_unpack_pending(self):
+        """Receive the last push of ``solve_flow_exchange`` outside a flow launch (ghost cells -> state planes)."""
+        self._ck(self.lib.swe2d_flow_unpack_pending(self.h))
 
     def flow_prepare_exchange(self):
         """Tables of ``solve_flow_exchange`` ahead of its first launch (which must not allocate inside a capture)."""

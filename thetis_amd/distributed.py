@@ -72,12 +72,14 @@ class HaloExchanger(object):
 
 class P2PHalo(object):
     """Set-up of the peer-to-peer exchange of one handle: landing zone, IPC handles swapped through ``group`` (any backend;
-    an object all-gather at set-up only), peers' zones mapped, segments connected.  Channel 0 = SWE state, 1 + t = tracer t."""
+    an object all-gather at set-up only), peers' zones mapped, segments connected.  Channel 0 = SWE state, 1 + t = tracer t;
+    on triangles a last channel of 18 doubles per cell carries the granules of the flow kernel's in-launch exchange
+    (csrc/swe2d_flow.h, FX kernels: nine 16-byte {value, push number} pairs per cell)."""
 
     def __init__(self, dev, part, rank, world, n_tracers=0, group=None):
         import torch.distributed as dist
         k = int(part.cells.shape[1])
-        self.dev, self.n_channels = dev, 1 + int(n_tracers)
+        self.dev, self.n_channels = dev, 1 + int(n_tracers) + (1 if k == 3 else 0)
 
         def gather(obj):
             out = [None]*world
@@ -95,7 +97,7 @@ class P2PHalo(object):
         # together instead of leaving the others waiting in a collective
         mine = {'pid': os.getpid(), 'error': None}
         try:
-            dev.p2p_create([3*k] + [k]*int(n_tracers))
+            dev.p2p_create([3*k] + [k]*int(n_tracers) + ([18] if k == 3 else []))
             handle, base, kind = dev.p2p_export()
             self.zone_kind = {1: 'uncached', 2: 'fine-grained', 3: 'device'}.get(kind, '?')
             mine.update(handle=handle, base=base, n_recv=int(len(part.recv_cells)),
@@ -212,8 +214,9 @@ class DistributedSwe2d(object):
 
         ``flow_exchange`` (with ``flow`` and the peer-to-peer transport): the exchange INSIDE the flow launch - up to 16 cycles per
         launch, a cycle starts by reading the ghost cells from the landing zone and ends by pushing the send cells into the
-        peers' zones (csrc/swe2d_flow.h, FX kernels); the push of an advance's last cycle is received by one unpack kernel at
-        its end.  None = where it applies, False = flow launch + push + unpack kernels per cycle.
+        peers' zones, cell by cell as tagged granules (csrc/swe2d_flow.h, FX kernels: no flag per rank, a ghost cell is ready as
+        soon as the peer's block that owns it has finished); the push of an advance's last cycle is received by one unpack kernel
+        at its end.  None = where it applies, False = flow launch + push + unpack kernels per cycle.
 
         ``exchange``: 'p2p' | 'rccl' | 'host' (module docstring); default 'host' if ``host_staged`` else 'rccl'.
         ``partition``: a LocalPartition already built for this rank with the halo depth the other arguments imply.
@@ -342,7 +345,7 @@ class DistributedSwe2d(object):
         if rem:
             ends_r = [p.stage_range(g, depth=3*rem) for g in range(3*rem)]
             self._launch(('X', 1, rem), lambda: dev.solve_flow_exchange(1, ends_r), graphed)
-        self._launch(('XU',), lambda: dev.p2p_wait_unpack(0, 0), graphed)
+        self._launch(('XU',), lambda: dev.flow_unpack_pending(), graphed)
 
     def _cycle_swe_flow(self, n_steps, graphed):
         """``n_steps`` time steps = 3 n_steps stages on the shrinking ranges in ONE launch, then the exchange."""

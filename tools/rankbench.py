@@ -45,7 +45,8 @@ def main():
         def __init__(self, dev, part, rank, world, n_tracers=0, group=None):
             k = int(part.cells.shape[1])
             self.dev, self.n_channels = dev, 1
-            dev.p2p_create([3*k])
+            dev.p2p_create([3*k] + ([18] if k == 3 else []))
+            self.n_channels = 2 if k == 3 else 1
             _, base, kind = dev.p2p_export()
             self.zone_kind = {1: 'uncached', 2: 'fine-grained', 3: 'device'}.get(kind, '?')
             peers = sorted(part.send)
@@ -55,7 +56,7 @@ def main():
                             n_from=len(peers))
 
         def timeouts(self):
-            return self.dev.p2p_status(1)[2]
+            return self.dev.p2p_status(self.n_channels)[2]
 
     distributed.HaloExchanger = NoExchange
     distributed.P2PHalo = LoopbackP2P
