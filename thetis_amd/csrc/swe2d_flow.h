@@ -314,6 +314,8 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
     __shared__ double lds[SWE_FLOW_LDS_DOUBLES];
     __shared__ int xsrc[SWE_FLOW_MAX_RIM];                     // the block's incoming list (SweFlowArgs::xsrc)
     __shared__ int lact[SWE_BLOCK];                            // is the lane's cell inside the running stage's range?
+    __shared__ unsigned lrec[SWE_BLOCK];                       // FX: places of the block's ghost / send cells' records in a landing zone
+    __shared__ int lpeer[SWE_BLOCK];
     __shared__ double lu0[9][SWE_BLOCK];                       // U(0) of the running time step (18 registers the stage loop cannot spare)
     const SweStageArgs &p = q.st;
     const int lb = swe_logical_block(blockIdx.x, gridDim.x);
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                     for (unsigned spins = 0; !late; spins++) {
                         const swe_u32x3 g1 = swe_flow_get_sys(rz, lane == 0 ? hint : SWE_FLOW_NOWHERE);
                         if (__any(lane == 0 && (int)(g1.z - target) >= 0)) break;
-                        __builtin_amdgcn_s_sleep(16);
+                        __builtin_amdgcn_s_sleep(8);
                         if ((spins & 15u) == 15u) {
                             const unsigned long long now = wall_clock64();
                             if (t_start == 0ull) t_start = now;
@@ -491,18 +493,24 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                     }
                     t_start = 0ull;
                 }
+                // the records (nine granules = 144 B per ghost cell) are read by nine consecutive lanes each - a 16-byte access per
+                // lane and granule would be nine fabric reads per cell and pass - into the staging area, ghost cell after ghost cell
+                // of the block; the ghost lanes then pick their nine values from LDS
+                const unsigned long long gm = __ballot(xr >= 0);
+                const int ng = (int)__builtin_popcountll(gm);
+                const int ci = (int)__builtin_popcountll(gm & ((1ull << lane) - 1ull));       // this ghost lane's rank among them
+                __syncthreads();
+                if (xr >= 0) lrec[ci] = zo;
+                __syncthreads();
                 for (unsigned spins = 0;; spins++) {
-                    swe_u32x3 gz[9];
-#pragma unroll
-                    for (int i = 0; i < 9; i++) gz[i] = swe_flow_get_sys(rz, zo + 16u*i);
                     bool ok = true;
-#pragma unroll
-                    for (int i = 0; i < 9; i++) ok = ok && (int)(gz[i].z - target) >= 0;
-                    if (xr >= 0) {
-#pragma unroll
-                        for (int i = 0; i < 3; i++) { u[i] = swe_flow_val(gz[i]); v[i] = swe_flow_val(gz[3 + i]); e[i] = swe_flow_val(gz[6 + i]); }
+                    for (int t = lane; t < 9*ng; t += SWE_BLOCK) {
+                        const int cc = (t*7282) >> 16, gi = t - 9*cc;                              // t / 9, t % 9
+                        const swe_u32x3 gz = swe_flow_get_sys(rz, lrec[cc] + 16u*(unsigned)gi);
+                        ok = ok && (int)(gz.z - target) >= 0;
+                        lds[SWE_FLOW_XG + t] = swe_flow_val(gz);
                     }
-                    if (__all(ok || xr < 0) || late) break;
+                    if (__all(ok) || late) break;
                     __builtin_amdgcn_s_sleep(4);
                     if ((spins & 31u) == 31u) {
                         const unsigned long long now = wall_clock64();
@@ -514,6 +522,11 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                     }
                 }
                 t_start = 0ull;
+                __syncthreads();
+                if (xr >= 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { u[i] = lds[SWE_FLOW_XG + 9*ci + i]; v[i] = lds[SWE_FLOW_XG + 9*ci + 3 + i]; e[i] = lds[SWE_FLOW_XG + 9*ci + 6 + i]; }
+                }
                 if (xr >= 0) {                                 // ... and into the state planes, for the kernels after this launch
                     const swe_rsrc_t gou = swe_rsrc(q.buf[0]), gov = swe_rsrc(q.buf[0] + 3*S), goe = swe_rsrc(q.buf[0] + 6*S);
 #pragma unroll
@@ -643,20 +656,31 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             // ---- push: the send cells of this block straight into the peers' landing zones as granules tagged with the push number
             //      (the cycle's last stage left the step result in u, v, e).  No drain, no flag.
             const unsigned target = (unsigned)(S0 + (unsigned long long)c + 1ull);
-            for (int pp = 0; pp < q.x_n_peers; pp++) {         // uniform: one buffer resource per peer
-                const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(q.x_rdata[pp], 0, q.x_rbytes[pp], 0x00020000);
-                const int lo = q.x_off[pp], hi = pp + 1 < q.x_n_peers ? q.x_off[pp + 1] : 0x7fffffff;
+            // a cell's record (nine granules = 144 B) is written by nine consecutive lanes: the send lanes drop their values and
+            // the record's place in LDS (send cell after send cell of the block), then the wave stores record after record
+#pragma unroll 1
+            for (int w = 0; w < 2; w++) {
+                const int j = w ? xs2 : xs1;
+                const unsigned long long sm = __ballot(j >= 0);
+                if (sm == 0ull) break;                         // uniform
+                const int ns = (int)__builtin_popcountll(sm);
+                const int ci = (int)__builtin_popcountll(sm & ((1ull << lane) - 1ull));
+                __syncthreads();
+                if (j >= 0) {
+                    int pp = 0;
+#pragma unroll 1
+                    for (int i = 1; i < q.x_n_peers; i++) if (j >= q.x_off[i]) pp = i;          // segments are sorted by offset
+                    lrec[ci] = (target & 1u)*q.x_rslot[pp] + (unsigned)(j - q.x_off[pp])*144u;
+                    lpeer[ci] = pp;
 #pragma unroll
-                for (int w = 0; w < 2; w++) {
-                    const int j = w ? xs2 : xs1;
-                    if (j >= lo && j < hi) {
-                        const unsigned o = (target & 1u)*q.x_rslot[pp] + (unsigned)(j - lo)*144u;
-#pragma unroll
-                        for (int i = 0; i < 3; i++) {
-                            swe_flow_put_sys(rp, o + 16u*i, u[i], target);
-                            swe_flow_put_sys(rp, o + 16u*(3 + i), v[i], target);
-                            swe_flow_put_sys(rp, o + 16u*(6 + i), e[i], target);
-                        }
+                    for (int i = 0; i < 3; i++) { lds[SWE_FLOW_XG + 9*ci + i] = u[i]; lds[SWE_FLOW_XG + 9*ci + 3 + i] = v[i]; lds[SWE_FLOW_XG + 9*ci + 6 + i] = e[i]; }
+                }
+                __syncthreads();
+                for (int pp = 0; pp < q.x_n_peers; pp++) {     // uniform: one buffer resource per peer
+                    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(q.x_rdata[pp], 0, q.x_rbytes[pp], 0x00020000);
+                    for (int t = lane; t < 9*ns; t += SWE_BLOCK) {
+                        const int cc = (t*7282) >> 16, gi = t - 9*cc;
+                        if (lpeer[cc] == pp) swe_flow_put_sys(rp, lrec[cc] + 16u*(unsigned)gi, lds[SWE_FLOW_XG + t], target);
                     }
                 }
             }

@@ -336,7 +336,7 @@ class DistributedSwe2d(object):
         if graphed:
             dev.flow_prepare_exchange()            # tables: never inside the capture of the first launch
         full, rem = divmod(n_steps, m)
-        per_launch = max(1, min(16, 48//(3*m)))
+        per_launch = max(1, min(16, 48//(3*m), int(os.environ.get('THETIS_AMD_FLOWX_CYCLES', '16'))))
         ends = [p.stage_range(g, depth=3*m) for g in range(3*m)]
         while full > 0:
             nc = min(per_launch, full)
