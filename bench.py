@@ -36,7 +36,7 @@ PREWARM_S = 0.5                          # seconds of untimed stepping before th
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_ELEMENT_STEP = 684.0          # 180 + 252 + 252 algorithmic bytes per triangle per step
 BYTES_PER_ELEMENT_UPDATE = BYTES_PER_ELEMENT_STEP/3.0
-TRAFFIC_JSON = 'r02f_traffic.json'         # committed PMC passes of the stage kernel on this workload (profiles/README.md)
+TRAFFIC_JSON = 'r03a_traffic.json'         # committed PMC passes of the stage kernel on this workload (profiles/README.md)
 BEYOND_CACHE_NX, BEYOND_CACHE_NY = 2000, 1000   # 4M triangles: 3 x 288 MB of state, beyond the 256 MB Infinity Cache
 
 
@@ -149,7 +149,7 @@ def beyond_cache(args):
     achieved = BYTES_PER_ELEMENT_UPDATE*n/(ms_kernel*1e-3)/1e9
     traffic = None
     try:                                       # committed PMC passes on this very workload (profiles/README.md)
-        with open(os.path.join(ROOT, 'profiles', 'r02f_traffic_4m.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r03a_traffic_4m.json')) as f:
             traffic = float(json.load(f)['traffic_bytes_per_launch']) if n == 4000000 else None
     except (OSError, KeyError, ValueError):
         pass
@@ -157,7 +157,7 @@ def beyond_cache(args):
             'beyond_cache': {'workload': 'RectangleMesh({:d},{:d}) = {:d} triangles, same channel and kernel'.format(
                                  BEYOND_CACHE_NX, BEYOND_CACHE_NY, n),
                              'achieved': achieved, 'avg_launch_ms': ms_kernel, 'steps': steps, 'traffic': traffic,
-                             'traffic_source': 'profiles/r02f_traffic_4m.json' if traffic else None,
+                             'traffic_source': 'profiles/r03a_traffic_4m.json' if traffic else None,
                              'algorithmic_bytes_per_launch': BYTES_PER_ELEMENT_UPDATE*n,
                              'element_updates_per_s': n*3.0*steps/(ms_events*1e-3)}}
 
