@@ -266,14 +266,13 @@ stage_kernel_t pick_src(bool src, int binl)          // binl: 0 epilogue variant
 }
 // wetting-drying variants (nonlinear equations only)
 template <bool LF, bool U0>
-stage_kernel_t pick_wd_src(bool src, int quad, bool binl)
+stage_kernel_t pick_wd_src(bool src, bool quad, bool binl)
 {
-    if (quad == 2) return src ? swe_stage_kernel_quad2<true, LF, U0, true, true> : swe_stage_kernel_quad2<true, LF, U0, false, true>;
     if (quad) return src ? swe_stage_kernel_quad<true, LF, U0, true, true> : swe_stage_kernel_quad<true, LF, U0, false, true>;
     if (binl) return src ? swe_stage_kernel<true, LF, U0, true, true, false, true> : swe_stage_kernel<true, LF, U0, false, true, false, true>;
     return src ? swe_stage_kernel<true, LF, U0, true, true> : swe_stage_kernel<true, LF, U0, false, true>;
 }
-stage_kernel_t pick_kernel_wd(bool lf, bool u0, bool src, int quad, bool binl)
+stage_kernel_t pick_kernel_wd(bool lf, bool u0, bool src, bool quad, bool binl)
 {
     if (lf) return u0 ? pick_wd_src<true, true>(src, quad, binl) : pick_wd_src<true, false>(src, quad, binl);
     return u0 ? pick_wd_src<false, true>(src, quad, binl) : pick_wd_src<false, false>(src, quad, binl);
@@ -302,18 +301,17 @@ stage_kernel_t pick_kernel_visc(bool nl, bool lf, bool u0, bool src)
 }
 
 template <bool NL, bool LF, bool U0>
-stage_kernel_t pickq_src(bool src, bool two)
+stage_kernel_t pickq_src(bool src)
 {
-    if (two) return src ? swe_stage_kernel_quad2<NL, LF, U0, true, false> : swe_stage_kernel_quad2<NL, LF, U0, false, false>;
     return src ? swe_stage_kernel_quad<NL, LF, U0, true, false> : swe_stage_kernel_quad<NL, LF, U0, false, false>;
 }
 template <bool NL, bool LF>
-stage_kernel_t pickq_u0(bool u0, bool src, bool two) { return u0 ? pickq_src<NL, LF, true>(src, two) : pickq_src<NL, LF, false>(src, two); }
+stage_kernel_t pickq_u0(bool u0, bool src) { return u0 ? pickq_src<NL, LF, true>(src) : pickq_src<NL, LF, false>(src); }
 template <bool NL>
-stage_kernel_t pickq_lf(bool lf, bool u0, bool src, bool two) { return lf ? pickq_u0<NL, true>(u0, src, two) : pickq_u0<NL, false>(u0, src, two); }
-stage_kernel_t pick_kernel_quad(bool nl, bool lf, bool u0, bool src, bool two)
+stage_kernel_t pickq_lf(bool lf, bool u0, bool src) { return lf ? pickq_u0<NL, true>(u0, src) : pickq_u0<NL, false>(u0, src); }
+stage_kernel_t pick_kernel_quad(bool nl, bool lf, bool u0, bool src)
 {
-    return nl ? pickq_lf<true>(lf, u0, src, two) : pickq_lf<false>(lf, u0, src, two);
+    return nl ? pickq_lf<true>(lf, u0, src) : pickq_lf<false>(lf, u0, src);
 }
 
 void fill_stage_args(Handle *h, SweStageArgs &a, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1)
@@ -381,20 +379,15 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     // 4 M 573-583 / 544.  Same bits in every variant: the kernel has no implicit contraction.
     const char *env_ldsx_s = std::getenv("THETIS_AMD_LDSX");
     const bool ldsx = env_ldsx_s ? std::atoi(env_ldsx_s) != 0 : (c1 - c0) >= 3000000;
-    // quadrilaterals: THETIS_AMD_QUAD_LANES=2 selects the kernel with a cell split over two lanes (swe_stage_kernel_quad2: four
-    // waves per SIMD instead of two) - an experiment that did not pay, see profiles/r03j_quad_two_lanes.txt
-    const char *env_ql = std::getenv("THETIS_AMD_QUAD_LANES");
-    const bool quad2 = h->npc == 4 && env_ql && std::atoi(env_ql) == 2;
     stage_kernel_t kern = fused_visc
         ? pick_kernel_visc(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
-        : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4 ? (quad2 ? 2 : 1) : 0, binl)
+        : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4, binl)
         : (h->npc == 4)
-        ? pick_kernel_quad(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), quad2)
+        ? pick_kernel_quad(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
         : pick_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), binl ? (ldsx ? 2 : 1) : 0);
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
     // the XCD-chunked block map needs a grid that is a multiple of 8; surplus blocks exit immediately
     const int grid = ((nblocks + 7)/8)*8;
-    const int grid_stage = quad2 ? (((c1 - c0 + SWE_QUAD2_CELLS - 1)/SWE_QUAD2_CELLS + 7)/8)*8 : grid;
     // Launches whose state no longer fits the Infinity Cache (three buffers of 24 B per node against 256 MB: beyond ~1.2 M
     // triangles / 0.9 M quadrilaterals) alternate the direction in which they walk the range: the cells a launch touched last -
     // still in the cache - are the first the next one reads.  Same results (cells are independent).  Same box, fraction of the
@@ -406,7 +399,7 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
         if (alt) { a.reverse = h->launch_parity; h->launch_parity ^= 1; }
     }
     SWE_CHK_SYNC(h->stream);
-    hipLaunchKernelGGL(kern, dim3(grid_stage), dim3(SWE_BLOCK), 0, h->stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     if (h->visc) {
         // HorizontalViscosityTerm: U_out[uv] += beta*dt*M^-1 R_visc(U_in) on the same cells (swe2d_sipg.h)

@@ -1784,6 +1784,16 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_calibration_copy(const double *
 // facets: the same 2-point rule and numerical fluxes as the triangles (a facet carries two nodes);
 // mass inverse: (M^-1 b)_i = (16 b_i - 8 b_{i+1} - 8 b_{i-1} + 4 b_{i+2})/A.
 // Algorithmic bytes per cell per stage: 96 read + 96 write (+96 U0 in stages 2,3) + 56 static.
+//
+// One lane per cell, 196-223 VGPRs, two waves per SIMD.  Splitting a cell over TWO lanes (half-turn local frames, partner values
+// by DPP quad_perm, 118-120 VGPRs = four waves per SIMD, twice the instruction streams) was built, passed the same parity tests
+// and ran at the SAME speed at every size from 122 k to 2 M cells (1 M: 201-207 against 193-203 us/step, with 3 or 4 waves per
+// SIMD alike): this kernel is not bound by its occupancy.  PMC: HBM traffic x 1.05 of the algorithmic bytes, 1182 VALU
+// instructions per wave (~45 % of the SIMD cycles), the rest is the index -> gather -> arithmetic -> store chain of a wave
+// against HBM latency, which more waves of half the size do not shorten.  A lesson from the same experiment: a cold code path
+// (the boundary-facet copy) that SPILLS costs every wave - the kernel then carries a scratch allocation, 251 against 201 us/step
+// although no wave of the timed mesh interior ever touches the scratch.  profiles/r03j_quad_two_lanes.txt; the kernel is in the
+// history (commit "Experiment: quadrilateral stage kernel with a cell split over two lanes").
 // ===============================================================================================================
 template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD>
 __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStageArgs p)
@@ -2037,383 +2047,6 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         swe_st(swe_rsrc(p.uout + 4*S), k8, i*S8, ov[i]);
         swe_st(swe_rsrc(p.uout + 8*S), k8, i*S8, oe[i]);
     }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The same stage with a cell split over TWO lanes (lanes 2j, 2j+1 of a wave = cell j of its 32 cells).
-//
-// Why: the one-lane kernel above needs 196-223 VGPRs = 2 waves per SIMD, its loads and its arithmetic run in lock step and the
-// SIMDs are ~40 % busy (0.57 of the HBM roofline at 1 M cells).  Half a cell per lane fits ~128 VGPRs: four waves per SIMD,
-// the same number of cells in flight, twice the instruction streams to overlap one wave's gathers with another's arithmetic.
-//
-// Lane `hh` (0 / 1) sees the cell ROTATED by 2 hh nodes: its local node i is node (2 hh + i) & 3 - a half turn of the reference
-// square, under which a parallelogram is again a counter-clockwise parallelogram, the bilinear basis maps onto itself and the
-// 2 x 2 Gauss points onto each other.  Everything below is written in the lane's local frame; the rotation costs nothing but the
-// plane a load / store addresses (a per-lane byte offset).  The lane
-//   * loads the state, bathymetry and coordinates of its local nodes 0, 1 and takes nodes 2, 3 from its partner (DPP quad_perm
-//     [1,0,3,2]: a register move, no LDS, no memory),
-//   * owns local facets 0 (nodes 0-1) and 1 (nodes 1-2): 12 neighbour traces instead of 24,
-//   * owns the two Gauss points next to facet 0 (zeta' = xi_0),
-//   * adds its partner's twelve residual entries to its own (a + b = b + a: both lanes hold the same sums), applies the rows 0, 1
-//     of the mass inverse and stores six values.
-// Geometry in the local frame: a' = p1' - p0', b' = p2' - p1' (= p3' - p0' on a parallelogram; swe2d_create checks the cells).
-// Facet normals are built from the same two vertices as in the neighbour cell, so the numerical flux is antisymmetric to the bit
-// as before.  Same quadrature, fluxes and formulas as swe_stage_kernel_quad; the summation ORDER of a residual entry differs
-// (two partial sums), so the two kernels agree to round-off, not to the bit (tests/test_gpu_quads.py compares both with the
-// oracle at 1e-12).  THETIS_AMD_QUAD_LANES=1 selects the one-lane kernel (A/B).
-// ---------------------------------------------------------------------------------------------------------------
-#ifndef SWE_QUAD2_OCCUPANCY
-#define SWE_QUAD2_OCCUPANCY __attribute__((amdgpu_waves_per_eu(4, 4)))
-#endif
-#define SWE_QUAD2_CELLS 32       // cells per one-wave workgroup
-// keeps the scheduler from interleaving the two quadrature points of a facet (their temporaries would be live together)
-#ifndef SWE_QUAD2_SCHED_FENCE
-#define SWE_QUAD2_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
-
-__device__ __forceinline__ double swe_pair(double x)      // the partner lane's x
-{
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-
-// swe_wd_finish<4> for a cell held by two lanes (two nodes each): the cell mean is (own pair) + (partner's pair)
-__device__ __forceinline__ void swe_wd_finish_pair(double g, double dt_stage, const double h[2], const double al[2], double ou[2],
-                                                   double ov[2], double oe[2], bool relax)
-{
-#pragma clang fp contract(off)
-    double D[2] = {oe[0] + h[0], oe[1] + h[1]};
-    const double sm = D[0] + D[1];
-    const double mean = (sm + swe_pair(sm))*0.25;
-    const double dm = fmin(D[0], D[1]);
-    const double dmin = fmin(dm, swe_pair(dm));
-    const double fm = fmax(SWE_WD_FLOOR*al[0], SWE_WD_FLOOR*al[1]);
-    const double fl = fmax(fm, swe_pair(fm));
-    if (dmin < fl) {
-        if (mean <= fl) {
-            const double flat = fmax(mean, 0.1*fl);
-            D[0] = flat; D[1] = flat;
-        } else {
-            const double theta = (mean - fl)*swe_rcp(mean - dmin);
-            D[0] = mean + theta*(D[0] - mean);
-            D[1] = mean + theta*(D[1] - mean);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const double eta = D[i] - 0.25*al[i]*al[i]*swe_rcp(D[i]) - h[i];
-        oe[i] = eta;
-        if (!relax) continue;
-        const double ral = swe_rcp(al[i]);
-        const double psi = fmin(1.0, fmax(0.0, -(h[i] + eta)*ral - 1.0));
-        if (psi > 0.0) {
-            const double fac = exp(-dt_stage*(1.0/SWE_WD_TAU)*swe_sqrt(g*ral)*psi*psi);
-            ou[i] *= fac;
-            ov[i] *= fac;
-        }
-    }
-}
-
-// Everything after the loads of the lane's own half of the cell.  BND: the wave holds a boundary facet.  The boundary code
-// needs ~40 VGPRs more than the interior path; with both in one body the register allocator spills on the common path
-// (36-276 B/lane under the 128-VGPR cap, depending on where the boundary code is placed), so the kernel carries two copies of
-// this function and branches PER WAVE: a wave without boundary facets (97-99 % of them) runs code that never heard of them.
-template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD, bool BND>
-__device__ __forceinline__ void swe_quad2_rest(const SweStageArgs &p, const int k, const unsigned r0, const unsigned S8,
-                                               const unsigned o0, const unsigned o1, const unsigned o2, const unsigned o3,
-                                               const int nb0, const int nb1, const int vid0, const int vid1,
-                                               const double u0_, const double u1_, const double v0_, const double v1_,
-                                               const double e0_, const double e1_)
-{
-#pragma clang fp contract(off)
-    const size_t S = p.stride;
-    const double g = p.g;
-    const swe_rsrc_t gu = swe_rsrc(p.uin), gv = swe_rsrc(p.uin + 4*S), ge = swe_rsrc(p.uin + 8*S);
-    const int nb[2] = {nb0, nb1}, vid[2] = {vid0, vid1};
-    double u[4], v[4], e[4];
-    u[0] = u0_; u[1] = u1_; v[0] = v0_; v[1] = v1_; e[0] = e0_; e[1] = e1_;
-    // traces across the lane's two facets (see swe_stage_kernel_quad: a boundary facet carries the cell's own values)
-    double una[2], unb[2], vna[2], vnb[2], ena[2], enb[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int nbf = nb[j];
-        const int kn = nbf >= 0 ? (nbf >> 2) : k;
-        const int f2 = nbf >= 0 ? (nbf & 3) : (int)r0 + j;
-        const int na = (f2 + 1) & 3;
-        const unsigned kn8 = (unsigned)kn*8u;
-        const unsigned ob = kn8 + (unsigned)f2*S8;
-        const unsigned oa = kn8 + (unsigned)na*S8;
-        una[j] = swe_ld(gu, oa, 0);
-        unb[j] = swe_ld(gu, ob, 0);
-        vna[j] = swe_ld(gv, oa, 0);
-        vnb[j] = swe_ld(gv, ob, 0);
-        ena[j] = swe_ld(ge, oa, 0);
-        enb[j] = swe_ld(ge, ob, 0);
-    }
-    double px[3], py[3], h[3], H[4], al[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const unsigned v8 = (unsigned)vid[i]*8u;
-        px[i] = swe_ld(swe_rsrc(p.vx), v8, 0);
-        py[i] = swe_ld(swe_rsrc(p.vy), v8, 0);
-        h[i] = swe_ld(swe_rsrc(p.vh), v8, 0);
-        if (WD) al[i] = swe_ld(swe_rsrc(p.valpha), v8, 0);
-        H[i] = WD ? swe_wd_depth(h[i] + e[i], al[i]) : (NONLIN ? h[i] + e[i] : h[i]);
-    }
-    // the partner's half of the cell (its node 1 = my node 3 is not needed before the cell integrals)
-    u[2] = swe_pair(u[0]); v[2] = swe_pair(v[0]); e[2] = swe_pair(e[0]); H[2] = swe_pair(H[0]);
-    px[2] = swe_pair(px[0]); py[2] = swe_pair(py[0]);
-    h[2] = (NONLIN || WD) ? swe_pair(h[0]) : H[2];
-    if (WD) al[2] = swe_pair(al[0]);
-
-    const double ax = px[1] - px[0], ay = py[1] - py[0];
-    const double bx = px[2] - px[1], by = py[2] - py[1];
-    const double A = fma(ax, by, -(ay*bx));
-    const double rA = swe_rcp(A);
-    const double xix = by, xiy = -bx, zex = -ay, zey = ax;          // A * grad(xi'), A * grad(zeta')
-
-    double bu[4] = {0.0, 0.0, 0.0, 0.0}, bv[4] = {0.0, 0.0, 0.0, 0.0}, be[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int a = j, b = j + 1;
-        const double nxs = py[b] - py[a], nys = px[a] - px[b];
-        const double len2 = swe_dot2(nxs, nxs, nys, nys);
-        double L, rL;
-        swe_sqrt_rsqrt(len2, L, rL);
-        double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
-        {
-            const double Dna = WD ? swe_wd_depth(h[a] + ena[j], al[a]) : 0.0;
-            const double Dnb = WD ? swe_wd_depth(h[b] + enb[j], al[b]) : 0.0;
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
-                const double uq = swe_dot2(xa, u[a], xb, u[b]), vq = swe_dot2(xa, v[a], xb, v[b]), eq = swe_dot2(xa, e[a], xb, e[b]);
-                const double hq = swe_dot2(xa, h[a], xb, h[b]);
-                const double un = swe_dot2(xa, una[j], xb, unb[j]), vn = swe_dot2(xa, vna[j], xb, vnb[j]),
-                             en = swe_dot2(xa, ena[j], xb, enb[j]);
-                const double eav = 0.5*(eq + en);
-                const double Hav = WD ? 0.5*(swe_dot2(xa, H[a], xb, H[b]) + swe_dot2(xa, Dna, xb, Dnb)) : (NONLIN ? hq + eav : hq);
-                const double c = swe_sqrt(g*Hav);
-                const double du = uq - un, dv = vq - vn;
-                const double dun = swe_dot2(du, nxs, dv, nys);
-                const double spg = fma(c*dun, rL, g*eav);
-                double fu = spg*nxs, fv = spg*nys;
-                const double uav = 0.5*(uq + un), vav = 0.5*(vq + vn);
-                const double uavn = swe_dot2(uav, nxs, vav, nys);
-                const double fe = fma(c*(eq - en), L, Hav*uavn);
-                if (NONLIN) {
-                    const double unown = swe_dot2(uq, nxs, vq, nys);
-                    fu = fma(uav, unown, fu);
-                    fv = fma(vav, unown, fv);
-                    if (LF) {
-                        const double gam = 0.5*fabs(uavn)*p.sigma_lf;
-                        fu = fma(gam, du, fu);
-                        fv = fma(gam, dv, fv);
-                    }
-                }
-                Fau = fma(xa, fu, Fau); Fbu = fma(xb, fu, Fbu);
-                Fav = fma(xa, fv, Fav); Fbv = fma(xb, fv, Fbv);
-                Fae = fma(xa, fe, Fae); Fbe = fma(xb, fe, Fbe);
-                SWE_QUAD2_SCHED_FENCE();
-            }
-        }
-        if (BND && nb[j] < 0) { Fau = 0.0; Fbu = 0.0; Fav = 0.0; Fbv = 0.0; Fae = 0.0; Fbe = 0.0; }
-        bu[a] = fma(-0.5, Fau, bu[a]); bu[b] = fma(-0.5, Fbu, bu[b]);
-        bv[a] = fma(-0.5, Fav, bv[a]); bv[b] = fma(-0.5, Fbv, bv[b]);
-        be[a] = fma(-0.5, Fae, be[a]); be[b] = fma(-0.5, Fbe, be[b]);
-        SWE_QUAD2_SCHED_FENCE();
-    }
-    u[3] = swe_pair(u[1]); v[3] = swe_pair(v[1]); e[3] = swe_pair(e[1]); H[3] = swe_pair(H[1]);
-    // U(0) of the lane's two nodes: asked for here, where the 24 trace registers are free, used after the cell integrals
-    double u0u[2] = {0.0, 0.0}, u0v[2] = {0.0, 0.0}, u0e[2] = {0.0, 0.0};
-    if (HASU0) {
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const unsigned oi = i ? o1 : o0;
-            u0u[i] = swe_ld(swe_rsrc(p.u0), oi, 0);
-            u0v[i] = swe_ld(swe_rsrc(p.u0 + 4*S), oi, 0);
-            u0e[i] = swe_ld(swe_rsrc(p.u0 + 8*S), oi, 0);
-        }
-    }
-
-    SWE_QUAD2_SCHED_FENCE();
-    // ---- the lane's two Gauss points (xi' = xi_0, xi_1; zeta' = xi_0)
-    constexpr int UNROLL_Q = SRC ? 1 : 2;
-#pragma unroll UNROLL_Q
-    for (int qi = 0; qi < 2; qi++) {
-        const double xi = qi ? SWE_XI1 : SWE_XI0, ze = SWE_XI0;
-        const double phi[4] = {(1.0 - xi)*(1.0 - ze), xi*(1.0 - ze), xi*ze, (1.0 - xi)*ze};
-        const double dxi[4] = {-(1.0 - ze), (1.0 - ze), ze, -ze};
-        const double dze[4] = {-(1.0 - xi), -xi, xi, (1.0 - xi)};
-        double gx[4], gy[4];                           // A * grad(phi_i)
-        double uq = 0.0, vq = 0.0, eq = 0.0, Hq = 0.0, D = 0.0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            gx[i] = swe_dot2(dxi[i], xix, dze[i], zex);
-            gy[i] = swe_dot2(dxi[i], xiy, dze[i], zey);
-            uq = fma(phi[i], u[i], uq);
-            vq = fma(phi[i], v[i], vq);
-            eq = fma(phi[i], e[i], eq);
-            Hq = fma(phi[i], H[i], Hq);
-            D = fma(gy[i], v[i], fma(gx[i], u[i], D));  // A * div(u)
-        }
-        double cu = 0.0, cv_ = 0.0, ce = 0.0;          // coefficients of phi_i (times A)
-        if (SRC) {
-            const unsigned on[4] = {o0, o1, o2, o3};
-            double corq = 0.0, gpx = 0.0, gpy = 0.0, sx = 0.0, sy = 0.0, sv = 0.0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (p.coriolis) corq += phi[i]*swe_ld(swe_rsrc(p.coriolis), on[i], 0);
-                if (p.patm) {
-                    const double pa = swe_ld(swe_rsrc(p.patm), on[i], 0);
-                    gpx += gx[i]*pa;
-                    gpy += gy[i]*pa;
-                }
-                if (p.msrc) {
-                    sx += phi[i]*swe_ld(swe_rsrc(p.msrc), on[i], 0);
-                    sy += phi[i]*swe_ld(swe_rsrc(p.msrc + 4*S), on[i], 0);
-                }
-                if (p.vsrc) sv += phi[i]*swe_ld(swe_rsrc(p.vsrc), on[i], 0);
-                if (p.wind) {
-                    sx += phi[i]*swe_ld(swe_rsrc(p.wind), on[i], 0)/(Hq*1000.0);
-                    sy += phi[i]*swe_ld(swe_rsrc(p.wind + 4*S), on[i], 0)/(Hq*1000.0);
-                }
-            }
-            double drag = 0.0;
-            if (p.quad_drag >= 0.0 || p.manning >= 0.0 || p.nikuradse >= 0.0 || p.quad_f) {
-                double cq = 0.0;
-                if (p.quad_f) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) cq += phi[i]*swe_ld(swe_rsrc(p.quad_f), on[i], 0);
-                }
-                const int kind = p.quad_f ? p.quad_f_kind : (p.manning >= 0.0 ? 2 : (p.nikuradse >= 0.0 ? 3 : 1));
-                const double coef = p.quad_f ? cq : (kind == 2 ? p.manning : (kind == 3 ? p.nikuradse : p.quad_drag));
-                double cd = coef;
-                if (kind == 2) cd = g*coef*coef*swe_rcbrt(Hq);
-                if (kind == 3) {
-                    const double lg = log(11.036*Hq/coef);
-                    cd = (Hq > coef) ? 0.32/(lg*lg) : 0.0;
-                }
-                drag = cd*swe_sqrt(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother)*swe_rcp(Hq);
-            }
-            if (p.lin_drag_f) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) drag += phi[i]*swe_ld(swe_rsrc(p.lin_drag_f), on[i], 0);
-            } else if (p.linear_drag >= 0.0) drag += p.linear_drag;
-            cu = A*(corq*vq - drag*uq + sx) - gpx*(1.0/1000.0);
-            cv_ = A*(-corq*uq - drag*vq + sy) - gpy*(1.0/1000.0);
-            ce = A*sv;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            double fu = g*eq*gx[i], fv = g*eq*gy[i];                       // shallowwater_eq.py:361
-            if (NONLIN) {                                                  // :478
-                const double adv = fma(vq, gy[i], fma(uq, gx[i], phi[i]*D));
-                fu = fma(adv, uq, fu);
-                fv = fma(adv, vq, fv);
-            }
-            bu[i] = fma(0.25, fma(cu, phi[i], fu), bu[i]);
-            bv[i] = fma(0.25, fma(cv_, phi[i], fv), bv[i]);
-            be[i] = fma(0.25, fma(ce, phi[i], Hq*swe_dot2(gx[i], uq, gy[i], vq)), be[i]);          // :422
-        }
-        SWE_QUAD2_SCHED_FENCE();
-    }
-
-    // ---- boundary facets (BND copy only)
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        if (BND && nb[j] < 0) {
-            const int a = j, b = j + 1;
-            const double nxs = py[b] - py[a], nys = px[a] - px[b];
-            double L, rL;
-            swe_sqrt_rsqrt(swe_dot2(nxs, nxs, nys, nys), L, rL);
-            double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
-            // (per-facet boundary data are addressed by the facet's index in the cell, r0 + j)
-            swe_boundary_facet<NONLIN, LF, WD>(p, -nb[j], k, (int)r0 + j, 0, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
-                                               al[a], al[b], nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
-            bu[a] = fma(-0.5, Fau, bu[a]); bu[b] = fma(-0.5, Fbu, bu[b]);
-            bv[a] = fma(-0.5, Fav, bv[a]); bv[b] = fma(-0.5, Fbv, bv[b]);
-            be[a] = fma(-0.5, Fae, be[a]); be[b] = fma(-0.5, Fbe, be[b]);
-        }
-    }
-
-    // ---- the partner's share: its local entry (i + 2) & 3 is my entry i
-    double tu[4], tv[4], te[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        tu[i] = bu[i] + swe_pair(bu[(i + 2) & 3]);
-        tv[i] = bv[i] + swe_pair(bv[(i + 2) & 3]);
-        te[i] = be[i] + swe_pair(be[(i + 2) & 3]);
-    }
-    // ---- rows 0, 1 of the tensor mass inverse and Shu-Osher combine
-    const double s = p.dt*p.beta*rA;
-    double ou[2], ov[2], oe[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int n1 = (i + 1) & 3, n2 = (i + 2) & 3, n3 = (i + 3) & 3;
-        double wu = p.a1*u[i], wv = p.a1*v[i], we = p.a1*e[i];
-        if (HASU0) {
-            wu = fma(p.a0, u0u[i], wu);
-            wv = fma(p.a0, u0v[i], wv);
-            if (!WD) we = fma(p.a0, u0e[i], we);
-        }
-        if (WD) {           // the continuity equation advances zeta = D - h
-            we = p.a1*(H[i] - h[i]);
-            if (HASU0) we = fma(p.a0, swe_wd_depth(h[i] + u0e[i], al[i]) - h[i], we);
-        }
-        ou[i] = fma(s, fma(4.0, tu[n2], fma(-8.0, tu[n3], fma(-8.0, tu[n1], 16.0*tu[i]))), wu);
-        ov[i] = fma(s, fma(4.0, tv[n2], fma(-8.0, tv[n3], fma(-8.0, tv[n1], 16.0*tv[i]))), wv);
-        oe[i] = fma(s, fma(4.0, te[n2], fma(-8.0, te[n3], fma(-8.0, te[n1], 16.0*te[i]))), we);
-    }
-    if (WD && !(p.a0 == 0.0 && p.a1 == 0.0)) swe_wd_finish_pair(p.g, p.beta*p.dt, h, al, ou, ov, oe, !p.wd_skip_relax);
-    swe_st(swe_rsrc(p.uout), o0, 0, ou[0]); swe_st(swe_rsrc(p.uout), o1, 0, ou[1]);
-    swe_st(swe_rsrc(p.uout + 4*S), o0, 0, ov[0]); swe_st(swe_rsrc(p.uout + 4*S), o1, 0, ov[1]);
-    swe_st(swe_rsrc(p.uout + 8*S), o0, 0, oe[0]); swe_st(swe_rsrc(p.uout + 8*S), o1, 0, oe[1]);
-}
-
-template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD>
-__global__ __launch_bounds__(SWE_BLOCK) SWE_QUAD2_OCCUPANCY void swe_stage_kernel_quad2(const SweStageArgs p)
-{
-#pragma clang fp contract(off)
-#ifdef SWE_NO_XCD_MAP
-    int lb = blockIdx.x;
-#else
-    int lb = swe_logical_block(blockIdx.x, gridDim.x);
-#endif
-    if (p.reverse) {
-        lb = (p.cell_end - p.cell_begin + SWE_QUAD2_CELLS - 1)/SWE_QUAD2_CELLS - 1 - lb;
-        if (lb < 0) return;
-    }
-    const unsigned hh = threadIdx.x & 1u;
-    const int k = p.cell_begin + lb*SWE_QUAD2_CELLS + (int)(threadIdx.x >> 1);
-    if (k >= p.cell_end) return;                      // both lanes of a pair leave together
-    const size_t S = p.stride;
-    const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u, S4 = (unsigned)S*4u, k4 = (unsigned)k*4u;
-    const swe_rsrc_t gu = swe_rsrc(p.uin), gv = swe_rsrc(p.uin + 4*S), ge = swe_rsrc(p.uin + 8*S);
-    // byte offsets of the lane's local nodes inside a group of four planes
-    const unsigned r0 = 2u*hh;                        // local node 0 = node r0 of the cell
-    const unsigned o0 = k8 + r0*S8, o1 = o0 + S8, o2 = k8 + (2u - r0)*S8, o3 = o2 + S8;
-    const unsigned i0 = k4 + r0*S4, i1 = i0 + S4;
-
-    int nb[2], vid[2];
-    nb[0] = swe_ldi(swe_rsrc(p.nbr), i0, 0); nb[1] = swe_ldi(swe_rsrc(p.nbr), i1, 0);
-    vid[0] = swe_ldi(swe_rsrc(p.cv), i0, 0); vid[1] = swe_ldi(swe_rsrc(p.cv), i1, 0);
-    double u[2], v[2], e[2];
-    u[0] = swe_ld(gu, o0, 0); u[1] = swe_ld(gu, o1, 0);
-    v[0] = swe_ld(gv, o0, 0); v[1] = swe_ld(gv, o1, 0);
-    e[0] = swe_ld(ge, o0, 0); e[1] = swe_ld(ge, o1, 0);
-    // one branch per wave (see swe_quad2_rest)
-#ifdef SWE_QUAD2_INTERIOR_ONLY                        // (resource-usage experiments: the interior copy alone)
-    const bool bnd = false;
-#else
-    const bool bnd = __builtin_amdgcn_ballot_w64(nb[0] < 0 || nb[1] < 0) != 0;
-#endif
-    if (__builtin_expect(bnd, 0)) swe_quad2_rest<NONLIN, LF, HASU0, SRC, WD, true>(p, k, r0, S8, o0, o1, o2, o3, nb[0], nb[1], vid[0], vid[1], u[0], u[1], v[0],
-                                                              v[1], e[0], e[1]);
-    else swe_quad2_rest<NONLIN, LF, HASU0, SRC, WD, false>(p, k, r0, S8, o0, o1, o2, o3, nb[0], nb[1], vid[0], vid[1], u[0], u[1], v[0],
-                                                           v[1], e[0], e[1]);
 }
 
 // quad diagnostics: int a*b over a parallelogram = A/36 * a^T K b, K = [[4,2,1,2],[2,4,2,1],[1,2,4,2],[2,1,2,4]]

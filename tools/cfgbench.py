@@ -63,11 +63,32 @@ def quads(rng):
     dev.close()
 
 
+def cfg5(steps=50, profile_only=False):
+    # ---- cfg 5: wetting-drying variant on the Balzano geometry, 500k triangles (+12 B alpha per cell-stage via vertices ~ +6)
+    mesh5 = RectangleMesh(707, 354, 13800.0, 7200.0)
+    n5 = mesh5.num_cells
+    dev = Swe2dDevice(mesh5, mesh5.vertex_xy[:, 0]/2760.0, 0.1)
+    dev.set_wetting_and_drying(0.4)
+    dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+    dev.set_bc(2, {'elev': -0.5})
+    dev.set_state(np.zeros((n5, 3, 2)), np.zeros((n5, 3)))
+    if profile_only:                                      # a few steps for rocprofv3 --pmc
+        dev.advance(steps)
+        dev.synchronize()
+    else:
+        report('cfg5 triangles SWE wetting-drying + Manning + open bc', n5, 684.0 + 18.0, timed(dev, dev.advance, steps))
+    dev.close()
+
+
 def main():
     only = os.environ.get('CFGBENCH_ONLY', '')          # e.g. 'quads' for kernel A/B runs
     rng = np.random.default_rng(1234)
     if only == 'quads':
         return quads(rng)
+    if only == 'cfg5':
+        return cfg5()
+    if only == 'cfg5_profile':
+        return cfg5(12, True)
     # ---- cfg 2 reference point: triangles, SWE only (684 B per cell per step)
     mesh = RectangleMesh(1000, 500, 100e3, 50e3)
     n = mesh.num_cells
@@ -96,16 +117,7 @@ def main():
     report('cfg2 + SIPG viscosity', n, 684.0 + 3*204.0, timed(dev, dev.advance, 50))
     dev.set_viscosity(None)
     dev.close()
-    # ---- cfg 5: wetting-drying variant on the Balzano geometry, 500k triangles (+12 B alpha per cell-stage via vertices ~ +6)
-    mesh5 = RectangleMesh(707, 354, 13800.0, 7200.0)
-    n5 = mesh5.num_cells
-    dev = Swe2dDevice(mesh5, mesh5.vertex_xy[:, 0]/2760.0, 0.1)
-    dev.set_wetting_and_drying(0.4)
-    dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
-    dev.set_bc(2, {'elev': -0.5})
-    dev.set_state(np.zeros((n5, 3, 2)), np.zeros((n5, 3)))
-    report('cfg5 triangles SWE wetting-drying + Manning + open bc', n5, 684.0 + 18.0, timed(dev, dev.advance, 50))
-    dev.close()
+    cfg5()
     quads(rng)
 
 
