@@ -317,7 +317,7 @@ def gpu_coupled_worker(rank, world, port, n_steps, out_dir, axis, case='channel'
     global CASE
     p2p, combined, no_lim, fe = '+p2p' in case, '+combined' in case, '+nolim' in case, '+fe' in case
     case = case.replace('+p2p', '').replace('+combined', '').replace('+nolim', '').replace('+fe', '')
-    case, every, _ = _split_every(case)
+    case, every, overlap = _split_every(case)
     CASE = case
     from thetis_amd.distributed import DistributedSwe2d
     from thetis_amd.partition import strip_owner
@@ -326,7 +326,7 @@ def gpu_coupled_worker(rank, world, port, n_steps, out_dir, axis, case='channel'
     owner = strip_owner(mesh, world, axis=axis)
     solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, n_tracers=1, exchange=('p2p' if p2p else 'host'),
                               exchange_every=every, combined_exchange=combined, use_limiter=not no_lim,
-                              stepper=('ForwardEuler' if fe else 'SSPRK33'))
+                              stepper=('ForwardEuler' if fe else 'SSPRK33'), overlap_stages=overlap)
     solver.set_state_global(uv, eta)
     solver.set_tracer_global(0, tracer_initial(mesh))
     solver.advance(n_steps, use_graph=False)

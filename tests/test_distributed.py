@@ -351,10 +351,13 @@ def test_coupled_cycle_schedule_counts_layers():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('case,n_steps', [('channel+every2', 5), ('channel+combined', 3), ('channel+every2+p2p', 4),
-                                          ('channel+every3+nolim+p2p', 4), ('channel+every2+fe', 5), ('channel+every1+fe+p2p', 3)])
+                                          ('channel+every3+nolim+p2p', 4), ('channel+every2+fe', 5), ('channel+every1+fe+p2p', 3),
+                                          ('channel+every2+overlap3', 7), ('channel+every1+overlap2+combined+p2p', 4),
+                                          ('channel+every3+overlap3+nolim+p2p', 8)])
 def test_two_ranks_coupled_cycles_with_one_exchange_match_single_device(tmp_path, hip_lib, case, n_steps):
     """DistributedSwe2d(n_tracers=1, exchange_every=m | combined_exchange): one exchange of all fields per m coupled steps,
-    host-staged and peer-to-peer, == the single-device coupled stepping, bitwise."""
+    host-staged and peer-to-peer, == the single-device coupled stepping, bitwise.  ``+overlapJ``: the first J shallow water
+    stages of the next cycle run while the tracer's exchange is in flight (overlap_stages on coupled runs)."""
     from thetis_amd.device import Swe2dDevice
     mesh, bath, uv, eta = _case()
     run_workers(gpu_coupled_worker, 2, n_steps, str(tmp_path), axis=0, case=case)

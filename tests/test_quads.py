@@ -1,4 +1,5 @@
-"""DQ-1 on parallelogram quadrilaterals: oracle pins on CPU, HIP parity on GPU (BASELINE cfg 1(ii), demo_2d_tracer mesh)."""
+"""DQ-1 on quadrilaterals (parallelograms: affine kernels; general convex cells: bilinear map, true mass matrix): oracle pins on
+CPU, HIP parity on GPU (BASELINE cfg 1(ii), demo_2d_tracer mesh)."""
 import math
 
 import numpy as np
@@ -39,9 +40,58 @@ def test_quad_mesh_connectivity():
                 f2 = m.cell_nbr_facet[c, f]
                 assert m.cell_nbr[nb, f2] == c
                 assert m.cells[c, f] == m.cells[nb, (f2 + 1) % 4] and m.cells[c, (f + 1) % 4] == m.cells[nb, f2]
-    with pytest.raises(NotImplementedError):
-        from thetis_amd.mesh import Mesh2d
-        Mesh2d(np.array([[0, 0], [1, 0], [1.2, 1.1], [0, 1.0]]), np.array([[0, 1, 2, 3]]))      # not a parallelogram
+    from thetis_amd.mesh import Mesh2d
+    assert m.affine
+    g = Mesh2d(np.array([[0, 0], [1, 0], [1.2, 1.1], [0, 1.0]]), np.array([[0, 1, 2, 3]]))      # not a parallelogram: general kernels
+    assert not g.affine and math.isclose(g.cell_areas()[0], 0.5*(1.2*1.0 + 1.1*1.0 - 0.0))     # shoelace: 1.15
+    with pytest.raises(ValueError):
+        Mesh2d(np.array([[0, 0], [1, 0], [0.2, 0.2], [0, 1.0]]), np.array([[0, 1, 2, 3]]))      # not convex
+
+
+def test_general_quadrilaterals_oracle_invariants():
+    """The numpy oracle on warped (non-affine) cells - what the HIP kernels are compared with under -m gpu: lake at rest, closed
+    domain conserves volume, 2 x 2 and 3 x 3 Gauss rules agree on the polynomial integrands (the mass matrix: det J is linear),
+    a constant tracer stays constant, the mass-weighted cell mean is the P0 projection, the limiter conserves the tracer integral,
+    and the closed form of the mass matrix the kernels use (swe_quad_mass) equals the quadrature."""
+    mesh, bath, uv, eta = quad_case(skew=0.2, warp=0.3)
+    assert not mesh.affine
+    orc = make_oracle_generic(mesh, bath)
+    assert not orc.affine and np.allclose(orc.mean_w.sum(axis=1), 1.0) and np.abs(orc.mean_w - 0.25).max() > 1e-3
+    ru, re = orc.residual(np.zeros_like(uv), np.full_like(eta, 0.3))
+    assert np.abs(ru).max() < 1e-8 and np.abs(re).max() == 0.0
+    ru, re = orc.residual(uv, eta)
+    assert abs(re.sum()) < 1e-12*np.abs(re).sum()
+    from oracle.swe2d_oracle import SWEOracle
+    o3 = SWEOracle(mesh.vertex_xy, mesh.cells, bath, quad_rule_points=3)
+    assert rel_linf(o3.mass_matrix(), orc.mass_matrix()) < 1e-13
+    ru3, re3 = o3.residual(uv, eta)
+    # (on a warped cell adj(J) is linear in (xi, zeta): the integrands H u . adj(J)^T grad_ref(phi) have degree 4 per direction,
+    #  beyond the 2-point rule - the two rules agree to discretisation accuracy only; on parallelograms they are equal)
+    assert rel_linf(re3, re) < 5e-2
+    T = np.full((mesh.num_cells, 4), 4.5)
+    assert np.abs(orc.tracer_residual(T, uv, eta)).max() < 1e-9
+    u1, e1 = orc.ssprk33_step(uv, eta, 2.0)
+    assert abs(orc.volume(e1) - orc.volume(eta))/orc.volume(eta) < 1e-13
+    # closed form of the mass matrix
+    p = mesh.cell_xy()
+    a, b, c = p[:, 1] - p[:, 0], p[:, 3] - p[:, 0], p[:, 0] - p[:, 1] + p[:, 2] - p[:, 3]
+    cr = lambda u, v: u[:, 0]*v[:, 1] - u[:, 1]*v[:, 0]
+    d0, d1, d2 = cr(a, b), cr(a, c), cr(c, b)
+    m_, m1 = np.array([[1/3, 1/6], [1/6, 1/3]]), np.array([[1/12, 1/12], [1/12, 1/4]])
+    ia, ib = [0, 1, 1, 0], [0, 0, 1, 1]
+    M = np.zeros((mesh.num_cells, 4, 4))
+    for i in range(4):
+        for j in range(4):
+            M[:, i, j] = (d0*m_[ia[i], ia[j]]*m_[ib[i], ib[j]] + d1*m1[ia[i], ia[j]]*m_[ib[i], ib[j]]
+                          + d2*m_[ia[i], ia[j]]*m1[ib[i], ib[j]])
+    assert rel_linf(M, orc.mass_matrix()) < 1e-14
+    assert np.allclose(d0 + 0.5*(d1 + d2), mesh.cell_areas(), rtol=1e-14)
+    # limiter: P0 projection with the mass weights, tracer integral conserved
+    rng = np.random.default_rng(5)
+    T = rng.normal(size=(mesh.num_cells, 4))
+    Tl = orc.limit(T)
+    integral = lambda q: float((mesh.cell_areas()*(orc.mean_w*q).sum(axis=1)).sum())
+    assert abs(integral(Tl) - integral(T)) < 1e-12*abs(mesh.cell_areas().sum())
 
 
 def test_quad_oracle_invariants():
@@ -103,10 +153,14 @@ def test_quad_standing_wave_second_order(ref_so):
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', ['default', 'linear', 'no_lf', 'sources', 'manning', 'quad_drag', 'drag_fields',
                                   'nikuradse_field', 'bcs', 'wind_bdrag'])
-def test_quad_gpu_tendency_matches_oracle(hip_lib, case):
+@pytest.mark.parametrize('geometry', ['parallelograms', 'general'])
+def test_quad_gpu_tendency_matches_oracle(hip_lib, case, geometry):
+    """``general``: warped convex cells (bilinear map with a varying Jacobian, 4 x 4 mass solve per cell: the AFFINE = false
+    kernels; thetis/solver2d.py:340-345 accepts any quadrilateral mesh)."""
     from thetis_amd import _lib
     from thetis_amd.device import Swe2dDevice
-    mesh, bath, uv, eta = quad_case(skew=0.3, seed=1)
+    mesh, bath, uv, eta = quad_case(skew=0.3, seed=1, warp=(0.3 if geometry == 'general' else 0.0))
+    assert mesh.affine == (geometry == 'parallelograms')
     kw = _cases(mesh, mesh.num_cells)[case]
     if case in ('manning', 'quad_drag', 'wind_bdrag', 'drag_fields', 'nikuradse_field'):
         eta = np.abs(eta)
@@ -201,9 +255,10 @@ def test_quad_two_ranks_on_one_gpu(tmp_path, hip_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', ['default', 'lf', 'value_bc'])
-def test_quad_tracer_and_limiter_match_oracle(hip_lib, case):
+@pytest.mark.parametrize('geometry', ['parallelograms', 'general'])
+def test_quad_tracer_and_limiter_match_oracle(hip_lib, case, geometry):
     from thetis_amd.device import Swe2dDevice
-    mesh, bath, uv, eta = quad_case(skew=0.3, seed=2)
+    mesh, bath, uv, eta = quad_case(skew=0.3, seed=2, warp=(0.3 if geometry == 'general' else 0.0))
     rng = np.random.default_rng(3)
     T = rng.normal(size=(mesh.num_cells, 4))
     src = 1e-3*rng.normal(size=T.shape)
@@ -235,6 +290,41 @@ def test_quad_tracer_and_limiter_match_oracle(hip_lib, case):
     dev.tracer_set_state(tid, T)
     dev.tracer_limit(tid)
     assert rel_linf(dev.tracer_get_state(tid), orc.limit(T)) < 1e-14
+    dev.close()
+
+
+@pytest.mark.gpu
+def test_general_quadrilaterals_coupled_steps_and_refusals(hip_lib):
+    """Warped cells through the coupled step (shallow water, tracer with the updated velocity, limiter from the means the last
+    tracer stage writes): five steps against the numpy oracle, volume and tracer integral conserved; wetting-drying, viscosity and
+    diffusion are refused on such a mesh (the SIPG kernels and the positivity limiter assume a constant Jacobian)."""
+    from thetis_amd import _lib
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, uv, eta = quad_case(nx=12, ny=8, skew=0.1, seed=4, warp=0.35, amp_eta=0.2, amp_u=0.2)
+    assert not mesh.affine
+    rng = np.random.default_rng(8)
+    T = 1.0 + 0.5*rng.normal(size=(mesh.num_cells, 4))
+    dt = 2.0
+    orc = make_oracle_generic(mesh, bath)
+    dev = Swe2dDevice(mesh, bath, dt, boundary_len=mesh.boundary_len)
+    tid = dev.add_tracer()
+    dev.set_state(uv, eta)
+    dev.tracer_set_state(tid, T)
+    v0, m0 = dev.diagnostics()[2], dev.tracer_diagnostics(tid)[0]
+    dev.advance_coupled(5, tracer_only=False, use_limiter=True)
+    u_o, e_o, T_o = uv, eta, T
+    for _ in range(5):
+        u_o, e_o = orc.ssprk33_step(u_o, e_o, dt)
+        T_o = orc.limit(orc.tracer_ssprk33_step(T_o, u_o, e_o, dt))
+    u_d, e_d = dev.get_state()
+    assert rel_linf(u_d, u_o) < 1e-11 and rel_linf(e_d, e_o) < 1e-11
+    assert rel_linf(dev.tracer_get_state(tid), T_o) < 1e-10
+    assert math.isclose(dev.diagnostics()[2], v0, rel_tol=1e-13)
+    assert math.isclose(dev.tracer_diagnostics(tid)[0], orc.tracer_mass(T_o, e_o), rel_tol=1e-10)
+    for call in (lambda: dev.set_wetting_and_drying(0.5), lambda: dev.set_viscosity(10.0),
+                 lambda: dev.tracer_set_diffusivity(tid, 5.0)):
+        with pytest.raises(_lib.Swe2dError, match='parallelogram'):
+            call()
     dev.close()
 
 

@@ -95,7 +95,8 @@ struct Handle {
     bool own_stream = false;
     hipStream_t my_stream = nullptr;
     int n_cells = 0, n_owned = 0, n_interior = 0, n_vertices = 0;
-    int npc = 3;                                       // nodes per cell: 3 triangles, 4 parallelograms
+    int npc = 3;                                       // nodes per cell: 3 triangles, 4 quadrilaterals
+    bool affine = true;                                // quadrilaterals: every cell a parallelogram (constant Jacobian, tensor mass inverse)
     size_t stride = 0;
     double *state[3] = {nullptr, nullptr, nullptr};   // A (U0 / step result), B (U1), C (U2)
     int *nbr = nullptr, *cv = nullptr;
@@ -301,17 +302,18 @@ stage_kernel_t pick_kernel_visc(bool nl, bool lf, bool u0, bool src)
 }
 
 template <bool NL, bool LF, bool U0>
-stage_kernel_t pickq_src(bool src)
+stage_kernel_t pickq_src(bool src, bool affine)
 {
+    if (!affine) return src ? swe_stage_kernel_quad<NL, LF, U0, true, false, false> : swe_stage_kernel_quad<NL, LF, U0, false, false, false>;
     return src ? swe_stage_kernel_quad<NL, LF, U0, true, false> : swe_stage_kernel_quad<NL, LF, U0, false, false>;
 }
 template <bool NL, bool LF>
-stage_kernel_t pickq_u0(bool u0, bool src) { return u0 ? pickq_src<NL, LF, true>(src) : pickq_src<NL, LF, false>(src); }
+stage_kernel_t pickq_u0(bool u0, bool src, bool affine) { return u0 ? pickq_src<NL, LF, true>(src, affine) : pickq_src<NL, LF, false>(src, affine); }
 template <bool NL>
-stage_kernel_t pickq_lf(bool lf, bool u0, bool src) { return lf ? pickq_u0<NL, true>(u0, src) : pickq_u0<NL, false>(u0, src); }
-stage_kernel_t pick_kernel_quad(bool nl, bool lf, bool u0, bool src)
+stage_kernel_t pickq_lf(bool lf, bool u0, bool src, bool affine) { return lf ? pickq_u0<NL, true>(u0, src, affine) : pickq_u0<NL, false>(u0, src, affine); }
+stage_kernel_t pick_kernel_quad(bool nl, bool lf, bool u0, bool src, bool affine)
 {
-    return nl ? pickq_lf<true>(lf, u0, src) : pickq_lf<false>(lf, u0, src);
+    return nl ? pickq_lf<true>(lf, u0, src, affine) : pickq_lf<false>(lf, u0, src, affine);
 }
 
 void fill_stage_args(Handle *h, SweStageArgs &a, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1)
@@ -383,7 +385,7 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
         ? pick_kernel_visc(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
         : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4, binl)
         : (h->npc == 4)
-        ? pick_kernel_quad(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
+        ? pick_kernel_quad(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->affine)
         : pick_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), binl ? (ldsx ? 2 : 1) : 0);
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
     // the XCD-chunked block map needs a grid that is a multiple of 8; surplus blocks exit immediately
@@ -754,7 +756,7 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
     if (!mesh || !params || !out) return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (mesh->nodes_per_cell != 3 && mesh->nodes_per_cell != 4)
-        return fail(nullptr, SWE2D_ERR_UNSUPPORTED, "nodes_per_cell must be 3 (triangles) or 4 (parallelograms)");
+        return fail(nullptr, SWE2D_ERR_UNSUPPORTED, "nodes_per_cell must be 3 (triangles) or 4 (quadrilaterals)");
     if (mesh->n_cells <= 0 || mesh->n_owned <= 0 || mesh->n_owned > mesh->n_cells || mesh->n_vertices <= 0)
         return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "bad mesh sizes");
     if (mesh->n_cells >= (1 << 29))
@@ -867,11 +869,18 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
             return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "cells must be counter-clockwise with positive area");
         }
         if (npc == 4) {
+            // a cell that is not a parallelogram selects the general bilinear kernels for the whole mesh (swe_quad_mass); it must
+            // be convex: det J = d0 + d1 xi + d2 zeta > 0 at the four corners
             const int d = mesh->cell_vertices[4*(size_t)k + 2];
             const double sx = vx[a] - vx[b] + vx[d] - vx[c], sy = vy[a] - vy[b] + vy[d] - vy[c];
             if (std::fabs(sx) + std::fabs(sy) > 1e-9*std::sqrt(area2)) {
-                swe2d_destroy(reinterpret_cast<swe2d_handle *>(h));
-                return fail(nullptr, SWE2D_ERR_UNSUPPORTED, "quadrilateral cells must be parallelograms");
+                h->affine = false;
+                const double ax = vx[b] - vx[a], ay = vy[b] - vy[a], bx = vx[c] - vx[a], by = vy[c] - vy[a];
+                const double d1 = ax*sy - ay*sx, d2 = sx*by - sy*bx;
+                if (!(area2 + d1 > 0.0 && area2 + d2 > 0.0 && area2 + d1 + d2 > 0.0)) {
+                    swe2d_destroy(reinterpret_cast<swe2d_handle *>(h));
+                    return fail(nullptr, SWE2D_ERR_INVALID_ARGUMENT, "quadrilateral cells must be convex");
+                }
             }
         }
     }
@@ -1231,6 +1240,7 @@ int swe2d_set_wetting_and_drying(swe2d_handle *hh, int enable, const double *alp
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
     if (!enable) { h->wd = false; return SWE2D_OK; }
+    if (!h->affine) return fail(h, SWE2D_ERR_UNSUPPORTED, "wetting and drying"" is implemented for parallelogram quadrilaterals only (general quadrilaterals: shallow water, sources, boundary conditions, tracers, limiter)");
     if (!alpha_vertex) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "alpha_vertex is required");
     if (!h->par.use_nonlinear_equations)
         return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "wetting and drying needs use_nonlinear_equations");
@@ -1266,6 +1276,7 @@ int swe2d_set_viscosity(swe2d_handle *hh, int enable, const double *nu_vertex, d
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
     if (!enable) { h->visc = false; return SWE2D_OK; }
+    if (!h->affine) return fail(h, SWE2D_ERR_UNSUPPORTED, "horizontal viscosity"" is implemented for parallelogram quadrilaterals only (general quadrilaterals: shallow water, sources, boundary conditions, tracers, limiter)");
     if (!nu_vertex && !(nu_const >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "viscosity must be >= 0");
     if (!(sipg_factor > 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "sipg_factor must be > 0");
     int rc = upload_vertex_coefficient(h, nu_vertex, &h->nu_v);
@@ -1538,7 +1549,7 @@ int swe2d_diagnostics(swe2d_handle *hh, double out[4])
     if (h->npc == 4)
         hipLaunchKernelGGL(swe_diag_kernel_quad, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
                            h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial,
-                           h->wd ? h->valpha : nullptr);
+                           h->wd ? h->valpha : nullptr, h->affine ? 1 : 0);
     else
         hipLaunchKernelGGL(swe_diag_kernel, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
                            h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial,
@@ -1626,8 +1637,17 @@ namespace {
 
 typedef void (*tracer_kernel_t)(const SweTracerArgs);
 
-tracer_kernel_t pick_tracer_kernel_quad(bool lf, bool t0, bool src)
+template <bool LF, bool T0>
+tracer_kernel_t pick_tracer_kernel_quad_general(bool src)
 {
+    return src ? swe_tracer_stage_kernel_quad<LF, T0, true, false> : swe_tracer_stage_kernel_quad<LF, T0, false, false>;
+}
+tracer_kernel_t pick_tracer_kernel_quad(bool lf, bool t0, bool src, bool affine = true)
+{
+    if (!affine) {
+        if (lf) return t0 ? pick_tracer_kernel_quad_general<true, true>(src) : pick_tracer_kernel_quad_general<true, false>(src);
+        return t0 ? pick_tracer_kernel_quad_general<false, true>(src) : pick_tracer_kernel_quad_general<false, false>(src);
+    }
     if (lf) {
         if (t0) return src ? swe_tracer_stage_kernel_quad<true, true, true> : swe_tracer_stage_kernel_quad<true, true, false>;
         return src ? swe_tracer_stage_kernel_quad<true, false, true> : swe_tracer_stage_kernel_quad<true, false, false>;
@@ -1689,7 +1709,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     a.opp4 = h->opp4;
     a.mu_v = t.mu_v; a.mu_const = t.mu_const;
     a.diff_sipg = 3.0*t.sipg_factor;
-    tracer_kernel_t kern = (h->npc == 4) ? pick_tracer_kernel_quad(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr)
+    tracer_kernel_t kern = (h->npc == 4) ? pick_tracer_kernel_quad(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr, h->affine)
         : fused_diff ? pick_tracer_kernel_diff(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr)
                      : pick_tracer_kernel(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr);
     const int nblocks = (c1 - c0 + SWE_BLOCK - 1)/SWE_BLOCK;
@@ -1807,13 +1827,14 @@ int limiter_apply(Handle *h, int id, int cell_end, bool means_done = false)
     double *t = h->tracers[id].buf[0];
     const int n = h->n_cells, nv = h->lim_nv;
     if (!means_done)       // swe2d_advance_coupled has the last tracer stage write the means
-        hipLaunchKernelGGL(swe_limiter_cell_mean, dim3(grid_for(n)), dim3(256), 0, h->stream, t, h->stride, n, h->lim_mean, h->npc);
+        hipLaunchKernelGGL(swe_limiter_cell_mean, dim3(grid_for(n)), dim3(256), 0, h->stream, t, h->stride, n, h->lim_mean, h->npc,
+                           h->affine ? nullptr : h->cv, h->vx, h->vy);
     hipLaunchKernelGGL(swe_limiter_vertex_bounds, dim3(grid_for(nv)), dim3(256), 0, h->stream, h->lim_v2c_off,
                        h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_mean, t, h->stride, nv, h->lim_qmin,
                        h->lim_qmax, h->npc);
     if (cell_end > 0)
         hipLaunchKernelGGL(swe_limiter_apply, dim3(grid_for(cell_end)), dim3(256), 0, h->stream, t, h->stride, cell_end,
-                           h->lim_tv, h->lim_qmin, h->lim_qmax, h->npc);
+                           h->lim_tv, h->lim_qmin, h->lim_qmax, h->npc, h->affine ? nullptr : h->lim_mean);
     HIP_TRY(h, hipGetLastError());
     return SWE2D_OK;
 }
@@ -2040,6 +2061,7 @@ int swe2d_tracer_set_diffusivity(swe2d_handle *hh, int id, int enable, const dou
     if (rc) return rc;
     Handle::Tracer &t = h->tracers[id];
     if (!enable) { t.diff = false; return SWE2D_OK; }
+    if (!h->affine) return fail(h, SWE2D_ERR_UNSUPPORTED, "horizontal diffusion"" is implemented for parallelogram quadrilaterals only (general quadrilaterals: shallow water, sources, boundary conditions, tracers, limiter)");
     if (!mu_vertex && !(mu_const >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "diffusivity must be >= 0");
     if (!(sipg_factor_tracer > 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "sipg_factor_tracer must be > 0");
     rc = upload_vertex_coefficient(h, mu_vertex, &t.mu_v);
@@ -2164,7 +2186,7 @@ int swe2d_tracer_diagnostics(swe2d_handle *hh, int id, double out[4])
     if (h->npc == 4)
         hipLaunchKernelGGL(swe_tracer_diag_kernel_quad, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
                            h->tracers[id].buf[0], h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh,
-                           h->par.use_nonlinear_equations, h->n_owned, h->partial, h->wd ? h->valpha : nullptr);
+                           h->par.use_nonlinear_equations, h->n_owned, h->partial, h->wd ? h->valpha : nullptr, h->affine ? 1 : 0);
     else
         hipLaunchKernelGGL(swe_tracer_diag_kernel, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
                            h->tracers[id].buf[0], h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh,

@@ -1663,10 +1663,24 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
 }
 
 // ---- limiter, step 1: cell means (P0 projection of an affine P1 / Q1 field = mean of the nodal values)
-__global__ void swe_limiter_cell_mean(const double *t, size_t stride, int n, double *mean, int npc)
+// (general quadrilaterals, cv != nullptr: the P0 projection is the mass-weighted mean, see swe_quad_mean_weights below)
+__device__ __forceinline__ void swe_quad_mean_weights(double d0, double d1, double d2, double w[4]);
+__global__ void swe_limiter_cell_mean(const double *t, size_t stride, int n, double *mean, int npc, const int *cv,
+                                      const double *vx, const double *vy)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
+    if (cv) {
+        double px[4], py[4], w[4];
+        for (int i = 0; i < 4; i++) { const int v = cv[(size_t)i*stride + k]; px[i] = vx[v]; py[i] = vy[v]; }
+        const double ax = px[1] - px[0], ay = py[1] - py[0], bx = px[3] - px[0], by = py[3] - py[0];
+        const double cx = (px[0] - px[1]) + (px[2] - px[3]), cy = (py[0] - py[1]) + (py[2] - py[3]);
+        swe_quad_mean_weights(ax*by - ay*bx, ax*cy - ay*cx, cx*by - cy*bx, w);
+        double s = 0.0;
+        for (int i = 0; i < 4; i++) s += w[i]*t[(size_t)i*stride + k];
+        mean[k] = s;
+        return;
+    }
     double s = 0.0;
     for (int i = 0; i < npc; i++) s += t[(size_t)i*stride + k];
     mean[k] = s/(double)npc;
@@ -1698,8 +1712,9 @@ __global__ void swe_limiter_vertex_bounds(const int *v2c_off, const int *v2c_cel
 }
 
 // ---- limiter, step 3: per-cell scaling towards the mean
+// (``mean_in`` != nullptr, general quadrilaterals: the mass-weighted means of step 1 instead of the nodal average)
 __global__ void swe_limiter_apply(double *t, size_t stride, int n, const int *tv, const double *qmin, const double *qmax,
-                                  int npc)
+                                  int npc, const double *mean_in)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -1711,7 +1726,7 @@ __global__ void swe_limiter_apply(double *t, size_t stride, int n, const int *tv
         vv[i] = tv[(size_t)i*stride + k];
         s += c[i];
     }
-    const double mean = s/(double)npc;
+    const double mean = mean_in ? mean_in[k] : s/(double)npc;
     double alpha = 1.0;
     for (int i = 0; i < npc; i++) {
         if (c[i] > mean) alpha = fmin(alpha, fmin(1.0, (qmax[vv[i]] - mean)/(c[i] - mean)));
@@ -1795,7 +1810,74 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_calibration_copy(const double *
 // although no wave of the timed mesh interior ever touches the scratch.  profiles/r03j_quad_two_lanes.txt; the kernel is in the
 // history (commit "Experiment: quadrilateral stage kernel with a cell split over two lanes").
 // ===============================================================================================================
-template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD>
+// ---- general (non-affine) quadrilaterals: bilinear map x = p0 + xi a + zeta b + xi zeta c,  a = p1 - p0,  b = p3 - p0,
+// c = p0 - p1 + p2 - p3 (zero on a parallelogram).  Jacobian columns x_xi = a + zeta c, x_zeta = b + xi c;
+//   det J = d0 + d1 xi + d2 zeta,  d0 = a x b,  d1 = a x c,  d2 = c x b      (c x c = 0: the determinant is LINEAR);
+//   det J * grad(phi) = adj(J)^T grad_ref(phi): the kernels' "A * grad" terms need no division, only x_xi, x_zeta at the point.
+// Mass matrix M_ij = int det J phi_i phi_j = d0 (m (x) m) + d1 (m1 (x) m) + d2 (m (x) m1) with the 1D matrices m = [[1/3, 1/6],
+// [1/6, 1/3]] and m1 = int t N_a N_b = [[1/12, 1/12], [1/12, 1/4]] - closed form, equal to what the 2 x 2 Gauss rule of the
+// oracle (oracle/swe2d_oracle.py: mass_matrix) gives, which is exact for this integrand.  Node i = (xi index, zeta index):
+// 0 = (0,0), 1 = (1,0), 2 = (1,1), 3 = (0,1).  The 4 x 4 solve is an LDL^T factorisation in registers (M is SPD with a
+// condition number of ~9).  Reference: thetis/solver2d.py:340-345 accepts any quadrilateral mesh (DQ-1 with the true mass matrix).
+struct SweQuadMass { double m[10]; };          // upper triangle, row-major: 00 01 02 03 11 12 13 22 23 33
+__device__ __forceinline__ void swe_quad_mass(double d0, double d1, double d2, SweQuadMass &M)
+{
+#pragma clang fp contract(off)
+    // 1D entries: m[a][b], m1[a][b]
+    const double m_[2][2] = {{1.0/3.0, 1.0/6.0}, {1.0/6.0, 1.0/3.0}};
+    const double m1[2][2] = {{1.0/12.0, 1.0/12.0}, {1.0/12.0, 1.0/4.0}};
+    const int ia[4] = {0, 1, 1, 0}, ib[4] = {0, 0, 1, 1};
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = i; j < 4; j++) {
+            const double c0 = m_[ia[i]][ia[j]]*m_[ib[i]][ib[j]], c1 = m1[ia[i]][ia[j]]*m_[ib[i]][ib[j]],
+                         c2 = m_[ia[i]][ia[j]]*m1[ib[i]][ib[j]];
+            M.m[q++] = fma(d2, c2, fma(d1, c1, d0*c0));
+        }
+}
+// row sums of M = int det J phi_i (the weights of the P0 projection / cell mean), divided by the cell area
+__device__ __forceinline__ void swe_quad_mean_weights(double d0, double d1, double d2, double w[4])
+{
+#pragma clang fp contract(off)
+    const double rA = swe_rcp(d0 + 0.5*(d1 + d2));
+    w[0] = (0.25*d0 + (1.0/12.0)*d1 + (1.0/12.0)*d2)*rA;
+    w[1] = (0.25*d0 + (1.0/6.0)*d1 + (1.0/12.0)*d2)*rA;
+    w[2] = (0.25*d0 + (1.0/6.0)*d1 + (1.0/6.0)*d2)*rA;
+    w[3] = (0.25*d0 + (1.0/12.0)*d1 + (1.0/6.0)*d2)*rA;
+}
+struct SweQuadLDL { double l10, l20, l30, l21, l31, l32, r0, r1, r2, r3; };
+__device__ __forceinline__ void swe_quad_mass_factor(const SweQuadMass &M, SweQuadLDL &F)
+{
+#pragma clang fp contract(off)
+    const double *m = M.m;               // 0:00 1:01 2:02 3:03 4:11 5:12 6:13 7:22 8:23 9:33
+    F.r0 = swe_rcp(m[0]);
+    F.l10 = m[1]*F.r0; F.l20 = m[2]*F.r0; F.l30 = m[3]*F.r0;
+    F.r1 = swe_rcp(m[4] - F.l10*m[1]);
+    const double t21 = m[5] - F.l20*m[1], t31 = m[6] - F.l30*m[1];
+    F.l21 = t21*F.r1; F.l31 = t31*F.r1;
+    F.r2 = swe_rcp(m[7] - F.l20*m[2] - F.l21*t21);
+    const double t32 = m[8] - F.l30*m[2] - F.l31*t21;
+    F.l32 = t32*F.r2;
+    F.r3 = swe_rcp(m[9] - F.l30*m[3] - F.l31*t31 - F.l32*t32);
+}
+__device__ __forceinline__ void swe_quad_mass_solve(const SweQuadLDL &F, double b[4])      // b <- M^-1 b
+{
+#pragma clang fp contract(off)
+    const double y0 = b[0];
+    const double y1 = b[1] - F.l10*y0;
+    const double y2 = b[2] - F.l20*y0 - F.l21*y1;
+    const double y3 = b[3] - F.l30*y0 - F.l31*y1 - F.l32*y2;
+    const double x3 = y3*F.r3;
+    const double x2 = y2*F.r2 - F.l32*x3;
+    const double x1 = y1*F.r1 - F.l21*x2 - F.l31*x3;
+    const double x0 = y0*F.r0 - F.l10*x1 - F.l20*x2 - F.l30*x3;
+    b[0] = x0; b[1] = x1; b[2] = x2; b[3] = x3;
+}
+
+// AFFINE = false: general quadrilaterals (see above); not with wetting-drying (the positivity limiter's cell mean) - the host refuses
+template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD, bool AFFINE = true>
 __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStageArgs p)
 {
     // no implicit contraction (see swe_stage_kernel)
@@ -1883,10 +1965,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
     }
     const double ax = px[1] - px[0], ay = py[1] - py[0];
     const double bx = px[3] - px[0], by = py[3] - py[0];
-    const double A = fma(ax, by, -(ay*bx));
+    const double A = fma(ax, by, -(ay*bx));                      // AFFINE: the cell area; else d0 = det J at (0, 0)
     const double rA = swe_rcp(A);
     // A * grad(xi), A * grad(zeta)
     const double xix = by, xiy = -bx, zex = -ay, zey = ax;
+    // general quadrilateral: c = p0 - p1 + p2 - p3, det J = A + d1 xi + d2 zeta
+    const double cx = AFFINE ? 0.0 : (px[0] - px[1]) + (px[2] - px[3]), cy = AFFINE ? 0.0 : (py[0] - py[1]) + (py[2] - py[3]);
+    const double d1 = AFFINE ? 0.0 : fma(ax, cy, -(ay*cx)), d2 = AFFINE ? 0.0 : fma(cx, by, -(cy*bx));
 
     double bu[4] = {0.0, 0.0, 0.0, 0.0}, bv[4] = {0.0, 0.0, 0.0, 0.0}, be[4] = {0.0, 0.0, 0.0, 0.0};
     // ---- facets first: the 24 neighbour traces (48 VGPRs) are dead before the cell quadrature starts
@@ -1957,12 +2042,16 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
             const double phi[4] = {(1.0 - xi)*(1.0 - ze), xi*(1.0 - ze), xi*ze, (1.0 - xi)*ze};
             const double dxi[4] = {-(1.0 - ze), (1.0 - ze), ze, -ze};
             const double dze[4] = {-(1.0 - xi), -xi, xi, (1.0 - xi)};
-            double gx[4], gy[4];                           // A * grad(phi_i)
+            double gx[4], gy[4];                           // A * grad(phi_i)  (general cell: det J * grad(phi_i) at the point)
             double uq = 0.0, vq = 0.0, eq = 0.0, Hq = 0.0, D = 0.0;
+            // adj(J)^T at the point: x_zeta = b + xi c, x_xi = a + zeta c
+            const double xix_q = AFFINE ? xix : fma(cy, xi, by), xiy_q = AFFINE ? xiy : -fma(cx, xi, bx);
+            const double zex_q = AFFINE ? zex : -fma(cy, ze, ay), zey_q = AFFINE ? zey : fma(cx, ze, ax);
+            const double Aq = AFFINE ? A : fma(d2, ze, fma(d1, xi, A));          // det J at the point
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                gx[i] = swe_dot2(dxi[i], xix, dze[i], zex);
-                gy[i] = swe_dot2(dxi[i], xiy, dze[i], zey);
+                gx[i] = swe_dot2(dxi[i], xix_q, dze[i], zex_q);
+                gy[i] = swe_dot2(dxi[i], xiy_q, dze[i], zey_q);
                 uq = fma(phi[i], u[i], uq);
                 vq = fma(phi[i], v[i], vq);
                 eq = fma(phi[i], e[i], eq);
@@ -2011,9 +2100,9 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
 #pragma unroll
                     for (int i = 0; i < 4; i++) drag += phi[i]*swe_ld(swe_rsrc(p.lin_drag_f), k8, i*S8);
                 } else if (p.linear_drag >= 0.0) drag += p.linear_drag;
-                cu = A*(corq*vq - drag*uq + sx) - gpx*(1.0/1000.0);
-                cv_ = A*(-corq*uq - drag*vq + sy) - gpy*(1.0/1000.0);
-                ce = A*sv;
+                cu = Aq*(corq*vq - drag*uq + sx) - gpx*(1.0/1000.0);
+                cv_ = Aq*(-corq*uq - drag*vq + sy) - gpy*(1.0/1000.0);
+                ce = Aq*sv;
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -2031,14 +2120,31 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
     }
 
     // ---- tensor mass inverse and Shu-Osher combine
-    const double s = p.dt*p.beta*rA;
     double ou[4], ov[4], oe[4];
+    if constexpr (AFFINE) {
+    const double s = p.dt*p.beta*rA;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int n1 = (i + 1) & 3, n2 = (i + 2) & 3, n3 = (i + 3) & 3;
         ou[i] = fma(s, fma(4.0, bu[n2], fma(-8.0, bu[n3], fma(-8.0, bu[n1], 16.0*bu[i]))), wu[i]);
         ov[i] = fma(s, fma(4.0, bv[n2], fma(-8.0, bv[n3], fma(-8.0, bv[n1], 16.0*bv[i]))), wv[i]);
         oe[i] = fma(s, fma(4.0, be[n2], fma(-8.0, be[n3], fma(-8.0, be[n1], 16.0*be[i]))), we[i]);
+    }
+    } else {
+    SweQuadMass M;
+    SweQuadLDL F;
+    swe_quad_mass(A, d1, d2, M);
+    swe_quad_mass_factor(M, F);
+    swe_quad_mass_solve(F, bu);
+    swe_quad_mass_solve(F, bv);
+    swe_quad_mass_solve(F, be);
+    const double s = p.dt*p.beta;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        ou[i] = fma(s, bu[i], wu[i]);
+        ov[i] = fma(s, bv[i], wv[i]);
+        oe[i] = fma(s, be[i], we[i]);
+    }
     }
     if (WD && !(p.a0 == 0.0 && p.a1 == 0.0)) swe_wd_finish<4>(p.g, p.beta*p.dt, h, al, ou, ov, oe, !p.wd_skip_relax);
 #pragma unroll
@@ -2059,9 +2165,18 @@ __device__ __forceinline__ double swe_int2_quad(const double a[4], const double 
     return s;
 }
 
+// a^T M b for the general quadrilateral mass matrix
+__device__ __forceinline__ double swe_quad_form(const SweQuadMass &M, const double a[4], const double b[4])
+{
+    const double *m = M.m;               // 0:00 1:01 2:02 3:03 4:11 5:12 6:13 7:22 8:23 9:33
+    return m[0]*a[0]*b[0] + m[4]*a[1]*b[1] + m[7]*a[2]*b[2] + m[9]*a[3]*b[3]
+         + m[1]*(a[0]*b[1] + a[1]*b[0]) + m[2]*(a[0]*b[2] + a[2]*b[0]) + m[3]*(a[0]*b[3] + a[3]*b[0])
+         + m[5]*(a[1]*b[2] + a[2]*b[1]) + m[6]*(a[1]*b[3] + a[3]*b[1]) + m[8]*(a[2]*b[3] + a[3]*b[2]);
+}
+
 __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel_quad(const double *planes, size_t stride, const int *cv,
                                                                   const double *vx, const double *vy, const double *vh,
-                                                                  int n, double *partial, const double *valpha)
+                                                                  int n, double *partial, const double *valpha, int affine)
 {
     __shared__ double red[4][SWE_BLOCK];
     const int k = blockIdx.x*SWE_BLOCK + threadIdx.x;
@@ -2077,9 +2192,21 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel_quad(const double *
             h[i] = valpha ? swe_wd_depth(h[i] + e[i], valpha[vid]) : h[i] + e[i];      // nodal total depth
         }
         const double A = (px[1] - px[0])*(py[3] - py[0]) - (py[1] - py[0])*(px[3] - px[0]);
-        s_e2 = A*(1.0/36.0)*swe_int2_quad(e, e);
-        s_u2 = A*(1.0/36.0)*(swe_int2_quad(u, u) + swe_int2_quad(v, v));
-        s_vol = A*0.25*(h[0] + h[1] + h[2] + h[3]);
+        if (affine) {
+            s_e2 = A*(1.0/36.0)*swe_int2_quad(e, e);
+            s_u2 = A*(1.0/36.0)*(swe_int2_quad(u, u) + swe_int2_quad(v, v));
+            s_vol = A*0.25*(h[0] + h[1] + h[2] + h[3]);
+        } else {
+            const double cx = (px[0] - px[1]) + (px[2] - px[3]), cy = (py[0] - py[1]) + (py[2] - py[3]);
+            const double d1 = (px[1] - px[0])*cy - (py[1] - py[0])*cx, d2 = cx*(py[3] - py[0]) - cy*(px[3] - px[0]);
+            SweQuadMass M;
+            swe_quad_mass(A, d1, d2, M);
+            s_e2 = swe_quad_form(M, e, e);
+            s_u2 = swe_quad_form(M, u, u) + swe_quad_form(M, v, v);
+            double w[4];
+            swe_quad_mean_weights(A, d1, d2, w);
+            s_vol = (A + 0.5*(d1 + d2))*(w[0]*h[0] + w[1]*h[1] + w[2]*h[2] + w[3]*h[3]);
+        }
         s_min = fmin(fmin(h[0], h[1]), fmin(h[2], h[3]));
     }
     red[0][threadIdx.x] = s_e2; red[1][threadIdx.x] = s_u2; red[2][threadIdx.x] = s_vol; red[3][threadIdx.x] = s_min;
@@ -2098,7 +2225,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel_quad(const double *
 }
 
 // ---- tracer stage on parallelogram quadrilaterals (see swe_tracer_stage_kernel and swe_stage_kernel_quad)
-template <bool LF, bool HAST0, bool SRC>
+template <bool LF, bool HAST0, bool SRC, bool AFFINE = true>
 __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const SweTracerArgs p)
 {
 #ifdef SWE_NO_XCD_MAP
@@ -2155,6 +2282,9 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
     const double bx = px[3] - px[0], by = py[3] - py[0];
     const double A = ax*by - ay*bx;
     const double xix = by, xiy = -bx, zex = -ay, zey = ax;       // A*grad(xi), A*grad(zeta)
+    // general quadrilateral (see swe_quad_mass): c = p0 - p1 + p2 - p3, det J = A + d1 xi + d2 zeta
+    const double cx = AFFINE ? 0.0 : (px[0] - px[1]) + (px[2] - px[3]), cy = AFFINE ? 0.0 : (py[0] - py[1]) + (py[2] - py[3]);
+    const double d1 = AFFINE ? 0.0 : ax*cy - ay*cx, d2 = AFFINE ? 0.0 : cx*by - cy*bx;
     double b[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int qi = 0; qi < 2; qi++) {
@@ -2165,10 +2295,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
             const double dxi[4] = {-(1.0 - ze), (1.0 - ze), ze, -ze};
             const double dze[4] = {-(1.0 - xi), -xi, xi, (1.0 - xi)};
             double gx[4], gy[4], uq = 0.0, vq = 0.0, cq = 0.0, D = 0.0, sq = 0.0;
+            const double xix_q = AFFINE ? xix : by + cy*xi, xiy_q = AFFINE ? xiy : -(bx + cx*xi);
+            const double zex_q = AFFINE ? zex : -(ay + cy*ze), zey_q = AFFINE ? zey : ax + cx*ze;
+            const double Aq = AFFINE ? A : A + d1*xi + d2*ze;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                gx[i] = dxi[i]*xix + dze[i]*zex;
-                gy[i] = dxi[i]*xiy + dze[i]*zey;
+                gx[i] = dxi[i]*xix_q + dze[i]*zex_q;
+                gy[i] = dxi[i]*xiy_q + dze[i]*zey_q;
                 uq += phi[i]*u[i];
                 vq += phi[i]*v[i];
                 cq += phi[i]*c[i];
@@ -2187,7 +2320,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
             }
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                b[i] += 0.25*(((p.conservative ? 0.0 : phi[i]*D) + uq*gx[i] + vq*gy[i])*cq + A*sq*phi[i]);
+                b[i] += 0.25*(((p.conservative ? 0.0 : phi[i]*D) + uq*gx[i] + vq*gy[i])*cq + Aq*sq*phi[i]);
         }
     }
 #pragma unroll
@@ -2236,6 +2369,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
         b[a] -= 0.5*Fa;
         b[bb] -= 0.5*Fb;
     }
+    if constexpr (AFFINE) {
     const double s = p.dt*p.beta*swe_rcp(A);
     double msum = 0.0;
 #pragma unroll
@@ -2245,13 +2379,30 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
         msum += o;
     }
     if (p.mean_out) p.mean_out[k] = msum/4.0;
+    } else {
+    SweQuadMass M;
+    SweQuadLDL F;
+    swe_quad_mass(A, d1, d2, M);
+    swe_quad_mass_factor(M, F);
+    swe_quad_mass_solve(F, b);
+    double mw[4], msum = 0.0;
+    swe_quad_mean_weights(A, d1, d2, mw);
+    const double s = p.dt*p.beta;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double o = s*b[i] + w[i];
+        swe_st(swe_rsrc(p.tout), k8, i*S8, o);
+        msum += mw[i]*o;
+    }
+    if (p.mean_out) p.mean_out[k] = msum;         // P0 projection: int o dx / area
+    }
 }
 
 // tracer diagnostics on quadrilaterals
 __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel_quad(const double *t, const double *state, size_t stride,
                                                                          const int *cv, const double *vx, const double *vy,
                                                                          const double *vh, int nonlinear, int n, double *partial,
-                                                                         const double *valpha)
+                                                                         const double *valpha, int affine)
 {
     __shared__ double red[4][SWE_BLOCK];
     const int k = blockIdx.x*SWE_BLOCK + threadIdx.x;
@@ -2266,8 +2417,19 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel_quad(const d
             if (valpha) H[i] = swe_wd_depth(H[i], valpha[vid]);
         }
         const double A = (px[1] - px[0])*(py[3] - py[0]) - (py[1] - py[0])*(px[3] - px[0]);
-        s_m = A*(1.0/36.0)*swe_int2_quad(c, H);
-        s_i = A*0.25*(c[0] + c[1] + c[2] + c[3]);
+        if (affine) {
+            s_m = A*(1.0/36.0)*swe_int2_quad(c, H);
+            s_i = A*0.25*(c[0] + c[1] + c[2] + c[3]);
+        } else {
+            const double cx = (px[0] - px[1]) + (px[2] - px[3]), cy = (py[0] - py[1]) + (py[2] - py[3]);
+            const double d1 = (px[1] - px[0])*cy - (py[1] - py[0])*cx, d2 = cx*(py[3] - py[0]) - cy*(px[3] - px[0]);
+            SweQuadMass M;
+            swe_quad_mass(A, d1, d2, M);
+            s_m = swe_quad_form(M, c, H);
+            double w[4];
+            swe_quad_mean_weights(A, d1, d2, w);
+            s_i = (A + 0.5*(d1 + d2))*(w[0]*c[0] + w[1]*c[1] + w[2]*c[2] + w[3]*c[3]);
+        }
         s_min = fmin(fmin(c[0], c[1]), fmin(c[2], c[3]));
         s_max = fmax(fmax(c[0], c[1]), fmax(c[2], c[3]));
     }

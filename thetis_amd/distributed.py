@@ -206,6 +206,10 @@ class DistributedSwe2d(object):
         numbering (LocalPartition.owned_prefix) - and completes those stages on the remaining wedge (cells at distance
         <= g + 1 and the ghost layers) after the unpack.  Disjoint read / write sets (a late stage g reads distance
         <= g + 2, an early stage g' > g writes distance >= g' + 2), bitwise the same result.
+        On coupled runs with the combined exchange: the first j shallow water stages of the NEXT cycle (at most those of its
+        first step) run while the last tracer's exchange of this cycle is in flight - the shallow water state has already
+        been exchanged by then (it travels during the tracer stages) and does not depend on the tracers, so the stages run on
+        their full ranges and nothing is left to complete afterwards.  Bitwise the same result.
 
         ``flow``: the 3m stages of a cycle as ONE launch without grid-wide barriers (csrc/swe2d_flow.h: a 64-cell block starts
         its next stage as soon as the blocks around it have finished the previous one; bit for bit the stage launches),
@@ -240,11 +244,14 @@ class DistributedSwe2d(object):
             raise ValueError('ForwardEuler on partitions: no overlap_stages')
         self.exchange_every = m = int(exchange_every)
         self.overlap_stages = int(overlap_stages)
-        if m < 1 or (self.overlap_stages > 0 and n_tracers > 0):
-            raise ValueError('overlap_stages is implemented for shallow-water-only runs')
+        if m < 1:
+            raise ValueError('exchange_every must be >= 1')
         # coupled runs: exchange_every = 1 exchanges after the shallow water step and after every tracer step (four ghost
         # layers); exchange_every = m > 1 (or combined_exchange) runs m coupled steps between two exchanges of ALL fields
         self.coupled_cycles = n_tracers > 0 and (m > 1 or bool(combined_exchange) or self.stages_per_step == 1)
+        if self.overlap_stages > 0 and n_tracers > 0 and (not self.coupled_cycles or tracer_only):
+            raise ValueError('overlap_stages on coupled runs needs the combined exchange (exchange_every > 1 or '
+                             'combined_exchange=True) and a shallow water step to overlap with (not tracer_only)')
         if not 0 <= self.overlap_stages <= 3*m - 1:
             raise ValueError('overlap_stages must be in 0 .. 3*exchange_every - 1')
         self.exchange = exchange or ('host' if host_staged else 'rccl')
@@ -527,13 +534,27 @@ class DistributedSwe2d(object):
             ran = True
         return ran
 
-    def _cycle_coupled(self, n_steps):
-        """``n_steps`` (<= exchange_every) coupled steps, then one exchange of the shallow water state and every tracer."""
+    def _coupled_ops(self, n_steps):
+        return coupled_cycle_schedule(self.part, n_steps, len(self.tids), self.use_limiter, self.tracer_only, self.stages_per_step)
+
+    def _coupled_early_ops(self, n_steps_next):
+        """The shallow water stages of the next cycle that may run during this cycle's last tracer exchange (overlap_stages)"""
+        early = []
+        for op in self._coupled_ops(n_steps_next):
+            if op[0] != 'swe' or len(early) >= self.overlap_stages:
+                break
+            early.append(op)
+        return early
+
+    def _cycle_coupled(self, n_steps, early_done=0, early_next=()):
+        """``n_steps`` (<= exchange_every) coupled steps, then one exchange of the shallow water state and every tracer.
+        ``early_done``: leading launches of this cycle that already ran during the previous cycle's tracer exchange;
+        ``early_next``: launches of the next cycle to run during this cycle's last tracer exchange."""
         dev = self.dev
         reqs = None
         sent = False
         fe = self.stages_per_step == 1         # ForwardEuler: a "stage" is the whole step, buffer 0 -> 1, then the buffers swap
-        for op in coupled_cycle_schedule(self.part, n_steps, len(self.tids), self.use_limiter, self.tracer_only, self.stages_per_step):
+        for op in self._coupled_ops(n_steps)[early_done:]:
             if op[0] == 'swe':
                 if fe:
                     dev.forward_euler_cells(0, op[2])
@@ -551,14 +572,24 @@ class DistributedSwe2d(object):
                 dev.tracer_limit_cells(self.tids[op[1]], op[2])
         if sent:
             self._receive(0, 0, reqs)
-        for i in range(len(self.tids)):
-            self._receive(1 + i, 0, self._send(1 + i, 0))
+        nt = len(self.tids)
+        for i in range(nt):
+            reqs = self._send(1 + i, 0)
+            if i == nt - 1:
+                for op in early_next:               # shallow water stages of the next cycle: they read no tracer
+                    dev.solve_stage_cells(op[1], 0, op[2])
+            self._receive(1 + i, 0, reqs)
 
     def _steps_eager(self, n_steps, graphed=False):
         m = self.exchange_every
         if self.coupled_cycles:
-            for r in [m]*(n_steps//m) + ([n_steps % m] if n_steps % m else []):
-                self._cycle_coupled(r)
+            cycles = [m]*(n_steps//m) + ([n_steps % m] if n_steps % m else [])
+            done = 0
+            for i, r in enumerate(cycles):
+                # never across advance() calls: after the last cycle buffer 0 holds the step result and nothing is half done
+                nxt = self._coupled_early_ops(cycles[i + 1]) if self.overlap_stages and i + 1 < len(cycles) else []
+                self._cycle_coupled(r, early_done=done, early_next=nxt)
+                done = len(nxt)
             return
         if self.tids or self.tracer_only:
             for _ in range(n_steps):

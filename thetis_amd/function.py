@@ -180,9 +180,30 @@ class Function(object):
         if npc == 3:
             # (M/A)^-1 = 12 [[2,1,1],..]^-1  ->  x_i = 3 (4 b_i - sum b)
             x = 3.0*(4.0*b - b.sum(axis=1, keepdims=True))
-        else:
+        elif getattr(mesh, 'affine', True):
             # parallelogram: (M/A)^-1 = m^-1 (x) m^-1, m^-1 = [[4,-2],[-2,4]]
             x = 16.0*b - 8.0*np.roll(b, -1, axis=1) - 8.0*np.roll(b, 1, axis=1) + 4.0*np.roll(b, 2, axis=1)
+        else:
+            # general quadrilateral: det J = d0 + d1 xi + d2 zeta varies over the cell - weight the right-hand side with it and
+            # solve with the true 4 x 4 mass matrix of every cell (same 2 x 2 rule: exact for M)
+            a, bb = p[:, 1] - p[:, 0], p[:, 3] - p[:, 0]
+            c = p[:, 0] - p[:, 1] + p[:, 2] - p[:, 3]
+            cross = lambda u, v: u[:, 0]*v[:, 1] - u[:, 1]*v[:, 0]
+            d0, d1, d2 = cross(a, bb), cross(a, c), cross(c, bb)
+            b[...] = 0.0
+            M = np.zeros((n, 4, 4))
+            for l, wq in zip(bary, w):
+                xi, ze = l[1] + l[2], l[2] + l[3]
+                det = wq*(d0 + d1*xi + d2*ze)
+                xq = np.einsum('nic,i->nc', p, l)
+                val = expr(xq[:, 0], xq[:, 1])
+                if fs.vector:
+                    val = np.stack([np.asarray(val[0])*np.ones(n), np.asarray(val[1])*np.ones(n)], axis=1)
+                else:
+                    val = (np.asarray(val)*np.ones(n))[:, None]
+                b += det[:, None, None]*l[None, :, None]*val[:, None, :]
+                M += det[:, None, None]*np.outer(l, l)[None]
+            x = np.linalg.solve(M, b)
         self._pull()
         self._data[...] = x.reshape(self._data.shape)
         self._host_version += 1

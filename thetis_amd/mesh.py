@@ -12,7 +12,8 @@ own topology.  Here a mesh is a handful of numpy arrays that go straight to HBM:
                                  <0: ``-marker`` of the boundary the facet lies on
 ``cell_nbr_facet`` (N, k) int8   local facet number of the same facet inside the neighbour
 
-Quadrilaterals must be parallelograms (affine; every quadrilateral mesh of the reference is a rectangle grid).
+Quadrilaterals: parallelograms take the affine kernels (every quadrilateral mesh the reference builds itself is a rectangle
+grid); any other convex quadrilateral the general bilinear ones (no wetting-drying / viscosity / diffusion there).
 
 Conventions [FD-assumed, SURVEY.md A.8]: vertices on a regular grid, 'left' diagonal
 (from (i, j+1) to (i+1, j)), boundary markers 1: x=0, 2: x=Lx, 3: y=0, 4: y=Ly.
@@ -29,7 +30,7 @@ def _signed_area2(p):
 
 
 class Mesh2d(object):
-    """2D mesh of triangles or parallelogram quadrilaterals with facet-neighbour connectivity."""
+    """2D mesh of triangles or (convex) quadrilaterals with facet-neighbour connectivity."""
 
     def __init__(self, vertex_xy, cells, topo_vertex=None, marker_fn=None, name='mesh2d'):
         """
@@ -49,14 +50,23 @@ class Mesh2d(object):
         if np.any(area2 == 0):
             raise ValueError('degenerate (zero area) cell in mesh')
         flip = area2 < 0
+        self.affine = True
         if self.nodes_per_cell == 3:
             cells[flip, 1], cells[flip, 2] = cells[flip, 2].copy(), cells[flip, 1].copy()
         else:
             cells[flip, 1], cells[flip, 3] = cells[flip, 3].copy(), cells[flip, 1].copy()
             p = self.vertex_xy[cells]
-            skew = np.abs(p[:, 0] - p[:, 1] + p[:, 2] - p[:, 3]).max(axis=1)
-            if np.any(skew > 1e-9*np.sqrt(np.abs(area2))):
-                raise NotImplementedError('quadrilateral cells must be parallelograms (affine)')
+            c = p[:, 0] - p[:, 1] + p[:, 2] - p[:, 3]
+            # a cell that is not a parallelogram selects the general bilinear kernels (csrc/swe2d_kernels.h: swe_quad_mass;
+            # solver2d.py:340-345 of the reference accepts any quadrilateral mesh); it must be convex: det J > 0 at the corners
+            self.affine = not np.any(np.abs(c).max(axis=1) > 1e-9*np.sqrt(np.abs(area2)))
+            if not self.affine:
+                a, b = p[:, 1] - p[:, 0], p[:, 3] - p[:, 0]
+                d0 = a[:, 0]*b[:, 1] - a[:, 1]*b[:, 0]
+                d1 = a[:, 0]*c[:, 1] - a[:, 1]*c[:, 0]
+                d2 = c[:, 0]*b[:, 1] - c[:, 1]*b[:, 0]
+                if np.any(np.minimum.reduce([d0, d0 + d1, d0 + d2, d0 + d1 + d2]) <= 0.0):
+                    raise ValueError('quadrilateral cells must be convex')
         self.cells = np.ascontiguousarray(cells)
         self.topo_vertex = (np.arange(len(self.vertex_xy), dtype=np.int64) if topo_vertex is None
                             else np.asarray(topo_vertex, dtype=np.int64))
