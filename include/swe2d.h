@@ -86,9 +86,8 @@ typedef enum {
  * Triangles (nodes_per_cell == 3, DG-P1) or convex quadrilaterals (nodes_per_cell == 4, DQ-1), counter-clockwise.  A mesh of
  * parallelograms (every quadrilateral mesh the reference builds itself) takes the kernels with a constant Jacobian and the tensor
  * mass inverse; one cell that is not a parallelogram selects the general bilinear kernels for the whole mesh (Jacobian per
- * quadrature point, 4 x 4 mass solve per cell; thetis/solver2d.py:340-345 accepts any quadrilateral mesh) - shallow water with all
- * source terms and boundary conditions, tracers and the limiter; swe2d_set_wetting_and_drying, swe2d_set_viscosity and
- * swe2d_tracer_set_diffusivity return SWE2D_ERR_UNSUPPORTED there.
+ * quadrature point, 4 x 4 mass solve per cell, mass-weighted cell means; thetis/solver2d.py:340-345 accepts any quadrilateral
+ * mesh) - every option of the path runs on either kind.
  * Local facet f joins local vertices f and (f+1)%nodes_per_cell; all [..][3] shapes below read [..][nodes_per_cell].
  * In a multi-GPU partition the first n_owned cells are updated by this handle and cells n_owned..n_cells-1 are
  * ghost cells (one layer, facet-adjacent) whose state arrives through swe2d_halo_*. */

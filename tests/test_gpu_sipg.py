@@ -342,11 +342,15 @@ QUAD_VISC_CASES = {
 
 
 @pytest.mark.parametrize('case', sorted(QUAD_VISC_CASES))
-def test_quad_viscosity_matches_oracle(hip_lib, case):
-    """swe_sipg_kernel_quad<2> on skewed parallelograms, with Dirichlet terms of every velocity-type boundary kind."""
+@pytest.mark.parametrize('geometry', ['parallelograms', 'general'])
+def test_quad_viscosity_matches_oracle(hip_lib, case, geometry):
+    """swe_sipg_kernel_quad<2> on skewed parallelograms, with Dirichlet terms of every velocity-type boundary kind; ``general``:
+    warped convex cells (swe_sipg_kernel_quad<2, false>: gradients through the Jacobian at every quadrature point on both sides of
+    a facet, true cell areas in the penalty, 4 x 4 mass solve)."""
     from helpers import make_oracle_generic, quad_case
     cfg = dict(QUAD_VISC_CASES[case])
-    mesh, bath, uv, eta = quad_case(nx=8, ny=6, skew=0.3, seed=33)
+    mesh, bath, uv, eta = quad_case(nx=8, ny=6, skew=0.3, seed=33, warp=(0.25 if geometry == 'general' else 0.0))
+    assert mesh.affine == (geometry == 'parallelograms')
     rng = np.random.default_rng(17)
     nu = 40.0 if cfg.pop('nu') == 'const' else 20.0 + 30.0*rng.uniform(size=mesh.num_vertices)
     nonlin = cfg.pop('use_nonlinear_equations', True)
@@ -376,9 +380,10 @@ def test_quad_viscosity_matches_oracle(hip_lib, case):
 
 
 @pytest.mark.parametrize('case', ['const', 'field_and_bcs'])
-def test_quad_tracer_diffusion_matches_oracle(hip_lib, case):
+@pytest.mark.parametrize('geometry', ['parallelograms', 'general'])
+def test_quad_tracer_diffusion_matches_oracle(hip_lib, case, geometry):
     from helpers import make_oracle_generic, quad_case
-    mesh, bath, uv, eta = quad_case(nx=8, ny=6, skew=0.3, seed=35)
+    mesh, bath, uv, eta = quad_case(nx=8, ny=6, skew=0.3, seed=35, warp=(0.25 if geometry == 'general' else 0.0))
     rng = np.random.default_rng(19)
     n = mesh.num_cells
     T = rng.normal(size=(n, 4))

@@ -204,6 +204,57 @@ def test_wd_gpu_matches_oracle(hip_lib, ref_so, quad):
 
 
 @pytest.mark.gpu
+def test_wd_on_general_quadrilaterals_matches_oracle(hip_lib):
+    """The beach on warped (non-parallelogram) cells: the AFFINE = false kernels with the positivity limiter's cell mean taken as
+    the mass-weighted P0 projection (so that int D dx is what the limiter conserves); tendency and ten steps against the numpy
+    oracle, wet volume conserved to round-off on a closed basin."""
+    from thetis_amd import _lib
+    from thetis_amd.device import Swe2dDevice
+    from thetis_amd.mesh import Mesh2d
+    base, _, alpha_v, uv, eta = _beach(True)
+    xy = base.vertex_xy.copy()
+    wr = np.random.default_rng(21)
+    mx = (xy[:, 0] > 1e-6*LX) & (xy[:, 0] < LX*(1 - 1e-6))
+    my = (xy[:, 1] > 1e-6*LY) & (xy[:, 1] < LY*(1 - 1e-6))
+    xy[:, 0] += np.where(mx, 0.3*LX/12*wr.uniform(-1, 1, size=len(xy)), 0.0)
+    xy[:, 1] += np.where(my, 0.3*LY/6*wr.uniform(-1, 1, size=len(xy)), 0.0)
+    mesh = Mesh2d(xy, base.cells, marker_fn=None)
+    mesh.cell_nbr = base.cell_nbr                          # same topology and markers as the rectangle grid
+    mesh.boundary_len = mesh._boundary_length()
+    assert not mesh.affine
+    bath = xy[:, 0]/2760.0 - 1.0
+    dt = 2.0
+    from helpers import make_oracle_generic
+    for kw, closed in ((_KW, False), ({}, True)):
+        orc = make_oracle_generic(mesh, bath, use_wetting_and_drying=True, wd_mode='nodal', wetting_and_drying_alpha=alpha_v, **kw)
+        assert orc.mean_w is not None
+        dev = Swe2dDevice(mesh, bath, dt, boundary_len=mesh.boundary_len)
+        dev.set_wetting_and_drying(alpha_v)
+        if not closed:
+            dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+            for m, funcs in kw['bnd_conditions'].items():
+                dev.set_bc(m, funcs)
+        dev.set_state(uv, eta)
+        e_adm = orc.wd_clip_state(eta)
+        assert np.abs(e_adm - dev.get_state()[1]).max() < 1e-13 and np.abs(e_adm - eta).max() > 1e-3
+        ku, ke = dev.tendency()
+        ku_o, ke_o = orc.tendency(uv, e_adm, dt)
+        assert rel_linf(ku, ku_o) < 1e-12 and rel_linf(ke, ke_o) < 1e-12
+        v0 = dev.diagnostics()[2]
+        dev.advance(10)
+        ud, ed = dev.get_state()
+        uo, eo = uv, e_adm
+        for _ in range(10):
+            uo, eo = orc.ssprk33_step(uo, eo, dt)
+        assert rel_linf(ud, uo) < 1e-10 and rel_linf(ed, eo) < 1e-10
+        d = dev.diagnostics()
+        assert math.isclose(d[2], orc.wd_volume(ed), rel_tol=1e-12)
+        if closed:
+            assert math.isclose(d[2], v0, rel_tol=1e-12)
+        dev.close()
+
+
+@pytest.mark.gpu
 def test_balzano_through_flowsolver_matches_cpu(hip_lib, ref_so):
     """examples/balzano/balzano.py through FlowSolver2d with swe_timestepper_type='SSPRK33' (the reference runs it with
     CrankNicolson): falling tide for one hour, time-dependent elevation through update_forcings, against the C restatement."""

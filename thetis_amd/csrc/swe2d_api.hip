@@ -267,13 +267,14 @@ stage_kernel_t pick_src(bool src, int binl)          // binl: 0 epilogue variant
 }
 // wetting-drying variants (nonlinear equations only)
 template <bool LF, bool U0>
-stage_kernel_t pick_wd_src(bool src, bool quad, bool binl)
+stage_kernel_t pick_wd_src(bool src, int quad, bool binl)
 {
+    if (quad == 2) return src ? swe_stage_kernel_quad<true, LF, U0, true, true, false> : swe_stage_kernel_quad<true, LF, U0, false, true, false>;
     if (quad) return src ? swe_stage_kernel_quad<true, LF, U0, true, true> : swe_stage_kernel_quad<true, LF, U0, false, true>;
     if (binl) return src ? swe_stage_kernel<true, LF, U0, true, true, false, true> : swe_stage_kernel<true, LF, U0, false, true, false, true>;
     return src ? swe_stage_kernel<true, LF, U0, true, true> : swe_stage_kernel<true, LF, U0, false, true>;
 }
-stage_kernel_t pick_kernel_wd(bool lf, bool u0, bool src, bool quad, bool binl)
+stage_kernel_t pick_kernel_wd(bool lf, bool u0, bool src, int quad, bool binl)
 {
     if (lf) return u0 ? pick_wd_src<true, true>(src, quad, binl) : pick_wd_src<true, false>(src, quad, binl);
     return u0 ? pick_wd_src<false, true>(src, quad, binl) : pick_wd_src<false, false>(src, quad, binl);
@@ -383,7 +384,7 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     const bool ldsx = env_ldsx_s ? std::atoi(env_ldsx_s) != 0 : (c1 - c0) >= 3000000;
     stage_kernel_t kern = fused_visc
         ? pick_kernel_visc(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
-        : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4, binl)
+        : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4 ? (h->affine ? 1 : 2) : 0, binl)
         : (h->npc == 4)
         ? pick_kernel_quad(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->affine)
         : pick_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), binl ? (ldsx ? 2 : 1) : 0);
@@ -429,7 +430,8 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
             if (any && h->n_bnd > 0)
                 hipLaunchKernelGGL((swe_sipg_kernel<2, true>), dim3((h->n_bnd + SWE_BLOCK - 1)/SWE_BLOCK), dim3(SWE_BLOCK), 0,
                                    h->stream, v);
-        } else if (h->npc == 4) hipLaunchKernelGGL(swe_sipg_kernel_quad<2>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
+        } else if (h->npc == 4 && !h->affine) hipLaunchKernelGGL((swe_sipg_kernel_quad<2, false>), dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
+        else if (h->npc == 4) hipLaunchKernelGGL(swe_sipg_kernel_quad<2>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         else hipLaunchKernelGGL(swe_sipg_kernel<2>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         HIP_TRY(h, hipGetLastError());
         if (h->wd && !(a0 == 0.0 && a1 == 0.0)) {
@@ -1001,9 +1003,10 @@ int swe2d_set_state(swe2d_handle *hh, const double *uv, const double *eta)
         // explicit wetting-drying: the admissible state next to the one handed in (nodal depths through the positivity
         // limiter; enable wetting-drying BEFORE setting the state)
         if (h->npc == 4) hipLaunchKernelGGL(swe_wd_clip_kernel<4>, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                                            h->state[0], h->stride, h->cv, h->vh, h->valpha, h->n_cells);
+                                            h->state[0], h->stride, h->cv, h->vh, h->valpha, h->n_cells,
+                                            h->affine ? nullptr : h->vx, h->vy);
         else hipLaunchKernelGGL(swe_wd_clip_kernel<3>, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                                h->state[0], h->stride, h->cv, h->vh, h->valpha, h->n_cells);
+                                h->state[0], h->stride, h->cv, h->vh, h->valpha, h->n_cells, nullptr, nullptr);
         HIP_TRY(h, hipGetLastError());
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
@@ -1240,7 +1243,6 @@ int swe2d_set_wetting_and_drying(swe2d_handle *hh, int enable, const double *alp
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
     if (!enable) { h->wd = false; return SWE2D_OK; }
-    if (!h->affine) return fail(h, SWE2D_ERR_UNSUPPORTED, "wetting and drying"" is implemented for parallelogram quadrilaterals only (general quadrilaterals: shallow water, sources, boundary conditions, tracers, limiter)");
     if (!alpha_vertex) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "alpha_vertex is required");
     if (!h->par.use_nonlinear_equations)
         return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "wetting and drying needs use_nonlinear_equations");
@@ -1276,7 +1278,6 @@ int swe2d_set_viscosity(swe2d_handle *hh, int enable, const double *nu_vertex, d
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
     if (!enable) { h->visc = false; return SWE2D_OK; }
-    if (!h->affine) return fail(h, SWE2D_ERR_UNSUPPORTED, "horizontal viscosity"" is implemented for parallelogram quadrilaterals only (general quadrilaterals: shallow water, sources, boundary conditions, tracers, limiter)");
     if (!nu_vertex && !(nu_const >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "viscosity must be >= 0");
     if (!(sipg_factor > 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "sipg_factor must be > 0");
     int rc = upload_vertex_coefficient(h, nu_vertex, &h->nu_v);
@@ -1742,7 +1743,8 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
             if (any && h->n_bnd > 0)
                 hipLaunchKernelGGL((swe_sipg_kernel<1, true>), dim3((h->n_bnd + SWE_BLOCK - 1)/SWE_BLOCK), dim3(SWE_BLOCK), 0,
                                    h->stream, v);
-        } else if (h->npc == 4) hipLaunchKernelGGL(swe_sipg_kernel_quad<1>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
+        } else if (h->npc == 4 && !h->affine) hipLaunchKernelGGL((swe_sipg_kernel_quad<1, false>), dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
+        else if (h->npc == 4) hipLaunchKernelGGL(swe_sipg_kernel_quad<1>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         else hipLaunchKernelGGL(swe_sipg_kernel<1>, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, v);
         HIP_TRY(h, hipGetLastError());
     }
@@ -2061,7 +2063,6 @@ int swe2d_tracer_set_diffusivity(swe2d_handle *hh, int id, int enable, const dou
     if (rc) return rc;
     Handle::Tracer &t = h->tracers[id];
     if (!enable) { t.diff = false; return SWE2D_OK; }
-    if (!h->affine) return fail(h, SWE2D_ERR_UNSUPPORTED, "horizontal diffusion"" is implemented for parallelogram quadrilaterals only (general quadrilaterals: shallow water, sources, boundary conditions, tracers, limiter)");
     if (!mu_vertex && !(mu_const >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "diffusivity must be >= 0");
     if (!(sipg_factor_tracer > 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "sipg_factor_tracer must be > 0");
     rc = upload_vertex_coefficient(h, mu_vertex, &t.mu_v);

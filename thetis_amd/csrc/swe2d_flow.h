@@ -70,6 +70,23 @@
 typedef unsigned int swe_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int swe_u32x3 __attribute__((ext_vector_type(3)));
 #define SWE_FLOW_NOWHERE 0x80000000u       // byte offset beyond the exchange array (< 2 GiB): a load returns zeros without touching memory
+// LDS layout of a block: nine planes of 64 stage values, then six trace values per incoming rim facet
+#define SWE_FLOW_XG (9*SWE_BLOCK)
+#define SWE_FLOW_LDS_DOUBLES (SWE_FLOW_XG + 6*SWE_FLOW_MAX_RIM)
+// LDS indices are computed from host-built tables (xo4 / xo2 / xsrc, flow_build): the -DSWE_RANGE_CHECK build (tools/range_check.sh)
+// tests every one of them against the array it indexes; a violation is reported like an out-of-range memory access and redirected
+// to element 0.
+#ifdef SWE_RANGE_CHECK
+__device__ __forceinline__ unsigned swe_lds_index_chk(unsigned i, unsigned n, int line)
+{
+    if (i < n) return i;
+    if (atomicAdd(&swe_chk_report[0], 1ull) == 0ull) { swe_chk_report[1] = 0x1d5000000000ull | i; swe_chk_report[2] = (unsigned long long)line; }
+    return 0u;
+}
+#define SWE_LDSI(i, n) swe_lds_index_chk((unsigned)(i), (unsigned)(n), __LINE__)
+#else
+#define SWE_LDSI(i, n) (i)
+#endif
 
 struct SweFlowArgs {
     SweStageArgs st;                       // geometry, connectivity, boundary tables, sources; uin/u0/uout/a0/a1/beta/cell_* unused
@@ -185,9 +202,9 @@ __device__ __forceinline__ void swe_flow_rhs(const SweStageArgs &p, int k, const
         const int a = f, b = (f + 1) % 3;
         const bool bnd = ((bmarkers >> (8*f)) & 0xff) != 0;
         // tr[f][c] = address of component c (u, v, e) at the neighbour's node on my node f + 1 | the same on my node f << 16
-        const double unb = lds[tr[f][0] & 0xffffu], una = lds[tr[f][0] >> 16];
-        const double vnb = lds[tr[f][1] & 0xffffu], vna = lds[tr[f][1] >> 16];
-        const double enb = lds[tr[f][2] & 0xffffu], ena = lds[tr[f][2] >> 16];
+        const double unb = lds[SWE_LDSI(tr[f][0] & 0xffffu, SWE_FLOW_LDS_DOUBLES)], una = lds[SWE_LDSI(tr[f][0] >> 16, SWE_FLOW_LDS_DOUBLES)];
+        const double vnb = lds[SWE_LDSI(tr[f][1] & 0xffffu, SWE_FLOW_LDS_DOUBLES)], vna = lds[SWE_LDSI(tr[f][1] >> 16, SWE_FLOW_LDS_DOUBLES)];
+        const double enb = lds[SWE_LDSI(tr[f][2] & 0xffffu, SWE_FLOW_LDS_DOUBLES)], ena = lds[SWE_LDSI(tr[f][2] >> 16, SWE_FLOW_LDS_DOUBLES)];
         const double nxs = nx[f], nys = ny[f];
         double Lf, rLf;
         swe_sqrt_rsqrt(swe_dot2(nxs, nxs, nys, nys), Lf, rLf);
@@ -296,8 +313,6 @@ __device__ __forceinline__ void swe_flow_finish(const SweStageArgs &p, int k, do
 
 // LDS of a block, in doubles: [0, 9*64) the block's stage values xs[plane][lane] (u0 u1 u2 v0 v1 v2 e0 e1 e2),
 // then the rim staging area xg[slot][6] (incoming traces at the top of a stage, outgoing ones at its end)
-#define SWE_FLOW_XG (9*SWE_BLOCK)
-#define SWE_FLOW_LDS_DOUBLES (SWE_FLOW_XG + 6*SWE_FLOW_MAX_RIM)
 
 // FX = false: n_stages stages on the ranges cell_end[0 .. n_stages); the rim traces of the first stage come from the state planes.
 // FX = true:  n_cycles exchange cycles (see SweFlowArgs); every cycle starts by publishing its input across the rims (the ghost
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
     const __amdgpu_buffer_rsrc_t rex = __builtin_amdgcn_make_buffer_rsrc(q.ex, 0, 3*q.parity_bytes, 0x00020000);
     const int2 myslots = q.xblk[lb];                           // uniform: first slot, count
     const int nrim = myslots.y;
-    for (int i = lane; i < nrim; i += SWE_BLOCK) xsrc[i] = q.xsrc[myslots.x + i];
+    for (int i = lane; i < nrim; i += SWE_BLOCK) xsrc[SWE_LDSI(i, SWE_FLOW_MAX_RIM)] = q.xsrc[myslots.x + i];
 
     // ---- launch invariants of the cell: connectivity, exchange slots, geometry
     int bmarkers, bkind1 = 0;
@@ -413,7 +428,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             for (int f = 0; f < 3; f++) {
                 if (xown[f] >= 0) {
 #pragma unroll
-                    for (int j = 0; j < 6; j++) lds[SWE_FLOW_XG + 6*xin[f] + j] = r0[f][j];
+                    for (int j = 0; j < 6; j++) lds[SWE_LDSI(SWE_FLOW_XG + 6*xin[f] + j, SWE_FLOW_LDS_DOUBLES)] = r0[f][j];
                 }
             }
         }
@@ -448,14 +463,14 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
         for (int f = 0; f < 3; f++) {                                                                                             \
             if (xown[f] >= 0 && (who)) {                                                                                          \
                 const int a_ = f, b_ = (f + 1) % 3;                                                                               \
-                double *d_ = lds + SWE_FLOW_XG + 6*xown[f];                                                                       \
+                double *d_ = lds + SWE_LDSI(SWE_FLOW_XG + 6*xown[f] + 5, SWE_FLOW_LDS_DOUBLES) - 5;                                                                       \
                 d_[0] = pu[a_]; d_[1] = pv[a_]; d_[2] = pe[a_]; d_[3] = pu[b_]; d_[4] = pv[b_]; d_[5] = pe[b_];                   \
             }                                                                                                                     \
         }                                                                                                                         \
         __syncthreads();                                                                                                          \
         for (int t_ = lane; t_ < 8*nrim; t_ += SWE_BLOCK) {                                                                       \
             const int gi_ = t_ & 7;                                                                                               \
-            const double x_ = gi_ < 6 ? lds[SWE_FLOW_XG + 6*(t_ >> 3) + gi_] : 0.0;                                               \
+            const double x_ = gi_ < 6 ? lds[SWE_LDSI(SWE_FLOW_XG + 6*(t_ >> 3) + gi_, SWE_FLOW_LDS_DOUBLES)] : 0.0;                                               \
             swe_flow_put(rex, par_ + 16u*(unsigned)t_, x_, tag_);                                                                 \
         }                                                                                                                         \
     } while (0)
@@ -500,15 +515,15 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                 const int ng = (int)__builtin_popcountll(gm);
                 const int ci = (int)__builtin_popcountll(gm & ((1ull << lane) - 1ull));       // this ghost lane's rank among them
                 __syncthreads();
-                if (xr >= 0) lrec[ci] = zo;
+                if (xr >= 0) lrec[SWE_LDSI(ci, SWE_BLOCK)] = zo;
                 __syncthreads();
                 for (unsigned spins = 0;; spins++) {
                     bool ok = true;
                     for (int t = lane; t < 9*ng; t += SWE_BLOCK) {
                         const int cc = (t*7282) >> 16, gi = t - 9*cc;                              // t / 9, t % 9
-                        const swe_u32x3 gz = swe_flow_get_sys(rz, lrec[cc] + 16u*(unsigned)gi);
+                        const swe_u32x3 gz = swe_flow_get_sys(rz, lrec[SWE_LDSI(cc, SWE_BLOCK)] + 16u*(unsigned)gi);
                         ok = ok && (int)(gz.z - target) >= 0;
-                        lds[SWE_FLOW_XG + t] = swe_flow_val(gz);
+                        lds[SWE_LDSI(SWE_FLOW_XG + t, SWE_FLOW_LDS_DOUBLES)] = swe_flow_val(gz);
                     }
                     if (__all(ok) || late) break;
                     __builtin_amdgcn_s_sleep(4);
@@ -525,7 +540,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                 __syncthreads();
                 if (xr >= 0) {
 #pragma unroll
-                    for (int i = 0; i < 3; i++) { u[i] = lds[SWE_FLOW_XG + 9*ci + i]; v[i] = lds[SWE_FLOW_XG + 9*ci + 3 + i]; e[i] = lds[SWE_FLOW_XG + 9*ci + 6 + i]; }
+                    for (int i = 0; i < 3; i++) { u[i] = lds[SWE_LDSI(SWE_FLOW_XG + 9*ci + i, SWE_FLOW_LDS_DOUBLES)]; v[i] = lds[SWE_LDSI(SWE_FLOW_XG + 9*ci + 3 + i, SWE_FLOW_LDS_DOUBLES)]; e[i] = lds[SWE_LDSI(SWE_FLOW_XG + 9*ci + 6 + i, SWE_FLOW_LDS_DOUBLES)]; }
                 }
                 if (xr >= 0) {                                 // ... and into the state planes, for the kernels after this launch
                     const swe_rsrc_t gou = swe_rsrc(q.buf[0]), gov = swe_rsrc(q.buf[0] + 3*S), goe = swe_rsrc(q.buf[0] + 6*S);
@@ -560,8 +575,8 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             }
             // ---- the block's stage values for its own lanes
 #pragma unroll
-            for (int i = 0; i < 3; i++) { lds[i*SWE_BLOCK + lane] = u[i]; lds[(3 + i)*SWE_BLOCK + lane] = v[i]; lds[(6 + i)*SWE_BLOCK + lane] = e[i]; }
-            lact[lane] = act ? 1 : 0;
+            for (int i = 0; i < 3; i++) { lds[SWE_LDSI(i*SWE_BLOCK + lane, SWE_FLOW_LDS_DOUBLES)] = u[i]; lds[SWE_LDSI((3 + i)*SWE_BLOCK + lane, SWE_FLOW_LDS_DOUBLES)] = v[i]; lds[SWE_LDSI((6 + i)*SWE_BLOCK + lane, SWE_FLOW_LDS_DOUBLES)] = e[i]; }
+            lact[SWE_LDSI(lane, SWE_BLOCK)] = act ? 1 : 0;
             // ---- traces across the rim: the chunks the neighbour blocks wrote for this block, consecutive lanes on consecutive
             //      granules, re-read until every granule a cell of this stage's range needs carries this stage's tag
             if (FX || g > 0) {
@@ -577,9 +592,9 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
                             const int t = c0 + j*SWE_BLOCK + lane;
-                            ent[j] = t < 8*nrim ? xsrc[t >> 3] : -1;
+                            ent[j] = t < 8*nrim ? xsrc[SWE_LDSI(t >> 3, SWE_FLOW_MAX_RIM)] : -1;
                             // a cell outside this stage's range needs nothing (and its neighbour may never have published)
-                            if (ent[j] >= 0 && !lact[ent[j] & (SWE_BLOCK - 1)]) ent[j] = -1;
+                            if (ent[j] >= 0 && !lact[SWE_LDSI(ent[j] & (SWE_BLOCK - 1), SWE_BLOCK)]) ent[j] = -1;
                             gr[j] = swe_flow_get(rex, ent[j] >= 0 ? (unsigned)(ent[j] >> 6)*SWE_FLOW_SLOT_BYTES + 16u*(unsigned)(t & 7) + par
                                                                   : SWE_FLOW_NOWHERE);
                         }
@@ -588,7 +603,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                             const int t = c0 + j*SWE_BLOCK + lane;
                             if (ent[j] >= 0) {
                                 ok = ok && (int)(gr[j].z - need) >= 0;
-                                if ((t & 7) < 6) lds[SWE_FLOW_XG + 6*(t >> 3) + (t & 7)] = swe_flow_val(gr[j]);
+                                if ((t & 7) < 6) lds[SWE_LDSI(SWE_FLOW_XG + 6*(t >> 3) + (t & 7), SWE_FLOW_LDS_DOUBLES)] = swe_flow_val(gr[j]);
                             }
                         }
                     }
@@ -670,17 +685,17 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                     int pp = 0;
 #pragma unroll 1
                     for (int i = 1; i < q.x_n_peers; i++) if (j >= q.x_off[i]) pp = i;          // segments are sorted by offset
-                    lrec[ci] = (target & 1u)*q.x_rslot[pp] + (unsigned)(j - q.x_off[pp])*144u;
-                    lpeer[ci] = pp;
+                    lrec[SWE_LDSI(ci, SWE_BLOCK)] = (target & 1u)*q.x_rslot[pp] + (unsigned)(j - q.x_off[pp])*144u;
+                    lpeer[SWE_LDSI(ci, SWE_BLOCK)] = pp;
 #pragma unroll
-                    for (int i = 0; i < 3; i++) { lds[SWE_FLOW_XG + 9*ci + i] = u[i]; lds[SWE_FLOW_XG + 9*ci + 3 + i] = v[i]; lds[SWE_FLOW_XG + 9*ci + 6 + i] = e[i]; }
+                    for (int i = 0; i < 3; i++) { lds[SWE_LDSI(SWE_FLOW_XG + 9*ci + i, SWE_FLOW_LDS_DOUBLES)] = u[i]; lds[SWE_LDSI(SWE_FLOW_XG + 9*ci + 3 + i, SWE_FLOW_LDS_DOUBLES)] = v[i]; lds[SWE_LDSI(SWE_FLOW_XG + 9*ci + 6 + i, SWE_FLOW_LDS_DOUBLES)] = e[i]; }
                 }
                 __syncthreads();
                 for (int pp = 0; pp < q.x_n_peers; pp++) {     // uniform: one buffer resource per peer
                     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(q.x_rdata[pp], 0, q.x_rbytes[pp], 0x00020000);
                     for (int t = lane; t < 9*ns; t += SWE_BLOCK) {
                         const int cc = (t*7282) >> 16, gi = t - 9*cc;
-                        if (lpeer[cc] == pp) swe_flow_put_sys(rp, lrec[cc] + 16u*(unsigned)gi, lds[SWE_FLOW_XG + t], target);
+                        if (lpeer[SWE_LDSI(cc, SWE_BLOCK)] == pp) swe_flow_put_sys(rp, lrec[SWE_LDSI(cc, SWE_BLOCK)] + 16u*(unsigned)gi, lds[SWE_LDSI(SWE_FLOW_XG + t, SWE_FLOW_LDS_DOUBLES)], target);
                     }
                 }
             }

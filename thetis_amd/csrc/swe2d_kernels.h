@@ -171,20 +171,21 @@ __device__ __forceinline__ double swe_wd_depth(double H, double a)
 //      psi = clamp(-H/alpha - 1, 0, 1).
 #define SWE_WD_FLOOR 0.1
 #define SWE_WD_TAU 10.0
+// ``mw``: weights of the cell mean (general quadrilaterals: int phi_i dx / area, swe_quad_mean_weights); nullptr: 1/K.
 template <int K>
 __device__ __forceinline__ void swe_wd_finish(double g, double dt_stage, const double h[K], const double al[K], double ou[K],
-                                              double ov[K], double oe[K], bool relax = true)
+                                              double ov[K], double oe[K], bool relax = true, const double *mw = nullptr)
 {
 #pragma clang fp contract(off)
     double D[K], mean = 0.0, dmin = 1e300, fl = 0.0;
 #pragma unroll
     for (int i = 0; i < K; i++) {
         D[i] = oe[i] + h[i];
-        mean += D[i];
+        mean += mw ? mw[i]*D[i] : D[i];
         dmin = fmin(dmin, D[i]);
         fl = fmax(fl, SWE_WD_FLOOR*al[i]);
     }
-    mean *= (K == 3 ? (1.0/3.0) : 0.25);
+    if (!mw) mean *= (K == 3 ? (1.0/3.0) : 0.25);
     if (dmin < fl) {
         if (mean <= fl) {
             const double flat = fmax(mean, 0.1*fl);
@@ -1260,19 +1261,29 @@ __global__ void swe_halo_unpack(double *planes, size_t stride, const int *cells,
 // wetting-drying: bring a state handed in by the caller to the admissible set of the explicit scheme (every nodal depth through
 // the positivity limiter of swe_wd_finish; velocities untouched) - otherwise the first stage would do it and the volume of the
 // initial state would not be the volume the run conserves
+__device__ __forceinline__ void swe_quad_mean_weights(double d0, double d1, double d2, double w[4]);
+// (vx != nullptr: general quadrilaterals, the limiter's cell mean is mass-weighted)
 template <int K>
-__global__ void swe_wd_clip_kernel(double *planes, size_t stride, const int *cv, const double *vh, const double *valpha, int n)
+__global__ void swe_wd_clip_kernel(double *planes, size_t stride, const int *cv, const double *vh, const double *valpha, int n,
+                                   const double *vx = nullptr, const double *vy = nullptr)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
-    double h[K], al[K], zu[K], zv[K], ze[K];
+    double h[K], al[K], zu[K], zv[K], ze[K], px[K], py[K];
     for (int i = 0; i < K; i++) {
         const int v = cv[(size_t)i*stride + k];
         h[i] = vh[v]; al[i] = valpha[v];
+        px[i] = vx ? vx[v] : 0.0; py[i] = vx ? vy[v] : 0.0;
         zu[i] = 0.0; zv[i] = 0.0;
         ze[i] = swe_wd_depth(h[i] + planes[(size_t)(2*K + i)*stride + k], al[i]) - h[i];
     }
-    swe_wd_finish<K>(9.81, 0.0, h, al, zu, zv, ze);
+    if (K == 4 && vx) {
+        const double ax = px[1] - px[0], ay = py[1] - py[0], bx = px[K - 1] - px[0], by = py[K - 1] - py[0];
+        const double cx = (px[0] - px[1]) + (px[2] - px[K - 1]), cy = (py[0] - py[1]) + (py[2] - py[K - 1]);
+        double mw[4];
+        swe_quad_mean_weights(ax*by - ay*bx, ax*cy - ay*cx, cx*by - cy*bx, mw);
+        swe_wd_finish<K>(9.81, 0.0, h, al, zu, zv, ze, true, mw);
+    } else swe_wd_finish<K>(9.81, 0.0, h, al, zu, zv, ze);
     for (int i = 0; i < K; i++) planes[(size_t)(2*K + i)*stride + k] = ze[i];
 }
 
@@ -1876,7 +1887,7 @@ __device__ __forceinline__ void swe_quad_mass_solve(const SweQuadLDL &F, double 
     b[0] = x0; b[1] = x1; b[2] = x2; b[3] = x3;
 }
 
-// AFFINE = false: general quadrilaterals (see above); not with wetting-drying (the positivity limiter's cell mean) - the host refuses
+// AFFINE = false: general quadrilaterals (see above)
 template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD, bool AFFINE = true>
 __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStageArgs p)
 {
@@ -2146,7 +2157,14 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         oe[i] = fma(s, be[i], we[i]);
     }
     }
-    if (WD && !(p.a0 == 0.0 && p.a1 == 0.0)) swe_wd_finish<4>(p.g, p.beta*p.dt, h, al, ou, ov, oe, !p.wd_skip_relax);
+    if (WD && !(p.a0 == 0.0 && p.a1 == 0.0)) {
+        if constexpr (AFFINE) swe_wd_finish<4>(p.g, p.beta*p.dt, h, al, ou, ov, oe, !p.wd_skip_relax);
+        else {
+            double mw[4];
+            swe_quad_mean_weights(A, d1, d2, mw);
+            swe_wd_finish<4>(p.g, p.beta*p.dt, h, al, ou, ov, oe, !p.wd_skip_relax, mw);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         swe_st(swe_rsrc(p.uout), k8, i*S8, ou[i]);

@@ -352,7 +352,20 @@ __device__ __forceinline__ void swe_q1_basis(double xi, double ze, double gxi_x,
     }
 }
 
-template <int NC>
+// grad(xi), grad(zeta) at the reference point (xi, zeta) of a general quadrilateral x = p0 + xi a + zeta b + xi zeta c (see
+// swe_quad_mass in swe2d_kernels.h): J^-1 = adj(J)/det J with x_xi = a + zeta c, x_zeta = b + xi c.  Returns det J.
+__device__ __forceinline__ double swe_q1_map_grads(double ax, double ay, double bx, double by, double cx, double cy, double xi,
+                                                   double ze, double &gxi_x, double &gxi_y, double &gze_x, double &gze_y)
+{
+    const double xxi = ax + cx*ze, yxi = ay + cy*ze, xze = bx + cx*xi, yze = by + cy*xi;
+    const double det = xxi*yze - yxi*xze, rd = swe_rcp(det);
+    gxi_x = yze*rd; gxi_y = -xze*rd; gze_x = -yxi*rd; gze_y = xxi*rd;
+    return det;
+}
+
+// AFFINE = false: general quadrilaterals - the gradients through the Jacobian at every quadrature point (cell and facets, both
+// sides), det J at the point as the cell weight, the true cell areas in the penalty, the 4 x 4 mass solve of swe_quad_mass.
+template <int NC, bool AFFINE = true>
 __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgArgs p)
 {
     const int lb = swe_logical_block(blockIdx.x, gridDim.x);
@@ -386,8 +399,11 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
         mu[i] = p.mu_v ? swe_ld(swe_rsrc(p.mu_v), (unsigned)vid[i]*8u, 0) : p.mu_const;
     }
     const double ax = px[1] - px[0], ay = py[1] - py[0], bx = px[3] - px[0], by = py[3] - py[0];
-    const double A = ax*by - ay*bx, rA = swe_rcp(A);
-    const double gxi_x = by*rA, gxi_y = -bx*rA, gze_x = -ay*rA, gze_y = ax*rA;     // grad(xi), grad(zeta)
+    const double A0 = ax*by - ay*bx, rA = swe_rcp(A0);
+    double gxi_x = by*rA, gxi_y = -bx*rA, gze_x = -ay*rA, gze_y = ax*rA;     // grad(xi), grad(zeta) (AFFINE: everywhere in the cell)
+    const double cx = AFFINE ? 0.0 : (px[0] - px[1]) + (px[2] - px[3]), cy = AFFINE ? 0.0 : (py[0] - py[1]) + (py[2] - py[3]);
+    const double d1 = AFFINE ? 0.0 : ax*cy - ay*cx, d2 = AFFINE ? 0.0 : cx*by - cy*bx;
+    const double A = AFFINE ? A0 : A0 + 0.5*(d1 + d2);                       // cell area
     double eo[4] = {0.0, 0.0, 0.0, 0.0}, ho[4] = {0.0, 0.0, 0.0, 0.0}, alo[4] = {0.0, 0.0, 0.0, 0.0};
     if (NC == 2) {
 #pragma unroll
@@ -409,6 +425,8 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
 #pragma unroll
         for (int qz = 0; qz < 2; qz++) {
             double phi[4], gx[4], gy[4];
+            double Aq = A;
+            if (!AFFINE) Aq = swe_q1_map_grads(ax, ay, bx, by, cx, cy, qi ? SWE_XI1 : SWE_XI0, qz ? SWE_XI1 : SWE_XI0, gxi_x, gxi_y, gze_x, gze_y);
             swe_q1_basis(qi ? SWE_XI1 : SWE_XI0, qz ? SWE_XI1 : SWE_XI0, gxi_x, gxi_y, gze_x, gze_y, phi, gx, gy);
             double muq = 0.0, Hq = 0.0, gHx = 0.0, gHy = 0.0;
 #pragma unroll
@@ -430,7 +448,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
             for (int r = 0; r < NC; r++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) S0[r][j] = G[r][j] + ((NC == 2 && gd) ? G[j % NC][r] : 0.0);
-            const double w = 0.25*A*muq;
+            const double w = 0.25*Aq*muq;
             const double rHq = (NC == 2 && p.grad_depth) ? swe_rcp(Hq) : 0.0;
 #pragma unroll
             for (int r = 0; r < NC; r++) {
@@ -469,13 +487,20 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
 #pragma unroll
                 for (int i = 0; i < 4; i++) cn[r][i] = swe_ld(rin[r], (unsigned)kn*8u, i*S8);
             const double anx = qx[1] - qx[0], any_ = qy[1] - qy[0], bnx = qx[3] - qx[0], bny = qy[3] - qy[0];
-            const double An = anx*bny - any_*bnx, rAn = swe_rcp(An);
-            const double hxi_x = bny*rAn, hxi_y = -bnx*rAn, hze_x = -any_*rAn, hze_y = anx*rAn;
+            const double An0 = anx*bny - any_*bnx, rAn = swe_rcp(An0);
+            double hxi_x = bny*rAn, hxi_y = -bnx*rAn, hze_x = -any_*rAn, hze_y = anx*rAn;
+            const double cnx = AFFINE ? 0.0 : (qx[0] - qx[1]) + (qx[2] - qx[3]), cny = AFFINE ? 0.0 : (qy[0] - qy[1]) + (qy[2] - qy[3]);
+            const double An = AFFINE ? An0 : An0 + 0.5*((anx*cny - any_*cnx) + (cnx*bny - cny*bnx));
             const double sigma = p.sipg*L*swe_rcp(fmin(A, An));
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const double s = q ? SWE_XI1 : SWE_XI0;
                 double phi[4], gx[4], gy[4], phn[4], hx[4], hy[4];
+                if (!AFFINE) {
+                    swe_q1_map_grads(ax, ay, bx, by, cx, cy, (1.0 - s)*RX[a] + s*RX[bb], (1.0 - s)*RZ[a] + s*RZ[bb], gxi_x, gxi_y, gze_x, gze_y);
+                    swe_q1_map_grads(anx, any_, bnx, bny, cnx, cny, (1.0 - s)*RX[na] + s*RX[f2], (1.0 - s)*RZ[na] + s*RZ[f2], hxi_x, hxi_y,
+                                     hze_x, hze_y);
+                }
                 swe_q1_basis((1.0 - s)*RX[a] + s*RX[bb], (1.0 - s)*RZ[a] + s*RZ[bb], gxi_x, gxi_y, gze_x, gze_y, phi, gx, gy);
                 swe_q1_basis((1.0 - s)*RX[na] + s*RX[f2], (1.0 - s)*RZ[na] + s*RZ[f2], hxi_x, hxi_y, hze_x, hze_y, phn, hx, hy);
                 const double muq = (1.0 - s)*mu[a] + s*mu[bb];
@@ -529,6 +554,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
                 for (int q = 0; q < 2; q++) {
                     const double s = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - s, xb = s;
                     double phi[4], gx[4], gy[4];
+                    if (!AFFINE) swe_q1_map_grads(ax, ay, bx, by, cx, cy, xa*RX[a] + xb*RX[bb], xa*RZ[a] + xb*RZ[bb], gxi_x, gxi_y, gze_x, gze_y);
                     swe_q1_basis(xa*RX[a] + xb*RX[bb], xa*RZ[a] + xb*RZ[bb], gxi_x, gxi_y, gze_x, gze_y, phi, gx, gy);
                     const double muq = xa*mu[a] + xb*mu[bb];
                     const double uq = xa*c[0][a] + xb*c[0][bb], vq = xa*c[1 % NC][a] + xb*c[1 % NC][bb];
@@ -586,6 +612,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
                         val = -p.bc_diff_flux[marker];
                     } else {
                         double phi[4], gx[4], gy[4];
+                        if (!AFFINE) swe_q1_map_grads(ax, ay, bx, by, cx, cy, xa*RX[a] + xb*RX[bb], xa*RZ[a] + xb*RZ[bb], gxi_x, gxi_y, gze_x, gze_y);
                         swe_q1_basis(xa*RX[a] + xb*RX[bb], xa*RZ[a] + xb*RZ[bb], gxi_x, gxi_y, gze_x, gze_y, phi, gx, gy);
                         double g0 = 0.0, g1 = 0.0, e0_ = 0.0, e1_ = 0.0;
 #pragma unroll
@@ -615,6 +642,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
         }
     }
     // ---- tensor mass inverse (M^-1 b)_i = (16 b_i - 8 b_{i+1} - 8 b_{i-1} + 4 b_{i+2})/A
+    if constexpr (AFFINE) {
     const double sc = p.dt*p.beta*rA;
 #pragma unroll
     for (int r = 0; r < NC; r++)
@@ -624,4 +652,20 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
             swe_st(ro, k8, i*S8, swe_ld(ro, k8, i*S8)
                    + sc*(16.0*b[r][i] - 8.0*b[r][(i + 1) & 3] - 8.0*b[r][(i + 3) & 3] + 4.0*b[r][(i + 2) & 3]));
         }
+    } else {
+    SweQuadMass M;
+    SweQuadLDL F;
+    swe_quad_mass(A0, d1, d2, M);
+    swe_quad_mass_factor(M, F);
+    const double sc = p.dt*p.beta;
+#pragma unroll
+    for (int r = 0; r < NC; r++) {
+        swe_quad_mass_solve(F, b[r]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const swe_rsrc_t ro = swe_rsrc(p.out + (size_t)4*r*S);
+            swe_st(ro, k8, i*S8, swe_ld(ro, k8, i*S8) + sc*b[r][i]);
+        }
+    }
+    }
 }

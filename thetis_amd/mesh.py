@@ -13,7 +13,7 @@ own topology.  Here a mesh is a handful of numpy arrays that go straight to HBM:
 ``cell_nbr_facet`` (N, k) int8   local facet number of the same facet inside the neighbour
 
 Quadrilaterals: parallelograms take the affine kernels (every quadrilateral mesh the reference builds itself is a rectangle
-grid); any other convex quadrilateral the general bilinear ones (no wetting-drying / viscosity / diffusion there).
+grid); any other convex quadrilateral the general bilinear ones.
 
 Conventions [FD-assumed, SURVEY.md A.8]: vertices on a regular grid, 'left' diagonal
 (from (i, j+1) to (i+1, j)), boundary markers 1: x=0, 2: x=Lx, 3: y=0, 4: y=Ly.
