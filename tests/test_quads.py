@@ -234,6 +234,63 @@ def test_baseline_cfg1_quad_unit_rectangle(hip_lib, ref_so):
     assert abs(rerr) < 1e-12
 
 
+def test_project_on_general_quadrilaterals_is_the_l2_projection():
+    """Function.project on warped cells: right-hand side weighted with det J at the Gauss points, true 4 x 4 mass matrix per cell -
+    a bilinear function of the reference coordinates is reproduced, and the projection of x y conserves its integral."""
+    mesh, _, _, _ = quad_case(nx=6, ny=5, lx=3.0, ly=2.0, skew=0.1, warp=0.3)
+    assert not mesh.affine
+    P1DG = get_functionspace(mesh, 'DG', 1)
+    f = Function(P1DG).project(lambda x, y: 2.0 + 0.5*x - 0.25*y)           # affine in x: exactly representable on every cell
+    v = f.cell_node_values()
+    p = mesh.cell_xy()
+    assert np.abs(v - (2.0 + 0.5*p[:, :, 0] - 0.25*p[:, :, 1])).max() < 1e-12
+    g = Function(P1DG).project(lambda x, y: x*y).cell_node_values()
+    orc = make_oracle_generic(mesh, np.ones(mesh.num_vertices))
+    integral = sum(float(np.sum(w*(g @ phi))) for phi, _, w in orc.cell_quad)
+    exact = sum(float(np.sum(w*((p[:, :, 0] @ phi)*(p[:, :, 1] @ phi)))) for phi, _, w in
+                make_oracle_generic(mesh, np.ones(mesh.num_vertices), quad_rule_points=4).cell_quad)
+    assert abs(integral - exact) < 1e-3*abs(exact)         # (the right-hand side is integrated with the 2 x 2 rule)
+
+
+@pytest.mark.gpu
+def test_general_quadrilaterals_through_flowsolver(hip_lib):
+    """FlowSolver2d on a mesh of warped convex quadrilaterals (thetis/solver2d.py:340-345 accepts any quadrilateral mesh): a seiche
+    with bottom friction and an open boundary, 60 steps against the numpy oracle, volume conservation callback on a closed basin."""
+    mesh2d, _, _, _ = quad_case(nx=16, ny=8, lx=8e3, ly=4e3, skew=0.0, warp=0.3)
+    assert not mesh2d.affine
+    x, y = mesh2d.vertex_xy.T
+    bath_v = 10.0 + 2.0*np.sin(x/2e3)
+    for closed in (True, False):
+        bath = Function(get_functionspace(mesh2d, 'CG', 1)).assign(bath_v)
+        s = solver2d.FlowSolver2d(mesh2d, bath)
+        o = s.options
+        o.swe_timestepper_type = 'SSPRK33'
+        o.swe_timestepper_options.use_automatic_timestep = False
+        o.timestep = 2.0
+        o.simulation_end_time = 120.0
+        o.simulation_export_time = 60.0
+        o.no_exports = True
+        o.check_volume_conservation_2d = True
+        kw = {}
+        if not closed:
+            o.manning_drag_coefficient = Constant(0.02)
+            s.bnd_functions['shallow_water'] = {2: {'elev': Constant(0.05)}}
+            kw = dict(manning_drag_coefficient=0.02, bnd_conditions={2: {'elev': 0.05}})
+        s.assign_initial_conditions(elev=lambda x, y: 0.1*np.cos(np.pi*x/8e3))
+        eta0 = s.fields.elev_2d.cell_node_values().copy()
+        s.iterate()
+        assert s.iteration == 60
+        orc = make_oracle_generic(mesh2d, bath_v, **kw)
+        u_o, e_o = np.zeros((mesh2d.num_cells, 4, 2)), eta0
+        for _ in range(60):
+            u_o, e_o = orc.ssprk33_step(u_o, e_o, 2.0)
+        assert rel_linf(s.fields.elev_2d.cell_node_values(), e_o) < 1e-10
+        assert rel_linf(s.fields.uv_2d.cell_node_values(), u_o) < 1e-10
+        if closed:
+            vol, rerr = s.callbacks['export']['volume2d']()
+            assert abs(rerr) < 1e-12 and math.isclose(vol, orc.volume(e_o), rel_tol=1e-12)
+
+
 @pytest.mark.gpu
 def test_quad_two_ranks_on_one_gpu(tmp_path, hip_lib):
     import dist_worker
