@@ -61,6 +61,20 @@ def quads(rng):
     report('cfg4 quadrilaterals tracer only + limiter (demo_2d_tracer mode)', nq, 616.0 + 136.0,
            timed(dev, lambda k: dev.advance_coupled(k, tracer_only=True, use_limiter=True), 50))
     dev.close()
+    # ---- the same SWE step on GENERAL quadrilaterals (vertices moved by up to 20 % of a cell width: Jacobian per Gauss point,
+    #      4 x 4 mass solve per cell - the AFFINE = false kernels)
+    from thetis_amd.mesh import Mesh2d
+    xy = meshq.vertex_xy.copy()
+    inner = (xy[:, 0] > 1.0) & (xy[:, 0] < 100e3 - 1.0) & (xy[:, 1] > 1.0) & (xy[:, 1] < 100e3 - 1.0)
+    xy[inner] += 20.0*rng.uniform(-1, 1, size=(int(inner.sum()), 2))
+    warped = Mesh2d(xy, meshq.cells, marker_fn=None)
+    warped.cell_nbr = meshq.cell_nbr
+    warped.boundary_len = warped._boundary_length()
+    assert not warped.affine
+    dev = Swe2dDevice(warped, np.full(warped.num_vertices, 20.0), 0.25, boundary_len=warped.boundary_len)
+    dev.set_state(1e-3*rng.uniform(-1, 1, size=(nq, 4, 2)), etaq)
+    report('general quadrilaterals SWE (bilinear map, 4x4 mass solve)', nq, 936.0, timed(dev, dev.advance, 50))
+    dev.close()
 
 
 def cfg5(steps=50, profile_only=False):
