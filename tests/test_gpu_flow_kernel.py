@@ -73,6 +73,31 @@ def test_flow_launch_gives_the_bits_of_the_stage_launches(hip_lib, case):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize('poll', ['auto', '8', '9'])
+def test_flow_polling_width_follows_the_widest_block(hip_lib, monkeypatch, poll):
+    """A flow order in which some block has more than 64 rim facets (a mesh whose width is no multiple of the 16-quad tiles: the
+    partial tiles at the edge make such blocks) takes the kernel instance with nine granule loads per lane and polling trip - a
+    block that needs a second trip per pass paces the whole launch.  Same bits with eight (two trips) and nine loads, on a mesh
+    with and on one without wide blocks; THETIS_AMD_FLOW_POLL forces the choice."""
+    if poll != 'auto':
+        monkeypatch.setenv('THETIS_AMD_FLOW_POLL', poll)
+    for nx, ny in ((67, 31), (128, 64)):            # widest block: 67 / 36 rim facets
+        mesh, bath, uv, eta = channel_case(nx=nx, ny=ny, seed=3)
+        out = []
+        for flow in (False, True):
+            dev = _device(mesh, bath, 0.05)
+            dev.set_state(uv, eta)
+            ends = [dev.n_cells]*9
+            if flow:
+                dev.solve_flow(ends)
+            else:
+                _by_stage(dev, ends)
+            out.append(dev.get_state())
+            assert dev.flow_timeouts() == 0
+            dev.close()
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize('shape', ['shrinking', 'ragged'])
 def test_flow_launch_on_shrinking_ranges(hip_lib, shape):
     """The ranges of an exchange cycle: stage s updates [0, end_s), ends non-increasing and not block-aligned, every cell of a

@@ -131,6 +131,7 @@ struct Handle {
     size_t flow_ex_bytes = 0;
     int flow_blocks = 0;                                // 64-cell blocks of the handle
     int flow_capacity = -1;                             // resident one-wave workgroups of the flow kernel on this device (-1: not asked yet)
+    int flow_max_rim = 0;                               // most rim facets of a block in the current flow order (selects the polling width)
     int launch_parity = 0;                              // direction of the next large stage launch (launch_stage)
     bool flow_used = false;                             // a flow launch since the status word was last read
     double flow_timeout_s = 2.0;                        // THETIS_AMD_FLOW_TIMEOUT_S
@@ -488,6 +489,7 @@ int flow_build(Handle *h, const int32_t *order)
     std::vector<int2> blk((size_t)nb, int2{0, 0});
     int n_slots = 0;
     bool too_many = false;
+    int max_rim = 0;
     std::vector<Rim> rim;
     for (int b = 0; b < nb; b++) {
         rim.clear();
@@ -499,6 +501,7 @@ int flow_build(Handle *h, const int32_t *order)
         std::sort(rim.begin(), rim.end(), [](const Rim &x, const Rim &y) {
             return x.nbblock != y.nbblock ? x.nbblock < y.nbblock : (x.pos != y.pos ? x.pos < y.pos : x.f < y.f); });
         if ((int)rim.size() > SWE_FLOW_MAX_RIM) too_many = true;      // the kernel's staging area holds SWE_FLOW_MAX_RIM facets
+        max_rim = std::max(max_rim, (int)rim.size());
         blk[b] = int2{n_slots, (int)rim.size()};
         for (const Rim &r : rim) own[(size_t)3*r.pos + r.f] = n_slots++;
     }
@@ -547,6 +550,8 @@ int flow_build(Handle *h, const int32_t *order)
     // locality), or slot numbers that do not fit
     if (too_many || !((size_t)3*n_slots*SWE_FLOW_SLOT_BYTES < ((size_t)1 << 31) && n_slots < (1 << 25))) return SWE2D_OK;
     h->flow_fpos = fpos;
+    h->flow_max_rim = max_rim;
+    if (const char *e = std::getenv("THETIS_AMD_FLOW_POLL")) h->flow_max_rim = std::atoi(e) > 8 ? 65 : std::min(max_rim, 64);   // A/B, tests
     h->flow_x_ready = false;
     h->flow_parity_bytes = (unsigned)((size_t)std::max(n_slots, 1)*SWE_FLOW_SLOT_BYTES);
     h->flow_ex_bytes = (size_t)3*h->flow_parity_bytes;
@@ -569,16 +574,22 @@ int flow_build(Handle *h, const int32_t *order)
 
 // ---- dataflow stage loop (swe2d_flow.h)
 typedef void (*flow_kernel_t)(const SweFlowArgs);
-template <bool NL, bool LF>
+template <bool NL, bool LF, int POLL>
 flow_kernel_t pick_flow_src(bool src, bool fx)
 {
-    if (fx) return src ? swe_flow_kernel<NL, LF, true, true> : swe_flow_kernel<NL, LF, false, true>;
-    return src ? swe_flow_kernel<NL, LF, true, false> : swe_flow_kernel<NL, LF, false, false>;
+    if (fx) return src ? swe_flow_kernel<NL, LF, true, true, POLL> : swe_flow_kernel<NL, LF, false, true, POLL>;
+    return src ? swe_flow_kernel<NL, LF, true, false, POLL> : swe_flow_kernel<NL, LF, false, false, POLL>;
 }
-flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src, bool fx = false)
+template <int POLL>
+flow_kernel_t pick_flow_poll(bool nl, bool lf, bool src, bool fx)
 {
-    return nl ? (lf ? pick_flow_src<true, true>(src, fx) : pick_flow_src<true, false>(src, fx))
-              : (lf ? pick_flow_src<false, true>(src, fx) : pick_flow_src<false, false>(src, fx));
+    return nl ? (lf ? pick_flow_src<true, true, POLL>(src, fx) : pick_flow_src<true, false, POLL>(src, fx))
+              : (lf ? pick_flow_src<false, true, POLL>(src, fx) : pick_flow_src<false, false, POLL>(src, fx));
+}
+// wide: some block of the flow order has more than 64 rim facets (one more granule load per lane and polling trip)
+flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src, bool fx = false, bool wide = false)
+{
+    return wide ? pick_flow_poll<9>(nl, lf, src, fx) : pick_flow_poll<8>(nl, lf, src, fx);
 }
 
 // the configurations the flow kernel covers (the step kernel's: triangles, no wetting-drying, no viscosity)
@@ -595,7 +606,7 @@ int flow_capacity(Handle *h)
     if (h->flow_capacity >= 0) return h->flow_capacity;
     h->flow_capacity = 0;
     int per_cu = 0, dev_cus = 0;
-    flow_kernel_t kern = pick_flow_kernel(true, true, true, true);     // the largest variant
+    flow_kernel_t kern = pick_flow_kernel(true, true, true, true, true);     // the largest variant
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), SWE_BLOCK, 0) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) return 0;
     if (const char *e = std::getenv("THETIS_AMD_FLOW_CAPACITY")) h->flow_capacity = std::atoi(e);      // tests: force the limit
@@ -697,7 +708,8 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles =
     for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) q.cell_end[s] = s < n_stages ? cell_end[s] : 0;
     for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
     q.timeout_ticks = (unsigned long long)(h->flow_timeout_s*1e8);
-    flow_kernel_t kern = pick_flow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h), fx);
+    flow_kernel_t kern = pick_flow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h), fx,
+                                          h->flow_max_rim > 64);
     SWE_CHK_SYNC(h->stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, q);
     HIP_TRY(h, hipGetLastError());

@@ -322,7 +322,12 @@ __device__ __forceinline__ void swe_flow_finish(const SweStageArgs &p, int k, do
 // cycle's start long before its neighbours have read its last stage results - it may overwrite its previous INPUT (read by stage 0
 // of the previous cycle, which every neighbour that needs it has finished before this rank's push, hence before the flags that
 // lets this block start the cycle: it also waits for this rank's own previous push to be complete) but nothing else.
-template <bool NONLIN, bool LF, bool SRC, bool FX>
+// POLL: granule loads per lane in flight in a polling trip = POLL*8 rim facets per trip (8 granules per facet, 64 lanes).  The block
+// with the most rim facets sets the pace of the whole launch, and a block that needs a second trip per pass (+1.3 us per stage)
+// slowed a 131 k-cell mesh from 18.7 to 22.1 us per step; a ninth load in EVERY block costs 0.3 us per step (its issue slot and its
+// place in the return queue, even when all lanes point nowhere).  The host picks POLL = 8 when no block of the flow order has more
+// than 64 rim facets, 9 otherwise (launch_flow); same results either way.
+template <bool NONLIN, bool LF, bool SRC, bool FX, int POLL = 8>
 __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(const SweFlowArgs q)
 {
 #pragma clang fp contract(off)
@@ -586,11 +591,11 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                 __syncthreads();                               // the incoming list / the previous stage's staging reads
                 for (unsigned spins = 0;; spins++) {
                     bool ok = true;
-                    for (int c0 = 0; c0 < 8*nrim; c0 += 8*SWE_BLOCK) {         // eight loads per lane in flight (64 rim facets per trip)
-                        swe_u32x3 gr[8];
-                        int ent[8];
+                    for (int c0 = 0; c0 < 8*nrim; c0 += POLL*SWE_BLOCK) {      // POLL loads per lane in flight (8*POLL rim facets per trip)
+                        swe_u32x3 gr[POLL];
+                        int ent[POLL];
 #pragma unroll
-                        for (int j = 0; j < 8; j++) {
+                        for (int j = 0; j < POLL; j++) {
                             const int t = c0 + j*SWE_BLOCK + lane;
                             ent[j] = t < 8*nrim ? xsrc[SWE_LDSI(t >> 3, SWE_FLOW_MAX_RIM)] : -1;
                             // a cell outside this stage's range needs nothing (and its neighbour may never have published)
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                                                                   : SWE_FLOW_NOWHERE);
                         }
 #pragma unroll
-                        for (int j = 0; j < 8; j++) {
+                        for (int j = 0; j < POLL; j++) {
                             const int t = c0 + j*SWE_BLOCK + lane;
                             if (ent[j] >= 0) {
                                 ok = ok && (int)(gr[j].z - need) >= 0;
