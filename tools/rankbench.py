@@ -27,6 +27,8 @@ def main():
     ap.add_argument('--flow', type=int, default=-1, help='1 / 0: the stages of a cycle as one dataflow launch (csrc/swe2d_flow.h) / stage launches (default: the solver decides)')
     ap.add_argument('--flowx', type=int, default=-1, help='1 / 0: the exchange inside the flow launches / separate push and unpack kernels')
     ap.add_argument('--nx', type=int, default=0, help='mesh RectangleMesh(nx, nx/2) instead of the bench mesh')
+    ap.add_argument('--timing', action='store_true', help='-DSWE_WAVE_TIMING -DSWE_FLOW_TS_STAGE=S build of the library (THETIS_AMD_LIB): '
+                    "per-block time stamps of stage S of the last flow launch, by the block's role")
     args = ap.parse_args()
     import torch
     import bench
@@ -83,6 +85,38 @@ def main():
         s.synchronize()
         best = min(best, time.perf_counter() - t0)
     to = s.p2p.timeouts() if s.p2p is not None else 0
+    if args.timing:
+        import ctypes
+        import numpy as np
+        fn = s.dev.lib.swe2d_debug_read_wave_timing
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        ts = np.zeros((6, 8192), dtype=np.uint64)
+        s.dev._ck(fn(s.dev.h, ts.ctypes.data))
+        nb = (p.num_cells + 63)//64
+        t = ts[:5, :nb].astype(np.int64)
+        prev = (ts[5, :nb] & np.uint64(0xffffffffffff)).astype(np.int64)
+        # the blocks' roles, from the flow order the solver set (device ids -> flow position)
+        from thetis_amd import ordering
+        order = np.asarray(ordering.auto_cell_order(p, 0, p.num_cells))
+        pos = np.empty(p.num_cells, dtype=np.int64)
+        pos[order] = np.arange(p.num_cells)
+        blk = pos//64
+        role = np.zeros(nb, dtype=np.int64)                      # 1 ghost, 2 send, 4 boundary
+        role[np.unique(blk[p.n_owned:])] |= 1
+        role[np.unique(blk[np.asarray(p.send_cells)])] |= 2
+        role[np.unique(blk[(np.asarray(p.cell_nbr) < 0).any(axis=1)])] |= 4
+        ok = (t[0] > 0) & (prev > 0) & (t[4] >= t[0])
+        us = lambda x: 0.01*x
+        out = {}
+        for name, sel in (('all', ok), ('interior', ok & (role == 0)), ('ghost', ok & ((role & 1) != 0)), ('send', ok & ((role & 2) != 0)),
+                          ('boundary only', ok & (role == 4))):
+            if not sel.any():
+                continue
+            q = lambda x: [round(float(v), 2) for v in np.percentile(us(x[sel]), [10, 50, 90, 100])]
+            out[name] = {'blocks': int(sel.sum()), 'gap_prev_publish_to_stage_top': q(t[0] - prev), 'wait': q(t[1] - t[0]),
+                         'arith': q(t[3] - t[2]), 'publish': q(t[4] - t[3]), 'period_prev_publish_to_publish': q(t[4] - prev)}
+        print(json.dumps({'timing_p10_p50_p90_max_us': out}))
     print(json.dumps({'exchange': args.exchange, 'split': not args.nosplit, 'p2p_timeouts': to,
                       'world': args.world, 'rank': args.rank, 'every': args.every, 'overlap': args.overlap, 'n_owned': int(p.n_owned),
                       'n_ghost': int(p.n_ghost), 'n_send': int(len(p.send_cells)), 'graph': s.graphed, 'graph_mode': s.graph_mode, 'flow': bool(s.flow), 'flow_exchange': bool(s.flow_exchange), 'flow_timeouts': s.dev.flow_timeouts(),
