@@ -117,6 +117,15 @@ def main():
             out[name] = {'blocks': int(sel.sum()), 'gap_prev_publish_to_stage_top': q(t[0] - prev), 'wait': q(t[1] - t[0]),
                          'arith': q(t[3] - t[2]), 'publish': q(t[4] - t[3]), 'period_prev_publish_to_publish': q(t[4] - prev)}
         print(json.dumps({'timing_p10_p50_p90_max_us': out}))
+        dump = os.environ.get('RANKBENCH_TIMING_DUMP')
+        if dump:                                                  # raw stamps (10 ns ticks) for offline analysis
+            nbr = np.asarray(p.cell_nbr)
+            rim = np.zeros(nb, dtype=np.int64)
+            for f in range(nbr.shape[1]):
+                okf = nbr[:, f] >= 0
+                a, b = blk[np.nonzero(okf)[0]], blk[nbr[okf, f]]
+                np.add.at(rim, a[a != b], 1)
+            np.savez(dump, t=t, prev=prev, role=role, rim=rim, n_owned=p.n_owned, blk=blk)
     print(json.dumps({'exchange': args.exchange, 'split': not args.nosplit, 'p2p_timeouts': to,
                       'world': args.world, 'rank': args.rank, 'every': args.every, 'overlap': args.overlap, 'n_owned': int(p.n_owned),
                       'n_ghost': int(p.n_ghost), 'n_send': int(len(p.send_cells)), 'graph': s.graphed, 'graph_mode': s.graph_mode, 'flow': bool(s.flow), 'flow_exchange': bool(s.flow_exchange), 'flow_timeouts': s.dev.flow_timeouts(),
