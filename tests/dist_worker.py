@@ -17,6 +17,8 @@ def _case():
     from helpers import channel_case, delaunay_case, quad_case
     if CASE == 'quad':
         return quad_case(nx=16, ny=6, seed=21, amp_eta=0.3, amp_u=0.2)
+    if CASE == 'quadgen':                        # general (non-parallelogram) convex cells
+        return quad_case(nx=16, ny=6, seed=21, amp_eta=0.3, amp_u=0.2, warp=0.3)
     if CASE == 'delaunay':
         mesh, bath, uv, eta = delaunay_case(n_points=600, lx=100e3, ly=60e3, seed=7)
         return mesh, bath, 0.1*uv, 0.1*eta

@@ -292,13 +292,16 @@ def test_general_quadrilaterals_through_flowsolver(hip_lib):
 
 
 @pytest.mark.gpu
-def test_quad_two_ranks_on_one_gpu(tmp_path, hip_lib):
+@pytest.mark.parametrize('kind', ['quad', 'quadgen'])
+def test_quad_two_ranks_on_one_gpu(tmp_path, hip_lib, kind):
+    """Strip partitions of a quadrilateral mesh (``quadgen``: general convex cells), two ranks sharing one GPU == one device, bitwise."""
     import dist_worker
     from thetis_amd.device import Swe2dDevice
-    dist_worker.CASE = 'quad'
+    dist_worker.CASE = kind
     try:
         mesh, bath, uv, eta = dist_worker._case()
-        dist_worker.run_workers(dist_worker.gpu_worker, 2, 3, str(tmp_path), axis=0, case='quad')
+        assert mesh.affine == (kind == 'quad')
+        dist_worker.run_workers(dist_worker.gpu_worker, 2, 3, str(tmp_path), axis=0, case=kind)
         u_p, e_p, _ = dist_worker.gather(str(tmp_path), 2, mesh.num_cells)
     finally:
         dist_worker.CASE = 'channel'
