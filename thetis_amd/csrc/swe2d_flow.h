@@ -248,7 +248,8 @@ __device__ __forceinline__ void swe_flow_rhs(const SweStageArgs &p, int k, const
 }
 
 // mass inverse, Shu-Osher combine and the boundary facets of the cell (the BINL pass of swe_stage_kernel)
-template <bool NONLIN, bool LF>
+// (WALLFAST: the closed-wall path of swe_boundary_facet; not in the variants with source terms - no registers to spare, 68 B of scratch)
+template <bool NONLIN, bool LF, bool WALLFAST>
 __device__ __forceinline__ void swe_flow_finish(const SweStageArgs &p, int k, double beta, const double u[3], const double v[3],
                                                 const double e[3], const double h[3], const double nx[3], const double ny[3],
                                                 double twoA, int bmarkers, int bkind1, const double bu[3], const double bv[3], const double be[3],
@@ -284,7 +285,7 @@ __device__ __forceinline__ void swe_flow_finish(const SweStageArgs &p, int k, do
             double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
             const double Ha_ = !NONLIN ? SWE_SEL3(h, a) : SWE_SEL3(h, a) + SWE_SEL3(e, a);
             const double Hb_ = !NONLIN ? SWE_SEL3(h, b) : SWE_SEL3(h, b) + SWE_SEL3(e, b);
-            swe_boundary_facet<NONLIN, LF, false>(p, (bmarkers >> (8*f)) & 0xff, k, a, b, SWE_SEL3(u, a), SWE_SEL3(u, b), SWE_SEL3(v, a),
+            swe_boundary_facet<NONLIN, LF, false, WALLFAST>(p, (bmarkers >> (8*f)) & 0xff, k, a, b, SWE_SEL3(u, a), SWE_SEL3(u, b), SWE_SEL3(v, a),
                                                   SWE_SEL3(v, b), SWE_SEL3(e, a), SWE_SEL3(e, b), SWE_SEL3(h, a), SWE_SEL3(h, b),
                                                   Ha_, Hb_, 0.0, 0.0, nxs, nys, Lf, rLf, Fau, Fbu, Fav, Fbv, Fae, Fbe, kind_next);
             kind_next = -1;
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             // (a lane outside the stage's range has no boundary facets to do: the outermost ghost layer of a partition, which is in no
             //  stage's range, points its missing neighbours at a wall - unmasked, every block that holds such a cell ran the boundary
             //  pass in every stage, +0.8 us for the 300 blocks next to the cuts of a rank of eight)
-            swe_flow_finish<NONLIN, LF>(p, k, q.beta[i3], u, v, e, h, nx, ny, twoA, act ? bmarkers : 0, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
+            swe_flow_finish<NONLIN, LF, !SRC>(p, k, q.beta[i3], u, v, e, h, nx, ny, twoA, act ? bmarkers : 0, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
 #ifdef SWE_WAVE_TIMING
             if (ou[0] == 1.2345e300) return;          // the arithmetic has to be finished before the time stamp
             SWE_FT(3);

@@ -333,7 +333,7 @@ __device__ __forceinline__ void swe_boundary_flux(const SweStageArgs &p, int mar
 }
 
 // Both quadrature points of a boundary facet; kept out of line of the interior fast path (few cells take it).
-template <bool NONLIN, bool LF, bool WD>
+template <bool NONLIN, bool LF, bool WD, bool WALLFAST = true>
 __device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int marker, int k, int a, int b, double ua,
                                                    double ub, double va,
                                                    double vb, double ea, double eb, double ha, double hb, double Ha,
@@ -346,6 +346,36 @@ __device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int ma
     // (kind_in >= 0: the marker's table entry, already fetched by the caller together with its other loads)
     const int kind_all = kind_in >= 0 ? kind_in : ((marker < SWE_MAX_MARKERS) ? p.bc.kind[marker] : 0);
     const int kind = kind_all & 0xff;
+#ifndef SWE_NO_WALL_FAST_PATH
+    if (WALLFAST && kind_all == 0) {
+        // Closed wall without boundary drag - what most boundary facets are, and in a dataflow launch the blocks that own them set
+        // the pace: the land branch of swe_boundary_flux (shallowwater_eq.py:377-381, :489-497) operation for operation, without
+        // the interpolation of boundary data that is not there and the tests of the boundary kind.  Same bits as the general path.
+        const double g = p.g;
+        const double rg = swe_rcp(g);
+        const double nx = nxs*rL, ny = nys*rL;
+#pragma unroll 1
+        for (int q = 0; q < 2; q++) {
+            const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+            const double uq = swe_dot2(xa, ua, xb, ub), vq = swe_dot2(xa, va, xb, vb), eq = swe_dot2(xa, ea, xb, eb);
+            const double Hq = swe_dot2(xa, Ha, xb, Hb);
+            const double un_own = swe_dot2(uq, nx, vq, ny);
+            const double head_rie = eq + swe_sqrt(Hq*rg)*un_own;
+            double fu = g*head_rie*nx;
+            double fv = g*head_rie*ny;
+            if (NONLIN && LF) {
+                const double gamma = 0.5*fabs(un_own)*p.sigma_lf;
+                fu += gamma*2.0*un_own*nx;
+                fv += gamma*2.0*un_own*ny;
+            }
+            fu *= L;
+            fv *= L;
+            Fau += xa*fu; Fbu += xb*fu;
+            Fav += xa*fv; Fbv += xb*fv;
+        }
+        return;
+    }
+#endif
     const size_t S = p.stride;
     double fea = 0.0, feb = 0.0, fua = 0.0, fub = 0.0, fva = 0.0, fvb = 0.0, fna = 0.0, fnb = 0.0, fxa = 0.0, fxb = 0.0;
     const size_t pa = (size_t)(2*a)*S + k, pb = pa + S;            // per-facet planes: facet index = first node a
