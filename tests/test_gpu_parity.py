@@ -481,3 +481,40 @@ def test_alternating_launch_direction_gives_the_same_bits(hip_lib, monkeypatch, 
         dev.close()
     assert np.isfinite(out[0][0]).all()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('config', ['triangles', 'triangles_flow', 'triangles_linear', 'triangles_wd_manning', 'quads', 'quads_wd_manning',
+                                    'quads_general'])
+def test_closed_wall_path_gives_the_bits_of_the_general_boundary_path(hip_lib, monkeypatch, config):
+    """swe_boundary_facet starts with the closed wall without boundary drag as a path of its own (the blocks that own boundary
+    cells set the pace of a dataflow launch); THETIS_AMD_WALL_FAST=0 sends walls through the general path: the same bits, for every
+    kernel family that inlines the boundary code, next to open boundaries and a wall WITH drag (which stay on the general path)."""
+    from helpers import channel_case, quad_case
+    from thetis_amd import _lib
+    from thetis_amd.device import Swe2dDevice
+    quad = config.startswith('quads')
+    if quad:
+        mesh, bath, uv, eta = quad_case(nx=17, ny=9, seed=2, warp=(0.3 if config == 'quads_general' else 0.0))
+    else:
+        mesh, bath, uv, eta = channel_case(nx=23, ny=11, seed=1)
+    wd = config.endswith('wd_manning')
+    out = []
+    for fast in ('1', '0'):
+        monkeypatch.setenv('THETIS_AMD_WALL_FAST', fast)
+        monkeypatch.setenv('THETIS_AMD_FLOW', '1' if config == 'triangles_flow' else '0')
+        dev = Swe2dDevice(mesh, bath - 0.6*bath.max() if wd else bath, 0.05, boundary_len=mesh.boundary_len,
+                          **({'use_nonlinear_equations': False} if config == 'triangles_linear' else {}))
+        m = mesh.boundary_markers
+        dev.set_bc(m[0], {'elev': 0.1})
+        dev.set_bc(m[-1], {'drag': 0.01})
+        if wd:
+            dev.set_wetting_and_drying(0.5)
+            dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+        dev.set_state(0.1*uv, 0.1*np.abs(eta))
+        dev.advance(7)
+        out.append(dev.get_state() + (dev.tendency(),))
+        dev.close()
+    assert np.isfinite(out[0][0]).all() and np.isfinite(out[0][1]).all()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2][0], out[1][2][0]) and np.array_equal(out[0][2][1], out[1][2][1])

@@ -331,6 +331,7 @@ void fill_stage_args(Handle *h, SweStageArgs &a, int in, int u0, int out, double
     a.idx4 = h->idx4; a.idx2 = h->idx2;
     a.cell_begin = c0; a.cell_end = c1;
     a.reverse = 0;
+    { const char *e = std::getenv("THETIS_AMD_WALL_FAST"); a.wall_general = (e && std::atoi(e) == 0) ? 1 : 0; }
     a.wd_skip_relax = (h->wd && h->visc) ? 1 : 0;
     a.g = h->par.g_grav;
     a.sigma_lf = h->par.lax_friedrichs_velocity_scaling_factor;

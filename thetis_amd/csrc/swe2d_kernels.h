@@ -71,6 +71,7 @@ struct SweStageArgs {
     int cell_begin, cell_end;
     int wd_skip_relax;            // wetting-drying + viscosity: the dry-ground relaxation of the velocity follows the viscosity pass
     int reverse;                  // walk the blocks of the range from its end (launches beyond the Infinity Cache alternate, see launch_stage)
+    int wall_general;             // 1: closed walls through the general boundary path (THETIS_AMD_WALL_FAST=0: parity test of the wall path)
     double g, sigma_lf, dt;
     double a0, a1, beta;   // U_out = beta*k + a0*U0 + a1*U_in
     // optional cell-local terms (SRC variant)
@@ -346,8 +347,11 @@ __device__ __forceinline__ void swe_boundary_facet(const SweStageArgs &p, int ma
     // (kind_in >= 0: the marker's table entry, already fetched by the caller together with its other loads)
     const int kind_all = kind_in >= 0 ? kind_in : ((marker < SWE_MAX_MARKERS) ? p.bc.kind[marker] : 0);
     const int kind = kind_all & 0xff;
-#ifndef SWE_NO_WALL_FAST_PATH
-    if (WALLFAST && kind_all == 0) {
+    // (not in the -DSWE_RANGE_CHECK build: there the kernels call a non-inlined checker, and with this early return the
+    //  quadrilateral wetting-drying + source-term instance produced NaN in its third stage - a code generation difference that was
+    //  not chased; the path touches no memory, so the checked build loses nothing by taking the general one)
+#if !defined(SWE_NO_WALL_FAST_PATH) && !defined(SWE_RANGE_CHECK)
+    if (WALLFAST && kind_all == 0 && !p.wall_general) {
         // Closed wall without boundary drag - what most boundary facets are, and in a dataflow launch the blocks that own them set
         // the pace: the land branch of swe_boundary_flux (shallowwater_eq.py:377-381, :489-497) operation for operation, without
         // the interpolation of boundary data that is not there and the tests of the boundary kind.  Same bits as the general path.
