@@ -324,7 +324,7 @@ int  swe2d_solve_stage_cells(swe2d_handle *h, int i_stage, int32_t cell_begin, i
  * index).  Not capturable in a replayed graph across an odd number of swaps. */
 int  swe2d_forward_euler_cells(swe2d_handle *h, int32_t cell_begin, int32_t cell_end);
 int  swe2d_swap_state_buffers(swe2d_handle *h);
-/* n_stages (a multiple of 3, at most 48) consecutive solve_stage calls - i.e. n_stages / 3 calls of ERKGenericShuOsher.advance
+/* n_stages (a multiple of 3, at most 384) consecutive solve_stage calls - i.e. n_stages / 3 calls of ERKGenericShuOsher.advance
  * (rungekutta.py:949-952) - in ONE launch without a grid-wide barrier between the stages (csrc/swe2d_flow.h): stage s updates
  * the cells [0, cell_end[s]) (cell_end non-increasing, and every cell of stage s + 1's range has its facet neighbours inside
  * stage s's range: the shrinking ranges of a partition's exchange cycle, or n_owned throughout), a 64-cell block starts stage
@@ -339,8 +339,8 @@ int  swe2d_swap_state_buffers(swe2d_handle *h);
  * (swe2d_flow_status reads the count without failing). */
 int  swe2d_solve_flow(swe2d_handle *h, int32_t n_stages, const int32_t *cell_end);
 int  swe2d_flow_supported(swe2d_handle *h);
-/* The same with the halo exchange of a partition INSIDE the launch, cell by cell: n_cycles exchange cycles (at most 16) of
- * stages_per_cycle stages each (at most 48 stages in all) on the ranges cell_end[0 .. stages_per_cycle) of ONE cycle.  Needs the
+/* The same with the halo exchange of a partition INSIDE the launch, cell by cell: n_cycles exchange cycles (at most 64) of
+ * stages_per_cycle stages each (at most 384 stages in all) on the ranges cell_end[0 .. stages_per_cycle) of ONE cycle.  Needs the
  * peer-to-peer halo connected with a LAST channel of width 18 (swe2d_p2p_create: nine 16-byte {value, push number} granules per
  * cell; the channel's epoch flags are not used).  Every cycle but the launch's first starts by receiving what the peers pushed at
  * the end of their previous cycle - every ghost cell's lane waits for the nine granules of ITS cell, so a ghost cell is ready as

@@ -196,7 +196,8 @@ def test_advance_takes_the_flow_path_and_matches_the_stage_by_stage_path(hip_lib
         monkeypatch.setenv('THETIS_AMD_FUSED_STEP', '0')
         dev = _device(mesh, bath, 0.05)
         dev.set_state(uv, eta)
-        dev.advance(37)             # three launches of at most 16 steps
+        dev.advance(37)             # one launch (at most 128 steps per launch)
+        dev.advance(263)            # three launches: the stage counters carry over
         res.append(dev.get_state() + (dev.diagnostics(),))
         dev.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])

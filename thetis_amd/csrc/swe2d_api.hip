@@ -665,7 +665,7 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles =
     const bool fx = n_cycles > 0;
     const int total = n_stages*(fx ? n_cycles : 1);
     if (n_stages <= 0 || n_stages % 3 != 0 || total > SWE_FLOW_MAX_STAGES || n_cycles > SWE_FLOW_MAX_CYCLES)
-        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "flow: n_stages must be a multiple of 3, at most 48 stages and 16 cycles per launch");
+        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "flow: n_stages must be a multiple of 3, at most 384 stages and 64 cycles per launch");
     for (int s = 0; s < n_stages; s++)
         if (cell_end[s] < 0 || cell_end[s] > h->n_cells || (s > 0 && cell_end[s] > cell_end[s - 1]))
             return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "flow: the stage ranges must shrink and stay inside the mesh");
@@ -1330,7 +1330,7 @@ int swe2d_advance(swe2d_handle *hh, int n_steps)
         return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_advance on a partition: drive stages + halo exchange from the host");
     HIP_TRY(h, hipSetDevice(h->device));
     RoctxRange range("swe2d_advance");
-    // Up to 16 steps per launch without grid barriers (swe2d_flow.h) where every 64-cell block of the mesh is resident at once
+    // Up to 128 steps per launch without grid barriers (swe2d_flow.h) where every 64-cell block of the mesh is resident at once
     // (<= 131 k cells) and the kernel covers the configuration.  Same box, us/step, three stage launches per step -> flow launches:
     // 15 k cells 16.5 -> 15.3, 62 k 20.1 -> 15.1, 125 k 24.3 -> 18.3 (the one-launch step kernel of round 2, which this replaces:
     // 14.1 / 16.8 / 24.9).  THETIS_AMD_FLOW=0 selects the stage launches (the same bits either way).

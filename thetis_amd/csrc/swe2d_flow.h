@@ -59,8 +59,8 @@
 #ifndef SWE_FLOW_OCCUPANCY
 #define SWE_FLOW_OCCUPANCY __attribute__((amdgpu_waves_per_eu(2, 2)))      // <= 256 VGPRs: two one-wave workgroups per SIMD
 #endif
-#define SWE_FLOW_MAX_STAGES 48             // 16 time steps per launch
-#define SWE_FLOW_MAX_CYCLES 16             // exchange cycles per launch (FX kernels)
+#define SWE_FLOW_MAX_STAGES 384            // 128 time steps per launch
+#define SWE_FLOW_MAX_CYCLES 64             // exchange cycles per launch (FX kernels)
 #ifndef SWE_FLOW_FLAG_STRIDE
 #define SWE_FLOW_FLAG_STRIDE 16           // unsigned words between two blocks' stage counters (64 B)
 #endif

@@ -216,7 +216,7 @@ class DistributedSwe2d(object):
         followed by the exchange: None = where the kernel covers the partition (every block resident at once; shallow water
         only, triangles without wetting-drying / viscosity, no ``overlap_stages``), True = required, False = never.
 
-        ``flow_exchange`` (with ``flow`` and the peer-to-peer transport): the exchange INSIDE the flow launch - up to 16 cycles per
+        ``flow_exchange`` (with ``flow`` and the peer-to-peer transport): the exchange INSIDE the flow launch - up to 64 cycles per
         launch, a cycle starts by reading the ghost cells from the landing zone and ends by pushing the send cells into the
         peers' zones, cell by cell as tagged granules (csrc/swe2d_flow.h, FX kernels: no flag per rank, a ghost cell is ready as
         soon as the peer's block that owns it has finished); the push of an advance's last cycle is received by one unpack kernel
@@ -323,7 +323,7 @@ class DistributedSwe2d(object):
         if self._flow_request is False or os.environ.get('THETIS_AMD_FLOW') == '0':
             return False
         plain = (self.stages_per_step == 3 and not self.tids and not self.tracer_only and self.overlap_stages == 0
-                 and 3*self.exchange_every <= 48)
+                 and 3*self.exchange_every <= 384)
         if not plain or not self.dev.flow_supported():
             if self._flow_request is True:
                 raise ValueError('flow=True: the flow kernel covers SSPRK33 shallow-water-only runs on triangles without wetting-drying, '
@@ -337,13 +337,13 @@ class DistributedSwe2d(object):
         return self.flow and self.p2p is not None and self._flowx_request is not False and os.environ.get('THETIS_AMD_FLOWX') != '0'
 
     def _steps_flow_exchange(self, n_steps, graphed):
-        """``n_steps`` time steps as flow launches with the exchange inside: up to 16 cycles (48 stages) per launch, a shorter
+        """``n_steps`` time steps as flow launches with the exchange inside: up to 64 cycles (384 stages) per launch, a shorter
         trailing cycle in a launch of its own, and one unpack kernel for the last push."""
         dev, p, m = self.dev, self.part, self.exchange_every
         if graphed:
             dev.flow_prepare_exchange()            # tables: never inside the capture of the first launch
         full, rem = divmod(n_steps, m)
-        per_launch = max(1, min(16, 48//(3*m), int(os.environ.get('THETIS_AMD_FLOWX_CYCLES', '16'))))
+        per_launch = max(1, min(64, 384//(3*m), int(os.environ.get("THETIS_AMD_FLOWX_CYCLES", "64"))))
         ends = [p.stage_range(g, depth=3*m) for g in range(3*m)]
         while full > 0:
             nc = min(per_launch, full)
@@ -1126,7 +1126,7 @@ def _timed_region(args, solver, chosen, agree, uv, eta, use_graph, n_total, worl
     per_gpu_bytes = bytes_per_update*n_total/world
     transport = {'p2p': 'peer-to-peer stores into IPC-mapped landing zones ({:} memory) + epoch flags, {:}'.format(
                         solver.p2p.zone_kind if solver.p2p is not None else '',
-                        'made by the flow kernel itself (FX: up to 16 exchange cycles per launch)' if solver.flow_exchange
+                        'made by the flow kernel itself (FX: up to 64 exchange cycles per launch)' if solver.flow_exchange
                         else 'exchange kernels inside the per-cycle HIP graph'),
                  'rccl': 'RCCL batch_isend_irecv between two graph launches',
                  'host': 'gloo through host memory (fallback)'}[ex]
