@@ -438,3 +438,54 @@ def gather(out_dir, world, n_cells):
         extra.append(T)
     assert not np.isnan(uv).any() and not np.isnan(eta).any(), 'some cell is owned by no rank'
     return uv, eta, extra
+
+
+def spmd_worker(rank, world, port, out_dir, name, cpu=True, env=None):
+    """One rank of an UNCHANGED FlowSolver2d user script (tests/spmd_cases.py) under ``world`` ranks: what
+    ``python -m torch.distributed.run --nproc-per-node world script.py`` starts.  ``cpu``: the host stand-in device
+    (tests/cpu_device.py) instead of the HIP library; on the GPU all ranks share device 0 (gloo control plane, p2p / host halos)."""
+    import pickle
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank), 'WORLD_SIZE': str(world),
+                       'LOCAL_RANK': str(rank), 'LOCAL_WORLD_SIZE': str(world), 'THETIS_AMD_DIST_BACKEND': 'gloo'})
+    os.environ.update(env or {})
+    from thetis_amd import solver2d
+    if cpu:
+        from cpu_device import CpuSwe2dDevice
+        solver2d.FlowSolver2d._device_cls = CpuSwe2dDevice
+    import spmd_cases
+    res = spmd_cases.run(name, os.path.join(out_dir, 'out_w{:d}'.format(world)))
+    with open(os.path.join(out_dir, 'res_w{:d}_r{:d}.pkl'.format(world, rank)), 'wb') as f:
+        pickle.dump(res, f)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_spmd(world, out_dir, name, cpu=True, env=None, timeout=600):
+    """spawn ``world`` ranks of ``spmd_worker``; returns the per-rank result dictionaries"""
+    import multiprocessing as mp
+    import pickle
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=spmd_worker, args=(r, world, port, out_dir, name, cpu, env)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+    for p in procs:
+        if p.is_alive():
+            for q in procs:
+                if q.is_alive():
+                    q.terminate()
+            raise RuntimeError('spmd worker timed out')
+        assert p.exitcode == 0, 'spmd worker failed with exit code {:}'.format(p.exitcode)
+    out = []
+    for r in range(world):
+        with open(os.path.join(out_dir, 'res_w{:d}_r{:d}.pkl'.format(world, r)), 'rb') as f:
+            out.append(pickle.load(f))
+    return out

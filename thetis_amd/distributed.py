@@ -180,7 +180,7 @@ class DistributedSwe2d(object):
     def __init__(self, mesh, bathymetry_vertex, dt, rank, world_size, device_id, owner=None, host_staged=False,
                  n_tracers=0, use_limiter=True, tracer_only=False, exchange_every=1, overlap_stages=0,
                  graph_mode=None, stepper='SSPRK33', exchange=None, split_last_stage=True, group=None, partition=None,
-                 combined_exchange=False, flow=None, flow_exchange=None, **opts):
+                 combined_exchange=False, flow=None, flow_exchange=None, device_cls=None, **opts):
         """``n_tracers`` > 0: the coupled step of GeneralCoupledTimeIntegrator2D.advance (coupled_timeintegrator_2d.py:
         93-113) on the partition - shallow water step, then every tracer with the updated velocity, then the limiter.
         The vertex-based limiter needs every cell around a vertex, so coupled runs with the limiter use four ghost layers
@@ -226,9 +226,13 @@ class DistributedSwe2d(object):
         ``partition``: a LocalPartition already built for this rank with the halo depth the other arguments imply.
         ``split_last_stage`` = False: the last stage of a cycle is ONE launch over the owned cells followed by the send
         (one launch fewer per cycle, the exchange latency is exposed) instead of send cells first / interior during the
-        exchange.  ``group``: process group of the exchange and the reductions (default: the world group)."""
+        exchange.  ``group``: process group of the exchange and the reductions (default: the world group).
+        ``device_cls``: the class of the per-rank handle (default ``Swe2dDevice`` = the HIP library; tests/cpu_device.py passes a
+        host stand-in with ``is_host = True`` to run this class's launch schedule and exchange logic without a GPU)."""
         import torch
         from .device import Swe2dDevice
+        device_cls = Swe2dDevice if device_cls is None else device_cls
+        self._on_gpu = not getattr(device_cls, 'is_host', False)
         self.rank, self.world = rank, world_size
         self.group = group
         # default: strips (<= 2 peers = one xGMI link each); pass owner=rcb_owner(mesh, n) for compact parts of a general mesh
@@ -274,14 +278,21 @@ class DistributedSwe2d(object):
         else:
             self.part = build_partition(mesh, owner, rank)
         p = self.part
-        torch.cuda.set_device(device_id)
-        self.torch_device = torch.device('cuda', device_id)
-        self.dev = Swe2dDevice(p, np.asarray(bathymetry_vertex)[p.vertex_global], dt, device_id=device_id,
-                               n_owned=p.n_owned, boundary_len=p.boundary_len, ranges=p.reorder_ranges(), **opts)
+        if self._on_gpu:
+            torch.cuda.set_device(device_id)
+            self.torch_device = torch.device('cuda', device_id)
+        else:
+            self.torch_device = torch.device('cpu')
+            if self.exchange != 'host':
+                raise ValueError("a host stand-in device exchanges through host memory: exchange='host'")
+        self.dev = device_cls(p, np.asarray(bathymetry_vertex)[p.vertex_global], dt, device_id=device_id,
+                              n_owned=p.n_owned, boundary_len=p.boundary_len, ranges=p.reorder_ranges(), **opts)
         self.dev.halo_setup(p.send_cells, p.recv_cells)
         self._flow_request = flow
         self._flowx_request = flow_exchange
-        if flow is not False and self.dev.npc == 3:
+        self._flow_now = None                    # the rank-collective decision of the current advance() (see _decide_flow)
+        self._shared_device = None               # do several ranks step on this GPU?  (found out at the first automatic decision)
+        if flow is not False and self.dev.npc == 3 and self._on_gpu:
             # the flow kernel's blocks: all local cells (owned + ghost layers) in one locality order, so that a ghost cell
             # shares its block with the cells it touches (in the device numbering - ghost layers appended layer by layer - a
             # block of ghost cells has more rim facets than the kernel's staging area holds)
@@ -293,11 +304,14 @@ class DistributedSwe2d(object):
         if self.exchange == 'p2p':
             self.p2p = P2PHalo(self.dev, p, rank, world_size, n_tracers=n_tracers, group=group)
         else:
-            staged = self.exchange == 'host'
+            staged = self.exchange == 'host' and self._on_gpu       # a host stand-in's buffers are CPU tensors already
             self.halo = HaloExchanger(p, self.torch_device, host_staged=staged, group=group)
             self.thalo = HaloExchanger(p, self.torch_device, host_staged=staged, width=p.cells.shape[1], group=group) if n_tracers else None
-        self.stream = torch.cuda.Stream(device=self.torch_device)
-        self.dev.set_stream(self.stream.cuda_stream)
+        if self._on_gpu:
+            self.stream = torch.cuda.Stream(device=self.torch_device)
+            self.dev.set_stream(self.stream.cuda_stream)
+        else:
+            self.stream = None
         self.graph = None
         self.graph_steps = 0
         # 'cycle' (default): HIP graphs of the kernel sequences of a cycle - with 'p2p' the whole cycle incl. the exchange
@@ -311,16 +325,17 @@ class DistributedSwe2d(object):
             raise ValueError("graph_mode / THETIS_AMD_GRAPH_MODE must be 'cycle', 'full' or 'none'")
         if self.exchange == 'host' and self.graph_mode == 'full':
             self.graph_mode = 'cycle'       # a host-staged exchange synchronises the stream: never inside a capture
+        if not self._on_gpu:
+            self.graph_mode = 'none'
         self._cycle_graphs = {}
 
     def close(self):
         self.dev.close()
 
-    @property
-    def flow(self):
-        """True when a cycle runs as one dataflow launch (see ``flow``); evaluated per call: the device configuration (source
-        terms, viscosity, wetting-drying) may be set after construction."""
-        if self._flow_request is False or os.environ.get('THETIS_AMD_FLOW') == '0':
+    def _flow_local(self):
+        """This rank's own answer to "does a cycle run as one dataflow launch?" (see ``flow``); evaluated per call: the device
+        configuration (source terms, viscosity, wetting-drying) may be set after construction."""
+        if self._flow_request is False or os.environ.get('THETIS_AMD_FLOW') == '0' or not self._on_gpu:
             return False
         plain = (self.stages_per_step == 3 and not self.tids and not self.tracer_only and self.overlap_stages == 0
                  and 3*self.exchange_every <= 384)
@@ -330,6 +345,54 @@ class DistributedSwe2d(object):
                                  'viscosity and overlap_stages, on partitions whose 64-cell blocks are all resident at once')
             return False
         return True
+
+    def _ranks_share_a_device(self):
+        """Do two ranks of the group step on the same GPU?  (one all-gather, once.)  The flow kernel needs every block of a launch
+        resident at once; its capacity check assumes the device is this rank's alone."""
+        if self._shared_device is None:
+            import socket
+            import torch
+            import torch.distributed as dist
+            prop = torch.cuda.get_device_properties(self.torch_device)
+            ident = (socket.gethostname(), str(getattr(prop, 'uuid', '')), getattr(prop, 'pci_bus_id', -1),
+                     getattr(prop, 'pci_device_id', -1), getattr(prop, 'pci_domain_id', -1),
+                     os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('ROCR_VISIBLE_DEVICES', '')), self.torch_device.index)
+            everyone = [None]*self.world
+            dist.all_gather_object(everyone, ident, group=self.group)
+            self._shared_device = len(set(everyone)) < len(everyone)
+        return self._shared_device
+
+    def _decide_flow(self):
+        """The decision all ranks take TOGETHER at the start of an ``advance`` (collective when world > 1 and the choice is not
+        ``flow=False``): a rank whose partition the kernel does not cover (one ghost side more than its neighbour, just over the
+        resident capacity) would otherwise wait for stage-launch halos while its peers push flow granules, and every wait would
+        run into its timeout.  Automatic choice (``flow=None``): only where every rank is covered and no two ranks share a GPU,
+        agreed anew at every ``advance`` (the configuration may have changed in between, on every rank alike); ``flow=True``:
+        agreed once, a rank that is not covered makes all ranks raise."""
+        import torch.distributed as dist
+        if self._flow_request is False or self.world == 1:
+            self._flow_now = self._flow_local()
+            return self._flow_now
+        if self._flow_request is True:
+            if self._flow_now is None:
+                try:
+                    ok = self._flow_local()
+                except ValueError:
+                    ok = False
+                if self._all_reduce([1.0 if ok else 0.0], dist.ReduceOp.MIN)[0] < 0.5:
+                    raise ValueError('flow=True: the flow kernel does not cover the partition of every rank (rank {:d}: {:})'.format(
+                        self.rank, 'covered' if ok else 'not covered'))
+                self._flow_now = True
+            return self._flow_now
+        ok = self._flow_local() and not self._ranks_share_a_device()
+        self._flow_now = bool(self._all_reduce([1.0 if ok else 0.0], dist.ReduceOp.MIN)[0] > 0.5)
+        return self._flow_now
+
+    @property
+    def flow(self):
+        """True when a cycle runs as one dataflow launch (see ``flow``): the ranks' common decision of the last ``advance``, before
+        the first one this rank's own answer."""
+        return self._flow_local() if self._flow_now is None else self._flow_now
 
     @property
     def flow_exchange(self):
@@ -605,10 +668,15 @@ class DistributedSwe2d(object):
             self._cycle_swe(r, early_done=early, early_next=nxt, graphed=graphed)
             early = nxt
 
-    def advance(self, n_steps, use_graph=True):
-        """``n_steps`` SSPRK33 steps (enqueued; call ``synchronize``)."""
+    def _stream_ctx(self):
+        import contextlib
         import torch
-        with torch.cuda.stream(self.stream):
+        return torch.cuda.stream(self.stream) if self._on_gpu else contextlib.nullcontext()
+
+    def advance(self, n_steps, use_graph=True):
+        """``n_steps`` SSPRK33 steps (enqueued; call ``synchronize``).  COLLECTIVE: every rank calls it with the same count."""
+        self._decide_flow()
+        with self._stream_ctx():
             if not use_graph or self.graph_mode == 'none' or os.environ.get('THETIS_AMD_NO_GRAPH'):
                 self._steps_eager(n_steps)
                 return
@@ -622,6 +690,101 @@ class DistributedSwe2d(object):
             else:
                 self._steps_eager(n_steps)
 
+    # ---- one time step stage by stage (the host runs ``update_forcings`` between the stages, rungekutta.py:933-934)
+    def _one_step_ops(self):
+        """The launches of ONE time step keyed by what the host asks for: ('swe', i) | ('tracer', t, i) | ('limit', t) -> callable.
+        Every field is exchanged right after its last launch of the step (the state after stage 3, a tracer after its limiter),
+        so that between two host calls nothing is in flight and the ghost layers a later launch reads are valid: with per-step
+        exchanges the ranges are those of ``_cycle_swe(1)`` / ``_step_tracer``, on the deep halos of combined cycles those of a
+        one-step ``coupled_cycle_schedule``.  Bitwise the batched ``advance`` (same launches on the same ranges; a received ghost
+        value is bitwise the redundantly computed one it replaces)."""
+        if getattr(self, '_step_ops', None) is not None:
+            return self._step_ops
+        dev, p, sps = self.dev, self.part, self.stages_per_step
+        fe = sps == 1
+        ops = {}
+
+        def exchange(channel, i_buffer=0):
+            self._receive(channel, i_buffer, self._send(channel, i_buffer))
+        if self.coupled_cycles:
+            last_tracer_op = {}
+            for op in self._coupled_ops(1):
+                if op[0] == 'swe':
+                    _, i, end = op
+                    if fe:
+                        def run(end=end):
+                            dev.forward_euler_cells(0, end)
+                            dev.swap_state_buffers()
+                            exchange(0)
+                    elif i == sps - 1:
+                        def run(i=i, end=end):
+                            dev.solve_stage_cells(i, 0, end)
+                            exchange(0)
+                    else:
+                        def run(i=i, end=end):
+                            dev.solve_stage_cells(i, 0, end)
+                    ops[('swe', i)] = run
+                elif op[0] == 'tracer':
+                    _, t, i, end = op
+
+                    def run(t=t, i=i, end=end):
+                        dev.tracer_solve_stage_cells(self.tids[t], i, 0, end)
+                        if fe:
+                            dev.tracer_swap_buffers(self.tids[t])
+                        if not self.use_limiter and i == sps - 1:
+                            exchange(1 + t)
+                    ops[('tracer', t, i)] = run
+                elif op[0] == 'limit':
+                    _, t, end = op
+
+                    def run(t=t, end=end):
+                        dev.tracer_limit_cells(self.tids[t], end)
+                        exchange(1 + t)
+                    ops[('limit', t)] = run
+        else:
+            if fe:
+                def run():
+                    self._cycle_forward_euler(1)
+                ops[('swe', 0)] = run
+            else:
+                r = [p.stage_range(g, depth=3) for g in range(3)]
+                ops[('swe', 0)] = lambda: dev.solve_stage_cells(0, 0, r[0])
+                ops[('swe', 1)] = lambda: dev.solve_stage_cells(1, 0, r[1])
+
+                def last():
+                    dev.solve_stage_cells(2, p.n_interior, p.n_owned)          # the cells the peers are waiting for
+                    reqs = self._send(0, 0)
+                    dev.solve_stage_cells(2, 0, p.n_interior)
+                    self._receive(0, 0, reqs)
+                ops[('swe', 2)] = last
+            for t in range(len(self.tids)):
+                tid = self.tids[t]
+                ops[('tracer', t, 0)] = lambda tid=tid: dev.tracer_solve_stage_cells(tid, 0, 0, self._ranges[0])
+                ops[('tracer', t, 1)] = lambda tid=tid: dev.tracer_solve_stage_cells(tid, 1, 0, self._ranges[1])
+
+                def tlast(t=t, tid=tid):
+                    dev.tracer_solve_stage_cells(tid, 2, p.n_interior, p.n_owned)
+                    reqs = self._send(1 + t, 0)
+                    dev.tracer_solve_stage_cells(tid, 2, 0, p.n_interior)
+                    self._receive(1 + t, 0, reqs)
+                ops[('tracer', t, 2)] = tlast
+                ops[('limit', t)] = lambda tid=tid: dev.tracer_limit_cells(tid, p.layer_end(3))
+        self._step_ops = ops
+        return ops
+
+    def run_stage(self, *key):
+        """One host-visible piece of a time step: ``run_stage('swe', i)``, ``run_stage('tracer', t, i)``, ``run_stage('limit', t)``
+        in the order of the coupled step (coupled_timeintegrator_2d.py:93-113).  COLLECTIVE (the last piece of a field exchanges it)."""
+        with self._stream_ctx():
+            self._one_step_ops()[tuple(key)]()
+
+    def get_stage_state_owned(self, i_stage=2):
+        """(global ids, uv, eta) of the owned cells after stage ``i_stage`` of the current step (2: the step result)."""
+        self._check_exchange()
+        uv, eta = self.dev.get_state(i_stage)
+        n = self.part.n_owned
+        return self.part.local_to_global[:n], uv[:n], eta[:n]
+
     def _capture(self, n_steps):
         """Build the graphs for an ``n_steps`` advance (set-up, not stepping: the state it perturbs is restored).
         COLLECTIVE when it steps: every rank must call it with the same arguments."""
@@ -629,6 +792,7 @@ class DistributedSwe2d(object):
         self.graph, self.graph_steps = None, n_steps
         if os.environ.get('THETIS_AMD_NO_GRAPH') or self.graph_mode == 'none':
             return
+        self._decide_flow()
         # everything below must run on self.stream: the exchange orders its sends / receives against torch's CURRENT
         # stream, and the kernels of the handle are bound to self.stream
         with torch.cuda.stream(self.stream):
@@ -671,7 +835,8 @@ class DistributedSwe2d(object):
                                    'are stale, the state is invalid'.format(n, self.rank))
 
     def synchronize(self):
-        self.stream.synchronize()
+        if self.stream is not None:
+            self.stream.synchronize()
         self._check_exchange()
 
     def diagnostics(self):

@@ -4,6 +4,8 @@ Field export and restart files around the hot path (thetis/exporter.py, thetis/s
 * ``VTKExporter``: ParaView ``.vtu`` (XML header + raw appended binary data) per export + a ``.pvd`` collection, directory/file naming of the
   reference (``<outputdir>/<Filename>/<Filename>_<ix>.vtu``, exporter.py:64-120).  DG fields are written cell by cell
   (duplicated points), i.e. exactly the discontinuous data.
+* Partitioned runs (one process per GPU, thetis_amd/spmd.py): reading a field for export gathers the owned cells of every rank
+  (collective), rank 0 writes - the files are those of the single-device run; the other ranks only count the export index.
 * ``CheckpointExporter``: the reference stores restart files with Firedrake's ``CheckpointFile`` (HDF5, exporter.py:123-242);
   neither h5py nor Firedrake exists here, so the same information (nodal data in the C-ABI host layout, export index,
   simulation time) goes to ``<outputdir>/hdf5/<Filename>_<ix:05d>.npz``.  NOT interchangeable with the reference's files.
@@ -23,12 +25,13 @@ field_metadata = {
 
 
 class VTKExporter(object):
-    def __init__(self, func_name, outputdir, filename, next_export_ix=0):
+    def __init__(self, func_name, outputdir, filename, next_export_ix=0, writes=True):
         self.func_name, self.filename = func_name, filename
         self.dir = os.path.join(outputdir, filename)
         self.next_export_ix = next_export_ix
         self.entries = []
-        os.makedirs(self.dir, exist_ok=True)
+        if writes:
+            os.makedirs(self.dir, exist_ok=True)
 
     def set_next_export_ix(self, ix):
         self.next_export_ix = ix
@@ -85,10 +88,11 @@ class VTKExporter(object):
 class CheckpointExporter(object):
     """Stand-in for ``HDF5Exporter`` (exporter.py:123-242): one ``.npz`` per export index."""
 
-    def __init__(self, outputdir, filename_prefix, next_export_ix=0):
+    def __init__(self, outputdir, filename_prefix, next_export_ix=0, writes=True):
         self.dir, self.prefix = outputdir, filename_prefix
         self.next_export_ix = next_export_ix
-        os.makedirs(self.dir, exist_ok=True)
+        if writes:
+            os.makedirs(self.dir, exist_ok=True)
 
     def set_next_export_ix(self, ix):
         self.next_export_ix = ix
@@ -119,23 +123,31 @@ class CheckpointExporter(object):
 class ExportManager(object):
     """Helper object for exporting multiple fields simultaneously (exporter.py:245-386)."""
 
-    def __init__(self, outputdir, fields_to_export, functions, metadata, export_type='vtk', next_export_ix=0):
+    def __init__(self, outputdir, fields_to_export, functions, metadata, export_type='vtk', next_export_ix=0, comm=None):
         self.exporters = OrderedDict()
         self.functions = dict(functions)
+        self.comm = comm
+        writes = comm is None or comm.rank == 0
         for key in fields_to_export:
             field = self.functions.get(key)
             if field is None or not hasattr(field, 'cell_node_values'):
                 continue
             meta = metadata[key]
             if export_type == 'vtk':
-                self.exporters[key] = VTKExporter(meta['shortname'], outputdir, meta['filename'], next_export_ix)
+                self.exporters[key] = VTKExporter(meta['shortname'], outputdir, meta['filename'], next_export_ix, writes=writes)
             else:
-                self.exporters[key] = CheckpointExporter(outputdir, meta['filename'], next_export_ix)
+                self.exporters[key] = CheckpointExporter(outputdir, meta['filename'], next_export_ix, writes=writes)
 
     def set_next_export_ix(self, ix):
         for e in self.exporters.values():
             e.set_next_export_ix(ix)
 
     def export(self, time=None):
+        writes = self.comm is None or self.comm.rank == 0
         for key, e in self.exporters.items():
-            e.export(self.functions[key], time=time)
+            f = self.functions[key]
+            f.dat.data_ro                   # refreshes a device-resident field; on partitioned runs a gather EVERY rank takes part in
+            if writes:
+                e.export(f, time=time)
+            else:
+                e.next_export_ix += 1

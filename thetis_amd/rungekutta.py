@@ -12,7 +12,7 @@ kernel launch per stage here (swe2d_solve_stage in include/swe2d.h).
 import numpy as np
 
 from . import _lib
-from .device import Swe2dDevice
+from .spmd import make_device
 from .function import Function
 from .options import Constant
 from .shallowwater_eq import g_grav
@@ -92,7 +92,10 @@ class ERKGenericShuOsher(TimeIntegrator):
     """Generic explicit Runge-Kutta time integrator in Shu-Osher form, device resident (rungekutta.py:870-952)."""
 
     def __init__(self, equation, solution, fields, dt, options, bnd_conditions, terms_to_add='all',
-                 device_id=0):
+                 device_id=0, comm=None, spmd=None, device_cls=None):
+        """``comm`` (thetis_amd/comm.py) with more than one rank: the mesh is partitioned over the ranks' GPUs and ``self.device`` is
+        a ``PartitionedDevice`` (thetis_amd/spmd.py; ``spmd``: what the partition must be built for - n_tracers, use_limiter,
+        tracer_only, stepper); otherwise one ``Swe2dDevice`` on ``device_id``."""
         super(ERKGenericShuOsher, self).__init__(equation, solution, fields, dt, options)
         if terms_to_add != 'all':
             raise NotImplementedError("the fused stage kernel evaluates all terms; terms_to_add must be 'all'")
@@ -114,8 +117,9 @@ class ERKGenericShuOsher(TimeIntegrator):
             bath_vertex[cells.ravel()] = vals.ravel()
             if np.abs(bath_vertex[cells] - vals).max() > 1e-12*max(1.0, np.abs(vals).max()):
                 raise NotImplementedError('discontinuous (DG) bathymetry is not supported on the device path')
-        self.device = Swe2dDevice(
-            mesh, bath_vertex, dt, g_grav=float(g_grav),
+        self.comm = comm
+        self.device = make_device(
+            mesh, bath_vertex, dt, comm=comm, spmd=spmd, device_cls=device_cls, g_grav=float(g_grav),
             use_nonlinear_equations=opts.use_nonlinear_equations,
             use_lax_friedrichs_velocity=opts.use_lax_friedrichs_velocity,
             lax_friedrichs_velocity_scaling_factor=float(fields.get('lax_friedrichs_velocity_scaling_factor') or 1.0),

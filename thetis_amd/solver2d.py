@@ -20,6 +20,7 @@ import numpy as np
 import os
 
 from . import callback, coupled_timeintegrator_2d, exporter
+from .comm import get_comm
 from .function import Function, FunctionSpace, MixedFunction, get_functionspace
 from .log import print_output
 from .options import Constant, ModelOptions2d
@@ -63,7 +64,10 @@ class FlowSolver2d(object):
         self.bnd_functions = {'shallow_water': {}, 'tracer': {}, 'sediment': {}}
         self.solve_tracer = False
         self.keep_log = keep_log
-        self.device_id = 0
+        # one process per GPU (python -m torch.distributed.run --nproc-per-node N script.py, the counterpart of the reference's
+        # mpiexec -n N): the communicator of this run; COLLECTIVE when WORLD_SIZE > 1 (thetis_amd/comm.py)
+        self.comm = get_comm()
+        self.device_id = self.comm.local_rank if self.comm.size > 1 else 0
 
     # ------------------------------------------------------------------ time step
     def compute_time_step(self, u_scale=0.0):
@@ -90,7 +94,10 @@ class FlowSolver2d(object):
                 automatic_timestep = True
         if automatic_timestep:
             mesh2d_dt = self.compute_time_step(u_scale=float(self.options.horizontal_velocity_scale))
-            self.dt = self.options.cfl_2d*alpha*float(mesh2d_dt.dat.data_ro.min())
+            dt = self.options.cfl_2d*alpha*float(mesh2d_dt.dat.data_ro.min())
+            # comm.allreduce(dt, op=MIN) (solver2d.py:240): the replicated meshes give every rank the same number; the reduction
+            # makes sure of it (ranks stepping with different dt would never meet again)
+            self.dt = float(self.comm.allreduce_min(dt)[0])
             if self.options.use_wetting_and_drying:
                 # the explicit wetting-drying formulation carries waves of speed sqrt(g |H|) through dry ground
                 # (|H| up to 2.4 alpha) and was measured stable up to ~0.4-0.5 of this step on the reference's Thacker and
@@ -210,7 +217,16 @@ class FlowSolver2d(object):
         }
         bnd_conditions = self.bnd_functions['shallow_water']
         return integrator(self.equations.sw, self.fields.solution_2d, fields, self.dt,
-                          o.swe_timestepper_options, bnd_conditions, device_id=self.device_id)
+                          o.swe_timestepper_options, bnd_conditions, device_id=self.device_id, comm=self.comm,
+                          spmd=self._partition_requirements(), device_cls=getattr(self, '_device_cls', None))
+
+    def _partition_requirements(self):
+        """What a partitioned run must know before it cuts the mesh (thetis_amd/spmd.py): the ghost layers depend on the number
+        of tracers, on the limiter (vertex neighbours) and on the stages per step."""
+        o = self.options
+        stepper = o.tracer_timestepper_type if (o.tracer_only and o.tracer) else o.swe_timestepper_type
+        return {'n_tracers': len(o.tracer), 'tracer_only': bool(o.tracer_only and o.tracer), 'stepper': stepper,
+                'use_limiter': bool(o.tracer and o.use_limiter_for_tracers and o.polynomial_degree > 0)}
 
     def get_tracer_timestepper(self, integrator, system, swe_stepper):
         """Gets tracer timestepper object with appropriate parameters (solver2d.py:576-598)"""
@@ -256,6 +272,9 @@ class FlowSolver2d(object):
             if self.options.tracer_timestepper_type not in tracer_steppers:
                 raise NotImplementedError("tracer_timestepper_type {!r} is outside the explicit device path; use "
                                           "'SSPRK33' or 'ForwardEuler'".format(self.options.tracer_timestepper_type))
+            if self.comm.size > 1 and not self.options.tracer_only and self.options.tracer_timestepper_type != name:
+                raise NotImplementedError('partitioned runs step the shallow water equations and the tracers with the same scheme '
+                                          '(the ghost layers are counted in stages per step)')
             swe = self.get_swe_timestepper(steppers[name])
             tracers = {}
             for system in self.options.tracer_fields:
@@ -272,7 +291,11 @@ class FlowSolver2d(object):
         print_output('2D cell type: {:}'.format('triangle' if m.cells.shape[1] == 3 else 'quadrilateral'))
         print_output('2D mesh: {:} vertices, {:} elements'.format(m.num_vertices, m.num_cells))
         a = np.sqrt(m.cell_areas())
-        print_output('Horizontal element size: {:.2f} ... {:.2f} m'.format(a.min(), a.max()))
+        # comm.allreduce MIN / MAX (solver2d.py:192-193)
+        lo, hi = float(self.comm.allreduce_min(a.min())[0]), float(self.comm.allreduce_max(a.max())[0])
+        print_output('Horizontal element size: {:.2f} ... {:.2f} m'.format(lo, hi))
+        if self.comm.size > 1:
+            print_output('Partitioned over {:d} ranks (one per GPU)'.format(self.comm.size))
         print_output('Number of 2D elevation DOFs: {:}'.format(self.function_spaces.H_2d.dim()))
         print_output('Number of 2D velocity DOFs: {:}'.format(self.function_spaces.U_2d.dim()))
 
@@ -290,10 +313,10 @@ class FlowSolver2d(object):
         o = self.options
         if o.fields_to_export:
             self.exporters['vtk'] = exporter.ExportManager(o.output_directory, o.fields_to_export, self.fields,
-                                                           self._field_metadata(), export_type='vtk')
+                                                           self._field_metadata(), export_type='vtk', comm=self.comm)
         if o.fields_to_export_hdf5:
             self.exporters['hdf5'] = exporter.ExportManager(os.path.join(o.output_directory, 'hdf5'), o.fields_to_export_hdf5,
-                                                            self.fields, self._field_metadata(), export_type='hdf5')
+                                                            self.fields, self._field_metadata(), export_type='hdf5', comm=self.comm)
 
     def initialize(self):
         """solver2d.py:732-744"""
@@ -339,8 +362,9 @@ class FlowSolver2d(object):
             self.initialize()
         if outputdir is None:
             outputdir = self.options.output_directory
+        self.comm.barrier()         # the files are written by rank 0 (of this run, or of the run that is being restarted)
         e = exporter.ExportManager(os.path.join(outputdir, 'hdf5'), ['uv_2d', 'elev_2d'], self.fields,
-                                   self._field_metadata(), export_type='hdf5')
+                                   self._field_metadata(), export_type='hdf5', comm=self.comm)
         metadata = {}
         metadata.update(e.exporters['uv_2d'].load(i_stored, self.fields.uv_2d))
         metadata.update(e.exporters['elev_2d'].load(i_stored, self.fields.elev_2d))
