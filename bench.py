@@ -185,6 +185,11 @@ def run_single(args):
     t_wall = time.perf_counter() - t0
     # mean stage-kernel launch duration over the timed region: 3 back-to-back launches per step, no gaps in between
     ms_kernel = ms_events/(3.0*args.steps)
+    # the spread of the figure: the same K-step region four more times (the state keeps evolving, no host reset in between);
+    # `value`, `ms_per_step` and `roofline.frac` stay those of the FIRST region (the contract's timed K steps), the samples say
+    # how far one 2-3 ms region is from the next on this box (clock state, Infinity Cache contents)
+    ms_samples = [ms_events] + [dev.advance_timed(args.steps, per_launch=False)[0] for _ in range(4)]
+    frac_samples = [BYTES_PER_ELEMENT_UPDATE*n/(ms/(3.0*args.steps)*1e-3)/1e9/HBM_PEAK_GBS for ms in ms_samples]
     # cross-check (separate pass): events around every single launch; ~3 % higher because of the event brackets
     n_ev = min(args.steps, 50)
     _, ms_kernel_each = dev.advance_timed(n_ev, per_launch=True)
@@ -202,7 +207,9 @@ def run_single(args):
                                'flat h=20, closed walls, dt=0.25', 'n_cells': n, 'parallelism': 'single',
                    'prewarm_s': args.prewarm},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
+                     'frac': achieved/HBM_PEAK_GBS, 'frac_samples': frac_samples, 'frac_median': float(np.median(frac_samples)),
+                     'frac_min': float(min(frac_samples)), 'frac_max': float(max(frac_samples)),
+                     'traffic': traffic, 'traffic_unit': 'bytes per launch',
                      'traffic_source': traffic_src,
                      'kernel': 'swe_stage_kernel', 'avg_launch_ms': ms_kernel, 'avg_launch_ms_per_launch_events': ms_kernel_each,
                      'algorithmic_bytes_per_launch': BYTES_PER_ELEMENT_UPDATE*n},
@@ -237,7 +244,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 or world > 1 or os.environ.get('THETIS_AMD_FORCE_DIST'):   # env: exercise the N>1 code path on one GPU
         from thetis_amd.distributed import run_distributed_bench
-        run_distributed_bench(args, build_case, DT, BYTES_PER_ELEMENT_UPDATE, HBM_PEAK_GBS)
+        case = build_case
+        if os.environ.get('THETIS_AMD_BENCH_MESH'):       # tests: "nx,ny" - many ranks sharing the one GPU of a test box
+            nx, ny = (int(v) for v in os.environ['THETIS_AMD_BENCH_MESH'].split(','))
+            case = lambda: build_case(nx, ny)
+        run_distributed_bench(args, case, DT, BYTES_PER_ELEMENT_UPDATE, HBM_PEAK_GBS)
     else:
         run_single(args)
 

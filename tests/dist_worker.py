@@ -395,7 +395,8 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
         assert timeouts == 0 and sent == received and sent[ch] > 0 and solver.dev.flow_timeouts() == 0, (sent, received, timeouts)
     d1 = solver.diagnostics()
     ids, u, e = solver.get_state_owned()
-    np.savez(os.path.join(out_dir, 'rank{:d}.npz'.format(rank)), ids=ids, uv=u, eta=e, d0=d0, d1=d1)
+    np.savez(os.path.join(out_dir, 'rank{:d}.npz'.format(rank)), ids=ids, uv=u, eta=e, d0=d0, d1=d1,
+             peers=np.array(solver.part.peers, dtype=np.int64))
     dist.barrier()
     dist.destroy_process_group()
 

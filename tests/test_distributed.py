@@ -51,7 +51,7 @@ def test_partition_invariants(world, axis):
         assert len(p.peers) <= 2                                  # strips: one xGMI link per side
 
 
-@pytest.mark.parametrize('world,axis', [(2, 0), (3, 1)])
+@pytest.mark.parametrize('world,axis', [(2, 0), (3, 1), (8, 0)])
 def test_gloo_partitioned_step_equals_global(tmp_path, ref_so, world, axis):
     mesh, bath, uv, eta = _case()
     run_workers(cpu_worker, world, 3, str(tmp_path), axis=axis)
@@ -61,7 +61,7 @@ def test_gloo_partitioned_step_equals_global(tmp_path, ref_so, world, axis):
     assert np.array_equal(u_p, u_g) and np.array_equal(e_p, e_g)
 
 
-@pytest.mark.parametrize('world,axis,every,n_steps', [(2, 0, 2, 5), (3, 1, 3, 4), (2, 1, 4, 8)])
+@pytest.mark.parametrize('world,axis,every,n_steps', [(2, 0, 2, 5), (3, 1, 3, 4), (2, 1, 4, 8), (8, 0, 2, 5)])
 def test_gloo_exchange_every_m_steps_equals_global(tmp_path, ref_so, world, axis, every, n_steps):
     """3m ghost layers, one exchange per m steps (the last cycle may be shorter): stale layers are NaN-poisoned in the
     worker, the result is bitwise the global one."""
@@ -538,6 +538,29 @@ def test_ranks_on_one_gpu_with_one_launch_per_cycle(tmp_path, hip_lib, monkeypat
     u_s, e_s = dev.get_state()
     dev.close()
     assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case,n_steps', [('channel+every2+p2p+flowx', 12), ('channel+every2+p2p+graph', 7), ('channel+every1+overlap2', 4)])
+def test_eight_ranks_on_one_gpu_match_single_device(tmp_path, hip_lib, case, n_steps):
+    """BASELINE cfg 3's rank count with the bits checked: eight processes share the test GPU, strips of two cell columns -
+    narrower than the six-layer halo of ``every2``, so a rank's ghost layers reach its second and third neighbours (up to six
+    peers, IPC handles exchanged among eight processes, SWE_P2P_MAX_PEERS = 8); in-launch exchange of the flow kernel ('+flowx'),
+    exchange kernels inside per-cycle HIP graphs, and the host-staged exchange with overlap.  Bitwise the single-device result."""
+    from thetis_amd.device import Swe2dDevice
+    import dist_worker
+    dist_worker.CASE = 'channel'
+    mesh, bath, uv, eta = dist_worker._case()
+    run_workers(gpu_worker, 8, n_steps, str(tmp_path), axis=0, case=case)
+    u_p, e_p, extra = gather(str(tmp_path), 8, mesh.num_cells)
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev.set_state(uv, eta)
+    dev.advance(n_steps)
+    u_s, e_s = dev.get_state()
+    dev.close()
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+    peers = [len(set(int(q) for q in np.atleast_1d(d['peers']))) for d in extra if 'peers' in d]
+    assert max(peers) >= 4                       # the halo is deeper than a strip is wide
 
 
 @pytest.mark.gpu

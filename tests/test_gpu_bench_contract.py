@@ -36,6 +36,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields(hip_lib, env):
     assert abs(d['value'] - 1e6*3*6/(d['ms_per_step']*6e-3))/d['value'] < 1e-9
     assert 1e9 < d['value'] < 1e11
     if not env:
+        # the line carries its own spread: five K-step regions back to back, the headline figures are those of the first
+        assert len(rf['frac_samples']) == 5 and rf['frac_samples'][0] == rf['frac']
+        assert rf['frac_min'] <= rf['frac_median'] <= rf['frac_max'] and rf['frac_min'] == min(rf['frac_samples'])
         # the same kernel beyond the Infinity Cache (4M triangles), reported next to the headline fraction
         assert 0.05 < rf['frac_beyond_cache'] < 1.0 and rf['beyond_cache']['algorithmic_bytes_per_launch'] == 228.0*4e6
     if env.get('THETIS_AMD_TUNE_SCHEDULE'):
@@ -76,6 +79,31 @@ def test_bench_two_ranks_through_torch_distributed_run(hip_lib):
     # the second, untuned timed region on the larger mesh of the same channel (here shrunk: 2 ranks share one GPU)
     lm = cfg['large_mesh']
     assert lm['n_cells'] == 2*1600*400 and lm['volume_conserved'] is True and lm['value'] > 1e8 and lm['speedup_model'] > 0
+
+
+def test_bench_eight_ranks_through_torch_distributed_run(hip_lib):
+    """BASELINE cfg 3's rank count, first contact rehearsed: ``--gpus 8`` with eight ranks sharing the test GPU (gloo control
+    plane, IPC peer-to-peer halos among eight processes, middle ranks with two peers) on a shrunk mesh of the same channel
+    (THETIS_AMD_BENCH_MESH; eight processes on the full mesh would only test the box's patience) and a shrunk large-mesh region.
+    The run must end in ONE complete JSON line with ``config.large_mesh``."""
+    e = dict(os.environ)
+    e.update({'THETIS_AMD_DIST_BACKEND': 'gloo', 'THETIS_AMD_BENCH_MESH': '256,64', 'THETIS_AMD_LARGE_MESH': '512,64',
+              'THETIS_AMD_SETUP_BUDGET_S': '40'})
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr',
+                        '127.0.0.1', '--master-port', '29581', os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '16',
+                        '--warmup', '2', '--prewarm', '0.05'],
+                       capture_output=True, text=True, env=e, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.lstrip().startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    cfg = d['config']
+    assert d['n_gpus'] == 8 and d['steps'] == 16 and d['scaling'] == 'strong' and d['value'] > 1e6
+    assert cfg['n_cells'] == 2*256*64 and 'NOT the BASELINE workload' in cfg['workload']
+    assert cfg['transports_verified'][0] == 'p2p' and cfg['exchange'] == 'p2p' and cfg['p2p_timeouts'] == 0 and cfg['flow_timeouts'] == 0
+    assert cfg['volume_conserved'] is True and len(cfg['schedule_tuning']) >= 1
+    lm = cfg['large_mesh']
+    assert lm is not None and lm['n_cells'] == 2*512*64 and lm['volume_conserved'] is True
 
 
 def test_bench_set_up_budget_cuts_the_candidate_list_short(hip_lib):

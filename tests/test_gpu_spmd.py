@@ -1,0 +1,70 @@
+"""
+GPU: an UNCHANGED FlowSolver2d user script under several ranks (one process per rank, here sharing the one GPU of the test box:
+gloo control plane, IPC peer-to-peer halos exactly as between GPUs) is domain-decomposed and gives the single-device run bit for
+bit - state, iteration / time / export counters, callback histories, exported files.  The reference's counterpart:
+``mpiexec -n N python script.py`` (examples/README.md:51-56).  CPU twin: tests/test_spmd.py.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from dist_worker import run_spmd
+from test_spmd import _check
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('name,world', [('channel', 2), ('channel', 4), ('forced', 2), ('forced', 3), ('tracer', 2), ('tracer_forced', 3),
+                                        ('tracer_only', 2), ('balzano', 2), ('balzano', 4), ('forced_fe', 2), ('tracer_fe', 2),
+                                        ('tracer_nolim', 2)])
+def test_user_script_under_n_ranks_on_one_gpu(tmp_path, hip_lib, name, world):
+    single = run_spmd(1, str(tmp_path), name, cpu=False)
+    ranks = run_spmd(world, str(tmp_path), name, cpu=False)
+    assert ranks[0]['exchange'] == 'p2p'            # the default transport set up (hipIpc* between the rank processes)
+    _check(single, ranks, exact_callbacks=True)
+
+
+@pytest.mark.parametrize('name,world,env', [
+    ('channel', 3, {'THETIS_AMD_SPMD_FLOW': '1'}),                                    # dataflow launches, exchange inside (FX)
+    ('channel', 2, {'THETIS_AMD_SPMD_FLOW': '1', 'THETIS_AMD_EXCHANGE_EVERY': '1'}),
+    ('forced', 2, {'THETIS_AMD_SPMD_FLOW': '1'}),                                     # stage by stage between flow-capable batches
+    ('channel', 2, {'THETIS_AMD_EXCHANGE': 'host'}), ('tracer', 2, {'THETIS_AMD_EXCHANGE': 'host', 'THETIS_AMD_EXCHANGE_EVERY': '1'}),
+    ('channel', 4, {'THETIS_AMD_PARTITION': 'rcb', 'THETIS_AMD_EXCHANGE_EVERY': '1'}),
+    ('tracer', 2, {'THETIS_AMD_OVERLAP_STAGES': '2'}),
+    ('channel', 8, {}),
+])
+def test_user_script_variants_on_one_gpu(tmp_path, hip_lib, name, world, env):
+    single = run_spmd(1, str(tmp_path), name, cpu=False)
+    ranks = run_spmd(world, str(tmp_path), name, cpu=False, env=env)
+    _check(single, ranks, exact_callbacks=True)
+
+
+def _script(args, world, port):
+    e = dict(os.environ)
+    e['THETIS_AMD_DIST_BACKEND'] = 'gloo'            # the ranks share the one GPU of the test box: RCCL would refuse them
+    cmd = [sys.executable] + args if world == 1 else \
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+         '--master-port', str(port)] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=e, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize('script,args,key,world', [
+    ('channel2d.py', ['--t-end', '200'], 'volume ', 2), ('channel2d.py', ['--t-end', '200'], 'volume ', 3),
+    ('balzano.py', ['--hours', '1'], 'finite ', 2), ('tracer2d.py', ['--revolutions', '0.25', '--limiter'], 'relative L2', 2)])
+def test_example_scripts_under_torch_distributed_run(hip_lib, script, args, key, world):
+    """the files under examples/ as they are: ``python -m torch.distributed.run --nproc-per-node N examples/x.py`` prints, on every
+    rank, the result line of ``python examples/x.py``; the solver's own output (print_state, callbacks) appears once (rank 0)"""
+    path = os.path.join('examples', script)
+    one = _script([path] + args, 1, 0)
+    many = _script([path] + args, world, 29640 + world)
+    ref = [l for l in one.splitlines() if l.startswith(key)]
+    got = [l for l in many.splitlines() if l.startswith(key)]
+    assert len(ref) == 1 and len(got) == world and all(g == ref[0] for g in got), (ref, got)
+    state = lambda out: [l for l in out.splitlines() if l.strip()[:1].isdigit() and len(l.split()) >= 5]
+    assert state(many) == state(one) and len(state(one)) >= 2              # print_state lines: once, and the same numbers

@@ -1300,8 +1300,10 @@ def _timed_region(args, solver, chosen, agree, uv, eta, use_graph, n_total, worl
         'value': float(value), 'unit': 'element-updates/s', 'n_gpus': int(world), 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': float(1e3*t/args.steps), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
         'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE cfg3: the cfg2 1M-triangle channel strip-partitioned along x over {:d} GPUs, '
-                               '{:d}-layer halo, one exchange per {:d} time steps'.format(world, 3*every, every),
+        'config': {'workload': ('BASELINE cfg3: the cfg2 1M-triangle channel' if n_total == 1000000 else
+                                'NOT the BASELINE workload (THETIS_AMD_BENCH_MESH): a {:d}-triangle channel'.format(n_total))
+                               + ' strip-partitioned along x over {:d} GPUs, {:d}-layer halo, one exchange per {:d} time steps'.format(
+                                   world, 3*every, every),
                    'n_cells': int(n_total),
                    'parallelism': 'dd{:d} (domain decomposition, {:d}-cell halo, 1 exchange per {:d} steps)'.format(
                        world, 3*every, every),

@@ -26,7 +26,8 @@ Results are bitwise those of the single-device run (tests/test_spmd.py, tests/te
 
 Environment: ``THETIS_AMD_EXCHANGE`` = p2p | rccl | host (default: the first that sets up on every rank),
 ``THETIS_AMD_EXCHANGE_EVERY`` (default 2), ``THETIS_AMD_OVERLAP_STAGES`` (default 0), ``THETIS_AMD_PARTITION`` = strip | strip_y |
-rcb (default: strips along the longer side of a structured mesh, recursive coordinate bisection otherwise).
+rcb (default: strips along the longer side of a structured mesh, recursive coordinate bisection otherwise),
+``THETIS_AMD_SPMD_FLOW`` = 1 | 0 (require / forbid the dataflow launches; default: the ranks' common automatic choice).
 """
 import os
 
@@ -86,6 +87,8 @@ class PartitionedDevice(object):
         else:
             wanted = ['p2p'] + (['rccl'] if comm.rccl else []) + ['host']
         device_id = comm.local_rank if device_id is None else device_id
+        # the dataflow launch (csrc/swe2d_flow.h): by default where every rank's partition is covered and no two ranks share a GPU
+        flow = {'1': True, '0': False}.get(os.environ.get('THETIS_AMD_SPMD_FLOW', ''), None)
         self.dist, errors = None, []
         for ex in wanted:
             d, err = None, None
@@ -93,7 +96,8 @@ class PartitionedDevice(object):
                 d = DistributedSwe2d(mesh, bathymetry_vertex, dt, comm.rank, comm.size, device_id, owner=owner,
                                      n_tracers=self.n_tracers, use_limiter=use_limiter, tracer_only=tracer_only,
                                      exchange_every=every, overlap_stages=overlap, stepper=stepper, exchange=ex,
-                                     group=(None if ex == 'rccl' else comm.group), device_cls=device_cls, **opts)
+                                     group=(None if ex == 'rccl' else comm.group), device_cls=device_cls,
+                                     flow=(flow if on_gpu else False), **opts)
             except Exception as e:                                    # e.g. IPC mapping refused: every rank moves on together
                 err = '{:}: {:}'.format(ex, (str(e).strip().splitlines() or [type(e).__name__])[0])
             if comm.all_agree(err is None):
