@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SWE2D_ABI_VERSION 7
+#define SWE2D_ABI_VERSION 8
 #define SWE2D_MAX_MARKERS 16          /* boundary markers must be in 1..SWE2D_MAX_MARKERS-1 */
 
 typedef enum {
@@ -131,6 +131,11 @@ void swe2d_ssprk33_coefficients(double alpha0[3], double alpha_in[3], double bet
  * 32-bit offsets: nodes_per_cell * n_cells * 8 bytes must stay below 2^32 (about 178 M triangles / 134 M quadrilaterals per
  * device), larger meshes return SWE2D_ERR_UNSUPPORTED and have to be partitioned (one handle per part). */
 int  swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handle **out);
+/* Partitions of ONE quadrilateral mesh must all take the same kernel family: the parallelogram kernels and the general bilinear
+ * ones differ in the last bits on the same parallelogram cell, and a ghost cell must repeat its owner's arithmetic.  A handle
+ * whose own cells are all parallelograms while the global mesh has a general cell is told so here (on = 1: general kernels;
+ * on = 0: back to what the handle's own cells allow).  Call before the first step. */
+int  swe2d_set_general_quadrilaterals(swe2d_handle *h, int on);
 void swe2d_destroy(swe2d_handle *h);
 const char *swe2d_last_error(const swe2d_handle *h);             /* h may be NULL: error of the last failed create */
 
@@ -203,6 +208,15 @@ int  swe2d_tendency(swe2d_handle *h, double *k_uv, double *k_eta);
  * out = { int eta^2 dx, int |u|^2 dx, int (eta+h) dx, min nodal (h+eta) } over the owned cells
  * (sums, not roots, so that partitions can be added). */
 int  swe2d_diagnostics(swe2d_handle *h, double out[4]);
+/* The same integrals as order-independent sums, for runs partitioned over several handles / ranks (the reference all-reduces its
+ * diagnostics over the MPI ranks, thetis/callback.py:478-482; a floating-point all-reduce would make the printed norms and the
+ * conservation checks depend on the partition in their last digits): every cell's contribution is split exactly into four
+ * signed 38-bit limbs of units 2^40, 2^2, 2^-36, 2^-74 and the limbs are summed as integers.  limbs[4 q + j] = limb j of
+ * quantity q (int eta^2, int |u|^2, int (eta+h)); add the limbs of all partitions (int64, any order), then
+ * swe2d_sum_limbs_to_double rounds a total to the nearest double.  swe2d_diagnostics returns exactly that for its own handle, so
+ * one handle over the whole mesh and N handles over its partitions give identical doubles. */
+int  swe2d_diagnostics_limbs(swe2d_handle *h, int64_t limbs[12], double *min_depth);
+double swe2d_sum_limbs_to_double(const int64_t limbs[4]);
 
 /* ---- SIPG horizontal viscosity: HorizontalViscosityTerm (thetis/shallowwater_eq.py:554-616), fields['viscosity_h'] =
  * options.horizontal_viscosity (solver2d.py:551).  nu is a constant (nu_vertex == NULL) or a continuous P1 field given per
@@ -278,6 +292,8 @@ int  swe2d_limiter_setup(swe2d_handle *h, int32_t n_topo_vertices, const int32_t
 int  swe2d_tracer_limit(swe2d_handle *h, int tracer_id);                             /* limiter.apply(field) */
 /* out = { int T*H dx (comp_tracer_mass_2d, utility.py:437-445), int T dx, min nodal T, max nodal T } */
 int  swe2d_tracer_diagnostics(swe2d_handle *h, int tracer_id, double out[4]);
+/* limb sums (see swe2d_diagnostics_limbs) of { int T*H dx, int T dx } + { min, max } of the owned cells */
+int  swe2d_tracer_diagnostics_limbs(swe2d_handle *h, int tracer_id, int64_t limbs[8], double minmax[2]);
 /* GeneralCoupledTimeIntegrator2D.advance (coupled_timeintegrator_2d.py:93-113) x n_steps: SWE step (unless tracer_only),
  * then every tracer with the updated velocity, then the limiter (once per step) */
 int  swe2d_advance_coupled(swe2d_handle *h, int n_steps, int tracer_only, int use_limiter);

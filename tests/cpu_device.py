@@ -204,23 +204,47 @@ class CpuSwe2dDevice(object):
     def flow_timeouts(self):
         return 0
 
-    def _p1_integral(self, a, b=None):
-        """sum over owned cells of int a [b] dx for P1 / Q1 nodal values on affine cells"""
+    def _cell_integrals(self, a, b=None):
+        """per owned cell: int a [b] dx for P1 / Q1 nodal values on affine cells"""
         n = self.n_owned
         a = a[:n]
         if b is None:
-            return float(np.sum(self.area[:n]*a.mean(axis=1)))
+            return self.area[:n]*a.mean(axis=1)
         b = b[:n]
         if self.npc == 3:
-            return float(np.sum(self.area[:n]/12.0*(a.sum(axis=1)*b.sum(axis=1) + (a*b).sum(axis=1))))
+            return self.area[:n]/12.0*(a.sum(axis=1)*b.sum(axis=1) + (a*b).sum(axis=1))
         kb = 4*b + 2*np.roll(b, -1, axis=1) + 2*np.roll(b, 1, axis=1) + np.roll(b, 2, axis=1)
-        return float(np.sum(self.area[:n]/36.0*(a*kb).sum(axis=1)))
+        return self.area[:n]/36.0*(a*kb).sum(axis=1)
 
-    def diagnostics(self):
+    @staticmethod
+    def _limbs(x):
+        """the limb sums of include/swe2d.h (swe2d_diagnostics_limbs) of the terms ``x``: units 2^40, 2^2, 2^-36, 2^-74"""
+        x = np.asarray(x, dtype=np.float64).copy()
+        assert (np.abs(x) < 2.0**78).all()
+        out = np.zeros(4, dtype=np.int64)
+        for j, s in enumerate((40, 2, -36, -74)):
+            t = np.trunc(np.ldexp(x, -s))
+            out[j] = int(t.astype(np.int64).sum())
+            x -= np.ldexp(t, s)
+        return out
+
+    @staticmethod
+    def limbs_to_double(limbs):
+        """exact total of limb sums, rounded once (Fraction -> float is correctly rounded)"""
+        from fractions import Fraction
+        v = sum(Fraction(int(l))*Fraction(2)**s for l, s in zip(np.asarray(limbs).reshape(4), (40, 2, -36, -74)))
+        return float(v)
+
+    def diagnostics_limbs(self):
         u, e = self.U[0], self.E[0]
         n = self.n_owned
-        return np.array([self._p1_integral(e, e), self._p1_integral(u[..., 0], u[..., 0]) + self._p1_integral(u[..., 1], u[..., 1]),
-                         self._p1_integral(e + self.h), float((self.h + e)[:n].min())])
+        terms = [self._cell_integrals(e, e), self._cell_integrals(u[..., 0], u[..., 0]) + self._cell_integrals(u[..., 1], u[..., 1]),
+                 self._cell_integrals(e + self.h)]
+        return np.stack([self._limbs(t) for t in terms]), float((self.h + e)[:n].min())
+
+    def diagnostics(self):
+        limbs, lo = self.diagnostics_limbs()
+        return np.array([self.limbs_to_double(l) for l in limbs] + [lo])
 
     # ---- halo plumbing (the exchange buffers are CPU torch tensors)
     def halo_setup(self, send_cells, recv_cells):
@@ -324,10 +348,15 @@ class CpuSwe2dDevice(object):
         if len(rc):
             self.tracers[tid]['T'][i_buffer][rc] = _as_array(recv_buf_ptr, self.npc*len(rc)).reshape(-1, self.npc)
 
-    def tracer_diagnostics(self, tid):
+    def tracer_diagnostics_limbs(self, tid):
         T = self.tracers[tid]['T'][0]
         n = self.n_owned
-        return np.array([self._p1_integral(T, self.h + self.E[0]), self._p1_integral(T), float(T[:n].min()), float(T[:n].max())])
+        terms = [self._cell_integrals(T, self.h + self.E[0]), self._cell_integrals(T)]
+        return np.stack([self._limbs(t) for t in terms]), np.array([float(T[:n].min()), float(T[:n].max())])
+
+    def tracer_diagnostics(self, tid):
+        limbs, mm = self.tracer_diagnostics_limbs(tid)
+        return np.array([self.limbs_to_double(limbs[0]), self.limbs_to_double(limbs[1]), mm[0], mm[1]])
 
     def advance_coupled(self, n_steps=1, tracer_only=False, use_limiter=True):
         for _ in range(int(n_steps)):

@@ -31,7 +31,7 @@ def test_abi_version_and_loud_failure_without_device(hip_lib):
     from thetis_amd import _lib
     from thetis_amd.device import Swe2dDevice
     from thetis_amd.mesh import RectangleMesh
-    assert hip_lib.swe2d_abi_version() == _lib.ABI_VERSION == 7
+    assert hip_lib.swe2d_abi_version() == _lib.ABI_VERSION == 8
     if hip_lib.swe2d_device_count() > 0:
         pytest.skip('a GPU is present')
     mesh = RectangleMesh(4, 3, 1.0, 1.0)
@@ -135,3 +135,29 @@ def test_general_butcher_to_shuosher_conversion_matches_the_reference_output():
             assert np.array_equal(al, SSPRK33Abstract.alpha) and np.array_equal(be, SSPRK33Abstract.beta)
     with pytest.raises(NotImplementedError):
         butcher_to_shuosher_form(np.array([[0.5]]), np.array([1.0]))              # implicit midpoint: not this path
+
+
+def test_limb_sums_round_to_the_nearest_double():
+    """swe2d_sum_limbs_to_double (host code of the library: runs without a GPU) against exact rational arithmetic: random limb
+    totals incl. negative ones, ties, carries between limbs, values below one unit of the top limb."""
+    import ctypes
+    from fractions import Fraction
+    import numpy as np
+    from thetis_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+
+    def exact(limbs):
+        return float(sum(Fraction(int(l))*Fraction(2)**s for l, s in zip(limbs, (40, 2, -36, -74))))
+
+    cases = [[0, 0, 0, 0], [0, 0, 0, 1], [0, 0, 0, -1], [1, 0, 0, 0], [-1, 0, 0, 1], [0, 0, 1 << 37, 1], [0, (1 << 53) + 1, 0, 0],
+             [1 << 13, 0, 0, 1], [1 << 13, 0, 0, -1], [-(1 << 20), 3, -5, 7], [0, 1 << 52, 1 << 36, 0], [0, 1 << 52, 1 << 36, 1],
+             [0, (1 << 52) + 1, 1 << 36, 0], [(1 << 62) - 1, (1 << 62) - 1, (1 << 62) - 1, (1 << 62) - 1],
+             [-(1 << 62), -(1 << 62), -(1 << 62), -(1 << 62)]]
+    for _ in range(2000):
+        mag = rng.integers(1, 62, size=4)
+        cases.append([int(rng.integers(-(1 << m), 1 << m)) if rng.random() > 0.2 else 0 for m in mag])
+    for c in cases:
+        a = np.array(c, dtype=np.int64)
+        got = lib.swe2d_sum_limbs_to_double(a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+        assert got == exact(c), (c, got, exact(c))

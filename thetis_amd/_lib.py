@@ -18,7 +18,7 @@ FIELD_LINEAR_DRAG, FIELD_QUADRATIC_DRAG, FIELD_MANNING_DRAG, FIELD_NIKURADSE = 5
 SCALAR_LINEAR_DRAG, SCALAR_QUADRATIC_DRAG, SCALAR_MANNING_DRAG, SCALAR_NORM_SMOOTHER, SCALAR_NIKURADSE = 0, 1, 2, 3, 4
 
 IPC_HANDLE_BYTES = 64    # include/swe2d.h SWE2D_IPC_HANDLE_BYTES (sizeof(hipIpcMemHandle_t))
-ABI_VERSION = 7          # include/swe2d.h SWE2D_ABI_VERSION
+ABI_VERSION = 8          # include/swe2d.h SWE2D_ABI_VERSION
 OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NOT_FINITE = 0, -1, -2, -3, -4, -5
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -68,6 +68,10 @@ SYMBOLS = {
     'swe2d_synchronize': (ctypes.c_int, [_H]),
     'swe2d_tendency': (ctypes.c_int, [_H, _dp, _dp]),
     'swe2d_diagnostics': (ctypes.c_int, [_H, _dp]),
+    'swe2d_diagnostics_limbs': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int64), _dp]),
+    'swe2d_sum_limbs_to_double': (ctypes.c_double, [ctypes.POINTER(ctypes.c_int64)]),
+    'swe2d_tracer_diagnostics_limbs': (ctypes.c_int, [_H, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), _dp]),
+    'swe2d_set_general_quadrilaterals': (ctypes.c_int, [_H, ctypes.c_int]),
     'swe2d_tracer_add': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int)]),
     'swe2d_tracer_set_options': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_double, ctypes.c_double]),
     'swe2d_tracer_set_state': (ctypes.c_int, [_H, ctypes.c_int, _dp]),

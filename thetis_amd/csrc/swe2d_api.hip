@@ -82,6 +82,8 @@ namespace {
 
 thread_local std::string g_create_error;
 
+#define SWE_DIAG_ACC (3*SWE_SUM_LIMBS + 1)             // limb sums of up to three integrals + the counter of unsummable terms
+
 // Shu-Osher coefficients of SSPRK33: output of thetis/rungekutta.py:13-87 (butcher_to_shuosher_form) for the
 // tableau of rungekutta.py:342-346; pinned by tests/golden/shuosher_ssprk33.json.
 //   U1 = 1*k0 + 1*U0;  U2 = 1/4*k1 + 3/4*U0 + 1/4*U1;  U3 = b32*k2 + a30*U0 + a32*U2
@@ -97,6 +99,7 @@ struct Handle {
     int n_cells = 0, n_owned = 0, n_interior = 0, n_vertices = 0;
     int npc = 3;                                       // nodes per cell: 3 triangles, 4 quadrilaterals
     bool affine = true;                                // quadrilaterals: every cell a parallelogram (constant Jacobian, tensor mass inverse)
+    bool affine_local = true;                          // ... as found in this handle's own cells (affine may be forced off: swe2d_set_general_quadrilaterals)
     size_t stride = 0;
     double *state[3] = {nullptr, nullptr, nullptr};   // A (U0 / step result), B (U1), C (U2)
     int *nbr = nullptr, *cv = nullptr;
@@ -149,6 +152,7 @@ struct Handle {
     double *stage_uv = nullptr, *stage_eta = nullptr;  // device staging in host layout (6N + 3N)
     double *partial = nullptr;                         // diagnostics partial sums
     int n_partial_blocks = 0;
+    unsigned long long *diag_acc = nullptr;            // limb sums of the diagnostics kernels (swe_sum_accumulate) + one counter
     int *send_cells = nullptr, *recv_cells = nullptr;
     int n_send = 0, n_recv = 0;
     // peer-to-peer halo (swe2d_p2p.h): my landing zone, the peers' zones mapped here, per-channel device counters
@@ -831,6 +835,7 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
     HIP_TRY_C(hipMalloc(&h->stage_eta, (size_t)npc*n*sizeof(double)));
     h->n_partial_blocks = (h->n_owned + SWE_BLOCK - 1)/SWE_BLOCK;
     HIP_TRY_C(hipMalloc(&h->partial, 4*(size_t)h->n_partial_blocks*sizeof(double)));
+    HIP_TRY_C(hipMalloc(&h->diag_acc, SWE_DIAG_ACC*sizeof(unsigned long long)));
 
     // connectivity -> SoA planes, validated on the way
     std::vector<int> nbr((size_t)npc*S, 0), cv((size_t)npc*S, 0);
@@ -890,6 +895,7 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
             const double sx = vx[a] - vx[b] + vx[d] - vx[c], sy = vy[a] - vy[b] + vy[d] - vy[c];
             if (std::fabs(sx) + std::fabs(sy) > 1e-9*std::sqrt(area2)) {
                 h->affine = false;
+                h->affine_local = false;
                 const double ax = vx[b] - vx[a], ay = vy[b] - vy[a], bx = vx[c] - vx[a], by = vy[c] - vy[a];
                 const double d1 = ax*sy - ay*sx, d2 = sx*by - sy*bx;
                 if (!(area2 + d1 > 0.0 && area2 + d2 > 0.0 && area2 + d1 + d2 > 0.0)) {
@@ -977,7 +983,7 @@ void swe2d_destroy(swe2d_handle *hh)
         if (t.bc_value_f) (void)hipFree(t.bc_value_f);
         if (t.bc_vel_f) (void)hipFree(t.bc_vel_f);
     }
-    void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->send_cells, h->recv_cells,
+    void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->diag_acc, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
                     h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1554,35 +1560,75 @@ int swe2d_tendency(swe2d_handle *hh, double *k_uv, double *k_eta)
     return SWE2D_OK;
 }
 
+// The total of limb sums (swe_sum_accumulate) rounded to the nearest double (ties to even), exactly: a pure function of the four
+// integers, so a sum taken over one device and the same sum taken over the partitions of eight agree in every bit.
+double swe2d_sum_limbs_to_double(const int64_t limbs[4])
+{
+    // carry-normalise: 0 <= L1, L2, L3 < 2^38, L0 signed;  V = L0 2^40 + L1 2^2 + L2 2^-36 + L3 2^-74
+    int64_t L[4] = {limbs[0], limbs[1], limbs[2], limbs[3]};
+    for (int j = 3; j > 0; j--) {
+        const int64_t carry = L[j] >> 38;                     // arithmetic shift: floor
+        L[j] -= carry*((int64_t)1 << 38);
+        L[j - 1] += carry;
+    }
+    const __int128 hi = (__int128)L[0]*((__int128)1 << 38) + L[1];                      // units of 2^2
+    const unsigned __int128 lo = ((unsigned __int128)(uint64_t)L[2] << 38) | (uint64_t)L[3];   // units of 2^-74, < 2^76
+    if (hi == 0) return std::ldexp((double)lo, -74);          // 76 bits -> double: correctly rounded by the conversion
+    // hi != 0:  V = (hi + f) 2^2, 0 <= f = lo 2^-76 < 1.  T = floor((hi + f) 2^s) with as many bits of f as fit into 127 bits, and a
+    // sticky bit for the rest: T has >= 77 significant bits, the sticky bit sits far below the rounding position
+    int bits = 0;
+    for (unsigned __int128 m = (unsigned __int128)(hi < 0 ? -hi : hi); m; m >>= 1) bits++;
+    const int sft = std::min(76, 125 - bits);
+    __int128 T = hi*((__int128)1 << sft) + (__int128)(lo >> (76 - sft));
+    if (sft < 76 && (lo & (((unsigned __int128)1 << (76 - sft)) - 1)) != 0) T |= 1;
+    return std::ldexp((double)T, 2 - sft);
+}
+
+namespace {
+// launches the shallow water diagnostics kernel: limb sums { int eta^2, int |u|^2, int (eta+h) } + min nodal depth of the owned cells
+int run_diagnostics(Handle *h, int64_t limbs[3*SWE_SUM_LIMBS], double *min_depth)
+{
+    HIP_TRY(h, hipSetDevice(h->device));
+    SWE_CHK_SYNC(h->stream);
+    HIP_TRY(h, hipMemsetAsync(h->diag_acc, 0, SWE_DIAG_ACC*sizeof(unsigned long long), h->stream));
+    if (h->npc == 4)
+        hipLaunchKernelGGL(swe_diag_kernel_quad, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
+                           h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial,
+                           h->wd ? h->valpha : nullptr, h->affine ? 1 : 0, h->diag_acc);
+    else
+        hipLaunchKernelGGL(swe_diag_kernel, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
+                           h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial,
+                           h->wd ? h->valpha : nullptr, h->diag_acc);
+    HIP_TRY(h, hipGetLastError());
+    std::vector<double> part((size_t)h->n_partial_blocks);
+    unsigned long long acc[SWE_DIAG_ACC];
+    HIP_TRY(h, hipMemcpyAsync(part.data(), h->partial, part.size()*sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(acc, h->diag_acc, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *min_depth = 1e300;
+    for (double v : part) *min_depth = std::fmin(*min_depth, v);
+    for (int i = 0; i < 3*SWE_SUM_LIMBS; i++) limbs[i] = (int64_t)acc[i];
+    if (int rc = flow_check(h)) return rc;
+    if (acc[3*SWE_SUM_LIMBS] != 0)
+        return fail(h, SWE2D_ERR_NOT_FINITE, "state is not finite");
+    return SWE2D_OK;
+}
+}  // namespace
+
+int swe2d_diagnostics_limbs(swe2d_handle *hh, int64_t limbs[12], double *min_depth)
+{
+    Handle *h = H(hh);
+    if (!h || !limbs || !min_depth) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    return run_diagnostics(h, limbs, min_depth);
+}
+
 int swe2d_diagnostics(swe2d_handle *hh, double out[4])
 {
     Handle *h = H(hh);
     if (!h || !out) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
-    HIP_TRY(h, hipSetDevice(h->device));
-    SWE_CHK_SYNC(h->stream);
-    if (h->npc == 4)
-        hipLaunchKernelGGL(swe_diag_kernel_quad, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
-                           h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial,
-                           h->wd ? h->valpha : nullptr, h->affine ? 1 : 0);
-    else
-        hipLaunchKernelGGL(swe_diag_kernel, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
-                           h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial,
-                           h->wd ? h->valpha : nullptr);
-    HIP_TRY(h, hipGetLastError());
-    std::vector<double> part(4*(size_t)h->n_partial_blocks);
-    HIP_TRY(h, hipMemcpyAsync(part.data(), h->partial, part.size()*sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    out[0] = out[1] = out[2] = 0.0;
-    out[3] = 1e300;
-    for (int b = 0; b < h->n_partial_blocks; b++) {
-        out[0] += part[4*(size_t)b];
-        out[1] += part[4*(size_t)b + 1];
-        out[2] += part[4*(size_t)b + 2];
-        out[3] = std::fmin(out[3], part[4*(size_t)b + 3]);
-    }
-    if (int rc = flow_check(h)) return rc;
-    if (!std::isfinite(out[0]) || !std::isfinite(out[1]) || !std::isfinite(out[2]))
-        return fail(h, SWE2D_ERR_NOT_FINITE, "state is not finite");
+    int64_t limbs[3*SWE_SUM_LIMBS];
+    if (int rc = run_diagnostics(h, limbs, &out[3])) return rc;
+    for (int q = 0; q < 3; q++) out[q] = swe2d_sum_limbs_to_double(limbs + SWE_SUM_LIMBS*q);
     return SWE2D_OK;
 }
 
@@ -2190,34 +2236,67 @@ int swe2d_tracer_halo_unpack(swe2d_handle *hh, int id, int i_buffer, const doubl
     return SWE2D_OK;
 }
 
+namespace {
+int run_tracer_diagnostics(Handle *h, int id, int64_t limbs[2*SWE_SUM_LIMBS], double minmax[2])
+{
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemsetAsync(h->diag_acc, 0, SWE_DIAG_ACC*sizeof(unsigned long long), h->stream));
+    if (h->npc == 4)
+        hipLaunchKernelGGL(swe_tracer_diag_kernel_quad, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
+                           h->tracers[id].buf[0], h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh,
+                           h->par.use_nonlinear_equations, h->n_owned, h->partial, h->wd ? h->valpha : nullptr, h->affine ? 1 : 0,
+                           h->diag_acc);
+    else
+        hipLaunchKernelGGL(swe_tracer_diag_kernel, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
+                           h->tracers[id].buf[0], h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh,
+                           h->par.use_nonlinear_equations, h->n_owned, h->partial, h->wd ? h->valpha : nullptr, h->diag_acc);
+    HIP_TRY(h, hipGetLastError());
+    std::vector<double> part(2*(size_t)h->n_partial_blocks);
+    unsigned long long acc[SWE_DIAG_ACC];
+    HIP_TRY(h, hipMemcpyAsync(part.data(), h->partial, part.size()*sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(acc, h->diag_acc, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    minmax[0] = 1e300; minmax[1] = -1e300;
+    for (int b = 0; b < h->n_partial_blocks; b++) {
+        minmax[0] = std::fmin(minmax[0], part[2*(size_t)b]);
+        minmax[1] = std::fmax(minmax[1], part[2*(size_t)b + 1]);
+    }
+    for (int i = 0; i < 2*SWE_SUM_LIMBS; i++) limbs[i] = (int64_t)acc[i];
+    if (acc[2*SWE_SUM_LIMBS] != 0)
+        return fail(h, SWE2D_ERR_NOT_FINITE, "tracer is not finite");
+    return SWE2D_OK;
+}
+}  // namespace
+
+int swe2d_tracer_diagnostics_limbs(swe2d_handle *hh, int id, int64_t limbs[8], double minmax[2])
+{
+    Handle *h = H(hh);
+    int rc = check_tracer(h, id);
+    if (rc) return rc;
+    if (!limbs || !minmax) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    return run_tracer_diagnostics(h, id, limbs, minmax);
+}
+
 int swe2d_tracer_diagnostics(swe2d_handle *hh, int id, double out[4])
 {
     Handle *h = H(hh);
     int rc = check_tracer(h, id);
     if (rc) return rc;
     if (!out) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
-    HIP_TRY(h, hipSetDevice(h->device));
-    if (h->npc == 4)
-        hipLaunchKernelGGL(swe_tracer_diag_kernel_quad, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
-                           h->tracers[id].buf[0], h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh,
-                           h->par.use_nonlinear_equations, h->n_owned, h->partial, h->wd ? h->valpha : nullptr, h->affine ? 1 : 0);
-    else
-        hipLaunchKernelGGL(swe_tracer_diag_kernel, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
-                           h->tracers[id].buf[0], h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh,
-                           h->par.use_nonlinear_equations, h->n_owned, h->partial, h->wd ? h->valpha : nullptr);
-    HIP_TRY(h, hipGetLastError());
-    std::vector<double> part(4*(size_t)h->n_partial_blocks);
-    HIP_TRY(h, hipMemcpyAsync(part.data(), h->partial, part.size()*sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    out[0] = out[1] = 0.0; out[2] = 1e300; out[3] = -1e300;
-    for (int b = 0; b < h->n_partial_blocks; b++) {
-        out[0] += part[4*(size_t)b];
-        out[1] += part[4*(size_t)b + 1];
-        out[2] = std::fmin(out[2], part[4*(size_t)b + 2]);
-        out[3] = std::fmax(out[3], part[4*(size_t)b + 3]);
-    }
-    if (!std::isfinite(out[0]) || !std::isfinite(out[1]))
-        return fail(h, SWE2D_ERR_NOT_FINITE, "tracer is not finite");
+    int64_t limbs[2*SWE_SUM_LIMBS];
+    if ((rc = run_tracer_diagnostics(h, id, limbs, out + 2))) return rc;
+    out[0] = swe2d_sum_limbs_to_double(limbs);
+    out[1] = swe2d_sum_limbs_to_double(limbs + SWE_SUM_LIMBS);
+    return SWE2D_OK;
+}
+
+int swe2d_set_general_quadrilaterals(swe2d_handle *hh, int on)
+{
+    Handle *h = H(hh);
+    if (!h) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null handle");
+    if (h->npc != 4) return on ? fail(h, SWE2D_ERR_INVALID_ARGUMENT, "not a quadrilateral mesh") : SWE2D_OK;
+    if (!on && !h->affine_local) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "the mesh has cells that are not parallelograms");
+    h->affine = !on;
     return SWE2D_OK;
 }
 

@@ -1343,12 +1343,53 @@ __global__ void swe_wd_relax_kernel(double *planes, size_t stride, const int *cv
     }
 }
 
-// diagnostics: per-block partial sums { int eta^2, int |u|^2, int (eta+h), min(h+eta) }, finished on the host
+// ---- order-independent sums for the diagnostics ---------------------------------------------------------------------------
+// A floating-point sum depends on the order of its terms, i.e. on how a mesh is cut into blocks and partitions; the integrals
+// print_state and the conservation callbacks show (solver2d.py:955-956, callback.py:323-328, all-reduced over the ranks in the
+// reference, callback.py:478-482) would then differ in their last digits between a run on one GPU and the same run on eight.
+// Every per-cell contribution x is therefore split EXACTLY into four signed 38-bit limbs of units 2^40, 2^2, 2^-36, 2^-74
+// (|x| < 2^78 ~ 3e23; what lies below 2^-74 ~ 5e-23 is truncated, per term, in the same way wherever the term is computed) and
+// the limbs are added as 64-bit integers - associative, so lanes, blocks and ranks may add them in any order (2^25 terms fit).
+// swe2d_sum_limbs_to_double (csrc/swe2d_api.hip) rounds the total to the nearest double, once.
+#define SWE_SUM_LIMBS 4
+__device__ __forceinline__ void swe_sum_split(double x, long long q[SWE_SUM_LIMBS], unsigned &bad)
+{
+    if (!(fabs(x) < 0x1p78)) { bad = 1u; x = 0.0; }                      // NaN, Inf, or out of range: reported, not summed
+    double t = trunc(x*0x1p-40); q[0] = (long long)t; x -= t*0x1p40;      // every product and difference here is exact
+    t = trunc(x*0x1p-2);  q[1] = (long long)t; x -= t*0x1p2;
+    t = trunc(x*0x1p36);  q[2] = (long long)t; x -= t*0x1p-36;
+    t = trunc(x*0x1p74);  q[3] = (long long)t;
+}
+// adds the block's (one wave's) sum of x to acc[0..3]; acc[4*n_sums] of the launch counts the terms that were not summed
+__device__ __forceinline__ void swe_sum_accumulate(double x, unsigned long long *acc, unsigned long long *bad_counter)
+{
+    long long q[SWE_SUM_LIMBS];
+    unsigned bad = 0u;
+    swe_sum_split(x, q, bad);
+    for (int j = 0; j < SWE_SUM_LIMBS; j++) {
+        long long v = q[j];
+        for (int off = SWE_BLOCK/2; off > 0; off >>= 1) v += __shfl_down(v, off, SWE_BLOCK);
+        if (threadIdx.x == 0 && v != 0) atomicAdd(acc + j, (unsigned long long)v);
+    }
+    if (bad) atomicAdd(bad_counter, 1ull);
+}
+__device__ __forceinline__ double swe_wave_min(double v)
+{
+    for (int off = SWE_BLOCK/2; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, SWE_BLOCK));
+    return v;
+}
+__device__ __forceinline__ double swe_wave_max(double v)
+{
+    for (int off = SWE_BLOCK/2; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, SWE_BLOCK));
+    return v;
+}
+
+// diagnostics: { int eta^2, int |u|^2, int (eta+h) } as limb sums in acc[12] (+ acc[12]: terms out of range), min(h+eta) per block
 __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel(const double *planes, size_t stride, const int *cv,
                                                              const double *vx, const double *vy, const double *vh,
-                                                             int n, double *partial, const double *valpha)
+                                                             int n, double *partial, const double *valpha,
+                                                             unsigned long long *acc)
 {
-    __shared__ double red[4][SWE_BLOCK];
     const int k = blockIdx.x*SWE_BLOCK + threadIdx.x;
     double s_e2 = 0.0, s_u2 = 0.0, s_vol = 0.0, s_min = 1e300;
     if (k < n) {
@@ -1367,19 +1408,11 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel(const double *plane
         s_vol = A*(1.0/3.0)*(h[0] + h[1] + h[2]);
         s_min = fmin(fmin(h[0], h[1]), h[2]);
     }
-    red[0][threadIdx.x] = s_e2; red[1][threadIdx.x] = s_u2; red[2][threadIdx.x] = s_vol; red[3][threadIdx.x] = s_min;
-    __syncthreads();
-    for (int off = SWE_BLOCK/2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + off];
-            red[1][threadIdx.x] += red[1][threadIdx.x + off];
-            red[2][threadIdx.x] += red[2][threadIdx.x + off];
-            red[3][threadIdx.x] = fmin(red[3][threadIdx.x], red[3][threadIdx.x + off]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        for (int q = 0; q < 4; q++) partial[4*(size_t)blockIdx.x + q] = red[q][0];
+    swe_sum_accumulate(s_e2, acc, acc + 3*SWE_SUM_LIMBS);
+    swe_sum_accumulate(s_u2, acc + SWE_SUM_LIMBS, acc + 3*SWE_SUM_LIMBS);
+    swe_sum_accumulate(s_vol, acc + 2*SWE_SUM_LIMBS, acc + 3*SWE_SUM_LIMBS);
+    s_min = swe_wave_min(s_min);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s_min;
 }
 
 // ===============================================================================================================
@@ -1784,9 +1817,8 @@ __global__ void swe_limiter_apply(double *t, size_t stride, int n, const int *tv
 __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel(const double *t, const double *state, size_t stride,
                                                                     const int *cv, const double *vx, const double *vy,
                                                                     const double *vh, int nonlinear, int n, double *partial,
-                                                                    const double *valpha)
+                                                                    const double *valpha, unsigned long long *acc)
 {
-    __shared__ double red[4][SWE_BLOCK];
     const int k = blockIdx.x*SWE_BLOCK + threadIdx.x;
     double s_m = 0.0, s_i = 0.0, s_min = 1e300, s_max = -1e300;
     if (k < n) {
@@ -1804,19 +1836,11 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel(const double
         s_min = fmin(fmin(c[0], c[1]), c[2]);
         s_max = fmax(fmax(c[0], c[1]), c[2]);
     }
-    red[0][threadIdx.x] = s_m; red[1][threadIdx.x] = s_i; red[2][threadIdx.x] = s_min; red[3][threadIdx.x] = s_max;
-    __syncthreads();
-    for (int off = SWE_BLOCK/2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + off];
-            red[1][threadIdx.x] += red[1][threadIdx.x + off];
-            red[2][threadIdx.x] = fmin(red[2][threadIdx.x], red[2][threadIdx.x + off]);
-            red[3][threadIdx.x] = fmax(red[3][threadIdx.x], red[3][threadIdx.x + off]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        for (int q = 0; q < 4; q++) partial[4*(size_t)blockIdx.x + q] = red[q][0];
+    swe_sum_accumulate(s_m, acc, acc + 2*SWE_SUM_LIMBS);
+    swe_sum_accumulate(s_i, acc + SWE_SUM_LIMBS, acc + 2*SWE_SUM_LIMBS);
+    s_min = swe_wave_min(s_min);
+    s_max = swe_wave_max(s_max);
+    if (threadIdx.x == 0) { partial[2*(size_t)blockIdx.x] = s_min; partial[2*(size_t)blockIdx.x + 1] = s_max; }
 }
 
 // scalar nodal field (3N) <-> 3 planes
@@ -2228,9 +2252,9 @@ __device__ __forceinline__ double swe_quad_form(const SweQuadMass &M, const doub
 
 __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel_quad(const double *planes, size_t stride, const int *cv,
                                                                   const double *vx, const double *vy, const double *vh,
-                                                                  int n, double *partial, const double *valpha, int affine)
+                                                                  int n, double *partial, const double *valpha, int affine,
+                                                                  unsigned long long *acc)
 {
-    __shared__ double red[4][SWE_BLOCK];
     const int k = blockIdx.x*SWE_BLOCK + threadIdx.x;
     double s_e2 = 0.0, s_u2 = 0.0, s_vol = 0.0, s_min = 1e300;
     if (k < n) {
@@ -2261,19 +2285,11 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel_quad(const double *
         }
         s_min = fmin(fmin(h[0], h[1]), fmin(h[2], h[3]));
     }
-    red[0][threadIdx.x] = s_e2; red[1][threadIdx.x] = s_u2; red[2][threadIdx.x] = s_vol; red[3][threadIdx.x] = s_min;
-    __syncthreads();
-    for (int off = SWE_BLOCK/2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + off];
-            red[1][threadIdx.x] += red[1][threadIdx.x + off];
-            red[2][threadIdx.x] += red[2][threadIdx.x + off];
-            red[3][threadIdx.x] = fmin(red[3][threadIdx.x], red[3][threadIdx.x + off]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        for (int q = 0; q < 4; q++) partial[4*(size_t)blockIdx.x + q] = red[q][0];
+    swe_sum_accumulate(s_e2, acc, acc + 3*SWE_SUM_LIMBS);
+    swe_sum_accumulate(s_u2, acc + SWE_SUM_LIMBS, acc + 3*SWE_SUM_LIMBS);
+    swe_sum_accumulate(s_vol, acc + 2*SWE_SUM_LIMBS, acc + 3*SWE_SUM_LIMBS);
+    s_min = swe_wave_min(s_min);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s_min;
 }
 
 // ---- tracer stage on parallelogram quadrilaterals (see swe_tracer_stage_kernel and swe_stage_kernel_quad)
@@ -2454,9 +2470,8 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
 __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel_quad(const double *t, const double *state, size_t stride,
                                                                          const int *cv, const double *vx, const double *vy,
                                                                          const double *vh, int nonlinear, int n, double *partial,
-                                                                         const double *valpha, int affine)
+                                                                         const double *valpha, int affine, unsigned long long *acc)
 {
-    __shared__ double red[4][SWE_BLOCK];
     const int k = blockIdx.x*SWE_BLOCK + threadIdx.x;
     double s_m = 0.0, s_i = 0.0, s_min = 1e300, s_max = -1e300;
     if (k < n) {
@@ -2485,17 +2500,9 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel_quad(const d
         s_min = fmin(fmin(c[0], c[1]), fmin(c[2], c[3]));
         s_max = fmax(fmax(c[0], c[1]), fmax(c[2], c[3]));
     }
-    red[0][threadIdx.x] = s_m; red[1][threadIdx.x] = s_i; red[2][threadIdx.x] = s_min; red[3][threadIdx.x] = s_max;
-    __syncthreads();
-    for (int off = SWE_BLOCK/2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + off];
-            red[1][threadIdx.x] += red[1][threadIdx.x + off];
-            red[2][threadIdx.x] = fmin(red[2][threadIdx.x], red[2][threadIdx.x + off]);
-            red[3][threadIdx.x] = fmax(red[3][threadIdx.x], red[3][threadIdx.x + off]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        for (int q = 0; q < 4; q++) partial[4*(size_t)blockIdx.x + q] = red[q][0];
+    swe_sum_accumulate(s_m, acc, acc + 2*SWE_SUM_LIMBS);
+    swe_sum_accumulate(s_i, acc + SWE_SUM_LIMBS, acc + 2*SWE_SUM_LIMBS);
+    s_min = swe_wave_min(s_min);
+    s_max = swe_wave_max(s_max);
+    if (threadIdx.x == 0) { partial[2*(size_t)blockIdx.x] = s_min; partial[2*(size_t)blockIdx.x + 1] = s_max; }
 }

@@ -140,6 +140,10 @@ class Swe2dDevice(object):
         p.device_id = device_id
         self.h = ctypes.c_void_p()
         _lib.check(self.lib.swe2d_create(ctypes.byref(m), ctypes.byref(p), ctypes.byref(self.h)))
+        if self.npc == 4 and not getattr(mesh, 'affine', True):
+            # a partition (LocalPartition.affine = the GLOBAL mesh's flag) whose own cells happen to be parallelograms takes the
+            # general kernels like every other rank: ghost and owned copies of a cell then agree bit for bit
+            self._ck(self.lib.swe2d_set_general_quadrilaterals(self.h, 1))
 
     # -- lifetime
     def close(self):
@@ -452,6 +456,26 @@ class Swe2dDevice(object):
         out = np.empty(4)
         self._ck(self.lib.swe2d_diagnostics(self.h, _ptr(out)))
         return out
+
+    def diagnostics_limbs(self):
+        """The three integrals of ``diagnostics`` as order-independent limb sums (int64 [3][4], include/swe2d.h) + the minimum
+        depth: partitions add their limbs as integers and round once with ``limbs_to_double``."""
+        limbs = np.zeros(12, dtype=np.int64)
+        lo = ctypes.c_double()
+        self._ck(self.lib.swe2d_diagnostics_limbs(self.h, limbs.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.byref(lo)))
+        return limbs.reshape(3, 4), float(lo.value)
+
+    def tracer_diagnostics_limbs(self, tid):
+        """limb sums [2][4] of {int T*H dx, int T dx} + (min, max)"""
+        limbs = np.zeros(8, dtype=np.int64)
+        mm = np.empty(2)
+        self._ck(self.lib.swe2d_tracer_diagnostics_limbs(self.h, int(tid), limbs.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _ptr(mm)))
+        return limbs.reshape(2, 4), mm
+
+    def limbs_to_double(self, limbs):
+        """the total of limb sums [4] rounded to the nearest double (swe2d_sum_limbs_to_double)"""
+        a = np.ascontiguousarray(limbs, dtype=np.int64).reshape(4)
+        return float(self.lib.swe2d_sum_limbs_to_double(a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
 
     # -- tracers + limiter
     def _nodal_in(self, a):

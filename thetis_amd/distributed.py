@@ -451,13 +451,24 @@ class DistributedSwe2d(object):
             dist.all_reduce(t, op=op, group=self.group)
         return t.cpu().numpy()
 
-    def tracer_diagnostics(self, i_tracer):
-        """Global {int T*H dx, int T dx, min, max} of tracer ``i_tracer``."""
+    def _all_reduce_int(self, values):
+        """Exact sum of int64 values over the ranks."""
+        import torch
         import torch.distributed as dist
-        d = self.dev.tracer_diagnostics(self.tids[i_tracer])
-        s = self._all_reduce(d[:2], dist.ReduceOp.SUM)
-        m = self._all_reduce([d[2], -d[3]], dist.ReduceOp.MIN)
-        return np.concatenate([s, [m[0], -m[1]]])
+        on_host = self.exchange != 'rccl'
+        t = torch.tensor(np.asarray(values, dtype=np.int64).ravel(), dtype=torch.int64, device='cpu' if on_host else self.torch_device)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def tracer_diagnostics(self, i_tracer):
+        """Global {int T*H dx, int T dx, min, max} of tracer ``i_tracer``: the integrals as order-independent limb sums added over
+        the ranks as integers (include/swe2d.h, swe2d_diagnostics_limbs) - the doubles of the single-device run, bit for bit."""
+        import torch.distributed as dist
+        limbs, mm = self.dev.tracer_diagnostics_limbs(self.tids[i_tracer])
+        total = self._all_reduce_int(limbs).reshape(2, 4)
+        m = self._all_reduce([mm[0], -mm[1]], dist.ReduceOp.MIN)
+        return np.array([self.dev.limbs_to_double(total[0]), self.dev.limbs_to_double(total[1]), m[0], -m[1]])
 
     def set_state_global(self, uv, eta):
         g = self.part.local_to_global
@@ -840,11 +851,13 @@ class DistributedSwe2d(object):
         self._check_exchange()
 
     def diagnostics(self):
-        """Global {int eta^2, int |u|^2, int (eta+h), min(h+eta)}: per-rank partial sums all-reduced."""
+        """Global {int eta^2, int |u|^2, int (eta+h), min(h+eta)}: the all-reduced diagnostics of the reference
+        (thetis/callback.py:478-482) as limb sums added over the ranks as integers - the doubles of the single-device run."""
         import torch.distributed as dist
         self._check_exchange()
-        d = self.dev.diagnostics()
-        return np.concatenate([self._all_reduce(d[:3], dist.ReduceOp.SUM), self._all_reduce(d[3:], dist.ReduceOp.MIN)])
+        limbs, lo = self.dev.diagnostics_limbs()
+        total = self._all_reduce_int(limbs).reshape(3, 4)
+        return np.array([self.dev.limbs_to_double(total[q]) for q in range(3)] + [self._all_reduce([lo], dist.ReduceOp.MIN)[0]])
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -206,6 +206,7 @@ def build_partition(mesh, owner, rank, halo_depth=3, adjacency='facet'):
     else:
         part.topo_vertex = np.arange(len(used), dtype=np.int64)
     part.halo_depth, part.adjacency = halo_depth, adjacency
+    part.affine = bool(getattr(mesh, 'affine', True))        # of the GLOBAL mesh: every rank takes the same kernel family
 
     nb_l = nbr[local_global].astype(np.int64)
     pos = nb_l >= 0
