@@ -17,6 +17,8 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <atomic>
+#include <mutex>
 
 static_assert(SWE2D_MAX_MARKERS == SWE_MAX_MARKERS, "marker table size mismatch");
 
@@ -82,6 +84,13 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// the last flow launch per device of this process (launch_flow)
+struct FlowChain { hipEvent_t ev = nullptr; unsigned long long last_uid = 0ull; };
+constexpr int kFlowChainDevices = 64;
+FlowChain g_flow_chain[kFlowChainDevices];
+std::mutex g_flow_chain_mu;
+std::atomic<unsigned long long> g_next_uid{1ull};
+
 #define SWE_DIAG_ACC (3*SWE_SUM_LIMBS + 1)             // limb sums of up to three integrals + the counter of unsummable terms
 
 // Shu-Osher coefficients of SSPRK33: output of thetis/rungekutta.py:13-87 (butcher_to_shuosher_form) for the
@@ -92,6 +101,7 @@ const double kAlpha0[3] = {1.0, 0.75, 0.33333333333333337};   // weight of stage
 const double kAlphaIn[3] = {0.0, 0.25, 0.6666666666666666};   // weight of the stage's input (stage 0: U0 itself)
 
 struct Handle {
+    unsigned long long uid = g_next_uid.fetch_add(1ull);   // never reused (a freed handle's address may be)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -716,8 +726,32 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles =
     flow_kernel_t kern = pick_flow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h), fx,
                                           h->flow_max_rim > 64);
     SWE_CHK_SYNC(h->stream);
+    // Every block of a flow launch must be resident at once, and flow_capacity counts the whole device: two flow launches of
+    // DIFFERENT handles (streams) of this process on one device could each get a part of it and wait for their missing blocks
+    // until the timeout.  Launches that do not exchange with a peer are therefore chained per device: a launch waits for the
+    // previous flow launch of another handle (an event wait on the stream, no host synchronisation).  FX launches are left alone
+    // (peers inside one process must run side by side; across processes DistributedSwe2d does not choose the flow path by itself
+    // when ranks share a device), and so are launches under stream capture (one handle per graph).
+    bool chained = false;
+    if (!fx) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool capturing = h->stream && hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        chained = !capturing && h->device >= 0 && h->device < kFlowChainDevices;
+    }
+    std::unique_lock<std::mutex> lock(g_flow_chain_mu, std::defer_lock);
+    if (chained) {
+        lock.lock();
+        FlowChain &fc = g_flow_chain[h->device];
+        if (fc.ev && fc.last_uid != h->uid) HIP_TRY(h, hipStreamWaitEvent(h->stream, fc.ev, 0));
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, q);
     HIP_TRY(h, hipGetLastError());
+    if (chained) {
+        FlowChain &fc = g_flow_chain[h->device];
+        if (!fc.ev) HIP_TRY(h, hipEventCreateWithFlags(&fc.ev, hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(fc.ev, h->stream));
+        fc.last_uid = h->uid;
+    }
     h->flow_used = true;
     return SWE2D_OK;
 }

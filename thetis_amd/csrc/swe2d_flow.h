@@ -337,6 +337,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
     __shared__ int lact[SWE_BLOCK];                            // is the lane's cell inside the running stage's range?
     __shared__ unsigned lrec[SWE_BLOCK];                       // FX: places of the block's ghost / send cells' records in a landing zone
     __shared__ int lpeer[SWE_BLOCK];
+    __shared__ unsigned char lpub[SWE_FLOW_MAX_RIM];           // does the cell that owns the block's i-th slot publish in the running stage?
     __shared__ double lu0[9][SWE_BLOCK];                       // U(0) of the running time step (18 registers the stage loop cannot spare)
     const SweStageArgs &p = q.st;
     const int lb = swe_logical_block(blockIdx.x, gridDim.x);
@@ -460,7 +461,11 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 
     // publish the rim traces held in (pu, pv, pe) of the lanes in `who`: facet f carries my nodes f (granules 0-2) and f + 1
     // (granules 3-5).  The values go to the staging area by slot, then the wave stores the block's whole slot range, consecutive
-    // lanes on consecutive granules (full lines).  (A rim cell outside `who` leaves its entry as it was: a value nobody reads.)
+    // lanes on consecutive granules (full lines).  The slots of rim cells outside `who` (cells that have dropped out of the shrinking
+    // stage range) are NOT stored: value and tag stay those of the cell's last active stage.  The two-parity argument above - a
+    // producer reaches the end of stage s + 2 only after the consumer has read stage s - holds for cells the producer still waits
+    // for; a cell active in stage s but not later makes its block wait for nothing from the block it faces, so the block may run
+    // two stages ahead of a consumer that is stalled on another neighbour and must not touch the slot that consumer has yet to read.
 #define SWE_FLOW_PUBLISH(pu, pv, pe, who, pc_, set_) do {                                                                               \
         const unsigned tag_ = base + (unsigned)(pc_) + 1u;                                                                        \
         const unsigned par_ = (unsigned)(set_)*q.parity_bytes + (unsigned)myslots.x*SWE_FLOW_SLOT_BYTES;                    \
@@ -472,12 +477,13 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                 double *d_ = lds + SWE_LDSI(SWE_FLOW_XG + 6*xown[f] + 5, SWE_FLOW_LDS_DOUBLES) - 5;                                                                       \
                 d_[0] = pu[a_]; d_[1] = pv[a_]; d_[2] = pe[a_]; d_[3] = pu[b_]; d_[4] = pv[b_]; d_[5] = pe[b_];                   \
             }                                                                                                                     \
+            if (xown[f] >= 0) lpub[SWE_LDSI(xown[f], SWE_FLOW_MAX_RIM)] = (who) ? 1 : 0;                                          \
         }                                                                                                                         \
         __syncthreads();                                                                                                          \
         for (int t_ = lane; t_ < 8*nrim; t_ += SWE_BLOCK) {                                                                       \
             const int gi_ = t_ & 7;                                                                                               \
             const double x_ = gi_ < 6 ? lds[SWE_LDSI(SWE_FLOW_XG + 6*(t_ >> 3) + gi_, SWE_FLOW_LDS_DOUBLES)] : 0.0;                                               \
-            swe_flow_put(rex, par_ + 16u*(unsigned)t_, x_, tag_);                                                                 \
+            if (lpub[SWE_LDSI(t_ >> 3, SWE_FLOW_MAX_RIM)]) swe_flow_put(rex, par_ + 16u*(unsigned)t_, x_, tag_);                   \
         }                                                                                                                         \
     } while (0)
 
@@ -739,6 +745,7 @@ __global__ __launch_bounds__(256) void swe_flow_unpack_kernel(double *planes, si
     for (int j = blockIdx.x*256 + threadIdx.x; j < n_recv; j += gridDim.x*256) {
         const unsigned zo = (target & 1u)*slot + (unsigned)j*144u;
         double x[9];
+        bool timed_out = false;
         for (;;) {
             bool ok = true;
             for (int i = 0; i < 9; i++) {
@@ -747,9 +754,16 @@ __global__ __launch_bounds__(256) void swe_flow_unpack_kernel(double *planes, si
                 ok = ok && (int)(g.z - target) >= 0;
             }
             if (ok) break;
-            if (wall_clock64() - w0 > timeout_ticks) { atomicAdd(status, 1u); break; }
+            if (wall_clock64() - w0 > timeout_ticks) {
+                // counted and located like a timeout of the flow kernel ("block" = this kernel's workgroup); the cell keeps its old
+                // values - the state is reported invalid either way, never silently patched with half-arrived granules
+                if (atomicAdd(status, 1u) == 0u) status[1] = (unsigned)blockIdx.x + 1u;
+                timed_out = true;
+                break;
+            }
             __builtin_amdgcn_s_sleep(4);
         }
+        if (timed_out) continue;
         const int k = recv_cells[j];
         for (int i = 0; i < 9; i++) planes[(size_t)i*stride + k] = x[i];
     }
