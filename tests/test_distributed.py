@@ -541,17 +541,23 @@ def test_ranks_on_one_gpu_with_one_launch_per_cycle(tmp_path, hip_lib, monkeypat
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case,n_steps', [('channel+every2+p2p+flowx', 12), ('channel+every2+p2p+graph', 7), ('channel+every1+overlap2', 4)])
-def test_eight_ranks_on_one_gpu_match_single_device(tmp_path, hip_lib, case, n_steps):
-    """BASELINE cfg 3's rank count with the bits checked: eight processes share the test GPU, strips of two cell columns -
-    narrower than the six-layer halo of ``every2``, so a rank's ghost layers reach its second and third neighbours (up to six
-    peers, IPC handles exchanged among eight processes, SWE_P2P_MAX_PEERS = 8); in-launch exchange of the flow kernel ('+flowx'),
-    exchange kernels inside per-cycle HIP graphs, and the host-staged exchange with overlap.  Bitwise the single-device result."""
+@pytest.mark.parametrize('case,n_steps,min_peers', [('channel64+every2+p2p+flowx', 12, 2), ('channel+every2+p2p+flow+graph', 7, 4),
+                                                    ('channel+every2+p2p+graph', 7, 4), ('channel+every1+overlap2', 4, 2)])
+def test_eight_ranks_on_one_gpu_match_single_device(tmp_path, hip_lib, case, n_steps, min_peers):
+    """BASELINE cfg 3's rank count with the bits checked: eight processes share the test GPU (IPC handles exchanged among eight
+    processes, SWE_P2P_MAX_PEERS = 8).  'channel64': strips of eight cell columns, wider than the six-layer halo - the in-launch
+    exchange of the flow kernel ('+flowx', middle ranks with two peers).  'channel': strips of two columns, narrower than the
+    halo of ``every2``, so a rank's ghost layers reach its second and third neighbours (a cell is then sent to more than two peers:
+    flow launches followed by the exchange kernels, and exchange kernels inside per-cycle HIP graphs); host-staged exchange with
+    overlap.  Bitwise the single-device result."""
     from thetis_amd.device import Swe2dDevice
     import dist_worker
-    dist_worker.CASE = 'channel'
-    mesh, bath, uv, eta = dist_worker._case()
-    run_workers(gpu_worker, 8, n_steps, str(tmp_path), axis=0, case=case)
+    dist_worker.CASE = case.split('+')[0]
+    try:
+        mesh, bath, uv, eta = dist_worker._case()
+        run_workers(gpu_worker, 8, n_steps, str(tmp_path), axis=0, case=case)
+    finally:
+        dist_worker.CASE = 'channel'
     u_p, e_p, extra = gather(str(tmp_path), 8, mesh.num_cells)
     dev = Swe2dDevice(mesh, bath, 2.0)
     dev.set_state(uv, eta)
@@ -560,7 +566,18 @@ def test_eight_ranks_on_one_gpu_match_single_device(tmp_path, hip_lib, case, n_s
     dev.close()
     assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
     peers = [len(set(int(q) for q in np.atleast_1d(d['peers']))) for d in extra if 'peers' in d]
-    assert max(peers) >= 4                       # the halo is deeper than a strip is wide
+    assert max(peers) >= min_peers
+
+
+@pytest.mark.gpu
+def test_in_launch_exchange_is_refused_by_all_ranks_together(tmp_path, hip_lib):
+    """``flow_exchange=True`` where a cell goes to more than two peers (strips narrower than the halo): every rank raises the same
+    ValueError at its first ``advance`` - none is left waiting for granules that will never come."""
+    import dist_worker
+    with pytest.raises(AssertionError, match='exit code'):
+        run_workers(gpu_worker, 8, 4, str(tmp_path), axis=0, case='channel+every2+p2p+flowx')
+    log = (tmp_path/'refused.txt')
+    assert sorted(log.read_text().split()) == [str(r) for r in range(8)]
 
 
 @pytest.mark.gpu

@@ -91,7 +91,6 @@ FlowChain g_flow_chain[kFlowChainDevices];
 std::mutex g_flow_chain_mu;
 std::atomic<unsigned long long> g_next_uid{1ull};
 
-#define SWE_DIAG_ACC (3*SWE_SUM_LIMBS + 1)             // limb sums of up to three integrals + the counter of unsummable terms
 
 // Shu-Osher coefficients of SSPRK33: output of thetis/rungekutta.py:13-87 (butcher_to_shuosher_form) for the
 // tableau of rungekutta.py:342-346; pinned by tests/golden/shuosher_ssprk33.json.
@@ -869,7 +868,7 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
     HIP_TRY_C(hipMalloc(&h->stage_eta, (size_t)npc*n*sizeof(double)));
     h->n_partial_blocks = (h->n_owned + SWE_BLOCK - 1)/SWE_BLOCK;
     HIP_TRY_C(hipMalloc(&h->partial, 4*(size_t)h->n_partial_blocks*sizeof(double)));
-    HIP_TRY_C(hipMalloc(&h->diag_acc, SWE_DIAG_ACC*sizeof(unsigned long long)));
+    HIP_TRY_C(hipMalloc(&h->diag_acc, SWE_DIAG_BUCKETS*SWE_DIAG_ACC*sizeof(unsigned long long)));
 
     // connectivity -> SoA planes, validated on the way
     std::vector<int> nbr((size_t)npc*S, 0), cv((size_t)npc*S, 0);
@@ -1624,7 +1623,7 @@ int run_diagnostics(Handle *h, int64_t limbs[3*SWE_SUM_LIMBS], double *min_depth
 {
     HIP_TRY(h, hipSetDevice(h->device));
     SWE_CHK_SYNC(h->stream);
-    HIP_TRY(h, hipMemsetAsync(h->diag_acc, 0, SWE_DIAG_ACC*sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->diag_acc, 0, SWE_DIAG_BUCKETS*SWE_DIAG_ACC*sizeof(unsigned long long), h->stream));
     if (h->npc == 4)
         hipLaunchKernelGGL(swe_diag_kernel_quad, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
                            h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh, h->n_owned, h->partial,
@@ -1635,10 +1634,12 @@ int run_diagnostics(Handle *h, int64_t limbs[3*SWE_SUM_LIMBS], double *min_depth
                            h->wd ? h->valpha : nullptr, h->diag_acc);
     HIP_TRY(h, hipGetLastError());
     std::vector<double> part((size_t)h->n_partial_blocks);
-    unsigned long long acc[SWE_DIAG_ACC];
+    unsigned long long acc[SWE_DIAG_ACC] = {0}, copies[SWE_DIAG_BUCKETS*SWE_DIAG_ACC];
     HIP_TRY(h, hipMemcpyAsync(part.data(), h->partial, part.size()*sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(acc, h->diag_acc, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(copies, h->diag_acc, sizeof(copies), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int b = 0; b < SWE_DIAG_BUCKETS; b++)
+        for (int i = 0; i < SWE_DIAG_ACC; i++) acc[i] += copies[b*SWE_DIAG_ACC + i];        // mod 2^64 = two's complement sums
     *min_depth = 1e300;
     for (double v : part) *min_depth = std::fmin(*min_depth, v);
     for (int i = 0; i < 3*SWE_SUM_LIMBS; i++) limbs[i] = (int64_t)acc[i];
@@ -2274,7 +2275,7 @@ namespace {
 int run_tracer_diagnostics(Handle *h, int id, int64_t limbs[2*SWE_SUM_LIMBS], double minmax[2])
 {
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemsetAsync(h->diag_acc, 0, SWE_DIAG_ACC*sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->diag_acc, 0, SWE_DIAG_BUCKETS*SWE_DIAG_ACC*sizeof(unsigned long long), h->stream));
     if (h->npc == 4)
         hipLaunchKernelGGL(swe_tracer_diag_kernel_quad, dim3(h->n_partial_blocks), dim3(SWE_BLOCK), 0, h->stream,
                            h->tracers[id].buf[0], h->state[0], h->stride, h->cv, h->vx, h->vy, h->vh,
@@ -2286,10 +2287,12 @@ int run_tracer_diagnostics(Handle *h, int id, int64_t limbs[2*SWE_SUM_LIMBS], do
                            h->par.use_nonlinear_equations, h->n_owned, h->partial, h->wd ? h->valpha : nullptr, h->diag_acc);
     HIP_TRY(h, hipGetLastError());
     std::vector<double> part(2*(size_t)h->n_partial_blocks);
-    unsigned long long acc[SWE_DIAG_ACC];
+    unsigned long long acc[SWE_DIAG_ACC] = {0}, copies[SWE_DIAG_BUCKETS*SWE_DIAG_ACC];
     HIP_TRY(h, hipMemcpyAsync(part.data(), h->partial, part.size()*sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(acc, h->diag_acc, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(copies, h->diag_acc, sizeof(copies), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int b = 0; b < SWE_DIAG_BUCKETS; b++)
+        for (int i = 0; i < SWE_DIAG_ACC; i++) acc[i] += copies[b*SWE_DIAG_ACC + i];        // mod 2^64 = two's complement sums
     minmax[0] = 1e300; minmax[1] = -1e300;
     for (int b = 0; b < h->n_partial_blocks; b++) {
         minmax[0] = std::fmin(minmax[0], part[2*(size_t)b]);

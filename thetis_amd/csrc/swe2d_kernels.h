@@ -1352,6 +1352,9 @@ __global__ void swe_wd_relax_kernel(double *planes, size_t stride, const int *cv
 // the limbs are added as 64-bit integers - associative, so lanes, blocks and ranks may add them in any order (2^25 terms fit).
 // swe2d_sum_limbs_to_double (csrc/swe2d_api.hip) rounds the total to the nearest double, once.
 #define SWE_SUM_LIMBS 4
+#define SWE_DIAG_ACC (3*SWE_SUM_LIMBS + 1)             // limb sums of up to three integrals + the counter of unsummable terms
+#define SWE_DIAG_BUCKETS 64                            // copies of the accumulators (block b adds to copy b % 64; the host adds the copies):
+                                                       //  15 625 blocks x 12 atomics on ONE set of addresses took 0.9 ms, serialised in L2
 __device__ __forceinline__ void swe_sum_split(double x, long long q[SWE_SUM_LIMBS], unsigned &bad)
 {
     if (!(fabs(x) < 0x1p78)) { bad = 1u; x = 0.0; }                      // NaN, Inf, or out of range: reported, not summed
@@ -1408,6 +1411,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel(const double *plane
         s_vol = A*(1.0/3.0)*(h[0] + h[1] + h[2]);
         s_min = fmin(fmin(h[0], h[1]), h[2]);
     }
+    acc += (size_t)(blockIdx.x & (SWE_DIAG_BUCKETS - 1))*SWE_DIAG_ACC;
     swe_sum_accumulate(s_e2, acc, acc + 3*SWE_SUM_LIMBS);
     swe_sum_accumulate(s_u2, acc + SWE_SUM_LIMBS, acc + 3*SWE_SUM_LIMBS);
     swe_sum_accumulate(s_vol, acc + 2*SWE_SUM_LIMBS, acc + 3*SWE_SUM_LIMBS);
@@ -1836,6 +1840,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel(const double
         s_min = fmin(fmin(c[0], c[1]), c[2]);
         s_max = fmax(fmax(c[0], c[1]), c[2]);
     }
+    acc += (size_t)(blockIdx.x & (SWE_DIAG_BUCKETS - 1))*SWE_DIAG_ACC;
     swe_sum_accumulate(s_m, acc, acc + 2*SWE_SUM_LIMBS);
     swe_sum_accumulate(s_i, acc + SWE_SUM_LIMBS, acc + 2*SWE_SUM_LIMBS);
     s_min = swe_wave_min(s_min);
@@ -2285,6 +2290,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel_quad(const double *
         }
         s_min = fmin(fmin(h[0], h[1]), fmin(h[2], h[3]));
     }
+    acc += (size_t)(blockIdx.x & (SWE_DIAG_BUCKETS - 1))*SWE_DIAG_ACC;
     swe_sum_accumulate(s_e2, acc, acc + 3*SWE_SUM_LIMBS);
     swe_sum_accumulate(s_u2, acc + SWE_SUM_LIMBS, acc + 3*SWE_SUM_LIMBS);
     swe_sum_accumulate(s_vol, acc + 2*SWE_SUM_LIMBS, acc + 3*SWE_SUM_LIMBS);
@@ -2500,6 +2506,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel_quad(const d
         s_min = fmin(fmin(c[0], c[1]), fmin(c[2], c[3]));
         s_max = fmax(fmax(c[0], c[1]), fmax(c[2], c[3]));
     }
+    acc += (size_t)(blockIdx.x & (SWE_DIAG_BUCKETS - 1))*SWE_DIAG_ACC;
     swe_sum_accumulate(s_m, acc, acc + 2*SWE_SUM_LIMBS);
     swe_sum_accumulate(s_i, acc + SWE_SUM_LIMBS, acc + 2*SWE_SUM_LIMBS);
     s_min = swe_wave_min(s_min);

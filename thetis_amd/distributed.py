@@ -291,6 +291,7 @@ class DistributedSwe2d(object):
         self._flow_request = flow
         self._flowx_request = flow_exchange
         self._flow_now = None                    # the rank-collective decision of the current advance() (see _decide_flow)
+        self._flowx_now = False
         self._shared_device = None               # do several ranks step on this GPU?  (found out at the first automatic decision)
         if flow is not False and self.dev.npc == 3 and self._on_gpu:
             # the flow kernel's blocks: all local cells (owned + ghost layers) in one locality order, so that a ghost cell
@@ -362,16 +363,26 @@ class DistributedSwe2d(object):
             self._shared_device = len(set(everyone)) < len(everyone)
         return self._shared_device
 
+    def _flowx_local(self):
+        """Can the exchange run INSIDE this rank's flow launches?  The FX kernels push a cell to at most two peers (strips, RCB
+        corners); a halo deeper than a part is wide sends cells to more - then the flow launch is followed by the exchange kernels."""
+        if self.p2p is None or self._flowx_request is False or os.environ.get('THETIS_AMD_FLOWX') == '0':
+            return False
+        sc = np.asarray(self.part.send_cells)
+        return not len(sc) or int(np.bincount(sc).max()) <= 2
+
     def _decide_flow(self):
         """The decision all ranks take TOGETHER at the start of an ``advance`` (collective when world > 1 and the choice is not
         ``flow=False``): a rank whose partition the kernel does not cover (one ghost side more than its neighbour, just over the
         resident capacity) would otherwise wait for stage-launch halos while its peers push flow granules, and every wait would
         run into its timeout.  Automatic choice (``flow=None``): only where every rank is covered and no two ranks share a GPU,
         agreed anew at every ``advance`` (the configuration may have changed in between, on every rank alike); ``flow=True``:
-        agreed once, a rank that is not covered makes all ranks raise."""
+        agreed once, a rank that is not covered makes all ranks raise.  The exchange inside the launches (``flow_exchange``) is
+        part of the same agreement."""
         import torch.distributed as dist
         if self._flow_request is False or self.world == 1:
             self._flow_now = self._flow_local()
+            self._flowx_now = self._flow_now and self._flowx_local()
             return self._flow_now
         if self._flow_request is True:
             if self._flow_now is None:
@@ -379,13 +390,21 @@ class DistributedSwe2d(object):
                     ok = self._flow_local()
                 except ValueError:
                     ok = False
-                if self._all_reduce([1.0 if ok else 0.0], dist.ReduceOp.MIN)[0] < 0.5:
+                okx = ok and self._flowx_local()
+                both = self._all_reduce([1.0 if ok else 0.0, 1.0 if okx else 0.0], dist.ReduceOp.MIN)
+                if both[0] < 0.5:
                     raise ValueError('flow=True: the flow kernel does not cover the partition of every rank (rank {:d}: {:})'.format(
                         self.rank, 'covered' if ok else 'not covered'))
-                self._flow_now = True
+                if self._flowx_request is True and both[1] < 0.5:
+                    raise ValueError('flow_exchange=True: the exchange inside the flow launches needs the peer-to-peer transport and '
+                                     'cells that go to at most two peers, on every rank (rank {:d}: {:})'.format(
+                                         self.rank, 'possible' if okx else 'not possible'))
+                self._flow_now, self._flowx_now = True, bool(both[1] > 0.5)
             return self._flow_now
         ok = self._flow_local() and not self._ranks_share_a_device()
-        self._flow_now = bool(self._all_reduce([1.0 if ok else 0.0], dist.ReduceOp.MIN)[0] > 0.5)
+        okx = ok and self._flowx_local()
+        both = self._all_reduce([1.0 if ok else 0.0, 1.0 if okx else 0.0], dist.ReduceOp.MIN)
+        self._flow_now, self._flowx_now = bool(both[0] > 0.5), bool(both[1] > 0.5)
         return self._flow_now
 
     @property
@@ -396,8 +415,10 @@ class DistributedSwe2d(object):
 
     @property
     def flow_exchange(self):
-        """True when the exchange runs inside the flow launches (see ``flow_exchange``)."""
-        return self.flow and self.p2p is not None and self._flowx_request is not False and os.environ.get('THETIS_AMD_FLOWX') != '0'
+        """True when the exchange runs inside the flow launches (see ``flow_exchange``): part of the ranks' common decision."""
+        if self._flow_now is None:
+            return self._flow_local() and self._flowx_local()
+        return bool(self._flow_now and self._flowx_now)
 
     def _steps_flow_exchange(self, n_steps, graphed):
         """``n_steps`` time steps as flow launches with the exchange inside: up to 64 cycles (384 stages) per launch, a shorter
@@ -691,8 +712,26 @@ class DistributedSwe2d(object):
             if not use_graph or self.graph_mode == 'none' or os.environ.get('THETIS_AMD_NO_GRAPH'):
                 self._steps_eager(n_steps)
                 return
-            if self.graph_mode == 'cycle' and not (self.tids or self.tracer_only):
+            coupled = bool(self.tids or self.tracer_only)
+            if self.graph_mode == 'cycle' and not coupled:
                 self._steps_eager(n_steps, graphed=True)
+                return
+            if coupled:
+                # coupled steps: the launch sequence of a chunk of steps as ONE graph, replayed chunk after chunk (a graph of a
+                # whole export interval would have tens of thousands of nodes), the remainder eagerly.  Only with the peer-to-peer
+                # exchange, whose sends and receives are kernels of this library: nothing else belongs inside a capture.
+                m = self.exchange_every
+                chunk = m*max(1, 16//m)
+                if self.p2p is None or n_steps < chunk:
+                    self._steps_eager(n_steps)
+                    return
+                if self.graph is None or self.graph_steps != chunk:
+                    self._capture(chunk)
+                while self.graph is not None and n_steps >= chunk:
+                    self.graph.replay()
+                    n_steps -= chunk
+                if n_steps:
+                    self._steps_eager(n_steps)
                 return
             if self.graph is None or self.graph_steps != n_steps:
                 self._capture(n_steps)
@@ -817,11 +856,14 @@ class DistributedSwe2d(object):
                 return
             try:
                 g = torch.cuda.CUDAGraph()
-                # warm-up outside capture (RCCL connection set-up must not happen inside a capture)
+                # warm-up outside capture (RCCL connection set-up must not happen inside a capture); everything it steps is put back
                 saved = self.dev.get_state()
+                saved_t = [self.dev.tracer_get_state(tid) for tid in self.tids]
                 self._steps_eager(1)
                 torch.cuda.synchronize()
                 self.dev.set_state(*saved)
+                for tid, T in zip(self.tids, saved_t):
+                    self.dev.tracer_set_state(tid, T)
                 with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
                     self._steps_eager(n_steps)
                 self.graph = g

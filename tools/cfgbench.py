@@ -94,8 +94,37 @@ def cfg5(steps=50, profile_only=False):
     dev.close()
 
 
+def cfg5_parts(steps=50, profile_only=False):
+    """cfg 5 taken apart: the Balzano geometry with neither / one / both of wetting-drying and Manning friction.  The four stage
+    kernels have different template arguments, so a PMC pass (CFGBENCH_ONLY=cfg5_parts_profile under tools/pmc.sh) lists their
+    instruction counts side by side: what each option costs per wave."""
+    mesh5 = RectangleMesh(707, 354, 13800.0, 7200.0)
+    n5 = mesh5.num_cells
+    for wd, manning in ((False, False), (True, False), (False, True), (True, True)):
+        # without wetting-drying the beach must stay wet: a deeper, gently sloping bed of the same shape
+        bath = mesh5.vertex_xy[:, 0]/2760.0 + (0.0 if wd else 3.0)
+        dev = Swe2dDevice(mesh5, bath, 0.1)
+        if wd:
+            dev.set_wetting_and_drying(0.4)
+        if manning:
+            dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+        dev.set_bc(2, {'elev': -0.5})
+        dev.set_state(np.zeros((n5, 3, 2)), np.zeros((n5, 3)))
+        if profile_only:
+            dev.advance(steps)
+            dev.synchronize()
+        else:
+            report('cfg5 geometry, wetting-drying {:}, Manning {:}'.format('on' if wd else 'off', 'on' if manning else 'off'),
+                   n5, 684.0 + (18.0 if wd else 0.0), timed(dev, dev.advance, steps))
+        dev.close()
+
+
 def main():
     only = os.environ.get('CFGBENCH_ONLY', '')          # e.g. 'quads' for kernel A/B runs
+    if only == 'cfg5_parts':
+        return cfg5_parts()
+    if only == 'cfg5_parts_profile':
+        return cfg5_parts(12, True)
     rng = np.random.default_rng(1234)
     if only == 'quads':
         return quads(rng)
