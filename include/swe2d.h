@@ -377,6 +377,10 @@ int  swe2d_flow_unpack_pending(swe2d_handle *h);
 int  swe2d_flow_set_order(swe2d_handle *h, const int32_t *cells_in_flow_order);
 int  swe2d_flow_status(swe2d_handle *h, int32_t *timeouts);
 int  swe2d_debug_flow_poke(swe2d_handle *h, int32_t block, int32_t delta);      /* test hook: skews one block's stage counter */
+/* test hook of the -DSWE_FLOW_DELAY build (an adversary for the granule protocol, csrc/swe2d_flow.h): one block sleeps at chosen
+ * points of its stage loop; where = 1 before polling | 2 before publishing | 4 before an in-launch receive | 8 before an
+ * in-launch push.  SWE2D_ERR_UNSUPPORTED in the product build. */
+int  swe2d_debug_flow_delay(swe2d_handle *h, int32_t block, int32_t where, int32_t microseconds, int32_t every_nth_stage);
 /* run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the handle's own */
 int  swe2d_set_stream(swe2d_handle *h, void *hip_stream);
 

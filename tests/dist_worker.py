@@ -351,7 +351,7 @@ def viscosity_field(mesh):
 def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     global CASE
     flags = {}
-    for f in ('+capture', '+graph', '+p2p', '+nosplit', '+flowx', '+flow'):   # order-independent suffix flags
+    for f in ('+capture', '+graph', '+p2p', '+nosplit', '+flowx', '+flow', '+delay'):   # order-independent suffix flags
         flags[f] = f in case
         case = case.replace(f, '')
     graphed = flags['+graph']              # per-cycle HIP graphs (around the eager host-staged exchange, or incl. the p2p kernels)
@@ -374,6 +374,13 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
         solver.dev.set_viscosity(viscosity_field(mesh)[solver.part.vertex_global], use_grad_div_viscosity_term=True)
     solver.set_state_global(uv, eta)
     d0 = solver.diagnostics()
+    if flags['+delay']:
+        # -DSWE_FLOW_DELAY build: on every rank one block (rank r: block 2 + r) sleeps 15 us before every in-launch receive and push
+        # and before every second polling pass / publish
+        from thetis_amd import _lib
+        rc = solver.dev.lib.swe2d_debug_flow_delay(solver.dev.h, 2 + rank, int(os.environ.get('FLOW_DELAY_WHERE', '15')), 15, 2)
+        if rc != _lib.OK:
+            raise RuntimeError('the loaded library is not the -DSWE_FLOW_DELAY build')
     if flags['+capture']:
         # what bench.py does: capture outside advance() (state restored), one untimed replay, state reset, the run
         solver._capture(n_steps)

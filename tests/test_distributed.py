@@ -570,6 +570,36 @@ def test_eight_ranks_on_one_gpu_match_single_device(tmp_path, hip_lib, case, n_s
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('world,case,n_steps,where', [(2, 'channel+every2+p2p+flowx+delay', 12, 15), (3, 'channel+every1+p2p+flowx+delay', 9, 12),
+                                                      (4, 'channel64+every2+p2p+flowx+delay', 10, 3)])
+def test_lagging_blocks_do_not_change_the_in_launch_exchange(tmp_path, hip_lib, monkeypatch, world, case, n_steps, where):
+    """Adversary for the in-launch exchange (-DSWE_FLOW_DELAY build only; skipped with the product library): on every rank one block
+    sleeps 15 us - two to three stage periods - before in-launch receives (4) and pushes (8), before polling passes (1) and
+    publishes (2), while its peers run ahead as far as "push n + 2 only after receive n + 1" lets them.  Bitwise the single device."""
+    import ctypes
+    from thetis_amd import _lib
+    from thetis_amd.device import Swe2dDevice
+    import dist_worker
+    dist_worker.CASE = case.split('+')[0]
+    try:
+        mesh, bath, uv, eta = dist_worker._case()
+        dev = Swe2dDevice(mesh, bath, 2.0)
+        if dev.lib.swe2d_debug_flow_delay(dev.h, -1, 0, 0, 1) != _lib.OK:
+            dev.close()
+            pytest.skip('needs the -DSWE_FLOW_DELAY build (tools/range_check.sh)')
+        monkeypatch.setenv('FLOW_DELAY_WHERE', str(where))
+        run_workers(gpu_worker, world, n_steps, str(tmp_path), axis=0, case=case)
+    finally:
+        dist_worker.CASE = 'channel'
+    u_p, e_p, extra = gather(str(tmp_path), world, mesh.num_cells)
+    dev.set_state(uv, eta)
+    dev.advance(n_steps)
+    u_s, e_s = dev.get_state()
+    dev.close()
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+
+
+@pytest.mark.gpu
 def test_in_launch_exchange_is_refused_by_all_ranks_together(tmp_path, hip_lib):
     """``flow_exchange=True`` where a cell goes to more than two peers (strips narrower than the halo): every rank raises the same
     ValueError at its first ``advance`` - none is left waiting for granules that will never come."""

@@ -254,3 +254,55 @@ def test_a_block_that_never_arrives_costs_a_bounded_wait_and_is_reported(hip_lib
     b = dev.get_state()
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     dev.close()
+
+
+def _delay_build(dev):
+    """True when the loaded library is the -DSWE_FLOW_DELAY build (tools/range_check.sh runs these tests against it)"""
+    from thetis_amd import _lib
+    rc = dev.lib.swe2d_debug_flow_delay(dev.h, -1, 0, 0, 1)
+    return rc == _lib.OK
+
+
+@pytest.mark.parametrize('where,us,every', [(1, 15, 1), (2, 15, 1), (3, 12, 2), (1, 18, 3), (2, 18, 5)])
+@pytest.mark.parametrize('case', ['channel', 'shrinking'])
+def test_a_block_that_lags_two_to_three_stage_periods_changes_no_bit(hip_lib, case, where, us, every):
+    """Adversary for the granule protocol (-DSWE_FLOW_DELAY build only; skipped with the product library): one block sleeps
+    12-18 us - two to three stage periods - before its polling pass (1), before it publishes (2) or both (3), in every / every n-th
+    stage, while its neighbours run as far ahead as the two slot parities let them.  'shrinking': one rank's cells of a strip
+    partition on the twelve shrinking stage ranges of a halo cycle, twice - rim cells drop out of the range while the block that
+    faces them lags (their slots must keep the value of their last active stage).  Bit for bit the stage launches."""
+    from thetis_amd.device import Swe2dDevice
+    if case == 'shrinking':
+        from thetis_amd import ordering
+        from thetis_amd.partition import build_partition, strip_owner
+        mesh, bath, uv, eta = channel_case(nx=160, ny=48, seed=9)
+        part = build_partition(mesh, strip_owner(mesh, 4), 1, halo_depth=12)
+        g = part.local_to_global
+        dev = Swe2dDevice(part, np.asarray(bath)[part.vertex_global], 0.05, n_owned=part.n_owned, boundary_len=part.boundary_len,
+                          ranges=part.reorder_ranges())
+        dev.flow_set_order(ordering.auto_cell_order(part, 0, part.num_cells))
+        uv, eta = uv[g], eta[g]
+        ends = [part.stage_range(s_, depth=12) for s_ in range(12)]
+        launches = [ends, ends]
+    else:
+        mesh, bath, uv, eta = channel_case(nx=67, ny=31, seed=11)
+        dev = _device(mesh, bath, 0.05)
+        launches = [[dev.n_cells]*12, [dev.n_cells]*18]
+    if not _delay_build(dev):
+        dev.close()
+        pytest.skip('needs the -DSWE_FLOW_DELAY build (tools/range_check.sh)')
+    n_blocks = (dev.n_cells + 63)//64
+    dev.set_state(uv, eta)
+    for ends in launches:
+        _by_stage(dev, ends)
+    ref = dev.get_state()
+    for blk in (n_blocks//2, 1, n_blocks - 2, n_blocks//3):
+        dev.set_state(uv, eta)
+        assert dev.lib.swe2d_debug_flow_delay(dev.h, blk, where, us, every) == 0
+        for ends in launches:
+            dev.solve_flow(ends)
+        assert dev.flow_timeouts() == 0
+        got = dev.get_state()
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), 'block {:d}'.format(blk)
+    dev.lib.swe2d_debug_flow_delay(dev.h, -1, 0, 0, 1)
+    dev.close()

@@ -66,5 +66,6 @@ def test_example_scripts_under_torch_distributed_run(hip_lib, script, args, key,
     ref = [l for l in one.splitlines() if l.startswith(key)]
     got = [l for l in many.splitlines() if l.startswith(key)]
     assert len(ref) == 1 and len(got) == world and all(g == ref[0] for g in got), (ref, got)
-    state = lambda out: [l for l in out.splitlines() if l.strip()[:1].isdigit() and len(l.split()) >= 5]
-    assert state(many) == state(one) and len(state(one)) >= 2              # print_state lines: once, and the same numbers
+    # print_state lines (exp iter time norms... Tcpu): once, and the same numbers up to the wall-clock column
+    state = lambda out: [l.split()[:-1] for l in out.splitlines() if len(l.split()) >= 5 and l.split()[0].isdigit() and l.split()[1].isdigit()]
+    assert state(many) == state(one) and len(state(one)) >= 2

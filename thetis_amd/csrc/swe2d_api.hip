@@ -1488,6 +1488,24 @@ int swe2d_debug_flow_poke(swe2d_handle *hh, int32_t block, int32_t delta)
     return SWE2D_OK;
 }
 
+// test hook of the -DSWE_FLOW_DELAY build (csrc/swe2d_flow.h): block `block` of every flow launch of this process sleeps
+// `microseconds` at the points in `where` of every `every`-th stage; block < 0 switches it off.  SWE2D_ERR_UNSUPPORTED in the product build.
+int swe2d_debug_flow_delay(swe2d_handle *hh, int32_t block, int32_t where, int32_t microseconds, int32_t every)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+#ifdef SWE_FLOW_DELAY
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int cfg[4] = {block, where, microseconds*100, every < 1 ? 1 : every};
+    HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(swe_flow_delay), cfg, sizeof(cfg)));
+    return SWE2D_OK;
+#else
+    (void)block; (void)where; (void)microseconds; (void)every;
+    return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_debug_flow_delay: this library was built without -DSWE_FLOW_DELAY");
+#endif
+}
+
 int swe2d_advance_forward_euler(swe2d_handle *hh, int n_steps)
 {
     Handle *h = H(hh);

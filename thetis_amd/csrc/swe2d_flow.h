@@ -88,6 +88,25 @@ __device__ __forceinline__ unsigned swe_lds_index_chk(unsigned i, unsigned n, in
 #define SWE_LDSI(i, n) (i)
 #endif
 
+// -DSWE_FLOW_DELAY (tools/range_check.sh builds it next to the range-checked library): an adversary for the granule protocol.
+// One chosen block sleeps `ticks` of the 100 MHz wall clock (two to three stage periods) at a chosen point of every `every`-th
+// stage - before its polling pass (1), before it publishes (2), before an FX receive (4), before an FX push (8) - so that its
+// neighbours run ahead as far as the protocol lets them, or wait for it as long as it takes.  The slot-parity argument (a slot of
+// stage s is overwritten at the end of stage s + 2, which its producer cannot reach before every consumer that still waits for
+// has read it) and the "push n + 2 only after receive n + 1" argument of the FX exchange say the result cannot change; the tests
+// compare it bit for bit with the stage launches (tests/test_gpu_flow_kernel.py, tests/test_distributed.py).
+#ifdef SWE_FLOW_DELAY
+__device__ int swe_flow_delay[4] = {-1, 0, 0, 1};              // block, where (bit mask), ticks, every n-th stage
+#define SWE_FLOW_DELAY_AT(w) do {                                                                                            \
+        if (swe_flow_delay[0] == lb && (swe_flow_delay[1] & (w)) && (swe_flow_delay[3] <= 1 || (s % swe_flow_delay[3]) == 0)) {    \
+            const unsigned long long t0_ = wall_clock64();                                                                   \
+            while (wall_clock64() - t0_ < (unsigned long long)swe_flow_delay[2]) __builtin_amdgcn_s_sleep(64);                \
+        }                                                                                                                    \
+    } while (0)
+#else
+#define SWE_FLOW_DELAY_AT(w) do { } while (0)
+#endif
+
 struct SweFlowArgs {
     SweStageArgs st;                       // geometry, connectivity, boundary tables, sources; uin/u0/uout/a0/a1/beta/cell_* unused
     double *buf[3];                        // state buffers A (U0 / step result), B, C (B, C are not touched)
@@ -494,6 +513,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             //      granules of ITS cell to carry that push's number - no flag per rank: a ghost cell is ready as soon as the one block
             //      of the peer that owns it has finished, and the peer may overwrite the slot two pushes later only after it has
             //      received this rank's next push, which depends on this cell having been read
+            SWE_FLOW_DELAY_AT(4);
             if (((c > 0) || pend0) && has_ghost) {
                 const unsigned target = (unsigned)(R0 + (unsigned long long)c + (pend0 ? 1ull : 0ull));
                 const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(q.x_zone, 0, q.x_zbytes, 0x00020000);
@@ -592,6 +612,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             // ---- traces across the rim: the chunks the neighbour blocks wrote for this block, consecutive lanes on consecutive
             //      granules, re-read until every granule a cell of this stage's range needs carries this stage's tag
             if (FX || g > 0) {
+                SWE_FLOW_DELAY_AT(1);
                 const int pc_in = FX ? c*spc + g : g - 1;      // the publish this stage reads
                 const unsigned need = base + (unsigned)pc_in + 1u;
                 const unsigned par = ((FX && g == 0) ? 2u : ((unsigned)pc_in & 1u))*q.parity_bytes;       // a cycle's input has a slot set of its own
@@ -660,6 +681,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 #endif
             // ---- publish the rim traces of this stage's result (FX: the last stage of a cycle leaves that to the next cycle's input
             //      publish, after the exchange; FX = false: nobody reads the last stage of the launch)
+            SWE_FLOW_DELAY_AT(2);
             if (FX ? g + 1 < spc : s + 1 < q.n_stages) SWE_FLOW_PUBLISH(ou, ov, oe, act, FX ? c*spc + g + 1 : s, (FX ? c*spc + g + 1 : s) & 1);
             // ---- the step result (every third stage) goes to state buffer 0: read by later launches only
             if (act && i3 == 2) {
@@ -682,6 +704,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 #pragma unroll
             for (int i = 0; i < 3; i++) { u[i] = ou[i]; v[i] = ov[i]; e[i] = oe[i]; }
         }
+        if (FX) SWE_FLOW_DELAY_AT(8);
         if (FX && has_send) {
             // ---- push: the send cells of this block straight into the peers' landing zones as granules tagged with the push number
             //      (the cycle's last stage left the step result in u, v, e).  No drain, no flag.

@@ -3,18 +3,25 @@
 # Builds the library with -DSWE_RANGE_CHECK (swe2d_kernels.h: every raw-buffer access tested against the allocation table) and
 # runs tools/range_check.py, its negative control, and the GPU parity + fuzz tests against it (tests/conftest.py reads the
 # report at session end and fails the session on a violation).
-#   bash tools/range_check.sh [build]      (build: compile variants/libswe2d_rangecheck.so first; hipcc cross-compiles without a GPU)
+#   bash tools/range_check.sh [build]      (build: compile build_dbg/libswe2d_rangecheck.so first; hipcc cross-compiles without a GPU)
 set -u
 cd "$(dirname "$0")/.."
-if [ "${1:-}" = build ] || [ ! -f variants/libswe2d_rangecheck.so ]; then
-  mkdir -p variants
+if [ "${1:-}" = build ] || [ ! -f build_dbg/libswe2d_rangecheck.so ]; then
+  mkdir -p build_dbg
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSWE_RANGE_CHECK \
-      thetis_amd/csrc/swe2d_api.hip -o variants/libswe2d_rangecheck.so || exit 1
+      thetis_amd/csrc/swe2d_api.hip -o build_dbg/libswe2d_rangecheck.so || exit 1
   [ "${1:-}" = build ] && exit 0
 fi
-export THETIS_AMD_LIB=$PWD/variants/libswe2d_rangecheck.so
+export THETIS_AMD_LIB=$PWD/build_dbg/libswe2d_rangecheck.so
 timeout 900 python tools/range_check.py; echo "range_check rc=$?"
 THETIS_AMD_RANGE_SELFTEST=1 timeout 900 python tools/range_check.py | tail -1; echo "negative control rc=$?"
+# the adversary of the granule protocol: the same library with -DSWE_FLOW_DELAY (no range checks: the timing is the point)
+if [ ! -f build_dbg/libswe2d_delay.so ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSWE_FLOW_DELAY \
+      thetis_amd/csrc/swe2d_api.hip -o build_dbg/libswe2d_delay.so || exit 1
+fi
+THETIS_AMD_LIB=$PWD/build_dbg/libswe2d_delay.so timeout 1200 python -m pytest tests/test_gpu_flow_kernel.py tests/test_distributed.py -m gpu -q \
+    -k "lags or lagging" 2>&1 | tail -5
 # the checked kernels are an order of magnitude slower: the small-mesh tests only
 timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_tracer.py tests/test_gpu_sipg.py tests/test_quads.py tests/test_gpu_flow_kernel.py \
     -m gpu -q -k "not large_launch and not full_size" 2>&1 | tail -60
