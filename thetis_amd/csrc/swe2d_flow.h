@@ -696,9 +696,14 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             SWE_FT(4);
 #ifdef SWE_WAVE_TIMING
             if (s == SWE_FLOW_TS_STAGE - 1 && lane == 0 && lb < SWE_WT_MAX) {         // when the previous stage's granules left, and from which XCD
-                unsigned xcc;
+                // ... and where the block runs: bits 40-53 = simd_id (2) | cu_id (4) | sh_id (1) | se_id (3) | wave_id (4) of HW_ID, bits
+                // 56-59 the XCC - which blocks share a SIMD, and do they compute at the same time?  (tools/flowtiming.py --mates)
+                unsigned xcc, hw;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                swe_wave_ts[5][lb] = (wall_clock64() & 0xffffffffffffull) | ((unsigned long long)(xcc & 0xf) << 56);
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                const unsigned key = ((hw >> 4) & 0x3u) | (((hw >> 8) & 0xfu) << 2) | (((hw >> 12) & 0x1u) << 6) | (((hw >> 13) & 0x7u) << 7)
+                                     | ((hw & 0xfu) << 10);
+                swe_wave_ts[5][lb] = (wall_clock64() & 0xffffffffffull) | ((unsigned long long)key << 40) | ((unsigned long long)(xcc & 0xf) << 56);
             }
 #endif
 #pragma unroll

@@ -57,9 +57,11 @@ def main():
         dev._ck(fn(dev.h, ts.ctypes.data))
         m = min(nb, nmax)
         t = ts[:5, :m].astype(np.int64)
-        pub = (ts[5, :m] & np.uint64(0xffffffffffff)).astype(np.int64)      # previous stage's granules issued
+        pub = (ts[5, :m] & np.uint64(0xffffffffff)).astype(np.int64)      # previous stage's granules issued
         xcc = (ts[5, :m] >> np.uint64(56)).astype(np.int64)
-        t48 = t & 0xffffffffffff
+        t = t & 0xffffffffff                      # the clock as stored with the previous publish: 40 bits
+        t48 = t
+        key = ((ts[5, :m] >> np.uint64(40)) & np.uint64(0x3fff)).astype(np.int64)      # simd | cu << 2 | sh << 6 | se << 7 | wave slot << 10
         us = lambda x: float(np.mean(x))/100.0
         # hop latency: from the moment the LAST neighbour issued its granules (or this block started polling, whichever is later)
         # to the moment this block's polling pass saw them all
@@ -81,6 +83,33 @@ def main():
                      'last_neighbour_on_same_xcd': float(len(hop_same))/max(1, len(hop)),
                      'waiting_before_last_publish_frac': float(np.mean([t48[0, b] < pub[max([a for a in nbrs[b] if a < m], key=lambda a: pub[a])]
                                                                          for b in range(m) if [a for a in nbrs[b] if a < m]]))})
+        # ---- SIMD mates: blocks on the same SIMD (XCC, SE, SH, CU, SIMD).  Do they compute at the same time (each then takes twice
+        #      as long: one f64 pipe), one right after the other (in phase: the second waits for the pipe), or apart?
+        simd = xcc*1024 + (key & 0x3ff)
+        by_simd = {}
+        for b in range(m):
+            by_simd.setdefault(int(simd[b]), []).append(b)
+        period = float(np.median(t[4] - pub))                    # previous publish -> this publish
+        sep, overlap_frac, dist = [], [], []
+        for blocks in by_simd.values():
+            for i in range(len(blocks)):
+                for j in range(i + 1, len(blocks)):
+                    a, b = blocks[i], blocks[j]
+                    sep.append(abs(int(t[2, a]) - int(t[2, b]))/100.0)               # between the starts of their arithmetic
+                    lo, hi = max(t[2, a], t[2, b]), min(t[3, a], t[3, b])
+                    overlap_frac.append(max(0.0, float(hi - lo))/max(1.0, float(min(t[3, a] - t[2, a], t[3, b] - t[2, b]))))
+                    dist.append(abs(a - b))
+        sizes = np.bincount([len(v) for v in by_simd.values()])
+        runs[-1]['mates'] = {'simds_used': len(by_simd), 'blocks_per_simd_histogram': sizes.tolist(), 'pairs': len(sep),
+                             'stage_period_us': period/100.0,
+                             'start_separation_us_p10_p50_p90': [float(np.percentile(sep, q)) for q in (10, 50, 90)] if sep else None,
+                             'arith_overlap_fraction_p10_p50_p90': [float(np.percentile(overlap_frac, q)) for q in (10, 50, 90)] if sep else None,
+                             'pairs_overlapping_more_than_half': float(np.mean(np.asarray(overlap_frac) > 0.5)) if sep else None,
+                             'block_index_distance_p10_p50_p90': [float(np.percentile(dist, q)) for q in (10, 50, 90)] if sep else None,
+                             'arith_us_alone_vs_overlapping': [float(np.mean((t[3] - t[2])[[b for v in by_simd.values() if len(v) == 1 for b in v]]))/100.0
+                                                               if any(len(v) == 1 for v in by_simd.values()) else None,
+                                                               float(np.mean((t[3] - t[2])[[b for v in by_simd.values() if len(v) > 1 for b in v]]))/100.0
+                                                               if any(len(v) > 1 for v in by_simd.values()) else None]}
     print(json.dumps({'n_cells': mesh.num_cells, 'stages': args.stages, 'runs': runs}, indent=1))
     dev.close()
 

@@ -10,6 +10,8 @@ if [ "${1:-}" = build ] || [ ! -f build_dbg/libswe2d_rangecheck.so ]; then
   mkdir -p build_dbg
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSWE_RANGE_CHECK \
       thetis_amd/csrc/swe2d_api.hip -o build_dbg/libswe2d_rangecheck.so || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSWE_FLOW_DELAY \
+      thetis_amd/csrc/swe2d_api.hip -o build_dbg/libswe2d_delay.so || exit 1
   [ "${1:-}" = build ] && exit 0
 fi
 export THETIS_AMD_LIB=$PWD/build_dbg/libswe2d_rangecheck.so

@@ -94,8 +94,8 @@ def main():
         ts = np.zeros((6, 8192), dtype=np.uint64)
         s.dev._ck(fn(s.dev.h, ts.ctypes.data))
         nb = (p.num_cells + 63)//64
-        t = ts[:5, :nb].astype(np.int64)
-        prev = (ts[5, :nb] & np.uint64(0xffffffffffff)).astype(np.int64)
+        t = (ts[:5, :nb] & np.uint64(0xffffffffff)).astype(np.int64)        # 40 bits of clock, as stored with the previous publish
+        prev = (ts[5, :nb] & np.uint64(0xffffffffff)).astype(np.int64)
         # the blocks' roles, from the flow order the solver set (device ids -> flow position)
         from thetis_amd import ordering
         order = np.asarray(ordering.auto_cell_order(p, 0, p.num_cells))
