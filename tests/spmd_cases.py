@@ -163,7 +163,32 @@ def _balzano(outdir, nx=12, ny=6, cpu=False):
     return solver_obj
 
 
+def _restart(outdir, cpu=False):
+    """examples/channel2d.py stopped after two exports and restarted from its checkpoint files by a NEW solver object
+    (``load_state``, solver2d.py:820-921): on partitioned runs rank 0 writes the files, every rank reads them"""
+    first = _channel(outdir, export=True)
+    lx = 100e3
+    mesh2d = RectangleMesh(24, 3, lx, 3750.0)
+    P1_2d = get_functionspace(mesh2d, 'CG', 1)
+    bathymetry_2d = Function(P1_2d, name='Bathymetry').interpolate(lambda x, y: 20.0 + (5.0 - 20.0)*x/lx)
+    solver_obj = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+    o = solver_obj.options
+    o.simulation_export_time = 100.0
+    o.simulation_end_time = 600.0
+    o.horizontal_velocity_scale = Constant(6.0)
+    o.check_volume_conservation_2d = True
+    o.fields_to_export = ['uv_2d', 'elev_2d']
+    o.fields_to_export_hdf5 = ['uv_2d', 'elev_2d']
+    o.output_directory = outdir
+    o.swe_timestepper_type = 'SSPRK33'
+    solver_obj.load_state(2)
+    assert solver_obj.i_export == 2 and solver_obj.iteration == int(np.ceil(200.0/first.dt))
+    solver_obj.iterate()
+    return solver_obj
+
+
 CASES = {
+    'restart': _restart,
     'channel': _channel,
     'forced': _forced,
     'forced_fe': lambda outdir, **kw: _forced(outdir, stepper='ForwardEuler', **kw),

@@ -36,6 +36,7 @@ def test_user_script_under_n_ranks_on_one_gpu(tmp_path, hip_lib, name, world):
     ('channel', 4, {'THETIS_AMD_PARTITION': 'rcb', 'THETIS_AMD_EXCHANGE_EVERY': '1'}),
     ('tracer', 2, {'THETIS_AMD_OVERLAP_STAGES': '2'}),
     ('channel', 8, {}),
+    ('restart', 3, {}),
 ])
 def test_user_script_variants_on_one_gpu(tmp_path, hip_lib, name, world, env):
     single = run_spmd(1, str(tmp_path), name, cpu=False)

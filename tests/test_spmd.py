@@ -49,6 +49,7 @@ def test_user_script_under_n_ranks_equals_single_rank(tmp_path, ref_so, name, wo
     ('channel', 2, {'THETIS_AMD_EXCHANGE_EVERY': '1'}), ('tracer', 2, {'THETIS_AMD_EXCHANGE_EVERY': '1'}),
     ('tracer_forced', 3, {'THETIS_AMD_EXCHANGE_EVERY': '1'}), ('channel', 3, {'THETIS_AMD_PARTITION': 'rcb'}),
     ('forced', 2, {'THETIS_AMD_PARTITION': 'strip_y', 'THETIS_AMD_EXCHANGE_EVERY': '3'}),
+    ('restart', 2, {}),
 ])
 def test_user_script_variants(tmp_path, ref_so, name, world, env):
     single = run_spmd(1, str(tmp_path), name)

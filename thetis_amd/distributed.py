@@ -999,9 +999,14 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
         s = DistributedSwe2d(mesh, bath, dt, rank, world, local_rank, exchange_every=every, overlap_stages=overlap,
                              graph_mode=mode, exchange=exchange, split_last_stage=split, partition=parts[every],
                              group=(ctrl if exchange != 'rccl' else None), flow=flow)
-        if flow and not agree.all_ok(s.flow):          # the kernel must cover every rank's partition (all its blocks resident at once)
-            s.close()
-            raise RuntimeError('the flow kernel does not cover the partition of every rank')
+        if flow:                                       # the kernel must cover every rank's partition (all its blocks resident at once)
+            try:
+                covered = bool(s.flow)
+            except ValueError:                         # this rank's answer is "no": the others must still meet it in the all-reduce
+                covered = False
+            if not agree.all_ok(covered):
+                s.close()
+                raise RuntimeError('the flow kernel does not cover the partition of every rank')
         s.set_state_global(uv, eta)
         return s
 
