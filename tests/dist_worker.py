@@ -19,6 +19,8 @@ def _case():
         return quad_case(nx=16, ny=6, seed=21, amp_eta=0.3, amp_u=0.2)
     if CASE == 'quadgen':                        # general (non-parallelogram) convex cells
         return quad_case(nx=16, ny=6, seed=21, amp_eta=0.3, amp_u=0.2, warp=0.3)
+    if CASE == 'quadhalf':                       # general cells only in the rightmost columns: rank 0 of two holds parallelograms only
+        return quad_case(nx=24, ny=6, seed=21, amp_eta=0.3, amp_u=0.2, warp=0.3, warp_from=0.85)
     if CASE == 'delaunay':
         mesh, bath, uv, eta = delaunay_case(n_points=600, lx=100e3, ly=60e3, seed=7)
         return mesh, bath, 0.1*uv, 0.1*eta

@@ -62,10 +62,11 @@ def delaunay_case(n_points=400, lx=10e3, ly=6e3, seed=0):
     return mesh, bath, uv, eta
 
 
-def quad_case(nx=10, ny=6, lx=100e3, ly=30e3, seed=0, amp_eta=0.5, amp_u=0.5, skew=0.0, warp=0.0):
+def quad_case(nx=10, ny=6, lx=100e3, ly=30e3, seed=0, amp_eta=0.5, amp_u=0.5, skew=0.0, warp=0.0, warp_from=0.0):
     """Quadrilateral mesh; ``skew`` shears the grid so that cells are not axis-aligned rectangles (still parallelograms);
     ``warp`` > 0 moves every vertex by up to that fraction of a cell width (boundary vertices along the boundary only): general
-    convex quadrilaterals, no longer affine."""
+    convex quadrilaterals, no longer affine; ``warp_from``: only vertices with x > warp_from * lx move (the rest of the mesh stays a
+    grid of rectangles: a partition of it may hold parallelograms only)."""
     mesh = RectangleMesh(nx, ny, lx, ly, quadrilateral=True)
     if skew or warp:
         xy = mesh.vertex_xy.copy()
@@ -75,8 +76,9 @@ def quad_case(nx=10, ny=6, lx=100e3, ly=30e3, seed=0, amp_eta=0.5, amp_u=0.5, sk
             x0, y0 = xy[:, 0].copy(), xy[:, 1].copy()
             mx = (x0 > 1e-9*lx) & (x0 < lx*(1 - 1e-9))
             my = (y0 > 1e-9*ly) & (y0 < ly*(1 - 1e-9))
-            xy[:, 0] += np.where(mx, warp*dx*wr.uniform(-1, 1, size=len(xy)), 0.0)
-            xy[:, 1] += np.where(my, warp*dy*wr.uniform(-1, 1, size=len(xy)), 0.0)
+            far = x0 > warp_from*lx
+            xy[:, 0] += np.where(mx & far, warp*dx*wr.uniform(-1, 1, size=len(xy)), 0.0)
+            xy[:, 1] += np.where(my & far, warp*dy*wr.uniform(-1, 1, size=len(xy)), 0.0)
         xy[:, 0] += skew*xy[:, 1]
         from thetis_amd.mesh import Mesh2d
         sheared = Mesh2d(xy, mesh.cells, marker_fn=None)

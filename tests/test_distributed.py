@@ -600,6 +600,36 @@ def test_lagging_blocks_do_not_change_the_in_launch_exchange(tmp_path, hip_lib, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('case,n_steps', [('quadhalf', 4), ('quadhalf+every2+p2p', 5)])
+def test_a_rank_of_parallelograms_takes_the_general_kernels_of_the_mesh(tmp_path, hip_lib, case, n_steps):
+    """A quadrilateral mesh whose general (non-parallelogram) cells all lie in the right third, two strips: rank 0's own cells and
+    ghost layers are parallelograms only.  Left to itself its handle would take the constant-Jacobian kernels and its cells next to
+    the cut would differ from the single-device run (general kernels everywhere) in the last bits; the partition carries the global
+    mesh's flag (``LocalPartition.affine`` -> ``swe2d_set_general_quadrilaterals``).  Bitwise the single device."""
+    from thetis_amd.device import Swe2dDevice
+    from thetis_amd.partition import build_partition, strip_owner
+    import dist_worker
+    dist_worker.CASE = 'quadhalf'
+    try:
+        mesh, bath, uv, eta = dist_worker._case()
+        assert not mesh.affine
+        part0 = build_partition(mesh, strip_owner(mesh, 2), 0, halo_depth=6)
+        from thetis_amd.mesh import Mesh2d
+        local = Mesh2d(part0.vertex_xy, part0.cells)
+        assert local.affine and not part0.affine                 # the premise: rank 0 alone would decide otherwise
+        run_workers(gpu_worker, 2, n_steps, str(tmp_path), axis=0, case=case)
+    finally:
+        dist_worker.CASE = 'channel'
+    u_p, e_p, extra = gather(str(tmp_path), 2, mesh.num_cells)
+    dev = Swe2dDevice(mesh, bath, 2.0, boundary_len=mesh.boundary_len)
+    dev.set_state(uv, eta)
+    dev.advance(n_steps)
+    u_s, e_s = dev.get_state()
+    dev.close()
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+
+
+@pytest.mark.gpu
 def test_in_launch_exchange_is_refused_by_all_ranks_together(tmp_path, hip_lib):
     """``flow_exchange=True`` where a cell goes to more than two peers (strips narrower than the halo): every rank raises the same
     ValueError at its first ``advance`` - none is left waiting for granules that will never come."""
