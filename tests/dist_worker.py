@@ -353,7 +353,7 @@ def viscosity_field(mesh):
 def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     global CASE
     flags = {}
-    for f in ('+capture', '+graph', '+p2p', '+nosplit', '+flowx', '+flow', '+delay'):   # order-independent suffix flags
+    for f in ('+capture', '+graph', '+p2p', '+nosplit', '+flowx', '+flow', '+delay', '+mix'):   # order-independent suffix flags
         flags[f] = f in case
         case = case.replace(f, '')
     graphed = flags['+graph']              # per-cycle HIP graphs (around the eager host-staged exchange, or incl. the p2p kernels)
@@ -383,7 +383,17 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
         rc = solver.dev.lib.swe2d_debug_flow_delay(solver.dev.h, 2 + rank, int(os.environ.get('FLOW_DELAY_WHERE', '15')), 15, 2)
         if rc != _lib.OK:
             raise RuntimeError('the loaded library is not the -DSWE_FLOW_DELAY build')
-    if flags['+capture']:
+    if flags['+mix']:
+        # batches (flow launches with the exchange inside, or stage launches in graphs) alternating with time steps driven stage by
+        # stage from the host, as FlowSolver2d does when some steps have forcing updates and others do not
+        a = n_steps//3
+        solver.advance(a, use_graph=graphed)
+        for i in range(3):
+            solver.run_stage('swe', i)
+        solver.advance(n_steps - a - 2, use_graph=graphed)
+        for i in range(3):
+            solver.run_stage('swe', i)
+    elif flags['+capture']:
         # what bench.py does: capture outside advance() (state restored), one untimed replay, state reset, the run
         solver._capture(n_steps)
         assert solver.graphed

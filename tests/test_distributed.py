@@ -513,14 +513,17 @@ def test_ranks_on_one_gpu_with_peer_to_peer_halos(tmp_path, hip_lib, world, case
     (2, 'channel+every2+p2p+flow+nosplit+graph', 9), (2, 'channel+every4+p2p+flow+capture', 8), (3, 'delaunay+p2p+flow+graph', 2),
     (2, 'channel+p2p+flowx', 3), (2, 'channel+every2+p2p+flowx', 5), (3, 'channel+every3+p2p+flowx+graph', 11), (4, 'channel+every2+p2p+flowx', 24),
     (2, 'channel+every4+p2p+flowx+capture', 8), (3, 'delaunay+p2p+flowx+graph', 2), (2, 'delaunay+every2+p2p+flowx', 3), (2, 'channel+every1+p2p+flowx', 40),
-    (2, 'channel+every1+p2p+flowx', 150)])
+    (2, 'channel+every1+p2p+flowx', 150), (3, 'channel+every2+p2p+flowx+mix', 11), (2, 'channel+every2+p2p+flow+mix+graph', 9),
+    (2, 'channel+every4+p2p+mix+graph', 10)])
 def test_ranks_on_one_gpu_with_one_launch_per_cycle(tmp_path, hip_lib, monkeypatch, world, case, n_steps):
     """flow: the 3m stages of a cycle in ONE dataflow launch on the shrinking ranges (csrc/swe2d_flow.h; the blocks of the
     launch follow a locality order over owned and ghost cells), then the exchange - eager, host-staged and peer-to-peer, and
     replayed from per-cycle HIP graphs, with a shorter trailing cycle.  '+flowx': the exchange inside the launches (FX kernels: up
     to 64 cycles per launch, ghost lanes read the landing zone, send lanes store into the peers' zones; the runs of 24 and 40 steps
     are cut into launches of at most five cycles, so that they take several launches and a trailing partial cycle; the 150-step run
-    takes launches of 64, 64 and 22 cycles).  Bitwise the single-device result."""
+    takes launches of 64, 64 and 22 cycles).  '+mix': batches alternate with time steps driven stage by stage from the host
+    (``run_stage``: exchange kernels on channel 0 between flow launches whose granules travel on the last channel).  Bitwise the
+    single-device result."""
     from thetis_amd.device import Swe2dDevice
     import dist_worker
     if '+flowx' in case and n_steps in (24, 40):

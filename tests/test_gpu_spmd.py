@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from dist_worker import run_spmd
-from test_spmd import _check
+from test_spmd import _check, single_rank
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,8 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize('name,world', [('channel', 2), ('channel', 4), ('forced', 2), ('forced', 3), ('tracer', 2), ('tracer_forced', 3),
                                         ('tracer_only', 2), ('balzano', 2), ('balzano', 4), ('forced_fe', 2), ('tracer_fe', 2),
                                         ('tracer_nolim', 2)])
-def test_user_script_under_n_ranks_on_one_gpu(tmp_path, hip_lib, name, world):
-    single = run_spmd(1, str(tmp_path), name, cpu=False)
+def test_user_script_under_n_ranks_on_one_gpu(tmp_path, tmp_path_factory, hip_lib, name, world):
+    single = single_rank(name, tmp_path_factory, cpu=False)
     ranks = run_spmd(world, str(tmp_path), name, cpu=False)
     assert ranks[0]['exchange'] == 'p2p'            # the default transport set up (hipIpc* between the rank processes)
     _check(single, ranks, exact_callbacks=True)
@@ -38,8 +38,8 @@ def test_user_script_under_n_ranks_on_one_gpu(tmp_path, hip_lib, name, world):
     ('channel', 8, {}),
     ('restart', 3, {}),
 ])
-def test_user_script_variants_on_one_gpu(tmp_path, hip_lib, name, world, env):
-    single = run_spmd(1, str(tmp_path), name, cpu=False)
+def test_user_script_variants_on_one_gpu(tmp_path, tmp_path_factory, hip_lib, name, world, env):
+    single = single_rank(name, tmp_path_factory, cpu=False)
     ranks = run_spmd(world, str(tmp_path), name, cpu=False, env=env)
     _check(single, ranks, exact_callbacks=True)
 

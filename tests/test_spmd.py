@@ -11,6 +11,15 @@ import pytest
 from dist_worker import run_spmd
 
 STATE_KEYS = ('uv', 'elev', 'tracer_2d')
+_SINGLE = {}
+
+
+def single_rank(name, tmp_path_factory, cpu=True):
+    """the one-rank run of a scenario (once per test session: several partitioned variants are compared with it)"""
+    key = (name, cpu)
+    if key not in _SINGLE:
+        _SINGLE[key] = run_spmd(1, str(tmp_path_factory.mktemp('single_' + name)), name, cpu=cpu)
+    return _SINGLE[key]
 
 
 def _check(single, ranks, exact_callbacks=True):
@@ -36,8 +45,8 @@ def _check(single, ranks, exact_callbacks=True):
 
 @pytest.mark.parametrize('world', [2, 3])
 @pytest.mark.parametrize('name', ['channel', 'forced', 'tracer', 'tracer_forced', 'tracer_only'])
-def test_user_script_under_n_ranks_equals_single_rank(tmp_path, ref_so, name, world):
-    single = run_spmd(1, str(tmp_path), name)
+def test_user_script_under_n_ranks_equals_single_rank(tmp_path, tmp_path_factory, ref_so, name, world):
+    single = single_rank(name, tmp_path_factory)
     ranks = run_spmd(world, str(tmp_path), name)
     _check(single, ranks)
     if name == 'channel':
@@ -51,15 +60,15 @@ def test_user_script_under_n_ranks_equals_single_rank(tmp_path, ref_so, name, wo
     ('forced', 2, {'THETIS_AMD_PARTITION': 'strip_y', 'THETIS_AMD_EXCHANGE_EVERY': '3'}),
     ('restart', 2, {}),
 ])
-def test_user_script_variants(tmp_path, ref_so, name, world, env):
-    single = run_spmd(1, str(tmp_path), name)
+def test_user_script_variants(tmp_path, tmp_path_factory, ref_so, name, world, env):
+    single = single_rank(name, tmp_path_factory)
     ranks = run_spmd(world, str(tmp_path), name, env=env)
     _check(single, ranks)
 
 
-def test_world_8(tmp_path, ref_so):
+def test_world_8(tmp_path, tmp_path_factory, ref_so):
     """eight ranks on a channel whose strips (3 columns of cells) are narrower than the six-layer halo: a rank's ghost layers
     reach into its second neighbours"""
-    single = run_spmd(1, str(tmp_path), 'channel')
+    single = single_rank('channel', tmp_path_factory)
     ranks = run_spmd(8, str(tmp_path), 'channel')
     _check(single, ranks)
