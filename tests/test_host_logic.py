@@ -250,3 +250,67 @@ def test_firedrake_shaped_quadrilateral_arrays_give_the_swe2d_mesh_of_mesh2d():
     assert np.array_equal(dg_vertex[out['dg_perm']], out['cell_vertices'])
     with pytest.raises(NotImplementedError):
         swe2d_mesh_arrays(fx['coords'], [c + [0] for c in fx['cell_vertices']], [], [], [], [], [])
+
+
+def _reference_surface():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_surface.json')) as f:
+        return json.load(f)
+
+
+def test_option_names_and_defaults_are_the_references():
+    """Every option of this build's ``ModelOptions2d`` / explicit time stepper option classes exists in the reference under the
+    same name with the same default (tests/golden/reference_surface.json: trait defaults read from thetis/options.py by AST,
+    tests/golden/make_surface_golden.py) - except the ones this build adds, listed here."""
+    from thetis_amd import options as o
+    ref = _reference_surface()
+
+    def ref_options(cls_name):
+        out = {}
+        c = ref['options'][cls_name]
+        for b in c['bases']:
+            if b in ref['options']:
+                out.update(ref_options(b))
+        out.update(c['options'])
+        return out
+
+    def value(v):
+        if isinstance(v, o.Constant):
+            vals = v.values()
+            return vals[0] if len(vals) == 1 else list(vals)
+        return v
+    own = {'ModelOptions2d': {'wetting_and_drying_cfl_factor'}}
+    checked = 0
+    for cls_name, cls in (('ModelOptions2d', o.ModelOptions2d), ('ExplicitSWETimeStepperOptions2d', o.ExplicitSWETimeStepperOptions2d),
+                          ('ExplicitTracerTimeStepperOptions2d', o.ExplicitTracerTimeStepperOptions2d)):
+        theirs = ref_options(cls_name)
+        obj = cls()
+        for key in cls._all_spec():
+            if key in own.get(cls_name, ()) or key in ref['paired']:
+                continue
+            assert key in theirs, '{:}.{:} is not an option of the reference'.format(cls_name, key)
+            d = theirs[key]['default']
+            if isinstance(d, dict) and 'expr' in d:
+                continue                                   # not a literal in the reference (e.g. PETSc parameter dictionaries)
+            assert value(getattr(obj, key)) == d, '{:}.{:}: {!r} != reference default {!r}'.format(cls_name, key, value(getattr(obj, key)), d)
+            checked += 1
+    assert checked >= 50
+    # the steppers tables and their defaults (attach_paired_options of ModelOptions2d)
+    m = o.ModelOptions2d()
+    for name, table in (('swe_timestepper_type', o._SWE_STEPPERS), ('tracer_timestepper_type', o._TRACER_STEPPERS)):
+        p = ref['paired'][name]
+        assert [c[0] for c in p['choices']] == list(table) and getattr(m, name) == p['default']
+        explicit = [c[0] for c in p['choices'] if c[1].startswith('Explicit')]
+        assert explicit == ['SSPRK33', 'ForwardEuler'] and all(table[e].__name__ == dict(p['choices'])[e] for e in explicit)
+
+
+def test_field_metadata_and_physical_constants_are_the_references():
+    """thetis/field_defs.py executed, thetis/physical_constants.py read (tests/golden/make_surface_golden.py): export file names,
+    units, g and rho_0 of this build are theirs"""
+    from thetis_amd import exporter, shallowwater_eq
+    ref = _reference_surface()
+    for key, meta in exporter.field_metadata.items():
+        assert ref['field_metadata'][key] == meta, key
+    assert float(shallowwater_eq.g_grav) == ref['physical_constants']['g_grav'] == 9.81
+    assert float(shallowwater_eq.rho_0) == ref['physical_constants']['rho0']
