@@ -332,6 +332,10 @@ int  swe2d_p2p_connect(swe2d_handle *h, int32_t n_peers, void *const *remote_bas
                        const int32_t *remote_n_recv, int32_t n_from);
 int  swe2d_p2p_push(swe2d_handle *h, int channel, int i_buffer);
 int  swe2d_p2p_wait_unpack(swe2d_handle *h, int channel, int i_buffer);
+/* swe2d_p2p_push / swe2d_p2p_wait_unpack on a stream of their own (null: the handle's stream), so that the stage kernels of the
+ * interior cells run while the halo travels - PyOP2 overlaps its halo exchange with the core of a par_loop the same way
+ * [FD-assumed].  The caller orders the two streams with events; no synchronisation here. */
+int  swe2d_set_exchange_stream(swe2d_handle *h, void *hip_stream);
 int  swe2d_p2p_status(swe2d_handle *h, int64_t *epochs_sent, int64_t *epochs_received, int32_t *timeouts);
 /* ERKGenericShuOsher.solve_stage restricted to cells [cell_begin, cell_end) (may include ghost layers) */
 int  swe2d_solve_stage_cells(swe2d_handle *h, int i_stage, int32_t cell_begin, int32_t cell_end);

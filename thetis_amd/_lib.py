@@ -124,6 +124,7 @@ SYMBOLS = {
     'swe2d_debug_flow_poke': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_debug_flow_delay': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_set_stream': (ctypes.c_int, [_H, ctypes.c_void_p]),
+    'swe2d_set_exchange_stream': (ctypes.c_int, [_H, ctypes.c_void_p]),
 }
 
 _lib = None

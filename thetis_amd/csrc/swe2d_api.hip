@@ -105,6 +105,7 @@ struct Handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t my_stream = nullptr;
+    hipStream_t xstream = nullptr;                     // the exchange kernels' stream (swe2d_set_exchange_stream), null: `stream`
     int n_cells = 0, n_owned = 0, n_interior = 0, n_vertices = 0;
     int npc = 3;                                       // nodes per cell: 3 triangles, 4 quadrilaterals
     bool affine = true;                                // quadrilaterals: every cell a parallelogram (constant Jacobian, tensor mass inverse)
@@ -2558,7 +2559,7 @@ int swe2d_p2p_push(swe2d_handle *hh, int channel, int i_buffer)
                      + (size_t)(channel*SWE_P2P_MAX_PEERS + z.remote_flag[i])*SWE_P2P_FLAG_STRIDE;
     }
     a.ctr = z.ctr + channel;
-    hipLaunchKernelGGL(swe_p2p_push_kernel, dim3(std::min(SWE_P2P_MAX_BLOCKS, grid_for(np*h->n_send))), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(swe_p2p_push_kernel, dim3(std::min(SWE_P2P_MAX_BLOCKS, grid_for(np*h->n_send))), dim3(256), 0, h->xstream ? h->xstream : h->stream, a);
     HIP_TRY(h, hipGetLastError());
     return SWE2D_OK;
 }
@@ -2583,8 +2584,20 @@ int swe2d_p2p_wait_unpack(swe2d_handle *hh, int channel, int i_buffer)
     a.timeout_ticks = (unsigned long long)(z.timeout_s*1e8);
     a.ctr = z.ctr + channel;
     a.fence = z.zone_kind == 3;
-    hipLaunchKernelGGL(swe_p2p_unpack_kernel, dim3(std::min(SWE_P2P_MAX_BLOCKS, grid_for(np*h->n_recv))), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(swe_p2p_unpack_kernel, dim3(std::min(SWE_P2P_MAX_BLOCKS, grid_for(np*h->n_recv))), dim3(256), 0, h->xstream ? h->xstream : h->stream, a);
     HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
+}
+
+// The exchange kernels (swe2d_p2p_push / swe2d_p2p_wait_unpack: a few thousand cells, 5-6 us each, mostly latency) on a stream of
+// their own: the caller orders it against the handle's stream with events (push after the send cells' stage, the next reader of the
+// ghost cells after the unpack) and the stage kernels of the interior run meanwhile.  Null: back on the handle's stream.  No
+// synchronisation here (usable around a stream capture that forks into this stream and joins again).
+int swe2d_set_exchange_stream(swe2d_handle *hh, void *hip_stream)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    h->xstream = reinterpret_cast<hipStream_t>(hip_stream);
     return SWE2D_OK;
 }
 
@@ -2594,6 +2607,7 @@ int swe2d_p2p_status(swe2d_handle *hh, int64_t *epochs_sent, int64_t *epochs_rec
     if (!h || !h->p2p.ctr) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_status: not created");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->xstream) HIP_TRY(h, hipStreamSynchronize(h->xstream));
     std::vector<SweP2pCounters> c(h->p2p.n_channels);
     HIP_TRY(h, hipMemcpy(c.data(), h->p2p.ctr, c.size()*sizeof(SweP2pCounters), hipMemcpyDeviceToHost));
     int to = 0;

@@ -649,5 +649,9 @@ class Swe2dDevice(object):
         self._ck(self.lib.swe2d_p2p_status(self.h, a, b, ctypes.byref(t)))
         return list(a), list(b), int(t.value)
 
+    def set_exchange_stream(self, stream_ptr):
+        """the peer-to-peer exchange kernels on a stream of their own (None: the handle's stream); ordering by the caller's events"""
+        self._ck(self.lib.swe2d_set_exchange_stream(self.h, ctypes.c_void_p(stream_ptr) if stream_ptr else None))
+
     def set_stream(self, stream_ptr):
         self._ck(self.lib.swe2d_set_stream(self.h, ctypes.c_void_p(stream_ptr) if stream_ptr else None))

@@ -308,9 +308,19 @@ class DistributedSwe2d(object):
             staged = self.exchange == 'host' and self._on_gpu       # a host stand-in's buffers are CPU tensors already
             self.halo = HaloExchanger(p, self.torch_device, host_staged=staged, group=group)
             self.thalo = HaloExchanger(p, self.torch_device, host_staged=staged, width=p.cells.shape[1], group=group) if n_tracers else None
+        self.xstream = None
         if self._on_gpu:
             self.stream = torch.cuda.Stream(device=self.torch_device)
             self.dev.set_stream(self.stream.cuda_stream)
+            if self.p2p is not None and os.environ.get('THETIS_AMD_P2P_SIDE_STREAM', '1') != '0':
+                # the exchange kernels (push: 5-6 us, wait + unpack: 5-6 us per cycle, a few thousand cells each) on a stream of their
+                # own: forked off after the send cells' stage, joined before the next reader of the ghost cells, they run beside
+                # the stage kernels of the interior instead of between them (same disjoint read / write sets as an exchange in
+                # flight on the other transports)
+                self.xstream = torch.cuda.Stream(device=self.torch_device)
+                self.dev.set_exchange_stream(self.xstream.cuda_stream)
+                self._ev_fork = torch.cuda.Event()
+                self._ev_join = torch.cuda.Event()
         else:
             self.stream = None
         self.graph = None
@@ -446,8 +456,7 @@ class DistributedSwe2d(object):
         if self.p2p is not None:
             def whole_cycle():
                 dev.solve_flow(ends)
-                dev.p2p_push(0, 0)
-                dev.p2p_wait_unpack(0, 0)
+                self._receive(0, 0, self._send(0, 0))
             return self._launch(('W', n_steps), whole_cycle, graphed)
         self._launch(('WA', n_steps), lambda: dev.solve_flow(ends), graphed)
         dev.halo_pack(0, self.halo.send_buf.data_ptr())
@@ -506,6 +515,9 @@ class DistributedSwe2d(object):
     def _send(self, channel, i_buffer):
         dev = self.dev
         if self.p2p is not None:
+            if self.xstream is not None:                 # fork: the push follows everything enqueued so far
+                self._ev_fork.record(self.stream)
+                self.xstream.wait_event(self._ev_fork)
             dev.p2p_push(channel, i_buffer)
             return None
         if channel == 0:
@@ -518,6 +530,9 @@ class DistributedSwe2d(object):
         dev = self.dev
         if self.p2p is not None:
             dev.p2p_wait_unpack(channel, i_buffer)
+            if self.xstream is not None:                 # join: whatever comes next sees the ghost cells
+                self._ev_join.record(self.xstream)
+                self.stream.wait_event(self._ev_join)
         elif channel == 0:
             self.halo.finish(reqs)
             dev.halo_unpack(i_buffer, self.halo.recv_buf.data_ptr())
@@ -557,9 +572,9 @@ class DistributedSwe2d(object):
             # the exchange is two kernels of this library: the whole cycle is one capturable launch sequence
             def whole_cycle():
                 self._cycle_before_exchange(n_steps, early_done)
-                self.dev.p2p_push(0, 0)
+                reqs = self._send(0, 0)
                 self._cycle_during_exchange(early_next)
-                self.dev.p2p_wait_unpack(0, 0)
+                self._receive(0, 0, reqs)
             return self._launch(('P', n_steps, early_done, early_next), whole_cycle, graphed)
         self._launch(('A', n_steps, early_done), lambda: self._cycle_before_exchange(n_steps, early_done), graphed)
         self.dev.halo_pack(0, self.halo.send_buf.data_ptr())         # stage 3 leaves the step result in buffer 0
@@ -890,6 +905,8 @@ class DistributedSwe2d(object):
     def synchronize(self):
         if self.stream is not None:
             self.stream.synchronize()
+        if self.xstream is not None:
+            self.xstream.synchronize()
         self._check_exchange()
 
     def diagnostics(self):
