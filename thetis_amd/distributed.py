@@ -312,11 +312,11 @@ class DistributedSwe2d(object):
         if self._on_gpu:
             self.stream = torch.cuda.Stream(device=self.torch_device)
             self.dev.set_stream(self.stream.cuda_stream)
-            if self.p2p is not None and os.environ.get('THETIS_AMD_P2P_SIDE_STREAM', '1') != '0':
-                # the exchange kernels (push: 5-6 us, wait + unpack: 5-6 us per cycle, a few thousand cells each) on a stream of their
-                # own: forked off after the send cells' stage, joined before the next reader of the ghost cells, they run beside
-                # the stage kernels of the interior instead of between them (same disjoint read / write sets as an exchange in
-                # flight on the other transports)
+            if self.p2p is not None and os.environ.get('THETIS_AMD_P2P_SIDE_STREAM', '0') == '1':
+                # OPT-IN (measured slower, DESIGN_ANNEX.md A5): the exchange kernels (push: 5-6 us, wait + unpack: 5-6 us per cycle,
+                # a few thousand cells each) on a stream of their own - forked off after the send cells' stage, joined before the
+                # next reader of the ghost cells, they run beside the stage kernels of the interior instead of between them (same
+                # disjoint read / write sets as an exchange in flight on the other transports; bitwise the same results)
                 self.xstream = torch.cuda.Stream(device=self.torch_device)
                 self.dev.set_exchange_stream(self.xstream.cuda_stream)
                 self._ev_fork = torch.cuda.Event()

@@ -93,7 +93,6 @@ def main():
     to = s.p2p.timeouts() if s.p2p is not None else 0
     if args.timing:
         import ctypes
-        import numpy as np
         fn = s.dev.lib.swe2d_debug_read_wave_timing
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
