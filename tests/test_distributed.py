@@ -603,6 +603,27 @@ def test_lagging_blocks_do_not_change_the_in_launch_exchange(tmp_path, hip_lib, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('world,case,n_steps', [(2, 'channel+every4+overlap3+p2p+graph', 16), (3, 'channel+every2+p2p', 7),
+                                                (2, 'channel+every2+p2p+flow+graph', 9)])
+def test_exchange_kernels_on_a_side_stream(tmp_path, hip_lib, monkeypatch, world, case, n_steps):
+    """THETIS_AMD_P2P_SIDE_STREAM=1 (opt-in; measured slower, DESIGN_ANNEX.md A5): push and wait-and-unpack on a stream of their own,
+    forked and joined by events - eagerly and inside per-cycle HIP graphs (cross-stream capture).  Bitwise the single device."""
+    from thetis_amd.device import Swe2dDevice
+    import dist_worker
+    monkeypatch.setenv('THETIS_AMD_P2P_SIDE_STREAM', '1')
+    dist_worker.CASE = 'channel'
+    mesh, bath, uv, eta = dist_worker._case()
+    run_workers(gpu_worker, world, n_steps, str(tmp_path), axis=0, case=case)
+    u_p, e_p, extra = gather(str(tmp_path), world, mesh.num_cells)
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev.set_state(uv, eta)
+    dev.advance(n_steps)
+    u_s, e_s = dev.get_state()
+    dev.close()
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('case,n_steps', [('quadhalf', 4), ('quadhalf+every2+p2p', 5)])
 def test_a_rank_of_parallelograms_takes_the_general_kernels_of_the_mesh(tmp_path, hip_lib, case, n_steps):
     """A quadrilateral mesh whose general (non-parallelogram) cells all lie in the right third, two strips: rank 0's own cells and
