@@ -74,6 +74,8 @@ def test_bench_two_ranks_through_torch_distributed_run(hip_lib):
     assert cfg['transports_verified'] == ['p2p', 'host'] and cfg['exchange'] == 'p2p' and cfg['p2p_timeouts'] == 0
     assert cfg['failures'] == [] and any(t['graph_mode'] != 'none' for t in cfg['schedule_tuning'])
     assert 1e8 < d['value'] < 1e11
+    # SURVEY 8(d) cfg 3: the exchange's share of the step, measured after the timed region (the same steps without sends / receives)
+    assert cfg['exchange_time_fraction'] is not None and 0.0 <= cfg['exchange_time_fraction'] < 0.9, cfg['exchange_time_fraction_note']
     # set-up (transport checks + schedule tuning) is bounded: candidates beyond the budget are skipped and listed
     assert cfg['setup_s'] <= cfg['setup_budget_s'] + 15.0 and cfg['setup_budget_s'] == 60.0 and isinstance(cfg['setup_skipped'], list)
     # the second, untuned timed region on the larger mesh of the same channel (here shrunk: 2 ranks share one GPU)

@@ -292,6 +292,7 @@ class DistributedSwe2d(object):
         self._flowx_request = flow_exchange
         self._flow_now = None                    # the rank-collective decision of the current advance() (see _decide_flow)
         self._flowx_now = False
+        self._no_exchange = False                # measurement only (bench: config.exchange_time_fraction): the schedule without its exchanges
         self._shared_device = None               # do several ranks step on this GPU?  (found out at the first automatic decision)
         if flow is not False and self.dev.npc == 3 and self._on_gpu:
             # the flow kernel's blocks: all local cells (owned + ghost layers) in one locality order, so that a ghost cell
@@ -426,6 +427,8 @@ class DistributedSwe2d(object):
     @property
     def flow_exchange(self):
         """True when the exchange runs inside the flow launches (see ``flow_exchange``): part of the ranks' common decision."""
+        if self._no_exchange:
+            return False
         if self._flow_now is None:
             return self._flow_local() and self._flowx_local()
         return bool(self._flow_now and self._flowx_now)
@@ -459,10 +462,7 @@ class DistributedSwe2d(object):
                 self._receive(0, 0, self._send(0, 0))
             return self._launch(('W', n_steps), whole_cycle, graphed)
         self._launch(('WA', n_steps), lambda: dev.solve_flow(ends), graphed)
-        dev.halo_pack(0, self.halo.send_buf.data_ptr())
-        reqs = self.halo.start()
-        self.halo.finish(reqs)
-        dev.halo_unpack(0, self.halo.recv_buf.data_ptr())
+        self._receive(0, 0, self._send(0, 0))
 
     def set_tracer_global(self, i_tracer, nodal):
         self.dev.tracer_set_state(self.tids[i_tracer], np.asarray(nodal)[self.part.local_to_global])
@@ -514,6 +514,8 @@ class DistributedSwe2d(object):
     # ---- the exchange: send = pack + post (or push), receive = wait + unpack
     def _send(self, channel, i_buffer):
         dev = self.dev
+        if self._no_exchange:
+            return None
         if self.p2p is not None:
             if self.xstream is not None:                 # fork: the push follows everything enqueued so far
                 self._ev_fork.record(self.stream)
@@ -528,6 +530,8 @@ class DistributedSwe2d(object):
 
     def _receive(self, channel, i_buffer, reqs):
         dev = self.dev
+        if self._no_exchange:
+            return
         if self.p2p is not None:
             dev.p2p_wait_unpack(channel, i_buffer)
             if self.xstream is not None:                 # join: whatever comes next sees the ghost cells
@@ -577,11 +581,9 @@ class DistributedSwe2d(object):
                 self._receive(0, 0, reqs)
             return self._launch(('P', n_steps, early_done, early_next), whole_cycle, graphed)
         self._launch(('A', n_steps, early_done), lambda: self._cycle_before_exchange(n_steps, early_done), graphed)
-        self.dev.halo_pack(0, self.halo.send_buf.data_ptr())         # stage 3 leaves the step result in buffer 0
-        reqs = self.halo.start()
+        reqs = self._send(0, 0)                                      # stage 3 leaves the step result in buffer 0
         self._launch(('B', early_next), lambda: self._cycle_during_exchange(early_next), graphed)
-        self.halo.finish(reqs)
-        self.dev.halo_unpack(0, self.halo.recv_buf.data_ptr())
+        self._receive(0, 0, reqs)
 
     def _cycle_forward_euler(self, n_steps):
         """``n_steps`` ForwardEuler steps on shrinking ranges (one ghost layer per step), then one exchange."""
@@ -1364,11 +1366,38 @@ def _timed_region(args, solver, chosen, agree, uv, eta, use_graph, n_total, worl
     ok = bool(np.isfinite(d1).all() and abs(d1[2] - d0[2])/d0[2] < 1e-10)
     timeouts = solver.p2p.timeouts() if solver.p2p is not None else 0
     hip_graph = bool(solver.graphed)
+    was_flowx = bool(solver.flow_exchange)
+    # SURVEY 8(d) cfg 3 "exchange time fraction": the same K steps twice more, eagerly - once as they are, once with every send and
+    # receive left out (the halo goes stale: timing only, after everything that is reported has been read) - never fatal
+    exchange_fraction, exchange_note = None, None
+    try:
+        times = []
+        for stub in (False, True):
+            solver._no_exchange = stub
+            solver.advance(min(args.steps, 4*every), use_graph=False)          # the launches of this mode once, untimed
+            solver.synchronize()
+            agree.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            solver.advance(args.steps, use_graph=False)
+            if solver.stream is not None:
+                solver.stream.synchronize()
+            torch.cuda.synchronize()
+            times.append(agree.max(time.perf_counter() - t1))
+        solver._no_exchange = False
+        if times[0] > 0:
+            exchange_fraction = float(max(0.0, 1.0 - times[1]/times[0]))
+            exchange_note = ('eager launches, max over ranks: {:.1f} us per step with the exchange, {:.1f} without '
+                             '(the in-launch exchange of the flow kernel is replaced by flow launches without an exchange)'.format(
+                                 1e6*times[0]/args.steps, 1e6*times[1]/args.steps))
+    except Exception as e:                                                     # noqa: BLE001
+        solver._no_exchange = False
+        exchange_note = 'not measured: {:}'.format((str(e).strip().splitlines() or [type(e).__name__])[0][:200])
     value = n_total*3.0*args.steps/t
     per_gpu_bytes = bytes_per_update*n_total/world
     transport = {'p2p': 'peer-to-peer stores into IPC-mapped landing zones ({:} memory) + epoch flags, {:}'.format(
                         solver.p2p.zone_kind if solver.p2p is not None else '',
-                        'made by the flow kernel itself (FX: up to 64 exchange cycles per launch)' if solver.flow_exchange
+                        'made by the flow kernel itself (FX: up to 64 exchange cycles per launch)' if was_flowx
                         else 'exchange kernels inside the per-cycle HIP graph'),
                  'rccl': 'RCCL batch_isend_irecv between two graph launches',
                  'host': 'gloo through host memory (fallback)'}[ex]
@@ -1385,7 +1414,8 @@ def _timed_region(args, solver, chosen, agree, uv, eta, use_graph, n_total, worl
                    'parallelism': 'dd{:d} (domain decomposition, {:d}-cell halo, 1 exchange per {:d} steps)'.format(
                        world, 3*every, every),
                    'exchange': ex, 'exchange_transport': transport, 'transports_verified': transports,
-                   'exchange_every': every, 'overlap_stages': overlap, 'split_last_stage': split, 'flow': bool(solver.flow), 'flow_exchange': bool(solver.flow_exchange),
+                   'exchange_every': every, 'overlap_stages': overlap, 'split_last_stage': split, 'flow': bool(solver.flow), 'flow_exchange': was_flowx,
+                   'exchange_time_fraction': exchange_fraction, 'exchange_time_fraction_note': exchange_note,
                    'flow_timeouts': int(solver.dev.flow_timeouts()), 'schedule_tuning': tuning,
                    'hip_graph': hip_graph, 'graph_mode': solver.graph_mode, 'graph_warm_replays': int(hip_graph),
                    'volume_conserved': ok, 'p2p_timeouts': int(timeouts), 'prewarm_s': prewarm},
