@@ -25,7 +25,7 @@ thetis/rungekutta.py:933-934) run the same launches one host call at a time with
 Results are bitwise those of the single-device run (tests/test_spmd.py, tests/test_gpu_spmd.py).
 
 Environment: ``THETIS_AMD_EXCHANGE`` = p2p | rccl | host (default: the first that sets up on every rank),
-``THETIS_AMD_EXCHANGE_EVERY`` (default 2), ``THETIS_AMD_OVERLAP_STAGES`` (default 0), ``THETIS_AMD_PARTITION`` = strip | strip_y |
+``THETIS_AMD_EXCHANGE_EVERY`` (default 2; 4 for shallow-water-only ranks too large for the dataflow kernel), ``THETIS_AMD_OVERLAP_STAGES`` (default 0), ``THETIS_AMD_PARTITION`` = strip | strip_y |
 rcb (default: strips along the longer side of a structured mesh, recursive coordinate bisection otherwise),
 ``THETIS_AMD_SPMD_FLOW`` = 1 | 0 (require / forbid the dataflow launches; default: the ranks' common automatic choice).
 """
@@ -72,7 +72,12 @@ class PartitionedDevice(object):
         self.use_limiter = bool(use_limiter) and self.n_tracers > 0
         self._tracers_handed_out = 0
         on_gpu = not getattr(device_cls, 'is_host', False)
-        every = max(1, int(os.environ.get('THETIS_AMD_EXCHANGE_EVERY', '2')))
+        # time steps between two exchanges (3m ghost layers): ranks that fit the dataflow kernel (<= ~131 k cells incl. their ghost
+        # layers: m = 2 is what fits an eighth of a 1 M-triangle mesh) exchange every 2 steps inside its launches; larger ranks run
+        # stage launches, where the two exchange kernels of a cycle are spread over 4 steps (measured: a rank of two 69-70 us per
+        # step at m = 4 / 8 against 72 at m = 2, a rank of four 42.5-44 against 45).  The same rule on every rank.
+        small = self.npc == 3 and not self.n_tracers and self.n_cells <= 122000*comm.size
+        every = max(1, int(os.environ.get('THETIS_AMD_EXCHANGE_EVERY', '2' if (small or self.n_tracers) else '4')))
         overlap = int(os.environ.get('THETIS_AMD_OVERLAP_STAGES', '0'))
         if stepper == 'ForwardEuler' or (self.n_tracers and overlap and (every == 1 or tracer_only)):
             overlap = 0
