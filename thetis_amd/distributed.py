@@ -322,6 +322,7 @@ class DistributedSwe2d(object):
                 self.dev.set_exchange_stream(self.xstream.cuda_stream)
                 self._ev_fork = torch.cuda.Event()
                 self._ev_join = torch.cuda.Event()
+                self._ev_pushed = torch.cuda.Event()
         else:
             self.stream = None
         self.graph = None
@@ -521,6 +522,8 @@ class DistributedSwe2d(object):
                 self._ev_fork.record(self.stream)
                 self.xstream.wait_event(self._ev_fork)
             dev.p2p_push(channel, i_buffer)
+            if self.xstream is not None:
+                self._ev_pushed.record(self.xstream)
             return None
         if channel == 0:
             dev.halo_pack(i_buffer, self.halo.send_buf.data_ptr())
@@ -613,6 +616,10 @@ class DistributedSwe2d(object):
         dev, p = self.dev, self.part
         if self.split_last_stage:
             dev.solve_stage_cells(2, 0, p.n_interior)               # interior cells overlap the exchange
+        if early_next and self.xstream is not None:
+            # the third early stage writes buffer 0 on cells at distance >= 4 from the cut - send cells among them - which the push on
+            # the side stream may still be reading (on one stream it has finished; the other transports pack before this point)
+            self.stream.wait_event(self._ev_pushed)
         for g in range(early_next):                                 # ... and so does the ghost-independent part of the next stages
             dev.solve_stage_cells(g % 3, 0, p.owned_prefix(g + 2))
 
