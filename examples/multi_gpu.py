@@ -8,6 +8,10 @@ over torch.distributed (RCCL), thetis_amd/distributed.py.
 
 Every rank builds its own partition from the replicated mesh (deterministic, no handshake); results are bitwise those of
 a single-device run of the same mesh for every partitioning and exchange schedule.
+
+This script drives the multi-GPU ENGINE directly (arrays in, arrays out: what bench.py times).  A ``FlowSolver2d`` user script needs
+none of it: ``python -m torch.distributed.run --nproc-per-node N examples/channel2d.py`` runs the unchanged single-GPU script
+partitioned (thetis_amd/spmd.py), as ``mpiexec -n N`` does for the reference.
 """
 import argparse
 import os
