@@ -37,6 +37,9 @@ def test_user_script_under_n_ranks_on_one_gpu(tmp_path, tmp_path_factory, hip_li
     ('tracer', 2, {'THETIS_AMD_OVERLAP_STAGES': '2'}),
     ('channel', 8, {}),
     ('restart', 3, {}),
+    # the ranks DISAGREE on whether the dataflow kernel covers their partition (capacity forced to 16 blocks: the end ranks of three,
+    # with one ghost side, fit; the middle rank does not): the common decision must be reached without leaving anyone in a collective
+    ('channel_wide', 3, {'THETIS_AMD_FLOW_CAPACITY': '16'}),
 ])
 def test_user_script_variants_on_one_gpu(tmp_path, tmp_path_factory, hip_lib, name, world, env):
     single = single_rank(name, tmp_path_factory, cpu=False)

@@ -413,7 +413,11 @@ class DistributedSwe2d(object):
                                          self.rank, 'possible' if okx else 'not possible'))
                 self._flow_now, self._flowx_now = True, bool(both[1] > 0.5)
             return self._flow_now
-        ok = self._flow_local() and not self._ranks_share_a_device()
+        # (every rank takes part in the all-gather behind _ranks_share_a_device, whatever its own answer: a rank that skipped it
+        #  because its partition is not covered would leave the others waiting in it - seen with the eight strips of the 1 M-triangle
+        #  mesh, whose end ranks are covered and whose middle ranks, with two ghost sides, are not)
+        shared = self._ranks_share_a_device()
+        ok = self._flow_local() and not shared
         okx = ok and self._flowx_local()
         both = self._all_reduce([1.0 if ok else 0.0, 1.0 if okx else 0.0], dist.ReduceOp.MIN)
         self._flow_now, self._flowx_now = bool(both[0] > 0.5), bool(both[1] > 0.5)
