@@ -190,7 +190,7 @@ def _restart(outdir, cpu=False):
 CASES = {
     'restart': _restart,
     'channel': _channel,
-    'channel_wide': lambda outdir, **kw: _channel(outdir, nx=72, ny=16, export=False, **kw),
+    'channel_wide': lambda outdir, **kw: _channel(outdir, nx=84, ny=16, export=False, **kw),
     'forced': _forced,
     'forced_fe': lambda outdir, **kw: _forced(outdir, stepper='ForwardEuler', **kw),
     'tracer': _tracer,
