@@ -25,7 +25,8 @@ thetis/rungekutta.py:933-934) run the same launches one host call at a time with
 Results are bitwise those of the single-device run (tests/test_spmd.py, tests/test_gpu_spmd.py).
 
 Environment: ``THETIS_AMD_EXCHANGE`` = p2p | rccl | host (default: the first that sets up on every rank),
-``THETIS_AMD_EXCHANGE_EVERY`` (default 2; 4 for shallow-water-only ranks too large for the dataflow kernel), ``THETIS_AMD_OVERLAP_STAGES`` (default 0), ``THETIS_AMD_PARTITION`` = strip | strip_y |
+``THETIS_AMD_EXCHANGE_EVERY`` (default: 2 or 1 where every rank then fits the dataflow kernel with its ghost layers, else 4; 2 for
+coupled / ForwardEuler / quadrilateral runs), ``THETIS_AMD_OVERLAP_STAGES`` (default 0), ``THETIS_AMD_PARTITION`` = strip | strip_y |
 rcb (default: strips along the longer side of a structured mesh, recursive coordinate bisection otherwise),
 ``THETIS_AMD_SPMD_FLOW`` = 1 | 0 (require / forbid the dataflow launches; default: the ranks' common automatic choice).
 """
@@ -34,9 +35,11 @@ import os
 import numpy as np
 
 from .device import FacetValues, Swe2dDevice
-from .partition import rcb_owner, strip_owner
+from .partition import build_partition, rcb_owner, strip_owner
 
 __all__ = ['PartitionedDevice', 'make_device', 'default_owner']
+
+FLOW_RESIDENT_CELLS = 2048*64          # cells of the 64-cell blocks an MI355X holds resident for the dataflow kernel (2 per SIMD x 1024)
 
 
 def default_owner(mesh, n_parts):
@@ -72,18 +75,30 @@ class PartitionedDevice(object):
         self.use_limiter = bool(use_limiter) and self.n_tracers > 0
         self._tracers_handed_out = 0
         on_gpu = not getattr(device_cls, 'is_host', False)
-        # time steps between two exchanges (3m ghost layers): ranks that fit the dataflow kernel (<= ~131 k cells incl. their ghost
-        # layers: m = 2 is what fits an eighth of a 1 M-triangle mesh) exchange every 2 steps inside its launches; larger ranks run
-        # stage launches, where the two exchange kernels of a cycle are spread over 4 steps (measured: a rank of two 69-70 us per
-        # step at m = 4 / 8 against 72 at m = 2, a rank of four 42.5-44 against 45).  The same rule on every rank.
-        small = self.npc == 3 and not self.n_tracers and self.n_cells <= 122000*comm.size
-        every = max(1, int(os.environ.get('THETIS_AMD_EXCHANGE_EVERY', '2' if (small or self.n_tracers) else '4')))
-        overlap = int(os.environ.get('THETIS_AMD_OVERLAP_STAGES', '0'))
-        if stepper == 'ForwardEuler' or (self.n_tracers and overlap and (every == 1 or tracer_only)):
-            overlap = 0
         owner = default_owner(mesh, comm.size) if owner is None else np.asarray(owner)
         if len(np.unique(owner)) != comm.size:
             raise ValueError('the mesh has fewer cells than the run has ranks')
+        # time steps between two exchanges (3m ghost layers).  Ranks that fit the dataflow kernel WITH their ghost layers (2048
+        # resident 64-cell blocks on an MI355X: an eighth of a 1 M-triangle mesh fits with the six layers of m = 2, not with the twelve
+        # of m = 4) exchange every 2 steps (or every step) inside its launches; larger ranks run stage launches, where the two
+        # exchange kernels of a cycle are spread over 4 steps (measured: a rank of two 69-70 us per step at m = 4 / 8 against 72 at
+        # m = 2, a rank of four 42.5-44 against 45).  Decided by all ranks together from the partitions themselves.
+        partition = None
+        if os.environ.get('THETIS_AMD_EXCHANGE_EVERY'):
+            every = max(1, int(os.environ['THETIS_AMD_EXCHANGE_EVERY']))
+        elif self.n_tracers or stepper != 'SSPRK33' or self.npc != 3 or not on_gpu:
+            every = 2
+        else:
+            every = 4
+            if self.n_cells <= FLOW_RESIDENT_CELLS*comm.size:
+                for m in (2, 1):
+                    part = build_partition(mesh, owner, comm.rank, halo_depth=3*m)
+                    if comm.all_agree(part.num_cells <= FLOW_RESIDENT_CELLS):
+                        every, partition = m, part
+                        break
+        overlap = int(os.environ.get('THETIS_AMD_OVERLAP_STAGES', '0'))
+        if stepper == 'ForwardEuler' or (self.n_tracers and overlap and (every == 1 or tracer_only)):
+            overlap = 0
         forced = os.environ.get('THETIS_AMD_EXCHANGE')
         if not on_gpu:
             wanted = ['host']
@@ -102,7 +117,7 @@ class PartitionedDevice(object):
                                      n_tracers=self.n_tracers, use_limiter=use_limiter, tracer_only=tracer_only,
                                      exchange_every=every, overlap_stages=overlap, stepper=stepper, exchange=ex,
                                      group=(None if ex == 'rccl' else comm.group), device_cls=device_cls,
-                                     flow=(flow if on_gpu else False), **opts)
+                                     flow=(flow if on_gpu else False), partition=partition, **opts)
             except Exception as e:                                    # e.g. IPC mapping refused: every rank moves on together
                 err = '{:}: {:}'.format(ex, (str(e).strip().splitlines() or [type(e).__name__])[0])
             if comm.all_agree(err is None):
