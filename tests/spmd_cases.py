@@ -187,7 +187,46 @@ def _restart(outdir, cpu=False):
     return solver_obj
 
 
+def _fields(outdir, nx=20, ny=6, cpu=False):
+    """Function-valued data that ``update_forcings`` changes before every stage (GPU only): a tidal elevation FIELD on the open
+    boundary (CG-P1 -> the values at the end nodes of the boundary facets), a wind stress field (CG-P1 vector -> per-vertex upload),
+    an atmospheric pressure field held in DG-P1 (nodal upload), a spatially varying Manning coefficient and a viscosity field"""
+    lx, ly = 40e3, 12e3
+    mesh2d = RectangleMesh(nx, ny, lx, ly)
+    P1_2d = get_functionspace(mesh2d, 'CG', 1)
+    P1v_2d = get_functionspace(mesh2d, 'CG', 1, vector=True)
+    P1DG_2d = get_functionspace(mesh2d, 'DG', 1)
+    bathymetry_2d = Function(P1_2d).interpolate(lambda x, y: 15.0 - 5.0*x/lx + np.cos(y/2000.0))
+    solver_obj = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+    o = solver_obj.options
+    o.swe_timestepper_type = 'SSPRK33'
+    o.swe_timestepper_options.use_automatic_timestep = False
+    o.timestep = 12.0
+    o.simulation_end_time = 360.0
+    o.simulation_export_time = 120.0
+    o.no_exports = True
+    o.output_directory = outdir
+    o.check_volume_conservation_2d = True
+    tide = Function(P1_2d)
+    wind = Function(P1v_2d)
+    patm = Function(P1DG_2d)
+    o.wind_stress = wind
+    o.atmospheric_pressure = patm
+    o.manning_drag_coefficient = Function(P1_2d).interpolate(lambda x, y: 0.02 + 0.01*x/lx)
+    o.horizontal_viscosity = Function(P1_2d).interpolate(lambda x, y: 5.0 + 10.0*y/ly)
+    solver_obj.bnd_functions['shallow_water'] = {1: {'elev': tide}, 2: {'un': Constant(0.01)}}
+    solver_obj.assign_initial_conditions(elev=Constant(0.0))
+
+    def update_forcings(t):
+        tide.interpolate(lambda x, y: 0.5*math.sin(2*math.pi*t/3600.0)*(1.0 + 0.1*y/ly))
+        wind.interpolate(lambda x, y: (0.1*math.cos(t/500.0) + 0*x, 0.05*np.sin(math.pi*x/lx)))
+        patm.interpolate(lambda x, y: 50.0*np.sin(math.pi*y/ly)*math.sin(t/400.0))
+    solver_obj.iterate(update_forcings=update_forcings)
+    return solver_obj
+
+
 CASES = {
+    'fields': _fields,
     'restart': _restart,
     'channel': _channel,
     'channel_wide': lambda outdir, **kw: _channel(outdir, nx=84, ny=16, export=False, **kw),

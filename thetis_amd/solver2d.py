@@ -68,6 +68,8 @@ class FlowSolver2d(object):
         # mpiexec -n N): the communicator of this run; COLLECTIVE when WORLD_SIZE > 1 (thetis_amd/comm.py)
         self.comm = get_comm()
         self.device_id = self.comm.local_rank if self.comm.size > 1 else 0
+        # (test seam: ``FlowSolver2d._device_cls``, if set, replaces ``Swe2dDevice`` as the class of the per-rank handle - the CPU
+        #  tests of the rank-parallel host logic hand in a stand-in there, tests/cpu_device.py; the product never sets it)
 
     # ------------------------------------------------------------------ time step
     def compute_time_step(self, u_scale=0.0):
