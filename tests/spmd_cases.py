@@ -225,7 +225,40 @@ def _fields(outdir, nx=20, ny=6, cpu=False):
     return solver_obj
 
 
+def _periodic(outdir, nx=24, ny=8, cpu=False, tracer=True):
+    """a channel periodic in x (test/swe2d/test_rossby_wave.py's mesh type) on an f-plane, with a tracer and the limiter: the first
+    and the last strip are neighbours across the seam, the limiter's vertex patches wrap around it"""
+    from thetis_amd import PeriodicRectangleMesh
+    lx, ly = 48e3, 16e3
+    mesh2d = PeriodicRectangleMesh(nx, ny, lx, ly, direction='x')
+    P1_2d = get_functionspace(mesh2d, 'CG', 1)
+    bathymetry_2d = Function(P1_2d).assign(30.0)
+    solver_obj = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+    o = solver_obj.options
+    if tracer:
+        o.add_tracer_2d('tracer_2d', 'Depth averaged tracer', 'Tracer2d', source=None, diffusivity=None)
+        o.tracer_timestepper_type = 'SSPRK33'
+        o.tracer_timestepper_options.use_automatic_timestep = False
+        o.check_tracer_conservation = True
+        o.check_tracer_overshoot = True
+    o.swe_timestepper_type = 'SSPRK33'
+    o.swe_timestepper_options.use_automatic_timestep = False
+    o.timestep = 5.0
+    o.simulation_end_time = 150.0
+    o.simulation_export_time = 50.0
+    o.coriolis_frequency = Constant(1e-4)
+    o.check_volume_conservation_2d = True
+    o.no_exports = True
+    o.output_directory = outdir
+    bump = lambda x, y: 0.4*np.exp(-((np.minimum(x, lx - x))**2 + (y - 0.5*ly)**2)/(4e3)**2)       # sits ON the seam
+    kw = {'tracer': Function(P1_2d).interpolate(lambda x, y: 1.0 + 1.0*(np.abs(x - 0.5*lx) > 0.3*lx))} if tracer else {}
+    solver_obj.assign_initial_conditions(elev=Function(P1_2d).interpolate(bump), uv=Constant((0.3, 0.0)), **kw)
+    solver_obj.iterate()
+    return solver_obj
+
+
 CASES = {
+    'periodic': _periodic,
     'fields': _fields,
     'restart': _restart,
     'channel': _channel,
