@@ -257,7 +257,45 @@ def _periodic(outdir, nx=24, ny=8, cpu=False, tracer=True):
     return solver_obj
 
 
+def _coast(outdir, cpu=False):
+    """an unstructured mesh read from a Gmsh file (tests/golden/coast.msh, the shape of demos/north_sea.msh: arbitrary marker ids),
+    cut into compact parts by recursive coordinate bisection: open boundary with a tide through ``update_forcings`` in the first half
+    of the run (stage by stage), batches in the second, tracer with the limiter"""
+    from thetis_amd import Mesh
+    mesh2d = Mesh(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'coast.msh'))
+    P1_2d = get_functionspace(mesh2d, 'CG', 1)
+    x, y = mesh2d.vertex_xy.T
+    bathymetry_2d = Function(P1_2d).assign(12.0 + 6.0*(x - x.min())/(x.max() - x.min()))
+    solver_obj = solver2d.FlowSolver2d(mesh2d, bathymetry_2d)
+    o = solver_obj.options
+    o.add_tracer_2d('tracer_2d', 'Depth averaged tracer', 'Tracer2d', source=None, diffusivity=None)
+    o.swe_timestepper_type = 'SSPRK33'
+    o.tracer_timestepper_type = 'SSPRK33'
+    o.swe_timestepper_options.use_automatic_timestep = False     # (the CG-P1 projection behind the automatic step undershoots to a
+    o.tracer_timestepper_options.use_automatic_timestep = False  #  negative number on this strongly graded mesh: FlowSolver2d raises)
+    o.timestep = 0.4
+    o.simulation_export_time = 40.0
+    o.simulation_end_time = 80.0
+    o.check_volume_conservation_2d = True
+    o.check_tracer_conservation = True
+    o.no_exports = True
+    o.output_directory = outdir
+    tide = Constant(0.0)
+    open_marker = sorted(mesh2d.boundary_markers)[-1]
+    solver_obj.bnd_functions['shallow_water'] = {open_marker: {'elev': tide}}
+    solver_obj.assign_initial_conditions(elev=Constant(0.0), tracer=Function(P1_2d).assign(1.0 + (y > y.mean())))
+    it = solver_obj.create_iterator(update_forcings=lambda t: tide.assign(0.3*math.sin(2*math.pi*t/600.0)))
+    for t in it:                                   # stage by stage up to the first export ...
+        if solver_obj.i_export >= 1:
+            break
+    o.simulation_end_time = 160.0                  # ... then the rest in batches (no forcing updates)
+    solver_obj.export_initial_state = False
+    solver_obj.iterate()
+    return solver_obj
+
+
 CASES = {
+    'coast': _coast,
     'periodic': _periodic,
     'fields': _fields,
     'restart': _restart,

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize('name,world', [('channel', 2), ('channel', 4), ('forced', 2), ('forced', 3), ('tracer', 2), ('tracer_forced', 3),
                                         ('tracer_only', 2), ('balzano', 2), ('balzano', 4), ('forced_fe', 2), ('tracer_fe', 2),
-                                        ('tracer_nolim', 2), ('fields', 2), ('fields', 3), ('periodic', 2), ('periodic', 4)])
+                                        ('tracer_nolim', 2), ('fields', 2), ('fields', 3), ('periodic', 2), ('periodic', 4), ('coast', 2), ('coast', 4)])
 def test_user_script_under_n_ranks_on_one_gpu(tmp_path, tmp_path_factory, hip_lib, name, world):
     single = single_rank(name, tmp_path_factory, cpu=False)
     ranks = run_spmd(world, str(tmp_path), name, cpu=False)

@@ -60,6 +60,7 @@ def test_user_script_under_n_ranks_equals_single_rank(tmp_path, tmp_path_factory
     ('forced', 2, {'THETIS_AMD_PARTITION': 'strip_y', 'THETIS_AMD_EXCHANGE_EVERY': '3'}),
     ('restart', 2, {}),
     ('periodic', 2, {}), ('periodic', 3, {'THETIS_AMD_EXCHANGE_EVERY': '1'}),
+    ('coast', 3, {}),
 ])
 def test_user_script_variants(tmp_path, tmp_path_factory, ref_so, name, world, env):
     single = single_rank(name, tmp_path_factory)

@@ -100,6 +100,11 @@ class FlowSolver2d(object):
             # comm.allreduce(dt, op=MIN) (solver2d.py:240): the replicated meshes give every rank the same number; the reduction
             # makes sure of it (ranks stepping with different dt would never meet again)
             self.dt = float(self.comm.allreduce_min(dt)[0])
+            if not self.dt > 0.0:
+                # the consistent-mass L2 projections of solver2d.py:149-177 / utility.py:620-640 undershoot where the cell size
+                # changes by an order of magnitude between neighbours; the reference would step with that number
+                raise ValueError('the automatic time step is not positive ({:g}): the CG-P1 projection of cell size / wave speed '
+                                 'undershoots on this strongly graded mesh - set options.timestep'.format(self.dt))
             if self.options.use_wetting_and_drying:
                 # the explicit wetting-drying formulation carries waves of speed sqrt(g |H|) through dry ground
                 # (|H| up to 2.4 alpha) and was measured stable up to ~0.4-0.5 of this step on the reference's Thacker and
