@@ -301,6 +301,8 @@ CASES = {
     'restart': _restart,
     'channel': _channel,
     'channel_wide': lambda outdir, **kw: _channel(outdir, nx=84, ny=16, export=False, **kw),
+    # BASELINE cfg 2 / cfg 3's mesh: 1 M triangles (the examples/channel2d.py physics on the bench mesh's cell count)
+    'channel_1m': lambda outdir, **kw: _channel(outdir, nx=1000, ny=500, export=False, **kw),
     'forced': _forced,
     'forced_fe': lambda outdir, **kw: _forced(outdir, stepper='ForwardEuler', **kw),
     'tracer': _tracer,

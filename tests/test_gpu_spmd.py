@@ -47,6 +47,18 @@ def test_user_script_variants_on_one_gpu(tmp_path, tmp_path_factory, hip_lib, na
     _check(single, ranks, exact_callbacks=True)
 
 
+@pytest.mark.parametrize('world', [2, 8])
+def test_full_size_channel_under_ranks_matches_single_device(tmp_path, tmp_path_factory, hip_lib, world):
+    """BASELINE cfg 3's mesh size with the bits checked: the channel2d script on 1 M triangles (8 000 automatic time steps, five
+    print_state / volume-check points), one device against 2 and 8 ranks sharing it - every cell of the final state, the step and
+    export counters and the callback histories identical.  (Eight strips of 125 000 cells: the end ranks would fit the dataflow
+    kernel, the middle ranks with their two ghost sides would not - the ranks' common decision, and they share a GPU: stage launches.)"""
+    single = single_rank('channel_1m', tmp_path_factory, cpu=False)
+    ranks = run_spmd(world, str(tmp_path), 'channel_1m', cpu=False, timeout=900)
+    _check(single, ranks, exact_callbacks=True)
+    assert single[0]['elev'].shape == (3000000,) and single[0]['iteration'] > 5000
+
+
 def _script(args, world, port):
     e = dict(os.environ)
     e['THETIS_AMD_DIST_BACKEND'] = 'gloo'            # the ranks share the one GPU of the test box: RCCL would refuse them
