@@ -292,6 +292,7 @@ class DistributedSwe2d(object):
         self._flowx_request = flow_exchange
         self._flow_now = None                    # the rank-collective decision of the current advance() (see _decide_flow)
         self._flowx_now = False
+        self._flow_epoch, self._decided_epoch = 0, None
         self._no_exchange = False                # measurement only (bench: config.exchange_time_fraction): the schedule without its exchanges
         self._shared_device = None               # do several ranks step on this GPU?  (found out at the first automatic decision)
         if flow is not False and self.dev.npc == 3 and self._on_gpu:
@@ -388,7 +389,7 @@ class DistributedSwe2d(object):
         ``flow=False``): a rank whose partition the kernel does not cover (one ghost side more than its neighbour, just over the
         resident capacity) would otherwise wait for stage-launch halos while its peers push flow granules, and every wait would
         run into its timeout.  Automatic choice (``flow=None``): only where every rank is covered and no two ranks share a GPU,
-        agreed anew at every ``advance`` (the configuration may have changed in between, on every rank alike); ``flow=True``:
+        agreed anew at the first ``advance`` after a configuration change that matters (``config_changed``); ``flow=True``:
         agreed once, a rank that is not covered makes all ranks raise.  The exchange inside the launches (``flow_exchange``) is
         part of the same agreement."""
         import torch.distributed as dist
@@ -416,12 +417,21 @@ class DistributedSwe2d(object):
         # (every rank takes part in the all-gather behind _ranks_share_a_device, whatever its own answer: a rank that skipped it
         #  because its partition is not covered would leave the others waiting in it - seen with the eight strips of the 1 M-triangle
         #  mesh, whose end ranks are covered and whose middle ranks, with two ghost sides, are not)
+        if self._decided_epoch == self._flow_epoch and self._flow_now is not None:
+            return self._flow_now               # nothing that decides coverage has changed since the ranks last agreed
         shared = self._ranks_share_a_device()
         ok = self._flow_local() and not shared
         okx = ok and self._flowx_local()
         both = self._all_reduce([1.0 if ok else 0.0, 1.0 if okx else 0.0], dist.ReduceOp.MIN)
         self._flow_now, self._flowx_now = bool(both[0] > 0.5), bool(both[1] > 0.5)
+        self._decided_epoch = self._flow_epoch
         return self._flow_now
+
+    def config_changed(self):
+        """To be called (by every rank alike) after a change of the handle's configuration that decides whether the flow kernel covers it
+        - wetting-drying, viscosity: the next ``advance`` lets the ranks agree anew.  ``PartitionedDevice`` does; a caller that
+        configures ``self.dev`` directly after the first ``advance`` must."""
+        self._flow_epoch += 1
 
     @property
     def flow(self):

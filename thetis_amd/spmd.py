@@ -220,9 +220,11 @@ class PartitionedDevice(object):
 
     def set_wetting_and_drying(self, alpha):
         self.dev.set_wetting_and_drying(None if alpha is None else self._vertices(alpha))
+        self.dist.config_changed()
 
     def set_viscosity(self, nu, **kwargs):
         self.dev.set_viscosity(None if nu is None else self._vertices(nu), **kwargs)
+        self.dist.config_changed()
 
     def set_bc(self, marker, funcs):
         self._slot(marker)
