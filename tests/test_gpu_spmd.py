@@ -59,6 +59,15 @@ def test_full_size_channel_under_ranks_matches_single_device(tmp_path, tmp_path_
     assert single[0]['elev'].shape == (3000000,) and single[0]['iteration'] > 5000
 
 
+def test_a_transport_that_cannot_be_set_up_is_left_by_all_ranks_together(tmp_path, tmp_path_factory, hip_lib):
+    """the peer-to-peer zones cannot be mapped (THETIS_AMD_TEST_BREAK_P2P makes swe2d_p2p_open fail, as on a node without IPC peer
+    access): every rank gives the transport up in the same all-reduce and the run goes through host memory - same bits"""
+    single = single_rank('forced', tmp_path_factory, cpu=False)
+    ranks = run_spmd(3, str(tmp_path), 'forced', cpu=False, env={'THETIS_AMD_TEST_BREAK_P2P': '1'})
+    assert [r['exchange'] for r in ranks] == ['host']*3
+    _check(single, ranks, exact_callbacks=True)
+
+
 def _script(args, world, port):
     e = dict(os.environ)
     e['THETIS_AMD_DIST_BACKEND'] = 'gloo'            # the ranks share the one GPU of the test box: RCCL would refuse them
