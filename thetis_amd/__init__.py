@@ -10,6 +10,9 @@ thetis_amd - MI355X-native explicit 2D shallow-water time stepper behind Thetis'
     solver_obj.iterate()
 
 Importing this package never loads the HIP extension; creating a time stepper does, and fails loudly without it.
+
+Several GPUs: the same script under ``python -m torch.distributed.run --nproc-per-node N script.py`` (one process per GPU) is
+domain-decomposed as ``mpiexec -n N`` does it for the reference (thetis_amd/comm.py, thetis_amd/spmd.py).
 """
 from . import solver2d  # noqa: F401
 from .function import Function, FunctionSpace, get_functionspace  # noqa: F401
