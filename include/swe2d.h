@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SWE2D_ABI_VERSION 9
+#define SWE2D_ABI_VERSION 8
 #define SWE2D_MAX_MARKERS 16          /* boundary markers must be in 1..SWE2D_MAX_MARKERS-1 */
 
 typedef enum {
@@ -190,14 +190,6 @@ int  swe2d_set_wetting_and_drying(swe2d_handle *h, int enable, const double *alp
 /* ERKGenericShuOsher.advance (rungekutta.py:949-952) repeated n_steps times, forcings constant in time.
  * Asynchronous: returns after enqueueing. */
 int  swe2d_advance(swe2d_handle *h, int n_steps);
-/* How swe2d_advance issues its stage launches on ONE device (nothing the reference has a counterpart for: PyOP2 runs one
- * par_loop after the other): with a table of n_stages >= 3 "front ends" e_0 >= e_1 >= ..., stage j after a join runs as two
- * launches, cells [0, e_j) on the handle's stream and [e_j, n_cells) on a second stream one dependency behind, so that the
- * device always holds a kernel of each chain and the ramp and the last partly filled round of one launch are covered by the
- * other; the chains join every n_stages / 3 steps and at the end of the call.  The caller's numbering must put the cells of the
- * front part that lie within j facets of the rear part at the end of [0, e_0), nearest last, e_j dropping one such layer per
- * stage (thetis_amd/ordering.py chain_order).  Same bits as single launches.  n_stages = 0 switches back. */
-int  swe2d_set_chains(swe2d_handle *h, int32_t n_stages, const int32_t *front_end);
 /* ERKGenericShuOsher.solve_stage(i_stage) (rungekutta.py:930-946); i_stage = 0,1,2 in order. */
 int  swe2d_solve_stage(swe2d_handle *h, int i_stage);
 /* timeintegrator.ForwardEuler.advance (thetis/timeintegrator.py:115-165; 'ForwardEuler' in the steppers table,

@@ -145,17 +145,7 @@ struct Handle {
     int flow_blocks = 0;                                // 64-cell blocks of the handle
     int flow_capacity = -1;                             // resident one-wave workgroups of the flow kernel on this device (-1: not asked yet)
     int flow_max_rim = 0;                               // most rim facets of a block in the current flow order (selects the polling width)
-    int launch_parity[2] = {0, 0};                      // direction of the next large stage launch (launch_stage), per chain
-    // Two chains of half-launches (swe2d_set_chains, advance_chains): the front part of the cell range runs its stages on the
-    // handle's stream, the rest one dependency behind on chain_stream, so that the ramp and the tail of every launch are
-    // filled by the other chain's kernel.  chain_end[j]: end of the front part in the j-th stage after a join.
-    std::vector<int> chain_end;
-    hipStream_t chain_stream = nullptr;
-    std::vector<hipEvent_t> chain_ev;                   // [2*stages]: front launch j done, rear launch j done
-    hipEvent_t chain_fork = nullptr, chain_join = nullptr;
-    int cur_chain = 0;                                  // which chain launch_stage is launching for (parity of the direction)
-    bool chain_active = false;                          // inside advance_chains: size thresholds of launch_stage look at the whole mesh
-    int chain_lead = 2;                                 // the front chain runs at most this many stages ahead (THETIS_AMD_CHAIN_LEAD)
+    int launch_parity = 0;                              // direction of the next large stage launch (launch_stage)
     bool flow_used = false;                             // a flow launch since the status word was last read
     double flow_timeout_s = 2.0;                        // THETIS_AMD_FLOW_TIMEOUT_S
     double *vx = nullptr, *vy = nullptr, *vh = nullptr;
@@ -407,8 +397,7 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     // us/step without / with: 250 k cells 37.9 / 42.2, 500 k 63.5 / 68.3, 1 M 115-118 / 118-119, 2 M 295-312 / 297-298,
     // 4 M 573-583 / 544.  Same bits in every variant: the kernel has no implicit contraction.
     const char *env_ldsx_s = std::getenv("THETIS_AMD_LDSX");
-    const int span = h->chain_active ? h->n_owned : (c1 - c0);          // half-launches of two chains: the mesh decides
-    const bool ldsx = env_ldsx_s ? std::atoi(env_ldsx_s) != 0 : span >= 3000000;
+    const bool ldsx = env_ldsx_s ? std::atoi(env_ldsx_s) != 0 : (c1 - c0) >= 3000000;
     stage_kernel_t kern = fused_visc
         ? pick_kernel_visc(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
         : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4 ? (h->affine ? 1 : 2) : 0, binl)
@@ -425,8 +414,8 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     // 0.732).  THETIS_AMD_ALTERNATE=0/1 forces the choice.
     if (!fused_visc) {
         const char *env_alt = std::getenv("THETIS_AMD_ALTERNATE");
-        const bool alt = env_alt ? std::atoi(env_alt) != 0 : (size_t)span*h->npc*72 >= ((size_t)256 << 20);
-        if (alt) { a.reverse = h->launch_parity[h->cur_chain]; h->launch_parity[h->cur_chain] ^= 1; }
+        const bool alt = env_alt ? std::atoi(env_alt) != 0 : (size_t)(c1 - c0)*h->npc*72 >= ((size_t)256 << 20);
+        if (alt) { a.reverse = h->launch_parity; h->launch_parity ^= 1; }
     }
     SWE_CHK_SYNC(h->stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
@@ -1037,10 +1026,6 @@ void swe2d_destroy(swe2d_handle *hh)
     if (h->p2p.zone) (void)hipFree(h->p2p.zone);
     if (h->p2p.ctr) (void)hipFree(h->p2p.ctr);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
-    for (auto &e : h->chain_ev) if (e) (void)hipEventDestroy(e);
-    if (h->chain_fork) (void)hipEventDestroy(h->chain_fork);
-    if (h->chain_join) (void)hipEventDestroy(h->chain_join);
-    if (h->chain_stream) { (void)hipStreamSynchronize(h->chain_stream); (void)hipStreamDestroy(h->chain_stream); }
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->my_stream) (void)hipStreamDestroy(h->my_stream);
     delete h;
@@ -1377,54 +1362,6 @@ int swe2d_solve_stage(swe2d_handle *hh, int i_stage)
     return swe2d_solve_stage_cells(hh, i_stage, 0, h->n_owned);
 }
 
-// Two chains of half-launches.  Within a window of K stages after a join, stage j of the FRONT part [0, e_j) needs the stage
-// before on [0, e_j) and its facet neighbours, which lie in [0, e_(j-1)) by the construction of the numbering (the cells of the
-// front part that touch the rear part come last, layer by layer, and e_j drops one layer per stage): the front chain depends on
-// nothing but itself.  Stage j of the REAR part [e_j, n) needs stage j - 1 of both parts.  What one chain writes the other does
-// not read: front launch j writes [0, e_j), rear launch i < j reads [e_(i+1), n) at most; rear launch i writes [e_i, n), front
-// launch j > i reads [0, e_(j-1)) - so the three-buffer rotation with its in-place third stage needs no further ordering.
-// The device then always holds a kernel of each chain, and the ramp and the last, partly filled round of waves of one are
-// covered by the other (two independent half-size meshes side by side: tools/concurrency_probe.py, profiles/r04m).
-bool chains_wanted(const Handle *h)
-{
-    if (h->chain_end.size() < 3 || h->n_owned != h->n_cells) return false;
-    const char *e = std::getenv("THETIS_AMD_CHAINS");
-    return !(e && std::atoi(e) == 0);
-}
-
-int advance_chains(Handle *h, int n_steps)
-{
-    const int kmax = (int)h->chain_end.size()/3*3;
-    hipStream_t front = h->stream, rear = h->chain_stream;
-    struct Restore { Handle *h; hipStream_t s; ~Restore() { h->stream = s; h->cur_chain = 0; h->chain_active = false; } } restore{h, front};
-    h->chain_active = true;
-    for (int done = 0; done < n_steps;) {
-        const int m = std::min(n_steps - done, kmax/3);
-        HIP_TRY(h, hipEventRecord(h->chain_fork, front));
-        HIP_TRY(h, hipStreamWaitEvent(rear, h->chain_fork, 0));
-        for (int j = 0; j < 3*m; j++) {
-            const int e = h->chain_end[j];
-            // front launch j: after rear launch j - lead (keeps the chains side by side; not needed for the result)
-            if (j - h->chain_lead >= 0) HIP_TRY(h, hipStreamWaitEvent(front, h->chain_ev[2*(j - h->chain_lead) + 1], 0));
-            h->stream = front; h->cur_chain = 0;
-            int rc = stage_on_range(h, j % 3, 0, e);
-            if (rc) return rc;
-            HIP_TRY(h, hipEventRecord(h->chain_ev[2*j], front));
-            // rear launch j: after front launch j - 1 (and rear launch j - 1, by stream order)
-            if (j > 0) HIP_TRY(h, hipStreamWaitEvent(rear, h->chain_ev[2*(j - 1)], 0));
-            h->stream = rear; h->cur_chain = 1;
-            rc = stage_on_range(h, j % 3, e, h->n_owned);
-            if (rc) return rc;
-            HIP_TRY(h, hipEventRecord(h->chain_ev[2*j + 1], rear));
-        }
-        h->stream = front;
-        HIP_TRY(h, hipEventRecord(h->chain_join, rear));
-        HIP_TRY(h, hipStreamWaitEvent(front, h->chain_join, 0));
-        done += m;
-    }
-    return SWE2D_OK;
-}
-
 int swe2d_advance(swe2d_handle *hh, int n_steps)
 {
     Handle *h = H(hh);
@@ -1452,42 +1389,11 @@ int swe2d_advance(swe2d_handle *hh, int n_steps)
             return SWE2D_OK;
         }
     }
-    if (chains_wanted(h)) return advance_chains(h, n_steps);
     for (int it = 0; it < n_steps; it++)
         for (int s = 0; s < 3; s++) {
             int rc = stage_on_range(h, s, 0, h->n_owned);
             if (rc) return rc;
         }
-    return SWE2D_OK;
-}
-
-int swe2d_set_chains(swe2d_handle *hh, int32_t n_stages, const int32_t *front_end)
-{
-    Handle *h = H(hh);
-    if (!h || n_stages < 0 || (n_stages > 0 && !front_end)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad argument");
-    if (n_stages > 0 && n_stages < 3) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_set_chains: at least one step (three stages)");
-    if (h->n_owned != h->n_cells && n_stages > 0)
-        return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_set_chains on a partition");
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (h->chain_stream) HIP_TRY(h, hipStreamSynchronize(h->chain_stream));
-    // The front part may only shrink, by the cells that touch the rear part of the stage before (not checked here cell by cell:
-    // the caller builds the numbering, thetis_amd/ordering.py chain_order; tests compare the bits with single launches).
-    for (int j = 0; j < n_stages; j++)
-        if (front_end[j] < 0 || front_end[j] > h->n_owned || (j > 0 && front_end[j] > front_end[j - 1]))
-            return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_set_chains: front ends must lie in the mesh and not grow");
-    h->chain_end.assign(front_end, front_end + n_stages);
-    if (n_stages == 0) return SWE2D_OK;
-    if (!h->chain_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->chain_stream, hipStreamNonBlocking));
-    if (!h->chain_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->chain_fork, hipEventDisableTiming));
-    if (!h->chain_join) HIP_TRY(h, hipEventCreateWithFlags(&h->chain_join, hipEventDisableTiming));
-    while ((int)h->chain_ev.size() < 2*n_stages) {
-        hipEvent_t e = nullptr;
-        HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        h->chain_ev.push_back(e);
-    }
-    const char *env_lead = std::getenv("THETIS_AMD_CHAIN_LEAD");
-    if (env_lead) h->chain_lead = std::max(1, std::atoi(env_lead));
     return SWE2D_OK;
 }
 

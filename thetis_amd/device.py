@@ -5,8 +5,6 @@ Arrays cross the boundary in the reference's dof layout (cell c owns nodes 3c..3
 ``eta`` (N,3) float64.
 """
 import ctypes
-import os
-
 import numpy as np
 
 from . import _lib, ordering
@@ -14,11 +12,6 @@ from . import _lib, ordering
 __all__ = ['Swe2dDevice']
 
 _dp = ctypes.POINTER(ctypes.c_double)
-
-# ``advance`` as two chains of half-launches (swe2d_set_chains): whole meshes from this size (below, the dataflow kernel takes
-# the steps), joined every CHAIN_STAGES / 3 steps
-CHAIN_MIN_CELLS = 140000
-CHAIN_STAGES = 24
 
 
 def _ptr(a):
@@ -40,14 +33,12 @@ class FacetValues(object):
 class Swe2dDevice(object):
     def __init__(self, mesh, bathymetry_vertex, dt, g_grav=9.81, use_nonlinear_equations=True,
                  use_lax_friedrichs_velocity=True, lax_friedrichs_velocity_scaling_factor=1.0,
-                 device_id=0, n_owned=None, boundary_len=None, reorder='auto', ranges=None, chains='auto'):
+                 device_id=0, n_owned=None, boundary_len=None, reorder='auto', ranges=None):
         """
         :arg mesh: object with ``cells`` (N,3), ``vertex_xy`` (V,2), ``cell_nbr`` (N,3), ``cell_nbr_facet`` (N,3)
         :arg bathymetry_vertex: (V,) CG-P1 bathymetry at the vertices
         :kwarg reorder: None | 'auto' | 'hilbert' | explicit cell permutation: device-side cell numbering (callers never see it)
         :kwarg ranges: cell ranges that a reordering must not mix, e.g. (n_interior, n_owned) of a partition
-        :kwarg chains: 'auto' | None | number of stages between joins: ``advance`` as two chains of half-launches
-            (``swe2d_set_chains``); 'auto' = CHAIN_STAGES on a whole mesh of CHAIN_MIN_CELLS cells or more with a device numbering
         """
         self.lib = _lib.load()
         self.n_cells = int(mesh.cells.shape[0])
@@ -78,7 +69,6 @@ class Swe2dDevice(object):
         # ---- device numbering: perm[i_dev] = i_caller
         self.perm = None
         self._vperm = None
-        self._chain_front_end = None
         if reorder is not None:
             if isinstance(reorder, str):
                 if reorder not in ('hilbert', 'auto'):
@@ -93,11 +83,6 @@ class Swe2dDevice(object):
                             perm[a:b] = a + ordering.auto_cell_order(mesh, a, b)
                         else:
                             perm[a:b] = a + ordering.hilbert_cell_order(cen[a:b])
-                if chains == 'auto':
-                    min_cells = int(os.environ.get('THETIS_AMD_CHAIN_MIN_CELLS', CHAIN_MIN_CELLS))
-                    chains = CHAIN_STAGES if (ranges is None and self.n_owned == self.n_cells and self.n_cells >= min_cells) else None
-                if chains:
-                    perm, self._chain_front_end = ordering.chain_order(nbr0, perm, int(chains))
             else:
                 perm = np.asarray(reorder, dtype=np.int64)
                 assert sorted(perm) == list(range(self.n_cells))
@@ -159,9 +144,6 @@ class Swe2dDevice(object):
             # a partition (LocalPartition.affine = the GLOBAL mesh's flag) whose own cells happen to be parallelograms takes the
             # general kernels like every other rank: ghost and owned copies of a cell then agree bit for bit
             self._ck(self.lib.swe2d_set_general_quadrilaterals(self.h, 1))
-        if self._chain_front_end is not None:
-            fe = np.ascontiguousarray(self._chain_front_end, dtype=np.int32)
-            self._ck(self.lib.swe2d_set_chains(self.h, fe.size, fe.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
 
     # -- lifetime
     def close(self):

@@ -8,7 +8,7 @@ Firedrake gives the reference the same service by reordering DMPlex points (reve
 import numpy as np
 
 __all__ = ['hilbert_index', 'hilbert_cell_order', 'tile_cell_order', 'structured_tile_order', 'structured_subset_order', 'auto_cell_order',
-           'patch_row_order', 'first_touch_vertex_order', 'chain_order']
+           'patch_row_order', 'first_touch_vertex_order']
 
 
 def hilbert_index(ix, iy, order):
@@ -117,33 +117,3 @@ def first_touch_vertex_order(cells):
     flat = np.asarray(cells).reshape(-1)
     _, first = np.unique(flat, return_index=True)
     return flat[np.sort(first)]
-
-
-def chain_order(cell_nbr, perm, n_stages, front_fraction=0.5):
-    """Numbering for two chains of half-launches (``swe2d_set_chains``, include/swe2d.h): the cells of ``perm`` (new cell i =
-    old cell perm[i]) are cut into a front part (the first ``front_fraction`` of them) and a rear part; the cells of the front
-    part within ``n_stages - 1`` facets of the rear part are moved to the end of the front part, layer by layer, the layer
-    touching the rear part last.  Everything else keeps the order of ``perm``.
-
-    Returns (new perm, front_end) with ``front_end[j]`` = end of the front part of the j-th stage after a join: the whole front
-    part for j = 0, one layer less per stage.  Stage j of cells [0, front_end[j]) then reads only cells of [0, front_end[j-1]).
-    ``cell_nbr``: (N, k) facet neighbours in the OLD numbering, negative = boundary."""
-    perm = np.asarray(perm, dtype=np.int64)
-    nbr = np.asarray(cell_nbr, dtype=np.int64)
-    n = perm.shape[0]
-    n_front = int(round(n*front_fraction))
-    pos = np.empty(n, dtype=np.int64)
-    pos[perm] = np.arange(n)
-    dist = np.where(pos >= n_front, 0, -1)               # 0: rear part, -1: front part not reached yet
-    safe = np.where(nbr >= 0, nbr, 0)
-    for layer in range(1, max(int(n_stages), 1)):
-        reached = ((dist[safe] == layer - 1) & (nbr >= 0)).any(axis=1) & (dist < 0)
-        if not reached.any():
-            break
-        dist[reached] = layer
-    d = dist[perm[:n_front]]                              # layers of the front part in the order of perm
-    key = np.where(d < 0, 0, n_stages - d)                # core first, then far layers ... then layer 1
-    front = perm[:n_front][np.argsort(key, kind='stable')]
-    counts = np.bincount(np.where(d < 0, 0, d), minlength=max(int(n_stages), 1))[:max(int(n_stages), 1)]
-    front_end = n_front - np.concatenate([[0], np.cumsum(counts[1:])])
-    return np.concatenate([front, perm[n_front:]]), front_end.astype(np.int32)
