@@ -142,6 +142,19 @@ __device__ __forceinline__ double swe_sqrt(double x)
 #endif
 }
 
+// sqrt(x) for x >= 0 that need not be exact below 1e-150 (sums of squares): the argument is clamped away from 0, where
+// v_rsq_f64 gives inf, instead of the compare and the two selects of swe_sqrt; x = 0 -> 1e-150
+__device__ __forceinline__ double swe_sqrt_sumsq(double x)
+{
+#if SWE_FAST_SQRT
+    double s, rs;
+    swe_sqrt_rsqrt(fmax(x, 1e-300), s, rs);
+    return s;
+#else
+    return sqrt(x);
+#endif
+}
+
 // 1/x for normal-range x: v_rcp_f64 seed + two Newton steps
 __device__ __forceinline__ double swe_rcp(double x)
 {
@@ -159,7 +172,7 @@ __device__ __forceinline__ double swe_rcp(double x)
 // D = (H + sqrt(H^2 + a^2))/2 with H = h + eta (thetis/utility.py:975-993), and its inverse H = D - a^2/(4 D).
 __device__ __forceinline__ double swe_wd_depth(double H, double a)
 {
-    return 0.5*(H + swe_sqrt(fma(H, H, a*a)));
+    return 0.5*(H + swe_sqrt_sumsq(fma(H, H, a*a)));
 }
 
 // End of a wetting-drying stage in one cell (explicit formulation, oracle/swe2d_oracle.py module docstring and
@@ -205,9 +218,11 @@ __device__ __forceinline__ void swe_wd_finish(double g, double dt_stage, const d
         const double eta = D[i] - 0.25*al[i]*al[i]*swe_rcp(D[i]) - h[i];
         oe[i] = eta;
         if (!relax) continue;      // viscous runs: the relaxation follows the viscosity pass (swe_wd_relax_kernel)
-        const double ral = swe_rcp(al[i]);
-        const double psi = fmin(1.0, fmax(0.0, -(h[i] + eta)*ral - 1.0));
-        if (psi > 0.0) {
+        // psi > 0 <=> the water table lies more than alpha below the bed: decided without the quotient, which only dry nodes
+        // then pay for (a node within rounding of the threshold gets exp(-O(1e-32)) = 1 from the formula: the same bits)
+        if (-(h[i] + eta) > al[i]) {
+            const double ral = swe_rcp(al[i]);
+            const double psi = fmin(1.0, fmax(0.0, -(h[i] + eta)*ral - 1.0));
             const double fac = exp(-dt_stage*(1.0/SWE_WD_TAU)*swe_sqrt(g*ral)*psi*psi);     // 1/sqrt(alpha/g) = sqrt(g/alpha)
             ou[i] *= fac;
             ov[i] *= fac;
@@ -216,15 +231,16 @@ __device__ __forceinline__ void swe_wd_finish(double g, double dt_stage, const d
 }
 
 // x^(-1/3) for normal-range x > 0 (Manning: C_D = g mu^2 / H^(1/3), shallowwater_eq.py:693): f32 seed through
-// v_log_f32 / v_exp_f32, two Newton steps y <- y + y (1 - x y^3)/3 in f64 (quadratic: 1e-7 -> 1e-13 -> round-off)
+// v_log_f32 / v_exp_f32 (1e-7), then ONE step of third order: with r = 1 - x y^3 the root is y (1 - r)^(-1/3) =
+// y (1 + r/3 + 2 r^2/9 + 14 r^3/81 ...), truncated after r^2 (remainder 14/81 (3e-7)^3 ~ 5e-21; r itself carries 2e-16 from the
+// two rounded products) - six FP64 instructions where two Newton steps took ten
 __device__ __forceinline__ double swe_rcbrt(double x)
 {
 #if SWE_FAST_SQRT
     const float lf = __builtin_amdgcn_logf((float)x);              // log2
-    double y = (double)__builtin_amdgcn_exp2f(-0.33333334f*lf);
-    y = fma(y*(1.0/3.0), fma(-x*y, y*y, 1.0), y);
-    y = fma(y*(1.0/3.0), fma(-x*y, y*y, 1.0), y);
-    return y;
+    const double y = (double)__builtin_amdgcn_exp2f(-0.33333334f*lf);
+    const double r = fma(-(x*y), y*y, 1.0);
+    return fma(y*r, fma(r, 2.0/9.0, 1.0/3.0), y);
 #else
     return 1.0/cbrt(x);
 #endif
@@ -528,43 +544,80 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
         }
     }
     if (p.quad_drag >= 0.0 || p.manning >= 0.0 || p.nikuradse >= 0.0 || p.quad_f) {   // shallowwater_eq.py:685-700, 6-point rule
+        // The rule's points come in two orbits of three, barycentric (a, a, a) with one entry replaced by b.  A P1 field at the
+        // point that has b at node i is a*(x_0 + x_1 + x_2) + (b - a)*x_i, and the three points' contributions s_q w_q to the
+        // node integrals add up to a*(s_0 + s_1 + s_2) + (b - a)*s_i: one fma per field and point instead of three, and two
+        // instructions per node, orbit and component instead of three fmas per node, POINT and component (the kernel's time
+        // follows its instruction count on meshes that sit in the Infinity Cache).
         const double a1 = 0.445948490915965, b1 = 0.108103018168070, w1 = 0.223381589678011;
         const double a2 = 0.091576213509771, b2 = 0.816847572980459, w2 = 0.109951743655322;
-        double cf[3] = {0.0, 0.0, 0.0};
-        if (p.quad_f) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) cf[i] = swe_ld(swe_rsrc(p.quad_f), k8, i*S8);
-        }
+        const bool fld = p.quad_f != nullptr;
+        const int kind = fld ? p.quad_f_kind : (p.manning >= 0.0 ? 2 : (p.nikuradse >= 0.0 ? 3 : 1));
+        const double Hs = H[0] + H[1] + H[2];
         const double sm2 = p.norm_smoother*p.norm_smoother;
+        if (!fld && kind == 2) {
+            // Manning with a constant coefficient (cfg 5, options.manning_drag_coefficient = Constant): a path of its own, so that
+            // neither the selects between field and constant nor the other laws' code sit between its instructions
+            const double gm2 = g*p.manning*p.manning;
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const double aa = q < 3 ? a1 : a2, bb = q < 3 ? b1 : b2, ww = q < 3 ? w1 : w2;
-            double l[3] = {aa, aa, aa};
-            l[q % 3] = bb;
-            const double uq = fma(l[2], u[2], fma(l[1], u[1], l[0]*u[0]));
-            const double vq = fma(l[2], v[2], fma(l[1], v[1], l[0]*v[0]));
-            const double Hq = fma(l[2], H[2], fma(l[1], H[1], l[0]*H[0]));
-            const double cq = fma(l[2], cf[2], fma(l[1], cf[1], l[0]*cf[0]));    // field coefficient at the point
-            const int kind = p.quad_f ? p.quad_f_kind : (p.manning >= 0.0 ? 2 : (p.nikuradse >= 0.0 ? 3 : 1));
-            const double coef = p.quad_f ? cq : (kind == 2 ? p.manning : (kind == 3 ? p.nikuradse : p.quad_drag));
-            double cdh;                                  // C_D / H
-            if (kind == 2) {                             // Manning: C_D/H = g mu^2 H^(-4/3) = g mu^2 (H^(-1/3))^4: no reciprocal
-                const double y = swe_rcbrt(Hq);
-                cdh = g*coef*coef*((y*y)*(y*y));
-            } else {
-                double cd = coef;
-                if (kind == 3) {                         // C_D = 2 kappa^2 / ln(11.036 H/k_s)^2 for H > k_s, else 0   :696-697
-                    const double lg = log(11.036*Hq/coef);
-                    cd = (Hq > coef) ? 0.32/(lg*lg) : 0.0;
+            for (int o = 0; o < 2; o++) {
+                const double aa = o ? a2 : a1, dd = o ? b2 - a2 : b1 - a1, wAc = (o ? w2 : w1)*A*gm2;
+                const double au = aa*us, av = aa*vs, aH = aa*Hs;
+                double su[3], sv[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const double uq = fma(dd, u[i], au), vq = fma(dd, v[i], av), Hq = fma(dd, H[i], aH);
+                    const double y = swe_rcbrt(Hq), y2 = y*y;          // C_D/H = g mu^2 H^(-4/3) = g mu^2 (H^(-1/3))^4: no reciprocal
+                    const double s = (wAc*(y2*y2))*swe_sqrt_sumsq(fma(uq, uq, fma(vq, vq, sm2)));
+                    su[i] = s*uq;
+                    sv[i] = s*vq;
                 }
-                cdh = cd*swe_rcp(Hq);
-            }
-            const double s = ww*A*cdh*swe_sqrt(fma(uq, uq, fma(vq, vq, sm2)));
-            const double su = s*uq, sv = s*vq;
+                const double aSu = aa*(su[0] + su[1] + su[2]), aSv = aa*(sv[0] + sv[1] + sv[2]);
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                bu[i] = fma(-su, l[i], bu[i]);
-                bv[i] = fma(-sv, l[i], bv[i]);
+                for (int i = 0; i < 3; i++) {
+                    bu[i] -= fma(dd, su[i], aSu);
+                    bv[i] -= fma(dd, sv[i], aSv);
+                }
+            }
+        } else {
+            const double c0 = kind == 2 ? p.manning : (kind == 3 ? p.nikuradse : p.quad_drag);
+            double cf[3] = {0.0, 0.0, 0.0};
+            if (fld) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) cf[i] = swe_ld(swe_rsrc(p.quad_f), k8, i*S8);
+            }
+            const double cfs = cf[0] + cf[1] + cf[2];
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                const double aa = o ? a2 : a1, dd = o ? b2 - a2 : b1 - a1, wA = (o ? w2 : w1)*A;
+                const double au = aa*us, av = aa*vs, aH = aa*Hs, ac = aa*cfs;
+                double su[3], sv[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const double uq = fma(dd, u[i], au), vq = fma(dd, v[i], av), Hq = fma(dd, H[i], aH);
+                    const double coef = fld ? fma(dd, cf[i], ac) : c0;      // field coefficient at the point
+                    double cdh;                              // C_D / H
+                    if (kind == 2) {                         // Manning with a coefficient field
+                        const double y = swe_rcbrt(Hq), y2 = y*y;
+                        cdh = g*coef*coef*(y2*y2);
+                    } else {
+                        double cd = coef;
+                        if (kind == 3) {                     // C_D = 2 kappa^2 / ln(11.036 H/k_s)^2 for H > k_s, else 0   :696-697
+                            const double lg = log(11.036*Hq/coef);
+                            cd = (Hq > coef) ? 0.32/(lg*lg) : 0.0;
+                        }
+                        cdh = cd*swe_rcp(Hq);
+                    }
+                    const double s = wA*cdh*swe_sqrt_sumsq(fma(uq, uq, fma(vq, vq, sm2)));
+                    su[i] = s*uq;
+                    sv[i] = s*vq;
+                }
+                const double aSu = aa*(su[0] + su[1] + su[2]), aSv = aa*(sv[0] + sv[1] + sv[2]);
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    bu[i] -= fma(dd, su[i], aSu);
+                    bv[i] -= fma(dd, sv[i], aSv);
+                }
             }
         }
     }
@@ -2162,13 +2215,19 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
                     }
                     const int kind = p.quad_f ? p.quad_f_kind : (p.manning >= 0.0 ? 2 : (p.nikuradse >= 0.0 ? 3 : 1));
                     const double coef = p.quad_f ? cq : (kind == 2 ? p.manning : (kind == 3 ? p.nikuradse : p.quad_drag));
-                    double cd = coef;
-                    if (kind == 2) cd = g*coef*coef*swe_rcbrt(Hq);
-                    if (kind == 3) {
-                        const double lg = log(11.036*Hq/coef);
-                        cd = (Hq > coef) ? 0.32/(lg*lg) : 0.0;
+                    double cdh;                                  // C_D / H
+                    if (kind == 2) {                             // Manning: g mu^2 H^(-4/3) = g mu^2 (H^(-1/3))^4, no reciprocal
+                        const double y = swe_rcbrt(Hq), y2 = y*y;
+                        cdh = g*coef*coef*(y2*y2);
+                    } else {
+                        double cd = coef;
+                        if (kind == 3) {
+                            const double lg = log(11.036*Hq/coef);
+                            cd = (Hq > coef) ? 0.32/(lg*lg) : 0.0;
+                        }
+                        cdh = cd*swe_rcp(Hq);
                     }
-                    drag = cd*swe_sqrt(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother)*swe_rcp(Hq);
+                    drag = cdh*swe_sqrt_sumsq(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother);
                 }
                 if (p.lin_drag_f) {
 #pragma unroll
