@@ -274,8 +274,8 @@ def _coast(outdir, cpu=False):
     o.swe_timestepper_options.use_automatic_timestep = False     # (the CG-P1 projection behind the automatic step undershoots to a
     o.tracer_timestepper_options.use_automatic_timestep = False  #  negative number on this strongly graded mesh: FlowSolver2d raises)
     o.timestep = 0.4
-    o.simulation_export_time = 40.0
-    o.simulation_end_time = 80.0
+    o.simulation_export_time = 20.0
+    o.simulation_end_time = 40.0
     o.check_volume_conservation_2d = True
     o.check_tracer_conservation = True
     o.no_exports = True
@@ -288,7 +288,7 @@ def _coast(outdir, cpu=False):
     for t in it:                                   # stage by stage up to the first export ...
         if solver_obj.i_export >= 1:
             break
-    o.simulation_end_time = 160.0                  # ... then the rest in batches (no forcing updates)
+    o.simulation_end_time = 80.0                   # ... then the rest in batches (no forcing updates)
     solver_obj.export_initial_state = False
     solver_obj.iterate()
     return solver_obj

@@ -9,7 +9,7 @@ import mms_basin
 
 @pytest.mark.parametrize('name', ['setup7', 'setup8', 'setup9'])
 def test_steady_state_basin_convergence_oracle(name):
-    refs = [1, 2, 3]                       # the reference uses [1, 2, 4, 6] (GPU test); kept short for the CPU suite
+    refs = [1, 2]                          # the reference uses [1, 2, 4, 6] (the GPU test does too); kept short for the CPU suite
     errs = [mms_basin.run_oracle(name, r) for r in refs]
     slope_e, slope_u = mms_basin.convergence_rates(errs, refs)
     # test_steady_state_basin_mms.py:277-278: |slope - (order+1)|/(order+1) < 0.2

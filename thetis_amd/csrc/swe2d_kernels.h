@@ -622,6 +622,7 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
         }
     }
     if (p.wind) {                                        // shallowwater_eq.py:648, + tau.psi/(H rho0), 6-point rule
+        // (by orbits, like the quadratic drag above; the quotient through the v_rcp helper)
         const double a1 = 0.445948490915965, b1 = 0.108103018168070, w1 = 0.223381589678011;
         const double a2 = 0.091576213509771, b2 = 0.816847572980459, w2 = 0.109951743655322;
         double tx[3], ty[3];
@@ -630,18 +631,23 @@ __device__ __forceinline__ void swe_source_terms(const SweStageArgs &p, int k, s
             tx[i] = swe_ld(swe_rsrc(p.wind), k8, i*S8);
             ty[i] = swe_ld(swe_rsrc(p.wind + 3*S), k8, i*S8);
         }
+        const double txs = tx[0] + tx[1] + tx[2], tys = ty[0] + ty[1] + ty[2], Hs = H[0] + H[1] + H[2];
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const double aa = q < 3 ? a1 : a2, bb = q < 3 ? b1 : b2, ww = q < 3 ? w1 : w2;
-            double l[3] = {aa, aa, aa};
-            l[q % 3] = bb;
-            const double Hq = fma(l[2], H[2], fma(l[1], H[1], l[0]*H[0]));
-            const double s = ww*A/(Hq*1000.0);
-            const double wx = s*fma(l[2], tx[2], fma(l[1], tx[1], l[0]*tx[0])), wy = s*fma(l[2], ty[2], fma(l[1], ty[1], l[0]*ty[0]));
+        for (int o = 0; o < 2; o++) {
+            const double aa = o ? a2 : a1, dd = o ? b2 - a2 : b1 - a1, wA = (o ? w2 : w1)*A*(1.0/1000.0);
+            const double ax = aa*txs, ay = aa*tys, aH = aa*Hs;
+            double wx[3], wy[3];
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                bu[i] = fma(wx, l[i], bu[i]);
-                bv[i] = fma(wy, l[i], bv[i]);
+                const double s = wA*swe_rcp(fma(dd, H[i], aH));
+                wx[i] = s*fma(dd, tx[i], ax);
+                wy[i] = s*fma(dd, ty[i], ay);
+            }
+            const double aSx = aa*(wx[0] + wx[1] + wx[2]), aSy = aa*(wy[0] + wy[1] + wy[2]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                bu[i] += fma(dd, wx[i], aSx);
+                bv[i] += fma(dd, wy[i], aSy);
             }
         }
     }

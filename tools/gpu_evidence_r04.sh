@@ -2,7 +2,7 @@
 # closing evidence of round 4 with the library as committed: the whole GPU suite, the bench line, kernel-trace stats of the bench
 # command, PMC traffic of the stage kernel at 1 M cells, every row of tools/cfgbench.py, ranks of 8 / 4 / 2 on one GPU
 set -u
-O=gpurun_out/evidence_r04; mkdir -p $O
+O=gpurun_out/evidence_r04; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout 3000 python -m pytest tests -q -m gpu > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -3 $O/gpu_tests.log
