@@ -308,7 +308,8 @@ int  swe2d_debug_calibration_copy(swe2d_handle *h, int n_times);
  * see thetis_amd/partition.py.  send_cells: local ids of owned cells whose state peers need, grouped by peer;
  * recv_cells: local ids of the ghost cells in the order the peers' messages deliver them.  Buffers are device pointers
  * owned by the caller (cell-major: 3k doubles u0..u(k-1) v0.. e0.. per cell, [n][3k], k = nodes_per_cell, so per-peer
- * segments are contiguous).  i_buffer selects the state buffer (0 = the step result / stage-1 input). */
+ * segments are contiguous).  i_buffer selects the state buffer (0 = the step result / stage-1 input).  On a handle without ghost
+ * cells (n_owned = n_cells) recv_cells may name any cell: pack + unpack then copy between cells of the same mesh. */
 int  swe2d_halo_setup(swe2d_handle *h, int32_t n_send, const int32_t *send_cells, int32_t n_recv, const int32_t *recv_cells);
 int  swe2d_halo_pack(swe2d_handle *h, int i_buffer, double *send_buf_dev);
 int  swe2d_halo_unpack(swe2d_handle *h, int i_buffer, const double *recv_buf_dev);

@@ -434,7 +434,7 @@ def test_boundary_inline_variant_gives_the_bits_of_the_epilogue_variant(hip_lib,
 
 
 def test_stage_kernel_variants_agree_bitwise_on_a_large_launch(hip_lib):
-    """The host picks the stage-kernel variant by launch size (LDS exchange from 3 M cells up), so a partition and the
+    """The host picks the stage-kernel variant by launch size (LDS exchange once the state exceeds the Infinity Cache, 1.24 M triangles), so a partition and the
     whole mesh of the bench run different variants: 200 k cells, 5 steps, every variant forced in turn."""
     import os
     from thetis_amd.device import Swe2dDevice

@@ -392,12 +392,15 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     // 1 M 117.9 -> 117.8); both give the same bits.  THETIS_AMD_BND_INLINE=0 selects the epilogue variant (parity test, A/B).
     const char *env_binl_s = std::getenv("THETIS_AMD_BND_INLINE");       // read per launch: tests switch it inside one process
     const bool binl = !(env_binl_s && std::atoi(env_binl_s) == 0);
-    // ... and for launches of three million cells or more (state beyond the Infinity Cache) with the in-wave neighbour traces
-    // exchanged through LDS (LDSX; THETIS_AMD_LDSX=0/1 forces the choice).  With the device's tile-Hilbert numbering, same box,
-    // us/step without / with: 250 k cells 37.9 / 42.2, 500 k 63.5 / 68.3, 1 M 115-118 / 118-119, 2 M 295-312 / 297-298,
-    // 4 M 573-583 / 544.  Same bits in every variant: the kernel has no implicit contraction.
+    // ... and for launches whose state no longer fits the Infinity Cache (three buffers of 24 B per node against 256 MB: beyond
+    // ~1.24 M triangles) with the in-wave neighbour traces exchanged through LDS (LDSX; THETIS_AMD_LDSX=0/1 forces the choice).
+    // With the device's tile-Hilbert numbering and the alternating direction below, same box, us/step without / with:
+    // 1 M cells 115-118 / 118-119, 1.25 M 166-168 / 162-163, 1.5 M 206-210 / 197-199, 2 M 288-294 / 275, 2.5 M 363-364 / 345-347,
+    // 3 M 420-428 / 394-398, 4 M 573-583 / 544 (profiles/r04w_ldsx_threshold.txt; rounds 2-3 took it from 3 M cells only).
+    // Same bits in every variant: the kernel has no implicit contraction.
+    const bool beyond_cache = (size_t)(c1 - c0)*h->npc*72 >= ((size_t)256 << 20);
     const char *env_ldsx_s = std::getenv("THETIS_AMD_LDSX");
-    const bool ldsx = env_ldsx_s ? std::atoi(env_ldsx_s) != 0 : (c1 - c0) >= 3000000;
+    const bool ldsx = env_ldsx_s ? std::atoi(env_ldsx_s) != 0 : beyond_cache;
     stage_kernel_t kern = fused_visc
         ? pick_kernel_visc(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
         : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4 ? (h->affine ? 1 : 2) : 0, binl)
@@ -414,7 +417,7 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     // 0.732).  THETIS_AMD_ALTERNATE=0/1 forces the choice.
     if (!fused_visc) {
         const char *env_alt = std::getenv("THETIS_AMD_ALTERNATE");
-        const bool alt = env_alt ? std::atoi(env_alt) != 0 : (size_t)(c1 - c0)*h->npc*72 >= ((size_t)256 << 20);
+        const bool alt = env_alt ? std::atoi(env_alt) != 0 : beyond_cache;
         if (alt) { a.reverse = h->launch_parity; h->launch_parity ^= 1; }
     }
     SWE_CHK_SYNC(h->stream);
@@ -1694,8 +1697,10 @@ int swe2d_halo_setup(swe2d_handle *hh, int32_t n_send, const int32_t *send_cells
     for (int i = 0; i < n_send; i++)
         if (send_cells[i] < 0 || send_cells[i] >= h->n_owned)
             return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "send cell is not an owned cell");
+    // (a handle WITHOUT ghost cells may copy between its own cells: chunks of one mesh that carry copies of their neighbours' rim,
+    // tools/chunkbench.py)
     for (int i = 0; i < n_recv; i++)
-        if (recv_cells[i] < h->n_owned || recv_cells[i] >= h->n_cells)
+        if (recv_cells[i] < (h->n_owned < h->n_cells ? h->n_owned : 0) || recv_cells[i] >= h->n_cells)
             return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "receive cell is not a ghost cell");
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->send_cells) { HIP_TRY(h, hipFree(h->send_cells)); h->send_cells = nullptr; }
