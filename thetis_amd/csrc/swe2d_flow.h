@@ -227,37 +227,9 @@ __device__ __forceinline__ void swe_flow_rhs(const SweStageArgs &p, int k, const
         const double nxs = nx[f], nys = ny[f];
         double Lf, rLf;
         swe_sqrt_rsqrt(swe_dot2(nxs, nxs, nys, nys), Lf, rLf);
-        double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
-            const double uq = swe_dot2(xa, u[a], xb, u[b]), vq = swe_dot2(xa, v[a], xb, v[b]), eq = swe_dot2(xa, e[a], xb, e[b]);
-            const double hq = swe_dot2(xa, h[a], xb, h[b]);
-            const double un = swe_dot2(xa, una, xb, unb), vn = swe_dot2(xa, vna, xb, vnb), en = swe_dot2(xa, ena, xb, enb);
-            const double eav = 0.5*(eq + en);
-            const double Hav = NONLIN ? hq + eav : hq;
-            const double c = swe_sqrt(g*Hav);
-            const double du = uq - un, dv = vq - vn;
-            const double dun = swe_dot2(du, nxs, dv, nys);
-            const double spg = fma(c*dun, rLf, g*eav);
-            double fu = spg*nxs, fv = spg*nys;
-            const double uav = 0.5*(uq + un), vav = 0.5*(vq + vn);
-            const double uavn = swe_dot2(uav, nxs, vav, nys);
-            const double fe = fma(c*(eq - en), Lf, Hav*uavn);
-            if (NONLIN) {
-                const double unown = swe_dot2(uq, nxs, vq, nys);
-                fu = fma(uav, unown, fu);
-                fv = fma(vav, unown, fv);
-                if (LF) {
-                    const double gam = 0.5*fabs(uavn)*p.sigma_lf;
-                    fu = fma(gam, du, fu);
-                    fv = fma(gam, dv, fv);
-                }
-            }
-            Fau = fma(xa, fu, Fau); Fbu = fma(xb, fu, Fbu);
-            Fav = fma(xa, fv, Fav); Fbv = fma(xb, fv, Fbv);
-            Fae = fma(xa, fe, Fae); Fbe = fma(xb, fe, Fbe);
-        }
+        double Fau, Fbu, Fav, Fbv, Fae, Fbe;
+        swe_facet_flux<NONLIN, LF, false>(g, p.sigma_lf, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], 0.0, 0.0, una, unb, vna, vnb, ena, enb,
+                                          0.0, 0.0, nxs, nys, Lf, rLf, Fau, Fbu, Fav, Fbv, Fae, Fbe);
         if (bnd) { Fau = 0.0; Fbu = 0.0; Fav = 0.0; Fbv = 0.0; Fae = 0.0; Fbe = 0.0; }
         bu[a] = fma(-0.5, Fau, bu[a]); bu[b] = fma(-0.5, Fbu, bu[b]);
         bv[a] = fma(-0.5, Fav, bv[a]); bv[b] = fma(-0.5, Fbv, bv[b]);

@@ -264,6 +264,67 @@ __device__ __forceinline__ double swe_int2(const double a[3], const double b[3])
     return fma(a[2], b[2], fma(a[1], b[1], fma(a[0], b[0], (a[0] + a[1] + a[2])*(b[0] + b[1] + b[2]))));
 }
 
+// A P1 trace (A at the facet's first node, B at its second) at the two Gauss points: the first lies SWE_XI0 from A, the second
+// SWE_XI0 from B.  One difference and two fmas for the pair (xa*A + xb*B per point takes four).
+__device__ __forceinline__ void swe_gl2(double A, double B, double &p0, double &p1)
+{
+    const double D = B - A;
+    p0 = fma(SWE_XI0, D, A);
+    p1 = fma(-SWE_XI0, D, B);
+}
+
+// The numerical fluxes of ONE interior facet seen from this cell, integrated against the facet's two nodal basis functions with the
+// two-point rule (shallowwater_eq.py:360-366, :421-427, :480-488): shared by the stage kernels and the dataflow kernel
+// (swe2d_flow.h), which must give the same bits.  (.)a / (.)b: this cell's values at the facet's nodes, (.)na / (.)nb: the
+// neighbour's on the same nodes; Ha, Hb, Dna, Dnb: nodal total depths of both sides (wetting-drying only); nxs, nys = |F| n, L = |F|.
+// The jump and the average come from one interpolation each: [u] = u - u_n, {u} = u - [u]/2.
+template <bool NONLIN, bool LF, bool WD>
+__device__ __forceinline__ void swe_facet_flux(double g, double sigma_lf, double ua, double ub, double va, double vb, double ea, double eb,
+                                               double ha, double hb, double Ha, double Hb, double una, double unb, double vna, double vnb,
+                                               double ena, double enb, double Dna, double Dnb, double nxs, double nys, double L, double rL,
+                                               double &Fau, double &Fbu, double &Fav, double &Fbv, double &Fae, double &Fbe)
+{
+#pragma clang fp contract(off)
+    double uq[2], vq[2], eq[2], hq[2], un[2], vn[2], en[2], Hs[2] = {0.0, 0.0};
+    swe_gl2(ua, ub, uq[0], uq[1]);
+    swe_gl2(va, vb, vq[0], vq[1]);
+    swe_gl2(ea, eb, eq[0], eq[1]);
+    swe_gl2(una, unb, un[0], un[1]);
+    swe_gl2(vna, vnb, vn[0], vn[1]);
+    swe_gl2(ena, enb, en[0], en[1]);
+    if (WD) swe_gl2(0.5*(Ha + Dna), 0.5*(Hb + Dnb), Hs[0], Hs[1]);      // {H} of the nodal displaced depths
+    else swe_gl2(ha, hb, hq[0], hq[1]);
+    Fau = 0.0; Fbu = 0.0; Fav = 0.0; Fbv = 0.0; Fae = 0.0; Fbe = 0.0;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+        const double de = eq[q] - en[q];
+        const double eav = fma(-0.5, de, eq[q]);
+        const double Hav = WD ? Hs[q] : (NONLIN ? hq[q] + eav : hq[q]);
+        const double c = swe_sqrt(g*Hav);
+        const double du = uq[q] - un[q], dv = vq[q] - vn[q];
+        const double dun = swe_dot2(du, nxs, dv, nys);            // |F| jump(u.n)
+        const double spg = fma(c*dun, rL, g*eav);                 // g*head_star            :363
+        double fu = spg*nxs, fv = spg*nys;                        //                        :366
+        const double uav = fma(-0.5, du, uq[q]), vav = fma(-0.5, dv, vq[q]);
+        const double uavn = swe_dot2(uav, nxs, vav, nys);         // |F| {u}.n
+        const double fe = fma(c*de, L, Hav*uavn);                 // {H}({u}+sqrt(g/{H})[eta n]).n  :424-427
+        if (NONLIN) {
+            const double unown = swe_dot2(uq[q], nxs, vq[q], nys);
+            fu = fma(uav, unown, fu);                             //                        :483
+            fv = fma(vav, unown, fv);
+            if (LF) {
+                const double gam = 0.5*fabs(uavn)*sigma_lf;       //                        :487
+                fu = fma(gam, du, fu);                            //                        :488
+                fv = fma(gam, dv, fv);
+            }
+        }
+        Fau = fma(xa, fu, Fau); Fbu = fma(xb, fu, Fbu);
+        Fav = fma(xa, fv, Fav); Fbv = fma(xb, fv, Fbv);
+        Fae = fma(xa, fe, Fae); Fbe = fma(xb, fe, Fbe);
+    }
+}
+
 // Boundary facet (closed wall or open boundary); rare, so written for clarity with unit normals.
 // Returns the form values f (residual is -f) already multiplied by the facet length.
 struct SweBcFieldValues { double elev, u, v, un, flux; };   // Function-valued boundary data at the quadrature point
@@ -1129,37 +1190,8 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
             // neighbour's nodal depth on this facet (bathymetry and alpha are continuous: same vertices)
             const double Dna = WD ? swe_wd_depth(h[a] + ena[f], al[a]) : 0.0;
             const double Dnb = WD ? swe_wd_depth(h[b] + enb[f], al[b]) : 0.0;
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
-                const double uq = swe_dot2(xa, u[a], xb, u[b]), vq = swe_dot2(xa, v[a], xb, v[b]), eq = swe_dot2(xa, e[a], xb, e[b]);
-                const double hq = swe_dot2(xa, h[a], xb, h[b]);
-                const double un = swe_dot2(xa, una[f], xb, unb[f]), vn = swe_dot2(xa, vna[f], xb, vnb[f]),
-                             en = swe_dot2(xa, ena[f], xb, enb[f]);
-                const double eav = 0.5*(eq + en);
-                const double Hav = WD ? 0.5*(swe_dot2(xa, H[a], xb, H[b]) + swe_dot2(xa, Dna, xb, Dnb)) : (NONLIN ? hq + eav : hq);
-                const double c = swe_sqrt(g*Hav);
-                const double du = uq - un, dv = vq - vn;
-                const double dun = swe_dot2(du, nxs, dv, nys);            // |F| jump(u.n)
-                const double spg = fma(c*dun, rL, g*eav);                 // g*head_star            :363
-                double fu = spg*nxs, fv = spg*nys;                        //                        :366
-                const double uav = 0.5*(uq + un), vav = 0.5*(vq + vn);
-                const double uavn = swe_dot2(uav, nxs, vav, nys);         // |F| {u}.n
-                const double fe = fma(c*(eq - en), L, Hav*uavn);          // {H}({u}+sqrt(g/{H})[eta n]).n  :424-427
-                if (NONLIN) {
-                    const double unown = swe_dot2(uq, nxs, vq, nys);
-                    fu = fma(uav, unown, fu);                             //                        :483
-                    fv = fma(vav, unown, fv);
-                    if (LF) {
-                        const double gam = 0.5*fabs(uavn)*p.sigma_lf;     //                        :487
-                        fu = fma(gam, du, fu);                            //                        :488
-                        fv = fma(gam, dv, fv);
-                    }
-                }
-                Fau = fma(xa, fu, Fau); Fbu = fma(xb, fu, Fbu);
-                Fav = fma(xa, fv, Fav); Fbv = fma(xb, fv, Fbv);
-                Fae = fma(xa, fe, Fae); Fbe = fma(xb, fe, Fbe);
-            }
+            swe_facet_flux<NONLIN, LF, WD>(g, p.sigma_lf, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b], una[f], unb[f],
+                                           vna[f], vnb[f], ena[f], enb[f], Dna, Dnb, nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
         }
         if (nb[f] < 0) { Fau = 0.0; Fbu = 0.0; Fav = 0.0; Fbv = 0.0; Fae = 0.0; Fbe = 0.0; }   // see swe_boundary_epilogue / BINL
         bu[a] = fma(-0.5, Fau, bu[a]); bu[b] = fma(-0.5, Fbu, bu[b]);
