@@ -130,13 +130,21 @@ __device__ __forceinline__ void swe_sqrt_rsqrt(double x, double &s, double &rs)
 #endif
 }
 
-// sqrt(x) for x >= 0 (x == 0 -> 0; x < 0 -> NaN, like sqrt)
+// sqrt(x) for x >= 0 (x == 0 -> 0; x < 0 -> NaN, like sqrt).  The seed is taken at x + 1e-300 (= x for every x >= 1e-283; below,
+// the corrections still converge): v_rsq_f64 then gives a finite number at 0, which the sequence carries to g = 0 exactly, and NaN
+// for negative x as before - one addition instead of a compare and two selects on the result.
 __device__ __forceinline__ double swe_sqrt(double x)
 {
 #if SWE_FAST_SQRT
-    double s, rs;
-    swe_sqrt_rsqrt(x, s, rs);
-    return x == 0.0 ? 0.0 : s;
+    const double y = __builtin_amdgcn_rsq(x + 1e-300);
+    double g = x*y, h = 0.5*y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d0 = fma(-g, g, x);
+    g = fma(d0, h, g);
+    const double d1 = fma(-g, g, x);
+    return fma(d1, h, g);
 #else
     return sqrt(x);
 #endif
