@@ -2160,37 +2160,8 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
             // neighbour's nodal depth on this facet (bathymetry and alpha are continuous: same vertices)
             const double Dna = WD ? swe_wd_depth(h[a] + ena[f], al[a]) : 0.0;
             const double Dnb = WD ? swe_wd_depth(h[b] + enb[f], al[b]) : 0.0;
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
-                const double uq = swe_dot2(xa, u[a], xb, u[b]), vq = swe_dot2(xa, v[a], xb, v[b]), eq = swe_dot2(xa, e[a], xb, e[b]);
-                const double hq = swe_dot2(xa, h[a], xb, h[b]);
-                const double un = swe_dot2(xa, una[f], xb, unb[f]), vn = swe_dot2(xa, vna[f], xb, vnb[f]),
-                             en = swe_dot2(xa, ena[f], xb, enb[f]);
-                const double eav = 0.5*(eq + en);
-                const double Hav = WD ? 0.5*(swe_dot2(xa, H[a], xb, H[b]) + swe_dot2(xa, Dna, xb, Dnb)) : (NONLIN ? hq + eav : hq);
-                const double c = swe_sqrt(g*Hav);
-                const double du = uq - un, dv = vq - vn;
-                const double dun = swe_dot2(du, nxs, dv, nys);
-                const double spg = fma(c*dun, rL, g*eav);
-                double fu = spg*nxs, fv = spg*nys;
-                const double uav = 0.5*(uq + un), vav = 0.5*(vq + vn);
-                const double uavn = swe_dot2(uav, nxs, vav, nys);
-                const double fe = fma(c*(eq - en), L, Hav*uavn);
-                if (NONLIN) {
-                    const double unown = swe_dot2(uq, nxs, vq, nys);
-                    fu = fma(uav, unown, fu);
-                    fv = fma(vav, unown, fv);
-                    if (LF) {
-                        const double gam = 0.5*fabs(uavn)*p.sigma_lf;
-                        fu = fma(gam, du, fu);
-                        fv = fma(gam, dv, fv);
-                    }
-                }
-                Fau = fma(xa, fu, Fau); Fbu = fma(xb, fu, Fbu);
-                Fav = fma(xa, fv, Fav); Fbv = fma(xb, fv, Fbv);
-                Fae = fma(xa, fe, Fae); Fbe = fma(xb, fe, Fbe);
-            }
+            swe_facet_flux<NONLIN, LF, WD>(g, p.sigma_lf, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b], una[f], unb[f],
+                                           vna[f], vnb[f], ena[f], enb[f], Dna, Dnb, nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
         }
         if (nb[f] < 0) {
             // boundary facets inline: this kernel runs at 2 waves/SIMD either way, and the post-compute epilogue of the
