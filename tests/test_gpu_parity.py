@@ -195,6 +195,34 @@ def test_full_size_properties(hip_lib):
     dev.close()
 
 
+@pytest.mark.parametrize('cells', ['triangles', 'quadrilaterals'])
+@pytest.mark.parametrize('wd', [False, True])
+def test_lake_at_rest_with_manning_friction_has_no_tendency(hip_lib, cells, wd):
+    """|u| = 0 exactly at every quadrature point of the Manning term (shallowwater_eq.py:685-700): the square root of the velocity
+    magnitude is taken through a clamped reciprocal square root, H^(-1/3) through a float seed - the drag must still vanish
+    identically and the lake stay at rest (no NaN from 0 * rsq(0)), with and without the displaced depth of wetting-drying."""
+    from helpers import quad_case
+    from thetis_amd import _lib
+    from thetis_amd.device import Swe2dDevice
+    if cells == 'quadrilaterals':
+        mesh, bath = quad_case(nx=24, ny=11, seed=3, skew=0.2)[:2]
+    else:
+        mesh, bath = channel_case(nx=31, ny=13, seed=3)[:2]
+    n, k = mesh.cells.shape
+    dev = Swe2dDevice(mesh, bath, 2.0, boundary_len=mesh.boundary_len)
+    dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+    if wd:
+        dev.set_wetting_and_drying(0.4)
+    dev.set_state(np.zeros((n, k, 2)), np.full((n, k), 0.25))
+    ku, ke = dev.tendency()
+    assert np.isfinite(ku).all() and np.isfinite(ke).all()
+    assert np.abs(ku).max() < 1e-13*9.81*20 and np.abs(ke).max() == 0.0
+    dev.advance(3)
+    uv, eta = dev.get_state()
+    assert np.abs(uv).max() < 1e-12 and np.abs(eta - 0.25).max() < 1e-12
+    dev.close()
+
+
 @pytest.mark.parametrize('quad', [False, True])
 def test_function_valued_boundary_data(hip_lib, quad):
     """Spatially varying external elevation / velocity / normal velocity (Function-valued bnd_functions entries)."""
