@@ -243,7 +243,7 @@ def main():
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 or world > 1 or os.environ.get('THETIS_AMD_FORCE_DIST'):   # env: exercise the N>1 code path on one GPU
-        from thetis_amd.distributed import run_distributed_bench
+        from tools.benchlib import run_distributed_bench
         case = build_case
         if os.environ.get('THETIS_AMD_BENCH_MESH'):       # tests: "nx,ny" - many ranks sharing the one GPU of a test box
             nx, ny = (int(v) for v in os.environ['THETIS_AMD_BENCH_MESH'].split(','))

@@ -68,6 +68,16 @@ def test_a_transport_that_cannot_be_set_up_is_left_by_all_ranks_together(tmp_pat
     _check(single, ranks, exact_callbacks=True)
 
 
+def test_a_rank_whose_handle_cannot_be_built_takes_its_peers_out_of_the_handshake(tmp_path, tmp_path_factory, hip_lib):
+    """rank 1 fails BEFORE the peer-to-peer handshake (its first handle cannot be built); it still enters the
+    handshake's all-gather with its error, every rank leaves it with the same exception, agrees on the failure and the run goes
+    through host memory - nobody is left waiting in a mismatched collective until the gloo timeout.  Same bits."""
+    single = single_rank('forced', tmp_path_factory, cpu=False)
+    ranks = run_spmd(3, str(tmp_path), 'forced', cpu=False, env={'THETIS_AMD_TEST_FAIL_HANDLE_RANK': '1'}, timeout=240)
+    assert [r['exchange'] for r in ranks] == ['host']*3
+    _check(single, ranks, exact_callbacks=True)
+
+
 def _script(args, world, port):
     e = dict(os.environ)
     e['THETIS_AMD_DIST_BACKEND'] = 'gloo'            # the ranks share the one GPU of the test box: RCCL would refuse them

@@ -1,33 +1,99 @@
-"""Builds thetis_amd/libswe2d_hip.so (gfx950) in-tree with hipcc.  Cross-compiles without a GPU."""
+"""Builds thetis_amd/libswe2d_hip.so (gfx950) in-tree with hipcc.  Cross-compiles without a GPU.
+
+The library is several translation units (csrc/swe2d_api*.hip: the C ABI by concern; csrc/swe2d_k_*.hip: one kernel family
+each - the template instantiations are what takes the time).  Objects are compiled in parallel and only when a file they include
+changed (hipcc -MD dependency files), so a kernel edit rebuilds the families that see it and nothing else.
+
+``build(unity=True, defines=[...], lib=...)`` compiles csrc/swe2d_unity.hip instead - every unit in one, for the debug variants
+whose device-side globals all kernels must share (-DSWE_RANGE_CHECK, -DSWE_FLOW_DELAY, -DSWE_WAVE_TIMING)."""
+import concurrent.futures
+import glob
 import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(_HERE, 'csrc', 'swe2d_api.hip')
-import glob
-# every header the translation unit can include: editing any of them must trigger a rebuild
-DEPS = [SRC] + sorted(glob.glob(os.path.join(_HERE, 'csrc', '*.h'))) + [os.path.join(_HERE, '..', 'include', 'swe2d.h')]
+CSRC = os.path.join(_HERE, 'csrc')
+UNITS = ['swe2d_api.hip', 'swe2d_api_flow.hip', 'swe2d_api_tracer.hip', 'swe2d_api_p2p.hip',
+         'swe2d_k_tri.hip', 'swe2d_k_wd.hip', 'swe2d_k_quad.hip', 'swe2d_k_flow.hip', 'swe2d_k_tracer.hip']
+UNITY = os.path.join(CSRC, 'swe2d_unity.hip')
+OBJ_DIR = os.path.join(CSRC, '.obj')
 LIB = os.path.join(_HERE, 'libswe2d_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+# every file a translation unit can include (the fallback when an object has no dependency file yet)
+ALL_DEPS = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(_HERE, '..', 'include', 'swe2d.h')]
+
+
+def _obj(unit):
+    return os.path.join(OBJ_DIR, unit[:-4] + '.o')
+
+
+def _deps(unit):
+    """Files the object of `unit` was built from, by the compiler's own dependency file."""
+    d = _obj(unit)[:-2] + '.d'
+    if not os.path.exists(d):
+        return None
+    text = open(d).read().replace('\\\n', ' ')
+    out = []
+    for part in text.split(':', 1)[1].split():
+        if part.startswith('/opt/rocm') or part.startswith('/usr/'):
+            continue
+        out.append(part)
+    return out
+
+
+def _stale(unit):
+    o = _obj(unit)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    deps = _deps(unit)
+    if deps is None:
+        deps = [os.path.join(CSRC, unit)] + ALL_DEPS
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
 
 
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    if any(os.path.getmtime(os.path.join(CSRC, u)) > t for u in UNITS) or any(os.path.getmtime(d) > t for d in ALL_DEPS):
+        return True
+    return False
 
 
-def build(force=False, verbose=False):
+def _compile(unit, verbose):
+    cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, unit), '-o', _obj(unit), '-MD', '-MF', _obj(unit)[:-2] + '.d']
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build(force=False, verbose=False, unity=False, defines=(), lib=None, jobs=None):
     """Compile the HIP extension; returns the path of the shared library."""
-    if force or needs_build():
-        cmd = [HIPCC] + FLAGS + [SRC, '-o', LIB]
+    if unity:
+        out = lib or LIB
+        cmd = [HIPCC] + FLAGS + ['-shared'] + ['-D' + d for d in defines] + [UNITY, '-o', out]
         if verbose:
-            print(' '.join(cmd))
+            print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+        return out
+    if not (force or needs_build()):
+        return LIB
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    todo = [u for u in UNITS if force or _stale(u)]
+    jobs = jobs or int(os.environ.get('THETIS_AMD_BUILD_JOBS', '0')) or min(len(UNITS), os.cpu_count() or 1)
+    if todo:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+            for f in [ex.submit(_compile, u, verbose) for u in todo]:
+                f.result()
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + [_obj(u) for u in UNITS] + ['-o', LIB]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
     return LIB
 
 
 if __name__ == '__main__':
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -37,7 +37,7 @@
 // read with sc1 loads; the XCD-chunked block map (swe_logical_block) is used for speed only.
 //
 // Deadlock freedom needs every block of the launch resident: the host launches this kernel only when the grid fits the
-// occupancy the runtime reports (swe2d_api.hip: flow_capacity), and every spin is bounded by the wall clock - a timeout is
+// occupancy the runtime reports (swe2d_api_flow.hip: flow_capacity), and every spin is bounded by the wall clock - a timeout is
 // counted in the status word, the wave carries on (the result is then wrong and the host reports SWE2D_ERR_HIP at the next
 // synchronisation point), it never hangs the device.
 //
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 
 // Receives a pending push (pushes > receives) outside a flow launch: the ghost cells' granules into the state planes.  For the
 // end of an advance - the next FX launch would do it itself, but the state may leave the device or other kernels may run first.
-__global__ __launch_bounds__(256) void swe_flow_unpack_kernel(double *planes, size_t stride, const int *recv_cells, int n_recv,
+static __global__ __launch_bounds__(256) void swe_flow_unpack_kernel(double *planes, size_t stride, const int *recv_cells, int n_recv,
                                                               void *zone, unsigned zbytes, unsigned slot, SweP2pCounters *ctr,
                                                               unsigned *status, unsigned long long timeout_ticks)
 {

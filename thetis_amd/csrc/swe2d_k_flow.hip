@@ -1,0 +1,22 @@
+// swe2d_k_flow.hip - the dataflow stage loop (swe2d_flow.h): instantiations + picker
+#include "swe2d_kernels.h"
+#include "swe2d_flow.h"
+#include "swe2d_pick.h"
+
+template <bool NL, bool LF, int POLL>
+flow_kernel_t pick_flow_src(bool src, bool fx)
+{
+    if (fx) return src ? swe_flow_kernel<NL, LF, true, true, POLL> : swe_flow_kernel<NL, LF, false, true, POLL>;
+    return src ? swe_flow_kernel<NL, LF, true, false, POLL> : swe_flow_kernel<NL, LF, false, false, POLL>;
+}
+template <int POLL>
+flow_kernel_t pick_flow_poll(bool nl, bool lf, bool src, bool fx)
+{
+    return nl ? (lf ? pick_flow_src<true, true, POLL>(src, fx) : pick_flow_src<true, false, POLL>(src, fx))
+              : (lf ? pick_flow_src<false, true, POLL>(src, fx) : pick_flow_src<false, false, POLL>(src, fx));
+}
+// wide: some block of the flow order has more than 64 rim facets (one more granule load per lane and polling trip)
+flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src, bool fx, bool wide)
+{
+    return wide ? pick_flow_poll<9>(nl, lf, src, fx) : pick_flow_poll<8>(nl, lf, src, fx);
+}

@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
 
 // ---------------------------------------------------------------------------------------------------------------
 // layout conversion: host (Firedrake-like) AoS  uv[kN][2], eta[kN]  <->  3k SoA planes (k = nodes per cell)
-__global__ void swe_aos_to_planes(const double *uv, const double *eta, double *planes, size_t stride, int n, int npc)
+static __global__ void swe_aos_to_planes(const double *uv, const double *eta, double *planes, size_t stride, int n, int npc)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -1295,7 +1295,7 @@ __global__ void swe_aos_to_planes(const double *uv, const double *eta, double *p
     }
 }
 
-__global__ void swe_planes_to_aos(const double *planes, double *uv, double *eta, size_t stride, int n, int npc)
+static __global__ void swe_planes_to_aos(const double *planes, double *uv, double *eta, size_t stride, int n, int npc)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -1307,7 +1307,7 @@ __global__ void swe_planes_to_aos(const double *planes, double *uv, double *eta,
 }
 
 // nodal scalar field (kN) -> k planes;  vector (kN,2) -> 2k planes (x0.. y0..)
-__global__ void swe_nodal_to_planes(const double *nodal, double *planes, size_t stride, int n, int ncomp, int npc)
+static __global__ void swe_nodal_to_planes(const double *nodal, double *planes, size_t stride, int n, int ncomp, int npc)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -1318,7 +1318,7 @@ __global__ void swe_nodal_to_planes(const double *nodal, double *planes, size_t 
 
 // continuous P1 coefficient given per VERTEX -> nodal planes (the CG -> DG injection done on the device: a time-dependent
 // wind / pressure field costs one value per vertex over PCIe instead of one per DG node plus a host-side gather)
-__global__ void swe_vertex_to_planes(const double *vert, double *planes, size_t stride, const int *cv, int n, int ncomp, int npc)
+static __global__ void swe_vertex_to_planes(const double *vert, double *planes, size_t stride, const int *cv, int n, int ncomp, int npc)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -1330,7 +1330,7 @@ __global__ void swe_vertex_to_planes(const double *vert, double *planes, size_t 
 
 // Function-valued boundary data of ONE marker: copy the two end-node values of every boundary facet carrying `marker` from a
 // nodal field in host layout into the per-facet planes (plane 2f: node f, plane 2f+1: node f+1; component c: + 2*npc*c)
-__global__ void swe_bc_field_scatter(const double *nodal, double *planes, size_t stride, const int *nbr, int n, int ncomp,
+static __global__ void swe_bc_field_scatter(const double *nodal, double *planes, size_t stride, const int *nbr, int n, int ncomp,
                                      int npc, int marker)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
@@ -1348,7 +1348,7 @@ __global__ void swe_bc_field_scatter(const double *nodal, double *planes, size_t
 // The same from a COMPACT list: entry t = boundary facet `facet[t]` of cell `cell[t]` with `nval` values per component
 // (2 = the facet's end nodes -> planes 2f, 2f+1 of component c at + 2*npc*c; npc = all nodes of the cell -> planes npc*f + i).
 // What a time-dependent boundary Function costs per update: a few KB over PCIe instead of the whole nodal field.
-__global__ void swe_bc_facet_scatter(const double *vals, double *planes, size_t stride, const int *cell, const int *facet, int n,
+static __global__ void swe_bc_facet_scatter(const double *vals, double *planes, size_t stride, const int *cell, const int *facet, int n,
                                      int ncomp, int npc, int nval)
 {
     const int t = blockIdx.x*blockDim.x + threadIdx.x;
@@ -1363,7 +1363,7 @@ __global__ void swe_bc_facet_scatter(const double *vals, double *planes, size_t 
 
 // Function-valued tracer boundary value of ONE marker: all npc nodal values of the cell are kept per boundary facet (the
 // diffusive boundary term needs the cell gradient of the external value, tracer_eq_2d.py:270-276): plane npc*f + i
-__global__ void swe_bc_cellfield_scatter(const double *nodal, double *planes, size_t stride, const int *nbr, int n, int npc,
+static __global__ void swe_bc_cellfield_scatter(const double *nodal, double *planes, size_t stride, const int *nbr, int n, int npc,
                                          int marker)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
@@ -1375,7 +1375,7 @@ __global__ void swe_bc_cellfield_scatter(const double *nodal, double *planes, si
 }
 
 // halo: message layout [n][np] (cell-major, np = 3k planes), so the per-peer segments of one buffer are contiguous
-__global__ void swe_halo_pack(const double *planes, size_t stride, const int *cells, int n, double *buf, int np)
+static __global__ void swe_halo_pack(const double *planes, size_t stride, const int *cells, int n, double *buf, int np)
 {
     const int t = blockIdx.x*blockDim.x + threadIdx.x;
     if (t >= np*n) return;
@@ -1383,7 +1383,7 @@ __global__ void swe_halo_pack(const double *planes, size_t stride, const int *ce
     buf[t] = planes[(size_t)q*stride + cells[j]];
 }
 
-__global__ void swe_halo_unpack(double *planes, size_t stride, const int *cells, int n, const double *buf, int np)
+static __global__ void swe_halo_unpack(double *planes, size_t stride, const int *cells, int n, const double *buf, int np)
 {
     const int t = blockIdx.x*blockDim.x + threadIdx.x;
     if (t >= np*n) return;
@@ -1487,7 +1487,7 @@ __device__ __forceinline__ double swe_wave_max(double v)
 }
 
 // diagnostics: { int eta^2, int |u|^2, int (eta+h) } as limb sums in acc[12] (+ acc[12]: terms out of range), min(h+eta) per block
-__global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel(const double *planes, size_t stride, const int *cv,
+static __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel(const double *planes, size_t stride, const int *cv,
                                                              const double *vx, const double *vy, const double *vh,
                                                              int n, double *partial, const double *valpha,
                                                              unsigned long long *acc)
@@ -1846,7 +1846,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
 // ---- limiter, step 1: cell means (P0 projection of an affine P1 / Q1 field = mean of the nodal values)
 // (general quadrilaterals, cv != nullptr: the P0 projection is the mass-weighted mean, see swe_quad_mean_weights below)
 __device__ __forceinline__ void swe_quad_mean_weights(double d0, double d1, double d2, double w[4]);
-__global__ void swe_limiter_cell_mean(const double *t, size_t stride, int n, double *mean, int npc, const int *cv,
+static __global__ void swe_limiter_cell_mean(const double *t, size_t stride, int n, double *mean, int npc, const int *cv,
                                       const double *vx, const double *vy)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
@@ -1869,7 +1869,7 @@ __global__ void swe_limiter_cell_mean(const double *t, size_t stride, int n, dou
 
 // ---- limiter, step 2: per (topological) vertex min/max of the means of the cells around it (CSR gather: no atomics,
 // deterministic) + Thetis's boundary-facet means (limiter.py:109-145)
-__global__ void swe_limiter_vertex_bounds(const int *v2c_off, const int *v2c_cell, const int *vbf_off, const int *vbf_facet,
+static __global__ void swe_limiter_vertex_bounds(const int *v2c_off, const int *v2c_cell, const int *vbf_off, const int *vbf_facet,
                                           const double *mean, const double *t, size_t stride, int nv,
                                           double *qmin, double *qmax, int npc)
 {
@@ -1894,7 +1894,7 @@ __global__ void swe_limiter_vertex_bounds(const int *v2c_off, const int *v2c_cel
 
 // ---- limiter, step 3: per-cell scaling towards the mean
 // (``mean_in`` != nullptr, general quadrilaterals: the mass-weighted means of step 1 instead of the nodal average)
-__global__ void swe_limiter_apply(double *t, size_t stride, int n, const int *tv, const double *qmin, const double *qmax,
+static __global__ void swe_limiter_apply(double *t, size_t stride, int n, const int *tv, const double *qmin, const double *qmax,
                                   int npc, const double *mean_in)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
@@ -1917,7 +1917,7 @@ __global__ void swe_limiter_apply(double *t, size_t stride, int n, const int *tv
 }
 
 // ---- tracer diagnostics: per-block { int T*H dx, int T dx, min T, max T }
-__global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel(const double *t, const double *state, size_t stride,
+static __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel(const double *t, const double *state, size_t stride,
                                                                     const int *cv, const double *vx, const double *vy,
                                                                     const double *vh, int nonlinear, int n, double *partial,
                                                                     const double *valpha, unsigned long long *acc)
@@ -1948,7 +1948,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel(const double
 }
 
 // scalar nodal field (3N) <-> 3 planes
-__global__ void swe_planes_to_nodal(const double *planes, double *nodal, size_t stride, int n, int npc)
+static __global__ void swe_planes_to_nodal(const double *planes, double *nodal, size_t stride, int n, int npc)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -1957,7 +1957,7 @@ __global__ void swe_planes_to_nodal(const double *planes, double *nodal, size_t 
 
 // PMC calibration aid (MI355X_MICROARCH.md section HBM: "calibrate on a known byte count in your own access pattern"):
 // streams n doubles per plane with the same 8-B/lane coalesced loads and stores the stage kernel uses.
-__global__ __launch_bounds__(SWE_BLOCK) void swe_calibration_copy(const double *src, double *dst, size_t n)
+static __global__ __launch_bounds__(SWE_BLOCK) void swe_calibration_copy(const double *src, double *dst, size_t n)
 {
     const size_t i = (size_t)blockIdx.x*SWE_BLOCK + threadIdx.x;
     if (i < n) dst[i] = src[i];
@@ -2331,7 +2331,7 @@ __device__ __forceinline__ double swe_quad_form(const SweQuadMass &M, const doub
          + m[5]*(a[1]*b[2] + a[2]*b[1]) + m[6]*(a[1]*b[3] + a[3]*b[1]) + m[8]*(a[2]*b[3] + a[3]*b[2]);
 }
 
-__global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel_quad(const double *planes, size_t stride, const int *cv,
+static __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel_quad(const double *planes, size_t stride, const int *cv,
                                                                   const double *vx, const double *vy, const double *vh,
                                                                   int n, double *partial, const double *valpha, int affine,
                                                                   unsigned long long *acc)
@@ -2549,7 +2549,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
 }
 
 // tracer diagnostics on quadrilaterals
-__global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel_quad(const double *t, const double *state, size_t stride,
+static __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel_quad(const double *t, const double *state, size_t stride,
                                                                          const int *cv, const double *vx, const double *vy,
                                                                          const double *vh, int nonlinear, int n, double *partial,
                                                                          const double *valpha, int affine, unsigned long long *acc)

@@ -75,7 +75,7 @@ __device__ __forceinline__ double swe_p2p_load(const double *p)
 }
 
 // first-contact probe of a freshly mapped peer zone (swe2d_p2p_open): system-scope store + load of one word
-__global__ void swe_p2p_probe_kernel(unsigned long long *word, unsigned long long pattern, unsigned long long *out)
+static __global__ void swe_p2p_probe_kernel(unsigned long long *word, unsigned long long pattern, unsigned long long *out)
 {
     if (threadIdx.x == 0) {
         __hip_atomic_store(word, pattern, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -94,7 +94,7 @@ __device__ __forceinline__ int swe_p2p_peer_of(const SweP2pPushArgs &a, int j)
     return p;
 }
 
-__global__ __launch_bounds__(256) void swe_p2p_push_kernel(const SweP2pPushArgs a)
+static __global__ __launch_bounds__(256) void swe_p2p_push_kernel(const SweP2pPushArgs a)
 {
     const unsigned long long target = a.ctr->epoch_send + 1ull;      // every workgroup reads it before the last one advances it
     const int total = a.np*a.n_send, step = gridDim.x*256;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void swe_p2p_push_kernel(const SweP2pPushArgs 
     }
 }
 
-__global__ __launch_bounds__(256) void swe_p2p_unpack_kernel(const SweP2pUnpackArgs a)
+static __global__ __launch_bounds__(256) void swe_p2p_unpack_kernel(const SweP2pUnpackArgs a)
 {
     const unsigned long long target = a.ctr->epoch_recv + 1ull;
     if (threadIdx.x == 0) {

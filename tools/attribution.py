@@ -4,7 +4,7 @@ Static instruction attribution of one gfx950 kernel with inline stacks: which so
 owns how many VALU / SALU / LDS / memory instructions.
 
     cd /tmp
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -c -gline-tables-only $REPO/thetis_amd/csrc/swe2d_api.hip -o swe2d_dev.o
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -c -gline-tables-only $REPO/thetis_amd/csrc/swe2d_unity.hip -o swe2d_dev.o
     clang-offload-bundler --unbundle --type=o --input=swe2d_dev.o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=swe2d_gfx950.co
     python tools/attribution.py swe2d_gfx950.co <mangled kernel symbol> [--by callee|kline|innermost] [--regions file]
 

@@ -9,9 +9,9 @@ cd "$(dirname "$0")/.."
 if [ "${1:-}" = build ] || [ ! -f build_dbg/libswe2d_rangecheck.so ]; then
   mkdir -p build_dbg
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSWE_RANGE_CHECK \
-      thetis_amd/csrc/swe2d_api.hip -o build_dbg/libswe2d_rangecheck.so || exit 1
+      thetis_amd/csrc/swe2d_unity.hip -o build_dbg/libswe2d_rangecheck.so || exit 1
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSWE_FLOW_DELAY \
-      thetis_amd/csrc/swe2d_api.hip -o build_dbg/libswe2d_delay.so || exit 1
+      thetis_amd/csrc/swe2d_unity.hip -o build_dbg/libswe2d_delay.so || exit 1
   [ "${1:-}" = build ] && exit 0
 fi
 export THETIS_AMD_LIB=$PWD/build_dbg/libswe2d_rangecheck.so
@@ -20,7 +20,7 @@ THETIS_AMD_RANGE_SELFTEST=1 timeout 900 python tools/range_check.py | tail -1; e
 # the adversary of the granule protocol: the same library with -DSWE_FLOW_DELAY (no range checks: the timing is the point)
 if [ ! -f build_dbg/libswe2d_delay.so ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSWE_FLOW_DELAY \
-      thetis_amd/csrc/swe2d_api.hip -o build_dbg/libswe2d_delay.so || exit 1
+      thetis_amd/csrc/swe2d_unity.hip -o build_dbg/libswe2d_delay.so || exit 1
 fi
 THETIS_AMD_LIB=$PWD/build_dbg/libswe2d_delay.so timeout 1200 python -m pytest tests/test_gpu_flow_kernel.py tests/test_distributed.py -m gpu -q \
     -k "lags or lagging" 2>&1 | tail -5
