@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SWE2D_ABI_VERSION 8
+#define SWE2D_ABI_VERSION 9
 #define SWE2D_MAX_MARKERS 16          /* boundary markers must be in 1..SWE2D_MAX_MARKERS-1 */
 
 typedef enum {
@@ -386,6 +386,11 @@ int  swe2d_debug_flow_poke(swe2d_handle *h, int32_t block, int32_t delta);      
  * points of its stage loop; where = 1 before polling | 2 before publishing | 4 before an in-launch receive | 8 before an
  * in-launch push.  SWE2D_ERR_UNSUPPORTED in the product build. */
 int  swe2d_debug_flow_delay(swe2d_handle *h, int32_t block, int32_t where, int32_t microseconds, int32_t every_nth_stage);
+/* test hook of the -DSWE_FLOW_TEAR build (the adversary of the granules' check word, csrc/swe2d_flow.h): block `block` (-2: every
+ * block, -1: off) makes the granule stores of every n-th publish in two halves, the half with the new tag first and the value
+ * `microseconds` later; across_ranks: also the pushes into the peers' landing zones.  block = -3 asks whether the build's consumers
+ * test the check word (1; 0 in the -DSWE_FLOW_NOCHECK negative control).  SWE2D_ERR_UNSUPPORTED in the product build. */
+int  swe2d_debug_flow_tear(swe2d_handle *h, int32_t block, int32_t microseconds, int32_t every_nth_publish, int32_t across_ranks);
 /* run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the handle's own */
 int  swe2d_set_stream(swe2d_handle *h, void *hip_stream);
 

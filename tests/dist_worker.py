@@ -353,7 +353,7 @@ def viscosity_field(mesh):
 def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     global CASE
     flags = {}
-    for f in ('+capture', '+graph', '+p2p', '+nosplit', '+flowx', '+flow', '+delay', '+mix'):   # order-independent suffix flags
+    for f in ('+capture', '+graph', '+p2p', '+nosplit', '+flowx', '+flow', '+delay', '+mix', '+tear'):   # order-independent suffix flags
         flags[f] = f in case
         case = case.replace(f, '')
     graphed = flags['+graph']              # per-cycle HIP graphs (around the eager host-staged exchange, or incl. the p2p kernels)
@@ -383,6 +383,12 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
         rc = solver.dev.lib.swe2d_debug_flow_delay(solver.dev.h, 2 + rank, int(os.environ.get('FLOW_DELAY_WHERE', '15')), 15, 2)
         if rc != _lib.OK:
             raise RuntimeError('the loaded library is not the -DSWE_FLOW_DELAY build')
+    if flags['+tear']:
+        # -DSWE_FLOW_TEAR build: every block makes the granule stores of every second publish - and every push into a peer's landing
+        # zone - in two halves, the new tag 3 us ahead of the value it belongs to
+        rc = solver.dev.lib.swe2d_debug_flow_tear(solver.dev.h, -2, 3, 2, 1)
+        if rc != 0:
+            raise RuntimeError('the loaded library is not the -DSWE_FLOW_TEAR build')
     if flags['+mix']:
         # batches (flow launches with the exchange inside, or stage launches in graphs) alternating with time steps driven stage by
         # stage from the host, as FlowSolver2d does when some steps have forcing updates and others do not

@@ -341,4 +341,5 @@ def run(name, outdir, **kw):
     res['files'] = _file_digests(outdir)
     dev = solver_obj.timestepper.device if hasattr(solver_obj.timestepper, 'device') else None
     res['exchange'] = getattr(dev, 'exchange', None)
+    res['verify_report'] = getattr(getattr(dev, 'dist', None), 'verify_report', None)
     return res

@@ -603,6 +603,34 @@ def test_lagging_blocks_do_not_change_the_in_launch_exchange(tmp_path, hip_lib, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('world,case,n_steps', [(2, 'channel+every2+p2p+flowx+tear', 12), (3, 'channel+every1+p2p+flowx+tear', 9)])
+def test_torn_granules_do_not_change_the_in_launch_exchange(tmp_path, hip_lib, world, case, n_steps):
+    """Adversary for the granules that cross ranks (-DSWE_FLOW_TEAR build only; skipped with the product library): every rim publish
+    and every push into a peer's landing zone stores the half with the new tag 3 us before the value it belongs to.  With the check
+    word the receiving side re-polls: bitwise the single device.  (Negative control, -DSWE_FLOW_NOCHECK: must differ.)"""
+    from thetis_amd.device import Swe2dDevice
+    import dist_worker
+    dist_worker.CASE = 'channel'
+    mesh, bath, uv, eta = dist_worker._case()
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    rc = dev.lib.swe2d_debug_flow_tear(dev.h, -3, 0, 1, 0)
+    if rc < 0:
+        dev.close()
+        pytest.skip('needs the -DSWE_FLOW_TEAR build (tools/range_check.sh)')
+    run_workers(gpu_worker, world, n_steps, str(tmp_path), axis=0, case=case)
+    u_p, e_p, extra = gather(str(tmp_path), world, mesh.num_cells)
+    dev.set_state(uv, eta)
+    dev.lib.swe2d_debug_flow_tear(dev.h, -1, 0, 1, 0)
+    for _ in range(n_steps):
+        for i in range(3):
+            dev.solve_stage(i)
+    u_s, e_s = dev.get_state()
+    dev.close()
+    same = np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+    assert same if rc == 1 else not same
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('world,case,n_steps', [(2, 'channel+every4+overlap3+p2p+graph', 16), (3, 'channel+every2+p2p', 7),
                                                 (2, 'channel+every2+p2p+flow+graph', 9)])
 def test_exchange_kernels_on_a_side_stream(tmp_path, hip_lib, monkeypatch, world, case, n_steps):

@@ -59,7 +59,7 @@ def test_bench_two_ranks_through_torch_distributed_run(hip_lib):
     against the host-staged exchange and timed, and everything else - partitioning, schedule tuning with the max over
     ranks, graph capture, the timed region, rank 0 printing one JSON line - is the code a multi-GPU node runs."""
     e = dict(os.environ)
-    e.update({'THETIS_AMD_DIST_BACKEND': 'gloo', 'THETIS_AMD_LARGE_MESH': '1600,400'})
+    e.update({'THETIS_AMD_DIST_BACKEND': 'gloo', 'THETIS_AMD_LARGE_MESH': '1600,400', 'THETIS_AMD_SOAK_S': '0.5'})
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                         '127.0.0.1', '--master-port', '29577', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '16',
                         '--warmup', '2', '--prewarm', '0.05'],
@@ -81,6 +81,10 @@ def test_bench_two_ranks_through_torch_distributed_run(hip_lib):
     # the second, untuned timed region on the larger mesh of the same channel (here shrunk: 2 ranks share one GPU)
     lm = cfg['large_mesh']
     assert lm['n_cells'] == 2*1600*400 and lm['volume_conserved'] is True and lm['value'] > 1e8 and lm['speedup_model'] > 0
+    # the soak (round 5): the peer-to-peer transport stepped >= 0.5 s from the initial state and ended on the bits of the whole mesh
+    # stepped by one GPU alone
+    sk = cfg['soak']
+    assert sk['steps'] >= 240 and any(v['what'] == "transport 'p2p'" and v['seconds'] >= 0.4 for v in sk['verified']), sk
 
 
 def test_bench_eight_ranks_through_torch_distributed_run(hip_lib):
@@ -90,7 +94,7 @@ def test_bench_eight_ranks_through_torch_distributed_run(hip_lib):
     The run must end in ONE complete JSON line with ``config.large_mesh``."""
     e = dict(os.environ)
     e.update({'THETIS_AMD_DIST_BACKEND': 'gloo', 'THETIS_AMD_BENCH_MESH': '256,64', 'THETIS_AMD_LARGE_MESH': '512,64',
-              'THETIS_AMD_SETUP_BUDGET_S': '40'})
+              'THETIS_AMD_SETUP_BUDGET_S': '40', 'THETIS_AMD_SOAK_S': '0.3'})
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr',
                         '127.0.0.1', '--master-port', '29581', os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '16',
                         '--warmup', '2', '--prewarm', '0.05'],
@@ -112,7 +116,7 @@ def test_bench_set_up_budget_cuts_the_candidate_list_short(hip_lib):
     """THETIS_AMD_SETUP_BUDGET_S = 0: after the first transport and the first candidate nothing more is tried; the line is
     still complete and says what was skipped."""
     e = dict(os.environ)
-    e.update({'THETIS_AMD_DIST_BACKEND': 'gloo', 'THETIS_AMD_SETUP_BUDGET_S': '0', 'THETIS_AMD_NO_LARGE_MESH': '1'})
+    e.update({'THETIS_AMD_DIST_BACKEND': 'gloo', 'THETIS_AMD_SETUP_BUDGET_S': '0', 'THETIS_AMD_NO_LARGE_MESH': '1', 'THETIS_AMD_SOAK_S': '0'})
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                         '127.0.0.1', '--master-port', '29579', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '8',
                         '--warmup', '2', '--prewarm', '0.05'],

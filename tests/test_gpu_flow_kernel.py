@@ -306,3 +306,43 @@ def test_a_block_that_lags_two_to_three_stage_periods_changes_no_bit(hip_lib, ca
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), 'block {:d}'.format(blk)
     dev.lib.swe2d_debug_flow_delay(dev.h, -1, 0, 0, 1)
     dev.close()
+
+
+def _tear_build(dev):
+    """None with the product library; else whether the -DSWE_FLOW_TEAR build's consumers test the granules' check word (True) or not
+    (False: -DSWE_FLOW_NOCHECK, the negative control)"""
+    rc = dev.lib.swe2d_debug_flow_tear(dev.h, -3, 0, 1, 0)
+    return None if rc < 0 else bool(rc)
+
+
+@pytest.mark.parametrize('every', [1, 3])
+def test_granule_stores_that_land_in_two_halves_change_no_bit(hip_lib, every):
+    """Adversary for the 16-byte granules (-DSWE_FLOW_TEAR build only; skipped with the product library): every block stores the
+    half of a granule that carries the NEW tag first and the value it belongs to 3 us later - what a store torn on its way to another
+    XCD or another device would look like to a consumer polling in between.  The check word (tag ^ lo ^ hi of the value) makes the
+    consumer re-poll such a granule: bit for bit the stage launches.  With the negative-control build (-DSWE_FLOW_NOCHECK: the consumer
+    looks at the tag only, the protocol of rounds 3-4) the same run MUST give other bits - the test then asserts that it does."""
+    mesh, bath, uv, eta = channel_case(nx=67, ny=31, seed=11)
+    dev = _device(mesh, bath, 0.05)
+    checked = _tear_build(dev)
+    if checked is None:
+        dev.close()
+        pytest.skip('needs the -DSWE_FLOW_TEAR build (tools/range_check.sh)')
+    launches = [[dev.n_cells]*12, [dev.n_cells]*18]
+    dev.set_state(uv, eta)
+    for ends in launches:
+        _by_stage(dev, ends)
+    ref = dev.get_state()
+    dev.set_state(uv, eta)
+    assert dev.lib.swe2d_debug_flow_tear(dev.h, -2, 3, every, 0) == 0
+    for ends in launches:
+        dev.solve_flow(ends)
+    assert dev.flow_timeouts() == 0
+    got = dev.get_state()
+    dev.lib.swe2d_debug_flow_tear(dev.h, -1, 0, 1, 0)
+    dev.close()
+    same = np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    if checked:
+        assert same
+    else:
+        assert not same, 'negative control: torn granules taken by their tag alone must show up as wrong bits'

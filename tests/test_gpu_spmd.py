@@ -78,6 +78,30 @@ def test_a_rank_whose_handle_cannot_be_built_takes_its_peers_out_of_the_handshak
     _check(single, ranks, exact_callbacks=True)
 
 
+def test_periodic_verification_of_the_in_launch_exchange(tmp_path, tmp_path_factory, hip_lib):
+    """THETIS_AMD_VERIFY_EVERY on the GPU: the channel script under three ranks with the dataflow launches and the exchange inside
+    them, every window of eight steps replayed with stage launches through host memory.  Product library: every window agrees.
+    -DSWE_FLOW_TEAR build (tools/range_check.sh; granule stores in two halves): the same with the check word; with its negative
+    control (-DSWE_FLOW_NOCHECK: torn granules are taken by their tag) the verification MUST report mismatches, keep the replayed
+    state, drop the dataflow launches - and the run still ends on the single-device bits."""
+    from thetis_amd.device import Swe2dDevice
+    from thetis_amd.mesh import RectangleMesh
+    m = RectangleMesh(4, 2, 1.0, 1.0)
+    dev = Swe2dDevice(m, np.ones(m.num_vertices), 1e-3)
+    kind = dev.lib.swe2d_debug_flow_tear(dev.h, -3, 0, 1, 0)          # < 0 product build, 1 tear + check word, 0 tear without
+    dev.close()
+    env = {'THETIS_AMD_SPMD_FLOW': '1', 'THETIS_AMD_VERIFY_EVERY': '8'}
+    if kind >= 0:
+        env['THETIS_AMD_TEST_TEAR'] = '3:1'
+    single = single_rank('channel', tmp_path_factory, cpu=False)
+    ranks = run_spmd(3, str(tmp_path), 'channel', cpu=False, env=env)
+    _check(single, ranks, exact_callbacks=True)
+    for r in ranks:
+        rep = r['verify_report']
+        assert rep['windows'] >= 3
+        assert (rep['mismatches'] >= 1) if kind == 0 else (rep['mismatches'] == 0), rep
+
+
 def _script(args, world, port):
     e = dict(os.environ)
     e['THETIS_AMD_DIST_BACKEND'] = 'gloo'            # the ranks share the one GPU of the test box: RCCL would refuse them

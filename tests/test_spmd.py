@@ -68,6 +68,27 @@ def test_user_script_variants(tmp_path, tmp_path_factory, ref_so, name, world, e
     _check(single, ranks)
 
 
+@pytest.mark.parametrize('name,world,fault', [('channel', 2, None), ('channel', 3, '1:1'), ('tracer', 2, '0:0')])
+def test_periodic_verification_keeps_the_replayed_state(tmp_path, tmp_path_factory, ref_so, name, world, fault):
+    """THETIS_AMD_VERIFY_EVERY = 3: every window of three steps is replayed from its start with stage launches and the exchange
+    through host memory, the ranks' blake2b verdicts are gathered.  Without a fault: same bits, every window agrees.  With ONE wrong
+    bit planted in one rank's fast result of one window (THETIS_AMD_TEST_VERIFY_FAULT = rank:window): the mismatch is reported
+    with that rank, the replayed state is kept, and the run ends on the single-rank bits all the same."""
+    single = single_rank(name, tmp_path_factory)
+    env = {'THETIS_AMD_VERIFY_EVERY': '3'}
+    if fault:
+        env['THETIS_AMD_TEST_VERIFY_FAULT'] = fault
+    ranks = run_spmd(world, str(tmp_path), name, env=env)
+    _check(single, ranks)
+    for r in ranks:
+        rep = r['verify_report']
+        assert rep['windows'] > 2
+        if fault:
+            assert rep['mismatches'] == 1 and rep['bad_ranks'] == [[int(fault.split(':')[0])]]
+        else:
+            assert rep['mismatches'] == 0
+
+
 def test_world_8(tmp_path, tmp_path_factory, ref_so):
     """eight ranks on a channel whose strips (3 columns of cells) are narrower than the six-layer halo: a rank's ghost layers
     reach into its second neighbours"""

@@ -4,8 +4,10 @@ The library is several translation units (csrc/swe2d_api*.hip: the C ABI by conc
 each - the template instantiations are what takes the time).  Objects are compiled in parallel and only when a file they include
 changed (hipcc -MD dependency files), so a kernel edit rebuilds the families that see it and nothing else.
 
+``build(defines=[...], lib=...)`` builds a variant (its objects in a directory of its own next to ``lib``): the adversaries of the
+granule protocol, -DSWE_FLOW_DELAY / -DSWE_FLOW_TEAR, whose device-side switches live in the flow kernels' unit.
 ``build(unity=True, defines=[...], lib=...)`` compiles csrc/swe2d_unity.hip instead - every unit in one, for the debug variants
-whose device-side globals all kernels must share (-DSWE_RANGE_CHECK, -DSWE_FLOW_DELAY, -DSWE_WAVE_TIMING)."""
+whose device-side globals all kernels must share (-DSWE_RANGE_CHECK, -DSWE_WAVE_TIMING)."""
 import concurrent.futures
 import glob
 import os
@@ -24,8 +26,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 ALL_DEPS = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(_HERE, '..', 'include', 'swe2d.h')]
 
 
-def _obj(unit):
-    return os.path.join(OBJ_DIR, unit[:-4] + '.o')
+def _obj(unit, obj_dir=None):
+    return os.path.join(obj_dir or OBJ_DIR, unit[:-4] + '.o')
 
 
 def _deps(unit):
@@ -62,8 +64,9 @@ def needs_build():
     return False
 
 
-def _compile(unit, verbose):
-    cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, unit), '-o', _obj(unit), '-MD', '-MF', _obj(unit)[:-2] + '.d']
+def _compile(unit, verbose, defines=(), obj_dir=None):
+    o = _obj(unit, obj_dir)
+    cmd = [HIPCC] + FLAGS + ['-D' + d for d in defines] + ['-c', os.path.join(CSRC, unit), '-o', o, '-MD', '-MF', o[:-2] + '.d']
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -78,11 +81,21 @@ def build(force=False, verbose=False, unity=False, defines=(), lib=None, jobs=No
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
         return out
+    jobs = jobs or int(os.environ.get('THETIS_AMD_BUILD_JOBS', '0')) or min(len(UNITS), os.cpu_count() or 1)
+    if defines or lib:
+        # a variant: all units with the extra defines, objects next to the variant's library
+        out = os.path.abspath(lib or LIB)
+        obj_dir = out + '.obj'
+        os.makedirs(obj_dir, exist_ok=True)
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+            for f in [ex.submit(_compile, u, verbose, defines, obj_dir) for u in UNITS]:
+                f.result()
+        subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + [_obj(u, obj_dir) for u in UNITS] + ['-o', out])
+        return out
     if not (force or needs_build()):
         return LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
     todo = [u for u in UNITS if force or _stale(u)]
-    jobs = jobs or int(os.environ.get('THETIS_AMD_BUILD_JOBS', '0')) or min(len(UNITS), os.cpu_count() or 1)
     if todo:
         with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
             for f in [ex.submit(_compile, u, verbose) for u in todo]:

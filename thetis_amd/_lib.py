@@ -18,7 +18,7 @@ FIELD_LINEAR_DRAG, FIELD_QUADRATIC_DRAG, FIELD_MANNING_DRAG, FIELD_NIKURADSE = 5
 SCALAR_LINEAR_DRAG, SCALAR_QUADRATIC_DRAG, SCALAR_MANNING_DRAG, SCALAR_NORM_SMOOTHER, SCALAR_NIKURADSE = 0, 1, 2, 3, 4
 
 IPC_HANDLE_BYTES = 64    # include/swe2d.h SWE2D_IPC_HANDLE_BYTES (sizeof(hipIpcMemHandle_t))
-ABI_VERSION = 8          # include/swe2d.h SWE2D_ABI_VERSION
+ABI_VERSION = 9          # include/swe2d.h SWE2D_ABI_VERSION
 OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NOT_FINITE = 0, -1, -2, -3, -4, -5
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -123,6 +123,7 @@ SYMBOLS = {
     'swe2d_flow_status': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_debug_flow_poke': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_debug_flow_delay': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    'swe2d_debug_flow_tear': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_set_stream': (ctypes.c_int, [_H, ctypes.c_void_p]),
     'swe2d_set_exchange_stream': (ctypes.c_int, [_H, ctypes.c_void_p]),
 }

@@ -388,11 +388,37 @@ int swe2d_debug_flow_delay(swe2d_handle *hh, int32_t block, int32_t where, int32
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const int cfg[4] = {block, where, microseconds*100, every < 1 ? 1 : every};
-    HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(swe_flow_delay), cfg, sizeof(cfg)));
+    if (swe_flow_debug_config(0, cfg) != 0) return fail(h, SWE2D_ERR_HIP, "swe2d_debug_flow_delay: the switch could not be set");
     return SWE2D_OK;
 #else
     (void)block; (void)where; (void)microseconds; (void)every;
     return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_debug_flow_delay: this library was built without -DSWE_FLOW_DELAY");
+#endif
+}
+
+// test hook of the -DSWE_FLOW_TEAR build (csrc/swe2d_flow.h): the granule stores of block `block` (-2: of every block, -1: off) of
+// every `every`-th publish are made in two halves - the half with the NEW tag first, the value `microseconds` later; across_ranks:
+// also the pushes into the peers' landing zones.  SWE2D_ERR_UNSUPPORTED in the product build.
+int swe2d_debug_flow_tear(swe2d_handle *hh, int32_t block, int32_t microseconds, int32_t every, int32_t across_ranks)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+#ifdef SWE_FLOW_TEAR
+    if (block == -3) {                       // query: does this build's consumer test the check word?  (1 yes, 0: -DSWE_FLOW_NOCHECK, the negative control)
+#ifdef SWE_FLOW_NOCHECK
+        return 0;
+#else
+        return 1;
+#endif
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int cfg[4] = {block, microseconds*100, every < 1 ? 1 : every, across_ranks ? 1 : 0};
+    if (swe_flow_debug_config(1, cfg) != 0) return fail(h, SWE2D_ERR_HIP, "swe2d_debug_flow_tear: the switch could not be set");
+    return SWE2D_OK;
+#else
+    (void)block; (void)microseconds; (void)every; (void)across_ranks;
+    return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_debug_flow_tear: this library was built without -DSWE_FLOW_TEAR");
 #endif
 }
 

@@ -12,16 +12,18 @@
 //     written once per time step (the step result, buffer 0);
 //   * traces of neighbours INSIDE the block (~85 % with the tile numbering) go through LDS: the wave publishes its nine nodal
 //     values per cell there at the top of a stage and reads its neighbours' - no memory, no waiting;
-//   * traces of neighbours in OTHER blocks travel as 16-byte granules {value, stage tag}: a facet on the block's rim owns a slot
-//     (host-built numbering: a block's slots are contiguous and grouped by the block they face), its six trace values are
-//     stored there after every stage, each granule by ONE 16-byte `sc1` (write-through) store of one lane, tag = stage counter;
+//   * traces of neighbours in OTHER blocks travel as 16-byte granules {value, stage tag, check word}: a facet on the block's rim
+//     owns a slot (host-built numbering: a block's slots are contiguous and grouped by the block they face), its six trace values
+//     are stored there after every stage, each granule by ONE 16-byte `sc1` (write-through) store of one lane, tag = stage counter;
 //     the block across the rim re-reads the granules with `sc1` loads (past its CU's L1) until all carry the tag of the stage
 //     it needs.  The data IS the flag:
 //     no drain (s_waitcnt vmcnt(0)) before a flag store, no flag store, no separate poll before a dependent gather - measured
 //     on the first version of this kernel (stage values through the state planes + one stage counter per block) those three
 //     hops were 2.1 of the 4.0 us a stage took with one block per compute unit.  A naturally aligned 16-byte store of one lane
-//     lands untorn on gfx950 (MI355X_MICROARCH.md, "observed untorn, also for 16-B sc1 halves; not an architectural
-//     guarantee"); the parity tests would see a torn granule as a wrong bit.  Two slots per facet alternate by stage parity:
+//     was observed to land untorn on gfx950 (MI355X_MICROARCH.md, "observed untorn, also for 16-B sc1 halves; not an
+//     architectural guarantee"); the protocol does not rely on it: the check word (tag ^ lo32 ^ hi32 of the value, round 5) ties
+//     the tag to the value it was stored with, and a granule whose halves come from two different stores is re-polled like one
+//     that has not arrived (swe_flow_arrived; adversary build -DSWE_FLOW_TEAR).  Two slots per facet alternate by stage parity:
 //     the producer overwrites the values of stage s at the end of stage s + 2, which it can only reach after the consumer has
 //     finished stage s + 1, i.e. has read them.
 //     Both directions are coalesced through an LDS staging area: the rim lanes drop their values there by slot and the wave
@@ -64,11 +66,10 @@
 #ifndef SWE_FLOW_FLAG_STRIDE
 #define SWE_FLOW_FLAG_STRIDE 16           // unsigned words between two blocks' stage counters (64 B)
 #endif
-#define SWE_FLOW_SLOT_BYTES 128            // exchange slot of one rim facet and stage parity: 8 granules of 16 B (6 values + 2 pads)
+#define SWE_FLOW_SLOT_BYTES 128            // exchange slot of one rim facet and stage parity: 8 granules of 16 B {value, tag, check} (6 values + 2 pads)
 #define SWE_FLOW_MAX_RIM 160               // rim facets of a block (3*64 at worst: such flow orders are refused, see flow_build)
 
 typedef unsigned int swe_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int swe_u32x3 __attribute__((ext_vector_type(3)));
 #define SWE_FLOW_NOWHERE 0x80000000u       // byte offset beyond the exchange array (< 2 GiB): a load returns zeros without touching memory
 // LDS layout of a block: nine planes of 64 stage values, then six trace values per incoming rim facet
 #define SWE_FLOW_XG (9*SWE_BLOCK)
@@ -146,32 +147,75 @@ struct SweFlowArgs {
     unsigned long long x_timeout;                                            // wall_clock64 ticks
 };
 
-// one granule: {value, tag} written / read by ONE 16-byte access of one lane, sc1 (aux 16): write-through / past the L1
-__device__ __forceinline__ void swe_flow_put(__amdgpu_buffer_rsrc_t r, unsigned off, double x, unsigned tag)
+// one granule: {value, tag, check} written / read by ONE 16-byte access of one lane, sc1 (aux 16): write-through / past the L1.
+// check = tag ^ lo32(value) ^ hi32(value).  An untorn 16-byte store of one lane is what gfx950 was OBSERVED to do, on one device; it
+// is not an architectural guarantee, and across devices (the FX exchange: a peer's IPC-mapped zone over xGMI) it had never run at
+// all.  The consumer therefore takes a granule only when the tag is the one it waits for AND the check word agrees
+// with the value it travelled with: a store that lands in two halves (value before tag or tag before value, 8 + 8 or 4 + 12 bytes)
+// shows either an old tag - not taken anyway - or a new tag whose check word belongs to another value - re-polled like a granule
+// that has not arrived.  (An old value with the new tag passes only if lo ^ hi of the two values agree, i.e. never for a changed
+// value by less than one chance in 2^32 - and a granule whose value did not change is right whichever half is read.)  Three VALU
+// operations on either side.  -DSWE_FLOW_TEAR (tools/range_check.sh) is the adversary that splits the stores on purpose;
+// -DSWE_FLOW_NOCHECK its negative control (the consumer ignores the check word: the torn build must then give wrong bits).
+__device__ __forceinline__ unsigned swe_flow_check_word(unsigned lo, unsigned hi, unsigned tag) { return tag ^ lo ^ hi; }
+#ifdef SWE_FLOW_TEAR
+// block (-2: every block), ticks of the 100 MHz clock between the two halves of a store, every n-th publish, 1 = also the pushes across ranks
+__device__ int swe_flow_tear[4] = {-1, 0, 1, 0};
+__device__ __forceinline__ void swe_flow_put_torn(__amdgpu_buffer_rsrc_t r, unsigned off, swe_u32x4 g, int aux_sys, int ticks)
+{
+    // the dangerous order: the half with the NEW tag first, the value it belongs to a few microseconds later
+    const swe_u32x2 hi2 = {g.z, g.w}, lo2 = {g.x, g.y};
+    if (aux_sys) __builtin_amdgcn_raw_buffer_store_b64(hi2, r, off + 8u, 0, 17); else __builtin_amdgcn_raw_buffer_store_b64(hi2, r, off + 8u, 0, 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(16);
+    if (aux_sys) __builtin_amdgcn_raw_buffer_store_b64(lo2, r, off, 0, 17); else __builtin_amdgcn_raw_buffer_store_b64(lo2, r, off, 0, 16);
+}
+#define SWE_FLOW_TORN(lb_, pc_, sys_) ((swe_flow_tear[0] == (lb_) || swe_flow_tear[0] == -2) && swe_flow_tear[1] > 0 \
+                                       && ((pc_) % (swe_flow_tear[2] < 1 ? 1 : swe_flow_tear[2])) == 0 && (!(sys_) || swe_flow_tear[3]))
+#endif
+__device__ __forceinline__ void swe_flow_put(__amdgpu_buffer_rsrc_t r, unsigned off, double x, unsigned tag, bool torn = false)
 {
     const swe_u32x2 xb = __builtin_bit_cast(swe_u32x2, x);
-    const swe_u32x4 g = {xb.x, xb.y, tag, 0u};
+    const swe_u32x4 g = {xb.x, xb.y, tag, swe_flow_check_word(xb.x, xb.y, tag)};
+#ifdef SWE_FLOW_TEAR
+    if (torn) { swe_flow_put_torn(r, off, g, 0, swe_flow_tear[1]); return; }
+#endif
+    (void)torn;
     __builtin_amdgcn_raw_buffer_store_b128(g, r, off, 0, 16);
 }
-__device__ __forceinline__ swe_u32x3 swe_flow_get(__amdgpu_buffer_rsrc_t r, unsigned off)       // value + tag: 12 of the 16 bytes
+__device__ __forceinline__ swe_u32x4 swe_flow_get(__amdgpu_buffer_rsrc_t r, unsigned off)       // value, tag, check
 {
-    return __builtin_amdgcn_raw_buffer_load_b96(r, off, 0, 16);
+    return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);
 }
 // the same across devices: system scope (sc0 sc1, aux 17), tag = push number
-__device__ __forceinline__ void swe_flow_put_sys(__amdgpu_buffer_rsrc_t r, unsigned off, double x, unsigned tag)
+__device__ __forceinline__ void swe_flow_put_sys(__amdgpu_buffer_rsrc_t r, unsigned off, double x, unsigned tag, bool torn = false)
 {
     const swe_u32x2 xb = __builtin_bit_cast(swe_u32x2, x);
-    const swe_u32x4 g = {xb.x, xb.y, tag, 0u};
+    const swe_u32x4 g = {xb.x, xb.y, tag, swe_flow_check_word(xb.x, xb.y, tag)};
+#ifdef SWE_FLOW_TEAR
+    if (torn) { swe_flow_put_torn(r, off, g, 1, swe_flow_tear[1]); return; }
+#endif
+    (void)torn;
     __builtin_amdgcn_raw_buffer_store_b128(g, r, off, 0, 17);
 }
-__device__ __forceinline__ swe_u32x3 swe_flow_get_sys(__amdgpu_buffer_rsrc_t r, unsigned off)
+__device__ __forceinline__ swe_u32x4 swe_flow_get_sys(__amdgpu_buffer_rsrc_t r, unsigned off)
 {
-    return __builtin_amdgcn_raw_buffer_load_b96(r, off, 0, 17);
+    return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 17);
 }
-__device__ __forceinline__ double swe_flow_val(swe_u32x3 g)
+__device__ __forceinline__ double swe_flow_val(swe_u32x4 g)
 {
     const swe_u32x2 xb = {g.x, g.y};
     return __builtin_bit_cast(double, xb);
+}
+// has the granule of publish / push `need` (or a later one) arrived, whole?
+__device__ __forceinline__ bool swe_flow_arrived(swe_u32x4 g, unsigned need)
+{
+#ifdef SWE_FLOW_NOCHECK
+    return (int)(g.z - need) >= 0;
+#else
+    return (int)(g.z - need) >= 0 && g.w == swe_flow_check_word(g.x, g.y, g.z);
+#endif
 }
 
 // right-hand side integrals of one cell: cell integrals + interior facet fluxes (boundary facets contribute zero here, their
@@ -457,6 +501,11 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
     // producer reaches the end of stage s + 2 only after the consumer has read stage s - holds for cells the producer still waits
     // for; a cell active in stage s but not later makes its block wait for nothing from the block it faces, so the block may run
     // two stages ahead of a consumer that is stalled on another neighbour and must not touch the slot that consumer has yet to read.
+#ifdef SWE_FLOW_TEAR
+#define SWE_FLOW_TORN_HERE(pc_, sys_) SWE_FLOW_TORN(lb, pc_, sys_)
+#else
+#define SWE_FLOW_TORN_HERE(pc_, sys_) false
+#endif
 #define SWE_FLOW_PUBLISH(pu, pv, pe, who, pc_, set_) do {                                                                               \
         const unsigned tag_ = base + (unsigned)(pc_) + 1u;                                                                        \
         const unsigned par_ = (unsigned)(set_)*q.parity_bytes + (unsigned)myslots.x*SWE_FLOW_SLOT_BYTES;                    \
@@ -474,7 +523,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
         for (int t_ = lane; t_ < 8*nrim; t_ += SWE_BLOCK) {                                                                       \
             const int gi_ = t_ & 7;                                                                                               \
             const double x_ = gi_ < 6 ? lds[SWE_LDSI(SWE_FLOW_XG + 6*(t_ >> 3) + gi_, SWE_FLOW_LDS_DOUBLES)] : 0.0;                                               \
-            if (lpub[SWE_LDSI(t_ >> 3, SWE_FLOW_MAX_RIM)]) swe_flow_put(rex, par_ + 16u*(unsigned)t_, x_, tag_);                   \
+            if (lpub[SWE_LDSI(t_ >> 3, SWE_FLOW_MAX_RIM)]) swe_flow_put(rex, par_ + 16u*(unsigned)t_, x_, tag_, SWE_FLOW_TORN_HERE(pc_, 0));   \
         }                                                                                                                         \
     } while (0)
 
@@ -498,8 +547,8 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                     const int first = (int)__builtin_ctzll(gm);
                     const unsigned hint = __builtin_amdgcn_readlane(zo, first);
                     for (unsigned spins = 0; !late; spins++) {
-                        const swe_u32x3 g1 = swe_flow_get_sys(rz, lane == 0 ? hint : SWE_FLOW_NOWHERE);
-                        if (__any(lane == 0 && (int)(g1.z - target) >= 0)) break;
+                        const swe_u32x4 g1 = swe_flow_get_sys(rz, lane == 0 ? hint : SWE_FLOW_NOWHERE);
+                        if (__any(lane == 0 && swe_flow_arrived(g1, target))) break;
                         __builtin_amdgcn_s_sleep(8);
                         if ((spins & 15u) == 15u) {
                             const unsigned long long now = wall_clock64();
@@ -525,8 +574,8 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                     bool ok = true;
                     for (int t = lane; t < 9*ng; t += SWE_BLOCK) {
                         const int cc = (t*7282) >> 16, gi = t - 9*cc;                              // t / 9, t % 9
-                        const swe_u32x3 gz = swe_flow_get_sys(rz, lrec[SWE_LDSI(cc, SWE_BLOCK)] + 16u*(unsigned)gi);
-                        ok = ok && (int)(gz.z - target) >= 0;
+                        const swe_u32x4 gz = swe_flow_get_sys(rz, lrec[SWE_LDSI(cc, SWE_BLOCK)] + 16u*(unsigned)gi);
+                        ok = ok && swe_flow_arrived(gz, target);
                         lds[SWE_LDSI(SWE_FLOW_XG + t, SWE_FLOW_LDS_DOUBLES)] = swe_flow_val(gz);
                     }
                     if (__all(ok) || late) break;
@@ -592,7 +641,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                 for (unsigned spins = 0;; spins++) {
                     bool ok = true;
                     for (int c0 = 0; c0 < 8*nrim; c0 += POLL*SWE_BLOCK) {      // POLL loads per lane in flight (8*POLL rim facets per trip)
-                        swe_u32x3 gr[POLL];
+                        swe_u32x4 gr[POLL];
                         int ent[POLL];
 #pragma unroll
                         for (int j = 0; j < POLL; j++) {
@@ -607,7 +656,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                         for (int j = 0; j < POLL; j++) {
                             const int t = c0 + j*SWE_BLOCK + lane;
                             if (ent[j] >= 0) {
-                                ok = ok && (int)(gr[j].z - need) >= 0;
+                                ok = ok && swe_flow_arrived(gr[j], need);
                                 if ((t & 7) < 6) lds[SWE_LDSI(SWE_FLOW_XG + 6*(t >> 3) + (t & 7), SWE_FLOW_LDS_DOUBLES)] = swe_flow_val(gr[j]);
                             }
                         }
@@ -710,13 +759,14 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(q.x_rdata[pp], 0, q.x_rbytes[pp], 0x00020000);
                     for (int t = lane; t < 9*ns; t += SWE_BLOCK) {
                         const int cc = (t*7282) >> 16, gi = t - 9*cc;
-                        if (lpeer[SWE_LDSI(cc, SWE_BLOCK)] == pp) swe_flow_put_sys(rp, lrec[SWE_LDSI(cc, SWE_BLOCK)] + 16u*(unsigned)gi, lds[SWE_LDSI(SWE_FLOW_XG + t, SWE_FLOW_LDS_DOUBLES)], target);
+                        if (lpeer[SWE_LDSI(cc, SWE_BLOCK)] == pp) swe_flow_put_sys(rp, lrec[SWE_LDSI(cc, SWE_BLOCK)] + 16u*(unsigned)gi, lds[SWE_LDSI(SWE_FLOW_XG + t, SWE_FLOW_LDS_DOUBLES)], target, SWE_FLOW_TORN_HERE(c, 1));
                     }
                 }
             }
         }
     }
 #undef SWE_FLOW_PUBLISH
+#undef SWE_FLOW_TORN_HERE
     // retired or finished: every block's counter ends the launch at base + n_stages
     if (lane == 0) *myflag = fin;
     if (FX && lane == 0) {
@@ -749,9 +799,9 @@ static __global__ __launch_bounds__(256) void swe_flow_unpack_kernel(double *pla
         for (;;) {
             bool ok = true;
             for (int i = 0; i < 9; i++) {
-                const swe_u32x3 g = swe_flow_get_sys(rz, zo + 16u*i);
+                const swe_u32x4 g = swe_flow_get_sys(rz, zo + 16u*i);
                 x[i] = swe_flow_val(g);
-                ok = ok && (int)(g.z - target) >= 0;
+                ok = ok && swe_flow_arrived(g, target);
             }
             if (ok) break;
             if (wall_clock64() - w0 > timeout_ticks) {

@@ -20,3 +20,16 @@ flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src, bool fx, bool wide)
 {
     return wide ? pick_flow_poll<9>(nl, lf, src, fx) : pick_flow_poll<8>(nl, lf, src, fx);
 }
+
+// the adversary builds' device-side switches live in this translation unit (with the kernels that read them)
+int swe_flow_debug_config(int which, const int cfg[4])
+{
+#ifdef SWE_FLOW_DELAY
+    if (which == 0) return hipMemcpyToSymbol(HIP_SYMBOL(swe_flow_delay), cfg, 4*sizeof(int)) == hipSuccess ? 0 : 1;
+#endif
+#ifdef SWE_FLOW_TEAR
+    if (which == 1) return hipMemcpyToSymbol(HIP_SYMBOL(swe_flow_tear), cfg, 4*sizeof(int)) == hipSuccess ? 0 : 1;
+#endif
+    (void)which; (void)cfg;
+    return -1;                               // this build has no such switch
+}

@@ -19,3 +19,5 @@ flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src, bool fx = false, bool
 tracer_kernel_t pick_tracer_kernel(bool lf, bool t0, bool src);
 tracer_kernel_t pick_tracer_kernel_diff(bool lf, bool t0, bool src);      // horizontal diffusion fused in (swe_diff_interior)
 tracer_kernel_t pick_tracer_kernel_quad(bool lf, bool t0, bool src, bool affine = true);
+// -DSWE_FLOW_DELAY (which = 0) / -DSWE_FLOW_TEAR (1) builds: sets the device-side switches of the adversary; -1 in other builds
+int swe_flow_debug_config(int which, const int cfg[4]);

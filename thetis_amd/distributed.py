@@ -291,6 +291,14 @@ class DistributedSwe2d(object):
             if self.exchange != 'host':
                 raise ValueError("a host stand-in device exchanges through host memory: exchange='host'")
         self._flow_request = flow
+        # opt-in periodic check of the fast path (THETIS_AMD_VERIFY_EVERY = n, or verify_every=n): see _advance_verified
+        ve = opts.pop('verify_every', None)
+        self._verify_every = int(ve if ve is not None else os.environ.get('THETIS_AMD_VERIFY_EVERY', '0') or 0)
+        self._v_snapshot, self._v_steps = None, 0
+        self._replaying = False                  # a verification replay runs: stage launches, host-staged exchange, no graphs
+        self._distrust = 0                       # 0 as configured | 1 after a mismatch: no dataflow launches | 2: and the exchange through the host
+        self.verify_report = {'windows': 0, 'mismatches': 0, 'bad_ranks': []}
+        self._host_halos = {}
         self._flowx_request = flow_exchange
         self._flow_now = None                    # the rank-collective decision of the current advance() (see _decide_flow)
         self._flowx_now = False
@@ -331,6 +339,10 @@ class DistributedSwe2d(object):
         self.dev = device_cls(p, np.asarray(bathymetry_vertex)[p.vertex_global], dt, device_id=device_id,
                               n_owned=p.n_owned, boundary_len=p.boundary_len, ranges=p.reorder_ranges(), **opts)
         self.dev.halo_setup(p.send_cells, p.recv_cells)
+        if os.environ.get('THETIS_AMD_TEST_TEAR'):         # tests, -DSWE_FLOW_TEAR builds: "microseconds:every" - granule stores in two halves
+            us, ev = (int(v) for v in os.environ['THETIS_AMD_TEST_TEAR'].split(':'))
+            if self.dev.lib.swe2d_debug_flow_tear(self.dev.h, -2, us, ev, 1) != 0:
+                raise RuntimeError('THETIS_AMD_TEST_TEAR needs the -DSWE_FLOW_TEAR build of the library')
         if flow is not False and self.dev.npc == 3 and self._on_gpu:
             # the flow kernel's blocks: all local cells (owned + ghost layers) in one locality order, so that a ghost cell
             # shares its block with the cells it touches (in the device numbering - ghost layers appended layer by layer - a
@@ -381,7 +393,7 @@ class DistributedSwe2d(object):
     def _flow_local(self):
         """This rank's own answer to "does a cycle run as one dataflow launch?" (see ``flow``); evaluated per call: the device
         configuration (source terms, viscosity, wetting-drying) may be set after construction."""
-        if self._flow_request is False or os.environ.get('THETIS_AMD_FLOW') == '0' or not self._on_gpu:
+        if self._flow_request is False or os.environ.get('THETIS_AMD_FLOW') == '0' or not self._on_gpu or self._distrust:
             return False
         plain = (self.stages_per_step == 3 and not self.tids and not self.tracer_only and self.overlap_stages == 0
                  and 3*self.exchange_every <= 384)
@@ -469,12 +481,14 @@ class DistributedSwe2d(object):
     def flow(self):
         """True when a cycle runs as one dataflow launch (see ``flow``): the ranks' common decision of the last ``advance``, before
         the first one this rank's own answer."""
+        if self._replaying or self._distrust:
+            return False
         return self._flow_local() if self._flow_now is None else self._flow_now
 
     @property
     def flow_exchange(self):
         """True when the exchange runs inside the flow launches (see ``flow_exchange``): part of the ranks' common decision."""
-        if self._no_exchange:
+        if self._no_exchange or self._replaying or self._distrust:
             return False
         if self._flow_now is None:
             return self._flow_local() and self._flowx_local()
@@ -559,10 +573,34 @@ class DistributedSwe2d(object):
         return self.part.local_to_global[:n], uv[:n], eta[:n]
 
     # ---- the exchange: send = pack + post (or push), receive = wait + unpack
+    def _through_host(self):
+        return self._replaying or self._distrust >= 2
+
+    def _host_halo(self, channel):
+        """The host-staged exchanger of a channel, built on first use (verification replays of a run whose transport is not 'host')"""
+        w = 3*self.dev.npc if channel == 0 else self.dev.npc
+        if w not in self._host_halos:
+            if self.exchange == 'host':
+                self._host_halos[w] = self.halo if channel == 0 else self.thalo
+            else:
+                self._host_halos[w] = HaloExchanger(self.part, self.torch_device, host_staged=self._on_gpu, width=w, group=self._host_group())
+        return self._host_halos[w]
+
+    def _host_group(self):
+        """a group that moves CPU tensors: the run's own for 'p2p' / 'host' (gloo), the world group for 'rccl' (cpu:gloo,cuda:nccl)"""
+        return self.group
+
     def _send(self, channel, i_buffer):
         dev = self.dev
         if self._no_exchange:
             return None
+        if self._through_host():
+            halo = self._host_halo(channel)
+            if channel == 0:
+                dev.halo_pack(i_buffer, halo.send_buf.data_ptr())
+            else:
+                dev.tracer_halo_pack(self.tids[channel - 1], i_buffer, halo.send_buf.data_ptr())
+            return halo.start()
         if self.p2p is not None:
             if self.xstream is not None:                 # fork: the push follows everything enqueued so far
                 self._ev_fork.record(self.stream)
@@ -580,6 +618,14 @@ class DistributedSwe2d(object):
     def _receive(self, channel, i_buffer, reqs):
         dev = self.dev
         if self._no_exchange:
+            return
+        if self._through_host():
+            halo = self._host_halo(channel)
+            halo.finish(reqs)
+            if channel == 0:
+                dev.halo_unpack(i_buffer, halo.recv_buf.data_ptr())
+            else:
+                dev.tracer_halo_unpack(self.tids[channel - 1], i_buffer, halo.recv_buf.data_ptr())
             return
         if self.p2p is not None:
             dev.p2p_wait_unpack(channel, i_buffer)
@@ -621,7 +667,7 @@ class DistributedSwe2d(object):
             return self._cycle_forward_euler(n_steps)
         if self.flow:
             return self._cycle_swe_flow(n_steps, graphed)
-        if self.p2p is not None:
+        if self.p2p is not None and not self._through_host():
             # the exchange is two kernels of this library: the whole cycle is one capturable launch sequence
             def whole_cycle():
                 self._cycle_before_exchange(n_steps, early_done)
@@ -777,6 +823,93 @@ class DistributedSwe2d(object):
 
     def advance(self, n_steps, use_graph=True):
         """``n_steps`` SSPRK33 steps (enqueued; call ``synchronize``).  COLLECTIVE: every rank calls it with the same count."""
+        if self._verify_every > 0 and self.world > 1 and not self._no_exchange:
+            return self._advance_verified(int(n_steps), use_graph)
+        return self._advance(n_steps, use_graph)
+
+    # ---- opt-in periodic verification of the fast path (THETIS_AMD_VERIFY_EVERY = n)
+    def _local_digest(self):
+        import hashlib
+        n = self.part.n_owned
+        h = hashlib.blake2b(digest_size=16)
+        uv, eta = self.dev.get_state()
+        h.update(np.ascontiguousarray(uv[:n]).tobytes())
+        h.update(np.ascontiguousarray(eta[:n]).tobytes())
+        for tid in self.tids:
+            h.update(np.ascontiguousarray(self.dev.tracer_get_state(tid)[:n]).tobytes())
+        return h.hexdigest()
+
+    def _advance_verified(self, n_steps, use_graph):
+        """``advance`` in windows of ``verify_every`` steps (windows run on across calls).  At the end of a window every rank takes the
+        blake2b of its owned state, goes back to the window's start and REPLAYS it the conservative way - stage launches, eager, the
+        exchange staged through host memory and gloo: nothing of the fast path's machinery (dataflow launches, tagged granules,
+        peer-to-peer stores into mapped zones, HIP graphs) - and compares.  The verdicts are all-gathered over the control plane:
+        on a mismatch anywhere every rank keeps the replayed state, the ranks that differed are reported
+        (``verify_report``, a line on rank 0) and the run goes on one level more conservative (first without dataflow launches,
+        then with the exchange through the host as well).  Costs the window twice plus two state copies: a soak / commissioning
+        tool for a new node, not a production setting.  COLLECTIVE like ``advance``."""
+        ve = self._verify_every
+        while n_steps > 0:
+            if self._v_snapshot is None:
+                self.synchronize()
+                self._v_snapshot = (self.dev.get_state(), [self.dev.tracer_get_state(tid) for tid in self.tids])
+                self._v_steps = 0
+            r = min(n_steps, ve - self._v_steps)
+            self._advance(r, use_graph)
+            self._v_steps += r
+            n_steps -= r
+            if self._v_steps >= ve:
+                fault = os.environ.get('THETIS_AMD_TEST_VERIFY_FAULT')       # tests: "rank:window" - one wrong bit in that window's fast result
+                if fault and [int(v) for v in fault.split(':')] == [self.rank, self.verify_report['windows']]:
+                    self.synchronize()
+                    uv, eta = self.dev.get_state()
+                    eta[0, 0] = np.nextafter(eta[0, 0], np.inf)
+                    self.dev.set_state(uv, eta)
+                self._verify_window()
+
+    def _verify_window(self):
+        import torch.distributed as dist
+        try:
+            self.synchronize()
+            fast = self._local_digest()
+        except RuntimeError as e:                        # a wait of the fast path timed out: a mismatch by definition
+            fast = 'timeout: {:}'.format(e)
+        (uv0, eta0), tr0 = self._v_snapshot
+        n = self._v_steps
+        self._v_snapshot, self._v_steps = None, 0
+        self.dev.set_state(uv0, eta0)
+        for tid, T in zip(self.tids, tr0):
+            self.dev.tracer_set_state(tid, T)
+        self._replaying = True
+        try:
+            with self._stream_ctx():
+                self._steps_eager(n)
+            if self.stream is not None:
+                self.stream.synchronize()
+            slow = self._local_digest()
+        finally:
+            self._replaying = False
+        bad = np.zeros(self.world, dtype=np.int64)
+        bad[self.rank] = 0 if fast == slow else 1
+        bad = self._all_reduce_int(bad)
+        self.verify_report['windows'] += 1
+        if bad.any():
+            ranks = [int(r) for r in np.nonzero(bad)[0]]
+            self.verify_report['mismatches'] += 1
+            self.verify_report['bad_ranks'].append(ranks)
+            # (a wait of the peer-to-peer kernels that timed out is sticky in the handle: that transport is not used again)
+            timed_out = self._all_reduce([1.0 if fast.startswith('timeout') else 0.0], dist.ReduceOp.MAX)[0] > 0.5
+            self._distrust = 2 if timed_out else min(2, self._distrust + 1)
+            self.graph, self._cycle_graphs = None, {}
+            self.config_changed()
+            if self.rank == 0:
+                print('[thetis_amd] VERIFY: the fast path and its stage-launch replay through host memory differ on rank(s) {:} after a '
+                      'window of {:d} steps: the replayed state is kept, the run goes on {:}'.format(
+                          ranks, n, 'without dataflow launches' if self._distrust == 1 else 'with stage launches and the exchange through the host'),
+                      flush=True)
+        # either way the device now holds the replayed state (bitwise the fast one when they agreed), ghosts exchanged, nothing pending
+
+    def _advance(self, n_steps, use_graph=True):
         self._decide_flow()
         with self._stream_ctx():
             if not use_graph or self.graph_mode == 'none' or os.environ.get('THETIS_AMD_NO_GRAPH'):
@@ -963,7 +1096,7 @@ class DistributedSwe2d(object):
     def _check_exchange(self):
         """A peer-to-peer wait that timed out (a lost or very late peer: bounded, counted, sticky - csrc/swe2d_p2p.h) leaves stale
         ghost values behind: every point where results leave the device raises instead of returning them."""
-        if self.p2p is not None:
+        if self.p2p is not None and self._distrust < 2:
             n = self.p2p.timeouts()
             if n:
                 raise RuntimeError('{:d} peer-to-peer halo waits timed out on rank {:d} (THETIS_AMD_P2P_TIMEOUT_S): the ghost cells '

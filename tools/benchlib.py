@@ -149,6 +149,56 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
     wanted = [forced] if forced else ['p2p'] + (['rccl'] if have_rccl else []) + ['host']
     digest_ref = None
 
+    # ---- soak (round 5): nine steps catch a transport that is broken, not one that delivers a wrong word once in 10^6 messages.
+    #      Every verified transport (and every flow candidate, which moves the halo itself) therefore also steps for >= soak_s
+    #      seconds (THETIS_AMD_SOAK_S, default 2; inside the set-up budget) and must end on the bits of a run that has NO exchange at
+    #      all: the whole mesh stepped by this rank's own GPU alone, the rank's owned rows hashed.  One reference serves all.
+    soak_s = float(os.environ.get('THETIS_AMD_SOAK_S', '2'))
+    soak = {'steps': 0, 'digest': None, 'seconds': soak_s, 'verified': [], 'reference_s': None}
+
+    def soak_reference(n_steps, solver):
+        from thetis_amd.device import Swe2dDevice
+        import hashlib
+        t0 = time.perf_counter()
+        one = Swe2dDevice(mesh, bath, dt, device_id=local_rank)
+        try:
+            one.set_state(uv, eta)
+            one.advance(n_steps)
+            u1, e1 = one.get_state()
+        finally:
+            one.close()
+        ids = solver.part.local_to_global[:solver.part.n_owned]
+        soak['reference_s'] = time.perf_counter() - t0
+        return hashlib.blake2b(np.ascontiguousarray(u1[ids]).tobytes() + np.ascontiguousarray(e1[ids]).tobytes(), digest_size=16).hexdigest()
+
+    def soak_run(s, label):
+        """steps `s` (already past its short check) from the initial state for the soak's step count and compares; collective"""
+        if soak_s <= 0 or world == 1:
+            return
+        if soak['digest'] is None:
+            # the step count: what the first soaked schedule needs for soak_s seconds (timed on 240 steps, max over ranks), a multiple of 24
+            s.set_state_global(uv, eta)
+            s.advance(240, use_graph=False)
+            s.synchronize()
+            agree.barrier()
+            t0 = time.perf_counter()
+            s.advance(240, use_graph=False)
+            s.synchronize()
+            t_step = agree.max(time.perf_counter() - t0)/240
+            soak['steps'] = int(min(400000, max(240, 24*int(np.ceil(soak_s/t_step/24)))))
+            soak['digest'] = soak_reference(soak['steps'], s)
+        s.set_state_global(uv, eta)
+        t0 = time.perf_counter()
+        s.advance(soak['steps'], use_graph=False)
+        s.synchronize()
+        took = agree.max(time.perf_counter() - t0)
+        if s.p2p is not None and s.p2p.timeouts():
+            raise RuntimeError('{:d} peer-to-peer waits timed out during the soak'.format(s.p2p.timeouts()))
+        if not agree.all_ok(state_digest(s) == soak['digest']):
+            raise RuntimeError('{:}: after {:d} steps ({:.1f} s) the state differs from the single-device run of the same mesh'.format(
+                label, soak['steps'], took))
+        soak['verified'].append({'what': label, 'steps': soak['steps'], 'seconds': took})
+
     def short_run(exchange):
         s = make(exchange, 2, 0, True, 'none')
         try:
@@ -156,7 +206,10 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
             s.synchronize()
             if s.p2p is not None and s.p2p.timeouts():
                 raise RuntimeError('{:d} peer-to-peer waits timed out'.format(s.p2p.timeouts()))
-            return state_digest(s)
+            dg = state_digest(s)
+            if exchange != 'host' and digest_ref is not None and agree.all_ok(dg == digest_ref):
+                soak_run(s, "transport '{:}'".format(exchange))
+            return dg
         finally:
             s.close()
 
@@ -242,6 +295,8 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
                     s.synchronize()
                     if not agree.all_ok(state_digest(s) == digest_ref):
                         raise RuntimeError('the flow path does not reproduce the host-staged exchange bit for bit')
+                    if bool(s.flow_exchange) and not any(v['what'].startswith('in-launch') for v in soak['verified']):
+                        soak_run(s, 'in-launch exchange of the flow kernel (m = {:d})'.format(every_c))
                     s.set_state_global(uv, eta)
                 s.advance(2000 if first else n_tune, use_graph=False)          # connections; clocks (first candidate)
                 s.synchronize()
@@ -297,7 +352,11 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
         if not ok:
             out = None
     if out is not None:
-        out['config'].update({'setup_s': setup_s, 'setup_budget_s': setup_budget, 'setup_skipped': skipped})
+        out['config'].update({'setup_s': setup_s, 'setup_budget_s': setup_budget, 'setup_skipped': skipped,
+                              'soak': {'seconds_asked': soak['seconds'], 'steps': soak['steps'], 'reference_s': soak['reference_s'],
+                                       'verified': soak['verified'],
+                                       'note': 'every entry stepped that long from the initial state and ended on the bits of the whole '
+                                               'mesh stepped by one GPU alone (no exchange of any kind)'}})
         # second, untuned timed region: an 8x larger mesh of the same channel (1 M triangles per rank at N = 8), where a rank is
         # bandwidth-bound like the single-GPU headline - it shows whether partitions, halo transport and graphs scale once the
         # latency floor of a 125 k-cell rank is out of the picture
