@@ -145,6 +145,13 @@ int  swe2d_get_state(swe2d_handle *h, double *uv, double *eta);
 /* the stage solution the reference assigns to `solution` after solve_stage(i_stage) (rungekutta.py:930-946): i_stage 0, 1 read
  * the buffers holding U1, U2; i_stage 2 (= swe2d_get_state) the step result */
 int  swe2d_get_stage_state(swe2d_handle *h, int i_stage, double *uv, double *eta);
+/* Save (restore = 0) / bring back (restore = 1) the time-stepping state - the step result and every tracer - in a device-side
+ * copy, exactly, without the host: for steps that have to be undone (graph capture warm-ups, verification replays, benchmarks).
+ * No reference counterpart (there `solution.assign(saved)` does it; here swe2d_get_state + swe2d_set_state is exact only without
+ * wetting-drying: with it the device carries the displaced depth D = (H + sqrt(H^2 + alpha^2))/2 instead of eta, which it hands
+ * out and takes in through the closed forms of thetis/utility.py:975-996 - the identity up to rounding, not bit for bit).
+ * Enqueued on the handle's stream. */
+int  swe2d_state_snapshot(swe2d_handle *h, int restore);
 
 /* TimeIntegrator.set_dt (timeintegrator.py:70-73) */
 int  swe2d_set_dt(swe2d_handle *h, double dt);

@@ -51,6 +51,7 @@ SYMBOLS = {
     'swe2d_set_state': (ctypes.c_int, [_H, _dp, _dp]),
     'swe2d_get_state': (ctypes.c_int, [_H, _dp, _dp]),
     'swe2d_get_stage_state': (ctypes.c_int, [_H, ctypes.c_int, _dp, _dp]),
+    'swe2d_state_snapshot': (ctypes.c_int, [_H, ctypes.c_int]),
     'swe2d_set_dt': (ctypes.c_int, [_H, ctypes.c_double]),
     'swe2d_set_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),
     'swe2d_set_bc_field': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),

@@ -81,6 +81,10 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     // 1 M 117.9 -> 117.8); both give the same bits.  THETIS_AMD_BND_INLINE=0 selects the epilogue variant (parity test, A/B).
     const char *env_binl_s = std::getenv("THETIS_AMD_BND_INLINE");       // read per launch: tests switch it inside one process
     const bool binl = !(env_binl_s && std::atoi(env_binl_s) == 0);
+    // Wetting-drying (round 5, the device carries D): the epilogue variant (158 VGPRs, 3 waves per SIMD) beats the boundary-inline
+    // one (190 VGPRs, 2 waves) - cfg 5 at 500 k cells 83.5 against 89.3 us per step, same box (profiles/r05c_cfg5.txt); with the
+    // eta-carrying kernels of rounds 2-4 the two ran the same.  THETIS_AMD_BND_INLINE=1 forces the inline variant (same bits).
+    const bool binl_wd = env_binl_s && std::atoi(env_binl_s) != 0;
     // ... and for launches whose state no longer fits the Infinity Cache (three buffers of 24 B per node against 256 MB: beyond
     // ~1.24 M triangles) with the in-wave neighbour traces exchanged through LDS (LDSX; THETIS_AMD_LDSX=0/1 forces the choice).
     // With the device's tile-Hilbert numbering and the alternating direction below, same box, us/step without / with:
@@ -92,7 +96,7 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     const bool ldsx = env_ldsx_s ? std::atoi(env_ldsx_s) != 0 : beyond_cache;
     stage_kernel_t kern = fused_visc
         ? pick_kernel_visc(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
-        : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4 ? (h->affine ? 1 : 2) : 0, binl)
+        : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4 ? (h->affine ? 1 : 2) : 0, binl_wd)
         : (h->npc == 4)
         ? pick_kernel_quad(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->affine)
         : pick_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), binl ? (ldsx ? 2 : 1) : 0);
@@ -466,7 +470,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->diag_acc, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->snapshot, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
     for (void *m : h->p2p.opened) (void)hipIpcCloseMemHandle(m);
@@ -509,7 +513,35 @@ int swe2d_set_state(swe2d_handle *hh, const double *uv, const double *eta)
                                 h->state[0], h->stride, h->cv, h->vh, h->valpha, h->n_cells, nullptr, nullptr);
         HIP_TRY(h, hipGetLastError());
     }
+    h->state_holds_D = h->wd;                      // wetting-drying: the elevation planes now hold the displaced depth D
     HIP_TRY(h, hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
+    return SWE2D_OK;
+}
+
+// Library-internal save / restore of the time-stepping state (buffer A and every tracer's buffer A) on the device: what graph
+// capture, verification replays and benchmarks need around steps they must undo.  Exact - unlike swe2d_get_state followed by
+// swe2d_set_state with wetting-drying, where the planes hold D and eta -> D -> eta is the identity only up to rounding.
+int swe2d_state_snapshot(swe2d_handle *hh, int restore)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nb = (size_t)3*h->npc*h->stride*sizeof(double), nt = (size_t)h->npc*h->stride*sizeof(double);
+    const size_t total = nb + h->tracers.size()*nt;
+    if (restore) {
+        if (!h->snapshot || h->snapshot_bytes != total) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_state_snapshot: nothing to restore");
+        HIP_TRY(h, hipMemcpyAsync(h->state[0], h->snapshot, nb, hipMemcpyDeviceToDevice, h->stream));
+        for (size_t t = 0; t < h->tracers.size(); t++)
+            HIP_TRY(h, hipMemcpyAsync(h->tracers[t].buf[0], (char *)h->snapshot + nb + t*nt, nt, hipMemcpyDeviceToDevice, h->stream));
+        h->state_holds_D = h->snapshot_holds_D;
+        return SWE2D_OK;
+    }
+    if (h->snapshot && h->snapshot_bytes != total) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->snapshot); h->snapshot = nullptr; }
+    if (!h->snapshot) { HIP_TRY(h, hipMalloc(&h->snapshot, total)); h->snapshot_bytes = total; }
+    HIP_TRY(h, hipMemcpyAsync(h->snapshot, h->state[0], nb, hipMemcpyDeviceToDevice, h->stream));
+    for (size_t t = 0; t < h->tracers.size(); t++)
+        HIP_TRY(h, hipMemcpyAsync((char *)h->snapshot + nb + t*nt, h->tracers[t].buf[0], nt, hipMemcpyDeviceToDevice, h->stream));
+    h->snapshot_holds_D = h->state_holds_D;
     return SWE2D_OK;
 }
 
@@ -522,8 +554,11 @@ int swe2d_get_stage_state(swe2d_handle *hh, int i_stage, double *uv, double *eta
     if (i_stage < 0 || i_stage > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "i_stage must be 0, 1 or 2");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t n = (size_t)h->n_cells*h->npc;
+    // (wetting-drying: the planes of all three buffers hold D, the host gets eta)
+    const bool isD = h->wd && (i_stage != 2 || h->state_holds_D);
     hipLaunchKernelGGL(swe_planes_to_aos, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
-                       h->state[(i_stage + 1) % 3], h->stage_uv, h->stage_eta, h->stride, h->n_cells, h->npc);
+                       h->state[(i_stage + 1) % 3], h->stage_uv, h->stage_eta, h->stride, h->n_cells, h->npc,
+                       isD ? h->cv : nullptr, isD ? h->vh : nullptr, isD ? h->valpha : nullptr);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(uv, h->stage_uv, 2*n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(eta, h->stage_eta, n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -702,17 +737,33 @@ int swe2d_set_wetting_and_drying(swe2d_handle *hh, int enable, const double *alp
 {
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
-    if (!enable) { h->wd = false; return SWE2D_OK; }
-    if (!alpha_vertex) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "alpha_vertex is required");
-    if (!h->par.use_nonlinear_equations)
-        return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "wetting and drying needs use_nonlinear_equations");
-    for (int i = 0; i < h->n_vertices; i++)
-        if (!(alpha_vertex[i] >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "alpha must be >= 0");
+    if (enable) {
+        if (!alpha_vertex) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "alpha_vertex is required");
+        if (!h->par.use_nonlinear_equations)
+            return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "wetting and drying needs use_nonlinear_equations");
+        for (int i = 0; i < h->n_vertices; i++)
+            if (!(alpha_vertex[i] >= 0.0)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "alpha must be >= 0");
+    }
     HIP_TRY(h, hipSetDevice(h->device));
+    // The device carries D (swe2d_kernels.h, swe_wd_eta) while wetting-drying is on.  A state that is resident when the switch or
+    // alpha changes keeps its ELEVATION: D -> eta with the alpha it was formed with, then eta -> D with the new one.
+    if (h->state_holds_D) {
+        hipLaunchKernelGGL(swe_wd_planes_to_eta, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream, h->state[0], h->stride, h->n_cells,
+                           h->npc, h->cv, h->vh, h->valpha);
+        HIP_TRY(h, hipGetLastError());
+        h->state_holds_D = false;
+    }
+    if (!enable) { h->wd = false; return SWE2D_OK; }
     if (!h->valpha) HIP_TRY(h, hipMalloc(&h->valpha, (size_t)h->n_vertices*sizeof(double)));
     HIP_TRY(h, hipMemcpyAsync(h->valpha, alpha_vertex, (size_t)h->n_vertices*sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->wd = true;
+    if (h->npc == 4) hipLaunchKernelGGL(swe_wd_clip_kernel<4>, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                                        h->state[0], h->stride, h->cv, h->vh, h->valpha, h->n_cells, h->affine ? nullptr : h->vx, h->vy);
+    else hipLaunchKernelGGL(swe_wd_clip_kernel<3>, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
+                            h->state[0], h->stride, h->cv, h->vh, h->valpha, h->n_cells, nullptr, nullptr);
+    HIP_TRY(h, hipGetLastError());
+    h->state_holds_D = true;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SWE2D_OK;
 }
 

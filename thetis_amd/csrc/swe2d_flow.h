@@ -224,11 +224,10 @@ __device__ __forceinline__ bool swe_flow_arrived(swe_u32x4 g, unsigned need)
 // neighbour's node on my node f + 1; u, v, e at its node on my node f} - the block's own stage values for a neighbour inside
 // the block (a boundary facet points at this cell itself), the incoming staging entry for a rim facet.
 // Lines as in swe_stage_kernel, same order.
-template <bool NONLIN, bool LF, bool SRC>
-__device__ __forceinline__ void swe_flow_rhs(const SweStageArgs &p, int k, const double u[3], const double v[3], const double e[3],
-                                             const double h[3], const double *lds, const unsigned tr[3][3], int bmarkers,
-                                             const double nx[3], const double ny[3], double twoA, double bu[3], double bv[3],
-                                             double be[3])
+template <bool NONLIN>
+__device__ __forceinline__ void swe_flow_rhs_cell(const SweStageArgs &p, const double u[3], const double v[3], const double e[3],
+                                                  const double h[3], const double nx[3], const double ny[3], double bu[3], double bv[3],
+                                                  double be[3])
 {
 #pragma clang fp contract(off)
     const double g = p.g;
@@ -239,27 +238,35 @@ __device__ __forceinline__ void swe_flow_rhs(const SweStageArgs &p, int k, const
         gxs[i] = -0.5*nx[(i + 1) % 3];                     // A*grad(phi_i) = -nF_{i+1}/2
         gys[i] = -0.5*ny[(i + 1) % 3];
     }
-    {
-        const double ge3 = g*(e[0] + e[1] + e[2])*(1.0/3.0);
-        const double SHu = swe_int2(H, u)*(1.0/12.0), SHv = swe_int2(H, v)*(1.0/12.0);
+    const double ge3 = g*(e[0] + e[1] + e[2])*(1.0/3.0);
+    const double SHu = swe_int2(H, u)*(1.0/12.0), SHv = swe_int2(H, v)*(1.0/12.0);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        bu[i] = gxs[i]*ge3;
+        bv[i] = gys[i]*ge3;
+        be[i] = swe_dot2(gxs[i], SHu, gys[i], SHv);
+    }
+    if (NONLIN) {
+        const double Suu = swe_int2(u, u)*(1.0/12.0), Suv = swe_int2(u, v)*(1.0/12.0), Svv = swe_int2(v, v)*(1.0/12.0);
+        const double D12 = fma(gys[2], v[2], fma(gys[1], v[1], fma(gys[0], v[0],
+                           fma(gxs[2], u[2], fma(gxs[1], u[1], gxs[0]*u[0])))))*(1.0/12.0);
+        const double us = u[0] + u[1] + u[2], vs = v[0] + v[1] + v[2];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            bu[i] = gxs[i]*ge3;
-            bv[i] = gys[i]*ge3;
-            be[i] = swe_dot2(gxs[i], SHu, gys[i], SHv);
-        }
-        if (NONLIN) {
-            const double Suu = swe_int2(u, u)*(1.0/12.0), Suv = swe_int2(u, v)*(1.0/12.0), Svv = swe_int2(v, v)*(1.0/12.0);
-            const double D12 = fma(gys[2], v[2], fma(gys[1], v[1], fma(gys[0], v[0],
-                               fma(gxs[2], u[2], fma(gxs[1], u[1], gxs[0]*u[0])))))*(1.0/12.0);
-            const double us = u[0] + u[1] + u[2], vs = v[0] + v[1] + v[2];
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                bu[i] = fma(gys[i], Suv, fma(gxs[i], Suu, fma(D12, us + u[i], bu[i])));
-                bv[i] = fma(gys[i], Svv, fma(gxs[i], Suv, fma(D12, vs + v[i], bv[i])));
-            }
+            bu[i] = fma(gys[i], Suv, fma(gxs[i], Suu, fma(D12, us + u[i], bu[i])));
+            bv[i] = fma(gys[i], Svv, fma(gxs[i], Suv, fma(D12, vs + v[i], bv[i])));
         }
     }
+}
+
+template <bool NONLIN, bool LF, bool SRC>
+__device__ __forceinline__ void swe_flow_rhs_facets(const SweStageArgs &p, int k, const double u[3], const double v[3], const double e[3],
+                                                    const double h[3], const double *lds, const unsigned tr[3][3], int bmarkers,
+                                                    const double nx[3], const double ny[3], double twoA, double bu[3], double bv[3],
+                                                    double be[3])
+{
+#pragma clang fp contract(off)
+    const double g = p.g;
 #pragma unroll
     for (int f = 0; f < 3; f++) {
         const int a = f, b = (f + 1) % 3;
@@ -279,7 +286,16 @@ __device__ __forceinline__ void swe_flow_rhs(const SweStageArgs &p, int k, const
         bv[a] = fma(-0.5, Fav, bv[a]); bv[b] = fma(-0.5, Fbv, bv[b]);
         be[a] = fma(-0.5, Fae, be[a]); be[b] = fma(-0.5, Fbe, be[b]);
     }
-    if (SRC) swe_source_terms(p, k, p.stride, twoA, u, v, H, gxs, gys, bu, bv, be);
+    if (SRC) {
+        double H[3], gxs[3], gys[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            H[i] = NONLIN ? h[i] + e[i] : h[i];
+            gxs[i] = -0.5*nx[(i + 1) % 3];
+            gys[i] = -0.5*ny[(i + 1) % 3];
+        }
+        swe_source_terms(p, k, p.stride, twoA, u, v, H, gxs, gys, bu, bv, be);
+    }
 }
 
 // mass inverse, Shu-Osher combine and the boundary facets of the cell (the BINL pass of swe_stage_kernel)
@@ -506,6 +522,38 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 #else
 #define SWE_FLOW_TORN_HERE(pc_, sys_) false
 #endif
+#ifdef SWE_FLOW_OLD_PUBLISH
+#define SWE_FLOW_PUBLISH_STORES(pc_) \
+        for (int t_ = lane; t_ < 8*nrim; t_ += SWE_BLOCK) {                                                                       \
+            const int gi_ = t_ & 7;                                                                                               \
+            const double x_ = gi_ < 6 ? lds[SWE_LDSI(SWE_FLOW_XG + 6*(t_ >> 3) + gi_, SWE_FLOW_LDS_DOUBLES)] : 0.0;               \
+            if (lpub[SWE_LDSI(t_ >> 3, SWE_FLOW_MAX_RIM)]) swe_flow_put(rex, par_ + 16u*(unsigned)t_, x_, tag_, SWE_FLOW_TORN_HERE(pc_, 0));   \
+        }
+#else
+#define SWE_FLOW_PUBLISH_STORES(pc_) \
+        /* SWE_FLOW_PUB granules per lane and trip: the LDS reads of a trip are issued together (unconditional, clamped indices), then the  \
+           stores - one LDS round trip per trip instead of one per granule (the rolled loop waited for every ds_read: eight          \
+           dependent LDS latencies in the publish of a block with 64 rim facets, profiles/r05b) */                                  \
+        for (int c0_ = 0; c0_ < 8*nrim; c0_ += SWE_FLOW_PUB*SWE_BLOCK) {                                                          \
+            double x_[SWE_FLOW_PUB];                                                                                              \
+            unsigned char p_[SWE_FLOW_PUB];                                                                                       \
+            _Pragma("unroll")                                                                                                     \
+            for (int j_ = 0; j_ < SWE_FLOW_PUB; j_++) {                                                                                   \
+                const int t_ = min(c0_ + j_*SWE_BLOCK + lane, 8*nrim - 1);                                                        \
+                const int gi_ = min(t_ & 7, 5);                                                                                   \
+                x_[j_] = lds[SWE_LDSI(SWE_FLOW_XG + 6*(t_ >> 3) + gi_, SWE_FLOW_LDS_DOUBLES)];                                    \
+                p_[j_] = lpub[SWE_LDSI(t_ >> 3, SWE_FLOW_MAX_RIM)];                                                               \
+            }                                                                                                                     \
+            _Pragma("unroll")                                                                                                     \
+            for (int j_ = 0; j_ < SWE_FLOW_PUB; j_++) {                                                                           \
+                const int t_ = c0_ + j_*SWE_BLOCK + lane;                                                                         \
+                if (t_ < 8*nrim && p_[j_]) swe_flow_put(rex, par_ + 16u*(unsigned)t_, (t_ & 7) < 6 ? x_[j_] : 0.0, tag_, SWE_FLOW_TORN_HERE(pc_, 0)); \
+            }                                                                                                                     \
+        }
+#endif
+#ifndef SWE_FLOW_PUB
+#define SWE_FLOW_PUB 4                     // granules per lane and trip of the publish loop
+#endif
 #define SWE_FLOW_PUBLISH(pu, pv, pe, who, pc_, set_) do {                                                                               \
         const unsigned tag_ = base + (unsigned)(pc_) + 1u;                                                                        \
         const unsigned par_ = (unsigned)(set_)*q.parity_bytes + (unsigned)myslots.x*SWE_FLOW_SLOT_BYTES;                    \
@@ -520,11 +568,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             if (xown[f] >= 0) lpub[SWE_LDSI(xown[f], SWE_FLOW_MAX_RIM)] = (who) ? 1 : 0;                                          \
         }                                                                                                                         \
         __syncthreads();                                                                                                          \
-        for (int t_ = lane; t_ < 8*nrim; t_ += SWE_BLOCK) {                                                                       \
-            const int gi_ = t_ & 7;                                                                                               \
-            const double x_ = gi_ < 6 ? lds[SWE_LDSI(SWE_FLOW_XG + 6*(t_ >> 3) + gi_, SWE_FLOW_LDS_DOUBLES)] : 0.0;                                               \
-            if (lpub[SWE_LDSI(t_ >> 3, SWE_FLOW_MAX_RIM)]) swe_flow_put(rex, par_ + 16u*(unsigned)t_, x_, tag_, SWE_FLOW_TORN_HERE(pc_, 0));   \
-        }                                                                                                                         \
+SWE_FLOW_PUBLISH_STORES(pc_)                                                            \
     } while (0)
 
 #pragma unroll 1
@@ -572,12 +616,38 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                 __syncthreads();
                 for (unsigned spins = 0;; spins++) {
                     bool ok = true;
+#ifdef SWE_FLOW_OLD_RXTX
                     for (int t = lane; t < 9*ng; t += SWE_BLOCK) {
                         const int cc = (t*7282) >> 16, gi = t - 9*cc;                              // t / 9, t % 9
                         const swe_u32x4 gz = swe_flow_get_sys(rz, lrec[SWE_LDSI(cc, SWE_BLOCK)] + 16u*(unsigned)gi);
                         ok = ok && swe_flow_arrived(gz, target);
                         lds[SWE_LDSI(SWE_FLOW_XG + t, SWE_FLOW_LDS_DOUBLES)] = swe_flow_val(gz);
                     }
+#else
+                    // the loads of a pass are issued TOGETHER (three per lane and trip: 21 ghost cells; a block next to a cut holds
+                    // ~30): one round trip to the zone - uncached memory the peers write over the fabric - per trip instead of one
+                    // per 64 granules (the rolled loop waited for every load before it issued the next, round 5)
+                    for (int c0 = 0; c0 < 9*ng; c0 += 3*SWE_BLOCK) {
+                        swe_u32x4 gz[3];
+                        unsigned zoff[3];
+#pragma unroll
+                        for (int j = 0; j < 3; j++) {
+                            const int t = min(c0 + j*SWE_BLOCK + lane, 9*ng - 1);
+                            const int cc = (t*7282) >> 16;                                         // t / 9
+                            zoff[j] = lrec[SWE_LDSI(cc, SWE_BLOCK)] + 16u*(unsigned)(t - 9*cc);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 3; j++) gz[j] = swe_flow_get_sys(rz, c0 + j*SWE_BLOCK + lane < 9*ng ? zoff[j] : SWE_FLOW_NOWHERE);
+#pragma unroll
+                        for (int j = 0; j < 3; j++) {
+                            const int t = c0 + j*SWE_BLOCK + lane;
+                            if (t < 9*ng) {
+                                ok = ok && swe_flow_arrived(gz[j], target);
+                                lds[SWE_LDSI(SWE_FLOW_XG + t, SWE_FLOW_LDS_DOUBLES)] = swe_flow_val(gz[j]);
+                            }
+                        }
+                    }
+#endif
                     if (__all(ok) || late) break;
                     __builtin_amdgcn_s_sleep(4);
                     if ((spins & 31u) == 31u) {
@@ -632,30 +702,63 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             lact[SWE_LDSI(lane, SWE_BLOCK)] = act ? 1 : 0;
             // ---- traces across the rim: the chunks the neighbour blocks wrote for this block, consecutive lanes on consecutive
             //      granules, re-read until every granule a cell of this stage's range needs carries this stage's tag
+            // The cell integrals need no neighbour: they are evaluated BEFORE the wave starts to wait for its rim granules (it would
+            // sleep in the polling loop otherwise), which takes them - a quarter of a stage's arithmetic - off the chain
+            // "neighbour publishes -> this block sees it -> computes -> publishes" that sets the period of a stage (round 5).
+            // Same operations in the same order as before: the same bits.
+            double bu[3], bv[3], be[3];
+            const double twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
+#define SWE_FLOW_CELL_TERMS_HERE swe_flow_rhs_cell<NONLIN>(p, u, v, e, h, nx, ny, bu, bv, be)
             if (FX || g > 0) {
                 SWE_FLOW_DELAY_AT(1);
                 const int pc_in = FX ? c*spc + g : g - 1;      // the publish this stage reads
                 const unsigned need = base + (unsigned)pc_in + 1u;
                 const unsigned par = ((FX && g == 0) ? 2u : ((unsigned)pc_in & 1u))*q.parity_bytes;       // a cycle's input has a slot set of its own
                 __syncthreads();                               // the incoming list / the previous stage's staging reads
+                // Where a trip's granules live: the incoming list and the cells' activity come from LDS by UNCONDITIONAL reads of
+                // clamped indices, all of a trip issued together (two LDS round trips per trip; inside `if`s the compiler waited for
+                // each read - sixteen dependent LDS latencies per polling pass, ~0.7 us of the 1.5 us between a neighbour's publish
+                // and this block seeing it, profiles/r05b).
+                unsigned poff[POLL];
+#define SWE_FLOW_POLL_OFFSETS(c0_) do {                                                                                               \
+                    int ent_[POLL], act_[POLL];                                                                                   \
+                    _Pragma("unroll")                                                                                             \
+                    for (int j = 0; j < POLL; j++) ent_[j] = xsrc[SWE_LDSI(min(((c0_) + j*SWE_BLOCK + lane) >> 3, SWE_FLOW_MAX_RIM - 1), SWE_FLOW_MAX_RIM)]; \
+                    _Pragma("unroll")                                                                                             \
+                    for (int j = 0; j < POLL; j++) act_[j] = lact[SWE_LDSI(ent_[j] & (SWE_BLOCK - 1), SWE_BLOCK)];                \
+                    _Pragma("unroll")                                                                                             \
+                    for (int j = 0; j < POLL; j++) {                                                                              \
+                        const int t = (c0_) + j*SWE_BLOCK + lane;                                                                 \
+                        /* a cell outside this stage's range needs nothing (and its neighbour may never have published) */        \
+                        poff[j] = (t < 8*nrim && act_[j]) ? (unsigned)(ent_[j] >> 6)*SWE_FLOW_SLOT_BYTES + 16u*(unsigned)(t & 7) + par : SWE_FLOW_NOWHERE; \
+                    }                                                                                                             \
+                } while (0)
+                // (computed once per stage outside the spin loop - eight registers across the loop - the kernel spills: 24-48 B/lane)
+#ifndef SWE_FLOW_LATE_CELL_TERMS
+                SWE_FLOW_CELL_TERMS_HERE;
+#endif
                 for (unsigned spins = 0;; spins++) {
                     bool ok = true;
                     for (int c0 = 0; c0 < 8*nrim; c0 += POLL*SWE_BLOCK) {      // POLL loads per lane in flight (8*POLL rim facets per trip)
                         swe_u32x4 gr[POLL];
-                        int ent[POLL];
+#ifdef SWE_FLOW_OLD_POLL
 #pragma unroll
-                        for (int j = 0; j < POLL; j++) {
+                        for (int j = 0; j < POLL; j++) {                       // round 4: a list entry and an activity read inside `if`s per load
                             const int t = c0 + j*SWE_BLOCK + lane;
-                            ent[j] = t < 8*nrim ? xsrc[SWE_LDSI(t >> 3, SWE_FLOW_MAX_RIM)] : -1;
-                            // a cell outside this stage's range needs nothing (and its neighbour may never have published)
-                            if (ent[j] >= 0 && !lact[SWE_LDSI(ent[j] & (SWE_BLOCK - 1), SWE_BLOCK)]) ent[j] = -1;
-                            gr[j] = swe_flow_get(rex, ent[j] >= 0 ? (unsigned)(ent[j] >> 6)*SWE_FLOW_SLOT_BYTES + 16u*(unsigned)(t & 7) + par
-                                                                  : SWE_FLOW_NOWHERE);
+                            int ent = t < 8*nrim ? xsrc[SWE_LDSI(t >> 3, SWE_FLOW_MAX_RIM)] : -1;
+                            if (ent >= 0 && !lact[SWE_LDSI(ent & (SWE_BLOCK - 1), SWE_BLOCK)]) ent = -1;
+                            poff[j] = ent >= 0 ? (unsigned)(ent >> 6)*SWE_FLOW_SLOT_BYTES + 16u*(unsigned)(t & 7) + par : SWE_FLOW_NOWHERE;
+                            gr[j] = swe_flow_get(rex, poff[j]);
                         }
+#else
+                        SWE_FLOW_POLL_OFFSETS(c0);
+#pragma unroll
+                        for (int j = 0; j < POLL; j++) gr[j] = swe_flow_get(rex, poff[j]);
+#endif
 #pragma unroll
                         for (int j = 0; j < POLL; j++) {
                             const int t = c0 + j*SWE_BLOCK + lane;
-                            if (ent[j] >= 0) {
+                            if (poff[j] != SWE_FLOW_NOWHERE) {
                                 ok = ok && swe_flow_arrived(gr[j], need);
                                 if ((t & 7) < 6) lds[SWE_LDSI(SWE_FLOW_XG + 6*(t >> 3) + (t & 7), SWE_FLOW_LDS_DOUBLES)] = swe_flow_val(gr[j]);
                             }
@@ -673,13 +776,27 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                     }
                 }
                 t_start = 0ull;
+#undef SWE_FLOW_POLL_OFFSETS
+            } else {
+#ifndef SWE_FLOW_LATE_CELL_TERMS
+                SWE_FLOW_CELL_TERMS_HERE;
+#endif
             }
             __syncthreads();
             SWE_FT(1);
             SWE_FT(2);
-            double bu[3], bv[3], be[3], ou[3], ov[3], oe[3], wu[3], wv[3], we[3];
-            const double twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
-            swe_flow_rhs<NONLIN, LF, SRC>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+            // From here to the publish the wave is on the chain that sets the period of a stage; the block it shares its SIMD with is
+            // most likely polling (cheap instructions in a loop, which take issue slots all the same): priority to the one that
+            // computes (-DSWE_FLOW_NO_PRIO: A/B)
+#ifndef SWE_FLOW_NO_PRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
+#ifdef SWE_FLOW_LATE_CELL_TERMS
+            SWE_FLOW_CELL_TERMS_HERE;
+#endif
+#undef SWE_FLOW_CELL_TERMS_HERE
+            double ou[3], ov[3], oe[3], wu[3], wv[3], we[3];
+            swe_flow_rhs_facets<NONLIN, LF, SRC>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
             // w = a0*U(0) + a1*U_in: the first stage of a step has no U(0) term (swe_stage_kernel<., ., HASU0 = false>)
             const double a0 = q.a0[i3], a1 = q.a1[i3];
 #pragma unroll
@@ -704,6 +821,9 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             //      publish, after the exchange; FX = false: nobody reads the last stage of the launch)
             SWE_FLOW_DELAY_AT(2);
             if (FX ? g + 1 < spc : s + 1 < q.n_stages) SWE_FLOW_PUBLISH(ou, ov, oe, act, FX ? c*spc + g + 1 : s, (FX ? c*spc + g + 1 : s) & 1);
+#ifndef SWE_FLOW_NO_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             // ---- the step result (every third stage) goes to state buffer 0: read by later launches only
             if (act && i3 == 2) {
                 const swe_rsrc_t gou = swe_rsrc(q.buf[0]), gov = swe_rsrc(q.buf[0] + 3*S), goe = swe_rsrc(q.buf[0] + 6*S);
@@ -757,10 +877,29 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
                 __syncthreads();
                 for (int pp = 0; pp < q.x_n_peers; pp++) {     // uniform: one buffer resource per peer
                     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(q.x_rdata[pp], 0, q.x_rbytes[pp], 0x00020000);
+#ifdef SWE_FLOW_OLD_RXTX
                     for (int t = lane; t < 9*ns; t += SWE_BLOCK) {
                         const int cc = (t*7282) >> 16, gi = t - 9*cc;
                         if (lpeer[SWE_LDSI(cc, SWE_BLOCK)] == pp) swe_flow_put_sys(rp, lrec[SWE_LDSI(cc, SWE_BLOCK)] + 16u*(unsigned)gi, lds[SWE_LDSI(SWE_FLOW_XG + t, SWE_FLOW_LDS_DOUBLES)], target, SWE_FLOW_TORN_HERE(c, 1));
                     }
+#else
+                    for (int c0 = 0; c0 < 9*ns; c0 += 3*SWE_BLOCK) {          // LDS reads of a trip together, then its stores
+                        double xv[3];
+                        unsigned zoff[3];
+                        int pr[3];
+#pragma unroll
+                        for (int j = 0; j < 3; j++) {
+                            const int t = min(c0 + j*SWE_BLOCK + lane, 9*ns - 1);
+                            const int cc = (t*7282) >> 16;
+                            pr[j] = lpeer[SWE_LDSI(cc, SWE_BLOCK)];
+                            zoff[j] = lrec[SWE_LDSI(cc, SWE_BLOCK)] + 16u*(unsigned)(t - 9*cc);
+                            xv[j] = lds[SWE_LDSI(SWE_FLOW_XG + t, SWE_FLOW_LDS_DOUBLES)];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 3; j++)
+                            if (c0 + j*SWE_BLOCK + lane < 9*ns && pr[j] == pp) swe_flow_put_sys(rp, zoff[j], xv[j], target, SWE_FLOW_TORN_HERE(c, 1));
+                    }
+#endif
                 }
             }
         }

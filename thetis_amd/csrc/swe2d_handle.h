@@ -143,6 +143,10 @@ struct Handle {
     double *bc_field[4] = {nullptr, nullptr, nullptr, nullptr};  // Function-valued boundary data per facet: elev, uv, un, flux
     double *valpha = nullptr;                          // per-vertex wetting-drying alpha
     bool wd = false;
+    bool state_holds_D = false;                        // wetting-drying: the elevation planes of buffer A hold the displaced depth D
+    void *snapshot = nullptr;                          // swe2d_state_snapshot: buffer A + the tracers' buffers A
+    size_t snapshot_bytes = 0;
+    bool snapshot_holds_D = false;
     // SIPG horizontal viscosity (optional pass after each stage kernel)
     bool visc = false;
     double *nu_v = nullptr;                            // per-vertex viscosity or null (constant)

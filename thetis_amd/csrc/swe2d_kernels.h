@@ -182,15 +182,26 @@ __device__ __forceinline__ double swe_wd_depth(double H, double a)
 {
     return 0.5*(H + swe_sqrt_sumsq(fma(H, H, a*a)));
 }
+// ROUND 5: with wetting-drying the DEVICE carries D, not eta.  The "elevation" planes of the three state buffers hold the nodal
+// displaced depth D (the quantity the explicit scheme advances: zeta = D - h), the elevation is recovered where the equations need
+// it - the pressure gradient and the elevation jumps of the fluxes - by eta = D - alpha^2/(4 D) - h: a reciprocal, where the
+// eta-carrying kernels of rounds 1-4 took twelve square roots per cell and stage to get D back (own nodes, U(0), six neighbour
+// nodes) and three reciprocals to store eta again.  Host layout and ABI are unchanged: swe2d_set_state converts eta -> D (and brings
+// it to the admissible set, swe_wd_clip_kernel), swe2d_get_state D -> eta (swe_planes_to_aos); eta -> D -> eta is the identity up
+// to rounding (one ulp of D), not bit for bit - library-internal save / restore goes through swe2d_state_snapshot instead.
+__device__ __forceinline__ double swe_wd_eta(double D, double h, double a)
+{
+    return D - 0.25*a*a*swe_rcp(D) - h;
+}
 
 // End of a wetting-drying stage in one cell (explicit formulation, oracle/swe2d_oracle.py module docstring and
-// SWEOracle.wd_finish_stage): oe[] holds zeta = D - h on entry and eta on exit.
+// SWEOracle.wd_finish_stage): oe[] holds zeta = D - h on entry and the limited depth D on exit (the state the device carries).
 //  (1) positivity limiter on the nodal depths: deviations from the cell mean scaled so that every node keeps
 //      D >= SWE_WD_FLOOR * alpha (mean unchanged = conservative); a cell whose mean is below the floor is flattened to its
 //      mean, below a tenth of the floor raised to that;
-//  (2) eta from D in closed form, H = D - alpha^2/(4 D);
+//  (2) [eta = D - alpha^2/(4 D) - h is no longer formed here: the device carries D]
 //  (3) relaxation of the velocity on dry ground: u *= exp(-dt_stage/tau psi^2), tau = SWE_WD_TAU sqrt(alpha/g),
-//      psi = clamp(-H/alpha - 1, 0, 1).
+//      psi = clamp(-H/alpha - 1, 0, 1), H = h + eta = D - alpha^2/(4 D).
 #define SWE_WD_FLOOR 0.1
 #define SWE_WD_TAU 10.0
 // ``mw``: weights of the cell mean (general quadrilaterals: int phi_i dx / area, swe_quad_mean_weights); nullptr: 1/K.
@@ -219,18 +230,17 @@ __device__ __forceinline__ void swe_wd_finish(double g, double dt_stage, const d
             for (int i = 0; i < K; i++) D[i] = mean + theta*(D[i] - mean);
         }
     }
-    // (quotients and the square root through the v_rcp / v_rsq helpers: this kernel is bound by its arithmetic)
-    const double rg = swe_rcp(g);
 #pragma unroll
     for (int i = 0; i < K; i++) {
-        const double eta = D[i] - 0.25*al[i]*al[i]*swe_rcp(D[i]) - h[i];
-        oe[i] = eta;
+        oe[i] = D[i];
         if (!relax) continue;      // viscous runs: the relaxation follows the viscosity pass (swe_wd_relax_kernel)
-        // psi > 0 <=> the water table lies more than alpha below the bed: decided without the quotient, which only dry nodes
-        // then pay for (a node within rounding of the threshold gets exp(-O(1e-32)) = 1 from the formula: the same bits)
-        if (-(h[i] + eta) > al[i]) {
+        // psi > 0 <=> the water table H = D - alpha^2/(4 D) lies more than alpha below the bed <=> alpha^2 > 4 D (D + alpha)
+        // (D > 0): decided without a quotient, which only dry nodes then pay for (a node within rounding of the threshold gets
+        // exp(-O(1e-32)) = 1 from the formula either way)
+        if (al[i]*al[i] > 4.0*D[i]*(D[i] + al[i])) {
             const double ral = swe_rcp(al[i]);
-            const double psi = fmin(1.0, fmax(0.0, -(h[i] + eta)*ral - 1.0));
+            const double Hw = D[i] - 0.25*al[i]*al[i]*swe_rcp(D[i]);
+            const double psi = fmin(1.0, fmax(0.0, -Hw*ral - 1.0));
             const double fac = exp(-dt_stage*(1.0/SWE_WD_TAU)*swe_sqrt(g*ral)*psi*psi);     // 1/sqrt(alpha/g) = sqrt(g/alpha)
             ou[i] *= fac;
             ov[i] *= fac;
@@ -797,9 +807,10 @@ __device__ __forceinline__ void swe_boundary_epilogue(const SweStageArgs &p, int
         const double ala = WD ? p.valpha[va] : 0.0, alb = WD ? p.valpha[vb] : 0.0;
         const double ua = p.uin[(size_t)a*S + k], ub = p.uin[(size_t)b*S + k];
         const double va_ = p.uin[(size_t)(3 + a)*S + k], vb_ = p.uin[(size_t)(3 + b)*S + k];
-        const double ea = p.uin[(size_t)(6 + a)*S + k], eb = p.uin[(size_t)(6 + b)*S + k];
-        const double Ha = WD ? swe_wd_depth(ha + ea, ala) : (NONLIN ? ha + ea : ha);
-        const double Hb = WD ? swe_wd_depth(hb + eb, alb) : (NONLIN ? hb + eb : hb);
+        const double da_ = p.uin[(size_t)(6 + a)*S + k], db_ = p.uin[(size_t)(6 + b)*S + k];      // eta, or D with wetting-drying
+        const double ea = WD ? swe_wd_eta(da_, ha, ala) : da_, eb = WD ? swe_wd_eta(db_, hb, alb) : db_;
+        const double Ha = WD ? da_ : (NONLIN ? ha + ea : ha);
+        const double Hb = WD ? db_ : (NONLIN ? hb + eb : hb);
         const double nxs = yb_ - ya_, nys = xa_ - xb_;
         double L, rL;
         swe_sqrt_rsqrt(swe_dot2(nxs, nxs, nys, nys), L, rL);
@@ -1128,11 +1139,12 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         py[i] = swe_ld(rvy, v8, 0);
         h[i] = swe_ld(rvh, v8, 0);
         if (WD) al[i] = swe_ld(swe_rsrc(p.valpha), v8, 0);
-        H[i] = WD ? swe_wd_depth(h[i] + e[i], al[i]) : (NONLIN ? h[i] + e[i] : h[i]);
-        if (WD) {           // the continuity equation advances zeta = D - h
+        if (WD) {           // the planes hold D (U(0)'s too); the continuity equation advances zeta = D - h
+            H[i] = e[i];
             we[i] = p.a1*(H[i] - h[i]);
-            if (HASU0) we[i] = fma(p.a0, swe_wd_depth(h[i] + e0[i], al[i]) - h[i], we[i]);
-        }
+            if (HASU0) we[i] = fma(p.a0, e0[i] - h[i], we[i]);
+            e[i] = swe_wd_eta(H[i], h[i], al[i]);
+        } else H[i] = NONLIN ? h[i] + e[i] : h[i];
     }
     SWE_WT_DRAIN();
     SWE_WT(2);
@@ -1195,11 +1207,12 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
         // keeps the branch: its traces stay live for swe_visc_interior and the branch-free form needs 256 VGPRs = 1 wave/SIMD,
         // 248 instead of 185-198 us/step at 1 M cells.)
         if (!(VISC || WD) || nb[f] >= 0) {
-            // neighbour's nodal depth on this facet (bathymetry and alpha are continuous: same vertices)
-            const double Dna = WD ? swe_wd_depth(h[a] + ena[f], al[a]) : 0.0;
-            const double Dnb = WD ? swe_wd_depth(h[b] + enb[f], al[b]) : 0.0;
+            // neighbour's nodal depth on this facet: what its planes hold; its elevation by the closed form (bathymetry and alpha
+            // are continuous: same vertices)
+            const double Dna = WD ? ena[f] : 0.0, Dnb = WD ? enb[f] : 0.0;
+            const double ena_ = WD ? swe_wd_eta(Dna, h[a], al[a]) : ena[f], enb_ = WD ? swe_wd_eta(Dnb, h[b], al[b]) : enb[f];
             swe_facet_flux<NONLIN, LF, WD>(g, p.sigma_lf, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b], una[f], unb[f],
-                                           vna[f], vnb[f], ena[f], enb[f], Dna, Dnb, nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
+                                           vna[f], vnb[f], ena_, enb_, Dna, Dnb, nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
         }
         if (nb[f] < 0) { Fau = 0.0; Fbu = 0.0; Fav = 0.0; Fbv = 0.0; Fae = 0.0; Fbe = 0.0; }   // see swe_boundary_epilogue / BINL
         bu[a] = fma(-0.5, Fau, bu[a]); bu[b] = fma(-0.5, Fbu, bu[b]);
@@ -1269,7 +1282,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     if (ou[0] == 1.2345e300) return;          // the arithmetic has to be finished before the time stamp
     SWE_WT(3);
 #endif
-    // zeta = D - h -> limited depth -> eta; dry-ground relaxation.  (Not for the parity hook swe2d_tendency, a0 = a1 = 0: it
+    // zeta = D - h -> limited depth D (stored); dry-ground relaxation.  (Not for the parity hook swe2d_tendency, a0 = a1 = 0: it
     // returns the raw tendencies of (u, v, zeta).)
     if (WD && !(p.a0 == 0.0 && p.a1 == 0.0)) swe_wd_finish<3>(g, p.beta*p.dt, h, al, ou, ov, oe, !p.wd_skip_relax);
 #pragma unroll
@@ -1295,14 +1308,34 @@ static __global__ void swe_aos_to_planes(const double *uv, const double *eta, do
     }
 }
 
-static __global__ void swe_planes_to_aos(const double *planes, double *uv, double *eta, size_t stride, int n, int npc)
+// valpha != nullptr: wetting-drying, the elevation planes hold the displaced depth D (swe_wd_eta): the host gets
+// eta = D - alpha^2/(4 D) - h (IEEE division: this is the boundary, not the hot path)
+static __global__ void swe_planes_to_aos(const double *planes, double *uv, double *eta, size_t stride, int n, int npc,
+                                         const int *cv = nullptr, const double *vh = nullptr, const double *valpha = nullptr)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
     for (int i = 0; i < npc; i++) {
         uv[2*((size_t)npc*k + i)] = planes[(size_t)i*stride + k];
         uv[2*((size_t)npc*k + i) + 1] = planes[(size_t)(npc + i)*stride + k];
-        eta[(size_t)npc*k + i] = planes[(size_t)(2*npc + i)*stride + k];
+        double e = planes[(size_t)(2*npc + i)*stride + k];
+        if (valpha) {
+            const int v = cv[(size_t)i*stride + k];
+            e = e - 0.25*valpha[v]*valpha[v]/e - vh[v];
+        }
+        eta[(size_t)npc*k + i] = e;
+    }
+}
+// the inverse of the above for buffers whose elevation planes hold D although wetting-drying is about to be switched off or its
+// alpha changed (swe2d_set_wetting_and_drying with a resident state): D -> eta in place
+static __global__ void swe_wd_planes_to_eta(double *planes, size_t stride, int n, int npc, const int *cv, const double *vh, const double *valpha)
+{
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    for (int i = 0; i < npc; i++) {
+        const int v = cv[(size_t)i*stride + k];
+        const double D = planes[(size_t)(2*npc + i)*stride + k];
+        planes[(size_t)(2*npc + i)*stride + k] = D - 0.25*valpha[v]*valpha[v]/D - vh[v];
     }
 }
 
@@ -1391,9 +1424,9 @@ static __global__ void swe_halo_unpack(double *planes, size_t stride, const int 
     planes[(size_t)q*stride + cells[j]] = buf[t];
 }
 
-// wetting-drying: bring a state handed in by the caller to the admissible set of the explicit scheme (every nodal depth through
-// the positivity limiter of swe_wd_finish; velocities untouched) - otherwise the first stage would do it and the volume of the
-// initial state would not be the volume the run conserves
+// wetting-drying: the elevation planes as handed in by the caller (eta) become the device's D planes, brought to the admissible
+// set of the explicit scheme (every nodal depth through the positivity limiter of swe_wd_finish; velocities untouched) - otherwise
+// the first stage would do it and the volume of the initial state would not be the volume the run conserves
 __device__ __forceinline__ void swe_quad_mean_weights(double d0, double d1, double d2, double w[4]);
 // (vx != nullptr: general quadrilaterals, the limiter's cell mean is mass-weighted)
 template <int K>
@@ -1431,9 +1464,9 @@ __global__ void swe_wd_relax_kernel(double *planes, size_t stride, const int *cv
     if (k >= c1) return;
     for (int i = 0; i < K; i++) {
         const int vtx = cv[(size_t)i*stride + k];
-        const double al = valpha[vtx], eta = planes[(size_t)(2*K + i)*stride + k];
+        const double al = valpha[vtx], D = planes[(size_t)(2*K + i)*stride + k];          // the planes hold D
         const double ral = swe_rcp(al);
-        const double psi = fmin(1.0, fmax(0.0, -(vh[vtx] + eta)*ral - 1.0));
+        const double psi = fmin(1.0, fmax(0.0, -(D - 0.25*al*al*swe_rcp(D))*ral - 1.0));
         if (psi > 0.0) {
             const double fac = exp(-dt_stage*(1.0/SWE_WD_TAU)*swe_sqrt(g*ral)*psi*psi);
             planes[(size_t)i*stride + k] *= fac;
@@ -1502,7 +1535,8 @@ static __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel(const double
             e[i] = planes[(size_t)(6 + i)*stride + k];
             const int vid = cv[(size_t)i*stride + k];
             px[i] = vx[vid]; py[i] = vy[vid]; h[i] = vh[vid];
-            h[i] = valpha ? swe_wd_depth(h[i] + e[i], valpha[vid]) : h[i] + e[i];      // nodal total depth
+            if (valpha) { const double D = e[i]; e[i] = D - 0.25*valpha[vid]*valpha[vid]/D - h[i]; h[i] = D; }   // the planes hold D
+            else h[i] = h[i] + e[i];                                                   // nodal total depth
         }
         const double A = 0.5*((px[1] - px[0])*(py[2] - py[0]) - (px[2] - px[0])*(py[1] - py[0]));
         s_e2 = A*(1.0/12.0)*swe_int2(e, e);
@@ -1773,7 +1807,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
             for (int i = 0; i < 3; i++) {
                 const double hh = p.vh[vid[i]];
                 const double ee = swe_ld(swe_rsrc(p.uv + 6*S), k8, i*S8);
-                H[i] = p.depth_mode == 2 ? swe_wd_depth(hh + ee, p.valpha[vid[i]]) : (p.depth_mode == 1 ? hh + ee : hh);
+                H[i] = p.depth_mode == 2 ? ee : (p.depth_mode == 1 ? hh + ee : hh);       // wetting-drying: the planes hold D
             }
             const double Hs = H[0] + H[1] + H[2], Hss = H[0]*s[0] + H[1]*s[1] + H[2]*s[2];
 #pragma unroll
@@ -1817,7 +1851,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
                         hq = xa*swe_ld(swe_rsrc(p.vh), va8, 0) + xb*swe_ld(swe_rsrc(p.vh), vb8, 0);
                         if (p.depth_mode == 2) alq = xa*swe_ld(swe_rsrc(p.valpha), va8, 0) + xb*swe_ld(swe_rsrc(p.valpha), vb8, 0);
                         const swe_rsrc_t ge = swe_rsrc(p.uv + 6*S);
-                        eq = xa*swe_ld(ge, k8, a*S8) + xb*swe_ld(ge, k8, bb*S8);
+                        double ea_ = swe_ld(ge, k8, a*S8), eb_ = swe_ld(ge, k8, bb*S8);
+                        if (p.depth_mode == 2) {           // the planes hold D: the nodal elevations by the closed form
+                            const double aa_ = swe_ld(swe_rsrc(p.valpha), va8, 0), ab_ = swe_ld(swe_rsrc(p.valpha), vb8, 0);
+                            ea_ = ea_ - 0.25*aa_*aa_/ea_ - swe_ld(swe_rsrc(p.vh), va8, 0);
+                            eb_ = eb_ - 0.25*ab_*ab_/eb_ - swe_ld(swe_rsrc(p.vh), vb8, 0);
+                        }
+                        eq = xa*ea_ + xb*eb_;
                     }
                     fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys, hq, eq, alq, xa, xb, k, f, 3, S);
                 } else {
@@ -1931,7 +1971,7 @@ static __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel(const
             const int vid = cv[(size_t)i*stride + k];
             px[i] = vx[vid]; py[i] = vy[vid];
             H[i] = vh[vid] + (nonlinear ? state[(size_t)(6 + i)*stride + k] : 0.0);
-            if (valpha) H[i] = swe_wd_depth(H[i], valpha[vid]);        // total depth with wetting-drying: the displaced depth D
+            if (valpha) H[i] = state[(size_t)(6 + i)*stride + k];      // total depth with wetting-drying: the displaced depth D the planes hold
         }
         const double A = 0.5*((px[1] - px[0])*(py[2] - py[0]) - (px[2] - px[0])*(py[1] - py[0]));
         s_m = A*(1.0/12.0)*swe_int2(c, H);
@@ -2130,11 +2170,12 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         py[i] = swe_ld(swe_rsrc(p.vy), v8, 0);
         h[i] = swe_ld(swe_rsrc(p.vh), v8, 0);
         if (WD) al[i] = swe_ld(swe_rsrc(p.valpha), v8, 0);
-        H[i] = WD ? swe_wd_depth(h[i] + e[i], al[i]) : (NONLIN ? h[i] + e[i] : h[i]);
-        if (WD) {           // the continuity equation advances zeta = D - h
+        if (WD) {           // the planes hold D (U(0)'s too); the continuity equation advances zeta = D - h
+            H[i] = e[i];
             we[i] = p.a1*(H[i] - h[i]);
-            if (HASU0) we[i] = fma(p.a0, swe_wd_depth(h[i] + e0[i], al[i]) - h[i], we[i]);
-        }
+            if (HASU0) we[i] = fma(p.a0, e0[i] - h[i], we[i]);
+            e[i] = swe_wd_eta(H[i], h[i], al[i]);
+        } else H[i] = NONLIN ? h[i] + e[i] : h[i];
     }
     const double ax = px[1] - px[0], ay = py[1] - py[0];
     const double bx = px[3] - px[0], by = py[3] - py[0];
@@ -2157,11 +2198,12 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         swe_sqrt_rsqrt(len2, L, rL);
         double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
         {   // branch-free (see swe_stage_kernel): a boundary facet carries the cell's own values as traces, its flux is discarded
-            // neighbour's nodal depth on this facet (bathymetry and alpha are continuous: same vertices)
-            const double Dna = WD ? swe_wd_depth(h[a] + ena[f], al[a]) : 0.0;
-            const double Dnb = WD ? swe_wd_depth(h[b] + enb[f], al[b]) : 0.0;
+            // neighbour's nodal depth on this facet: what its planes hold; its elevation by the closed form (bathymetry and alpha
+            // are continuous: same vertices)
+            const double Dna = WD ? ena[f] : 0.0, Dnb = WD ? enb[f] : 0.0;
+            const double ena_ = WD ? swe_wd_eta(Dna, h[a], al[a]) : ena[f], enb_ = WD ? swe_wd_eta(Dnb, h[b], al[b]) : enb[f];
             swe_facet_flux<NONLIN, LF, WD>(g, p.sigma_lf, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b], una[f], unb[f],
-                                           vna[f], vnb[f], ena[f], enb[f], Dna, Dnb, nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
+                                           vna[f], vnb[f], ena_, enb_, Dna, Dnb, nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
         }
         if (nb[f] < 0) {
             // boundary facets inline: this kernel runs at 2 waves/SIMD either way, and the post-compute epilogue of the
@@ -2346,7 +2388,8 @@ static __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel_quad(const d
             e[i] = planes[(size_t)(8 + i)*stride + k];
             const int vid = cv[(size_t)i*stride + k];
             px[i] = vx[vid]; py[i] = vy[vid]; h[i] = vh[vid];
-            h[i] = valpha ? swe_wd_depth(h[i] + e[i], valpha[vid]) : h[i] + e[i];      // nodal total depth
+            if (valpha) { const double D = e[i]; e[i] = D - 0.25*valpha[vid]*valpha[vid]/D - h[i]; h[i] = D; }   // the planes hold D
+            else h[i] = h[i] + e[i];                                                   // nodal total depth
         }
         const double A = (px[1] - px[0])*(py[3] - py[0]) - (py[1] - py[0])*(px[3] - px[0]);
         if (affine) {
@@ -2464,7 +2507,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
                 for (int i = 0; i < 4; i++) {
                     const double hh = p.vh[vid[i]];
                     const double ee = swe_ld(swe_rsrc(p.uv + 8*S), k8, i*S8);
-                    Hq += phi[i]*(p.depth_mode == 2 ? swe_wd_depth(hh + ee, p.valpha[vid[i]]) : (p.depth_mode == 1 ? hh + ee : hh));
+                    Hq += phi[i]*(p.depth_mode == 2 ? ee : (p.depth_mode == 1 ? hh + ee : hh));      // wetting-drying: the planes hold D
                 }
                 sq *= Hq;
             }
@@ -2506,7 +2549,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
                         hq = xa*swe_ld(swe_rsrc(p.vh), va8, 0) + xb*swe_ld(swe_rsrc(p.vh), vb8, 0);
                         if (p.depth_mode == 2) alq = xa*swe_ld(swe_rsrc(p.valpha), va8, 0) + xb*swe_ld(swe_rsrc(p.valpha), vb8, 0);
                         const swe_rsrc_t ge = swe_rsrc(p.uv + 8*S);
-                        eq = xa*swe_ld(ge, k8, a*S8) + xb*swe_ld(ge, k8, bb*S8);
+                        double ea_ = swe_ld(ge, k8, a*S8), eb_ = swe_ld(ge, k8, bb*S8);
+                        if (p.depth_mode == 2) {           // the planes hold D: the nodal elevations by the closed form
+                            const double aa_ = swe_ld(swe_rsrc(p.valpha), va8, 0), ab_ = swe_ld(swe_rsrc(p.valpha), vb8, 0);
+                            ea_ = ea_ - 0.25*aa_*aa_/ea_ - swe_ld(swe_rsrc(p.vh), va8, 0);
+                            eb_ = eb_ - 0.25*ab_*ab_/eb_ - swe_ld(swe_rsrc(p.vh), vb8, 0);
+                        }
+                        eq = xa*ea_ + xb*eb_;
                     }
                     fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys, hq, eq, alq, xa, xb, k, f, 4, S);
                 } else {
@@ -2563,7 +2612,7 @@ static __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_diag_kernel_quad(
             const int vid = cv[(size_t)i*stride + k];
             px[i] = vx[vid]; py[i] = vy[vid];
             H[i] = vh[vid] + (nonlinear ? state[(size_t)(8 + i)*stride + k] : 0.0);
-            if (valpha) H[i] = swe_wd_depth(H[i], valpha[vid]);
+            if (valpha) H[i] = state[(size_t)(8 + i)*stride + k];      // wetting-drying: the displaced depth D the planes hold
         }
         const double A = (px[1] - px[0])*(py[3] - py[0]) - (py[1] - py[0])*(px[3] - px[0]);
         if (affine) {

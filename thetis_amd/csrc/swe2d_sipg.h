@@ -130,20 +130,24 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
 #pragma unroll
             for (int i = 0; i < 3; i++) b[r][i] = BND_ONLY ? 0.0 : -am*(gx[i]*S0[r][0] + gy[i]*S0[r][1]);     // inner(grad test, stress)*dx
     }
-    double eo[3] = {0.0, 0.0, 0.0}, ho[3] = {0.0, 0.0, 0.0}, alo[3] = {0.0, 0.0, 0.0};
+    double eo[3] = {0.0, 0.0, 0.0}, ho[3] = {0.0, 0.0, 0.0}, alo[3] = {0.0, 0.0, 0.0}, dno[3] = {0.0, 0.0, 0.0};
     if (NC == 2) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             ho[i] = swe_ld(swe_rsrc(p.vh), (unsigned)vid[i]*8u, 0);
             eo[i] = swe_ld(swe_rsrc(p.eta), k8, i*S8);
-            if (p.wd) alo[i] = swe_ld(swe_rsrc(p.valpha), (unsigned)vid[i]*8u, 0);
+            if (p.wd) {                      // the planes hold the displaced depth D (swe2d_kernels.h, swe_wd_eta)
+                alo[i] = swe_ld(swe_rsrc(p.valpha), (unsigned)vid[i]*8u, 0);
+                dno[i] = eo[i];
+                eo[i] = dno[i] - 0.25*alo[i]*alo[i]/dno[i] - ho[i];
+            }
         }
     }
     if (NC == 2 && p.grad_depth && !BND_ONLY) {
         // -dot(test, dot(grad(H)/H, stress))*dx, shallowwater_eq.py:611-612; 6-point rule as the drag terms
         double Hn[3];
 #pragma unroll
-        for (int i = 0; i < 3; i++) Hn[i] = p.wd ? swe_wd_depth(ho[i] + eo[i], alo[i]) : (p.nonlin ? ho[i] + eo[i] : ho[i]);
+        for (int i = 0; i < 3; i++) Hn[i] = p.wd ? dno[i] : (p.nonlin ? ho[i] + eo[i] : ho[i]);
         const double gHx = Hn[0]*gx[0] + Hn[1]*gx[1] + Hn[2]*gx[2], gHy = Hn[0]*gy[0] + Hn[1]*gy[1] + Hn[2]*gy[2];
         double t[2];
 #pragma unroll
@@ -306,7 +310,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel(const SweSipgArgs p
                             const double hq = xa*swe_ld(swe_rsrc(p.vh), va8, 0) + xb*swe_ld(swe_rsrc(p.vh), vb8, 0);
                             const double alq = p.depth_mode == 2
                                 ? xa*swe_ld(swe_rsrc(p.valpha), va8, 0) + xb*swe_ld(swe_rsrc(p.valpha), vb8, 0) : 0.0;
-                            const double eq = xa*p.uv[(size_t)(6 + a)*S + k] + xb*p.uv[(size_t)(6 + bb)*S + k];
+                            double ea_ = p.uv[(size_t)(6 + a)*S + k], eb_ = p.uv[(size_t)(6 + bb)*S + k];
+                            if (p.depth_mode == 2) {           // the planes hold D: the nodal elevations by the closed form
+                                const double aa_ = swe_ld(swe_rsrc(p.valpha), va8, 0), ab_ = swe_ld(swe_rsrc(p.valpha), vb8, 0);
+                                ea_ = ea_ - 0.25*aa_*aa_/ea_ - swe_ld(swe_rsrc(p.vh), va8, 0);
+                                eb_ = eb_ - 0.25*ab_*ab_/eb_ - swe_ld(swe_rsrc(p.vh), vb8, 0);
+                            }
+                            const double eq = xa*ea_ + xb*eb_;
                             const double sp = swe_tracer_flux_speed(p.depth_mode, hq, eq, alq, p.bc_vel_kind[marker] == 4,
                                                                     p.bc_v[marker], p.bc_u[marker], p.bc.len[marker], p.vel_factor);
                             ue = sp*n0; ve = sp*n1;
@@ -404,13 +414,17 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
     const double cx = AFFINE ? 0.0 : (px[0] - px[1]) + (px[2] - px[3]), cy = AFFINE ? 0.0 : (py[0] - py[1]) + (py[2] - py[3]);
     const double d1 = AFFINE ? 0.0 : ax*cy - ay*cx, d2 = AFFINE ? 0.0 : cx*by - cy*bx;
     const double A = AFFINE ? A0 : A0 + 0.5*(d1 + d2);                       // cell area
-    double eo[4] = {0.0, 0.0, 0.0, 0.0}, ho[4] = {0.0, 0.0, 0.0, 0.0}, alo[4] = {0.0, 0.0, 0.0, 0.0};
+    double eo[4] = {0.0, 0.0, 0.0, 0.0}, ho[4] = {0.0, 0.0, 0.0, 0.0}, alo[4] = {0.0, 0.0, 0.0, 0.0}, dno[4] = {0.0, 0.0, 0.0, 0.0};
     if (NC == 2) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             ho[i] = swe_ld(swe_rsrc(p.vh), (unsigned)vid[i]*8u, 0);
             eo[i] = swe_ld(swe_rsrc(p.eta), k8, i*S8);
-            if (p.wd) alo[i] = swe_ld(swe_rsrc(p.valpha), (unsigned)vid[i]*8u, 0);
+            if (p.wd) {                      // the planes hold the displaced depth D (swe2d_kernels.h, swe_wd_eta)
+                alo[i] = swe_ld(swe_rsrc(p.valpha), (unsigned)vid[i]*8u, 0);
+                dno[i] = eo[i];
+                eo[i] = dno[i] - 0.25*alo[i]*alo[i]/dno[i] - ho[i];
+            }
         }
     }
     double b[NC][4];
@@ -433,7 +447,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
             for (int i = 0; i < 4; i++) {
                 muq += phi[i]*mu[i];
                 if (NC == 2 && p.grad_depth) {
-                    const double Hn = p.wd ? swe_wd_depth(ho[i] + eo[i], alo[i]) : (p.nonlin ? ho[i] + eo[i] : ho[i]);
+                    const double Hn = p.wd ? dno[i] : (p.nonlin ? ho[i] + eo[i] : ho[i]);
                     Hq += phi[i]*Hn; gHx += gx[i]*Hn; gHy += gy[i]*Hn;
                 }
             }
@@ -626,7 +640,13 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_sipg_kernel_quad(const SweSipgA
                             const double hq = xa*swe_ld(swe_rsrc(p.vh), va8, 0) + xb*swe_ld(swe_rsrc(p.vh), vb8, 0);
                             const double alq = p.depth_mode == 2
                                 ? xa*swe_ld(swe_rsrc(p.valpha), va8, 0) + xb*swe_ld(swe_rsrc(p.valpha), vb8, 0) : 0.0;
-                            const double eq = xa*p.uv[(size_t)(8 + a)*S + k] + xb*p.uv[(size_t)(8 + bb)*S + k];
+                            double ea_ = p.uv[(size_t)(8 + a)*S + k], eb_ = p.uv[(size_t)(8 + bb)*S + k];
+                            if (p.depth_mode == 2) {           // the planes hold D: the nodal elevations by the closed form
+                                const double aa_ = swe_ld(swe_rsrc(p.valpha), va8, 0), ab_ = swe_ld(swe_rsrc(p.valpha), vb8, 0);
+                                ea_ = ea_ - 0.25*aa_*aa_/ea_ - swe_ld(swe_rsrc(p.vh), va8, 0);
+                                eb_ = eb_ - 0.25*ab_*ab_/eb_ - swe_ld(swe_rsrc(p.vh), vb8, 0);
+                            }
+                            const double eq = xa*ea_ + xb*eb_;
                             const double sp = swe_tracer_flux_speed(p.depth_mode, hq, eq, alq, p.bc_vel_kind[marker] == 4,
                                                                     p.bc_v[marker], p.bc_u[marker], p.bc.len[marker], p.vel_factor);
                             ue = sp*n0; ve = sp*n1;

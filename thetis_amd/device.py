@@ -178,6 +178,14 @@ class Swe2dDevice(object):
             uv, eta = uv[self.inv_perm], eta[self.inv_perm]
         return uv, eta
 
+    def snapshot(self):
+        """Save the time-stepping state (and every tracer) in a device-side copy; ``restore`` brings it back - exactly, also with
+        wetting-drying, where ``set_state(*get_state())`` is the identity only up to rounding (the device carries D, not eta)."""
+        self._ck(self.lib.swe2d_state_snapshot(self.h, 0))
+
+    def restore(self):
+        self._ck(self.lib.swe2d_state_snapshot(self.h, 1))
+
     def set_dt(self, dt):
         self._ck(self.lib.swe2d_set_dt(self.h, float(dt)))
 

@@ -852,7 +852,8 @@ class DistributedSwe2d(object):
         while n_steps > 0:
             if self._v_snapshot is None:
                 self.synchronize()
-                self._v_snapshot = (self.dev.get_state(), [self.dev.tracer_get_state(tid) for tid in self.tids])
+                self.dev.snapshot()                      # on the device: exact also with wetting-drying (the device carries D)
+                self._v_snapshot = True
                 self._v_steps = 0
             r = min(n_steps, ve - self._v_steps)
             self._advance(r, use_graph)
@@ -874,12 +875,9 @@ class DistributedSwe2d(object):
             fast = self._local_digest()
         except RuntimeError as e:                        # a wait of the fast path timed out: a mismatch by definition
             fast = 'timeout: {:}'.format(e)
-        (uv0, eta0), tr0 = self._v_snapshot
         n = self._v_steps
         self._v_snapshot, self._v_steps = None, 0
-        self.dev.set_state(uv0, eta0)
-        for tid, T in zip(self.tids, tr0):
-            self.dev.tracer_set_state(tid, T)
+        self.dev.restore()
         self._replaying = True
         try:
             with self._stream_ctx():
@@ -1051,22 +1049,19 @@ class DistributedSwe2d(object):
         with torch.cuda.stream(self.stream):
             if self.graph_mode == 'cycle' and not (self.tids or self.tracer_only):
                 # build the per-cycle graphs of this step count's schedule by running it once (state restored)
-                saved = self.dev.get_state()
+                self.dev.snapshot()
                 self._steps_eager(1)                     # RCCL connections, module loading: never inside a capture
                 self._steps_eager(n_steps, graphed=True)
                 torch.cuda.synchronize()
-                self.dev.set_state(*saved)
+                self.dev.restore()
                 return
             try:
                 g = torch.cuda.CUDAGraph()
                 # warm-up outside capture (RCCL connection set-up must not happen inside a capture); everything it steps is put back
-                saved = self.dev.get_state()
-                saved_t = [self.dev.tracer_get_state(tid) for tid in self.tids]
+                self.dev.snapshot()                      # (state and tracers, on the device: exact also with wetting-drying)
                 self._steps_eager(1)
                 torch.cuda.synchronize()
-                self.dev.set_state(*saved)
-                for tid, T in zip(self.tids, saved_t):
-                    self.dev.tracer_set_state(tid, T)
+                self.dev.restore()
                 with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
                     self._steps_eager(n_steps)
                 self.graph = g

@@ -46,7 +46,7 @@ def main():
     class LoopbackP2P(object):
         """every peer's landing segment is my own: the push kernel stores into this device's zone, the wait finds the flags
         it raised itself (strips: what I send to a peer is as long as what I receive from it)"""
-        def __init__(self, dev, part, rank, world, n_tracers=0, group=None):
+        def __init__(self, dev, part, rank, world, n_tracers=0, group=None, local_error=None):
             k = int(part.cells.shape[1])
             self.dev, self.n_channels = dev, 1
             dev.p2p_create([3*k] + ([18] if k == 3 else []))
