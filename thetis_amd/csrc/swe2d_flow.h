@@ -522,38 +522,16 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 #else
 #define SWE_FLOW_TORN_HERE(pc_, sys_) false
 #endif
-#ifdef SWE_FLOW_OLD_PUBLISH
+// (Measured and not kept, round 5: the LDS reads of a trip of the store loop issued together - four granules per lane and trip,
+//  clamped indices - instead of one read, wait and store per granule: 19.3 against 19.3 us per step for rank 3 of eight, 17.2
+//  against 17.1 on one device at 125 k cells, and 92 instead of 28 B/lane of scratch in the source-term + exchange variant;
+//  profiles/r05d_flow_loops_ab.txt.)
 #define SWE_FLOW_PUBLISH_STORES(pc_) \
         for (int t_ = lane; t_ < 8*nrim; t_ += SWE_BLOCK) {                                                                       \
             const int gi_ = t_ & 7;                                                                                               \
             const double x_ = gi_ < 6 ? lds[SWE_LDSI(SWE_FLOW_XG + 6*(t_ >> 3) + gi_, SWE_FLOW_LDS_DOUBLES)] : 0.0;               \
             if (lpub[SWE_LDSI(t_ >> 3, SWE_FLOW_MAX_RIM)]) swe_flow_put(rex, par_ + 16u*(unsigned)t_, x_, tag_, SWE_FLOW_TORN_HERE(pc_, 0));   \
         }
-#else
-#define SWE_FLOW_PUBLISH_STORES(pc_) \
-        /* SWE_FLOW_PUB granules per lane and trip: the LDS reads of a trip are issued together (unconditional, clamped indices), then the  \
-           stores - one LDS round trip per trip instead of one per granule (the rolled loop waited for every ds_read: eight          \
-           dependent LDS latencies in the publish of a block with 64 rim facets, profiles/r05b) */                                  \
-        for (int c0_ = 0; c0_ < 8*nrim; c0_ += SWE_FLOW_PUB*SWE_BLOCK) {                                                          \
-            double x_[SWE_FLOW_PUB];                                                                                              \
-            unsigned char p_[SWE_FLOW_PUB];                                                                                       \
-            _Pragma("unroll")                                                                                                     \
-            for (int j_ = 0; j_ < SWE_FLOW_PUB; j_++) {                                                                                   \
-                const int t_ = min(c0_ + j_*SWE_BLOCK + lane, 8*nrim - 1);                                                        \
-                const int gi_ = min(t_ & 7, 5);                                                                                   \
-                x_[j_] = lds[SWE_LDSI(SWE_FLOW_XG + 6*(t_ >> 3) + gi_, SWE_FLOW_LDS_DOUBLES)];                                    \
-                p_[j_] = lpub[SWE_LDSI(t_ >> 3, SWE_FLOW_MAX_RIM)];                                                               \
-            }                                                                                                                     \
-            _Pragma("unroll")                                                                                                     \
-            for (int j_ = 0; j_ < SWE_FLOW_PUB; j_++) {                                                                           \
-                const int t_ = c0_ + j_*SWE_BLOCK + lane;                                                                         \
-                if (t_ < 8*nrim && p_[j_]) swe_flow_put(rex, par_ + 16u*(unsigned)t_, (t_ & 7) < 6 ? x_[j_] : 0.0, tag_, SWE_FLOW_TORN_HERE(pc_, 0)); \
-            }                                                                                                                     \
-        }
-#endif
-#ifndef SWE_FLOW_PUB
-#define SWE_FLOW_PUB 4                     // granules per lane and trip of the publish loop
-#endif
 #define SWE_FLOW_PUBLISH(pu, pv, pe, who, pc_, set_) do {                                                                               \
         const unsigned tag_ = base + (unsigned)(pc_) + 1u;                                                                        \
         const unsigned par_ = (unsigned)(set_)*q.parity_bytes + (unsigned)myslots.x*SWE_FLOW_SLOT_BYTES;                    \
