@@ -218,12 +218,13 @@ int  swe2d_diagnostics(swe2d_handle *h, double out[4]);
 /* The same integrals as order-independent sums, for runs partitioned over several handles / ranks (the reference all-reduces its
  * diagnostics over the MPI ranks, thetis/callback.py:478-482; a floating-point all-reduce would make the printed norms and the
  * conservation checks depend on the partition in their last digits): every cell's contribution is split exactly into four
- * signed 38-bit limbs of units 2^40, 2^2, 2^-36, 2^-74 and the limbs are summed as integers.  limbs[4 q + j] = limb j of
+ * signed 38-bit limbs of units 2^40, 2^2, 2^-36, 2^-74, 2^-112, 2^-150 (what a term has below 2^-150 ~ 7e-46 is dropped) and the limbs are
+ * summed as integers.  limbs[6 q + j] = limb j of
  * quantity q (int eta^2, int |u|^2, int (eta+h)); add the limbs of all partitions (int64, any order), then
  * swe2d_sum_limbs_to_double rounds a total to the nearest double.  swe2d_diagnostics returns exactly that for its own handle, so
  * one handle over the whole mesh and N handles over its partitions give identical doubles. */
-int  swe2d_diagnostics_limbs(swe2d_handle *h, int64_t limbs[12], double *min_depth);
-double swe2d_sum_limbs_to_double(const int64_t limbs[4]);
+int  swe2d_diagnostics_limbs(swe2d_handle *h, int64_t limbs[18], double *min_depth);
+double swe2d_sum_limbs_to_double(const int64_t limbs[6]);
 
 /* ---- SIPG horizontal viscosity: HorizontalViscosityTerm (thetis/shallowwater_eq.py:554-616), fields['viscosity_h'] =
  * options.horizontal_viscosity (solver2d.py:551).  nu is a constant (nu_vertex == NULL) or a continuous P1 field given per
@@ -300,7 +301,7 @@ int  swe2d_tracer_limit(swe2d_handle *h, int tracer_id);                        
 /* out = { int T*H dx (comp_tracer_mass_2d, utility.py:437-445), int T dx, min nodal T, max nodal T } */
 int  swe2d_tracer_diagnostics(swe2d_handle *h, int tracer_id, double out[4]);
 /* limb sums (see swe2d_diagnostics_limbs) of { int T*H dx, int T dx } + { min, max } of the owned cells */
-int  swe2d_tracer_diagnostics_limbs(swe2d_handle *h, int tracer_id, int64_t limbs[8], double minmax[2]);
+int  swe2d_tracer_diagnostics_limbs(swe2d_handle *h, int tracer_id, int64_t limbs[12], double minmax[2]);
 /* GeneralCoupledTimeIntegrator2D.advance (coupled_timeintegrator_2d.py:93-113) x n_steps: SWE step (unless tracer_only),
  * then every tracer with the updated velocity, then the limiter (once per step) */
 int  swe2d_advance_coupled(swe2d_handle *h, int n_steps, int tracer_only, int use_limiter);
@@ -361,8 +362,12 @@ int  swe2d_swap_state_buffers(swe2d_handle *h);
  * are not produced.  swe2d_advance uses it on its own where it applies (THETIS_AMD_FLOW=0: never).  Needs every block of the
  * handle resident at once:
  * swe2d_flow_supported returns 0 when the mesh is too large for that (or the configuration is not covered: quadrilaterals,
- * wetting-drying, viscosity), 1 covered, 2 covered and without source terms; SWE2D_ERR_UNSUPPORTED from swe2d_solve_flow
- * otherwise.  Every wait inside the kernel is bounded (THETIS_AMD_FLOW_TIMEOUT_S, default 2 s); a timeout invalidates the
+ * wetting-drying, viscosity), 1 covered, 2 covered and without source terms; 3 / 4 (round 5, only with THETIS_AMD_MFLOW=1 in the
+ * environment - measured slower than the stage launches, kept as an option): the same through the multi-block kernel
+ * (csrc/swe2d_mflow.h: a wave owns up to 8 consecutive 64-cell blocks and keeps their stage values in the state buffers like
+ * the stage launches do - cell ranges up to 8 x the one-block limit; swe2d_solve_flow and swe2d_advance take it on their own, the
+ * exchange inside the launch, swe2d_solve_flow_exchange, is not available there, and the stage buffers 1, 2 ARE written);
+ * SWE2D_ERR_UNSUPPORTED from swe2d_solve_flow otherwise.  Every wait inside the kernel is bounded (THETIS_AMD_FLOW_TIMEOUT_S, default 2 s); a timeout invalidates the
  * state and is reported as SWE2D_ERR_HIP by the next swe2d_synchronize / swe2d_get_state / swe2d_diagnostics
  * (swe2d_flow_status reads the count without failing). */
 int  swe2d_solve_flow(swe2d_handle *h, int32_t n_stages, const int32_t *cell_end);

@@ -226,11 +226,11 @@ class CpuSwe2dDevice(object):
 
     @staticmethod
     def _limbs(x):
-        """the limb sums of include/swe2d.h (swe2d_diagnostics_limbs) of the terms ``x``: units 2^40, 2^2, 2^-36, 2^-74"""
+        """the limb sums of include/swe2d.h (swe2d_diagnostics_limbs) of the terms ``x``: units 2^40, 2^2, 2^-36, 2^-74, 2^-112, 2^-150"""
         x = np.asarray(x, dtype=np.float64).copy()
         assert (np.abs(x) < 2.0**78).all()
-        out = np.zeros(4, dtype=np.int64)
-        for j, s in enumerate((40, 2, -36, -74)):
+        out = np.zeros(6, dtype=np.int64)
+        for j, s in enumerate((40, 2, -36, -74, -112, -150)):
             t = np.trunc(np.ldexp(x, -s))
             out[j] = int(t.astype(np.int64).sum())
             x -= np.ldexp(t, s)
@@ -240,7 +240,7 @@ class CpuSwe2dDevice(object):
     def limbs_to_double(limbs):
         """exact total of limb sums, rounded once (Fraction -> float is correctly rounded)"""
         from fractions import Fraction
-        v = sum(Fraction(int(l))*Fraction(2)**s for l, s in zip(np.asarray(limbs).reshape(4), (40, 2, -36, -74)))
+        v = sum(Fraction(int(l))*Fraction(2)**s for l, s in zip(np.asarray(limbs).reshape(6), (40, 2, -36, -74, -112, -150)))
         return float(v)
 
     def diagnostics_limbs(self):

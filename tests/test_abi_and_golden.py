@@ -147,16 +147,22 @@ def test_limb_sums_round_to_the_nearest_double():
     lib = _lib.load()
     rng = np.random.default_rng(5)
 
-    def exact(limbs):
-        return float(sum(Fraction(int(l))*Fraction(2)**s for l, s in zip(limbs, (40, 2, -36, -74))))
+    units = (40, 2, -36, -74, -112, -150)
 
-    cases = [[0, 0, 0, 0], [0, 0, 0, 1], [0, 0, 0, -1], [1, 0, 0, 0], [-1, 0, 0, 1], [0, 0, 1 << 37, 1], [0, (1 << 53) + 1, 0, 0],
-             [1 << 13, 0, 0, 1], [1 << 13, 0, 0, -1], [-(1 << 20), 3, -5, 7], [0, 1 << 52, 1 << 36, 0], [0, 1 << 52, 1 << 36, 1],
-             [0, (1 << 52) + 1, 1 << 36, 0], [(1 << 62) - 1, (1 << 62) - 1, (1 << 62) - 1, (1 << 62) - 1],
-             [-(1 << 62), -(1 << 62), -(1 << 62), -(1 << 62)]]
-    for _ in range(2000):
-        mag = rng.integers(1, 62, size=4)
-        cases.append([int(rng.integers(-(1 << m), 1 << m)) if rng.random() > 0.2 else 0 for m in mag])
+    def exact(limbs):
+        return float(sum(Fraction(int(l))*Fraction(2)**s for l, s in zip(limbs, units)))
+
+    four = [[0, 0, 0, 0], [0, 0, 0, 1], [0, 0, 0, -1], [1, 0, 0, 0], [-1, 0, 0, 1], [0, 0, 1 << 37, 1], [0, (1 << 53) + 1, 0, 0],
+            [1 << 13, 0, 0, 1], [1 << 13, 0, 0, -1], [-(1 << 20), 3, -5, 7], [0, 1 << 52, 1 << 36, 0], [0, 1 << 52, 1 << 36, 1],
+            [0, (1 << 52) + 1, 1 << 36, 0], [(1 << 62) - 1, (1 << 62) - 1, (1 << 62) - 1, (1 << 62) - 1],
+            [-(1 << 62), -(1 << 62), -(1 << 62), -(1 << 62)]]
+    # the round-4 cases in the upper four limbs, in the lower four, and with a lone unit far below them (a sticky bit that decides a tie)
+    cases = [c + [0, 0] for c in four] + [[0, 0] + c for c in four] + [c + [0, 1] for c in four] + [c + [0, -1] for c in four]
+    cases += [[0, 0, 0, 0, 0, 1], [0, 0, 0, 0, 0, -1], [0, 0, 0, 0, 1, 0], [-1, 0, 0, 0, 0, 1], [1, 0, 0, 0, 0, -1], [0, -1, 0, 0, 0, 1],
+              [(1 << 62) - 1]*6, [-(1 << 62)]*6, [1 << 52, 0, 0, 0, 0, 1], [(1 << 53) + 1, 0, 0, 0, 0, 0], [0, 0, 0, (1 << 53) + 1, 0, 0]]
+    for _ in range(3000):
+        mag = rng.integers(1, 62, size=6)
+        cases.append([int(rng.integers(-(1 << m), 1 << m)) if rng.random() > 0.35 else 0 for m in mag])
     for c in cases:
         a = np.array(c, dtype=np.int64)
         got = lib.swe2d_sum_limbs_to_double(a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))

@@ -546,3 +546,36 @@ def test_closed_wall_path_gives_the_bits_of_the_general_boundary_path(hip_lib, m
     assert np.isfinite(out[0][0]).all() and np.isfinite(out[0][1]).all()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][2][0], out[1][2][0]) and np.array_equal(out[0][2][1], out[1][2][1])
+
+
+@pytest.mark.parametrize('cells', ['triangles', 'quadrilaterals'])
+def test_diagnostics_of_small_fields_on_small_cells_keep_their_digits(hip_lib, cells):
+    """the order-independent limb sums had a floor of 2^-74 ~ 5e-23 per cell term - a lake-at-rest residual of 1e-14 on a
+    unit-square mesh with 1e-4 cells (eta^2 A ~ 1e-32) summed to exactly 0 where the reference's floating-point all-reduce keeps
+    the value (thetis/solver2d.py:955-956, callback.py:478-482).  With six limbs (floor 2^-150) the integrals of such fields agree
+    with the plain sums to rounding."""
+    from thetis_amd.mesh import RectangleMesh
+    mesh = RectangleMesh(100, 100, 1.0, 1.0, quadrilateral=(cells == 'quadrilaterals'))
+    n, k = mesh.cells.shape
+    rng = np.random.default_rng(3)
+    eta = 1e-14*rng.uniform(-1, 1, size=(n, k))
+    uv = 1e-12*rng.uniform(-1, 1, size=(n, k, 2))
+    dev = _device(mesh, np.ones(mesh.num_vertices), 1e-3)
+    dev.set_state(uv, eta)
+    d = dev.diagnostics()
+    dev.close()
+    xy = mesh.vertex_xy[mesh.cells]
+    if k == 3:
+        area = 0.5*np.abs((xy[:, 1, 0] - xy[:, 0, 0])*(xy[:, 2, 1] - xy[:, 0, 1]) - (xy[:, 2, 0] - xy[:, 0, 0])*(xy[:, 1, 1] - xy[:, 0, 1]))
+        m = (np.ones((3, 3)) + np.eye(3))/12.0
+    else:
+        area = np.abs((xy[:, 1, 0] - xy[:, 0, 0])*(xy[:, 3, 1] - xy[:, 0, 1]) - (xy[:, 1, 1] - xy[:, 0, 1])*(xy[:, 3, 0] - xy[:, 0, 0]))
+        m1 = np.array([[2.0, 1.0], [1.0, 2.0]])/6.0
+        # cyclic node order 0 (0,0), 1 (1,0), 2 (1,1), 3 (0,1): tensor mass matrix in that order
+        pos = [(0, 0), (1, 0), (1, 1), (0, 1)]
+        m = np.array([[m1[a[0], b[0]]*m1[a[1], b[1]] for b in pos] for a in pos])
+    e2 = float(np.sum(area*np.einsum('ci,ij,cj->c', eta, m, eta)))
+    u2 = float(np.sum(area*(np.einsum('ci,ij,cj->c', uv[..., 0], m, uv[..., 0]) + np.einsum('ci,ij,cj->c', uv[..., 1], m, uv[..., 1]))))
+    assert e2 > 0 and abs(d[0] - e2) <= 1e-12*e2, (d[0], e2)
+    assert abs(d[1] - u2) <= 1e-12*u2, (d[1], u2)
+    assert abs(d[2] - 1.0) < 1e-13           # volume: int (eta + h) over the unit square

@@ -411,3 +411,63 @@ def test_balzano_cfg5_full_tidal_cycle_volume_budget(hip_lib):
     # the boundary tide is back at mean water level; the basin lags it on the ebb (free surface 0 ... 0.47 m above it in the
     # CPU run on 48 x 24): +8 % of volume
     assert 0.0 < (d1[2] - d0[2])/d0[2] < 0.15
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('quad', [False, True])
+def test_device_carries_the_displaced_depth_and_hands_out_the_elevation(hip_lib, ref_so, quad):
+    """Round 5: with wetting-drying the device's elevation planes hold D = (H + sqrt(H^2 + alpha^2))/2 (csrc/swe2d_kernels.h,
+    swe_wd_eta).  What must hold at the boundary: (1) get_state after set_state returns the admissible elevation to rounding;
+    (2) get / set round trips stay put to rounding and do not drift; (3) snapshot / restore is EXACT - ten steps, restore, the same
+    ten steps again give the same bits; (4) switching wetting-drying on AFTER the state was set, or changing alpha under a resident
+    state, keeps the elevation: the same run to rounding as with the switch set first; (5) switching it off hands the state back
+    as elevations."""
+    from thetis_amd import _lib
+    from thetis_amd.device import Swe2dDevice
+    mesh, bath, alpha_v, uv, eta = _beach(quad)
+    orc = _oracle(mesh, bath, alpha_v, **_KW)
+    eta_adm = orc.wd_clip_state(eta)
+
+    def device(wd_first):
+        dev = Swe2dDevice(mesh, bath, 2.0)
+        if wd_first:
+            dev.set_wetting_and_drying(alpha_v)
+        dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+        for m, funcs in _KW['bnd_conditions'].items():
+            dev.set_bc(m, funcs)
+        return dev
+    dev = device(True)
+    dev.set_state(uv, eta)
+    u1, e1 = dev.get_state()
+    assert np.array_equal(u1, uv) and np.abs(e1 - eta_adm).max() < 1e-13                       # (1)
+    e_rt = e1
+    for _ in range(5):                                                                        # (2)
+        dev.set_state(u1, e_rt)
+        e_rt = dev.get_state()[1]
+    # (eta = D - alpha^2/(4 D) - h: one ulp of D is up to 1 + alpha^2/(4 D^2) = 26 ulps of eta at the hard floor D = 0.1 alpha)
+    assert np.abs(e_rt - e1).max() <= 1e-13
+    dev.set_state(uv, eta)
+    dev.snapshot()                                                                            # (3)
+    dev.advance(10)
+    a = dev.get_state()
+    dev.restore()
+    dev.advance(10)
+    b = dev.get_state()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    dev.close()
+    dev2 = device(False)                                                                      # (4) the switch after the state
+    dev2.set_state(uv, eta_adm)
+    dev2.set_wetting_and_drying(alpha_v)
+    assert np.abs(dev2.get_state()[1] - eta_adm).max() < 1e-13
+    dev2.advance(10)
+    c = dev2.get_state()
+    assert rel_linf(c[0], a[0]) < 1e-11 and rel_linf(c[1], a[1]) < 1e-11
+    # ... alpha changed under the resident state: the elevation stays what it was
+    e_before = dev2.get_state()[1]
+    dev2.set_wetting_and_drying(1.5*alpha_v)
+    e_after = dev2.get_state()[1]
+    orc15 = _oracle(mesh, bath, 1.5*alpha_v, **_KW)
+    assert np.abs(e_after - orc15.wd_clip_state(e_before)).max() < 1e-12
+    dev2.set_wetting_and_drying(None)                                                         # (5)
+    assert np.abs(dev2.get_state()[1] - e_after).max() < 1e-13
+    dev2.close()

@@ -14,7 +14,10 @@ Importing this package never loads the HIP extension; creating a time stepper do
 Several GPUs: the same script under ``python -m torch.distributed.run --nproc-per-node N script.py`` (one process per GPU) is
 domain-decomposed as ``mpiexec -n N`` does it for the reference (thetis_amd/comm.py, thetis_amd/spmd.py).
 """
+import os  # noqa: F401  (the reference's scripts use os.getenv after `from thetis import *`)
+
 from . import solver2d  # noqa: F401
+from .expr import *  # noqa: F401,F403  (SpatialCoordinate, conditional, as_vector, sin, cos, exp, sqrt, pi ...)
 from .function import Function, FunctionSpace, get_functionspace  # noqa: F401
 from .mesh import Mesh2d, PeriodicRectangleMesh, RectangleMesh, SquareMesh, UnitSquareMesh  # noqa: F401
 from .meshio import read_gmsh, write_gmsh  # noqa: F401

@@ -820,7 +820,16 @@ int swe2d_advance(swe2d_handle *hh, int n_steps)
     {
         const char *env_fl = std::getenv("THETIS_AMD_FLOW");
         const bool want = env_fl ? std::atoi(env_fl) != 0 : true;
-        if (want && n_steps > 0 && flow_kernel_covers(h) && ((h->flow_blocks + 7)/8)*8 <= flow_capacity(h)) {
+        // ... and with several blocks per wave (swe2d_mflow.h) where the mesh is larger than that but a visit is still latency, not
+        // bandwidth: up to THETIS_AMD_MFLOW_ADVANCE_K blocks per wave (default 4: ~520 k cells)
+        bool covered = want && n_steps > 0 && flow_kernel_covers(h);
+        if (covered && ((h->flow_blocks + 7)/8)*8 > flow_capacity(h)) {
+            const char *ek = std::getenv("THETIS_AMD_MFLOW_ADVANCE_K");
+            const int kmax = ek ? std::atoi(ek) : 4;
+            const int K = mflow_blocks_per_wave(h);
+            covered = K > 0 && K <= kmax;
+        }
+        if (covered) {
             int32_t ends[SWE_FLOW_MAX_STAGES];
             for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) ends[s] = h->n_owned;
             for (int done = 0; done < n_steps;) {
@@ -945,28 +954,52 @@ int swe2d_tendency(swe2d_handle *hh, double *k_uv, double *k_eta)
     return SWE2D_OK;
 }
 
-// The total of limb sums (swe_sum_accumulate) rounded to the nearest double (ties to even), exactly: a pure function of the four
+// The total of limb sums (swe_sum_accumulate) rounded to the nearest double (ties to even), exactly: a pure function of the six
 // integers, so a sum taken over one device and the same sum taken over the partitions of eight agree in every bit.
-double swe2d_sum_limbs_to_double(const int64_t limbs[4])
+//   V = sum_j L_j 2^(40 - 38 j),  j = 0 .. 5
+double swe2d_sum_limbs_to_double(const int64_t limbs[SWE_SUM_LIMBS])
 {
-    // carry-normalise: 0 <= L1, L2, L3 < 2^38, L0 signed;  V = L0 2^40 + L1 2^2 + L2 2^-36 + L3 2^-74
-    int64_t L[4] = {limbs[0], limbs[1], limbs[2], limbs[3]};
-    for (int j = 3; j > 0; j--) {
-        const int64_t carry = L[j] >> 38;                     // arithmetic shift: floor
-        L[j] -= carry*((int64_t)1 << 38);
-        L[j - 1] += carry;
+    constexpr int N = SWE_SUM_LIMBS;
+    // carry-normalise: 0 <= L_1 .. L_5 < 2^38, L_0 signed (the sums of at most 2^25 limbs of 38 bits fit 64 bits with room)
+    int64_t L[N];
+    for (int j = 0; j < N; j++) L[j] = limbs[j];
+    auto normalise = [&]() {
+        for (int j = N - 1; j > 0; j--) {
+            const int64_t carry = L[j] >> 38;                 // arithmetic shift: floor
+            L[j] -= carry*((int64_t)1 << 38);
+            L[j - 1] += carry;
+        }
+    };
+    normalise();
+    const bool neg = L[0] < 0;
+    if (neg) { for (int j = 0; j < N; j++) L[j] = -L[j]; normalise(); }      // |V|: now every limb is >= 0
+    int t = 0;
+    while (t < N && L[t] == 0) t++;
+    if (t == N) return neg ? -0.0 : 0.0;
+    // the three leading limbs (114 bits, at least 77 of them significant once L_0 needs more than one: L_0 < 2^63 -> take it apart)
+    unsigned __int128 T;
+    int unit;                                                 // exponent of T's last bit
+    bool sticky = false;
+    if (t == 0 && (L[0] >> 38) != 0) {
+        // a top limb wider than 38 bits (up to 63): T = L_0 2^38 + L_1 (101 bits), the rest is sticky
+        T = ((unsigned __int128)(uint64_t)L[0] << 38) | (uint64_t)L[1];
+        unit = 40 - 38;
+        for (int j = 2; j < N; j++) sticky = sticky || L[j] != 0;
+    } else {
+        const int64_t a = L[t], b = t + 1 < N ? L[t + 1] : 0, c = t + 2 < N ? L[t + 2] : 0;
+        T = ((unsigned __int128)(uint64_t)a << 76) | ((unsigned __int128)(uint64_t)b << 38) | (uint64_t)c;
+        unit = 40 - 38*(t + 2);
+        for (int j = t + 3; j < N; j++) sticky = sticky || L[j] != 0;
     }
-    const __int128 hi = (__int128)L[0]*((__int128)1 << 38) + L[1];                      // units of 2^2
-    const unsigned __int128 lo = ((unsigned __int128)(uint64_t)L[2] << 38) | (uint64_t)L[3];   // units of 2^-74, < 2^76
-    if (hi == 0) return std::ldexp((double)lo, -74);          // 76 bits -> double: correctly rounded by the conversion
-    // hi != 0:  V = (hi + f) 2^2, 0 <= f = lo 2^-76 < 1.  T = floor((hi + f) 2^s) with as many bits of f as fit into 127 bits, and a
-    // sticky bit for the rest: T has >= 77 significant bits, the sticky bit sits far below the rounding position
+    // T has at most 114 bits; bring its leading bit up to bit 120 so that a sticky bit at position 0 sits at least 60 bits below the
+    // rounding position of the conversion (the compiler's 128-bit -> double conversion rounds to nearest even)
     int bits = 0;
-    for (unsigned __int128 m = (unsigned __int128)(hi < 0 ? -hi : hi); m; m >>= 1) bits++;
-    const int sft = std::min(76, 125 - bits);
-    __int128 T = hi*((__int128)1 << sft) + (__int128)(lo >> (76 - sft));
-    if (sft < 76 && (lo & (((unsigned __int128)1 << (76 - sft)) - 1)) != 0) T |= 1;
-    return std::ldexp((double)T, 2 - sft);
+    for (unsigned __int128 m = T; m; m >>= 1) bits++;
+    const int sft = 120 - bits;
+    T <<= sft;
+    if (sticky) T |= 1;
+    const double r = std::ldexp((double)T, unit - sft);
+    return neg ? -r : r;
 }
 
 namespace {
@@ -1002,7 +1035,7 @@ int run_diagnostics(Handle *h, int64_t limbs[3*SWE_SUM_LIMBS], double *min_depth
 }
 }  // namespace
 
-int swe2d_diagnostics_limbs(swe2d_handle *hh, int64_t limbs[12], double *min_depth)
+int swe2d_diagnostics_limbs(swe2d_handle *hh, int64_t limbs[3*SWE_SUM_LIMBS], double *min_depth)
 {
     Handle *h = H(hh);
     if (!h || !limbs || !min_depth) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");

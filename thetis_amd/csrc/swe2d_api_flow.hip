@@ -141,6 +141,38 @@ int flow_capacity(Handle *h)
     return h->flow_capacity;
 }
 
+// ... and of the multi-block kernel (swe2d_mflow.h), whose waves own several blocks each
+int mflow_capacity(Handle *h)
+{
+    if (h->mflow_capacity >= 0) return h->mflow_capacity;
+    h->mflow_capacity = 0;
+    int per_cu = 0, dev_cus = 0;
+    flow_kernel_t kern = pick_mflow_kernel(true, true, true, true);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), SWE_BLOCK, 0) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) return 0;
+    if (const char *e = std::getenv("THETIS_AMD_MFLOW_CAPACITY")) h->mflow_capacity = std::atoi(e);    // tests: force the limit
+    else h->mflow_capacity = per_cu*dev_cus;
+    return h->mflow_capacity;
+}
+
+// blocks per wave of a multi-block launch (0: the range does not fit, or the kernel is switched off): as few as keep every wave
+// resident.  OPT-IN, THETIS_AMD_MFLOW=1: measured slower than the stage launches it was built to replace at every size it applies to
+// (profiles/r05e_multi_block_flow.txt: one device 250 k / 500 k / 1 M cells 53.5 / 106 / 258 against 37.0 / 63.0 / 114 us per step, a
+// rank of four 62.4 against 42.3, a rank of two 108.7 against 67.9 - a visit of a block costs its polling pass and its publish,
+// ~2.2 us, on top of the dependent loads of a stage launch, which is more than the launch boundary shared by the ~4 visits a SIMD
+// makes per stage).  THETIS_AMD_MFLOW_MAX_K bounds K (default 8).
+int mflow_blocks_per_wave(Handle *h)
+{
+    const char *on = std::getenv("THETIS_AMD_MFLOW");
+    if (!on || std::atoi(on) == 0) return 0;
+    const int cap = (mflow_capacity(h)/8)*8;                   // the XCD-chunked block map needs a grid that is a multiple of 8
+    if (cap <= 0) return 0;
+    int kmax = 8;
+    if (const char *e = std::getenv("THETIS_AMD_MFLOW_MAX_K")) kmax = std::max(1, std::atoi(e));
+    const int K = std::max(2, (h->flow_blocks + cap - 1)/cap);   // (asked for because one block per wave does not fit: at least two)
+    return K <= kmax ? K : 0;
+}
+
 // FX launches: the places of every flow position's cell in the halo lists, the blocks that hold send / ghost cells
 int flow_build_exchange(Handle *h)
 {
@@ -187,8 +219,19 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles)
     for (int s = 0; s < n_stages; s++)
         if (cell_end[s] < 0 || cell_end[s] > h->n_cells || (s > 0 && cell_end[s] > cell_end[s - 1]))
             return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "flow: the stage ranges must shrink and stay inside the mesh");
-    const int grid = ((h->flow_blocks + 7)/8)*8;
-    if (grid > flow_capacity(h)) return fail(h, SWE2D_ERR_UNSUPPORTED, "flow: more 64-cell blocks than the device holds resident at once");
+    int grid = ((h->flow_blocks + 7)/8)*8;
+    int K = 1;                                                 // blocks per wave: 1 = swe_flow_kernel, > 1 = swe_mflow_kernel
+    if (grid > flow_capacity(h)) {
+        K = fx ? 0 : mflow_blocks_per_wave(h);
+        if (K <= 0) return fail(h, SWE2D_ERR_UNSUPPORTED, fx ? "flow with the exchange inside: more 64-cell blocks than the device holds resident at once"
+                                                              : "flow: more 64-cell blocks than the device holds resident, also with several blocks per wave");
+        grid = (((h->flow_blocks + K - 1)/K + 7)/8)*8;
+    } else if (!fx) {
+        if (const char *e = std::getenv("THETIS_AMD_MFLOW_FORCE_K")) {       // tests / A-B: the multi-block kernel on a range the one-block kernel covers
+            K = std::max(1, std::atoi(e));
+            if (K > 1) grid = (((h->flow_blocks + K - 1)/K + 7)/8)*8;
+        }
+    }
     SweFlowArgs q{};
     if (fx) {
         auto &z = h->p2p;
@@ -224,11 +267,14 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles)
     q.xblk = h->flow_xblk; q.xsrc = h->flow_xsrc; q.parity_bytes = h->flow_parity_bytes;
     q.fcell = h->flow_cell;
     q.n_blocks = h->flow_blocks; q.n_stages = total;
+    q.blocks_per_wave = K;
     for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) q.cell_end[s] = s < n_stages ? cell_end[s] : 0;
     for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
     q.timeout_ticks = (unsigned long long)(h->flow_timeout_s*1e8);
-    flow_kernel_t kern = pick_flow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h), fx,
-                                          h->flow_max_rim > 64);
+    flow_kernel_t kern = K > 1 ? pick_mflow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h),
+                                                   h->flow_max_rim > 64)
+                               : pick_flow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h), fx,
+                                                  h->flow_max_rim > 64);
     SWE_CHK_SYNC(h->stream);
     // Every block of a flow launch must be resident at once, and flow_capacity counts the whole device: two flow launches of
     // DIFFERENT handles (streams) of this process on one device could each get a part of it and wait for their missing blocks
@@ -347,7 +393,9 @@ int swe2d_flow_supported(swe2d_handle *hh)
     Handle *h = H(hh);
     if (!h || !flow_kernel_covers(h)) return 0;
     if (hipSetDevice(h->device) != hipSuccess) return 0;
-    return ((h->flow_blocks + 7)/8)*8 <= flow_capacity(h) ? (has_sources(h) ? 1 : 2) : 0;
+    if (((h->flow_blocks + 7)/8)*8 <= flow_capacity(h)) return has_sources(h) ? 1 : 2;
+    // more blocks than waves can be resident: several consecutive blocks per wave (swe2d_mflow.h; no exchange inside the launch)
+    return mflow_blocks_per_wave(h) > 0 ? (has_sources(h) ? 3 : 4) : 0;
 }
 
 int swe2d_flow_status(swe2d_handle *hh, int32_t *timeouts)

@@ -538,7 +538,7 @@ int run_tracer_diagnostics(Handle *h, int id, int64_t limbs[2*SWE_SUM_LIMBS], do
 }
 }  // namespace
 
-int swe2d_tracer_diagnostics_limbs(swe2d_handle *hh, int id, int64_t limbs[8], double minmax[2])
+int swe2d_tracer_diagnostics_limbs(swe2d_handle *hh, int id, int64_t limbs[2*SWE_SUM_LIMBS], double minmax[2])
 {
     Handle *h = H(hh);
     int rc = check_tracer(h, id);

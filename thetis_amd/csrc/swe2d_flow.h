@@ -123,6 +123,7 @@ struct SweFlowArgs {
     void *ex;                              // [3 slot sets][n_slots] exchange slots, SWE_FLOW_SLOT_BYTES each: two stage parities + the cycle inputs (FX)
     unsigned parity_bytes;                 // n_slots * SWE_FLOW_SLOT_BYTES
     int n_blocks;                          // blocks of the handle (cells rounded up to 64)
+    int blocks_per_wave;                   // swe_mflow_kernel (swe2d_mflow.h): consecutive blocks a wave owns; 1 for swe_flow_kernel
     int n_stages;                          // a multiple of 3: stage s is Shu-Osher stage s % 3
     int cell_end[SWE_FLOW_MAX_STAGES];     // stage s updates the cells [0, cell_end[s]); non-increasing
     double a0[3], a1[3], beta[3];          // Shu-Osher weights per stage (swe2d_ssprk33_coefficients)

@@ -134,6 +134,7 @@ struct Handle {
     void *flow_ex = nullptr;
     size_t flow_ex_bytes = 0;
     int flow_blocks = 0;                                // 64-cell blocks of the handle
+    int mflow_capacity = -1;                            // ... and of the multi-block kernel (swe2d_mflow.h)
     int flow_capacity = -1;                             // resident one-wave workgroups of the flow kernel on this device (-1: not asked yet)
     int flow_max_rim = 0;                               // most rim facets of a block in the current flow order (selects the polling width)
     int launch_parity = 0;                              // direction of the next large stage launch (launch_stage)
@@ -276,6 +277,8 @@ int upload_vertex_coefficient(Handle *h, const double *vertex_values, double **d
 int flow_build(Handle *h, const int32_t *order);
 bool flow_kernel_covers(const Handle *h);
 int flow_capacity(Handle *h);
+int mflow_capacity(Handle *h);
+int mflow_blocks_per_wave(Handle *h);
 int flow_build_exchange(Handle *h);
 int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles = 0);
 int flow_check(Handle *h);

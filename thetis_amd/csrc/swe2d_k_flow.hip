@@ -1,6 +1,7 @@
 // swe2d_k_flow.hip - the dataflow stage loop (swe2d_flow.h): instantiations + picker
 #include "swe2d_kernels.h"
 #include "swe2d_flow.h"
+#include "swe2d_mflow.h"
 #include "swe2d_pick.h"
 
 template <bool NL, bool LF, int POLL>
@@ -19,6 +20,20 @@ flow_kernel_t pick_flow_poll(bool nl, bool lf, bool src, bool fx)
 flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src, bool fx, bool wide)
 {
     return wide ? pick_flow_poll<9>(nl, lf, src, fx) : pick_flow_poll<8>(nl, lf, src, fx);
+}
+
+// the multi-block kernel (swe2d_mflow.h): a wave owns several consecutive blocks; no exchange inside
+template <int POLL>
+static flow_kernel_t pick_mflow_poll(bool nl, bool lf, bool src)
+{
+    if (nl) return lf ? (src ? swe_mflow_kernel<true, true, true, POLL> : swe_mflow_kernel<true, true, false, POLL>)
+                      : (src ? swe_mflow_kernel<true, false, true, POLL> : swe_mflow_kernel<true, false, false, POLL>);
+    return lf ? (src ? swe_mflow_kernel<false, true, true, POLL> : swe_mflow_kernel<false, true, false, POLL>)
+              : (src ? swe_mflow_kernel<false, false, true, POLL> : swe_mflow_kernel<false, false, false, POLL>);
+}
+flow_kernel_t pick_mflow_kernel(bool nl, bool lf, bool src, bool wide)
+{
+    return wide ? pick_mflow_poll<9>(nl, lf, src) : pick_mflow_poll<8>(nl, lf, src);
 }
 
 // the adversary builds' device-side switches live in this translation unit (with the kernels that read them)

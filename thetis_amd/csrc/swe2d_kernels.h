@@ -521,6 +521,12 @@ __device__ __forceinline__ double swe_ld(swe_rsrc_t r, unsigned voff, unsigned s
 {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
+// the same past this CU's L1 (sc1: L2-served): for planes the wave itself stored earlier in the launch (swe2d_mflow.h), whose stale
+// L1 line from an even earlier read must not be hit
+__device__ __forceinline__ double swe_ld_l2(swe_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 16));
+}
 __device__ __forceinline__ int swe_ldi(swe_rsrc_t r, unsigned voff, unsigned soff)
 {
     return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
@@ -1479,11 +1485,15 @@ __global__ void swe_wd_relax_kernel(double *planes, size_t stride, const int *cv
 // A floating-point sum depends on the order of its terms, i.e. on how a mesh is cut into blocks and partitions; the integrals
 // print_state and the conservation callbacks show (solver2d.py:955-956, callback.py:323-328, all-reduced over the ranks in the
 // reference, callback.py:478-482) would then differ in their last digits between a run on one GPU and the same run on eight.
-// Every per-cell contribution x is therefore split EXACTLY into four signed 38-bit limbs of units 2^40, 2^2, 2^-36, 2^-74
-// (|x| < 2^78 ~ 3e23; what lies below 2^-74 ~ 5e-23 is truncated, per term, in the same way wherever the term is computed) and
-// the limbs are added as 64-bit integers - associative, so lanes, blocks and ranks may add them in any order (2^25 terms fit).
+// Every per-cell contribution x is therefore split EXACTLY into six signed 38-bit limbs of units 2^40, 2^2, 2^-36, 2^-74, 2^-112,
+// 2^-150 (|x| < 2^78 ~ 3e23; what lies below 2^-150 ~ 7e-46 is truncated, per term, in the same way wherever the term is computed)
+// and the limbs are added as 64-bit integers - associative, so lanes, blocks and ranks may add them in any order (2^25 terms fit).
+// (Rounds 4 had four limbs, i.e. a floor of 2^-74 ~ 5e-23 per term: integrals of small fields on small cells - a lake-at-rest
+// residual of 1e-14 on a unit-square mesh, eta^2 A ~ 1e-32 - lost most of their digits or came out as exactly 0 where the reference's
+// floating-point all-reduce keeps them.  228 bits below 2^78 leave nothing of a double behind that a sum of doubles
+// of one magnitude would keep.)
 // swe2d_sum_limbs_to_double (csrc/swe2d_api.hip) rounds the total to the nearest double, once.
-#define SWE_SUM_LIMBS 4
+#define SWE_SUM_LIMBS 6
 #define SWE_DIAG_ACC (3*SWE_SUM_LIMBS + 1)             // limb sums of up to three integrals + the counter of unsummable terms
 #define SWE_DIAG_BUCKETS 64                            // copies of the accumulators (block b adds to copy b % 64; the host adds the copies):
                                                        //  15 625 blocks x 12 atomics on ONE set of addresses took 0.9 ms, serialised in L2
@@ -1493,7 +1503,9 @@ __device__ __forceinline__ void swe_sum_split(double x, long long q[SWE_SUM_LIMB
     double t = trunc(x*0x1p-40); q[0] = (long long)t; x -= t*0x1p40;      // every product and difference here is exact
     t = trunc(x*0x1p-2);  q[1] = (long long)t; x -= t*0x1p2;
     t = trunc(x*0x1p36);  q[2] = (long long)t; x -= t*0x1p-36;
-    t = trunc(x*0x1p74);  q[3] = (long long)t;
+    t = trunc(x*0x1p74);  q[3] = (long long)t; x -= t*0x1p-74;
+    t = trunc(x*0x1p112); q[4] = (long long)t; x -= t*0x1p-112;
+    t = trunc(x*0x1p150); q[5] = (long long)t;
 }
 // adds the block's (one wave's) sum of x to acc[0..3]; acc[4*n_sums] of the launch counts the terms that were not summed
 __device__ __forceinline__ void swe_sum_accumulate(double x, unsigned long long *acc, unsigned long long *bad_counter)

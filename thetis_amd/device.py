@@ -433,7 +433,8 @@ class Swe2dDevice(object):
 
     def flow_supported(self):
         """0: the flow kernel does not cover this handle (configuration, or more 64-cell blocks than the device holds
-        resident); 1: covered; 2: covered and without source terms."""
+        resident even with several blocks per wave); 1: covered; 2: covered and without source terms; 3 / 4: the same through the
+        multi-block kernel (csrc/swe2d_mflow.h: no exchange inside the launch)."""
         return int(self.lib.swe2d_flow_supported(self.h))
 
     def flow_timeouts(self):
@@ -468,21 +469,21 @@ class Swe2dDevice(object):
     def diagnostics_limbs(self):
         """The three integrals of ``diagnostics`` as order-independent limb sums (int64 [3][4], include/swe2d.h) + the minimum
         depth: partitions add their limbs as integers and round once with ``limbs_to_double``."""
-        limbs = np.zeros(12, dtype=np.int64)
+        limbs = np.zeros(3*_lib.SUM_LIMBS, dtype=np.int64)
         lo = ctypes.c_double()
         self._ck(self.lib.swe2d_diagnostics_limbs(self.h, limbs.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.byref(lo)))
-        return limbs.reshape(3, 4), float(lo.value)
+        return limbs.reshape(3, _lib.SUM_LIMBS), float(lo.value)
 
     def tracer_diagnostics_limbs(self, tid):
         """limb sums [2][4] of {int T*H dx, int T dx} + (min, max)"""
-        limbs = np.zeros(8, dtype=np.int64)
+        limbs = np.zeros(2*_lib.SUM_LIMBS, dtype=np.int64)
         mm = np.empty(2)
         self._ck(self.lib.swe2d_tracer_diagnostics_limbs(self.h, int(tid), limbs.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _ptr(mm)))
-        return limbs.reshape(2, 4), mm
+        return limbs.reshape(2, _lib.SUM_LIMBS), mm
 
     def limbs_to_double(self, limbs):
-        """the total of limb sums [4] rounded to the nearest double (swe2d_sum_limbs_to_double)"""
-        a = np.ascontiguousarray(limbs, dtype=np.int64).reshape(4)
+        """the total of limb sums [6] rounded to the nearest double (swe2d_sum_limbs_to_double)"""
+        a = np.ascontiguousarray(limbs, dtype=np.int64).reshape(_lib.SUM_LIMBS)
         return float(self.lib.swe2d_sum_limbs_to_double(a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
 
     # -- tracers + limiter

@@ -425,6 +425,8 @@ class DistributedSwe2d(object):
         corners); a halo deeper than a part is wide sends cells to more - then the flow launch is followed by the exchange kernels."""
         if self.p2p is None or self._flowx_request is False or os.environ.get('THETIS_AMD_FLOWX') == '0':
             return False
+        if self.dev.flow_supported() not in (1, 2):          # several blocks per wave (csrc/swe2d_mflow.h): exchange kernels after the launch
+            return False
         sc = np.asarray(self.part.send_cells)
         return not len(sc) or int(np.bincount(sc).max()) <= 2
 
@@ -557,7 +559,7 @@ class DistributedSwe2d(object):
         the ranks as integers (include/swe2d.h, swe2d_diagnostics_limbs) - the doubles of the single-device run, bit for bit."""
         import torch.distributed as dist
         limbs, mm = self.dev.tracer_diagnostics_limbs(self.tids[i_tracer])
-        total = self._all_reduce_int(limbs).reshape(2, 4)
+        total = self._all_reduce_int(limbs).reshape(2, -1)
         m = self._all_reduce([mm[0], -mm[1]], dist.ReduceOp.MIN)
         return np.array([self.dev.limbs_to_double(total[0]), self.dev.limbs_to_double(total[1]), m[0], -m[1]])
 
@@ -1110,7 +1112,7 @@ class DistributedSwe2d(object):
         import torch.distributed as dist
         self._check_exchange()
         limbs, lo = self.dev.diagnostics_limbs()
-        total = self._all_reduce_int(limbs).reshape(3, 4)
+        total = self._all_reduce_int(limbs).reshape(3, -1)
         return np.array([self.dev.limbs_to_double(total[q]) for q in range(3)] + [self._all_reduce([lo], dist.ReduceOp.MIN)[0]])
 
 

@@ -131,6 +131,22 @@ class Function(object):
         self._host_version += 1
         return self
 
+    # -- a Function inside an expression (thetis_amd/expr.py): lazy, evaluated on the nodes it lives on
+    def _expr(self):
+        from .expr import Expr, _value
+        return Expr(lambda x, y: _value(self, x, y))
+
+    def __add__(self, o): return self._expr() + o
+    def __radd__(self, o): return o + self._expr()
+    def __sub__(self, o): return self._expr() - o
+    def __rsub__(self, o): return o - self._expr()
+    def __mul__(self, o): return self._expr()*o
+    def __rmul__(self, o): return o*self._expr()
+    def __truediv__(self, o): return self._expr()/o
+    def __rtruediv__(self, o): return o/self._expr()
+    def __pow__(self, o): return self._expr()**o
+    def __neg__(self): return -self._expr()
+
     def interpolate(self, expr):
         """Nodal interpolation."""
         self._pull()

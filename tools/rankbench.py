@@ -29,6 +29,9 @@ def main():
     ap.add_argument('--flow', type=int, default=-1, help='1 / 0: the stages of a cycle as one dataflow launch (csrc/swe2d_flow.h) / stage launches (default: the solver decides)')
     ap.add_argument('--flowx', type=int, default=-1, help='1 / 0: the exchange inside the flow launches / separate push and unpack kernels')
     ap.add_argument('--nx', type=int, default=0, help='mesh RectangleMesh(nx, nx/2) instead of the bench mesh')
+    ap.add_argument('--case', default='cfg2', help="cfg2: the bench mesh, shallow water only | cfg4: + one tracer with the limiter (coupled cycles, "
+                    "combined exchange) | cfg4_tracer_only: the tracer alone (demo_2d_tracer mode) | cfg5: the Balzano geometry at 500 k "
+                    "triangles with wetting-drying, Manning friction and the tidal boundary (BASELINE cfg 5), strips along x")
     ap.add_argument('--timing', action='store_true', help='-DSWE_WAVE_TIMING -DSWE_FLOW_TS_STAGE=S build of the library (THETIS_AMD_LIB): '
                     "per-block time stamps of stage S of the last flow launch, by the block's role")
     args = ap.parse_args()
@@ -49,8 +52,8 @@ def main():
         def __init__(self, dev, part, rank, world, n_tracers=0, group=None, local_error=None):
             k = int(part.cells.shape[1])
             self.dev, self.n_channels = dev, 1
-            dev.p2p_create([3*k] + ([18] if k == 3 else []))
-            self.n_channels = 2 if k == 3 else 1
+            dev.p2p_create([3*k] + [k]*int(n_tracers) + ([18] if k == 3 else []))
+            self.n_channels = 1 + int(n_tracers) + (1 if k == 3 else 0)
             _, base, kind = dev.p2p_export()
             self.zone_kind = {1: 'uncached', 2: 'fine-grained', 3: 'device'}.get(kind, '?')
             peers = sorted(part.send)
@@ -68,13 +71,33 @@ def main():
     distributed.DistributedSwe2d._all_reduce = lambda self, values, op: np.asarray(list(values), dtype=float)
     distributed.DistributedSwe2d._all_reduce_int = lambda self, values: np.asarray(values, dtype=np.int64).ravel()
     distributed.DistributedSwe2d._ranks_share_a_device = lambda self: False
-    mesh, bath, uv, eta = bench.build_case(args.nx, args.nx//2) if args.nx else bench.build_case()
-    dt = bench.DT*(1000.0/args.nx if args.nx else 1.0)
+    kw = {}
+    if args.case == 'cfg5':
+        from thetis_amd import _lib
+        from thetis_amd.mesh import RectangleMesh
+        mesh = RectangleMesh(707, 354, 13800.0, 7200.0)
+        bath = mesh.vertex_xy[:, 0]/2760.0
+        uv, eta = np.zeros((mesh.num_cells, 3, 2)), np.zeros((mesh.num_cells, 3))
+        dt = 0.1
+    else:
+        mesh, bath, uv, eta = bench.build_case(args.nx, args.nx//2) if args.nx else bench.build_case()
+        dt = bench.DT*(1000.0/args.nx if args.nx else 1.0)
+        if args.case in ('cfg4', 'cfg4_tracer_only'):
+            kw = dict(n_tracers=1, use_limiter=True, tracer_only=(args.case == 'cfg4_tracer_only'))
     s = distributed.DistributedSwe2d(mesh, bath, dt, args.rank, args.world, 0, exchange_every=args.every, overlap_stages=args.overlap,
                                      exchange=('p2p' if args.exchange == 'p2p' else 'rccl'), split_last_stage=not args.nosplit,
                                      graph_mode=args.graph_mode,
-                                     flow=(None if args.flow < 0 else bool(args.flow)), flow_exchange=(None if args.flowx < 0 else bool(args.flowx)))
+                                     flow=(None if args.flow < 0 else bool(args.flow)), flow_exchange=(None if args.flowx < 0 else bool(args.flowx)), **kw)
+    if args.case == 'cfg5':
+        s.dev.set_wetting_and_drying(0.4)
+        s.dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+        if 2 in s.dev._marker_slot:
+            s.dev.set_bc(2, {'elev': -0.5})
+        s.config_changed()
     s.set_state_global(uv, eta)
+    if kw:
+        cxy = mesh.cell_xy()
+        s.set_tracer_global(0, np.where(cxy[:, :, 0] < 40e3, 0.0, 30.0))
     p = s.part
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < args.prewarm:
@@ -131,7 +154,7 @@ def main():
                 a, b = blk[np.nonzero(okf)[0]], blk[nbr[okf, f]]
                 np.add.at(rim, a[a != b], 1)
             np.savez(dump, t=t, prev=prev, role=role, rim=rim, n_owned=p.n_owned, blk=blk)
-    print(json.dumps({'exchange': args.exchange, 'split': not args.nosplit, 'p2p_timeouts': to,
+    print(json.dumps({'case': args.case, 'exchange': args.exchange, 'split': not args.nosplit, 'p2p_timeouts': to,
                       'world': args.world, 'rank': args.rank, 'every': args.every, 'overlap': args.overlap, 'n_owned': int(p.n_owned),
                       'n_ghost': int(p.n_ghost), 'n_send': int(len(p.send_cells)), 'graph': s.graphed, 'graph_mode': s.graph_mode, 'flow': bool(s.flow), 'flow_exchange': bool(s.flow_exchange), 'flow_timeouts': s.dev.flow_timeouts(),
                       'us_per_step': 1e6*best/args.steps}))
