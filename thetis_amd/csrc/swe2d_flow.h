@@ -67,6 +67,9 @@
 #define SWE_FLOW_FLAG_STRIDE 16           // unsigned words between two blocks' stage counters (64 B)
 #endif
 #define SWE_FLOW_SLOT_BYTES 128            // exchange slot of one rim facet and stage parity: 8 granules of 16 B {value, tag, check} (6 values + 2 pads)
+#ifndef SWE_FLOW_RX
+#define SWE_FLOW_RX 3                      // FX receive: granule loads per lane in flight in a trip of a pass
+#endif
 #define SWE_FLOW_MAX_RIM 160               // rim facets of a block (3*64 at worst: such flow orders are refused, see flow_build)
 
 typedef unsigned int swe_u32x4 __attribute__((ext_vector_type(4)));
@@ -565,6 +568,7 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                 // A block of outer ghost cells skips the late stages of a cycle and waits here for most of it: ONE lane watches ONE
                 // granule, slowly (every polling pass of every lane is nine fabric reads per ghost cell - MI355X_MICROARCH.md,
                 // polling-cost), the full passes start when that one has arrived
+#ifndef SWE_FLOW_NO_HINT
                 {
                     const unsigned long long gm = __ballot(xr >= 0);
                     const int first = (int)__builtin_ctzll(gm);
@@ -584,6 +588,7 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                     }
                     t_start = 0ull;
                 }
+#endif
                 // the records (nine granules = 144 B per ghost cell) are read by nine consecutive lanes each - a 16-byte access per
                 // lane and granule would be nine fabric reads per cell and pass - into the staging area, ghost cell after ghost cell
                 // of the block; the ghost lanes then pick their nine values from LDS
@@ -606,19 +611,19 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                     // the loads of a pass are issued TOGETHER (three per lane and trip: 21 ghost cells; a block next to a cut holds
                     // ~30): one round trip to the zone - uncached memory the peers write over the fabric - per trip instead of one
                     // per 64 granules (the rolled loop waited for every load before it issued the next, round 5)
-                    for (int c0 = 0; c0 < 9*ng; c0 += 3*SWE_BLOCK) {
-                        swe_u32x4 gz[3];
-                        unsigned zoff[3];
+                    for (int c0 = 0; c0 < 9*ng; c0 += SWE_FLOW_RX*SWE_BLOCK) {
+                        swe_u32x4 gz[SWE_FLOW_RX];
+                        unsigned zoff[SWE_FLOW_RX];
 #pragma unroll
-                        for (int j = 0; j < 3; j++) {
+                        for (int j = 0; j < SWE_FLOW_RX; j++) {
                             const int t = min(c0 + j*SWE_BLOCK + lane, 9*ng - 1);
                             const int cc = (t*7282) >> 16;                                         // t / 9
                             zoff[j] = lrec[SWE_LDSI(cc, SWE_BLOCK)] + 16u*(unsigned)(t - 9*cc);
                         }
 #pragma unroll
-                        for (int j = 0; j < 3; j++) gz[j] = swe_flow_get_sys(rz, c0 + j*SWE_BLOCK + lane < 9*ng ? zoff[j] : SWE_FLOW_NOWHERE);
+                        for (int j = 0; j < SWE_FLOW_RX; j++) gz[j] = swe_flow_get_sys(rz, c0 + j*SWE_BLOCK + lane < 9*ng ? zoff[j] : SWE_FLOW_NOWHERE);
 #pragma unroll
-                        for (int j = 0; j < 3; j++) {
+                        for (int j = 0; j < SWE_FLOW_RX; j++) {
                             const int t = c0 + j*SWE_BLOCK + lane;
                             if (t < 9*ng) {
                                 ok = ok && swe_flow_arrived(gz[j], target);

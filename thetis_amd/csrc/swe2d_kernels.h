@@ -2025,7 +2025,9 @@ static __global__ __launch_bounds__(SWE_BLOCK) void swe_calibration_copy(const d
 // mass inverse: (M^-1 b)_i = (16 b_i - 8 b_{i+1} - 8 b_{i-1} + 4 b_{i+2})/A.
 // Algorithmic bytes per cell per stage: 96 read + 96 write (+96 U0 in stages 2,3) + 56 static.
 //
-// One lane per cell, 196-223 VGPRs, two waves per SIMD.  Splitting a cell over TWO lanes (half-turn local frames, partner values
+// One lane per cell.  Rounds 1-4: 172-223 VGPRs, two waves per SIMD.  Round 5: boundary facets after the outputs
+// (swe_boundary_epilogue_quad), U(0) requested after the facet loop, optional terms in a pass of their own - 140-167 VGPRs, three
+// waves per SIMD for the parallelogram kernels, +2.5 ... 4 % (profiles/r05g_quad_three_waves.txt).  Splitting a cell over TWO lanes (half-turn local frames, partner values
 // by DPP quad_perm, 118-120 VGPRs = four waves per SIMD, twice the instruction streams) was built, passed the same parity tests
 // and ran at the SAME speed at every size from 122 k to 2 M cells (1 M: 201-207 against 193-203 us/step, with 3 or 4 waves per
 // SIMD alike): this kernel is not bound by its occupancy.  PMC: HBM traffic x 1.05 of the algorithmic bytes, 1182 VALU
@@ -2101,6 +2103,93 @@ __device__ __forceinline__ void swe_quad_mass_solve(const SweQuadLDL &F, double 
     b[0] = x0; b[1] = x1; b[2] = x2; b[3] = x3;
 }
 
+// Boundary facets of a quadrilateral, evaluated AFTER the cell's outputs are finished (the counterpart of swe_boundary_epilogue):
+// the facet's inputs are reloaded by plane index (L1 / L2 hits: this wave has just read them), the flux goes through the mass
+// inverse of a vector that is non-zero at the facet's two nodes and is added to the outputs still in registers.  Four inlined
+// copies of swe_boundary_facet inside the facet loop cost every wave 24-36 VGPRs (172-201 = two waves per SIMD, rounds 1-4); with
+// the boundary code here, where little else is live, the kernel fits three (140-167; profiles/r05g_quad_three_waves.txt).
+// The residual is linear in the facet contributions: the same result up to summation order.
+template <bool NONLIN, bool LF, bool WD, bool AFFINE>
+__device__ __forceinline__ void swe_boundary_epilogue_quad(const SweStageArgs &p, int k, unsigned bmarkers, double ou[4], double ov[4],
+                                                           double oe[4])
+{
+#pragma clang fp contract(off)
+    const size_t S = p.stride;
+    // the cell's frame (as the stage kernel forms it)
+    double A, d1 = 0.0, d2 = 0.0;
+    {
+        const int v0 = p.cv[k], v1 = p.cv[S + k], v3 = p.cv[3*S + k];
+        const double x0 = p.vx[v0], y0 = p.vy[v0], x1 = p.vx[v1], y1 = p.vy[v1], x3 = p.vx[v3], y3 = p.vy[v3];
+        const double ax = x1 - x0, ay = y1 - y0, bx = x3 - x0, by = y3 - y0;
+        A = fma(ax, by, -(ay*bx));
+        if (!AFFINE) {
+            const int v2 = p.cv[2*S + k];
+            const double x2 = p.vx[v2], y2 = p.vy[v2];
+            const double cx = (x0 - x1) + (x2 - x3), cy = (y0 - y1) + (y2 - y3);
+            d1 = fma(ax, cy, -(ay*cx));
+            d2 = fma(cx, by, -(cy*bx));
+        }
+    }
+    const double sb = p.dt*p.beta;
+    const double s = AFFINE ? sb*swe_rcp(A) : sb;
+    SweQuadLDL Fb;
+    if constexpr (!AFFINE) {
+        SweQuadMass Mb;
+        swe_quad_mass(A, d1, d2, Mb);
+        swe_quad_mass_factor(Mb, Fb);
+    }
+    // one facet at a time, everything addressed in memory by plane index: no dynamically indexed register arrays
+#pragma unroll 1
+    for (int f = 0; f < 4; f++) {
+        const int marker = (int)((bmarkers >> (8*f)) & 0xffu);
+        if (marker == 0) continue;
+        const int a = f, b = (f + 1) & 3;
+        const int va = p.cv[(size_t)a*S + k], vb = p.cv[(size_t)b*S + k];
+        const double xa_ = p.vx[va], ya_ = p.vy[va], xb_ = p.vx[vb], yb_ = p.vy[vb];
+        const double ha = p.vh[va], hb = p.vh[vb];
+        const double ala = WD ? p.valpha[va] : 0.0, alb = WD ? p.valpha[vb] : 0.0;
+        const double ua = p.uin[(size_t)a*S + k], ub = p.uin[(size_t)b*S + k];
+        const double va_ = p.uin[(size_t)(4 + a)*S + k], vb_ = p.uin[(size_t)(4 + b)*S + k];
+        const double da_ = p.uin[(size_t)(8 + a)*S + k], db_ = p.uin[(size_t)(8 + b)*S + k];      // eta, or D with wetting-drying
+        const double ea = WD ? swe_wd_eta(da_, ha, ala) : da_, eb = WD ? swe_wd_eta(db_, hb, alb) : db_;
+        const double Ha = WD ? da_ : (NONLIN ? ha + ea : ha);
+        const double Hb = WD ? db_ : (NONLIN ? hb + eb : hb);
+        const double nxs = yb_ - ya_, nys = xa_ - xb_;
+        double L, rL;
+        swe_sqrt_rsqrt(swe_dot2(nxs, nxs, nys, nys), L, rL);
+        double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
+        swe_boundary_facet<NONLIN, LF, WD>(p, marker, k, a, b, ua, ub, va_, vb_, ea, eb, ha, hb, Ha, Hb, ala, alb, nxs, nys,
+                                           L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
+        const double dau = -0.5*Fau, dbu = -0.5*Fbu, dav = -0.5*Fav, dbv = -0.5*Fbv, dae = -0.5*Fae, dbe = -0.5*Fbe;
+        if constexpr (AFFINE) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {            // row i of the tensor mass inverse (16, -8, 4, -8)/A on (da at a, db at b)
+                const double ca = (i == a) ? 16.0 : (i == (a ^ 2) ? 4.0 : -8.0), cb = (i == b) ? 16.0 : (i == (b ^ 2) ? 4.0 : -8.0);
+                ou[i] = fma(s, fma(ca, dau, cb*dbu), ou[i]);
+                ov[i] = fma(s, fma(ca, dav, cb*dbv), ov[i]);
+                oe[i] = fma(s, fma(ca, dae, cb*dbe), oe[i]);
+            }
+        } else {
+            double ru[4], rv[4], re[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ru[i] = (i == a) ? dau : ((i == b) ? dbu : 0.0);
+                rv[i] = (i == a) ? dav : ((i == b) ? dbv : 0.0);
+                re[i] = (i == a) ? dae : ((i == b) ? dbe : 0.0);
+            }
+            swe_quad_mass_solve(Fb, ru);
+            swe_quad_mass_solve(Fb, rv);
+            swe_quad_mass_solve(Fb, re);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ou[i] = fma(s, ru[i], ou[i]);
+                ov[i] = fma(s, rv[i], ov[i]);
+                oe[i] = fma(s, re[i], oe[i]);
+            }
+        }
+    }
+}
+
 // AFFINE = false: general quadrilaterals (see above)
 template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD, bool AFFINE = true>
 __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStageArgs p)
@@ -2137,23 +2226,12 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         v[i] = swe_ld(gv, k8, i*S8);
         e[i] = swe_ld(ge, k8, i*S8);
     }
+    // boundary markers of the four facets in one register (0: interior facet): all the boundary pass at the end needs of nb[]
+    const unsigned bmarkers = (nb[0] < 0 ? (unsigned)(-nb[0]) : 0u) | (nb[1] < 0 ? (unsigned)(-nb[1]) << 8 : 0u) |
+                              (nb[2] < 0 ? (unsigned)(-nb[2]) << 16 : 0u) | (nb[3] < 0 ? (unsigned)(-nb[3]) << 24 : 0u);
+    // (U(0) of the velocity and of eta is NOT requested here: its twelve values would be live through the facet loop - 24 of the
+    //  registers that kept this kernel at two waves per SIMD; see below)
     double wu[4], wv[4], we[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        wu[i] = p.a1*u[i];
-        wv[i] = p.a1*v[i];
-        we[i] = p.a1*e[i];
-        if (HASU0) {
-            wu[i] = fma(p.a0, swe_ld(swe_rsrc(p.u0), k8, i*S8), wu[i]);
-            wv[i] = fma(p.a0, swe_ld(swe_rsrc(p.u0 + 4*S), k8, i*S8), wv[i]);
-            if (!WD) we[i] = fma(p.a0, swe_ld(swe_rsrc(p.u0 + 8*S), k8, i*S8), we[i]);
-        }
-    }
-    double e0[4] = {0.0, 0.0, 0.0, 0.0};
-    if (WD && HASU0) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) e0[i] = swe_ld(swe_rsrc(p.u0 + 8*S), k8, i*S8);
-    }
     double una[4], unb[4], vna[4], vnb[4], ena[4], enb[4];
     {   // (an LDS exchange of the in-wave traces as in swe_stage_kernel<..., LDSX> was measured: 201 vs 203 us/step at 1 M
         //  quadrilaterals - this kernel is bound by its 198 VGPRs and its arithmetic, not by the gathers; not kept)
@@ -2184,8 +2262,6 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         if (WD) al[i] = swe_ld(swe_rsrc(p.valpha), v8, 0);
         if (WD) {           // the planes hold D (U(0)'s too); the continuity equation advances zeta = D - h
             H[i] = e[i];
-            we[i] = p.a1*(H[i] - h[i]);
-            if (HASU0) we[i] = fma(p.a0, e0[i] - h[i], we[i]);
             e[i] = swe_wd_eta(H[i], h[i], al[i]);
         } else H[i] = NONLIN ? h[i] + e[i] : h[i];
     }
@@ -2217,24 +2293,26 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
             swe_facet_flux<NONLIN, LF, WD>(g, p.sigma_lf, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b], una[f], unb[f],
                                            vna[f], vnb[f], ena_, enb_, Dna, Dnb, nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
         }
-        if (nb[f] < 0) {
-            // boundary facets inline: this kernel runs at 2 waves/SIMD either way, and the post-compute epilogue of the
-            // triangle kernel costs 14 % here (measured: 249 vs 219 us/step on 1M quadrilaterals)
-            Fau = 0.0; Fbu = 0.0; Fav = 0.0; Fbv = 0.0; Fae = 0.0; Fbe = 0.0;
-            swe_boundary_facet<NONLIN, LF, WD>(p, -nb[f], k, a, b, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], H[a], H[b],
-                                               al[a], al[b], nxs, nys, L, rL, Fau, Fbu, Fav, Fbv, Fae, Fbe);
-        }
+        if (nb[f] < 0) { Fau = 0.0; Fbu = 0.0; Fav = 0.0; Fbv = 0.0; Fae = 0.0; Fbe = 0.0; }     // see swe_boundary_epilogue_quad
         bu[a] = fma(-0.5, Fau, bu[a]); bu[b] = fma(-0.5, Fbu, bu[b]);
         bv[a] = fma(-0.5, Fav, bv[a]); bv[b] = fma(-0.5, Fbv, bv[b]);
         be[a] = fma(-0.5, Fae, be[a]); be[b] = fma(-0.5, Fbe, be[b]);
     }
 
+    // U(0) is requested here: the 24 neighbour traces are dead, the cell quadrature hides the trip
+    double u0u[4], u0v[4], u0e[4];
+    if (HASU0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            u0u[i] = swe_ld(swe_rsrc(p.u0), k8, i*S8);
+            u0v[i] = swe_ld(swe_rsrc(p.u0 + 4*S), k8, i*S8);
+            u0e[i] = swe_ld(swe_rsrc(p.u0 + 8*S), k8, i*S8);
+        }
+    }
     // ---- cell integrals, 2 x 2 Gauss-Legendre; weights A/4, gradients carry 1/A  ->  factor 1/4 on gradient terms
-    // (with the optional terms the unrolled loop needs 286-306 VGPRs = 1 wave/SIMD; rolled: 205-223 = 2 waves)
-    constexpr int UNROLL_Q = SRC ? 1 : 2;
-#pragma unroll UNROLL_Q
+#pragma unroll
     for (int qi = 0; qi < 2; qi++) {
-#pragma unroll UNROLL_Q
+#pragma unroll
         for (int qz = 0; qz < 2; qz++) {
             const double xi = qi ? SWE_XI1 : SWE_XI0, ze = qz ? SWE_XI1 : SWE_XI0;
             const double phi[4] = {(1.0 - xi)*(1.0 - ze), xi*(1.0 - ze), xi*ze, (1.0 - xi)*ze};
@@ -2245,7 +2323,6 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
             // adj(J)^T at the point: x_zeta = b + xi c, x_xi = a + zeta c
             const double xix_q = AFFINE ? xix : fma(cy, xi, by), xiy_q = AFFINE ? xiy : -fma(cx, xi, bx);
             const double zex_q = AFFINE ? zex : -fma(cy, ze, ay), zey_q = AFFINE ? zey : fma(cx, ze, ax);
-            const double Aq = AFFINE ? A : fma(d2, ze, fma(d1, xi, A));          // det J at the point
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 gx[i] = swe_dot2(dxi[i], xix_q, dze[i], zex_q);
@@ -2256,58 +2333,6 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
                 Hq = fma(phi[i], H[i], Hq);
                 D = fma(gy[i], v[i], fma(gx[i], u[i], D));  // A * div(u)
             }
-            double cu = 0.0, cv_ = 0.0, ce = 0.0;          // coefficients of phi_i (times A)
-            if (SRC) {
-                double corq = 0.0, gpx = 0.0, gpy = 0.0, sx = 0.0, sy = 0.0, sv = 0.0;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if (p.coriolis) corq += phi[i]*swe_ld(swe_rsrc(p.coriolis), k8, i*S8);
-                    if (p.patm) {
-                        const double pa = swe_ld(swe_rsrc(p.patm), k8, i*S8);
-                        gpx += gx[i]*pa;
-                        gpy += gy[i]*pa;
-                    }
-                    if (p.msrc) {
-                        sx += phi[i]*swe_ld(swe_rsrc(p.msrc), k8, i*S8);
-                        sy += phi[i]*swe_ld(swe_rsrc(p.msrc + 4*S), k8, i*S8);
-                    }
-                    if (p.vsrc) sv += phi[i]*swe_ld(swe_rsrc(p.vsrc), k8, i*S8);
-                    if (p.wind) {
-                        sx += phi[i]*swe_ld(swe_rsrc(p.wind), k8, i*S8)/(Hq*1000.0);
-                        sy += phi[i]*swe_ld(swe_rsrc(p.wind + 4*S), k8, i*S8)/(Hq*1000.0);
-                    }
-                }
-                double drag = 0.0;
-                if (p.quad_drag >= 0.0 || p.manning >= 0.0 || p.nikuradse >= 0.0 || p.quad_f) {
-                    double cq = 0.0;
-                    if (p.quad_f) {
-#pragma unroll
-                        for (int i = 0; i < 4; i++) cq += phi[i]*swe_ld(swe_rsrc(p.quad_f), k8, i*S8);
-                    }
-                    const int kind = p.quad_f ? p.quad_f_kind : (p.manning >= 0.0 ? 2 : (p.nikuradse >= 0.0 ? 3 : 1));
-                    const double coef = p.quad_f ? cq : (kind == 2 ? p.manning : (kind == 3 ? p.nikuradse : p.quad_drag));
-                    double cdh;                                  // C_D / H
-                    if (kind == 2) {                             // Manning: g mu^2 H^(-4/3) = g mu^2 (H^(-1/3))^4, no reciprocal
-                        const double y = swe_rcbrt(Hq), y2 = y*y;
-                        cdh = g*coef*coef*(y2*y2);
-                    } else {
-                        double cd = coef;
-                        if (kind == 3) {
-                            const double lg = log(11.036*Hq/coef);
-                            cd = (Hq > coef) ? 0.32/(lg*lg) : 0.0;
-                        }
-                        cdh = cd*swe_rcp(Hq);
-                    }
-                    drag = cdh*swe_sqrt_sumsq(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother);
-                }
-                if (p.lin_drag_f) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) drag += phi[i]*swe_ld(swe_rsrc(p.lin_drag_f), k8, i*S8);
-                } else if (p.linear_drag >= 0.0) drag += p.linear_drag;
-                cu = Aq*(corq*vq - drag*uq + sx) - gpx*(1.0/1000.0);
-                cv_ = Aq*(-corq*uq - drag*vq + sy) - gpy*(1.0/1000.0);
-                ce = Aq*sv;
-            }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 double fu = g*eq*gx[i], fv = g*eq*gy[i];                       // shallowwater_eq.py:361
@@ -2316,14 +2341,107 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
                     fu = fma(adv, uq, fu);
                     fv = fma(adv, vq, fv);
                 }
-                bu[i] = fma(0.25, fma(cu, phi[i], fu), bu[i]);
-                bv[i] = fma(0.25, fma(cv_, phi[i], fv), bv[i]);
-                be[i] = fma(0.25, fma(ce, phi[i], Hq*swe_dot2(gx[i], uq, gy[i], vq)), be[i]);          // :422
+                bu[i] = fma(0.25, fu, bu[i]);
+                bv[i] = fma(0.25, fv, bv[i]);
+                be[i] = fma(0.25, Hq*swe_dot2(gx[i], uq, gy[i], vq), be[i]);          // :422
+            }
+        }
+    }
+    // ---- optional cell-local terms (Coriolis, drag, wind, sources, atmospheric pressure) in a pass of their own over the four
+    // quadrature points, rolled: inside the unrolled loop above they cost 286-306 VGPRs, inside a rolled copy of it 197-225 (two
+    // waves per SIMD, rounds 1-4); here the main loop is the one of the plain kernel and this pass lives in the registers it
+    // leaves (167 with the parallelogram kernel: three waves)
+    if (SRC) {
+#pragma unroll 1
+        for (int q = 0; q < 4; q++) {
+            const double xi = (q & 2) ? SWE_XI1 : SWE_XI0, ze = (q & 1) ? SWE_XI1 : SWE_XI0;
+            const double phi[4] = {(1.0 - xi)*(1.0 - ze), xi*(1.0 - ze), xi*ze, (1.0 - xi)*ze};
+            double uq = 0.0, vq = 0.0, Hq = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uq = fma(phi[i], u[i], uq);
+                vq = fma(phi[i], v[i], vq);
+                Hq = fma(phi[i], H[i], Hq);
+            }
+            const double Aq = AFFINE ? A : fma(d2, ze, fma(d1, xi, A));          // det J at the point
+            double corq = 0.0, gpx = 0.0, gpy = 0.0, sx = 0.0, sy = 0.0, sv = 0.0;
+            if (p.patm) {
+                const double dxi[4] = {-(1.0 - ze), (1.0 - ze), ze, -ze};
+                const double dze[4] = {-(1.0 - xi), -xi, xi, (1.0 - xi)};
+                const double xix_q = AFFINE ? xix : fma(cy, xi, by), xiy_q = AFFINE ? xiy : -fma(cx, xi, bx);
+                const double zex_q = AFFINE ? zex : -fma(cy, ze, ay), zey_q = AFFINE ? zey : fma(cx, ze, ax);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const double pa = swe_ld(swe_rsrc(p.patm), k8, i*S8);
+                    gpx += swe_dot2(dxi[i], xix_q, dze[i], zex_q)*pa;
+                    gpy += swe_dot2(dxi[i], xiy_q, dze[i], zey_q)*pa;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (p.coriolis) corq += phi[i]*swe_ld(swe_rsrc(p.coriolis), k8, i*S8);
+                if (p.msrc) {
+                    sx += phi[i]*swe_ld(swe_rsrc(p.msrc), k8, i*S8);
+                    sy += phi[i]*swe_ld(swe_rsrc(p.msrc + 4*S), k8, i*S8);
+                }
+                if (p.vsrc) sv += phi[i]*swe_ld(swe_rsrc(p.vsrc), k8, i*S8);
+                if (p.wind) {
+                    sx += phi[i]*swe_ld(swe_rsrc(p.wind), k8, i*S8)/(Hq*1000.0);
+                    sy += phi[i]*swe_ld(swe_rsrc(p.wind + 4*S), k8, i*S8)/(Hq*1000.0);
+                }
+            }
+            double drag = 0.0;
+            if (p.quad_drag >= 0.0 || p.manning >= 0.0 || p.nikuradse >= 0.0 || p.quad_f) {
+                double cq = 0.0;
+                if (p.quad_f) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) cq += phi[i]*swe_ld(swe_rsrc(p.quad_f), k8, i*S8);
+                }
+                const int kind = p.quad_f ? p.quad_f_kind : (p.manning >= 0.0 ? 2 : (p.nikuradse >= 0.0 ? 3 : 1));
+                const double coef = p.quad_f ? cq : (kind == 2 ? p.manning : (kind == 3 ? p.nikuradse : p.quad_drag));
+                double cdh;                                  // C_D / H
+                if (kind == 2) {                             // Manning: g mu^2 H^(-4/3) = g mu^2 (H^(-1/3))^4, no reciprocal
+                    const double y = swe_rcbrt(Hq), y2 = y*y;
+                    cdh = g*coef*coef*(y2*y2);
+                } else {
+                    double cd = coef;
+                    if (kind == 3) {
+                        const double lg = log(11.036*Hq/coef);
+                        cd = (Hq > coef) ? 0.32/(lg*lg) : 0.0;
+                    }
+                    cdh = cd*swe_rcp(Hq);
+                }
+                drag = cdh*swe_sqrt_sumsq(uq*uq + vq*vq + p.norm_smoother*p.norm_smoother);
+            }
+            if (p.lin_drag_f) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) drag += phi[i]*swe_ld(swe_rsrc(p.lin_drag_f), k8, i*S8);
+            } else if (p.linear_drag >= 0.0) drag += p.linear_drag;
+            const double cu = Aq*(corq*vq - drag*uq + sx) - gpx*(1.0/1000.0);
+            const double cv_ = Aq*(-corq*uq - drag*vq + sy) - gpy*(1.0/1000.0);
+            const double ce = Aq*sv;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                bu[i] = fma(0.25, cu*phi[i], bu[i]);
+                bv[i] = fma(0.25, cv_*phi[i], bv[i]);
+                be[i] = fma(0.25, ce*phi[i], be[i]);
             }
         }
     }
 
-    // ---- tensor mass inverse and Shu-Osher combine
+    // ---- tensor mass inverse and Shu-Osher combine (w = a0*U0 + a1*U_in; with wetting-drying the continuity equation advances
+    //      zeta = D - h: the planes hold D, U(0)'s too)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        wu[i] = p.a1*u[i];
+        wv[i] = p.a1*v[i];
+        we[i] = WD ? p.a1*(H[i] - h[i]) : p.a1*e[i];
+        if (HASU0) {
+            wu[i] = fma(p.a0, u0u[i], wu[i]);
+            wv[i] = fma(p.a0, u0v[i], wv[i]);
+            we[i] = fma(p.a0, WD ? u0e[i] - h[i] : u0e[i], we[i]);
+        }
+    }
     double ou[4], ov[4], oe[4];
     if constexpr (AFFINE) {
     const double s = p.dt*p.beta*rA;
@@ -2350,6 +2468,8 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
         oe[i] = fma(s, be[i], we[i]);
     }
     }
+    // boundary facets were skipped in the facet loop
+    if (bmarkers != 0u) swe_boundary_epilogue_quad<NONLIN, LF, WD, AFFINE>(p, k, bmarkers, ou, ov, oe);
     if (WD && !(p.a0 == 0.0 && p.a1 == 0.0)) {
         if constexpr (AFFINE) swe_wd_finish<4>(p.g, p.beta*p.dt, h, al, ou, ov, oe, !p.wd_skip_relax);
         else {

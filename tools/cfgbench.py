@@ -42,7 +42,10 @@ def report(name, n_cells, bytes_per_cell_step, t_step, extra=None):
 
 def quads(rng):
     # ---- quads: 1M quadrilaterals (cfg 1(ii) cell type at bench size): 248 / 344 / 344 = 936 B per cell per step
-    meshq = RectangleMesh(1000, 1000, 100e3, 100e3, quadrilateral=True)
+    # CFGBENCH_QUAD_N: cells per side (1000 = the bench size, 936 B x 3 state buffers = 288 MB: beyond the 256 MB Infinity Cache;
+    # 800 = 640 k cells, 184 MB: inside it, like the 1 M triangles of cfg 2)
+    nside = int(os.environ.get('CFGBENCH_QUAD_N', '1000'))
+    meshq = RectangleMesh(nside, nside, 100e3, 100e3, quadrilateral=True)
     nq = meshq.num_cells
     cq = meshq.cell_xy()
     etaq = 0.5*np.exp(-((cq[:, :, 0] - 50e3)**2 + (cq[:, :, 1] - 50e3)**2)/(5e3)**2)
