@@ -540,61 +540,3 @@ def test_full_size_coupled_tracer_properties(hip_lib, cells):
     d = dev.diagnostics()
     assert abs(d[2] - v0) < 1e-12*abs(v0) and d[1] > 0.0                 # volume conserved, the water moves
     dev.close()
-
-
-@pytest.mark.parametrize('cells', ['tri', 'quad', 'general_quad', 'tri_periodic'])
-def test_limiter_in_one_launch_gives_the_bits_of_bounds_plus_apply(hip_lib, cells, monkeypatch):
-    """The last tracer stage writes the cell means and the boundary-facet means; the limiter then runs as ONE launch
-    (swe_limiter_fused: bounds of the cell's own vertices from the CSR lists + scaling in place).  min / max are exact: the same
-    bits as swe_limiter_vertex_bounds + swe_limiter_apply (THETIS_AMD_LIMITER_UNFUSED=1), also through the per-stage entry points
-    with a last stage in two pieces, and with several tracers."""
-    kw = {}
-    if cells == 'tri_periodic':
-        mesh = PeriodicRectangleMesh(14, 9, 7.0e3, 4.5e3, direction='x')
-    elif cells == 'general_quad':
-        from helpers import quad_case
-        mesh = quad_case(nx=17, ny=11, lx=8.5e3, ly=5.5e3, skew=0.1, seed=4, warp=0.3)[0]
-        assert not mesh.affine
-        kw = dict(boundary_len=mesh.boundary_len)
-    else:
-        mesh = RectangleMesh(17, 11, 8.5e3, 5.5e3, quadrilateral=cells != 'tri')
-    npc = mesh.cells.shape[1]
-    rng = np.random.default_rng(11)
-    bath = 20.0 + rng.uniform(0.0, 1.0, mesh.num_vertices)
-    uv = rng.uniform(-0.5, 0.5, size=(mesh.num_cells, npc, 2))
-    eta = 0.1*rng.uniform(-1, 1, size=(mesh.num_cells, npc))
-    T0 = [rng.normal(size=(mesh.num_cells, npc)), np.where(mesh.cell_xy()[:, :, 0] < 4e3, 0.0, 30.0) + 0.0]
-
-    def run(unfused, staged):
-        if unfused:
-            monkeypatch.setenv('THETIS_AMD_LIMITER_UNFUSED', '1')
-        else:
-            monkeypatch.delenv('THETIS_AMD_LIMITER_UNFUSED', raising=False)
-        dev = _dev(mesh, bath, 4.0, **kw)
-        tids = [dev.add_tracer() for _ in T0]
-        dev.set_state(uv, eta)
-        for tid, T in zip(tids, T0):
-            dev.tracer_set_state(tid, T)
-        n = mesh.num_cells
-        for _ in range(4):
-            if staged:                                 # the entry points a partition's host loop uses
-                for tid in tids:
-                    dev.tracer_solve_stage_cells(tid, 0, 0, n)
-                    dev.tracer_solve_stage_cells(tid, 1, 0, n)
-                    dev.tracer_solve_stage_cells(tid, 2, n//3, n)
-                    dev.tracer_solve_stage_cells(tid, 2, 0, n//3)
-                    dev.tracer_limit_cells(tid, n)
-            else:
-                dev.advance_coupled(1, tracer_only=True, use_limiter=True)
-        out = [dev.tracer_get_state(tid).copy() for tid in tids]
-        dev.close()
-        return out
-
-    ref = run(True, False)
-    assert not np.array_equal(ref[1], T0[1])
-    for staged in (False, True):
-        got = run(False, staged)
-        for a, b in zip(got, ref):
-            assert np.array_equal(a, b)
-    for a, b in zip(run(True, True), ref):
-        assert np.array_equal(a, b)

@@ -470,7 +470,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->diag_acc, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->lim_bfm, h->valpha, h->snapshot, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->snapshot, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
     for (void *m : h->p2p.opened) (void)hipIpcCloseMemHandle(m);
@@ -533,7 +533,6 @@ int swe2d_state_snapshot(swe2d_handle *hh, int restore)
         HIP_TRY(h, hipMemcpyAsync(h->state[0], h->snapshot, nb, hipMemcpyDeviceToDevice, h->stream));
         for (size_t t = 0; t < h->tracers.size(); t++)
             HIP_TRY(h, hipMemcpyAsync(h->tracers[t].buf[0], (char *)h->snapshot + nb + t*nt, nt, hipMemcpyDeviceToDevice, h->stream));
-            h->lim_fresh_id = -1;
         h->state_holds_D = h->snapshot_holds_D;
         return SWE2D_OK;
     }

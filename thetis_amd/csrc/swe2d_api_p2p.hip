@@ -242,7 +242,6 @@ int swe2d_p2p_push(swe2d_handle *hh, int channel, int i_buffer)
 int swe2d_p2p_wait_unpack(swe2d_handle *hh, int channel, int i_buffer)
 {
     Handle *h = H(hh);
-    if (h && channel > 0) h->lim_fresh_id = -1;         // ghost values of a tracer change: see limiter_apply
     if (!h || !h->p2p.zone) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_wait_unpack: not connected");
     double *planes; int np;
     if (int rc = p2p_field(h, channel, i_buffer, &planes, &np)) return rc;

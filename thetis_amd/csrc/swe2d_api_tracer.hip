@@ -14,7 +14,6 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     a.t0 = t.buf[0];
     a.tout = t.buf[out];
     a.mean_out = mean_out;
-    a.bfm_out = mean_out ? h->lim_bfm : nullptr;
     a.uv = h->state[0];
     a.stride = h->stride;
     a.nbr = h->nbr; a.cv = h->cv; a.vx = h->vx; a.vy = h->vy;
@@ -81,16 +80,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
 
 int tracer_stage(Handle *h, int id, int i_stage, int c0, int c1, double *mean_out = nullptr)
 {
-    // The last stage also writes the cell means and the boundary-facet means the limiter starts from (where its tables exist and
-    // no diffusion pass follows): the limiter of this tracer can then run as ONE launch (limiter_apply) - unless something else
-    // writes the tracer's buffer 0 in between (every such entry point resets lim_fresh_id).
-    if (i_stage == 2 && !mean_out && h->lim_nv > 0 && h->lim_mean && h->lim_bfm && !h->tracers[id].diff) mean_out = h->lim_mean;
-    if (i_stage != 2 || !mean_out || (h->lim_fresh_id >= 0 && h->lim_fresh_id != id)) h->lim_fresh_id = -1;
-    if (mean_out) {
-        int rc = launch_tracer_stage(h, id, 2, 0, kAlpha0[2], kAlphaIn[2], kBeta[2], c0, c1, mean_out);
-        if (rc == SWE2D_OK && h->lim_bfm && c1 > c0) h->lim_fresh_id = id;
-        return rc;
-    }
+    if (mean_out) return launch_tracer_stage(h, id, 2, 0, kAlpha0[2], kAlphaIn[2], kBeta[2], c0, c1, mean_out);
     switch (i_stage) {
     case 0: return launch_tracer_stage(h, id, 0, 1, 0.0, 1.0, kBeta[0], c0, c1);
     case 1: return launch_tracer_stage(h, id, 1, 2, kAlpha0[1], kAlphaIn[1], kBeta[1], c0, c1);
@@ -135,8 +125,7 @@ int limiter_build(Handle *h, int nv, const int *topo /* [n][3] */)
         }
     int **ptrs[] = {&h->lim_v2c_off, &h->lim_v2c_cell, &h->lim_vbf_off, &h->lim_vbf_facet, &h->lim_tv};
     for (int **pp : ptrs) if (*pp) { HIP_TRY(h, hipFree(*pp)); *pp = nullptr; }
-    double **dptrs[] = {&h->lim_mean, &h->lim_qmin, &h->lim_qmax, &h->lim_bfm};
-    h->lim_fresh_id = -1;
+    double **dptrs[] = {&h->lim_mean, &h->lim_qmin, &h->lim_qmax};
     for (double **pp : dptrs) if (*pp) { HIP_TRY(h, hipFree(*pp)); *pp = nullptr; }
     HIP_TRY(h, hipMalloc(&h->lim_v2c_off, off.size()*sizeof(int)));
     HIP_TRY(h, hipMalloc(&h->lim_v2c_cell, cell.size()*sizeof(int)));
@@ -144,8 +133,6 @@ int limiter_build(Handle *h, int nv, const int *topo /* [n][3] */)
     HIP_TRY(h, hipMalloc(&h->lim_vbf_facet, bf.size()*sizeof(int)));
     HIP_TRY(h, hipMalloc(&h->lim_tv, tv.size()*sizeof(int)));
     HIP_TRY(h, hipMalloc(&h->lim_mean, S*sizeof(double)));
-    HIP_TRY(h, hipMalloc(&h->lim_bfm, (size_t)npc*S*sizeof(double)));
-    HIP_TRY(h, hipMemsetAsync(h->lim_bfm, 0, (size_t)npc*S*sizeof(double), h->stream));
     HIP_TRY(h, hipMalloc(&h->lim_qmin, (size_t)nv*sizeof(double)));
     HIP_TRY(h, hipMalloc(&h->lim_qmax, (size_t)nv*sizeof(double)));
     HIP_TRY(h, hipMemcpy(h->lim_v2c_off, off.data(), off.size()*sizeof(int), hipMemcpyHostToDevice));
@@ -168,17 +155,6 @@ int limiter_apply(Handle *h, int id, int cell_end, bool means_done = false)
     }
     double *t = h->tracers[id].buf[0];
     const int n = h->n_cells, nv = h->lim_nv;
-    const bool fresh = h->lim_fresh_id == id && !std::getenv("THETIS_AMD_LIMITER_UNFUSED");       // (env: A/B and tests)
-    h->lim_fresh_id = -1;                                  // the limited field is not what the means were taken of
-    if (fresh && h->lim_bfm) {
-        // means and boundary-facet means come from the last stage launches of this tracer: bounds + scaling in one launch
-        if (cell_end > 0)
-            hipLaunchKernelGGL(swe_limiter_fused, dim3(grid_for(cell_end)), dim3(256), 0, h->stream, t, h->stride, cell_end, h->lim_tv,
-                               h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_mean, h->lim_bfm, h->npc,
-                               h->affine ? 0 : 1);
-        HIP_TRY(h, hipGetLastError());
-        return SWE2D_OK;
-    }
     if (!means_done)       // swe2d_advance_coupled has the last tracer stage write the means
         hipLaunchKernelGGL(swe_limiter_cell_mean, dim3(grid_for(n)), dim3(256), 0, h->stream, t, h->stride, n, h->lim_mean, h->npc,
                            h->affine ? nullptr : h->cv, h->vx, h->vy);
@@ -230,7 +206,6 @@ int swe2d_tracer_set_options(swe2d_handle *hh, int use_lax_friedrichs_tracer, do
 int swe2d_tracer_set_state(swe2d_handle *hh, int id, const double *nodal)
 {
     Handle *h = H(hh);
-    if (h) h->lim_fresh_id = -1;
     int rc = check_tracer(h, id);
     if (rc) return rc;
     if (!nodal) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
@@ -377,7 +352,6 @@ int swe2d_tracer_set_source(swe2d_handle *hh, int id, const double *nodal)
 int swe2d_tracer_forward_euler(swe2d_handle *hh, int id)
 {
     Handle *h = H(hh);
-    if (h) h->lim_fresh_id = -1;
     int rc = check_tracer(h, id);
     if (rc) return rc;
     if (h->n_owned != h->n_cells) return fail(h, SWE2D_ERR_UNSUPPORTED, "ForwardEuler is not available on partitions");
@@ -393,7 +367,6 @@ int swe2d_tracer_forward_euler(swe2d_handle *hh, int id)
 int swe2d_tracer_swap_buffers(swe2d_handle *hh, int id)
 {
     Handle *h = H(hh);
-    if (h) h->lim_fresh_id = -1;
     int rc = check_tracer(h, id);
     if (rc) return rc;
     std::swap(h->tracers[id].buf[0], h->tracers[id].buf[1]);
@@ -413,7 +386,6 @@ int swe2d_tracer_set_diffusivity(swe2d_handle *hh, int id, int enable, const dou
                                  double sipg_factor_tracer)
 {
     Handle *h = H(hh);
-    if (h) h->lim_fresh_id = -1;
     int rc = check_tracer(h, id);
     if (rc) return rc;
     Handle::Tracer &t = h->tracers[id];
@@ -454,7 +426,6 @@ int swe2d_tracer_solve_stage(swe2d_handle *hh, int id, int i_stage)
 int swe2d_tracer_tendency(swe2d_handle *hh, int id, double *k_nodal)
 {
     Handle *h = H(hh);
-    if (h) h->lim_fresh_id = -1;
     int rc = check_tracer(h, id);
     if (rc) return rc;
     if (!k_nodal) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
@@ -521,7 +492,6 @@ int swe2d_tracer_halo_pack(swe2d_handle *hh, int id, int i_buffer, double *send_
 int swe2d_tracer_halo_unpack(swe2d_handle *hh, int id, int i_buffer, const double *recv_buf_dev)
 {
     Handle *h = H(hh);
-    if (h) h->lim_fresh_id = -1;
     int rc = check_tracer(h, id);
     if (rc) return rc;
     if (i_buffer < 0 || i_buffer > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad buffer index");

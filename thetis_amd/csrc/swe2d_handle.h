@@ -202,9 +202,6 @@ struct Handle {
     int lim_nv = 0;
     int *lim_v2c_off = nullptr, *lim_v2c_cell = nullptr, *lim_vbf_off = nullptr, *lim_vbf_facet = nullptr, *lim_tv = nullptr;
     double *lim_mean = nullptr, *lim_qmin = nullptr, *lim_qmax = nullptr;
-    double *lim_bfm = nullptr;                   // boundary-facet means of the last tracer stage's output (npc planes), see swe_limiter_fused
-    int lim_fresh_id = -1;                       // the tracer whose lim_mean / lim_bfm were written by its last-stage launches and
-                                                 // whose buffer 0 nothing else has written since (-1: none): limiter in one launch
     swe2d_params par{};
     SweBcTable bc{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

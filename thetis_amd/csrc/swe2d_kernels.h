@@ -1578,8 +1578,6 @@ struct SweTracerArgs {
     const double *t0;      // 3 planes (stage_sol[0])
     double *tout;          // 3 planes
     double *mean_out;      // or null: cell means of the output for the limiter (= swe_limiter_cell_mean, same arithmetic)
-    double *bfm_out;       // with mean_out: k planes, plane f = mean of the output's two nodal values on facet f where f is a boundary
-                           // facet (what swe_limiter_vertex_bounds forms from the field) - for swe_limiter_fused
     // horizontal diffusion fused into the triangle tracer kernel (DIFF variants; swe_diff_interior)
     const int4 *opp4;      // see SweStageArgs
     const double *mu_v;    // per-vertex diffusivity or null (then mu_const)
@@ -1887,20 +1885,14 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
     if (DIFF) swe_diff_interior(p, k, S8, gt, nb, vid, c, cna, cnb, px, py, nx, ny, twoA, b);
     const double s = 6.0*p.dt*p.beta*swe_rcp(twoA);
     const double sb = b[0] + b[1] + b[2];
-    double msum = 0.0, o[3];
+    double msum = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        o[i] = s*(4.0*b[i] - sb) + w[i];
-        swe_st(swe_rsrc(p.tout), k8, i*S8, o[i]);
-        msum += o[i];
+        const double o = s*(4.0*b[i] - sb) + w[i];
+        swe_st(swe_rsrc(p.tout), k8, i*S8, o);
+        msum += o;
     }
-    if (p.mean_out) {
-        p.mean_out[k] = msum/3.0;
-        if (p.bfm_out) {
-#pragma unroll
-            for (int f = 0; f < 3; f++) if (nb[f] < 0) p.bfm_out[(size_t)f*S + k] = (o[f] + o[(f + 1) % 3])/2.0;
-        }
-    }
+    if (p.mean_out) p.mean_out[k] = msum/3.0;
 }
 
 // ---- limiter, step 1: cell means (P0 projection of an affine P1 / Q1 field = mean of the nodal values)
@@ -1972,48 +1964,6 @@ static __global__ void swe_limiter_apply(double *t, size_t stride, int n, const 
     for (int i = 0; i < npc; i++) {
         if (c[i] > mean) alpha = fmin(alpha, fmin(1.0, (qmax[vv[i]] - mean)/(c[i] - mean)));
         else if (c[i] < mean) alpha = fmin(alpha, fmin(1.0, (mean - qmin[vv[i]])/(mean - c[i])));
-    }
-    for (int i = 0; i < npc; i++) t[(size_t)i*stride + k] = mean + alpha*(c[i] - mean);
-}
-
-// ---- limiter, steps 2 + 3 in ONE launch (round 5): every cell forms the bounds of its own vertices from the CSR lists (the means
-// of the cells around a vertex are read by each of them: L1 / L2 hits) and limits itself IN PLACE.  In place is race-free because
-// nothing here reads the field of another cell: the means come from `mean`, the boundary-facet means from `bfm`, both written by
-// the last tracer stage launch (SweTracerArgs::mean_out / bfm_out).  min / max are exact and order-independent: the same bits as
-// swe_limiter_vertex_bounds + swe_limiter_apply.  One launch boundary and the qmin / qmax round trip through memory less per step.
-static __global__ void swe_limiter_fused(double *t, size_t stride, int n, const int *tv, const int *v2c_off, const int *v2c_cell,
-                                         const int *vbf_off, const int *vbf_facet, const double *mean_arr, const double *bfm, int npc,
-                                         int mean_from_array)
-{
-    const int k = blockIdx.x*blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    double c[4], qlo[4], qhi[4];
-    double s = 0.0;
-    for (int i = 0; i < npc; i++) {
-        c[i] = t[(size_t)i*stride + k];
-        s += c[i];
-        const int v = tv[(size_t)i*stride + k];
-        double lo = 1.0e10, hi = -1.0e10;
-        const int j0 = v2c_off[v], j1 = v2c_off[v + 1];
-        for (int j = j0; j < j1; j++) {
-            const double m = mean_arr[v2c_cell[j]];
-            lo = fmin(lo, m);
-            hi = fmax(hi, m);
-        }
-        const int b0 = vbf_off[v], b1 = vbf_off[v + 1];
-        for (int j = b0; j < b1; j++) {
-            const int packed = vbf_facet[j];
-            const double fm = bfm[(size_t)(packed & 3)*stride + (packed >> 2)];
-            lo = fmin(lo, fm);
-            hi = fmax(hi, fm);
-        }
-        qlo[i] = lo; qhi[i] = hi;
-    }
-    const double mean = mean_from_array ? mean_arr[k] : s/(double)npc;
-    double alpha = 1.0;
-    for (int i = 0; i < npc; i++) {
-        if (c[i] > mean) alpha = fmin(alpha, fmin(1.0, (qhi[i] - mean)/(c[i] - mean)));
-        else if (c[i] < mean) alpha = fmin(alpha, fmin(1.0, (mean - qlo[i])/(mean - c[i])));
     }
     for (int i = 0; i < npc; i++) t[(size_t)i*stride + k] = mean + alpha*(c[i] - mean);
 }
@@ -2752,42 +2702,30 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
     }
     if constexpr (AFFINE) {
     const double s = p.dt*p.beta*swe_rcp(A);
-    double msum = 0.0, o[4];
+    double msum = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        o[i] = s*(16.0*b[i] - 8.0*b[(i + 1) & 3] - 8.0*b[(i + 3) & 3] + 4.0*b[(i + 2) & 3]) + w[i];
-        swe_st(swe_rsrc(p.tout), k8, i*S8, o[i]);
-        msum += o[i];
+        const double o = s*(16.0*b[i] - 8.0*b[(i + 1) & 3] - 8.0*b[(i + 3) & 3] + 4.0*b[(i + 2) & 3]) + w[i];
+        swe_st(swe_rsrc(p.tout), k8, i*S8, o);
+        msum += o;
     }
-    if (p.mean_out) {
-        p.mean_out[k] = msum/4.0;
-        if (p.bfm_out) {
-#pragma unroll
-            for (int f = 0; f < 4; f++) if (nb[f] < 0) p.bfm_out[(size_t)f*S + k] = (o[f] + o[(f + 1) & 3])/2.0;
-        }
-    }
+    if (p.mean_out) p.mean_out[k] = msum/4.0;
     } else {
     SweQuadMass M;
     SweQuadLDL F;
     swe_quad_mass(A, d1, d2, M);
     swe_quad_mass_factor(M, F);
     swe_quad_mass_solve(F, b);
-    double mw[4], msum = 0.0, o[4];
+    double mw[4], msum = 0.0;
     swe_quad_mean_weights(A, d1, d2, mw);
     const double s = p.dt*p.beta;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        o[i] = s*b[i] + w[i];
-        swe_st(swe_rsrc(p.tout), k8, i*S8, o[i]);
-        msum += mw[i]*o[i];
+        const double o = s*b[i] + w[i];
+        swe_st(swe_rsrc(p.tout), k8, i*S8, o);
+        msum += mw[i]*o;
     }
-    if (p.mean_out) {
-        p.mean_out[k] = msum;         // P0 projection: int o dx / area
-        if (p.bfm_out) {
-#pragma unroll
-            for (int f = 0; f < 4; f++) if (nb[f] < 0) p.bfm_out[(size_t)f*S + k] = (o[f] + o[(f + 1) & 3])/2.0;
-        }
-    }
+    if (p.mean_out) p.mean_out[k] = msum;         // P0 projection: int o dx / area
     }
 }
 
