@@ -22,6 +22,14 @@ OBJ_DIR = os.path.join(CSRC, '.obj')
 LIB = os.path.join(_HERE, 'libswe2d_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+# Per-unit compiler flags.  The dataflow kernels and the quadrilateral kernels are compiled WITHOUT machine LICM: hoisted literal
+# materialisations and address arithmetic stay live across the stage loop / the quadrature, which cost the flow kernels 14-20 VGPRs
+# and every variant with source terms its scratch (254-256 VGPRs + 12-28 B/lane -> 224-242, none), the quadrilateral kernels the
+# third wave of their remaining instances (profiles/r05m_no_machine_licm.txt: flow kernel on one device 17.1 -> 16.8 us per step,
+# quadrilaterals -1.5 ... -2 %).  Not for the triangle stage kernels (no change, although the first-stage epilogue variant reaches
+# four waves per SIMD) and not for the wetting-drying unit (cfg 5 +3 %).
+_NO_MLICM = ['-mllvm', '-disable-machine-licm']
+UNIT_FLAGS = {'swe2d_k_flow.hip': _NO_MLICM, 'swe2d_k_quad.hip': _NO_MLICM}
 # every file a translation unit can include (the fallback when an object has no dependency file yet)
 ALL_DEPS = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(_HERE, '..', 'include', 'swe2d.h')]
 
@@ -64,16 +72,17 @@ def needs_build():
     return False
 
 
-def _compile(unit, verbose, defines=(), obj_dir=None):
+def _compile(unit, verbose, defines=(), obj_dir=None, extra_flags=()):
     o = _obj(unit, obj_dir)
-    cmd = [HIPCC] + FLAGS + ['-D' + d for d in defines] + ['-c', os.path.join(CSRC, unit), '-o', o, '-MD', '-MF', o[:-2] + '.d']
+    cmd = [HIPCC] + FLAGS + list(UNIT_FLAGS.get(unit, [])) + list(extra_flags) + ['-D' + d for d in defines] \
+        + ['-c', os.path.join(CSRC, unit), '-o', o, '-MD', '-MF', o[:-2] + '.d']
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
 
 
-def build(force=False, verbose=False, unity=False, defines=(), lib=None, jobs=None):
-    """Compile the HIP extension; returns the path of the shared library."""
+def build(force=False, verbose=False, unity=False, defines=(), lib=None, jobs=None, extra_flags=()):
+    """Compile the HIP extension; returns the path of the shared library.  ``extra_flags``: compiler flags of a variant build (A/B)."""
     if unity:
         out = lib or LIB
         cmd = [HIPCC] + FLAGS + ['-shared'] + ['-D' + d for d in defines] + [UNITY, '-o', out]
@@ -82,13 +91,13 @@ def build(force=False, verbose=False, unity=False, defines=(), lib=None, jobs=No
         subprocess.check_call(cmd)
         return out
     jobs = jobs or int(os.environ.get('THETIS_AMD_BUILD_JOBS', '0')) or min(len(UNITS), os.cpu_count() or 1)
-    if defines or lib:
+    if defines or lib or extra_flags:
         # a variant: all units with the extra defines, objects next to the variant's library
         out = os.path.abspath(lib or LIB)
         obj_dir = out + '.obj'
         os.makedirs(obj_dir, exist_ok=True)
         with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
-            for f in [ex.submit(_compile, u, verbose, defines, obj_dir) for u in UNITS]:
+            for f in [ex.submit(_compile, u, verbose, defines, obj_dir, extra_flags) for u in UNITS]:
                 f.result()
         subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + [_obj(u, obj_dir) for u in UNITS] + ['-o', out])
         return out

@@ -67,6 +67,12 @@
 #define SWE_FLOW_FLAG_STRIDE 16           // unsigned words between two blocks' stage counters (64 B)
 #endif
 #define SWE_FLOW_SLOT_BYTES 128            // exchange slot of one rim facet and stage parity: 8 granules of 16 B {value, tag, check} (6 values + 2 pads)
+#ifndef SWE_FLOW_NTR_SRC
+#define SWE_FLOW_NTR_SRC 3                 // (SRC ? 1 : 3): the trace addresses of the source-term variants packed, see swe_flow_rhs_facets
+#endif
+#ifndef SWE_FLOW_WALLFAST_SRC
+#define SWE_FLOW_WALLFAST_SRC true         // the closed-wall fast path of swe_boundary_facet also in the variants with source terms
+#endif
 #ifndef SWE_FLOW_RX
 #define SWE_FLOW_RX 3                      // FX receive: granule loads per lane in flight in a trip of a pass
 #endif
@@ -263,9 +269,13 @@ __device__ __forceinline__ void swe_flow_rhs_cell(const SweStageArgs &p, const d
     }
 }
 
-template <bool NONLIN, bool LF, bool SRC>
+// NTR = 3: tr[f][c] holds the two addresses of component c; NTR = 1 (the variants with source terms, which have no registers to
+// spare: 28 B/lane of scratch with the exchange inside, round 4-5): only component 0's pair is kept, the others follow from it -
+// the components of a trace are 1 apart in the staging area (a rim facet: address >= SWE_FLOW_XG) and 3*64 apart in the block's own
+// planes - at the price of eight integer instructions per facet and stage.
+template <bool NONLIN, bool LF, bool SRC, int NTR>
 __device__ __forceinline__ void swe_flow_rhs_facets(const SweStageArgs &p, int k, const double u[3], const double v[3], const double e[3],
-                                                    const double h[3], const double *lds, const unsigned tr[3][3], int bmarkers,
+                                                    const double h[3], const double *lds, const unsigned tr[3][NTR], int bmarkers,
                                                     const double nx[3], const double ny[3], double twoA, double bu[3], double bv[3],
                                                     double be[3])
 {
@@ -276,9 +286,13 @@ __device__ __forceinline__ void swe_flow_rhs_facets(const SweStageArgs &p, int k
         const int a = f, b = (f + 1) % 3;
         const bool bnd = ((bmarkers >> (8*f)) & 0xff) != 0;
         // tr[f][c] = address of component c (u, v, e) at the neighbour's node on my node f + 1 | the same on my node f << 16
-        const double unb = lds[SWE_LDSI(tr[f][0] & 0xffffu, SWE_FLOW_LDS_DOUBLES)], una = lds[SWE_LDSI(tr[f][0] >> 16, SWE_FLOW_LDS_DOUBLES)];
-        const double vnb = lds[SWE_LDSI(tr[f][1] & 0xffffu, SWE_FLOW_LDS_DOUBLES)], vna = lds[SWE_LDSI(tr[f][1] >> 16, SWE_FLOW_LDS_DOUBLES)];
-        const double enb = lds[SWE_LDSI(tr[f][2] & 0xffffu, SWE_FLOW_LDS_DOUBLES)], ena = lds[SWE_LDSI(tr[f][2] >> 16, SWE_FLOW_LDS_DOUBLES)];
+        const unsigned ab0 = tr[f][0] & 0xffffu, aa0 = tr[f][0] >> 16;
+        const unsigned step = ab0 >= (unsigned)SWE_FLOW_XG ? 1u : (unsigned)(3*SWE_BLOCK);
+        const unsigned ab1 = NTR == 3 ? tr[f][NTR - 2] & 0xffffu : ab0 + step, aa1 = NTR == 3 ? tr[f][NTR - 2] >> 16 : aa0 + step;
+        const unsigned ab2 = NTR == 3 ? tr[f][NTR - 1] & 0xffffu : ab0 + 2u*step, aa2 = NTR == 3 ? tr[f][NTR - 1] >> 16 : aa0 + 2u*step;
+        const double unb = lds[SWE_LDSI(ab0, SWE_FLOW_LDS_DOUBLES)], una = lds[SWE_LDSI(aa0, SWE_FLOW_LDS_DOUBLES)];
+        const double vnb = lds[SWE_LDSI(ab1, SWE_FLOW_LDS_DOUBLES)], vna = lds[SWE_LDSI(aa1, SWE_FLOW_LDS_DOUBLES)];
+        const double enb = lds[SWE_LDSI(ab2, SWE_FLOW_LDS_DOUBLES)], ena = lds[SWE_LDSI(aa2, SWE_FLOW_LDS_DOUBLES)];
         const double nxs = nx[f], nys = ny[f];
         double Lf, rLf;
         swe_sqrt_rsqrt(swe_dot2(nxs, nxs, nys, nys), Lf, rLf);
@@ -419,7 +433,8 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 
     // ---- launch invariants of the cell: connectivity, exchange slots, geometry
     int bmarkers, bkind1 = 0;
-    unsigned tr[3][3];                     // LDS addresses of the six traces of every facet (see swe_flow_rhs)
+    constexpr int NTR = SWE_FLOW_NTR_SRC;
+    unsigned tr[3][NTR];                   // LDS addresses of the six traces of every facet (see swe_flow_rhs_facets)
     int xown[3];                           // rim facets: my slot, counted from the block's first slot; else -1
     double h[3], nx[3], ny[3];
     double u[3], v[3], e[3];
@@ -455,7 +470,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             const int ls = rim ? lane : xin[f];
             const int f2 = inw ? (nbf & 3) : f, f2a = f2 == 2 ? 0 : f2 + 1;
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
+            for (int c = 0; c < NTR; c++) {
                 const unsigned ab = rim ? (unsigned)(SWE_FLOW_XG + 6*xin[f] + c) : (unsigned)((3*c + f2)*SWE_BLOCK + ls);
                 const unsigned aa = rim ? (unsigned)(SWE_FLOW_XG + 6*xin[f] + 3 + c) : (unsigned)((3*c + f2a)*SWE_BLOCK + ls);
                 tr[f][c] = ab | (aa << 16);
@@ -675,7 +690,9 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
             for (int i = 0; i < 3; i++) asm volatile("" : "+v"(nx[i]), "+v"(ny[i]), "+v"(h[i]));
             asm volatile("" : "+v"(bmarkers));
 #pragma unroll
-            for (int f = 0; f < 3; f++) asm volatile("" : "+v"(tr[f][0]), "+v"(tr[f][1]), "+v"(tr[f][2]));
+            for (int f = 0; f < 3; f++)
+#pragma unroll
+                for (int c = 0; c < NTR; c++) asm volatile("" : "+v"(tr[f][c]));
             if (i3 == 0) {
 #pragma unroll
                 for (int i = 0; i < 3; i++) { lu0[i][lane] = u[i]; lu0[3 + i][lane] = v[i]; lu0[6 + i][lane] = e[i]; }
@@ -717,9 +734,18 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                         poff[j] = (t < 8*nrim && act_[j]) ? (unsigned)(ent_[j] >> 6)*SWE_FLOW_SLOT_BYTES + 16u*(unsigned)(t & 7) + par : SWE_FLOW_NOWHERE; \
                     }                                                                                                             \
                 } while (0)
-                // (computed once per stage outside the spin loop - eight registers across the loop - the kernel spills: 24-48 B/lane)
+                // Computed ONCE per stage, outside the spin loop, where a pass is one trip (no block of the order has more rim facets than
+                // a trip covers: the product case): a pass is then the granule loads and nothing before them.  (Rounds 3-5 recomputed them
+                // in every pass - eight registers across the loop made the kernel spill 24-48 B/lane; the unit is now compiled without
+                // machine LICM, _build.py UNIT_FLAGS, which left 14-20 registers free.  -DSWE_FLOW_NO_HOIST_POLL: A/B.)
 #ifndef SWE_FLOW_LATE_CELL_TERMS
                 SWE_FLOW_CELL_TERMS_HERE;
+#endif
+#ifndef SWE_FLOW_NO_HOIST_POLL
+                const bool one_trip = 8*nrim <= POLL*SWE_BLOCK;
+                SWE_FLOW_POLL_OFFSETS(0);
+#else
+                const bool one_trip = false;
 #endif
                 for (unsigned spins = 0;; spins++) {
                     bool ok = true;
@@ -735,7 +761,7 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                             gr[j] = swe_flow_get(rex, poff[j]);
                         }
 #else
-                        SWE_FLOW_POLL_OFFSETS(c0);
+                        if (!one_trip) SWE_FLOW_POLL_OFFSETS(c0);
 #pragma unroll
                         for (int j = 0; j < POLL; j++) gr[j] = swe_flow_get(rex, poff[j]);
 #endif
@@ -780,7 +806,7 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
 #endif
 #undef SWE_FLOW_CELL_TERMS_HERE
             double ou[3], ov[3], oe[3], wu[3], wv[3], we[3];
-            swe_flow_rhs_facets<NONLIN, LF, SRC>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+            swe_flow_rhs_facets<NONLIN, LF, SRC, NTR>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
             // w = a0*U(0) + a1*U_in: the first stage of a step has no U(0) term (swe_stage_kernel<., ., HASU0 = false>)
             const double a0 = q.a0[i3], a1 = q.a1[i3];
 #pragma unroll
@@ -796,7 +822,7 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
             // (a lane outside the stage's range has no boundary facets to do: the outermost ghost layer of a partition, which is in no
             //  stage's range, points its missing neighbours at a wall - unmasked, every block that holds such a cell ran the boundary
             //  pass in every stage, +0.8 us for the 300 blocks next to the cuts of a rank of eight)
-            swe_flow_finish<NONLIN, LF, !SRC>(p, k, q.beta[i3], u, v, e, h, nx, ny, twoA, act ? bmarkers : 0, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
+            swe_flow_finish<NONLIN, LF, SWE_FLOW_WALLFAST_SRC || !SRC>(p, k, q.beta[i3], u, v, e, h, nx, ny, twoA, act ? bmarkers : 0, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
 #ifdef SWE_WAVE_TIMING
             if (ou[0] == 1.2345e300) return;          // the arithmetic has to be finished before the time stamp
             SWE_FT(3);

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_MFLOW_OCCUPANCY void swe_mflow_kerne
             }
             __syncthreads();
             double ou[3], ov[3], oe[3];
-            swe_flow_rhs_facets<NONLIN, LF, SRC>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+            swe_flow_rhs_facets<NONLIN, LF, SRC, 3>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
             swe_flow_finish<NONLIN, LF, !SRC>(p, k, q.beta[i3], u, v, e, h, nx, ny, twoA, act ? bmarkers : 0, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
             // ---- publish the rim traces of this stage's result (nobody reads the last stage of the launch)
             if (s + 1 < q.n_stages) {

@@ -31,7 +31,8 @@ def main():
     ap.add_argument('--nx', type=int, default=0, help='mesh RectangleMesh(nx, nx/2) instead of the bench mesh')
     ap.add_argument('--case', default='cfg2', help="cfg2: the bench mesh, shallow water only | cfg4: + one tracer with the limiter (coupled cycles, "
                     "combined exchange) | cfg4_tracer_only: the tracer alone (demo_2d_tracer mode) | cfg5: the Balzano geometry at 500 k "
-                    "triangles with wetting-drying, Manning friction and the tidal boundary (BASELINE cfg 5), strips along x")
+                    "triangles with wetting-drying, Manning friction and the tidal boundary (BASELINE cfg 5), strips along x | cfg2_src: cfg2 + a "
+                    "Coriolis field + Manning friction (the kernels with source terms)")
     ap.add_argument('--timing', action='store_true', help='-DSWE_WAVE_TIMING -DSWE_FLOW_TS_STAGE=S build of the library (THETIS_AMD_LIB): '
                     "per-block time stamps of stage S of the last flow launch, by the block's role")
     args = ap.parse_args()
@@ -88,6 +89,11 @@ def main():
                                      exchange=('p2p' if args.exchange == 'p2p' else 'rccl'), split_last_stage=not args.nosplit,
                                      graph_mode=args.graph_mode,
                                      flow=(None if args.flow < 0 else bool(args.flow)), flow_exchange=(None if args.flowx < 0 else bool(args.flowx)), **kw)
+    if args.case == 'cfg2_src':                   # the bench mesh with optional terms: Coriolis field + Manning friction (the SRC kernels)
+        from thetis_amd import _lib
+        s.dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+        s.dev.set_field(_lib.FIELD_CORIOLIS, 1.0e-4)
+        s.config_changed()
     if args.case == 'cfg5':
         s.dev.set_wetting_and_drying(0.4)
         s.dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
