@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 5, run o: the early pass of the flow kernel (the next stage's granule loads issued before this stage's publish, looked at
+# round 5, run p: the LDS ordering points of the flow kernel without the vector-memory drain of __syncthreads() (product) against __syncthreads() (-DSWE_FLOW_SYNCTHREADS);
 # after it) against the same kernel without it (-DSWE_FLOW_NO_EARLY); flow / distributed / spmd tests; the adversaries of the granule
 # protocol (-DSWE_FLOW_DELAY, -DSWE_FLOW_TEAR, -DSWE_FLOW_TEAR -DSWE_FLOW_NOCHECK) built from this tree
 set -u
-O=gpurun_out/r05o; rm -rf $O; mkdir -p $O
+O=gpurun_out/r05p; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 timeout 2400 python -m pytest tests/test_gpu_flow_kernel.py tests/test_distributed.py tests/test_gpu_spmd.py tests/test_gpu_fuzz.py -q -m gpu -x > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -3 $O/gpu_tests.log | cut -c1-300
 THETIS_AMD_LIB=$PWD/build_dbg/libswe2d_delay.so timeout 1200 python -m pytest tests/test_gpu_flow_kernel.py tests/test_distributed.py -m gpu -q -k "lags or lagging" 2>&1 | tail -3 | sed "s/^/[delay] /" | tee -a $O/adversaries.txt
@@ -13,7 +13,7 @@ done
 rb() { timeout 300 python tools/rankbench.py --case $1 --world 8 --rank $2 --every 2 --exchange p2p --nosplit --flow 1 --flowx 1 --graph-mode full --steps 1920 2>&1 | tail -1; }
 kb() { THETIS_AMD_FLOW=1 timeout 300 python tools/kbench.py --nx $1 --ny $2 --steps 384 --prewarm 0.5 --tag flow1 2>&1 | tail -1; }
 for rep in 1 2 3; do
-  for v in product noearly; do
+  for v in product syncthreads; do
     if [ $v = product ]; then unset THETIS_AMD_LIB; else export THETIS_AMD_LIB=$PWD/build_dbg/libswe2d_$v.so; fi
     rb cfg2 3 | sed "s/^/$v /" >> $O/rank_ab.txt
     rb cfg2 0 | sed "s/^/$v /" >> $O/rank_ab.txt
