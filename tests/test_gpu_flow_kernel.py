@@ -207,7 +207,9 @@ def test_flow_is_refused_where_it_does_not_apply(hip_lib, monkeypatch):
     from thetis_amd._lib import Swe2dError
     mesh, bath, uv, eta = channel_case(nx=9, ny=5, seed=1)
     dev = _device(mesh, bath - 0.6*bath.max(), 0.05)
-    dev.set_wetting_and_drying(0.5)
+    dev.set_wetting_and_drying(0.5)                  # wetting-drying is covered since round 5 ...
+    assert dev.flow_supported()
+    dev.set_viscosity(1.0)                           # ... viscosity is not
     assert not dev.flow_supported()
     with pytest.raises(Swe2dError):
         dev.solve_flow([dev.n_cells]*3)
@@ -421,3 +423,74 @@ def test_advance_takes_several_blocks_per_wave_on_its_own(hip_lib, monkeypatch):
         res.append(dev.get_state())
         dev.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def _beach(nx, ny, seed):
+    """A sloping beach with dry ground at rest level (the Balzano geometry in small): bed -h from -1.2 m (sea) to +0.6 m (land)."""
+    from thetis_amd.mesh import RectangleMesh
+    mesh = RectangleMesh(nx, ny, 13800.0, 7200.0)
+    x, y = mesh.vertex_xy.T
+    bath = 1.2 - 1.8*x/13800.0 + 0.05*np.sin(y/900.0)
+    rng = np.random.default_rng(seed)
+    cxy = mesh.cell_xy()
+    eta = 0.1*np.cos(cxy[:, :, 0]/4000.0) + 0.02*rng.uniform(-1, 1, size=(mesh.num_cells, 3))
+    uv = 0.05*rng.uniform(-1, 1, size=(mesh.num_cells, 3, 2))
+    return mesh, bath, uv, eta
+
+
+@pytest.mark.parametrize('case', ['plain', 'manning_tide', 'no_lf', 'sources_large', 'ranges'])
+def test_flow_launch_with_wetting_and_drying_gives_the_bits_of_the_stage_launches(hip_lib, case, monkeypatch):
+    """swe_flow_kernel<..., WD> (round 5): the block's values, rim granules and U(0) are the displaced depth D the planes hold, the
+    elevation is recovered per stage, the stage ends with the positivity limiter and the dry-ground relaxation - bit for bit
+    swe_stage_kernel<true, LF, ., SRC, true> on a beach with dry cells, with Manning friction and a tidal boundary, on shrinking
+    ranges, over several launches; swe2d_advance takes the kernel by itself and THETIS_AMD_FLOW_WD=0 keeps it away."""
+    from thetis_amd import _lib
+    nx, ny = (250, 125) if case == 'sources_large' else (61, 29)
+    mesh, bath, uv, eta = _beach(nx, ny, seed=5)
+    kw = {'use_lax_friedrichs_velocity': False} if case == 'no_lf' else {}
+    n_steps = 6
+    out = []
+    for flow in (False, True, 'advance'):
+        if case == 'ranges':
+            kw['reorder'] = None                       # natural numbering: a cell's neighbours lie within one mesh row of 2 nx cells
+        dev = _device(mesh, bath, 0.4 if nx < 100 else 0.1, **kw)
+        dev.set_wetting_and_drying(0.4)
+        if case in ('manning_tide', 'sources_large', 'ranges'):
+            dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+            dev.set_bc(mesh.boundary_markers[0], {'elev': -0.3})
+        if case == 'sources_large':
+            dev.set_field(_lib.FIELD_CORIOLIS, 1e-4*np.ones((mesh.num_cells, 3)))
+        assert dev.flow_supported() == (2 if case in ('plain', 'no_lf') else 1)
+        dev.set_state(uv, eta)
+        n = dev.n_cells
+        if case == 'ranges':
+            ends = [n - 2*nx*s for s in range(12)]                             # the shrinking ranges of an exchange cycle
+        else:
+            ends = [n]*(3*n_steps)
+        if flow == 'advance':
+            if case == 'ranges':
+                dev.close()
+                continue
+            dev.advance(n_steps)                                               # picks the flow kernel by itself
+        elif flow:
+            if case == 'ranges':
+                dev.solve_flow(ends)
+            else:
+                dev.solve_flow(ends[:6])
+                dev.solve_flow(ends[6:])
+        else:
+            _by_stage(dev, ends)
+        out.append(dev.get_state())
+        assert dev.flow_timeouts() == 0
+        dev.close()
+    assert np.isfinite(out[0][0]).all() and np.isfinite(out[0][1]).all()
+    depth = out[0][1] + bath[mesh.cells]
+    assert (depth < 0.0).any() and (depth > 0.5).any()                          # dry land and open water in the same mesh
+    for o in out[1:]:
+        assert np.array_equal(out[0][0], o[0]) and np.array_equal(out[0][1], o[1])
+    if case == 'plain':
+        monkeypatch.setenv('THETIS_AMD_FLOW_WD', '0')
+        dev = _device(mesh, bath, 0.4)
+        dev.set_wetting_and_drying(0.4)
+        assert dev.flow_supported() == 0
+        dev.close()

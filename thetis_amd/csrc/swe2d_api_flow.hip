@@ -119,11 +119,16 @@ int flow_build(Handle *h, const int32_t *order)
     return SWE2D_OK;
 }
 
-// the configurations the flow kernel covers (the step kernel's: triangles, no wetting-drying, no viscosity)
+// the configurations the flow kernel covers: triangles, no viscosity; wetting-drying since round 5 (swe_flow_kernel<..., WD>, nonlinear
+// equations as in the stage kernels; THETIS_AMD_FLOW_WD=0 leaves it to the stage launches)
 bool flow_kernel_covers(const Handle *h)
 {
     const char *e = std::getenv("THETIS_AMD_BND_INLINE");
-    return h->npc == 3 && !h->wd && !h->visc && h->idx4 && h->flow_flag && h->flow_ex && !(e && std::atoi(e) == 0);
+    if (h->wd) {
+        const char *w = std::getenv("THETIS_AMD_FLOW_WD");
+        if (!h->par.use_nonlinear_equations || (w && std::atoi(w) == 0)) return false;
+    }
+    return h->npc == 3 && !h->visc && h->idx4 && h->flow_flag && h->flow_ex && !(e && std::atoi(e) == 0);
 }
 
 // Resident one-wave workgroups of the flow kernel: every block of a launch must be resident (a block waits for its
@@ -164,7 +169,7 @@ int mflow_capacity(Handle *h)
 int mflow_blocks_per_wave(Handle *h)
 {
     const char *on = std::getenv("THETIS_AMD_MFLOW");
-    if (!on || std::atoi(on) == 0) return 0;
+    if (!on || std::atoi(on) == 0 || h->wd) return 0;          // (no wetting-drying instances of the multi-block kernel)
     const int cap = (mflow_capacity(h)/8)*8;                   // the XCD-chunked block map needs a grid that is a multiple of 8
     if (cap <= 0) return 0;
     int kmax = 8;
@@ -211,7 +216,7 @@ int flow_build_exchange(Handle *h)
 // n_stages stages each with the peer-to-peer halo exchange (channel 0) inside the launch
 int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles)
 {
-    if (!flow_kernel_covers(h)) return fail(h, SWE2D_ERR_UNSUPPORTED, "the flow kernel covers triangles without wetting-drying and viscosity");
+    if (!flow_kernel_covers(h)) return fail(h, SWE2D_ERR_UNSUPPORTED, "the flow kernel covers triangles without viscosity (wetting-drying: nonlinear equations)");
     const bool fx = n_cycles > 0;
     const int total = n_stages*(fx ? n_cycles : 1);
     if (n_stages <= 0 || n_stages % 3 != 0 || total > SWE_FLOW_MAX_STAGES || n_cycles > SWE_FLOW_MAX_CYCLES)
@@ -227,7 +232,7 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles)
                                                               : "flow: more 64-cell blocks than the device holds resident, also with several blocks per wave");
         grid = (((h->flow_blocks + K - 1)/K + 7)/8)*8;
     } else if (!fx) {
-        if (const char *e = std::getenv("THETIS_AMD_MFLOW_FORCE_K")) {       // tests / A-B: the multi-block kernel on a range the one-block kernel covers
+        if (const char *e = std::getenv("THETIS_AMD_MFLOW_FORCE_K"); e && !h->wd) {       // tests / A-B: the multi-block kernel on a range the one-block kernel covers
             K = std::max(1, std::atoi(e));
             if (K > 1) grid = (((h->flow_blocks + K - 1)/K + 7)/8)*8;
         }
@@ -271,7 +276,8 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles)
     for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) q.cell_end[s] = s < n_stages ? cell_end[s] : 0;
     for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
     q.timeout_ticks = (unsigned long long)(h->flow_timeout_s*1e8);
-    flow_kernel_t kern = K > 1 ? pick_mflow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h),
+    flow_kernel_t kern = h->wd ? pick_flow_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_sources(h), fx, h->flow_max_rim > 64)
+                       : K > 1 ? pick_mflow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h),
                                                    h->flow_max_rim > 64)
                                : pick_flow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h), fx,
                                                   h->flow_max_rim > 64);

@@ -234,17 +234,19 @@ __device__ __forceinline__ bool swe_flow_arrived(swe_u32x4 g, unsigned need)
 // neighbour's node on my node f + 1; u, v, e at its node on my node f} - the block's own stage values for a neighbour inside
 // the block (a boundary facet points at this cell itself), the incoming staging entry for a rim facet.
 // Lines as in swe_stage_kernel, same order.
-template <bool NONLIN>
+// WD (wetting-drying, round 5): e[] is the elevation recovered from the displaced depth D the planes hold, Dn[] that depth = the
+// nodal total depth (swe_stage_kernel<..., WD>)
+template <bool NONLIN, bool WD = false>
 __device__ __forceinline__ void swe_flow_rhs_cell(const SweStageArgs &p, const double u[3], const double v[3], const double e[3],
                                                   const double h[3], const double nx[3], const double ny[3], double bu[3], double bv[3],
-                                                  double be[3])
+                                                  double be[3], const double *Dn = nullptr)
 {
 #pragma clang fp contract(off)
     const double g = p.g;
     double H[3], gxs[3], gys[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        H[i] = NONLIN ? h[i] + e[i] : h[i];
+        H[i] = WD ? Dn[i] : (NONLIN ? h[i] + e[i] : h[i]);
         gxs[i] = -0.5*nx[(i + 1) % 3];                     // A*grad(phi_i) = -nF_{i+1}/2
         gys[i] = -0.5*ny[(i + 1) % 3];
     }
@@ -273,11 +275,11 @@ __device__ __forceinline__ void swe_flow_rhs_cell(const SweStageArgs &p, const d
 // spare: 28 B/lane of scratch with the exchange inside, round 4-5): only component 0's pair is kept, the others follow from it -
 // the components of a trace are 1 apart in the staging area (a rim facet: address >= SWE_FLOW_XG) and 3*64 apart in the block's own
 // planes - at the price of eight integer instructions per facet and stage.
-template <bool NONLIN, bool LF, bool SRC, int NTR>
+template <bool NONLIN, bool LF, bool SRC, int NTR, bool WD = false>
 __device__ __forceinline__ void swe_flow_rhs_facets(const SweStageArgs &p, int k, const double u[3], const double v[3], const double e[3],
                                                     const double h[3], const double *lds, const unsigned tr[3][NTR], int bmarkers,
                                                     const double nx[3], const double ny[3], double twoA, double bu[3], double bv[3],
-                                                    double be[3])
+                                                    double be[3], const double *Dn = nullptr, const double *al = nullptr)
 {
 #pragma clang fp contract(off)
     const double g = p.g;
@@ -297,6 +299,12 @@ __device__ __forceinline__ void swe_flow_rhs_facets(const SweStageArgs &p, int k
         double Lf, rLf;
         swe_sqrt_rsqrt(swe_dot2(nxs, nxs, nys, nys), Lf, rLf);
         double Fau, Fbu, Fav, Fbv, Fae, Fbe;
+        if constexpr (WD) {
+            // the neighbour's traces carry its nodal depth D; its elevation by the closed form (bathymetry and alpha are continuous)
+            const double ena_ = swe_wd_eta(ena, h[a], al[a]), enb_ = swe_wd_eta(enb, h[b], al[b]);
+            swe_facet_flux<NONLIN, LF, true>(g, p.sigma_lf, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], Dn[a], Dn[b], una, unb, vna, vnb,
+                                             ena_, enb_, ena, enb, nxs, nys, Lf, rLf, Fau, Fbu, Fav, Fbv, Fae, Fbe);
+        } else
         swe_facet_flux<NONLIN, LF, false>(g, p.sigma_lf, u[a], u[b], v[a], v[b], e[a], e[b], h[a], h[b], 0.0, 0.0, una, unb, vna, vnb, ena, enb,
                                           0.0, 0.0, nxs, nys, Lf, rLf, Fau, Fbu, Fav, Fbv, Fae, Fbe);
         if (bnd) { Fau = 0.0; Fbu = 0.0; Fav = 0.0; Fbv = 0.0; Fae = 0.0; Fbe = 0.0; }
@@ -308,7 +316,7 @@ __device__ __forceinline__ void swe_flow_rhs_facets(const SweStageArgs &p, int k
         double H[3], gxs[3], gys[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            H[i] = NONLIN ? h[i] + e[i] : h[i];
+            H[i] = WD ? Dn[i] : (NONLIN ? h[i] + e[i] : h[i]);
             gxs[i] = -0.5*nx[(i + 1) % 3];
             gys[i] = -0.5*ny[(i + 1) % 3];
         }
@@ -318,12 +326,12 @@ __device__ __forceinline__ void swe_flow_rhs_facets(const SweStageArgs &p, int k
 
 // mass inverse, Shu-Osher combine and the boundary facets of the cell (the BINL pass of swe_stage_kernel)
 // (WALLFAST: the closed-wall path of swe_boundary_facet; not in the variants with source terms - no registers to spare, 68 B of scratch)
-template <bool NONLIN, bool LF, bool WALLFAST>
+template <bool NONLIN, bool LF, bool WALLFAST, bool WD = false>
 __device__ __forceinline__ void swe_flow_finish(const SweStageArgs &p, int k, double beta, const double u[3], const double v[3],
                                                 const double e[3], const double h[3], const double nx[3], const double ny[3],
                                                 double twoA, int bmarkers, int bkind1, const double bu[3], const double bv[3], const double be[3],
                                                 const double wu[3], const double wv[3], const double we[3], double ou[3],
-                                                double ov[3], double oe[3])
+                                                double ov[3], double oe[3], const double *Dn = nullptr, const double *al = nullptr)
 {
 #pragma clang fp contract(off)
     const double s = 6.0*p.dt*beta*swe_rcp(twoA);
@@ -342,6 +350,8 @@ __device__ __forceinline__ void swe_flow_finish(const SweStageArgs &p, int k, do
         // address and the arrays end up in scratch
         const double u_0 = u[0], u_1 = u[1], u_2 = u[2], v_0 = v[0], v_1 = v[1], v_2 = v[2], e_0 = e[0], e_1 = e[1], e_2 = e[2];
         const double h_0 = h[0], h_1 = h[1], h_2 = h[2], nx_0 = nx[0], nx_1 = nx[1], nx_2 = nx[2], ny_0 = ny[0], ny_1 = ny[1], ny_2 = ny[2];
+        const double D_0 = WD ? Dn[0] : 0.0, D_1 = WD ? Dn[1] : 0.0, D_2 = WD ? Dn[2] : 0.0;
+        const double al_0 = WD ? al[0] : 0.0, al_1 = WD ? al[1] : 0.0, al_2 = WD ? al[2] : 0.0;
 #define SWE_SEL3(x, i) ((i) == 0 ? x##_0 : ((i) == 1 ? x##_1 : x##_2))
 #pragma unroll 1
         while (rem) {
@@ -352,11 +362,12 @@ __device__ __forceinline__ void swe_flow_finish(const SweStageArgs &p, int k, do
             double Lf, rLf;
             swe_sqrt_rsqrt(swe_dot2(nxs, nxs, nys, nys), Lf, rLf);
             double Fau = 0.0, Fbu = 0.0, Fav = 0.0, Fbv = 0.0, Fae = 0.0, Fbe = 0.0;
-            const double Ha_ = !NONLIN ? SWE_SEL3(h, a) : SWE_SEL3(h, a) + SWE_SEL3(e, a);
-            const double Hb_ = !NONLIN ? SWE_SEL3(h, b) : SWE_SEL3(h, b) + SWE_SEL3(e, b);
-            swe_boundary_facet<NONLIN, LF, false, WALLFAST>(p, (bmarkers >> (8*f)) & 0xff, k, a, b, SWE_SEL3(u, a), SWE_SEL3(u, b), SWE_SEL3(v, a),
+            const double Ha_ = WD ? SWE_SEL3(D, a) : (!NONLIN ? SWE_SEL3(h, a) : SWE_SEL3(h, a) + SWE_SEL3(e, a));
+            const double Hb_ = WD ? SWE_SEL3(D, b) : (!NONLIN ? SWE_SEL3(h, b) : SWE_SEL3(h, b) + SWE_SEL3(e, b));
+            swe_boundary_facet<NONLIN, LF, WD, WALLFAST>(p, (bmarkers >> (8*f)) & 0xff, k, a, b, SWE_SEL3(u, a), SWE_SEL3(u, b), SWE_SEL3(v, a),
                                                   SWE_SEL3(v, b), SWE_SEL3(e, a), SWE_SEL3(e, b), SWE_SEL3(h, a), SWE_SEL3(h, b),
-                                                  Ha_, Hb_, 0.0, 0.0, nxs, nys, Lf, rLf, Fau, Fbu, Fav, Fbv, Fae, Fbe, kind_next);
+                                                  Ha_, Hb_, WD ? SWE_SEL3(al, a) : 0.0, WD ? SWE_SEL3(al, b) : 0.0, nxs, nys, Lf, rLf, Fau, Fbu, Fav,
+                                                  Fbv, Fae, Fbe, kind_next);
             kind_next = -1;
             const double dau = -0.5*Fau, dbu = -0.5*Fbu, dav = -0.5*Fav, dbv = -0.5*Fbv, dae = -0.5*Fae, dbe = -0.5*Fbe;
 #pragma unroll
@@ -369,6 +380,8 @@ __device__ __forceinline__ void swe_flow_finish(const SweStageArgs &p, int k, do
         }
 #undef SWE_SEL3
     }
+    // zeta = D - h -> the limited depth D the device carries; dry-ground relaxation of the velocity (swe_stage_kernel<..., WD>)
+    if constexpr (WD) swe_wd_finish<3>(p.g, beta*p.dt, h, al, ou, ov, oe, !p.wd_skip_relax);
 }
 
 #ifdef SWE_WAVE_TIMING
@@ -397,7 +410,11 @@ __device__ __forceinline__ void swe_flow_finish(const SweStageArgs &p, int k, do
 // slowed a 131 k-cell mesh from 18.7 to 22.1 us per step; a ninth load in EVERY block costs 0.3 us per step (its issue slot and its
 // place in the return queue, even when all lanes point nowhere).  The host picks POLL = 8 when no block of the flow order has more
 // than 64 rim facets, 9 otherwise (launch_flow); same results either way.
-template <bool NONLIN, bool LF, bool SRC, bool FX, int POLL = 8>
+// WD (round 5): wetting-drying.  The "elevation" values of the block - registers, LDS planes, rim granules, U(0), the exchange records -
+// are the displaced depth D the state planes hold; the elevation is recovered per stage (own nodes before the wave starts to wait,
+// the neighbours' where the fluxes are formed), the stage ends with swe_wd_finish: swe_stage_kernel<true, LF, ., SRC, true>'s
+// operations.  alpha of the cell's vertices stays in registers with the rest of the geometry.
+template <bool NONLIN, bool LF, bool SRC, bool FX, int POLL = 8, bool WD = false>
 __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(const SweFlowArgs q)
 {
 #pragma clang fp contract(off)
@@ -433,10 +450,10 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
 
     // ---- launch invariants of the cell: connectivity, exchange slots, geometry
     int bmarkers, bkind1 = 0;
-    constexpr int NTR = SWE_FLOW_NTR_SRC;
+    constexpr int NTR = WD ? 1 : SWE_FLOW_NTR_SRC;          // (wetting-drying: no registers to spare, see swe_flow_rhs_facets)
     unsigned tr[3][NTR];                   // LDS addresses of the six traces of every facet (see swe_flow_rhs_facets)
     int xown[3];                           // rim facets: my slot, counted from the block's first slot; else -1
-    double h[3], nx[3], ny[3];
+    double h[3], nx[3], ny[3], al[3] = {0.0, 0.0, 0.0};
     double u[3], v[3], e[3];
     {
         const int4 q4 = p.idx4[k];
@@ -493,6 +510,7 @@ __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(
             px[i] = swe_ld(rvx, v8, 0);
             py[i] = swe_ld(rvy, v8, 0);
             h[i] = swe_ld(rvh, v8, 0);
+            if (WD) al[i] = swe_ld(swe_rsrc(p.valpha), v8, 0);
         }
 #pragma unroll
         for (int f = 0; f < 3; f++) {
@@ -688,6 +706,10 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
             // them in every stage as well.
 #pragma unroll
             for (int i = 0; i < 3; i++) asm volatile("" : "+v"(nx[i]), "+v"(ny[i]), "+v"(h[i]));
+            if (WD) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) asm volatile("" : "+v"(al[i]));
+            }
             asm volatile("" : "+v"(bmarkers));
 #pragma unroll
             for (int f = 0; f < 3; f++)
@@ -709,7 +731,11 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
             // Same operations in the same order as before: the same bits.
             double bu[3], bv[3], be[3];
             const double twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
-#define SWE_FLOW_CELL_TERMS_HERE swe_flow_rhs_cell<NONLIN>(p, u, v, e, h, nx, ny, bu, bv, be)
+            // wetting-drying: e[] holds D; the elevation of the own nodes (three reciprocals) is formed here, before the wait
+            double eta[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) eta[i] = WD ? swe_wd_eta(e[i], h[i], al[i]) : e[i];
+#define SWE_FLOW_CELL_TERMS_HERE swe_flow_rhs_cell<NONLIN, WD>(p, u, v, eta, h, nx, ny, bu, bv, be, e)
             if (FX || g > 0) {
                 SWE_FLOW_DELAY_AT(1);
                 const int pc_in = FX ? c*spc + g : g - 1;      // the publish this stage reads
@@ -742,8 +768,8 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                 SWE_FLOW_CELL_TERMS_HERE;
 #endif
 #ifndef SWE_FLOW_NO_HOIST_POLL
-                const bool one_trip = 8*nrim <= POLL*SWE_BLOCK;
-                SWE_FLOW_POLL_OFFSETS(0);
+                const bool one_trip = !WD && 8*nrim <= POLL*SWE_BLOCK;      // (not with wetting-drying: eight registers too many)
+                if constexpr (!WD) SWE_FLOW_POLL_OFFSETS(0);
 #else
                 const bool one_trip = false;
 #endif
@@ -806,23 +832,24 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
 #endif
 #undef SWE_FLOW_CELL_TERMS_HERE
             double ou[3], ov[3], oe[3], wu[3], wv[3], we[3];
-            swe_flow_rhs_facets<NONLIN, LF, SRC, NTR>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
-            // w = a0*U(0) + a1*U_in: the first stage of a step has no U(0) term (swe_stage_kernel<., ., HASU0 = false>)
+            swe_flow_rhs_facets<NONLIN, LF, SRC, NTR, WD>(p, k, u, v, eta, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be, e, al);
+            // w = a0*U(0) + a1*U_in: the first stage of a step has no U(0) term (swe_stage_kernel<., ., HASU0 = false>); with
+            // wetting-drying the continuity equation advances zeta = D - h (the planes, U(0)'s too, hold D)
             const double a0 = q.a0[i3], a1 = q.a1[i3];
 #pragma unroll
-            for (int i = 0; i < 3; i++) { wu[i] = a1*u[i]; wv[i] = a1*v[i]; we[i] = a1*e[i]; }
+            for (int i = 0; i < 3; i++) { wu[i] = a1*u[i]; wv[i] = a1*v[i]; we[i] = WD ? a1*(e[i] - h[i]) : a1*e[i]; }
             if (i3 > 0) {
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
                     wu[i] = fma(a0, lu0[i][lane], wu[i]);
                     wv[i] = fma(a0, lu0[3 + i][lane], wv[i]);
-                    we[i] = fma(a0, lu0[6 + i][lane], we[i]);
+                    we[i] = fma(a0, WD ? lu0[6 + i][lane] - h[i] : lu0[6 + i][lane], we[i]);
                 }
             }
             // (a lane outside the stage's range has no boundary facets to do: the outermost ghost layer of a partition, which is in no
             //  stage's range, points its missing neighbours at a wall - unmasked, every block that holds such a cell ran the boundary
             //  pass in every stage, +0.8 us for the 300 blocks next to the cuts of a rank of eight)
-            swe_flow_finish<NONLIN, LF, SWE_FLOW_WALLFAST_SRC || !SRC>(p, k, q.beta[i3], u, v, e, h, nx, ny, twoA, act ? bmarkers : 0, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
+            swe_flow_finish<NONLIN, LF, SWE_FLOW_WALLFAST_SRC || !SRC, WD>(p, k, q.beta[i3], u, v, eta, h, nx, ny, twoA, act ? bmarkers : 0, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe, e, al);
 #ifdef SWE_WAVE_TIMING
             if (ou[0] == 1.2345e300) return;          // the arithmetic has to be finished before the time stamp
             SWE_FT(3);

@@ -9,4 +9,5 @@
 #include "swe2d_k_wd.hip"
 #include "swe2d_k_quad.hip"
 #include "swe2d_k_flow.hip"
+#include "swe2d_k_flow_wd.hip"
 #include "swe2d_k_tracer.hip"
