@@ -362,7 +362,8 @@ int  swe2d_swap_state_buffers(swe2d_handle *h);
  * are not produced.  swe2d_advance uses it on its own where it applies (THETIS_AMD_FLOW=0: never).  Needs every block of the
  * handle resident at once:
  * swe2d_flow_supported returns 0 when the mesh is too large for that (or the configuration is not covered: quadrilaterals,
- * wetting-drying, viscosity), 1 covered, 2 covered and without source terms; 3 / 4 (round 5, only with THETIS_AMD_MFLOW=1 in the
+ * viscosity; wetting-drying IS covered since round 5 - csrc/swe2d_k_flow_wd.hip, THETIS_AMD_FLOW_WD=0 leaves it to the stage
+ * launches), 1 covered, 2 covered and without source terms; 3 / 4 (round 5, only with THETIS_AMD_MFLOW=1 in the
  * environment - measured slower than the stage launches, kept as an option): the same through the multi-block kernel
  * (csrc/swe2d_mflow.h: a wave owns up to 8 consecutive 64-cell blocks and keeps their stage values in the state buffers like
  * the stage launches do - cell ranges up to 8 x the one-block limit; swe2d_solve_flow and swe2d_advance take it on their own, the
