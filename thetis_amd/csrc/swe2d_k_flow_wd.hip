@@ -10,9 +10,10 @@ static flow_kernel_t pick_flow_wd_src(bool src, bool fx)
     if (fx) return src ? swe_flow_kernel<true, LF, true, true, POLL, true> : swe_flow_kernel<true, LF, false, true, POLL, true>;
     return src ? swe_flow_kernel<true, LF, true, false, POLL, true> : swe_flow_kernel<true, LF, false, false, POLL, true>;
 }
-// wetting-drying variants (nonlinear equations only); wide: see pick_flow_kernel
-flow_kernel_t pick_flow_kernel_wd(bool lf, bool src, bool fx, bool wide)
+// wetting-drying variants (nonlinear equations only); poll: see pick_flow_kernel
+flow_kernel_t pick_flow_kernel_wd(bool lf, bool src, bool fx, int poll)
 {
-    if (wide) return lf ? pick_flow_wd_src<true, 9>(src, fx) : pick_flow_wd_src<false, 9>(src, fx);
-    return lf ? pick_flow_wd_src<true, 8>(src, fx) : pick_flow_wd_src<false, 8>(src, fx);
+    if (poll >= 9) return lf ? pick_flow_wd_src<true, 9>(src, fx) : pick_flow_wd_src<false, 9>(src, fx);
+    if (poll >= 8) return lf ? pick_flow_wd_src<true, 8>(src, fx) : pick_flow_wd_src<false, 8>(src, fx);
+    return lf ? pick_flow_wd_src<true, 4>(src, fx) : pick_flow_wd_src<false, 4>(src, fx);
 }

@@ -14,9 +14,9 @@ stage_kernel_t pick_kernel_wd(bool lf, bool u0, bool src, int quad, bool binl);
 // triangles with the horizontal viscosity fused in (swe_visc_interior)
 stage_kernel_t pick_kernel_visc(bool nl, bool lf, bool u0, bool src);
 stage_kernel_t pick_kernel_quad(bool nl, bool lf, bool u0, bool src, bool affine);
-// wide: some block of the flow order has more than 64 rim facets (one more granule load per lane and polling trip)
-flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src, bool fx = false, bool wide = false);
-flow_kernel_t pick_flow_kernel_wd(bool lf, bool src, bool fx, bool wide);       // wetting-drying (swe2d_k_flow_wd.hip)
+// poll: granule loads per lane and polling trip (4 / 8 / 9 for blocks of at most 32 / 64 / more rim facets)
+flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src, bool fx = false, int poll = 8);
+flow_kernel_t pick_flow_kernel_wd(bool lf, bool src, bool fx, int poll);        // wetting-drying (swe2d_k_flow_wd.hip)
 // swe2d_mflow.h: several consecutive blocks per wave (cell ranges beyond the one-block kernel's residency), no exchange inside
 flow_kernel_t pick_mflow_kernel(bool nl, bool lf, bool src, bool wide);
 tracer_kernel_t pick_tracer_kernel(bool lf, bool t0, bool src);

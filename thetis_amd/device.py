@@ -5,6 +5,7 @@ Arrays cross the boundary in the reference's dof layout (cell c owns nodes 3c..3
 ``eta`` (N,3) float64.
 """
 import ctypes
+import os
 import numpy as np
 
 from . import _lib, ordering
@@ -140,6 +141,11 @@ class Swe2dDevice(object):
         p.device_id = device_id
         self.h = ctypes.c_void_p()
         _lib.check(self.lib.swe2d_create(ctypes.byref(m), ctypes.byref(p), ctypes.byref(self.h)))
+        if (self.npc == 3 and isinstance(reorder, str) and reorder == 'auto' and self.n_owned == self.n_cells
+                and getattr(mesh, 'structured', False) and self.n_cells <= 196608 and os.environ.get('THETIS_AMD_FLOW_BLOCKS', '1') != '0'):
+            # a mesh small enough for the dataflow kernel (swe2d_advance takes it by itself): its 64-cell blocks as compact tiles
+            # (ordering.flow_block_order) instead of two mesh rows of the device numbering - a third fewer rim facets
+            self.flow_set_order(ordering.flow_block_order(mesh))
         if self.npc == 4 and not getattr(mesh, 'affine', True):
             # a partition (LocalPartition.affine = the GLOBAL mesh's flag) whose own cells happen to be parallelograms takes the
             # general kernels like every other rank: ghost and owned copies of a cell then agree bit for bit

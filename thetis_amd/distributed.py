@@ -348,7 +348,8 @@ class DistributedSwe2d(object):
             # shares its block with the cells it touches (in the device numbering - ghost layers appended layer by layer - a
             # block of ghost cells has more rim facets than the kernel's staging area holds)
             from . import ordering
-            self.dev.flow_set_order(ordering.auto_cell_order(p, 0, p.num_cells))
+            blocks = os.environ.get('THETIS_AMD_FLOW_BLOCKS', '1') != '0'        # (0: the tile order of the device numbering, A/B)
+            self.dev.flow_set_order((ordering.flow_block_order if blocks else ordering.auto_cell_order)(p, 0, p.num_cells))
         self._ranges = [p.stage_range(i) for i in range(3)]
         self.tids = [self.dev.add_tracer() for _ in range(n_tracers)]
 

@@ -7,7 +7,7 @@ Firedrake gives the reference the same service by reordering DMPlex points (reve
 """
 import numpy as np
 
-__all__ = ['hilbert_index', 'hilbert_cell_order', 'tile_cell_order', 'structured_tile_order', 'structured_subset_order', 'auto_cell_order',
+__all__ = ['hilbert_index', 'hilbert_cell_order', 'tile_cell_order', 'structured_tile_order', 'structured_subset_order', 'auto_cell_order', 'flow_block_order',
            'patch_row_order', 'first_touch_vertex_order']
 
 
@@ -109,6 +109,35 @@ def auto_cell_order(mesh, a=0, b=None):
         return structured_subset_order(g, parent[0], parent[1])
     cen = np.asarray(mesh.vertex_xy)[np.asarray(mesh.cells)[a:b]].mean(axis=1)
     return hilbert_cell_order(cen)
+
+
+def flow_block_order(mesh, a=0, b=None):
+    """Order of cells a..b of ``mesh`` for the BLOCKS of the dataflow kernel (csrc/swe2d_flow.h: 64 consecutive cells = one wave's
+    block; a facet between two blocks is a rim facet whose six trace values travel as granules after every stage).  What counts is
+    a block's perimeter, not how its lanes walk through memory - the kernel touches the state planes at the start and the end of a
+    launch only.  On a (partition of a) RectangleMesh of triangles a block is a tile of 8 x 4 quads = 64 triangles, aligned with the
+    LOCAL extent of the cells (a partition's ghost columns start a tile of their own instead of cutting through the global tile
+    grid), tiles along a Hilbert curve: 24 rim facets per block (31 at most next to a partition's cuts) where the 16 x 2 blocks of
+    the device numbering have 36 (68) - a third fewer granules to publish and to poll, and four granule loads per lane and polling
+    pass instead of eight or nine (profiles/r05s_flow_block_order.txt).  Other meshes: ``auto_cell_order``."""
+    b = mesh.cells.shape[0] if b is None else b
+    k = np.asarray(mesh.cells).shape[1]
+    if k != 3:
+        return auto_cell_order(mesh, a, b)
+    if a == 0 and b == mesh.cells.shape[0] and getattr(mesh, 'structured', False):
+        g, nx, ny = np.arange(b, dtype=np.int64), mesh.nx, mesh.ny
+    elif getattr(mesh, 'structured_parent', None) is not None:
+        g = np.asarray(mesh.local_to_global, dtype=np.int64)[a:b]
+        nx, ny = mesh.structured_parent
+    else:
+        return auto_cell_order(mesh, a, b)
+    q = g//2
+    i, j = q % nx, q//nx
+    il, jl = i - i.min(), j - j.min()
+    bx, by = 8, 4
+    order = max(1, int(np.ceil(np.log2(max(il.max()//bx + 2, jl.max()//by + 2)))))
+    d = hilbert_index(il//bx, jl//by, order)
+    return np.lexsort((g, il % bx, jl % by, d))
 
 
 def first_touch_vertex_order(cells):

@@ -35,7 +35,10 @@ rb --case cfg2 --world 4 --rank 1 --every 4 --exchange p2p --nosplit --flow 0 --
 rb --case cfg2 --world 2 --rank 0 --every 4 --exchange p2p --nosplit --flow 0 --graph-mode full --steps 960
 rb --case cfg4 --world 8 --rank 3 --every 2 --exchange p2p --graph-mode full --steps 480
 rb --case cfg4_tracer_only --world 8 --rank 3 --every 2 --exchange p2p --graph-mode full --steps 480
-rb --case cfg5 --world 8 --rank 3 --every 4 --exchange p2p --nosplit --graph-mode full --steps 960
+rb --case cfg2_src --world 8 --rank 3 --every 2 --exchange p2p --nosplit --flow 1 --flowx 1 --graph-mode full --steps 1920
+rb --case cfg5 --world 8 --rank 3 --every 2 --exchange p2p --nosplit --flow 1 --flowx 1 --graph-mode full --steps 960
+rb --case cfg5 --world 8 --rank 7 --every 2 --exchange p2p --nosplit --flow 1 --flowx 1 --graph-mode full --steps 960
+rb --case cfg5 --world 8 --rank 3 --every 4 --exchange p2p --nosplit --flow 0 --graph-mode full --steps 960
 cut -c1-20,230- $O/r05z_rank.txt
 find $O -name "*.csv" -size +3M -delete
 find $O -name "*kernel_trace.csv" -delete
