@@ -98,7 +98,7 @@ int flow_build(Handle *h, const int32_t *order)
     if (too_many || !((size_t)3*n_slots*SWE_FLOW_SLOT_BYTES < ((size_t)1 << 31) && n_slots < (1 << 25))) return SWE2D_OK;
     h->flow_fpos = fpos;
     h->flow_max_rim = max_rim;
-    // A/B, tests: 9 forces the widest instance, 8 / 4 the narrower ones (more than one trip per pass where a block has more rim facets)
+    // A/B, tests: 9 forces the widest instance, 5 ... 8 / up to 4 the narrower ones (more than one trip per pass where a block has more rim facets)
     if (const char *e = std::getenv("THETIS_AMD_FLOW_POLL")) h->flow_max_rim = std::atoi(e) > 8 ? 65 : (std::atoi(e) > 4 ? 64 : 32);
     h->flow_x_ready = false;
     h->flow_parity_bytes = (unsigned)((size_t)std::max(n_slots, 1)*SWE_FLOW_SLOT_BYTES);
@@ -277,7 +277,7 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles)
     for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) q.cell_end[s] = s < n_stages ? cell_end[s] : 0;
     for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
     q.timeout_ticks = (unsigned long long)(h->flow_timeout_s*1e8);
-    const int poll = h->flow_max_rim > 64 ? 9 : (h->flow_max_rim > 32 ? 8 : 4);
+    const int poll = h->flow_max_rim > 64 ? 9 : (h->flow_max_rim > 32 ? 6 : 3);
     flow_kernel_t kern = h->wd ? pick_flow_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_sources(h), fx, poll)
                        : K > 1 ? pick_mflow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h),
                                                    h->flow_max_rim > 64)

@@ -67,6 +67,10 @@
 #define SWE_FLOW_FLAG_STRIDE 16           // unsigned words between two blocks' stage counters (64 B)
 #endif
 #define SWE_FLOW_SLOT_BYTES 128            // exchange slot of one rim facet and stage parity: 8 granules of 16 B {value, tag, check} (6 values + 2 pads)
+// t / 6 for 0 <= t < 2^14 (a polling pass visits the SIX value granules of every incoming 128-byte slot, lane after lane: the two
+// padding granules that make a slot one full line for the producer's write-through stores are never read - 32 rim facets per three
+// load instructions, where one load per granule of the slot needed four, round 5)
+#define SWE_FLOW_DIV6(t_) ((int)(((unsigned)(t_)*43691u) >> 18))
 #ifndef SWE_FLOW_NTR_SRC
 #define SWE_FLOW_NTR_SRC 3                 // (SRC ? 1 : 3): the trace addresses of the source-term variants packed, see swe_flow_rhs_facets
 #endif
@@ -405,16 +409,19 @@ __device__ __forceinline__ void swe_flow_finish(const SweStageArgs &p, int k, do
 // cycle's start long before its neighbours have read its last stage results - it may overwrite its previous INPUT (read by stage 0
 // of the previous cycle, which every neighbour that needs it has finished before this rank's push, hence before the flags that
 // lets this block start the cycle: it also waits for this rank's own previous push to be complete) but nothing else.
-// POLL: granule loads per lane in flight in a polling trip = POLL*8 rim facets per trip (8 granules per facet, 64 lanes).  The block
+// POLL: granule loads per lane in flight in a polling trip = POLL*64/6 rim facets per trip (6 value granules per facet, 64 lanes:
+// 32 / 64 / 96 facets with 3 / 6 / 9 loads; rounds 3-5 read the padding granules too: 8 / 9 loads for 64 / 72 facets).  The block
 // with the most rim facets sets the pace of the whole launch, and a block that needs a second trip per pass (+1.3 us per stage)
 // slowed a 131 k-cell mesh from 18.7 to 22.1 us per step; a ninth load in EVERY block costs 0.3 us per step (its issue slot and its
-// place in the return queue, even when all lanes point nowhere).  The host picks POLL = 8 when no block of the flow order has more
-// than 64 rim facets, 9 otherwise (launch_flow); same results either way.
+// place in the return queue, even when all lanes point nowhere).  The host picks POLL = 3 when no block of the flow order has more
+// than 32 rim facets (the 8 x 4-quad blocks of ordering.flow_block_order), 6 up to 64, 9 otherwise (launch_flow); same results
+// whichever instance runs.  Round 5: the slowest rank of eight 19.1 us per step with nine loads on two-row blocks, 17.1 with four
+// on tiles (padding granules still read), ... with three (profiles/r05s_flow_block_order.txt, r05t_flow_poll6.txt).
 // WD (round 5): wetting-drying.  The "elevation" values of the block - registers, LDS planes, rim granules, U(0), the exchange records -
 // are the displaced depth D the state planes hold; the elevation is recovered per stage (own nodes before the wave starts to wait,
 // the neighbours' where the fluxes are formed), the stage ends with swe_wd_finish: swe_stage_kernel<true, LF, ., SRC, true>'s
 // operations.  alpha of the cell's vertices stays in registers with the rest of the geometry.
-template <bool NONLIN, bool LF, bool SRC, bool FX, int POLL = 8, bool WD = false>
+template <bool NONLIN, bool LF, bool SRC, bool FX, int POLL = 6, bool WD = false>
 __global__ __launch_bounds__(SWE_BLOCK) SWE_FLOW_OCCUPANCY void swe_flow_kernel(const SweFlowArgs q)
 {
 #pragma clang fp contract(off)
@@ -750,14 +757,14 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
 #define SWE_FLOW_POLL_OFFSETS(c0_) do {                                                                                               \
                     int ent_[POLL], act_[POLL];                                                                                   \
                     _Pragma("unroll")                                                                                             \
-                    for (int j = 0; j < POLL; j++) ent_[j] = xsrc[SWE_LDSI(min(((c0_) + j*SWE_BLOCK + lane) >> 3, SWE_FLOW_MAX_RIM - 1), SWE_FLOW_MAX_RIM)]; \
+                    for (int j = 0; j < POLL; j++) ent_[j] = xsrc[SWE_LDSI(min(SWE_FLOW_DIV6((c0_) + j*SWE_BLOCK + lane), SWE_FLOW_MAX_RIM - 1), SWE_FLOW_MAX_RIM)]; \
                     _Pragma("unroll")                                                                                             \
                     for (int j = 0; j < POLL; j++) act_[j] = lact[SWE_LDSI(ent_[j] & (SWE_BLOCK - 1), SWE_BLOCK)];                \
                     _Pragma("unroll")                                                                                             \
                     for (int j = 0; j < POLL; j++) {                                                                              \
                         const int t = (c0_) + j*SWE_BLOCK + lane;                                                                 \
                         /* a cell outside this stage's range needs nothing (and its neighbour may never have published) */        \
-                        poff[j] = (t < 8*nrim && act_[j]) ? (unsigned)(ent_[j] >> 6)*SWE_FLOW_SLOT_BYTES + 16u*(unsigned)(t & 7) + par : SWE_FLOW_NOWHERE; \
+                        poff[j] = (t < 6*nrim && act_[j]) ? (unsigned)(ent_[j] >> 6)*SWE_FLOW_SLOT_BYTES + 16u*(unsigned)(t - 6*SWE_FLOW_DIV6(t)) + par : SWE_FLOW_NOWHERE; \
                     }                                                                                                             \
                 } while (0)
                 // Computed ONCE per stage, outside the spin loop, where a pass is one trip (no block of the order has more rim facets than
@@ -768,35 +775,24 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                 SWE_FLOW_CELL_TERMS_HERE;
 #endif
 #ifndef SWE_FLOW_NO_HOIST_POLL
-                const bool one_trip = !WD && 8*nrim <= POLL*SWE_BLOCK;      // (not with wetting-drying: eight registers too many)
+                const bool one_trip = !WD && 6*nrim <= POLL*SWE_BLOCK;      // (not with wetting-drying: eight registers too many)
                 if constexpr (!WD) SWE_FLOW_POLL_OFFSETS(0);
 #else
                 const bool one_trip = false;
 #endif
                 for (unsigned spins = 0;; spins++) {
                     bool ok = true;
-                    for (int c0 = 0; c0 < 8*nrim; c0 += POLL*SWE_BLOCK) {      // POLL loads per lane in flight (8*POLL rim facets per trip)
+                    for (int c0 = 0; c0 < 6*nrim; c0 += POLL*SWE_BLOCK) {      // POLL loads per lane in flight (32 rim facets per three loads)
                         swe_u32x4 gr[POLL];
-#ifdef SWE_FLOW_OLD_POLL
-#pragma unroll
-                        for (int j = 0; j < POLL; j++) {                       // round 4: a list entry and an activity read inside `if`s per load
-                            const int t = c0 + j*SWE_BLOCK + lane;
-                            int ent = t < 8*nrim ? xsrc[SWE_LDSI(t >> 3, SWE_FLOW_MAX_RIM)] : -1;
-                            if (ent >= 0 && !lact[SWE_LDSI(ent & (SWE_BLOCK - 1), SWE_BLOCK)]) ent = -1;
-                            poff[j] = ent >= 0 ? (unsigned)(ent >> 6)*SWE_FLOW_SLOT_BYTES + 16u*(unsigned)(t & 7) + par : SWE_FLOW_NOWHERE;
-                            gr[j] = swe_flow_get(rex, poff[j]);
-                        }
-#else
                         if (!one_trip) SWE_FLOW_POLL_OFFSETS(c0);
 #pragma unroll
                         for (int j = 0; j < POLL; j++) gr[j] = swe_flow_get(rex, poff[j]);
-#endif
 #pragma unroll
                         for (int j = 0; j < POLL; j++) {
                             const int t = c0 + j*SWE_BLOCK + lane;
                             if (poff[j] != SWE_FLOW_NOWHERE) {
                                 ok = ok && swe_flow_arrived(gr[j], need);
-                                if ((t & 7) < 6) lds[SWE_LDSI(SWE_FLOW_XG + 6*(t >> 3) + (t & 7), SWE_FLOW_LDS_DOUBLES)] = swe_flow_val(gr[j]);
+                                lds[SWE_LDSI(SWE_FLOW_XG + t, SWE_FLOW_LDS_DOUBLES)] = swe_flow_val(gr[j]);      // staging: [slot][6]
                             }
                         }
                     }
