@@ -857,8 +857,16 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
 #ifndef SWE_FLOW_NO_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
-            // ---- the step result (every third stage) goes to state buffer 0: read by later launches only
-            if (act && i3 == 2) {
+            // ---- the step result (every third stage) goes to state buffer 0: read by later launches only - so only the LAST result
+            //      the launch computes for the cell is stored (the cell is in no later step's final range: the ranges never grow; with
+            //      the exchange inside, in the last cycle).  Rounds 3-5 stored every step's result: nine store instructions per lane and
+            //      step that nothing ever read, between a publish and the next polling pass (-DSWE_FLOW_STORE_EVERY_STEP: A/B).
+#ifdef SWE_FLOW_STORE_EVERY_STEP
+            const bool last_result = true;
+#else
+            const bool last_result = (!FX || c == ncyc - 1) && (g + 3 >= spc || k >= q.cell_end[g + 3]);
+#endif
+            if (act && i3 == 2 && last_result) {
                 const swe_rsrc_t gou = swe_rsrc(q.buf[0]), gov = swe_rsrc(q.buf[0] + 3*S), goe = swe_rsrc(q.buf[0] + 6*S);
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
