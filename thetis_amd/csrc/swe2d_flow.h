@@ -689,7 +689,13 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
 #pragma unroll
                     for (int i = 0; i < 3; i++) { u[i] = lds[SWE_LDSI(SWE_FLOW_XG + 9*ci + i, SWE_FLOW_LDS_DOUBLES)]; v[i] = lds[SWE_LDSI(SWE_FLOW_XG + 9*ci + 3 + i, SWE_FLOW_LDS_DOUBLES)]; e[i] = lds[SWE_LDSI(SWE_FLOW_XG + 9*ci + 6 + i, SWE_FLOW_LDS_DOUBLES)]; }
                 }
-                if (xr >= 0) {                                 // ... and into the state planes, for the kernels after this launch
+                // ... and into the state planes, for the kernels after this launch: what the LAST cycle receives (an earlier cycle's
+                // copy is overwritten by the next one's before anything reads it; -DSWE_FLOW_STORE_EVERY_STEP: every cycle, A/B)
+#ifdef SWE_FLOW_STORE_EVERY_STEP
+                if (xr >= 0) {
+#else
+                if (xr >= 0 && c == ncyc - 1) {
+#endif
                     const swe_rsrc_t gou = swe_rsrc(q.buf[0]), gov = swe_rsrc(q.buf[0] + 3*S), goe = swe_rsrc(q.buf[0] + 6*S);
 #pragma unroll
                     for (int i = 0; i < 3; i++) { swe_st(gou, k8, i*S8, u[i]); swe_st(gov, k8, i*S8, v[i]); swe_st(goe, k8, i*S8, e[i]); }
