@@ -85,7 +85,7 @@ def build(force=False, verbose=False, unity=False, defines=(), lib=None, jobs=No
     """Compile the HIP extension; returns the path of the shared library.  ``extra_flags``: compiler flags of a variant build (A/B)."""
     if unity:
         out = lib or LIB
-        cmd = [HIPCC] + FLAGS + ['-shared'] + ['-D' + d for d in defines] + [UNITY, '-o', out]
+        cmd = [HIPCC] + FLAGS + list(extra_flags) + ['-shared'] + ['-D' + d for d in defines] + [UNITY, '-o', out]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
