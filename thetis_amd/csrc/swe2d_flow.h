@@ -71,6 +71,9 @@
 // padding granules that make a slot one full line for the producer's write-through stores are never read - 32 rim facets per three
 // load instructions, where one load per granule of the slot needed four, round 5)
 #define SWE_FLOW_DIV6(t_) ((int)(((unsigned)(t_)*43691u) >> 18))
+#ifndef SWE_FLOW_POLL_SLEEP
+#define SWE_FLOW_POLL_SLEEP 2              // s_sleep (x 64 cycles) between two polling passes of a block that is still waiting
+#endif
 #ifndef SWE_FLOW_NTR_SRC
 #define SWE_FLOW_NTR_SRC 3                 // (SRC ? 1 : 3): the trace addresses of the source-term variants packed, see swe_flow_rhs_facets
 #endif
@@ -803,7 +806,7 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                         }
                     }
                     if (__all(ok) || late) break;
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(SWE_FLOW_POLL_SLEEP);
                     if ((spins & 31u) == 31u) {
                         const unsigned long long now = wall_clock64();
                         if (t_start == 0ull) t_start = now;
