@@ -350,6 +350,11 @@ def test_flow_block_order_makes_compact_blocks():
         r_old = rims(p.cell_nbr, ordering.auto_cell_order(p, 0, p.num_cells))
         # (53 / 56 local quad columns: the partial tile column at the far edge lets the blocks behind it straddle two tiles)
         assert r_new.max() <= 40 < r_old.max() and r_new.mean() < 0.75*r_old.mean(), (rank, r_new.max(), r_old.max())
-    # quadrilaterals and unstructured meshes: the device order
+    # quadrilaterals: the device order (no flow kernel)
     mq = RectangleMesh(20, 10, 20e3, 10e3, quadrilateral=True)
     assert np.array_equal(ordering.flow_block_order(mq), ordering.auto_cell_order(mq))
+    # any other triangulation: bisection boxes of exactly 64 cells
+    from helpers import delaunay_case
+    md = delaunay_case(n_points=6000, seed=5)[0]
+    r_new, r_old = rims(md.cell_nbr, ordering.flow_block_order(md)), rims(md.cell_nbr, ordering.auto_cell_order(md))
+    assert r_new.max() <= 42 and r_new.max() < r_old.max() and r_new.mean() < 0.9*r_old.mean(), (r_new.max(), r_old.max(), r_new.mean(), r_old.mean())

@@ -277,7 +277,7 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles)
     for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) q.cell_end[s] = s < n_stages ? cell_end[s] : 0;
     for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
     q.timeout_ticks = (unsigned long long)(h->flow_timeout_s*1e8);
-    const int poll = h->flow_max_rim > 64 ? 9 : (h->flow_max_rim > 32 ? 6 : 3);
+    const int poll = h->flow_max_rim > 64 ? 9 : (h->flow_max_rim > 42 ? 6 : (h->flow_max_rim > 32 ? 4 : 3));
     flow_kernel_t kern = h->wd ? pick_flow_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_sources(h), fx, poll)
                        : K > 1 ? pick_mflow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h),
                                                    h->flow_max_rim > 64)

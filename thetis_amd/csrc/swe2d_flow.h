@@ -417,7 +417,7 @@ __device__ __forceinline__ void swe_flow_finish(const SweStageArgs &p, int k, do
 // with the most rim facets sets the pace of the whole launch, and a block that needs a second trip per pass (+1.3 us per stage)
 // slowed a 131 k-cell mesh from 18.7 to 22.1 us per step; a ninth load in EVERY block costs 0.3 us per step (its issue slot and its
 // place in the return queue, even when all lanes point nowhere).  The host picks POLL = 3 when no block of the flow order has more
-// than 32 rim facets (the 8 x 4-quad blocks of ordering.flow_block_order), 6 up to 64, 9 otherwise (launch_flow); same results
+// than 32 rim facets (the 8 x 4-quad blocks of ordering.flow_block_order), 4 / 6 up to 42 / 64, 9 otherwise (launch_flow); same results
 // whichever instance runs.  Round 5: the slowest rank of eight 19.1 us per step with nine loads on two-row blocks, 17.1 with four
 // on tiles (padding granules still read), ... with three (profiles/r05s_flow_block_order.txt, r05t_flow_poll6.txt).
 // WD (round 5): wetting-drying.  The "elevation" values of the block - registers, LDS planes, rim granules, U(0), the exchange records -

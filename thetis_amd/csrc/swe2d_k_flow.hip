@@ -17,10 +17,11 @@ flow_kernel_t pick_flow_poll(bool nl, bool lf, bool src, bool fx)
               : (lf ? pick_flow_src<false, true, POLL>(src, fx) : pick_flow_src<false, false, POLL>(src, fx));
 }
 // poll: granule loads per lane and polling trip - 3 where no block of the flow order has more than 32 rim facets (the 8 x 4-quad
-// blocks of ordering.flow_block_order), 6 up to 64, 9 beyond (a block that needs a second trip per pass paces the whole launch)
+// blocks of ordering.flow_block_order), 4 up to 42 (its bisection boxes on unstructured meshes), 6 up to 64, 9 beyond (a block that needs a second trip per pass paces the whole launch)
 flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src, bool fx, int poll)
 {
-    return poll >= 9 ? pick_flow_poll<9>(nl, lf, src, fx) : (poll >= 6 ? pick_flow_poll<6>(nl, lf, src, fx) : pick_flow_poll<3>(nl, lf, src, fx));
+    return poll >= 9 ? pick_flow_poll<9>(nl, lf, src, fx) : (poll >= 6 ? pick_flow_poll<6>(nl, lf, src, fx)
+         : (poll >= 4 ? pick_flow_poll<4>(nl, lf, src, fx) : pick_flow_poll<3>(nl, lf, src, fx)));
 }
 
 // the multi-block kernel (swe2d_mflow.h): a wave owns several consecutive blocks; no exchange inside

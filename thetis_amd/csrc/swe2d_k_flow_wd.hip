@@ -15,5 +15,6 @@ flow_kernel_t pick_flow_kernel_wd(bool lf, bool src, bool fx, int poll)
 {
     if (poll >= 9) return lf ? pick_flow_wd_src<true, 9>(src, fx) : pick_flow_wd_src<false, 9>(src, fx);
     if (poll >= 6) return lf ? pick_flow_wd_src<true, 6>(src, fx) : pick_flow_wd_src<false, 6>(src, fx);
+    if (poll >= 4) return lf ? pick_flow_wd_src<true, 4>(src, fx) : pick_flow_wd_src<false, 4>(src, fx);
     return lf ? pick_flow_wd_src<true, 3>(src, fx) : pick_flow_wd_src<false, 3>(src, fx);
 }

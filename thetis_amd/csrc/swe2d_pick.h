@@ -14,7 +14,7 @@ stage_kernel_t pick_kernel_wd(bool lf, bool u0, bool src, int quad, bool binl);
 // triangles with the horizontal viscosity fused in (swe_visc_interior)
 stage_kernel_t pick_kernel_visc(bool nl, bool lf, bool u0, bool src);
 stage_kernel_t pick_kernel_quad(bool nl, bool lf, bool u0, bool src, bool affine);
-// poll: granule loads per lane and polling trip (3 / 6 / 9 for blocks of at most 32 / 64 / more rim facets)
+// poll: granule loads per lane and polling trip (3 / 4 / 6 / 9 for blocks of at most 32 / 42 / 64 / more rim facets)
 flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src, bool fx = false, int poll = 6);
 flow_kernel_t pick_flow_kernel_wd(bool lf, bool src, bool fx, int poll);        // wetting-drying (swe2d_k_flow_wd.hip)
 // swe2d_mflow.h: several consecutive blocks per wave (cell ranges beyond the one-block kernel's residency), no exchange inside

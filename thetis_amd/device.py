@@ -141,10 +141,11 @@ class Swe2dDevice(object):
         p.device_id = device_id
         self.h = ctypes.c_void_p()
         _lib.check(self.lib.swe2d_create(ctypes.byref(m), ctypes.byref(p), ctypes.byref(self.h)))
-        if (self.npc == 3 and isinstance(reorder, str) and reorder == 'auto' and self.n_owned == self.n_cells
-                and getattr(mesh, 'structured', False) and self.n_cells <= 196608 and os.environ.get('THETIS_AMD_FLOW_BLOCKS', '1') != '0'):
-            # a mesh small enough for the dataflow kernel (swe2d_advance takes it by itself): its 64-cell blocks as compact tiles
-            # (ordering.flow_block_order) instead of two mesh rows of the device numbering - a third fewer rim facets
+        if (self.npc == 3 and isinstance(reorder, str) and self.n_owned == self.n_cells and 64 < self.n_cells <= 196608
+                and os.environ.get('THETIS_AMD_FLOW_BLOCKS', '1') != '0'):
+            # a mesh small enough for the dataflow kernel (swe2d_advance takes it by itself): its 64-cell blocks as compact tiles /
+            # bisection boxes (ordering.flow_block_order) instead of 64 consecutive cells of the device numbering - a fifth to a
+            # third fewer rim facets
             self.flow_set_order(ordering.flow_block_order(mesh))
         if self.npc == 4 and not getattr(mesh, 'affine', True):
             # a partition (LocalPartition.affine = the GLOBAL mesh's flag) whose own cells happen to be parallelograms takes the

@@ -7,7 +7,7 @@ Firedrake gives the reference the same service by reordering DMPlex points (reve
 """
 import numpy as np
 
-__all__ = ['hilbert_index', 'hilbert_cell_order', 'tile_cell_order', 'structured_tile_order', 'structured_subset_order', 'auto_cell_order', 'flow_block_order',
+__all__ = ['hilbert_index', 'hilbert_cell_order', 'tile_cell_order', 'structured_tile_order', 'structured_subset_order', 'auto_cell_order', 'flow_block_order', 'bisection_block_order',
            'patch_row_order', 'first_touch_vertex_order']
 
 
@@ -111,6 +111,28 @@ def auto_cell_order(mesh, a=0, b=None):
     return hilbert_cell_order(cen)
 
 
+def bisection_block_order(centroids, block=64):
+    """Cells in the order of the leaves of a recursive coordinate bisection whose leaves hold exactly ``block`` cells (the last one
+    the remainder): every cut is along the longer side of the box at the count that gives the left part a multiple of ``block``."""
+    cen = np.asarray(centroids, dtype=np.float64)
+    out = []
+    stack = [np.arange(len(cen), dtype=np.int64)]
+    while stack:
+        idx = stack.pop()
+        m = len(idx)
+        if m <= block:
+            out.append(idx)
+            continue
+        nl = ((-(-m//block))//2)*block
+        c = cen[idx]
+        ext = c.max(axis=0) - c.min(axis=0)
+        ax = int(ext[1] > ext[0])
+        part = np.argpartition(c[:, ax], nl)
+        stack.append(idx[part[nl:]])                 # (popped after the left part: leaves come out left to right)
+        stack.append(idx[part[:nl]])
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.int64)
+
+
 def flow_block_order(mesh, a=0, b=None):
     """Order of cells a..b of ``mesh`` for the BLOCKS of the dataflow kernel (csrc/swe2d_flow.h: 64 consecutive cells = one wave's
     block; a facet between two blocks is a rim facet whose six trace values travel as granules after every stage).  What counts is
@@ -119,7 +141,8 @@ def flow_block_order(mesh, a=0, b=None):
     LOCAL extent of the cells (a partition's ghost columns start a tile of their own instead of cutting through the global tile
     grid), tiles along a Hilbert curve: 24 rim facets per block (31 at most next to a partition's cuts) where the 16 x 2 blocks of
     the device numbering have 36 (68) - a third fewer granules to publish and to poll, and four granule loads per lane and polling
-    pass instead of eight or nine (profiles/r05s_flow_block_order.txt).  Other meshes: ``auto_cell_order``."""
+    pass instead of eight or nine (profiles/r05s_flow_block_order.txt).  Other triangulations: ``bisection_block_order``;
+    quadrilaterals (no flow kernel): ``auto_cell_order``."""
     b = mesh.cells.shape[0] if b is None else b
     k = np.asarray(mesh.cells).shape[1]
     if k != 3:
@@ -130,7 +153,11 @@ def flow_block_order(mesh, a=0, b=None):
         g = np.asarray(mesh.local_to_global, dtype=np.int64)[a:b]
         nx, ny = mesh.structured_parent
     else:
-        return auto_cell_order(mesh, a, b)
+        # any other triangulation: recursive coordinate bisection of the centroids down to leaves of exactly 64 cells (the left
+        # half of every cut takes a multiple of 64) - boxes of aspect <= 2, 27 rim facets per block on a Delaunay mesh (38 at most)
+        # where 64 consecutive cells of the Hilbert curve have 33 (51)
+        cen = np.asarray(mesh.vertex_xy)[np.asarray(mesh.cells)[a:b]].mean(axis=1)
+        return bisection_block_order(cen)
     q = g//2
     i, j = q % nx, q//nx
     il, jl = i - i.min(), j - j.min()
