@@ -2549,6 +2549,80 @@ static __global__ __launch_bounds__(SWE_BLOCK) void swe_diag_kernel_quad(const d
     if (threadIdx.x == 0) partial[blockIdx.x] = s_min;
 }
 
+// Boundary facets of a quadrilateral whose marker carries a boundary value or an external velocity (tracer_eq_2d.py:177-188, :380-393),
+// evaluated AFTER the cell's outputs are finished: inputs reloaded by plane index, the facet's two node integrals through the mass
+// inverse into the outputs (see swe_boundary_epilogue_quad).  bdefer: bit f = facet f is such a facet.
+template <bool AFFINE>
+__device__ __forceinline__ void swe_tracer_boundary_epilogue_quad(const SweTracerArgs &p, int k, unsigned bdefer, double o[4])
+{
+    const size_t S = p.stride;
+    const double cf = p.vel_factor;
+    int vid[4];
+    double px[4], py[4];
+    for (int i = 0; i < 4; i++) { vid[i] = p.cv[(size_t)i*S + k]; px[i] = p.vx[vid[i]]; py[i] = p.vy[vid[i]]; }
+    const double ax = px[1] - px[0], ay = py[1] - py[0], bx = px[3] - px[0], by = py[3] - py[0];
+    const double A = ax*by - ay*bx;
+    const double cx = AFFINE ? 0.0 : (px[0] - px[1]) + (px[2] - px[3]), cy = AFFINE ? 0.0 : (py[0] - py[1]) + (py[2] - py[3]);
+    const double d1 = AFFINE ? 0.0 : ax*cy - ay*cx, d2 = AFFINE ? 0.0 : cx*by - cy*bx;
+    SweQuadLDL F;
+    if constexpr (!AFFINE) {
+        SweQuadMass M;
+        swe_quad_mass(A, d1, d2, M);
+        swe_quad_mass_factor(M, F);
+    }
+    const double s = AFFINE ? p.dt*p.beta*swe_rcp(A) : p.dt*p.beta;
+#pragma unroll 1
+    for (int f = 0; f < 4; f++) {
+        if (!((bdefer >> f) & 1u)) continue;
+        const int a = f, bb = (f + 1) & 3;
+        const int marker = -p.nbr[(size_t)f*S + k];
+        const double ua = cf*p.uv[(size_t)a*S + k], ub = cf*p.uv[(size_t)bb*S + k];
+        const double va = cf*p.uv[(size_t)(4 + a)*S + k], vb = cf*p.uv[(size_t)(4 + bb)*S + k];
+        const double ca = p.tin[(size_t)a*S + k], cb = p.tin[(size_t)bb*S + k];
+        const double nxs = py[bb] - py[a], nys = px[a] - px[bb];
+        double Fa = 0.0, Fb = 0.0;
+#pragma unroll 1
+        for (int q = 0; q < 2; q++) {
+            const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+            const double uq = xa*ua + xb*ub, vq = xa*va + xb*vb, cq = xa*ca + xb*cb;
+            const double cext = (p.bc_has_value[marker] == 2)
+                ? xa*p.bc_value_f[(size_t)(4*f + a)*S + k] + xb*p.bc_value_f[(size_t)(4*f + bb)*S + k]
+                : (p.bc_has_value[marker] ? p.bc_value[marker] : cq);
+            double hq = 0.0, eq = 0.0, alq = 0.0;
+            if (p.bc_vel_kind[marker] >= 3) {                  // 'flux': total depth at the quadrature point
+                const double ha = p.vh[vid[a]], hb = p.vh[vid[bb]];
+                hq = xa*ha + xb*hb;
+                double ea_ = p.uv[(size_t)(8 + a)*S + k], eb_ = p.uv[(size_t)(8 + bb)*S + k];
+                if (p.depth_mode == 2) {           // the planes hold D: the nodal elevations by the closed form
+                    const double aa_ = p.valpha[vid[a]], ab_ = p.valpha[vid[bb]];
+                    alq = xa*aa_ + xb*ab_;
+                    ea_ = ea_ - 0.25*aa_*aa_/ea_ - ha;
+                    eb_ = eb_ - 0.25*ab_*ab_/eb_ - hb;
+                }
+                eq = xa*ea_ + xb*eb_;
+            }
+            const double fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys, hq, eq, alq, xa, xb, k, f, 4, S);
+            Fa += xa*fq;
+            Fb += xb*fq;
+        }
+        const double da = -0.5*Fa, db = -0.5*Fb;
+        if constexpr (AFFINE) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {            // row i of the tensor mass inverse (16, -8, 4, -8)/A on (da at a, db at bb)
+                const double wa = (i == a) ? 16.0 : (i == (a ^ 2) ? 4.0 : -8.0), wb = (i == bb) ? 16.0 : (i == (bb ^ 2) ? 4.0 : -8.0);
+                o[i] += s*(wa*da + wb*db);
+            }
+        } else {
+            double r[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) r[i] = (i == a) ? da : ((i == bb) ? db : 0.0);
+            swe_quad_mass_solve(F, r);
+#pragma unroll
+            for (int i = 0; i < 4; i++) o[i] += s*r[i];
+        }
+    }
+}
+
 // ---- tracer stage on parallelogram quadrilaterals (see swe_tracer_stage_kernel and swe_stage_kernel_quad)
 template <bool LF, bool HAST0, bool SRC, bool AFFINE = true>
 __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const SweTracerArgs p)
@@ -2579,6 +2653,14 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
         c[i] = swe_ld(gt, k8, i*S8);
         w[i] = p.a1*c[i];
         if (HAST0) w[i] += p.a0*swe_ld(swe_rsrc(p.t0), k8, i*S8);
+    }
+    // boundary facets whose marker carries a boundary value or an external velocity: bit f (the tables are kernel arguments: an
+    // entry indexed per lane is a load, issued here with all the others)
+    unsigned bdefer = 0u;
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        const int marker = nb[f] < 0 ? -nb[f] : 0;
+        if (marker > 0 && marker < SWE_MAX_MARKERS && (p.bc_has_value[marker] || p.bc_vel_kind[marker])) bdefer |= 1u << f;
     }
     double una[4], unb[4], vna[4], vnb[4], cna[4], cnb[4];
 #pragma unroll
@@ -2670,29 +2752,10 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
                 }
                 if (LF) fq += 0.5*fabs(uavn)*p.lf_factor*(cq - cn);
             } else {
-                const int marker = -nb[f];
-                if (marker < SWE_MAX_MARKERS && (p.bc_has_value[marker] || p.bc_vel_kind[marker])) {
-                    const double cext = (p.bc_has_value[marker] == 2)
-                        ? xa*p.bc_value_f[(size_t)(4*f + a)*S + k] + xb*p.bc_value_f[(size_t)(4*f + bb)*S + k]
-                        : (p.bc_has_value[marker] ? p.bc_value[marker] : cq);
-                    double hq = 0.0, eq = 0.0, alq = 0.0;
-                    if (p.bc_vel_kind[marker] >= 3) {                  // 'flux': total depth at the quadrature point
-                        const unsigned va8 = (unsigned)vid[a]*8u, vb8 = (unsigned)vid[bb]*8u;
-                        hq = xa*swe_ld(swe_rsrc(p.vh), va8, 0) + xb*swe_ld(swe_rsrc(p.vh), vb8, 0);
-                        if (p.depth_mode == 2) alq = xa*swe_ld(swe_rsrc(p.valpha), va8, 0) + xb*swe_ld(swe_rsrc(p.valpha), vb8, 0);
-                        const swe_rsrc_t ge = swe_rsrc(p.uv + 8*S);
-                        double ea_ = swe_ld(ge, k8, a*S8), eb_ = swe_ld(ge, k8, bb*S8);
-                        if (p.depth_mode == 2) {           // the planes hold D: the nodal elevations by the closed form
-                            const double aa_ = swe_ld(swe_rsrc(p.valpha), va8, 0), ab_ = swe_ld(swe_rsrc(p.valpha), vb8, 0);
-                            ea_ = ea_ - 0.25*aa_*aa_/ea_ - swe_ld(swe_rsrc(p.vh), va8, 0);
-                            eb_ = eb_ - 0.25*ab_*ab_/eb_ - swe_ld(swe_rsrc(p.vh), vb8, 0);
-                        }
-                        eq = xa*ea_ + xb*eb_;
-                    }
-                    fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys, hq, eq, alq, xa, xb, k, f, 4, S);
-                } else {
-                    fq = cq*unown;
-                }
+                // boundary facet: with a boundary value or an external velocity it is evaluated AFTER the outputs are finished
+                // (swe_tracer_boundary_epilogue_quad: four inlined copies of that code cost every wave ~30 VGPRs and the third wave
+                // per SIMD); here only the default, the interior state on both sides (tracer_eq_2d.py:189-191)
+                fq = (bdefer >> f) & 1u ? 0.0 : cq*unown;
             }
             Fa += xa*fq;
             Fb += xb*fq;
@@ -2702,12 +2765,14 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
     }
     if constexpr (AFFINE) {
     const double s = p.dt*p.beta*swe_rcp(A);
-    double msum = 0.0;
+    double msum = 0.0, o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = s*(16.0*b[i] - 8.0*b[(i + 1) & 3] - 8.0*b[(i + 3) & 3] + 4.0*b[(i + 2) & 3]) + w[i];
+    if (bdefer) swe_tracer_boundary_epilogue_quad<true>(p, k, bdefer, o);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const double o = s*(16.0*b[i] - 8.0*b[(i + 1) & 3] - 8.0*b[(i + 3) & 3] + 4.0*b[(i + 2) & 3]) + w[i];
-        swe_st(swe_rsrc(p.tout), k8, i*S8, o);
-        msum += o;
+        swe_st(swe_rsrc(p.tout), k8, i*S8, o[i]);
+        msum += o[i];
     }
     if (p.mean_out) p.mean_out[k] = msum/4.0;
     } else {
@@ -2716,14 +2781,16 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
     swe_quad_mass(A, d1, d2, M);
     swe_quad_mass_factor(M, F);
     swe_quad_mass_solve(F, b);
-    double mw[4], msum = 0.0;
+    double mw[4], msum = 0.0, o[4];
     swe_quad_mean_weights(A, d1, d2, mw);
     const double s = p.dt*p.beta;
 #pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = s*b[i] + w[i];
+    if (bdefer) swe_tracer_boundary_epilogue_quad<false>(p, k, bdefer, o);
+#pragma unroll
     for (int i = 0; i < 4; i++) {
-        const double o = s*b[i] + w[i];
-        swe_st(swe_rsrc(p.tout), k8, i*S8, o);
-        msum += mw[i]*o;
+        swe_st(swe_rsrc(p.tout), k8, i*S8, o[i]);
+        msum += mw[i]*o[i];
     }
     if (p.mean_out) p.mean_out[k] = msum;         // P0 projection: int o dx / area
     }
