@@ -1729,6 +1729,55 @@ __device__ __forceinline__ void swe_diff_interior(const SweTracerArgs &p, int k,
     for (int i = 0; i < 3; i++) b[i] += d[i];
 }
 
+// Boundary facets of a triangle whose marker carries a boundary value or an external velocity, after the outputs (the counterpart of
+// swe_tracer_boundary_epilogue_quad): inputs reloaded by plane index, (M^-1 d)_i = 3/A (4 d_i - sum d) with s = 6 dt beta / (2A).
+__device__ __forceinline__ void swe_tracer_boundary_epilogue_tri(const SweTracerArgs &p, int k, unsigned bdefer, double s, double o[3])
+{
+    const size_t S = p.stride;
+    const double cf = p.vel_factor;
+    int vid[3];
+    double px[3], py[3];
+    for (int i = 0; i < 3; i++) { vid[i] = p.cv[(size_t)i*S + k]; px[i] = p.vx[vid[i]]; py[i] = p.vy[vid[i]]; }
+#pragma unroll 1
+    for (int f = 0; f < 3; f++) {
+        if (!((bdefer >> f) & 1u)) continue;
+        const int a = f, bb = (f == 2) ? 0 : f + 1;
+        const int marker = -p.nbr[(size_t)f*S + k];
+        const double ua = cf*p.uv[(size_t)a*S + k], ub = cf*p.uv[(size_t)bb*S + k];
+        const double va = cf*p.uv[(size_t)(3 + a)*S + k], vb = cf*p.uv[(size_t)(3 + bb)*S + k];
+        const double ca = p.tin[(size_t)a*S + k], cb = p.tin[(size_t)bb*S + k];
+        const double nxs = py[bb] - py[a], nys = px[a] - px[bb];
+        double Fa = 0.0, Fb = 0.0;
+#pragma unroll 1
+        for (int q = 0; q < 2; q++) {
+            const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+            const double uq = xa*ua + xb*ub, vq = xa*va + xb*vb, cq = xa*ca + xb*cb;
+            const double cext = (p.bc_has_value[marker] == 2)
+                ? xa*p.bc_value_f[(size_t)(3*f + a)*S + k] + xb*p.bc_value_f[(size_t)(3*f + bb)*S + k]
+                : (p.bc_has_value[marker] ? p.bc_value[marker] : cq);
+            double hq = 0.0, eq = 0.0, alq = 0.0;
+            if (p.bc_vel_kind[marker] >= 3) {                  // 'flux': total depth at the quadrature point
+                const double ha = p.vh[vid[a]], hb = p.vh[vid[bb]];
+                hq = xa*ha + xb*hb;
+                double ea_ = p.uv[(size_t)(6 + a)*S + k], eb_ = p.uv[(size_t)(6 + bb)*S + k];
+                if (p.depth_mode == 2) {           // the planes hold D: the nodal elevations by the closed form
+                    const double aa_ = p.valpha[vid[a]], ab_ = p.valpha[vid[bb]];
+                    alq = xa*aa_ + xb*ab_;
+                    ea_ = ea_ - 0.25*aa_*aa_/ea_ - ha;
+                    eb_ = eb_ - 0.25*ab_*ab_/eb_ - hb;
+                }
+                eq = xa*ea_ + xb*eb_;
+            }
+            const double fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys, hq, eq, alq, xa, xb, k, f, 3, S);
+            Fa += xa*fq;
+            Fb += xb*fq;
+        }
+        const double da = -0.5*Fa, db = -0.5*Fb, sd = da + db;
+#pragma unroll
+        for (int i = 0; i < 3; i++) o[i] += s*(4.0*((i == a) ? da : ((i == bb) ? db : 0.0)) - sd);
+    }
+}
+
 template <bool LF, bool HAST0, bool SRC, bool DIFF = false>
 __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTracerArgs p)
 {
@@ -1759,6 +1808,14 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
         c[i] = swe_ld(gt, k8, i*S8);
         w[i] = p.a1*c[i];
         if (HAST0) w[i] += p.a0*swe_ld(swe_rsrc(p.t0), k8, i*S8);
+    }
+    unsigned bdefer = 0u;             // boundary facets whose marker carries a boundary value or an external velocity: bit f
+    if (DIFF && (nb[0] | nb[1] | nb[2]) < 0) {      // (the tables are read by the lanes - and waves - that own a boundary facet only)
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            const int marker = nb[f] < 0 ? -nb[f] : 0;
+            if (marker > 0 && marker < SWE_MAX_MARKERS && (p.bc_has_value[marker] || p.bc_vel_kind[marker])) bdefer |= 1u << f;
+        }
     }
     double una[3], unb[3], vna[3], vnb[3], cna[3], cnb[3];
 #pragma unroll
@@ -1851,7 +1908,15 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
                     fq = uavn > 0.0 ? cq*unown : (uavn < 0.0 ? fn : 0.5*(cq*unown + fn));
                 }
                 if (LF) fq += 0.5*fabs(uavn)*p.lf_factor*(cq - cn);                       // :173-175
+            } else if constexpr (DIFF) {
+                // boundary facet of the instances with the diffusion fused in (176-192 VGPRs with the code below inlined: two waves per
+                // SIMD): with a boundary value or an external velocity it is evaluated after the outputs (swe_tracer_boundary_epilogue_tri,
+                // see swe_tracer_stage_kernel_quad) - 150-162 VGPRs, three waves, 1 M cells 127.2 -> 108.9 us per step; here only the
+                // default, the interior state on both sides                                                        :189-191
+                fq = (bdefer >> f) & 1u ? 0.0 : cq*unown;
             } else {
+                // (the plain instances keep the boundary code inline: at 154 VGPRs they run three waves already, and the epilogue
+                //  form measured 3.5 % slower for them - 102.7 against 99.2 us per step, profiles/r05z3)
                 const int marker = -nb[f];
                 if (marker < SWE_MAX_MARKERS && (p.bc_has_value[marker] || p.bc_vel_kind[marker])) {     // :181-188
                     const double cext = (p.bc_has_value[marker] == 2)
@@ -1885,12 +1950,14 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
     if (DIFF) swe_diff_interior(p, k, S8, gt, nb, vid, c, cna, cnb, px, py, nx, ny, twoA, b);
     const double s = 6.0*p.dt*p.beta*swe_rcp(twoA);
     const double sb = b[0] + b[1] + b[2];
-    double msum = 0.0;
+    double msum = 0.0, o[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[i] = s*(4.0*b[i] - sb) + w[i];
+    if (bdefer) swe_tracer_boundary_epilogue_tri(p, k, bdefer, s, o);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const double o = s*(4.0*b[i] - sb) + w[i];
-        swe_st(swe_rsrc(p.tout), k8, i*S8, o);
-        msum += o;
+        swe_st(swe_rsrc(p.tout), k8, i*S8, o[i]);
+        msum += o[i];
     }
     if (p.mean_out) p.mean_out[k] = msum/3.0;
 }
@@ -2657,10 +2724,12 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel_quad(const 
     // boundary facets whose marker carries a boundary value or an external velocity: bit f (the tables are kernel arguments: an
     // entry indexed per lane is a load, issued here with all the others)
     unsigned bdefer = 0u;
+    if ((nb[0] | nb[1] | nb[2] | nb[3]) < 0) {      // (read by the lanes - and waves - that own a boundary facet only)
 #pragma unroll
-    for (int f = 0; f < 4; f++) {
-        const int marker = nb[f] < 0 ? -nb[f] : 0;
-        if (marker > 0 && marker < SWE_MAX_MARKERS && (p.bc_has_value[marker] || p.bc_vel_kind[marker])) bdefer |= 1u << f;
+        for (int f = 0; f < 4; f++) {
+            const int marker = nb[f] < 0 ? -nb[f] : 0;
+            if (marker > 0 && marker < SWE_MAX_MARKERS && (p.bc_has_value[marker] || p.bc_vel_kind[marker])) bdefer |= 1u << f;
+        }
     }
     double una[4], unb[4], vna[4], vnb[4], cna[4], cnb[4];
 #pragma unroll

@@ -163,6 +163,8 @@ def main():
     report('cfg2 + SIPG viscosity', n, 684.0 + 3*204.0, timed(dev, dev.advance, 50))
     dev.set_viscosity(None)
     dev.close()
+    if only == 'tracers':                         # the triangle rows only (kernel A/B runs)
+        return
     cfg5()
     quads(rng)
 

@@ -1,0 +1,23 @@
+#!/bin/bash
+# round 5, run z3: the triangle tracer kernels with the data-carrying boundary facets after the outputs (126 VGPRs: FOUR waves per SIMD;
+# with the diffusion fused in 150-162) against the form with them inlined (154-162: three waves); tracer / sipg / distributed tests
+set -u
+O=gpurun_out/r05z3; rm -rf $O; mkdir -p $O
+export TMPDIR=/tmp
+timeout 2400 python -m pytest tests/test_gpu_tracer.py tests/test_gpu_sipg.py -q -m gpu -x > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -3 $O/gpu_tests.log | cut -c1-300
+for rep in 1 2; do
+  for lib in new old; do
+    if [ $lib = new ]; then unset THETIS_AMD_LIB; else export THETIS_AMD_LIB=$PWD/build_dbg/libswe2d_tt_$lib.so; fi
+    CFGBENCH_ONLY=tracers timeout 600 python tools/cfgbench.py 2>&1 | grep "^{" | sed "s/^/$lib /" >> $O/tri_ab.txt
+
+  done
+done
+unset THETIS_AMD_LIB
+sed 's/"algorithmic_bytes.*frac_of_8TBs/"frac/' $O/tri_ab.txt | cut -c1-170
+sed 's/"exchange.*"world"/ world/; s/"overlap.*"n_owned"/ n_owned/; s/"n_send.*"flow"/ flow/' $O/rank.txt
+for rep in 1 2; do
+  for lib in new old; do
+    if [ $lib = new ]; then unset THETIS_AMD_LIB; else export THETIS_AMD_LIB=$PWD/build_dbg/libswe2d_tt_$lib.so; fi
+    CFGBENCH_ONLY=quads timeout 600 python tools/cfgbench.py 2>&1 | grep "^{" | grep -i tracer | sed "s/^/$lib /" | sed 's/"algorithmic_bytes.*frac_of_8TBs/"frac/' | cut -c1-170
+  done
+done
