@@ -565,6 +565,11 @@ __device__ __forceinline__ double swe_ld_chk(swe_rsrc_t r, unsigned voff, unsign
     if (!swe_chk(r.base + voff + soff, 8, line)) return 0.0;
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r.r, voff, soff, 0));
 }
+__device__ __forceinline__ double swe_ld_l2_chk(swe_rsrc_t r, unsigned voff, unsigned soff, int line)
+{
+    if (!swe_chk(r.base + voff + soff, 8, line)) return 0.0;
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r.r, voff, soff, 16));
+}
 __device__ __forceinline__ int swe_ldi_chk(swe_rsrc_t r, unsigned voff, unsigned soff, int line)
 {
     if (!swe_chk(r.base + voff + soff, 4, line)) return 0;
@@ -576,6 +581,7 @@ __device__ __forceinline__ void swe_st_chk(swe_rsrc_t r, unsigned voff, unsigned
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(swe_u32x2, x), r.r, voff, soff, SWE_ST_AUX);
 }
 #define swe_ld(r, v, s) swe_ld_chk(r, v, s, __LINE__)
+#define swe_ld_l2(r, v, s) swe_ld_l2_chk(r, v, s, __LINE__)
 #define swe_ldi(r, v, s) swe_ldi_chk(r, v, s, __LINE__)
 #define swe_st(r, v, s, x) swe_st_chk(r, v, s, x, __LINE__)
 #endif
