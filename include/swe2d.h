@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SWE2D_ABI_VERSION 9
+#define SWE2D_ABI_VERSION 10
 #define SWE2D_MAX_MARKERS 16          /* boundary markers must be in 1..SWE2D_MAX_MARKERS-1 */
 
 typedef enum {
@@ -119,6 +119,11 @@ typedef struct swe2d_handle swe2d_handle;
 
 /* version / capability */
 int  swe2d_abi_version(void);
+/* How the triangle kernels read the connectivity: out[0] = 1 when from the 16-B records (neighbour and vertex ids as differences
+ * to the cell's own, csrc/swe2d_kernels.h swe_conn_pack; in launches of >= 250 k cells, where it pays;
+ * THETIS_AMD_COMPACT_IDX=0 keeps the 24-B records everywhere, =2 takes the 16-B records in every launch), out[1] = the number
+ * of cells whose differences did not fit and which read the 24-B record after all.  Results do not depend on it. */
+int  swe2d_connectivity_info(swe2d_handle *h, int32_t out[2]);
 int  swe2d_device_count(void);                                   /* number of visible HIP devices, <0 on error */
 
 /* Shu-Osher coefficients the stage kernels use (host-only, needs no device): stage i computes

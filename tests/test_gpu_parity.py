@@ -485,6 +485,58 @@ def test_stage_kernel_variants_agree_bitwise_on_a_large_launch(hip_lib):
         assert np.array_equal(out['00'][0], out[key][0]) and np.array_equal(out['00'][1], out[key][1]), key
 
 
+@pytest.mark.parametrize('numbering', ['device', 'device_wetting_drying', 'caller_random'])
+def test_compact_connectivity_gives_the_bits_of_the_wide_records(hip_lib, monkeypatch, numbering):
+    """The triangle kernels read the connectivity as 16-B records of differences (csrc/swe2d_conn.h; the wide
+    24-B records where a difference does not fit).  Same bits as with THETIS_AMD_COMPACT_IDX=0: SWE stages with open boundaries,
+    a tracer with its limiter; in the device's numbering (few escapes) and in a RANDOM numbering of cells and vertices that is
+    kept as it is (a third of the cells of a 400 k-cell mesh escape, the rest decode differences of every size and sign); with
+    wetting-drying and Manning friction (kernels that take the records only when forced: they are bound by their arithmetic)."""
+    from thetis_amd.device import Swe2dDevice
+    from thetis_amd import _lib
+    from thetis_amd.mesh import Mesh2d, _rect_marker_fn
+    monkeypatch.setenv('THETIS_AMD_FLOW', '0')
+    if numbering.startswith('device'):
+        mesh, bath, uv, eta = channel_case(nx=450, ny=300, lx=100e3, ly=50e3, seed=5, amp_eta=0.3, amp_u=0.2)      # 270 k cells
+        reorder = 'auto'
+    else:
+        m0, bath0, uv0, eta0 = channel_case(nx=500, ny=400, lx=100e3, ly=80e3, seed=6, amp_eta=0.3, amp_u=0.2)
+        rng = np.random.default_rng(11)
+        cperm, vperm = rng.permutation(m0.num_cells), rng.permutation(m0.num_vertices)
+        vinv = np.empty_like(vperm)
+        vinv[vperm] = np.arange(len(vperm))
+        mesh = Mesh2d(m0.vertex_xy[vperm], vinv[m0.cells[cperm]], marker_fn=_rect_marker_fn(100e3, 80e3))
+        bath, uv, eta = bath0[vperm], uv0[cperm], eta0[cperm]
+        reorder = None
+    tr0 = np.where(mesh.cell_xy()[:, :, 0] < 40e3, 0.0, 30.0)
+    out, info = [], []
+    for compact in ('0', '2', '1'):                             # never / in every launch / where it pays (conn_pays: >= 250 k cells)
+        monkeypatch.setenv('THETIS_AMD_COMPACT_IDX', compact)
+        dev = Swe2dDevice(mesh, bath, 0.5, reorder=reorder)
+        info.append(dev.connectivity_info())
+        if numbering == 'device_wetting_drying':
+            dev.set_wetting_and_drying(0.5)
+            dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+        dev.set_bc(2, {'elev': 0.1})
+        dev.set_state(0.1*uv, eta)
+        tid = dev.add_tracer()
+        dev.tracer_set_state(tid, tr0)
+        dev.advance_coupled(3, tracer_only=False, use_limiter=True)
+        dev.advance(2)
+        out.append(dev.get_state() + (dev.tracer_get_state(tid),))
+        dev.close()
+    assert info[0] == (0, 0) and info[1][0] == 1 and info[2] == info[1]
+    n = mesh.num_cells
+    if numbering.startswith('device'):
+        assert 0 <= info[1][1] < 0.02*n, info
+    else:
+        assert 0.2*n < info[1][1] < n, info
+    assert np.isfinite(out[0][1]).all()
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize('quad', [False, True])
 def test_alternating_launch_direction_gives_the_same_bits(hip_lib, monkeypatch, quad):
     """Launches whose state does not fit the Infinity Cache walk the cell range alternately forwards and backwards

@@ -358,3 +358,67 @@ def test_flow_block_order_makes_compact_blocks():
     md = delaunay_case(n_points=6000, seed=5)[0]
     r_new, r_old = rims(md.cell_nbr, ordering.flow_block_order(md)), rims(md.cell_nbr, ordering.auto_cell_order(md))
     assert r_new.max() <= 42 and r_new.max() < r_old.max() and r_new.mean() < 0.9*r_old.mean(), (r_new.max(), r_old.max(), r_new.mean(), r_old.mean())
+
+
+def test_compact_connectivity_records_round_trip(tmp_path):
+    """thetis_amd/csrc/swe2d_conn.h: the 16-B connectivity records the triangle kernels read.  Host packing against the kernels'
+    unpacking (the same header compiled with g++): random records of every span, markers, the edges of the 19-bit range, and that
+    exactly the records that do not fit come back as escapes."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path/'conn.cpp'
+    src.write_text(r'''
+#include <cstdio>
+#include <cstdlib>
+#include "swe2d_conn.h"
+static int check(int k, const int nb[3], const int vid[3], int want_escape) {
+    int nb2[3], vid2[3];
+    const bool e = swe_conn_unpack(swe_conn_pack(k, nb, vid), k, nb2, vid2);
+    if (want_escape >= 0 && (int)e != want_escape) { printf("escape %d, expected %d at k %d\n", (int)e, want_escape, k); return -1; }
+    if (!e) for (int i = 0; i < 3; i++) if (nb2[i] != nb[i] || vid2[i] != vid[i]) { printf("mismatch at k %d\n", k); return -1; }
+    return e ? 1 : 0;
+}
+int main() {
+    srand(1);
+    long esc = 0, n = 0;
+    for (int it = 0; it < 2000000; it++) {
+        const int span = (it & 1) ? 300000 : 1 << (rand() % 24);
+        const int k = rand() % (1 << 24);
+        int nb[3], vid[3];
+        vid[0] = rand() % (1 << 26);
+        for (int i = 1; i < 3; i++) vid[i] = vid[0] + rand() % (2*span + 1) - span;
+        if (vid[1] < 0 || vid[2] < 0) continue;
+        bool fits = swe_conn_fits((long long)vid[1] - vid[0]) && swe_conn_fits((long long)vid[2] - vid[0]);
+        for (int f = 0; f < 3; f++) {
+            if (rand() % 8 == 0) nb[f] = -(1 + rand() % 15);
+            else {
+                long long kn = (long long)k + rand() % (2*span + 1) - span;
+                if (kn < 0) kn = 0;
+                nb[f] = (int)((kn << 2) | (rand() % 3));
+                fits = fits && swe_conn_fits(kn - k);
+            }
+        }
+        const int r = check(k, nb, vid, fits ? 0 : 1);
+        if (r < 0) return 1;
+        esc += r; n++;
+    }
+    const int lim = 1 << (SWE_CONN_DBITS - 1);
+    for (int d = -lim - 2; d <= lim + 2; d++) {
+        if (d > -lim + 2 && d < lim - 2 && d != 0 && d != 1 && d != -1) continue;
+        const int k = 1000000;
+        const int nb[3] = {((k + d) << 2) | 2, -15, ((k - d) << 2) | 0}, vid[3] = {5000000, 5000000 + d, 5000000 - d};
+        if (check(k, nb, vid, (d >= -lim && d < lim && -d >= -lim && -d < lim) ? 0 : 1) < 0) return 1;
+    }
+    { const int nb[3] = {-1, -2, -3}, vid[3] = {(1 << 26), 5, 6}; if (check(0, nb, vid, 1) < 0) return 1; }      // vertex id too large
+    { const int nb[3] = {-1, -2, 4}, vid[3] = {(1 << 26) - 1, (1 << 26) - 2, (1 << 26) - 3}; if (check(0, nb, vid, 0) < 0) return 1; }
+    printf("ok %ld %ld\n", n, esc);
+    return 0;
+}
+''')
+    exe = tmp_path/'conn'
+    subprocess.run(['g++', '-O1', '-w', '-I', os.path.join(root, 'thetis_amd', 'csrc'), str(src), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith('ok '), out.stdout + out.stderr
+    n, esc = (int(x) for x in out.stdout.split()[1:3])
+    assert n > 1500000 and 0.1*n < esc < 0.6*n

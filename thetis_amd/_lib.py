@@ -19,7 +19,7 @@ SCALAR_LINEAR_DRAG, SCALAR_QUADRATIC_DRAG, SCALAR_MANNING_DRAG, SCALAR_NORM_SMOO
 
 IPC_HANDLE_BYTES = 64    # include/swe2d.h SWE2D_IPC_HANDLE_BYTES (sizeof(hipIpcMemHandle_t))
 SUM_LIMBS = 6             # include/swe2d.h: limbs per order-independent sum (swe2d_diagnostics_limbs)
-ABI_VERSION = 9          # include/swe2d.h SWE2D_ABI_VERSION
+ABI_VERSION = 10         # include/swe2d.h SWE2D_ABI_VERSION
 OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NOT_FINITE = 0, -1, -2, -3, -4, -5
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -44,6 +44,7 @@ class Swe2dParams(ctypes.Structure):
 _H = ctypes.c_void_p
 SYMBOLS = {
     'swe2d_abi_version': (ctypes.c_int, []),
+    'swe2d_connectivity_info': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_device_count': (ctypes.c_int, []),
     'swe2d_ssprk33_coefficients': (None, [_dp, _dp, _dp]),
     'swe2d_create': (ctypes.c_int, [ctypes.POINTER(Swe2dMesh), ctypes.POINTER(Swe2dParams), ctypes.POINTER(_H)]),

@@ -32,6 +32,7 @@ void fill_stage_args(Handle *h, SweStageArgs &a, int in, int u0, int out, double
     a.vx = h->vx; a.vy = h->vy; a.vh = h->vh;
     a.valpha = h->valpha;
     a.idx4 = h->idx4; a.idx2 = h->idx2;
+    a.idxc = conn_pays(h, c1 - c0, h->wd) ? h->idxc : nullptr;
     a.cell_begin = c0; a.cell_end = c1;
     a.reverse = 0;
     { const char *e = std::getenv("THETIS_AMD_WALL_FAST"); a.wall_general = (e && std::atoi(e) == 0) ? 1 : 0; }
@@ -233,6 +234,15 @@ extern "C" {
 
 int swe2d_abi_version(void) { return SWE2D_ABI_VERSION; }
 
+int swe2d_connectivity_info(swe2d_handle *hh, int32_t out[2])
+{
+    Handle *h = H(hh);
+    if (!h || !out) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    out[0] = h->idxc ? 1 : 0;
+    out[1] = h->idxc ? h->n_conn_escapes : 0;
+    return SWE2D_OK;
+}
+
 int swe2d_device_count(void)
 {
     int n = 0;
@@ -410,6 +420,21 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
         HIP_TRY_C(hipMalloc(&h->idx2, (size_t)S*sizeof(int2)));
         HIP_TRY_C(hipMemcpy(h->idx4, p4.data(), (size_t)S*sizeof(int4), hipMemcpyHostToDevice));
         HIP_TRY_C(hipMemcpy(h->idx2, p2.data(), (size_t)S*sizeof(int2), hipMemcpyHostToDevice));
+        {   // the 16-B form of the same records (swe_conn_pack): what the stage kernels read
+            const char *e = std::getenv("THETIS_AMD_COMPACT_IDX");
+            h->idxc_always = (e && std::atoi(e) == 2) ? 1 : 0;
+            if (!(e && std::atoi(e) == 0)) {
+                std::vector<int4> pc((size_t)S, int4{0, 0, 0, (int)0x80000000u});
+                h->n_conn_escapes = 0;
+                for (int kk = 0; kk < n; kk++) {
+                    const int nb3[3] = {nbr[kk], nbr[S + kk], nbr[2*S + kk]}, v3[3] = {cv[kk], cv[S + kk], cv[2*S + kk]};
+                    pc[kk] = swe_conn_pack(kk, nb3, v3);
+                    if (pc[kk].w < 0) h->n_conn_escapes++;
+                }
+                HIP_TRY_C(hipMalloc(&h->idxc, (size_t)S*sizeof(int4)));
+                HIP_TRY_C(hipMemcpy(h->idxc, pc.data(), (size_t)S*sizeof(int4), hipMemcpyHostToDevice));
+            }
+        }
         // fused viscosity: the neighbour's vertex opposite the shared facet (its node (f2 + 2) % 3) per facet, and the list
         // of cells that own a boundary facet
         std::vector<int> bnd;
@@ -470,7 +495,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->diag_acc, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->snapshot, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->snapshot, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->idxc, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
     for (void *m : h->p2p.opened) (void)hipIpcCloseMemHandle(m);

@@ -34,6 +34,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     // triangles: cell integral and interior facets of the diffusion inside the stage kernel, boundary facets by a launch
     // over the boundary cells (only when a marker has a diffusive boundary term at all)
     const bool fused_diff = t.diff && h->fuse_visc && h->npc == 3 && h->opp4;
+    a.idxc = conn_pays(h, c1 - c0, fused_diff) ? h->idxc : nullptr;
     a.opp4 = h->opp4;
     a.mu_v = t.mu_v; a.mu_const = t.mu_const;
     a.diff_sipg = 3.0*t.sipg_factor;

@@ -115,6 +115,9 @@ struct Handle {
     bool fuse_visc = true;                              // THETIS_AMD_NO_VISC_FUSION=1: separate SIPG pass (A/B, debugging)
     int4 *idx4 = nullptr;                               // packed triangle connectivity (stage kernel), see SweStageArgs
     int2 *idx2 = nullptr;
+    int4 *idxc = nullptr;                               // ... in 16 B (swe_conn_pack), what the stage kernels read; THETIS_AMD_COMPACT_IDX=0: not used
+    int idxc_always = 0;                                // THETIS_AMD_COMPACT_IDX=2: in every launch (default: where it pays, swe_conn_pays)
+    int n_conn_escapes = 0;                             // cells whose record is an escape to the wide ones
     std::vector<int> h_nbr;                             // host copy of the packed neighbour codes [3][S] (triangles; flow_build)
     // dataflow stage loop (swe2d_flow.h): per-block stage counters, status word {timeouts, first late block + 1}
     unsigned *flow_flag = nullptr, *flow_status = nullptr;
@@ -266,6 +269,14 @@ inline bool has_sources(const Handle *h)
 inline int grid_for(int n) { return (n + 255)/256; }
 
 // ---- stage launches (swe2d_api.hip)
+// Where the 16-B connectivity records (swe2d_conn.h) pay: launches that stream from memory - from ~250 k cells, where the 8 B
+// they save per cell are 2-3 % of a stage's traffic (profiles/r05zc: 1 M triangles 113.1 -> 110.3 us per step, 500 k 63.6 -> 62.7);
+// a launch of 125 k cells is latency-bound and the ~20 integer instructions of the decode make it 1 % slower (24.0 against 23.8),
+// and so are the kernels bound by their arithmetic (wetting-drying + Manning: 80.5 against 79.8; tracer with fused diffusion).
+inline bool conn_pays(const Handle *h, int n_cells_of_launch, bool arithmetic_bound)
+{
+    return h->idxc && (h->idxc_always || (n_cells_of_launch >= 250000 && !arithmetic_bound));
+}
 void fill_stage_args(Handle *h, SweStageArgs &a, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1);
 int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1);
 int stage_on_range(Handle *h, int i_stage, int c0, int c1);

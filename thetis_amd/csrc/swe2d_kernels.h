@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "swe2d_conn.h"
 
 #define SWE_MAX_MARKERS 16
 #define SWE_BC_ELEV 1
@@ -63,6 +64,9 @@ struct SweStageArgs {
     // (one 16-B and one 8-B load per lane instead of six 4-B loads from six planes)
     const int4 *idx4;
     const int2 *idx2;
+    // ... and the same in 16 B (swe_conn_pack / swe_conn_load below), or null: what the stage kernels read (idx4 / idx2 stay as the
+    // escape for the few cells whose differences do not fit)
+    const int4 *idxc;
     // horizontal viscosity fused into the triangle stage kernel (VISC variants; swe_visc_interior)
     const int4 *opp4;             // {vertex of neighbour 0 / 1 / 2 opposite the shared facet, 0}
     const double *nu_v;           // per-vertex viscosity or null (then nu_const)
@@ -106,6 +110,24 @@ __device__ __forceinline__ int swe_logical_block(int b, int nblocks)
 {
     const int per = (nblocks + 7) >> 3;
     return (b & 7)*per + (b >> 3);
+}
+
+// ---- Compact triangle connectivity (swe2d_conn.h): 16 B per cell instead of 24, the wide records where a difference does not fit
+__device__ __forceinline__ void swe_conn_load(const int4 *idxc, const int4 *idx4, const int2 *idx2, int k, int nb[3], int vid[3])
+{
+    if (idxc) {                                          // uniform
+        if (swe_conn_unpack(idxc[k], k, nb, vid)) {      // escape (rare): the wide records
+            const int4 q4 = idx4[k];
+            const int2 q2 = idx2[k];
+            nb[0] = q4.x; nb[1] = q4.y; nb[2] = q4.z;
+            vid[0] = q4.w; vid[1] = q2.x; vid[2] = q2.y;
+        }
+    } else {
+        const int4 q4 = idx4[k];
+        const int2 q2 = idx2[k];
+        nb[0] = q4.x; nb[1] = q4.y; nb[2] = q4.z;
+        vid[0] = q4.w; vid[1] = q2.x; vid[2] = q2.y;
+    }
 }
 
 // sqrt(x) and 1/sqrt(x) for normal-range x > 0: v_rsq_f64 seed, one Goldschmidt iteration, two residual corrections
@@ -1032,12 +1054,7 @@ __global__ __launch_bounds__(SWE_BLOCK, SWE_MIN_WAVES) void swe_stage_kernel(con
     //      (own data + indices, then the gathers) instead of one per facet and one per output plane.
     double u[3], v[3], e[3];
     int nb[3], vid[3];
-    {
-        const int4 q4 = p.idx4[k];
-        const int2 q2 = p.idx2[k];
-        nb[0] = q4.x; nb[1] = q4.y; nb[2] = q4.z;
-        vid[0] = q4.w; vid[1] = q2.x; vid[2] = q2.y;
-    }
+    swe_conn_load(p.idxc, p.idx4, p.idx2, k, nb, vid);
     // boundary markers of the three facets in one register (0: interior facet): all the boundary pass of the BINL variant
     // needs of nb[] at the end of the kernel
     const int bmarkers = (nb[0] < 0 ? -nb[0] : 0) | (nb[1] < 0 ? (-nb[1]) << 8 : 0) | (nb[2] < 0 ? (-nb[2]) << 16 : 0);
@@ -1593,6 +1610,7 @@ struct SweTracerArgs {
     const int *nbr, *cv;
     const int4 *idx4;      // packed triangle connectivity, see SweStageArgs (null for quadrilaterals)
     const int2 *idx2;
+    const int4 *idxc;      // its 16-B form or null, see SweStageArgs
     const double *vx, *vy;
     int cell_begin, cell_end;
     double dt, a0, a1, beta;
@@ -1801,12 +1819,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
 
     double u[3], v[3], c[3], w[3];
     int nb[3], vid[3];
-    {
-        const int4 q4 = p.idx4[k];
-        const int2 q2 = p.idx2[k];
-        nb[0] = q4.x; nb[1] = q4.y; nb[2] = q4.z;
-        vid[0] = q4.w; vid[1] = q2.x; vid[2] = q2.y;
-    }
+    swe_conn_load(p.idxc, p.idx4, p.idx2, k, nb, vid);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         u[i] = cf*swe_ld(gu, k8, i*S8);

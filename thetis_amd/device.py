@@ -444,6 +444,12 @@ class Swe2dDevice(object):
         multi-block kernel (csrc/swe2d_mflow.h: no exchange inside the launch)."""
         return int(self.lib.swe2d_flow_supported(self.h))
 
+    def connectivity_info(self):
+        """(compact records in use, cells that escape to the wide records): swe2d_connectivity_info"""
+        out = (ctypes.c_int32*2)()
+        self._ck(self.lib.swe2d_connectivity_info(self.h, out))
+        return int(out[0]), int(out[1])
+
     def flow_timeouts(self):
         n = ctypes.c_int32()
         self._ck(self.lib.swe2d_flow_status(self.h, ctypes.byref(n)))
