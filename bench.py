@@ -36,7 +36,7 @@ PREWARM_S = 0.5                          # seconds of untimed stepping before th
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_ELEMENT_STEP = 684.0          # 180 + 252 + 252 algorithmic bytes per triangle per step
 BYTES_PER_ELEMENT_UPDATE = BYTES_PER_ELEMENT_STEP/3.0
-TRAFFIC_JSON = 'r05z_traffic.json'         # committed PMC passes of the stage kernel on this workload (profiles/README.md)
+TRAFFIC_JSON = 'r05zz_traffic.json'         # committed PMC passes of the stage kernel on this workload (profiles/README.md)
 BEYOND_CACHE_NX, BEYOND_CACHE_NY = 2000, 1000   # 4M triangles: 3 x 288 MB of state, beyond the 256 MB Infinity Cache
 
 
