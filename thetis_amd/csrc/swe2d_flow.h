@@ -752,6 +752,37 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
 #pragma unroll
             for (int i = 0; i < 3; i++) eta[i] = WD ? swe_wd_eta(e[i], h[i], al[i]) : e[i];
 #define SWE_FLOW_CELL_TERMS_HERE swe_flow_rhs_cell<NONLIN, WD>(p, u, v, eta, h, nx, ny, bu, bv, be, e)
+            // w = a0*U(0) + a1*U_in: the first stage of a step has no U(0) term (swe_stage_kernel<., ., HASU0 = false>); with
+            // wetting-drying the continuity equation advances zeta = D - h (the planes, U(0)'s too, hold D)
+#define SWE_FLOW_W_HERE do {                                                                                                          \
+                const double a0 = q.a0[i3], a1 = q.a1[i3];                                                                        \
+                _Pragma("unroll")                                                                                                 \
+                for (int i = 0; i < 3; i++) { wu[i] = a1*u[i]; wv[i] = a1*v[i]; we[i] = WD ? a1*(e[i] - h[i]) : a1*e[i]; }        \
+                if (i3 > 0) {                                                                                                     \
+                    _Pragma("unroll")                                                                                             \
+                    for (int i = 0; i < 3; i++) {                                                                                 \
+                        wu[i] = fma(a0, lu0[i][lane], wu[i]);                                                                     \
+                        wv[i] = fma(a0, lu0[3 + i][lane], wv[i]);                                                                 \
+                        we[i] = fma(a0, WD ? lu0[6 + i][lane] - h[i] : lu0[6 + i][lane], we[i]);                                  \
+                    }                                                                                                             \
+                }                                                                                                                 \
+            } while (0)
+            // What is evaluated in front of the wait has to be PINNED there: the compiler otherwise sinks the whole evaluation past the
+            // polling loop to its first use (the ISA of the build that introduced "cell integrals before the wait" had every FP64
+            // instruction of a stage behind the loop).  An empty asm that "modifies" the results keeps them where they are written.
+            // Rank 3 of eight, us per step (profiles/r05zf_flow_pinned_before_wait.txt): nothing pinned 16.46, cell integrals 16.25,
+            // + the weights 15.90; with source terms 21.22 / 20.47 / 20.66; wetting-drying 20.15 / 20.24 / 20.68 (registers) - hence:
+#ifdef SWE_FLOW_NO_PIN
+            constexpr bool PIN_CELL = false, PIN_W = false;
+#else
+            constexpr bool PIN_CELL = !WD, PIN_W = !WD && !SRC;
+#endif
+            double wu[3], wv[3], we[3];
+            if constexpr (PIN_W) {
+                SWE_FLOW_W_HERE;
+#pragma unroll
+                for (int i = 0; i < 3; i++) asm volatile("" : "+v"(wu[i]), "+v"(wv[i]), "+v"(we[i]));
+            }
             if (FX || g > 0) {
                 SWE_FLOW_DELAY_AT(1);
                 const int pc_in = FX ? c*spc + g : g - 1;      // the publish this stage reads
@@ -782,6 +813,10 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                 // machine LICM, _build.py UNIT_FLAGS, which left 14-20 registers free.  -DSWE_FLOW_NO_HOIST_POLL: A/B.)
 #ifndef SWE_FLOW_LATE_CELL_TERMS
                 SWE_FLOW_CELL_TERMS_HERE;
+                if constexpr (PIN_CELL) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) asm volatile("" : "+v"(bu[i]), "+v"(bv[i]), "+v"(be[i]));
+                }
 #endif
 #ifndef SWE_FLOW_NO_HOIST_POLL
                 const bool one_trip = !WD && 6*nrim <= POLL*SWE_BLOCK;      // (not with wetting-drying: eight registers too many)
@@ -836,21 +871,10 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
             SWE_FLOW_CELL_TERMS_HERE;
 #endif
 #undef SWE_FLOW_CELL_TERMS_HERE
-            double ou[3], ov[3], oe[3], wu[3], wv[3], we[3];
+            double ou[3], ov[3], oe[3];
             swe_flow_rhs_facets<NONLIN, LF, SRC, NTR, WD>(p, k, u, v, eta, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be, e, al);
-            // w = a0*U(0) + a1*U_in: the first stage of a step has no U(0) term (swe_stage_kernel<., ., HASU0 = false>); with
-            // wetting-drying the continuity equation advances zeta = D - h (the planes, U(0)'s too, hold D)
-            const double a0 = q.a0[i3], a1 = q.a1[i3];
-#pragma unroll
-            for (int i = 0; i < 3; i++) { wu[i] = a1*u[i]; wv[i] = a1*v[i]; we[i] = WD ? a1*(e[i] - h[i]) : a1*e[i]; }
-            if (i3 > 0) {
-#pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    wu[i] = fma(a0, lu0[i][lane], wu[i]);
-                    wv[i] = fma(a0, lu0[3 + i][lane], wv[i]);
-                    we[i] = fma(a0, WD ? lu0[6 + i][lane] - h[i] : lu0[6 + i][lane], we[i]);
-                }
-            }
+            if constexpr (!PIN_W) SWE_FLOW_W_HERE;
+#undef SWE_FLOW_W_HERE
             // (a lane outside the stage's range has no boundary facets to do: the outermost ghost layer of a partition, which is in no
             //  stage's range, points its missing neighbours at a wall - unmasked, every block that holds such a cell ran the boundary
             //  pass in every stage, +0.8 us for the 300 blocks next to the cuts of a rank of eight)
