@@ -198,6 +198,7 @@ def run_single(args):
     value = n*3.0*args.steps/t_wall
     achieved = BYTES_PER_ELEMENT_UPDATE*n/(ms_kernel*1e-3)/1e9
     traffic, traffic_src = measured_traffic(n)
+    fused = dev.fused_pair_info()
     out = {
         'metric': 'DG element-updates/sec, 2D SWE DG-P1 SSPRK33',
         'value': value, 'unit': 'element-updates/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
@@ -211,7 +212,11 @@ def run_single(args):
                      'frac_min': float(min(frac_samples)), 'frac_max': float(max(frac_samples)),
                      'traffic': traffic, 'traffic_unit': 'bytes per launch',
                      'traffic_source': traffic_src,
-                     'kernel': 'swe_stage_kernel', 'avg_launch_ms': ms_kernel, 'avg_launch_ms_per_launch_events': ms_kernel_each,
+                     'kernel': ('swe_fuse12_kernel (stages 1 + 2 in one launch) + swe_stage_kernel (stage 3): avg_launch_ms is per '
+                                'element-update = a third of a step') if fused[0] else 'swe_stage_kernel',
+                     'launches_per_step': 2 if fused[0] else 3,
+                     'fused_stage_pair': {'tiles': fused[1], 'ring_cells': fused[2]} if fused[0] else None,
+                     'avg_launch_ms': ms_kernel, 'avg_launch_ms_per_launch_events': ms_kernel_each,
                      'algorithmic_bytes_per_launch': BYTES_PER_ELEMENT_UPDATE*n},
     }
     if not args.no_beyond_cache:

@@ -124,6 +124,14 @@ int  swe2d_abi_version(void);
  * THETIS_AMD_COMPACT_IDX=0 keeps the 24-B records everywhere, =2 takes the 16-B records in every launch), out[1] = the number
  * of cells whose differences did not fit and which read the 24-B record after all.  Results do not depend on it. */
 int  swe2d_connectivity_info(swe2d_handle *h, int32_t out[2]);
+/* Stages 1 and 2 of a step in ONE launch by overlapped tiles (csrc/swe2d_fuse.h: 192 interior cells + their ring per workgroup,
+ * the first stage's result never leaves the chip), stage 3 as a stage launch: what swe2d_advance does from 250 k triangles on a
+ * whole mesh without source terms, wetting-drying or viscosity, when the cell numbering gives compact tiles (THETIS_AMD_FUSE12=0:
+ * never, =1: on every such mesh).  Same results bit for bit; the intermediate stage_sol[1] is then not in the state buffers
+ * (swe2d_get_stage_state(1) after swe2d_advance returns what the last stage launch left there).
+ * out[0] = 1 when swe2d_advance would take it now (builds the tile tables on first use), out[1] = tiles, out[2] = ring cells
+ * (cells evaluated redundantly in stage 1), out[3] = cells. */
+int  swe2d_fused_pair_info(swe2d_handle *h, int32_t out[4]);
 int  swe2d_device_count(void);                                   /* number of visible HIP devices, <0 on error */
 
 /* Shu-Osher coefficients the stage kernels use (host-only, needs no device): stage i computes

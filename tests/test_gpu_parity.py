@@ -537,6 +537,53 @@ def test_compact_connectivity_gives_the_bits_of_the_wide_records(hip_lib, monkey
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('case', ['structured', 'linear_no_lf', 'ragged_small', 'random_numbering', 'by_the_rule_270k'])
+def test_fused_stage_pair_gives_the_bits_of_the_stage_launches(hip_lib, monkeypatch, case):
+    """csrc/swe2d_fuse.h: stages 1 and 2 of a step in one launch by overlapped tiles (192 interior cells + their ring per 256-lane
+    workgroup, U(1) never leaves the chip), stage 3 as a stage launch - what swe2d_advance takes from 250 k cells where the kernel
+    covers the configuration.  Bit for bit THETIS_AMD_FUSE12=0 (three stage launches): open boundaries and walls, linear equations
+    without the Lax-Friedrichs term, partial tiles on a small ragged mesh, a random numbering (tiles of a few cells with rings that
+    fill the workgroup; forced), and a 270 k-cell mesh where the library decides by itself."""
+    from thetis_amd.device import Swe2dDevice
+    from thetis_amd.mesh import Mesh2d, _rect_marker_fn
+    monkeypatch.setenv('THETIS_AMD_FLOW', '0')
+    kw, reorder, forced = {}, 'auto', '1'
+    if case == 'structured':
+        mesh, bath, uv, eta = channel_case(nx=200, ny=120, lx=100e3, ly=50e3, seed=5, amp_eta=0.3, amp_u=0.2)
+    elif case == 'linear_no_lf':
+        mesh, bath, uv, eta = channel_case(nx=120, ny=90, lx=100e3, ly=50e3, seed=6, amp_eta=0.3, amp_u=0.2)
+        kw = dict(use_nonlinear_equations=False, use_lax_friedrichs_velocity=False)
+    elif case == 'ragged_small':
+        mesh, bath, uv, eta = channel_case(nx=53, ny=31, seed=5)
+    elif case == 'random_numbering':
+        m0, bath0, uv0, eta0 = channel_case(nx=90, ny=70, lx=100e3, ly=80e3, seed=6, amp_eta=0.3, amp_u=0.2)
+        rng = np.random.default_rng(11)
+        cperm, vperm = rng.permutation(m0.num_cells), rng.permutation(m0.num_vertices)
+        vinv = np.empty_like(vperm)
+        vinv[vperm] = np.arange(len(vperm))
+        mesh = Mesh2d(m0.vertex_xy[vperm], vinv[m0.cells[cperm]], marker_fn=_rect_marker_fn(100e3, 80e3))
+        bath, uv, eta, reorder = bath0[vperm], uv0[cperm], eta0[cperm], None
+    else:
+        mesh, bath, uv, eta = channel_case(nx=450, ny=300, lx=100e3, ly=50e3, seed=5, amp_eta=0.3, amp_u=0.2)
+        forced = None
+    out = []
+    for fuse in ('0', forced):
+        if fuse is None:
+            monkeypatch.delenv('THETIS_AMD_FUSE12', raising=False)
+        else:
+            monkeypatch.setenv('THETIS_AMD_FUSE12', fuse)
+        dev = Swe2dDevice(mesh, bath, 0.5, reorder=reorder, **kw)
+        dev.set_bc(2, {'elev': 0.1})
+        dev.set_bc(3, {'un': 0.05})
+        dev.set_state(uv, eta)
+        dev.advance(3)
+        dev.advance(2)
+        out.append(dev.get_state())
+        dev.close()
+    assert np.isfinite(out[0][1]).all()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize('quad', [False, True])
 def test_alternating_launch_direction_gives_the_same_bits(hip_lib, monkeypatch, quad):
     """Launches whose state does not fit the Infinity Cache walk the cell range alternately forwards and backwards

@@ -15,7 +15,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-UNITS = ['swe2d_api.hip', 'swe2d_api_flow.hip', 'swe2d_api_tracer.hip', 'swe2d_api_p2p.hip',
+UNITS = ['swe2d_api.hip', 'swe2d_api_flow.hip', 'swe2d_api_tracer.hip', 'swe2d_api_p2p.hip', 'swe2d_api_fuse.hip',
          'swe2d_k_tri.hip', 'swe2d_k_wd.hip', 'swe2d_k_quad.hip', 'swe2d_k_flow.hip', 'swe2d_k_flow_wd.hip', 'swe2d_k_tracer.hip']
 UNITY = os.path.join(CSRC, 'swe2d_unity.hip')
 OBJ_DIR = os.path.join(CSRC, '.obj')
@@ -29,7 +29,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 # quadrilaterals -1.5 ... -2 %).  Not for the triangle stage kernels (no change, although the first-stage epilogue variant reaches
 # four waves per SIMD) and not for the wetting-drying unit (cfg 5 +3 %).
 _NO_MLICM = ['-mllvm', '-disable-machine-licm']
-UNIT_FLAGS = {'swe2d_k_flow.hip': _NO_MLICM, 'swe2d_k_flow_wd.hip': _NO_MLICM, 'swe2d_k_quad.hip': _NO_MLICM}
+UNIT_FLAGS = {'swe2d_api_fuse.hip': _NO_MLICM, 'swe2d_k_flow.hip': _NO_MLICM, 'swe2d_k_flow_wd.hip': _NO_MLICM, 'swe2d_k_quad.hip': _NO_MLICM}
 # every file a translation unit can include (the fallback when an object has no dependency file yet)
 ALL_DEPS = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(_HERE, '..', 'include', 'swe2d.h')]
 

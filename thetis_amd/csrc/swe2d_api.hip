@@ -234,6 +234,19 @@ extern "C" {
 
 int swe2d_abi_version(void) { return SWE2D_ABI_VERSION; }
 
+static bool advance_takes_flow(Handle *h);
+int swe2d_fused_pair_info(swe2d_handle *hh, int32_t out[4])
+{
+    Handle *h = H(hh);
+    if (!h || !out) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    out[0] = out[1] = out[2] = 0; out[3] = h->n_cells;
+    if (!fuse12_covers(h) || advance_takes_flow(h)) return SWE2D_OK;       // (small meshes: the dataflow kernel comes first)
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc = fuse12_build(h)) return rc;
+    if (h->fuse_tile) { out[0] = 1; out[1] = h->fuse_n_tiles; out[2] = (int32_t)h->fuse_ring_cells; }
+    return SWE2D_OK;
+}
+
 int swe2d_connectivity_info(swe2d_handle *hh, int32_t out[2])
 {
     Handle *h = H(hh);
@@ -495,7 +508,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->diag_acc, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->snapshot, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->idxc, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->snapshot, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->idxc, h->fuse_tile, h->fuse_inner, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
     for (void *m : h->p2p.opened) (void)hipIpcCloseMemHandle(m);
@@ -830,6 +843,23 @@ int swe2d_solve_stage(swe2d_handle *hh, int i_stage)
     return swe2d_solve_stage_cells(hh, i_stage, 0, h->n_owned);
 }
 
+// does swe2d_advance run this handle's steps in the dataflow kernel?
+static bool advance_takes_flow(Handle *h)
+{
+    const char *env_fl = std::getenv("THETIS_AMD_FLOW");
+    const bool want = env_fl ? std::atoi(env_fl) != 0 : true;
+    // ... and with several blocks per wave (swe2d_mflow.h) where the mesh is larger than that but a visit is still latency, not
+    // bandwidth: up to THETIS_AMD_MFLOW_ADVANCE_K blocks per wave (default 4: ~520 k cells)
+    bool covered = want && flow_kernel_covers(h);
+    if (covered && ((h->flow_blocks + 7)/8)*8 > flow_capacity(h)) {
+        const char *ek = std::getenv("THETIS_AMD_MFLOW_ADVANCE_K");
+        const int kmax = ek ? std::atoi(ek) : 4;
+        const int K = mflow_blocks_per_wave(h);
+        covered = K > 0 && K <= kmax;
+    }
+    return covered;
+}
+
 int swe2d_advance(swe2d_handle *hh, int n_steps)
 {
     Handle *h = H(hh);
@@ -843,18 +873,7 @@ int swe2d_advance(swe2d_handle *hh, int n_steps)
     // 15 k cells 16.5 -> 15.3, 62 k 20.1 -> 15.1, 125 k 24.3 -> 18.3 (the one-launch step kernel of round 2, which this replaces:
     // 14.1 / 16.8 / 24.9).  THETIS_AMD_FLOW=0 selects the stage launches (the same bits either way).
     {
-        const char *env_fl = std::getenv("THETIS_AMD_FLOW");
-        const bool want = env_fl ? std::atoi(env_fl) != 0 : true;
-        // ... and with several blocks per wave (swe2d_mflow.h) where the mesh is larger than that but a visit is still latency, not
-        // bandwidth: up to THETIS_AMD_MFLOW_ADVANCE_K blocks per wave (default 4: ~520 k cells)
-        bool covered = want && n_steps > 0 && flow_kernel_covers(h);
-        if (covered && ((h->flow_blocks + 7)/8)*8 > flow_capacity(h)) {
-            const char *ek = std::getenv("THETIS_AMD_MFLOW_ADVANCE_K");
-            const int kmax = ek ? std::atoi(ek) : 4;
-            const int K = mflow_blocks_per_wave(h);
-            covered = K > 0 && K <= kmax;
-        }
-        if (covered) {
+        if (n_steps > 0 && advance_takes_flow(h)) {
             int32_t ends[SWE_FLOW_MAX_STAGES];
             for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) ends[s] = h->n_owned;
             for (int done = 0; done < n_steps;) {
@@ -865,6 +884,19 @@ int swe2d_advance(swe2d_handle *hh, int n_steps)
             }
             return SWE2D_OK;
         }
+    }
+    if (n_steps > 0 && fuse12_covers(h)) {
+        if (int rc = fuse12_build(h)) return rc;
+    }
+    if (n_steps > 0 && fuse12_covers(h) && h->fuse_tile) {
+        // stages 1 and 2 in one launch by overlapped tiles (swe2d_fuse.h), stage 3 as a stage launch: the same bits
+        for (int it = 0; it < n_steps; it++) {
+            int rc = launch_fuse12(h);
+            if (rc) return rc;
+            rc = stage_on_range(h, 2, 0, h->n_owned);
+            if (rc) return rc;
+        }
+        return SWE2D_OK;
     }
     for (int it = 0; it < n_steps; it++)
         for (int s = 0; s < 3; s++) {
@@ -926,16 +958,20 @@ int swe2d_advance_timed(swe2d_handle *hh, int n_steps, int per_launch, float *ms
         if (ms_kernel_avg) *ms_kernel_avg = *ms_total/(3.0f*n_steps);
         return SWE2D_OK;
     }
-    // events around every stage launch, on the launch stream
-    const int nl = 3*n_steps;
+    // events around every launch of a step, on the launch stream: three stage launches, or the fused stage pair + stage 3
+    // (the mean is per element-update - a third of a step - either way)
+    if (fuse12_covers(h)) { if (int rc = fuse12_build(h)) return rc; }
+    const bool fused = fuse12_covers(h) && h->fuse_tile;
+    const int lps = fused ? 2 : 3;
+    const int nl = lps*n_steps;
     std::vector<hipEvent_t> ev(2*(size_t)nl);
     for (auto &e : ev) HIP_TRY(h, hipEventCreate(&e));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     int l = 0;
     for (int it = 0; it < n_steps; it++)
-        for (int s = 0; s < 3; s++, l++) {
+        for (int s = 0; s < lps; s++, l++) {
             HIP_TRY(h, hipEventRecord(ev[2*l], h->stream));
-            int rc = stage_on_range(h, s, 0, h->n_owned);
+            int rc = fused ? (s == 0 ? launch_fuse12(h) : stage_on_range(h, 2, 0, h->n_owned)) : stage_on_range(h, s, 0, h->n_owned);
             if (rc) return rc;
             HIP_TRY(h, hipEventRecord(ev[2*l + 1], h->stream));
         }
@@ -949,7 +985,7 @@ int swe2d_advance_timed(swe2d_handle *hh, int n_steps, int per_launch, float *ms
         sum += ms;
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
-    if (ms_kernel_avg) *ms_kernel_avg = (float)(sum/nl);
+    if (ms_kernel_avg) *ms_kernel_avg = (float)(sum/(3.0*n_steps));
     return SWE2D_OK;
 }
 

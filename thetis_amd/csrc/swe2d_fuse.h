@@ -1,0 +1,176 @@
+// swe2d_fuse.h - stages 1 and 2 of an SSPRK33 step in ONE launch by overlapped tiles (round 5, opt-in: THETIS_AMD_FUSE12=1).
+//
+// A stage launch streams the state: per triangle and step 72 B read + 72 B written in stage 1, 72 + 72 B read + 72 B written in
+// stage 2.  U(1) is read by stage 2 and by nothing else (rungekutta.py:ERKGenericShuOsher, stage 3 takes
+// U(2) and U(0)), so a workgroup that owns a TILE of the mesh can keep it on chip: 256 lanes = up to 192 interior cells (lanes
+// 0 .. n_inner-1: three waves) + the cells that share a facet with them (the ring, at most 64: the fourth wave).  Stage 1 is
+// evaluated for every cell of the tile - the ring's redundantly, its outer neighbours' traces gathered from the state planes -,
+// the results go to LDS, and stage 2 is evaluated for the interior cells with every neighbour trace from LDS.  Per interior
+// cell the launch reads U(0) once (x 1.33 for the ring) and writes U(2): ~230 B where the two stage launches move ~420.
+// The arithmetic is the dataflow kernel's (swe_flow_rhs_cell / swe_flow_rhs_facets / swe_flow_finish = swe_stage_kernel's
+// operations in its order): bit for bit the stage launches (tests/test_gpu_parity.py::test_fused_stage_pair_...).
+// Covers what those functions cover without options: triangles, no source terms, no wetting-drying, no viscosity, whole mesh.
+#pragma once
+#include "swe2d_kernels.h"
+#include "swe2d_flow.h"
+
+#define SWE_FUSE_WG 256
+#ifndef SWE_FUSE_MIN_WG
+#define SWE_FUSE_MIN_WG 3                                 // workgroups per CU the compiler has to make room for (3: 168 VGPRs)
+#endif
+#define SWE_FUSE_INNER 192
+#define SWE_FUSE_RING (SWE_FUSE_WG - SWE_FUSE_INNER)
+#define SWE_FUSE_XG (9*SWE_FUSE_WG)                    // staging area of the traces from outside the tile: [slot][6]
+#define SWE_FUSE_MAX_OUT (2*SWE_FUSE_RING)             // a ring cell has a facet towards the interior: at most two towards the outside
+#define SWE_FUSE_LDS (SWE_FUSE_XG + 6*SWE_FUSE_MAX_OUT)
+
+struct SweFuseArgs {
+    SweStageArgs st;          // uin = U(0) (state buffer A); geometry, connectivity, boundary tables; dt, g, sigma_lf
+    const int2 *tile;         // [n_tiles][256]: {cell or -1, per facet 9 bits: [7:0] lane of the neighbour in the tile (a boundary
+                              //  facet: the lane itself) or, with bit 8 set, the staging slot of a neighbour outside the tile}
+    const int *n_inner;       // [n_tiles]: lanes 0 .. n_inner-1 hold the interior cells
+    int n_tiles;
+    double beta1;             // stage 1: U(1) = U(0) + beta1 dt M^-1 R(U(0))
+    double a0_2, a1_2, beta2; // stage 2: U(2) = a0 U(0) + a1 U(1) + beta2 dt M^-1 R(U(1))
+    double *out;              // 9 planes: U(2) (state buffer C)
+};
+
+template <bool NONLIN, bool LF>
+__global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kernel(const SweFuseArgs q)
+{
+#pragma clang fp contract(off)
+    __shared__ double lds[SWE_FUSE_LDS];
+    __shared__ double lw[9][SWE_FUSE_INNER];               // a0 U(0) + a1 U(1) of the interior cells: 18 registers stage 2 cannot spare
+    const SweStageArgs &p = q.st;
+    const int tile = swe_logical_block(blockIdx.x, gridDim.x);
+    if (tile >= q.n_tiles) return;                         // padding of the grid to a multiple of 8
+    const int lane = (int)threadIdx.x;
+    const int2 tl = q.tile[(size_t)tile*SWE_FUSE_WG + lane];
+    const bool real = tl.x >= 0;
+    const int k = real ? tl.x : 0;
+    const int n_inner = q.n_inner[tile];
+    const size_t S = p.stride;
+    const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u;
+
+    int bmarkers = 0, bkind1 = 0;
+    unsigned tr[3][3];                     // LDS addresses of the six traces of every facet (swe_flow_rhs_facets)
+    double h[3], nx[3], ny[3], u[3], v[3], e[3];
+    if (real) {
+        int nb[3], vid[3];
+        swe_conn_load(p.idxc, p.idx4, p.idx2, k, nb, vid);
+        bmarkers = (nb[0] < 0 ? -nb[0] : 0) | (nb[1] < 0 ? (-nb[1]) << 8 : 0) | (nb[2] < 0 ? (-nb[2]) << 16 : 0);
+        if (bmarkers != 0) {
+            const int m1 = (bmarkers & 0xff) ? (bmarkers & 0xff) : ((bmarkers & 0xff00) ? ((bmarkers >> 8) & 0xff) : (bmarkers >> 16));
+            bkind1 = m1 < SWE_MAX_MARKERS ? p.bc.kind[m1] : 0;
+        }
+        const swe_rsrc_t gu = swe_rsrc(p.uin), gv = swe_rsrc(p.uin + 3*S), ge = swe_rsrc(p.uin + 6*S);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            u[i] = swe_ld(gu, k8, i*S8);
+            v[i] = swe_ld(gv, k8, i*S8);
+            e[i] = swe_ld(ge, k8, i*S8);
+        }
+        double r0[3][6];
+        bool outside[3];
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            const int nbf = nb[f];
+            const unsigned w = ((unsigned)tl.y >> (9*f)) & 0x1ffu;
+            outside[f] = (w & 0x100u) != 0u;
+            const unsigned at = w & 0xffu;                                    // lane in the tile, or staging slot
+            // the neighbour traverses the shared facet backwards: its node f2 sits on my node f + 1, its node (f2 + 1) % 3 on my node f
+            const int f2 = nbf >= 0 ? (nbf & 3) : f, f2a = f2 == 2 ? 0 : f2 + 1;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const unsigned ab = outside[f] ? (unsigned)(SWE_FUSE_XG + 6*at + c) : (unsigned)((3*c + f2)*SWE_FUSE_WG + at);
+                const unsigned aa = outside[f] ? (unsigned)(SWE_FUSE_XG + 6*at + 3 + c) : (unsigned)((3*c + f2a)*SWE_FUSE_WG + at);
+                tr[f][c] = ab | (aa << 16);
+            }
+            // (issued for every facet: a facet inside the tile reads this cell itself, value unused - no branch around the loads)
+            const int code = outside[f] ? nbf : ((k << 2) | f);
+            const unsigned kn8 = (unsigned)(code >> 2)*8u;
+            const int g2 = code & 3;
+            const unsigned ob = kn8 + (g2 == 0 ? 0u : (g2 == 1 ? S8 : 2u*S8));         // node g2
+            const unsigned oa = kn8 + (g2 == 0 ? S8 : (g2 == 1 ? 2u*S8 : 0u));         // node (g2 + 1) % 3
+            r0[f][0] = swe_ld(gu, ob, 0); r0[f][1] = swe_ld(gv, ob, 0); r0[f][2] = swe_ld(ge, ob, 0);
+            r0[f][3] = swe_ld(gu, oa, 0); r0[f][4] = swe_ld(gv, oa, 0); r0[f][5] = swe_ld(ge, oa, 0);
+        }
+        double px[3], py[3];
+        const swe_rsrc_t rvx = swe_rsrc(p.vx), rvy = swe_rsrc(p.vy), rvh = swe_rsrc(p.vh);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const unsigned v8 = (unsigned)vid[i]*8u;
+            px[i] = swe_ld(rvx, v8, 0);
+            py[i] = swe_ld(rvy, v8, 0);
+            h[i] = swe_ld(rvh, v8, 0);
+        }
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            const int b = (f + 1) % 3;
+            nx[f] = py[b] - py[f];
+            ny[f] = px[f] - px[b];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) { lds[i*SWE_FUSE_WG + lane] = u[i]; lds[(3 + i)*SWE_FUSE_WG + lane] = v[i]; lds[(6 + i)*SWE_FUSE_WG + lane] = e[i]; }
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            if (outside[f]) {
+                const unsigned at = ((unsigned)tl.y >> (9*f)) & 0xffu;
+#pragma unroll
+                for (int j = 0; j < 6; j++) lds[SWE_FUSE_XG + 6*at + j] = r0[f][j];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- stage 1 on every cell of the tile: U(1) = U(0) + beta1 dt M^-1 R(U(0))
+    double o1u[3], o1v[3], o1e[3];
+    double twoA = 0.0;
+    if (real) {
+        twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
+        double bu[3], bv[3], be[3], wu[3], wv[3], we[3];
+        swe_flow_rhs_cell<NONLIN>(p, u, v, e, h, nx, ny, bu, bv, be);
+        swe_flow_rhs_facets<NONLIN, LF, false, 3>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { wu[i] = 1.0*u[i]; wv[i] = 1.0*v[i]; we[i] = 1.0*e[i]; }
+        swe_flow_finish<NONLIN, LF, true>(p, k, q.beta1, u, v, e, h, nx, ny, twoA, bmarkers, bkind1, bu, bv, be, wu, wv, we, o1u, o1v, o1e);
+    }
+    __syncthreads();                                       // every lane has read its traces of U(0)
+    if (real) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) { lds[i*SWE_FUSE_WG + lane] = o1u[i]; lds[(3 + i)*SWE_FUSE_WG + lane] = o1v[i]; lds[(6 + i)*SWE_FUSE_WG + lane] = o1e[i]; }
+    }
+    if (lane < n_inner) {                                  // the part of stage 2's combine that does not depend on its tendency; U(0) is dead after this
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            lw[i][lane] = fma(q.a0_2, u[i], q.a1_2*o1u[i]);
+            lw[3 + i][lane] = fma(q.a0_2, v[i], q.a1_2*o1v[i]);
+            lw[6 + i][lane] = fma(q.a0_2, e[i], q.a1_2*o1e[i]);
+        }
+    }
+    __syncthreads();
+    // ---- stage 2 on the interior cells (every neighbour is a cell of the tile): U(2) = a0 U(0) + a1 U(1) + beta2 dt M^-1 R(U(1))
+    if (lane < n_inner) {
+        // opaque to the optimiser (as in swe_flow_kernel): what stage 1 derived from the geometry - facet lengths, reciprocals,
+        // gradients - would otherwise stay live across the barrier for stage 2, past the register budget of three waves per SIMD
+#pragma unroll
+        for (int i = 0; i < 3; i++) asm volatile("" : "+v"(nx[i]), "+v"(ny[i]), "+v"(h[i]));
+#pragma unroll
+        for (int f = 0; f < 3; f++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) asm volatile("" : "+v"(tr[f][c]));
+        asm volatile("" : "+v"(bmarkers), "+v"(twoA));
+        double bu[3], bv[3], be[3], wu[3], wv[3], we[3], ou[3], ov[3], oe[3];
+        swe_flow_rhs_cell<NONLIN>(p, o1u, o1v, o1e, h, nx, ny, bu, bv, be);
+        swe_flow_rhs_facets<NONLIN, LF, false, 3>(p, k, o1u, o1v, o1e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { wu[i] = lw[i][lane]; wv[i] = lw[3 + i][lane]; we[i] = lw[6 + i][lane]; }
+        swe_flow_finish<NONLIN, LF, true>(p, k, q.beta2, o1u, o1v, o1e, h, nx, ny, twoA, bmarkers, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
+        const swe_rsrc_t gou = swe_rsrc(q.out), gov = swe_rsrc(q.out + 3*S), goe = swe_rsrc(q.out + 6*S);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            swe_st(gou, k8, i*S8, ou[i]);
+            swe_st(gov, k8, i*S8, ov[i]);
+            swe_st(goe, k8, i*S8, oe[i]);
+        }
+    }
+}

@@ -116,6 +116,12 @@ struct Handle {
     int4 *idx4 = nullptr;                               // packed triangle connectivity (stage kernel), see SweStageArgs
     int2 *idx2 = nullptr;
     int4 *idxc = nullptr;                               // ... in 16 B (swe_conn_pack), what the stage kernels read; THETIS_AMD_COMPACT_IDX=0: not used
+    // stages 1 + 2 of a step in one launch by overlapped tiles (swe2d_fuse.h; THETIS_AMD_FUSE12=1): tile tables, built at first use
+    int2 *fuse_tile = nullptr;
+    int *fuse_inner = nullptr;
+    int fuse_n_tiles = 0;
+    int fuse_state = 0;                                 // -1: the numbering gives poor tiles, -2: first use inside a stream capture: stage launches
+    long long fuse_ring_cells = 0;
     int idxc_always = 0;                                // THETIS_AMD_COMPACT_IDX=2: in every launch (default: where it pays, swe_conn_pays)
     int n_conn_escapes = 0;                             // cells whose record is an escape to the wide ones
     std::vector<int> h_nbr;                             // host copy of the packed neighbour codes [3][S] (triangles; flow_build)
@@ -277,6 +283,9 @@ inline bool conn_pays(const Handle *h, int n_cells_of_launch, bool arithmetic_bo
 {
     return h->idxc && (h->idxc_always || (n_cells_of_launch >= 250000 && !arithmetic_bound));
 }
+bool fuse12_covers(const Handle *h);
+int fuse12_build(Handle *h);
+int launch_fuse12(Handle *h);
 void fill_stage_args(Handle *h, SweStageArgs &a, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1);
 int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1);
 int stage_on_range(Handle *h, int i_stage, int c0, int c1);

@@ -5,6 +5,7 @@
 #include "swe2d_api_flow.hip"
 #include "swe2d_api_tracer.hip"
 #include "swe2d_api_p2p.hip"
+#include "swe2d_api_fuse.hip"
 #include "swe2d_k_tri.hip"
 #include "swe2d_k_wd.hip"
 #include "swe2d_k_quad.hip"

@@ -450,6 +450,12 @@ class Swe2dDevice(object):
         self._ck(self.lib.swe2d_connectivity_info(self.h, out))
         return int(out[0]), int(out[1])
 
+    def fused_pair_info(self):
+        """(swe2d_advance takes the fused stage pair, tiles, ring cells, cells): swe2d_fused_pair_info"""
+        out = (ctypes.c_int32*4)()
+        self._ck(self.lib.swe2d_fused_pair_info(self.h, out))
+        return bool(out[0]), int(out[1]), int(out[2]), int(out[3])
+
     def flow_timeouts(self):
         n = ctypes.c_int32()
         self._ck(self.lib.swe2d_flow_status(self.h, ctypes.byref(n)))
