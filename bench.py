@@ -36,7 +36,7 @@ PREWARM_S = 0.5                          # seconds of untimed stepping before th
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_ELEMENT_STEP = 684.0          # 180 + 252 + 252 algorithmic bytes per triangle per step
 BYTES_PER_ELEMENT_UPDATE = BYTES_PER_ELEMENT_STEP/3.0
-TRAFFIC_JSON = 'r05zz_traffic.json'         # committed PMC passes of the stage kernel on this workload (profiles/README.md)
+TRAFFIC_JSON = 'r05zy_traffic.json'         # committed PMC passes of the stage kernel on this workload (profiles/README.md)
 BEYOND_CACHE_NX, BEYOND_CACHE_NY = 2000, 1000   # 4M triangles: 3 x 288 MB of state, beyond the 256 MB Infinity Cache
 
 
@@ -210,7 +210,11 @@ def run_single(args):
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved/HBM_PEAK_GBS, 'frac_samples': frac_samples, 'frac_median': float(np.median(frac_samples)),
                      'frac_min': float(min(frac_samples)), 'frac_max': float(max(frac_samples)),
-                     'traffic': traffic, 'traffic_unit': 'bytes per launch',
+                     'traffic': traffic, 'traffic_unit': 'bytes per launch (with the fused stage pair: per element-update = a third of a step)',
+                     # what the memory system actually delivered: `achieved` counts SURVEY.md 8d's bytes of three stage launches (228 B per
+                     # element-update); the fused stage pair keeps U(1) on chip and moves fewer
+                     'traffic_rate_GBs': (traffic/(ms_kernel*1e-3)/1e9) if traffic else None,
+                     'traffic_rate_frac': (traffic/(ms_kernel*1e-3)/1e9/HBM_PEAK_GBS) if traffic else None,
                      'traffic_source': traffic_src,
                      'kernel': ('swe_fuse12_kernel (stages 1 + 2 in one launch) + swe_stage_kernel (stage 3): avg_launch_ms is per '
                                 'element-update = a third of a step') if fused[0] else 'swe_stage_kernel',
