@@ -28,6 +28,7 @@ bool fuse12_covers(const Handle *h)
     const char *e = std::getenv("THETIS_AMD_FUSE12");
     const int mode = e ? std::atoi(e) : -1;                // -1: by size and tile quality
     if (mode == 0 || h->fuse_state < 0) return false;
+    { const char *b = std::getenv("THETIS_AMD_BND_INLINE"); if (b && std::atoi(b) == 0) return false; }      // the epilogue variant was asked for
     return h->npc == 3 && !h->wd && !h->visc && !has_sources(h) && h->n_owned == h->n_cells && !h->h_nbr.empty()
            && h->n_cells >= (mode > 0 ? 4*SWE_FUSE_INNER : 250000);
 #endif

@@ -282,7 +282,9 @@ __device__ __forceinline__ void swe_flow_rhs_cell(const SweStageArgs &p, const d
 // spare: 28 B/lane of scratch with the exchange inside, round 4-5): only component 0's pair is kept, the others follow from it -
 // the components of a trace are 1 apart in the staging area (a rim facet: address >= SWE_FLOW_XG) and 3*64 apart in the block's own
 // planes - at the price of eight integer instructions per facet and stage.
-template <bool NONLIN, bool LF, bool SRC, int NTR, bool WD = false>
+// (XG, PLANE: where the staging area starts and how long a plane of the block's own values is - the fused stage pair of swe2d_fuse.h
+//  has 256-lane planes)
+template <bool NONLIN, bool LF, bool SRC, int NTR, bool WD = false, int XG = SWE_FLOW_XG, int PLANE = SWE_BLOCK>
 __device__ __forceinline__ void swe_flow_rhs_facets(const SweStageArgs &p, int k, const double u[3], const double v[3], const double e[3],
                                                     const double h[3], const double *lds, const unsigned tr[3][NTR], int bmarkers,
                                                     const double nx[3], const double ny[3], double twoA, double bu[3], double bv[3],
@@ -296,7 +298,7 @@ __device__ __forceinline__ void swe_flow_rhs_facets(const SweStageArgs &p, int k
         const bool bnd = ((bmarkers >> (8*f)) & 0xff) != 0;
         // tr[f][c] = address of component c (u, v, e) at the neighbour's node on my node f + 1 | the same on my node f << 16
         const unsigned ab0 = tr[f][0] & 0xffffu, aa0 = tr[f][0] >> 16;
-        const unsigned step = ab0 >= (unsigned)SWE_FLOW_XG ? 1u : (unsigned)(3*SWE_BLOCK);
+        const unsigned step = ab0 >= (unsigned)XG ? 1u : (unsigned)(3*PLANE);
         const unsigned ab1 = NTR == 3 ? tr[f][NTR - 2] & 0xffffu : ab0 + step, aa1 = NTR == 3 ? tr[f][NTR - 2] >> 16 : aa0 + step;
         const unsigned ab2 = NTR == 3 ? tr[f][NTR - 1] & 0xffffu : ab0 + 2u*step, aa2 = NTR == 3 ? tr[f][NTR - 1] >> 16 : aa0 + 2u*step;
         const double unb = lds[SWE_LDSI(ab0, SWE_FLOW_LDS_DOUBLES)], una = lds[SWE_LDSI(aa0, SWE_FLOW_LDS_DOUBLES)];

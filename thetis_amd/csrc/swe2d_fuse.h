@@ -53,7 +53,9 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
     const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u;
 
     int bmarkers = 0, bkind1 = 0;
-    unsigned tr[3][3];                     // LDS addresses of the six traces of every facet (swe_flow_rhs_facets)
+    // LDS addresses of the traces of every facet (swe_flow_rhs_facets): component 0's pair, the others follow from it - 3*256 apart in
+    // the planes, 1 apart in the staging area (six registers less than one pair per component: what three workgroups per CU need)
+    unsigned tr[3][1];
     double h[3], nx[3], ny[3], u[3], v[3], e[3];
     if (real) {
         int nb[3], vid[3];
@@ -80,11 +82,10 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
             const unsigned at = w & 0xffu;                                    // lane in the tile, or staging slot
             // the neighbour traverses the shared facet backwards: its node f2 sits on my node f + 1, its node (f2 + 1) % 3 on my node f
             const int f2 = nbf >= 0 ? (nbf & 3) : f, f2a = f2 == 2 ? 0 : f2 + 1;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const unsigned ab = outside[f] ? (unsigned)(SWE_FUSE_XG + 6*at + c) : (unsigned)((3*c + f2)*SWE_FUSE_WG + at);
-                const unsigned aa = outside[f] ? (unsigned)(SWE_FUSE_XG + 6*at + 3 + c) : (unsigned)((3*c + f2a)*SWE_FUSE_WG + at);
-                tr[f][c] = ab | (aa << 16);
+            {
+                const unsigned ab = outside[f] ? (unsigned)(SWE_FUSE_XG + 6*at) : (unsigned)(f2*SWE_FUSE_WG + at);
+                const unsigned aa = outside[f] ? (unsigned)(SWE_FUSE_XG + 6*at + 3) : (unsigned)(f2a*SWE_FUSE_WG + at);
+                tr[f][0] = ab | (aa << 16);
             }
             // (issued for every facet: a facet inside the tile reads this cell itself, value unused - no branch around the loads)
             const int code = outside[f] ? nbf : ((k << 2) | f);
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
         twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
         double bu[3], bv[3], be[3], wu[3], wv[3], we[3];
         swe_flow_rhs_cell<NONLIN>(p, u, v, e, h, nx, ny, bu, bv, be);
-        swe_flow_rhs_facets<NONLIN, LF, false, 3>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+        swe_flow_rhs_facets<NONLIN, LF, false, 1, false, SWE_FUSE_XG, SWE_FUSE_WG>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
 #pragma unroll
         for (int i = 0; i < 3; i++) { wu[i] = 1.0*u[i]; wv[i] = 1.0*v[i]; we[i] = 1.0*e[i]; }
         swe_flow_finish<NONLIN, LF, true>(p, k, q.beta1, u, v, e, h, nx, ny, twoA, bmarkers, bkind1, bu, bv, be, wu, wv, we, o1u, o1v, o1e);
@@ -155,13 +156,11 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
 #pragma unroll
         for (int i = 0; i < 3; i++) asm volatile("" : "+v"(nx[i]), "+v"(ny[i]), "+v"(h[i]));
 #pragma unroll
-        for (int f = 0; f < 3; f++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) asm volatile("" : "+v"(tr[f][c]));
+        for (int f = 0; f < 3; f++) asm volatile("" : "+v"(tr[f][0]));
         asm volatile("" : "+v"(bmarkers), "+v"(twoA));
         double bu[3], bv[3], be[3], wu[3], wv[3], we[3], ou[3], ov[3], oe[3];
         swe_flow_rhs_cell<NONLIN>(p, o1u, o1v, o1e, h, nx, ny, bu, bv, be);
-        swe_flow_rhs_facets<NONLIN, LF, false, 3>(p, k, o1u, o1v, o1e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+        swe_flow_rhs_facets<NONLIN, LF, false, 1, false, SWE_FUSE_XG, SWE_FUSE_WG>(p, k, o1u, o1v, o1e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
 #pragma unroll
         for (int i = 0; i < 3; i++) { wu[i] = lw[i][lane]; wv[i] = lw[3 + i][lane]; we[i] = lw[6 + i][lane]; }
         swe_flow_finish<NONLIN, LF, true>(p, k, q.beta2, o1u, o1v, o1e, h, nx, ny, twoA, bmarkers, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
