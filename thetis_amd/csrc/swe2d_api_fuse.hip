@@ -17,7 +17,8 @@ fuse_kernel_t pick_fuse_kernel(bool nl, bool lf)
 // 250 k cells, where a step streams from memory (same box, us per step, stage launches -> fused pair + stage 3, device numbering in
 // 16 x 6-quad tiles: 125 k cells 23.9 -> 24.1, 250 k 38.8 -> 37.0, 500 k 64.9 -> 61.1, 1 M 121.0 -> 107.3, 2 M 264 -> 235, 4 M 525 -> 477;
 // profiles/r05zl_fused_stage_pair.txt), and where the numbering gives tiles worth it (mean interior >= 176 of 192 cells: the
-// structured tile order; a Hilbert order of an unstructured mesh does not - its launches stay what they were).
+// structured tile order, and the Hilbert order of an unstructured mesh - 1 M Delaunay triangles 192.0 + 49.9 cells per tile, 120.8 ->
+// 113.3 us per step; an order that does not keeps its stage launches).
 // THETIS_AMD_FUSE12=0: never; =1: on every mesh of at least 768 cells whatever its tiles.  (Not in the range-checked build: the
 // LDS index checks of the shared functions know the flow kernel's array only.)
 bool fuse12_covers(const Handle *h)
