@@ -97,9 +97,9 @@ int fuse12_build(Handle *h)
                 else if (state[code >> 2] != 0) field = (unsigned)lane_of[code >> 2];
                 else {
                     if (l < ni || n_out >= SWE_FUSE_MAX_OUT) return fail(h, SWE2D_ERR_UNSUPPORTED, "fused stage pair: ring bookkeeping");
-                    field = 0x100u | (unsigned)n_out++;
+                    field = 0x200u | (unsigned)n_out++;
                 }
-                w |= field << (9*f);
+                w |= field << (SWE_FUSE_FBITS*f);
             }
             tl[base + l] = int2{c, (int)w};
         }

@@ -14,11 +14,16 @@
 #include "swe2d_kernels.h"
 #include "swe2d_flow.h"
 
+#ifndef SWE_FUSE_WG
 #define SWE_FUSE_WG 256
+#endif
 #ifndef SWE_FUSE_MIN_WG
 #define SWE_FUSE_MIN_WG 3                                 // workgroups per CU the compiler has to make room for (3: 168 VGPRs)
 #endif
+#ifndef SWE_FUSE_INNER
 #define SWE_FUSE_INNER 192
+#endif
+#define SWE_FUSE_FBITS 10                                // bits per facet in the tile table's packed word: 9 of lane / slot + the flag
 #define SWE_FUSE_RING (SWE_FUSE_WG - SWE_FUSE_INNER)
 #define SWE_FUSE_XG (9*SWE_FUSE_WG)                    // staging area of the traces from outside the tile: [slot][6]
 #define SWE_FUSE_MAX_OUT (2*SWE_FUSE_RING)             // a ring cell has a facet towards the interior: at most two towards the outside
@@ -26,8 +31,8 @@
 
 struct SweFuseArgs {
     SweStageArgs st;          // uin = U(0) (state buffer A); geometry, connectivity, boundary tables; dt, g, sigma_lf
-    const int2 *tile;         // [n_tiles][256]: {cell or -1, per facet 9 bits: [7:0] lane of the neighbour in the tile (a boundary
-                              //  facet: the lane itself) or, with bit 8 set, the staging slot of a neighbour outside the tile}
+    const int2 *tile;         // [n_tiles][256]: {cell or -1, per facet 10 bits: [8:0] lane of the neighbour in the tile (a boundary
+                              //  facet: the lane itself) or, with bit 9 set, the staging slot of a neighbour outside the tile}
     const int *n_inner;       // [n_tiles]: lanes 0 .. n_inner-1 hold the interior cells
     int n_tiles;
     double beta1;             // stage 1: U(1) = U(0) + beta1 dt M^-1 R(U(0))
@@ -77,9 +82,9 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
 #pragma unroll
         for (int f = 0; f < 3; f++) {
             const int nbf = nb[f];
-            const unsigned w = ((unsigned)tl.y >> (9*f)) & 0x1ffu;
-            outside[f] = (w & 0x100u) != 0u;
-            const unsigned at = w & 0xffu;                                    // lane in the tile, or staging slot
+            const unsigned w = ((unsigned)tl.y >> (SWE_FUSE_FBITS*f)) & 0x3ffu;
+            outside[f] = (w & 0x200u) != 0u;
+            const unsigned at = w & 0x1ffu;                                   // lane in the tile, or staging slot
             // the neighbour traverses the shared facet backwards: its node f2 sits on my node f + 1, its node (f2 + 1) % 3 on my node f
             const int f2 = nbf >= 0 ? (nbf & 3) : f, f2a = f2 == 2 ? 0 : f2 + 1;
             {
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
 #pragma unroll
         for (int f = 0; f < 3; f++) {
             if (outside[f]) {
-                const unsigned at = ((unsigned)tl.y >> (9*f)) & 0xffu;
+                const unsigned at = ((unsigned)tl.y >> (SWE_FUSE_FBITS*f)) & 0x1ffu;
 #pragma unroll
                 for (int j = 0; j < 6; j++) lds[SWE_FUSE_XG + 6*at + j] = r0[f][j];
             }
