@@ -584,6 +584,30 @@ def test_fused_stage_pair_gives_the_bits_of_the_stage_launches(hip_lib, monkeypa
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
+def test_fused_stage_pair_is_what_a_large_plain_mesh_takes(hip_lib, monkeypatch):
+    """swe2d_fused_pair_info: by itself from 250 k triangles on a whole mesh in the device numbering, not below, not with source
+    terms or wetting-drying, not with THETIS_AMD_FUSE12=0 - so that a silent return to three stage launches shows up here."""
+    from thetis_amd import _lib
+    from thetis_amd.device import Swe2dDevice
+    monkeypatch.delenv('THETIS_AMD_FUSE12', raising=False)
+    mesh, bath, uv, eta = channel_case(nx=450, ny=300, lx=100e3, ly=50e3, seed=5)                     # 270 k cells
+    dev = Swe2dDevice(mesh, bath, 0.5)
+    on, tiles, ring, cells = dev.fused_pair_info()
+    assert on and cells == mesh.num_cells and cells/192.0 <= tiles < cells/176.0 and 0.15*cells < ring < 0.34*cells, (on, tiles, ring, cells)
+    dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+    assert not dev.fused_pair_info()[0]
+    dev.set_scalar(_lib.SCALAR_MANNING_DRAG, None)
+    assert dev.fused_pair_info()[0]
+    monkeypatch.setenv('THETIS_AMD_FUSE12', '0')
+    assert not dev.fused_pair_info()[0]
+    dev.close()
+    monkeypatch.delenv('THETIS_AMD_FUSE12', raising=False)
+    small, bath_s, _, _ = channel_case(nx=300, ny=200, lx=100e3, ly=50e3, seed=5)                     # 120 k cells: the dataflow kernel's
+    dev = Swe2dDevice(small, bath_s, 0.5)
+    assert not dev.fused_pair_info()[0]
+    dev.close()
+
+
 @pytest.mark.parametrize('quad', [False, True])
 def test_alternating_launch_direction_gives_the_same_bits(hip_lib, monkeypatch, quad):
     """Launches whose state does not fit the Infinity Cache walk the cell range alternately forwards and backwards
