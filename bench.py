@@ -36,7 +36,13 @@ PREWARM_S = 0.5                          # seconds of untimed stepping before th
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_ELEMENT_STEP = 684.0          # 180 + 252 + 252 algorithmic bytes per triangle per step
 BYTES_PER_ELEMENT_UPDATE = BYTES_PER_ELEMENT_STEP/3.0
-TRAFFIC_JSON = 'r05zy_traffic.json'         # committed PMC passes of the stage kernel on this workload (profiles/README.md)
+# what the FUSED algorithm must move per triangle and step in the same perfect-cache model: stages 1 + 2 in one
+# launch read U(0) and the static data once and write U(2) - 72 + 36 + 72 = 180 B, U(1) never leaves the chip -, stage 3 its 252 B
+FUSED_BYTES_PER_ELEMENT_STEP = 180.0 + 252.0
+TRAFFIC_JSON = 'r06_traffic.json'           # committed PMC passes of this library's kernels on this workload (profiles/README.md)
+TRAFFIC_4M_JSON = 'r06_traffic_4m.json'     # ... on the 4M-triangle mesh behind roofline.beyond_cache
+FP64_CLOCK_HZ = 2.4e9                       # MI355X_MICROARCH.md: max clock 2400 MHz
+N_SIMD = 1024                               # 256 CUs x 4 SIMDs; a wave64 FP64-rate instruction issues in 4 cycles (16 lanes per clock)
 BEYOND_CACHE_NX, BEYOND_CACHE_NY = 2000, 1000   # 4M triangles: 3 x 288 MB of state, beyond the 256 MB Infinity Cache
 
 
@@ -113,19 +119,22 @@ def cpu_baseline(budget_s=10.0):
     return out, best_state
 
 
-def measured_traffic(n_cells):
-    """HBM bytes per stage-kernel launch from the committed PMC passes (rocprofv3 cannot run inside the timed bench):
-    FETCH_SIZE/WRITE_SIZE collected in separate --pmc runs and corrected with the calibration copy kernel, see
-    profiles/README.md.  Only valid for the workload it was measured on."""
-    path = os.path.join(ROOT, 'profiles', TRAFFIC_JSON)
+def measured_traffic(n_cells, fused, name=None, want_cells=1000000):
+    """HBM bytes per element-update (a third of a step) and VALU wave-instructions per step from the committed PMC passes
+    (rocprofv3 cannot run inside the timed bench): FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU collected in separate --pmc runs, the
+    fetch counter corrected with the calibration copy kernel, see profiles/README.md.  Only valid for the workload AND the launch
+    structure it was measured on: with the stages fused the file must hold the fused kernel, without it must not - else nothing
+    is reported (a static figure next to a run it does not belong to)."""
+    name = name or TRAFFIC_JSON
+    path = os.path.join(ROOT, 'profiles', name)
     try:
         with open(path) as f:
             t = json.load(f)
-        if n_cells == 1000000:
-            return float(t['traffic_bytes_per_launch']), 'profiles/' + TRAFFIC_JSON
+        if n_cells == want_cells and bool(fused) == ('fused_stage_pair_kernel' in t):
+            return float(t['traffic_bytes_per_launch']), t.get('valu_wave_instructions_per_step'), 'profiles/' + name
     except (OSError, KeyError, ValueError):
         pass
-    return None, None
+    return None, None, None
 
 
 def beyond_cache(args):
@@ -145,19 +154,20 @@ def beyond_cache(args):
     ms_events = min(dev.advance_timed(steps, per_launch=False)[0] for _ in range(2))
     ms_kernel = ms_events/(3.0*steps)
     assert np.isfinite(dev.diagnostics()).all()
+    fused = dev.fused_pair_info()[0]
     dev.close()
     achieved = BYTES_PER_ELEMENT_UPDATE*n/(ms_kernel*1e-3)/1e9
-    traffic = None
-    try:                                       # committed PMC passes on this very workload (profiles/README.md)
-        with open(os.path.join(ROOT, 'profiles', 'r03a_traffic_4m.json')) as f:
-            traffic = float(json.load(f)['traffic_bytes_per_launch']) if n == 4000000 else None
-    except (OSError, KeyError, ValueError):
-        pass
+    # committed PMC passes of THIS library's launches on this very workload (profiles/README.md)
+    traffic, valu, src = measured_traffic(n, fused, TRAFFIC_4M_JSON, 4000000)
+    model = (FUSED_BYTES_PER_ELEMENT_STEP if fused else BYTES_PER_ELEMENT_STEP)*n
     return {'frac_beyond_cache': achieved/HBM_PEAK_GBS,
-            'beyond_cache': {'workload': 'RectangleMesh({:d},{:d}) = {:d} triangles, same channel and kernel'.format(
+            'beyond_cache': {'workload': 'RectangleMesh({:d},{:d}) = {:d} triangles, same channel and kernels'.format(
                                  BEYOND_CACHE_NX, BEYOND_CACHE_NY, n),
                              'achieved': achieved, 'avg_launch_ms': ms_kernel, 'steps': steps, 'traffic': traffic,
-                             'traffic_source': 'profiles/r03a_traffic_4m.json' if traffic else None,
+                             'traffic_source': src, 'launches_per_step': 2 if fused else 3,
+                             'frac_fused_model': model/(ms_events/steps*1e-3)/1e9/HBM_PEAK_GBS,
+                             'traffic_rate_frac': (3.0*traffic/(ms_events/steps*1e-3)/1e9/HBM_PEAK_GBS) if traffic else None,
+                             'valu_issue_frac': (valu*4.0/(N_SIMD*FP64_CLOCK_HZ)/(ms_events/steps*1e-3)) if valu else None,
                              'algorithmic_bytes_per_launch': BYTES_PER_ELEMENT_UPDATE*n,
                              'element_updates_per_s': n*3.0*steps/(ms_events*1e-3)}}
 
@@ -197,8 +207,10 @@ def run_single(args):
     assert np.isfinite(d).all()
     value = n*3.0*args.steps/t_wall
     achieved = BYTES_PER_ELEMENT_UPDATE*n/(ms_kernel*1e-3)/1e9
-    traffic, traffic_src = measured_traffic(n)
     fused = dev.fused_pair_info()
+    traffic, valu, traffic_src = measured_traffic(n, fused[0])
+    step_s = ms_events/args.steps*1e-3
+    model_step = (FUSED_BYTES_PER_ELEMENT_STEP if fused[0] else BYTES_PER_ELEMENT_STEP)*n
     out = {
         'metric': 'DG element-updates/sec, 2D SWE DG-P1 SSPRK33',
         'value': value, 'unit': 'element-updates/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
@@ -208,14 +220,25 @@ def run_single(args):
                                'flat h=20, closed walls, dt=0.25', 'n_cells': n, 'parallelism': 'single',
                    'prewarm_s': args.prewarm},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     # `frac` keeps SURVEY.md 8d's definition: the bytes of THREE stage launches (228 B per element-update) over the
+                     # time - a useful-work rate.  With stages fused the launches move fewer bytes than that model, so `frac` contains an
+                     # algorithmic saving and could pass 1 as fusion deepens; the three figures after it say what the hardware did:
                      'frac': achieved/HBM_PEAK_GBS, 'frac_samples': frac_samples, 'frac_median': float(np.median(frac_samples)),
                      'frac_min': float(min(frac_samples)), 'frac_max': float(max(frac_samples)),
+                     'frac_definition': 'SURVEY 8d model bytes of three stage launches (684 B per triangle and step) / step time / 8 TB/s',
+                     # (1) the bytes the launch structure that RAN must move in the same perfect-cache model (fused pair + stage 3: 432 B
+                     #     per triangle and step; three stage launches: 684 = frac) over the time
+                     'frac_fused_model': model_step/step_s/1e9/HBM_PEAK_GBS,
+                     'fused_model_bytes_per_step': model_step,
+                     # (2) what the memory system delivered by the counters (profiles/, same library and workload)
                      'traffic': traffic, 'traffic_unit': 'bytes per launch (with the fused stage pair: per element-update = a third of a step)',
-                     # what the memory system actually delivered: `achieved` counts SURVEY.md 8d's bytes of three stage launches (228 B per
-                     # element-update); the fused stage pair keeps U(1) on chip and moves fewer
                      'traffic_rate_GBs': (traffic/(ms_kernel*1e-3)/1e9) if traffic else None,
                      'traffic_rate_frac': (traffic/(ms_kernel*1e-3)/1e9/HBM_PEAK_GBS) if traffic else None,
                      'traffic_source': traffic_src,
+                     # (3) how busy the FP64 pipes were: VALU wave-instructions per step by the counters x 4 issue cycles over
+                     #     1024 SIMDs x 2.4 GHz, against the step time (a kernel near 1 here is bound by its arithmetic, not by HBM)
+                     'valu_wave_instructions_per_step': valu,
+                     'valu_issue_frac': (valu*4.0/(N_SIMD*FP64_CLOCK_HZ)/step_s) if valu else None,
                      'kernel': ('swe_fuse12_kernel (stages 1 + 2 in one launch) + swe_stage_kernel (stage 3): avg_launch_ms is per '
                                 'element-update = a third of a step') if fused[0] else 'swe_stage_kernel',
                      'launches_per_step': 2 if fused[0] else 3,

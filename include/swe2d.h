@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SWE2D_ABI_VERSION 10
+#define SWE2D_ABI_VERSION 11
 #define SWE2D_MAX_MARKERS 16          /* boundary markers must be in 1..SWE2D_MAX_MARKERS-1 */
 
 typedef enum {
@@ -82,6 +82,32 @@ typedef enum {
     SWE2D_SCALAR_COUNT = 5
 } swe2d_scalar;
 
+/* Library options: how the path is carried out, never what it computes (every setting gives the same bits; the parity tests
+ * force each in turn).  Read by the library from the handle only - it never looks at the process environment; the THETIS_AMD_*
+ * variables of the same names are a convenience of the Python binding (thetis_amd/_lib.py: OPTION_ENV), applied once after
+ * swe2d_create.  value -1 = the library's own rule.  No reference counterpart (Firedrake's analogue is the
+ * solver_parameters / PyOP2 configuration a script may pass, thetis/options.py:145-152). */
+typedef enum {
+    SWE2D_OPT_FUSED_STAGES = 0,   /* stages of a step in one launch by overlapped tiles (csrc/swe2d_fuse.h): -1 from 250 k triangles
+                                     when the numbering gives compact tiles, 0 never, 1 on every mesh the kernel covers */
+    SWE2D_OPT_FLOW = 1,           /* swe2d_advance takes the dataflow stage loop (csrc/swe2d_flow.h) where it applies: -1 / 1 yes, 0 no */
+    SWE2D_OPT_FLOW_WD = 2,        /* ... also with wetting-drying: -1 / 1 yes, 0 no */
+    SWE2D_OPT_BND_INLINE = 3,     /* triangle stage kernels: boundary facets from registers (1) or by the epilogue that reloads them (0);
+                                     -1: inline, with wetting-drying the epilogue.  0 also keeps the fused / dataflow kernels away */
+    SWE2D_OPT_LDSX = 4,           /* in-wave neighbour traces through LDS: -1 in launches beyond the Infinity Cache, 0 / 1 forced */
+    SWE2D_OPT_ALTERNATE = 5,      /* alternating launch direction: -1 in launches beyond the Infinity Cache, 0 / 1 forced */
+    SWE2D_OPT_COMPACT_IDX = 6,    /* 16-B connectivity records: -1 / 1 in launches of >= 250 k cells, 0 never, 2 in every launch */
+    SWE2D_OPT_VISC_FUSION = 7,    /* triangles: viscosity inside the stage kernel (-1 / 1) or as a separate pass (0) */
+    SWE2D_OPT_WALL_FAST = 8,      /* closed walls on a path of their own in the boundary code (-1 / 1) or through the general one (0) */
+    SWE2D_OPT_FLOW_POLL = 9,      /* granule loads per polling trip of the dataflow kernel: -1 by the blocks' rim facets, else 3 ... 9 */
+    SWE2D_OPT_FLOW_CAPACITY = 10, /* resident 64-cell blocks the dataflow kernel may assume: -1 what the device holds (tests force less) */
+    SWE2D_OPT_FLOW_TIMEOUT_MS = 11, /* bound of every wait inside the dataflow kernel, default 2000 */
+    SWE2D_OPT_P2P_TIMEOUT_MS = 12,  /* bound of the peer-to-peer waits, default 5000 */
+    SWE2D_OPT_P2P_ZONE = 13,      /* landing zone memory: -1 first that works, 1 uncached, 2 fine-grained, 3 ordinary device memory */
+    SWE2D_OPT_ROCTX = 14,         /* 1: ROCTx ranges around the entry points that advance the state (rocprofv3 --marker-trace) */
+    SWE2D_OPT_COUNT = 15
+} swe2d_option;
+
 /* Mesh = what FlowSolver2d(mesh2d, bathymetry_2d) receives (thetis/solver2d.py:81-147) flattened to arrays.
  * Triangles (nodes_per_cell == 3, DG-P1) or convex quadrilaterals (nodes_per_cell == 4, DQ-1), counter-clockwise.  A mesh of
  * parallelograms (every quadrilateral mesh the reference builds itself) takes the kernels with a constant Jacobian and the tensor
@@ -121,14 +147,14 @@ typedef struct swe2d_handle swe2d_handle;
 int  swe2d_abi_version(void);
 /* How the triangle kernels read the connectivity: out[0] = 1 when from the 16-B records (neighbour and vertex ids as differences
  * to the cell's own, csrc/swe2d_kernels.h swe_conn_pack; in launches of >= 250 k cells, where it pays;
- * THETIS_AMD_COMPACT_IDX=0 keeps the 24-B records everywhere, =2 takes the 16-B records in every launch), out[1] = the number
+ * SWE2D_OPT_COMPACT_IDX = 0 keeps the 24-B records everywhere, = 2 takes the 16-B records in every launch), out[1] = the number
  * of cells whose differences did not fit and which read the 24-B record after all.  Results do not depend on it. */
 int  swe2d_connectivity_info(swe2d_handle *h, int32_t out[2]);
 /* Stages 1 and 2 of a step in ONE launch by overlapped tiles (csrc/swe2d_fuse.h: 192 interior cells + their ring per workgroup,
  * the first stage's result never leaves the chip), stage 3 as a stage launch: what swe2d_advance does from 250 k triangles on a
- * whole mesh without source terms, wetting-drying or viscosity, when the cell numbering gives compact tiles (THETIS_AMD_FUSE12=0:
- * never, =1: on every such mesh).  Same results bit for bit; the intermediate stage_sol[1] is then not in the state buffers
- * (swe2d_get_stage_state(1) after swe2d_advance returns what the last stage launch left there).
+ * whole mesh without source terms, wetting-drying or viscosity, when the cell numbering gives compact tiles (SWE2D_OPT_FUSED_STAGES = 0:
+ * never, = 1: on every such mesh).  Same results bit for bit; the intermediate stage_sol[0] = U(1) then never reaches the state buffers
+ * (swe2d_get_stage_state(h, 0) after such a step returns SWE2D_ERR_UNSUPPORTED, not a stale buffer).
  * out[0] = 1 when swe2d_advance would take it now (builds the tile tables on first use), out[1] = tiles, out[2] = ring cells
  * (cells evaluated redundantly in stage 1), out[3] = cells. */
 int  swe2d_fused_pair_info(swe2d_handle *h, int32_t out[4]);
@@ -151,12 +177,18 @@ int  swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_hand
 int  swe2d_set_general_quadrilaterals(swe2d_handle *h, int on);
 void swe2d_destroy(swe2d_handle *h);
 const char *swe2d_last_error(const swe2d_handle *h);             /* h may be NULL: error of the last failed create */
+/* library options (swe2d_option above); takes effect from the next call on */
+int  swe2d_set_option(swe2d_handle *h, int option, int value);
+int  swe2d_get_option(swe2d_handle *h, int option, int *value);
 
 /* state: the mixed Function solution_2d = (uv_2d, elev_2d) (solver2d.py:410-413); host pointers */
 int  swe2d_set_state(swe2d_handle *h, const double *uv, const double *eta);
 int  swe2d_get_state(swe2d_handle *h, double *uv, double *eta);
 /* the stage solution the reference assigns to `solution` after solve_stage(i_stage) (rungekutta.py:930-946): i_stage 0, 1 read
- * the buffers holding U1, U2; i_stage 2 (= swe2d_get_state) the step result */
+ * the buffers holding U1, U2; i_stage 2 (= swe2d_get_state) the step result.  The reference's stage_sol[i] always is what stage i
+ * left; here the fused stage pair keeps U1, the dataflow kernel U1 and U2, on chip: when the step made last did not leave the asked
+ * stage solution in memory (or no stage has run since swe2d_set_state / a restore) the call returns SWE2D_ERR_UNSUPPORTED - drive
+ * the step with swe2d_solve_stage to read intermediate stages */
 int  swe2d_get_stage_state(swe2d_handle *h, int i_stage, double *uv, double *eta);
 /* Save (restore = 0) / bring back (restore = 1) the time-stepping state - the step result and every tracer - in a device-side
  * copy, exactly, without the host: for steps that have to be undone (graph capture warm-ups, verification replays, benchmarks).
@@ -164,7 +196,11 @@ int  swe2d_get_stage_state(swe2d_handle *h, int i_stage, double *uv, double *eta
  * wetting-drying: with it the device carries the displaced depth D = (H + sqrt(H^2 + alpha^2))/2 instead of eta, which it hands
  * out and takes in through the closed forms of thetis/utility.py:975-996 - the identity up to rounding, not bit for bit).
  * Enqueued on the handle's stream. */
-int  swe2d_state_snapshot(swe2d_handle *h, int restore);
+int  swe2d_state_snapshot(swe2d_handle *h, int restore);         /* slot 0 */
+/* ... in one of SWE2D_SNAPSHOT_SLOTS independent slots: a caller that keeps a long-lived copy (the start of a verification window)
+ * and needs short-lived ones in between (graph capture warm-ups) gives each its own */
+#define SWE2D_SNAPSHOT_SLOTS 2
+int  swe2d_state_snapshot_slot(swe2d_handle *h, int slot, int restore);
 
 /* TimeIntegrator.set_dt (timeintegrator.py:70-73) */
 int  swe2d_set_dt(swe2d_handle *h, double dt);
@@ -343,7 +379,7 @@ int  swe2d_halo_unpack(swe2d_handle *h, int i_buffer, const double *recv_buf_dev
  * [send_offset[i], + send_count[i]) at cell offset remote_recv_offset[i] of ITS recv list (remote_n_recv[i] cells long) and
  * knows me as its sender number remote_flag_index[i]; n_from = number of ranks that send to me (their flag indices are
  * 0..n_from-1).  Then, per exchange and channel, on every rank in the same order: swe2d_p2p_push ... swe2d_p2p_wait_unpack.
- * A rank may run at most one exchange ahead of a peer (double-buffered slots); waits are bounded (THETIS_AMD_P2P_TIMEOUT_S,
+ * A rank may run at most one exchange ahead of a peer (double-buffered slots); waits are bounded (SWE2D_OPT_P2P_TIMEOUT_MS,
  * default 5 s) and counted in swe2d_p2p_status.timeouts instead of hanging the device. */
 #define SWE2D_IPC_HANDLE_BYTES 64
 int  swe2d_p2p_create(swe2d_handle *h, int32_t n_channels, const int32_t *widths);
@@ -372,16 +408,12 @@ int  swe2d_swap_state_buffers(swe2d_handle *h);
  * stage s's range: the shrinking ranges of a partition's exchange cycle, or n_owned throughout), a 64-cell block starts stage
  * s + 1 as soon as the trace values it needs from the blocks around it have arrived.  State buffer 0 (swe2d_get_state) ends bit for
  * bit as the swe2d_solve_stage_cells calls it stands for leave it; the intermediate stage solutions (swe2d_get_stage_state 0, 1)
- * are not produced.  swe2d_advance uses it on its own where it applies (THETIS_AMD_FLOW=0: never).  Needs every block of the
+ * are not produced.  swe2d_advance uses it on its own where it applies (SWE2D_OPT_FLOW = 0: never).  Needs every block of the
  * handle resident at once:
  * swe2d_flow_supported returns 0 when the mesh is too large for that (or the configuration is not covered: quadrilaterals,
- * viscosity; wetting-drying IS covered since round 5 - csrc/swe2d_k_flow_wd.hip, THETIS_AMD_FLOW_WD=0 leaves it to the stage
- * launches), 1 covered, 2 covered and without source terms; 3 / 4 (round 5, only with THETIS_AMD_MFLOW=1 in the
- * environment - measured slower than the stage launches, kept as an option): the same through the multi-block kernel
- * (csrc/swe2d_mflow.h: a wave owns up to 8 consecutive 64-cell blocks and keeps their stage values in the state buffers like
- * the stage launches do - cell ranges up to 8 x the one-block limit; swe2d_solve_flow and swe2d_advance take it on their own, the
- * exchange inside the launch, swe2d_solve_flow_exchange, is not available there, and the stage buffers 1, 2 ARE written);
- * SWE2D_ERR_UNSUPPORTED from swe2d_solve_flow otherwise.  Every wait inside the kernel is bounded (THETIS_AMD_FLOW_TIMEOUT_S, default 2 s); a timeout invalidates the
+ * viscosity; wetting-drying IS covered since round 5 - csrc/swe2d_k_flow_wd.hip, SWE2D_OPT_FLOW_WD = 0 leaves it to the stage
+ * launches), 1 covered, 2 covered and without source terms;
+ * SWE2D_ERR_UNSUPPORTED from swe2d_solve_flow otherwise.  Every wait inside the kernel is bounded (SWE2D_OPT_FLOW_TIMEOUT_MS, default 2 s); a timeout invalidates the
  * state and is reported as SWE2D_ERR_HIP by the next swe2d_synchronize / swe2d_get_state / swe2d_diagnostics
  * (swe2d_flow_status reads the count without failing). */
 int  swe2d_solve_flow(swe2d_handle *h, int32_t n_stages, const int32_t *cell_end);

@@ -161,12 +161,15 @@ class CpuSwe2dDevice(object):
         b = (int(i_stage) + 1) % 3
         return self.U[b].copy(), self.E[b].copy()
 
-    def snapshot(self):
-        self._snap = (self.U[0].copy(), self.E[0].copy(), [t['T'][0].copy() for t in self.tracers])
+    def snapshot(self, slot=0):
+        if not hasattr(self, '_snaps'):
+            self._snaps = {}
+        self._snaps[slot] = (self.U[0].copy(), self.E[0].copy(), [t['T'][0].copy() for t in self.tracers])
 
-    def restore(self):
-        self.U[0][...], self.E[0][...] = self._snap[0], self._snap[1]
-        for t, T in zip(self.tracers, self._snap[2]):
+    def restore(self, slot=0):
+        snap = self._snaps[slot]
+        self.U[0][...], self.E[0][...] = snap[0], snap[1]
+        for t, T in zip(self.tracers, snap[2]):
             t['T'][0][...] = T
 
     def synchronize(self):

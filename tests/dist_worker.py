@@ -353,7 +353,7 @@ def viscosity_field(mesh):
 def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     global CASE
     flags = {}
-    for f in ('+capture', '+graph', '+p2p', '+nosplit', '+flowx', '+flow', '+delay', '+mix', '+tear'):   # order-independent suffix flags
+    for f in ('+capture', '+graph', '+p2p', '+nosplit', '+flowx', '+flow', '+delay', '+mix', '+tear', '+verify'):   # order-independent suffix flags
         flags[f] = f in case
         case = case.replace(f, '')
     graphed = flags['+graph']              # per-cycle HIP graphs (around the eager host-staged exchange, or incl. the p2p kernels)
@@ -371,7 +371,8 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     owner = strip_owner(mesh, world, axis=axis)
     solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, exchange=('p2p' if flags['+p2p'] else 'host'),
                               exchange_every=every, overlap_stages=overlap, split_last_stage=not flags['+nosplit'],
-                              stepper=('ForwardEuler' if fe else 'SSPRK33'), flow=(True if (flags['+flow'] or flags['+flowx']) else False), flow_exchange=flags['+flowx'])
+                              stepper=('ForwardEuler' if fe else 'SSPRK33'), flow=(True if (flags['+flow'] or flags['+flowx']) else False), flow_exchange=flags['+flowx'],
+                              **(dict(verify_every=5, graph_mode='full') if flags['+verify'] else {}))
     if viscous:     # SIPG pass on the partition: same cell ranges as the stage kernels, per-vertex viscosity of the local vertices
         solver.dev.set_viscosity(viscosity_field(mesh)[solver.part.vertex_global], use_grad_div_viscosity_term=True)
     solver.set_state_global(uv, eta)
@@ -407,6 +408,16 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
         solver.synchronize()
         solver.set_state_global(uv, eta)
         solver.advance(n_steps, use_graph=True)
+    elif flags['+verify']:
+        # verification windows of five steps that the advance sizes do not divide, whole advances captured as ONE graph: the second
+        # and third call capture (warm-up steps, state restored) in the MIDDLE of a window - the window's start must survive that
+        # (one snapshot buffer served both; every rank then replayed from the wrong state and "found" a mismatch)
+        a = n_steps//3
+        solver.advance(a, use_graph=True)
+        solver.advance(a + 1, use_graph=True)
+        solver.advance(n_steps - 2*a - 1, use_graph=True)
+        assert solver.graph_mode == 'full' and solver.verify_report['windows'] >= 2, solver.verify_report
+        assert solver.verify_report['mismatches'] == 0, solver.verify_report
     elif graphed:
         # twice the same advance: the second call replays the graphs the first one captured
         solver.advance(n_steps - n_steps//2, use_graph=True)

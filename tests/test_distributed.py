@@ -483,7 +483,7 @@ def _single_device(n_steps):
 @pytest.mark.parametrize('world,case,n_steps', [
     (2, 'channel+p2p', 3), (2, 'channel+every2+p2p', 5), (2, 'channel+every4+overlap3+p2p+graph', 16),
     (2, 'channel+every2+p2p+nosplit+graph', 9), (3, 'channel+every4+p2p+graph', 8), (4, 'channel+every2+overlap3+p2p+graph', 9),
-    (2, 'quad+p2p', 3), (3, 'delaunay+p2p+graph', 2), (2, 'channel+every3+fe+p2p', 7)])
+    (2, 'quad+p2p', 3), (3, 'delaunay+p2p+graph', 2), (2, 'channel+every3+fe+p2p', 7), (2, 'channel+every2+p2p+verify', 20)])
 def test_ranks_on_one_gpu_with_peer_to_peer_halos(tmp_path, hip_lib, world, case, n_steps):
     """The exchange as two kernels writing into / polling IPC-mapped landing zones (csrc/swe2d_p2p.h): separate processes on
     one GPU map each other's zones with hipIpcOpenMemHandle exactly as ranks on different GPUs do; with '+graph' the whole

@@ -219,9 +219,8 @@ def test_flow_is_refused_where_it_does_not_apply(hip_lib, monkeypatch):
         with pytest.raises(Swe2dError):
             dev.solve_flow(bad)
     dev.close()
-    # more blocks than the device holds resident at once (the multi-block kernel is opt-in): refused, not deadlocked
+    # more blocks than the device holds resident at once: refused, not deadlocked
     monkeypatch.setenv('THETIS_AMD_FLOW_CAPACITY', '16')
-    monkeypatch.delenv('THETIS_AMD_MFLOW', raising=False)
     mesh, bath, uv, eta = channel_case(nx=40, ny=20, seed=1)        # 1600 cells = 25 blocks
     dev = _device(mesh, bath, 0.05)
     assert dev.flow_supported() == 0
@@ -349,80 +348,6 @@ def test_granule_stores_that_land_in_two_halves_change_no_bit(hip_lib, every):
         assert same
     else:
         assert not same, 'negative control: torn granules taken by their tag alone must show up as wrong bits'
-
-
-@pytest.mark.parametrize('case,cap', [('channel', 24), ('channel_open', 16), ('sources', 24), ('unstructured', 40), ('linear', 24),
-                                      ('no_lf', 16), ('shrinking', 24), ('forced_k', 0)])
-def test_several_blocks_per_wave_give_the_bits_of_the_stage_launches(hip_lib, monkeypatch, case, cap):
-    """csrc/swe2d_mflow.h: cell ranges with more 64-cell blocks than waves can be resident - a wave owns K consecutive blocks, their
-    stage values live in the state buffers between visits.  The residency limits are forced down (one-block kernel: 8 waves,
-    multi-block kernel: `cap` waves) so that small meshes take K = 3 ... 9 blocks per wave; 'shrinking': one rank's cells of a strip
-    partition on the twelve shrinking ranges of a halo cycle; 'forced_k': K = 3 on a range the one-block kernel would cover.
-    Several launches in a row (the stage counters carry over).  Bit for bit the stage launches."""
-    from thetis_amd.device import Swe2dDevice
-    monkeypatch.setenv('THETIS_AMD_MFLOW', '1')             # opt-in: measured slower than the stage launches (profiles/r05e)
-    monkeypatch.setenv('THETIS_AMD_FLOW_CAPACITY', '8')
-    if cap:
-        monkeypatch.setenv('THETIS_AMD_MFLOW_CAPACITY', str(cap))
-    else:
-        monkeypatch.delenv('THETIS_AMD_FLOW_CAPACITY')
-        monkeypatch.setenv('THETIS_AMD_MFLOW_FORCE_K', '3')
-    kw = {}
-    if case == 'linear':
-        kw['use_nonlinear_equations'] = False
-    if case == 'no_lf':
-        kw['use_lax_friedrichs_velocity'] = False
-    if case == 'shrinking':
-        from thetis_amd import ordering
-        from thetis_amd.partition import build_partition, strip_owner
-        mesh, bath, uv, eta = channel_case(nx=160, ny=48, seed=9)
-        part = build_partition(mesh, strip_owner(mesh, 4), 1, halo_depth=12)
-        g = part.local_to_global
-        dev = Swe2dDevice(part, np.asarray(bath)[part.vertex_global], 0.05, n_owned=part.n_owned, boundary_len=part.boundary_len,
-                          ranges=part.reorder_ranges())
-        dev.flow_set_order(ordering.auto_cell_order(part, 0, part.num_cells))
-        uv, eta = uv[g], eta[g]
-        ends = [part.stage_range(s_, depth=12) for s_ in range(12)]
-        launches = [ends, ends]
-    else:
-        if case == 'unstructured':
-            mesh, bath, uv, eta = delaunay_case(n_points=3000, seed=5)[:4]
-        else:
-            mesh, bath, uv, eta = channel_case(nx=67, ny=31, seed=11)
-        dev = _device(mesh, bath, 0.05 if case != 'unstructured' else 0.02, **kw)
-        _configure(dev, mesh, case)
-        launches = [[dev.n_cells]*12, [dev.n_cells]*18, [dev.n_cells]*3]
-    assert dev.flow_supported() == ((2 if case != 'sources' else 1) if case == 'forced_k' else (3 if case == 'sources' else 4))
-    dev.set_state(uv, eta)
-    for ends in launches:
-        _by_stage(dev, ends)
-    ref = dev.get_state()
-    dev.set_state(uv, eta)
-    for ends in launches:
-        dev.solve_flow(ends)
-    assert dev.flow_timeouts() == 0
-    got = dev.get_state()
-    dev.close()
-    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
-
-
-def test_advance_takes_several_blocks_per_wave_on_its_own(hip_lib, monkeypatch):
-    """swe2d_advance on a mesh beyond the one-block kernel's residency (forced down to 8 waves): flow launches with several blocks
-    per wave up to THETIS_AMD_MFLOW_ADVANCE_K, the stage launches beyond - the same bits either way"""
-    monkeypatch.setenv('THETIS_AMD_MFLOW', '1')
-    monkeypatch.setenv('THETIS_AMD_FLOW_CAPACITY', '8')
-    monkeypatch.setenv('THETIS_AMD_MFLOW_CAPACITY', '24')
-    mesh, bath, uv, eta = channel_case(nx=67, ny=31, seed=11)
-    res = []
-    for kmax in ('8', '1'):
-        monkeypatch.setenv('THETIS_AMD_MFLOW_ADVANCE_K', kmax)
-        dev = _device(mesh, bath, 0.05)
-        dev.set_state(uv, eta)
-        dev.advance(7)
-        dev.advance(130)
-        res.append(dev.get_state())
-        dev.close()
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
 def _beach(nx, ny, seed):

@@ -584,6 +584,137 @@ def test_fused_stage_pair_gives_the_bits_of_the_stage_launches(hip_lib, monkeypa
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
+def _bump_state(mesh, seed=1234):
+    n = mesh.num_cells
+    rng = np.random.default_rng(seed)
+    cx, cy = mesh.cell_xy()[:, :, 0], mesh.cell_xy()[:, :, 1]
+    eta = 0.5*np.exp(-((cx - 50e3)**2 + (cy - 25e3)**2)/(5e3)**2) + 1e-3*rng.uniform(-1, 1, size=(n, 3))
+    uv = 1e-3*rng.uniform(-1, 1, size=(n, 3, 2))
+    return uv, eta
+
+
+@pytest.mark.parametrize('bcs', [
+    {},
+    {1: {'elev': 0.3}, 2: {'un': 0.2}, 3: {'flux': 1e4, 'elev': 0.1}},
+    {4: {'uv': (0.1, -0.2)}, 1: {'flux': -3e3}, 2: {'elev': 0.1, 'uv': (0.3, 0.1)}, 3: {'elev': -0.1, 'un': 0.05}},
+], ids=['walls', 'open_a', 'open_b'])
+def test_fused_stage_pair_matches_the_c_restatement(hip_lib, ref_so, monkeypatch, bcs):
+    """The headline kernel against the ORACLE, not against the stage launches: 270 k triangles - the size from
+    which swe2d_advance takes the fused stage pair by itself, asserted - 1, 10 and 100 SSPRK33 steps against oracle/swe2d_ref.c at
+    1e-12 / 1e-11 / 1e-10, closed walls and both open-boundary sets of test_open_boundaries_match_oracle."""
+    for v in ('THETIS_AMD_FUSE12', 'THETIS_AMD_FLOW', 'THETIS_AMD_BND_INLINE'):
+        monkeypatch.delenv(v, raising=False)
+    mesh, bath, _, _ = channel_case(nx=450, ny=300, lx=100e3, ly=50e3)
+    uv, eta = _bump_state(mesh)
+    dt = 0.5
+    ref = make_ref(mesh, bath, bnd_conditions=bcs)
+    dev = _device(mesh, bath, dt)
+    for marker, funcs in bcs.items():
+        dev.set_bc(marker, funcs)
+    assert dev.fused_pair_info()[0], 'the library did not take the fused stage pair on a 270 k-cell plain mesh'
+    ur, er = uv, eta
+    done = 0
+    for n_steps, tol in ((1, 1e-12), (10, 1e-11), (100, 1e-10)):
+        dev.set_state(uv, eta)
+        dev.advance(n_steps)
+        ud, ed = dev.get_state()
+        ur, er = ref.advance(ur, er, dt, n_steps - done)          # the restatement steps on from where it was
+        done = n_steps
+        assert np.isfinite(ed).all()
+        assert rel_linf(ud, ur) < tol and rel_linf(ed, er) < tol, (n_steps, rel_linf(ud, ur), rel_linf(ed, er))
+    assert dev.fused_pair_info()[0]
+    dev.close()
+
+
+def test_fused_stage_pair_matches_the_c_restatement_at_bench_size(hip_lib, ref_so, monkeypatch):
+    """BASELINE cfg 2 itself (1 M triangles, the bench's state and time step): 20 steps of the path bench.py times - fused stage
+    pair + stage 3, asserted - against oracle/swe2d_ref.c at 1e-11."""
+    from thetis_amd.mesh import RectangleMesh
+    for v in ('THETIS_AMD_FUSE12', 'THETIS_AMD_FLOW', 'THETIS_AMD_BND_INLINE'):
+        monkeypatch.delenv(v, raising=False)
+    mesh = RectangleMesh(1000, 500, 100e3, 50e3)
+    bath = np.full(mesh.num_vertices, 20.0)
+    uv, eta = _bump_state(mesh)
+    dt = 0.25
+    dev = _device(mesh, bath, dt)
+    assert dev.fused_pair_info()[0]
+    dev.set_state(uv, eta)
+    dev.advance(20)
+    ud, ed = dev.get_state()
+    dev.close()
+    ur, er = make_ref(mesh, bath).advance(uv, eta, dt, 20)
+    assert rel_linf(ud, ur) < 1e-11 and rel_linf(ed, er) < 1e-11, (rel_linf(ud, ur), rel_linf(ed, er))
+
+
+def test_stage_solutions_the_step_did_not_leave_in_memory_are_refused(hip_lib, monkeypatch):
+    """swe2d_get_stage_state(h, i) hands out stage_sol[i] of the reference (rungekutta.py:930-946) - or SWE2D_ERR_UNSUPPORTED when
+    the kernels that made the last step kept it on chip (fused stage pair: U(1); dataflow kernel: U(1) and U(2)), never the stale
+    contents of the buffer."""
+    from thetis_amd import _lib
+    for v in ('THETIS_AMD_FUSE12', 'THETIS_AMD_FLOW'):
+        monkeypatch.delenv(v, raising=False)
+    mesh, bath, uv, eta = channel_case(nx=40, ny=20, seed=3)
+    dev = _device(mesh, bath, 0.5)
+    dev.set_state(uv, eta)
+    for i in (0, 1):                                   # nothing has run yet
+        with pytest.raises(_lib.Swe2dError) as e:
+            dev.get_state(i)
+        assert e.value.code == _lib.ERR_UNSUPPORTED
+    dev.solve_stage(0)
+    u1 = dev.get_state(0)                              # a stage launch leaves its solution
+    with pytest.raises(_lib.Swe2dError):
+        dev.get_state(1)
+    dev.solve_stage(1)
+    u2 = dev.get_state(1)
+    dev.solve_stage(2)
+    u3 = dev.get_state()
+    assert not np.array_equal(u1[1], u2[1]) and not np.array_equal(u2[1], u3[1])
+    dev.advance(1)                                     # small mesh: the dataflow kernel - neither stage solution in memory
+    for i in (0, 1):
+        with pytest.raises(_lib.Swe2dError) as e:
+            dev.get_state(i)
+        assert e.value.code == _lib.ERR_UNSUPPORTED
+    dev.get_state()
+    dev.set_option(_lib.OPT_FLOW, 0)
+    dev.set_option(_lib.OPT_FUSED_STAGES, 1)           # forced on the small mesh: U(1) on chip, U(2) in buffer C
+    dev.set_state(uv, eta)
+    assert dev.fused_pair_info()[0]
+    dev.advance(1)
+    with pytest.raises(_lib.Swe2dError):
+        dev.get_state(0)
+    assert np.array_equal(dev.get_state(1)[1], u2[1]) and np.array_equal(dev.get_state()[1], u3[1])
+    dev.set_option(_lib.OPT_FUSED_STAGES, 0)           # three stage launches: everything is there
+    dev.set_state(uv, eta)
+    dev.advance(1)
+    assert np.array_equal(dev.get_state(0)[1], u1[1]) and np.array_equal(dev.get_state(1)[1], u2[1])
+    dev.close()
+
+
+def test_options_are_the_handles_not_the_process_environments(hip_lib, monkeypatch):
+    """include/swe2d.h swe2d_set_option: the library reads no environment variable; the binding hands THETIS_AMD_* over once, at
+    construction (thetis_amd/_lib.py OPTION_ENV); changing the environment afterwards changes nothing, swe2d_set_option does."""
+    from thetis_amd import _lib
+    monkeypatch.setenv('THETIS_AMD_FUSE12', '1')
+    monkeypatch.setenv('THETIS_AMD_FLOW', '0')
+    monkeypatch.setenv('THETIS_AMD_FLOW_TIMEOUT_S', '0.25')
+    mesh, bath, uv, eta = channel_case(nx=40, ny=20, seed=3)
+    dev = _device(mesh, bath, 0.5)
+    assert dev.get_option(_lib.OPT_FUSED_STAGES) == 1 and dev.get_option(_lib.OPT_FLOW) == 0
+    assert dev.get_option(_lib.OPT_FLOW_TIMEOUT_MS) == 250 and dev.get_option(_lib.OPT_LDSX) == -1
+    assert dev.fused_pair_info()[0]
+    monkeypatch.setenv('THETIS_AMD_FUSE12', '0')       # too late for this handle
+    assert dev.fused_pair_info()[0]
+    dev.set_option(_lib.OPT_FUSED_STAGES, 0)
+    assert not dev.fused_pair_info()[0]
+    dev.set_option(_lib.OPT_FUSED_STAGES, None)        # the library's rule: 1600 cells are far below 250 k
+    assert not dev.fused_pair_info()[0]
+    with pytest.raises(_lib.Swe2dError):
+        dev.set_option(99, 1)
+    with pytest.raises(_lib.Swe2dError):
+        dev.set_option(_lib.OPT_FLOW, -7)
+    dev.close()
+
+
 def test_fused_stage_pair_is_what_a_large_plain_mesh_takes(hip_lib, monkeypatch):
     """swe2d_fused_pair_info: by itself from 250 k triangles on a whole mesh in the device numbering, not below, not with source
     terms or wetting-drying, not with THETIS_AMD_FUSE12=0 - so that a silent return to three stage launches shows up here."""

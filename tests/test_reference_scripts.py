@@ -69,6 +69,51 @@ def test_expressions_evaluate_like_numpy():
         bool(x < 1.0)
 
 
+def test_function_operands_are_evaluated_through_their_spaces():
+    """A Function inside an expression (the reference's scripts: a CG bathymetry inside the initial elevation that is PROJECTED into
+    P1DG, a P1DG field inside an expression interpolated into P1DG, a P0 field): evaluated at the requested points through its own
+    space - CG -> DG injection, interpolation to the cells' quadrature points - not by array length."""
+    from thetis_amd import Function, RectangleMesh, SpatialCoordinate, get_functionspace, sqrt
+    mesh = RectangleMesh(6, 4, 3.0, 2.0)
+    x, y = SpatialCoordinate(mesh)
+    P1, P1DG, P0 = get_functionspace(mesh, 'CG', 1), get_functionspace(mesh, 'DG', 1), get_functionspace(mesh, 'DG', 0)
+    bath = Function(P1).interpolate(10.0 - 2.0*x + y)                       # linear: P1 holds it exactly
+    xy = P1DG.node_xy()
+    # CG operand, DG target, nodal interpolation
+    f = Function(P1DG).interpolate(bath*2.0 + x)
+    assert np.allclose(f.dat.data_ro, 2.0*(10.0 - 2.0*xy[:, 0] + xy[:, 1]) + xy[:, 0])
+    # CG operand, DG target, L2 PROJECTION: evaluated at the quadrature points (one per cell and call) - exact for a linear field
+    g = Function(P1DG).project(0.5*bath - y)
+    assert np.allclose(g.dat.data_ro, 0.5*(10.0 - 2.0*xy[:, 0] + xy[:, 1]) - xy[:, 1])
+    # DG operand in a projection, a nonlinear expression of it: against numpy quadrature of the same thing
+    h = Function(P1DG).project(sqrt(f + 1.0))
+    from thetis_amd.function import triangle_quadrature
+    bary, w = triangle_quadrature()
+    fc = f.dat.data_ro.reshape(-1, 3)
+    b = np.zeros_like(fc)
+    for l, wq in zip(bary, w):
+        b += wq*np.sqrt(fc @ l + 1.0)[:, None]*l[None, :]
+    assert np.allclose(h.dat.data_ro.reshape(-1, 3), 3.0*(4.0*b - b.sum(axis=1, keepdims=True)))
+    # a P0 field has as many values as ... nothing else here: injected cell-wise, and into a projection as the cell's constant
+    c = Function(P0)
+    c.dat.data[:] = np.arange(mesh.num_cells)
+    k = Function(P1DG).interpolate(c + 0.0*x)
+    assert np.array_equal(k.dat.data_ro, np.repeat(np.arange(mesh.num_cells, dtype=float), 3))
+    assert np.allclose(Function(P1DG).project(c*1.0).dat.data_ro, np.repeat(np.arange(mesh.num_cells, dtype=float), 3))
+    # CG target of a projection with a DG operand: the global P1 projection of a continuous linear field returns it
+    assert np.allclose(Function(P1).project(f*1.0 - x).dat.data_ro, 2.0*bath.dat.data_ro)
+    # a DG-P1 field cannot be read at CG nodes (it is two-valued there): refused, not guessed
+    with pytest.raises(NotImplementedError):
+        Function(P1).interpolate(f*1.0)
+    # another mesh: refused
+    other = RectangleMesh(6, 4, 3.0, 2.0)
+    with pytest.raises(ValueError):
+        Function(get_functionspace(other, 'DG', 1)).interpolate(bath*1.0)
+    # outside interpolate / project there are no points to evaluate a Function at
+    with pytest.raises(ValueError):
+        (bath*1.0)(np.zeros(3), np.zeros(3))
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, 'demos/demo_2d_tracer.py')), reason='the reference tree is not here')
 def test_reference_demo_2d_tracer_script_runs_with_the_import_line_changed(ref_so, monkeypatch, tmp_path):
     """demos/demo_2d_tracer.py (BASELINE cfg 4's source: 40 x 40 quadrilaterals, tracer only, SSPRK33, LeVeque's bell + cone + slotted

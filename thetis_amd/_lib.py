@@ -19,8 +19,45 @@ SCALAR_LINEAR_DRAG, SCALAR_QUADRATIC_DRAG, SCALAR_MANNING_DRAG, SCALAR_NORM_SMOO
 
 IPC_HANDLE_BYTES = 64    # include/swe2d.h SWE2D_IPC_HANDLE_BYTES (sizeof(hipIpcMemHandle_t))
 SUM_LIMBS = 6             # include/swe2d.h: limbs per order-independent sum (swe2d_diagnostics_limbs)
-ABI_VERSION = 10         # include/swe2d.h SWE2D_ABI_VERSION
+ABI_VERSION = 11         # include/swe2d.h SWE2D_ABI_VERSION
+# include/swe2d.h swe2d_option
+(OPT_FUSED_STAGES, OPT_FLOW, OPT_FLOW_WD, OPT_BND_INLINE, OPT_LDSX, OPT_ALTERNATE, OPT_COMPACT_IDX, OPT_VISC_FUSION, OPT_WALL_FAST,
+ OPT_FLOW_POLL, OPT_FLOW_CAPACITY, OPT_FLOW_TIMEOUT_MS, OPT_P2P_TIMEOUT_MS, OPT_P2P_ZONE, OPT_ROCTX) = range(15)
+OPT_COUNT = 15
+SNAPSHOT_SLOTS = 2
 OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NOT_FINITE = 0, -1, -2, -3, -4, -5
+
+# The library itself never reads the environment (include/swe2d.h, swe2d_set_option).  As a convenience of THIS binding the variables
+# below are read once per handle, right after swe2d_create (Swe2dDevice.__init__), and handed over as options: A/B runs and the parity
+# tests that force every kernel variant in turn set them around the construction of a device.  name -> (option, conversion)
+OPTION_ENV = {
+    'THETIS_AMD_FUSE12': (OPT_FUSED_STAGES, int),
+    'THETIS_AMD_FLOW': (OPT_FLOW, int),
+    'THETIS_AMD_FLOW_WD': (OPT_FLOW_WD, int),
+    'THETIS_AMD_BND_INLINE': (OPT_BND_INLINE, int),
+    'THETIS_AMD_LDSX': (OPT_LDSX, int),
+    'THETIS_AMD_ALTERNATE': (OPT_ALTERNATE, int),
+    'THETIS_AMD_COMPACT_IDX': (OPT_COMPACT_IDX, int),
+    'THETIS_AMD_NO_VISC_FUSION': (OPT_VISC_FUSION, lambda v: 0),
+    'THETIS_AMD_WALL_FAST': (OPT_WALL_FAST, int),
+    'THETIS_AMD_FLOW_POLL': (OPT_FLOW_POLL, int),
+    'THETIS_AMD_FLOW_CAPACITY': (OPT_FLOW_CAPACITY, int),
+    'THETIS_AMD_FLOW_TIMEOUT_S': (OPT_FLOW_TIMEOUT_MS, lambda v: max(1, int(round(1e3*float(v))))),
+    'THETIS_AMD_P2P_TIMEOUT_S': (OPT_P2P_TIMEOUT_MS, lambda v: max(1, int(round(1e3*float(v))))),
+    'THETIS_AMD_P2P_ZONE': (OPT_P2P_ZONE, lambda v: {'uncached': 1, 'finegrained': 2, 'device': 3}[v]),
+    'THETIS_AMD_ROCTX': (OPT_ROCTX, int),
+}
+
+
+def options_from_environment():
+    """[(option, value)] for the variables of OPTION_ENV that are set."""
+    out = []
+    for name, (opt, conv) in OPTION_ENV.items():
+        v = os.environ.get(name)
+        if v is not None and v != '':
+            out.append((opt, int(conv(v))))
+    return out
+
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int32)
@@ -55,6 +92,9 @@ SYMBOLS = {
     'swe2d_get_state': (ctypes.c_int, [_H, _dp, _dp]),
     'swe2d_get_stage_state': (ctypes.c_int, [_H, ctypes.c_int, _dp, _dp]),
     'swe2d_state_snapshot': (ctypes.c_int, [_H, ctypes.c_int]),
+    'swe2d_state_snapshot_slot': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int]),
+    'swe2d_set_option': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int]),
+    'swe2d_get_option': (ctypes.c_int, [_H, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     'swe2d_set_dt': (ctypes.c_int, [_H, ctypes.c_double]),
     'swe2d_set_bc': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),
     'swe2d_set_bc_field': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int, _dp]),

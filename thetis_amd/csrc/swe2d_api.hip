@@ -35,7 +35,7 @@ void fill_stage_args(Handle *h, SweStageArgs &a, int in, int u0, int out, double
     a.idxc = conn_pays(h, c1 - c0, h->wd) ? h->idxc : nullptr;
     a.cell_begin = c0; a.cell_end = c1;
     a.reverse = 0;
-    { const char *e = std::getenv("THETIS_AMD_WALL_FAST"); a.wall_general = (e && std::atoi(e) == 0) ? 1 : 0; }
+    a.wall_general = opt_on(h, SWE2D_OPT_WALL_FAST) ? 0 : 1;
     a.wd_skip_relax = (h->wd && h->visc) ? 1 : 0;
     a.g = h->par.g_grav;
     a.sigma_lf = h->par.lax_friedrichs_velocity_scaling_factor;
@@ -76,25 +76,23 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     const bool has_u0 = (a0 != 0.0);
     // triangles: cell integral and interior facets of the viscosity inside the stage kernel, boundary facets by a small
     // launch over the boundary cells
-    const bool fused_visc = h->visc && h->fuse_visc && h->npc == 3 && !h->wd && h->opp4;
+    const bool fused_visc = h->visc && opt_on(h, SWE2D_OPT_VISC_FUSION) && h->npc == 3 && !h->wd && h->opp4;
     // Boundary-inline variant of the triangle kernel (BINL, swe2d_kernels.h): faster than or equal to the epilogue variant at
     // every size (us/step, same box, production numbering: 125 k cells 27.9 -> 26.3, 250 k 41.0 -> 38.2, 500 k 66.1 -> 63.6,
-    // 1 M 117.9 -> 117.8); both give the same bits.  THETIS_AMD_BND_INLINE=0 selects the epilogue variant (parity test, A/B).
-    const char *env_binl_s = std::getenv("THETIS_AMD_BND_INLINE");       // read per launch: tests switch it inside one process
-    const bool binl = !(env_binl_s && std::atoi(env_binl_s) == 0);
+    // 1 M 117.9 -> 117.8); both give the same bits.  SWE2D_OPT_BND_INLINE = 0 selects the epilogue variant (parity test, A/B).
+    const bool binl = h->opt[SWE2D_OPT_BND_INLINE] != 0;
     // Wetting-drying (round 5, the device carries D): the epilogue variant (158 VGPRs, 3 waves per SIMD) beats the boundary-inline
     // one (190 VGPRs, 2 waves) - cfg 5 at 500 k cells 83.5 against 89.3 us per step, same box (profiles/r05c_cfg5.txt); with the
-    // eta-carrying kernels of rounds 2-4 the two ran the same.  THETIS_AMD_BND_INLINE=1 forces the inline variant (same bits).
-    const bool binl_wd = env_binl_s && std::atoi(env_binl_s) != 0;
+    // eta-carrying kernels of rounds 2-4 the two ran the same.  SWE2D_OPT_BND_INLINE = 1 forces the inline variant (same bits).
+    const bool binl_wd = h->opt[SWE2D_OPT_BND_INLINE] > 0;
     // ... and for launches whose state no longer fits the Infinity Cache (three buffers of 24 B per node against 256 MB: beyond
-    // ~1.24 M triangles) with the in-wave neighbour traces exchanged through LDS (LDSX; THETIS_AMD_LDSX=0/1 forces the choice).
+    // ~1.24 M triangles) with the in-wave neighbour traces exchanged through LDS (LDSX; SWE2D_OPT_LDSX = 0 / 1 forces the choice).
     // With the device's tile-Hilbert numbering and the alternating direction below, same box, us/step without / with:
     // 1 M cells 115-118 / 118-119, 1.25 M 166-168 / 162-163, 1.5 M 206-210 / 197-199, 2 M 288-294 / 275, 2.5 M 363-364 / 345-347,
     // 3 M 420-428 / 394-398, 4 M 573-583 / 544 (profiles/r04w_ldsx_threshold.txt; rounds 2-3 took it from 3 M cells only).
     // Same bits in every variant: the kernel has no implicit contraction.
     const bool beyond_cache = (size_t)(c1 - c0)*h->npc*72 >= ((size_t)256 << 20);
-    const char *env_ldsx_s = std::getenv("THETIS_AMD_LDSX");
-    const bool ldsx = env_ldsx_s ? std::atoi(env_ldsx_s) != 0 : beyond_cache;
+    const bool ldsx = h->opt[SWE2D_OPT_LDSX] >= 0 ? h->opt[SWE2D_OPT_LDSX] != 0 : beyond_cache;
     stage_kernel_t kern = fused_visc
         ? pick_kernel_visc(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h))
         : h->wd ? pick_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_u0, has_sources(h), h->npc == 4 ? (h->affine ? 1 : 2) : 0, binl_wd)
@@ -108,15 +106,15 @@ int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, doubl
     // triangles / 0.9 M quadrilaterals) alternate the direction in which they walk the range: the cells a launch touched last -
     // still in the cache - are the first the next one reads.  Same results (cells are independent).  Same box, fraction of the
     // 8 TB/s roofline without / with: 2 M triangles 0.530 / 0.588, 4 M 0.581 / 0.602, 8 M 0.582 / 0.598 (1 M, which fits: 0.728 /
-    // 0.732).  THETIS_AMD_ALTERNATE=0/1 forces the choice.
+    // 0.732).  SWE2D_OPT_ALTERNATE = 0 / 1 forces the choice.
     if (!fused_visc) {
-        const char *env_alt = std::getenv("THETIS_AMD_ALTERNATE");
-        const bool alt = env_alt ? std::atoi(env_alt) != 0 : beyond_cache;
+        const bool alt = h->opt[SWE2D_OPT_ALTERNATE] >= 0 ? h->opt[SWE2D_OPT_ALTERNATE] != 0 : beyond_cache;
         if (alt) { a.reverse = h->launch_parity; h->launch_parity ^= 1; }
     }
     SWE_CHK_SYNC(h->stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_BLOCK), 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
+    if (out == 1 || out == 2) h->stage_valid[out - 1] = true;      // a stage launch leaves its stage solution in its buffer
     if (h->visc) {
         // HorizontalViscosityTerm: U_out[uv] += beta*dt*M^-1 R_visc(U_in) on the same cells (swe2d_sipg.h)
         SweSipgArgs v{};
@@ -251,8 +249,9 @@ int swe2d_connectivity_info(swe2d_handle *hh, int32_t out[2])
 {
     Handle *h = H(hh);
     if (!h || !out) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
-    out[0] = h->idxc ? 1 : 0;
-    out[1] = h->idxc ? h->n_conn_escapes : 0;
+    const bool on = h->idxc && h->opt[SWE2D_OPT_COMPACT_IDX] != 0;
+    out[0] = on ? 1 : 0;
+    out[1] = on ? h->n_conn_escapes : 0;
     return SWE2D_OK;
 }
 
@@ -274,6 +273,27 @@ void swe2d_ssprk33_coefficients(double alpha0[3], double alpha_in[3], double bet
 const char *swe2d_last_error(const swe2d_handle *h)
 {
     return h ? H(h)->err.c_str() : g_create_error.c_str();
+}
+
+int swe2d_set_option(swe2d_handle *hh, int option, int value)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (option < 0 || option >= SWE2D_OPT_COUNT) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_set_option: unknown option");
+    if (value < -1) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_set_option: value must be >= -1 (-1: the library's own rule)");
+    h->opt[option] = value;
+    if (option == SWE2D_OPT_FUSED_STAGES && h->fuse_state == -1) h->fuse_state = 0;     // tiles judged not worth it: judged again under the new setting
+    if (option == SWE2D_OPT_FLOW_CAPACITY) h->flow_capacity = -1;
+    return SWE2D_OK;
+}
+
+int swe2d_get_option(swe2d_handle *hh, int option, int *value)
+{
+    Handle *h = H(hh);
+    if (!h || !value) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    if (option < 0 || option >= SWE2D_OPT_COUNT) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_get_option: unknown option");
+    *value = h->opt[option];
+    return SWE2D_OK;
 }
 
 int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handle **out)
@@ -434,9 +454,7 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
         HIP_TRY_C(hipMemcpy(h->idx4, p4.data(), (size_t)S*sizeof(int4), hipMemcpyHostToDevice));
         HIP_TRY_C(hipMemcpy(h->idx2, p2.data(), (size_t)S*sizeof(int2), hipMemcpyHostToDevice));
         {   // the 16-B form of the same records (swe_conn_pack): what the stage kernels read
-            const char *e = std::getenv("THETIS_AMD_COMPACT_IDX");
-            h->idxc_always = (e && std::atoi(e) == 2) ? 1 : 0;
-            if (!(e && std::atoi(e) == 0)) {
+            {
                 std::vector<int4> pc((size_t)S, int4{0, 0, 0, (int)0x80000000u});
                 h->n_conn_escapes = 0;
                 for (int kk = 0; kk < n; kk++) {
@@ -469,7 +487,6 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
             HIP_TRY_C(hipMalloc(&h->bnd_cells, bnd.size()*sizeof(int)));
             HIP_TRY_C(hipMemcpy(h->bnd_cells, bnd.data(), bnd.size()*sizeof(int), hipMemcpyHostToDevice));
         }
-        h->fuse_visc = std::getenv("THETIS_AMD_NO_VISC_FUSION") == nullptr;
         // dataflow stage loop (swe2d_flow.h): one stage counter per 64-cell block, the status word, and the exchange slots of
         // the rim facets - interior facets whose two cells sit in different blocks - numbered in cell order
         h->flow_blocks = (n + SWE_BLOCK - 1)/SWE_BLOCK;
@@ -478,7 +495,6 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
         HIP_TRY_C(hipMemset(h->flow_flag, 0, (size_t)h->flow_blocks*SWE_FLOW_FLAG_STRIDE*sizeof(unsigned)));
         HIP_TRY_C(hipMemset(h->flow_status, 0, 4*sizeof(unsigned)));
         if (int rc = flow_build(h, nullptr)) { g_create_error = h->err; swe2d_destroy(reinterpret_cast<swe2d_handle *>(h)); return rc; }
-        if (const char *e = std::getenv("THETIS_AMD_FLOW_TIMEOUT_S")) { const double t = std::atof(e); if (t > 0.0) h->flow_timeout_s = t; }
     }
     HIP_TRY_C(hipMemcpyAsync(h->nbr, nbr.data(), (size_t)npc*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY_C(hipMemcpyAsync(h->cv, cv.data(), (size_t)npc*S*sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -508,7 +524,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->diag_acc, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->snapshot, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->idxc, h->fuse_tile, h->fuse_inner, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->snapshot[0].data, h->snapshot[1].data, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->idxc, h->fuse_tile, h->fuse_inner, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
     for (void *m : h->p2p.opened) (void)hipIpcCloseMemHandle(m);
@@ -552,6 +568,7 @@ int swe2d_set_state(swe2d_handle *hh, const double *uv, const double *eta)
         HIP_TRY(h, hipGetLastError());
     }
     h->state_holds_D = h->wd;                      // wetting-drying: the elevation planes now hold the displaced depth D
+    h->stage_valid[0] = h->stage_valid[1] = false; // no stage of this state has run yet
     HIP_TRY(h, hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
     return SWE2D_OK;
 }
@@ -559,27 +576,32 @@ int swe2d_set_state(swe2d_handle *hh, const double *uv, const double *eta)
 // Library-internal save / restore of the time-stepping state (buffer A and every tracer's buffer A) on the device: what graph
 // capture, verification replays and benchmarks need around steps they must undo.  Exact - unlike swe2d_get_state followed by
 // swe2d_set_state with wetting-drying, where the planes hold D and eta -> D -> eta is the identity only up to rounding.
-int swe2d_state_snapshot(swe2d_handle *hh, int restore)
+int swe2d_state_snapshot(swe2d_handle *hh, int restore) { return swe2d_state_snapshot_slot(hh, 0, restore); }
+
+int swe2d_state_snapshot_slot(swe2d_handle *hh, int slot, int restore)
 {
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (slot < 0 || slot >= SWE2D_SNAPSHOT_SLOTS) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_state_snapshot: no such slot");
     HIP_TRY(h, hipSetDevice(h->device));
+    Handle::Snapshot &sn = h->snapshot[slot];
     const size_t nb = (size_t)3*h->npc*h->stride*sizeof(double), nt = (size_t)h->npc*h->stride*sizeof(double);
     const size_t total = nb + h->tracers.size()*nt;
     if (restore) {
-        if (!h->snapshot || h->snapshot_bytes != total) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_state_snapshot: nothing to restore");
-        HIP_TRY(h, hipMemcpyAsync(h->state[0], h->snapshot, nb, hipMemcpyDeviceToDevice, h->stream));
+        if (!sn.data || sn.bytes != total) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_state_snapshot: nothing to restore");
+        HIP_TRY(h, hipMemcpyAsync(h->state[0], sn.data, nb, hipMemcpyDeviceToDevice, h->stream));
         for (size_t t = 0; t < h->tracers.size(); t++)
-            HIP_TRY(h, hipMemcpyAsync(h->tracers[t].buf[0], (char *)h->snapshot + nb + t*nt, nt, hipMemcpyDeviceToDevice, h->stream));
-        h->state_holds_D = h->snapshot_holds_D;
+            HIP_TRY(h, hipMemcpyAsync(h->tracers[t].buf[0], (char *)sn.data + nb + t*nt, nt, hipMemcpyDeviceToDevice, h->stream));
+        h->state_holds_D = sn.holds_D;
+        h->stage_valid[0] = h->stage_valid[1] = false;     // the stage buffers belong to the steps that are being undone
         return SWE2D_OK;
     }
-    if (h->snapshot && h->snapshot_bytes != total) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->snapshot); h->snapshot = nullptr; }
-    if (!h->snapshot) { HIP_TRY(h, hipMalloc(&h->snapshot, total)); h->snapshot_bytes = total; }
-    HIP_TRY(h, hipMemcpyAsync(h->snapshot, h->state[0], nb, hipMemcpyDeviceToDevice, h->stream));
+    if (sn.data && sn.bytes != total) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(sn.data); sn.data = nullptr; }
+    if (!sn.data) { HIP_TRY(h, hipMalloc(&sn.data, total)); sn.bytes = total; }
+    HIP_TRY(h, hipMemcpyAsync(sn.data, h->state[0], nb, hipMemcpyDeviceToDevice, h->stream));
     for (size_t t = 0; t < h->tracers.size(); t++)
-        HIP_TRY(h, hipMemcpyAsync((char *)h->snapshot + nb + t*nt, h->tracers[t].buf[0], nt, hipMemcpyDeviceToDevice, h->stream));
-    h->snapshot_holds_D = h->state_holds_D;
+        HIP_TRY(h, hipMemcpyAsync((char *)sn.data + nb + t*nt, h->tracers[t].buf[0], nt, hipMemcpyDeviceToDevice, h->stream));
+    sn.holds_D = h->state_holds_D;
     return SWE2D_OK;
 }
 
@@ -590,6 +612,11 @@ int swe2d_get_stage_state(swe2d_handle *hh, int i_stage, double *uv, double *eta
     Handle *h = H(hh);
     if (!h || !uv || !eta) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     if (i_stage < 0 || i_stage > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "i_stage must be 0, 1 or 2");
+    // stage_sol[i] of the reference always is what stage i left (rungekutta.py:930-946).  Here the fused and the dataflow kernels keep
+    // the intermediate stage solutions on chip: a buffer they did not write is not handed out as if they had
+    if (i_stage < 2 && !h->stage_valid[i_stage])
+        return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_get_stage_state: the last step did not leave this stage solution in memory (fused stages / "
+                    "dataflow kernel, or no stage has run since the state was set); run the step with swe2d_solve_stage to read it");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t n = (size_t)h->n_cells*h->npc;
     // (wetting-drying: the planes of all three buffers hold D, the host gets eta)
@@ -832,7 +859,7 @@ int swe2d_solve_stage_cells(swe2d_handle *hh, int i_stage, int32_t cell_begin, i
         return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell range");
     HIP_TRY(h, hipSetDevice(h->device));
     static const char *names[3] = {"swe2d_solve_stage[0]", "swe2d_solve_stage[1]", "swe2d_solve_stage[2]"};
-    RoctxRange range(names[(i_stage >= 0 && i_stage < 3) ? i_stage : 0]);
+    RoctxRange range(h, names[(i_stage >= 0 && i_stage < 3) ? i_stage : 0]);
     return stage_on_range(h, i_stage, cell_begin, cell_end);
 }
 
@@ -846,18 +873,7 @@ int swe2d_solve_stage(swe2d_handle *hh, int i_stage)
 // does swe2d_advance run this handle's steps in the dataflow kernel?
 static bool advance_takes_flow(Handle *h)
 {
-    const char *env_fl = std::getenv("THETIS_AMD_FLOW");
-    const bool want = env_fl ? std::atoi(env_fl) != 0 : true;
-    // ... and with several blocks per wave (swe2d_mflow.h) where the mesh is larger than that but a visit is still latency, not
-    // bandwidth: up to THETIS_AMD_MFLOW_ADVANCE_K blocks per wave (default 4: ~520 k cells)
-    bool covered = want && flow_kernel_covers(h);
-    if (covered && ((h->flow_blocks + 7)/8)*8 > flow_capacity(h)) {
-        const char *ek = std::getenv("THETIS_AMD_MFLOW_ADVANCE_K");
-        const int kmax = ek ? std::atoi(ek) : 4;
-        const int K = mflow_blocks_per_wave(h);
-        covered = K > 0 && K <= kmax;
-    }
-    return covered;
+    return opt_on(h, SWE2D_OPT_FLOW) && flow_kernel_covers(h) && ((h->flow_blocks + 7)/8)*8 <= flow_capacity(h);
 }
 
 int swe2d_advance(swe2d_handle *hh, int n_steps)
@@ -867,11 +883,11 @@ int swe2d_advance(swe2d_handle *hh, int n_steps)
     if (h->n_owned != h->n_cells)
         return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_advance on a partition: drive stages + halo exchange from the host");
     HIP_TRY(h, hipSetDevice(h->device));
-    RoctxRange range("swe2d_advance");
+    RoctxRange range(h, "swe2d_advance");
     // Up to 128 steps per launch without grid barriers (swe2d_flow.h) where every 64-cell block of the mesh is resident at once
     // (<= 131 k cells) and the kernel covers the configuration.  Same box, us/step, three stage launches per step -> flow launches:
     // 15 k cells 16.5 -> 15.3, 62 k 20.1 -> 15.1, 125 k 24.3 -> 18.3 (the one-launch step kernel of round 2, which this replaces:
-    // 14.1 / 16.8 / 24.9).  THETIS_AMD_FLOW=0 selects the stage launches (the same bits either way).
+    // 14.1 / 16.8 / 24.9).  SWE2D_OPT_FLOW = 0 selects the stage launches (the same bits either way).
     {
         if (n_steps > 0 && advance_takes_flow(h)) {
             int32_t ends[SWE_FLOW_MAX_STAGES];
@@ -938,6 +954,7 @@ int swe2d_swap_state_buffers(swe2d_handle *hh)
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
     std::swap(h->state[0], h->state[1]);
+    h->stage_valid[0] = h->stage_valid[1] = false;
     return SWE2D_OK;
 }
 
@@ -1005,6 +1022,7 @@ int swe2d_tendency(swe2d_handle *hh, double *k_uv, double *k_eta)
     // k into buffer B: U_out = 1*k + 0*U0 + 0*U_in
     int rc = launch_stage(h, 0, 0, 1, 0.0, 0.0, 1.0, 0, h->n_owned);
     if (rc) return rc;
+    h->stage_valid[0] = false;                               // buffer B holds the tendency, not a stage solution
     const size_t n = (size_t)h->n_cells*h->npc;
     hipLaunchKernelGGL(swe_planes_to_aos, dim3(grid_for(h->n_cells)), dim3(256), 0, h->stream,
                        h->state[1], h->stage_uv, h->stage_eta, h->stride, h->n_cells, h->npc);

@@ -98,8 +98,6 @@ int flow_build(Handle *h, const int32_t *order)
     if (too_many || !((size_t)3*n_slots*SWE_FLOW_SLOT_BYTES < ((size_t)1 << 31) && n_slots < (1 << 25))) return SWE2D_OK;
     h->flow_fpos = fpos;
     h->flow_max_rim = max_rim;
-    // A/B, tests: 9 forces the widest instance, 5 ... 8 / up to 4 the narrower ones (more than one trip per pass where a block has more rim facets)
-    if (const char *e = std::getenv("THETIS_AMD_FLOW_POLL")) h->flow_max_rim = std::atoi(e) > 8 ? 65 : (std::atoi(e) > 4 ? 64 : 32);
     h->flow_x_ready = false;
     h->flow_parity_bytes = (unsigned)((size_t)std::max(n_slots, 1)*SWE_FLOW_SLOT_BYTES);
     h->flow_ex_bytes = (size_t)3*h->flow_parity_bytes;
@@ -121,15 +119,11 @@ int flow_build(Handle *h, const int32_t *order)
 }
 
 // the configurations the flow kernel covers: triangles, no viscosity; wetting-drying since round 5 (swe_flow_kernel<..., WD>, nonlinear
-// equations as in the stage kernels; THETIS_AMD_FLOW_WD=0 leaves it to the stage launches)
+// equations as in the stage kernels; SWE2D_OPT_FLOW_WD = 0 leaves it to the stage launches)
 bool flow_kernel_covers(const Handle *h)
 {
-    const char *e = std::getenv("THETIS_AMD_BND_INLINE");
-    if (h->wd) {
-        const char *w = std::getenv("THETIS_AMD_FLOW_WD");
-        if (!h->par.use_nonlinear_equations || (w && std::atoi(w) == 0)) return false;
-    }
-    return h->npc == 3 && !h->visc && h->idx4 && h->flow_flag && h->flow_ex && !(e && std::atoi(e) == 0);
+    if (h->wd && (!h->par.use_nonlinear_equations || !opt_on(h, SWE2D_OPT_FLOW_WD))) return false;
+    return h->npc == 3 && !h->visc && h->idx4 && h->flow_flag && h->flow_ex && h->opt[SWE2D_OPT_BND_INLINE] != 0;
 }
 
 // Resident one-wave workgroups of the flow kernel: every block of a launch must be resident (a block waits for its
@@ -142,41 +136,8 @@ int flow_capacity(Handle *h)
     flow_kernel_t kern = pick_flow_kernel(true, true, true, true, 9);        // the largest variant
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), SWE_BLOCK, 0) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) return 0;
-    if (const char *e = std::getenv("THETIS_AMD_FLOW_CAPACITY")) h->flow_capacity = std::atoi(e);      // tests: force the limit
-    else h->flow_capacity = per_cu*dev_cus;
+    h->flow_capacity = h->opt[SWE2D_OPT_FLOW_CAPACITY] >= 0 ? h->opt[SWE2D_OPT_FLOW_CAPACITY] : per_cu*dev_cus;    // (tests force the limit)
     return h->flow_capacity;
-}
-
-// ... and of the multi-block kernel (swe2d_mflow.h), whose waves own several blocks each
-int mflow_capacity(Handle *h)
-{
-    if (h->mflow_capacity >= 0) return h->mflow_capacity;
-    h->mflow_capacity = 0;
-    int per_cu = 0, dev_cus = 0;
-    flow_kernel_t kern = pick_mflow_kernel(true, true, true, true);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), SWE_BLOCK, 0) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) return 0;
-    if (const char *e = std::getenv("THETIS_AMD_MFLOW_CAPACITY")) h->mflow_capacity = std::atoi(e);    // tests: force the limit
-    else h->mflow_capacity = per_cu*dev_cus;
-    return h->mflow_capacity;
-}
-
-// blocks per wave of a multi-block launch (0: the range does not fit, or the kernel is switched off): as few as keep every wave
-// resident.  OPT-IN, THETIS_AMD_MFLOW=1: measured slower than the stage launches it was built to replace at every size it applies to
-// (profiles/r05e_multi_block_flow.txt: one device 250 k / 500 k / 1 M cells 53.5 / 106 / 258 against 37.0 / 63.0 / 114 us per step, a
-// rank of four 62.4 against 42.3, a rank of two 108.7 against 67.9 - a visit of a block costs its polling pass and its publish,
-// ~2.2 us, on top of the dependent loads of a stage launch, which is more than the launch boundary shared by the ~4 visits a SIMD
-// makes per stage).  THETIS_AMD_MFLOW_MAX_K bounds K (default 8).
-int mflow_blocks_per_wave(Handle *h)
-{
-    const char *on = std::getenv("THETIS_AMD_MFLOW");
-    if (!on || std::atoi(on) == 0 || h->wd) return 0;          // (no wetting-drying instances of the multi-block kernel)
-    const int cap = (mflow_capacity(h)/8)*8;                   // the XCD-chunked block map needs a grid that is a multiple of 8
-    if (cap <= 0) return 0;
-    int kmax = 8;
-    if (const char *e = std::getenv("THETIS_AMD_MFLOW_MAX_K")) kmax = std::max(1, std::atoi(e));
-    const int K = std::max(2, (h->flow_blocks + cap - 1)/cap);   // (asked for because one block per wave does not fit: at least two)
-    return K <= kmax ? K : 0;
 }
 
 // FX launches: the places of every flow position's cell in the halo lists, the blocks that hold send / ghost cells
@@ -225,19 +186,9 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles)
     for (int s = 0; s < n_stages; s++)
         if (cell_end[s] < 0 || cell_end[s] > h->n_cells || (s > 0 && cell_end[s] > cell_end[s - 1]))
             return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "flow: the stage ranges must shrink and stay inside the mesh");
-    int grid = ((h->flow_blocks + 7)/8)*8;
-    int K = 1;                                                 // blocks per wave: 1 = swe_flow_kernel, > 1 = swe_mflow_kernel
-    if (grid > flow_capacity(h)) {
-        K = fx ? 0 : mflow_blocks_per_wave(h);
-        if (K <= 0) return fail(h, SWE2D_ERR_UNSUPPORTED, fx ? "flow with the exchange inside: more 64-cell blocks than the device holds resident at once"
-                                                              : "flow: more 64-cell blocks than the device holds resident, also with several blocks per wave");
-        grid = (((h->flow_blocks + K - 1)/K + 7)/8)*8;
-    } else if (!fx) {
-        if (const char *e = std::getenv("THETIS_AMD_MFLOW_FORCE_K"); e && !h->wd) {       // tests / A-B: the multi-block kernel on a range the one-block kernel covers
-            K = std::max(1, std::atoi(e));
-            if (K > 1) grid = (((h->flow_blocks + K - 1)/K + 7)/8)*8;
-        }
-    }
+    const int grid = ((h->flow_blocks + 7)/8)*8;
+    if (grid > flow_capacity(h))
+        return fail(h, SWE2D_ERR_UNSUPPORTED, "flow: more 64-cell blocks than the device holds resident at once");
     SweFlowArgs q{};
     if (fx) {
         auto &z = h->p2p;
@@ -264,7 +215,7 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles)
         q.x_zone = mine + p2p_channel_offset(z.width, ch, h->n_recv);
         q.x_slot = (unsigned)((size_t)h->n_recv*144);
         q.x_zbytes = 2*q.x_slot;
-        q.x_timeout = (unsigned long long)(z.timeout_s*1e8);
+        q.x_timeout = (unsigned long long)(opt_seconds(h, SWE2D_OPT_P2P_TIMEOUT_MS, 5.0)*1e8);
     }
     fill_stage_args(h, q.st, 0, 0, 1, 0.0, 1.0, 1.0, 0, 0);
     for (int i = 0; i < 3; i++) q.buf[i] = h->state[i];
@@ -273,14 +224,14 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles)
     q.xblk = h->flow_xblk; q.xsrc = h->flow_xsrc; q.parity_bytes = h->flow_parity_bytes;
     q.fcell = h->flow_cell;
     q.n_blocks = h->flow_blocks; q.n_stages = total;
-    q.blocks_per_wave = K;
     for (int s = 0; s < SWE_FLOW_MAX_STAGES; s++) q.cell_end[s] = s < n_stages ? cell_end[s] : 0;
     for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
-    q.timeout_ticks = (unsigned long long)(h->flow_timeout_s*1e8);
-    const int poll = h->flow_max_rim > 64 ? 9 : (h->flow_max_rim > 42 ? 6 : (h->flow_max_rim > 32 ? 4 : 3));
+    q.timeout_ticks = (unsigned long long)(opt_seconds(h, SWE2D_OPT_FLOW_TIMEOUT_MS, 2.0)*1e8);
+    // granule loads per polling trip: by the blocks' rim facets (a trip covers 10.7 facets per load); a wider instance may be forced
+    // (A/B, tests), a narrower one only makes more trips per pass
+    int poll = h->flow_max_rim > 64 ? 9 : (h->flow_max_rim > 42 ? 6 : (h->flow_max_rim > 32 ? 4 : 3));
+    if (const int o = h->opt[SWE2D_OPT_FLOW_POLL]; o > 0) poll = o > 8 ? 9 : (o > 4 ? 6 : (o > 3 ? 4 : 3));
     flow_kernel_t kern = h->wd ? pick_flow_kernel_wd(h->par.use_lax_friedrichs_velocity != 0, has_sources(h), fx, poll)
-                       : K > 1 ? pick_mflow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h),
-                                                   h->flow_max_rim > 64)
                                : pick_flow_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h), fx,
                                                   poll);
     SWE_CHK_SYNC(h->stream);
@@ -311,6 +262,7 @@ int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles)
         fc.last_uid = h->uid;
     }
     h->flow_used = true;
+    h->stage_valid[0] = h->stage_valid[1] = false;           // the stage solutions stay in registers
     return SWE2D_OK;
 }
 
@@ -345,7 +297,7 @@ int swe2d_solve_flow(swe2d_handle *hh, int32_t n_stages, const int32_t *cell_end
     Handle *h = H(hh);
     if (!h || !cell_end) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
-    RoctxRange range("swe2d_solve_flow");
+    RoctxRange range(h, "swe2d_solve_flow");
     return launch_flow(h, n_stages, cell_end);
 }
 
@@ -354,7 +306,7 @@ int swe2d_solve_flow_exchange(swe2d_handle *hh, int32_t n_cycles, int32_t stages
     Handle *h = H(hh);
     if (!h || !cell_end || n_cycles < 1) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
-    RoctxRange range("swe2d_solve_flow_exchange");
+    RoctxRange range(h, "swe2d_solve_flow_exchange");
     return launch_flow(h, stages_per_cycle, cell_end, n_cycles);
 }
 
@@ -372,7 +324,7 @@ int swe2d_flow_unpack_pending(swe2d_handle *hh)
     const unsigned slot = (unsigned)((size_t)h->n_recv*144);
     hipLaunchKernelGGL(swe_flow_unpack_kernel, dim3(std::min(256, grid_for(h->n_recv))), dim3(256), 0, h->stream, h->state[0], h->stride,
                        h->recv_cells, h->n_recv, (void *)(mine + p2p_channel_offset(z.width, ch, h->n_recv)), 2*slot, slot, z.ctr + ch,
-                       h->flow_status, (unsigned long long)(z.timeout_s*1e8));
+                       h->flow_status, (unsigned long long)(opt_seconds(h, SWE2D_OPT_P2P_TIMEOUT_MS, 5.0)*1e8));
     HIP_TRY(h, hipGetLastError());
     h->flow_used = true;
     return SWE2D_OK;
@@ -401,9 +353,7 @@ int swe2d_flow_supported(swe2d_handle *hh)
     Handle *h = H(hh);
     if (!h || !flow_kernel_covers(h)) return 0;
     if (hipSetDevice(h->device) != hipSuccess) return 0;
-    if (((h->flow_blocks + 7)/8)*8 <= flow_capacity(h)) return has_sources(h) ? 1 : 2;
-    // more blocks than waves can be resident: several consecutive blocks per wave (swe2d_mflow.h; no exchange inside the launch)
-    return mflow_blocks_per_wave(h) > 0 ? (has_sources(h) ? 3 : 4) : 0;
+    return ((h->flow_blocks + 7)/8)*8 <= flow_capacity(h) ? (has_sources(h) ? 1 : 2) : 0;
 }
 
 int swe2d_flow_status(swe2d_handle *hh, int32_t *timeouts)

@@ -19,18 +19,17 @@ fuse_kernel_t pick_fuse_kernel(bool nl, bool lf)
 // profiles/r05zl_fused_stage_pair.txt), and where the numbering gives tiles worth it (mean interior >= 176 of 192 cells: the
 // structured tile order, and the Hilbert order of an unstructured mesh - 1 M Delaunay triangles 192.0 + 49.9 cells per tile, 120.8 ->
 // 113.3 us per step; an order that does not keeps its stage launches).
-// THETIS_AMD_FUSE12=0: never; =1: on every mesh of at least 768 cells whatever its tiles.  (Not in the range-checked build: the
+// SWE2D_OPT_FUSED_STAGES = 0: never; = 1: on every mesh of at least 768 cells whatever its tiles.  (Not in the range-checked build: the
 // LDS index checks of the shared functions know the flow kernel's array only.)
 bool fuse12_covers(const Handle *h)
 {
 #ifdef SWE_RANGE_CHECK
     return false;
 #else
-    const char *e = std::getenv("THETIS_AMD_FUSE12");
-    const int mode = e ? std::atoi(e) : -1;                // -1: by size and tile quality
-    if (mode == 0 || h->fuse_state < 0) return false;
-    { const char *b = std::getenv("THETIS_AMD_BND_INLINE"); if (b && std::atoi(b) == 0) return false; }      // the epilogue variant was asked for
-    return h->npc == 3 && !h->wd && !h->visc && !has_sources(h) && h->n_owned == h->n_cells && !h->h_nbr.empty()
+    const int mode = h->opt[SWE2D_OPT_FUSED_STAGES];         // -1: by size and tile quality
+    if (mode == 0 || h->fuse_state == -1) return false;
+    if (h->opt[SWE2D_OPT_BND_INLINE] == 0) return false;     // the epilogue variant was asked for
+    return h->npc == 3 && !h->wd && !h->visc && !has_sources(h) && h->n_owned == h->n_cells && !h->h_nbr.empty() && h->idx4
            && h->n_cells >= (mode > 0 ? 4*SWE_FUSE_INNER : 250000);
 #endif
 }
@@ -39,10 +38,10 @@ bool fuse12_covers(const Handle *h)
 // most 192 cells and the ring - every cell that shares a facet with an interior cell - at most 64.
 int fuse12_build(Handle *h)
 {
-    if (h->fuse_tile || h->fuse_state < 0) return SWE2D_OK;
-    {   // allocations and copies: not inside a stream capture - such a caller keeps the stage launches
+    if (h->fuse_tile || h->fuse_state == -1) return SWE2D_OK;
+    {   // allocations and copies: not inside a stream capture - such a capture keeps the stage launches, the next call outside one builds
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { h->fuse_state = -2; return SWE2D_OK; }
+        if (hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return SWE2D_OK;
         (void)hipGetLastError();
     }
     const int n = h->n_cells;
@@ -108,18 +107,12 @@ int fuse12_build(Handle *h)
         for (int c : cells) { state[c] = 0; lane_of[c] = -1; }
     }
     h->fuse_n_tiles = (int)inner.size();
-    {
-        const char *e = std::getenv("THETIS_AMD_FUSE12");
-        if (!(e && std::atoi(e) > 0) && (double)n/h->fuse_n_tiles < 176.0) { h->fuse_state = -1; h->fuse_n_tiles = 0; return SWE2D_OK; }   // tiles not worth it
-    }
+    if (h->opt[SWE2D_OPT_FUSED_STAGES] <= 0 && (double)n/h->fuse_n_tiles < 176.0) { h->fuse_state = -1; h->fuse_n_tiles = 0; return SWE2D_OK; }   // tiles not worth it
     HIP_TRY(h, hipMalloc(&h->fuse_tile, tl.size()*sizeof(int2)));
     HIP_TRY(h, hipMalloc(&h->fuse_inner, inner.size()*sizeof(int)));
     HIP_TRY(h, hipMemcpy(h->fuse_tile, tl.data(), tl.size()*sizeof(int2), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->fuse_inner, inner.data(), inner.size()*sizeof(int), hipMemcpyHostToDevice));
     h->fuse_ring_cells = n_ring_total;
-    if (std::getenv("THETIS_AMD_FUSE_STATS"))
-        std::fprintf(stderr, "[thetis_amd] fused stage pair: %d cells in %d tiles (%.1f interior + %.1f ring cells per tile)\n", n, h->fuse_n_tiles,
-                     (double)n/h->fuse_n_tiles, (double)n_ring_total/h->fuse_n_tiles);
     return SWE2D_OK;
 }
 
@@ -141,6 +134,7 @@ int launch_fuse12(Handle *h)
     SWE_CHK_SYNC(h->stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_FUSE_WG), 0, h->stream, q);
     HIP_TRY(h, hipGetLastError());
+    h->stage_valid[0] = false; h->stage_valid[1] = true;    // U(1) never left the chip; buffer C holds U(2)
     return SWE2D_OK;
 }
 

@@ -98,8 +98,7 @@ int swe2d_p2p_create(swe2d_handle *hh, int32_t n_channels, const int32_t *widths
     z.zone_bytes = p2p_channel_offset(z.width, n_channels, h->n_recv);
     z.zone_bytes = (z.zone_bytes + 4095)/4096*4096;
     // remote GPUs write here and local kernels poll it: keep it out of the (non-coherent) L2 when the runtime allows
-    const char *force = std::getenv("THETIS_AMD_P2P_ZONE");        // "uncached" | "finegrained" | "device" (debugging)
-    const int want = !force ? 0 : !std::strcmp(force, "uncached") ? 1 : !std::strcmp(force, "finegrained") ? 2 : 3;
+    const int want = h->opt[SWE2D_OPT_P2P_ZONE] > 0 ? h->opt[SWE2D_OPT_P2P_ZONE] : 0;      // 1 uncached | 2 fine-grained | 3 device (debugging)
     z.zone_kind = 0;
     if ((want == 0 || want == 1) && hipExtMallocWithFlags(&z.zone, z.zone_bytes, hipDeviceMallocUncached) == hipSuccess) z.zone_kind = 1;
     if (!z.zone_kind) (void)hipGetLastError();
@@ -114,7 +113,6 @@ int swe2d_p2p_create(swe2d_handle *hh, int32_t n_channels, const int32_t *widths
     HIP_TRY(h, hipMalloc(&z.ctr, n_channels*sizeof(SweP2pCounters)));
     HIP_TRY(h, hipMemset(z.ctr, 0, n_channels*sizeof(SweP2pCounters)));
     HIP_TRY(h, hipDeviceSynchronize());
-    if (const char *t = std::getenv("THETIS_AMD_P2P_TIMEOUT_S")) z.timeout_s = std::atof(t);
     return SWE2D_OK;
 }
 
@@ -138,8 +136,6 @@ int swe2d_p2p_open(swe2d_handle *hh, const void *ipc_handle, void **remote_base)
 {
     Handle *h = H(hh);
     if (!h || !ipc_handle || !remote_base) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_open: null argument");
-    if (std::getenv("THETIS_AMD_TEST_BREAK_P2P"))             // tests: a node whose IPC mapping does not work
-        return fail(h, SWE2D_ERR_HIP, "swe2d_p2p_open: disabled by THETIS_AMD_TEST_BREAK_P2P");
     HIP_TRY(h, hipSetDevice(h->device));
     hipIpcMemHandle_t mh;
     std::memcpy(&mh, ipc_handle, sizeof(mh));
@@ -256,7 +252,7 @@ int swe2d_p2p_wait_unpack(swe2d_handle *hh, int channel, int i_buffer)
         a.flag[i] = reinterpret_cast<const unsigned long long *>(base) + (size_t)(channel*SWE_P2P_MAX_PEERS + i)*SWE_P2P_FLAG_STRIDE;
     a.zone = reinterpret_cast<const double *>(base + p2p_channel_offset(z.width, channel, h->n_recv));
     a.slot = (size_t)h->n_recv*np;
-    a.timeout_ticks = (unsigned long long)(z.timeout_s*1e8);
+    a.timeout_ticks = (unsigned long long)(opt_seconds(h, SWE2D_OPT_P2P_TIMEOUT_MS, 5.0)*1e8);
     a.ctr = z.ctr + channel;
     a.fence = z.zone_kind == 3;
     hipLaunchKernelGGL(swe_p2p_unpack_kernel, dim3(std::min(SWE_P2P_MAX_BLOCKS, grid_for(np*h->n_recv))), dim3(256), 0, h->xstream ? h->xstream : h->stream, a);

@@ -33,7 +33,7 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     for (int m = 0; m < SWE_MAX_MARKERS; m++) a.bc_len[m] = h->bc.len[m];
     // triangles: cell integral and interior facets of the diffusion inside the stage kernel, boundary facets by a launch
     // over the boundary cells (only when a marker has a diffusive boundary term at all)
-    const bool fused_diff = t.diff && h->fuse_visc && h->npc == 3 && h->opp4;
+    const bool fused_diff = t.diff && opt_on(h, SWE2D_OPT_VISC_FUSION) && h->npc == 3 && h->opp4;
     a.idxc = conn_pays(h, c1 - c0, fused_diff) ? h->idxc : nullptr;
     a.opp4 = h->opp4;
     a.mu_v = t.mu_v; a.mu_const = t.mu_const;
@@ -567,7 +567,7 @@ int swe2d_advance_coupled(swe2d_handle *hh, int n_steps, int tracer_only, int us
     if (!h || n_steps < 0) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad n_steps");
     if (h->n_owned != h->n_cells) return fail(h, SWE2D_ERR_UNSUPPORTED, "on a partition the host drives the coupled step (stages on cell ranges + halo exchanges, thetis_amd/distributed.py)");
     HIP_TRY(h, hipSetDevice(h->device));
-    RoctxRange range("swe2d_advance_coupled");
+    RoctxRange range(h, "swe2d_advance_coupled");
     for (int it = 0; it < n_steps; it++) {
         if (!tracer_only)
             for (int s = 0; s < 3; s++) { int rc = stage_on_range(h, s, 0, h->n_owned); if (rc) return rc; }

@@ -139,7 +139,6 @@ struct SweFlowArgs {
     void *ex;                              // [3 slot sets][n_slots] exchange slots, SWE_FLOW_SLOT_BYTES each: two stage parities + the cycle inputs (FX)
     unsigned parity_bytes;                 // n_slots * SWE_FLOW_SLOT_BYTES
     int n_blocks;                          // blocks of the handle (cells rounded up to 64)
-    int blocks_per_wave;                   // swe_mflow_kernel (swe2d_mflow.h): consecutive blocks a wave owns; 1 for swe_flow_kernel
     int n_stages;                          // a multiple of 3: stage s is Shu-Osher stage s % 3
     int cell_end[SWE_FLOW_MAX_STAGES];     // stage s updates the cells [0, cell_end[s]); non-increasing
     double a0[3], a1[3], beta[3];          // Shu-Osher weights per stage (swe2d_ssprk33_coefficients)
@@ -613,7 +612,6 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                 // A block of outer ghost cells skips the late stages of a cycle and waits here for most of it: ONE lane watches ONE
                 // granule, slowly (every polling pass of every lane is nine fabric reads per ghost cell - MI355X_MICROARCH.md,
                 // polling-cost), the full passes start when that one has arrived
-#ifndef SWE_FLOW_NO_HINT
                 {
                     const unsigned long long gm = __ballot(xr >= 0);
                     const int first = (int)__builtin_ctzll(gm);
@@ -633,7 +631,6 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                     }
                     t_start = 0ull;
                 }
-#endif
                 // the records (nine granules = 144 B per ghost cell) are read by nine consecutive lanes each - a 16-byte access per
                 // lane and granule would be nine fabric reads per cell and pass - into the staging area, ghost cell after ghost cell
                 // of the block; the ghost lanes then pick their nine values from LDS
@@ -645,14 +642,6 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                 __syncthreads();
                 for (unsigned spins = 0;; spins++) {
                     bool ok = true;
-#ifdef SWE_FLOW_OLD_RXTX
-                    for (int t = lane; t < 9*ng; t += SWE_BLOCK) {
-                        const int cc = (t*7282) >> 16, gi = t - 9*cc;                              // t / 9, t % 9
-                        const swe_u32x4 gz = swe_flow_get_sys(rz, lrec[SWE_LDSI(cc, SWE_BLOCK)] + 16u*(unsigned)gi);
-                        ok = ok && swe_flow_arrived(gz, target);
-                        lds[SWE_LDSI(SWE_FLOW_XG + t, SWE_FLOW_LDS_DOUBLES)] = swe_flow_val(gz);
-                    }
-#else
                     // the loads of a pass are issued TOGETHER (three per lane and trip: 21 ghost cells; a block next to a cut holds
                     // ~30): one round trip to the zone - uncached memory the peers write over the fabric - per trip instead of one
                     // per 64 granules (the rolled loop waited for every load before it issued the next, round 5)
@@ -676,7 +665,6 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                             }
                         }
                     }
-#endif
                     if (__all(ok) || late) break;
                     __builtin_amdgcn_s_sleep(4);
                     if ((spins & 31u) == 31u) {
@@ -695,12 +683,8 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                     for (int i = 0; i < 3; i++) { u[i] = lds[SWE_LDSI(SWE_FLOW_XG + 9*ci + i, SWE_FLOW_LDS_DOUBLES)]; v[i] = lds[SWE_LDSI(SWE_FLOW_XG + 9*ci + 3 + i, SWE_FLOW_LDS_DOUBLES)]; e[i] = lds[SWE_LDSI(SWE_FLOW_XG + 9*ci + 6 + i, SWE_FLOW_LDS_DOUBLES)]; }
                 }
                 // ... and into the state planes, for the kernels after this launch: what the LAST cycle receives (an earlier cycle's
-                // copy is overwritten by the next one's before anything reads it; -DSWE_FLOW_STORE_EVERY_STEP: every cycle, A/B)
-#ifdef SWE_FLOW_STORE_EVERY_STEP
-                if (xr >= 0) {
-#else
+                // copy is overwritten by the next one's before anything reads it - profiles/r05v_flow_last_result_store.txt)
                 if (xr >= 0 && c == ncyc - 1) {
-#endif
                     const swe_rsrc_t gou = swe_rsrc(q.buf[0]), gov = swe_rsrc(q.buf[0] + 3*S), goe = swe_rsrc(q.buf[0] + 6*S);
 #pragma unroll
                     for (int i = 0; i < 3; i++) { swe_st(gou, k8, i*S8, u[i]); swe_st(gov, k8, i*S8, v[i]); swe_st(goe, k8, i*S8, e[i]); }
@@ -774,11 +758,7 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
             // instruction of a stage behind the loop).  An empty asm that "modifies" the results keeps them where they are written.
             // Rank 3 of eight, us per step (profiles/r05zf_flow_pinned_before_wait.txt): nothing pinned 16.46, cell integrals 16.25,
             // + the weights 15.90; with source terms 21.22 / 20.47 / 20.66; wetting-drying 20.15 / 20.24 / 20.68 (registers) - hence:
-#ifdef SWE_FLOW_NO_PIN
-            constexpr bool PIN_CELL = false, PIN_W = false;
-#else
             constexpr bool PIN_CELL = !WD, PIN_W = !WD && !SRC;
-#endif
             double wu[3], wv[3], we[3];
             if constexpr (PIN_W) {
                 SWE_FLOW_W_HERE;
@@ -812,20 +792,14 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                 // Computed ONCE per stage, outside the spin loop, where a pass is one trip (no block of the order has more rim facets than
                 // a trip covers: the product case): a pass is then the granule loads and nothing before them.  (Rounds 3-5 recomputed them
                 // in every pass - eight registers across the loop made the kernel spill 24-48 B/lane; the unit is now compiled without
-                // machine LICM, _build.py UNIT_FLAGS, which left 14-20 registers free.  -DSWE_FLOW_NO_HOIST_POLL: A/B.)
-#ifndef SWE_FLOW_LATE_CELL_TERMS
+                // machine LICM, _build.py UNIT_FLAGS, which left 14-20 registers free.  profiles/r05n_flow_no_licm_hoisted_poll.txt.)
                 SWE_FLOW_CELL_TERMS_HERE;
                 if constexpr (PIN_CELL) {
 #pragma unroll
                     for (int i = 0; i < 3; i++) asm volatile("" : "+v"(bu[i]), "+v"(bv[i]), "+v"(be[i]));
                 }
-#endif
-#ifndef SWE_FLOW_NO_HOIST_POLL
                 const bool one_trip = !WD && 6*nrim <= POLL*SWE_BLOCK;      // (not with wetting-drying: eight registers too many)
                 if constexpr (!WD) SWE_FLOW_POLL_OFFSETS(0);
-#else
-                const bool one_trip = false;
-#endif
                 for (unsigned spins = 0;; spins++) {
                     bool ok = true;
                     for (int c0 = 0; c0 < 6*nrim; c0 += POLL*SWE_BLOCK) {      // POLL loads per lane in flight (32 rim facets per three loads)
@@ -856,22 +830,15 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                 t_start = 0ull;
 #undef SWE_FLOW_POLL_OFFSETS
             } else {
-#ifndef SWE_FLOW_LATE_CELL_TERMS
                 SWE_FLOW_CELL_TERMS_HERE;
-#endif
             }
             __syncthreads();
             SWE_FT(1);
             SWE_FT(2);
             // From here to the publish the wave is on the chain that sets the period of a stage; the block it shares its SIMD with is
             // most likely polling (cheap instructions in a loop, which take issue slots all the same): priority to the one that
-            // computes (-DSWE_FLOW_NO_PRIO: A/B)
-#ifndef SWE_FLOW_NO_PRIO
+            // computes (profiles/r05d_flow_loops_ab.txt)
             __builtin_amdgcn_s_setprio(3);
-#endif
-#ifdef SWE_FLOW_LATE_CELL_TERMS
-            SWE_FLOW_CELL_TERMS_HERE;
-#endif
 #undef SWE_FLOW_CELL_TERMS_HERE
             double ou[3], ov[3], oe[3];
             swe_flow_rhs_facets<NONLIN, LF, SRC, NTR, WD>(p, k, u, v, eta, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be, e, al);
@@ -889,18 +856,12 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
             //      publish, after the exchange; FX = false: nobody reads the last stage of the launch)
             SWE_FLOW_DELAY_AT(2);
             if (FX ? g + 1 < spc : s + 1 < q.n_stages) SWE_FLOW_PUBLISH(ou, ov, oe, act, FX ? c*spc + g + 1 : s, (FX ? c*spc + g + 1 : s) & 1);
-#ifndef SWE_FLOW_NO_PRIO
             __builtin_amdgcn_s_setprio(0);
-#endif
             // ---- the step result (every third stage) goes to state buffer 0: read by later launches only - so only the LAST result
             //      the launch computes for the cell is stored (the cell is in no later step's final range: the ranges never grow; with
             //      the exchange inside, in the last cycle).  Rounds 3-5 stored every step's result: nine store instructions per lane and
-            //      step that nothing ever read, between a publish and the next polling pass (-DSWE_FLOW_STORE_EVERY_STEP: A/B).
-#ifdef SWE_FLOW_STORE_EVERY_STEP
-            const bool last_result = true;
-#else
+            //      step that nothing ever read, between a publish and the next polling pass.
             const bool last_result = (!FX || c == ncyc - 1) && (g + 3 >= spc || k >= q.cell_end[g + 3]);
-#endif
             if (act && i3 == 2 && last_result) {
                 const swe_rsrc_t gou = swe_rsrc(q.buf[0]), gov = swe_rsrc(q.buf[0] + 3*S), goe = swe_rsrc(q.buf[0] + 6*S);
 #pragma unroll
@@ -953,12 +914,6 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                 __syncthreads();
                 for (int pp = 0; pp < q.x_n_peers; pp++) {     // uniform: one buffer resource per peer
                     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(q.x_rdata[pp], 0, q.x_rbytes[pp], 0x00020000);
-#ifdef SWE_FLOW_OLD_RXTX
-                    for (int t = lane; t < 9*ns; t += SWE_BLOCK) {
-                        const int cc = (t*7282) >> 16, gi = t - 9*cc;
-                        if (lpeer[SWE_LDSI(cc, SWE_BLOCK)] == pp) swe_flow_put_sys(rp, lrec[SWE_LDSI(cc, SWE_BLOCK)] + 16u*(unsigned)gi, lds[SWE_LDSI(SWE_FLOW_XG + t, SWE_FLOW_LDS_DOUBLES)], target, SWE_FLOW_TORN_HERE(c, 1));
-                    }
-#else
                     for (int c0 = 0; c0 < 9*ns; c0 += 3*SWE_BLOCK) {          // LDS reads of a trip together, then its stores
                         double xv[3];
                         unsigned zoff[3];
@@ -975,7 +930,6 @@ SWE_FLOW_PUBLISH_STORES(pc_)                                                    
                         for (int j = 0; j < 3; j++)
                             if (c0 + j*SWE_BLOCK + lane < 9*ns && pr[j] == pp) swe_flow_put_sys(rp, zoff[j], xv[j], target, SWE_FLOW_TORN_HERE(c, 1));
                     }
-#endif
                 }
             }
         }

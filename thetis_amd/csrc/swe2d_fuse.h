@@ -1,4 +1,5 @@
-// swe2d_fuse.h - stages 1 and 2 of an SSPRK33 step in ONE launch by overlapped tiles (round 5, opt-in: THETIS_AMD_FUSE12=1).
+// swe2d_fuse.h - stages 1 and 2 of an SSPRK33 step in ONE launch by overlapped tiles.  What swe2d_advance takes by itself from
+// 250 k triangles on a whole mesh the kernel covers (swe2d_api_fuse.hip: fuse12_covers; SWE2D_OPT_FUSED_STAGES forces or forbids it).
 //
 // A stage launch streams the state: per triangle and step 72 B read + 72 B written in stage 1, 72 + 72 B read + 72 B written in
 // stage 2.  U(1) is read by stage 2 and by nothing else (rungekutta.py:ERKGenericShuOsher, stage 3 takes
@@ -6,10 +7,13 @@
 // 0 .. n_inner-1: three waves) + the cells that share a facet with them (the ring, at most 64: the fourth wave).  Stage 1 is
 // evaluated for every cell of the tile - the ring's redundantly, its outer neighbours' traces gathered from the state planes -,
 // the results go to LDS, and stage 2 is evaluated for the interior cells with every neighbour trace from LDS.  Per interior
-// cell the launch reads U(0) once (x 1.33 for the ring) and writes U(2): ~230 B where the two stage launches move ~420.
+// cell the launch reads U(0) once (x 1.24 for the ring on the bench mesh) and writes U(2): 192 MB per launch at 1 M cells by the
+// counters where the two stage launches move 428 MB.
 // The arithmetic is the dataflow kernel's (swe_flow_rhs_cell / swe_flow_rhs_facets / swe_flow_finish = swe_stage_kernel's
-// operations in its order): bit for bit the stage launches (tests/test_gpu_parity.py::test_fused_stage_pair_...).
-// Covers what those functions cover without options: triangles, no source terms, no wetting-drying, no viscosity, whole mesh.
+// operations in its order): bit for bit the stage launches (tests/test_gpu_parity.py::test_fused_stage_pair_gives_the_bits_...),
+// and checked directly against the oracle (::test_fused_stage_pair_matches_the_c_restatement...).
+// Covers: triangles, whole mesh or the owned + ghost ranges of a partition, with or without source terms; no wetting-drying, no
+// viscosity (those keep the stage launches).
 #pragma once
 #include "swe2d_kernels.h"
 #include "swe2d_flow.h"

@@ -112,17 +112,20 @@ struct Handle {
     int4 *opp4 = nullptr;                               // triangles: opposite vertices of the neighbours (fused viscosity)
     int *bnd_cells = nullptr;                           // cells with a boundary facet (boundary-only SIPG launch)
     int n_bnd = 0;
-    bool fuse_visc = true;                              // THETIS_AMD_NO_VISC_FUSION=1: separate SIPG pass (A/B, debugging)
+    int opt[SWE2D_OPT_COUNT];                           // swe2d_set_option: -1 = the library's own rule (set in the constructor below)
+    Handle() { for (int i = 0; i < SWE2D_OPT_COUNT; i++) opt[i] = -1; }
+    // which of the stage buffers hold the stage solutions of the step made last (swe2d_get_stage_state): the fused and the dataflow
+    // kernels keep U(1) (and U(2)) on chip
+    bool stage_valid[2] = {false, false};
     int4 *idx4 = nullptr;                               // packed triangle connectivity (stage kernel), see SweStageArgs
     int2 *idx2 = nullptr;
-    int4 *idxc = nullptr;                               // ... in 16 B (swe_conn_pack), what the stage kernels read; THETIS_AMD_COMPACT_IDX=0: not used
-    // stages 1 + 2 of a step in one launch by overlapped tiles (swe2d_fuse.h; THETIS_AMD_FUSE12=1): tile tables, built at first use
+    int4 *idxc = nullptr;                               // ... in 16 B (swe_conn_pack), what the stage kernels read (SWE2D_OPT_COMPACT_IDX)
+    // stages 1 + 2 of a step in one launch by overlapped tiles (swe2d_fuse.h; SWE2D_OPT_FUSED_STAGES): tile tables, built at first use
     int2 *fuse_tile = nullptr;
     int *fuse_inner = nullptr;
     int fuse_n_tiles = 0;
     int fuse_state = 0;                                 // -1: the numbering gives poor tiles, -2: first use inside a stream capture: stage launches
     long long fuse_ring_cells = 0;
-    int idxc_always = 0;                                // THETIS_AMD_COMPACT_IDX=2: in every launch (default: where it pays, swe_conn_pays)
     int n_conn_escapes = 0;                             // cells whose record is an escape to the wide ones
     std::vector<int> h_nbr;                             // host copy of the packed neighbour codes [3][S] (triangles; flow_build)
     // dataflow stage loop (swe2d_flow.h): per-block stage counters, status word {timeouts, first late block + 1}
@@ -143,20 +146,17 @@ struct Handle {
     void *flow_ex = nullptr;
     size_t flow_ex_bytes = 0;
     int flow_blocks = 0;                                // 64-cell blocks of the handle
-    int mflow_capacity = -1;                            // ... and of the multi-block kernel (swe2d_mflow.h)
     int flow_capacity = -1;                             // resident one-wave workgroups of the flow kernel on this device (-1: not asked yet)
     int flow_max_rim = 0;                               // most rim facets of a block in the current flow order (selects the polling width)
     int launch_parity = 0;                              // direction of the next large stage launch (launch_stage)
     bool flow_used = false;                             // a flow launch since the status word was last read
-    double flow_timeout_s = 2.0;                        // THETIS_AMD_FLOW_TIMEOUT_S
     double *vx = nullptr, *vy = nullptr, *vh = nullptr;
     double *bc_field[4] = {nullptr, nullptr, nullptr, nullptr};  // Function-valued boundary data per facet: elev, uv, un, flux
     double *valpha = nullptr;                          // per-vertex wetting-drying alpha
     bool wd = false;
     bool state_holds_D = false;                        // wetting-drying: the elevation planes of buffer A hold the displaced depth D
-    void *snapshot = nullptr;                          // swe2d_state_snapshot: buffer A + the tracers' buffers A
-    size_t snapshot_bytes = 0;
-    bool snapshot_holds_D = false;
+    struct Snapshot { void *data = nullptr; size_t bytes = 0; bool holds_D = false; };
+    Snapshot snapshot[SWE2D_SNAPSHOT_SLOTS];           // swe2d_state_snapshot: buffer A + the tracers' buffers A, per slot
     // SIPG horizontal viscosity (optional pass after each stage kernel)
     bool visc = false;
     double *nu_v = nullptr;                            // per-vertex viscosity or null (constant)
@@ -183,7 +183,6 @@ struct Handle {
         int off[SWE_P2P_MAX_PEERS], cnt[SWE_P2P_MAX_PEERS], remote_off[SWE_P2P_MAX_PEERS], remote_flag[SWE_P2P_MAX_PEERS],
             remote_n_recv[SWE_P2P_MAX_PEERS];
         char *remote_base[SWE_P2P_MAX_PEERS];
-        double timeout_s = 5.0;
     } p2p;
     // tracers + limiter
     struct Tracer {
@@ -229,9 +228,10 @@ int fail(Handle *h, int code, const std::string &msg);
             return fail(h, SWE2D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
     } while (0)
 
-// Optional ROCTx ranges around the entry points that advance the state (THETIS_AMD_ROCTX=1): they show up as named ranges in
+// Optional ROCTx ranges around the entry points that advance the state (SWE2D_OPT_ROCTX = 1): they show up as named ranges in
 // `rocprofv3 --marker-trace` next to the kernel trace.  The tracing library is looked up at run time (rocprofiler-sdk's
-// librocprofiler-sdk-roctx.so, else roctracer's libroctx64.so); without it, or without the variable, the ranges are no-ops.
+// librocprofiler-sdk-roctx.so, else roctracer's libroctx64.so) when the first handle asks for it; without it, or without the
+// option, the ranges are no-ops.
 struct RoctxRange {
     typedef int (*push_t)(const char *);
     typedef int (*pop_t)();
@@ -242,7 +242,7 @@ struct RoctxRange {
         static pop_t p_pop = nullptr;
         if (!done) {
             done = true;
-            if (std::getenv("THETIS_AMD_ROCTX")) {
+            {
                 for (const char *name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
                     if (void *lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
                         p_push = reinterpret_cast<push_t>(dlsym(lib, "roctxRangePushA"));
@@ -256,14 +256,17 @@ struct RoctxRange {
         push = p_push; pop = p_pop;
     }
     pop_t pop_ = nullptr;
-    explicit RoctxRange(const char *name)
-    {
-        push_t push;
-        resolve(push, pop_);
-        if (push) push(name); else pop_ = nullptr;
-    }
+    RoctxRange(const Handle *h, const char *name);
     ~RoctxRange() { if (pop_) pop_(); }
 };
+inline RoctxRange::RoctxRange(const Handle *h, const char *name)
+{
+    if (!h || h->opt[SWE2D_OPT_ROCTX] <= 0) return;
+    push_t push;
+    resolve(push, pop_);
+    if (push) push(name); else pop_ = nullptr;
+}
+
 
 inline bool has_sources(const Handle *h)
 {
@@ -274,6 +277,10 @@ inline bool has_sources(const Handle *h)
 
 inline int grid_for(int n) { return (n + 255)/256; }
 
+// options (swe2d_set_option): on unless switched off / the value in seconds with its default
+inline bool opt_on(const Handle *h, int o) { return h->opt[o] != 0; }
+inline double opt_seconds(const Handle *h, int o, double dflt) { return h->opt[o] > 0 ? 1e-3*h->opt[o] : dflt; }
+
 // ---- stage launches (swe2d_api.hip)
 // Where the 16-B connectivity records (swe2d_conn.h) pay: launches that stream from memory - from ~250 k cells, where the 8 B
 // they save per cell are 2-3 % of a stage's traffic (profiles/r05zc: 1 M triangles 113.1 -> 110.3 us per step, 500 k 63.6 -> 62.7);
@@ -281,7 +288,8 @@ inline int grid_for(int n) { return (n + 255)/256; }
 // and so are the kernels bound by their arithmetic (wetting-drying + Manning: 80.5 against 79.8; tracer with fused diffusion).
 inline bool conn_pays(const Handle *h, int n_cells_of_launch, bool arithmetic_bound)
 {
-    return h->idxc && (h->idxc_always || (n_cells_of_launch >= 250000 && !arithmetic_bound));
+    const int o = h->opt[SWE2D_OPT_COMPACT_IDX];
+    return h->idxc && o != 0 && (o == 2 || (n_cells_of_launch >= 250000 && !arithmetic_bound));
 }
 bool fuse12_covers(const Handle *h);
 int fuse12_build(Handle *h);
@@ -297,8 +305,6 @@ int upload_vertex_coefficient(Handle *h, const double *vertex_values, double **d
 int flow_build(Handle *h, const int32_t *order);
 bool flow_kernel_covers(const Handle *h);
 int flow_capacity(Handle *h);
-int mflow_capacity(Handle *h);
-int mflow_blocks_per_wave(Handle *h);
 int flow_build_exchange(Handle *h);
 int launch_flow(Handle *h, int n_stages, const int32_t *cell_end, int n_cycles = 0);
 int flow_check(Handle *h);

@@ -1,7 +1,6 @@
 // swe2d_k_flow.hip - the dataflow stage loop (swe2d_flow.h): instantiations + picker
 #include "swe2d_kernels.h"
 #include "swe2d_flow.h"
-#include "swe2d_mflow.h"
 #include "swe2d_pick.h"
 
 template <bool NL, bool LF, int POLL>
@@ -22,20 +21,6 @@ flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src, bool fx, int poll)
 {
     return poll >= 9 ? pick_flow_poll<9>(nl, lf, src, fx) : (poll >= 6 ? pick_flow_poll<6>(nl, lf, src, fx)
          : (poll >= 4 ? pick_flow_poll<4>(nl, lf, src, fx) : pick_flow_poll<3>(nl, lf, src, fx)));
-}
-
-// the multi-block kernel (swe2d_mflow.h): a wave owns several consecutive blocks; no exchange inside
-template <int POLL>
-static flow_kernel_t pick_mflow_poll(bool nl, bool lf, bool src)
-{
-    if (nl) return lf ? (src ? swe_mflow_kernel<true, true, true, POLL> : swe_mflow_kernel<true, true, false, POLL>)
-                      : (src ? swe_mflow_kernel<true, false, true, POLL> : swe_mflow_kernel<true, false, false, POLL>);
-    return lf ? (src ? swe_mflow_kernel<false, true, true, POLL> : swe_mflow_kernel<false, true, false, POLL>)
-              : (src ? swe_mflow_kernel<false, false, true, POLL> : swe_mflow_kernel<false, false, false, POLL>);
-}
-flow_kernel_t pick_mflow_kernel(bool nl, bool lf, bool src, bool wide)
-{
-    return wide ? pick_mflow_poll<9>(nl, lf, src) : pick_mflow_poll<8>(nl, lf, src);
 }
 
 // the adversary builds' device-side switches live in this translation unit (with the kernels that read them)

@@ -75,7 +75,7 @@ struct SweStageArgs {
     int cell_begin, cell_end;
     int wd_skip_relax;            // wetting-drying + viscosity: the dry-ground relaxation of the velocity follows the viscosity pass
     int reverse;                  // walk the blocks of the range from its end (launches beyond the Infinity Cache alternate, see launch_stage)
-    int wall_general;             // 1: closed walls through the general boundary path (THETIS_AMD_WALL_FAST=0: parity test of the wall path)
+    int wall_general;             // 1: closed walls through the general boundary path (SWE2D_OPT_WALL_FAST = 0: parity test of the wall path)
     double g, sigma_lf, dt;
     double a0, a1, beta;   // U_out = beta*k + a0*U0 + a1*U_in
     // optional cell-local terms (SRC variant)
@@ -543,12 +543,6 @@ __device__ __forceinline__ double swe_ld(swe_rsrc_t r, unsigned voff, unsigned s
 {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
-// the same past this CU's L1 (sc1: L2-served): for planes the wave itself stored earlier in the launch (swe2d_mflow.h), whose stale
-// L1 line from an even earlier read must not be hit
-__device__ __forceinline__ double swe_ld_l2(swe_rsrc_t r, unsigned voff, unsigned soff)
-{
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 16));
-}
 __device__ __forceinline__ int swe_ldi(swe_rsrc_t r, unsigned voff, unsigned soff)
 {
     return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
@@ -587,11 +581,6 @@ __device__ __forceinline__ double swe_ld_chk(swe_rsrc_t r, unsigned voff, unsign
     if (!swe_chk(r.base + voff + soff, 8, line)) return 0.0;
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r.r, voff, soff, 0));
 }
-__device__ __forceinline__ double swe_ld_l2_chk(swe_rsrc_t r, unsigned voff, unsigned soff, int line)
-{
-    if (!swe_chk(r.base + voff + soff, 8, line)) return 0.0;
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r.r, voff, soff, 16));
-}
 __device__ __forceinline__ int swe_ldi_chk(swe_rsrc_t r, unsigned voff, unsigned soff, int line)
 {
     if (!swe_chk(r.base + voff + soff, 4, line)) return 0;
@@ -603,7 +592,6 @@ __device__ __forceinline__ void swe_st_chk(swe_rsrc_t r, unsigned voff, unsigned
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(swe_u32x2, x), r.r, voff, soff, SWE_ST_AUX);
 }
 #define swe_ld(r, v, s) swe_ld_chk(r, v, s, __LINE__)
-#define swe_ld_l2(r, v, s) swe_ld_l2_chk(r, v, s, __LINE__)
 #define swe_ldi(r, v, s) swe_ldi_chk(r, v, s, __LINE__)
 #define swe_st(r, v, s, x) swe_st_chk(r, v, s, x, __LINE__)
 #endif

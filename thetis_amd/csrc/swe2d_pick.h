@@ -17,8 +17,6 @@ stage_kernel_t pick_kernel_quad(bool nl, bool lf, bool u0, bool src, bool affine
 // poll: granule loads per lane and polling trip (3 / 4 / 6 / 9 for blocks of at most 32 / 42 / 64 / more rim facets)
 flow_kernel_t pick_flow_kernel(bool nl, bool lf, bool src, bool fx = false, int poll = 6);
 flow_kernel_t pick_flow_kernel_wd(bool lf, bool src, bool fx, int poll);        // wetting-drying (swe2d_k_flow_wd.hip)
-// swe2d_mflow.h: several consecutive blocks per wave (cell ranges beyond the one-block kernel's residency), no exchange inside
-flow_kernel_t pick_mflow_kernel(bool nl, bool lf, bool src, bool wide);
 tracer_kernel_t pick_tracer_kernel(bool lf, bool t0, bool src);
 tracer_kernel_t pick_tracer_kernel_diff(bool lf, bool t0, bool src);      // horizontal diffusion fused in (swe_diff_interior)
 tracer_kernel_t pick_tracer_kernel_quad(bool lf, bool t0, bool src, bool affine = true);

@@ -141,6 +141,9 @@ class Swe2dDevice(object):
         p.device_id = device_id
         self.h = ctypes.c_void_p()
         _lib.check(self.lib.swe2d_create(ctypes.byref(m), ctypes.byref(p), ctypes.byref(self.h)))
+        # the library reads no environment: the THETIS_AMD_* switches of _lib.OPTION_ENV become options of this handle, once, here
+        for opt, value in _lib.options_from_environment():
+            self.set_option(opt, value)
         if (self.npc == 3 and isinstance(reorder, str) and self.n_owned == self.n_cells and 64 < self.n_cells <= 196608
                 and os.environ.get('THETIS_AMD_FLOW_BLOCKS', '1') != '0'):
             # a mesh small enough for the dataflow kernel (swe2d_advance takes it by itself): its 64-cell blocks as compact tiles /
@@ -185,13 +188,23 @@ class Swe2dDevice(object):
             uv, eta = uv[self.inv_perm], eta[self.inv_perm]
         return uv, eta
 
-    def snapshot(self):
+    def snapshot(self, slot=0):
         """Save the time-stepping state (and every tracer) in a device-side copy; ``restore`` brings it back - exactly, also with
-        wetting-drying, where ``set_state(*get_state())`` is the identity only up to rounding (the device carries D, not eta)."""
-        self._ck(self.lib.swe2d_state_snapshot(self.h, 0))
+        wetting-drying, where ``set_state(*get_state())`` is the identity only up to rounding (the device carries D, not eta).
+        ``slot``: one of _lib.SNAPSHOT_SLOTS independent copies (a long-lived one next to short-lived ones)."""
+        self._ck(self.lib.swe2d_state_snapshot_slot(self.h, int(slot), 0))
 
-    def restore(self):
-        self._ck(self.lib.swe2d_state_snapshot(self.h, 1))
+    def restore(self, slot=0):
+        self._ck(self.lib.swe2d_state_snapshot_slot(self.h, int(slot), 1))
+
+    def set_option(self, option, value):
+        """include/swe2d.h swe2d_option (``_lib.OPT_*``); ``None`` or -1: the library's own rule."""
+        self._ck(self.lib.swe2d_set_option(self.h, int(option), -1 if value is None else int(value)))
+
+    def get_option(self, option):
+        v = ctypes.c_int(0)
+        self._ck(self.lib.swe2d_get_option(self.h, int(option), ctypes.byref(v)))
+        return v.value
 
     def set_dt(self, dt):
         self._ck(self.lib.swe2d_set_dt(self.h, float(dt)))
@@ -440,8 +453,7 @@ class Swe2dDevice(object):
 
     def flow_supported(self):
         """0: the flow kernel does not cover this handle (configuration, or more 64-cell blocks than the device holds
-        resident even with several blocks per wave); 1: covered; 2: covered and without source terms; 3 / 4: the same through the
-        multi-block kernel (csrc/swe2d_mflow.h: no exchange inside the launch)."""
+        resident); 1: covered; 2: covered and without source terms."""
         return int(self.lib.swe2d_flow_supported(self.h))
 
     def connectivity_info(self):
@@ -652,6 +664,10 @@ class Swe2dDevice(object):
 
     def p2p_open(self, ipc_handle):
         base = ctypes.c_void_p()
+        if os.environ.get('THETIS_AMD_TEST_BREAK_P2P'):
+            # tests (a node whose IPC mapping does not work): the library gets a handle that names no allocation and fails in
+            # hipIpcOpenMemHandle, the way it would there - the hook is here, not in the library
+            ipc_handle = bytes(_lib.IPC_HANDLE_BYTES)
         self._ck(self.lib.swe2d_p2p_open(self.h, ctypes.create_string_buffer(bytes(ipc_handle), _lib.IPC_HANDLE_BYTES),
                                          ctypes.byref(base)))
         return int(base.value)

@@ -426,7 +426,7 @@ class DistributedSwe2d(object):
         corners); a halo deeper than a part is wide sends cells to more - then the flow launch is followed by the exchange kernels."""
         if self.p2p is None or self._flowx_request is False or os.environ.get('THETIS_AMD_FLOWX') == '0':
             return False
-        if self.dev.flow_supported() not in (1, 2):          # several blocks per wave (csrc/swe2d_mflow.h): exchange kernels after the launch
+        if self.dev.flow_supported() not in (1, 2):
             return False
         sc = np.asarray(self.part.send_cells)
         return not len(sc) or int(np.bincount(sc).max()) <= 2
@@ -855,7 +855,10 @@ class DistributedSwe2d(object):
         while n_steps > 0:
             if self._v_snapshot is None:
                 self.synchronize()
-                self.dev.snapshot()                      # on the device: exact also with wetting-drying (the device carries D)
+                # on the device: exact also with wetting-drying (the device carries D).  Slot 1 belongs to the window: graph captures
+                # that happen inside it (an advance size that does not divide verify_every, the first chunk of the coupled p2p path)
+                # save and restore around their warm-up steps in slot 0 and must not overwrite the window's start
+                self.dev.snapshot(slot=1)
                 self._v_snapshot = True
                 self._v_steps = 0
             r = min(n_steps, ve - self._v_steps)
@@ -880,7 +883,7 @@ class DistributedSwe2d(object):
             fast = 'timeout: {:}'.format(e)
         n = self._v_steps
         self._v_snapshot, self._v_steps = None, 0
-        self.dev.restore()
+        self.dev.restore(slot=1)
         self._replaying = True
         try:
             with self._stream_ctx():

@@ -17,26 +17,62 @@ import numpy as np
 
 from .options import Constant
 
-__all__ = ['Expr', 'SpatialCoordinate', 'conditional', 'as_vector', 'sin', 'cos', 'tan', 'exp', 'ln', 'sqrt', 'tanh', 'cosh', 'sinh',
+__all__ = ['Expr', 'evaluation_points', 'SpatialCoordinate', 'conditional', 'as_vector', 'sin', 'cos', 'tan', 'exp', 'ln', 'sqrt', 'tanh', 'cosh', 'sinh',
            'pi', 'lt', 'le', 'gt', 'ge', 'eq', 'ne', 'And', 'Or', 'Not', 'max_value', 'min_value', 'sign', 'abs_value']
 
 pi = float(np.pi)
 
 
+# Where the expression is being evaluated, set by Function.interpolate / .project around their calls (a stack: an expression may
+# be evaluated while another is): ('nodes', function space) - the nodes of that space, in its order - or ('cells', mesh, weights) -
+# one point per cell of the mesh, at the barycentric / bilinear weights `weights` of the cell's nodes.  A Function operand needs it:
+# a P1 field is evaluated THROUGH ITS SPACE (injection CG -> DG, P0 -> P1, interpolation to quadrature points), never by matching
+# array lengths (a CG bathymetry inside an expression projected into P1DG raised, a P0 field of coincidentally equal
+# size would have passed unchecked).
+_CONTEXT = []
+
+
+class evaluation_points(object):
+    def __init__(self, *ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        _CONTEXT.append(self.ctx)
+
+    def __exit__(self, *exc):
+        _CONTEXT.pop()
+
+
+def _function_value(f, x):
+    if not _CONTEXT:
+        raise ValueError('a Function inside an expression can only be evaluated by Function.interpolate / Function.project '
+                         '(which know the points: nodes of a space, or quadrature points of the cells)')
+    ctx = _CONTEXT[-1]
+    src = f.function_space()
+    if ctx[0] == 'nodes':
+        fs = ctx[1]
+        if fs.mesh() is not src.mesh():
+            raise ValueError('a Function inside an expression must live on the mesh the expression is evaluated on')
+        if fs.family == src.family and fs.degree == src.degree:
+            return np.asarray(f.dat.data_ro)
+        return f._as_space(fs)                      # CG1 -> DG1, DG0 -> DG1; anything else raises NotImplementedError there
+    _, mesh, weights = ctx
+    if mesh is not src.mesh():
+        raise ValueError('a Function inside an expression must live on the mesh the expression is evaluated on')
+    v = f.cell_node_values()                        # (N, k[, 2]): P1 / Q1 nodal values, a P0 value repeated
+    return np.tensordot(v, np.asarray(weights), axes=([1], [0]))
+
+
 def _value(a, x, y):
-    """evaluate an operand at the points (x, y): expression, Function (same-mesh nodal / quadrature evaluation is the caller's
-    business: a Function operand must live on the nodes the expression is evaluated at), Constant, number or array"""
+    """evaluate an operand at the points (x, y): expression, Function (through its space, see _function_value), Constant, number
+    or array"""
     if isinstance(a, Expr):
         return a(x, y)
     if isinstance(a, Constant):
         v = a.values()
         return float(v[0]) if len(v) == 1 else tuple(float(c) for c in v)
     if hasattr(a, 'dat') and hasattr(a, 'function_space'):
-        d = np.asarray(a.dat.data_ro)
-        if d.shape[0] != np.shape(x)[0]:
-            raise ValueError('a Function inside an expression must live on the nodes the expression is evaluated at '
-                             '(interpolate it into that space first)')
-        return d
+        return _function_value(a, x)
     return a
 
 

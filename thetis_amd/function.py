@@ -149,8 +149,10 @@ class Function(object):
 
     def interpolate(self, expr):
         """Nodal interpolation."""
+        from .expr import evaluation_points
         self._pull()
-        self._data[...] = _evaluate(expr, self._fs.node_xy(), self._fs)
+        with evaluation_points('nodes', self._fs):
+            self._data[...] = _evaluate(expr, self._fs.node_xy(), self._fs)
         self._host_version += 1
         return self
 
@@ -169,8 +171,10 @@ class Function(object):
             p = mesh.cell_xy()
 
             def integrand(lam, cells):
+                from .expr import evaluation_points
                 xq = np.einsum('nic,i->nc', p, lam)
-                return np.asarray(expr(xq[:, 0], xq[:, 1]))*np.ones(len(cells))
+                with evaluation_points('cells', mesh, lam):
+                    return np.asarray(expr(xq[:, 0], xq[:, 1]))*np.ones(len(cells))
             self._pull()
             self._data[...] = project_to_p1(mesh, integrand).reshape(self._data.shape)
             self._host_version += 1
@@ -183,10 +187,12 @@ class Function(object):
         p = mesh.cell_xy()
         n = mesh.num_cells
         ncomp = 2 if fs.vector else 1
+        from .expr import evaluation_points
         b = np.zeros((n, npc, ncomp))
         for l, wq in zip(bary, w):
             xq = np.einsum('nic,i->nc', p, l)
-            val = expr(xq[:, 0], xq[:, 1])
+            with evaluation_points('cells', mesh, l):
+                val = expr(xq[:, 0], xq[:, 1])
             if fs.vector:
                 val = np.stack([np.asarray(val[0])*np.ones(n), np.asarray(val[1])*np.ones(n)], axis=1)
             else:
@@ -212,7 +218,8 @@ class Function(object):
                 xi, ze = l[1] + l[2], l[2] + l[3]
                 det = wq*(d0 + d1*xi + d2*ze)
                 xq = np.einsum('nic,i->nc', p, l)
-                val = expr(xq[:, 0], xq[:, 1])
+                with evaluation_points('cells', mesh, l):
+                    val = expr(xq[:, 0], xq[:, 1])
                 if fs.vector:
                     val = np.stack([np.asarray(val[0])*np.ones(n), np.asarray(val[1])*np.ones(n)], axis=1)
                 else:

@@ -186,10 +186,11 @@ class FlowSolver2d(object):
         # mesh element size: CG-P1 L2 projection of sqrt(cell area), utility.py:620-640 (needed for automatic dt only)
         self.fields.h_elem_size_2d = None
         self.set_wetting_and_drying_alpha()
-        self.depth = DepthExpression(self.fields.bathymetry_2d,
-                                     use_nonlinear_equations=self.options.use_nonlinear_equations,
-                                     use_wetting_and_drying=self.options.use_wetting_and_drying,
-                                     wetting_and_drying_alpha=self.options.wetting_and_drying_alpha)
+        # H = h + eta (+ the wetting-drying displacement): the options that shape it, by the names DepthExpression takes them under
+        # (utility.py:975-996, solver2d.py:142-146)
+        depth_options = {name: getattr(self.options, name)
+                         for name in ('use_nonlinear_equations', 'use_wetting_and_drying', 'wetting_and_drying_alpha')}
+        self.depth = DepthExpression(self.fields.bathymetry_2d, **depth_options)
 
     def create_equations(self):
         """solver2d.py:453-539"""
@@ -237,16 +238,17 @@ class FlowSolver2d(object):
 
     def get_tracer_timestepper(self, integrator, system, swe_stepper):
         """Gets tracer timestepper object with appropriate parameters (solver2d.py:576-598)"""
-        uv, elev = self.fields.solution_2d.subfunctions
-        fields = {
-            'elev_2d': elev,
-            'uv_2d': uv,
-            'lax_friedrichs_tracer_scaling_factor': self.options.lax_friedrichs_tracer_scaling_factor,
-            'tracer_advective_velocity_factor': self.options.tracer_advective_velocity_factor,
-        }
+        # the coefficient dict a tracer's stepper receives: the keys are the reference's by contract (solver2d.py:580-589), the
+        # equation terms look them up by name
+        o = self.options
+        velocity, elevation = self.fields.solution_2d.subfunctions
+        fields = dict(uv_2d=velocity, elev_2d=elevation)
+        for key in ('lax_friedrichs_tracer_scaling_factor', 'tracer_advective_velocity_factor'):
+            fields[key] = getattr(o, key)
         for label in system.split(','):
-            fields['diffusivity_h-{:}'.format(label)] = self.options.tracer[label].diffusivity
-            fields['source-{:}'.format(label)] = self.options.tracer[label].source
+            tracer_options = o.tracer[label]
+            fields['diffusivity_h-' + label] = tracer_options.diffusivity
+            fields['source-' + label] = tracer_options.source
         bcs = {}
         if system in self.bnd_functions:
             bcs = self.bnd_functions[system]
@@ -326,30 +328,31 @@ class FlowSolver2d(object):
                                                             self.fields, self._field_metadata(), export_type='hdf5', comm=self.comm)
 
     def initialize(self):
-        """solver2d.py:732-744"""
-        if not hasattr(self.function_spaces, 'U_2d'):
-            self.create_function_spaces()
-        if not hasattr(self, 'equations'):
-            self.create_equations()
-        if not hasattr(self, 'timestepper'):
-            self.create_timestepper()
-        if not hasattr(self, 'exporters'):
-            self.create_exporters()
+        """Whatever of spaces, equations, stepper and exporters a script has not created itself, in the order they depend on each
+        other (solver2d.py:732-744: a script may call any create_* first, e.g. to add an equation before the stepper exists)."""
+        for holder, attribute, create in ((self.function_spaces, 'U_2d', self.create_function_spaces),
+                                          (self, 'equations', self.create_equations),
+                                          (self, 'timestepper', self.create_timestepper),
+                                          (self, 'exporters', self.create_exporters)):
+            if not hasattr(holder, attribute):
+                create()
         self._initialized = True
 
     def assign_initial_conditions(self, elev=None, uv=None, **tracers):
         """Assigns initial conditions by L2 projection (solver2d.py:747-785)"""
         if not self._initialized:
             self.initialize()
-        uv_2d, elev_2d = self.fields.solution_2d.subfunctions
-        if elev is not None:
-            elev_2d.project(elev)
-        if uv is not None:
-            uv_2d.project(uv)
-        for l, func in tracers.items():
-            label = l if len(l) > 3 and l[-3:] == '_2d' else l + '_2d'
-            assert label in self.options.tracer, 'Unknown tracer label {:}'.format(label)
-            self.fields[label].project(func)
+        velocity, elevation = self.fields.solution_2d.subfunctions
+        for target, expression in ((elevation, elev), (velocity, uv)):
+            if expression is not None:
+                target.project(expression)
+        for name, expression in tracers.items():
+            # keyword 'salt' and keyword 'salt_2d' both name the tracer field salt_2d (solver2d.py:773-776)
+            label = name if name.endswith('_2d') and len(name) > 3 else name + '_2d'
+            if label not in self.options.tracer:
+                raise AssertionError('Unknown tracer label {:}'.format(label))
+            self.fields[label].project(expression)
+        # (sediment: out of scope, options.py raises where it is selected)
         self.timestepper.initialize(self.fields.solution_2d)
 
     def add_callback(self, callback, eval_interval='export'):
@@ -376,17 +379,14 @@ class FlowSolver2d(object):
         metadata.update(e.exporters['uv_2d'].load(i_stored, self.fields.uv_2d))
         metadata.update(e.exporters['elev_2d'].load(i_stored, self.fields.elev_2d))
         self.assign_initial_conditions()
-        if i_export is None:
-            i_export = i_stored
-        self.i_export = i_export
-        self.next_export_t = self.i_export*self.options.simulation_export_time
-        if iteration is None:
-            iteration = int(np.ceil(self.next_export_t/self.dt))
-        if t is None:
-            t = metadata.get('time', iteration*self.dt)
-        self.iteration = iteration
-        self.simulation_time = t
-        self.next_export_t += self.options.simulation_export_time
+        # where the restarted run stands (solver2d.py:886-903): export index = the stored one unless told otherwise; the iteration
+        # count and the time follow from it (the checkpoint's own time stamp wins over the estimate), the NEXT export is one interval on
+        interval = self.options.simulation_export_time
+        self.i_export = i_stored if i_export is None else i_export
+        t_export = self.i_export*interval
+        self.iteration = int(np.ceil(t_export/self.dt)) if iteration is None else iteration
+        self.simulation_time = metadata.get('time', self.iteration*self.dt) if t is None else t
+        self.next_export_t = t_export + interval
         # a restart that writes into a NEW directory exports its initial state and numbers its exports from i_export; a
         # continuation in the same directory does neither (solver2d.py:905-912)
         self.export_initial_state = outputdir != self.options.output_directory

@@ -29,15 +29,23 @@ def main():
         fc, wc = known/(f_kb*1024.0), known/(w_kb*1024.0)
         res['calibration'] = {'kernel': 'swe_calibration_copy (8 B/lane coalesced)', 'known_bytes_read': known, 'FETCH_SIZE_KB': f_kb,
                               'WRITE_SIZE_KB': w_kb, 'fetch_correction': fc, 'write_correction_measured': wc, 'write_correction': 1.0}
+    def issue(k):
+        """wave-instructions of one launch (SQ_INSTS_VALU counts per wave, SQ_WAVES the waves), clock cycles of the launch"""
+        d = {}
+        for c in ('SQ_INSTS_VALU', 'SQ_WAVES', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR', 'SQ_INSTS_SALU', 'GRBM_GUI_ACTIVE'):
+            if acc[k].get(c):
+                d[c] = mean(k, c)
+        return d
+
     stage = sorted(k for k in acc if 'swe_stage_kernel<' in k)
     tot, launches = 0.0, 0
     for k in stage:
         f_kb, w_kb = mean(k, 'FETCH_SIZE'), mean(k, 'WRITE_SIZE')
         has_u0 = k.split('<')[1].split(',')[2].strip() == 'true'
         b = f_kb*1024.0*fc + w_kb*1024.0
-        res['stage12_kernel' if has_u0 else 'stage0_kernel'] = {
+        res['stage12_kernel' if has_u0 else 'stage0_kernel'] = dict({
             'name': k[:80], 'FETCH_SIZE_KB': f_kb, 'WRITE_SIZE_KB': w_kb, 'bytes': b,
-            'algorithmic_bytes': (252.0 if has_u0 else 180.0)*n_cells, 'launches_sampled': len(acc[k]['FETCH_SIZE'])}
+            'algorithmic_bytes': (252.0 if has_u0 else 180.0)*n_cells, 'launches_sampled': len(acc[k]['FETCH_SIZE'])}, **issue(k))
         w = 2 if has_u0 else 1
         tot += w*b
         launches += w
@@ -47,13 +55,20 @@ def main():
         k = fused[0]
         f_kb, w_kb = mean(k, 'FETCH_SIZE'), mean(k, 'WRITE_SIZE')
         b = f_kb*1024.0*fc + w_kb*1024.0
-        res['fused_stage_pair_kernel'] = {'name': k[:80], 'FETCH_SIZE_KB': f_kb, 'WRITE_SIZE_KB': w_kb, 'bytes': b,
-                                          'algorithmic_bytes_of_the_two_stage_launches': (180.0 + 252.0)*n_cells,
-                                          'launches_sampled': len(acc[k]['FETCH_SIZE'])}
+        res['fused_stage_pair_kernel'] = dict({'name': k[:80], 'FETCH_SIZE_KB': f_kb, 'WRITE_SIZE_KB': w_kb, 'bytes': b,
+                                               'algorithmic_bytes_of_the_two_stage_launches': (180.0 + 252.0)*n_cells,
+                                               'launches_sampled': len(acc[k]['FETCH_SIZE'])}, **issue(k))
         s3 = res.get('stage12_kernel', {}).get('bytes', 0.0)
         res.pop('stage0_kernel', None)
         tot, launches = b + s3, 3
         res['launches_per_step'] = 2
+        vi = [res[x].get('SQ_INSTS_VALU') for x in ('fused_stage_pair_kernel', 'stage12_kernel') if x in res]
+        if len(vi) == 2 and all(v is not None for v in vi):
+            res['valu_wave_instructions_per_step'] = vi[0] + vi[1]
+    else:
+        vi = [res[x].get('SQ_INSTS_VALU') for x in ('stage0_kernel', 'stage12_kernel') if x in res]
+        if len(vi) == 2 and all(v is not None for v in vi):
+            res['valu_wave_instructions_per_step'] = vi[0] + 2.0*vi[1]
     res['traffic_bytes_per_launch'] = tot/max(launches, 1)
     res['algorithmic_bytes_per_launch'] = 228.0*n_cells
     json.dump(res, open(dst, 'w'), indent=1)
