@@ -89,7 +89,8 @@ typedef enum {
  * solver_parameters / PyOP2 configuration a script may pass, thetis/options.py:145-152). */
 typedef enum {
     SWE2D_OPT_FUSED_STAGES = 0,   /* stages of a step in one launch by overlapped tiles (csrc/swe2d_fuse.h): -1 from 250 k triangles
-                                     when the numbering gives compact tiles, 0 never, 1 on every mesh the kernel covers */
+                                     when the numbering gives compact tiles, 0 never, 1 on every mesh the kernel covers,
+                                     3: all three stages in one launch (whole meshes, swe2d_fused_triple_info) */
     SWE2D_OPT_FLOW = 1,           /* swe2d_advance takes the dataflow stage loop (csrc/swe2d_flow.h) where it applies: -1 / 1 yes, 0 no */
     SWE2D_OPT_FLOW_WD = 2,        /* ... also with wetting-drying: -1 / 1 yes, 0 no */
     SWE2D_OPT_BND_INLINE = 3,     /* triangle stage kernels: boundary facets from registers (1) or by the epilogue that reloads them (0);
@@ -151,13 +152,24 @@ int  swe2d_abi_version(void);
  * of cells whose differences did not fit and which read the 24-B record after all.  Results do not depend on it. */
 int  swe2d_connectivity_info(swe2d_handle *h, int32_t out[2]);
 /* Stages 1 and 2 of a step in ONE launch by overlapped tiles (csrc/swe2d_fuse.h: 192 interior cells + their ring per workgroup,
- * the first stage's result never leaves the chip), stage 3 as a stage launch: what swe2d_advance does from 250 k triangles on a
- * whole mesh without source terms, wetting-drying or viscosity, when the cell numbering gives compact tiles (SWE2D_OPT_FUSED_STAGES = 0:
+ * the first stage's result never leaves the chip), stage 3 as a stage launch: what swe2d_advance and swe2d_advance_coupled do from
+ * 250 k triangles without wetting-drying or viscosity (source terms are covered), when the cell numbering gives compact tiles, and
+ * what swe2d_solve_stage_pair_cells does on a partition of that size (SWE2D_OPT_FUSED_STAGES = 0:
  * never, = 1: on every such mesh).  Same results bit for bit; the intermediate stage_sol[0] = U(1) then never reaches the state buffers
  * (swe2d_get_stage_state(h, 0) after such a step returns SWE2D_ERR_UNSUPPORTED, not a stale buffer).
  * out[0] = 1 when swe2d_advance would take it now (builds the tile tables on first use), out[1] = tiles, out[2] = ring cells
  * (cells evaluated redundantly in stage 1), out[3] = cells. */
 int  swe2d_fused_pair_info(swe2d_handle *h, int32_t out[4]);
+/* The tiles are cut from consecutive cells of an ORDER (default: the numbering of swe2d_mesh, NULL restores it): a partition whose
+ * ghost layers are appended to its numbering layer by layer passes one in which every ghost cell sits next to the owned cells it
+ * touches (cf. swe2d_flow_set_order).  Results do not depend on it.  Drops tile tables built before; synchronises the stream. */
+int  swe2d_fused_set_order(swe2d_handle *h, const int32_t *cells_in_tile_order);
+/* ALL three stages of a step in one launch (SWE2D_OPT_FUSED_STAGES = 3; csrc/swe2d_fuse.h swe_fuse123_kernel: tiles of interior +
+ * two rings, U(1) and U(2) stay on chip, U(3) goes to the second state buffer and the two change places - so not inside a stream
+ * capture, where swe2d_advance keeps the fused pair): opt-in, whole meshes; out[0] = 1 when swe2d_advance would take it now (builds
+ * the tile tables), out[1] = tiles, out[2] / out[3] = cells of the first / second rings (stage 1 is evaluated on interior + both,
+ * stage 2 on interior + the first).  Same results bit for bit. */
+int  swe2d_fused_triple_info(swe2d_handle *h, int32_t out[4]);
 int  swe2d_device_count(void);                                   /* number of visible HIP devices, <0 on error */
 
 /* Shu-Osher coefficients the stage kernels use (host-only, needs no device): stage i computes
@@ -397,6 +409,12 @@ int  swe2d_set_exchange_stream(swe2d_handle *h, void *hip_stream);
 int  swe2d_p2p_status(swe2d_handle *h, int64_t *epochs_sent, int64_t *epochs_received, int32_t *timeouts);
 /* ERKGenericShuOsher.solve_stage restricted to cells [cell_begin, cell_end) (may include ghost layers) */
 int  swe2d_solve_stage_cells(swe2d_handle *h, int i_stage, int32_t cell_begin, int32_t cell_end);
+/* solve_stage(0) on [0, cell_end_0) followed by solve_stage(1) on [0, cell_end_1) (rungekutta.py:930-946; cell_end_1 <= cell_end_0
+ * and every cell of the second range has its facet neighbours inside the first: the stage ranges of a partition's exchange cycle, or
+ * the whole mesh twice) as ONE launch by overlapped tiles where that kernel covers the handle (swe2d_fused_pair_info), as the two
+ * stage launches otherwise.  Either way state buffer 2 holds stage_sol[1] on [0, cell_end_1) afterwards, bit for bit the same;
+ * stage_sol[0] is only left behind by the stage launches. */
+int  swe2d_solve_stage_pair_cells(swe2d_handle *h, int32_t cell_end_0, int32_t cell_end_1);
 /* ForwardEuler (timeintegrator.py:115-165) on a partition: the step from state buffer 0 into buffer 1 on a cell range;
  * after the last range of a step swe2d_swap_state_buffers makes buffer 1 the state (halo pack / unpack take the buffer
  * index).  Not capturable in a replayed graph across an odd number of swaps. */

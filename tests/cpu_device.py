@@ -187,6 +187,10 @@ class CpuSwe2dDevice(object):
         ne = BE[i]*ke[s] + AL0[i]*self.E[0][s] + ALI[i]*self.E[src][s]
         self.U[dst][s], self.E[dst][s] = nu, ne
 
+    def solve_stage_pair_cells(self, end_0, end_1):
+        self.solve_stage_cells(0, 0, end_0)
+        self.solve_stage_cells(1, 0, end_1)
+
     def solve_stage(self, i):
         self.solve_stage_cells(i, 0, self.n_cells)
 

@@ -509,6 +509,36 @@ def test_ranks_on_one_gpu_with_peer_to_peer_halos(tmp_path, hip_lib, world, case
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('world,case,n_steps', [
+    (2, 'channel64+every2+p2p', 7), (2, 'channel64+every4', 9), (3, 'delaunay+p2p+graph', 4), (4, 'channel64+every2+overlap3+p2p+graph', 9),
+    (2, 'channel64+every2+p2p+capture', 8)])
+def test_ranks_on_one_gpu_with_the_fused_stage_pair(tmp_path, hip_lib, monkeypatch, world, case, n_steps):
+    """Stages 1 and 2 of every step of an exchange cycle as ONE launch by overlapped tiles on a partition (csrc/swe2d_fuse.h,
+    swe2d_solve_stage_pair_cells: tiles cut from an order in which the ghost layers sit next to the owned cells they touch, stage 2
+    on the shrinking range of its stage; forced here - ranks of the bench mesh take it from 250 k cells by themselves): bitwise the
+    single-device run, with host-staged and peer-to-peer halos, per-cycle graphs, overlap (the early stages stay stage launches) and
+    a capture outside advance()."""
+    from thetis_amd.device import Swe2dDevice
+    import dist_worker
+    monkeypatch.setenv('THETIS_AMD_FUSE12', '1')
+    base = case.split('+')[0]
+    dist_worker.CASE = base
+    mesh, bath, uv, eta = dist_worker._case()
+    run_workers(gpu_worker, world, n_steps, str(tmp_path), axis=0, case=case)
+    u_p, e_p, extra = gather(str(tmp_path), world, mesh.num_cells)
+    assert all(int(d['fused']) == 1 for d in extra), 'a rank did not take the fused stage pair'
+    monkeypatch.setenv('THETIS_AMD_FUSE12', '0')
+    monkeypatch.setenv('THETIS_AMD_FLOW', '0')
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev.set_state(uv, eta)
+    dev.advance(n_steps)
+    u_s, e_s = dev.get_state()
+    dev.close()
+    dist_worker.CASE = 'channel'
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,case,n_steps', [
     (2, 'channel+flow', 3), (2, 'channel+every2+flow', 5), (2, 'channel+p2p+flow', 3), (3, 'channel+every3+p2p+flow+graph', 11),
     (2, 'channel+every2+p2p+flow+nosplit+graph', 9), (2, 'channel+every4+p2p+flow+capture', 8), (3, 'delaunay+p2p+flow+graph', 2),
     (2, 'channel+p2p+flowx', 3), (2, 'channel+every2+p2p+flowx', 5), (3, 'channel+every3+p2p+flowx+graph', 11), (4, 'channel+every2+p2p+flowx', 24),

@@ -537,7 +537,8 @@ def test_compact_connectivity_gives_the_bits_of_the_wide_records(hip_lib, monkey
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize('case', ['structured', 'linear_no_lf', 'ragged_small', 'random_numbering', 'by_the_rule_270k'])
+@pytest.mark.parametrize('case', ['structured', 'linear_no_lf', 'ragged_small', 'random_numbering', 'by_the_rule_270k', 'sources', 'sources_by_the_rule_270k',
+                                  'coupled_by_the_rule_270k', 'tile_order'])
 def test_fused_stage_pair_gives_the_bits_of_the_stage_launches(hip_lib, monkeypatch, case):
     """csrc/swe2d_fuse.h: stages 1 and 2 of a step in one launch by overlapped tiles (192 interior cells + their ring per 256-lane
     workgroup, U(1) never leaves the chip), stage 3 as a stage launch - what swe2d_advance takes from 250 k cells where the kernel
@@ -563,9 +564,13 @@ def test_fused_stage_pair_gives_the_bits_of_the_stage_launches(hip_lib, monkeypa
         vinv[vperm] = np.arange(len(vperm))
         mesh = Mesh2d(m0.vertex_xy[vperm], vinv[m0.cells[cperm]], marker_fn=_rect_marker_fn(100e3, 80e3))
         bath, uv, eta, reorder = bath0[vperm], uv0[cperm], eta0[cperm], None
+    elif case in ('sources', 'tile_order'):
+        mesh, bath, uv, eta = channel_case(nx=120, ny=90, lx=100e3, ly=50e3, seed=8, amp_eta=0.3, amp_u=0.2)
     else:
         mesh, bath, uv, eta = channel_case(nx=450, ny=300, lx=100e3, ly=50e3, seed=5, amp_eta=0.3, amp_u=0.2)
         forced = None
+    from thetis_amd import _lib
+    cxy = mesh.cell_xy()
     out = []
     for fuse in ('0', forced):
         if fuse is None:
@@ -575,13 +580,102 @@ def test_fused_stage_pair_gives_the_bits_of_the_stage_launches(hip_lib, monkeypa
         dev = Swe2dDevice(mesh, bath, 0.5, reorder=reorder, **kw)
         dev.set_bc(2, {'elev': 0.1})
         dev.set_bc(3, {'un': 0.05})
+        if case.startswith('sources'):
+            # round 6: the SRC instances - a Coriolis field, Manning friction, wind stress, a linear drag field, atmospheric pressure
+            dev.set_field(_lib.FIELD_CORIOLIS, 1e-4*(1.0 + cxy[:, :, 1]/50e3))
+            dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+            dev.set_field(_lib.FIELD_WIND_STRESS, np.stack([0.1*np.sin(cxy[:, :, 0]/2e4), 0.05*np.cos(cxy[:, :, 1]/1e4)], axis=2))
+            dev.set_field(_lib.FIELD_LINEAR_DRAG, 1e-4*(1.0 + np.cos(cxy[:, :, 0]/3e4)))
+            dev.set_field(_lib.FIELD_ATMOSPHERIC_PRESSURE, 1e5 + 200.0*np.sin(cxy[:, :, 0]/2.5e4))
+        if case == 'tile_order' and fuse != '0':
+            # tiles cut from another order than the numbering (what a partition passes): same bits
+            dev.fused_set_order(np.random.default_rng(3).permutation(mesh.num_cells)[np.argsort(
+                np.random.default_rng(3).permutation(mesh.num_cells)//5000, kind='stable')])
+        dev.set_state(uv if not case.startswith('sources') else 0.1*uv, eta if not case.startswith('sources') else 0.1*np.abs(eta))
+        if fuse != '0':
+            assert dev.fused_pair_info()[0], case
+        if case.startswith('coupled'):
+            # round 6: swe2d_advance_coupled takes the fused pair for its shallow-water half (cfg 4 on triangles)
+            tid = dev.add_tracer()
+            dev.tracer_set_state(tid, np.where(cxy[:, :, 0] < 40e3, 0.0, 30.0))
+            dev.advance_coupled(3, tracer_only=False, use_limiter=True)
+            dev.advance_coupled(2, tracer_only=False, use_limiter=True)
+            out.append(dev.get_state() + (dev.tracer_get_state(tid),))
+        else:
+            dev.advance(3)
+            dev.advance(2)
+            out.append(dev.get_state())
+        dev.close()
+    assert np.isfinite(out[0][1]).all()
+    for a_, b_ in zip(out[0], out[1]):
+        assert np.array_equal(a_, b_)
+
+
+@pytest.mark.parametrize('case', ['structured', 'linear_no_lf', 'ragged_small', 'random_numbering', 'sources', 'bench_size_vs_oracle'])
+def test_fused_stage_triple_gives_the_bits_of_the_stage_launches(hip_lib, ref_so, monkeypatch, case):
+    """csrc/swe2d_fuse.h, swe_fuse123_kernel (round 6; SWE2D_OPT_FUSED_STAGES = 3): ALL three stages of a step in one launch, tiles of
+    interior + two rings in a 256-lane workgroup, U(1) and U(2) never leave the chip, U(3) into the second state buffer and the two
+    swap.  Bit for bit the three stage launches (open boundaries and walls, linear equations without Lax-Friedrichs, partial tiles,
+    a random numbering with tiny tiles, source terms; odd and even numbers of steps: the buffers change places every step), and at
+    1 M cells 20 steps against oracle/swe2d_ref.c at 1e-11."""
+    from thetis_amd import _lib
+    from thetis_amd.device import Swe2dDevice
+    from thetis_amd.mesh import Mesh2d, RectangleMesh, _rect_marker_fn
+    monkeypatch.setenv('THETIS_AMD_FLOW', '0')
+    kw, reorder = {}, 'auto'
+    if case == 'bench_size_vs_oracle':
+        mesh = RectangleMesh(1000, 500, 100e3, 50e3)
+        bath = np.full(mesh.num_vertices, 20.0)
+        uv, eta = _bump_state(mesh)
+        monkeypatch.setenv('THETIS_AMD_FUSE12', '3')
+        dev = Swe2dDevice(mesh, bath, 0.25)
+        dev.set_state(uv, eta)
+        dev.advance(20)
+        ud, ed = dev.get_state()
+        dev.close()
+        ur, er = make_ref(mesh, bath).advance(uv, eta, 0.25, 20)
+        assert rel_linf(ud, ur) < 1e-11 and rel_linf(ed, er) < 1e-11, (rel_linf(ud, ur), rel_linf(ed, er))
+        return
+    if case == 'structured':
+        mesh, bath, uv, eta = channel_case(nx=200, ny=120, lx=100e3, ly=50e3, seed=5, amp_eta=0.3, amp_u=0.2)
+    elif case == 'linear_no_lf':
+        mesh, bath, uv, eta = channel_case(nx=120, ny=90, lx=100e3, ly=50e3, seed=6, amp_eta=0.3, amp_u=0.2)
+        kw = dict(use_nonlinear_equations=False, use_lax_friedrichs_velocity=False)
+    elif case == 'ragged_small':
+        mesh, bath, uv, eta = channel_case(nx=53, ny=31, seed=5)
+    elif case == 'random_numbering':
+        m0, bath0, uv0, eta0 = channel_case(nx=90, ny=70, lx=100e3, ly=80e3, seed=6, amp_eta=0.3, amp_u=0.2)
+        rng = np.random.default_rng(11)
+        cperm, vperm = rng.permutation(m0.num_cells), rng.permutation(m0.num_vertices)
+        vinv = np.empty_like(vperm)
+        vinv[vperm] = np.arange(len(vperm))
+        mesh = Mesh2d(m0.vertex_xy[vperm], vinv[m0.cells[cperm]], marker_fn=_rect_marker_fn(100e3, 80e3))
+        bath, uv, eta, reorder = bath0[vperm], uv0[cperm], eta0[cperm], None
+    else:
+        mesh, bath, uv, eta = channel_case(nx=120, ny=90, lx=100e3, ly=50e3, seed=8, amp_eta=0.3, amp_u=0.2)
+        uv, eta = 0.1*uv, 0.1*np.abs(eta)
+    cxy = mesh.cell_xy()
+    out = []
+    for fuse in ('0', '3'):
+        monkeypatch.setenv('THETIS_AMD_FUSE12', fuse)
+        dev = Swe2dDevice(mesh, bath, 0.5, reorder=reorder, **kw)
+        dev.set_bc(2, {'elev': 0.1})
+        dev.set_bc(3, {'un': 0.05})
+        if case == 'sources':
+            dev.set_field(_lib.FIELD_CORIOLIS, 1e-4*(1.0 + cxy[:, :, 1]/50e3))
+            dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+            dev.set_field(_lib.FIELD_WIND_STRESS, np.stack([0.1*np.sin(cxy[:, :, 0]/2e4), 0.05*np.cos(cxy[:, :, 1]/1e4)], axis=2))
         dev.set_state(uv, eta)
         dev.advance(3)
         dev.advance(2)
-        out.append(dev.get_state())
+        a = dev.get_state()
+        dev.solve_stage(0); dev.solve_stage(1); dev.solve_stage(2)     # stage launches after an odd number of buffer swaps
+        dev.advance(1)
+        out.append(a + dev.get_state())
         dev.close()
     assert np.isfinite(out[0][1]).all()
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    for a_, b_ in zip(out[0], out[1]):
+        assert np.array_equal(a_, b_)
 
 
 def _bump_state(mesh, seed=1234):
@@ -726,13 +820,14 @@ def test_fused_stage_pair_is_what_a_large_plain_mesh_takes(hip_lib, monkeypatch)
     on, tiles, ring, cells = dev.fused_pair_info()
     assert on and cells == mesh.num_cells and cells/192.0 <= tiles < cells/176.0 and 0.15*cells < ring < 0.34*cells, (on, tiles, ring, cells)
     dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
-    assert not dev.fused_pair_info()[0]
-    dev.set_scalar(_lib.SCALAR_MANNING_DRAG, None)
+    assert dev.fused_pair_info()[0]                    # round 6: source terms are covered
+    dev.set_viscosity(1.0)
+    assert not dev.fused_pair_info()[0]                # viscosity is not
+    dev.set_viscosity(None)
     assert dev.fused_pair_info()[0]
-    monkeypatch.setenv('THETIS_AMD_FUSE12', '0')
+    dev.set_option(_lib.OPT_FUSED_STAGES, 0)
     assert not dev.fused_pair_info()[0]
     dev.close()
-    monkeypatch.delenv('THETIS_AMD_FUSE12', raising=False)
     small, bath_s, _, _ = channel_case(nx=300, ny=200, lx=100e3, ly=50e3, seed=5)                     # 120 k cells: the dataflow kernel's
     dev = Swe2dDevice(small, bath_s, 0.5)
     assert not dev.fused_pair_info()[0]

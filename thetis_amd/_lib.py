@@ -83,6 +83,9 @@ SYMBOLS = {
     'swe2d_abi_version': (ctypes.c_int, []),
     'swe2d_connectivity_info': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_fused_pair_info': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
+    'swe2d_fused_triple_info': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
+    'swe2d_fused_set_order': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
+    'swe2d_solve_stage_pair_cells': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_device_count': (ctypes.c_int, []),
     'swe2d_ssprk33_coefficients': (None, [_dp, _dp, _dp]),
     'swe2d_create': (ctypes.c_int, [ctypes.POINTER(Swe2dMesh), ctypes.POINTER(Swe2dParams), ctypes.POINTER(_H)]),

@@ -238,7 +238,8 @@ int swe2d_fused_pair_info(swe2d_handle *hh, int32_t out[4])
     Handle *h = H(hh);
     if (!h || !out) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     out[0] = out[1] = out[2] = 0; out[3] = h->n_cells;
-    if (!fuse12_covers(h) || advance_takes_flow(h)) return SWE2D_OK;       // (small meshes: the dataflow kernel comes first)
+    // (small whole meshes: swe2d_advance takes the dataflow kernel first; a partition's stage pairs are driven by the host)
+    if (!fuse12_covers(h) || (h->n_owned == h->n_cells && advance_takes_flow(h))) return SWE2D_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     if (int rc = fuse12_build(h)) return rc;
     if (h->fuse_tile) { out[0] = 1; out[1] = h->fuse_n_tiles; out[2] = (int32_t)h->fuse_ring_cells; }
@@ -524,7 +525,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->diag_acc, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->snapshot[0].data, h->snapshot[1].data, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->idxc, h->fuse_tile, h->fuse_inner, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->snapshot[0].data, h->snapshot[1].data, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->idxc, h->fuse_tile, h->fuse_inner, h->fuse3_tile, h->fuse3_cnt, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
     for (void *m : h->p2p.opened) (void)hipIpcCloseMemHandle(m);
@@ -901,24 +902,10 @@ int swe2d_advance(swe2d_handle *hh, int n_steps)
             return SWE2D_OK;
         }
     }
-    if (n_steps > 0 && fuse12_covers(h)) {
-        if (int rc = fuse12_build(h)) return rc;
-    }
-    if (n_steps > 0 && fuse12_covers(h) && h->fuse_tile) {
-        // stages 1 and 2 in one launch by overlapped tiles (swe2d_fuse.h), stage 3 as a stage launch: the same bits
-        for (int it = 0; it < n_steps; it++) {
-            int rc = launch_fuse12(h);
-            if (rc) return rc;
-            rc = stage_on_range(h, 2, 0, h->n_owned);
-            if (rc) return rc;
-        }
-        return SWE2D_OK;
-    }
+    // stages 1 and 2 in one launch by overlapped tiles (swe2d_fuse.h) + stage 3 as a stage launch where that kernel covers the
+    // handle, three stage launches otherwise: the same bits (step_swe, swe2d_api_fuse.hip)
     for (int it = 0; it < n_steps; it++)
-        for (int s = 0; s < 3; s++) {
-            int rc = stage_on_range(h, s, 0, h->n_owned);
-            if (rc) return rc;
-        }
+        if (int rc = step_swe(h)) return rc;
     return SWE2D_OK;
 }
 
@@ -965,7 +952,7 @@ int swe2d_advance_timed(swe2d_handle *hh, int n_steps, int per_launch, float *ms
     if (h->n_owned != h->n_cells)
         return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_advance_timed on a partition is not supported");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (!per_launch) {
+    if (!per_launch || h->opt[SWE2D_OPT_FUSED_STAGES] == 3) {     // (all stages in one launch: a step IS a launch)
         HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
         int rc = swe2d_advance(hh, n_steps);
         if (rc) return rc;
@@ -988,7 +975,7 @@ int swe2d_advance_timed(swe2d_handle *hh, int n_steps, int per_launch, float *ms
     for (int it = 0; it < n_steps; it++)
         for (int s = 0; s < lps; s++, l++) {
             HIP_TRY(h, hipEventRecord(ev[2*l], h->stream));
-            int rc = fused ? (s == 0 ? launch_fuse12(h) : stage_on_range(h, 2, 0, h->n_owned)) : stage_on_range(h, s, 0, h->n_owned);
+            int rc = fused ? (s == 0 ? launch_fuse12(h, h->n_owned) : stage_on_range(h, 2, 0, h->n_owned)) : stage_on_range(h, s, 0, h->n_owned);
             if (rc) return rc;
             HIP_TRY(h, hipEventRecord(ev[2*l + 1], h->stream));
         }

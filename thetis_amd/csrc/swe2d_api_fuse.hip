@@ -6,20 +6,24 @@ namespace swe2d_impl {
 
 namespace {
 typedef void (*fuse_kernel_t)(const SweFuseArgs);
-fuse_kernel_t pick_fuse_kernel(bool nl, bool lf)
+template <bool SRC>
+fuse_kernel_t pick_fuse_src(bool nl, bool lf)
 {
-    if (nl) return lf ? swe_fuse12_kernel<true, true> : swe_fuse12_kernel<true, false>;
-    return lf ? swe_fuse12_kernel<false, true> : swe_fuse12_kernel<false, false>;
+    if (nl) return lf ? swe_fuse12_kernel<true, true, SRC> : swe_fuse12_kernel<true, false, SRC>;
+    return lf ? swe_fuse12_kernel<false, true, SRC> : swe_fuse12_kernel<false, false, SRC>;
 }
+fuse_kernel_t pick_fuse_kernel(bool nl, bool lf, bool src) { return src ? pick_fuse_src<true>(nl, lf) : pick_fuse_src<false>(nl, lf); }
 }  // namespace
 
-// What the kernel covers: triangles, the whole mesh on one device, no source terms, no wetting-drying, no viscosity; taken from
+// What the kernel covers: triangles, no wetting-drying, no viscosity - with or without source terms (the SRC instances keep the 168
+// VGPRs / three workgroups per CU of the plain ones, tools/kres.py), the whole mesh or a partition's owned + ghost cells on its
+// shrinking stage ranges (round 6); taken from
 // 250 k cells, where a step streams from memory (same box, us per step, stage launches -> fused pair + stage 3, device numbering in
 // 16 x 6-quad tiles: 125 k cells 23.9 -> 24.1, 250 k 38.8 -> 37.0, 500 k 64.9 -> 61.1, 1 M 121.0 -> 107.3, 2 M 264 -> 235, 4 M 525 -> 477;
 // profiles/r05zl_fused_stage_pair.txt), and where the numbering gives tiles worth it (mean interior >= 176 of 192 cells: the
 // structured tile order, and the Hilbert order of an unstructured mesh - 1 M Delaunay triangles 192.0 + 49.9 cells per tile, 120.8 ->
 // 113.3 us per step; an order that does not keeps its stage launches).
-// SWE2D_OPT_FUSED_STAGES = 0: never; = 1: on every mesh of at least 768 cells whatever its tiles.  (Not in the range-checked build: the
+// SWE2D_OPT_FUSED_STAGES = 0: never; = 1: on every mesh (of at least 64 cells) whatever its tiles.  (Not in the range-checked build: the
 // LDS index checks of the shared functions know the flow kernel's array only.)
 bool fuse12_covers(const Handle *h)
 {
@@ -29,13 +33,15 @@ bool fuse12_covers(const Handle *h)
     const int mode = h->opt[SWE2D_OPT_FUSED_STAGES];         // -1: by size and tile quality
     if (mode == 0 || h->fuse_state == -1) return false;
     if (h->opt[SWE2D_OPT_BND_INLINE] == 0) return false;     // the epilogue variant was asked for
-    return h->npc == 3 && !h->wd && !h->visc && !has_sources(h) && h->n_owned == h->n_cells && !h->h_nbr.empty() && h->idx4
-           && h->n_cells >= (mode > 0 ? 4*SWE_FUSE_INNER : 250000);
+    return h->npc == 3 && !h->wd && !h->visc && !h->h_nbr.empty() && h->idx4
+           && h->n_cells >= (mode > 0 ? 64 : 250000);
 #endif
 }
 
-// Tiles: consecutive cells of the device numbering (compact patches in the tile-Hilbert order) as long as the interior holds at
-// most 192 cells and the ring - every cell that shares a facet with an interior cell - at most 64.
+// Tiles: consecutive cells of the device numbering (compact patches in the tile-Hilbert order) - or of the order handed in with
+// swe2d_fused_set_order: a partition's ghost layers are appended to its numbering layer by layer, strips one cell wide whose tiles
+// would be all ring - as long as the interior holds at most 192 cells and the ring - every cell that shares a facet with an
+// interior cell - at most 64.
 int fuse12_build(Handle *h)
 {
     if (h->fuse_tile || h->fuse_state == -1) return SWE2D_OK;
@@ -52,11 +58,12 @@ int fuse12_build(Handle *h)
     std::vector<int> state((size_t)n, 0), lane_of((size_t)n, -1);      // 0 outside | 1 interior | 2 ring, of the tile being built
     std::vector<int> ring, cells;
     long long n_ring_total = 0;
+    const int *order = (int)h->fuse_order.size() == n ? h->fuse_order.data() : nullptr;
     for (int pos = 0; pos < n;) {
         cells.clear(); ring.clear();
         int n_ring = 0;
         while (pos < n && (int)cells.size() < SWE_FUSE_INNER) {
-            const int kk = pos;
+            const int kk = order ? order[pos] : pos;
             int delta = state[kk] == 2 ? -1 : 0;
             for (int f = 0; f < 3; f++) {
                 const int code = nbr[(size_t)f*S + kk];
@@ -107,7 +114,12 @@ int fuse12_build(Handle *h)
         for (int c : cells) { state[c] = 0; lane_of[c] = -1; }
     }
     h->fuse_n_tiles = (int)inner.size();
-    if (h->opt[SWE2D_OPT_FUSED_STAGES] <= 0 && (double)n/h->fuse_n_tiles < 176.0) { h->fuse_state = -1; h->fuse_n_tiles = 0; return SWE2D_OK; }   // tiles not worth it
+    // tiles not worth it: the mean interior below 176 of 192 cells on a whole mesh, below 150 on a partition (its tiles along the cuts
+    // and through the ghost layers are partial by construction)
+    if (h->opt[SWE2D_OPT_FUSED_STAGES] <= 0 && (double)n/h->fuse_n_tiles < (h->n_owned == h->n_cells ? 176.0 : 150.0)) {
+        h->fuse_state = -1; h->fuse_n_tiles = 0;
+        return SWE2D_OK;
+    }
     HIP_TRY(h, hipMalloc(&h->fuse_tile, tl.size()*sizeof(int2)));
     HIP_TRY(h, hipMalloc(&h->fuse_inner, inner.size()*sizeof(int)));
     HIP_TRY(h, hipMemcpy(h->fuse_tile, tl.data(), tl.size()*sizeof(int2), hipMemcpyHostToDevice));
@@ -116,20 +128,22 @@ int fuse12_build(Handle *h)
     return SWE2D_OK;
 }
 
-// stages 1 and 2 of a step: state buffer A (U(0)) -> state buffer C (U(2)); stage 3 follows as a stage launch
-int launch_fuse12(Handle *h)
+// stages 1 and 2 of a step: state buffer A (U(0)) -> state buffer C (U(2)) on the cells [0, cell_end); stage 3 follows as a stage launch
+int launch_fuse12(Handle *h, int cell_end)
 {
     if (int rc = fuse12_build(h)) return rc;
+    if (!h->fuse_tile) return fail(h, SWE2D_ERR_UNSUPPORTED, "fused stage pair: no tile tables");
     SweFuseArgs q;
     fill_stage_args(h, q.st, 0, 0, 2, 0.0, 1.0, kBeta[0], 0, h->n_owned);
-    q.st.idxc = h->idxc;                                  // (the 16-B connectivity records where they exist: a streaming kernel)
+    q.st.idxc = h->opt[SWE2D_OPT_COMPACT_IDX] == 0 ? nullptr : h->idxc;      // (the 16-B connectivity records: a streaming kernel)
     q.tile = h->fuse_tile;
     q.n_inner = h->fuse_inner;
     q.n_tiles = h->fuse_n_tiles;
+    q.cell_end = cell_end;
     q.beta1 = kBeta[0];
     q.a0_2 = kAlpha0[1]; q.a1_2 = kAlphaIn[1]; q.beta2 = kBeta[1];
     q.out = h->state[2];
-    fuse_kernel_t kern = pick_fuse_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0);
+    fuse_kernel_t kern = pick_fuse_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h));
     const int grid = ((h->fuse_n_tiles + 7)/8)*8;
     SWE_CHK_SYNC(h->stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_FUSE_WG), 0, h->stream, q);
@@ -138,4 +152,205 @@ int launch_fuse12(Handle *h)
     return SWE2D_OK;
 }
 
+// ---- all three stages in one launch (swe_fuse123_kernel): tiles with two rings
+namespace {
+typedef void (*fuse3_kernel_t)(const SweFuse3Args);
+template <bool SRC>
+fuse3_kernel_t pick_fuse3_src(bool nl, bool lf)
+{
+    if (nl) return lf ? swe_fuse123_kernel<true, true, SRC> : swe_fuse123_kernel<true, false, SRC>;
+    return lf ? swe_fuse123_kernel<false, true, SRC> : swe_fuse123_kernel<false, false, SRC>;
+}
+fuse3_kernel_t pick_fuse3_kernel(bool nl, bool lf, bool src) { return src ? pick_fuse3_src<true>(nl, lf) : pick_fuse3_src<false>(nl, lf); }
+}  // namespace
+
+// Tiles: consecutive cells of the tile order as long as interior + ring 1 (facet neighbours of the interior) + ring 2 (facet
+// neighbours of ring 1) fit the 256 lanes and ring 2's facets towards the outside fit the staging area.
+int fuse123_build(Handle *h)
+{
+    if (h->fuse3_tile) return SWE2D_OK;
+    const int n = h->n_cells;
+    const size_t S = h->stride;
+    const int *nbr = h->h_nbr.data();
+    const int *order = (int)h->fuse_order.size() == n ? h->fuse_order.data() : nullptr;
+    std::vector<int2> tl, cnt;
+    std::vector<unsigned char> state((size_t)n, 0);                // 0 outside | 1 interior | 2 ring 1 | 3 ring 2, of the tile being built
+    std::vector<int> lane_of((size_t)n, -1), touched, inner;
+    std::vector<std::pair<int, unsigned char>> undo;
+    int count[4] = {0, 0, 0, 0};
+    long long r1_total = 0, r2_total = 0;
+    auto set = [&](int c, unsigned char ns) {
+        undo.push_back({c, state[c]});
+        if (state[c] == 0) touched.push_back(c);
+        count[state[c]]--; state[c] = ns; count[ns]++;
+    };
+    for (int pos = 0; pos < n;) {
+        inner.clear(); touched.clear();
+        count[1] = count[2] = count[3] = 0;
+        while (pos < n) {
+            const int kk = order ? order[pos] : pos;
+            undo.clear();
+            const size_t touched_before = touched.size();
+            set(kk, 1);
+            for (int f = 0; f < 3; f++) {
+                const int code = nbr[(size_t)f*S + kk];
+                if (code < 0) continue;
+                const int c1 = code >> 2;
+                if (state[c1] == 0 || state[c1] == 3) {
+                    set(c1, 2);
+                    for (int g = 0; g < 3; g++) {
+                        const int code2 = nbr[(size_t)g*S + c1];
+                        if (code2 >= 0 && state[code2 >> 2] == 0) set(code2 >> 2, 3);
+                    }
+                }
+            }
+            if (count[1] + count[2] + count[3] > SWE_FUSE_WG || 2*count[3] > SWE_FUSE3_MAX_OUT) {
+                if (inner.empty()) return fail(h, SWE2D_ERR_UNSUPPORTED, "fused stages: a cell whose two rings do not fit a tile");
+                for (size_t i = undo.size(); i-- > 0;) { count[state[undo[i].first]]--; state[undo[i].first] = undo[i].second; count[undo[i].second]++; }
+                touched.resize(touched_before);
+                break;
+            }
+            inner.push_back(kk);
+            pos++;
+        }
+        // lanes: the interior in the order it was added, ring 1, ring 2 (in the order of discovery)
+        std::vector<int> cells(inner);
+        for (int want = 2; want <= 3; want++)
+            for (int c : touched) if (state[c] == want) cells.push_back(c);
+        const int ni = (int)inner.size(), nm = ni + count[2], nt = (int)cells.size();
+        if (nt != count[1] + count[2] + count[3] || ni != count[1] || nt > SWE_FUSE_WG) return fail(h, SWE2D_ERR_UNSUPPORTED, "fused stages: tile bookkeeping");
+        for (int l = 0; l < nt; l++) lane_of[cells[l]] = l;
+        const size_t base = tl.size();
+        tl.resize(base + SWE_FUSE_WG, int2{-1, 0});
+        int n_out = 0;
+        for (int l = 0; l < nt; l++) {
+            const int c = cells[l];
+            unsigned w = 0u;
+            for (int f = 0; f < 3; f++) {
+                const int code = nbr[(size_t)f*S + c];
+                unsigned field;
+                if (code < 0) field = (unsigned)l;                                   // boundary facet: the cell itself
+                else if (state[code >> 2] != 0) field = (unsigned)lane_of[code >> 2];
+                else {
+                    if (l < nm || n_out >= SWE_FUSE3_MAX_OUT) return fail(h, SWE2D_ERR_UNSUPPORTED, "fused stages: ring bookkeeping");
+                    field = 0x200u | (unsigned)n_out++;
+                }
+                w |= field << (SWE_FUSE_FBITS*f);
+            }
+            tl[base + l] = int2{c, (int)w};
+        }
+        cnt.push_back(int2{ni, nm});
+        r1_total += count[2]; r2_total += count[3];
+        for (int c : cells) { state[c] = 0; lane_of[c] = -1; }
+    }
+    h->fuse3_n_tiles = (int)cnt.size();
+    HIP_TRY(h, hipMalloc(&h->fuse3_tile, tl.size()*sizeof(int2)));
+    HIP_TRY(h, hipMalloc(&h->fuse3_cnt, cnt.size()*sizeof(int2)));
+    HIP_TRY(h, hipMemcpy(h->fuse3_tile, tl.data(), tl.size()*sizeof(int2), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->fuse3_cnt, cnt.data(), cnt.size()*sizeof(int2), hipMemcpyHostToDevice));
+    h->fuse3_ring1 = r1_total; h->fuse3_ring2 = r2_total;
+    return SWE2D_OK;
+}
+
+// a whole step: state buffer A (U(0)) -> state buffer B (U(3)), then the two change places
+int launch_fuse123(Handle *h)
+{
+    if (int rc = fuse123_build(h)) return rc;
+    SweFuse3Args q;
+    fill_stage_args(h, q.st, 0, 0, 1, 0.0, 1.0, kBeta[0], 0, h->n_owned);
+    q.st.idxc = h->opt[SWE2D_OPT_COMPACT_IDX] == 0 ? nullptr : h->idxc;
+    q.tile = h->fuse3_tile;
+    q.counts = h->fuse3_cnt;
+    q.n_tiles = h->fuse3_n_tiles;
+    for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
+    q.out = h->state[1];
+    fuse3_kernel_t kern = pick_fuse3_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h));
+    const int grid = ((h->fuse3_n_tiles + 7)/8)*8;
+    SWE_CHK_SYNC(h->stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_FUSE_WG), 0, h->stream, q);
+    HIP_TRY(h, hipGetLastError());
+    std::swap(h->state[0], h->state[1]);
+    h->stage_valid[0] = h->stage_valid[1] = false;          // U(1) and U(2) never left the chip
+    return SWE2D_OK;
+}
+
+// one SSPRK33 step of the shallow-water state on the whole mesh by the launches swe2d_advance would take when the dataflow kernel
+// does not apply: the fused stage pair + stage 3 where it covers the handle, three stage launches otherwise
+int step_swe(Handle *h)
+{
+    if (h->opt[SWE2D_OPT_FUSED_STAGES] == 3 && fuse12_covers(h) && h->n_owned == h->n_cells) {
+        // all three stages in one launch (whole meshes; the launch swaps two state buffers on the host: not inside a stream capture)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        (void)hipGetLastError();
+        if (!capturing) return launch_fuse123(h);
+    }
+    if (fuse12_covers(h)) { if (int rc = fuse12_build(h)) return rc; }
+    if (fuse12_covers(h) && h->fuse_tile) {
+        if (int rc = launch_fuse12(h, h->n_owned)) return rc;
+        return stage_on_range(h, 2, 0, h->n_owned);
+    }
+    for (int s = 0; s < 3; s++)
+        if (int rc = stage_on_range(h, s, 0, h->n_owned)) return rc;
+    return SWE2D_OK;
+}
+
 }  // namespace swe2d_impl
+
+extern "C" {
+
+int swe2d_fused_set_order(swe2d_handle *hh, const int32_t *cells_in_tile_order)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<int> order;
+    if (cells_in_tile_order) {
+        std::vector<char> seen((size_t)h->n_cells, 0);
+        for (int i = 0; i < h->n_cells; i++) {
+            const int c = cells_in_tile_order[i];
+            if (c < 0 || c >= h->n_cells || seen[c]) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "fused stages: the tile order is not a permutation of the cells");
+            seen[c] = 1;
+        }
+        order.assign(cells_in_tile_order, cells_in_tile_order + h->n_cells);
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->fuse_tile) { (void)hipFree(h->fuse_tile); h->fuse_tile = nullptr; }
+    if (h->fuse_inner) { (void)hipFree(h->fuse_inner); h->fuse_inner = nullptr; }
+    if (h->fuse3_tile) { (void)hipFree(h->fuse3_tile); h->fuse3_tile = nullptr; }
+    if (h->fuse3_cnt) { (void)hipFree(h->fuse3_cnt); h->fuse3_cnt = nullptr; }
+    h->fuse3_n_tiles = 0;
+    h->fuse_n_tiles = 0; h->fuse_ring_cells = 0;
+    if (h->fuse_state == -1) h->fuse_state = 0;
+    h->fuse_order.swap(order);
+    return SWE2D_OK;
+}
+
+int swe2d_fused_triple_info(swe2d_handle *hh, int32_t out[4])
+{
+    Handle *h = H(hh);
+    if (!h || !out) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!(h->opt[SWE2D_OPT_FUSED_STAGES] == 3 && fuse12_covers(h) && h->n_owned == h->n_cells)) return SWE2D_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc = fuse123_build(h)) return rc;
+    out[0] = 1; out[1] = h->fuse3_n_tiles; out[2] = (int32_t)h->fuse3_ring1; out[3] = (int32_t)h->fuse3_ring2;
+    return SWE2D_OK;
+}
+
+// stages 0 and 1 of a step on the ranges [0, cell_end_0) and [0, cell_end_1) (cell_end_1 <= cell_end_0, every cell of the second
+// range with its facet neighbours inside the first: a partition's stage ranges): one fused launch where the kernel covers the
+// handle, else the two stage launches.  Buffer C holds U(2) on [0, cell_end_1) afterwards either way.
+int swe2d_solve_stage_pair_cells(swe2d_handle *hh, int32_t cell_end_0, int32_t cell_end_1)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (cell_end_1 < 0 || cell_end_1 > cell_end_0 || cell_end_0 > h->n_cells) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell ranges");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (fuse12_covers(h)) { if (int rc = fuse12_build(h)) return rc; }
+    if (fuse12_covers(h) && h->fuse_tile) return launch_fuse12(h, cell_end_1);
+    if (int rc = stage_on_range(h, 0, 0, cell_end_0)) return rc;
+    return stage_on_range(h, 1, 0, cell_end_1);
+}
+
+}  // extern "C"

@@ -569,8 +569,9 @@ int swe2d_advance_coupled(swe2d_handle *hh, int n_steps, int tracer_only, int us
     HIP_TRY(h, hipSetDevice(h->device));
     RoctxRange range(h, "swe2d_advance_coupled");
     for (int it = 0; it < n_steps; it++) {
-        if (!tracer_only)
-            for (int s = 0; s < 3; s++) { int rc = stage_on_range(h, s, 0, h->n_owned); if (rc) return rc; }
+        // the shallow-water step as swe2d_advance makes it on a mesh beyond the dataflow kernel: fused stage pair + stage 3 where
+        // that covers the handle (cfg 4 on 1 M triangles), stage launches otherwise
+        if (!tracer_only) { if (int rc = step_swe(h)) return rc; }
         for (int id = 0; id < (int)h->tracers.size(); id++) {
             // without a diffusion pass behind it the last stage kernel also writes the cell means the limiter starts from
             const bool fuse_mean = use_limiter && !h->tracers[id].diff;

@@ -39,12 +39,13 @@ struct SweFuseArgs {
                               //  facet: the lane itself) or, with bit 9 set, the staging slot of a neighbour outside the tile}
     const int *n_inner;       // [n_tiles]: lanes 0 .. n_inner-1 hold the interior cells
     int n_tiles;
+    int cell_end;             // stage 2 updates the interior cells < cell_end (a partition's shrinking stage ranges; else n_cells)
     double beta1;             // stage 1: U(1) = U(0) + beta1 dt M^-1 R(U(0))
     double a0_2, a1_2, beta2; // stage 2: U(2) = a0 U(0) + a1 U(1) + beta2 dt M^-1 R(U(1))
     double *out;              // 9 planes: U(2) (state buffer C)
 };
 
-template <bool NONLIN, bool LF>
+template <bool NONLIN, bool LF, bool SRC = false>
 __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kernel(const SweFuseArgs q)
 {
 #pragma clang fp contract(off)
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
         twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
         double bu[3], bv[3], be[3], wu[3], wv[3], we[3];
         swe_flow_rhs_cell<NONLIN>(p, u, v, e, h, nx, ny, bu, bv, be);
-        swe_flow_rhs_facets<NONLIN, LF, false, 1, false, SWE_FUSE_XG, SWE_FUSE_WG>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+        swe_flow_rhs_facets<NONLIN, LF, SRC, 1, false, SWE_FUSE_XG, SWE_FUSE_WG>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
 #pragma unroll
         for (int i = 0; i < 3; i++) { wu[i] = 1.0*u[i]; wv[i] = 1.0*v[i]; we[i] = 1.0*e[i]; }
         swe_flow_finish<NONLIN, LF, true>(p, k, q.beta1, u, v, e, h, nx, ny, twoA, bmarkers, bkind1, bu, bv, be, wu, wv, we, o1u, o1v, o1e);
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
 #pragma unroll
         for (int i = 0; i < 3; i++) { lds[i*SWE_FUSE_WG + lane] = o1u[i]; lds[(3 + i)*SWE_FUSE_WG + lane] = o1v[i]; lds[(6 + i)*SWE_FUSE_WG + lane] = o1e[i]; }
     }
-    if (lane < n_inner) {                                  // the part of stage 2's combine that does not depend on its tendency; U(0) is dead after this
+    const bool act2 = lane < n_inner && k < q.cell_end;    // (a partition: stage 2's range ends before stage 1's)
+    if (act2) {                                            // the part of stage 2's combine that does not depend on its tendency; U(0) is dead after this
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             lw[i][lane] = fma(q.a0_2, u[i], q.a1_2*o1u[i]);
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
     }
     __syncthreads();
     // ---- stage 2 on the interior cells (every neighbour is a cell of the tile): U(2) = a0 U(0) + a1 U(1) + beta2 dt M^-1 R(U(1))
-    if (lane < n_inner) {
+    if (act2) {
         // opaque to the optimiser (as in swe_flow_kernel): what stage 1 derived from the geometry - facet lengths, reciprocals,
         // gradients - would otherwise stay live across the barrier for stage 2, past the register budget of three waves per SIMD
 #pragma unroll
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
         asm volatile("" : "+v"(bmarkers), "+v"(twoA));
         double bu[3], bv[3], be[3], wu[3], wv[3], we[3], ou[3], ov[3], oe[3];
         swe_flow_rhs_cell<NONLIN>(p, o1u, o1v, o1e, h, nx, ny, bu, bv, be);
-        swe_flow_rhs_facets<NONLIN, LF, false, 1, false, SWE_FUSE_XG, SWE_FUSE_WG>(p, k, o1u, o1v, o1e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+        swe_flow_rhs_facets<NONLIN, LF, SRC, 1, false, SWE_FUSE_XG, SWE_FUSE_WG>(p, k, o1u, o1v, o1e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
 #pragma unroll
         for (int i = 0; i < 3; i++) { wu[i] = lw[i][lane]; wv[i] = lw[3 + i][lane]; we[i] = lw[6 + i][lane]; }
         swe_flow_finish<NONLIN, LF, true>(p, k, q.beta2, o1u, o1v, o1e, h, nx, ny, twoA, bmarkers, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
@@ -179,6 +181,177 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
             swe_st(gou, k8, i*S8, ou[i]);
             swe_st(gov, k8, i*S8, ov[i]);
             swe_st(goe, k8, i*S8, oe[i]);
+        }
+    }
+}
+
+// ---- all THREE stages of a step in one launch: two rings per tile (round 6, VERDICT r05 "next 2d") ---------------------------------
+// A tile = interior cells (lanes 0 .. n_inner-1) + ring 1 (their facet neighbours, lanes n_inner .. n_mid-1) + ring 2 (the facet
+// neighbours of ring 1, lanes n_mid .. n_all-1), 256 lanes in all.  Stage 1 on every cell of the tile (ring 2's outer neighbours'
+// traces gathered from the state planes), stage 2 on interior + ring 1, stage 3 on the interior: U(1) and U(2) never leave the chip,
+// per interior cell the launch reads U(0) once (x the tile's redundancy) and writes U(3).  U(3) goes to ANOTHER buffer than U(0) -
+// a tile reads ring cells whose owners may already have finished - and the host swaps the two pointers after the launch.
+// LDS: P0 [9][256] = U(0) (traces of stage 1; every lane's own U(0) for the Shu-Osher weights of stages 2 and 3), P1 [9][256] = the
+// running stage values (U(1), then U(2)), then the staging area of the traces from outside the tile: 36.9 KB + 6 x 8 B per slot.
+// Same arithmetic, same order as the stage launches: the same bits (tests/test_gpu_parity.py::test_fused_stage_triple...).
+#define SWE_FUSE3_XG (18*SWE_FUSE_WG)                   // the staging area follows P0 and P1
+#ifndef SWE_FUSE3_MAX_OUT
+#define SWE_FUSE3_MAX_OUT 224                           // staging slots (a ring-2 cell has at most two facets towards the outside)
+#endif
+#define SWE_FUSE3_LDS (SWE_FUSE3_XG + 6*SWE_FUSE3_MAX_OUT)
+
+struct SweFuse3Args {
+    SweStageArgs st;          // uin = U(0) (state buffer A); geometry, connectivity, boundary tables; dt, g, sigma_lf
+    const int2 *tile;         // [n_tiles][256]: as SweFuseArgs::tile (lane of the neighbour in the tile, or bit 9 + staging slot)
+    const int2 *counts;       // [n_tiles]: {n_inner, n_mid}
+    int n_tiles;
+    double a0[3], a1[3], beta[3];   // Shu-Osher weights per stage (swe2d_ssprk33_coefficients)
+    double *out;              // 9 planes: U(3), NOT the buffer of U(0)
+};
+
+template <bool NONLIN, bool LF, bool SRC = false>
+__global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse123_kernel(const SweFuse3Args q)
+{
+#pragma clang fp contract(off)
+    __shared__ double lds[SWE_FUSE3_LDS];
+    const SweStageArgs &p = q.st;
+    const int tile = swe_logical_block(blockIdx.x, gridDim.x);
+    if (tile >= q.n_tiles) return;                         // padding of the grid to a multiple of 8
+    const int lane = (int)threadIdx.x;
+    const int2 tl = q.tile[(size_t)tile*SWE_FUSE_WG + lane];
+    const bool real = tl.x >= 0;
+    const int k = real ? tl.x : 0;
+    const int2 cnt = q.counts[tile];
+    const size_t S = p.stride;
+    const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u;
+    double *const P1 = lds + 9*SWE_FUSE_WG;
+
+    int bmarkers = 0, bkind1 = 0;
+    unsigned tr[3][1];
+    double h[3], nx[3], ny[3], u[3], v[3], e[3];
+    if (real) {
+        int nb[3], vid[3];
+        swe_conn_load(p.idxc, p.idx4, p.idx2, k, nb, vid);
+        bmarkers = (nb[0] < 0 ? -nb[0] : 0) | (nb[1] < 0 ? (-nb[1]) << 8 : 0) | (nb[2] < 0 ? (-nb[2]) << 16 : 0);
+        if (bmarkers != 0) {
+            const int m1 = (bmarkers & 0xff) ? (bmarkers & 0xff) : ((bmarkers & 0xff00) ? ((bmarkers >> 8) & 0xff) : (bmarkers >> 16));
+            bkind1 = m1 < SWE_MAX_MARKERS ? p.bc.kind[m1] : 0;
+        }
+        const swe_rsrc_t gu = swe_rsrc(p.uin), gv = swe_rsrc(p.uin + 3*S), ge = swe_rsrc(p.uin + 6*S);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            u[i] = swe_ld(gu, k8, i*S8);
+            v[i] = swe_ld(gv, k8, i*S8);
+            e[i] = swe_ld(ge, k8, i*S8);
+        }
+        double r0[3][6];
+        bool outside[3];
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            const int nbf = nb[f];
+            const unsigned w = ((unsigned)tl.y >> (SWE_FUSE_FBITS*f)) & 0x3ffu;
+            outside[f] = (w & 0x200u) != 0u;
+            const unsigned at = w & 0x1ffu;                                   // lane in the tile, or staging slot
+            const int f2 = nbf >= 0 ? (nbf & 3) : f, f2a = f2 == 2 ? 0 : f2 + 1;
+            {
+                const unsigned ab = outside[f] ? (unsigned)(SWE_FUSE3_XG + 6*at) : (unsigned)(f2*SWE_FUSE_WG + at);
+                const unsigned aa = outside[f] ? (unsigned)(SWE_FUSE3_XG + 6*at + 3) : (unsigned)(f2a*SWE_FUSE_WG + at);
+                tr[f][0] = ab | (aa << 16);
+            }
+            const int code = outside[f] ? nbf : ((k << 2) | f);
+            const unsigned kn8 = (unsigned)(code >> 2)*8u;
+            const int g2 = code & 3;
+            const unsigned ob = kn8 + (g2 == 0 ? 0u : (g2 == 1 ? S8 : 2u*S8));         // node g2
+            const unsigned oa = kn8 + (g2 == 0 ? S8 : (g2 == 1 ? 2u*S8 : 0u));         // node (g2 + 1) % 3
+            r0[f][0] = swe_ld(gu, ob, 0); r0[f][1] = swe_ld(gv, ob, 0); r0[f][2] = swe_ld(ge, ob, 0);
+            r0[f][3] = swe_ld(gu, oa, 0); r0[f][4] = swe_ld(gv, oa, 0); r0[f][5] = swe_ld(ge, oa, 0);
+        }
+        double px[3], py[3];
+        const swe_rsrc_t rvx = swe_rsrc(p.vx), rvy = swe_rsrc(p.vy), rvh = swe_rsrc(p.vh);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const unsigned v8 = (unsigned)vid[i]*8u;
+            px[i] = swe_ld(rvx, v8, 0);
+            py[i] = swe_ld(rvy, v8, 0);
+            h[i] = swe_ld(rvh, v8, 0);
+        }
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            const int b = (f + 1) % 3;
+            nx[f] = py[b] - py[f];
+            ny[f] = px[f] - px[b];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) { lds[i*SWE_FUSE_WG + lane] = u[i]; lds[(3 + i)*SWE_FUSE_WG + lane] = v[i]; lds[(6 + i)*SWE_FUSE_WG + lane] = e[i]; }
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            if (outside[f]) {
+                const unsigned at = ((unsigned)tl.y >> (SWE_FUSE_FBITS*f)) & 0x1ffu;
+#pragma unroll
+                for (int j = 0; j < 6; j++) lds[SWE_FUSE3_XG + 6*at + j] = r0[f][j];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- stage 1 on every cell of the tile: U(1) = U(0) + beta1 dt M^-1 R(U(0)), into P1 (nobody reads P1 yet: no barrier in front)
+    double twoA = 0.0;
+    if (real) {
+        twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
+        double bu[3], bv[3], be[3], wu[3], wv[3], we[3], ou[3], ov[3], oe[3];
+        swe_flow_rhs_cell<NONLIN>(p, u, v, e, h, nx, ny, bu, bv, be);
+        swe_flow_rhs_facets<NONLIN, LF, SRC, 1, false, SWE_FUSE3_XG, SWE_FUSE_WG>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { wu[i] = 1.0*u[i]; wv[i] = 1.0*v[i]; we[i] = 1.0*e[i]; }
+        swe_flow_finish<NONLIN, LF, true>(p, k, q.beta[0], u, v, e, h, nx, ny, twoA, bmarkers, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { u[i] = ou[i]; v[i] = ov[i]; e[i] = oe[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; i++) { P1[i*SWE_FUSE_WG + lane] = u[i]; P1[(3 + i)*SWE_FUSE_WG + lane] = v[i]; P1[(6 + i)*SWE_FUSE_WG + lane] = e[i]; }
+    }
+    __syncthreads();
+    // ---- stage 2 on interior + ring 1, stage 3 on the interior: every neighbour is a cell of the tile, traces from P1; the lane's own
+    //      U(0) for the weights from P0
+#pragma unroll 1
+    for (int s = 1; s < 3; s++) {
+        const bool act = lane < (s == 1 ? cnt.y : cnt.x);
+        double ou[3], ov[3], oe[3];
+        if (act) {
+            // opaque to the optimiser (as in swe_flow_kernel): what the previous stage derived from the geometry would otherwise stay
+            // live across the barrier, past the register budget of three waves per SIMD
+#pragma unroll
+            for (int i = 0; i < 3; i++) asm volatile("" : "+v"(nx[i]), "+v"(ny[i]), "+v"(h[i]));
+#pragma unroll
+            for (int f = 0; f < 3; f++) asm volatile("" : "+v"(tr[f][0]));
+            asm volatile("" : "+v"(bmarkers), "+v"(twoA));
+            double bu[3], bv[3], be[3], wu[3], wv[3], we[3];
+            swe_flow_rhs_cell<NONLIN>(p, u, v, e, h, nx, ny, bu, bv, be);
+            swe_flow_rhs_facets<NONLIN, LF, SRC, 1, false, SWE_FUSE3_XG, SWE_FUSE_WG>(p, k, u, v, e, h, P1, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+            const double a0 = q.a0[s], a1 = q.a1[s];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                wu[i] = fma(a0, lds[i*SWE_FUSE_WG + lane], a1*u[i]);
+                wv[i] = fma(a0, lds[(3 + i)*SWE_FUSE_WG + lane], a1*v[i]);
+                we[i] = fma(a0, lds[(6 + i)*SWE_FUSE_WG + lane], a1*e[i]);
+            }
+            swe_flow_finish<NONLIN, LF, true>(p, k, q.beta[s], u, v, e, h, nx, ny, twoA, bmarkers, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
+        }
+        if (s == 1) {
+            __syncthreads();                               // every lane has read its traces of U(1)
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) { P1[i*SWE_FUSE_WG + lane] = ou[i]; P1[(3 + i)*SWE_FUSE_WG + lane] = ov[i]; P1[(6 + i)*SWE_FUSE_WG + lane] = oe[i]; }
+#pragma unroll
+                for (int i = 0; i < 3; i++) { u[i] = ou[i]; v[i] = ov[i]; e[i] = oe[i]; }
+            }
+            __syncthreads();
+        } else if (act) {
+            const swe_rsrc_t gou = swe_rsrc(q.out), gov = swe_rsrc(q.out + 3*S), goe = swe_rsrc(q.out + 6*S);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                swe_st(gou, k8, i*S8, ou[i]);
+                swe_st(gov, k8, i*S8, ov[i]);
+                swe_st(goe, k8, i*S8, oe[i]);
+            }
         }
     }
 }

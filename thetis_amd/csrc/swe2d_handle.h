@@ -126,6 +126,11 @@ struct Handle {
     int fuse_n_tiles = 0;
     int fuse_state = 0;                                 // -1: the numbering gives poor tiles, -2: first use inside a stream capture: stage launches
     long long fuse_ring_cells = 0;
+    // ... all three stages in one launch, two rings per tile (SWE2D_OPT_FUSED_STAGES = 3): tile tables, built at first use
+    int2 *fuse3_tile = nullptr, *fuse3_cnt = nullptr;
+    int fuse3_n_tiles = 0;
+    long long fuse3_ring1 = 0, fuse3_ring2 = 0;
+    std::vector<int> fuse_order;                        // cells in the order the tiles are cut from (swe2d_fused_set_order); empty: the numbering
     int n_conn_escapes = 0;                             // cells whose record is an escape to the wide ones
     std::vector<int> h_nbr;                             // host copy of the packed neighbour codes [3][S] (triangles; flow_build)
     // dataflow stage loop (swe2d_flow.h): per-block stage counters, status word {timeouts, first late block + 1}
@@ -293,7 +298,10 @@ inline bool conn_pays(const Handle *h, int n_cells_of_launch, bool arithmetic_bo
 }
 bool fuse12_covers(const Handle *h);
 int fuse12_build(Handle *h);
-int launch_fuse12(Handle *h);
+int launch_fuse12(Handle *h, int cell_end);
+int fuse123_build(Handle *h);
+int launch_fuse123(Handle *h);
+int step_swe(Handle *h);                               // one SSPRK33 step of the shallow-water state on the whole mesh: fused pair + stage 3, or stage launches
 void fill_stage_args(Handle *h, SweStageArgs &a, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1);
 int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1);
 int stage_on_range(Handle *h, int i_stage, int c0, int c1);

@@ -415,6 +415,21 @@ class Swe2dDevice(object):
         """Stage ``i_stage`` on device cells [cell_begin, cell_end) (partitions: may include ghost layers)."""
         self._ck(self.lib.swe2d_solve_stage_cells(self.h, int(i_stage), int(cell_begin), int(cell_end)))
 
+    def solve_stage_pair_cells(self, cell_end_0, cell_end_1):
+        """stage 0 on [0, cell_end_0) and stage 1 on [0, cell_end_1): one fused launch where the kernel covers the handle"""
+        self._ck(self.lib.swe2d_solve_stage_pair_cells(self.h, int(cell_end_0), int(cell_end_1)))
+
+    def fused_set_order(self, cells_in_tile_order):
+        """The order the tiles of the fused stage pair are cut from (``None``: the device numbering); caller's cell numbering."""
+        if cells_in_tile_order is None:
+            self._ck(self.lib.swe2d_fused_set_order(self.h, None))
+            return
+        order = np.asarray(cells_in_tile_order, dtype=np.int64)
+        if self.perm is not None:
+            order = self.inv_perm[order]
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        self._ck(self.lib.swe2d_fused_set_order(self.h, _iptr(order)))
+
     def forward_euler_cells(self, cell_begin, cell_end):
         """ForwardEuler step of device cells [cell_begin, cell_end) from state buffer 0 into buffer 1 (partitions)."""
         self._ck(self.lib.swe2d_forward_euler_cells(self.h, int(cell_begin), int(cell_end)))
@@ -466,6 +481,12 @@ class Swe2dDevice(object):
         """(swe2d_advance takes the fused stage pair, tiles, ring cells, cells): swe2d_fused_pair_info"""
         out = (ctypes.c_int32*4)()
         self._ck(self.lib.swe2d_fused_pair_info(self.h, out))
+        return bool(out[0]), int(out[1]), int(out[2]), int(out[3])
+
+    def fused_triple_info(self):
+        """(swe2d_advance takes all three stages in one launch, tiles, ring-1 cells, ring-2 cells): swe2d_fused_triple_info"""
+        out = (ctypes.c_int32*4)()
+        self._ck(self.lib.swe2d_fused_triple_info(self.h, out))
         return bool(out[0]), int(out[1]), int(out[2]), int(out[3])
 
     def flow_timeouts(self):

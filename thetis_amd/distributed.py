@@ -350,6 +350,15 @@ class DistributedSwe2d(object):
             from . import ordering
             blocks = os.environ.get('THETIS_AMD_FLOW_BLOCKS', '1') != '0'        # (0: the tile order of the device numbering, A/B)
             self.dev.flow_set_order((ordering.flow_block_order if blocks else ordering.auto_cell_order)(p, 0, p.num_cells))
+        if self.dev.npc == 3 and self._on_gpu:
+            # the tiles of the fused stage pair (stages 1 + 2 of a step in one launch where the kernel covers the partition:
+            # _cycle_before_exchange): cut from an order in which the ghost cells sit in the tiles of the owned cells they touch;
+            # built here, never inside a graph capture
+            from . import ordering
+            order = ordering.fused_tile_order(p)
+            if order is not None:
+                self.dev.fused_set_order(order)
+            self.dev.fused_pair_info()
         self._ranges = [p.stage_range(i) for i in range(3)]
         self.tids = [self.dev.add_tracer() for _ in range(n_tracers)]
 
@@ -699,9 +708,17 @@ class DistributedSwe2d(object):
         dev, p = self.dev, self.part
         n = 3*n_steps
         assert early_done <= n - 1
-        for g in range(n - 1):
+        g = 0
+        while g < n - 1:
             begin = p.owned_prefix(g + 2) if g < early_done else 0
+            if g % 3 == 0 and g >= early_done:             # (n is a multiple of 3: stage g + 1 <= n - 2 is in this loop's range too)
+                # stages 1 and 2 of a step on their full ranges: one launch by overlapped tiles where the kernel covers the partition
+                # (csrc/swe2d_fuse.h; the two stage launches otherwise - swe2d_solve_stage_pair_cells decides, same bits)
+                dev.solve_stage_pair_cells(p.stage_range(g, depth=n), p.stage_range(g + 1, depth=n))
+                g += 2
+                continue
             dev.solve_stage_cells(g % 3, begin, p.stage_range(g, depth=n))
+            g += 1
         if self.split_last_stage:
             dev.solve_stage_cells(2, p.n_interior, p.n_owned)       # the cells the peers are waiting for
         else:
@@ -768,11 +785,20 @@ class DistributedSwe2d(object):
         reqs = None
         sent = False
         fe = self.stages_per_step == 1         # ForwardEuler: a "stage" is the whole step, buffer 0 -> 1, then the buffers swap
-        for op in self._coupled_ops(n_steps)[early_done:]:
+        ops = self._coupled_ops(n_steps)[early_done:]
+        skip = False
+        for i_op, op in enumerate(ops):
+            if skip:                           # the second stage of a pair that went out as one launch
+                skip = False
+                continue
             if op[0] == 'swe':
                 if fe:
                     dev.forward_euler_cells(0, op[2])
                     dev.swap_state_buffers()
+                elif op[1] == 0 and i_op + 1 < len(ops) and ops[i_op + 1][0] == 'swe' and ops[i_op + 1][1] == 1:
+                    # stages 1 and 2 of a step: one launch by overlapped tiles where the kernel covers the partition (csrc/swe2d_fuse.h)
+                    dev.solve_stage_pair_cells(op[2], ops[i_op + 1][2])
+                    skip = True
                 else:
                     dev.solve_stage_cells(op[1], 0, op[2])
             elif op[0] == 'swe_done':

@@ -7,7 +7,7 @@ Firedrake gives the reference the same service by reordering DMPlex points (reve
 """
 import numpy as np
 
-__all__ = ['hilbert_index', 'hilbert_cell_order', 'tile_cell_order', 'structured_tile_order', 'structured_subset_order', 'auto_cell_order', 'flow_block_order', 'bisection_block_order',
+__all__ = ['hilbert_index', 'hilbert_cell_order', 'tile_cell_order', 'structured_tile_order', 'structured_subset_order', 'auto_cell_order', 'flow_block_order', 'fused_tile_order', 'bisection_block_order',
            'patch_row_order', 'first_touch_vertex_order']
 
 
@@ -108,7 +108,7 @@ def auto_cell_order(mesh, a=0, b=None):
         g = np.asarray(mesh.local_to_global)[a:b]
         if k == 4:
             return structured_subset_order(g, parent[0], parent[1], bx=16, by=16, cells_per_quad=1)
-        return structured_subset_order(g, parent[0], parent[1])
+        return structured_subset_order(g, parent[0], parent[1], bx=16, by=6)      # (the whole mesh's 16 x 6-quad tiles, see above)
     cen = np.asarray(mesh.vertex_xy)[np.asarray(mesh.cells)[a:b]].mean(axis=1)
     return hilbert_cell_order(cen)
 
@@ -167,6 +167,25 @@ def flow_block_order(mesh, a=0, b=None):
     order = max(1, int(np.ceil(np.log2(max(il.max()//bx + 2, jl.max()//by + 2)))))
     d = hilbert_index(il//bx, jl//by, order)
     return np.lexsort((g, il % bx, jl % by, d))
+
+
+def fused_tile_order(mesh):
+    """The order the TILES of the fused stage pair (csrc/swe2d_fuse.h: 192 consecutive cells + their ring per workgroup) are cut
+    from, over ALL cells of ``mesh``; ``None`` where the device numbering already is that order (a whole mesh).  A partition's
+    numbering is [interior | send cells | ghost layer 1 | ghost layer 2 ...] (what the stage ranges need): cut from it, the strips
+    along the cut and every ghost layer - one cell wide - would give tiles that are all ring.  Here every cell, owned or ghost,
+    sits in its 16 x 6-quad tile of the parent RectangleMesh (the tiles of the owned interior's numbering: their lanes still read
+    consecutive addresses), tiles along the Hilbert curve; any other partition: a Hilbert curve through the centroids of all cells."""
+    if getattr(mesh, 'local_to_global', None) is None:
+        return None
+    k = np.asarray(mesh.cells).shape[1]
+    if k != 3:
+        return None
+    parent = getattr(mesh, 'structured_parent', None)
+    if parent is not None:
+        return structured_subset_order(np.asarray(mesh.local_to_global), parent[0], parent[1], bx=16, by=6)
+    cen = np.asarray(mesh.vertex_xy)[np.asarray(mesh.cells)].mean(axis=1)
+    return hilbert_cell_order(cen)
 
 
 def first_touch_vertex_order(cells):

@@ -67,12 +67,18 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     failures = []
+    t_start = time.perf_counter()
+
+    def progress(msg):
+        """the running log of first contact (rank 0, stderr, flushed at once: a run that dies half way leaves what it got to)"""
+        if rank == 0:
+            import sys
+            print('[thetis_amd {:7.1f} s] {:}'.format(time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
     def note(what, exc=None):
         msg = what if exc is None else '{:}: {:}'.format(what, (str(exc).strip().splitlines() or [type(exc).__name__])[0][:300])
         failures.append(msg)
-        if rank == 0:
-            print('[thetis_amd] ' + msg, flush=True)
+        progress('FAILED / dropped: ' + msg)
 
     # control plane = gloo on CPU tensors (always available); RCCL only carries device-side exchanges and is created
     # lazily by its first use, so a node whose RCCL is broken still produces a number through 'p2p' or 'host'
@@ -89,6 +95,8 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
         dist.init_process_group(backend='gloo', rank=rank, world_size=world, timeout=timeout)
     ctrl = dist.new_group(backend='gloo', timeout=timeout) if world > 1 else None
     agree = _Agree(ctrl, world)
+    progress('{:d} ranks, control plane gloo, device collectives {:}; visible devices {:d}'.format(
+        world, 'RCCL (created by its first use)' if have_rccl else 'none (gloo backend)', torch.cuda.device_count()))
     mesh, bath, uv, eta = build_case()
     n_total = mesh.num_cells
     use_graph = not os.environ.get('THETIS_AMD_NO_GRAPH')
@@ -198,6 +206,7 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
             raise RuntimeError('{:}: after {:d} steps ({:.1f} s) the state differs from the single-device run of the same mesh'.format(
                 label, soak['steps'], took))
         soak['verified'].append({'what': label, 'steps': soak['steps'], 'seconds': took})
+        progress('soak: {:} stepped {:d} steps in {:.1f} s and ended on the bits of the single-device run'.format(label, soak['steps'], took))
 
     def short_run(exchange):
         s = make(exchange, 2, 0, True, 'none')
@@ -233,6 +242,7 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
             ok = same
         if ok:
             transports.append(ex)
+            progress("transport '{:}': set up on every rank, {:d} steps reproduce the host-staged exchange bit for bit".format(ex, n_check))
     if not transports:
         transports = ['host']
 
@@ -332,6 +342,9 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
         us = 1e6*agree.max(t_best)/n_tune
         tuning.append({'exchange': ex, 'exchange_every': every_c, 'overlap_stages': overlap_c, 'split_last_stage': split_c,
                        'graph_mode': mode_c, 'flow': bool(flow_c), 'us_per_step': us})
+        progress('schedule {:}: exchange every {:d} steps, overlap {:d}, split last stage {:}, graphs {:}, dataflow launches {:}: '
+                 '{:.2f} us per step (max over ranks, best of 4 x {:d} steps){:}'.format(
+                     ex, every_c, overlap_c, split_c, mode_c, bool(flow_c), us, n_tune, '  <- best so far' if us < best_us else ''))
         if us < best_us:
             if solver is not None:
                 solver.close()
@@ -345,6 +358,8 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
         if not ok:
             solver = None
     setup_s = agree.max(time.perf_counter() - t_setup0)
+    progress('set-up took {:.1f} s (budget {:.0f} s); transports verified: {:}; chosen schedule: {:}{:}'.format(
+        setup_s, setup_budget, transports, chosen, '; skipped for the budget: {:}'.format(skipped) if skipped else ''))
     out = None
     if solver is not None:
         ok, out = attempt('timed region', lambda: _timed_region(args, solver, chosen, agree, uv, eta, use_graph, n_total, world,
@@ -352,6 +367,8 @@ def run_distributed_bench(args, build_case, dt, bytes_per_update, hbm_peak):
         if not ok:
             out = None
     if out is not None:
+        progress('timed region: {:d} steps, {:.4f} ms per step, {:.3e} element-updates/s, volume conserved: {:}, p2p time-outs: {:}'.format(
+            out['steps'], out['ms_per_step'], out['value'], out['config'].get('volume_conserved'), out['config'].get('p2p_timeouts')))
         out['config'].update({'setup_s': setup_s, 'setup_budget_s': setup_budget, 'setup_skipped': skipped,
                               'soak': {'seconds_asked': soak['seconds'], 'steps': soak['steps'], 'reference_s': soak['reference_s'],
                                        'verified': soak['verified'],

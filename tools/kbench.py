@@ -82,7 +82,12 @@ def main():
     except Exception:          # experimental kernel variants may produce garbage
         d = [float('nan')]*4
     n = mesh.num_cells
-    print(json.dumps({'tag': args.tag or os.environ.get('THETIS_AMD_LIB', 'default'), 'order': args.order, 'n_cells': n,
+    fused = {}
+    try:
+        fused = {'fused_pair': list(dev.fused_pair_info()), 'fused_triple': list(dev.fused_triple_info())}
+    except Exception:
+        pass
+    print(json.dumps({'tag': args.tag or os.environ.get('THETIS_AMD_LIB', 'default'), 'order': args.order, 'n_cells': n, 'fused': fused,
                       'us_per_step': 1e3*best, 'us_per_launch': 1e3*ms_k, 'frac': 684.0*n/(best*1e-3)/8e12,
                       'vol': d[2]}))
     dev.close()
