@@ -337,6 +337,7 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
     do {                                                                                                 \
         hipError_t e_ = (expr);                                                                          \
         if (e_ != hipSuccess) {                                                                          \
+            (void)hipGetLastError();                                                                     \
             int rc_ = fail(nullptr, SWE2D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
             swe2d_destroy(reinterpret_cast<swe2d_handle *>(h));                                          \
             return rc_;                                                                                  \

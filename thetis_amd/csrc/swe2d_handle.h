@@ -229,8 +229,12 @@ int fail(Handle *h, int code, const std::string &msg);
 #define HIP_TRY(h, expr)                                                                         \
     do {                                                                                         \
         hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
+        if (e_ != hipSuccess) {                                                                  \
+            /* the error is reported through the return code; left in the runtime's "last error" it would surface in the NEXT  \
+               caller that checks it - e.g. torch's launch check after a peer mapping that failed (first contact with a node) */ \
+            (void)hipGetLastError();                                                             \
             return fail(h, SWE2D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+        }                                                                                        \
     } while (0)
 
 // Optional ROCTx ranges around the entry points that advance the state (SWE2D_OPT_ROCTX = 1): they show up as named ranges in

@@ -145,6 +145,15 @@ def main():
     dev = Swe2dDevice(mesh, bath, 0.25)
     dev.set_state(uv, eta)
     report('cfg2 triangles SWE', n, 684.0, timed(dev, dev.advance, 50))
+    # ---- the same with the source terms of a tidal case: Coriolis field (24 B per cell and stage), Manning friction, wind stress (48 B)
+    dev.set_field(_lib.FIELD_CORIOLIS, 1e-4*(1.0 + cxy[:, :, 1]/50e3))
+    dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+    dev.set_field(_lib.FIELD_WIND_STRESS, np.stack([0.1*np.sin(cxy[:, :, 0]/2e4), 0.05*np.cos(cxy[:, :, 1]/1e4)], axis=2))
+    report('cfg2 + Coriolis field + Manning + wind stress', n, 684.0 + 3*72.0, timed(dev, dev.advance, 50),
+           {'fused_pair': bool(dev.fused_pair_info()[0])})
+    dev.set_field(_lib.FIELD_CORIOLIS, None)
+    dev.set_scalar(_lib.SCALAR_MANNING_DRAG, None)
+    dev.set_field(_lib.FIELD_WIND_STRESS, None)
     # ---- cfg 4: coupled SWE + 1 tracer + limiter.  Tracer per stage: 24 r + 24 w (+24 T0) + 48 velocity + 36 static
     #      = 132 / 156 / 156 B; limiter once per step: 24 r (means) + 8 w + 8 r + vertex bounds ~16 + 24 r + 24 w + 12 idx ~ 116 B
     tid = dev.add_tracer()

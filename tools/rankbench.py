@@ -162,7 +162,7 @@ def main():
             np.savez(dump, t=t, prev=prev, role=role, rim=rim, n_owned=p.n_owned, blk=blk)
     print(json.dumps({'case': args.case, 'exchange': args.exchange, 'split': not args.nosplit, 'p2p_timeouts': to,
                       'world': args.world, 'rank': args.rank, 'every': args.every, 'overlap': args.overlap, 'n_owned': int(p.n_owned),
-                      'n_ghost': int(p.n_ghost), 'n_send': int(len(p.send_cells)), 'graph': s.graphed, 'graph_mode': s.graph_mode, 'flow': bool(s.flow), 'flow_exchange': bool(s.flow_exchange), 'flow_timeouts': s.dev.flow_timeouts(),
+                      'n_ghost': int(p.n_ghost), 'n_send': int(len(p.send_cells)), 'graph': s.graphed, 'graph_mode': s.graph_mode, 'flow': bool(s.flow), 'flow_exchange': bool(s.flow_exchange), 'flow_timeouts': s.dev.flow_timeouts(), 'fused_pair': list(s.dev.fused_pair_info()) if hasattr(s.dev, 'fused_pair_info') else None,
                       'us_per_step': 1e6*best/args.steps}))
 
 
