@@ -39,6 +39,8 @@ BYTES_PER_ELEMENT_UPDATE = BYTES_PER_ELEMENT_STEP/3.0
 # what the FUSED algorithm must move per triangle and step in the same perfect-cache model: stages 1 + 2 in one
 # launch read U(0) and the static data once and write U(2) - 72 + 36 + 72 = 180 B, U(1) never leaves the chip -, stage 3 its 252 B
 FUSED_BYTES_PER_ELEMENT_STEP = 180.0 + 252.0
+# ... and with all three stages in one launch: U(0) and the static data read once, U(3) written
+TRIPLE_BYTES_PER_ELEMENT_STEP = 180.0
 TRAFFIC_JSON = 'r06_traffic.json'           # committed PMC passes of this library's kernels on this workload (profiles/README.md)
 TRAFFIC_4M_JSON = 'r06_traffic_4m.json'     # ... on the 4M-triangle mesh behind roofline.beyond_cache
 FP64_CLOCK_HZ = 2.4e9                       # MI355X_MICROARCH.md: max clock 2400 MHz
@@ -119,7 +121,18 @@ def cpu_baseline(budget_s=10.0):
     return out, best_state
 
 
-def measured_traffic(n_cells, fused, name=None, want_cells=1000000):
+def launch_structure(dev):
+    """'triple' (all three stages of a step in one launch), 'pair' (stages 1 + 2 fused, stage 3 a stage launch) or 'stages'"""
+    if dev.fused_triple_info()[0]:
+        return 'triple'
+    return 'pair' if dev.fused_pair_info()[0] else 'stages'
+
+
+MODEL_BYTES = {'stages': BYTES_PER_ELEMENT_STEP, 'pair': FUSED_BYTES_PER_ELEMENT_STEP, 'triple': TRIPLE_BYTES_PER_ELEMENT_STEP}
+LAUNCHES = {'stages': 3, 'pair': 2, 'triple': 1}
+
+
+def measured_traffic(n_cells, structure, name=None, want_cells=1000000):
     """HBM bytes per element-update (a third of a step) and VALU wave-instructions per step from the committed PMC passes
     (rocprofv3 cannot run inside the timed bench): FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU collected in separate --pmc runs, the
     fetch counter corrected with the calibration copy kernel, see profiles/README.md.  Only valid for the workload AND the launch
@@ -130,7 +143,8 @@ def measured_traffic(n_cells, fused, name=None, want_cells=1000000):
     try:
         with open(path) as f:
             t = json.load(f)
-        if n_cells == want_cells and bool(fused) == ('fused_stage_pair_kernel' in t):
+        in_file = 'triple' if 'fused_stage_triple_kernel' in t else ('pair' if 'fused_stage_pair_kernel' in t else 'stages')
+        if n_cells == want_cells and structure == in_file:
             return float(t['traffic_bytes_per_launch']), t.get('valu_wave_instructions_per_step'), 'profiles/' + name
     except (OSError, KeyError, ValueError):
         pass
@@ -154,17 +168,17 @@ def beyond_cache(args):
     ms_events = min(dev.advance_timed(steps, per_launch=False)[0] for _ in range(2))
     ms_kernel = ms_events/(3.0*steps)
     assert np.isfinite(dev.diagnostics()).all()
-    fused = dev.fused_pair_info()[0]
+    structure = launch_structure(dev)
     dev.close()
     achieved = BYTES_PER_ELEMENT_UPDATE*n/(ms_kernel*1e-3)/1e9
     # committed PMC passes of THIS library's launches on this very workload (profiles/README.md)
-    traffic, valu, src = measured_traffic(n, fused, TRAFFIC_4M_JSON, 4000000)
-    model = (FUSED_BYTES_PER_ELEMENT_STEP if fused else BYTES_PER_ELEMENT_STEP)*n
+    traffic, valu, src = measured_traffic(n, structure, TRAFFIC_4M_JSON, 4000000)
+    model = MODEL_BYTES[structure]*n
     return {'frac_beyond_cache': achieved/HBM_PEAK_GBS,
             'beyond_cache': {'workload': 'RectangleMesh({:d},{:d}) = {:d} triangles, same channel and kernels'.format(
                                  BEYOND_CACHE_NX, BEYOND_CACHE_NY, n),
                              'achieved': achieved, 'avg_launch_ms': ms_kernel, 'steps': steps, 'traffic': traffic,
-                             'traffic_source': src, 'launches_per_step': 2 if fused else 3,
+                             'traffic_source': src, 'launch_structure': structure, 'launches_per_step': LAUNCHES[structure],
                              'frac_fused_model': model/(ms_events/steps*1e-3)/1e9/HBM_PEAK_GBS,
                              'traffic_rate_frac': (3.0*traffic/(ms_events/steps*1e-3)/1e9/HBM_PEAK_GBS) if traffic else None,
                              'valu_issue_frac': (valu*4.0/(N_SIMD*FP64_CLOCK_HZ)/(ms_events/steps*1e-3)) if valu else None,
@@ -208,9 +222,10 @@ def run_single(args):
     value = n*3.0*args.steps/t_wall
     achieved = BYTES_PER_ELEMENT_UPDATE*n/(ms_kernel*1e-3)/1e9
     fused = dev.fused_pair_info()
-    traffic, valu, traffic_src = measured_traffic(n, fused[0])
+    structure = launch_structure(dev)
+    traffic, valu, traffic_src = measured_traffic(n, structure)
     step_s = ms_events/args.steps*1e-3
-    model_step = (FUSED_BYTES_PER_ELEMENT_STEP if fused[0] else BYTES_PER_ELEMENT_STEP)*n
+    model_step = MODEL_BYTES[structure]*n
     out = {
         'metric': 'DG element-updates/sec, 2D SWE DG-P1 SSPRK33',
         'value': value, 'unit': 'element-updates/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
@@ -241,7 +256,7 @@ def run_single(args):
                      'valu_issue_frac': (valu*4.0/(N_SIMD*FP64_CLOCK_HZ)/step_s) if valu else None,
                      'kernel': ('swe_fuse12_kernel (stages 1 + 2 in one launch) + swe_stage_kernel (stage 3): avg_launch_ms is per '
                                 'element-update = a third of a step') if fused[0] else 'swe_stage_kernel',
-                     'launches_per_step': 2 if fused[0] else 3,
+                     'launch_structure': structure, 'launches_per_step': LAUNCHES[structure],
                      'fused_stage_pair': {'tiles': fused[1], 'ring_cells': fused[2]} if fused[0] else None,
                      'avg_launch_ms': ms_kernel, 'avg_launch_ms_per_launch_events': ms_kernel_each,
                      'algorithmic_bytes_per_launch': BYTES_PER_ELEMENT_UPDATE*n},

@@ -509,7 +509,7 @@ def test_ranks_on_one_gpu_with_peer_to_peer_halos(tmp_path, hip_lib, world, case
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('world,case,n_steps', [
-    (2, 'channel64+every2+p2p', 7), (2, 'channel64+every4', 9), (3, 'delaunay+p2p+graph', 4), (4, 'channel64+every2+overlap3+p2p+graph', 9),
+    (2, 'channel64+every2+p2p', 7), (2, 'channel64+every4', 9), (3, 'delaunay+p2p+graph', 2), (4, 'channel64+every2+overlap3+p2p+graph', 9),
     (2, 'channel64+every2+p2p+capture', 8)])
 def test_ranks_on_one_gpu_with_the_fused_stage_pair(tmp_path, hip_lib, monkeypatch, world, case, n_steps):
     """Stages 1 and 2 of every step of an exchange cycle as ONE launch by overlapped tiles on a partition (csrc/swe2d_fuse.h,

@@ -953,7 +953,7 @@ int swe2d_advance_timed(swe2d_handle *hh, int n_steps, int per_launch, float *ms
     if (h->n_owned != h->n_cells)
         return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_advance_timed on a partition is not supported");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (!per_launch || h->opt[SWE2D_OPT_FUSED_STAGES] == 3) {     // (all stages in one launch: a step IS a launch)
+    if (!per_launch || fuse123_wanted(h)) {     // (all stages in one launch: a step IS a launch)
         HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
         int rc = swe2d_advance(hh, n_steps);
         if (rc) return rc;

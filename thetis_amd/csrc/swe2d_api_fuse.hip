@@ -30,11 +30,11 @@ bool fuse12_covers(const Handle *h)
 #ifdef SWE_RANGE_CHECK
     return false;
 #else
-    const int mode = h->opt[SWE2D_OPT_FUSED_STAGES];         // -1: by size and tile quality
+    const int mode = h->opt[SWE2D_OPT_FUSED_STAGES];         // -1, 2: by size and tile quality; 1, 3: forced
     if (mode == 0 || h->fuse_state == -1) return false;
     if (h->opt[SWE2D_OPT_BND_INLINE] == 0) return false;     // the epilogue variant was asked for
     return h->npc == 3 && !h->wd && !h->visc && !h->h_nbr.empty() && h->idx4
-           && h->n_cells >= (mode > 0 ? 64 : 250000);
+           && h->n_cells >= ((mode == 1 || mode == 3) ? 64 : 250000);
 #endif
 }
 
@@ -116,7 +116,8 @@ int fuse12_build(Handle *h)
     h->fuse_n_tiles = (int)inner.size();
     // tiles not worth it: the mean interior below 176 of 192 cells on a whole mesh, below 150 on a partition (its tiles along the cuts
     // and through the ghost layers are partial by construction)
-    if (h->opt[SWE2D_OPT_FUSED_STAGES] <= 0 && (double)n/h->fuse_n_tiles < (h->n_owned == h->n_cells ? 176.0 : 150.0)) {
+    const bool forced = h->opt[SWE2D_OPT_FUSED_STAGES] == 1 || h->opt[SWE2D_OPT_FUSED_STAGES] == 3;
+    if (!forced && (double)n/h->fuse_n_tiles < (h->n_owned == h->n_cells ? 176.0 : 150.0)) {
         h->fuse_state = -1; h->fuse_n_tiles = 0;
         return SWE2D_OK;
     }
@@ -274,11 +275,24 @@ int launch_fuse123(Handle *h)
     return SWE2D_OK;
 }
 
+// All three stages in one launch: where the state no longer fits the Infinity Cache.  Same box, us per step, three stage launches /
+// fused pair + stage 3 / all three fused (profiles/r06b_fused_sizes.txt): 250 k cells 37.0 / 35.2 / 36.1, 500 k 63.8 / 59.4 / 60.5,
+// 1 M 110.0 / 103.0 / 110.8, 2 M 272.0 / 233.3 / 229.9, 4 M 527.9 / 475.3 / 452.1 - two rings cost 1.26 x the arithmetic of the pair
+// (147 interior cells per 256-lane tile against 192), which a mesh inside the cache cannot win back; beyond it the bytes decide.
+// SWE2D_OPT_FUSED_STAGES = 3 forces it, = 2 keeps the pair at every size.  Whole meshes; not inside a stream capture (the launch
+// swaps two state buffers on the host).
+bool fuse123_wanted(const Handle *h)
+{
+    const int mode = h->opt[SWE2D_OPT_FUSED_STAGES];
+    // (by itself only without source terms: those instances spill 80-132 B per lane at the 168 VGPRs of three workgroups per CU)
+    return (mode == 3 || (mode == -1 && h->n_cells >= 2500000 && !has_sources(h))) && fuse12_covers(h) && h->n_owned == h->n_cells;
+}
+
 // one SSPRK33 step of the shallow-water state on the whole mesh by the launches swe2d_advance would take when the dataflow kernel
 // does not apply: the fused stage pair + stage 3 where it covers the handle, three stage launches otherwise
 int step_swe(Handle *h)
 {
-    if (h->opt[SWE2D_OPT_FUSED_STAGES] == 3 && fuse12_covers(h) && h->n_owned == h->n_cells) {
+    if (fuse123_wanted(h)) {
         // all three stages in one launch (whole meshes; the launch swaps two state buffers on the host: not inside a stream capture)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
@@ -331,7 +345,7 @@ int swe2d_fused_triple_info(swe2d_handle *hh, int32_t out[4])
     Handle *h = H(hh);
     if (!h || !out) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
     out[0] = out[1] = out[2] = out[3] = 0;
-    if (!(h->opt[SWE2D_OPT_FUSED_STAGES] == 3 && fuse12_covers(h) && h->n_owned == h->n_cells)) return SWE2D_OK;
+    if (!fuse123_wanted(h)) return SWE2D_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     if (int rc = fuse123_build(h)) return rc;
     out[0] = 1; out[1] = h->fuse3_n_tiles; out[2] = (int32_t)h->fuse3_ring1; out[3] = (int32_t)h->fuse3_ring2;

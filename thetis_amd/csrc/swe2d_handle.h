@@ -303,6 +303,7 @@ inline bool conn_pays(const Handle *h, int n_cells_of_launch, bool arithmetic_bo
 bool fuse12_covers(const Handle *h);
 int fuse12_build(Handle *h);
 int launch_fuse12(Handle *h, int cell_end);
+bool fuse123_wanted(const Handle *h);
 int fuse123_build(Handle *h);
 int launch_fuse123(Handle *h);
 int step_swe(Handle *h);                               // one SSPRK33 step of the shallow-water state on the whole mesh: fused pair + stage 3, or stage launches

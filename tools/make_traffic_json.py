@@ -49,8 +49,23 @@ def main():
         w = 2 if has_u0 else 1
         tot += w*b
         launches += w
+    triple = sorted(k for k in acc if 'swe_fuse123_kernel<' in k)
     fused = sorted(k for k in acc if 'swe_fuse12_kernel<' in k)
-    if fused:
+    if triple:
+        # all three stages in one launch (csrc/swe2d_fuse.h, swe_fuse123_kernel): a step is this launch; per element-update = / 3
+        k = triple[0]
+        f_kb, w_kb = mean(k, 'FETCH_SIZE'), mean(k, 'WRITE_SIZE')
+        b = f_kb*1024.0*fc + w_kb*1024.0
+        res['fused_stage_triple_kernel'] = dict({'name': k[:80], 'FETCH_SIZE_KB': f_kb, 'WRITE_SIZE_KB': w_kb, 'bytes': b,
+                                                 'algorithmic_bytes_of_the_three_stage_launches': 684.0*n_cells,
+                                                 'launches_sampled': len(acc[k]['FETCH_SIZE'])}, **issue(k))
+        res.pop('stage0_kernel', None)
+        res.pop('stage12_kernel', None)
+        tot, launches = b, 3
+        res['launches_per_step'] = 1
+        if res['fused_stage_triple_kernel'].get('SQ_INSTS_VALU') is not None:
+            res['valu_wave_instructions_per_step'] = res['fused_stage_triple_kernel']['SQ_INSTS_VALU']
+    elif fused:
         # stages 1 + 2 in one launch (csrc/swe2d_fuse.h) + stage 3 as a stage launch: a step is these two; per element-update = / 3
         k = fused[0]
         f_kb, w_kb = mean(k, 'FETCH_SIZE'), mean(k, 'WRITE_SIZE')
