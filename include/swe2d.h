@@ -403,6 +403,11 @@ int  swe2d_p2p_connect(swe2d_handle *h, int32_t n_peers, void *const *remote_bas
                        const int32_t *remote_n_recv, int32_t n_from);
 int  swe2d_p2p_push(swe2d_handle *h, int channel, int i_buffer);
 int  swe2d_p2p_wait_unpack(swe2d_handle *h, int channel, int i_buffer);
+/* the same for up to four channels (the shallow water state and the tracers at the end of a coupled exchange cycle) in ONE launch each
+ * way: the channels' own kernels side by side, every channel with its own epochs and flags - interchangeable with the
+ * single-channel calls, exchange by exchange */
+int  swe2d_p2p_push_multi(swe2d_handle *h, int n, const int32_t *channels, const int32_t *i_buffers);
+int  swe2d_p2p_wait_unpack_multi(swe2d_handle *h, int n, const int32_t *channels, const int32_t *i_buffers);
 /* swe2d_p2p_push / swe2d_p2p_wait_unpack on a stream of their own (null: the handle's stream), so that the stage kernels of the
  * interior cells run while the halo travels - PyOP2 overlaps its halo exchange with the core of a par_loop the same way
  * [FD-assumed].  The caller orders the two streams with events; no synchronisation here. */

@@ -157,6 +157,8 @@ SYMBOLS = {
                                           ctypes.c_int32]),
     'swe2d_p2p_push': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int]),
     'swe2d_p2p_wait_unpack': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int]),
+    'swe2d_p2p_push_multi': (ctypes.c_int, [_H, ctypes.c_int, _ip, _ip]),
+    'swe2d_p2p_wait_unpack_multi': (ctypes.c_int, [_H, ctypes.c_int, _ip, _ip]),
     'swe2d_p2p_status': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _ip]),
     'swe2d_solve_stage_cells': (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_forward_euler_cells': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),

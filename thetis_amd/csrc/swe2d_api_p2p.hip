@@ -208,16 +208,13 @@ int p2p_field(Handle *h, int channel, int i_buffer, double **planes, int *np)
 }
 }  // namespace
 
-int swe2d_p2p_push(swe2d_handle *hh, int channel, int i_buffer)
+namespace {
+int p2p_push_args(Handle *h, int channel, int i_buffer, SweP2pPushArgs &a)
 {
-    Handle *h = H(hh);
-    if (!h || !h->p2p.zone) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_push: not connected");
     double *planes; int np;
     if (int rc = p2p_field(h, channel, i_buffer, &planes, &np)) return rc;
     auto &z = h->p2p;
-    if (z.n_peers == 0 || h->n_send == 0) return SWE2D_OK;
-    HIP_TRY(h, hipSetDevice(h->device));
-    SweP2pPushArgs a{};
+    a = SweP2pPushArgs{};
     a.planes = planes; a.stride = h->stride; a.send_cells = h->send_cells; a.n_send = h->n_send; a.np = np;
     a.n_peers = z.n_peers;
     for (int i = 0; i < z.n_peers; i++) {
@@ -230,21 +227,15 @@ int swe2d_p2p_push(swe2d_handle *hh, int channel, int i_buffer)
                      + (size_t)(channel*SWE_P2P_MAX_PEERS + z.remote_flag[i])*SWE_P2P_FLAG_STRIDE;
     }
     a.ctr = z.ctr + channel;
-    hipLaunchKernelGGL(swe_p2p_push_kernel, dim3(std::min(SWE_P2P_MAX_BLOCKS, grid_for(np*h->n_send))), dim3(256), 0, h->xstream ? h->xstream : h->stream, a);
-    HIP_TRY(h, hipGetLastError());
     return SWE2D_OK;
 }
 
-int swe2d_p2p_wait_unpack(swe2d_handle *hh, int channel, int i_buffer)
+int p2p_unpack_args(Handle *h, int channel, int i_buffer, SweP2pUnpackArgs &a)
 {
-    Handle *h = H(hh);
-    if (!h || !h->p2p.zone) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_wait_unpack: not connected");
     double *planes; int np;
     if (int rc = p2p_field(h, channel, i_buffer, &planes, &np)) return rc;
     auto &z = h->p2p;
-    if (z.n_from == 0 || h->n_recv == 0) return SWE2D_OK;
-    HIP_TRY(h, hipSetDevice(h->device));
-    SweP2pUnpackArgs a{};
+    a = SweP2pUnpackArgs{};
     a.planes = planes; a.stride = h->stride; a.recv_cells = h->recv_cells; a.n_recv = h->n_recv; a.np = np;
     a.n_from = z.n_from;
     char *base = static_cast<char *>(z.zone);
@@ -255,7 +246,71 @@ int swe2d_p2p_wait_unpack(swe2d_handle *hh, int channel, int i_buffer)
     a.timeout_ticks = (unsigned long long)(opt_seconds(h, SWE2D_OPT_P2P_TIMEOUT_MS, 5.0)*1e8);
     a.ctr = z.ctr + channel;
     a.fence = z.zone_kind == 3;
-    hipLaunchKernelGGL(swe_p2p_unpack_kernel, dim3(std::min(SWE_P2P_MAX_BLOCKS, grid_for(np*h->n_recv))), dim3(256), 0, h->xstream ? h->xstream : h->stream, a);
+    return SWE2D_OK;
+}
+}  // namespace
+
+int swe2d_p2p_push(swe2d_handle *hh, int channel, int i_buffer)
+{
+    Handle *h = H(hh);
+    if (!h || !h->p2p.zone) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_push: not connected");
+    SweP2pPushArgs a;
+    if (int rc = p2p_push_args(h, channel, i_buffer, a)) return rc;
+    if (h->p2p.n_peers == 0 || h->n_send == 0) return SWE2D_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(swe_p2p_push_kernel, dim3(std::min(SWE_P2P_MAX_BLOCKS, grid_for(a.np*h->n_send))), dim3(256), 0, h->xstream ? h->xstream : h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
+}
+
+// the same for several channels in ONE launch each way (swe_p2p_push_multi_kernel: the single-channel kernels side by side)
+int swe2d_p2p_push_multi(swe2d_handle *hh, int n, const int32_t *channels, const int32_t *i_buffers)
+{
+    Handle *h = H(hh);
+    if (!h || !h->p2p.zone) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_push_multi: not connected");
+    if (n < 1 || n > SWE_P2P_MULTI || !channels || !i_buffers) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_push_multi: 1 .. 4 channels");
+    SweP2pPushMulti m;
+    int np_max = 0;
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < i; j++) if (channels[j] == channels[i]) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_push_multi: a channel twice");
+        if (int rc = p2p_push_args(h, channels[i], i_buffers[i], m.a[i])) return rc;
+        np_max = std::max(np_max, m.a[i].np);
+    }
+    if (h->p2p.n_peers == 0 || h->n_send == 0) return SWE2D_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(swe_p2p_push_multi_kernel, dim3(std::min(SWE_P2P_MAX_BLOCKS, grid_for(np_max*h->n_send)), n), dim3(256), 0, h->xstream ? h->xstream : h->stream, m);
+    HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
+}
+
+int swe2d_p2p_wait_unpack_multi(swe2d_handle *hh, int n, const int32_t *channels, const int32_t *i_buffers)
+{
+    Handle *h = H(hh);
+    if (!h || !h->p2p.zone) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_wait_unpack_multi: not connected");
+    if (n < 1 || n > SWE_P2P_MULTI || !channels || !i_buffers) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_wait_unpack_multi: 1 .. 4 channels");
+    SweP2pUnpackMulti m;
+    int np_max = 0;
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < i; j++) if (channels[j] == channels[i]) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_wait_unpack_multi: a channel twice");
+        if (int rc = p2p_unpack_args(h, channels[i], i_buffers[i], m.a[i])) return rc;
+        np_max = std::max(np_max, m.a[i].np);
+    }
+    if (h->p2p.n_from == 0 || h->n_recv == 0) return SWE2D_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(swe_p2p_unpack_multi_kernel, dim3(std::min(SWE_P2P_MAX_BLOCKS, grid_for(np_max*h->n_recv)), n), dim3(256), 0, h->xstream ? h->xstream : h->stream, m);
+    HIP_TRY(h, hipGetLastError());
+    return SWE2D_OK;
+}
+
+int swe2d_p2p_wait_unpack(swe2d_handle *hh, int channel, int i_buffer)
+{
+    Handle *h = H(hh);
+    if (!h || !h->p2p.zone) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "swe2d_p2p_wait_unpack: not connected");
+    SweP2pUnpackArgs a;
+    if (int rc = p2p_unpack_args(h, channel, i_buffer, a)) return rc;
+    if (h->p2p.n_from == 0 || h->n_recv == 0) return SWE2D_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(swe_p2p_unpack_kernel, dim3(std::min(SWE_P2P_MAX_BLOCKS, grid_for(a.np*h->n_recv))), dim3(256), 0, h->xstream ? h->xstream : h->stream, a);
     HIP_TRY(h, hipGetLastError());
     return SWE2D_OK;
 }

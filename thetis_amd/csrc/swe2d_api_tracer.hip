@@ -4,12 +4,10 @@
 
 namespace {
 
-int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1, double beta, int c0, int c1,
-                        double *mean_out = nullptr)
+// what a tracer stage kernel needs besides its buffers, weights and cell range
+void fill_tracer_args(Handle *h, int id, SweTracerArgs &a, int in, int out, double a0, double a1, double beta, int c0, int c1, double *mean_out)
 {
-    if (c1 <= c0) return SWE2D_OK;
     Handle::Tracer &t = h->tracers[id];
-    SweTracerArgs a;
     a.tin = t.buf[in];
     a.t0 = t.buf[0];
     a.tout = t.buf[out];
@@ -31,13 +29,23 @@ int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1
     for (int m = 0; m < SWE_MAX_MARKERS; m++) { a.bc_vel_kind[m] = t.bc_vel_kind[m]; a.bc_u[m] = t.bc_u[m]; a.bc_v[m] = t.bc_v[m]; a.bc_vel_field[m] = t.bc_vel_field[m]; }
     a.bc_vel_f = t.bc_vel_f;
     for (int m = 0; m < SWE_MAX_MARKERS; m++) a.bc_len[m] = h->bc.len[m];
+    a.opp4 = h->opp4;
+    a.mu_v = t.mu_v; a.mu_const = t.mu_const;
+    a.diff_sipg = 3.0*t.sipg_factor;
+    a.idxc = nullptr;
+}
+
+int launch_tracer_stage(Handle *h, int id, int in, int out, double a0, double a1, double beta, int c0, int c1,
+                        double *mean_out = nullptr)
+{
+    if (c1 <= c0) return SWE2D_OK;
+    Handle::Tracer &t = h->tracers[id];
+    SweTracerArgs a;
+    fill_tracer_args(h, id, a, in, out, a0, a1, beta, c0, c1, mean_out);
     // triangles: cell integral and interior facets of the diffusion inside the stage kernel, boundary facets by a launch
     // over the boundary cells (only when a marker has a diffusive boundary term at all)
     const bool fused_diff = t.diff && opt_on(h, SWE2D_OPT_VISC_FUSION) && h->npc == 3 && h->opp4;
     a.idxc = conn_pays(h, c1 - c0, fused_diff) ? h->idxc : nullptr;
-    a.opp4 = h->opp4;
-    a.mu_v = t.mu_v; a.mu_const = t.mu_const;
-    a.diff_sipg = 3.0*t.sipg_factor;
     tracer_kernel_t kern = (h->npc == 4) ? pick_tracer_kernel_quad(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr, h->affine)
         : fused_diff ? pick_tracer_kernel_diff(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr)
                      : pick_tracer_kernel(h->tracer_use_lf != 0, a0 != 0.0, t.source != nullptr);
@@ -156,11 +164,15 @@ int limiter_apply(Handle *h, int id, int cell_end, bool means_done = false)
     }
     double *t = h->tracers[id].buf[0];
     const int n = h->n_cells, nv = h->lim_nv;
-    if (!means_done)       // swe2d_advance_coupled has the last tracer stage write the means
+    // Small cell ranges (a rank of eight: every launch is latency) on cells whose mean is the nodal average: the vertex kernel forms the
+    // means itself - one launch less (3.5 us of 77 per step on a rank of eight of cfg 4, profiles/r06c_cfg4_rank8_kernel_stats.csv); on
+    // a large mesh every cell would be averaged once per vertex instead of once (72 B read per cell instead of 24 + 24)
+    const bool inline_means = !means_done && (h->npc == 3 || h->affine) && n < 250000;
+    if (!means_done && !inline_means)       // (swe2d_advance_coupled has the last tracer stage write the means)
         hipLaunchKernelGGL(swe_limiter_cell_mean, dim3(grid_for(n)), dim3(256), 0, h->stream, t, h->stride, n, h->lim_mean, h->npc,
                            h->affine ? nullptr : h->cv, h->vx, h->vy);
     hipLaunchKernelGGL(swe_limiter_vertex_bounds, dim3(grid_for(nv)), dim3(256), 0, h->stream, h->lim_v2c_off,
-                       h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_mean, t, h->stride, nv, h->lim_qmin,
+                       h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, inline_means ? nullptr : h->lim_mean, t, h->stride, nv, h->lim_qmin,
                        h->lim_qmax, h->npc);
     if (cell_end > 0)
         hipLaunchKernelGGL(swe_limiter_apply, dim3(grid_for(cell_end)), dim3(256), 0, h->stream, t, h->stride, cell_end,

@@ -1628,6 +1628,7 @@ struct SweTracerArgs {
 __device__ __forceinline__ double swe_tracer_flux_speed(int depth_mode, double hq, double eq, double alq, int elev_given,
                                                         double elev_ext, double flux, double len, double vel_factor)
 {
+#pragma clang fp contract(off)
     const double ee = elev_given ? elev_ext : eq;
     const double Hx = depth_mode == 2 ? swe_wd_depth(hq + ee, alq) : (depth_mode == 1 ? hq + ee : hq);
     return vel_factor*flux/(Hx*len);
@@ -1640,16 +1641,19 @@ __device__ __forceinline__ double swe_tracer_boundary_flux(const SweTracerArgs &
                                                            double eq, double alq, double xa, double xb, int k, int f,
                                                            int npc_, size_t S)
 {
+    // No implicit contraction: inlined into the stage kernels, their boundary epilogues and the fused three-stage kernel, which must all
+    // give the same bits (which product of a*b + c*d is fused depends on the surrounding code otherwise)
+#pragma clang fp contract(off)
     double ue = uq, ve = vq;
     const int vk = p.bc_vel_kind[marker];
     double bu = p.bc_u[marker], bv = p.bc_v[marker];
     if (p.bc_vel_field[marker] && p.bc_vel_f) {                  // tracer_eq_2d.py:100-109 with Function-valued entries
         const size_t pa = (size_t)(2*f)*S + k;
-        bu = xa*p.bc_vel_f[pa] + xb*p.bc_vel_f[pa + S];
-        if (vk == 1) bv = xa*p.bc_vel_f[pa + (size_t)(2*npc_)*S] + xb*p.bc_vel_f[pa + (size_t)(2*npc_ + 1)*S];
+        bu = swe_dot2(xa, p.bc_vel_f[pa], xb, p.bc_vel_f[pa + S]);
+        if (vk == 1) bv = swe_dot2(xa, p.bc_vel_f[pa + (size_t)(2*npc_)*S], xb, p.bc_vel_f[pa + (size_t)(2*npc_ + 1)*S]);
     }
     if (vk >= 3) {
-        const double rl = 1.0/sqrt(nxs*nxs + nys*nys);
+        const double rl = 1.0/sqrt(swe_dot2(nxs, nxs, nys, nys));
         const double sp = swe_tracer_flux_speed(p.depth_mode, hq, eq, alq, vk == 4, bv, bu, p.bc_len[marker], p.vel_factor);
         ue = sp*nxs*rl;
         ve = sp*nys*rl;
@@ -1657,13 +1661,13 @@ __device__ __forceinline__ double swe_tracer_boundary_flux(const SweTracerArgs &
         ue = p.vel_factor*bu;
         ve = p.vel_factor*bv;
     } else if (vk == 2) {
-        const double rl = 1.0/sqrt(nxs*nxs + nys*nys);
+        const double rl = 1.0/sqrt(swe_dot2(nxs, nxs, nys, nys));
         ue = bu*nxs*rl;
         ve = bu*nys*rl;
     }
-    const double unav = 0.5*((uq + ue)*nxs + (vq + ve)*nys);
+    const double unav = 0.5*swe_dot2(uq + ue, nxs, vq + ve, nys);
     if (p.conservative) {                    // flux_up = c_in*uv*s + c_ext*uv_ext*(1-s)
-        const double fin = cq*(uq*nxs + vq*nys), fex = cext*(ue*nxs + ve*nys);
+        const double fin = cq*swe_dot2(uq, nxs, vq, nys), fex = cext*swe_dot2(ue, nxs, ve, nys);
         return unav > 0.0 ? fin : (unav < 0.0 ? fex : 0.5*(fin + fex));
     }
     const double cup = unav > 0.0 ? cq : (unav < 0.0 ? cext : 0.5*(cq + cext));
@@ -1790,9 +1794,144 @@ __device__ __forceinline__ void swe_tracer_boundary_epilogue_tri(const SweTracer
     }
 }
 
+// Advective right-hand side integrals of ONE triangle for the tracer stage (tracer_eq_2d.py:147-193, :341-395): cell integral, source,
+// the three facets.  Shared by swe_tracer_stage_kernel and the three-stages-in-one-launch kernel of swe2d_fuse.h, which must give
+// the same bits: no implicit contraction, every fused multiply-add written out (round 6; rounds 1-5 left the contraction to the
+// compiler, whose choice for a*b + c*d depends on the code around it).
+// u, v: the cell's velocity times tracer_advective_velocity_factor; una / unb (vna / vnb, cna / cnb): the neighbour's velocity
+// (tracer) at its node on my node f + 1 / on my node f, for a boundary facet the cell's own.
+// DEFER: boundary facets whose bit is set in `bdefer` contribute nothing here (the instances with the diffusion fused in evaluate
+// them after the outputs, swe_tracer_boundary_epilogue_tri); otherwise every boundary facet is evaluated in place.
+template <bool LF, bool SRC, bool DEFER>
+__device__ __forceinline__ void swe_tracer_rhs_tri(const SweTracerArgs &p, int k, unsigned k8, unsigned S8, const int nb[3], const int vid[3],
+                                                   const double u[3], const double v[3], const double c[3], const double una[3],
+                                                   const double unb[3], const double vna[3], const double vnb[3], const double cna[3],
+                                                   const double cnb[3], const double nx[3], const double ny[3], double twoA,
+                                                   unsigned bdefer, double b[3])
+{
+#pragma clang fp contract(off)
+    const size_t S = p.stride;
+    double gxs[3], gys[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        gxs[i] = -0.5*nx[(i + 1) % 3];
+        gys[i] = -0.5*ny[(i + 1) % 3];
+    }
+    // cell integral  +(phi div u + u.grad phi) c                                      tracer_eq_2d.py:157-158
+    {
+        const double D12 = fma(gys[2], v[2], fma(gys[1], v[1], fma(gys[0], v[0],
+                           fma(gxs[2], u[2], fma(gxs[1], u[1], gxs[0]*u[0])))))*(1.0/12.0);
+        const double Suc = swe_int2(u, c)*(1.0/12.0), Svc = swe_int2(v, c)*(1.0/12.0);
+        const double cs = c[0] + c[1] + c[2];
+        // conservative form: +grad(phi).u q only                                      tracer_eq_2d.py:358-359
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const double t = swe_dot2(gys[i], Svc, gxs[i], Suc);
+            b[i] = p.conservative ? t : fma(D12, cs + c[i], t);
+        }
+    }
+    if (SRC) {                                                                         // tracer_eq_2d.py:293-297
+        const double A = 0.5*twoA;
+        double s[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) s[i] = swe_ld(swe_rsrc(p.source), k8, i*S8);
+        const double ss = s[0] + s[1] + s[2];
+        if (p.conservative) {                                                          // H*source, :434-436
+            double H[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const double hh = p.vh[vid[i]];
+                const double ee = swe_ld(swe_rsrc(p.uv + 6*S), k8, i*S8);
+                H[i] = p.depth_mode == 2 ? ee : (p.depth_mode == 1 ? hh + ee : hh);       // wetting-drying: the planes hold D
+            }
+            const double Hs = H[0] + H[1] + H[2], Hss = fma(H[2], s[2], fma(H[1], s[1], H[0]*s[0]));
+            const double A60 = A*(1.0/60.0);
+#pragma unroll
+            for (int i = 0; i < 3; i++)      // 60/A int phi_i H s = Hs*ss + sum H_a s_a + H_i*ss + s_i*Hs + 2 H_i s_i
+                b[i] = fma(A60, fma(2.0*H[i], s[i], fma(s[i], Hs, fma(H[i], ss, fma(Hs, ss, Hss)))), b[i]);
+        } else {
+            const double A12 = A*(1.0/12.0);
+#pragma unroll
+            for (int i = 0; i < 3; i++) b[i] = fma(A12, ss + s[i], b[i]);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        const int a = f, bb = (f + 1) % 3;
+        const double nxs = nx[f], nys = ny[f];
+        double Fa = 0.0, Fb = 0.0;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
+            const double uq = swe_dot2(xa, u[a], xb, u[bb]), vq = swe_dot2(xa, v[a], xb, v[bb]), cq = swe_dot2(xa, c[a], xb, c[bb]);
+            const double unown = swe_dot2(uq, nxs, vq, nys);            // |F| u.n of this side   :170-171
+            double fq;
+            if (nb[f] >= 0) {
+                const double un = swe_dot2(xa, una[f], xb, unb[f]), vn = swe_dot2(xa, vna[f], xb, vnb[f]), cn = swe_dot2(xa, cna[f], xb, cnb[f]);
+                const double uavn = 0.5*swe_dot2(uq + un, nxs, vq + vn, nys);              // :163-165
+                const double cup = uavn > 0.0 ? cq : (uavn < 0.0 ? cn : 0.5*(cq + cn));   // :166-168
+                fq = cup*unown;
+                if (p.conservative) {                           // upwind FLUX q u (both from the upwind side), :366-372
+                    const double fn = cn*swe_dot2(un, nxs, vn, nys);
+                    fq = uavn > 0.0 ? cq*unown : (uavn < 0.0 ? fn : 0.5*(cq*unown + fn));
+                }
+                if (LF) fq = fma(0.5*fabs(uavn)*p.lf_factor, cq - cn, fq);                 // :173-175
+            } else if constexpr (DEFER) {
+                // boundary facet of the instances with the diffusion fused in (176-192 VGPRs with the code below inlined: two waves per
+                // SIMD): with a boundary value or an external velocity it is evaluated after the outputs (swe_tracer_boundary_epilogue_tri,
+                // see swe_tracer_stage_kernel_quad) - 150-162 VGPRs, three waves, 1 M cells 127.2 -> 108.9 us per step; here only the
+                // default, the interior state on both sides                                                        :189-191
+                fq = (bdefer >> f) & 1u ? 0.0 : cq*unown;
+            } else {
+                // (the plain instances keep the boundary code inline: at 154 VGPRs they run three waves already, and the epilogue
+                //  form measured 3.5 % slower for them - 102.7 against 99.2 us per step, profiles/r05z3)
+                const int marker = -nb[f];
+                if (marker < SWE_MAX_MARKERS && (p.bc_has_value[marker] || p.bc_vel_kind[marker])) {     // :181-188
+                    const double cext = (p.bc_has_value[marker] == 2)
+                        ? swe_dot2(xa, p.bc_value_f[(size_t)(3*f + a)*S + k], xb, p.bc_value_f[(size_t)(3*f + bb)*S + k])
+                        : (p.bc_has_value[marker] ? p.bc_value[marker] : cq);
+                    double hq = 0.0, eq = 0.0, alq = 0.0;
+                    if (p.bc_vel_kind[marker] >= 3) {                  // 'flux': total depth at the quadrature point
+                        const unsigned va8 = (unsigned)vid[a]*8u, vb8 = (unsigned)vid[bb]*8u;
+                        hq = swe_dot2(xa, swe_ld(swe_rsrc(p.vh), va8, 0), xb, swe_ld(swe_rsrc(p.vh), vb8, 0));
+                        if (p.depth_mode == 2) alq = swe_dot2(xa, swe_ld(swe_rsrc(p.valpha), va8, 0), xb, swe_ld(swe_rsrc(p.valpha), vb8, 0));
+                        const swe_rsrc_t ge = swe_rsrc(p.uv + 6*S);
+                        double ea_ = swe_ld(ge, k8, a*S8), eb_ = swe_ld(ge, k8, bb*S8);
+                        if (p.depth_mode == 2) {           // the planes hold D: the nodal elevations by the closed form
+                            const double aa_ = swe_ld(swe_rsrc(p.valpha), va8, 0), ab_ = swe_ld(swe_rsrc(p.valpha), vb8, 0);
+                            ea_ = ea_ - 0.25*aa_*aa_/ea_ - swe_ld(swe_rsrc(p.vh), va8, 0);
+                            eb_ = eb_ - 0.25*ab_*ab_/eb_ - swe_ld(swe_rsrc(p.vh), vb8, 0);
+                        }
+                        eq = swe_dot2(xa, ea_, xb, eb_);
+                    }
+                    fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys, hq, eq, alq, xa, xb, k, f, 3, S);
+                } else {
+                    fq = cq*unown;                                                         // :189-191
+                }
+            }
+            Fa = fma(xa, fq, Fa);
+            Fb = fma(xb, fq, Fb);
+        }
+        b[a] = fma(-0.5, Fa, b[a]);
+        b[bb] = fma(-0.5, Fb, b[bb]);
+    }
+}
+
+// mass inverse and Shu-Osher combine of a triangle's tracer stage: o = beta dt M^-1 b + w, (M^-1 b)_i = 3/A (4 b_i - sum b)
+__device__ __forceinline__ double swe_tracer_finish_tri(double dt, double beta, double twoA, const double b[3], const double w[3], double o[3])
+{
+#pragma clang fp contract(off)
+    const double s = 6.0*dt*beta*swe_rcp(twoA);
+    const double sb = b[0] + b[1] + b[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[i] = fma(s, fma(4.0, b[i], -sb), w[i]);
+    return s;
+}
+
 template <bool LF, bool HAST0, bool SRC, bool DIFF = false>
 __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTracerArgs p)
 {
+#pragma clang fp contract(off)
 #ifdef SWE_NO_XCD_MAP
     const int lb = blockIdx.x;
 #else
@@ -1814,7 +1953,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
         v[i] = cf*swe_ld(gv, k8, i*S8);
         c[i] = swe_ld(gt, k8, i*S8);
         w[i] = p.a1*c[i];
-        if (HAST0) w[i] += p.a0*swe_ld(swe_rsrc(p.t0), k8, i*S8);
+        if (HAST0) w[i] = fma(p.a0, swe_ld(swe_rsrc(p.t0), k8, i*S8), w[i]);
     }
     unsigned bdefer = 0u;             // boundary facets whose marker carries a boundary value or an external velocity: bit f
     if (DIFF && (nb[0] | nb[1] | nb[2]) < 0) {      // (the tables are read by the lanes - and waves - that own a boundary facet only)
@@ -1853,113 +1992,12 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_tracer_stage_kernel(const SweTr
         nx[f] = py[b] - py[f];
         ny[f] = px[f] - px[b];
     }
-    const double twoA = nx[0]*ny[1] - ny[0]*nx[1];
-    double gxs[3], gys[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        gxs[i] = -0.5*nx[(i + 1) % 3];
-        gys[i] = -0.5*ny[(i + 1) % 3];
-    }
-    // cell integral  +(phi div u + u.grad phi) c                                      tracer_eq_2d.py:157-158
+    const double twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
     double b[3];
-    {
-        const double D12 = (gxs[0]*u[0] + gxs[1]*u[1] + gxs[2]*u[2]
-                            + gys[0]*v[0] + gys[1]*v[1] + gys[2]*v[2])*(1.0/12.0);
-        const double Suc = swe_int2(u, c)*(1.0/12.0), Svc = swe_int2(v, c)*(1.0/12.0);
-        const double cs = c[0] + c[1] + c[2];
-        // conservative form: +grad(phi).u q only                                      tracer_eq_2d.py:358-359
-#pragma unroll
-        for (int i = 0; i < 3; i++) b[i] = (p.conservative ? 0.0 : D12*(cs + c[i])) + gxs[i]*Suc + gys[i]*Svc;
-    }
-    if (SRC) {                                                                         // tracer_eq_2d.py:293-297
-        const double A = 0.5*twoA;
-        double s[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) s[i] = swe_ld(swe_rsrc(p.source), k8, i*S8);
-        const double ss = s[0] + s[1] + s[2];
-        if (p.conservative) {                                                          // H*source, :434-436
-            double H[3];
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const double hh = p.vh[vid[i]];
-                const double ee = swe_ld(swe_rsrc(p.uv + 6*S), k8, i*S8);
-                H[i] = p.depth_mode == 2 ? ee : (p.depth_mode == 1 ? hh + ee : hh);       // wetting-drying: the planes hold D
-            }
-            const double Hs = H[0] + H[1] + H[2], Hss = H[0]*s[0] + H[1]*s[1] + H[2]*s[2];
-#pragma unroll
-            for (int i = 0; i < 3; i++)      // 60/A int phi_i H s = Hs*ss + sum H_a s_a + H_i*ss + s_i*Hs + 2 H_i s_i
-                b[i] += A*(1.0/60.0)*(Hs*ss + Hss + H[i]*ss + s[i]*Hs + 2.0*H[i]*s[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 3; i++) b[i] += A*(1.0/12.0)*(ss + s[i]);
-        }
-    }
-#pragma unroll
-    for (int f = 0; f < 3; f++) {
-        const int a = f, bb = (f + 1) % 3;
-        const double nxs = nx[f], nys = ny[f];
-        double Fa = 0.0, Fb = 0.0;
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const double xb = q ? SWE_XI1 : SWE_XI0, xa = 1.0 - xb;
-            const double uq = xa*u[a] + xb*u[bb], vq = xa*v[a] + xb*v[bb], cq = xa*c[a] + xb*c[bb];
-            const double unown = uq*nxs + vq*nys;                       // |F| u.n of this side   :170-171
-            double fq;
-            if (nb[f] >= 0) {
-                const double un = xa*una[f] + xb*unb[f], vn = xa*vna[f] + xb*vnb[f], cn = xa*cna[f] + xb*cnb[f];
-                const double uavn = 0.5*((uq + un)*nxs + (vq + vn)*nys);                   // :163-165
-                const double cup = uavn > 0.0 ? cq : (uavn < 0.0 ? cn : 0.5*(cq + cn));   // :166-168
-                fq = cup*unown;
-                if (p.conservative) {                           // upwind FLUX q u (both from the upwind side), :366-372
-                    const double fn = cn*(un*nxs + vn*nys);
-                    fq = uavn > 0.0 ? cq*unown : (uavn < 0.0 ? fn : 0.5*(cq*unown + fn));
-                }
-                if (LF) fq += 0.5*fabs(uavn)*p.lf_factor*(cq - cn);                       // :173-175
-            } else if constexpr (DIFF) {
-                // boundary facet of the instances with the diffusion fused in (176-192 VGPRs with the code below inlined: two waves per
-                // SIMD): with a boundary value or an external velocity it is evaluated after the outputs (swe_tracer_boundary_epilogue_tri,
-                // see swe_tracer_stage_kernel_quad) - 150-162 VGPRs, three waves, 1 M cells 127.2 -> 108.9 us per step; here only the
-                // default, the interior state on both sides                                                        :189-191
-                fq = (bdefer >> f) & 1u ? 0.0 : cq*unown;
-            } else {
-                // (the plain instances keep the boundary code inline: at 154 VGPRs they run three waves already, and the epilogue
-                //  form measured 3.5 % slower for them - 102.7 against 99.2 us per step, profiles/r05z3)
-                const int marker = -nb[f];
-                if (marker < SWE_MAX_MARKERS && (p.bc_has_value[marker] || p.bc_vel_kind[marker])) {     // :181-188
-                    const double cext = (p.bc_has_value[marker] == 2)
-                        ? xa*p.bc_value_f[(size_t)(3*f + a)*S + k] + xb*p.bc_value_f[(size_t)(3*f + bb)*S + k]
-                        : (p.bc_has_value[marker] ? p.bc_value[marker] : cq);
-                    double hq = 0.0, eq = 0.0, alq = 0.0;
-                    if (p.bc_vel_kind[marker] >= 3) {                  // 'flux': total depth at the quadrature point
-                        const unsigned va8 = (unsigned)vid[a]*8u, vb8 = (unsigned)vid[bb]*8u;
-                        hq = xa*swe_ld(swe_rsrc(p.vh), va8, 0) + xb*swe_ld(swe_rsrc(p.vh), vb8, 0);
-                        if (p.depth_mode == 2) alq = xa*swe_ld(swe_rsrc(p.valpha), va8, 0) + xb*swe_ld(swe_rsrc(p.valpha), vb8, 0);
-                        const swe_rsrc_t ge = swe_rsrc(p.uv + 6*S);
-                        double ea_ = swe_ld(ge, k8, a*S8), eb_ = swe_ld(ge, k8, bb*S8);
-                        if (p.depth_mode == 2) {           // the planes hold D: the nodal elevations by the closed form
-                            const double aa_ = swe_ld(swe_rsrc(p.valpha), va8, 0), ab_ = swe_ld(swe_rsrc(p.valpha), vb8, 0);
-                            ea_ = ea_ - 0.25*aa_*aa_/ea_ - swe_ld(swe_rsrc(p.vh), va8, 0);
-                            eb_ = eb_ - 0.25*ab_*ab_/eb_ - swe_ld(swe_rsrc(p.vh), vb8, 0);
-                        }
-                        eq = xa*ea_ + xb*eb_;
-                    }
-                    fq = swe_tracer_boundary_flux(p, marker, cq, cext, uq, vq, nxs, nys, hq, eq, alq, xa, xb, k, f, 3, S);
-                } else {
-                    fq = cq*unown;                                                         // :189-191
-                }
-            }
-            Fa += xa*fq;
-            Fb += xb*fq;
-        }
-        b[a] -= 0.5*Fa;
-        b[bb] -= 0.5*Fb;
-    }
+    swe_tracer_rhs_tri<LF, SRC, DIFF>(p, k, k8, S8, nb, vid, u, v, c, una, unb, vna, vnb, cna, cnb, nx, ny, twoA, bdefer, b);
     if (DIFF) swe_diff_interior(p, k, S8, gt, nb, vid, c, cna, cnb, px, py, nx, ny, twoA, b);
-    const double s = 6.0*p.dt*p.beta*swe_rcp(twoA);
-    const double sb = b[0] + b[1] + b[2];
     double msum = 0.0, o[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) o[i] = s*(4.0*b[i] - sb) + w[i];
+    const double s = swe_tracer_finish_tri(p.dt, p.beta, twoA, b, w, o);
     if (bdefer) swe_tracer_boundary_epilogue_tri(p, k, bdefer, s, o);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -2003,7 +2041,14 @@ static __global__ void swe_limiter_vertex_bounds(const int *v2c_off, const int *
     if (v >= nv) return;
     double lo = 1.0e10, hi = -1.0e10;
     for (int j = v2c_off[v]; j < v2c_off[v + 1]; j++) {
-        const double m = mean[v2c_cell[j]];
+        const int kc = v2c_cell[j];
+        double m;
+        if (mean) m = mean[kc];
+        else {                                   // no means array: the nodal average formed here (swe_limiter_cell_mean's sum, same bits)
+            double s = 0.0;
+            for (int i = 0; i < npc; i++) s += t[(size_t)i*stride + kc];
+            m = s/(double)npc;
+        }
         lo = fmin(lo, m);
         hi = fmax(hi, m);
     }

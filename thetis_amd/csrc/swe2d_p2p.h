@@ -94,7 +94,7 @@ __device__ __forceinline__ int swe_p2p_peer_of(const SweP2pPushArgs &a, int j)
     return p;
 }
 
-static __global__ __launch_bounds__(256) void swe_p2p_push_kernel(const SweP2pPushArgs a)
+__device__ __forceinline__ void swe_p2p_push_body(const SweP2pPushArgs &a)
 {
     const unsigned long long target = a.ctr->epoch_send + 1ull;      // every workgroup reads it before the last one advances it
     const int total = a.np*a.n_send, step = gridDim.x*256;
@@ -131,7 +131,16 @@ static __global__ __launch_bounds__(256) void swe_p2p_push_kernel(const SweP2pPu
     }
 }
 
-static __global__ __launch_bounds__(256) void swe_p2p_unpack_kernel(const SweP2pUnpackArgs a)
+static __global__ __launch_bounds__(256) void swe_p2p_push_kernel(const SweP2pPushArgs a) { swe_p2p_push_body(a); }
+
+// Several channels (the shallow water state and the tracers of a coupled cycle) in ONE launch: blockIdx.y is the channel, every
+// channel keeps its own epoch counters, tickets and flags - exactly the single-channel kernels side by side, two kernel boundaries
+// per channel less (6-7 us each on a rank of eight: profiles/r06c_cfg4_rank8_kernel_stats.csv)
+#define SWE_P2P_MULTI 4
+struct SweP2pPushMulti { SweP2pPushArgs a[SWE_P2P_MULTI]; };
+static __global__ __launch_bounds__(256) void swe_p2p_push_multi_kernel(const SweP2pPushMulti m) { swe_p2p_push_body(m.a[blockIdx.y]); }
+
+__device__ __forceinline__ void swe_p2p_unpack_body(const SweP2pUnpackArgs &a)
 {
     const unsigned long long target = a.ctr->epoch_recv + 1ull;
     if (threadIdx.x == 0) {
@@ -173,3 +182,7 @@ static __global__ __launch_bounds__(256) void swe_p2p_unpack_kernel(const SweP2p
         }
     }
 }
+
+static __global__ __launch_bounds__(256) void swe_p2p_unpack_kernel(const SweP2pUnpackArgs a) { swe_p2p_unpack_body(a); }
+struct SweP2pUnpackMulti { SweP2pUnpackArgs a[SWE_P2P_MULTI]; };
+static __global__ __launch_bounds__(256) void swe_p2p_unpack_multi_kernel(const SweP2pUnpackMulti m) { swe_p2p_unpack_body(m.a[blockIdx.y]); }

@@ -706,6 +706,14 @@ class Swe2dDevice(object):
     def p2p_wait_unpack(self, channel, i_buffer):
         self._ck(self.lib.swe2d_p2p_wait_unpack(self.h, int(channel), int(i_buffer)))
 
+    def p2p_push_multi(self, channels, i_buffers):
+        c, b = np.ascontiguousarray(channels, dtype=np.int32), np.ascontiguousarray(i_buffers, dtype=np.int32)
+        self._ck(self.lib.swe2d_p2p_push_multi(self.h, len(c), _iptr(c), _iptr(b)))
+
+    def p2p_wait_unpack_multi(self, channels, i_buffers):
+        c, b = np.ascontiguousarray(channels, dtype=np.int32), np.ascontiguousarray(i_buffers, dtype=np.int32)
+        self._ck(self.lib.swe2d_p2p_wait_unpack_multi(self.h, len(c), _iptr(c), _iptr(b)))
+
     def p2p_status(self, n_channels=1):
         """(epochs sent, epochs received, number of timed-out waits) after a stream synchronisation"""
         a = (ctypes.c_int64*n_channels)()

@@ -786,6 +786,16 @@ class DistributedSwe2d(object):
         sent = False
         fe = self.stages_per_step == 1         # ForwardEuler: a "stage" is the whole step, buffer 0 -> 1, then the buffers swap
         ops = self._coupled_ops(n_steps)[early_done:]
+        nt = len(self.tids)
+        # peer-to-peer halos: the shallow water state and the tracers leave together at the end of the cycle, ONE push and ONE
+        # wait-and-unpack launch for all channels (swe2d_p2p_push_multi: the channels' kernels side by side) instead of one pair per
+        # channel - on a rank of eight of cfg 4 the four exchange kernels of a cycle were 13 of 77 us per step
+        # (profiles/r06c_cfg4_rank8_kernel_stats.csv); the shallow water state has nothing to overlap with that the tracers' exchange,
+        # which cannot start earlier, does not wait for anyway
+        # (not with overlap_stages: the early shallow water stages of the next cycle need this cycle's shallow water ghosts, which the
+        #  per-channel exchange has received by then)
+        merged = (self.p2p is not None and not self._through_host() and self.xstream is None and not self._no_exchange
+                  and self.overlap_stages == 0 and not early_next and 1 + nt <= 4 and hasattr(dev, 'p2p_push_multi'))
         skip = False
         for i_op, op in enumerate(ops):
             if skip:                           # the second stage of a pair that went out as one launch
@@ -802,7 +812,8 @@ class DistributedSwe2d(object):
                 else:
                     dev.solve_stage_cells(op[1], 0, op[2])
             elif op[0] == 'swe_done':
-                reqs = self._send(0, 0)               # travels while the tracers step
+                if not merged:
+                    reqs = self._send(0, 0)           # travels while the tracers step
                 sent = True
             elif op[0] == 'tracer':
                 dev.tracer_solve_stage_cells(self.tids[op[1]], op[2], 0, op[3])
@@ -810,9 +821,13 @@ class DistributedSwe2d(object):
                     dev.tracer_swap_buffers(self.tids[op[1]])
             else:
                 dev.tracer_limit_cells(self.tids[op[1]], op[2])
+        if merged:
+            channels = ([0] if sent else []) + [1 + i for i in range(nt)]
+            dev.p2p_push_multi(channels, [0]*len(channels))
+            dev.p2p_wait_unpack_multi(channels, [0]*len(channels))
+            return
         if sent:
             self._receive(0, 0, reqs)
-        nt = len(self.tids)
         for i in range(nt):
             reqs = self._send(1 + i, 0)
             if i == nt - 1:

@@ -136,13 +136,14 @@ def main():
     if only == 'cfg5_profile':
         return cfg5(12, True)
     # ---- cfg 2 reference point: triangles, SWE only (684 B per cell per step)
-    mesh = RectangleMesh(1000, 500, 100e3, 50e3)
+    nx = int(os.environ.get('CFGBENCH_NX', '1000'))       # 2000: the same channel with 4 M triangles (beyond the Infinity Cache)
+    mesh = RectangleMesh(nx, nx//2, 100e3, 50e3)
     n = mesh.num_cells
     bath = np.full(mesh.num_vertices, 20.0)
     cxy = mesh.cell_xy()
     eta = 0.5*np.exp(-((cxy[:, :, 0] - 50e3)**2 + (cxy[:, :, 1] - 25e3)**2)/(5e3)**2) + 1e-3*rng.uniform(-1, 1, size=(n, 3))
     uv = 1e-3*rng.uniform(-1, 1, size=(n, 3, 2))
-    dev = Swe2dDevice(mesh, bath, 0.25)
+    dev = Swe2dDevice(mesh, bath, 0.25*1000.0/nx)
     dev.set_state(uv, eta)
     report('cfg2 triangles SWE', n, 684.0, timed(dev, dev.advance, 50))
     # ---- the same with the source terms of a tidal case: Coriolis field (24 B per cell and stage), Manning friction, wind stress (48 B)
@@ -158,10 +159,13 @@ def main():
     #      = 132 / 156 / 156 B; limiter once per step: 24 r (means) + 8 w + 8 r + vertex bounds ~16 + 24 r + 24 w + 12 idx ~ 116 B
     tid = dev.add_tracer()
     dev.tracer_set_state(tid, np.where(cxy[:, :, 0] < 40e3, 0.0, 30.0))
+    fz = {'fused_pair': bool(dev.fused_pair_info()[0])}
     report('cfg4 triangles SWE + tracer + limiter', n, 684.0 + 444.0 + 116.0,
-           timed(dev, lambda k: dev.advance_coupled(k, tracer_only=False, use_limiter=True), 50))
+           timed(dev, lambda k: dev.advance_coupled(k, tracer_only=False, use_limiter=True), 50), fz)
     report('cfg4 tracer only + limiter', n, 444.0 + 116.0,
-           timed(dev, lambda k: dev.advance_coupled(k, tracer_only=True, use_limiter=True), 50))
+           timed(dev, lambda k: dev.advance_coupled(k, tracer_only=True, use_limiter=True), 50), fz)
+    report('tracer only, no limiter', n, 444.0,
+           timed(dev, lambda k: dev.advance_coupled(k, tracer_only=True, use_limiter=False), 50), fz)
     # ---- optional SIPG passes (swe2d_sipg.h): per stage the pass re-reads the rows (+ neighbour rows through L2) and
     #      read-modify-writes them: viscosity 48 r + 48 r/w + 24 eta + 36 static = 204 B, tracer diffusion 24 + 48 + 36 = 108 B
     dev.tracer_set_diffusivity(tid, 10.0)
