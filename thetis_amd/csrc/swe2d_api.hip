@@ -445,7 +445,6 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
 
     if (npc == 3) {
         h->h_nbr = nbr;
-        h->host_cv = cv;
         std::vector<int4> p4((size_t)S, int4{0, 0, 0, 0});
         std::vector<int2> p2((size_t)S, int2{0, 0});
         for (int kk = 0; kk < n; kk++) {

@@ -53,9 +53,8 @@ int fuse12_build(Handle *h)
     const int n = h->n_cells;
     const size_t S = h->stride;
     const int *nbr = h->h_nbr.data();
-    std::vector<int4> tl;                                             // two per lane
+    std::vector<int2> tl;
     std::vector<int> inner;
-    const int *cvh = h->host_cv.data();
     std::vector<int> state((size_t)n, 0), lane_of((size_t)n, -1);      // 0 outside | 1 interior | 2 ring, of the tile being built
     std::vector<int> ring, cells;
     long long n_ring_total = 0;
@@ -92,26 +91,23 @@ int fuse12_build(Handle *h)
         if (nt - ni != n_ring || nt > SWE_FUSE_WG) return fail(h, SWE2D_ERR_UNSUPPORTED, "fused stage pair: tile bookkeeping");
         for (int l = 0; l < nt; l++) lane_of[cells[l]] = l;
         const size_t base = tl.size();
-        tl.resize(base + 2*SWE_FUSE_WG, int4{-1, 0, 0, 0});
+        tl.resize(base + SWE_FUSE_WG, int2{-1, 0});
         int n_out = 0;
         for (int l = 0; l < nt; l++) {
             const int c = cells[l];
             unsigned w = 0u;
-            int x[3];
             for (int f = 0; f < 3; f++) {
                 const int code = nbr[(size_t)f*S + c];
                 unsigned field;
-                x[f] = code;                                                         // outside the tile, or the boundary marker
                 if (code < 0) field = (unsigned)l;                                   // boundary facet: the cell itself
-                else if (state[code >> 2] != 0) { field = (unsigned)lane_of[code >> 2]; x[f] = code & 3; }
+                else if (state[code >> 2] != 0) field = (unsigned)lane_of[code >> 2];
                 else {
                     if (l < ni || n_out >= SWE_FUSE_MAX_OUT) return fail(h, SWE2D_ERR_UNSUPPORTED, "fused stage pair: ring bookkeeping");
                     field = 0x200u | (unsigned)n_out++;
                 }
                 w |= field << (SWE_FUSE_FBITS*f);
             }
-            tl[base + 2*l] = int4{c, (int)w, x[0], x[1]};
-            tl[base + 2*l + 1] = int4{cvh[c], cvh[S + c], cvh[2*S + c], x[2]};
+            tl[base + l] = int2{c, (int)w};
         }
         inner.push_back(ni);
         n_ring_total += nt - ni;
@@ -125,9 +121,9 @@ int fuse12_build(Handle *h)
         h->fuse_state = -1; h->fuse_n_tiles = 0;
         return SWE2D_OK;
     }
-    HIP_TRY(h, hipMalloc(&h->fuse_tile, tl.size()*sizeof(int4)));
+    HIP_TRY(h, hipMalloc(&h->fuse_tile, tl.size()*sizeof(int2)));
     HIP_TRY(h, hipMalloc(&h->fuse_inner, inner.size()*sizeof(int)));
-    HIP_TRY(h, hipMemcpy(h->fuse_tile, tl.data(), tl.size()*sizeof(int4), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->fuse_tile, tl.data(), tl.size()*sizeof(int2), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->fuse_inner, inner.data(), inner.size()*sizeof(int), hipMemcpyHostToDevice));
     h->fuse_ring_cells = n_ring_total;
     return SWE2D_OK;
@@ -178,9 +174,7 @@ int fuse123_build(Handle *h)
     const size_t S = h->stride;
     const int *nbr = h->h_nbr.data();
     const int *order = (int)h->fuse_order.size() == n ? h->fuse_order.data() : nullptr;
-    std::vector<int4> tl;                                             // two per lane
-    std::vector<int2> cnt;
-    const int *cvh = h->host_cv.data();
+    std::vector<int2> tl, cnt;
     std::vector<unsigned char> state((size_t)n, 0);                // 0 outside | 1 interior | 2 ring 1 | 3 ring 2, of the tile being built
     std::vector<int> lane_of((size_t)n, -1), touched, inner;
     std::vector<std::pair<int, unsigned char>> undo;
@@ -228,35 +222,32 @@ int fuse123_build(Handle *h)
         if (nt != count[1] + count[2] + count[3] || ni != count[1] || nt > SWE_FUSE_WG) return fail(h, SWE2D_ERR_UNSUPPORTED, "fused stages: tile bookkeeping");
         for (int l = 0; l < nt; l++) lane_of[cells[l]] = l;
         const size_t base = tl.size();
-        tl.resize(base + 2*SWE_FUSE_WG, int4{-1, 0, 0, 0});
+        tl.resize(base + SWE_FUSE_WG, int2{-1, 0});
         int n_out = 0;
         for (int l = 0; l < nt; l++) {
             const int c = cells[l];
             unsigned w = 0u;
-            int x[3];
             for (int f = 0; f < 3; f++) {
                 const int code = nbr[(size_t)f*S + c];
                 unsigned field;
-                x[f] = code;
                 if (code < 0) field = (unsigned)l;                                   // boundary facet: the cell itself
-                else if (state[code >> 2] != 0) { field = (unsigned)lane_of[code >> 2]; x[f] = code & 3; }
+                else if (state[code >> 2] != 0) field = (unsigned)lane_of[code >> 2];
                 else {
                     if (l < nm || n_out >= SWE_FUSE3_MAX_OUT) return fail(h, SWE2D_ERR_UNSUPPORTED, "fused stages: ring bookkeeping");
                     field = 0x200u | (unsigned)n_out++;
                 }
                 w |= field << (SWE_FUSE_FBITS*f);
             }
-            tl[base + 2*l] = int4{c, (int)w, x[0], x[1]};
-            tl[base + 2*l + 1] = int4{cvh[c], cvh[S + c], cvh[2*S + c], x[2]};
+            tl[base + l] = int2{c, (int)w};
         }
         cnt.push_back(int2{ni, nm});
         r1_total += count[2]; r2_total += count[3];
         for (int c : cells) { state[c] = 0; lane_of[c] = -1; }
     }
     h->fuse3_n_tiles = (int)cnt.size();
-    HIP_TRY(h, hipMalloc(&h->fuse3_tile, tl.size()*sizeof(int4)));
+    HIP_TRY(h, hipMalloc(&h->fuse3_tile, tl.size()*sizeof(int2)));
     HIP_TRY(h, hipMalloc(&h->fuse3_cnt, cnt.size()*sizeof(int2)));
-    HIP_TRY(h, hipMemcpy(h->fuse3_tile, tl.data(), tl.size()*sizeof(int4), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->fuse3_tile, tl.data(), tl.size()*sizeof(int2), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->fuse3_cnt, cnt.data(), cnt.size()*sizeof(int2), hipMemcpyHostToDevice));
     h->fuse3_ring1 = r1_total; h->fuse3_ring2 = r2_total;
     return SWE2D_OK;

@@ -35,12 +35,8 @@
 
 struct SweFuseArgs {
     SweStageArgs st;          // uin = U(0) (state buffer A); geometry, connectivity, boundary tables; dt, g, sigma_lf
-    const int4 *tile;         // [n_tiles][256][2]: {cell or -1, w, x0, x1}, {vertex 0, 1, 2, x2}.  w: per facet 10 bits - [8:0] lane of
-                              //  the neighbour in the tile (a boundary facet: the lane itself) or, with bit 9 set, the staging slot of a
-                              //  neighbour outside the tile; x_f: the facet's neighbour code - (cell << 2 | facet in it) outside the tile,
-                              //  -marker on the boundary, just the facet in the neighbour (0 .. 2) inside the tile.  Everything a lane needs
-                              //  to issue its loads in ONE record: the connectivity records of the stage kernels would be a second
-                              //  dependent trip to memory per tile (round 6)
+    const int2 *tile;         // [n_tiles][256]: {cell or -1, per facet 10 bits: [8:0] lane of the neighbour in the tile (a boundary
+                              //  facet: the lane itself) or, with bit 9 set, the staging slot of a neighbour outside the tile}
     const int *n_inner;       // [n_tiles]: lanes 0 .. n_inner-1 hold the interior cells
     int n_tiles;
     int cell_end;             // stage 2 updates the interior cells < cell_end (a partition's shrinking stage ranges; else n_cells)
@@ -59,7 +55,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
     const int tile = swe_logical_block(blockIdx.x, gridDim.x);
     if (tile >= q.n_tiles) return;                         // padding of the grid to a multiple of 8
     const int lane = (int)threadIdx.x;
-    const int4 tl = q.tile[2*((size_t)tile*SWE_FUSE_WG + lane)], tv = q.tile[2*((size_t)tile*SWE_FUSE_WG + lane) + 1];
+    const int2 tl = q.tile[(size_t)tile*SWE_FUSE_WG + lane];
     const bool real = tl.x >= 0;
     const int k = real ? tl.x : 0;
     const int n_inner = q.n_inner[tile];
@@ -72,7 +68,8 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
     unsigned tr[3][1];
     double h[3], nx[3], ny[3], u[3], v[3], e[3];
     if (real) {
-        const int nb[3] = {tl.z, tl.w, tv.w}, vid[3] = {tv.x, tv.y, tv.z};
+        int nb[3], vid[3];
+        swe_conn_load(p.idxc, p.idx4, p.idx2, k, nb, vid);
         bmarkers = (nb[0] < 0 ? -nb[0] : 0) | (nb[1] < 0 ? (-nb[1]) << 8 : 0) | (nb[2] < 0 ? (-nb[2]) << 16 : 0);
         if (bmarkers != 0) {
             const int m1 = (bmarkers & 0xff) ? (bmarkers & 0xff) : ((bmarkers & 0xff00) ? ((bmarkers >> 8) & 0xff) : (bmarkers >> 16));
@@ -205,7 +202,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
 
 struct SweFuse3Args {
     SweStageArgs st;          // uin = U(0) (state buffer A); geometry, connectivity, boundary tables; dt, g, sigma_lf
-    const int4 *tile;         // [n_tiles][256][2]: records as SweFuseArgs::tile
+    const int2 *tile;         // [n_tiles][256]: as SweFuseArgs::tile (lane of the neighbour in the tile, or bit 9 + staging slot)
     const int2 *counts;       // [n_tiles]: {n_inner, n_mid}
     int n_tiles;
     double a0[3], a1[3], beta[3];   // Shu-Osher weights per stage (swe2d_ssprk33_coefficients)
@@ -221,7 +218,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse123_kern
     const int tile = swe_logical_block(blockIdx.x, gridDim.x);
     if (tile >= q.n_tiles) return;                         // padding of the grid to a multiple of 8
     const int lane = (int)threadIdx.x;
-    const int4 tl = q.tile[2*((size_t)tile*SWE_FUSE_WG + lane)], tv = q.tile[2*((size_t)tile*SWE_FUSE_WG + lane) + 1];
+    const int2 tl = q.tile[(size_t)tile*SWE_FUSE_WG + lane];
     const bool real = tl.x >= 0;
     const int k = real ? tl.x : 0;
     const int2 cnt = q.counts[tile];
@@ -233,7 +230,8 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse123_kern
     unsigned tr[3][1];
     double h[3], nx[3], ny[3], u[3], v[3], e[3];
     if (real) {
-        const int nb[3] = {tl.z, tl.w, tv.w}, vid[3] = {tv.x, tv.y, tv.z};
+        int nb[3], vid[3];
+        swe_conn_load(p.idxc, p.idx4, p.idx2, k, nb, vid);
         bmarkers = (nb[0] < 0 ? -nb[0] : 0) | (nb[1] < 0 ? (-nb[1]) << 8 : 0) | (nb[2] < 0 ? (-nb[2]) << 16 : 0);
         if (bmarkers != 0) {
             const int m1 = (bmarkers & 0xff) ? (bmarkers & 0xff) : ((bmarkers & 0xff00) ? ((bmarkers >> 8) & 0xff) : (bmarkers >> 16));
@@ -361,3 +359,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse123_kern
 // (Round 6, measured and removed: the three stages of a TRACER step in one launch on these two-ring tiles - the tracer in LDS between
 //  the stages, the velocity traces in registers, bit for bit the stage launches.  Slower at every size: tracer only at 1 M cells 89.7
 //  against 78.0 us per step, at 4 M 424.9 against 391.6 - profiles/r06d_cfgs*.txt, r06e_cfgs_4m.txt, DESIGN_ANNEX.md A8.)
+//
+// (Also measured and not kept: tile records that carry the cell's connectivity - 32 B per lane, two int4 - so that a lane issues its
+//  loads after ONE trip to memory instead of two (tile entry, then the connectivity record): 2-6 % slower at 250 k ... 4 M cells,
+//  the 12 B per cell it adds cost more than the trip it saves - profiles/r06f_fused_sizes.txt against r06b_fused_sizes.txt.)

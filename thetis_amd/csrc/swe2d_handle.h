@@ -121,20 +121,18 @@ struct Handle {
     int2 *idx2 = nullptr;
     int4 *idxc = nullptr;                               // ... in 16 B (swe_conn_pack), what the stage kernels read (SWE2D_OPT_COMPACT_IDX)
     // stages 1 + 2 of a step in one launch by overlapped tiles (swe2d_fuse.h; SWE2D_OPT_FUSED_STAGES): tile tables, built at first use
-    int4 *fuse_tile = nullptr;                          // two int4 per lane (SweFuseArgs::tile)
+    int2 *fuse_tile = nullptr;
     int *fuse_inner = nullptr;
     int fuse_n_tiles = 0;
     int fuse_state = 0;                                 // -1: the numbering gives poor tiles, -2: first use inside a stream capture: stage launches
     long long fuse_ring_cells = 0;
     // ... all three stages in one launch, two rings per tile (SWE2D_OPT_FUSED_STAGES = 3): tile tables, built at first use
-    int4 *fuse3_tile = nullptr;
-    int2 *fuse3_cnt = nullptr;
+    int2 *fuse3_tile = nullptr, *fuse3_cnt = nullptr;
     int fuse3_n_tiles = 0;
     long long fuse3_ring1 = 0, fuse3_ring2 = 0;
     std::vector<int> fuse_order;                        // cells in the order the tiles are cut from (swe2d_fused_set_order); empty: the numbering
     int n_conn_escapes = 0;                             // cells whose record is an escape to the wide ones
     std::vector<int> h_nbr;                             // host copy of the packed neighbour codes [3][S] (triangles; flow_build)
-    std::vector<int> host_cv;                           // ... and of the vertex ids [3][S] (triangles; the tile records of swe2d_fuse.h)
     // dataflow stage loop (swe2d_flow.h): per-block stage counters, status word {timeouts, first late block + 1}
     unsigned *flow_flag = nullptr, *flow_status = nullptr;
     int4 *flow_xo4 = nullptr;                           // exchange slots of the rim facets (facets between two 64-cell blocks), see SweFlowArgs

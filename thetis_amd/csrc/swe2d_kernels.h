@@ -2229,8 +2229,10 @@ __device__ __forceinline__ void swe_quad_mass_solve(const SweQuadLDL &F, double 
 // the boundary code here, where little else is live, the kernel fits three (140-167; profiles/r05g_quad_three_waves.txt).
 // The residual is linear in the facet contributions: the same result up to summation order.
 template <bool NONLIN, bool LF, bool WD, bool AFFINE>
+// uin / Su / ku: where the stage's input lives - the state planes (p.uin, the stride, the cell) for the stage launches, the LDS planes of a
+// tile (the lane) for the fused stage pair of swe2d_fuse.h; beta: the stage's weight
 __device__ __forceinline__ void swe_boundary_epilogue_quad(const SweStageArgs &p, int k, unsigned bmarkers, double ou[4], double ov[4],
-                                                           double oe[4])
+                                                           double oe[4], const double *uin, size_t Su, int ku, double beta)
 {
 #pragma clang fp contract(off)
     const size_t S = p.stride;
@@ -2249,7 +2251,7 @@ __device__ __forceinline__ void swe_boundary_epilogue_quad(const SweStageArgs &p
             d2 = fma(cx, by, -(cy*bx));
         }
     }
-    const double sb = p.dt*p.beta;
+    const double sb = p.dt*beta;
     const double s = AFFINE ? sb*swe_rcp(A) : sb;
     SweQuadLDL Fb;
     if constexpr (!AFFINE) {
@@ -2267,9 +2269,9 @@ __device__ __forceinline__ void swe_boundary_epilogue_quad(const SweStageArgs &p
         const double xa_ = p.vx[va], ya_ = p.vy[va], xb_ = p.vx[vb], yb_ = p.vy[vb];
         const double ha = p.vh[va], hb = p.vh[vb];
         const double ala = WD ? p.valpha[va] : 0.0, alb = WD ? p.valpha[vb] : 0.0;
-        const double ua = p.uin[(size_t)a*S + k], ub = p.uin[(size_t)b*S + k];
-        const double va_ = p.uin[(size_t)(4 + a)*S + k], vb_ = p.uin[(size_t)(4 + b)*S + k];
-        const double da_ = p.uin[(size_t)(8 + a)*S + k], db_ = p.uin[(size_t)(8 + b)*S + k];      // eta, or D with wetting-drying
+        const double ua = uin[(size_t)a*Su + ku], ub = uin[(size_t)b*Su + ku];
+        const double va_ = uin[(size_t)(4 + a)*Su + ku], vb_ = uin[(size_t)(4 + b)*Su + ku];
+        const double da_ = uin[(size_t)(8 + a)*Su + ku], db_ = uin[(size_t)(8 + b)*Su + ku];      // eta, or D with wetting-drying
         const double ea = WD ? swe_wd_eta(da_, ha, ala) : da_, eb = WD ? swe_wd_eta(db_, hb, alb) : db_;
         const double Ha = WD ? da_ : (NONLIN ? ha + ea : ha);
         const double Hb = WD ? db_ : (NONLIN ? hb + eb : hb);
@@ -2309,68 +2311,23 @@ __device__ __forceinline__ void swe_boundary_epilogue_quad(const SweStageArgs &p
     }
 }
 
-// AFFINE = false: general quadrilaterals (see above)
-template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD, bool AFFINE = true>
-__global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStageArgs p)
+// One stage of one quadrilateral from its inputs in registers to its outputs in registers: geometry, the four facets (u ... e: the
+// cell's nodal values as the planes hold them; una / unb ...: the neighbour's values at its node on my node f / on my node f + 1, for
+// a boundary facet the cell's own), U(0), the cell quadrature, the optional terms, mass inverse, Shu-Osher combine, boundary facets,
+// wetting-drying.  Shared by swe_stage_kernel_quad and the fused stage pair of swe2d_fuse.h (TILE: the stage's input and the lane's own
+// U(0) live in the LDS planes `tin` of a tile - [12] stage values then [12] of U(0), stride Su, lane ku - instead of the state planes):
+// the same operations in the same order, the same bits.
+template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD, bool AFFINE, bool TILE>
+__device__ __forceinline__ void swe_quad_stage_cell(const SweStageArgs &p, int k, unsigned k8, unsigned S8, const int nb[4], const int vid[4],
+                                                    unsigned bmarkers, double u[4], double v[4], double e[4], const double una[4],
+                                                    const double unb[4], const double vna[4], const double vnb[4], const double ena[4],
+                                                    const double enb[4], double a0, double a1, double beta, const double *tin, size_t Su,
+                                                    int ku, double ou[4], double ov[4], double oe[4])
 {
-    // no implicit contraction (see swe_stage_kernel)
 #pragma clang fp contract(off)
-#ifdef SWE_NO_XCD_MAP
-    int lb = blockIdx.x;
-#else
-    int lb = swe_logical_block(blockIdx.x, gridDim.x);
-#endif
-    if (p.reverse) {              // see swe_stage_kernel: launches beyond the Infinity Cache alternate their direction
-        lb = (p.cell_end - p.cell_begin + SWE_BLOCK - 1)/SWE_BLOCK - 1 - lb;
-        if (lb < 0) return;
-    }
-    const int k = p.cell_begin + lb*SWE_BLOCK + (int)threadIdx.x;
-    if (k >= p.cell_end) return;
+    double wu[4], wv[4], we[4];
     const size_t S = p.stride;
     const double g = p.g;
-    // raw buffer addressing (see swe_ld): one resource per group of four planes, 4*stride*8 < 2^32 checked at create
-    const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u, S4 = (unsigned)S*4u, k4 = (unsigned)k*4u;
-    const swe_rsrc_t gu = swe_rsrc(p.uin), gv = swe_rsrc(p.uin + 4*S), ge = swe_rsrc(p.uin + 8*S);
-
-    double u[4], v[4], e[4];
-    int nb[4], vid[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        nb[i] = swe_ldi(swe_rsrc(p.nbr), k4, i*S4);
-        vid[i] = swe_ldi(swe_rsrc(p.cv), k4, i*S4);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        u[i] = swe_ld(gu, k8, i*S8);
-        v[i] = swe_ld(gv, k8, i*S8);
-        e[i] = swe_ld(ge, k8, i*S8);
-    }
-    // boundary markers of the four facets in one register (0: interior facet): all the boundary pass at the end needs of nb[]
-    const unsigned bmarkers = (nb[0] < 0 ? (unsigned)(-nb[0]) : 0u) | (nb[1] < 0 ? (unsigned)(-nb[1]) << 8 : 0u) |
-                              (nb[2] < 0 ? (unsigned)(-nb[2]) << 16 : 0u) | (nb[3] < 0 ? (unsigned)(-nb[3]) << 24 : 0u);
-    // (U(0) of the velocity and of eta is NOT requested here: its twelve values would be live through the facet loop - 24 of the
-    //  registers that kept this kernel at two waves per SIMD; see below)
-    double wu[4], wv[4], we[4];
-    double una[4], unb[4], vna[4], vnb[4], ena[4], enb[4];
-    {   // (an LDS exchange of the in-wave traces as in swe_stage_kernel<..., LDSX> was measured: 201 vs 203 us/step at 1 M
-        //  quadrilaterals - this kernel is bound by its 198 VGPRs and its arithmetic, not by the gathers; not kept)
-#pragma unroll
-        for (int f = 0; f < 4; f++) {
-            const int nbf = nb[f];
-            const int kn = nbf >= 0 ? (nbf >> 2) : k;
-            const int f2 = nbf >= 0 ? (nbf & 3) : f;
-            const int na = (f2 + 1) & 3;
-            const unsigned kn8 = (unsigned)kn*8u;
-            const unsigned ob = kn8 + ((f2 & 1) ? S8 : 0u) + ((f2 & 2) ? 2u*S8 : 0u);
-            const unsigned oa = kn8 + ((na & 1) ? S8 : 0u) + ((na & 2) ? 2u*S8 : 0u);
-            una[f] = swe_ld(gu, oa, 0);
-            unb[f] = swe_ld(gu, ob, 0);
-            vna[f] = swe_ld(gv, oa, 0);
-            vnb[f] = swe_ld(gv, ob, 0);
-            ena[f] = swe_ld(ge, oa, 0);
-            enb[f] = swe_ld(ge, ob, 0);
-        }
-    }
     double px[4], py[4], h[4], H[4], al[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -2423,9 +2380,15 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
     if (HASU0) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            u0u[i] = swe_ld(swe_rsrc(p.u0), k8, i*S8);
-            u0v[i] = swe_ld(swe_rsrc(p.u0 + 4*S), k8, i*S8);
-            u0e[i] = swe_ld(swe_rsrc(p.u0 + 8*S), k8, i*S8);
+            if constexpr (TILE) {                          // the lane's own U(0) waits in LDS (swe2d_fuse.h)
+                u0u[i] = tin[(size_t)(12 + i)*Su + ku];
+                u0v[i] = tin[(size_t)(16 + i)*Su + ku];
+                u0e[i] = tin[(size_t)(20 + i)*Su + ku];
+            } else {
+                u0u[i] = swe_ld(swe_rsrc(p.u0), k8, i*S8);
+                u0v[i] = swe_ld(swe_rsrc(p.u0 + 4*S), k8, i*S8);
+                u0e[i] = swe_ld(swe_rsrc(p.u0 + 8*S), k8, i*S8);
+            }
         }
     }
     // ---- cell integrals, 2 x 2 Gauss-Legendre; weights A/4, gradients carry 1/A  ->  factor 1/4 on gradient terms
@@ -2552,18 +2515,17 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
     //      zeta = D - h: the planes hold D, U(0)'s too)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        wu[i] = p.a1*u[i];
-        wv[i] = p.a1*v[i];
-        we[i] = WD ? p.a1*(H[i] - h[i]) : p.a1*e[i];
+        wu[i] = a1*u[i];
+        wv[i] = a1*v[i];
+        we[i] = WD ? a1*(H[i] - h[i]) : a1*e[i];
         if (HASU0) {
-            wu[i] = fma(p.a0, u0u[i], wu[i]);
-            wv[i] = fma(p.a0, u0v[i], wv[i]);
-            we[i] = fma(p.a0, WD ? u0e[i] - h[i] : u0e[i], we[i]);
+            wu[i] = fma(a0, u0u[i], wu[i]);
+            wv[i] = fma(a0, u0v[i], wv[i]);
+            we[i] = fma(a0, WD ? u0e[i] - h[i] : u0e[i], we[i]);
         }
     }
-    double ou[4], ov[4], oe[4];
     if constexpr (AFFINE) {
-    const double s = p.dt*p.beta*rA;
+    const double s = p.dt*beta*rA;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int n1 = (i + 1) & 3, n2 = (i + 2) & 3, n3 = (i + 3) & 3;
@@ -2579,7 +2541,7 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
     swe_quad_mass_solve(F, bu);
     swe_quad_mass_solve(F, bv);
     swe_quad_mass_solve(F, be);
-    const double s = p.dt*p.beta;
+    const double s = p.dt*beta;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         ou[i] = fma(s, bu[i], wu[i]);
@@ -2588,15 +2550,83 @@ __global__ __launch_bounds__(SWE_BLOCK) void swe_stage_kernel_quad(const SweStag
     }
     }
     // boundary facets were skipped in the facet loop
-    if (bmarkers != 0u) swe_boundary_epilogue_quad<NONLIN, LF, WD, AFFINE>(p, k, bmarkers, ou, ov, oe);
-    if (WD && !(p.a0 == 0.0 && p.a1 == 0.0)) {
-        if constexpr (AFFINE) swe_wd_finish<4>(p.g, p.beta*p.dt, h, al, ou, ov, oe, !p.wd_skip_relax);
+    if (bmarkers != 0u) {
+        if constexpr (TILE) swe_boundary_epilogue_quad<NONLIN, LF, WD, AFFINE>(p, k, bmarkers, ou, ov, oe, tin, Su, ku, beta);
+        else swe_boundary_epilogue_quad<NONLIN, LF, WD, AFFINE>(p, k, bmarkers, ou, ov, oe, p.uin, p.stride, k, beta);
+    }
+    if (WD && !(a0 == 0.0 && a1 == 0.0)) {
+        if constexpr (AFFINE) swe_wd_finish<4>(p.g, beta*p.dt, h, al, ou, ov, oe, !p.wd_skip_relax);
         else {
             double mw[4];
             swe_quad_mean_weights(A, d1, d2, mw);
-            swe_wd_finish<4>(p.g, p.beta*p.dt, h, al, ou, ov, oe, !p.wd_skip_relax, mw);
+            swe_wd_finish<4>(p.g, beta*p.dt, h, al, ou, ov, oe, !p.wd_skip_relax, mw);
         }
     }
+}
+
+// AFFINE = false: general quadrilaterals (see above)
+template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD, bool AFFINE = true>
+__global__ __launch_bounds__(SWE_BLOCK) __attribute__((amdgpu_waves_per_eu(3))) void swe_stage_kernel_quad(const SweStageArgs p)
+{
+    // no implicit contraction (see swe_stage_kernel)
+#pragma clang fp contract(off)
+#ifdef SWE_NO_XCD_MAP
+    int lb = blockIdx.x;
+#else
+    int lb = swe_logical_block(blockIdx.x, gridDim.x);
+#endif
+    if (p.reverse) {              // see swe_stage_kernel: launches beyond the Infinity Cache alternate their direction
+        lb = (p.cell_end - p.cell_begin + SWE_BLOCK - 1)/SWE_BLOCK - 1 - lb;
+        if (lb < 0) return;
+    }
+    const int k = p.cell_begin + lb*SWE_BLOCK + (int)threadIdx.x;
+    if (k >= p.cell_end) return;
+    const size_t S = p.stride;
+    // raw buffer addressing (see swe_ld): one resource per group of four planes, 4*stride*8 < 2^32 checked at create
+    const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u, S4 = (unsigned)S*4u, k4 = (unsigned)k*4u;
+    const swe_rsrc_t gu = swe_rsrc(p.uin), gv = swe_rsrc(p.uin + 4*S), ge = swe_rsrc(p.uin + 8*S);
+
+    double u[4], v[4], e[4];
+    int nb[4], vid[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        nb[i] = swe_ldi(swe_rsrc(p.nbr), k4, i*S4);
+        vid[i] = swe_ldi(swe_rsrc(p.cv), k4, i*S4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u[i] = swe_ld(gu, k8, i*S8);
+        v[i] = swe_ld(gv, k8, i*S8);
+        e[i] = swe_ld(ge, k8, i*S8);
+    }
+    // boundary markers of the four facets in one register (0: interior facet): all the boundary pass at the end needs of nb[]
+    const unsigned bmarkers = (nb[0] < 0 ? (unsigned)(-nb[0]) : 0u) | (nb[1] < 0 ? (unsigned)(-nb[1]) << 8 : 0u) |
+                              (nb[2] < 0 ? (unsigned)(-nb[2]) << 16 : 0u) | (nb[3] < 0 ? (unsigned)(-nb[3]) << 24 : 0u);
+    // (U(0) of the velocity and of eta is NOT requested here: its twelve values would be live through the facet loop - 24 of the
+    //  registers that kept this kernel at two waves per SIMD; see below)
+    double una[4], unb[4], vna[4], vnb[4], ena[4], enb[4];
+    {   // (an LDS exchange of the in-wave traces as in swe_stage_kernel<..., LDSX> was measured: 201 vs 203 us/step at 1 M
+        //  quadrilaterals - this kernel is bound by its 198 VGPRs and its arithmetic, not by the gathers; not kept)
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            const int nbf = nb[f];
+            const int kn = nbf >= 0 ? (nbf >> 2) : k;
+            const int f2 = nbf >= 0 ? (nbf & 3) : f;
+            const int na = (f2 + 1) & 3;
+            const unsigned kn8 = (unsigned)kn*8u;
+            const unsigned ob = kn8 + ((f2 & 1) ? S8 : 0u) + ((f2 & 2) ? 2u*S8 : 0u);
+            const unsigned oa = kn8 + ((na & 1) ? S8 : 0u) + ((na & 2) ? 2u*S8 : 0u);
+            una[f] = swe_ld(gu, oa, 0);
+            unb[f] = swe_ld(gu, ob, 0);
+            vna[f] = swe_ld(gv, oa, 0);
+            vnb[f] = swe_ld(gv, ob, 0);
+            ena[f] = swe_ld(ge, oa, 0);
+            enb[f] = swe_ld(ge, ob, 0);
+        }
+    }
+    double ou[4], ov[4], oe[4];
+    swe_quad_stage_cell<NONLIN, LF, HASU0, SRC, WD, AFFINE, false>(p, k, k8, S8, nb, vid, bmarkers, u, v, e, una, unb, vna, vnb, ena, enb, p.a0,
+                                                                  p.a1, p.beta, p.uin, S, k, ou, ov, oe);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         swe_st(swe_rsrc(p.uout), k8, i*S8, ou[i]);
