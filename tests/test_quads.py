@@ -487,3 +487,72 @@ def test_demo_2d_multiple_tracers(hip_lib, ref_so):
     # the three fields are different tracers, not copies
     assert np.abs(solver_obj.fields['bell_2d'].cell_node_values() - solver_obj.fields['cone_2d'].cell_node_values()).max() > 0.1
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['parallelograms_open', 'skewed_sources', 'general', 'general_sources', 'ragged_random_numbering', 'linear_no_lf',
+                                  'by_the_rule_900k', 'coupled_tracer_270k'])
+def test_fused_stage_pair_on_quadrilaterals_gives_the_bits_of_the_stage_launches(hip_lib, ref_so, monkeypatch, case):
+    """csrc/swe2d_fuse.h, swe_fuse12_quad_kernel (round 6): stages 1 and 2 of a step in one launch on tiles of up to 192 quadrilaterals
+    + their ring, U(1) in LDS; the arithmetic is swe_quad_stage_cell, the function the stage launches call.  Bit for bit
+    SWE2D_OPT_FUSED_STAGES = 0: parallelograms with open boundaries and walls, a skewed mesh with Coriolis + Manning + wind, general
+    (warped) cells with and without source terms, partial tiles in a random numbering, linear equations without Lax-Friedrichs, a
+    900 k-cell mesh where the library takes it by itself (beyond the Infinity Cache), the shallow-water half of swe2d_advance_coupled; and one step
+    against the oracle's C restatement."""
+    from thetis_amd import _lib
+    from thetis_amd.device import Swe2dDevice
+    monkeypatch.setenv('THETIS_AMD_FLOW', '0')
+    kw, reorder, forced = {}, 'auto', '1'
+    if case in ('by_the_rule_900k', 'coupled_tracer_270k'):
+        mesh, bath, uv, eta = quad_case(nx=600, ny=450, lx=100e3, ly=75e3, seed=5, amp_eta=0.3, amp_u=0.2)
+        forced = None
+    elif case == 'skewed_sources':
+        mesh, bath, uv, eta = quad_case(nx=90, ny=70, lx=100e3, ly=70e3, seed=6, amp_eta=0.05, amp_u=0.05, skew=0.2)
+    elif case.startswith('general'):
+        mesh, bath, uv, eta = quad_case(nx=90, ny=70, lx=100e3, ly=70e3, seed=7, amp_eta=0.05, amp_u=0.05, warp=0.25)
+    elif case == 'ragged_random_numbering':
+        m0, bath, uv0, eta0 = quad_case(nx=53, ny=31, lx=100e3, ly=60e3, seed=6, amp_eta=0.3, amp_u=0.2)
+        cperm = np.random.default_rng(11).permutation(m0.num_cells)
+        mesh = m0.renumbered(cperm)
+        uv, eta, reorder = uv0[cperm], eta0[cperm], None
+    else:
+        mesh, bath, uv, eta = quad_case(nx=120, ny=90, lx=100e3, ly=75e3, seed=8, amp_eta=0.3, amp_u=0.2)
+        if case == 'linear_no_lf':
+            kw = dict(use_nonlinear_equations=False, use_lax_friedrichs_velocity=False)
+    cxy = mesh.cell_xy()
+    src = case.endswith('sources')
+    out = []
+    for fuse in ('0', forced):
+        if fuse is None:
+            monkeypatch.delenv('THETIS_AMD_FUSE12', raising=False)
+        else:
+            monkeypatch.setenv('THETIS_AMD_FUSE12', fuse)
+        dev = Swe2dDevice(mesh, bath, 0.5, reorder=reorder, boundary_len=mesh.boundary_len, **kw)
+        m = mesh.boundary_markers
+        dev.set_bc(m[1], {'elev': 0.1})
+        dev.set_bc(m[2], {'un': 0.05})
+        if src:
+            dev.set_field(_lib.FIELD_CORIOLIS, 1e-4*(1.0 + cxy[:, :, 1]/50e3))
+            dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+            dev.set_field(_lib.FIELD_WIND_STRESS, np.stack([0.1*np.sin(cxy[:, :, 0]/2e4), 0.05*np.cos(cxy[:, :, 1]/1e4)], axis=2))
+        dev.set_state(uv, np.abs(eta) if src else eta)
+        assert dev.fused_pair_info()[0] == (fuse != '0'), (case, fuse, dev.fused_pair_info())
+        if case == 'coupled_tracer_270k':
+            tid = dev.add_tracer()
+            dev.tracer_set_state(tid, np.where(cxy[:, :, 0] < 40e3, 0.0, 30.0))
+            dev.advance_coupled(3, tracer_only=False, use_limiter=True)
+            out.append(dev.get_state() + (dev.tracer_get_state(tid),))
+        else:
+            dev.advance(1)
+            first = dev.get_state()
+            dev.advance(2)
+            dev.advance(2)
+            out.append(first + dev.get_state())
+        dev.close()
+    assert np.isfinite(out[0][1]).all()
+    for a_, b_ in zip(out[0], out[1]):
+        assert np.array_equal(a_, b_)
+    if case == 'parallelograms_open':                 # ... and the fused launch against the oracle directly
+        ref = make_ref(mesh, bath, bnd_conditions={mesh.boundary_markers[1]: {'elev': 0.1}, mesh.boundary_markers[2]: {'un': 0.05}})
+        ur, er = ref.advance(uv, eta, 0.5, 1)
+        assert rel_linf(out[1][0], ur) < 1e-11 and rel_linf(out[1][1], er) < 1e-11

@@ -242,7 +242,8 @@ int swe2d_fused_pair_info(swe2d_handle *hh, int32_t out[4])
     if (!fuse12_covers(h) || (h->n_owned == h->n_cells && advance_takes_flow(h))) return SWE2D_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     if (int rc = fuse12_build(h)) return rc;
-    if (h->fuse_tile) { out[0] = 1; out[1] = h->fuse_n_tiles; out[2] = (int32_t)h->fuse_ring_cells; }
+    if (h->npc == 4) { if (h->fuseq_tile) { out[0] = 1; out[1] = h->fuseq_n_tiles; out[2] = (int32_t)h->fuseq_ring_cells; } }
+    else if (h->fuse_tile) { out[0] = 1; out[1] = h->fuse_n_tiles; out[2] = (int32_t)h->fuse_ring_cells; }
     return SWE2D_OK;
 }
 
@@ -443,8 +444,8 @@ int swe2d_create(const swe2d_mesh *mesh, const swe2d_params *params, swe2d_handl
     for (int m = 0; m < SWE2D_MAX_MARKERS; m++) h->bc.drag[m] = -1.0;
     for (int m = 0; m < SWE2D_MAX_MARKERS; m++) h->bc.len[m] = mesh->boundary_len ? mesh->boundary_len[m] : blen[m];
 
+    h->h_nbr = nbr;                                    // (host copy of the packed neighbour codes: tile tables of the fused stage pair)
     if (npc == 3) {
-        h->h_nbr = nbr;
         std::vector<int4> p4((size_t)S, int4{0, 0, 0, 0});
         std::vector<int2> p2((size_t)S, int2{0, 0});
         for (int kk = 0; kk < n; kk++) {
@@ -526,7 +527,7 @@ void swe2d_destroy(swe2d_handle *hh)
     }
     void *ptrs[] = {h->nbr, h->cv, h->vx, h->vy, h->vh, h->stage_uv, h->stage_eta, h->partial, h->diag_acc, h->send_cells, h->recv_cells,
                     h->lim_v2c_off, h->lim_v2c_cell, h->lim_vbf_off, h->lim_vbf_facet, h->lim_tv, h->lim_mean,
-                    h->lim_qmin, h->lim_qmax, h->valpha, h->snapshot[0].data, h->snapshot[1].data, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->idxc, h->fuse_tile, h->fuse_inner, h->fuse3_tile, h->fuse3_cnt, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
+                    h->lim_qmin, h->lim_qmax, h->valpha, h->snapshot[0].data, h->snapshot[1].data, h->bc_field[0], h->bc_field[1], h->bc_field[2], h->bc_field[3], h->nu_v, h->idx4, h->idx2, h->idxc, h->fuse_tile, h->fuse_inner, h->fuse3_tile, h->fuse3_cnt, h->fuseq_tile, h->fuseq_inner, h->opp4, h->bnd_cells, h->flow_flag, h->flow_status, h->flow_xo4, h->flow_xo2, h->flow_ex, h->flow_xblk, h->flow_xsrc, h->flow_cell, h->flow_xsend, h->flow_xrecv, h->flow_xtick};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &fl : h->facet_lists) if (fl.dev) (void)hipFree(fl.dev);
     for (void *m : h->p2p.opened) (void)hipIpcCloseMemHandle(m);
@@ -966,7 +967,7 @@ int swe2d_advance_timed(swe2d_handle *hh, int n_steps, int per_launch, float *ms
     // events around every launch of a step, on the launch stream: three stage launches, or the fused stage pair + stage 3
     // (the mean is per element-update - a third of a step - either way)
     if (fuse12_covers(h)) { if (int rc = fuse12_build(h)) return rc; }
-    const bool fused = fuse12_covers(h) && h->fuse_tile;
+    const bool fused = fuse12_covers(h) && (h->npc == 4 ? h->fuseq_tile != nullptr : h->fuse_tile != nullptr);
     const int lps = fused ? 2 : 3;
     const int nl = lps*n_steps;
     std::vector<hipEvent_t> ev(2*(size_t)nl);

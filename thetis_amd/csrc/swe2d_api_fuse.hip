@@ -33,8 +33,14 @@ bool fuse12_covers(const Handle *h)
     const int mode = h->opt[SWE2D_OPT_FUSED_STAGES];         // -1, 2: by size and tile quality; 1, 3: forced
     if (mode == 0 || h->fuse_state == -1) return false;
     if (h->opt[SWE2D_OPT_BND_INLINE] == 0) return false;     // the epilogue variant was asked for
-    return h->npc == 3 && !h->wd && !h->visc && !h->h_nbr.empty() && h->idx4
-           && h->n_cells >= ((mode == 1 || mode == 3) ? 64 : 250000);
+    const bool forced = mode == 1 || mode == 3;
+    if (h->wd || h->visc || h->h_nbr.empty()) return false;
+    // triangles: whole meshes and partitions, from 250 k cells
+    if (h->npc == 3) return h->idx4 != nullptr && h->n_cells >= (forced ? 64 : 250000);
+    // quadrilaterals (swe_fuse12_quad_kernel, round 6): whole meshes, from the size at which the three state buffers (3 x 96 B per cell)
+    // leave the Infinity Cache - same box, us per step without -> with: 1 M cells 188.9 -> 172.6, + Manning 221.1 -> 212.0, cfg 4 338.8 ->
+    // 329.3; 640 k cells 115.7 -> 114.6, + Manning 136.8 -> 142.7 (profiles/r06g_quads*.txt)
+    return h->n_owned == h->n_cells && h->n_cells >= (forced ? 64 : 850000);
 #endif
 }
 
@@ -42,8 +48,10 @@ bool fuse12_covers(const Handle *h)
 // swe2d_fused_set_order: a partition's ghost layers are appended to its numbering layer by layer, strips one cell wide whose tiles
 // would be all ring - as long as the interior holds at most 192 cells and the ring - every cell that shares a facet with an
 // interior cell - at most 64.
+int fuseq_build(Handle *h);
 int fuse12_build(Handle *h)
 {
+    if (h->npc == 4) return fuseq_build(h);
     if (h->fuse_tile || h->fuse_state == -1) return SWE2D_OK;
     {   // allocations and copies: not inside a stream capture - such a capture keeps the stage launches, the next call outside one builds
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -130,8 +138,10 @@ int fuse12_build(Handle *h)
 }
 
 // stages 1 and 2 of a step: state buffer A (U(0)) -> state buffer C (U(2)) on the cells [0, cell_end); stage 3 follows as a stage launch
+int launch_fuse12_quad(Handle *h, int cell_end);
 int launch_fuse12(Handle *h, int cell_end)
 {
+    if (h->npc == 4) return launch_fuse12_quad(h, cell_end);
     if (int rc = fuse12_build(h)) return rc;
     if (!h->fuse_tile) return fail(h, SWE2D_ERR_UNSUPPORTED, "fused stage pair: no tile tables");
     SweFuseArgs q;
@@ -150,6 +160,122 @@ int launch_fuse12(Handle *h, int cell_end)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_FUSE_WG), 0, h->stream, q);
     HIP_TRY(h, hipGetLastError());
     h->stage_valid[0] = false; h->stage_valid[1] = true;    // U(1) never left the chip; buffer C holds U(2)
+    return SWE2D_OK;
+}
+
+// ---- the stage pair on quadrilaterals (swe_fuse12_quad_kernel): tiles of up to 192 consecutive cells + their ring of at most 64
+int fuseq_build(Handle *h)
+{
+    if (h->fuseq_tile || h->fuse_state == -1) return SWE2D_OK;
+    {   // allocations and copies: not inside a stream capture
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return SWE2D_OK;
+        (void)hipGetLastError();
+    }
+    const int n = h->n_cells;
+    const size_t S = h->stride;
+    const int *nbr = h->h_nbr.data();
+    const int *order = (int)h->fuse_order.size() == n ? h->fuse_order.data() : nullptr;
+    std::vector<int4> tl;
+    std::vector<int> inner, ring, cells;
+    std::vector<int> state((size_t)n, 0), lane_of((size_t)n, -1);      // 0 outside | 1 interior | 2 ring, of the tile being built
+    long long n_ring_total = 0;
+    for (int pos = 0; pos < n;) {
+        cells.clear(); ring.clear();
+        int n_ring = 0;
+        while (pos < n && (int)cells.size() < SWE_QFUSE_INNER) {
+            const int kk = order ? order[pos] : pos;
+            int delta = state[kk] == 2 ? -1 : 0;
+            for (int f = 0; f < 4; f++) {
+                const int code = nbr[(size_t)f*S + kk];
+                if (code >= 0 && state[code >> 2] == 0) {
+                    bool dup = false;
+                    for (int g = 0; g < f; g++) dup = dup || (nbr[(size_t)g*S + kk] >= 0 && (nbr[(size_t)g*S + kk] >> 2) == (code >> 2));
+                    if (!dup) delta++;
+                }
+            }
+            if (!cells.empty() && n_ring + delta > SWE_QFUSE_RING) break;
+            if (n_ring + delta > SWE_QFUSE_RING) return fail(h, SWE2D_ERR_UNSUPPORTED, "fused stage pair: a cell with more neighbours than a ring holds");
+            if (state[kk] == 2) n_ring--;
+            state[kk] = 1;
+            cells.push_back(kk);
+            for (int f = 0; f < 4; f++) {
+                const int code = nbr[(size_t)f*S + kk];
+                if (code >= 0 && state[code >> 2] == 0) { state[code >> 2] = 2; ring.push_back(code >> 2); n_ring++; }
+            }
+            pos++;
+        }
+        const int ni = (int)cells.size();
+        for (int c : ring) if (state[c] == 2) cells.push_back(c);
+        const int nt = (int)cells.size();
+        if (nt - ni != n_ring || nt > SWE_FUSE_WG) return fail(h, SWE2D_ERR_UNSUPPORTED, "fused stage pair: tile bookkeeping");
+        for (int l = 0; l < nt; l++) lane_of[cells[l]] = l;
+        const size_t base = tl.size();
+        tl.resize(base + SWE_FUSE_WG, int4{-1, 0, 0, 0});
+        int n_out = 0;
+        for (int l = 0; l < nt; l++) {
+            const int c = cells[l];
+            unsigned w[4];
+            for (int f = 0; f < 4; f++) {
+                const int code = nbr[(size_t)f*S + c];
+                if (code < 0) w[f] = (unsigned)l;                                    // boundary facet: the cell itself
+                else if (state[code >> 2] != 0) w[f] = (unsigned)lane_of[code >> 2];
+                else {
+                    if (l < ni || n_out >= SWE_QFUSE_MAX_OUT) return fail(h, SWE2D_ERR_UNSUPPORTED, "fused stage pair: ring bookkeeping");
+                    w[f] = 0x200u | (unsigned)n_out++;
+                }
+            }
+            tl[base + l] = int4{c, (int)(w[0] | (w[1] << SWE_FUSE_FBITS) | (w[2] << (2*SWE_FUSE_FBITS))), (int)w[3], 0};
+        }
+        inner.push_back(ni);
+        n_ring_total += nt - ni;
+        for (int c : cells) { state[c] = 0; lane_of[c] = -1; }
+    }
+    h->fuseq_n_tiles = (int)inner.size();
+    const bool forced = h->opt[SWE2D_OPT_FUSED_STAGES] == 1 || h->opt[SWE2D_OPT_FUSED_STAGES] == 3;
+    if (!forced && (double)n/h->fuseq_n_tiles < 176.0) { h->fuse_state = -1; h->fuseq_n_tiles = 0; return SWE2D_OK; }   // tiles not worth it
+    HIP_TRY(h, hipMalloc(&h->fuseq_tile, tl.size()*sizeof(int4)));
+    HIP_TRY(h, hipMalloc(&h->fuseq_inner, inner.size()*sizeof(int)));
+    HIP_TRY(h, hipMemcpy(h->fuseq_tile, tl.data(), tl.size()*sizeof(int4), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->fuseq_inner, inner.data(), inner.size()*sizeof(int), hipMemcpyHostToDevice));
+    h->fuseq_ring_cells = n_ring_total;
+    return SWE2D_OK;
+}
+
+namespace {
+typedef void (*fuseq_kernel_t)(const SweFuseQuadArgs);
+template <bool SRC, bool AFFINE>
+fuseq_kernel_t pick_fuseq_2(bool nl, bool lf)
+{
+    if (nl) return lf ? swe_fuse12_quad_kernel<true, true, SRC, AFFINE> : swe_fuse12_quad_kernel<true, false, SRC, AFFINE>;
+    return lf ? swe_fuse12_quad_kernel<false, true, SRC, AFFINE> : swe_fuse12_quad_kernel<false, false, SRC, AFFINE>;
+}
+fuseq_kernel_t pick_fuseq_kernel(bool nl, bool lf, bool src, bool affine)
+{
+    if (affine) return src ? pick_fuseq_2<true, true>(nl, lf) : pick_fuseq_2<false, true>(nl, lf);
+    return src ? pick_fuseq_2<true, false>(nl, lf) : pick_fuseq_2<false, false>(nl, lf);
+}
+}  // namespace
+
+int launch_fuse12_quad(Handle *h, int cell_end)
+{
+    if (int rc = fuseq_build(h)) return rc;
+    if (!h->fuseq_tile) return fail(h, SWE2D_ERR_UNSUPPORTED, "fused stage pair: no tile tables");
+    SweFuseQuadArgs q;
+    fill_stage_args(h, q.st, 0, 0, 2, 0.0, 1.0, kBeta[0], 0, h->n_owned);
+    q.tile = h->fuseq_tile;
+    q.n_inner = h->fuseq_inner;
+    q.n_tiles = h->fuseq_n_tiles;
+    q.cell_end = cell_end;
+    q.beta1 = kBeta[0];
+    q.a0_2 = kAlpha0[1]; q.a1_2 = kAlphaIn[1]; q.beta2 = kBeta[1];
+    q.out = h->state[2];
+    fuseq_kernel_t kern = pick_fuseq_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h), h->affine);
+    const int grid = ((h->fuseq_n_tiles + 7)/8)*8;
+    SWE_CHK_SYNC(h->stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SWE_FUSE_WG), 0, h->stream, q);
+    HIP_TRY(h, hipGetLastError());
+    h->stage_valid[0] = false; h->stage_valid[1] = true;
     return SWE2D_OK;
 }
 
@@ -285,7 +411,7 @@ bool fuse123_wanted(const Handle *h)
 {
     const int mode = h->opt[SWE2D_OPT_FUSED_STAGES];
     // (by itself only without source terms: those instances spill 80-132 B per lane at the 168 VGPRs of three workgroups per CU)
-    return (mode == 3 || (mode == -1 && h->n_cells >= 2500000 && !has_sources(h))) && fuse12_covers(h) && h->n_owned == h->n_cells;
+    return h->npc == 3 && (mode == 3 || (mode == -1 && h->n_cells >= 2500000 && !has_sources(h))) && fuse12_covers(h) && h->n_owned == h->n_cells;
 }
 
 // one SSPRK33 step of the shallow-water state on the whole mesh by the launches swe2d_advance would take when the dataflow kernel
@@ -300,7 +426,7 @@ int step_swe(Handle *h)
         if (!capturing) return launch_fuse123(h);
     }
     if (fuse12_covers(h)) { if (int rc = fuse12_build(h)) return rc; }
-    if (fuse12_covers(h) && h->fuse_tile) {
+    if (fuse12_covers(h) && (h->npc == 4 ? h->fuseq_tile != nullptr : h->fuse_tile != nullptr)) {
         if (int rc = launch_fuse12(h, h->n_owned)) return rc;
         return stage_on_range(h, 2, 0, h->n_owned);
     }
@@ -331,6 +457,9 @@ int swe2d_fused_set_order(swe2d_handle *hh, const int32_t *cells_in_tile_order)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->fuse_tile) { (void)hipFree(h->fuse_tile); h->fuse_tile = nullptr; }
     if (h->fuse_inner) { (void)hipFree(h->fuse_inner); h->fuse_inner = nullptr; }
+    if (h->fuseq_tile) { (void)hipFree(h->fuseq_tile); h->fuseq_tile = nullptr; }
+    if (h->fuseq_inner) { (void)hipFree(h->fuseq_inner); h->fuseq_inner = nullptr; }
+    h->fuseq_n_tiles = 0;
     if (h->fuse3_tile) { (void)hipFree(h->fuse3_tile); h->fuse3_tile = nullptr; }
     if (h->fuse3_cnt) { (void)hipFree(h->fuse3_cnt); h->fuse3_cnt = nullptr; }
     h->fuse3_n_tiles = 0;
@@ -362,7 +491,7 @@ int swe2d_solve_stage_pair_cells(swe2d_handle *hh, int32_t cell_end_0, int32_t c
     if (cell_end_1 < 0 || cell_end_1 > cell_end_0 || cell_end_0 > h->n_cells) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell ranges");
     HIP_TRY(h, hipSetDevice(h->device));
     if (fuse12_covers(h)) { if (int rc = fuse12_build(h)) return rc; }
-    if (fuse12_covers(h) && h->fuse_tile) return launch_fuse12(h, cell_end_1);
+    if (fuse12_covers(h) && (h->npc == 4 ? h->fuseq_tile != nullptr : h->fuse_tile != nullptr)) return launch_fuse12(h, cell_end_1);
     if (int rc = stage_on_range(h, 0, 0, cell_end_0)) return rc;
     return stage_on_range(h, 1, 0, cell_end_1);
 }

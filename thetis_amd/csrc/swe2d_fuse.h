@@ -363,3 +363,144 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse123_kern
 // (Also measured and not kept: tile records that carry the cell's connectivity - 32 B per lane, two int4 - so that a lane issues its
 //  loads after ONE trip to memory instead of two (tile entry, then the connectivity record): 2-6 % slower at 250 k ... 4 M cells,
 //  the 12 B per cell it adds cost more than the trip it saves - profiles/r06f_fused_sizes.txt against r06b_fused_sizes.txt.)
+
+// ---- stages 1 and 2 of a step in one launch on QUADRILATERALS (round 6): the triangle kernel's tiles with four facets per cell ------
+// 256 lanes = up to 192 interior cells + their ring of at most 64 (a 16 x 12 tile of a structured mesh: ring 56); the arithmetic is
+// swe_quad_stage_cell, the function the stage launches call - the same bits (tests/test_quads.py::test_fused_stage_pair_on_quad...).
+// LDS: [12][256] stage values (u0..3 v0..3 e0..3 of every lane: U(0), then U(1)), the staging area of the traces from outside the tile
+// ([slot][6]: u, v, e at the neighbour's node on my node f + 1, then at its node on my node f), and [12][192] = U(0) of the interior
+// lanes for stage 2's Shu-Osher weights: 52.2 KB, three workgroups per CU.  At 1 M quadrilaterals the three state buffers (288 MB) do
+// not fit the Infinity Cache: the two stage launches this replaces move 592 B per cell, the fused launch ~290.
+#define SWE_QFUSE_INNER 192
+#define SWE_QFUSE_RING (SWE_FUSE_WG - SWE_QFUSE_INNER)
+#define SWE_QFUSE_XG (12*SWE_FUSE_WG)
+#define SWE_QFUSE_MAX_OUT (3*SWE_QFUSE_RING)            // a ring cell has a facet towards the interior: at most three towards the outside
+#define SWE_QFUSE_LDS (SWE_QFUSE_XG + 6*SWE_QFUSE_MAX_OUT)
+
+struct SweFuseQuadArgs {
+    SweStageArgs st;          // uin = U(0) (state buffer A); geometry, connectivity planes, boundary tables; dt, g, sigma_lf
+    const int4 *tile;         // [n_tiles][256]: {cell or -1, facets 0-2 (10 bits each: lane of the neighbour in the tile - a boundary facet:
+                              //  the lane itself - or bit 9 + staging slot), facet 3, 0}
+    const int *n_inner;       // [n_tiles]
+    int n_tiles;
+    int cell_end;             // stage 2 updates the interior cells < cell_end
+    double beta1, a0_2, a1_2, beta2;
+    double *out;              // 12 planes: U(2) (state buffer C)
+};
+
+template <bool NONLIN, bool LF, bool SRC, bool AFFINE>
+__global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_quad_kernel(const SweFuseQuadArgs q)
+{
+#pragma clang fp contract(off)
+    __shared__ double lds[SWE_QFUSE_LDS];
+    __shared__ double lu0[12*SWE_QFUSE_INNER];
+    const SweStageArgs &p = q.st;
+    const int tile = swe_logical_block(blockIdx.x, gridDim.x);
+    if (tile >= q.n_tiles) return;
+    const int lane = (int)threadIdx.x;
+    const int4 tl = q.tile[(size_t)tile*SWE_FUSE_WG + lane];
+    const bool real = tl.x >= 0;
+    const int k = real ? tl.x : 0;
+    const int n_inner = q.n_inner[tile];
+    const size_t S = p.stride;
+    const unsigned S8 = (unsigned)S*8u, k8 = (unsigned)k*8u, S4 = (unsigned)S*4u, k4 = (unsigned)k*4u;
+
+    unsigned tr[4] = {0u, 0u, 0u, 0u}, bmarkers = 0u;
+    int nb[4] = {-1, -1, -1, -1}, vid[4] = {0, 0, 0, 0};
+    double u[4], v[4], e[4];
+    if (real) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            nb[i] = swe_ldi(swe_rsrc(p.nbr), k4, i*S4);
+            vid[i] = swe_ldi(swe_rsrc(p.cv), k4, i*S4);
+        }
+        const swe_rsrc_t gu = swe_rsrc(p.uin), gv = swe_rsrc(p.uin + 4*S), ge = swe_rsrc(p.uin + 8*S);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            u[i] = swe_ld(gu, k8, i*S8);
+            v[i] = swe_ld(gv, k8, i*S8);
+            e[i] = swe_ld(ge, k8, i*S8);
+        }
+        bmarkers = (nb[0] < 0 ? (unsigned)(-nb[0]) : 0u) | (nb[1] < 0 ? (unsigned)(-nb[1]) << 8 : 0u) |
+                   (nb[2] < 0 ? (unsigned)(-nb[2]) << 16 : 0u) | (nb[3] < 0 ? (unsigned)(-nb[3]) << 24 : 0u);
+        double r0[4][6];
+        bool outside[4];
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            const int nbf = nb[f];
+            const unsigned w = f < 3 ? (((unsigned)tl.y >> (SWE_FUSE_FBITS*f)) & 0x3ffu) : ((unsigned)tl.z & 0x3ffu);
+            outside[f] = (w & 0x200u) != 0u;
+            const unsigned at = w & 0x1ffu;                                   // lane in the tile, or staging slot
+            // the neighbour traverses the shared facet backwards: its node f2 sits on my node f + 1, its node (f2 + 1) & 3 on my node f
+            const int f2 = nbf >= 0 ? (nbf & 3) : f, na = (f2 + 1) & 3;
+            const unsigned ab = outside[f] ? (unsigned)(SWE_QFUSE_XG + 6*at) : (unsigned)(f2*SWE_FUSE_WG + at);
+            const unsigned aa = outside[f] ? (unsigned)(SWE_QFUSE_XG + 6*at + 3) : (unsigned)(na*SWE_FUSE_WG + at);
+            tr[f] = ab | (aa << 16);
+            // (issued for every facet: a facet inside the tile reads this cell itself, value unused - no branch around the loads)
+            const int code = outside[f] ? nbf : ((k << 2) | f);
+            const unsigned kn8 = (unsigned)(code >> 2)*8u;
+            const int g2 = code & 3, ga = (g2 + 1) & 3;
+            const unsigned ob = kn8 + ((g2 & 1) ? S8 : 0u) + ((g2 & 2) ? 2u*S8 : 0u);
+            const unsigned oa = kn8 + ((ga & 1) ? S8 : 0u) + ((ga & 2) ? 2u*S8 : 0u);
+            r0[f][0] = swe_ld(gu, ob, 0); r0[f][1] = swe_ld(gv, ob, 0); r0[f][2] = swe_ld(ge, ob, 0);
+            r0[f][3] = swe_ld(gu, oa, 0); r0[f][4] = swe_ld(gv, oa, 0); r0[f][5] = swe_ld(ge, oa, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { lds[i*SWE_FUSE_WG + lane] = u[i]; lds[(4 + i)*SWE_FUSE_WG + lane] = v[i]; lds[(8 + i)*SWE_FUSE_WG + lane] = e[i]; }
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            if (outside[f]) {
+                const unsigned at = (f < 3 ? ((unsigned)tl.y >> (SWE_FUSE_FBITS*f)) : (unsigned)tl.z) & 0x1ffu;
+#pragma unroll
+                for (int j = 0; j < 6; j++) lds[SWE_QFUSE_XG + 6*at + j] = r0[f][j];
+            }
+        }
+    }
+    __syncthreads();
+    // the six traces of facet f from LDS: component c is 4 planes further inside the tile, one double further in the staging area
+#define SWE_QFUSE_TRACES(una, unb, vna, vnb, ena, enb) \
+    _Pragma("unroll") \
+    for (int f = 0; f < 4; f++) { \
+        const unsigned ab = tr[f] & 0xffffu, aa = tr[f] >> 16; \
+        const unsigned step = ab >= (unsigned)SWE_QFUSE_XG ? 1u : (unsigned)(4*SWE_FUSE_WG); \
+        unb[f] = lds[ab]; vnb[f] = lds[ab + step]; enb[f] = lds[ab + 2u*step]; \
+        una[f] = lds[aa]; vna[f] = lds[aa + step]; ena[f] = lds[aa + 2u*step]; \
+    }
+    // ---- stage 1 on every cell of the tile: U(1) = U(0) + beta1 dt M^-1 R(U(0))
+    double o1u[4], o1v[4], o1e[4];
+    if (real) {
+        double una[4], unb[4], vna[4], vnb[4], ena[4], enb[4];
+        SWE_QFUSE_TRACES(una, unb, vna, vnb, ena, enb)
+        swe_quad_stage_cell<NONLIN, LF, false, SRC, false, AFFINE, true>(p, k, k8, S8, nb, vid, bmarkers, u, v, e, una, unb, vna, vnb, ena, enb,
+                                                                        0.0, 1.0, q.beta1, lds, SWE_FUSE_WG, lane, nullptr, 0, o1u, o1v, o1e);
+    }
+    __syncthreads();                                       // every lane has read its traces (and its boundary facets' inputs) of U(0)
+    const bool act2 = lane < n_inner && k < q.cell_end;
+    if (real) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { lds[i*SWE_FUSE_WG + lane] = o1u[i]; lds[(4 + i)*SWE_FUSE_WG + lane] = o1v[i]; lds[(8 + i)*SWE_FUSE_WG + lane] = o1e[i]; }
+    }
+    if (act2) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { lu0[i*SWE_QFUSE_INNER + lane] = u[i]; lu0[(4 + i)*SWE_QFUSE_INNER + lane] = v[i]; lu0[(8 + i)*SWE_QFUSE_INNER + lane] = e[i]; }
+    }
+    __syncthreads();
+    // ---- stage 2 on the interior cells (every neighbour is a cell of the tile): U(2) = a0 U(0) + a1 U(1) + beta2 dt M^-1 R(U(1))
+    if (act2) {
+#pragma unroll
+        for (int f = 0; f < 4; f++) asm volatile("" : "+v"(tr[f]));
+        asm volatile("" : "+v"(bmarkers));
+        double una[4], unb[4], vna[4], vnb[4], ena[4], enb[4], ou[4], ov[4], oe[4];
+        SWE_QFUSE_TRACES(una, unb, vna, vnb, ena, enb)
+        swe_quad_stage_cell<NONLIN, LF, true, SRC, false, AFFINE, true>(p, k, k8, S8, nb, vid, bmarkers, o1u, o1v, o1e, una, unb, vna, vnb, ena, enb,
+                                                                       q.a0_2, q.a1_2, q.beta2, lds, SWE_FUSE_WG, lane, lu0, SWE_QFUSE_INNER, ou, ov, oe);
+        const swe_rsrc_t gou = swe_rsrc(q.out), gov = swe_rsrc(q.out + 4*S), goe = swe_rsrc(q.out + 8*S);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            swe_st(gou, k8, i*S8, ou[i]);
+            swe_st(gov, k8, i*S8, ov[i]);
+            swe_st(goe, k8, i*S8, oe[i]);
+        }
+    }
+#undef SWE_QFUSE_TRACES
+}

@@ -126,6 +126,11 @@ struct Handle {
     int fuse_n_tiles = 0;
     int fuse_state = 0;                                 // -1: the numbering gives poor tiles, -2: first use inside a stream capture: stage launches
     long long fuse_ring_cells = 0;
+    // ... the stage pair on quadrilaterals (swe_fuse12_quad_kernel)
+    int4 *fuseq_tile = nullptr;
+    int *fuseq_inner = nullptr;
+    int fuseq_n_tiles = 0;
+    long long fuseq_ring_cells = 0;
     // ... all three stages in one launch, two rings per tile (SWE2D_OPT_FUSED_STAGES = 3): tile tables, built at first use
     int2 *fuse3_tile = nullptr, *fuse3_cnt = nullptr;
     int fuse3_n_tiles = 0;

@@ -2315,14 +2315,15 @@ __device__ __forceinline__ void swe_boundary_epilogue_quad(const SweStageArgs &p
 // cell's nodal values as the planes hold them; una / unb ...: the neighbour's values at its node on my node f / on my node f + 1, for
 // a boundary facet the cell's own), U(0), the cell quadrature, the optional terms, mass inverse, Shu-Osher combine, boundary facets,
 // wetting-drying.  Shared by swe_stage_kernel_quad and the fused stage pair of swe2d_fuse.h (TILE: the stage's input and the lane's own
-// U(0) live in the LDS planes `tin` of a tile - [12] stage values then [12] of U(0), stride Su, lane ku - instead of the state planes):
+// U(0) live in LDS - the tile's [12] planes of stage values `tin` with stride Su, the [12] planes `t0` of U(0) with stride S0, lane ku -
+// instead of the state planes):
 // the same operations in the same order, the same bits.
 template <bool NONLIN, bool LF, bool HASU0, bool SRC, bool WD, bool AFFINE, bool TILE>
 __device__ __forceinline__ void swe_quad_stage_cell(const SweStageArgs &p, int k, unsigned k8, unsigned S8, const int nb[4], const int vid[4],
                                                     unsigned bmarkers, double u[4], double v[4], double e[4], const double una[4],
                                                     const double unb[4], const double vna[4], const double vnb[4], const double ena[4],
                                                     const double enb[4], double a0, double a1, double beta, const double *tin, size_t Su,
-                                                    int ku, double ou[4], double ov[4], double oe[4])
+                                                    int ku, const double *t0, size_t S0, double ou[4], double ov[4], double oe[4])
 {
 #pragma clang fp contract(off)
     double wu[4], wv[4], we[4];
@@ -2381,9 +2382,9 @@ __device__ __forceinline__ void swe_quad_stage_cell(const SweStageArgs &p, int k
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if constexpr (TILE) {                          // the lane's own U(0) waits in LDS (swe2d_fuse.h)
-                u0u[i] = tin[(size_t)(12 + i)*Su + ku];
-                u0v[i] = tin[(size_t)(16 + i)*Su + ku];
-                u0e[i] = tin[(size_t)(20 + i)*Su + ku];
+                u0u[i] = t0[(size_t)i*S0 + ku];
+                u0v[i] = t0[(size_t)(4 + i)*S0 + ku];
+                u0e[i] = t0[(size_t)(8 + i)*S0 + ku];
             } else {
                 u0u[i] = swe_ld(swe_rsrc(p.u0), k8, i*S8);
                 u0v[i] = swe_ld(swe_rsrc(p.u0 + 4*S), k8, i*S8);
@@ -2626,7 +2627,7 @@ __global__ __launch_bounds__(SWE_BLOCK) __attribute__((amdgpu_waves_per_eu(3))) 
     }
     double ou[4], ov[4], oe[4];
     swe_quad_stage_cell<NONLIN, LF, HASU0, SRC, WD, AFFINE, false>(p, k, k8, S8, nb, vid, bmarkers, u, v, e, una, unb, vna, vnb, ena, enb, p.a0,
-                                                                  p.a1, p.beta, p.uin, S, k, ou, ov, oe);
+                                                                  p.a1, p.beta, p.uin, S, k, nullptr, 0, ou, ov, oe);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         swe_st(swe_rsrc(p.uout), k8, i*S8, ou[i]);

@@ -99,7 +99,9 @@ def auto_cell_order(mesh, a=0, b=None):
     k = np.asarray(mesh.cells).shape[1]
     if a == 0 and b == mesh.cells.shape[0] and getattr(mesh, 'structured', False):
         if k == 4:
-            return structured_tile_order(mesh.nx, mesh.ny, bx=16, by=16, cells_per_quad=1)
+            # 16 x 12 quadrilaterals = 192 cells: one tile of the fused stage pair on quadrilaterals (csrc/swe2d_fuse.h: 192 interior cells
+            # + their ring of 56 in a 256-lane workgroup); rounds 1-5 had 16 x 16
+            return structured_tile_order(mesh.nx, mesh.ny, bx=16, by=12, cells_per_quad=1)
         # 16 x 6 quads = 192 triangles: one tile of the fused stage pair (csrc/swe2d_fuse.h: 192 interior cells + their ring of 44
         # in a 256-lane workgroup); the stage kernels run the same in 16 x 6 and in 16 x 8 tiles (112.3 against 111.4-112.8 us per step)
         return structured_tile_order(mesh.nx, mesh.ny, bx=16, by=6)
@@ -107,7 +109,7 @@ def auto_cell_order(mesh, a=0, b=None):
     if parent is not None:
         g = np.asarray(mesh.local_to_global)[a:b]
         if k == 4:
-            return structured_subset_order(g, parent[0], parent[1], bx=16, by=16, cells_per_quad=1)
+            return structured_subset_order(g, parent[0], parent[1], bx=16, by=12, cells_per_quad=1)
         return structured_subset_order(g, parent[0], parent[1], bx=16, by=6)      # (the whole mesh's 16 x 6-quad tiles, see above)
     cen = np.asarray(mesh.vertex_xy)[np.asarray(mesh.cells)[a:b]].mean(axis=1)
     return hilbert_cell_order(cen)

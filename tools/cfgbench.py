@@ -51,16 +51,17 @@ def quads(rng):
     etaq = 0.5*np.exp(-((cq[:, :, 0] - 50e3)**2 + (cq[:, :, 1] - 50e3)**2)/(5e3)**2)
     dev = Swe2dDevice(meshq, np.full(meshq.num_vertices, 20.0), 0.25)
     dev.set_state(1e-3*rng.uniform(-1, 1, size=(nq, 4, 2)), etaq)
-    report('quadrilaterals SWE (DQ-1)', nq, 936.0, timed(dev, dev.advance, 50))
+    fz = {'fused_pair': bool(dev.fused_pair_info()[0])}
+    report('quadrilaterals SWE (DQ-1)', nq, 936.0, timed(dev, dev.advance, 50), fz)
     dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
-    report('quadrilaterals SWE + Manning drag', nq, 936.0, timed(dev, dev.advance, 50))
+    report('quadrilaterals SWE + Manning drag', nq, 936.0, timed(dev, dev.advance, 50), fz)
     dev.set_scalar(_lib.SCALAR_MANNING_DRAG, None)
     # cfg 4 on its own cell type (demos/demo_2d_tracer.py is a quadrilateral mesh): tracer per stage 32 r + 32 w (+32 T0)
     # + 64 velocity + 56 static = 184 / 216 / 216 B; limiter ~ 32 + 8 + 8 + 8 + 32 + 32 + 16 = 136 B
     tid = dev.add_tracer()
     dev.tracer_set_state(tid, np.where(cq[:, :, 0] < 40e3, 0.0, 30.0))
     report('cfg4 quadrilaterals SWE + tracer + limiter', nq, 936.0 + 616.0 + 136.0,
-           timed(dev, lambda k: dev.advance_coupled(k, tracer_only=False, use_limiter=True), 50))
+           timed(dev, lambda k: dev.advance_coupled(k, tracer_only=False, use_limiter=True), 50), fz)
     report('cfg4 quadrilaterals tracer only + limiter (demo_2d_tracer mode)', nq, 616.0 + 136.0,
            timed(dev, lambda k: dev.advance_coupled(k, tracer_only=True, use_limiter=True), 50))
     dev.close()
@@ -76,7 +77,8 @@ def quads(rng):
     assert not warped.affine
     dev = Swe2dDevice(warped, np.full(warped.num_vertices, 20.0), 0.25, boundary_len=warped.boundary_len)
     dev.set_state(1e-3*rng.uniform(-1, 1, size=(nq, 4, 2)), etaq)
-    report('general quadrilaterals SWE (bilinear map, 4x4 mass solve)', nq, 936.0, timed(dev, dev.advance, 50))
+    report('general quadrilaterals SWE (bilinear map, 4x4 mass solve)', nq, 936.0, timed(dev, dev.advance, 50),
+           {'fused_pair': bool(dev.fused_pair_info()[0])})
     dev.close()
 
 
