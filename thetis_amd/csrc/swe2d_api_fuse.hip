@@ -23,13 +23,10 @@ fuse_kernel_t pick_fuse_kernel(bool nl, bool lf, bool src) { return src ? pick_f
 // profiles/r05zl_fused_stage_pair.txt), and where the numbering gives tiles worth it (mean interior >= 176 of 192 cells: the
 // structured tile order, and the Hilbert order of an unstructured mesh - 1 M Delaunay triangles 192.0 + 49.9 cells per tile, 120.8 ->
 // 113.3 us per step; an order that does not keeps its stage launches).
-// SWE2D_OPT_FUSED_STAGES = 0: never; = 1: on every mesh (of at least 64 cells) whatever its tiles.  (Not in the range-checked build: the
-// LDS index checks of the shared functions know the flow kernel's array only.)
+// SWE2D_OPT_FUSED_STAGES = 0: never; = 1: on every mesh (of at least 64 cells) whatever its tiles.  (In the range-checked build too since
+// round 6: the shared functions test their LDS indices against the array they are handed, the tile tables are host-built indices.)
 bool fuse12_covers(const Handle *h)
 {
-#ifdef SWE_RANGE_CHECK
-    return false;
-#else
     const int mode = h->opt[SWE2D_OPT_FUSED_STAGES];         // -1, 2: by size and tile quality; 1, 3: forced
     if (mode == 0 || h->fuse_state == -1) return false;
     if (h->opt[SWE2D_OPT_BND_INLINE] == 0) return false;     // the epilogue variant was asked for
@@ -41,7 +38,6 @@ bool fuse12_covers(const Handle *h)
     // leave the Infinity Cache - same box, us per step without -> with: 1 M cells 188.9 -> 172.6, + Manning 221.1 -> 212.0, cfg 4 338.8 ->
     // 329.3; 640 k cells 115.7 -> 114.6, + Manning 136.8 -> 142.7 (profiles/r06g_quads*.txt)
     return h->n_owned == h->n_cells && h->n_cells >= (forced ? 64 : 850000);
-#endif
 }
 
 // Tiles: consecutive cells of the device numbering (compact patches in the tile-Hilbert order) - or of the order handed in with

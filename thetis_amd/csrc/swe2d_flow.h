@@ -283,7 +283,8 @@ __device__ __forceinline__ void swe_flow_rhs_cell(const SweStageArgs &p, const d
 // planes - at the price of eight integer instructions per facet and stage.
 // (XG, PLANE: where the staging area starts and how long a plane of the block's own values is - the fused stage pair of swe2d_fuse.h
 //  has 256-lane planes)
-template <bool NONLIN, bool LF, bool SRC, int NTR, bool WD = false, int XG = SWE_FLOW_XG, int PLANE = SWE_BLOCK>
+// (NLDS: the size of the array `lds` points into - what the -DSWE_RANGE_CHECK build tests every index against)
+template <bool NONLIN, bool LF, bool SRC, int NTR, bool WD = false, int XG = SWE_FLOW_XG, int PLANE = SWE_BLOCK, int NLDS = SWE_FLOW_LDS_DOUBLES>
 __device__ __forceinline__ void swe_flow_rhs_facets(const SweStageArgs &p, int k, const double u[3], const double v[3], const double e[3],
                                                     const double h[3], const double *lds, const unsigned tr[3][NTR], int bmarkers,
                                                     const double nx[3], const double ny[3], double twoA, double bu[3], double bv[3],
@@ -300,9 +301,9 @@ __device__ __forceinline__ void swe_flow_rhs_facets(const SweStageArgs &p, int k
         const unsigned step = ab0 >= (unsigned)XG ? 1u : (unsigned)(3*PLANE);
         const unsigned ab1 = NTR == 3 ? tr[f][NTR - 2] & 0xffffu : ab0 + step, aa1 = NTR == 3 ? tr[f][NTR - 2] >> 16 : aa0 + step;
         const unsigned ab2 = NTR == 3 ? tr[f][NTR - 1] & 0xffffu : ab0 + 2u*step, aa2 = NTR == 3 ? tr[f][NTR - 1] >> 16 : aa0 + 2u*step;
-        const double unb = lds[SWE_LDSI(ab0, SWE_FLOW_LDS_DOUBLES)], una = lds[SWE_LDSI(aa0, SWE_FLOW_LDS_DOUBLES)];
-        const double vnb = lds[SWE_LDSI(ab1, SWE_FLOW_LDS_DOUBLES)], vna = lds[SWE_LDSI(aa1, SWE_FLOW_LDS_DOUBLES)];
-        const double enb = lds[SWE_LDSI(ab2, SWE_FLOW_LDS_DOUBLES)], ena = lds[SWE_LDSI(aa2, SWE_FLOW_LDS_DOUBLES)];
+        const double unb = lds[SWE_LDSI(ab0, NLDS)], una = lds[SWE_LDSI(aa0, NLDS)];
+        const double vnb = lds[SWE_LDSI(ab1, NLDS)], vna = lds[SWE_LDSI(aa1, NLDS)];
+        const double enb = lds[SWE_LDSI(ab2, NLDS)], ena = lds[SWE_LDSI(aa2, NLDS)];
         const double nxs = nx[f], nys = ny[f];
         double Lf, rLf;
         swe_sqrt_rsqrt(swe_dot2(nxs, nxs, nys, nys), Lf, rLf);

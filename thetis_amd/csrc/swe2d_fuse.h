@@ -128,7 +128,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
             if (outside[f]) {
                 const unsigned at = ((unsigned)tl.y >> (SWE_FUSE_FBITS*f)) & 0x1ffu;
 #pragma unroll
-                for (int j = 0; j < 6; j++) lds[SWE_FUSE_XG + 6*at + j] = r0[f][j];
+                for (int j = 0; j < 6; j++) lds[SWE_LDSI(SWE_FUSE_XG + 6*at + j, SWE_FUSE_LDS)] = r0[f][j];
             }
         }
     }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
         twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
         double bu[3], bv[3], be[3], wu[3], wv[3], we[3];
         swe_flow_rhs_cell<NONLIN>(p, u, v, e, h, nx, ny, bu, bv, be);
-        swe_flow_rhs_facets<NONLIN, LF, SRC, 1, false, SWE_FUSE_XG, SWE_FUSE_WG>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+        swe_flow_rhs_facets<NONLIN, LF, SRC, 1, false, SWE_FUSE_XG, SWE_FUSE_WG, SWE_FUSE_LDS>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
 #pragma unroll
         for (int i = 0; i < 3; i++) { wu[i] = 1.0*u[i]; wv[i] = 1.0*v[i]; we[i] = 1.0*e[i]; }
         swe_flow_finish<NONLIN, LF, true>(p, k, q.beta1, u, v, e, h, nx, ny, twoA, bmarkers, bkind1, bu, bv, be, wu, wv, we, o1u, o1v, o1e);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
         asm volatile("" : "+v"(bmarkers), "+v"(twoA));
         double bu[3], bv[3], be[3], wu[3], wv[3], we[3], ou[3], ov[3], oe[3];
         swe_flow_rhs_cell<NONLIN>(p, o1u, o1v, o1e, h, nx, ny, bu, bv, be);
-        swe_flow_rhs_facets<NONLIN, LF, SRC, 1, false, SWE_FUSE_XG, SWE_FUSE_WG>(p, k, o1u, o1v, o1e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+        swe_flow_rhs_facets<NONLIN, LF, SRC, 1, false, SWE_FUSE_XG, SWE_FUSE_WG, SWE_FUSE_LDS>(p, k, o1u, o1v, o1e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
 #pragma unroll
         for (int i = 0; i < 3; i++) { wu[i] = lw[i][lane]; wv[i] = lw[3 + i][lane]; we[i] = lw[6 + i][lane]; }
         swe_flow_finish<NONLIN, LF, true>(p, k, q.beta2, o1u, o1v, o1e, h, nx, ny, twoA, bmarkers, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse123_kern
             if (outside[f]) {
                 const unsigned at = ((unsigned)tl.y >> (SWE_FUSE_FBITS*f)) & 0x1ffu;
 #pragma unroll
-                for (int j = 0; j < 6; j++) lds[SWE_FUSE3_XG + 6*at + j] = r0[f][j];
+                for (int j = 0; j < 6; j++) lds[SWE_LDSI(SWE_FUSE3_XG + 6*at + j, SWE_FUSE3_LDS)] = r0[f][j];
             }
         }
     }
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse123_kern
         twoA = fma(nx[0], ny[1], -(ny[0]*nx[1]));
         double bu[3], bv[3], be[3], wu[3], wv[3], we[3], ou[3], ov[3], oe[3];
         swe_flow_rhs_cell<NONLIN>(p, u, v, e, h, nx, ny, bu, bv, be);
-        swe_flow_rhs_facets<NONLIN, LF, SRC, 1, false, SWE_FUSE3_XG, SWE_FUSE_WG>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+        swe_flow_rhs_facets<NONLIN, LF, SRC, 1, false, SWE_FUSE3_XG, SWE_FUSE_WG, SWE_FUSE3_LDS>(p, k, u, v, e, h, lds, tr, bmarkers, nx, ny, twoA, bu, bv, be);
 #pragma unroll
         for (int i = 0; i < 3; i++) { wu[i] = 1.0*u[i]; wv[i] = 1.0*v[i]; we[i] = 1.0*e[i]; }
         swe_flow_finish<NONLIN, LF, true>(p, k, q.beta[0], u, v, e, h, nx, ny, twoA, bmarkers, bkind1, bu, bv, be, wu, wv, we, ou, ov, oe);
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse123_kern
             asm volatile("" : "+v"(bmarkers), "+v"(twoA));
             double bu[3], bv[3], be[3], wu[3], wv[3], we[3];
             swe_flow_rhs_cell<NONLIN>(p, u, v, e, h, nx, ny, bu, bv, be);
-            swe_flow_rhs_facets<NONLIN, LF, SRC, 1, false, SWE_FUSE3_XG, SWE_FUSE_WG>(p, k, u, v, e, h, P1, tr, bmarkers, nx, ny, twoA, bu, bv, be);
+            swe_flow_rhs_facets<NONLIN, LF, SRC, 1, false, SWE_FUSE3_XG, SWE_FUSE_WG, 9*SWE_FUSE_WG>(p, k, u, v, e, h, P1, tr, bmarkers, nx, ny, twoA, bu, bv, be);
             const double a0 = q.a0[s], a1 = q.a1[s];
 #pragma unroll
             for (int i = 0; i < 3; i++) {
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_quad_
             if (outside[f]) {
                 const unsigned at = (f < 3 ? ((unsigned)tl.y >> (SWE_FUSE_FBITS*f)) : (unsigned)tl.z) & 0x1ffu;
 #pragma unroll
-                for (int j = 0; j < 6; j++) lds[SWE_QFUSE_XG + 6*at + j] = r0[f][j];
+                for (int j = 0; j < 6; j++) lds[SWE_LDSI(SWE_QFUSE_XG + 6*at + j, SWE_QFUSE_LDS)] = r0[f][j];
             }
         }
     }
@@ -463,8 +463,8 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_quad_
     for (int f = 0; f < 4; f++) { \
         const unsigned ab = tr[f] & 0xffffu, aa = tr[f] >> 16; \
         const unsigned step = ab >= (unsigned)SWE_QFUSE_XG ? 1u : (unsigned)(4*SWE_FUSE_WG); \
-        unb[f] = lds[ab]; vnb[f] = lds[ab + step]; enb[f] = lds[ab + 2u*step]; \
-        una[f] = lds[aa]; vna[f] = lds[aa + step]; ena[f] = lds[aa + 2u*step]; \
+        unb[f] = lds[SWE_LDSI(ab, SWE_QFUSE_LDS)]; vnb[f] = lds[SWE_LDSI(ab + step, SWE_QFUSE_LDS)]; enb[f] = lds[SWE_LDSI(ab + 2u*step, SWE_QFUSE_LDS)]; \
+        una[f] = lds[SWE_LDSI(aa, SWE_QFUSE_LDS)]; vna[f] = lds[SWE_LDSI(aa + step, SWE_QFUSE_LDS)]; ena[f] = lds[SWE_LDSI(aa + 2u*step, SWE_QFUSE_LDS)]; \
     }
     // ---- stage 1 on every cell of the tile: U(1) = U(0) + beta1 dt M^-1 R(U(0))
     double o1u[4], o1v[4], o1e[4];

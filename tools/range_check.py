@@ -61,6 +61,17 @@ def exercise():
             if dev.flow_supported():                # the dataflow launch (plane accesses are checked; granules use a bounded resource)
                 dev.solve_flow([mesh.num_cells]*6)
                 n_launch += 1
+            if variant in ('plain', 'open+fields', 'sources'):
+                # round 6: the fused stage kernels (csrc/swe2d_fuse.h: the tile tables are host-built indices into LDS and memory) -
+                # stages 1 + 2 in one launch on triangles and quadrilaterals, all three on triangles, forced on these small meshes
+                dev.set_option(_lib.OPT_FLOW, 0)
+                for mode in ((1, 3) if k == 3 else (1,)):
+                    dev.set_option(_lib.OPT_FUSED_STAGES, mode)
+                    assert dev.fused_pair_info()[0] and (mode != 3 or dev.fused_triple_info()[0]), (name, variant, mode)
+                    dev.advance(3)
+                    n_launch += 6
+                dev.set_option(_lib.OPT_FUSED_STAGES, None)
+                dev.set_option(_lib.OPT_FLOW, None)
             dev.tendency()
             d = dev.diagnostics()
             assert np.isfinite(d).all(), (name, variant, d)
@@ -82,9 +93,16 @@ def exercise():
             inner = p.owned_prefix(3)
             dev.solve_stage_cells(i, 0, inner)
             dev.solve_stage_cells(i, inner, p.stage_range(i))
+        # the fused stage pair on the partition's ranges (tiles cut from an order that mixes owned and ghost cells)
+        from thetis_amd import ordering
+        dev.set_option(_lib.OPT_FUSED_STAGES, 1)
+        dev.fused_set_order(ordering.fused_tile_order(p))
+        assert dev.fused_pair_info()[0]
+        dev.solve_stage_pair_cells(p.stage_range(0), p.stage_range(1))
+        dev.solve_stage_cells(2, 0, p.n_owned)
         dev.diagnostics()
         dev.close()
-        n_launch += 8
+        n_launch += 10
     print('ok partitions', flush=True)
     return n_launch
 
