@@ -26,6 +26,8 @@ def _case():
         return mesh, bath, 0.1*uv, 0.1*eta
     if CASE == 'channel64':                      # eight cell columns per rank of eight: wider than a six-layer halo
         return channel_case(nx=64, ny=6, seed=21, amp_eta=0.3, amp_u=0.2)
+    if CASE == 'channel256':                     # the mesh of the first-contact test (tests/test_gpu_bench_contract.py): 64 x 64 quads per rank of four
+        return channel_case(nx=256, ny=64, seed=21, amp_eta=0.3, amp_u=0.2)
     return channel_case(nx=16, ny=6, seed=21, amp_eta=0.3, amp_u=0.2)
 
 

@@ -142,6 +142,33 @@ def test_owned_cells_are_sorted_by_distance_from_the_cut():
             assert p.owned_prefix(1) == p.n_owned and p.owned_prefix(depth + 1) == p.n_interior
 
 
+def test_state_digest_does_not_depend_on_the_halo_depth():
+    """``state_digest`` compares runs of DIFFERENT exchange schedules (first contact: a dataflow candidate with one exchange per step
+    against the host-staged reference with one per two steps): a rank numbers its send cells last and which cells those are depends on
+    the halo depth, so the fingerprint must take the owned cells in the order of their global ids.  (Found by ``tools.first_contact``
+    at the end of round 6: the candidate was dropped as "does not reproduce the host-staged exchange" with identical states.)"""
+    from thetis_amd.distributed import state_digest
+    from helpers import channel_case
+    mesh, bath, uv, eta = channel_case(nx=24, ny=6, seed=3, amp_eta=0.3, amp_u=0.2)
+    owner = strip_owner(mesh, 2)
+
+    class Stub(object):
+        def __init__(self, part):
+            self.part = part
+
+        def get_state_owned(self):
+            g = self.part.local_to_global[:self.part.n_owned]
+            return g, uv[g], eta[g]
+    parts = [build_partition(mesh, owner, 0, halo_depth=d) for d in (3, 6, 12)]
+    assert any(not np.array_equal(parts[0].local_to_global[:parts[0].n_owned], q.local_to_global[:q.n_owned]) for q in parts[1:])
+    assert len({state_digest(Stub(q)) for q in parts}) == 1
+    eta2 = eta.copy()
+    eta2[parts[0].local_to_global[0], 0] += 1e-13
+    one = state_digest(Stub(parts[0]))
+    eta[:] = eta2
+    assert state_digest(Stub(parts[0])) != one
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('every,overlap,n_steps,graph', [(1, 2, 4, ''), (2, 3, 7, ''), (4, 3, 8, ''), (2, 3, 8, '+graph'),
                                                          (4, 0, 16, '+graph'), (1, 0, 6, '+graph')])
@@ -544,7 +571,7 @@ def test_ranks_on_one_gpu_with_the_fused_stage_pair(tmp_path, hip_lib, monkeypat
     (2, 'channel+p2p+flowx', 3), (2, 'channel+every2+p2p+flowx', 5), (3, 'channel+every3+p2p+flowx+graph', 11), (4, 'channel+every2+p2p+flowx', 24),
     (2, 'channel+every4+p2p+flowx+capture', 8), (3, 'delaunay+p2p+flowx+graph', 2), (2, 'delaunay+every2+p2p+flowx', 3), (2, 'channel+every1+p2p+flowx', 40),
     (2, 'channel+every1+p2p+flowx', 150), (3, 'channel+every2+p2p+flowx+mix', 11), (2, 'channel+every2+p2p+flow+mix+graph', 9),
-    (2, 'channel+every4+p2p+mix+graph', 10)])
+    (2, 'channel+every4+p2p+mix+graph', 10), (4, 'channel64+every1+p2p+flowx', 9), (4, 'channel256+every1+p2p+flowx', 9), (4, 'channel256+every2+p2p+flowx', 9)])
 def test_ranks_on_one_gpu_with_one_launch_per_cycle(tmp_path, hip_lib, monkeypatch, world, case, n_steps):
     """flow: the 3m stages of a cycle in ONE dataflow launch on the shrinking ranges (csrc/swe2d_flow.h; the blocks of the
     launch follow a locality order over owned and ghost cells), then the exchange - eager, host-staged and peer-to-peer, and

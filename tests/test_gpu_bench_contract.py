@@ -136,7 +136,8 @@ def test_first_contact_tells_the_story_of_a_multi_rank_run(hip_lib, tmp_path):
         if broken:
             assert d['config']['exchange'] == 'host' and "FAILED / dropped: transport 'p2p'" in text and "  - transport 'p2p'" in text
         else:
-            assert d['config']['exchange'] == 'p2p' and 'failures: none' in text and 'schedule candidates' in text
+            assert d['config']['exchange'] == 'p2p' and 'failures: none' in text and 'schedule candidates' in text, \
+                [l for l in text.splitlines() if 'FAILED' in l or l.startswith('  - ')]
             assert "transport 'p2p': set up on every rank" in text and 'soak: ' in text
 
 

@@ -503,9 +503,11 @@ def test_fused_stage_pair_on_quadrilaterals_gives_the_bits_of_the_stage_launches
     from thetis_amd.device import Swe2dDevice
     monkeypatch.setenv('THETIS_AMD_FLOW', '0')
     kw, reorder, forced = {}, 'auto', '1'
-    if case in ('by_the_rule_900k', 'coupled_tracer_270k'):
-        mesh, bath, uv, eta = quad_case(nx=600, ny=450, lx=100e3, ly=75e3, seed=5, amp_eta=0.3, amp_u=0.2)
+    if case == 'by_the_rule_900k':                    # (the rule: whole meshes of >= 850 k quadrilaterals)
+        mesh, bath, uv, eta = quad_case(nx=1200, ny=750, lx=100e3, ly=62.5e3, seed=5, amp_eta=0.3, amp_u=0.2)
         forced = None
+    elif case == 'coupled_tracer_270k':
+        mesh, bath, uv, eta = quad_case(nx=600, ny=450, lx=100e3, ly=75e3, seed=5, amp_eta=0.3, amp_u=0.2)
     elif case == 'skewed_sources':
         mesh, bath, uv, eta = quad_case(nx=90, ny=70, lx=100e3, ly=70e3, seed=6, amp_eta=0.05, amp_u=0.05, skew=0.2)
     elif case.startswith('general'):

@@ -1162,9 +1162,13 @@ class DistributedSwe2d(object):
 
 
 def state_digest(solver):
-    """bitwise fingerprint of the owned state (blake2b of the raw doubles)"""
+    """bitwise fingerprint of the owned state (blake2b of the raw doubles, cells in the order of their GLOBAL ids: a rank's local
+    numbering puts its send cells last, and which cells those are depends on the halo depth - two schedules with different
+    ``exchange_every`` hold the same owned cells in different orders)"""
     import hashlib
-    _, u, e = solver.get_state_owned()
+    ids, u, e = solver.get_state_owned()
+    o = np.argsort(ids, kind='stable')
+    u, e = u[o], e[o]
     return hashlib.blake2b(np.ascontiguousarray(u).tobytes() + np.ascontiguousarray(e).tobytes(), digest_size=16).hexdigest()
 
 
