@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SWE2D_ABI_VERSION 11
+#define SWE2D_ABI_VERSION 12
 #define SWE2D_MAX_MARKERS 16          /* boundary markers must be in 1..SWE2D_MAX_MARKERS-1 */
 
 typedef enum {
@@ -171,6 +171,11 @@ int  swe2d_fused_set_order(swe2d_handle *h, const int32_t *cells_in_tile_order);
  * the tile tables), out[1] = tiles, out[2] / out[3] = cells of the first / second rings (stage 1 is evaluated on interior + both,
  * stage 2 on interior + the first).  Same results bit for bit. */
 int  swe2d_fused_triple_info(swe2d_handle *h, int32_t out[4]);
+/* The two-ring tiles alone may be cut from an order of their own, with positions at which a tile must begin (tile_starts, n_starts
+ * of them; NULL / 0: none): compact patches sized for interior + two rings (thetis_amd/ordering.py triple_tile_order: 12 x 7 quads of
+ * a RectangleMesh) instead of as many consecutive cells as fit.  cells_in_tile_order = NULL: the order of swe2d_fused_set_order.
+ * Results do not depend on it.  Replaces nothing in the reference (Firedrake's PyOP2 has no tiling to steer). */
+int  swe2d_fused_set_triple_tiles(swe2d_handle *h, const int32_t *cells_in_tile_order, const int32_t *tile_starts, int32_t n_starts);
 int  swe2d_device_count(void);                                   /* number of visible HIP devices, <0 on error */
 
 /* Shu-Osher coefficients the stage kernels use (host-only, needs no device): stage i computes

@@ -31,7 +31,7 @@ def test_abi_version_and_loud_failure_without_device(hip_lib):
     from thetis_amd import _lib
     from thetis_amd.device import Swe2dDevice
     from thetis_amd.mesh import RectangleMesh
-    assert hip_lib.swe2d_abi_version() == _lib.ABI_VERSION == 11
+    assert hip_lib.swe2d_abi_version() == _lib.ABI_VERSION == 12
     if hip_lib.swe2d_device_count() > 0:
         pytest.skip('a GPU is present')
     mesh = RectangleMesh(4, 3, 1.0, 1.0)

@@ -551,6 +551,8 @@ def test_fused_stage_pair_gives_the_bits_of_the_stage_launches(hip_lib, monkeypa
     kw, reorder, forced = {}, 'auto', '1'
     if case == 'structured':
         mesh, bath, uv, eta = channel_case(nx=200, ny=120, lx=100e3, ly=50e3, seed=5, amp_eta=0.3, amp_u=0.2)
+    elif case.startswith('patches'):
+        mesh, bath, uv, eta = channel_case(nx=131, ny=75, lx=100e3, ly=50e3, seed=9, amp_eta=0.3, amp_u=0.2)
     elif case == 'linear_no_lf':
         mesh, bath, uv, eta = channel_case(nx=120, ny=90, lx=100e3, ly=50e3, seed=6, amp_eta=0.3, amp_u=0.2)
         kw = dict(use_nonlinear_equations=False, use_lax_friedrichs_velocity=False)
@@ -611,13 +613,14 @@ def test_fused_stage_pair_gives_the_bits_of_the_stage_launches(hip_lib, monkeypa
         assert np.array_equal(a_, b_)
 
 
-@pytest.mark.parametrize('case', ['structured', 'linear_no_lf', 'ragged_small', 'random_numbering', 'sources', 'bench_size_vs_oracle'])
+@pytest.mark.parametrize('case', ['structured', 'linear_no_lf', 'ragged_small', 'random_numbering', 'sources', 'patches_12x7', 'patches_5x3', 'bench_size_vs_oracle'])
 def test_fused_stage_triple_gives_the_bits_of_the_stage_launches(hip_lib, ref_so, monkeypatch, case):
     """csrc/swe2d_fuse.h, swe_fuse123_kernel (round 6; SWE2D_OPT_FUSED_STAGES = 3): ALL three stages of a step in one launch, tiles of
     interior + two rings in a 256-lane workgroup, U(1) and U(2) never leave the chip, U(3) into the second state buffer and the two
     swap.  Bit for bit the three stage launches (open boundaries and walls, linear equations without Lax-Friedrichs, partial tiles,
-    a random numbering with tiny tiles, source terms; odd and even numbers of steps: the buffers change places every step), and at
-    1 M cells 20 steps against oracle/swe2d_ref.c at 1e-11."""
+    a random numbering with tiny tiles, source terms; tiles cut as patches of 12 x 7 quads - what a RectangleMesh of >= 500 k triangles
+    gets by itself - and of 5 x 3 (swe2d_fused_set_triple_tiles; a mesh whose sides are no multiples of the patch); odd and even numbers of
+    steps: the buffers change places every step), and at 1 M cells 20 steps against oracle/swe2d_ref.c at 1e-11."""
     from thetis_amd import _lib
     from thetis_amd.device import Swe2dDevice
     from thetis_amd.mesh import Mesh2d, RectangleMesh, _rect_marker_fn
@@ -638,6 +641,8 @@ def test_fused_stage_triple_gives_the_bits_of_the_stage_launches(hip_lib, ref_so
         return
     if case == 'structured':
         mesh, bath, uv, eta = channel_case(nx=200, ny=120, lx=100e3, ly=50e3, seed=5, amp_eta=0.3, amp_u=0.2)
+    elif case.startswith('patches'):
+        mesh, bath, uv, eta = channel_case(nx=131, ny=75, lx=100e3, ly=50e3, seed=9, amp_eta=0.3, amp_u=0.2)
     elif case == 'linear_no_lf':
         mesh, bath, uv, eta = channel_case(nx=120, ny=90, lx=100e3, ly=50e3, seed=6, amp_eta=0.3, amp_u=0.2)
         kw = dict(use_nonlinear_equations=False, use_lax_friedrichs_velocity=False)
@@ -665,6 +670,13 @@ def test_fused_stage_triple_gives_the_bits_of_the_stage_launches(hip_lib, ref_so
             dev.set_field(_lib.FIELD_CORIOLIS, 1e-4*(1.0 + cxy[:, :, 1]/50e3))
             dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
             dev.set_field(_lib.FIELD_WIND_STRESS, np.stack([0.1*np.sin(cxy[:, :, 0]/2e4), 0.05*np.cos(cxy[:, :, 1]/1e4)], axis=2))
+        if case.startswith('patches') and fuse == '3':
+            from thetis_amd import ordering
+            bx, by = (12, 7) if case == 'patches_12x7' else (5, 3)
+            order, starts = ordering.triple_tile_order(mesh, bx, by)
+            dev.fused_set_triple_tiles(order, starts)
+            on, tiles, ring1, ring2 = dev.fused_triple_info()
+            assert on and tiles >= len(starts) and (tiles == len(starts) or case == 'patches_12x7'), (tiles, len(starts))
         dev.set_state(uv, eta)
         dev.advance(3)
         dev.advance(2)

@@ -19,7 +19,7 @@ SCALAR_LINEAR_DRAG, SCALAR_QUADRATIC_DRAG, SCALAR_MANNING_DRAG, SCALAR_NORM_SMOO
 
 IPC_HANDLE_BYTES = 64    # include/swe2d.h SWE2D_IPC_HANDLE_BYTES (sizeof(hipIpcMemHandle_t))
 SUM_LIMBS = 6             # include/swe2d.h: limbs per order-independent sum (swe2d_diagnostics_limbs)
-ABI_VERSION = 11         # include/swe2d.h SWE2D_ABI_VERSION
+ABI_VERSION = 12         # include/swe2d.h SWE2D_ABI_VERSION
 # include/swe2d.h swe2d_option
 (OPT_FUSED_STAGES, OPT_FLOW, OPT_FLOW_WD, OPT_BND_INLINE, OPT_LDSX, OPT_ALTERNATE, OPT_COMPACT_IDX, OPT_VISC_FUSION, OPT_WALL_FAST,
  OPT_FLOW_POLL, OPT_FLOW_CAPACITY, OPT_FLOW_TIMEOUT_MS, OPT_P2P_TIMEOUT_MS, OPT_P2P_ZONE, OPT_ROCTX) = range(15)
@@ -85,6 +85,7 @@ SYMBOLS = {
     'swe2d_fused_pair_info': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_fused_triple_info': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_fused_set_order': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
+    'swe2d_fused_set_triple_tiles': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]),
     'swe2d_solve_stage_pair_cells': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_device_count': (ctypes.c_int, []),
     'swe2d_ssprk33_coefficients': (None, [_dp, _dp, _dp]),

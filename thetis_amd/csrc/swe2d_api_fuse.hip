@@ -288,14 +288,17 @@ fuse3_kernel_t pick_fuse3_kernel(bool nl, bool lf, bool src) { return src ? pick
 }  // namespace
 
 // Tiles: consecutive cells of the tile order as long as interior + ring 1 (facet neighbours of the interior) + ring 2 (facet
-// neighbours of ring 1) fit the 256 lanes and ring 2's facets towards the outside fit the staging area.
+// neighbours of ring 1) fit the 256 lanes and ring 2's facets towards the outside fit the staging area - and up to the next
+// position the caller marked as the start of a tile (swe2d_fused_set_triple_tiles: patches of 12 x 7 quads = 168 triangles + 38 + 42
+// fill 248 lanes, where 147 consecutive cells of the 16 x 6 numbering leave ragged patches with rings of 52 + 57).
 int fuse123_build(Handle *h)
 {
     if (h->fuse3_tile) return SWE2D_OK;
     const int n = h->n_cells;
     const size_t S = h->stride;
     const int *nbr = h->h_nbr.data();
-    const int *order = (int)h->fuse_order.size() == n ? h->fuse_order.data() : nullptr;
+    const int *order = (int)h->fuse3_order.size() == n ? h->fuse3_order.data() : ((int)h->fuse_order.size() == n ? h->fuse_order.data() : nullptr);
+    const unsigned char *start = (int)h->fuse3_start.size() == n ? h->fuse3_start.data() : nullptr;
     std::vector<int2> tl, cnt;
     std::vector<unsigned char> state((size_t)n, 0);                // 0 outside | 1 interior | 2 ring 1 | 3 ring 2, of the tile being built
     std::vector<int> lane_of((size_t)n, -1), touched, inner;
@@ -311,6 +314,7 @@ int fuse123_build(Handle *h)
         inner.clear(); touched.clear();
         count[1] = count[2] = count[3] = 0;
         while (pos < n) {
+            if (start && start[pos] && !inner.empty()) break;      // the caller's tiles (swe2d_fused_set_triple_tiles): compact patches
             const int kk = order ? order[pos] : pos;
             undo.clear();
             const size_t touched_before = touched.size();
@@ -462,6 +466,39 @@ int swe2d_fused_set_order(swe2d_handle *hh, const int32_t *cells_in_tile_order)
     h->fuse_n_tiles = 0; h->fuse_ring_cells = 0;
     if (h->fuse_state == -1) h->fuse_state = 0;
     h->fuse_order.swap(order);
+    return SWE2D_OK;
+}
+
+int swe2d_fused_set_triple_tiles(swe2d_handle *hh, const int32_t *cells_in_tile_order, const int32_t *tile_starts, int32_t n_starts)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<int> order;
+    std::vector<unsigned char> start;
+    if (cells_in_tile_order) {
+        std::vector<char> seen((size_t)h->n_cells, 0);
+        for (int i = 0; i < h->n_cells; i++) {
+            const int c = cells_in_tile_order[i];
+            if (c < 0 || c >= h->n_cells || seen[c]) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "fused stages: the tile order is not a permutation of the cells");
+            seen[c] = 1;
+        }
+        order.assign(cells_in_tile_order, cells_in_tile_order + h->n_cells);
+    }
+    if (n_starts < 0 || (n_starts > 0 && !tile_starts)) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "fused stages: tile starts");
+    if (n_starts > 0) {
+        start.assign((size_t)h->n_cells, 0);
+        for (int i = 0; i < n_starts; i++) {
+            if (tile_starts[i] < 0 || tile_starts[i] >= h->n_cells) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "fused stages: a tile start outside the cells");
+            start[tile_starts[i]] = 1;
+        }
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->fuse3_tile) { (void)hipFree(h->fuse3_tile); h->fuse3_tile = nullptr; }
+    if (h->fuse3_cnt) { (void)hipFree(h->fuse3_cnt); h->fuse3_cnt = nullptr; }
+    h->fuse3_n_tiles = 0;
+    h->fuse3_order.swap(order);
+    h->fuse3_start.swap(start);
     return SWE2D_OK;
 }
 

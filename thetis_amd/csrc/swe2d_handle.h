@@ -136,6 +136,8 @@ struct Handle {
     int fuse3_n_tiles = 0;
     long long fuse3_ring1 = 0, fuse3_ring2 = 0;
     std::vector<int> fuse_order;                        // cells in the order the tiles are cut from (swe2d_fused_set_order); empty: the numbering
+    std::vector<int> fuse3_order;                       // the same for the two-ring tiles alone (swe2d_fused_set_triple_tiles); empty: fuse_order
+    std::vector<unsigned char> fuse3_start;             // [n_cells] 1 = a two-ring tile must begin at this position of the order; empty: none
     int n_conn_escapes = 0;                             // cells whose record is an escape to the wide ones
     std::vector<int> h_nbr;                             // host copy of the packed neighbour codes [3][S] (triangles; flow_build)
     // dataflow stage loop (swe2d_flow.h): per-block stage counters, status word {timeouts, first late block + 1}

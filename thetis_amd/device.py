@@ -150,6 +150,14 @@ class Swe2dDevice(object):
             # bisection boxes (ordering.flow_block_order) instead of 64 consecutive cells of the device numbering - a fifth to a
             # third fewer rim facets
             self.flow_set_order(ordering.flow_block_order(mesh))
+        tt = os.environ.get('THETIS_AMD_TRIPLE_TILE', '12,7')
+        if (self.npc == 3 and isinstance(reorder, str) and self.n_owned == self.n_cells and getattr(mesh, 'structured', False)
+                and self.n_cells >= 500000 and tt != '0'):
+            # a mesh large enough for all three stages in one launch (csrc/swe2d_fuse.h, swe_fuse123_kernel): its two-ring tiles as
+            # patches of 12 x 7 quads (168 triangles + rings of 38 + 42 = 248 of 256 lanes) instead of as many consecutive cells of the
+            # 16 x 6 numbering as fit (147 + 52 + 57: ragged)
+            bx, by = (int(v) for v in tt.split(','))
+            self.fused_set_triple_tiles(*ordering.triple_tile_order(mesh, bx, by))
         if self.npc == 4 and not getattr(mesh, 'affine', True):
             # a partition (LocalPartition.affine = the GLOBAL mesh's flag) whose own cells happen to be parallelograms takes the
             # general kernels like every other rank: ghost and owned copies of a cell then agree bit for bit
@@ -429,6 +437,19 @@ class Swe2dDevice(object):
             order = self.inv_perm[order]
         order = np.ascontiguousarray(order, dtype=np.int32)
         self._ck(self.lib.swe2d_fused_set_order(self.h, _iptr(order)))
+
+    def fused_set_triple_tiles(self, cells_in_tile_order, tile_starts=None):
+        """The order the two-ring tiles (all three stages in one launch) are cut from and the positions of that order at which a
+        tile must begin (``ordering.triple_tile_order``); ``None``: as the fused pair.  Caller's cell numbering."""
+        if cells_in_tile_order is None:
+            self._ck(self.lib.swe2d_fused_set_triple_tiles(self.h, None, None, 0))
+            return
+        order = np.asarray(cells_in_tile_order, dtype=np.int64)
+        if self.perm is not None:
+            order = self.inv_perm[order]
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        starts = np.ascontiguousarray(np.zeros(0) if tile_starts is None else tile_starts, dtype=np.int32)
+        self._ck(self.lib.swe2d_fused_set_triple_tiles(self.h, _iptr(order), _iptr(starts) if len(starts) else None, len(starts)))
 
     def forward_euler_cells(self, cell_begin, cell_end):
         """ForwardEuler step of device cells [cell_begin, cell_end) from state buffer 0 into buffer 1 (partitions)."""

@@ -7,7 +7,7 @@ Firedrake gives the reference the same service by reordering DMPlex points (reve
 """
 import numpy as np
 
-__all__ = ['hilbert_index', 'hilbert_cell_order', 'tile_cell_order', 'structured_tile_order', 'structured_subset_order', 'auto_cell_order', 'flow_block_order', 'fused_tile_order', 'bisection_block_order',
+__all__ = ['hilbert_index', 'hilbert_cell_order', 'tile_cell_order', 'structured_tile_order', 'structured_subset_order', 'auto_cell_order', 'flow_block_order', 'fused_tile_order', 'triple_tile_order', 'bisection_block_order',
            'patch_row_order', 'first_touch_vertex_order']
 
 
@@ -188,6 +188,22 @@ def fused_tile_order(mesh):
         return structured_subset_order(np.asarray(mesh.local_to_global), parent[0], parent[1], bx=16, by=6)
     cen = np.asarray(mesh.vertex_xy)[np.asarray(mesh.cells)].mean(axis=1)
     return hilbert_cell_order(cen)
+
+
+def triple_tile_order(mesh, bx=12, by=7):
+    """(order, tile starts) of the TWO-RING tiles of a RectangleMesh of triangles (csrc/swe2d_fuse.h, swe_fuse123_kernel: interior +
+    facet neighbours + their facet neighbours in 256 lanes): patches of bx x by quads along the Hilbert curve, row by row inside a
+    patch.  12 x 7 quads = 168 triangles + 38 + 42 = 248 lanes; a patch cut short by the mesh's edge is a tile of its own."""
+    nx, ny = mesh.nx, mesh.ny
+    n = 2*nx*ny
+    q = np.arange(n)//2
+    i, j = q % nx, q//nx
+    lev = max(1, int(np.ceil(np.log2(max(nx//bx + 1, ny//by + 1)))))
+    d = hilbert_index(i//bx, j//by, lev)
+    order = np.lexsort((np.arange(n), i % bx, j % by, d))
+    ds = d[order]
+    starts = np.nonzero(np.concatenate(([True], ds[1:] != ds[:-1])))[0]
+    return order, starts
 
 
 def first_touch_vertex_order(cells):
