@@ -241,12 +241,12 @@ def run_single(args):
                      'frac': achieved/HBM_PEAK_GBS, 'frac_samples': frac_samples, 'frac_median': float(np.median(frac_samples)),
                      'frac_min': float(min(frac_samples)), 'frac_max': float(max(frac_samples)),
                      'frac_definition': 'SURVEY 8d model bytes of three stage launches (684 B per triangle and step) / step time / 8 TB/s',
-                     # (1) the bytes the launch structure that RAN must move in the same perfect-cache model (fused pair + stage 3: 432 B
-                     #     per triangle and step; three stage launches: 684 = frac) over the time
+                     # (1) the bytes the launch structure that RAN must move in the same perfect-cache model (all three stages in one
+                     #     launch: 180 B per triangle and step; fused pair + stage 3: 432; three stage launches: 684 = frac) over the time
                      'frac_fused_model': model_step/step_s/1e9/HBM_PEAK_GBS,
                      'fused_model_bytes_per_step': model_step,
                      # (2) what the memory system delivered by the counters (profiles/, same library and workload)
-                     'traffic': traffic, 'traffic_unit': 'bytes per launch (with the fused stage pair: per element-update = a third of a step)',
+                     'traffic': traffic, 'traffic_unit': 'bytes per element-update = a third of a step (three stage launches: per launch)',
                      'traffic_rate_GBs': (traffic/(ms_kernel*1e-3)/1e9) if traffic else None,
                      'traffic_rate_frac': (traffic/(ms_kernel*1e-3)/1e9/HBM_PEAK_GBS) if traffic else None,
                      'traffic_source': traffic_src,
@@ -254,10 +254,15 @@ def run_single(args):
                      #     1024 SIMDs x 2.4 GHz, against the step time (a kernel near 1 here is bound by its arithmetic, not by HBM)
                      'valu_wave_instructions_per_step': valu,
                      'valu_issue_frac': (valu*4.0/(N_SIMD*FP64_CLOCK_HZ)/step_s) if valu else None,
-                     'kernel': ('swe_fuse12_kernel (stages 1 + 2 in one launch) + swe_stage_kernel (stage 3): avg_launch_ms is per '
-                                'element-update = a third of a step') if fused[0] else 'swe_stage_kernel',
+                     'kernel': {'triple': 'swe_fuse123_kernel (all three stages of a step in one launch on two-ring tiles, U(1) and U(2) in LDS): '
+                                          'avg_launch_ms is per element-update = a third of the launch',
+                                'pair': 'swe_fuse12_kernel (stages 1 + 2 in one launch) + swe_stage_kernel (stage 3): avg_launch_ms is per '
+                                        'element-update = a third of a step',
+                                'stages': 'swe_stage_kernel'}[structure],
                      'launch_structure': structure, 'launches_per_step': LAUNCHES[structure],
-                     'fused_stage_pair': {'tiles': fused[1], 'ring_cells': fused[2]} if fused[0] else None,
+                     'fused_stage_pair': {'tiles': fused[1], 'ring_cells': fused[2]} if (fused[0] and structure == 'pair') else None,
+                     'fused_stage_triple': (dict(zip(('tiles', 'ring1_cells', 'ring2_cells'), dev.fused_triple_info()[1:]))
+                                            if structure == 'triple' else None),
                      'avg_launch_ms': ms_kernel, 'avg_launch_ms_per_launch_events': ms_kernel_each,
                      'algorithmic_bytes_per_launch': BYTES_PER_ELEMENT_UPDATE*n},
     }

@@ -176,6 +176,17 @@ int  swe2d_fused_triple_info(swe2d_handle *h, int32_t out[4]);
  * a RectangleMesh) instead of as many consecutive cells as fit.  cells_in_tile_order = NULL: the order of swe2d_fused_set_order.
  * Results do not depend on it.  Replaces nothing in the reference (Firedrake's PyOP2 has no tiling to steer). */
 int  swe2d_fused_set_triple_tiles(swe2d_handle *h, const int32_t *cells_in_tile_order, const int32_t *tile_starts, int32_t n_starts);
+/* A PARTITION's whole step in one launch (round 6, last): stage 3 on cells [0, cell_end), the last of the step's three shrinking ranges
+ * (thetis_amd/partition.py stage_range); stages 1 and 2 are evaluated on the tiles' supersets of theirs and never leave the chip.  The
+ * result goes to the second state buffer and the two change places: inside a stream capture call it an EVEN number of times per
+ * captured sequence (the pointers a replay uses are those of the capture), and build the tables before (swe2d_fused_step_info).
+ * Cells of the state beyond cell_end hold stale values afterwards (ghost cells the next exchange rewrites).  SWE2D_ERR_UNSUPPORTED
+ * where the kernel does not cover the handle (quadrilaterals, wetting-drying, viscosity, source terms unless forced).
+ * swe2d_fused_step_info: out[0] = 1 when the caller should take it (patches handed in with swe2d_fused_set_triple_tiles and more
+ * cells than the dataflow kernel holds, or SWE2D_OPT_FUSED_STAGES = 3), out[1..3] as swe2d_fused_triple_info.  Same bits as
+ * swe2d_solve_stage_cells x 3.  Replaces: one ERKGenericShuOsher.advance on a rank's cells (thetis/rungekutta.py:949-952). */
+int  swe2d_solve_step_cells(swe2d_handle *h, int32_t cell_end);
+int  swe2d_fused_step_info(swe2d_handle *h, int32_t out[4]);
 int  swe2d_device_count(void);                                   /* number of visible HIP devices, <0 on error */
 
 /* Shu-Osher coefficients the stage kernels use (host-only, needs no device): stage i computes

@@ -442,7 +442,7 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     d1 = solver.diagnostics()
     ids, u, e = solver.get_state_owned()
     np.savez(os.path.join(out_dir, 'rank{:d}.npz'.format(rank)), ids=ids, uv=u, eta=e, d0=d0, d1=d1,
-             peers=np.array(solver.part.peers, dtype=np.int64), fused=np.array(int(solver.dev.fused_pair_info()[0])))
+             peers=np.array(solver.part.peers, dtype=np.int64), fused=np.array(int(solver.dev.fused_pair_info()[0])), step3=np.array(int(solver.dev.fused_step_info()[0])))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -566,6 +566,38 @@ def test_ranks_on_one_gpu_with_the_fused_stage_pair(tmp_path, hip_lib, monkeypat
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('world,case,n_steps', [
+    (2, 'channel64+every2+p2p+nosplit', 7), (2, 'channel64+every4+nosplit', 9), (3, 'delaunay+every2+p2p+nosplit+graph', 4),
+    (4, 'channel64+every3+p2p+nosplit+graph', 9), (2, 'channel64+every2+p2p+nosplit+capture', 8), (2, 'channel256+every4+p2p+nosplit+capture', 8),
+    (4, 'channel256+every4+p2p+nosplit+graph', 11)])
+def test_ranks_on_one_gpu_with_whole_steps_in_one_launch(tmp_path, hip_lib, monkeypatch, world, case, n_steps):
+    """A partition's steps as ONE launch each (csrc/swe2d_fuse.h swe_fuse123_kernel through swe2d_solve_step_cells: two-ring tiles over
+    owned and ghost cells - the 11 x 8-quad patches of the parent mesh, or runs of the Hilbert order on a Delaunay partition -, stage 3
+    on the step's last shrinking range, the state buffers change places after every launch): DistributedSwe2d takes the steps of a cycle
+    in pairs, so that every cycle - eager, per-cycle graph or one graph for the whole advance - ends on the buffer it began on; an odd
+    step of a cycle (m = 3, and the trailing cycles of these step counts) goes by the fused pair + stage 3.  Forced here (ranks take it by
+    themselves beyond 131 k cells).  Bitwise the single-device run by stage launches."""
+    from thetis_amd.device import Swe2dDevice
+    import dist_worker
+    monkeypatch.setenv('THETIS_AMD_FUSE12', '3')
+    base = case.split('+')[0]
+    dist_worker.CASE = base
+    mesh, bath, uv, eta = dist_worker._case()
+    run_workers(gpu_worker, world, n_steps, str(tmp_path), axis=0, case=case)
+    u_p, e_p, extra = gather(str(tmp_path), world, mesh.num_cells)
+    assert all(int(d['step3']) == 1 for d in extra), 'a rank did not take the one-launch steps'
+    monkeypatch.setenv('THETIS_AMD_FUSE12', '0')
+    monkeypatch.setenv('THETIS_AMD_FLOW', '0')
+    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev.set_state(uv, eta)
+    dev.advance(n_steps)
+    u_s, e_s = dev.get_state()
+    dev.close()
+    dist_worker.CASE = 'channel'
+    assert np.array_equal(u_p, u_s) and np.array_equal(e_p, e_s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,case,n_steps', [
     (2, 'channel+flow', 3), (2, 'channel+every2+flow', 5), (2, 'channel+p2p+flow', 3), (3, 'channel+every3+p2p+flow+graph', 11),
     (2, 'channel+every2+p2p+flow+nosplit+graph', 9), (2, 'channel+every4+p2p+flow+capture', 8), (3, 'delaunay+p2p+flow+graph', 2),
     (2, 'channel+p2p+flowx', 3), (2, 'channel+every2+p2p+flowx', 5), (3, 'channel+every3+p2p+flowx+graph', 11), (4, 'channel+every2+p2p+flowx', 24),

@@ -551,8 +551,6 @@ def test_fused_stage_pair_gives_the_bits_of_the_stage_launches(hip_lib, monkeypa
     kw, reorder, forced = {}, 'auto', '1'
     if case == 'structured':
         mesh, bath, uv, eta = channel_case(nx=200, ny=120, lx=100e3, ly=50e3, seed=5, amp_eta=0.3, amp_u=0.2)
-    elif case.startswith('patches'):
-        mesh, bath, uv, eta = channel_case(nx=131, ny=75, lx=100e3, ly=50e3, seed=9, amp_eta=0.3, amp_u=0.2)
     elif case == 'linear_no_lf':
         mesh, bath, uv, eta = channel_case(nx=120, ny=90, lx=100e3, ly=50e3, seed=6, amp_eta=0.3, amp_u=0.2)
         kw = dict(use_nonlinear_equations=False, use_lax_friedrichs_velocity=False)
@@ -570,7 +568,7 @@ def test_fused_stage_pair_gives_the_bits_of_the_stage_launches(hip_lib, monkeypa
         mesh, bath, uv, eta = channel_case(nx=120, ny=90, lx=100e3, ly=50e3, seed=8, amp_eta=0.3, amp_u=0.2)
     else:
         mesh, bath, uv, eta = channel_case(nx=450, ny=300, lx=100e3, ly=50e3, seed=5, amp_eta=0.3, amp_u=0.2)
-        forced = None
+        forced = '2'              # the pair by the library's rule (250 k cells), never the three-stage launch the mesh would take by itself
     from thetis_amd import _lib
     cxy = mesh.cell_xy()
     out = []
@@ -613,7 +611,8 @@ def test_fused_stage_pair_gives_the_bits_of_the_stage_launches(hip_lib, monkeypa
         assert np.array_equal(a_, b_)
 
 
-@pytest.mark.parametrize('case', ['structured', 'linear_no_lf', 'ragged_small', 'random_numbering', 'sources', 'patches_12x7', 'patches_5x3', 'bench_size_vs_oracle'])
+@pytest.mark.parametrize('case', ['structured', 'linear_no_lf', 'ragged_small', 'random_numbering', 'sources', 'patches_12x7', 'patches_5x3', 'by_the_rule_270k', 'coupled_by_the_rule_270k',
+                                  'bench_size_vs_oracle'])
 def test_fused_stage_triple_gives_the_bits_of_the_stage_launches(hip_lib, ref_so, monkeypatch, case):
     """csrc/swe2d_fuse.h, swe_fuse123_kernel (round 6; SWE2D_OPT_FUSED_STAGES = 3): ALL three stages of a step in one launch, tiles of
     interior + two rings in a 256-lane workgroup, U(1) and U(2) never leave the chip, U(3) into the second state buffer and the two
@@ -643,6 +642,8 @@ def test_fused_stage_triple_gives_the_bits_of_the_stage_launches(hip_lib, ref_so
         mesh, bath, uv, eta = channel_case(nx=200, ny=120, lx=100e3, ly=50e3, seed=5, amp_eta=0.3, amp_u=0.2)
     elif case.startswith('patches'):
         mesh, bath, uv, eta = channel_case(nx=131, ny=75, lx=100e3, ly=50e3, seed=9, amp_eta=0.3, amp_u=0.2)
+    elif case.endswith('by_the_rule_270k'):
+        mesh, bath, uv, eta = channel_case(nx=450, ny=300, lx=100e3, ly=50e3, seed=5, amp_eta=0.3, amp_u=0.2)
     elif case == 'linear_no_lf':
         mesh, bath, uv, eta = channel_case(nx=120, ny=90, lx=100e3, ly=50e3, seed=6, amp_eta=0.3, amp_u=0.2)
         kw = dict(use_nonlinear_equations=False, use_lax_friedrichs_velocity=False)
@@ -663,6 +664,8 @@ def test_fused_stage_triple_gives_the_bits_of_the_stage_launches(hip_lib, ref_so
     out = []
     for fuse in ('0', '3'):
         monkeypatch.setenv('THETIS_AMD_FUSE12', fuse)
+        if fuse == '3' and case.endswith('by_the_rule_270k'):
+            monkeypatch.delenv('THETIS_AMD_FUSE12')          # what the library takes by itself (11 x 8-quad patches from Swe2dDevice)
         dev = Swe2dDevice(mesh, bath, 0.5, reorder=reorder, **kw)
         dev.set_bc(2, {'elev': 0.1})
         dev.set_bc(3, {'un': 0.05})
@@ -678,6 +681,17 @@ def test_fused_stage_triple_gives_the_bits_of_the_stage_launches(hip_lib, ref_so
             on, tiles, ring1, ring2 = dev.fused_triple_info()
             assert on and tiles >= len(starts) and (tiles == len(starts) or case == 'patches_12x7'), (tiles, len(starts))
         dev.set_state(uv, eta)
+        if fuse == '3':
+            assert dev.fused_triple_info()[0], case
+        if case.startswith('coupled'):
+            # swe2d_advance_coupled: the shallow-water half in one launch, the tracer stages read the velocity from the buffer it ends in
+            tid = dev.add_tracer()
+            dev.tracer_set_state(tid, np.where(cxy[:, :, 0] < 40e3, 0.0, 30.0))
+            dev.advance_coupled(3, tracer_only=False, use_limiter=True)
+            dev.advance_coupled(2, tracer_only=False, use_limiter=True)
+            out.append(dev.get_state() + (dev.tracer_get_state(tid),))
+            dev.close()
+            continue
         dev.advance(3)
         dev.advance(2)
         a = dev.get_state()
@@ -704,12 +718,17 @@ def _bump_state(mesh, seed=1234):
     {1: {'elev': 0.3}, 2: {'un': 0.2}, 3: {'flux': 1e4, 'elev': 0.1}},
     {4: {'uv': (0.1, -0.2)}, 1: {'flux': -3e3}, 2: {'elev': 0.1, 'uv': (0.3, 0.1)}, 3: {'elev': -0.1, 'un': 0.05}},
 ], ids=['walls', 'open_a', 'open_b'])
-def test_fused_stage_pair_matches_the_c_restatement(hip_lib, ref_so, monkeypatch, bcs):
+@pytest.mark.parametrize('kernel', ['pair', 'triple'])
+def test_fused_stage_pair_matches_the_c_restatement(hip_lib, ref_so, monkeypatch, bcs, kernel):
     """The headline kernel against the ORACLE, not against the stage launches: 270 k triangles - the size from
     which swe2d_advance takes the fused stage pair by itself, asserted - 1, 10 and 100 SSPRK33 steps against oracle/swe2d_ref.c at
-    1e-12 / 1e-11 / 1e-10, closed walls and both open-boundary sets of test_open_boundaries_match_oracle."""
-    for v in ('THETIS_AMD_FUSE12', 'THETIS_AMD_FLOW', 'THETIS_AMD_BND_INLINE'):
+    1e-12 / 1e-11 / 1e-10, closed walls and both open-boundary sets of test_open_boundaries_match_oracle.  'triple': what that mesh takes
+    by itself since the end of round 6 - all three stages in one launch on 11 x 8-quad patches, asserted; 'pair': SWE2D_OPT_FUSED_STAGES
+    = 2, the fused pair + stage 3 (what a mesh with source terms, a partition or a stream capture takes)."""
+    for v in ('THETIS_AMD_FUSE12', 'THETIS_AMD_FLOW', 'THETIS_AMD_BND_INLINE', 'THETIS_AMD_TRIPLE_TILE'):
         monkeypatch.delenv(v, raising=False)
+    if kernel == 'pair':
+        monkeypatch.setenv('THETIS_AMD_FUSE12', '2')
     mesh, bath, _, _ = channel_case(nx=450, ny=300, lx=100e3, ly=50e3)
     uv, eta = _bump_state(mesh)
     dt = 0.5
@@ -718,6 +737,7 @@ def test_fused_stage_pair_matches_the_c_restatement(hip_lib, ref_so, monkeypatch
     for marker, funcs in bcs.items():
         dev.set_bc(marker, funcs)
     assert dev.fused_pair_info()[0], 'the library did not take the fused stage pair on a 270 k-cell plain mesh'
+    assert bool(dev.fused_triple_info()[0]) == (kernel == 'triple'), (kernel, dev.fused_triple_info())
     ur, er = uv, eta
     done = 0
     for n_steps, tol in ((1, 1e-12), (10, 1e-11), (100, 1e-10)):
@@ -732,18 +752,22 @@ def test_fused_stage_pair_matches_the_c_restatement(hip_lib, ref_so, monkeypatch
     dev.close()
 
 
-def test_fused_stage_pair_matches_the_c_restatement_at_bench_size(hip_lib, ref_so, monkeypatch):
-    """BASELINE cfg 2 itself (1 M triangles, the bench's state and time step): 20 steps of the path bench.py times - fused stage
-    pair + stage 3, asserted - against oracle/swe2d_ref.c at 1e-11."""
+@pytest.mark.parametrize('kernel', ['pair', 'triple'])
+def test_fused_stage_pair_matches_the_c_restatement_at_bench_size(hip_lib, ref_so, monkeypatch, kernel):
+    """BASELINE cfg 2 itself (1 M triangles, the bench's state and time step): 20 steps of the path bench.py times - 'triple': all
+    three stages in one launch, what the library takes there, asserted; 'pair': fused stage pair + stage 3 (SWE2D_OPT_FUSED_STAGES = 2) -
+    against oracle/swe2d_ref.c at 1e-11."""
     from thetis_amd.mesh import RectangleMesh
-    for v in ('THETIS_AMD_FUSE12', 'THETIS_AMD_FLOW', 'THETIS_AMD_BND_INLINE'):
+    for v in ('THETIS_AMD_FUSE12', 'THETIS_AMD_FLOW', 'THETIS_AMD_BND_INLINE', 'THETIS_AMD_TRIPLE_TILE'):
         monkeypatch.delenv(v, raising=False)
+    if kernel == 'pair':
+        monkeypatch.setenv('THETIS_AMD_FUSE12', '2')
     mesh = RectangleMesh(1000, 500, 100e3, 50e3)
     bath = np.full(mesh.num_vertices, 20.0)
     uv, eta = _bump_state(mesh)
     dt = 0.25
     dev = _device(mesh, bath, dt)
-    assert dev.fused_pair_info()[0]
+    assert dev.fused_pair_info()[0] and bool(dev.fused_triple_info()[0]) == (kernel == 'triple')
     dev.set_state(uv, eta)
     dev.advance(20)
     ud, ed = dev.get_state()
@@ -839,10 +863,26 @@ def test_fused_stage_pair_is_what_a_large_plain_mesh_takes(hip_lib, monkeypatch)
     assert dev.fused_pair_info()[0]
     dev.set_option(_lib.OPT_FUSED_STAGES, 0)
     assert not dev.fused_pair_info()[0]
+    # all three stages in one launch (swe2d_fused_triple_info): what a RectangleMesh beyond the dataflow kernel takes by itself - its
+    # two-ring tiles are the 11 x 8-quad patches Swe2dDevice hands over (every patch one tile) -, not with source terms, not when the
+    # pair is asked for (2), not without the patches below 2.5 M cells
+    dev.set_option(_lib.OPT_FUSED_STAGES, None)
+    dev.set_scalar(_lib.SCALAR_MANNING_DRAG, None)
+    on, tiles, ring1, ring2 = dev.fused_triple_info()
+    assert on and tiles == (-(-450//11))*(-(-300//8)) and ring1 < 0.25*cells and ring2 < 0.28*cells, (on, tiles, ring1, ring2)
+    dev.set_scalar(_lib.SCALAR_MANNING_DRAG, 0.02)
+    assert not dev.fused_triple_info()[0] and dev.fused_pair_info()[0]
+    dev.set_scalar(_lib.SCALAR_MANNING_DRAG, None)
+    assert dev.fused_triple_info()[0]
+    dev.set_option(_lib.OPT_FUSED_STAGES, 2)
+    assert not dev.fused_triple_info()[0] and dev.fused_pair_info()[0]
+    dev.set_option(_lib.OPT_FUSED_STAGES, None)
+    dev.fused_set_triple_tiles(None)
+    assert not dev.fused_triple_info()[0] and dev.fused_pair_info()[0]
     dev.close()
     small, bath_s, _, _ = channel_case(nx=300, ny=200, lx=100e3, ly=50e3, seed=5)                     # 120 k cells: the dataflow kernel's
     dev = Swe2dDevice(small, bath_s, 0.5)
-    assert not dev.fused_pair_info()[0]
+    assert not dev.fused_pair_info()[0] and not dev.fused_triple_info()[0]
     dev.close()
 
 

@@ -85,6 +85,8 @@ SYMBOLS = {
     'swe2d_fused_pair_info': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_fused_triple_info': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_fused_set_order': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
+    'swe2d_solve_step_cells': (ctypes.c_int, [_H, ctypes.c_int32]),
+    'swe2d_fused_step_info': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32)]),
     'swe2d_fused_set_triple_tiles': (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]),
     'swe2d_solve_stage_pair_cells': (ctypes.c_int, [_H, ctypes.c_int32, ctypes.c_int32]),
     'swe2d_device_count': (ctypes.c_int, []),

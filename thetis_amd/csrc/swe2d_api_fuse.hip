@@ -25,13 +25,18 @@ fuse_kernel_t pick_fuse_kernel(bool nl, bool lf, bool src) { return src ? pick_f
 // 113.3 us per step; an order that does not keeps its stage launches).
 // SWE2D_OPT_FUSED_STAGES = 0: never; = 1: on every mesh (of at least 64 cells) whatever its tiles.  (In the range-checked build too since
 // round 6: the shared functions test their LDS indices against the array they are handed, the tile tables are host-built indices.)
+static bool fuse_applies(const Handle *h)                      // what every fused kernel needs, whatever the size
+{
+    if (h->opt[SWE2D_OPT_FUSED_STAGES] == 0) return false;
+    if (h->opt[SWE2D_OPT_BND_INLINE] == 0) return false;     // the epilogue variant was asked for
+    return !h->wd && !h->visc && !h->h_nbr.empty();
+}
+
 bool fuse12_covers(const Handle *h)
 {
     const int mode = h->opt[SWE2D_OPT_FUSED_STAGES];         // -1, 2: by size and tile quality; 1, 3: forced
-    if (mode == 0 || h->fuse_state == -1) return false;
-    if (h->opt[SWE2D_OPT_BND_INLINE] == 0) return false;     // the epilogue variant was asked for
+    if (!fuse_applies(h) || h->fuse_state == -1) return false;
     const bool forced = mode == 1 || mode == 3;
-    if (h->wd || h->visc || h->h_nbr.empty()) return false;
     // triangles: whole meshes and partitions, from 250 k cells
     if (h->npc == 3) return h->idx4 != nullptr && h->n_cells >= (forced ? 64 : 250000);
     // quadrilaterals (swe_fuse12_quad_kernel, round 6): whole meshes, from the size at which the three state buffers (3 x 96 B per cell)
@@ -380,7 +385,7 @@ int fuse123_build(Handle *h)
 }
 
 // a whole step: state buffer A (U(0)) -> state buffer B (U(3)), then the two change places
-int launch_fuse123(Handle *h)
+int launch_fuse123(Handle *h, int cell_end)
 {
     if (int rc = fuse123_build(h)) return rc;
     SweFuse3Args q;
@@ -389,6 +394,7 @@ int launch_fuse123(Handle *h)
     q.tile = h->fuse3_tile;
     q.counts = h->fuse3_cnt;
     q.n_tiles = h->fuse3_n_tiles;
+    q.cell_end = cell_end;
     for (int s = 0; s < 3; s++) { q.a0[s] = s ? kAlpha0[s] : 0.0; q.a1[s] = s ? kAlphaIn[s] : 1.0; q.beta[s] = kBeta[s]; }
     q.out = h->state[1];
     fuse3_kernel_t kern = pick_fuse3_kernel(h->par.use_nonlinear_equations != 0, h->par.use_lax_friedrichs_velocity != 0, has_sources(h));
@@ -401,17 +407,23 @@ int launch_fuse123(Handle *h)
     return SWE2D_OK;
 }
 
-// All three stages in one launch: where the state no longer fits the Infinity Cache.  Same box, us per step, three stage launches /
-// fused pair + stage 3 / all three fused (profiles/r06b_fused_sizes.txt): 250 k cells 37.0 / 35.2 / 36.1, 500 k 63.8 / 59.4 / 60.5,
-// 1 M 110.0 / 103.0 / 110.8, 2 M 272.0 / 233.3 / 229.9, 4 M 527.9 / 475.3 / 452.1 - two rings cost 1.26 x the arithmetic of the pair
-// (147 interior cells per 256-lane tile against 192), which a mesh inside the cache cannot win back; beyond it the bytes decide.
-// SWE2D_OPT_FUSED_STAGES = 3 forces it, = 2 keeps the pair at every size.  Whole meshes; not inside a stream capture (the launch
-// swaps two state buffers on the host).
+// All three stages in one launch.  With tiles cut as consecutive cells of the numbering (147 + 52 + 57 per tile, ragged) the second ring
+// costs 1.26 x the arithmetic of the pair and only pays where the state no longer fits the Infinity Cache - same box, us per step,
+// three stage launches / fused pair + stage 3 / all three fused (profiles/r06b_fused_sizes.txt): 250 k cells 37.0 / 35.2 / 36.1,
+// 1 M 110.0 / 103.0 / 110.8, 2 M 272.0 / 233.3 / 229.9, 4 M 527.9 / 475.3 / 452.1: by itself from 2.5 M cells.  With the caller's
+// patches (swe2d_fused_set_triple_tiles: 11 x 8 quads of a RectangleMesh = 176 + 38 + 42 cells, every lane of the 256 used) it wins
+// wherever the dataflow kernel does not apply (profiles/r06l_triple_tiles.txt, r06m_triple_sizes.txt): 150 k cells 28.3 / 27.5 / 24.1,
+// 250 k 36.9 / 34.8 / 31.5, 500 k 62.4 / 57.9 / 53.8, 1 M - / 103.4 / 96.8, 2 M - / 235.4 / 207.5, 4 M - / 476.7 / 406.9: by itself from
+// 131 073 cells.  Not with source terms (those instances spill 80-132 B per lane at the 168 VGPRs of three workgroups per CU: 1 M cells
+// 159-161 us per step by the pair, 235-239 by this kernel; SWE2D_OPT_FUSED_STAGES = 3 forces it, = 2 keeps the pair at every size).
+// Whole meshes; not inside a stream capture (the launch swaps two state buffers on the host).
 bool fuse123_wanted(const Handle *h)
 {
     const int mode = h->opt[SWE2D_OPT_FUSED_STAGES];
-    // (by itself only without source terms: those instances spill 80-132 B per lane at the 168 VGPRs of three workgroups per CU)
-    return h->npc == 3 && (mode == 3 || (mode == -1 && h->n_cells >= 2500000 && !has_sources(h))) && fuse12_covers(h) && h->n_owned == h->n_cells;
+    const bool patches = (int)h->fuse3_start.size() == h->n_cells;
+    const int from = patches ? 131073 : 2500000;              // (131 072 cells = 2048 resident blocks: what the dataflow kernel holds)
+    if (h->npc != 3 || !fuse_applies(h) || h->idx4 == nullptr || h->n_owned != h->n_cells) return false;
+    return mode == 3 ? h->n_cells >= 64 : (mode == -1 && h->n_cells >= from && !has_sources(h));
 }
 
 // one SSPRK33 step of the shallow-water state on the whole mesh by the launches swe2d_advance would take when the dataflow kernel
@@ -423,7 +435,7 @@ int step_swe(Handle *h)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
         (void)hipGetLastError();
-        if (!capturing) return launch_fuse123(h);
+        if (!capturing) return launch_fuse123(h, h->n_owned);
     }
     if (fuse12_covers(h)) { if (int rc = fuse12_build(h)) return rc; }
     if (fuse12_covers(h) && (h->npc == 4 ? h->fuseq_tile != nullptr : h->fuse_tile != nullptr)) {
@@ -512,6 +524,49 @@ int swe2d_fused_triple_info(swe2d_handle *hh, int32_t out[4])
     if (int rc = fuse123_build(h)) return rc;
     out[0] = 1; out[1] = h->fuse3_n_tiles; out[2] = (int32_t)h->fuse3_ring1; out[3] = (int32_t)h->fuse3_ring2;
     return SWE2D_OK;
+}
+
+// A partition's whole step in one launch: what swe2d_solve_step_cells needs (the rule is the caller's - see swe2d_fused_step_info)
+static bool fuse123_partition_ok(const Handle *h)
+{
+    const int mode = h->opt[SWE2D_OPT_FUSED_STAGES];
+    if (h->npc != 3 || !fuse_applies(h) || h->idx4 == nullptr || mode == 2 || mode == 1) return false;
+    return mode == 3 || !has_sources(h);
+}
+
+int swe2d_fused_step_info(swe2d_handle *hh, int32_t out[4])
+{
+    Handle *h = H(hh);
+    if (!h || !out) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "null argument");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    // by itself where the caller handed in patches (swe2d_fused_set_triple_tiles) and the cell range is beyond the dataflow kernel's
+    const int mode = h->opt[SWE2D_OPT_FUSED_STAGES];
+    if (!fuse123_partition_ok(h)) return SWE2D_OK;
+    if (mode != 3 && ((int)h->fuse3_start.size() != h->n_cells || h->n_cells <= 131072)) return SWE2D_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc = fuse123_build(h)) return rc;
+    out[0] = 1; out[1] = h->fuse3_n_tiles; out[2] = (int32_t)h->fuse3_ring1; out[3] = (int32_t)h->fuse3_ring2;
+    return SWE2D_OK;
+}
+
+// All three stages of a step on a partition: stage 3 on [0, cell_end) - the last of the step's three shrinking ranges; the tiles
+// evaluate stages 1 and 2 on supersets of theirs (every cell of a tile / interior + first ring), values that never leave the chip.
+// U(3) goes to state buffer B and the two change places: cells of the new buffer A beyond cell_end hold what B held before - stale
+// ghost values that the next exchange rewrites, and that no later stage of the cycle reads (its ranges end inside cell_end).
+int swe2d_solve_step_cells(swe2d_handle *hh, int32_t cell_end)
+{
+    Handle *h = H(hh);
+    if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
+    if (cell_end < 0 || cell_end > h->n_cells) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell range");
+    if (!fuse123_partition_ok(h)) return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_solve_step_cells: the three-stage kernel does not cover this handle");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->fuse3_tile) {           // tile tables: allocations and copies, not inside a stream capture
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        (void)hipGetLastError();
+        if (capturing) return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_solve_step_cells: first call inside a stream capture (swe2d_fused_step_info builds the tables)");
+    }
+    return launch_fuse123(h, cell_end);
 }
 
 // stages 0 and 1 of a step on the ranges [0, cell_end_0) and [0, cell_end_1) (cell_end_1 <= cell_end_0, every cell of the second

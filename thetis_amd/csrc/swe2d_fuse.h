@@ -205,6 +205,7 @@ struct SweFuse3Args {
     const int2 *tile;         // [n_tiles][256]: as SweFuseArgs::tile (lane of the neighbour in the tile, or bit 9 + staging slot)
     const int2 *counts;       // [n_tiles]: {n_inner, n_mid}
     int n_tiles;
+    int cell_end;             // stage 3 (the only one that leaves the chip) on cells [0, cell_end): a partition's last stage range
     double a0[3], a1[3], beta[3];   // Shu-Osher weights per stage (swe2d_ssprk33_coefficients)
     double *out;              // 9 planes: U(3), NOT the buffer of U(0)
 };
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse123_kern
     //      U(0) for the weights from P0
 #pragma unroll 1
     for (int s = 1; s < 3; s++) {
-        const bool act = lane < (s == 1 ? cnt.y : cnt.x);
+        const bool act = lane < (s == 1 ? cnt.y : cnt.x) && (s == 1 || k < q.cell_end);
         double ou[3], ov[3], oe[3];
         if (act) {
             // opaque to the optimiser (as in swe_flow_kernel): what the previous stage derived from the geometry would otherwise stay

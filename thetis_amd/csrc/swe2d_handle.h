@@ -312,7 +312,7 @@ int fuse12_build(Handle *h);
 int launch_fuse12(Handle *h, int cell_end);
 bool fuse123_wanted(const Handle *h);
 int fuse123_build(Handle *h);
-int launch_fuse123(Handle *h);
+int launch_fuse123(Handle *h, int cell_end);
 int step_swe(Handle *h);                               // one SSPRK33 step of the shallow-water state on the whole mesh: fused pair + stage 3, or stage launches
 void fill_stage_args(Handle *h, SweStageArgs &a, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1);
 int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1);

@@ -150,12 +150,13 @@ class Swe2dDevice(object):
             # bisection boxes (ordering.flow_block_order) instead of 64 consecutive cells of the device numbering - a fifth to a
             # third fewer rim facets
             self.flow_set_order(ordering.flow_block_order(mesh))
-        tt = os.environ.get('THETIS_AMD_TRIPLE_TILE', '12,7')
+        tt = os.environ.get('THETIS_AMD_TRIPLE_TILE', '11,8')
         if (self.npc == 3 and isinstance(reorder, str) and self.n_owned == self.n_cells and getattr(mesh, 'structured', False)
-                and self.n_cells >= 500000 and tt != '0'):
-            # a mesh large enough for all three stages in one launch (csrc/swe2d_fuse.h, swe_fuse123_kernel): its two-ring tiles as
-            # patches of 12 x 7 quads (168 triangles + rings of 38 + 42 = 248 of 256 lanes) instead of as many consecutive cells of the
-            # 16 x 6 numbering as fit (147 + 52 + 57: ragged)
+                and self.n_cells > 131072 and tt != '0'):
+            # a mesh beyond the dataflow kernel: all three stages of a step in one launch (csrc/swe2d_fuse.h, swe_fuse123_kernel) on
+            # two-ring tiles cut as patches of 11 x 8 quads - 176 triangles + rings of 38 + 42 = the 256 lanes - instead of as many
+            # consecutive cells of the 16 x 6 numbering as fit (147 + 52 + 57, ragged: 1 M cells 110.7 -> 96.8 us per step, where the
+            # fused pair takes 103.4; profiles/r06l_triple_tiles.txt).  THETIS_AMD_TRIPLE_TILE = "bx,by" | 0: A/B runs
             bx, by = (int(v) for v in tt.split(','))
             self.fused_set_triple_tiles(*ordering.triple_tile_order(mesh, bx, by))
         if self.npc == 4 and not getattr(mesh, 'affine', True):
@@ -426,6 +427,16 @@ class Swe2dDevice(object):
     def solve_stage_pair_cells(self, cell_end_0, cell_end_1):
         """stage 0 on [0, cell_end_0) and stage 1 on [0, cell_end_1): one fused launch where the kernel covers the handle"""
         self._ck(self.lib.swe2d_solve_stage_pair_cells(self.h, int(cell_end_0), int(cell_end_1)))
+
+    def solve_step_cells(self, cell_end):
+        """all three stages of a step in one launch, stage 3 on [0, cell_end): swe2d_solve_step_cells (the state buffers change places)"""
+        self._ck(self.lib.swe2d_solve_step_cells(self.h, int(cell_end)))
+
+    def fused_step_info(self):
+        """(a partition's steps should take solve_step_cells, tiles, ring-1 cells, ring-2 cells): swe2d_fused_step_info"""
+        out = (ctypes.c_int32*4)()
+        self._ck(self.lib.swe2d_fused_step_info(self.h, out))
+        return bool(out[0]), int(out[1]), int(out[2]), int(out[3])
 
     def fused_set_order(self, cells_in_tile_order):
         """The order the tiles of the fused stage pair are cut from (``None``: the device numbering); caller's cell numbering."""

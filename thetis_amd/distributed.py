@@ -359,6 +359,13 @@ class DistributedSwe2d(object):
             if order is not None:
                 self.dev.fused_set_order(order)
             self.dev.fused_pair_info()
+            # ... and the two-ring tiles of a whole step in one launch (swe2d_solve_step_cells: pairs of steps of a cycle, see
+            # _cycle_before_exchange): the 11 x 8-quad patches of the parent mesh, over owned and ghost cells alike
+            tt = os.environ.get('THETIS_AMD_TRIPLE_TILE', '11,8')
+            tiles = ordering.triple_tile_order(p, *(int(v) for v in tt.split(','))) if tt != '0' else None
+            if tiles is not None:
+                self.dev.fused_set_triple_tiles(*tiles)
+            self.dev.fused_step_info()
         self._ranges = [p.stage_range(i) for i in range(3)]
         self.tids = [self.dev.add_tracer() for _ in range(n_tracers)]
 
@@ -709,6 +716,18 @@ class DistributedSwe2d(object):
         n = 3*n_steps
         assert early_done <= n - 1
         g = 0
+        if (self._on_gpu and early_done == 0 and not self.split_last_stage and n >= 6 and self.stages_per_step == 3
+                and dev.fused_step_info()[0]):
+            # whole steps in one launch each (csrc/swe2d_fuse.h, swe_fuse123_kernel on the partition's two-ring tiles): stage 3 on the
+            # step's last range, stages 1 and 2 on the tiles' supersets of theirs, never leaving the chip.  The launch leaves its result in
+            # the other state buffer and the two change places - so steps are taken in PAIRS: every cycle, eager or captured, ends on the
+            # buffer it started from (a replayed graph uses the pointers of its capture); an odd step goes by the launches below
+            while n - g >= 6:
+                for _ in range(2):
+                    dev.solve_step_cells(p.n_owned if g + 3 == n else p.stage_range(g + 2, depth=n))
+                    g += 3
+            if g == n:
+                return
         while g < n - 1:
             begin = p.owned_prefix(g + 2) if g < early_done else 0
             if g % 3 == 0 and g >= early_done:             # (n is a multiple of 3: stage g + 1 <= n - 2 is in this loop's range too)

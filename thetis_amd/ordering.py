@@ -190,19 +190,38 @@ def fused_tile_order(mesh):
     return hilbert_cell_order(cen)
 
 
-def triple_tile_order(mesh, bx=12, by=7):
-    """(order, tile starts) of the TWO-RING tiles of a RectangleMesh of triangles (csrc/swe2d_fuse.h, swe_fuse123_kernel: interior +
-    facet neighbours + their facet neighbours in 256 lanes): patches of bx x by quads along the Hilbert curve, row by row inside a
-    patch.  12 x 7 quads = 168 triangles + 38 + 42 = 248 lanes; a patch cut short by the mesh's edge is a tile of its own."""
-    nx, ny = mesh.nx, mesh.ny
-    n = 2*nx*ny
-    q = np.arange(n)//2
+def triple_tile_order(mesh, bx=11, by=8):
+    """(order, tile starts) of the TWO-RING tiles of a RectangleMesh of triangles - or of a partition of one, over ALL its cells, owned and
+    ghost - (csrc/swe2d_fuse.h, swe_fuse123_kernel: interior + facet neighbours + their facet neighbours in 256 lanes): patches of
+    bx x by quads of the (parent) mesh along the Hilbert curve, row by row inside a patch.  11 x 8 quads = 176 triangles + rings of
+    38 + 42 = 256 lanes exactly (measured against 12 x 7, 14 x 6, 16 x 5, 10 x 8 and against as many consecutive cells of the 16 x 6
+    numbering as fit - 147 + 52 + 57, ragged - at 0.5 ... 4 M cells: profiles/r06l_triple_tiles.txt); a patch cut short by the mesh's
+    edge or by a partition's is a tile of its own.  ``None`` for any other mesh."""
+    if np.asarray(mesh.cells).shape[1] != 3:
+        return None
+    parent = getattr(mesh, 'structured_parent', None)
+    if parent is not None and getattr(mesh, 'local_to_global', None) is not None:
+        nx, ny = parent
+        g = np.asarray(mesh.local_to_global, dtype=np.int64)
+    elif getattr(mesh, 'structured', False):
+        nx, ny = mesh.nx, mesh.ny
+        g = np.arange(2*nx*ny, dtype=np.int64)
+    else:
+        return None
+    ntx, nty = -(-nx//bx), -(-ny//by)
+    lev = max(1, int(np.ceil(np.log2(max(ntx, nty) + 1))))
+    ti, tj = np.meshgrid(np.arange(ntx), np.arange(nty), indexing='ij')
+    d_tile = hilbert_index(ti.ravel(), tj.ravel(), lev)
+    rank_tile = np.empty(ntx*nty, dtype=np.int64)
+    rank_tile[np.argsort(d_tile, kind='stable')] = np.arange(ntx*nty)               # patches numbered along the curve
+    rank_tile = rank_tile.reshape(ntx, nty)
+    q = g//2
     i, j = q % nx, q//nx
-    lev = max(1, int(np.ceil(np.log2(max(nx//bx + 1, ny//by + 1)))))
-    d = hilbert_index(i//bx, j//by, lev)
-    order = np.lexsort((np.arange(n), i % bx, j % by, d))
-    ds = d[order]
-    starts = np.nonzero(np.concatenate(([True], ds[1:] != ds[:-1])))[0]
+    patch = rank_tile[i//bx, j//by]
+    key = ((patch*by + j % by)*bx + i % bx)*2 + g % 2
+    order = np.argsort(key, kind='stable')
+    pk = patch[order]
+    starts = np.nonzero(np.concatenate(([True], pk[1:] != pk[:-1])))[0]
     return order, starts
 
 
