@@ -323,8 +323,8 @@ def cpu_coupled_cycles_worker(rank, world, port, n_steps, out_dir, axis, case='c
 def gpu_coupled_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     """DistributedSwe2d with one tracer + limiter, two ranks sharing ONE GPU (gloo + host staging stands in for RCCL)."""
     global CASE
-    p2p, combined, no_lim, fe = '+p2p' in case, '+combined' in case, '+nolim' in case, '+fe' in case
-    case = case.replace('+p2p', '').replace('+combined', '').replace('+nolim', '').replace('+fe', '')
+    p2p, combined, no_lim, fe, step3, graph = '+p2p' in case, '+combined' in case, '+nolim' in case, '+fe' in case, '+step3' in case, '+graph' in case
+    case = case.replace('+p2p', '').replace('+combined', '').replace('+nolim', '').replace('+fe', '').replace('+step3', '').replace('+graph', '')
     case, every, overlap = _split_every(case)
     CASE = case
     from thetis_amd.distributed import DistributedSwe2d
@@ -337,7 +337,13 @@ def gpu_coupled_worker(rank, world, port, n_steps, out_dir, axis, case='channel'
                               stepper=('ForwardEuler' if fe else 'SSPRK33'), overlap_stages=overlap)
     solver.set_state_global(uv, eta)
     solver.set_tracer_global(0, tracer_initial(mesh))
-    solver.advance(n_steps, use_graph=False)
+    if step3:            # whole shallow-water steps in one launch each (forced by the test: THETIS_AMD_FUSE12=3)
+        assert solver.dev.fused_step_info()[0]
+    if graph:            # twice the same advance: the second call replays what the first one captured
+        solver.advance(n_steps - n_steps//2, use_graph=True)
+        solver.advance(n_steps//2, use_graph=True)
+    else:
+        solver.advance(n_steps, use_graph=False)
     solver.synchronize()
     ids, u, e = solver.get_state_owned()
     _, T = solver.get_tracer_owned(0)

@@ -380,14 +380,20 @@ def test_coupled_cycle_schedule_counts_layers():
 @pytest.mark.parametrize('case,n_steps', [('channel+every2', 5), ('channel+combined', 3), ('channel+every2+p2p', 4),
                                           ('channel+every3+nolim+p2p', 4), ('channel+every2+fe', 5), ('channel+every1+fe+p2p', 3),
                                           ('channel+every2+overlap3', 7), ('channel+every1+overlap2+combined+p2p', 4),
-                                          ('channel+every3+overlap3+nolim+p2p', 8)])
-def test_two_ranks_coupled_cycles_with_one_exchange_match_single_device(tmp_path, hip_lib, case, n_steps):
+                                          ('channel+every3+overlap3+nolim+p2p', 8), ('channel+every2+p2p+step3', 5), ('channel+every4+step3', 9),
+                                          ('channel+every3+nolim+p2p+step3', 7), ('channel+every2+p2p+step3+graph', 36)])
+def test_two_ranks_coupled_cycles_with_one_exchange_match_single_device(tmp_path, hip_lib, monkeypatch, case, n_steps):
     """DistributedSwe2d(n_tracers=1, exchange_every=m | combined_exchange): one exchange of all fields per m coupled steps,
     host-staged and peer-to-peer, == the single-device coupled stepping, bitwise.  ``+overlapJ``: the first J shallow water
-    stages of the next cycle run while the tracer's exchange is in flight (overlap_stages on coupled runs)."""
+    stages of the next cycle run while the tracer's exchange is in flight (overlap_stages on coupled runs).  ``+step3``: the shallow-water
+    steps of a cycle as one launch each, in pairs (swe2d_solve_step_cells; the state buffers change places under the tracer stages), also
+    replayed from HIP graphs."""
     from thetis_amd.device import Swe2dDevice
     mesh, bath, uv, eta = _case()
+    if '+step3' in case:
+        monkeypatch.setenv('THETIS_AMD_FUSE12', '3')
     run_workers(gpu_coupled_worker, 2, n_steps, str(tmp_path), axis=0, case=case)
+    monkeypatch.setenv('THETIS_AMD_FUSE12', '0')
     u_p, e_p, extra = gather(str(tmp_path), 2, mesh.num_cells)
     T_p = extra[-1]
     dev = Swe2dDevice(mesh, bath, 2.0)
@@ -566,7 +572,7 @@ def test_ranks_on_one_gpu_with_the_fused_stage_pair(tmp_path, hip_lib, monkeypat
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('world,case,n_steps', [
-    (2, 'channel64+every2+p2p+nosplit', 7), (2, 'channel64+every4+nosplit', 9), (3, 'delaunay+every2+p2p+nosplit+graph', 4),
+    (2, 'channel64+every2+p2p+nosplit', 7), (2, 'channel64+every4+nosplit', 9), (3, 'delaunay+every2+p2p+nosplit', 2),
     (4, 'channel64+every3+p2p+nosplit+graph', 9), (2, 'channel64+every2+p2p+nosplit+capture', 8), (2, 'channel256+every4+p2p+nosplit+capture', 8),
     (4, 'channel256+every4+p2p+nosplit+graph', 11)])
 def test_ranks_on_one_gpu_with_whole_steps_in_one_launch(tmp_path, hip_lib, monkeypatch, world, case, n_steps):

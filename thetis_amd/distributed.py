@@ -815,19 +815,31 @@ class DistributedSwe2d(object):
         #  per-channel exchange has received by then)
         merged = (self.p2p is not None and not self._through_host() and self.xstream is None and not self._no_exchange
                   and self.overlap_stages == 0 and not early_next and 1 + nt <= 4 and hasattr(dev, 'p2p_push_multi'))
-        skip = False
+        # whole shallow-water steps in one launch each (swe2d_solve_step_cells, see _cycle_before_exchange): in pairs, so that the cycle
+        # ends on the state buffer it began on; the tracer stages read the velocity from whichever buffer holds it when they are launched
+        n3 = 0
+        if (self._on_gpu and not fe and early_done == 0 and not early_next and not self.tracer_only
+                and hasattr(dev, 'fused_step_info') and dev.fused_step_info()[0]):
+            n3 = 2*(sum(1 for op in ops if op[0] == 'swe' and op[1] == 0)//2)
+        i_step = 0
+        skip = 0
         for i_op, op in enumerate(ops):
-            if skip:                           # the second stage of a pair that went out as one launch
-                skip = False
+            if skip:                           # the later stages of a step (or pair) that went out as one launch
+                skip -= 1
                 continue
             if op[0] == 'swe':
                 if fe:
                     dev.forward_euler_cells(0, op[2])
                     dev.swap_state_buffers()
+                elif (op[1] == 0 and i_step < n3 and i_op + 2 < len(ops) and ops[i_op + 1][:2] == ('swe', 1)
+                      and ops[i_op + 2][:2] == ('swe', 2)):
+                    dev.solve_step_cells(ops[i_op + 2][2])
+                    i_step += 1
+                    skip = 2
                 elif op[1] == 0 and i_op + 1 < len(ops) and ops[i_op + 1][0] == 'swe' and ops[i_op + 1][1] == 1:
                     # stages 1 and 2 of a step: one launch by overlapped tiles where the kernel covers the partition (csrc/swe2d_fuse.h)
                     dev.solve_stage_pair_cells(op[2], ops[i_op + 1][2])
-                    skip = True
+                    skip = 1
                 else:
                     dev.solve_stage_cells(op[1], 0, op[2])
             elif op[0] == 'swe_done':

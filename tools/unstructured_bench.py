@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--points', type=int, default=500000)
     ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--triple', action='store_true', help='the three-stage kernel on patches of the bisection order against the fused pair')
     args = ap.parse_args()
     from scipy.spatial import Delaunay
     from helpers import _rect_marker_fn
@@ -60,10 +61,30 @@ def main():
     variants = {'warmup(auto)': 'auto', 'auto': 'auto', 'hilbert': hil, 'None': None}
     for patch in (64, 256, 1024):
         variants['hilbert+rows{:d}'.format(patch)] = ordering.patch_row_order(cen, hil, patch=patch)
+    tiles = {}
+    if args.triple:
+        # all three stages in one launch (csrc/swe2d_fuse.h): two-ring tiles as runs of the Hilbert order (what the library cuts by
+        # itself), as leaves of a coordinate bisection with exactly K cells (compact boxes) over the Hilbert numbering, and with the
+        # leaves as the device numbering itself (a tile's cells consecutive in memory)
+        from thetis_amd import _lib
+        variants = {'warmup(auto)': 'auto', 'pair (auto)': 'auto', 'triple, runs of the Hilbert order': 'auto'}
+        for K in (144, 152, 160, 168):
+            leaves = ordering.bisection_block_order(cen, block=K)
+            variants['triple, bisection leaves of {:d} over the Hilbert numbering'.format(K)] = 'auto'
+            variants['triple, bisection leaves of {:d} as the numbering'.format(K)] = leaves
+            tiles['triple, bisection leaves of {:d} over the Hilbert numbering'.format(K)] = (leaves, np.arange(0, n, K))
+            tiles['triple, bisection leaves of {:d} as the numbering'.format(K)] = (leaves, np.arange(0, n, K))
+        variants['pair (auto) again'] = 'auto'
     for name, reorder in variants.items():
         if name == 'None' and os.environ.get('SKIP_UNORDERED'):
             continue
         dev = Swe2dDevice(mesh, bath, dt, reorder=reorder)
+        info = None
+        if args.triple:
+            dev.set_option(_lib.OPT_FUSED_STAGES, 3 if name.startswith('triple') else 2)
+            if name in tiles:
+                dev.fused_set_triple_tiles(*tiles[name])
+            info = list(dev.fused_triple_info()) if name.startswith('triple') else list(dev.fused_pair_info())
         dev.set_state(0.01*uv, 0.01*eta)
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.6:
@@ -75,6 +96,8 @@ def main():
             best = min(best, ms/args.steps)
         d = dev.diagnostics()
         out[name] = {'us_per_step': 1e3*best, 'frac_of_8TBs': 684.0*n/(best*1e-3)/8e12, 'finite': bool(np.isfinite(d).all())}
+        if info is not None:
+            out[name]['tiles'] = info
         dev.close()
     print(json.dumps({'n_cells': int(n), 'mesh_build_s': t_mesh, 'dt': dt, 'order': out}))
 
