@@ -89,8 +89,9 @@ typedef enum {
  * solver_parameters / PyOP2 configuration a script may pass, thetis/options.py:145-152). */
 typedef enum {
     SWE2D_OPT_FUSED_STAGES = 0,   /* stages of a step in one launch by overlapped tiles (csrc/swe2d_fuse.h): -1 from 250 k triangles
-                                     when the numbering gives compact tiles and all three stages in one launch from 2.5 M (whole
-                                     meshes beyond the Infinity Cache, swe2d_fused_triple_info); 0 never; 1 the pair on every mesh the
+                                     when the numbering gives compact tiles - and all three stages in one launch on whole meshes
+                                     without source terms (swe2d_fused_triple_info): from 131 073 cells where the caller handed in
+                                     patches (swe2d_fused_set_triple_tiles), from 2.5 M otherwise; 0 never; 1 the pair on every mesh the
                                      kernel covers; 2 the pair by the size rule, never the triple; 3 the triple on every whole mesh */
     SWE2D_OPT_FLOW = 1,           /* swe2d_advance takes the dataflow stage loop (csrc/swe2d_flow.h) where it applies: -1 / 1 yes, 0 no */
     SWE2D_OPT_FLOW_WD = 2,        /* ... also with wetting-drying: -1 / 1 yes, 0 no */
@@ -165,7 +166,7 @@ int  swe2d_fused_pair_info(swe2d_handle *h, int32_t out[4]);
  * ghost layers are appended to its numbering layer by layer passes one in which every ghost cell sits next to the owned cells it
  * touches (cf. swe2d_flow_set_order).  Results do not depend on it.  Drops tile tables built before; synchronises the stream. */
 int  swe2d_fused_set_order(swe2d_handle *h, const int32_t *cells_in_tile_order);
-/* ALL three stages of a step in one launch (by itself from 2.5 M triangles, SWE2D_OPT_FUSED_STAGES = 3 forces it; csrc/swe2d_fuse.h swe_fuse123_kernel: tiles of interior +
+/* ALL three stages of a step in one launch (by itself from 2.5 M triangles, from 131 073 with the caller's patches - see SWE2D_OPT_FUSED_STAGES; = 3 forces it; csrc/swe2d_fuse.h swe_fuse123_kernel: tiles of interior +
  * two rings, U(1) and U(2) stay on chip, U(3) goes to the second state buffer and the two change places - so not inside a stream
  * capture, where swe2d_advance keeps the fused pair): whole meshes; out[0] = 1 when swe2d_advance would take it now (builds
  * the tile tables), out[1] = tiles, out[2] / out[3] = cells of the first / second rings (stage 1 is evaluated on interior + both,
