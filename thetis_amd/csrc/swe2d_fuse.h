@@ -199,6 +199,9 @@ __global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse12_kerne
 #define SWE_FUSE3_MAX_OUT 224                           // staging slots (a ring-2 cell has at most two facets towards the outside)
 #endif
 #define SWE_FUSE3_LDS (SWE_FUSE3_XG + 6*SWE_FUSE3_MAX_OUT)
+#ifndef SWE_FUSE3_SRC_MIN_WG
+#define SWE_FUSE3_SRC_MIN_WG 2                          // the source-term instances need 187-199 VGPRs: two workgroups per CU (at three: 80-132 B of scratch per lane)
+#endif
 
 struct SweFuse3Args {
     SweStageArgs st;          // uin = U(0) (state buffer A); geometry, connectivity, boundary tables; dt, g, sigma_lf
@@ -211,7 +214,7 @@ struct SweFuse3Args {
 };
 
 template <bool NONLIN, bool LF, bool SRC = false>
-__global__ __launch_bounds__(SWE_FUSE_WG, SWE_FUSE_MIN_WG) void swe_fuse123_kernel(const SweFuse3Args q)
+__global__ __launch_bounds__(SWE_FUSE_WG, SRC ? SWE_FUSE3_SRC_MIN_WG : SWE_FUSE_MIN_WG) void swe_fuse123_kernel(const SweFuse3Args q)
 {
 #pragma clang fp contract(off)
     __shared__ double lds[SWE_FUSE3_LDS];

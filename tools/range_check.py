@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 def exercise():
     from helpers import channel_case, delaunay_case, quad_case
-    from thetis_amd import _lib
+    from thetis_amd import _lib, ordering
     from thetis_amd.device import Swe2dDevice
     n_launch = 0
     for name, case in (('triangles', channel_case(nx=23, ny=11, seed=1)), ('quadrilaterals', quad_case(nx=17, ny=9, seed=2)),
@@ -65,7 +65,14 @@ def exercise():
                 # round 6: the fused stage kernels (csrc/swe2d_fuse.h: the tile tables are host-built indices into LDS and memory) -
                 # stages 1 + 2 in one launch on triangles and quadrilaterals, all three on triangles, forced on these small meshes
                 dev.set_option(_lib.OPT_FLOW, 0)
-                for mode in ((1, 3) if k == 3 else (1,)):
+                for mode in ((1, 3, 33) if k == 3 else (1,)):
+                    if mode == 33:                   # the two-ring tiles as patches (structured meshes: 5 x 3 quads; else bisection leaves of 40 cells)
+                        mode = 3
+                        tiles = ordering.triple_tile_order(mesh, 5, 3)
+                        if tiles is None:
+                            cen = mesh.cell_xy().mean(axis=1)
+                            tiles = (ordering.bisection_block_order(cen, block=40), np.arange(0, mesh.num_cells, 40))
+                        dev.fused_set_triple_tiles(*tiles)
                     dev.set_option(_lib.OPT_FUSED_STAGES, mode)
                     assert dev.fused_pair_info()[0] and (mode != 3 or dev.fused_triple_info()[0]), (name, variant, mode)
                     dev.advance(3)
@@ -100,6 +107,14 @@ def exercise():
         assert dev.fused_pair_info()[0]
         dev.solve_stage_pair_cells(p.stage_range(0), p.stage_range(1))
         dev.solve_stage_cells(2, 0, p.n_owned)
+        # ... and whole steps in one launch each on the partition's two-ring tiles, cut as patches of the parent mesh (5 x 3 quads here),
+        # the state buffers changing places (swe2d_solve_step_cells)
+        dev.set_option(_lib.OPT_FUSED_STAGES, 3)
+        tiles = ordering.triple_tile_order(p, 5, 3)
+        if tiles is not None:
+            dev.fused_set_triple_tiles(*tiles)
+        assert dev.fused_step_info()[0]
+        dev.solve_step_cells(p.n_owned)
         dev.diagnostics()
         dev.close()
         n_launch += 10
