@@ -414,8 +414,9 @@ int launch_fuse123(Handle *h, int cell_end)
 // patches (swe2d_fused_set_triple_tiles: 11 x 8 quads of a RectangleMesh = 176 + 38 + 42 cells, every lane of the 256 used) it wins
 // wherever the dataflow kernel does not apply (profiles/r06l_triple_tiles.txt, r06m_triple_sizes.txt): 150 k cells 28.3 / 27.5 / 24.1,
 // 250 k 36.9 / 34.8 / 31.5, 500 k 62.4 / 57.9 / 53.8, 1 M - / 103.4 / 96.8, 2 M - / 235.4 / 207.5, 4 M - / 476.7 / 406.9: by itself from
-// 131 073 cells.  Not with source terms (those instances spill 80-132 B per lane at the 168 VGPRs of three workgroups per CU: 1 M cells
-// 159-161 us per step by the pair, 235-239 by this kernel; SWE2D_OPT_FUSED_STAGES = 3 forces it, = 2 keeps the pair at every size).
+// 131 073 cells.  Not with source terms (those instances need 187-199 VGPRs: at three workgroups per CU they spill 80-132 B per lane - 1 M
+// cells 159-161 us per step by the pair, 235-239 by this kernel -, at two, as built, 195-196 against 163-164: profiles/r06q_*;
+// SWE2D_OPT_FUSED_STAGES = 3 forces it, = 2 keeps the pair at every size).
 // Whole meshes; not inside a stream capture (the launch swaps two state buffers on the host).
 bool fuse123_wanted(const Handle *h)
 {
