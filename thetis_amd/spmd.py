@@ -117,7 +117,12 @@ class PartitionedDevice(object):
                                      n_tracers=self.n_tracers, use_limiter=use_limiter, tracer_only=tracer_only,
                                      exchange_every=every, overlap_stages=overlap, stepper=stepper, exchange=ex,
                                      group=(None if ex == 'rccl' else comm.group), device_cls=device_cls,
-                                     flow=(flow if on_gpu else False), partition=partition, **opts)
+                                     flow=(flow if on_gpu else False), partition=partition,
+                                     # the last stage of a cycle in two launches (send cells first) lets a host-staged or RCCL exchange
+                                     # travel while the interior finishes; peer-to-peer pushes are kernels on the same stream - one
+                                     # launch less per cycle, and the steps of a large partition can go as one launch each
+                                     # (DistributedSwe2d._cycle_before_exchange)
+                                     split_last_stage=(ex != 'p2p' or overlap > 0), **opts)
             except Exception as e:                                    # e.g. IPC mapping refused: every rank moves on together
                 err = '{:}: {:}'.format(ex, (str(e).strip().splitlines() or [type(e).__name__])[0])
             if comm.all_agree(err is None):
