@@ -360,6 +360,51 @@ def test_flow_block_order_makes_compact_blocks():
     assert r_new.max() <= 42 and r_new.max() < r_old.max() and r_new.mean() < 0.9*r_old.mean(), (r_new.max(), r_old.max(), r_new.mean(), r_old.mean())
 
 
+def test_triple_tile_order_gives_patches_that_fill_a_workgroup():
+    """ordering.triple_tile_order: the two-ring tiles of the three-stage kernel (csrc/swe2d_fuse.h swe_fuse123_kernel) as patches of
+    11 x 8 quads of a RectangleMesh - a permutation, every patch its own run of the order, interior + facet neighbours + their facet
+    neighbours = 176 + 38 + 42 = 256 lanes for a patch inside the mesh and never more (what fuse123_build counts, restated here), also
+    over the owned and ghost cells of a partition; ``None`` for quadrilaterals and for meshes that are no RectangleMesh."""
+    import numpy as np
+    from thetis_amd import ordering, partition
+    from thetis_amd.mesh import RectangleMesh
+    from helpers import delaunay_case
+
+    def lanes(cell_nbr, cells):
+        cells = np.asarray(cells)
+        inside = set(cells.tolist())
+        ring1 = set(int(c) for c in np.asarray(cell_nbr)[cells].ravel() if c >= 0) - inside
+        ring2 = set(int(c) for c in np.asarray(cell_nbr)[np.array(sorted(ring1), dtype=np.int64)].ravel() if c >= 0) - inside - ring1
+        return len(inside), len(ring1), len(ring2)
+
+    mesh = RectangleMesh(60, 37, 60e3, 37e3)
+    order, starts = ordering.triple_tile_order(mesh)
+    assert sorted(order.tolist()) == list(range(mesh.num_cells)) and starts[0] == 0 and (np.diff(starts) > 0).all()
+    assert len(starts) == (-(-60//11))*(-(-37//8))
+    full = 0
+    for a, b in zip(starts, list(starts[1:]) + [mesh.num_cells]):
+        q = order[a:b]//2
+        assert (q % 60).max() - (q % 60).min() < 11 and (q//60).max() - (q//60).min() < 8
+        n = lanes(mesh.cell_nbr, order[a:b])
+        assert sum(n) <= 256, n
+        if n[0] == 176 and n[1] == 38:
+            full += 1
+            assert n == (176, 38, 42)
+    assert full >= 6
+    # a partition: patches of the PARENT mesh over all local cells
+    owner = partition.strip_owner(mesh, 3)
+    p = partition.build_partition(mesh, owner, 1, halo_depth=6)
+    order, starts = ordering.triple_tile_order(p)
+    assert sorted(order.tolist()) == list(range(p.num_cells))
+    g = np.asarray(p.local_to_global)
+    for a, b in zip(starts, list(starts[1:]) + [p.num_cells]):
+        q = g[order[a:b]]//2
+        assert (q % 60).max() - (q % 60).min() < 11 and (q//60).max() - (q//60).min() < 8
+        assert sum(lanes(p.cell_nbr, order[a:b])) <= 256
+    assert ordering.triple_tile_order(RectangleMesh(20, 10, 20e3, 10e3, quadrilateral=True)) is None
+    assert ordering.triple_tile_order(delaunay_case(n_points=400, seed=5)[0]) is None
+
+
 def test_compact_connectivity_records_round_trip(tmp_path):
     """thetis_amd/csrc/swe2d_conn.h: the 16-B connectivity records the triangle kernels read.  Host packing against the kernels'
     unpacking (the same header compiled with g++): random records of every span, markers, the edges of the 19-bit range, and that
