@@ -264,6 +264,9 @@ def run_single(args):
                      'fused_stage_triple': (dict(zip(('tiles', 'ring1_cells', 'ring2_cells'), dev.fused_triple_info()[1:]))
                                             if structure == 'triple' else None),
                      'avg_launch_ms': ms_kernel, 'avg_launch_ms_per_launch_events': ms_kernel_each,
+                     # the mean duration of ONE launch by the per-launch events: what the launch-weighted mean of the kernel rows of
+                     # `rocprofv3 --kernel-trace --stats` of this command comes to (profiles/)
+                     'avg_kernel_launch_ms': ms_kernel_each*3.0/LAUNCHES[structure],
                      'algorithmic_bytes_per_launch': BYTES_PER_ELEMENT_UPDATE*n},
     }
     if not args.no_beyond_cache:

@@ -954,7 +954,7 @@ int swe2d_advance_timed(swe2d_handle *hh, int n_steps, int per_launch, float *ms
     if (h->n_owned != h->n_cells)
         return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_advance_timed on a partition is not supported");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (!per_launch || fuse123_wanted(h)) {     // (all stages in one launch: a step IS a launch)
+    if (!per_launch) {
         HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
         int rc = swe2d_advance(hh, n_steps);
         if (rc) return rc;
@@ -964,11 +964,12 @@ int swe2d_advance_timed(swe2d_handle *hh, int n_steps, int per_launch, float *ms
         if (ms_kernel_avg) *ms_kernel_avg = *ms_total/(3.0f*n_steps);
         return SWE2D_OK;
     }
-    // events around every launch of a step, on the launch stream: three stage launches, or the fused stage pair + stage 3
-    // (the mean is per element-update - a third of a step - either way)
-    if (fuse12_covers(h)) { if (int rc = fuse12_build(h)) return rc; }
-    const bool fused = fuse12_covers(h) && (h->npc == 4 ? h->fuseq_tile != nullptr : h->fuse_tile != nullptr);
-    const int lps = fused ? 2 : 3;
+    // events around every launch of a step, on the launch stream: three stage launches, the fused stage pair + stage 3, or the one
+    // launch of all three stages (the mean is per element-update - a third of a step - in every case)
+    const bool triple = fuse123_wanted(h);
+    if (!triple && fuse12_covers(h)) { if (int rc = fuse12_build(h)) return rc; }
+    const bool fused = !triple && fuse12_covers(h) && (h->npc == 4 ? h->fuseq_tile != nullptr : h->fuse_tile != nullptr);
+    const int lps = triple ? 1 : (fused ? 2 : 3);
     const int nl = lps*n_steps;
     std::vector<hipEvent_t> ev(2*(size_t)nl);
     for (auto &e : ev) HIP_TRY(h, hipEventCreate(&e));
@@ -977,7 +978,8 @@ int swe2d_advance_timed(swe2d_handle *hh, int n_steps, int per_launch, float *ms
     for (int it = 0; it < n_steps; it++)
         for (int s = 0; s < lps; s++, l++) {
             HIP_TRY(h, hipEventRecord(ev[2*l], h->stream));
-            int rc = fused ? (s == 0 ? launch_fuse12(h, h->n_owned) : stage_on_range(h, 2, 0, h->n_owned)) : stage_on_range(h, s, 0, h->n_owned);
+            int rc = triple ? launch_fuse123(h, h->n_owned)
+                            : (fused ? (s == 0 ? launch_fuse12(h, h->n_owned) : stage_on_range(h, 2, 0, h->n_owned)) : stage_on_range(h, s, 0, h->n_owned));
             if (rc) return rc;
             HIP_TRY(h, hipEventRecord(ev[2*l + 1], h->stream));
         }
