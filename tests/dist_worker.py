@@ -26,9 +26,16 @@ def _case():
         return mesh, bath, 0.1*uv, 0.1*eta
     if CASE == 'channel64':                      # eight cell columns per rank of eight: wider than a six-layer halo
         return channel_case(nx=64, ny=6, seed=21, amp_eta=0.3, amp_u=0.2)
+    if CASE == 'channel360k':                    # two ranks of 180 k cells each: beyond the dataflow kernel, where a partition takes its steps as one launch each by itself
+        return channel_case(nx=600, ny=300, lx=100e3, ly=50e3, seed=21, amp_eta=0.3, amp_u=0.2)
     if CASE == 'channel256':                     # the mesh of the first-contact test (tests/test_gpu_bench_contract.py): 64 x 64 quads per rank of four
         return channel_case(nx=256, ny=64, seed=21, amp_eta=0.3, amp_u=0.2)
     return channel_case(nx=16, ny=6, seed=21, amp_eta=0.3, amp_u=0.2)
+
+
+def _dt():
+    """time step of the GPU workers: 2 s on the small cases, 0.5 s on the 167 m cells of 'channel360k' (2 s is beyond its CFL limit)"""
+    return 0.5 if CASE == 'channel360k' else 2.0
 
 
 def _split_every(case):
@@ -377,7 +384,7 @@ def gpu_worker(rank, world, port, n_steps, out_dir, axis, case='channel'):
     dist = _init(rank, world, port)
     mesh, bath, uv, eta = _case()
     owner = strip_owner(mesh, world, axis=axis)
-    solver = DistributedSwe2d(mesh, bath, 2.0, rank, world, 0, owner=owner, exchange=('p2p' if flags['+p2p'] else 'host'),
+    solver = DistributedSwe2d(mesh, bath, _dt(), rank, world, 0, owner=owner, exchange=('p2p' if flags['+p2p'] else 'host'),
                               exchange_every=every, overlap_stages=overlap, split_last_stage=not flags['+nosplit'],
                               stepper=('ForwardEuler' if fe else 'SSPRK33'), flow=(True if (flags['+flow'] or flags['+flowx']) else False), flow_exchange=flags['+flowx'],
                               **(dict(verify_every=5, graph_mode='full') if flags['+verify'] else {}))

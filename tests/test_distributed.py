@@ -574,17 +574,21 @@ def test_ranks_on_one_gpu_with_the_fused_stage_pair(tmp_path, hip_lib, monkeypat
 @pytest.mark.parametrize('world,case,n_steps', [
     (2, 'channel64+every2+p2p+nosplit', 7), (2, 'channel64+every4+nosplit', 9), (3, 'delaunay+every2+p2p+nosplit', 2),
     (4, 'channel64+every3+p2p+nosplit+graph', 9), (2, 'channel64+every2+p2p+nosplit+capture', 8), (2, 'channel256+every4+p2p+nosplit+capture', 8),
-    (4, 'channel256+every4+p2p+nosplit+graph', 11)])
+    (4, 'channel256+every4+p2p+nosplit+graph', 11), (2, 'channel360k+every4+p2p+nosplit+capture+byrule', 8)])
 def test_ranks_on_one_gpu_with_whole_steps_in_one_launch(tmp_path, hip_lib, monkeypatch, world, case, n_steps):
     """A partition's steps as ONE launch each (csrc/swe2d_fuse.h swe_fuse123_kernel through swe2d_solve_step_cells: two-ring tiles over
     owned and ghost cells - the 11 x 8-quad patches of the parent mesh, or runs of the Hilbert order on a Delaunay partition -, stage 3
     on the step's last shrinking range, the state buffers change places after every launch): DistributedSwe2d takes the steps of a cycle
     in pairs, so that every cycle - eager, per-cycle graph or one graph for the whole advance - ends on the buffer it began on; an odd
-    step of a cycle (m = 3, and the trailing cycles of these step counts) goes by the fused pair + stage 3.  Forced here (ranks take it by
-    themselves beyond 131 k cells).  Bitwise the single-device run by stage launches."""
+    step of a cycle (m = 3, and the trailing cycles of these step counts) goes by the fused pair + stage 3.  Forced here - ranks take it by
+    themselves beyond 131 k cells: the last case, two ranks of 180 k cells.  Bitwise the single-device run by stage launches."""
     from thetis_amd.device import Swe2dDevice
     import dist_worker
-    monkeypatch.setenv('THETIS_AMD_FUSE12', '3')
+    if '+byrule' in case:                 # 180 k cells per rank: taken without being asked for
+        monkeypatch.delenv('THETIS_AMD_FUSE12', raising=False)
+        case = case.replace('+byrule', '')
+    else:
+        monkeypatch.setenv('THETIS_AMD_FUSE12', '3')
     base = case.split('+')[0]
     dist_worker.CASE = base
     mesh, bath, uv, eta = dist_worker._case()
@@ -593,7 +597,7 @@ def test_ranks_on_one_gpu_with_whole_steps_in_one_launch(tmp_path, hip_lib, monk
     assert all(int(d['step3']) == 1 for d in extra), 'a rank did not take the one-launch steps'
     monkeypatch.setenv('THETIS_AMD_FUSE12', '0')
     monkeypatch.setenv('THETIS_AMD_FLOW', '0')
-    dev = Swe2dDevice(mesh, bath, 2.0)
+    dev = Swe2dDevice(mesh, bath, dist_worker._dt())
     dev.set_state(uv, eta)
     dev.advance(n_steps)
     u_s, e_s = dev.get_state()
