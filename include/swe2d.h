@@ -180,7 +180,9 @@ int  swe2d_fused_set_triple_tiles(swe2d_handle *h, const int32_t *cells_in_tile_
 /* A PARTITION's whole step in one launch (round 6, last): stage 3 on cells [0, cell_end), the last of the step's three shrinking ranges
  * (thetis_amd/partition.py stage_range); stages 1 and 2 are evaluated on the tiles' supersets of theirs and never leave the chip.  The
  * result goes to the second state buffer and the two change places: inside a stream capture call it an EVEN number of times per
- * captured sequence (the pointers a replay uses are those of the capture), and build the tables before (swe2d_fused_step_info).
+ * captured sequence (the pointers a replay uses are those of the capture; an odd number is reported as SWE2D_ERR_UNSUPPORTED by the
+ * next swe2d_synchronize / swe2d_get_stage_state / swe2d_solve_step_cells outside the capture), and build the tables before
+ * (swe2d_fused_step_info).
  * Cells of the state beyond cell_end hold stale values afterwards (ghost cells the next exchange rewrites).  SWE2D_ERR_UNSUPPORTED
  * where the kernel does not cover the handle (quadrilaterals, wetting-drying, viscosity, source terms unless forced).
  * swe2d_fused_step_info: out[0] = 1 when the caller should take it (patches handed in with swe2d_fused_set_triple_tiles and more

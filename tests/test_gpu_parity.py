@@ -704,6 +704,49 @@ def test_fused_stage_triple_gives_the_bits_of_the_stage_launches(hip_lib, ref_so
         assert np.array_equal(a_, b_)
 
 
+def test_step_launches_inside_a_stream_capture_must_come_in_pairs(hip_lib, monkeypatch):
+    """swe2d_solve_step_cells leaves its result in the second state buffer and swaps the two on the host: a captured sequence with an
+    EVEN number of them replays (twice here: four steps, the bits of four eager steps by stage launches); one with an odd number ends
+    on the other buffer than it began on - the library says so at the next call outside the capture (SWE2D_ERR_UNSUPPORTED), it does not
+    let a second replay read a stale buffer silently."""
+    import torch
+    from thetis_amd import _lib
+    from thetis_amd.device import Swe2dDevice
+    monkeypatch.setenv('THETIS_AMD_FLOW', '0')
+    monkeypatch.setenv('THETIS_AMD_FUSE12', '0')
+    mesh, bath, uv, eta = channel_case(nx=60, ny=40, seed=3, amp_eta=0.3, amp_u=0.2)
+    dev = Swe2dDevice(mesh, bath, 0.5)
+    dev.set_state(uv, eta)
+    dev.advance(4)
+    ref_state = dev.get_state()
+    dev.set_option(_lib.OPT_FUSED_STAGES, 3)
+    assert dev.fused_step_info()[0]                      # (builds the tile tables: never inside a capture)
+    s = torch.cuda.Stream()
+    dev.set_stream(s.cuda_stream)
+    n = mesh.num_cells
+    with torch.cuda.stream(s):
+        dev.set_state(uv, eta)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
+            dev.solve_step_cells(n)
+            dev.solve_step_cells(n)
+        g.replay()
+        g.replay()
+        s.synchronize()
+        dev.synchronize()
+        u, e = dev.get_state()
+        assert np.array_equal(u, ref_state[0]) and np.array_equal(e, ref_state[1])
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, stream=s, capture_error_mode='thread_local'):
+            dev.solve_step_cells(n)
+        with pytest.raises(_lib.Swe2dError) as err:
+            dev.synchronize()
+        assert err.value.code == _lib.ERR_UNSUPPORTED and 'odd number' in str(err.value)
+        dev.synchronize()                                # reported once
+    dev.set_stream(None)
+    dev.close()
+
+
 def _bump_state(mesh, seed=1234):
     n = mesh.num_cells
     rng = np.random.default_rng(seed)

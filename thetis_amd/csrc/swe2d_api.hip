@@ -617,6 +617,7 @@ int swe2d_get_stage_state(swe2d_handle *hh, int i_stage, double *uv, double *eta
     if (i_stage < 0 || i_stage > 2) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "i_stage must be 0, 1 or 2");
     // stage_sol[i] of the reference always is what stage i left (rungekutta.py:930-946).  Here the fused and the dataflow kernels keep
     // the intermediate stage solutions on chip: a buffer they did not write is not handed out as if they had
+    if (int rc = capture_parity_check(h)) return rc;
     if (i_stage < 2 && !h->stage_valid[i_stage])
         return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_get_stage_state: the last step did not leave this stage solution in memory (fused stages / "
                     "dataflow kernel, or no stage has run since the state was set); run the step with swe2d_solve_stage to read it");
@@ -631,6 +632,7 @@ int swe2d_get_stage_state(swe2d_handle *hh, int i_stage, double *uv, double *eta
     HIP_TRY(h, hipMemcpyAsync(uv, h->stage_uv, 2*n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(eta, h->stage_eta, n*sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (int rc = capture_parity_check(h)) return rc;
     return flow_check(h);
 }
 
@@ -1002,6 +1004,7 @@ int swe2d_synchronize(swe2d_handle *hh)
     Handle *h = H(hh);
     if (!h) return SWE2D_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (int rc = capture_parity_check(h)) return rc;
     return flow_check(h);
 }
 

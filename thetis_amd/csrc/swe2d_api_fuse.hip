@@ -404,6 +404,26 @@ int launch_fuse123(Handle *h, int cell_end)
     HIP_TRY(h, hipGetLastError());
     std::swap(h->state[0], h->state[1]);
     h->stage_valid[0] = h->stage_valid[1] = false;          // U(1) and U(2) never left the chip
+    {   // inside a stream capture the swap is only the host's: a graph that holds an odd number of them ends on the other buffer than
+        // it began on and cannot be replayed twice - counted here, reported by capture_parity_check at the next call outside the capture
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) h->capture_swaps++;
+        (void)hipGetLastError();
+    }
+    return SWE2D_OK;
+}
+
+int capture_parity_check(Handle *h)
+{
+    if (h->capture_swaps == 0) return SWE2D_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return SWE2D_OK; }
+    (void)hipGetLastError();
+    const int swaps = h->capture_swaps;
+    h->capture_swaps = 0;
+    if (swaps & 1)
+        return fail(h, SWE2D_ERR_UNSUPPORTED, "a stream capture recorded an odd number of swe2d_solve_step_cells launches: the graph ends on the other "
+                    "state buffer than it began on and cannot be replayed; capture an even number per sequence");
     return SWE2D_OK;
 }
 
@@ -561,6 +581,7 @@ int swe2d_solve_step_cells(swe2d_handle *hh, int32_t cell_end)
     if (cell_end < 0 || cell_end > h->n_cells) return fail(h, SWE2D_ERR_INVALID_ARGUMENT, "bad cell range");
     if (!fuse123_partition_ok(h)) return fail(h, SWE2D_ERR_UNSUPPORTED, "swe2d_solve_step_cells: the three-stage kernel does not cover this handle");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc = capture_parity_check(h)) return rc;
     if (!h->fuse3_tile) {           // tile tables: allocations and copies, not inside a stream capture
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;

@@ -117,6 +117,7 @@ struct Handle {
     // which of the stage buffers hold the stage solutions of the step made last (swe2d_get_stage_state): the fused and the dataflow
     // kernels keep U(1) (and U(2)) on chip
     bool stage_valid[2] = {false, false};
+    int capture_swaps = 0;                              // buffer swaps made while the stream was capturing (launch_fuse123): must be even per captured sequence
     int4 *idx4 = nullptr;                               // packed triangle connectivity (stage kernel), see SweStageArgs
     int2 *idx2 = nullptr;
     int4 *idxc = nullptr;                               // ... in 16 B (swe_conn_pack), what the stage kernels read (SWE2D_OPT_COMPACT_IDX)
@@ -313,6 +314,7 @@ int launch_fuse12(Handle *h, int cell_end);
 bool fuse123_wanted(const Handle *h);
 int fuse123_build(Handle *h);
 int launch_fuse123(Handle *h, int cell_end);
+int capture_parity_check(Handle *h);                    // SWE2D_ERR_UNSUPPORTED once after a capture that swapped the state buffers an odd number of times
 int step_swe(Handle *h);                               // one SSPRK33 step of the shallow-water state on the whole mesh: fused pair + stage 3, or stage launches
 void fill_stage_args(Handle *h, SweStageArgs &a, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1);
 int launch_stage(Handle *h, int in, int u0, int out, double a0, double a1, double beta, int c0, int c1);
